@@ -1,0 +1,175 @@
+"""ctypes front-end of the CPU oracle (oracle/rrrmc_oracle.c).
+
+ORACLE — TEST INFRASTRUCTURE ONLY: imported by tests/, ``__graft_entry__.smoke()`` and
+``bench.py``'s ``cpu_baseline`` leg, never by the product package.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "_build", "librrrmc_oracle.so")
+
+u64p = np.ctypeslib.ndpointer(np.uint64, flags="C_CONTIGUOUS")
+i64p = np.ctypeslib.ndpointer(np.int64, flags="C_CONTIGUOUS")
+i32p = np.ctypeslib.ndpointer(np.int32, flags="C_CONTIGUOUS")
+u32p = np.ctypeslib.ndpointer(np.uint32, flags="C_CONTIGUOUS")
+f64p = np.ctypeslib.ndpointer(np.float64, flags="C_CONTIGUOUS")
+u8p = np.ctypeslib.ndpointer(np.uint8, flags="C_CONTIGUOUS")
+
+
+def build(force=False):
+    """Compile the oracle with gcc (no-op when the .so is newer than its sources)."""
+    srcs = [os.path.join(_HERE, f) for f in os.listdir(_HERE) if f.endswith((".c", ".h"))]
+    if not force and os.path.exists(_SO) and all(os.path.getmtime(_SO) >= os.path.getmtime(s) for s in srcs):
+        return _SO
+    subprocess.check_call(["make", "-s", "-C", _HERE, "all"])
+    return _SO
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(_SO)
+        L.orc_philox.argtypes = [u32p, u32p, u32p]
+        L.orc_site_of.restype = C.c_int64
+        L.orc_site_of.argtypes = [C.c_uint64, C.c_uint64, C.c_int64]
+        L.orc_accept_uniform.restype = C.c_uint64
+        L.orc_accept_uniform.argtypes = [C.c_uint64, C.c_uint64, C.c_uint32]
+        L.orc_accept_less.restype = C.c_int
+        L.orc_accept_less.argtypes = [C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint64]
+        L.orc_threshold.restype = C.c_uint64
+        L.orc_threshold.argtypes = [C.c_double, C.POINTER(C.c_int)]
+        L.orc_init_config.argtypes = [C.c_uint64, C.c_uint32, C.c_int64, u64p]
+        L.orc_gen_rrg.restype = C.c_int
+        L.orc_gen_rrg.argtypes = [C.c_int64, C.c_int64, C.c_uint64, i32p]
+        L.orc_gen_ea.restype = C.c_int
+        L.orc_gen_ea.argtypes = [C.c_int64, C.c_int64, i32p]
+        L.orc_gen_couplings.restype = C.c_int
+        L.orc_gen_couplings.argtypes = [C.c_int64, C.c_int64, i32p, C.c_uint64, C.c_int64, i32p, i32p]
+        L.orc_sparse_energy.restype = C.c_int64
+        L.orc_sparse_energy.argtypes = [C.c_int64, C.c_int64, i32p, i32p, u64p, C.c_void_p]
+        L.orc_standard_mc_sparse.restype = C.c_int64
+        L.orc_standard_mc_sparse.argtypes = [C.c_int64, C.c_int64, i32p, i32p, C.c_double, C.c_int64, C.c_int64,
+                                             C.c_uint64, C.c_uint64, C.c_uint32, u64p, i64p,
+                                             C.POINTER(C.c_int64), C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_standard_mc_sparse_batch.restype = C.c_int64
+        L.orc_standard_mc_sparse_batch.argtypes = [C.c_int64, C.c_int64, i32p, i32p, C.c_double, C.c_int64,
+                                                   C.c_int64, C.c_uint64, C.c_uint64, C.c_uint32, C.c_int64,
+                                                   u64p, i64p, i64p]
+        L.orc_all_delta_e_pm1.restype = C.c_int64
+        L.orc_all_delta_e_pm1.argtypes = [C.c_int64, i64p]
+        _lib = L
+    return _lib
+
+
+# ------------------------------------------------------------------------------------------------
+def philox(ctr, key):
+    out = np.zeros(4, np.uint32)
+    lib().orc_philox(np.asarray(ctr, np.uint32), np.asarray(key, np.uint32), out)
+    return out
+
+
+def site_of(seed, g, N):
+    return int(lib().orc_site_of(seed, g, N))
+
+
+def accept_uniform(seed, g, replica):
+    return int(lib().orc_accept_uniform(seed, g, replica))
+
+
+def accept_less(seed, g, replica, T):
+    return bool(lib().orc_accept_less(seed, g, replica, T))
+
+
+def threshold(p):
+    a = C.c_int(0)
+    t = lib().orc_threshold(p, C.byref(a))
+    return int(t), bool(a.value)
+
+
+def nchunks(N):
+    return (N + 63) // 64
+
+
+def init_config(seed, replica, N):
+    ch = np.zeros(nchunks(N), np.uint64)
+    lib().orc_init_config(seed, replica, N, ch)
+    return ch
+
+
+def init_configs(seed, replica0, R, N):
+    return np.stack([init_config(seed, replica0 + r, N) for r in range(R)])
+
+
+def gen_rrg(N, K, seed):
+    A = np.zeros((N, K), np.int32)
+    rc = lib().orc_gen_rrg(N, K, seed, A)
+    if rc < 0:
+        raise ValueError("gen_rrg failed rc=%d" % rc)
+    return A
+
+
+def gen_ea(L, D):
+    A = np.zeros((L ** D, 2 * D), np.int32)
+    rc = lib().orc_gen_ea(L, D, A)
+    if rc < 0:
+        raise ValueError("gen_ea failed rc=%d" % rc)
+    return A
+
+
+def gen_couplings(A, seed, lev=(-1, 1)):
+    N, K = A.shape
+    J = np.zeros((N, K), np.int32)
+    rc = lib().orc_gen_couplings(N, K, np.ascontiguousarray(A), seed, len(lev), np.asarray(lev, np.int32), J)
+    if rc < 0:
+        raise ValueError("gen_couplings failed")
+    return J
+
+
+def sparse_energy(A, J, chunks, want_fields=False):
+    N, K = A.shape
+    lf = np.zeros(N, np.int64)
+    E = lib().orc_sparse_energy(N, K, A, J, np.ascontiguousarray(chunks), lf.ctypes.data)
+    return (int(E), lf) if want_fields else int(E)
+
+
+def standard_mc_sparse(A, J, beta, iters, step, seed, chunks, it0=0, replica=0, trace=False):
+    """One chain.  Returns (Es, chunks_out, accepted, lfields[, sites, flips])."""
+    N, K = A.shape
+    ch = np.array(chunks, np.uint64, copy=True)
+    Es = np.zeros(max(iters // step, 1), np.int64)
+    acc = C.c_int64(0)
+    lf = np.zeros(N, np.int64)
+    sites = np.zeros(iters if trace else 1, np.int32)
+    flips = np.zeros(iters if trace else 1, np.uint8)
+    n = lib().orc_standard_mc_sparse(N, K, A, J, beta, iters, step, seed, it0, replica, ch, Es, C.byref(acc),
+                                     lf.ctypes.data, sites.ctypes.data if trace else None,
+                                     flips.ctypes.data if trace else None)
+    out = (Es[:n], ch, int(acc.value), lf)
+    return out + (sites, flips) if trace else out
+
+
+def standard_mc_sparse_batch(A, J, beta, iters, step, seed, chunks, it0=0, replica0=0):
+    """R chains, chunks shaped [R, nchunks].  Returns (Es[R, nsamp], chunks_out, accepted[R])."""
+    N, K = A.shape
+    ch = np.array(chunks, np.uint64, copy=True)
+    R = ch.shape[0]
+    nsamp = iters // step
+    Es = np.zeros((R, max(nsamp, 1)), np.int64)
+    acc = np.zeros(R, np.int64)
+    lib().orc_standard_mc_sparse_batch(N, K, A, J, beta, iters, step, seed, it0, replica0, R, ch,
+                                       Es.reshape(-1)[: R * nsamp] if nsamp else Es.reshape(-1), acc)
+    return Es[:, :nsamp] if nsamp else Es[:, :0], ch, acc
+
+
+def all_delta_e_pm1(K):
+    out = np.zeros(K + 1, np.int64)
+    n = lib().orc_all_delta_e_pm1(K, out)
+    return tuple(int(v) for v in out[:n])
