@@ -1,0 +1,134 @@
+/*
+ * rrrmc_hip.h — C ABI of the MI355X (gfx950) Ising Monte Carlo sweep engine.
+ *
+ * This is the drop-in boundary behind RRRMC.jl's AbstractGraph / standardMC API.
+ * In the reference the samplers call the graph through a per-site interface
+ * (src/Interface.jl:87-158: energy, delta_energy, spinflip!/update_cache!, neighbors, allΔE);
+ * a per-site call across an FFI is useless on a GPU, so the boundary sits one level up: one call
+ * runs the WHOLE sampler loop (src/RRRMC.jl:81-127) for a batch of R replicas of one graph.
+ *
+ * Conventions
+ *  - every function returns an int32 status (RRRMC_OK == 0); the text of the last failure is
+ *    available from rrrmc_last_error(ctx) (ctx may be NULL for creation failures);
+ *    nothing throws or aborts across the ABI (the reference raises ArgumentError, src/RRRMC.jl:94).
+ *  - the caller owns every host buffer and keeps it alive for the duration of the call
+ *    (Julia: GC.@preserve); the library owns all device memory inside the ctx.
+ *  - spins travel in Julia's BitVector chunk layout (src/Interface.jl:21-29, src/Common.jl:15-23):
+ *    replica r, site x (0-based) = bit (x & 63) of chunks[r * nchunks + (x >> 6)], nchunks = ceil(N/64);
+ *    spin value sigma = 2*bit - 1.  Unused high bits of the last chunk are zero.
+ *  - neighbour tables are row-major N x K, 0-BASED int32 (the Julia glue subtracts 1 from
+ *    reinterpret(Int64, X.A), src/graphs/RRG.jl:118-119); couplings are N x K int8 (+-1).
+ *  - a ctx is bound to ONE device and is not re-entrant (the reference's graph objects are stateful
+ *    too: src/graphs/RRG.jl:121); multi-GPU = one ctx per process/device with a replica offset.
+ *  - random numbers: Philox4x32-10 streams addressed by (seed; iteration, replica) — see DESIGN.md
+ *    "Random-stream contract"; results do not depend on how replicas are sharded over devices.
+ */
+#ifndef RRRMC_HIP_H
+#define RRRMC_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RRRMC_API __attribute__((visibility("default")))
+
+typedef struct rrrmc_ctx rrrmc_ctx;
+
+enum rrrmc_status {
+    RRRMC_OK = 0,
+    RRRMC_ERR_INVALID_ARG = 1,   /* reference: ArgumentError */
+    RRRMC_ERR_STATE = 2,         /* call order violated (e.g. sampling before set_graph) */
+    RRRMC_ERR_UNSUPPORTED = 3,   /* model/size outside what the HIP kernels cover */
+    RRRMC_ERR_HIP = 4,           /* HIP runtime failure (no device, launch error, ...) */
+    RRRMC_ERR_NOMEM = 5
+};
+
+enum rrrmc_model {
+    RRRMC_MODEL_SPARSE_PM1 = 1   /* GraphRRG{Int,(-1,1),K} src/graphs/RRG.jl:116 and GraphEA{Int,(-1,1),2D} src/graphs/EA.jl:138 */
+};
+
+/* Library ABI version (major*10000 + minor*100 + patch). */
+RRRMC_API int32_t rrrmc_version(void);
+
+/* Text of the most recent error on this ctx (or of the last failed rrrmc_ctx_create when ctx == NULL).
+ * The pointer stays valid until the next failing call on the same ctx / thread. */
+RRRMC_API const char *rrrmc_last_error(const rrrmc_ctx *ctx);
+
+/* Number of visible HIP devices (0 when there is none; never fails). */
+RRRMC_API int32_t rrrmc_device_count(void);
+
+/*
+ * Create a context for R replicas (chains) of one graph with N spins and K neighbour slots per spin.
+ *   model     rrrmc_model
+ *   device    HIP device ordinal
+ *   replica0  global id of this ctx's first replica (replica ids address the random streams; a job of
+ *             R_total replicas sharded over several devices passes the shard offset here; must be a
+ *             multiple of 32)
+ * Replaces: constructing the graph object + its LocalFields cache, src/graphs/RRG.jl:122-138.
+ */
+RRRMC_API int32_t rrrmc_ctx_create(rrrmc_ctx **out, int32_t model, int64_t N, int64_t K, int64_t R,
+                                   int32_t device, uint32_t replica0);
+RRRMC_API void rrrmc_ctx_destroy(rrrmc_ctx *ctx);
+
+/* Disorder: A[N*K] 0-based neighbours, J[N*K] couplings in {-1,+1}; J[x*K+k] belongs to the bond
+ * (x, A[x*K+k]) and must be symmetric (checked).  Replaces GraphRRG{Int,(-1,1),K}(A, J), RRG.jl:122. */
+RRRMC_API int32_t rrrmc_set_graph(rrrmc_ctx *ctx, const int32_t *A, const int8_t *J);
+
+/* Random.seed!(seed) (src/RRRMC.jl:89): selects the Philox key and rewinds the iteration counter.
+ * Not calling it between two sampling calls continues the streams (the reference's `seed <= 0`). */
+RRRMC_API int32_t rrrmc_seed(rrrmc_ctx *ctx, uint64_t seed);
+
+/* Config(N) with random spins for every replica (src/Interface.jl:24-28), INIT stream of the seed. */
+RRRMC_API int32_t rrrmc_init_spins_random(rrrmc_ctx *ctx);
+/* C0 (src/RRRMC.jl:93): chunks[R * ceil(N/64)] in BitVector layout. */
+RRRMC_API int32_t rrrmc_set_spins(rrrmc_ctx *ctx, const uint64_t *chunks);
+RRRMC_API int32_t rrrmc_get_spins(rrrmc_ctx *ctx, uint64_t *chunks);
+
+/* energy(X, C) for every replica (src/Interface.jl:105, src/graphs/RRG.jl:164-189): E_out[R] (int64).
+ * Also rebuilds the device-side caches, exactly as the reference's `energy` resets LocalFields. */
+RRRMC_API int32_t rrrmc_energy(rrrmc_ctx *ctx, int64_t *E_out);
+
+/* Debug/parity view of the cache: lfields_out[R * N] (int64), lfields[x] = -delta_energy(X, C, x)
+ * (src/graphs/RRG.jl:236-244), recomputed from the current spins. */
+RRRMC_API int32_t rrrmc_get_fields(rrrmc_ctx *ctx, int64_t *lfields_out);
+
+/*
+ * standardMC(X, beta, iters; step) for all R replicas (src/RRRMC.jl:81-127).
+ *   Es_out        [R * (iters / step)] int64, replica-major: the energy BEFORE the move of iteration
+ *                 k*step (src/RRRMC.jl:104-108).  May be NULL.
+ *   accepted_out  [R] accepted moves of this call.  May be NULL.
+ * The configuration is resumed from the ctx and left updated (C0 is mutated in place, RRRMC.jl:93).
+ * Synchronous: returns when the results are on the host.
+ */
+RRRMC_API int32_t rrrmc_standard_mc(rrrmc_ctx *ctx, double beta, int64_t iters, int64_t step,
+                                    int64_t *Es_out, int64_t *accepted_out);
+
+/* Device-resident form of the same call: enqueue on the ctx's stream and return; results stay in HBM
+ * until fetched.  rrrmc_sync waits for the stream.  Used by bench.py for the timed region. */
+RRRMC_API int32_t rrrmc_standard_mc_async(rrrmc_ctx *ctx, double beta, int64_t iters, int64_t step);
+RRRMC_API int32_t rrrmc_sync(rrrmc_ctx *ctx);
+/* Results of the last (a)sync sampling call: Es_out[R * nsamples] replica-major, accepted_out[R]. */
+RRRMC_API int32_t rrrmc_fetch_results(rrrmc_ctx *ctx, int64_t *Es_out, int64_t *accepted_out);
+
+/* Timing of the last sampling call measured with HIP events on the ctx's stream:
+ *   total_ms   first planner launch -> last sweep kernel end
+ *   sweep_ms   sum of the sweep (dominant) kernel's durations,  sweep_launches = how many launches */
+RRRMC_API int32_t rrrmc_last_timing(rrrmc_ctx *ctx, double *total_ms, double *sweep_ms, int32_t *sweep_launches);
+
+/* Iterations consumed from the current seed's streams so far. */
+RRRMC_API int64_t rrrmc_iterations_done(const rrrmc_ctx *ctx);
+
+/* ---- host-side graph constructors (setup, not hot): the disorder formats of SURVEY.md §8 a7/a8 ---- */
+/* gen_RRG (src/graphs/RRG.jl:26-69): A_out[N*K] 0-based, rows ascending. GRAPH stream of `seed`. */
+RRRMC_API int32_t rrrmc_gen_rrg(int64_t N, int64_t K, uint64_t seed, int32_t *A_out);
+/* gen_EA (src/graphs/EA.jl:24-43): periodic L^D lattice, A_out[L^D * 2D]. */
+RRRMC_API int32_t rrrmc_gen_ea(int64_t L, int64_t D, int32_t *A_out);
+/* gen_J with LEV = (-1, 1) (src/graphs/RRG.jl:71-96, :154-156): J_out[N*K]. COUPLING stream. */
+RRRMC_API int32_t rrrmc_gen_couplings_pm1(int64_t N, int64_t K, const int32_t *A, uint64_t seed, int8_t *J_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RRRMC_HIP_H */

@@ -1,0 +1,12 @@
+"""MI355X-native Ising Monte Carlo sweep engine behind RRRMC.jl's graph / sampler API.
+
+Host-side mirror (Python, since Julia is not available in this image) of the reference interface for
+the hot path: ``Config`` (src/Interface.jl:21-29), ``GraphRRG`` (src/graphs/RRG.jl:116-162), ``GraphEA``
+(src/graphs/EA.jl:138-193) and ``standardMC`` (src/RRRMC.jl:81-127).  All computation happens in the
+gfx950 library ``lib/librrrmc_hip.so`` through the C ABI of ``include/rrrmc_hip.h``.
+"""
+from ._lib import RRRMCError, SYMBOLS, lib  # noqa: F401
+from .graphs import Config, GraphEA, GraphRRG, all_delta_e, getN, neighbors  # noqa: F401
+from .engine import Engine, standardMC  # noqa: F401
+
+__all__ = ["Config", "GraphRRG", "GraphEA", "Engine", "standardMC", "RRRMCError", "getN", "neighbors", "all_delta_e"]

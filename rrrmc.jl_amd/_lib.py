@@ -1,0 +1,91 @@
+"""ctypes binding of include/rrrmc_hip.h.  No fallback: a missing library or device is an error."""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import build as _build
+
+_lib = None
+
+u64p = np.ctypeslib.ndpointer(np.uint64, flags="C_CONTIGUOUS")
+i64p = np.ctypeslib.ndpointer(np.int64, flags="C_CONTIGUOUS")
+i32p = np.ctypeslib.ndpointer(np.int32, flags="C_CONTIGUOUS")
+i8p = np.ctypeslib.ndpointer(np.int8, flags="C_CONTIGUOUS")
+
+# every symbol include/rrrmc_hip.h declares
+SYMBOLS = [
+    "rrrmc_version", "rrrmc_last_error", "rrrmc_device_count", "rrrmc_ctx_create", "rrrmc_ctx_destroy",
+    "rrrmc_set_graph", "rrrmc_seed", "rrrmc_init_spins_random", "rrrmc_set_spins", "rrrmc_get_spins",
+    "rrrmc_energy", "rrrmc_get_fields", "rrrmc_standard_mc", "rrrmc_standard_mc_async", "rrrmc_sync",
+    "rrrmc_fetch_results", "rrrmc_last_timing", "rrrmc_iterations_done", "rrrmc_gen_rrg", "rrrmc_gen_ea",
+    "rrrmc_gen_couplings_pm1",
+]
+
+
+class RRRMCError(RuntimeError):
+    """Raised for every non-zero status of the C ABI (the reference raises ArgumentError / ErrorException)."""
+
+    def __init__(self, code, msg):
+        super().__init__("rrrmc_hip status %d: %s" % (code, msg))
+        self.code = code
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = _build.lib_path()
+    if not os.path.exists(path):
+        raise RuntimeError("%s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                           "(there is no CPU fallback)" % path)
+    L = C.CDLL(path)
+    vp = C.c_void_p
+    L.rrrmc_version.restype = C.c_int32
+    L.rrrmc_last_error.restype = C.c_char_p
+    L.rrrmc_last_error.argtypes = [vp]
+    L.rrrmc_device_count.restype = C.c_int32
+    L.rrrmc_ctx_create.restype = C.c_int32
+    L.rrrmc_ctx_create.argtypes = [C.POINTER(vp), C.c_int32, C.c_int64, C.c_int64, C.c_int64, C.c_int32, C.c_uint32]
+    L.rrrmc_ctx_destroy.restype = None
+    L.rrrmc_ctx_destroy.argtypes = [vp]
+    L.rrrmc_set_graph.restype = C.c_int32
+    L.rrrmc_set_graph.argtypes = [vp, i32p, i8p]
+    L.rrrmc_seed.restype = C.c_int32
+    L.rrrmc_seed.argtypes = [vp, C.c_uint64]
+    L.rrrmc_init_spins_random.restype = C.c_int32
+    L.rrrmc_init_spins_random.argtypes = [vp]
+    L.rrrmc_set_spins.restype = C.c_int32
+    L.rrrmc_set_spins.argtypes = [vp, u64p]
+    L.rrrmc_get_spins.restype = C.c_int32
+    L.rrrmc_get_spins.argtypes = [vp, u64p]
+    L.rrrmc_energy.restype = C.c_int32
+    L.rrrmc_energy.argtypes = [vp, i64p]
+    L.rrrmc_get_fields.restype = C.c_int32
+    L.rrrmc_get_fields.argtypes = [vp, i64p]
+    L.rrrmc_standard_mc.restype = C.c_int32
+    L.rrrmc_standard_mc.argtypes = [vp, C.c_double, C.c_int64, C.c_int64, vp, vp]
+    L.rrrmc_standard_mc_async.restype = C.c_int32
+    L.rrrmc_standard_mc_async.argtypes = [vp, C.c_double, C.c_int64, C.c_int64]
+    L.rrrmc_sync.restype = C.c_int32
+    L.rrrmc_sync.argtypes = [vp]
+    L.rrrmc_fetch_results.restype = C.c_int32
+    L.rrrmc_fetch_results.argtypes = [vp, vp, vp]
+    L.rrrmc_last_timing.restype = C.c_int32
+    L.rrrmc_last_timing.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int32)]
+    L.rrrmc_iterations_done.restype = C.c_int64
+    L.rrrmc_iterations_done.argtypes = [vp]
+    L.rrrmc_gen_rrg.restype = C.c_int32
+    L.rrrmc_gen_rrg.argtypes = [C.c_int64, C.c_int64, C.c_uint64, i32p]
+    L.rrrmc_gen_ea.restype = C.c_int32
+    L.rrrmc_gen_ea.argtypes = [C.c_int64, C.c_int64, i32p]
+    L.rrrmc_gen_couplings_pm1.restype = C.c_int32
+    L.rrrmc_gen_couplings_pm1.argtypes = [C.c_int64, C.c_int64, i32p, C.c_uint64, i8p]
+    _lib = L
+    return L
+
+
+def check(rc, ctx=None):
+    if rc != 0:
+        msg = lib().rrrmc_last_error(ctx)
+        raise RRRMCError(rc, msg.decode() if msg else "")

@@ -1,0 +1,43 @@
+"""Build the gfx950 C-ABI library in-tree (rrrmc.jl_amd/lib/librrrmc_hip.so) with hipcc.
+
+hipcc cross-compiles without a GPU; the .so is git-ignored but travels to the GPU box with the snapshot.
+"""
+import os
+import shutil
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SRC = os.path.join(HERE, "csrc", "rrrmc_hip.hip")
+DEPS = [SRC, os.path.join(HERE, "csrc", "sparse_kernels.hpp"), os.path.join(HERE, "csrc", "philox.hpp"),
+        os.path.join(HERE, "..", "include", "rrrmc_hip.h")]
+OUT = os.path.join(HERE, "lib", "librrrmc_hip.so")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden", "-Wall", "-Wextra"]
+
+
+def lib_path():
+    return OUT
+
+
+def is_stale():
+    if not os.path.exists(OUT):
+        return True
+    t = os.path.getmtime(OUT)
+    return any(os.path.exists(d) and os.path.getmtime(d) > t for d in DEPS)
+
+
+def build(force=False, verbose=False):
+    if not force and not is_stale():
+        return OUT
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        raise RuntimeError("hipcc not found: cannot build librrrmc_hip.so")
+    os.makedirs(os.path.dirname(OUT), exist_ok=True)
+    cmd = [hipcc] + FLAGS + [SRC, "-o", OUT]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return OUT
+
+
+if __name__ == "__main__":
+    print(build(force=True, verbose=True))

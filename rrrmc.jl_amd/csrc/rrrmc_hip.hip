@@ -1,0 +1,677 @@
+// C ABI of the engine (include/rrrmc_hip.h): context, graph marshalling, sampling-call orchestration.
+// Product path only: there is no CPU fallback — without a HIP device every compute entry point fails
+// with RRRMC_ERR_HIP and a message.
+#include "../../include/rrrmc_hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "sparse_kernels.hpp"
+
+using namespace rrrmc;
+
+namespace {
+
+thread_local std::string g_create_error;
+
+constexpr int64_t kMaxSlotsPerBatch = 1 << 22;    // plan buffers: 2 x 16 MiB
+constexpr int64_t kMaxChunksPerBatch = 1 << 16;
+constexpr int kLdsLimit = 160 * 1024;
+
+}  // namespace
+
+struct rrrmc_ctx {
+    int32_t model = 0;
+    int64_t N = 0, K = 0, R = 0;
+    int64_t G = 0, Rpad = 0;
+    int device = 0;
+    uint32_t replica0 = 0;
+    hipStream_t stream = nullptr;
+    uint64_t seed = 0;
+    bool seeded = false;
+    uint64_t it_done = 0;
+    bool graph_set = false, spins_set = false;
+
+    // disorder
+    int32_t* d_A = nullptr;
+    int8_t* d_J = nullptr;
+    uint16_t* d_table = nullptr;
+    int TS = 0;
+    // state
+    uint32_t* d_spins = nullptr;   // [G][N]
+    int32_t* d_E = nullptr;        // [Rpad]
+    int64_t* d_acc = nullptr;      // [Rpad]
+    // plan buffers
+    ChunkDesc* d_chunks = nullptr;
+    size_t chunks_cap = 0;
+    ChunkDesc* h_chunks = nullptr; // pinned
+    size_t h_chunks_cap = 0;
+    uint32_t* d_slots = nullptr;
+    uint32_t* d_vecs = nullptr;
+    // results of the last sampling call
+    int32_t* d_Es = nullptr;
+    size_t Es_cap = 0;
+    int64_t nsamp = 0;
+    bool results_valid = false;
+    // sweep geometry
+    int C = 0;
+    size_t lds_bytes = 0, plan_lds_bytes = 0;
+    // timing
+    hipEvent_t ev_begin = nullptr, ev_end = nullptr;
+    std::vector<hipEvent_t> ev_sweep;   // pairs
+    int sweep_launches = 0;
+    bool timing_valid = false;
+
+    std::string err;
+};
+
+namespace {
+
+int32_t fail(rrrmc_ctx* ctx, int32_t code, const char* fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (ctx) ctx->err = buf; else g_create_error = buf;
+    return code;
+}
+
+#define HIP_TRY(ctx, expr)                                                                              \
+    do {                                                                                                \
+        hipError_t e_ = (expr);                                                                         \
+        if (e_ != hipSuccess)                                                                           \
+            return fail(ctx, RRRMC_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+template <typename T> void free_dev(T*& p) { if (p) { (void)hipFree(p); p = nullptr; } }
+
+// ceil(p * 2^64) for 0 < p < 1; *always when p >= 1.  accept(x) = x >= 0 || rand() < exp(x), src/RRRMC.jl:39
+uint64_t threshold64(double p, bool* always)
+{
+    *always = false;
+    if (!(p > 0.0)) return 0;
+    if (p >= 1.0) { *always = true; return ~0ull; }
+    uint64_t bits;
+    std::memcpy(&bits, &p, 8);
+    const int bexp = (int)((bits >> 52) & 0x7ff);
+    uint64_t man = bits & ((1ull << 52) - 1);
+    int e;
+    if (bexp == 0) e = -1074; else { man |= 1ull << 52; e = bexp - 1075; }
+    const int sh = e + 64;
+    if (sh >= 0) return man << sh;
+    const int s = -sh;
+    if (s >= 64) return 1;
+    return (man + ((1ull << s) - 1)) >> s;
+}
+
+typedef void (*sweep_fn)(SweepParams);
+sweep_fn sweep_for_K(int K)
+{
+    switch (K) {
+        case 1: return sweep_kernel<1>;
+        case 2: return sweep_kernel<2>;
+        case 3: return sweep_kernel<3>;
+        case 4: return sweep_kernel<4>;
+        case 5: return sweep_kernel<5>;
+        case 6: return sweep_kernel<6>;
+        case 7: return sweep_kernel<7>;
+        default: return nullptr;
+    }
+}
+
+size_t sweep_lds_bytes(int64_t N, int K, int TS, int C)
+{
+    const int NT = (K + 1) / 2, NF = NT + K + 1;
+    const size_t words = (size_t)((2 * N + 3) & ~3ll) + (size_t)2 * NF * C + (size_t)8 * C + 64;
+    return words * 4 + (size_t)N * TS * 2;
+}
+
+size_t plan_lds_bytes(int64_t N, int K, int C)
+{
+    return 2 * ((size_t)3 * C + 2 * ((size_t)C + 2) + (size_t)C * K + (size_t)N);
+}
+
+int32_t ensure_state(rrrmc_ctx* ctx, bool need_spins)
+{
+    if (!ctx) return RRRMC_ERR_INVALID_ARG;
+    if (!ctx->graph_set) return fail(ctx, RRRMC_ERR_STATE, "rrrmc_set_graph has not been called");
+    if (need_spins && !ctx->spins_set)
+        return fail(ctx, RRRMC_ERR_STATE, "no configuration: call rrrmc_init_spins_random or rrrmc_set_spins first");
+    return RRRMC_OK;
+}
+
+int32_t run_energy(rrrmc_ctx* ctx, uint8_t* d_nun)
+{
+    hipLaunchKernelGGL(energy_kernel, dim3((unsigned)ctx->G), dim3(256), 0, ctx->stream, ctx->d_spins, ctx->d_A, ctx->d_J,
+                       (int)ctx->N, (int)ctx->K, ctx->d_E, d_nun);
+    HIP_TRY(ctx, hipGetLastError());
+    return RRRMC_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int32_t rrrmc_version(void) { return 100; }
+
+const char* rrrmc_last_error(const rrrmc_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+int32_t rrrmc_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int32_t rrrmc_ctx_create(rrrmc_ctx** out, int32_t model, int64_t N, int64_t K, int64_t R, int32_t device, uint32_t replica0)
+{
+    if (!out) return fail(nullptr, RRRMC_ERR_INVALID_ARG, "out is NULL");
+    *out = nullptr;
+    if (model != RRRMC_MODEL_SPARSE_PM1) return fail(nullptr, RRRMC_ERR_UNSUPPORTED, "unknown model kind %d", model);
+    if (N < 1 || K < 1 || R < 1) return fail(nullptr, RRRMC_ERR_INVALID_ARG, "N, K, R must be >= 1 (given N=%lld K=%lld R=%lld)", (long long)N, (long long)K, (long long)R);
+    if (K > kMaxK) return fail(nullptr, RRRMC_ERR_UNSUPPORTED, "K=%lld: the sparse +-J kernels cover K <= %d", (long long)K, kMaxK);
+    if (N > 32767) return fail(nullptr, RRRMC_ERR_UNSUPPORTED, "N=%lld: the LDS-resident sparse kernel covers N <= 32767", (long long)N);
+    if (replica0 % 32) return fail(nullptr, RRRMC_ERR_INVALID_ARG, "replica0 must be a multiple of 32 (given %u)", replica0);
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(nullptr, RRRMC_ERR_HIP, "no HIP device is visible: this library has no CPU path");
+    if (device < 0 || device >= ndev) return fail(nullptr, RRRMC_ERR_INVALID_ARG, "device %d out of range (0..%d)", device, ndev - 1);
+
+    rrrmc_ctx* ctx = new (std::nothrow) rrrmc_ctx();
+    if (!ctx) return fail(nullptr, RRRMC_ERR_NOMEM, "out of host memory");
+    ctx->model = model; ctx->N = N; ctx->K = K; ctx->R = R;
+    ctx->G = (R + 31) / 32; ctx->Rpad = ctx->G * 32;
+    ctx->device = device; ctx->replica0 = replica0;
+    ctx->TS = K <= 4 ? 4 : 8;
+
+    // chunk length: a multiple of (producer waves x 64) that fits the 160 KiB LDS next to the state
+    int C = kProducerWaves * kWave;
+    while (C >= kWave && sweep_lds_bytes(N, (int)K, ctx->TS, C) > (size_t)kLdsLimit) C -= kWave;
+    if (C < kWave) {
+        delete ctx;
+        return fail(nullptr, RRRMC_ERR_UNSUPPORTED, "N=%lld K=%lld does not fit the LDS-resident sweep kernel", (long long)N, (long long)K);
+    }
+    ctx->C = C;
+    ctx->lds_bytes = sweep_lds_bytes(N, (int)K, ctx->TS, C);
+    ctx->plan_lds_bytes = plan_lds_bytes(N, (int)K, C);
+
+#define CREATE_TRY(expr)                                                                                         \
+    do {                                                                                                         \
+        hipError_t e_ = (expr);                                                                                  \
+        if (e_ != hipSuccess) {                                                                                  \
+            int32_t rc_ = fail(nullptr, RRRMC_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_));           \
+            rrrmc_ctx_destroy(ctx);                                                                              \
+            return rc_;                                                                                          \
+        }                                                                                                        \
+    } while (0)
+    CREATE_TRY(hipSetDevice(device));
+    CREATE_TRY(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+    CREATE_TRY(hipEventCreate(&ctx->ev_begin));
+    CREATE_TRY(hipEventCreate(&ctx->ev_end));
+    CREATE_TRY(hipMalloc(&ctx->d_A, sizeof(int32_t) * N * K));
+    CREATE_TRY(hipMalloc(&ctx->d_J, sizeof(int8_t) * N * K));
+    CREATE_TRY(hipMalloc(&ctx->d_table, sizeof(uint16_t) * N * ctx->TS));
+    CREATE_TRY(hipMalloc(&ctx->d_spins, sizeof(uint32_t) * ctx->G * N));
+    CREATE_TRY(hipMalloc(&ctx->d_E, sizeof(int32_t) * ctx->Rpad));
+    CREATE_TRY(hipMalloc(&ctx->d_acc, sizeof(int64_t) * ctx->Rpad));
+    CREATE_TRY(hipMalloc(&ctx->d_slots, sizeof(uint32_t) * kMaxSlotsPerBatch));
+    CREATE_TRY(hipMalloc(&ctx->d_vecs, sizeof(uint32_t) * kMaxSlotsPerBatch));
+    CREATE_TRY(hipMemset(ctx->d_spins, 0, sizeof(uint32_t) * ctx->G * N));
+    CREATE_TRY(hipMemset(ctx->d_E, 0, sizeof(int32_t) * ctx->Rpad));
+    CREATE_TRY(hipMemset(ctx->d_acc, 0, sizeof(int64_t) * ctx->Rpad));
+    sweep_fn fn = sweep_for_K((int)K);
+    CREATE_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->lds_bytes));
+    CREATE_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(plan_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->plan_lds_bytes));
+#undef CREATE_TRY
+    *out = ctx;
+    return RRRMC_OK;
+}
+
+void rrrmc_ctx_destroy(rrrmc_ctx* ctx)
+{
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    free_dev(ctx->d_A); free_dev(ctx->d_J); free_dev(ctx->d_table); free_dev(ctx->d_spins);
+    free_dev(ctx->d_E); free_dev(ctx->d_acc); free_dev(ctx->d_chunks); free_dev(ctx->d_slots);
+    free_dev(ctx->d_vecs); free_dev(ctx->d_Es);
+    if (ctx->h_chunks) (void)hipHostFree(ctx->h_chunks);
+    for (hipEvent_t e : ctx->ev_sweep) (void)hipEventDestroy(e);
+    if (ctx->ev_begin) (void)hipEventDestroy(ctx->ev_begin);
+    if (ctx->ev_end) (void)hipEventDestroy(ctx->ev_end);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+int32_t rrrmc_set_graph(rrrmc_ctx* ctx, const int32_t* A, const int8_t* J)
+{
+    if (!ctx) return RRRMC_ERR_INVALID_ARG;
+    if (!A || !J) return fail(ctx, RRRMC_ERR_INVALID_ARG, "A and J must not be NULL");
+    const int64_t N = ctx->N, K = ctx->K;
+    for (int64_t q = 0; q < N * K; ++q) {
+        if (A[q] < 0 || A[q] >= N) return fail(ctx, RRRMC_ERR_INVALID_ARG, "A[%lld] = %d out of range 0..%lld", (long long)q, A[q], (long long)(N - 1));
+        if (J[q] != 1 && J[q] != -1)    // GraphRRG ctor: "the given J is incompatible with levels" RRG.jl:130
+            return fail(ctx, RRRMC_ERR_INVALID_ARG, "J[%lld] = %d: couplings must be -1 or +1", (long long)q, (int)J[q]);
+        if (A[q] == q / K) return fail(ctx, RRRMC_ERR_INVALID_ARG, "self loop at site %lld", (long long)(q / K));
+    }
+    // every bond must appear from both ends with the same coupling (multi-edges allowed: GraphEA with L = 2)
+    std::vector<uint8_t> used((size_t)(N * K), 0);
+    for (int64_t x = 0; x < N; ++x)
+        for (int64_t k = 0; k < K; ++k) {
+            const int64_t y = A[x * K + k];
+            bool found = false;
+            for (int64_t l = 0; l < K && !found; ++l)
+                if (!used[y * K + l] && A[y * K + l] == x && J[y * K + l] == J[x * K + k]) { used[y * K + l] = 1; found = true; }
+            if (!found) return fail(ctx, RRRMC_ERR_INVALID_ARG, "bond (%lld,%lld) is not symmetric in (A, J)", (long long)x, (long long)y);
+        }
+    std::vector<uint16_t> table((size_t)(N * ctx->TS), 0);
+    for (int64_t x = 0; x < N; ++x)
+        for (int64_t k = 0; k < K; ++k)
+            table[x * ctx->TS + k] = (uint16_t)(A[x * K + k] + (J[x * K + k] < 0 ? N : 0));
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipMemcpy(ctx->d_A, A, sizeof(int32_t) * N * K, hipMemcpyHostToDevice));
+    HIP_TRY(ctx, hipMemcpy(ctx->d_J, J, sizeof(int8_t) * N * K, hipMemcpyHostToDevice));
+    HIP_TRY(ctx, hipMemcpy(ctx->d_table, table.data(), sizeof(uint16_t) * table.size(), hipMemcpyHostToDevice));
+    ctx->graph_set = true;
+    return RRRMC_OK;
+}
+
+int32_t rrrmc_seed(rrrmc_ctx* ctx, uint64_t seed)
+{
+    if (!ctx) return RRRMC_ERR_INVALID_ARG;
+    ctx->seed = seed;
+    ctx->seeded = true;
+    ctx->it_done = 0;
+    return RRRMC_OK;
+}
+
+int64_t rrrmc_iterations_done(const rrrmc_ctx* ctx) { return ctx ? (int64_t)ctx->it_done : -1; }
+
+int32_t rrrmc_init_spins_random(rrrmc_ctx* ctx)
+{
+    if (!ctx) return RRRMC_ERR_INVALID_ARG;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const dim3 grid((unsigned)((ctx->N + 255) / 256), (unsigned)ctx->G);
+    hipLaunchKernelGGL(init_spins_kernel, grid, dim3(256), 0, ctx->stream, ctx->d_spins, (int)ctx->N, ctx->replica0 / 32,
+                       (uint32_t)ctx->seed, (uint32_t)(ctx->seed >> 32));
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->spins_set = true;
+    return RRRMC_OK;
+}
+
+int32_t rrrmc_set_spins(rrrmc_ctx* ctx, const uint64_t* chunks)
+{
+    if (!ctx) return RRRMC_ERR_INVALID_ARG;
+    if (!chunks) return fail(ctx, RRRMC_ERR_INVALID_ARG, "chunks is NULL");
+    const int64_t N = ctx->N, nch = (N + 63) / 64;
+    if (N % 64) {   // BitVector invariant: unused bits of the last chunk are zero
+        const uint64_t tailmask = ~0ull << (N % 64);
+        for (int64_t r = 0; r < ctx->R; ++r)
+            if (chunks[r * nch + nch - 1] & tailmask)
+                return fail(ctx, RRRMC_ERR_INVALID_ARG, "replica %lld: bits beyond N are set in the last chunk", (long long)r);
+    }
+    std::vector<uint32_t> bs((size_t)(ctx->G * N), 0);
+    for (int64_t r = 0; r < ctx->R; ++r) {
+        uint32_t* dst = bs.data() + (r >> 5) * N;
+        const uint32_t bit = 1u << (r & 31);
+        const uint64_t* src = chunks + r * nch;
+        for (int64_t x = 0; x < N; ++x)
+            if ((src[x >> 6] >> (x & 63)) & 1ull) dst[x] |= bit;
+    }
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipMemcpy(ctx->d_spins, bs.data(), sizeof(uint32_t) * bs.size(), hipMemcpyHostToDevice));
+    ctx->spins_set = true;
+    return RRRMC_OK;
+}
+
+int32_t rrrmc_get_spins(rrrmc_ctx* ctx, uint64_t* chunks)
+{
+    int32_t rc = ensure_state(ctx, true);
+    if (rc) return rc;
+    if (!chunks) return fail(ctx, RRRMC_ERR_INVALID_ARG, "chunks is NULL");
+    const int64_t N = ctx->N, nch = (N + 63) / 64;
+    std::vector<uint32_t> bs((size_t)(ctx->G * N));
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipMemcpy(bs.data(), ctx->d_spins, sizeof(uint32_t) * bs.size(), hipMemcpyDeviceToHost));
+    std::memset(chunks, 0, sizeof(uint64_t) * ctx->R * nch);
+    for (int64_t r = 0; r < ctx->R; ++r) {
+        const uint32_t* src = bs.data() + (r >> 5) * N;
+        const int sh = (int)(r & 31);
+        uint64_t* dst = chunks + r * nch;
+        for (int64_t x = 0; x < N; ++x) dst[x >> 6] |= (uint64_t)((src[x] >> sh) & 1u) << (x & 63);
+    }
+    return RRRMC_OK;
+}
+
+int32_t rrrmc_energy(rrrmc_ctx* ctx, int64_t* E_out)
+{
+    int32_t rc = ensure_state(ctx, true);
+    if (rc) return rc;
+    if (!E_out) return fail(ctx, RRRMC_ERR_INVALID_ARG, "E_out is NULL");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    rc = run_energy(ctx, nullptr);
+    if (rc) return rc;
+    std::vector<int32_t> E((size_t)ctx->Rpad);
+    HIP_TRY(ctx, hipMemcpyAsync(E.data(), ctx->d_E, sizeof(int32_t) * ctx->Rpad, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    for (int64_t r = 0; r < ctx->R; ++r) E_out[r] = E[r];
+    return RRRMC_OK;
+}
+
+int32_t rrrmc_get_fields(rrrmc_ctx* ctx, int64_t* lfields_out)
+{
+    int32_t rc = ensure_state(ctx, true);
+    if (rc) return rc;
+    if (!lfields_out) return fail(ctx, RRRMC_ERR_INVALID_ARG, "lfields_out is NULL");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    uint8_t* d_nun = nullptr;
+    HIP_TRY(ctx, hipMalloc(&d_nun, (size_t)ctx->Rpad * ctx->N));
+    rc = run_energy(ctx, d_nun);
+    if (rc) { (void)hipFree(d_nun); return rc; }
+    std::vector<uint8_t> nun((size_t)ctx->Rpad * ctx->N);
+    hipError_t e = hipMemcpyAsync(nun.data(), d_nun, nun.size(), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    (void)hipFree(d_nun);
+    HIP_TRY(ctx, e);
+    // lfields[x] = -dE(x) = -2 (K - 2 n)   (src/graphs/RRG.jl:164-189, 236-244)
+    for (int64_t r = 0; r < ctx->R; ++r)
+        for (int64_t x = 0; x < ctx->N; ++x) lfields_out[r * ctx->N + x] = 4 * (int64_t)nun[r * ctx->N + x] - 2 * ctx->K;
+    return RRRMC_OK;
+}
+
+int32_t rrrmc_standard_mc_async(rrrmc_ctx* ctx, double beta, int64_t iters, int64_t step)
+{
+    int32_t rc = ensure_state(ctx, true);
+    if (rc) return rc;
+    if (iters < 0) return fail(ctx, RRRMC_ERR_INVALID_ARG, "iters must be >= 0, given %lld", (long long)iters);
+    if (step < 1) return fail(ctx, RRRMC_ERR_INVALID_ARG, "step must be >= 1, given %lld", (long long)step);
+    if (std::isnan(beta)) return fail(ctx, RRRMC_ERR_INVALID_ARG, "beta is NaN");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const int64_t N = ctx->N, K = ctx->K;
+    const int C = ctx->C;
+    ctx->results_valid = false;
+    ctx->timing_valid = false;
+
+    // thresholds for the classes with dE > 0: class n (unsatisfied bonds) has dE = 2 (K - 2n)
+    SweepParams P{};
+    const int NT = (int)(K + 1) / 2;
+    for (int n = 0; n < NT; ++n) {
+        const double dE = 2.0 * (double)(K - 2 * n);
+        bool always;
+        P.T[n] = threshold64(std::exp(-beta * dE), &always);
+        if (always) P.always_mask |= 1u << n;
+    }
+
+    // chunk list: cuts at every multiple of `step` (a sample precedes the move of iteration k*step) and every C moves
+    const int64_t nsamp = iters / step;
+    std::vector<ChunkDesc> chunks;
+    chunks.reserve((size_t)(iters / C + nsamp + 2));
+    for (int64_t cur = 1; cur <= iters;) {
+        const int64_t next_sample = (cur / step + 1) * step;
+        int64_t end = cur + C;
+        if (end > next_sample) end = next_sample;
+        if (end > iters + 1) end = iters + 1;
+        ChunkDesc cd{};
+        cd.g0 = ctx->it_done + (uint64_t)cur;
+        cd.count = (uint32_t)(end - cur);
+        cd.flags = (cur % step == 0) ? kChunkSampleBefore : 0u;
+        chunks.push_back(cd);
+        cur = end;
+    }
+    const size_t nchunks = chunks.size();
+
+    // (re)allocate chunk and sample buffers
+    if (nchunks > ctx->chunks_cap) {
+        free_dev(ctx->d_chunks);
+        ctx->chunks_cap = 0;
+        HIP_TRY(ctx, hipMalloc(&ctx->d_chunks, sizeof(ChunkDesc) * nchunks));
+        ctx->chunks_cap = nchunks;
+    }
+    if (nchunks > ctx->h_chunks_cap) {
+        if (ctx->h_chunks) { (void)hipHostFree(ctx->h_chunks); ctx->h_chunks = nullptr; }
+        ctx->h_chunks_cap = 0;
+        HIP_TRY(ctx, hipHostMalloc(&ctx->h_chunks, sizeof(ChunkDesc) * nchunks));
+        ctx->h_chunks_cap = nchunks;
+    }
+    const size_t es_need = (size_t)(nsamp > 0 ? nsamp : 1) * ctx->Rpad;
+    if (es_need > ctx->Es_cap) {
+        free_dev(ctx->d_Es);
+        ctx->Es_cap = 0;
+        HIP_TRY(ctx, hipMalloc(&ctx->d_Es, sizeof(int32_t) * es_need));
+        ctx->Es_cap = es_need;
+    }
+
+    // batches: bounded by the plan buffers; slot_base restarts in every batch
+    struct Batch { size_t first, n; int64_t sample0; };
+    std::vector<Batch> batches;
+    {
+        size_t first = 0;
+        int64_t slots = 0, samples = 0, sample0 = 0;
+        for (size_t c = 0; c < nchunks; ++c) {
+            if (c > first && (slots + chunks[c].count > kMaxSlotsPerBatch || (int64_t)(c - first) >= kMaxChunksPerBatch)) {
+                batches.push_back({first, c - first, sample0});
+                first = c; slots = 0; sample0 = samples;
+            }
+            chunks[c].slot_base = (uint32_t)slots;
+            slots += chunks[c].count;
+            if (chunks[c].flags & kChunkSampleBefore) samples += 1;
+        }
+        if (nchunks > first) batches.push_back({first, nchunks - first, sample0});
+    }
+    if (nchunks) std::memcpy(ctx->h_chunks, chunks.data(), sizeof(ChunkDesc) * nchunks);
+
+    while (ctx->ev_sweep.size() < 2 * batches.size()) {
+        hipEvent_t e;
+        HIP_TRY(ctx, hipEventCreate(&e));
+        ctx->ev_sweep.push_back(e);
+    }
+
+    hipStream_t st = ctx->stream;
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_begin, st));
+    // E = energy(X, C) at the start of every call (src/RRRMC.jl:95); accepted = 0 (:96)
+    rc = run_energy(ctx, nullptr);
+    if (rc) return rc;
+    HIP_TRY(ctx, hipMemsetAsync(ctx->d_acc, 0, sizeof(int64_t) * ctx->Rpad, st));
+    if (nchunks) HIP_TRY(ctx, hipMemcpyAsync(ctx->d_chunks, ctx->h_chunks, sizeof(ChunkDesc) * nchunks, hipMemcpyHostToDevice, st));
+
+    P.spins = ctx->d_spins;
+    P.table = ctx->d_table;
+    P.slots = ctx->d_slots;
+    P.vecs = ctx->d_vecs;
+    P.Es = ctx->d_Es;
+    P.E_cur = ctx->d_E;
+    P.acc_cur = ctx->d_acc;
+    P.k0 = (uint32_t)ctx->seed;
+    P.k1 = (uint32_t)(ctx->seed >> 32);
+    P.group0 = ctx->replica0 / 32;
+    P.N = (int)N; P.C = C; P.TS = ctx->TS; P.Rpad = (int)ctx->Rpad;
+    sweep_fn fn = sweep_for_K((int)K);
+    int b = 0;
+    for (const Batch& bt : batches) {
+        hipLaunchKernelGGL(plan_kernel, dim3((unsigned)bt.n), dim3(kPlanThreads), ctx->plan_lds_bytes, st, ctx->d_chunks + bt.first,
+                           ctx->d_slots, ctx->d_vecs, ctx->d_A, (int)N, (int)K, C, P.k0, P.k1);
+        HIP_TRY(ctx, hipGetLastError());
+        P.chunks = ctx->d_chunks + bt.first;
+        P.nchunks = (int)bt.n;
+        P.sample0 = bt.sample0;
+        HIP_TRY(ctx, hipEventRecord(ctx->ev_sweep[2 * b], st));
+        hipLaunchKernelGGL(fn, dim3((unsigned)ctx->G), dim3(kSweepThreads), ctx->lds_bytes, st, P);
+        HIP_TRY(ctx, hipGetLastError());
+        HIP_TRY(ctx, hipEventRecord(ctx->ev_sweep[2 * b + 1], st));
+        ++b;
+    }
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_end, st));
+    ctx->sweep_launches = (int)batches.size();
+    ctx->nsamp = nsamp;
+    ctx->it_done += (uint64_t)iters;
+    ctx->results_valid = true;
+    ctx->timing_valid = true;
+    return RRRMC_OK;
+}
+
+int32_t rrrmc_sync(rrrmc_ctx* ctx)
+{
+    if (!ctx) return RRRMC_ERR_INVALID_ARG;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return RRRMC_OK;
+}
+
+int32_t rrrmc_fetch_results(rrrmc_ctx* ctx, int64_t* Es_out, int64_t* accepted_out)
+{
+    if (!ctx) return RRRMC_ERR_INVALID_ARG;
+    if (!ctx->results_valid) return fail(ctx, RRRMC_ERR_STATE, "no sampling call has been made");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (accepted_out) {
+        std::vector<int64_t> acc((size_t)ctx->Rpad);
+        HIP_TRY(ctx, hipMemcpy(acc.data(), ctx->d_acc, sizeof(int64_t) * ctx->Rpad, hipMemcpyDeviceToHost));
+        for (int64_t r = 0; r < ctx->R; ++r) accepted_out[r] = acc[r];
+    }
+    if (Es_out && ctx->nsamp > 0) {
+        int64_t* d_out = nullptr;
+        const size_t bytes = sizeof(int64_t) * (size_t)ctx->R * ctx->nsamp;
+        HIP_TRY(ctx, hipMalloc(&d_out, bytes));
+        const dim3 grid((unsigned)((ctx->nsamp + 31) / 32), (unsigned)ctx->G);
+        hipLaunchKernelGGL(transpose_es_kernel, grid, dim3(256), 0, ctx->stream, ctx->d_Es, d_out, ctx->nsamp, (int)ctx->Rpad, (int)ctx->R);
+        hipError_t e = hipGetLastError();
+        if (e == hipSuccess) e = hipMemcpyAsync(Es_out, d_out, bytes, hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        (void)hipFree(d_out);
+        HIP_TRY(ctx, e);
+    }
+    return RRRMC_OK;
+}
+
+int32_t rrrmc_standard_mc(rrrmc_ctx* ctx, double beta, int64_t iters, int64_t step, int64_t* Es_out, int64_t* accepted_out)
+{
+    int32_t rc = rrrmc_standard_mc_async(ctx, beta, iters, step);
+    if (rc) return rc;
+    rc = rrrmc_sync(ctx);
+    if (rc) return rc;
+    return rrrmc_fetch_results(ctx, Es_out, accepted_out);
+}
+
+int32_t rrrmc_last_timing(rrrmc_ctx* ctx, double* total_ms, double* sweep_ms, int32_t* sweep_launches)
+{
+    if (!ctx) return RRRMC_ERR_INVALID_ARG;
+    if (!ctx->timing_valid) return fail(ctx, RRRMC_ERR_STATE, "no sampling call has been made");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipEventSynchronize(ctx->ev_end));
+    float ms = 0.f;
+    HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev_begin, ctx->ev_end));
+    if (total_ms) *total_ms = ms;
+    double sw = 0.0;
+    for (int b = 0; b < ctx->sweep_launches; ++b) {
+        HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev_sweep[2 * b], ctx->ev_sweep[2 * b + 1]));
+        sw += ms;
+    }
+    if (sweep_ms) *sweep_ms = sw;
+    if (sweep_launches) *sweep_launches = ctx->sweep_launches;
+    return RRRMC_OK;
+}
+
+// ---- host-side graph constructors -------------------------------------------------------------------
+
+int32_t rrrmc_gen_rrg(int64_t N, int64_t K, uint64_t seed, int32_t* A_out)
+{
+    // gen_RRG, src/graphs/RRG.jl:26-69: pairing model, restart of the whole attempt on a self loop or a double edge
+    if (!A_out) return fail(nullptr, RRRMC_ERR_INVALID_ARG, "A_out is NULL");
+    if (K < 1 || N < 1) return fail(nullptr, RRRMC_ERR_INVALID_ARG, "N and K must be >= 1");
+    if ((N * K) % 2) return fail(nullptr, RRRMC_ERR_INVALID_ARG, "N * K must be even, given N=%lld, K=%lld", (long long)N, (long long)K);
+    const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+    const int64_t NK = N * K;
+    std::vector<int64_t> stubs((size_t)NK);
+    std::vector<std::vector<int32_t>> nb((size_t)N);
+    uint64_t ndraw = 0;
+    for (int attempt = 0; attempt < 100000; ++attempt) {
+        for (int64_t q = 0; q < NK; ++q) stubs[q] = q;
+        for (auto& v : nb) v.clear();
+        int64_t len = NK;
+        bool bad = false;
+        while (len > 0 && !bad) {
+            const int64_t j = (int64_t)mulhi64(stream_u64(k0, k1, TAG_GRAPH, ndraw++), (uint64_t)(len - 1));   // rand(1:(l-1)) - 1
+            const int64_t v1 = stubs[len - 1] % N;
+            std::swap(stubs[j], stubs[len - 2]);
+            const int64_t v2 = stubs[len - 2] % N;
+            len -= 2;
+            bad = (v1 == v2);
+            for (int32_t y : nb[v1]) bad = bad || (y == v2);
+            if (!bad) { nb[v1].push_back((int32_t)v2); nb[v2].push_back((int32_t)v1); }
+        }
+        if (bad) continue;
+        for (int64_t x = 0; x < N; ++x) {
+            std::vector<int32_t>& v = nb[x];
+            for (size_t a = 1; a < v.size(); ++a) for (size_t b2 = a; b2 > 0 && v[b2 - 1] > v[b2]; --b2) std::swap(v[b2 - 1], v[b2]);
+            for (int64_t k = 0; k < K; ++k) A_out[x * K + k] = v[k];
+        }
+        return RRRMC_OK;
+    }
+    return fail(nullptr, RRRMC_ERR_UNSUPPORTED, "gen_rrg: no simple graph after 100000 attempts (K too large?)");
+}
+
+int32_t rrrmc_gen_ea(int64_t L, int64_t D, int32_t* A_out)
+{
+    // gen_EA, src/graphs/EA.jl:24-43
+    if (!A_out) return fail(nullptr, RRRMC_ERR_INVALID_ARG, "A_out is NULL");
+    if (L < 2) return fail(nullptr, RRRMC_ERR_INVALID_ARG, "L must be >= 2, given: %lld", (long long)L);
+    if (D < 1) return fail(nullptr, RRRMC_ERR_INVALID_ARG, "D must be >= 1, given: %lld", (long long)D);
+    int64_t N = 1;
+    for (int64_t d = 0; d < D; ++d) N *= L;
+    std::vector<std::vector<int32_t>> nb((size_t)N);
+    for (int64_t x = 0; x < N; ++x) {
+        int64_t stride = 1;
+        for (int64_t d = 0; d < D; ++d, stride *= L) {
+            const int64_t c = (x / stride) % L;
+            const int64_t y = x + (((c + 1) % L) - c) * stride;
+            nb[x].push_back((int32_t)y);
+            nb[y].push_back((int32_t)x);
+        }
+    }
+    for (int64_t x = 0; x < N; ++x) {
+        std::vector<int32_t>& v = nb[x];
+        for (size_t a = 1; a < v.size(); ++a) for (size_t b = a; b > 0 && v[b - 1] > v[b]; --b) std::swap(v[b - 1], v[b]);
+        for (int64_t k = 0; k < 2 * D; ++k) A_out[x * 2 * D + k] = v[k];
+    }
+    return RRRMC_OK;
+}
+
+int32_t rrrmc_gen_couplings_pm1(int64_t N, int64_t K, const int32_t* A, uint64_t seed, int8_t* J_out)
+{
+    // gen_J, src/graphs/RRG.jl:71-96 / src/graphs/EA.jl:45-71 with rand((-1, 1)) (RRG.jl:154-156)
+    if (!A || !J_out) return fail(nullptr, RRRMC_ERR_INVALID_ARG, "A / J_out is NULL");
+    const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+    std::vector<int64_t> filled((size_t)N, 0);   // next unfilled slot of J[y]
+    std::memset(J_out, 0, (size_t)(N * K));
+    uint64_t ndraw = 0;
+    for (int64_t x = 0; x < N; ++x)
+        for (int64_t k = 0; k < K; ++k) {
+            const int64_t y = A[x * K + k];
+            if (y < 0 || y >= N) return fail(nullptr, RRRMC_ERR_INVALID_ARG, "A[%lld] out of range", (long long)(x * K + k));
+            if (x < y) {
+                const int8_t Jxy = mulhi64(stream_u64(k0, k1, TAG_COUPLING, ndraw++), 2) ? 1 : -1;
+                if (J_out[x * K + k] != 0) return fail(nullptr, RRRMC_ERR_INVALID_ARG, "inconsistent neighbour table at site %lld", (long long)x);
+                J_out[x * K + k] = Jxy;
+                while (filled[y] < K && J_out[y * K + filled[y]] != 0) filled[y]++;
+                if (filled[y] >= K) return fail(nullptr, RRRMC_ERR_INVALID_ARG, "inconsistent neighbour table at site %lld", (long long)y);
+                J_out[y * K + filled[y]] = Jxy;
+            }
+        }
+    for (int64_t q = 0; q < N * K; ++q)
+        if (J_out[q] == 0) return fail(nullptr, RRRMC_ERR_INVALID_ARG, "neighbour table is not symmetric");
+    return RRRMC_OK;
+}
+
+}  // extern "C"

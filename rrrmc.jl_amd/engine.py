@@ -1,0 +1,166 @@
+"""Sampler front-end: ``Engine`` owns a device context; ``standardMC`` mirrors src/RRRMC.jl:81-127."""
+import ctypes as C
+
+import numpy as np
+
+from ._lib import RRRMCError, check, lib
+from .graphs import DEFAULT_SEED, Config, nchunks
+
+MODEL_SPARSE_PM1 = 1
+
+
+class Engine:
+    """R replicas of one graph on one MI355X (one ctx = one device, SURVEY.md §8b "Threading")."""
+
+    def __init__(self, X, R=1, device=0, replica0=0):
+        self.X, self.R = X, int(R)
+        self._ctx = C.c_void_p()
+        check(lib().rrrmc_ctx_create(C.byref(self._ctx), MODEL_SPARSE_PM1, X.N, X.K, self.R, device, replica0))
+        try:
+            check(lib().rrrmc_set_graph(self._ctx, X.A, X.J), self._ctx)
+        except RRRMCError:
+            self.close()
+            raise
+
+    # -- lifetime ---------------------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_ctx", None) is not None and self._ctx:
+            lib().rrrmc_ctx_destroy(self._ctx)
+            self._ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    # -- state ------------------------------------------------------------------------------------
+    def seed(self, seed):
+        check(lib().rrrmc_seed(self._ctx, int(seed) & (2 ** 64 - 1)), self._ctx)
+
+    def iterations_done(self):
+        return int(lib().rrrmc_iterations_done(self._ctx))
+
+    def init_spins_random(self):
+        check(lib().rrrmc_init_spins_random(self._ctx), self._ctx)
+
+    def set_config(self, Cfg):
+        if Cfg.N != self.X.N:
+            raise ValueError("Invalid C0, wrong N, expected %d, given: %d" % (self.X.N, Cfg.N))   # RRRMC.jl:94
+        if Cfg.R != self.R:
+            raise ValueError("Invalid C0, wrong number of replicas, expected %d, given: %d" % (self.R, Cfg.R))
+        check(lib().rrrmc_set_spins(self._ctx, Cfg.s), self._ctx)
+
+    def get_config(self, out=None):
+        if out is None:
+            out = Config(self.X.N, self.R)
+        check(lib().rrrmc_get_spins(self._ctx, out.s), self._ctx)
+        return out
+
+    def energy(self):
+        E = np.zeros(self.R, np.int64)
+        check(lib().rrrmc_energy(self._ctx, E), self._ctx)
+        return E
+
+    def fields(self):
+        lf = np.zeros((self.R, self.X.N), np.int64)
+        check(lib().rrrmc_get_fields(self._ctx, lf.reshape(-1)), self._ctx)
+        return lf
+
+    # -- sampling ---------------------------------------------------------------------------------
+    def standard_mc(self, beta, iters, step=1, want_energies=True):
+        """Returns (Es[R, iters // step], accepted[R])."""
+        nsamp = int(iters) // int(step)
+        Es = np.zeros((self.R, nsamp), np.int64)
+        acc = np.zeros(self.R, np.int64)
+        check(lib().rrrmc_standard_mc(self._ctx, float(beta), int(iters), int(step),
+                                      Es.ctypes.data if (want_energies and nsamp) else None, acc.ctypes.data), self._ctx)
+        return Es, acc
+
+    def standard_mc_async(self, beta, iters, step=1):
+        check(lib().rrrmc_standard_mc_async(self._ctx, float(beta), int(iters), int(step)), self._ctx)
+        self._last = (int(iters), int(step))
+
+    def sync(self):
+        check(lib().rrrmc_sync(self._ctx), self._ctx)
+
+    def fetch_results(self, want_energies=True):
+        iters, step = self._last
+        nsamp = iters // step
+        Es = np.zeros((self.R, nsamp), np.int64)
+        acc = np.zeros(self.R, np.int64)
+        check(lib().rrrmc_fetch_results(self._ctx, Es.ctypes.data if (want_energies and nsamp) else None, acc.ctypes.data), self._ctx)
+        return Es, acc
+
+    def last_timing(self):
+        """(total_ms, sweep_ms, sweep_launches) of the last sampling call, from HIP events on the ctx's stream."""
+        t, s, n = C.c_double(0), C.c_double(0), C.c_int32(0)
+        check(lib().rrrmc_last_timing(self._ctx, C.byref(t), C.byref(s), C.byref(n)), self._ctx)
+        return t.value, s.value, n.value
+
+
+def standardMC(X, beta, iters, *, seed=DEFAULT_SEED, step=1, hook=None, C0=None, quiet=False,
+               replicas=None, device=0, replica0=0, engine=None):
+    """``standardMC(X, β, iters; seed, step, hook, C0, quiet)`` for a batch of replicas (src/RRRMC.jl:81-127).
+
+    Returns ``(Es, C)``: ``Es[r]`` is replica r's vector of energies (one per ``step`` iterations, taken
+    before the move of iteration k*step, RRRMC.jl:104-108) and ``C`` the final ``Config``.  As in the
+    reference ``C0`` is resumed and mutated in place, and ``seed <= 0`` does not reseed (meaningful with a
+    caller-supplied ``engine``, which carries the stream position).  ``hook(it, X, C, accepted, E)`` is
+    called every ``step`` iterations with per-replica arrays; returning False stops the run (:61-64).
+    """
+    own = engine is None
+    R = replicas if replicas is not None else (C0.R if C0 is not None else (engine.R if engine else 1))
+    if C0 is not None and C0.N != X.N:
+        raise ValueError("Invalid C0, wrong N, expected %d, given: %d" % (X.N, C0.N))   # RRRMC.jl:94
+    eng = engine if engine is not None else Engine(X, R, device=device, replica0=replica0)
+    try:
+        if seed > 0 or own:
+            eng.seed(seed if seed > 0 else 0)
+        if C0 is not None:
+            eng.set_config(C0)
+        elif own:
+            eng.init_spins_random()
+        Cfg = C0 if C0 is not None else Config(X.N, eng.R)
+        accepted = np.zeros(eng.R, np.int64)
+        it = 0
+        if hook is None:
+            Es, accepted = eng.standard_mc(beta, iters, step)
+            it = int(iters)
+        else:
+            samples = []
+            # run up to the move before iteration k*step, call the hook with that state, continue
+            while it < iters:
+                nxt = (it // step + 1) * step          # next sampled iteration
+                n = min(nxt - 1, iters) - it
+                if n > 0:
+                    _, a = eng.standard_mc(beta, n, step=n + 1, want_energies=False)
+                    accepted += a
+                    it += n
+                if nxt > iters:
+                    break
+                E = eng.energy()
+                samples.append(E)
+                eng.get_config(Cfg)
+                if not hook(nxt, X, Cfg, accepted.copy(), E):
+                    it = nxt
+                    break
+                _, a = eng.standard_mc(beta, 1, step=2, want_energies=False)   # the move of iteration nxt
+                accepted += a
+                it = nxt
+            Es = np.stack(samples, axis=1) if samples else np.zeros((eng.R, 0), np.int64)
+        eng.get_config(Cfg)
+        if not quiet:
+            print("samples = ", Es.shape[1])
+            print("iters = ", it)
+            print("accept rate = ", float(accepted.mean()) / max(it, 1))
+        return Es, Cfg
+    finally:
+        if own:
+            eng.close()

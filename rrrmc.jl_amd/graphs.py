@@ -1,0 +1,128 @@
+"""Graph and configuration objects: the data the drop-in boundary marshals.
+
+Indices are 0-based here; the Julia glue converts from the reference's 1-based tuples.
+"""
+import numpy as np
+
+from ._lib import check, lib
+
+DEFAULT_SEED = 167432777111  # src/RRRMC.jl:82
+
+
+def nchunks(N):
+    return (int(N) + 63) // 64
+
+
+class Config:
+    """R configurations of N spins in Julia BitVector chunk layout (src/Interface.jl:21-29).
+
+    ``s[r, c]`` is chunk c of replica r; spin x of replica r is bit (x & 63) of ``s[r, x >> 6]``,
+    sigma = 2*bit - 1.  ``Config(N, R)`` alone is all-zeros; random initialisation is done on the
+    device by ``Engine.init_spins_random`` (the reference draws rand!(BitVector), Interface.jl:26).
+    """
+
+    def __init__(self, N, R=1, s=None):
+        self.N = int(N)
+        self.R = int(R)
+        if s is None:
+            s = np.zeros((self.R, nchunks(N)), np.uint64)
+        s = np.ascontiguousarray(s, np.uint64).reshape(self.R, nchunks(N))
+        self.s = s
+
+    def __len__(self):
+        return self.N
+
+    def copy(self):
+        return Config(self.N, self.R, self.s.copy())
+
+    def __eq__(self, other):
+        return isinstance(other, Config) and self.N == other.N and self.R == other.R and bool((self.s == other.s).all())
+
+    def bits(self):
+        """[R, N] array of 0/1."""
+        x = np.arange(self.N)
+        return ((self.s[:, x >> 6] >> (x & 63).astype(np.uint64)) & np.uint64(1)).astype(np.uint8)
+
+    @staticmethod
+    def from_bits(bits):
+        bits = np.atleast_2d(np.asarray(bits)).astype(np.uint64)
+        R, N = bits.shape
+        s = np.zeros((R, nchunks(N)), np.uint64)
+        x = np.arange(N)
+        np.bitwise_or.at(s, (np.arange(R)[:, None], (x >> 6)[None, :]), bits << (x & 63).astype(np.uint64))
+        return Config(N, R, s)
+
+
+class _SparsePM1Graph:
+    """Common part of GraphRRG / GraphEA with LEV = (-1, 1): neighbour table A[N, K], couplings J[N, K]."""
+
+    def __init__(self, A, J):
+        A = np.ascontiguousarray(A, np.int32)
+        J = np.ascontiguousarray(J, np.int8)
+        if A.ndim != 2 or A.shape != J.shape:
+            raise ValueError("incompatible shapes of A and J: %r, %r" % (A.shape, J.shape))
+        if not np.isin(J, (-1, 1)).all():
+            raise ValueError("the given J is incompatible with levels (-1, 1)")   # RRG.jl:130
+        self.N, self.K = A.shape
+        self.A, self.J = A, J
+
+
+class GraphRRG(_SparsePM1Graph):
+    """``GraphRRG(N, K)`` — random regular graph, +-1 couplings (src/graphs/RRG.jl:140-162).
+
+    ``GraphRRG.from_AJ(A, J)`` is the inner constructor ``GraphRRG{Int,(-1,1),K}(A, J)`` (RRG.jl:122).
+    The disorder comes from the GRAPH / COUPLING Philox streams of ``seed`` (the reference uses the
+    global RNG, RRG.jl:45,155).
+    """
+
+    def __init__(self, N, K, LEV=(-1, 1), seed=DEFAULT_SEED):
+        if tuple(LEV) != (-1, 1):
+            raise NotImplementedError("only LEV = (-1, 1) is covered by the HIP path")
+        A = np.zeros((int(N), int(K)), np.int32)
+        check(lib().rrrmc_gen_rrg(N, K, seed, A))
+        J = np.zeros((int(N), int(K)), np.int8)
+        check(lib().rrrmc_gen_couplings_pm1(N, K, A, seed, J))
+        super().__init__(A, J)
+
+    @classmethod
+    def from_AJ(cls, A, J):
+        self = cls.__new__(cls)
+        _SparsePM1Graph.__init__(self, A, J)
+        return self
+
+
+class GraphEA(_SparsePM1Graph):
+    """``GraphEA(L, D)`` — Edwards-Anderson lattice, +-1 couplings (src/graphs/EA.jl:171-193)."""
+
+    def __init__(self, L, D, LEV=(-1, 1), seed=DEFAULT_SEED):
+        if tuple(LEV) != (-1, 1):
+            raise NotImplementedError("only LEV = (-1, 1) is covered by the HIP path")
+        N = int(L) ** int(D)
+        A = np.zeros((N, 2 * int(D)), np.int32)
+        check(lib().rrrmc_gen_ea(L, D, A))
+        J = np.zeros((N, 2 * int(D)), np.int8)
+        check(lib().rrrmc_gen_couplings_pm1(N, 2 * int(D), A, seed, J))
+        super().__init__(A, J)
+        self.L, self.D = int(L), int(D)
+
+    @classmethod
+    def from_AJ(cls, A, J):
+        self = cls.__new__(cls)
+        _SparsePM1Graph.__init__(self, A, J)
+        return self
+
+
+def getN(X):
+    """src/Interface.jl:145"""
+    return X.N
+
+
+def neighbors(X, i):
+    """src/Interface.jl:158; RRG.jl:261 (uA = neighbours with non-zero coupling), EA.jl:292 (de-duplicated)."""
+    return np.unique(X.A[i])
+
+
+def all_delta_e(X):
+    """allΔE (src/Interface.jl:200-201): RRG.jl:262-281, EA.jl:293 — sorted values of |dE|."""
+    K = X.K
+    return tuple(2 * m for m in range(K & 1, K + 1, 2))

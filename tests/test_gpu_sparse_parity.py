@@ -1,0 +1,127 @@
+"""GPU parity: the HIP sweep path (through the C ABI) against the CPU oracle on identical seeds.
+Bit-exact for +-J models: energies at every sample, final spins (BitVector chunks), accepted counts."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _graph(pkg, kind, seed):
+    if kind[0] == "rrg":
+        return pkg.GraphRRG(kind[1], kind[2], seed=seed)
+    return pkg.GraphEA(kind[1], kind[2], seed=seed)
+
+
+CASES = [
+    # kind,            R,   beta, iters, step
+    (("rrg", 10, 3),   32,  2.0,  10000, 100),    # test/runtests.jl:36,125-130 (GraphRRG(10,3), beta=2, 10^4 iters, step 100)
+    (("ea", 2, 3),     32,  2.0,  10000, 100),    # runtests.jl:46 GraphEA(2,3): L=2 => doubled neighbours
+    (("ea", 3, 2),     32,  2.0,  10000, 100),    # runtests.jl:56 GraphEA(3,2)
+    (("rrg", 128, 3),  1,   1.0,  20000, 1000),   # BASELINE config 1 shape (1 chain)
+    (("rrg", 128, 3),  40,  1.0,  5000,  1),      # step = 1 (reference default), R not a multiple of 32
+    (("rrg", 256, 3),  96,  0.5,  30000, 4096),
+    (("rrg", 1024, 3), 64,  1.0,  50000, 1024),
+    (("rrg", 4096, 3), 64,  1.0,  40000, 4096),   # BASELINE config 2 graph, few replicas
+    (("ea", 8, 3),     64,  1.0,  30000, 512),    # K = 6
+    (("rrg", 64, 5),   32,  0.7,  8000,  64),     # odd K > 3
+    (("rrg", 50, 4),   32,  1.3,  8000,  77),     # even K, step not dividing anything
+    (("rrg", 100, 7),  32,  0.4,  5000,  500),    # K = 7 (4 classes)
+    (("rrg", 64, 3),   32,  0.0,  3000,  100),    # beta = 0: everything accepted
+    (("rrg", 64, 3),   32,  50.0, 3000,  100),    # very low temperature: thresholds of ~2^-144 underflow the 64-bit fraction
+]
+
+
+@pytest.mark.parametrize("kind,R,beta,iters,step", CASES)
+def test_standard_mc_bit_exact(pkg, oracle, kind, R, beta, iters, step):
+    seed = 0xC0FFEE + 7 * kind[1] + R
+    X = _graph(pkg, kind, seed)
+    with pkg.Engine(X, R) as eng:
+        eng.seed(seed)
+        eng.init_spins_random()
+        C0 = eng.get_config()
+        E0 = eng.energy()
+        Es, acc = eng.standard_mc(beta, iters, step)
+        C1 = eng.get_config()
+        E1 = eng.energy()
+        lf = eng.fields()
+    A, J = X.A, X.J.astype(np.int32)
+    assert (C0.s == oracle.init_configs(seed, 0, R, X.N)).all()
+    Es_ref, ch_ref, acc_ref = oracle.standard_mc_sparse_batch(A, J, beta, iters, step, seed, C0.s)
+    assert Es.shape == Es_ref.shape
+    assert (Es == Es_ref).all()
+    assert (C1.s == ch_ref).all()
+    assert (acc == acc_ref).all()
+    for r in range(min(R, 4)):
+        e0 = oracle.sparse_energy(A, J, C0.s[r])
+        e1, lf_ref = oracle.sparse_energy(A, J, C1.s[r], want_fields=True)
+        assert E0[r] == e0 and E1[r] == e1
+        assert (lf[r] == lf_ref).all()
+
+
+def test_resume_continues_the_streams(pkg, oracle):
+    """Two calls without reseeding == one long call (reference: seed <= 0 keeps the RNG going, RRRMC.jl:89)."""
+    seed, N, R, beta = 99, 512, 64, 1.0
+    X = pkg.GraphRRG(N, 3, seed=seed)
+    A, J = X.A, X.J.astype(np.int32)
+    with pkg.Engine(X, R) as eng:
+        eng.seed(seed)
+        eng.init_spins_random()
+        C0 = eng.get_config()
+        Es1, a1 = eng.standard_mc(beta, 7000, 500)
+        assert eng.iterations_done() == 7000
+        Es2, a2 = eng.standard_mc(beta, 9001, 300)
+        C2 = eng.get_config()
+    r1 = oracle.standard_mc_sparse_batch(A, J, beta, 7000, 500, seed, C0.s)
+    r2 = oracle.standard_mc_sparse_batch(A, J, beta, 9001, 300, seed, r1[1], it0=7000)
+    assert (Es1 == r1[0]).all() and (a1 == r1[2]).all()
+    assert (Es2 == r2[0]).all() and (a2 == r2[2]).all()
+    assert (C2.s == r2[1]).all()
+
+
+def test_sharding_invariance(pkg, oracle):
+    """A shard with replica0 = 64 reproduces replicas 64..127 of the unsharded job."""
+    seed, N, beta, iters, step = 4242, 256, 1.0, 6000, 250
+    X = pkg.GraphRRG(N, 3, seed=seed)
+    with pkg.Engine(X, 128) as eng:
+        eng.seed(seed); eng.init_spins_random()
+        Es_all, acc_all = eng.standard_mc(beta, iters, step)
+        C_all = eng.get_config()
+    with pkg.Engine(X, 64, replica0=64) as eng:
+        eng.seed(seed); eng.init_spins_random()
+        Es_sh, acc_sh = eng.standard_mc(beta, iters, step)
+        C_sh = eng.get_config()
+    assert (Es_sh == Es_all[64:]).all() and (acc_sh == acc_all[64:]).all() and (C_sh.s == C_all.s[64:]).all()
+
+
+def test_set_spins_roundtrip_and_c0(pkg, oracle):
+    seed, N, R = 5, 200, 37
+    X = pkg.GraphRRG(N, 3, seed=seed)
+    rng = np.random.default_rng(3)
+    C0 = pkg.Config.from_bits(rng.integers(0, 2, (R, N)))
+    with pkg.Engine(X, R) as eng:
+        eng.seed(seed)
+        eng.set_config(C0)
+        assert eng.get_config() == C0
+        Es, acc = eng.standard_mc(1.2, 4000, 40)
+        C1 = eng.get_config()
+    ref = oracle.standard_mc_sparse_batch(X.A, X.J.astype(np.int32), 1.2, 4000, 40, seed, C0.s)
+    assert (Es == ref[0]).all() and (C1.s == ref[1]).all() and (acc == ref[2]).all()
+
+
+def test_standardMC_front_end_and_hook(pkg, oracle):
+    """standardMC(X, beta, iters; step, seed, hook): the reference's own check — tracked E == energy(X, C) at
+    every sample (test/runtests.jl:12-20) — plus equality with the hook-free run."""
+    seed = 8426732438942 % (2 ** 63)
+    X = pkg.GraphRRG(10, 3, seed=seed)
+    seen = []
+
+    def hook(it, X_, C, accepted, E):
+        for r in range(C.R):
+            assert E[r] == oracle.sparse_energy(X_.A, X_.J.astype(np.int32), C.s[r])
+        seen.append((it, E.copy()))
+        return True
+
+    Es_h, C_h = pkg.standardMC(X, 2.0, 2000, step=100, seed=seed, hook=hook, quiet=True, replicas=32)
+    Es, C = pkg.standardMC(X, 2.0, 2000, step=100, seed=seed, quiet=True, replicas=32)
+    assert [it for it, _ in seen] == list(range(100, 2001, 100))
+    assert (Es_h == Es).all() and C_h == C
