@@ -1,0 +1,146 @@
+#!/usr/bin/env python3
+"""Headline benchmark: spin-flip attempts per second of standardMC on GraphRRG(N=4096, K=3, +-J), beta = 1,
+8192 replicas per MI355X (BASELINE.json configs[1]).
+
+  python bench.py --gpus N --steps K --warmup W
+One "step" = one sampling call (rrrmc_standard_mc_async) of ITERS iterations for every replica with the
+configuration already resident in HBM; results (energy samples, accepted counts) stay in HBM inside the
+timed region.  For N > 1 launch under torch.distributed.run: one process per GPU, replicas sharded by
+global replica id (no data-path collective; one RCCL all_gather of observables after the timed region).
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+import __graft_entry__ as entry  # noqa: E402
+
+N_SITES, K_DEG, BETA = 4096, 3, 1.0
+REPLICAS_PER_GPU = 8192
+ITERS = 1 << 22          # iterations per replica per step (1024 lattice sweeps)
+SAMPLE_STEP = 1 << 12    # energy sample every N iterations
+SEED = 0x5EED
+HBM_PEAK_GBS = 8000.0    # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def cpu_baseline(O, X, seconds_target=12.0):
+    """Single-thread CPU oracle (port of the reference loop) on a bounded sample of the same workload."""
+    A, J = X.A, X.J.astype(np.int32)
+    iters, R = 1 << 21, 1
+    ch = O.init_configs(SEED, 0, R, N_SITES)
+    t0 = time.perf_counter()
+    O.standard_mc_sparse_batch(A, J, BETA, iters, SAMPLE_STEP, SEED, ch)
+    dt = time.perf_counter() - t0
+    R = max(1, min(64, int(seconds_target / max(dt, 1e-3))))
+    ch = O.init_configs(SEED, 0, R, N_SITES)
+    t0 = time.perf_counter()
+    O.standard_mc_sparse_batch(A, J, BETA, iters, SAMPLE_STEP, SEED, ch)
+    dt = time.perf_counter() - t0
+    return {"value": R * iters / dt, "unit": "attempts/s", "cores": 1, "kind": "port",
+            "sample": "%d replicas x 2^21 iterations of the same graph/beta, single thread, oracle/rrrmc_oracle.c (%.1f s)" % (R, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=6)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--iters", type=int, default=ITERS)
+    ap.add_argument("--replicas", type=int, default=REPLICAS_PER_GPU)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    n_gpus = world
+
+    entry.build() if rank == 0 and not os.path.exists(os.path.join(ROOT, "rrrmc.jl_amd", "lib", "librrrmc_hip.so")) else None
+    pkg = entry.load_package()
+    X = pkg.GraphRRG(N_SITES, K_DEG, seed=SEED)
+    R = args.replicas
+    eng = pkg.Engine(X, R, device=local_rank, replica0=rank * R)
+    eng.seed(SEED)
+    eng.init_spins_random()
+
+    def barrier():
+        if dist is not None:
+            import torch
+            dist.barrier()
+            torch.cuda.synchronize()
+        eng.sync()
+
+    for _ in range(args.warmup):
+        eng.standard_mc_async(BETA, args.iters, SAMPLE_STEP)
+    barrier()
+    sweep_ms, launches = 0.0, 0
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        eng.standard_mc_async(BETA, args.iters, SAMPLE_STEP)
+        if args.steps <= 64:      # HIP-event bookkeeping of each call (forces that call's completion)
+            _, s, n = eng.last_timing()
+            sweep_ms += s
+            launches += n
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        import torch
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    Es, acc = eng.fetch_results()
+    acc_rate = float(acc.mean()) / args.iters
+    e_mean = float(Es[:, -1].mean()) / N_SITES if Es.shape[1] else float("nan")
+    if dist is not None:   # the only exchange: gather per-rank observables over RCCL
+        import torch
+        obs = torch.tensor([acc_rate, e_mean], dtype=torch.float64, device="cuda")
+        allobs = [torch.zeros_like(obs) for _ in range(world)]
+        dist.all_gather(allobs, obs)
+        acc_rate = float(sum(o[0].item() for o in allobs) / world)
+        e_mean = float(sum(o[1].item() for o in allobs) / world)
+
+    if rank == 0:
+        attempts = float(R) * args.iters * args.steps * n_gpus
+        value = attempts / dt
+        bytes_per_attempt = 1.0 + acc_rate * (3 + 3 * K_DEG)          # SURVEY.md §8d fixed-width accounting
+        out = {
+            "metric": "spin-flip attempts/sec (whole node), GraphRRG N=4096 K=3 +-J standardMC beta=1.0",
+            "value": value, "unit": "attempts/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u32", "data": "synthetic",
+            "config": {"workload": "GraphRRG(N=4096,K=3,+-J) standardMC beta=1.0, %d replicas per GPU, %d iterations per replica per step, energy sample every %d"
+                                   % (R, args.iters, SAMPLE_STEP),
+                       "replicas_total": R * n_gpus, "acceptance": acc_rate, "energy_per_spin": e_mean,
+                       "parallelism": "replicas sharded x%d, no data-path collective" % n_gpus},
+        }
+        if launches:
+            per_launch_attempts = float(R) * args.iters * args.steps / launches
+            avg_ms = sweep_ms / launches
+            achieved = bytes_per_attempt * per_launch_attempts / (avg_ms * 1e-3) / 1e9
+            out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                               "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                               "kernel": "sweep_kernel<3>", "avg_launch_ms": avg_ms, "launches": launches,
+                               "algorithmic_bytes_per_attempt": bytes_per_attempt}
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(entry.load_oracle(), X)
+        print(json.dumps(out))
+    eng.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

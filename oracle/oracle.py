@@ -56,11 +56,11 @@ def lib():
         L.orc_sparse_energy.restype = C.c_int64
         L.orc_sparse_energy.argtypes = [C.c_int64, C.c_int64, i32p, i32p, u64p, C.c_void_p]
         L.orc_standard_mc_sparse.restype = C.c_int64
-        L.orc_standard_mc_sparse.argtypes = [C.c_int64, C.c_int64, i32p, i32p, C.c_double, C.c_int64, C.c_int64,
+        L.orc_standard_mc_sparse.argtypes = [C.c_int, C.c_int64, C.c_int64, i32p, i32p, C.c_double, C.c_int64, C.c_int64,
                                              C.c_uint64, C.c_uint64, C.c_uint32, u64p, i64p,
                                              C.POINTER(C.c_int64), C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_standard_mc_sparse_batch.restype = C.c_int64
-        L.orc_standard_mc_sparse_batch.argtypes = [C.c_int64, C.c_int64, i32p, i32p, C.c_double, C.c_int64,
+        L.orc_standard_mc_sparse_batch.argtypes = [C.c_int, C.c_int64, C.c_int64, i32p, i32p, C.c_double, C.c_int64,
                                                    C.c_int64, C.c_uint64, C.c_uint64, C.c_uint32, C.c_int64,
                                                    u64p, i64p, i64p]
         L.orc_all_delta_e_pm1.restype = C.c_int64
@@ -140,8 +140,11 @@ def sparse_energy(A, J, chunks, want_fields=False):
     return (int(E), lf) if want_fields else int(E)
 
 
-def standard_mc_sparse(A, J, beta, iters, step, seed, chunks, it0=0, replica=0, trace=False):
-    """One chain.  Returns (Es, chunks_out, accepted, lfields[, sites, flips])."""
+FORM = {"rrg": 0, "ea": 1}
+
+
+def standard_mc_sparse(A, J, beta, iters, step, seed, chunks, it0=0, replica=0, trace=False, form="rrg"):
+    """One chain (form: which graph type's update_cache! is followed, 'rrg' = GraphRRG, 'ea' = GraphEA).  Returns (Es, chunks_out, accepted, lfields[, sites, flips])."""
     N, K = A.shape
     ch = np.array(chunks, np.uint64, copy=True)
     Es = np.zeros(max(iters // step, 1), np.int64)
@@ -149,14 +152,14 @@ def standard_mc_sparse(A, J, beta, iters, step, seed, chunks, it0=0, replica=0, 
     lf = np.zeros(N, np.int64)
     sites = np.zeros(iters if trace else 1, np.int32)
     flips = np.zeros(iters if trace else 1, np.uint8)
-    n = lib().orc_standard_mc_sparse(N, K, A, J, beta, iters, step, seed, it0, replica, ch, Es, C.byref(acc),
+    n = lib().orc_standard_mc_sparse(FORM[form], N, K, A, J, beta, iters, step, seed, it0, replica, ch, Es, C.byref(acc),
                                      lf.ctypes.data, sites.ctypes.data if trace else None,
                                      flips.ctypes.data if trace else None)
     out = (Es[:n], ch, int(acc.value), lf)
     return out + (sites, flips) if trace else out
 
 
-def standard_mc_sparse_batch(A, J, beta, iters, step, seed, chunks, it0=0, replica0=0):
+def standard_mc_sparse_batch(A, J, beta, iters, step, seed, chunks, it0=0, replica0=0, form="rrg"):
     """R chains, chunks shaped [R, nchunks].  Returns (Es[R, nsamp], chunks_out, accepted[R])."""
     N, K = A.shape
     ch = np.array(chunks, np.uint64, copy=True)
@@ -164,7 +167,7 @@ def standard_mc_sparse_batch(A, J, beta, iters, step, seed, chunks, it0=0, repli
     nsamp = iters // step
     Es = np.zeros((R, max(nsamp, 1)), np.int64)
     acc = np.zeros(R, np.int64)
-    lib().orc_standard_mc_sparse_batch(N, K, A, J, beta, iters, step, seed, it0, replica0, R, ch,
+    lib().orc_standard_mc_sparse_batch(FORM[form], N, K, A, J, beta, iters, step, seed, it0, replica0, R, ch,
                                        Es.reshape(-1)[: R * nsamp] if nsamp else Es.reshape(-1), acc)
     return Es[:, :nsamp] if nsamp else Es[:, :0], ch, acc
 

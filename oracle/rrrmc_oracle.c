@@ -165,7 +165,10 @@ typedef struct {
     const int32_t *A, *J;
     int64_t *lfields, *lfields_last;   /* LocalFields: src/Common.jl:27-36 */
     int64_t move_last;                 /* -1 = none (reference: 0) */
+    int ea_form;                       /* 0: GraphRRG's update_cache!, 1: GraphEA's (walks the de-duplicated uA) */
 } sparse_t;
+
+enum { ORC_FORM_RRG = 0, ORC_FORM_EA = 1 };
 
 /* energy: src/graphs/RRG.jl:164-189 (EA twin src/graphs/EA.jl:195-222). Also (re)builds the cache. */
 static int64_t sparse_energy(sparse_t *X, const uint64_t *s)
@@ -191,12 +194,20 @@ static int64_t sparse_energy(sparse_t *X, const uint64_t *s)
 /* delta_energy: src/graphs/RRG.jl:236-244, src/graphs/EA.jl:266-275 */
 static inline int64_t sparse_delta_energy(const sparse_t *X, int64_t move) { return -X->lfields[move]; }
 
-/* update_cache!: src/graphs/RRG.jl:191-234, src/graphs/EA.jl:224-264; called after the bit flip. */
+/* uA[move] of GraphEA (src/graphs/EA.jl:158): the sorted neighbour tuple with repeats removed.  A is
+ * sorted, so a repeat is an entry equal to its predecessor (for L = 2 every neighbour appears twice). */
+static inline int ea_is_repeat(const int32_t *Ax, int64_t k) { return k > 0 && Ax[k] == Ax[k - 1]; }
+
+/* update_cache!, called after the bit flip.
+ * GraphRRG form: src/graphs/RRG.jl:191-234.  GraphEA form: src/graphs/EA.jl:224-264 — same arithmetic, but the
+ * undo buffer is saved/swapped once per DISTINCT neighbour (uA), which is what makes the L = 2 lattice
+ * (two parallel bonds per neighbour) work. */
 static void sparse_update_cache(sparse_t *X, const uint64_t *s, int64_t move)
 {
     const int32_t *Ax = X->A + move * X->K;
-    if (X->move_last == move) {          /* undo fast path: RRG.jl:198-209 */
+    if (X->move_last == move) {          /* undo fast path: RRG.jl:198-209, EA.jl:231-241 */
         for (int64_t k = 0; k < X->K; ++k) {
+            if (X->ea_form && ea_is_repeat(Ax, k)) continue;
             int64_t y = Ax[k];
             int64_t t = X->lfields[y]; X->lfields[y] = X->lfields_last[y]; X->lfields_last[y] = t;
         }
@@ -206,11 +217,14 @@ static void sparse_update_cache(sparse_t *X, const uint64_t *s, int64_t move)
     }
     const int32_t *Jx = X->J + move * X->K;
     int sx = spin_bit(s, move);
+    if (X->ea_form)                      /* EA.jl:245-248 */
+        for (int64_t k = 0; k < X->K; ++k)
+            if (!ea_is_repeat(Ax, k)) X->lfields_last[Ax[k]] = X->lfields[Ax[k]];
     for (int64_t k = 0; k < X->K; ++k) {
         int64_t y = Ax[k];
         int64_t sxy = 1 - 2 * (sx ^ spin_bit(s, y));
         int64_t lfy = X->lfields[y];
-        X->lfields_last[y] = lfy;
+        if (!X->ea_form) X->lfields_last[y] = lfy;      /* RRG.jl:219 */
         X->lfields[y] = lfy - 4 * sxy * (int64_t)Jx[k];
     }
     int64_t lfm = X->lfields[move];
@@ -222,7 +236,7 @@ static void sparse_update_cache(sparse_t *X, const uint64_t *s, int64_t move)
 ORC_API int64_t orc_sparse_energy(int64_t N, int64_t K, const int32_t *A, const int32_t *J,
                                   const uint64_t *chunks, int64_t *lfields_out)
 {
-    sparse_t X = {N, K, A, J, NULL, NULL, -1};
+    sparse_t X = {N, K, A, J, NULL, NULL, -1, 0};
     X.lfields = (int64_t *)malloc((size_t)N * sizeof(int64_t));
     X.lfields_last = (int64_t *)malloc((size_t)N * sizeof(int64_t));
     int64_t E = sparse_energy(&X, chunks);
@@ -243,6 +257,7 @@ static inline int accept_move(double x, uint64_t seed, uint64_t g, uint32_t repl
 
 /*
  * standardMC: src/RRRMC.jl:81-127 for a sparse integer model, one chain.
+ *   form            ORC_FORM_RRG (GraphRRG) or ORC_FORM_EA (GraphEA): which update_cache! is followed
  *   chunks  in/out  configuration (C0 is resumed and mutated in place, :93)
  *   it0             iterations already consumed from this seed's streams (the reference continues the
  *                   global RNG when seed <= 0, :89; here the caller passes the stream position)
@@ -250,13 +265,13 @@ static inline int accept_move(double x, uint64_t seed, uint64_t g, uint32_t repl
  *   sites_out/flips_out (optional, length iters): the attempted site and whether it was accepted
  * Returns the number of samples written.
  */
-ORC_API int64_t orc_standard_mc_sparse(int64_t N, int64_t K, const int32_t *A, const int32_t *J,
+ORC_API int64_t orc_standard_mc_sparse(int form, int64_t N, int64_t K, const int32_t *A, const int32_t *J,
                                        double beta, int64_t iters, int64_t step,
                                        uint64_t seed, uint64_t it0, uint32_t replica,
                                        uint64_t *chunks, int64_t *Es, int64_t *accepted_out,
                                        int64_t *lfields_out, int32_t *sites_out, uint8_t *flips_out)
 {
-    sparse_t X = {N, K, A, J, NULL, NULL, -1};
+    sparse_t X = {N, K, A, J, NULL, NULL, -1, form};
     X.lfields = (int64_t *)malloc((size_t)N * sizeof(int64_t));
     X.lfields_last = (int64_t *)malloc((size_t)N * sizeof(int64_t));
     int64_t E = sparse_energy(&X, chunks);           /* :95 */
@@ -283,14 +298,14 @@ ORC_API int64_t orc_standard_mc_sparse(int64_t N, int64_t K, const int32_t *A, c
 
 /* R independent chains (replica ids replica0 .. replica0+R-1), configurations stored replica-major:
  * chunks[r * nch + c].  Es is [R][nsamples]. */
-ORC_API int64_t orc_standard_mc_sparse_batch(int64_t N, int64_t K, const int32_t *A, const int32_t *J,
+ORC_API int64_t orc_standard_mc_sparse_batch(int form, int64_t N, int64_t K, const int32_t *A, const int32_t *J,
                                              double beta, int64_t iters, int64_t step,
                                              uint64_t seed, uint64_t it0, uint32_t replica0, int64_t R,
                                              uint64_t *chunks, int64_t *Es, int64_t *accepted)
 {
     int64_t nch = (N + 63) / 64, nsamp = iters / step, got = 0;
     for (int64_t r = 0; r < R; ++r)
-        got = orc_standard_mc_sparse(N, K, A, J, beta, iters, step, seed, it0, replica0 + (uint32_t)r,
+        got = orc_standard_mc_sparse(form, N, K, A, J, beta, iters, step, seed, it0, replica0 + (uint32_t)r,
                                      chunks + r * nch, Es + r * nsamp, accepted + r, NULL, NULL, NULL);
     return got;
 }

@@ -46,7 +46,7 @@ def test_standard_mc_bit_exact(pkg, oracle, kind, R, beta, iters, step):
         lf = eng.fields()
     A, J = X.A, X.J.astype(np.int32)
     assert (C0.s == oracle.init_configs(seed, 0, R, X.N)).all()
-    Es_ref, ch_ref, acc_ref = oracle.standard_mc_sparse_batch(A, J, beta, iters, step, seed, C0.s)
+    Es_ref, ch_ref, acc_ref = oracle.standard_mc_sparse_batch(A, J, beta, iters, step, seed, C0.s, form=kind[0])
     assert Es.shape == Es_ref.shape
     assert (Es == Es_ref).all()
     assert (C1.s == ch_ref).all()
