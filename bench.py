@@ -29,10 +29,10 @@ SEED = 0x5EED
 HBM_PEAK_GBS = 8000.0    # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
-def cpu_baseline(O, X, seconds_target=12.0):
+def cpu_baseline(O, X, seconds_target=15.0):
     """Single-thread CPU oracle (port of the reference loop) on a bounded sample of the same workload."""
     A, J = X.A, X.J.astype(np.int32)
-    iters, R = 1 << 21, 1
+    iters, R = 1 << 22, 1
     ch = O.init_configs(SEED, 0, R, N_SITES)
     t0 = time.perf_counter()
     O.standard_mc_sparse_batch(A, J, BETA, iters, SAMPLE_STEP, SEED, ch)
@@ -43,7 +43,7 @@ def cpu_baseline(O, X, seconds_target=12.0):
     O.standard_mc_sparse_batch(A, J, BETA, iters, SAMPLE_STEP, SEED, ch)
     dt = time.perf_counter() - t0
     return {"value": R * iters / dt, "unit": "attempts/s", "cores": 1, "kind": "port",
-            "sample": "%d replicas x 2^21 iterations of the same graph/beta, single thread, oracle/rrrmc_oracle.c (%.1f s)" % (R, dt)}
+            "sample": "%d replicas x 2^22 iterations of the same graph/beta, single thread, oracle/rrrmc_oracle.c (%.1f s)" % (R, dt)}
 
 
 def main():

@@ -9,6 +9,16 @@ pytestmark = pytest.mark.gpu
 def _graph(pkg, kind, seed):
     if kind[0] == "rrg":
         return pkg.GraphRRG(kind[1], kind[2], seed=seed)
+    if kind[0] == "circ":
+        # K-regular circulant graph (the pairing model practically never yields a simple graph for K = 7):
+        # x ~ x +- 1..K//2 and, for odd K, x + N/2; couplings from the library's gen_J restatement
+        N, K = kind[1], kind[2]
+        offs = [d for j in range(1, K // 2 + 1) for d in (j, -j)] + ([N // 2] if K % 2 else [])
+        A = np.sort(np.array([[(x + d) % N for d in offs] for x in range(N)], np.int32), axis=1)
+        J = np.zeros((N, K), np.int8)
+        from rrrmc_jl_amd._lib import check, lib
+        check(lib().rrrmc_gen_couplings_pm1(N, K, A, seed, J))
+        return pkg.GraphRRG.from_AJ(A, J)
     return pkg.GraphEA(kind[1], kind[2], seed=seed)
 
 
@@ -25,7 +35,7 @@ CASES = [
     (("ea", 8, 3),     64,  1.0,  30000, 512),    # K = 6
     (("rrg", 64, 5),   32,  0.7,  8000,  64),     # odd K > 3
     (("rrg", 50, 4),   32,  1.3,  8000,  77),     # even K, step not dividing anything
-    (("rrg", 100, 7),  32,  0.4,  5000,  500),    # K = 7 (4 classes)
+    (("circ", 100, 7), 32,  0.4,  5000,  500),    # K = 7 (4 classes)
     (("rrg", 64, 3),   32,  0.0,  3000,  100),    # beta = 0: everything accepted
     (("rrg", 64, 3),   32,  50.0, 3000,  100),    # very low temperature: thresholds of ~2^-144 underflow the 64-bit fraction
 ]
@@ -46,7 +56,7 @@ def test_standard_mc_bit_exact(pkg, oracle, kind, R, beta, iters, step):
         lf = eng.fields()
     A, J = X.A, X.J.astype(np.int32)
     assert (C0.s == oracle.init_configs(seed, 0, R, X.N)).all()
-    Es_ref, ch_ref, acc_ref = oracle.standard_mc_sparse_batch(A, J, beta, iters, step, seed, C0.s, form=kind[0])
+    Es_ref, ch_ref, acc_ref = oracle.standard_mc_sparse_batch(A, J, beta, iters, step, seed, C0.s, form="ea" if kind[0] == "ea" else "rrg")
     assert Es.shape == Es_ref.shape
     assert (Es == Es_ref).all()
     assert (C1.s == ch_ref).all()
