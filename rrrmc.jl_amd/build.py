@@ -15,7 +15,8 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fvi
 
 
 def lib_path():
-    return OUT
+    # RRRMC_HIP_LIB: point the binding at another build of the same ABI (timing experiments, tools/ablate.sh)
+    return os.environ.get("RRRMC_HIP_LIB", OUT)
 
 
 def is_stale():

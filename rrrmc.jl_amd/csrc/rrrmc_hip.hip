@@ -23,6 +23,9 @@ thread_local std::string g_create_error;
 constexpr int64_t kMaxSlotsPerBatch = 1 << 22;    // plan buffers: 2 x 16 MiB
 constexpr int64_t kMaxChunksPerBatch = 1 << 16;
 constexpr int kLdsLimit = 160 * 1024;
+#ifdef RRRMC_STAMPS
+unsigned long long* g_stamps = nullptr;
+#endif
 
 }  // namespace
 
@@ -129,8 +132,8 @@ sweep_fn sweep_for_K(int K)
 
 size_t sweep_lds_bytes(int64_t N, int K, int TS, int C)
 {
-    const int NT = (K + 1) / 2, NF = NT + K + 1;
-    const size_t words = (size_t)((2 * N + 3) & ~3ll) + (size_t)2 * NF * C + (size_t)8 * C + 64;
+    const int NT = (K + 1) / 2, NW = NT + (K + 2) / 2, NQ = (NW + 3) / 4;
+    const size_t words = (size_t)((2 * N + 128 + 3) & ~3ll) + (size_t)2 * NQ * 4 * C + (size_t)8 * (C + 64);
     return words * 4 + (size_t)N * TS * 2;
 }
 
@@ -178,7 +181,7 @@ int32_t rrrmc_ctx_create(rrrmc_ctx** out, int32_t model, int64_t N, int64_t K, i
     if (model != RRRMC_MODEL_SPARSE_PM1) return fail(nullptr, RRRMC_ERR_UNSUPPORTED, "unknown model kind %d", model);
     if (N < 1 || K < 1 || R < 1) return fail(nullptr, RRRMC_ERR_INVALID_ARG, "N, K, R must be >= 1 (given N=%lld K=%lld R=%lld)", (long long)N, (long long)K, (long long)R);
     if (K > kMaxK) return fail(nullptr, RRRMC_ERR_UNSUPPORTED, "K=%lld: the sparse +-J kernels cover K <= %d", (long long)K, kMaxK);
-    if (N > 32767) return fail(nullptr, RRRMC_ERR_UNSUPPORTED, "N=%lld: the LDS-resident sparse kernel covers N <= 32767", (long long)N);
+    if (N > 8192) return fail(nullptr, RRRMC_ERR_UNSUPPORTED, "N=%lld: the LDS-resident sparse kernel covers N <= 8192", (long long)N);
     if (replica0 % 32) return fail(nullptr, RRRMC_ERR_INVALID_ARG, "replica0 must be a multiple of 32 (given %u)", replica0);
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
@@ -275,7 +278,7 @@ int32_t rrrmc_set_graph(rrrmc_ctx* ctx, const int32_t* A, const int8_t* J)
     std::vector<uint16_t> table((size_t)(N * ctx->TS), 0);
     for (int64_t x = 0; x < N; ++x)
         for (int64_t k = 0; k < K; ++k)
-            table[x * ctx->TS + k] = (uint16_t)(A[x * K + k] + (J[x * K + k] < 0 ? N : 0));
+            table[x * ctx->TS + k] = (uint16_t)(4 * (A[x * K + k] + (J[x * K + k] < 0 ? N : 0)));   // byte offset in the LDS spin array
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     HIP_TRY(ctx, hipMemcpy(ctx->d_A, A, sizeof(int32_t) * N * K, hipMemcpyHostToDevice));
@@ -498,6 +501,10 @@ int32_t rrrmc_standard_mc_async(rrrmc_ctx* ctx, double beta, int64_t iters, int6
     P.group0 = ctx->replica0 / 32;
     P.N = (int)N; P.C = C; P.TS = ctx->TS; P.Rpad = (int)ctx->Rpad;
     sweep_fn fn = sweep_for_K((int)K);
+#ifdef RRRMC_STAMPS
+    if (!g_stamps) HIP_TRY(ctx, hipMalloc(&g_stamps, sizeof(unsigned long long) * 16 * 65536));
+    P.stamps = g_stamps;
+#endif
     int b = 0;
     for (const Batch& bt : batches) {
         hipLaunchKernelGGL(plan_kernel, dim3((unsigned)bt.n), dim3(kPlanThreads), ctx->plan_lds_bytes, st, ctx->d_chunks + bt.first,
@@ -582,6 +589,16 @@ int32_t rrrmc_last_timing(rrrmc_ctx* ctx, double* total_ms, double* sweep_ms, in
     if (sweep_launches) *sweep_launches = ctx->sweep_launches;
     return RRRMC_OK;
 }
+
+#ifdef RRRMC_STAMPS
+// diagnostic builds only (tools/ablate.sh): busy shader cycles of the 16 waves of workgroup `group`, last sweep launch
+RRRMC_API int32_t rrrmc_debug_stamps(rrrmc_ctx* ctx, int32_t group, unsigned long long* out16)
+{
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipMemcpy(out16, g_stamps + (size_t)group * 16, sizeof(unsigned long long) * 16, hipMemcpyDeviceToHost));
+    return RRRMC_OK;
+}
+#endif
 
 // ---- host-side graph constructors -------------------------------------------------------------------
 
