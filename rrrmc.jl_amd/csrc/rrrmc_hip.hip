@@ -20,7 +20,7 @@ namespace {
 
 thread_local std::string g_create_error;
 
-constexpr int64_t kMaxSlotsPerBatch = 1 << 22;    // plan buffers: 2 x 16 MiB
+constexpr int64_t kMaxSlotsPerBatch = 1 << 22;    // plan buffers: 2 sets x 2 x 16 MiB; one sweep launch per batch
 constexpr int64_t kMaxChunksPerBatch = 1 << 16;
 constexpr int kLdsLimit = 160 * 1024;
 #ifdef RRRMC_STAMPS
@@ -55,8 +55,11 @@ struct rrrmc_ctx {
     size_t chunks_cap = 0;
     ChunkDesc* h_chunks = nullptr; // pinned
     size_t h_chunks_cap = 0;
-    uint32_t* d_slots = nullptr;
-    uint32_t* d_vecs = nullptr;
+    uint32_t* d_slots[2] = {nullptr, nullptr};   // double-buffered: the planner of batch b+1 overlaps the sweep of batch b
+    uint32_t* d_vecs[2] = {nullptr, nullptr};
+    hipStream_t plan_stream = nullptr;
+    hipEvent_t ev_upload = nullptr;
+    std::vector<hipEvent_t> ev_plan;     // plan of batch b finished
     // results of the last sampling call
     int32_t* d_Es = nullptr;
     size_t Es_cap = 0;
@@ -115,6 +118,21 @@ uint64_t threshold64(double p, bool* always)
     return (man + ((1ull << s) - 1)) >> s;
 }
 
+typedef void (*plan_fn)(ChunkDesc*, uint32_t*, uint32_t*, const int32_t*, int, int, uint32_t, uint32_t);
+plan_fn plan_for_K(int K)
+{
+    switch (K) {
+        case 1: return plan_kernel<1>;
+        case 2: return plan_kernel<2>;
+        case 3: return plan_kernel<3>;
+        case 4: return plan_kernel<4>;
+        case 5: return plan_kernel<5>;
+        case 6: return plan_kernel<6>;
+        case 7: return plan_kernel<7>;
+        default: return nullptr;
+    }
+}
+
 typedef void (*sweep_fn)(SweepParams);
 sweep_fn sweep_for_K(int K)
 {
@@ -133,13 +151,13 @@ sweep_fn sweep_for_K(int K)
 size_t sweep_lds_bytes(int64_t N, int K, int TS, int C)
 {
     const int NT = (K + 1) / 2, NW = NT + (K + 2) / 2, NQ = (NW + 3) / 4;
-    const size_t words = (size_t)((2 * N + 128 + 3) & ~3ll) + (size_t)2 * NQ * 4 * C + (size_t)8 * (C + 64);
+    const size_t words = (size_t)((2 * N + 128 + 3) & ~3ll) + (size_t)3 * NQ * 4 * C + (size_t)8 * (C + 64) + (size_t)2 * (4 + kLeftMax * (1 + 2 * NT));
     return words * 4 + (size_t)N * TS * 2;
 }
 
 size_t plan_lds_bytes(int64_t N, int K, int C)
 {
-    return 2 * ((size_t)3 * C + 2 * ((size_t)C + 2) + (size_t)C * K + (size_t)N);
+    return 4 * 3 * ((size_t)C + 2) + 2 * ((size_t)2 * C + (size_t)C * K + (size_t)N) + 16;
 }
 
 int32_t ensure_state(rrrmc_ctx* ctx, bool need_spins)
@@ -225,14 +243,18 @@ int32_t rrrmc_ctx_create(rrrmc_ctx** out, int32_t model, int64_t N, int64_t K, i
     CREATE_TRY(hipMalloc(&ctx->d_spins, sizeof(uint32_t) * ctx->G * N));
     CREATE_TRY(hipMalloc(&ctx->d_E, sizeof(int32_t) * ctx->Rpad));
     CREATE_TRY(hipMalloc(&ctx->d_acc, sizeof(int64_t) * ctx->Rpad));
-    CREATE_TRY(hipMalloc(&ctx->d_slots, sizeof(uint32_t) * kMaxSlotsPerBatch));
-    CREATE_TRY(hipMalloc(&ctx->d_vecs, sizeof(uint32_t) * kMaxSlotsPerBatch));
+    for (int i = 0; i < 2; ++i) {
+        CREATE_TRY(hipMalloc(&ctx->d_slots[i], sizeof(uint32_t) * kMaxSlotsPerBatch));
+        CREATE_TRY(hipMalloc(&ctx->d_vecs[i], sizeof(uint32_t) * kMaxSlotsPerBatch));
+    }
+    CREATE_TRY(hipStreamCreateWithFlags(&ctx->plan_stream, hipStreamNonBlocking));
+    CREATE_TRY(hipEventCreateWithFlags(&ctx->ev_upload, hipEventDisableTiming));
     CREATE_TRY(hipMemset(ctx->d_spins, 0, sizeof(uint32_t) * ctx->G * N));
     CREATE_TRY(hipMemset(ctx->d_E, 0, sizeof(int32_t) * ctx->Rpad));
     CREATE_TRY(hipMemset(ctx->d_acc, 0, sizeof(int64_t) * ctx->Rpad));
     sweep_fn fn = sweep_for_K((int)K);
     CREATE_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->lds_bytes));
-    CREATE_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(plan_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->plan_lds_bytes));
+    CREATE_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(plan_for_K((int)K)), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->plan_lds_bytes));
 #undef CREATE_TRY
     *out = ctx;
     return RRRMC_OK;
@@ -244,8 +266,11 @@ void rrrmc_ctx_destroy(rrrmc_ctx* ctx)
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     free_dev(ctx->d_A); free_dev(ctx->d_J); free_dev(ctx->d_table); free_dev(ctx->d_spins);
-    free_dev(ctx->d_E); free_dev(ctx->d_acc); free_dev(ctx->d_chunks); free_dev(ctx->d_slots);
-    free_dev(ctx->d_vecs); free_dev(ctx->d_Es);
+    free_dev(ctx->d_E); free_dev(ctx->d_acc); free_dev(ctx->d_chunks); free_dev(ctx->d_Es);
+    for (int i = 0; i < 2; ++i) { free_dev(ctx->d_slots[i]); free_dev(ctx->d_vecs[i]); }
+    if (ctx->plan_stream) { (void)hipStreamSynchronize(ctx->plan_stream); (void)hipStreamDestroy(ctx->plan_stream); }
+    if (ctx->ev_upload) (void)hipEventDestroy(ctx->ev_upload);
+    for (hipEvent_t e : ctx->ev_plan) (void)hipEventDestroy(e);
     if (ctx->h_chunks) (void)hipHostFree(ctx->h_chunks);
     for (hipEvent_t e : ctx->ev_sweep) (void)hipEventDestroy(e);
     if (ctx->ev_begin) (void)hipEventDestroy(ctx->ev_begin);
@@ -413,8 +438,9 @@ int32_t rrrmc_standard_mc_async(rrrmc_ctx* ctx, double beta, int64_t iters, int6
     for (int n = 0; n < NT; ++n) {
         const double dE = 2.0 * (double)(K - 2 * n);
         bool always;
-        P.T[n] = threshold64(std::exp(-beta * dE), &always);
+        const uint64_t T = threshold64(std::exp(-beta * dE), &always);
         if (always) P.always_mask |= 1u << n;
+        for (int plane = 0; plane < 64; ++plane) P.taum[plane * 4 + n] = ((T >> (63 - plane)) & 1ull) ? ~0u : 0u;
     }
 
     // chunk list: cuts at every multiple of `step` (a sample precedes the move of iteration k*step) and every C moves
@@ -480,6 +506,11 @@ int32_t rrrmc_standard_mc_async(rrrmc_ctx* ctx, double beta, int64_t iters, int6
         HIP_TRY(ctx, hipEventCreate(&e));
         ctx->ev_sweep.push_back(e);
     }
+    while (ctx->ev_plan.size() < batches.size()) {
+        hipEvent_t e;
+        HIP_TRY(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        ctx->ev_plan.push_back(e);
+    }
 
     hipStream_t st = ctx->stream;
     HIP_TRY(ctx, hipEventRecord(ctx->ev_begin, st));
@@ -488,11 +519,11 @@ int32_t rrrmc_standard_mc_async(rrrmc_ctx* ctx, double beta, int64_t iters, int6
     if (rc) return rc;
     HIP_TRY(ctx, hipMemsetAsync(ctx->d_acc, 0, sizeof(int64_t) * ctx->Rpad, st));
     if (nchunks) HIP_TRY(ctx, hipMemcpyAsync(ctx->d_chunks, ctx->h_chunks, sizeof(ChunkDesc) * nchunks, hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_upload, st));
+    HIP_TRY(ctx, hipStreamWaitEvent(ctx->plan_stream, ctx->ev_upload, 0));
 
     P.spins = ctx->d_spins;
     P.table = ctx->d_table;
-    P.slots = ctx->d_slots;
-    P.vecs = ctx->d_vecs;
     P.Es = ctx->d_Es;
     P.E_cur = ctx->d_E;
     P.acc_cur = ctx->d_acc;
@@ -502,22 +533,37 @@ int32_t rrrmc_standard_mc_async(rrrmc_ctx* ctx, double beta, int64_t iters, int6
     P.N = (int)N; P.C = C; P.TS = ctx->TS; P.Rpad = (int)ctx->Rpad;
     sweep_fn fn = sweep_for_K((int)K);
 #ifdef RRRMC_STAMPS
-    if (!g_stamps) HIP_TRY(ctx, hipMalloc(&g_stamps, sizeof(unsigned long long) * 16 * 65536));
+    if (!g_stamps) HIP_TRY(ctx, hipMalloc(&g_stamps, sizeof(unsigned long long) * 16 * (65536 + 4096)));
     P.stamps = g_stamps;
 #endif
-    int b = 0;
-    for (const Batch& bt : batches) {
-        hipLaunchKernelGGL(plan_kernel, dim3((unsigned)bt.n), dim3(kPlanThreads), ctx->plan_lds_bytes, st, ctx->d_chunks + bt.first,
-                           ctx->d_slots, ctx->d_vecs, ctx->d_A, (int)N, (int)K, C, P.k0, P.k1);
+    // The site-stream planner runs on its own stream, one batch ahead of the sweep: plan(b) may start as soon as
+    // sweep(b-2) has released the plan buffer set b & 1; sweep(b) waits for plan(b).
+    const int nb = (int)batches.size();
+    auto launch_plan = [&](int b) -> int32_t {
+        const Batch& bt = batches[b];
+        if (b >= 2) HIP_TRY(ctx, hipStreamWaitEvent(ctx->plan_stream, ctx->ev_sweep[2 * (b - 2) + 1], 0));
+        hipLaunchKernelGGL(plan_for_K((int)K), dim3((unsigned)bt.n), dim3(kPlanThreads), ctx->plan_lds_bytes, ctx->plan_stream,
+                           ctx->d_chunks + bt.first, ctx->d_slots[b & 1], ctx->d_vecs[b & 1], ctx->d_A, (int)N, C, P.k0, P.k1);
         HIP_TRY(ctx, hipGetLastError());
+        HIP_TRY(ctx, hipEventRecord(ctx->ev_plan[b], ctx->plan_stream));
+        return RRRMC_OK;
+    };
+    if (nb > 0) { rc = launch_plan(0); if (rc) return rc; }
+    for (int b = 0; b < nb; ++b) {
+        const Batch& bt = batches[b];
+        HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->ev_plan[b], 0));
         P.chunks = ctx->d_chunks + bt.first;
         P.nchunks = (int)bt.n;
         P.sample0 = bt.sample0;
+        P.slots = ctx->d_slots[b & 1];
+        P.vecs = ctx->d_vecs[b & 1];
         HIP_TRY(ctx, hipEventRecord(ctx->ev_sweep[2 * b], st));
         hipLaunchKernelGGL(fn, dim3((unsigned)ctx->G), dim3(kSweepThreads), ctx->lds_bytes, st, P);
         HIP_TRY(ctx, hipGetLastError());
         HIP_TRY(ctx, hipEventRecord(ctx->ev_sweep[2 * b + 1], st));
-        ++b;
+        // the next plan is enqueued AFTER this sweep so that the sweep's workgroups (one per CU, most of the LDS)
+        // are placed first and the planner's small workgroups fill in beside them
+        if (b + 1 < nb) { rc = launch_plan(b + 1); if (rc) return rc; }
     }
     HIP_TRY(ctx, hipEventRecord(ctx->ev_end, st));
     ctx->sweep_launches = (int)batches.size();
@@ -596,6 +642,13 @@ RRRMC_API int32_t rrrmc_debug_stamps(rrrmc_ctx* ctx, int32_t group, unsigned lon
 {
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     HIP_TRY(ctx, hipMemcpy(out16, g_stamps + (size_t)group * 16, sizeof(unsigned long long) * 16, hipMemcpyDeviceToHost));
+    return RRRMC_OK;
+}
+// per-step busy cycles of workgroup 0: out[4096][16]
+RRRMC_API int32_t rrrmc_debug_step_trace(rrrmc_ctx* ctx, unsigned long long* out)
+{
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipMemcpy(out, g_stamps + (size_t)16 * 65536, sizeof(unsigned long long) * 16 * 4096, hipMemcpyDeviceToHost));
     return RRRMC_OK;
 }
 #endif

@@ -20,9 +20,11 @@
 namespace rrrmc {
 
 constexpr int kWave = 64;
-constexpr int kSweepThreads = 1024;              // 16 waves: wave 0 consumes, wave 1 tallies, waves 2..15 produce
-constexpr int kFirstProducer = 2;
-constexpr int kProducerWaves = kSweepThreads / kWave - kFirstProducer;
+constexpr int kSweepThreads = 1024;              // 16 waves: consumer, tally, fixer and 13 producers
+constexpr int kConsumerWave = 0, kTallyWave = 1, kFixerWave = 13;   // 0, 1 and 13 sit on two different SIMDs' queues
+constexpr int kProducerWaves = kSweepThreads / kWave - 3;
+constexpr int kProducerBlocks = 3;               // Philox blocks (4 bit planes each) every producer lane computes
+constexpr int kLeftMax = 128;                    // capacity of the per-chunk list of slots still undecided after that
 constexpr int kPlanThreads = 256;
 constexpr int kMaxK = 7;                          // 3 bit planes for the unsatisfied-bond count
 constexpr int kRows = 4;                          // rows of 64 slots the consumer keeps in flight
@@ -38,23 +40,26 @@ struct ChunkDesc {
 };
 
 // ---------------------------------------------------------------------------------------------------
-// plan_kernel: one workgroup per chunk.
-//   slots[slot_base + p] = site | (t << 16)   attempts sorted by dependency level (t = index in chunk)
+// plan_kernel<K>: one workgroup per chunk (state-independent: the plan is shared by every replica group).
+//   slots[slot_base + p] = site | (t << 16)       attempts sorted by dependency level (t = index in chunk)
 //   vecs [slot_base + b] = start | ((n-1) << 16)  consumer batches: runs of n <= 256 sorted slots inside one level
 // Level rule: L(t) = 1 + max_{x in N[site_t]} W[x], W[site_t] = L(t), W = level of the last attempt AT x.
+// The order of the slots INSIDE a level is arbitrary (they commute), so it is left to LDS atomics.
 // ---------------------------------------------------------------------------------------------------
+template <int K>
 __global__ __launch_bounds__(kPlanThreads) void plan_kernel(ChunkDesc* __restrict__ chunks, uint32_t* __restrict__ slots,
                                                             uint32_t* __restrict__ vecs, const int32_t* __restrict__ A,
-                                                            int N, int K, int Cmax, uint32_t k0, uint32_t k1)
+                                                            int N, int Cmax, uint32_t k0, uint32_t k1)
 {
-    extern __shared__ uint16_t plds[];
-    uint16_t* s_site = plds;                   // [Cmax]
-    uint16_t* s_lvl = s_site + Cmax;           // [Cmax]
-    uint16_t* s_rank = s_lvl + Cmax;           // [Cmax]
-    uint16_t* s_cnt = s_rank + Cmax;           // [Cmax + 2]  slots per level (levels are 1-based)
-    uint16_t* s_start = s_cnt + Cmax + 2;      // [Cmax + 2]
-    uint16_t* s_nb = s_start + Cmax + 2;       // [Cmax * K]
-    uint16_t* s_W = s_nb + (size_t)Cmax * K;   // [N]
+    extern __shared__ uint32_t plds32[];
+    uint32_t* s_cnt = plds32;                                   // [Cmax + 2]  slots per level (levels are 1-based)
+    uint32_t* s_start = s_cnt + Cmax + 2;                       // [Cmax + 2]
+    uint32_t* s_cur = s_start + Cmax + 2;                       // [Cmax + 2]
+    uint16_t* s_site = reinterpret_cast<uint16_t*>(s_cur + Cmax + 2);   // [Cmax]
+    uint16_t* s_lvl = s_site + Cmax;                            // [Cmax]
+    uint16_t* s_nb = s_lvl + Cmax;                              // [Cmax * K]
+    uint16_t* s_W = s_nb + (size_t)Cmax * K;                    // [N]
+    __shared__ uint32_t s_maxlvl;
 
     const ChunkDesc cd = chunks[blockIdx.x];
     const int count = (int)cd.count;
@@ -63,30 +68,50 @@ __global__ __launch_bounds__(kPlanThreads) void plan_kernel(ChunkDesc* __restric
     for (int t = tid; t < count; t += kPlanThreads) {
         const uint32_t site = site_of(k0, k1, cd.g0 + (uint64_t)t, (uint32_t)N);
         s_site[t] = (uint16_t)site;
+#pragma unroll
         for (int k = 0; k < K; ++k) s_nb[t * K + k] = (uint16_t)A[(size_t)site * K + k];
     }
     for (int x = tid; x < N; x += kPlanThreads) s_W[x] = 0;
-    for (int l = tid; l < count + 2; l += kPlanThreads) s_cnt[l] = 0;
+    for (int l = tid; l < count + 2; l += kPlanThreads) { s_cnt[l] = 0; s_cur[l] = 0; }
     __syncthreads();
 
     if (tid == 0) {
+        // the sequential part: one dependent LDS round trip per attempt (operands of the next attempt are prefetched)
         uint32_t maxlvl = 0;
+        uint32_t site = count > 0 ? s_site[0] : 0u;
+        uint32_t nb[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) nb[k] = count > 0 ? s_nb[k] : 0u;
         for (int t = 0; t < count; ++t) {
-            uint32_t l = s_W[s_site[t]];
+            const int tn = t + 1 < count ? t + 1 : t;
+            const uint32_t site_n = s_site[tn];
+            uint32_t nb_n[K];
+#pragma unroll
+            for (int k = 0; k < K; ++k) nb_n[k] = s_nb[tn * K + k];
+            uint32_t l = s_W[site];
+#pragma unroll
             for (int k = 0; k < K; ++k) {
-                const uint32_t w = s_W[s_nb[t * K + k]];
+                const uint32_t w = s_W[nb[k]];
                 l = w > l ? w : l;
             }
             l += 1;
-            s_W[s_site[t]] = (uint16_t)l;
+            s_W[site] = (uint16_t)l;
             s_lvl[t] = (uint16_t)l;
-            s_rank[t] = s_cnt[l];
-            s_cnt[l] = (uint16_t)(s_cnt[l] + 1);
             maxlvl = l > maxlvl ? l : maxlvl;
+            site = site_n;
+#pragma unroll
+            for (int k = 0; k < K; ++k) nb[k] = nb_n[k];
         }
+        s_maxlvl = maxlvl;
+    }
+    __syncthreads();
+    for (int t = tid; t < count; t += kPlanThreads) atomicAdd(&s_cnt[s_lvl[t]], 1u);
+    __syncthreads();
+    if (tid == 0) {
+        const uint32_t maxlvl = s_maxlvl;
         uint32_t pos = 0, nvec = 0;
         for (uint32_t l = 1; l <= maxlvl; ++l) {
-            s_start[l] = (uint16_t)pos;
+            s_start[l] = pos;
             uint32_t n = s_cnt[l], q = pos;
             while (n > 0) {      // the consumer works on batches of <= kBatchSlots slots that lie inside one level
                 const uint32_t m = n < (uint32_t)kBatchSlots ? n : (uint32_t)kBatchSlots;
@@ -100,7 +125,8 @@ __global__ __launch_bounds__(kPlanThreads) void plan_kernel(ChunkDesc* __restric
     }
     __syncthreads();
     for (int t = tid; t < count; t += kPlanThreads) {
-        const uint32_t pos = (uint32_t)s_start[s_lvl[t]] + s_rank[t];
+        const uint32_t l = s_lvl[t];
+        const uint32_t pos = s_start[l] + atomicAdd(&s_cur[l], 1u);
         slots[cd.slot_base + pos] = (uint32_t)s_site[t] | ((uint32_t)t << 16);
     }
 }
@@ -122,7 +148,8 @@ struct SweepParams {
     int32_t* Es;              // [nsamples][Rpad] energies (sample-major); may be null
     int32_t* E_cur;           // [Rpad] running energy of every replica
     int64_t* acc_cur;         // [Rpad] accepted moves of this sampling call
-    uint64_t T[4];            // acceptance thresholds, class n = number of unsatisfied bonds (dE = 2(K-2n) > 0)
+    uint32_t taum[64 * 4];    // acceptance thresholds T_n as bit planes: [plane][n] = bit (63 - plane) of T_n as 0 / ~0;
+                              // class n = number of unsatisfied bonds (dE = 2(K-2n) > 0)
     uint32_t always_mask;     // bit n: class n is always accepted (exp(-beta dE) >= 1)
     uint32_t k0, k1;          // Philox key
     uint32_t group0;          // global id of this ctx's first group
@@ -139,10 +166,47 @@ template <int K> struct SweepCfg {
     static constexpr int NS = K <= 1 ? 2 : (K <= 3 ? 3 : 4);   // tally streams: A and the planes of n
 };
 
+// list of the slots of one chunk that the producers could not decide within kProducerBlocks blocks
+struct LeftList {
+    uint32_t* count;     // [1]
+    uint32_t* slot;      // [kLeftMax]      position in the chunk | (index of the attempt in the chunk << 16)
+    uint32_t* lt;        // [NT][kLeftMax]  masks so far
+    uint32_t* eq;        // [NT][kLeftMax]  replicas still undecided
+};
+
+template <int NT> __device__ __forceinline__ bool any_set(const uint32_t (&eq)[NT])
+{
+    uint32_t u = 0u;
+#pragma unroll
+    for (int n = 0; n < NT; ++n) u |= eq[n];
+    return u != 0u;
+}
+
+// four more bit planes (block pb of the ACCEPT stream) of the comparison u < T_n for the 32 replicas of a word.
+// taum[plane * 4 + n] is bit `plane` of T_n (plane 0 = MSB) spread to a full word (0 or ~0), precomputed by the
+// host: the index is wave-uniform, so the words are scalar loads and every VALU op below has a scalar operand.
+//   replicas still equal keep being equal where the u bit equals the threshold bit; those that leave with a u bit
+//   of 0 against a threshold bit of 1 are below T.
+template <int NT>
+__device__ __forceinline__ void refine_block(uint32_t (&lt)[NT], uint32_t (&eq)[NT], const Philox4& o, uint32_t pb, const uint32_t* __restrict__ taum)
+{
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const uint32_t w = o.w[j];
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+            const uint32_t tm = taum[(pb * 4 + j) * 4 + n];
+            const uint32_t e2 = eq[n] & ~(w ^ tm);
+            lt[n] |= (eq[n] ^ e2) & tm;
+            eq[n] = e2;
+        }
+    }
+}
+
 // ---- producers -------------------------------------------------------------------------------------
 template <int K>
 __device__ __forceinline__ void produce_chunk(const SweepParams& P, const ChunkDesc& cd, uint4* __restrict__ desc,
-                                              const uint16_t* __restrict__ tbl, int pw, int lane, uint32_t group)
+                                              const uint16_t* __restrict__ tbl, const LeftList& left, int pw, int lane, uint32_t group)
 {
     constexpr int NT = SweepCfg<K>::NT, NQ = SweepCfg<K>::NQ;
     const int C = P.C;
@@ -185,27 +249,34 @@ __device__ __forceinline__ void produce_chunk(const SweepParams& P, const ChunkD
             lt[n] = always ? 0xffffffffu : 0u;
             eq[n] = (live && !always) ? 0xffffffffu : 0u;
         }
-        // u < T_n, bit-sliced over the 32 replicas, most significant plane first, stopping as soon as every
-        // lane of the wave is decided (lazy evaluation of a counter-based stream: the result does not depend on
-        // where we stop).
-        for (uint32_t pb = 0; pb < 16; ++pb) {
-            uint32_t undecided = 0;
+        // u < T_n, bit-sliced over the 32 replicas, most significant plane first (lazy evaluation of a counter-based
+        // stream: the result does not depend on where we stop).  Every lane computes kProducerBlocks blocks of 4
+        // planes; the ~1.5 % of lanes that still have an undecided replica then hand the slot to the fixer wave
+        // through the leftover list, so that a producer's time does not depend on its unluckiest lane.
+        uint32_t pb = 0;
+        for (; pb < (uint32_t)kProducerBlocks; ++pb) {
+            if (!__any(any_set<NT>(eq))) break;
+            refine_block<NT>(lt, eq, accept_planes(P.k0, P.k1, g, group, pb), pb, P.taum);
+        }
+        bool need = any_set<NT>(eq);
+        const unsigned long long bal = __ballot(need);
+        if (bal != 0ull) {       // wave-uniform
+            uint32_t base = 0u;
+            if (lane == 0) base = atomicAdd(left.count, (uint32_t)__popcll(bal));
+            base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+            const uint32_t idx = base + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
+            if (need && idx < (uint32_t)kLeftMax) {
+                left.slot[idx] = (uint32_t)p | (slot & 0xffff0000u);     // position in the chunk | index of the attempt
 #pragma unroll
-            for (int n = 0; n < NT; ++n) undecided |= eq[n];
-            if (!__any(undecided != 0)) break;
-            const Philox4 o = accept_planes(P.k0, P.k1, g, group, pb);
+                for (int n = 0; n < NT; ++n) { left.lt[n * kLeftMax + idx] = lt[n]; left.eq[n * kLeftMax + idx] = eq[n]; }
+                need = false;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const uint32_t w = o.w[j];
-                const int sh = 63 - (int)(pb * 4 + j);
-#pragma unroll
-                for (int n = 0; n < NT; ++n) {
-                    const uint32_t taum = 0u - (uint32_t)((P.T[n] >> sh) & 1ull);   // wave-uniform
-                    const uint32_t z = w ^ ~taum;
-                    const uint32_t e2 = eq[n] & z;
-                    lt[n] |= (eq[n] ^ e2) & taum;
-                    eq[n] = e2;
-                }
+                for (int n = 0; n < NT; ++n) eq[n] = 0u;
+            }
+            // list full (practically never): finish those lanes here
+            for (; pb < 16u; ++pb) {
+                if (!__any(any_set<NT>(eq))) break;
+                refine_block<NT>(lt, eq, accept_planes(P.k0, P.k1, g, group, pb), pb, P.taum);
             }
         }
         if (live) {
@@ -215,6 +286,36 @@ __device__ __forceinline__ void produce_chunk(const SweepParams& P, const ChunkD
             for (int q = 0; q < NQ; ++q) desc[q * C + p] = make_uint4(f[4 * q], f[4 * q + 1], f[4 * q + 2], f[4 * q + 3]);
         }
     }
+}
+
+// ---- fixer: finishes the slots the producers left undecided and patches their masks into the descriptors ----
+template <int K>
+__device__ __forceinline__ void fix_chunk(const SweepParams& P, const ChunkDesc& cd, uint4* __restrict__ desc, const LeftList& left,
+                                          int lane, uint32_t group)
+{
+    constexpr int NT = SweepCfg<K>::NT;
+    uint32_t n = *left.count;
+    n = (uint32_t)__builtin_amdgcn_readfirstlane((int)n);
+    n = n < (uint32_t)kLeftMax ? n : (uint32_t)kLeftMax;
+    for (uint32_t base = 0; base < n; base += kWave) {
+        const uint32_t i = base + (uint32_t)lane;
+        const bool live = i < n;
+        uint32_t lt[NT], eq[NT], sl = 0u;
+        if (live) sl = left.slot[i];
+#pragma unroll
+        for (int q = 0; q < NT; ++q) { lt[q] = live ? left.lt[q * kLeftMax + i] : 0u; eq[q] = live ? left.eq[q * kLeftMax + i] : 0u; }
+        const uint64_t g = cd.g0 + (uint64_t)(sl >> 16);
+        for (uint32_t pb = kProducerBlocks; pb < 16u; ++pb) {
+            if (!__any(any_set<NT>(eq))) break;
+            refine_block<NT>(lt, eq, accept_planes(P.k0, P.k1, g, group, pb), pb, P.taum);
+        }
+        if (live) {
+            uint32_t* m = reinterpret_cast<uint32_t*>(desc + (sl & 0xffffu));      // the masks are the first NT words of q[0]
+#pragma unroll
+            for (int q = 0; q < NT; ++q) m[q] = lt[q];
+        }
+    }
+    if (lane == 0) *left.count = 0u;
 }
 
 // ---- consumer --------------------------------------------------------------------------------------
@@ -430,49 +531,111 @@ __device__ __forceinline__ void tally_add8(TallyState<NS>& t, const uint32_t (&x
 }
 
 // 32x32 bit-matrix transpose across the 32 lanes of each wave half: on return bit i of lane r is bit r of lane i.
-__device__ __forceinline__ uint32_t transpose32(uint32_t a, int lane)
+// Butterfly over J = 16, 8, 4, 2, 1: exchange with lane ^ J (ds_swizzle), rotate the partner's word so that the
+// bits to take land on the positions this lane gives up (the wrapped-around bits fall on positions it keeps and are
+// masked by the bit-field insert): 3 instructions per stage.
+struct TransposeConsts {
+    uint32_t keep[5];   // bit positions this lane keeps at stage s
+    uint32_t rot[5];    // right-rotation of the partner's word at stage s
+    __device__ __forceinline__ void init(int lane)
+    {
+        const uint32_t m[5] = {0x0000ffffu, 0x00ff00ffu, 0x0f0f0f0fu, 0x33333333u, 0x55555555u};
+#pragma unroll
+        for (int s = 0; s < 5; ++s) {
+            const int J = 16 >> s;
+            const bool hi = (lane & J) != 0;
+            keep[s] = hi ? ~m[s] : m[s];
+            rot[s] = hi ? (uint32_t)J : (uint32_t)(32 - J);
+        }
+    }
+};
+
+__device__ __forceinline__ uint32_t transpose32(uint32_t a, const TransposeConsts& tc)
 {
-#define RRRMC_TSTAGE(J, M)                                                                           \
+#define RRRMC_TSTAGE(S, J)                                                                           \
     {                                                                                                \
         const uint32_t o = (uint32_t)__builtin_amdgcn_ds_swizzle((int)a, ((J) << 10) | 0x1f);        \
-        const bool hi = (lane & (J)) != 0;                                                           \
-        const uint32_t keep = hi ? ~(M) : (M);                                                       \
-        const uint32_t sel = hi ? (o >> (J)) : (o << (J));                                           \
-        a = (a & keep) | (sel & ~keep);                                                              \
+        const uint32_t sel = __builtin_amdgcn_alignbit(o, o, tc.rot[S]);                             \
+        a = (a & tc.keep[S]) | (sel & ~tc.keep[S]);                                                  \
     }
-    RRRMC_TSTAGE(16, 0x0000ffffu)
-    RRRMC_TSTAGE(8, 0x00ff00ffu)
-    RRRMC_TSTAGE(4, 0x0f0f0f0fu)
-    RRRMC_TSTAGE(2, 0x33333333u)
-    RRRMC_TSTAGE(1, 0x55555555u)
+    RRRMC_TSTAGE(0, 16)
+    RRRMC_TSTAGE(1, 8)
+    RRRMC_TSTAGE(2, 4)
+    RRRMC_TSTAGE(3, 2)
+    RRRMC_TSTAGE(4, 1)
 #undef RRRMC_TSTAGE
     return a;
 }
 
-// Fold the counters into per-replica integers: totA / totS of replica (lane & 31), summed over both wave halves.
-// Branch-free over the planes (3 tree planes + kTallyHi x {S, Pd}) so that the independent transposes overlap.
+// Column sums of one stream of a counter set: returns, in lane r and r + 32, the count of replica r over this wave
+// half's 32 lanes (the caller adds the two halves).  Branch-free over the planes so that the transposes overlap.
 template <int NS>
-__device__ __forceinline__ void tally_flush(TallyState<NS>& t, int lane, uint32_t& totA, uint32_t& totS)
+__device__ __forceinline__ uint32_t tally_stream_total(const TallyState<NS>& t, int s, const TransposeConsts& tc)
 {
-    uint32_t tot[2] = {0u, 0u};
     const uint32_t ng = __builtin_amdgcn_readfirstlane(t.ngrp);
+    uint32_t c = 0u;
+#pragma unroll
+    for (int l = 0; l < 3; ++l) c += (uint32_t)__popc(transpose32(t.lo[s][l], tc)) << l;
+#pragma unroll
+    for (int l = 0; l < kTallyHi; ++l) {
+        const uint32_t pend = ((ng >> l) & 1u) ? t.Pd[s][l] : 0u;     // pending word is live iff bit l of the group count
+        c += ((uint32_t)__popc(transpose32(t.S[s][l], tc)) + (uint32_t)__popc(transpose32(pend, tc))) << (3 + l);
+    }
+    return c;
+}
+
+// Deferred flush.  Folding a counter set into per-replica integers costs ~11 transposes per stream; doing all of it in
+// the step where an energy sample falls would make the tally wave that step's slowest wave.  Instead the live set
+// is moved aside ("drain" set, registers) and one stream per step is folded; the sample is written when the last
+// stream is done.  Energies only have to be complete when the kernel ends, so the delay is invisible.
+template <int NS, int K> struct TallyDrain {
+    TallyState<NS> set;
+    uint32_t tot[2];        // partial totals (A, S) of this wave half
+    int phase;              // next stream to fold; NS = idle
+    bool emit;              // write an energy sample when done
+    int64_t sample;         // ... at this sample index
+
+    __device__ __forceinline__ void step(const TransposeConsts& tc)       // fold one stream
+    {
+        uint32_t c = 0u;
+        switch (phase) {        // wave-uniform
+            case 0: c = tally_stream_total<NS>(set, 0, tc); break;
+            case 1: c = tally_stream_total<NS>(set, 1 % NS, tc); break;
+            case 2: c = tally_stream_total<NS>(set, 2 % NS, tc); break;
+            default: c = tally_stream_total<NS>(set, 3 % NS, tc); break;
+        }
+        if (phase == 0) tot[0] += c; else tot[1] += c << (phase - 1);   // stream 0 counts A; streams 1.. are the planes of n
+        phase += 1;
+    }
+    // finished: update the running energy / accepted count and write the pending sample
+    __device__ __forceinline__ void finish(const SweepParams& P, int lane, int32_t& E_run, int64_t& A_run)
+    {
+        const uint32_t a = tot[0] + (uint32_t)__shfl_xor((int)tot[0], 32);
+        const uint32_t sn = tot[1] + (uint32_t)__shfl_xor((int)tot[1], 32);
+        E_run += 2 * (K * (int32_t)a - 2 * (int32_t)sn);      // sum over accepted moves of dE = 2(K - 2n)
+        A_run += a;
+        if (emit && lane < 32 && P.Es) P.Es[sample * P.Rpad + blockIdx.x * 32 + lane] = E_run;
+        emit = false;
+    }
+    __device__ __forceinline__ void run_to_end(const SweepParams& P, const TransposeConsts& tc, int lane, int32_t& E_run, int64_t& A_run)
+    {
+        if (phase >= NS) return;
+        while (phase < NS) step(tc);
+        finish(P, lane, E_run, A_run);
+    }
+};
+
+template <int NS>
+__device__ __forceinline__ void tally_reset(TallyState<NS>& t)
+{
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
-        const int wsh = s == 0 ? 0 : s - 1;          // stream 0 counts A; streams 1.. are the planes n0, n1, n2 of S
-        uint32_t c = 0u;
 #pragma unroll
-        for (int l = 0; l < 3; ++l) { c += (uint32_t)__popc(transpose32(t.lo[s][l], lane)) << l; t.lo[s][l] = 0u; }
+        for (int l = 0; l < 3; ++l) t.lo[s][l] = 0u;
 #pragma unroll
-        for (int l = 0; l < kTallyHi; ++l) {
-            const uint32_t pend = ((ng >> l) & 1u) ? t.Pd[s][l] : 0u;     // pending word is live iff bit l of the group count
-            c += ((uint32_t)__popc(transpose32(t.S[s][l], lane)) + (uint32_t)__popc(transpose32(pend, lane))) << (3 + l);
-            t.S[s][l] = 0u;
-        }
-        tot[s == 0 ? 0 : 1] += c << wsh;
+        for (int l = 0; l < kTallyHi; ++l) { t.S[s][l] = 0u; t.Pd[s][l] = 0u; }
     }
     t.ngrp = 0u;
-    totA = tot[0] + (uint32_t)__shfl_xor((int)tot[0], 32);
-    totS = tot[1] + (uint32_t)__shfl_xor((int)tot[1], 32);
 }
 
 template <int NS>
@@ -501,9 +664,11 @@ __global__ __launch_bounds__(kSweepThreads) void sweep_kernel(SweepParams P)
     extern __shared__ uint32_t lds[];
     const int N = P.N, C = P.C;
     uint32_t* sp = lds;                                              // [2N]  words, then complements
-    uint4* desc = reinterpret_cast<uint4*>(sp + ((2 * N + 128 + 3) & ~3)); // [2][NQ][C]   (128 dummy words behind the spins)
-    uint4* tal = desc + 2 * NQ * C;                                  // [2][C + 64]  (64 dummy entries per buffer)
-    uint16_t* tbl = reinterpret_cast<uint16_t*>(tal + 2 * (C + kWave));   // [N][TS]
+    uint4* desc = reinterpret_cast<uint4*>(sp + ((2 * N + 128 + 3) & ~3)); // [3][NQ][C]   (128 dummy words behind the spins)
+    uint4* tal = desc + 3 * NQ * C;                                  // [2][C + 64]  (64 dummy entries per buffer)
+    uint32_t* leftmem = reinterpret_cast<uint32_t*>(tal + 2 * (C + kWave));   // [2] leftover lists
+    constexpr int kLeftWords = 4 + kLeftMax * (1 + 2 * SweepCfg<K>::NT);
+    uint16_t* tbl = reinterpret_cast<uint16_t*>(leftmem + 2 * kLeftWords);     // [N][TS]
 
     const int tid = threadIdx.x, lane = tid & 63;
     // the wave index as a SCALAR: role dispatch becomes s_cbranch (and s_setprio below really is per wave)
@@ -517,45 +682,51 @@ __global__ __launch_bounds__(kSweepThreads) void sweep_kernel(SweepParams P)
         sp[x + N] = ~w;
     }
     for (int q = tid; q < N * P.TS; q += kSweepThreads) tbl[q] = P.table[q];
+    if (tid < 2) leftmem[tid * kLeftWords] = 0u;
     __syncthreads();
+    auto left_list = [&](int c) {
+        uint32_t* m = leftmem + (c & 1) * kLeftWords;
+        LeftList l;
+        l.count = m; l.slot = m + 4; l.lt = m + 4 + kLeftMax; l.eq = m + 4 + kLeftMax * (1 + SweepCfg<K>::NT);
+        return l;
+    };
 
-    // Software pipeline over chunks, one workgroup barrier per step:  produce(c) | consume(c-1) | tally(c-2).
+    // Software pipeline over chunks, one workgroup barrier per step:  produce(c) | fix(c-1) | consume(c-2) | tally(c-3).
     // Each role runs its OWN loop (the branch on the scalar wave index is outside the loops), so that a role's
     // registers are not live across the other roles' code; every wave executes exactly nsteps barriers.
-    const int nsteps = P.nchunks + 2;
+    const int nsteps = P.nchunks + 3;
     const int tal_stride = C + kWave;
 #ifdef RRRMC_STAMPS
     unsigned long long busy = 0;
 #define RRRMC_T0 const unsigned long long t_in = __builtin_amdgcn_s_memtime();
-#define RRRMC_T1 busy += __builtin_amdgcn_s_memtime() - t_in;
+#define RRRMC_T1 { const unsigned long long dt_ = __builtin_amdgcn_s_memtime() - t_in; busy += dt_; \
+        if (blockIdx.x == 0 && lane == 0 && P.stamps && c < 4096) P.stamps[16 * 65536 + c * 16 + wave] = dt_; }
 #else
 #define RRRMC_T0
 #define RRRMC_T1
 #endif
-    if (wave == 0) {
+    if (wave == kConsumerWave) {
         // consumer: single latency-bound wave on the critical path -> let it win the SIMD's issue arbitration
         __builtin_amdgcn_s_setprio(3);
         for (int c = 0; c < nsteps; ++c) {
             RRRMC_T0
 #ifndef RRRMC_ABLATE_CONSUME      // timing experiments only (tools/ablate.sh): results are wrong with a role removed
-            if (c >= 1 && c - 1 < P.nchunks)
-                consume_chunk<K>(P, P.chunks[c - 1], desc + ((c - 1) & 1) * NQ * C, sp, tal + ((c - 1) & 1) * tal_stride, lane);
+            if (c >= 2 && c - 2 < P.nchunks)
+                consume_chunk<K>(P, P.chunks[c - 2], desc + ((c - 2) % 3) * NQ * C, sp, tal + ((c - 2) & 1) * tal_stride, lane);
 #endif
             RRRMC_T1
             __syncthreads();
         }
-    } else if (wave == 1) {
+    } else if (wave == kTallyWave) {
         // tally: lanes 0..31 own the running energy / accepted count of replica `lane`
         __builtin_amdgcn_s_setprio(2);
+        TransposeConsts tc;
+        tc.init(lane);
         TallyState<NS> ts;
-#pragma unroll
-        for (int s = 0; s < NS; ++s) {
-#pragma unroll
-            for (int l = 0; l < 3; ++l) ts.lo[s][l] = 0u;
-#pragma unroll
-            for (int l = 0; l < kTallyHi; ++l) { ts.S[s][l] = 0u; ts.Pd[s][l] = 0u; }
-        }
-        ts.ngrp = 0u;
+        tally_reset<NS>(ts);
+        TallyDrain<NS, K> dr;
+        tally_reset<NS>(dr.set);
+        dr.tot[0] = 0u; dr.tot[1] = 0u; dr.phase = NS; dr.emit = false; dr.sample = 0;
         int32_t E_run = 0;
         int64_t A_run = 0;
         if (lane < 32) { E_run = P.E_cur[blockIdx.x * 32 + lane]; A_run = P.acc_cur[blockIdx.x * 32 + lane]; }
@@ -564,36 +735,46 @@ __global__ __launch_bounds__(kSweepThreads) void sweep_kernel(SweepParams P)
         for (int c = 0; c < nsteps; ++c) {
             RRRMC_T0
 #ifndef RRRMC_ABLATE_TALLY
-            if (c >= 2) {
-                const ChunkDesc cd = P.chunks[c - 2];
+            if (c >= 3) {
+                const ChunkDesc cd = P.chunks[c - 3];
                 // an energy sample is due BEFORE this chunk's moves (RRRMC.jl:104-108)
                 const bool sample = (cd.flags & kChunkSampleBefore) != 0;
                 if (sample || ts.ngrp + grp_per_chunk > (1u << kTallyHi) - 1u) {
-                    uint32_t a, sn;
-                    tally_flush<NS>(ts, lane, a, sn);
-                    E_run += 2 * (K * (int32_t)a - 2 * (int32_t)sn);
-                    A_run += a;
+                    dr.run_to_end(P, tc, lane, E_run, A_run);     // an older set still draining goes first (order matters)
+                    dr.set = ts;                                   // move the live counters aside and start afresh
+                    tally_reset<NS>(ts);
+                    dr.tot[0] = 0u; dr.tot[1] = 0u; dr.phase = 0;
+                    dr.emit = sample; dr.sample = ns;
+                    if (sample) ns += 1;
                 }
-                if (sample) {
-                    if (lane < 32 && P.Es) P.Es[ns * P.Rpad + blockIdx.x * 32 + lane] = E_run;
-                    ns += 1;
+                if (dr.phase < NS) {                               // fold one stream of the draining set per step
+                    dr.step(tc);
+                    if (dr.phase == NS) dr.finish(P, lane, E_run, A_run);
                 }
-                tally_chunk<NS>(ts, cd, tal + ((c - 2) & 1) * tal_stride, lane);
+                tally_chunk<NS>(ts, cd, tal + ((c - 3) & 1) * tal_stride, lane);
             }
 #endif
             RRRMC_T1
             __syncthreads();
         }
-        uint32_t a, sn;
-        tally_flush<NS>(ts, lane, a, sn);
-        E_run += 2 * (K * (int32_t)a - 2 * (int32_t)sn);
-        A_run += a;
+        dr.run_to_end(P, tc, lane, E_run, A_run);
+        dr.set = ts;
+        dr.tot[0] = 0u; dr.tot[1] = 0u; dr.phase = 0; dr.emit = false;
+        dr.run_to_end(P, tc, lane, E_run, A_run);
         if (lane < 32) { P.E_cur[blockIdx.x * 32 + lane] = E_run; P.acc_cur[blockIdx.x * 32 + lane] = A_run; }
+    } else if (wave == kFixerWave) {
+        for (int c = 0; c < nsteps; ++c) {
+            RRRMC_T0
+            if (c >= 1 && c - 1 < P.nchunks) fix_chunk<K>(P, P.chunks[c - 1], desc + ((c - 1) % 3) * NQ * C, left_list(c - 1), lane, group);
+            RRRMC_T1
+            __syncthreads();
+        }
     } else {
+        const int pw = wave < kFixerWave ? wave - 2 : wave - 3;     // producer index 0 .. kProducerWaves-1
         for (int c = 0; c < nsteps; ++c) {
             RRRMC_T0
 #ifndef RRRMC_ABLATE_PRODUCE
-            if (c < P.nchunks) produce_chunk<K>(P, P.chunks[c], desc + (c & 1) * NQ * C, tbl, wave - kFirstProducer, lane, group);
+            if (c < P.nchunks) produce_chunk<K>(P, P.chunks[c], desc + (c % 3) * NQ * C, tbl, left_list(c), pw, lane, group);
 #endif
             RRRMC_T1
             __syncthreads();

@@ -20,3 +20,14 @@ for g in (0, 100, 255):
     L.rrrmc_debug_stamps(eng._ctx, g, out.ctypes.data)
     print("group", g, "busy cycles per chunk by wave:", (out / nch).astype(int).tolist())
 print("sweep ms", sw, "-> per chunk us", sw * 1e3 / nch, " (~100MHz memtime? see ratio)")
+
+tr = np.zeros((4096, 16), np.uint64)
+L.rrrmc_debug_step_trace.argtypes = [C.c_void_p, C.c_void_p]
+L.rrrmc_debug_step_trace(eng._ctx, tr.ctypes.data)
+tr = tr[2:1200].astype(np.float64)
+cons, tal, prod = tr[:, 0], tr[:, 1], tr[:, 2:]
+pmax = prod.max(axis=1)
+step = np.maximum(np.maximum(cons, tal), pmax)
+print("per-step means: consumer %.0f tally %.0f producer-mean %.0f producer-max %.0f  max-of-all %.0f" % (cons.mean(), tal.mean(), prod.mean(), pmax.mean(), step.mean()))
+print("consumer slowest in %.0f%% of steps; tally slowest in %.0f%%" % (100 * (cons >= step).mean(), 100 * (tal >= step).mean()))
+print("consumer pct 10/50/90: %s   producer-max pct: %s  tally pct: %s" % (np.percentile(cons, [10, 50, 90]).astype(int), np.percentile(pmax, [10, 50, 90]).astype(int), np.percentile(tal, [10, 50, 90]).astype(int)))
