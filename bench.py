@@ -71,7 +71,9 @@ def main():
     pkg = entry.load_package()
     X = pkg.GraphRRG(N_SITES, K_DEG, seed=SEED)
     R = args.replicas
-    eng = pkg.Engine(X, R, device=local_rank, replica0=rank * R)
+    r0, r_local = pkg.shard_bounds(R * world, world, rank)      # weak scaling: R replicas per GPU, ids 0 .. R*world-1
+    assert r_local == R
+    eng = pkg.Engine(X, R, device=local_rank, replica0=r0)
     eng.seed(SEED)
     eng.init_spins_random()
 
@@ -104,13 +106,13 @@ def main():
     Es, acc = eng.fetch_results()
     acc_rate = float(acc.mean()) / args.iters
     e_mean = float(Es[:, -1].mean()) / N_SITES if Es.shape[1] else float("nan")
-    if dist is not None:   # the only exchange: gather per-rank observables over RCCL
+    if dist is not None:   # the only exchange of the job: gather the per-replica observables over RCCL
         import torch
-        obs = torch.tensor([acc_rate, e_mean], dtype=torch.float64, device="cuda")
-        allobs = [torch.zeros_like(obs) for _ in range(world)]
-        dist.all_gather(allobs, obs)
-        acc_rate = float(sum(o[0].item() for o in allobs) / world)
-        e_mean = float(sum(o[1].item() for o in allobs) / world)
+        dev = torch.device("cuda", local_rank)
+        E_last = pkg.gather_replica_major(Es[:, -1].copy(), R * world, dist, device=dev)
+        acc_all = pkg.gather_replica_major(acc, R * world, dist, device=dev)
+        acc_rate = float(acc_all.mean()) / args.iters
+        e_mean = float(E_last.mean()) / N_SITES
 
     if rank == 0:
         attempts = float(R) * args.iters * args.steps * n_gpus
@@ -130,8 +132,13 @@ def main():
             per_launch_attempts = float(R) * args.iters * args.steps / launches
             avg_ms = sweep_ms / launches
             achieved = bytes_per_attempt * per_launch_attempts / (avg_ms * 1e-3) / 1e9
+            traffic = None     # HBM bytes per sweep launch from the committed PMC passes (same workload), if present
+            tf = os.path.join(ROOT, "profiles", "r01", "traffic.json")
+            if os.path.exists(tf) and R == REPLICAS_PER_GPU and args.iters == ITERS:
+                traffic = json.load(open(tf))["hbm_bytes_per_launch"]
             out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                               "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                               "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                               "algorithmic_bytes_per_launch": bytes_per_attempt * per_launch_attempts,
                                "kernel": "sweep_kernel<3>", "avg_launch_ms": avg_ms, "launches": launches,
                                "algorithmic_bytes_per_attempt": bytes_per_attempt}
         if not args.no_cpu_baseline:

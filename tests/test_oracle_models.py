@@ -1,0 +1,144 @@
+"""CPU tests of the oracle's model code against what the reference itself pins: the
+tracked-energy invariant of test/runtests.jl:12-20, cache == recomputation, allΔE tables, a closed-form
+toy model and the exact Boltzmann law for a tiny system.  No GPU."""
+import itertools
+import math
+
+import numpy as np
+import pytest
+
+
+def _bits(ch, N):
+    x = np.arange(N)
+    return ((ch[x >> 6] >> (x & 63).astype(np.uint64)) & np.uint64(1)).astype(np.int64)
+
+
+def brute_energy(A, J, bits):
+    s = 2 * bits - 1
+    N, K = A.shape
+    return -int(sum(J[x, k] * s[x] * s[A[x, k]] for x in range(N) for k in range(K))) // 2
+
+
+def test_gen_rrg_is_simple_regular_sorted(oracle):
+    for N, K, seed in [(10, 3, 1), (128, 3, 2), (50, 4, 3), (64, 5, 4)]:
+        A = oracle.gen_rrg(N, K, seed)
+        assert A.shape == (N, K)
+        for x in range(N):
+            row = list(A[x])
+            assert row == sorted(row) and len(set(row)) == K and x not in row       # findall on a bit row: RRG.jl:64
+            for y in row:
+                assert x in A[y]
+    with pytest.raises(ValueError):
+        oracle.gen_rrg(5, 3, 1)                                                     # N*K must be even, RRG.jl:28
+
+
+def test_gen_ea_lattice(oracle):
+    A = oracle.gen_ea(4, 3)                 # column-major linear index, periodic, sorted rows (EA.jl:24-43)
+    assert A.shape == (64, 6)
+    x = 1 + 4 * 2 + 16 * 3                  # (1, 2, 3)
+    want = sorted([0 + 8 + 48, 2 + 8 + 48, 1 + 4 + 48, 1 + 12 + 48, 1 + 8 + 32, 1 + 8 + 0])
+    assert list(A[x]) == want
+    A2 = oracle.gen_ea(2, 3)                # L = 2: every neighbour twice (EA.jl:156)
+    assert list(A2[0]) == [1, 1, 2, 2, 4, 4]
+    A3 = oracle.gen_ea(3, 2)
+    assert list(A3[0]) == [1, 2, 3, 6]
+
+
+def test_couplings_symmetric_pm1(oracle):
+    for A in (oracle.gen_rrg(40, 3, 5), oracle.gen_ea(2, 3), oracle.gen_ea(3, 2)):
+        J = oracle.gen_couplings(A, 11)
+        assert set(np.unique(J)) <= {-1, 1}
+        N, K = A.shape
+        used = np.zeros((N, K), bool)
+        for x in range(N):
+            for k in range(K):
+                y = A[x, k]
+                ok = False
+                for l in range(K):
+                    if not used[y, l] and A[y, l] == x and J[y, l] == J[x, k]:
+                        used[y, l] = ok = True
+                        break
+                assert ok
+
+
+def test_all_delta_e_tables(oracle):
+    assert oracle.all_delta_e_pm1(3) == (2, 6)              # GraphRRG K=3: RRG.jl:262-265
+    assert oracle.all_delta_e_pm1(6) == (0, 4, 8, 12)       # GraphEA D=3: EA.jl:293
+    assert oracle.all_delta_e_pm1(4) == (0, 4, 8)
+    assert oracle.all_delta_e_pm1(1) == (2,)                # GraphTwoSpin: TwoSpin.jl:41
+
+
+@pytest.mark.parametrize("kind", ["rrg10", "ea23", "ea32"])
+def test_energy_and_fields_match_brute_force(oracle, kind):
+    A = {"rrg10": lambda: oracle.gen_rrg(10, 3, 3), "ea23": lambda: oracle.gen_ea(2, 3), "ea32": lambda: oracle.gen_ea(3, 2)}[kind]()
+    J = oracle.gen_couplings(A, 17)
+    N, K = A.shape
+    for r in range(8):
+        ch = oracle.init_config(5, r, N)
+        E, lf = oracle.sparse_energy(A, J, ch, want_fields=True)
+        bits = _bits(ch, N)
+        assert E == brute_energy(A, J, bits)
+        for x in range(N):                                  # lfields[x] = -dE(x): flip and recompute
+            b2 = bits.copy()
+            b2[x] ^= 1
+            assert -lf[x] == brute_energy(A, J, b2) - E
+        assert set(abs(int(v)) for v in lf) <= set(oracle.all_delta_e_pm1(K))      # Interface.jl:123-125
+
+
+@pytest.mark.parametrize("kind,form", [("rrg10", "rrg"), ("ea23", "ea"), ("ea32", "ea"), ("rrg10", "ea")])
+def test_tracked_energy_equals_recomputed(oracle, kind, form):
+    """The reference's only assertion (test/runtests.jl:12-20,125-130): E tracked by the sampler == energy(X, C),
+    here at every sample by re-running prefixes; plus cache == recomputation at the end (RRG.jl:229-231)."""
+    A = {"rrg10": lambda: oracle.gen_rrg(10, 3, 3), "ea23": lambda: oracle.gen_ea(2, 3), "ea32": lambda: oracle.gen_ea(3, 2)}[kind]()
+    J = oracle.gen_couplings(A, 23)
+    N = A.shape[0]
+    seed, beta, iters, step = 8426732438942, 2.0, 10000, 100
+    ch0 = oracle.init_config(seed, 0, N)
+    Es, ch1, acc, lf = oracle.standard_mc_sparse(A, J, beta, iters, step, seed, ch0, form=form)
+    assert len(Es) == iters // step
+    E1, lf1 = oracle.sparse_energy(A, J, ch1, want_fields=True)
+    assert (lf == lf1).all()
+    for k in (1, 2, 37, 100):                               # sample k is taken BEFORE the move of iteration k*step
+        _, chk, _, _ = oracle.standard_mc_sparse(A, J, beta, k * step - 1, step, seed, ch0, form=form)
+        assert Es[k - 1] == oracle.sparse_energy(A, J, chk)
+    # resumed run (C0 = previous C, stream continued) == one long run
+    Es_a, ch_a, acc_a, _ = oracle.standard_mc_sparse(A, J, beta, 6000, step, seed, ch0, form=form)
+    Es_b, ch_b, acc_b, _ = oracle.standard_mc_sparse(A, J, beta, 4000, step, seed, ch_a, it0=6000, form=form)
+    assert (np.concatenate([Es_a, Es_b]) == Es).all() and (ch_b == ch1).all() and acc_a + acc_b == acc
+
+
+def test_two_spin_closed_form(oracle):
+    """GraphTwoSpin (graphs/TwoSpin.jl:26-41): E = -s1 s2, dE = 2 s1 s2 — as the K = 1 sparse model."""
+    A = np.array([[1], [0]], np.int32)
+    J = np.array([[1], [1]], np.int32)
+    for b0, b1 in itertools.product((0, 1), repeat=2):
+        ch = np.array([b0 | (b1 << 1)], np.uint64)
+        E, lf = oracle.sparse_energy(A, J, ch, want_fields=True)
+        s0, s1 = 2 * b0 - 1, 2 * b1 - 1
+        assert E == -s0 * s1 and list(-lf) == [2 * s0 * s1] * 2
+
+
+def test_boltzmann_law_small_system(oracle):
+    """truep (src/RRRMC.jl:528-543): the chain's stationary law is exp(-beta E)/Z.  N = 8 ring-with-chords graph,
+    long single chain of the oracle, total-variation distance to the exact law."""
+    N, beta = 8, 0.7
+    A = oracle.gen_rrg(N, 3, 12)
+    J = oracle.gen_couplings(A, 12)
+    p = np.zeros(1 << N)
+    for c in range(1 << N):
+        p[c] = math.exp(-beta * oracle.sparse_energy(A, J, np.array([c], np.uint64)))
+    p /= p.sum()
+    seed, step, nsamp = 2024, 8, 60000
+    ch = oracle.init_config(seed, 0, N)
+    hist = np.zeros(1 << N)
+    it0 = 0
+    for _ in range(nsamp // 2000):
+        for _ in range(2000):
+            _, ch, _, _ = oracle.standard_mc_sparse(A, J, beta, step, step + 1, seed, ch, it0=it0)
+            it0 += step
+            hist[int(ch[0])] += 1
+    hist /= hist.sum()
+    assert 0.5 * np.abs(hist - p).sum() < 0.04
+    # mean energy against the exact value
+    Es = np.array([oracle.sparse_energy(A, J, np.array([c], np.uint64)) for c in range(1 << N)])
+    assert abs((hist * Es).sum() - (p * Es).sum()) < 0.15
