@@ -46,7 +46,8 @@ enum rrrmc_status {
 };
 
 enum rrrmc_model {
-    RRRMC_MODEL_SPARSE_PM1 = 1   /* GraphRRG{Int,(-1,1),K} src/graphs/RRG.jl:116 and GraphEA{Int,(-1,1),2D} src/graphs/EA.jl:138 */
+    RRRMC_MODEL_SPARSE_PM1 = 1,  /* GraphRRG{Int,(-1,1),K} src/graphs/RRG.jl:116 and GraphEA{Int,(-1,1),2D} src/graphs/EA.jl:138 */
+    RRRMC_MODEL_SK_NORMAL = 2    /* GraphSKNormal (Float64 couplings) src/graphs/SK.jl:181-210; K is ignored */
 };
 
 /* Library ABI version (major*10000 + minor*100 + patch). */
@@ -111,6 +112,20 @@ RRRMC_API int32_t rrrmc_standard_mc_async(rrrmc_ctx *ctx, double beta, int64_t i
 RRRMC_API int32_t rrrmc_sync(rrrmc_ctx *ctx);
 /* Results of the last (a)sync sampling call: Es_out[R * nsamples] replica-major, accepted_out[R]. */
 RRRMC_API int32_t rrrmc_fetch_results(rrrmc_ctx *ctx, int64_t *Es_out, int64_t *accepted_out);
+
+/* ---- Float64-energy models (RRRMC_MODEL_SK_NORMAL): ET = Float64 (src/graphs/SK.jl:181) --------------------
+ * Dense couplings J[N*N] row-major; must be symmetric with a zero diagonal (GraphSKNormal(J; check=true),
+ * SK.jl:184-195: violations are RRRMC_ERR_INVALID_ARG).  Replaces GraphSKNormal(J). */
+RRRMC_API int32_t rrrmc_set_couplings_dense(rrrmc_ctx *ctx, const double *J);
+/* energy / cache / sampler results as Float64 (same meaning as the integer forms above; delta_energy = +lfields,
+ * SK.jl:278-284).  rrrmc_standard_mc_async / rrrmc_sync are shared by all models. */
+RRRMC_API int32_t rrrmc_energy_f64(rrrmc_ctx *ctx, double *E_out);
+RRRMC_API int32_t rrrmc_get_fields_f64(rrrmc_ctx *ctx, double *lfields_out);
+RRRMC_API int32_t rrrmc_standard_mc_f64(rrrmc_ctx *ctx, double beta, int64_t iters, int64_t step,
+                                        double *Es_out, int64_t *accepted_out);
+RRRMC_API int32_t rrrmc_fetch_results_f64(rrrmc_ctx *ctx, double *Es_out, int64_t *accepted_out);
+/* gen_J_gauss (src/graphs/SK.jl:170-179): J_out[N*N], normal(0, 1/N), symmetric, zero diagonal. GAUSS stream. */
+RRRMC_API int32_t rrrmc_gen_sk_gauss(int64_t N, uint64_t seed, double *J_out);
 
 /* Timing of the last sampling call measured with HIP events on the ctx's stream:
  *   total_ms   first planner launch -> last sweep kernel end

@@ -63,6 +63,18 @@ def lib():
         L.orc_standard_mc_sparse_batch.argtypes = [C.c_int, C.c_int64, C.c_int64, i32p, i32p, C.c_double, C.c_int64,
                                                    C.c_int64, C.c_uint64, C.c_uint64, C.c_uint32, C.c_int64,
                                                    u64p, i64p, i64p]
+        L.orc_gauss.restype = C.c_double
+        L.orc_gauss.argtypes = [C.c_uint64, C.c_uint64]
+        L.orc_exp.restype = C.c_double
+        L.orc_exp.argtypes = [C.c_double]
+        L.orc_rand53_of.restype = C.c_double
+        L.orc_rand53_of.argtypes = [C.c_uint64, C.c_uint64, C.c_uint32]
+        L.orc_gen_sk_gauss.argtypes = [C.c_int64, C.c_uint64, f64p]
+        L.orc_skn_energy.restype = C.c_double
+        L.orc_skn_energy.argtypes = [C.c_int64, f64p, u64p, C.c_void_p]
+        L.orc_standard_mc_skn.restype = C.c_int64
+        L.orc_standard_mc_skn.argtypes = [C.c_int64, f64p, C.c_double, C.c_int64, C.c_int64, C.c_uint64, C.c_uint64, C.c_uint32,
+                                          u64p, f64p, C.POINTER(C.c_int64), C.c_void_p]
         L.orc_all_delta_e_pm1.restype = C.c_int64
         L.orc_all_delta_e_pm1.argtypes = [C.c_int64, i64p]
         _lib = L
@@ -176,3 +188,43 @@ def all_delta_e_pm1(K):
     out = np.zeros(K + 1, np.int64)
     n = lib().orc_all_delta_e_pm1(K, out)
     return tuple(int(v) for v in out[:n])
+
+
+# ---- dense Gaussian SK (GraphSKNormal) ------------------------------------------------------------
+def det_exp(x):
+    return float(lib().orc_exp(x))
+
+
+def rand53(seed, g, replica):
+    return float(lib().orc_rand53_of(seed, g, replica))
+
+
+def gen_sk_gauss(N, seed):
+    J = np.zeros((N, N), np.float64)
+    lib().orc_gen_sk_gauss(N, seed, J.reshape(-1))
+    return J
+
+
+def skn_energy(J, chunks, want_fields=False):
+    N = J.shape[0]
+    lf = np.zeros(N, np.float64)
+    E = lib().orc_skn_energy(N, np.ascontiguousarray(J).reshape(-1), np.ascontiguousarray(chunks), lf.ctypes.data)
+    return (float(E), lf) if want_fields else float(E)
+
+
+def standard_mc_skn(J, beta, iters, step, seed, chunks, it0=0, replica=0):
+    """One chain on GraphSKNormal.  Returns (Es, chunks_out, accepted, lfields)."""
+    N = J.shape[0]
+    ch = np.array(chunks, np.uint64, copy=True)
+    Es = np.zeros(max(iters // step, 1), np.float64)
+    acc = C.c_int64(0)
+    lf = np.zeros(N, np.float64)
+    n = lib().orc_standard_mc_skn(N, np.ascontiguousarray(J).reshape(-1), beta, iters, step, seed, it0, replica, ch, Es,
+                                  C.byref(acc), lf.ctypes.data)
+    return Es[:n], ch, int(acc.value), lf
+
+
+def standard_mc_skn_batch(J, beta, iters, step, seed, chunks, it0=0, replica0=0):
+    outs = [standard_mc_skn(J, beta, iters, step, seed, chunks[r], it0=it0, replica=replica0 + r) for r in range(len(chunks))]
+    return (np.stack([o[0] for o in outs]), np.stack([o[1] for o in outs]), np.array([o[2] for o in outs], np.int64),
+            np.stack([o[3] for o in outs]))

@@ -142,4 +142,41 @@ static inline int orc_init_spin(uint64_t seed, uint32_t replica, uint64_t x)
     return (int)((w[x & 3] >> (replica & 31u)) & 1u);
 }
 
+/* ------------------------------------------------------------------------------------------------
+ * Float64-energy models (GraphSKNormal, DoubleGraph residuals): one 53-bit uniform per replica and iteration,
+ *   ACCEPT_F64: ctr = (lo32(g>>1), hi32(g>>1), replica, TAG_ACCEPT_F64); u64 = (w[2h] << 32) | w[2h+1], h = g & 1;
+ *               rand() = (u64 >> 11) * 2^-53                       [replaces `rand()`, src/RRRMC.jl:39]
+ * and a deterministic exp shared (same algorithm, same operation order, no FMA) by the oracle and the device so that
+ * `rand() < exp(x)` is decided identically on both sides (SURVEY.md §7 hard part 3).
+ * ---------------------------------------------------------------------------------------------- */
+enum { ORC_TAG_ACCEPT_F64 = 9 };
+
+static inline double orc_rand53(uint64_t seed, uint64_t g, uint32_t replica)
+{
+    uint32_t w[4];
+    uint64_t blk = g >> 1;
+    orc_draw(seed, (uint32_t)blk, (uint32_t)(blk >> 32), replica, ORC_TAG_ACCEPT_F64, w);
+    unsigned h = (unsigned)(g & 1u);
+    uint64_t u = ((uint64_t)w[2 * h] << 32) | w[2 * h + 1];
+    return (double)(u >> 11) * 0x1.0p-53;
+}
+
+/* exp(x): Cody-Waite reduction x = k ln2 + r, degree-13 Taylor polynomial in Horner form (separate multiply and
+ * add roundings), exact scaling by 2^k.  Relative error ~2e-16; compile with -ffp-contract=off. */
+static inline double orc_det_exp(double x)
+{
+    static const double LOG2E = 1.44269504088896338700e+00;
+    static const double LN2_HI = 6.93147180369123816490e-01, LN2_LO = 1.90821492927058770002e-10;
+    static const double c[14] = {1.0, 1.0, 0.5, 1.0 / 6, 1.0 / 24, 1.0 / 120, 1.0 / 720, 1.0 / 5040, 1.0 / 40320, 1.0 / 362880,
+                                 1.0 / 3628800, 1.0 / 39916800, 1.0 / 479001600, 1.0 / 6227020800.0};
+    if (x != x) return x;
+    if (x < -745.2) return 0.0;
+    if (x > 709.7) return __builtin_inf();
+    double k = __builtin_floor(x * LOG2E + 0.5);
+    double r = (x - k * LN2_HI) - k * LN2_LO;
+    double p = c[13];
+    for (int n = 12; n >= 0; --n) p = p * r + c[n];
+    return __builtin_ldexp(p, (int)k);
+}
+
 #endif

@@ -317,3 +317,124 @@ ORC_API int64_t orc_all_delta_e_pm1(int64_t K, int64_t *out)
     for (int64_t m = (K & 1); m <= K; m += 2) out[n++] = 2 * m;
     return n;
 }
+
+/* ---------------------------------------------------------------------------------------------
+ * Dense Gaussian SK model GraphSKNormal (ET = Float64): src/graphs/SK.jl:170-297
+ * ------------------------------------------------------------------------------------------- */
+
+/* n-th standard normal of the GAUSS stream: Box-Muller on two 53-bit uniforms of draw n >> 1 (cos branch for even n,
+ * sin branch for odd n).  [replaces `randn(N)`, SK.jl:171] */
+static double gauss_draw(uint64_t seed, uint64_t n)
+{
+    uint32_t w[4];
+    uint64_t blk = n >> 1;
+    orc_draw(seed, (uint32_t)blk, (uint32_t)(blk >> 32), 0u, ORC_TAG_GAUSS, w);
+    uint64_t a = ((uint64_t)w[0] << 32) | w[1], b = ((uint64_t)w[2] << 32) | w[3];
+    double u1 = ((double)(a >> 11) + 1.0) * 0x1.0p-53;       /* (0, 1] */
+    double u2 = (double)(b >> 11) * 0x1.0p-53;               /* [0, 1) */
+    double rad = sqrt(-2.0 * log(u1)), ang = 6.283185307179586476925286766559 * u2;
+    return (n & 1u) ? rad * sin(ang) : rad * cos(ang);
+}
+
+ORC_API double orc_gauss(uint64_t seed, uint64_t n) { return gauss_draw(seed, n); }
+ORC_API double orc_exp(double x) { return orc_det_exp(x); }
+ORC_API double orc_rand53_of(uint64_t seed, uint64_t g, uint32_t replica) { return orc_rand53(seed, g, replica); }
+
+/* gen_J_gauss: SK.jl:170-179.  Row i = randn(N) scaled by 1/sqrt(N) (rmul!), then zero diagonal and the upper
+ * triangle copied onto the lower one.  Draw index of J[i][j] before symmetrisation: i*N + j. */
+ORC_API void orc_gen_sk_gauss(int64_t N, uint64_t seed, double *J)
+{
+    const double scale = 1.0 / sqrt((double)N);
+    for (int64_t i = 0; i < N; ++i)
+        for (int64_t j = 0; j < N; ++j) J[i * N + j] = gauss_draw(seed, (uint64_t)(i * N + j)) * scale;
+    for (int64_t i = 0; i < N; ++i) {
+        J[i * N + i] = 0.0;
+        for (int64_t j = i + 1; j < N; ++j) J[j * N + i] = J[i * N + j];
+    }
+}
+
+typedef struct {
+    int64_t N;
+    const double *J;
+    double *lfields, *lfields_last;    /* swapped wholesale by the undo path, SK.jl:248 */
+    int64_t move_last;
+} skn_t;
+
+/* energy: SK.jl:212-237 (sequential sums in j order; also rebuilds the cache) */
+static double skn_energy(skn_t *X, const uint64_t *s)
+{
+    double n = 0.0;
+    for (int64_t i = 0; i < X->N; ++i) {
+        const double *Ji = X->J + i * X->N;
+        int si = spin_bit(s, i);
+        double lf = 0.0;
+        for (int64_t j = 0; j < X->N; ++j) lf += (double)(1 - 2 * (si ^ spin_bit(s, j))) * Ji[j];
+        X->lfields[i] = 2 * lf;
+        n -= lf;
+    }
+    n /= 2;
+    X->move_last = -1;
+    memset(X->lfields_last, 0, (size_t)X->N * sizeof(double));
+    return n;
+}
+
+/* update_cache!: SK.jl:239-276, called after the bit flip */
+static void skn_update_cache(skn_t *X, const uint64_t *s, int64_t move)
+{
+    if (X->move_last == move) {          /* SK.jl:247-250: swap the two arrays, move_last stays */
+        double *t = X->lfields; X->lfields = X->lfields_last; X->lfields_last = t;
+        return;
+    }
+    const double *Ji = X->J + move * X->N;
+    int si = spin_bit(s, move);
+    double lfm = X->lfields[move];
+    for (int64_t j = 0; j < X->N; ++j) {
+        double Jsij = (double)(1 - 2 * (si ^ spin_bit(s, j))) * Ji[j];
+        double lfj = X->lfields[j];
+        X->lfields_last[j] = lfj;
+        X->lfields[j] = lfj + 4 * Jsij;
+    }
+    X->lfields_last[move] = lfm;
+    X->lfields[move] = -lfm;
+    X->move_last = move;
+}
+
+ORC_API double orc_skn_energy(int64_t N, const double *J, const uint64_t *chunks, double *lfields_out)
+{
+    skn_t X = {N, J, NULL, NULL, -1};
+    X.lfields = (double *)malloc((size_t)N * sizeof(double));
+    X.lfields_last = (double *)malloc((size_t)N * sizeof(double));
+    double E = skn_energy(&X, chunks);
+    if (lfields_out) memcpy(lfields_out, X.lfields, (size_t)N * sizeof(double));
+    free(X.lfields); free(X.lfields_last);
+    return E;
+}
+
+/* standardMC (src/RRRMC.jl:81-127) on GraphSKNormal, one chain; delta_energy = +lfields[move] (SK.jl:278-284). */
+ORC_API int64_t orc_standard_mc_skn(int64_t N, const double *J, double beta, int64_t iters, int64_t step,
+                                    uint64_t seed, uint64_t it0, uint32_t replica,
+                                    uint64_t *chunks, double *Es, int64_t *accepted_out, double *lfields_out)
+{
+    skn_t X = {N, J, NULL, NULL, -1};
+    X.lfields = (double *)malloc((size_t)N * sizeof(double));
+    X.lfields_last = (double *)malloc((size_t)N * sizeof(double));
+    double E = skn_energy(&X, chunks);
+    int64_t accepted = 0, nsamp = 0;
+    for (int64_t it = 1; it <= iters; ++it) {
+        if (it % step == 0) Es[nsamp++] = E;
+        uint64_t g = it0 + (uint64_t)it;
+        int64_t i = orc_site(seed, g, N);
+        double dE = X.lfields[i];
+        double x = -beta * dE;
+        int acc = (x >= 0) || (orc_rand53(seed, g, replica) < orc_det_exp(x));      /* RRRMC.jl:39 */
+        if (!acc) continue;
+        bitflip(chunks, i);
+        skn_update_cache(&X, chunks, i);
+        E += dE;
+        accepted += 1;
+    }
+    if (accepted_out) *accepted_out = accepted;
+    if (lfields_out) memcpy(lfields_out, X.lfields, (size_t)N * sizeof(double));
+    free(X.lfields); free(X.lfields_last);
+    return nsamp;
+}

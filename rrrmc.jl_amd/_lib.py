@@ -12,6 +12,7 @@ u64p = np.ctypeslib.ndpointer(np.uint64, flags="C_CONTIGUOUS")
 i64p = np.ctypeslib.ndpointer(np.int64, flags="C_CONTIGUOUS")
 i32p = np.ctypeslib.ndpointer(np.int32, flags="C_CONTIGUOUS")
 i8p = np.ctypeslib.ndpointer(np.int8, flags="C_CONTIGUOUS")
+f64p = np.ctypeslib.ndpointer(np.float64, flags="C_CONTIGUOUS")
 
 # every symbol include/rrrmc_hip.h declares
 SYMBOLS = [
@@ -19,7 +20,8 @@ SYMBOLS = [
     "rrrmc_set_graph", "rrrmc_seed", "rrrmc_init_spins_random", "rrrmc_set_spins", "rrrmc_get_spins",
     "rrrmc_energy", "rrrmc_get_fields", "rrrmc_standard_mc", "rrrmc_standard_mc_async", "rrrmc_sync",
     "rrrmc_fetch_results", "rrrmc_last_timing", "rrrmc_iterations_done", "rrrmc_gen_rrg", "rrrmc_gen_ea",
-    "rrrmc_gen_couplings_pm1",
+    "rrrmc_gen_couplings_pm1", "rrrmc_set_couplings_dense", "rrrmc_energy_f64", "rrrmc_get_fields_f64",
+    "rrrmc_standard_mc_f64", "rrrmc_fetch_results_f64", "rrrmc_gen_sk_gauss",
 ]
 
 
@@ -81,6 +83,18 @@ def lib():
     L.rrrmc_gen_ea.argtypes = [C.c_int64, C.c_int64, i32p]
     L.rrrmc_gen_couplings_pm1.restype = C.c_int32
     L.rrrmc_gen_couplings_pm1.argtypes = [C.c_int64, C.c_int64, i32p, C.c_uint64, i8p]
+    L.rrrmc_set_couplings_dense.restype = C.c_int32
+    L.rrrmc_set_couplings_dense.argtypes = [vp, f64p]
+    L.rrrmc_energy_f64.restype = C.c_int32
+    L.rrrmc_energy_f64.argtypes = [vp, f64p]
+    L.rrrmc_get_fields_f64.restype = C.c_int32
+    L.rrrmc_get_fields_f64.argtypes = [vp, f64p]
+    L.rrrmc_standard_mc_f64.restype = C.c_int32
+    L.rrrmc_standard_mc_f64.argtypes = [vp, C.c_double, C.c_int64, C.c_int64, vp, vp]
+    L.rrrmc_fetch_results_f64.restype = C.c_int32
+    L.rrrmc_fetch_results_f64.argtypes = [vp, vp, vp]
+    L.rrrmc_gen_sk_gauss.restype = C.c_int32
+    L.rrrmc_gen_sk_gauss.argtypes = [C.c_int64, C.c_uint64, f64p]
     _lib = L
     return L
 

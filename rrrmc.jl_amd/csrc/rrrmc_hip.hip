@@ -12,6 +12,7 @@
 #include <string>
 #include <vector>
 
+#include "sk_kernels.hpp"
 #include "sparse_kernels.hpp"
 
 using namespace rrrmc;
@@ -73,6 +74,17 @@ struct rrrmc_ctx {
     std::vector<hipEvent_t> ev_sweep;   // pairs
     int sweep_launches = 0;
     bool timing_valid = false;
+
+    // ---- RRRMC_MODEL_SK_NORMAL ----
+    double* sk_J = nullptr;        // [N][N]
+    double* sk_lf = nullptr;       // [G8][N][8]
+    double* sk_lfl = nullptr;
+    int32_t* sk_move_last = nullptr;
+    uint8_t* sk_spins = nullptr;   // [G8][N]
+    double* sk_E = nullptr;        // [G8 * 8]
+    double* sk_Es = nullptr;
+    size_t sk_Es_cap = 0;
+    int64_t G8 = 0;
 
     std::string err;
 };
@@ -177,9 +189,129 @@ int32_t run_energy(rrrmc_ctx* ctx, uint8_t* d_nun)
     return RRRMC_OK;
 }
 
+
+// ---- GraphSKNormal (dense Float64) host side -----------------------------------------------------------------------
+typedef void (*sk_fn)(SkParams);
+sk_fn sk_sweep_for(int spt)
+{
+    switch (spt) {
+        case 1: return sk_sweep_kernel<1>;
+        case 2: return sk_sweep_kernel<2>;
+        case 3: return sk_sweep_kernel<3>;
+        case 4: return sk_sweep_kernel<4>;
+        case 5: return sk_sweep_kernel<5>;
+        case 6: return sk_sweep_kernel<6>;
+        case 7: return sk_sweep_kernel<7>;
+        case 8: return sk_sweep_kernel<8>;
+        default: return nullptr;
+    }
+}
+
+int32_t sk_ctx_create(rrrmc_ctx** out, int64_t N, int64_t R, int32_t device, uint32_t replica0)
+{
+    if (N < 1 || R < 1) return fail(nullptr, RRRMC_ERR_INVALID_ARG, "N, R must be >= 1 (given N=%lld R=%lld)", (long long)N, (long long)R);
+    if (N > (int64_t)kSkThreads * kSkMaxSPT) return fail(nullptr, RRRMC_ERR_UNSUPPORTED, "N=%lld: the register-resident SK kernel covers N <= %d", (long long)N, kSkThreads * kSkMaxSPT);
+    if (replica0 % 32) return fail(nullptr, RRRMC_ERR_INVALID_ARG, "replica0 must be a multiple of 32 (given %u)", replica0);
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(nullptr, RRRMC_ERR_HIP, "no HIP device is visible: this library has no CPU path");
+    if (device < 0 || device >= ndev) return fail(nullptr, RRRMC_ERR_INVALID_ARG, "device %d out of range (0..%d)", device, ndev - 1);
+    rrrmc_ctx* ctx = new (std::nothrow) rrrmc_ctx();
+    if (!ctx) return fail(nullptr, RRRMC_ERR_NOMEM, "out of host memory");
+    ctx->model = RRRMC_MODEL_SK_NORMAL; ctx->N = N; ctx->K = 0; ctx->R = R;
+    ctx->G8 = (R + kSkRB - 1) / kSkRB; ctx->Rpad = ctx->G8 * kSkRB; ctx->G = 0;
+    ctx->device = device; ctx->replica0 = replica0;
+#define SK_TRY(expr)                                                                                             \
+    do {                                                                                                         \
+        hipError_t e_ = (expr);                                                                                  \
+        if (e_ != hipSuccess) {                                                                                  \
+            int32_t rc_ = fail(nullptr, RRRMC_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_));           \
+            rrrmc_ctx_destroy(ctx);                                                                              \
+            return rc_;                                                                                          \
+        }                                                                                                        \
+    } while (0)
+    SK_TRY(hipSetDevice(device));
+    SK_TRY(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+    SK_TRY(hipEventCreate(&ctx->ev_begin));
+    SK_TRY(hipEventCreate(&ctx->ev_end));
+    const size_t nf = (size_t)ctx->G8 * N * kSkRB;
+    SK_TRY(hipMalloc(&ctx->sk_J, sizeof(double) * N * N));
+    SK_TRY(hipMalloc(&ctx->sk_lf, sizeof(double) * nf));
+    SK_TRY(hipMalloc(&ctx->sk_lfl, sizeof(double) * nf));
+    SK_TRY(hipMalloc(&ctx->sk_move_last, sizeof(int32_t) * ctx->Rpad));
+    SK_TRY(hipMalloc(&ctx->sk_spins, (size_t)ctx->G8 * N));
+    SK_TRY(hipMalloc(&ctx->sk_E, sizeof(double) * ctx->Rpad));
+    SK_TRY(hipMalloc(&ctx->d_acc, sizeof(int64_t) * ctx->Rpad));
+    SK_TRY(hipMemset(ctx->sk_spins, 0, (size_t)ctx->G8 * N));
+    SK_TRY(hipMemset(ctx->sk_lf, 0, sizeof(double) * nf));
+    SK_TRY(hipMemset(ctx->sk_lfl, 0, sizeof(double) * nf));
+#undef SK_TRY
+    *out = ctx;
+    return RRRMC_OK;
+}
+
+// energy(X, C), SK.jl:212-237: rebuilds lfields, zeroes lfields_last, move_last = none; E into sk_E
+int32_t sk_run_energy(rrrmc_ctx* ctx)
+{
+    const dim3 grid((unsigned)((ctx->N + 31) / 32), (unsigned)ctx->G8);
+    hipLaunchKernelGGL(sk_fields_kernel, grid, dim3(256), 0, ctx->stream, ctx->sk_J, ctx->sk_spins, ctx->sk_lf, ctx->sk_lfl,
+                       ctx->sk_move_last, (int)ctx->N);
+    HIP_TRY(ctx, hipGetLastError());
+    hipLaunchKernelGGL(sk_energy_kernel, dim3((unsigned)((ctx->Rpad + 63) / 64)), dim3(64), 0, ctx->stream, ctx->sk_lf, ctx->sk_E,
+                       (int)ctx->N, (int)ctx->Rpad);
+    HIP_TRY(ctx, hipGetLastError());
+    return RRRMC_OK;
+}
+
+int32_t sk_standard_mc_async(rrrmc_ctx* ctx, double beta, int64_t iters, int64_t step)
+{
+    if (iters < 0) return fail(ctx, RRRMC_ERR_INVALID_ARG, "iters must be >= 0, given %lld", (long long)iters);
+    if (step < 1) return fail(ctx, RRRMC_ERR_INVALID_ARG, "step must be >= 1, given %lld", (long long)step);
+    if (std::isnan(beta)) return fail(ctx, RRRMC_ERR_INVALID_ARG, "beta is NaN");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    ctx->results_valid = false;
+    ctx->timing_valid = false;
+    const int64_t nsamp = iters / step;
+    const size_t es_need = (size_t)(nsamp > 0 ? nsamp : 1) * ctx->Rpad;
+    if (es_need > ctx->sk_Es_cap) {
+        free_dev(ctx->sk_Es);
+        ctx->sk_Es_cap = 0;
+        HIP_TRY(ctx, hipMalloc(&ctx->sk_Es, sizeof(double) * es_need));
+        ctx->sk_Es_cap = es_need;
+    }
+    while (ctx->ev_sweep.size() < 2) {
+        hipEvent_t e;
+        HIP_TRY(ctx, hipEventCreate(&e));
+        ctx->ev_sweep.push_back(e);
+    }
+    hipStream_t st = ctx->stream;
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_begin, st));
+    int32_t rc = sk_run_energy(ctx);          // E = energy(X, C) at the start of every call, RRRMC.jl:95
+    if (rc) return rc;
+    HIP_TRY(ctx, hipMemsetAsync(ctx->d_acc, 0, sizeof(int64_t) * ctx->Rpad, st));
+    SkParams P{};
+    P.J = ctx->sk_J; P.lf = ctx->sk_lf; P.lfl = ctx->sk_lfl; P.move_last = ctx->sk_move_last; P.spins = ctx->sk_spins;
+    P.E_cur = ctx->sk_E; P.acc_cur = ctx->d_acc; P.Es = ctx->sk_Es;
+    P.beta = beta; P.g0 = ctx->it_done; P.iters = iters; P.step = step; P.sample0 = 0;
+    P.k0 = (uint32_t)ctx->seed; P.k1 = (uint32_t)(ctx->seed >> 32); P.replica0 = ctx->replica0; P.N = (int)ctx->N;
+    const int spt = (int)((ctx->N + kSkThreads - 1) / kSkThreads);
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_sweep[0], st));
+    hipLaunchKernelGGL(sk_sweep_for(spt), dim3((unsigned)ctx->G8), dim3(kSkThreads), 0, st, P);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_sweep[1], st));
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_end, st));
+    ctx->sweep_launches = 1;
+    ctx->nsamp = nsamp;
+    ctx->it_done += (uint64_t)iters;
+    ctx->results_valid = true;
+    ctx->timing_valid = true;
+    return RRRMC_OK;
+}
+
 }  // namespace
 
 extern "C" {
+
 
 int32_t rrrmc_version(void) { return 100; }
 
@@ -196,7 +328,8 @@ int32_t rrrmc_ctx_create(rrrmc_ctx** out, int32_t model, int64_t N, int64_t K, i
 {
     if (!out) return fail(nullptr, RRRMC_ERR_INVALID_ARG, "out is NULL");
     *out = nullptr;
-    if (model != RRRMC_MODEL_SPARSE_PM1) return fail(nullptr, RRRMC_ERR_UNSUPPORTED, "unknown model kind %d", model);
+    if (model != RRRMC_MODEL_SPARSE_PM1 && model != RRRMC_MODEL_SK_NORMAL) return fail(nullptr, RRRMC_ERR_UNSUPPORTED, "unknown model kind %d", model);
+    if (model == RRRMC_MODEL_SK_NORMAL) return sk_ctx_create(out, N, R, device, replica0);
     if (N < 1 || K < 1 || R < 1) return fail(nullptr, RRRMC_ERR_INVALID_ARG, "N, K, R must be >= 1 (given N=%lld K=%lld R=%lld)", (long long)N, (long long)K, (long long)R);
     if (K > kMaxK) return fail(nullptr, RRRMC_ERR_UNSUPPORTED, "K=%lld: the sparse +-J kernels cover K <= %d", (long long)K, kMaxK);
     if (N > 8192) return fail(nullptr, RRRMC_ERR_UNSUPPORTED, "N=%lld: the LDS-resident sparse kernel covers N <= 8192", (long long)N);
@@ -267,6 +400,8 @@ void rrrmc_ctx_destroy(rrrmc_ctx* ctx)
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     free_dev(ctx->d_A); free_dev(ctx->d_J); free_dev(ctx->d_table); free_dev(ctx->d_spins);
     free_dev(ctx->d_E); free_dev(ctx->d_acc); free_dev(ctx->d_chunks); free_dev(ctx->d_Es);
+    free_dev(ctx->sk_J); free_dev(ctx->sk_lf); free_dev(ctx->sk_lfl); free_dev(ctx->sk_move_last); free_dev(ctx->sk_spins);
+    free_dev(ctx->sk_E); free_dev(ctx->sk_Es);
     for (int i = 0; i < 2; ++i) { free_dev(ctx->d_slots[i]); free_dev(ctx->d_vecs[i]); }
     if (ctx->plan_stream) { (void)hipStreamSynchronize(ctx->plan_stream); (void)hipStreamDestroy(ctx->plan_stream); }
     if (ctx->ev_upload) (void)hipEventDestroy(ctx->ev_upload);
@@ -282,6 +417,7 @@ void rrrmc_ctx_destroy(rrrmc_ctx* ctx)
 int32_t rrrmc_set_graph(rrrmc_ctx* ctx, const int32_t* A, const int8_t* J)
 {
     if (!ctx) return RRRMC_ERR_INVALID_ARG;
+    if (ctx->model != RRRMC_MODEL_SPARSE_PM1) return fail(ctx, RRRMC_ERR_STATE, "rrrmc_set_graph is for sparse +-J models; use rrrmc_set_couplings_dense");
     if (!A || !J) return fail(ctx, RRRMC_ERR_INVALID_ARG, "A and J must not be NULL");
     const int64_t N = ctx->N, K = ctx->K;
     for (int64_t q = 0; q < N * K; ++q) {
@@ -328,6 +464,15 @@ int32_t rrrmc_init_spins_random(rrrmc_ctx* ctx)
 {
     if (!ctx) return RRRMC_ERR_INVALID_ARG;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (ctx->model == RRRMC_MODEL_SK_NORMAL) {
+        const dim3 grid((unsigned)((ctx->N + 255) / 256), (unsigned)ctx->G8);
+        hipLaunchKernelGGL(sk_init_spins_kernel, grid, dim3(256), 0, ctx->stream, ctx->sk_spins, (int)ctx->N, ctx->replica0,
+                           (uint32_t)ctx->seed, (uint32_t)(ctx->seed >> 32));
+        HIP_TRY(ctx, hipGetLastError());
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        ctx->spins_set = true;
+        return RRRMC_OK;
+    }
     const dim3 grid((unsigned)((ctx->N + 255) / 256), (unsigned)ctx->G);
     hipLaunchKernelGGL(init_spins_kernel, grid, dim3(256), 0, ctx->stream, ctx->d_spins, (int)ctx->N, ctx->replica0 / 32,
                        (uint32_t)ctx->seed, (uint32_t)(ctx->seed >> 32));
@@ -347,6 +492,17 @@ int32_t rrrmc_set_spins(rrrmc_ctx* ctx, const uint64_t* chunks)
         for (int64_t r = 0; r < ctx->R; ++r)
             if (chunks[r * nch + nch - 1] & tailmask)
                 return fail(ctx, RRRMC_ERR_INVALID_ARG, "replica %lld: bits beyond N are set in the last chunk", (long long)r);
+    }
+    if (ctx->model == RRRMC_MODEL_SK_NORMAL) {
+        std::vector<uint8_t> b8((size_t)(ctx->G8 * N), 0);
+        for (int64_t r = 0; r < ctx->R; ++r)
+            for (int64_t x = 0; x < N; ++x)
+                if ((chunks[r * nch + (x >> 6)] >> (x & 63)) & 1ull) b8[(r >> 3) * N + x] |= (uint8_t)(1u << (r & 7));
+        HIP_TRY(ctx, hipSetDevice(ctx->device));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        HIP_TRY(ctx, hipMemcpy(ctx->sk_spins, b8.data(), b8.size(), hipMemcpyHostToDevice));
+        ctx->spins_set = true;
+        return RRRMC_OK;
     }
     std::vector<uint32_t> bs((size_t)(ctx->G * N), 0);
     for (int64_t r = 0; r < ctx->R; ++r) {
@@ -369,6 +525,17 @@ int32_t rrrmc_get_spins(rrrmc_ctx* ctx, uint64_t* chunks)
     if (rc) return rc;
     if (!chunks) return fail(ctx, RRRMC_ERR_INVALID_ARG, "chunks is NULL");
     const int64_t N = ctx->N, nch = (N + 63) / 64;
+    if (ctx->model == RRRMC_MODEL_SK_NORMAL) {
+        std::vector<uint8_t> b8((size_t)(ctx->G8 * N));
+        HIP_TRY(ctx, hipSetDevice(ctx->device));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        HIP_TRY(ctx, hipMemcpy(b8.data(), ctx->sk_spins, b8.size(), hipMemcpyDeviceToHost));
+        std::memset(chunks, 0, sizeof(uint64_t) * ctx->R * nch);
+        for (int64_t r = 0; r < ctx->R; ++r)
+            for (int64_t x = 0; x < N; ++x)
+                chunks[r * nch + (x >> 6)] |= (uint64_t)((b8[(r >> 3) * N + x] >> (r & 7)) & 1u) << (x & 63);
+        return RRRMC_OK;
+    }
     std::vector<uint32_t> bs((size_t)(ctx->G * N));
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -387,6 +554,7 @@ int32_t rrrmc_energy(rrrmc_ctx* ctx, int64_t* E_out)
 {
     int32_t rc = ensure_state(ctx, true);
     if (rc) return rc;
+    if (ctx->model != RRRMC_MODEL_SPARSE_PM1) return fail(ctx, RRRMC_ERR_STATE, "this model's energies are Float64: use the _f64 entry point");
     if (!E_out) return fail(ctx, RRRMC_ERR_INVALID_ARG, "E_out is NULL");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     rc = run_energy(ctx, nullptr);
@@ -402,6 +570,7 @@ int32_t rrrmc_get_fields(rrrmc_ctx* ctx, int64_t* lfields_out)
 {
     int32_t rc = ensure_state(ctx, true);
     if (rc) return rc;
+    if (ctx->model != RRRMC_MODEL_SPARSE_PM1) return fail(ctx, RRRMC_ERR_STATE, "this model's energies are Float64: use the _f64 entry point");
     if (!lfields_out) return fail(ctx, RRRMC_ERR_INVALID_ARG, "lfields_out is NULL");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     uint8_t* d_nun = nullptr;
@@ -423,6 +592,7 @@ int32_t rrrmc_standard_mc_async(rrrmc_ctx* ctx, double beta, int64_t iters, int6
 {
     int32_t rc = ensure_state(ctx, true);
     if (rc) return rc;
+    if (ctx->model == RRRMC_MODEL_SK_NORMAL) return sk_standard_mc_async(ctx, beta, iters, step);
     if (iters < 0) return fail(ctx, RRRMC_ERR_INVALID_ARG, "iters must be >= 0, given %lld", (long long)iters);
     if (step < 1) return fail(ctx, RRRMC_ERR_INVALID_ARG, "step must be >= 1, given %lld", (long long)step);
     if (std::isnan(beta)) return fail(ctx, RRRMC_ERR_INVALID_ARG, "beta is NaN");
@@ -585,6 +755,7 @@ int32_t rrrmc_sync(rrrmc_ctx* ctx)
 int32_t rrrmc_fetch_results(rrrmc_ctx* ctx, int64_t* Es_out, int64_t* accepted_out)
 {
     if (!ctx) return RRRMC_ERR_INVALID_ARG;
+    if (ctx->model != RRRMC_MODEL_SPARSE_PM1) return fail(ctx, RRRMC_ERR_STATE, "this model's energies are Float64: use rrrmc_fetch_results_f64");
     if (!ctx->results_valid) return fail(ctx, RRRMC_ERR_STATE, "no sampling call has been made");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -652,6 +823,119 @@ RRRMC_API int32_t rrrmc_debug_step_trace(rrrmc_ctx* ctx, unsigned long long* out
     return RRRMC_OK;
 }
 #endif
+
+// ---- Float64-energy models: exported entry points ---------------------------------------------------------------
+
+int32_t rrrmc_set_couplings_dense(rrrmc_ctx* ctx, const double* J)
+{
+    if (!ctx) return RRRMC_ERR_INVALID_ARG;
+    if (ctx->model != RRRMC_MODEL_SK_NORMAL) return fail(ctx, RRRMC_ERR_STATE, "rrrmc_set_couplings_dense is for RRRMC_MODEL_SK_NORMAL");
+    if (!J) return fail(ctx, RRRMC_ERR_INVALID_ARG, "J is NULL");
+    const int64_t N = ctx->N;
+    for (int64_t i = 0; i < N; ++i) {        // GraphSKNormal(J; check = true), SK.jl:187-194
+        if (J[i * N + i] != 0.0) return fail(ctx, RRRMC_ERR_INVALID_ARG, "diagonal entries of J must be 0, found: J[%lld][%lld] = %g", (long long)i, (long long)i, J[i * N + i]);
+        for (int64_t j = i + 1; j < N; ++j)
+            if (!(J[i * N + j] == J[j * N + i]))
+                return fail(ctx, RRRMC_ERR_INVALID_ARG, "J must be symmetric, found: J[%lld][%lld] = %g, J[%lld][%lld] = %g", (long long)i, (long long)j, J[i * N + j], (long long)j, (long long)i, J[j * N + i]);
+    }
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipMemcpy(ctx->sk_J, J, sizeof(double) * N * N, hipMemcpyHostToDevice));
+    ctx->graph_set = true;
+    return RRRMC_OK;
+}
+
+int32_t rrrmc_energy_f64(rrrmc_ctx* ctx, double* E_out)
+{
+    int32_t rc = ensure_state(ctx, true);
+    if (rc) return rc;
+    if (ctx->model != RRRMC_MODEL_SK_NORMAL) return fail(ctx, RRRMC_ERR_STATE, "this model's energies are integers: use rrrmc_energy");
+    if (!E_out) return fail(ctx, RRRMC_ERR_INVALID_ARG, "E_out is NULL");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    rc = sk_run_energy(ctx);
+    if (rc) return rc;
+    std::vector<double> E((size_t)ctx->Rpad);
+    HIP_TRY(ctx, hipMemcpyAsync(E.data(), ctx->sk_E, sizeof(double) * ctx->Rpad, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    for (int64_t r = 0; r < ctx->R; ++r) E_out[r] = E[r];
+    return RRRMC_OK;
+}
+
+int32_t rrrmc_get_fields_f64(rrrmc_ctx* ctx, double* lfields_out)
+{
+    int32_t rc = ensure_state(ctx, true);
+    if (rc) return rc;
+    if (ctx->model != RRRMC_MODEL_SK_NORMAL) return fail(ctx, RRRMC_ERR_STATE, "this model's fields are integers: use rrrmc_get_fields");
+    if (!lfields_out) return fail(ctx, RRRMC_ERR_INVALID_ARG, "lfields_out is NULL");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const int64_t N = ctx->N;
+    std::vector<double> lf((size_t)ctx->G8 * N * kSkRB);
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipMemcpy(lf.data(), ctx->sk_lf, sizeof(double) * lf.size(), hipMemcpyDeviceToHost));   // the live cache (not recomputed)
+    for (int64_t r = 0; r < ctx->R; ++r)
+        for (int64_t x = 0; x < N; ++x) lfields_out[r * N + x] = lf[((r / kSkRB) * N + x) * kSkRB + (r % kSkRB)];
+    return RRRMC_OK;
+}
+
+int32_t rrrmc_fetch_results_f64(rrrmc_ctx* ctx, double* Es_out, int64_t* accepted_out)
+{
+    if (!ctx) return RRRMC_ERR_INVALID_ARG;
+    if (ctx->model != RRRMC_MODEL_SK_NORMAL) return fail(ctx, RRRMC_ERR_STATE, "this model's energies are integers: use rrrmc_fetch_results");
+    if (!ctx->results_valid) return fail(ctx, RRRMC_ERR_STATE, "no sampling call has been made");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (accepted_out) {
+        std::vector<int64_t> acc((size_t)ctx->Rpad);
+        HIP_TRY(ctx, hipMemcpy(acc.data(), ctx->d_acc, sizeof(int64_t) * ctx->Rpad, hipMemcpyDeviceToHost));
+        for (int64_t r = 0; r < ctx->R; ++r) accepted_out[r] = acc[r];
+    }
+    if (Es_out && ctx->nsamp > 0) {
+        double* d_out = nullptr;
+        const size_t bytes = sizeof(double) * (size_t)ctx->R * ctx->nsamp;
+        HIP_TRY(ctx, hipMalloc(&d_out, bytes));
+        const dim3 grid((unsigned)((ctx->nsamp + 31) / 32), (unsigned)((ctx->Rpad + 31) / 32));
+        hipLaunchKernelGGL(transpose_es_f64_kernel, grid, dim3(256), 0, ctx->stream, ctx->sk_Es, d_out, ctx->nsamp, (int)ctx->Rpad, (int)ctx->R);
+        hipError_t e = hipGetLastError();
+        if (e == hipSuccess) e = hipMemcpyAsync(Es_out, d_out, bytes, hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        (void)hipFree(d_out);
+        HIP_TRY(ctx, e);
+    }
+    return RRRMC_OK;
+}
+
+int32_t rrrmc_standard_mc_f64(rrrmc_ctx* ctx, double beta, int64_t iters, int64_t step, double* Es_out, int64_t* accepted_out)
+{
+    int32_t rc = rrrmc_standard_mc_async(ctx, beta, iters, step);
+    if (rc) return rc;
+    rc = rrrmc_sync(ctx);
+    if (rc) return rc;
+    return rrrmc_fetch_results_f64(ctx, Es_out, accepted_out);
+}
+
+int32_t rrrmc_gen_sk_gauss(int64_t N, uint64_t seed, double* J_out)
+{
+    // gen_J_gauss, src/graphs/SK.jl:170-179: rows of randn(N) scaled by 1/sqrt(N), zero diagonal, upper triangle mirrored.
+    // n-th normal of the GAUSS stream: Box-Muller on the two 53-bit uniforms of Philox block n >> 1 (cos / sin branch).
+    if (!J_out) return fail(nullptr, RRRMC_ERR_INVALID_ARG, "J_out is NULL");
+    if (N < 1) return fail(nullptr, RRRMC_ERR_INVALID_ARG, "N must be >= 1");
+    const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+    const double scale = 1.0 / std::sqrt((double)N);
+    for (int64_t i = 0; i < N; ++i)
+        for (int64_t j = 0; j < N; ++j) {
+            const uint64_t n = (uint64_t)(i * N + j), blk = n >> 1;
+            const Philox4 o = philox4x32_10((uint32_t)blk, (uint32_t)(blk >> 32), 0u, TAG_GAUSS, k0, k1);
+            const uint64_t a = ((uint64_t)o.w[0] << 32) | o.w[1], b = ((uint64_t)o.w[2] << 32) | o.w[3];
+            const double u1 = ((double)(a >> 11) + 1.0) * 0x1.0p-53, u2 = (double)(b >> 11) * 0x1.0p-53;
+            const double rad = std::sqrt(-2.0 * std::log(u1)), ang = 6.283185307179586476925286766559 * u2;
+            J_out[i * N + j] = ((n & 1u) ? rad * std::sin(ang) : rad * std::cos(ang)) * scale;
+        }
+    for (int64_t i = 0; i < N; ++i) {
+        J_out[i * N + i] = 0.0;
+        for (int64_t j = i + 1; j < N; ++j) J_out[j * N + i] = J_out[i * N + j];
+    }
+    return RRRMC_OK;
+}
 
 // ---- host-side graph constructors -------------------------------------------------------------------
 

@@ -1,0 +1,254 @@
+// gfx950 kernels for the dense Gaussian SK model GraphSKNormal (src/graphs/SK.jl:170-297) under standardMC
+// (src/RRRMC.jl:81-127).  Float64 couplings and local fields; delta_energy(i) = +lfields[i] (SK.jl:278-284).
+//
+// Layout: one workgroup of 256 threads owns kSkRB = 8 replicas; thread t holds the local fields (and the undo copy
+// lfields_last, SK.jl:247-250) of the sites j = q*256 + t, q < SPT, for its 8 replicas in REGISTERS, plus their spin
+// bits.  All replicas attempt the same site (SITE stream); the J row of that site (8 KiB at N = 1024, shared by every
+// workgroup, L2-resident) is prefetched one step ahead.  Per step: the site's owner thread publishes the 8 fields,
+// 8 lanes decide (rand53 < exp(-beta dE), deterministic exp shared with the oracle), every thread applies
+// lf[j] += 4 sigma_ij J_ij for the accepted replicas.  Each field receives exactly the reference's sequence of
+// floating-point operations, so trajectories and energies are bit-identical to the oracle, not merely within 1e-6.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "philox.hpp"
+
+namespace rrrmc {
+
+constexpr int kSkThreads = 256;
+constexpr int kSkRB = 8;              // replicas per workgroup
+constexpr int kSkMaxSPT = 8;          // sites per thread -> N <= 2048
+constexpr uint32_t TAG_ACCEPT_F64 = 9;
+constexpr uint32_t TAG_GAUSS = 6;
+
+// rand() of replica `replica` at global iteration g: 53-bit uniform of the ACCEPT_F64 stream
+RRRMC_HD double rand53(uint32_t k0, uint32_t k1, uint64_t g, uint32_t replica)
+{
+    const uint64_t blk = g >> 1;
+    const Philox4 o = philox4x32_10((uint32_t)blk, (uint32_t)(blk >> 32), replica, TAG_ACCEPT_F64, k0, k1);
+    const uint64_t u = (g & 1u) ? (((uint64_t)o.w[2] << 32) | o.w[3]) : (((uint64_t)o.w[0] << 32) | o.w[1]);
+    return (double)(u >> 11) * 0x1.0p-53;
+}
+
+// exp(x) with a fixed operation order and no fused multiply-add: Cody-Waite reduction, degree-13 Taylor polynomial in
+// Horner form, exact scaling.  The oracle evaluates the same sequence, so `rand() < exp(x)` agrees bit for bit.
+__device__ __forceinline__ double det_exp(double x)
+{
+    const double LOG2E = 1.44269504088896338700e+00;
+    const double LN2_HI = 6.93147180369123816490e-01, LN2_LO = 1.90821492927058770002e-10;
+    const double c[14] = {1.0, 1.0, 0.5, 1.0 / 6, 1.0 / 24, 1.0 / 120, 1.0 / 720, 1.0 / 5040, 1.0 / 40320, 1.0 / 362880,
+                          1.0 / 3628800, 1.0 / 39916800, 1.0 / 479001600, 1.0 / 6227020800.0};
+    if (x != x) return x;
+    if (x < -745.2) return 0.0;
+    if (x > 709.7) return __builtin_inf();
+    const double k = floor(__dadd_rn(__dmul_rn(x, LOG2E), 0.5));
+    const double r = __dadd_rn(__dadd_rn(x, -__dmul_rn(k, LN2_HI)), -__dmul_rn(k, LN2_LO));
+    double p = c[13];
+#pragma unroll
+    for (int n = 12; n >= 0; --n) p = __dadd_rn(__dmul_rn(p, r), c[n]);
+    return ldexp(p, (int)k);
+}
+
+struct SkParams {
+    const double* J;        // [N][N]
+    double* lf;             // [G][N][kSkRB]  local fields (replica fastest)
+    double* lfl;            // [G][N][kSkRB]  lfields_last
+    int32_t* move_last;     // [G][kSkRB]     -1 = none
+    uint8_t* spins;         // [G][N]         bit r = spin of replica 8*group + r
+    double* E_cur;          // [G * kSkRB]
+    int64_t* acc_cur;       // [G * kSkRB]
+    double* Es;             // [nsamples][G * kSkRB]; may be null
+    double beta;
+    uint64_t g0;            // iterations already consumed from the streams
+    int64_t iters, step, sample0;
+    uint32_t k0, k1, replica0;
+    int N;
+};
+
+template <int SPT>
+__global__ __launch_bounds__(kSkThreads) void sk_sweep_kernel(SkParams P)
+{
+    __shared__ double sh_lfi[2][kSkRB];
+    __shared__ uint32_t sh_si[2], sh_acc[2], sh_swap[2];
+    const int tid = threadIdx.x, N = P.N;
+    const int grp = blockIdx.x, Rp = gridDim.x * kSkRB;
+    double lf[SPT][kSkRB], lfl[SPT][kSkRB];
+    uint32_t sb[SPT];
+#pragma unroll
+    for (int q = 0; q < SPT; ++q) {
+        const int j = q * kSkThreads + tid;
+        sb[q] = j < N ? P.spins[(size_t)grp * N + j] : 0u;
+#pragma unroll
+        for (int r = 0; r < kSkRB; ++r) {
+            lf[q][r] = j < N ? P.lf[((size_t)grp * N + j) * kSkRB + r] : 0.0;
+            lfl[q][r] = j < N ? P.lfl[((size_t)grp * N + j) * kSkRB + r] : 0.0;
+        }
+    }
+    // lanes 0..7 of wave 0 each own one replica's scalar state
+    double E_run = 0.0;
+    int64_t A_run = 0;
+    int32_t mlast = -1;
+    if (tid < kSkRB) { E_run = P.E_cur[grp * kSkRB + tid]; A_run = P.acc_cur[grp * kSkRB + tid]; mlast = P.move_last[grp * kSkRB + tid]; }
+    int64_t ns = P.sample0;
+
+    double Jq[SPT], Jn[SPT];
+    uint32_t site = P.iters > 0 ? site_of(P.k0, P.k1, P.g0 + 1, (uint32_t)N) : 0u;
+#pragma unroll
+    for (int q = 0; q < SPT; ++q) { const int j = q * kSkThreads + tid; Jq[q] = j < N ? P.J[(size_t)site * N + j] : 0.0; }
+
+    for (int64_t it = 1; it <= P.iters; ++it) {
+        const int b = (int)(it & 1);
+        const uint64_t g = P.g0 + (uint64_t)it;
+        // prefetch the next site's J row
+        const uint32_t site_n = it < P.iters ? site_of(P.k0, P.k1, g + 1, (uint32_t)N) : site;
+#pragma unroll
+        for (int q = 0; q < SPT; ++q) { const int j = q * kSkThreads + tid; Jn[q] = j < N ? P.J[(size_t)site_n * N + j] : 0.0; }
+
+        const int qi = (int)(site >> 8), owner = (int)(site & 255u);
+        if (tid == owner) {
+#pragma unroll
+            for (int q = 0; q < SPT; ++q)
+                if (q == qi) {
+#pragma unroll
+                    for (int r = 0; r < kSkRB; ++r) sh_lfi[b][r] = lf[q][r];
+                    sh_si[b] = sb[q];
+                }
+        }
+        __syncthreads();
+        if (tid < 64) {          // the first wave: lanes 0..7 decide, the whole wave ballots
+            bool acc = false, swp = false;
+            if (tid < kSkRB) {
+                if (it % P.step == 0) {          // sample BEFORE the move (RRRMC.jl:104-108)
+                    if (P.Es) P.Es[ns * Rp + grp * kSkRB + tid] = E_run;
+                    ns += 1;
+                }
+                const double dE = sh_lfi[b][tid];                       // delta_energy, SK.jl:278-284
+                const double x = -P.beta * dE;
+                acc = (x >= 0.0) || (rand53(P.k0, P.k1, g, P.replica0 + (uint32_t)(grp * kSkRB + tid)) < det_exp(x));   // RRRMC.jl:39
+                swp = acc && (mlast == (int32_t)site);                  // undo path of update_cache!, SK.jl:247-250
+                if (acc) { E_run += dE; A_run += 1; mlast = (int32_t)site; }
+            }
+            const unsigned long long ba = __ballot(acc), bs = __ballot(swp);
+            if (tid == 0) { sh_acc[b] = (uint32_t)ba; sh_swap[b] = (uint32_t)bs; }
+        }
+        __syncthreads();
+        const uint32_t accm = sh_acc[b], swpm = sh_swap[b], si_old = sh_si[b];
+        const uint32_t normal = accm & ~swpm;
+        const uint32_t si_new = si_old ^ accm;
+        if (swpm) {          // workgroup-uniform: swap lfields <-> lfields_last of those replicas
+#pragma unroll
+            for (int q = 0; q < SPT; ++q)
+#pragma unroll
+                for (int r = 0; r < kSkRB; ++r)
+                    if ((swpm >> r) & 1u) { const double t = lf[q][r]; lf[q][r] = lfl[q][r]; lfl[q][r] = t; }
+        }
+        if (normal) {        // workgroup-uniform
+#pragma unroll
+            for (int q = 0; q < SPT; ++q) {
+                const double d4 = 4.0 * Jq[q];
+                const uint32_t diff = si_new ^ sb[q];                   // bit r set: s_i != s_j for replica r -> sigma = -1
+#pragma unroll
+                for (int r = 0; r < kSkRB; ++r)
+                    if ((normal >> r) & 1u) {
+                        const double old = lf[q][r];
+                        lfl[q][r] = old;
+                        lf[q][r] = old + (((diff >> r) & 1u) ? -d4 : d4);   // lfields[j] = lfj + 4*J*sigma, SK.jl:256-262
+                    }
+            }
+            if (tid == owner) {
+#pragma unroll
+                for (int q = 0; q < SPT; ++q)
+                    if (q == qi) {
+#pragma unroll
+                        for (int r = 0; r < kSkRB; ++r)
+                            if ((normal >> r) & 1u) { const double lfm = sh_lfi[b][r]; lfl[q][r] = lfm; lf[q][r] = -lfm; }   // SK.jl:263-264
+                    }
+            }
+        }
+        if (tid == owner) {
+#pragma unroll
+            for (int q = 0; q < SPT; ++q)
+                if (q == qi) sb[q] ^= accm;                              // spinflip!, Interface.jl:89-92
+        }
+        site = site_n;
+#pragma unroll
+        for (int q = 0; q < SPT; ++q) Jq[q] = Jn[q];
+    }
+
+#pragma unroll
+    for (int q = 0; q < SPT; ++q) {
+        const int j = q * kSkThreads + tid;
+        if (j < N) {
+            P.spins[(size_t)grp * N + j] = (uint8_t)sb[q];
+#pragma unroll
+            for (int r = 0; r < kSkRB; ++r) {
+                P.lf[((size_t)grp * N + j) * kSkRB + r] = lf[q][r];
+                P.lfl[((size_t)grp * N + j) * kSkRB + r] = lfl[q][r];
+            }
+        }
+    }
+    if (tid < kSkRB) { P.E_cur[grp * kSkRB + tid] = E_run; P.acc_cur[grp * kSkRB + tid] = A_run; P.move_last[grp * kSkRB + tid] = mlast; }
+}
+
+// energy(X, C) of SK.jl:212-237 with the reference's summation order: thread = (site i, replica r) sums over j in order;
+// then one thread per replica accumulates n -= lf over i in order.  Also resets the undo state.
+__global__ __launch_bounds__(256) void sk_fields_kernel(const double* __restrict__ J, const uint8_t* __restrict__ spins,
+                                                        double* __restrict__ lf, double* __restrict__ lfl,
+                                                        int32_t* __restrict__ move_last, int N)
+{
+    const int grp = blockIdx.y;
+    const int i = blockIdx.x * 32 + (threadIdx.x >> 3), r = threadIdx.x & 7;
+    if (i >= N) return;
+    const uint8_t* sp = spins + (size_t)grp * N;
+    const uint32_t si = (sp[i] >> r) & 1u;
+    double acc = 0.0;
+    for (int j = 0; j < N; ++j) {
+        const uint32_t sj = (sp[j] >> r) & 1u;
+        const double Jij = J[(size_t)j * N + i];          // = J[i][j]: symmetric, read transposed for coalescing
+        acc += (si ^ sj) ? -Jij : Jij;                    // (1 - 2(si xor sj)) * Ji[j]
+    }
+    lf[((size_t)grp * N + i) * kSkRB + r] = 2 * acc;
+    lfl[((size_t)grp * N + i) * kSkRB + r] = 0.0;
+    if (i == 0) move_last[grp * kSkRB + r] = -1;
+}
+
+__global__ __launch_bounds__(64) void sk_energy_kernel(const double* __restrict__ lf, double* __restrict__ E_out, int N, int Rp)
+{
+    const int rep = blockIdx.x * 64 + threadIdx.x;
+    if (rep >= Rp) return;
+    const int grp = rep / kSkRB, r = rep % kSkRB;
+    double n = 0.0;
+    for (int i = 0; i < N; ++i) n -= lf[((size_t)grp * N + i) * kSkRB + r] * 0.5;     // n -= lf_half, SK.jl:231 (lfields = 2 lf_half, exact)
+    E_out[rep] = n / 2;
+}
+
+__global__ __launch_bounds__(256) void sk_init_spins_kernel(uint8_t* __restrict__ spins, int N, uint32_t replica0, uint32_t k0, uint32_t k1)
+{
+    // INIT stream: bit of replica rho at site x = bit (rho & 31) of word (x & 3) of ctr (x >> 2, 0, rho >> 5, TAG_INIT)
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    if (x >= N) return;
+    const uint32_t rho0 = replica0 + blockIdx.y * kSkRB;                 // 8 consecutive replicas: same 32-group (replica0 % 32 == 0)
+    const uint32_t w = init_spin_word(k0, k1, rho0 >> 5, (uint64_t)x);
+    spins[(size_t)blockIdx.y * N + x] = (uint8_t)((w >> (rho0 & 31u)) & 0xffu);
+}
+
+__global__ __launch_bounds__(256) void transpose_es_f64_kernel(const double* __restrict__ Es, double* __restrict__ out, int64_t nsamp, int Rp, int R)
+{
+    __shared__ double tile[32][33];
+    const int64_t s0 = (int64_t)blockIdx.x * 32;
+    const int r0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int j = ty; j < 32; j += 8) {
+        const int64_t s = s0 + j;
+        tile[j][tx] = (s < nsamp && r0 + tx < Rp) ? Es[s * Rp + r0 + tx] : 0.0;
+    }
+    __syncthreads();
+    for (int j = ty; j < 32; j += 8) {
+        const int r = r0 + j;
+        const int64_t s = s0 + tx;
+        if (r < R && s < nsamp) out[(int64_t)r * nsamp + s] = tile[tx][j];
+    }
+}
+
+}  // namespace rrrmc

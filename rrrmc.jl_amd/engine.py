@@ -7,6 +7,7 @@ from ._lib import RRRMCError, check, lib
 from .graphs import DEFAULT_SEED, Config, nchunks
 
 MODEL_SPARSE_PM1 = 1
+MODEL_SK_NORMAL = 2
 
 
 class Engine:
@@ -15,9 +16,13 @@ class Engine:
     def __init__(self, X, R=1, device=0, replica0=0):
         self.X, self.R = X, int(R)
         self._ctx = C.c_void_p()
-        check(lib().rrrmc_ctx_create(C.byref(self._ctx), MODEL_SPARSE_PM1, X.N, X.K, self.R, device, replica0))
+        self._f64 = X.model_kind == MODEL_SK_NORMAL
+        check(lib().rrrmc_ctx_create(C.byref(self._ctx), X.model_kind, X.N, X.K, self.R, device, replica0))
         try:
-            check(lib().rrrmc_set_graph(self._ctx, X.A, X.J), self._ctx)
+            if self._f64:
+                check(lib().rrrmc_set_couplings_dense(self._ctx, X.J.reshape(-1)), self._ctx)
+            else:
+                check(lib().rrrmc_set_graph(self._ctx, X.A, X.J), self._ctx)
         except RRRMCError:
             self.close()
             raise
@@ -64,23 +69,24 @@ class Engine:
         return out
 
     def energy(self):
-        E = np.zeros(self.R, np.int64)
-        check(lib().rrrmc_energy(self._ctx, E), self._ctx)
+        E = np.zeros(self.R, self.X.energy_dtype)
+        check((lib().rrrmc_energy_f64 if self._f64 else lib().rrrmc_energy)(self._ctx, E), self._ctx)
         return E
 
     def fields(self):
-        lf = np.zeros((self.R, self.X.N), np.int64)
-        check(lib().rrrmc_get_fields(self._ctx, lf.reshape(-1)), self._ctx)
+        lf = np.zeros((self.R, self.X.N), self.X.energy_dtype)
+        check((lib().rrrmc_get_fields_f64 if self._f64 else lib().rrrmc_get_fields)(self._ctx, lf.reshape(-1)), self._ctx)
         return lf
 
     # -- sampling ---------------------------------------------------------------------------------
     def standard_mc(self, beta, iters, step=1, want_energies=True):
         """Returns (Es[R, iters // step], accepted[R])."""
         nsamp = int(iters) // int(step)
-        Es = np.zeros((self.R, nsamp), np.int64)
+        Es = np.zeros((self.R, nsamp), self.X.energy_dtype)
         acc = np.zeros(self.R, np.int64)
-        check(lib().rrrmc_standard_mc(self._ctx, float(beta), int(iters), int(step),
-                                      Es.ctypes.data if (want_energies and nsamp) else None, acc.ctypes.data), self._ctx)
+        fn = lib().rrrmc_standard_mc_f64 if self._f64 else lib().rrrmc_standard_mc
+        check(fn(self._ctx, float(beta), int(iters), int(step), Es.ctypes.data if (want_energies and nsamp) else None,
+                 acc.ctypes.data), self._ctx)
         return Es, acc
 
     def standard_mc_async(self, beta, iters, step=1):
@@ -93,9 +99,10 @@ class Engine:
     def fetch_results(self, want_energies=True):
         iters, step = self._last
         nsamp = iters // step
-        Es = np.zeros((self.R, nsamp), np.int64)
+        Es = np.zeros((self.R, nsamp), self.X.energy_dtype)
         acc = np.zeros(self.R, np.int64)
-        check(lib().rrrmc_fetch_results(self._ctx, Es.ctypes.data if (want_energies and nsamp) else None, acc.ctypes.data), self._ctx)
+        fn = lib().rrrmc_fetch_results_f64 if self._f64 else lib().rrrmc_fetch_results
+        check(fn(self._ctx, Es.ctypes.data if (want_energies and nsamp) else None, acc.ctypes.data), self._ctx)
         return Es, acc
 
     def last_timing(self):
@@ -154,7 +161,7 @@ def standardMC(X, beta, iters, *, seed=DEFAULT_SEED, step=1, hook=None, C0=None,
                 _, a = eng.standard_mc(beta, 1, step=2, want_energies=False)   # the move of iteration nxt
                 accepted += a
                 it = nxt
-            Es = np.stack(samples, axis=1) if samples else np.zeros((eng.R, 0), np.int64)
+            Es = np.stack(samples, axis=1) if samples else np.zeros((eng.R, 0), X.energy_dtype)
         eng.get_config(Cfg)
         if not quiet:
             print("samples = ", Es.shape[1])

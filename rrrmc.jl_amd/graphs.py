@@ -55,6 +55,8 @@ class Config:
 
 class _SparsePM1Graph:
     """Common part of GraphRRG / GraphEA with LEV = (-1, 1): neighbour table A[N, K], couplings J[N, K]."""
+    model_kind = 1          # RRRMC_MODEL_SPARSE_PM1
+    energy_dtype = np.int64
 
     def __init__(self, A, J):
         A = np.ascontiguousarray(A, np.int32)
@@ -109,6 +111,35 @@ class GraphEA(_SparsePM1Graph):
     def from_AJ(cls, A, J):
         self = cls.__new__(cls)
         _SparsePM1Graph.__init__(self, A, J)
+        return self
+
+
+class GraphSKNormal:
+    """``GraphSKNormal(N)`` — Sherrington-Kirkpatrick model, couplings ~ Normal(0, 1/N) (src/graphs/SK.jl:181-210).
+
+    ``GraphSKNormal.from_J(J)`` is ``GraphSKNormal(J; check=true)`` (SK.jl:184-197): J must be symmetric with a
+    zero diagonal.  ``ET = Float64``: energies are float64.
+    """
+    model_kind = 2          # RRRMC_MODEL_SK_NORMAL
+    energy_dtype = np.float64
+    K = 0
+
+    def __init__(self, N, seed=DEFAULT_SEED):
+        J = np.zeros((int(N), int(N)), np.float64)
+        check(lib().rrrmc_gen_sk_gauss(N, seed, J.reshape(-1)))
+        self.N, self.J = int(N), J
+
+    @classmethod
+    def from_J(cls, J):
+        J = np.ascontiguousarray(J, np.float64)
+        if J.ndim != 2 or J.shape[0] != J.shape[1]:
+            raise ValueError("invalid J inner length, expected %d" % J.shape[0])
+        if (np.diag(J) != 0).any():
+            raise ValueError("diagonal entries of J must be 0")
+        if not (J == J.T).all():
+            raise ValueError("J must be symmetric")
+        self = cls.__new__(cls)
+        self.N, self.J = J.shape[0], J
         return self
 
 

@@ -1,0 +1,41 @@
+#!/usr/bin/env python3
+"""Secondary benchmarks (not the headline metric): throughput of the other model kernels on one GPU.
+  python tools/bench_models.py sk      GraphSKNormal N=1024, 2048 replicas (BASELINE.json configs[2])
+"""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import __graft_entry__ as entry  # noqa: E402
+
+
+def bench_sk(N=1024, R=2048, beta=1.0, iters=1 << 16, step=1 << 10, seed=0x5EED):
+    pkg = entry.load_package()
+    X = pkg.GraphSKNormal(N, seed=seed)
+    eng = pkg.Engine(X, R)
+    eng.seed(seed)
+    eng.init_spins_random()
+    eng.standard_mc_async(beta, iters // 4, step); eng.sync()
+    t0 = time.perf_counter()
+    eng.standard_mc_async(beta, iters, step); eng.sync()
+    dt = time.perf_counter() - t0
+    total_ms, sweep_ms, _ = eng.last_timing()
+    Es, acc = eng.fetch_results()
+    a = float(acc.mean()) / iters
+    attempts = float(R) * iters
+    bytes_per_attempt = 8 + a * (17 * N + 2)                 # SURVEY.md §8d, dense SK Float64
+    out = {"model": "GraphSKNormal", "N": N, "replicas": R, "beta": beta, "iters": iters, "attempts_per_s": attempts / dt,
+           "kernel_ms": sweep_ms, "acceptance": a, "energy_per_spin": float(Es[:, -1].mean()) / N,
+           "algorithmic_bytes_per_attempt": bytes_per_attempt,
+           "algorithmic_GBps_kernel": bytes_per_attempt * attempts / (sweep_ms * 1e-3) / 1e9}
+    print(json.dumps(out))
+    eng.close()
+
+
+if __name__ == "__main__":
+    which = sys.argv[1] if len(sys.argv) > 1 else "sk"
+    {"sk": bench_sk}[which]()
