@@ -47,7 +47,10 @@ enum rrrmc_status {
 
 enum rrrmc_model {
     RRRMC_MODEL_SPARSE_PM1 = 1,  /* GraphRRG{Int,(-1,1),K} src/graphs/RRG.jl:116 and GraphEA{Int,(-1,1),2D} src/graphs/EA.jl:138 */
-    RRRMC_MODEL_SK_NORMAL = 2    /* GraphSKNormal (Float64 couplings) src/graphs/SK.jl:181-210; K is ignored */
+    RRRMC_MODEL_SK_NORMAL = 2,   /* GraphSKNormal (Float64 couplings) src/graphs/SK.jl:181-210; K is ignored */
+    RRRMC_MODEL_QUANT_RRG = 3    /* GraphQuant over M Suzuki-Trotter slices of one GraphRRG{Int,(-1,1),K} disorder
+                                    (src/graphs/QT.jl:126-170 with the shared-disorder pattern of src/QAliases.jl:43-67);
+                                    created with rrrmc_ctx_create_quant */
 };
 
 /* Library ABI version (major*10000 + minor*100 + patch). */
@@ -126,6 +129,26 @@ RRRMC_API int32_t rrrmc_standard_mc_f64(rrrmc_ctx *ctx, double beta, int64_t ite
 RRRMC_API int32_t rrrmc_fetch_results_f64(rrrmc_ctx *ctx, double *Es_out, int64_t *accepted_out);
 /* gen_J_gauss (src/graphs/SK.jl:170-179): J_out[N*N], normal(0, 1/N), symmetric, zero diagonal. GAUSS stream. */
 RRRMC_API int32_t rrrmc_gen_sk_gauss(int64_t N, uint64_t seed, double *J_out);
+
+/* ---- GraphQuant + rrrMC (RRRMC_MODEL_QUANT_RRG) ---------------------------------------------------------------
+ * N = Nk * M spins per replica, slice-major (slice k holds spins k*Nk .. (k+1)*Nk-1, QT.jl:105-108); the slice graph's
+ * (A, J) [Nk x K] is given with rrrmc_set_graph.  Energies are Float64: use the _f64 entry points for energy / results.
+ * Replaces GraphQuant{fourK,GraphRRG}(...) (QT.jl:139-170). */
+RRRMC_API int32_t rrrmc_ctx_create_quant(rrrmc_ctx **out, int64_t Nk, int64_t K, int64_t M, int64_t R,
+                                         int32_t device, uint32_t replica0);
+/* The Trotter coupling fourK (a type parameter of GraphQuant in the reference, QT.jl:126) and the beta it was derived
+ * from: needed by rrrmc_energy_f64 before the first rrrMC call. */
+RRRMC_API int32_t rrrmc_quant_set_field(rrrmc_ctx *ctx, double beta, double fourK);
+/* rrrMC(X::DoubleGraph, beta, iters; step, staged_thr, staged_thr_fact) (src/RRRMC.jl:221-290) for all R replicas.
+ *   fourK = round(2/beta * log(coth(beta * Gamma / M)), digits = 8)  (QT.jl:165) is computed by the caller.
+ * Enqueues on the ctx's stream; rrrmc_sync + rrrmc_fetch_results_f64 return Es [R x iters/step] and accepted [R];
+ * rrrmc_rrr_stats adds the number of staged iterations per replica ("frac. staged iters", RRRMC.jl:287). */
+RRRMC_API int32_t rrrmc_rrr_mc_async(rrrmc_ctx *ctx, double beta, double fourK, int64_t iters, int64_t step,
+                                     double staged_thr, double staged_thr_fact);
+RRRMC_API int32_t rrrmc_rrr_stats(rrrmc_ctx *ctx, int64_t *staged_iters_out);
+/* parity/debug view of the move-selection cache after the last rrrMC call: pos_out[R * N] = class of every spin
+ * (DeltaECache.pos, 0-based a + 2*up), sizes_out[R * 4] = |class k| (DeltaE.jl:63-73). */
+RRRMC_API int32_t rrrmc_rrr_cache(rrrmc_ctx *ctx, int8_t *pos_out, int32_t *sizes_out);
 
 /* Timing of the last sampling call measured with HIP events on the ctx's stream:
  *   total_ms   first planner launch -> last sweep kernel end

@@ -75,6 +75,11 @@ def lib():
         L.orc_standard_mc_skn.restype = C.c_int64
         L.orc_standard_mc_skn.argtypes = [C.c_int64, f64p, C.c_double, C.c_int64, C.c_int64, C.c_uint64, C.c_uint64, C.c_uint32,
                                           u64p, f64p, C.POINTER(C.c_int64), C.c_void_p]
+        L.orc_rrr_mc_quant.restype = C.c_int64
+        L.orc_rrr_mc_quant.argtypes = [C.c_int64, C.c_int64, C.c_int64, i32p, i32p, C.c_double, C.c_double, C.c_int64, C.c_int64,
+                                       C.c_double, C.c_double, C.c_uint64, C.c_uint64, C.c_uint32, u64p, f64p, i64p, C.c_void_p]
+        L.orc_quant_energy.restype = C.c_double
+        L.orc_quant_energy.argtypes = [C.c_int64, C.c_int64, C.c_int64, i32p, i32p, C.c_double, u64p, C.POINTER(C.c_double)]
         L.orc_all_delta_e_pm1.restype = C.c_int64
         L.orc_all_delta_e_pm1.argtypes = [C.c_int64, i64p]
         _lib = L
@@ -228,3 +233,35 @@ def standard_mc_skn_batch(J, beta, iters, step, seed, chunks, it0=0, replica0=0)
     outs = [standard_mc_skn(J, beta, iters, step, seed, chunks[r], it0=it0, replica=replica0 + r) for r in range(len(chunks))]
     return (np.stack([o[0] for o in outs]), np.stack([o[1] for o in outs]), np.array([o[2] for o in outs], np.int64),
             np.stack([o[3] for o in outs]))
+
+
+# ---- GraphQuant (Suzuki-Trotter slices of a GraphRRG disorder) under rrrMC ------------------------------
+def quant_fourK(beta, Gamma, M):
+    """fourK = round(2/beta * log(coth(beta*Gamma/M)), digits=8): src/graphs/QT.jl:165"""
+    import math
+    x = beta * Gamma / M
+    return round(2.0 / beta * math.log(1.0 / math.tanh(x)), 8)
+
+
+def quant_energy(A, J, M, fourK, chunks):
+    Nk, K = A.shape
+    qt = C.c_double(0)
+    E = lib().orc_quant_energy(Nk, M, K, A, J, fourK, np.ascontiguousarray(chunks), C.byref(qt))
+    return float(E), float(qt.value)
+
+
+def rrr_mc_quant(A, J, M, fourK, beta, iters, step, seed, chunks, it0=0, replica=0, staged_thr=0.5, staged_thr_fact=5.0,
+                 want_cache=False):
+    """One chain of rrrMC on GraphQuant.  Returns (Es, chunks_out, accepted, staged_its[, pos, set_sizes])."""
+    Nk, K = A.shape
+    N = Nk * M
+    ch = np.array(chunks, np.uint64, copy=True)
+    Es = np.zeros(max(iters // step, 1), np.float64)
+    stats = np.zeros(2, np.int64)
+    cache = np.zeros(N + 4, np.int32)
+    n = lib().orc_rrr_mc_quant(Nk, M, K, A, J, fourK, beta, iters, step, staged_thr, staged_thr_fact, seed, it0, replica, ch, Es,
+                               stats, cache.ctypes.data if want_cache else None)
+    if n < 0:
+        raise AssertionError("DeltaECache / ArraySet consistency check failed")
+    out = (Es[:n], ch, int(stats[0]), int(stats[1]))
+    return out + (cache[:N].copy(), cache[N:].copy()) if want_cache else out

@@ -438,3 +438,372 @@ ORC_API int64_t orc_standard_mc_skn(int64_t N, const double *J, double beta, int
     free(X.lfields); free(X.lfields_last);
     return nsamp;
 }
+
+/* =============================================================================================
+ * Reduced-rejection-rate path: ArraySet, DeltaECache, GraphQT, GraphQuant, rrrMC(DoubleGraph)
+ * ============================================================================================= */
+
+/* RRR stream: the draws of replica r at global iteration g,
+ *   ctr = (lo32(g), hi32(g), r, TAG_RRR | sub << 8):
+ *   sub 0: words 0,1 -> class uniform (53 bit)  [rand() of rand_move, src/DeltaE.jl:148]
+ *          words 2,3 -> 64-bit word for the member index floor(u64 * t / 2^64)  [rand(1:t), src/ArraySets.jl:83]
+ *   sub 1: words 0,1 -> acceptance uniform (53 bit)  [rand() of accept(c, x), src/RRRMC.jl:43] */
+static void rrr_draw(uint64_t seed, uint64_t g, uint32_t replica, uint32_t sub, uint32_t w[4])
+{
+    orc_draw(seed, (uint32_t)g, (uint32_t)(g >> 32), replica, (uint32_t)ORC_TAG_RRR | (sub << 8), w);
+}
+static inline double u53_of(uint32_t hi, uint32_t lo) { return (double)((((uint64_t)hi << 32) | lo) >> 11) * 0x1.0p-53; }
+
+/* ---- ArraySet: src/ArraySets.jl:19-85 (0-based elements; pos stores index + 1, 0 = absent) ---- */
+typedef struct { int64_t N; int32_t *v, *pos; int64_t t; } aset_t;
+static void aset_init(aset_t *a, int64_t N) { a->N = N; a->v = (int32_t *)calloc((size_t)N, 4); a->pos = (int32_t *)calloc((size_t)N, 4); a->t = 0; }
+static void aset_free(aset_t *a) { free(a->v); free(a->pos); }
+static void aset_push(aset_t *a, int32_t i) { a->v[a->t] = i; a->t += 1; a->pos[i] = (int32_t)a->t; }             /* :56-65 */
+static void aset_delete(aset_t *a, int32_t i)                                                                     /* :66-76 */
+{
+    int32_t p = a->pos[i];
+    a->v[p - 1] = a->v[a->t - 1];
+    a->pos[a->v[p - 1]] = p;
+    a->pos[i] = 0;
+    a->t -= 1;
+}
+
+/* ---- the inner DiscrGraph as seen by the cache: GraphQT (src/graphs/QT.jl:42-122) ---- */
+typedef struct { int64_t N, M, Nk; double fourK; } qt_t;
+static inline void qt_neighbors(const qt_t *X, int64_t i, int64_t *j1, int64_t *j2)      /* QT.jl:105-108 (0-based) */
+{
+    *j1 = i - X->Nk + (i < X->Nk ? X->N : 0);
+    *j2 = i + X->Nk - (i + X->Nk >= X->N ? X->N : 0);
+}
+static inline double qt_delta_energy(const qt_t *X, const uint64_t *s, int64_t i)        /* QT.jl:86-103 */
+{
+    int64_t k1, k2;
+    qt_neighbors(X, i, &k1, &k2);
+    int sk = spin_bit(s, i), s1 = spin_bit(s, k1), s2 = spin_bit(s, k2);
+    int d = (sk == s1) - (sk != s2);                   /* (sk xor ~s1) - (sk xor s2) */
+    return (double)d * X->fourK;
+}
+static int64_t qt_energy0(const qt_t *X, const uint64_t *s)                              /* QT.jl:68-82 */
+{
+    int64_t n = 0;
+    for (int64_t i = 0; i < X->Nk; ++i) {
+        int sj = spin_bit(s, i + (X->M - 1) * X->Nk);
+        for (int64_t k = 0; k < X->M; ++k) {
+            int sk = spin_bit(s, i + k * X->Nk);
+            n -= 1 - 2 * (sk ^ sj);
+            sj = sk;
+        }
+    }
+    return n;
+}
+static inline double qt_energy(const qt_t *X, const uint64_t *s) { return (double)qt_energy0(X, s) * X->fourK / 4; }   /* QT.jl:84 */
+
+/* ---- DeltaECache{Float64, L = 2} over GraphQT: src/DeltaE.jl:63-295 (classes 0-based: k = a + L*up) ---- */
+enum { QL = 2 };
+typedef struct {
+    int64_t N;
+    double dElist[QL], ft[QL], T[2 * QL], Tp[2 * QL], z, zp;
+    aset_t as[2 * QL];
+    int8_t *pos;
+    int64_t staged[3][3];
+    int nstaged;
+} dec_t;
+
+static inline int dec_findk(const dec_t *c, double dE)           /* findk: DeltaE.jl:28-60 (exact comparison of |dE|) */
+{
+    double a = fabs(dE);
+    for (int k = 0; k < QL; ++k) if (a == c->dElist[k]) return k;
+    return -1;
+}
+static inline double dec_class_f(const dec_t *c, int k) { return k >= QL ? c->ft[k - QL] : 1.0; }     /* get_class_f: :139 */
+static inline int dec_class_of(const dec_t *c, double dE, int sbit)                                 /* :80-86, :214-216 */
+{
+    int a = dec_findk(c, dE);
+    int up = dE > 0 || (dE == 0 && sbit == 1);
+    return a + QL * up;
+}
+
+static void dec_init(dec_t *c, const qt_t *X0, const uint64_t *s, double beta)                      /* DeltaE.jl:74-103 */
+{
+    c->N = X0->N;
+    c->dElist[0] = 0.0; c->dElist[1] = X0->fourK;                /* allΔE(GraphQT) = (0.0, fourK): QT.jl:111 */
+    for (int k = 0; k < 2 * QL; ++k) aset_init(&c->as[k], c->N);
+    c->pos = (int8_t *)calloc((size_t)c->N, 1);
+    for (int64_t i = 0; i < c->N; ++i) {
+        int k = dec_class_of(c, qt_delta_energy(X0, s, i), spin_bit(s, i));
+        c->pos[i] = (int8_t)k;
+        aset_push(&c->as[k], (int32_t)i);
+    }
+    for (int k = 0; k < QL; ++k) c->ft[k] = orc_det_exp(-beta * c->dElist[k]);      /* exp(-beta dE): :91 (shared deterministic exp) */
+    c->z = 0.0;
+    for (int k = 0; k < 2 * QL; ++k) {
+        double x = (double)c->as[k].t * dec_class_f(c, k);
+        c->z += x;
+        c->T[k] = x;
+    }
+    c->zp = c->z;
+    c->nstaged = 0;
+}
+static void dec_free(dec_t *c) { for (int k = 0; k < 2 * QL; ++k) aset_free(&c->as[k]); free(c->pos); }
+
+/* rand_move: DeltaE.jl:146-167 */
+static int64_t dec_rand_move(const dec_t *c, uint64_t seed, uint64_t g, uint32_t replica, double *dE)
+{
+    uint32_t w[4];
+    rrr_draw(seed, g, replica, 0, w);
+    double r = u53_of(w[0], w[1]) * c->z;
+    int k = 0;
+    double cT = 0.0;
+    for (k = 0; k < 2 * QL; ++k) {
+        cT += c->T[k];
+        if (r < cT) break;
+    }
+    if (k == 2 * QL) k = 2 * QL - 1;                 /* `for outer k` leaves k at the last value */
+    if (!(r < cT)) while (c->T[k] == 0) k -= 1;      /* :155-157 */
+    *dE = k < QL ? -c->dElist[k] : c->dElist[k - QL];
+    uint64_t u = ((uint64_t)w[2] << 32) | w[3];
+    int64_t idx = (int64_t)orc_mulhi64(u, (uint64_t)c->as[k].t);        /* rand(1:t) - 1 */
+    return c->as[k].v[idx];
+}
+
+/* compute_staged!: DeltaE.jl:202-230 on X0 = GraphQT (no cache: spinflip! only flips the bit) */
+static void dec_compute_staged(dec_t *c, const qt_t *X0, uint64_t *s, int64_t i)
+{
+    bitflip(s, i);
+    c->nstaged = 0;
+    int64_t nb[2];
+    qt_neighbors(X0, i, &nb[0], &nb[1]);
+    for (int q = 0; q < 2; ++q) {
+        int64_t j = nb[q];
+        int k0 = c->pos[j];
+        int k1 = dec_class_of(c, qt_delta_energy(X0, s, j), spin_bit(s, j));
+        if (k0 == k1) continue;
+        c->staged[c->nstaged][0] = j; c->staged[c->nstaged][1] = k0; c->staged[c->nstaged][2] = k1; c->nstaged++;
+    }
+    int k0 = c->pos[i];
+    int k1 = k0 >= QL ? k0 - QL : k0 + QL;           /* k1 = k0 - L(2(k0 > L) - 1) */
+    c->staged[c->nstaged][0] = i; c->staged[c->nstaged][1] = k0; c->staged[c->nstaged][2] = k1; c->nstaged++;
+    bitflip(s, i);
+}
+
+/* compute_reverse_probabilities!: DeltaE.jl:184-200 */
+static double dec_reverse(dec_t *c)
+{
+    double zp = c->z;
+    memcpy(c->Tp, c->T, sizeof c->T);
+    for (int q = 0; q < c->nstaged; ++q) {
+        int k0 = (int)c->staged[q][1], k1 = (int)c->staged[q][2];
+        double f0 = dec_class_f(c, k0), f1 = dec_class_f(c, k1);
+        c->Tp[k0] -= f0;
+        c->Tp[k1] += f1;
+        zp += f1 - f0;
+    }
+    c->zp = zp;
+    return zp;
+}
+
+/* apply_staged!: DeltaE.jl:169-182 */
+static void dec_apply_staged(dec_t *c)
+{
+    for (int q = 0; q < c->nstaged; ++q) {
+        int32_t j = (int32_t)c->staged[q][0];
+        int k0 = (int)c->staged[q][1], k1 = (int)c->staged[q][2];
+        aset_delete(&c->as[k0], j);
+        aset_push(&c->as[k1], j);
+        c->pos[j] = (int8_t)k1;
+    }
+    double tmp[2 * QL];
+    memcpy(tmp, c->T, sizeof tmp); memcpy(c->T, c->Tp, sizeof tmp); memcpy(c->Tp, tmp, sizeof tmp);     /* T, T' = T', T */
+    c->z = c->zp;
+}
+
+/* ---- GraphQuant over M slices of one GraphRRG disorder (A, J): src/graphs/QT.jl:126-321, src/QAliases.jl:43-67 ---- */
+typedef struct {
+    qt_t X0;
+    int64_t Nk, M, K;
+    sparse_t *X1;            /* M slice graphs sharing A, J; each with its own LocalFields */
+    uint64_t **C1;           /* M slice configurations (copies of the slice bits) */
+} quant_t;
+
+static void quant_init(quant_t *Q, int64_t Nk, int64_t M, int64_t K, const int32_t *A, const int32_t *J, double fourK)
+{
+    Q->X0.N = Nk * M; Q->X0.M = M; Q->X0.Nk = Nk; Q->X0.fourK = fourK;
+    Q->Nk = Nk; Q->M = M; Q->K = K;
+    Q->X1 = (sparse_t *)calloc((size_t)M, sizeof(sparse_t));
+    Q->C1 = (uint64_t **)calloc((size_t)M, sizeof(uint64_t *));
+    for (int64_t k = 0; k < M; ++k) {
+        sparse_t X = {Nk, K, A, J, NULL, NULL, -1, 0};
+        X.lfields = (int64_t *)calloc((size_t)Nk, 8);
+        X.lfields_last = (int64_t *)calloc((size_t)Nk, 8);
+        Q->X1[k] = X;
+        Q->C1[k] = (uint64_t *)calloc((size_t)((Nk + 63) / 64), 8);
+    }
+}
+static void quant_free(quant_t *Q)
+{
+    for (int64_t k = 0; k < Q->M; ++k) { free(Q->X1[k].lfields); free(Q->X1[k].lfields_last); free(Q->C1[k]); }
+    free(Q->X1); free(Q->C1);
+}
+/* energy: QT.jl:185-199 — copies the slice bits into C1[k] and (re)builds every slice cache */
+static double quant_energy(quant_t *Q, const uint64_t *s)
+{
+    double E = qt_energy(&Q->X0, s);
+    for (int64_t k = 0; k < Q->M; ++k) {
+        memset(Q->C1[k], 0, (size_t)((Q->Nk + 63) / 64) * 8);
+        for (int64_t i = 0; i < Q->Nk; ++i)
+            if (spin_bit(s, k * Q->Nk + i)) Q->C1[k][i >> 6] |= 1ull << (i & 63);
+        E += (double)sparse_energy(&Q->X1[k], Q->C1[k]) / (double)Q->M;
+    }
+    return E;
+}
+/* delta_energy_residual: QT.jl:270-281 */
+static inline double quant_residual(const quant_t *Q, int64_t move)
+{
+    int64_t k = move / Q->Nk, i = move % Q->Nk;
+    return (double)sparse_delta_energy(&Q->X1[k], i) / (double)Q->M;
+}
+/* spinflip!(X::GraphQuant, C, move): Interface.jl:89-92 + update_cache! QT.jl:172-183 */
+static void quant_spinflip(quant_t *Q, uint64_t *s, int64_t move)
+{
+    bitflip(s, move);
+    int64_t k = move / Q->Nk, i = move % Q->Nk;
+    bitflip(Q->C1[k], i);
+    sparse_update_cache(&Q->X1[k], Q->C1[k], i);
+}
+
+/* apply_move!: DeltaE.jl:232-295 with X = GraphQuant, X0 = inner_graph(X) = GraphQT */
+static double dec_apply_move(dec_t *c, quant_t *Q, uint64_t *s, int64_t move)
+{
+    quant_spinflip(Q, s, move);
+    const qt_t *X0 = &Q->X0;
+    double zp = c->z;
+    int64_t nb[2];
+    qt_neighbors(X0, move, &nb[0], &nb[1]);
+    for (int q = 0; q < 2; ++q) {
+        int32_t j = (int32_t)nb[q];
+        int k0 = c->pos[j];
+        int k1 = dec_class_of(c, qt_delta_energy(X0, s, j), spin_bit(s, j));
+        if (k0 == k1) continue;
+        double f0 = dec_class_f(c, k0), f1 = dec_class_f(c, k1);
+        c->T[k0] -= f0;
+        c->T[k1] += f1;
+        zp += f1 - f0;
+        aset_delete(&c->as[k0], j);
+        aset_push(&c->as[k1], j);
+        c->pos[j] = (int8_t)k1;
+    }
+    int k0 = c->pos[move];
+    int k1 = k0 >= QL ? k0 - QL : k0 + QL;
+    double f0 = dec_class_f(c, k0), f1 = dec_class_f(c, k1);
+    c->T[k0] -= f0;
+    c->T[k1] += f1;
+    zp += f1 - f0;
+    aset_delete(&c->as[k0], (int32_t)move);
+    aset_push(&c->as[k1], (int32_t)move);
+    c->pos[move] = (int8_t)k1;
+    double cc = c->z / zp;
+    c->z = zp;
+    return cc;
+}
+
+/* accept(c, x): src/RRRMC.jl:40-44 */
+static int accept_cx(double c, double x, uint64_t seed, uint64_t g, uint32_t replica)
+{
+    if (c >= 1 && x >= 0) return 1;
+    double a = c * orc_det_exp(x);
+    if (a >= 1) return 1;
+    uint32_t w[4];
+    rrr_draw(seed, g, replica, 1, w);
+    return u53_of(w[0], w[1]) < a;
+}
+
+/*
+ * rrrMC(X::DoubleGraph, beta, iters; step, staged_thr, staged_thr_fact): src/RRRMC.jl:221-290, X = GraphQuant over
+ * M slices of GraphRRG{Int,(-1,1),K}(A, J) with Nk spins each.  One chain.
+ *   chunks  in/out  the N = Nk*M spins, slice-major (slice k holds bits k*Nk .. (k+1)*Nk-1)
+ *   Es      out     energies sampled before the move of iteration k*step
+ *   stats   out     [accepted, staged_its]; cache_out (optional): pos[N] then the four set sizes
+ */
+ORC_API int64_t orc_rrr_mc_quant(int64_t Nk, int64_t M, int64_t K, const int32_t *A, const int32_t *J, double fourK,
+                                 double beta, int64_t iters, int64_t step, double staged_thr, double staged_thr_fact,
+                                 uint64_t seed, uint64_t it0, uint32_t replica,
+                                 uint64_t *chunks, double *Es, int64_t *stats, int32_t *cache_out)
+{
+    quant_t Q;
+    quant_init(&Q, Nk, M, K, A, J, fourK);
+    const int64_t N = Nk * M;
+    double E = quant_energy(&Q, chunks);                                    /* :237 */
+    dec_t cache;
+    dec_init(&cache, &Q.X0, chunks, beta);                                  /* :239-240 */
+    const double lambda = staged_thr_fact / (double)N;                      /* :243 */
+    int64_t staged_its = 0, accepted = 0, nsamp = 0;
+    double acc_rate = 0.5;
+    for (int64_t it = 1; it <= iters; ++it) {                               /* :249-282 */
+        if (it % step == 0) Es[nsamp++] = E;
+        const uint64_t g = it0 + (uint64_t)it;
+        int acc = 0;
+        if (acc_rate < staged_thr) {
+            staged_its += 1;
+            double z = cache.z, dE0;
+            int64_t move = dec_rand_move(&cache, seed, g, replica, &dE0);   /* step_rrr: :131-138 */
+            dec_compute_staged(&cache, &Q.X0, chunks, move);
+            double zp = dec_reverse(&cache);
+            double c = z / zp;
+            double dE1 = quant_residual(&Q, move);
+            if (accept_cx(c, -beta * dE1, seed, g, replica)) {
+                quant_spinflip(&Q, chunks, move);
+                dec_apply_staged(&cache);
+                E += dE0 + dE1;
+                accepted += 1;
+                acc = 1;
+            }
+        } else {
+            double dE0;
+            int64_t move = dec_rand_move(&cache, seed, g, replica, &dE0);
+            double dE1 = quant_residual(&Q, move);
+            double c = dec_apply_move(&cache, &Q, chunks, move);
+            if (accept_cx(c, -beta * dE1, seed, g, replica)) {
+                E += dE0 + dE1;
+                accepted += 1;
+                acc = 1;
+            } else {
+                dec_apply_move(&cache, &Q, chunks, move);
+            }
+        }
+        acc_rate = acc_rate * (1 - lambda) + (double)acc * lambda;          /* :281 */
+    }
+    if (stats) { stats[0] = accepted; stats[1] = staged_its; }
+    if (cache_out) {
+        for (int64_t i = 0; i < N; ++i) cache_out[i] = cache.pos[i];
+        for (int k = 0; k < 2 * QL; ++k) cache_out[N + k] = (int32_t)cache.as[k].t;
+    }
+    /* check_consistency(ΔEcache): DeltaE.jl:120-136, ArraySets.jl:27-42 — returns -1 on violation */
+    int64_t bad = 0, total = 0;
+    for (int k = 0; k < 2 * QL; ++k) {
+        total += cache.as[k].t;
+        for (int64_t p = 0; p < cache.as[k].t; ++p) {
+            int32_t x = cache.as[k].v[p];
+            if (cache.as[k].pos[x] != p + 1 || cache.pos[x] != k) bad = 1;
+        }
+    }
+    for (int64_t i = 0; i < N; ++i) {
+        int k = dec_class_of(&cache, qt_delta_energy(&Q.X0, chunks, i), spin_bit(chunks, i));
+        if (k != cache.pos[i]) bad = 1;
+    }
+    if (total != N) bad = 1;
+    dec_free(&cache);
+    quant_free(&Q);
+    return bad ? -1 : nsamp;
+}
+
+/* energy(X::GraphQuant, C) and its parts, for the tests */
+ORC_API double orc_quant_energy(int64_t Nk, int64_t M, int64_t K, const int32_t *A, const int32_t *J, double fourK,
+                                const uint64_t *chunks, double *qt_part)
+{
+    quant_t Q;
+    quant_init(&Q, Nk, M, K, A, J, fourK);
+    double E = quant_energy(&Q, chunks);
+    if (qt_part) *qt_part = qt_energy(&Q.X0, chunks);
+    quant_free(&Q);
+    return E;
+}

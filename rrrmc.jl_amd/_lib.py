@@ -22,6 +22,7 @@ SYMBOLS = [
     "rrrmc_fetch_results", "rrrmc_last_timing", "rrrmc_iterations_done", "rrrmc_gen_rrg", "rrrmc_gen_ea",
     "rrrmc_gen_couplings_pm1", "rrrmc_set_couplings_dense", "rrrmc_energy_f64", "rrrmc_get_fields_f64",
     "rrrmc_standard_mc_f64", "rrrmc_fetch_results_f64", "rrrmc_gen_sk_gauss",
+    "rrrmc_ctx_create_quant", "rrrmc_quant_set_field", "rrrmc_rrr_mc_async", "rrrmc_rrr_stats", "rrrmc_rrr_cache",
 ]
 
 
@@ -95,6 +96,16 @@ def lib():
     L.rrrmc_fetch_results_f64.argtypes = [vp, vp, vp]
     L.rrrmc_gen_sk_gauss.restype = C.c_int32
     L.rrrmc_gen_sk_gauss.argtypes = [C.c_int64, C.c_uint64, f64p]
+    L.rrrmc_ctx_create_quant.restype = C.c_int32
+    L.rrrmc_ctx_create_quant.argtypes = [C.POINTER(vp), C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int32, C.c_uint32]
+    L.rrrmc_quant_set_field.restype = C.c_int32
+    L.rrrmc_quant_set_field.argtypes = [vp, C.c_double, C.c_double]
+    L.rrrmc_rrr_mc_async.restype = C.c_int32
+    L.rrrmc_rrr_mc_async.argtypes = [vp, C.c_double, C.c_double, C.c_int64, C.c_int64, C.c_double, C.c_double]
+    L.rrrmc_rrr_stats.restype = C.c_int32
+    L.rrrmc_rrr_stats.argtypes = [vp, i64p]
+    L.rrrmc_rrr_cache.restype = C.c_int32
+    L.rrrmc_rrr_cache.argtypes = [vp, vp, vp]
     _lib = L
     return L
 

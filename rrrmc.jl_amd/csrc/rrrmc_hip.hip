@@ -13,6 +13,7 @@
 #include <vector>
 
 #include "sk_kernels.hpp"
+#include "rrr_kernels.hpp"
 #include "sparse_kernels.hpp"
 
 using namespace rrrmc;
@@ -85,6 +86,18 @@ struct rrrmc_ctx {
     double* sk_Es = nullptr;
     size_t sk_Es_cap = 0;
     int64_t G8 = 0;
+    // ---- RRRMC_MODEL_QUANT_RRG ----
+    int64_t qM = 0, qNk = 0, qW = 0;      // Trotter slices, spins per slice, 32-bit words per replica
+    uint32_t* q_spins = nullptr;
+    uint8_t* q_cls = nullptr;
+    uint16_t* q_sv = nullptr;
+    uint16_t* q_spos = nullptr;
+    int32_t* q_st = nullptr;
+    double* q_T = nullptr;
+    double* q_z = nullptr;
+    double* q_accrate = nullptr;
+    int64_t* q_stats = nullptr;
+    double last_fourK = 0.0, last_beta = 0.0;
 
     std::string err;
 };
@@ -308,9 +321,55 @@ int32_t sk_standard_mc_async(rrrmc_ctx* ctx, double beta, int64_t iters, int64_t
     return RRRMC_OK;
 }
 
+
+// ---- GraphQuant / rrrMC host side -----------------------------------------------------------------------------------
+RrrParams quant_params(rrrmc_ctx* ctx, double beta, double fourK)
+{
+    RrrParams P{};
+    P.A = ctx->d_A; P.J = ctx->d_J;
+    P.spins = ctx->q_spins; P.cls = ctx->q_cls; P.sv = ctx->q_sv; P.spos = ctx->q_spos; P.st = ctx->q_st;
+    P.T = ctx->q_T; P.zz = ctx->q_z; P.E_cur = ctx->sk_E; P.acc_rate = ctx->q_accrate; P.stats = ctx->q_stats; P.Es = ctx->sk_Es;
+    P.beta = beta; P.fourK = fourK;
+    P.ft1 = 0.0;
+    P.k0 = (uint32_t)ctx->seed; P.k1 = (uint32_t)(ctx->seed >> 32); P.replica0 = ctx->replica0;
+    P.Nk = (int)ctx->qNk; P.M = (int)ctx->qM; P.K = (int)ctx->K; P.N = (int)ctx->N; P.W = (int)ctx->qW; P.R = (int)ctx->R;
+    return P;
+}
+
+// deterministic exp on the host: the same operation sequence as det_exp on the device / orc_det_exp in the oracle
+double host_det_exp(double x)
+{
+    static const double LOG2E = 1.44269504088896338700e+00;
+    static const double LN2_HI = 6.93147180369123816490e-01, LN2_LO = 1.90821492927058770002e-10;
+    static const double c[14] = {1.0, 1.0, 0.5, 1.0 / 6, 1.0 / 24, 1.0 / 120, 1.0 / 720, 1.0 / 5040, 1.0 / 40320, 1.0 / 362880,
+                                 1.0 / 3628800, 1.0 / 39916800, 1.0 / 479001600, 1.0 / 6227020800.0};
+    if (x != x) return x;
+    if (x < -745.2) return 0.0;
+    if (x > 709.7) return HUGE_VAL;
+    volatile double t0 = x * LOG2E;
+    const double k = std::floor(t0 + 0.5);
+    volatile double a = k * LN2_HI, b = k * LN2_LO;
+    volatile double r0 = x - a;
+    const double r = r0 - b;
+    double p = c[13];
+    for (int n = 12; n >= 0; --n) { volatile double m = p * r; p = m + c[n]; }
+    return std::ldexp(p, (int)k);
+}
+
+// energy(X, C) + gen_ΔEcache (RRRMC.jl:237-240): E into sk_E, cache arrays rebuilt
+int32_t quant_run_init(rrrmc_ctx* ctx, double beta, double fourK)
+{
+    RrrParams P = quant_params(ctx, beta, fourK);
+    P.ft1 = host_det_exp(-beta * fourK);
+    hipLaunchKernelGGL(rrr_init_kernel, dim3((unsigned)((ctx->R + kRrrThreads - 1) / kRrrThreads)), dim3(kRrrThreads), 0, ctx->stream, P);
+    HIP_TRY(ctx, hipGetLastError());
+    return RRRMC_OK;
+}
+
 }  // namespace
 
 extern "C" {
+
 
 
 int32_t rrrmc_version(void) { return 100; }
@@ -402,6 +461,8 @@ void rrrmc_ctx_destroy(rrrmc_ctx* ctx)
     free_dev(ctx->d_E); free_dev(ctx->d_acc); free_dev(ctx->d_chunks); free_dev(ctx->d_Es);
     free_dev(ctx->sk_J); free_dev(ctx->sk_lf); free_dev(ctx->sk_lfl); free_dev(ctx->sk_move_last); free_dev(ctx->sk_spins);
     free_dev(ctx->sk_E); free_dev(ctx->sk_Es);
+    free_dev(ctx->q_spins); free_dev(ctx->q_cls); free_dev(ctx->q_sv); free_dev(ctx->q_spos); free_dev(ctx->q_st);
+    free_dev(ctx->q_T); free_dev(ctx->q_z); free_dev(ctx->q_accrate); free_dev(ctx->q_stats);
     for (int i = 0; i < 2; ++i) { free_dev(ctx->d_slots[i]); free_dev(ctx->d_vecs[i]); }
     if (ctx->plan_stream) { (void)hipStreamSynchronize(ctx->plan_stream); (void)hipStreamDestroy(ctx->plan_stream); }
     if (ctx->ev_upload) (void)hipEventDestroy(ctx->ev_upload);
@@ -417,9 +478,10 @@ void rrrmc_ctx_destroy(rrrmc_ctx* ctx)
 int32_t rrrmc_set_graph(rrrmc_ctx* ctx, const int32_t* A, const int8_t* J)
 {
     if (!ctx) return RRRMC_ERR_INVALID_ARG;
-    if (ctx->model != RRRMC_MODEL_SPARSE_PM1) return fail(ctx, RRRMC_ERR_STATE, "rrrmc_set_graph is for sparse +-J models; use rrrmc_set_couplings_dense");
+    if (ctx->model != RRRMC_MODEL_SPARSE_PM1 && ctx->model != RRRMC_MODEL_QUANT_RRG)
+        return fail(ctx, RRRMC_ERR_STATE, "rrrmc_set_graph is for sparse +-J models; use rrrmc_set_couplings_dense");
     if (!A || !J) return fail(ctx, RRRMC_ERR_INVALID_ARG, "A and J must not be NULL");
-    const int64_t N = ctx->N, K = ctx->K;
+    const int64_t N = ctx->model == RRRMC_MODEL_QUANT_RRG ? ctx->qNk : ctx->N, K = ctx->K;
     for (int64_t q = 0; q < N * K; ++q) {
         if (A[q] < 0 || A[q] >= N) return fail(ctx, RRRMC_ERR_INVALID_ARG, "A[%lld] = %d out of range 0..%lld", (long long)q, A[q], (long long)(N - 1));
         if (J[q] != 1 && J[q] != -1)    // GraphRRG ctor: "the given J is incompatible with levels" RRG.jl:130
@@ -436,6 +498,14 @@ int32_t rrrmc_set_graph(rrrmc_ctx* ctx, const int32_t* A, const int8_t* J)
                 if (!used[y * K + l] && A[y * K + l] == x && J[y * K + l] == J[x * K + k]) { used[y * K + l] = 1; found = true; }
             if (!found) return fail(ctx, RRRMC_ERR_INVALID_ARG, "bond (%lld,%lld) is not symmetric in (A, J)", (long long)x, (long long)y);
         }
+    if (ctx->model == RRRMC_MODEL_QUANT_RRG) {
+        HIP_TRY(ctx, hipSetDevice(ctx->device));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        HIP_TRY(ctx, hipMemcpy(ctx->d_A, A, sizeof(int32_t) * N * K, hipMemcpyHostToDevice));
+        HIP_TRY(ctx, hipMemcpy(ctx->d_J, J, sizeof(int8_t) * N * K, hipMemcpyHostToDevice));
+        ctx->graph_set = true;
+        return RRRMC_OK;
+    }
     std::vector<uint16_t> table((size_t)(N * ctx->TS), 0);
     for (int64_t x = 0; x < N; ++x)
         for (int64_t k = 0; k < K; ++k)
@@ -464,6 +534,15 @@ int32_t rrrmc_init_spins_random(rrrmc_ctx* ctx)
 {
     if (!ctx) return RRRMC_ERR_INVALID_ARG;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (ctx->model == RRRMC_MODEL_QUANT_RRG) {
+        const dim3 grid((unsigned)((ctx->qW + 255) / 256), (unsigned)ctx->R);
+        hipLaunchKernelGGL(quant_init_spins_kernel, grid, dim3(256), 0, ctx->stream, ctx->q_spins, (int)ctx->N, (int)ctx->qW,
+                           ctx->replica0, (uint32_t)ctx->seed, (uint32_t)(ctx->seed >> 32));
+        HIP_TRY(ctx, hipGetLastError());
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        ctx->spins_set = true;
+        return RRRMC_OK;
+    }
     if (ctx->model == RRRMC_MODEL_SK_NORMAL) {
         const dim3 grid((unsigned)((ctx->N + 255) / 256), (unsigned)ctx->G8);
         hipLaunchKernelGGL(sk_init_spins_kernel, grid, dim3(256), 0, ctx->stream, ctx->sk_spins, (int)ctx->N, ctx->replica0,
@@ -492,6 +571,13 @@ int32_t rrrmc_set_spins(rrrmc_ctx* ctx, const uint64_t* chunks)
         for (int64_t r = 0; r < ctx->R; ++r)
             if (chunks[r * nch + nch - 1] & tailmask)
                 return fail(ctx, RRRMC_ERR_INVALID_ARG, "replica %lld: bits beyond N are set in the last chunk", (long long)r);
+    }
+    if (ctx->model == RRRMC_MODEL_QUANT_RRG) {     // chunk c of a replica = words 2c, 2c+1 (little endian): same bytes
+        HIP_TRY(ctx, hipSetDevice(ctx->device));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        HIP_TRY(ctx, hipMemcpy(ctx->q_spins, chunks, sizeof(uint64_t) * ctx->R * nch, hipMemcpyHostToDevice));
+        ctx->spins_set = true;
+        return RRRMC_OK;
     }
     if (ctx->model == RRRMC_MODEL_SK_NORMAL) {
         std::vector<uint8_t> b8((size_t)(ctx->G8 * N), 0);
@@ -525,6 +611,12 @@ int32_t rrrmc_get_spins(rrrmc_ctx* ctx, uint64_t* chunks)
     if (rc) return rc;
     if (!chunks) return fail(ctx, RRRMC_ERR_INVALID_ARG, "chunks is NULL");
     const int64_t N = ctx->N, nch = (N + 63) / 64;
+    if (ctx->model == RRRMC_MODEL_QUANT_RRG) {
+        HIP_TRY(ctx, hipSetDevice(ctx->device));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        HIP_TRY(ctx, hipMemcpy(chunks, ctx->q_spins, sizeof(uint64_t) * ctx->R * nch, hipMemcpyDeviceToHost));
+        return RRRMC_OK;
+    }
     if (ctx->model == RRRMC_MODEL_SK_NORMAL) {
         std::vector<uint8_t> b8((size_t)(ctx->G8 * N));
         HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -593,6 +685,7 @@ int32_t rrrmc_standard_mc_async(rrrmc_ctx* ctx, double beta, int64_t iters, int6
     int32_t rc = ensure_state(ctx, true);
     if (rc) return rc;
     if (ctx->model == RRRMC_MODEL_SK_NORMAL) return sk_standard_mc_async(ctx, beta, iters, step);
+    if (ctx->model != RRRMC_MODEL_SPARSE_PM1) return fail(ctx, RRRMC_ERR_UNSUPPORTED, "standardMC is not wired for this model on the device: use rrrmc_rrr_mc_async");
     if (iters < 0) return fail(ctx, RRRMC_ERR_INVALID_ARG, "iters must be >= 0, given %lld", (long long)iters);
     if (step < 1) return fail(ctx, RRRMC_ERR_INVALID_ARG, "step must be >= 1, given %lld", (long long)step);
     if (std::isnan(beta)) return fail(ctx, RRRMC_ERR_INVALID_ARG, "beta is NaN");
@@ -824,6 +917,138 @@ RRRMC_API int32_t rrrmc_debug_step_trace(rrrmc_ctx* ctx, unsigned long long* out
 }
 #endif
 
+// ---- GraphQuant + rrrMC: exported entry points ---------------------------------------------------------------------
+
+int32_t rrrmc_ctx_create_quant(rrrmc_ctx** out, int64_t Nk, int64_t K, int64_t M, int64_t R, int32_t device, uint32_t replica0)
+{
+    if (!out) return fail(nullptr, RRRMC_ERR_INVALID_ARG, "out is NULL");
+    *out = nullptr;
+    if (Nk < 1 || K < 1 || R < 1) return fail(nullptr, RRRMC_ERR_INVALID_ARG, "Nk, K, R must be >= 1");
+    if (M <= 2) return fail(nullptr, RRRMC_ERR_INVALID_ARG, "M must be greater than 2, given: %lld", (long long)M);   // QT.jl:47
+    if (Nk * M > 65535) return fail(nullptr, RRRMC_ERR_UNSUPPORTED, "N = Nk*M = %lld: the rrrMC kernel indexes spins with 16 bits", (long long)(Nk * M));
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(nullptr, RRRMC_ERR_HIP, "no HIP device is visible: this library has no CPU path");
+    if (device < 0 || device >= ndev) return fail(nullptr, RRRMC_ERR_INVALID_ARG, "device %d out of range (0..%d)", device, ndev - 1);
+    rrrmc_ctx* ctx = new (std::nothrow) rrrmc_ctx();
+    if (!ctx) return fail(nullptr, RRRMC_ERR_NOMEM, "out of host memory");
+    ctx->model = RRRMC_MODEL_QUANT_RRG; ctx->N = Nk * M; ctx->K = K; ctx->R = R; ctx->Rpad = R;
+    ctx->qNk = Nk; ctx->qM = M; ctx->qW = 2 * ((Nk * M + 63) / 64);
+    ctx->device = device; ctx->replica0 = replica0;
+    const int64_t N = ctx->N;
+#define Q_TRY(expr)                                                                                              \
+    do {                                                                                                         \
+        hipError_t e_ = (expr);                                                                                  \
+        if (e_ != hipSuccess) {                                                                                  \
+            int32_t rc_ = fail(nullptr, RRRMC_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_));           \
+            rrrmc_ctx_destroy(ctx);                                                                              \
+            return rc_;                                                                                          \
+        }                                                                                                        \
+    } while (0)
+    Q_TRY(hipSetDevice(device));
+    Q_TRY(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+    Q_TRY(hipEventCreate(&ctx->ev_begin));
+    Q_TRY(hipEventCreate(&ctx->ev_end));
+    Q_TRY(hipMalloc(&ctx->d_A, sizeof(int32_t) * Nk * K));
+    Q_TRY(hipMalloc(&ctx->d_J, sizeof(int8_t) * Nk * K));
+    Q_TRY(hipMalloc(&ctx->q_spins, sizeof(uint32_t) * R * ctx->qW));
+    Q_TRY(hipMalloc(&ctx->q_cls, (size_t)R * N));
+    Q_TRY(hipMalloc(&ctx->q_sv, sizeof(uint16_t) * R * 4 * N));
+    Q_TRY(hipMalloc(&ctx->q_spos, sizeof(uint16_t) * R * N));
+    Q_TRY(hipMalloc(&ctx->q_st, sizeof(int32_t) * R * 4));
+    Q_TRY(hipMalloc(&ctx->q_T, sizeof(double) * R * 4));
+    Q_TRY(hipMalloc(&ctx->q_z, sizeof(double) * R));
+    Q_TRY(hipMalloc(&ctx->q_accrate, sizeof(double) * R));
+    Q_TRY(hipMalloc(&ctx->q_stats, sizeof(int64_t) * R * 2));
+    Q_TRY(hipMalloc(&ctx->sk_E, sizeof(double) * R));
+    Q_TRY(hipMemset(ctx->q_spins, 0, sizeof(uint32_t) * R * ctx->qW));
+#undef Q_TRY
+    *out = ctx;
+    return RRRMC_OK;
+}
+
+int32_t rrrmc_rrr_mc_async(rrrmc_ctx* ctx, double beta, double fourK, int64_t iters, int64_t step, double staged_thr, double staged_thr_fact)
+{
+    int32_t rc = ensure_state(ctx, true);
+    if (rc) return rc;
+    if (ctx->model != RRRMC_MODEL_QUANT_RRG) return fail(ctx, RRRMC_ERR_UNSUPPORTED, "rrrMC is wired for RRRMC_MODEL_QUANT_RRG only");
+    if (!std::isfinite(beta)) return fail(ctx, RRRMC_ERR_INVALID_ARG, "beta must be finite, given: %g", beta);       // RRRMC.jl:230
+    if (!(fourK > 0.0) || !std::isfinite(fourK)) return fail(ctx, RRRMC_ERR_INVALID_ARG, "fourK must be positive and finite, given: %g", fourK);
+    if (iters < 0) return fail(ctx, RRRMC_ERR_INVALID_ARG, "iters must be >= 0, given %lld", (long long)iters);
+    if (step < 1) return fail(ctx, RRRMC_ERR_INVALID_ARG, "step must be >= 1, given %lld", (long long)step);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    ctx->results_valid = false;
+    ctx->timing_valid = false;
+    const int64_t nsamp = iters / step;
+    const size_t es_need = (size_t)(nsamp > 0 ? nsamp : 1) * ctx->R;
+    if (es_need > ctx->sk_Es_cap) {
+        free_dev(ctx->sk_Es);
+        ctx->sk_Es_cap = 0;
+        HIP_TRY(ctx, hipMalloc(&ctx->sk_Es, sizeof(double) * es_need));
+        ctx->sk_Es_cap = es_need;
+    }
+    while (ctx->ev_sweep.size() < 2) {
+        hipEvent_t e;
+        HIP_TRY(ctx, hipEventCreate(&e));
+        ctx->ev_sweep.push_back(e);
+    }
+    hipStream_t st = ctx->stream;
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_begin, st));
+    ctx->last_beta = beta; ctx->last_fourK = fourK;
+    rc = quant_run_init(ctx, beta, fourK);
+    if (rc) return rc;
+    RrrParams P = quant_params(ctx, beta, fourK);
+    P.ft1 = host_det_exp(-beta * fourK);
+    P.staged_thr = staged_thr;
+    P.lambda = staged_thr_fact / (double)ctx->N;              // RRRMC.jl:243
+    P.g0 = ctx->it_done; P.iters = iters; P.step = step;
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_sweep[0], st));
+    hipLaunchKernelGGL(rrr_quant_kernel, dim3((unsigned)((ctx->R + kRrrThreads - 1) / kRrrThreads)), dim3(kRrrThreads), 0, st, P);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_sweep[1], st));
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_end, st));
+    ctx->sweep_launches = 1;
+    ctx->nsamp = nsamp;
+    ctx->it_done += (uint64_t)iters;
+    ctx->results_valid = true;
+    ctx->timing_valid = true;
+    return RRRMC_OK;
+}
+
+int32_t rrrmc_quant_set_field(rrrmc_ctx* ctx, double beta, double fourK)
+{
+    if (!ctx) return RRRMC_ERR_INVALID_ARG;
+    if (ctx->model != RRRMC_MODEL_QUANT_RRG) return fail(ctx, RRRMC_ERR_STATE, "rrrmc_quant_set_field is for RRRMC_MODEL_QUANT_RRG");
+    if (!(fourK > 0.0) || !std::isfinite(fourK) || !std::isfinite(beta)) return fail(ctx, RRRMC_ERR_INVALID_ARG, "beta and fourK must be finite, fourK > 0");
+    ctx->last_beta = beta;
+    ctx->last_fourK = fourK;
+    return RRRMC_OK;
+}
+
+int32_t rrrmc_rrr_stats(rrrmc_ctx* ctx, int64_t* staged_iters_out)
+{
+    if (!ctx) return RRRMC_ERR_INVALID_ARG;
+    if (ctx->model != RRRMC_MODEL_QUANT_RRG || !ctx->results_valid) return fail(ctx, RRRMC_ERR_STATE, "no rrrMC call has been made");
+    if (!staged_iters_out) return fail(ctx, RRRMC_ERR_INVALID_ARG, "staged_iters_out is NULL");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    std::vector<int64_t> st((size_t)ctx->R * 2);
+    HIP_TRY(ctx, hipMemcpy(st.data(), ctx->q_stats, sizeof(int64_t) * st.size(), hipMemcpyDeviceToHost));
+    for (int64_t r = 0; r < ctx->R; ++r) staged_iters_out[r] = st[2 * r + 1];
+    return RRRMC_OK;
+}
+
+int32_t rrrmc_rrr_cache(rrrmc_ctx* ctx, int8_t* pos_out, int32_t* sizes_out)
+{
+    if (!ctx) return RRRMC_ERR_INVALID_ARG;
+    if (ctx->model != RRRMC_MODEL_QUANT_RRG || !ctx->results_valid) return fail(ctx, RRRMC_ERR_STATE, "no rrrMC call has been made");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (pos_out) HIP_TRY(ctx, hipMemcpy(pos_out, ctx->q_cls, (size_t)ctx->R * ctx->N, hipMemcpyDeviceToHost));
+    if (sizes_out) HIP_TRY(ctx, hipMemcpy(sizes_out, ctx->q_st, sizeof(int32_t) * ctx->R * 4, hipMemcpyDeviceToHost));
+    return RRRMC_OK;
+}
+
 // ---- Float64-energy models: exported entry points ---------------------------------------------------------------
 
 int32_t rrrmc_set_couplings_dense(rrrmc_ctx* ctx, const double* J)
@@ -849,10 +1074,15 @@ int32_t rrrmc_energy_f64(rrrmc_ctx* ctx, double* E_out)
 {
     int32_t rc = ensure_state(ctx, true);
     if (rc) return rc;
-    if (ctx->model != RRRMC_MODEL_SK_NORMAL) return fail(ctx, RRRMC_ERR_STATE, "this model's energies are integers: use rrrmc_energy");
+    if (ctx->model == RRRMC_MODEL_SPARSE_PM1) return fail(ctx, RRRMC_ERR_STATE, "this model's energies are integers: use rrrmc_energy");
     if (!E_out) return fail(ctx, RRRMC_ERR_INVALID_ARG, "E_out is NULL");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    rc = sk_run_energy(ctx);
+    if (ctx->model == RRRMC_MODEL_QUANT_RRG) {
+        if (!(ctx->last_fourK > 0.0)) return fail(ctx, RRRMC_ERR_STATE, "energy of a GraphQuant needs fourK: call rrrmc_quant_set_field first");
+        rc = quant_run_init(ctx, ctx->last_beta, ctx->last_fourK);
+    } else {
+        rc = sk_run_energy(ctx);
+    }
     if (rc) return rc;
     std::vector<double> E((size_t)ctx->Rpad);
     HIP_TRY(ctx, hipMemcpyAsync(E.data(), ctx->sk_E, sizeof(double) * ctx->Rpad, hipMemcpyDeviceToHost, ctx->stream));
@@ -880,11 +1110,15 @@ int32_t rrrmc_get_fields_f64(rrrmc_ctx* ctx, double* lfields_out)
 int32_t rrrmc_fetch_results_f64(rrrmc_ctx* ctx, double* Es_out, int64_t* accepted_out)
 {
     if (!ctx) return RRRMC_ERR_INVALID_ARG;
-    if (ctx->model != RRRMC_MODEL_SK_NORMAL) return fail(ctx, RRRMC_ERR_STATE, "this model's energies are integers: use rrrmc_fetch_results");
+    if (ctx->model == RRRMC_MODEL_SPARSE_PM1) return fail(ctx, RRRMC_ERR_STATE, "this model's energies are integers: use rrrmc_fetch_results");
     if (!ctx->results_valid) return fail(ctx, RRRMC_ERR_STATE, "no sampling call has been made");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    if (accepted_out) {
+    if (accepted_out && ctx->model == RRRMC_MODEL_QUANT_RRG) {
+        std::vector<int64_t> st((size_t)ctx->R * 2);
+        HIP_TRY(ctx, hipMemcpy(st.data(), ctx->q_stats, sizeof(int64_t) * st.size(), hipMemcpyDeviceToHost));
+        for (int64_t r = 0; r < ctx->R; ++r) accepted_out[r] = st[2 * r];
+    } else if (accepted_out) {
         std::vector<int64_t> acc((size_t)ctx->Rpad);
         HIP_TRY(ctx, hipMemcpy(acc.data(), ctx->d_acc, sizeof(int64_t) * ctx->Rpad, hipMemcpyDeviceToHost));
         for (int64_t r = 0; r < ctx->R; ++r) accepted_out[r] = acc[r];

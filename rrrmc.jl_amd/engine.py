@@ -8,6 +8,7 @@ from .graphs import DEFAULT_SEED, Config, nchunks
 
 MODEL_SPARSE_PM1 = 1
 MODEL_SK_NORMAL = 2
+MODEL_QUANT_RRG = 3
 
 
 class Engine:
@@ -16,10 +17,16 @@ class Engine:
     def __init__(self, X, R=1, device=0, replica0=0):
         self.X, self.R = X, int(R)
         self._ctx = C.c_void_p()
-        self._f64 = X.model_kind == MODEL_SK_NORMAL
-        check(lib().rrrmc_ctx_create(C.byref(self._ctx), X.model_kind, X.N, X.K, self.R, device, replica0))
+        self._f64 = X.model_kind != MODEL_SPARSE_PM1
+        if X.model_kind == MODEL_QUANT_RRG:
+            check(lib().rrrmc_ctx_create_quant(C.byref(self._ctx), X.Nk, X.K, X.M, self.R, device, replica0))
+        else:
+            check(lib().rrrmc_ctx_create(C.byref(self._ctx), X.model_kind, X.N, X.K, self.R, device, replica0))
         try:
-            if self._f64:
+            if X.model_kind == MODEL_QUANT_RRG:
+                check(lib().rrrmc_set_graph(self._ctx, X.A, X.J), self._ctx)
+                check(lib().rrrmc_quant_set_field(self._ctx, X.beta, X.fourK), self._ctx)
+            elif self._f64:
                 check(lib().rrrmc_set_couplings_dense(self._ctx, X.J.reshape(-1)), self._ctx)
             else:
                 check(lib().rrrmc_set_graph(self._ctx, X.A, X.J), self._ctx)
@@ -105,11 +112,63 @@ class Engine:
         check(fn(self._ctx, Es.ctypes.data if (want_energies and nsamp) else None, acc.ctypes.data), self._ctx)
         return Es, acc
 
+    # -- reduced-rejection-rate sampler (GraphQuant) ------------------------------------------------
+    def rrr_mc(self, beta, iters, step=1, staged_thr=0.5, staged_thr_fact=5.0, want_energies=True):
+        """rrrMC(X::DoubleGraph, β, iters; step, staged_thr, staged_thr_fact) (src/RRRMC.jl:221-290).
+        Returns (Es[R, iters // step], accepted[R], staged_iters[R])."""
+        check(lib().rrrmc_rrr_mc_async(self._ctx, float(beta), float(self.X.fourK), int(iters), int(step), float(staged_thr),
+                                       float(staged_thr_fact)), self._ctx)
+        self._last = (int(iters), int(step))
+        self.sync()
+        Es, acc = self.fetch_results(want_energies)
+        st = np.zeros(self.R, np.int64)
+        check(lib().rrrmc_rrr_stats(self._ctx, st), self._ctx)
+        return Es, acc, st
+
+    def rrr_cache(self):
+        """(pos[R, N], sizes[R, 4]) of the DeltaECache after the last rrrMC call."""
+        pos = np.zeros((self.R, self.X.N), np.int8)
+        sizes = np.zeros((self.R, 4), np.int32)
+        check(lib().rrrmc_rrr_cache(self._ctx, pos.ctypes.data, sizes.ctypes.data), self._ctx)
+        return pos, sizes
+
     def last_timing(self):
         """(total_ms, sweep_ms, sweep_launches) of the last sampling call, from HIP events on the ctx's stream."""
         t, s, n = C.c_double(0), C.c_double(0), C.c_int32(0)
         check(lib().rrrmc_last_timing(self._ctx, C.byref(t), C.byref(s), C.byref(n)), self._ctx)
         return t.value, s.value, n.value
+
+
+def rrrMC(X, beta, iters, *, seed=DEFAULT_SEED, step=1, C0=None, staged_thr=0.5, staged_thr_fact=5.0, quiet=False,
+          replicas=None, device=0, replica0=0, engine=None):
+    """``rrrMC(X::DoubleGraph, β, iters; seed, step, C0, staged_thr, staged_thr_fact, quiet)`` (src/RRRMC.jl:221-290) for a
+    batch of replicas of a ``GraphQuant``.  Returns ``(Es, C)`` like ``standardMC``."""
+    import math
+    if not math.isfinite(beta):
+        raise ValueError("β must be finite, given: %r" % beta)                     # RRRMC.jl:230
+    own = engine is None
+    R = replicas if replicas is not None else (C0.R if C0 is not None else (engine.R if engine else 1))
+    if C0 is not None and C0.N != X.N:
+        raise ValueError("Invalid C0, wrong N, expected %d, given: %d" % (X.N, C0.N))
+    eng = engine if engine is not None else Engine(X, R, device=device, replica0=replica0)
+    try:
+        if seed > 0 or own:
+            eng.seed(seed if seed > 0 else 0)
+        if C0 is not None:
+            eng.set_config(C0)
+        elif own:
+            eng.init_spins_random()
+        Es, acc, staged = eng.rrr_mc(beta, iters, step, staged_thr, staged_thr_fact)
+        Cfg = eng.get_config(C0 if C0 is not None else None)
+        if not quiet:
+            print("samples = ", Es.shape[1])
+            print("iters = ", iters)
+            print("accept rate = ", float(acc.mean()) / max(iters, 1))
+            print("frac. staged iters = ", float(staged.mean()) / max(iters, 1))
+        return Es, Cfg
+    finally:
+        if own:
+            eng.close()
 
 
 def standardMC(X, beta, iters, *, seed=DEFAULT_SEED, step=1, hook=None, C0=None, quiet=False,

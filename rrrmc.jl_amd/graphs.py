@@ -143,6 +143,30 @@ class GraphSKNormal:
         return self
 
 
+class GraphQuant:
+    """``GraphQuant(Nk, M, Γ, β, GraphRRG, Nk, K)`` — quantum Ising model in a transverse field Γ via the Suzuki-Trotter
+    transformation: M coupled copies ("slices") of a classical graph (src/graphs/QT.jl:126-170).
+
+    As the in-tree aliases do (src/QAliases.jl:43-67) the disorder is generated ONCE and shared by all slices:
+    ``GraphQuant(X1, M, Γ, β)`` with ``X1`` a ``GraphRRG``.  ``N = Nk * M`` spins, slice-major.  ``ET = Float64``.
+    """
+    model_kind = 3          # RRRMC_MODEL_QUANT_RRG
+    energy_dtype = np.float64
+
+    def __init__(self, X1, M, Gamma, beta):
+        import math
+        if M <= 2:
+            raise ValueError("M must be greater than 2, given: %d" % M)          # QT.jl:47
+        if Gamma < 0:
+            raise ValueError("Γ must be >= 0")                                   # QT.jl:164
+        self.X1, self.M, self.Gamma, self.beta = X1, int(M), float(Gamma), float(beta)
+        self.Nk, self.K = X1.N, X1.K
+        self.N = self.Nk * self.M
+        self.A, self.J = X1.A, X1.J
+        # fourK = round(2/β * log(coth(β Γ / M)), digits = MAXDIGITS): QT.jl:165
+        self.fourK = round(2.0 / beta * math.log(1.0 / math.tanh(beta * Gamma / M)), 8)
+
+
 def getN(X):
     """src/Interface.jl:145"""
     return X.N

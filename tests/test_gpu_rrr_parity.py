@@ -1,0 +1,57 @@
+"""GPU parity for rrrMC(X::DoubleGraph) on GraphQuant (src/RRRMC.jl:221-290, src/graphs/QT.jl, src/DeltaE.jl, src/ArraySets.jl).
+north_star tolerance for Float64 models is 1e-6 relative; the kernel keeps the reference's operation order and the
+deterministic exp, so we additionally require bit equality with the oracle."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("Nk,M,Gamma,beta,R,iters,step,thr", [
+    (10, 8, 0.5, 2.0, 8, 10000, 100, 0.5),     # test/runtests.jl:78 GraphQuant(10, 8, 0.5, 2.0, GraphRRG, 10, 3); default staged_thr
+    (10, 8, 0.5, 2.0, 8, 10000, 100, 0.0),     # runtests.jl:150 staged_thr = 0.0 (always direct)
+    (10, 8, 0.5, 2.0, 8, 10000, 100, 1.0),     # runtests.jl:155 staged_thr = 1.0 (always staged)
+    (64, 16, 0.3, 1.0, 70, 20000, 250, 0.5),   # more than one 64-thread block, R not a multiple of 64
+    (256, 32, 0.5, 2.0, 16, 30000, 1000, 0.5),
+    (1024, 32, 0.5, 2.0, 4, 20000, 4096, 0.5), # BASELINE config 5 geometry (Nk=1024, M=32 -> N=32768), few replicas
+])
+def test_rrr_quant_bit_exact(pkg, oracle, Nk, M, Gamma, beta, R, iters, step, thr):
+    seed = 8426732438942 + Nk
+    X1 = pkg.GraphRRG(Nk, 3, seed=seed)
+    X = pkg.GraphQuant(X1, M, Gamma, beta)
+    assert X.fourK == oracle.quant_fourK(beta, Gamma, M)
+    A, J = X1.A, X1.J.astype(np.int32)
+    with pkg.Engine(X, R) as eng:
+        eng.seed(seed)
+        eng.init_spins_random()
+        C0 = eng.get_config()
+        E0 = eng.energy()
+        Es, acc, staged = eng.rrr_mc(beta, iters, step, staged_thr=thr)
+        C1 = eng.get_config()
+        pos, sizes = eng.rrr_cache()
+        E1 = eng.energy()
+    assert (C0.s == oracle.init_configs(seed, 0, R, X.N)).all()
+    for r in range(R):
+        e0, _ = oracle.quant_energy(A, J, M, X.fourK, C0.s[r])
+        assert E0[r] == e0
+        Es_ref, ch_ref, acc_ref, st_ref, pos_ref, sizes_ref = oracle.rrr_mc_quant(A, J, M, X.fourK, beta, iters, step, seed, C0.s[r],
+                                                                                  replica=r, staged_thr=thr, want_cache=True)
+        assert np.allclose(Es[r], Es_ref, rtol=1e-6, atol=1e-9)          # north-star tolerance
+        assert (Es[r] == Es_ref).all()                                    # ... and bit for bit
+        assert (C1.s[r] == ch_ref).all() and acc[r] == acc_ref and staged[r] == st_ref
+        assert (pos[r] == pos_ref).all() and (sizes[r] == sizes_ref).all()
+        # the reference's invariant: tracked E ~ energy(X, C) (test/runtests.jl:12-20)
+        e1, _ = oracle.quant_energy(A, J, M, X.fourK, C1.s[r])
+        assert E1[r] == e1
+
+
+def test_rrrMC_front_end(pkg, oracle):
+    seed = 4242
+    X = pkg.GraphQuant(pkg.GraphRRG(16, 3, seed=seed), 4, 0.7, 1.5)
+    Es, C = pkg.rrrMC(X, 1.5, 4000, step=50, seed=seed, quiet=True, replicas=4)
+    C0 = pkg.Config(X.N, 4, oracle.init_configs(seed, 0, 4, X.N))
+    for r in range(4):
+        ref = oracle.rrr_mc_quant(X.A, X.J.astype(np.int32), X.M, X.fourK, 1.5, 4000, 50, seed, C0.s[r], replica=r)
+        assert (Es[r] == ref[0]).all() and (C.s[r] == ref[1]).all()
+    with pytest.raises(ValueError):
+        pkg.GraphQuant(pkg.GraphRRG(16, 3, seed=seed), 2, 0.7, 1.5)       # "M must be greater than 2", QT.jl:47
