@@ -116,6 +116,19 @@ RRRMC_API int32_t rrrmc_sync(rrrmc_ctx *ctx);
 /* Results of the last (a)sync sampling call: Es_out[R * nsamples] replica-major, accepted_out[R]. */
 RRRMC_API int32_t rrrmc_fetch_results(rrrmc_ctx *ctx, int64_t *Es_out, int64_t *accepted_out);
 
+/* ---- colour-parallel ("checkerboard") sweeps: build-defined extension for large sparse graphs ---------------------
+ * The reference's standardMC is random-site (src/RRRMC.jl:113) and its kernel here keeps a replica group's spins in
+ * LDS (N <= 8192).  For larger graphs (BASELINE.json config 4: GraphEA L=64, D=3) the engine offers sweeps over a
+ * proper colouring: one sweep attempts every site once, colour by colour, all sites of a colour at once, with the
+ * reference's delta_energy and accept rule (src/graphs/EA.jl:266-275, src/RRRMC.jl:39).  A ctx of
+ * RRRMC_MODEL_SPARSE_PM1 with N > 8192 supports only this sampler (rrrmc_standard_mc* return RRRMC_ERR_UNSUPPORTED).
+ *   color[N] in 0..ncolors-1, adjacent sites must differ (checked).
+ *   rrrmc_colored_sweeps_async: `sweeps` sweeps; an energy sample is taken BEFORE sweep k*step (as RRRMC.jl:104-108
+ *   with a sweep as the unit); results through rrrmc_sync + rrrmc_fetch_results (Es [R x sweeps/step]; accepted_out
+ *   is not tracked by this sampler and reads -1). */
+RRRMC_API int32_t rrrmc_set_coloring(rrrmc_ctx *ctx, const int32_t *color, int32_t ncolors);
+RRRMC_API int32_t rrrmc_colored_sweeps_async(rrrmc_ctx *ctx, double beta, int64_t sweeps, int64_t step);
+
 /* ---- Float64-energy models (RRRMC_MODEL_SK_NORMAL): ET = Float64 (src/graphs/SK.jl:181) --------------------
  * Dense couplings J[N*N] row-major; must be symmetric with a zero diagonal (GraphSKNormal(J; check=true),
  * SK.jl:184-195: violations are RRRMC_ERR_INVALID_ARG).  Replaces GraphSKNormal(J). */

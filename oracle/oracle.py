@@ -80,6 +80,9 @@ def lib():
                                        C.c_double, C.c_double, C.c_uint64, C.c_uint64, C.c_uint32, u64p, f64p, i64p, C.c_void_p]
         L.orc_quant_energy.restype = C.c_double
         L.orc_quant_energy.argtypes = [C.c_int64, C.c_int64, C.c_int64, i32p, i32p, C.c_double, u64p, C.POINTER(C.c_double)]
+        L.orc_colored_sweeps_sparse.restype = C.c_int64
+        L.orc_colored_sweeps_sparse.argtypes = [C.c_int64, C.c_int64, i32p, i32p, i32p, C.c_int32, C.c_double, C.c_int64, C.c_int64,
+                                                C.c_uint64, C.c_uint64, C.c_uint32, u64p, i64p, C.POINTER(C.c_int64)]
         L.orc_all_delta_e_pm1.restype = C.c_int64
         L.orc_all_delta_e_pm1.argtypes = [C.c_int64, i64p]
         _lib = L
@@ -265,3 +268,37 @@ def rrr_mc_quant(A, J, M, fourK, beta, iters, step, seed, chunks, it0=0, replica
         raise AssertionError("DeltaECache / ArraySet consistency check failed")
     out = (Es[:n], ch, int(stats[0]), int(stats[1]))
     return out + (cache[:N].copy(), cache[N:].copy()) if want_cache else out
+
+
+# ---- colour-parallel sweeps (build-defined "checkerboard" sampler) -------------------------------------
+def checkerboard_coloring(L, D):
+    """Parity colouring of the periodic L^D lattice in the reference's column-major site order (EA.jl:24-43); L even."""
+    x = np.arange(L ** D)
+    par = np.zeros_like(x)
+    for d in range(D):
+        par += (x // L ** d) % L
+    return (par % 2).astype(np.int32)
+
+
+def greedy_coloring(A):
+    N = A.shape[0]
+    col = -np.ones(N, np.int32)
+    for x in range(N):
+        used = {int(col[y]) for y in A[x] if col[y] >= 0}
+        c = 0
+        while c in used:
+            c += 1
+        col[x] = c
+    return col
+
+
+def colored_sweeps_sparse(A, J, color, beta, sweeps, step, seed, chunks, sweep0=0, replica=0):
+    """One chain.  Returns (Es, chunks_out, accepted)."""
+    N, K = A.shape
+    ch = np.array(chunks, np.uint64, copy=True)
+    Es = np.zeros(max(sweeps // step, 1), np.int64)
+    acc = C.c_int64(0)
+    color = np.ascontiguousarray(color, np.int32)
+    n = lib().orc_colored_sweeps_sparse(N, K, A, J, color, int(color.max()) + 1, beta, sweeps, step, seed, sweep0, replica, ch, Es,
+                                        C.byref(acc))
+    return Es[:n], ch, int(acc.value)

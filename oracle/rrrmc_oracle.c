@@ -807,3 +807,60 @@ ORC_API double orc_quant_energy(int64_t Nk, int64_t M, int64_t K, const int32_t 
     quant_free(&Q);
     return E;
 }
+
+/* ---------------------------------------------------------------------------------------------
+ * Colour-parallel ("checkerboard") sweeps on a sparse +-J model: the build-defined sampler of BASELINE.json config 4
+ * (not in the reference; SURVEY.md §7 hard part 7).  One sweep = for each colour in order, every site of that colour
+ * attempts a Metropolis flip (RRRMC.jl:39 accept rule, EA.jl:266-275 delta_energy) against the current spins; sites of
+ * one colour do not interact, so visiting them in index order equals updating them simultaneously.
+ * SWEEP stream: bit j (MSB first) of replica r's uniform at (sweep, site) = bit (r & 31) of word (j & 3) of
+ *   ctr = (site, lo32(sweep), r >> 5, TAG_SWEEP | (j >> 2) << 8 | bits 32..47 of sweep << 16).
+ * ------------------------------------------------------------------------------------------- */
+static int sweep_accept_lt(uint64_t seed, uint64_t sweep, uint32_t site, uint32_t replica, uint64_t T)
+{
+    uint32_t w[4];
+    const uint32_t grp = replica >> 5, bit = replica & 31u;
+    const uint32_t c3hi = (uint32_t)((sweep >> 32) & 0xffffu) << 16;
+    for (int j = 0; j < 64; ++j) {
+        if ((j & 3) == 0) orc_draw(seed, site, (uint32_t)sweep, grp, (uint32_t)ORC_TAG_SWEEP | ((uint32_t)(j >> 2) << 8) | c3hi, w);
+        unsigned ub = (w[j & 3] >> bit) & 1u, tb = (unsigned)((T >> (63 - j)) & 1u);
+        if (ub != tb) return ub < tb;
+    }
+    return 0;
+}
+
+/* Es[k] = energy BEFORE sweep (k+1)*step; returns the number of samples.  color[N] must be a proper colouring. */
+ORC_API int64_t orc_colored_sweeps_sparse(int64_t N, int64_t K, const int32_t *A, const int32_t *J, const int32_t *color, int32_t ncolors,
+                                          double beta, int64_t sweeps, int64_t step, uint64_t seed, uint64_t sweep0, uint32_t replica,
+                                          uint64_t *chunks, int64_t *Es, int64_t *accepted_out)
+{
+    sparse_t X = {N, K, A, J, NULL, NULL, -1, 1};
+    X.lfields = (int64_t *)malloc((size_t)N * sizeof(int64_t));
+    X.lfields_last = (int64_t *)malloc((size_t)N * sizeof(int64_t));
+    int64_t E = sparse_energy(&X, chunks);
+    int64_t accepted = 0, nsamp = 0;
+    for (int64_t sw = 1; sw <= sweeps; ++sw) {
+        if (sw % step == 0) Es[nsamp++] = E;
+        const uint64_t gsw = sweep0 + (uint64_t)sw;
+        for (int32_t c = 0; c < ncolors; ++c)
+            for (int64_t i = 0; i < N; ++i) {
+                if (color[i] != c) continue;
+                int64_t dE = sparse_delta_energy(&X, i);
+                double x = -beta * (double)dE;
+                int acc = 1;
+                if (!(x >= 0)) {
+                    int always;
+                    uint64_t T = orc_threshold64(exp(x), &always);
+                    acc = always ? 1 : sweep_accept_lt(seed, gsw, (uint32_t)i, replica, T);
+                }
+                if (!acc) continue;
+                bitflip(chunks, i);
+                sparse_update_cache(&X, chunks, i);
+                E += dE;
+                accepted += 1;
+            }
+    }
+    if (accepted_out) *accepted_out = accepted;
+    free(X.lfields); free(X.lfields_last);
+    return nsamp;
+}

@@ -76,6 +76,15 @@ struct rrrmc_ctx {
     int sweep_launches = 0;
     bool timing_valid = false;
 
+    // ---- colour-parallel sweeps (any sparse ctx; the only sampler when lds_mode is false) ----
+    bool lds_mode = true;               // the LDS-resident random-site kernel is available (N <= 8192 and it fits)
+    int ncolors = 0;
+    std::vector<int32_t> color_count;   // sites per colour
+    std::vector<int32_t*> d_color_list; // device lists
+    uint32_t* d_U = nullptr;            // [Rpad] unsatisfied-bond counters of the bit-sliced energy kernel
+    uint64_t sweeps_done = 0;
+    std::vector<int32_t> h_A;           // host copy of the neighbour table (colouring check)
+    bool colored_call = false;          // the last sampling call was a colored-sweep call
     // ---- RRRMC_MODEL_SK_NORMAL ----
     double* sk_J = nullptr;        // [N][N]
     double* sk_lf = nullptr;       // [G8][N][8]
@@ -194,8 +203,50 @@ int32_t ensure_state(rrrmc_ctx* ctx, bool need_spins)
     return RRRMC_OK;
 }
 
+typedef void (*ebs_fn)(const uint32_t*, const int32_t*, const int8_t*, int, uint32_t*);
+ebs_fn energy_bs_for_K(int K)
+{
+    switch (K) {
+        case 1: return energy_bs_kernel<1>;
+        case 2: return energy_bs_kernel<2>;
+        case 3: return energy_bs_kernel<3>;
+        case 4: return energy_bs_kernel<4>;
+        case 5: return energy_bs_kernel<5>;
+        case 6: return energy_bs_kernel<6>;
+        case 7: return energy_bs_kernel<7>;
+        default: return nullptr;
+    }
+}
+typedef void (*csweep_fn)(ColorSweepParams);
+csweep_fn csweep_for_K(int K)
+{
+    switch (K) {
+        case 1: return colored_sweep_kernel<1>;
+        case 2: return colored_sweep_kernel<2>;
+        case 3: return colored_sweep_kernel<3>;
+        case 4: return colored_sweep_kernel<4>;
+        case 5: return colored_sweep_kernel<5>;
+        case 6: return colored_sweep_kernel<6>;
+        case 7: return colored_sweep_kernel<7>;
+        default: return nullptr;
+    }
+}
+
+// bit-sliced energy of every replica into d_E (and, optionally, one row of the sample buffer)
+int32_t run_energy_bs(rrrmc_ctx* ctx, int32_t* es_row)
+{
+    const dim3 grid((unsigned)((ctx->N + 255) / 256), (unsigned)ctx->G);
+    hipLaunchKernelGGL(energy_bs_for_K((int)ctx->K), grid, dim3(256), 0, ctx->stream, ctx->d_spins, ctx->d_A, ctx->d_J, (int)ctx->N, ctx->d_U);
+    HIP_TRY(ctx, hipGetLastError());
+    hipLaunchKernelGGL(energy_bs_finish_kernel, dim3((unsigned)((ctx->Rpad + 255) / 256)), dim3(256), 0, ctx->stream, ctx->d_U, ctx->d_E, es_row,
+                       (int)ctx->Rpad, (int)(ctx->N * ctx->K / 2));
+    HIP_TRY(ctx, hipGetLastError());
+    return RRRMC_OK;
+}
+
 int32_t run_energy(rrrmc_ctx* ctx, uint8_t* d_nun)
 {
+    if (!d_nun) return run_energy_bs(ctx, nullptr);
     hipLaunchKernelGGL(energy_kernel, dim3((unsigned)ctx->G), dim3(256), 0, ctx->stream, ctx->d_spins, ctx->d_A, ctx->d_J,
                        (int)ctx->N, (int)ctx->K, ctx->d_E, d_nun);
     HIP_TRY(ctx, hipGetLastError());
@@ -391,7 +442,7 @@ int32_t rrrmc_ctx_create(rrrmc_ctx** out, int32_t model, int64_t N, int64_t K, i
     if (model == RRRMC_MODEL_SK_NORMAL) return sk_ctx_create(out, N, R, device, replica0);
     if (N < 1 || K < 1 || R < 1) return fail(nullptr, RRRMC_ERR_INVALID_ARG, "N, K, R must be >= 1 (given N=%lld K=%lld R=%lld)", (long long)N, (long long)K, (long long)R);
     if (K > kMaxK) return fail(nullptr, RRRMC_ERR_UNSUPPORTED, "K=%lld: the sparse +-J kernels cover K <= %d", (long long)K, kMaxK);
-    if (N > 8192) return fail(nullptr, RRRMC_ERR_UNSUPPORTED, "N=%lld: the LDS-resident sparse kernel covers N <= 8192", (long long)N);
+    if (N > (int64_t)INT32_MAX / 8) return fail(nullptr, RRRMC_ERR_UNSUPPORTED, "N=%lld is too large", (long long)N);
     if (replica0 % 32) return fail(nullptr, RRRMC_ERR_INVALID_ARG, "replica0 must be a multiple of 32 (given %u)", replica0);
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
@@ -407,14 +458,12 @@ int32_t rrrmc_ctx_create(rrrmc_ctx** out, int32_t model, int64_t N, int64_t K, i
 
     // chunk length: a multiple of (producer waves x 64) that fits the 160 KiB LDS next to the state
     int C = kProducerWaves * kWave;
-    while (C >= kWave && sweep_lds_bytes(N, (int)K, ctx->TS, C) > (size_t)kLdsLimit) C -= kWave;
-    if (C < kWave) {
-        delete ctx;
-        return fail(nullptr, RRRMC_ERR_UNSUPPORTED, "N=%lld K=%lld does not fit the LDS-resident sweep kernel", (long long)N, (long long)K);
-    }
+    while (C >= kWave && (N > 8192 || sweep_lds_bytes(N, (int)K, ctx->TS, C) > (size_t)kLdsLimit)) C -= kWave;
+    ctx->lds_mode = C >= kWave;      // otherwise only the colour-parallel sweeps are available (HBM/L2-resident spins)
+    if (!ctx->lds_mode) C = kWave;
     ctx->C = C;
-    ctx->lds_bytes = sweep_lds_bytes(N, (int)K, ctx->TS, C);
-    ctx->plan_lds_bytes = plan_lds_bytes(N, (int)K, C);
+    ctx->lds_bytes = ctx->lds_mode ? sweep_lds_bytes(N, (int)K, ctx->TS, C) : 0;
+    ctx->plan_lds_bytes = ctx->lds_mode ? plan_lds_bytes(N, (int)K, C) : 0;
 
 #define CREATE_TRY(expr)                                                                                         \
     do {                                                                                                         \
@@ -431,7 +480,9 @@ int32_t rrrmc_ctx_create(rrrmc_ctx** out, int32_t model, int64_t N, int64_t K, i
     CREATE_TRY(hipEventCreate(&ctx->ev_end));
     CREATE_TRY(hipMalloc(&ctx->d_A, sizeof(int32_t) * N * K));
     CREATE_TRY(hipMalloc(&ctx->d_J, sizeof(int8_t) * N * K));
-    CREATE_TRY(hipMalloc(&ctx->d_table, sizeof(uint16_t) * N * ctx->TS));
+    CREATE_TRY(hipMalloc(&ctx->d_table, sizeof(uint16_t) * (ctx->lds_mode ? N * ctx->TS : 8)));
+    CREATE_TRY(hipMalloc(&ctx->d_U, sizeof(uint32_t) * ctx->Rpad));
+    CREATE_TRY(hipMemset(ctx->d_U, 0, sizeof(uint32_t) * ctx->Rpad));
     CREATE_TRY(hipMalloc(&ctx->d_spins, sizeof(uint32_t) * ctx->G * N));
     CREATE_TRY(hipMalloc(&ctx->d_E, sizeof(int32_t) * ctx->Rpad));
     CREATE_TRY(hipMalloc(&ctx->d_acc, sizeof(int64_t) * ctx->Rpad));
@@ -444,9 +495,11 @@ int32_t rrrmc_ctx_create(rrrmc_ctx** out, int32_t model, int64_t N, int64_t K, i
     CREATE_TRY(hipMemset(ctx->d_spins, 0, sizeof(uint32_t) * ctx->G * N));
     CREATE_TRY(hipMemset(ctx->d_E, 0, sizeof(int32_t) * ctx->Rpad));
     CREATE_TRY(hipMemset(ctx->d_acc, 0, sizeof(int64_t) * ctx->Rpad));
-    sweep_fn fn = sweep_for_K((int)K);
-    CREATE_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->lds_bytes));
-    CREATE_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(plan_for_K((int)K)), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->plan_lds_bytes));
+    if (ctx->lds_mode) {
+        sweep_fn fn = sweep_for_K((int)K);
+        CREATE_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->lds_bytes));
+        CREATE_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(plan_for_K((int)K)), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->plan_lds_bytes));
+    }
 #undef CREATE_TRY
     *out = ctx;
     return RRRMC_OK;
@@ -459,6 +512,8 @@ void rrrmc_ctx_destroy(rrrmc_ctx* ctx)
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     free_dev(ctx->d_A); free_dev(ctx->d_J); free_dev(ctx->d_table); free_dev(ctx->d_spins);
     free_dev(ctx->d_E); free_dev(ctx->d_acc); free_dev(ctx->d_chunks); free_dev(ctx->d_Es);
+    free_dev(ctx->d_U);
+    for (int32_t*& l : ctx->d_color_list) free_dev(l);
     free_dev(ctx->sk_J); free_dev(ctx->sk_lf); free_dev(ctx->sk_lfl); free_dev(ctx->sk_move_last); free_dev(ctx->sk_spins);
     free_dev(ctx->sk_E); free_dev(ctx->sk_Es);
     free_dev(ctx->q_spins); free_dev(ctx->q_cls); free_dev(ctx->q_sv); free_dev(ctx->q_spos); free_dev(ctx->q_st);
@@ -506,10 +561,12 @@ int32_t rrrmc_set_graph(rrrmc_ctx* ctx, const int32_t* A, const int8_t* J)
         ctx->graph_set = true;
         return RRRMC_OK;
     }
-    std::vector<uint16_t> table((size_t)(N * ctx->TS), 0);
-    for (int64_t x = 0; x < N; ++x)
-        for (int64_t k = 0; k < K; ++k)
-            table[x * ctx->TS + k] = (uint16_t)(4 * (A[x * K + k] + (J[x * K + k] < 0 ? N : 0)));   // byte offset in the LDS spin array
+    std::vector<uint16_t> table((size_t)(ctx->lds_mode ? N * ctx->TS : 8), 0);
+    if (ctx->lds_mode)
+        for (int64_t x = 0; x < N; ++x)
+            for (int64_t k = 0; k < K; ++k)
+                table[x * ctx->TS + k] = (uint16_t)(4 * (A[x * K + k] + (J[x * K + k] < 0 ? N : 0)));   // byte offset in the LDS spin array
+    ctx->h_A.assign(A, A + N * K);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     HIP_TRY(ctx, hipMemcpy(ctx->d_A, A, sizeof(int32_t) * N * K, hipMemcpyHostToDevice));
@@ -525,6 +582,7 @@ int32_t rrrmc_seed(rrrmc_ctx* ctx, uint64_t seed)
     ctx->seed = seed;
     ctx->seeded = true;
     ctx->it_done = 0;
+    ctx->sweeps_done = 0;
     return RRRMC_OK;
 }
 
@@ -686,6 +744,8 @@ int32_t rrrmc_standard_mc_async(rrrmc_ctx* ctx, double beta, int64_t iters, int6
     if (rc) return rc;
     if (ctx->model == RRRMC_MODEL_SK_NORMAL) return sk_standard_mc_async(ctx, beta, iters, step);
     if (ctx->model != RRRMC_MODEL_SPARSE_PM1) return fail(ctx, RRRMC_ERR_UNSUPPORTED, "standardMC is not wired for this model on the device: use rrrmc_rrr_mc_async");
+    if (!ctx->lds_mode) return fail(ctx, RRRMC_ERR_UNSUPPORTED, "N=%lld does not fit the LDS-resident random-site kernel: use rrrmc_colored_sweeps_async", (long long)ctx->N);
+    ctx->colored_call = false;
     if (iters < 0) return fail(ctx, RRRMC_ERR_INVALID_ARG, "iters must be >= 0, given %lld", (long long)iters);
     if (step < 1) return fail(ctx, RRRMC_ERR_INVALID_ARG, "step must be >= 1, given %lld", (long long)step);
     if (std::isnan(beta)) return fail(ctx, RRRMC_ERR_INVALID_ARG, "beta is NaN");
@@ -916,6 +976,106 @@ RRRMC_API int32_t rrrmc_debug_step_trace(rrrmc_ctx* ctx, unsigned long long* out
     return RRRMC_OK;
 }
 #endif
+
+// ---- colour-parallel sweeps -----------------------------------------------------------------------------------------
+
+int32_t rrrmc_set_coloring(rrrmc_ctx* ctx, const int32_t* color, int32_t ncolors)
+{
+    if (!ctx) return RRRMC_ERR_INVALID_ARG;
+    if (ctx->model != RRRMC_MODEL_SPARSE_PM1) return fail(ctx, RRRMC_ERR_STATE, "colourings are for sparse +-J models");
+    if (!ctx->graph_set) return fail(ctx, RRRMC_ERR_STATE, "rrrmc_set_graph has not been called");
+    if (!color || ncolors < 1 || ncolors > 64) return fail(ctx, RRRMC_ERR_INVALID_ARG, "color is NULL or ncolors out of range 1..64");
+    const int64_t N = ctx->N, K = ctx->K;
+    std::vector<std::vector<int32_t>> lists((size_t)ncolors);
+    for (int64_t x = 0; x < N; ++x) {
+        if (color[x] < 0 || color[x] >= ncolors) return fail(ctx, RRRMC_ERR_INVALID_ARG, "color[%lld] = %d out of range", (long long)x, color[x]);
+        for (int64_t k = 0; k < K; ++k)
+            if (color[ctx->h_A[x * K + k]] == color[x])
+                return fail(ctx, RRRMC_ERR_INVALID_ARG, "not a proper colouring: sites %lld and %d are adjacent and both have colour %d", (long long)x, ctx->h_A[x * K + k], color[x]);
+        lists[color[x]].push_back((int32_t)x);
+    }
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    for (int32_t*& l : ctx->d_color_list) free_dev(l);
+    ctx->d_color_list.assign((size_t)ncolors, nullptr);
+    ctx->color_count.assign((size_t)ncolors, 0);
+    for (int c = 0; c < ncolors; ++c) {
+        ctx->color_count[c] = (int32_t)lists[c].size();
+        if (lists[c].empty()) continue;
+        HIP_TRY(ctx, hipMalloc(&ctx->d_color_list[c], sizeof(int32_t) * lists[c].size()));
+        HIP_TRY(ctx, hipMemcpy(ctx->d_color_list[c], lists[c].data(), sizeof(int32_t) * lists[c].size(), hipMemcpyHostToDevice));
+    }
+    ctx->ncolors = ncolors;
+    return RRRMC_OK;
+}
+
+int32_t rrrmc_colored_sweeps_async(rrrmc_ctx* ctx, double beta, int64_t sweeps, int64_t step)
+{
+    int32_t rc = ensure_state(ctx, true);
+    if (rc) return rc;
+    if (ctx->model != RRRMC_MODEL_SPARSE_PM1) return fail(ctx, RRRMC_ERR_UNSUPPORTED, "colour-parallel sweeps are for sparse +-J models");
+    if (ctx->ncolors < 1) return fail(ctx, RRRMC_ERR_STATE, "rrrmc_set_coloring has not been called");
+    if (sweeps < 0) return fail(ctx, RRRMC_ERR_INVALID_ARG, "sweeps must be >= 0, given %lld", (long long)sweeps);
+    if (step < 1) return fail(ctx, RRRMC_ERR_INVALID_ARG, "step must be >= 1, given %lld", (long long)step);
+    if (std::isnan(beta)) return fail(ctx, RRRMC_ERR_INVALID_ARG, "beta is NaN");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    ctx->results_valid = false;
+    ctx->timing_valid = false;
+    const int64_t K = ctx->K, nsamp = sweeps / step;
+    const size_t es_need = (size_t)(nsamp > 0 ? nsamp : 1) * ctx->Rpad;
+    if (es_need > ctx->Es_cap) {
+        free_dev(ctx->d_Es);
+        ctx->Es_cap = 0;
+        HIP_TRY(ctx, hipMalloc(&ctx->d_Es, sizeof(int32_t) * es_need));
+        ctx->Es_cap = es_need;
+    }
+    while (ctx->ev_sweep.size() < 2) {
+        hipEvent_t e;
+        HIP_TRY(ctx, hipEventCreate(&e));
+        ctx->ev_sweep.push_back(e);
+    }
+    ColorSweepParams P{};
+    const int NT = (int)(K + 1) / 2;
+    for (int n = 0; n < NT; ++n) {
+        bool always;
+        const uint64_t T = threshold64(std::exp(-beta * 2.0 * (double)(K - 2 * n)), &always);
+        if (always) P.always_mask |= 1u << n;
+        for (int plane = 0; plane < 64; ++plane) P.taum[plane * 4 + n] = ((T >> (63 - plane)) & 1ull) ? ~0u : 0u;
+    }
+    P.spins = ctx->d_spins; P.A = ctx->d_A; P.J = ctx->d_J;
+    P.k0 = (uint32_t)ctx->seed; P.k1 = (uint32_t)(ctx->seed >> 32); P.group0 = ctx->replica0 / 32; P.N = (int)ctx->N;
+    csweep_fn fn = csweep_for_K((int)K);
+    hipStream_t st = ctx->stream;
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_begin, st));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->d_acc, 0xff, sizeof(int64_t) * ctx->Rpad, st));      // accepted counts are not tracked: -1
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_sweep[0], st));
+    int64_t ns = 0;
+    for (int64_t sw = 1; sw <= sweeps; ++sw) {
+        if (sw % step == 0) {      // the sample precedes sweep k*step
+            rc = run_energy_bs(ctx, ctx->d_Es + ns * ctx->Rpad);
+            if (rc) return rc;
+            ns += 1;
+        }
+        P.sweep = ctx->sweeps_done + (uint64_t)sw;
+        for (int c = 0; c < ctx->ncolors; ++c) {
+            if (ctx->color_count[c] == 0) continue;
+            P.list = ctx->d_color_list[c];
+            P.nlist = ctx->color_count[c];
+            const dim3 grid((unsigned)((P.nlist + 255) / 256), (unsigned)ctx->G);
+            hipLaunchKernelGGL(fn, grid, dim3(256), 0, st, P);
+            HIP_TRY(ctx, hipGetLastError());
+        }
+    }
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_sweep[1], st));
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_end, st));
+    ctx->sweep_launches = 1;
+    ctx->nsamp = nsamp;
+    ctx->sweeps_done += (uint64_t)sweeps;
+    ctx->results_valid = true;
+    ctx->timing_valid = true;
+    ctx->colored_call = true;
+    return RRRMC_OK;
+}
 
 // ---- GraphQuant + rrrMC: exported entry points ---------------------------------------------------------------------
 

@@ -845,4 +845,119 @@ __global__ __launch_bounds__(256) void transpose_es_kernel(const int32_t* __rest
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Colour-parallel Metropolis sweeps for graphs that do not fit the LDS-resident kernel (BASELINE.json config 4:
+// GraphEA L = 64, D = 3).  NOT in the reference (its standardMC is random-site, src/RRRMC.jl:113); this is the
+// build-defined "checkerboard" extension of SURVEY.md §7 hard part 7: given a proper colouring of the graph, one
+// sweep visits the colours in order and attempts every site of a colour simultaneously (they do not interact), with
+// the reference's energy function, delta_energy and accept rule (src/graphs/EA.jl:195-275, src/RRRMC.jl:39).
+// Random numbers: SWEEP stream, bit planes of the acceptance uniforms of replica group `group` at (sweep, site):
+//   ctr = (site, lo32(sweep), group, TAG_SWEEP | pb << 8 | bits 32..47 of sweep << 16), plane j = word j & 3 of block j >> 2.
+// Spins stay bit-sliced in HBM/L2: spins[G][N].
+// ---------------------------------------------------------------------------------------------------
+constexpr uint32_t TAG_SWEEP = 7;
+
+struct ColorSweepParams {
+    uint32_t* spins;          // [G][N]
+    const int32_t* A;         // [N][K]
+    const int8_t* J;          // [N][K]
+    const int32_t* list;      // sites of the colour being updated
+    uint32_t taum[64 * 4];    // threshold bit planes, class n = unsatisfied bonds (dE = 2(K - 2n) > 0)
+    uint32_t always_mask;
+    uint32_t k0, k1, group0;
+    uint64_t sweep;           // global sweep index (1-based)
+    int N, nlist;
+};
+
+template <int K>
+__global__ __launch_bounds__(256) void colored_sweep_kernel(ColorSweepParams P)
+{
+    constexpr int NT = SweepCfg<K>::NT;
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    const bool live = idx < P.nlist;
+    const uint32_t group = P.group0 + blockIdx.y;
+    uint32_t* sp = P.spins + (size_t)blockIdx.y * P.N;
+    const int x = live ? P.list[idx] : 0;
+    const uint32_t s = sp[x];
+    uint32_t n0 = 0u, n1 = 0u, n2 = 0u;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const uint32_t u = s ^ sp[P.A[(size_t)x * K + k]] ^ (P.J[(size_t)x * K + k] < 0 ? 0xffffffffu : 0u);   // bond k unsatisfied
+        const uint32_t c0 = n0 & u;
+        n0 ^= u;
+        const uint32_t c1 = n1 & c0;
+        n1 ^= c0;
+        n2 ^= c1;
+    }
+    uint32_t lt[NT], eq[NT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+        const bool always = (P.always_mask >> n) & 1u;
+        // only the replicas that are in class n need the comparison at all
+        uint32_t cls = (n & 1) ? n0 : ~n0;
+        cls &= (n & 2) ? n1 : ~n1;
+        if (K > 3) cls &= (n & 4) ? n2 : ~n2;
+        lt[n] = always ? 0xffffffffu : 0u;
+        eq[n] = (live && !always) ? cls : 0u;
+    }
+    const uint32_t c3hi = (uint32_t)((P.sweep >> 32) & 0xffffu) << 16;
+    for (uint32_t pb = 0; pb < 16u; ++pb) {
+        if (!__any(any_set<NT>(eq))) break;
+        const Philox4 o = philox4x32_10((uint32_t)x, (uint32_t)P.sweep, group, TAG_SWEEP | (pb << 8) | c3hi, P.k0, P.k1);
+        refine_block<NT>(lt, eq, o, pb, P.taum);
+    }
+    uint32_t rej = 0u;
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+        uint32_t e = ~lt[n];
+        e &= (n & 1) ? n0 : ~n0;
+        e &= (n & 2) ? n1 : ~n1;
+        if (K > 3) e &= (n & 4) ? n2 : ~n2;
+        rej |= e;
+    }
+    if (live) sp[x] = s ^ ~rej;
+}
+
+// Bit-sliced energy: U[group*32 + r] += sum over sites of the number of unsatisfied bonds of replica r (every bond
+// from both ends); E = U - N*K/2 (RRG.jl:164-189).  One lane per site, three count planes, 32x32 bit transpose +
+// popcount per wave, one atomic per replica and wave.
+template <int K>
+__global__ __launch_bounds__(256) void energy_bs_kernel(const uint32_t* __restrict__ spins, const int32_t* __restrict__ A,
+                                                        const int8_t* __restrict__ J, int N, uint32_t* __restrict__ U)
+{
+    const int x = blockIdx.x * 256 + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const uint32_t* sp = spins + (size_t)blockIdx.y * N;
+    uint32_t n0 = 0u, n1 = 0u, n2 = 0u;
+    if (x < N) {
+        const uint32_t s = sp[x];
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const uint32_t u = s ^ sp[A[(size_t)x * K + k]] ^ (J[(size_t)x * K + k] < 0 ? 0xffffffffu : 0u);
+            const uint32_t c0 = n0 & u;
+            n0 ^= u;
+            const uint32_t c1 = n1 & c0;
+            n1 ^= c0;
+            n2 ^= c1;
+        }
+    }
+    TransposeConsts tc;
+    tc.init(lane);
+    uint32_t tot = (uint32_t)__popc(transpose32(n0, tc)) + ((uint32_t)__popc(transpose32(n1, tc)) << 1) + ((uint32_t)__popc(transpose32(n2, tc)) << 2);
+    tot += (uint32_t)__shfl_xor((int)tot, 32);
+    if (lane < 32) atomicAdd(&U[blockIdx.y * 32 + lane], tot);
+}
+
+// Es[sample][r] = U[r] - N*K/2 (also leaves the value in E_cur) and clears U for the next sample
+__global__ __launch_bounds__(256) void energy_bs_finish_kernel(uint32_t* __restrict__ U, int32_t* __restrict__ E_cur, int32_t* __restrict__ Es_row,
+                                                               int Rpad, int halfNK)
+{
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    if (r >= Rpad) return;
+    const int32_t E = (int32_t)U[r] - halfNK;
+    U[r] = 0u;
+    if (E_cur) E_cur[r] = E;
+    if (Es_row) Es_row[r] = E;
+}
+
 }  // namespace rrrmc

@@ -112,6 +112,21 @@ class Engine:
         check(fn(self._ctx, Es.ctypes.data if (want_energies and nsamp) else None, acc.ctypes.data), self._ctx)
         return Es, acc
 
+    # -- colour-parallel sweeps (build-defined checkerboard sampler for large sparse graphs) ---------
+    def set_coloring(self, color):
+        color = np.ascontiguousarray(color, np.int32)
+        check(lib().rrrmc_set_coloring(self._ctx, color, int(color.max()) + 1), self._ctx)
+
+    def colored_sweeps_async(self, beta, sweeps, step=1):
+        check(lib().rrrmc_colored_sweeps_async(self._ctx, float(beta), int(sweeps), int(step)), self._ctx)
+        self._last = (int(sweeps), int(step))
+
+    def colored_sweeps(self, beta, sweeps, step=1):
+        """`sweeps` colour-parallel sweeps; returns Es[R, sweeps // step] (energy before sweep k*step)."""
+        self.colored_sweeps_async(beta, sweeps, step)
+        self.sync()
+        return self.fetch_results()[0]
+
     # -- reduced-rejection-rate sampler (GraphQuant) ------------------------------------------------
     def rrr_mc(self, beta, iters, step=1, staged_thr=0.5, staged_thr_fact=5.0, want_energies=True):
         """rrrMC(X::DoubleGraph, β, iters; step, staged_thr, staged_thr_fact) (src/RRRMC.jl:221-290).

@@ -167,6 +167,17 @@ class GraphQuant:
         self.fourK = round(2.0 / beta * math.log(1.0 / math.tanh(beta * Gamma / M)), 8)
 
 
+def checkerboard_coloring(L, D):
+    """Two-colouring (parity of the coordinate sum) of the periodic L^D lattice of ``GraphEA``; L must be even."""
+    if L % 2:
+        raise ValueError("the periodic lattice is two-colourable only for even L, given: %d" % L)
+    x = np.arange(int(L) ** int(D))
+    par = np.zeros_like(x)
+    for d in range(int(D)):
+        par += (x // int(L) ** d) % int(L)
+    return (par % 2).astype(np.int32)
+
+
 def getN(X):
     """src/Interface.jl:145"""
     return X.N

@@ -36,6 +36,45 @@ def bench_sk(N=1024, R=2048, beta=1.0, iters=1 << 16, step=1 << 10, seed=0x5EED)
     eng.close()
 
 
+def bench_ea(L=64, D=3, R=512, beta=1.0, sweeps=64, step=16, seed=0x5EED):
+    """BASELINE.json configs[3] on ONE GPU's share: GraphEA L=64 D=3, 512 of the 4096 replicas, checkerboard sweeps."""
+    pkg = entry.load_package()
+    X = pkg.GraphEA(L, D, seed=seed)
+    eng = pkg.Engine(X, R)
+    eng.seed(seed)
+    eng.init_spins_random()
+    eng.set_coloring(pkg.checkerboard_coloring(L, D))
+    eng.colored_sweeps_async(beta, 8, 8); eng.sync()
+    t0 = time.perf_counter()
+    eng.colored_sweeps_async(beta, sweeps, step); eng.sync()
+    dt = time.perf_counter() - t0
+    total_ms, sweep_ms, _ = eng.last_timing()
+    Es, _ = eng.fetch_results()
+    attempts = float(R) * sweeps * X.N
+    out = {"model": "GraphEA checkerboard", "L": L, "D": D, "replicas": R, "beta": beta, "sweeps": sweeps,
+           "attempts_per_s": attempts / dt, "device_ms": sweep_ms, "energy_per_spin": float(Es[:, -1].mean()) / X.N}
+    print(json.dumps(out))
+    eng.close()
+
+
+def bench_quant(Nk=1024, M=32, R=128, beta=2.0, Gamma=0.5, iters=1 << 16, step=1 << 12, seed=0x5EED):
+    """BASELINE.json configs[4] on ONE GPU's share: GraphQuant(GraphRRG(1024,3), M=32) under rrrMC, 128 of the 1024 replicas."""
+    pkg = entry.load_package()
+    X = pkg.GraphQuant(pkg.GraphRRG(Nk, 3, seed=seed), M, Gamma, beta)
+    eng = pkg.Engine(X, R)
+    eng.seed(seed)
+    eng.init_spins_random()
+    t0 = time.perf_counter()
+    Es, acc, staged = eng.rrr_mc(beta, iters, step)
+    dt = time.perf_counter() - t0
+    total_ms, sweep_ms, _ = eng.last_timing()
+    out = {"model": "GraphQuant rrrMC", "Nk": Nk, "M": M, "replicas": R, "beta": beta, "Gamma": Gamma, "iters": iters,
+           "iterations_per_s": float(R) * iters / dt, "kernel_ms": sweep_ms, "acceptance": float(acc.mean()) / iters,
+           "staged_frac": float(staged.mean()) / iters, "energy_per_spin": float(Es[:, -1].mean()) / X.N}
+    print(json.dumps(out))
+    eng.close()
+
+
 if __name__ == "__main__":
     which = sys.argv[1] if len(sys.argv) > 1 else "sk"
-    {"sk": bench_sk}[which]()
+    {"sk": bench_sk, "ea": bench_ea, "quant": bench_quant}[which]()
