@@ -48,6 +48,7 @@ enum rrrmc_status {
 enum rrrmc_model {
     RRRMC_MODEL_SPARSE_PM1 = 1,  /* GraphRRG{Int,(-1,1),K} src/graphs/RRG.jl:116 and GraphEA{Int,(-1,1),2D} src/graphs/EA.jl:138 */
     RRRMC_MODEL_SK_NORMAL = 2,   /* GraphSKNormal (Float64 couplings) src/graphs/SK.jl:181-210; K is ignored */
+    RRRMC_MODEL_SK_BINARY = 4,   /* GraphSK (couplings +-1/sqrt(N), bit-packed) src/graphs/SK.jl:28-60; K is ignored; energies Float64 */
     RRRMC_MODEL_QUANT_RRG = 3    /* GraphQuant over M Suzuki-Trotter slices of one GraphRRG{Int,(-1,1),K} disorder
                                     (src/graphs/QT.jl:126-170 with the shared-disorder pattern of src/QAliases.jl:43-67);
                                     created with rrrmc_ctx_create_quant */
@@ -140,6 +141,11 @@ RRRMC_API int32_t rrrmc_get_fields_f64(rrrmc_ctx *ctx, double *lfields_out);
 RRRMC_API int32_t rrrmc_standard_mc_f64(rrrmc_ctx *ctx, double beta, int64_t iters, int64_t step,
                                         double *Es_out, int64_t *accepted_out);
 RRRMC_API int32_t rrrmc_fetch_results_f64(rrrmc_ctx *ctx, double *Es_out, int64_t *accepted_out);
+/* RRRMC_MODEL_SK_BINARY: couplings as N BitVector rows of ceil(N/64) chunks (GraphSK(J::Vector{BitVector}), SK.jl:34-48):
+ * symmetric, zero diagonal (checked).  The integer cache is read with rrrmc_get_fields (lfields = sqrt(N) * delta_energy,
+ * SK.jl:137-140), energies with the _f64 entry points.  rrrmc_gen_sk_binary = gen_J (SK.jl:17-26), SKBITS stream. */
+RRRMC_API int32_t rrrmc_set_couplings_bits(rrrmc_ctx *ctx, const uint64_t *J_chunks);
+RRRMC_API int32_t rrrmc_gen_sk_binary(int64_t N, uint64_t seed, uint64_t *J_chunks_out);
 /* gen_J_gauss (src/graphs/SK.jl:170-179): J_out[N*N], normal(0, 1/N), symmetric, zero diagonal. GAUSS stream. */
 RRRMC_API int32_t rrrmc_gen_sk_gauss(int64_t N, uint64_t seed, double *J_out);
 

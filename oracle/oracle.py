@@ -83,6 +83,12 @@ def lib():
         L.orc_colored_sweeps_sparse.restype = C.c_int64
         L.orc_colored_sweeps_sparse.argtypes = [C.c_int64, C.c_int64, i32p, i32p, i32p, C.c_int32, C.c_double, C.c_int64, C.c_int64,
                                                 C.c_uint64, C.c_uint64, C.c_uint32, u64p, i64p, C.POINTER(C.c_int64)]
+        L.orc_gen_sk_binary.argtypes = [C.c_int64, C.c_uint64, u64p]
+        L.orc_skb_energy.restype = C.c_double
+        L.orc_skb_energy.argtypes = [C.c_int64, u64p, u64p, C.c_void_p]
+        L.orc_standard_mc_skb.restype = C.c_int64
+        L.orc_standard_mc_skb.argtypes = [C.c_int64, u64p, C.c_double, C.c_int64, C.c_int64, C.c_uint64, C.c_uint64, C.c_uint32,
+                                          u64p, f64p, C.POINTER(C.c_int64), C.c_void_p]
         L.orc_all_delta_e_pm1.restype = C.c_int64
         L.orc_all_delta_e_pm1.argtypes = [C.c_int64, i64p]
         _lib = L
@@ -302,3 +308,29 @@ def colored_sweeps_sparse(A, J, color, beta, sweeps, step, seed, chunks, sweep0=
     n = lib().orc_colored_sweeps_sparse(N, K, A, J, color, int(color.max()) + 1, beta, sweeps, step, seed, sweep0, replica, ch, Es,
                                         C.byref(acc))
     return Es[:n], ch, int(acc.value)
+
+
+# ---- binary SK (GraphSK) ----------------------------------------------------------------------------
+def gen_sk_binary(N, seed):
+    """J as [N, ceil(N/64)] BitVector chunk rows."""
+    J = np.zeros((N, nchunks(N)), np.uint64)
+    lib().orc_gen_sk_binary(N, seed, J.reshape(-1))
+    return J
+
+
+def skb_energy(J, chunks, want_fields=False):
+    N = J.shape[0]
+    lf = np.zeros(N, np.int64)
+    E = lib().orc_skb_energy(N, np.ascontiguousarray(J).reshape(-1), np.ascontiguousarray(chunks), lf.ctypes.data)
+    return (float(E), lf) if want_fields else float(E)
+
+
+def standard_mc_skb(J, beta, iters, step, seed, chunks, it0=0, replica=0):
+    N = J.shape[0]
+    ch = np.array(chunks, np.uint64, copy=True)
+    Es = np.zeros(max(iters // step, 1), np.float64)
+    acc = C.c_int64(0)
+    lf = np.zeros(N, np.int64)
+    n = lib().orc_standard_mc_skb(N, np.ascontiguousarray(J).reshape(-1), beta, iters, step, seed, it0, replica, ch, Es,
+                                  C.byref(acc), lf.ctypes.data)
+    return Es[:n], ch, int(acc.value), lf

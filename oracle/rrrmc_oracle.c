@@ -864,3 +864,120 @@ ORC_API int64_t orc_colored_sweeps_sparse(int64_t N, int64_t K, const int32_t *A
     free(X.lfields); free(X.lfields_last);
     return nsamp;
 }
+
+/* ---------------------------------------------------------------------------------------------
+ * Binary SK model GraphSK (couplings +-1/sqrt(N), bit-packed; integer cache): src/graphs/SK.jl:17-165
+ * J is given as N rows of Julia-BitVector chunks (nch = ceil(N/64) words per row).
+ * ------------------------------------------------------------------------------------------- */
+enum { ORC_TAG_SKBITS = 10 };
+
+/* gen_J: SK.jl:17-26.  Row i = bitrand(N): bit j = bit (j & 31) of word ((j >> 5) & 3) of ctr (j >> 7, i, 0, TAG_SKBITS);
+ * then J[i][i] = 0 and the upper triangle is mirrored. */
+ORC_API void orc_gen_sk_binary(int64_t N, uint64_t seed, uint64_t *J)
+{
+    int64_t nch = (N + 63) / 64;
+    memset(J, 0, (size_t)(N * nch) * 8);
+    for (int64_t i = 0; i < N; ++i)
+        for (int64_t j = 0; j < N; ++j) {
+            uint32_t w[4];
+            orc_draw(seed, (uint32_t)(j >> 7), (uint32_t)i, 0u, ORC_TAG_SKBITS, w);
+            if ((w[(j >> 5) & 3] >> (j & 31)) & 1u) J[i * nch + (j >> 6)] |= 1ull << (j & 63);
+        }
+    for (int64_t i = 0; i < N; ++i) {
+        J[i * nch + (i >> 6)] &= ~(1ull << (i & 63));
+        for (int64_t j = i + 1; j < N; ++j) {
+            uint64_t b = (J[i * nch + (j >> 6)] >> (j & 63)) & 1ull;
+            J[j * nch + (i >> 6)] = (J[j * nch + (i >> 6)] & ~(1ull << (i & 63))) | (b << (i & 63));
+        }
+    }
+}
+
+typedef struct {
+    int64_t N, nch;
+    double sN;
+    const uint64_t *J;
+    int64_t *lfields, *lfields_last;
+    int64_t move_last;
+} skb_t;
+
+/* energy: SK.jl:62-96 */
+static double skb_energy(skb_t *X, const uint64_t *s)
+{
+    int64_t sum_s = 0;
+    for (int64_t c = 0; c < X->nch; ++c) sum_s += __builtin_popcountll(s[c]);
+    int64_t n = -2 * sum_s;
+    for (int64_t i = 0; i < X->N; ++i) {
+        const uint64_t *Ji = X->J + i * X->nch;
+        int64_t sc = 0;
+        for (int64_t c = 0; c < X->nch; ++c) sc += __builtin_popcountll(Ji[c] ^ s[c]);      /* sum(map!(xor, tmps, Ji, s)) */
+        int64_t si = spin_bit(s, i);
+        int64_t lf = -(2 * si - 1) * (X->N - 1 - 2 * sc);
+        X->lfields[i] = 2 * (-lf + 2 * si);
+        n += lf;
+    }
+    n /= 2;                                   /* @assert n % 2 == 0 */
+    X->move_last = -1;
+    memset(X->lfields_last, 0, (size_t)X->N * 8);
+    return (double)n / X->sN;
+}
+
+/* update_cache!: SK.jl:98-135 */
+static void skb_update_cache(skb_t *X, const uint64_t *s, int64_t move)
+{
+    if (X->move_last == move) {
+        int64_t *t = X->lfields; X->lfields = X->lfields_last; X->lfields_last = t;
+        return;
+    }
+    const uint64_t *Ji = X->J + move * X->nch;
+    int64_t si = spin_bit(s, move);
+    int64_t lfm = X->lfields[move];
+    for (int64_t j = 0; j < X->N; ++j) {
+        int64_t Jsij = si ^ spin_bit(s, j) ^ spin_bit(Ji, j);
+        int64_t lfj = X->lfields[j];
+        X->lfields_last[j] = lfj;
+        X->lfields[j] = lfj + 8 * Jsij - 4;
+    }
+    X->lfields_last[move] = lfm;
+    X->lfields[move] = -lfm;
+    X->move_last = move;
+}
+
+ORC_API double orc_skb_energy(int64_t N, const uint64_t *J, const uint64_t *chunks, int64_t *lfields_out)
+{
+    skb_t X = {N, (N + 63) / 64, sqrt((double)N), J, NULL, NULL, -1};
+    X.lfields = (int64_t *)malloc((size_t)N * 8);
+    X.lfields_last = (int64_t *)malloc((size_t)N * 8);
+    double E = skb_energy(&X, chunks);
+    if (lfields_out) memcpy(lfields_out, X.lfields, (size_t)N * 8);
+    free(X.lfields); free(X.lfields_last);
+    return E;
+}
+
+/* standardMC (src/RRRMC.jl:81-127) on GraphSK; delta_energy = lfields[move] / sqrt(N) (SK.jl:137-140) */
+ORC_API int64_t orc_standard_mc_skb(int64_t N, const uint64_t *J, double beta, int64_t iters, int64_t step,
+                                    uint64_t seed, uint64_t it0, uint32_t replica,
+                                    uint64_t *chunks, double *Es, int64_t *accepted_out, int64_t *lfields_out)
+{
+    skb_t X = {N, (N + 63) / 64, sqrt((double)N), J, NULL, NULL, -1};
+    X.lfields = (int64_t *)malloc((size_t)N * 8);
+    X.lfields_last = (int64_t *)malloc((size_t)N * 8);
+    double E = skb_energy(&X, chunks);
+    int64_t accepted = 0, nsamp = 0;
+    for (int64_t it = 1; it <= iters; ++it) {
+        if (it % step == 0) Es[nsamp++] = E;
+        uint64_t g = it0 + (uint64_t)it;
+        int64_t i = orc_site(seed, g, N);
+        double dE = (double)X.lfields[i] / X.sN;
+        double x = -beta * dE;
+        int acc = (x >= 0) || (orc_rand53(seed, g, replica) < orc_det_exp(x));
+        if (!acc) continue;
+        bitflip(chunks, i);
+        skb_update_cache(&X, chunks, i);
+        E += dE;
+        accepted += 1;
+    }
+    if (accepted_out) *accepted_out = accepted;
+    if (lfields_out) memcpy(lfields_out, X.lfields, (size_t)N * 8);
+    free(X.lfields); free(X.lfields_last);
+    return nsamp;
+}

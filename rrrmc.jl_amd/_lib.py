@@ -22,7 +22,7 @@ SYMBOLS = [
     "rrrmc_fetch_results", "rrrmc_last_timing", "rrrmc_iterations_done", "rrrmc_gen_rrg", "rrrmc_gen_ea",
     "rrrmc_gen_couplings_pm1", "rrrmc_set_couplings_dense", "rrrmc_energy_f64", "rrrmc_get_fields_f64",
     "rrrmc_standard_mc_f64", "rrrmc_fetch_results_f64", "rrrmc_gen_sk_gauss",
-    "rrrmc_set_coloring", "rrrmc_colored_sweeps_async",
+    "rrrmc_set_couplings_bits", "rrrmc_gen_sk_binary", "rrrmc_set_coloring", "rrrmc_colored_sweeps_async",
     "rrrmc_ctx_create_quant", "rrrmc_quant_set_field", "rrrmc_rrr_mc_async", "rrrmc_rrr_stats", "rrrmc_rrr_cache",
 ]
 
@@ -111,6 +111,10 @@ def lib():
     L.rrrmc_set_coloring.argtypes = [vp, i32p, C.c_int32]
     L.rrrmc_colored_sweeps_async.restype = C.c_int32
     L.rrrmc_colored_sweeps_async.argtypes = [vp, C.c_double, C.c_int64, C.c_int64]
+    L.rrrmc_set_couplings_bits.restype = C.c_int32
+    L.rrrmc_set_couplings_bits.argtypes = [vp, u64p]
+    L.rrrmc_gen_sk_binary.restype = C.c_int32
+    L.rrrmc_gen_sk_binary.argtypes = [C.c_int64, C.c_uint64, u64p]
     _lib = L
     return L
 

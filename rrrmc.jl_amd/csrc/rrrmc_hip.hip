@@ -95,6 +95,11 @@ struct rrrmc_ctx {
     double* sk_Es = nullptr;
     size_t sk_Es_cap = 0;
     int64_t G8 = 0;
+    // ---- RRRMC_MODEL_SK_BINARY (shares the SK buffers above except the fields / couplings) ----
+    uint32_t* skb_J = nullptr;     // [N][NW]
+    int32_t* skb_lf = nullptr;
+    int32_t* skb_lfl = nullptr;
+    int skb_NW = 0;
     // ---- RRRMC_MODEL_QUANT_RRG ----
     int64_t qM = 0, qNk = 0, qW = 0;      // Trotter slices, spins per slice, 32-bit words per replica
     uint32_t* q_spins = nullptr;
@@ -271,7 +276,23 @@ sk_fn sk_sweep_for(int spt)
     }
 }
 
-int32_t sk_ctx_create(rrrmc_ctx** out, int64_t N, int64_t R, int32_t device, uint32_t replica0)
+typedef void (*skb_fn)(SkbParams);
+skb_fn skb_sweep_for(int spt)
+{
+    switch (spt) {
+        case 1: return skb_sweep_kernel<1>;
+        case 2: return skb_sweep_kernel<2>;
+        case 3: return skb_sweep_kernel<3>;
+        case 4: return skb_sweep_kernel<4>;
+        case 5: return skb_sweep_kernel<5>;
+        case 6: return skb_sweep_kernel<6>;
+        case 7: return skb_sweep_kernel<7>;
+        case 8: return skb_sweep_kernel<8>;
+        default: return nullptr;
+    }
+}
+
+int32_t sk_ctx_create(rrrmc_ctx** out, int32_t model, int64_t N, int64_t R, int32_t device, uint32_t replica0)
 {
     if (N < 1 || R < 1) return fail(nullptr, RRRMC_ERR_INVALID_ARG, "N, R must be >= 1 (given N=%lld R=%lld)", (long long)N, (long long)R);
     if (N > (int64_t)kSkThreads * kSkMaxSPT) return fail(nullptr, RRRMC_ERR_UNSUPPORTED, "N=%lld: the register-resident SK kernel covers N <= %d", (long long)N, kSkThreads * kSkMaxSPT);
@@ -282,7 +303,7 @@ int32_t sk_ctx_create(rrrmc_ctx** out, int64_t N, int64_t R, int32_t device, uin
     if (device < 0 || device >= ndev) return fail(nullptr, RRRMC_ERR_INVALID_ARG, "device %d out of range (0..%d)", device, ndev - 1);
     rrrmc_ctx* ctx = new (std::nothrow) rrrmc_ctx();
     if (!ctx) return fail(nullptr, RRRMC_ERR_NOMEM, "out of host memory");
-    ctx->model = RRRMC_MODEL_SK_NORMAL; ctx->N = N; ctx->K = 0; ctx->R = R;
+    ctx->model = model; ctx->N = N; ctx->K = 0; ctx->R = R;
     ctx->G8 = (R + kSkRB - 1) / kSkRB; ctx->Rpad = ctx->G8 * kSkRB; ctx->G = 0;
     ctx->device = device; ctx->replica0 = replica0;
 #define SK_TRY(expr)                                                                                             \
@@ -299,16 +320,25 @@ int32_t sk_ctx_create(rrrmc_ctx** out, int64_t N, int64_t R, int32_t device, uin
     SK_TRY(hipEventCreate(&ctx->ev_begin));
     SK_TRY(hipEventCreate(&ctx->ev_end));
     const size_t nf = (size_t)ctx->G8 * N * kSkRB;
-    SK_TRY(hipMalloc(&ctx->sk_J, sizeof(double) * N * N));
-    SK_TRY(hipMalloc(&ctx->sk_lf, sizeof(double) * nf));
-    SK_TRY(hipMalloc(&ctx->sk_lfl, sizeof(double) * nf));
+    if (model == RRRMC_MODEL_SK_BINARY) {
+        ctx->skb_NW = (int)(2 * ((N + 63) / 64));
+        SK_TRY(hipMalloc(&ctx->skb_J, sizeof(uint32_t) * N * ctx->skb_NW));
+        SK_TRY(hipMalloc(&ctx->skb_lf, sizeof(int32_t) * nf));
+        SK_TRY(hipMalloc(&ctx->skb_lfl, sizeof(int32_t) * nf));
+        SK_TRY(hipMemset(ctx->skb_lf, 0, sizeof(int32_t) * nf));
+        SK_TRY(hipMemset(ctx->skb_lfl, 0, sizeof(int32_t) * nf));
+    } else {
+        SK_TRY(hipMalloc(&ctx->sk_J, sizeof(double) * N * N));
+        SK_TRY(hipMalloc(&ctx->sk_lf, sizeof(double) * nf));
+        SK_TRY(hipMalloc(&ctx->sk_lfl, sizeof(double) * nf));
+        SK_TRY(hipMemset(ctx->sk_lf, 0, sizeof(double) * nf));
+        SK_TRY(hipMemset(ctx->sk_lfl, 0, sizeof(double) * nf));
+    }
     SK_TRY(hipMalloc(&ctx->sk_move_last, sizeof(int32_t) * ctx->Rpad));
     SK_TRY(hipMalloc(&ctx->sk_spins, (size_t)ctx->G8 * N));
     SK_TRY(hipMalloc(&ctx->sk_E, sizeof(double) * ctx->Rpad));
     SK_TRY(hipMalloc(&ctx->d_acc, sizeof(int64_t) * ctx->Rpad));
     SK_TRY(hipMemset(ctx->sk_spins, 0, (size_t)ctx->G8 * N));
-    SK_TRY(hipMemset(ctx->sk_lf, 0, sizeof(double) * nf));
-    SK_TRY(hipMemset(ctx->sk_lfl, 0, sizeof(double) * nf));
 #undef SK_TRY
     *out = ctx;
     return RRRMC_OK;
@@ -318,6 +348,15 @@ int32_t sk_ctx_create(rrrmc_ctx** out, int64_t N, int64_t R, int32_t device, uin
 int32_t sk_run_energy(rrrmc_ctx* ctx)
 {
     const dim3 grid((unsigned)((ctx->N + 31) / 32), (unsigned)ctx->G8);
+    if (ctx->model == RRRMC_MODEL_SK_BINARY) {
+        hipLaunchKernelGGL(skb_fields_kernel, grid, dim3(256), 0, ctx->stream, ctx->skb_J, ctx->sk_spins, ctx->skb_lf, ctx->skb_lfl,
+                           ctx->sk_move_last, (int)ctx->N, ctx->skb_NW);
+        HIP_TRY(ctx, hipGetLastError());
+        hipLaunchKernelGGL(skb_energy_kernel, dim3((unsigned)((ctx->Rpad + 63) / 64)), dim3(64), 0, ctx->stream, ctx->skb_lf, ctx->sk_spins,
+                           ctx->sk_E, (int)ctx->N, (int)ctx->Rpad, std::sqrt((double)ctx->N));
+        HIP_TRY(ctx, hipGetLastError());
+        return RRRMC_OK;
+    }
     hipLaunchKernelGGL(sk_fields_kernel, grid, dim3(256), 0, ctx->stream, ctx->sk_J, ctx->sk_spins, ctx->sk_lf, ctx->sk_lfl,
                        ctx->sk_move_last, (int)ctx->N);
     HIP_TRY(ctx, hipGetLastError());
@@ -353,6 +392,25 @@ int32_t sk_standard_mc_async(rrrmc_ctx* ctx, double beta, int64_t iters, int64_t
     int32_t rc = sk_run_energy(ctx);          // E = energy(X, C) at the start of every call, RRRMC.jl:95
     if (rc) return rc;
     HIP_TRY(ctx, hipMemsetAsync(ctx->d_acc, 0, sizeof(int64_t) * ctx->Rpad, st));
+    if (ctx->model == RRRMC_MODEL_SK_BINARY) {
+        SkbParams B{};
+        B.Jbits = ctx->skb_J; B.lf = ctx->skb_lf; B.lfl = ctx->skb_lfl; B.move_last = ctx->sk_move_last; B.spins = ctx->sk_spins;
+        B.E_cur = ctx->sk_E; B.acc_cur = ctx->d_acc; B.Es = ctx->sk_Es;
+        B.beta = beta; B.sN = std::sqrt((double)ctx->N); B.g0 = ctx->it_done; B.iters = iters; B.step = step; B.sample0 = 0;
+        B.k0 = (uint32_t)ctx->seed; B.k1 = (uint32_t)(ctx->seed >> 32); B.replica0 = ctx->replica0; B.N = (int)ctx->N; B.NW = ctx->skb_NW;
+        const int sptb = (int)((ctx->N + kSkThreads - 1) / kSkThreads);
+        HIP_TRY(ctx, hipEventRecord(ctx->ev_sweep[0], st));
+        hipLaunchKernelGGL(skb_sweep_for(sptb), dim3((unsigned)ctx->G8), dim3(kSkThreads), 0, st, B);
+        HIP_TRY(ctx, hipGetLastError());
+        HIP_TRY(ctx, hipEventRecord(ctx->ev_sweep[1], st));
+        HIP_TRY(ctx, hipEventRecord(ctx->ev_end, st));
+        ctx->sweep_launches = 1;
+        ctx->nsamp = nsamp;
+        ctx->it_done += (uint64_t)iters;
+        ctx->results_valid = true;
+        ctx->timing_valid = true;
+        return RRRMC_OK;
+    }
     SkParams P{};
     P.J = ctx->sk_J; P.lf = ctx->sk_lf; P.lfl = ctx->sk_lfl; P.move_last = ctx->sk_move_last; P.spins = ctx->sk_spins;
     P.E_cur = ctx->sk_E; P.acc_cur = ctx->d_acc; P.Es = ctx->sk_Es;
@@ -438,8 +496,9 @@ int32_t rrrmc_ctx_create(rrrmc_ctx** out, int32_t model, int64_t N, int64_t K, i
 {
     if (!out) return fail(nullptr, RRRMC_ERR_INVALID_ARG, "out is NULL");
     *out = nullptr;
-    if (model != RRRMC_MODEL_SPARSE_PM1 && model != RRRMC_MODEL_SK_NORMAL) return fail(nullptr, RRRMC_ERR_UNSUPPORTED, "unknown model kind %d", model);
-    if (model == RRRMC_MODEL_SK_NORMAL) return sk_ctx_create(out, N, R, device, replica0);
+    if (model == RRRMC_MODEL_QUANT_RRG) return fail(nullptr, RRRMC_ERR_INVALID_ARG, "RRRMC_MODEL_QUANT_RRG contexts are created with rrrmc_ctx_create_quant");
+    if (model != RRRMC_MODEL_SPARSE_PM1 && model != RRRMC_MODEL_SK_NORMAL && model != RRRMC_MODEL_SK_BINARY) return fail(nullptr, RRRMC_ERR_UNSUPPORTED, "unknown model kind %d", model);
+    if (model == RRRMC_MODEL_SK_NORMAL || model == RRRMC_MODEL_SK_BINARY) return sk_ctx_create(out, model, N, R, device, replica0);
     if (N < 1 || K < 1 || R < 1) return fail(nullptr, RRRMC_ERR_INVALID_ARG, "N, K, R must be >= 1 (given N=%lld K=%lld R=%lld)", (long long)N, (long long)K, (long long)R);
     if (K > kMaxK) return fail(nullptr, RRRMC_ERR_UNSUPPORTED, "K=%lld: the sparse +-J kernels cover K <= %d", (long long)K, kMaxK);
     if (N > (int64_t)INT32_MAX / 8) return fail(nullptr, RRRMC_ERR_UNSUPPORTED, "N=%lld is too large", (long long)N);
@@ -515,7 +574,7 @@ void rrrmc_ctx_destroy(rrrmc_ctx* ctx)
     free_dev(ctx->d_U);
     for (int32_t*& l : ctx->d_color_list) free_dev(l);
     free_dev(ctx->sk_J); free_dev(ctx->sk_lf); free_dev(ctx->sk_lfl); free_dev(ctx->sk_move_last); free_dev(ctx->sk_spins);
-    free_dev(ctx->sk_E); free_dev(ctx->sk_Es);
+    free_dev(ctx->sk_E); free_dev(ctx->sk_Es); free_dev(ctx->skb_J); free_dev(ctx->skb_lf); free_dev(ctx->skb_lfl);
     free_dev(ctx->q_spins); free_dev(ctx->q_cls); free_dev(ctx->q_sv); free_dev(ctx->q_spos); free_dev(ctx->q_st);
     free_dev(ctx->q_T); free_dev(ctx->q_z); free_dev(ctx->q_accrate); free_dev(ctx->q_stats);
     for (int i = 0; i < 2; ++i) { free_dev(ctx->d_slots[i]); free_dev(ctx->d_vecs[i]); }
@@ -601,7 +660,7 @@ int32_t rrrmc_init_spins_random(rrrmc_ctx* ctx)
         ctx->spins_set = true;
         return RRRMC_OK;
     }
-    if (ctx->model == RRRMC_MODEL_SK_NORMAL) {
+    if (ctx->model == RRRMC_MODEL_SK_NORMAL || ctx->model == RRRMC_MODEL_SK_BINARY) {
         const dim3 grid((unsigned)((ctx->N + 255) / 256), (unsigned)ctx->G8);
         hipLaunchKernelGGL(sk_init_spins_kernel, grid, dim3(256), 0, ctx->stream, ctx->sk_spins, (int)ctx->N, ctx->replica0,
                            (uint32_t)ctx->seed, (uint32_t)(ctx->seed >> 32));
@@ -637,7 +696,7 @@ int32_t rrrmc_set_spins(rrrmc_ctx* ctx, const uint64_t* chunks)
         ctx->spins_set = true;
         return RRRMC_OK;
     }
-    if (ctx->model == RRRMC_MODEL_SK_NORMAL) {
+    if (ctx->model == RRRMC_MODEL_SK_NORMAL || ctx->model == RRRMC_MODEL_SK_BINARY) {
         std::vector<uint8_t> b8((size_t)(ctx->G8 * N), 0);
         for (int64_t r = 0; r < ctx->R; ++r)
             for (int64_t x = 0; x < N; ++x)
@@ -675,7 +734,7 @@ int32_t rrrmc_get_spins(rrrmc_ctx* ctx, uint64_t* chunks)
         HIP_TRY(ctx, hipMemcpy(chunks, ctx->q_spins, sizeof(uint64_t) * ctx->R * nch, hipMemcpyDeviceToHost));
         return RRRMC_OK;
     }
-    if (ctx->model == RRRMC_MODEL_SK_NORMAL) {
+    if (ctx->model == RRRMC_MODEL_SK_NORMAL || ctx->model == RRRMC_MODEL_SK_BINARY) {
         std::vector<uint8_t> b8((size_t)(ctx->G8 * N));
         HIP_TRY(ctx, hipSetDevice(ctx->device));
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -720,6 +779,16 @@ int32_t rrrmc_get_fields(rrrmc_ctx* ctx, int64_t* lfields_out)
 {
     int32_t rc = ensure_state(ctx, true);
     if (rc) return rc;
+    if (ctx->model == RRRMC_MODEL_SK_BINARY) {       // the live integer cache, lfields = sqrt(N) * delta_energy (SK.jl:137-140)
+        if (!lfields_out) return fail(ctx, RRRMC_ERR_INVALID_ARG, "lfields_out is NULL");
+        HIP_TRY(ctx, hipSetDevice(ctx->device));
+        std::vector<int32_t> lf((size_t)ctx->G8 * ctx->N * kSkRB);
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        HIP_TRY(ctx, hipMemcpy(lf.data(), ctx->skb_lf, sizeof(int32_t) * lf.size(), hipMemcpyDeviceToHost));
+        for (int64_t r = 0; r < ctx->R; ++r)
+            for (int64_t x = 0; x < ctx->N; ++x) lfields_out[r * ctx->N + x] = lf[((r / kSkRB) * ctx->N + x) * kSkRB + (r % kSkRB)];
+        return RRRMC_OK;
+    }
     if (ctx->model != RRRMC_MODEL_SPARSE_PM1) return fail(ctx, RRRMC_ERR_STATE, "this model's energies are Float64: use the _f64 entry point");
     if (!lfields_out) return fail(ctx, RRRMC_ERR_INVALID_ARG, "lfields_out is NULL");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -742,7 +811,7 @@ int32_t rrrmc_standard_mc_async(rrrmc_ctx* ctx, double beta, int64_t iters, int6
 {
     int32_t rc = ensure_state(ctx, true);
     if (rc) return rc;
-    if (ctx->model == RRRMC_MODEL_SK_NORMAL) return sk_standard_mc_async(ctx, beta, iters, step);
+    if (ctx->model == RRRMC_MODEL_SK_NORMAL || ctx->model == RRRMC_MODEL_SK_BINARY) return sk_standard_mc_async(ctx, beta, iters, step);
     if (ctx->model != RRRMC_MODEL_SPARSE_PM1) return fail(ctx, RRRMC_ERR_UNSUPPORTED, "standardMC is not wired for this model on the device: use rrrmc_rrr_mc_async");
     if (!ctx->lds_mode) return fail(ctx, RRRMC_ERR_UNSUPPORTED, "N=%lld does not fit the LDS-resident random-site kernel: use rrrmc_colored_sweeps_async", (long long)ctx->N);
     ctx->colored_call = false;
@@ -1255,7 +1324,7 @@ int32_t rrrmc_get_fields_f64(rrrmc_ctx* ctx, double* lfields_out)
 {
     int32_t rc = ensure_state(ctx, true);
     if (rc) return rc;
-    if (ctx->model != RRRMC_MODEL_SK_NORMAL) return fail(ctx, RRRMC_ERR_STATE, "this model's fields are integers: use rrrmc_get_fields");
+    if (ctx->model != RRRMC_MODEL_SK_NORMAL) return fail(ctx, RRRMC_ERR_STATE, "this model's fields are integers (or not cached): use rrrmc_get_fields");
     if (!lfields_out) return fail(ctx, RRRMC_ERR_INVALID_ARG, "lfields_out is NULL");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const int64_t N = ctx->N;
@@ -1305,6 +1374,51 @@ int32_t rrrmc_standard_mc_f64(rrrmc_ctx* ctx, double beta, int64_t iters, int64_
     rc = rrrmc_sync(ctx);
     if (rc) return rc;
     return rrrmc_fetch_results_f64(ctx, Es_out, accepted_out);
+}
+
+int32_t rrrmc_set_couplings_bits(rrrmc_ctx* ctx, const uint64_t* Jc)
+{
+    if (!ctx) return RRRMC_ERR_INVALID_ARG;
+    if (ctx->model != RRRMC_MODEL_SK_BINARY) return fail(ctx, RRRMC_ERR_STATE, "rrrmc_set_couplings_bits is for RRRMC_MODEL_SK_BINARY");
+    if (!Jc) return fail(ctx, RRRMC_ERR_INVALID_ARG, "J_chunks is NULL");
+    const int64_t N = ctx->N, nch = (N + 63) / 64;
+    auto bit = [&](int64_t i, int64_t j) { return (int)((Jc[i * nch + (j >> 6)] >> (j & 63)) & 1ull); };
+    for (int64_t i = 0; i < N; ++i) {        // GraphSK(J; check = true), SK.jl:36-46
+        if (bit(i, i)) return fail(ctx, RRRMC_ERR_INVALID_ARG, "diagonal entries of J must be 0, found: J[%lld][%lld] = 1", (long long)i, (long long)i);
+        for (int64_t j = i + 1; j < N; ++j)
+            if (bit(i, j) != bit(j, i)) return fail(ctx, RRRMC_ERR_INVALID_ARG, "J must be symmetric, found: J[%lld][%lld] != J[%lld][%lld]", (long long)i, (long long)j, (long long)j, (long long)i);
+        if (N % 64 && (Jc[i * nch + nch - 1] >> (N % 64))) return fail(ctx, RRRMC_ERR_INVALID_ARG, "row %lld: bits beyond N are set", (long long)i);
+    }
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipMemcpy(ctx->skb_J, Jc, sizeof(uint64_t) * N * nch, hipMemcpyHostToDevice));     // chunk = two little-endian words
+    ctx->graph_set = true;
+    return RRRMC_OK;
+}
+
+int32_t rrrmc_gen_sk_binary(int64_t N, uint64_t seed, uint64_t* Jc)
+{
+    // gen_J, src/graphs/SK.jl:17-26: rows of bitrand(N), zero diagonal, upper triangle mirrored.  SKBITS stream:
+    // bit j of row i = bit (j & 31) of word ((j >> 5) & 3) of ctr (j >> 7, i, 0, TAG_SKBITS)
+    if (!Jc) return fail(nullptr, RRRMC_ERR_INVALID_ARG, "J_chunks_out is NULL");
+    if (N < 1) return fail(nullptr, RRRMC_ERR_INVALID_ARG, "N must be >= 1");
+    const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+    const int64_t nch = (N + 63) / 64;
+    std::memset(Jc, 0, sizeof(uint64_t) * N * nch);
+    for (int64_t i = 0; i < N; ++i)
+        for (int64_t jb = 0; jb < N; jb += 128) {
+            const Philox4 o = philox4x32_10((uint32_t)(jb >> 7), (uint32_t)i, 0u, TAG_SKBITS, k0, k1);
+            for (int64_t j = jb; j < N && j < jb + 128; ++j)
+                if ((o.w[(j >> 5) & 3] >> (j & 31)) & 1u) Jc[i * nch + (j >> 6)] |= 1ull << (j & 63);
+        }
+    for (int64_t i = 0; i < N; ++i) {
+        Jc[i * nch + (i >> 6)] &= ~(1ull << (i & 63));
+        for (int64_t j = i + 1; j < N; ++j) {
+            const uint64_t b = (Jc[i * nch + (j >> 6)] >> (j & 63)) & 1ull;
+            Jc[j * nch + (i >> 6)] = (Jc[j * nch + (i >> 6)] & ~(1ull << (i & 63))) | (b << (i & 63));
+        }
+    }
+    return RRRMC_OK;
 }
 
 int32_t rrrmc_gen_sk_gauss(int64_t N, uint64_t seed, double* J_out)

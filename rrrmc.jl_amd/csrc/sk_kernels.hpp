@@ -251,4 +251,180 @@ __global__ __launch_bounds__(256) void transpose_es_f64_kernel(const double* __r
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Binary SK model GraphSK (src/graphs/SK.jl:28-165): couplings +-1/sqrt(N) bit-packed, integer cache
+// lfields[i] = sqrt(N) * delta_energy(i).  Same workgroup layout as the Gaussian kernel, int32 fields.
+// ---------------------------------------------------------------------------------------------------
+constexpr uint32_t TAG_SKBITS = 10;
+
+struct SkbParams {
+    const uint32_t* Jbits;  // [N][NW] rows of coupling bits (bit j of row i = J_ij in {0,1}; J~ = 2J - 1)
+    int32_t* lf;            // [G][N][kSkRB]
+    int32_t* lfl;           // [G][N][kSkRB]
+    int32_t* move_last;     // [G][kSkRB]
+    uint8_t* spins;         // [G][N]
+    double* E_cur;          // [G * kSkRB]
+    int64_t* acc_cur;
+    double* Es;
+    double beta, sN;
+    uint64_t g0;
+    int64_t iters, step, sample0;
+    uint32_t k0, k1, replica0;
+    int N, NW;
+};
+
+template <int SPT>
+__global__ __launch_bounds__(kSkThreads) void skb_sweep_kernel(SkbParams P)
+{
+    __shared__ int32_t sh_lfi[2][kSkRB];
+    __shared__ uint32_t sh_si[2], sh_acc[2], sh_swap[2];
+    const int tid = threadIdx.x, N = P.N;
+    const int grp = blockIdx.x, Rp = gridDim.x * kSkRB;
+    int32_t lf[SPT][kSkRB], lfl[SPT][kSkRB];
+    uint32_t sb[SPT];
+#pragma unroll
+    for (int q = 0; q < SPT; ++q) {
+        const int j = q * kSkThreads + tid;
+        sb[q] = j < N ? P.spins[(size_t)grp * N + j] : 0u;
+#pragma unroll
+        for (int r = 0; r < kSkRB; ++r) {
+            lf[q][r] = j < N ? P.lf[((size_t)grp * N + j) * kSkRB + r] : 0;
+            lfl[q][r] = j < N ? P.lfl[((size_t)grp * N + j) * kSkRB + r] : 0;
+        }
+    }
+    double E_run = 0.0;
+    int64_t A_run = 0;
+    int32_t mlast = -1;
+    if (tid < kSkRB) { E_run = P.E_cur[grp * kSkRB + tid]; A_run = P.acc_cur[grp * kSkRB + tid]; mlast = P.move_last[grp * kSkRB + tid]; }
+    int64_t ns = P.sample0;
+
+    uint32_t Jq[SPT], Jn[SPT];     // coupling bit of (site, j) for this thread's sites
+    uint32_t site = P.iters > 0 ? site_of(P.k0, P.k1, P.g0 + 1, (uint32_t)N) : 0u;
+#pragma unroll
+    for (int q = 0; q < SPT; ++q) { const int j = q * kSkThreads + tid; Jq[q] = j < N ? (P.Jbits[(size_t)site * P.NW + (j >> 5)] >> (j & 31)) & 1u : 0u; }
+
+    for (int64_t it = 1; it <= P.iters; ++it) {
+        const int b = (int)(it & 1);
+        const uint64_t g = P.g0 + (uint64_t)it;
+        const uint32_t site_n = it < P.iters ? site_of(P.k0, P.k1, g + 1, (uint32_t)N) : site;
+#pragma unroll
+        for (int q = 0; q < SPT; ++q) { const int j = q * kSkThreads + tid; Jn[q] = j < N ? (P.Jbits[(size_t)site_n * P.NW + (j >> 5)] >> (j & 31)) & 1u : 0u; }
+
+        const int qi = (int)(site >> 8), owner = (int)(site & 255u);
+        if (tid == owner) {
+#pragma unroll
+            for (int q = 0; q < SPT; ++q)
+                if (q == qi) {
+#pragma unroll
+                    for (int r = 0; r < kSkRB; ++r) sh_lfi[b][r] = lf[q][r];
+                    sh_si[b] = sb[q];
+                }
+        }
+        __syncthreads();
+        if (tid < 64) {
+            bool acc = false, swp = false;
+            if (tid < kSkRB) {
+                if (it % P.step == 0) {
+                    if (P.Es) P.Es[ns * Rp + grp * kSkRB + tid] = E_run;
+                    ns += 1;
+                }
+                const double dE = (double)sh_lfi[b][tid] / P.sN;            // delta_energy = lfields / sqrt(N), SK.jl:137-140
+                const double x = -P.beta * dE;
+                acc = (x >= 0.0) || (rand53(P.k0, P.k1, g, P.replica0 + (uint32_t)(grp * kSkRB + tid)) < det_exp(x));
+                swp = acc && (mlast == (int32_t)site);
+                if (acc) { E_run += dE; A_run += 1; mlast = (int32_t)site; }
+            }
+            const unsigned long long ba = __ballot(acc), bs = __ballot(swp);
+            if (tid == 0) { sh_acc[b] = (uint32_t)ba; sh_swap[b] = (uint32_t)bs; }
+        }
+        __syncthreads();
+        const uint32_t accm = sh_acc[b], swpm = sh_swap[b], si_old = sh_si[b];
+        const uint32_t normal = accm & ~swpm;
+        const uint32_t si_new = si_old ^ accm;
+        if (swpm) {
+#pragma unroll
+            for (int q = 0; q < SPT; ++q)
+#pragma unroll
+                for (int r = 0; r < kSkRB; ++r)
+                    if ((swpm >> r) & 1u) { const int32_t t = lf[q][r]; lf[q][r] = lfl[q][r]; lfl[q][r] = t; }
+        }
+        if (normal) {
+#pragma unroll
+            for (int q = 0; q < SPT; ++q) {
+                const uint32_t x3 = si_new ^ sb[q] ^ (Jq[q] ? 0xffu : 0u);   // bit r: s_i xor s_j xor J_ij
+#pragma unroll
+                for (int r = 0; r < kSkRB; ++r)
+                    if ((normal >> r) & 1u) {
+                        const int32_t old = lf[q][r];
+                        lfl[q][r] = old;
+                        lf[q][r] = old + (((x3 >> r) & 1u) ? 4 : -4);          // lfj + 8*Jsij - 4, SK.jl:118-121
+                    }
+            }
+            if (tid == owner) {
+#pragma unroll
+                for (int q = 0; q < SPT; ++q)
+                    if (q == qi) {
+#pragma unroll
+                        for (int r = 0; r < kSkRB; ++r)
+                            if ((normal >> r) & 1u) { const int32_t lfm = sh_lfi[b][r]; lfl[q][r] = lfm; lf[q][r] = -lfm; }
+                    }
+            }
+        }
+        if (tid == owner) {
+#pragma unroll
+            for (int q = 0; q < SPT; ++q)
+                if (q == qi) sb[q] ^= accm;
+        }
+        site = site_n;
+#pragma unroll
+        for (int q = 0; q < SPT; ++q) Jq[q] = Jn[q];
+    }
+#pragma unroll
+    for (int q = 0; q < SPT; ++q) {
+        const int j = q * kSkThreads + tid;
+        if (j < N) {
+            P.spins[(size_t)grp * N + j] = (uint8_t)sb[q];
+#pragma unroll
+            for (int r = 0; r < kSkRB; ++r) {
+                P.lf[((size_t)grp * N + j) * kSkRB + r] = lf[q][r];
+                P.lfl[((size_t)grp * N + j) * kSkRB + r] = lfl[q][r];
+            }
+        }
+    }
+    if (tid < kSkRB) { P.E_cur[grp * kSkRB + tid] = E_run; P.acc_cur[grp * kSkRB + tid] = A_run; P.move_last[grp * kSkRB + tid] = mlast; }
+}
+
+// energy(X::GraphSK, C) SK.jl:62-96: lfields[i] = 2(-lf + 2 s_i), lf = -(2 s_i - 1)(N - 1 - 2 sc), sc = popcount(J_i xor s)
+__global__ __launch_bounds__(256) void skb_fields_kernel(const uint32_t* __restrict__ Jbits, const uint8_t* __restrict__ spins,
+                                                         int32_t* __restrict__ lf, int32_t* __restrict__ lfl,
+                                                         int32_t* __restrict__ move_last, int N, int NW)
+{
+    const int grp = blockIdx.y;
+    const int i = blockIdx.x * 32 + (threadIdx.x >> 3), r = threadIdx.x & 7;
+    if (i >= N) return;
+    const uint8_t* sp = spins + (size_t)grp * N;
+    int sc = 0;
+    for (int j = 0; j < N; ++j) sc += (int)(((Jbits[(size_t)i * NW + (j >> 5)] >> (j & 31)) ^ (sp[j] >> r)) & 1u);
+    const int si = (sp[i] >> r) & 1;
+    const int l = -(2 * si - 1) * (N - 1 - 2 * sc);
+    lf[((size_t)grp * N + i) * kSkRB + r] = 2 * (-l + 2 * si);
+    lfl[((size_t)grp * N + i) * kSkRB + r] = 0;
+    if (i == 0) move_last[grp * kSkRB + r] = -1;
+}
+
+// n = -2 sum(s) + sum_i lf_i, lf_i = 2 s_i - lfields_i / 2;  E = (n / 2) / sqrt(N)
+__global__ __launch_bounds__(64) void skb_energy_kernel(const int32_t* __restrict__ lf, const uint8_t* __restrict__ spins,
+                                                        double* __restrict__ E_out, int N, int Rp, double sN)
+{
+    const int rep = blockIdx.x * 64 + threadIdx.x;
+    if (rep >= Rp) return;
+    const int grp = rep / kSkRB, r = rep % kSkRB;
+    long long n = 0;
+    for (int i = 0; i < N; ++i) {
+        const int si = (spins[(size_t)grp * N + i] >> r) & 1;
+        n += -2 * si + (2 * si - lf[((size_t)grp * N + i) * kSkRB + r] / 2);
+    }
+    E_out[rep] = (double)(n / 2) / sN;
+}
+
 }  // namespace rrrmc

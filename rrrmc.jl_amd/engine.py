@@ -9,6 +9,7 @@ from .graphs import DEFAULT_SEED, Config, nchunks
 MODEL_SPARSE_PM1 = 1
 MODEL_SK_NORMAL = 2
 MODEL_QUANT_RRG = 3
+MODEL_SK_BINARY = 4
 
 
 class Engine:
@@ -26,6 +27,8 @@ class Engine:
             if X.model_kind == MODEL_QUANT_RRG:
                 check(lib().rrrmc_set_graph(self._ctx, X.A, X.J), self._ctx)
                 check(lib().rrrmc_quant_set_field(self._ctx, X.beta, X.fourK), self._ctx)
+            elif X.model_kind == MODEL_SK_BINARY:
+                check(lib().rrrmc_set_couplings_bits(self._ctx, X.J.reshape(-1)), self._ctx)
             elif self._f64:
                 check(lib().rrrmc_set_couplings_dense(self._ctx, X.J.reshape(-1)), self._ctx)
             else:
@@ -81,8 +84,9 @@ class Engine:
         return E
 
     def fields(self):
-        lf = np.zeros((self.R, self.X.N), self.X.energy_dtype)
-        check((lib().rrrmc_get_fields_f64 if self._f64 else lib().rrrmc_get_fields)(self._ctx, lf.reshape(-1)), self._ctx)
+        f64 = self.X.model_kind == MODEL_SK_NORMAL        # GraphSK's cache is integer (SK.jl:33)
+        lf = np.zeros((self.R, self.X.N), np.float64 if f64 else np.int64)
+        check((lib().rrrmc_get_fields_f64 if f64 else lib().rrrmc_get_fields)(self._ctx, lf.reshape(-1)), self._ctx)
         return lf
 
     # -- sampling ---------------------------------------------------------------------------------

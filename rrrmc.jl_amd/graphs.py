@@ -143,6 +143,20 @@ class GraphSKNormal:
         return self
 
 
+class GraphSK:
+    """``GraphSK(N)`` — Sherrington-Kirkpatrick model with binary couplings J in {-1/sqrt(N), 1/sqrt(N)}
+    (src/graphs/SK.jl:28-60).  ``J`` holds N BitVector rows ([N, ceil(N/64)] chunks, bit = 1 means +1/sqrt(N)).
+    ``ET = Float64``; the cache is integer (lfields = sqrt(N) * delta_energy, SK.jl:137-140)."""
+    model_kind = 4          # RRRMC_MODEL_SK_BINARY
+    energy_dtype = np.float64
+    K = 0
+
+    def __init__(self, N, seed=DEFAULT_SEED):
+        J = np.zeros((int(N), nchunks(N)), np.uint64)
+        check(lib().rrrmc_gen_sk_binary(N, seed, J.reshape(-1)))
+        self.N, self.J = int(N), J
+
+
 class GraphQuant:
     """``GraphQuant(Nk, M, Γ, β, GraphRRG, Nk, K)`` — quantum Ising model in a transverse field Γ via the Suzuki-Trotter
     transformation: M coupled copies ("slices") of a classical graph (src/graphs/QT.jl:126-170).

@@ -74,3 +74,32 @@ def test_skn_rejects_bad_couplings(pkg):
     with pytest.raises(pkg.RRRMCError) as e:              # checked again at the ABI (SK.jl:189)
         pkg.Engine(X, 8)
     assert e.value.code == 1 and "diagonal" in str(e.value)
+
+
+@pytest.mark.parametrize("N,R,beta,iters,step", [
+    (10, 8, 2.0, 10000, 100),        # test/runtests.jl:66 GraphSK(10)
+    (100, 12, 1.0, 20000, 200),
+    (1024, 16, 0.7, 5000, 500),
+])
+def test_binary_sk_standard_mc(pkg, oracle, N, R, beta, iters, step):
+    """GraphSK (bit-packed +-1/sqrt(N) couplings, integer cache): src/graphs/SK.jl:28-165"""
+    seed = 1234 + N
+    X = pkg.GraphSK(N, seed=seed)
+    assert (X.J == oracle.gen_sk_binary(N, seed)).all()
+    with pkg.Engine(X, R) as eng:
+        eng.seed(seed)
+        eng.init_spins_random()
+        C0 = eng.get_config()
+        E0 = eng.energy()
+        lf0 = eng.fields()
+        Es, acc = eng.standard_mc(beta, iters, step)
+        C1 = eng.get_config()
+        lf1 = eng.fields()
+        E1 = eng.energy()
+    for r in range(R):
+        e0, f0 = oracle.skb_energy(X.J, C0.s[r], want_fields=True)
+        assert E0[r] == e0 and (lf0[r] == f0).all()
+        Es_ref, ch_ref, acc_ref, lf_ref = oracle.standard_mc_skb(X.J, beta, iters, step, seed, C0.s[r], replica=r)
+        assert np.allclose(Es[r], Es_ref, rtol=REL_TOL, atol=1e-9)
+        assert (Es[r] == Es_ref).all() and (C1.s[r] == ch_ref).all() and acc[r] == acc_ref and (lf1[r] == lf_ref).all()
+        assert E1[r] == oracle.skb_energy(X.J, C1.s[r])
