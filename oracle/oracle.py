@@ -89,6 +89,11 @@ def lib():
         L.orc_standard_mc_skb.restype = C.c_int64
         L.orc_standard_mc_skb.argtypes = [C.c_int64, u64p, C.c_double, C.c_int64, C.c_int64, C.c_uint64, C.c_uint64, C.c_uint32,
                                           u64p, f64p, C.POINTER(C.c_int64), C.c_void_p]
+        L.orc_rrr_mc_skn.restype = C.c_int64
+        L.orc_rrr_mc_skn.argtypes = [C.c_int64, f64p, C.c_double, C.c_int64, C.c_int64, C.c_double, C.c_double, C.c_uint64, C.c_uint64,
+                                     C.c_uint32, u64p, f64p, i64p, C.c_void_p, C.POINTER(C.c_double)]
+        L.orc_dyns_test.restype = C.c_int64
+        L.orc_dyns_test.argtypes = [C.c_int64, f64p, C.c_int64, i64p, f64p, C.c_int64, f64p, i64p, C.POINTER(C.c_double), C.c_void_p]
         L.orc_all_delta_e_pm1.restype = C.c_int64
         L.orc_all_delta_e_pm1.argtypes = [C.c_int64, i64p]
         _lib = L
@@ -334,3 +339,36 @@ def standard_mc_skb(J, beta, iters, step, seed, chunks, it0=0, replica=0):
     n = lib().orc_standard_mc_skb(N, np.ascontiguousarray(J).reshape(-1), beta, iters, step, seed, it0, replica, ch, Es,
                                   C.byref(acc), lf.ctypes.data)
     return Es[:n], ch, int(acc.value), lf
+
+
+# ---- continuous-energy RRR path: DynamicSampler + DeltaECacheCont + rrrMC(SingleGraph) on GraphSKNormal ----
+def dyns_test(v, upd_i, upd_x, xs):
+    """Build a DynamicSampler from v, apply setindex!(i, x) updates, then getel for each uniform in xs.
+    Returns (elements (0-based), z, ps)."""
+    v = np.ascontiguousarray(v, np.float64)
+    N = len(v)
+    upd_i = np.ascontiguousarray(upd_i, np.int64); upd_x = np.ascontiguousarray(upd_x, np.float64)
+    xs = np.ascontiguousarray(xs, np.float64)
+    out = np.zeros(max(len(xs), 1), np.int64)
+    z = C.c_double(0)
+    levs = max(int(np.ceil(np.log2(N))), 0) if N > 1 else 0
+    ps = np.zeros(max((1 << levs) - 1, 1), np.float64)
+    lib().orc_dyns_test(N, v, len(upd_i), upd_i if len(upd_i) else np.zeros(1, np.int64), upd_x if len(upd_x) else np.zeros(1),
+                        len(xs), xs if len(xs) else np.zeros(1), out, C.byref(z), ps.ctypes.data)
+    return out[: len(xs)], float(z.value), ps
+
+
+def rrr_mc_skn(J, beta, iters, step, seed, chunks, it0=0, replica=0, staged_thr=0.8, staged_thr_fact=5.0, want_cache=False):
+    """One chain of rrrMC on GraphSKNormal.  Returns (Es, chunks_out, accepted, staged_its[, dEs, z])."""
+    N = J.shape[0]
+    ch = np.array(chunks, np.uint64, copy=True)
+    Es = np.zeros(max(iters // step, 1), np.float64)
+    stats = np.zeros(2, np.int64)
+    dEs = np.zeros(N, np.float64)
+    z = C.c_double(0)
+    n = lib().orc_rrr_mc_skn(N, np.ascontiguousarray(J).reshape(-1), beta, iters, step, staged_thr, staged_thr_fact, seed, it0, replica,
+                             ch, Es, stats, dEs.ctypes.data, C.byref(z))
+    if n < 0:
+        raise AssertionError("Unrecoverable loss of precision detected in the dynamic sampler")
+    out = (Es[:n], ch, int(stats[0]), int(stats[1]))
+    return out + (dEs, float(z.value)) if want_cache else out

@@ -981,3 +981,194 @@ ORC_API int64_t orc_standard_mc_skb(int64_t N, const uint64_t *J, double beta, i
     free(X.lfields); free(X.lfields_last);
     return nsamp;
 }
+
+/* =============================================================================================
+ * Continuous-energy RRR path: DynamicSampler (src/DynamicSamplers.jl:18-176), DeltaECacheCont
+ * (src/DeltaE.jl:297-410) and rrrMC(X::SingleGraph) (src/RRRMC.jl:149-219) on GraphSKNormal.
+ * ============================================================================================= */
+
+/* ---- DynamicSampler: Wong-Easton binary tree of partial sums.  ps is stored level by level (level lev occupies
+ * indices off-1 .. 2*off-2 with off = 2^(lev-1)); node (lev, k) holds the sum of its LEFT subtree.  0-based elements. */
+typedef struct {
+    double *v, *ps, z;
+    int64_t N, N2;
+    int levs;
+    int64_t trefresh;
+} dyns_t;
+
+static void dyns_refresh(dyns_t *d)                                   /* refresh!: DynamicSamplers.jl:84-98 */
+{
+    double z = 0.0;
+    for (int64_t i = 0; i < d->N2; ++i) z += d->v[i];                 /* sum(v), left to right */
+    d->z = z;
+    for (int64_t k = 0; k < d->N2 - 1; ++k) d->ps[k] = 0.0;
+    for (int64_t i = 0; i < d->N; ++i) {
+        int64_t k = 0, u = (int64_t)1 << (d->levs - 1), off = 1;     /* the tinds/tpos table of :54-82, walked directly (:178-197) */
+        for (int lev = 0; lev < d->levs; ++lev) {
+            if ((i & u) == 0) { d->ps[off - 1 + k] += d->v[i]; k *= 2; }
+            else k = 2 * k + 1;
+            u >>= 1; off *= 2;
+        }
+    }
+    d->trefresh = 0;
+}
+static void dyns_init(dyns_t *d, int64_t N)                           /* DynamicSampler(v): :34-51 (v filled by the caller) */
+{
+    d->N = N;
+    d->levs = 0;
+    while (((int64_t)1 << d->levs) < N) d->levs++;                   /* ceil(log2(N)) */
+    d->N2 = (int64_t)1 << d->levs;
+    d->v = (double *)calloc((size_t)d->N2, 8);
+    d->ps = (double *)calloc((size_t)(d->N2 > 1 ? d->N2 - 1 : 1), 8);
+    d->z = 0.0; d->trefresh = 0;
+}
+static void dyns_free(dyns_t *d) { free(d->v); free(d->ps); }
+static void dyns_set(dyns_t *d, int64_t i, double x)                  /* setindex!: :159-176 */
+{
+    int64_t lim = d->N > 100 ? d->N : 100;
+    if (d->trefresh >= lim) dyns_refresh(d);
+    d->trefresh += 1;
+    double dd = x - d->v[i];
+    d->v[i] = x;
+    d->z += dd;
+    int64_t k = 0, u = (int64_t)1 << (d->levs - 1), off = 1;
+    for (int lev = 0; lev < d->levs; ++lev) {
+        if ((i & u) == 0) { d->ps[off - 1 + k] += dd; k *= 2; }
+        else k = 2 * k + 1;
+        u >>= 1; off *= 2;
+    }
+}
+/* getel: :130-152.  Returns the 0-based element, or -1 for the reference's "Unrecoverable loss of precision" error. */
+static int64_t dyns_getel(dyns_t *d, double x)
+{
+    for (;;) {
+        x *= d->z;
+        int64_t k = 0, off = 1;
+        for (int lev = 0; lev < d->levs; ++lev) {
+            double p = d->ps[off - 1 + k];
+            k *= 2;
+            if (x > p) { x -= p; k += 1; }
+            off *= 2;
+        }
+        if (k >= d->N || d->v[k] == 0) {
+            if (!(d->trefresh > 0)) return -1;
+            dyns_refresh(d);
+            continue;                                                  /* `return getel(dynsmp, x)` with the already reduced x */
+        }
+        return k;
+    }
+}
+
+static inline double prior_of(double x) { return x > 0 ? orc_det_exp(-x) : 1.0; }      /* prior: DeltaE.jl:297 */
+
+/* RRR stream for rrrMC(SingleGraph): sub 0 words 0,1 -> rand() of rand_move (getel); sub 1 words 0,1 -> rand() < c */
+
+/*
+ * rrrMC(X::SingleGraph, beta, iters; step, staged_thr = 0.8 for a SimpleGraph, staged_thr_fact): src/RRRMC.jl:149-219
+ * with X = GraphSKNormal and gen_ΔEcache = DeltaECacheCont (DeltaE.jl:299-316).  One chain.
+ * Returns the number of samples, or -1 on the sampler's precision-loss error.
+ */
+ORC_API int64_t orc_rrr_mc_skn(int64_t N, const double *J, double beta, int64_t iters, int64_t step,
+                               double staged_thr, double staged_thr_fact, uint64_t seed, uint64_t it0, uint32_t replica,
+                               uint64_t *chunks, double *Es, int64_t *stats, double *dE_out, double *z_out)
+{
+    skn_t X = {N, J, NULL, NULL, -1};
+    X.lfields = (double *)malloc((size_t)N * 8);
+    X.lfields_last = (double *)malloc((size_t)N * 8);
+    double E = skn_energy(&X, chunks);                                        /* :177 */
+    /* DeltaECacheCont: DeltaE.jl:304-313 */
+    double *dEs = (double *)malloc((size_t)N * 8);
+    dyns_t ds;
+    dyns_init(&ds, N);
+    for (int64_t i = 0; i < N; ++i) { dEs[i] = X.lfields[i]; ds.v[i] = prior_of(beta * dEs[i]); }
+    dyns_refresh(&ds);
+    double *st_dE = (double *)malloc((size_t)N * 8), *st_p = (double *)malloc((size_t)N * 8);
+    int64_t *st_j = (int64_t *)malloc((size_t)N * 8);
+
+    const double lambda = staged_thr_fact / (double)N;
+    int64_t staged_its = 0, accepted = 0, nsamp = 0, bad = 0;
+    double acc_rate = 0.5;
+    for (int64_t it = 1; it <= iters && !bad; ++it) {
+        if (it % step == 0) Es[nsamp++] = E;
+        const uint64_t g = it0 + (uint64_t)it;
+        uint32_t w[4];
+        rrr_draw(seed, g, replica, 0, w);
+        int acc = 0;
+        if (acc_rate < staged_thr) {
+            staged_its += 1;
+            double z = ds.z;                                                  /* step_rrr: :131-138 */
+            int64_t move = dyns_getel(&ds, u53_of(w[0], w[1]));               /* rand_move: DeltaE.jl:327-333 */
+            if (move < 0) { bad = 1; break; }
+            double dE = dEs[move];
+            /* compute_staged!: DeltaE.jl:357-374 */
+            bitflip(chunks, move); skn_update_cache(&X, chunks, move);
+            int64_t ns = 0;
+            st_j[ns] = move; st_dE[ns] = X.lfields[move]; st_p[ns] = prior_of(beta * st_dE[ns]); ns++;
+            for (int64_t j = 0; j < N; ++j) {                                 /* AllButOne(N, move): Common.jl:78-92 */
+                if (j == move) continue;
+                st_j[ns] = j; st_dE[ns] = X.lfields[j]; st_p[ns] = prior_of(beta * st_dE[ns]); ns++;
+            }
+            bitflip(chunks, move); skn_update_cache(&X, chunks, move);
+            /* compute_reverse_probabilities!: DeltaE.jl:345-355 */
+            double zp = ds.z;
+            for (int64_t q = 0; q < ns; ++q) zp += st_p[q] - ds.v[st_j[q]];
+            if (zp < 2.2250738585072014e-308) zp = 2.2250738585072014e-308;   /* clamp(z, floatmin, N) */
+            if (zp > (double)N) zp = (double)N;
+            double c = z / zp;
+            rrr_draw(seed, g, replica, 1, w);
+            if (u53_of(w[0], w[1]) < c) {                                     /* :192-198 */
+                bitflip(chunks, move); skn_update_cache(&X, chunks, move);
+                for (int64_t q = 0; q < ns; ++q) { dEs[st_j[q]] = st_dE[q]; dyns_set(&ds, st_j[q], st_p[q]); }     /* apply_staged! */
+                E += dE;
+                accepted += 1;
+                acc = 1;
+            }
+        } else {
+            int64_t move = dyns_getel(&ds, u53_of(w[0], w[1]));
+            if (move < 0) { bad = 1; break; }
+            double dE = dEs[move];
+            double c = 0.0;
+            for (int pass = 0; pass < 2; ++pass) {                            /* apply_move!: DeltaE.jl:379-410 */
+                bitflip(chunks, move); skn_update_cache(&X, chunks, move);
+                double z = ds.z;
+                dEs[move] = X.lfields[move];
+                dyns_set(&ds, move, prior_of(beta * dEs[move]));
+                for (int64_t j = 0; j < N; ++j) {
+                    if (j == move) continue;
+                    dEs[j] = X.lfields[j];
+                    dyns_set(&ds, j, prior_of(beta * dEs[j]));
+                }
+                double cc = z / ds.z;
+                if (pass == 1) break;
+                c = cc;
+                rrr_draw(seed, g, replica, 1, w);
+                if (u53_of(w[0], w[1]) < c) { E += dE; accepted += 1; acc = 1; break; }     /* :202-208 */
+            }
+        }
+        acc_rate = acc_rate * (1 - lambda) + (double)acc * lambda;
+    }
+    if (stats) { stats[0] = accepted; stats[1] = staged_its; }
+    if (dE_out) memcpy(dE_out, dEs, (size_t)N * 8);
+    if (z_out) *z_out = ds.z;
+    free(dEs); free(st_dE); free(st_p); free(st_j);
+    dyns_free(&ds);
+    free(X.lfields); free(X.lfields_last);
+    return bad ? -1 : nsamp;
+}
+
+/* DynamicSampler unit access for the tests: build from v, apply updates (i, x), sample with the given uniforms */
+ORC_API int64_t orc_dyns_test(int64_t N, const double *v, int64_t nupd, const int64_t *upd_i, const double *upd_x,
+                              int64_t nsmp, const double *xs, int64_t *out, double *z_out, double *ps_out)
+{
+    dyns_t d;
+    dyns_init(&d, N);
+    for (int64_t i = 0; i < N; ++i) d.v[i] = v[i];
+    dyns_refresh(&d);
+    for (int64_t q = 0; q < nupd; ++q) dyns_set(&d, upd_i[q], upd_x[q]);
+    for (int64_t q = 0; q < nsmp; ++q) out[q] = dyns_getel(&d, xs[q]);
+    if (z_out) *z_out = d.z;
+    if (ps_out) memcpy(ps_out, d.ps, (size_t)(d.N2 - 1) * 8);
+    int64_t n2 = d.N2;
+    dyns_free(&d);
+    return n2;
+}

@@ -302,4 +302,264 @@ __global__ __launch_bounds__(256) void quant_init_spins_kernel(uint32_t* __restr
     spins[(size_t)blockIdx.y * W + w] = word;
 }
 
+// ---------------------------------------------------------------------------------------------------
+// rrrMC(X::SingleGraph) (src/RRRMC.jl:149-219) on GraphSKNormal with the continuous-energy cache DeltaECacheCont
+// (src/DeltaE.jl:297-410) over a DynamicSampler (src/DynamicSamplers.jl:18-176, Wong-Easton tree of partial sums).
+// Every iteration touches all N fields and re-weights all N leaves (every spin is a neighbour of every other), and the
+// reference's running sums are order dependent, so each replica is one THREAD that walks j = 0..N-1 in the reference's
+// order; arrays are replica-interleaved ([index][replica]) so that the lock-step walks of a wave coalesce.
+// ---------------------------------------------------------------------------------------------------
+struct RrrSkParams {
+    const double* J;         // [N][N]
+    double* lfA;             // [N][Rp]  one of the two field arrays (lfields / lfields_last swap by index, SK.jl:247-250)
+    double* lfB;             // [N][Rp]
+    double* v;               // [N2][Rp]  sampler weights
+    double* ps;              // [N2-1][Rp] partial sums (level by level)
+    double* dEs;             // [N][Rp]
+    double* st_dE;           // [N][Rp]  staged values
+    double* st_p;            // [N][Rp]
+    uint32_t* spins;         // [W][Rp]
+    double* E_cur;           // [Rp]
+    int64_t* stats;          // [Rp][2]
+    int32_t* status;         // [Rp]   1 = the sampler's "unrecoverable loss of precision" error
+    double* Es;              // [nsamples][Rp]
+    double* z_out;           // [Rp]
+    double beta, staged_thr, lambda;
+    uint64_t g0;
+    int64_t iters, step;
+    uint32_t k0, k1, replica0;
+    int N, N2, levs, W, R, Rp;
+};
+
+struct SkChain {             // one replica's view
+    const RrrSkParams* P;
+    int r;
+    int cur;                 // which array currently is `lfields`
+    int move_last;
+    double z;
+    long long trefresh;
+    __device__ __forceinline__ double* lf() const { return (cur ? P->lfB : P->lfA) + r; }
+    __device__ __forceinline__ double* lfl() const { return (cur ? P->lfA : P->lfB) + r; }
+    __device__ __forceinline__ int sbit(int x) const { return (int)((P->spins[(size_t)(x >> 5) * P->Rp + r] >> (x & 31)) & 1u); }
+    __device__ __forceinline__ void sflip(int x) { P->spins[(size_t)(x >> 5) * P->Rp + r] ^= 1u << (x & 31); }
+
+    // spinflip!(X, C, move) = bit flip + update_cache! (SK.jl:239-276)
+    __device__ void flip(int move)
+    {
+        sflip(move);
+        if (move_last == move) { cur ^= 1; return; }
+        const int Rp = P->Rp, N = P->N;
+        double* a = lf();
+        double* b = lfl();
+        const double* Ji = P->J + (size_t)move * N;
+        const int si = sbit(move);
+        const double lfm = a[(size_t)move * Rp];
+        for (int j = 0; j < N; ++j) {
+            const double Js = (si ^ sbit(j)) ? -Ji[j] : Ji[j];
+            const double lfj = a[(size_t)j * Rp];
+            b[(size_t)j * Rp] = lfj;
+            a[(size_t)j * Rp] = lfj + 4 * Js;
+        }
+        b[(size_t)move * Rp] = lfm;
+        a[(size_t)move * Rp] = -lfm;
+        move_last = move;
+    }
+    // refresh!: DynamicSamplers.jl:84-98
+    __device__ void refresh()
+    {
+        const int Rp = P->Rp;
+        double* v = P->v + r;
+        double* ps = P->ps + r;
+        double zz = 0.0;
+        for (int i = 0; i < P->N2; ++i) zz += v[(size_t)i * Rp];
+        z = zz;
+        for (int k = 0; k < P->N2 - 1; ++k) ps[(size_t)k * Rp] = 0.0;
+        for (int i = 0; i < P->N; ++i) {
+            const double vi = v[(size_t)i * Rp];
+            int k = 0, u = 1 << (P->levs - 1), off = 1;
+            for (int lev = 0; lev < P->levs; ++lev) {
+                if ((i & u) == 0) { ps[(size_t)(off - 1 + k) * Rp] += vi; k *= 2; }
+                else k = 2 * k + 1;
+                u >>= 1; off *= 2;
+            }
+        }
+        trefresh = 0;
+    }
+    // setindex!: DynamicSamplers.jl:159-176
+    __device__ void set(int i, double x)
+    {
+        const int Rp = P->Rp;
+        if (trefresh >= (P->N > 100 ? P->N : 100)) refresh();
+        trefresh += 1;
+        double* v = P->v + r;
+        double* ps = P->ps + r;
+        const double d = x - v[(size_t)i * Rp];
+        v[(size_t)i * Rp] = x;
+        z += d;
+        int k = 0, u = 1 << (P->levs - 1), off = 1;
+        for (int lev = 0; lev < P->levs; ++lev) {
+            if ((i & u) == 0) { ps[(size_t)(off - 1 + k) * Rp] += d; k *= 2; }
+            else k = 2 * k + 1;
+            u >>= 1; off *= 2;
+        }
+    }
+    // getel: DynamicSamplers.jl:130-152; -1 = unrecoverable loss of precision
+    __device__ int getel(double x)
+    {
+        const int Rp = P->Rp;
+        for (;;) {
+            x *= z;
+            int k = 0, off = 1;
+            for (int lev = 0; lev < P->levs; ++lev) {
+                const double p = P->ps[(size_t)(off - 1 + k) * Rp + r];
+                k *= 2;
+                if (x > p) { x -= p; k += 1; }
+                off *= 2;
+            }
+            if (k >= P->N || P->v[(size_t)k * Rp + r] == 0) {
+                if (!(trefresh > 0)) return -1;
+                refresh();
+                continue;
+            }
+            return k;
+        }
+    }
+};
+
+__device__ __forceinline__ double prior_of(double x) { return x > 0 ? det_exp(-x) : 1.0; }      // DeltaE.jl:297
+
+// energy(X, C) (SK.jl:212-237) + DeltaECacheCont construction (DeltaE.jl:304-313) + the sampling loop
+__global__ __launch_bounds__(kRrrThreads) void rrr_skn_kernel(RrrSkParams P)
+{
+    const int r = blockIdx.x * kRrrThreads + threadIdx.x;
+    if (r >= P.R) return;
+    const int N = P.N, Rp = P.Rp;
+    SkChain c;
+    c.P = &P; c.r = r; c.cur = 0; c.move_last = -1; c.z = 0.0; c.trefresh = 0;
+    // energy: sequential sums in the reference's order
+    double n = 0.0;
+    for (int i = 0; i < N; ++i) {
+        const double* Ji = P.J + (size_t)i * N;
+        const int si = c.sbit(i);
+        double lfh = 0.0;
+        for (int j = 0; j < N; ++j) lfh += (si ^ c.sbit(j)) ? -Ji[j] : Ji[j];
+        P.lfA[(size_t)i * Rp + r] = 2 * lfh;
+        P.lfB[(size_t)i * Rp + r] = 0.0;
+        n -= lfh;
+    }
+    double E = n / 2;
+    for (int i = 0; i < P.N2; ++i) P.v[(size_t)i * Rp + r] = 0.0;
+    for (int i = 0; i < N; ++i) {
+        const double dE = P.lfA[(size_t)i * Rp + r];
+        P.dEs[(size_t)i * Rp + r] = dE;
+        P.v[(size_t)i * Rp + r] = prior_of(P.beta * dE);
+    }
+    c.refresh();
+
+    const uint32_t rep = P.replica0 + (uint32_t)r;
+    double acc_rate = 0.5;
+    long long accepted = 0, staged_its = 0, ns = 0;
+    int bad = 0;
+    for (long long it = 1; it <= P.iters && !bad; ++it) {
+        if (it % P.step == 0) { P.Es[(size_t)ns * Rp + r] = E; ns += 1; }
+        const uint64_t g = P.g0 + (uint64_t)it;
+        const Philox4 o = philox4x32_10((uint32_t)g, (uint32_t)(g >> 32), rep, TAG_RRR, P.k0, P.k1);
+        const double u0 = (double)((((uint64_t)o.w[0] << 32) | o.w[1]) >> 11) * 0x1.0p-53;
+        const Philox4 o2 = philox4x32_10((uint32_t)g, (uint32_t)(g >> 32), rep, TAG_RRR | (1u << 8), P.k0, P.k1);
+        const double u1 = (double)((((uint64_t)o2.w[0] << 32) | o2.w[1]) >> 11) * 0x1.0p-53;
+        bool acc = false;
+        if (acc_rate < P.staged_thr) {
+            staged_its += 1;
+            const double z = c.z;
+            const int move = c.getel(u0);
+            if (move < 0) { bad = 1; break; }
+            const double dE = P.dEs[(size_t)move * Rp + r];
+            // compute_staged!: flip, record (dE', p') for move then every other spin in order, flip back
+            c.flip(move);
+            {
+                const double* a = c.lf();
+                for (int j = 0; j < N; ++j) {
+                    const double d = a[(size_t)j * Rp];
+                    P.st_dE[(size_t)j * Rp + r] = d;
+                    P.st_p[(size_t)j * Rp + r] = prior_of(P.beta * d);
+                }
+            }
+            c.flip(move);
+            // compute_reverse_probabilities!: z' = z + sum (p' - v) in staged order (move first, then AllButOne)
+            double zp = c.z;
+            zp += P.st_p[(size_t)move * Rp + r] - P.v[(size_t)move * Rp + r];
+            for (int j = 0; j < N; ++j) {
+                if (j == move) continue;
+                zp += P.st_p[(size_t)j * Rp + r] - P.v[(size_t)j * Rp + r];
+            }
+            if (zp < 2.2250738585072014e-308) zp = 2.2250738585072014e-308;
+            if (zp > (double)N) zp = (double)N;
+            const double cc = z / zp;
+            if (u1 < cc) {
+                c.flip(move);
+                P.dEs[(size_t)move * Rp + r] = P.st_dE[(size_t)move * Rp + r];
+                c.set(move, P.st_p[(size_t)move * Rp + r]);
+                for (int j = 0; j < N; ++j) {
+                    if (j == move) continue;
+                    P.dEs[(size_t)j * Rp + r] = P.st_dE[(size_t)j * Rp + r];
+                    c.set(j, P.st_p[(size_t)j * Rp + r]);
+                }
+                E += dE;
+                accepted += 1;
+                acc = true;
+            }
+        } else {
+            const int move = c.getel(u0);
+            if (move < 0) { bad = 1; break; }
+            const double dE = P.dEs[(size_t)move * Rp + r];
+            for (int pass = 0; pass < 2; ++pass) {
+                c.flip(move);
+                const double z = c.z;
+                const double* a = c.lf();
+                {
+                    const double d = a[(size_t)move * Rp];
+                    P.dEs[(size_t)move * Rp + r] = d;
+                    c.set(move, prior_of(P.beta * d));
+                }
+                for (int j = 0; j < N; ++j) {
+                    if (j == move) continue;
+                    const double d = a[(size_t)j * Rp];
+                    P.dEs[(size_t)j * Rp + r] = d;
+                    c.set(j, prior_of(P.beta * d));
+                }
+                const double cc = z / c.z;
+                if (pass == 1) break;
+                if (u1 < cc) { E += dE; accepted += 1; acc = true; break; }
+            }
+        }
+        acc_rate = acc_rate * (1 - P.lambda) + (acc ? 1.0 : 0.0) * P.lambda;
+    }
+    P.E_cur[r] = E;
+    P.stats[(size_t)r * 2] = accepted;
+    P.stats[(size_t)r * 2 + 1] = staged_its;
+    P.status[r] = bad;
+    P.z_out[r] = c.z;
+}
+
+// layout changes between the SK sweep kernel's spins ([G8][N] bytes, bit = replica & 7) and this kernel's ([W][Rp] words)
+__global__ __launch_bounds__(256) void rrsk_spins_in_kernel(const uint8_t* __restrict__ sk_spins, uint32_t* __restrict__ spins, int N, int /*W*/, int Rp)
+{
+    const int r = blockIdx.x * 256 + threadIdx.x, w = blockIdx.y;
+    if (r >= Rp) return;
+    uint32_t word = 0u;
+    for (int b = 0; b < 32; ++b) {
+        const int x = 32 * w + b;
+        if (x < N) word |= (uint32_t)((sk_spins[(size_t)(r >> 3) * N + x] >> (r & 7)) & 1u) << b;
+    }
+    spins[(size_t)w * Rp + r] = word;
+}
+__global__ __launch_bounds__(256) void rrsk_spins_out_kernel(const uint32_t* __restrict__ spins, uint8_t* __restrict__ sk_spins, int N, int Rp)
+{
+    const int x = blockIdx.x * 256 + threadIdx.x, g8 = blockIdx.y;
+    if (x >= N) return;
+    uint32_t byte = 0u;
+    for (int b = 0; b < 8; ++b) byte |= ((spins[(size_t)(x >> 5) * Rp + g8 * 8 + b] >> (x & 31)) & 1u) << b;
+    sk_spins[(size_t)g8 * N + x] = (uint8_t)byte;
+}
+
 }  // namespace rrrmc

@@ -112,6 +112,11 @@ struct rrrmc_ctx {
     double* q_accrate = nullptr;
     int64_t* q_stats = nullptr;
     double last_fourK = 0.0, last_beta = 0.0;
+    bool last_call_rrr = false;
+    // ---- rrrMC(SingleGraph) on RRRMC_MODEL_SK_NORMAL: DeltaECacheCont + DynamicSampler state (allocated on first use) ----
+    double* rs_buf = nullptr;      // lfA, lfB, v, ps, dEs, st_dE, st_p, z_out
+    uint32_t* rs_spins = nullptr;
+    int32_t* rs_status = nullptr;
 
     std::string err;
 };
@@ -374,6 +379,7 @@ int32_t sk_standard_mc_async(rrrmc_ctx* ctx, double beta, int64_t iters, int64_t
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     ctx->results_valid = false;
     ctx->timing_valid = false;
+    ctx->last_call_rrr = false;
     const int64_t nsamp = iters / step;
     const size_t es_need = (size_t)(nsamp > 0 ? nsamp : 1) * ctx->Rpad;
     if (es_need > ctx->sk_Es_cap) {
@@ -475,9 +481,80 @@ int32_t quant_run_init(rrrmc_ctx* ctx, double beta, double fourK)
     return RRRMC_OK;
 }
 
+
+// rrrMC(X::SingleGraph) on GraphSKNormal (RRRMC.jl:149-219): thread-per-replica kernel over interleaved arrays
+int32_t sk_rrr_mc_async(rrrmc_ctx* ctx, double beta, int64_t iters, int64_t step, double staged_thr, double staged_thr_fact)
+{
+    if (iters < 0) return fail(ctx, RRRMC_ERR_INVALID_ARG, "iters must be >= 0, given %lld", (long long)iters);
+    if (step < 1) return fail(ctx, RRRMC_ERR_INVALID_ARG, "step must be >= 1, given %lld", (long long)step);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    ctx->results_valid = false;
+    ctx->timing_valid = false;
+    const int64_t N = ctx->N, Rp = ctx->Rpad;
+    int levs = 0;
+    while (((int64_t)1 << levs) < N) ++levs;
+    const int64_t N2 = (int64_t)1 << levs, W = (N + 31) / 32;
+    const size_t per = (size_t)Rp;
+    const size_t ndbl = per * (size_t)(5 * N + 2 * N2 + 1);
+    if (!ctx->rs_buf) {
+        HIP_TRY(ctx, hipMalloc(&ctx->rs_buf, sizeof(double) * ndbl));
+        HIP_TRY(ctx, hipMalloc(&ctx->rs_spins, sizeof(uint32_t) * W * per));
+        HIP_TRY(ctx, hipMalloc(&ctx->rs_status, sizeof(int32_t) * per));
+        HIP_TRY(ctx, hipMalloc(&ctx->q_stats, sizeof(int64_t) * per * 2));
+    }
+    const int64_t nsamp = iters / step;
+    const size_t es_need = (size_t)(nsamp > 0 ? nsamp : 1) * Rp;
+    if (es_need > ctx->sk_Es_cap) {
+        free_dev(ctx->sk_Es);
+        ctx->sk_Es_cap = 0;
+        HIP_TRY(ctx, hipMalloc(&ctx->sk_Es, sizeof(double) * es_need));
+        ctx->sk_Es_cap = es_need;
+    }
+    while (ctx->ev_sweep.size() < 2) {
+        hipEvent_t e;
+        HIP_TRY(ctx, hipEventCreate(&e));
+        ctx->ev_sweep.push_back(e);
+    }
+    hipStream_t st = ctx->stream;
+    RrrSkParams P{};
+    double* b = ctx->rs_buf;
+    P.J = ctx->sk_J;
+    P.lfA = b; b += per * N;
+    P.lfB = b; b += per * N;
+    P.v = b; b += per * N2;
+    P.ps = b; b += per * N2;
+    P.dEs = b; b += per * N;
+    P.st_dE = b; b += per * N;
+    P.st_p = b; b += per * N;
+    P.z_out = b;
+    P.spins = ctx->rs_spins; P.E_cur = ctx->sk_E; P.stats = ctx->q_stats; P.status = ctx->rs_status; P.Es = ctx->sk_Es;
+    P.beta = beta; P.staged_thr = staged_thr; P.lambda = staged_thr_fact / (double)N;
+    P.g0 = ctx->it_done; P.iters = iters; P.step = step;
+    P.k0 = (uint32_t)ctx->seed; P.k1 = (uint32_t)(ctx->seed >> 32); P.replica0 = ctx->replica0;
+    P.N = (int)N; P.N2 = (int)N2; P.levs = levs; P.W = (int)W; P.R = (int)ctx->R; P.Rp = (int)Rp;
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_begin, st));
+    hipLaunchKernelGGL(rrsk_spins_in_kernel, dim3((unsigned)((Rp + 255) / 256), (unsigned)W), dim3(256), 0, st, ctx->sk_spins, ctx->rs_spins, (int)N, (int)W, (int)Rp);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_sweep[0], st));
+    hipLaunchKernelGGL(rrr_skn_kernel, dim3((unsigned)((ctx->R + kRrrThreads - 1) / kRrrThreads)), dim3(kRrrThreads), 0, st, P);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_sweep[1], st));
+    hipLaunchKernelGGL(rrsk_spins_out_kernel, dim3((unsigned)((N + 255) / 256), (unsigned)ctx->G8), dim3(256), 0, st, ctx->rs_spins, ctx->sk_spins, (int)N, (int)Rp);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_end, st));
+    ctx->sweep_launches = 1;
+    ctx->nsamp = nsamp;
+    ctx->it_done += (uint64_t)iters;
+    ctx->results_valid = true;
+    ctx->timing_valid = true;
+    ctx->last_call_rrr = true;
+    return RRRMC_OK;
+}
+
 }  // namespace
 
 extern "C" {
+
 
 
 
@@ -577,6 +654,7 @@ void rrrmc_ctx_destroy(rrrmc_ctx* ctx)
     free_dev(ctx->sk_E); free_dev(ctx->sk_Es); free_dev(ctx->skb_J); free_dev(ctx->skb_lf); free_dev(ctx->skb_lfl);
     free_dev(ctx->q_spins); free_dev(ctx->q_cls); free_dev(ctx->q_sv); free_dev(ctx->q_spos); free_dev(ctx->q_st);
     free_dev(ctx->q_T); free_dev(ctx->q_z); free_dev(ctx->q_accrate); free_dev(ctx->q_stats);
+    free_dev(ctx->rs_buf); free_dev(ctx->rs_spins); free_dev(ctx->rs_status);
     for (int i = 0; i < 2; ++i) { free_dev(ctx->d_slots[i]); free_dev(ctx->d_vecs[i]); }
     if (ctx->plan_stream) { (void)hipStreamSynchronize(ctx->plan_stream); (void)hipStreamDestroy(ctx->plan_stream); }
     if (ctx->ev_upload) (void)hipEventDestroy(ctx->ev_upload);
@@ -971,6 +1049,12 @@ int32_t rrrmc_sync(rrrmc_ctx* ctx)
     if (!ctx) return RRRMC_ERR_INVALID_ARG;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->last_call_rrr && ctx->model == RRRMC_MODEL_SK_NORMAL && ctx->rs_status) {
+        std::vector<int32_t> stt((size_t)ctx->Rpad);
+        HIP_TRY(ctx, hipMemcpy(stt.data(), ctx->rs_status, sizeof(int32_t) * stt.size(), hipMemcpyDeviceToHost));
+        for (int64_t r = 0; r < ctx->R; ++r)
+            if (stt[r]) return fail(ctx, RRRMC_ERR_STATE, "replica %lld: Unrecoverable loss of precision detected in the dynamic sampler", (long long)r);   // DynamicSamplers.jl:147
+    }
     return RRRMC_OK;
 }
 
@@ -1200,8 +1284,9 @@ int32_t rrrmc_rrr_mc_async(rrrmc_ctx* ctx, double beta, double fourK, int64_t it
 {
     int32_t rc = ensure_state(ctx, true);
     if (rc) return rc;
-    if (ctx->model != RRRMC_MODEL_QUANT_RRG) return fail(ctx, RRRMC_ERR_UNSUPPORTED, "rrrMC is wired for RRRMC_MODEL_QUANT_RRG only");
-    if (!std::isfinite(beta)) return fail(ctx, RRRMC_ERR_INVALID_ARG, "beta must be finite, given: %g", beta);       // RRRMC.jl:230
+    if (!std::isfinite(beta)) return fail(ctx, RRRMC_ERR_INVALID_ARG, "beta must be finite, given: %g", beta);       // RRRMC.jl:230, :166
+    if (ctx->model == RRRMC_MODEL_SK_NORMAL) return sk_rrr_mc_async(ctx, beta, iters, step, staged_thr, staged_thr_fact);
+    if (ctx->model != RRRMC_MODEL_QUANT_RRG) return fail(ctx, RRRMC_ERR_UNSUPPORTED, "rrrMC is wired for RRRMC_MODEL_QUANT_RRG and RRRMC_MODEL_SK_NORMAL");
     if (!(fourK > 0.0) || !std::isfinite(fourK)) return fail(ctx, RRRMC_ERR_INVALID_ARG, "fourK must be positive and finite, given: %g", fourK);
     if (iters < 0) return fail(ctx, RRRMC_ERR_INVALID_ARG, "iters must be >= 0, given %lld", (long long)iters);
     if (step < 1) return fail(ctx, RRRMC_ERR_INVALID_ARG, "step must be >= 1, given %lld", (long long)step);
@@ -1241,6 +1326,7 @@ int32_t rrrmc_rrr_mc_async(rrrmc_ctx* ctx, double beta, double fourK, int64_t it
     ctx->it_done += (uint64_t)iters;
     ctx->results_valid = true;
     ctx->timing_valid = true;
+    ctx->last_call_rrr = true;
     return RRRMC_OK;
 }
 
@@ -1257,7 +1343,7 @@ int32_t rrrmc_quant_set_field(rrrmc_ctx* ctx, double beta, double fourK)
 int32_t rrrmc_rrr_stats(rrrmc_ctx* ctx, int64_t* staged_iters_out)
 {
     if (!ctx) return RRRMC_ERR_INVALID_ARG;
-    if (ctx->model != RRRMC_MODEL_QUANT_RRG || !ctx->results_valid) return fail(ctx, RRRMC_ERR_STATE, "no rrrMC call has been made");
+    if (!ctx->last_call_rrr || !ctx->results_valid) return fail(ctx, RRRMC_ERR_STATE, "no rrrMC call has been made");
     if (!staged_iters_out) return fail(ctx, RRRMC_ERR_INVALID_ARG, "staged_iters_out is NULL");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -1343,7 +1429,7 @@ int32_t rrrmc_fetch_results_f64(rrrmc_ctx* ctx, double* Es_out, int64_t* accepte
     if (!ctx->results_valid) return fail(ctx, RRRMC_ERR_STATE, "no sampling call has been made");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    if (accepted_out && ctx->model == RRRMC_MODEL_QUANT_RRG) {
+    if (accepted_out && ctx->last_call_rrr) {
         std::vector<int64_t> st((size_t)ctx->R * 2);
         HIP_TRY(ctx, hipMemcpy(st.data(), ctx->q_stats, sizeof(int64_t) * st.size(), hipMemcpyDeviceToHost));
         for (int64_t r = 0; r < ctx->R; ++r) accepted_out[r] = st[2 * r];

@@ -132,11 +132,13 @@ class Engine:
         return self.fetch_results()[0]
 
     # -- reduced-rejection-rate sampler (GraphQuant) ------------------------------------------------
-    def rrr_mc(self, beta, iters, step=1, staged_thr=0.5, staged_thr_fact=5.0, want_energies=True):
+    def rrr_mc(self, beta, iters, step=1, staged_thr=None, staged_thr_fact=5.0, want_energies=True):
         """rrrMC(X::DoubleGraph, β, iters; step, staged_thr, staged_thr_fact) (src/RRRMC.jl:221-290).
         Returns (Es[R, iters // step], accepted[R], staged_iters[R])."""
-        check(lib().rrrmc_rrr_mc_async(self._ctx, float(beta), float(self.X.fourK), int(iters), int(step), float(staged_thr),
-                                       float(staged_thr_fact)), self._ctx)
+        if staged_thr is None:          # RRRMC.jl:162-164 (SimpleGraph 0.8, DiscrGraph 0.5) and :226 (DoubleGraph 0.5)
+            staged_thr = 0.8 if self.X.model_kind == MODEL_SK_NORMAL else 0.5
+        check(lib().rrrmc_rrr_mc_async(self._ctx, float(beta), float(getattr(self.X, "fourK", 0.0)), int(iters), int(step),
+                                       float(staged_thr), float(staged_thr_fact)), self._ctx)
         self._last = (int(iters), int(step))
         self.sync()
         Es, acc = self.fetch_results(want_energies)
@@ -158,10 +160,11 @@ class Engine:
         return t.value, s.value, n.value
 
 
-def rrrMC(X, beta, iters, *, seed=DEFAULT_SEED, step=1, C0=None, staged_thr=0.5, staged_thr_fact=5.0, quiet=False,
+def rrrMC(X, beta, iters, *, seed=DEFAULT_SEED, step=1, C0=None, staged_thr=None, staged_thr_fact=5.0, quiet=False,
           replicas=None, device=0, replica0=0, engine=None):
     """``rrrMC(X::DoubleGraph, β, iters; seed, step, C0, staged_thr, staged_thr_fact, quiet)`` (src/RRRMC.jl:221-290) for a
-    batch of replicas of a ``GraphQuant``.  Returns ``(Es, C)`` like ``standardMC``."""
+    batch of replicas of a ``GraphQuant``, or ``rrrMC(X::SingleGraph, ...)`` (RRRMC.jl:149-219) for a ``GraphSKNormal``
+    (continuous-energy cache DeltaECacheCont over a DynamicSampler).  Returns ``(Es, C)`` like ``standardMC``."""
     import math
     if not math.isfinite(beta):
         raise ValueError("β must be finite, given: %r" % beta)                     # RRRMC.jl:230

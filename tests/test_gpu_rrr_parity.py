@@ -55,3 +55,28 @@ def test_rrrMC_front_end(pkg, oracle):
         assert (Es[r] == ref[0]).all() and (C.s[r] == ref[1]).all()
     with pytest.raises(ValueError):
         pkg.GraphQuant(pkg.GraphRRG(16, 3, seed=seed), 2, 0.7, 1.5)       # "M must be greater than 2", QT.jl:47
+
+
+@pytest.mark.parametrize("N,R,beta,iters,step,thr", [
+    (10, 8, 2.0, 10000, 100, None),     # test/runtests.jl:67,144-157 GraphSKNormal(10): default staged_thr (0.8 for a SimpleGraph)
+    (10, 8, 2.0, 10000, 100, 0.0),
+    (10, 8, 2.0, 10000, 100, 1.0),
+    (100, 20, 1.0, 3000, 50, None),     # N not a power of two: the sampler tree is padded to 128 leaves
+    (256, 70, 1.5, 600, 100, None),
+])
+def test_rrr_skn_continuous_cache(pkg, oracle, N, R, beta, iters, step, thr):
+    """rrrMC(X::SingleGraph) with DeltaECacheCont + DynamicSampler (src/DeltaE.jl:297-410, src/DynamicSamplers.jl) on GraphSKNormal."""
+    seed = 555 + N
+    X = pkg.GraphSKNormal(N, seed=seed)
+    with pkg.Engine(X, R) as eng:
+        eng.seed(seed)
+        eng.init_spins_random()
+        C0 = eng.get_config()
+        Es, acc, staged = eng.rrr_mc(beta, iters, step, staged_thr=thr)
+        C1 = eng.get_config()
+        E1 = eng.energy()
+    for r in range(R):
+        ref = oracle.rrr_mc_skn(X.J, beta, iters, step, seed, C0.s[r], replica=r, staged_thr=0.8 if thr is None else thr)
+        assert np.allclose(Es[r], ref[0], rtol=1e-6, atol=1e-9)          # north-star tolerance
+        assert (Es[r] == ref[0]).all() and (C1.s[r] == ref[1]).all() and acc[r] == ref[2] and staged[r] == ref[3]
+        assert E1[r] == oracle.skn_energy(X.J, C1.s[r])
