@@ -60,11 +60,19 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     dist = None
+    # RRRMC_BENCH_BACKEND=gloo is a debugging aid only: it lets several ranks share one GPU (RCCL refuses that) so that the
+    # multi-rank code path can be exercised on a 1-GPU box; the driver's multi-GPU runs use the default, RCCL ("nccl").
+    backend = os.environ.get("RRRMC_BENCH_BACKEND", "nccl")
     if world > 1:
         import torch
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            local_rank = local_rank % max(torch.cuda.device_count(), 1)
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group(backend)
     n_gpus = world
 
     entry.build() if rank == 0 and not os.path.exists(os.path.join(ROOT, "rrrmc.jl_amd", "lib", "librrrmc_hip.so")) else None
@@ -99,7 +107,7 @@ def main():
     dt = time.perf_counter() - t0
     if dist is not None:
         import torch
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
@@ -108,7 +116,7 @@ def main():
     e_mean = float(Es[:, -1].mean()) / N_SITES if Es.shape[1] else float("nan")
     if dist is not None:   # the only exchange of the job: gather the per-replica observables over RCCL
         import torch
-        dev = torch.device("cuda", local_rank)
+        dev = torch.device("cuda", local_rank) if backend == "nccl" else None
         E_last = pkg.gather_replica_major(Es[:, -1].copy(), R * world, dist, device=dev)
         acc_all = pkg.gather_replica_major(acc, R * world, dist, device=dev)
         acc_rate = float(acc_all.mean()) / args.iters
