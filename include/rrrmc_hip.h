@@ -165,6 +165,12 @@ RRRMC_API int32_t rrrmc_quant_set_field(rrrmc_ctx *ctx, double beta, double four
 RRRMC_API int32_t rrrmc_rrr_mc_async(rrrmc_ctx *ctx, double beta, double fourK, int64_t iters, int64_t step,
                                      double staged_thr, double staged_thr_fact);
 RRRMC_API int32_t rrrmc_rrr_stats(rrrmc_ctx *ctx, int64_t *staged_iters_out);
+/* rrrmc_rrr_mc_async also serves rrrMC(X::SingleGraph, ...) (src/RRRMC.jl:149-219): on RRRMC_MODEL_SPARSE_PM1 with the
+ * integer-level DeltaECache{Int,L} (fourK ignored, results through rrrmc_fetch_results), on RRRMC_MODEL_SK_NORMAL with
+ * DeltaECacheCont + DynamicSampler (src/DeltaE.jl:297-410, src/DynamicSamplers.jl; results through rrrmc_fetch_results_f64).
+ * bklMC(X, beta, iters; step) (src/RRRMC.jl:311-359) on RRRMC_MODEL_SPARSE_PM1: rejection-free Bortz-Kalos-Lebowitz sampler;
+ * `iters` counts the skipped rejections too; rrrmc_rrr_stats then returns the number of moves actually made ("true it"). */
+RRRMC_API int32_t rrrmc_bkl_mc_async(rrrmc_ctx *ctx, double beta, int64_t iters, int64_t step);
 /* parity/debug view of the move-selection cache after the last rrrMC call: pos_out[R * N] = class of every spin
  * (DeltaECache.pos, 0-based a + 2*up), sizes_out[R * 4] = |class k| (DeltaE.jl:63-73). */
 RRRMC_API int32_t rrrmc_rrr_cache(rrrmc_ctx *ctx, int8_t *pos_out, int32_t *sizes_out);

@@ -94,6 +94,9 @@ def lib():
                                      C.c_uint32, u64p, f64p, i64p, C.c_void_p, C.POINTER(C.c_double)]
         L.orc_dyns_test.restype = C.c_int64
         L.orc_dyns_test.argtypes = [C.c_int64, f64p, C.c_int64, i64p, f64p, C.c_int64, f64p, i64p, C.POINTER(C.c_double), C.c_void_p]
+        L.orc_rrr_bkl_sparse.restype = C.c_int64
+        L.orc_rrr_bkl_sparse.argtypes = [C.c_int, C.c_int, C.c_int64, C.c_int64, i32p, i32p, C.c_double, C.c_int64, C.c_int64,
+                                         C.c_double, C.c_double, C.c_uint64, C.c_uint64, C.c_uint32, u64p, i64p, i64p, C.c_void_p]
         L.orc_all_delta_e_pm1.restype = C.c_int64
         L.orc_all_delta_e_pm1.argtypes = [C.c_int64, i64p]
         _lib = L
@@ -372,3 +375,21 @@ def rrr_mc_skn(J, beta, iters, step, seed, chunks, it0=0, replica=0, staged_thr=
         raise AssertionError("Unrecoverable loss of precision detected in the dynamic sampler")
     out = (Es[:n], ch, int(stats[0]), int(stats[1]))
     return out + (dEs, float(z.value)) if want_cache else out
+
+
+# ---- rrrMC(SingleGraph) / bklMC on the DiscrGraphs GraphRRG / GraphEA --------------------------------
+def rrr_sparse(A, J, beta, iters, step, seed, chunks, it0=0, replica=0, staged_thr=0.5, staged_thr_fact=5.0, form="rrg", bkl=False,
+               want_cache=False):
+    """One chain of rrrMC (or bklMC with bkl=True).  Returns (Es, chunks_out, accepted, staged_its_or_moves, iters_done[, pos, sizes])."""
+    N, K = A.shape
+    ch = np.array(chunks, np.uint64, copy=True)
+    Es = np.zeros(max(iters // step, 1) + 1, np.int64)
+    stats = np.zeros(3, np.int64)
+    L = len(all_delta_e_pm1(K))
+    cache = np.zeros(N + 2 * L, np.int32)
+    n = lib().orc_rrr_bkl_sparse(1 if bkl else 0, FORM[form], N, K, A, J, beta, iters, step, staged_thr, staged_thr_fact, seed, it0, replica,
+                                 ch, Es, stats, cache.ctypes.data if want_cache else None)
+    if n < 0:
+        raise AssertionError("DeltaECache / ArraySet consistency check failed")
+    out = (Es[:n], ch, int(stats[0]), int(stats[1]), int(stats[2]))
+    return out + (cache[:N].copy(), cache[N:].copy()) if want_cache else out

@@ -179,4 +179,27 @@ static inline double orc_det_exp(double x)
     return __builtin_ldexp(p, (int)k);
 }
 
+/* log1p(y) for -1 < y <= 0 with a fixed operation order (used by rand_skip of bklMC, src/DeltaE.jl:141-144): u = 1 + y,
+ * log(u) by reduction to m in (sqrt(1/2), sqrt(2)] and the atanh series in s = (m-1)/(m+1), plus the classic
+ * correction ((u - 1) - y) / u for the rounding of 1 + y.  Relative error ~3e-16; same code on the device. */
+static inline double orc_det_log1p(double y)
+{
+    static const double LN2_HI = 6.93147180369123816490e-01, LN2_LO = 1.90821492927058770002e-10;
+    double u = 1.0 + y;
+    if (u == 1.0) return y;
+    if (!(u > 0.0)) return -__builtin_inf();
+    union { double d; uint64_t b; } v; v.d = u;
+    int e = (int)((v.b >> 52) & 0x7ff) - 1023;              /* u is normal here (u >= 2^-53) */
+    v.b = (v.b & ((1ull << 52) - 1)) | (1023ull << 52);     /* m in [1, 2) */
+    double m = v.d;
+    if (m > 1.4142135623730951) { m = m * 0.5; e += 1; }
+    double s = (m - 1.0) / (m + 1.0);
+    double s2 = s * s;
+    double p = 1.0 / 21.0;
+    for (int n = 19; n >= 1; n -= 2) p = p * s2 + 1.0 / (double)n;
+    double lg = 2.0 * s * p;
+    double r = (double)e * LN2_HI + (lg + (double)e * LN2_LO);
+    return r - ((u - 1.0) - y) / u;
+}
+
 #endif

@@ -1172,3 +1172,215 @@ ORC_API int64_t orc_dyns_test(int64_t N, const double *v, int64_t nupd, const in
     dyns_free(&d);
     return n2;
 }
+
+/* =============================================================================================
+ * rrrMC(X::SingleGraph) (src/RRRMC.jl:149-219) and bklMC (src/RRRMC.jl:311-359) on the DiscrGraphs GraphRRG / GraphEA
+ * with DeltaECache{Int, L} (src/DeltaE.jl:63-295): SURVEY.md §8(f) rank 1.
+ * ============================================================================================= */
+enum { SL_MAX = 4, SK_MAX = 8 };
+typedef struct {
+    int64_t N;
+    int L;
+    int64_t dElist[SL_MAX];
+    double ft[SL_MAX], T[2 * SL_MAX], Tp[2 * SL_MAX], z, zp;
+    aset_t as[2 * SL_MAX];
+    int8_t *pos;
+    int64_t staged[SK_MAX + 1][3];
+    int nstaged;
+} decs_t;
+
+static inline int decs_findk(const decs_t *c, int64_t dE) { int64_t a = dE < 0 ? -dE : dE; for (int k = 0; k < c->L; ++k) if (a == c->dElist[k]) return k; return -1; }
+static inline double decs_f(const decs_t *c, int k) { return k >= c->L ? c->ft[k - c->L] : 1.0; }
+static inline int decs_class(const decs_t *c, int64_t dE, int sbit) { return decs_findk(c, dE) + c->L * (dE > 0 || (dE == 0 && sbit == 1)); }
+
+static void decs_init(decs_t *c, sparse_t *X, const uint64_t *s, double beta)                 /* DeltaE.jl:74-103 */
+{
+    c->N = X->N;
+    int64_t tmp[SK_MAX + 1];
+    c->L = (int)orc_all_delta_e_pm1(X->K, tmp);                    /* allΔE: RRG.jl:262-281, EA.jl:293 */
+    for (int k = 0; k < c->L; ++k) c->dElist[k] = tmp[k];
+    for (int k = 0; k < 2 * c->L; ++k) aset_init(&c->as[k], c->N);
+    c->pos = (int8_t *)calloc((size_t)c->N, 1);
+    for (int64_t i = 0; i < c->N; ++i) {
+        int k = decs_class(c, sparse_delta_energy(X, i), spin_bit(s, i));
+        c->pos[i] = (int8_t)k;
+        aset_push(&c->as[k], (int32_t)i);
+    }
+    for (int k = 0; k < c->L; ++k) c->ft[k] = orc_det_exp(-beta * (double)c->dElist[k]);
+    c->z = 0.0;
+    for (int k = 0; k < 2 * c->L; ++k) { double x = (double)c->as[k].t * decs_f(c, k); c->z += x; c->T[k] = x; }
+    c->zp = c->z;
+    c->nstaged = 0;
+}
+static void decs_free(decs_t *c) { for (int k = 0; k < 2 * c->L; ++k) aset_free(&c->as[k]); free(c->pos); }
+
+static int64_t decs_rand_move(const decs_t *c, uint64_t seed, uint64_t g, uint32_t replica, int64_t *dE)      /* DeltaE.jl:146-167 */
+{
+    uint32_t w[4];
+    rrr_draw(seed, g, replica, 0, w);
+    double r = u53_of(w[0], w[1]) * c->z;
+    int k = 0, K2 = 2 * c->L;
+    double cT = 0.0;
+    for (k = 0; k < K2; ++k) { cT += c->T[k]; if (r < cT) break; }
+    if (k == K2) k = K2 - 1;
+    if (!(r < cT)) while (c->T[k] == 0) k -= 1;
+    *dE = k < c->L ? -c->dElist[k] : c->dElist[k - c->L];
+    uint64_t u = ((uint64_t)w[2] << 32) | w[3];
+    return c->as[k].v[(int64_t)orc_mulhi64(u, (uint64_t)c->as[k].t)];
+}
+/* neighbors(X, i) = uA[i]: RRG.jl:133,261 (all K for +-J), EA.jl:158,292 (repeats removed; A is sorted) */
+static int sparse_neighbors(const sparse_t *X, int64_t i, int64_t *out)
+{
+    int n = 0;
+    const int32_t *Ax = X->A + i * X->K;
+    for (int64_t k = 0; k < X->K; ++k) { if (k > 0 && Ax[k] == Ax[k - 1]) continue; out[n++] = Ax[k]; }
+    return n;
+}
+static void sparse_spinflip(sparse_t *X, uint64_t *s, int64_t i) { bitflip(s, i); sparse_update_cache(X, s, i); }
+
+static void decs_compute_staged(decs_t *c, sparse_t *X, uint64_t *s, int64_t i)                 /* DeltaE.jl:202-230 */
+{
+    sparse_spinflip(X, s, i);
+    c->nstaged = 0;
+    int64_t nb[SK_MAX];
+    int nn = sparse_neighbors(X, i, nb);
+    for (int q = 0; q < nn; ++q) {
+        int64_t j = nb[q];
+        int k0 = c->pos[j], k1 = decs_class(c, sparse_delta_energy(X, j), spin_bit(s, j));
+        if (k0 == k1) continue;
+        c->staged[c->nstaged][0] = j; c->staged[c->nstaged][1] = k0; c->staged[c->nstaged][2] = k1; c->nstaged++;
+    }
+    int k0 = c->pos[i], k1 = k0 >= c->L ? k0 - c->L : k0 + c->L;
+    c->staged[c->nstaged][0] = i; c->staged[c->nstaged][1] = k0; c->staged[c->nstaged][2] = k1; c->nstaged++;
+    sparse_spinflip(X, s, i);
+}
+static double decs_reverse(decs_t *c)                                                           /* DeltaE.jl:184-200 */
+{
+    double zp = c->z;
+    memcpy(c->Tp, c->T, sizeof c->T);
+    for (int q = 0; q < c->nstaged; ++q) {
+        int k0 = (int)c->staged[q][1], k1 = (int)c->staged[q][2];
+        double f0 = decs_f(c, k0), f1 = decs_f(c, k1);
+        c->Tp[k0] -= f0; c->Tp[k1] += f1; zp += f1 - f0;
+    }
+    c->zp = zp;
+    return zp;
+}
+static void decs_apply_staged(decs_t *c)                                                        /* DeltaE.jl:169-182 */
+{
+    for (int q = 0; q < c->nstaged; ++q) {
+        int32_t j = (int32_t)c->staged[q][0];
+        int k0 = (int)c->staged[q][1], k1 = (int)c->staged[q][2];
+        aset_delete(&c->as[k0], j); aset_push(&c->as[k1], j); c->pos[j] = (int8_t)k1;
+    }
+    double tmp[2 * SL_MAX];
+    memcpy(tmp, c->T, sizeof tmp); memcpy(c->T, c->Tp, sizeof tmp); memcpy(c->Tp, tmp, sizeof tmp);
+    c->z = c->zp;
+}
+static double decs_apply_move(decs_t *c, sparse_t *X, uint64_t *s, int64_t move)                /* DeltaE.jl:232-295 */
+{
+    sparse_spinflip(X, s, move);
+    double zp = c->z;
+    int64_t nb[SK_MAX];
+    int nn = sparse_neighbors(X, move, nb);
+    for (int q = 0; q <= nn; ++q) {
+        int32_t j = (int32_t)(q < nn ? nb[q] : move);
+        int k0 = c->pos[j];
+        int k1 = q < nn ? decs_class(c, sparse_delta_energy(X, j), spin_bit(s, j)) : (k0 >= c->L ? k0 - c->L : k0 + c->L);
+        if (q < nn && k0 == k1) continue;
+        double f0 = decs_f(c, k0), f1 = decs_f(c, k1);
+        c->T[k0] -= f0; c->T[k1] += f1; zp += f1 - f0;
+        aset_delete(&c->as[k0], j); aset_push(&c->as[k1], j); c->pos[j] = (int8_t)k1;
+    }
+    double cc = c->z / zp;
+    c->z = zp;
+    return cc;
+}
+static int decs_consistent(const decs_t *c, const sparse_t *X, const uint64_t *s)               /* DeltaE.jl:120-136 */
+{
+    int64_t total = 0;
+    for (int k = 0; k < 2 * c->L; ++k) {
+        total += c->as[k].t;
+        for (int64_t p = 0; p < c->as[k].t; ++p) { int32_t x = c->as[k].v[p]; if (c->as[k].pos[x] != p + 1 || c->pos[x] != k) return 0; }
+    }
+    for (int64_t i = 0; i < c->N; ++i) if (decs_class(c, sparse_delta_energy(X, i), spin_bit(s, i)) != c->pos[i]) return 0;
+    return total == c->N;
+}
+
+/* mode 0: rrrMC(X::SingleGraph) RRRMC.jl:149-219 (staged_thr = 0.5 for a DiscrGraph); mode 1: bklMC RRRMC.jl:311-359.
+ * Streams: RRR sub 0 = rand_move, sub 1 = `rand() < c`, sub 2 = rand_skip; g counts iterations (rrrMC) or moves (bklMC).
+ * stats = [accepted, staged_its or true moves, iterations done]. */
+ORC_API int64_t orc_rrr_bkl_sparse(int mode, int form, int64_t N, int64_t K, const int32_t *A, const int32_t *J,
+                                   double beta, int64_t iters, int64_t step, double staged_thr, double staged_thr_fact,
+                                   uint64_t seed, uint64_t it0, uint32_t replica,
+                                   uint64_t *chunks, int64_t *Es, int64_t *stats, int32_t *cache_out)
+{
+    sparse_t X = {N, K, A, J, NULL, NULL, -1, form};
+    X.lfields = (int64_t *)malloc((size_t)N * 8);
+    X.lfields_last = (int64_t *)malloc((size_t)N * 8);
+    int64_t E = sparse_energy(&X, chunks);
+    decs_t c;
+    decs_init(&c, &X, chunks, beta);
+    int64_t accepted = 0, staged_its = 0, nsamp = 0, it = 0;
+    if (mode == 0) {
+        const double lambda = staged_thr_fact / (double)N;
+        double acc_rate = 0.5;
+        for (it = 1; it <= iters; ++it) {
+            if (it % step == 0) Es[nsamp++] = E;
+            const uint64_t g = it0 + (uint64_t)it;
+            int acc = 0;
+            uint32_t w[4];
+            if (acc_rate < staged_thr) {
+                staged_its += 1;
+                double z = c.z;
+                int64_t dE, move = decs_rand_move(&c, seed, g, replica, &dE);
+                decs_compute_staged(&c, &X, chunks, move);
+                double cc = z / decs_reverse(&c);
+                rrr_draw(seed, g, replica, 1, w);
+                if (u53_of(w[0], w[1]) < cc) { sparse_spinflip(&X, chunks, move); decs_apply_staged(&c); E += dE; accepted++; acc = 1; }
+            } else {
+                int64_t dE, move = decs_rand_move(&c, seed, g, replica, &dE);
+                double cc = decs_apply_move(&c, &X, chunks, move);
+                rrr_draw(seed, g, replica, 1, w);
+                if (u53_of(w[0], w[1]) < cc) { E += dE; accepted++; acc = 1; }
+                else decs_apply_move(&c, &X, chunks, move);
+            }
+            acc_rate = acc_rate * (1 - lambda) + (double)acc * lambda;
+        }
+        it = iters;
+    } else {
+        int64_t nextstep = step, m = 0;
+        it = 0;
+        while (it < iters) {
+            m += 1;
+            const uint64_t g = it0 + (uint64_t)m;
+            uint32_t w[4];
+            rrr_draw(seed, g, replica, 2, w);
+            /* rand_skip: floor(Int, log1p(-rand()) / log1p(-z / N)), DeltaE.jl:141-144 */
+            double skipf = __builtin_floor(orc_det_log1p(-u53_of(w[0], w[1])) / orc_det_log1p(-c.z / (double)N));
+            int64_t skip = skipf >= 9.0e18 ? (int64_t)9.0e18 : (int64_t)skipf;
+            int64_t dE, move = decs_rand_move(&c, seed, g, replica, &dE);
+            int out = 0;
+            while (it + skip + 1 >= nextstep) {
+                Es[nsamp++] = E;
+                nextstep += step;
+                if (nextstep > iters) { out = 1; break; }
+            }
+            if (out) break;
+            decs_apply_move(&c, &X, chunks, move);
+            it += skip + 1;
+            E += dE;
+            accepted += 1;
+        }
+        staged_its = accepted;
+    }
+    if (stats) { stats[0] = accepted; stats[1] = staged_its; stats[2] = it; }
+    if (cache_out) {
+        for (int64_t i = 0; i < N; ++i) cache_out[i] = c.pos[i];
+        for (int k = 0; k < 2 * c.L; ++k) cache_out[N + k] = (int32_t)c.as[k].t;
+    }
+    int ok = decs_consistent(&c, &X, chunks);
+    decs_free(&c);
+    free(X.lfields); free(X.lfields_last);
+    return ok ? nsamp : -1;
+}

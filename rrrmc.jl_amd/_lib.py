@@ -23,7 +23,7 @@ SYMBOLS = [
     "rrrmc_gen_couplings_pm1", "rrrmc_set_couplings_dense", "rrrmc_energy_f64", "rrrmc_get_fields_f64",
     "rrrmc_standard_mc_f64", "rrrmc_fetch_results_f64", "rrrmc_gen_sk_gauss",
     "rrrmc_set_couplings_bits", "rrrmc_gen_sk_binary", "rrrmc_set_coloring", "rrrmc_colored_sweeps_async",
-    "rrrmc_ctx_create_quant", "rrrmc_quant_set_field", "rrrmc_rrr_mc_async", "rrrmc_rrr_stats", "rrrmc_rrr_cache",
+    "rrrmc_ctx_create_quant", "rrrmc_quant_set_field", "rrrmc_rrr_mc_async", "rrrmc_rrr_stats", "rrrmc_rrr_cache", "rrrmc_bkl_mc_async",
 ]
 
 
@@ -115,6 +115,8 @@ def lib():
     L.rrrmc_set_couplings_bits.argtypes = [vp, u64p]
     L.rrrmc_gen_sk_binary.restype = C.c_int32
     L.rrrmc_gen_sk_binary.argtypes = [C.c_int64, C.c_uint64, u64p]
+    L.rrrmc_bkl_mc_async.restype = C.c_int32
+    L.rrrmc_bkl_mc_async.argtypes = [vp, C.c_double, C.c_int64, C.c_int64]
     _lib = L
     return L
 

@@ -562,4 +562,223 @@ __global__ __launch_bounds__(256) void rrsk_spins_out_kernel(const uint32_t* __r
     sk_spins[(size_t)g8 * N + x] = (uint8_t)byte;
 }
 
+// ---------------------------------------------------------------------------------------------------
+// rrrMC(X::SingleGraph) (src/RRRMC.jl:149-219) and bklMC (src/RRRMC.jl:311-359) on the DiscrGraphs GraphRRG / GraphEA with the
+// integer-level DeltaECache{Int,L} (src/DeltaE.jl:63-295): SURVEY.md §8(f) rank 1.  One thread per replica, as above.
+// ---------------------------------------------------------------------------------------------------
+constexpr int kSLmax = 4;          // levels of allΔE for K <= 7
+struct RrrSparseParams {
+    const int32_t* A;        // [N][K]
+    const int8_t* J;         // [N][K]
+    uint32_t* spins;         // [R][W]   replica-contiguous words
+    uint8_t* cls;            // [R][N]
+    uint16_t* sv;            // [R][2L][N]
+    uint16_t* spos;          // [R][N]
+    int32_t* E_cur;          // [Rpad]
+    int64_t* acc_cur;        // [Rpad]
+    int64_t* stats;          // [R][3]   accepted, staged iterations / true moves, iterations done
+    int32_t* Es;             // [nsamples][Rpad]
+    double ft[kSLmax];
+    double beta, staged_thr, lambda;
+    uint64_t g0;
+    int64_t iters, step;
+    uint32_t k0, k1, replica0;
+    int N, K, L, W, R, Rpad, mode;      // mode 0 = rrrMC, 1 = bklMC
+};
+
+struct SparseChain {
+    const RrrSparseParams* P;
+    uint32_t* sp; uint8_t* cls; uint16_t* sv; uint16_t* spos;
+    int t[2 * kSLmax];
+    double T[2 * kSLmax], z;
+    __device__ __forceinline__ int sbit(int x) const { return (int)((sp[x >> 5] >> (x & 31)) & 1u); }
+    __device__ __forceinline__ void sflip(int x) { sp[x >> 5] ^= 1u << (x & 31); }
+    // delta_energy (RRG.jl:236-244 / EA.jl:266-275) recomputed from the spins: 2 sigma_i sum_k J_ik sigma_k
+    __device__ __forceinline__ int dE(int i) const
+    {
+        const int si = sbit(i);
+        int acc = 0;
+        for (int q = 0; q < P->K; ++q) {
+            const int sy = sbit(P->A[(size_t)i * P->K + q]);
+            acc += (si == sy) ? (int)P->J[(size_t)i * P->K + q] : -(int)P->J[(size_t)i * P->K + q];
+        }
+        return 2 * acc;
+    }
+    __device__ __forceinline__ int klass(int i) const      // a + L*up, DeltaE.jl:80-86; allΔE(+-J) = 2m, m = K&1, K&1 + 2, ...
+    {
+        const int d = dE(i), a = ((d < 0 ? -d : d) / 2 - (P->K & 1)) / 2;
+        const int up = d > 0 || (d == 0 && sbit(i) == 1);
+        return a + P->L * up;
+    }
+    __device__ __forceinline__ double f(int k) const { return k >= P->L ? P->ft[k - P->L] : 1.0; }
+    __device__ __forceinline__ void set_move(int j, int k0, int k1)
+    {
+        uint16_t* v0 = sv + (size_t)k0 * P->N;
+        uint16_t* v1 = sv + (size_t)k1 * P->N;
+        const int p = spos[j], last = v0[t[k0] - 1];
+        v0[p] = (uint16_t)last; spos[last] = (uint16_t)p; t[k0] -= 1;
+        v1[t[k1]] = (uint16_t)j; spos[j] = (uint16_t)t[k1]; t[k1] += 1;
+        cls[j] = (uint8_t)k1;
+    }
+    // apply_move!: DeltaE.jl:232-295; returns c = z / z'
+    __device__ double apply_move(int move)
+    {
+        sflip(move);
+        double zp = z;
+        const int32_t* Ax = P->A + (size_t)move * P->K;
+        for (int q = 0; q <= P->K; ++q) {
+            if (q < P->K && q > 0 && Ax[q] == Ax[q - 1]) continue;        // uA: repeats removed (EA.jl:158)
+            const int j = q < P->K ? Ax[q] : move;
+            const int k0 = cls[j];
+            const int k1 = q < P->K ? klass(j) : (k0 >= P->L ? k0 - P->L : k0 + P->L);
+            if (q < P->K && k0 == k1) continue;
+            const double f0 = f(k0), f1 = f(k1);
+            T[k0] -= f0; T[k1] += f1; zp += f1 - f0;
+            set_move(j, k0, k1);
+        }
+        const double cc = z / zp;
+        z = zp;
+        return cc;
+    }
+};
+
+__global__ __launch_bounds__(kRrrThreads) void rrr_sparse_kernel(RrrSparseParams P)
+{
+    const int r = blockIdx.x * kRrrThreads + threadIdx.x;
+    if (r >= P.R) return;
+    const int N = P.N, L = P.L, K2 = 2 * P.L;
+    SparseChain c;
+    c.P = &P;
+    c.sp = P.spins + (size_t)r * P.W; c.cls = P.cls + (size_t)r * N; c.sv = P.sv + (size_t)r * K2 * N; c.spos = P.spos + (size_t)r * N;
+    // energy(X, C) and gen_ΔEcache in site order (RRRMC.jl:177-178, DeltaE.jl:74-103)
+    long long n = 0;
+    for (int k = 0; k < K2; ++k) c.t[k] = 0;
+    for (int i = 0; i < N; ++i) {
+        n -= c.dE(i) / 2;                       // lf_x = -sum J sx sy
+        const int k = c.klass(i);
+        c.cls[i] = (uint8_t)k;
+        c.sv[(size_t)k * N + c.t[k]] = (uint16_t)i;
+        c.spos[i] = (uint16_t)c.t[k];
+        c.t[k] += 1;
+    }
+    long long E = n / 2;
+    c.z = 0.0;
+    for (int k = 0; k < 2 * kSLmax; ++k) c.T[k] = 0.0;
+    for (int k = 0; k < K2; ++k) { const double x = (double)c.t[k] * c.f(k); c.z += x; c.T[k] = x; }
+
+    const uint32_t rep = P.replica0 + (uint32_t)r;
+    long long accepted = 0, staged_its = 0, ns = 0, itdone = 0;
+    if (P.mode == 0) {
+        double acc_rate = 0.5;
+        for (long long it = 1; it <= P.iters; ++it) {
+            if (it % P.step == 0) { P.Es[(size_t)ns * P.Rpad + r] = (int32_t)E; ns += 1; }
+            const uint64_t g = P.g0 + (uint64_t)it;
+            const Philox4 o = philox4x32_10((uint32_t)g, (uint32_t)(g >> 32), rep, TAG_RRR, P.k0, P.k1);
+            const Philox4 o2 = philox4x32_10((uint32_t)g, (uint32_t)(g >> 32), rep, TAG_RRR | (1u << 8), P.k0, P.k1);
+            const double u1 = (double)((((uint64_t)o2.w[0] << 32) | o2.w[1]) >> 11) * 0x1.0p-53;
+            // rand_move
+            const double rr = (double)((((uint64_t)o.w[0] << 32) | o.w[1]) >> 11) * 0x1.0p-53 * c.z;
+            int k = 0;
+            double cT = 0.0;
+            for (k = 0; k < K2; ++k) { cT += c.T[k]; if (rr < cT) break; }
+            if (k == K2) k = K2 - 1;
+            if (!(rr < cT)) while (c.T[k] == 0) k -= 1;
+            const int a = k < L ? k : k - L;
+            const int dE = (k < L ? -1 : 1) * 2 * (2 * a + (P.K & 1));
+            const int move = c.sv[(size_t)k * N + (int)mulhi64(((uint64_t)o.w[2] << 32) | o.w[3], (uint64_t)c.t[k])];
+            bool acc = false;
+            if (acc_rate < P.staged_thr) {
+                staged_its += 1;
+                int sj[9], s0[9], s1[9], nst = 0;
+                c.sflip(move);
+                const int32_t* Ax = P.A + (size_t)move * P.K;
+                for (int q = 0; q < P.K; ++q) {
+                    if (q > 0 && Ax[q] == Ax[q - 1]) continue;
+                    const int j = Ax[q], k0 = c.cls[j], k1 = c.klass(j);
+                    if (k0 == k1) continue;
+                    sj[nst] = j; s0[nst] = k0; s1[nst] = k1; ++nst;
+                }
+                { const int k0 = c.cls[move]; sj[nst] = move; s0[nst] = k0; s1[nst] = k0 >= L ? k0 - L : k0 + L; ++nst; }
+                c.sflip(move);
+                double Tp[2 * kSLmax], zp = c.z;
+                for (int q = 0; q < 2 * kSLmax; ++q) Tp[q] = c.T[q];
+                for (int q = 0; q < nst; ++q) { const double f0 = c.f(s0[q]), f1 = c.f(s1[q]); Tp[s0[q]] -= f0; Tp[s1[q]] += f1; zp += f1 - f0; }
+                if (u1 < c.z / zp) {
+                    c.sflip(move);
+                    for (int q = 0; q < nst; ++q) c.set_move(sj[q], s0[q], s1[q]);
+                    for (int q = 0; q < 2 * kSLmax; ++q) c.T[q] = Tp[q];
+                    c.z = zp;
+                    E += dE; accepted += 1; acc = true;
+                }
+            } else {
+                const double cc = c.apply_move(move);
+                if (u1 < cc) { E += dE; accepted += 1; acc = true; }
+                else c.apply_move(move);
+            }
+            acc_rate = acc_rate * (1 - P.lambda) + (acc ? 1.0 : 0.0) * P.lambda;
+        }
+        itdone = P.iters;
+    } else {
+        long long it = 0, nextstep = P.step, m = 0;
+        while (it < P.iters) {
+            m += 1;
+            const uint64_t g = P.g0 + (uint64_t)m;
+            const Philox4 o3 = philox4x32_10((uint32_t)g, (uint32_t)(g >> 32), rep, TAG_RRR | (2u << 8), P.k0, P.k1);
+            const double us = (double)((((uint64_t)o3.w[0] << 32) | o3.w[1]) >> 11) * 0x1.0p-53;
+            const double skipf = floor(__ddiv_rn(det_log1p(-us), det_log1p(-__ddiv_rn(c.z, (double)N))));     // rand_skip, DeltaE.jl:141-144
+            const long long skip = skipf >= 9.0e18 ? (long long)9.0e18 : (long long)skipf;
+            const Philox4 o = philox4x32_10((uint32_t)g, (uint32_t)(g >> 32), rep, TAG_RRR, P.k0, P.k1);
+            const double rr = (double)((((uint64_t)o.w[0] << 32) | o.w[1]) >> 11) * 0x1.0p-53 * c.z;
+            int k = 0;
+            double cT = 0.0;
+            for (k = 0; k < K2; ++k) { cT += c.T[k]; if (rr < cT) break; }
+            if (k == K2) k = K2 - 1;
+            if (!(rr < cT)) while (c.T[k] == 0) k -= 1;
+            const int a = k < L ? k : k - L;
+            const int dE = (k < L ? -1 : 1) * 2 * (2 * a + (P.K & 1));
+            const int move = c.sv[(size_t)k * N + (int)mulhi64(((uint64_t)o.w[2] << 32) | o.w[3], (uint64_t)c.t[k])];
+            bool out = false;
+            while (it + skip + 1 >= nextstep) {
+                P.Es[(size_t)ns * P.Rpad + r] = (int32_t)E; ns += 1;
+                nextstep += P.step;
+                if (nextstep > P.iters) { out = true; break; }
+            }
+            if (out) break;
+            c.apply_move(move);
+            it += skip + 1;
+            E += dE;
+            accepted += 1;
+        }
+        staged_its = accepted;
+        itdone = it;
+    }
+    P.E_cur[r] = (int32_t)E;
+    P.acc_cur[r] = accepted;
+    P.stats[(size_t)r * 3] = accepted; P.stats[(size_t)r * 3 + 1] = staged_its; P.stats[(size_t)r * 3 + 2] = itdone;
+}
+
+// bit-sliced [G][N] words (bit = replica & 31)  <->  replica-contiguous [R][W] words (bit = site & 31)
+__global__ __launch_bounds__(256) void rrsp_spins_in_kernel(const uint32_t* __restrict__ bs, uint32_t* __restrict__ spins, int N, int W, int R)
+{
+    const int w = blockIdx.x * 256 + threadIdx.x, r = blockIdx.y;
+    if (w >= W || r >= R) return;
+    uint32_t word = 0u;
+    for (int b = 0; b < 32; ++b) {
+        const int x = 32 * w + b;
+        if (x < N) word |= ((bs[(size_t)(r >> 5) * N + x] >> (r & 31)) & 1u) << b;
+    }
+    spins[(size_t)r * W + w] = word;
+}
+__global__ __launch_bounds__(256) void rrsp_spins_out_kernel(const uint32_t* __restrict__ spins, uint32_t* __restrict__ bs, int N, int W, int R)
+{
+    const int x = blockIdx.x * 256 + threadIdx.x, g = blockIdx.y;
+    if (x >= N) return;
+    uint32_t word = 0u;
+    for (int b = 0; b < 32; ++b) {
+        const int r = g * 32 + b;
+        if (r < R) word |= ((spins[(size_t)r * W + (x >> 5)] >> (x & 31)) & 1u) << b;
+    }
+    bs[(size_t)g * N + x] = word;
+}
+
 }  // namespace rrrmc

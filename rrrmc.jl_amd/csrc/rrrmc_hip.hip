@@ -113,6 +113,12 @@ struct rrrmc_ctx {
     int64_t* q_stats = nullptr;
     double last_fourK = 0.0, last_beta = 0.0;
     bool last_call_rrr = false;
+    int stats_stride = 2;
+    // ---- rrrMC / bklMC on RRRMC_MODEL_SPARSE_PM1 (allocated on first use) ----
+    uint32_t* rp_spins = nullptr;
+    uint8_t* rp_cls = nullptr;
+    uint16_t* rp_sv = nullptr;
+    uint16_t* rp_spos = nullptr;
     // ---- rrrMC(SingleGraph) on RRRMC_MODEL_SK_NORMAL: DeltaECacheCont + DynamicSampler state (allocated on first use) ----
     double* rs_buf = nullptr;      // lfA, lfB, v, ps, dEs, st_dE, st_p, z_out
     uint32_t* rs_spins = nullptr;
@@ -532,6 +538,7 @@ int32_t sk_rrr_mc_async(rrrmc_ctx* ctx, double beta, int64_t iters, int64_t step
     P.g0 = ctx->it_done; P.iters = iters; P.step = step;
     P.k0 = (uint32_t)ctx->seed; P.k1 = (uint32_t)(ctx->seed >> 32); P.replica0 = ctx->replica0;
     P.N = (int)N; P.N2 = (int)N2; P.levs = levs; P.W = (int)W; P.R = (int)ctx->R; P.Rp = (int)Rp;
+    ctx->stats_stride = 2;
     HIP_TRY(ctx, hipEventRecord(ctx->ev_begin, st));
     hipLaunchKernelGGL(rrsk_spins_in_kernel, dim3((unsigned)((Rp + 255) / 256), (unsigned)W), dim3(256), 0, st, ctx->sk_spins, ctx->rs_spins, (int)N, (int)W, (int)Rp);
     HIP_TRY(ctx, hipGetLastError());
@@ -551,9 +558,73 @@ int32_t sk_rrr_mc_async(rrrmc_ctx* ctx, double beta, int64_t iters, int64_t step
     return RRRMC_OK;
 }
 
+
+// rrrMC(SingleGraph) / bklMC on GraphRRG / GraphEA: thread-per-replica kernel over replica-contiguous arrays
+int32_t sparse_rrr_bkl_async(rrrmc_ctx* ctx, int mode, double beta, int64_t iters, int64_t step, double staged_thr, double staged_thr_fact)
+{
+    if (iters < 0) return fail(ctx, RRRMC_ERR_INVALID_ARG, "iters must be >= 0, given %lld", (long long)iters);
+    if (step < 1) return fail(ctx, RRRMC_ERR_INVALID_ARG, "step must be >= 1, given %lld", (long long)step);
+    if (ctx->N > 65535) return fail(ctx, RRRMC_ERR_UNSUPPORTED, "N=%lld: the rrrMC kernel indexes spins with 16 bits", (long long)ctx->N);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    ctx->results_valid = false;
+    ctx->timing_valid = false;
+    const int64_t N = ctx->N, K = ctx->K, R = ctx->R, W = (N + 31) / 32;
+    const int L = (int)(K / 2 + 1);                       // allΔE has K/2 + 1 levels for +-J couplings (RRG.jl:262-265)
+    if (!ctx->rp_spins) {
+        HIP_TRY(ctx, hipMalloc(&ctx->rp_spins, sizeof(uint32_t) * R * W));
+        HIP_TRY(ctx, hipMalloc(&ctx->rp_cls, (size_t)R * N));
+        HIP_TRY(ctx, hipMalloc(&ctx->rp_sv, sizeof(uint16_t) * R * 2 * L * N));
+        HIP_TRY(ctx, hipMalloc(&ctx->rp_spos, sizeof(uint16_t) * R * N));
+        HIP_TRY(ctx, hipMalloc(&ctx->q_stats, sizeof(int64_t) * R * 3));
+    }
+    ctx->stats_stride = 3;
+    const int64_t nsamp = iters / step;
+    const size_t es_need = (size_t)(nsamp > 0 ? nsamp : 1) * ctx->Rpad;
+    if (es_need > ctx->Es_cap) {
+        free_dev(ctx->d_Es);
+        ctx->Es_cap = 0;
+        HIP_TRY(ctx, hipMalloc(&ctx->d_Es, sizeof(int32_t) * es_need));
+        ctx->Es_cap = es_need;
+    }
+    while (ctx->ev_sweep.size() < 2) {
+        hipEvent_t e;
+        HIP_TRY(ctx, hipEventCreate(&e));
+        ctx->ev_sweep.push_back(e);
+    }
+    RrrSparseParams P{};
+    P.A = ctx->d_A; P.J = ctx->d_J; P.spins = ctx->rp_spins; P.cls = ctx->rp_cls; P.sv = ctx->rp_sv; P.spos = ctx->rp_spos;
+    P.E_cur = ctx->d_E; P.acc_cur = ctx->d_acc; P.stats = ctx->q_stats; P.Es = ctx->d_Es;
+    for (int k = 0; k < L && k < kSLmax; ++k) P.ft[k] = host_det_exp(-beta * (double)(2 * (2 * k + (K & 1))));     // exp(-beta dE_k), DeltaE.jl:91
+    P.beta = beta; P.staged_thr = staged_thr; P.lambda = staged_thr_fact / (double)N;
+    P.g0 = ctx->it_done; P.iters = iters; P.step = step;
+    P.k0 = (uint32_t)ctx->seed; P.k1 = (uint32_t)(ctx->seed >> 32); P.replica0 = ctx->replica0;
+    P.N = (int)N; P.K = (int)K; P.L = L; P.W = (int)W; P.R = (int)R; P.Rpad = (int)ctx->Rpad; P.mode = mode;
+    hipStream_t st = ctx->stream;
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_begin, st));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->d_acc, 0, sizeof(int64_t) * ctx->Rpad, st));
+    hipLaunchKernelGGL(rrsp_spins_in_kernel, dim3((unsigned)((W + 255) / 256), (unsigned)R), dim3(256), 0, st, ctx->d_spins, ctx->rp_spins, (int)N, (int)W, (int)R);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_sweep[0], st));
+    hipLaunchKernelGGL(rrr_sparse_kernel, dim3((unsigned)((R + kRrrThreads - 1) / kRrrThreads)), dim3(kRrrThreads), 0, st, P);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_sweep[1], st));
+    hipLaunchKernelGGL(rrsp_spins_out_kernel, dim3((unsigned)((N + 255) / 256), (unsigned)ctx->G), dim3(256), 0, st, ctx->rp_spins, ctx->d_spins, (int)N, (int)W, (int)R);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_end, st));
+    ctx->sweep_launches = 1;
+    ctx->nsamp = nsamp;
+    ctx->it_done += (uint64_t)iters;
+    ctx->results_valid = true;
+    ctx->timing_valid = true;
+    ctx->last_call_rrr = true;
+    ctx->colored_call = false;
+    return RRRMC_OK;
+}
+
 }  // namespace
 
 extern "C" {
+
 
 
 
@@ -655,6 +726,7 @@ void rrrmc_ctx_destroy(rrrmc_ctx* ctx)
     free_dev(ctx->q_spins); free_dev(ctx->q_cls); free_dev(ctx->q_sv); free_dev(ctx->q_spos); free_dev(ctx->q_st);
     free_dev(ctx->q_T); free_dev(ctx->q_z); free_dev(ctx->q_accrate); free_dev(ctx->q_stats);
     free_dev(ctx->rs_buf); free_dev(ctx->rs_spins); free_dev(ctx->rs_status);
+    free_dev(ctx->rp_spins); free_dev(ctx->rp_cls); free_dev(ctx->rp_sv); free_dev(ctx->rp_spos);
     for (int i = 0; i < 2; ++i) { free_dev(ctx->d_slots[i]); free_dev(ctx->d_vecs[i]); }
     if (ctx->plan_stream) { (void)hipStreamSynchronize(ctx->plan_stream); (void)hipStreamDestroy(ctx->plan_stream); }
     if (ctx->ev_upload) (void)hipEventDestroy(ctx->ev_upload);
@@ -1286,6 +1358,7 @@ int32_t rrrmc_rrr_mc_async(rrrmc_ctx* ctx, double beta, double fourK, int64_t it
     if (rc) return rc;
     if (!std::isfinite(beta)) return fail(ctx, RRRMC_ERR_INVALID_ARG, "beta must be finite, given: %g", beta);       // RRRMC.jl:230, :166
     if (ctx->model == RRRMC_MODEL_SK_NORMAL) return sk_rrr_mc_async(ctx, beta, iters, step, staged_thr, staged_thr_fact);
+    if (ctx->model == RRRMC_MODEL_SPARSE_PM1) return sparse_rrr_bkl_async(ctx, 0, beta, iters, step, staged_thr, staged_thr_fact);
     if (ctx->model != RRRMC_MODEL_QUANT_RRG) return fail(ctx, RRRMC_ERR_UNSUPPORTED, "rrrMC is wired for RRRMC_MODEL_QUANT_RRG and RRRMC_MODEL_SK_NORMAL");
     if (!(fourK > 0.0) || !std::isfinite(fourK)) return fail(ctx, RRRMC_ERR_INVALID_ARG, "fourK must be positive and finite, given: %g", fourK);
     if (iters < 0) return fail(ctx, RRRMC_ERR_INVALID_ARG, "iters must be >= 0, given %lld", (long long)iters);
@@ -1309,6 +1382,7 @@ int32_t rrrmc_rrr_mc_async(rrrmc_ctx* ctx, double beta, double fourK, int64_t it
     hipStream_t st = ctx->stream;
     HIP_TRY(ctx, hipEventRecord(ctx->ev_begin, st));
     ctx->last_beta = beta; ctx->last_fourK = fourK;
+    ctx->stats_stride = 2;
     rc = quant_run_init(ctx, beta, fourK);
     if (rc) return rc;
     RrrParams P = quant_params(ctx, beta, fourK);
@@ -1330,6 +1404,15 @@ int32_t rrrmc_rrr_mc_async(rrrmc_ctx* ctx, double beta, double fourK, int64_t it
     return RRRMC_OK;
 }
 
+int32_t rrrmc_bkl_mc_async(rrrmc_ctx* ctx, double beta, int64_t iters, int64_t step)
+{
+    int32_t rc = ensure_state(ctx, true);
+    if (rc) return rc;
+    if (ctx->model != RRRMC_MODEL_SPARSE_PM1) return fail(ctx, RRRMC_ERR_UNSUPPORTED, "bklMC is wired for RRRMC_MODEL_SPARSE_PM1");
+    if (!std::isfinite(beta)) return fail(ctx, RRRMC_ERR_INVALID_ARG, "beta must be finite, given: %g", beta);
+    return sparse_rrr_bkl_async(ctx, 1, beta, iters, step, 0.0, 5.0);
+}
+
 int32_t rrrmc_quant_set_field(rrrmc_ctx* ctx, double beta, double fourK)
 {
     if (!ctx) return RRRMC_ERR_INVALID_ARG;
@@ -1347,9 +1430,9 @@ int32_t rrrmc_rrr_stats(rrrmc_ctx* ctx, int64_t* staged_iters_out)
     if (!staged_iters_out) return fail(ctx, RRRMC_ERR_INVALID_ARG, "staged_iters_out is NULL");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    std::vector<int64_t> st((size_t)ctx->R * 2);
+    std::vector<int64_t> st((size_t)ctx->R * ctx->stats_stride);
     HIP_TRY(ctx, hipMemcpy(st.data(), ctx->q_stats, sizeof(int64_t) * st.size(), hipMemcpyDeviceToHost));
-    for (int64_t r = 0; r < ctx->R; ++r) staged_iters_out[r] = st[2 * r + 1];
+    for (int64_t r = 0; r < ctx->R; ++r) staged_iters_out[r] = st[ctx->stats_stride * r + 1];
     return RRRMC_OK;
 }
 
@@ -1430,9 +1513,9 @@ int32_t rrrmc_fetch_results_f64(rrrmc_ctx* ctx, double* Es_out, int64_t* accepte
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     if (accepted_out && ctx->last_call_rrr) {
-        std::vector<int64_t> st((size_t)ctx->R * 2);
+        std::vector<int64_t> st((size_t)ctx->R * ctx->stats_stride);
         HIP_TRY(ctx, hipMemcpy(st.data(), ctx->q_stats, sizeof(int64_t) * st.size(), hipMemcpyDeviceToHost));
-        for (int64_t r = 0; r < ctx->R; ++r) accepted_out[r] = st[2 * r];
+        for (int64_t r = 0; r < ctx->R; ++r) accepted_out[r] = st[ctx->stats_stride * r];
     } else if (accepted_out) {
         std::vector<int64_t> acc((size_t)ctx->Rpad);
         HIP_TRY(ctx, hipMemcpy(acc.data(), ctx->d_acc, sizeof(int64_t) * ctx->Rpad, hipMemcpyDeviceToHost));

@@ -50,6 +50,28 @@ __device__ __forceinline__ double det_exp(double x)
     return ldexp(p, (int)k);
 }
 
+// log1p(y) for -1 < y <= 0 with a fixed operation order (rand_skip of bklMC, src/DeltaE.jl:141-144); same sequence as the oracle's
+__device__ __forceinline__ double det_log1p(double y)
+{
+    const double LN2_HI = 6.93147180369123816490e-01, LN2_LO = 1.90821492927058770002e-10;
+    const double u = __dadd_rn(1.0, y);
+    if (u == 1.0) return y;
+    if (!(u > 0.0)) return -__builtin_inf();
+    unsigned long long b = (unsigned long long)__double_as_longlong(u);
+    int e = (int)((b >> 52) & 0x7ff) - 1023;
+    b = (b & ((1ull << 52) - 1)) | (1023ull << 52);
+    double m = __longlong_as_double((long long)b);
+    if (m > 1.4142135623730951) { m = __dmul_rn(m, 0.5); e += 1; }
+    const double s = __ddiv_rn(__dadd_rn(m, -1.0), __dadd_rn(m, 1.0));
+    const double s2 = __dmul_rn(s, s);
+    double p = 1.0 / 21.0;
+#pragma unroll
+    for (int n = 19; n >= 1; n -= 2) p = __dadd_rn(__dmul_rn(p, s2), 1.0 / (double)n);
+    const double lg = __dmul_rn(__dmul_rn(2.0, s), p);
+    const double r = __dadd_rn(__dmul_rn((double)e, LN2_HI), __dadd_rn(lg, __dmul_rn((double)e, LN2_LO)));
+    return __dadd_rn(r, -__ddiv_rn(__dadd_rn(__dadd_rn(u, -1.0), -y), u));
+}
+
 struct SkParams {
     const double* J;        // [N][N]
     double* lf;             // [G][N][kSkRB]  local fields (replica fastest)

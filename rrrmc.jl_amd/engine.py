@@ -136,7 +136,7 @@ class Engine:
         """rrrMC(X::DoubleGraph, β, iters; step, staged_thr, staged_thr_fact) (src/RRRMC.jl:221-290).
         Returns (Es[R, iters // step], accepted[R], staged_iters[R])."""
         if staged_thr is None:          # RRRMC.jl:162-164 (SimpleGraph 0.8, DiscrGraph 0.5) and :226 (DoubleGraph 0.5)
-            staged_thr = 0.8 if self.X.model_kind == MODEL_SK_NORMAL else 0.5
+            staged_thr = 0.8 if self.X.model_kind in (MODEL_SK_NORMAL, MODEL_SK_BINARY) else 0.5
         check(lib().rrrmc_rrr_mc_async(self._ctx, float(beta), float(getattr(self.X, "fourK", 0.0)), int(iters), int(step),
                                        float(staged_thr), float(staged_thr_fact)), self._ctx)
         self._last = (int(iters), int(step))
@@ -145,6 +145,13 @@ class Engine:
         st = np.zeros(self.R, np.int64)
         check(lib().rrrmc_rrr_stats(self._ctx, st), self._ctx)
         return Es, acc, st
+
+    def bkl_mc(self, beta, iters, step=1):
+        """bklMC(X, β, iters; step) (src/RRRMC.jl:311-359).  Returns (Es[R, iters // step], accepted = true moves [R])."""
+        check(lib().rrrmc_bkl_mc_async(self._ctx, float(beta), int(iters), int(step)), self._ctx)
+        self._last = (int(iters), int(step))
+        self.sync()
+        return self.fetch_results()
 
     def rrr_cache(self):
         """(pos[R, N], sizes[R, 4]) of the DeltaECache after the last rrrMC call."""
@@ -187,6 +194,30 @@ def rrrMC(X, beta, iters, *, seed=DEFAULT_SEED, step=1, C0=None, staged_thr=None
             print("iters = ", iters)
             print("accept rate = ", float(acc.mean()) / max(iters, 1))
             print("frac. staged iters = ", float(staged.mean()) / max(iters, 1))
+        return Es, Cfg
+    finally:
+        if own:
+            eng.close()
+
+
+def bklMC(X, beta, iters, *, seed=DEFAULT_SEED, step=1, C0=None, quiet=False, replicas=None, device=0, replica0=0, engine=None):
+    """``bklMC(X, β, iters; seed, step, C0, quiet)`` (src/RRRMC.jl:311-359) for a batch of replicas of a GraphRRG / GraphEA."""
+    own = engine is None
+    R = replicas if replicas is not None else (C0.R if C0 is not None else (engine.R if engine else 1))
+    eng = engine if engine is not None else Engine(X, R, device=device, replica0=replica0)
+    try:
+        if seed > 0 or own:
+            eng.seed(seed if seed > 0 else 0)
+        if C0 is not None:
+            eng.set_config(C0)
+        elif own:
+            eng.init_spins_random()
+        Es, moves = eng.bkl_mc(beta, iters, step)
+        Cfg = eng.get_config(C0 if C0 is not None else None)
+        if not quiet:
+            print("samples = ", Es.shape[1])
+            print("accept rate = ", float(moves.mean()) / max(iters, 1))
+            print("true it = ", float(moves.mean()))
         return Es, Cfg
     finally:
         if own:

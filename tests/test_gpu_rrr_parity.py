@@ -80,3 +80,37 @@ def test_rrr_skn_continuous_cache(pkg, oracle, N, R, beta, iters, step, thr):
         assert np.allclose(Es[r], ref[0], rtol=1e-6, atol=1e-9)          # north-star tolerance
         assert (Es[r] == ref[0]).all() and (C1.s[r] == ref[1]).all() and acc[r] == ref[2] and staged[r] == ref[3]
         assert E1[r] == oracle.skn_energy(X.J, C1.s[r])
+
+
+@pytest.mark.parametrize("kind,R,beta,iters,step,thr", [
+    (("rrg", 10, 3), 8, 2.0, 10000, 100, None),     # test/runtests.jl:36,144-157: GraphRRG(10,3) under rrrMC, three staged_thr regimes
+    (("rrg", 10, 3), 8, 2.0, 10000, 100, 0.0),
+    (("rrg", 10, 3), 8, 2.0, 10000, 100, 1.0),
+    (("ea", 2, 3), 8, 2.0, 10000, 100, None),       # runtests.jl:46: doubled neighbours -> uA de-duplication
+    (("ea", 3, 2), 8, 2.0, 10000, 100, None),
+    (("rrg", 4096, 3), 70, 1.0, 20000, 1000, None), # BASELINE config 2 graph under the RRR sampler
+    (("ea", 6, 3), 40, 1.5, 8000, 80, None),        # K = 6: four ΔE levels
+])
+def test_rrr_and_bkl_on_discrete_graphs(pkg, oracle, kind, R, beta, iters, step, thr):
+    """rrrMC(X::SingleGraph) and bklMC on GraphRRG / GraphEA with DeltaECache{Int,L} (SURVEY.md §8f rank 1)."""
+    seed = 8426732438942 % 2 ** 40 + kind[1]
+    X = pkg.GraphRRG(kind[1], kind[2], seed=seed) if kind[0] == "rrg" else pkg.GraphEA(kind[1], kind[2], seed=seed)
+    A, J = X.A, X.J.astype(np.int32)
+    form = "ea" if kind[0] == "ea" else "rrg"
+    with pkg.Engine(X, R) as eng:
+        eng.seed(seed)
+        eng.init_spins_random()
+        C0 = eng.get_config()
+        Es, acc, staged = eng.rrr_mc(beta, iters, step, staged_thr=thr)
+        C1 = eng.get_config()
+        E1 = eng.energy()
+        eng.seed(seed)
+        eng.set_config(C0)
+        Eb, moves = eng.bkl_mc(beta, iters, step)
+        Cb = eng.get_config()
+    for r in list(range(min(R, 6))) + [R - 1]:
+        ref = oracle.rrr_sparse(A, J, beta, iters, step, seed, C0.s[r], replica=r, staged_thr=0.5 if thr is None else thr, form=form)
+        assert (Es[r] == ref[0]).all() and (C1.s[r] == ref[1]).all() and acc[r] == ref[2] and staged[r] == ref[3]
+        assert E1[r] == oracle.sparse_energy(A, J, C1.s[r])
+        refb = oracle.rrr_sparse(A, J, beta, iters, step, seed, C0.s[r], replica=r, form=form, bkl=True)
+        assert (Eb[r] == refb[0]).all() and (Cb.s[r] == refb[1]).all() and moves[r] == refb[2]
