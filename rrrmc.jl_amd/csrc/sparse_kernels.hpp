@@ -253,11 +253,11 @@ __device__ __forceinline__ void produce_chunk(const SweepParams& P, const ChunkD
         // stream: the result does not depend on where we stop).  Every lane computes kProducerBlocks blocks of 4
         // planes; the ~1.5 % of lanes that still have an undecided replica then hand the slot to the fixer wave
         // through the leftover list, so that a producer's time does not depend on its unluckiest lane.
+        // fully unrolled: the block index is a compile-time constant, so the threshold words are loop-invariant scalars
         uint32_t pb = 0;
-        for (; pb < (uint32_t)kProducerBlocks; ++pb) {
-            if (!__any(any_set<NT>(eq))) break;
-            refine_block<NT>(lt, eq, accept_planes(P.k0, P.k1, g, group, pb), pb, P.taum);
-        }
+#pragma unroll
+        for (int b = 0; b < kProducerBlocks; ++b) refine_block<NT>(lt, eq, accept_planes(P.k0, P.k1, g, group, (uint32_t)b), (uint32_t)b, P.taum);
+        pb = (uint32_t)kProducerBlocks;
         bool need = any_set<NT>(eq);
         const unsigned long long bal = __ballot(need);
         if (bal != 0ull) {       // wave-uniform
