@@ -183,6 +183,27 @@ RRRMC_API int32_t rrrmc_last_timing(rrrmc_ctx *ctx, double *total_ms, double *sw
 /* Iterations consumed from the current seed's streams so far. */
 RRRMC_API int64_t rrrmc_iterations_done(const rrrmc_ctx *ctx);
 
+/* ---- snapshots and observables -------------------------------------------------------
+ * The reference's scripts keep a copy of C.s at every hook call (scripts/scripts.jl:56-66, to_mat :13-21) and later
+ * compute time overlaps with pm1dot (:283-295, parseovs :368-405).  Here the copies stay in HBM (a "snapshot" = the
+ * context's spin buffer in its native layout) and the popcounts run on the device.
+ *   rrrmc_snapshot_reserve  (re)allocates room for nslots snapshots (drops existing ones)
+ *   rrrmc_snapshot_store    copies the live configuration into `slot` (device-to-device, on the ctx's stream)
+ *   rrrmc_snapshot_get      returns slot as R x ceil(N/64) BitVector chunks, like rrrmc_get_spins (the BitMatrix column dump)
+ *   rrrmc_overlaps          q_out[p * R + r] = pm1dot(replica r in slotA[p], replica r in slotB[p]) = N - 2|a xor b|;
+ *                           slot -1 names the live configuration */
+RRRMC_API int32_t rrrmc_snapshot_reserve(rrrmc_ctx *ctx, int32_t nslots);
+RRRMC_API int32_t rrrmc_snapshot_store(rrrmc_ctx *ctx, int32_t slot);
+RRRMC_API int32_t rrrmc_snapshot_get(rrrmc_ctx *ctx, int32_t slot, uint64_t *chunks);
+RRRMC_API int32_t rrrmc_overlaps(rrrmc_ctx *ctx, int64_t npairs, const int32_t *slotA, const int32_t *slotB, int32_t *q_out);
+/* GraphQuant observables of the live configuration of every replica (RRRMC_MODEL_QUANT_RRG):
+ *   Qenergy_out[R]   Qenergy(X, C)            (src/graphs/QT.jl:253-268)
+ *   tmag_out[R]      transverse_mag(X0, C, beta) (QT.jl:113-122)
+ *   ovs_out[R * (M/2)] overlaps(X)            (QT.jl:213-251)
+ * Any output may be NULL.  The integer sums run on the device; the Float64 tail follows the reference's operation order. */
+RRRMC_API int32_t rrrmc_quant_observables(rrrmc_ctx *ctx, double beta, double Gamma, double *Qenergy_out, double *tmag_out,
+                                          double *ovs_out);
+
 /* ---- host-side graph constructors (setup, not hot): the disorder formats of SURVEY.md §8 a7/a8 ---- */
 /* gen_RRG (src/graphs/RRG.jl:26-69): A_out[N*K] 0-based, rows ascending. GRAPH stream of `seed`. */
 RRRMC_API int32_t rrrmc_gen_rrg(int64_t N, int64_t K, uint64_t seed, int32_t *A_out);

@@ -393,3 +393,38 @@ def rrr_sparse(A, J, beta, iters, step, seed, chunks, it0=0, replica=0, staged_t
         raise AssertionError("DeltaECache / ArraySet consistency check failed")
     out = (Es[:n], ch, int(stats[0]), int(stats[1]), int(stats[2]))
     return out + (cache[:N].copy(), cache[N:].copy()) if want_cache else out
+
+
+def pm1dot(a, b, N):
+    """scripts/scripts.jl:283-295"""
+    L = lib()
+    L.orc_pm1dot.restype = C.c_int64
+    L.orc_pm1dot.argtypes = [u64p, u64p, C.c_int64]
+    return int(L.orc_pm1dot(np.ascontiguousarray(a, np.uint64), np.ascontiguousarray(b, np.uint64), int(N)))
+
+
+def q2_window(Cs, N, i, j):
+    """parseovs window statistic (scripts/scripts.jl:380-401) over samples [i, j) of one chain; Cs[samples, nch]."""
+    L = lib()
+    L.orc_q2_window.restype = C.c_int
+    L.orc_q2_window.argtypes = [u64p, C.c_int64, C.c_int64, C.c_int64, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    m, s = C.c_double(0), C.c_double(0)
+    rc = L.orc_q2_window(np.ascontiguousarray(Cs, np.uint64), int(N), int(i), int(j), C.byref(m), C.byref(s))
+    return (m.value, s.value) if rc == 0 else (float("nan"), float("nan"))
+
+
+def quant_observables(A, J, M, fourK, beta, Gamma, chunks):
+    """(Qenergy, transverse_mag, overlaps[M//2], energy0, Eslice[M], ovs_raw[M//2]) — QT.jl:113-122, 213-268."""
+    L = lib()
+    L.orc_quant_observables.restype = C.c_int
+    L.orc_quant_observables.argtypes = [C.c_int64, C.c_int64, C.c_int64, i32p, i32p, C.c_double, C.c_double, C.c_double, u64p,
+                                        C.POINTER(C.c_double), C.POINTER(C.c_double), f64p, C.POINTER(C.c_int64), i64p, i64p]
+    A = np.ascontiguousarray(A, np.int32)
+    Nk, K = A.shape
+    Q, tm, e0 = C.c_double(0), C.c_double(0), C.c_int64(0)
+    ovs = np.zeros(max(M // 2, 1))
+    Es = np.zeros(M, np.int64)
+    raw = np.zeros(max(M // 2, 1), np.int64)
+    L.orc_quant_observables(Nk, int(M), K, A, np.ascontiguousarray(J, np.int32), float(fourK), float(beta), float(Gamma),
+                            np.ascontiguousarray(chunks, np.uint64), C.byref(Q), C.byref(tm), ovs, C.byref(e0), Es, raw)
+    return Q.value, tm.value, ovs[:M // 2], e0.value, Es, raw[:M // 2]

@@ -809,6 +809,83 @@ ORC_API double orc_quant_energy(int64_t Nk, int64_t M, int64_t K, const int32_t 
 }
 
 /* ---------------------------------------------------------------------------------------------
+ * Observables
+ * ------------------------------------------------------------------------------------------- */
+/* pm1dot(a, b) = (2a-1).(2b-1) = N - 2 popcount(a xor b): scripts/scripts.jl:283-295 */
+ORC_API int64_t orc_pm1dot(const uint64_t *a, const uint64_t *b, int64_t N)
+{
+    int64_t l = N;
+    for (int64_t c = 0; c < (N + 63) / 64; ++c) l -= 2 * __builtin_popcountll(a[c] ^ b[c]);
+    return l;
+}
+
+/* Window statistic of parseovs (scripts/scripts.jl:368-405): over the samples i1 in [i, j-2], j1 in [i+1, j-1]
+ * (0-based half-open window [i, j)), q2 = (pm1dot/N)^2; returns mean q2 and sqrt(max(0, <q2^2> - <q2>^2)).
+ * Cs = samples x nch chunk rows of ONE chain.  Note the reference's loop ranges include i1 == j1 and both orders. */
+ORC_API int orc_q2_window(const uint64_t *Cs, int64_t N, int64_t i, int64_t j, double *mq2_out, double *sq2_out)
+{
+    const int64_t nch = (N + 63) / 64;
+    double mq2 = 0.0, mq4 = 0.0;
+    int64_t n = 0;
+    for (int64_t i1 = i; i1 <= j - 2; ++i1)
+        for (int64_t j1 = i + 1; j1 <= j - 1; ++j1) {
+            double q = (double)orc_pm1dot(Cs + i1 * nch, Cs + j1 * nch, N) / (double)N;
+            double q2 = q * q;
+            mq2 += q2;
+            mq4 += q2 * q2;
+            n += 1;
+        }
+    if (n == 0) return 1;
+    mq2 /= (double)n;
+    mq4 /= (double)n;
+    double v = mq4 - mq2 * mq2;
+    *mq2_out = mq2;
+    *sq2_out = sqrt(v > 0.0 ? v : 0.0);
+    return 0;
+}
+
+/* GraphQuant observables of one configuration:
+ *   transverse_mag (QT.jl:113-122): p = -energy0/N, x = beta*fourK/2, cosh(x) - p sinh(x)
+ *   overlaps (QT.jl:213-251): ovs[d-1] = sum over slice pairs at ring distance d of (Nk - 2|s1 xor s2|), normalised by M*Nk
+ *                             (by M*Nk/2 for the last entry when M is even)
+ *   Qenergy (QT.jl:253-268): -Gamma*transverse_mag + sum_k energy(X1[k], C1[k]) / N, accumulated in slice order
+ * Integer parts (energy0, per-slice energies, raw overlap sums) are returned too: they are what the device computes. */
+ORC_API int orc_quant_observables(int64_t Nk, int64_t M, int64_t K, const int32_t *A, const int32_t *J, double fourK, double beta,
+                                  double Gamma, const uint64_t *chunks, double *Qenergy, double *tmag, double *ovs,
+                                  int64_t *energy0_out, int64_t *Eslice_out, int64_t *ovs_raw_out)
+{
+    quant_t Q;
+    quant_init(&Q, Nk, M, K, A, J, fourK);
+    const int64_t N = Nk * M;
+    (void)quant_energy(&Q, chunks);                    /* fills C1[k] */
+    const int64_t e0 = qt_energy0(&Q.X0, chunks);
+    const double p = -(double)e0 / (double)N;
+    const double x = beta * fourK / 2;
+    const double tm = cosh(x) - p * sinh(x);
+    double E = -Gamma * tm;
+    for (int64_t k = 0; k < M; ++k) {
+        const int64_t Ek = sparse_energy(&Q.X1[k], Q.C1[k]);
+        if (Eslice_out) Eslice_out[k] = Ek;
+        E += (double)Ek / (double)N;
+    }
+    for (int64_t d = 0; d < M / 2; ++d) { ovs[d] = 0.0; if (ovs_raw_out) ovs_raw_out[d] = 0; }
+    for (int64_t k1 = 0; k1 < M - 1; ++k1)
+        for (int64_t k2 = k1 + 1; k2 < M; ++k2) {
+            int64_t d = k2 - k1 < M + k1 - k2 ? k2 - k1 : M + k1 - k2;
+            int64_t o = orc_pm1dot(Q.C1[k1], Q.C1[k2], Nk);
+            ovs[d - 1] += (double)o;
+            if (ovs_raw_out) ovs_raw_out[d - 1] += o;
+        }
+    for (int64_t d = 1; d <= (M - 1) / 2; ++d) ovs[d - 1] /= (double)(M * Nk);
+    if (M % 2 == 0 && M >= 2) ovs[M / 2 - 1] /= (double)(M * Nk) / 2;
+    *Qenergy = E;
+    *tmag = tm;
+    if (energy0_out) *energy0_out = e0;
+    quant_free(&Q);
+    return 0;
+}
+
+/* ---------------------------------------------------------------------------------------------
  * Colour-parallel ("checkerboard") sweeps on a sparse +-J model: the build-defined sampler of BASELINE.json config 4
  * (not in the reference; SURVEY.md §7 hard part 7).  One sweep = for each colour in order, every site of that colour
  * attempts a Metropolis flip (RRRMC.jl:39 accept rule, EA.jl:266-275 delta_energy) against the current spins; sites of

@@ -24,6 +24,7 @@ SYMBOLS = [
     "rrrmc_standard_mc_f64", "rrrmc_fetch_results_f64", "rrrmc_gen_sk_gauss",
     "rrrmc_set_couplings_bits", "rrrmc_gen_sk_binary", "rrrmc_set_coloring", "rrrmc_colored_sweeps_async",
     "rrrmc_ctx_create_quant", "rrrmc_quant_set_field", "rrrmc_rrr_mc_async", "rrrmc_rrr_stats", "rrrmc_rrr_cache", "rrrmc_bkl_mc_async",
+    "rrrmc_snapshot_reserve", "rrrmc_snapshot_store", "rrrmc_snapshot_get", "rrrmc_overlaps", "rrrmc_quant_observables",
 ]
 
 
@@ -117,6 +118,16 @@ def lib():
     L.rrrmc_gen_sk_binary.argtypes = [C.c_int64, C.c_uint64, u64p]
     L.rrrmc_bkl_mc_async.restype = C.c_int32
     L.rrrmc_bkl_mc_async.argtypes = [vp, C.c_double, C.c_int64, C.c_int64]
+    L.rrrmc_snapshot_reserve.restype = C.c_int32
+    L.rrrmc_snapshot_reserve.argtypes = [vp, C.c_int32]
+    L.rrrmc_snapshot_store.restype = C.c_int32
+    L.rrrmc_snapshot_store.argtypes = [vp, C.c_int32]
+    L.rrrmc_snapshot_get.restype = C.c_int32
+    L.rrrmc_snapshot_get.argtypes = [vp, C.c_int32, u64p]
+    L.rrrmc_overlaps.restype = C.c_int32
+    L.rrrmc_overlaps.argtypes = [vp, C.c_int64, i32p, i32p, i32p]
+    L.rrrmc_quant_observables.restype = C.c_int32
+    L.rrrmc_quant_observables.argtypes = [vp, C.c_double, C.c_double, vp, vp, vp]
     _lib = L
     return L
 

@@ -15,6 +15,7 @@
 #include "sk_kernels.hpp"
 #include "rrr_kernels.hpp"
 #include "sparse_kernels.hpp"
+#include "obs_kernels.hpp"
 
 using namespace rrrmc;
 
@@ -123,6 +124,15 @@ struct rrrmc_ctx {
     double* rs_buf = nullptr;      // lfA, lfB, v, ps, dEs, st_dE, st_p, z_out
     uint32_t* rs_spins = nullptr;
     int32_t* rs_status = nullptr;
+
+    // ---- snapshots / observables ----
+    uint8_t* snap = nullptr;       // [nslots][snap_bytes]: copies of the model's native spin buffer
+    int32_t snap_slots = 0;
+    std::vector<uint8_t> snap_valid;
+    void** d_pairs = nullptr;      // [2][pairs_cap] device pointer tables of the overlap kernels
+    size_t pairs_cap = 0;
+    int32_t* d_ovl = nullptr;      // [pairs_cap][Rpad]
+    int32_t* d_qobs = nullptr;     // GraphQuant: e0[R], Eslice[R][M], ovs_raw[R][M/2]
 
     std::string err;
 };
@@ -727,6 +737,7 @@ void rrrmc_ctx_destroy(rrrmc_ctx* ctx)
     free_dev(ctx->q_T); free_dev(ctx->q_z); free_dev(ctx->q_accrate); free_dev(ctx->q_stats);
     free_dev(ctx->rs_buf); free_dev(ctx->rs_spins); free_dev(ctx->rs_status);
     free_dev(ctx->rp_spins); free_dev(ctx->rp_cls); free_dev(ctx->rp_sv); free_dev(ctx->rp_spos);
+    free_dev(ctx->snap); free_dev(ctx->d_pairs); free_dev(ctx->d_ovl); free_dev(ctx->d_qobs);
     for (int i = 0; i < 2; ++i) { free_dev(ctx->d_slots[i]); free_dev(ctx->d_vecs[i]); }
     if (ctx->plan_stream) { (void)hipStreamSynchronize(ctx->plan_stream); (void)hipStreamDestroy(ctx->plan_stream); }
     if (ctx->ev_upload) (void)hipEventDestroy(ctx->ev_upload);
@@ -872,23 +883,34 @@ int32_t rrrmc_set_spins(rrrmc_ctx* ctx, const uint64_t* chunks)
     return RRRMC_OK;
 }
 
-int32_t rrrmc_get_spins(rrrmc_ctx* ctx, uint64_t* chunks)
+namespace {
+// the model's native device spin buffer and its size (the unit a snapshot stores)
+const void* native_spins(const rrrmc_ctx* ctx)
 {
-    int32_t rc = ensure_state(ctx, true);
-    if (rc) return rc;
-    if (!chunks) return fail(ctx, RRRMC_ERR_INVALID_ARG, "chunks is NULL");
+    if (ctx->model == RRRMC_MODEL_QUANT_RRG) return ctx->q_spins;
+    if (ctx->model == RRRMC_MODEL_SK_NORMAL || ctx->model == RRRMC_MODEL_SK_BINARY) return ctx->sk_spins;
+    return ctx->d_spins;
+}
+size_t native_spin_bytes(const rrrmc_ctx* ctx)
+{
+    if (ctx->model == RRRMC_MODEL_QUANT_RRG) return sizeof(uint32_t) * (size_t)ctx->R * (size_t)ctx->qW;
+    if (ctx->model == RRRMC_MODEL_SK_NORMAL || ctx->model == RRRMC_MODEL_SK_BINARY) return (size_t)ctx->G8 * (size_t)ctx->N;
+    return sizeof(uint32_t) * (size_t)ctx->G * (size_t)ctx->N;
+}
+
+// device buffer in the model's native layout -> R x ceil(N/64) BitVector chunks on the host
+int32_t spins_to_chunks(rrrmc_ctx* ctx, const void* src, uint64_t* chunks)
+{
     const int64_t N = ctx->N, nch = (N + 63) / 64;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     if (ctx->model == RRRMC_MODEL_QUANT_RRG) {
-        HIP_TRY(ctx, hipSetDevice(ctx->device));
-        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-        HIP_TRY(ctx, hipMemcpy(chunks, ctx->q_spins, sizeof(uint64_t) * ctx->R * nch, hipMemcpyDeviceToHost));
+        HIP_TRY(ctx, hipMemcpy(chunks, src, sizeof(uint64_t) * ctx->R * nch, hipMemcpyDeviceToHost));
         return RRRMC_OK;
     }
     if (ctx->model == RRRMC_MODEL_SK_NORMAL || ctx->model == RRRMC_MODEL_SK_BINARY) {
         std::vector<uint8_t> b8((size_t)(ctx->G8 * N));
-        HIP_TRY(ctx, hipSetDevice(ctx->device));
-        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-        HIP_TRY(ctx, hipMemcpy(b8.data(), ctx->sk_spins, b8.size(), hipMemcpyDeviceToHost));
+        HIP_TRY(ctx, hipMemcpy(b8.data(), src, b8.size(), hipMemcpyDeviceToHost));
         std::memset(chunks, 0, sizeof(uint64_t) * ctx->R * nch);
         for (int64_t r = 0; r < ctx->R; ++r)
             for (int64_t x = 0; x < N; ++x)
@@ -896,17 +918,24 @@ int32_t rrrmc_get_spins(rrrmc_ctx* ctx, uint64_t* chunks)
         return RRRMC_OK;
     }
     std::vector<uint32_t> bs((size_t)(ctx->G * N));
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    HIP_TRY(ctx, hipMemcpy(bs.data(), ctx->d_spins, sizeof(uint32_t) * bs.size(), hipMemcpyDeviceToHost));
+    HIP_TRY(ctx, hipMemcpy(bs.data(), src, sizeof(uint32_t) * bs.size(), hipMemcpyDeviceToHost));
     std::memset(chunks, 0, sizeof(uint64_t) * ctx->R * nch);
     for (int64_t r = 0; r < ctx->R; ++r) {
-        const uint32_t* src = bs.data() + (r >> 5) * N;
+        const uint32_t* w = bs.data() + (r >> 5) * N;
         const int sh = (int)(r & 31);
         uint64_t* dst = chunks + r * nch;
-        for (int64_t x = 0; x < N; ++x) dst[x >> 6] |= (uint64_t)((src[x] >> sh) & 1u) << (x & 63);
+        for (int64_t x = 0; x < N; ++x) dst[x >> 6] |= (uint64_t)((w[x] >> sh) & 1u) << (x & 63);
     }
     return RRRMC_OK;
+}
+}  // namespace
+
+int32_t rrrmc_get_spins(rrrmc_ctx* ctx, uint64_t* chunks)
+{
+    int32_t rc = ensure_state(ctx, true);
+    if (rc) return rc;
+    if (!chunks) return fail(ctx, RRRMC_ERR_INVALID_ARG, "chunks is NULL");
+    return spins_to_chunks(ctx, native_spins(ctx), chunks);
 }
 
 int32_t rrrmc_energy(rrrmc_ctx* ctx, int64_t* E_out)
@@ -1562,6 +1591,143 @@ int32_t rrrmc_set_couplings_bits(rrrmc_ctx* ctx, const uint64_t* Jc)
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     HIP_TRY(ctx, hipMemcpy(ctx->skb_J, Jc, sizeof(uint64_t) * N * nch, hipMemcpyHostToDevice));     // chunk = two little-endian words
     ctx->graph_set = true;
+    return RRRMC_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Snapshots and observables
+// ---------------------------------------------------------------------------------------------------
+int32_t rrrmc_snapshot_reserve(rrrmc_ctx* ctx, int32_t nslots)
+{
+    if (!ctx) return RRRMC_ERR_INVALID_ARG;
+    if (nslots < 0) return fail(ctx, RRRMC_ERR_INVALID_ARG, "nslots must be >= 0");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    free_dev(ctx->snap);
+    ctx->snap_slots = 0;
+    ctx->snap_valid.clear();
+    if (nslots == 0) return RRRMC_OK;
+    const size_t bytes = native_spin_bytes(ctx) * (size_t)nslots;
+    if (hipMalloc(&ctx->snap, bytes) != hipSuccess) {
+        ctx->snap = nullptr;
+        return fail(ctx, RRRMC_ERR_NOMEM, "cannot allocate %zu bytes for %d snapshots", bytes, nslots);
+    }
+    ctx->snap_slots = nslots;
+    ctx->snap_valid.assign((size_t)nslots, 0);
+    return RRRMC_OK;
+}
+
+int32_t rrrmc_snapshot_store(rrrmc_ctx* ctx, int32_t slot)
+{
+    int32_t rc = ensure_state(ctx, true);
+    if (rc) return rc;
+    if (slot < 0 || slot >= ctx->snap_slots) return fail(ctx, RRRMC_ERR_INVALID_ARG, "snapshot slot %d out of range (0..%d)", slot, ctx->snap_slots - 1);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const size_t sb = native_spin_bytes(ctx);
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->snap + sb * (size_t)slot, native_spins(ctx), sb, hipMemcpyDeviceToDevice, ctx->stream));
+    ctx->snap_valid[(size_t)slot] = 1;
+    return RRRMC_OK;
+}
+
+int32_t rrrmc_snapshot_get(rrrmc_ctx* ctx, int32_t slot, uint64_t* chunks)
+{
+    if (!ctx) return RRRMC_ERR_INVALID_ARG;
+    if (!chunks) return fail(ctx, RRRMC_ERR_INVALID_ARG, "chunks is NULL");
+    if (slot < 0 || slot >= ctx->snap_slots || !ctx->snap_valid[(size_t)slot])
+        return fail(ctx, RRRMC_ERR_INVALID_ARG, "snapshot slot %d is out of range or empty", slot);
+    return spins_to_chunks(ctx, ctx->snap + native_spin_bytes(ctx) * (size_t)slot, chunks);
+}
+
+int32_t rrrmc_overlaps(rrrmc_ctx* ctx, int64_t npairs, const int32_t* slotA, const int32_t* slotB, int32_t* q_out)
+{
+    int32_t rc = ensure_state(ctx, true);
+    if (rc) return rc;
+    if (npairs < 0) return fail(ctx, RRRMC_ERR_INVALID_ARG, "npairs must be >= 0");
+    if (npairs == 0) return RRRMC_OK;
+    if (!slotA || !slotB || !q_out) return fail(ctx, RRRMC_ERR_INVALID_ARG, "slotA, slotB, q_out must not be NULL");
+    if (npairs > 65535) return fail(ctx, RRRMC_ERR_INVALID_ARG, "at most 65535 pairs per call, given %lld", (long long)npairs);
+    const size_t sb = native_spin_bytes(ctx);
+    std::vector<const void*> tab((size_t)(2 * npairs));
+    for (int64_t p = 0; p < npairs; ++p)
+        for (int side = 0; side < 2; ++side) {
+            const int32_t sl = side ? slotB[p] : slotA[p];
+            if (sl == -1) { tab[(size_t)(side * npairs + p)] = native_spins(ctx); continue; }     // the live configuration
+            if (sl < 0 || sl >= ctx->snap_slots || !ctx->snap_valid[(size_t)sl])
+                return fail(ctx, RRRMC_ERR_INVALID_ARG, "pair %lld: snapshot slot %d is out of range or empty", (long long)p, sl);
+            tab[(size_t)(side * npairs + p)] = ctx->snap + sb * (size_t)sl;
+        }
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if ((size_t)npairs > ctx->pairs_cap) {
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        free_dev(ctx->d_pairs); free_dev(ctx->d_ovl);
+        ctx->pairs_cap = 0;
+        HIP_TRY(ctx, hipMalloc(&ctx->d_pairs, sizeof(void*) * 2 * (size_t)npairs));
+        HIP_TRY(ctx, hipMalloc(&ctx->d_ovl, sizeof(int32_t) * (size_t)npairs * (size_t)ctx->Rpad));
+        ctx->pairs_cap = (size_t)npairs;
+    }
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_pairs, tab.data(), sizeof(void*) * tab.size(), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));      // tab is pageable host memory
+    void** pa = ctx->d_pairs;
+    void** pb = ctx->d_pairs + npairs;
+    if (ctx->model == RRRMC_MODEL_QUANT_RRG) {
+        hipLaunchKernelGGL(overlap_chunks_kernel, dim3((unsigned)ctx->R, (unsigned)npairs), dim3(64), 0, ctx->stream,
+                           (const uint32_t* const*)pa, (const uint32_t* const*)pb, (int)ctx->N, (int)ctx->qW, (int)ctx->Rpad, ctx->d_ovl);
+    } else if (ctx->model == RRRMC_MODEL_SK_NORMAL || ctx->model == RRRMC_MODEL_SK_BINARY) {
+        hipLaunchKernelGGL(overlap_b8_kernel, dim3((unsigned)ctx->G8, (unsigned)npairs), dim3(256), 0, ctx->stream,
+                           (const uint8_t* const*)pa, (const uint8_t* const*)pb, (int)ctx->N, (int)ctx->Rpad, ctx->d_ovl);
+    } else {
+        hipLaunchKernelGGL(overlap_bs32_kernel, dim3((unsigned)ctx->G, (unsigned)npairs), dim3(256), 0, ctx->stream,
+                           (const uint32_t* const*)pa, (const uint32_t* const*)pb, (int)ctx->N, (int)ctx->Rpad, ctx->d_ovl);
+    }
+    HIP_TRY(ctx, hipGetLastError());
+    std::vector<int32_t> h((size_t)npairs * (size_t)ctx->Rpad);
+    HIP_TRY(ctx, hipMemcpyAsync(h.data(), ctx->d_ovl, sizeof(int32_t) * h.size(), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    for (int64_t p = 0; p < npairs; ++p)
+        std::memcpy(q_out + p * ctx->R, h.data() + p * ctx->Rpad, sizeof(int32_t) * (size_t)ctx->R);
+    return RRRMC_OK;
+}
+
+int32_t rrrmc_quant_observables(rrrmc_ctx* ctx, double beta, double Gamma, double* Qenergy_out, double* tmag_out, double* ovs_out)
+{
+    int32_t rc = ensure_state(ctx, true);
+    if (rc) return rc;
+    if (ctx->model != RRRMC_MODEL_QUANT_RRG) return fail(ctx, RRRMC_ERR_STATE, "rrrmc_quant_observables needs a GraphQuant context");
+    if (!(ctx->last_fourK > 0.0)) return fail(ctx, RRRMC_ERR_STATE, "observables of a GraphQuant need fourK: call rrrmc_quant_set_field first");
+    const int64_t R = ctx->R, M = ctx->qM, Nk = ctx->qNk, N = ctx->N, H = M / 2;
+    const size_t lds = sizeof(uint32_t) * (size_t)(M * ((Nk + 31) / 32) + M + H + 1);
+    if (lds > (size_t)64 * 1024) return fail(ctx, RRRMC_ERR_UNSUPPORTED, "N = %lld spins per replica do not fit the observables kernel's LDS", (long long)N);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (!ctx->d_qobs) HIP_TRY(ctx, hipMalloc(&ctx->d_qobs, sizeof(int32_t) * (size_t)R * (size_t)(1 + M + H)));
+    int32_t* d_e0 = ctx->d_qobs;
+    int32_t* d_es = d_e0 + R;
+    int32_t* d_ov = d_es + R * M;
+    hipLaunchKernelGGL(quant_observables_kernel, dim3((unsigned)R), dim3(256), lds, ctx->stream, ctx->q_spins, ctx->d_A, ctx->d_J,
+                       (int)Nk, (int)M, (int)ctx->K, (int)ctx->qW, d_e0, d_es, d_ov);
+    HIP_TRY(ctx, hipGetLastError());
+    std::vector<int32_t> h((size_t)R * (size_t)(1 + M + H));
+    HIP_TRY(ctx, hipMemcpyAsync(h.data(), ctx->d_qobs, sizeof(int32_t) * h.size(), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    // Float64 tail in the reference's operation order (QT.jl:113-122, 235-251, 253-268); beta here is the caller's, as in
+    // transverse_mag(X0, C, beta), fourK the context's
+    const double x = beta * ctx->last_fourK / 2;
+    const double ch = std::cosh(x), sh = std::sinh(x);
+    for (int64_t r = 0; r < R; ++r) {
+        const double p = -(double)h[(size_t)r] / (double)N;
+        const double tm = ch - p * sh;
+        double E = -Gamma * tm;
+        for (int64_t k = 0; k < M; ++k) E += (double)h[(size_t)(R + r * M + k)] / (double)N;
+        if (tmag_out) tmag_out[r] = tm;
+        if (Qenergy_out) Qenergy_out[r] = E;
+        if (ovs_out) {
+            for (int64_t d = 1; d <= H; ++d) {
+                double o = (double)h[(size_t)(R + R * M + r * H + d - 1)];
+                if (d <= (M - 1) / 2) o /= (double)(M * Nk);
+                else o /= (double)(M * Nk) / 2;          // even M, d = M/2: each slice has one partner at that distance
+                ovs_out[r * H + d - 1] = o;
+            }
+        }
+    }
     return RRRMC_OK;
 }
 

@@ -160,6 +160,40 @@ class Engine:
         check(lib().rrrmc_rrr_cache(self._ctx, pos.ctypes.data, sizes.ctypes.data), self._ctx)
         return pos, sizes
 
+    # -- snapshots and observables ---------------------------------------------
+    def snapshot_reserve(self, nslots):
+        check(lib().rrrmc_snapshot_reserve(self._ctx, int(nslots)), self._ctx)
+
+    def snapshot_store(self, slot):
+        """Keep a device-side copy of the live configuration (what the reference's hooks do with ``copy(C.s)``)."""
+        check(lib().rrrmc_snapshot_store(self._ctx, int(slot)), self._ctx)
+
+    def snapshot_get(self, slot, out=None):
+        if out is None:
+            out = Config(self.X.N, self.R)
+        check(lib().rrrmc_snapshot_get(self._ctx, int(slot), out.s), self._ctx)
+        return out
+
+    def overlaps(self, slotA, slotB):
+        """q[p, r] = pm1dot(replica r of slotA[p], replica r of slotB[p]) (scripts/scripts.jl:283-295); slot -1 = live."""
+        a = np.ascontiguousarray(np.atleast_1d(slotA), np.int32)
+        b = np.ascontiguousarray(np.atleast_1d(slotB), np.int32)
+        if a.shape != b.shape:
+            raise ValueError("slotA and slotB must have the same length")
+        q = np.zeros((a.size, self.R), np.int32)
+        check(lib().rrrmc_overlaps(self._ctx, a.size, a, b, q.reshape(-1)), self._ctx)
+        return q
+
+    def quant_observables(self, beta=None, Gamma=None):
+        """(Qenergy[R], transverse_mag[R], overlaps[R, M // 2]) of a GraphQuant (src/graphs/QT.jl:113-122, 213-268)."""
+        X = self.X
+        Q = np.zeros(self.R)
+        tm = np.zeros(self.R)
+        ov = np.zeros((self.R, X.M // 2))
+        check(lib().rrrmc_quant_observables(self._ctx, float(X.beta if beta is None else beta), float(X.Gamma if Gamma is None else Gamma),
+                                            Q.ctypes.data, tm.ctypes.data, ov.ctypes.data), self._ctx)
+        return Q, tm, ov
+
     def last_timing(self):
         """(total_ms, sweep_ms, sweep_launches) of the last sampling call, from HIP events on the ctx's stream."""
         t, s, n = C.c_double(0), C.c_double(0), C.c_int32(0)
