@@ -48,6 +48,7 @@ enum rrrmc_status {
 enum rrrmc_model {
     RRRMC_MODEL_SPARSE_PM1 = 1,  /* GraphRRG{Int,(-1,1),K} src/graphs/RRG.jl:116 and GraphEA{Int,(-1,1),2D} src/graphs/EA.jl:138 */
     RRRMC_MODEL_SK_NORMAL = 2,   /* GraphSKNormal (Float64 couplings) src/graphs/SK.jl:181-210; K is ignored */
+    RRRMC_MODEL_SPARSE_F64 = 5,  /* GraphRRGNormal{K} src/graphs/RRG.jl:503-520 and GraphEANormal{2D} src/graphs/EA.jl:534-552: sparse, Float64 couplings */
     RRRMC_MODEL_SK_BINARY = 4,   /* GraphSK (couplings +-1/sqrt(N), bit-packed) src/graphs/SK.jl:28-60; K is ignored; energies Float64 */
     RRRMC_MODEL_QUANT_RRG = 3    /* GraphQuant over M Suzuki-Trotter slices of one GraphRRG{Int,(-1,1),K} disorder
                                     (src/graphs/QT.jl:126-170 with the shared-disorder pattern of src/QAliases.jl:43-67);
@@ -182,6 +183,16 @@ RRRMC_API int32_t rrrmc_last_timing(rrrmc_ctx *ctx, double *total_ms, double *sw
 
 /* Iterations consumed from the current seed's streams so far. */
 RRRMC_API int64_t rrrmc_iterations_done(const rrrmc_ctx *ctx);
+
+/* ---- Float64-coupling sparse models (RRRMC_MODEL_SPARSE_F64) ---------------------------
+ * GraphRRGNormal / GraphEANormal: SimpleGraph{Float64} on the neighbour table of GraphRRG / GraphEA.  Create with
+ * rrrmc_ctx_create(model = RRRMC_MODEL_SPARSE_F64, N, K, R); K <= 8.  A [N x K] 0-based with ascending rows (a neighbour may
+ * repeat: EA with L = 2, handled through the de-duplicated list like EA.jl:613-653), J [N x K] Float64, symmetric.
+ * Energies / fields / results through the _f64 entry points; sampler: rrrmc_standard_mc_async / rrrmc_standard_mc_f64.
+ * Replaces GraphRRGNormal{K}(N) (RRG.jl:503-520), GraphEANormal{twoD}(L, A, J) (EA.jl:539-552). */
+RRRMC_API int32_t rrrmc_set_graph_f64(rrrmc_ctx *ctx, const int32_t *A, const double *J);
+/* gen_J(Float64, N, A) do randn() end (RRG.jl:71-96, EA.jl:45-71): one GAUSS-stream normal per bond. J_out[N*K]. */
+RRRMC_API int32_t rrrmc_gen_couplings_gauss(int64_t N, int64_t K, const int32_t *A, uint64_t seed, double *J_out);
 
 /* ---- snapshots and observables -------------------------------------------------------
  * The reference's scripts keep a copy of C.s at every hook call (scripts/scripts.jl:56-66, to_mat :13-21) and later

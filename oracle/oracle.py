@@ -428,3 +428,46 @@ def quant_observables(A, J, M, fourK, beta, Gamma, chunks):
     L.orc_quant_observables(Nk, int(M), K, A, np.ascontiguousarray(J, np.int32), float(fourK), float(beta), float(Gamma),
                             np.ascontiguousarray(chunks, np.uint64), C.byref(Q), C.byref(tm), ovs, C.byref(e0), Es, raw)
     return Q.value, tm.value, ovs[:M // 2], e0.value, Es, raw[:M // 2]
+
+
+def gen_couplings_gauss(A, seed):
+    """gen_J(Float64, N, A) do randn() end — RRG.jl:71-96 / EA.jl:45-71"""
+    L = lib()
+    L.orc_gen_couplings_gauss.restype = C.c_int
+    L.orc_gen_couplings_gauss.argtypes = [C.c_int64, C.c_int64, i32p, C.c_uint64, f64p]
+    A = np.ascontiguousarray(A, np.int32)
+    N, K = A.shape
+    J = np.zeros((N, K))
+    if L.orc_gen_couplings_gauss(N, K, A, seed, J.reshape(-1)) < 0:
+        raise ValueError("gen_couplings_gauss failed")
+    return J
+
+
+def spf_energy(A, J, chunks, want_fields=False, form="rrg"):
+    """energy of GraphRRGNormal / GraphEANormal (RRG.jl:546-574, EA.jl:584-611)"""
+    L = lib()
+    L.orc_spf_energy.restype = C.c_double
+    L.orc_spf_energy.argtypes = [C.c_int, C.c_int64, C.c_int64, i32p, f64p, u64p, C.c_void_p]
+    A = np.ascontiguousarray(A, np.int32)
+    N, K = A.shape
+    lf = np.zeros(N)
+    E = L.orc_spf_energy(1 if form == "ea" else 0, N, K, A, np.ascontiguousarray(J, np.float64).reshape(-1),
+                         np.ascontiguousarray(chunks, np.uint64), lf.ctypes.data if want_fields else None)
+    return (float(E), lf) if want_fields else float(E)
+
+
+def standard_mc_spf(A, J, beta, iters, step, seed, chunks, it0=0, replica=0, form="rrg"):
+    """standardMC on GraphRRGNormal / GraphEANormal; returns (Es, final chunks, accepted, final lfields)."""
+    L = lib()
+    L.orc_standard_mc_spf.restype = C.c_int64
+    L.orc_standard_mc_spf.argtypes = [C.c_int, C.c_int64, C.c_int64, i32p, f64p, C.c_double, C.c_int64, C.c_int64, C.c_uint64,
+                                      C.c_uint64, C.c_uint32, u64p, f64p, C.POINTER(C.c_int64), f64p]
+    A = np.ascontiguousarray(A, np.int32)
+    N, K = A.shape
+    ch = np.array(chunks, np.uint64, copy=True)
+    Es = np.zeros(max(iters // step, 1))
+    acc = C.c_int64(0)
+    lf = np.zeros(N)
+    n = L.orc_standard_mc_spf(1 if form == "ea" else 0, N, K, A, np.ascontiguousarray(J, np.float64).reshape(-1), float(beta), int(iters),
+                              int(step), seed, it0, replica, ch, Es, C.byref(acc), lf)
+    return Es[:n], ch, acc.value, lf

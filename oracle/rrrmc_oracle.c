@@ -439,6 +439,145 @@ ORC_API int64_t orc_standard_mc_skn(int64_t N, const double *J, double beta, int
     return nsamp;
 }
 
+/* ---------------------------------------------------------------------------------------------
+ * Float64-coupling sparse models GraphRRGNormal / GraphEANormal (SimpleGraph{Float64}):
+ * src/graphs/RRG.jl:503-627, src/graphs/EA.jl:534-680
+ * ------------------------------------------------------------------------------------------- */
+
+/* gen_J(Float64, N, A) do randn() end — RRG.jl:71-96 / EA.jl:45-71 with f = randn: one GAUSS-stream draw per bond
+ * visited from its smaller endpoint in (x, k) order, stored at J[x][k] and at the first unfilled slot of J[y]. */
+ORC_API int orc_gen_couplings_gauss(int64_t N, int64_t K, const int32_t *A, uint64_t seed, double *J)
+{
+    uint8_t *filled = (uint8_t *)calloc((size_t)(N * K), 1);
+    uint64_t ndraw = 0;
+    int rc = 0;
+    for (int64_t x = 0; x < N && !rc; ++x)
+        for (int64_t k = 0; k < K; ++k) {
+            int64_t y = A[x * K + k];
+            if (x < y) {
+                double Jxy = gauss_draw(seed, ndraw++);
+                if (filled[x * K + k]) { rc = -1; break; }
+                J[x * K + k] = Jxy; filled[x * K + k] = 1;
+                int64_t l = 0;
+                while (l < K && filled[y * K + l]) ++l;
+                if (l == K) { rc = -1; break; }
+                J[y * K + l] = Jxy; filled[y * K + l] = 1;
+            }
+        }
+    for (int64_t q = 0; q < N * K && !rc; ++q) if (!filled[q]) rc = -1;
+    free(filled);
+    return rc;
+}
+
+typedef struct {
+    int64_t N, K;
+    const int32_t *A;
+    const double *J;
+    double *lfields, *lfields_last;
+    int64_t move_last;
+    int ea_form;
+} spf_t;
+
+/* energy: RRG.jl:546-574 / EA.jl:584-611 */
+static double spf_energy(spf_t *X, const uint64_t *s)
+{
+    double E1 = 0.0;
+    for (int64_t x = 0; x < X->N; ++x) {
+        int sx = 2 * spin_bit(s, x) - 1;
+        double lf = 0.0;
+        for (int64_t k = 0; k < X->K; ++k) {
+            int sy = 2 * spin_bit(s, X->A[x * X->K + k]) - 1;
+            lf -= X->J[x * X->K + k] * (double)sx * (double)sy;
+        }
+        E1 += lf;
+        X->lfields[x] = 2 * lf;
+    }
+    E1 /= 2;
+    X->move_last = -1;
+    memset(X->lfields_last, 0, (size_t)X->N * sizeof(double));
+    return E1;
+}
+
+/* update_cache!: RRG.jl:576-617 (GraphRRGNormal) and EA.jl:613-653 (GraphEANormal: de-duplicated uA), after the flip */
+static void spf_update_cache(spf_t *X, const uint64_t *s, int64_t move)
+{
+    const int32_t *Ax = X->A + move * X->K;
+    const double *Jx = X->J + move * X->K;
+    const int64_t K = X->K;
+    if (X->move_last == move) {
+        for (int64_t k = 0; k < K; ++k) {
+            if (X->ea_form && ea_is_repeat(Ax, k)) continue;
+            int64_t y = Ax[k];
+            double t = X->lfields[y]; X->lfields[y] = X->lfields_last[y]; X->lfields_last[y] = t;
+        }
+        X->lfields[move] = -X->lfields[move];
+        X->lfields_last[move] = -X->lfields_last[move];
+        return;
+    }
+    int sx = spin_bit(s, move);
+    if (X->ea_form) {
+        for (int64_t k = 0; k < K; ++k) if (!ea_is_repeat(Ax, k)) X->lfields_last[Ax[k]] = X->lfields[Ax[k]];
+        for (int64_t k = 0; k < K; ++k) {
+            int64_t y = Ax[k];
+            int sxy = 1 - 2 * (sx ^ spin_bit(s, y));
+            X->lfields[y] -= (double)(4 * sxy) * Jx[k];
+        }
+    } else {
+        for (int64_t k = 0; k < K; ++k) {
+            int64_t y = Ax[k];
+            int sxy = 1 - 2 * (sx ^ spin_bit(s, y));
+            double lfy = X->lfields[y];
+            X->lfields_last[y] = lfy;
+            X->lfields[y] = lfy - (double)(4 * sxy) * Jx[k];
+        }
+    }
+    double lfm = X->lfields[move];
+    X->lfields_last[move] = lfm;
+    X->lfields[move] = -lfm;
+    X->move_last = move;
+}
+
+ORC_API double orc_spf_energy(int form, int64_t N, int64_t K, const int32_t *A, const double *J, const uint64_t *chunks, double *lfields_out)
+{
+    spf_t X = {N, K, A, J, NULL, NULL, -1, form};
+    X.lfields = (double *)malloc((size_t)N * sizeof(double));
+    X.lfields_last = (double *)malloc((size_t)N * sizeof(double));
+    double E = spf_energy(&X, chunks);
+    if (lfields_out) memcpy(lfields_out, X.lfields, (size_t)N * sizeof(double));
+    free(X.lfields); free(X.lfields_last);
+    return E;
+}
+
+/* standardMC (src/RRRMC.jl:81-127) on GraphRRGNormal / GraphEANormal, one chain; delta_energy = -lfields[move]
+ * (RRG.jl:619-625).  SITE stream shared by all replicas, ACCEPT_F64 uniform per replica. */
+ORC_API int64_t orc_standard_mc_spf(int form, int64_t N, int64_t K, const int32_t *A, const double *J, double beta, int64_t iters,
+                                    int64_t step, uint64_t seed, uint64_t it0, uint32_t replica,
+                                    uint64_t *chunks, double *Es, int64_t *accepted_out, double *lfields_out)
+{
+    spf_t X = {N, K, A, J, NULL, NULL, -1, form};
+    X.lfields = (double *)malloc((size_t)N * sizeof(double));
+    X.lfields_last = (double *)malloc((size_t)N * sizeof(double));
+    double E = spf_energy(&X, chunks);
+    int64_t accepted = 0, nsamp = 0;
+    for (int64_t it = 1; it <= iters; ++it) {
+        if (it % step == 0) Es[nsamp++] = E;
+        uint64_t g = it0 + (uint64_t)it;
+        int64_t i = orc_site(seed, g, N);
+        double dE = -X.lfields[i];
+        double x = -beta * dE;
+        int acc = (x >= 0) || (orc_rand53(seed, g, replica) < orc_det_exp(x));      /* RRRMC.jl:39 */
+        if (!acc) continue;
+        bitflip(chunks, i);
+        spf_update_cache(&X, chunks, i);
+        E += dE;
+        accepted += 1;
+    }
+    if (accepted_out) *accepted_out = accepted;
+    if (lfields_out) memcpy(lfields_out, X.lfields, (size_t)N * sizeof(double));
+    free(X.lfields); free(X.lfields_last);
+    return nsamp;
+}
+
 /* =============================================================================================
  * Reduced-rejection-rate path: ArraySet, DeltaECache, GraphQT, GraphQuant, rrrMC(DoubleGraph)
  * ============================================================================================= */

@@ -25,6 +25,7 @@ SYMBOLS = [
     "rrrmc_set_couplings_bits", "rrrmc_gen_sk_binary", "rrrmc_set_coloring", "rrrmc_colored_sweeps_async",
     "rrrmc_ctx_create_quant", "rrrmc_quant_set_field", "rrrmc_rrr_mc_async", "rrrmc_rrr_stats", "rrrmc_rrr_cache", "rrrmc_bkl_mc_async",
     "rrrmc_snapshot_reserve", "rrrmc_snapshot_store", "rrrmc_snapshot_get", "rrrmc_overlaps", "rrrmc_quant_observables",
+    "rrrmc_set_graph_f64", "rrrmc_gen_couplings_gauss",
 ]
 
 
@@ -128,6 +129,10 @@ def lib():
     L.rrrmc_overlaps.argtypes = [vp, C.c_int64, i32p, i32p, i32p]
     L.rrrmc_quant_observables.restype = C.c_int32
     L.rrrmc_quant_observables.argtypes = [vp, C.c_double, C.c_double, vp, vp, vp]
+    L.rrrmc_set_graph_f64.restype = C.c_int32
+    L.rrrmc_set_graph_f64.argtypes = [vp, i32p, f64p]
+    L.rrrmc_gen_couplings_gauss.restype = C.c_int32
+    L.rrrmc_gen_couplings_gauss.argtypes = [C.c_int64, C.c_int64, i32p, C.c_uint64, f64p]
     _lib = L
     return L
 

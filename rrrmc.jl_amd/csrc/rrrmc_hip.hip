@@ -16,6 +16,7 @@
 #include "rrr_kernels.hpp"
 #include "sparse_kernels.hpp"
 #include "obs_kernels.hpp"
+#include "spf_kernels.hpp"
 
 using namespace rrrmc;
 
@@ -125,6 +126,12 @@ struct rrrmc_ctx {
     uint32_t* rs_spins = nullptr;
     int32_t* rs_status = nullptr;
 
+    // ---- RRRMC_MODEL_SPARSE_F64 (GraphRRGNormal / GraphEANormal): shares sk_lf / sk_lfl / sk_move_last / sk_E / sk_Es / d_acc ----
+    double* pf_J = nullptr;        // [N][K]
+    uint32_t* pf_spins = nullptr;  // [W][NW][64] lane-private bit words
+    uint32_t* pf_stage = nullptr;  // [Rpad][2*nch] staging in BitVector word order
+    int32_t* pf_sites = nullptr;   // site stream of one launch
+    int64_t pfW = 0, pfNW = 0;
     // ---- snapshots / observables ----
     uint8_t* snap = nullptr;       // [nslots][snap_bytes]: copies of the model's native spin buffer
     int32_t snap_slots = 0;
@@ -453,6 +460,159 @@ int32_t sk_standard_mc_async(rrrmc_ctx* ctx, double beta, int64_t iters, int64_t
 }
 
 
+// ---- Float64-coupling sparse models (GraphRRGNormal / GraphEANormal) host side ------------------------------------
+constexpr int64_t kSpfItersPerLaunch = 1 << 20;
+
+int32_t spf_ctx_create(rrrmc_ctx** out, int64_t N, int64_t K, int64_t R, int32_t device, uint32_t replica0)
+{
+    if (N < 1 || K < 1 || R < 1) return fail(nullptr, RRRMC_ERR_INVALID_ARG, "N, K, R must be >= 1 (given N=%lld K=%lld R=%lld)", (long long)N, (long long)K, (long long)R);
+    if (K > kSpfMaxK) return fail(nullptr, RRRMC_ERR_UNSUPPORTED, "K=%lld: the Float64 sparse kernels cover K <= %d", (long long)K, kSpfMaxK);
+    if (N > (int64_t)INT32_MAX / 64) return fail(nullptr, RRRMC_ERR_UNSUPPORTED, "N=%lld is too large", (long long)N);
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(nullptr, RRRMC_ERR_HIP, "no HIP device is visible: this library has no CPU path");
+    if (device < 0 || device >= ndev) return fail(nullptr, RRRMC_ERR_INVALID_ARG, "device %d out of range (0..%d)", device, ndev - 1);
+    rrrmc_ctx* ctx = new (std::nothrow) rrrmc_ctx();
+    if (!ctx) return fail(nullptr, RRRMC_ERR_NOMEM, "out of host memory");
+    ctx->model = RRRMC_MODEL_SPARSE_F64; ctx->N = N; ctx->K = K; ctx->R = R;
+    ctx->pfW = (R + 63) / 64; ctx->Rpad = ctx->pfW * 64; ctx->pfNW = (N + 31) / 32;
+    ctx->device = device; ctx->replica0 = replica0;
+#define PF_TRY(expr)                                                                                             \
+    do {                                                                                                         \
+        hipError_t e_ = (expr);                                                                                  \
+        if (e_ != hipSuccess) {                                                                                  \
+            int32_t rc_ = fail(nullptr, e_ == hipErrorOutOfMemory ? RRRMC_ERR_NOMEM : RRRMC_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
+            rrrmc_ctx_destroy(ctx);                                                                              \
+            return rc_;                                                                                          \
+        }                                                                                                        \
+    } while (0)
+    PF_TRY(hipSetDevice(device));
+    PF_TRY(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+    PF_TRY(hipEventCreate(&ctx->ev_begin));
+    PF_TRY(hipEventCreate(&ctx->ev_end));
+    const size_t nf = (size_t)ctx->Rpad * (size_t)N;
+    const size_t nsw = (size_t)ctx->pfW * (size_t)ctx->pfNW * 64;
+    PF_TRY(hipMalloc(&ctx->d_A, sizeof(int32_t) * N * K));
+    PF_TRY(hipMalloc(&ctx->pf_J, sizeof(double) * N * K));
+    PF_TRY(hipMalloc(&ctx->sk_lf, sizeof(double) * nf));
+    PF_TRY(hipMalloc(&ctx->sk_lfl, sizeof(double) * nf));
+    PF_TRY(hipMalloc(&ctx->pf_spins, sizeof(uint32_t) * nsw));
+    PF_TRY(hipMalloc(&ctx->pf_stage, sizeof(uint64_t) * (size_t)ctx->Rpad * (size_t)((N + 63) / 64)));
+    PF_TRY(hipMalloc(&ctx->pf_sites, sizeof(int32_t) * kSpfItersPerLaunch));
+    PF_TRY(hipMalloc(&ctx->sk_move_last, sizeof(int32_t) * ctx->Rpad));
+    PF_TRY(hipMalloc(&ctx->sk_E, sizeof(double) * ctx->Rpad));
+    PF_TRY(hipMalloc(&ctx->d_acc, sizeof(int64_t) * ctx->Rpad));
+    PF_TRY(hipMemset(ctx->pf_spins, 0, sizeof(uint32_t) * nsw));
+    PF_TRY(hipMemset(ctx->sk_lf, 0, sizeof(double) * nf));
+    PF_TRY(hipMemset(ctx->sk_lfl, 0, sizeof(double) * nf));
+#undef PF_TRY
+    *out = ctx;
+    return RRRMC_OK;
+}
+
+SpfParams spf_params(rrrmc_ctx* ctx)
+{
+    SpfParams P{};
+    P.A = ctx->d_A; P.J = ctx->pf_J; P.sites = ctx->pf_sites; P.spins = ctx->pf_spins; P.lf = ctx->sk_lf; P.lfl = ctx->sk_lfl;
+    P.move_last = ctx->sk_move_last; P.E_cur = ctx->sk_E; P.acc_cur = ctx->d_acc; P.Es = ctx->sk_Es;
+    P.k0 = (uint32_t)ctx->seed; P.k1 = (uint32_t)(ctx->seed >> 32); P.replica0 = ctx->replica0;
+    P.N = (int)ctx->N; P.NW = (int)ctx->pfNW; P.Rpad = (int)ctx->Rpad;
+    return P;
+}
+
+typedef void (*spf_fn)(SpfParams);
+spf_fn spf_sweep_for_K(int K)
+{
+    switch (K) {
+        case 1: return spf_sweep_kernel<1>;
+        case 2: return spf_sweep_kernel<2>;
+        case 3: return spf_sweep_kernel<3>;
+        case 4: return spf_sweep_kernel<4>;
+        case 5: return spf_sweep_kernel<5>;
+        case 6: return spf_sweep_kernel<6>;
+        case 7: return spf_sweep_kernel<7>;
+        case 8: return spf_sweep_kernel<8>;
+        default: return nullptr;
+    }
+}
+spf_fn spf_energy_for_K(int K)
+{
+    switch (K) {
+        case 1: return spf_energy_kernel<1>;
+        case 2: return spf_energy_kernel<2>;
+        case 3: return spf_energy_kernel<3>;
+        case 4: return spf_energy_kernel<4>;
+        case 5: return spf_energy_kernel<5>;
+        case 6: return spf_energy_kernel<6>;
+        case 7: return spf_energy_kernel<7>;
+        case 8: return spf_energy_kernel<8>;
+        default: return nullptr;
+    }
+}
+
+int32_t spf_run_energy(rrrmc_ctx* ctx)
+{
+    hipLaunchKernelGGL(spf_energy_for_K((int)ctx->K), dim3((unsigned)ctx->pfW), dim3(64), 0, ctx->stream, spf_params(ctx));
+    HIP_TRY(ctx, hipGetLastError());
+    return RRRMC_OK;
+}
+
+int32_t spf_standard_mc_async(rrrmc_ctx* ctx, double beta, int64_t iters, int64_t step)
+{
+    if (iters < 0) return fail(ctx, RRRMC_ERR_INVALID_ARG, "iters must be >= 0, given %lld", (long long)iters);
+    if (step < 1) return fail(ctx, RRRMC_ERR_INVALID_ARG, "step must be >= 1, given %lld", (long long)step);
+    if (std::isnan(beta)) return fail(ctx, RRRMC_ERR_INVALID_ARG, "beta is NaN");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    ctx->results_valid = false;
+    ctx->timing_valid = false;
+    ctx->last_call_rrr = false;
+    const int64_t nsamp = iters / step;
+    const size_t es_need = (size_t)(nsamp > 0 ? nsamp : 1) * ctx->Rpad;
+    if (es_need > ctx->sk_Es_cap) {
+        free_dev(ctx->sk_Es);
+        ctx->sk_Es_cap = 0;
+        HIP_TRY(ctx, hipMalloc(&ctx->sk_Es, sizeof(double) * es_need));
+        ctx->sk_Es_cap = es_need;
+    }
+    const int64_t nl = (iters + kSpfItersPerLaunch - 1) / kSpfItersPerLaunch;
+    while ((int64_t)ctx->ev_sweep.size() < 2 * (nl > 0 ? nl : 1)) {
+        hipEvent_t e;
+        HIP_TRY(ctx, hipEventCreate(&e));
+        ctx->ev_sweep.push_back(e);
+    }
+    hipStream_t st = ctx->stream;
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_begin, st));
+    int32_t rc = spf_run_energy(ctx);          // E = energy(X, C) at the start of every call, RRRMC.jl:95
+    if (rc) return rc;
+    HIP_TRY(ctx, hipMemsetAsync(ctx->d_acc, 0, sizeof(int64_t) * ctx->Rpad, st));
+    spf_fn fn = spf_sweep_for_K((int)ctx->K);
+    int64_t done = 0;
+    int launches = 0;
+    while (done < iters) {
+        const int64_t n = std::min<int64_t>(kSpfItersPerLaunch, iters - done);
+        hipLaunchKernelGGL(spf_sites_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, ctx->pf_sites, n, ctx->it_done + (uint64_t)done,
+                           (uint32_t)ctx->seed, (uint32_t)(ctx->seed >> 32), (uint32_t)ctx->N);
+        HIP_TRY(ctx, hipGetLastError());
+        SpfParams P = spf_params(ctx);
+        P.beta = beta; P.g0 = ctx->it_done + (uint64_t)done; P.iters = n; P.step = step;
+        P.it_off = done; P.sample0 = done / step;
+        HIP_TRY(ctx, hipEventRecord(ctx->ev_sweep[2 * launches], st));
+        hipLaunchKernelGGL(fn, dim3((unsigned)ctx->pfW), dim3(64), 0, st, P);
+        HIP_TRY(ctx, hipGetLastError());
+        HIP_TRY(ctx, hipEventRecord(ctx->ev_sweep[2 * launches + 1], st));
+        ++launches;
+        done += n;
+    }
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_end, st));
+    ctx->sweep_launches = launches;
+    ctx->nsamp = nsamp;
+    ctx->it_done += (uint64_t)iters;
+    ctx->results_valid = true;
+    ctx->timing_valid = true;
+    return RRRMC_OK;
+}
+
+
 // ---- GraphQuant / rrrMC host side -----------------------------------------------------------------------------------
 RrrParams quant_params(rrrmc_ctx* ctx, double beta, double fourK)
 {
@@ -655,7 +815,9 @@ int32_t rrrmc_ctx_create(rrrmc_ctx** out, int32_t model, int64_t N, int64_t K, i
     if (!out) return fail(nullptr, RRRMC_ERR_INVALID_ARG, "out is NULL");
     *out = nullptr;
     if (model == RRRMC_MODEL_QUANT_RRG) return fail(nullptr, RRRMC_ERR_INVALID_ARG, "RRRMC_MODEL_QUANT_RRG contexts are created with rrrmc_ctx_create_quant");
-    if (model != RRRMC_MODEL_SPARSE_PM1 && model != RRRMC_MODEL_SK_NORMAL && model != RRRMC_MODEL_SK_BINARY) return fail(nullptr, RRRMC_ERR_UNSUPPORTED, "unknown model kind %d", model);
+    if (model != RRRMC_MODEL_SPARSE_PM1 && model != RRRMC_MODEL_SK_NORMAL && model != RRRMC_MODEL_SK_BINARY && model != RRRMC_MODEL_SPARSE_F64)
+        return fail(nullptr, RRRMC_ERR_UNSUPPORTED, "unknown model kind %d", model);
+    if (model == RRRMC_MODEL_SPARSE_F64) return spf_ctx_create(out, N, K, R, device, replica0);
     if (model == RRRMC_MODEL_SK_NORMAL || model == RRRMC_MODEL_SK_BINARY) return sk_ctx_create(out, model, N, R, device, replica0);
     if (N < 1 || K < 1 || R < 1) return fail(nullptr, RRRMC_ERR_INVALID_ARG, "N, K, R must be >= 1 (given N=%lld K=%lld R=%lld)", (long long)N, (long long)K, (long long)R);
     if (K > kMaxK) return fail(nullptr, RRRMC_ERR_UNSUPPORTED, "K=%lld: the sparse +-J kernels cover K <= %d", (long long)K, kMaxK);
@@ -737,6 +899,7 @@ void rrrmc_ctx_destroy(rrrmc_ctx* ctx)
     free_dev(ctx->q_T); free_dev(ctx->q_z); free_dev(ctx->q_accrate); free_dev(ctx->q_stats);
     free_dev(ctx->rs_buf); free_dev(ctx->rs_spins); free_dev(ctx->rs_status);
     free_dev(ctx->rp_spins); free_dev(ctx->rp_cls); free_dev(ctx->rp_sv); free_dev(ctx->rp_spos);
+    free_dev(ctx->pf_J); free_dev(ctx->pf_spins); free_dev(ctx->pf_stage); free_dev(ctx->pf_sites);
     free_dev(ctx->snap); free_dev(ctx->d_pairs); free_dev(ctx->d_ovl); free_dev(ctx->d_qobs);
     for (int i = 0; i < 2; ++i) { free_dev(ctx->d_slots[i]); free_dev(ctx->d_vecs[i]); }
     if (ctx->plan_stream) { (void)hipStreamSynchronize(ctx->plan_stream); (void)hipStreamDestroy(ctx->plan_stream); }
@@ -830,6 +993,15 @@ int32_t rrrmc_init_spins_random(rrrmc_ctx* ctx)
         ctx->spins_set = true;
         return RRRMC_OK;
     }
+    if (ctx->model == RRRMC_MODEL_SPARSE_F64) {
+        const dim3 grid((unsigned)((ctx->pfNW + 3) / 4), (unsigned)ctx->pfW);
+        hipLaunchKernelGGL(spf_init_spins_kernel, grid, dim3(256), 0, ctx->stream, ctx->pf_spins, (int)ctx->N, (int)ctx->pfNW, ctx->replica0,
+                           (uint32_t)ctx->seed, (uint32_t)(ctx->seed >> 32));
+        HIP_TRY(ctx, hipGetLastError());
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        ctx->spins_set = true;
+        return RRRMC_OK;
+    }
     const dim3 grid((unsigned)((ctx->N + 255) / 256), (unsigned)ctx->G);
     hipLaunchKernelGGL(init_spins_kernel, grid, dim3(256), 0, ctx->stream, ctx->d_spins, (int)ctx->N, ctx->replica0 / 32,
                        (uint32_t)ctx->seed, (uint32_t)(ctx->seed >> 32));
@@ -854,6 +1026,18 @@ int32_t rrrmc_set_spins(rrrmc_ctx* ctx, const uint64_t* chunks)
         HIP_TRY(ctx, hipSetDevice(ctx->device));
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
         HIP_TRY(ctx, hipMemcpy(ctx->q_spins, chunks, sizeof(uint64_t) * ctx->R * nch, hipMemcpyHostToDevice));
+        ctx->spins_set = true;
+        return RRRMC_OK;
+    }
+    if (ctx->model == RRRMC_MODEL_SPARSE_F64) {    // BitVector words -> lane-private words on the device
+        HIP_TRY(ctx, hipSetDevice(ctx->device));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        HIP_TRY(ctx, hipMemset(ctx->pf_stage, 0, sizeof(uint64_t) * ctx->Rpad * nch));
+        HIP_TRY(ctx, hipMemcpy(ctx->pf_stage, chunks, sizeof(uint64_t) * ctx->R * nch, hipMemcpyHostToDevice));
+        const dim3 grid((unsigned)((ctx->pfNW + 3) / 4), (unsigned)ctx->pfW);
+        hipLaunchKernelGGL(spf_spins_in_kernel, grid, dim3(256), 0, ctx->stream, ctx->pf_stage, ctx->pf_spins, (int)ctx->pfNW, (int)(2 * nch));
+        HIP_TRY(ctx, hipGetLastError());
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
         ctx->spins_set = true;
         return RRRMC_OK;
     }
@@ -888,12 +1072,14 @@ namespace {
 const void* native_spins(const rrrmc_ctx* ctx)
 {
     if (ctx->model == RRRMC_MODEL_QUANT_RRG) return ctx->q_spins;
+    if (ctx->model == RRRMC_MODEL_SPARSE_F64) return ctx->pf_spins;
     if (ctx->model == RRRMC_MODEL_SK_NORMAL || ctx->model == RRRMC_MODEL_SK_BINARY) return ctx->sk_spins;
     return ctx->d_spins;
 }
 size_t native_spin_bytes(const rrrmc_ctx* ctx)
 {
     if (ctx->model == RRRMC_MODEL_QUANT_RRG) return sizeof(uint32_t) * (size_t)ctx->R * (size_t)ctx->qW;
+    if (ctx->model == RRRMC_MODEL_SPARSE_F64) return sizeof(uint32_t) * (size_t)ctx->pfW * (size_t)ctx->pfNW * 64;
     if (ctx->model == RRRMC_MODEL_SK_NORMAL || ctx->model == RRRMC_MODEL_SK_BINARY) return (size_t)ctx->G8 * (size_t)ctx->N;
     return sizeof(uint32_t) * (size_t)ctx->G * (size_t)ctx->N;
 }
@@ -906,6 +1092,15 @@ int32_t spins_to_chunks(rrrmc_ctx* ctx, const void* src, uint64_t* chunks)
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     if (ctx->model == RRRMC_MODEL_QUANT_RRG) {
         HIP_TRY(ctx, hipMemcpy(chunks, src, sizeof(uint64_t) * ctx->R * nch, hipMemcpyDeviceToHost));
+        return RRRMC_OK;
+    }
+    if (ctx->model == RRRMC_MODEL_SPARSE_F64) {
+        HIP_TRY(ctx, hipMemsetAsync(ctx->pf_stage, 0, sizeof(uint64_t) * ctx->Rpad * nch, ctx->stream));
+        const dim3 grid((unsigned)((ctx->pfNW + 3) / 4), (unsigned)ctx->pfW);
+        hipLaunchKernelGGL(spf_spins_out_kernel, grid, dim3(256), 0, ctx->stream, (const uint32_t*)src, ctx->pf_stage, (int)ctx->pfNW, (int)(2 * nch));
+        HIP_TRY(ctx, hipGetLastError());
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        HIP_TRY(ctx, hipMemcpy(chunks, ctx->pf_stage, sizeof(uint64_t) * ctx->R * nch, hipMemcpyDeviceToHost));
         return RRRMC_OK;
     }
     if (ctx->model == RRRMC_MODEL_SK_NORMAL || ctx->model == RRRMC_MODEL_SK_BINARY) {
@@ -991,6 +1186,7 @@ int32_t rrrmc_standard_mc_async(rrrmc_ctx* ctx, double beta, int64_t iters, int6
     int32_t rc = ensure_state(ctx, true);
     if (rc) return rc;
     if (ctx->model == RRRMC_MODEL_SK_NORMAL || ctx->model == RRRMC_MODEL_SK_BINARY) return sk_standard_mc_async(ctx, beta, iters, step);
+    if (ctx->model == RRRMC_MODEL_SPARSE_F64) return spf_standard_mc_async(ctx, beta, iters, step);
     if (ctx->model != RRRMC_MODEL_SPARSE_PM1) return fail(ctx, RRRMC_ERR_UNSUPPORTED, "standardMC is not wired for this model on the device: use rrrmc_rrr_mc_async");
     if (!ctx->lds_mode) return fail(ctx, RRRMC_ERR_UNSUPPORTED, "N=%lld does not fit the LDS-resident random-site kernel: use rrrmc_colored_sweeps_async", (long long)ctx->N);
     ctx->colored_call = false;
@@ -1507,6 +1703,8 @@ int32_t rrrmc_energy_f64(rrrmc_ctx* ctx, double* E_out)
     if (ctx->model == RRRMC_MODEL_QUANT_RRG) {
         if (!(ctx->last_fourK > 0.0)) return fail(ctx, RRRMC_ERR_STATE, "energy of a GraphQuant needs fourK: call rrrmc_quant_set_field first");
         rc = quant_run_init(ctx, ctx->last_beta, ctx->last_fourK);
+    } else if (ctx->model == RRRMC_MODEL_SPARSE_F64) {
+        rc = spf_run_energy(ctx);
     } else {
         rc = sk_run_energy(ctx);
     }
@@ -1522,10 +1720,19 @@ int32_t rrrmc_get_fields_f64(rrrmc_ctx* ctx, double* lfields_out)
 {
     int32_t rc = ensure_state(ctx, true);
     if (rc) return rc;
-    if (ctx->model != RRRMC_MODEL_SK_NORMAL) return fail(ctx, RRRMC_ERR_STATE, "this model's fields are integers (or not cached): use rrrmc_get_fields");
+    if (ctx->model != RRRMC_MODEL_SK_NORMAL && ctx->model != RRRMC_MODEL_SPARSE_F64)
+        return fail(ctx, RRRMC_ERR_STATE, "this model's fields are integers (or not cached): use rrrmc_get_fields");
     if (!lfields_out) return fail(ctx, RRRMC_ERR_INVALID_ARG, "lfields_out is NULL");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const int64_t N = ctx->N;
+    if (ctx->model == RRRMC_MODEL_SPARSE_F64) {
+        std::vector<double> lf((size_t)ctx->Rpad * N);
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        HIP_TRY(ctx, hipMemcpy(lf.data(), ctx->sk_lf, sizeof(double) * lf.size(), hipMemcpyDeviceToHost));
+        for (int64_t r = 0; r < ctx->R; ++r)
+            for (int64_t x = 0; x < N; ++x) lfields_out[r * N + x] = lf[((r >> 6) * N + x) * 64 + (r & 63)];
+        return RRRMC_OK;
+    }
     std::vector<double> lf((size_t)ctx->G8 * N * kSkRB);
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     HIP_TRY(ctx, hipMemcpy(lf.data(), ctx->sk_lf, sizeof(double) * lf.size(), hipMemcpyDeviceToHost));   // the live cache (not recomputed)
@@ -1669,7 +1876,10 @@ int32_t rrrmc_overlaps(rrrmc_ctx* ctx, int64_t npairs, const int32_t* slotA, con
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));      // tab is pageable host memory
     void** pa = ctx->d_pairs;
     void** pb = ctx->d_pairs + npairs;
-    if (ctx->model == RRRMC_MODEL_QUANT_RRG) {
+    if (ctx->model == RRRMC_MODEL_SPARSE_F64) {
+        hipLaunchKernelGGL(overlap_lanes_kernel, dim3((unsigned)ctx->pfW, (unsigned)npairs), dim3(64), 0, ctx->stream,
+                           (const uint32_t* const*)pa, (const uint32_t* const*)pb, (int)ctx->N, (int)ctx->pfNW, (int)ctx->Rpad, ctx->d_ovl);
+    } else if (ctx->model == RRRMC_MODEL_QUANT_RRG) {
         hipLaunchKernelGGL(overlap_chunks_kernel, dim3((unsigned)ctx->R, (unsigned)npairs), dim3(64), 0, ctx->stream,
                            (const uint32_t* const*)pa, (const uint32_t* const*)pb, (int)ctx->N, (int)ctx->qW, (int)ctx->Rpad, ctx->d_ovl);
     } else if (ctx->model == RRRMC_MODEL_SK_NORMAL || ctx->model == RRRMC_MODEL_SK_BINARY) {
@@ -1731,6 +1941,73 @@ int32_t rrrmc_quant_observables(rrrmc_ctx* ctx, double beta, double Gamma, doubl
     return RRRMC_OK;
 }
 
+namespace {
+// n-th normal of the GAUSS stream: Box-Muller on the two 53-bit uniforms of Philox block n >> 1 (cos / sin branch)  [randn()]
+double gauss_draw(uint64_t seed, uint64_t n)
+{
+    const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+    const uint64_t blk = n >> 1;
+    const Philox4 o = philox4x32_10((uint32_t)blk, (uint32_t)(blk >> 32), 0u, TAG_GAUSS, k0, k1);
+    const uint64_t a = ((uint64_t)o.w[0] << 32) | o.w[1], b = ((uint64_t)o.w[2] << 32) | o.w[3];
+    const double u1 = ((double)(a >> 11) + 1.0) * 0x1.0p-53, u2 = (double)(b >> 11) * 0x1.0p-53;
+    const double rad = std::sqrt(-2.0 * std::log(u1)), ang = 6.283185307179586476925286766559 * u2;
+    return (n & 1u) ? rad * std::sin(ang) : rad * std::cos(ang);
+}
+}  // namespace
+
+int32_t rrrmc_set_graph_f64(rrrmc_ctx* ctx, const int32_t* A, const double* J)
+{
+    if (!ctx) return RRRMC_ERR_INVALID_ARG;
+    if (ctx->model != RRRMC_MODEL_SPARSE_F64) return fail(ctx, RRRMC_ERR_STATE, "rrrmc_set_graph_f64 is for RRRMC_MODEL_SPARSE_F64");
+    if (!A || !J) return fail(ctx, RRRMC_ERR_INVALID_ARG, "A and J must not be NULL");
+    const int64_t N = ctx->N, K = ctx->K;
+    for (int64_t q = 0; q < N * K; ++q) {
+        if (A[q] < 0 || A[q] >= N) return fail(ctx, RRRMC_ERR_INVALID_ARG, "A[%lld] = %d out of range 0..%lld", (long long)q, A[q], (long long)(N - 1));
+        if (!std::isfinite(J[q])) return fail(ctx, RRRMC_ERR_INVALID_ARG, "J[%lld] is not finite", (long long)q);
+        if (A[q] == q / K) return fail(ctx, RRRMC_ERR_INVALID_ARG, "self loop at site %lld", (long long)(q / K));
+        if (q % K && A[q] < A[q - 1]) return fail(ctx, RRRMC_ERR_INVALID_ARG, "row %lld of A is not sorted", (long long)(q / K));   // EA.jl:46, RRG.jl:64
+    }
+    // every bond must appear from both ends with the same coupling (multi-edges allowed: GraphEANormal with L = 2)
+    std::vector<uint8_t> used((size_t)(N * K), 0);
+    for (int64_t x = 0; x < N; ++x)
+        for (int64_t k = 0; k < K; ++k) {
+            const int64_t y = A[x * K + k];
+            bool found = false;
+            for (int64_t l = 0; l < K && !found; ++l)
+                if (!used[y * K + l] && A[y * K + l] == x && J[y * K + l] == J[x * K + k]) { used[y * K + l] = 1; found = true; }
+            if (!found) return fail(ctx, RRRMC_ERR_INVALID_ARG, "bond (%lld,%lld) is not symmetric in (A, J)", (long long)x, (long long)y);
+        }
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipMemcpy(ctx->d_A, A, sizeof(int32_t) * N * K, hipMemcpyHostToDevice));
+    HIP_TRY(ctx, hipMemcpy(ctx->pf_J, J, sizeof(double) * N * K, hipMemcpyHostToDevice));
+    ctx->graph_set = true;
+    return RRRMC_OK;
+}
+
+int32_t rrrmc_gen_couplings_gauss(int64_t N, int64_t K, const int32_t* A, uint64_t seed, double* J_out)
+{
+    if (N < 1 || K < 1 || !A || !J_out) return RRRMC_ERR_INVALID_ARG;
+    std::vector<uint8_t> filled((size_t)(N * K), 0);
+    uint64_t ndraw = 0;
+    for (int64_t x = 0; x < N; ++x)
+        for (int64_t k = 0; k < K; ++k) {
+            const int64_t y = A[x * K + k];
+            if (y < 0 || y >= N) return RRRMC_ERR_INVALID_ARG;
+            if (x < y) {
+                const double Jxy = gauss_draw(seed, ndraw++);
+                if (filled[x * K + k]) return RRRMC_ERR_INVALID_ARG;
+                J_out[x * K + k] = Jxy; filled[x * K + k] = 1;
+                int64_t l = 0;
+                while (l < K && filled[y * K + l]) ++l;          // findfirst(==(m), J[y]): RRG.jl:84
+                if (l == K) return RRRMC_ERR_INVALID_ARG;
+                J_out[y * K + l] = Jxy; filled[y * K + l] = 1;
+            }
+        }
+    for (int64_t q = 0; q < N * K; ++q) if (!filled[q]) return RRRMC_ERR_INVALID_ARG;
+    return RRRMC_OK;
+}
+
 int32_t rrrmc_gen_sk_binary(int64_t N, uint64_t seed, uint64_t* Jc)
 {
     // gen_J, src/graphs/SK.jl:17-26: rows of bitrand(N), zero diagonal, upper triangle mirrored.  SKBITS stream:
@@ -1759,20 +2036,11 @@ int32_t rrrmc_gen_sk_binary(int64_t N, uint64_t seed, uint64_t* Jc)
 int32_t rrrmc_gen_sk_gauss(int64_t N, uint64_t seed, double* J_out)
 {
     // gen_J_gauss, src/graphs/SK.jl:170-179: rows of randn(N) scaled by 1/sqrt(N), zero diagonal, upper triangle mirrored.
-    // n-th normal of the GAUSS stream: Box-Muller on the two 53-bit uniforms of Philox block n >> 1 (cos / sin branch).
     if (!J_out) return fail(nullptr, RRRMC_ERR_INVALID_ARG, "J_out is NULL");
     if (N < 1) return fail(nullptr, RRRMC_ERR_INVALID_ARG, "N must be >= 1");
-    const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
     const double scale = 1.0 / std::sqrt((double)N);
     for (int64_t i = 0; i < N; ++i)
-        for (int64_t j = 0; j < N; ++j) {
-            const uint64_t n = (uint64_t)(i * N + j), blk = n >> 1;
-            const Philox4 o = philox4x32_10((uint32_t)blk, (uint32_t)(blk >> 32), 0u, TAG_GAUSS, k0, k1);
-            const uint64_t a = ((uint64_t)o.w[0] << 32) | o.w[1], b = ((uint64_t)o.w[2] << 32) | o.w[3];
-            const double u1 = ((double)(a >> 11) + 1.0) * 0x1.0p-53, u2 = (double)(b >> 11) * 0x1.0p-53;
-            const double rad = std::sqrt(-2.0 * std::log(u1)), ang = 6.283185307179586476925286766559 * u2;
-            J_out[i * N + j] = ((n & 1u) ? rad * std::sin(ang) : rad * std::cos(ang)) * scale;
-        }
+        for (int64_t j = 0; j < N; ++j) J_out[i * N + j] = gauss_draw(seed, (uint64_t)(i * N + j)) * scale;
     for (int64_t i = 0; i < N; ++i) {
         J_out[i * N + i] = 0.0;
         for (int64_t j = i + 1; j < N; ++j) J_out[j * N + i] = J_out[i * N + j];

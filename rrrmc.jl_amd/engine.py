@@ -10,6 +10,7 @@ MODEL_SPARSE_PM1 = 1
 MODEL_SK_NORMAL = 2
 MODEL_QUANT_RRG = 3
 MODEL_SK_BINARY = 4
+MODEL_SPARSE_F64 = 5
 
 
 class Engine:
@@ -27,6 +28,8 @@ class Engine:
             if X.model_kind == MODEL_QUANT_RRG:
                 check(lib().rrrmc_set_graph(self._ctx, X.A, X.J), self._ctx)
                 check(lib().rrrmc_quant_set_field(self._ctx, X.beta, X.fourK), self._ctx)
+            elif X.model_kind == MODEL_SPARSE_F64:
+                check(lib().rrrmc_set_graph_f64(self._ctx, X.A, X.J.reshape(-1)), self._ctx)
             elif X.model_kind == MODEL_SK_BINARY:
                 check(lib().rrrmc_set_couplings_bits(self._ctx, X.J.reshape(-1)), self._ctx)
             elif self._f64:
@@ -84,7 +87,7 @@ class Engine:
         return E
 
     def fields(self):
-        f64 = self.X.model_kind == MODEL_SK_NORMAL        # GraphSK's cache is integer (SK.jl:33)
+        f64 = self.X.model_kind in (MODEL_SK_NORMAL, MODEL_SPARSE_F64)        # GraphSK's cache is integer (SK.jl:33)
         lf = np.zeros((self.R, self.X.N), np.float64 if f64 else np.int64)
         check((lib().rrrmc_get_fields_f64 if f64 else lib().rrrmc_get_fields)(self._ctx, lf.reshape(-1)), self._ctx)
         return lf

@@ -114,6 +114,98 @@ class GraphEA(_SparsePM1Graph):
         return self
 
 
+class _SparseF64Graph:
+    """Common part of GraphRRGNormal / GraphEANormal: neighbour table A[N, K], Float64 couplings J[N, K]."""
+    model_kind = 5          # RRRMC_MODEL_SPARSE_F64
+    energy_dtype = np.float64
+
+    def __init__(self, A, J):
+        A = np.ascontiguousarray(A, np.int32)
+        J = np.ascontiguousarray(J, np.float64)
+        if A.ndim != 2 or A.shape != J.shape:
+            raise ValueError("incompatible shapes of A and J: %r, %r" % (A.shape, J.shape))
+        self.N, self.K = A.shape
+        self.A, self.J = A, J
+
+    @classmethod
+    def from_AJ(cls, A, J):
+        self = cls.__new__(cls)
+        _SparseF64Graph.__init__(self, A, J)
+        return self
+
+
+class GraphRRGNormal(_SparseF64Graph):
+    """``GraphRRGNormal(N, K)`` — random regular graph, couplings ~ Normal(0, 1) (src/graphs/RRG.jl:503-531).
+    GRAPH stream for the pairing, one GAUSS-stream normal per bond where the reference calls ``randn()`` (RRG.jl:510-512)."""
+
+    def __init__(self, N, K, seed=DEFAULT_SEED):
+        A = np.zeros((int(N), int(K)), np.int32)
+        check(lib().rrrmc_gen_rrg(N, K, seed, A))
+        J = np.zeros((int(N), int(K)), np.float64)
+        check(lib().rrrmc_gen_couplings_gauss(N, K, A, seed, J.reshape(-1)))
+        super().__init__(A, J)
+
+
+class GraphEANormal(_SparseF64Graph):
+    """``GraphEANormal(L, D)`` — Edwards-Anderson lattice, couplings ~ Normal(0, 1) (src/graphs/EA.jl:534-574), or
+    ``GraphEANormal(fname)`` from the text format of ``gen_AJ`` (EA.jl:73-118, D = 2):
+
+        type: <anything>
+        size: L
+        name: <anything>
+        x y Jxy          (one line per bond, 1-based sites)
+    """
+
+    def __init__(self, L, D=None, seed=DEFAULT_SEED):
+        if isinstance(L, str):
+            L, D, A, J = self._gen_AJ(L)
+        else:
+            if D < 1:
+                raise ValueError("D must be >= 0, given: %d" % D)                  # EA.jl:566
+            N = int(L) ** int(D)
+            A = np.zeros((N, 2 * int(D)), np.int32)
+            check(lib().rrrmc_gen_ea(L, D, A))
+            J = np.zeros((N, 2 * int(D)), np.float64)
+            check(lib().rrrmc_gen_couplings_gauss(N, 2 * int(D), A, seed, J.reshape(-1)))
+        super().__init__(A, J)
+        self.L, self.D = int(L), int(D)
+
+    @staticmethod
+    def _gen_AJ(fname):
+        D = 2
+        with open(fname) as f:
+            if not f.readline().strip().startswith("type:"):
+                raise ValueError("%s: expected a 'type:' line" % fname)
+            ls = f.readline().split()
+            if len(ls) != 2 or ls[0] != "size:":
+                raise ValueError("%s: expected 'size: L'" % fname)
+            L = int(ls[1])
+            if not f.readline().strip().startswith("name:"):
+                raise ValueError("%s: expected a 'name:' line" % fname)
+            N = L ** D
+            A = np.zeros((N, 2 * D), np.int32)
+            check(lib().rrrmc_gen_ea(L, D, A))
+            J = np.full((N, 2 * D), np.nan)
+            for line in f:
+                ls = line.split()
+                if not ls:
+                    continue
+                if len(ls) != 3:
+                    raise ValueError("%s: expected 'x y J', got %r" % (fname, line))
+                x, y, Jxy = int(ls[0]) - 1, int(ls[1]) - 1, float(ls[2])
+                for a, b in ((x, y), (y, x)):
+                    ks = np.nonzero(A[a] == b)[0]
+                    if ks.size == 0:
+                        raise ValueError("%s: sites %d and %d are not neighbours" % (fname, x + 1, y + 1))
+                    k = ks[0]                                                   # findfirst(Ax, y): EA.jl:99
+                    if not np.isnan(J[a, k]):
+                        raise ValueError("%s: bond (%d,%d) given twice" % (fname, x + 1, y + 1))
+                    J[a, k] = Jxy
+            if np.isnan(J).any():
+                raise ValueError("%s: some bonds are missing" % fname)
+        return L, D, A, J
+
+
 class GraphSKNormal:
     """``GraphSKNormal(N)`` — Sherrington-Kirkpatrick model, couplings ~ Normal(0, 1/N) (src/graphs/SK.jl:181-210).
 

@@ -142,3 +142,55 @@ def test_boltzmann_law_small_system(oracle):
     # mean energy against the exact value
     Es = np.array([oracle.sparse_energy(A, J, np.array([c], np.uint64)) for c in range(1 << N)])
     assert abs((hist * Es).sum() - (p * Es).sum()) < 0.15
+
+
+# ---- Float64-coupling sparse models GraphRRGNormal / GraphEANormal ----
+
+def _brute_energy_f64(A, J, bits):
+    s = 2 * bits - 1
+    N, K = A.shape
+    return -sum(J[x, k] * s[x] * s[A[x, k]] for x in range(N) for k in range(K)) / 2
+
+
+@pytest.mark.parametrize("kind,form", [("rrg", "rrg"), ("ea3", "ea"), ("ea2L2", "ea")])
+def test_spf_tracked_energy_and_cache(oracle, kind, form):
+    """test/runtests.jl:12-20 on GraphRRGNormal(10,3) / GraphEANormal(3,2) (runtests.jl:40,60) + the L=2 double-bond lattice."""
+    seed = 99
+    A = {"rrg": lambda: oracle.gen_rrg(10, 3, seed), "ea3": lambda: oracle.gen_ea(3, 2), "ea2L2": lambda: oracle.gen_ea(2, 3)}[kind]()
+    J = oracle.gen_couplings_gauss(A, seed)
+    N, K = A.shape
+    for x in range(N):                       # symmetric: bond (x, y) carries one value from both ends
+        for k in range(K):
+            y = A[x, k]
+            assert J[x, k] in J[y][A[y] == x]
+    ch = oracle.init_config(seed, 0, N)
+    E0, lf0 = oracle.spf_energy(A, J, ch, want_fields=True, form=form)
+    assert math.isclose(E0, _brute_energy_f64(A, J, _bits(ch, N)), rel_tol=1e-12, abs_tol=1e-12)
+    Es, ch1, acc, lf = oracle.standard_mc_spf(A, J, 1.5, 4000, 100, seed, ch, form=form)
+    assert len(Es) == 40 and Es[0] != Es[-1] and 0 < acc < 4000
+    E1, lf1 = oracle.spf_energy(A, J, ch1, want_fields=True, form=form)
+    assert np.allclose(lf, lf1, rtol=0, atol=1e-11)                  # incremental cache == recomputation
+    # continue the chain sample by sample: tracked energy == energy(X, C) within the reference's 1e-11 (runtests.jl:17)
+    ch2 = ch.copy()
+    for k in range(1, 6):
+        Es_k, ch2, _, _ = oracle.standard_mc_spf(A, J, 1.5, 100, 100, seed, ch2, it0=100 * (k - 1), form=form)
+        # Es_k[0] is the energy before iteration 100 of this leg == tracked energy after 99 moves; compare a fresh energy
+        assert math.isclose(Es_k[0], Es[k - 1], rel_tol=0, abs_tol=1e-11)
+
+
+def test_spf_boltzmann_small(oracle):
+    """Exact Boltzmann law on a tiny GraphRRGNormal (the reference's truep check, RRRMC.jl:528-543) through many short chains."""
+    seed, N, beta = 5, 6, 0.7
+    A = oracle.gen_rrg(N, 3, seed)
+    J = oracle.gen_couplings_gauss(A, seed)
+    counts = np.zeros(2 ** N)
+    R, iters = 3000, 400
+    for r in range(R):
+        ch = oracle.init_config(seed, r, N)
+        _, ch1, _, _ = oracle.standard_mc_spf(A, J, beta, iters, iters, seed, ch, replica=r)
+        counts[int(ch1[0])] += 1
+    Es = np.array([_brute_energy_f64(A, J, np.array([(c >> i) & 1 for i in range(N)])) for c in range(2 ** N)])
+    p = np.exp(-beta * Es)
+    p /= p.sum()
+    # chains share the site stream, so they are not independent; allow 6 sigma of the multinomial error
+    assert np.abs(counts / R - p).max() < 6 * np.sqrt(p.max() / R) + 0.01
