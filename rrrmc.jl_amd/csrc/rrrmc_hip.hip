@@ -128,10 +128,10 @@ struct rrrmc_ctx {
 
     // ---- RRRMC_MODEL_SPARSE_F64 (GraphRRGNormal / GraphEANormal): shares sk_lf / sk_lfl / sk_move_last / sk_E / sk_Es / d_acc ----
     double* pf_J = nullptr;        // [N][K]
-    uint32_t* pf_spins = nullptr;  // [W][NW][64] lane-private bit words
-    uint32_t* pf_stage = nullptr;  // [Rpad][2*nch] staging in BitVector word order
+    unsigned long long* pf_spins = nullptr;  // [W][N]: bit l = spin of replica 64 w + l
+    double* pf_undo = nullptr;     // [W][K+1][64]: live part of lfields_last (see spf_kernels.hpp)
     int32_t* pf_sites = nullptr;   // site stream of one launch
-    int64_t pfW = 0, pfNW = 0;
+    int64_t pfW = 0;
     // ---- snapshots / observables ----
     uint8_t* snap = nullptr;       // [nslots][snap_bytes]: copies of the model's native spin buffer
     int32_t snap_slots = 0;
@@ -475,7 +475,7 @@ int32_t spf_ctx_create(rrrmc_ctx** out, int64_t N, int64_t K, int64_t R, int32_t
     rrrmc_ctx* ctx = new (std::nothrow) rrrmc_ctx();
     if (!ctx) return fail(nullptr, RRRMC_ERR_NOMEM, "out of host memory");
     ctx->model = RRRMC_MODEL_SPARSE_F64; ctx->N = N; ctx->K = K; ctx->R = R;
-    ctx->pfW = (R + 63) / 64; ctx->Rpad = ctx->pfW * 64; ctx->pfNW = (N + 31) / 32;
+    ctx->pfW = (R + 63) / 64; ctx->Rpad = ctx->pfW * 64;
     ctx->device = device; ctx->replica0 = replica0;
 #define PF_TRY(expr)                                                                                             \
     do {                                                                                                         \
@@ -491,20 +491,19 @@ int32_t spf_ctx_create(rrrmc_ctx** out, int64_t N, int64_t K, int64_t R, int32_t
     PF_TRY(hipEventCreate(&ctx->ev_begin));
     PF_TRY(hipEventCreate(&ctx->ev_end));
     const size_t nf = (size_t)ctx->Rpad * (size_t)N;
-    const size_t nsw = (size_t)ctx->pfW * (size_t)ctx->pfNW * 64;
+    const size_t nsw = (size_t)ctx->pfW * (size_t)N;
     PF_TRY(hipMalloc(&ctx->d_A, sizeof(int32_t) * N * K));
     PF_TRY(hipMalloc(&ctx->pf_J, sizeof(double) * N * K));
     PF_TRY(hipMalloc(&ctx->sk_lf, sizeof(double) * nf));
-    PF_TRY(hipMalloc(&ctx->sk_lfl, sizeof(double) * nf));
-    PF_TRY(hipMalloc(&ctx->pf_spins, sizeof(uint32_t) * nsw));
-    PF_TRY(hipMalloc(&ctx->pf_stage, sizeof(uint64_t) * (size_t)ctx->Rpad * (size_t)((N + 63) / 64)));
+    PF_TRY(hipMalloc(&ctx->pf_undo, sizeof(double) * (size_t)ctx->Rpad * (size_t)(K + 1)));
+    PF_TRY(hipMalloc(&ctx->pf_spins, sizeof(unsigned long long) * nsw));
     PF_TRY(hipMalloc(&ctx->pf_sites, sizeof(int32_t) * kSpfItersPerLaunch));
     PF_TRY(hipMalloc(&ctx->sk_move_last, sizeof(int32_t) * ctx->Rpad));
     PF_TRY(hipMalloc(&ctx->sk_E, sizeof(double) * ctx->Rpad));
     PF_TRY(hipMalloc(&ctx->d_acc, sizeof(int64_t) * ctx->Rpad));
-    PF_TRY(hipMemset(ctx->pf_spins, 0, sizeof(uint32_t) * nsw));
+    PF_TRY(hipMemset(ctx->pf_spins, 0, sizeof(unsigned long long) * nsw));
     PF_TRY(hipMemset(ctx->sk_lf, 0, sizeof(double) * nf));
-    PF_TRY(hipMemset(ctx->sk_lfl, 0, sizeof(double) * nf));
+    PF_TRY(hipMemset(ctx->pf_undo, 0, sizeof(double) * (size_t)ctx->Rpad * (size_t)(K + 1)));
 #undef PF_TRY
     *out = ctx;
     return RRRMC_OK;
@@ -513,10 +512,10 @@ int32_t spf_ctx_create(rrrmc_ctx** out, int64_t N, int64_t K, int64_t R, int32_t
 SpfParams spf_params(rrrmc_ctx* ctx)
 {
     SpfParams P{};
-    P.A = ctx->d_A; P.J = ctx->pf_J; P.sites = ctx->pf_sites; P.spins = ctx->pf_spins; P.lf = ctx->sk_lf; P.lfl = ctx->sk_lfl;
+    P.A = ctx->d_A; P.J = ctx->pf_J; P.sites = ctx->pf_sites; P.spins = ctx->pf_spins; P.lf = ctx->sk_lf; P.undo = ctx->pf_undo;
     P.move_last = ctx->sk_move_last; P.E_cur = ctx->sk_E; P.acc_cur = ctx->d_acc; P.Es = ctx->sk_Es;
     P.k0 = (uint32_t)ctx->seed; P.k1 = (uint32_t)(ctx->seed >> 32); P.replica0 = ctx->replica0;
-    P.N = (int)ctx->N; P.NW = (int)ctx->pfNW; P.Rpad = (int)ctx->Rpad;
+    P.N = (int)ctx->N; P.Rpad = (int)ctx->Rpad;
     return P;
 }
 
@@ -899,7 +898,7 @@ void rrrmc_ctx_destroy(rrrmc_ctx* ctx)
     free_dev(ctx->q_T); free_dev(ctx->q_z); free_dev(ctx->q_accrate); free_dev(ctx->q_stats);
     free_dev(ctx->rs_buf); free_dev(ctx->rs_spins); free_dev(ctx->rs_status);
     free_dev(ctx->rp_spins); free_dev(ctx->rp_cls); free_dev(ctx->rp_sv); free_dev(ctx->rp_spos);
-    free_dev(ctx->pf_J); free_dev(ctx->pf_spins); free_dev(ctx->pf_stage); free_dev(ctx->pf_sites);
+    free_dev(ctx->pf_J); free_dev(ctx->pf_spins); free_dev(ctx->pf_undo); free_dev(ctx->pf_sites);
     free_dev(ctx->snap); free_dev(ctx->d_pairs); free_dev(ctx->d_ovl); free_dev(ctx->d_qobs);
     for (int i = 0; i < 2; ++i) { free_dev(ctx->d_slots[i]); free_dev(ctx->d_vecs[i]); }
     if (ctx->plan_stream) { (void)hipStreamSynchronize(ctx->plan_stream); (void)hipStreamDestroy(ctx->plan_stream); }
@@ -994,8 +993,8 @@ int32_t rrrmc_init_spins_random(rrrmc_ctx* ctx)
         return RRRMC_OK;
     }
     if (ctx->model == RRRMC_MODEL_SPARSE_F64) {
-        const dim3 grid((unsigned)((ctx->pfNW + 3) / 4), (unsigned)ctx->pfW);
-        hipLaunchKernelGGL(spf_init_spins_kernel, grid, dim3(256), 0, ctx->stream, ctx->pf_spins, (int)ctx->N, (int)ctx->pfNW, ctx->replica0,
+        const dim3 grid((unsigned)((ctx->N + 255) / 256), (unsigned)ctx->pfW);
+        hipLaunchKernelGGL(spf_init_spins_kernel, grid, dim3(256), 0, ctx->stream, ctx->pf_spins, (int)ctx->N, ctx->replica0,
                            (uint32_t)ctx->seed, (uint32_t)(ctx->seed >> 32));
         HIP_TRY(ctx, hipGetLastError());
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -1029,15 +1028,18 @@ int32_t rrrmc_set_spins(rrrmc_ctx* ctx, const uint64_t* chunks)
         ctx->spins_set = true;
         return RRRMC_OK;
     }
-    if (ctx->model == RRRMC_MODEL_SPARSE_F64) {    // BitVector words -> lane-private words on the device
+    if (ctx->model == RRRMC_MODEL_SPARSE_F64) {
+        std::vector<unsigned long long> bs((size_t)(ctx->pfW * N), 0ull);
+        for (int64_t r = 0; r < ctx->R; ++r) {
+            unsigned long long* dst = bs.data() + (r >> 6) * N;
+            const unsigned long long bit = 1ull << (r & 63);
+            const uint64_t* src = chunks + r * nch;
+            for (int64_t x = 0; x < N; ++x)
+                if ((src[x >> 6] >> (x & 63)) & 1ull) dst[x] |= bit;
+        }
         HIP_TRY(ctx, hipSetDevice(ctx->device));
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-        HIP_TRY(ctx, hipMemset(ctx->pf_stage, 0, sizeof(uint64_t) * ctx->Rpad * nch));
-        HIP_TRY(ctx, hipMemcpy(ctx->pf_stage, chunks, sizeof(uint64_t) * ctx->R * nch, hipMemcpyHostToDevice));
-        const dim3 grid((unsigned)((ctx->pfNW + 3) / 4), (unsigned)ctx->pfW);
-        hipLaunchKernelGGL(spf_spins_in_kernel, grid, dim3(256), 0, ctx->stream, ctx->pf_stage, ctx->pf_spins, (int)ctx->pfNW, (int)(2 * nch));
-        HIP_TRY(ctx, hipGetLastError());
-        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        HIP_TRY(ctx, hipMemcpy(ctx->pf_spins, bs.data(), sizeof(unsigned long long) * bs.size(), hipMemcpyHostToDevice));
         ctx->spins_set = true;
         return RRRMC_OK;
     }
@@ -1079,7 +1081,7 @@ const void* native_spins(const rrrmc_ctx* ctx)
 size_t native_spin_bytes(const rrrmc_ctx* ctx)
 {
     if (ctx->model == RRRMC_MODEL_QUANT_RRG) return sizeof(uint32_t) * (size_t)ctx->R * (size_t)ctx->qW;
-    if (ctx->model == RRRMC_MODEL_SPARSE_F64) return sizeof(uint32_t) * (size_t)ctx->pfW * (size_t)ctx->pfNW * 64;
+    if (ctx->model == RRRMC_MODEL_SPARSE_F64) return sizeof(unsigned long long) * (size_t)ctx->pfW * (size_t)ctx->N;
     if (ctx->model == RRRMC_MODEL_SK_NORMAL || ctx->model == RRRMC_MODEL_SK_BINARY) return (size_t)ctx->G8 * (size_t)ctx->N;
     return sizeof(uint32_t) * (size_t)ctx->G * (size_t)ctx->N;
 }
@@ -1095,12 +1097,15 @@ int32_t spins_to_chunks(rrrmc_ctx* ctx, const void* src, uint64_t* chunks)
         return RRRMC_OK;
     }
     if (ctx->model == RRRMC_MODEL_SPARSE_F64) {
-        HIP_TRY(ctx, hipMemsetAsync(ctx->pf_stage, 0, sizeof(uint64_t) * ctx->Rpad * nch, ctx->stream));
-        const dim3 grid((unsigned)((ctx->pfNW + 3) / 4), (unsigned)ctx->pfW);
-        hipLaunchKernelGGL(spf_spins_out_kernel, grid, dim3(256), 0, ctx->stream, (const uint32_t*)src, ctx->pf_stage, (int)ctx->pfNW, (int)(2 * nch));
-        HIP_TRY(ctx, hipGetLastError());
-        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-        HIP_TRY(ctx, hipMemcpy(chunks, ctx->pf_stage, sizeof(uint64_t) * ctx->R * nch, hipMemcpyDeviceToHost));
+        std::vector<unsigned long long> bs((size_t)(ctx->pfW * N));
+        HIP_TRY(ctx, hipMemcpy(bs.data(), src, sizeof(unsigned long long) * bs.size(), hipMemcpyDeviceToHost));
+        std::memset(chunks, 0, sizeof(uint64_t) * ctx->R * nch);
+        for (int64_t r = 0; r < ctx->R; ++r) {
+            const unsigned long long* w = bs.data() + (r >> 6) * N;
+            const int sh = (int)(r & 63);
+            uint64_t* dst = chunks + r * nch;
+            for (int64_t x = 0; x < N; ++x) dst[x >> 6] |= (uint64_t)((w[x] >> sh) & 1ull) << (x & 63);
+        }
         return RRRMC_OK;
     }
     if (ctx->model == RRRMC_MODEL_SK_NORMAL || ctx->model == RRRMC_MODEL_SK_BINARY) {
@@ -1878,7 +1883,7 @@ int32_t rrrmc_overlaps(rrrmc_ctx* ctx, int64_t npairs, const int32_t* slotA, con
     void** pb = ctx->d_pairs + npairs;
     if (ctx->model == RRRMC_MODEL_SPARSE_F64) {
         hipLaunchKernelGGL(overlap_lanes_kernel, dim3((unsigned)ctx->pfW, (unsigned)npairs), dim3(64), 0, ctx->stream,
-                           (const uint32_t* const*)pa, (const uint32_t* const*)pb, (int)ctx->N, (int)ctx->pfNW, (int)ctx->Rpad, ctx->d_ovl);
+                           (const unsigned long long* const*)pa, (const unsigned long long* const*)pb, (int)ctx->N, (int)ctx->Rpad, ctx->d_ovl);
     } else if (ctx->model == RRRMC_MODEL_QUANT_RRG) {
         hipLaunchKernelGGL(overlap_chunks_kernel, dim3((unsigned)ctx->R, (unsigned)npairs), dim3(64), 0, ctx->stream,
                            (const uint32_t* const*)pa, (const uint32_t* const*)pb, (int)ctx->N, (int)ctx->qW, (int)ctx->Rpad, ctx->d_ovl);

@@ -3,12 +3,15 @@
 //
 // Float64 fields cannot be bit-sliced, so this is the HBM-bound picture of the north star: one lane per replica,
 // replica-minor arrays so that a wavefront's access to one site is one coalesced 512-byte line:
-//   lf, lfl : [W][N][64] Float64     local fields and lfields_last (the undo copy of update_cache!, RRG.jl:583-593)
-//   spins   : [W][ceil(N/32)][64] uint32   lane-private bit words (bit x&31 of word x>>5)
-// W = Rpad/64 wavefronts, one per workgroup; occupancy (up to 32 wavefronts per CU) hides the latency of the
-// accept path, so the kernel wants many replicas: 64 Ki replicas of N = 4096 are 4.3 GB of fields — 288 GB of HBM
-// hold millions.  All replicas attempt the same site (SITE stream, precomputed by spf_sites_kernel), the local field
-// of the next D sites is prefetched D iterations ahead and re-read only when an accepted move touched it.
+//   lf    : [W][N][64] Float64   local fields
+//   spins : [W][N] uint64        bit l of word (w, x) = spin x of lane l's replica (one 8-byte broadcast load per site)
+//   undo  : [W][K+2][64] Float64 the part of lfields_last that update_cache!'s undo path (RRG.jl:583-593) can ever read:
+//           the K neighbour fields and the own field saved by the LAST accepted move of the replica, plus move_last.
+//           (All other entries of the reference's lfields_last are dead: the swap happens only when move_last == move.)
+// W = Rpad/64 wavefronts, one per workgroup; occupancy hides the latency of the accept path, so the kernel wants many
+// replicas: 256 Ki replicas of N = 4096 are 8.6 GB of fields — 288 GB of HBM hold millions.  All replicas attempt the
+// same site (SITE stream, precomputed by spf_sites_kernel); the local field of the next D sites is prefetched D
+// iterations ahead and re-read only when an accepted move touched it.
 // Every field receives exactly the reference's sequence of IEEE operations (no FMA contraction) and det_exp is the
 // fixed-order exp shared with the oracle, so trajectories and energies are bit-identical to the oracle.
 #pragma once
@@ -21,15 +24,16 @@
 namespace rrrmc {
 
 constexpr int kSpfMaxK = 8;
-constexpr int kSpfDepth = 8;          // prefetch distance in iterations (even: two iterations share one Philox block)
+constexpr int kSpfDepth = 4;          // prefetch distance of the attempted site's field, in iterations
+constexpr int kSpfNb = 2;             // prefetch distance of the neighbour fields / spin words
 
 struct SpfParams {
     const int32_t* A;       // [N][K]
     const double* J;        // [N][K]
     const int32_t* sites;   // [iters] sites of this launch's iterations
-    uint32_t* spins;        // [W][NW][64]
+    unsigned long long* spins;   // [W][N]
     double* lf;             // [W][N][64]
-    double* lfl;            // [W][N][64]
+    double* undo;           // [W][K+1][64]: saved neighbour fields (slot k) and own field (slot K) of the last accepted move
     int32_t* move_last;     // [Rpad], -1 = none
     double* E_cur;          // [Rpad]
     int64_t* acc_cur;       // [Rpad]
@@ -39,7 +43,7 @@ struct SpfParams {
     int64_t iters, step, sample0;
     int64_t it_off;         // iterations of this sampling call done by earlier launches (samples are taken at call-relative k*step)
     uint32_t k0, k1, replica0;
-    int N, NW, Rpad;
+    int N, Rpad;
 };
 
 __global__ __launch_bounds__(256) void spf_sites_kernel(int32_t* __restrict__ sites, int64_t n, uint64_t g0, uint32_t k0, uint32_t k1, uint32_t N)
@@ -48,70 +52,133 @@ __global__ __launch_bounds__(256) void spf_sites_kernel(int32_t* __restrict__ si
     if (t < n) sites[t] = (int32_t)site_of(k0, k1, g0 + 1 + (uint64_t)t, N);
 }
 
-// initial spins (INIT stream, same bits as init_spins_kernel) in the lane-private layout. grid (ceil(NW/4), W), block 256
-__global__ __launch_bounds__(256) void spf_init_spins_kernel(uint32_t* __restrict__ spins, int N, int NW, uint32_t replica0, uint32_t k0, uint32_t k1)
+__device__ __forceinline__ unsigned long long spf_load_spins(const unsigned long long* p)
 {
-    const int lane = threadIdx.x & 63, q = blockIdx.x * 4 + (threadIdx.x >> 6), w = blockIdx.y;
-    if (q >= NW) return;
-    const uint32_t replica = replica0 + (uint32_t)(w * 64 + lane);
-    uint32_t word = 0u;
-    for (int j = 0; j < 32; ++j) {
-        const int x = q * 32 + j;
-        if (x < N) word |= ((init_spin_word(k0, k1, replica >> 5, (uint64_t)x) >> (replica & 31u)) & 1u) << j;
-    }
-    spins[((size_t)w * NW + q) * 64 + lane] = word;
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
 }
 
-// energy (RRG.jl:546-574 / EA.jl:584-611): rebuilds lfields, clears lfields_last and move_last. grid W, block 64
+// initial spins (INIT stream, same bits as init_spins_kernel). grid (ceil(N/256), W), block 256
+__global__ __launch_bounds__(256) void spf_init_spins_kernel(unsigned long long* __restrict__ spins, int N, uint32_t replica0, uint32_t k0, uint32_t k1)
+{
+    const int x = blockIdx.x * 256 + threadIdx.x, w = blockIdx.y;
+    if (x >= N) return;
+    unsigned long long word = 0ull;
+    for (int l = 0; l < 64; ++l) {
+        const uint32_t replica = replica0 + (uint32_t)(w * 64 + l);
+        word |= (unsigned long long)((init_spin_word(k0, k1, replica >> 5, (uint64_t)x) >> (replica & 31u)) & 1u) << l;
+    }
+    spins[(size_t)w * N + x] = word;
+}
+
+// energy (RRG.jl:546-574 / EA.jl:584-611): rebuilds lfields and clears the undo record. grid W, block 64
 template <int K>
 __global__ __launch_bounds__(64) void spf_energy_kernel(SpfParams P)
 {
     const int lane = threadIdx.x, w = blockIdx.x, N = P.N;
     const int r = w * 64 + lane;
     double* lf = P.lf + (size_t)w * N * 64 + lane;
-    double* lfl = P.lfl + (size_t)w * N * 64 + lane;
-    const uint32_t* sp = P.spins + (size_t)w * P.NW * 64 + lane;
+    const unsigned long long* sp = P.spins + (size_t)w * N;
     double E1 = 0.0;
     for (int x = 0; x < N; ++x) {
-        const int sx = 2 * (int)((sp[(size_t)(x >> 5) * 64] >> (x & 31)) & 1u) - 1;
+        const int sx = 2 * (int)((sp[x] >> lane) & 1ull) - 1;
         double f = 0.0;
 #pragma unroll
         for (int k = 0; k < K; ++k) {
             const int y = P.A[(size_t)x * K + k];
-            const int sy = 2 * (int)((sp[(size_t)(y >> 5) * 64] >> (y & 31)) & 1u) - 1;
+            const int sy = 2 * (int)((sp[y] >> lane) & 1ull) - 1;
             f = __dadd_rn(f, -__dmul_rn(__dmul_rn(P.J[(size_t)x * K + k], (double)sx), (double)sy));
         }
         E1 = __dadd_rn(E1, f);
         lf[(size_t)x * 64] = __dmul_rn(2.0, f);
-        lfl[(size_t)x * 64] = 0.0;
     }
     P.E_cur[r] = __dmul_rn(E1, 0.5);
     P.move_last[r] = -1;
 }
 
+// One wavefront = 64 replicas.  Everything an iteration needs is requested ahead of time:
+//   local field of the attempted site          kSpfDepth iterations ahead  (pre[])
+//   neighbour table row (A, J: scalar loads)   kSpfNb + 1 iterations ahead (staging SGPRs)
+//   neighbour fields / spin words               kSpfNb iterations ahead     (nb slots), speculatively: they are only used
+//                                               by accepting lanes, but some lane accepts in almost every iteration
+// so the accept path never waits for a dependent load.  An accepted move at site i invalidates what was requested for later
+// iterations only inside the closed neighbourhood of i; `pend` keeps the site ids of all outstanding requests one per lane,
+// K+1 compares find the intersecting slots and those (rare, ~D K^2 / N) are re-read after the stores, in program order.
 // grid W, block 64
 template <int K>
 __global__ __launch_bounds__(64) void spf_sweep_kernel(SpfParams P)
 {
-    constexpr int D = kSpfDepth;
+    constexpr int D = kSpfDepth, NB = kSpfNb;
+    static_assert(D % NB == 0 && D % 2 == 0 && NB * (K + 1) <= 64 - D, "slot geometry");
     const int lane = threadIdx.x, w = blockIdx.x, N = P.N;
     const int r = w * 64 + lane;
     double* lf = P.lf + (size_t)w * N * 64 + lane;
-    double* lfl = P.lfl + (size_t)w * N * 64 + lane;
-    uint32_t* sp = P.spins + (size_t)w * P.NW * 64 + lane;
+    double* undo = P.undo + (size_t)w * (K + 1) * 64 + lane;
+    unsigned long long* sp = P.spins + (size_t)w * N;
     const uint32_t replica = P.replica0 + (uint32_t)r;
     double E = P.E_cur[r];
     int64_t nacc = P.acc_cur[r];
     int32_t mlast = P.move_last[r];
+    double sv[K + 1];
+#pragma unroll
+    for (int k = 0; k <= K; ++k) sv[k] = undo[(size_t)k * 64];
     int64_t ns = P.sample0;
     const int64_t iters = P.iters, step = P.step;
 
+    // outstanding requests.  Lane f*(K+1)+j of `pend` (j = 0: site, j >= 1: neighbour j-1) describes nb slot f,
+    // lane 64-D+e the site of pre slot e; -1 = nothing outstanding.
+    int pend = -1;
     double pre[D];
     int ps[D];
+    int ny[NB][K];
+    double nJ[NB][K], nf[NB][K];
+    unsigned long long nw[NB][K], nwi[NB];
+    int sy[K];                 // staged neighbour row of the iteration NB+1 ahead
+    double sJ[K];
+
+    auto load_row = [&](int site, int (&yy)[K], double (&JJ)[K]) {
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            yy[k] = P.A[(size_t)site * K + k];
+            JJ[k] = P.J[(size_t)site * K + k];
+        }
+    };
+    auto request_nb = [&](int f, int site) {      // (re)issue the speculative loads of nb slot f from its row
+        nwi[f] = spf_load_spins(sp + site);
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            nw[f][k] = spf_load_spins(sp + ny[f][k]);
+            nf[f][k] = lf[(size_t)ny[f][k] * 64];
+        }
+    };
+    auto mark_nb = [&](int f, int site) {
+        pend = lane == (f * (K + 1)) ? (site) : pend;
+#pragma unroll
+        for (int k = 0; k < K; ++k) pend = lane == (f * (K + 1) + 1 + k) ? (ny[f][k]) : pend;
+    };
+
+    // prologue: sites and fields of iterations 1..D, neighbour data of iterations 1..NB, staged row of iteration NB+1
 #pragma unroll
     for (int d = 0; d < D; ++d) {
-        ps[d] = d < iters ? P.sites[d] : 0;
+        ps[d] = d < iters ? __builtin_amdgcn_readfirstlane(P.sites[d]) : -1;
         pre[d] = d < iters ? lf[(size_t)ps[d] * 64] : 0.0;
+        pend = lane == (64 - D + d) ? (ps[d]) : pend;
+    }
+#pragma unroll
+    for (int f = 0; f < NB; ++f) {
+        if (f < iters) {
+            load_row(ps[f], ny[f], nJ[f]);
+            request_nb(f, ps[f]);
+            mark_nb(f, ps[f]);
+        } else {
+#pragma unroll
+            for (int k = 0; k < K; ++k) { ny[f][k] = 0; nJ[f][k] = 0.0; nf[f][k] = 0.0; nw[f][k] = 0ull; }
+            nwi[f] = 0ull;
+        }
+    }
+    if (NB < iters) load_row(ps[NB % D], sy, sJ);
+    else {
+#pragma unroll
+        for (int k = 0; k < K; ++k) { sy[k] = 0; sJ[k] = 0.0; }
     }
     Philox4 blk = {{0u, 0u, 0u, 0u}};
     uint64_t blk_id = ~0ull;
@@ -119,6 +186,8 @@ __global__ __launch_bounds__(64) void spf_sweep_kernel(SpfParams P)
     for (int64_t base = 0; base < iters; base += D) {
 #pragma unroll
         for (int d = 0; d < D; ++d) {
+            constexpr int dummy = 0; (void)dummy;
+            const int f = d % NB;
             const int64_t it = base + d + 1;
             if (it > iters) break;
             const uint64_t g = P.g0 + (uint64_t)it;
@@ -126,7 +195,7 @@ __global__ __launch_bounds__(64) void spf_sweep_kernel(SpfParams P)
                 if (P.Es) P.Es[(size_t)ns * P.Rpad + r] = E;
                 ++ns;
             }
-            const int i = __builtin_amdgcn_readfirstlane(ps[d]);
+            const int i = ps[d];
             const double lfi = pre[d];
             const double dE = -lfi;                          // delta_energy: RRG.jl:619-625
             const double x = __dmul_rn(-P.beta, dE);
@@ -136,106 +205,106 @@ __global__ __launch_bounds__(64) void spf_sweep_kernel(SpfParams P)
             }
             const uint64_t u = (g & 1u) ? (((uint64_t)blk.w[2] << 32) | blk.w[3]) : (((uint64_t)blk.w[0] << 32) | blk.w[1]);
             const bool acc = x >= 0.0 || (double)(u >> 11) * 0x1.0p-53 < det_exp(x);       // accept: RRRMC.jl:39
-            if (__builtin_amdgcn_ballot_w64(acc) != 0ull) {
+            const unsigned long long amask = __builtin_amdgcn_ballot_w64(acc);
+            // this iteration's requests are consumed now
+            pend = lane == (64 - D + d) ? (-1) : pend;
+#pragma unroll
+            for (int j = 0; j <= K; ++j) pend = lane == (f * (K + 1) + j) ? (-1) : pend;
+            if (amask != 0ull) {
                 // update_cache! (RRG.jl:576-617, EA.jl:613-653) for the accepting lanes; neighbours are common to all lanes
-                int y[K];
-                double Jk[K], fy[K];
-                uint32_t wy[K];
-#pragma unroll
-                for (int k = 0; k < K; ++k) {
-                    y[k] = P.A[(size_t)i * K + k];
-                    Jk[k] = P.J[(size_t)i * K + k];
-                }
-                const uint32_t wi = sp[(size_t)(i >> 5) * 64];
-                const bool fast = acc && mlast == i;
+                const unsigned long long wi = nwi[f];
+                if (lane == 0) __hip_atomic_store(sp + i, wi ^ amask, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
                 if (acc) {
-#pragma unroll
-                    for (int k = 0; k < K; ++k) {
-                        wy[k] = sp[(size_t)(y[k] >> 5) * 64];
-                        fy[k] = lf[(size_t)y[k] * 64];
-                    }
-                    const uint32_t snew = ((wi >> (i & 31)) & 1u) ^ 1u;
-                    sp[(size_t)(i >> 5) * 64] = wi ^ (1u << (i & 31));
-                    if (fast) {                              // exact undo: swap lfields <-> lfields_last on the (unique) neighbours
+                    const uint32_t snew = (uint32_t)((wi >> lane) & 1ull) ^ 1u;
+                    if (mlast == i) {                        // exact undo: swap lfields <-> lfields_last on the (unique) neighbours
 #pragma unroll
                         for (int k = 0; k < K; ++k) {
-                            if (k > 0 && y[k] == y[k - 1]) continue;
-                            const double t = lfl[(size_t)y[k] * 64];
-                            lf[(size_t)y[k] * 64] = t;
-                            lfl[(size_t)y[k] * 64] = fy[k];
+                            if (k > 0 && ny[f][k] == ny[f][k - 1]) continue;
+                            lf[(size_t)ny[f][k] * 64] = sv[k];
+                            sv[k] = nf[f][k];
                         }
-                        lf[(size_t)i * 64] = -lfi;
-                        lfl[(size_t)i * 64] = -lfl[(size_t)i * 64];
+                        sv[K] = -sv[K];
                     } else {
                         double v = 0.0;
 #pragma unroll
                         for (int k = 0; k < K; ++k) {
-                            const bool rep = k > 0 && y[k] == y[k - 1];      // GraphEA with L = 2: two bonds to the same neighbour
+                            const bool rep = k > 0 && ny[f][k] == ny[f][k - 1];   // GraphEA with L = 2: two bonds to the same neighbour
                             if (!rep) {
-                                v = fy[k];
-                                lfl[(size_t)y[k] * 64] = v;
+                                v = nf[f][k];
+                                sv[k] = v;                                   // lfields_last[y] = lfields[y]
                             }
-                            // a flip of the neighbour itself cannot have happened in between: y != i
-                            const uint32_t sy = (wy[k] >> (y[k] & 31)) & 1u;
-                            const double c = (snew ^ sy) ? -4.0 : 4.0;       // 4 * sigma_xy with the NEW s_x
-                            v = __dadd_rn(v, -__dmul_rn(c, Jk[k]));
-                            const bool last = k == K - 1 || y[k + 1] != y[k];
-                            if (last) lf[(size_t)y[k] * 64] = v;
+                            const uint32_t sbit = (uint32_t)((nw[f][k] >> lane) & 1ull);
+                            const double c = (snew ^ sbit) ? -4.0 : 4.0;     // 4 * sigma_xy with the NEW s_x
+                            v = __dadd_rn(v, -__dmul_rn(c, nJ[f][k]));
+                            const bool last = k == K - 1 || ny[f][k + 1] != ny[f][k];
+                            if (last) lf[(size_t)ny[f][k] * 64] = v;
                         }
-                        lfl[(size_t)i * 64] = lfi;
-                        lf[(size_t)i * 64] = -lfi;
+                        sv[K] = lfi;
                         mlast = i;
                     }
+                    lf[(size_t)i * 64] = -lfi;
                     E = __dadd_rn(E, dE);
                     nacc += 1;
                 }
-                // prefetched fields that this move may have changed (closed neighbourhood of i): read them again
+                // outstanding requests inside the closed neighbourhood of i are stale: read them again (after the stores)
+                unsigned long long hit = __builtin_amdgcn_ballot_w64(pend == i);
 #pragma unroll
-                for (int e = 0; e < D; ++e) {
-                    if (e == d) continue;
-                    const int64_t ite = e > d ? base + e + 1 : base + D + e + 1;
-                    if (ite > iters) continue;
-                    const int pe = __builtin_amdgcn_readfirstlane(ps[e]);
-                    bool stale = pe == i;
+                for (int k = 0; k < K; ++k) hit |= __builtin_amdgcn_ballot_w64(pend == ny[f][k]);
+                if (hit != 0ull) {
 #pragma unroll
-                    for (int k = 0; k < K; ++k) stale |= pe == y[k];
-                    if (stale) pre[e] = lf[(size_t)pe * 64];
+                    for (int e = 0; e < D; ++e)
+                        if (e != d && ((hit >> (64 - D + e)) & 1ull)) pre[e] = lf[(size_t)ps[e] * 64];
+#pragma unroll
+                    for (int h = 0; h < NB; ++h) {
+                        if (h == f) continue;
+                        if ((hit >> (h * (K + 1))) & ((1ull << (K + 1)) - 1ull)) {
+                            // slot h serves iteration it + ((h - f + NB) % NB): its site is ps[(d + (h - f + NB) % NB) % D]
+                            request_nb(h, ps[(d + (h - f + NB) % NB) % D]);
+                        }
+                    }
                 }
             }
+            // refill: neighbour data of iteration it+NB from the staged row, the row of iteration it+NB+1, field of iteration it+D
+            if (it + NB <= iters) {
+#pragma unroll
+                for (int k = 0; k < K; ++k) { ny[f][k] = sy[k]; nJ[f][k] = sJ[k]; }
+                request_nb(f, ps[(d + NB) % D]);
+                mark_nb(f, ps[(d + NB) % D]);
+            }
+            if (it + NB + 1 <= iters) load_row(ps[(d + NB + 1) % D], sy, sJ);
             if (it + D <= iters) {
-                ps[d] = P.sites[it + D - 1];
+                ps[d] = __builtin_amdgcn_readfirstlane(P.sites[it + D - 1]);
                 pre[d] = lf[(size_t)ps[d] * 64];
+                pend = lane == (64 - D + d) ? (ps[d]) : pend;
             }
         }
     }
     P.E_cur[r] = E;
     P.acc_cur[r] = nacc;
     P.move_last[r] = mlast;
+#pragma unroll
+    for (int k = 0; k <= K; ++k) undo[(size_t)k * 64] = sv[k];
 }
 
-// lane-private spins -> bit words per replica in BitVector order, out[r][q] (q < NW); grid (ceil(NW/4), W), block 256
-__global__ __launch_bounds__(256) void spf_spins_out_kernel(const uint32_t* __restrict__ spins, uint32_t* __restrict__ out, int NW, int NWout)
-{
-    const int lane = threadIdx.x & 63, q = blockIdx.x * 4 + (threadIdx.x >> 6), w = blockIdx.y;
-    if (q >= NW) return;
-    out[(size_t)(w * 64 + lane) * NWout + q] = spins[((size_t)w * NW + q) * 64 + lane];
-}
-__global__ __launch_bounds__(256) void spf_spins_in_kernel(const uint32_t* __restrict__ in, uint32_t* __restrict__ spins, int NW, int NWin)
-{
-    const int lane = threadIdx.x & 63, q = blockIdx.x * 4 + (threadIdx.x >> 6), w = blockIdx.y;
-    if (q >= NW) return;
-    spins[((size_t)w * NW + q) * 64 + lane] = in[(size_t)(w * 64 + lane) * NWin + q];
-}
-
-// pm1dot between two lane-private snapshots; grid (W, npairs), block 64
-__global__ __launch_bounds__(64) void overlap_lanes_kernel(const uint32_t* const* __restrict__ srcA, const uint32_t* const* __restrict__ srcB,
-                                                           int N, int NW, int Rpad, int32_t* __restrict__ out)
+// pm1dot between two snapshots in the [W][N] uint64 layout; grid (W, npairs), block 64
+__global__ __launch_bounds__(64) void overlap_lanes_kernel(const unsigned long long* const* __restrict__ srcA,
+                                                           const unsigned long long* const* __restrict__ srcB,
+                                                           int N, int Rpad, int32_t* __restrict__ out)
 {
     const int lane = threadIdx.x, w = blockIdx.x, p = blockIdx.y;
-    const uint32_t* a = srcA[p] + (size_t)w * NW * 64 + lane;
-    const uint32_t* b = srcB[p] + (size_t)w * NW * 64 + lane;
+    const unsigned long long* a = srcA[p] + (size_t)w * N;
+    const unsigned long long* b = srcB[p] + (size_t)w * N;
     int32_t c = 0;
-    for (int q = 0; q < NW; ++q) c += __popc(a[(size_t)q * 64] ^ b[(size_t)q * 64]);
+    for (int x0 = 0; x0 < N; x0 += 64) {                       // lane j loads word x0 + j, then every lane picks its bit
+        const int x = x0 + lane;
+        const unsigned long long v = x < N ? (a[x] ^ b[x]) : 0ull;
+        const uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
+#pragma unroll 8
+        for (int j = 0; j < 64; ++j) {
+            const uint32_t wl = (uint32_t)__builtin_amdgcn_readlane((int)lo, j), wh = (uint32_t)__builtin_amdgcn_readlane((int)hi, j);
+            c += (int32_t)(((lane < 32 ? wl : wh) >> (lane & 31)) & 1u);
+        }
+    }
     out[(size_t)p * Rpad + w * 64 + lane] = N - 2 * c;
 }
 

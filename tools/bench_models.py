@@ -75,6 +75,31 @@ def bench_quant(Nk=1024, M=32, R=128, beta=2.0, Gamma=0.5, iters=1 << 16, step=1
     eng.close()
 
 
+def bench_spf(N=4096, K=3, R=65536, beta=1.0, iters=1 << 14, step=1 << 12, seed=0x5EED):
+    """GraphRRGNormal (Float64 sparse): config-2 geometry with Gaussian couplings; the lane-per-replica
+    kernel hides its accept-path latency with occupancy, so it is measured at several replica counts."""
+    pkg = entry.load_package()
+    X = pkg.GraphRRGNormal(N, K, seed=seed)
+    for R in ([int(a) for a in sys.argv[2:]] or [8192, 65536, 262144]):
+        eng = pkg.Engine(X, R)
+        eng.seed(seed)
+        eng.init_spins_random()
+        eng.standard_mc_async(beta, iters // 4, step); eng.sync()
+        t0 = time.perf_counter()
+        eng.standard_mc_async(beta, iters, step); eng.sync()
+        dt = time.perf_counter() - t0
+        total_ms, sweep_ms, _ = eng.last_timing()
+        Es, acc = eng.fetch_results()
+        a = float(acc.mean()) / iters
+        attempts = float(R) * iters
+        bpa = 8 + a * (10 + 17 * K)          # SURVEY.md §8d widths: field 8 B, spin 1 B; lfields_last excluded
+        out = {"model": "GraphRRGNormal", "N": N, "K": K, "replicas": R, "beta": beta, "iters": iters, "attempts_per_s": attempts / dt,
+               "kernel_ms": sweep_ms, "acceptance": a, "energy_per_spin": float(Es[:, -1].mean()) / N,
+               "algorithmic_bytes_per_attempt": bpa, "algorithmic_GBps_kernel": bpa * attempts / (sweep_ms * 1e-3) / 1e9}
+        print(json.dumps(out), flush=True)
+        eng.close()
+
+
 if __name__ == "__main__":
     which = sys.argv[1] if len(sys.argv) > 1 else "sk"
-    {"sk": bench_sk, "ea": bench_ea, "quant": bench_quant}[which]()
+    {"sk": bench_sk, "ea": bench_ea, "quant": bench_quant, "spf": bench_spf}[which]()
