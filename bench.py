@@ -149,7 +149,7 @@ def main():
                                "algorithmic_bytes_per_launch": bytes_per_attempt * per_launch_attempts,
                                "kernel": "sweep_kernel<3>", "avg_launch_ms": avg_ms, "launches": launches,
                                "algorithmic_bytes_per_attempt": bytes_per_attempt}
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:      # reported at N = 1 only (rank 0's host cores)
             out["cpu_baseline"] = cpu_baseline(entry.load_oracle(), X)
         print(json.dumps(out))
     eng.close()

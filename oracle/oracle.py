@@ -471,3 +471,59 @@ def standard_mc_spf(A, J, beta, iters, step, seed, chunks, it0=0, replica=0, for
     n = L.orc_standard_mc_spf(1 if form == "ea" else 0, N, K, A, np.ascontiguousarray(J, np.float64).reshape(-1), float(beta), int(iters),
                               int(step), seed, it0, replica, ch, Es, C.byref(acc), lf)
     return Es[:n], ch, acc.value, lf
+
+
+def all_delta_e(K, lev):
+    """allΔE for integer levels (RRG.jl:268-281, EA.jl:295-309)"""
+    L = lib()
+    L.orc_all_delta_e.restype = C.c_int64
+    L.orc_all_delta_e.argtypes = [C.c_int64, i32p, C.c_int64, i64p, C.c_int64]
+    out = np.zeros(64, np.int64)
+    n = L.orc_all_delta_e(int(K), np.asarray(lev, np.int32), len(lev), out, 64)
+    if n < 0:
+        raise ValueError("too many levels")
+    return tuple(int(v) for v in out[:n])
+
+
+def discretize(x, lev):
+    """discretize (Common.jl:38-72): (levels, residuals) with the shape of x"""
+    L = lib()
+    L.orc_discretize.restype = None
+    L.orc_discretize.argtypes = [f64p, C.c_int64, i32p, C.c_int64, i32p, f64p]
+    x = np.ascontiguousarray(x, np.float64)
+    d = np.zeros(x.shape, np.int32)
+    r = np.zeros(x.shape, np.float64)
+    L.orc_discretize(x.reshape(-1), x.size, np.asarray(lev, np.int32), len(lev), d.reshape(-1), r.reshape(-1))
+    return d, r
+
+
+def dbl_energy(A, dJ, rJ, chunks, form="rrg"):
+    L = lib()
+    L.orc_dbl_energy.restype = C.c_double
+    L.orc_dbl_energy.argtypes = [C.c_int, C.c_int64, C.c_int64, i32p, i32p, f64p, u64p]
+    A = np.ascontiguousarray(A, np.int32)
+    N, K = A.shape
+    return float(L.orc_dbl_energy(1 if form == "ea" else 0, N, K, A, np.ascontiguousarray(dJ, np.int32).reshape(-1),
+                                  np.ascontiguousarray(rJ, np.float64).reshape(-1), np.ascontiguousarray(chunks, np.uint64)))
+
+
+def rrr_double_sparse(A, dJ, rJ, lev, beta, iters, step, seed, chunks, it0=0, replica=0, staged_thr=0.5, staged_thr_fact=5.0,
+                      form="rrg"):
+    """rrrMC(X::DoubleGraph) on Graph{RRG,EA}NormalDiscretized; returns (Es, chunks, accepted, staged_its, pos[N], sizes[2L])."""
+    L = lib()
+    L.orc_rrr_double_sparse.restype = C.c_int64
+    L.orc_rrr_double_sparse.argtypes = [C.c_int, C.c_int64, C.c_int64, i32p, i32p, f64p, i32p, C.c_int64, C.c_double, C.c_int64,
+                                        C.c_int64, C.c_double, C.c_double, C.c_uint64, C.c_uint64, C.c_uint32, u64p, f64p, i64p, i32p]
+    A = np.ascontiguousarray(A, np.int32)
+    N, K = A.shape
+    nl = len(all_delta_e(K, lev))
+    ch = np.array(chunks, np.uint64, copy=True)
+    Es = np.zeros(max(iters // step, 1))
+    stats = np.zeros(2, np.int64)
+    cache = np.zeros(N + 2 * nl, np.int32)
+    n = L.orc_rrr_double_sparse(1 if form == "ea" else 0, N, K, A, np.ascontiguousarray(dJ, np.int32).reshape(-1),
+                                np.ascontiguousarray(rJ, np.float64).reshape(-1), np.asarray(lev, np.int32), len(lev), float(beta),
+                                int(iters), int(step), float(staged_thr), float(staged_thr_fact), seed, it0, replica, ch, Es, stats, cache)
+    if n < 0:
+        raise RuntimeError("rrr_double_sparse: cache inconsistent (rc=%d)" % n)
+    return Es[:n], ch, int(stats[0]), int(stats[1]), cache[:N].copy(), cache[N:].copy()

@@ -318,6 +318,47 @@ ORC_API int64_t orc_all_delta_e_pm1(int64_t K, int64_t *out)
     return n;
 }
 
+/* allΔE for GraphRRG{Int,LEV,K} / GraphEA{Int,LEV,twoD} with any integer levels (RRG.jl:268-281, EA.jl:295-309): the set
+ * of sums of K terms +-l, l in LEV, mapped to 2|x|, sorted.  Returns the number of levels (<= cap) or -1. */
+ORC_API int64_t orc_all_delta_e(int64_t K, const int32_t *lev, int64_t nlev, int64_t *out, int64_t cap)
+{
+    int64_t amax = 0;
+    for (int64_t l = 0; l < nlev; ++l) { int64_t a = lev[l] < 0 ? -(int64_t)lev[l] : lev[l]; if (a > amax) amax = a; }
+    const int64_t span = K * amax;                              /* reachable sums lie in [-span, span] */
+    uint8_t *cur = (uint8_t *)calloc((size_t)(2 * span + 1), 1), *nxt = (uint8_t *)calloc((size_t)(2 * span + 1), 1);
+    cur[span] = 1;
+    for (int64_t n = 0; n < K; ++n) {
+        memset(nxt, 0, (size_t)(2 * span + 1));
+        for (int64_t v = -span; v <= span; ++v)
+            if (cur[v + span])
+                for (int64_t l = 0; l < nlev; ++l) {
+                    if (v + lev[l] >= -span && v + lev[l] <= span) nxt[v + lev[l] + span] = 1;
+                    if (v - lev[l] >= -span && v - lev[l] <= span) nxt[v - lev[l] + span] = 1;
+                }
+        uint8_t *t = cur; cur = nxt; nxt = t;
+    }
+    int64_t n = 0;
+    for (int64_t a = 0; a <= span; ++a)
+        if (cur[span + a] || cur[span - a]) { if (n == cap) { n = -1; break; } out[n++] = 2 * a; }
+    free(cur); free(nxt);
+    return n;
+}
+
+/* discretize(x, LEV): Common.jl:38-49 — the nearest level (the first one on ties) and the residual x - d */
+ORC_API void orc_discretize(const double *x, int64_t n, const int32_t *lev, int64_t nlev, int32_t *d_out, double *r_out)
+{
+    for (int64_t q = 0; q < n; ++q) {
+        int32_t d = lev[0];
+        double r = x[q] - (double)d;
+        for (int64_t l = 1; l < nlev; ++l) {
+            double r1 = x[q] - (double)lev[l];
+            if (fabs(r1) < fabs(r)) { d = lev[l]; r = r1; }
+        }
+        d_out[q] = d;
+        r_out[q] = r;
+    }
+}
+
 /* ---------------------------------------------------------------------------------------------
  * Dense Gaussian SK model GraphSKNormal (ET = Float64): src/graphs/SK.jl:170-297
  * ------------------------------------------------------------------------------------------- */
@@ -1393,7 +1434,7 @@ ORC_API int64_t orc_dyns_test(int64_t N, const double *v, int64_t nupd, const in
  * rrrMC(X::SingleGraph) (src/RRRMC.jl:149-219) and bklMC (src/RRRMC.jl:311-359) on the DiscrGraphs GraphRRG / GraphEA
  * with DeltaECache{Int, L} (src/DeltaE.jl:63-295): SURVEY.md §8(f) rank 1.
  * ============================================================================================= */
-enum { SL_MAX = 4, SK_MAX = 8 };
+enum { SL_MAX = 8, SK_MAX = 8 };
 typedef struct {
     int64_t N;
     int L;
@@ -1409,11 +1450,13 @@ static inline int decs_findk(const decs_t *c, int64_t dE) { int64_t a = dE < 0 ?
 static inline double decs_f(const decs_t *c, int k) { return k >= c->L ? c->ft[k - c->L] : 1.0; }
 static inline int decs_class(const decs_t *c, int64_t dE, int sbit) { return decs_findk(c, dE) + c->L * (dE > 0 || (dE == 0 && sbit == 1)); }
 
-static void decs_init(decs_t *c, sparse_t *X, const uint64_t *s, double beta)                 /* DeltaE.jl:74-103 */
+/* dElist == NULL: the +-J table (RRG.jl:262-266, EA.jl:293) */
+static void decs_init_levels(decs_t *c, sparse_t *X, const uint64_t *s, double beta, const int64_t *dElist, int L)   /* DeltaE.jl:74-103 */
 {
     c->N = X->N;
     int64_t tmp[SK_MAX + 1];
-    c->L = (int)orc_all_delta_e_pm1(X->K, tmp);                    /* allΔE: RRG.jl:262-281, EA.jl:293 */
+    if (dElist) { c->L = L; for (int k = 0; k < L; ++k) tmp[k] = dElist[k]; }
+    else c->L = (int)orc_all_delta_e_pm1(X->K, tmp);
     for (int k = 0; k < c->L; ++k) c->dElist[k] = tmp[k];
     for (int k = 0; k < 2 * c->L; ++k) aset_init(&c->as[k], c->N);
     c->pos = (int8_t *)calloc((size_t)c->N, 1);
@@ -1428,6 +1471,7 @@ static void decs_init(decs_t *c, sparse_t *X, const uint64_t *s, double beta)   
     c->zp = c->z;
     c->nstaged = 0;
 }
+static void decs_init(decs_t *c, sparse_t *X, const uint64_t *s, double beta) { decs_init_levels(c, X, s, beta, NULL, 0); }
 static void decs_free(decs_t *c) { for (int k = 0; k < 2 * c->L; ++k) aset_free(&c->as[k]); free(c->pos); }
 
 static int64_t decs_rand_move(const decs_t *c, uint64_t seed, uint64_t g, uint32_t replica, int64_t *dE)      /* DeltaE.jl:146-167 */
@@ -1444,12 +1488,17 @@ static int64_t decs_rand_move(const decs_t *c, uint64_t seed, uint64_t g, uint32
     uint64_t u = ((uint64_t)w[2] << 32) | w[3];
     return c->as[k].v[(int64_t)orc_mulhi64(u, (uint64_t)c->as[k].t)];
 }
-/* neighbors(X, i) = uA[i]: RRG.jl:133,261 (all K for +-J), EA.jl:158,292 (repeats removed; A is sorted) */
+/* neighbors(X, i) = uA[i]: GraphRRG keeps the neighbours with a non-zero coupling (RRG.jl:133,261); GraphEA removes the
+ * repeats of the sorted list and keeps zero couplings (EA.jl:158,292). */
 static int sparse_neighbors(const sparse_t *X, int64_t i, int64_t *out)
 {
     int n = 0;
     const int32_t *Ax = X->A + i * X->K;
-    for (int64_t k = 0; k < X->K; ++k) { if (k > 0 && Ax[k] == Ax[k - 1]) continue; out[n++] = Ax[k]; }
+    for (int64_t k = 0; k < X->K; ++k) {
+        if (X->ea_form) { if (k > 0 && Ax[k] == Ax[k - 1]) continue; }
+        else if (X->J[i * X->K + k] == 0) continue;
+        out[n++] = Ax[k];
+    }
     return n;
 }
 static void sparse_spinflip(sparse_t *X, uint64_t *s, int64_t i) { bitflip(s, i); sparse_update_cache(X, s, i); }
@@ -1598,5 +1647,110 @@ ORC_API int64_t orc_rrr_bkl_sparse(int mode, int form, int64_t N, int64_t K, con
     int ok = decs_consistent(&c, &X, chunks);
     decs_free(&c);
     free(X.lfields); free(X.lfields_last);
+    return ok ? nsamp : -1;
+}
+
+/* =============================================================================================
+ * rrrMC(X::DoubleGraph) (src/RRRMC.jl:221-290) on GraphRRGNormalDiscretized / GraphEANormalDiscretized with integer levels
+ * (src/graphs/RRG.jl:285-500, src/graphs/EA.jl:311-532): Gaussian couplings split by discretize (Common.jl:38-72) into an inner
+ * DiscrGraph X0 = GraphRRG{Int,LEV,K}(A, dJ) — which drives the DeltaECache — and a Float64 residual rJ whose local-field
+ * cache (with its own lfields_last / move_last) gives delta_energy_residual.  SURVEY.md §8f rank 3.
+ * spinflip!(X, C, move) = bit flip + update_cache!(X0) + update_cache_residual!(X): the combined update_cache! (RRG.jl:362-428)
+ * is the two separate updates whenever the two move_last agree and falls back to them otherwise (:366-370).
+ * ============================================================================================= */
+static void dbl_spinflip(sparse_t *X0, spf_t *X1, uint64_t *s, int64_t move)
+{
+    bitflip(s, move);
+    sparse_update_cache(X0, s, move);
+    spf_update_cache(X1, s, move);
+}
+/* apply_move!(X::DoubleGraph, ...): DeltaE.jl:232-295 — decs_apply_move with the full graph's spinflip! */
+static double dbl_apply_move(decs_t *c, sparse_t *X0, spf_t *X1, uint64_t *s, int64_t move)
+{
+    dbl_spinflip(X0, X1, s, move);
+    double zp = c->z;
+    int64_t nb[SK_MAX];
+    int nn = sparse_neighbors(X0, move, nb);
+    for (int q = 0; q <= nn; ++q) {
+        int32_t j = (int32_t)(q < nn ? nb[q] : move);
+        int k0 = c->pos[j];
+        int k1 = q < nn ? decs_class(c, sparse_delta_energy(X0, j), spin_bit(s, j)) : (k0 >= c->L ? k0 - c->L : k0 + c->L);
+        if (q < nn && k0 == k1) continue;
+        double f0 = decs_f(c, k0), f1 = decs_f(c, k1);
+        c->T[k0] -= f0; c->T[k1] += f1; zp += f1 - f0;
+        aset_delete(&c->as[k0], j); aset_push(&c->as[k1], j); c->pos[j] = (int8_t)k1;
+    }
+    double cc = c->z / zp;
+    c->z = zp;
+    return cc;
+}
+
+ORC_API double orc_dbl_energy(int form, int64_t N, int64_t K, const int32_t *A, const int32_t *dJ, const double *rJ, const uint64_t *chunks)
+{
+    sparse_t X0 = {N, K, A, dJ, NULL, NULL, -1, form};
+    spf_t X1 = {N, K, A, rJ, NULL, NULL, -1, form};
+    X0.lfields = (int64_t *)malloc((size_t)N * 8); X0.lfields_last = (int64_t *)malloc((size_t)N * 8);
+    X1.lfields = (double *)malloc((size_t)N * 8); X1.lfields_last = (double *)malloc((size_t)N * 8);
+    const int64_t E0 = sparse_energy(&X0, chunks);
+    const double E1 = spf_energy(&X1, chunks);
+    free(X0.lfields); free(X0.lfields_last); free(X1.lfields); free(X1.lfields_last);
+    return (double)E0 + E1;                                   /* convert(Float64, E0 + E1): RRG.jl:359 */
+}
+
+/* stats = [accepted, staged iterations]; cache_out = pos[N] then the 2L class sizes */
+ORC_API int64_t orc_rrr_double_sparse(int form, int64_t N, int64_t K, const int32_t *A, const int32_t *dJ, const double *rJ,
+                                      const int32_t *lev, int64_t nlev, double beta, int64_t iters, int64_t step,
+                                      double staged_thr, double staged_thr_fact, uint64_t seed, uint64_t it0, uint32_t replica,
+                                      uint64_t *chunks, double *Es, int64_t *stats, int32_t *cache_out)
+{
+    int64_t dElist[SL_MAX];
+    const int64_t L = orc_all_delta_e(K, lev, nlev, dElist, SL_MAX);
+    if (L < 1) return -2;
+    sparse_t X0 = {N, K, A, dJ, NULL, NULL, -1, form};
+    spf_t X1 = {N, K, A, rJ, NULL, NULL, -1, form};
+    X0.lfields = (int64_t *)malloc((size_t)N * 8); X0.lfields_last = (int64_t *)malloc((size_t)N * 8);
+    X1.lfields = (double *)malloc((size_t)N * 8); X1.lfields_last = (double *)malloc((size_t)N * 8);
+    double E = (double)sparse_energy(&X0, chunks);
+    E = E + spf_energy(&X1, chunks);
+    decs_t c;
+    decs_init_levels(&c, &X0, chunks, beta, dElist, (int)L);
+    const double lambda = staged_thr_fact / (double)N;
+    double acc_rate = 0.5;
+    int64_t accepted = 0, staged_its = 0, nsamp = 0;
+    for (int64_t it = 1; it <= iters; ++it) {
+        if (it % step == 0) Es[nsamp++] = E;
+        const uint64_t g = it0 + (uint64_t)it;
+        int acc = 0;
+        if (acc_rate < staged_thr) {
+            staged_its += 1;
+            double z = c.z;
+            int64_t dE0, move = decs_rand_move(&c, seed, g, replica, &dE0);
+            decs_compute_staged(&c, &X0, chunks, move);             /* step_rrr(X0, C, cache): flips X0's cache twice */
+            double cc = z / decs_reverse(&c);
+            double dE1 = -X1.lfields[move];                         /* delta_energy_residual: RRG.jl:468-476 */
+            if (accept_cx(cc, -beta * dE1, seed, g, replica)) {
+                dbl_spinflip(&X0, &X1, chunks, move);
+                decs_apply_staged(&c);
+                E += (double)dE0 + dE1;
+                accepted++; acc = 1;
+            }
+        } else {
+            int64_t dE0, move = decs_rand_move(&c, seed, g, replica, &dE0);
+            double dE1 = -X1.lfields[move];
+            double cc = dbl_apply_move(&c, &X0, &X1, chunks, move);
+            if (accept_cx(cc, -beta * dE1, seed, g, replica)) { E += (double)dE0 + dE1; accepted++; acc = 1; }
+            else dbl_apply_move(&c, &X0, &X1, chunks, move);
+        }
+        acc_rate = acc_rate * (1 - lambda) + (double)acc * lambda;
+    }
+    if (stats) { stats[0] = accepted; stats[1] = staged_its; }
+    if (cache_out) {
+        for (int64_t i = 0; i < N; ++i) cache_out[i] = c.pos[i];
+        for (int k = 0; k < 2 * c.L; ++k) cache_out[N + k] = (int32_t)c.as[k].t;
+    }
+    int ok = decs_consistent(&c, &X0, chunks);
+    /* the residual cache must equal a recomputation up to rounding (the reference's invariant, runtests.jl:12-20) */
+    decs_free(&c);
+    free(X0.lfields); free(X0.lfields_last); free(X1.lfields); free(X1.lfields_last);
     return ok ? nsamp : -1;
 }

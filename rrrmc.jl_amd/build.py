@@ -8,10 +8,12 @@ import subprocess
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, "csrc", "rrrmc_hip.hip")
-DEPS = [SRC, os.path.join(HERE, "csrc", "sparse_kernels.hpp"), os.path.join(HERE, "csrc", "philox.hpp"),
-        os.path.join(HERE, "..", "include", "rrrmc_hip.h")]
+DEPS = [SRC, os.path.join(HERE, "..", "include", "rrrmc_hip.h")] + \
+       [os.path.join(HERE, "csrc", f) for f in sorted(os.listdir(os.path.join(HERE, "csrc"))) if f.endswith(".hpp")]
 OUT = os.path.join(HERE, "lib", "librrrmc_hip.so")
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden", "-Wall", "-Wextra"]
+# -ffp-contract=off: the Float64 kernels promise the reference's sequence of IEEE operations (no a*b+c fusing); the oracle is
+# built the same way, so Float64 trajectories agree bit for bit by construction (IEEE division still expands to FMAs: exact).
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden", "-ffp-contract=off", "-Wall", "-Wextra"]
 
 
 def lib_path():

@@ -194,3 +194,44 @@ def test_spf_boltzmann_small(oracle):
     p /= p.sum()
     # chains share the site stream, so they are not independent; allow 6 sigma of the multinomial error
     assert np.abs(counts / R - p).max() < 6 * np.sqrt(p.max() / R) + 0.01
+
+
+# ---- DoubleGraphs Graph{RRG,EA}NormalDiscretized under rrrMC ----
+
+def test_all_delta_e_and_discretize(oracle):
+    assert oracle.all_delta_e(3, (-1, 1)) == (2, 6)                     # RRG.jl:262-266
+    assert oracle.all_delta_e(6, (-1, 1)) == (0, 4, 8, 12)              # EA.jl:293
+    assert oracle.all_delta_e(3, (-1, 0, 1)) == (0, 2, 4, 6)
+    assert oracle.all_delta_e(2, (-2, 1)) == (0, 2, 4, 6, 8)            # sums of 2 terms +-{1,2}: 0, +-1, +-2, +-3, +-4
+    d, r = oracle.discretize(np.array([0.2, -0.7, 0.5, -0.5, 3.0]), (-1, 0, 1))
+    assert list(d) == [0, -1, 0, -1, 1]                                 # ties keep the first level (strict <, Common.jl:44)
+    assert np.allclose(r, [0.2, 0.3, 0.5, 0.5, 2.0])
+
+
+@pytest.mark.parametrize("kind,form,lev,thr", [
+    ("rrg", "rrg", (-1, 0, 1), 0.5), ("rrg", "rrg", (-1, 1), 0.0), ("rrg", "rrg", (-1, 0, 1), 1.0),
+    ("ea3", "ea", (-1, 0, 1), 0.5), ("ea2L2", "ea", (-1, 0, 1), 0.5),
+])
+def test_double_graph_tracked_energy(oracle, kind, form, lev, thr):
+    """test/runtests.jl:41-44,61-64 (GraphRRGNormalDiscretized(10,3,(-1,0,1)), GraphEANormalDiscretized(2,3,...), (3,2,...))
+    with the tracked-energy invariant of :12-20 and the staged_thr = 0 / 1 variants of :150-159."""
+    seed = 123
+    A = {"rrg": lambda: oracle.gen_rrg(10, 3, seed), "ea3": lambda: oracle.gen_ea(3, 2), "ea2L2": lambda: oracle.gen_ea(2, 3)}[kind]()
+    cJ = oracle.gen_couplings_gauss(A, seed)
+    dJ, rJ = oracle.discretize(cJ, lev)
+    assert np.allclose(dJ + rJ, cJ, rtol=0, atol=1e-15) and set(np.unique(dJ)) <= set(lev)
+    N = A.shape[0]
+    ch = oracle.init_config(seed, 0, N)
+    n = 3000
+    Es, ch_n, acc, staged, pos, sizes = oracle.rrr_double_sparse(A, dJ, rJ, lev, 1.2, n, 1, seed, ch, staged_thr=thr, form=form)
+    assert sizes.sum() == N and 0 < acc <= n
+    if thr == 0.0:
+        assert staged == 0
+    if thr == 1.0:
+        assert staged == n
+    # energy before iteration k+1 == energy of the configuration after k iterations, replayed chain by chain
+    for k in (1, 7, 500, n - 1):
+        _, ch_k, *_ = oracle.rrr_double_sparse(A, dJ, rJ, lev, 1.2, k, k, seed, ch, staged_thr=thr, form=form)
+        assert abs(Es[k] - oracle.dbl_energy(A, dJ, rJ, ch_k, form=form)) < 1e-9
+    # the double graph's energy is the energy of the undiscretized Gaussian model
+    assert abs(oracle.dbl_energy(A, dJ, rJ, ch_n, form=form) - oracle.spf_energy(A, cJ, ch_n, form=form)) < 1e-9
