@@ -49,6 +49,7 @@ enum rrrmc_model {
     RRRMC_MODEL_SPARSE_PM1 = 1,  /* GraphRRG{Int,(-1,1),K} src/graphs/RRG.jl:116 and GraphEA{Int,(-1,1),2D} src/graphs/EA.jl:138 */
     RRRMC_MODEL_SK_NORMAL = 2,   /* GraphSKNormal (Float64 couplings) src/graphs/SK.jl:181-210; K is ignored */
     RRRMC_MODEL_SPARSE_F64 = 5,  /* GraphRRGNormal{K} src/graphs/RRG.jl:503-520 and GraphEANormal{2D} src/graphs/EA.jl:534-552: sparse, Float64 couplings */
+    RRRMC_MODEL_SPARSE_DISCRETIZED = 6, /* GraphRRGNormalDiscretized src/graphs/RRG.jl:285-307, GraphEANormalDiscretized src/graphs/EA.jl:311-352 (integer LEV) */
     RRRMC_MODEL_SK_BINARY = 4,   /* GraphSK (couplings +-1/sqrt(N), bit-packed) src/graphs/SK.jl:28-60; K is ignored; energies Float64 */
     RRRMC_MODEL_QUANT_RRG = 3    /* GraphQuant over M Suzuki-Trotter slices of one GraphRRG{Int,(-1,1),K} disorder
                                     (src/graphs/QT.jl:126-170 with the shared-disorder pattern of src/QAliases.jl:43-67);
@@ -193,6 +194,20 @@ RRRMC_API int64_t rrrmc_iterations_done(const rrrmc_ctx *ctx);
 RRRMC_API int32_t rrrmc_set_graph_f64(rrrmc_ctx *ctx, const int32_t *A, const double *J);
 /* gen_J(Float64, N, A) do randn() end (RRG.jl:71-96, EA.jl:45-71): one GAUSS-stream normal per bond. J_out[N*K]. */
 RRRMC_API int32_t rrrmc_gen_couplings_gauss(int64_t N, int64_t K, const int32_t *A, uint64_t seed, double *J_out);
+
+/* ---- DoubleGraphs with discretised Gaussian couplings (RRRMC_MODEL_SPARSE_DISCRETIZED) --------
+ * GraphRRGNormalDiscretized{Int,LEV,K} / GraphEANormalDiscretized{Int,LEV,2D}: couplings cJ ~ Normal(0,1) split by
+ * discretize (src/Common.jl:38-72) into integer levels dJ (the inner DiscrGraph X0, which drives the DeltaECache) and
+ * Float64 residuals rJ.  Create with rrrmc_ctx_create(model = RRRMC_MODEL_SPARSE_DISCRETIZED, N, K, R); N <= 65535, K <= 8.
+ *   lev[nlev]  the levels (distinct integers in -127..127; allΔE(X0) must have <= 8 values)
+ *   ea_form    0: GraphRRG conventions (neighbors = non-zero couplings, RRG.jl:133), 1: GraphEA (repeats removed, EA.jl:158)
+ * Sampler: rrrmc_rrr_mc_async (rrrMC(X::DoubleGraph), src/RRRMC.jl:221-290; fourK ignored); results through
+ * rrrmc_fetch_results_f64 / rrrmc_rrr_stats; rrrmc_rrr_cache returns pos[R*N] and sizes[R*16] (class k of replica r at 16 r + k, k < 2L); energy through rrrmc_energy_f64.
+ * standardMC on these graphs is not wired (use RRRMC_MODEL_SPARSE_F64 with cJ = dJ + rJ). */
+RRRMC_API int32_t rrrmc_set_graph_discretized(rrrmc_ctx *ctx, const int32_t *A, const int8_t *dJ, const double *rJ,
+                                              const int32_t *lev, int32_t nlev, int32_t ea_form);
+/* discretize(cvec, LEV) (src/Common.jl:38-72): d_out[n] levels, r_out[n] residuals. */
+RRRMC_API int32_t rrrmc_discretize(const double *x, int64_t n, const int32_t *lev, int32_t nlev, int8_t *d_out, double *r_out);
 
 /* ---- snapshots and observables -------------------------------------------------------
  * The reference's scripts keep a copy of C.s at every hook call (scripts/scripts.jl:56-66, to_mat :13-21) and later

@@ -17,6 +17,7 @@
 #include "sparse_kernels.hpp"
 #include "obs_kernels.hpp"
 #include "spf_kernels.hpp"
+#include "dbl_kernels.hpp"
 
 using namespace rrrmc;
 
@@ -132,6 +133,17 @@ struct rrrmc_ctx {
     double* pf_undo = nullptr;     // [W][K+1][64]: live part of lfields_last (see spf_kernels.hpp)
     int32_t* pf_sites = nullptr;   // site stream of one launch
     int64_t pfW = 0;
+    // ---- RRRMC_MODEL_SPARSE_DISCRETIZED (Graph{RRG,EA}NormalDiscretized): spins in q_spins / qW (BitVector word order),
+    //      energies in sk_E / sk_Es, statistics in q_stats ----
+    int8_t* db_dJ = nullptr;       // [N][K] discretised couplings (levels)
+    double* db_rJ = nullptr;       // [N][K] residuals
+    uint8_t* db_cls = nullptr;
+    uint16_t* db_sv = nullptr;
+    uint16_t* db_spos = nullptr;
+    double* db_lf = nullptr;       // [R][N]
+    double* db_undo = nullptr;     // [R][K+1]
+    int db_L = 0, db_ea_form = 0;
+    int db_dElist[kDLmax] = {0};
     // ---- snapshots / observables ----
     uint8_t* snap = nullptr;       // [nslots][snap_bytes]: copies of the model's native spin buffer
     int32_t snap_slots = 0;
@@ -226,6 +238,9 @@ size_t plan_lds_bytes(int64_t N, int K, int C)
 {
     return 4 * 3 * ((size_t)C + 2) + 2 * ((size_t)2 * C + (size_t)C * K + (size_t)N) + 16;
 }
+
+// models whose device spins are R x W 32-bit words in BitVector order (q_spins, qW)
+inline bool chunk_layout(const rrrmc_ctx* ctx) { return ctx->model == RRRMC_MODEL_QUANT_RRG || ctx->model == RRRMC_MODEL_SPARSE_DISCRETIZED; }
 
 int32_t ensure_state(rrrmc_ctx* ctx, bool need_spins)
 {
@@ -612,6 +627,116 @@ int32_t spf_standard_mc_async(rrrmc_ctx* ctx, double beta, int64_t iters, int64_
 }
 
 
+// ---- DoubleGraphs Graph{RRG,EA}NormalDiscretized host side -----------------------------------------------------------
+double host_det_exp(double x);
+int32_t dbl_ctx_create(rrrmc_ctx** out, int64_t N, int64_t K, int64_t R, int32_t device, uint32_t replica0)
+{
+    if (N < 1 || K < 1 || R < 1) return fail(nullptr, RRRMC_ERR_INVALID_ARG, "N, K, R must be >= 1 (given N=%lld K=%lld R=%lld)", (long long)N, (long long)K, (long long)R);
+    if (K > kDKmax) return fail(nullptr, RRRMC_ERR_UNSUPPORTED, "K=%lld: the DoubleGraph kernel covers K <= %d", (long long)K, kDKmax);
+    if (N > 65535) return fail(nullptr, RRRMC_ERR_UNSUPPORTED, "N=%lld: the rrrMC kernels index spins with 16 bits", (long long)N);
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(nullptr, RRRMC_ERR_HIP, "no HIP device is visible: this library has no CPU path");
+    if (device < 0 || device >= ndev) return fail(nullptr, RRRMC_ERR_INVALID_ARG, "device %d out of range (0..%d)", device, ndev - 1);
+    rrrmc_ctx* ctx = new (std::nothrow) rrrmc_ctx();
+    if (!ctx) return fail(nullptr, RRRMC_ERR_NOMEM, "out of host memory");
+    ctx->model = RRRMC_MODEL_SPARSE_DISCRETIZED; ctx->N = N; ctx->K = K; ctx->R = R; ctx->Rpad = R;
+    ctx->qW = 2 * ((N + 63) / 64);
+    ctx->device = device; ctx->replica0 = replica0;
+#define DB_TRY(expr)                                                                                             \
+    do {                                                                                                         \
+        hipError_t e_ = (expr);                                                                                  \
+        if (e_ != hipSuccess) {                                                                                  \
+            int32_t rc_ = fail(nullptr, e_ == hipErrorOutOfMemory ? RRRMC_ERR_NOMEM : RRRMC_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
+            rrrmc_ctx_destroy(ctx);                                                                              \
+            return rc_;                                                                                          \
+        }                                                                                                        \
+    } while (0)
+    DB_TRY(hipSetDevice(device));
+    DB_TRY(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+    DB_TRY(hipEventCreate(&ctx->ev_begin));
+    DB_TRY(hipEventCreate(&ctx->ev_end));
+    DB_TRY(hipMalloc(&ctx->d_A, sizeof(int32_t) * N * K));
+    DB_TRY(hipMalloc(&ctx->db_dJ, sizeof(int8_t) * N * K));
+    DB_TRY(hipMalloc(&ctx->db_rJ, sizeof(double) * N * K));
+    DB_TRY(hipMalloc(&ctx->q_spins, sizeof(uint32_t) * R * ctx->qW));
+    DB_TRY(hipMalloc(&ctx->db_cls, (size_t)R * N));
+    DB_TRY(hipMalloc(&ctx->db_sv, sizeof(uint16_t) * (size_t)R * 2 * kDLmax * N));
+    DB_TRY(hipMalloc(&ctx->db_spos, sizeof(uint16_t) * (size_t)R * N));
+    DB_TRY(hipMalloc(&ctx->db_lf, sizeof(double) * (size_t)R * N));
+    DB_TRY(hipMalloc(&ctx->db_undo, sizeof(double) * (size_t)R * (K + 1)));
+    DB_TRY(hipMalloc(&ctx->q_stats, sizeof(int64_t) * R * 2));
+    DB_TRY(hipMalloc(&ctx->sk_E, sizeof(double) * R));
+    DB_TRY(hipMalloc(&ctx->d_acc, sizeof(int64_t) * R));
+    DB_TRY(hipMemset(ctx->q_spins, 0, sizeof(uint32_t) * R * ctx->qW));
+    DB_TRY(hipMemset(ctx->q_stats, 0, sizeof(int64_t) * R * 2));
+#undef DB_TRY
+    *out = ctx;
+    return RRRMC_OK;
+}
+
+RrrDblParams dbl_params(rrrmc_ctx* ctx, double beta)
+{
+    RrrDblParams P{};
+    P.A = ctx->d_A; P.dJ = ctx->db_dJ; P.rJ = ctx->db_rJ; P.spins = ctx->q_spins; P.cls = ctx->db_cls; P.sv = ctx->db_sv; P.spos = ctx->db_spos;
+    P.lf = ctx->db_lf; P.undo = ctx->db_undo; P.E_cur = ctx->sk_E; P.stats = ctx->q_stats; P.Es = ctx->sk_Es;
+    for (int k = 0; k < ctx->db_L; ++k) { P.dElist[k] = ctx->db_dElist[k]; P.ft[k] = host_det_exp(-beta * (double)ctx->db_dElist[k]); }   // DeltaE.jl:91
+    P.beta = beta;
+    P.k0 = (uint32_t)ctx->seed; P.k1 = (uint32_t)(ctx->seed >> 32); P.replica0 = ctx->replica0;
+    P.N = (int)ctx->N; P.K = (int)ctx->K; P.L = ctx->db_L; P.W = (int)ctx->qW; P.R = (int)ctx->R; P.ea_form = ctx->db_ea_form;
+    return P;
+}
+
+int32_t dbl_run_energy(rrrmc_ctx* ctx)
+{
+    RrrDblParams P = dbl_params(ctx, 0.0);
+    P.energy_only = 1;
+    hipLaunchKernelGGL(rrr_dbl_kernel, dim3((unsigned)((ctx->R + kRrrThreads - 1) / kRrrThreads)), dim3(kRrrThreads), 0, ctx->stream, P);
+    HIP_TRY(ctx, hipGetLastError());
+    return RRRMC_OK;
+}
+
+int32_t dbl_rrr_mc_async(rrrmc_ctx* ctx, double beta, int64_t iters, int64_t step, double staged_thr, double staged_thr_fact)
+{
+    if (iters < 0) return fail(ctx, RRRMC_ERR_INVALID_ARG, "iters must be >= 0, given %lld", (long long)iters);
+    if (step < 1) return fail(ctx, RRRMC_ERR_INVALID_ARG, "step must be >= 1, given %lld", (long long)step);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    ctx->results_valid = false;
+    ctx->timing_valid = false;
+    const int64_t nsamp = iters / step;
+    const size_t es_need = (size_t)(nsamp > 0 ? nsamp : 1) * ctx->R;
+    if (es_need > ctx->sk_Es_cap) {
+        free_dev(ctx->sk_Es);
+        ctx->sk_Es_cap = 0;
+        HIP_TRY(ctx, hipMalloc(&ctx->sk_Es, sizeof(double) * es_need));
+        ctx->sk_Es_cap = es_need;
+    }
+    while (ctx->ev_sweep.size() < 2) {
+        hipEvent_t e;
+        HIP_TRY(ctx, hipEventCreate(&e));
+        ctx->ev_sweep.push_back(e);
+    }
+    RrrDblParams P = dbl_params(ctx, beta);
+    P.staged_thr = staged_thr; P.lambda = staged_thr_fact / (double)ctx->N;
+    P.g0 = ctx->it_done; P.iters = iters; P.step = step;
+    hipStream_t st = ctx->stream;
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_begin, st));
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_sweep[0], st));
+    hipLaunchKernelGGL(rrr_dbl_kernel, dim3((unsigned)((ctx->R + kRrrThreads - 1) / kRrrThreads)), dim3(kRrrThreads), 0, st, P);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_sweep[1], st));
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_end, st));
+    ctx->stats_stride = 2;
+    ctx->sweep_launches = 1;
+    ctx->nsamp = nsamp;
+    ctx->it_done += (uint64_t)iters;
+    ctx->results_valid = true;
+    ctx->timing_valid = true;
+    ctx->last_call_rrr = true;
+    return RRRMC_OK;
+}
+
+
 // ---- GraphQuant / rrrMC host side -----------------------------------------------------------------------------------
 RrrParams quant_params(rrrmc_ctx* ctx, double beta, double fourK)
 {
@@ -814,9 +939,11 @@ int32_t rrrmc_ctx_create(rrrmc_ctx** out, int32_t model, int64_t N, int64_t K, i
     if (!out) return fail(nullptr, RRRMC_ERR_INVALID_ARG, "out is NULL");
     *out = nullptr;
     if (model == RRRMC_MODEL_QUANT_RRG) return fail(nullptr, RRRMC_ERR_INVALID_ARG, "RRRMC_MODEL_QUANT_RRG contexts are created with rrrmc_ctx_create_quant");
-    if (model != RRRMC_MODEL_SPARSE_PM1 && model != RRRMC_MODEL_SK_NORMAL && model != RRRMC_MODEL_SK_BINARY && model != RRRMC_MODEL_SPARSE_F64)
+    if (model != RRRMC_MODEL_SPARSE_PM1 && model != RRRMC_MODEL_SK_NORMAL && model != RRRMC_MODEL_SK_BINARY && model != RRRMC_MODEL_SPARSE_F64 &&
+        model != RRRMC_MODEL_SPARSE_DISCRETIZED)
         return fail(nullptr, RRRMC_ERR_UNSUPPORTED, "unknown model kind %d", model);
     if (model == RRRMC_MODEL_SPARSE_F64) return spf_ctx_create(out, N, K, R, device, replica0);
+    if (model == RRRMC_MODEL_SPARSE_DISCRETIZED) return dbl_ctx_create(out, N, K, R, device, replica0);
     if (model == RRRMC_MODEL_SK_NORMAL || model == RRRMC_MODEL_SK_BINARY) return sk_ctx_create(out, model, N, R, device, replica0);
     if (N < 1 || K < 1 || R < 1) return fail(nullptr, RRRMC_ERR_INVALID_ARG, "N, K, R must be >= 1 (given N=%lld K=%lld R=%lld)", (long long)N, (long long)K, (long long)R);
     if (K > kMaxK) return fail(nullptr, RRRMC_ERR_UNSUPPORTED, "K=%lld: the sparse +-J kernels cover K <= %d", (long long)K, kMaxK);
@@ -899,6 +1026,7 @@ void rrrmc_ctx_destroy(rrrmc_ctx* ctx)
     free_dev(ctx->rs_buf); free_dev(ctx->rs_spins); free_dev(ctx->rs_status);
     free_dev(ctx->rp_spins); free_dev(ctx->rp_cls); free_dev(ctx->rp_sv); free_dev(ctx->rp_spos);
     free_dev(ctx->pf_J); free_dev(ctx->pf_spins); free_dev(ctx->pf_undo); free_dev(ctx->pf_sites);
+    free_dev(ctx->db_dJ); free_dev(ctx->db_rJ); free_dev(ctx->db_cls); free_dev(ctx->db_sv); free_dev(ctx->db_spos); free_dev(ctx->db_lf); free_dev(ctx->db_undo);
     free_dev(ctx->snap); free_dev(ctx->d_pairs); free_dev(ctx->d_ovl); free_dev(ctx->d_qobs);
     for (int i = 0; i < 2; ++i) { free_dev(ctx->d_slots[i]); free_dev(ctx->d_vecs[i]); }
     if (ctx->plan_stream) { (void)hipStreamSynchronize(ctx->plan_stream); (void)hipStreamDestroy(ctx->plan_stream); }
@@ -974,7 +1102,7 @@ int32_t rrrmc_init_spins_random(rrrmc_ctx* ctx)
 {
     if (!ctx) return RRRMC_ERR_INVALID_ARG;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    if (ctx->model == RRRMC_MODEL_QUANT_RRG) {
+    if (chunk_layout(ctx)) {
         const dim3 grid((unsigned)((ctx->qW + 255) / 256), (unsigned)ctx->R);
         hipLaunchKernelGGL(quant_init_spins_kernel, grid, dim3(256), 0, ctx->stream, ctx->q_spins, (int)ctx->N, (int)ctx->qW,
                            ctx->replica0, (uint32_t)ctx->seed, (uint32_t)(ctx->seed >> 32));
@@ -1021,7 +1149,7 @@ int32_t rrrmc_set_spins(rrrmc_ctx* ctx, const uint64_t* chunks)
             if (chunks[r * nch + nch - 1] & tailmask)
                 return fail(ctx, RRRMC_ERR_INVALID_ARG, "replica %lld: bits beyond N are set in the last chunk", (long long)r);
     }
-    if (ctx->model == RRRMC_MODEL_QUANT_RRG) {     // chunk c of a replica = words 2c, 2c+1 (little endian): same bytes
+    if (chunk_layout(ctx)) {     // chunk c of a replica = words 2c, 2c+1 (little endian): same bytes
         HIP_TRY(ctx, hipSetDevice(ctx->device));
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
         HIP_TRY(ctx, hipMemcpy(ctx->q_spins, chunks, sizeof(uint64_t) * ctx->R * nch, hipMemcpyHostToDevice));
@@ -1073,14 +1201,14 @@ namespace {
 // the model's native device spin buffer and its size (the unit a snapshot stores)
 const void* native_spins(const rrrmc_ctx* ctx)
 {
-    if (ctx->model == RRRMC_MODEL_QUANT_RRG) return ctx->q_spins;
+    if (chunk_layout(ctx)) return ctx->q_spins;
     if (ctx->model == RRRMC_MODEL_SPARSE_F64) return ctx->pf_spins;
     if (ctx->model == RRRMC_MODEL_SK_NORMAL || ctx->model == RRRMC_MODEL_SK_BINARY) return ctx->sk_spins;
     return ctx->d_spins;
 }
 size_t native_spin_bytes(const rrrmc_ctx* ctx)
 {
-    if (ctx->model == RRRMC_MODEL_QUANT_RRG) return sizeof(uint32_t) * (size_t)ctx->R * (size_t)ctx->qW;
+    if (chunk_layout(ctx)) return sizeof(uint32_t) * (size_t)ctx->R * (size_t)ctx->qW;
     if (ctx->model == RRRMC_MODEL_SPARSE_F64) return sizeof(unsigned long long) * (size_t)ctx->pfW * (size_t)ctx->N;
     if (ctx->model == RRRMC_MODEL_SK_NORMAL || ctx->model == RRRMC_MODEL_SK_BINARY) return (size_t)ctx->G8 * (size_t)ctx->N;
     return sizeof(uint32_t) * (size_t)ctx->G * (size_t)ctx->N;
@@ -1092,7 +1220,7 @@ int32_t spins_to_chunks(rrrmc_ctx* ctx, const void* src, uint64_t* chunks)
     const int64_t N = ctx->N, nch = (N + 63) / 64;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    if (ctx->model == RRRMC_MODEL_QUANT_RRG) {
+    if (chunk_layout(ctx)) {
         HIP_TRY(ctx, hipMemcpy(chunks, src, sizeof(uint64_t) * ctx->R * nch, hipMemcpyDeviceToHost));
         return RRRMC_OK;
     }
@@ -1192,6 +1320,8 @@ int32_t rrrmc_standard_mc_async(rrrmc_ctx* ctx, double beta, int64_t iters, int6
     if (rc) return rc;
     if (ctx->model == RRRMC_MODEL_SK_NORMAL || ctx->model == RRRMC_MODEL_SK_BINARY) return sk_standard_mc_async(ctx, beta, iters, step);
     if (ctx->model == RRRMC_MODEL_SPARSE_F64) return spf_standard_mc_async(ctx, beta, iters, step);
+    if (ctx->model == RRRMC_MODEL_SPARSE_DISCRETIZED || ctx->model == RRRMC_MODEL_QUANT_RRG)
+        return fail(ctx, RRRMC_ERR_UNSUPPORTED, "standardMC is not wired for this DoubleGraph: use rrrmc_rrr_mc_async");
     if (ctx->model != RRRMC_MODEL_SPARSE_PM1) return fail(ctx, RRRMC_ERR_UNSUPPORTED, "standardMC is not wired for this model on the device: use rrrmc_rrr_mc_async");
     if (!ctx->lds_mode) return fail(ctx, RRRMC_ERR_UNSUPPORTED, "N=%lld does not fit the LDS-resident random-site kernel: use rrrmc_colored_sweeps_async", (long long)ctx->N);
     ctx->colored_call = false;
@@ -1589,7 +1719,8 @@ int32_t rrrmc_rrr_mc_async(rrrmc_ctx* ctx, double beta, double fourK, int64_t it
     if (!std::isfinite(beta)) return fail(ctx, RRRMC_ERR_INVALID_ARG, "beta must be finite, given: %g", beta);       // RRRMC.jl:230, :166
     if (ctx->model == RRRMC_MODEL_SK_NORMAL) return sk_rrr_mc_async(ctx, beta, iters, step, staged_thr, staged_thr_fact);
     if (ctx->model == RRRMC_MODEL_SPARSE_PM1) return sparse_rrr_bkl_async(ctx, 0, beta, iters, step, staged_thr, staged_thr_fact);
-    if (ctx->model != RRRMC_MODEL_QUANT_RRG) return fail(ctx, RRRMC_ERR_UNSUPPORTED, "rrrMC is wired for RRRMC_MODEL_QUANT_RRG and RRRMC_MODEL_SK_NORMAL");
+    if (ctx->model == RRRMC_MODEL_SPARSE_DISCRETIZED) return dbl_rrr_mc_async(ctx, beta, iters, step, staged_thr, staged_thr_fact);
+    if (ctx->model != RRRMC_MODEL_QUANT_RRG) return fail(ctx, RRRMC_ERR_UNSUPPORTED, "rrrMC is not available for model kind %d", ctx->model);
     if (!(fourK > 0.0) || !std::isfinite(fourK)) return fail(ctx, RRRMC_ERR_INVALID_ARG, "fourK must be positive and finite, given: %g", fourK);
     if (iters < 0) return fail(ctx, RRRMC_ERR_INVALID_ARG, "iters must be >= 0, given %lld", (long long)iters);
     if (step < 1) return fail(ctx, RRRMC_ERR_INVALID_ARG, "step must be >= 1, given %lld", (long long)step);
@@ -1669,9 +1800,22 @@ int32_t rrrmc_rrr_stats(rrrmc_ctx* ctx, int64_t* staged_iters_out)
 int32_t rrrmc_rrr_cache(rrrmc_ctx* ctx, int8_t* pos_out, int32_t* sizes_out)
 {
     if (!ctx) return RRRMC_ERR_INVALID_ARG;
-    if (ctx->model != RRRMC_MODEL_QUANT_RRG || !ctx->results_valid) return fail(ctx, RRRMC_ERR_STATE, "no rrrMC call has been made");
+    if ((ctx->model != RRRMC_MODEL_QUANT_RRG && ctx->model != RRRMC_MODEL_SPARSE_DISCRETIZED) || !ctx->results_valid || !ctx->last_call_rrr)
+        return fail(ctx, RRRMC_ERR_STATE, "no rrrMC call has been made");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->model == RRRMC_MODEL_SPARSE_DISCRETIZED) {      // sizes_out[R * 16]: counted from the classes
+        std::vector<uint8_t> cls((size_t)ctx->R * ctx->N);
+        HIP_TRY(ctx, hipMemcpy(cls.data(), ctx->db_cls, cls.size(), hipMemcpyDeviceToHost));
+        const int K2 = 2 * kDLmax;                           // fixed stride: class k of replica r at sizes_out[16 r + k]
+        if (pos_out) std::memcpy(pos_out, cls.data(), cls.size());
+        if (sizes_out) {
+            std::memset(sizes_out, 0, sizeof(int32_t) * (size_t)ctx->R * K2);
+            for (int64_t r = 0; r < ctx->R; ++r)
+                for (int64_t i = 0; i < ctx->N; ++i) sizes_out[r * K2 + cls[(size_t)(r * ctx->N + i)]] += 1;
+        }
+        return RRRMC_OK;
+    }
     if (pos_out) HIP_TRY(ctx, hipMemcpy(pos_out, ctx->q_cls, (size_t)ctx->R * ctx->N, hipMemcpyDeviceToHost));
     if (sizes_out) HIP_TRY(ctx, hipMemcpy(sizes_out, ctx->q_st, sizeof(int32_t) * ctx->R * 4, hipMemcpyDeviceToHost));
     return RRRMC_OK;
@@ -1710,6 +1854,8 @@ int32_t rrrmc_energy_f64(rrrmc_ctx* ctx, double* E_out)
         rc = quant_run_init(ctx, ctx->last_beta, ctx->last_fourK);
     } else if (ctx->model == RRRMC_MODEL_SPARSE_F64) {
         rc = spf_run_energy(ctx);
+    } else if (ctx->model == RRRMC_MODEL_SPARSE_DISCRETIZED) {
+        rc = dbl_run_energy(ctx);
     } else {
         rc = sk_run_energy(ctx);
     }
@@ -1884,7 +2030,7 @@ int32_t rrrmc_overlaps(rrrmc_ctx* ctx, int64_t npairs, const int32_t* slotA, con
     if (ctx->model == RRRMC_MODEL_SPARSE_F64) {
         hipLaunchKernelGGL(overlap_lanes_kernel, dim3((unsigned)ctx->pfW, (unsigned)npairs), dim3(64), 0, ctx->stream,
                            (const unsigned long long* const*)pa, (const unsigned long long* const*)pb, (int)ctx->N, (int)ctx->Rpad, ctx->d_ovl);
-    } else if (ctx->model == RRRMC_MODEL_QUANT_RRG) {
+    } else if (chunk_layout(ctx)) {
         hipLaunchKernelGGL(overlap_chunks_kernel, dim3((unsigned)ctx->R, (unsigned)npairs), dim3(64), 0, ctx->stream,
                            (const uint32_t* const*)pa, (const uint32_t* const*)pb, (int)ctx->N, (int)ctx->qW, (int)ctx->Rpad, ctx->d_ovl);
     } else if (ctx->model == RRRMC_MODEL_SK_NORMAL || ctx->model == RRRMC_MODEL_SK_BINARY) {
@@ -1942,6 +2088,89 @@ int32_t rrrmc_quant_observables(rrrmc_ctx* ctx, double beta, double Gamma, doubl
                 ovs_out[r * H + d - 1] = o;
             }
         }
+    }
+    return RRRMC_OK;
+}
+
+int32_t rrrmc_set_graph_discretized(rrrmc_ctx* ctx, const int32_t* A, const int8_t* dJ, const double* rJ, const int32_t* lev, int32_t nlev,
+                                    int32_t ea_form)
+{
+    if (!ctx) return RRRMC_ERR_INVALID_ARG;
+    if (ctx->model != RRRMC_MODEL_SPARSE_DISCRETIZED) return fail(ctx, RRRMC_ERR_STATE, "rrrmc_set_graph_discretized is for RRRMC_MODEL_SPARSE_DISCRETIZED");
+    if (!A || !dJ || !rJ || !lev) return fail(ctx, RRRMC_ERR_INVALID_ARG, "A, dJ, rJ, lev must not be NULL");
+    if (nlev < 1 || nlev > 16) return fail(ctx, RRRMC_ERR_INVALID_ARG, "between 1 and 16 levels are supported, given %d", nlev);
+    for (int32_t a = 0; a < nlev; ++a) {
+        if (lev[a] < -127 || lev[a] > 127) return fail(ctx, RRRMC_ERR_UNSUPPORTED, "level %d does not fit the int8 coupling table", lev[a]);
+        for (int32_t b = 0; b < a; ++b)
+            if (lev[a] == lev[b]) return fail(ctx, RRRMC_ERR_INVALID_ARG, "repeated levels in LEV");     // RRG.jl:100
+    }
+    const int64_t N = ctx->N, K = ctx->K;
+    for (int64_t q = 0; q < N * K; ++q) {
+        if (A[q] < 0 || A[q] >= N) return fail(ctx, RRRMC_ERR_INVALID_ARG, "A[%lld] = %d out of range 0..%lld", (long long)q, A[q], (long long)(N - 1));
+        if (A[q] == q / K) return fail(ctx, RRRMC_ERR_INVALID_ARG, "self loop at site %lld", (long long)(q / K));
+        if (q % K && A[q] < A[q - 1]) return fail(ctx, RRRMC_ERR_INVALID_ARG, "row %lld of A is not sorted", (long long)(q / K));
+        if (!std::isfinite(rJ[q])) return fail(ctx, RRRMC_ERR_INVALID_ARG, "rJ[%lld] is not finite", (long long)q);
+        bool ok = false;
+        for (int32_t a = 0; a < nlev; ++a) ok |= (int32_t)dJ[q] == lev[a];
+        if (!ok) return fail(ctx, RRRMC_ERR_INVALID_ARG, "the given J is incompatible with the levels (dJ[%lld] = %d)", (long long)q, (int)dJ[q]);   // RRG.jl:130
+        if (!ea_form && q % K && A[q] == A[q - 1]) return fail(ctx, RRRMC_ERR_INVALID_ARG, "repeated neighbour in row %lld: pass ea_form = 1 for GraphEA tables", (long long)(q / K));
+    }
+    std::vector<uint8_t> used((size_t)(N * K), 0);
+    for (int64_t x = 0; x < N; ++x)
+        for (int64_t k = 0; k < K; ++k) {
+            const int64_t y = A[x * K + k];
+            bool found = false;
+            for (int64_t l = 0; l < K && !found; ++l)
+                if (!used[y * K + l] && A[y * K + l] == x && dJ[y * K + l] == dJ[x * K + k] && rJ[y * K + l] == rJ[x * K + k]) { used[y * K + l] = 1; found = true; }
+            if (!found) return fail(ctx, RRRMC_ERR_INVALID_ARG, "bond (%lld,%lld) is not symmetric in (A, dJ, rJ)", (long long)x, (long long)y);
+        }
+    // allΔE(X0): sums of K terms +-l (RRG.jl:268-281, EA.jl:295-309)
+    int64_t amax = 0;
+    for (int32_t a = 0; a < nlev; ++a) amax = std::max<int64_t>(amax, lev[a] < 0 ? -(int64_t)lev[a] : lev[a]);
+    const int64_t span = K * amax;
+    std::vector<uint8_t> cur((size_t)(2 * span + 1), 0), nxt((size_t)(2 * span + 1), 0);
+    cur[(size_t)span] = 1;
+    for (int64_t n = 0; n < K; ++n) {
+        std::fill(nxt.begin(), nxt.end(), 0);
+        for (int64_t v = -span; v <= span; ++v)
+            if (cur[(size_t)(v + span)])
+                for (int32_t a = 0; a < nlev; ++a) {
+                    if (v + lev[a] >= -span && v + lev[a] <= span) nxt[(size_t)(v + lev[a] + span)] = 1;
+                    if (v - lev[a] >= -span && v - lev[a] <= span) nxt[(size_t)(v - lev[a] + span)] = 1;
+                }
+        cur.swap(nxt);
+    }
+    int L = 0;
+    for (int64_t a = 0; a <= span; ++a)
+        if (cur[(size_t)(span + a)] || cur[(size_t)(span - a)]) {
+            if (L == kDLmax) return fail(ctx, RRRMC_ERR_UNSUPPORTED, "more than %d energy levels: not covered by the DoubleGraph kernel", kDLmax);
+            ctx->db_dElist[L++] = (int)(2 * a);
+        }
+    ctx->db_L = L;
+    ctx->db_ea_form = ea_form ? 1 : 0;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipMemcpy(ctx->d_A, A, sizeof(int32_t) * N * K, hipMemcpyHostToDevice));
+    HIP_TRY(ctx, hipMemcpy(ctx->db_dJ, dJ, sizeof(int8_t) * N * K, hipMemcpyHostToDevice));
+    HIP_TRY(ctx, hipMemcpy(ctx->db_rJ, rJ, sizeof(double) * N * K, hipMemcpyHostToDevice));
+    ctx->graph_set = true;
+    return RRRMC_OK;
+}
+
+int32_t rrrmc_discretize(const double* x, int64_t n, const int32_t* lev, int32_t nlev, int8_t* d_out, double* r_out)
+{
+    // discretize: src/Common.jl:38-49 (nearest level, the first one on ties; residual = x - level)
+    if (!x || !lev || !d_out || !r_out || nlev < 1 || n < 0) return RRRMC_ERR_INVALID_ARG;
+    for (int64_t q = 0; q < n; ++q) {
+        int32_t d = lev[0];
+        double r = x[q] - (double)d;
+        for (int32_t l = 1; l < nlev; ++l) {
+            const double r1 = x[q] - (double)lev[l];
+            if (std::fabs(r1) < std::fabs(r)) { d = lev[l]; r = r1; }
+        }
+        if (d < -127 || d > 127) return RRRMC_ERR_UNSUPPORTED;
+        d_out[q] = (int8_t)d;
+        r_out[q] = r;
     }
     return RRRMC_OK;
 }

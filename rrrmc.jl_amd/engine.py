@@ -11,6 +11,7 @@ MODEL_SK_NORMAL = 2
 MODEL_QUANT_RRG = 3
 MODEL_SK_BINARY = 4
 MODEL_SPARSE_F64 = 5
+MODEL_SPARSE_DISCRETIZED = 6
 
 
 class Engine:
@@ -28,6 +29,9 @@ class Engine:
             if X.model_kind == MODEL_QUANT_RRG:
                 check(lib().rrrmc_set_graph(self._ctx, X.A, X.J), self._ctx)
                 check(lib().rrrmc_quant_set_field(self._ctx, X.beta, X.fourK), self._ctx)
+            elif X.model_kind == MODEL_SPARSE_DISCRETIZED:
+                check(lib().rrrmc_set_graph_discretized(self._ctx, X.A, X.dJ, X.rJ.reshape(-1), np.asarray(X.LEV, np.int32), len(X.LEV),
+                                                        X.ea_form), self._ctx)
             elif X.model_kind == MODEL_SPARSE_F64:
                 check(lib().rrrmc_set_graph_f64(self._ctx, X.A, X.J.reshape(-1)), self._ctx)
             elif X.model_kind == MODEL_SK_BINARY:
@@ -159,7 +163,7 @@ class Engine:
     def rrr_cache(self):
         """(pos[R, N], sizes[R, 4]) of the DeltaECache after the last rrrMC call."""
         pos = np.zeros((self.R, self.X.N), np.int8)
-        sizes = np.zeros((self.R, 4), np.int32)
+        sizes = np.zeros((self.R, 16 if self.X.model_kind == MODEL_SPARSE_DISCRETIZED else 4), np.int32)
         check(lib().rrrmc_rrr_cache(self._ctx, pos.ctypes.data, sizes.ctypes.data), self._ctx)
         return pos, sizes
 

@@ -206,6 +206,54 @@ class GraphEANormal(_SparseF64Graph):
         return L, D, A, J
 
 
+class _DiscretizedGraph:
+    """Common part of Graph{RRG,EA}NormalDiscretized: ``A``, the Gaussian couplings ``cJ`` and their split
+    ``dJ`` (levels, the inner DiscrGraph ``X0``) + ``rJ`` (residuals) by ``discretize`` (src/Common.jl:38-72)."""
+    model_kind = 6          # RRRMC_MODEL_SPARSE_DISCRETIZED
+    energy_dtype = np.float64
+
+    def _split(self, A, cJ, LEV):
+        LEV = tuple(LEV)
+        if any(int(l) != l for l in LEV):
+            raise NotImplementedError("only integer levels are covered by the HIP path, given: %r" % (LEV,))
+        if len(set(LEV)) != len(LEV):
+            raise ValueError("repeated levels in LEV: %r" % (LEV,))                   # RRG.jl:100
+        self.LEV = tuple(int(l) for l in LEV)
+        self.A = np.ascontiguousarray(A, np.int32)
+        self.cJ = np.ascontiguousarray(cJ, np.float64)
+        self.N, self.K = self.A.shape
+        self.dJ = np.zeros(self.A.shape, np.int8)
+        self.rJ = np.zeros(self.A.shape, np.float64)
+        check(lib().rrrmc_discretize(self.cJ.reshape(-1), self.cJ.size, np.asarray(self.LEV, np.int32), len(self.LEV),
+                                     self.dJ.reshape(-1), self.rJ.reshape(-1)))
+
+
+class GraphRRGNormalDiscretized(_DiscretizedGraph):
+    """``GraphRRGNormalDiscretized(N, K, LEV)`` — DoubleGraph{DiscrGraph,Float64} (src/graphs/RRG.jl:285-324)."""
+    ea_form = 0
+
+    def __init__(self, N, K, LEV, seed=DEFAULT_SEED):
+        A = np.zeros((int(N), int(K)), np.int32)
+        check(lib().rrrmc_gen_rrg(N, K, seed, A))
+        cJ = np.zeros((int(N), int(K)), np.float64)
+        check(lib().rrrmc_gen_couplings_gauss(N, K, A, seed, cJ.reshape(-1)))
+        self._split(A, cJ, LEV)
+
+
+class GraphEANormalDiscretized(_DiscretizedGraph):
+    """``GraphEANormalDiscretized(L, D, LEV)`` — DoubleGraph{DiscrGraph,Float64} (src/graphs/EA.jl:311-357)."""
+    ea_form = 1
+
+    def __init__(self, L, D, LEV, seed=DEFAULT_SEED):
+        N = int(L) ** int(D)
+        A = np.zeros((N, 2 * int(D)), np.int32)
+        check(lib().rrrmc_gen_ea(L, D, A))
+        cJ = np.zeros((N, 2 * int(D)), np.float64)
+        check(lib().rrrmc_gen_couplings_gauss(N, 2 * int(D), A, seed, cJ.reshape(-1)))
+        self._split(A, cJ, LEV)
+        self.L, self.D = int(L), int(D)
+
+
 class GraphSKNormal:
     """``GraphSKNormal(N)`` — Sherrington-Kirkpatrick model, couplings ~ Normal(0, 1/N) (src/graphs/SK.jl:181-210).
 

@@ -100,6 +100,25 @@ def bench_spf(N=4096, K=3, R=65536, beta=1.0, iters=1 << 14, step=1 << 12, seed=
         eng.close()
 
 
+def bench_dbl(N=4096, K=3, R=8192, beta=2.0, iters=1 << 14, step=1 << 12, seed=0x5EED):
+    """GraphRRGNormalDiscretized(N, K, (-1,0,1)) under rrrMC(X::DoubleGraph) (SURVEY.md §8f rank 3): thread-per-replica kernel."""
+    pkg = entry.load_package()
+    X = pkg.GraphRRGNormalDiscretized(N, K, (-1, 0, 1), seed=seed)
+    for R in ([int(a) for a in sys.argv[2:]] or [R]):
+        eng = pkg.Engine(X, R)
+        eng.seed(seed)
+        eng.init_spins_random()
+        t0 = time.perf_counter()
+        Es, acc, staged = eng.rrr_mc(beta, iters, step)
+        dt = time.perf_counter() - t0
+        total_ms, sweep_ms, _ = eng.last_timing()
+        out = {"model": "GraphRRGNormalDiscretized rrrMC", "N": N, "K": K, "replicas": R, "beta": beta, "iters": iters,
+               "iterations_per_s": float(R) * iters / dt, "kernel_ms": sweep_ms, "acceptance": float(acc.mean()) / iters,
+               "staged_frac": float(staged.mean()) / iters, "energy_per_spin": float(Es[:, -1].mean()) / X.N}
+        print(json.dumps(out), flush=True)
+        eng.close()
+
+
 if __name__ == "__main__":
     which = sys.argv[1] if len(sys.argv) > 1 else "sk"
-    {"sk": bench_sk, "ea": bench_ea, "quant": bench_quant, "spf": bench_spf}[which]()
+    {"sk": bench_sk, "ea": bench_ea, "quant": bench_quant, "spf": bench_spf, "dbl": bench_dbl}[which]()
