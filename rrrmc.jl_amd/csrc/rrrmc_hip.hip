@@ -512,7 +512,7 @@ int32_t spf_ctx_create(rrrmc_ctx** out, int64_t N, int64_t K, int64_t R, int32_t
     PF_TRY(hipMalloc(&ctx->sk_lf, sizeof(double) * nf));
     PF_TRY(hipMalloc(&ctx->pf_undo, sizeof(double) * (size_t)ctx->Rpad * (size_t)(K + 1)));
     PF_TRY(hipMalloc(&ctx->pf_spins, sizeof(unsigned long long) * nsw));
-    PF_TRY(hipMalloc(&ctx->pf_sites, sizeof(int32_t) * kSpfItersPerLaunch));
+    PF_TRY(hipMalloc(&ctx->pf_sites, sizeof(int32_t) * (kSpfItersPerLaunch + 2 * kSpfDepth)));
     PF_TRY(hipMalloc(&ctx->sk_move_last, sizeof(int32_t) * ctx->Rpad));
     PF_TRY(hipMalloc(&ctx->sk_E, sizeof(double) * ctx->Rpad));
     PF_TRY(hipMalloc(&ctx->d_acc, sizeof(int64_t) * ctx->Rpad));
@@ -604,7 +604,8 @@ int32_t spf_standard_mc_async(rrrmc_ctx* ctx, double beta, int64_t iters, int64_
     int launches = 0;
     while (done < iters) {
         const int64_t n = std::min<int64_t>(kSpfItersPerLaunch, iters - done);
-        hipLaunchKernelGGL(spf_sites_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, ctx->pf_sites, n, ctx->it_done + (uint64_t)done,
+        const int64_t nsites = n + 2 * kSpfDepth;       // the kernel requests (and never consumes) data of the iterations just past its end
+        hipLaunchKernelGGL(spf_sites_kernel, dim3((unsigned)((nsites + 255) / 256)), dim3(256), 0, st, ctx->pf_sites, nsites, ctx->it_done + (uint64_t)done,
                            (uint32_t)ctx->seed, (uint32_t)(ctx->seed >> 32), (uint32_t)ctx->N);
         HIP_TRY(ctx, hipGetLastError());
         SpfParams P = spf_params(ctx);

@@ -24,13 +24,17 @@
 namespace rrrmc {
 
 constexpr int kSpfMaxK = 8;
-constexpr int kSpfDepth = 4;          // prefetch distance of the attempted site's field, in iterations
-constexpr int kSpfNb = 2;             // prefetch distance of the neighbour fields / spin words
+#ifndef RRRMC_SPF_DEPTH
+#define RRRMC_SPF_DEPTH 4
+#define RRRMC_SPF_NB 2
+#endif
+constexpr int kSpfDepth = RRRMC_SPF_DEPTH;          // prefetch distance of the attempted site's field, in iterations
+constexpr int kSpfNb = RRRMC_SPF_NB;             // prefetch distance of the neighbour fields / spin words
 
 struct SpfParams {
     const int32_t* A;       // [N][K]
     const double* J;        // [N][K]
-    const int32_t* sites;   // [iters] sites of this launch's iterations
+    const int32_t* sites;   // [iters + 2 kSpfDepth] sites of this launch's iterations and of the 2 kSpfDepth following ones
     unsigned long long* spins;   // [W][N]
     double* lf;             // [W][N][64]
     double* undo;           // [W][K+1][64]: saved neighbour fields (slot k) and own field (slot K) of the last accepted move
@@ -157,29 +161,21 @@ __global__ __launch_bounds__(64) void spf_sweep_kernel(SpfParams P)
     };
 
     // prologue: sites and fields of iterations 1..D, neighbour data of iterations 1..NB, staged row of iteration NB+1
+    // (P.sites holds iters + 2 D entries)
 #pragma unroll
     for (int d = 0; d < D; ++d) {
-        ps[d] = d < iters ? __builtin_amdgcn_readfirstlane(P.sites[d]) : -1;
-        pre[d] = d < iters ? lf[(size_t)ps[d] * 64] : 0.0;
+        ps[d] = __builtin_amdgcn_readfirstlane(P.sites[d]);
+        pre[d] = lf[(size_t)ps[d] * 64];
         pend = lane == (64 - D + d) ? (ps[d]) : pend;
     }
 #pragma unroll
     for (int f = 0; f < NB; ++f) {
-        if (f < iters) {
-            load_row(ps[f], ny[f], nJ[f]);
-            request_nb(f, ps[f]);
-            mark_nb(f, ps[f]);
-        } else {
-#pragma unroll
-            for (int k = 0; k < K; ++k) { ny[f][k] = 0; nJ[f][k] = 0.0; nf[f][k] = 0.0; nw[f][k] = 0ull; }
-            nwi[f] = 0ull;
-        }
+        load_row(ps[f], ny[f], nJ[f]);
+        request_nb(f, ps[f]);
+        mark_nb(f, ps[f]);
     }
-    if (NB < iters) load_row(ps[NB % D], sy, sJ);
-    else {
-#pragma unroll
-        for (int k = 0; k < K; ++k) { sy[k] = 0; sJ[k] = 0.0; }
-    }
+    load_row(ps[NB % D], sy, sJ);
+    int snext = P.sites[D];                                       // site of iteration D+1, consumed by the refill of iteration 1
     Philox4 blk = {{0u, 0u, 0u, 0u}};
     uint64_t blk_id = ~0ull;
 
@@ -210,47 +206,42 @@ __global__ __launch_bounds__(64) void spf_sweep_kernel(SpfParams P)
             pend = lane == (64 - D + d) ? (-1) : pend;
 #pragma unroll
             for (int j = 0; j <= K; ++j) pend = lane == (f * (K + 1) + j) ? (-1) : pend;
-            if (amask != 0ull) {
-                // update_cache! (RRG.jl:576-617, EA.jl:613-653) for the accepting lanes; neighbours are common to all lanes
+            {
+                // update_cache! (RRG.jl:576-617, EA.jl:613-653); neighbours are common to all lanes.  No branch around a memory
+                // operation: every lane stores to every neighbour line — lanes that do not accept write the value they read back
+                // (full 512-byte lines instead of masked partial ones) — so the compiler can count the outstanding requests
+                // (s_waitcnt vmcnt(n)) instead of draining them, and the prefetch distances above survive.
                 const unsigned long long wi = nwi[f];
-                if (lane == 0) __hip_atomic_store(sp + i, wi ^ amask, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-                if (acc) {
-                    const uint32_t snew = (uint32_t)((wi >> lane) & 1ull) ^ 1u;
-                    if (mlast == i) {                        // exact undo: swap lfields <-> lfields_last on the (unique) neighbours
+                __hip_atomic_store(sp + i, wi ^ amask, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);   // same value from every lane
+                const uint32_t snew = (uint32_t)((wi >> lane) & 1ull) ^ 1u;
+                const bool fast = acc && mlast == i;         // exact undo: swap lfields <-> lfields_last on the (unique) neighbours
+                const bool slow = acc && !fast;
+                double v = 0.0, svrun = 0.0, frun = 0.0;
 #pragma unroll
-                        for (int k = 0; k < K; ++k) {
-                            if (k > 0 && ny[f][k] == ny[f][k - 1]) continue;
-                            lf[(size_t)ny[f][k] * 64] = sv[k];
-                            sv[k] = nf[f][k];
-                        }
-                        sv[K] = -sv[K];
-                    } else {
-                        double v = 0.0;
-#pragma unroll
-                        for (int k = 0; k < K; ++k) {
-                            const bool rep = k > 0 && ny[f][k] == ny[f][k - 1];   // GraphEA with L = 2: two bonds to the same neighbour
-                            if (!rep) {
-                                v = nf[f][k];
-                                sv[k] = v;                                   // lfields_last[y] = lfields[y]
-                            }
-                            const uint32_t sbit = (uint32_t)((nw[f][k] >> lane) & 1ull);
-                            const double c = (snew ^ sbit) ? -4.0 : 4.0;     // 4 * sigma_xy with the NEW s_x
-                            v = __dadd_rn(v, -__dmul_rn(c, nJ[f][k]));
-                            const bool last = k == K - 1 || ny[f][k + 1] != ny[f][k];
-                            if (last) lf[(size_t)ny[f][k] * 64] = v;
-                        }
-                        sv[K] = lfi;
-                        mlast = i;
+                for (int k = 0; k < K; ++k) {
+                    const bool rep = k > 0 && ny[f][k] == ny[f][k - 1];       // GraphEA with L = 2: two bonds to the same neighbour
+                    if (!rep) {                                               // wave-uniform
+                        frun = nf[f][k];
+                        svrun = sv[k];
+                        v = frun;
+                        sv[k] = acc ? frun : svrun;                           // lfields_last[y] = lfields[y] (slow) / the swap (fast)
                     }
-                    lf[(size_t)i * 64] = -lfi;
-                    E = __dadd_rn(E, dE);
-                    nacc += 1;
+                    const uint32_t sbit = (uint32_t)((nw[f][k] >> lane) & 1ull);
+                    const double c = (snew ^ sbit) ? -4.0 : 4.0;             // 4 * sigma_xy with the NEW s_x
+                    v = __dadd_rn(v, -__dmul_rn(c, nJ[f][k]));
+                    // the last store of a run of equal neighbours wins (same wavefront, same address: in order)
+                    lf[(size_t)ny[f][k] * 64] = fast ? svrun : (slow ? v : frun);
                 }
+                lf[(size_t)i * 64] = acc ? -lfi : lfi;
+                sv[K] = fast ? -sv[K] : (slow ? lfi : sv[K]);
+                mlast = slow ? i : mlast;
+                E = acc ? __dadd_rn(E, dE) : E;
+                nacc += acc ? 1 : 0;
                 // outstanding requests inside the closed neighbourhood of i are stale: read them again (after the stores)
                 unsigned long long hit = __builtin_amdgcn_ballot_w64(pend == i);
 #pragma unroll
                 for (int k = 0; k < K; ++k) hit |= __builtin_amdgcn_ballot_w64(pend == ny[f][k]);
-                if (hit != 0ull) {
+                if (amask != 0ull && hit != 0ull) {
 #pragma unroll
                     for (int e = 0; e < D; ++e)
                         if (e != d && ((hit >> (64 - D + e)) & 1ull)) pre[e] = lf[(size_t)ps[e] * 64];
@@ -264,18 +255,29 @@ __global__ __launch_bounds__(64) void spf_sweep_kernel(SpfParams P)
                     }
                 }
             }
-            // refill: neighbour data of iteration it+NB from the staged row, the row of iteration it+NB+1, field of iteration it+D
-            if (it + NB <= iters) {
+            // refill (unconditional: the host pads the site stream with the D following iterations, whose requests are simply
+            // never consumed): neighbour data of iteration it+NB from the staged row, the row of iteration it+NB+1, field of it+D
+            {
 #pragma unroll
-                for (int k = 0; k < K; ++k) { ny[f][k] = sy[k]; nJ[f][k] = sJ[k]; }
+                for (int k = 0; k < K; ++k) {
+                    // the staged row was loaded one iteration ago into VGPRs; it becomes scalar only HERE (the empty asm pins the
+                    // value to a VGPR until now, otherwise the compiler scalarises — and waits for — it right after the load)
+                    int yv = sy[k];
+                    asm volatile("" : "+v"(yv));
+                    ny[f][k] = __builtin_amdgcn_readfirstlane(yv);
+                    nJ[f][k] = sJ[k];
+                }
                 request_nb(f, ps[(d + NB) % D]);
                 mark_nb(f, ps[(d + NB) % D]);
             }
-            if (it + NB + 1 <= iters) load_row(ps[(d + NB + 1) % D], sy, sJ);
-            if (it + D <= iters) {
-                ps[d] = __builtin_amdgcn_readfirstlane(P.sites[it + D - 1]);
+            load_row(ps[(d + NB + 1) % D], sy, sJ);
+            {
+                int sv_next = snext;                                  // loaded one iteration ago: no dependent load chain here
+                asm volatile("" : "+v"(sv_next));
+                ps[d] = __builtin_amdgcn_readfirstlane(sv_next);
                 pre[d] = lf[(size_t)ps[d] * 64];
                 pend = lane == (64 - D + d) ? (ps[d]) : pend;
+                snext = P.sites[it + D];
             }
         }
     }
