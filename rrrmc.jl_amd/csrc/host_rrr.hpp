@@ -1,0 +1,180 @@
+// Host side of the reduced-rejection samplers: GraphQuant, rrrMC on GraphSKNormal, rrrMC / bklMC on GraphRRG / GraphEA.
+// Included by rrrmc_hip.hip inside its anonymous namespace, after the context struct and the common helpers
+// (fail, HIP_TRY, free_dev, ensure_state); not a stand-alone translation unit.
+// ---- GraphQuant / rrrMC host side -----------------------------------------------------------------------------------
+RrrParams quant_params(rrrmc_ctx* ctx, double beta, double fourK)
+{
+    RrrParams P{};
+    P.A = ctx->d_A; P.J = ctx->d_J;
+    P.spins = ctx->q_spins; P.cls = ctx->q_cls; P.sv = ctx->q_sv; P.spos = ctx->q_spos; P.st = ctx->q_st;
+    P.T = ctx->q_T; P.zz = ctx->q_z; P.E_cur = ctx->sk_E; P.acc_rate = ctx->q_accrate; P.stats = ctx->q_stats; P.Es = ctx->sk_Es;
+    P.beta = beta; P.fourK = fourK;
+    P.ft1 = 0.0;
+    P.k0 = (uint32_t)ctx->seed; P.k1 = (uint32_t)(ctx->seed >> 32); P.replica0 = ctx->replica0;
+    P.Nk = (int)ctx->qNk; P.M = (int)ctx->qM; P.K = (int)ctx->K; P.N = (int)ctx->N; P.W = (int)ctx->qW; P.R = (int)ctx->R;
+    return P;
+}
+
+// deterministic exp on the host: the same operation sequence as det_exp on the device / orc_det_exp in the oracle
+double host_det_exp(double x)
+{
+    static const double LOG2E = 1.44269504088896338700e+00;
+    static const double LN2_HI = 6.93147180369123816490e-01, LN2_LO = 1.90821492927058770002e-10;
+    static const double c[14] = {1.0, 1.0, 0.5, 1.0 / 6, 1.0 / 24, 1.0 / 120, 1.0 / 720, 1.0 / 5040, 1.0 / 40320, 1.0 / 362880,
+                                 1.0 / 3628800, 1.0 / 39916800, 1.0 / 479001600, 1.0 / 6227020800.0};
+    if (x != x) return x;
+    if (x < -745.2) return 0.0;
+    if (x > 709.7) return HUGE_VAL;
+    volatile double t0 = x * LOG2E;
+    const double k = std::floor(t0 + 0.5);
+    volatile double a = k * LN2_HI, b = k * LN2_LO;
+    volatile double r0 = x - a;
+    const double r = r0 - b;
+    double p = c[13];
+    for (int n = 12; n >= 0; --n) { volatile double m = p * r; p = m + c[n]; }
+    return std::ldexp(p, (int)k);
+}
+
+// energy(X, C) + gen_ΔEcache (RRRMC.jl:237-240): E into sk_E, cache arrays rebuilt
+int32_t quant_run_init(rrrmc_ctx* ctx, double beta, double fourK)
+{
+    RrrParams P = quant_params(ctx, beta, fourK);
+    P.ft1 = host_det_exp(-beta * fourK);
+    hipLaunchKernelGGL(rrr_init_kernel, dim3((unsigned)((ctx->R + kRrrThreads - 1) / kRrrThreads)), dim3(kRrrThreads), 0, ctx->stream, P);
+    HIP_TRY(ctx, hipGetLastError());
+    return RRRMC_OK;
+}
+
+
+// rrrMC(X::SingleGraph) on GraphSKNormal (RRRMC.jl:149-219): thread-per-replica kernel over interleaved arrays
+int32_t sk_rrr_mc_async(rrrmc_ctx* ctx, double beta, int64_t iters, int64_t step, double staged_thr, double staged_thr_fact)
+{
+    if (iters < 0) return fail(ctx, RRRMC_ERR_INVALID_ARG, "iters must be >= 0, given %lld", (long long)iters);
+    if (step < 1) return fail(ctx, RRRMC_ERR_INVALID_ARG, "step must be >= 1, given %lld", (long long)step);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    ctx->results_valid = false;
+    ctx->timing_valid = false;
+    const int64_t N = ctx->N, Rp = ctx->Rpad;
+    int levs = 0;
+    while (((int64_t)1 << levs) < N) ++levs;
+    const int64_t N2 = (int64_t)1 << levs, W = (N + 31) / 32;
+    const size_t per = (size_t)Rp;
+    const size_t ndbl = per * (size_t)(5 * N + 2 * N2 + 1);
+    if (!ctx->rs_buf) {
+        HIP_TRY(ctx, hipMalloc(&ctx->rs_buf, sizeof(double) * ndbl));
+        HIP_TRY(ctx, hipMalloc(&ctx->rs_spins, sizeof(uint32_t) * W * per));
+        HIP_TRY(ctx, hipMalloc(&ctx->rs_status, sizeof(int32_t) * per));
+        HIP_TRY(ctx, hipMalloc(&ctx->q_stats, sizeof(int64_t) * per * 2));
+    }
+    const int64_t nsamp = iters / step;
+    const size_t es_need = (size_t)(nsamp > 0 ? nsamp : 1) * Rp;
+    if (es_need > ctx->sk_Es_cap) {
+        free_dev(ctx->sk_Es);
+        ctx->sk_Es_cap = 0;
+        HIP_TRY(ctx, hipMalloc(&ctx->sk_Es, sizeof(double) * es_need));
+        ctx->sk_Es_cap = es_need;
+    }
+    while (ctx->ev_sweep.size() < 2) {
+        hipEvent_t e;
+        HIP_TRY(ctx, hipEventCreate(&e));
+        ctx->ev_sweep.push_back(e);
+    }
+    hipStream_t st = ctx->stream;
+    RrrSkParams P{};
+    double* b = ctx->rs_buf;
+    P.J = ctx->sk_J;
+    P.lfA = b; b += per * N;
+    P.lfB = b; b += per * N;
+    P.v = b; b += per * N2;
+    P.ps = b; b += per * N2;
+    P.dEs = b; b += per * N;
+    P.st_dE = b; b += per * N;
+    P.st_p = b; b += per * N;
+    P.z_out = b;
+    P.spins = ctx->rs_spins; P.E_cur = ctx->sk_E; P.stats = ctx->q_stats; P.status = ctx->rs_status; P.Es = ctx->sk_Es;
+    P.beta = beta; P.staged_thr = staged_thr; P.lambda = staged_thr_fact / (double)N;
+    P.g0 = ctx->it_done; P.iters = iters; P.step = step;
+    P.k0 = (uint32_t)ctx->seed; P.k1 = (uint32_t)(ctx->seed >> 32); P.replica0 = ctx->replica0;
+    P.N = (int)N; P.N2 = (int)N2; P.levs = levs; P.W = (int)W; P.R = (int)ctx->R; P.Rp = (int)Rp;
+    ctx->stats_stride = 2;
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_begin, st));
+    hipLaunchKernelGGL(rrsk_spins_in_kernel, dim3((unsigned)((Rp + 255) / 256), (unsigned)W), dim3(256), 0, st, ctx->sk_spins, ctx->rs_spins, (int)N, (int)W, (int)Rp);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_sweep[0], st));
+    hipLaunchKernelGGL(rrr_skn_kernel, dim3((unsigned)((ctx->R + kRrrThreads - 1) / kRrrThreads)), dim3(kRrrThreads), 0, st, P);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_sweep[1], st));
+    hipLaunchKernelGGL(rrsk_spins_out_kernel, dim3((unsigned)((N + 255) / 256), (unsigned)ctx->G8), dim3(256), 0, st, ctx->rs_spins, ctx->sk_spins, (int)N, (int)Rp);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_end, st));
+    ctx->sweep_launches = 1;
+    ctx->nsamp = nsamp;
+    ctx->it_done += (uint64_t)iters;
+    ctx->results_valid = true;
+    ctx->timing_valid = true;
+    ctx->last_call_rrr = true;
+    return RRRMC_OK;
+}
+
+
+// rrrMC(SingleGraph) / bklMC on GraphRRG / GraphEA: thread-per-replica kernel over replica-contiguous arrays
+int32_t sparse_rrr_bkl_async(rrrmc_ctx* ctx, int mode, double beta, int64_t iters, int64_t step, double staged_thr, double staged_thr_fact)
+{
+    if (iters < 0) return fail(ctx, RRRMC_ERR_INVALID_ARG, "iters must be >= 0, given %lld", (long long)iters);
+    if (step < 1) return fail(ctx, RRRMC_ERR_INVALID_ARG, "step must be >= 1, given %lld", (long long)step);
+    if (ctx->N > 65535) return fail(ctx, RRRMC_ERR_UNSUPPORTED, "N=%lld: the rrrMC kernel indexes spins with 16 bits", (long long)ctx->N);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    ctx->results_valid = false;
+    ctx->timing_valid = false;
+    const int64_t N = ctx->N, K = ctx->K, R = ctx->R, W = (N + 31) / 32;
+    const int L = (int)(K / 2 + 1);                       // allΔE has K/2 + 1 levels for +-J couplings (RRG.jl:262-265)
+    if (!ctx->rp_spins) {
+        HIP_TRY(ctx, hipMalloc(&ctx->rp_spins, sizeof(uint32_t) * R * W));
+        HIP_TRY(ctx, hipMalloc(&ctx->rp_cls, (size_t)R * N));
+        HIP_TRY(ctx, hipMalloc(&ctx->rp_sv, sizeof(uint16_t) * R * 2 * L * N));
+        HIP_TRY(ctx, hipMalloc(&ctx->rp_spos, sizeof(uint16_t) * R * N));
+        HIP_TRY(ctx, hipMalloc(&ctx->q_stats, sizeof(int64_t) * R * 3));
+    }
+    ctx->stats_stride = 3;
+    const int64_t nsamp = iters / step;
+    const size_t es_need = (size_t)(nsamp > 0 ? nsamp : 1) * ctx->Rpad;
+    if (es_need > ctx->Es_cap) {
+        free_dev(ctx->d_Es);
+        ctx->Es_cap = 0;
+        HIP_TRY(ctx, hipMalloc(&ctx->d_Es, sizeof(int32_t) * es_need));
+        ctx->Es_cap = es_need;
+    }
+    while (ctx->ev_sweep.size() < 2) {
+        hipEvent_t e;
+        HIP_TRY(ctx, hipEventCreate(&e));
+        ctx->ev_sweep.push_back(e);
+    }
+    RrrSparseParams P{};
+    P.A = ctx->d_A; P.J = ctx->d_J; P.spins = ctx->rp_spins; P.cls = ctx->rp_cls; P.sv = ctx->rp_sv; P.spos = ctx->rp_spos;
+    P.E_cur = ctx->d_E; P.acc_cur = ctx->d_acc; P.stats = ctx->q_stats; P.Es = ctx->d_Es;
+    for (int k = 0; k < L && k < kSLmax; ++k) P.ft[k] = host_det_exp(-beta * (double)(2 * (2 * k + (K & 1))));     // exp(-beta dE_k), DeltaE.jl:91
+    P.beta = beta; P.staged_thr = staged_thr; P.lambda = staged_thr_fact / (double)N;
+    P.g0 = ctx->it_done; P.iters = iters; P.step = step;
+    P.k0 = (uint32_t)ctx->seed; P.k1 = (uint32_t)(ctx->seed >> 32); P.replica0 = ctx->replica0;
+    P.N = (int)N; P.K = (int)K; P.L = L; P.W = (int)W; P.R = (int)R; P.Rpad = (int)ctx->Rpad; P.mode = mode;
+    hipStream_t st = ctx->stream;
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_begin, st));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->d_acc, 0, sizeof(int64_t) * ctx->Rpad, st));
+    hipLaunchKernelGGL(rrsp_spins_in_kernel, dim3((unsigned)((W + 255) / 256), (unsigned)R), dim3(256), 0, st, ctx->d_spins, ctx->rp_spins, (int)N, (int)W, (int)R);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_sweep[0], st));
+    hipLaunchKernelGGL(rrr_sparse_kernel, dim3((unsigned)((R + kRrrThreads - 1) / kRrrThreads)), dim3(kRrrThreads), 0, st, P);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_sweep[1], st));
+    hipLaunchKernelGGL(rrsp_spins_out_kernel, dim3((unsigned)((N + 255) / 256), (unsigned)ctx->G), dim3(256), 0, st, ctx->rp_spins, ctx->d_spins, (int)N, (int)W, (int)R);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_end, st));
+    ctx->sweep_launches = 1;
+    ctx->nsamp = nsamp;
+    ctx->it_done += (uint64_t)iters;
+    ctx->results_valid = true;
+    ctx->timing_valid = true;
+    ctx->last_call_rrr = true;
+    ctx->colored_call = false;
+    return RRRMC_OK;
+}

@@ -1,0 +1,148 @@
+// Host side of the dense SK models (GraphSKNormal, GraphSK): context creation, energy, standardMC orchestration.
+// Included by rrrmc_hip.hip inside its anonymous namespace, after the context struct and the common helpers
+// (fail, HIP_TRY, free_dev, ensure_state); not a stand-alone translation unit.
+// ---- GraphSKNormal (dense Float64) host side -----------------------------------------------------------------------
+typedef void (*sk_fn)(SkParams);
+sk_fn sk_sweep_for(int spt) { RRRMC_DISPATCH_UPTO8(spt, sk_sweep_kernel) }
+
+typedef void (*skb_fn)(SkbParams);
+skb_fn skb_sweep_for(int spt) { RRRMC_DISPATCH_UPTO8(spt, skb_sweep_kernel) }
+
+int32_t sk_ctx_create(rrrmc_ctx** out, int32_t model, int64_t N, int64_t R, int32_t device, uint32_t replica0)
+{
+    if (N < 1 || R < 1) return fail(nullptr, RRRMC_ERR_INVALID_ARG, "N, R must be >= 1 (given N=%lld R=%lld)", (long long)N, (long long)R);
+    if (N > (int64_t)kSkThreads * kSkMaxSPT) return fail(nullptr, RRRMC_ERR_UNSUPPORTED, "N=%lld: the register-resident SK kernel covers N <= %d", (long long)N, kSkThreads * kSkMaxSPT);
+    if (replica0 % 32) return fail(nullptr, RRRMC_ERR_INVALID_ARG, "replica0 must be a multiple of 32 (given %u)", replica0);
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(nullptr, RRRMC_ERR_HIP, "no HIP device is visible: this library has no CPU path");
+    if (device < 0 || device >= ndev) return fail(nullptr, RRRMC_ERR_INVALID_ARG, "device %d out of range (0..%d)", device, ndev - 1);
+    rrrmc_ctx* ctx = new (std::nothrow) rrrmc_ctx();
+    if (!ctx) return fail(nullptr, RRRMC_ERR_NOMEM, "out of host memory");
+    ctx->model = model; ctx->N = N; ctx->K = 0; ctx->R = R;
+    ctx->G8 = (R + kSkRB - 1) / kSkRB; ctx->Rpad = ctx->G8 * kSkRB; ctx->G = 0;
+    ctx->device = device; ctx->replica0 = replica0;
+#define SK_TRY(expr)                                                                                             \
+    do {                                                                                                         \
+        hipError_t e_ = (expr);                                                                                  \
+        if (e_ != hipSuccess) {                                                                                  \
+            int32_t rc_ = fail(nullptr, RRRMC_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_));           \
+            rrrmc_ctx_destroy(ctx);                                                                              \
+            return rc_;                                                                                          \
+        }                                                                                                        \
+    } while (0)
+    SK_TRY(hipSetDevice(device));
+    SK_TRY(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+    SK_TRY(hipEventCreate(&ctx->ev_begin));
+    SK_TRY(hipEventCreate(&ctx->ev_end));
+    const size_t nf = (size_t)ctx->G8 * N * kSkRB;
+    if (model == RRRMC_MODEL_SK_BINARY) {
+        ctx->skb_NW = (int)(2 * ((N + 63) / 64));
+        SK_TRY(hipMalloc(&ctx->skb_J, sizeof(uint32_t) * N * ctx->skb_NW));
+        SK_TRY(hipMalloc(&ctx->skb_lf, sizeof(int32_t) * nf));
+        SK_TRY(hipMalloc(&ctx->skb_lfl, sizeof(int32_t) * nf));
+        SK_TRY(hipMemset(ctx->skb_lf, 0, sizeof(int32_t) * nf));
+        SK_TRY(hipMemset(ctx->skb_lfl, 0, sizeof(int32_t) * nf));
+    } else {
+        SK_TRY(hipMalloc(&ctx->sk_J, sizeof(double) * N * N));
+        SK_TRY(hipMalloc(&ctx->sk_lf, sizeof(double) * nf));
+        SK_TRY(hipMalloc(&ctx->sk_lfl, sizeof(double) * nf));
+        SK_TRY(hipMemset(ctx->sk_lf, 0, sizeof(double) * nf));
+        SK_TRY(hipMemset(ctx->sk_lfl, 0, sizeof(double) * nf));
+    }
+    SK_TRY(hipMalloc(&ctx->sk_move_last, sizeof(int32_t) * ctx->Rpad));
+    SK_TRY(hipMalloc(&ctx->sk_spins, (size_t)ctx->G8 * N));
+    SK_TRY(hipMalloc(&ctx->sk_E, sizeof(double) * ctx->Rpad));
+    SK_TRY(hipMalloc(&ctx->d_acc, sizeof(int64_t) * ctx->Rpad));
+    SK_TRY(hipMemset(ctx->sk_spins, 0, (size_t)ctx->G8 * N));
+#undef SK_TRY
+    *out = ctx;
+    return RRRMC_OK;
+}
+
+// energy(X, C), SK.jl:212-237: rebuilds lfields, zeroes lfields_last, move_last = none; E into sk_E
+int32_t sk_run_energy(rrrmc_ctx* ctx)
+{
+    const dim3 grid((unsigned)((ctx->N + 31) / 32), (unsigned)ctx->G8);
+    if (ctx->model == RRRMC_MODEL_SK_BINARY) {
+        hipLaunchKernelGGL(skb_fields_kernel, grid, dim3(256), 0, ctx->stream, ctx->skb_J, ctx->sk_spins, ctx->skb_lf, ctx->skb_lfl,
+                           ctx->sk_move_last, (int)ctx->N, ctx->skb_NW);
+        HIP_TRY(ctx, hipGetLastError());
+        hipLaunchKernelGGL(skb_energy_kernel, dim3((unsigned)((ctx->Rpad + 63) / 64)), dim3(64), 0, ctx->stream, ctx->skb_lf, ctx->sk_spins,
+                           ctx->sk_E, (int)ctx->N, (int)ctx->Rpad, std::sqrt((double)ctx->N));
+        HIP_TRY(ctx, hipGetLastError());
+        return RRRMC_OK;
+    }
+    hipLaunchKernelGGL(sk_fields_kernel, grid, dim3(256), 0, ctx->stream, ctx->sk_J, ctx->sk_spins, ctx->sk_lf, ctx->sk_lfl,
+                       ctx->sk_move_last, (int)ctx->N);
+    HIP_TRY(ctx, hipGetLastError());
+    hipLaunchKernelGGL(sk_energy_kernel, dim3((unsigned)((ctx->Rpad + 63) / 64)), dim3(64), 0, ctx->stream, ctx->sk_lf, ctx->sk_E,
+                       (int)ctx->N, (int)ctx->Rpad);
+    HIP_TRY(ctx, hipGetLastError());
+    return RRRMC_OK;
+}
+
+int32_t sk_standard_mc_async(rrrmc_ctx* ctx, double beta, int64_t iters, int64_t step)
+{
+    if (iters < 0) return fail(ctx, RRRMC_ERR_INVALID_ARG, "iters must be >= 0, given %lld", (long long)iters);
+    if (step < 1) return fail(ctx, RRRMC_ERR_INVALID_ARG, "step must be >= 1, given %lld", (long long)step);
+    if (std::isnan(beta)) return fail(ctx, RRRMC_ERR_INVALID_ARG, "beta is NaN");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    ctx->results_valid = false;
+    ctx->timing_valid = false;
+    ctx->last_call_rrr = false;
+    const int64_t nsamp = iters / step;
+    const size_t es_need = (size_t)(nsamp > 0 ? nsamp : 1) * ctx->Rpad;
+    if (es_need > ctx->sk_Es_cap) {
+        free_dev(ctx->sk_Es);
+        ctx->sk_Es_cap = 0;
+        HIP_TRY(ctx, hipMalloc(&ctx->sk_Es, sizeof(double) * es_need));
+        ctx->sk_Es_cap = es_need;
+    }
+    while (ctx->ev_sweep.size() < 2) {
+        hipEvent_t e;
+        HIP_TRY(ctx, hipEventCreate(&e));
+        ctx->ev_sweep.push_back(e);
+    }
+    hipStream_t st = ctx->stream;
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_begin, st));
+    int32_t rc = sk_run_energy(ctx);          // E = energy(X, C) at the start of every call, RRRMC.jl:95
+    if (rc) return rc;
+    HIP_TRY(ctx, hipMemsetAsync(ctx->d_acc, 0, sizeof(int64_t) * ctx->Rpad, st));
+    if (ctx->model == RRRMC_MODEL_SK_BINARY) {
+        SkbParams B{};
+        B.Jbits = ctx->skb_J; B.lf = ctx->skb_lf; B.lfl = ctx->skb_lfl; B.move_last = ctx->sk_move_last; B.spins = ctx->sk_spins;
+        B.E_cur = ctx->sk_E; B.acc_cur = ctx->d_acc; B.Es = ctx->sk_Es;
+        B.beta = beta; B.sN = std::sqrt((double)ctx->N); B.g0 = ctx->it_done; B.iters = iters; B.step = step; B.sample0 = 0;
+        B.k0 = (uint32_t)ctx->seed; B.k1 = (uint32_t)(ctx->seed >> 32); B.replica0 = ctx->replica0; B.N = (int)ctx->N; B.NW = ctx->skb_NW;
+        const int sptb = (int)((ctx->N + kSkThreads - 1) / kSkThreads);
+        HIP_TRY(ctx, hipEventRecord(ctx->ev_sweep[0], st));
+        hipLaunchKernelGGL(skb_sweep_for(sptb), dim3((unsigned)ctx->G8), dim3(kSkThreads), 0, st, B);
+        HIP_TRY(ctx, hipGetLastError());
+        HIP_TRY(ctx, hipEventRecord(ctx->ev_sweep[1], st));
+        HIP_TRY(ctx, hipEventRecord(ctx->ev_end, st));
+        ctx->sweep_launches = 1;
+        ctx->nsamp = nsamp;
+        ctx->it_done += (uint64_t)iters;
+        ctx->results_valid = true;
+        ctx->timing_valid = true;
+        return RRRMC_OK;
+    }
+    SkParams P{};
+    P.J = ctx->sk_J; P.lf = ctx->sk_lf; P.lfl = ctx->sk_lfl; P.move_last = ctx->sk_move_last; P.spins = ctx->sk_spins;
+    P.E_cur = ctx->sk_E; P.acc_cur = ctx->d_acc; P.Es = ctx->sk_Es;
+    P.beta = beta; P.g0 = ctx->it_done; P.iters = iters; P.step = step; P.sample0 = 0;
+    P.k0 = (uint32_t)ctx->seed; P.k1 = (uint32_t)(ctx->seed >> 32); P.replica0 = ctx->replica0; P.N = (int)ctx->N;
+    const int spt = (int)((ctx->N + kSkThreads - 1) / kSkThreads);
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_sweep[0], st));
+    hipLaunchKernelGGL(sk_sweep_for(spt), dim3((unsigned)ctx->G8), dim3(kSkThreads), 0, st, P);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_sweep[1], st));
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_end, st));
+    ctx->sweep_launches = 1;
+    ctx->nsamp = nsamp;
+    ctx->it_done += (uint64_t)iters;
+    ctx->results_valid = true;
+    ctx->timing_valid = true;
+    return RRRMC_OK;
+}

@@ -1,0 +1,128 @@
+// Host side of the Float64-coupling sparse models (GraphRRGNormal / GraphEANormal).
+// Included by rrrmc_hip.hip inside its anonymous namespace, after the context struct and the common helpers
+// (fail, HIP_TRY, free_dev, ensure_state); not a stand-alone translation unit.
+// ---- Float64-coupling sparse models (GraphRRGNormal / GraphEANormal) host side ------------------------------------
+constexpr int64_t kSpfItersPerLaunch = 1 << 20;
+
+int32_t spf_ctx_create(rrrmc_ctx** out, int64_t N, int64_t K, int64_t R, int32_t device, uint32_t replica0)
+{
+    if (N < 1 || K < 1 || R < 1) return fail(nullptr, RRRMC_ERR_INVALID_ARG, "N, K, R must be >= 1 (given N=%lld K=%lld R=%lld)", (long long)N, (long long)K, (long long)R);
+    if (K > kSpfMaxK) return fail(nullptr, RRRMC_ERR_UNSUPPORTED, "K=%lld: the Float64 sparse kernels cover K <= %d", (long long)K, kSpfMaxK);
+    if (N > (int64_t)INT32_MAX / 64) return fail(nullptr, RRRMC_ERR_UNSUPPORTED, "N=%lld is too large", (long long)N);
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(nullptr, RRRMC_ERR_HIP, "no HIP device is visible: this library has no CPU path");
+    if (device < 0 || device >= ndev) return fail(nullptr, RRRMC_ERR_INVALID_ARG, "device %d out of range (0..%d)", device, ndev - 1);
+    rrrmc_ctx* ctx = new (std::nothrow) rrrmc_ctx();
+    if (!ctx) return fail(nullptr, RRRMC_ERR_NOMEM, "out of host memory");
+    ctx->model = RRRMC_MODEL_SPARSE_F64; ctx->N = N; ctx->K = K; ctx->R = R;
+    ctx->pfW = (R + 63) / 64; ctx->Rpad = ctx->pfW * 64;
+    ctx->device = device; ctx->replica0 = replica0;
+#define PF_TRY(expr)                                                                                             \
+    do {                                                                                                         \
+        hipError_t e_ = (expr);                                                                                  \
+        if (e_ != hipSuccess) {                                                                                  \
+            int32_t rc_ = fail(nullptr, e_ == hipErrorOutOfMemory ? RRRMC_ERR_NOMEM : RRRMC_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
+            rrrmc_ctx_destroy(ctx);                                                                              \
+            return rc_;                                                                                          \
+        }                                                                                                        \
+    } while (0)
+    PF_TRY(hipSetDevice(device));
+    PF_TRY(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+    PF_TRY(hipEventCreate(&ctx->ev_begin));
+    PF_TRY(hipEventCreate(&ctx->ev_end));
+    const size_t nf = (size_t)ctx->Rpad * (size_t)N;
+    const size_t nsw = (size_t)ctx->pfW * (size_t)N;
+    PF_TRY(hipMalloc(&ctx->d_A, sizeof(int32_t) * N * K));
+    PF_TRY(hipMalloc(&ctx->pf_J, sizeof(double) * N * K));
+    PF_TRY(hipMalloc(&ctx->sk_lf, sizeof(double) * nf));
+    PF_TRY(hipMalloc(&ctx->pf_undo, sizeof(double) * (size_t)ctx->Rpad * (size_t)(K + 1)));
+    PF_TRY(hipMalloc(&ctx->pf_spins, sizeof(unsigned long long) * nsw));
+    PF_TRY(hipMalloc(&ctx->pf_sites, sizeof(int32_t) * (kSpfItersPerLaunch + 2 * kSpfDepth)));
+    PF_TRY(hipMalloc(&ctx->sk_move_last, sizeof(int32_t) * ctx->Rpad));
+    PF_TRY(hipMalloc(&ctx->sk_E, sizeof(double) * ctx->Rpad));
+    PF_TRY(hipMalloc(&ctx->d_acc, sizeof(int64_t) * ctx->Rpad));
+    PF_TRY(hipMemset(ctx->pf_spins, 0, sizeof(unsigned long long) * nsw));
+    PF_TRY(hipMemset(ctx->sk_lf, 0, sizeof(double) * nf));
+    PF_TRY(hipMemset(ctx->pf_undo, 0, sizeof(double) * (size_t)ctx->Rpad * (size_t)(K + 1)));
+#undef PF_TRY
+    *out = ctx;
+    return RRRMC_OK;
+}
+
+SpfParams spf_params(rrrmc_ctx* ctx)
+{
+    SpfParams P{};
+    P.A = ctx->d_A; P.J = ctx->pf_J; P.sites = ctx->pf_sites; P.spins = ctx->pf_spins; P.lf = ctx->sk_lf; P.undo = ctx->pf_undo;
+    P.move_last = ctx->sk_move_last; P.E_cur = ctx->sk_E; P.acc_cur = ctx->d_acc; P.Es = ctx->sk_Es;
+    P.k0 = (uint32_t)ctx->seed; P.k1 = (uint32_t)(ctx->seed >> 32); P.replica0 = ctx->replica0;
+    P.N = (int)ctx->N; P.Rpad = (int)ctx->Rpad;
+    return P;
+}
+
+typedef void (*spf_fn)(SpfParams);
+spf_fn spf_sweep_for_K(int K) { RRRMC_DISPATCH_UPTO8(K, spf_sweep_kernel) }
+spf_fn spf_energy_for_K(int K) { RRRMC_DISPATCH_UPTO8(K, spf_energy_kernel) }
+
+int32_t spf_run_energy(rrrmc_ctx* ctx)
+{
+    hipLaunchKernelGGL(spf_energy_for_K((int)ctx->K), dim3((unsigned)ctx->pfW), dim3(64), 0, ctx->stream, spf_params(ctx));
+    HIP_TRY(ctx, hipGetLastError());
+    return RRRMC_OK;
+}
+
+int32_t spf_standard_mc_async(rrrmc_ctx* ctx, double beta, int64_t iters, int64_t step)
+{
+    if (iters < 0) return fail(ctx, RRRMC_ERR_INVALID_ARG, "iters must be >= 0, given %lld", (long long)iters);
+    if (step < 1) return fail(ctx, RRRMC_ERR_INVALID_ARG, "step must be >= 1, given %lld", (long long)step);
+    if (std::isnan(beta)) return fail(ctx, RRRMC_ERR_INVALID_ARG, "beta is NaN");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    ctx->results_valid = false;
+    ctx->timing_valid = false;
+    ctx->last_call_rrr = false;
+    const int64_t nsamp = iters / step;
+    const size_t es_need = (size_t)(nsamp > 0 ? nsamp : 1) * ctx->Rpad;
+    if (es_need > ctx->sk_Es_cap) {
+        free_dev(ctx->sk_Es);
+        ctx->sk_Es_cap = 0;
+        HIP_TRY(ctx, hipMalloc(&ctx->sk_Es, sizeof(double) * es_need));
+        ctx->sk_Es_cap = es_need;
+    }
+    const int64_t nl = (iters + kSpfItersPerLaunch - 1) / kSpfItersPerLaunch;
+    while ((int64_t)ctx->ev_sweep.size() < 2 * (nl > 0 ? nl : 1)) {
+        hipEvent_t e;
+        HIP_TRY(ctx, hipEventCreate(&e));
+        ctx->ev_sweep.push_back(e);
+    }
+    hipStream_t st = ctx->stream;
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_begin, st));
+    int32_t rc = spf_run_energy(ctx);          // E = energy(X, C) at the start of every call, RRRMC.jl:95
+    if (rc) return rc;
+    HIP_TRY(ctx, hipMemsetAsync(ctx->d_acc, 0, sizeof(int64_t) * ctx->Rpad, st));
+    spf_fn fn = spf_sweep_for_K((int)ctx->K);
+    int64_t done = 0;
+    int launches = 0;
+    while (done < iters) {
+        const int64_t n = std::min<int64_t>(kSpfItersPerLaunch, iters - done);
+        const int64_t nsites = n + 2 * kSpfDepth;       // the kernel requests (and never consumes) data of the iterations just past its end
+        hipLaunchKernelGGL(spf_sites_kernel, dim3((unsigned)((nsites + 255) / 256)), dim3(256), 0, st, ctx->pf_sites, nsites, ctx->it_done + (uint64_t)done,
+                           (uint32_t)ctx->seed, (uint32_t)(ctx->seed >> 32), (uint32_t)ctx->N);
+        HIP_TRY(ctx, hipGetLastError());
+        SpfParams P = spf_params(ctx);
+        P.beta = beta; P.g0 = ctx->it_done + (uint64_t)done; P.iters = n; P.step = step;
+        P.it_off = done; P.sample0 = done / step;
+        HIP_TRY(ctx, hipEventRecord(ctx->ev_sweep[2 * launches], st));
+        hipLaunchKernelGGL(fn, dim3((unsigned)ctx->pfW), dim3(64), 0, st, P);
+        HIP_TRY(ctx, hipGetLastError());
+        HIP_TRY(ctx, hipEventRecord(ctx->ev_sweep[2 * launches + 1], st));
+        ++launches;
+        done += n;
+    }
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_end, st));
+    ctx->sweep_launches = launches;
+    ctx->nsamp = nsamp;
+    ctx->it_done += (uint64_t)iters;
+    ctx->results_valid = true;
+    ctx->timing_valid = true;
+    return RRRMC_OK;
+}

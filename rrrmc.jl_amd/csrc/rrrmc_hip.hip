@@ -197,35 +197,19 @@ uint64_t threshold64(double p, bool* always)
     return (man + ((1ull << s) - 1)) >> s;
 }
 
+// template instantiation tables: runtime K (or sites-per-thread) -> kernel pointer
+#define RRRMC_DISPATCH_UPTO7(k, F)                                                                                     \
+    switch (k) { case 1: return F<1>; case 2: return F<2>; case 3: return F<3>; case 4: return F<4>; case 5: return F<5>;   \
+                 case 6: return F<6>; case 7: return F<7>; default: return nullptr; }
+#define RRRMC_DISPATCH_UPTO8(k, F)                                                                                     \
+    switch (k) { case 1: return F<1>; case 2: return F<2>; case 3: return F<3>; case 4: return F<4>; case 5: return F<5>;   \
+                 case 6: return F<6>; case 7: return F<7>; case 8: return F<8>; default: return nullptr; }
+
 typedef void (*plan_fn)(ChunkDesc*, uint32_t*, uint32_t*, const int32_t*, int, int, uint32_t, uint32_t);
-plan_fn plan_for_K(int K)
-{
-    switch (K) {
-        case 1: return plan_kernel<1>;
-        case 2: return plan_kernel<2>;
-        case 3: return plan_kernel<3>;
-        case 4: return plan_kernel<4>;
-        case 5: return plan_kernel<5>;
-        case 6: return plan_kernel<6>;
-        case 7: return plan_kernel<7>;
-        default: return nullptr;
-    }
-}
+plan_fn plan_for_K(int K) { RRRMC_DISPATCH_UPTO7(K, plan_kernel) }
 
 typedef void (*sweep_fn)(SweepParams);
-sweep_fn sweep_for_K(int K)
-{
-    switch (K) {
-        case 1: return sweep_kernel<1>;
-        case 2: return sweep_kernel<2>;
-        case 3: return sweep_kernel<3>;
-        case 4: return sweep_kernel<4>;
-        case 5: return sweep_kernel<5>;
-        case 6: return sweep_kernel<6>;
-        case 7: return sweep_kernel<7>;
-        default: return nullptr;
-    }
-}
+sweep_fn sweep_for_K(int K) { RRRMC_DISPATCH_UPTO7(K, sweep_kernel) }
 
 size_t sweep_lds_bytes(int64_t N, int K, int TS, int C)
 {
@@ -252,33 +236,9 @@ int32_t ensure_state(rrrmc_ctx* ctx, bool need_spins)
 }
 
 typedef void (*ebs_fn)(const uint32_t*, const int32_t*, const int8_t*, int, uint32_t*);
-ebs_fn energy_bs_for_K(int K)
-{
-    switch (K) {
-        case 1: return energy_bs_kernel<1>;
-        case 2: return energy_bs_kernel<2>;
-        case 3: return energy_bs_kernel<3>;
-        case 4: return energy_bs_kernel<4>;
-        case 5: return energy_bs_kernel<5>;
-        case 6: return energy_bs_kernel<6>;
-        case 7: return energy_bs_kernel<7>;
-        default: return nullptr;
-    }
-}
+ebs_fn energy_bs_for_K(int K) { RRRMC_DISPATCH_UPTO7(K, energy_bs_kernel) }
 typedef void (*csweep_fn)(ColorSweepParams);
-csweep_fn csweep_for_K(int K)
-{
-    switch (K) {
-        case 1: return colored_sweep_kernel<1>;
-        case 2: return colored_sweep_kernel<2>;
-        case 3: return colored_sweep_kernel<3>;
-        case 4: return colored_sweep_kernel<4>;
-        case 5: return colored_sweep_kernel<5>;
-        case 6: return colored_sweep_kernel<6>;
-        case 7: return colored_sweep_kernel<7>;
-        default: return nullptr;
-    }
-}
+csweep_fn csweep_for_K(int K) { RRRMC_DISPATCH_UPTO7(K, colored_sweep_kernel) }
 
 // bit-sliced energy of every replica into d_E (and, optionally, one row of the sample buffer)
 int32_t run_energy_bs(rrrmc_ctx* ctx, int32_t* es_row)
@@ -302,619 +262,10 @@ int32_t run_energy(rrrmc_ctx* ctx, uint8_t* d_nun)
 }
 
 
-// ---- GraphSKNormal (dense Float64) host side -----------------------------------------------------------------------
-typedef void (*sk_fn)(SkParams);
-sk_fn sk_sweep_for(int spt)
-{
-    switch (spt) {
-        case 1: return sk_sweep_kernel<1>;
-        case 2: return sk_sweep_kernel<2>;
-        case 3: return sk_sweep_kernel<3>;
-        case 4: return sk_sweep_kernel<4>;
-        case 5: return sk_sweep_kernel<5>;
-        case 6: return sk_sweep_kernel<6>;
-        case 7: return sk_sweep_kernel<7>;
-        case 8: return sk_sweep_kernel<8>;
-        default: return nullptr;
-    }
-}
-
-typedef void (*skb_fn)(SkbParams);
-skb_fn skb_sweep_for(int spt)
-{
-    switch (spt) {
-        case 1: return skb_sweep_kernel<1>;
-        case 2: return skb_sweep_kernel<2>;
-        case 3: return skb_sweep_kernel<3>;
-        case 4: return skb_sweep_kernel<4>;
-        case 5: return skb_sweep_kernel<5>;
-        case 6: return skb_sweep_kernel<6>;
-        case 7: return skb_sweep_kernel<7>;
-        case 8: return skb_sweep_kernel<8>;
-        default: return nullptr;
-    }
-}
-
-int32_t sk_ctx_create(rrrmc_ctx** out, int32_t model, int64_t N, int64_t R, int32_t device, uint32_t replica0)
-{
-    if (N < 1 || R < 1) return fail(nullptr, RRRMC_ERR_INVALID_ARG, "N, R must be >= 1 (given N=%lld R=%lld)", (long long)N, (long long)R);
-    if (N > (int64_t)kSkThreads * kSkMaxSPT) return fail(nullptr, RRRMC_ERR_UNSUPPORTED, "N=%lld: the register-resident SK kernel covers N <= %d", (long long)N, kSkThreads * kSkMaxSPT);
-    if (replica0 % 32) return fail(nullptr, RRRMC_ERR_INVALID_ARG, "replica0 must be a multiple of 32 (given %u)", replica0);
-    int ndev = 0;
-    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
-        return fail(nullptr, RRRMC_ERR_HIP, "no HIP device is visible: this library has no CPU path");
-    if (device < 0 || device >= ndev) return fail(nullptr, RRRMC_ERR_INVALID_ARG, "device %d out of range (0..%d)", device, ndev - 1);
-    rrrmc_ctx* ctx = new (std::nothrow) rrrmc_ctx();
-    if (!ctx) return fail(nullptr, RRRMC_ERR_NOMEM, "out of host memory");
-    ctx->model = model; ctx->N = N; ctx->K = 0; ctx->R = R;
-    ctx->G8 = (R + kSkRB - 1) / kSkRB; ctx->Rpad = ctx->G8 * kSkRB; ctx->G = 0;
-    ctx->device = device; ctx->replica0 = replica0;
-#define SK_TRY(expr)                                                                                             \
-    do {                                                                                                         \
-        hipError_t e_ = (expr);                                                                                  \
-        if (e_ != hipSuccess) {                                                                                  \
-            int32_t rc_ = fail(nullptr, RRRMC_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_));           \
-            rrrmc_ctx_destroy(ctx);                                                                              \
-            return rc_;                                                                                          \
-        }                                                                                                        \
-    } while (0)
-    SK_TRY(hipSetDevice(device));
-    SK_TRY(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
-    SK_TRY(hipEventCreate(&ctx->ev_begin));
-    SK_TRY(hipEventCreate(&ctx->ev_end));
-    const size_t nf = (size_t)ctx->G8 * N * kSkRB;
-    if (model == RRRMC_MODEL_SK_BINARY) {
-        ctx->skb_NW = (int)(2 * ((N + 63) / 64));
-        SK_TRY(hipMalloc(&ctx->skb_J, sizeof(uint32_t) * N * ctx->skb_NW));
-        SK_TRY(hipMalloc(&ctx->skb_lf, sizeof(int32_t) * nf));
-        SK_TRY(hipMalloc(&ctx->skb_lfl, sizeof(int32_t) * nf));
-        SK_TRY(hipMemset(ctx->skb_lf, 0, sizeof(int32_t) * nf));
-        SK_TRY(hipMemset(ctx->skb_lfl, 0, sizeof(int32_t) * nf));
-    } else {
-        SK_TRY(hipMalloc(&ctx->sk_J, sizeof(double) * N * N));
-        SK_TRY(hipMalloc(&ctx->sk_lf, sizeof(double) * nf));
-        SK_TRY(hipMalloc(&ctx->sk_lfl, sizeof(double) * nf));
-        SK_TRY(hipMemset(ctx->sk_lf, 0, sizeof(double) * nf));
-        SK_TRY(hipMemset(ctx->sk_lfl, 0, sizeof(double) * nf));
-    }
-    SK_TRY(hipMalloc(&ctx->sk_move_last, sizeof(int32_t) * ctx->Rpad));
-    SK_TRY(hipMalloc(&ctx->sk_spins, (size_t)ctx->G8 * N));
-    SK_TRY(hipMalloc(&ctx->sk_E, sizeof(double) * ctx->Rpad));
-    SK_TRY(hipMalloc(&ctx->d_acc, sizeof(int64_t) * ctx->Rpad));
-    SK_TRY(hipMemset(ctx->sk_spins, 0, (size_t)ctx->G8 * N));
-#undef SK_TRY
-    *out = ctx;
-    return RRRMC_OK;
-}
-
-// energy(X, C), SK.jl:212-237: rebuilds lfields, zeroes lfields_last, move_last = none; E into sk_E
-int32_t sk_run_energy(rrrmc_ctx* ctx)
-{
-    const dim3 grid((unsigned)((ctx->N + 31) / 32), (unsigned)ctx->G8);
-    if (ctx->model == RRRMC_MODEL_SK_BINARY) {
-        hipLaunchKernelGGL(skb_fields_kernel, grid, dim3(256), 0, ctx->stream, ctx->skb_J, ctx->sk_spins, ctx->skb_lf, ctx->skb_lfl,
-                           ctx->sk_move_last, (int)ctx->N, ctx->skb_NW);
-        HIP_TRY(ctx, hipGetLastError());
-        hipLaunchKernelGGL(skb_energy_kernel, dim3((unsigned)((ctx->Rpad + 63) / 64)), dim3(64), 0, ctx->stream, ctx->skb_lf, ctx->sk_spins,
-                           ctx->sk_E, (int)ctx->N, (int)ctx->Rpad, std::sqrt((double)ctx->N));
-        HIP_TRY(ctx, hipGetLastError());
-        return RRRMC_OK;
-    }
-    hipLaunchKernelGGL(sk_fields_kernel, grid, dim3(256), 0, ctx->stream, ctx->sk_J, ctx->sk_spins, ctx->sk_lf, ctx->sk_lfl,
-                       ctx->sk_move_last, (int)ctx->N);
-    HIP_TRY(ctx, hipGetLastError());
-    hipLaunchKernelGGL(sk_energy_kernel, dim3((unsigned)((ctx->Rpad + 63) / 64)), dim3(64), 0, ctx->stream, ctx->sk_lf, ctx->sk_E,
-                       (int)ctx->N, (int)ctx->Rpad);
-    HIP_TRY(ctx, hipGetLastError());
-    return RRRMC_OK;
-}
-
-int32_t sk_standard_mc_async(rrrmc_ctx* ctx, double beta, int64_t iters, int64_t step)
-{
-    if (iters < 0) return fail(ctx, RRRMC_ERR_INVALID_ARG, "iters must be >= 0, given %lld", (long long)iters);
-    if (step < 1) return fail(ctx, RRRMC_ERR_INVALID_ARG, "step must be >= 1, given %lld", (long long)step);
-    if (std::isnan(beta)) return fail(ctx, RRRMC_ERR_INVALID_ARG, "beta is NaN");
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
-    ctx->results_valid = false;
-    ctx->timing_valid = false;
-    ctx->last_call_rrr = false;
-    const int64_t nsamp = iters / step;
-    const size_t es_need = (size_t)(nsamp > 0 ? nsamp : 1) * ctx->Rpad;
-    if (es_need > ctx->sk_Es_cap) {
-        free_dev(ctx->sk_Es);
-        ctx->sk_Es_cap = 0;
-        HIP_TRY(ctx, hipMalloc(&ctx->sk_Es, sizeof(double) * es_need));
-        ctx->sk_Es_cap = es_need;
-    }
-    while (ctx->ev_sweep.size() < 2) {
-        hipEvent_t e;
-        HIP_TRY(ctx, hipEventCreate(&e));
-        ctx->ev_sweep.push_back(e);
-    }
-    hipStream_t st = ctx->stream;
-    HIP_TRY(ctx, hipEventRecord(ctx->ev_begin, st));
-    int32_t rc = sk_run_energy(ctx);          // E = energy(X, C) at the start of every call, RRRMC.jl:95
-    if (rc) return rc;
-    HIP_TRY(ctx, hipMemsetAsync(ctx->d_acc, 0, sizeof(int64_t) * ctx->Rpad, st));
-    if (ctx->model == RRRMC_MODEL_SK_BINARY) {
-        SkbParams B{};
-        B.Jbits = ctx->skb_J; B.lf = ctx->skb_lf; B.lfl = ctx->skb_lfl; B.move_last = ctx->sk_move_last; B.spins = ctx->sk_spins;
-        B.E_cur = ctx->sk_E; B.acc_cur = ctx->d_acc; B.Es = ctx->sk_Es;
-        B.beta = beta; B.sN = std::sqrt((double)ctx->N); B.g0 = ctx->it_done; B.iters = iters; B.step = step; B.sample0 = 0;
-        B.k0 = (uint32_t)ctx->seed; B.k1 = (uint32_t)(ctx->seed >> 32); B.replica0 = ctx->replica0; B.N = (int)ctx->N; B.NW = ctx->skb_NW;
-        const int sptb = (int)((ctx->N + kSkThreads - 1) / kSkThreads);
-        HIP_TRY(ctx, hipEventRecord(ctx->ev_sweep[0], st));
-        hipLaunchKernelGGL(skb_sweep_for(sptb), dim3((unsigned)ctx->G8), dim3(kSkThreads), 0, st, B);
-        HIP_TRY(ctx, hipGetLastError());
-        HIP_TRY(ctx, hipEventRecord(ctx->ev_sweep[1], st));
-        HIP_TRY(ctx, hipEventRecord(ctx->ev_end, st));
-        ctx->sweep_launches = 1;
-        ctx->nsamp = nsamp;
-        ctx->it_done += (uint64_t)iters;
-        ctx->results_valid = true;
-        ctx->timing_valid = true;
-        return RRRMC_OK;
-    }
-    SkParams P{};
-    P.J = ctx->sk_J; P.lf = ctx->sk_lf; P.lfl = ctx->sk_lfl; P.move_last = ctx->sk_move_last; P.spins = ctx->sk_spins;
-    P.E_cur = ctx->sk_E; P.acc_cur = ctx->d_acc; P.Es = ctx->sk_Es;
-    P.beta = beta; P.g0 = ctx->it_done; P.iters = iters; P.step = step; P.sample0 = 0;
-    P.k0 = (uint32_t)ctx->seed; P.k1 = (uint32_t)(ctx->seed >> 32); P.replica0 = ctx->replica0; P.N = (int)ctx->N;
-    const int spt = (int)((ctx->N + kSkThreads - 1) / kSkThreads);
-    HIP_TRY(ctx, hipEventRecord(ctx->ev_sweep[0], st));
-    hipLaunchKernelGGL(sk_sweep_for(spt), dim3((unsigned)ctx->G8), dim3(kSkThreads), 0, st, P);
-    HIP_TRY(ctx, hipGetLastError());
-    HIP_TRY(ctx, hipEventRecord(ctx->ev_sweep[1], st));
-    HIP_TRY(ctx, hipEventRecord(ctx->ev_end, st));
-    ctx->sweep_launches = 1;
-    ctx->nsamp = nsamp;
-    ctx->it_done += (uint64_t)iters;
-    ctx->results_valid = true;
-    ctx->timing_valid = true;
-    return RRRMC_OK;
-}
-
-
-// ---- Float64-coupling sparse models (GraphRRGNormal / GraphEANormal) host side ------------------------------------
-constexpr int64_t kSpfItersPerLaunch = 1 << 20;
-
-int32_t spf_ctx_create(rrrmc_ctx** out, int64_t N, int64_t K, int64_t R, int32_t device, uint32_t replica0)
-{
-    if (N < 1 || K < 1 || R < 1) return fail(nullptr, RRRMC_ERR_INVALID_ARG, "N, K, R must be >= 1 (given N=%lld K=%lld R=%lld)", (long long)N, (long long)K, (long long)R);
-    if (K > kSpfMaxK) return fail(nullptr, RRRMC_ERR_UNSUPPORTED, "K=%lld: the Float64 sparse kernels cover K <= %d", (long long)K, kSpfMaxK);
-    if (N > (int64_t)INT32_MAX / 64) return fail(nullptr, RRRMC_ERR_UNSUPPORTED, "N=%lld is too large", (long long)N);
-    int ndev = 0;
-    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
-        return fail(nullptr, RRRMC_ERR_HIP, "no HIP device is visible: this library has no CPU path");
-    if (device < 0 || device >= ndev) return fail(nullptr, RRRMC_ERR_INVALID_ARG, "device %d out of range (0..%d)", device, ndev - 1);
-    rrrmc_ctx* ctx = new (std::nothrow) rrrmc_ctx();
-    if (!ctx) return fail(nullptr, RRRMC_ERR_NOMEM, "out of host memory");
-    ctx->model = RRRMC_MODEL_SPARSE_F64; ctx->N = N; ctx->K = K; ctx->R = R;
-    ctx->pfW = (R + 63) / 64; ctx->Rpad = ctx->pfW * 64;
-    ctx->device = device; ctx->replica0 = replica0;
-#define PF_TRY(expr)                                                                                             \
-    do {                                                                                                         \
-        hipError_t e_ = (expr);                                                                                  \
-        if (e_ != hipSuccess) {                                                                                  \
-            int32_t rc_ = fail(nullptr, e_ == hipErrorOutOfMemory ? RRRMC_ERR_NOMEM : RRRMC_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
-            rrrmc_ctx_destroy(ctx);                                                                              \
-            return rc_;                                                                                          \
-        }                                                                                                        \
-    } while (0)
-    PF_TRY(hipSetDevice(device));
-    PF_TRY(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
-    PF_TRY(hipEventCreate(&ctx->ev_begin));
-    PF_TRY(hipEventCreate(&ctx->ev_end));
-    const size_t nf = (size_t)ctx->Rpad * (size_t)N;
-    const size_t nsw = (size_t)ctx->pfW * (size_t)N;
-    PF_TRY(hipMalloc(&ctx->d_A, sizeof(int32_t) * N * K));
-    PF_TRY(hipMalloc(&ctx->pf_J, sizeof(double) * N * K));
-    PF_TRY(hipMalloc(&ctx->sk_lf, sizeof(double) * nf));
-    PF_TRY(hipMalloc(&ctx->pf_undo, sizeof(double) * (size_t)ctx->Rpad * (size_t)(K + 1)));
-    PF_TRY(hipMalloc(&ctx->pf_spins, sizeof(unsigned long long) * nsw));
-    PF_TRY(hipMalloc(&ctx->pf_sites, sizeof(int32_t) * (kSpfItersPerLaunch + 2 * kSpfDepth)));
-    PF_TRY(hipMalloc(&ctx->sk_move_last, sizeof(int32_t) * ctx->Rpad));
-    PF_TRY(hipMalloc(&ctx->sk_E, sizeof(double) * ctx->Rpad));
-    PF_TRY(hipMalloc(&ctx->d_acc, sizeof(int64_t) * ctx->Rpad));
-    PF_TRY(hipMemset(ctx->pf_spins, 0, sizeof(unsigned long long) * nsw));
-    PF_TRY(hipMemset(ctx->sk_lf, 0, sizeof(double) * nf));
-    PF_TRY(hipMemset(ctx->pf_undo, 0, sizeof(double) * (size_t)ctx->Rpad * (size_t)(K + 1)));
-#undef PF_TRY
-    *out = ctx;
-    return RRRMC_OK;
-}
-
-SpfParams spf_params(rrrmc_ctx* ctx)
-{
-    SpfParams P{};
-    P.A = ctx->d_A; P.J = ctx->pf_J; P.sites = ctx->pf_sites; P.spins = ctx->pf_spins; P.lf = ctx->sk_lf; P.undo = ctx->pf_undo;
-    P.move_last = ctx->sk_move_last; P.E_cur = ctx->sk_E; P.acc_cur = ctx->d_acc; P.Es = ctx->sk_Es;
-    P.k0 = (uint32_t)ctx->seed; P.k1 = (uint32_t)(ctx->seed >> 32); P.replica0 = ctx->replica0;
-    P.N = (int)ctx->N; P.Rpad = (int)ctx->Rpad;
-    return P;
-}
-
-typedef void (*spf_fn)(SpfParams);
-spf_fn spf_sweep_for_K(int K)
-{
-    switch (K) {
-        case 1: return spf_sweep_kernel<1>;
-        case 2: return spf_sweep_kernel<2>;
-        case 3: return spf_sweep_kernel<3>;
-        case 4: return spf_sweep_kernel<4>;
-        case 5: return spf_sweep_kernel<5>;
-        case 6: return spf_sweep_kernel<6>;
-        case 7: return spf_sweep_kernel<7>;
-        case 8: return spf_sweep_kernel<8>;
-        default: return nullptr;
-    }
-}
-spf_fn spf_energy_for_K(int K)
-{
-    switch (K) {
-        case 1: return spf_energy_kernel<1>;
-        case 2: return spf_energy_kernel<2>;
-        case 3: return spf_energy_kernel<3>;
-        case 4: return spf_energy_kernel<4>;
-        case 5: return spf_energy_kernel<5>;
-        case 6: return spf_energy_kernel<6>;
-        case 7: return spf_energy_kernel<7>;
-        case 8: return spf_energy_kernel<8>;
-        default: return nullptr;
-    }
-}
-
-int32_t spf_run_energy(rrrmc_ctx* ctx)
-{
-    hipLaunchKernelGGL(spf_energy_for_K((int)ctx->K), dim3((unsigned)ctx->pfW), dim3(64), 0, ctx->stream, spf_params(ctx));
-    HIP_TRY(ctx, hipGetLastError());
-    return RRRMC_OK;
-}
-
-int32_t spf_standard_mc_async(rrrmc_ctx* ctx, double beta, int64_t iters, int64_t step)
-{
-    if (iters < 0) return fail(ctx, RRRMC_ERR_INVALID_ARG, "iters must be >= 0, given %lld", (long long)iters);
-    if (step < 1) return fail(ctx, RRRMC_ERR_INVALID_ARG, "step must be >= 1, given %lld", (long long)step);
-    if (std::isnan(beta)) return fail(ctx, RRRMC_ERR_INVALID_ARG, "beta is NaN");
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
-    ctx->results_valid = false;
-    ctx->timing_valid = false;
-    ctx->last_call_rrr = false;
-    const int64_t nsamp = iters / step;
-    const size_t es_need = (size_t)(nsamp > 0 ? nsamp : 1) * ctx->Rpad;
-    if (es_need > ctx->sk_Es_cap) {
-        free_dev(ctx->sk_Es);
-        ctx->sk_Es_cap = 0;
-        HIP_TRY(ctx, hipMalloc(&ctx->sk_Es, sizeof(double) * es_need));
-        ctx->sk_Es_cap = es_need;
-    }
-    const int64_t nl = (iters + kSpfItersPerLaunch - 1) / kSpfItersPerLaunch;
-    while ((int64_t)ctx->ev_sweep.size() < 2 * (nl > 0 ? nl : 1)) {
-        hipEvent_t e;
-        HIP_TRY(ctx, hipEventCreate(&e));
-        ctx->ev_sweep.push_back(e);
-    }
-    hipStream_t st = ctx->stream;
-    HIP_TRY(ctx, hipEventRecord(ctx->ev_begin, st));
-    int32_t rc = spf_run_energy(ctx);          // E = energy(X, C) at the start of every call, RRRMC.jl:95
-    if (rc) return rc;
-    HIP_TRY(ctx, hipMemsetAsync(ctx->d_acc, 0, sizeof(int64_t) * ctx->Rpad, st));
-    spf_fn fn = spf_sweep_for_K((int)ctx->K);
-    int64_t done = 0;
-    int launches = 0;
-    while (done < iters) {
-        const int64_t n = std::min<int64_t>(kSpfItersPerLaunch, iters - done);
-        const int64_t nsites = n + 2 * kSpfDepth;       // the kernel requests (and never consumes) data of the iterations just past its end
-        hipLaunchKernelGGL(spf_sites_kernel, dim3((unsigned)((nsites + 255) / 256)), dim3(256), 0, st, ctx->pf_sites, nsites, ctx->it_done + (uint64_t)done,
-                           (uint32_t)ctx->seed, (uint32_t)(ctx->seed >> 32), (uint32_t)ctx->N);
-        HIP_TRY(ctx, hipGetLastError());
-        SpfParams P = spf_params(ctx);
-        P.beta = beta; P.g0 = ctx->it_done + (uint64_t)done; P.iters = n; P.step = step;
-        P.it_off = done; P.sample0 = done / step;
-        HIP_TRY(ctx, hipEventRecord(ctx->ev_sweep[2 * launches], st));
-        hipLaunchKernelGGL(fn, dim3((unsigned)ctx->pfW), dim3(64), 0, st, P);
-        HIP_TRY(ctx, hipGetLastError());
-        HIP_TRY(ctx, hipEventRecord(ctx->ev_sweep[2 * launches + 1], st));
-        ++launches;
-        done += n;
-    }
-    HIP_TRY(ctx, hipEventRecord(ctx->ev_end, st));
-    ctx->sweep_launches = launches;
-    ctx->nsamp = nsamp;
-    ctx->it_done += (uint64_t)iters;
-    ctx->results_valid = true;
-    ctx->timing_valid = true;
-    return RRRMC_OK;
-}
-
-
-// ---- DoubleGraphs Graph{RRG,EA}NormalDiscretized host side -----------------------------------------------------------
-double host_det_exp(double x);
-int32_t dbl_ctx_create(rrrmc_ctx** out, int64_t N, int64_t K, int64_t R, int32_t device, uint32_t replica0)
-{
-    if (N < 1 || K < 1 || R < 1) return fail(nullptr, RRRMC_ERR_INVALID_ARG, "N, K, R must be >= 1 (given N=%lld K=%lld R=%lld)", (long long)N, (long long)K, (long long)R);
-    if (K > kDKmax) return fail(nullptr, RRRMC_ERR_UNSUPPORTED, "K=%lld: the DoubleGraph kernel covers K <= %d", (long long)K, kDKmax);
-    if (N > 65535) return fail(nullptr, RRRMC_ERR_UNSUPPORTED, "N=%lld: the rrrMC kernels index spins with 16 bits", (long long)N);
-    int ndev = 0;
-    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
-        return fail(nullptr, RRRMC_ERR_HIP, "no HIP device is visible: this library has no CPU path");
-    if (device < 0 || device >= ndev) return fail(nullptr, RRRMC_ERR_INVALID_ARG, "device %d out of range (0..%d)", device, ndev - 1);
-    rrrmc_ctx* ctx = new (std::nothrow) rrrmc_ctx();
-    if (!ctx) return fail(nullptr, RRRMC_ERR_NOMEM, "out of host memory");
-    ctx->model = RRRMC_MODEL_SPARSE_DISCRETIZED; ctx->N = N; ctx->K = K; ctx->R = R; ctx->Rpad = R;
-    ctx->qW = 2 * ((N + 63) / 64);
-    ctx->device = device; ctx->replica0 = replica0;
-#define DB_TRY(expr)                                                                                             \
-    do {                                                                                                         \
-        hipError_t e_ = (expr);                                                                                  \
-        if (e_ != hipSuccess) {                                                                                  \
-            int32_t rc_ = fail(nullptr, e_ == hipErrorOutOfMemory ? RRRMC_ERR_NOMEM : RRRMC_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
-            rrrmc_ctx_destroy(ctx);                                                                              \
-            return rc_;                                                                                          \
-        }                                                                                                        \
-    } while (0)
-    DB_TRY(hipSetDevice(device));
-    DB_TRY(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
-    DB_TRY(hipEventCreate(&ctx->ev_begin));
-    DB_TRY(hipEventCreate(&ctx->ev_end));
-    DB_TRY(hipMalloc(&ctx->d_A, sizeof(int32_t) * N * K));
-    DB_TRY(hipMalloc(&ctx->db_dJ, sizeof(int8_t) * N * K));
-    DB_TRY(hipMalloc(&ctx->db_rJ, sizeof(double) * N * K));
-    DB_TRY(hipMalloc(&ctx->q_spins, sizeof(uint32_t) * R * ctx->qW));
-    DB_TRY(hipMalloc(&ctx->db_cls, (size_t)R * N));
-    DB_TRY(hipMalloc(&ctx->db_sv, sizeof(uint16_t) * (size_t)R * 2 * kDLmax * N));
-    DB_TRY(hipMalloc(&ctx->db_spos, sizeof(uint16_t) * (size_t)R * N));
-    DB_TRY(hipMalloc(&ctx->db_lf, sizeof(double) * (size_t)R * N));
-    DB_TRY(hipMalloc(&ctx->db_undo, sizeof(double) * (size_t)R * (K + 1)));
-    DB_TRY(hipMalloc(&ctx->q_stats, sizeof(int64_t) * R * 2));
-    DB_TRY(hipMalloc(&ctx->sk_E, sizeof(double) * R));
-    DB_TRY(hipMalloc(&ctx->d_acc, sizeof(int64_t) * R));
-    DB_TRY(hipMemset(ctx->q_spins, 0, sizeof(uint32_t) * R * ctx->qW));
-    DB_TRY(hipMemset(ctx->q_stats, 0, sizeof(int64_t) * R * 2));
-#undef DB_TRY
-    *out = ctx;
-    return RRRMC_OK;
-}
-
-RrrDblParams dbl_params(rrrmc_ctx* ctx, double beta)
-{
-    RrrDblParams P{};
-    P.A = ctx->d_A; P.dJ = ctx->db_dJ; P.rJ = ctx->db_rJ; P.spins = ctx->q_spins; P.cls = ctx->db_cls; P.sv = ctx->db_sv; P.spos = ctx->db_spos;
-    P.lf = ctx->db_lf; P.undo = ctx->db_undo; P.E_cur = ctx->sk_E; P.stats = ctx->q_stats; P.Es = ctx->sk_Es;
-    for (int k = 0; k < ctx->db_L; ++k) { P.dElist[k] = ctx->db_dElist[k]; P.ft[k] = host_det_exp(-beta * (double)ctx->db_dElist[k]); }   // DeltaE.jl:91
-    P.beta = beta;
-    P.k0 = (uint32_t)ctx->seed; P.k1 = (uint32_t)(ctx->seed >> 32); P.replica0 = ctx->replica0;
-    P.N = (int)ctx->N; P.K = (int)ctx->K; P.L = ctx->db_L; P.W = (int)ctx->qW; P.R = (int)ctx->R; P.ea_form = ctx->db_ea_form;
-    return P;
-}
-
-int32_t dbl_run_energy(rrrmc_ctx* ctx)
-{
-    RrrDblParams P = dbl_params(ctx, 0.0);
-    P.energy_only = 1;
-    hipLaunchKernelGGL(rrr_dbl_kernel, dim3((unsigned)((ctx->R + kRrrThreads - 1) / kRrrThreads)), dim3(kRrrThreads), 0, ctx->stream, P);
-    HIP_TRY(ctx, hipGetLastError());
-    return RRRMC_OK;
-}
-
-int32_t dbl_rrr_mc_async(rrrmc_ctx* ctx, double beta, int64_t iters, int64_t step, double staged_thr, double staged_thr_fact)
-{
-    if (iters < 0) return fail(ctx, RRRMC_ERR_INVALID_ARG, "iters must be >= 0, given %lld", (long long)iters);
-    if (step < 1) return fail(ctx, RRRMC_ERR_INVALID_ARG, "step must be >= 1, given %lld", (long long)step);
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
-    ctx->results_valid = false;
-    ctx->timing_valid = false;
-    const int64_t nsamp = iters / step;
-    const size_t es_need = (size_t)(nsamp > 0 ? nsamp : 1) * ctx->R;
-    if (es_need > ctx->sk_Es_cap) {
-        free_dev(ctx->sk_Es);
-        ctx->sk_Es_cap = 0;
-        HIP_TRY(ctx, hipMalloc(&ctx->sk_Es, sizeof(double) * es_need));
-        ctx->sk_Es_cap = es_need;
-    }
-    while (ctx->ev_sweep.size() < 2) {
-        hipEvent_t e;
-        HIP_TRY(ctx, hipEventCreate(&e));
-        ctx->ev_sweep.push_back(e);
-    }
-    RrrDblParams P = dbl_params(ctx, beta);
-    P.staged_thr = staged_thr; P.lambda = staged_thr_fact / (double)ctx->N;
-    P.g0 = ctx->it_done; P.iters = iters; P.step = step;
-    hipStream_t st = ctx->stream;
-    HIP_TRY(ctx, hipEventRecord(ctx->ev_begin, st));
-    HIP_TRY(ctx, hipEventRecord(ctx->ev_sweep[0], st));
-    hipLaunchKernelGGL(rrr_dbl_kernel, dim3((unsigned)((ctx->R + kRrrThreads - 1) / kRrrThreads)), dim3(kRrrThreads), 0, st, P);
-    HIP_TRY(ctx, hipGetLastError());
-    HIP_TRY(ctx, hipEventRecord(ctx->ev_sweep[1], st));
-    HIP_TRY(ctx, hipEventRecord(ctx->ev_end, st));
-    ctx->stats_stride = 2;
-    ctx->sweep_launches = 1;
-    ctx->nsamp = nsamp;
-    ctx->it_done += (uint64_t)iters;
-    ctx->results_valid = true;
-    ctx->timing_valid = true;
-    ctx->last_call_rrr = true;
-    return RRRMC_OK;
-}
-
-
-// ---- GraphQuant / rrrMC host side -----------------------------------------------------------------------------------
-RrrParams quant_params(rrrmc_ctx* ctx, double beta, double fourK)
-{
-    RrrParams P{};
-    P.A = ctx->d_A; P.J = ctx->d_J;
-    P.spins = ctx->q_spins; P.cls = ctx->q_cls; P.sv = ctx->q_sv; P.spos = ctx->q_spos; P.st = ctx->q_st;
-    P.T = ctx->q_T; P.zz = ctx->q_z; P.E_cur = ctx->sk_E; P.acc_rate = ctx->q_accrate; P.stats = ctx->q_stats; P.Es = ctx->sk_Es;
-    P.beta = beta; P.fourK = fourK;
-    P.ft1 = 0.0;
-    P.k0 = (uint32_t)ctx->seed; P.k1 = (uint32_t)(ctx->seed >> 32); P.replica0 = ctx->replica0;
-    P.Nk = (int)ctx->qNk; P.M = (int)ctx->qM; P.K = (int)ctx->K; P.N = (int)ctx->N; P.W = (int)ctx->qW; P.R = (int)ctx->R;
-    return P;
-}
-
-// deterministic exp on the host: the same operation sequence as det_exp on the device / orc_det_exp in the oracle
-double host_det_exp(double x)
-{
-    static const double LOG2E = 1.44269504088896338700e+00;
-    static const double LN2_HI = 6.93147180369123816490e-01, LN2_LO = 1.90821492927058770002e-10;
-    static const double c[14] = {1.0, 1.0, 0.5, 1.0 / 6, 1.0 / 24, 1.0 / 120, 1.0 / 720, 1.0 / 5040, 1.0 / 40320, 1.0 / 362880,
-                                 1.0 / 3628800, 1.0 / 39916800, 1.0 / 479001600, 1.0 / 6227020800.0};
-    if (x != x) return x;
-    if (x < -745.2) return 0.0;
-    if (x > 709.7) return HUGE_VAL;
-    volatile double t0 = x * LOG2E;
-    const double k = std::floor(t0 + 0.5);
-    volatile double a = k * LN2_HI, b = k * LN2_LO;
-    volatile double r0 = x - a;
-    const double r = r0 - b;
-    double p = c[13];
-    for (int n = 12; n >= 0; --n) { volatile double m = p * r; p = m + c[n]; }
-    return std::ldexp(p, (int)k);
-}
-
-// energy(X, C) + gen_ΔEcache (RRRMC.jl:237-240): E into sk_E, cache arrays rebuilt
-int32_t quant_run_init(rrrmc_ctx* ctx, double beta, double fourK)
-{
-    RrrParams P = quant_params(ctx, beta, fourK);
-    P.ft1 = host_det_exp(-beta * fourK);
-    hipLaunchKernelGGL(rrr_init_kernel, dim3((unsigned)((ctx->R + kRrrThreads - 1) / kRrrThreads)), dim3(kRrrThreads), 0, ctx->stream, P);
-    HIP_TRY(ctx, hipGetLastError());
-    return RRRMC_OK;
-}
-
-
-// rrrMC(X::SingleGraph) on GraphSKNormal (RRRMC.jl:149-219): thread-per-replica kernel over interleaved arrays
-int32_t sk_rrr_mc_async(rrrmc_ctx* ctx, double beta, int64_t iters, int64_t step, double staged_thr, double staged_thr_fact)
-{
-    if (iters < 0) return fail(ctx, RRRMC_ERR_INVALID_ARG, "iters must be >= 0, given %lld", (long long)iters);
-    if (step < 1) return fail(ctx, RRRMC_ERR_INVALID_ARG, "step must be >= 1, given %lld", (long long)step);
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
-    ctx->results_valid = false;
-    ctx->timing_valid = false;
-    const int64_t N = ctx->N, Rp = ctx->Rpad;
-    int levs = 0;
-    while (((int64_t)1 << levs) < N) ++levs;
-    const int64_t N2 = (int64_t)1 << levs, W = (N + 31) / 32;
-    const size_t per = (size_t)Rp;
-    const size_t ndbl = per * (size_t)(5 * N + 2 * N2 + 1);
-    if (!ctx->rs_buf) {
-        HIP_TRY(ctx, hipMalloc(&ctx->rs_buf, sizeof(double) * ndbl));
-        HIP_TRY(ctx, hipMalloc(&ctx->rs_spins, sizeof(uint32_t) * W * per));
-        HIP_TRY(ctx, hipMalloc(&ctx->rs_status, sizeof(int32_t) * per));
-        HIP_TRY(ctx, hipMalloc(&ctx->q_stats, sizeof(int64_t) * per * 2));
-    }
-    const int64_t nsamp = iters / step;
-    const size_t es_need = (size_t)(nsamp > 0 ? nsamp : 1) * Rp;
-    if (es_need > ctx->sk_Es_cap) {
-        free_dev(ctx->sk_Es);
-        ctx->sk_Es_cap = 0;
-        HIP_TRY(ctx, hipMalloc(&ctx->sk_Es, sizeof(double) * es_need));
-        ctx->sk_Es_cap = es_need;
-    }
-    while (ctx->ev_sweep.size() < 2) {
-        hipEvent_t e;
-        HIP_TRY(ctx, hipEventCreate(&e));
-        ctx->ev_sweep.push_back(e);
-    }
-    hipStream_t st = ctx->stream;
-    RrrSkParams P{};
-    double* b = ctx->rs_buf;
-    P.J = ctx->sk_J;
-    P.lfA = b; b += per * N;
-    P.lfB = b; b += per * N;
-    P.v = b; b += per * N2;
-    P.ps = b; b += per * N2;
-    P.dEs = b; b += per * N;
-    P.st_dE = b; b += per * N;
-    P.st_p = b; b += per * N;
-    P.z_out = b;
-    P.spins = ctx->rs_spins; P.E_cur = ctx->sk_E; P.stats = ctx->q_stats; P.status = ctx->rs_status; P.Es = ctx->sk_Es;
-    P.beta = beta; P.staged_thr = staged_thr; P.lambda = staged_thr_fact / (double)N;
-    P.g0 = ctx->it_done; P.iters = iters; P.step = step;
-    P.k0 = (uint32_t)ctx->seed; P.k1 = (uint32_t)(ctx->seed >> 32); P.replica0 = ctx->replica0;
-    P.N = (int)N; P.N2 = (int)N2; P.levs = levs; P.W = (int)W; P.R = (int)ctx->R; P.Rp = (int)Rp;
-    ctx->stats_stride = 2;
-    HIP_TRY(ctx, hipEventRecord(ctx->ev_begin, st));
-    hipLaunchKernelGGL(rrsk_spins_in_kernel, dim3((unsigned)((Rp + 255) / 256), (unsigned)W), dim3(256), 0, st, ctx->sk_spins, ctx->rs_spins, (int)N, (int)W, (int)Rp);
-    HIP_TRY(ctx, hipGetLastError());
-    HIP_TRY(ctx, hipEventRecord(ctx->ev_sweep[0], st));
-    hipLaunchKernelGGL(rrr_skn_kernel, dim3((unsigned)((ctx->R + kRrrThreads - 1) / kRrrThreads)), dim3(kRrrThreads), 0, st, P);
-    HIP_TRY(ctx, hipGetLastError());
-    HIP_TRY(ctx, hipEventRecord(ctx->ev_sweep[1], st));
-    hipLaunchKernelGGL(rrsk_spins_out_kernel, dim3((unsigned)((N + 255) / 256), (unsigned)ctx->G8), dim3(256), 0, st, ctx->rs_spins, ctx->sk_spins, (int)N, (int)Rp);
-    HIP_TRY(ctx, hipGetLastError());
-    HIP_TRY(ctx, hipEventRecord(ctx->ev_end, st));
-    ctx->sweep_launches = 1;
-    ctx->nsamp = nsamp;
-    ctx->it_done += (uint64_t)iters;
-    ctx->results_valid = true;
-    ctx->timing_valid = true;
-    ctx->last_call_rrr = true;
-    return RRRMC_OK;
-}
-
-
-// rrrMC(SingleGraph) / bklMC on GraphRRG / GraphEA: thread-per-replica kernel over replica-contiguous arrays
-int32_t sparse_rrr_bkl_async(rrrmc_ctx* ctx, int mode, double beta, int64_t iters, int64_t step, double staged_thr, double staged_thr_fact)
-{
-    if (iters < 0) return fail(ctx, RRRMC_ERR_INVALID_ARG, "iters must be >= 0, given %lld", (long long)iters);
-    if (step < 1) return fail(ctx, RRRMC_ERR_INVALID_ARG, "step must be >= 1, given %lld", (long long)step);
-    if (ctx->N > 65535) return fail(ctx, RRRMC_ERR_UNSUPPORTED, "N=%lld: the rrrMC kernel indexes spins with 16 bits", (long long)ctx->N);
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
-    ctx->results_valid = false;
-    ctx->timing_valid = false;
-    const int64_t N = ctx->N, K = ctx->K, R = ctx->R, W = (N + 31) / 32;
-    const int L = (int)(K / 2 + 1);                       // allΔE has K/2 + 1 levels for +-J couplings (RRG.jl:262-265)
-    if (!ctx->rp_spins) {
-        HIP_TRY(ctx, hipMalloc(&ctx->rp_spins, sizeof(uint32_t) * R * W));
-        HIP_TRY(ctx, hipMalloc(&ctx->rp_cls, (size_t)R * N));
-        HIP_TRY(ctx, hipMalloc(&ctx->rp_sv, sizeof(uint16_t) * R * 2 * L * N));
-        HIP_TRY(ctx, hipMalloc(&ctx->rp_spos, sizeof(uint16_t) * R * N));
-        HIP_TRY(ctx, hipMalloc(&ctx->q_stats, sizeof(int64_t) * R * 3));
-    }
-    ctx->stats_stride = 3;
-    const int64_t nsamp = iters / step;
-    const size_t es_need = (size_t)(nsamp > 0 ? nsamp : 1) * ctx->Rpad;
-    if (es_need > ctx->Es_cap) {
-        free_dev(ctx->d_Es);
-        ctx->Es_cap = 0;
-        HIP_TRY(ctx, hipMalloc(&ctx->d_Es, sizeof(int32_t) * es_need));
-        ctx->Es_cap = es_need;
-    }
-    while (ctx->ev_sweep.size() < 2) {
-        hipEvent_t e;
-        HIP_TRY(ctx, hipEventCreate(&e));
-        ctx->ev_sweep.push_back(e);
-    }
-    RrrSparseParams P{};
-    P.A = ctx->d_A; P.J = ctx->d_J; P.spins = ctx->rp_spins; P.cls = ctx->rp_cls; P.sv = ctx->rp_sv; P.spos = ctx->rp_spos;
-    P.E_cur = ctx->d_E; P.acc_cur = ctx->d_acc; P.stats = ctx->q_stats; P.Es = ctx->d_Es;
-    for (int k = 0; k < L && k < kSLmax; ++k) P.ft[k] = host_det_exp(-beta * (double)(2 * (2 * k + (K & 1))));     // exp(-beta dE_k), DeltaE.jl:91
-    P.beta = beta; P.staged_thr = staged_thr; P.lambda = staged_thr_fact / (double)N;
-    P.g0 = ctx->it_done; P.iters = iters; P.step = step;
-    P.k0 = (uint32_t)ctx->seed; P.k1 = (uint32_t)(ctx->seed >> 32); P.replica0 = ctx->replica0;
-    P.N = (int)N; P.K = (int)K; P.L = L; P.W = (int)W; P.R = (int)R; P.Rpad = (int)ctx->Rpad; P.mode = mode;
-    hipStream_t st = ctx->stream;
-    HIP_TRY(ctx, hipEventRecord(ctx->ev_begin, st));
-    HIP_TRY(ctx, hipMemsetAsync(ctx->d_acc, 0, sizeof(int64_t) * ctx->Rpad, st));
-    hipLaunchKernelGGL(rrsp_spins_in_kernel, dim3((unsigned)((W + 255) / 256), (unsigned)R), dim3(256), 0, st, ctx->d_spins, ctx->rp_spins, (int)N, (int)W, (int)R);
-    HIP_TRY(ctx, hipGetLastError());
-    HIP_TRY(ctx, hipEventRecord(ctx->ev_sweep[0], st));
-    hipLaunchKernelGGL(rrr_sparse_kernel, dim3((unsigned)((R + kRrrThreads - 1) / kRrrThreads)), dim3(kRrrThreads), 0, st, P);
-    HIP_TRY(ctx, hipGetLastError());
-    HIP_TRY(ctx, hipEventRecord(ctx->ev_sweep[1], st));
-    hipLaunchKernelGGL(rrsp_spins_out_kernel, dim3((unsigned)((N + 255) / 256), (unsigned)ctx->G), dim3(256), 0, st, ctx->rp_spins, ctx->d_spins, (int)N, (int)W, (int)R);
-    HIP_TRY(ctx, hipGetLastError());
-    HIP_TRY(ctx, hipEventRecord(ctx->ev_end, st));
-    ctx->sweep_launches = 1;
-    ctx->nsamp = nsamp;
-    ctx->it_done += (uint64_t)iters;
-    ctx->results_valid = true;
-    ctx->timing_valid = true;
-    ctx->last_call_rrr = true;
-    ctx->colored_call = false;
-    return RRRMC_OK;
-}
+#include "host_sk.hpp"
+#include "host_spf.hpp"
+#include "host_dbl.hpp"
+#include "host_rrr.hpp"
 
 }  // namespace
 
