@@ -173,6 +173,12 @@ RRRMC_API int32_t rrrmc_rrr_stats(rrrmc_ctx *ctx, int64_t *staged_iters_out);
  * bklMC(X, beta, iters; step) (src/RRRMC.jl:311-359) on RRRMC_MODEL_SPARSE_PM1: rejection-free Bortz-Kalos-Lebowitz sampler;
  * `iters` counts the skipped rejections too; rrrmc_rrr_stats then returns the number of moves actually made ("true it"). */
 RRRMC_API int32_t rrrmc_bkl_mc_async(rrrmc_ctx *ctx, double beta, int64_t iters, int64_t step);
+/* wtmMC(X, beta, samples; step) (src/RRRMC.jl:376-426, src/WaitingTimes.jl) on RRRMC_MODEL_SPARSE_PM1: the waiting-time
+ * method.  `step` is in sweeps (it is divided by N like RRRMC.jl:391); `samples` energies are taken at global times k*step/N.
+ * rrrmc_sync + rrrmc_fetch_results return Es [R x samples] and, as `accepted`, num_moves; rrrmc_wtm_times the final global time
+ * of every replica ("global time", RRRMC.jl:421). */
+RRRMC_API int32_t rrrmc_wtm_mc_async(rrrmc_ctx *ctx, double beta, int64_t samples, double step);
+RRRMC_API int32_t rrrmc_wtm_times(rrrmc_ctx *ctx, double *t_out);
 /* parity/debug view of the move-selection cache after the last rrrMC call: pos_out[R * N] = class of every spin
  * (DeltaECache.pos, 0-based a + 2*up), sizes_out[R * 4] = |class k| (DeltaE.jl:63-73). */
 RRRMC_API int32_t rrrmc_rrr_cache(rrrmc_ctx *ctx, int8_t *pos_out, int32_t *sizes_out);

@@ -527,3 +527,20 @@ def rrr_double_sparse(A, dJ, rJ, lev, beta, iters, step, seed, chunks, it0=0, re
     if n < 0:
         raise RuntimeError("rrr_double_sparse: cache inconsistent (rc=%d)" % n)
     return Es[:n], ch, int(stats[0]), int(stats[1]), cache[:N].copy(), cache[N:].copy()
+
+
+def wtm_mc_sparse(A, J, beta, samples, step, seed, chunks, call=0, replica=0, form="rrg"):
+    """wtmMC (RRRMC.jl:376-426) on GraphRRG / GraphEA; returns (Es, chunks, num_moves, t, E_final)."""
+    L = lib()
+    L.orc_wtm_mc_sparse.restype = C.c_int64
+    L.orc_wtm_mc_sparse.argtypes = [C.c_int, C.c_int64, C.c_int64, i32p, i32p, C.c_double, C.c_int64, C.c_double, C.c_uint64, C.c_uint32,
+                                    C.c_uint32, u64p, i64p, i64p, C.POINTER(C.c_double)]
+    A = np.ascontiguousarray(A, np.int32)
+    N, K = A.shape
+    ch = np.array(chunks, np.uint64, copy=True)
+    Es = np.zeros(max(samples, 1), np.int64)
+    stats = np.zeros(3, np.int64)
+    t = C.c_double(0)
+    n = L.orc_wtm_mc_sparse(1 if form == "ea" else 0, N, K, A, np.ascontiguousarray(J, np.int32), float(beta), int(samples), float(step),
+                            seed, call, replica, ch, Es, stats, C.byref(t))
+    return Es[:n], ch, int(stats[0]), t.value, int(stats[2])

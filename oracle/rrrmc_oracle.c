@@ -1754,3 +1754,73 @@ ORC_API int64_t orc_rrr_double_sparse(int form, int64_t N, int64_t K, const int3
     free(X0.lfields); free(X0.lfields_last); free(X1.lfields); free(X1.lfields_last);
     return ok ? nsamp : -1;
 }
+
+/* =============================================================================================
+ * wtmMC (waiting-time method; src/RRRMC.jl:376-426, src/WaitingTimes.jl) on the DiscrGraphs GraphRRG / GraphEA.
+ * SURVEY.md §8f rank 4.  Every spin carries the time of its next flip, t_i = t + gen_wt(tau_i) with
+ * tau = max(1, exp(beta dE)) and gen_wt(tau) = -tau log1p(-rand()) (WaitingTimes.jl:16-22); the spin with the smallest time moves.
+ * The reference keeps the times in DataStructures' MutableBinaryMinHeap (third party, v0.18, not under /root/reference): only its
+ * contract "top = smallest key" matters (ties have probability zero; here the lower site index wins), so this restatement
+ * simply scans for the minimum.  WTM stream: the n-th uniform of replica r in call `call` is the 53-bit word (n & 1) of
+ *   ctr = (lo32(n >> 1), hi32(n >> 1), r, TAG_WTM | call << 8);
+ * n = i for the initial time of spin i (THeap(X, C, beta), :26-36), then one draw per updated spin in the order of update_heap!
+ * (:40-52: the moved spin, then its neighbours).  exp and log1p are the deterministic ones of philox_contract.h.
+ * ============================================================================================= */
+enum { ORC_TAG_WTM = 11 };
+static double wtm_uniform(uint64_t seed, uint64_t n, uint32_t replica, uint32_t call)
+{
+    uint32_t w[4];
+    uint64_t blk = n >> 1;
+    orc_draw(seed, (uint32_t)blk, (uint32_t)(blk >> 32), replica, (uint32_t)ORC_TAG_WTM | (call << 8), w);
+    unsigned h = (unsigned)(n & 1u);
+    return u53_of(w[2 * h], w[2 * h + 1]);
+}
+static inline double wtm_tau(double beta, int64_t dE) { double e = orc_det_exp(beta * (double)dE); return e > 1.0 ? e : 1.0; }   /* tauDE: :16 */
+static inline double wtm_gen(double tau, double u) { return -tau * orc_det_log1p(-u); }                                          /* gen_wt: :18-22 */
+
+/* Es[samples] energies at global times k*step/N; stats = [num_moves, samples taken, final tracked energy]; t_out = final global time */
+ORC_API int64_t orc_wtm_mc_sparse(int form, int64_t N, int64_t K, const int32_t *A, const int32_t *J, double beta, int64_t samples,
+                                  double step, uint64_t seed, uint32_t call, uint32_t replica,
+                                  uint64_t *chunks, int64_t *Es, int64_t *stats, double *t_out)
+{
+    sparse_t X = {N, K, A, J, NULL, NULL, -1, form};
+    X.lfields = (int64_t *)malloc((size_t)N * 8);
+    X.lfields_last = (int64_t *)malloc((size_t)N * 8);
+    int64_t E = sparse_energy(&X, chunks);
+    double *tm = (double *)malloc((size_t)N * sizeof(double));
+    uint64_t nd = 0;
+    for (int64_t i = 0; i < N; ++i) tm[i] = wtm_gen(wtm_tau(beta, sparse_delta_energy(&X, i)), wtm_uniform(seed, nd++, replica, call));
+    step /= (double)N;
+    const double tmax = step * (double)samples;
+    double t = 0.0, nextstep = step;
+    int64_t num_moves = 0, nsamp = 0;
+    int out = 0;
+    while (t < tmax && !out) {
+        int64_t move = 0;
+        for (int64_t i = 1; i < N; ++i) if (tm[i] < tm[move]) move = i;          /* pick_next: top_with_handle */
+        const double tp = tm[move];
+        while (tp >= nextstep) {
+            Es[nsamp++] = E;
+            nextstep += step;
+            if (nextstep > tmax + 1e-10) { out = 1; break; }
+        }
+        if (out) break;
+        t = tp;
+        /* update_heap!: WaitingTimes.jl:40-52 */
+        const int64_t dE = sparse_delta_energy(&X, move);
+        sparse_spinflip(&X, chunks, move);
+        tm[move] = t + wtm_gen(wtm_tau(beta, -dE), wtm_uniform(seed, nd++, replica, call));
+        int64_t nb[SK_MAX];
+        int nn = sparse_neighbors(&X, move, nb);
+        for (int q = 0; q < nn; ++q) {
+            int64_t j = nb[q];
+            tm[j] = t + wtm_gen(wtm_tau(beta, sparse_delta_energy(&X, j)), wtm_uniform(seed, nd++, replica, call));
+        }
+        E += dE;
+        num_moves += 1;
+    }
+    if (stats) { stats[0] = num_moves; stats[1] = nsamp; stats[2] = E; }
+    if (t_out) *t_out = t;
+    free(tm); free(X.lfields); free(X.lfields_last);
+    return nsamp;
+}

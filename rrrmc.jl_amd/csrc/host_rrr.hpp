@@ -52,7 +52,7 @@ int32_t sk_rrr_mc_async(rrrmc_ctx* ctx, double beta, int64_t iters, int64_t step
     if (iters < 0) return fail(ctx, RRRMC_ERR_INVALID_ARG, "iters must be >= 0, given %lld", (long long)iters);
     if (step < 1) return fail(ctx, RRRMC_ERR_INVALID_ARG, "step must be >= 1, given %lld", (long long)step);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    ctx->results_valid = false;
+    ctx->results_valid = false; ctx->last_call_wtm = false;
     ctx->timing_valid = false;
     const int64_t N = ctx->N, Rp = ctx->Rpad;
     int levs = 0;
@@ -124,16 +124,16 @@ int32_t sparse_rrr_bkl_async(rrrmc_ctx* ctx, int mode, double beta, int64_t iter
     if (step < 1) return fail(ctx, RRRMC_ERR_INVALID_ARG, "step must be >= 1, given %lld", (long long)step);
     if (ctx->N > 65535) return fail(ctx, RRRMC_ERR_UNSUPPORTED, "N=%lld: the rrrMC kernel indexes spins with 16 bits", (long long)ctx->N);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    ctx->results_valid = false;
+    ctx->results_valid = false; ctx->last_call_wtm = false;
     ctx->timing_valid = false;
     const int64_t N = ctx->N, K = ctx->K, R = ctx->R, W = (N + 31) / 32;
     const int L = (int)(K / 2 + 1);                       // allΔE has K/2 + 1 levels for +-J couplings (RRG.jl:262-265)
-    if (!ctx->rp_spins) {
-        HIP_TRY(ctx, hipMalloc(&ctx->rp_spins, sizeof(uint32_t) * R * W));
+    if (!ctx->rp_spins) HIP_TRY(ctx, hipMalloc(&ctx->rp_spins, sizeof(uint32_t) * R * W));
+    if (!ctx->rp_cls) {
         HIP_TRY(ctx, hipMalloc(&ctx->rp_cls, (size_t)R * N));
         HIP_TRY(ctx, hipMalloc(&ctx->rp_sv, sizeof(uint16_t) * R * 2 * L * N));
         HIP_TRY(ctx, hipMalloc(&ctx->rp_spos, sizeof(uint16_t) * R * N));
-        HIP_TRY(ctx, hipMalloc(&ctx->q_stats, sizeof(int64_t) * R * 3));
+        if (!ctx->q_stats) HIP_TRY(ctx, hipMalloc(&ctx->q_stats, sizeof(int64_t) * R * 3));
     }
     ctx->stats_stride = 3;
     const int64_t nsamp = iters / step;
@@ -175,6 +175,68 @@ int32_t sparse_rrr_bkl_async(rrrmc_ctx* ctx, int mode, double beta, int64_t iter
     ctx->results_valid = true;
     ctx->timing_valid = true;
     ctx->last_call_rrr = true;
+    ctx->colored_call = false;
+    return RRRMC_OK;
+}
+
+// wtmMC (src/RRRMC.jl:376-426) on GraphRRG / GraphEA: thread-per-replica kernel with a binary heap of next-flip times
+int32_t sparse_wtm_async(rrrmc_ctx* ctx, double beta, int64_t samples, double step)
+{
+    if (samples < 0) return fail(ctx, RRRMC_ERR_INVALID_ARG, "samples must be >= 0, given %lld", (long long)samples);
+    if (!(step > 0.0) || !std::isfinite(step)) return fail(ctx, RRRMC_ERR_INVALID_ARG, "step must be positive and finite, given %g", step);
+    if (!std::isfinite(beta)) return fail(ctx, RRRMC_ERR_INVALID_ARG, "beta must be finite, given: %g", beta);
+    if (ctx->N > 65535) return fail(ctx, RRRMC_ERR_UNSUPPORTED, "N=%lld: the wtmMC kernel indexes spins with 16 bits", (long long)ctx->N);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    ctx->results_valid = false; ctx->last_call_wtm = false;
+    ctx->timing_valid = false;
+    const int64_t N = ctx->N, K = ctx->K, R = ctx->R, W = (N + 31) / 32;
+    if (!ctx->rp_spins) HIP_TRY(ctx, hipMalloc(&ctx->rp_spins, sizeof(uint32_t) * R * W));
+    if (!ctx->wt_t) {
+        HIP_TRY(ctx, hipMalloc(&ctx->wt_t, sizeof(double) * R * N));
+        HIP_TRY(ctx, hipMalloc(&ctx->wt_id, sizeof(uint16_t) * R * N));
+        HIP_TRY(ctx, hipMalloc(&ctx->wt_pos, sizeof(uint16_t) * R * N));
+        HIP_TRY(ctx, hipMalloc(&ctx->wt_time, sizeof(double) * R));
+    }
+    const size_t es_need = (size_t)(samples > 0 ? samples : 1) * ctx->Rpad;
+    if (es_need > ctx->Es_cap) {
+        free_dev(ctx->d_Es);
+        ctx->Es_cap = 0;
+        HIP_TRY(ctx, hipMalloc(&ctx->d_Es, sizeof(int32_t) * es_need));
+        ctx->Es_cap = es_need;
+    }
+    while (ctx->ev_sweep.size() < 2) {
+        hipEvent_t e;
+        HIP_TRY(ctx, hipEventCreate(&e));
+        ctx->ev_sweep.push_back(e);
+    }
+    WtmParams P{};
+    P.A = ctx->d_A; P.J = ctx->d_J; P.spins = ctx->rp_spins; P.ht = ctx->wt_t; P.hid = ctx->wt_id; P.hpos = ctx->wt_pos;
+    P.E_cur = ctx->d_E; P.acc_cur = ctx->d_acc; P.t_out = ctx->wt_time; P.Es = ctx->d_Es;
+    for (int64_t q = 0; q <= K; ++q) {            // tauDE = max(1, exp(beta dE)), WaitingTimes.jl:16
+        const double e = host_det_exp(beta * (double)(-2 * K + 4 * q));
+        P.tau[q] = e > 1.0 ? e : 1.0;
+    }
+    P.step = step / (double)N; P.samples = samples;
+    P.k0 = (uint32_t)ctx->seed; P.k1 = (uint32_t)(ctx->seed >> 32); P.replica0 = ctx->replica0; P.call = ctx->wtm_calls & 0xffffffu;
+    P.N = (int)N; P.K = (int)K; P.W = (int)W; P.R = (int)R; P.Rpad = (int)ctx->Rpad;
+    hipStream_t st = ctx->stream;
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_begin, st));
+    hipLaunchKernelGGL(rrsp_spins_in_kernel, dim3((unsigned)((W + 255) / 256), (unsigned)R), dim3(256), 0, st, ctx->d_spins, ctx->rp_spins, (int)N, (int)W, (int)R);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_sweep[0], st));
+    hipLaunchKernelGGL(wtm_sparse_kernel, dim3((unsigned)((R + kRrrThreads - 1) / kRrrThreads)), dim3(kRrrThreads), 0, st, P);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_sweep[1], st));
+    hipLaunchKernelGGL(rrsp_spins_out_kernel, dim3((unsigned)((N + 255) / 256), (unsigned)ctx->G), dim3(256), 0, st, ctx->rp_spins, ctx->d_spins, (int)N, (int)W, (int)R);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_end, st));
+    ctx->wtm_calls += 1;
+    ctx->sweep_launches = 1;
+    ctx->nsamp = samples;
+    ctx->results_valid = true;
+    ctx->timing_valid = true;
+    ctx->last_call_rrr = false;
+    ctx->last_call_wtm = true;
     ctx->colored_call = false;
     return RRRMC_OK;
 }

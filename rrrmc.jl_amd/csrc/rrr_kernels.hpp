@@ -757,6 +757,147 @@ __global__ __launch_bounds__(kRrrThreads) void rrr_sparse_kernel(RrrSparseParams
     P.stats[(size_t)r * 3] = accepted; P.stats[(size_t)r * 3 + 1] = staged_its; P.stats[(size_t)r * 3 + 2] = itdone;
 }
 
+// ---------------------------------------------------------------------------------------------------
+// wtmMC — waiting-time method (src/RRRMC.jl:376-426, src/WaitingTimes.jl) on GraphRRG / GraphEA: SURVEY.md §8(f) rank 4.
+// One thread per replica; the reference's MutableBinaryMinHeap becomes a binary min-heap per replica in HBM/L2, ordered by
+// (time, site) — only "top = smallest time" is observable.  WTM stream: uniform n of replica r in call c is the 53-bit word
+// (n & 1) of ctr = (lo(n >> 1), hi(n >> 1), r, TAG_WTM | c << 8).
+// ---------------------------------------------------------------------------------------------------
+constexpr uint32_t TAG_WTM = 11;
+struct WtmParams {
+    const int32_t* A;        // [N][K]
+    const int8_t* J;         // [N][K]
+    uint32_t* spins;         // [R][W]   replica-contiguous words
+    double* ht;              // [R][N]   heap keys (next-flip times) by heap position
+    uint16_t* hid;           // [R][N]   site at heap position
+    uint16_t* hpos;          // [R][N]   heap position of site
+    int32_t* E_cur;          // [Rpad]
+    int64_t* acc_cur;        // [Rpad]   num_moves
+    double* t_out;           // [R]      final global time
+    int32_t* Es;             // [samples][Rpad]
+    double tau[8];           // max(1, exp(beta dE)), dE = -2K + 4 q, K <= 7
+    double step;             // already divided by N
+    int64_t samples;
+    uint32_t k0, k1, replica0, call;
+    int N, K, W, R, Rpad;
+};
+
+struct WtmChain {
+    const WtmParams* P;
+    uint32_t* sp; double* ht; uint16_t* hid; uint16_t* hpos;
+    uint32_t rep;
+    uint64_t nd;
+    __device__ __forceinline__ int sbit(int x) const { return (int)((sp[x >> 5] >> (x & 31)) & 1u); }
+    __device__ __forceinline__ void sflip(int x) { sp[x >> 5] ^= 1u << (x & 31); }
+    __device__ __forceinline__ int dE(int i) const
+    {
+        const int si = sbit(i);
+        int acc = 0;
+        for (int q = 0; q < P->K; ++q) {
+            const int sy = sbit(P->A[(size_t)i * P->K + q]);
+            acc += (si == sy) ? (int)P->J[(size_t)i * P->K + q] : -(int)P->J[(size_t)i * P->K + q];
+        }
+        return 2 * acc;
+    }
+    __device__ __forceinline__ double uniform()
+    {
+        const uint64_t n = nd++, blk = n >> 1;
+        const Philox4 o = philox4x32_10((uint32_t)blk, (uint32_t)(blk >> 32), rep, TAG_WTM | (P->call << 8), P->k0, P->k1);
+        const uint64_t u = (n & 1u) ? (((uint64_t)o.w[2] << 32) | o.w[3]) : (((uint64_t)o.w[0] << 32) | o.w[1]);
+        return (double)(u >> 11) * 0x1.0p-53;
+    }
+    // gen_wt(tau) = -tau * log1p(-rand()), tau = tauDE(dE): WaitingTimes.jl:16-22
+    __device__ __forceinline__ double gen_wt(int d) { return -P->tau[(d + 2 * P->K) / 4] * det_log1p(-uniform()); }
+    __device__ __forceinline__ bool before(double ta, int a, double tb, int b) const { return ta < tb || (ta == tb && a < b); }
+    __device__ void sift_down(int pos, int n)
+    {
+        const double t = ht[pos];
+        const int id = hid[pos];
+        for (;;) {
+            int c = 2 * pos + 1;
+            if (c >= n) break;
+            if (c + 1 < n && before(ht[c + 1], hid[c + 1], ht[c], hid[c])) c += 1;
+            if (!before(ht[c], hid[c], t, id)) break;
+            ht[pos] = ht[c]; hid[pos] = hid[c]; hpos[hid[c]] = (uint16_t)pos;
+            pos = c;
+        }
+        ht[pos] = t; hid[pos] = (uint16_t)id; hpos[id] = (uint16_t)pos;
+    }
+    __device__ void sift_up(int pos)
+    {
+        const double t = ht[pos];
+        const int id = hid[pos];
+        while (pos > 0) {
+            const int par = (pos - 1) >> 1;
+            if (!before(t, id, ht[par], hid[par])) break;
+            ht[pos] = ht[par]; hid[pos] = hid[par]; hpos[hid[par]] = (uint16_t)pos;
+            pos = par;
+        }
+        ht[pos] = t; hid[pos] = (uint16_t)id; hpos[id] = (uint16_t)pos;
+    }
+    __device__ __forceinline__ void update(int i, double t)     // update!(theap, i, t)
+    {
+        const int pos = hpos[i];
+        const double old = ht[pos];
+        ht[pos] = t;
+        if (t < old) sift_up(pos); else sift_down(pos, P->N);
+    }
+};
+
+__global__ __launch_bounds__(kRrrThreads) void wtm_sparse_kernel(WtmParams P)
+{
+    const int r = blockIdx.x * kRrrThreads + threadIdx.x;
+    if (r >= P.R) return;
+    const int N = P.N;
+    WtmChain c;
+    c.P = &P;
+    c.sp = P.spins + (size_t)r * P.W; c.ht = P.ht + (size_t)r * N; c.hid = P.hid + (size_t)r * N; c.hpos = P.hpos + (size_t)r * N;
+    c.rep = P.replica0 + (uint32_t)r;
+    c.nd = 0;
+    // E = energy(X, C); theap = THeap(X, C, beta): one waiting time per spin, in site order (WaitingTimes.jl:26-36)
+    long long n = 0;
+    for (int i = 0; i < N; ++i) {
+        const int d = c.dE(i);
+        n -= d / 2;
+        c.ht[i] = c.gen_wt(d);
+        c.hid[i] = (uint16_t)i;
+        c.hpos[i] = (uint16_t)i;
+    }
+    for (int pos = N / 2 - 1; pos >= 0; --pos) c.sift_down(pos, N);
+    long long E = n / 2;
+    const double step = P.step, tmax = step * (double)P.samples;
+    double t = 0.0, nextstep = step;
+    long long moves = 0, ns = 0;
+    bool out = false;
+    while (t < tmax && !out) {
+        const double tp = c.ht[0];                  // pick_next
+        const int move = c.hid[0];
+        while (tp >= nextstep) {
+            P.Es[(size_t)ns * P.Rpad + r] = (int32_t)E; ns += 1;
+            nextstep += step;
+            if (nextstep > tmax + 1e-10) { out = true; break; }
+        }
+        if (out) break;
+        t = tp;
+        // update_heap!: WaitingTimes.jl:40-52
+        const int d = c.dE(move);
+        c.sflip(move);
+        c.update(move, t + c.gen_wt(-d));
+        const int32_t* Ax = P.A + (size_t)move * P.K;
+        for (int q = 0; q < P.K; ++q) {
+            if (q > 0 && Ax[q] == Ax[q - 1]) continue;        // uA: repeats removed (EA.jl:158)
+            const int j = Ax[q];
+            c.update(j, t + c.gen_wt(c.dE(j)));
+        }
+        E += d;
+        moves += 1;
+    }
+    for (; ns < P.samples; ++ns) P.Es[(size_t)ns * P.Rpad + r] = (int32_t)E;     // not reached: the loop always emits `samples` samples
+    P.E_cur[r] = (int32_t)E;
+    P.acc_cur[r] = moves;
+    P.t_out[r] = t;
+}
+
 // bit-sliced [G][N] words (bit = replica & 31)  <->  replica-contiguous [R][W] words (bit = site & 31)
 __global__ __launch_bounds__(256) void rrsp_spins_in_kernel(const uint32_t* __restrict__ bs, uint32_t* __restrict__ spins, int N, int W, int R)
 {

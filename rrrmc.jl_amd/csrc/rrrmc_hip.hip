@@ -122,6 +122,13 @@ struct rrrmc_ctx {
     uint8_t* rp_cls = nullptr;
     uint16_t* rp_sv = nullptr;
     uint16_t* rp_spos = nullptr;
+    // ---- wtmMC on RRRMC_MODEL_SPARSE_PM1 (allocated on first use) ----
+    double* wt_t = nullptr;        // [R][N] heap keys
+    uint16_t* wt_id = nullptr;
+    uint16_t* wt_pos = nullptr;
+    double* wt_time = nullptr;     // [R] final global time of the last call
+    uint32_t wtm_calls = 0;        // wtmMC calls since the last rrrmc_seed (part of the WTM stream address)
+    bool last_call_wtm = false;
     // ---- rrrMC(SingleGraph) on RRRMC_MODEL_SK_NORMAL: DeltaECacheCont + DynamicSampler state (allocated on first use) ----
     double* rs_buf = nullptr;      // lfA, lfB, v, ps, dEs, st_dE, st_p, z_out
     uint32_t* rs_spins = nullptr;
@@ -379,6 +386,7 @@ void rrrmc_ctx_destroy(rrrmc_ctx* ctx)
     free_dev(ctx->rp_spins); free_dev(ctx->rp_cls); free_dev(ctx->rp_sv); free_dev(ctx->rp_spos);
     free_dev(ctx->pf_J); free_dev(ctx->pf_spins); free_dev(ctx->pf_undo); free_dev(ctx->pf_sites);
     free_dev(ctx->db_dJ); free_dev(ctx->db_rJ); free_dev(ctx->db_cls); free_dev(ctx->db_sv); free_dev(ctx->db_spos); free_dev(ctx->db_lf); free_dev(ctx->db_undo);
+    free_dev(ctx->wt_t); free_dev(ctx->wt_id); free_dev(ctx->wt_pos); free_dev(ctx->wt_time);
     free_dev(ctx->snap); free_dev(ctx->d_pairs); free_dev(ctx->d_ovl); free_dev(ctx->d_qobs);
     for (int i = 0; i < 2; ++i) { free_dev(ctx->d_slots[i]); free_dev(ctx->d_vecs[i]); }
     if (ctx->plan_stream) { (void)hipStreamSynchronize(ctx->plan_stream); (void)hipStreamDestroy(ctx->plan_stream); }
@@ -445,6 +453,7 @@ int32_t rrrmc_seed(rrrmc_ctx* ctx, uint64_t seed)
     ctx->seeded = true;
     ctx->it_done = 0;
     ctx->sweeps_done = 0;
+    ctx->wtm_calls = 0;
     return RRRMC_OK;
 }
 
@@ -683,7 +692,7 @@ int32_t rrrmc_standard_mc_async(rrrmc_ctx* ctx, double beta, int64_t iters, int6
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const int64_t N = ctx->N, K = ctx->K;
     const int C = ctx->C;
-    ctx->results_valid = false;
+    ctx->results_valid = false; ctx->last_call_wtm = false;
     ctx->timing_valid = false;
 
     // thresholds for the classes with dE > 0: class n (unsatisfied bonds) has dE = 2 (K - 2n)
@@ -956,7 +965,7 @@ int32_t rrrmc_colored_sweeps_async(rrrmc_ctx* ctx, double beta, int64_t sweeps, 
     if (step < 1) return fail(ctx, RRRMC_ERR_INVALID_ARG, "step must be >= 1, given %lld", (long long)step);
     if (std::isnan(beta)) return fail(ctx, RRRMC_ERR_INVALID_ARG, "beta is NaN");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    ctx->results_valid = false;
+    ctx->results_valid = false; ctx->last_call_wtm = false;
     ctx->timing_valid = false;
     const int64_t K = ctx->K, nsamp = sweeps / step;
     const size_t es_need = (size_t)(nsamp > 0 ? nsamp : 1) * ctx->Rpad;
@@ -1077,7 +1086,7 @@ int32_t rrrmc_rrr_mc_async(rrrmc_ctx* ctx, double beta, double fourK, int64_t it
     if (iters < 0) return fail(ctx, RRRMC_ERR_INVALID_ARG, "iters must be >= 0, given %lld", (long long)iters);
     if (step < 1) return fail(ctx, RRRMC_ERR_INVALID_ARG, "step must be >= 1, given %lld", (long long)step);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    ctx->results_valid = false;
+    ctx->results_valid = false; ctx->last_call_wtm = false;
     ctx->timing_valid = false;
     const int64_t nsamp = iters / step;
     const size_t es_need = (size_t)(nsamp > 0 ? nsamp : 1) * ctx->R;
@@ -1133,6 +1142,25 @@ int32_t rrrmc_quant_set_field(rrrmc_ctx* ctx, double beta, double fourK)
     if (!(fourK > 0.0) || !std::isfinite(fourK) || !std::isfinite(beta)) return fail(ctx, RRRMC_ERR_INVALID_ARG, "beta and fourK must be finite, fourK > 0");
     ctx->last_beta = beta;
     ctx->last_fourK = fourK;
+    return RRRMC_OK;
+}
+
+int32_t rrrmc_wtm_mc_async(rrrmc_ctx* ctx, double beta, int64_t samples, double step)
+{
+    int32_t rc = ensure_state(ctx, true);
+    if (rc) return rc;
+    if (ctx->model != RRRMC_MODEL_SPARSE_PM1) return fail(ctx, RRRMC_ERR_UNSUPPORTED, "wtmMC is wired for RRRMC_MODEL_SPARSE_PM1");
+    return sparse_wtm_async(ctx, beta, samples, step);
+}
+
+int32_t rrrmc_wtm_times(rrrmc_ctx* ctx, double* t_out)
+{
+    if (!ctx) return RRRMC_ERR_INVALID_ARG;
+    if (!ctx->last_call_wtm || !ctx->results_valid) return fail(ctx, RRRMC_ERR_STATE, "no wtmMC call has been made");
+    if (!t_out) return fail(ctx, RRRMC_ERR_INVALID_ARG, "t_out is NULL");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipMemcpy(t_out, ctx->wt_time, sizeof(double) * ctx->R, hipMemcpyDeviceToHost));
     return RRRMC_OK;
 }
 

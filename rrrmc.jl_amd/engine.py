@@ -160,6 +160,16 @@ class Engine:
         self.sync()
         return self.fetch_results()
 
+    def wtm_mc(self, beta, samples, step=1.0):
+        """wtmMC(X, β, samples; step) (src/RRRMC.jl:376-426).  Returns (Es[R, samples], num_moves[R], global_time[R])."""
+        check(lib().rrrmc_wtm_mc_async(self._ctx, float(beta), int(samples), float(step)), self._ctx)
+        self._last = (int(samples), 1)
+        self.sync()
+        Es, moves = self.fetch_results()
+        t = np.zeros(self.R)
+        check(lib().rrrmc_wtm_times(self._ctx, t), self._ctx)
+        return Es, moves, t
+
     def rrr_cache(self):
         """(pos[R, N], sizes[R, 4]) of the DeltaECache after the last rrrMC call."""
         pos = np.zeros((self.R, self.X.N), np.int8)
@@ -259,6 +269,31 @@ def bklMC(X, beta, iters, *, seed=DEFAULT_SEED, step=1, C0=None, quiet=False, re
             print("samples = ", Es.shape[1])
             print("accept rate = ", float(moves.mean()) / max(iters, 1))
             print("true it = ", float(moves.mean()))
+        return Es, Cfg
+    finally:
+        if own:
+            eng.close()
+
+
+def wtmMC(X, beta, samples, *, seed=DEFAULT_SEED, step=1.0, C0=None, quiet=False, replicas=None, device=0, replica0=0, engine=None):
+    """``wtmMC(X, β, samples; seed, step, C0, quiet)`` (src/RRRMC.jl:376-426) for a batch of replicas of a GraphRRG / GraphEA."""
+    own = engine is None
+    R = replicas if replicas is not None else (C0.R if C0 is not None else (engine.R if engine else 1))
+    eng = engine if engine is not None else Engine(X, R, device=device, replica0=replica0)
+    try:
+        if seed > 0 or own:
+            eng.seed(seed if seed > 0 else 0)
+        if C0 is not None:
+            eng.set_config(C0)
+        elif own:
+            eng.init_spins_random()
+        Es, moves, t = eng.wtm_mc(beta, samples, step)
+        Cfg = eng.get_config(C0 if C0 is not None else None)
+        if not quiet:
+            print("samples = ", Es.shape[1])
+            print("num_moves = ", float(moves.mean()))
+            print("global time = ", float(t.mean()))
+            print("ratio = ", float(t.mean()) / max(float(moves.mean()), 1.0))
         return Es, Cfg
     finally:
         if own:

@@ -235,3 +235,36 @@ def test_double_graph_tracked_energy(oracle, kind, form, lev, thr):
         assert abs(Es[k] - oracle.dbl_energy(A, dJ, rJ, ch_k, form=form)) < 1e-9
     # the double graph's energy is the energy of the undiscretized Gaussian model
     assert abs(oracle.dbl_energy(A, dJ, rJ, ch_n, form=form) - oracle.spf_energy(A, cJ, ch_n, form=form)) < 1e-9
+
+
+# ---- wtmMC (waiting-time method) on GraphRRG / GraphEA ----
+
+@pytest.mark.parametrize("kind,form", [("rrg", "rrg"), ("ea2L2", "ea")])
+def test_wtm_tracked_energy_and_sampling_times(oracle, kind, form):
+    seed = 31
+    A = oracle.gen_rrg(20, 3, seed) if kind == "rrg" else oracle.gen_ea(2, 3)
+    J = oracle.gen_couplings(A, seed)
+    N = A.shape[0]
+    ch = oracle.init_config(seed, 0, N)
+    Es, ch1, moves, t, Ef = oracle.wtm_mc_sparse(A, J, 1.2, 400, 1.0, seed, ch, form=form)
+    assert len(Es) == 400 and moves > 0
+    assert t < 400 / N + 1e-9                                   # global time: `samples` steps of 1/N sweeps (RRRMC.jl:391-393)
+    assert Ef == oracle.sparse_energy(A, J, ch1)                # tracked energy == energy(X, C): test/runtests.jl:12-20
+    # a different call index draws different waiting times
+    Es2, *_ = oracle.wtm_mc_sparse(A, J, 1.2, 400, 1.0, seed, ch, call=1, form=form)
+    assert (Es2 != Es).any()
+
+
+def test_wtm_equilibrium_matches_metropolis(oracle):
+    """The waiting-time method samples the same Boltzmann law as Metropolis: compare the time-averaged energy (loose, statistical)."""
+    seed, N, beta = 7, 16, 0.8
+    A = oracle.gen_rrg(N, 3, seed)
+    J = oracle.gen_couplings(A, seed)
+    e_wtm, e_met = [], []
+    for r in range(20):
+        ch = oracle.init_config(seed, r, N)
+        Es, *_ = oracle.wtm_mc_sparse(A, J, beta, 40000, 1.0, seed, ch, replica=r)
+        e_wtm.append(Es[4000:].mean())
+        Em, *_ = oracle.standard_mc_sparse(A, J, beta, 40000, 1, seed, ch, replica=r)
+        e_met.append(Em[4000:].mean())
+    assert abs(np.mean(e_wtm) - np.mean(e_met)) < 0.35           # both ~ -11; the spread of a 20-chain mean is ~0.1
