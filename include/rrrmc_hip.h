@@ -179,6 +179,13 @@ RRRMC_API int32_t rrrmc_bkl_mc_async(rrrmc_ctx *ctx, double beta, int64_t iters,
  * of every replica ("global time", RRRMC.jl:421). */
 RRRMC_API int32_t rrrmc_wtm_mc_async(rrrmc_ctx *ctx, double beta, int64_t samples, double step);
 RRRMC_API int32_t rrrmc_wtm_times(rrrmc_ctx *ctx, double *t_out);
+/* extremal_opt(X, tau, iters; step) (src/RRRMC.jl:474-521) on RRRMC_MODEL_SPARSE_PM1, EOCache{Int,L} (src/DeltaE.jl:412-555).
+ *   ftau[N] = cumsum(j^-tau, j = 1..N), computed by the caller as the reference does at DeltaE.jl:444-445.
+ * rrrmc_sync + rrrmc_fetch_results return the energies the hook would see (E at iterations k*step, before the move; `accepted`
+ * is not meaningful); rrrmc_extremal_opt_results returns Emin[R], Cmin (R x ceil(N/64) chunks) and itmin[R]; the final
+ * configuration is read with rrrmc_get_spins. */
+RRRMC_API int32_t rrrmc_extremal_opt_async(rrrmc_ctx *ctx, const double *ftau, int64_t iters, int64_t step);
+RRRMC_API int32_t rrrmc_extremal_opt_results(rrrmc_ctx *ctx, int64_t *Emin_out, uint64_t *Cmin_chunks, int64_t *itmin_out);
 /* parity/debug view of the move-selection cache after the last rrrMC call: pos_out[R * N] = class of every spin
  * (DeltaECache.pos, 0-based a + 2*up), sizes_out[R * 4] = |class k| (DeltaE.jl:63-73). */
 RRRMC_API int32_t rrrmc_rrr_cache(rrrmc_ctx *ctx, int8_t *pos_out, int32_t *sizes_out);

@@ -544,3 +544,27 @@ def wtm_mc_sparse(A, J, beta, samples, step, seed, chunks, call=0, replica=0, fo
     n = L.orc_wtm_mc_sparse(1 if form == "ea" else 0, N, K, A, np.ascontiguousarray(J, np.int32), float(beta), int(samples), float(step),
                             seed, call, replica, ch, Es, stats, C.byref(t))
     return Es[:n], ch, int(stats[0]), t.value, int(stats[2])
+
+
+def eo_ftau(N, tau):
+    """cumsum([j^(-tau) for j = 1:N]) (DeltaE.jl:444): the rank-probability table, an INPUT of both oracle and device."""
+    return np.cumsum(np.arange(1, int(N) + 1, dtype=np.float64) ** (-float(tau)))
+
+
+def extremal_opt_sparse(A, J, tau, iters, step, seed, chunks, it0=0, replica=0, form="rrg"):
+    """extremal_opt (RRRMC.jl:474-521) on GraphRRG / GraphEA; returns (Es, final chunks, Emin, Cmin chunks, itmin)."""
+    L = lib()
+    L.orc_extremal_opt_sparse.restype = C.c_int64
+    L.orc_extremal_opt_sparse.argtypes = [C.c_int, C.c_int64, C.c_int64, i32p, i32p, f64p, C.c_int64, C.c_int64, C.c_uint64, C.c_uint64,
+                                          C.c_uint32, u64p, i64p, C.POINTER(C.c_int64), u64p, C.POINTER(C.c_int64)]
+    A = np.ascontiguousarray(A, np.int32)
+    N, K = A.shape
+    ch = np.array(chunks, np.uint64, copy=True)
+    Es = np.zeros(max(iters // step, 1), np.int64)
+    Cmin = np.zeros_like(ch)
+    Emin, itmin = C.c_int64(0), C.c_int64(0)
+    n = L.orc_extremal_opt_sparse(1 if form == "ea" else 0, N, K, A, np.ascontiguousarray(J, np.int32), eo_ftau(N, tau), int(iters),
+                                  int(step), seed, it0, replica, ch, Es, C.byref(Emin), Cmin, C.byref(itmin))
+    if n < 0:
+        raise RuntimeError("extremal_opt_sparse: inconsistent cache / energy")
+    return Es[:n], ch, Emin.value, Cmin, itmin.value

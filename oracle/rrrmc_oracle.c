@@ -1824,3 +1824,91 @@ ORC_API int64_t orc_wtm_mc_sparse(int form, int64_t N, int64_t K, const int32_t 
     free(tm); free(X.lfields); free(X.lfields_last);
     return nsamp;
 }
+
+/* =============================================================================================
+ * extremal_opt (tau-EO; src/RRRMC.jl:474-521) on the DiscrGraphs GraphRRG / GraphEA with EOCache{Int,L} (src/DeltaE.jl:412-555).
+ * SURVEY.md §8f rank 4.  Spins are ranked by dE (classes of equal dE, ArraySets as in DeltaECache); a rank i is drawn with
+ * probability ~ i^-tau from the cumulative table ftau[i] = sum_{j<=i} j^-tau (computed by the caller: DeltaE.jl:444-445), the class
+ * holding that rank is found and a uniform member of it flips — always.  RRR stream sub 3: words 0,1 -> rand() of `r`, words 2,3 ->
+ * the member index.  Returns the samples (E at iterations k*step, before the move: the hook's argument), Emin, Cmin, itmin.
+ * ============================================================================================= */
+typedef struct {
+    int64_t N;
+    int L, has_zero, K2;
+    int64_t dElist[SL_MAX];
+    aset_t as[2 * SL_MAX];
+    int8_t *pos;
+} eoc_t;
+static inline int eoc_findks(const eoc_t *c, int64_t dE)                                   /* findks: DeltaE.jl:412-421 (0-based class) */
+{
+    int64_t a = dE < 0 ? -dE : dE;
+    int ak = 0;
+    for (int k = 0; k < c->L; ++k) if (c->dElist[k] == a) ak = k + 1;
+    return (dE >= 0 ? ak + c->L - c->has_zero : c->L + 1 - ak) - 1;
+}
+
+ORC_API int64_t orc_extremal_opt_sparse(int form, int64_t N, int64_t K, const int32_t *A, const int32_t *J, const double *ftau,
+                                        int64_t iters, int64_t step, uint64_t seed, uint64_t it0, uint32_t replica,
+                                        uint64_t *chunks, int64_t *Es, int64_t *Emin_out, uint64_t *Cmin, int64_t *itmin_out)
+{
+    sparse_t X = {N, K, A, J, NULL, NULL, -1, form};
+    X.lfields = (int64_t *)malloc((size_t)N * 8);
+    X.lfields_last = (int64_t *)malloc((size_t)N * 8);
+    const int64_t nch = (N + 63) / 64;
+    int64_t E = sparse_energy(&X, chunks), Emin = E, itmin = 0;
+    memcpy(Cmin, chunks, (size_t)nch * 8);
+    eoc_t c;
+    memset(&c, 0, sizeof c);
+    c.N = N;
+    int64_t tmp[SK_MAX + 1];
+    c.L = (int)orc_all_delta_e_pm1(K, tmp);
+    for (int k = 0; k < c.L; ++k) c.dElist[k] = tmp[k];
+    c.has_zero = c.dElist[0] == 0;
+    c.K2 = 2 * c.L - c.has_zero;
+    for (int k = 0; k < c.K2; ++k) aset_init(&c.as[k], N);
+    c.pos = (int8_t *)calloc((size_t)N, 1);
+    for (int64_t i = 0; i < N; ++i) {                                     /* EOCache: DeltaE.jl:431-448 */
+        int k = eoc_findks(&c, sparse_delta_energy(&X, i));
+        c.pos[i] = (int8_t)k;
+        aset_push(&c.as[k], (int32_t)i);
+    }
+    const double z = ftau[N - 1];
+    int64_t nsamp = 0;
+    for (int64_t it = 1; it <= iters; ++it) {
+        if (it % step == 0) Es[nsamp++] = E;
+        const uint64_t g = it0 + (uint64_t)it;
+        uint32_t w[4];
+        rrr_draw(seed, g, replica, 3, w);
+        /* rand_move: DeltaE.jl:473-507 */
+        const double r = (1 - u53_of(w[0], w[1])) * z;
+        int64_t lo = 0, hi = N;                                           /* searchsortedfirst(ftau, r): first index with ftau >= r */
+        while (lo < hi) { int64_t mid = (lo + hi) >> 1; if (ftau[mid] < r) lo = mid + 1; else hi = mid; }
+        int64_t rank = lo + 1;
+        if (rank > N) rank = N;
+        int k = -1;
+        int64_t t = 0;
+        while (rank > t) { k += 1; t += c.as[k].t; }
+        const int64_t dE = k < c.L ? -c.dElist[c.L - 1 - k] : c.dElist[k - c.L + c.has_zero];
+        const uint64_t u = ((uint64_t)w[2] << 32) | w[3];
+        const int64_t move = c.as[k].v[(int64_t)orc_mulhi64(u, (uint64_t)c.as[k].t)];
+        /* apply_move!: DeltaE.jl:509-541 */
+        sparse_spinflip(&X, chunks, move);
+        int64_t nb[SK_MAX];
+        int nn = sparse_neighbors(&X, move, nb);
+        for (int q = 0; q <= nn; ++q) {
+            int32_t j = (int32_t)(q < nn ? nb[q] : move);
+            int k0 = c.pos[j], k1 = eoc_findks(&c, sparse_delta_energy(&X, j));
+            if (k0 == k1) continue;
+            aset_delete(&c.as[k0], j); aset_push(&c.as[k1], j); c.pos[j] = (int8_t)k1;
+        }
+        E += dE;
+        if (E < Emin) { Emin = E; memcpy(Cmin, chunks, (size_t)nch * 8); itmin = it; }
+    }
+    int ok = E == sparse_energy(&X, chunks);                              /* tracked energy == energy(X, C) */
+    for (int64_t i = 0; i < N && ok; ++i) ok = eoc_findks(&c, sparse_delta_energy(&X, i)) == c.pos[i];
+    if (Emin_out) *Emin_out = Emin;
+    if (itmin_out) *itmin_out = itmin;
+    for (int k = 0; k < c.K2; ++k) aset_free(&c.as[k]);
+    free(c.pos); free(X.lfields); free(X.lfields_last);
+    return ok ? nsamp : -1;
+}

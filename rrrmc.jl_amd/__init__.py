@@ -7,9 +7,9 @@ gfx950 library ``lib/librrrmc_hip.so`` through the C ABI of ``include/rrrmc_hip.
 """
 from ._lib import RRRMCError, SYMBOLS, lib  # noqa: F401
 from .graphs import Config, GraphEA, GraphEANormal, GraphEANormalDiscretized, GraphQuant, GraphRRG, GraphRRGNormal, GraphRRGNormalDiscretized, GraphSK, GraphSKNormal, all_delta_e, checkerboard_coloring, getN, neighbors  # noqa: F401
-from .engine import Engine, bklMC, rrrMC, standardMC, wtmMC  # noqa: F401
+from .engine import Engine, bklMC, extremal_opt, rrrMC, standardMC, wtmMC  # noqa: F401
 from .observables import SnapshotLog, bitmatrix_chunks, get_ts_range, log_range, parseovs, parsets  # noqa: F401
 from .sharding import gather_replica_major, shard_bounds  # noqa: F401
 
-__all__ = ["Config", "GraphRRG", "GraphEA", "GraphSKNormal", "GraphSK", "GraphRRGNormal", "GraphEANormal", "GraphRRGNormalDiscretized", "GraphEANormalDiscretized", "GraphQuant", "rrrMC", "bklMC", "wtmMC", "checkerboard_coloring", "Engine", "standardMC", "RRRMCError", "getN", "neighbors", "all_delta_e",
+__all__ = ["Config", "GraphRRG", "GraphEA", "GraphSKNormal", "GraphSK", "GraphRRGNormal", "GraphEANormal", "GraphRRGNormalDiscretized", "GraphEANormalDiscretized", "GraphQuant", "rrrMC", "bklMC", "wtmMC", "extremal_opt", "checkerboard_coloring", "Engine", "standardMC", "RRRMCError", "getN", "neighbors", "all_delta_e",
            "shard_bounds", "gather_replica_major", "SnapshotLog", "parseovs", "parsets", "log_range", "get_ts_range", "bitmatrix_chunks"]

@@ -75,7 +75,7 @@ int32_t dbl_rrr_mc_async(rrrmc_ctx* ctx, double beta, int64_t iters, int64_t ste
     if (iters < 0) return fail(ctx, RRRMC_ERR_INVALID_ARG, "iters must be >= 0, given %lld", (long long)iters);
     if (step < 1) return fail(ctx, RRRMC_ERR_INVALID_ARG, "step must be >= 1, given %lld", (long long)step);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    ctx->results_valid = false; ctx->last_call_wtm = false;
+    ctx->results_valid = false; ctx->last_call_wtm = false; ctx->last_call_eo = false;
     ctx->timing_valid = false;
     const int64_t nsamp = iters / step;
     const size_t es_need = (size_t)(nsamp > 0 ? nsamp : 1) * ctx->R;

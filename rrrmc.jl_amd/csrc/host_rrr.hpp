@@ -52,7 +52,7 @@ int32_t sk_rrr_mc_async(rrrmc_ctx* ctx, double beta, int64_t iters, int64_t step
     if (iters < 0) return fail(ctx, RRRMC_ERR_INVALID_ARG, "iters must be >= 0, given %lld", (long long)iters);
     if (step < 1) return fail(ctx, RRRMC_ERR_INVALID_ARG, "step must be >= 1, given %lld", (long long)step);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    ctx->results_valid = false; ctx->last_call_wtm = false;
+    ctx->results_valid = false; ctx->last_call_wtm = false; ctx->last_call_eo = false;
     ctx->timing_valid = false;
     const int64_t N = ctx->N, Rp = ctx->Rpad;
     int levs = 0;
@@ -124,7 +124,7 @@ int32_t sparse_rrr_bkl_async(rrrmc_ctx* ctx, int mode, double beta, int64_t iter
     if (step < 1) return fail(ctx, RRRMC_ERR_INVALID_ARG, "step must be >= 1, given %lld", (long long)step);
     if (ctx->N > 65535) return fail(ctx, RRRMC_ERR_UNSUPPORTED, "N=%lld: the rrrMC kernel indexes spins with 16 bits", (long long)ctx->N);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    ctx->results_valid = false; ctx->last_call_wtm = false;
+    ctx->results_valid = false; ctx->last_call_wtm = false; ctx->last_call_eo = false;
     ctx->timing_valid = false;
     const int64_t N = ctx->N, K = ctx->K, R = ctx->R, W = (N + 31) / 32;
     const int L = (int)(K / 2 + 1);                       // allΔE has K/2 + 1 levels for +-J couplings (RRG.jl:262-265)
@@ -187,7 +187,7 @@ int32_t sparse_wtm_async(rrrmc_ctx* ctx, double beta, int64_t samples, double st
     if (!std::isfinite(beta)) return fail(ctx, RRRMC_ERR_INVALID_ARG, "beta must be finite, given: %g", beta);
     if (ctx->N > 65535) return fail(ctx, RRRMC_ERR_UNSUPPORTED, "N=%lld: the wtmMC kernel indexes spins with 16 bits", (long long)ctx->N);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    ctx->results_valid = false; ctx->last_call_wtm = false;
+    ctx->results_valid = false; ctx->last_call_wtm = false; ctx->last_call_eo = false;
     ctx->timing_valid = false;
     const int64_t N = ctx->N, K = ctx->K, R = ctx->R, W = (N + 31) / 32;
     if (!ctx->rp_spins) HIP_TRY(ctx, hipMalloc(&ctx->rp_spins, sizeof(uint32_t) * R * W));
@@ -237,6 +237,77 @@ int32_t sparse_wtm_async(rrrmc_ctx* ctx, double beta, int64_t samples, double st
     ctx->timing_valid = true;
     ctx->last_call_rrr = false;
     ctx->last_call_wtm = true;
+    ctx->colored_call = false;
+    return RRRMC_OK;
+}
+
+// extremal_opt (src/RRRMC.jl:474-521) on GraphRRG / GraphEA: thread-per-replica kernel over the rrrMC class arrays
+int32_t sparse_eo_async(rrrmc_ctx* ctx, const double* ftau, int64_t iters, int64_t step)
+{
+    if (iters < 0) return fail(ctx, RRRMC_ERR_INVALID_ARG, "iters must be >= 0, given %lld", (long long)iters);
+    if (step < 1) return fail(ctx, RRRMC_ERR_INVALID_ARG, "step must be >= 1, given %lld", (long long)step);
+    if (!ftau) return fail(ctx, RRRMC_ERR_INVALID_ARG, "ftau is NULL");
+    if (ctx->N > 65535) return fail(ctx, RRRMC_ERR_UNSUPPORTED, "N=%lld: the extremal_opt kernel indexes spins with 16 bits", (long long)ctx->N);
+    const int64_t N = ctx->N, K = ctx->K, R = ctx->R, W = (N + 31) / 32;
+    for (int64_t i = 0; i < N; ++i)
+        if (!(ftau[i] > 0.0) || !std::isfinite(ftau[i]) || (i && ftau[i] < ftau[i - 1]))
+            return fail(ctx, RRRMC_ERR_INVALID_ARG, "ftau must be a positive non-decreasing table (cumsum of j^-tau), violated at %lld", (long long)i);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    ctx->results_valid = false; ctx->last_call_wtm = false; ctx->last_call_eo = false;
+    ctx->timing_valid = false;
+    const int L = (int)(K / 2 + 1);
+    if (!ctx->rp_spins) HIP_TRY(ctx, hipMalloc(&ctx->rp_spins, sizeof(uint32_t) * R * W));
+    if (!ctx->rp_cls) {
+        HIP_TRY(ctx, hipMalloc(&ctx->rp_cls, (size_t)R * N));
+        HIP_TRY(ctx, hipMalloc(&ctx->rp_sv, sizeof(uint16_t) * R * 2 * L * N));
+        HIP_TRY(ctx, hipMalloc(&ctx->rp_spos, sizeof(uint16_t) * R * N));
+        if (!ctx->q_stats) HIP_TRY(ctx, hipMalloc(&ctx->q_stats, sizeof(int64_t) * R * 3));
+    }
+    if (!ctx->eo_cmin) {
+        HIP_TRY(ctx, hipMalloc(&ctx->eo_cmin, sizeof(uint32_t) * R * 2 * ((N + 63) / 64)));
+        HIP_TRY(ctx, hipMalloc(&ctx->eo_ftau, sizeof(double) * N));
+    }
+    ctx->stats_stride = 3;
+    const int64_t nsamp = iters / step;
+    const size_t es_need = (size_t)(nsamp > 0 ? nsamp : 1) * ctx->Rpad;
+    if (es_need > ctx->Es_cap) {
+        free_dev(ctx->d_Es);
+        ctx->Es_cap = 0;
+        HIP_TRY(ctx, hipMalloc(&ctx->d_Es, sizeof(int32_t) * es_need));
+        ctx->Es_cap = es_need;
+    }
+    while (ctx->ev_sweep.size() < 2) {
+        hipEvent_t e;
+        HIP_TRY(ctx, hipEventCreate(&e));
+        ctx->ev_sweep.push_back(e);
+    }
+    hipStream_t st = ctx->stream;
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+    HIP_TRY(ctx, hipMemcpy(ctx->eo_ftau, ftau, sizeof(double) * N, hipMemcpyHostToDevice));
+    HIP_TRY(ctx, hipMemset(ctx->eo_cmin, 0, sizeof(uint32_t) * R * 2 * ((N + 63) / 64)));
+    EoParams P{};
+    P.A = ctx->d_A; P.J = ctx->d_J; P.ftau = ctx->eo_ftau; P.spins = ctx->rp_spins; P.cmin = ctx->eo_cmin;
+    P.cls = ctx->rp_cls; P.sv = ctx->rp_sv; P.spos = ctx->rp_spos; P.E_cur = ctx->d_E; P.stats = ctx->q_stats; P.Es = ctx->d_Es;
+    P.g0 = ctx->it_done; P.iters = iters; P.step = step;
+    P.k0 = (uint32_t)ctx->seed; P.k1 = (uint32_t)(ctx->seed >> 32); P.replica0 = ctx->replica0;
+    P.N = (int)N; P.K = (int)K; P.L = L; P.has_zero = (K % 2 == 0) ? 1 : 0; P.W = (int)W; P.R = (int)R; P.Rpad = (int)ctx->Rpad;
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_begin, st));
+    hipLaunchKernelGGL(rrsp_spins_in_kernel, dim3((unsigned)((W + 255) / 256), (unsigned)R), dim3(256), 0, st, ctx->d_spins, ctx->rp_spins, (int)N, (int)W, (int)R);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_sweep[0], st));
+    hipLaunchKernelGGL(eo_sparse_kernel, dim3((unsigned)((R + kRrrThreads - 1) / kRrrThreads)), dim3(kRrrThreads), 0, st, P);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_sweep[1], st));
+    hipLaunchKernelGGL(rrsp_spins_out_kernel, dim3((unsigned)((N + 255) / 256), (unsigned)ctx->G), dim3(256), 0, st, ctx->rp_spins, ctx->d_spins, (int)N, (int)W, (int)R);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_end, st));
+    ctx->sweep_launches = 1;
+    ctx->nsamp = nsamp;
+    ctx->it_done += (uint64_t)iters;
+    ctx->results_valid = true;
+    ctx->timing_valid = true;
+    ctx->last_call_rrr = false;
+    ctx->last_call_eo = true;
     ctx->colored_call = false;
     return RRRMC_OK;
 }

@@ -77,7 +77,7 @@ int32_t spf_standard_mc_async(rrrmc_ctx* ctx, double beta, int64_t iters, int64_
     if (step < 1) return fail(ctx, RRRMC_ERR_INVALID_ARG, "step must be >= 1, given %lld", (long long)step);
     if (std::isnan(beta)) return fail(ctx, RRRMC_ERR_INVALID_ARG, "beta is NaN");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    ctx->results_valid = false; ctx->last_call_wtm = false;
+    ctx->results_valid = false; ctx->last_call_wtm = false; ctx->last_call_eo = false;
     ctx->timing_valid = false;
     ctx->last_call_rrr = false;
     const int64_t nsamp = iters / step;

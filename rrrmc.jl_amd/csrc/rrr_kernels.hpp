@@ -898,6 +898,111 @@ __global__ __launch_bounds__(kRrrThreads) void wtm_sparse_kernel(WtmParams P)
     P.t_out[r] = t;
 }
 
+// ---------------------------------------------------------------------------------------------------
+// extremal_opt — tau-EO (src/RRRMC.jl:474-521) on GraphRRG / GraphEA with EOCache{Int,L} (src/DeltaE.jl:412-555): SURVEY.md §8(f)
+// rank 4.  One thread per replica.  Classes = values of dE in ascending order (2L - has_zero of them); a rank is drawn from the
+// caller's cumulative table ftau (binary search = searchsortedfirst), the class holding it gives a uniform member, which flips.
+// RRR stream sub 3.
+// ---------------------------------------------------------------------------------------------------
+struct EoParams {
+    const int32_t* A;        // [N][K]
+    const int8_t* J;         // [N][K]
+    const double* ftau;      // [N] cumsum(j^-tau)
+    uint32_t* spins;         // [R][W]
+    uint32_t* cmin;          // [R][W] configuration of minimum energy
+    uint8_t* cls;            // [R][N]
+    uint16_t* sv;            // [R][K2][N]
+    uint16_t* spos;          // [R][N]
+    int32_t* E_cur;          // [Rpad]
+    int64_t* stats;          // [R][3]: Emin, itmin, -
+    int32_t* Es;             // [nsamples][Rpad]
+    uint64_t g0;
+    int64_t iters, step;
+    uint32_t k0, k1, replica0;
+    int N, K, L, has_zero, W, R, Rpad;
+};
+
+__global__ __launch_bounds__(kRrrThreads) void eo_sparse_kernel(EoParams P)
+{
+    const int r = blockIdx.x * kRrrThreads + threadIdx.x;
+    if (r >= P.R) return;
+    const int N = P.N, L = P.L, K = P.K, K2 = 2 * P.L - P.has_zero;
+    uint32_t* sp = P.spins + (size_t)r * P.W;
+    uint32_t* cm = P.cmin + (size_t)r * P.W;
+    uint8_t* cls = P.cls + (size_t)r * N;
+    uint16_t* sv = P.sv + (size_t)r * K2 * N;
+    uint16_t* spos = P.spos + (size_t)r * N;
+    int t[2 * kSLmax];
+    auto sbit = [&](int x) { return (int)((sp[x >> 5] >> (x & 31)) & 1u); };
+    auto dE_of = [&](int i) {
+        const int si = sbit(i);
+        int acc = 0;
+        for (int q = 0; q < K; ++q) {
+            const int sy = sbit(P.A[(size_t)i * K + q]);
+            acc += (si == sy) ? (int)P.J[(size_t)i * K + q] : -(int)P.J[(size_t)i * K + q];
+        }
+        return 2 * acc;
+    };
+    // findks (DeltaE.jl:412-421), 0-based; allΔE(+-J) = 2m, m = K&1, K&1 + 2, ...: ak = (|d|/2 - (K&1))/2 + 1
+    auto klass = [&](int d) {
+        const int ak = ((d < 0 ? -d : d) / 2 - (K & 1)) / 2 + 1;
+        return (d >= 0 ? ak + L - P.has_zero : L + 1 - ak) - 1;
+    };
+    long long n = 0;
+    for (int k = 0; k < K2; ++k) t[k] = 0;
+    for (int i = 0; i < N; ++i) {
+        const int d = dE_of(i);
+        n -= d / 2;
+        const int k = klass(d);
+        cls[i] = (uint8_t)k;
+        sv[(size_t)k * N + t[k]] = (uint16_t)i;
+        spos[i] = (uint16_t)t[k];
+        t[k] += 1;
+    }
+    long long E = n / 2, Emin = E, itmin = 0, ns = 0;
+    for (int w = 0; w < P.W; ++w) cm[w] = sp[w];
+    const double z = P.ftau[N - 1];
+    const uint32_t rep = P.replica0 + (uint32_t)r;
+    for (long long it = 1; it <= P.iters; ++it) {
+        if (it % P.step == 0) { P.Es[(size_t)ns * P.Rpad + r] = (int32_t)E; ns += 1; }
+        const uint64_t g = P.g0 + (uint64_t)it;
+        const Philox4 o = philox4x32_10((uint32_t)g, (uint32_t)(g >> 32), rep, TAG_RRR | (3u << 8), P.k0, P.k1);
+        // rand_move: DeltaE.jl:473-507
+        const double rr = (1 - (double)((((uint64_t)o.w[0] << 32) | o.w[1]) >> 11) * 0x1.0p-53) * z;
+        int lo = 0, hi = N;
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if (P.ftau[mid] < rr) lo = mid + 1; else hi = mid; }
+        int rank = lo + 1;
+        if (rank > N) rank = N;
+        int k = -1, tt = 0;
+        while (rank > tt) { k += 1; tt += t[k]; }
+        const int a = k < L ? L - 1 - k : k - L + P.has_zero;                        // index into allΔE
+        const int dE = (k < L ? -1 : 1) * 2 * (2 * a + (K & 1));
+        const int move = sv[(size_t)k * N + (int)mulhi64(((uint64_t)o.w[2] << 32) | o.w[3], (uint64_t)t[k])];
+        // apply_move!: DeltaE.jl:509-541
+        sp[move >> 5] ^= 1u << (move & 31);
+        const int32_t* Ax = P.A + (size_t)move * K;
+        for (int q = 0; q <= K; ++q) {
+            if (q < K && q > 0 && Ax[q] == Ax[q - 1]) continue;                      // uA: repeats removed (EA.jl:158)
+            const int j = q < K ? Ax[q] : move;
+            const int k0 = cls[j], k1 = klass(dE_of(j));
+            if (k0 == k1) continue;
+            uint16_t* v0 = sv + (size_t)k0 * N;
+            uint16_t* v1 = sv + (size_t)k1 * N;
+            const int p = spos[j], last = v0[t[k0] - 1];
+            v0[p] = (uint16_t)last; spos[last] = (uint16_t)p; t[k0] -= 1;
+            v1[t[k1]] = (uint16_t)j; spos[j] = (uint16_t)t[k1]; t[k1] += 1;
+            cls[j] = (uint8_t)k1;
+        }
+        E += dE;
+        if (E < Emin) {
+            Emin = E; itmin = it;
+            for (int w = 0; w < P.W; ++w) cm[w] = sp[w];
+        }
+    }
+    P.E_cur[r] = (int32_t)E;
+    P.stats[(size_t)r * 3] = Emin; P.stats[(size_t)r * 3 + 1] = itmin; P.stats[(size_t)r * 3 + 2] = P.iters;
+}
+
 // bit-sliced [G][N] words (bit = replica & 31)  <->  replica-contiguous [R][W] words (bit = site & 31)
 __global__ __launch_bounds__(256) void rrsp_spins_in_kernel(const uint32_t* __restrict__ bs, uint32_t* __restrict__ spins, int N, int W, int R)
 {

@@ -129,6 +129,10 @@ struct rrrmc_ctx {
     double* wt_time = nullptr;     // [R] final global time of the last call
     uint32_t wtm_calls = 0;        // wtmMC calls since the last rrrmc_seed (part of the WTM stream address)
     bool last_call_wtm = false;
+    // ---- extremal_opt on RRRMC_MODEL_SPARSE_PM1 (allocated on first use; shares the rrrMC class arrays) ----
+    uint32_t* eo_cmin = nullptr;   // [R][2*nch] configuration of minimum energy, BitVector word order
+    double* eo_ftau = nullptr;     // [N]
+    bool last_call_eo = false;
     // ---- rrrMC(SingleGraph) on RRRMC_MODEL_SK_NORMAL: DeltaECacheCont + DynamicSampler state (allocated on first use) ----
     double* rs_buf = nullptr;      // lfA, lfB, v, ps, dEs, st_dE, st_p, z_out
     uint32_t* rs_spins = nullptr;
@@ -387,6 +391,7 @@ void rrrmc_ctx_destroy(rrrmc_ctx* ctx)
     free_dev(ctx->pf_J); free_dev(ctx->pf_spins); free_dev(ctx->pf_undo); free_dev(ctx->pf_sites);
     free_dev(ctx->db_dJ); free_dev(ctx->db_rJ); free_dev(ctx->db_cls); free_dev(ctx->db_sv); free_dev(ctx->db_spos); free_dev(ctx->db_lf); free_dev(ctx->db_undo);
     free_dev(ctx->wt_t); free_dev(ctx->wt_id); free_dev(ctx->wt_pos); free_dev(ctx->wt_time);
+    free_dev(ctx->eo_cmin); free_dev(ctx->eo_ftau);
     free_dev(ctx->snap); free_dev(ctx->d_pairs); free_dev(ctx->d_ovl); free_dev(ctx->d_qobs);
     for (int i = 0; i < 2; ++i) { free_dev(ctx->d_slots[i]); free_dev(ctx->d_vecs[i]); }
     if (ctx->plan_stream) { (void)hipStreamSynchronize(ctx->plan_stream); (void)hipStreamDestroy(ctx->plan_stream); }
@@ -692,7 +697,7 @@ int32_t rrrmc_standard_mc_async(rrrmc_ctx* ctx, double beta, int64_t iters, int6
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const int64_t N = ctx->N, K = ctx->K;
     const int C = ctx->C;
-    ctx->results_valid = false; ctx->last_call_wtm = false;
+    ctx->results_valid = false; ctx->last_call_wtm = false; ctx->last_call_eo = false;
     ctx->timing_valid = false;
 
     // thresholds for the classes with dE > 0: class n (unsatisfied bonds) has dE = 2 (K - 2n)
@@ -965,7 +970,7 @@ int32_t rrrmc_colored_sweeps_async(rrrmc_ctx* ctx, double beta, int64_t sweeps, 
     if (step < 1) return fail(ctx, RRRMC_ERR_INVALID_ARG, "step must be >= 1, given %lld", (long long)step);
     if (std::isnan(beta)) return fail(ctx, RRRMC_ERR_INVALID_ARG, "beta is NaN");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    ctx->results_valid = false; ctx->last_call_wtm = false;
+    ctx->results_valid = false; ctx->last_call_wtm = false; ctx->last_call_eo = false;
     ctx->timing_valid = false;
     const int64_t K = ctx->K, nsamp = sweeps / step;
     const size_t es_need = (size_t)(nsamp > 0 ? nsamp : 1) * ctx->Rpad;
@@ -1086,7 +1091,7 @@ int32_t rrrmc_rrr_mc_async(rrrmc_ctx* ctx, double beta, double fourK, int64_t it
     if (iters < 0) return fail(ctx, RRRMC_ERR_INVALID_ARG, "iters must be >= 0, given %lld", (long long)iters);
     if (step < 1) return fail(ctx, RRRMC_ERR_INVALID_ARG, "step must be >= 1, given %lld", (long long)step);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    ctx->results_valid = false; ctx->last_call_wtm = false;
+    ctx->results_valid = false; ctx->last_call_wtm = false; ctx->last_call_eo = false;
     ctx->timing_valid = false;
     const int64_t nsamp = iters / step;
     const size_t es_need = (size_t)(nsamp > 0 ? nsamp : 1) * ctx->R;
@@ -1161,6 +1166,37 @@ int32_t rrrmc_wtm_times(rrrmc_ctx* ctx, double* t_out)
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     HIP_TRY(ctx, hipMemcpy(t_out, ctx->wt_time, sizeof(double) * ctx->R, hipMemcpyDeviceToHost));
+    return RRRMC_OK;
+}
+
+int32_t rrrmc_extremal_opt_async(rrrmc_ctx* ctx, const double* ftau, int64_t iters, int64_t step)
+{
+    int32_t rc = ensure_state(ctx, true);
+    if (rc) return rc;
+    if (ctx->model != RRRMC_MODEL_SPARSE_PM1) return fail(ctx, RRRMC_ERR_UNSUPPORTED, "extremal_opt is wired for RRRMC_MODEL_SPARSE_PM1");
+    return sparse_eo_async(ctx, ftau, iters, step);
+}
+
+int32_t rrrmc_extremal_opt_results(rrrmc_ctx* ctx, int64_t* Emin_out, uint64_t* Cmin_chunks, int64_t* itmin_out)
+{
+    if (!ctx) return RRRMC_ERR_INVALID_ARG;
+    if (!ctx->last_call_eo || !ctx->results_valid) return fail(ctx, RRRMC_ERR_STATE, "no extremal_opt call has been made");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    std::vector<int64_t> st((size_t)ctx->R * 3);
+    HIP_TRY(ctx, hipMemcpy(st.data(), ctx->q_stats, sizeof(int64_t) * st.size(), hipMemcpyDeviceToHost));
+    for (int64_t r = 0; r < ctx->R; ++r) {
+        if (Emin_out) Emin_out[r] = st[(size_t)(3 * r)];
+        if (itmin_out) itmin_out[r] = st[(size_t)(3 * r + 1)];
+    }
+    if (Cmin_chunks) {
+        const int64_t nch = (ctx->N + 63) / 64, W = (ctx->N + 31) / 32;
+        std::vector<uint32_t> w((size_t)ctx->R * (size_t)W);
+        HIP_TRY(ctx, hipMemcpy(w.data(), ctx->eo_cmin, sizeof(uint32_t) * w.size(), hipMemcpyDeviceToHost));
+        std::memset(Cmin_chunks, 0, sizeof(uint64_t) * ctx->R * nch);
+        for (int64_t r = 0; r < ctx->R; ++r)
+            for (int64_t q = 0; q < W; ++q) Cmin_chunks[r * nch + (q >> 1)] |= (uint64_t)w[(size_t)(r * W + q)] << (32 * (q & 1));
+    }
     return RRRMC_OK;
 }
 

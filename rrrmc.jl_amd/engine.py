@@ -170,6 +170,20 @@ class Engine:
         check(lib().rrrmc_wtm_times(self._ctx, t), self._ctx)
         return Es, moves, t
 
+    def extremal_opt(self, tau, iters, step=1):
+        """extremal_opt(X, τ, iters; step) (src/RRRMC.jl:474-521).  Returns (Es[R, iters // step], Emin[R], Cmin: Config, itmin[R])."""
+        N = self.X.N
+        ftau = np.cumsum(np.arange(1, N + 1, dtype=np.float64) ** (-float(tau)))          # DeltaE.jl:444
+        check(lib().rrrmc_extremal_opt_async(self._ctx, ftau, int(iters), int(step)), self._ctx)
+        self._last = (int(iters), int(step))
+        self.sync()
+        Es, _ = self.fetch_results()
+        Emin = np.zeros(self.R, np.int64)
+        itmin = np.zeros(self.R, np.int64)
+        Cmin = Config(N, self.R)
+        check(lib().rrrmc_extremal_opt_results(self._ctx, Emin, Cmin.s.reshape(-1), itmin), self._ctx)
+        return Es, Emin, Cmin, itmin
+
     def rrr_cache(self):
         """(pos[R, N], sizes[R, 4]) of the DeltaECache after the last rrrMC call."""
         pos = np.zeros((self.R, self.X.N), np.int8)
@@ -295,6 +309,30 @@ def wtmMC(X, beta, samples, *, seed=DEFAULT_SEED, step=1.0, C0=None, quiet=False
             print("global time = ", float(t.mean()))
             print("ratio = ", float(t.mean()) / max(float(moves.mean()), 1.0))
         return Es, Cfg
+    finally:
+        if own:
+            eng.close()
+
+
+def extremal_opt(X, tau, iters, *, seed=DEFAULT_SEED, step=1, C0=None, quiet=False, replicas=None, device=0, replica0=0, engine=None):
+    """``extremal_opt(X, τ, iters; seed, step, C0, quiet)`` (src/RRRMC.jl:474-521) for a batch of replicas of a GraphRRG / GraphEA.
+    Returns ``(C, Emin, Cmin, itmin)`` like the reference, with per-replica arrays."""
+    own = engine is None
+    R = replicas if replicas is not None else (C0.R if C0 is not None else (engine.R if engine else 1))
+    eng = engine if engine is not None else Engine(X, R, device=device, replica0=replica0)
+    try:
+        if seed > 0 or own:
+            eng.seed(seed if seed > 0 else 0)
+        if C0 is not None:
+            eng.set_config(C0)
+        elif own:
+            eng.init_spins_random()
+        _, Emin, Cmin, itmin = eng.extremal_opt(tau, iters, step)
+        Cfg = eng.get_config(C0 if C0 is not None else None)
+        if not quiet:
+            print("iters = ", iters)
+            print("min [it = %s] = %s" % (itmin.tolist(), Emin.tolist()))
+        return Cfg, Emin, Cmin, itmin
     finally:
         if own:
             eng.close()

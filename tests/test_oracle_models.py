@@ -268,3 +268,24 @@ def test_wtm_equilibrium_matches_metropolis(oracle):
         Em, *_ = oracle.standard_mc_sparse(A, J, beta, 40000, 1, seed, ch, replica=r)
         e_met.append(Em[4000:].mean())
     assert abs(np.mean(e_wtm) - np.mean(e_met)) < 0.35           # both ~ -11; the spread of a 20-chain mean is ~0.1
+
+
+# ---- extremal_opt (tau-EO) on GraphRRG / GraphEA ----
+
+@pytest.mark.parametrize("kind,form", [("rrg", "rrg"), ("ea", "ea"), ("ea2L2", "ea")])
+def test_extremal_opt_invariants(oracle, kind, form):
+    seed = 17
+    A = {"rrg": lambda: oracle.gen_rrg(40, 3, seed), "ea": lambda: oracle.gen_ea(4, 2), "ea2L2": lambda: oracle.gen_ea(2, 3)}[kind]()
+    J = oracle.gen_couplings(A, seed)
+    N = A.shape[0]
+    ch = oracle.init_config(seed, 0, N)
+    E0 = oracle.sparse_energy(A, J, ch)
+    Es, ch1, Emin, Cmin, itmin = oracle.extremal_opt_sparse(A, J, 1.3, 3000, 10, seed, ch, form=form)   # also checks cache + tracked E
+    assert len(Es) == 300 and Emin <= min(E0, Es.min()) and 0 <= itmin <= 3000
+    assert Emin == oracle.sparse_energy(A, J, Cmin)                 # Cmin is the configuration of minimum energy
+    # tau-EO is a descent-biased walk: it finds something well below the random start
+    assert Emin < E0
+    # ground-state check on the tiny ring-like case by brute force
+    if N <= 16:
+        best = min(brute_energy(A, J, np.array([(c >> i) & 1 for i in range(N)])) for c in range(2 ** N))
+        assert Emin >= best
