@@ -121,10 +121,11 @@ RRRMC_API int32_t rrrmc_fetch_results(rrrmc_ctx *ctx, int64_t *Es_out, int64_t *
 
 /* ---- colour-parallel ("checkerboard") sweeps: build-defined extension for large sparse graphs ---------------------
  * The reference's standardMC is random-site (src/RRRMC.jl:113) and its kernel here keeps a replica group's spins in
- * LDS (N <= 8192).  For larger graphs (BASELINE.json config 4: GraphEA L=64, D=3) the engine offers sweeps over a
+ * LDS (two 4-byte words per site next to the chunk buffers: up to N of about 17 000).  For larger graphs (BASELINE.json
+ * config 4: GraphEA L=64, D=3) the engine offers sweeps over a
  * proper colouring: one sweep attempts every site once, colour by colour, all sites of a colour at once, with the
  * reference's delta_energy and accept rule (src/graphs/EA.jl:266-275, src/RRRMC.jl:39).  A ctx of
- * RRRMC_MODEL_SPARSE_PM1 with N > 8192 supports only this sampler (rrrmc_standard_mc* return RRRMC_ERR_UNSUPPORTED).
+ * RRRMC_MODEL_SPARSE_PM1 whose state does not fit LDS supports only this sampler (rrrmc_standard_mc* return RRRMC_ERR_UNSUPPORTED).
  *   color[N] in 0..ncolors-1, adjacent sites must differ (checked).
  *   rrrmc_colored_sweeps_async: `sweeps` sweeps; an energy sample is taken BEFORE sweep k*step (as RRRMC.jl:104-108
  *   with a sweep as the unit); results through rrrmc_sync + rrrmc_fetch_results (Es [R x sweeps/step]; accepted_out

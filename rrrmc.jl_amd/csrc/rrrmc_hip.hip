@@ -8,6 +8,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -80,7 +81,8 @@ struct rrrmc_ctx {
     bool timing_valid = false;
 
     // ---- colour-parallel sweeps (any sparse ctx; the only sampler when lds_mode is false) ----
-    bool lds_mode = true;               // the LDS-resident random-site kernel is available (N <= 8192 and it fits)
+    bool lds_mode = true;               // the LDS-resident random-site kernel is available (the state fits the 160 KiB LDS)
+    bool wide = false;                  // ... in its WIDE build (8192 < N)
     int ncolors = 0;
     std::vector<int32_t> color_count;   // sites per colour
     std::vector<int32_t*> d_color_list; // device lists
@@ -220,13 +222,22 @@ typedef void (*plan_fn)(ChunkDesc*, uint32_t*, uint32_t*, const int32_t*, int, i
 plan_fn plan_for_K(int K) { RRRMC_DISPATCH_UPTO7(K, plan_kernel) }
 
 typedef void (*sweep_fn)(SweepParams);
-sweep_fn sweep_for_K(int K) { RRRMC_DISPATCH_UPTO7(K, sweep_kernel) }
+sweep_fn sweep_for_K(int K, bool wide)
+{
+    if (!wide) { RRRMC_DISPATCH_UPTO7(K, sweep_kernel) }
+    switch (K) {
+        case 1: return sweep_kernel<1, true>; case 2: return sweep_kernel<2, true>; case 3: return sweep_kernel<3, true>;
+        case 4: return sweep_kernel<4, true>; case 5: return sweep_kernel<5, true>; case 6: return sweep_kernel<6, true>;
+        case 7: return sweep_kernel<7, true>; default: return nullptr;
+    }
+}
 
-size_t sweep_lds_bytes(int64_t N, int K, int TS, int C)
+// wide = the neighbour table is not staged in LDS (8192 < N: offsets are word indices, see SweepParams::table)
+size_t sweep_lds_bytes(int64_t N, int K, int TS, int C, bool wide = false)
 {
     const int NT = (K + 1) / 2, NW = NT + (K + 2) / 2, NQ = (NW + 3) / 4;
     const size_t words = (size_t)((2 * N + 128 + 3) & ~3ll) + (size_t)3 * NQ * 4 * C + (size_t)8 * (C + 64) + (size_t)2 * (4 + kLeftMax * (1 + 2 * NT));
-    return words * 4 + (size_t)N * TS * 2;
+    return words * 4 + (wide ? (size_t)0 : (size_t)N * TS * 2);
 }
 
 size_t plan_lds_bytes(int64_t N, int K, int C)
@@ -326,11 +337,16 @@ int32_t rrrmc_ctx_create(rrrmc_ctx** out, int32_t model, int64_t N, int64_t K, i
 
     // chunk length: a multiple of (producer waves x 64) that fits the 160 KiB LDS next to the state
     int C = kProducerWaves * kWave;
-    while (C >= kWave && (N > 8192 || sweep_lds_bytes(N, (int)K, ctx->TS, C) > (size_t)kLdsLimit)) C -= kWave;
-    ctx->lds_mode = C >= kWave;      // otherwise only the colour-parallel sweeps are available (HBM/L2-resident spins)
+    // WIDE build (word indices instead of byte offsets, neighbour table in HBM/L2 instead of LDS): needed when byte offsets into
+    // the 2N-word LDS spin array no longer fit 16 bits (N > 8192), and preferred as soon as the LDS copy of the table would
+    // force a shorter chunk (measured: same speed as the normal build at equal chunk length)
+    ctx->wide = N > 8192 || sweep_lds_bytes(N, (int)K, ctx->TS, C, false) > (size_t)kLdsLimit;
+    if (const char* fw = std::getenv("RRRMC_FORCE_WIDE")) ctx->wide = ctx->wide || fw[0] == '1';       // timing experiments
+    while (C >= kWave && (2 * N + 128 > 65535 || sweep_lds_bytes(N, (int)K, ctx->TS, C, ctx->wide) > (size_t)kLdsLimit)) C -= kWave;
+    ctx->lds_mode = C >= 4 * kWave;  // otherwise only the colour-parallel sweeps are available (HBM/L2-resident spins)
     if (!ctx->lds_mode) C = kWave;
     ctx->C = C;
-    ctx->lds_bytes = ctx->lds_mode ? sweep_lds_bytes(N, (int)K, ctx->TS, C) : 0;
+    ctx->lds_bytes = ctx->lds_mode ? sweep_lds_bytes(N, (int)K, ctx->TS, C, ctx->wide) : 0;
     ctx->plan_lds_bytes = ctx->lds_mode ? plan_lds_bytes(N, (int)K, C) : 0;
 
 #define CREATE_TRY(expr)                                                                                         \
@@ -364,7 +380,7 @@ int32_t rrrmc_ctx_create(rrrmc_ctx** out, int32_t model, int64_t N, int64_t K, i
     CREATE_TRY(hipMemset(ctx->d_E, 0, sizeof(int32_t) * ctx->Rpad));
     CREATE_TRY(hipMemset(ctx->d_acc, 0, sizeof(int64_t) * ctx->Rpad));
     if (ctx->lds_mode) {
-        sweep_fn fn = sweep_for_K((int)K);
+        sweep_fn fn = sweep_for_K((int)K, ctx->wide);
         CREATE_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->lds_bytes));
         CREATE_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(plan_for_K((int)K)), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->plan_lds_bytes));
     }
@@ -440,7 +456,7 @@ int32_t rrrmc_set_graph(rrrmc_ctx* ctx, const int32_t* A, const int8_t* J)
     if (ctx->lds_mode)
         for (int64_t x = 0; x < N; ++x)
             for (int64_t k = 0; k < K; ++k)
-                table[x * ctx->TS + k] = (uint16_t)(4 * (A[x * K + k] + (J[x * K + k] < 0 ? N : 0)));   // byte offset in the LDS spin array
+                table[x * ctx->TS + k] = (uint16_t)((ctx->wide ? 1 : 4) * (A[x * K + k] + (J[x * K + k] < 0 ? N : 0)));   // byte offset (word index if wide) in the LDS spin array
     ctx->h_A.assign(A, A + N * K);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -799,7 +815,7 @@ int32_t rrrmc_standard_mc_async(rrrmc_ctx* ctx, double beta, int64_t iters, int6
     P.k1 = (uint32_t)(ctx->seed >> 32);
     P.group0 = ctx->replica0 / 32;
     P.N = (int)N; P.C = C; P.TS = ctx->TS; P.Rpad = (int)ctx->Rpad;
-    sweep_fn fn = sweep_for_K((int)K);
+    sweep_fn fn = sweep_for_K((int)K, ctx->wide);
 #ifdef RRRMC_STAMPS
     if (!g_stamps) HIP_TRY(ctx, hipMalloc(&g_stamps, sizeof(unsigned long long) * 16 * (65536 + 4096)));
     P.stamps = g_stamps;

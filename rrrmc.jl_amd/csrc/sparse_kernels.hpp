@@ -140,8 +140,9 @@ __global__ __launch_bounds__(kPlanThreads) void plan_kernel(ChunkDesc* __restric
 // ---------------------------------------------------------------------------------------------------
 struct SweepParams {
     uint32_t* spins;          // [G][N]   bit-sliced configuration
-    const uint16_t* table;    // [N][TS]  BYTE offsets of the neighbour words in the LDS spin array:
-                              //          4*y (J=+1) or 4*(y+N) (J=-1, complemented copy); TS = row stride
+    const uint16_t* table;    // [N][TS]  offsets of the neighbour words in the LDS spin array: y (J=+1) or y+N (J=-1, complemented
+                              //          copy), as BYTE offsets (x4) in the normal build and as WORD indices in the WIDE one
+                              //          (8192 < N < 32768: byte offsets no longer fit 16 bits; the table then stays in HBM/L2)
     const ChunkDesc* chunks;  // chunks of this launch
     const uint32_t* slots;
     const uint32_t* vecs;
@@ -204,7 +205,7 @@ __device__ __forceinline__ void refine_block(uint32_t (&lt)[NT], uint32_t (&eq)[
 }
 
 // ---- producers -------------------------------------------------------------------------------------
-template <int K>
+template <int K, bool WIDE>
 __device__ __forceinline__ void produce_chunk(const SweepParams& P, const ChunkDesc& cd, uint4* __restrict__ desc,
                                               const uint16_t* __restrict__ tbl, const LeftList& left, int pw, int lane, uint32_t group)
 {
@@ -224,7 +225,7 @@ __device__ __forceinline__ void produce_chunk(const SweepParams& P, const ChunkD
         for (int q = 0; q < NQ * 4; ++q) f[q] = 0u;
         {   // gather offsets: own word, then the K neighbour words (table row = K uint16 byte offsets)
             uint32_t off[K + 2];
-            off[0] = site * 4u;
+            off[0] = WIDE ? site : site * 4u;
             off[K + 1] = 0u;
             const uint16_t* row = tbl + (size_t)site * P.TS;
             if constexpr (K <= 4) {
@@ -336,20 +337,29 @@ template <int K> __device__ __forceinline__ uint32_t desc_off(const SlotDesc<K>&
     return (f & 1) ? (w >> 16) : (w & 0xffffu);
 }
 
-__device__ __forceinline__ uint32_t lds_word(const uint32_t* sp, uint32_t byte_off)
+// off = byte offset (normal) or word index (WIDE) into the LDS spin array
+template <bool WIDE>
+__device__ __forceinline__ uint32_t lds_word(const uint32_t* sp, uint32_t off)
 {
-    return *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(sp) + byte_off);
+    if constexpr (WIDE) return sp[off];
+    else return *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(sp) + off);
+}
+template <bool WIDE>
+__device__ __forceinline__ void lds_store(uint32_t* sp, uint32_t off, uint32_t v)
+{
+    if constexpr (WIDE) sp[off] = v;
+    else *reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(sp) + off) = v;
 }
 
 // the K+1 spin words one attempt reads: own word first, then the neighbour words
 template <int K> struct SlotWords { uint32_t s; uint32_t g[K]; };
 
-template <int K>
+template <int K, bool WIDE>
 __device__ __forceinline__ void gather_words(SlotWords<K>& w, const SlotDesc<K>& d, const uint32_t* __restrict__ sp)
 {
-    w.s = lds_word(sp, desc_off<K>(d, 0));
+    w.s = lds_word<WIDE>(sp, desc_off<K>(d, 0));
 #pragma unroll
-    for (int k = 0; k < K; ++k) w.g[k] = lds_word(sp, desc_off<K>(d, 1 + k));
+    for (int k = 0; k < K; ++k) w.g[k] = lds_word<WIDE>(sp, desc_off<K>(d, 1 + k));
 }
 
 // accept decision of one slot for the 32 replicas: planes n0..n2 of n = number of unsatisfied bonds, acc = accepted mask
@@ -397,7 +407,7 @@ __device__ __forceinline__ void slot_logic(const SlotDesc<K>& d, const SlotWords
 // latency-bound, this is its instruction-level parallelism).  The code is branch-free inside a step so that the
 // LDS waits can be counted (s_waitcnt lgkmcnt(N)) instead of drained: rows 0..NR-2 are full; in the last row the
 // lanes past the end of the level re-read the level's last slot (a broadcast) and store to private dummy words.
-template <int K, int NR>
+template <int K, int NR, bool WIDE>
 __device__ __forceinline__ void consume_rows(const uint4* __restrict__ desc, uint32_t* __restrict__ sp, uint4* __restrict__ tal,
                                              int C, int N, int p0, int plast, int lane)
 {
@@ -412,23 +422,24 @@ __device__ __forceinline__ void consume_rows(const uint4* __restrict__ desc, uin
         for (int q = 0; q < NQ; ++q) d[j].q[q] = desc[q * C + p];
     }
 #pragma unroll
-    for (int j = 0; j < NR; ++j) gather_words<K>(w[j], d[j], sp);
+    for (int j = 0; j < NR; ++j) gather_words<K, WIDE>(w[j], d[j], sp);
 #pragma unroll
     for (int j = 0; j < NR; ++j) {
         uint32_t n0, n1, n2, acc;
         slot_logic<K>(d[j], w[j], n0, n1, n2, acc);
         const uint32_t snew = w[j].s ^ acc;      // spinflip! + update_cache! (Interface.jl:89-92, RRG.jl:191-234)
-        uint32_t oa = desc_off<K>(d[j], 0);      // byte offset of the site's word; its complement lives N words further
-        uint32_t ob = oa + 4u * (uint32_t)N;
+        constexpr uint32_t kUnit = WIDE ? 1u : 4u;   // offsets are word indices (WIDE) or byte offsets
+        uint32_t oa = desc_off<K>(d[j], 0);      // offset of the site's word; its complement lives N words further
+        uint32_t ob = oa + kUnit * (uint32_t)N;
         int pt = p0 + j * kWave;
         if (j == NR - 1) {
             const bool dead = pt > plast;
-            oa = dead ? 8u * (uint32_t)N + 4u * (uint32_t)lane : oa;            // dummy words behind the two spin copies
-            ob = dead ? 8u * (uint32_t)N + 256u + 4u * (uint32_t)lane : ob;
+            oa = dead ? kUnit * (2u * (uint32_t)N + (uint32_t)lane) : oa;       // dummy words behind the two spin copies
+            ob = dead ? kUnit * (2u * (uint32_t)N + 64u + (uint32_t)lane) : ob;
             pt = dead ? C + lane : pt;                                          // dummy tally entries behind the chunk's
         }
-        *reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(sp) + oa) = snew;
-        *reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(sp) + ob) = ~snew;
+        lds_store<WIDE>(sp, oa, snew);
+        lds_store<WIDE>(sp, ob, ~snew);
         tal[pt] = make_uint4(acc, n0, n1, n2);
     }
 }
@@ -438,7 +449,7 @@ __device__ __forceinline__ void consume_rows(const uint4* __restrict__ desc, uin
 // (the single consumer wave is latency-bound: this is its instruction-level parallelism).  A batch is branch-free
 // so that the LDS waits can be counted instead of drained: rows 0..NR-2 are full; in the last row the lanes past
 // the end of the batch re-read its last slot (a broadcast) and store to private dummy words.
-template <int K>
+template <int K, bool WIDE>
 __device__ __forceinline__ void consume_chunk(const SweepParams& P, const ChunkDesc& cd, const uint4* __restrict__ desc,
                                               uint32_t* __restrict__ sp, uint4* __restrict__ tal, int lane)
 {
@@ -452,10 +463,10 @@ __device__ __forceinline__ void consume_chunk(const SweepParams& P, const ChunkD
             const uint32_t vd = __builtin_amdgcn_readlane(myvd, v);
             const int start = (int)(vd & 0xffffu), cm1 = (int)(vd >> 16);   // cm1 = slots - 1
             const int p0 = start + lane, plast = start + cm1;
-            if (cm1 >= 3 * kWave) consume_rows<K, 4>(desc, sp, tal, C, N, p0, plast, lane);
-            else if (cm1 >= 2 * kWave) consume_rows<K, 3>(desc, sp, tal, C, N, p0, plast, lane);
-            else if (cm1 >= kWave) consume_rows<K, 2>(desc, sp, tal, C, N, p0, plast, lane);
-            else consume_rows<K, 1>(desc, sp, tal, C, N, p0, plast, lane);
+            if (cm1 >= 3 * kWave) consume_rows<K, 4, WIDE>(desc, sp, tal, C, N, p0, plast, lane);
+            else if (cm1 >= 2 * kWave) consume_rows<K, 3, WIDE>(desc, sp, tal, C, N, p0, plast, lane);
+            else if (cm1 >= kWave) consume_rows<K, 2, WIDE>(desc, sp, tal, C, N, p0, plast, lane);
+            else consume_rows<K, 1, WIDE>(desc, sp, tal, C, N, p0, plast, lane);
         }
     }
 }
@@ -657,7 +668,7 @@ __device__ __forceinline__ void tally_chunk(TallyState<NS>& t, const ChunkDesc& 
     }
 }
 
-template <int K>
+template <int K, bool WIDE = false>
 __global__ __launch_bounds__(kSweepThreads) void sweep_kernel(SweepParams P)
 {
     constexpr int NQ = SweepCfg<K>::NQ, NS = SweepCfg<K>::NS;
@@ -668,7 +679,8 @@ __global__ __launch_bounds__(kSweepThreads) void sweep_kernel(SweepParams P)
     uint4* tal = desc + 3 * NQ * C;                                  // [2][C + 64]  (64 dummy entries per buffer)
     uint32_t* leftmem = reinterpret_cast<uint32_t*>(tal + 2 * (C + kWave));   // [2] leftover lists
     constexpr int kLeftWords = 4 + kLeftMax * (1 + 2 * SweepCfg<K>::NT);
-    uint16_t* tbl = reinterpret_cast<uint16_t*>(leftmem + 2 * kLeftWords);     // [N][TS]
+    // [N][TS] neighbour table: a copy in LDS, or (WIDE) the HBM/L2 original
+    const uint16_t* tbl = WIDE ? P.table : reinterpret_cast<const uint16_t*>(leftmem + 2 * kLeftWords);
 
     const int tid = threadIdx.x, lane = tid & 63;
     // the wave index as a SCALAR: role dispatch becomes s_cbranch (and s_setprio below really is per wave)
@@ -681,7 +693,10 @@ __global__ __launch_bounds__(kSweepThreads) void sweep_kernel(SweepParams P)
         sp[x] = w;
         sp[x + N] = ~w;
     }
-    for (int q = tid; q < N * P.TS; q += kSweepThreads) tbl[q] = P.table[q];
+    if constexpr (!WIDE) {
+        uint16_t* tbl_w = reinterpret_cast<uint16_t*>(leftmem + 2 * kLeftWords);
+        for (int q = tid; q < N * P.TS; q += kSweepThreads) tbl_w[q] = P.table[q];
+    }
     if (tid < 2) leftmem[tid * kLeftWords] = 0u;
     __syncthreads();
     auto left_list = [&](int c) {
@@ -712,7 +727,7 @@ __global__ __launch_bounds__(kSweepThreads) void sweep_kernel(SweepParams P)
             RRRMC_T0
 #ifndef RRRMC_ABLATE_CONSUME      // timing experiments only (tools/ablate.sh): results are wrong with a role removed
             if (c >= 2 && c - 2 < P.nchunks)
-                consume_chunk<K>(P, P.chunks[c - 2], desc + ((c - 2) % 3) * NQ * C, sp, tal + ((c - 2) & 1) * tal_stride, lane);
+                consume_chunk<K, WIDE>(P, P.chunks[c - 2], desc + ((c - 2) % 3) * NQ * C, sp, tal + ((c - 2) & 1) * tal_stride, lane);
 #endif
             RRRMC_T1
             __syncthreads();
@@ -774,7 +789,7 @@ __global__ __launch_bounds__(kSweepThreads) void sweep_kernel(SweepParams P)
         for (int c = 0; c < nsteps; ++c) {
             RRRMC_T0
 #ifndef RRRMC_ABLATE_PRODUCE
-            if (c < P.nchunks) produce_chunk<K>(P, P.chunks[c], desc + (c % 3) * NQ * C, tbl, left_list(c), pw, lane, group);
+            if (c < P.nchunks) produce_chunk<K, WIDE>(P, P.chunks[c], desc + (c % 3) * NQ * C, tbl, left_list(c), pw, lane, group);
 #endif
             RRRMC_T1
             __syncthreads();

@@ -38,6 +38,13 @@ CASES = [
     (("circ", 100, 7), 32,  0.4,  5000,  500),    # K = 7 (4 classes)
     (("rrg", 64, 3),   32,  0.0,  3000,  100),    # beta = 0: everything accepted
     (("rrg", 64, 3),   32,  50.0, 3000,  100),    # very low temperature: thresholds of ~2^-144 underflow the 64-bit fraction
+    (("rrg", 5400, 3), 32,  1.0,  40000, 5000),   # about the largest N whose neighbour table still fits LDS next to a full chunk
+    (("rrg", 6000, 3), 32,  1.0,  40000, 5000),   # WIDE build by choice: word offsets, neighbour table in HBM/L2
+    (("rrg", 8192, 3), 32,  1.0,  60000, 8192),
+    (("rrg", 8200, 3), 32,  1.0,  60000, 8192),   # WIDE build by necessity (byte offsets no longer fit 16 bits)
+    (("rrg", 10000, 3), 40, 2.0,  80000, 10000),  # the size of the reference's scripts (scripts/scripts.jl:23 N = 10_000)
+    (("rrg", 12000, 4), 32, 1.0,  50000, 5000),   # even K, shorter chunks (LDS)
+    (("ea", 24, 3),    32,  1.0,  60000, 6000),   # EA 24^3 = 13824 spins, K = 6
 ]
 
 
