@@ -1,0 +1,103 @@
+"""GPU edge cases of the C ABI for the headline path: empty / degenerate runs, several plan batches in one call, misuse."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_empty_and_degenerate_runs(pkg, oracle):
+    seed = 1
+    X = pkg.GraphRRG(64, 3, seed=seed)
+    with pkg.Engine(X, 5) as eng:
+        eng.seed(seed)
+        eng.init_spins_random()
+        C0 = eng.get_config()
+        Es, acc = eng.standard_mc(1.0, 0, 10)                     # iters = 0
+        assert Es.shape == (5, 0) and (acc == 0).all() and eng.get_config() == C0 and eng.iterations_done() == 0
+        Es, acc = eng.standard_mc(1.0, 7, 10)                     # step > iters: moves, but no sample
+        assert Es.shape == (5, 0) and eng.iterations_done() == 7
+        ref = oracle.standard_mc_sparse_batch(X.A, X.J.astype(np.int32), 1.0, 7, 10, seed, C0.s)
+        assert (eng.get_config().s == ref[1]).all() and (acc == ref[2]).all()
+        Es, acc = eng.standard_mc(1.0, 1, 1)                      # a single iteration, sampled before its move
+        ref1 = oracle.standard_mc_sparse_batch(X.A, X.J.astype(np.int32), 1.0, 1, 1, seed, ref[1], it0=7)
+        assert (Es == ref1[0]).all() and (eng.get_config().s == ref1[1]).all()
+
+
+def test_two_spin_model(pkg, oracle):
+    """GraphTwoSpin (src/graphs/TwoSpin.jl:26-41) as the N = 2, K = 1 sparse model: E = -J s1 s2."""
+    A = np.array([[1], [0]], np.int32)
+    J = np.array([[1], [1]], np.int8)
+    X = pkg.GraphRRG.from_AJ(A, J)
+    with pkg.Engine(X, 33) as eng:
+        eng.seed(3)
+        eng.init_spins_random()
+        C0 = eng.get_config()
+        E0 = eng.energy()
+        Es, acc = eng.standard_mc(0.7, 500, 1)
+        C1 = eng.get_config()
+    b = C0.bits().astype(np.int64)
+    assert (E0 == -(2 * b[:, 0] - 1) * (2 * b[:, 1] - 1)).all() and set(np.unique(Es)) <= {-1, 1}
+    ref = oracle.standard_mc_sparse_batch(A, J.astype(np.int32), 0.7, 500, 1, 3, C0.s)
+    assert (Es == ref[0]).all() and (C1.s == ref[1]).all() and (acc == ref[2]).all()
+
+
+def test_several_plan_batches_in_one_call(pkg, oracle):
+    """More iterations than one planner batch (2^22 slots), with a step that straddles the batch boundary."""
+    seed, N, R = 77, 64, 32
+    iters, step = (1 << 22) + 12345, 100003
+    X = pkg.GraphRRG(N, 3, seed=seed)
+    with pkg.Engine(X, R) as eng:
+        eng.seed(seed)
+        eng.init_spins_random()
+        C0 = eng.get_config()
+        Es, acc = eng.standard_mc(1.0, iters, step)
+        C1 = eng.get_config()
+        assert eng.last_timing()[2] == 2                              # two sweep launches
+    ref = oracle.standard_mc_sparse_batch(X.A, X.J.astype(np.int32), 1.0, iters, step, seed, C0.s)
+    assert Es.shape == (R, iters // step)
+    assert (Es == ref[0]).all() and (C1.s == ref[1]).all() and (acc == ref[2]).all()
+
+
+def test_misuse_is_reported_not_crashed(pkg):
+    L = pkg.lib()
+    X = pkg.GraphRRG(64, 3, seed=5)
+    ctx = C.c_void_p()
+    assert L.rrrmc_ctx_create(C.byref(ctx), 1, 64, 3, 8, 0, 0) == 0
+    try:
+        Es = np.zeros(8 * 10, np.int64)
+        acc = np.zeros(8, np.int64)
+        # sampling before the graph / the configuration exist
+        assert L.rrrmc_standard_mc(ctx, 1.0, 100, 10, Es.ctypes.data, acc.ctypes.data) == 2
+        assert b"rrrmc_set_graph" in L.rrrmc_last_error(ctx)
+        assert L.rrrmc_set_graph(ctx, X.A, X.J) == 0
+        assert L.rrrmc_standard_mc(ctx, 1.0, 100, 10, Es.ctypes.data, acc.ctypes.data) == 2
+        assert L.rrrmc_seed(ctx, 5) == 0 and L.rrrmc_init_spins_random(ctx) == 0
+        # bad arguments
+        assert L.rrrmc_standard_mc(ctx, float("nan"), 100, 10, Es.ctypes.data, acc.ctypes.data) == 1
+        assert L.rrrmc_standard_mc(ctx, 1.0, -1, 10, Es.ctypes.data, acc.ctypes.data) == 1
+        assert L.rrrmc_standard_mc(ctx, 1.0, 100, 0, Es.ctypes.data, acc.ctypes.data) == 1
+        assert L.rrrmc_fetch_results_f64(ctx, None, None) == 2          # integer model: wrong entry point
+        bad = X.A.copy()
+        bad[0, 0] = 64
+        assert L.rrrmc_set_graph(ctx, bad, X.J) == 1                     # neighbour out of range
+        # the context is still usable afterwards
+        assert L.rrrmc_set_graph(ctx, X.A, X.J) == 0
+        assert L.rrrmc_standard_mc(ctx, 1.0, 100, 10, Es.ctypes.data, acc.ctypes.data) == 0
+    finally:
+        L.rrrmc_ctx_destroy(ctx)
+    # out-of-range sizes at creation
+    assert L.rrrmc_ctx_create(C.byref(ctx), 1, 64, 9, 8, 0, 0) == 3      # K > 7
+    assert L.rrrmc_ctx_create(C.byref(ctx), 1, 0, 3, 8, 0, 0) == 1
+    assert L.rrrmc_ctx_create(C.byref(ctx), 1, 64, 3, 8, 99, 0) == 1     # no such device
+    assert L.rrrmc_ctx_create(C.byref(ctx), 42, 64, 3, 8, 0, 0) == 3     # unknown model
+
+
+def test_create_destroy_cycles(pkg):
+    X = pkg.GraphRRG(256, 3, seed=9)
+    for k in range(40):
+        with pkg.Engine(X, 64) as eng:
+            eng.seed(k + 1)
+            eng.init_spins_random()
+            eng.standard_mc(1.0, 2000, 500)
