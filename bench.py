@@ -37,7 +37,7 @@ def cpu_baseline(O, X, seconds_target=15.0):
     t0 = time.perf_counter()
     O.standard_mc_sparse_batch(A, J, BETA, iters, SAMPLE_STEP, SEED, ch)
     dt = time.perf_counter() - t0
-    R = max(1, min(64, int(seconds_target / max(dt, 1e-3))))
+    R = max(1, min(128, int(seconds_target / max(dt, 1e-3))))
     ch = O.init_configs(SEED, 0, R, N_SITES)
     t0 = time.perf_counter()
     O.standard_mc_sparse_batch(A, J, BETA, iters, SAMPLE_STEP, SEED, ch)
