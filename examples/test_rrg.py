@@ -2,6 +2,7 @@
 """The reference's `scripts/scripts.jl:test_RRG` experiment on the MI355X engine: the four samplers of the paper
 (Metropolis, BKL, RRR, waiting-time) on one GraphRRG(N, K) instance, a batch of replicas each, with the per-sample log files
 (`#mctime acc E clocktime`), device-side configuration snapshots and the time-overlap analysis of `parseovs`.
+With --cont the couplings are Gaussian (GraphRRGNormal) and the samplers use the continuous-energy caches: `test_RRGCont`.
 
   python examples/test_rrg.py [--N 10000] [--K 3] [--beta 2.0] [--samples 50] [--step 10000] [--replicas 64] [--out out_rrg]
 
@@ -30,6 +31,7 @@ def main():
     ap.add_argument("--seedx", type=int, default=8370000274)  # graph seed, scripts.jl:28
     ap.add_argument("--seed", type=int, default=6540000789)   # sampler seed, scripts.jl:29
     ap.add_argument("--out", default="output_RRG")
+    ap.add_argument("--cont", action="store_true", help="Gaussian couplings: GraphRRGNormal, scripts.jl:152-281 test_RRGCont")
     # work per sample of the other samplers relative to RRR, scripts.jl:34-37 (beta = 2)
     ap.add_argument("--met-factor", type=float, default=3.7)
     ap.add_argument("--bkl-factor", type=float, default=94.9)
@@ -38,7 +40,7 @@ def main():
 
     pkg = entry.load_package()
     os.makedirs(args.out, exist_ok=True)
-    X = pkg.GraphRRG(args.N, args.K, seed=args.seedx)
+    X = (pkg.GraphRRGNormal if args.cont else pkg.GraphRRG)(args.N, args.K, seed=args.seedx)
     R = args.replicas
     curves = {}
     for alg in ("met", "bkl", "rrr", "wtm"):

@@ -568,3 +568,28 @@ def extremal_opt_sparse(A, J, tau, iters, step, seed, chunks, it0=0, replica=0, 
     if n < 0:
         raise RuntimeError("extremal_opt_sparse: inconsistent cache / energy")
     return Es[:n], ch, Emin.value, Cmin, itmin.value
+
+
+def cont_sparse(mode, A, J, beta, iters, step, seed, chunks, it0=0, call=0, replica=0, staged_thr=0.8, staged_thr_fact=5.0,
+                stepf=1.0, form="rrg"):
+    """rrrMC (mode "rrr"), bklMC ("bkl"), wtmMC ("wtm") on GraphRRGNormal / GraphEANormal with the continuous-energy caches.
+    Returns (Es, chunks, stats[3], t)."""
+    L = lib()
+    L.orc_cont_sparse.restype = C.c_int64
+    L.orc_cont_sparse.argtypes = [C.c_int, C.c_int, C.c_int64, C.c_int64, i32p, f64p, C.c_double, C.c_int64, C.c_int64, C.c_double,
+                                  C.c_double, C.c_double, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, u64p, f64p, i64p,
+                                  C.POINTER(C.c_double)]
+    A = np.ascontiguousarray(A, np.int32)
+    N, K = A.shape
+    ch = np.array(chunks, np.uint64, copy=True)
+    m = {"rrr": 0, "bkl": 1, "wtm": 2}[mode]
+    nmax = iters if m == 2 else max(iters // step, 1)
+    Es = np.zeros(max(nmax, 1))
+    stats = np.zeros(3, np.int64)
+    t = C.c_double(0)
+    n = L.orc_cont_sparse(m, 1 if form == "ea" else 0, N, K, A, np.ascontiguousarray(J, np.float64).reshape(-1), float(beta), int(iters),
+                          int(step), float(stepf), float(staged_thr), float(staged_thr_fact), seed, it0, call, replica, ch, Es, stats,
+                          C.byref(t))
+    if n < 0:
+        raise RuntimeError("cont_sparse: DynamicSampler lost precision")
+    return Es[:n], ch, stats, t.value

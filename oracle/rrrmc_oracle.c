@@ -1912,3 +1912,180 @@ ORC_API int64_t orc_extremal_opt_sparse(int form, int64_t N, int64_t K, const in
     free(c.pos); free(X.lfields); free(X.lfields_last);
     return ok ? nsamp : -1;
 }
+
+/* =============================================================================================
+ * Continuous-energy samplers on the Float64 sparse models GraphRRGNormal / GraphEANormal — the reference's second experiment
+ * (scripts/scripts.jl:152-281 test_RRGCont): rrrMC(X::SingleGraph) (src/RRRMC.jl:149-219, staged_thr = 0.8 for a SimpleGraph),
+ * bklMC (:311-359) and wtmMC (:376-426) over DeltaECacheCont + DynamicSampler (src/DeltaE.jl:297-410) / THeap.
+ *   mode 0 rrrMC: RRR stream sub 0 (getel uniform), sub 1 (`rand() < c`), g = iteration
+ *   mode 1 bklMC: sub 2 (rand_skip), sub 0 (getel); g = move counter
+ *   mode 2 wtmMC: WTM stream (n-th uniform of the call), `iters` = samples, `stepf` = step in sweeps
+ * neighbors(X, i) = A[i] for GraphRRGNormal (RRG.jl:627), the de-duplicated uA[i] for GraphEANormal (EA.jl:680).
+ * stats = [accepted / moves, staged iterations / true moves, iterations done]; t_out = wtmMC's final global time.
+ * Returns the number of samples, -1 on DynamicSampler's precision-loss error.
+ * ============================================================================================= */
+static int spf_neighbors(const spf_t *X, int64_t i, int64_t *out)
+{
+    int n = 0;
+    const int32_t *Ax = X->A + i * X->K;
+    for (int64_t k = 0; k < X->K; ++k) {
+        if (X->ea_form && k > 0 && Ax[k] == Ax[k - 1]) continue;
+        out[n++] = Ax[k];
+    }
+    return n;
+}
+static inline void spf_spinflip(spf_t *X, uint64_t *s, int64_t i) { bitflip(s, i); spf_update_cache(X, s, i); }
+static inline double spf_dE(const spf_t *X, int64_t i) { return -X->lfields[i]; }                /* RRG.jl:619-625 */
+/* apply_move!(X, C, move, cache::DeltaECacheCont): DeltaE.jl:376-410; returns c = z / z' */
+static double cont_apply_move(spf_t *X, uint64_t *s, dyns_t *ds, double *dEs, double beta, int64_t move)
+{
+    spf_spinflip(X, s, move);
+    const double z = ds->z;
+    dEs[move] = spf_dE(X, move);
+    dyns_set(ds, move, prior_of(beta * dEs[move]));
+    int64_t nb[SK_MAX];
+    int nn = spf_neighbors(X, move, nb);
+    for (int q = 0; q < nn; ++q) {
+        int64_t j = nb[q];
+        dEs[j] = spf_dE(X, j);
+        dyns_set(ds, j, prior_of(beta * dEs[j]));
+    }
+    return z / ds->z;
+}
+
+ORC_API int64_t orc_cont_sparse(int mode, int form, int64_t N, int64_t K, const int32_t *A, const double *J, double beta,
+                                int64_t iters, int64_t step, double stepf, double staged_thr, double staged_thr_fact,
+                                uint64_t seed, uint64_t it0, uint32_t call, uint32_t replica,
+                                uint64_t *chunks, double *Es, int64_t *stats, double *t_out)
+{
+    spf_t X = {N, K, A, J, NULL, NULL, -1, form};
+    X.lfields = (double *)malloc((size_t)N * 8);
+    X.lfields_last = (double *)malloc((size_t)N * 8);
+    double E = spf_energy(&X, chunks);
+    int64_t accepted = 0, second = 0, nsamp = 0, itdone = 0, bad = 0;
+    double t = 0.0;
+    if (mode == 2) {
+        /* wtmMC: WaitingTimes.jl with tau = max(1, exp(beta dE)) evaluated per update */
+        double *tm = (double *)malloc((size_t)N * 8);
+        uint64_t nd = 0;
+        for (int64_t i = 0; i < N; ++i) {
+            double e = orc_det_exp(beta * spf_dE(&X, i));
+            tm[i] = wtm_gen(e > 1.0 ? e : 1.0, wtm_uniform(seed, nd++, replica, call));
+        }
+        const double st = stepf / (double)N, tmax = st * (double)iters;
+        double nextstep = st;
+        int out = 0;
+        while (t < tmax && !out) {
+            int64_t move = 0;
+            for (int64_t i = 1; i < N; ++i) if (tm[i] < tm[move]) move = i;
+            const double tp = tm[move];
+            while (tp >= nextstep) {
+                Es[nsamp++] = E;
+                nextstep += st;
+                if (nextstep > tmax + 1e-10) { out = 1; break; }
+            }
+            if (out) break;
+            t = tp;
+            const double dE = spf_dE(&X, move);
+            spf_spinflip(&X, chunks, move);
+            double e = orc_det_exp(beta * -dE);
+            tm[move] = t + wtm_gen(e > 1.0 ? e : 1.0, wtm_uniform(seed, nd++, replica, call));
+            int64_t nb[SK_MAX];
+            int nn = spf_neighbors(&X, move, nb);
+            for (int q = 0; q < nn; ++q) {
+                e = orc_det_exp(beta * spf_dE(&X, nb[q]));
+                tm[nb[q]] = t + wtm_gen(e > 1.0 ? e : 1.0, wtm_uniform(seed, nd++, replica, call));
+            }
+            E += dE;
+            accepted += 1;
+        }
+        free(tm);
+        second = accepted; itdone = nsamp;
+    } else {
+        double *dEs = (double *)malloc((size_t)N * 8);
+        dyns_t ds;
+        dyns_init(&ds, N);
+        for (int64_t i = 0; i < N; ++i) { dEs[i] = spf_dE(&X, i); ds.v[i] = prior_of(beta * dEs[i]); }    /* DeltaECacheCont: DeltaE.jl:304-313 */
+        dyns_refresh(&ds);
+        if (mode == 0) {
+            const double lambda = staged_thr_fact / (double)N;
+            double acc_rate = 0.5;
+            int64_t st_j[SK_MAX + 1];
+            double st_dE[SK_MAX + 1], st_p[SK_MAX + 1];
+            for (int64_t it = 1; it <= iters && !bad; ++it) {
+                if (it % step == 0) Es[nsamp++] = E;
+                const uint64_t g = it0 + (uint64_t)it;
+                uint32_t w[4];
+                rrr_draw(seed, g, replica, 0, w);
+                int acc = 0;
+                int64_t move = dyns_getel(&ds, u53_of(w[0], w[1]));                    /* rand_move: DeltaE.jl:327-333 */
+                if (move < 0) { bad = 1; break; }
+                const double dE = dEs[move];
+                if (acc_rate < staged_thr) {
+                    second += 1;
+                    const double z = ds.z;
+                    spf_spinflip(&X, chunks, move);                                    /* compute_staged!: DeltaE.jl:357-374 */
+                    int ns = 0;
+                    st_j[ns] = move; st_dE[ns] = spf_dE(&X, move); st_p[ns] = prior_of(beta * st_dE[ns]); ns++;
+                    int64_t nb[SK_MAX];
+                    int nn = spf_neighbors(&X, move, nb);
+                    for (int q = 0; q < nn; ++q) { st_j[ns] = nb[q]; st_dE[ns] = spf_dE(&X, nb[q]); st_p[ns] = prior_of(beta * st_dE[ns]); ns++; }
+                    spf_spinflip(&X, chunks, move);
+                    double zp = ds.z;                                                  /* compute_reverse_probabilities!: :345-355 */
+                    for (int q = 0; q < ns; ++q) zp += st_p[q] - ds.v[st_j[q]];
+                    if (zp < 2.2250738585072014e-308) zp = 2.2250738585072014e-308;
+                    if (zp > (double)N) zp = (double)N;
+                    const double c = z / zp;
+                    rrr_draw(seed, g, replica, 1, w);
+                    if (u53_of(w[0], w[1]) < c) {
+                        spf_spinflip(&X, chunks, move);
+                        for (int q = 0; q < ns; ++q) { dEs[st_j[q]] = st_dE[q]; dyns_set(&ds, st_j[q], st_p[q]); }       /* apply_staged! */
+                        E += dE; accepted += 1; acc = 1;
+                    }
+                } else {
+                    const double c = cont_apply_move(&X, chunks, &ds, dEs, beta, move);
+                    rrr_draw(seed, g, replica, 1, w);
+                    if (u53_of(w[0], w[1]) < c) { E += dE; accepted += 1; acc = 1; }
+                    else cont_apply_move(&X, chunks, &ds, dEs, beta, move);
+                }
+                acc_rate = acc_rate * (1 - lambda) + (double)acc * lambda;
+            }
+            itdone = iters;
+        } else {
+            int64_t it = 0, nextstep = step, m = 0;
+            while (it < iters) {
+                m += 1;
+                const uint64_t g = it0 + (uint64_t)m;
+                uint32_t w[4];
+                rrr_draw(seed, g, replica, 2, w);
+                double b = ds.z / (double)N;                                           /* rand_skip: DeltaE.jl:319-325 */
+                if (b < 2.2250738585072014e-308) b = 2.2250738585072014e-308;
+                if (b > 1.0) b = 1.0;
+                double skipf = __builtin_floor(orc_det_log1p(-u53_of(w[0], w[1])) / orc_det_log1p(-b));
+                int64_t skip = skipf >= 9.0e18 ? (int64_t)9.0e18 : (int64_t)skipf;
+                rrr_draw(seed, g, replica, 0, w);
+                int64_t move = dyns_getel(&ds, u53_of(w[0], w[1]));
+                if (move < 0) { bad = 1; break; }
+                const double dE = dEs[move];
+                int out = 0;
+                while (it + skip + 1 >= nextstep) {
+                    Es[nsamp++] = E;
+                    nextstep += step;
+                    if (nextstep > iters) { out = 1; break; }
+                }
+                if (out) break;
+                cont_apply_move(&X, chunks, &ds, dEs, beta, move);                    /* apply_step_bkl!: RRRMC.jl:294-295 */
+                it += skip + 1;
+                E += dE;
+                accepted += 1;
+            }
+            second = accepted; itdone = it;
+        }
+        free(dEs);
+        dyns_free(&ds);
+    }
+    if (stats) { stats[0] = accepted; stats[1] = second; stats[2] = itdone; }
+    if (t_out) *t_out = t;
+    free(X.lfields); free(X.lfields_last);
+    return bad ? -1 : nsamp;
+}

@@ -1,0 +1,376 @@
+// gfx950 kernel for the continuous-energy samplers on the Float64 sparse models GraphRRGNormal / GraphEANormal — the reference's
+// second experiment (scripts/scripts.jl:152-281, test_RRGCont):
+//   mode 0  rrrMC(X::SingleGraph)  src/RRRMC.jl:149-219   DeltaECacheCont + DynamicSampler (src/DeltaE.jl:297-410, DynamicSamplers.jl)
+//   mode 1  bklMC                  src/RRRMC.jl:311-359   same cache, rand_skip (DeltaE.jl:319-325)
+//   mode 2  wtmMC                  src/RRRMC.jl:376-426   THeap of next-flip times (src/WaitingTimes.jl), tau = max(1, exp(beta dE))
+// One thread per replica, replica-contiguous state in HBM/L2 (the move is state dependent, as for the other reduced-rejection
+// kernels).  The graph's local-field cache is the one of spf_kernels.hpp (delta_energy = -lfields, update_cache! with the exact
+// undo path through the K+1-entry record), exp / log1p are the fixed-order ones shared with the oracle, every Float64 running sum
+// (tree nodes, z, E, acc_rate, t) is updated in the reference's order: bit-identical to the CPU restatement.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "philox.hpp"
+#include "rrr_kernels.hpp"   // TAG_RRR, TAG_WTM, prior_of, kRrrThreads
+#include "sk_kernels.hpp"    // det_exp, det_log1p
+
+namespace rrrmc {
+
+constexpr int kContKmax = 8;
+
+struct ContParams {
+    const int32_t* A;        // [N][K]
+    const double* J;         // [N][K]
+    uint32_t* spins;         // [R][W]
+    double* lf;              // [R][N]   local fields
+    double* undo;            // [R][K+1]
+    double* dEs;             // [R][N]   DeltaECacheCont.ΔEs          (wtmMC: heap keys)
+    double* v;               // [R][N2]  DynamicSampler.v
+    double* ps;              // [R][N2]  DynamicSampler.ps (N2 - 1 used)
+    uint16_t* hid;           // [R][N]   wtmMC: site at heap position
+    uint16_t* hpos;          // [R][N]   wtmMC: heap position of site
+    double* E_cur;           // [R]
+    int64_t* stats;          // [R][3]
+    double* Es;              // [nsamples][R]
+    double* t_out;           // [R]
+    int32_t* status;         // [R]  1 = DynamicSampler's "unrecoverable loss of precision"
+    double beta, staged_thr, lambda, stepf;
+    uint64_t g0;
+    int64_t iters, step;
+    uint32_t k0, k1, replica0, call;
+    int N, K, N2, levs, W, R, Rp, ea_form, mode;      // Rp = row stride of Es
+};
+
+struct ContChain {
+    const ContParams* P;
+    uint32_t* sp; double* lf; double* undo; double* dEs; double* v; double* ps; uint16_t* hid; uint16_t* hpos;
+    int mlast;
+    double z;
+    long long trefresh;
+    uint32_t rep;
+    uint64_t nd;
+
+    __device__ __forceinline__ int sbit(int x) const { return (int)((sp[x >> 5] >> (x & 31)) & 1u); }
+    __device__ __forceinline__ bool is_nb(const int32_t* Ax, int q) const { return !(P->ea_form && q > 0 && Ax[q] == Ax[q - 1]); }
+    // spinflip!(X, C, move): bit flip + update_cache! (RRG.jl:576-617, EA.jl:613-653) with the undo record
+    __device__ void flip(int move)
+    {
+        sp[move >> 5] ^= 1u << (move & 31);
+        const int K = P->K;
+        const int32_t* Ax = P->A + (size_t)move * K;
+        const double* Jx = P->J + (size_t)move * K;
+        const double lfm = lf[move];
+        if (mlast == move) {
+            for (int k = 0; k < K; ++k) {
+                if (k > 0 && Ax[k] == Ax[k - 1]) continue;
+                const int y = Ax[k];
+                const double tmp = lf[y];
+                lf[y] = undo[k];
+                undo[k] = tmp;
+            }
+            lf[move] = -lfm;
+            undo[K] = -undo[K];
+            return;
+        }
+        const int sx = sbit(move);
+        double vv = 0.0;
+        for (int k = 0; k < K; ++k) {
+            const int y = Ax[k];
+            if (!(k > 0 && Ax[k] == Ax[k - 1])) { vv = lf[y]; undo[k] = vv; }
+            const double c = (sx ^ sbit(y)) ? -4.0 : 4.0;
+            vv = vv - c * Jx[k];
+            if (k == K - 1 || Ax[k + 1] != y) lf[y] = vv;
+        }
+        undo[K] = lfm;
+        lf[move] = -lfm;
+        mlast = move;
+    }
+    __device__ __forceinline__ double dE(int i) const { return -lf[i]; }          // RRG.jl:619-625
+
+    // ---- DynamicSampler (DynamicSamplers.jl:84-176) ----
+    __device__ void refresh()
+    {
+        double zz = 0.0;
+        for (int i = 0; i < P->N2; ++i) zz += v[i];
+        z = zz;
+        for (int k = 0; k < P->N2 - 1; ++k) ps[k] = 0.0;
+        for (int i = 0; i < P->N; ++i) {
+            const double vi = v[i];
+            int k = 0, u = 1 << (P->levs - 1), off = 1;
+            for (int lev = 0; lev < P->levs; ++lev) {
+                if ((i & u) == 0) { ps[off - 1 + k] += vi; k *= 2; }
+                else k = 2 * k + 1;
+                u >>= 1; off *= 2;
+            }
+        }
+        trefresh = 0;
+    }
+    __device__ void set(int i, double x)
+    {
+        if (trefresh >= (P->N > 100 ? P->N : 100)) refresh();
+        trefresh += 1;
+        const double d = x - v[i];
+        v[i] = x;
+        z += d;
+        int k = 0, u = 1 << (P->levs - 1), off = 1;
+        for (int lev = 0; lev < P->levs; ++lev) {
+            if ((i & u) == 0) { ps[off - 1 + k] += d; k *= 2; }
+            else k = 2 * k + 1;
+            u >>= 1; off *= 2;
+        }
+    }
+    __device__ int getel(double x)
+    {
+        for (;;) {
+            x *= z;
+            int k = 0, off = 1;
+            for (int lev = 0; lev < P->levs; ++lev) {
+                const double p = ps[off - 1 + k];
+                k *= 2;
+                if (x > p) { x -= p; k += 1; }
+                off *= 2;
+            }
+            if (k >= P->N || v[k] == 0) {
+                if (!(trefresh > 0)) return -1;
+                refresh();
+                continue;
+            }
+            return k;
+        }
+    }
+    // apply_move!(X, C, move, cache::DeltaECacheCont): DeltaE.jl:376-410; returns c = z / z'
+    __device__ double apply_move(int move)
+    {
+        flip(move);
+        const double z0 = z;
+        dEs[move] = dE(move);
+        set(move, prior_of(P->beta * dEs[move]));
+        const int32_t* Ax = P->A + (size_t)move * P->K;
+        for (int q = 0; q < P->K; ++q) {
+            if (!is_nb(Ax, q)) continue;
+            const int j = Ax[q];
+            dEs[j] = dE(j);
+            set(j, prior_of(P->beta * dEs[j]));
+        }
+        return z0 / z;
+    }
+
+    // ---- wtmMC heap (keys in dEs[], by heap position) ----
+    __device__ __forceinline__ double uniform()
+    {
+        const uint64_t n = nd++, blk = n >> 1;
+        const Philox4 o = philox4x32_10((uint32_t)blk, (uint32_t)(blk >> 32), rep, TAG_WTM | (P->call << 8), P->k0, P->k1);
+        const uint64_t u = (n & 1u) ? (((uint64_t)o.w[2] << 32) | o.w[3]) : (((uint64_t)o.w[0] << 32) | o.w[1]);
+        return (double)(u >> 11) * 0x1.0p-53;
+    }
+    __device__ __forceinline__ double gen_wt(double d)           // gen_wt(tauDE(d)): WaitingTimes.jl:16-22
+    {
+        const double e = det_exp(P->beta * d);
+        return -(e > 1.0 ? e : 1.0) * det_log1p(-uniform());
+    }
+    __device__ __forceinline__ bool before(double ta, int a, double tb, int b) const { return ta < tb || (ta == tb && a < b); }
+    __device__ void sift_down(int pos, int n)
+    {
+        double* ht = dEs;
+        const double t = ht[pos];
+        const int id = hid[pos];
+        for (;;) {
+            int c = 2 * pos + 1;
+            if (c >= n) break;
+            if (c + 1 < n && before(ht[c + 1], hid[c + 1], ht[c], hid[c])) c += 1;
+            if (!before(ht[c], hid[c], t, id)) break;
+            ht[pos] = ht[c]; hid[pos] = hid[c]; hpos[hid[c]] = (uint16_t)pos;
+            pos = c;
+        }
+        ht[pos] = t; hid[pos] = (uint16_t)id; hpos[id] = (uint16_t)pos;
+    }
+    __device__ void sift_up(int pos)
+    {
+        double* ht = dEs;
+        const double t = ht[pos];
+        const int id = hid[pos];
+        while (pos > 0) {
+            const int par = (pos - 1) >> 1;
+            if (!before(t, id, ht[par], hid[par])) break;
+            ht[pos] = ht[par]; hid[pos] = hid[par]; hpos[hid[par]] = (uint16_t)pos;
+            pos = par;
+        }
+        ht[pos] = t; hid[pos] = (uint16_t)id; hpos[id] = (uint16_t)pos;
+    }
+    __device__ __forceinline__ void heap_update(int i, double t)
+    {
+        const int pos = hpos[i];
+        const double old = dEs[pos];
+        dEs[pos] = t;
+        if (t < old) sift_up(pos); else sift_down(pos, P->N);
+    }
+};
+
+__global__ __launch_bounds__(kRrrThreads) void cont_sparse_kernel(ContParams P)
+{
+    const int r = blockIdx.x * kRrrThreads + threadIdx.x;
+    if (r >= P.R) return;
+    const int N = P.N, K = P.K;
+    ContChain c;
+    c.P = &P;
+    c.sp = P.spins + (size_t)r * P.W; c.lf = P.lf + (size_t)r * N; c.undo = P.undo + (size_t)r * (K + 1);
+    c.dEs = P.dEs + (size_t)r * N; c.v = P.v + (size_t)r * P.N2; c.ps = P.ps + (size_t)r * P.N2;
+    c.hid = P.hid + (size_t)r * N; c.hpos = P.hpos + (size_t)r * N;
+    c.mlast = -1; c.z = 0.0; c.trefresh = 0; c.nd = 0;
+    c.rep = P.replica0 + (uint32_t)r;
+    // energy(X, C): RRG.jl:546-574 / EA.jl:584-611
+    double E1 = 0.0;
+    for (int i = 0; i < N; ++i) {
+        const int sx = 2 * c.sbit(i) - 1;
+        double fl = 0.0;
+        for (int q = 0; q < K; ++q) {
+            const int sy = 2 * c.sbit(P.A[(size_t)i * K + q]) - 1;
+            fl = fl - P.J[(size_t)i * K + q] * (double)sx * (double)sy;
+        }
+        E1 = E1 + fl;
+        c.lf[i] = 2.0 * fl;
+    }
+    double E = E1 / 2;
+    long long accepted = 0, second = 0, ns = 0, itdone = 0;
+    int bad = 0;
+    double t = 0.0;
+
+    if (P.mode == 2) {
+        for (int i = 0; i < N; ++i) { c.dEs[i] = c.gen_wt(c.dE(i)); c.hid[i] = (uint16_t)i; c.hpos[i] = (uint16_t)i; }
+        for (int pos = N / 2 - 1; pos >= 0; --pos) c.sift_down(pos, N);
+        const double st = P.stepf / (double)N, tmax = st * (double)P.iters;
+        double nextstep = st;
+        bool out = false;
+        while (t < tmax && !out) {
+            const double tp = c.dEs[0];
+            const int move = c.hid[0];
+            while (tp >= nextstep) {
+                P.Es[(size_t)ns * P.Rp + r] = E; ns += 1;
+                nextstep += st;
+                if (nextstep > tmax + 1e-10) { out = true; break; }
+            }
+            if (out) break;
+            t = tp;
+            const double d = c.dE(move);
+            c.flip(move);
+            c.heap_update(move, t + c.gen_wt(-d));
+            const int32_t* Ax = P.A + (size_t)move * K;
+            for (int q = 0; q < K; ++q) {
+                if (!c.is_nb(Ax, q)) continue;
+                const int j = Ax[q];
+                c.heap_update(j, t + c.gen_wt(c.dE(j)));
+            }
+            E += d;
+            accepted += 1;
+        }
+        second = accepted; itdone = ns;
+    } else {
+        for (int i = 0; i < P.N2; ++i) c.v[i] = 0.0;
+        for (int i = 0; i < N; ++i) { c.dEs[i] = c.dE(i); c.v[i] = prior_of(P.beta * c.dEs[i]); }      // DeltaECacheCont: DeltaE.jl:304-313
+        c.refresh();
+        if (P.mode == 0) {
+            double acc_rate = 0.5;
+            for (long long it = 1; it <= P.iters && !bad; ++it) {
+                if (it % P.step == 0) { P.Es[(size_t)ns * P.Rp + r] = E; ns += 1; }
+                const uint64_t g = P.g0 + (uint64_t)it;
+                const Philox4 o = philox4x32_10((uint32_t)g, (uint32_t)(g >> 32), c.rep, TAG_RRR, P.k0, P.k1);
+                const double u0 = (double)((((uint64_t)o.w[0] << 32) | o.w[1]) >> 11) * 0x1.0p-53;
+                const Philox4 o2 = philox4x32_10((uint32_t)g, (uint32_t)(g >> 32), c.rep, TAG_RRR | (1u << 8), P.k0, P.k1);
+                const double u1 = (double)((((uint64_t)o2.w[0] << 32) | o2.w[1]) >> 11) * 0x1.0p-53;
+                bool acc = false;
+                const int move = c.getel(u0);                                   // rand_move: DeltaE.jl:327-333
+                if (move < 0) { bad = 1; break; }
+                const double dE = c.dEs[move];
+                if (acc_rate < P.staged_thr) {
+                    second += 1;
+                    const double z0 = c.z;
+                    c.flip(move);                                               // compute_staged!: DeltaE.jl:357-374
+                    int sj[kContKmax + 1], nst = 0;
+                    double sdE[kContKmax + 1], spv[kContKmax + 1];
+                    sj[nst] = move; sdE[nst] = c.dE(move); spv[nst] = prior_of(P.beta * sdE[nst]); ++nst;
+                    const int32_t* Ax = P.A + (size_t)move * K;
+                    for (int q = 0; q < K; ++q) {
+                        if (!c.is_nb(Ax, q)) continue;
+                        sj[nst] = Ax[q]; sdE[nst] = c.dE(Ax[q]); spv[nst] = prior_of(P.beta * sdE[nst]); ++nst;
+                    }
+                    c.flip(move);
+                    double zp = c.z;                                            // compute_reverse_probabilities!: :345-355
+                    for (int q = 0; q < nst; ++q) zp += spv[q] - c.v[sj[q]];
+                    if (zp < 2.2250738585072014e-308) zp = 2.2250738585072014e-308;
+                    if (zp > (double)N) zp = (double)N;
+                    if (u1 < z0 / zp) {
+                        c.flip(move);
+                        for (int q = 0; q < nst; ++q) { c.dEs[sj[q]] = sdE[q]; c.set(sj[q], spv[q]); }      // apply_staged!
+                        E += dE; accepted += 1; acc = true;
+                    }
+                } else {
+                    const double cc = c.apply_move(move);
+                    if (u1 < cc) { E += dE; accepted += 1; acc = true; }
+                    else c.apply_move(move);
+                }
+                acc_rate = acc_rate * (1 - P.lambda) + (acc ? 1.0 : 0.0) * P.lambda;
+            }
+            itdone = P.iters;
+        } else {
+            long long it = 0, nextstep = P.step, m = 0;
+            while (it < P.iters) {
+                m += 1;
+                const uint64_t g = P.g0 + (uint64_t)m;
+                const Philox4 o3 = philox4x32_10((uint32_t)g, (uint32_t)(g >> 32), c.rep, TAG_RRR | (2u << 8), P.k0, P.k1);
+                const double us = (double)((((uint64_t)o3.w[0] << 32) | o3.w[1]) >> 11) * 0x1.0p-53;
+                double b = c.z / (double)N;                                     // rand_skip: DeltaE.jl:319-325
+                if (b < 2.2250738585072014e-308) b = 2.2250738585072014e-308;
+                if (b > 1.0) b = 1.0;
+                const double skipf = floor(det_log1p(-us) / det_log1p(-b));
+                const long long skip = skipf >= 9.0e18 ? (long long)9.0e18 : (long long)skipf;
+                const Philox4 o = philox4x32_10((uint32_t)g, (uint32_t)(g >> 32), c.rep, TAG_RRR, P.k0, P.k1);
+                const int move = c.getel((double)((((uint64_t)o.w[0] << 32) | o.w[1]) >> 11) * 0x1.0p-53);
+                if (move < 0) { bad = 1; break; }
+                const double dE = c.dEs[move];
+                bool out = false;
+                while (it + skip + 1 >= nextstep) {
+                    P.Es[(size_t)ns * P.Rp + r] = E; ns += 1;
+                    nextstep += P.step;
+                    if (nextstep > P.iters) { out = true; break; }
+                }
+                if (out) break;
+                c.apply_move(move);                                             // apply_step_bkl!: RRRMC.jl:294-295
+                it += skip + 1;
+                E += dE;
+                accepted += 1;
+            }
+            second = accepted; itdone = it;
+        }
+    }
+    P.E_cur[r] = E;
+    P.stats[(size_t)r * 3] = accepted; P.stats[(size_t)r * 3 + 1] = second; P.stats[(size_t)r * 3 + 2] = itdone;
+    P.t_out[r] = t;
+    P.status[r] = bad;
+}
+
+// [W][N] uint64 (bit l of word (w, x) = spin x of replica 64 w + l)  <->  replica-contiguous [R][Wr] 32-bit words (bit = site & 31)
+__global__ __launch_bounds__(256) void cont_spins_in_kernel(const unsigned long long* __restrict__ bs, uint32_t* __restrict__ spins, int N, int Wr, int R)
+{
+    const int w = blockIdx.x * 256 + threadIdx.x, r = blockIdx.y;
+    if (w >= Wr || r >= R) return;
+    uint32_t word = 0u;
+    for (int b = 0; b < 32; ++b) {
+        const int x = 32 * w + b;
+        if (x < N) word |= (uint32_t)((bs[(size_t)(r >> 6) * N + x] >> (r & 63)) & 1ull) << b;
+    }
+    spins[(size_t)r * Wr + w] = word;
+}
+__global__ __launch_bounds__(256) void cont_spins_out_kernel(const uint32_t* __restrict__ spins, unsigned long long* __restrict__ bs, int N, int Wr, int R)
+{
+    const int x = blockIdx.x * 256 + threadIdx.x, g = blockIdx.y;
+    if (x >= N) return;
+    unsigned long long word = 0ull;
+    for (int b = 0; b < 64; ++b) {
+        const int r = g * 64 + b;
+        if (r < R) word |= (unsigned long long)((spins[(size_t)r * Wr + (x >> 5)] >> (x & 31)) & 1u) << b;
+    }
+    bs[(size_t)g * N + x] = word;
+}
+
+}  // namespace rrrmc

@@ -126,3 +126,77 @@ int32_t spf_standard_mc_async(rrrmc_ctx* ctx, double beta, int64_t iters, int64_
     ctx->timing_valid = true;
     return RRRMC_OK;
 }
+
+// rrrMC / bklMC / wtmMC with the continuous-energy caches on GraphRRGNormal / GraphEANormal (cont_kernels.hpp)
+int32_t spf_cont_async(rrrmc_ctx* ctx, int mode, double beta, int64_t iters, int64_t step, double stepf, double staged_thr, double staged_thr_fact)
+{
+    if (iters < 0) return fail(ctx, RRRMC_ERR_INVALID_ARG, "iters / samples must be >= 0, given %lld", (long long)iters);
+    if (mode != 2 && step < 1) return fail(ctx, RRRMC_ERR_INVALID_ARG, "step must be >= 1, given %lld", (long long)step);
+    if (mode == 2 && (!(stepf > 0.0) || !std::isfinite(stepf))) return fail(ctx, RRRMC_ERR_INVALID_ARG, "step must be positive and finite, given %g", stepf);
+    if (!std::isfinite(beta)) return fail(ctx, RRRMC_ERR_INVALID_ARG, "beta must be finite, given: %g", beta);
+    if (ctx->N > 65535) return fail(ctx, RRRMC_ERR_UNSUPPORTED, "N=%lld: the thread-per-replica samplers index spins with 16 bits", (long long)ctx->N);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    ctx->results_valid = false; ctx->last_call_wtm = false; ctx->last_call_eo = false;
+    ctx->timing_valid = false;
+    const int64_t N = ctx->N, K = ctx->K, R = ctx->R, W = (N + 31) / 32;
+    int levs = 0;
+    while (((int64_t)1 << levs) < N) ++levs;
+    const int64_t N2 = (int64_t)1 << levs;
+    if (!ctx->cs_buf) {
+        HIP_TRY(ctx, hipMalloc(&ctx->cs_spins, sizeof(uint32_t) * R * W));
+        HIP_TRY(ctx, hipMalloc(&ctx->cs_buf, sizeof(double) * (size_t)R * (size_t)(2 * N + 2 * N2 + K + 1)));
+        HIP_TRY(ctx, hipMalloc(&ctx->cs_u16, sizeof(uint16_t) * (size_t)R * 2 * N));
+        HIP_TRY(ctx, hipMalloc(&ctx->rs_status, sizeof(int32_t) * R));
+        if (!ctx->q_stats) HIP_TRY(ctx, hipMalloc(&ctx->q_stats, sizeof(int64_t) * R * 3));
+        if (!ctx->wt_time) HIP_TRY(ctx, hipMalloc(&ctx->wt_time, sizeof(double) * R));
+    }
+    const int64_t nsamp = mode == 2 ? iters : iters / step;
+    const size_t es_need = (size_t)(nsamp > 0 ? nsamp : 1) * ctx->Rpad;
+    if (es_need > ctx->sk_Es_cap) {
+        free_dev(ctx->sk_Es);
+        ctx->sk_Es_cap = 0;
+        HIP_TRY(ctx, hipMalloc(&ctx->sk_Es, sizeof(double) * es_need));
+        ctx->sk_Es_cap = es_need;
+    }
+    while (ctx->ev_sweep.size() < 2) {
+        hipEvent_t e;
+        HIP_TRY(ctx, hipEventCreate(&e));
+        ctx->ev_sweep.push_back(e);
+    }
+    ContParams P{};
+    double* b = ctx->cs_buf;
+    P.A = ctx->d_A; P.J = ctx->pf_J; P.spins = ctx->cs_spins;
+    P.lf = b; b += (size_t)R * N;
+    P.dEs = b; b += (size_t)R * N;
+    P.v = b; b += (size_t)R * N2;
+    P.ps = b; b += (size_t)R * N2;
+    P.undo = b;
+    P.hid = ctx->cs_u16; P.hpos = ctx->cs_u16 + (size_t)R * N;
+    P.E_cur = ctx->sk_E; P.stats = ctx->q_stats; P.Es = ctx->sk_Es; P.t_out = ctx->wt_time; P.status = ctx->rs_status;
+    P.beta = beta; P.staged_thr = staged_thr; P.lambda = staged_thr_fact / (double)N; P.stepf = stepf;
+    P.g0 = ctx->it_done; P.iters = iters; P.step = step;
+    P.k0 = (uint32_t)ctx->seed; P.k1 = (uint32_t)(ctx->seed >> 32); P.replica0 = ctx->replica0; P.call = ctx->wtm_calls & 0xffffffu;
+    P.N = (int)N; P.K = (int)K; P.N2 = (int)N2; P.levs = levs; P.W = (int)W; P.R = (int)R; P.Rp = (int)ctx->Rpad;
+    P.ea_form = 1;           // de-duplicate repeated neighbours (EA.jl:680); a no-op for GraphRRGNormal tables
+    P.mode = mode;
+    hipStream_t st = ctx->stream;
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_begin, st));
+    hipLaunchKernelGGL(cont_spins_in_kernel, dim3((unsigned)((W + 255) / 256), (unsigned)R), dim3(256), 0, st, ctx->pf_spins, ctx->cs_spins, (int)N, (int)W, (int)R);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_sweep[0], st));
+    hipLaunchKernelGGL(cont_sparse_kernel, dim3((unsigned)((R + kRrrThreads - 1) / kRrrThreads)), dim3(kRrrThreads), 0, st, P);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_sweep[1], st));
+    hipLaunchKernelGGL(cont_spins_out_kernel, dim3((unsigned)((N + 255) / 256), (unsigned)ctx->pfW), dim3(256), 0, st, ctx->cs_spins, ctx->pf_spins, (int)N, (int)W, (int)R);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_end, st));
+    if (mode == 2) ctx->wtm_calls += 1; else ctx->it_done += (uint64_t)iters;
+    ctx->stats_stride = 3;
+    ctx->sweep_launches = 1;
+    ctx->nsamp = nsamp;
+    ctx->results_valid = true;
+    ctx->timing_valid = true;
+    ctx->last_call_rrr = true;          // accepted / moves come from q_stats
+    ctx->last_call_wtm = mode == 2;
+    return RRRMC_OK;
+}

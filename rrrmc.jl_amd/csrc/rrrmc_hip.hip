@@ -19,6 +19,7 @@
 #include "obs_kernels.hpp"
 #include "spf_kernels.hpp"
 #include "dbl_kernels.hpp"
+#include "cont_kernels.hpp"
 
 using namespace rrrmc;
 
@@ -157,6 +158,10 @@ struct rrrmc_ctx {
     double* db_undo = nullptr;     // [R][K+1]
     int db_L = 0, db_ea_form = 0;
     int db_dElist[kDLmax] = {0};
+    // ---- continuous-energy rrrMC / bklMC / wtmMC on RRRMC_MODEL_SPARSE_F64 (allocated on first use) ----
+    uint32_t* cs_spins = nullptr;  // [R][W] replica-contiguous words
+    double* cs_buf = nullptr;      // lf, dEs (heap keys), v, ps, undo
+    uint16_t* cs_u16 = nullptr;    // heap id / position
     // ---- snapshots / observables ----
     uint8_t* snap = nullptr;       // [nslots][snap_bytes]: copies of the model's native spin buffer
     int32_t snap_slots = 0;
@@ -408,6 +413,7 @@ void rrrmc_ctx_destroy(rrrmc_ctx* ctx)
     free_dev(ctx->db_dJ); free_dev(ctx->db_rJ); free_dev(ctx->db_cls); free_dev(ctx->db_sv); free_dev(ctx->db_spos); free_dev(ctx->db_lf); free_dev(ctx->db_undo);
     free_dev(ctx->wt_t); free_dev(ctx->wt_id); free_dev(ctx->wt_pos); free_dev(ctx->wt_time);
     free_dev(ctx->eo_cmin); free_dev(ctx->eo_ftau);
+    free_dev(ctx->cs_spins); free_dev(ctx->cs_buf); free_dev(ctx->cs_u16);
     free_dev(ctx->snap); free_dev(ctx->d_pairs); free_dev(ctx->d_ovl); free_dev(ctx->d_qobs);
     for (int i = 0; i < 2; ++i) { free_dev(ctx->d_slots[i]); free_dev(ctx->d_vecs[i]); }
     if (ctx->plan_stream) { (void)hipStreamSynchronize(ctx->plan_stream); (void)hipStreamDestroy(ctx->plan_stream); }
@@ -863,8 +869,8 @@ int32_t rrrmc_sync(rrrmc_ctx* ctx)
     if (!ctx) return RRRMC_ERR_INVALID_ARG;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    if (ctx->last_call_rrr && ctx->model == RRRMC_MODEL_SK_NORMAL && ctx->rs_status) {
-        std::vector<int32_t> stt((size_t)ctx->Rpad);
+    if (ctx->last_call_rrr && (ctx->model == RRRMC_MODEL_SK_NORMAL || ctx->model == RRRMC_MODEL_SPARSE_F64) && ctx->rs_status) {
+        std::vector<int32_t> stt((size_t)ctx->R);
         HIP_TRY(ctx, hipMemcpy(stt.data(), ctx->rs_status, sizeof(int32_t) * stt.size(), hipMemcpyDeviceToHost));
         for (int64_t r = 0; r < ctx->R; ++r)
             if (stt[r]) return fail(ctx, RRRMC_ERR_STATE, "replica %lld: Unrecoverable loss of precision detected in the dynamic sampler", (long long)r);   // DynamicSamplers.jl:147
@@ -1102,6 +1108,7 @@ int32_t rrrmc_rrr_mc_async(rrrmc_ctx* ctx, double beta, double fourK, int64_t it
     if (ctx->model == RRRMC_MODEL_SK_NORMAL) return sk_rrr_mc_async(ctx, beta, iters, step, staged_thr, staged_thr_fact);
     if (ctx->model == RRRMC_MODEL_SPARSE_PM1) return sparse_rrr_bkl_async(ctx, 0, beta, iters, step, staged_thr, staged_thr_fact);
     if (ctx->model == RRRMC_MODEL_SPARSE_DISCRETIZED) return dbl_rrr_mc_async(ctx, beta, iters, step, staged_thr, staged_thr_fact);
+    if (ctx->model == RRRMC_MODEL_SPARSE_F64) return spf_cont_async(ctx, 0, beta, iters, step, 1.0, staged_thr, staged_thr_fact);
     if (ctx->model != RRRMC_MODEL_QUANT_RRG) return fail(ctx, RRRMC_ERR_UNSUPPORTED, "rrrMC is not available for model kind %d", ctx->model);
     if (!(fourK > 0.0) || !std::isfinite(fourK)) return fail(ctx, RRRMC_ERR_INVALID_ARG, "fourK must be positive and finite, given: %g", fourK);
     if (iters < 0) return fail(ctx, RRRMC_ERR_INVALID_ARG, "iters must be >= 0, given %lld", (long long)iters);
@@ -1151,8 +1158,9 @@ int32_t rrrmc_bkl_mc_async(rrrmc_ctx* ctx, double beta, int64_t iters, int64_t s
 {
     int32_t rc = ensure_state(ctx, true);
     if (rc) return rc;
-    if (ctx->model != RRRMC_MODEL_SPARSE_PM1) return fail(ctx, RRRMC_ERR_UNSUPPORTED, "bklMC is wired for RRRMC_MODEL_SPARSE_PM1");
     if (!std::isfinite(beta)) return fail(ctx, RRRMC_ERR_INVALID_ARG, "beta must be finite, given: %g", beta);
+    if (ctx->model == RRRMC_MODEL_SPARSE_F64) return spf_cont_async(ctx, 1, beta, iters, step, 1.0, 0.0, 5.0);
+    if (ctx->model != RRRMC_MODEL_SPARSE_PM1) return fail(ctx, RRRMC_ERR_UNSUPPORTED, "bklMC is wired for RRRMC_MODEL_SPARSE_PM1 and RRRMC_MODEL_SPARSE_F64");
     return sparse_rrr_bkl_async(ctx, 1, beta, iters, step, 0.0, 5.0);
 }
 
@@ -1170,7 +1178,8 @@ int32_t rrrmc_wtm_mc_async(rrrmc_ctx* ctx, double beta, int64_t samples, double 
 {
     int32_t rc = ensure_state(ctx, true);
     if (rc) return rc;
-    if (ctx->model != RRRMC_MODEL_SPARSE_PM1) return fail(ctx, RRRMC_ERR_UNSUPPORTED, "wtmMC is wired for RRRMC_MODEL_SPARSE_PM1");
+    if (ctx->model == RRRMC_MODEL_SPARSE_F64) return spf_cont_async(ctx, 2, beta, samples, 1, step, 0.0, 5.0);
+    if (ctx->model != RRRMC_MODEL_SPARSE_PM1) return fail(ctx, RRRMC_ERR_UNSUPPORTED, "wtmMC is wired for RRRMC_MODEL_SPARSE_PM1 and RRRMC_MODEL_SPARSE_F64");
     return sparse_wtm_async(ctx, beta, samples, step);
 }
 

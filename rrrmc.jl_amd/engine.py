@@ -143,7 +143,7 @@ class Engine:
         """rrrMC(X::DoubleGraph, β, iters; step, staged_thr, staged_thr_fact) (src/RRRMC.jl:221-290).
         Returns (Es[R, iters // step], accepted[R], staged_iters[R])."""
         if staged_thr is None:          # RRRMC.jl:162-164 (SimpleGraph 0.8, DiscrGraph 0.5) and :226 (DoubleGraph 0.5)
-            staged_thr = 0.8 if self.X.model_kind in (MODEL_SK_NORMAL, MODEL_SK_BINARY) else 0.5
+            staged_thr = 0.8 if self.X.model_kind in (MODEL_SK_NORMAL, MODEL_SK_BINARY, MODEL_SPARSE_F64) else 0.5
         check(lib().rrrmc_rrr_mc_async(self._ctx, float(beta), float(getattr(self.X, "fourK", 0.0)), int(iters), int(step),
                                        float(staged_thr), float(staged_thr_fact)), self._ctx)
         self._last = (int(iters), int(step))

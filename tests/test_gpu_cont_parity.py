@@ -1,0 +1,90 @@
+"""GPU parity for the continuous-energy samplers on GraphRRGNormal / GraphEANormal — the reference's second experiment
+(scripts/scripts.jl:152-281 test_RRGCont): rrrMC(X::SingleGraph) (src/RRRMC.jl:149-219), bklMC (:311-359), wtmMC (:376-426) over
+DeltaECacheCont + DynamicSampler / THeap.  north_star tolerance for Float64 models is 1e-6 relative; we require bit equality."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _graph(pkg, kind, seed):
+    if kind == "rrg10":
+        return pkg.GraphRRGNormal(10, 3, seed=seed), "rrg"          # test/runtests.jl:40
+    if kind == "rrg300":
+        return pkg.GraphRRGNormal(300, 3, seed=seed), "rrg"
+    if kind == "rrg4096":
+        return pkg.GraphRRGNormal(4096, 3, seed=seed), "rrg"
+    if kind == "ea2x3":
+        return pkg.GraphEANormal(2, 3, seed=seed), "ea"             # runtests.jl:50: double bonds
+    if kind == "ea5x3":
+        return pkg.GraphEANormal(5, 3, seed=seed), "ea"
+    raise KeyError(kind)
+
+
+@pytest.mark.parametrize("kind,R,beta,iters,step,thr", [
+    ("rrg10", 70, 2.0, 5000, 50, 0.8),
+    ("rrg10", 8, 2.0, 3000, 50, 0.0),          # always direct: every rejection goes through the undo path
+    ("rrg10", 8, 2.0, 3000, 50, 1.0),          # always staged
+    ("rrg300", 64, 1.5, 20000, 500, 0.8),
+    ("rrg4096", 5, 2.0, 20000, 1024, 0.8),
+    ("ea2x3", 16, 1.0, 4000, 64, 0.8),
+    ("ea5x3", 33, 1.5, 10000, 100, 0.8),
+])
+def test_rrr_cont_bit_exact(pkg, oracle, kind, R, beta, iters, step, thr):
+    seed = 313000 + len(kind) + R
+    X, form = _graph(pkg, kind, seed)
+    with pkg.Engine(X, R) as eng:
+        eng.seed(seed)
+        eng.init_spins_random()
+        C0 = eng.get_config()
+        Es, acc, staged = eng.rrr_mc(beta, iters, step, staged_thr=thr)
+        C1 = eng.get_config()
+        E1 = eng.energy()
+        Es2, acc2, staged2 = eng.rrr_mc(beta, 1000, 100, staged_thr=thr)          # continues the streams
+        C2 = eng.get_config()
+    for r in range(R):
+        Es_ref, ch_ref, st, _ = oracle.cont_sparse("rrr", X.A, X.J, beta, iters, step, seed, C0.s[r], replica=r, staged_thr=thr, form=form)
+        assert np.allclose(Es[r], Es_ref, rtol=1e-6, atol=1e-9)
+        assert (Es[r] == Es_ref).all() and (C1.s[r] == ch_ref).all() and acc[r] == st[0] and staged[r] == st[1]
+        assert abs(E1[r] - oracle.spf_energy(X.A, X.J, ch_ref, form=form)) == 0
+        Es2_ref, ch2_ref, st2, _ = oracle.cont_sparse("rrr", X.A, X.J, beta, 1000, 100, seed, ch_ref, it0=iters, replica=r, staged_thr=thr, form=form)
+        assert (Es2[r] == Es2_ref).all() and (C2.s[r] == ch2_ref).all() and acc2[r] == st2[0]
+
+
+@pytest.mark.parametrize("kind,R,beta,iters,step", [
+    ("rrg10", 40, 2.0, 20000, 100), ("rrg300", 64, 2.0, 50000, 1000), ("ea2x3", 16, 1.5, 8000, 64), ("rrg4096", 4, 3.0, 200000, 4096),
+])
+def test_bkl_cont_bit_exact(pkg, oracle, kind, R, beta, iters, step):
+    seed = 515000 + len(kind) + R
+    X, form = _graph(pkg, kind, seed)
+    with pkg.Engine(X, R) as eng:
+        eng.seed(seed)
+        eng.init_spins_random()
+        C0 = eng.get_config()
+        Es, moves = eng.bkl_mc(beta, iters, step)
+        C1 = eng.get_config()
+    assert Es.shape == (R, iters // step)
+    for r in range(R):
+        Es_ref, ch_ref, st, _ = oracle.cont_sparse("bkl", X.A, X.J, beta, iters, step, seed, C0.s[r], replica=r, form=form)
+        assert len(Es_ref) == iters // step
+        assert (Es[r] == Es_ref).all() and (C1.s[r] == ch_ref).all() and moves[r] == st[0]
+
+
+@pytest.mark.parametrize("kind,R,beta,samples,step", [
+    ("rrg10", 40, 2.0, 500, 1.0), ("rrg300", 64, 1.5, 3000, 2.0), ("ea2x3", 16, 1.0, 400, 1.0), ("rrg4096", 4, 2.0, 20000, 4.0),
+])
+def test_wtm_cont_bit_exact(pkg, oracle, kind, R, beta, samples, step):
+    seed = 717000 + len(kind) + R
+    X, form = _graph(pkg, kind, seed)
+    with pkg.Engine(X, R) as eng:
+        eng.seed(seed)
+        eng.init_spins_random()
+        C0 = eng.get_config()
+        Es, moves, t = eng.wtm_mc(beta, samples, step)
+        C1 = eng.get_config()
+        Es2, moves2, t2 = eng.wtm_mc(beta, 100, step)
+    for r in range(R):
+        Es_ref, ch_ref, st, t_ref = oracle.cont_sparse("wtm", X.A, X.J, beta, samples, 1, seed, C0.s[r], replica=r, stepf=step, form=form)
+        assert (Es[r] == Es_ref).all() and (C1.s[r] == ch_ref).all() and moves[r] == st[0] and t[r] == t_ref
+        Es2_ref, _, st2, t2_ref = oracle.cont_sparse("wtm", X.A, X.J, beta, 100, 1, seed, ch_ref, call=1, replica=r, stepf=step, form=form)
+        assert (Es2[r] == Es2_ref).all() and moves2[r] == st2[0] and t2[r] == t2_ref
