@@ -593,3 +593,19 @@ def cont_sparse(mode, A, J, beta, iters, step, seed, chunks, it0=0, call=0, repl
     if n < 0:
         raise RuntimeError("cont_sparse: DynamicSampler lost precision")
     return Es[:n], ch, stats, t.value
+
+
+def bkl_mc_skn(J, beta, iters, step, seed, chunks, it0=0, replica=0):
+    """bklMC on GraphSKNormal (continuous-energy cache); returns (Es, chunks, moves, iterations done)."""
+    L = lib()
+    L.orc_bkl_mc_skn.restype = C.c_int64
+    L.orc_bkl_mc_skn.argtypes = [C.c_int64, f64p, C.c_double, C.c_int64, C.c_int64, C.c_uint64, C.c_uint64, C.c_uint32, u64p, f64p, i64p]
+    J = np.ascontiguousarray(J, np.float64)
+    N = J.shape[0]
+    ch = np.array(chunks, np.uint64, copy=True)
+    Es = np.zeros(max(iters // step, 1))
+    stats = np.zeros(3, np.int64)
+    n = L.orc_bkl_mc_skn(N, J.reshape(-1), float(beta), int(iters), int(step), seed, it0, replica, ch, Es, stats)
+    if n < 0:
+        raise RuntimeError("bkl_mc_skn: DynamicSampler lost precision")
+    return Es[:n], ch, int(stats[0]), int(stats[2])

@@ -2089,3 +2089,58 @@ ORC_API int64_t orc_cont_sparse(int mode, int form, int64_t N, int64_t K, const 
     free(X.lfields); free(X.lfields_last);
     return bad ? -1 : nsamp;
 }
+
+/* bklMC (src/RRRMC.jl:311-359) on GraphSKNormal with DeltaECacheCont: rand_skip (DeltaE.jl:319-325),
+ * rand_move, apply_step_bkl! = apply_move!(X, C, move, cache, Val{false}) (RRRMC.jl:294-295) over all N - 1 neighbours.
+ * RRR stream sub 2 (skip), sub 0 (getel); g counts moves.  stats = [moves, moves, iterations done]. */
+ORC_API int64_t orc_bkl_mc_skn(int64_t N, const double *J, double beta, int64_t iters, int64_t step,
+                               uint64_t seed, uint64_t it0, uint32_t replica, uint64_t *chunks, double *Es, int64_t *stats)
+{
+    skn_t X = {N, J, NULL, NULL, -1};
+    X.lfields = (double *)malloc((size_t)N * 8);
+    X.lfields_last = (double *)malloc((size_t)N * 8);
+    double E = skn_energy(&X, chunks);
+    double *dEs = (double *)malloc((size_t)N * 8);
+    dyns_t ds;
+    dyns_init(&ds, N);
+    for (int64_t i = 0; i < N; ++i) { dEs[i] = X.lfields[i]; ds.v[i] = prior_of(beta * dEs[i]); }
+    dyns_refresh(&ds);
+    int64_t it = 0, nextstep = step, m = 0, accepted = 0, nsamp = 0, bad = 0;
+    while (it < iters) {
+        m += 1;
+        const uint64_t g = it0 + (uint64_t)m;
+        uint32_t w[4];
+        rrr_draw(seed, g, replica, 2, w);
+        double b = ds.z / (double)N;
+        if (b < 2.2250738585072014e-308) b = 2.2250738585072014e-308;
+        if (b > 1.0) b = 1.0;
+        double skipf = __builtin_floor(orc_det_log1p(-u53_of(w[0], w[1])) / orc_det_log1p(-b));
+        int64_t skip = skipf >= 9.0e18 ? (int64_t)9.0e18 : (int64_t)skipf;
+        rrr_draw(seed, g, replica, 0, w);
+        int64_t move = dyns_getel(&ds, u53_of(w[0], w[1]));
+        if (move < 0) { bad = 1; break; }
+        const double dE = dEs[move];
+        int out = 0;
+        while (it + skip + 1 >= nextstep) {
+            Es[nsamp++] = E;
+            nextstep += step;
+            if (nextstep > iters) { out = 1; break; }
+        }
+        if (out) break;
+        bitflip(chunks, move); skn_update_cache(&X, chunks, move);           /* apply_move!: DeltaE.jl:376-410 */
+        dEs[move] = X.lfields[move];
+        dyns_set(&ds, move, prior_of(beta * dEs[move]));
+        for (int64_t j = 0; j < N; ++j) {
+            if (j == move) continue;
+            dEs[j] = X.lfields[j];
+            dyns_set(&ds, j, prior_of(beta * dEs[j]));
+        }
+        it += skip + 1;
+        E += dE;
+        accepted += 1;
+    }
+    if (stats) { stats[0] = accepted; stats[1] = accepted; stats[2] = it; }
+    free(dEs); dyns_free(&ds);
+    free(X.lfields); free(X.lfields_last);
+    return bad ? -1 : nsamp;
+}

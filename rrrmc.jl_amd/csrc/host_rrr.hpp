@@ -47,7 +47,7 @@ int32_t quant_run_init(rrrmc_ctx* ctx, double beta, double fourK)
 
 
 // rrrMC(X::SingleGraph) on GraphSKNormal (RRRMC.jl:149-219): thread-per-replica kernel over interleaved arrays
-int32_t sk_rrr_mc_async(rrrmc_ctx* ctx, double beta, int64_t iters, int64_t step, double staged_thr, double staged_thr_fact)
+int32_t sk_rrr_mc_async(rrrmc_ctx* ctx, double beta, int64_t iters, int64_t step, double staged_thr, double staged_thr_fact, int mode = 0)
 {
     if (iters < 0) return fail(ctx, RRRMC_ERR_INVALID_ARG, "iters must be >= 0, given %lld", (long long)iters);
     if (step < 1) return fail(ctx, RRRMC_ERR_INVALID_ARG, "step must be >= 1, given %lld", (long long)step);
@@ -96,6 +96,7 @@ int32_t sk_rrr_mc_async(rrrmc_ctx* ctx, double beta, int64_t iters, int64_t step
     P.g0 = ctx->it_done; P.iters = iters; P.step = step;
     P.k0 = (uint32_t)ctx->seed; P.k1 = (uint32_t)(ctx->seed >> 32); P.replica0 = ctx->replica0;
     P.N = (int)N; P.N2 = (int)N2; P.levs = levs; P.W = (int)W; P.R = (int)ctx->R; P.Rp = (int)Rp;
+    P.mode = mode;
     ctx->stats_stride = 2;
     HIP_TRY(ctx, hipEventRecord(ctx->ev_begin, st));
     hipLaunchKernelGGL(rrsk_spins_in_kernel, dim3((unsigned)((Rp + 255) / 256), (unsigned)W), dim3(256), 0, st, ctx->sk_spins, ctx->rs_spins, (int)N, (int)W, (int)Rp);

@@ -329,6 +329,7 @@ struct RrrSkParams {
     int64_t iters, step;
     uint32_t k0, k1, replica0;
     int N, N2, levs, W, R, Rp;
+    int mode;                // 0 = rrrMC(SingleGraph), 1 = bklMC
 };
 
 struct SkChain {             // one replica's view
@@ -460,7 +461,50 @@ __global__ __launch_bounds__(kRrrThreads) void rrr_skn_kernel(RrrSkParams P)
     double acc_rate = 0.5;
     long long accepted = 0, staged_its = 0, ns = 0;
     int bad = 0;
-    for (long long it = 1; it <= P.iters && !bad; ++it) {
+    if (P.mode == 1) {
+        // bklMC (RRRMC.jl:311-359): rand_skip (DeltaE.jl:319-325), rand_move, apply_step_bkl! = apply_move! over all spins
+        long long it = 0, nextstep = P.step, m = 0;
+        while (it < P.iters) {
+            m += 1;
+            const uint64_t g = P.g0 + (uint64_t)m;
+            const Philox4 o3 = philox4x32_10((uint32_t)g, (uint32_t)(g >> 32), rep, TAG_RRR | (2u << 8), P.k0, P.k1);
+            const double us = (double)((((uint64_t)o3.w[0] << 32) | o3.w[1]) >> 11) * 0x1.0p-53;
+            double b = c.z / (double)N;
+            if (b < 2.2250738585072014e-308) b = 2.2250738585072014e-308;
+            if (b > 1.0) b = 1.0;
+            const double skipf = floor(det_log1p(-us) / det_log1p(-b));
+            const long long skip = skipf >= 9.0e18 ? (long long)9.0e18 : (long long)skipf;
+            const Philox4 o = philox4x32_10((uint32_t)g, (uint32_t)(g >> 32), rep, TAG_RRR, P.k0, P.k1);
+            const int move = c.getel((double)((((uint64_t)o.w[0] << 32) | o.w[1]) >> 11) * 0x1.0p-53);
+            if (move < 0) { bad = 1; break; }
+            const double dE = P.dEs[(size_t)move * Rp + r];
+            bool out = false;
+            while (it + skip + 1 >= nextstep) {
+                P.Es[(size_t)ns * Rp + r] = E; ns += 1;
+                nextstep += P.step;
+                if (nextstep > P.iters) { out = true; break; }
+            }
+            if (out) break;
+            c.flip(move);
+            const double* a = c.lf();
+            {
+                const double d = a[(size_t)move * Rp];
+                P.dEs[(size_t)move * Rp + r] = d;
+                c.set(move, prior_of(P.beta * d));
+            }
+            for (int j = 0; j < N; ++j) {
+                if (j == move) continue;
+                const double d = a[(size_t)j * Rp];
+                P.dEs[(size_t)j * Rp + r] = d;
+                c.set(j, prior_of(P.beta * d));
+            }
+            it += skip + 1;
+            E += dE;
+            accepted += 1;
+        }
+        staged_its = accepted;
+    }
+    for (long long it = 1; P.mode == 0 && it <= P.iters && !bad; ++it) {
         if (it % P.step == 0) { P.Es[(size_t)ns * Rp + r] = E; ns += 1; }
         const uint64_t g = P.g0 + (uint64_t)it;
         const Philox4 o = philox4x32_10((uint32_t)g, (uint32_t)(g >> 32), rep, TAG_RRR, P.k0, P.k1);

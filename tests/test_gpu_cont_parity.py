@@ -88,3 +88,22 @@ def test_wtm_cont_bit_exact(pkg, oracle, kind, R, beta, samples, step):
         assert (Es[r] == Es_ref).all() and (C1.s[r] == ch_ref).all() and moves[r] == st[0] and t[r] == t_ref
         Es2_ref, _, st2, t2_ref = oracle.cont_sparse("wtm", X.A, X.J, beta, 100, 1, seed, ch_ref, call=1, replica=r, stepf=step, form=form)
         assert (Es2[r] == Es2_ref).all() and moves2[r] == st2[0] and t2[r] == t2_ref
+
+
+@pytest.mark.parametrize("N,R,beta,iters,step", [(10, 40, 2.0, 20000, 100), (64, 33, 1.5, 30000, 500), (300, 8, 2.0, 60000, 2000)])
+def test_bkl_skn_bit_exact(pkg, oracle, N, R, beta, iters, step):
+    """bklMC on GraphSKNormal (test/runtests.jl:67 GraphSKNormal(10)): DeltaECacheCont with all N - 1 neighbours per move."""
+    seed = 919000 + N
+    X = pkg.GraphSKNormal(N, seed=seed)
+    with pkg.Engine(X, R) as eng:
+        eng.seed(seed)
+        eng.init_spins_random()
+        C0 = eng.get_config()
+        Es, moves = eng.bkl_mc(beta, iters, step)
+        C1 = eng.get_config()
+        E1 = eng.energy()
+    assert Es.shape == (R, iters // step)
+    for r in range(R):
+        Es_ref, ch_ref, m_ref, _ = oracle.bkl_mc_skn(X.J, beta, iters, step, seed, C0.s[r], replica=r)
+        assert (Es[r] == Es_ref).all() and (C1.s[r] == ch_ref).all() and moves[r] == m_ref
+        assert E1[r] == oracle.skn_energy(X.J, ch_ref)
