@@ -209,7 +209,7 @@ struct ContChain {
 
 __global__ __launch_bounds__(kRrrThreads) void cont_sparse_kernel(ContParams P)
 {
-    const int r = blockIdx.x * kRrrThreads + threadIdx.x;
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= P.R) return;
     const int N = P.N, K = P.K;
     ContChain c;

@@ -157,7 +157,7 @@ __device__ __forceinline__ bool dbl_accept(double c, double x, uint64_t g, uint3
 
 __global__ __launch_bounds__(kRrrThreads) void rrr_dbl_kernel(RrrDblParams P)
 {
-    const int r = blockIdx.x * kRrrThreads + threadIdx.x;
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= P.R) return;
     const int N = P.N, L = P.L, K2 = 2 * P.L, K = P.K;
     DblChain c;

@@ -65,7 +65,7 @@ int32_t dbl_run_energy(rrrmc_ctx* ctx)
 {
     RrrDblParams P = dbl_params(ctx, 0.0);
     P.energy_only = 1;
-    hipLaunchKernelGGL(rrr_dbl_kernel, dim3((unsigned)((ctx->R + kRrrThreads - 1) / kRrrThreads)), dim3(kRrrThreads), 0, ctx->stream, P);
+    hipLaunchKernelGGL(rrr_dbl_kernel, dim3(rrr_blocks(ctx->R)), dim3(rrr_tpb(ctx->R)), 0, ctx->stream, P);
     HIP_TRY(ctx, hipGetLastError());
     return RRRMC_OK;
 }
@@ -96,7 +96,7 @@ int32_t dbl_rrr_mc_async(rrrmc_ctx* ctx, double beta, int64_t iters, int64_t ste
     hipStream_t st = ctx->stream;
     HIP_TRY(ctx, hipEventRecord(ctx->ev_begin, st));
     HIP_TRY(ctx, hipEventRecord(ctx->ev_sweep[0], st));
-    hipLaunchKernelGGL(rrr_dbl_kernel, dim3((unsigned)((ctx->R + kRrrThreads - 1) / kRrrThreads)), dim3(kRrrThreads), 0, st, P);
+    hipLaunchKernelGGL(rrr_dbl_kernel, dim3(rrr_blocks(ctx->R)), dim3(rrr_tpb(ctx->R)), 0, st, P);
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipEventRecord(ctx->ev_sweep[1], st));
     HIP_TRY(ctx, hipEventRecord(ctx->ev_end, st));

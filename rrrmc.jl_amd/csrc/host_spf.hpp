@@ -184,7 +184,7 @@ int32_t spf_cont_async(rrrmc_ctx* ctx, int mode, double beta, int64_t iters, int
     hipLaunchKernelGGL(cont_spins_in_kernel, dim3((unsigned)((W + 255) / 256), (unsigned)R), dim3(256), 0, st, ctx->pf_spins, ctx->cs_spins, (int)N, (int)W, (int)R);
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipEventRecord(ctx->ev_sweep[0], st));
-    hipLaunchKernelGGL(cont_sparse_kernel, dim3((unsigned)((R + kRrrThreads - 1) / kRrrThreads)), dim3(kRrrThreads), 0, st, P);
+    hipLaunchKernelGGL(cont_sparse_kernel, dim3(rrr_blocks(R)), dim3(rrr_tpb(R)), 0, st, P);
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipEventRecord(ctx->ev_sweep[1], st));
     hipLaunchKernelGGL(cont_spins_out_kernel, dim3((unsigned)((N + 255) / 256), (unsigned)ctx->pfW), dim3(256), 0, st, ctx->cs_spins, ctx->pf_spins, (int)N, (int)W, (int)R);

@@ -17,7 +17,8 @@
 namespace rrrmc {
 
 constexpr uint32_t TAG_RRR = 8;
-constexpr int kRrrThreads = 64;
+constexpr int kRrrThreads = 64;          // most replicas (threads) a workgroup of the thread-per-replica kernels holds; the host picks
+                                        // fewer per workgroup when there are few replicas, to spread them over the CUs (rrr_tpb)
 constexpr int kQL = 2;          // levels of allΔE(GraphQT) = (0.0, fourK), QT.jl:111
 
 struct RrrParams {
@@ -120,7 +121,7 @@ __device__ __forceinline__ RrrView rrr_view(const RrrParams& P, int r)
 // energy(X::GraphQuant, C) (QT.jl:185-199) + DeltaECache construction (DeltaE.jl:74-103), one thread per replica
 __global__ __launch_bounds__(kRrrThreads) void rrr_init_kernel(RrrParams P)
 {
-    const int r = blockIdx.x * kRrrThreads + threadIdx.x;
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= P.R) return;
     const RrrView v = rrr_view(P, r);
     // E = energy0 * fourK / 4 + sum_k energy(X1[k]) / M
@@ -164,7 +165,7 @@ __global__ __launch_bounds__(kRrrThreads) void rrr_init_kernel(RrrParams P)
 
 __global__ __launch_bounds__(kRrrThreads) void rrr_quant_kernel(RrrParams P)
 {
-    const int r = blockIdx.x * kRrrThreads + threadIdx.x;
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= P.R) return;
     const RrrView v = rrr_view(P, r);
     const uint32_t rep = P.replica0 + (uint32_t)r;
@@ -432,7 +433,7 @@ __device__ __forceinline__ double prior_of(double x) { return x > 0 ? det_exp(-x
 // energy(X, C) (SK.jl:212-237) + DeltaECacheCont construction (DeltaE.jl:304-313) + the sampling loop
 __global__ __launch_bounds__(kRrrThreads) void rrr_skn_kernel(RrrSkParams P)
 {
-    const int r = blockIdx.x * kRrrThreads + threadIdx.x;
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= P.R) return;
     const int N = P.N, Rp = P.Rp;
     SkChain c;
@@ -688,7 +689,7 @@ struct SparseChain {
 
 __global__ __launch_bounds__(kRrrThreads) void rrr_sparse_kernel(RrrSparseParams P)
 {
-    const int r = blockIdx.x * kRrrThreads + threadIdx.x;
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= P.R) return;
     const int N = P.N, L = P.L, K2 = 2 * P.L;
     SparseChain c;
@@ -890,7 +891,7 @@ struct WtmChain {
 
 __global__ __launch_bounds__(kRrrThreads) void wtm_sparse_kernel(WtmParams P)
 {
-    const int r = blockIdx.x * kRrrThreads + threadIdx.x;
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= P.R) return;
     const int N = P.N;
     WtmChain c;
@@ -968,7 +969,7 @@ struct EoParams {
 
 __global__ __launch_bounds__(kRrrThreads) void eo_sparse_kernel(EoParams P)
 {
-    const int r = blockIdx.x * kRrrThreads + threadIdx.x;
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= P.R) return;
     const int N = P.N, L = P.L, K = P.K, K2 = 2 * P.L - P.has_zero;
     uint32_t* sp = P.spins + (size_t)r * P.W;

@@ -250,6 +250,20 @@ size_t plan_lds_bytes(int64_t N, int K, int C)
     return 4 * 3 * ((size_t)C + 2) + 2 * ((size_t)2 * C + (size_t)C * K + (size_t)N) + 16;
 }
 
+// Launch shape of the thread-per-replica kernels (rrr_*, wtm, eo, cont, dbl): these chains are latency bound and each lane walks
+// its own replica's arrays, so a full 64-lane wavefront issues 64 scattered requests per load.  With few replicas one replica per
+// workgroup spreads them over the CUs (measured at 128 replicas: 1.6x on GraphQuant, 2.5x on the discretised DoubleGraph);
+// with many, up to 64 per workgroup.  RRRMC_RRR_TPB overrides (timing experiments).
+inline unsigned rrr_tpb(int64_t R)
+{
+    if (const char* e = std::getenv("RRRMC_RRR_TPB")) { const int v = std::atoi(e); if (v >= 1 && v <= kRrrThreads) return (unsigned)v; }
+    // about one wavefront per CU (256 on MI355X): measured best at 128 / 4096 / 16384 replicas, within 5 % at 1024
+    unsigned t = 1u;
+    while (t < (unsigned)kRrrThreads && (int64_t)t * 256 < R) t *= 2u;
+    return t;
+}
+inline unsigned rrr_blocks(int64_t R) { const unsigned t = rrr_tpb(R); return (unsigned)((R + t - 1) / t); }
+
 // models whose device spins are R x W 32-bit words in BitVector order (q_spins, qW)
 inline bool chunk_layout(const rrrmc_ctx* ctx) { return ctx->model == RRRMC_MODEL_QUANT_RRG || ctx->model == RRRMC_MODEL_SPARSE_DISCRETIZED; }
 
@@ -1141,7 +1155,7 @@ int32_t rrrmc_rrr_mc_async(rrrmc_ctx* ctx, double beta, double fourK, int64_t it
     P.lambda = staged_thr_fact / (double)ctx->N;              // RRRMC.jl:243
     P.g0 = ctx->it_done; P.iters = iters; P.step = step;
     HIP_TRY(ctx, hipEventRecord(ctx->ev_sweep[0], st));
-    hipLaunchKernelGGL(rrr_quant_kernel, dim3((unsigned)((ctx->R + kRrrThreads - 1) / kRrrThreads)), dim3(kRrrThreads), 0, st, P);
+    hipLaunchKernelGGL(rrr_quant_kernel, dim3(rrr_blocks(ctx->R)), dim3(rrr_tpb(ctx->R)), 0, st, P);
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipEventRecord(ctx->ev_sweep[1], st));
     HIP_TRY(ctx, hipEventRecord(ctx->ev_end, st));
