@@ -68,6 +68,7 @@ int32_t spf_run_energy(rrrmc_ctx* ctx)
 {
     hipLaunchKernelGGL(spf_energy_for_K((int)ctx->K), dim3((unsigned)ctx->pfW), dim3(64), 0, ctx->stream, spf_params(ctx));
     HIP_TRY(ctx, hipGetLastError());
+    ctx->pf_lf_live = true;
     return RRRMC_OK;
 }
 
@@ -191,6 +192,7 @@ int32_t spf_cont_async(rrrmc_ctx* ctx, int mode, double beta, int64_t iters, int
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipEventRecord(ctx->ev_end, st));
     if (mode == 2) ctx->wtm_calls += 1; else ctx->it_done += (uint64_t)iters;
+    ctx->pf_lf_live = false;
     ctx->stats_stride = 3;
     ctx->sweep_launches = 1;
     ctx->nsamp = nsamp;

@@ -147,6 +147,7 @@ struct rrrmc_ctx {
     double* pf_undo = nullptr;     // [W][K+1][64]: live part of lfields_last (see spf_kernels.hpp)
     int32_t* pf_sites = nullptr;   // site stream of one launch
     int64_t pfW = 0;
+    bool pf_lf_live = false;       // sk_lf holds the local fields of the current configuration (false after the continuous samplers)
     // ---- RRRMC_MODEL_SPARSE_DISCRETIZED (Graph{RRG,EA}NormalDiscretized): spins in q_spins / qW (BitVector word order),
     //      energies in sk_E / sk_Es, statistics in q_stats ----
     int8_t* db_dJ = nullptr;       // [N][K] discretised couplings (levels)
@@ -528,6 +529,7 @@ int32_t rrrmc_init_spins_random(rrrmc_ctx* ctx)
                            (uint32_t)ctx->seed, (uint32_t)(ctx->seed >> 32));
         HIP_TRY(ctx, hipGetLastError());
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        ctx->pf_lf_live = false;
         ctx->spins_set = true;
         return RRRMC_OK;
     }
@@ -570,6 +572,7 @@ int32_t rrrmc_set_spins(rrrmc_ctx* ctx, const uint64_t* chunks)
         HIP_TRY(ctx, hipSetDevice(ctx->device));
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
         HIP_TRY(ctx, hipMemcpy(ctx->pf_spins, bs.data(), sizeof(unsigned long long) * bs.size(), hipMemcpyHostToDevice));
+        ctx->pf_lf_live = false;
         ctx->spins_set = true;
         return RRRMC_OK;
     }
@@ -1333,6 +1336,7 @@ int32_t rrrmc_get_fields_f64(rrrmc_ctx* ctx, double* lfields_out)
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const int64_t N = ctx->N;
     if (ctx->model == RRRMC_MODEL_SPARSE_F64) {
+        if (!ctx->pf_lf_live) return fail(ctx, RRRMC_ERR_STATE, "the cached local fields are not current (the last sampler kept its own): call rrrmc_energy_f64 first");
         std::vector<double> lf((size_t)ctx->Rpad * N);
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
         HIP_TRY(ctx, hipMemcpy(lf.data(), ctx->sk_lf, sizeof(double) * lf.size(), hipMemcpyDeviceToHost));
