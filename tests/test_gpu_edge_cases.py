@@ -101,3 +101,20 @@ def test_create_destroy_cycles(pkg):
             eng.seed(k + 1)
             eng.init_spins_random()
             eng.standard_mc(1.0, 2000, 500)
+
+
+def test_full_length_config2_chain(pkg, oracle):
+    """BASELINE config 2 at its full chain length (2^24 iterations, a sample every 2^12) for one replica group: four planner
+    batches, 4096 samples, tally-counter flushes — every energy sample and the final spins equal the oracle's."""
+    seed, N, R = 0x5EED, 4096, 32
+    iters, step = 1 << 24, 1 << 12
+    X = pkg.GraphRRG(N, 3, seed=seed)
+    with pkg.Engine(X, R) as eng:
+        eng.seed(seed)
+        eng.init_spins_random()
+        C0 = eng.get_config()
+        Es, acc = eng.standard_mc(1.0, iters, step)
+        C1 = eng.get_config()
+    ref = oracle.standard_mc_sparse_batch(X.A, X.J.astype(np.int32), 1.0, iters, step, seed, C0.s)
+    assert Es.shape == (R, iters // step)
+    assert (Es == ref[0]).all() and (C1.s == ref[1]).all() and (acc == ref[2]).all()
