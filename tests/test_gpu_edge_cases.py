@@ -118,3 +118,28 @@ def test_full_length_config2_chain(pkg, oracle):
     ref = oracle.standard_mc_sparse_batch(X.A, X.J.astype(np.int32), 1.0, iters, step, seed, C0.s)
     assert Es.shape == (R, iters // step)
     assert (Es == ref[0]).all() and (C1.s == ref[1]).all() and (acc == ref[2]).all()
+
+
+def test_full_width_config2_subset_against_oracle(pkg, oracle):
+    """BASELINE config 2 at its full width (8192 replicas = 256 workgroups, one per CU): three whole replica groups — the first,
+    one in the middle, the last — are checked against the oracle, and the acceptance rate of all replicas is sane."""
+    seed, N, R = 0x5EED, 4096, 8192
+    iters, step = 1 << 18, 1 << 12
+    X = pkg.GraphRRG(N, 3, seed=seed)
+    with pkg.Engine(X, R) as eng:
+        eng.seed(seed)
+        eng.init_spins_random()
+        C0 = eng.get_config()
+        Es, acc = eng.standard_mc(1.0, iters, step)
+        C1 = eng.get_config()
+        E1 = eng.energy()
+    A, J = X.A, X.J.astype(np.int32)
+    for g in (0, 100, 255):
+        sl = slice(32 * g, 32 * g + 32)
+        ref = oracle.standard_mc_sparse_batch(A, J, 1.0, iters, step, seed, C0.s[sl], replica0=32 * g)
+        assert (Es[sl] == ref[0]).all() and (C1.s[sl] == ref[1]).all() and (acc[sl] == ref[2]).all()
+        for r in (32 * g, 32 * g + 31):
+            assert E1[r] == oracle.sparse_energy(A, J, C1.s[r])
+    a = acc / iters
+    assert 0.07 < a.mean() < 0.12 and a.std() < 0.01          # beta = 1, K = 3: about 8-10 % of the attempts are accepted
+    assert E1.mean() / N < -1.05                                # well below the random-configuration energy 0
