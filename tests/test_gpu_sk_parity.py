@@ -103,3 +103,21 @@ def test_binary_sk_standard_mc(pkg, oracle, N, R, beta, iters, step):
         assert np.allclose(Es[r], Es_ref, rtol=REL_TOL, atol=1e-9)
         assert (Es[r] == Es_ref).all() and (C1.s[r] == ch_ref).all() and acc[r] == acc_ref and (lf1[r] == lf_ref).all()
         assert E1[r] == oracle.skb_energy(X.J, C1.s[r])
+
+
+def test_config3_full_width_subset(pkg, oracle):
+    """BASELINE config 3 at its full width (GraphSKNormal N = 1024, 2048 replicas = 256 workgroups of 8): three workgroups'
+    replicas against the oracle, bit for bit."""
+    seed, N, R, beta, iters, step = 0x5EED, 1024, 2048, 1.0, 4096, 1024
+    X = pkg.GraphSKNormal(N, seed=seed)
+    with pkg.Engine(X, R) as eng:
+        eng.seed(seed)
+        eng.init_spins_random()
+        C0 = eng.get_config()
+        Es, acc = eng.standard_mc(beta, iters, step)
+        C1 = eng.get_config()
+    for g in (0, 131, 255):
+        sl = slice(8 * g, 8 * g + 8)
+        Es_ref, ch_ref, acc_ref, _ = oracle.standard_mc_skn_batch(X.J, beta, iters, step, seed, C0.s[sl], replica0=8 * g)
+        assert (Es[sl] == Es_ref).all() and (C1.s[sl] == ch_ref).all() and (acc[sl] == acc_ref).all()
+    assert 0.2 < (acc / iters).mean() < 0.5
