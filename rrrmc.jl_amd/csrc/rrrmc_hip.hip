@@ -356,7 +356,11 @@ int32_t rrrmc_ctx_create(rrrmc_ctx** out, int32_t model, int64_t N, int64_t K, i
     ctx->TS = K <= 4 ? 4 : 8;
 
     // chunk length: a multiple of (producer waves x 64) that fits the 160 KiB LDS next to the state
+#ifdef RRRMC_CHUNK_TASKS
+    int C = RRRMC_CHUNK_TASKS * kWave;
+#else
     int C = kProducerWaves * kWave;
+#endif
     // WIDE build (word indices instead of byte offsets, neighbour table in HBM/L2 instead of LDS): needed when byte offsets into
     // the 2N-word LDS spin array no longer fit 16 bits (N > 8192), and preferred as soon as the LDS copy of the table would
     // force a shorter chunk (measured: same speed as the normal build at equal chunk length)

@@ -21,7 +21,10 @@ namespace rrrmc {
 
 constexpr int kWave = 64;
 constexpr int kSweepThreads = 1024;              // 16 waves: consumer, tally, fixer and 13 producers
-constexpr int kConsumerWave = 0, kTallyWave = 1, kFixerWave = 13;   // 0, 1 and 13 sit on two different SIMDs' queues
+#ifndef RRRMC_FIXER_WAVE
+#define RRRMC_FIXER_WAVE 13
+#endif
+constexpr int kConsumerWave = 0, kTallyWave = 1, kFixerWave = RRRMC_FIXER_WAVE;   // waves w, w+4, w+8, w+12 share a SIMD
 constexpr int kProducerWaves = kSweepThreads / kWave - 3;
 constexpr int kProducerBlocks = 3;               // Philox blocks (4 bit planes each) every producer lane computes
 constexpr int kLeftMax = 128;                    // capacity of the per-chunk list of slots still undecided after that
