@@ -30,6 +30,7 @@ thread_local std::string g_create_error;
 constexpr int64_t kMaxSlotsPerBatch = 1 << 22;    // plan buffers: 2 sets x 2 x 16 MiB; one sweep launch per batch
 constexpr int64_t kMaxChunksPerBatch = 1 << 16;
 constexpr int kLdsLimit = 160 * 1024;
+constexpr int kMaxChunk = 2048;                   // longest chunk (slots per pipeline step) the sweep kernel is given
 #ifdef RRRMC_STAMPS
 unsigned long long* g_stamps = nullptr;
 #endif
@@ -355,18 +356,24 @@ int32_t rrrmc_ctx_create(rrrmc_ctx** out, int32_t model, int64_t N, int64_t K, i
     ctx->device = device; ctx->replica0 = replica0;
     ctx->TS = K <= 4 ? 4 : 8;
 
-    // chunk length: a multiple of (producer waves x 64) that fits the 160 KiB LDS next to the state
-#ifdef RRRMC_CHUNK_TASKS
-    int C = RRRMC_CHUNK_TASKS * kWave;
-#else
-    int C = kProducerWaves * kWave;
-#endif
+    // chunk length: the longest multiple of 64 that fits the 160 KiB LDS next to the state (a step of the sweep kernel has a fixed
+    // cost of about a microsecond, so long chunks pay: 2.7 ns per slot at C = 1472 against 3.2 at 832), capped by kMaxChunk.
     // WIDE build (word indices instead of byte offsets, neighbour table in HBM/L2 instead of LDS): needed when byte offsets into
-    // the 2N-word LDS spin array no longer fit 16 bits (N > 8192), and preferred as soon as the LDS copy of the table would
-    // force a shorter chunk (measured: same speed as the normal build at equal chunk length)
-    ctx->wide = N > 8192 || sweep_lds_bytes(N, (int)K, ctx->TS, C, false) > (size_t)kLdsLimit;
+    // the 2N-word LDS spin array no longer fit 16 bits (N > 8192); chosen as well when dropping the LDS copy of the table buys a
+    // clearly longer chunk (at equal chunk length it is 1.6 % slower than the normal build).
+    auto max_chunk = [&](bool wide) {
+#ifdef RRRMC_CHUNK_TASKS
+        int c = RRRMC_CHUNK_TASKS * kWave;
+#else
+        int c = kMaxChunk;
+#endif
+        while (c >= kWave && (2 * N + 128 > 65535 || (!wide && N > 8192) || sweep_lds_bytes(N, (int)K, ctx->TS, c, wide) > (size_t)kLdsLimit)) c -= kWave;
+        return c;
+    };
+    const int Cn = max_chunk(false), Cw = max_chunk(true);
+    ctx->wide = Cw >= Cn + Cn / 8;
     if (const char* fw = std::getenv("RRRMC_FORCE_WIDE")) ctx->wide = ctx->wide || fw[0] == '1';       // timing experiments
-    while (C >= kWave && (2 * N + 128 > 65535 || sweep_lds_bytes(N, (int)K, ctx->TS, C, ctx->wide) > (size_t)kLdsLimit)) C -= kWave;
+    int C = ctx->wide ? Cw : Cn;
     ctx->lds_mode = C >= 4 * kWave;  // otherwise only the colour-parallel sweeps are available (HBM/L2-resident spins)
     if (!ctx->lds_mode) C = kWave;
     ctx->C = C;
@@ -758,11 +765,15 @@ int32_t rrrmc_standard_mc_async(rrrmc_ctx* ctx, double beta, int64_t iters, int6
     const int64_t nsamp = iters / step;
     std::vector<ChunkDesc> chunks;
     chunks.reserve((size_t)(iters / C + nsamp + 2));
+    // Every step of the sweep kernel costs about a microsecond whatever its chunk holds, so the iterations between two cuts
+    // (sample points, the end of the call) are divided into the FEWEST chunks of at most C and those are made equally long
     for (int64_t cur = 1; cur <= iters;) {
         const int64_t next_sample = (cur / step + 1) * step;
-        int64_t end = cur + C;
-        if (end > next_sample) end = next_sample;
-        if (end > iters + 1) end = iters + 1;
+        int64_t seg_end = next_sample;                        // exclusive end of the segment that may be chunked freely
+        if (seg_end > iters + 1) seg_end = iters + 1;
+        const int64_t seg = seg_end - cur, nch = (seg + C - 1) / C;
+        int64_t end = cur + (seg + nch - 1) / nch;            // ceil(seg / nch) <= C: the remaining chunks re-balance themselves
+        if (end > seg_end) end = seg_end;
         ChunkDesc cd{};
         cd.g0 = ctx->it_done + (uint64_t)cur;
         cd.count = (uint32_t)(end - cur);
