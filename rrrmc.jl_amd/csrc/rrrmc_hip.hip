@@ -30,7 +30,7 @@ thread_local std::string g_create_error;
 constexpr int64_t kMaxSlotsPerBatch = 1 << 22;    // plan buffers: 2 sets x 2 x 16 MiB; one sweep launch per batch
 constexpr int64_t kMaxChunksPerBatch = 1 << 16;
 constexpr int kLdsLimit = 160 * 1024;
-constexpr int kMaxChunk = 2048;                   // longest chunk (slots per pipeline step) the sweep kernel is given
+constexpr int kMaxChunk = kMaxChunkSlots;          // longest chunk (slots per pipeline step) the sweep kernel is given
 #ifdef RRRMC_STAMPS
 unsigned long long* g_stamps = nullptr;
 #endif

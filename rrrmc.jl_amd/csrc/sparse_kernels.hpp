@@ -26,6 +26,8 @@ constexpr int kSweepThreads = 1024;              // 16 waves: consumer, tally, f
 #endif
 constexpr int kConsumerWave = 0, kTallyWave = 1, kFixerWave = RRRMC_FIXER_WAVE;   // waves w, w+4, w+8, w+12 share a SIMD
 constexpr int kProducerWaves = kSweepThreads / kWave - 3;
+constexpr int kMaxChunkSlots = 2048;              // longest chunk the host may choose (rrrmc_hip.hip: kMaxChunk)
+constexpr int kProducerTasksMax = (kMaxChunkSlots / kWave + kProducerWaves - 1) / kProducerWaves;   // 64-slot tasks per producer wave and chunk
 constexpr int kProducerBlocks = 3;               // Philox blocks (4 bit planes each) every producer lane computes
 constexpr int kLeftMax = 128;                    // capacity of the per-chunk list of slots still undecided after that
 constexpr int kPlanThreads = 256;
@@ -210,16 +212,19 @@ __device__ __forceinline__ void refine_block(uint32_t (&lt)[NT], uint32_t (&eq)[
 // ---- producers -------------------------------------------------------------------------------------
 template <int K, bool WIDE>
 __device__ __forceinline__ void produce_chunk(const SweepParams& P, const ChunkDesc& cd, uint4* __restrict__ desc,
-                                              const uint16_t* __restrict__ tbl, const LeftList& left, int pw, int lane, uint32_t group)
+                                              const uint16_t* __restrict__ tbl, const LeftList& left, int pw, int lane, uint32_t group,
+                                              const uint32_t (&slots)[kProducerTasksMax])
 {
     constexpr int NT = SweepCfg<K>::NT, NQ = SweepCfg<K>::NQ;
     const int C = P.C;
     const int ntask = ((int)cd.count + kWave - 1) / kWave;
-    for (int task = pw; task < ntask; task += kProducerWaves) {
+#pragma unroll
+    for (int j = 0; j < kProducerTasksMax; ++j) {
+        const int task = pw + j * kProducerWaves;
+        if (task >= ntask) break;
         const int p = task * kWave + lane;
         const bool live = p < (int)cd.count;
-        uint32_t slot = 0;
-        if (live) slot = P.slots[cd.slot_base + p];
+        const uint32_t slot = slots[j];            // P.slots[cd.slot_base + p], requested one step ago (0 for dead lanes)
         const uint32_t site = slot & 0xffffu;
         const uint64_t g = cd.g0 + (uint64_t)(slot >> 16);
 
@@ -789,10 +794,32 @@ __global__ __launch_bounds__(kSweepThreads) void sweep_kernel(SweepParams P)
         }
     } else {
         const int pw = wave < kFixerWave ? wave - 2 : wave - 3;     // producer index 0 .. kProducerWaves-1
+        // The chunk descriptor (scalar loads) and the slot words (one coalesced global load per task) are requested ahead of
+        // time — the descriptor two steps, the slots one step before they are used — so a step starts computing right after the
+        // barrier instead of waiting a microsecond for HBM/L2 (that latency was a third of a step).
+        ChunkDesc cd0{}, cd1{}, cd2{};
+        uint32_t sl0[kProducerTasksMax], sl1[kProducerTasksMax];
+#pragma unroll
+        for (int j = 0; j < kProducerTasksMax; ++j) { sl0[j] = 0u; sl1[j] = 0u; }
+        auto fetch_slots = [&](const ChunkDesc& cd, uint32_t (&sl)[kProducerTasksMax]) {
+#pragma unroll
+            for (int j = 0; j < kProducerTasksMax; ++j) {
+                const int p = (pw + j * kProducerWaves) * kWave + lane;
+                sl[j] = p < (int)cd.count ? P.slots[cd.slot_base + p] : 0u;
+            }
+        };
+        if (P.nchunks > 0) { cd1 = P.chunks[0]; fetch_slots(cd1, sl1); }
+        if (P.nchunks > 1) cd2 = P.chunks[1];
         for (int c = 0; c < nsteps; ++c) {
             RRRMC_T0
+            cd0 = cd1;
+#pragma unroll
+            for (int j = 0; j < kProducerTasksMax; ++j) sl0[j] = sl1[j];
+            cd1 = cd2;
+            if (c + 1 < P.nchunks) fetch_slots(cd1, sl1);
+            if (c + 2 < P.nchunks) cd2 = P.chunks[c + 2];
 #ifndef RRRMC_ABLATE_PRODUCE
-            if (c < P.nchunks) produce_chunk<K, WIDE>(P, P.chunks[c], desc + (c % 3) * NQ * C, tbl, left_list(c), pw, lane, group);
+            if (c < P.nchunks) produce_chunk<K, WIDE>(P, cd0, desc + (c % 3) * NQ * C, tbl, left_list(c), pw, lane, group, sl0);
 #endif
             RRRMC_T1
             __syncthreads();
