@@ -459,13 +459,15 @@ __device__ __forceinline__ void consume_rows(const uint4* __restrict__ desc, uin
 // the end of the batch re-read its last slot (a broadcast) and store to private dummy words.
 template <int K, bool WIDE>
 __device__ __forceinline__ void consume_chunk(const SweepParams& P, const ChunkDesc& cd, const uint4* __restrict__ desc,
-                                              uint32_t* __restrict__ sp, uint4* __restrict__ tal, int lane)
+                                              uint32_t* __restrict__ sp, uint4* __restrict__ tal, int lane, uint32_t first_vd)
 {
     const int C = P.C, N = P.N;
     const uint32_t nb = cd.nvec;
     for (uint32_t v0 = 0; v0 < nb; v0 += kWave) {
-        // the batch table is read 64 entries at a time (one coalesced load) and broadcast lane by lane
-        const uint32_t myvd = (v0 + lane < nb) ? P.vecs[cd.slot_base + v0 + lane] : 0u;
+        // the batch table is read 64 entries at a time (one coalesced load) and broadcast lane by lane; the first 64 entries
+        // (all of them, for the usual chunk) were requested one step ago
+        uint32_t myvd = first_vd;
+        if (v0 > 0) myvd = (v0 + lane < nb) ? P.vecs[cd.slot_base + v0 + lane] : 0u;
         const uint32_t vn = (nb - v0) < (uint32_t)kWave ? (nb - v0) : (uint32_t)kWave;
         for (uint32_t v = 0; v < vn; ++v) {
             const uint32_t vd = __builtin_amdgcn_readlane(myvd, v);
@@ -731,11 +733,18 @@ __global__ __launch_bounds__(kSweepThreads) void sweep_kernel(SweepParams P)
     if (wave == kConsumerWave) {
         // consumer: single latency-bound wave on the critical path -> let it win the SIMD's issue arbitration
         __builtin_amdgcn_s_setprio(3);
+        // chunk descriptors are requested two steps, the head of the batch table one step before use (as the producers do)
+        ChunkDesc ca{}, cb{}, cc{};
+        uint32_t va = 0u, vb = 0u;
         for (int c = 0; c < nsteps; ++c) {
             RRRMC_T0
+            ca = cb; va = vb;           // chunk c-2: consumed now
+            cb = cc;                    // chunk c-1: its batch table is requested now
+            vb = (c >= 1 && c - 1 < P.nchunks && (uint32_t)lane < cb.nvec) ? P.vecs[cb.slot_base + lane] : 0u;
+            if (c < P.nchunks) cc = P.chunks[c];
 #ifndef RRRMC_ABLATE_CONSUME      // timing experiments only (tools/ablate.sh): results are wrong with a role removed
             if (c >= 2 && c - 2 < P.nchunks)
-                consume_chunk<K, WIDE>(P, P.chunks[c - 2], desc + ((c - 2) % 3) * NQ * C, sp, tal + ((c - 2) & 1) * tal_stride, lane);
+                consume_chunk<K, WIDE>(P, ca, desc + ((c - 2) % 3) * NQ * C, sp, tal + ((c - 2) & 1) * tal_stride, lane, va);
 #endif
             RRRMC_T1
             __syncthreads();
