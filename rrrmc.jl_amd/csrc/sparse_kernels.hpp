@@ -764,11 +764,14 @@ __global__ __launch_bounds__(kSweepThreads) void sweep_kernel(SweepParams P)
         if (lane < 32) { E_run = P.E_cur[blockIdx.x * 32 + lane]; A_run = P.acc_cur[blockIdx.x * 32 + lane]; }
         int64_t ns = P.sample0;
         const uint32_t grp_per_chunk = (uint32_t)((C + 8 * kWave - 1) / (8 * kWave));   // 8-word groups one chunk adds per lane
+        ChunkDesc ta{}, tb{};
         for (int c = 0; c < nsteps; ++c) {
             RRRMC_T0
+            ta = tb;                                        // chunk c-3, requested one step ago
+            if (c >= 2 && c - 2 < P.nchunks) tb = P.chunks[c - 2];
 #ifndef RRRMC_ABLATE_TALLY
             if (c >= 3) {
-                const ChunkDesc cd = P.chunks[c - 3];
+                const ChunkDesc cd = ta;
                 // an energy sample is due BEFORE this chunk's moves (RRRMC.jl:104-108)
                 const bool sample = (cd.flags & kChunkSampleBefore) != 0;
                 if (sample || ts.ngrp + grp_per_chunk > (1u << kTallyHi) - 1u) {
@@ -795,9 +798,12 @@ __global__ __launch_bounds__(kSweepThreads) void sweep_kernel(SweepParams P)
         dr.run_to_end(P, tc, lane, E_run, A_run);
         if (lane < 32) { P.E_cur[blockIdx.x * 32 + lane] = E_run; P.acc_cur[blockIdx.x * 32 + lane] = A_run; }
     } else if (wave == kFixerWave) {
+        ChunkDesc fa{}, fb{};
         for (int c = 0; c < nsteps; ++c) {
             RRRMC_T0
-            if (c >= 1 && c - 1 < P.nchunks) fix_chunk<K>(P, P.chunks[c - 1], desc + ((c - 1) % 3) * NQ * C, left_list(c - 1), lane, group);
+            fa = fb;                                        // chunk c-1, requested one step ago
+            if (c < P.nchunks) fb = P.chunks[c];
+            if (c >= 1 && c - 1 < P.nchunks) fix_chunk<K>(P, fa, desc + ((c - 1) % 3) * NQ * C, left_list(c - 1), lane, group);
             RRRMC_T1
             __syncthreads();
         }
