@@ -5,6 +5,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -249,7 +250,9 @@ size_t sweep_lds_bytes(int64_t N, int K, int TS, int C, bool wide = false)
 
 size_t plan_lds_bytes(int64_t N, int K, int C)
 {
-    return 4 * 3 * ((size_t)C + 2) + 2 * ((size_t)2 * C + (size_t)C * K + (size_t)N) + 16;
+    // max(s_bin [N+1], s_cnt + s_start + s_cur [3 (C+2)]) u32 (two phases share it); s_site, s_lvl, s_item [C], s_nb [C*K], s_pred [C*(K+1)] u16
+    const size_t share = std::max((size_t)N + 1, 3 * ((size_t)C + 2));
+    return 4 * share + 2 * ((size_t)3 * C + (size_t)C * K + (size_t)C * (K + 1)) + 16;
 }
 
 // Launch shape of the thread-per-replica kernels (rrr_*, wtm, eo, cont, dbl): these chains are latency bound and each lane walks
@@ -374,7 +377,8 @@ int32_t rrrmc_ctx_create(rrrmc_ctx** out, int32_t model, int64_t N, int64_t K, i
     ctx->wide = Cw >= Cn + Cn / 8;
     if (const char* fw = std::getenv("RRRMC_FORCE_WIDE")) ctx->wide = ctx->wide || fw[0] == '1';       // timing experiments
     int C = ctx->wide ? Cw : Cn;
-    ctx->lds_mode = C >= 4 * kWave;  // otherwise only the colour-parallel sweeps are available (HBM/L2-resident spins)
+    // otherwise only the colour-parallel sweeps are available (HBM/L2-resident spins)
+    ctx->lds_mode = C >= 4 * kWave && plan_lds_bytes(N, (int)K, C) <= (size_t)kLdsLimit;
     if (!ctx->lds_mode) C = kWave;
     ctx->C = C;
     ctx->lds_bytes = ctx->lds_mode ? sweep_lds_bytes(N, (int)K, ctx->TS, C, ctx->wide) : 0;

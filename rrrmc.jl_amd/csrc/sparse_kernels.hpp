@@ -48,69 +48,107 @@ struct ChunkDesc {
 // plan_kernel<K>: one workgroup per chunk (state-independent: the plan is shared by every replica group).
 //   slots[slot_base + p] = site | (t << 16)       attempts sorted by dependency level (t = index in chunk)
 //   vecs [slot_base + b] = start | ((n-1) << 16)  consumer batches: runs of n <= 256 sorted slots inside one level
-// Level rule: L(t) = 1 + max_{x in N[site_t]} W[x], W[site_t] = L(t), W = level of the last attempt AT x.
-// The order of the slots INSIDE a level is arbitrary (they commute), so it is left to LDS atomics.
+// Level rule: L(t) = 1 + max_{x in N[site_t]} W_t[x], W_t[x] = level of the last attempt AT x before t (0 if none).
+// Computed without a sequential pass: the attempts are bucketed by site (counting sort), every attempt looks up, for each
+// site x of its closed neighbourhood, the latest earlier attempt at x (its predecessors), and the levels are the longest-path
+// depths of that DAG, reached by relaxing L(t) = 1 + max L(pred) until nothing changes (as many rounds as there are levels,
+// about ten).  The order of the slots INSIDE a level is arbitrary (they commute), so it is left to LDS atomics.
 // ---------------------------------------------------------------------------------------------------
+constexpr uint32_t kNoPred = 0xffffu;
+
 template <int K>
 __global__ __launch_bounds__(kPlanThreads) void plan_kernel(ChunkDesc* __restrict__ chunks, uint32_t* __restrict__ slots,
                                                             uint32_t* __restrict__ vecs, const int32_t* __restrict__ A,
                                                             int N, int Cmax, uint32_t k0, uint32_t k1)
 {
     extern __shared__ uint32_t plds32[];
+    // two phases share the first region: the site buckets (until the predecessors are known), then the level counters
+    const int nshare = (N + 1) > 3 * (Cmax + 2) ? (N + 1) : 3 * (Cmax + 2);
+    uint32_t* s_bin = plds32;                                   // [N + 1]     attempts per site -> bucket END offsets (bin x = [end(x-1), end(x)))
     uint32_t* s_cnt = plds32;                                   // [Cmax + 2]  slots per level (levels are 1-based)
     uint32_t* s_start = s_cnt + Cmax + 2;                       // [Cmax + 2]
     uint32_t* s_cur = s_start + Cmax + 2;                       // [Cmax + 2]
-    uint16_t* s_site = reinterpret_cast<uint16_t*>(s_cur + Cmax + 2);   // [Cmax]
+    uint16_t* s_site = reinterpret_cast<uint16_t*>(plds32 + nshare); // [Cmax]
     uint16_t* s_lvl = s_site + Cmax;                            // [Cmax]
     uint16_t* s_nb = s_lvl + Cmax;                              // [Cmax * K]
-    uint16_t* s_W = s_nb + (size_t)Cmax * K;                    // [N]
-    __shared__ uint32_t s_maxlvl;
+    uint16_t* s_item = s_nb + (size_t)Cmax * K;                 // [Cmax]      attempt ids bucketed by site
+    uint16_t* s_pred = s_item + Cmax;                           // [Cmax * (K + 1)]
+    __shared__ uint32_t s_maxlvl, s_changed, s_part[kPlanThreads / 64];
 
     const ChunkDesc cd = chunks[blockIdx.x];
     const int count = (int)cd.count;
     const int tid = threadIdx.x;
 
+    for (int x = tid; x <= N; x += kPlanThreads) s_bin[x] = 0u;
+    __syncthreads();
     for (int t = tid; t < count; t += kPlanThreads) {
         const uint32_t site = site_of(k0, k1, cd.g0 + (uint64_t)t, (uint32_t)N);
         s_site[t] = (uint16_t)site;
+        s_lvl[t] = 1;
 #pragma unroll
         for (int k = 0; k < K; ++k) s_nb[t * K + k] = (uint16_t)A[(size_t)site * K + k];
+        atomicAdd(&s_bin[site], 1u);
     }
-    for (int x = tid; x < N; x += kPlanThreads) s_W[x] = 0;
-    for (int l = tid; l < count + 2; l += kPlanThreads) { s_cnt[l] = 0; s_cur[l] = 0; }
     __syncthreads();
-
-    if (tid == 0) {
-        // the sequential part: one dependent LDS round trip per attempt (operands of the next attempt are prefetched)
-        uint32_t maxlvl = 0;
-        uint32_t site = count > 0 ? s_site[0] : 0u;
-        uint32_t nb[K];
+    // exclusive scan of the site histogram: each thread owns a contiguous range of sites; the 256 partial sums are scanned with
+    // wave shuffles (a serial pass over them would cost more than the rest of the kernel)
+    {
+        const int per = (N + kPlanThreads - 1) / kPlanThreads, x0 = tid * per, x1 = (x0 + per < N) ? x0 + per : N;
+        uint32_t sum = 0u;
+        for (int x = x0; x < x1; ++x) sum += s_bin[x];
+        uint32_t incl = sum;
+        const int ln = tid & 63, wv = tid >> 6;
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t n = (uint32_t)__shfl_up((int)incl, o);
+            if (ln >= o) incl += n;
+        }
+        if (ln == 63) s_part[wv] = incl;
+        __syncthreads();
+        uint32_t run = incl - sum;
+        for (int q = 0; q < wv; ++q) run += s_part[q];
+        for (int x = x0; x < x1; ++x) { const uint32_t v = s_bin[x]; s_bin[x] = run; run += v; }      // start offsets ...
+    }
+    __syncthreads();
+    // ... used as fill cursors: afterwards s_bin[x] is the END of bucket x and its start is the end of bucket x-1
+    for (int t = tid; t < count; t += kPlanThreads) s_item[atomicAdd(&s_bin[s_site[t]], 1u)] = (uint16_t)t;
+    __syncthreads();
+    // predecessors: for every site x of the closed neighbourhood, the latest earlier attempt at x
+    for (int q = tid; q < count * (K + 1); q += kPlanThreads) {
+        const int t = q / (K + 1), j = q - t * (K + 1);
+        const uint32_t x = j == 0 ? (uint32_t)s_site[t] : (uint32_t)s_nb[t * K + j - 1];
+        uint32_t best = kNoPred;
+        for (uint32_t b = x ? s_bin[x - 1] : 0u; b < s_bin[x]; ++b) {
+            const uint32_t tp = s_item[b];
+            if (tp < (uint32_t)t && (best == kNoPred || tp > best)) best = tp;
+        }
+        s_pred[q] = (uint16_t)best;
+    }
+    __syncthreads();
+    for (int l = tid; l < count + 2; l += kPlanThreads) { s_cnt[l] = 0u; s_cur[l] = 0u; }      // the buckets are dead: level counters
+    // longest-path depths by relaxation (levels only grow; the fixed point is the sequential rule's result)
+    for (;;) {
+        if (tid == 0) s_changed = 0u;
+        __syncthreads();
+        bool ch = false;
+        for (int t = tid; t < count; t += kPlanThreads) {
+            uint32_t l = 0u;
 #pragma unroll
-        for (int k = 0; k < K; ++k) nb[k] = count > 0 ? s_nb[k] : 0u;
-        for (int t = 0; t < count; ++t) {
-            const int tn = t + 1 < count ? t + 1 : t;
-            const uint32_t site_n = s_site[tn];
-            uint32_t nb_n[K];
-#pragma unroll
-            for (int k = 0; k < K; ++k) nb_n[k] = s_nb[tn * K + k];
-            uint32_t l = s_W[site];
-#pragma unroll
-            for (int k = 0; k < K; ++k) {
-                const uint32_t w = s_W[nb[k]];
+            for (int j = 0; j <= K; ++j) {
+                const uint32_t pr = s_pred[t * (K + 1) + j];
+                const uint32_t w = pr == kNoPred ? 0u : (uint32_t)s_lvl[pr];
                 l = w > l ? w : l;
             }
-            l += 1;
-            s_W[site] = (uint16_t)l;
-            s_lvl[t] = (uint16_t)l;
-            maxlvl = l > maxlvl ? l : maxlvl;
-            site = site_n;
-#pragma unroll
-            for (int k = 0; k < K; ++k) nb[k] = nb_n[k];
+            l += 1u;
+            if (l != (uint32_t)s_lvl[t]) { s_lvl[t] = (uint16_t)l; ch = true; }
         }
-        s_maxlvl = maxlvl;
+        if (ch) s_changed = 1u;
+        __syncthreads();
+        if (s_changed == 0u) break;
+        __syncthreads();
     }
+    if (tid == 0) s_maxlvl = 0u;
     __syncthreads();
-    for (int t = tid; t < count; t += kPlanThreads) atomicAdd(&s_cnt[s_lvl[t]], 1u);
+    for (int t = tid; t < count; t += kPlanThreads) { atomicAdd(&s_cnt[s_lvl[t]], 1u); atomicMax(&s_maxlvl, (uint32_t)s_lvl[t]); }
     __syncthreads();
     if (tid == 0) {
         const uint32_t maxlvl = s_maxlvl;
