@@ -119,6 +119,7 @@ __global__ __launch_bounds__(kSkThreads) void sk_sweep_kernel(SkParams P)
 #pragma unroll
     for (int q = 0; q < SPT; ++q) { const int j = q * kSkThreads + tid; Jq[q] = j < N ? P.J[(size_t)site * N + j] : 0.0; }
 
+    double u_acc = tid < kSkRB ? rand53(P.k0, P.k1, P.g0 + 1, P.replica0 + (uint32_t)(grp * kSkRB + tid)) : 0.0;   // ACCEPT_F64 uniform of iteration 1
     for (int64_t it = 1; it <= P.iters; ++it) {
         const int b = (int)(it & 1);
         const uint64_t g = P.g0 + (uint64_t)it;
@@ -147,7 +148,7 @@ __global__ __launch_bounds__(kSkThreads) void sk_sweep_kernel(SkParams P)
                 }
                 const double dE = sh_lfi[b][tid];                       // delta_energy, SK.jl:278-284
                 const double x = -P.beta * dE;
-                acc = (x >= 0.0) || (rand53(P.k0, P.k1, g, P.replica0 + (uint32_t)(grp * kSkRB + tid)) < det_exp(x));   // RRRMC.jl:39
+                acc = (x >= 0.0) || (u_acc < det_exp(x));                                                           // RRRMC.jl:39
                 swp = acc && (mlast == (int32_t)site);                  // undo path of update_cache!, SK.jl:247-250
                 if (acc) { E_run += dE; A_run += 1; mlast = (int32_t)site; }
             }
@@ -196,6 +197,9 @@ __global__ __launch_bounds__(kSkThreads) void sk_sweep_kernel(SkParams P)
         site = site_n;
 #pragma unroll
         for (int q = 0; q < SPT; ++q) Jq[q] = Jn[q];
+        // the next iteration's uniform does not depend on the state: draw it here, next to the field updates, instead of
+        // between the two barriers of the next step
+        if (tid < kSkRB) u_acc = rand53(P.k0, P.k1, g + 1, P.replica0 + (uint32_t)(grp * kSkRB + tid));
     }
 
 #pragma unroll
