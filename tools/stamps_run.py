@@ -14,7 +14,7 @@ eng.standard_mc_async(1.0, iters, 4096); eng.sync()
 tot, sw, n = eng.last_timing()
 L = pkg.lib()
 L.rrrmc_debug_stamps.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
-nch = iters // 4096 * 5
+nch = iters // 4096 * 3          # chunks per launch: 4096 iterations between samples = 3 balanced chunks at C = 1472
 for g in (0, 100, 255):
     out = np.zeros(16, np.uint64)
     L.rrrmc_debug_stamps(eng._ctx, g, out.ctypes.data)
