@@ -377,6 +377,10 @@ int32_t rrrmc_ctx_create(rrrmc_ctx** out, int32_t model, int64_t N, int64_t K, i
     ctx->wide = Cw >= Cn + Cn / 8;
     if (const char* fw = std::getenv("RRRMC_FORCE_WIDE")) ctx->wide = ctx->wide || fw[0] == '1';       // timing experiments
     int C = ctx->wide ? Cw : Cn;
+    // tiny graphs: the dependency depth of a chunk grows like C (K+1) / N, and both the planner's relaxation rounds and the
+    // consumer's sequential levels follow it — long chunks stop paying
+    const int64_t cap = std::max<int64_t>(4 * kWave, (8 * N) / kWave * kWave);
+    if (C > cap) C = (int)cap;
     // otherwise only the colour-parallel sweeps are available (HBM/L2-resident spins)
     ctx->lds_mode = C >= 4 * kWave && plan_lds_bytes(N, (int)K, C) <= (size_t)kLdsLimit;
     if (!ctx->lds_mode) C = kWave;
