@@ -289,7 +289,8 @@ csweep_fn csweep_for_K(int K) { RRRMC_DISPATCH_UPTO7(K, colored_sweep_kernel) }
 // bit-sliced energy of every replica into d_E (and, optionally, one row of the sample buffer)
 int32_t run_energy_bs(rrrmc_ctx* ctx, int32_t* es_row)
 {
-    const dim3 grid((unsigned)((ctx->N + 255) / 256), (unsigned)ctx->G);
+    const int64_t per = 256 * kEnergySitesPerThread;
+    const dim3 grid((unsigned)((ctx->N + per - 1) / per), (unsigned)ctx->G);
     hipLaunchKernelGGL(energy_bs_for_K((int)ctx->K), grid, dim3(256), 0, ctx->stream, ctx->d_spins, ctx->d_A, ctx->d_J, (int)ctx->N, ctx->d_U);
     HIP_TRY(ctx, hipGetLastError());
     hipLaunchKernelGGL(energy_bs_finish_kernel, dim3((unsigned)((ctx->Rpad + 255) / 256)), dim3(256), 0, ctx->stream, ctx->d_U, ctx->d_E, es_row,

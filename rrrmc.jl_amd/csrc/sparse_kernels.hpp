@@ -1018,32 +1018,42 @@ __global__ __launch_bounds__(256) void colored_sweep_kernel(ColorSweepParams P)
 
 // Bit-sliced energy: U[group*32 + r] += sum over sites of the number of unsatisfied bonds of replica r (every bond
 // from both ends); E = U - N*K/2 (RRG.jl:164-189).  One lane per site, three count planes, 32x32 bit transpose +
-// popcount per wave, one atomic per replica and wave.
+// popcount per wave, one atomic per replica and workgroup (2048 sites).
+constexpr int kEnergySitesPerThread = 8;
 template <int K>
 __global__ __launch_bounds__(256) void energy_bs_kernel(const uint32_t* __restrict__ spins, const int32_t* __restrict__ A,
                                                         const int8_t* __restrict__ J, int N, uint32_t* __restrict__ U)
 {
-    const int x = blockIdx.x * 256 + threadIdx.x;
-    const int lane = threadIdx.x & 63;
+    __shared__ uint32_t part[4][32];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t* sp = spins + (size_t)blockIdx.y * N;
-    uint32_t n0 = 0u, n1 = 0u, n2 = 0u;
-    if (x < N) {
-        const uint32_t s = sp[x];
-#pragma unroll
-        for (int k = 0; k < K; ++k) {
-            const uint32_t u = s ^ sp[A[(size_t)x * K + k]] ^ (J[(size_t)x * K + k] < 0 ? 0xffffffffu : 0u);
-            const uint32_t c0 = n0 & u;
-            n0 ^= u;
-            const uint32_t c1 = n1 & c0;
-            n1 ^= c0;
-            n2 ^= c1;
-        }
-    }
     TransposeConsts tc;
     tc.init(lane);
-    uint32_t tot = (uint32_t)__popc(transpose32(n0, tc)) + ((uint32_t)__popc(transpose32(n1, tc)) << 1) + ((uint32_t)__popc(transpose32(n2, tc)) << 2);
+    uint32_t tot = 0u;
+    // a workgroup covers 256 * kEnergySitesPerThread sites, so that the per-replica sums meet in registers / LDS and only one
+    // atomic per replica and workgroup reaches HBM (at N = 262144 the atomics of a wave-per-256-sites layout took 0.2 ms)
+    for (int i = 0; i < kEnergySitesPerThread; ++i) {              // uniform trip count: the transpose exchanges data across lanes
+        const int x = (blockIdx.x * kEnergySitesPerThread + i) * 256 + (int)threadIdx.x;
+        uint32_t n0 = 0u, n1 = 0u, n2 = 0u;
+        if (x < N) {
+            const uint32_t s = sp[x];
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                const uint32_t u = s ^ sp[A[(size_t)x * K + k]] ^ (J[(size_t)x * K + k] < 0 ? 0xffffffffu : 0u);
+                const uint32_t c0 = n0 & u;
+                n0 ^= u;
+                const uint32_t c1 = n1 & c0;
+                n1 ^= c0;
+                n2 ^= c1;
+            }
+        }
+        tot += (uint32_t)__popc(transpose32(n0, tc)) + ((uint32_t)__popc(transpose32(n1, tc)) << 1) + ((uint32_t)__popc(transpose32(n2, tc)) << 2);
+    }
     tot += (uint32_t)__shfl_xor((int)tot, 32);
-    if (lane < 32) atomicAdd(&U[blockIdx.y * 32 + lane], tot);
+    if (lane < 32) part[wave][lane] = tot;
+    __syncthreads();
+    if (threadIdx.x < 32)
+        atomicAdd(&U[blockIdx.y * 32 + threadIdx.x], part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x]);
 }
 
 // Es[sample][r] = U[r] - N*K/2 (also leaves the value in E_cur) and clears U for the next sample
