@@ -1,3 +1,5 @@
+"""Diagnostic (GPU box): sweep-kernel time per chunk as a function of the sample step (all-full vs ragged chunks).
+Set CH to the chunk length the context will choose (for the printed per-chunk figures only)."""
 import sys, os, json
 sys.path.insert(0, os.getcwd())
 import __graft_entry__ as e
