@@ -143,3 +143,24 @@ def test_full_width_config2_subset_against_oracle(pkg, oracle):
     a = acc / iters
     assert 0.07 < a.mean() < 0.12 and a.std() < 0.01          # beta = 1, K = 3: about 8-10 % of the attempts are accepted
     assert E1.mean() / N < -1.05                                # well below the random-configuration energy 0
+
+
+def test_gpu_replicas_follow_the_boltzmann_law(pkg, oracle):
+    """The reference's stationarity check (exact `truep`, RRRMC.jl:528-543, on a tiny system): after many sweeps the 8192 GPU
+    replicas of a 6-spin GraphRRG are distributed like exp(-beta E) / Z.  (All replicas attempt the same sites, so they are not
+    independent samples: the chi-square bound is generous.)"""
+    seed, N, beta, R = 11, 6, 0.6, 8192
+    X = pkg.GraphRRG(N, 3, seed=seed)
+    with pkg.Engine(X, R) as eng:
+        eng.seed(seed)
+        eng.init_spins_random()
+        eng.standard_mc(beta, 6000, 6000)
+        C = eng.get_config()
+    counts = np.bincount(C.s[:, 0].astype(np.int64), minlength=2 ** N).astype(np.float64)
+    A, J = X.A, X.J.astype(np.int32)
+    Es = np.array([oracle.sparse_energy(A, J, np.array([c], np.uint64)) for c in range(2 ** N)], np.float64)
+    p = np.exp(-beta * Es)
+    p /= p.sum()
+    chi2 = float((((counts - R * p) ** 2) / (R * p)).sum())
+    assert chi2 < 4 * 2 ** N, chi2                                 # 63 degrees of freedom
+    assert abs((counts / R) @ Es - p @ Es) < 0.15                 # mean energy
