@@ -42,9 +42,16 @@ def lib():
     if _lib is not None:
         return _lib
     path = _build.lib_path()
+    if path == _build.OUT and (not os.path.exists(path) or _build.is_stale()):
+        # the in-tree library is missing or older than its sources: (re)build it with hipcc if there is one — never fall back
+        try:
+            _build.build()
+        except Exception as e:      # no hipcc, or the compilation failed
+            if not os.path.exists(path):
+                raise RuntimeError("%s is missing and could not be built (%s): run `python -c 'import __graft_entry__ as g; "
+                                   "g.build()'` (there is no CPU fallback)" % (path, e))
     if not os.path.exists(path):
-        raise RuntimeError("%s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
-                           "(there is no CPU fallback)" % path)
+        raise RuntimeError("%s is missing (there is no CPU fallback)" % path)
     L = C.CDLL(path)
     vp = C.c_void_p
     L.rrrmc_version.restype = C.c_int32
