@@ -42,8 +42,8 @@ def lib():
     if _lib is not None:
         return _lib
     path = _build.lib_path()
-    if path == _build.OUT and (not os.path.exists(path) or _build.is_stale()):
-        # the in-tree library is missing or older than its sources: (re)build it with hipcc if there is one — never fall back
+    if path == _build.OUT and not os.path.exists(path):
+        # the in-tree library is missing: build it with hipcc if there is one (atomic rename, safe with several ranks) — never fall back
         try:
             _build.build()
         except Exception as e:      # no hipcc, or the compilation failed

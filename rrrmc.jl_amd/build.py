@@ -35,10 +35,16 @@ def build(force=False, verbose=False):
     if not os.path.exists(hipcc):
         raise RuntimeError("hipcc not found: cannot build librrrmc_hip.so")
     os.makedirs(os.path.dirname(OUT), exist_ok=True)
-    cmd = [hipcc] + FLAGS + [SRC, "-o", OUT]
+    tmp = "%s.tmp%d" % (OUT, os.getpid())          # several processes may build at once: each writes its own file, rename is atomic
+    cmd = [hipcc] + FLAGS + [SRC, "-o", tmp]
     if verbose:
         print(" ".join(cmd))
-    subprocess.check_call(cmd)
+    try:
+        subprocess.check_call(cmd)
+        os.replace(tmp, OUT)
+    finally:
+        if os.path.exists(tmp):
+            os.remove(tmp)
     return OUT
 
 
