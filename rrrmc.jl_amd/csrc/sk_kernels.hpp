@@ -148,7 +148,11 @@ __global__ __launch_bounds__(kSkThreads) void sk_sweep_kernel(SkParams P)
                 }
                 const double dE = sh_lfi[b][tid];                       // delta_energy, SK.jl:278-284
                 const double x = -P.beta * dE;
+#ifdef RRRMC_SK_ABLATE_EXP      // timing experiments only
+                acc = (x >= 0.0) || (u_acc < 0.3);
+#else
                 acc = (x >= 0.0) || (u_acc < det_exp(x));                                                           // RRRMC.jl:39
+#endif
                 swp = acc && (mlast == (int32_t)site);                  // undo path of update_cache!, SK.jl:247-250
                 if (acc) { E_run += dE; A_run += 1; mlast = (int32_t)site; }
             }
@@ -161,24 +165,31 @@ __global__ __launch_bounds__(kSkThreads) void sk_sweep_kernel(SkParams P)
         const uint32_t si_new = si_old ^ accm;
         if (swpm) {          // workgroup-uniform: swap lfields <-> lfields_last of those replicas
 #pragma unroll
-            for (int q = 0; q < SPT; ++q)
+            for (int r = 0; r < kSkRB; ++r)
+                if ((swpm >> r) & 1u) {
 #pragma unroll
-                for (int r = 0; r < kSkRB; ++r)
-                    if ((swpm >> r) & 1u) { const double t = lf[q][r]; lf[q][r] = lfl[q][r]; lfl[q][r] = t; }
+                    for (int q = 0; q < SPT; ++q) { const double t = lf[q][r]; lf[q][r] = lfl[q][r]; lfl[q][r] = t; }
+                }
         }
         if (normal) {        // workgroup-uniform
+            // replica outermost: one scalar branch per replica (8 per step) instead of one per (site, replica) pair
+            double d4[SPT];
+            uint32_t diff[SPT];
 #pragma unroll
             for (int q = 0; q < SPT; ++q) {
-                const double d4 = 4.0 * Jq[q];
-                const uint32_t diff = si_new ^ sb[q];                   // bit r set: s_i != s_j for replica r -> sigma = -1
+                d4[q] = 4.0 * Jq[q];
+                diff[q] = si_new ^ sb[q];                               // bit r set: s_i != s_j for replica r -> sigma = -1
+            }
 #pragma unroll
-                for (int r = 0; r < kSkRB; ++r)
-                    if ((normal >> r) & 1u) {
+            for (int r = 0; r < kSkRB; ++r)
+                if ((normal >> r) & 1u) {
+#pragma unroll
+                    for (int q = 0; q < SPT; ++q) {
                         const double old = lf[q][r];
                         lfl[q][r] = old;
-                        lf[q][r] = old + (((diff >> r) & 1u) ? -d4 : d4);   // lfields[j] = lfj + 4*J*sigma, SK.jl:256-262
+                        lf[q][r] = old + (((diff[q] >> r) & 1u) ? -d4[q] : d4[q]);   // lfields[j] = lfj + 4*J*sigma, SK.jl:256-262
                     }
-            }
+                }
             if (tid == owner) {
 #pragma unroll
                 for (int q = 0; q < SPT; ++q)
@@ -369,23 +380,27 @@ __global__ __launch_bounds__(kSkThreads) void skb_sweep_kernel(SkbParams P)
         const uint32_t si_new = si_old ^ accm;
         if (swpm) {
 #pragma unroll
-            for (int q = 0; q < SPT; ++q)
+            for (int r = 0; r < kSkRB; ++r)
+                if ((swpm >> r) & 1u) {
 #pragma unroll
-                for (int r = 0; r < kSkRB; ++r)
-                    if ((swpm >> r) & 1u) { const int32_t t = lf[q][r]; lf[q][r] = lfl[q][r]; lfl[q][r] = t; }
+                    for (int q = 0; q < SPT; ++q) { const int32_t t = lf[q][r]; lf[q][r] = lfl[q][r]; lfl[q][r] = t; }
+                }
         }
         if (normal) {
+            // replica outermost: one scalar branch per replica instead of one per (site, replica) pair
+            uint32_t x3[SPT];
 #pragma unroll
-            for (int q = 0; q < SPT; ++q) {
-                const uint32_t x3 = si_new ^ sb[q] ^ (Jq[q] ? 0xffu : 0u);   // bit r: s_i xor s_j xor J_ij
+            for (int q = 0; q < SPT; ++q) x3[q] = si_new ^ sb[q] ^ (Jq[q] ? 0xffu : 0u);   // bit r: s_i xor s_j xor J_ij
 #pragma unroll
-                for (int r = 0; r < kSkRB; ++r)
-                    if ((normal >> r) & 1u) {
+            for (int r = 0; r < kSkRB; ++r)
+                if ((normal >> r) & 1u) {
+#pragma unroll
+                    for (int q = 0; q < SPT; ++q) {
                         const int32_t old = lf[q][r];
                         lfl[q][r] = old;
-                        lf[q][r] = old + (((x3 >> r) & 1u) ? 4 : -4);          // lfj + 8*Jsij - 4, SK.jl:118-121
+                        lf[q][r] = old + (((x3[q] >> r) & 1u) ? 4 : -4);       // lfj + 8*Jsij - 4, SK.jl:118-121
                     }
-            }
+                }
             if (tid == owner) {
 #pragma unroll
                 for (int q = 0; q < SPT; ++q)
