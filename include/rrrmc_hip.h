@@ -49,7 +49,7 @@ enum rrrmc_model {
     RRRMC_MODEL_SPARSE_PM1 = 1,  /* GraphRRG{Int,(-1,1),K} src/graphs/RRG.jl:116 and GraphEA{Int,(-1,1),2D} src/graphs/EA.jl:138 */
     RRRMC_MODEL_SK_NORMAL = 2,   /* GraphSKNormal (Float64 couplings) src/graphs/SK.jl:181-210; K is ignored */
     RRRMC_MODEL_SPARSE_F64 = 5,  /* GraphRRGNormal{K} src/graphs/RRG.jl:503-520 and GraphEANormal{2D} src/graphs/EA.jl:534-552: sparse, Float64 couplings */
-    RRRMC_MODEL_SPARSE_DISCRETIZED = 6, /* GraphRRGNormalDiscretized src/graphs/RRG.jl:285-307, GraphEANormalDiscretized src/graphs/EA.jl:311-352 (integer LEV) */
+    RRRMC_MODEL_SPARSE_DISCRETIZED = 6, /* GraphRRGNormalDiscretized src/graphs/RRG.jl:285-307, GraphEANormalDiscretized src/graphs/EA.jl:311-352 (Int or DFloat64 LEV) */
     RRRMC_MODEL_SK_BINARY = 4,   /* GraphSK (couplings +-1/sqrt(N), bit-packed) src/graphs/SK.jl:28-60; K is ignored; energies Float64 */
     RRRMC_MODEL_QUANT_RRG = 3    /* GraphQuant over M Suzuki-Trotter slices of one GraphRRG{Int,(-1,1),K} disorder
                                     (src/graphs/QT.jl:126-170 with the shared-disorder pattern of src/QAliases.jl:43-67);
@@ -220,11 +220,21 @@ RRRMC_API int32_t rrrmc_gen_couplings_gauss(int64_t N, int64_t K, const int32_t 
  *   ea_form    0: GraphRRG conventions (neighbors = non-zero couplings, RRG.jl:133), 1: GraphEA (repeats removed, EA.jl:158)
  * Sampler: rrrmc_rrr_mc_async (rrrMC(X::DoubleGraph), src/RRRMC.jl:221-290; fourK ignored); results through
  * rrrmc_fetch_results_f64 / rrrmc_rrr_stats; rrrmc_rrr_cache returns pos[R*N] and sizes[R*16] (class k of replica r at 16 r + k, k < 2L); energy through rrrmc_energy_f64.
- * standardMC on these graphs is not wired (use RRRMC_MODEL_SPARSE_F64 with cJ = dJ + rJ). */
+ * rrrmc_standard_mc_async / rrrmc_standard_mc_f64 run standardMC (src/RRRMC.jl:81-127) with
+ * delta_energy = convert(Float64, dE0 + dE1) (RRG.jl:493-497, EA.jl:523-527).
+ *
+ * Level units.  The reference's level type is Int or DFloat64 (src/DFloats.jl:11-36: the Int64 t = round(x * 10^5) whose
+ * Float64 value is t / 10^5; Float64 LEV tuples are mapped to it, RRG.jl:324, EA.jl:357).  lev[] and dJ[] are integer *units*;
+ * wherever the reference promotes a level quantity to Float64 the library computes (units * mul) / div, with (mul, div) set by
+ * rrrmc_set_level_scale: (1, 1.0) for Int levels (the default), (g, 1e5) for DFloat64 levels with units = t / g, g = gcd of
+ * the levels' t.  Call it before rrrmc_energy_f64 / the samplers; rrrmc_discretize_scaled is the matching discretize. */
 RRRMC_API int32_t rrrmc_set_graph_discretized(rrrmc_ctx *ctx, const int32_t *A, const int8_t *dJ, const double *rJ,
                                               const int32_t *lev, int32_t nlev, int32_t ea_form);
-/* discretize(cvec, LEV) (src/Common.jl:38-72): d_out[n] levels, r_out[n] residuals. */
+RRRMC_API int32_t rrrmc_set_level_scale(rrrmc_ctx *ctx, int64_t mul, double div);
+/* discretize(cvec, LEV) (src/Common.jl:38-72): d_out[n] levels (units), r_out[n] residuals. */
 RRRMC_API int32_t rrrmc_discretize(const double *x, int64_t n, const int32_t *lev, int32_t nlev, int8_t *d_out, double *r_out);
+RRRMC_API int32_t rrrmc_discretize_scaled(const double *x, int64_t n, const int32_t *lev, int32_t nlev, int64_t mul, double div,
+                                          int8_t *d_out, double *r_out);
 
 /* ---- snapshots and observables -------------------------------------------------------
  * The reference's scripts keep a copy of C.s at every hook call (scripts/scripts.jl:56-66, to_mat :13-21) and later

@@ -485,35 +485,52 @@ def all_delta_e(K, lev):
     return tuple(int(v) for v in out[:n])
 
 
-def discretize(x, lev):
-    """discretize (Common.jl:38-72): (levels, residuals) with the shape of x"""
+def dfloat_units(LEV):
+    """Float64 levels -> (units, mul, div): DFloat64(x) is the Int64 t = round(x * 10^5) (src/DFloats.jl:11-24, ties to even);
+    units = t / g with g = gcd of the |t| so that they fit narrow tables; value = units * mul / div with (mul, div) = (g, 1e5).
+    Integer levels -> (LEV, 1, 1.0)."""
+    if all(isinstance(l, (int, np.integer)) for l in LEV):
+        return tuple(int(l) for l in LEV), 1, 1.0
+    import math
+    t = [int(np.rint(float(l) * 100000.0)) for l in LEV]
+    g = 0
+    for x in t:
+        g = math.gcd(g, abs(x))
+    g = max(g, 1)
+    return tuple(x // g for x in t), g, 100000.0
+
+
+def discretize(x, lev, mul=1, div=1.0):
+    """discretize (Common.jl:38-72): (levels [units], residuals) with the shape of x"""
     L = lib()
-    L.orc_discretize.restype = None
-    L.orc_discretize.argtypes = [f64p, C.c_int64, i32p, C.c_int64, i32p, f64p]
+    L.orc_discretize_scaled.restype = None
+    L.orc_discretize_scaled.argtypes = [f64p, C.c_int64, i32p, C.c_int64, C.c_int64, C.c_double, i32p, f64p]
     x = np.ascontiguousarray(x, np.float64)
     d = np.zeros(x.shape, np.int32)
     r = np.zeros(x.shape, np.float64)
-    L.orc_discretize(x.reshape(-1), x.size, np.asarray(lev, np.int32), len(lev), d.reshape(-1), r.reshape(-1))
+    L.orc_discretize_scaled(x.reshape(-1), x.size, np.asarray(lev, np.int32), len(lev), int(mul), float(div), d.reshape(-1), r.reshape(-1))
     return d, r
 
 
-def dbl_energy(A, dJ, rJ, chunks, form="rrg"):
+def dbl_energy(A, dJ, rJ, chunks, form="rrg", mul=1, div=1.0):
     L = lib()
-    L.orc_dbl_energy.restype = C.c_double
-    L.orc_dbl_energy.argtypes = [C.c_int, C.c_int64, C.c_int64, i32p, i32p, f64p, u64p]
+    L.orc_dbl_energy_scaled.restype = C.c_double
+    L.orc_dbl_energy_scaled.argtypes = [C.c_int, C.c_int64, C.c_int64, i32p, i32p, f64p, u64p, C.c_int64, C.c_double]
     A = np.ascontiguousarray(A, np.int32)
     N, K = A.shape
-    return float(L.orc_dbl_energy(1 if form == "ea" else 0, N, K, A, np.ascontiguousarray(dJ, np.int32).reshape(-1),
-                                  np.ascontiguousarray(rJ, np.float64).reshape(-1), np.ascontiguousarray(chunks, np.uint64)))
+    return float(L.orc_dbl_energy_scaled(1 if form == "ea" else 0, N, K, A, np.ascontiguousarray(dJ, np.int32).reshape(-1),
+                                         np.ascontiguousarray(rJ, np.float64).reshape(-1), np.ascontiguousarray(chunks, np.uint64),
+                                         int(mul), float(div)))
 
 
 def rrr_double_sparse(A, dJ, rJ, lev, beta, iters, step, seed, chunks, it0=0, replica=0, staged_thr=0.5, staged_thr_fact=5.0,
-                      form="rrg"):
+                      form="rrg", mul=1, div=1.0):
     """rrrMC(X::DoubleGraph) on Graph{RRG,EA}NormalDiscretized; returns (Es, chunks, accepted, staged_its, pos[N], sizes[2L])."""
     L = lib()
-    L.orc_rrr_double_sparse.restype = C.c_int64
-    L.orc_rrr_double_sparse.argtypes = [C.c_int, C.c_int64, C.c_int64, i32p, i32p, f64p, i32p, C.c_int64, C.c_double, C.c_int64,
-                                        C.c_int64, C.c_double, C.c_double, C.c_uint64, C.c_uint64, C.c_uint32, u64p, f64p, i64p, i32p]
+    L.orc_rrr_double_sparse_scaled.restype = C.c_int64
+    L.orc_rrr_double_sparse_scaled.argtypes = [C.c_int, C.c_int64, C.c_int64, i32p, i32p, f64p, i32p, C.c_int64, C.c_int64, C.c_double,
+                                               C.c_double, C.c_int64, C.c_int64, C.c_double, C.c_double, C.c_uint64, C.c_uint64,
+                                               C.c_uint32, u64p, f64p, i64p, i32p]
     A = np.ascontiguousarray(A, np.int32)
     N, K = A.shape
     nl = len(all_delta_e(K, lev))
@@ -521,12 +538,30 @@ def rrr_double_sparse(A, dJ, rJ, lev, beta, iters, step, seed, chunks, it0=0, re
     Es = np.zeros(max(iters // step, 1))
     stats = np.zeros(2, np.int64)
     cache = np.zeros(N + 2 * nl, np.int32)
-    n = L.orc_rrr_double_sparse(1 if form == "ea" else 0, N, K, A, np.ascontiguousarray(dJ, np.int32).reshape(-1),
-                                np.ascontiguousarray(rJ, np.float64).reshape(-1), np.asarray(lev, np.int32), len(lev), float(beta),
-                                int(iters), int(step), float(staged_thr), float(staged_thr_fact), seed, it0, replica, ch, Es, stats, cache)
+    n = L.orc_rrr_double_sparse_scaled(1 if form == "ea" else 0, N, K, A, np.ascontiguousarray(dJ, np.int32).reshape(-1),
+                                       np.ascontiguousarray(rJ, np.float64).reshape(-1), np.asarray(lev, np.int32), len(lev),
+                                       int(mul), float(div), float(beta), int(iters), int(step), float(staged_thr),
+                                       float(staged_thr_fact), seed, it0, replica, ch, Es, stats, cache)
     if n < 0:
         raise RuntimeError("rrr_double_sparse: cache inconsistent (rc=%d)" % n)
     return Es[:n], ch, int(stats[0]), int(stats[1]), cache[:N].copy(), cache[N:].copy()
+
+
+def standard_mc_dbl(A, dJ, rJ, beta, iters, step, seed, chunks, it0=0, replica=0, form="rrg", mul=1, div=1.0):
+    """standardMC on Graph{RRG,EA}NormalDiscretized; returns (Es, chunks, accepted)."""
+    L = lib()
+    L.orc_standard_mc_dbl.restype = C.c_int64
+    L.orc_standard_mc_dbl.argtypes = [C.c_int, C.c_int64, C.c_int64, i32p, i32p, f64p, C.c_int64, C.c_double, C.c_double, C.c_int64,
+                                      C.c_int64, C.c_uint64, C.c_uint64, C.c_uint32, u64p, f64p, i64p]
+    A = np.ascontiguousarray(A, np.int32)
+    N, K = A.shape
+    ch = np.array(chunks, np.uint64, copy=True)
+    Es = np.zeros(max(iters // step, 1))
+    acc = np.zeros(1, np.int64)
+    n = L.orc_standard_mc_dbl(1 if form == "ea" else 0, N, K, A, np.ascontiguousarray(dJ, np.int32).reshape(-1),
+                              np.ascontiguousarray(rJ, np.float64).reshape(-1), int(mul), float(div), float(beta), int(iters), int(step),
+                              seed, it0, replica, ch, Es, acc)
+    return Es[:n], ch, int(acc[0])
 
 
 def wtm_mc_sparse(A, J, beta, samples, step, seed, chunks, call=0, replica=0, form="rrg"):

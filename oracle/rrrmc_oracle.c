@@ -344,19 +344,30 @@ ORC_API int64_t orc_all_delta_e(int64_t K, const int32_t *lev, int64_t nlev, int
     return n;
 }
 
+/* Level units.  The reference's level type is either Int or DFloat64 — "an integer in disguise" (src/DFloats.jl:11-36): the
+ * Int64 t = round(x * 10^5) whose Float64 value is t / 10^5 (:23,26), with +, -, ==, < and Integer * DFloat64 acting on t.
+ * All level arithmetic here is done in integer *units*: value = (units * mul) / div, with (mul, div) = (1, 1.0) for Int levels
+ * and (g, 10^5) for DFloat64 levels, g = gcd of the levels' t (so that units fit the narrow coupling tables). */
+static inline double lev_to_f64(int64_t units, int64_t mul, double div) { return (double)(units * mul) / div; }
+
 /* discretize(x, LEV): Common.jl:38-49 — the nearest level (the first one on ties) and the residual x - d */
-ORC_API void orc_discretize(const double *x, int64_t n, const int32_t *lev, int64_t nlev, int32_t *d_out, double *r_out)
+ORC_API void orc_discretize_scaled(const double *x, int64_t n, const int32_t *lev, int64_t nlev, int64_t mul, double div,
+                                   int32_t *d_out, double *r_out)
 {
     for (int64_t q = 0; q < n; ++q) {
         int32_t d = lev[0];
-        double r = x[q] - (double)d;
+        double r = x[q] - lev_to_f64(d, mul, div);
         for (int64_t l = 1; l < nlev; ++l) {
-            double r1 = x[q] - (double)lev[l];
+            double r1 = x[q] - lev_to_f64(lev[l], mul, div);
             if (fabs(r1) < fabs(r)) { d = lev[l]; r = r1; }
         }
         d_out[q] = d;
         r_out[q] = r;
     }
+}
+ORC_API void orc_discretize(const double *x, int64_t n, const int32_t *lev, int64_t nlev, int32_t *d_out, double *r_out)
+{
+    orc_discretize_scaled(x, n, lev, nlev, 1, 1.0, d_out, r_out);
 }
 
 /* ---------------------------------------------------------------------------------------------
@@ -1451,7 +1462,7 @@ static inline double decs_f(const decs_t *c, int k) { return k >= c->L ? c->ft[k
 static inline int decs_class(const decs_t *c, int64_t dE, int sbit) { return decs_findk(c, dE) + c->L * (dE > 0 || (dE == 0 && sbit == 1)); }
 
 /* dElist == NULL: the +-J table (RRG.jl:262-266, EA.jl:293) */
-static void decs_init_levels(decs_t *c, sparse_t *X, const uint64_t *s, double beta, const int64_t *dElist, int L)   /* DeltaE.jl:74-103 */
+static void decs_init_scaled(decs_t *c, sparse_t *X, const uint64_t *s, double beta, const int64_t *dElist, int L, int64_t mul, double div)   /* DeltaE.jl:74-103 */
 {
     c->N = X->N;
     int64_t tmp[SK_MAX + 1];
@@ -1465,11 +1476,15 @@ static void decs_init_levels(decs_t *c, sparse_t *X, const uint64_t *s, double b
         c->pos[i] = (int8_t)k;
         aset_push(&c->as[k], (int32_t)i);
     }
-    for (int k = 0; k < c->L; ++k) c->ft[k] = orc_det_exp(-beta * (double)c->dElist[k]);
+    for (int k = 0; k < c->L; ++k) c->ft[k] = orc_det_exp(-beta * lev_to_f64(c->dElist[k], mul, div));
     c->z = 0.0;
     for (int k = 0; k < 2 * c->L; ++k) { double x = (double)c->as[k].t * decs_f(c, k); c->z += x; c->T[k] = x; }
     c->zp = c->z;
     c->nstaged = 0;
+}
+static void decs_init_levels(decs_t *c, sparse_t *X, const uint64_t *s, double beta, const int64_t *dElist, int L)
+{
+    decs_init_scaled(c, X, s, beta, dElist, L, 1, 1.0);
 }
 static void decs_init(decs_t *c, sparse_t *X, const uint64_t *s, double beta) { decs_init_levels(c, X, s, beta, NULL, 0); }
 static void decs_free(decs_t *c) { for (int k = 0; k < 2 * c->L; ++k) aset_free(&c->as[k]); free(c->pos); }
@@ -1685,7 +1700,8 @@ static double dbl_apply_move(decs_t *c, sparse_t *X0, spf_t *X1, uint64_t *s, in
     return cc;
 }
 
-ORC_API double orc_dbl_energy(int form, int64_t N, int64_t K, const int32_t *A, const int32_t *dJ, const double *rJ, const uint64_t *chunks)
+ORC_API double orc_dbl_energy_scaled(int form, int64_t N, int64_t K, const int32_t *A, const int32_t *dJ, const double *rJ, const uint64_t *chunks,
+                                     int64_t mul, double div)
 {
     sparse_t X0 = {N, K, A, dJ, NULL, NULL, -1, form};
     spf_t X1 = {N, K, A, rJ, NULL, NULL, -1, form};
@@ -1694,14 +1710,18 @@ ORC_API double orc_dbl_energy(int form, int64_t N, int64_t K, const int32_t *A, 
     const int64_t E0 = sparse_energy(&X0, chunks);
     const double E1 = spf_energy(&X1, chunks);
     free(X0.lfields); free(X0.lfields_last); free(X1.lfields); free(X1.lfields_last);
-    return (double)E0 + E1;                                   /* convert(Float64, E0 + E1): RRG.jl:359 */
+    return lev_to_f64(E0, mul, div) + E1;                     /* convert(Float64, E0 + E1): RRG.jl:359 */
+}
+ORC_API double orc_dbl_energy(int form, int64_t N, int64_t K, const int32_t *A, const int32_t *dJ, const double *rJ, const uint64_t *chunks)
+{
+    return orc_dbl_energy_scaled(form, N, K, A, dJ, rJ, chunks, 1, 1.0);
 }
 
 /* stats = [accepted, staged iterations]; cache_out = pos[N] then the 2L class sizes */
-ORC_API int64_t orc_rrr_double_sparse(int form, int64_t N, int64_t K, const int32_t *A, const int32_t *dJ, const double *rJ,
-                                      const int32_t *lev, int64_t nlev, double beta, int64_t iters, int64_t step,
-                                      double staged_thr, double staged_thr_fact, uint64_t seed, uint64_t it0, uint32_t replica,
-                                      uint64_t *chunks, double *Es, int64_t *stats, int32_t *cache_out)
+ORC_API int64_t orc_rrr_double_sparse_scaled(int form, int64_t N, int64_t K, const int32_t *A, const int32_t *dJ, const double *rJ,
+                                             const int32_t *lev, int64_t nlev, int64_t mul, double div, double beta, int64_t iters, int64_t step,
+                                             double staged_thr, double staged_thr_fact, uint64_t seed, uint64_t it0, uint32_t replica,
+                                             uint64_t *chunks, double *Es, int64_t *stats, int32_t *cache_out)
 {
     int64_t dElist[SL_MAX];
     const int64_t L = orc_all_delta_e(K, lev, nlev, dElist, SL_MAX);
@@ -1710,10 +1730,10 @@ ORC_API int64_t orc_rrr_double_sparse(int form, int64_t N, int64_t K, const int3
     spf_t X1 = {N, K, A, rJ, NULL, NULL, -1, form};
     X0.lfields = (int64_t *)malloc((size_t)N * 8); X0.lfields_last = (int64_t *)malloc((size_t)N * 8);
     X1.lfields = (double *)malloc((size_t)N * 8); X1.lfields_last = (double *)malloc((size_t)N * 8);
-    double E = (double)sparse_energy(&X0, chunks);
+    double E = lev_to_f64(sparse_energy(&X0, chunks), mul, div);
     E = E + spf_energy(&X1, chunks);
     decs_t c;
-    decs_init_levels(&c, &X0, chunks, beta, dElist, (int)L);
+    decs_init_scaled(&c, &X0, chunks, beta, dElist, (int)L, mul, div);
     const double lambda = staged_thr_fact / (double)N;
     double acc_rate = 0.5;
     int64_t accepted = 0, staged_its = 0, nsamp = 0;
@@ -1731,14 +1751,14 @@ ORC_API int64_t orc_rrr_double_sparse(int form, int64_t N, int64_t K, const int3
             if (accept_cx(cc, -beta * dE1, seed, g, replica)) {
                 dbl_spinflip(&X0, &X1, chunks, move);
                 decs_apply_staged(&c);
-                E += (double)dE0 + dE1;
+                E += lev_to_f64(dE0, mul, div) + dE1;
                 accepted++; acc = 1;
             }
         } else {
             int64_t dE0, move = decs_rand_move(&c, seed, g, replica, &dE0);
             double dE1 = -X1.lfields[move];
             double cc = dbl_apply_move(&c, &X0, &X1, chunks, move);
-            if (accept_cx(cc, -beta * dE1, seed, g, replica)) { E += (double)dE0 + dE1; accepted++; acc = 1; }
+            if (accept_cx(cc, -beta * dE1, seed, g, replica)) { E += lev_to_f64(dE0, mul, div) + dE1; accepted++; acc = 1; }
             else dbl_apply_move(&c, &X0, &X1, chunks, move);
         }
         acc_rate = acc_rate * (1 - lambda) + (double)acc * lambda;
@@ -1753,6 +1773,44 @@ ORC_API int64_t orc_rrr_double_sparse(int form, int64_t N, int64_t K, const int3
     decs_free(&c);
     free(X0.lfields); free(X0.lfields_last); free(X1.lfields); free(X1.lfields_last);
     return ok ? nsamp : -1;
+}
+ORC_API int64_t orc_rrr_double_sparse(int form, int64_t N, int64_t K, const int32_t *A, const int32_t *dJ, const double *rJ,
+                                      const int32_t *lev, int64_t nlev, double beta, int64_t iters, int64_t step,
+                                      double staged_thr, double staged_thr_fact, uint64_t seed, uint64_t it0, uint32_t replica,
+                                      uint64_t *chunks, double *Es, int64_t *stats, int32_t *cache_out)
+{
+    return orc_rrr_double_sparse_scaled(form, N, K, A, dJ, rJ, lev, nlev, 1, 1.0, beta, iters, step, staged_thr, staged_thr_fact, seed, it0,
+                                        replica, chunks, Es, stats, cache_out);
+}
+
+/* standardMC (src/RRRMC.jl:81-127) on the same DoubleGraphs: delta_energy(X, C, move) = convert(Float64, dE0 + dE1)
+ * (RRG.jl:493-497, EA.jl:523-527), spinflip! = bit flip + both caches.  SITE / ACCEPT_F64 streams as for the other Float64 models. */
+ORC_API int64_t orc_standard_mc_dbl(int form, int64_t N, int64_t K, const int32_t *A, const int32_t *dJ, const double *rJ,
+                                    int64_t mul, double div, double beta, int64_t iters, int64_t step, uint64_t seed, uint64_t it0,
+                                    uint32_t replica, uint64_t *chunks, double *Es, int64_t *accepted_out)
+{
+    sparse_t X0 = {N, K, A, dJ, NULL, NULL, -1, form};
+    spf_t X1 = {N, K, A, rJ, NULL, NULL, -1, form};
+    X0.lfields = (int64_t *)malloc((size_t)N * 8); X0.lfields_last = (int64_t *)malloc((size_t)N * 8);
+    X1.lfields = (double *)malloc((size_t)N * 8); X1.lfields_last = (double *)malloc((size_t)N * 8);
+    double E = lev_to_f64(sparse_energy(&X0, chunks), mul, div);
+    E = E + spf_energy(&X1, chunks);
+    int64_t accepted = 0, nsamp = 0;
+    for (int64_t it = 1; it <= iters; ++it) {
+        if (it % step == 0) Es[nsamp++] = E;
+        const uint64_t g = it0 + (uint64_t)it;
+        const int64_t i = orc_site(seed, g, N);
+        const double dE = lev_to_f64(sparse_delta_energy(&X0, i), mul, div) + (-X1.lfields[i]);
+        const double x = -beta * dE;
+        const int acc = (x >= 0) || (orc_rand53(seed, g, replica) < orc_det_exp(x));      /* RRRMC.jl:39 */
+        if (!acc) continue;
+        dbl_spinflip(&X0, &X1, chunks, i);
+        E += dE;
+        accepted += 1;
+    }
+    if (accepted_out) *accepted_out = accepted;
+    free(X0.lfields); free(X0.lfields_last); free(X1.lfields); free(X1.lfields_last);
+    return nsamp;
 }
 
 /* =============================================================================================

@@ -25,7 +25,7 @@ SYMBOLS = [
     "rrrmc_set_couplings_bits", "rrrmc_gen_sk_binary", "rrrmc_set_coloring", "rrrmc_colored_sweeps_async",
     "rrrmc_ctx_create_quant", "rrrmc_quant_set_field", "rrrmc_rrr_mc_async", "rrrmc_rrr_stats", "rrrmc_rrr_cache", "rrrmc_bkl_mc_async",
     "rrrmc_snapshot_reserve", "rrrmc_snapshot_store", "rrrmc_snapshot_get", "rrrmc_overlaps", "rrrmc_quant_observables",
-    "rrrmc_set_graph_f64", "rrrmc_gen_couplings_gauss", "rrrmc_set_graph_discretized", "rrrmc_discretize", "rrrmc_wtm_mc_async", "rrrmc_wtm_times", "rrrmc_extremal_opt_async", "rrrmc_extremal_opt_results",
+    "rrrmc_set_graph_f64", "rrrmc_gen_couplings_gauss", "rrrmc_set_graph_discretized", "rrrmc_set_level_scale", "rrrmc_discretize", "rrrmc_discretize_scaled", "rrrmc_wtm_mc_async", "rrrmc_wtm_times", "rrrmc_extremal_opt_async", "rrrmc_extremal_opt_results",
 ]
 
 
@@ -144,6 +144,10 @@ def lib():
     L.rrrmc_set_graph_discretized.argtypes = [vp, i32p, i8p, f64p, i32p, C.c_int32, C.c_int32]
     L.rrrmc_discretize.restype = C.c_int32
     L.rrrmc_discretize.argtypes = [f64p, C.c_int64, i32p, C.c_int32, i8p, f64p]
+    L.rrrmc_discretize_scaled.restype = C.c_int32
+    L.rrrmc_discretize_scaled.argtypes = [f64p, C.c_int64, i32p, C.c_int32, C.c_int64, C.c_double, i8p, f64p]
+    L.rrrmc_set_level_scale.restype = C.c_int32
+    L.rrrmc_set_level_scale.argtypes = [vp, C.c_int64, C.c_double]
     L.rrrmc_wtm_mc_async.restype = C.c_int32
     L.rrrmc_wtm_mc_async.argtypes = [vp, C.c_double, C.c_int64, C.c_double]
     L.rrrmc_wtm_times.restype = C.c_int32

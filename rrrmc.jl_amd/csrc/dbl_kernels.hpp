@@ -35,10 +35,15 @@ struct RrrDblParams {
     double ft[kDLmax];
     int dElist[kDLmax];
     double beta, staged_thr, lambda;
+    // level units -> Float64: value = (units * lev_mul) / lev_div; (1, 1.0) for Int levels, (g, 1e5) for DFloat64 levels
+    // (src/DFloats.jl:11-36: the Int64 t = round(x * 10^5), Float64(t) = t / 10^5; units = t / g, g = gcd of the levels' t)
+    long long lev_mul;
+    double lev_div;
     uint64_t g0;
     int64_t iters, step;
     uint32_t k0, k1, replica0;
     int N, K, L, W, R, ea_form, energy_only;
+    __host__ __device__ __forceinline__ double to_f64(long long units) const { return (double)(units * lev_mul) / lev_div; }
 };
 
 struct DblChain {
@@ -155,17 +160,15 @@ __device__ __forceinline__ bool dbl_accept(double c, double x, uint64_t g, uint3
     return (double)((((uint64_t)o2.w[0] << 32) | o2.w[1]) >> 11) * 0x1.0p-53 < a;
 }
 
-__global__ __launch_bounds__(kRrrThreads) void rrr_dbl_kernel(RrrDblParams P)
+// energy(X, C) = E0 + E1 (RRG.jl:326-360) — fills the residual fields — and, with `classes`, gen_ΔEcache(X0, C, beta)'s class
+// sets in site order (DeltaE.jl:74-103)
+__device__ __forceinline__ double dbl_init_chain(DblChain& c, const RrrDblParams& P, int r, bool classes)
 {
-    const int r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= P.R) return;
-    const int N = P.N, L = P.L, K2 = 2 * P.L, K = P.K;
-    DblChain c;
+    const int N = P.N, K2 = 2 * P.L, K = P.K;
     c.P = &P;
     c.sp = P.spins + (size_t)r * P.W; c.cls = P.cls + (size_t)r * N; c.sv = P.sv + (size_t)r * K2 * N; c.spos = P.spos + (size_t)r * N;
     c.lf = P.lf + (size_t)r * N; c.undo = P.undo + (size_t)r * (K + 1);
     c.mlast = -1;
-    // energy(X, C) = E0 + E1 (RRG.jl:326-360) and gen_ΔEcache(X0, C, beta) in site order (DeltaE.jl:74-103)
     long long n0 = 0;
     double E1 = 0.0;
     for (int k = 0; k < K2; ++k) c.t[k] = 0;
@@ -179,7 +182,7 @@ __global__ __launch_bounds__(kRrrThreads) void rrr_dbl_kernel(RrrDblParams P)
         }
         E1 = E1 + fl;
         c.lf[i] = 2.0 * fl;
-        if (!P.energy_only) {
+        if (classes) {
             const int k = c.klass(i);
             c.cls[i] = (uint8_t)k;
             c.sv[(size_t)k * N + c.t[k]] = (uint16_t)i;
@@ -188,7 +191,39 @@ __global__ __launch_bounds__(kRrrThreads) void rrr_dbl_kernel(RrrDblParams P)
         }
     }
     E1 = E1 / 2;
-    double E = (double)(n0 / 2) + E1;
+    return P.to_f64(n0 / 2) + E1;
+}
+
+// standardMC (RRRMC.jl:81-127) on the DoubleGraph: delta_energy = convert(Float64, dE0 + dE1) (RRG.jl:493-497), common site
+// (SITE stream), per-replica ACCEPT_F64 uniform; one thread per replica as for rrrMC.
+__global__ __launch_bounds__(kRrrThreads) void dbl_standard_kernel(RrrDblParams P)
+{
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= P.R) return;
+    DblChain c;
+    double E = dbl_init_chain(c, P, r, false);
+    const uint32_t rep = P.replica0 + (uint32_t)r;
+    long long accepted = 0, ns = 0;
+    for (long long it = 1; it <= P.iters; ++it) {
+        if (it % P.step == 0) { P.Es[(size_t)ns * P.R + r] = E; ns += 1; }
+        const uint64_t g = P.g0 + (uint64_t)it;
+        const int move = (int)site_of(P.k0, P.k1, g, (uint32_t)P.N);
+        const double dE = P.to_f64(c.dE0(move)) + (-c.lf[move]);
+        const double x = -P.beta * dE;
+        const bool acc = (x >= 0.0) || (rand53(P.k0, P.k1, g, rep) < det_exp(x));        // RRRMC.jl:39
+        if (acc) { c.spinflip(move); E += dE; accepted += 1; }
+    }
+    P.E_cur[r] = E;
+    P.stats[(size_t)r * 2] = accepted; P.stats[(size_t)r * 2 + 1] = 0;
+}
+
+__global__ __launch_bounds__(kRrrThreads) void rrr_dbl_kernel(RrrDblParams P)
+{
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= P.R) return;
+    const int N = P.N, L = P.L, K2 = 2 * P.L, K = P.K;
+    DblChain c;
+    double E = dbl_init_chain(c, P, r, !P.energy_only);
     if (P.energy_only) { P.E_cur[r] = E; return; }
     c.z = 0.0;
     for (int k = 0; k < 2 * kDLmax; ++k) c.T[k] = 0.0;
@@ -235,13 +270,13 @@ __global__ __launch_bounds__(kRrrThreads) void rrr_dbl_kernel(RrrDblParams P)
                 for (int q = 0; q < nst; ++q) c.set_move(sj[q], s0[q], s1[q]);   // apply_staged!
                 for (int q = 0; q < 2 * kDLmax; ++q) c.T[q] = Tp[q];
                 c.z = zp;
-                E += (double)dE0 + dE1;
+                E += P.to_f64(dE0) + dE1;
                 accepted += 1; acc = true;
             }
         } else {
             const double dE1 = -c.lf[move];
             const double cc = c.apply_move(move);
-            if (dbl_accept(cc, -P.beta * dE1, g, rep, P.k0, P.k1)) { E += (double)dE0 + dE1; accepted += 1; acc = true; }
+            if (dbl_accept(cc, -P.beta * dE1, g, rep, P.k0, P.k1)) { E += P.to_f64(dE0) + dE1; accepted += 1; acc = true; }
             else c.apply_move(move);
         }
         acc_rate = acc_rate * (1 - P.lambda) + (acc ? 1.0 : 0.0) * P.lambda;      // RRRMC.jl:281

@@ -54,7 +54,8 @@ RrrDblParams dbl_params(rrrmc_ctx* ctx, double beta)
     RrrDblParams P{};
     P.A = ctx->d_A; P.dJ = ctx->db_dJ; P.rJ = ctx->db_rJ; P.spins = ctx->q_spins; P.cls = ctx->db_cls; P.sv = ctx->db_sv; P.spos = ctx->db_spos;
     P.lf = ctx->db_lf; P.undo = ctx->db_undo; P.E_cur = ctx->sk_E; P.stats = ctx->q_stats; P.Es = ctx->sk_Es;
-    for (int k = 0; k < ctx->db_L; ++k) { P.dElist[k] = ctx->db_dElist[k]; P.ft[k] = host_det_exp(-beta * (double)ctx->db_dElist[k]); }   // DeltaE.jl:91
+    P.lev_mul = ctx->db_lev_mul; P.lev_div = ctx->db_lev_div;
+    for (int k = 0; k < ctx->db_L; ++k) { P.dElist[k] = ctx->db_dElist[k]; P.ft[k] = host_det_exp(-beta * P.to_f64(ctx->db_dElist[k])); }   // DeltaE.jl:91
     P.beta = beta;
     P.k0 = (uint32_t)ctx->seed; P.k1 = (uint32_t)(ctx->seed >> 32); P.replica0 = ctx->replica0;
     P.N = (int)ctx->N; P.K = (int)ctx->K; P.L = ctx->db_L; P.W = (int)ctx->qW; P.R = (int)ctx->R; P.ea_form = ctx->db_ea_form;
@@ -70,10 +71,12 @@ int32_t dbl_run_energy(rrrmc_ctx* ctx)
     return RRRMC_OK;
 }
 
-int32_t dbl_rrr_mc_async(rrrmc_ctx* ctx, double beta, int64_t iters, int64_t step, double staged_thr, double staged_thr_fact)
+// standard = false: rrrMC(X::DoubleGraph); true: standardMC on the same graph (staged_thr* unused)
+int32_t dbl_mc_async(rrrmc_ctx* ctx, bool standard, double beta, int64_t iters, int64_t step, double staged_thr, double staged_thr_fact)
 {
     if (iters < 0) return fail(ctx, RRRMC_ERR_INVALID_ARG, "iters must be >= 0, given %lld", (long long)iters);
     if (step < 1) return fail(ctx, RRRMC_ERR_INVALID_ARG, "step must be >= 1, given %lld", (long long)step);
+    if (std::isnan(beta)) return fail(ctx, RRRMC_ERR_INVALID_ARG, "beta is NaN");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     ctx->results_valid = false; ctx->last_call_wtm = false; ctx->last_call_eo = false;
     ctx->timing_valid = false;
@@ -96,7 +99,8 @@ int32_t dbl_rrr_mc_async(rrrmc_ctx* ctx, double beta, int64_t iters, int64_t ste
     hipStream_t st = ctx->stream;
     HIP_TRY(ctx, hipEventRecord(ctx->ev_begin, st));
     HIP_TRY(ctx, hipEventRecord(ctx->ev_sweep[0], st));
-    hipLaunchKernelGGL(rrr_dbl_kernel, dim3(rrr_blocks(ctx->R)), dim3(rrr_tpb(ctx->R)), 0, st, P);
+    if (standard) hipLaunchKernelGGL(dbl_standard_kernel, dim3(rrr_blocks(ctx->R)), dim3(rrr_tpb(ctx->R)), 0, st, P);
+    else hipLaunchKernelGGL(rrr_dbl_kernel, dim3(rrr_blocks(ctx->R)), dim3(rrr_tpb(ctx->R)), 0, st, P);
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipEventRecord(ctx->ev_sweep[1], st));
     HIP_TRY(ctx, hipEventRecord(ctx->ev_end, st));
@@ -106,6 +110,11 @@ int32_t dbl_rrr_mc_async(rrrmc_ctx* ctx, double beta, int64_t iters, int64_t ste
     ctx->it_done += (uint64_t)iters;
     ctx->results_valid = true;
     ctx->timing_valid = true;
-    ctx->last_call_rrr = true;
+    ctx->last_call_rrr = true;          // accepted counts live in q_stats
+    ctx->db_cache_valid = !standard;    // the class sets exist only after rrrMC
     return RRRMC_OK;
+}
+int32_t dbl_rrr_mc_async(rrrmc_ctx* ctx, double beta, int64_t iters, int64_t step, double staged_thr, double staged_thr_fact)
+{
+    return dbl_mc_async(ctx, false, beta, iters, step, staged_thr, staged_thr_fact);
 }

@@ -160,6 +160,9 @@ struct rrrmc_ctx {
     double* db_lf = nullptr;       // [R][N]
     double* db_undo = nullptr;     // [R][K+1]
     int db_L = 0, db_ea_form = 0;
+    long long db_lev_mul = 1;          // level units -> Float64: (units * mul) / div (DFloat64 levels: rrrmc_set_level_scale)
+    double db_lev_div = 1.0;
+    bool db_cache_valid = false;
     int db_dElist[kDLmax] = {0};
     // ---- continuous-energy rrrMC / bklMC / wtmMC on RRRMC_MODEL_SPARSE_F64 (allocated on first use) ----
     uint32_t* cs_spins = nullptr;  // [R][W] replica-contiguous words
@@ -745,7 +748,8 @@ int32_t rrrmc_standard_mc_async(rrrmc_ctx* ctx, double beta, int64_t iters, int6
     if (rc) return rc;
     if (ctx->model == RRRMC_MODEL_SK_NORMAL || ctx->model == RRRMC_MODEL_SK_BINARY) return sk_standard_mc_async(ctx, beta, iters, step);
     if (ctx->model == RRRMC_MODEL_SPARSE_F64) return spf_standard_mc_async(ctx, beta, iters, step);
-    if (ctx->model == RRRMC_MODEL_SPARSE_DISCRETIZED || ctx->model == RRRMC_MODEL_QUANT_RRG)
+    if (ctx->model == RRRMC_MODEL_SPARSE_DISCRETIZED) return dbl_mc_async(ctx, true, beta, iters, step, 0.0, 0.0);
+    if (ctx->model == RRRMC_MODEL_QUANT_RRG)
         return fail(ctx, RRRMC_ERR_UNSUPPORTED, "standardMC is not wired for this DoubleGraph: use rrrmc_rrr_mc_async");
     if (ctx->model != RRRMC_MODEL_SPARSE_PM1) return fail(ctx, RRRMC_ERR_UNSUPPORTED, "standardMC is not wired for this model on the device: use rrrmc_rrr_mc_async");
     if (!ctx->lds_mode) return fail(ctx, RRRMC_ERR_UNSUPPORTED, "N=%lld does not fit the LDS-resident random-site kernel: use rrrmc_colored_sweeps_async", (long long)ctx->N);
@@ -1288,6 +1292,7 @@ int32_t rrrmc_rrr_cache(rrrmc_ctx* ctx, int8_t* pos_out, int32_t* sizes_out)
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     if (ctx->model == RRRMC_MODEL_SPARSE_DISCRETIZED) {      // sizes_out[R * 16]: counted from the classes
+        if (!ctx->db_cache_valid) return fail(ctx, RRRMC_ERR_STATE, "no rrrMC call has been made");
         std::vector<uint8_t> cls((size_t)ctx->R * ctx->N);
         HIP_TRY(ctx, hipMemcpy(cls.data(), ctx->db_cls, cls.size(), hipMemcpyDeviceToHost));
         const int K2 = 2 * kDLmax;                           // fixed stride: class k of replica r at sizes_out[16 r + k]
@@ -1641,15 +1646,29 @@ int32_t rrrmc_set_graph_discretized(rrrmc_ctx* ctx, const int32_t* A, const int8
     return RRRMC_OK;
 }
 
-int32_t rrrmc_discretize(const double* x, int64_t n, const int32_t* lev, int32_t nlev, int8_t* d_out, double* r_out)
+int32_t rrrmc_set_level_scale(rrrmc_ctx* ctx, int64_t mul, double div)
 {
-    // discretize: src/Common.jl:38-49 (nearest level, the first one on ties; residual = x - level)
-    if (!x || !lev || !d_out || !r_out || nlev < 1 || n < 0) return RRRMC_ERR_INVALID_ARG;
+    if (!ctx) return RRRMC_ERR_INVALID_ARG;
+    if (ctx->model != RRRMC_MODEL_SPARSE_DISCRETIZED) return fail(ctx, RRRMC_ERR_STATE, "rrrmc_set_level_scale is for RRRMC_MODEL_SPARSE_DISCRETIZED");
+    if (mul < 1 || !(div > 0.0) || !std::isfinite(div)) return fail(ctx, RRRMC_ERR_INVALID_ARG, "level scale must have mul >= 1 and a finite div > 0");
+    // the largest level sum the kernels form is N * K * 127 units (the energy): keep units * mul inside the Float64-exact integers
+    if ((double)mul * 127.0 * (double)ctx->N * (double)ctx->K >= 9007199254740992.0)
+        return fail(ctx, RRRMC_ERR_UNSUPPORTED, "level scale mul=%lld too large for N=%lld, K=%lld", (long long)mul, (long long)ctx->N, (long long)ctx->K);
+    ctx->db_lev_mul = mul;
+    ctx->db_lev_div = div;
+    return RRRMC_OK;
+}
+
+int32_t rrrmc_discretize_scaled(const double* x, int64_t n, const int32_t* lev, int32_t nlev, int64_t mul, double div, int8_t* d_out, double* r_out)
+{
+    // discretize: src/Common.jl:38-49 (nearest level, the first one on ties; residual = x - level); the level's Float64 value is
+    // (units * mul) / div — DFloat64 levels promote to Float64 in `x - d` (src/DFloats.jl:26,42)
+    if (!x || !lev || !d_out || !r_out || nlev < 1 || n < 0 || mul < 1 || !(div > 0.0)) return RRRMC_ERR_INVALID_ARG;
     for (int64_t q = 0; q < n; ++q) {
         int32_t d = lev[0];
-        double r = x[q] - (double)d;
+        double r = x[q] - (double)((int64_t)d * mul) / div;
         for (int32_t l = 1; l < nlev; ++l) {
-            const double r1 = x[q] - (double)lev[l];
+            const double r1 = x[q] - (double)((int64_t)lev[l] * mul) / div;
             if (std::fabs(r1) < std::fabs(r)) { d = lev[l]; r = r1; }
         }
         if (d < -127 || d > 127) return RRRMC_ERR_UNSUPPORTED;
@@ -1657,6 +1676,11 @@ int32_t rrrmc_discretize(const double* x, int64_t n, const int32_t* lev, int32_t
         r_out[q] = r;
     }
     return RRRMC_OK;
+}
+
+int32_t rrrmc_discretize(const double* x, int64_t n, const int32_t* lev, int32_t nlev, int8_t* d_out, double* r_out)
+{
+    return rrrmc_discretize_scaled(x, n, lev, nlev, 1, 1.0, d_out, r_out);
 }
 
 namespace {

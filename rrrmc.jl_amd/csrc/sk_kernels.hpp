@@ -148,11 +148,7 @@ __global__ __launch_bounds__(kSkThreads) void sk_sweep_kernel(SkParams P)
                 }
                 const double dE = sh_lfi[b][tid];                       // delta_energy, SK.jl:278-284
                 const double x = -P.beta * dE;
-#ifdef RRRMC_SK_ABLATE_EXP      // timing experiments only
-                acc = (x >= 0.0) || (u_acc < 0.3);
-#else
-                acc = (x >= 0.0) || (u_acc < det_exp(x));                                                           // RRRMC.jl:39
-#endif
+                acc = (x >= 0.0) || (u_acc < det_exp(x));                // RRRMC.jl:39
                 swp = acc && (mlast == (int32_t)site);                  // undo path of update_cache!, SK.jl:247-250
                 if (acc) { E_run += dE; A_run += 1; mlast = (int32_t)site; }
             }

@@ -32,6 +32,7 @@ class Engine:
             elif X.model_kind == MODEL_SPARSE_DISCRETIZED:
                 check(lib().rrrmc_set_graph_discretized(self._ctx, X.A, X.dJ, X.rJ.reshape(-1), np.asarray(X.LEV, np.int32), len(X.LEV),
                                                         X.ea_form), self._ctx)
+                check(lib().rrrmc_set_level_scale(self._ctx, X.lev_mul, X.lev_div), self._ctx)
             elif X.model_kind == MODEL_SPARSE_F64:
                 check(lib().rrrmc_set_graph_f64(self._ctx, X.A, X.J.reshape(-1)), self._ctx)
             elif X.model_kind == MODEL_SK_BINARY:

@@ -2,6 +2,8 @@
 
 Indices are 0-based here; the Julia glue converts from the reference's 1-based tuples.
 """
+import math
+
 import numpy as np
 
 from ._lib import check, lib
@@ -214,18 +216,30 @@ class _DiscretizedGraph:
 
     def _split(self, A, cJ, LEV):
         LEV = tuple(LEV)
-        if any(int(l) != l for l in LEV):
-            raise NotImplementedError("only integer levels are covered by the HIP path, given: %r" % (LEV,))
-        if len(set(LEV)) != len(LEV):
+        if all(isinstance(l, (int, np.integer)) for l in LEV):
+            # Int levels: GraphRRGNormalDiscretized{Int,LEV,K}
+            self.LEV, self.lev_mul, self.lev_div = tuple(int(l) for l in LEV), 1, 1.0
+        else:
+            # Float64 levels -> DFloat64 (RRG.jl:324, EA.jl:357): the Int64 t = round(x * 10^5) (src/DFloats.jl:23, ties to even);
+            # the library works in units t / g (g = gcd) and converts with (units * g) / 1e5 where the reference promotes to Float64
+            t = [int(np.rint(float(l) * 100000.0)) for l in LEV]
+            g = 0
+            for x in t:
+                g = math.gcd(g, abs(x))
+            g = max(g, 1)
+            self.LEV, self.lev_mul, self.lev_div = tuple(x // g for x in t), g, 100000.0
+            if max(abs(u) for u in self.LEV) > 127:
+                raise NotImplementedError("levels %r need more than 8 bits per coupling after reduction by their gcd" % (LEV,))
+        self.levels = LEV                                                             # as given by the caller
+        if len(set(self.LEV)) != len(self.LEV):
             raise ValueError("repeated levels in LEV: %r" % (LEV,))                   # RRG.jl:100
-        self.LEV = tuple(int(l) for l in LEV)
         self.A = np.ascontiguousarray(A, np.int32)
         self.cJ = np.ascontiguousarray(cJ, np.float64)
         self.N, self.K = self.A.shape
         self.dJ = np.zeros(self.A.shape, np.int8)
         self.rJ = np.zeros(self.A.shape, np.float64)
-        check(lib().rrrmc_discretize(self.cJ.reshape(-1), self.cJ.size, np.asarray(self.LEV, np.int32), len(self.LEV),
-                                     self.dJ.reshape(-1), self.rJ.reshape(-1)))
+        check(lib().rrrmc_discretize_scaled(self.cJ.reshape(-1), self.cJ.size, np.asarray(self.LEV, np.int32), len(self.LEV),
+                                            self.lev_mul, self.lev_div, self.dJ.reshape(-1), self.rJ.reshape(-1)))
 
 
 class GraphRRGNormalDiscretized(_DiscretizedGraph):

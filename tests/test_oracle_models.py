@@ -208,6 +208,57 @@ def test_all_delta_e_and_discretize(oracle):
     assert np.allclose(r, [0.2, 0.3, 0.5, 0.5, 2.0])
 
 
+def test_dfloat_levels(oracle):
+    """DFloat64 (src/DFloats.jl:11-36): t = round(x * 10^5); the oracle works in units t / gcd."""
+    assert oracle.dfloat_units((-1, 0, 1)) == ((-1, 0, 1), 1, 1.0)
+    assert oracle.dfloat_units((-1.5, -0.5, 0.5, 1.5)) == ((-3, -1, 1, 3), 50000, 100000.0)
+    assert oracle.dfloat_units((-0.3, 0.3)) == ((-1, 1), 30000, 100000.0)
+    assert oracle.dfloat_units((0.123456, 1.0)) == ((6173, 50000), 2, 100000.0)          # t = (12346, 100000): rounded to 5 digits, gcd 2
+    lev, mul, div = oracle.dfloat_units((-1.5, -0.5, 0.5, 1.5))
+    x = np.array([0.2, -0.7, 1.0, -1.0, 3.0, 0.0])
+    d, r = oracle.discretize(x, lev, mul, div)
+    assert list(d) == [1, -1, 1, -3, 3, -1]                # ties (x = 1.0, -1.0, 0.0) keep the first level in LEV order
+    assert np.allclose(d * 0.5 + r, x, rtol=0, atol=1e-15)
+    # unit levels in DFloat64 form reproduce the Int-level energies bit for bit
+    A = oracle.gen_rrg(40, 3, 5)
+    cJ = oracle.gen_couplings_gauss(A, 5)
+    di, ri = oracle.discretize(cJ, (-1, 0, 1))
+    lf, mf, df = oracle.dfloat_units((-1.0, 0.0, 1.0))
+    dfl, rfl = oracle.discretize(cJ, lf, mf, df)
+    assert (di == dfl).all() and (ri == rfl).all()
+    ch = oracle.init_config(5, 0, 40)
+    a = oracle.rrr_double_sparse(A, di, ri, (-1, 0, 1), 1.5, 2000, 10, 5, ch)
+    b = oracle.rrr_double_sparse(A, dfl, rfl, lf, 1.5, 2000, 10, 5, ch, mul=mf, div=df)
+    assert (a[0] == b[0]).all() and (a[1] == b[1]).all()
+    a = oracle.standard_mc_dbl(A, di, ri, 1.5, 2000, 10, 5, ch)
+    b = oracle.standard_mc_dbl(A, dfl, rfl, 1.5, 2000, 10, 5, ch, mul=mf, div=df)
+    assert (a[0] == b[0]).all() and (a[1] == b[1]).all() and a[2] == b[2] > 0
+
+
+@pytest.mark.parametrize("form,lev", [("rrg", (-1, 0, 1)), ("rrg", (-1.5, -0.5, 0.5, 1.5)), ("ea", (-0.75, 0.0, 0.75))])
+def test_double_graph_standard_mc_tracked_energy(oracle, form, lev):
+    """The reference's invariant (test/runtests.jl:12-20) for standardMC on the DoubleGraphs, Int and DFloat64 levels."""
+    seed = 321
+    A = oracle.gen_rrg(10, 3, seed) if form == "rrg" else oracle.gen_ea(3, 2)
+    cJ = oracle.gen_couplings_gauss(A, seed)
+    lev, mul, div = oracle.dfloat_units(lev)
+    dJ, rJ = oracle.discretize(cJ, lev, mul, div)
+    assert np.allclose(dJ * (mul / div) + rJ, cJ, rtol=0, atol=1e-15)
+    N = A.shape[0]
+    ch = oracle.init_config(seed, 0, N)
+    n = 3000
+    Es, ch_n, acc = oracle.standard_mc_dbl(A, dJ, rJ, 1.2, n, 1, seed, ch, form=form, mul=mul, div=div)
+    assert 0 < acc < n and abs(Es[0] - oracle.dbl_energy(A, dJ, rJ, ch, form=form, mul=mul, div=div)) == 0
+    # replay: the tracked energy at sample k equals energy(X, C_k) within 1e-11
+    c = ch.copy()
+    for k in (1, 10, 500, n):
+        _, ck, _ = oracle.standard_mc_dbl(A, dJ, rJ, 1.2, k - 1, 1, seed, ch, form=form, mul=mul, div=div)
+        assert abs(Es[k - 1] - oracle.dbl_energy(A, dJ, rJ, ck, form=form, mul=mul, div=div)) < 1e-11
+    # the same chain on the undiscretised couplings (GraphRRGNormal with cJ = dJ + rJ) follows the same trajectory here
+    Es_f, ch_f, acc_f, _ = oracle.standard_mc_spf(A, cJ, 1.2, n, 1, seed, ch, form=form)
+    assert np.allclose(Es_f, Es, rtol=0, atol=1e-9)
+
+
 @pytest.mark.parametrize("kind,form,lev,thr", [
     ("rrg", "rrg", (-1, 0, 1), 0.5), ("rrg", "rrg", (-1, 1), 0.0), ("rrg", "rrg", (-1, 0, 1), 1.0),
     ("ea3", "ea", (-1, 0, 1), 0.5), ("ea2L2", "ea", (-1, 0, 1), 0.5),
