@@ -50,6 +50,7 @@ enum rrrmc_model {
     RRRMC_MODEL_SK_NORMAL = 2,   /* GraphSKNormal (Float64 couplings) src/graphs/SK.jl:181-210; K is ignored */
     RRRMC_MODEL_SPARSE_F64 = 5,  /* GraphRRGNormal{K} src/graphs/RRG.jl:503-520 and GraphEANormal{2D} src/graphs/EA.jl:534-552: sparse, Float64 couplings */
     RRRMC_MODEL_SPARSE_DISCRETIZED = 6, /* GraphRRGNormalDiscretized src/graphs/RRG.jl:285-307, GraphEANormalDiscretized src/graphs/EA.jl:311-352 (Int or DFloat64 LEV) */
+    RRRMC_MODEL_SPARSE_LEVELS = 7,      /* GraphRRG{ET,LEV,K} src/graphs/RRG.jl:116-162, GraphEA{ET,LEV,2D} src/graphs/EA.jl:138-193 with levels other than (-1,1); ET = Int or DFloat64 */
     RRRMC_MODEL_SK_BINARY = 4,   /* GraphSK (couplings +-1/sqrt(N), bit-packed) src/graphs/SK.jl:28-60; K is ignored; energies Float64 */
     RRRMC_MODEL_QUANT_RRG = 3    /* GraphQuant over M Suzuki-Trotter slices of one GraphRRG{Int,(-1,1),K} disorder
                                     (src/graphs/QT.jl:126-170 with the shared-disorder pattern of src/QAliases.jl:43-67);
@@ -235,6 +236,19 @@ RRRMC_API int32_t rrrmc_set_level_scale(rrrmc_ctx *ctx, int64_t mul, double div)
 RRRMC_API int32_t rrrmc_discretize(const double *x, int64_t n, const int32_t *lev, int32_t nlev, int8_t *d_out, double *r_out);
 RRRMC_API int32_t rrrmc_discretize_scaled(const double *x, int64_t n, const int32_t *lev, int32_t nlev, int64_t mul, double div,
                                           int8_t *d_out, double *r_out);
+
+/* ---- stand-alone GraphRRG / GraphEA with general levels (RRRMC_MODEL_SPARSE_LEVELS) ----------
+ * GraphRRG{ET,LEV,K}(A, J) / GraphEA{ET,LEV,2D}(A, J) with any levels (the reference's tests use (-1,0,1), (-1.0,0.0,1.0), ...:
+ * test/runtests.jl:36-60); LEV = (-1, 1) has its own bit-sliced context, RRRMC_MODEL_SPARSE_PM1.  Create with
+ * rrrmc_ctx_create(model = RRRMC_MODEL_SPARSE_LEVELS, N, K, R); N <= 65535, K <= 8, allΔE(X) <= 8 values.
+ *   J[N*K], lev[nlev]   integer level units in -127..127 (rrrmc_set_level_scale gives their value: Int levels (1, 1.0), DFloat64
+ *                       levels (g, 1e5), see above); ea_form as for rrrmc_set_graph_discretized
+ * Samplers: rrrmc_standard_mc_async (SITE stream + ACCEPT_F64 stream: rand53 < exp(-beta dE)), rrrmc_rrr_mc_async (rrrMC(X::SingleGraph),
+ * fourK ignored), rrrmc_bkl_mc_async, rrrmc_wtm_mc_async, rrrmc_extremal_opt_async.  Energies (rrrmc_energy, rrrmc_fetch_results,
+ * rrrmc_extremal_opt_results) are int64 level units — exactly the reference's Int / DFloat64 payload divided by g. */
+RRRMC_API int32_t rrrmc_set_graph_levels(rrrmc_ctx *ctx, const int32_t *A, const int8_t *J, const int32_t *lev, int32_t nlev, int32_t ea_form);
+/* gen_J with rand(vLEV) (RRG.jl:71-96, EA.jl:45-71): COUPLING stream, J_out[N*K] in the units of lev[]. */
+RRRMC_API int32_t rrrmc_gen_couplings_lev(int64_t N, int64_t K, const int32_t *A, uint64_t seed, const int32_t *lev, int32_t nlev, int8_t *J_out);
 
 /* ---- snapshots and observables -------------------------------------------------------
  * The reference's scripts keep a copy of C.s at every hook call (scripts/scripts.jl:56-66, to_mat :13-21) and later

@@ -379,16 +379,27 @@ def rrr_mc_skn(J, beta, iters, step, seed, chunks, it0=0, replica=0, staged_thr=
 
 # ---- rrrMC(SingleGraph) / bklMC on the DiscrGraphs GraphRRG / GraphEA --------------------------------
 def rrr_sparse(A, J, beta, iters, step, seed, chunks, it0=0, replica=0, staged_thr=0.5, staged_thr_fact=5.0, form="rrg", bkl=False,
-               want_cache=False):
-    """One chain of rrrMC (or bklMC with bkl=True).  Returns (Es, chunks_out, accepted, staged_its_or_moves, iters_done[, pos, sizes])."""
+               want_cache=False, lev=None, mul=1, div=1.0):
+    """One chain of rrrMC (or bklMC with bkl=True).  Returns (Es, chunks_out, accepted, staged_its_or_moves, iters_done[, pos, sizes]).
+    lev = None: the +-J graphs; otherwise a stand-alone GraphRRG / GraphEA with levels lev (units, value = units * mul / div)."""
     N, K = A.shape
+    A = np.ascontiguousarray(A, np.int32)
+    J = np.ascontiguousarray(J, np.int32)
     ch = np.array(chunks, np.uint64, copy=True)
     Es = np.zeros(max(iters // step, 1) + 1, np.int64)
     stats = np.zeros(3, np.int64)
-    L = len(all_delta_e_pm1(K))
+    L = len(all_delta_e_pm1(K)) if lev is None else len(all_delta_e(K, lev))
     cache = np.zeros(N + 2 * L, np.int32)
-    n = lib().orc_rrr_bkl_sparse(1 if bkl else 0, FORM[form], N, K, A, J, beta, iters, step, staged_thr, staged_thr_fact, seed, it0, replica,
-                                 ch, Es, stats, cache.ctypes.data if want_cache else None)
+    if lev is None:
+        n = lib().orc_rrr_bkl_sparse(1 if bkl else 0, FORM[form], N, K, A, J, beta, iters, step, staged_thr, staged_thr_fact, seed, it0,
+                                     replica, ch, Es, stats, cache.ctypes.data if want_cache else None)
+    else:
+        F = lib().orc_rrr_bkl_sparse_lev
+        F.restype = C.c_int64
+        F.argtypes = [C.c_int, C.c_int, C.c_int64, C.c_int64, i32p, i32p, i32p, C.c_int64, C.c_int64, C.c_double, C.c_double, C.c_int64,
+                      C.c_int64, C.c_double, C.c_double, C.c_uint64, C.c_uint64, C.c_uint32, u64p, i64p, i64p, C.c_void_p]
+        n = F(1 if bkl else 0, FORM[form], N, K, A, J, np.asarray(lev, np.int32), len(lev), int(mul), float(div), beta, iters, step,
+              staged_thr, staged_thr_fact, seed, it0, replica, ch, Es, stats, cache.ctypes.data if want_cache else None)
     if n < 0:
         raise AssertionError("DeltaECache / ArraySet consistency check failed")
     out = (Es[:n], ch, int(stats[0]), int(stats[1]), int(stats[2]))
@@ -564,20 +575,39 @@ def standard_mc_dbl(A, dJ, rJ, beta, iters, step, seed, chunks, it0=0, replica=0
     return Es[:n], ch, int(acc[0])
 
 
-def wtm_mc_sparse(A, J, beta, samples, step, seed, chunks, call=0, replica=0, form="rrg"):
-    """wtmMC (RRRMC.jl:376-426) on GraphRRG / GraphEA; returns (Es, chunks, num_moves, t, E_final)."""
+def standard_mc_lev(A, J, beta, iters, step, seed, chunks, it0=0, replica=0, form="rrg", mul=1, div=1.0):
+    """standardMC on a stand-alone GraphRRG / GraphEA with general levels (J in units); returns (Es [units], chunks, accepted)."""
     L = lib()
-    L.orc_wtm_mc_sparse.restype = C.c_int64
-    L.orc_wtm_mc_sparse.argtypes = [C.c_int, C.c_int64, C.c_int64, i32p, i32p, C.c_double, C.c_int64, C.c_double, C.c_uint64, C.c_uint32,
-                                    C.c_uint32, u64p, i64p, i64p, C.POINTER(C.c_double)]
+    L.orc_standard_mc_lev.restype = C.c_int64
+    L.orc_standard_mc_lev.argtypes = [C.c_int, C.c_int64, C.c_int64, i32p, i32p, C.c_int64, C.c_double, C.c_double, C.c_int64, C.c_int64,
+                                      C.c_uint64, C.c_uint64, C.c_uint32, u64p, i64p, i64p]
+    A = np.ascontiguousarray(A, np.int32)
+    N, K = A.shape
+    ch = np.array(chunks, np.uint64, copy=True)
+    Es = np.zeros(max(iters // step, 1), np.int64)
+    acc = np.zeros(1, np.int64)
+    n = L.orc_standard_mc_lev(1 if form == "ea" else 0, N, K, A, np.ascontiguousarray(J, np.int32), int(mul), float(div), float(beta),
+                              int(iters), int(step), seed, it0, replica, ch, Es, acc)
+    if n < 0:
+        raise RuntimeError("standard_mc_lev: tracked energy != energy(X, C)")
+    return Es[:n], ch, int(acc[0])
+
+
+def wtm_mc_sparse(A, J, beta, samples, step, seed, chunks, call=0, replica=0, form="rrg", mul=1, div=1.0):
+    """wtmMC (RRRMC.jl:376-426) on GraphRRG / GraphEA (any levels: J in units, value = units * mul / div);
+    returns (Es, chunks, num_moves, t, E_final)."""
+    L = lib()
+    L.orc_wtm_mc_sparse_lev.restype = C.c_int64
+    L.orc_wtm_mc_sparse_lev.argtypes = [C.c_int, C.c_int64, C.c_int64, i32p, i32p, C.c_int64, C.c_double, C.c_double, C.c_int64, C.c_double,
+                                        C.c_uint64, C.c_uint32, C.c_uint32, u64p, i64p, i64p, C.POINTER(C.c_double)]
     A = np.ascontiguousarray(A, np.int32)
     N, K = A.shape
     ch = np.array(chunks, np.uint64, copy=True)
     Es = np.zeros(max(samples, 1), np.int64)
     stats = np.zeros(3, np.int64)
     t = C.c_double(0)
-    n = L.orc_wtm_mc_sparse(1 if form == "ea" else 0, N, K, A, np.ascontiguousarray(J, np.int32), float(beta), int(samples), float(step),
-                            seed, call, replica, ch, Es, stats, C.byref(t))
+    n = L.orc_wtm_mc_sparse_lev(1 if form == "ea" else 0, N, K, A, np.ascontiguousarray(J, np.int32), int(mul), float(div), float(beta),
+                                int(samples), float(step), seed, call, replica, ch, Es, stats, C.byref(t))
     return Es[:n], ch, int(stats[0]), t.value, int(stats[2])
 
 
@@ -586,20 +616,23 @@ def eo_ftau(N, tau):
     return np.cumsum(np.arange(1, int(N) + 1, dtype=np.float64) ** (-float(tau)))
 
 
-def extremal_opt_sparse(A, J, tau, iters, step, seed, chunks, it0=0, replica=0, form="rrg"):
-    """extremal_opt (RRRMC.jl:474-521) on GraphRRG / GraphEA; returns (Es, final chunks, Emin, Cmin chunks, itmin)."""
+def extremal_opt_sparse(A, J, tau, iters, step, seed, chunks, it0=0, replica=0, form="rrg", lev=None):
+    """extremal_opt (RRRMC.jl:474-521) on GraphRRG / GraphEA (lev = None: +-J); returns (Es, final chunks, Emin, Cmin chunks, itmin)."""
     L = lib()
-    L.orc_extremal_opt_sparse.restype = C.c_int64
-    L.orc_extremal_opt_sparse.argtypes = [C.c_int, C.c_int64, C.c_int64, i32p, i32p, f64p, C.c_int64, C.c_int64, C.c_uint64, C.c_uint64,
-                                          C.c_uint32, u64p, i64p, C.POINTER(C.c_int64), u64p, C.POINTER(C.c_int64)]
+    L.orc_extremal_opt_sparse_lev.restype = C.c_int64
+    L.orc_extremal_opt_sparse_lev.argtypes = [C.c_int, C.c_int64, C.c_int64, i32p, i32p, C.c_void_p, C.c_int64, f64p, C.c_int64, C.c_int64,
+                                              C.c_uint64, C.c_uint64, C.c_uint32, u64p, i64p, C.POINTER(C.c_int64), u64p,
+                                              C.POINTER(C.c_int64)]
+    levp = None if lev is None else np.ascontiguousarray(lev, np.int32)
     A = np.ascontiguousarray(A, np.int32)
     N, K = A.shape
     ch = np.array(chunks, np.uint64, copy=True)
     Es = np.zeros(max(iters // step, 1), np.int64)
     Cmin = np.zeros_like(ch)
     Emin, itmin = C.c_int64(0), C.c_int64(0)
-    n = L.orc_extremal_opt_sparse(1 if form == "ea" else 0, N, K, A, np.ascontiguousarray(J, np.int32), eo_ftau(N, tau), int(iters),
-                                  int(step), seed, it0, replica, ch, Es, C.byref(Emin), Cmin, C.byref(itmin))
+    n = L.orc_extremal_opt_sparse_lev(1 if form == "ea" else 0, N, K, A, np.ascontiguousarray(J, np.int32),
+                                      None if levp is None else levp.ctypes.data, 0 if levp is None else len(levp), eo_ftau(N, tau),
+                                      int(iters), int(step), seed, it0, replica, ch, Es, C.byref(Emin), Cmin, C.byref(itmin))
     if n < 0:
         raise RuntimeError("extremal_opt_sparse: inconsistent cache / energy")
     return Es[:n], ch, Emin.value, Cmin, itmin.value

@@ -349,6 +349,9 @@ ORC_API int64_t orc_all_delta_e(int64_t K, const int32_t *lev, int64_t nlev, int
  * All level arithmetic here is done in integer *units*: value = (units * mul) / div, with (mul, div) = (1, 1.0) for Int levels
  * and (g, 10^5) for DFloat64 levels, g = gcd of the levels' t (so that units fit the narrow coupling tables). */
 static inline double lev_to_f64(int64_t units, int64_t mul, double div) { return (double)(units * mul) / div; }
+/* Level specification of a stand-alone GraphRRG{ET,LEV,K} / GraphEA{ET,LEV,2D} (RRG.jl:116-162, EA.jl:138-193) with levels other
+ * than (-1, 1): lev[nlev] in units, (mul, div) as above.  NULL = the +-J graphs (allΔE by RRG.jl:262-266 / EA.jl:293). */
+typedef struct { const int32_t *lev; int64_t nlev; int64_t mul; double div; } levspec_t;
 
 /* discretize(x, LEV): Common.jl:38-49 — the nearest level (the first one on ties) and the residual x - d */
 ORC_API void orc_discretize_scaled(const double *x, int64_t n, const int32_t *lev, int64_t nlev, int64_t mul, double div,
@@ -1590,7 +1593,7 @@ static int decs_consistent(const decs_t *c, const sparse_t *X, const uint64_t *s
 /* mode 0: rrrMC(X::SingleGraph) RRRMC.jl:149-219 (staged_thr = 0.5 for a DiscrGraph); mode 1: bklMC RRRMC.jl:311-359.
  * Streams: RRR sub 0 = rand_move, sub 1 = `rand() < c`, sub 2 = rand_skip; g counts iterations (rrrMC) or moves (bklMC).
  * stats = [accepted, staged_its or true moves, iterations done]. */
-ORC_API int64_t orc_rrr_bkl_sparse(int mode, int form, int64_t N, int64_t K, const int32_t *A, const int32_t *J,
+static int64_t rrr_bkl_sparse_impl(int mode, int form, int64_t N, int64_t K, const int32_t *A, const int32_t *J, const levspec_t *ls,
                                    double beta, int64_t iters, int64_t step, double staged_thr, double staged_thr_fact,
                                    uint64_t seed, uint64_t it0, uint32_t replica,
                                    uint64_t *chunks, int64_t *Es, int64_t *stats, int32_t *cache_out)
@@ -1600,7 +1603,12 @@ ORC_API int64_t orc_rrr_bkl_sparse(int mode, int form, int64_t N, int64_t K, con
     X.lfields_last = (int64_t *)malloc((size_t)N * 8);
     int64_t E = sparse_energy(&X, chunks);
     decs_t c;
-    decs_init(&c, &X, chunks, beta);
+    if (ls) {
+        int64_t dElist[SL_MAX];
+        const int64_t L = orc_all_delta_e(K, ls->lev, ls->nlev, dElist, SL_MAX);
+        if (L < 1) { free(X.lfields); free(X.lfields_last); return -2; }
+        decs_init_scaled(&c, &X, chunks, beta, dElist, (int)L, ls->mul, ls->div);
+    } else decs_init(&c, &X, chunks, beta);
     int64_t accepted = 0, staged_its = 0, nsamp = 0, it = 0;
     if (mode == 0) {
         const double lambda = staged_thr_fact / (double)N;
@@ -1661,6 +1669,54 @@ ORC_API int64_t orc_rrr_bkl_sparse(int mode, int form, int64_t N, int64_t K, con
     }
     int ok = decs_consistent(&c, &X, chunks);
     decs_free(&c);
+    free(X.lfields); free(X.lfields_last);
+    return ok ? nsamp : -1;
+}
+ORC_API int64_t orc_rrr_bkl_sparse(int mode, int form, int64_t N, int64_t K, const int32_t *A, const int32_t *J,
+                                   double beta, int64_t iters, int64_t step, double staged_thr, double staged_thr_fact,
+                                   uint64_t seed, uint64_t it0, uint32_t replica,
+                                   uint64_t *chunks, int64_t *Es, int64_t *stats, int32_t *cache_out)
+{
+    return rrr_bkl_sparse_impl(mode, form, N, K, A, J, NULL, beta, iters, step, staged_thr, staged_thr_fact, seed, it0, replica, chunks, Es,
+                               stats, cache_out);
+}
+ORC_API int64_t orc_rrr_bkl_sparse_lev(int mode, int form, int64_t N, int64_t K, const int32_t *A, const int32_t *J,
+                                       const int32_t *lev, int64_t nlev, int64_t mul, double div,
+                                       double beta, int64_t iters, int64_t step, double staged_thr, double staged_thr_fact,
+                                       uint64_t seed, uint64_t it0, uint32_t replica,
+                                       uint64_t *chunks, int64_t *Es, int64_t *stats, int32_t *cache_out)
+{
+    const levspec_t ls = {lev, nlev, mul, div};
+    return rrr_bkl_sparse_impl(mode, form, N, K, A, J, &ls, beta, iters, step, staged_thr, staged_thr_fact, seed, it0, replica, chunks, Es,
+                               stats, cache_out);
+}
+
+/* standardMC (src/RRRMC.jl:81-127) on a stand-alone GraphRRG / GraphEA with general levels: ET = Int or DFloat64, the energy is tracked
+ * in units (integer arithmetic, as DFloat64's + does: src/DFloats.jl:29-30); `-beta * dE` promotes to Float64 (:42-43).  SITE stream for
+ * the site, ACCEPT_F64 stream for rand() (the bit-plane ACCEPT stream belongs to the +-J kernel's threshold table). */
+ORC_API int64_t orc_standard_mc_lev(int form, int64_t N, int64_t K, const int32_t *A, const int32_t *J, int64_t mul, double div,
+                                    double beta, int64_t iters, int64_t step, uint64_t seed, uint64_t it0, uint32_t replica,
+                                    uint64_t *chunks, int64_t *Es, int64_t *accepted_out)
+{
+    sparse_t X = {N, K, A, J, NULL, NULL, -1, form};
+    X.lfields = (int64_t *)malloc((size_t)N * 8);
+    X.lfields_last = (int64_t *)malloc((size_t)N * 8);
+    int64_t E = sparse_energy(&X, chunks);
+    int64_t accepted = 0, nsamp = 0;
+    for (int64_t it = 1; it <= iters; ++it) {
+        if (it % step == 0) Es[nsamp++] = E;
+        const uint64_t g = it0 + (uint64_t)it;
+        const int64_t i = orc_site(seed, g, N);
+        const int64_t dE = sparse_delta_energy(&X, i);
+        const double x = -beta * lev_to_f64(dE, mul, div);
+        const int acc = (x >= 0) || (orc_rand53(seed, g, replica) < orc_det_exp(x));      /* RRRMC.jl:39 */
+        if (!acc) continue;
+        sparse_spinflip(&X, chunks, i);
+        E += dE;
+        accepted += 1;
+    }
+    if (accepted_out) *accepted_out = accepted;
+    const int ok = E == sparse_energy(&X, chunks);
     free(X.lfields); free(X.lfields_last);
     return ok ? nsamp : -1;
 }
@@ -1833,14 +1889,17 @@ static double wtm_uniform(uint64_t seed, uint64_t n, uint32_t replica, uint32_t 
     unsigned h = (unsigned)(n & 1u);
     return u53_of(w[2 * h], w[2 * h + 1]);
 }
-static inline double wtm_tau(double beta, int64_t dE) { double e = orc_det_exp(beta * (double)dE); return e > 1.0 ? e : 1.0; }   /* tauDE: :16 */
+static int64_t wtm_lev_mul = 1;          /* level units of the running orc_wtm_mc_sparse* call (set at entry, single-threaded oracle) */
+static double wtm_lev_div = 1.0;
+static inline double wtm_tau(double beta, int64_t dE) { double e = orc_det_exp(beta * lev_to_f64(dE, wtm_lev_mul, wtm_lev_div)); return e > 1.0 ? e : 1.0; }   /* tauDE: :16 */
 static inline double wtm_gen(double tau, double u) { return -tau * orc_det_log1p(-u); }                                          /* gen_wt: :18-22 */
 
 /* Es[samples] energies at global times k*step/N; stats = [num_moves, samples taken, final tracked energy]; t_out = final global time */
-ORC_API int64_t orc_wtm_mc_sparse(int form, int64_t N, int64_t K, const int32_t *A, const int32_t *J, double beta, int64_t samples,
-                                  double step, uint64_t seed, uint32_t call, uint32_t replica,
-                                  uint64_t *chunks, int64_t *Es, int64_t *stats, double *t_out)
+ORC_API int64_t orc_wtm_mc_sparse_lev(int form, int64_t N, int64_t K, const int32_t *A, const int32_t *J, int64_t mul, double div, double beta,
+                                      int64_t samples, double step, uint64_t seed, uint32_t call, uint32_t replica,
+                                      uint64_t *chunks, int64_t *Es, int64_t *stats, double *t_out)
 {
+    wtm_lev_mul = mul; wtm_lev_div = div;
     sparse_t X = {N, K, A, J, NULL, NULL, -1, form};
     X.lfields = (int64_t *)malloc((size_t)N * 8);
     X.lfields_last = (int64_t *)malloc((size_t)N * 8);
@@ -1882,6 +1941,12 @@ ORC_API int64_t orc_wtm_mc_sparse(int form, int64_t N, int64_t K, const int32_t 
     free(tm); free(X.lfields); free(X.lfields_last);
     return nsamp;
 }
+ORC_API int64_t orc_wtm_mc_sparse(int form, int64_t N, int64_t K, const int32_t *A, const int32_t *J, double beta, int64_t samples,
+                                  double step, uint64_t seed, uint32_t call, uint32_t replica,
+                                  uint64_t *chunks, int64_t *Es, int64_t *stats, double *t_out)
+{
+    return orc_wtm_mc_sparse_lev(form, N, K, A, J, 1, 1.0, beta, samples, step, seed, call, replica, chunks, Es, stats, t_out);
+}
 
 /* =============================================================================================
  * extremal_opt (tau-EO; src/RRRMC.jl:474-521) on the DiscrGraphs GraphRRG / GraphEA with EOCache{Int,L} (src/DeltaE.jl:412-555).
@@ -1905,9 +1970,9 @@ static inline int eoc_findks(const eoc_t *c, int64_t dE)                        
     return (dE >= 0 ? ak + c->L - c->has_zero : c->L + 1 - ak) - 1;
 }
 
-ORC_API int64_t orc_extremal_opt_sparse(int form, int64_t N, int64_t K, const int32_t *A, const int32_t *J, const double *ftau,
-                                        int64_t iters, int64_t step, uint64_t seed, uint64_t it0, uint32_t replica,
-                                        uint64_t *chunks, int64_t *Es, int64_t *Emin_out, uint64_t *Cmin, int64_t *itmin_out)
+ORC_API int64_t orc_extremal_opt_sparse_lev(int form, int64_t N, int64_t K, const int32_t *A, const int32_t *J, const int32_t *lev, int64_t nlev,
+                                            const double *ftau, int64_t iters, int64_t step, uint64_t seed, uint64_t it0, uint32_t replica,
+                                            uint64_t *chunks, int64_t *Es, int64_t *Emin_out, uint64_t *Cmin, int64_t *itmin_out)
 {
     sparse_t X = {N, K, A, J, NULL, NULL, -1, form};
     X.lfields = (int64_t *)malloc((size_t)N * 8);
@@ -1918,8 +1983,9 @@ ORC_API int64_t orc_extremal_opt_sparse(int form, int64_t N, int64_t K, const in
     eoc_t c;
     memset(&c, 0, sizeof c);
     c.N = N;
-    int64_t tmp[SK_MAX + 1];
-    c.L = (int)orc_all_delta_e_pm1(K, tmp);
+    int64_t tmp[SK_MAX + 1 > SL_MAX ? SK_MAX + 1 : SL_MAX];
+    c.L = lev ? (int)orc_all_delta_e(K, lev, nlev, tmp, SL_MAX) : (int)orc_all_delta_e_pm1(K, tmp);
+    if (c.L < 1) { free(X.lfields); free(X.lfields_last); return -2; }
     for (int k = 0; k < c.L; ++k) c.dElist[k] = tmp[k];
     c.has_zero = c.dElist[0] == 0;
     c.K2 = 2 * c.L - c.has_zero;
@@ -1969,6 +2035,12 @@ ORC_API int64_t orc_extremal_opt_sparse(int form, int64_t N, int64_t K, const in
     for (int k = 0; k < c.K2; ++k) aset_free(&c.as[k]);
     free(c.pos); free(X.lfields); free(X.lfields_last);
     return ok ? nsamp : -1;
+}
+ORC_API int64_t orc_extremal_opt_sparse(int form, int64_t N, int64_t K, const int32_t *A, const int32_t *J, const double *ftau,
+                                        int64_t iters, int64_t step, uint64_t seed, uint64_t it0, uint32_t replica,
+                                        uint64_t *chunks, int64_t *Es, int64_t *Emin_out, uint64_t *Cmin, int64_t *itmin_out)
+{
+    return orc_extremal_opt_sparse_lev(form, N, K, A, J, NULL, 0, ftau, iters, step, seed, it0, replica, chunks, Es, Emin_out, Cmin, itmin_out);
 }
 
 /* =============================================================================================

@@ -20,7 +20,7 @@ SYMBOLS = [
     "rrrmc_set_graph", "rrrmc_seed", "rrrmc_init_spins_random", "rrrmc_set_spins", "rrrmc_get_spins",
     "rrrmc_energy", "rrrmc_get_fields", "rrrmc_standard_mc", "rrrmc_standard_mc_async", "rrrmc_sync",
     "rrrmc_fetch_results", "rrrmc_last_timing", "rrrmc_iterations_done", "rrrmc_gen_rrg", "rrrmc_gen_ea",
-    "rrrmc_gen_couplings_pm1", "rrrmc_set_couplings_dense", "rrrmc_energy_f64", "rrrmc_get_fields_f64",
+    "rrrmc_gen_couplings_pm1", "rrrmc_gen_couplings_lev", "rrrmc_set_graph_levels", "rrrmc_set_couplings_dense", "rrrmc_energy_f64", "rrrmc_get_fields_f64",
     "rrrmc_standard_mc_f64", "rrrmc_fetch_results_f64", "rrrmc_gen_sk_gauss",
     "rrrmc_set_couplings_bits", "rrrmc_gen_sk_binary", "rrrmc_set_coloring", "rrrmc_colored_sweeps_async",
     "rrrmc_ctx_create_quant", "rrrmc_quant_set_field", "rrrmc_rrr_mc_async", "rrrmc_rrr_stats", "rrrmc_rrr_cache", "rrrmc_bkl_mc_async",
@@ -94,6 +94,10 @@ def lib():
     L.rrrmc_gen_ea.argtypes = [C.c_int64, C.c_int64, i32p]
     L.rrrmc_gen_couplings_pm1.restype = C.c_int32
     L.rrrmc_gen_couplings_pm1.argtypes = [C.c_int64, C.c_int64, i32p, C.c_uint64, i8p]
+    L.rrrmc_gen_couplings_lev.restype = C.c_int32
+    L.rrrmc_gen_couplings_lev.argtypes = [C.c_int64, C.c_int64, i32p, C.c_uint64, i32p, C.c_int32, i8p]
+    L.rrrmc_set_graph_levels.restype = C.c_int32
+    L.rrrmc_set_graph_levels.argtypes = [vp, i32p, i8p, i32p, C.c_int32, C.c_int32]
     L.rrrmc_set_couplings_dense.restype = C.c_int32
     L.rrrmc_set_couplings_dense.argtypes = [vp, f64p]
     L.rrrmc_energy_f64.restype = C.c_int32

@@ -118,6 +118,32 @@ int32_t sk_rrr_mc_async(rrrmc_ctx* ctx, double beta, int64_t iters, int64_t step
 }
 
 
+// The thread-per-replica kernels work on replica-contiguous spin words: the +-J contexts convert from / to their bit-sliced store
+// around the kernel, the general-level contexts (RRRMC_MODEL_SPARSE_LEVELS) keep that layout natively (q_spins, qW).
+struct RpView { uint32_t* spins; int64_t W; bool convert; };
+int32_t rp_prepare(rrrmc_ctx* ctx, RpView* v)
+{
+    if (ctx->model == RRRMC_MODEL_SPARSE_LEVELS) { v->spins = ctx->q_spins; v->W = ctx->qW; v->convert = false; return RRRMC_OK; }
+    v->W = (ctx->N + 31) / 32;
+    if (!ctx->rp_spins) HIP_TRY(ctx, hipMalloc(&ctx->rp_spins, sizeof(uint32_t) * ctx->R * v->W));
+    v->spins = ctx->rp_spins; v->convert = true;
+    return RRRMC_OK;
+}
+int32_t rp_in(rrrmc_ctx* ctx, const RpView& v, hipStream_t st)
+{
+    if (!v.convert) return RRRMC_OK;
+    hipLaunchKernelGGL(rrsp_spins_in_kernel, dim3((unsigned)((v.W + 255) / 256), (unsigned)ctx->R), dim3(256), 0, st, ctx->d_spins, ctx->rp_spins, (int)ctx->N, (int)v.W, (int)ctx->R);
+    HIP_TRY(ctx, hipGetLastError());
+    return RRRMC_OK;
+}
+int32_t rp_out(rrrmc_ctx* ctx, const RpView& v, hipStream_t st)
+{
+    if (!v.convert) return RRRMC_OK;
+    hipLaunchKernelGGL(rrsp_spins_out_kernel, dim3((unsigned)((ctx->N + 255) / 256), (unsigned)ctx->G), dim3(256), 0, st, ctx->rp_spins, ctx->d_spins, (int)ctx->N, (int)v.W, (int)ctx->R);
+    HIP_TRY(ctx, hipGetLastError());
+    return RRRMC_OK;
+}
+
 // rrrMC(SingleGraph) / bklMC on GraphRRG / GraphEA: thread-per-replica kernel over replica-contiguous arrays
 int32_t sparse_rrr_bkl_async(rrrmc_ctx* ctx, int mode, double beta, int64_t iters, int64_t step, double staged_thr, double staged_thr_fact)
 {
@@ -127,9 +153,12 @@ int32_t sparse_rrr_bkl_async(rrrmc_ctx* ctx, int mode, double beta, int64_t iter
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     ctx->results_valid = false; ctx->last_call_wtm = false; ctx->last_call_eo = false;
     ctx->timing_valid = false;
-    const int64_t N = ctx->N, K = ctx->K, R = ctx->R, W = (N + 31) / 32;
-    const int L = (int)(K / 2 + 1);                       // allΔE has K/2 + 1 levels for +-J couplings (RRG.jl:262-265)
-    if (!ctx->rp_spins) HIP_TRY(ctx, hipMalloc(&ctx->rp_spins, sizeof(uint32_t) * R * W));
+    const int64_t N = ctx->N, K = ctx->K, R = ctx->R;
+    const int L = ctx->lv.L;
+    RpView rv;
+    int32_t rc = rp_prepare(ctx, &rv);
+    if (rc) return rc;
+    const int64_t W = rv.W;
     if (!ctx->rp_cls) {
         HIP_TRY(ctx, hipMalloc(&ctx->rp_cls, (size_t)R * N));
         HIP_TRY(ctx, hipMalloc(&ctx->rp_sv, sizeof(uint16_t) * R * 2 * L * N));
@@ -151,9 +180,10 @@ int32_t sparse_rrr_bkl_async(rrrmc_ctx* ctx, int mode, double beta, int64_t iter
         ctx->ev_sweep.push_back(e);
     }
     RrrSparseParams P{};
-    P.A = ctx->d_A; P.J = ctx->d_J; P.spins = ctx->rp_spins; P.cls = ctx->rp_cls; P.sv = ctx->rp_sv; P.spos = ctx->rp_spos;
+    P.A = ctx->d_A; P.J = ctx->d_J; P.spins = rv.spins; P.cls = ctx->rp_cls; P.sv = ctx->rp_sv; P.spos = ctx->rp_spos;
     P.E_cur = ctx->d_E; P.acc_cur = ctx->d_acc; P.stats = ctx->q_stats; P.Es = ctx->d_Es;
-    for (int k = 0; k < L && k < kSLmax; ++k) P.ft[k] = host_det_exp(-beta * (double)(2 * (2 * k + (K & 1))));     // exp(-beta dE_k), DeltaE.jl:91
+    P.lv = ctx->lv;
+    for (int k = 0; k < L && k < kSLmax; ++k) P.ft[k] = host_det_exp(-beta * lv_to_f64(ctx, ctx->lv.dElist[k]));     // exp(-beta dE_k), DeltaE.jl:91
     P.beta = beta; P.staged_thr = staged_thr; P.lambda = staged_thr_fact / (double)N;
     P.g0 = ctx->it_done; P.iters = iters; P.step = step;
     P.k0 = (uint32_t)ctx->seed; P.k1 = (uint32_t)(ctx->seed >> 32); P.replica0 = ctx->replica0;
@@ -161,14 +191,12 @@ int32_t sparse_rrr_bkl_async(rrrmc_ctx* ctx, int mode, double beta, int64_t iter
     hipStream_t st = ctx->stream;
     HIP_TRY(ctx, hipEventRecord(ctx->ev_begin, st));
     HIP_TRY(ctx, hipMemsetAsync(ctx->d_acc, 0, sizeof(int64_t) * ctx->Rpad, st));
-    hipLaunchKernelGGL(rrsp_spins_in_kernel, dim3((unsigned)((W + 255) / 256), (unsigned)R), dim3(256), 0, st, ctx->d_spins, ctx->rp_spins, (int)N, (int)W, (int)R);
-    HIP_TRY(ctx, hipGetLastError());
+    if ((rc = rp_in(ctx, rv, st))) return rc;
     HIP_TRY(ctx, hipEventRecord(ctx->ev_sweep[0], st));
     hipLaunchKernelGGL(rrr_sparse_kernel, dim3(rrr_blocks(R)), dim3(rrr_tpb(R)), 0, st, P);
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipEventRecord(ctx->ev_sweep[1], st));
-    hipLaunchKernelGGL(rrsp_spins_out_kernel, dim3((unsigned)((N + 255) / 256), (unsigned)ctx->G), dim3(256), 0, st, ctx->rp_spins, ctx->d_spins, (int)N, (int)W, (int)R);
-    HIP_TRY(ctx, hipGetLastError());
+    if ((rc = rp_out(ctx, rv, st))) return rc;
     HIP_TRY(ctx, hipEventRecord(ctx->ev_end, st));
     ctx->sweep_launches = 1;
     ctx->nsamp = nsamp;
@@ -190,8 +218,11 @@ int32_t sparse_wtm_async(rrrmc_ctx* ctx, double beta, int64_t samples, double st
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     ctx->results_valid = false; ctx->last_call_wtm = false; ctx->last_call_eo = false;
     ctx->timing_valid = false;
-    const int64_t N = ctx->N, K = ctx->K, R = ctx->R, W = (N + 31) / 32;
-    if (!ctx->rp_spins) HIP_TRY(ctx, hipMalloc(&ctx->rp_spins, sizeof(uint32_t) * R * W));
+    const int64_t N = ctx->N, K = ctx->K, R = ctx->R;
+    RpView rv;
+    int32_t rc = rp_prepare(ctx, &rv);
+    if (rc) return rc;
+    const int64_t W = rv.W;
     if (!ctx->wt_t) {
         HIP_TRY(ctx, hipMalloc(&ctx->wt_t, sizeof(double) * R * N));
         HIP_TRY(ctx, hipMalloc(&ctx->wt_id, sizeof(uint16_t) * R * N));
@@ -211,25 +242,26 @@ int32_t sparse_wtm_async(rrrmc_ctx* ctx, double beta, int64_t samples, double st
         ctx->ev_sweep.push_back(e);
     }
     WtmParams P{};
-    P.A = ctx->d_A; P.J = ctx->d_J; P.spins = ctx->rp_spins; P.ht = ctx->wt_t; P.hid = ctx->wt_id; P.hpos = ctx->wt_pos;
+    P.A = ctx->d_A; P.J = ctx->d_J; P.spins = rv.spins; P.ht = ctx->wt_t; P.hid = ctx->wt_id; P.hpos = ctx->wt_pos;
     P.E_cur = ctx->d_E; P.acc_cur = ctx->d_acc; P.t_out = ctx->wt_time; P.Es = ctx->d_Es;
-    for (int64_t q = 0; q <= K; ++q) {            // tauDE = max(1, exp(beta dE)), WaitingTimes.jl:16
-        const double e = host_det_exp(beta * (double)(-2 * K + 4 * q));
-        P.tau[q] = e > 1.0 ? e : 1.0;
-    }
+    P.lv = ctx->lv;
+    for (int a = 0; a < ctx->lv.L; ++a)           // tauDE = max(1, exp(beta dE)), WaitingTimes.jl:16; dE = -+dElist[a]
+        for (int sgn = 0; sgn < 2; ++sgn) {
+            const double e = host_det_exp(beta * lv_to_f64(ctx, sgn ? ctx->lv.dElist[a] : -ctx->lv.dElist[a]));
+            P.tau[a + (sgn ? ctx->lv.L : 0)] = e > 1.0 ? e : 1.0;
+        }
+    (void)K;
     P.step = step / (double)N; P.samples = samples;
     P.k0 = (uint32_t)ctx->seed; P.k1 = (uint32_t)(ctx->seed >> 32); P.replica0 = ctx->replica0; P.call = ctx->wtm_calls & 0xffffffu;
     P.N = (int)N; P.K = (int)K; P.W = (int)W; P.R = (int)R; P.Rpad = (int)ctx->Rpad;
     hipStream_t st = ctx->stream;
     HIP_TRY(ctx, hipEventRecord(ctx->ev_begin, st));
-    hipLaunchKernelGGL(rrsp_spins_in_kernel, dim3((unsigned)((W + 255) / 256), (unsigned)R), dim3(256), 0, st, ctx->d_spins, ctx->rp_spins, (int)N, (int)W, (int)R);
-    HIP_TRY(ctx, hipGetLastError());
+    if ((rc = rp_in(ctx, rv, st))) return rc;
     HIP_TRY(ctx, hipEventRecord(ctx->ev_sweep[0], st));
     hipLaunchKernelGGL(wtm_sparse_kernel, dim3(rrr_blocks(R)), dim3(rrr_tpb(R)), 0, st, P);
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipEventRecord(ctx->ev_sweep[1], st));
-    hipLaunchKernelGGL(rrsp_spins_out_kernel, dim3((unsigned)((N + 255) / 256), (unsigned)ctx->G), dim3(256), 0, st, ctx->rp_spins, ctx->d_spins, (int)N, (int)W, (int)R);
-    HIP_TRY(ctx, hipGetLastError());
+    if ((rc = rp_out(ctx, rv, st))) return rc;
     HIP_TRY(ctx, hipEventRecord(ctx->ev_end, st));
     ctx->wtm_calls += 1;
     ctx->sweep_launches = 1;
@@ -249,15 +281,19 @@ int32_t sparse_eo_async(rrrmc_ctx* ctx, const double* ftau, int64_t iters, int64
     if (step < 1) return fail(ctx, RRRMC_ERR_INVALID_ARG, "step must be >= 1, given %lld", (long long)step);
     if (!ftau) return fail(ctx, RRRMC_ERR_INVALID_ARG, "ftau is NULL");
     if (ctx->N > 65535) return fail(ctx, RRRMC_ERR_UNSUPPORTED, "N=%lld: the extremal_opt kernel indexes spins with 16 bits", (long long)ctx->N);
-    const int64_t N = ctx->N, K = ctx->K, R = ctx->R, W = (N + 31) / 32;
+    const int64_t N = ctx->N, K = ctx->K, R = ctx->R;
     for (int64_t i = 0; i < N; ++i)
         if (!(ftau[i] > 0.0) || !std::isfinite(ftau[i]) || (i && ftau[i] < ftau[i - 1]))
             return fail(ctx, RRRMC_ERR_INVALID_ARG, "ftau must be a positive non-decreasing table (cumsum of j^-tau), violated at %lld", (long long)i);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     ctx->results_valid = false; ctx->last_call_wtm = false; ctx->last_call_eo = false;
     ctx->timing_valid = false;
-    const int L = (int)(K / 2 + 1);
-    if (!ctx->rp_spins) HIP_TRY(ctx, hipMalloc(&ctx->rp_spins, sizeof(uint32_t) * R * W));
+    const int L = ctx->lv.L;
+    RpView rv;
+    int32_t rc = rp_prepare(ctx, &rv);
+    if (rc) return rc;
+    const int64_t W = rv.W;
+    ctx->eo_W = W;
     if (!ctx->rp_cls) {
         HIP_TRY(ctx, hipMalloc(&ctx->rp_cls, (size_t)R * N));
         HIP_TRY(ctx, hipMalloc(&ctx->rp_sv, sizeof(uint16_t) * R * 2 * L * N));
@@ -287,20 +323,19 @@ int32_t sparse_eo_async(rrrmc_ctx* ctx, const double* ftau, int64_t iters, int64
     HIP_TRY(ctx, hipMemcpy(ctx->eo_ftau, ftau, sizeof(double) * N, hipMemcpyHostToDevice));
     HIP_TRY(ctx, hipMemset(ctx->eo_cmin, 0, sizeof(uint32_t) * R * 2 * ((N + 63) / 64)));
     EoParams P{};
-    P.A = ctx->d_A; P.J = ctx->d_J; P.ftau = ctx->eo_ftau; P.spins = ctx->rp_spins; P.cmin = ctx->eo_cmin;
+    P.A = ctx->d_A; P.J = ctx->d_J; P.ftau = ctx->eo_ftau; P.spins = rv.spins; P.cmin = ctx->eo_cmin;
+    P.lv = ctx->lv;
     P.cls = ctx->rp_cls; P.sv = ctx->rp_sv; P.spos = ctx->rp_spos; P.E_cur = ctx->d_E; P.stats = ctx->q_stats; P.Es = ctx->d_Es;
     P.g0 = ctx->it_done; P.iters = iters; P.step = step;
     P.k0 = (uint32_t)ctx->seed; P.k1 = (uint32_t)(ctx->seed >> 32); P.replica0 = ctx->replica0;
-    P.N = (int)N; P.K = (int)K; P.L = L; P.has_zero = (K % 2 == 0) ? 1 : 0; P.W = (int)W; P.R = (int)R; P.Rpad = (int)ctx->Rpad;
+    P.N = (int)N; P.K = (int)K; P.L = L; P.has_zero = ctx->lv.dElist[0] == 0 ? 1 : 0; P.W = (int)W; P.R = (int)R; P.Rpad = (int)ctx->Rpad;
     HIP_TRY(ctx, hipEventRecord(ctx->ev_begin, st));
-    hipLaunchKernelGGL(rrsp_spins_in_kernel, dim3((unsigned)((W + 255) / 256), (unsigned)R), dim3(256), 0, st, ctx->d_spins, ctx->rp_spins, (int)N, (int)W, (int)R);
-    HIP_TRY(ctx, hipGetLastError());
+    if ((rc = rp_in(ctx, rv, st))) return rc;
     HIP_TRY(ctx, hipEventRecord(ctx->ev_sweep[0], st));
     hipLaunchKernelGGL(eo_sparse_kernel, dim3(rrr_blocks(R)), dim3(rrr_tpb(R)), 0, st, P);
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipEventRecord(ctx->ev_sweep[1], st));
-    hipLaunchKernelGGL(rrsp_spins_out_kernel, dim3((unsigned)((N + 255) / 256), (unsigned)ctx->G), dim3(256), 0, st, ctx->rp_spins, ctx->d_spins, (int)N, (int)W, (int)R);
-    HIP_TRY(ctx, hipGetLastError());
+    if ((rc = rp_out(ctx, rv, st))) return rc;
     HIP_TRY(ctx, hipEventRecord(ctx->ev_end, st));
     ctx->sweep_launches = 1;
     ctx->nsamp = nsamp;

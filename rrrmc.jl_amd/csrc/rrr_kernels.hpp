@@ -611,7 +611,20 @@ __global__ __launch_bounds__(256) void rrsk_spins_out_kernel(const uint32_t* __r
 // rrrMC(X::SingleGraph) (src/RRRMC.jl:149-219) and bklMC (src/RRRMC.jl:311-359) on the DiscrGraphs GraphRRG / GraphEA with the
 // integer-level DeltaECache{Int,L} (src/DeltaE.jl:63-295): SURVEY.md §8(f) rank 1.  One thread per replica, as above.
 // ---------------------------------------------------------------------------------------------------
-constexpr int kSLmax = 4;          // levels of allΔE for K <= 7
+constexpr int kSLmax = 8;          // levels of allΔE: K/2 + 1 <= 4 for +-J couplings with K <= 7, up to 8 for general levels
+// Level table shared by the integer-level kernels below.  dElist = allΔE(X) in level units (RRG.jl:262-281, EA.jl:293-309);
+// skip_zero: GraphRRG's neighbors(X, i) keeps the non-zero couplings only (RRG.jl:133) — set for general-level GraphRRG
+// (GraphEA removes repeats instead, EA.jl:158, which every kernel does anyway: a GraphRRG row has none).
+struct LevTable {
+    int L, skip_zero;
+    int dElist[kSLmax];
+    __host__ __device__ __forceinline__ int find(int ad) const      // findk: DeltaE.jl:28-60 (exact comparison of |dE|)
+    {
+        int a = 0;
+        for (int k = 0; k < L; ++k) if (dElist[k] == ad) a = k;
+        return a;
+    }
+};
 struct RrrSparseParams {
     const int32_t* A;        // [N][K]
     const int8_t* J;         // [N][K]
@@ -628,6 +641,7 @@ struct RrrSparseParams {
     uint64_t g0;
     int64_t iters, step;
     uint32_t k0, k1, replica0;
+    LevTable lv;
     int N, K, L, W, R, Rpad, mode;      // mode 0 = rrrMC, 1 = bklMC
 };
 
@@ -649,11 +663,17 @@ struct SparseChain {
         }
         return 2 * acc;
     }
-    __device__ __forceinline__ int klass(int i) const      // a + L*up, DeltaE.jl:80-86; allΔE(+-J) = 2m, m = K&1, K&1 + 2, ...
+    __device__ __forceinline__ int klass(int i) const      // a + L*up, DeltaE.jl:80-86
     {
-        const int d = dE(i), a = ((d < 0 ? -d : d) / 2 - (P->K & 1)) / 2;
+        const int d = dE(i), a = P->lv.find(d < 0 ? -d : d);
         const int up = d > 0 || (d == 0 && sbit(i) == 1);
         return a + P->L * up;
+    }
+    // neighbors(X, move)[q]: repeats removed (uA, EA.jl:158); zero couplings dropped for a general-level GraphRRG (RRG.jl:133)
+    __device__ __forceinline__ bool is_nb(const int32_t* Ax, int move, int q) const
+    {
+        if (q > 0 && Ax[q] == Ax[q - 1]) return false;
+        return !(P->lv.skip_zero && P->J[(size_t)move * P->K + q] == 0);
     }
     __device__ __forceinline__ double f(int k) const { return k >= P->L ? P->ft[k - P->L] : 1.0; }
     __device__ __forceinline__ void set_move(int j, int k0, int k1)
@@ -672,7 +692,7 @@ struct SparseChain {
         double zp = z;
         const int32_t* Ax = P->A + (size_t)move * P->K;
         for (int q = 0; q <= P->K; ++q) {
-            if (q < P->K && q > 0 && Ax[q] == Ax[q - 1]) continue;        // uA: repeats removed (EA.jl:158)
+            if (q < P->K && !is_nb(Ax, move, q)) continue;
             const int j = q < P->K ? Ax[q] : move;
             const int k0 = cls[j];
             const int k1 = q < P->K ? klass(j) : (k0 >= P->L ? k0 - P->L : k0 + P->L);
@@ -728,8 +748,7 @@ __global__ __launch_bounds__(kRrrThreads) void rrr_sparse_kernel(RrrSparseParams
             for (k = 0; k < K2; ++k) { cT += c.T[k]; if (rr < cT) break; }
             if (k == K2) k = K2 - 1;
             if (!(rr < cT)) while (c.T[k] == 0) k -= 1;
-            const int a = k < L ? k : k - L;
-            const int dE = (k < L ? -1 : 1) * 2 * (2 * a + (P.K & 1));
+            const int dE = k < L ? -P.lv.dElist[k] : P.lv.dElist[k - L];
             const int move = c.sv[(size_t)k * N + (int)mulhi64(((uint64_t)o.w[2] << 32) | o.w[3], (uint64_t)c.t[k])];
             bool acc = false;
             if (acc_rate < P.staged_thr) {
@@ -738,7 +757,7 @@ __global__ __launch_bounds__(kRrrThreads) void rrr_sparse_kernel(RrrSparseParams
                 c.sflip(move);
                 const int32_t* Ax = P.A + (size_t)move * P.K;
                 for (int q = 0; q < P.K; ++q) {
-                    if (q > 0 && Ax[q] == Ax[q - 1]) continue;
+                    if (!c.is_nb(Ax, move, q)) continue;
                     const int j = Ax[q], k0 = c.cls[j], k1 = c.klass(j);
                     if (k0 == k1) continue;
                     sj[nst] = j; s0[nst] = k0; s1[nst] = k1; ++nst;
@@ -779,8 +798,7 @@ __global__ __launch_bounds__(kRrrThreads) void rrr_sparse_kernel(RrrSparseParams
             for (k = 0; k < K2; ++k) { cT += c.T[k]; if (rr < cT) break; }
             if (k == K2) k = K2 - 1;
             if (!(rr < cT)) while (c.T[k] == 0) k -= 1;
-            const int a = k < L ? k : k - L;
-            const int dE = (k < L ? -1 : 1) * 2 * (2 * a + (P.K & 1));
+            const int dE = k < L ? -P.lv.dElist[k] : P.lv.dElist[k - L];
             const int move = c.sv[(size_t)k * N + (int)mulhi64(((uint64_t)o.w[2] << 32) | o.w[3], (uint64_t)c.t[k])];
             bool out = false;
             while (it + skip + 1 >= nextstep) {
@@ -820,7 +838,8 @@ struct WtmParams {
     int64_t* acc_cur;        // [Rpad]   num_moves
     double* t_out;           // [R]      final global time
     int32_t* Es;             // [samples][Rpad]
-    double tau[8];           // max(1, exp(beta dE)), dE = -2K + 4 q, K <= 7
+    double tau[2 * kSLmax];  // tauDE = max(1, exp(beta dE)) for dE = -dElist[a] (entry a) and +dElist[a] (entry L + a)
+    LevTable lv;
     double step;             // already divided by N
     int64_t samples;
     uint32_t k0, k1, replica0, call;
@@ -852,7 +871,7 @@ struct WtmChain {
         return (double)(u >> 11) * 0x1.0p-53;
     }
     // gen_wt(tau) = -tau * log1p(-rand()), tau = tauDE(dE): WaitingTimes.jl:16-22
-    __device__ __forceinline__ double gen_wt(int d) { return -P->tau[(d + 2 * P->K) / 4] * det_log1p(-uniform()); }
+    __device__ __forceinline__ double gen_wt(int d) { return -P->tau[P->lv.find(d < 0 ? -d : d) + (d > 0 ? P->lv.L : 0)] * det_log1p(-uniform()); }
     __device__ __forceinline__ bool before(double ta, int a, double tb, int b) const { return ta < tb || (ta == tb && a < b); }
     __device__ void sift_down(int pos, int n)
     {
@@ -931,6 +950,7 @@ __global__ __launch_bounds__(kRrrThreads) void wtm_sparse_kernel(WtmParams P)
         const int32_t* Ax = P.A + (size_t)move * P.K;
         for (int q = 0; q < P.K; ++q) {
             if (q > 0 && Ax[q] == Ax[q - 1]) continue;        // uA: repeats removed (EA.jl:158)
+            if (P.lv.skip_zero && P.J[(size_t)move * P.K + q] == 0) continue;        // uA: non-zero couplings (RRG.jl:133)
             const int j = Ax[q];
             c.update(j, t + c.gen_wt(c.dE(j)));
         }
@@ -964,6 +984,7 @@ struct EoParams {
     uint64_t g0;
     int64_t iters, step;
     uint32_t k0, k1, replica0;
+    LevTable lv;
     int N, K, L, has_zero, W, R, Rpad;
 };
 
@@ -988,9 +1009,9 @@ __global__ __launch_bounds__(kRrrThreads) void eo_sparse_kernel(EoParams P)
         }
         return 2 * acc;
     };
-    // findks (DeltaE.jl:412-421), 0-based; allΔE(+-J) = 2m, m = K&1, K&1 + 2, ...: ak = (|d|/2 - (K&1))/2 + 1
+    // findks (DeltaE.jl:412-421), 0-based
     auto klass = [&](int d) {
-        const int ak = ((d < 0 ? -d : d) / 2 - (K & 1)) / 2 + 1;
+        const int ak = P.lv.find(d < 0 ? -d : d) + 1;
         return (d >= 0 ? ak + L - P.has_zero : L + 1 - ak) - 1;
     };
     long long n = 0;
@@ -1021,13 +1042,14 @@ __global__ __launch_bounds__(kRrrThreads) void eo_sparse_kernel(EoParams P)
         int k = -1, tt = 0;
         while (rank > tt) { k += 1; tt += t[k]; }
         const int a = k < L ? L - 1 - k : k - L + P.has_zero;                        // index into allΔE
-        const int dE = (k < L ? -1 : 1) * 2 * (2 * a + (K & 1));
+        const int dE = k < L ? -P.lv.dElist[a] : P.lv.dElist[a];
         const int move = sv[(size_t)k * N + (int)mulhi64(((uint64_t)o.w[2] << 32) | o.w[3], (uint64_t)t[k])];
         // apply_move!: DeltaE.jl:509-541
         sp[move >> 5] ^= 1u << (move & 31);
         const int32_t* Ax = P.A + (size_t)move * K;
         for (int q = 0; q <= K; ++q) {
             if (q < K && q > 0 && Ax[q] == Ax[q - 1]) continue;                      // uA: repeats removed (EA.jl:158)
+            if (q < K && P.lv.skip_zero && P.J[(size_t)move * K + q] == 0) continue;  // uA: non-zero couplings (RRG.jl:133)
             const int j = q < K ? Ax[q] : move;
             const int k0 = cls[j], k1 = klass(dE_of(j));
             if (k0 == k1) continue;
@@ -1046,6 +1068,61 @@ __global__ __launch_bounds__(kRrrThreads) void eo_sparse_kernel(EoParams P)
     }
     P.E_cur[r] = (int32_t)E;
     P.stats[(size_t)r * 3] = Emin; P.stats[(size_t)r * 3 + 1] = itmin; P.stats[(size_t)r * 3 + 2] = P.iters;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// standardMC (src/RRRMC.jl:81-127) on a stand-alone GraphRRG{ET,LEV,K} / GraphEA{ET,LEV,2D} with levels other than (-1, 1)
+// (ET = Int or DFloat64): no bit-plane threshold table exists for arbitrary levels, so one thread per
+// replica like the samplers above — common site (SITE stream), rand53 < exp(-beta dE) (ACCEPT_F64 stream), the energy tracked in
+// integer level units (what DFloat64's + does, src/DFloats.jl:29-30); `-beta * dE` promotes to Float64 as (units * mul) / div.
+// iters = 0 gives energy(X, C).
+// ---------------------------------------------------------------------------------------------------
+struct LevStdParams {
+    const int32_t* A;        // [N][K]
+    const int8_t* J;         // [N][K] level units
+    uint32_t* spins;         // [R][W]
+    int32_t* E_cur;          // [Rpad]
+    int64_t* acc_cur;        // [Rpad]
+    int32_t* Es;             // [nsamples][Rpad]
+    double beta, lev_div;
+    long long lev_mul;
+    uint64_t g0;
+    int64_t iters, step;
+    uint32_t k0, k1, replica0;
+    int N, K, W, R, Rpad;
+};
+
+__global__ __launch_bounds__(kRrrThreads) void lev_standard_kernel(LevStdParams P)
+{
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= P.R) return;
+    const int N = P.N, K = P.K;
+    uint32_t* sp = P.spins + (size_t)r * P.W;
+    auto sbit = [&](int x) { return (int)((sp[x >> 5] >> (x & 31)) & 1u); };
+    auto dE_of = [&](int i) {
+        const int si = sbit(i);
+        int acc = 0;
+        for (int q = 0; q < K; ++q) {
+            const int sy = sbit(P.A[(size_t)i * K + q]);
+            acc += (si == sy) ? (int)P.J[(size_t)i * K + q] : -(int)P.J[(size_t)i * K + q];
+        }
+        return 2 * acc;
+    };
+    long long n = 0;
+    for (int i = 0; i < N; ++i) n -= dE_of(i) / 2;
+    long long E = n / 2, accepted = 0, ns = 0;
+    const uint32_t rep = P.replica0 + (uint32_t)r;
+    for (long long it = 1; it <= P.iters; ++it) {
+        if (it % P.step == 0) { P.Es[(size_t)ns * P.Rpad + r] = (int32_t)E; ns += 1; }
+        const uint64_t g = P.g0 + (uint64_t)it;
+        const int move = (int)site_of(P.k0, P.k1, g, (uint32_t)N);
+        const int d = dE_of(move);
+        const double x = -P.beta * ((double)((long long)d * P.lev_mul) / P.lev_div);
+        const bool acc = (x >= 0.0) || (rand53(P.k0, P.k1, g, rep) < det_exp(x));        // RRRMC.jl:39
+        if (acc) { sp[move >> 5] ^= 1u << (move & 31); E += d; accepted += 1; }
+    }
+    P.E_cur[r] = (int32_t)E;
+    P.acc_cur[r] = accepted;
 }
 
 // bit-sliced [G][N] words (bit = replica & 31)  <->  replica-contiguous [R][W] words (bit = site & 31)

@@ -163,6 +163,12 @@ struct rrrmc_ctx {
     long long db_lev_mul = 1;          // level units -> Float64: (units * mul) / div (DFloat64 levels: rrrmc_set_level_scale)
     double db_lev_div = 1.0;
     bool db_cache_valid = false;
+    // ---- level table of the integer-level kernels (rrr_sparse / wtm / eo / lev_standard): the +-J table for RRRMC_MODEL_SPARSE_PM1,
+    // allΔE(X) of the given levels for RRRMC_MODEL_SPARSE_LEVELS (whose spins live in q_spins / qW, BitVector word order)
+    LevTable lv{};
+    long long lv_mul = 1;
+    double lv_div = 1.0;
+    int64_t eo_W = 0;                  // words per replica of eo_cmin
     int db_dElist[kDLmax] = {0};
     // ---- continuous-energy rrrMC / bklMC / wtmMC on RRRMC_MODEL_SPARSE_F64 (allocated on first use) ----
     uint32_t* cs_spins = nullptr;  // [R][W] replica-contiguous words
@@ -273,7 +279,9 @@ inline unsigned rrr_tpb(int64_t R)
 inline unsigned rrr_blocks(int64_t R) { const unsigned t = rrr_tpb(R); return (unsigned)((R + t - 1) / t); }
 
 // models whose device spins are R x W 32-bit words in BitVector order (q_spins, qW)
-inline bool chunk_layout(const rrrmc_ctx* ctx) { return ctx->model == RRRMC_MODEL_QUANT_RRG || ctx->model == RRRMC_MODEL_SPARSE_DISCRETIZED; }
+inline bool chunk_layout(const rrrmc_ctx* ctx) { return ctx->model == RRRMC_MODEL_QUANT_RRG || ctx->model == RRRMC_MODEL_SPARSE_DISCRETIZED || ctx->model == RRRMC_MODEL_SPARSE_LEVELS; }
+inline bool sparse_int_model(const rrrmc_ctx* ctx) { return ctx->model == RRRMC_MODEL_SPARSE_PM1 || ctx->model == RRRMC_MODEL_SPARSE_LEVELS; }
+inline double lv_to_f64(const rrrmc_ctx* ctx, long long units) { return (double)(units * ctx->lv_mul) / ctx->lv_div; }
 
 int32_t ensure_state(rrrmc_ctx* ctx, bool need_spins)
 {
@@ -316,6 +324,7 @@ int32_t run_energy(rrrmc_ctx* ctx, uint8_t* d_nun)
 #include "host_spf.hpp"
 #include "host_dbl.hpp"
 #include "host_rrr.hpp"
+#include "host_lev.hpp"
 
 }  // namespace
 
@@ -342,8 +351,9 @@ int32_t rrrmc_ctx_create(rrrmc_ctx** out, int32_t model, int64_t N, int64_t K, i
     *out = nullptr;
     if (model == RRRMC_MODEL_QUANT_RRG) return fail(nullptr, RRRMC_ERR_INVALID_ARG, "RRRMC_MODEL_QUANT_RRG contexts are created with rrrmc_ctx_create_quant");
     if (model != RRRMC_MODEL_SPARSE_PM1 && model != RRRMC_MODEL_SK_NORMAL && model != RRRMC_MODEL_SK_BINARY && model != RRRMC_MODEL_SPARSE_F64 &&
-        model != RRRMC_MODEL_SPARSE_DISCRETIZED)
+        model != RRRMC_MODEL_SPARSE_DISCRETIZED && model != RRRMC_MODEL_SPARSE_LEVELS)
         return fail(nullptr, RRRMC_ERR_UNSUPPORTED, "unknown model kind %d", model);
+    if (model == RRRMC_MODEL_SPARSE_LEVELS) return lev_ctx_create(out, N, K, R, device, replica0);
     if (model == RRRMC_MODEL_SPARSE_F64) return spf_ctx_create(out, N, K, R, device, replica0);
     if (model == RRRMC_MODEL_SPARSE_DISCRETIZED) return dbl_ctx_create(out, N, K, R, device, replica0);
     if (model == RRRMC_MODEL_SK_NORMAL || model == RRRMC_MODEL_SK_BINARY) return sk_ctx_create(out, model, N, R, device, replica0);
@@ -496,6 +506,9 @@ int32_t rrrmc_set_graph(rrrmc_ctx* ctx, const int32_t* A, const int8_t* J)
         ctx->graph_set = true;
         return RRRMC_OK;
     }
+    ctx->lv = LevTable{};
+    ctx->lv.L = (int)(K / 2 + 1);                       // allΔE has K/2 + 1 levels for +-J couplings (RRG.jl:262-265, EA.jl:293)
+    for (int k = 0; k < ctx->lv.L && k < kSLmax; ++k) ctx->lv.dElist[k] = 2 * (2 * k + (int)(K & 1));
     std::vector<uint16_t> table((size_t)(ctx->lds_mode ? N * ctx->TS : 8), 0);
     if (ctx->lds_mode)
         for (int64_t x = 0; x < N; ++x)
@@ -698,10 +711,10 @@ int32_t rrrmc_energy(rrrmc_ctx* ctx, int64_t* E_out)
 {
     int32_t rc = ensure_state(ctx, true);
     if (rc) return rc;
-    if (ctx->model != RRRMC_MODEL_SPARSE_PM1) return fail(ctx, RRRMC_ERR_STATE, "this model's energies are Float64: use the _f64 entry point");
+    if (!sparse_int_model(ctx)) return fail(ctx, RRRMC_ERR_STATE, "this model's energies are Float64: use the _f64 entry point");
     if (!E_out) return fail(ctx, RRRMC_ERR_INVALID_ARG, "E_out is NULL");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    rc = run_energy(ctx, nullptr);
+    rc = ctx->model == RRRMC_MODEL_SPARSE_LEVELS ? lev_standard_mc_async(ctx, 0.0, 0, 1, true) : run_energy(ctx, nullptr);
     if (rc) return rc;
     std::vector<int32_t> E((size_t)ctx->Rpad);
     HIP_TRY(ctx, hipMemcpyAsync(E.data(), ctx->d_E, sizeof(int32_t) * ctx->Rpad, hipMemcpyDeviceToHost, ctx->stream));
@@ -724,6 +737,7 @@ int32_t rrrmc_get_fields(rrrmc_ctx* ctx, int64_t* lfields_out)
             for (int64_t x = 0; x < ctx->N; ++x) lfields_out[r * ctx->N + x] = lf[((r / kSkRB) * ctx->N + x) * kSkRB + (r % kSkRB)];
         return RRRMC_OK;
     }
+    if (ctx->model == RRRMC_MODEL_SPARSE_LEVELS) return fail(ctx, RRRMC_ERR_UNSUPPORTED, "the general-level kernels keep no field cache (fields are recomputed from the spins)");
     if (ctx->model != RRRMC_MODEL_SPARSE_PM1) return fail(ctx, RRRMC_ERR_STATE, "this model's energies are Float64: use the _f64 entry point");
     if (!lfields_out) return fail(ctx, RRRMC_ERR_INVALID_ARG, "lfields_out is NULL");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -749,6 +763,7 @@ int32_t rrrmc_standard_mc_async(rrrmc_ctx* ctx, double beta, int64_t iters, int6
     if (ctx->model == RRRMC_MODEL_SK_NORMAL || ctx->model == RRRMC_MODEL_SK_BINARY) return sk_standard_mc_async(ctx, beta, iters, step);
     if (ctx->model == RRRMC_MODEL_SPARSE_F64) return spf_standard_mc_async(ctx, beta, iters, step);
     if (ctx->model == RRRMC_MODEL_SPARSE_DISCRETIZED) return dbl_mc_async(ctx, true, beta, iters, step, 0.0, 0.0);
+    if (ctx->model == RRRMC_MODEL_SPARSE_LEVELS) return lev_standard_mc_async(ctx, beta, iters, step, false);
     if (ctx->model == RRRMC_MODEL_QUANT_RRG)
         return fail(ctx, RRRMC_ERR_UNSUPPORTED, "standardMC is not wired for this DoubleGraph: use rrrmc_rrr_mc_async");
     if (ctx->model != RRRMC_MODEL_SPARSE_PM1) return fail(ctx, RRRMC_ERR_UNSUPPORTED, "standardMC is not wired for this model on the device: use rrrmc_rrr_mc_async");
@@ -926,7 +941,7 @@ int32_t rrrmc_sync(rrrmc_ctx* ctx)
 int32_t rrrmc_fetch_results(rrrmc_ctx* ctx, int64_t* Es_out, int64_t* accepted_out)
 {
     if (!ctx) return RRRMC_ERR_INVALID_ARG;
-    if (ctx->model != RRRMC_MODEL_SPARSE_PM1) return fail(ctx, RRRMC_ERR_STATE, "this model's energies are Float64: use rrrmc_fetch_results_f64");
+    if (!sparse_int_model(ctx)) return fail(ctx, RRRMC_ERR_STATE, "this model's energies are Float64: use rrrmc_fetch_results_f64");
     if (!ctx->results_valid) return fail(ctx, RRRMC_ERR_STATE, "no sampling call has been made");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -1151,7 +1166,7 @@ int32_t rrrmc_rrr_mc_async(rrrmc_ctx* ctx, double beta, double fourK, int64_t it
     if (rc) return rc;
     if (!std::isfinite(beta)) return fail(ctx, RRRMC_ERR_INVALID_ARG, "beta must be finite, given: %g", beta);       // RRRMC.jl:230, :166
     if (ctx->model == RRRMC_MODEL_SK_NORMAL) return sk_rrr_mc_async(ctx, beta, iters, step, staged_thr, staged_thr_fact);
-    if (ctx->model == RRRMC_MODEL_SPARSE_PM1) return sparse_rrr_bkl_async(ctx, 0, beta, iters, step, staged_thr, staged_thr_fact);
+    if (sparse_int_model(ctx)) return sparse_rrr_bkl_async(ctx, 0, beta, iters, step, staged_thr, staged_thr_fact);
     if (ctx->model == RRRMC_MODEL_SPARSE_DISCRETIZED) return dbl_rrr_mc_async(ctx, beta, iters, step, staged_thr, staged_thr_fact);
     if (ctx->model == RRRMC_MODEL_SPARSE_F64) return spf_cont_async(ctx, 0, beta, iters, step, 1.0, staged_thr, staged_thr_fact);
     if (ctx->model != RRRMC_MODEL_QUANT_RRG) return fail(ctx, RRRMC_ERR_UNSUPPORTED, "rrrMC is not available for model kind %d", ctx->model);
@@ -1206,7 +1221,7 @@ int32_t rrrmc_bkl_mc_async(rrrmc_ctx* ctx, double beta, int64_t iters, int64_t s
     if (!std::isfinite(beta)) return fail(ctx, RRRMC_ERR_INVALID_ARG, "beta must be finite, given: %g", beta);
     if (ctx->model == RRRMC_MODEL_SPARSE_F64) return spf_cont_async(ctx, 1, beta, iters, step, 1.0, 0.0, 5.0);
     if (ctx->model == RRRMC_MODEL_SK_NORMAL) return sk_rrr_mc_async(ctx, beta, iters, step, 0.0, 5.0, 1);
-    if (ctx->model != RRRMC_MODEL_SPARSE_PM1) return fail(ctx, RRRMC_ERR_UNSUPPORTED, "bklMC is wired for RRRMC_MODEL_SPARSE_PM1, RRRMC_MODEL_SPARSE_F64 and RRRMC_MODEL_SK_NORMAL");
+    if (!sparse_int_model(ctx)) return fail(ctx, RRRMC_ERR_UNSUPPORTED, "bklMC is wired for RRRMC_MODEL_SPARSE_PM1, RRRMC_MODEL_SPARSE_LEVELS, RRRMC_MODEL_SPARSE_F64 and RRRMC_MODEL_SK_NORMAL");
     return sparse_rrr_bkl_async(ctx, 1, beta, iters, step, 0.0, 5.0);
 }
 
@@ -1225,7 +1240,7 @@ int32_t rrrmc_wtm_mc_async(rrrmc_ctx* ctx, double beta, int64_t samples, double 
     int32_t rc = ensure_state(ctx, true);
     if (rc) return rc;
     if (ctx->model == RRRMC_MODEL_SPARSE_F64) return spf_cont_async(ctx, 2, beta, samples, 1, step, 0.0, 5.0);
-    if (ctx->model != RRRMC_MODEL_SPARSE_PM1) return fail(ctx, RRRMC_ERR_UNSUPPORTED, "wtmMC is wired for RRRMC_MODEL_SPARSE_PM1 and RRRMC_MODEL_SPARSE_F64");
+    if (!sparse_int_model(ctx)) return fail(ctx, RRRMC_ERR_UNSUPPORTED, "wtmMC is wired for RRRMC_MODEL_SPARSE_PM1, RRRMC_MODEL_SPARSE_LEVELS and RRRMC_MODEL_SPARSE_F64");
     return sparse_wtm_async(ctx, beta, samples, step);
 }
 
@@ -1244,7 +1259,7 @@ int32_t rrrmc_extremal_opt_async(rrrmc_ctx* ctx, const double* ftau, int64_t ite
 {
     int32_t rc = ensure_state(ctx, true);
     if (rc) return rc;
-    if (ctx->model != RRRMC_MODEL_SPARSE_PM1) return fail(ctx, RRRMC_ERR_UNSUPPORTED, "extremal_opt is wired for RRRMC_MODEL_SPARSE_PM1");
+    if (!sparse_int_model(ctx)) return fail(ctx, RRRMC_ERR_UNSUPPORTED, "extremal_opt is wired for RRRMC_MODEL_SPARSE_PM1 and RRRMC_MODEL_SPARSE_LEVELS");
     return sparse_eo_async(ctx, ftau, iters, step);
 }
 
@@ -1261,7 +1276,7 @@ int32_t rrrmc_extremal_opt_results(rrrmc_ctx* ctx, int64_t* Emin_out, uint64_t* 
         if (itmin_out) itmin_out[r] = st[(size_t)(3 * r + 1)];
     }
     if (Cmin_chunks) {
-        const int64_t nch = (ctx->N + 63) / 64, W = (ctx->N + 31) / 32;
+        const int64_t nch = (ctx->N + 63) / 64, W = ctx->eo_W;
         std::vector<uint32_t> w((size_t)ctx->R * (size_t)W);
         HIP_TRY(ctx, hipMemcpy(w.data(), ctx->eo_cmin, sizeof(uint32_t) * w.size(), hipMemcpyDeviceToHost));
         std::memset(Cmin_chunks, 0, sizeof(uint64_t) * ctx->R * nch);
@@ -1334,7 +1349,7 @@ int32_t rrrmc_energy_f64(rrrmc_ctx* ctx, double* E_out)
 {
     int32_t rc = ensure_state(ctx, true);
     if (rc) return rc;
-    if (ctx->model == RRRMC_MODEL_SPARSE_PM1) return fail(ctx, RRRMC_ERR_STATE, "this model's energies are integers: use rrrmc_energy");
+    if (sparse_int_model(ctx)) return fail(ctx, RRRMC_ERR_STATE, "this model's energies are integers: use rrrmc_energy");
     if (!E_out) return fail(ctx, RRRMC_ERR_INVALID_ARG, "E_out is NULL");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     if (ctx->model == RRRMC_MODEL_QUANT_RRG) {
@@ -1384,7 +1399,7 @@ int32_t rrrmc_get_fields_f64(rrrmc_ctx* ctx, double* lfields_out)
 int32_t rrrmc_fetch_results_f64(rrrmc_ctx* ctx, double* Es_out, int64_t* accepted_out)
 {
     if (!ctx) return RRRMC_ERR_INVALID_ARG;
-    if (ctx->model == RRRMC_MODEL_SPARSE_PM1) return fail(ctx, RRRMC_ERR_STATE, "this model's energies are integers: use rrrmc_fetch_results");
+    if (sparse_int_model(ctx)) return fail(ctx, RRRMC_ERR_STATE, "this model's energies are integers: use rrrmc_fetch_results");
     if (!ctx->results_valid) return fail(ctx, RRRMC_ERR_STATE, "no sampling call has been made");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -1581,12 +1596,12 @@ int32_t rrrmc_quant_observables(rrrmc_ctx* ctx, double beta, double Gamma, doubl
     return RRRMC_OK;
 }
 
-int32_t rrrmc_set_graph_discretized(rrrmc_ctx* ctx, const int32_t* A, const int8_t* dJ, const double* rJ, const int32_t* lev, int32_t nlev,
-                                    int32_t ea_form)
+namespace {
+// Shared checks of the level-unit sparse graphs (GraphRRG / GraphEA ctor: RRG.jl:122-139, EA.jl:145-169): table ranges, sorted rows,
+// couplings among the levels, bond symmetry (rJ, when given, too); computes allΔE(X) (RRG.jl:268-281, EA.jl:295-309) into dElist.
+int32_t validate_level_graph(rrrmc_ctx* ctx, const int32_t* A, const int8_t* dJ, const double* rJ, const int32_t* lev, int32_t nlev,
+                             int32_t ea_form, int* dElist, int* L_out, int cap)
 {
-    if (!ctx) return RRRMC_ERR_INVALID_ARG;
-    if (ctx->model != RRRMC_MODEL_SPARSE_DISCRETIZED) return fail(ctx, RRRMC_ERR_STATE, "rrrmc_set_graph_discretized is for RRRMC_MODEL_SPARSE_DISCRETIZED");
-    if (!A || !dJ || !rJ || !lev) return fail(ctx, RRRMC_ERR_INVALID_ARG, "A, dJ, rJ, lev must not be NULL");
     if (nlev < 1 || nlev > 16) return fail(ctx, RRRMC_ERR_INVALID_ARG, "between 1 and 16 levels are supported, given %d", nlev);
     for (int32_t a = 0; a < nlev; ++a) {
         if (lev[a] < -127 || lev[a] > 127) return fail(ctx, RRRMC_ERR_UNSUPPORTED, "level %d does not fit the int8 coupling table", lev[a]);
@@ -1598,10 +1613,10 @@ int32_t rrrmc_set_graph_discretized(rrrmc_ctx* ctx, const int32_t* A, const int8
         if (A[q] < 0 || A[q] >= N) return fail(ctx, RRRMC_ERR_INVALID_ARG, "A[%lld] = %d out of range 0..%lld", (long long)q, A[q], (long long)(N - 1));
         if (A[q] == q / K) return fail(ctx, RRRMC_ERR_INVALID_ARG, "self loop at site %lld", (long long)(q / K));
         if (q % K && A[q] < A[q - 1]) return fail(ctx, RRRMC_ERR_INVALID_ARG, "row %lld of A is not sorted", (long long)(q / K));
-        if (!std::isfinite(rJ[q])) return fail(ctx, RRRMC_ERR_INVALID_ARG, "rJ[%lld] is not finite", (long long)q);
+        if (rJ && !std::isfinite(rJ[q])) return fail(ctx, RRRMC_ERR_INVALID_ARG, "rJ[%lld] is not finite", (long long)q);
         bool ok = false;
         for (int32_t a = 0; a < nlev; ++a) ok |= (int32_t)dJ[q] == lev[a];
-        if (!ok) return fail(ctx, RRRMC_ERR_INVALID_ARG, "the given J is incompatible with the levels (dJ[%lld] = %d)", (long long)q, (int)dJ[q]);   // RRG.jl:130
+        if (!ok) return fail(ctx, RRRMC_ERR_INVALID_ARG, "the given J is incompatible with the levels (J[%lld] = %d)", (long long)q, (int)dJ[q]);   // RRG.jl:130
         if (!ea_form && q % K && A[q] == A[q - 1]) return fail(ctx, RRRMC_ERR_INVALID_ARG, "repeated neighbour in row %lld: pass ea_form = 1 for GraphEA tables", (long long)(q / K));
     }
     std::vector<uint8_t> used((size_t)(N * K), 0);
@@ -1610,8 +1625,8 @@ int32_t rrrmc_set_graph_discretized(rrrmc_ctx* ctx, const int32_t* A, const int8
             const int64_t y = A[x * K + k];
             bool found = false;
             for (int64_t l = 0; l < K && !found; ++l)
-                if (!used[y * K + l] && A[y * K + l] == x && dJ[y * K + l] == dJ[x * K + k] && rJ[y * K + l] == rJ[x * K + k]) { used[y * K + l] = 1; found = true; }
-            if (!found) return fail(ctx, RRRMC_ERR_INVALID_ARG, "bond (%lld,%lld) is not symmetric in (A, dJ, rJ)", (long long)x, (long long)y);
+                if (!used[y * K + l] && A[y * K + l] == x && dJ[y * K + l] == dJ[x * K + k] && (!rJ || rJ[y * K + l] == rJ[x * K + k])) { used[y * K + l] = 1; found = true; }
+            if (!found) return fail(ctx, RRRMC_ERR_INVALID_ARG, "bond (%lld,%lld) is not symmetric in (A, J)", (long long)x, (long long)y);
         }
     // allΔE(X0): sums of K terms +-l (RRG.jl:268-281, EA.jl:295-309)
     int64_t amax = 0;
@@ -1632,9 +1647,24 @@ int32_t rrrmc_set_graph_discretized(rrrmc_ctx* ctx, const int32_t* A, const int8
     int L = 0;
     for (int64_t a = 0; a <= span; ++a)
         if (cur[(size_t)(span + a)] || cur[(size_t)(span - a)]) {
-            if (L == kDLmax) return fail(ctx, RRRMC_ERR_UNSUPPORTED, "more than %d energy levels: not covered by the DoubleGraph kernel", kDLmax);
-            ctx->db_dElist[L++] = (int)(2 * a);
+            if (L == cap) return fail(ctx, RRRMC_ERR_UNSUPPORTED, "more than %d energy levels: not covered by the integer-level kernels", cap);
+            dElist[L++] = (int)(2 * a);
         }
+    *L_out = L;
+    return RRRMC_OK;
+}
+}  // namespace
+
+int32_t rrrmc_set_graph_discretized(rrrmc_ctx* ctx, const int32_t* A, const int8_t* dJ, const double* rJ, const int32_t* lev, int32_t nlev,
+                                    int32_t ea_form)
+{
+    if (!ctx) return RRRMC_ERR_INVALID_ARG;
+    if (ctx->model != RRRMC_MODEL_SPARSE_DISCRETIZED) return fail(ctx, RRRMC_ERR_STATE, "rrrmc_set_graph_discretized is for RRRMC_MODEL_SPARSE_DISCRETIZED");
+    if (!A || !dJ || !rJ || !lev) return fail(ctx, RRRMC_ERR_INVALID_ARG, "A, dJ, rJ, lev must not be NULL");
+    int L = 0;
+    int32_t rc = validate_level_graph(ctx, A, dJ, rJ, lev, nlev, ea_form, ctx->db_dElist, &L, kDLmax);
+    if (rc) return rc;
+    const int64_t N = ctx->N, K = ctx->K;
     ctx->db_L = L;
     ctx->db_ea_form = ea_form ? 1 : 0;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -1646,16 +1676,38 @@ int32_t rrrmc_set_graph_discretized(rrrmc_ctx* ctx, const int32_t* A, const int8
     return RRRMC_OK;
 }
 
+int32_t rrrmc_set_graph_levels(rrrmc_ctx* ctx, const int32_t* A, const int8_t* J, const int32_t* lev, int32_t nlev, int32_t ea_form)
+{
+    if (!ctx) return RRRMC_ERR_INVALID_ARG;
+    if (ctx->model != RRRMC_MODEL_SPARSE_LEVELS) return fail(ctx, RRRMC_ERR_STATE, "rrrmc_set_graph_levels is for RRRMC_MODEL_SPARSE_LEVELS");
+    if (!A || !J || !lev) return fail(ctx, RRRMC_ERR_INVALID_ARG, "A, J, lev must not be NULL");
+    LevTable lv{};
+    int32_t rc = validate_level_graph(ctx, A, J, nullptr, lev, nlev, ea_form, lv.dElist, &lv.L, kSLmax);
+    if (rc) return rc;
+    lv.skip_zero = ea_form ? 0 : 1;          // neighbors(X, i): non-zero couplings for GraphRRG (RRG.jl:133), de-duplicated A[i] for GraphEA (EA.jl:158)
+    const int64_t N = ctx->N, K = ctx->K;
+    ctx->lv = lv;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipMemcpy(ctx->d_A, A, sizeof(int32_t) * N * K, hipMemcpyHostToDevice));
+    HIP_TRY(ctx, hipMemcpy(ctx->d_J, J, sizeof(int8_t) * N * K, hipMemcpyHostToDevice));
+    // rrrMC / extremal_opt class arrays depend on L: drop those of a previous graph
+    free_dev(ctx->rp_cls); free_dev(ctx->rp_sv); free_dev(ctx->rp_spos);
+    ctx->graph_set = true;
+    return RRRMC_OK;
+}
+
 int32_t rrrmc_set_level_scale(rrrmc_ctx* ctx, int64_t mul, double div)
 {
     if (!ctx) return RRRMC_ERR_INVALID_ARG;
-    if (ctx->model != RRRMC_MODEL_SPARSE_DISCRETIZED) return fail(ctx, RRRMC_ERR_STATE, "rrrmc_set_level_scale is for RRRMC_MODEL_SPARSE_DISCRETIZED");
+    if (ctx->model != RRRMC_MODEL_SPARSE_DISCRETIZED && ctx->model != RRRMC_MODEL_SPARSE_LEVELS)
+        return fail(ctx, RRRMC_ERR_STATE, "rrrmc_set_level_scale is for RRRMC_MODEL_SPARSE_DISCRETIZED and RRRMC_MODEL_SPARSE_LEVELS");
     if (mul < 1 || !(div > 0.0) || !std::isfinite(div)) return fail(ctx, RRRMC_ERR_INVALID_ARG, "level scale must have mul >= 1 and a finite div > 0");
     // the largest level sum the kernels form is N * K * 127 units (the energy): keep units * mul inside the Float64-exact integers
     if ((double)mul * 127.0 * (double)ctx->N * (double)ctx->K >= 9007199254740992.0)
         return fail(ctx, RRRMC_ERR_UNSUPPORTED, "level scale mul=%lld too large for N=%lld, K=%lld", (long long)mul, (long long)ctx->N, (long long)ctx->K);
-    ctx->db_lev_mul = mul;
-    ctx->db_lev_div = div;
+    ctx->db_lev_mul = mul; ctx->db_lev_div = div;
+    ctx->lv_mul = mul; ctx->lv_div = div;
     return RRRMC_OK;
 }
 
@@ -1878,6 +1930,35 @@ int32_t rrrmc_gen_couplings_pm1(int64_t N, int64_t K, const int32_t* A, uint64_t
         }
     for (int64_t q = 0; q < N * K; ++q)
         if (J_out[q] == 0) return fail(nullptr, RRRMC_ERR_INVALID_ARG, "neighbour table is not symmetric");
+    return RRRMC_OK;
+}
+
+int32_t rrrmc_gen_couplings_lev(int64_t N, int64_t K, const int32_t* A, uint64_t seed, const int32_t* lev, int32_t nlev, int8_t* J_out)
+{
+    // gen_J, src/graphs/RRG.jl:71-96 / src/graphs/EA.jl:45-71 with rand(vLEV) (RRG.jl:154-156): COUPLING stream, one draw per bond
+    if (!A || !J_out || !lev || nlev < 1) return fail(nullptr, RRRMC_ERR_INVALID_ARG, "A / J_out / lev is NULL or nlev < 1");
+    for (int32_t a = 0; a < nlev; ++a)
+        if (lev[a] < -127 || lev[a] > 127) return fail(nullptr, RRRMC_ERR_UNSUPPORTED, "level %d does not fit the int8 coupling table", lev[a]);
+    const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+    std::vector<uint8_t> set((size_t)(N * K), 0);
+    std::memset(J_out, 0, (size_t)(N * K));
+    uint64_t ndraw = 0;
+    for (int64_t x = 0; x < N; ++x)
+        for (int64_t k = 0; k < K; ++k) {
+            const int64_t y = A[x * K + k];
+            if (y < 0 || y >= N) return fail(nullptr, RRRMC_ERR_INVALID_ARG, "A[%lld] out of range", (long long)(x * K + k));
+            if (x < y) {
+                const int8_t Jxy = (int8_t)lev[mulhi64(stream_u64(k0, k1, TAG_COUPLING, ndraw++), (uint64_t)nlev)];
+                if (set[(size_t)(x * K + k)]) return fail(nullptr, RRRMC_ERR_INVALID_ARG, "inconsistent neighbour table at site %lld", (long long)x);
+                J_out[x * K + k] = Jxy; set[(size_t)(x * K + k)] = 1;
+                int64_t l = 0;
+                while (l < K && set[(size_t)(y * K + l)]) ++l;
+                if (l == K) return fail(nullptr, RRRMC_ERR_INVALID_ARG, "inconsistent neighbour table at site %lld", (long long)y);
+                J_out[y * K + l] = Jxy; set[(size_t)(y * K + l)] = 1;
+            }
+        }
+    for (int64_t q = 0; q < N * K; ++q)
+        if (!set[(size_t)q]) return fail(nullptr, RRRMC_ERR_INVALID_ARG, "neighbour table is not symmetric");
     return RRRMC_OK;
 }
 

@@ -12,6 +12,7 @@ MODEL_QUANT_RRG = 3
 MODEL_SK_BINARY = 4
 MODEL_SPARSE_F64 = 5
 MODEL_SPARSE_DISCRETIZED = 6
+MODEL_SPARSE_LEVELS = 7
 
 
 class Engine:
@@ -20,7 +21,8 @@ class Engine:
     def __init__(self, X, R=1, device=0, replica0=0):
         self.X, self.R = X, int(R)
         self._ctx = C.c_void_p()
-        self._f64 = X.model_kind != MODEL_SPARSE_PM1
+        self._f64 = X.model_kind not in (MODEL_SPARSE_PM1, MODEL_SPARSE_LEVELS)
+        self._units = X.model_kind == MODEL_SPARSE_LEVELS        # device energies are int64 level units: X.energy_value converts
         if X.model_kind == MODEL_QUANT_RRG:
             check(lib().rrrmc_ctx_create_quant(C.byref(self._ctx), X.Nk, X.K, X.M, self.R, device, replica0))
         else:
@@ -32,6 +34,9 @@ class Engine:
             elif X.model_kind == MODEL_SPARSE_DISCRETIZED:
                 check(lib().rrrmc_set_graph_discretized(self._ctx, X.A, X.dJ, X.rJ.reshape(-1), np.asarray(X.LEV, np.int32), len(X.LEV),
                                                         X.ea_form), self._ctx)
+                check(lib().rrrmc_set_level_scale(self._ctx, X.lev_mul, X.lev_div), self._ctx)
+            elif X.model_kind == MODEL_SPARSE_LEVELS:
+                check(lib().rrrmc_set_graph_levels(self._ctx, X.A, X.J, np.asarray(X.LEV, np.int32), len(X.LEV), X.ea_form), self._ctx)
                 check(lib().rrrmc_set_level_scale(self._ctx, X.lev_mul, X.lev_div), self._ctx)
             elif X.model_kind == MODEL_SPARSE_F64:
                 check(lib().rrrmc_set_graph_f64(self._ctx, X.A, X.J.reshape(-1)), self._ctx)
@@ -87,9 +92,9 @@ class Engine:
         return out
 
     def energy(self):
-        E = np.zeros(self.R, self.X.energy_dtype)
+        E = np.zeros(self.R, np.float64 if self._f64 else np.int64)
         check((lib().rrrmc_energy_f64 if self._f64 else lib().rrrmc_energy)(self._ctx, E), self._ctx)
-        return E
+        return self.X.energy_value(E) if self._units else E.astype(self.X.energy_dtype, copy=False)
 
     def fields(self):
         f64 = self.X.model_kind in (MODEL_SK_NORMAL, MODEL_SPARSE_F64)        # GraphSK's cache is integer (SK.jl:33)
@@ -101,12 +106,12 @@ class Engine:
     def standard_mc(self, beta, iters, step=1, want_energies=True):
         """Returns (Es[R, iters // step], accepted[R])."""
         nsamp = int(iters) // int(step)
-        Es = np.zeros((self.R, nsamp), self.X.energy_dtype)
+        Es = np.zeros((self.R, nsamp), np.float64 if self._f64 else np.int64)
         acc = np.zeros(self.R, np.int64)
         fn = lib().rrrmc_standard_mc_f64 if self._f64 else lib().rrrmc_standard_mc
         check(fn(self._ctx, float(beta), int(iters), int(step), Es.ctypes.data if (want_energies and nsamp) else None,
                  acc.ctypes.data), self._ctx)
-        return Es, acc
+        return (self.X.energy_value(Es) if self._units else Es), acc
 
     def standard_mc_async(self, beta, iters, step=1):
         check(lib().rrrmc_standard_mc_async(self._ctx, float(beta), int(iters), int(step)), self._ctx)
@@ -118,11 +123,11 @@ class Engine:
     def fetch_results(self, want_energies=True):
         iters, step = self._last
         nsamp = iters // step
-        Es = np.zeros((self.R, nsamp), self.X.energy_dtype)
+        Es = np.zeros((self.R, nsamp), np.float64 if self._f64 else np.int64)
         acc = np.zeros(self.R, np.int64)
         fn = lib().rrrmc_fetch_results_f64 if self._f64 else lib().rrrmc_fetch_results
         check(fn(self._ctx, Es.ctypes.data if (want_energies and nsamp) else None, acc.ctypes.data), self._ctx)
-        return Es, acc
+        return (self.X.energy_value(Es) if self._units else Es), acc
 
     # -- colour-parallel sweeps (build-defined checkerboard sampler for large sparse graphs) ---------
     def set_coloring(self, color):
@@ -183,7 +188,7 @@ class Engine:
         itmin = np.zeros(self.R, np.int64)
         Cmin = Config(N, self.R)
         check(lib().rrrmc_extremal_opt_results(self._ctx, Emin, Cmin.s.reshape(-1), itmin), self._ctx)
-        return Es, Emin, Cmin, itmin
+        return Es, (self.X.energy_value(Emin) if self._units else Emin), Cmin, itmin
 
     def rrr_cache(self):
         """(pos[R, N], sizes[R, 4]) of the DeltaECache after the last rrrMC call."""

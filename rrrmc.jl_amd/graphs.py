@@ -55,6 +55,65 @@ class Config:
         return Config(N, R, s)
 
 
+def level_units(LEV):
+    """LEV as given to the reference's constructors -> (units, mul, div): value = units * mul / div.
+    Int levels: (LEV, 1, 1.0).  Float64 levels become DFloat64 (RRG.jl:162,324; EA.jl:193,357): the Int64 t = round(x * 10^5)
+    (src/DFloats.jl:23, ties to even); units = t / g with g = gcd of the |t|, (mul, div) = (g, 1e5).  Rational levels
+    (fractions.Fraction; runtests.jl:40) over the common denominator d: units = numerators / g, (mul, div) = (g, d)."""
+    from fractions import Fraction
+    LEV = tuple(LEV)
+    if all(isinstance(l, (int, np.integer)) for l in LEV):
+        return tuple(int(l) for l in LEV), 1, 1.0
+    if all(isinstance(l, (int, np.integer, Fraction)) for l in LEV):
+        d = 1
+        for l in LEV:
+            d = d * Fraction(l).denominator // math.gcd(d, Fraction(l).denominator)
+        t = [int(Fraction(l) * d) for l in LEV]
+        div = float(d)
+    else:
+        t = [int(np.rint(float(l) * 100000.0)) for l in LEV]
+        div = 100000.0
+    g = 0
+    for x in t:
+        g = math.gcd(g, abs(x))
+    g = max(g, 1)
+    return tuple(x // g for x in t), g, div
+
+
+class _SparseLevelsGraph:
+    """GraphRRG{ET,LEV,K} / GraphEA{ET,LEV,2D} with levels other than (-1, 1) (RRG.jl:116-162, EA.jl:138-193): couplings in level
+    units, energies come back from the device in units and are returned as ``units * lev_mul / lev_div`` (exact integers for Int
+    levels, the Float64 value of the reference's DFloat64 / Rational otherwise)."""
+    model_kind = 7          # RRRMC_MODEL_SPARSE_LEVELS
+
+    def _init_levels(self, A, J, LEV, ea_form):
+        self.levels = tuple(LEV)
+        self.LEV, self.lev_mul, self.lev_div = level_units(LEV)
+        if len(set(self.LEV)) != len(self.LEV):
+            raise ValueError("repeated levels in LEV: %r" % (LEV,))                   # RRG.jl:100
+        if max(abs(u) for u in self.LEV) > 127:
+            raise NotImplementedError("levels %r need more than 8 bits per coupling after reduction by their gcd" % (LEV,))
+        A = np.ascontiguousarray(A, np.int32)
+        self.N, self.K = A.shape
+        self.A = A
+        if J is None:
+            J = np.zeros(A.shape, np.int8)
+            check(lib().rrrmc_gen_couplings_lev(self.N, self.K, A, self._seed, np.asarray(self.LEV, np.int32), len(self.LEV), J))
+        J = np.ascontiguousarray(J, np.int8)
+        if J.shape != A.shape:
+            raise ValueError("incompatible shapes of A and J: %r, %r" % (A.shape, J.shape))
+        if not np.isin(J, self.LEV).all():
+            raise ValueError("the given J is incompatible with levels %r" % (LEV,))  # RRG.jl:130
+        self.J = J
+        self.ea_form = ea_form
+        self.energy_dtype = np.int64 if self.lev_div == 1.0 else np.float64
+
+    def energy_value(self, units):
+        """Level units -> the energy in the caller's terms (Int, or Float64(::DFloat64) = t / 10^5)."""
+        u = np.asarray(units, np.int64) * self.lev_mul
+        return u if self.lev_div == 1.0 else u / self.lev_div
+
+
 class _SparsePM1Graph:
     """Common part of GraphRRG / GraphEA with LEV = (-1, 1): neighbour table A[N, K], couplings J[N, K]."""
     model_kind = 1          # RRRMC_MODEL_SPARSE_PM1
@@ -79,9 +138,12 @@ class GraphRRG(_SparsePM1Graph):
     global RNG, RRG.jl:45,155).
     """
 
+    def __new__(cls, N=None, K=None, LEV=(-1, 1), seed=DEFAULT_SEED):
+        if cls is GraphRRG and not _is_pm1(LEV):
+            return object.__new__(GraphRRGLevels)        # GraphRRG{ET,LEV,K} with general levels: its own device context
+        return object.__new__(cls)
+
     def __init__(self, N, K, LEV=(-1, 1), seed=DEFAULT_SEED):
-        if tuple(LEV) != (-1, 1):
-            raise NotImplementedError("only LEV = (-1, 1) is covered by the HIP path")
         A = np.zeros((int(N), int(K)), np.int32)
         check(lib().rrrmc_gen_rrg(N, K, seed, A))
         J = np.zeros((int(N), int(K)), np.int8)
@@ -89,18 +151,41 @@ class GraphRRG(_SparsePM1Graph):
         super().__init__(A, J)
 
     @classmethod
-    def from_AJ(cls, A, J):
-        self = cls.__new__(cls)
+    def from_AJ(cls, A, J, LEV=(-1, 1)):
+        """``GraphRRG{ET,LEV,K}(A, J)`` (RRG.jl:122); J in level units when LEV is not (-1, 1)."""
+        if not _is_pm1(LEV):
+            self = object.__new__(GraphRRGLevels)
+            self._init_levels(A, J, LEV, 0)
+            return self
+        self = object.__new__(cls)
         _SparsePM1Graph.__init__(self, A, J)
         return self
+
+
+def _is_pm1(LEV):
+    LEV = tuple(LEV)
+    return LEV == (-1, 1) and all(isinstance(l, (int, np.integer)) for l in LEV)
+
+
+class GraphRRGLevels(_SparseLevelsGraph, GraphRRG):
+    """``GraphRRG(N, K, LEV)`` with LEV other than (-1, 1): Int, Float64 (-> DFloat64) or Fraction levels (test/runtests.jl:37-40)."""
+
+    def __init__(self, N, K, LEV, seed=DEFAULT_SEED):
+        A = np.zeros((int(N), int(K)), np.int32)
+        check(lib().rrrmc_gen_rrg(N, K, seed, A))
+        self._seed = seed
+        self._init_levels(A, None, LEV, 0)
 
 
 class GraphEA(_SparsePM1Graph):
     """``GraphEA(L, D)`` — Edwards-Anderson lattice, +-1 couplings (src/graphs/EA.jl:171-193)."""
 
+    def __new__(cls, L=None, D=None, LEV=(-1, 1), seed=DEFAULT_SEED):
+        if cls is GraphEA and not _is_pm1(LEV):
+            return object.__new__(GraphEALevels)
+        return object.__new__(cls)
+
     def __init__(self, L, D, LEV=(-1, 1), seed=DEFAULT_SEED):
-        if tuple(LEV) != (-1, 1):
-            raise NotImplementedError("only LEV = (-1, 1) is covered by the HIP path")
         N = int(L) ** int(D)
         A = np.zeros((N, 2 * int(D)), np.int32)
         check(lib().rrrmc_gen_ea(L, D, A))
@@ -110,10 +195,26 @@ class GraphEA(_SparsePM1Graph):
         self.L, self.D = int(L), int(D)
 
     @classmethod
-    def from_AJ(cls, A, J):
-        self = cls.__new__(cls)
+    def from_AJ(cls, A, J, LEV=(-1, 1)):
+        if not _is_pm1(LEV):
+            self = object.__new__(GraphEALevels)
+            self._init_levels(A, J, LEV, 1)
+            return self
+        self = object.__new__(cls)
         _SparsePM1Graph.__init__(self, A, J)
         return self
+
+
+class GraphEALevels(_SparseLevelsGraph, GraphEA):
+    """``GraphEA(L, D, LEV)`` with LEV other than (-1, 1) (test/runtests.jl:47-50, 57-60)."""
+
+    def __init__(self, L, D, LEV, seed=DEFAULT_SEED):
+        N = int(L) ** int(D)
+        A = np.zeros((N, 2 * int(D)), np.int32)
+        check(lib().rrrmc_gen_ea(L, D, A))
+        self._seed = seed
+        self._init_levels(A, None, LEV, 1)
+        self.L, self.D = int(L), int(D)
 
 
 class _SparseF64Graph:
@@ -216,20 +317,10 @@ class _DiscretizedGraph:
 
     def _split(self, A, cJ, LEV):
         LEV = tuple(LEV)
-        if all(isinstance(l, (int, np.integer)) for l in LEV):
-            # Int levels: GraphRRGNormalDiscretized{Int,LEV,K}
-            self.LEV, self.lev_mul, self.lev_div = tuple(int(l) for l in LEV), 1, 1.0
-        else:
-            # Float64 levels -> DFloat64 (RRG.jl:324, EA.jl:357): the Int64 t = round(x * 10^5) (src/DFloats.jl:23, ties to even);
-            # the library works in units t / g (g = gcd) and converts with (units * g) / 1e5 where the reference promotes to Float64
-            t = [int(np.rint(float(l) * 100000.0)) for l in LEV]
-            g = 0
-            for x in t:
-                g = math.gcd(g, abs(x))
-            g = max(g, 1)
-            self.LEV, self.lev_mul, self.lev_div = tuple(x // g for x in t), g, 100000.0
-            if max(abs(u) for u in self.LEV) > 127:
-                raise NotImplementedError("levels %r need more than 8 bits per coupling after reduction by their gcd" % (LEV,))
+        # Int levels: GraphRRGNormalDiscretized{Int,LEV,K}; Float64 levels -> DFloat64 (RRG.jl:324, EA.jl:357): see level_units
+        self.LEV, self.lev_mul, self.lev_div = level_units(LEV)
+        if max(abs(u) for u in self.LEV) > 127:
+            raise NotImplementedError("levels %r need more than 8 bits per coupling after reduction by their gcd" % (LEV,))
         self.levels = LEV                                                             # as given by the caller
         if len(set(self.LEV)) != len(self.LEV):
             raise ValueError("repeated levels in LEV: %r" % (LEV,))                   # RRG.jl:100
@@ -353,10 +444,17 @@ def getN(X):
 
 def neighbors(X, i):
     """src/Interface.jl:158; RRG.jl:261 (uA = neighbours with non-zero coupling), EA.jl:292 (de-duplicated)."""
+    if getattr(X, "model_kind", 0) == 7 and not X.ea_form:
+        return X.A[i][X.J[i] != 0]
     return np.unique(X.A[i])
 
 
 def all_delta_e(X):
-    """allΔE (src/Interface.jl:200-201): RRG.jl:262-281, EA.jl:293 — sorted values of |dE|."""
+    """allΔE (src/Interface.jl:200-201): RRG.jl:262-281, EA.jl:293-309 — sorted values of |dE|."""
     K = X.K
+    if getattr(X, "model_kind", 0) == 7:
+        es = {0}
+        for _ in range(K):
+            es = {e + s * l for e in es for l in X.LEV for s in (-1, 1)}
+        return tuple(X.energy_value(sorted({2 * abs(e) for e in es})).tolist())
     return tuple(2 * m for m in range(K & 1, K + 1, 2))

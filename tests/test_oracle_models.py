@@ -340,3 +340,41 @@ def test_extremal_opt_invariants(oracle, kind, form):
     if N <= 16:
         best = min(brute_energy(A, J, np.array([(c >> i) & 1 for i in range(N)])) for c in range(2 ** N))
         assert Emin >= best
+
+
+# ---- stand-alone GraphRRG / GraphEA with general levels (test/runtests.jl:36-60 x :140-163) ----------------------------------
+@pytest.mark.parametrize("kind,lev,mul,div", [
+    ("rrg", (-1, 0, 1), 1, 1.0),                    # GraphRRG(10, 3, (-1,0,1))          runtests.jl:37
+    ("rrg", (-1, 0, 1), 100000, 100000.0),          # GraphRRG(10, 3, (-1.0,0.0,1.0))    :38 (DFloat64, t = +-10^5)
+    ("rrg", (-3, -1, 1, 3), 50000, 100000.0),       # levels (-1.5,-0.5,0.5,1.5)
+    ("ea2", (-1, 0, 1), 1, 1.0),                    # GraphEA(2, 3, (-1,0,1))            :47 (double bonds)
+    ("ea3", (-1, 0, 1), 1, 3.0),                    # GraphEA(3, 2, (-1//3,0//1,1//3))   rational levels over the denominator 3
+])
+def test_general_level_graphs_all_samplers(oracle, kind, lev, mul, div):
+    """Every sampler keeps E_tracked == energy(X, C) (runtests.jl:12-20; checked inside the oracle for standardMC / extremal_opt, by the
+    DeltaECache consistency check for rrrMC / bklMC), zero couplings drop out of neighbors(X, i) for GraphRRG (RRG.jl:133), and the
+    level scale only enters through exp(-beta dE)."""
+    seed = 2024
+    A = {"rrg": lambda: oracle.gen_rrg(10, 3, seed), "ea2": lambda: oracle.gen_ea(2, 3), "ea3": lambda: oracle.gen_ea(3, 2)}[kind]()
+    form = "rrg" if kind == "rrg" else "ea"
+    J = oracle.gen_couplings(A, seed, lev)
+    assert set(np.unique(J)) <= set(lev) and ((J == 0).any() or 0 not in lev)
+    N = A.shape[0]
+    ch = oracle.init_config(seed, 0, N)
+    sc = dict(mul=mul, div=div)
+    E0 = oracle.sparse_energy(A, J, ch)
+    Es, c1, acc = oracle.standard_mc_lev(A, J, 0.9, 4000, 1, seed, ch, form=form, **sc)
+    assert Es[0] == E0 and 0 < acc < 4000 and len(Es) == 4000
+    for thr in (0.5, 0.0, 1.0):
+        r = oracle.rrr_sparse(A, J, 0.9, 3000, 1, seed, ch, staged_thr=thr, form=form, lev=lev, **sc)
+        assert r[0][0] == E0 and r[2] > 0
+    b = oracle.rrr_sparse(A, J, 0.9, 3000, 10, seed, ch, form=form, bkl=True, lev=lev, **sc)
+    assert b[2] > 0
+    w = oracle.wtm_mc_sparse(A, J, 0.9, 50, 1.0, seed, ch, form=form, **sc)
+    assert len(w[0]) == 50 and w[4] == oracle.sparse_energy(A, J, w[1])
+    e = oracle.extremal_opt_sparse(A, J, 1.2, 2000, 10, seed, ch, form=form, lev=lev)
+    assert e[2] == oracle.sparse_energy(A, J, e[3]) and e[2] <= min(e[0].min(), E0)
+    # the scale matters only through beta * dE: (lev, mul, div) and (lev, 1, 1.0) at beta * mul / div give the same chain
+    Es2, c2, acc2 = oracle.standard_mc_lev(A, J, 0.9, 4000, 1, seed, ch, form=form, mul=1, div=1.0)
+    if mul / div == 1.0:
+        assert (Es2 == Es).all() and (c2 == c1).all()
