@@ -43,6 +43,41 @@ def test_two_spin_model(pkg, oracle):
     assert (Es == ref[0]).all() and (C1.s == ref[1]).all() and (acc == ref[2]).all()
 
 
+def test_three_spin_model(pkg, oracle):
+    """GraphThreeSpin (src/graphs/ThreeSpin.jl:26-47) as the N = 3, K = 2 triangle: closed-form energies, every sampler against the oracle."""
+    A = np.array([[1, 2], [0, 2], [0, 1]], np.int32)
+    J = np.ones((3, 2), np.int8)
+    X = pkg.GraphRRG.from_AJ(A, J)
+    J32 = J.astype(np.int32)
+    with pkg.Engine(X, 40) as eng:
+        eng.seed(5)
+        eng.init_spins_random()
+        C0 = eng.get_config()
+        E0 = eng.energy()
+        Es, acc = eng.standard_mc(2.0, 2000, 10)
+        C1 = eng.get_config()
+        eng.seed(5); eng.set_config(C0)
+        Er, ar, st = eng.rrr_mc(2.0, 2000, 10)
+        Cr = eng.get_config()
+        eng.seed(5); eng.set_config(C0)
+        Ew, mw, tw = eng.wtm_mc(2.0, 50, 1.0)
+        Cw = eng.get_config()
+        eng.seed(5); eng.set_config(C0)
+        Ee, Emin, Cmin, itmin = eng.extremal_opt(1.3, 500, 5)
+    b = 2 * C0.bits().astype(np.int64) - 1
+    assert (E0 == -(b[:, 0] * b[:, 1] + b[:, 1] * b[:, 2] + b[:, 2] * b[:, 0])).all()
+    assert set(np.unique(Es)) <= {-3, 1} and (Emin == -3).all()
+    ref = oracle.standard_mc_sparse_batch(A, J32, 2.0, 2000, 10, 5, C0.s)
+    assert (Es == ref[0]).all() and (C1.s == ref[1]).all() and (acc == ref[2]).all()
+    for r in range(40):
+        rr = oracle.rrr_sparse(A, J32, 2.0, 2000, 10, 5, C0.s[r], replica=r)
+        assert (Er[r] == rr[0]).all() and (Cr.s[r] == rr[1]).all() and ar[r] == rr[2] and st[r] == rr[3]
+        w = oracle.wtm_mc_sparse(A, J32, 2.0, 50, 1.0, 5, C0.s[r], replica=r)
+        assert (Ew[r] == w[0]).all() and (Cw.s[r] == w[1]).all() and mw[r] == w[2] and tw[r] == w[3]
+        e = oracle.extremal_opt_sparse(A, J32, 1.3, 500, 5, 5, C0.s[r], replica=r)
+        assert (Ee[r] == e[0]).all() and (Cmin.s[r] == e[3]).all() and itmin[r] == e[4]
+
+
 def test_several_plan_batches_in_one_call(pkg, oracle):
     """More iterations than one planner batch (2^22 slots), with a step that straddles the batch boundary."""
     seed, N, R = 77, 64, 32

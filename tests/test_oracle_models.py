@@ -118,6 +118,28 @@ def test_two_spin_closed_form(oracle):
         assert E == -s0 * s1 and list(-lf) == [2 * s0 * s1] * 2
 
 
+def test_three_spin_closed_form(oracle):
+    """GraphThreeSpin (graphs/ThreeSpin.jl:26-47): E = -(s1 s2 + s2 s3 + s3 s1), dE(i) = 2 s_i (sum of the other two), allΔE = (0, 4) —
+    the K = 2 triangle as a sparse model; also under rrrMC / bklMC / wtmMC / extremal_opt (runtests.jl:27 x :140-163)."""
+    A = np.array([[1, 2], [0, 2], [0, 1]], np.int32)
+    J = np.ones((3, 2), np.int32)
+    assert oracle.all_delta_e_pm1(2) == (0, 4)
+    for bits in itertools.product((0, 1), repeat=3):
+        ch = np.array([bits[0] | (bits[1] << 1) | (bits[2] << 2)], np.uint64)
+        s = [2 * b - 1 for b in bits]
+        E, lf = oracle.sparse_energy(A, J, ch, want_fields=True)
+        assert E == -(s[0] * s[1] + s[1] * s[2] + s[2] * s[0])
+        assert list(-lf) == [2 * s[0] * (s[1] + s[2]), 2 * s[1] * (s[0] + s[2]), 2 * s[2] * (s[0] + s[1])]
+    ch = np.array([0b010], np.uint64)
+    for bkl in (False, True):
+        r = oracle.rrr_sparse(A, J, 2.0, 2000, 10, 11, ch, bkl=bkl)          # beta of runtests.jl:132
+        assert set(np.unique(r[0])) <= {-3, 1}
+    w = oracle.wtm_mc_sparse(A, J, 2.0, 100, 1.0, 11, ch)
+    assert set(np.unique(w[0])) <= {-3, 1} and w[4] == oracle.sparse_energy(A, J, w[1])
+    e = oracle.extremal_opt_sparse(A, J, 1.3, 500, 5, 11, ch)
+    assert e[2] == -3 and oracle.sparse_energy(A, J, e[3]) == -3
+
+
 def test_boltzmann_law_small_system(oracle):
     """truep (src/RRRMC.jl:528-543): the chain's stationary law is exp(-beta E)/Z.  N = 8 ring-with-chords graph,
     long single chain of the oracle, total-variation distance to the exact law."""
