@@ -160,7 +160,9 @@ RRRMC_API int32_t rrrmc_gen_sk_gauss(int64_t N, uint64_t seed, double *J_out);
 RRRMC_API int32_t rrrmc_ctx_create_quant(rrrmc_ctx **out, int64_t Nk, int64_t K, int64_t M, int64_t R,
                                          int32_t device, uint32_t replica0);
 /* The Trotter coupling fourK (a type parameter of GraphQuant in the reference, QT.jl:126) and the beta it was derived
- * from: needed by rrrmc_energy_f64 before the first rrrMC call. */
+ * from: needed by rrrmc_energy_f64 before the first rrrMC call, and by rrrmc_standard_mc_async — standardMC on the GraphQuant
+ * (src/RRRMC.jl:81-127 with delta_energy = delta_energy(X0) + delta_energy_residual, QT.jl:283-286; SITE + ACCEPT_F64 streams),
+ * which takes fourK from here. */
 RRRMC_API int32_t rrrmc_quant_set_field(rrrmc_ctx *ctx, double beta, double fourK);
 /* rrrMC(X::DoubleGraph, beta, iters; step, staged_thr, staged_thr_fact) (src/RRRMC.jl:221-290) for all R replicas.
  *   fourK = round(2/beta * log(coth(beta * Gamma / M)), digits = 8)  (QT.jl:165) is computed by the caller.

@@ -267,6 +267,22 @@ def quant_energy(A, J, M, fourK, chunks):
     return float(E), float(qt.value)
 
 
+def standard_mc_quant(A, J, M, fourK, beta, iters, step, seed, chunks, it0=0, replica=0):
+    """standardMC on GraphQuant(GraphRRG slices).  Returns (Es, chunks_out, accepted)."""
+    L = lib()
+    L.orc_standard_mc_quant.restype = C.c_int64
+    L.orc_standard_mc_quant.argtypes = [C.c_int64, C.c_int64, C.c_int64, i32p, i32p, C.c_double, C.c_double, C.c_int64, C.c_int64,
+                                        C.c_uint64, C.c_uint64, C.c_uint32, u64p, f64p, i64p]
+    A = np.ascontiguousarray(A, np.int32)
+    Nk, K = A.shape
+    ch = np.array(chunks, np.uint64, copy=True)
+    Es = np.zeros(max(iters // step, 1), np.float64)
+    acc = np.zeros(1, np.int64)
+    n = L.orc_standard_mc_quant(Nk, M, K, A, np.ascontiguousarray(J, np.int32), float(fourK), float(beta), int(iters), int(step), seed, it0,
+                                replica, ch, Es, acc)
+    return Es[:n], ch, int(acc[0])
+
+
 def rrr_mc_quant(A, J, M, fourK, beta, iters, step, seed, chunks, it0=0, replica=0, staged_thr=0.5, staged_thr_fact=5.0,
                  want_cache=False):
     """One chain of rrrMC on GraphQuant.  Returns (Es, chunks_out, accepted, staged_its[, pos, set_sizes])."""

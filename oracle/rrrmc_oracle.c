@@ -990,6 +990,34 @@ ORC_API int64_t orc_rrr_mc_quant(int64_t Nk, int64_t M, int64_t K, const int32_t
     return bad ? -1 : nsamp;
 }
 
+/* standardMC (src/RRRMC.jl:81-127) on GraphQuant: delta_energy = delta_energy(X0) + delta_energy_residual (QT.jl:283-286).
+ * SITE stream for the spin, ACCEPT_F64 stream for rand(). */
+ORC_API int64_t orc_standard_mc_quant(int64_t Nk, int64_t M, int64_t K, const int32_t *A, const int32_t *J, double fourK,
+                                      double beta, int64_t iters, int64_t step, uint64_t seed, uint64_t it0, uint32_t replica,
+                                      uint64_t *chunks, double *Es, int64_t *accepted_out)
+{
+    quant_t Q;
+    quant_init(&Q, Nk, M, K, A, J, fourK);
+    const int64_t N = Nk * M;
+    double E = quant_energy(&Q, chunks);
+    int64_t accepted = 0, nsamp = 0;
+    for (int64_t it = 1; it <= iters; ++it) {
+        if (it % step == 0) Es[nsamp++] = E;
+        const uint64_t g = it0 + (uint64_t)it;
+        const int64_t i = orc_site(seed, g, N);
+        const double dE = qt_delta_energy(&Q.X0, chunks, i) + quant_residual(&Q, i);
+        const double x = -beta * dE;
+        const int acc = (x >= 0) || (orc_rand53(seed, g, replica) < orc_det_exp(x));      /* RRRMC.jl:39 */
+        if (!acc) continue;
+        quant_spinflip(&Q, chunks, i);
+        E += dE;
+        accepted += 1;
+    }
+    if (accepted_out) *accepted_out = accepted;
+    quant_free(&Q);
+    return nsamp;
+}
+
 /* energy(X::GraphQuant, C) and its parts, for the tests */
 ORC_API double orc_quant_energy(int64_t Nk, int64_t M, int64_t K, const int32_t *A, const int32_t *J, double fourK,
                                 const uint64_t *chunks, double *qt_part)

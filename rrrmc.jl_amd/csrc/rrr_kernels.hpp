@@ -289,6 +289,29 @@ __global__ __launch_bounds__(kRrrThreads) void rrr_quant_kernel(RrrParams P)
     P.stats[(size_t)r * 2] = accepted; P.stats[(size_t)r * 2 + 1] = staged_its;
 }
 
+// standardMC (src/RRRMC.jl:81-127) on GraphQuant: delta_energy(X, C, move) = delta_energy(X0) + delta_energy_residual (QT.jl:283-286);
+// common site (SITE stream), rand53 < exp(-beta dE) (ACCEPT_F64 stream).  Runs after rrr_init_kernel (which leaves energy(X, C) in E_cur).
+__global__ __launch_bounds__(kRrrThreads) void quant_standard_kernel(RrrParams P)
+{
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= P.R) return;
+    const RrrView v = rrr_view(P, r);
+    const uint32_t rep = P.replica0 + (uint32_t)r;
+    double E = P.E_cur[r];
+    int64_t accepted = 0, ns = 0;
+    for (int64_t it = 1; it <= P.iters; ++it) {
+        if (it % P.step == 0) { P.Es[ns * P.R + r] = E; ns += 1; }
+        const uint64_t g = P.g0 + (uint64_t)it;
+        const int move = (int)site_of(P.k0, P.k1, g, (uint32_t)P.N);
+        const double dE = (double)qt_delta(v, move) * P.fourK + (double)slice_delta(v, move) / (double)P.M;
+        const double x = -P.beta * dE;
+        const bool acc = (x >= 0.0) || (rand53(P.k0, P.k1, g, rep) < det_exp(x));        // RRRMC.jl:39
+        if (acc) { sflip(v.sp, move); E += dE; accepted += 1; }
+    }
+    P.E_cur[r] = E;
+    P.stats[(size_t)r * 2] = accepted; P.stats[(size_t)r * 2 + 1] = 0;
+}
+
 // INIT stream for the replica-contiguous layout: word w of replica r holds sites 32w .. 32w+31
 __global__ __launch_bounds__(256) void quant_init_spins_kernel(uint32_t* __restrict__ spins, int N, int W, uint32_t replica0, uint32_t k0, uint32_t k1)
 {

@@ -163,6 +163,7 @@ struct rrrmc_ctx {
     long long db_lev_mul = 1;          // level units -> Float64: (units * mul) / div (DFloat64 levels: rrrmc_set_level_scale)
     double db_lev_div = 1.0;
     bool db_cache_valid = false;
+    bool q_cache_valid = false;         // GraphQuant: the DeltaECache arrays describe the last rrrMC call
     // ---- level table of the integer-level kernels (rrr_sparse / wtm / eo / lev_standard): the +-J table for RRRMC_MODEL_SPARSE_PM1,
     // allΔE(X) of the given levels for RRRMC_MODEL_SPARSE_LEVELS (whose spins live in q_spins / qW, BitVector word order)
     LevTable lv{};
@@ -325,6 +326,7 @@ int32_t run_energy(rrrmc_ctx* ctx, uint8_t* d_nun)
 #include "host_dbl.hpp"
 #include "host_rrr.hpp"
 #include "host_lev.hpp"
+int32_t quant_mc_async(rrrmc_ctx* ctx, bool standard, double beta, double fourK, int64_t iters, int64_t step, double staged_thr, double staged_thr_fact);
 
 }  // namespace
 
@@ -764,8 +766,10 @@ int32_t rrrmc_standard_mc_async(rrrmc_ctx* ctx, double beta, int64_t iters, int6
     if (ctx->model == RRRMC_MODEL_SPARSE_F64) return spf_standard_mc_async(ctx, beta, iters, step);
     if (ctx->model == RRRMC_MODEL_SPARSE_DISCRETIZED) return dbl_mc_async(ctx, true, beta, iters, step, 0.0, 0.0);
     if (ctx->model == RRRMC_MODEL_SPARSE_LEVELS) return lev_standard_mc_async(ctx, beta, iters, step, false);
-    if (ctx->model == RRRMC_MODEL_QUANT_RRG)
-        return fail(ctx, RRRMC_ERR_UNSUPPORTED, "standardMC is not wired for this DoubleGraph: use rrrmc_rrr_mc_async");
+    if (ctx->model == RRRMC_MODEL_QUANT_RRG) {
+        if (!(ctx->last_fourK > 0.0)) return fail(ctx, RRRMC_ERR_STATE, "standardMC on a GraphQuant needs fourK: call rrrmc_quant_set_field first");
+        return quant_mc_async(ctx, true, beta, ctx->last_fourK, iters, step, 0.0, 0.0);
+    }
     if (ctx->model != RRRMC_MODEL_SPARSE_PM1) return fail(ctx, RRRMC_ERR_UNSUPPORTED, "standardMC is not wired for this model on the device: use rrrmc_rrr_mc_async");
     if (!ctx->lds_mode) return fail(ctx, RRRMC_ERR_UNSUPPORTED, "N=%lld does not fit the LDS-resident random-site kernel: use rrrmc_colored_sweeps_async", (long long)ctx->N);
     ctx->colored_call = false;
@@ -1160,16 +1164,11 @@ int32_t rrrmc_ctx_create_quant(rrrmc_ctx** out, int64_t Nk, int64_t K, int64_t M
     return RRRMC_OK;
 }
 
-int32_t rrrmc_rrr_mc_async(rrrmc_ctx* ctx, double beta, double fourK, int64_t iters, int64_t step, double staged_thr, double staged_thr_fact)
+namespace {
+// rrrMC(X::DoubleGraph) (standard = false) or standardMC (standard = true) on GraphQuant: thread-per-replica kernels
+int32_t quant_mc_async(rrrmc_ctx* ctx, bool standard, double beta, double fourK, int64_t iters, int64_t step, double staged_thr, double staged_thr_fact)
 {
-    int32_t rc = ensure_state(ctx, true);
-    if (rc) return rc;
-    if (!std::isfinite(beta)) return fail(ctx, RRRMC_ERR_INVALID_ARG, "beta must be finite, given: %g", beta);       // RRRMC.jl:230, :166
-    if (ctx->model == RRRMC_MODEL_SK_NORMAL) return sk_rrr_mc_async(ctx, beta, iters, step, staged_thr, staged_thr_fact);
-    if (sparse_int_model(ctx)) return sparse_rrr_bkl_async(ctx, 0, beta, iters, step, staged_thr, staged_thr_fact);
-    if (ctx->model == RRRMC_MODEL_SPARSE_DISCRETIZED) return dbl_rrr_mc_async(ctx, beta, iters, step, staged_thr, staged_thr_fact);
-    if (ctx->model == RRRMC_MODEL_SPARSE_F64) return spf_cont_async(ctx, 0, beta, iters, step, 1.0, staged_thr, staged_thr_fact);
-    if (ctx->model != RRRMC_MODEL_QUANT_RRG) return fail(ctx, RRRMC_ERR_UNSUPPORTED, "rrrMC is not available for model kind %d", ctx->model);
+    int32_t rc = RRRMC_OK;
     if (!(fourK > 0.0) || !std::isfinite(fourK)) return fail(ctx, RRRMC_ERR_INVALID_ARG, "fourK must be positive and finite, given: %g", fourK);
     if (iters < 0) return fail(ctx, RRRMC_ERR_INVALID_ARG, "iters must be >= 0, given %lld", (long long)iters);
     if (step < 1) return fail(ctx, RRRMC_ERR_INVALID_ARG, "step must be >= 1, given %lld", (long long)step);
@@ -1201,7 +1200,8 @@ int32_t rrrmc_rrr_mc_async(rrrmc_ctx* ctx, double beta, double fourK, int64_t it
     P.lambda = staged_thr_fact / (double)ctx->N;              // RRRMC.jl:243
     P.g0 = ctx->it_done; P.iters = iters; P.step = step;
     HIP_TRY(ctx, hipEventRecord(ctx->ev_sweep[0], st));
-    hipLaunchKernelGGL(rrr_quant_kernel, dim3(rrr_blocks(ctx->R)), dim3(rrr_tpb(ctx->R)), 0, st, P);
+    if (standard) hipLaunchKernelGGL(quant_standard_kernel, dim3(rrr_blocks(ctx->R)), dim3(rrr_tpb(ctx->R)), 0, st, P);
+    else hipLaunchKernelGGL(rrr_quant_kernel, dim3(rrr_blocks(ctx->R)), dim3(rrr_tpb(ctx->R)), 0, st, P);
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipEventRecord(ctx->ev_sweep[1], st));
     HIP_TRY(ctx, hipEventRecord(ctx->ev_end, st));
@@ -1210,8 +1210,23 @@ int32_t rrrmc_rrr_mc_async(rrrmc_ctx* ctx, double beta, double fourK, int64_t it
     ctx->it_done += (uint64_t)iters;
     ctx->results_valid = true;
     ctx->timing_valid = true;
-    ctx->last_call_rrr = true;
+    ctx->last_call_rrr = true;          // accepted counts live in q_stats
+    ctx->q_cache_valid = !standard;
     return RRRMC_OK;
+}
+}  // namespace
+
+int32_t rrrmc_rrr_mc_async(rrrmc_ctx* ctx, double beta, double fourK, int64_t iters, int64_t step, double staged_thr, double staged_thr_fact)
+{
+    int32_t rc = ensure_state(ctx, true);
+    if (rc) return rc;
+    if (!std::isfinite(beta)) return fail(ctx, RRRMC_ERR_INVALID_ARG, "beta must be finite, given: %g", beta);       // RRRMC.jl:230, :166
+    if (ctx->model == RRRMC_MODEL_SK_NORMAL) return sk_rrr_mc_async(ctx, beta, iters, step, staged_thr, staged_thr_fact);
+    if (sparse_int_model(ctx)) return sparse_rrr_bkl_async(ctx, 0, beta, iters, step, staged_thr, staged_thr_fact);
+    if (ctx->model == RRRMC_MODEL_SPARSE_DISCRETIZED) return dbl_rrr_mc_async(ctx, beta, iters, step, staged_thr, staged_thr_fact);
+    if (ctx->model == RRRMC_MODEL_SPARSE_F64) return spf_cont_async(ctx, 0, beta, iters, step, 1.0, staged_thr, staged_thr_fact);
+    if (ctx->model != RRRMC_MODEL_QUANT_RRG) return fail(ctx, RRRMC_ERR_UNSUPPORTED, "rrrMC is not available for model kind %d", ctx->model);
+    return quant_mc_async(ctx, false, beta, fourK, iters, step, staged_thr, staged_thr_fact);
 }
 
 int32_t rrrmc_bkl_mc_async(rrrmc_ctx* ctx, double beta, int64_t iters, int64_t step)
@@ -1306,6 +1321,7 @@ int32_t rrrmc_rrr_cache(rrrmc_ctx* ctx, int8_t* pos_out, int32_t* sizes_out)
         return fail(ctx, RRRMC_ERR_STATE, "no rrrMC call has been made");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->model == RRRMC_MODEL_QUANT_RRG && !ctx->q_cache_valid) return fail(ctx, RRRMC_ERR_STATE, "no rrrMC call has been made");
     if (ctx->model == RRRMC_MODEL_SPARSE_DISCRETIZED) {      // sizes_out[R * 16]: counted from the classes
         if (!ctx->db_cache_valid) return fail(ctx, RRRMC_ERR_STATE, "no rrrMC call has been made");
         std::vector<uint8_t> cls((size_t)ctx->R * ctx->N);

@@ -45,6 +45,38 @@ def test_rrr_quant_bit_exact(pkg, oracle, Nk, M, Gamma, beta, R, iters, step, th
         assert E1[r] == e1
 
 
+@pytest.mark.parametrize("Nk,M,Gamma,beta,R,iters,step", [
+    (10, 8, 0.5, 2.0, 40, 10000, 100),         # test/runtests.jl:78 under standardMC (:141-143)
+    (64, 16, 0.3, 1.0, 70, 20000, 250),
+    (1024, 32, 0.5, 2.0, 4, 40000, 4096),      # BASELINE config 5 geometry
+])
+def test_standard_mc_quant_bit_exact(pkg, oracle, Nk, M, Gamma, beta, R, iters, step):
+    """standardMC on GraphQuant: delta_energy = delta_energy(X0) + delta_energy_residual (QT.jl:283-286); two calls continue the streams."""
+    seed = 8426732438942 + Nk + 1
+    X1 = pkg.GraphRRG(Nk, 3, seed=seed)
+    X = pkg.GraphQuant(X1, M, Gamma, beta)
+    A, J = X1.A, X1.J.astype(np.int32)
+    with pkg.Engine(X, R) as eng:
+        eng.seed(seed)
+        eng.init_spins_random()
+        C0 = eng.get_config()
+        Es, acc = eng.standard_mc(beta, iters, step)
+        C1 = eng.get_config()
+        Es2, acc2 = eng.standard_mc(beta, iters // 2, step)
+        C2 = eng.get_config()
+        E2 = eng.energy()
+        with pytest.raises(pkg.RRRMCError):
+            eng.rrr_cache()
+    for r in range(R):
+        ref = oracle.standard_mc_quant(A, J, M, X.fourK, beta, iters, step, seed, C0.s[r], replica=r)
+        assert np.allclose(Es[r], ref[0], rtol=1e-6, atol=1e-9)
+        assert (Es[r] == ref[0]).all() and (C1.s[r] == ref[1]).all() and acc[r] == ref[2]
+        ref2 = oracle.standard_mc_quant(A, J, M, X.fourK, beta, iters // 2, step, seed, ref[1], it0=iters, replica=r)
+        assert (Es2[r] == ref2[0]).all() and (C2.s[r] == ref2[1]).all() and acc2[r] == ref2[2]
+        assert E2[r] == oracle.quant_energy(A, J, M, X.fourK, C2.s[r])[0]
+    assert 0 < acc.sum() < R * iters
+
+
 def test_rrrMC_front_end(pkg, oracle):
     seed = 4242
     X = pkg.GraphQuant(pkg.GraphRRG(16, 3, seed=seed), 4, 0.7, 1.5)

@@ -400,3 +400,17 @@ def test_general_level_graphs_all_samplers(oracle, kind, lev, mul, div):
     Es2, c2, acc2 = oracle.standard_mc_lev(A, J, 0.9, 4000, 1, seed, ch, form=form, mul=1, div=1.0)
     if mul / div == 1.0:
         assert (Es2 == Es).all() and (c2 == c1).all()
+
+
+def test_quant_standard_mc_tracked_energy(oracle):
+    """standardMC on GraphQuant(10, 8, 0.5, 2.0, GraphRRG, 10, 3) (runtests.jl:78 x :141-143): E_tracked ~ energy(X, C) (:12-20)."""
+    seed, Nk, M, beta, Gamma = 99, 10, 8, 2.0, 0.5
+    A = oracle.gen_rrg(Nk, 3, seed)
+    J = oracle.gen_couplings(A, seed)
+    fourK = oracle.quant_fourK(beta, Gamma, M)
+    ch = oracle.init_config(seed, 0, Nk * M)
+    Es, ch1, acc = oracle.standard_mc_quant(A, J, M, fourK, beta, 5000, 1, seed, ch)
+    assert Es[0] == oracle.quant_energy(A, J, M, fourK, ch)[0] and 0 < acc < 5000
+    for k in (2, 77, 1234, 5000):
+        _, ck, _ = oracle.standard_mc_quant(A, J, M, fourK, beta, k - 1, 1, seed, ch)
+        assert abs(Es[k - 1] - oracle.quant_energy(A, J, M, fourK, ck)[0]) < 1e-11
