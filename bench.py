@@ -147,7 +147,7 @@ def main():
             out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                                "algorithmic_bytes_per_launch": bytes_per_attempt * per_launch_attempts,
-                               "kernel": "sweep_kernel<3, true>", "avg_launch_ms": avg_ms, "launches": launches,
+                               "kernel": "sweep_kernel<3, 1>", "avg_launch_ms": avg_ms, "launches": launches,
                                "algorithmic_bytes_per_attempt": bytes_per_attempt}
         if not args.no_cpu_baseline and world == 1:      # reported at N = 1 only (rank 0's host cores)
             out["cpu_baseline"] = cpu_baseline(entry.load_oracle(), X)

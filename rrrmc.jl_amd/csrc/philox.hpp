@@ -26,14 +26,25 @@ enum StreamTag : uint32_t {
 
 struct Philox4 { uint32_t w[4]; };
 
+// a ^ b ^ c in one VALU instruction: gfx950's v_bitop3_b32 with truth table 0x96 (the compiler keeps two v_xor_b32 when it is
+// given the plain expression; a Philox round has two such sums next to its two v_mad_u64_u32, so this is a fifth of the block)
+RRRMC_HD uint32_t xor3(uint32_t a, uint32_t b, uint32_t c)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_bitop3_b32(a, b, c, 0x96);
+#else
+    return a ^ b ^ c;
+#endif
+}
+
 RRRMC_HD Philox4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1)
 {
 #pragma unroll
     for (int r = 0; r < 10; ++r) {
         const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
         const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
-        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
-        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        const uint32_t n0 = xor3((uint32_t)(p1 >> 32), c1, k0);
+        const uint32_t n2 = xor3((uint32_t)(p0 >> 32), c3, k1);
         c1 = (uint32_t)p1;
         c3 = (uint32_t)p0;
         c0 = n0;

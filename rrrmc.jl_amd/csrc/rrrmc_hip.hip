@@ -85,7 +85,8 @@ struct rrrmc_ctx {
 
     // ---- colour-parallel sweeps (any sparse ctx; the only sampler when lds_mode is false) ----
     bool lds_mode = true;               // the LDS-resident random-site kernel is available (the state fits the 160 KiB LDS)
-    bool wide = false;                  // ... in its WIDE build (8192 < N)
+    bool wide = false;                  // the neighbour table stays in HBM/L2 (longer chunks; needed for 8192 < N)
+    int sweep_mode = 0;                 // sweep_kernel<K, MODE>: 0 LDS table / byte offsets, 1 HBM table / byte offsets, 2 HBM table / word indices
     int ncolors = 0;
     std::vector<int32_t> color_count;   // sites per colour
     std::vector<int32_t*> d_color_list; // device lists
@@ -240,13 +241,17 @@ typedef void (*plan_fn)(ChunkDesc*, uint32_t*, uint32_t*, const int32_t*, int, i
 plan_fn plan_for_K(int K) { RRRMC_DISPATCH_UPTO7(K, plan_kernel) }
 
 typedef void (*sweep_fn)(SweepParams);
-sweep_fn sweep_for_K(int K, bool wide)
+sweep_fn sweep_for_K(int K, int mode)
 {
-    if (!wide) { RRRMC_DISPATCH_UPTO7(K, sweep_kernel) }
-    switch (K) {
-        case 1: return sweep_kernel<1, true>; case 2: return sweep_kernel<2, true>; case 3: return sweep_kernel<3, true>;
-        case 4: return sweep_kernel<4, true>; case 5: return sweep_kernel<5, true>; case 6: return sweep_kernel<6, true>;
-        case 7: return sweep_kernel<7, true>; default: return nullptr;
+    // mode 0: table in LDS, byte offsets; 1: table in HBM/L2, byte offsets (N <= 8192); 2: table in HBM/L2, word indices
+    switch (mode * 8 + K) {
+        case 1: return sweep_kernel<1, 0>; case 2: return sweep_kernel<2, 0>; case 3: return sweep_kernel<3, 0>; case 4: return sweep_kernel<4, 0>;
+        case 5: return sweep_kernel<5, 0>; case 6: return sweep_kernel<6, 0>; case 7: return sweep_kernel<7, 0>;
+        case 9: return sweep_kernel<1, 1>; case 10: return sweep_kernel<2, 1>; case 11: return sweep_kernel<3, 1>; case 12: return sweep_kernel<4, 1>;
+        case 13: return sweep_kernel<5, 1>; case 14: return sweep_kernel<6, 1>; case 15: return sweep_kernel<7, 1>;
+        case 17: return sweep_kernel<1, 2>; case 18: return sweep_kernel<2, 2>; case 19: return sweep_kernel<3, 2>; case 20: return sweep_kernel<4, 2>;
+        case 21: return sweep_kernel<5, 2>; case 22: return sweep_kernel<6, 2>; case 23: return sweep_kernel<7, 2>;
+        default: return nullptr;
     }
 }
 
@@ -392,6 +397,7 @@ int32_t rrrmc_ctx_create(rrrmc_ctx** out, int32_t model, int64_t N, int64_t K, i
     const int Cn = max_chunk(false), Cw = max_chunk(true);
     ctx->wide = Cw >= Cn + Cn / 8;
     if (const char* fw = std::getenv("RRRMC_FORCE_WIDE")) ctx->wide = ctx->wide || fw[0] == '1';       // timing experiments
+    ctx->sweep_mode = !ctx->wide ? 0 : (N <= 8192 ? 1 : 2);
     int C = ctx->wide ? Cw : Cn;
     // tiny graphs: the dependency depth of a chunk grows like C (K+1) / N, and both the planner's relaxation rounds and the
     // consumer's sequential levels follow it — long chunks stop paying
@@ -435,7 +441,7 @@ int32_t rrrmc_ctx_create(rrrmc_ctx** out, int32_t model, int64_t N, int64_t K, i
     CREATE_TRY(hipMemset(ctx->d_E, 0, sizeof(int32_t) * ctx->Rpad));
     CREATE_TRY(hipMemset(ctx->d_acc, 0, sizeof(int64_t) * ctx->Rpad));
     if (ctx->lds_mode) {
-        sweep_fn fn = sweep_for_K((int)K, ctx->wide);
+        sweep_fn fn = sweep_for_K((int)K, ctx->sweep_mode);
         CREATE_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->lds_bytes));
         CREATE_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(plan_for_K((int)K)), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->plan_lds_bytes));
     }
@@ -515,7 +521,7 @@ int32_t rrrmc_set_graph(rrrmc_ctx* ctx, const int32_t* A, const int8_t* J)
     if (ctx->lds_mode)
         for (int64_t x = 0; x < N; ++x)
             for (int64_t k = 0; k < K; ++k)
-                table[x * ctx->TS + k] = (uint16_t)((ctx->wide ? 1 : 4) * (A[x * K + k] + (J[x * K + k] < 0 ? N : 0)));   // byte offset (word index if wide) in the LDS spin array
+                table[x * ctx->TS + k] = (uint16_t)((ctx->sweep_mode == 2 ? 1 : 4) * (A[x * K + k] + (J[x * K + k] < 0 ? N : 0)));   // byte offset (word index in mode 2) in the LDS spin array
     ctx->h_A.assign(A, A + N * K);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -885,7 +891,7 @@ int32_t rrrmc_standard_mc_async(rrrmc_ctx* ctx, double beta, int64_t iters, int6
     P.k1 = (uint32_t)(ctx->seed >> 32);
     P.group0 = ctx->replica0 / 32;
     P.N = (int)N; P.C = C; P.TS = ctx->TS; P.Rpad = (int)ctx->Rpad;
-    sweep_fn fn = sweep_for_K((int)K, ctx->wide);
+    sweep_fn fn = sweep_for_K((int)K, ctx->sweep_mode);
 #ifdef RRRMC_STAMPS
     if (!g_stamps) HIP_TRY(ctx, hipMalloc(&g_stamps, sizeof(unsigned long long) * 16 * (65536 + 4096)));
     P.stamps = g_stamps;

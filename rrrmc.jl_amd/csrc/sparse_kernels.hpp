@@ -184,7 +184,7 @@ __global__ __launch_bounds__(kPlanThreads) void plan_kernel(ChunkDesc* __restric
 struct SweepParams {
     uint32_t* spins;          // [G][N]   bit-sliced configuration
     const uint16_t* table;    // [N][TS]  offsets of the neighbour words in the LDS spin array: y (J=+1) or y+N (J=-1, complemented
-                              //          copy), as BYTE offsets (x4) in the normal build and as WORD indices in the WIDE one
+                              //          copy), as BYTE offsets (x4) in MODE 0 / 1 and as WORD indices in MODE 2
                               //          (8192 < N < 32768: byte offsets no longer fit 16 bits; the table then stays in HBM/L2)
     const ChunkDesc* chunks;  // chunks of this launch
     const uint32_t* slots;
@@ -248,7 +248,7 @@ __device__ __forceinline__ void refine_block(uint32_t (&lt)[NT], uint32_t (&eq)[
 }
 
 // ---- producers -------------------------------------------------------------------------------------
-template <int K, bool WIDE>
+template <int K, int MODE>
 __device__ __forceinline__ void produce_chunk(const SweepParams& P, const ChunkDesc& cd, uint4* __restrict__ desc,
                                               const uint16_t* __restrict__ tbl, const LeftList& left, int pw, int lane, uint32_t group,
                                               const uint32_t (&slots)[kProducerTasksMax])
@@ -271,7 +271,7 @@ __device__ __forceinline__ void produce_chunk(const SweepParams& P, const ChunkD
         for (int q = 0; q < NQ * 4; ++q) f[q] = 0u;
         {   // gather offsets: own word, then the K neighbour words (table row = K uint16 byte offsets)
             uint32_t off[K + 2];
-            off[0] = WIDE ? site : site * 4u;
+            off[0] = MODE == 2 ? site : site * 4u;
             off[K + 1] = 0u;
             const uint16_t* row = tbl + (size_t)site * P.TS;
             if constexpr (K <= 4) {
@@ -383,29 +383,31 @@ template <int K> __device__ __forceinline__ uint32_t desc_off(const SlotDesc<K>&
     return (f & 1) ? (w >> 16) : (w & 0xffffu);
 }
 
-// off = byte offset (normal) or word index (WIDE) into the LDS spin array
-template <bool WIDE>
+// MODE of the sweep kernel: 0 = neighbour table staged in LDS, byte offsets; 1 = table read from HBM/L2 (longer chunks), byte offsets
+// (8 N <= 65536); 2 = table in HBM/L2, word indices (N > 8192: byte offsets into the 2N-word spin array no longer fit 16 bits).
+// off = byte offset or word index (MODE 2) into the LDS spin array
+template <int MODE>
 __device__ __forceinline__ uint32_t lds_word(const uint32_t* sp, uint32_t off)
 {
-    if constexpr (WIDE) return sp[off];
+    if constexpr (MODE == 2) return sp[off];
     else return *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(sp) + off);
 }
-template <bool WIDE>
+template <int MODE>
 __device__ __forceinline__ void lds_store(uint32_t* sp, uint32_t off, uint32_t v)
 {
-    if constexpr (WIDE) sp[off] = v;
+    if constexpr (MODE == 2) sp[off] = v;
     else *reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(sp) + off) = v;
 }
 
 // the K+1 spin words one attempt reads: own word first, then the neighbour words
 template <int K> struct SlotWords { uint32_t s; uint32_t g[K]; };
 
-template <int K, bool WIDE>
+template <int K, int MODE>
 __device__ __forceinline__ void gather_words(SlotWords<K>& w, const SlotDesc<K>& d, const uint32_t* __restrict__ sp)
 {
-    w.s = lds_word<WIDE>(sp, desc_off<K>(d, 0));
+    w.s = lds_word<MODE>(sp, desc_off<K>(d, 0));
 #pragma unroll
-    for (int k = 0; k < K; ++k) w.g[k] = lds_word<WIDE>(sp, desc_off<K>(d, 1 + k));
+    for (int k = 0; k < K; ++k) w.g[k] = lds_word<MODE>(sp, desc_off<K>(d, 1 + k));
 }
 
 // accept decision of one slot for the 32 replicas: planes n0..n2 of n = number of unsatisfied bonds, acc = accepted mask
@@ -453,7 +455,7 @@ __device__ __forceinline__ void slot_logic(const SlotDesc<K>& d, const SlotWords
 // latency-bound, this is its instruction-level parallelism).  The code is branch-free inside a step so that the
 // LDS waits can be counted (s_waitcnt lgkmcnt(N)) instead of drained: rows 0..NR-2 are full; in the last row the
 // lanes past the end of the level re-read the level's last slot (a broadcast) and store to private dummy words.
-template <int K, int NR, bool WIDE>
+template <int K, int NR, int MODE>
 __device__ __forceinline__ void consume_rows(const uint4* __restrict__ desc, uint32_t* __restrict__ sp, uint4* __restrict__ tal,
                                              int C, int N, int p0, int plast, int lane)
 {
@@ -468,13 +470,13 @@ __device__ __forceinline__ void consume_rows(const uint4* __restrict__ desc, uin
         for (int q = 0; q < NQ; ++q) d[j].q[q] = desc[q * C + p];
     }
 #pragma unroll
-    for (int j = 0; j < NR; ++j) gather_words<K, WIDE>(w[j], d[j], sp);
+    for (int j = 0; j < NR; ++j) gather_words<K, MODE>(w[j], d[j], sp);
 #pragma unroll
     for (int j = 0; j < NR; ++j) {
         uint32_t n0, n1, n2, acc;
         slot_logic<K>(d[j], w[j], n0, n1, n2, acc);
         const uint32_t snew = w[j].s ^ acc;      // spinflip! + update_cache! (Interface.jl:89-92, RRG.jl:191-234)
-        constexpr uint32_t kUnit = WIDE ? 1u : 4u;   // offsets are word indices (WIDE) or byte offsets
+        constexpr uint32_t kUnit = MODE == 2 ? 1u : 4u;   // offsets are word indices (MODE 2) or byte offsets
         uint32_t oa = desc_off<K>(d[j], 0);      // offset of the site's word; its complement lives N words further
         uint32_t ob = oa + kUnit * (uint32_t)N;
         int pt = p0 + j * kWave;
@@ -484,8 +486,8 @@ __device__ __forceinline__ void consume_rows(const uint4* __restrict__ desc, uin
             ob = dead ? kUnit * (2u * (uint32_t)N + 64u + (uint32_t)lane) : ob;
             pt = dead ? C + lane : pt;                                          // dummy tally entries behind the chunk's
         }
-        lds_store<WIDE>(sp, oa, snew);
-        lds_store<WIDE>(sp, ob, ~snew);
+        lds_store<MODE>(sp, oa, snew);
+        lds_store<MODE>(sp, ob, ~snew);
         tal[pt] = make_uint4(acc, n0, n1, n2);
     }
 }
@@ -495,7 +497,7 @@ __device__ __forceinline__ void consume_rows(const uint4* __restrict__ desc, uin
 // (the single consumer wave is latency-bound: this is its instruction-level parallelism).  A batch is branch-free
 // so that the LDS waits can be counted instead of drained: rows 0..NR-2 are full; in the last row the lanes past
 // the end of the batch re-read its last slot (a broadcast) and store to private dummy words.
-template <int K, bool WIDE>
+template <int K, int MODE>
 __device__ __forceinline__ void consume_chunk(const SweepParams& P, const ChunkDesc& cd, const uint4* __restrict__ desc,
                                               uint32_t* __restrict__ sp, uint4* __restrict__ tal, int lane, uint32_t first_vd)
 {
@@ -511,10 +513,10 @@ __device__ __forceinline__ void consume_chunk(const SweepParams& P, const ChunkD
             const uint32_t vd = __builtin_amdgcn_readlane(myvd, v);
             const int start = (int)(vd & 0xffffu), cm1 = (int)(vd >> 16);   // cm1 = slots - 1
             const int p0 = start + lane, plast = start + cm1;
-            if (cm1 >= 3 * kWave) consume_rows<K, 4, WIDE>(desc, sp, tal, C, N, p0, plast, lane);
-            else if (cm1 >= 2 * kWave) consume_rows<K, 3, WIDE>(desc, sp, tal, C, N, p0, plast, lane);
-            else if (cm1 >= kWave) consume_rows<K, 2, WIDE>(desc, sp, tal, C, N, p0, plast, lane);
-            else consume_rows<K, 1, WIDE>(desc, sp, tal, C, N, p0, plast, lane);
+            if (cm1 >= 3 * kWave) consume_rows<K, 4, MODE>(desc, sp, tal, C, N, p0, plast, lane);
+            else if (cm1 >= 2 * kWave) consume_rows<K, 3, MODE>(desc, sp, tal, C, N, p0, plast, lane);
+            else if (cm1 >= kWave) consume_rows<K, 2, MODE>(desc, sp, tal, C, N, p0, plast, lane);
+            else consume_rows<K, 1, MODE>(desc, sp, tal, C, N, p0, plast, lane);
         }
     }
 }
@@ -716,7 +718,7 @@ __device__ __forceinline__ void tally_chunk(TallyState<NS>& t, const ChunkDesc& 
     }
 }
 
-template <int K, bool WIDE = false>
+template <int K, int MODE = 0>
 __global__ __launch_bounds__(kSweepThreads) void sweep_kernel(SweepParams P)
 {
     constexpr int NQ = SweepCfg<K>::NQ, NS = SweepCfg<K>::NS;
@@ -727,8 +729,8 @@ __global__ __launch_bounds__(kSweepThreads) void sweep_kernel(SweepParams P)
     uint4* tal = desc + 3 * NQ * C;                                  // [2][C + 64]  (64 dummy entries per buffer)
     uint32_t* leftmem = reinterpret_cast<uint32_t*>(tal + 2 * (C + kWave));   // [2] leftover lists
     constexpr int kLeftWords = 4 + kLeftMax * (1 + 2 * SweepCfg<K>::NT);
-    // [N][TS] neighbour table: a copy in LDS, or (WIDE) the HBM/L2 original
-    const uint16_t* tbl = WIDE ? P.table : reinterpret_cast<const uint16_t*>(leftmem + 2 * kLeftWords);
+    // [N][TS] neighbour table: a copy in LDS, or (MODE >= 1) the HBM/L2 original
+    const uint16_t* tbl = MODE >= 1 ? P.table : reinterpret_cast<const uint16_t*>(leftmem + 2 * kLeftWords);
 
     const int tid = threadIdx.x, lane = tid & 63;
     // the wave index as a SCALAR: role dispatch becomes s_cbranch (and s_setprio below really is per wave)
@@ -741,7 +743,7 @@ __global__ __launch_bounds__(kSweepThreads) void sweep_kernel(SweepParams P)
         sp[x] = w;
         sp[x + N] = ~w;
     }
-    if constexpr (!WIDE) {
+    if constexpr (MODE == 0) {
         uint16_t* tbl_w = reinterpret_cast<uint16_t*>(leftmem + 2 * kLeftWords);
         for (int q = tid; q < N * P.TS; q += kSweepThreads) tbl_w[q] = P.table[q];
     }
@@ -782,7 +784,7 @@ __global__ __launch_bounds__(kSweepThreads) void sweep_kernel(SweepParams P)
             if (c < P.nchunks) cc = P.chunks[c];
 #ifndef RRRMC_ABLATE_CONSUME      // timing experiments only (tools/ablate.sh): results are wrong with a role removed
             if (c >= 2 && c - 2 < P.nchunks)
-                consume_chunk<K, WIDE>(P, ca, desc + ((c - 2) % 3) * NQ * C, sp, tal + ((c - 2) & 1) * tal_stride, lane, va);
+                consume_chunk<K, MODE>(P, ca, desc + ((c - 2) % 3) * NQ * C, sp, tal + ((c - 2) & 1) * tal_stride, lane, va);
 #endif
             RRRMC_T1
             __syncthreads();
@@ -872,7 +874,7 @@ __global__ __launch_bounds__(kSweepThreads) void sweep_kernel(SweepParams P)
             if (c + 1 < P.nchunks) fetch_slots(cd1, sl1);
             if (c + 2 < P.nchunks) cd2 = P.chunks[c + 2];
 #ifndef RRRMC_ABLATE_PRODUCE
-            if (c < P.nchunks) produce_chunk<K, WIDE>(P, cd0, desc + (c % 3) * NQ * C, tbl, left_list(c), pw, lane, group, sl0);
+            if (c < P.nchunks) produce_chunk<K, MODE>(P, cd0, desc + (c % 3) * NQ * C, tbl, left_list(c), pw, lane, group, sl0);
 #endif
             RRRMC_T1
             __syncthreads();
