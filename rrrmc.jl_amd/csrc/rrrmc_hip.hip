@@ -521,7 +521,7 @@ int32_t rrrmc_set_graph(rrrmc_ctx* ctx, const int32_t* A, const int8_t* J)
     if (ctx->lds_mode)
         for (int64_t x = 0; x < N; ++x)
             for (int64_t k = 0; k < K; ++k)
-                table[x * ctx->TS + k] = (uint16_t)((ctx->sweep_mode == 2 ? 1 : 4) * (A[x * K + k] + (J[x * K + k] < 0 ? N : 0)));   // byte offset (word index in mode 2) in the LDS spin array
+                table[x * ctx->TS + k] = (uint16_t)((ctx->sweep_mode == 2 ? 1 : 4) * (2 * A[x * K + k] + (J[x * K + k] < 0 ? 1 : 0)));   // byte offset (word index in mode 2) in the LDS spin array: word 2y = s_y, word 2y + 1 = ~s_y
     ctx->h_A.assign(A, A + N * K);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));

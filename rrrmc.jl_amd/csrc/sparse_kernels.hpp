@@ -271,7 +271,7 @@ __device__ __forceinline__ void produce_chunk(const SweepParams& P, const ChunkD
         for (int q = 0; q < NQ * 4; ++q) f[q] = 0u;
         {   // gather offsets: own word, then the K neighbour words (table row = K uint16 byte offsets)
             uint32_t off[K + 2];
-            off[0] = MODE == 2 ? site : site * 4u;
+            off[0] = MODE == 2 ? 2u * site : site * 8u;        // the pair {s, ~s} of the site starts at word 2 * site
             off[K + 1] = 0u;
             const uint16_t* row = tbl + (size_t)site * P.TS;
             if constexpr (K <= 4) {
@@ -392,11 +392,12 @@ __device__ __forceinline__ uint32_t lds_word(const uint32_t* sp, uint32_t off)
     if constexpr (MODE == 2) return sp[off];
     else return *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(sp) + off);
 }
+// the pair {s, ~s} of one site in a single 8-byte store (off = the pair's offset)
 template <int MODE>
-__device__ __forceinline__ void lds_store(uint32_t* sp, uint32_t off, uint32_t v)
+__device__ __forceinline__ void lds_store_pair(uint32_t* sp, uint32_t off, uint32_t v)
 {
-    if constexpr (MODE == 2) sp[off] = v;
-    else *reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(sp) + off) = v;
+    if constexpr (MODE == 2) *reinterpret_cast<uint2*>(sp + off) = make_uint2(v, ~v);
+    else *reinterpret_cast<uint2*>(reinterpret_cast<char*>(sp) + off) = make_uint2(v, ~v);
 }
 
 // the K+1 spin words one attempt reads: own word first, then the neighbour words
@@ -451,13 +452,13 @@ __device__ __forceinline__ void slot_logic(const SlotDesc<K>& d, const SlotWords
 }
 
 // One dependency level at a time; inside a level the attempts commute, so up to kRows x 64 of them are in flight
-// per step: all descriptor loads, then all gathers, then the logic and the stores (the single consumer wave is
-// latency-bound, this is its instruction-level parallelism).  The code is branch-free inside a step so that the
-// LDS waits can be counted (s_waitcnt lgkmcnt(N)) instead of drained: rows 0..NR-2 are full; in the last row the
-// lanes past the end of the level re-read the level's last slot (a broadcast) and store to private dummy words.
+// per step: all descriptor loads, then all gathers, then the logic and the stores (the single consumer wave is bound by its own
+// instruction stream and by LDS latency: the rows are its instruction-level parallelism, and every instruction saved per row
+// counts).  The code is branch-free inside a step so that the LDS waits can be counted (s_waitcnt lgkmcnt(N)) instead of
+// drained: rows 0..NR-2 are full; in the last row the lanes past the end of the level duplicate the level's last slot.
 template <int K, int NR, int MODE>
 __device__ __forceinline__ void consume_rows(const uint4* __restrict__ desc, uint32_t* __restrict__ sp, uint4* __restrict__ tal,
-                                             int C, int N, int p0, int plast, int lane)
+                                             int C, int p0, int plast)
 {
     constexpr int NQ = SweepCfg<K>::NQ;
     SlotDesc<K> d[NR];
@@ -476,18 +477,11 @@ __device__ __forceinline__ void consume_rows(const uint4* __restrict__ desc, uin
         uint32_t n0, n1, n2, acc;
         slot_logic<K>(d[j], w[j], n0, n1, n2, acc);
         const uint32_t snew = w[j].s ^ acc;      // spinflip! + update_cache! (Interface.jl:89-92, RRG.jl:191-234)
-        constexpr uint32_t kUnit = MODE == 2 ? 1u : 4u;   // offsets are word indices (MODE 2) or byte offsets
-        uint32_t oa = desc_off<K>(d[j], 0);      // offset of the site's word; its complement lives N words further
-        uint32_t ob = oa + kUnit * (uint32_t)N;
+        // in the last row the lanes past the end of the batch hold a copy of its last slot: they compute and store exactly what
+        // that slot's own lane does (same addresses, same values), so they need no special treatment
         int pt = p0 + j * kWave;
-        if (j == NR - 1) {
-            const bool dead = pt > plast;
-            oa = dead ? kUnit * (2u * (uint32_t)N + (uint32_t)lane) : oa;       // dummy words behind the two spin copies
-            ob = dead ? kUnit * (2u * (uint32_t)N + 64u + (uint32_t)lane) : ob;
-            pt = dead ? C + lane : pt;                                          // dummy tally entries behind the chunk's
-        }
-        lds_store<MODE>(sp, oa, snew);
-        lds_store<MODE>(sp, ob, ~snew);
+        if (j == NR - 1) pt = pt < plast ? pt : plast;
+        lds_store_pair<MODE>(sp, desc_off<K>(d[j], 0), snew);
         tal[pt] = make_uint4(acc, n0, n1, n2);
     }
 }
@@ -496,12 +490,12 @@ __device__ __forceinline__ void consume_rows(const uint4* __restrict__ desc, uin
 // attempts commute, so all its descriptor loads, then all its gathers are issued before the logic and the stores
 // (the single consumer wave is latency-bound: this is its instruction-level parallelism).  A batch is branch-free
 // so that the LDS waits can be counted instead of drained: rows 0..NR-2 are full; in the last row the lanes past
-// the end of the batch re-read its last slot (a broadcast) and store to private dummy words.
+// the end of the batch duplicate its last slot (same loads, same stores).
 template <int K, int MODE>
 __device__ __forceinline__ void consume_chunk(const SweepParams& P, const ChunkDesc& cd, const uint4* __restrict__ desc,
                                               uint32_t* __restrict__ sp, uint4* __restrict__ tal, int lane, uint32_t first_vd)
 {
-    const int C = P.C, N = P.N;
+    const int C = P.C;
     const uint32_t nb = cd.nvec;
     for (uint32_t v0 = 0; v0 < nb; v0 += kWave) {
         // the batch table is read 64 entries at a time (one coalesced load) and broadcast lane by lane; the first 64 entries
@@ -513,10 +507,10 @@ __device__ __forceinline__ void consume_chunk(const SweepParams& P, const ChunkD
             const uint32_t vd = __builtin_amdgcn_readlane(myvd, v);
             const int start = (int)(vd & 0xffffu), cm1 = (int)(vd >> 16);   // cm1 = slots - 1
             const int p0 = start + lane, plast = start + cm1;
-            if (cm1 >= 3 * kWave) consume_rows<K, 4, MODE>(desc, sp, tal, C, N, p0, plast, lane);
-            else if (cm1 >= 2 * kWave) consume_rows<K, 3, MODE>(desc, sp, tal, C, N, p0, plast, lane);
-            else if (cm1 >= kWave) consume_rows<K, 2, MODE>(desc, sp, tal, C, N, p0, plast, lane);
-            else consume_rows<K, 1, MODE>(desc, sp, tal, C, N, p0, plast, lane);
+            if (cm1 >= 3 * kWave) consume_rows<K, 4, MODE>(desc, sp, tal, C, p0, plast);
+            else if (cm1 >= 2 * kWave) consume_rows<K, 3, MODE>(desc, sp, tal, C, p0, plast);
+            else if (cm1 >= kWave) consume_rows<K, 2, MODE>(desc, sp, tal, C, p0, plast);
+            else consume_rows<K, 1, MODE>(desc, sp, tal, C, p0, plast);
         }
     }
 }
@@ -740,8 +734,7 @@ __global__ __launch_bounds__(kSweepThreads) void sweep_kernel(SweepParams P)
 
     for (int x = tid; x < N; x += kSweepThreads) {
         const uint32_t w = gsp[x];
-        sp[x] = w;
-        sp[x + N] = ~w;
+        *reinterpret_cast<uint2*>(sp + 2 * x) = make_uint2(w, ~w);       // word 2x: the spins of site x, word 2x + 1: their complement
     }
     if constexpr (MODE == 0) {
         uint16_t* tbl_w = reinterpret_cast<uint16_t*>(leftmem + 2 * kLeftWords);
@@ -886,7 +879,7 @@ __global__ __launch_bounds__(kSweepThreads) void sweep_kernel(SweepParams P)
 #undef RRRMC_T0
 #undef RRRMC_T1
     __syncthreads();
-    for (int x = tid; x < N; x += kSweepThreads) gsp[x] = sp[x];
+    for (int x = tid; x < N; x += kSweepThreads) gsp[x] = sp[2 * x];
 }
 
 // ---------------------------------------------------------------------------------------------------
