@@ -37,6 +37,20 @@ RRRMC_HD uint32_t xor3(uint32_t a, uint32_t b, uint32_t c)
 #endif
 }
 
+// any three-input bitwise function in one instruction: bit (a << 2 | b << 1 | c) of the truth table TT is f(a, b, c)
+template <uint32_t TT>
+RRRMC_HD uint32_t bitop3(uint32_t a, uint32_t b, uint32_t c)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_bitop3_b32(a, b, c, TT);
+#else
+    uint32_t r = 0u;
+    for (uint32_t m = 0; m < 8u; ++m)
+        if ((TT >> m) & 1u) r |= ((m & 4u) ? a : ~a) & ((m & 2u) ? b : ~b) & ((m & 1u) ? c : ~c);
+    return r;
+#endif
+}
+
 RRRMC_HD Philox4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1)
 {
 #pragma unroll
