@@ -486,7 +486,13 @@ __device__ __forceinline__ void consume_rows(const uint4* __restrict__ desc, uin
         int pt = p0 + j * kWave;
         if (j == NR - 1) pt = pt < plast ? pt : plast;
         lds_store_pair<MODE>(sp, desc_off<K>(d[j], 0), snew);
-        tal[pt] = make_uint4(acc, n0, n1, n2);
+        if constexpr (SweepCfg<K>::NS <= 3) {
+            // the tally reads three words for K <= 3 (n2 = 0): a 12-byte LDS write issues faster than a 16-byte one
+            typedef uint32_t v3u __attribute__((ext_vector_type(3)));
+            *reinterpret_cast<v3u*>(tal + pt) = v3u{acc, n0, n1};
+        } else {
+            tal[pt] = make_uint4(acc, n0, n1, n2);
+        }
     }
 }
 
