@@ -163,11 +163,47 @@ __global__ __launch_bounds__(kRrrThreads) void rrr_init_kernel(RrrParams P)
     P.stats[(size_t)r * 2 + 1] = 0;
 }
 
+// bytes of LDS one replica's hot state takes in the LDS-resident build below
+inline size_t rrr_quant_lds_bytes(int64_t N, int64_t W, int64_t Nk, int64_t K)
+{
+    return (size_t)W * 4 + (((size_t)N * 2 + 3) & ~(size_t)3) + (((size_t)N + 3) & ~(size_t)3) + 16 + (size_t)Nk * K * 4 + (((size_t)Nk * K + 3) & ~(size_t)3);
+}
+
+// LDS = false: one thread per replica, everything in HBM/L2 (any number of replicas per workgroup).
+// LDS = true:  one workgroup (one wavefront) per replica — the launch shape of a few hundred replicas anyway — with the replica's
+//   spins, class bytes, set positions and set sizes, and the slice graph's (A, J), staged in LDS (3.1 bytes per spin + 5 K bytes
+//   per slice site: 115 KB at config 5) by all 64 lanes; lane 0 then runs the chain.  Only the ArraySet member arrays (sv, 8 bytes
+//   per spin) are left in HBM/L2.  Same arithmetic, same order: results are unchanged.  (Worth 10 % at config 5: a chain on one
+//   lane is bound by its instruction stream — 5 cycles per instruction — more than by the loads.)
+template <bool LDS>
 __global__ __launch_bounds__(kRrrThreads) void rrr_quant_kernel(RrrParams P)
 {
-    const int r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= P.R) return;
-    const RrrView v = rrr_view(P, r);
+    extern __shared__ uint32_t q_lds[];
+    int r;
+    if constexpr (LDS) {
+        r = (int)blockIdx.x;
+    } else {
+        r = blockIdx.x * blockDim.x + threadIdx.x;
+        if (r >= P.R) return;
+    }
+    RrrView v = rrr_view(P, r);
+    uint32_t* g_sp = v.sp; uint8_t* g_cls = v.cls; uint16_t* g_spos = v.spos; int32_t* g_t = v.t;
+    if constexpr (LDS) {
+        const int tid = (int)threadIdx.x, nt = (int)blockDim.x;
+        uint32_t* l_sp = q_lds;                                               // [W]
+        uint16_t* l_spos = reinterpret_cast<uint16_t*>(l_sp + P.W);           // [N]
+        uint8_t* l_cls = reinterpret_cast<uint8_t*>(l_spos) + ((2 * P.N + 3) & ~3);   // [N], both padded to a word
+        int32_t* l_t = reinterpret_cast<int32_t*>(l_cls + ((P.N + 3) & ~3));  // [4]
+        int32_t* l_A = l_t + 4;                                               // [Nk][K]
+        int8_t* l_J = reinterpret_cast<int8_t*>(l_A + P.Nk * P.K);            // [Nk][K]
+        for (int i = tid; i < P.W; i += nt) l_sp[i] = g_sp[i];
+        for (int i = tid; i < P.N; i += nt) { l_spos[i] = g_spos[i]; l_cls[i] = g_cls[i]; }
+        for (int i = tid; i < P.Nk * P.K; i += nt) { l_A[i] = P.A[i]; l_J[i] = P.J[i]; }
+        if (tid < 4) l_t[tid] = g_t[tid];
+        __syncthreads();
+        v.sp = l_sp; v.spos = l_spos; v.cls = l_cls; v.t = l_t; v.A = l_A; v.J = l_J;
+    }
+    if (!LDS || threadIdx.x == 0) {
     const uint32_t rep = P.replica0 + (uint32_t)r;
     double T[4], z = P.zz[r], E = P.E_cur[r], acc_rate = P.acc_rate[r];
     for (int k = 0; k < 4; ++k) T[k] = P.T[(size_t)r * 4 + k];
@@ -287,6 +323,14 @@ __global__ __launch_bounds__(kRrrThreads) void rrr_quant_kernel(RrrParams P)
     for (int k = 0; k < 4; ++k) P.T[(size_t)r * 4 + k] = T[k];
     P.zz[r] = z; P.E_cur[r] = E; P.acc_rate[r] = acc_rate;
     P.stats[(size_t)r * 2] = accepted; P.stats[(size_t)r * 2 + 1] = staged_its;
+    }
+    if constexpr (LDS) {
+        __syncthreads();
+        const int tid = (int)threadIdx.x, nt = (int)blockDim.x;
+        for (int i = tid; i < P.W; i += nt) g_sp[i] = v.sp[i];
+        for (int i = tid; i < P.N; i += nt) { g_spos[i] = v.spos[i]; g_cls[i] = v.cls[i]; }
+        if (tid < 4) g_t[tid] = v.t[tid];
+    }
 }
 
 // standardMC (src/RRRMC.jl:81-127) on GraphQuant: delta_energy(X, C, move) = delta_energy(X0) + delta_energy_residual (QT.jl:283-286);

@@ -164,6 +164,7 @@ struct rrrmc_ctx {
     long long db_lev_mul = 1;          // level units -> Float64: (units * mul) / div (DFloat64 levels: rrrmc_set_level_scale)
     double db_lev_div = 1.0;
     bool db_cache_valid = false;
+    bool q_lds_attr = false;            // hipFuncSetAttribute done for the LDS-resident rrrMC kernel
     bool q_cache_valid = false;         // GraphQuant: the DeltaECache arrays describe the last rrrMC call
     // ---- level table of the integer-level kernels (rrr_sparse / wtm / eo / lev_standard): the +-J table for RRRMC_MODEL_SPARSE_PM1,
     // allΔE(X) of the given levels for RRRMC_MODEL_SPARSE_LEVELS (whose spins live in q_spins / qW, BitVector word order)
@@ -1207,7 +1208,20 @@ int32_t quant_mc_async(rrrmc_ctx* ctx, bool standard, double beta, double fourK,
     P.g0 = ctx->it_done; P.iters = iters; P.step = step;
     HIP_TRY(ctx, hipEventRecord(ctx->ev_sweep[0], st));
     if (standard) hipLaunchKernelGGL(quant_standard_kernel, dim3(rrr_blocks(ctx->R)), dim3(rrr_tpb(ctx->R)), 0, st, P);
-    else hipLaunchKernelGGL(rrr_quant_kernel, dim3(rrr_blocks(ctx->R)), dim3(rrr_tpb(ctx->R)), 0, st, P);
+    else {
+        // one replica per workgroup anyway (few replicas): stage its hot state in LDS if it fits (config 5: 115 KB)
+        const size_t lds = rrr_quant_lds_bytes(ctx->N, ctx->qW, ctx->qNk, ctx->K);
+        const char* no_lds = std::getenv("RRRMC_QUANT_NO_LDS");          // timing experiments
+        if (rrr_tpb(ctx->R) == 1 && lds <= (size_t)kLdsLimit && !(no_lds && no_lds[0] == '1')) {
+            if (!ctx->q_lds_attr) {
+                HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(rrr_quant_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                ctx->q_lds_attr = true;
+            }
+            hipLaunchKernelGGL(rrr_quant_kernel<true>, dim3((unsigned)ctx->R), dim3(kRrrThreads), lds, st, P);
+        } else {
+            hipLaunchKernelGGL(rrr_quant_kernel<false>, dim3(rrr_blocks(ctx->R)), dim3(rrr_tpb(ctx->R)), 0, st, P);
+        }
+    }
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipEventRecord(ctx->ev_sweep[1], st));
     HIP_TRY(ctx, hipEventRecord(ctx->ev_end, st));

@@ -77,6 +77,36 @@ def test_standard_mc_quant_bit_exact(pkg, oracle, Nk, M, Gamma, beta, R, iters, 
     assert 0 < acc.sum() < R * iters
 
 
+def test_rrr_quant_lds_and_global_builds_agree(pkg, oracle, monkeypatch):
+    """Few replicas run one workgroup per replica with the hot state staged in LDS; many replicas (or RRRMC_QUANT_NO_LDS=1) run the
+    thread-per-replica build on HBM/L2.  Same chains bit for bit; odd N exercises the LDS carving's padding."""
+    seed = 31337
+    X = pkg.GraphQuant(pkg.GraphRRG(15, 4, seed=seed), 5, 0.4, 1.2)          # N = 75
+    out = []
+    for no_lds in ("0", "1"):
+        monkeypatch.setenv("RRRMC_QUANT_NO_LDS", no_lds)
+        with pkg.Engine(X, 9) as eng:
+            eng.seed(seed)
+            eng.init_spins_random()
+            C0 = eng.get_config()
+            a = eng.rrr_mc(1.2, 6000, 100)
+            b = eng.rrr_mc(1.2, 3000, 100, staged_thr=1.0)
+            out.append((a[0], a[1], a[2], b[0], b[1], b[2], eng.get_config().s, eng.rrr_cache()[0], eng.rrr_cache()[1]))
+    for u, v in zip(*out):
+        assert (u == v).all()
+    for r in range(9):
+        ref = oracle.rrr_mc_quant(X.A, X.J.astype(np.int32), X.M, X.fourK, 1.2, 6000, 100, seed, C0.s[r], replica=r)
+        assert (out[0][0][r] == ref[0]).all() and out[0][1][r] == ref[2]
+    with pkg.Engine(X, 300) as eng:                                            # more than 256 replicas: several per workgroup
+        eng.seed(seed)
+        eng.init_spins_random()
+        Es, acc, st = eng.rrr_mc(1.2, 2000, 100)
+        C0b = oracle.init_configs(seed, 0, 300, X.N)
+    for r in (0, 8, 255, 256, 299):
+        ref = oracle.rrr_mc_quant(X.A, X.J.astype(np.int32), X.M, X.fourK, 1.2, 2000, 100, seed, C0b[r], replica=r)
+        assert (Es[r] == ref[0]).all() and acc[r] == ref[2]
+
+
 def test_rrrMC_front_end(pkg, oracle):
     seed = 4242
     X = pkg.GraphQuant(pkg.GraphRRG(16, 3, seed=seed), 4, 0.7, 1.5)

@@ -61,18 +61,20 @@ def bench_quant(Nk=1024, M=32, R=128, beta=2.0, Gamma=0.5, iters=1 << 16, step=1
     """BASELINE.json configs[4] on ONE GPU's share: GraphQuant(GraphRRG(1024,3), M=32) under rrrMC, 128 of the 1024 replicas."""
     pkg = entry.load_package()
     X = pkg.GraphQuant(pkg.GraphRRG(Nk, 3, seed=seed), M, Gamma, beta)
-    eng = pkg.Engine(X, R)
-    eng.seed(seed)
-    eng.init_spins_random()
-    t0 = time.perf_counter()
-    Es, acc, staged = eng.rrr_mc(beta, iters, step)
-    dt = time.perf_counter() - t0
-    total_ms, sweep_ms, _ = eng.last_timing()
-    out = {"model": "GraphQuant rrrMC", "Nk": Nk, "M": M, "replicas": R, "beta": beta, "Gamma": Gamma, "iters": iters,
-           "iterations_per_s": float(R) * iters / dt, "kernel_ms": sweep_ms, "acceptance": float(acc.mean()) / iters,
-           "staged_frac": float(staged.mean()) / iters, "energy_per_spin": float(Es[:, -1].mean()) / X.N}
-    print(json.dumps(out))
-    eng.close()
+    for R in ([int(a) for a in sys.argv[2:]] or [R]):        # the path scales with the replicas: python tools/bench_models.py quant 128 1024 8192
+        it = max(step, iters * 128 // max(R, 128))
+        eng = pkg.Engine(X, R)
+        eng.seed(seed)
+        eng.init_spins_random()
+        t0 = time.perf_counter()
+        Es, acc, staged = eng.rrr_mc(beta, it, step)
+        dt = time.perf_counter() - t0
+        total_ms, sweep_ms, _ = eng.last_timing()
+        out = {"model": "GraphQuant rrrMC", "Nk": Nk, "M": M, "replicas": R, "beta": beta, "Gamma": Gamma, "iters": it,
+               "iterations_per_s": float(R) * it / dt, "kernel_iterations_per_s": float(R) * it / (sweep_ms * 1e-3), "kernel_ms": sweep_ms,
+               "acceptance": float(acc.mean()) / it, "staged_frac": float(staged.mean()) / it, "energy_per_spin": float(Es[:, -1].mean()) / X.N}
+        print(json.dumps(out), flush=True)
+        eng.close()
 
 
 def bench_spf(N=4096, K=3, R=65536, beta=1.0, iters=1 << 14, step=1 << 12, seed=0x5EED):
