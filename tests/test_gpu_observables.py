@@ -24,6 +24,10 @@ def _run_with_snapshots(pkg, eng, X, beta, nsnap, step, kind):
     ("rrg", 4096, 64),       # BASELINE config 2 geometry
     ("skn", 100, 13),        # byte-sliced SK layout, R not a multiple of 8
     ("quant", 10 * 8, 5),    # chunk layout
+    ("spf", 150, 70),        # GraphRRGNormal: one uint64 per (wavefront, site)
+    ("dbl", 90, 9),          # GraphRRGNormalDiscretized: chunk layout
+    ("lev", 90, 33),         # GraphRRG with general levels: chunk layout
+    ("skb", 70, 11),         # GraphSK (binary couplings): byte-sliced
 ])
 def test_overlaps_match_pm1dot(pkg, oracle, model, N, R):
     seed = 9001 + N
@@ -31,6 +35,14 @@ def test_overlaps_match_pm1dot(pkg, oracle, model, N, R):
         X = pkg.GraphRRG(N, 3, seed=seed)
     elif model == "skn":
         X = pkg.GraphSKNormal(N, seed=seed)
+    elif model == "spf":
+        X = pkg.GraphRRGNormal(N, 3, seed=seed)
+    elif model == "dbl":
+        X = pkg.GraphRRGNormalDiscretized(N, 3, (-1, 0, 1), seed=seed)
+    elif model == "lev":
+        X = pkg.GraphRRG(N, 3, (-1.0, 0.0, 1.0), seed=seed)
+    elif model == "skb":
+        X = pkg.GraphSK(N, seed=seed)
     else:
         X = pkg.GraphQuant(pkg.GraphRRG(10, 3, seed=seed), 8, 0.5, 2.0)
     T = 5
