@@ -17,6 +17,7 @@
 #include "sk_kernels.hpp"
 #include "rrr_kernels.hpp"
 #include "sparse_kernels.hpp"
+#include "bign_kernels.hpp"
 #include "obs_kernels.hpp"
 #include "spf_kernels.hpp"
 #include "dbl_kernels.hpp"
@@ -86,6 +87,7 @@ struct rrrmc_ctx {
     // ---- colour-parallel sweeps (any sparse ctx; the only sampler when lds_mode is false) ----
     bool lds_mode = true;               // the LDS-resident random-site kernel is available (the state fits the 160 KiB LDS)
     bool wide = false;                  // the neighbour table stays in HBM/L2 (longer chunks; needed for 8192 < N)
+    bool big_mode = false;              // N does not fit LDS: random-site standardMC through plan_big_kernel / big_sweep_kernel (spins in HBM/L2)
     int sweep_mode = 0;                 // sweep_kernel<K, MODE>: 0 LDS table / byte offsets, 1 HBM table / byte offsets, 2 HBM table / word indices
     int ncolors = 0;
     std::vector<int32_t> color_count;   // sites per colour
@@ -240,6 +242,11 @@ uint64_t threshold64(double p, bool* always)
 
 typedef void (*plan_fn)(ChunkDesc*, uint32_t*, uint32_t*, const int32_t*, int, int, uint32_t, uint32_t);
 plan_fn plan_for_K(int K) { RRRMC_DISPATCH_UPTO7(K, plan_kernel) }
+
+typedef void (*plan_big_fn)(ChunkDesc*, uint32_t*, uint32_t*, const int32_t*, int, uint32_t, uint32_t);
+plan_big_fn plan_big_for_K(int K) { RRRMC_DISPATCH_UPTO7(K, plan_big_kernel) }
+typedef void (*big_sweep_fn)(BigSweepParams);
+big_sweep_fn big_sweep_for_K(int K) { RRRMC_DISPATCH_UPTO7(K, big_sweep_kernel) }
 
 typedef void (*sweep_fn)(SweepParams);
 sweep_fn sweep_for_K(int K, int mode)
@@ -406,10 +413,12 @@ int32_t rrrmc_ctx_create(rrrmc_ctx** out, int32_t model, int64_t N, int64_t K, i
     if (C > cap) C = (int)cap;
     // otherwise only the colour-parallel sweeps are available (HBM/L2-resident spins)
     ctx->lds_mode = C >= 4 * kWave && plan_lds_bytes(N, (int)K, C) <= (size_t)kLdsLimit;
-    if (!ctx->lds_mode) C = kWave;
+    if (const char* fb = std::getenv("RRRMC_FORCE_BIG")) { if (fb[0] == '1') ctx->lds_mode = false; }      // tests: the big-N path at small N
+    ctx->big_mode = !ctx->lds_mode && N <= ((int64_t)1 << kBigSiteBits);
+    if (!ctx->lds_mode) C = ctx->big_mode ? kBigChunk : kWave;
     ctx->C = C;
     ctx->lds_bytes = ctx->lds_mode ? sweep_lds_bytes(N, (int)K, ctx->TS, C, ctx->wide) : 0;
-    ctx->plan_lds_bytes = ctx->lds_mode ? plan_lds_bytes(N, (int)K, C) : 0;
+    ctx->plan_lds_bytes = ctx->lds_mode ? plan_lds_bytes(N, (int)K, C) : (ctx->big_mode ? plan_big_lds_bytes((int)K) : 0);
 
 #define CREATE_TRY(expr)                                                                                         \
     do {                                                                                                         \
@@ -446,6 +455,8 @@ int32_t rrrmc_ctx_create(rrrmc_ctx** out, int32_t model, int64_t N, int64_t K, i
         CREATE_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->lds_bytes));
         CREATE_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(plan_for_K((int)K)), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->plan_lds_bytes));
     }
+    if (ctx->big_mode)
+        CREATE_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(plan_big_for_K((int)K)), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->plan_lds_bytes));
 #undef CREATE_TRY
     *out = ctx;
     return RRRMC_OK;
@@ -778,7 +789,7 @@ int32_t rrrmc_standard_mc_async(rrrmc_ctx* ctx, double beta, int64_t iters, int6
         return quant_mc_async(ctx, true, beta, ctx->last_fourK, iters, step, 0.0, 0.0);
     }
     if (ctx->model != RRRMC_MODEL_SPARSE_PM1) return fail(ctx, RRRMC_ERR_UNSUPPORTED, "standardMC is not wired for this model on the device: use rrrmc_rrr_mc_async");
-    if (!ctx->lds_mode) return fail(ctx, RRRMC_ERR_UNSUPPORTED, "N=%lld does not fit the LDS-resident random-site kernel: use rrrmc_colored_sweeps_async", (long long)ctx->N);
+    if (!ctx->lds_mode && !ctx->big_mode) return fail(ctx, RRRMC_ERR_UNSUPPORTED, "N=%lld is beyond the random-site kernels (N <= 2^20): use rrrmc_colored_sweeps_async", (long long)ctx->N);
     ctx->colored_call = false;
     if (iters < 0) return fail(ctx, RRRMC_ERR_INVALID_ARG, "iters must be >= 0, given %lld", (long long)iters);
     if (step < 1) return fail(ctx, RRRMC_ERR_INVALID_ARG, "step must be >= 1, given %lld", (long long)step);
@@ -892,7 +903,14 @@ int32_t rrrmc_standard_mc_async(rrrmc_ctx* ctx, double beta, int64_t iters, int6
     P.k1 = (uint32_t)(ctx->seed >> 32);
     P.group0 = ctx->replica0 / 32;
     P.N = (int)N; P.C = C; P.TS = ctx->TS; P.Rpad = (int)ctx->Rpad;
-    sweep_fn fn = sweep_for_K((int)K, ctx->sweep_mode);
+    sweep_fn fn = ctx->lds_mode ? sweep_for_K((int)K, ctx->sweep_mode) : nullptr;
+    BigSweepParams PB{};
+    if (ctx->big_mode) {
+        PB.spins = ctx->d_spins; PB.A = ctx->d_A; PB.J = ctx->d_J; PB.Es = ctx->d_Es; PB.E_cur = ctx->d_E; PB.acc_cur = ctx->d_acc;
+        std::memcpy(PB.taum, P.taum, sizeof(PB.taum));
+        PB.always_mask = P.always_mask; PB.k0 = P.k0; PB.k1 = P.k1; PB.group0 = P.group0;
+        PB.N = (int)N; PB.Rpad = (int)ctx->Rpad;
+    }
 #ifdef RRRMC_STAMPS
     if (!g_stamps) HIP_TRY(ctx, hipMalloc(&g_stamps, sizeof(unsigned long long) * 16 * (65536 + 4096)));
     P.stamps = g_stamps;
@@ -903,8 +921,12 @@ int32_t rrrmc_standard_mc_async(rrrmc_ctx* ctx, double beta, int64_t iters, int6
     auto launch_plan = [&](int b) -> int32_t {
         const Batch& bt = batches[b];
         if (b >= 2) HIP_TRY(ctx, hipStreamWaitEvent(ctx->plan_stream, ctx->ev_sweep[2 * (b - 2) + 1], 0));
-        hipLaunchKernelGGL(plan_for_K((int)K), dim3((unsigned)bt.n), dim3(kPlanThreads), ctx->plan_lds_bytes, ctx->plan_stream,
-                           ctx->d_chunks + bt.first, ctx->d_slots[b & 1], ctx->d_vecs[b & 1], ctx->d_A, (int)N, C, P.k0, P.k1);
+        if (ctx->big_mode)
+            hipLaunchKernelGGL(plan_big_for_K((int)K), dim3((unsigned)bt.n), dim3(kPlanThreads), ctx->plan_lds_bytes, ctx->plan_stream,
+                               ctx->d_chunks + bt.first, ctx->d_slots[b & 1], ctx->d_vecs[b & 1], ctx->d_A, (int)N, P.k0, P.k1);
+        else
+            hipLaunchKernelGGL(plan_for_K((int)K), dim3((unsigned)bt.n), dim3(kPlanThreads), ctx->plan_lds_bytes, ctx->plan_stream,
+                               ctx->d_chunks + bt.first, ctx->d_slots[b & 1], ctx->d_vecs[b & 1], ctx->d_A, (int)N, C, P.k0, P.k1);
         HIP_TRY(ctx, hipGetLastError());
         HIP_TRY(ctx, hipEventRecord(ctx->ev_plan[b], ctx->plan_stream));
         return RRRMC_OK;
@@ -919,7 +941,12 @@ int32_t rrrmc_standard_mc_async(rrrmc_ctx* ctx, double beta, int64_t iters, int6
         P.slots = ctx->d_slots[b & 1];
         P.vecs = ctx->d_vecs[b & 1];
         HIP_TRY(ctx, hipEventRecord(ctx->ev_sweep[2 * b], st));
-        hipLaunchKernelGGL(fn, dim3((unsigned)ctx->G), dim3(kSweepThreads), ctx->lds_bytes, st, P);
+        if (ctx->big_mode) {
+            PB.chunks = P.chunks; PB.nchunks = P.nchunks; PB.sample0 = P.sample0; PB.slots = P.slots; PB.vecs = P.vecs;
+            hipLaunchKernelGGL(big_sweep_for_K((int)K), dim3((unsigned)ctx->G), dim3(kBigThreads), 0, st, PB);
+        } else {
+            hipLaunchKernelGGL(fn, dim3((unsigned)ctx->G), dim3(kSweepThreads), ctx->lds_bytes, st, P);
+        }
         HIP_TRY(ctx, hipGetLastError());
         HIP_TRY(ctx, hipEventRecord(ctx->ev_sweep[2 * b + 1], st));
         // the next plan is enqueued AFTER this sweep so that the sweep's workgroups (one per CU, most of the LDS)

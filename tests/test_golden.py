@@ -6,7 +6,8 @@ import os
 import numpy as np
 import pytest
 
-FILES = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "*.npz")))
+FILES = sorted(f for f in glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "*.npz"))
+               if os.path.basename(f) != "models.npz")        # models.npz: tests/test_golden_models.py
 
 
 def test_fixtures_present():

@@ -57,7 +57,7 @@ def test_improper_coloring_is_rejected(pkg):
 def test_config4_lattice_properties(pkg, oracle):
     """GraphEA L = 64, D = 3 (N = 262144): the oracle is too slow for a full comparison, so check one replica group over two
     sweeps against it and size-independent properties on more replicas: energies are even multiples consistent with
-    allΔE = (0,4,8,12), the beta = inf limit never raises the energy, a random-site standardMC call is refused."""
+    allΔE = (0,4,8,12), the beta = inf limit never raises the energy (random-site standardMC at this size: test_gpu_bign_parity)."""
     L_, D = 64, 3
     seed = 64
     X = pkg.GraphEA(L_, D, seed=seed)
@@ -69,7 +69,7 @@ def test_config4_lattice_properties(pkg, oracle):
         eng.set_coloring(color)
         C0 = eng.get_config()
         with pytest.raises(pkg.RRRMCError) as e:
-            eng.standard_mc(1.0, 10, 1)
+            eng.rrr_mc(1.0, 10, 1)                        # the thread-per-replica samplers index spins with 16 bits
         assert e.value.code == 3
         Es = eng.colored_sweeps(1.0, 2, 1)
         C1 = eng.get_config()

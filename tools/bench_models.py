@@ -121,6 +121,28 @@ def bench_dbl(N=4096, K=3, R=8192, beta=2.0, iters=1 << 14, step=1 << 12, seed=0
         eng.close()
 
 
+def bench_ea_random(L=64, D=3, beta=1.0, sweeps=8, seed=0x5EED):
+    """GraphEA(64, 3) (BASELINE.json configs[3]'s lattice, N = 262 144) under the reference's own random-site standardMC: the big-N
+    kernels (spins in HBM/L2).  python tools/bench_models.py ea_random 512 4096"""
+    pkg = entry.load_package()
+    X = pkg.GraphEA(L, D, seed=seed)
+    for R in ([int(a) for a in sys.argv[2:]] or [512, 4096]):
+        eng = pkg.Engine(X, R)
+        eng.seed(seed)
+        eng.init_spins_random()
+        iters = sweeps * X.N
+        eng.standard_mc_async(beta, X.N, X.N); eng.sync()
+        t0 = time.perf_counter()
+        eng.standard_mc_async(beta, iters, X.N); eng.sync()
+        dt = time.perf_counter() - t0
+        total_ms, sweep_ms, nl = eng.last_timing()
+        Es, acc = eng.fetch_results()
+        print(json.dumps({"model": "GraphEA random-site standardMC (big-N kernels)", "L": L, "D": D, "replicas": R, "beta": beta,
+                          "iters": iters, "attempts_per_s": float(R) * iters / dt, "sweep_kernel_ms": sweep_ms, "launches": nl,
+                          "acceptance": float(acc.mean()) / iters, "energy_per_spin": float(Es[:, -1].mean()) / X.N}), flush=True)
+        eng.close()
+
+
 if __name__ == "__main__":
     which = sys.argv[1] if len(sys.argv) > 1 else "sk"
-    {"sk": bench_sk, "ea": bench_ea, "quant": bench_quant, "spf": bench_spf, "dbl": bench_dbl}[which]()
+    {"sk": bench_sk, "ea": bench_ea, "quant": bench_quant, "spf": bench_spf, "dbl": bench_dbl, "ea_random": bench_ea_random}[which]()
