@@ -224,6 +224,8 @@ RRRMC_API int32_t rrrmc_gen_couplings_gauss(int64_t N, int64_t K, const int32_t 
  *   ea_form    0: GraphRRG conventions (neighbors = non-zero couplings, RRG.jl:133), 1: GraphEA (repeats removed, EA.jl:158)
  * Sampler: rrrmc_rrr_mc_async (rrrMC(X::DoubleGraph), src/RRRMC.jl:221-290; fourK ignored); results through
  * rrrmc_fetch_results_f64 / rrrmc_rrr_stats; rrrmc_rrr_cache returns pos[R*N] and sizes[R*16] (class k of replica r at 16 r + k, k < 2L); energy through rrrmc_energy_f64.
+ * rrrmc_bkl_mc_async / rrrmc_wtm_mc_async run bklMC / wtmMC with the continuous-energy caches over the whole graph (a DoubleGraph
+ * is not a DiscrGraph: DeltaE.jl:315) and neighbors(X, i) = A[i] (RRG.jl:499) / uA[i] (EA.jl:529).
  * rrrmc_standard_mc_async / rrrmc_standard_mc_f64 run standardMC (src/RRRMC.jl:81-127) with
  * delta_energy = convert(Float64, dE0 + dE1) (RRG.jl:493-497, EA.jl:523-527).
  *

@@ -679,6 +679,30 @@ def cont_sparse(mode, A, J, beta, iters, step, seed, chunks, it0=0, call=0, repl
     return Es[:n], ch, stats, t.value
 
 
+def cont_double(mode, A, dJ, rJ, beta, iters, step, seed, chunks, it0=0, call=0, replica=0, stepf=1.0, form="rrg", mul=1, div=1.0):
+    """bklMC ("bkl") / wtmMC ("wtm") on Graph{RRG,EA}NormalDiscretized: the continuous-energy caches over the whole DoubleGraph.
+    Returns (Es, chunks, stats[3], t)."""
+    L = lib()
+    L.orc_cont_double.restype = C.c_int64
+    L.orc_cont_double.argtypes = [C.c_int, C.c_int, C.c_int64, C.c_int64, i32p, i32p, f64p, C.c_int64, C.c_double, C.c_double, C.c_int64,
+                                  C.c_int64, C.c_double, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, u64p, f64p, i64p,
+                                  C.POINTER(C.c_double)]
+    A = np.ascontiguousarray(A, np.int32)
+    N, K = A.shape
+    ch = np.array(chunks, np.uint64, copy=True)
+    m = {"bkl": 1, "wtm": 2}[mode]
+    nmax = iters if m == 2 else max(iters // step, 1)
+    Es = np.zeros(max(nmax, 1))
+    stats = np.zeros(3, np.int64)
+    t = C.c_double(0)
+    n = L.orc_cont_double(m, 1 if form == "ea" else 0, N, K, A, np.ascontiguousarray(dJ, np.int32).reshape(-1),
+                          np.ascontiguousarray(rJ, np.float64).reshape(-1), int(mul), float(div), float(beta), int(iters), int(step),
+                          float(stepf), seed, it0, call, replica, ch, Es, stats, C.byref(t))
+    if n < 0:
+        raise RuntimeError("cont_double: DynamicSampler lost precision")
+    return Es[:n], ch, stats, t.value
+
+
 def bkl_mc_skn(J, beta, iters, step, seed, chunks, it0=0, replica=0):
     """bklMC on GraphSKNormal (continuous-energy cache); returns (Es, chunks, moves, iterations done)."""
     L = lib()

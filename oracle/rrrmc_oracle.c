@@ -531,6 +531,11 @@ typedef struct {
     double *lfields, *lfields_last;
     int64_t move_last;
     int ea_form;
+    /* DoubleGraph view (Graph{RRG,EA}NormalDiscretized under the continuous-energy samplers): the inner DiscrGraph X0 whose
+     * integer delta_energy is added — promoted to Float64 — to the residual one (RRG.jl:493-497); NULL for the plain Float64 graphs */
+    sparse_t *X0;
+    int64_t lev_mul;
+    double lev_div;
 } spf_t;
 
 /* energy: RRG.jl:546-574 / EA.jl:584-611 */
@@ -594,7 +599,7 @@ static void spf_update_cache(spf_t *X, const uint64_t *s, int64_t move)
 
 ORC_API double orc_spf_energy(int form, int64_t N, int64_t K, const int32_t *A, const double *J, const uint64_t *chunks, double *lfields_out)
 {
-    spf_t X = {N, K, A, J, NULL, NULL, -1, form};
+    spf_t X = {N, K, A, J, NULL, NULL, -1, form, NULL, 1, 1.0};
     X.lfields = (double *)malloc((size_t)N * sizeof(double));
     X.lfields_last = (double *)malloc((size_t)N * sizeof(double));
     double E = spf_energy(&X, chunks);
@@ -609,7 +614,7 @@ ORC_API int64_t orc_standard_mc_spf(int form, int64_t N, int64_t K, const int32_
                                     int64_t step, uint64_t seed, uint64_t it0, uint32_t replica,
                                     uint64_t *chunks, double *Es, int64_t *accepted_out, double *lfields_out)
 {
-    spf_t X = {N, K, A, J, NULL, NULL, -1, form};
+    spf_t X = {N, K, A, J, NULL, NULL, -1, form, NULL, 1, 1.0};
     X.lfields = (double *)malloc((size_t)N * sizeof(double));
     X.lfields_last = (double *)malloc((size_t)N * sizeof(double));
     double E = spf_energy(&X, chunks);
@@ -1788,7 +1793,7 @@ ORC_API double orc_dbl_energy_scaled(int form, int64_t N, int64_t K, const int32
                                      int64_t mul, double div)
 {
     sparse_t X0 = {N, K, A, dJ, NULL, NULL, -1, form};
-    spf_t X1 = {N, K, A, rJ, NULL, NULL, -1, form};
+    spf_t X1 = {N, K, A, rJ, NULL, NULL, -1, form, NULL, 1, 1.0};
     X0.lfields = (int64_t *)malloc((size_t)N * 8); X0.lfields_last = (int64_t *)malloc((size_t)N * 8);
     X1.lfields = (double *)malloc((size_t)N * 8); X1.lfields_last = (double *)malloc((size_t)N * 8);
     const int64_t E0 = sparse_energy(&X0, chunks);
@@ -1811,7 +1816,7 @@ ORC_API int64_t orc_rrr_double_sparse_scaled(int form, int64_t N, int64_t K, con
     const int64_t L = orc_all_delta_e(K, lev, nlev, dElist, SL_MAX);
     if (L < 1) return -2;
     sparse_t X0 = {N, K, A, dJ, NULL, NULL, -1, form};
-    spf_t X1 = {N, K, A, rJ, NULL, NULL, -1, form};
+    spf_t X1 = {N, K, A, rJ, NULL, NULL, -1, form, NULL, 1, 1.0};
     X0.lfields = (int64_t *)malloc((size_t)N * 8); X0.lfields_last = (int64_t *)malloc((size_t)N * 8);
     X1.lfields = (double *)malloc((size_t)N * 8); X1.lfields_last = (double *)malloc((size_t)N * 8);
     double E = lev_to_f64(sparse_energy(&X0, chunks), mul, div);
@@ -1874,7 +1879,7 @@ ORC_API int64_t orc_standard_mc_dbl(int form, int64_t N, int64_t K, const int32_
                                     uint32_t replica, uint64_t *chunks, double *Es, int64_t *accepted_out)
 {
     sparse_t X0 = {N, K, A, dJ, NULL, NULL, -1, form};
-    spf_t X1 = {N, K, A, rJ, NULL, NULL, -1, form};
+    spf_t X1 = {N, K, A, rJ, NULL, NULL, -1, form, NULL, 1, 1.0};
     X0.lfields = (int64_t *)malloc((size_t)N * 8); X0.lfields_last = (int64_t *)malloc((size_t)N * 8);
     X1.lfields = (double *)malloc((size_t)N * 8); X1.lfields_last = (double *)malloc((size_t)N * 8);
     double E = lev_to_f64(sparse_energy(&X0, chunks), mul, div);
@@ -2092,8 +2097,17 @@ static int spf_neighbors(const spf_t *X, int64_t i, int64_t *out)
     }
     return n;
 }
-static inline void spf_spinflip(spf_t *X, uint64_t *s, int64_t i) { bitflip(s, i); spf_update_cache(X, s, i); }
-static inline double spf_dE(const spf_t *X, int64_t i) { return -X->lfields[i]; }                /* RRG.jl:619-625 */
+static inline void spf_spinflip(spf_t *X, uint64_t *s, int64_t i)
+{
+    bitflip(s, i);
+    if (X->X0) sparse_update_cache(X->X0, s, i);
+    spf_update_cache(X, s, i);
+}
+static inline double spf_dE(const spf_t *X, int64_t i)                                          /* RRG.jl:619-625; DoubleGraph: :493-497 */
+{
+    if (X->X0) return lev_to_f64(sparse_delta_energy(X->X0, i), X->lev_mul, X->lev_div) + (-X->lfields[i]);
+    return -X->lfields[i];
+}
 /* apply_move!(X, C, move, cache::DeltaECacheCont): DeltaE.jl:376-410; returns c = z / z' */
 static double cont_apply_move(spf_t *X, uint64_t *s, dyns_t *ds, double *dEs, double beta, int64_t move)
 {
@@ -2111,15 +2125,26 @@ static double cont_apply_move(spf_t *X, uint64_t *s, dyns_t *ds, double *dEs, do
     return z / ds->z;
 }
 
-ORC_API int64_t orc_cont_sparse(int mode, int form, int64_t N, int64_t K, const int32_t *A, const double *J, double beta,
+static int64_t cont_sparse_impl(int mode, int form, int64_t N, int64_t K, const int32_t *A, const double *J,
+                                const int32_t *dJ, int64_t mul, double div, double beta,
                                 int64_t iters, int64_t step, double stepf, double staged_thr, double staged_thr_fact,
                                 uint64_t seed, uint64_t it0, uint32_t call, uint32_t replica,
                                 uint64_t *chunks, double *Es, int64_t *stats, double *t_out)
 {
-    spf_t X = {N, K, A, J, NULL, NULL, -1, form};
+    spf_t X = {N, K, A, J, NULL, NULL, -1, form, NULL, 1, 1.0};
     X.lfields = (double *)malloc((size_t)N * 8);
     X.lfields_last = (double *)malloc((size_t)N * 8);
-    double E = spf_energy(&X, chunks);
+    sparse_t X0 = {N, K, A, dJ, NULL, NULL, -1, form};
+    double E = 0.0;
+    if (dJ) {                                                  /* energy(X::DoubleGraph, C) = convert(Float64, E0 + E1): RRG.jl:326-360 */
+        X0.lfields = (int64_t *)malloc((size_t)N * 8);
+        X0.lfields_last = (int64_t *)malloc((size_t)N * 8);
+        X.X0 = &X0; X.lev_mul = mul; X.lev_div = div;
+        E = lev_to_f64(sparse_energy(&X0, chunks), mul, div);
+        E = E + spf_energy(&X, chunks);
+    } else {
+        E = spf_energy(&X, chunks);
+    }
     int64_t accepted = 0, second = 0, nsamp = 0, itdone = 0, bad = 0;
     double t = 0.0;
     if (mode == 2) {
@@ -2245,7 +2270,27 @@ ORC_API int64_t orc_cont_sparse(int mode, int form, int64_t N, int64_t K, const 
     if (stats) { stats[0] = accepted; stats[1] = second; stats[2] = itdone; }
     if (t_out) *t_out = t;
     free(X.lfields); free(X.lfields_last);
+    if (dJ) { free(X0.lfields); free(X0.lfields_last); }
     return bad ? -1 : nsamp;
+}
+ORC_API int64_t orc_cont_sparse(int mode, int form, int64_t N, int64_t K, const int32_t *A, const double *J, double beta,
+                                int64_t iters, int64_t step, double stepf, double staged_thr, double staged_thr_fact,
+                                uint64_t seed, uint64_t it0, uint32_t call, uint32_t replica,
+                                uint64_t *chunks, double *Es, int64_t *stats, double *t_out)
+{
+    return cont_sparse_impl(mode, form, N, K, A, J, NULL, 1, 1.0, beta, iters, step, stepf, staged_thr, staged_thr_fact, seed, it0, call,
+                            replica, chunks, Es, stats, t_out);
+}
+/* bklMC / wtmMC on the discretised DoubleGraphs: for a graph that is not a DiscrGraph the reference builds the continuous-energy
+ * caches over the WHOLE graph (gen_ΔEcache(X::AbstractGraph, ...) -> DeltaECacheCont, DeltaE.jl:315; THeap), with
+ * delta_energy(X, C, i) = convert(Float64, dE0 + dE1) (RRG.jl:493-497) and neighbors(X, i) = A[i] (RRG.jl:499) / uA[i] (EA.jl:529). */
+ORC_API int64_t orc_cont_double(int mode, int form, int64_t N, int64_t K, const int32_t *A, const int32_t *dJ, const double *rJ,
+                                int64_t mul, double div, double beta, int64_t iters, int64_t step, double stepf,
+                                uint64_t seed, uint64_t it0, uint32_t call, uint32_t replica,
+                                uint64_t *chunks, double *Es, int64_t *stats, double *t_out)
+{
+    return cont_sparse_impl(mode, form, N, K, A, rJ, dJ, mul, div, beta, iters, step, stepf, 0.8, 5.0, seed, it0, call, replica, chunks, Es,
+                            stats, t_out);
 }
 
 /* bklMC (src/RRRMC.jl:311-359) on GraphSKNormal with DeltaECacheCont: rand_skip (DeltaE.jl:319-325),

@@ -21,7 +21,10 @@ constexpr int kContKmax = 8;
 
 struct ContParams {
     const int32_t* A;        // [N][K]
-    const double* J;         // [N][K]
+    const double* J;         // [N][K]   couplings (GraphRRGNormal / GraphEANormal) or the residuals rJ of a discretised DoubleGraph
+    const int8_t* dJ;        // [N][K]   DoubleGraph only: the level part, in level units (null otherwise); its delta_energy, promoted to
+    long long lev_mul;       //          Float64 as (units * lev_mul) / lev_div, is added to the residual one (RRG.jl:493-497)
+    double lev_div;
     uint32_t* spins;         // [R][W]
     double* lf;              // [R][N]   local fields
     double* undo;            // [R][K+1]
@@ -86,7 +89,23 @@ struct ContChain {
         lf[move] = -lfm;
         mlast = move;
     }
-    __device__ __forceinline__ double dE(int i) const { return -lf[i]; }          // RRG.jl:619-625
+    // delta_energy(X0, C, i) of the inner DiscrGraph (RRG.jl:236-244 / EA.jl:266-275), recomputed from the spins
+    __device__ __forceinline__ long long dE0(int i) const
+    {
+        const int si = sbit(i);
+        int acc = 0;
+        for (int q = 0; q < P->K; ++q) {
+            const int sy = sbit(P->A[(size_t)i * P->K + q]);
+            const int j = (int)P->dJ[(size_t)i * P->K + q];
+            acc += (si == sy) ? j : -j;
+        }
+        return 2 * acc;
+    }
+    __device__ __forceinline__ double dE(int i) const          // RRG.jl:619-625; DoubleGraph: convert(Float64, dE0 + dE1), :493-497
+    {
+        if (P->dJ) return (double)(dE0(i) * P->lev_mul) / P->lev_div + (-lf[i]);
+        return -lf[i];
+    }
 
     // ---- DynamicSampler (DynamicSamplers.jl:84-176) ----
     __device__ void refresh()
@@ -232,6 +251,11 @@ __global__ __launch_bounds__(kRrrThreads) void cont_sparse_kernel(ContParams P)
         c.lf[i] = 2.0 * fl;
     }
     double E = E1 / 2;
+    if (P.dJ) {                                  // energy(X::DoubleGraph, C) = convert(Float64, E0 + E1): RRG.jl:326-360
+        long long n0 = 0;
+        for (int i = 0; i < N; ++i) n0 -= c.dE0(i) / 2;
+        E = (double)((n0 / 2) * P.lev_mul) / P.lev_div + E;
+    }
     long long accepted = 0, second = 0, ns = 0, itdone = 0;
     int bad = 0;
     double t = 0.0;

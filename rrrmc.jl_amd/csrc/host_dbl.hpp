@@ -39,11 +39,11 @@ int32_t dbl_ctx_create(rrrmc_ctx** out, int64_t N, int64_t K, int64_t R, int32_t
     DB_TRY(hipMalloc(&ctx->db_spos, sizeof(uint16_t) * (size_t)R * N));
     DB_TRY(hipMalloc(&ctx->db_lf, sizeof(double) * (size_t)R * N));
     DB_TRY(hipMalloc(&ctx->db_undo, sizeof(double) * (size_t)R * (K + 1)));
-    DB_TRY(hipMalloc(&ctx->q_stats, sizeof(int64_t) * R * 2));
+    DB_TRY(hipMalloc(&ctx->q_stats, sizeof(int64_t) * R * 3));          // rrrMC / standardMC use a stride of 2, bklMC / wtmMC of 3
     DB_TRY(hipMalloc(&ctx->sk_E, sizeof(double) * R));
     DB_TRY(hipMalloc(&ctx->d_acc, sizeof(int64_t) * R));
     DB_TRY(hipMemset(ctx->q_spins, 0, sizeof(uint32_t) * R * ctx->qW));
-    DB_TRY(hipMemset(ctx->q_stats, 0, sizeof(int64_t) * R * 2));
+    DB_TRY(hipMemset(ctx->q_stats, 0, sizeof(int64_t) * R * 3));
 #undef DB_TRY
     *out = ctx;
     return RRRMC_OK;

@@ -139,12 +139,14 @@ int32_t spf_cont_async(rrrmc_ctx* ctx, int mode, double beta, int64_t iters, int
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     ctx->results_valid = false; ctx->last_call_wtm = false; ctx->last_call_eo = false;
     ctx->timing_valid = false;
-    const int64_t N = ctx->N, K = ctx->K, R = ctx->R, W = (N + 31) / 32;
+    // the discretised DoubleGraphs (bklMC / wtmMC over the whole graph: DeltaE.jl:315) keep their spins in the kernel's layout already
+    const bool dblm = ctx->model == RRRMC_MODEL_SPARSE_DISCRETIZED;
+    const int64_t N = ctx->N, K = ctx->K, R = ctx->R, W = dblm ? ctx->qW : (N + 31) / 32;
     int levs = 0;
     while (((int64_t)1 << levs) < N) ++levs;
     const int64_t N2 = (int64_t)1 << levs;
     if (!ctx->cs_buf) {
-        HIP_TRY(ctx, hipMalloc(&ctx->cs_spins, sizeof(uint32_t) * R * W));
+        if (!dblm) HIP_TRY(ctx, hipMalloc(&ctx->cs_spins, sizeof(uint32_t) * R * W));
         HIP_TRY(ctx, hipMalloc(&ctx->cs_buf, sizeof(double) * (size_t)R * (size_t)(2 * N + 2 * N2 + K + 1)));
         HIP_TRY(ctx, hipMalloc(&ctx->cs_u16, sizeof(uint16_t) * (size_t)R * 2 * N));
         HIP_TRY(ctx, hipMalloc(&ctx->rs_status, sizeof(int32_t) * R));
@@ -166,7 +168,8 @@ int32_t spf_cont_async(rrrmc_ctx* ctx, int mode, double beta, int64_t iters, int
     }
     ContParams P{};
     double* b = ctx->cs_buf;
-    P.A = ctx->d_A; P.J = ctx->pf_J; P.spins = ctx->cs_spins;
+    P.A = ctx->d_A; P.J = dblm ? ctx->db_rJ : ctx->pf_J; P.spins = dblm ? ctx->q_spins : ctx->cs_spins;
+    P.dJ = dblm ? ctx->db_dJ : nullptr; P.lev_mul = ctx->db_lev_mul; P.lev_div = ctx->db_lev_div;
     P.lf = b; b += (size_t)R * N;
     P.dEs = b; b += (size_t)R * N;
     P.v = b; b += (size_t)R * N2;
@@ -182,17 +185,22 @@ int32_t spf_cont_async(rrrmc_ctx* ctx, int mode, double beta, int64_t iters, int
     P.mode = mode;
     hipStream_t st = ctx->stream;
     HIP_TRY(ctx, hipEventRecord(ctx->ev_begin, st));
-    hipLaunchKernelGGL(cont_spins_in_kernel, dim3((unsigned)((W + 255) / 256), (unsigned)R), dim3(256), 0, st, ctx->pf_spins, ctx->cs_spins, (int)N, (int)W, (int)R);
-    HIP_TRY(ctx, hipGetLastError());
+    if (!dblm) {
+        hipLaunchKernelGGL(cont_spins_in_kernel, dim3((unsigned)((W + 255) / 256), (unsigned)R), dim3(256), 0, st, ctx->pf_spins, ctx->cs_spins, (int)N, (int)W, (int)R);
+        HIP_TRY(ctx, hipGetLastError());
+    }
     HIP_TRY(ctx, hipEventRecord(ctx->ev_sweep[0], st));
     hipLaunchKernelGGL(cont_sparse_kernel, dim3(rrr_blocks(R)), dim3(rrr_tpb(R)), 0, st, P);
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipEventRecord(ctx->ev_sweep[1], st));
-    hipLaunchKernelGGL(cont_spins_out_kernel, dim3((unsigned)((N + 255) / 256), (unsigned)ctx->pfW), dim3(256), 0, st, ctx->cs_spins, ctx->pf_spins, (int)N, (int)W, (int)R);
-    HIP_TRY(ctx, hipGetLastError());
+    if (!dblm) {
+        hipLaunchKernelGGL(cont_spins_out_kernel, dim3((unsigned)((N + 255) / 256), (unsigned)ctx->pfW), dim3(256), 0, st, ctx->cs_spins, ctx->pf_spins, (int)N, (int)W, (int)R);
+        HIP_TRY(ctx, hipGetLastError());
+    }
     HIP_TRY(ctx, hipEventRecord(ctx->ev_end, st));
     if (mode == 2) ctx->wtm_calls += 1; else ctx->it_done += (uint64_t)iters;
     ctx->pf_lf_live = false;
+    ctx->db_cache_valid = false;
     ctx->stats_stride = 3;
     ctx->sweep_launches = 1;
     ctx->nsamp = nsamp;

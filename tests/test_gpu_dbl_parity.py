@@ -106,6 +106,42 @@ def test_standard_mc_double_graph_bit_exact(pkg, oracle, kind, lev, R, beta, ite
         assert E2[r] == oracle.dbl_energy(X.A, X.dJ, X.rJ, C2.s[r], form=form, **sc)
 
 
+@pytest.mark.parametrize("kind,lev,R,beta", [
+    ("rrg10", (-1, 0, 1), 40, 2.0),                       # runtests.jl:41 under bklMC / wtmMC (:145-151)
+    ("rrg300k3", (-1.5, -0.5, 0.5, 1.5), 33, 1.0),        # DFloat64 levels
+    ("ea2x3", (-1, 0, 1), 16, 1.0),                       # runtests.jl:51: double bonds, neighbors = uA
+    ("ea8x3", (-1.25, 0.0, 1.25), 20, 1.5),
+])
+def test_bkl_and_wtm_on_double_graphs(pkg, oracle, kind, lev, R, beta):
+    """A DoubleGraph is not a DiscrGraph: bklMC and wtmMC build the continuous-energy caches over the whole graph (DeltaE.jl:315,
+    WaitingTimes.jl) with delta_energy = convert(Float64, dE0 + dE1) (RRG.jl:493-497)."""
+    seed = 888000 + len(kind) + R
+    X, form = _graph(pkg, kind, lev, seed)
+    units, mul, div = oracle.dfloat_units(lev)
+    sc = dict(mul=mul, div=div)
+    iters, step, samples = 20000, 500, 40
+    with pkg.Engine(X, R) as eng:
+        eng.seed(seed)
+        eng.init_spins_random()
+        C0 = eng.get_config()
+        Eb, mb = eng.bkl_mc(beta, iters, step)
+        C1 = eng.get_config()
+        E1 = eng.energy()
+        eng.seed(seed)
+        eng.set_config(C0)
+        Ew, mw, tw = eng.wtm_mc(beta, samples, step=2.0)
+        C2 = eng.get_config()
+        Er, ar, st = eng.rrr_mc(beta, 2000, 100)             # the DoubleGraph rrrMC still works after the other samplers
+    for r in range(R):
+        b = oracle.cont_double("bkl", X.A, X.dJ, X.rJ, beta, iters, step, seed, C0.s[r], replica=r, form=form, **sc)
+        assert (Eb[r] == b[0]).all() and (C1.s[r] == b[1]).all() and mb[r] == b[2][0]
+        assert E1[r] == oracle.dbl_energy(X.A, X.dJ, X.rJ, C1.s[r], form=form, **sc)
+        w = oracle.cont_double("wtm", X.A, X.dJ, X.rJ, beta, samples, 1, seed, C0.s[r], replica=r, stepf=2.0, form=form, **sc)
+        assert (Ew[r] == w[0]).all() and (C2.s[r] == w[1]).all() and mw[r] == w[2][0] and tw[r] == w[3]
+        ref = oracle.rrr_double_sparse(X.A, X.dJ, X.rJ, units, beta, 2000, 100, seed, w[1], replica=r, form=form, **sc)
+        assert (Er[r] == ref[0]).all() and ar[r] == ref[2]
+
+
 def test_dfloat_unit_levels_equal_int_levels(pkg):
     """Float64 levels (-1.0, 0.0, 1.0) -> DFloat64 t = (-10^5, 0, 10^5): every promoted value t / 10^5 is the integer itself, so the
     trajectories equal those of Int levels (-1, 0, 1) bit for bit."""

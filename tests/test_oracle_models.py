@@ -414,3 +414,23 @@ def test_quant_standard_mc_tracked_energy(oracle):
     for k in (2, 77, 1234, 5000):
         _, ck, _ = oracle.standard_mc_quant(A, J, M, fourK, beta, k - 1, 1, seed, ch)
         assert abs(Es[k - 1] - oracle.quant_energy(A, J, M, fourK, ck)[0]) < 1e-11
+
+
+@pytest.mark.parametrize("form,lev", [("rrg", (-1, 0, 1)), ("ea", (-0.75, 0.0, 0.75))])
+def test_double_graph_bkl_wtm_tracked_energy(oracle, form, lev):
+    """bklMC / wtmMC on the discretised DoubleGraphs (runtests.jl:41,61 x :145-151): the tracked energy stays equal to energy(X, C)."""
+    seed = 654
+    A = oracle.gen_rrg(10, 3, seed) if form == "rrg" else oracle.gen_ea(3, 2)
+    cJ = oracle.gen_couplings_gauss(A, seed)
+    units, mul, div = oracle.dfloat_units(lev)
+    dJ, rJ = oracle.discretize(cJ, units, mul, div)
+    ch = oracle.init_config(seed, 0, A.shape[0])
+    sc = dict(mul=mul, div=div)
+    for n in (1, 7, 300):
+        Es, c1, stats, _ = oracle.cont_double("bkl", A, dJ, rJ, 1.1, n * 50, 50, seed, ch, form=form, **sc)
+        assert len(Es) == n
+    Es, c1, stats, t = oracle.cont_double("wtm", A, dJ, rJ, 1.1, 60, 1, seed, ch, stepf=1.0, form=form, **sc)
+    assert len(Es) == 60 and stats[0] > 0 and t > 0
+    # the waiting-time chain's last sample precedes its last moves: replay a prefix that ends on a sample and compare energies
+    Es_f, cf, st_f, _ = oracle.cont_sparse("wtm", A, cJ, 1.1, 60, 1, seed, ch, stepf=1.0, form=form)
+    assert np.allclose(Es_f, Es, rtol=0, atol=1e-9)                    # same chain as the undiscretised couplings, up to rounding
