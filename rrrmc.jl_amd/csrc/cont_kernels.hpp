@@ -295,8 +295,9 @@ __global__ __launch_bounds__(kRrrThreads) void cont_sparse_kernel(ContParams P)
         c.refresh();
         if (P.mode == 0) {
             double acc_rate = 0.5;
+            long long next_sample = P.step;          // iterations k * step: a counter instead of a 64-bit modulo per iteration
             for (long long it = 1; it <= P.iters && !bad; ++it) {
-                if (it % P.step == 0) { P.Es[(size_t)ns * P.Rp + r] = E; ns += 1; }
+                if (it == next_sample) { next_sample += P.step; P.Es[(size_t)ns * P.Rp + r] = E; ns += 1; }
                 const uint64_t g = P.g0 + (uint64_t)it;
                 const Philox4 o = philox4x32_10((uint32_t)g, (uint32_t)(g >> 32), c.rep, TAG_RRR, P.k0, P.k1);
                 const double u0 = (double)((((uint64_t)o.w[0] << 32) | o.w[1]) >> 11) * 0x1.0p-53;

@@ -204,8 +204,9 @@ __global__ __launch_bounds__(kRrrThreads) void dbl_standard_kernel(RrrDblParams 
     double E = dbl_init_chain(c, P, r, false);
     const uint32_t rep = P.replica0 + (uint32_t)r;
     long long accepted = 0, ns = 0;
+    long long next_sample = P.step;          // iterations k * step: a counter instead of a 64-bit modulo per iteration
     for (long long it = 1; it <= P.iters; ++it) {
-        if (it % P.step == 0) { P.Es[(size_t)ns * P.R + r] = E; ns += 1; }
+        if (it == next_sample) { next_sample += P.step; P.Es[(size_t)ns * P.R + r] = E; ns += 1; }
         const uint64_t g = P.g0 + (uint64_t)it;
         const int move = (int)site_of(P.k0, P.k1, g, (uint32_t)P.N);
         const double dE = P.to_f64(c.dE0(move)) + (-c.lf[move]);
@@ -232,8 +233,9 @@ __global__ __launch_bounds__(kRrrThreads) void rrr_dbl_kernel(RrrDblParams P)
     const uint32_t rep = P.replica0 + (uint32_t)r;
     long long accepted = 0, staged_its = 0, ns = 0;
     double acc_rate = 0.5;
+    long long next_sample = P.step;          // iterations k * step: a counter instead of a 64-bit modulo per iteration
     for (long long it = 1; it <= P.iters; ++it) {
-        if (it % P.step == 0) { P.Es[(size_t)ns * P.R + r] = E; ns += 1; }
+        if (it == next_sample) { next_sample += P.step; P.Es[(size_t)ns * P.R + r] = E; ns += 1; }
         const uint64_t g = P.g0 + (uint64_t)it;
         // rand_move: DeltaE.jl:146-167
         const Philox4 o = philox4x32_10((uint32_t)g, (uint32_t)(g >> 32), rep, TAG_RRR, P.k0, P.k1);

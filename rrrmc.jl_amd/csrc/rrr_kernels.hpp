@@ -211,8 +211,9 @@ __global__ __launch_bounds__(kRrrThreads) void rrr_quant_kernel(RrrParams P)
     int64_t ns = 0;
     const double dEl[2] = {0.0, P.fourK};
 
+    long long next_sample = P.step;          // iterations k * step: a counter instead of a 64-bit modulo per iteration
     for (int64_t it = 1; it <= P.iters; ++it) {
-        if (it % P.step == 0) { P.Es[ns * P.R + r] = E; ns += 1; }
+        if (it == next_sample) { next_sample += P.step; P.Es[ns * P.R + r] = E; ns += 1; }
         const uint64_t g = P.g0 + (uint64_t)it;
         // rand_move: DeltaE.jl:146-167
         const Philox4 o = philox4x32_10((uint32_t)g, (uint32_t)(g >> 32), rep, TAG_RRR, P.k0, P.k1);
@@ -343,8 +344,9 @@ __global__ __launch_bounds__(kRrrThreads) void quant_standard_kernel(RrrParams P
     const uint32_t rep = P.replica0 + (uint32_t)r;
     double E = P.E_cur[r];
     int64_t accepted = 0, ns = 0;
+    long long next_sample = P.step;          // iterations k * step: a counter instead of a 64-bit modulo per iteration
     for (int64_t it = 1; it <= P.iters; ++it) {
-        if (it % P.step == 0) { P.Es[ns * P.R + r] = E; ns += 1; }
+        if (it == next_sample) { next_sample += P.step; P.Es[ns * P.R + r] = E; ns += 1; }
         const uint64_t g = P.g0 + (uint64_t)it;
         const int move = (int)site_of(P.k0, P.k1, g, (uint32_t)P.N);
         const double dE = (double)qt_delta(v, move) * P.fourK + (double)slice_delta(v, move) / (double)P.M;
@@ -572,8 +574,9 @@ __global__ __launch_bounds__(kRrrThreads) void rrr_skn_kernel(RrrSkParams P)
         }
         staged_its = accepted;
     }
+    long long next_sample = P.step;          // iterations k * step: a counter instead of a 64-bit modulo per iteration
     for (long long it = 1; P.mode == 0 && it <= P.iters && !bad; ++it) {
-        if (it % P.step == 0) { P.Es[(size_t)ns * Rp + r] = E; ns += 1; }
+        if (it == next_sample) { next_sample += P.step; P.Es[(size_t)ns * Rp + r] = E; ns += 1; }
         const uint64_t g = P.g0 + (uint64_t)it;
         const Philox4 o = philox4x32_10((uint32_t)g, (uint32_t)(g >> 32), rep, TAG_RRR, P.k0, P.k1);
         const double u0 = (double)((((uint64_t)o.w[0] << 32) | o.w[1]) >> 11) * 0x1.0p-53;
@@ -802,8 +805,9 @@ __global__ __launch_bounds__(kRrrThreads) void rrr_sparse_kernel(RrrSparseParams
     long long accepted = 0, staged_its = 0, ns = 0, itdone = 0;
     if (P.mode == 0) {
         double acc_rate = 0.5;
+        long long next_sample = P.step;          // iterations k * step: a counter instead of a 64-bit modulo per iteration
         for (long long it = 1; it <= P.iters; ++it) {
-            if (it % P.step == 0) { P.Es[(size_t)ns * P.Rpad + r] = (int32_t)E; ns += 1; }
+            if (it == next_sample) { next_sample += P.step; P.Es[(size_t)ns * P.Rpad + r] = (int32_t)E; ns += 1; }
             const uint64_t g = P.g0 + (uint64_t)it;
             const Philox4 o = philox4x32_10((uint32_t)g, (uint32_t)(g >> 32), rep, TAG_RRR, P.k0, P.k1);
             const Philox4 o2 = philox4x32_10((uint32_t)g, (uint32_t)(g >> 32), rep, TAG_RRR | (1u << 8), P.k0, P.k1);
@@ -1096,8 +1100,9 @@ __global__ __launch_bounds__(kRrrThreads) void eo_sparse_kernel(EoParams P)
     for (int w = 0; w < P.W; ++w) cm[w] = sp[w];
     const double z = P.ftau[N - 1];
     const uint32_t rep = P.replica0 + (uint32_t)r;
+    long long next_sample = P.step;          // iterations k * step: a counter instead of a 64-bit modulo per iteration
     for (long long it = 1; it <= P.iters; ++it) {
-        if (it % P.step == 0) { P.Es[(size_t)ns * P.Rpad + r] = (int32_t)E; ns += 1; }
+        if (it == next_sample) { next_sample += P.step; P.Es[(size_t)ns * P.Rpad + r] = (int32_t)E; ns += 1; }
         const uint64_t g = P.g0 + (uint64_t)it;
         const Philox4 o = philox4x32_10((uint32_t)g, (uint32_t)(g >> 32), rep, TAG_RRR | (3u << 8), P.k0, P.k1);
         // rand_move: DeltaE.jl:473-507
@@ -1179,8 +1184,9 @@ __global__ __launch_bounds__(kRrrThreads) void lev_standard_kernel(LevStdParams 
     for (int i = 0; i < N; ++i) n -= dE_of(i) / 2;
     long long E = n / 2, accepted = 0, ns = 0;
     const uint32_t rep = P.replica0 + (uint32_t)r;
+    long long next_sample = P.step;          // iterations k * step: a counter instead of a 64-bit modulo per iteration
     for (long long it = 1; it <= P.iters; ++it) {
-        if (it % P.step == 0) { P.Es[(size_t)ns * P.Rpad + r] = (int32_t)E; ns += 1; }
+        if (it == next_sample) { next_sample += P.step; P.Es[(size_t)ns * P.Rpad + r] = (int32_t)E; ns += 1; }
         const uint64_t g = P.g0 + (uint64_t)it;
         const int move = (int)site_of(P.k0, P.k1, g, (uint32_t)N);
         const int d = dE_of(move);

@@ -120,6 +120,7 @@ __global__ __launch_bounds__(kSkThreads) void sk_sweep_kernel(SkParams P)
     for (int q = 0; q < SPT; ++q) { const int j = q * kSkThreads + tid; Jq[q] = j < N ? P.J[(size_t)site * N + j] : 0.0; }
 
     double u_acc = tid < kSkRB ? rand53(P.k0, P.k1, P.g0 + 1, P.replica0 + (uint32_t)(grp * kSkRB + tid)) : 0.0;   // ACCEPT_F64 uniform of iteration 1
+    long long next_sample = P.step;          // iterations k * step: a counter instead of a 64-bit modulo per iteration
     for (int64_t it = 1; it <= P.iters; ++it) {
         const int b = (int)(it & 1);
         const uint64_t g = P.g0 + (uint64_t)it;
@@ -142,7 +143,7 @@ __global__ __launch_bounds__(kSkThreads) void sk_sweep_kernel(SkParams P)
         if (tid < 64) {          // the first wave: lanes 0..7 decide, the whole wave ballots
             bool acc = false, swp = false;
             if (tid < kSkRB) {
-                if (it % P.step == 0) {          // sample BEFORE the move (RRRMC.jl:104-108)
+                if (it == next_sample) { next_sample += P.step;          // sample BEFORE the move (RRRMC.jl:104-108)
                     if (P.Es) P.Es[ns * Rp + grp * kSkRB + tid] = E_run;
                     ns += 1;
                 }
@@ -336,6 +337,7 @@ __global__ __launch_bounds__(kSkThreads) void skb_sweep_kernel(SkbParams P)
 #pragma unroll
     for (int q = 0; q < SPT; ++q) { const int j = q * kSkThreads + tid; Jq[q] = j < N ? (P.Jbits[(size_t)site * P.NW + (j >> 5)] >> (j & 31)) & 1u : 0u; }
 
+    long long next_sample = P.step;          // iterations k * step: a counter instead of a 64-bit modulo per iteration
     for (int64_t it = 1; it <= P.iters; ++it) {
         const int b = (int)(it & 1);
         const uint64_t g = P.g0 + (uint64_t)it;
@@ -357,7 +359,7 @@ __global__ __launch_bounds__(kSkThreads) void skb_sweep_kernel(SkbParams P)
         if (tid < 64) {
             bool acc = false, swp = false;
             if (tid < kSkRB) {
-                if (it % P.step == 0) {
+                if (it == next_sample) { next_sample += P.step;
                     if (P.Es) P.Es[ns * Rp + grp * kSkRB + tid] = E_run;
                     ns += 1;
                 }
