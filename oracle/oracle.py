@@ -703,6 +703,24 @@ def cont_double(mode, A, dJ, rJ, beta, iters, step, seed, chunks, it0=0, call=0,
     return Es[:n], ch, stats, t.value
 
 
+def wtm_mc_skn(J, beta, samples, step, seed, chunks, call=0, replica=0):
+    """wtmMC on GraphSKNormal; returns (Es, chunks, num_moves, t)."""
+    L = lib()
+    L.orc_wtm_mc_skn.restype = C.c_int64
+    L.orc_wtm_mc_skn.argtypes = [C.c_int64, f64p, C.c_double, C.c_int64, C.c_double, C.c_uint64, C.c_uint32, C.c_uint32, u64p, f64p, i64p,
+                                 C.POINTER(C.c_double)]
+    J = np.ascontiguousarray(J, np.float64)
+    N = J.shape[0]
+    ch = np.array(chunks, np.uint64, copy=True)
+    Es = np.zeros(max(samples, 1))
+    stats = np.zeros(2, np.int64)
+    t = C.c_double(0)
+    n = L.orc_wtm_mc_skn(N, J.reshape(-1), float(beta), int(samples), float(step), seed, call, replica, ch, Es, stats, C.byref(t))
+    if n < 0:
+        raise RuntimeError("wtm_mc_skn: tracked energy != energy(X, C)")
+    return Es[:n], ch, int(stats[0]), t.value
+
+
 def bkl_mc_skn(J, beta, iters, step, seed, chunks, it0=0, replica=0):
     """bklMC on GraphSKNormal (continuous-energy cache); returns (Es, chunks, moves, iterations done)."""
     L = lib()

@@ -2293,6 +2293,58 @@ ORC_API int64_t orc_cont_double(int mode, int form, int64_t N, int64_t K, const 
                             stats, t_out);
 }
 
+/* wtmMC (src/RRRMC.jl:376-426, src/WaitingTimes.jl) on GraphSKNormal: as orc_wtm_mc_sparse with delta_energy = +lfields[i]
+ * (SK.jl:278-284) and neighbors(X, i) = AllButOne (every other spin, in index order: SK.jl:297).  WTM stream: spin i's initial
+ * time is draw i, then one draw per updated spin in the order of update_heap! (the moved spin, then j = 0..N-1 except it). */
+ORC_API int64_t orc_wtm_mc_skn(int64_t N, const double *J, double beta, int64_t samples, double step, uint64_t seed, uint32_t call,
+                               uint32_t replica, uint64_t *chunks, double *Es, int64_t *stats, double *t_out)
+{
+    skn_t X = {N, J, NULL, NULL, -1};
+    X.lfields = (double *)malloc((size_t)N * 8);
+    X.lfields_last = (double *)malloc((size_t)N * 8);
+    double E = skn_energy(&X, chunks);
+    double *tm = (double *)malloc((size_t)N * sizeof(double));
+    uint64_t nd = 0;
+    for (int64_t i = 0; i < N; ++i) {
+        double e = orc_det_exp(beta * X.lfields[i]);
+        tm[i] = wtm_gen(e > 1.0 ? e : 1.0, wtm_uniform(seed, nd++, replica, call));
+    }
+    step /= (double)N;
+    const double tmax = step * (double)samples;
+    double t = 0.0, nextstep = step;
+    int64_t num_moves = 0, nsamp = 0;
+    int out = 0;
+    while (t < tmax && !out) {
+        int64_t move = 0;
+        for (int64_t i = 1; i < N; ++i) if (tm[i] < tm[move]) move = i;          /* pick_next: top_with_handle */
+        const double tp = tm[move];
+        while (tp >= nextstep) {
+            Es[nsamp++] = E;
+            nextstep += step;
+            if (nextstep > tmax + 1e-10) { out = 1; break; }
+        }
+        if (out) break;
+        t = tp;
+        const double dE = X.lfields[move];
+        bitflip(chunks, move);
+        skn_update_cache(&X, chunks, move);
+        for (int64_t q = -1; q < N; ++q) {                                       /* the moved spin first, then every other spin */
+            const int64_t j = q < 0 ? move : q;
+            if (q == move) continue;
+            double e = orc_det_exp(beta * X.lfields[j]);
+            tm[j] = t + wtm_gen(e > 1.0 ? e : 1.0, wtm_uniform(seed, nd++, replica, call));
+        }
+        E += dE;
+        num_moves += 1;
+    }
+    if (stats) { stats[0] = num_moves; stats[1] = nsamp; }
+    if (t_out) *t_out = t;
+    const double Echeck = skn_energy(&X, chunks);
+    int ok = fabs(Echeck - E) < 1e-9 * (1.0 + fabs(E));
+    free(tm); free(X.lfields); free(X.lfields_last);
+    return ok ? nsamp : -1;
+}
+
 /* bklMC (src/RRRMC.jl:311-359) on GraphSKNormal with DeltaECacheCont: rand_skip (DeltaE.jl:319-325),
  * rand_move, apply_step_bkl! = apply_move!(X, C, move, cache, Val{false}) (RRRMC.jl:294-295) over all N - 1 neighbours.
  * RRR stream sub 2 (skip), sub 0 (getel); g counts moves.  stats = [moves, moves, iterations done]. */

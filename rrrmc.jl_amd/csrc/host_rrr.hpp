@@ -47,10 +47,13 @@ int32_t quant_run_init(rrrmc_ctx* ctx, double beta, double fourK)
 
 
 // rrrMC(X::SingleGraph) on GraphSKNormal (RRRMC.jl:149-219): thread-per-replica kernel over interleaved arrays
-int32_t sk_rrr_mc_async(rrrmc_ctx* ctx, double beta, int64_t iters, int64_t step, double staged_thr, double staged_thr_fact, int mode = 0)
+// mode 0 = rrrMC(SingleGraph), 1 = bklMC, 2 = wtmMC (iters = samples, stepf = step in sweeps)
+int32_t sk_rrr_mc_async(rrrmc_ctx* ctx, double beta, int64_t iters, int64_t step, double staged_thr, double staged_thr_fact, int mode = 0, double stepf = 1.0)
 {
     if (iters < 0) return fail(ctx, RRRMC_ERR_INVALID_ARG, "iters must be >= 0, given %lld", (long long)iters);
     if (step < 1) return fail(ctx, RRRMC_ERR_INVALID_ARG, "step must be >= 1, given %lld", (long long)step);
+    if (mode == 2 && (!(stepf > 0.0) || !std::isfinite(stepf))) return fail(ctx, RRRMC_ERR_INVALID_ARG, "step must be positive and finite, given %g", stepf);
+    if (mode == 2 && ctx->N > 65535) return fail(ctx, RRRMC_ERR_UNSUPPORTED, "N=%lld: the wtmMC heap indexes spins with 16 bits", (long long)ctx->N);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     ctx->results_valid = false; ctx->last_call_wtm = false; ctx->last_call_eo = false;
     ctx->timing_valid = false;
@@ -66,7 +69,8 @@ int32_t sk_rrr_mc_async(rrrmc_ctx* ctx, double beta, int64_t iters, int64_t step
         HIP_TRY(ctx, hipMalloc(&ctx->rs_status, sizeof(int32_t) * per));
         HIP_TRY(ctx, hipMalloc(&ctx->q_stats, sizeof(int64_t) * per * 2));
     }
-    const int64_t nsamp = iters / step;
+    if (mode == 2 && !ctx->wt_time) HIP_TRY(ctx, hipMalloc(&ctx->wt_time, sizeof(double) * per));
+    const int64_t nsamp = mode == 2 ? iters : iters / step;
     const size_t es_need = (size_t)(nsamp > 0 ? nsamp : 1) * Rp;
     if (es_need > ctx->sk_Es_cap) {
         free_dev(ctx->sk_Es);
@@ -97,6 +101,7 @@ int32_t sk_rrr_mc_async(rrrmc_ctx* ctx, double beta, int64_t iters, int64_t step
     P.k0 = (uint32_t)ctx->seed; P.k1 = (uint32_t)(ctx->seed >> 32); P.replica0 = ctx->replica0;
     P.N = (int)N; P.N2 = (int)N2; P.levs = levs; P.W = (int)W; P.R = (int)ctx->R; P.Rp = (int)Rp;
     P.mode = mode;
+    P.call = ctx->wtm_calls & 0xffffffu; P.stepf = stepf; P.t_out = ctx->wt_time;
     ctx->stats_stride = 2;
     HIP_TRY(ctx, hipEventRecord(ctx->ev_begin, st));
     hipLaunchKernelGGL(rrsk_spins_in_kernel, dim3((unsigned)((Rp + 255) / 256), (unsigned)W), dim3(256), 0, st, ctx->sk_spins, ctx->rs_spins, (int)N, (int)W, (int)Rp);
@@ -110,10 +115,11 @@ int32_t sk_rrr_mc_async(rrrmc_ctx* ctx, double beta, int64_t iters, int64_t step
     HIP_TRY(ctx, hipEventRecord(ctx->ev_end, st));
     ctx->sweep_launches = 1;
     ctx->nsamp = nsamp;
-    ctx->it_done += (uint64_t)iters;
+    if (mode == 2) ctx->wtm_calls += 1; else ctx->it_done += (uint64_t)iters;
     ctx->results_valid = true;
     ctx->timing_valid = true;
     ctx->last_call_rrr = true;
+    ctx->last_call_wtm = mode == 2;
     return RRRMC_OK;
 }
 

@@ -399,7 +399,10 @@ struct RrrSkParams {
     int64_t iters, step;
     uint32_t k0, k1, replica0;
     int N, N2, levs, W, R, Rp;
-    int mode;                // 0 = rrrMC(SingleGraph), 1 = bklMC
+    int mode;                // 0 = rrrMC(SingleGraph), 1 = bklMC, 2 = wtmMC (iters = samples)
+    uint32_t call;           // wtmMC: number of the call (WTM stream)
+    double stepf;            // wtmMC: step in sweeps
+    double* t_out;           // wtmMC: [Rp] final global time
 };
 
 struct SkChain {             // one replica's view
@@ -531,6 +534,90 @@ __global__ __launch_bounds__(kRrrThreads) void rrr_skn_kernel(RrrSkParams P)
     double acc_rate = 0.5;
     long long accepted = 0, staged_its = 0, ns = 0;
     int bad = 0;
+    if (P.mode == 2) {
+        // wtmMC (RRRMC.jl:376-426, WaitingTimes.jl): every spin carries the time of its next flip, the smallest one moves; a move
+        // re-draws the waiting times of the moved spin and of all the others (AllButOne, SK.jl:297) from tau = max(1, exp(beta dE)).
+        // Binary min-heap by (time, spin) per replica in the (interleaved) arrays of the unused sampler: keys in dEs, spin at
+        // position / position of spin as 16-bit entries in st_dE / st_p.  WTM stream: draw n of the call for the n-th waiting time.
+        double* ht = P.dEs + r;
+        uint16_t* hid = reinterpret_cast<uint16_t*>(P.st_dE) + r;
+        uint16_t* hpos = reinterpret_cast<uint16_t*>(P.st_p) + r;
+        uint64_t nd = 0;
+        auto uniform = [&]() {
+            const uint64_t n = nd++, blk = n >> 1;
+            const Philox4 o = philox4x32_10((uint32_t)blk, (uint32_t)(blk >> 32), rep, 11u | (P.call << 8), P.k0, P.k1);       // TAG_WTM
+            const uint64_t u = (n & 1u) ? (((uint64_t)o.w[2] << 32) | o.w[3]) : (((uint64_t)o.w[0] << 32) | o.w[1]);
+            return (double)(u >> 11) * 0x1.0p-53;
+        };
+        auto gen_wt = [&](double dE) { const double e = det_exp(P.beta * dE); return -(e > 1.0 ? e : 1.0) * det_log1p(-uniform()); };
+        auto before = [](double ta, int a, double tb, int b) { return ta < tb || (ta == tb && a < b); };
+        auto sift_down = [&](int pos) {
+            const double t = ht[(size_t)pos * Rp];
+            const int id = hid[(size_t)pos * Rp];
+            for (;;) {
+                int ch = 2 * pos + 1;
+                if (ch >= N) break;
+                if (ch + 1 < N && before(ht[(size_t)(ch + 1) * Rp], hid[(size_t)(ch + 1) * Rp], ht[(size_t)ch * Rp], hid[(size_t)ch * Rp])) ch += 1;
+                if (!before(ht[(size_t)ch * Rp], hid[(size_t)ch * Rp], t, id)) break;
+                ht[(size_t)pos * Rp] = ht[(size_t)ch * Rp];
+                const int cid = hid[(size_t)ch * Rp];
+                hid[(size_t)pos * Rp] = (uint16_t)cid; hpos[(size_t)cid * Rp] = (uint16_t)pos;
+                pos = ch;
+            }
+            ht[(size_t)pos * Rp] = t; hid[(size_t)pos * Rp] = (uint16_t)id; hpos[(size_t)id * Rp] = (uint16_t)pos;
+        };
+        auto sift_up = [&](int pos) {
+            const double t = ht[(size_t)pos * Rp];
+            const int id = hid[(size_t)pos * Rp];
+            while (pos > 0) {
+                const int par = (pos - 1) >> 1;
+                if (!before(t, id, ht[(size_t)par * Rp], hid[(size_t)par * Rp])) break;
+                ht[(size_t)pos * Rp] = ht[(size_t)par * Rp];
+                const int pid = hid[(size_t)par * Rp];
+                hid[(size_t)pos * Rp] = (uint16_t)pid; hpos[(size_t)pid * Rp] = (uint16_t)pos;
+                pos = par;
+            }
+            ht[(size_t)pos * Rp] = t; hid[(size_t)pos * Rp] = (uint16_t)id; hpos[(size_t)id * Rp] = (uint16_t)pos;
+        };
+        auto update = [&](int i, double t) {
+            const int pos = hpos[(size_t)i * Rp];
+            const double old = ht[(size_t)pos * Rp];
+            ht[(size_t)pos * Rp] = t;
+            if (t < old) sift_up(pos); else sift_down(pos);
+        };
+        for (int i = 0; i < N; ++i) {                 // THeap(X, C, beta): one waiting time per spin, in index order
+            ht[(size_t)i * Rp] = gen_wt(P.lfA[(size_t)i * Rp + r]);
+            hid[(size_t)i * Rp] = (uint16_t)i; hpos[(size_t)i * Rp] = (uint16_t)i;
+        }
+        for (int pos = N / 2 - 1; pos >= 0; --pos) sift_down(pos);
+        const double st = P.stepf / (double)N, tmax = st * (double)P.iters;
+        double t = 0.0, nextstep = st;
+        bool out = false;
+        while (t < tmax && !out) {
+            const double tp = ht[0];
+            const int move = hid[0];
+            while (tp >= nextstep) {
+                P.Es[(size_t)ns * Rp + r] = E; ns += 1;
+                nextstep += st;
+                if (nextstep > tmax + 1e-10) { out = true; break; }
+            }
+            if (out) break;
+            t = tp;
+            const double dE = c.lf()[(size_t)move * Rp];
+            c.flip(move);                             // update_heap!: WaitingTimes.jl:40-52
+            const double* a = c.lf();
+            update(move, t + gen_wt(a[(size_t)move * Rp]));          // = -dE
+            for (int j = 0; j < N; ++j) {
+                if (j == move) continue;
+                update(j, t + gen_wt(a[(size_t)j * Rp]));
+            }
+            E += dE;
+            accepted += 1;
+        }
+        for (; ns < P.iters; ++ns) P.Es[(size_t)ns * Rp + r] = E;   // not reached: the loop always emits `samples` samples
+        staged_its = accepted;
+        P.t_out[r] = t;
+    }
     if (P.mode == 1) {
         // bklMC (RRRMC.jl:311-359): rand_skip (DeltaE.jl:319-325), rand_move, apply_step_bkl! = apply_move! over all spins
         long long it = 0, nextstep = P.step, m = 0;

@@ -1302,7 +1302,8 @@ int32_t rrrmc_wtm_mc_async(rrrmc_ctx* ctx, double beta, int64_t samples, double 
     int32_t rc = ensure_state(ctx, true);
     if (rc) return rc;
     if (ctx->model == RRRMC_MODEL_SPARSE_F64 || ctx->model == RRRMC_MODEL_SPARSE_DISCRETIZED) return spf_cont_async(ctx, 2, beta, samples, 1, step, 0.0, 5.0);
-    if (!sparse_int_model(ctx)) return fail(ctx, RRRMC_ERR_UNSUPPORTED, "wtmMC is wired for RRRMC_MODEL_SPARSE_PM1, RRRMC_MODEL_SPARSE_LEVELS and RRRMC_MODEL_SPARSE_F64");
+    if (ctx->model == RRRMC_MODEL_SK_NORMAL) return sk_rrr_mc_async(ctx, beta, samples, 1, 0.0, 5.0, 2, step);
+    if (!sparse_int_model(ctx)) return fail(ctx, RRRMC_ERR_UNSUPPORTED, "wtmMC is wired for the sparse models and RRRMC_MODEL_SK_NORMAL");
     return sparse_wtm_async(ctx, beta, samples, step);
 }
 

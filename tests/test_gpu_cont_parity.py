@@ -107,3 +107,27 @@ def test_bkl_skn_bit_exact(pkg, oracle, N, R, beta, iters, step):
         Es_ref, ch_ref, m_ref, _ = oracle.bkl_mc_skn(X.J, beta, iters, step, seed, C0.s[r], replica=r)
         assert (Es[r] == Es_ref).all() and (C1.s[r] == ch_ref).all() and moves[r] == m_ref
         assert E1[r] == oracle.skn_energy(X.J, ch_ref)
+
+
+@pytest.mark.parametrize("N,R,beta,samples,step", [(10, 40, 2.0, 100, 100.0), (64, 33, 1.5, 60, 5.0), (200, 9, 1.0, 20, 2.0)])
+def test_wtm_skn_bit_exact(pkg, oracle, N, R, beta, samples, step):
+    """wtmMC on GraphSKNormal (test/runtests.jl:67 x :149-151): a heap of next-flip times, all N - 1 neighbours re-drawn per move;
+    a second call continues with the next WTM call number."""
+    seed = 929000 + N
+    X = pkg.GraphSKNormal(N, seed=seed)
+    with pkg.Engine(X, R) as eng:
+        eng.seed(seed)
+        eng.init_spins_random()
+        C0 = eng.get_config()
+        Es, moves, t = eng.wtm_mc(beta, samples, step=step)
+        C1 = eng.get_config()
+        E1 = eng.energy()
+        Es2, moves2, t2 = eng.wtm_mc(beta, samples // 2, step=step)
+    assert Es.shape == (R, samples)
+    for r in range(R):
+        Es_ref, ch_ref, m_ref, t_ref = oracle.wtm_mc_skn(X.J, beta, samples, step, seed, C0.s[r], replica=r)
+        assert (Es[r] == Es_ref).all() and (C1.s[r] == ch_ref).all() and moves[r] == m_ref and t[r] == t_ref
+        assert E1[r] == oracle.skn_energy(X.J, ch_ref)
+        Es_ref2, _, m_ref2, t_ref2 = oracle.wtm_mc_skn(X.J, beta, samples // 2, step, seed, ch_ref, call=1, replica=r)
+        assert (Es2[r] == Es_ref2).all() and moves2[r] == m_ref2 and t2[r] == t_ref2
+    assert moves.sum() > 0

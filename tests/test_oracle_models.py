@@ -434,3 +434,15 @@ def test_double_graph_bkl_wtm_tracked_energy(oracle, form, lev):
     # the waiting-time chain's last sample precedes its last moves: replay a prefix that ends on a sample and compare energies
     Es_f, cf, st_f, _ = oracle.cont_sparse("wtm", A, cJ, 1.1, 60, 1, seed, ch, stepf=1.0, form=form)
     assert np.allclose(Es_f, Es, rtol=0, atol=1e-9)                    # same chain as the undiscretised couplings, up to rounding
+
+
+def test_wtm_skn_tracked_energy(oracle):
+    """wtmMC on GraphSKNormal(10) (runtests.jl:67 x :149): the oracle checks E_tracked == energy(X, C) itself; the time-averaged energy
+    agrees with Metropolis' (loose, statistical)."""
+    seed = 4711
+    J = oracle.gen_sk_gauss(10, seed)
+    ch = oracle.init_config(seed, 0, 10)
+    Es, c1, moves, t = oracle.wtm_mc_skn(J, 1.0, 4000, 1.0, seed, ch)
+    assert len(Es) == 4000 and moves > 0 and t > 0
+    Em, _, _ = oracle.standard_mc_skn(J, 1.0, 400000, 10, seed, ch)[:3]
+    assert abs(Es[500:].mean() - Em[5000:].mean()) < 0.25
