@@ -47,4 +47,4 @@ def test_wtmMC_front_end(pkg, oracle):
         ref = oracle.wtm_mc_sparse(X.A, X.J.astype(np.int32), 1.0, 1000, 1.0, seed, C0[r], replica=r)
         assert (Es[r] == ref[0]).all() and (C.s[r] == ref[1]).all()
     with pytest.raises(pkg.RRRMCError):
-        pkg.wtmMC(pkg.GraphSKNormal(16, seed=seed), 1.0, 10, seed=seed, quiet=True)       # only the sparse +-J models are wired
+        pkg.wtmMC(pkg.GraphSK(16, seed=seed), 1.0, 10, seed=seed, quiet=True)             # the binary SK model has standardMC only
