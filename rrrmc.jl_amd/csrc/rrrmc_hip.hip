@@ -450,13 +450,15 @@ int32_t rrrmc_ctx_create(rrrmc_ctx** out, int32_t model, int64_t N, int64_t K, i
     CREATE_TRY(hipMemset(ctx->d_spins, 0, sizeof(uint32_t) * ctx->G * N));
     CREATE_TRY(hipMemset(ctx->d_E, 0, sizeof(int32_t) * ctx->Rpad));
     CREATE_TRY(hipMemset(ctx->d_acc, 0, sizeof(int64_t) * ctx->Rpad));
+    // the attribute belongs to the kernel, not to the context: always raise it to the device limit, so that contexts of different
+    // sizes can coexist (a later, smaller context must not lower the bound under an earlier one)
     if (ctx->lds_mode) {
         sweep_fn fn = sweep_for_K((int)K, ctx->sweep_mode);
-        CREATE_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->lds_bytes));
-        CREATE_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(plan_for_K((int)K)), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->plan_lds_bytes));
+        CREATE_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimit));
+        CREATE_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(plan_for_K((int)K)), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimit));
     }
     if (ctx->big_mode)
-        CREATE_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(plan_big_for_K((int)K)), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->plan_lds_bytes));
+        CREATE_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(plan_big_for_K((int)K)), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimit));
 #undef CREATE_TRY
     *out = ctx;
     return RRRMC_OK;
@@ -1241,7 +1243,7 @@ int32_t quant_mc_async(rrrmc_ctx* ctx, bool standard, double beta, double fourK,
         const char* no_lds = std::getenv("RRRMC_QUANT_NO_LDS");          // timing experiments
         if (rrr_tpb(ctx->R) == 1 && lds <= (size_t)kLdsLimit && !(no_lds && no_lds[0] == '1')) {
             if (!ctx->q_lds_attr) {
-                HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(rrr_quant_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(rrr_quant_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimit));
                 ctx->q_lds_attr = true;
             }
             hipLaunchKernelGGL(rrr_quant_kernel<true>, dim3((unsigned)ctx->R), dim3(kRrrThreads), lds, st, P);

@@ -129,6 +129,43 @@ def test_misuse_is_reported_not_crashed(pkg):
     assert L.rrrmc_ctx_create(C.byref(ctx), 42, 64, 3, 8, 0, 0) == 3     # unknown model
 
 
+def test_contexts_of_different_sizes_coexist(pkg, oracle):
+    """Kernel attributes (the dynamic-LDS bound) belong to the kernel, not to a context: a big context must keep working after a
+    small one of the same kernel has been created, and the other way round, with their calls interleaved."""
+    seed = 515
+    Xbig, Xsmall = pkg.GraphRRG(4096, 3, seed=seed), pkg.GraphRRG(64, 3, seed=seed)
+    Qbig = pkg.GraphQuant(pkg.GraphRRG(256, 3, seed=seed), 16, 0.5, 2.0)
+    Qsmall = pkg.GraphQuant(pkg.GraphRRG(10, 3, seed=seed), 4, 0.5, 2.0)
+    with pkg.Engine(Xbig, 32) as a:
+        a.seed(seed); a.init_spins_random()
+        Ca = a.get_config()
+        with pkg.Engine(Xsmall, 32) as b, pkg.Engine(Qbig, 4) as qa:
+            b.seed(seed); b.init_spins_random()
+            qa.seed(seed); qa.init_spins_random()
+            Cb, Cqa = b.get_config(), qa.get_config()
+            with pkg.Engine(Qsmall, 4) as qb:
+                qb.seed(seed); qb.init_spins_random()
+                Cqb = qb.get_config()
+                Ea, _ = a.standard_mc(1.0, 8192, 4096)
+                Eb, _ = b.standard_mc(1.0, 8192, 4096)
+                Eqa = qa.rrr_mc(2.0, 2000, 100)[0]
+                Eqb = qb.rrr_mc(2.0, 2000, 100)[0]
+                Ea2, _ = a.standard_mc(1.0, 4096, 4096)
+                Eqa2 = qa.rrr_mc(2.0, 1000, 100)[0]
+    ra = oracle.standard_mc_sparse_batch(Xbig.A, Xbig.J.astype(np.int32), 1.0, 8192, 4096, seed, Ca.s)
+    rb = oracle.standard_mc_sparse_batch(Xsmall.A, Xsmall.J.astype(np.int32), 1.0, 8192, 4096, seed, Cb.s)
+    assert (Ea == ra[0]).all() and (Eb == rb[0]).all()
+    ra2 = oracle.standard_mc_sparse_batch(Xbig.A, Xbig.J.astype(np.int32), 1.0, 4096, 4096, seed, ra[1], it0=8192)
+    assert (Ea2 == ra2[0]).all()
+    for r in range(4):
+        q = oracle.rrr_mc_quant(Qbig.A, Qbig.J.astype(np.int32), Qbig.M, Qbig.fourK, 2.0, 2000, 100, seed, Cqa.s[r], replica=r)
+        assert (Eqa[r] == q[0]).all()
+        q2 = oracle.rrr_mc_quant(Qbig.A, Qbig.J.astype(np.int32), Qbig.M, Qbig.fourK, 2.0, 1000, 100, seed, q[1], it0=2000, replica=r)
+        assert (Eqa2[r] == q2[0]).all()
+        qs = oracle.rrr_mc_quant(Qsmall.A, Qsmall.J.astype(np.int32), Qsmall.M, Qsmall.fourK, 2.0, 2000, 100, seed, Cqb.s[r], replica=r)
+        assert (Eqb[r] == qs[0]).all()
+
+
 def test_create_destroy_cycles(pkg):
     X = pkg.GraphRRG(256, 3, seed=9)
     for k in range(40):
