@@ -12,6 +12,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <map>
+#include <mutex>
 #include <vector>
 
 #include "sk_kernels.hpp"
@@ -293,6 +295,20 @@ inline unsigned rrr_tpb(int64_t R)
 inline unsigned rrr_blocks(int64_t R) { const unsigned t = rrr_tpb(R); return (unsigned)((R + t - 1) / t); }
 
 // models whose device spins are R x W 32-bit words in BitVector order (q_spins, qW)
+// The dynamic-LDS bound is an attribute of the KERNEL, not of a context: contexts of different sizes share it, so it is only ever
+// raised (a later, smaller context must not lower it under an earlier one).
+hipError_t raise_lds_attr(const void* fn, size_t bytes)
+{
+    static std::mutex mu;
+    static std::map<const void*, size_t> cur;
+    std::lock_guard<std::mutex> lock(mu);
+    size_t& have = cur[fn];
+    if (bytes <= have) return hipSuccess;
+    const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e == hipSuccess) have = bytes;
+    return e;
+}
+
 inline bool chunk_layout(const rrrmc_ctx* ctx) { return ctx->model == RRRMC_MODEL_QUANT_RRG || ctx->model == RRRMC_MODEL_SPARSE_DISCRETIZED || ctx->model == RRRMC_MODEL_SPARSE_LEVELS; }
 inline bool sparse_int_model(const rrrmc_ctx* ctx) { return ctx->model == RRRMC_MODEL_SPARSE_PM1 || ctx->model == RRRMC_MODEL_SPARSE_LEVELS; }
 inline double lv_to_f64(const rrrmc_ctx* ctx, long long units) { return (double)(units * ctx->lv_mul) / ctx->lv_div; }
@@ -450,15 +466,13 @@ int32_t rrrmc_ctx_create(rrrmc_ctx** out, int32_t model, int64_t N, int64_t K, i
     CREATE_TRY(hipMemset(ctx->d_spins, 0, sizeof(uint32_t) * ctx->G * N));
     CREATE_TRY(hipMemset(ctx->d_E, 0, sizeof(int32_t) * ctx->Rpad));
     CREATE_TRY(hipMemset(ctx->d_acc, 0, sizeof(int64_t) * ctx->Rpad));
-    // the attribute belongs to the kernel, not to the context: always raise it to the device limit, so that contexts of different
-    // sizes can coexist (a later, smaller context must not lower the bound under an earlier one)
     if (ctx->lds_mode) {
         sweep_fn fn = sweep_for_K((int)K, ctx->sweep_mode);
-        CREATE_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimit));
-        CREATE_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(plan_for_K((int)K)), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimit));
+        CREATE_TRY(raise_lds_attr(reinterpret_cast<const void*>(fn), ctx->lds_bytes));
+        CREATE_TRY(raise_lds_attr(reinterpret_cast<const void*>(plan_for_K((int)K)), ctx->plan_lds_bytes));
     }
     if (ctx->big_mode)
-        CREATE_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(plan_big_for_K((int)K)), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimit));
+        CREATE_TRY(raise_lds_attr(reinterpret_cast<const void*>(plan_big_for_K((int)K)), ctx->plan_lds_bytes));
 #undef CREATE_TRY
     *out = ctx;
     return RRRMC_OK;
@@ -1243,7 +1257,7 @@ int32_t quant_mc_async(rrrmc_ctx* ctx, bool standard, double beta, double fourK,
         const char* no_lds = std::getenv("RRRMC_QUANT_NO_LDS");          // timing experiments
         if (rrr_tpb(ctx->R) == 1 && lds <= (size_t)kLdsLimit && !(no_lds && no_lds[0] == '1')) {
             if (!ctx->q_lds_attr) {
-                HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(rrr_quant_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimit));
+                HIP_TRY(ctx, raise_lds_attr(reinterpret_cast<const void*>(rrr_quant_kernel<true>), lds));
                 ctx->q_lds_attr = true;
             }
             hipLaunchKernelGGL(rrr_quant_kernel<true>, dim3((unsigned)ctx->R), dim3(kRrrThreads), lds, st, P);
