@@ -122,7 +122,7 @@ RRRMC_API int32_t rrrmc_fetch_results(rrrmc_ctx *ctx, int64_t *Es_out, int64_t *
 
 /* ---- colour-parallel ("checkerboard") sweeps: build-defined extension for large sparse graphs ---------------------
  * The reference's standardMC is random-site (src/RRRMC.jl:113) and its kernel here keeps a replica group's spins in
- * LDS (two 4-byte words per site next to the chunk buffers: up to N of about 17 000).  For larger graphs (BASELINE.json
+ * LDS (one or two 4-byte words per site next to the chunk buffers: up to N = 32 767).  For larger graphs (BASELINE.json
  * config 4: GraphEA L=64, D=3) the engine offers sweeps over a
  * proper colouring: one sweep attempts every site once, colour by colour, all sites of a colour at once, with the
  * reference's delta_energy and accept rule (src/graphs/EA.jl:266-275, src/RRRMC.jl:39).  A ctx of

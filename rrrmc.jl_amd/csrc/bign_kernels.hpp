@@ -1,5 +1,5 @@
 // gfx950 kernels for random-site standardMC (src/RRRMC.jl:81-127) on +-J sparse graphs that do NOT fit the LDS-resident
-// sweep_kernel (N beyond ~17 000: GraphEA(64, 3) has N = 262 144).  Same chain, same streams, same planner idea as
+// sweep_kernel (N beyond 32 767, or wherever the planner's LDS buffers do not fit: GraphEA(64, 3) has N = 262 144).  Same chain, same streams, same planner idea as
 // sparse_kernels.hpp — the site sequence is cut into chunks, every chunk into dependency levels whose attempts commute —
 // but nothing here is sized by N:
 //   plan_big_kernel<K>   one workgroup per chunk (<= 4096 attempts): the attempts are SORTED by (site, index) in LDS (bitonic), an

@@ -253,7 +253,8 @@ big_sweep_fn big_sweep_for_K(int K) { RRRMC_DISPATCH_UPTO7(K, big_sweep_kernel) 
 typedef void (*sweep_fn)(SweepParams);
 sweep_fn sweep_for_K(int K, int mode)
 {
-    // mode 0: table in LDS, byte offsets; 1: table in HBM/L2, byte offsets (N <= 8192); 2: table in HBM/L2, word indices
+    // mode 0: table in LDS, byte offsets; 1: table in HBM/L2, byte offsets (N <= 8192); 2: table in HBM/L2, word indices;
+    // 3: table in HBM/L2, one word per site, word indices with the coupling sign in bit 15 (N <= 32767)
     switch (mode * 8 + K) {
         case 1: return sweep_kernel<1, 0>; case 2: return sweep_kernel<2, 0>; case 3: return sweep_kernel<3, 0>; case 4: return sweep_kernel<4, 0>;
         case 5: return sweep_kernel<5, 0>; case 6: return sweep_kernel<6, 0>; case 7: return sweep_kernel<7, 0>;
@@ -261,15 +262,17 @@ sweep_fn sweep_for_K(int K, int mode)
         case 13: return sweep_kernel<5, 1>; case 14: return sweep_kernel<6, 1>; case 15: return sweep_kernel<7, 1>;
         case 17: return sweep_kernel<1, 2>; case 18: return sweep_kernel<2, 2>; case 19: return sweep_kernel<3, 2>; case 20: return sweep_kernel<4, 2>;
         case 21: return sweep_kernel<5, 2>; case 22: return sweep_kernel<6, 2>; case 23: return sweep_kernel<7, 2>;
+        case 25: return sweep_kernel<1, 3>; case 26: return sweep_kernel<2, 3>; case 27: return sweep_kernel<3, 3>; case 28: return sweep_kernel<4, 3>;
+        case 29: return sweep_kernel<5, 3>; case 30: return sweep_kernel<6, 3>; case 31: return sweep_kernel<7, 3>;
         default: return nullptr;
     }
 }
 
 // wide = the neighbour table is not staged in LDS (8192 < N: offsets are word indices, see SweepParams::table)
-size_t sweep_lds_bytes(int64_t N, int K, int TS, int C, bool wide = false)
+size_t sweep_lds_bytes(int64_t N, int K, int TS, int C, bool wide = false, bool single = false)
 {
     const int NT = (K + 1) / 2, NW = NT + (K + 2) / 2, NQ = (NW + 3) / 4;
-    const size_t words = (size_t)((2 * N + 128 + 3) & ~3ll) + (size_t)3 * NQ * 4 * C + (size_t)8 * (C + 64) + (size_t)2 * (4 + kLeftMax * (1 + 2 * NT));
+    const size_t words = (size_t)(((single ? 1 : 2) * N + 128 + 3) & ~3ll) + (size_t)3 * NQ * 4 * C + (size_t)8 * (C + 64) + (size_t)2 * (4 + kLeftMax * (1 + 2 * NT));
     return words * 4 + (wide ? (size_t)0 : (size_t)N * TS * 2);
 }
 
@@ -409,20 +412,28 @@ int32_t rrrmc_ctx_create(rrrmc_ctx** out, int32_t model, int64_t N, int64_t K, i
     // WIDE build (word indices instead of byte offsets, neighbour table in HBM/L2 instead of LDS): needed when byte offsets into
     // the 2N-word LDS spin array no longer fit 16 bits (N > 8192); chosen as well when dropping the LDS copy of the table buys a
     // clearly longer chunk (at equal chunk length it is 1.6 % slower than the normal build).
-    auto max_chunk = [&](bool wide) {
+    auto max_chunk = [&](bool wide, bool single = false) {
 #ifdef RRRMC_CHUNK_TASKS
         int c = RRRMC_CHUNK_TASKS * kWave;
 #else
         int c = kMaxChunk;
 #endif
-        while (c >= kWave && (2 * N + 128 > 65535 || (!wide && N > 8192) || sweep_lds_bytes(N, (int)K, ctx->TS, c, wide) > (size_t)kLdsLimit)) c -= kWave;
+        while (c >= kWave && ((single ? N > 32767 : 2 * N + 128 > 65535) || (!wide && N > 8192) ||
+                              sweep_lds_bytes(N, (int)K, ctx->TS, c, wide, single) > (size_t)kLdsLimit)) c -= kWave;
         return c;
     };
-    const int Cn = max_chunk(false), Cw = max_chunk(true);
+    const int Cn = max_chunk(false), Cw = max_chunk(true), Cs = N > 8192 ? max_chunk(true, true) : 0;
     ctx->wide = Cw >= Cn + Cn / 8;
     if (const char* fw = std::getenv("RRRMC_FORCE_WIDE")) ctx->wide = ctx->wide || fw[0] == '1';       // timing experiments
     ctx->sweep_mode = !ctx->wide ? 0 : (N <= 8192 ? 1 : 2);
     int C = ctx->wide ? Cw : Cn;
+    // one word per site (the consumer pays three more instructions per neighbour): only where it buys clearly longer chunks
+    bool single = N > 8192 && N <= 32767 && Cs >= 4 * kWave && Cs >= C + C / 2;
+    if (const char* fs = std::getenv("RRRMC_FORCE_SINGLE")) {      // tests / timing experiments: "1" forces it at any N <= 32767, "0" forbids it
+        if (fs[0] == '1' && N <= 32767) single = true;
+        if (fs[0] == '0') single = false;
+    }
+    if (single) { ctx->wide = true; ctx->sweep_mode = 3; C = max_chunk(true, true); }
     // tiny graphs: the dependency depth of a chunk grows like C (K+1) / N, and both the planner's relaxation rounds and the
     // consumer's sequential levels follow it — long chunks stop paying
     const int64_t cap = std::max<int64_t>(4 * kWave, (8 * N) / kWave * kWave);
@@ -433,7 +444,7 @@ int32_t rrrmc_ctx_create(rrrmc_ctx** out, int32_t model, int64_t N, int64_t K, i
     ctx->big_mode = !ctx->lds_mode && N <= ((int64_t)1 << kBigSiteBits);
     if (!ctx->lds_mode) C = ctx->big_mode ? kBigChunk : kWave;
     ctx->C = C;
-    ctx->lds_bytes = ctx->lds_mode ? sweep_lds_bytes(N, (int)K, ctx->TS, C, ctx->wide) : 0;
+    ctx->lds_bytes = ctx->lds_mode ? sweep_lds_bytes(N, (int)K, ctx->TS, C, ctx->wide, ctx->sweep_mode == 3) : 0;
     ctx->plan_lds_bytes = ctx->lds_mode ? plan_lds_bytes(N, (int)K, C) : (ctx->big_mode ? plan_big_lds_bytes((int)K) : 0);
 
 #define CREATE_TRY(expr)                                                                                         \
@@ -549,7 +560,8 @@ int32_t rrrmc_set_graph(rrrmc_ctx* ctx, const int32_t* A, const int8_t* J)
     if (ctx->lds_mode)
         for (int64_t x = 0; x < N; ++x)
             for (int64_t k = 0; k < K; ++k)
-                table[x * ctx->TS + k] = (uint16_t)((ctx->sweep_mode == 2 ? 1 : 4) * (2 * A[x * K + k] + (J[x * K + k] < 0 ? 1 : 0)));   // byte offset (word index in mode 2) in the LDS spin array: word 2y = s_y, word 2y + 1 = ~s_y
+                table[x * ctx->TS + k] = ctx->sweep_mode == 3 ? (uint16_t)(A[x * K + k] | (J[x * K + k] < 0 ? 0x8000 : 0))      // one word per site, sign in bit 15
+                                                               : (uint16_t)((ctx->sweep_mode == 2 ? 1 : 4) * (2 * A[x * K + k] + (J[x * K + k] < 0 ? 1 : 0)));   // byte offset (word index in mode 2) in the LDS spin array: word 2y = s_y, word 2y + 1 = ~s_y
     ctx->h_A.assign(A, A + N * K);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));

@@ -275,7 +275,7 @@ __device__ __forceinline__ void produce_chunk(const SweepParams& P, const ChunkD
         for (int q = 0; q < NQ * 4; ++q) f[q] = 0u;
         {   // gather offsets: own word, then the K neighbour words (table row = K uint16 byte offsets)
             uint32_t off[K + 2];
-            off[0] = MODE == 2 ? 2u * site : site * 8u;        // the pair {s, ~s} of the site starts at word 2 * site
+            off[0] = MODE == 3 ? site : MODE == 2 ? 2u * site : site * 8u;   // the pair {s, ~s} of the site starts at word 2 * site (MODE 3: one word per site)
             off[K + 1] = 0u;
             const uint16_t* row = tbl + (size_t)site * P.TS;
             if constexpr (K <= 4) {
@@ -389,18 +389,22 @@ template <int K> __device__ __forceinline__ uint32_t desc_off(const SlotDesc<K>&
 
 // MODE of the sweep kernel: 0 = neighbour table staged in LDS, byte offsets; 1 = table read from HBM/L2 (longer chunks), byte offsets
 // (8 N <= 65536); 2 = table in HBM/L2, word indices (N > 8192: byte offsets into the 2N-word spin array no longer fit 16 bits).
-// off = byte offset or word index (MODE 2) into the LDS spin array
+// 3 = table in HBM/L2 and ONE word per site (8192 < N <= 32 767 when that buys clearly longer chunks): a table entry is the neighbour's
+// word index with the coupling's sign in bit 15, applied after the gather — three more consumer instructions per neighbour, half the state.
+// off = byte offset or word index (MODE 2, 3) into the LDS spin array
 template <int MODE>
 __device__ __forceinline__ uint32_t lds_word(const uint32_t* sp, uint32_t off)
 {
-    if constexpr (MODE == 2) return sp[off];
+    if constexpr (MODE == 3) return sp[off & 0x7fffu] ^ (uint32_t)((int32_t)(off << 16) >> 31);      // bit 15: J = -1, read as the complement
+    else if constexpr (MODE == 2) return sp[off];
     else return *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(sp) + off);
 }
 // the pair {s, ~s} of one site in a single 8-byte store (off = the pair's offset)
 template <int MODE>
 __device__ __forceinline__ void lds_store_pair(uint32_t* sp, uint32_t off, uint32_t v)
 {
-    if constexpr (MODE == 2) *reinterpret_cast<uint2*>(sp + off) = make_uint2(v, ~v);
+    if constexpr (MODE == 3) sp[off] = v;
+    else if constexpr (MODE == 2) *reinterpret_cast<uint2*>(sp + off) = make_uint2(v, ~v);
     else *reinterpret_cast<uint2*>(reinterpret_cast<char*>(sp) + off) = make_uint2(v, ~v);
 }
 
@@ -728,8 +732,8 @@ __global__ __launch_bounds__(kSweepThreads) void sweep_kernel(SweepParams P)
     constexpr int NQ = SweepCfg<K>::NQ, NS = SweepCfg<K>::NS;
     extern __shared__ uint32_t lds[];
     const int N = P.N, C = P.C;
-    uint32_t* sp = lds;                                              // [2N]  words, then complements
-    uint4* desc = reinterpret_cast<uint4*>(sp + ((2 * N + 128 + 3) & ~3)); // [3][NQ][C]   (128 dummy words behind the spins)
+    uint32_t* sp = lds;                                              // [2N]  pairs {s, ~s} ([N] words in MODE 3)
+    uint4* desc = reinterpret_cast<uint4*>(sp + (((MODE == 3 ? 1 : 2) * N + 128 + 3) & ~3)); // [3][NQ][C]   (128 spare words behind the spins)
     uint4* tal = desc + 3 * NQ * C;                                  // [2][C + 64]  (64 dummy entries per buffer)
     uint32_t* leftmem = reinterpret_cast<uint32_t*>(tal + 2 * (C + kWave));   // [2] leftover lists
     constexpr int kLeftWords = 4 + kLeftMax * (1 + 2 * SweepCfg<K>::NT);
@@ -744,7 +748,8 @@ __global__ __launch_bounds__(kSweepThreads) void sweep_kernel(SweepParams P)
 
     for (int x = tid; x < N; x += kSweepThreads) {
         const uint32_t w = gsp[x];
-        *reinterpret_cast<uint2*>(sp + 2 * x) = make_uint2(w, ~w);       // word 2x: the spins of site x, word 2x + 1: their complement
+        if constexpr (MODE == 3) sp[x] = w;
+        else *reinterpret_cast<uint2*>(sp + 2 * x) = make_uint2(w, ~w);  // word 2x: the spins of site x, word 2x + 1: their complement
     }
     if constexpr (MODE == 0) {
         uint16_t* tbl_w = reinterpret_cast<uint16_t*>(leftmem + 2 * kLeftWords);
@@ -889,7 +894,7 @@ __global__ __launch_bounds__(kSweepThreads) void sweep_kernel(SweepParams P)
 #undef RRRMC_T0
 #undef RRRMC_T1
     __syncthreads();
-    for (int x = tid; x < N; x += kSweepThreads) gsp[x] = sp[2 * x];
+    for (int x = tid; x < N; x += kSweepThreads) gsp[x] = sp[MODE == 3 ? x : 2 * x];
 }
 
 // ---------------------------------------------------------------------------------------------------

@@ -45,6 +45,8 @@ CASES = [
     (("rrg", 10000, 3), 40, 2.0,  80000, 10000),  # the size of the reference's scripts (scripts/scripts.jl:23 N = 10_000)
     (("rrg", 12000, 4), 32, 1.0,  50000, 5000),   # even K, shorter chunks (LDS)
     (("ea", 24, 3),    32,  1.0,  60000, 6000),   # EA 24^3 = 13824 spins, K = 6
+    (("rrg", 16384, 3), 32, 1.0,  70000, 16384),  # one word per site (MODE 3): half the state, chunks three times as long
+    (("rrg", 16500, 4), 32, 1.0,  50000, 7000),   # near the end of the two-copy layout's range (MODE 3 by choice)
 ]
 
 
@@ -142,3 +144,45 @@ def test_standardMC_front_end_and_hook(pkg, oracle):
     Es, C = pkg.standardMC(X, 2.0, 2000, step=100, seed=seed, quiet=True, replicas=32)
     assert [it for it, _ in seen] == list(range(100, 2001, 100))
     assert (Es_h == Es).all() and C_h == C
+
+
+@pytest.mark.parametrize("kind,R,beta,iters,step", [
+    (("rrg", 300, 3), 40, 1.0, 20000, 300),         # forced at a small size: several levels per chunk, ragged batches
+    (("ea", 8, 3), 33, 1.5, 20000, 512),            # K = 6, double-digit levels
+    (("rrg", 9000, 5), 32, 0.8, 40000, 9000),       # K = 5: three thresholds
+])
+def test_single_copy_layout_forced(pkg, oracle, monkeypatch, kind, R, beta, iters, step):
+    """MODE 3 of the sweep kernel (one LDS word per site, the coupling's sign in bit 15 of the neighbour index), forced where the
+    context would not choose it: same chain as the oracle and as the default layout."""
+    seed = 0xBEEF + kind[1]
+    X = _graph(pkg, kind, seed)
+    out = []
+    for single in ("1", "0"):
+        monkeypatch.setenv("RRRMC_FORCE_SINGLE", single)
+        with pkg.Engine(X, R) as eng:
+            eng.seed(seed)
+            eng.init_spins_random()
+            C0 = eng.get_config()
+            a = eng.standard_mc(beta, iters, step)
+            b = eng.standard_mc(beta, iters // 2, step)
+            out.append((a[0], a[1], b[0], b[1], eng.get_config().s))
+    for u, v in zip(*out):
+        assert (u == v).all()
+    ref = oracle.standard_mc_sparse_batch(X.A, X.J.astype(np.int32), beta, iters, step, seed, C0.s, form="ea" if kind[0] == "ea" else "rrg")
+    assert (out[0][0] == ref[0]).all() and (out[0][1] == ref[2]).all()
+
+
+def test_graphs_up_to_32767_sites_stay_on_the_lds_kernel(pkg, oracle):
+    """With one word per site the LDS-resident kernel reaches N = 32 767 (if the planner's buffers fit too); check a size in the new
+    range against the oracle (a few replicas: the oracle is sequential)."""
+    seed, N = 24242, 24000
+    X = pkg.GraphRRG(N, 3, seed=seed)
+    with pkg.Engine(X, 32) as eng:
+        eng.seed(seed)
+        eng.init_spins_random()
+        C0 = eng.get_config()
+        Es, acc = eng.standard_mc(1.0, 3 * N, N)
+        C1 = eng.get_config()
+    for r in (0, 31):
+        ref = oracle.standard_mc_sparse(X.A, X.J.astype(np.int32), 1.0, 3 * N, N, seed, C0.s[r], replica=r)
+        assert (Es[r] == ref[0]).all() and (C1.s[r] == ref[1]).all() and acc[r] == ref[2]
