@@ -186,3 +186,42 @@ def test_graphs_up_to_32767_sites_stay_on_the_lds_kernel(pkg, oracle):
     for r in (0, 31):
         ref = oracle.standard_mc_sparse(X.A, X.J.astype(np.int32), 1.0, 3 * N, N, seed, C0.s[r], replica=r)
         assert (Es[r] == ref[0]).all() and (C1.s[r] == ref[1]).all() and acc[r] == ref[2]
+
+
+def _random_cases(n, seed):
+    rng = np.random.default_rng(seed)
+    cases = []
+    while len(cases) < n:
+        K = int(rng.integers(1, 6))
+        N = int(rng.integers(max(8, 2 * K + 2), 2500))
+        if (N * K) % 2:
+            N += 1
+        R = int(rng.integers(1, 100))
+        beta = float(rng.choice([0.0, 0.3, 1.0, 2.5, float(rng.uniform(0.1, 3.0))]))
+        iters = int(rng.integers(1, 30000))
+        step = int(rng.integers(1, iters + 6))
+        layout = str(rng.choice(["default", "wide", "single", "big"]))
+        cases.append((N, K, R, beta, iters, step, layout))
+    return cases
+
+
+@pytest.mark.parametrize("N,K,R,beta,iters,step,layout", _random_cases(36, 20261003))
+def test_randomized_shapes(pkg, oracle, monkeypatch, N, K, R, beta, iters, step, layout):
+    """Seeded random (N, K, replicas, beta, iterations, sample step) with every layout of the random-site kernels forced in turn:
+    table in LDS / in HBM, one word per site, spins in HBM (big-N kernels).  Ragged chunks, steps longer than the run, single
+    replicas, K = 1: everything must equal the oracle."""
+    monkeypatch.setenv("RRRMC_FORCE_WIDE", "1" if layout == "wide" else "0")
+    if layout == "single":
+        monkeypatch.setenv("RRRMC_FORCE_SINGLE", "1")
+    if layout == "big":
+        monkeypatch.setenv("RRRMC_FORCE_BIG", "1")
+    seed = 31 * N + K
+    X = pkg.GraphRRG(N, K, seed=seed)
+    with pkg.Engine(X, R) as eng:
+        eng.seed(seed)
+        eng.init_spins_random()
+        C0 = eng.get_config()
+        Es, acc = eng.standard_mc(beta, iters, step)
+        C1 = eng.get_config()
+    ref = oracle.standard_mc_sparse_batch(X.A, X.J.astype(np.int32), beta, iters, step, seed, C0.s)
+    assert Es.shape == ref[0].shape and (Es == ref[0]).all() and (C1.s == ref[1]).all() and (acc == ref[2]).all()
