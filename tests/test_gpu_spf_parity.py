@@ -133,3 +133,37 @@ def test_spf_overlaps_and_snapshots(pkg, oracle):
     for idx, (a, b) in enumerate([(0, 1), (0, 2), (1, 2)]):
         for r in range(R):
             assert q[idx, r] == oracle.pm1dot(cfgs[a][r], cfgs[b][r], X.N)
+
+
+def _random_spf_cases(n, seed):
+    rng = np.random.default_rng(seed)
+    cases = []
+    while len(cases) < n:
+        K = int(rng.integers(1, 6))
+        N = int(rng.integers(max(6, 2 * K + 2), 700))
+        if (N * K) % 2:
+            N += 1
+        cases.append((N, K, int(rng.integers(1, 200)), float(rng.choice([0.0, 0.5, 1.0, 3.0])), int(rng.integers(1, 12000)),
+                      int(rng.integers(1, 3000))))
+    return cases
+
+
+@pytest.mark.parametrize("N,K,R,beta,iters,step", _random_spf_cases(16, 4242))
+def test_spf_randomized_shapes(pkg, oracle, N, K, R, beta, iters, step):
+    """The Float64 kernel speculates (fields requested iterations ahead, re-read when an accepted move lands in their neighbourhood):
+    seeded random shapes, small N included (hits in nearly every iteration), against the oracle; a second call checks the resume."""
+    seed = 77 * N + K
+    X = pkg.GraphRRGNormal(N, K, seed=seed)
+    with pkg.Engine(X, R) as eng:
+        eng.seed(seed)
+        eng.init_spins_random()
+        C0 = eng.get_config()
+        Es, acc = eng.standard_mc(beta, iters, step)
+        C1 = eng.get_config()
+        Es2, acc2 = eng.standard_mc(beta, iters // 2 + 1, step)
+        C2 = eng.get_config()
+    for r in sorted({0, R // 2, R - 1}):
+        ref = oracle.standard_mc_spf(X.A, X.J, beta, iters, step, seed, C0.s[r], replica=r)
+        assert (Es[r] == ref[0]).all() and (C1.s[r] == ref[1]).all() and acc[r] == ref[2]
+        ref2 = oracle.standard_mc_spf(X.A, X.J, beta, iters // 2 + 1, step, seed, ref[1], it0=iters, replica=r)
+        assert (Es2[r] == ref2[0]).all() and (C2.s[r] == ref2[1]).all() and acc2[r] == ref2[2]
