@@ -121,3 +121,30 @@ def test_config3_full_width_subset(pkg, oracle):
         Es_ref, ch_ref, acc_ref, _ = oracle.standard_mc_skn_batch(X.J, beta, iters, step, seed, C0.s[sl], replica0=8 * g)
         assert (Es[sl] == Es_ref).all() and (C1.s[sl] == ch_ref).all() and (acc[sl] == acc_ref).all()
     assert 0.2 < (acc / iters).mean() < 0.5
+
+
+def _random_sk_cases(n, seed):
+    rng = np.random.default_rng(seed)
+    return [(int(rng.integers(2, 1400)), int(rng.integers(1, 40)), float(rng.choice([0.0, 0.5, 1.0, 2.0])), int(rng.integers(1, 4000)),
+             int(rng.integers(1, 900)), bool(rng.integers(0, 2))) for _ in range(n)]
+
+
+@pytest.mark.parametrize("N,R,beta,iters,step,binary", _random_sk_cases(16, 777))
+def test_sk_randomized_shapes(pkg, oracle, N, R, beta, iters, step, binary):
+    """Seeded random sizes of the dense kernels (1 to 6 sites per thread, partially filled last tile, any number of replicas in the last
+    group of 8), Gaussian and binary couplings, with a resumed second call."""
+    seed = 13 * N + R
+    X = pkg.GraphSK(N, seed=seed) if binary else pkg.GraphSKNormal(N, seed=seed)
+    run = oracle.standard_mc_skb if binary else oracle.standard_mc_skn
+    with pkg.Engine(X, R) as eng:
+        eng.seed(seed)
+        eng.init_spins_random()
+        C0 = eng.get_config()
+        Es, acc = eng.standard_mc(beta, iters, step)
+        C1 = eng.get_config()
+        Es2, acc2 = eng.standard_mc(beta, iters // 2 + 1, step)
+    for r in sorted({0, R - 1}):
+        ref = run(X.J, beta, iters, step, seed, C0.s[r], replica=r)
+        assert (Es[r] == ref[0]).all() and (C1.s[r] == ref[1]).all() and acc[r] == ref[2]
+        ref2 = run(X.J, beta, iters // 2 + 1, step, seed, ref[1], it0=iters, replica=r)
+        assert (Es2[r] == ref2[0]).all() and acc2[r] == ref2[2]
