@@ -176,3 +176,50 @@ def test_rrr_and_bkl_on_discrete_graphs(pkg, oracle, kind, R, beta, iters, step,
         assert E1[r] == oracle.sparse_energy(A, J, C1.s[r])
         refb = oracle.rrr_sparse(A, J, beta, iters, step, seed, C0.s[r], replica=r, form=form, bkl=True)
         assert (Eb[r] == refb[0]).all() and (Cb.s[r] == refb[1]).all() and moves[r] == refb[2]
+
+
+def _random_rrr_cases(n, seed):
+    rng = np.random.default_rng(seed)
+    cases = []
+    while len(cases) < n:
+        K = int(rng.integers(1, 7))
+        N = int(rng.integers(max(6, 2 * K + 2), 500))
+        if (N * K) % 2:
+            N += 1
+        cases.append((N, K, int(rng.integers(1, 150)), float(rng.choice([0.3, 1.0, 2.0])), int(rng.integers(1, 6000)),
+                      int(rng.integers(1, 700)), str(rng.choice(["rrr", "bkl", "wtm", "eo"])), int(rng.choice([0, 1, 4, 16, 64]))))
+    return cases
+
+
+@pytest.mark.parametrize("N,K,R,beta,iters,step,sampler,tpb", _random_rrr_cases(20, 9090))
+def test_discrete_samplers_randomized(pkg, oracle, monkeypatch, N, K, R, beta, iters, step, sampler, tpb):
+    """Seeded random shapes for the thread-per-replica samplers on GraphRRG (K = 1 .. 6: with and without a zero level), with the
+    launch shape forced to 1 .. 64 replicas per workgroup (RRRMC_RRR_TPB): results must not depend on it."""
+    if tpb:
+        monkeypatch.setenv("RRRMC_RRR_TPB", str(tpb))
+    seed = 53 * N + K
+    X = pkg.GraphRRG(N, K, seed=seed)
+    A, J = X.A, X.J.astype(np.int32)
+    with pkg.Engine(X, R) as eng:
+        eng.seed(seed)
+        eng.init_spins_random()
+        C0 = eng.get_config()
+        if sampler == "rrr":
+            out = eng.rrr_mc(beta, iters, step)
+        elif sampler == "bkl":
+            out = eng.bkl_mc(beta, iters, step)
+        elif sampler == "wtm":
+            out = eng.wtm_mc(beta, max(iters // max(step, 1), 1), step=float(step))
+        else:
+            out = eng.extremal_opt(1.0 + beta / 4, iters, step)
+        C1 = eng.get_config()
+    for r in sorted({0, R - 1}):
+        if sampler in ("rrr", "bkl"):
+            ref = oracle.rrr_sparse(A, J, beta, iters, step, seed, C0.s[r], replica=r, bkl=sampler == "bkl")
+            assert (out[0][r] == ref[0]).all() and (C1.s[r] == ref[1]).all() and out[1][r] == ref[2]
+        elif sampler == "wtm":
+            ref = oracle.wtm_mc_sparse(A, J, beta, max(iters // max(step, 1), 1), float(step), seed, C0.s[r], replica=r)
+            assert (out[0][r] == ref[0]).all() and (C1.s[r] == ref[1]).all() and out[1][r] == ref[2] and out[2][r] == ref[3]
+        else:
+            ref = oracle.extremal_opt_sparse(A, J, 1.0 + beta / 4, iters, step, seed, C0.s[r], replica=r)
+            assert (out[0][r] == ref[0]).all() and (C1.s[r] == ref[1]).all() and out[1][r] == ref[2] and (out[2].s[r] == ref[3]).all()
