@@ -40,7 +40,11 @@ int32_t quant_run_init(rrrmc_ctx* ctx, double beta, double fourK)
 {
     RrrParams P = quant_params(ctx, beta, fourK);
     P.ft1 = host_det_exp(-beta * fourK);
-    hipLaunchKernelGGL(rrr_init_kernel, dim3(rrr_blocks(ctx->R)), dim3(rrr_tpb(ctx->R)), 0, ctx->stream, P);
+    // one workgroup per replica (a parallel construction of the same cache); the thread-per-replica form only for absurd M
+    if ((size_t)ctx->qM * sizeof(long long) <= 32768)
+        hipLaunchKernelGGL(rrr_init_coop_kernel, dim3((unsigned)ctx->R), dim3(kInitThreads), (size_t)ctx->qM * sizeof(long long), ctx->stream, P);
+    else
+        hipLaunchKernelGGL(rrr_init_kernel, dim3(rrr_blocks(ctx->R)), dim3(rrr_tpb(ctx->R)), 0, ctx->stream, P);
     HIP_TRY(ctx, hipGetLastError());
     return RRRMC_OK;
 }

@@ -163,6 +163,81 @@ __global__ __launch_bounds__(kRrrThreads) void rrr_init_kernel(RrrParams P)
     P.stats[(size_t)r * 2 + 1] = 0;
 }
 
+// The same construction — energy(X::GraphQuant, C) and the DeltaECache in site order — by one WORKGROUP per replica: every thread
+// classifies a contiguous block of spins, an exclusive scan of the per-class counts over the threads gives each block its
+// offsets inside the four member arrays (site order inside a class is what push! in site order produces: DeltaE.jl:79-88), the
+// integer parts of the energy are reduced with atomics (exact) and thread 0 combines them in the reference's Float64 order.
+// A sequential pass over N = 32 768 spins per replica at every call costs as much as thousands of iterations.
+constexpr int kInitThreads = 256;
+__global__ __launch_bounds__(kInitThreads) void rrr_init_coop_kernel(RrrParams P)
+{
+    __shared__ int s_cnt[4][kInitThreads];
+    __shared__ int s_tot[4];
+    __shared__ long long s_n0;
+    extern __shared__ long long s_slice[];             // [M] integer slice energies
+    const int r = (int)blockIdx.x, tid = (int)threadIdx.x;
+    const RrrView v = rrr_view(P, r);
+    const int N = P.N;
+    if (tid == 0) s_n0 = 0;
+    for (int k = tid; k < P.M; k += kInitThreads) s_slice[k] = 0;
+    __syncthreads();
+    // energy, integer parts: n0 = -sum over Trotter bonds of sigma sigma' (QT.jl:68-82); slice k: sum_x lf_x with lf_x = -(2 sx sum J sy)/2
+    {
+        long long n0 = 0;
+        for (int x = tid; x < N; x += kInitThreads) {
+            const int i = x % P.Nk, k = x / P.Nk;
+            const int prev = i + (k == 0 ? P.M - 1 : k - 1) * P.Nk;
+            n0 -= 1 - 2 * (sbit(v.sp, x) ^ sbit(v.sp, prev));
+            atomicAdd(reinterpret_cast<unsigned long long*>(&s_slice[k]), (unsigned long long)(long long)(-(slice_delta(v, x) / 2)));
+        }
+        atomicAdd(reinterpret_cast<unsigned long long*>(&s_n0), (unsigned long long)n0);
+    }
+    // classes of this thread's block of spins
+    const int per = (N + kInitThreads - 1) / kInitThreads, x0 = tid * per, x1 = x0 + per < N ? x0 + per : N;
+    int cnt[4] = {0, 0, 0, 0};
+    for (int x = x0; x < x1; ++x) {
+        const int k = qt_class(v, x);
+        v.cls[x] = (uint8_t)k;
+        cnt[k] += 1;
+    }
+    for (int k = 0; k < 4; ++k) s_cnt[k][tid] = cnt[k];
+    __syncthreads();
+    if (tid < 4) {                                     // exclusive scan over the threads, one class per lane (256 additions)
+        int run = 0;
+        for (int t = 0; t < kInitThreads; ++t) { const int c = s_cnt[tid][t]; s_cnt[tid][t] = run; run += c; }
+        s_tot[tid] = run;
+    }
+    __syncthreads();
+    int off[4];
+    for (int k = 0; k < 4; ++k) off[k] = s_cnt[k][tid];
+    for (int x = x0; x < x1; ++x) {
+        const int k = v.cls[x];
+        v.sv[(size_t)k * N + off[k]] = (uint16_t)x;
+        v.spos[x] = (uint16_t)off[k];
+        off[k] += 1;
+    }
+    if (tid == 0) {
+        double E = (double)s_n0 * P.fourK / 4;
+        for (int k = 0; k < P.M; ++k) {
+            long long n = s_slice[k];
+            n /= 2;
+            E += (double)n / (double)P.M;
+        }
+        P.E_cur[r] = E;
+        double z = 0.0;
+        for (int k = 0; k < 4; ++k) {
+            v.t[k] = s_tot[k];
+            const double x = (double)s_tot[k] * class_f(k, P.ft1);
+            z += x;
+            P.T[(size_t)r * 4 + k] = x;
+        }
+        P.zz[r] = z;
+        P.acc_rate[r] = 0.5;
+        P.stats[(size_t)r * 2] = 0;
+        P.stats[(size_t)r * 2 + 1] = 0;
+    }
+}
+
 // bytes of LDS one replica's hot state takes in the LDS-resident build below
 inline size_t rrr_quant_lds_bytes(int64_t N, int64_t W, int64_t Nk, int64_t K)
 {
