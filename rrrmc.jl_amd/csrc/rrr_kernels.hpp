@@ -241,7 +241,7 @@ __global__ __launch_bounds__(kInitThreads) void rrr_init_coop_kernel(RrrParams P
 // bytes of LDS one replica's hot state takes in the LDS-resident build below
 inline size_t rrr_quant_lds_bytes(int64_t N, int64_t W, int64_t Nk, int64_t K)
 {
-    return (size_t)W * 4 + (((size_t)N * 2 + 3) & ~(size_t)3) + (((size_t)N + 3) & ~(size_t)3) + 16 + (size_t)Nk * K * 4 + (((size_t)Nk * K + 3) & ~(size_t)3);
+    return (size_t)W * 4 + (((size_t)N * 2 + 3) & ~(size_t)3) + (((size_t)N + 3) & ~(size_t)3) + 16 + (size_t)Nk * K * 4 + (((size_t)Nk * K + 3) & ~(size_t)3) + (size_t)kRrrThreads * 8 * 4;
 }
 
 // LDS = false: one thread per replica, everything in HBM/L2 (any number of replicas per workgroup).
@@ -262,6 +262,7 @@ __global__ __launch_bounds__(kRrrThreads) void rrr_quant_kernel(RrrParams P)
         if (r >= P.R) return;
     }
     RrrView v = rrr_view(P, r);
+    uint32_t* l_rng = nullptr;
     uint32_t* g_sp = v.sp; uint8_t* g_cls = v.cls; uint16_t* g_spos = v.spos; int32_t* g_t = v.t;
     if constexpr (LDS) {
         const int tid = (int)threadIdx.x, nt = (int)blockDim.x;
@@ -271,6 +272,7 @@ __global__ __launch_bounds__(kRrrThreads) void rrr_quant_kernel(RrrParams P)
         int32_t* l_t = reinterpret_cast<int32_t*>(l_cls + ((P.N + 3) & ~3));  // [4]
         int32_t* l_A = l_t + 4;                                               // [Nk][K]
         int8_t* l_J = reinterpret_cast<int8_t*>(l_A + P.Nk * P.K);            // [Nk][K]
+        l_rng = reinterpret_cast<uint32_t*>(l_J + ((P.Nk * P.K + 3) & ~3));   // [64][8]  the RRR draws of the next 64 iterations
         for (int i = tid; i < P.W; i += nt) l_sp[i] = g_sp[i];
         for (int i = tid; i < P.N; i += nt) { l_spos[i] = g_spos[i]; l_cls[i] = g_cls[i]; }
         for (int i = tid; i < P.Nk * P.K; i += nt) { l_A[i] = P.A[i]; l_J[i] = P.J[i]; }
@@ -278,7 +280,7 @@ __global__ __launch_bounds__(kRrrThreads) void rrr_quant_kernel(RrrParams P)
         __syncthreads();
         v.sp = l_sp; v.spos = l_spos; v.cls = l_cls; v.t = l_t; v.A = l_A; v.J = l_J;
     }
-    if (!LDS || threadIdx.x == 0) {
+    const bool worker = !LDS || threadIdx.x == 0;
     const uint32_t rep = P.replica0 + (uint32_t)r;
     double T[4], z = P.zz[r], E = P.E_cur[r], acc_rate = P.acc_rate[r];
     for (int k = 0; k < 4; ++k) T[k] = P.T[(size_t)r * 4 + k];
@@ -287,11 +289,27 @@ __global__ __launch_bounds__(kRrrThreads) void rrr_quant_kernel(RrrParams P)
     const double dEl[2] = {0.0, P.fourK};
 
     long long next_sample = P.step;          // iterations k * step: a counter instead of a 64-bit modulo per iteration
-    for (int64_t it = 1; it <= P.iters; ++it) {
+    // LDS build: the chain runs on lane 0 and is bound by its instruction stream, so the state-independent part of an iteration —
+    // the two Philox blocks of the RRR stream — is computed for 64 iterations at a time by the whole wavefront (one iteration per lane)
+    for (int64_t base = 0; base < P.iters; base += (LDS ? kRrrThreads : P.iters)) {
+    if constexpr (LDS) {
+        __syncthreads();
+        const uint64_t gl = P.g0 + (uint64_t)(base + 1 + (int64_t)threadIdx.x);
+        const Philox4 a = philox4x32_10((uint32_t)gl, (uint32_t)(gl >> 32), rep, TAG_RRR, P.k0, P.k1);
+        const Philox4 b = philox4x32_10((uint32_t)gl, (uint32_t)(gl >> 32), rep, TAG_RRR | (1u << 8), P.k0, P.k1);
+        uint32_t* q = l_rng + threadIdx.x * 8;
+        q[0] = a.w[0]; q[1] = a.w[1]; q[2] = a.w[2]; q[3] = a.w[3]; q[4] = b.w[0]; q[5] = b.w[1]; q[6] = b.w[2]; q[7] = b.w[3];
+        __syncthreads();
+    }
+    const int64_t it_end = LDS ? (base + kRrrThreads < P.iters ? base + kRrrThreads : P.iters) : P.iters;
+    if (worker)
+    for (int64_t it = base + 1; it <= it_end; ++it) {
         if (it == next_sample) { next_sample += P.step; P.Es[ns * P.R + r] = E; ns += 1; }
         const uint64_t g = P.g0 + (uint64_t)it;
         // rand_move: DeltaE.jl:146-167
-        const Philox4 o = philox4x32_10((uint32_t)g, (uint32_t)(g >> 32), rep, TAG_RRR, P.k0, P.k1);
+        Philox4 o;
+        if constexpr (LDS) { const uint32_t* q = l_rng + (it - base - 1) * 8; o.w[0] = q[0]; o.w[1] = q[1]; o.w[2] = q[2]; o.w[3] = q[3]; }
+        else o = philox4x32_10((uint32_t)g, (uint32_t)(g >> 32), rep, TAG_RRR, P.k0, P.k1);
         const double rr = (double)((((uint64_t)o.w[0] << 32) | o.w[1]) >> 11) * 0x1.0p-53 * z;
         int k = 0;
         double cT = 0.0;
@@ -339,7 +357,9 @@ __global__ __launch_bounds__(kRrrThreads) void rrr_quant_kernel(RrrParams P)
                 const double a = c * det_exp(x);
                 ok = a >= 1;
                 if (!ok) {
-                    const Philox4 o2 = philox4x32_10((uint32_t)g, (uint32_t)(g >> 32), rep, TAG_RRR | (1u << 8), P.k0, P.k1);
+                    Philox4 o2;
+                    if constexpr (LDS) { const uint32_t* q = l_rng + (it - base - 1) * 8 + 4; o2.w[0] = q[0]; o2.w[1] = q[1]; }
+                    else o2 = philox4x32_10((uint32_t)g, (uint32_t)(g >> 32), rep, TAG_RRR | (1u << 8), P.k0, P.k1);
                     ok = (double)((((uint64_t)o2.w[0] << 32) | o2.w[1]) >> 11) * 0x1.0p-53 < a;
                 }
             }
@@ -387,7 +407,9 @@ __global__ __launch_bounds__(kRrrThreads) void rrr_quant_kernel(RrrParams P)
                     const double a = c * det_exp(x);
                     ok = a >= 1;
                     if (!ok) {
-                        const Philox4 o2 = philox4x32_10((uint32_t)g, (uint32_t)(g >> 32), rep, TAG_RRR | (1u << 8), P.k0, P.k1);
+                        Philox4 o2;
+                        if constexpr (LDS) { const uint32_t* q = l_rng + (it - base - 1) * 8 + 4; o2.w[0] = q[0]; o2.w[1] = q[1]; }
+                        else o2 = philox4x32_10((uint32_t)g, (uint32_t)(g >> 32), rep, TAG_RRR | (1u << 8), P.k0, P.k1);
                         ok = (double)((((uint64_t)o2.w[0] << 32) | o2.w[1]) >> 11) * 0x1.0p-53 < a;
                     }
                 }
@@ -396,6 +418,8 @@ __global__ __launch_bounds__(kRrrThreads) void rrr_quant_kernel(RrrParams P)
         }
         acc_rate = acc_rate * (1 - P.lambda) + (acc ? 1.0 : 0.0) * P.lambda;             // RRRMC.jl:281
     }
+    }
+    if (worker) {
     for (int k = 0; k < 4; ++k) P.T[(size_t)r * 4 + k] = T[k];
     P.zz[r] = z; P.E_cur[r] = E; P.acc_rate[r] = acc_rate;
     P.stats[(size_t)r * 2] = accepted; P.stats[(size_t)r * 2 + 1] = staged_its;
