@@ -47,6 +47,7 @@ struct RrrParams {
 struct RrrView {             // one replica's slices of the arrays above
     uint32_t* sp; uint8_t* cls; uint16_t* sv; uint16_t* spos; int32_t* t;
     int N, Nk, M, K;
+    uint32_t nk_magic;       // ceil(2^32 / Nk): floor(x / Nk) = mulhi(x, nk_magic) exactly for x < 2^16 (x e < 2^32 with e = Nk nk_magic - 2^32 < Nk)
     const int32_t* A; const int8_t* J;
     double fourK;
 };
@@ -78,7 +79,7 @@ __device__ __forceinline__ int qt_class(const RrrView& v, int i)      // DeltaE.
 // delta_energy of the slice graph (RRG.jl:236-244) recomputed from the slice's spins: 2 sigma_i sum_k J_ik sigma_k
 __device__ __forceinline__ int slice_delta(const RrrView& v, int move)
 {
-    const int k = move / v.Nk, i = move - k * v.Nk, off = k * v.Nk;
+    const int k = (int)__umulhi((uint32_t)move, v.nk_magic), i = move - k * v.Nk, off = k * v.Nk;
     const int si = sbit(v.sp, move);
     int acc = 0;
     for (int q = 0; q < v.K; ++q) {
@@ -115,6 +116,7 @@ __device__ __forceinline__ RrrView rrr_view(const RrrParams& P, int r)
     v.spos = P.spos + (size_t)r * P.N;
     v.t = P.st + (size_t)r * 4;
     v.N = P.N; v.Nk = P.Nk; v.M = P.M; v.K = P.K; v.A = P.A; v.J = P.J; v.fourK = P.fourK;
+    v.nk_magic = (uint32_t)((0x100000000ull + (uint32_t)P.Nk - 1u) / (uint32_t)P.Nk);
     return v;
 }
 
