@@ -203,7 +203,23 @@ int32_t sparse_rrr_bkl_async(rrrmc_ctx* ctx, int mode, double beta, int64_t iter
     HIP_TRY(ctx, hipMemsetAsync(ctx->d_acc, 0, sizeof(int64_t) * ctx->Rpad, st));
     if ((rc = rp_in(ctx, rv, st))) return rc;
     HIP_TRY(ctx, hipEventRecord(ctx->ev_sweep[0], st));
-    hipLaunchKernelGGL(rrr_sparse_kernel, dim3(rrr_blocks(R)), dim3(rrr_tpb(R)), 0, st, P);
+    {
+        // few replicas run one per workgroup anyway: stage the replica's hot state and the graph in LDS if they fit
+        const size_t lds = rrr_sparse_lds_bytes(N, W, K);
+        const char* no_lds = std::getenv("RRRMC_RRR_NO_LDS");            // tests / timing experiments
+        const bool use_lds = rrr_tpb(R) == 1 && lds <= (size_t)kLdsLimit && !(no_lds && no_lds[0] == '1');
+        // the per-class arrays are sized at compile time (2, 4 or 8 levels) so that they stay in registers
+        typedef void (*rs_fn)(RrrSparseParams);
+        const int slm = L <= 2 ? 0 : (L <= 4 ? 1 : 2);
+        static const rs_fn lds_fns[3] = {rrr_sparse_kernel<true, 2>, rrr_sparse_kernel<true, 4>, rrr_sparse_kernel<true, 8>};
+        static const rs_fn glb_fns[3] = {rrr_sparse_kernel<false, 2>, rrr_sparse_kernel<false, 4>, rrr_sparse_kernel<false, 8>};
+        if (use_lds) {
+            HIP_TRY(ctx, raise_lds_attr(reinterpret_cast<const void*>(lds_fns[slm]), lds));
+            hipLaunchKernelGGL(lds_fns[slm], dim3((unsigned)R), dim3(kRrrThreads), lds, st, P);
+        } else {
+            hipLaunchKernelGGL(glb_fns[slm], dim3(rrr_blocks(R)), dim3(rrr_tpb(R)), 0, st, P);
+        }
+    }
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipEventRecord(ctx->ev_sweep[1], st));
     if ((rc = rp_out(ctx, rv, st))) return rc;

@@ -903,11 +903,57 @@ struct RrrSparseParams {
     int N, K, L, W, R, Rpad, mode;      // mode 0 = rrrMC, 1 = bklMC
 };
 
+// LDS = true (one replica per workgroup, see rrr_sparse_kernel): spins, classes, positions and the neighbour table (as 16-bit ids)
+// are LDS copies
+// SLM = compile-time bound on the number of levels (2, 4 or 8): the per-class arrays have 2 SLM entries and must stay in REGISTERS
+// (dynamically indexed arrays of 16 doubles end up in scratch memory, a memory round trip per access: 5x slower kernels)
+template <bool LDS, int SLM>
 struct SparseChain {
-    const RrrSparseParams* P;
+    // copies of the few parameters the chain needs: a pointer to the kernel's parameter struct would force that struct — and every
+    // access to it — into scratch memory
+    struct Cfg { int N, K, L, skip_zero; const int32_t* A; const int8_t* J; int dEl[SLM]; double ft[SLM]; };
+    Cfg cfg;
     uint32_t* sp; uint8_t* cls; uint16_t* sv; uint16_t* spos;
-    int t[2 * kSLmax];
-    double T[2 * kSLmax], z;
+    const uint16_t* A16; const int8_t* Jl;          // LDS copies of the neighbour table / couplings (LDS build only)
+    __device__ __forceinline__ int nbr(int i, int q) const { if constexpr (LDS) return (int)A16[i * cfg.K + q]; else return (int)cfg.A[(size_t)i * cfg.K + q]; }
+    __device__ __forceinline__ int cpl(int i, int q) const { if constexpr (LDS) return (int)Jl[i * cfg.K + q]; else return (int)cfg.J[(size_t)i * cfg.K + q]; }
+    __device__ __forceinline__ int lev(int a) const { int d = 0;
+#pragma unroll
+        for (int k = 0; k < SLM; ++k) d = a == k ? cfg.dEl[k] : d;
+        return d; }
+    __device__ __forceinline__ int find(int ad) const { int a = 0;          // findk: DeltaE.jl:28-60 (exact comparison of |dE|)
+#pragma unroll
+        for (int k = 0; k < SLM; ++k) a = (k < cfg.L && cfg.dEl[k] == ad) ? k : a;
+        return a; }
+    int t[2 * SLM];
+    double T[2 * SLM], z;
+    // the per-class arrays are only ever indexed through these fully unrolled selects: a dynamically indexed local array would be
+    // placed in scratch memory
+    __device__ __forceinline__ int tg(int k) const { int x = 0;
+#pragma unroll
+        for (int a = 0; a < 2 * SLM; ++a) x = k == a ? t[a] : x;
+        return x; }
+    __device__ __forceinline__ void tadd(int k, int d) {
+#pragma unroll
+        for (int a = 0; a < 2 * SLM; ++a) t[a] = k == a ? t[a] + d : t[a]; }
+    __device__ __forceinline__ double Tg(int k) const { double x = 0.0;
+#pragma unroll
+        for (int a = 0; a < 2 * SLM; ++a) x = k == a ? T[a] : x;
+        return x; }
+    __device__ __forceinline__ void Tadd(int k, double d) {
+#pragma unroll
+        for (int a = 0; a < 2 * SLM; ++a) T[a] = k == a ? T[a] + d : T[a]; }
+    // rand_move's class: the first k with rr < T[0] + .. + T[k], else the last class of non-zero weight (DeltaE.jl:146-160)
+    __device__ __forceinline__ int pick_class(double rr, int K2) const
+    {
+        int ksel = -1;
+        double cT = 0.0;
+#pragma unroll
+        for (int a = 0; a < 2 * SLM; ++a)
+            if (a < K2 && ksel < 0) { cT += T[a]; if (rr < cT) ksel = a; }
+        if (ksel < 0) { ksel = K2 - 1; while (Tg(ksel) == 0) ksel -= 1; }
+        return ksel;
+    }
     __device__ __forceinline__ int sbit(int x) const { return (int)((sp[x >> 5] >> (x & 31)) & 1u); }
     __device__ __forceinline__ void sflip(int x) { sp[x >> 5] ^= 1u << (x & 31); }
     // delta_energy (RRG.jl:236-244 / EA.jl:266-275) recomputed from the spins: 2 sigma_i sum_k J_ik sigma_k
@@ -915,32 +961,36 @@ struct SparseChain {
     {
         const int si = sbit(i);
         int acc = 0;
-        for (int q = 0; q < P->K; ++q) {
-            const int sy = sbit(P->A[(size_t)i * P->K + q]);
-            acc += (si == sy) ? (int)P->J[(size_t)i * P->K + q] : -(int)P->J[(size_t)i * P->K + q];
+        for (int q = 0; q < cfg.K; ++q) {
+            const int sy = sbit(nbr(i, q));
+            acc += (si == sy) ? cpl(i, q) : -cpl(i, q);
         }
         return 2 * acc;
     }
     __device__ __forceinline__ int klass(int i) const      // a + L*up, DeltaE.jl:80-86
     {
-        const int d = dE(i), a = P->lv.find(d < 0 ? -d : d);
+        const int d = dE(i), a = find(d < 0 ? -d : d);
         const int up = d > 0 || (d == 0 && sbit(i) == 1);
-        return a + P->L * up;
+        return a + cfg.L * up;
     }
     // neighbors(X, move)[q]: repeats removed (uA, EA.jl:158); zero couplings dropped for a general-level GraphRRG (RRG.jl:133)
-    __device__ __forceinline__ bool is_nb(const int32_t* Ax, int move, int q) const
+    __device__ __forceinline__ bool is_nb(int move, int q) const
     {
-        if (q > 0 && Ax[q] == Ax[q - 1]) return false;
-        return !(P->lv.skip_zero && P->J[(size_t)move * P->K + q] == 0);
+        if (q > 0 && nbr(move, q) == nbr(move, q - 1)) return false;
+        return !(cfg.skip_zero && cpl(move, q) == 0);
     }
-    __device__ __forceinline__ double f(int k) const { return k >= P->L ? P->ft[k - P->L] : 1.0; }
+    __device__ __forceinline__ double f(int k) const { double x = 1.0;
+#pragma unroll
+        for (int a = 0; a < SLM; ++a) x = (k - cfg.L == a) ? cfg.ft[a] : x;
+        return x; }
     __device__ __forceinline__ void set_move(int j, int k0, int k1)
     {
-        uint16_t* v0 = sv + (size_t)k0 * P->N;
-        uint16_t* v1 = sv + (size_t)k1 * P->N;
-        const int p = spos[j], last = v0[t[k0] - 1];
-        v0[p] = (uint16_t)last; spos[last] = (uint16_t)p; t[k0] -= 1;
-        v1[t[k1]] = (uint16_t)j; spos[j] = (uint16_t)t[k1]; t[k1] += 1;
+        uint16_t* v0 = sv + (size_t)k0 * cfg.N;
+        uint16_t* v1 = sv + (size_t)k1 * cfg.N;
+        const int p = spos[j], last = v0[tg(k0) - 1];
+        v0[p] = (uint16_t)last; spos[last] = (uint16_t)p; tadd(k0, -1);
+        const int t1 = tg(k1);
+        v1[t1] = (uint16_t)j; spos[j] = (uint16_t)t1; tadd(k1, 1);
         cls[j] = (uint8_t)k1;
     }
     // apply_move!: DeltaE.jl:232-295; returns c = z / z'
@@ -948,15 +998,14 @@ struct SparseChain {
     {
         sflip(move);
         double zp = z;
-        const int32_t* Ax = P->A + (size_t)move * P->K;
-        for (int q = 0; q <= P->K; ++q) {
-            if (q < P->K && !is_nb(Ax, move, q)) continue;
-            const int j = q < P->K ? Ax[q] : move;
+        for (int q = 0; q <= cfg.K; ++q) {
+            if (q < cfg.K && !is_nb(move, q)) continue;
+            const int j = q < cfg.K ? nbr(move, q) : move;
             const int k0 = cls[j];
-            const int k1 = q < P->K ? klass(j) : (k0 >= P->L ? k0 - P->L : k0 + P->L);
-            if (q < P->K && k0 == k1) continue;
+            const int k1 = q < cfg.K ? klass(j) : (k0 >= cfg.L ? k0 - cfg.L : k0 + cfg.L);
+            if (q < cfg.K && k0 == k1) continue;
             const double f0 = f(k0), f1 = f(k1);
-            T[k0] -= f0; T[k1] += f1; zp += f1 - f0;
+            Tadd(k0, -f0); Tadd(k1, f1); zp += f1 - f0;
             set_move(j, k0, k1);
         }
         const double cc = z / zp;
@@ -965,71 +1014,146 @@ struct SparseChain {
     }
 };
 
+// bytes of LDS of the LDS build: spins, positions, classes, the neighbour table as 16-bit ids, the couplings, 64 x 8 draw words
+inline size_t rrr_sparse_lds_bytes(int64_t N, int64_t W, int64_t K)
+{
+    return (size_t)W * 4 + (((size_t)N * 2 + 3) & ~(size_t)3) + (((size_t)N + 3) & ~(size_t)3) + (((size_t)N * K * 2 + 3) & ~(size_t)3) +
+           (((size_t)N * K + 3) & ~(size_t)3) + (size_t)kRrrThreads * 8 * 4;
+}
+
+// LDS = false: one thread per replica, everything in HBM/L2.  LDS = true: one workgroup (one wavefront) per replica, as for
+// rrr_quant_kernel: the replica's spins, class bytes and set positions and the graph (16-bit neighbour ids, couplings) staged in LDS
+// by all 64 lanes, the two Philox blocks of an rrrMC iteration computed 64 iterations at a time by the whole wavefront; lane 0
+// runs the chain.  The reference's own experiment (scripts/scripts.jl:test_RRG: N = 10^4, K = 3) takes 121 KB.
+template <bool LDS, int SLM>
 __global__ __launch_bounds__(kRrrThreads) void rrr_sparse_kernel(RrrSparseParams P)
 {
-    const int r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= P.R) return;
+    extern __shared__ uint32_t rs_lds[];
+    int r;
+    if constexpr (LDS) {
+        r = (int)blockIdx.x;
+    } else {
+        r = blockIdx.x * blockDim.x + threadIdx.x;
+        if (r >= P.R) return;
+    }
     const int N = P.N, L = P.L, K2 = 2 * P.L;
-    SparseChain c;
-    c.P = &P;
+    SparseChain<LDS, SLM> c;
+    c.cfg.N = P.N; c.cfg.K = P.K; c.cfg.L = P.L; c.cfg.skip_zero = P.lv.skip_zero; c.cfg.A = P.A; c.cfg.J = P.J;
+#pragma unroll
+    for (int k = 0; k < SLM; ++k) { c.cfg.dEl[k] = P.lv.dElist[k]; c.cfg.ft[k] = P.ft[k]; }
     c.sp = P.spins + (size_t)r * P.W; c.cls = P.cls + (size_t)r * N; c.sv = P.sv + (size_t)r * K2 * N; c.spos = P.spos + (size_t)r * N;
+    c.A16 = nullptr; c.Jl = nullptr;
+    uint32_t* g_sp = c.sp; uint8_t* g_cls = c.cls; uint16_t* g_spos = c.spos;
+    uint32_t* l_rng = nullptr;
+    if constexpr (LDS) {
+        const int tid = (int)threadIdx.x, nt = (int)blockDim.x, NK = N * P.K;
+        uint32_t* l_sp = rs_lds;                                                          // [W]
+        uint16_t* l_spos = reinterpret_cast<uint16_t*>(l_sp + P.W);                       // [N]
+        uint8_t* l_cls = reinterpret_cast<uint8_t*>(l_spos) + ((2 * N + 3) & ~3);         // [N]
+        uint16_t* l_A = reinterpret_cast<uint16_t*>(l_cls + ((N + 3) & ~3));              // [N][K]
+        int8_t* l_J = reinterpret_cast<int8_t*>(l_A) + ((2 * NK + 3) & ~3);               // [N][K]
+        l_rng = reinterpret_cast<uint32_t*>(l_J + ((NK + 3) & ~3));                       // [64][8]
+        for (int i = tid; i < P.W; i += nt) l_sp[i] = g_sp[i];
+        for (int i = tid; i < NK; i += nt) { l_A[i] = (uint16_t)P.A[i]; l_J[i] = P.J[i]; }
+        __syncthreads();
+        c.sp = l_sp; c.spos = l_spos; c.cls = l_cls; c.A16 = l_A; c.Jl = l_J;
+    }
+    const bool worker = !LDS || threadIdx.x == 0;
+    long long E = 0, accepted = 0, staged_its = 0, ns = 0, itdone = 0;
+    if (worker) {
     // energy(X, C) and gen_ΔEcache in site order (RRRMC.jl:177-178, DeltaE.jl:74-103)
     long long n = 0;
-    for (int k = 0; k < K2; ++k) c.t[k] = 0;
+#pragma unroll
+    for (int k = 0; k < 2 * SLM; ++k) c.t[k] = 0;
     for (int i = 0; i < N; ++i) {
         n -= c.dE(i) / 2;                       // lf_x = -sum J sx sy
-        const int k = c.klass(i);
+        const int k = c.klass(i), tk = c.tg(k);
         c.cls[i] = (uint8_t)k;
-        c.sv[(size_t)k * N + c.t[k]] = (uint16_t)i;
-        c.spos[i] = (uint16_t)c.t[k];
-        c.t[k] += 1;
+        c.sv[(size_t)k * N + tk] = (uint16_t)i;
+        c.spos[i] = (uint16_t)tk;
+        c.tadd(k, 1);
     }
-    long long E = n / 2;
+    E = n / 2;
     c.z = 0.0;
-    for (int k = 0; k < 2 * kSLmax; ++k) c.T[k] = 0.0;
-    for (int k = 0; k < K2; ++k) { const double x = (double)c.t[k] * c.f(k); c.z += x; c.T[k] = x; }
+#pragma unroll
+    for (int k = 0; k < 2 * SLM; ++k) c.T[k] = 0.0;
+#pragma unroll
+    for (int k = 0; k < 2 * SLM; ++k)
+        if (k < K2) { const double x = (double)c.t[k] * c.f(k); c.z += x; c.T[k] = x; }
+    }
 
     const uint32_t rep = P.replica0 + (uint32_t)r;
-    long long accepted = 0, staged_its = 0, ns = 0, itdone = 0;
     if (P.mode == 0) {
         double acc_rate = 0.5;
         long long next_sample = P.step;          // iterations k * step: a counter instead of a 64-bit modulo per iteration
-        for (long long it = 1; it <= P.iters; ++it) {
+        for (long long base = 0; base < P.iters; base += (LDS ? (long long)kRrrThreads : (long long)P.iters)) {
+        if constexpr (LDS) {                     // the draws of the next 64 iterations, one iteration per lane
+            __syncthreads();
+            const uint64_t gl = P.g0 + (uint64_t)(base + 1 + (long long)threadIdx.x);
+            const Philox4 a = philox4x32_10((uint32_t)gl, (uint32_t)(gl >> 32), rep, TAG_RRR, P.k0, P.k1);
+            const Philox4 b = philox4x32_10((uint32_t)gl, (uint32_t)(gl >> 32), rep, TAG_RRR | (1u << 8), P.k0, P.k1);
+            uint32_t* q = l_rng + threadIdx.x * 8;
+            q[0] = a.w[0]; q[1] = a.w[1]; q[2] = a.w[2]; q[3] = a.w[3]; q[4] = b.w[0]; q[5] = b.w[1]; q[6] = b.w[2]; q[7] = b.w[3];
+            __syncthreads();
+        }
+        const long long it_end = LDS ? (base + kRrrThreads < P.iters ? base + kRrrThreads : (long long)P.iters) : (long long)P.iters;
+        if (worker)
+        for (long long it = base + 1; it <= it_end; ++it) {
             if (it == next_sample) { next_sample += P.step; P.Es[(size_t)ns * P.Rpad + r] = (int32_t)E; ns += 1; }
             const uint64_t g = P.g0 + (uint64_t)it;
-            const Philox4 o = philox4x32_10((uint32_t)g, (uint32_t)(g >> 32), rep, TAG_RRR, P.k0, P.k1);
-            const Philox4 o2 = philox4x32_10((uint32_t)g, (uint32_t)(g >> 32), rep, TAG_RRR | (1u << 8), P.k0, P.k1);
+            Philox4 o, o2;
+            if constexpr (LDS) {
+                const uint32_t* q = l_rng + (it - base - 1) * 8;
+                o.w[0] = q[0]; o.w[1] = q[1]; o.w[2] = q[2]; o.w[3] = q[3]; o2.w[0] = q[4]; o2.w[1] = q[5];
+            } else {
+                o = philox4x32_10((uint32_t)g, (uint32_t)(g >> 32), rep, TAG_RRR, P.k0, P.k1);
+                o2 = philox4x32_10((uint32_t)g, (uint32_t)(g >> 32), rep, TAG_RRR | (1u << 8), P.k0, P.k1);
+            }
             const double u1 = (double)((((uint64_t)o2.w[0] << 32) | o2.w[1]) >> 11) * 0x1.0p-53;
             // rand_move
             const double rr = (double)((((uint64_t)o.w[0] << 32) | o.w[1]) >> 11) * 0x1.0p-53 * c.z;
-            int k = 0;
-            double cT = 0.0;
-            for (k = 0; k < K2; ++k) { cT += c.T[k]; if (rr < cT) break; }
-            if (k == K2) k = K2 - 1;
-            if (!(rr < cT)) while (c.T[k] == 0) k -= 1;
-            const int dE = k < L ? -P.lv.dElist[k] : P.lv.dElist[k - L];
-            const int move = c.sv[(size_t)k * N + (int)mulhi64(((uint64_t)o.w[2] << 32) | o.w[3], (uint64_t)c.t[k])];
+            const int k = c.pick_class(rr, K2);
+            const int dE = k < L ? -c.lev(k) : c.lev(k - L);
+            const int move = c.sv[(size_t)k * N + (int)mulhi64(((uint64_t)o.w[2] << 32) | o.w[3], (uint64_t)c.tg(k))];
             bool acc = false;
             if (acc_rate < P.staged_thr) {
                 staged_its += 1;
-                int sj[9], s0[9], s1[9], nst = 0;
+                // staged changes: slot q = neighbour q (slot kNbMax = the moved spin), live[q] says whether it changes class; fixed slots
+                // and fully unrolled loops keep these arrays in registers
+                constexpr int kNbMax = 8;
+                int sj[kNbMax + 1], s0[kNbMax + 1], s1[kNbMax + 1];
+                bool live[kNbMax + 1];
                 c.sflip(move);
-                const int32_t* Ax = P.A + (size_t)move * P.K;
-                for (int q = 0; q < P.K; ++q) {
-                    if (!c.is_nb(Ax, move, q)) continue;
-                    const int j = Ax[q], k0 = c.cls[j], k1 = c.klass(j);
-                    if (k0 == k1) continue;
-                    sj[nst] = j; s0[nst] = k0; s1[nst] = k1; ++nst;
+#pragma unroll
+                for (int q = 0; q < kNbMax; ++q) {
+                    live[q] = false; sj[q] = 0; s0[q] = 0; s1[q] = 0;
+                    if (q < P.K && c.is_nb(move, q)) {
+                        const int j = c.nbr(move, q), k0 = c.cls[j], k1 = c.klass(j);
+                        if (k0 != k1) { live[q] = true; sj[q] = j; s0[q] = k0; s1[q] = k1; }
+                    }
                 }
-                { const int k0 = c.cls[move]; sj[nst] = move; s0[nst] = k0; s1[nst] = k0 >= L ? k0 - L : k0 + L; ++nst; }
+                { const int k0 = c.cls[move]; live[kNbMax] = true; sj[kNbMax] = move; s0[kNbMax] = k0; s1[kNbMax] = k0 >= L ? k0 - L : k0 + L; }
                 c.sflip(move);
-                double Tp[2 * kSLmax], zp = c.z;
-                for (int q = 0; q < 2 * kSLmax; ++q) Tp[q] = c.T[q];
-                for (int q = 0; q < nst; ++q) { const double f0 = c.f(s0[q]), f1 = c.f(s1[q]); Tp[s0[q]] -= f0; Tp[s1[q]] += f1; zp += f1 - f0; }
+                double Tp[2 * SLM], zp = c.z;
+#pragma unroll
+                for (int q = 0; q < 2 * SLM; ++q) Tp[q] = c.T[q];
+#pragma unroll
+                for (int q = 0; q <= kNbMax; ++q)
+                    if (live[q]) {
+                        const double f0 = c.f(s0[q]), f1 = c.f(s1[q]);
+#pragma unroll
+                        for (int a = 0; a < 2 * SLM; ++a) Tp[a] = s0[q] == a ? Tp[a] - f0 : Tp[a];
+#pragma unroll
+                        for (int a = 0; a < 2 * SLM; ++a) Tp[a] = s1[q] == a ? Tp[a] + f1 : Tp[a];
+                        zp += f1 - f0;
+                    }
                 if (u1 < c.z / zp) {
                     c.sflip(move);
-                    for (int q = 0; q < nst; ++q) c.set_move(sj[q], s0[q], s1[q]);
-                    for (int q = 0; q < 2 * kSLmax; ++q) c.T[q] = Tp[q];
+#pragma unroll
+                    for (int q = 0; q <= kNbMax; ++q)
+                        if (live[q]) c.set_move(sj[q], s0[q], s1[q]);
+#pragma unroll
+                    for (int q = 0; q < 2 * SLM; ++q) c.T[q] = Tp[q];
                     c.z = zp;
                     E += dE; accepted += 1; acc = true;
                 }
@@ -1040,8 +1164,9 @@ __global__ __launch_bounds__(kRrrThreads) void rrr_sparse_kernel(RrrSparseParams
             }
             acc_rate = acc_rate * (1 - P.lambda) + (acc ? 1.0 : 0.0) * P.lambda;
         }
+        }
         itdone = P.iters;
-    } else {
+    } else if (worker) {
         long long it = 0, nextstep = P.step, m = 0;
         while (it < P.iters) {
             m += 1;
@@ -1052,13 +1177,9 @@ __global__ __launch_bounds__(kRrrThreads) void rrr_sparse_kernel(RrrSparseParams
             const long long skip = skipf >= 9.0e18 ? (long long)9.0e18 : (long long)skipf;
             const Philox4 o = philox4x32_10((uint32_t)g, (uint32_t)(g >> 32), rep, TAG_RRR, P.k0, P.k1);
             const double rr = (double)((((uint64_t)o.w[0] << 32) | o.w[1]) >> 11) * 0x1.0p-53 * c.z;
-            int k = 0;
-            double cT = 0.0;
-            for (k = 0; k < K2; ++k) { cT += c.T[k]; if (rr < cT) break; }
-            if (k == K2) k = K2 - 1;
-            if (!(rr < cT)) while (c.T[k] == 0) k -= 1;
-            const int dE = k < L ? -P.lv.dElist[k] : P.lv.dElist[k - L];
-            const int move = c.sv[(size_t)k * N + (int)mulhi64(((uint64_t)o.w[2] << 32) | o.w[3], (uint64_t)c.t[k])];
+            const int k = c.pick_class(rr, K2);
+            const int dE = k < L ? -c.lev(k) : c.lev(k - L);
+            const int move = c.sv[(size_t)k * N + (int)mulhi64(((uint64_t)o.w[2] << 32) | o.w[3], (uint64_t)c.tg(k))];
             bool out = false;
             while (it + skip + 1 >= nextstep) {
                 P.Es[(size_t)ns * P.Rpad + r] = (int32_t)E; ns += 1;
@@ -1074,9 +1195,17 @@ __global__ __launch_bounds__(kRrrThreads) void rrr_sparse_kernel(RrrSparseParams
         staged_its = accepted;
         itdone = it;
     }
-    P.E_cur[r] = (int32_t)E;
-    P.acc_cur[r] = accepted;
-    P.stats[(size_t)r * 3] = accepted; P.stats[(size_t)r * 3 + 1] = staged_its; P.stats[(size_t)r * 3 + 2] = itdone;
+    if (worker) {
+        P.E_cur[r] = (int32_t)E;
+        P.acc_cur[r] = accepted;
+        P.stats[(size_t)r * 3] = accepted; P.stats[(size_t)r * 3 + 1] = staged_its; P.stats[(size_t)r * 3 + 2] = itdone;
+    }
+    if constexpr (LDS) {
+        __syncthreads();
+        const int tid = (int)threadIdx.x, nt = (int)blockDim.x;
+        for (int i = tid; i < P.W; i += nt) g_sp[i] = c.sp[i];
+        for (int i = tid; i < N; i += nt) { g_spos[i] = c.spos[i]; g_cls[i] = c.cls[i]; }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------

@@ -223,3 +223,32 @@ def test_discrete_samplers_randomized(pkg, oracle, monkeypatch, N, K, R, beta, i
         else:
             ref = oracle.extremal_opt_sparse(A, J, 1.0 + beta / 4, iters, step, seed, C0.s[r], replica=r)
             assert (out[0][r] == ref[0]).all() and (C1.s[r] == ref[1]).all() and out[1][r] == ref[2] and (out[2].s[r] == ref[3]).all()
+
+
+@pytest.mark.parametrize("kind,R,beta,iters,step,thr", [
+    (("rrg", 10000, 3), 6, 2.0, 30000, 1000, 0.5),     # the reference's experiment size (scripts.jl:23): 121 KB of LDS per replica
+    (("rrg", 333, 4), 40, 1.0, 12000, 100, 0.0),       # even K, always direct
+    (("ea", 5, 3), 33, 1.5, 9000, 125, 1.0),           # K = 6, always staged
+])
+def test_rrr_sparse_lds_and_global_builds_agree(pkg, oracle, monkeypatch, kind, R, beta, iters, step, thr):
+    """Few replicas run one workgroup per replica with the state and the graph staged in LDS (and the RRR draws batched over the
+    wavefront); RRRMC_RRR_NO_LDS=1 runs the thread-per-replica build on HBM/L2.  Same chains, rrrMC and bklMC."""
+    seed = 8800 + kind[1]
+    X = pkg.GraphRRG(kind[1], kind[2], seed=seed) if kind[0] == "rrg" else pkg.GraphEA(kind[1], kind[2], seed=seed)
+    form = "ea" if kind[0] == "ea" else "rrg"
+    out = []
+    for no_lds in ("0", "1"):
+        monkeypatch.setenv("RRRMC_RRR_NO_LDS", no_lds)
+        with pkg.Engine(X, R) as eng:
+            eng.seed(seed)
+            eng.init_spins_random()
+            C0 = eng.get_config()
+            a = eng.rrr_mc(beta, iters, step, staged_thr=thr)
+            Ca = eng.get_config().s
+            b = eng.bkl_mc(beta, iters * 5, step * 5)
+            out.append((a[0], a[1], a[2], Ca, b[0], b[1], eng.get_config().s))
+    for u, v in zip(*out):
+        assert (u == v).all()
+    for r in (0, R - 1):
+        ref = oracle.rrr_sparse(X.A, X.J.astype(np.int32), beta, iters, step, seed, C0.s[r], replica=r, staged_thr=thr, form=form)
+        assert (out[0][0][r] == ref[0]).all() and (out[0][3][r] == ref[1]).all() and out[0][1][r] == ref[2] and out[0][2][r] == ref[3]
