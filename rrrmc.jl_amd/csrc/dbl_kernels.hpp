@@ -46,13 +46,47 @@ struct RrrDblParams {
     __host__ __device__ __forceinline__ double to_f64(long long units) const { return (double)(units * lev_mul) / lev_div; }
 };
 
+// SLM = compile-time bound on the number of levels (4 or 8).  As for SparseChain (rrr_kernels.hpp): the chain keeps COPIES of the few
+// parameters it needs (a pointer to the kernel's parameter struct forces the struct into scratch memory) and its per-class arrays
+// are indexed only through fully unrolled selects, so that everything stays in registers.
+template <int SLM>
 struct DblChain {
-    const RrrDblParams* P;
+    struct Cfg { int N, K, L, ea_form; const int32_t* A; const int8_t* dJ; const double* rJ; int dElist[SLM]; double ft[SLM]; };
+    Cfg cfg;
     uint32_t* sp; uint8_t* cls; uint16_t* sv; uint16_t* spos;
     double* lf; double* undo;
-    int t[2 * kDLmax];
-    double T[2 * kDLmax], z;
+    int t[2 * SLM];
+    double T[2 * SLM], z;
     int mlast;
+    __device__ __forceinline__ int tg(int k) const { int x = 0;
+#pragma unroll
+        for (int a = 0; a < 2 * SLM; ++a) x = k == a ? t[a] : x;
+        return x; }
+    __device__ __forceinline__ void tadd(int k, int d) {
+#pragma unroll
+        for (int a = 0; a < 2 * SLM; ++a) t[a] = k == a ? t[a] + d : t[a]; }
+    __device__ __forceinline__ double Tg(int k) const { double x = 0.0;
+#pragma unroll
+        for (int a = 0; a < 2 * SLM; ++a) x = k == a ? T[a] : x;
+        return x; }
+    __device__ __forceinline__ void Tadd(int k, double d) {
+#pragma unroll
+        for (int a = 0; a < 2 * SLM; ++a) T[a] = k == a ? T[a] + d : T[a]; }
+    __device__ __forceinline__ int lev(int a) const { int d = 0;
+#pragma unroll
+        for (int k = 0; k < SLM; ++k) d = a == k ? cfg.dElist[k] : d;
+        return d; }
+    // rand_move's class: the first k with rr < T[0] + .. + T[k], else the last class of non-zero weight (DeltaE.jl:146-160)
+    __device__ __forceinline__ int pick_class(double rr, int K2) const
+    {
+        int ksel = -1;
+        double cT = 0.0;
+#pragma unroll
+        for (int a = 0; a < 2 * SLM; ++a)
+            if (a < K2 && ksel < 0) { cT += T[a]; if (rr < cT) ksel = a; }
+        if (ksel < 0) { ksel = K2 - 1; while (Tg(ksel) == 0) ksel -= 1; }
+        return ksel;
+    }
 
     __device__ __forceinline__ int sbit(int x) const { return (int)((sp[x >> 5] >> (x & 31)) & 1u); }
     __device__ __forceinline__ void sflip(int x) { sp[x >> 5] ^= 1u << (x & 31); }
@@ -61,9 +95,9 @@ struct DblChain {
     {
         const int si = sbit(i);
         int acc = 0;
-        for (int q = 0; q < P->K; ++q) {
-            const int sy = sbit(P->A[(size_t)i * P->K + q]);
-            const int j = (int)P->dJ[(size_t)i * P->K + q];
+        for (int q = 0; q < cfg.K; ++q) {
+            const int sy = sbit(cfg.A[(size_t)i * cfg.K + q]);
+            const int j = (int)cfg.dJ[(size_t)i * cfg.K + q];
             acc += (si == sy) ? j : -j;
         }
         return 2 * acc;
@@ -72,32 +106,37 @@ struct DblChain {
     {
         const int d = dE0(i), ad = d < 0 ? -d : d;
         int a = 0;
-        for (int k = 0; k < P->L; ++k) if (P->dElist[k] == ad) a = k;
+#pragma unroll
+        for (int k = 0; k < SLM; ++k) a = (k < cfg.L && cfg.dElist[k] == ad) ? k : a;
         const int up = d > 0 || (d == 0 && sbit(i) == 1);
-        return a + P->L * up;
+        return a + cfg.L * up;
     }
-    __device__ __forceinline__ double f(int k) const { return k >= P->L ? P->ft[k - P->L] : 1.0; }
+    __device__ __forceinline__ double f(int k) const { double x = 1.0;
+#pragma unroll
+        for (int a = 0; a < SLM; ++a) x = (k - cfg.L == a) ? cfg.ft[a] : x;
+        return x; }
     // neighbors(X0, i): GraphRRG keeps the non-zero couplings (RRG.jl:133), GraphEA removes repeats (EA.jl:158)
     __device__ __forceinline__ bool is_nb(int move, int q) const
     {
-        if (P->ea_form) return !(q > 0 && P->A[(size_t)move * P->K + q] == P->A[(size_t)move * P->K + q - 1]);
-        return P->dJ[(size_t)move * P->K + q] != 0;
+        if (cfg.ea_form) return !(q > 0 && cfg.A[(size_t)move * cfg.K + q] == cfg.A[(size_t)move * cfg.K + q - 1]);
+        return cfg.dJ[(size_t)move * cfg.K + q] != 0;
     }
     __device__ __forceinline__ void set_move(int j, int k0, int k1)
     {
-        uint16_t* v0 = sv + (size_t)k0 * P->N;
-        uint16_t* v1 = sv + (size_t)k1 * P->N;
-        const int p = spos[j], last = v0[t[k0] - 1];
-        v0[p] = (uint16_t)last; spos[last] = (uint16_t)p; t[k0] -= 1;
-        v1[t[k1]] = (uint16_t)j; spos[j] = (uint16_t)t[k1]; t[k1] += 1;
+        uint16_t* v0 = sv + (size_t)k0 * cfg.N;
+        uint16_t* v1 = sv + (size_t)k1 * cfg.N;
+        const int p = spos[j], last = v0[tg(k0) - 1];
+        v0[p] = (uint16_t)last; spos[last] = (uint16_t)p; tadd(k0, -1);
+        const int t1 = tg(k1);
+        v1[t1] = (uint16_t)j; spos[j] = (uint16_t)t1; tadd(k1, 1);
         cls[j] = (uint8_t)k1;
     }
     // update_cache_residual! (RRG.jl:430-466, EA.jl:456-496), called after the flip of `move`
     __device__ void res_update(int move)
     {
-        const int K = P->K;
-        const int32_t* Ax = P->A + (size_t)move * K;
-        const double* Jx = P->rJ + (size_t)move * K;
+        const int K = cfg.K;
+        const int32_t* Ax = cfg.A + (size_t)move * K;
+        const double* Jx = cfg.rJ + (size_t)move * K;
         const double lfm = lf[move];
         if (mlast == move) {
             for (int k = 0; k < K; ++k) {
@@ -133,15 +172,15 @@ struct DblChain {
     {
         spinflip(move);
         double zp = z;
-        const int32_t* Ax = P->A + (size_t)move * P->K;
-        for (int q = 0; q <= P->K; ++q) {
-            if (q < P->K && !is_nb(move, q)) continue;
-            const int j = q < P->K ? Ax[q] : move;
+        const int32_t* Ax = cfg.A + (size_t)move * cfg.K;
+        for (int q = 0; q <= cfg.K; ++q) {
+            if (q < cfg.K && !is_nb(move, q)) continue;
+            const int j = q < cfg.K ? Ax[q] : move;
             const int k0 = cls[j];
-            const int k1 = q < P->K ? klass(j) : (k0 >= P->L ? k0 - P->L : k0 + P->L);
-            if (q < P->K && k0 == k1) continue;
+            const int k1 = q < cfg.K ? klass(j) : (k0 >= cfg.L ? k0 - cfg.L : k0 + cfg.L);
+            if (q < cfg.K && k0 == k1) continue;
             const double f0 = f(k0), f1 = f(k1);
-            T[k0] -= f0; T[k1] += f1; zp += f1 - f0;
+            Tadd(k0, -f0); Tadd(k1, f1); zp += f1 - f0;
             set_move(j, k0, k1);
         }
         const double cc = z / zp;
@@ -162,16 +201,20 @@ __device__ __forceinline__ bool dbl_accept(double c, double x, uint64_t g, uint3
 
 // energy(X, C) = E0 + E1 (RRG.jl:326-360) — fills the residual fields — and, with `classes`, gen_ΔEcache(X0, C, beta)'s class
 // sets in site order (DeltaE.jl:74-103)
-__device__ __forceinline__ double dbl_init_chain(DblChain& c, const RrrDblParams& P, int r, bool classes)
+template <int SLM>
+__device__ __forceinline__ double dbl_init_chain(DblChain<SLM>& c, const RrrDblParams& P, int r, bool classes)
 {
     const int N = P.N, K2 = 2 * P.L, K = P.K;
-    c.P = &P;
+    c.cfg.N = P.N; c.cfg.K = P.K; c.cfg.L = P.L; c.cfg.ea_form = P.ea_form; c.cfg.A = P.A; c.cfg.dJ = P.dJ; c.cfg.rJ = P.rJ;
+#pragma unroll
+    for (int k = 0; k < SLM; ++k) { c.cfg.dElist[k] = P.dElist[k]; c.cfg.ft[k] = P.ft[k]; }
     c.sp = P.spins + (size_t)r * P.W; c.cls = P.cls + (size_t)r * N; c.sv = P.sv + (size_t)r * K2 * N; c.spos = P.spos + (size_t)r * N;
     c.lf = P.lf + (size_t)r * N; c.undo = P.undo + (size_t)r * (K + 1);
     c.mlast = -1;
     long long n0 = 0;
     double E1 = 0.0;
-    for (int k = 0; k < K2; ++k) c.t[k] = 0;
+#pragma unroll
+    for (int k = 0; k < 2 * SLM; ++k) c.t[k] = 0;
     for (int i = 0; i < N; ++i) {
         n0 -= c.dE0(i) / 2;                     // lf_x = -sum dJ sx sy
         const int sx = 2 * c.sbit(i) - 1;
@@ -183,11 +226,11 @@ __device__ __forceinline__ double dbl_init_chain(DblChain& c, const RrrDblParams
         E1 = E1 + fl;
         c.lf[i] = 2.0 * fl;
         if (classes) {
-            const int k = c.klass(i);
+            const int k = c.klass(i), tk = c.tg(k);
             c.cls[i] = (uint8_t)k;
-            c.sv[(size_t)k * N + c.t[k]] = (uint16_t)i;
-            c.spos[i] = (uint16_t)c.t[k];
-            c.t[k] += 1;
+            c.sv[(size_t)k * N + tk] = (uint16_t)i;
+            c.spos[i] = (uint16_t)tk;
+            c.tadd(k, 1);
         }
     }
     E1 = E1 / 2;
@@ -200,7 +243,7 @@ __global__ __launch_bounds__(kRrrThreads) void dbl_standard_kernel(RrrDblParams 
 {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= P.R) return;
-    DblChain c;
+    DblChain<1> c;           // no class bookkeeping under standardMC
     double E = dbl_init_chain(c, P, r, false);
     const uint32_t rep = P.replica0 + (uint32_t)r;
     long long accepted = 0, ns = 0;
@@ -218,17 +261,21 @@ __global__ __launch_bounds__(kRrrThreads) void dbl_standard_kernel(RrrDblParams 
     P.stats[(size_t)r * 2] = accepted; P.stats[(size_t)r * 2 + 1] = 0;
 }
 
+template <int SLM>
 __global__ __launch_bounds__(kRrrThreads) void rrr_dbl_kernel(RrrDblParams P)
 {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= P.R) return;
     const int N = P.N, L = P.L, K2 = 2 * P.L, K = P.K;
-    DblChain c;
+    DblChain<SLM> c;
     double E = dbl_init_chain(c, P, r, !P.energy_only);
     if (P.energy_only) { P.E_cur[r] = E; return; }
     c.z = 0.0;
-    for (int k = 0; k < 2 * kDLmax; ++k) c.T[k] = 0.0;
-    for (int k = 0; k < K2; ++k) { const double x = (double)c.t[k] * c.f(k); c.z += x; c.T[k] = x; }
+#pragma unroll
+    for (int k = 0; k < 2 * SLM; ++k) c.T[k] = 0.0;
+#pragma unroll
+    for (int k = 0; k < 2 * SLM; ++k)
+        if (k < K2) { const double x = (double)c.t[k] * c.f(k); c.z += x; c.T[k] = x; }
 
     const uint32_t rep = P.replica0 + (uint32_t)r;
     long long accepted = 0, staged_its = 0, ns = 0;
@@ -240,37 +287,50 @@ __global__ __launch_bounds__(kRrrThreads) void rrr_dbl_kernel(RrrDblParams P)
         // rand_move: DeltaE.jl:146-167
         const Philox4 o = philox4x32_10((uint32_t)g, (uint32_t)(g >> 32), rep, TAG_RRR, P.k0, P.k1);
         const double rr = (double)((((uint64_t)o.w[0] << 32) | o.w[1]) >> 11) * 0x1.0p-53 * c.z;
-        int k = 0;
-        double cT = 0.0;
-        for (k = 0; k < K2; ++k) { cT += c.T[k]; if (rr < cT) break; }
-        if (k == K2) k = K2 - 1;
-        if (!(rr < cT)) while (c.T[k] == 0) k -= 1;
-        const int dE0 = k < L ? -P.dElist[k] : P.dElist[k - L];
-        const int move = c.sv[(size_t)k * N + (int)mulhi64(((uint64_t)o.w[2] << 32) | o.w[3], (uint64_t)c.t[k])];
+        const int k = c.pick_class(rr, K2);
+        const int dE0 = k < L ? -c.lev(k) : c.lev(k - L);
+        const int move = c.sv[(size_t)k * N + (int)mulhi64(((uint64_t)o.w[2] << 32) | o.w[3], (uint64_t)c.tg(k))];
         bool acc = false;
         if (acc_rate < P.staged_thr) {
             // step_rrr(X0, C, cache) (RRRMC.jl:131-138): compute_staged! flips X0 only, and flips it back
             staged_its += 1;
-            int sj[kDKmax + 1], s0[kDKmax + 1], s1[kDKmax + 1], nst = 0;
+            // staged changes in fixed slots (slot q = neighbour q, slot kDKmax = the moved spin) and fully unrolled loops: registers
+            int sj[kDKmax + 1], s0[kDKmax + 1], s1[kDKmax + 1];
+            bool live[kDKmax + 1];
             c.sflip(move);
             const int32_t* Ax = P.A + (size_t)move * K;
-            for (int q = 0; q < K; ++q) {
-                if (!c.is_nb(move, q)) continue;
-                const int j = Ax[q], k0 = c.cls[j], k1 = c.klass(j);
-                if (k0 == k1) continue;
-                sj[nst] = j; s0[nst] = k0; s1[nst] = k1; ++nst;
+#pragma unroll
+            for (int q = 0; q < kDKmax; ++q) {
+                live[q] = false; sj[q] = 0; s0[q] = 0; s1[q] = 0;
+                if (q < K && c.is_nb(move, q)) {
+                    const int j = Ax[q], k0 = c.cls[j], k1 = c.klass(j);
+                    if (k0 != k1) { live[q] = true; sj[q] = j; s0[q] = k0; s1[q] = k1; }
+                }
             }
-            { const int k0 = c.cls[move]; sj[nst] = move; s0[nst] = k0; s1[nst] = k0 >= L ? k0 - L : k0 + L; ++nst; }
+            { const int k0 = c.cls[move]; live[kDKmax] = true; sj[kDKmax] = move; s0[kDKmax] = k0; s1[kDKmax] = k0 >= L ? k0 - L : k0 + L; }
             c.sflip(move);
-            double Tp[2 * kDLmax], zp = c.z;
-            for (int q = 0; q < 2 * kDLmax; ++q) Tp[q] = c.T[q];
-            for (int q = 0; q < nst; ++q) { const double f0 = c.f(s0[q]), f1 = c.f(s1[q]); Tp[s0[q]] -= f0; Tp[s1[q]] += f1; zp += f1 - f0; }
+            double Tp[2 * SLM], zp = c.z;
+#pragma unroll
+            for (int q = 0; q < 2 * SLM; ++q) Tp[q] = c.T[q];
+#pragma unroll
+            for (int q = 0; q <= kDKmax; ++q)
+                if (live[q]) {
+                    const double f0 = c.f(s0[q]), f1 = c.f(s1[q]);
+#pragma unroll
+                    for (int a = 0; a < 2 * SLM; ++a) Tp[a] = s0[q] == a ? Tp[a] - f0 : Tp[a];
+#pragma unroll
+                    for (int a = 0; a < 2 * SLM; ++a) Tp[a] = s1[q] == a ? Tp[a] + f1 : Tp[a];
+                    zp += f1 - f0;
+                }
             const double cc = c.z / zp;
             const double dE1 = -c.lf[move];                                   // delta_energy_residual
             if (dbl_accept(cc, -P.beta * dE1, g, rep, P.k0, P.k1)) {
                 c.spinflip(move);
-                for (int q = 0; q < nst; ++q) c.set_move(sj[q], s0[q], s1[q]);   // apply_staged!
-                for (int q = 0; q < 2 * kDLmax; ++q) c.T[q] = Tp[q];
+#pragma unroll
+                for (int q = 0; q <= kDKmax; ++q)
+                    if (live[q]) c.set_move(sj[q], s0[q], s1[q]);                 // apply_staged!
+#pragma unroll
+                for (int q = 0; q < 2 * SLM; ++q) c.T[q] = Tp[q];
                 c.z = zp;
                 E += P.to_f64(dE0) + dE1;
                 accepted += 1; acc = true;

@@ -66,7 +66,7 @@ int32_t dbl_run_energy(rrrmc_ctx* ctx)
 {
     RrrDblParams P = dbl_params(ctx, 0.0);
     P.energy_only = 1;
-    hipLaunchKernelGGL(rrr_dbl_kernel, dim3(rrr_blocks(ctx->R)), dim3(rrr_tpb(ctx->R)), 0, ctx->stream, P);
+    hipLaunchKernelGGL(rrr_dbl_kernel<4>, dim3(rrr_blocks(ctx->R)), dim3(rrr_tpb(ctx->R)), 0, ctx->stream, P);          // energy only: the level bound is irrelevant
     HIP_TRY(ctx, hipGetLastError());
     return RRRMC_OK;
 }
@@ -100,7 +100,8 @@ int32_t dbl_mc_async(rrrmc_ctx* ctx, bool standard, double beta, int64_t iters, 
     HIP_TRY(ctx, hipEventRecord(ctx->ev_begin, st));
     HIP_TRY(ctx, hipEventRecord(ctx->ev_sweep[0], st));
     if (standard) hipLaunchKernelGGL(dbl_standard_kernel, dim3(rrr_blocks(ctx->R)), dim3(rrr_tpb(ctx->R)), 0, st, P);
-    else hipLaunchKernelGGL(rrr_dbl_kernel, dim3(rrr_blocks(ctx->R)), dim3(rrr_tpb(ctx->R)), 0, st, P);
+    else if (ctx->db_L <= 4) hipLaunchKernelGGL(rrr_dbl_kernel<4>, dim3(rrr_blocks(ctx->R)), dim3(rrr_tpb(ctx->R)), 0, st, P);   // per-class arrays sized at compile time: registers
+    else hipLaunchKernelGGL(rrr_dbl_kernel<8>, dim3(rrr_blocks(ctx->R)), dim3(rrr_tpb(ctx->R)), 0, st, P);
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipEventRecord(ctx->ev_sweep[1], st));
     HIP_TRY(ctx, hipEventRecord(ctx->ev_end, st));
