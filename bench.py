@@ -46,6 +46,25 @@ def cpu_baseline(O, X, seconds_target=15.0):
             "sample": "%d replicas x 2^22 iterations of the same graph/beta, single thread, oracle/rrrmc_oracle.c (%.1f s)" % (R, dt)}
 
 
+def device_copy_bandwidth(device, nbytes=1 << 30, reps=10):
+    """Measured device-to-device copy rate (read + write bytes per second, GB/s): the practical HBM ceiling of this box
+    that SURVEY.md §8d asks to report beside the nominal 8 TB/s."""
+    import torch
+    with torch.cuda.device(device):
+        a = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+        b = torch.empty_like(a)
+        a.zero_()
+        b.copy_(a)
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+        for _ in range(reps):
+            b.copy_(a)
+        ev1.record()
+        torch.cuda.synchronize()
+        ms = ev0.elapsed_time(ev1) / reps
+    return 2.0 * nbytes / (ms * 1e-3) / 1e9
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -149,6 +168,13 @@ def main():
                                "algorithmic_bytes_per_launch": bytes_per_attempt * per_launch_attempts,
                                "kernel": "sweep_kernel<3, 1>", "avg_launch_ms": avg_ms, "launches": launches,
                                "algorithmic_bytes_per_attempt": bytes_per_attempt}
+            try:      # after the timed region: the box's own copy bandwidth, for reference only (peak stays the nominal figure)
+                bw = device_copy_bandwidth(local_rank)
+                out["roofline"]["measured_copy_GBps"] = bw
+                out["roofline"]["frac_of_measured_copy"] = achieved / bw
+            except Exception as e:      # never let the side measurement hide the bench line
+                out["roofline"]["measured_copy_GBps"] = None
+                sys.stderr.write("device copy bandwidth not measured: %r\n" % (e,))
         if not args.no_cpu_baseline and world == 1:      # reported at N = 1 only (rank 0's host cores)
             out["cpu_baseline"] = cpu_baseline(entry.load_oracle(), X)
         print(json.dumps(out))

@@ -703,6 +703,28 @@ def cont_double(mode, A, dJ, rJ, beta, iters, step, seed, chunks, it0=0, call=0,
     return Es[:n], ch, stats, t.value
 
 
+def extremal_opt_cont(A, J, tau, iters, step, seed, chunks, it0=0, replica=0, form="rrg", dJ=None, mul=1, div=1.0):
+    """extremal_opt (RRRMC.jl:474-521) with EOCacheCont (DeltaE.jl:557-635) on GraphRRGNormal / GraphEANormal (J Float64) or, with dJ
+    (level units) and J = the residuals, on the discretised DoubleGraphs.  Returns (Es, final chunks, Emin, Cmin chunks, itmin)."""
+    L = lib()
+    L.orc_extremal_opt_cont.restype = C.c_int64
+    L.orc_extremal_opt_cont.argtypes = [C.c_int, C.c_int64, C.c_int64, i32p, f64p, C.c_void_p, C.c_int64, C.c_double, f64p, C.c_int64, C.c_int64,
+                                        C.c_uint64, C.c_uint64, C.c_uint32, u64p, f64p, C.POINTER(C.c_double), u64p, C.POINTER(C.c_int64)]
+    A = np.ascontiguousarray(A, np.int32)
+    N, K = A.shape
+    dJp = None if dJ is None else np.ascontiguousarray(dJ, np.int32).reshape(-1)
+    ch = np.array(chunks, np.uint64, copy=True)
+    Es = np.zeros(max(iters // step, 1))
+    Cmin = np.zeros_like(ch)
+    Emin, itmin = C.c_double(0), C.c_int64(0)
+    n = L.orc_extremal_opt_cont(1 if form == "ea" else 0, N, K, A, np.ascontiguousarray(J, np.float64).reshape(-1),
+                                None if dJp is None else dJp.ctypes.data, int(mul), float(div), eo_ftau(N, tau), int(iters), int(step),
+                                seed, it0, replica, ch, Es, C.byref(Emin), Cmin, C.byref(itmin))
+    if n < 0:
+        raise RuntimeError("extremal_opt_cont: inconsistent cache / energy (%d)" % n)
+    return Es[:n], ch, Emin.value, Cmin, itmin.value
+
+
 def wtm_mc_skn(J, beta, samples, step, seed, chunks, call=0, replica=0):
     """wtmMC on GraphSKNormal; returns (Es, chunks, num_moves, t)."""
     L = lib()

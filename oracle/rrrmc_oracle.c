@@ -2293,6 +2293,116 @@ ORC_API int64_t orc_cont_double(int mode, int form, int64_t N, int64_t K, const 
                             stats, t_out);
 }
 
+/* =============================================================================================
+ * extremal_opt (src/RRRMC.jl:474-521) with EOCacheCont (src/DeltaE.jl:557-635) on the Float64 sparse graphs (dJ = NULL) and on the
+ * discretised DoubleGraphs (dJ = level part): the graphs that are not DiscrGraphs.
+ *   cache     dEs[i] = delta_energy(X, C, i); rank = sortperm(dEs) (stable: ties in site order), DeltaE.jl:563-573
+ *   rand_move r = (1 - rand()) z, i = searchsortedfirst(ftau, r), move = rank[i], dE = dEs[move] (:577-590); RRR stream sub 3
+ *   apply     spinflip!, dEs of the moved spin and of neighbors(X, move) refreshed, then the WHOLE vector re-sorted and every run of
+ *             equal values shuffled uniformly (sortperm! + rankshuffle!, :592-634).
+ * Neither the sort's tie order nor Julia's shuffle! is pinned, so the uniform shuffle is restated as a random key:
+ * in iteration g every site gets the 64-bit key Philox(g, replica, TAG_RRR | 4 << 8 | site << 16) and the ranking after the move is
+ * the ascending order of (dE, key, site) — a fresh uniform permutation of every tie run per move, as rankshuffle! gives.  (With
+ * Gaussian couplings ties have probability zero and the keys are never looked at.)
+ * Returns the number of samples (E before the move of iterations k * step), -1 if the tracked energy drifted from energy(X, C)
+ * by more than 1e-9 relative or the ranking is not sorted.
+ * ============================================================================================= */
+typedef struct { const double *dEs; uint64_t seed, g; uint32_t replica; int fresh; } eocmp_t;
+static inline uint64_t eo_tie_key(const eocmp_t *c, int32_t site)
+{
+    uint32_t w[4];
+    orc_draw(c->seed, (uint32_t)c->g, (uint32_t)(c->g >> 32), c->replica, (uint32_t)ORC_TAG_RRR | (4u << 8) | ((uint32_t)site << 16), w);
+    return ((uint64_t)w[0] << 32) | w[1];
+}
+static int eo_less(const eocmp_t *c, int32_t a, int32_t b)
+{
+    if (c->dEs[a] < c->dEs[b]) return 1;
+    if (c->dEs[a] > c->dEs[b]) return 0;
+    if (c->fresh) {
+        const uint64_t ka = eo_tie_key(c, a), kb = eo_tie_key(c, b);
+        if (ka != kb) return ka < kb;
+    }
+    return a < b;
+}
+static void eo_sort(const eocmp_t *c, int32_t *rank, int32_t *tmp, int64_t n)           /* top-down merge sort of rank[0..n) */
+{
+    if (n < 2) return;
+    const int64_t h = n / 2;
+    eo_sort(c, rank, tmp, h);
+    eo_sort(c, rank + h, tmp, n - h);
+    int64_t i = 0, j = h, k = 0;
+    while (i < h && j < n) tmp[k++] = eo_less(c, rank[j], rank[i]) ? rank[j++] : rank[i++];
+    while (i < h) tmp[k++] = rank[i++];
+    while (j < n) tmp[k++] = rank[j++];
+    memcpy(rank, tmp, (size_t)n * sizeof(int32_t));
+}
+ORC_API int64_t orc_extremal_opt_cont(int form, int64_t N, int64_t K, const int32_t *A, const double *J, const int32_t *dJ, int64_t mul, double div,
+                                      const double *ftau, int64_t iters, int64_t step, uint64_t seed, uint64_t it0, uint32_t replica,
+                                      uint64_t *chunks, double *Es, double *Emin_out, uint64_t *Cmin, int64_t *itmin_out)
+{
+    if (N > 65535) return -2;                                             /* the tie key carries the site in 16 bits */
+    spf_t X = {N, K, A, J, NULL, NULL, -1, form, NULL, 1, 1.0};
+    X.lfields = (double *)malloc((size_t)N * 8);
+    X.lfields_last = (double *)malloc((size_t)N * 8);
+    sparse_t X0 = {N, K, A, dJ, NULL, NULL, -1, form};
+    double E = 0.0;
+    if (dJ) {
+        X0.lfields = (int64_t *)malloc((size_t)N * 8);
+        X0.lfields_last = (int64_t *)malloc((size_t)N * 8);
+        X.X0 = &X0; X.lev_mul = mul; X.lev_div = div;
+        E = lev_to_f64(sparse_energy(&X0, chunks), mul, div);
+        E = E + spf_energy(&X, chunks);
+    } else {
+        E = spf_energy(&X, chunks);
+    }
+    const int64_t nch = (N + 63) / 64;
+    double Emin = E;
+    int64_t itmin = 0, nsamp = 0;
+    memcpy(Cmin, chunks, (size_t)nch * 8);
+    double *dEs = (double *)malloc((size_t)N * 8);
+    int32_t *rank = (int32_t *)malloc((size_t)N * 4), *tmp = (int32_t *)malloc((size_t)N * 4);
+    for (int64_t i = 0; i < N; ++i) { dEs[i] = spf_dE(&X, i); rank[i] = (int32_t)i; }
+    eocmp_t cmp = {dEs, seed, 0, replica, 0};
+    eo_sort(&cmp, rank, tmp, N);                                          /* sortperm(dEs): no shuffle at construction */
+    const double z = ftau[N - 1];
+    for (int64_t it = 1; it <= iters; ++it) {
+        if (it % step == 0) Es[nsamp++] = E;
+        const uint64_t g = it0 + (uint64_t)it;
+        uint32_t w[4];
+        rrr_draw(seed, g, replica, 3, w);
+        const double r = (1 - u53_of(w[0], w[1])) * z;
+        int64_t lo = 0, hi = N;
+        while (lo < hi) { int64_t mid = (lo + hi) >> 1; if (ftau[mid] < r) lo = mid + 1; else hi = mid; }
+        int64_t i = lo + 1;
+        if (i > N) i = N;
+        const int64_t move = rank[i - 1];
+        const double dE = dEs[move];
+        spf_spinflip(&X, chunks, move);
+        dEs[move] = spf_dE(&X, move);
+        int64_t nb[SK_MAX];
+        int nn = spf_neighbors(&X, move, nb);
+        for (int q = 0; q < nn; ++q) dEs[nb[q]] = spf_dE(&X, nb[q]);
+        cmp.g = g; cmp.fresh = 1;
+        eo_sort(&cmp, rank, tmp, N);
+        E += dE;
+        if (E < Emin) { Emin = E; memcpy(Cmin, chunks, (size_t)nch * 8); itmin = it; }
+    }
+    int ok = 1;
+    for (int64_t i = 1; i < N && ok; ++i) ok = dEs[rank[i - 1]] <= dEs[rank[i]];
+    for (int64_t i = 0; i < N && ok; ++i) ok = dEs[i] == spf_dE(&X, i);
+    {
+        double Ex = spf_energy(&X, chunks);
+        if (dJ) Ex = lev_to_f64(sparse_energy(&X0, chunks), mul, div) + Ex;
+        const double tol = 1e-9 * (fabs(Ex) > 1.0 ? fabs(Ex) : 1.0);
+        if (fabs(Ex - E) > tol) ok = 0;
+    }
+    if (Emin_out) *Emin_out = Emin;
+    if (itmin_out) *itmin_out = itmin;
+    free(dEs); free(rank); free(tmp); free(X.lfields); free(X.lfields_last);
+    if (dJ) { free(X0.lfields); free(X0.lfields_last); }
+    return ok ? nsamp : -1;
+}
+
 /* wtmMC (src/RRRMC.jl:376-426, src/WaitingTimes.jl) on GraphSKNormal: as orc_wtm_mc_sparse with delta_energy = +lfields[i]
  * (SK.jl:278-284) and neighbors(X, i) = AllButOne (every other spin, in index order: SK.jl:297).  WTM stream: spin i's initial
  * time is draw i, then one draw per updated spin in the order of update_heap! (the moved spin, then j = 0..N-1 except it). */

@@ -25,7 +25,7 @@ SYMBOLS = [
     "rrrmc_set_couplings_bits", "rrrmc_gen_sk_binary", "rrrmc_set_coloring", "rrrmc_colored_sweeps_async",
     "rrrmc_ctx_create_quant", "rrrmc_quant_set_field", "rrrmc_rrr_mc_async", "rrrmc_rrr_stats", "rrrmc_rrr_cache", "rrrmc_bkl_mc_async",
     "rrrmc_snapshot_reserve", "rrrmc_snapshot_store", "rrrmc_snapshot_get", "rrrmc_overlaps", "rrrmc_quant_observables",
-    "rrrmc_set_graph_f64", "rrrmc_gen_couplings_gauss", "rrrmc_set_graph_discretized", "rrrmc_set_level_scale", "rrrmc_discretize", "rrrmc_discretize_scaled", "rrrmc_wtm_mc_async", "rrrmc_wtm_times", "rrrmc_extremal_opt_async", "rrrmc_extremal_opt_results",
+    "rrrmc_set_graph_f64", "rrrmc_gen_couplings_gauss", "rrrmc_set_graph_discretized", "rrrmc_set_level_scale", "rrrmc_discretize", "rrrmc_discretize_scaled", "rrrmc_wtm_mc_async", "rrrmc_wtm_times", "rrrmc_extremal_opt_async", "rrrmc_extremal_opt_results", "rrrmc_extremal_opt_results_f64",
 ]
 
 
@@ -160,6 +160,8 @@ def lib():
     L.rrrmc_extremal_opt_async.argtypes = [vp, f64p, C.c_int64, C.c_int64]
     L.rrrmc_extremal_opt_results.restype = C.c_int32
     L.rrrmc_extremal_opt_results.argtypes = [vp, i64p, u64p, i64p]
+    L.rrrmc_extremal_opt_results_f64.restype = C.c_int32
+    L.rrrmc_extremal_opt_results_f64.argtypes = [vp, f64p, u64p, i64p]
     _lib = L
     return L
 

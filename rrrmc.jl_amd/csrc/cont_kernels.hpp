@@ -3,6 +3,7 @@
 //   mode 0  rrrMC(X::SingleGraph)  src/RRRMC.jl:149-219   DeltaECacheCont + DynamicSampler (src/DeltaE.jl:297-410, DynamicSamplers.jl)
 //   mode 1  bklMC                  src/RRRMC.jl:311-359   same cache, rand_skip (DeltaE.jl:319-325)
 //   mode 2  wtmMC                  src/RRRMC.jl:376-426   THeap of next-flip times (src/WaitingTimes.jl), tau = max(1, exp(beta dE))
+//   mode 3  extremal_opt           src/RRRMC.jl:474-521   EOCacheCont (src/DeltaE.jl:557-635): the ranking by dE kept sorted move by move
 // One thread per replica, replica-contiguous state in HBM/L2 (the move is state dependent, as for the other reduced-rejection
 // kernels).  The graph's local-field cache is the one of spf_kernels.hpp (delta_energy = -lfields, update_cache! with the exact
 // undo path through the K+1-entry record), exp / log1p are the fixed-order ones shared with the oracle, every Float64 running sum
@@ -38,12 +39,41 @@ struct ContParams {
     double* Es;              // [nsamples][R]
     double* t_out;           // [R]
     int32_t* status;         // [R]  1 = DynamicSampler's "unrecoverable loss of precision"
+    const double* ftau;      // [N]  extremal_opt: cumsum(j^-tau)
+    uint32_t* cmin;          // [R][W] extremal_opt: configuration of minimum energy
     double beta, staged_thr, lambda, stepf;
     uint64_t g0;
     int64_t iters, step;
     uint32_t k0, k1, replica0, call;
     int N, K, N2, levs, W, R, Rp, ea_form, mode;      // Rp = row stride of Es
 };
+
+// rankshuffle! (DeltaE.jl:611-634) restated with per-move keys: every run of equal dE is ordered by (Philox key of (g, site), site).
+// v[p] = dE of the site ranked p, hid[p] = that site, hpos = inverse, key = scratch of n words.
+__device__ inline void eo_order_ties_impl(const double* v, uint16_t* hid, uint16_t* hpos, unsigned long long* key, int n, uint64_t g, uint32_t rep,
+                                          uint32_t k0, uint32_t k1)
+{
+    int i0 = 0;
+    while (i0 < n) {
+        int i1 = i0 + 1;
+        while (i1 < n && v[i1] == v[i0]) ++i1;
+        if (i1 - i0 > 1) {
+            for (int p = i0; p < i1; ++p) {
+                const Philox4 o = philox4x32_10((uint32_t)g, (uint32_t)(g >> 32), rep, TAG_RRR | (4u << 8) | ((uint32_t)hid[p] << 16), k0, k1);
+                key[p] = ((unsigned long long)o.w[0] << 32) | o.w[1];
+            }
+            for (int p = i0 + 1; p < i1; ++p) {                  // insertion sort of the run by (key, site)
+                const unsigned long long kp = key[p];
+                const uint16_t sp_ = hid[p];
+                int q = p;
+                while (q > i0 && (key[q - 1] > kp || (key[q - 1] == kp && hid[q - 1] > sp_))) { key[q] = key[q - 1]; hid[q] = hid[q - 1]; q -= 1; }
+                key[q] = kp; hid[q] = sp_;
+            }
+            for (int p = i0; p < i1; ++p) hpos[hid[p]] = (uint16_t)p;
+        }
+        i0 = i1;
+    }
+}
 
 struct ContChain {
     const ContParams* P;
@@ -224,6 +254,52 @@ struct ContChain {
         dEs[pos] = t;
         if (t < old) sift_up(pos); else sift_down(pos, P->N);
     }
+
+    // ---- EOCacheCont (DeltaE.jl:557-635): v[p] = dE of the site ranked p (ascending), hid[p] = that site, hpos = inverse ----
+    __device__ __forceinline__ void eo_swap(int a, int b)
+    {
+        const double x = v[a]; v[a] = v[b]; v[b] = x;
+        const uint16_t h = hid[a]; hid[a] = hid[b]; hid[b] = h;
+    }
+    __device__ __forceinline__ bool eo_lt(int a, int b) const { return v[a] < v[b] || (v[a] == v[b] && hid[a] < hid[b]); }
+    __device__ void eo_sift(int root, int end)
+    {
+        for (;;) {
+            int ch = 2 * root + 1;
+            if (ch >= end) break;
+            if (ch + 1 < end && eo_lt(ch, ch + 1)) ch += 1;
+            if (!eo_lt(root, ch)) break;
+            eo_swap(root, ch);
+            root = ch;
+        }
+    }
+    // rank = sortperm(dEs): ascending (dE, site) — a stable sort of 1:N (DeltaE.jl:568); heapsort, the order is total
+    __device__ void eo_sort_all(int n)
+    {
+        for (int st = n / 2 - 1; st >= 0; --st) eo_sift(st, n);
+        for (int e = n - 1; e > 0; --e) { eo_swap(0, e); eo_sift(0, e); }
+    }
+    // site j takes the value x: slide it to its place among the others (which stay sorted); nties = adjacent equal pairs
+    __device__ int eo_reinsert(int j, double x, int nties)
+    {
+        const int n = P->N;
+        int p = hpos[j];
+        const double old = v[p];
+        if (p > 0 && v[p - 1] == old) nties -= 1;
+        if (p < n - 1 && v[p + 1] == old) nties -= 1;
+        if (p > 0 && p < n - 1 && v[p - 1] == v[p + 1]) nties += 1;
+        if (x > old) {
+            while (p < n - 1 && v[p + 1] < x) { v[p] = v[p + 1]; const uint16_t s = hid[p + 1]; hid[p] = s; hpos[s] = (uint16_t)p; p += 1; }
+        } else {
+            while (p > 0 && v[p - 1] > x) { v[p] = v[p - 1]; const uint16_t s = hid[p - 1]; hid[p] = s; hpos[s] = (uint16_t)p; p -= 1; }
+        }
+        if (p > 0 && p < n - 1 && v[p - 1] == v[p + 1]) nties -= 1;
+        if (p > 0 && v[p - 1] == x) nties += 1;
+        if (p < n - 1 && v[p + 1] == x) nties += 1;
+        v[p] = x; hid[p] = (uint16_t)j; hpos[j] = (uint16_t)p;
+        return nties;
+    }
+    __device__ void eo_order_ties(uint64_t g) { eo_order_ties_impl(v, hid, hpos, reinterpret_cast<unsigned long long*>(ps), P->N, g, rep, P->k0, P->k1); }
 };
 
 __global__ __launch_bounds__(kRrrThreads) void cont_sparse_kernel(ContParams P)
@@ -289,6 +365,44 @@ __global__ __launch_bounds__(kRrrThreads) void cont_sparse_kernel(ContParams P)
             accepted += 1;
         }
         second = accepted; itdone = ns;
+    } else if (P.mode == 3) {
+        // extremal_opt: RRRMC.jl:474-521; stats = (iterations, itmin, iterations), t_out = Emin
+        uint32_t* cm = P.cmin + (size_t)r * P.W;
+        for (int i = 0; i < N; ++i) { c.v[i] = c.dE(i); c.hid[i] = (uint16_t)i; }
+        c.eo_sort_all(N);
+        int nties = 0;
+        for (int p = 0; p < N; ++p) { c.hpos[c.hid[p]] = (uint16_t)p; if (p > 0 && c.v[p - 1] == c.v[p]) nties += 1; }
+        double Emin = E;
+        long long itmin = 0;
+        for (int w = 0; w < P.W; ++w) cm[w] = c.sp[w];
+        const double z = P.ftau[N - 1];
+        long long next_sample = P.step;
+        for (long long it = 1; it <= P.iters; ++it) {
+            if (it == next_sample) { next_sample += P.step; P.Es[(size_t)ns * P.Rp + r] = E; ns += 1; }
+            const uint64_t g = P.g0 + (uint64_t)it;
+            const Philox4 o = philox4x32_10((uint32_t)g, (uint32_t)(g >> 32), c.rep, TAG_RRR | (3u << 8), P.k0, P.k1);
+            const double rr = (1 - (double)((((uint64_t)o.w[0] << 32) | o.w[1]) >> 11) * 0x1.0p-53) * z;      // rand_move: DeltaE.jl:577-590
+            int lo = 0, hi = N;
+            while (lo < hi) { const int mid = (lo + hi) >> 1; if (P.ftau[mid] < rr) lo = mid + 1; else hi = mid; }
+            if (lo > N - 1) lo = N - 1;
+            const int move = c.hid[lo];
+            const double dE = c.v[lo];
+            c.flip(move);                                                                                    // apply_move!: :592-609
+            nties = c.eo_reinsert(move, c.dE(move), nties);
+            const int32_t* Ax = P.A + (size_t)move * K;
+            for (int q = 0; q < K; ++q) {
+                if (!c.is_nb(Ax, q)) continue;
+                nties = c.eo_reinsert(Ax[q], c.dE(Ax[q]), nties);
+            }
+            if (nties > 0) c.eo_order_ties(g);
+            E += dE;
+            if (E < Emin) {
+                Emin = E; itmin = it;
+                for (int w = 0; w < P.W; ++w) cm[w] = c.sp[w];
+            }
+        }
+        accepted = P.iters; second = itmin; itdone = P.iters;
+        t = Emin;
     } else {
         for (int i = 0; i < P.N2; ++i) c.v[i] = 0.0;
         for (int i = 0; i < N; ++i) { c.dEs[i] = c.dE(i); c.v[i] = prior_of(P.beta * c.dEs[i]); }      // DeltaECacheCont: DeltaE.jl:304-313
@@ -372,6 +486,164 @@ __global__ __launch_bounds__(kRrrThreads) void cont_sparse_kernel(ContParams P)
     P.stats[(size_t)r * 3] = accepted; P.stats[(size_t)r * 3 + 1] = second; P.stats[(size_t)r * 3 + 2] = itdone;
     P.t_out[r] = t;
     P.status[r] = bad;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// extremal_opt with EOCacheCont, one WAVEFRONT per replica (N <= kEoWaveMaxN): the ranking (v, hid, hpos: 12 bytes per spin) lives in
+// LDS; the chain itself (draw, flip, local fields) is executed redundantly by the 64 lanes — wave-uniform, so every global access is
+// one transaction — and the lanes split what the reference spends its time on, the re-ranking: the new place of a changed spin is
+// found by bisection and the entries between its old and new place move by one, 64 per step.  Same results as mode 3 of
+// cont_sparse_kernel (which remains for larger N), several tens of times faster: a moved spin's dE changes sign, so it travels across
+// most of the ranking at every move.
+// ---------------------------------------------------------------------------------------------------
+constexpr int kEoWaveMaxN = 13000;
+__host__ __device__ inline size_t eo_wave_lds_bytes(int N) { return ((size_t)N * 12 + 15) & ~(size_t)15; }
+
+__device__ __forceinline__ int wave_sum_i32(int x)
+{
+    for (int o = 32; o; o >>= 1) x += __shfl_xor(x, o);
+    return x;
+}
+
+__global__ __launch_bounds__(64) void eo_cont_wave_kernel(ContParams P)
+{
+    extern __shared__ __align__(16) unsigned char eo_lds[];
+    const int r = blockIdx.x, lane = threadIdx.x;
+    const int N = P.N, K = P.K;
+    double* v = reinterpret_cast<double*>(eo_lds);
+    uint16_t* hid = reinterpret_cast<uint16_t*>(v + N);
+    uint16_t* hpos = hid + N;
+    ContChain c;
+    c.P = &P;
+    c.sp = P.spins + (size_t)r * P.W; c.lf = P.lf + (size_t)r * N; c.undo = P.undo + (size_t)r * (K + 1);
+    c.dEs = P.dEs + (size_t)r * N; c.v = P.v + (size_t)r * P.N2; c.ps = P.ps + (size_t)r * P.N2;
+    c.hid = P.hid + (size_t)r * N; c.hpos = P.hpos + (size_t)r * N;
+    c.mlast = -1; c.z = 0.0; c.trefresh = 0; c.nd = 0;
+    c.rep = P.replica0 + (uint32_t)r;
+    unsigned long long* key = reinterpret_cast<unsigned long long*>(c.ps);
+    uint32_t* cm = P.cmin + (size_t)r * P.W;
+    // energy(X, C) (RRG.jl:546-574 / EA.jl:584-611): the fields site-parallel, their sum in site order
+    for (int i = lane; i < N; i += 64) {
+        const int sx = 2 * c.sbit(i) - 1;
+        double fl = 0.0;
+        for (int q = 0; q < K; ++q) {
+            const int sy = 2 * c.sbit(P.A[(size_t)i * K + q]) - 1;
+            fl = fl - P.J[(size_t)i * K + q] * (double)sx * (double)sy;
+        }
+        c.lf[i] = 2.0 * fl;
+    }
+    __syncthreads();
+    double E1 = 0.0;
+    for (int base = 0; base < N; base += 64) {
+        const int i = base + lane;
+        const double h = i < N ? c.lf[i] * 0.5 : 0.0;          // = fl exactly
+        const int m = N - base < 64 ? N - base : 64;
+        for (int l = 0; l < m; ++l) E1 = E1 + __shfl(h, l);
+    }
+    double E = E1 / 2;
+    if (P.dJ) {                                  // energy(X::DoubleGraph, C) = convert(Float64, E0 + E1): RRG.jl:326-360
+        int part = 0;
+        for (int i = lane; i < N; i += 64) part -= (int)(c.dE0(i) / 2);
+        const long long n0 = (long long)wave_sum_i32(part);
+        E = (double)((n0 / 2) * P.lev_mul) / P.lev_div + E;
+    }
+    // rank = sortperm(dEs) (DeltaE.jl:568): the place of a spin = the number of spins before it in the order (dE, site)
+    for (int i = lane; i < N; i += 64) { const double x = c.dE(i); v[i] = x; c.dEs[i] = x; }
+    __syncthreads();
+    for (int i = lane; i < N; i += 64) {
+        const double xi = v[i];
+        int cnt = 0;
+        for (int j = 0; j < N; ++j) { const double xj = v[j]; cnt += (xj < xi || (xj == xi && j < i)) ? 1 : 0; }
+        hpos[i] = (uint16_t)cnt;
+    }
+    __syncthreads();
+    for (int i = lane; i < N; i += 64) { const int p = hpos[i]; v[p] = c.dEs[i]; hid[p] = (uint16_t)i; }
+    __syncthreads();
+    int nties = 0;
+    {
+        int part = 0;
+        for (int p = 1 + lane; p < N; p += 64) part += v[p - 1] == v[p] ? 1 : 0;
+        nties = wave_sum_i32(part);
+    }
+    double Emin = E;
+    long long itmin = 0, ns = 0;
+    for (int w = lane; w < P.W; w += 64) cm[w] = c.sp[w];
+    const double z = P.ftau[N - 1];
+    long long next_sample = P.step;
+
+    // site j takes the value x (ContChain::eo_reinsert, the slide split over the lanes)
+    auto reinsert = [&](int j, double x) {
+        int p = hpos[j];
+        const double old = v[p];
+        if (p > 0 && v[p - 1] == old) nties -= 1;
+        if (p < N - 1 && v[p + 1] == old) nties -= 1;
+        if (p > 0 && p < N - 1 && v[p - 1] == v[p + 1]) nties += 1;
+        if (x > old) {
+            int lo = p + 1, hi = N;                              // first place in (p, N) whose value is >= x
+            while (lo < hi) { const int mid = (lo + hi) >> 1; if (v[mid] < x) lo = mid + 1; else hi = mid; }
+            const int q = lo - 1;
+            for (int base = p + 1; base <= q; base += 64) {
+                const int i = base + lane;
+                double xv = 0.0; uint16_t s = 0;
+                if (i <= q) { xv = v[i]; s = hid[i]; }
+                __syncthreads();
+                if (i <= q) { v[i - 1] = xv; hid[i - 1] = s; hpos[s] = (uint16_t)(i - 1); }
+                __syncthreads();
+            }
+            p = q;
+        } else if (x < old) {
+            int lo = 0, hi = p;                                  // first place in [0, p) whose value is > x
+            while (lo < hi) { const int mid = (lo + hi) >> 1; if (v[mid] <= x) lo = mid + 1; else hi = mid; }
+            const int q = lo;
+            for (int top = p - 1; top >= q; top -= 64) {
+                const int i = top - lane;
+                double xv = 0.0; uint16_t s = 0;
+                if (i >= q) { xv = v[i]; s = hid[i]; }
+                __syncthreads();
+                if (i >= q) { v[i + 1] = xv; hid[i + 1] = s; hpos[s] = (uint16_t)(i + 1); }
+                __syncthreads();
+            }
+            p = q;
+        }
+        if (p > 0 && p < N - 1 && v[p - 1] == v[p + 1]) nties -= 1;
+        if (p > 0 && v[p - 1] == x) nties += 1;
+        if (p < N - 1 && v[p + 1] == x) nties += 1;
+        v[p] = x; hid[p] = (uint16_t)j; hpos[j] = (uint16_t)p;
+        __syncthreads();
+    };
+
+    for (long long it = 1; it <= P.iters; ++it) {
+        if (it == next_sample) { next_sample += P.step; if (lane == 0) P.Es[(size_t)ns * P.Rp + r] = E; ns += 1; }
+        const uint64_t g = P.g0 + (uint64_t)it;
+        const Philox4 o = philox4x32_10((uint32_t)g, (uint32_t)(g >> 32), c.rep, TAG_RRR | (3u << 8), P.k0, P.k1);
+        const double rr = (1 - (double)((((uint64_t)o.w[0] << 32) | o.w[1]) >> 11) * 0x1.0p-53) * z;      // rand_move: DeltaE.jl:577-590
+        int lo = 0, hi = N;
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if (P.ftau[mid] < rr) lo = mid + 1; else hi = mid; }
+        if (lo > N - 1) lo = N - 1;
+        const int move = hid[lo];
+        const double dE = v[lo];
+        __syncthreads();
+        c.flip(move);                                                                                    // apply_move!: :592-609
+        __syncthreads();
+        reinsert(move, c.dE(move));
+        const int32_t* Ax = P.A + (size_t)move * K;
+        for (int q = 0; q < K; ++q) {
+            if (!c.is_nb(Ax, q)) continue;
+            reinsert(Ax[q], c.dE(Ax[q]));
+        }
+        if (nties > 0) { eo_order_ties_impl(v, hid, hpos, key, N, g, c.rep, P.k0, P.k1); __syncthreads(); }
+        E += dE;
+        if (E < Emin) {
+            Emin = E; itmin = it;
+            for (int w = lane; w < P.W; w += 64) cm[w] = c.sp[w];
+        }
+    }
+    if (lane == 0) {
+        P.E_cur[r] = E;
+        P.stats[(size_t)r * 3] = P.iters; P.stats[(size_t)r * 3 + 1] = itmin; P.stats[(size_t)r * 3 + 2] = P.iters;
+        P.t_out[r] = Emin;
+        P.status[r] = 0;
+    }
 }
 
 // [W][N] uint64 (bit l of word (w, x) = spin x of replica 64 w + l)  <->  replica-contiguous [R][Wr] 32-bit words (bit = site & 31)

@@ -128,14 +128,22 @@ int32_t spf_standard_mc_async(rrrmc_ctx* ctx, double beta, int64_t iters, int64_
     return RRRMC_OK;
 }
 
-// rrrMC / bklMC / wtmMC with the continuous-energy caches on GraphRRGNormal / GraphEANormal (cont_kernels.hpp)
-int32_t spf_cont_async(rrrmc_ctx* ctx, int mode, double beta, int64_t iters, int64_t step, double stepf, double staged_thr, double staged_thr_fact)
+// rrrMC / bklMC / wtmMC (modes 0 / 1 / 2) with the continuous-energy caches and extremal_opt (mode 3, EOCacheCont; `ftau` = its rank table)
+// on GraphRRGNormal / GraphEANormal (cont_kernels.hpp)
+int32_t spf_cont_async(rrrmc_ctx* ctx, int mode, double beta, int64_t iters, int64_t step, double stepf, double staged_thr, double staged_thr_fact,
+                       const double* ftau = nullptr)
 {
     if (iters < 0) return fail(ctx, RRRMC_ERR_INVALID_ARG, "iters / samples must be >= 0, given %lld", (long long)iters);
     if (mode != 2 && step < 1) return fail(ctx, RRRMC_ERR_INVALID_ARG, "step must be >= 1, given %lld", (long long)step);
     if (mode == 2 && (!(stepf > 0.0) || !std::isfinite(stepf))) return fail(ctx, RRRMC_ERR_INVALID_ARG, "step must be positive and finite, given %g", stepf);
     if (!std::isfinite(beta)) return fail(ctx, RRRMC_ERR_INVALID_ARG, "beta must be finite, given: %g", beta);
     if (ctx->N > 65535) return fail(ctx, RRRMC_ERR_UNSUPPORTED, "N=%lld: the thread-per-replica samplers index spins with 16 bits", (long long)ctx->N);
+    if (mode == 3) {
+        if (!ftau) return fail(ctx, RRRMC_ERR_INVALID_ARG, "ftau is NULL");
+        for (int64_t i = 0; i < ctx->N; ++i)
+            if (!(ftau[i] > 0.0) || !std::isfinite(ftau[i]) || (i && ftau[i] < ftau[i - 1]))
+                return fail(ctx, RRRMC_ERR_INVALID_ARG, "ftau must be a positive non-decreasing table (cumsum of j^-tau), violated at %lld", (long long)i);
+    }
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     ctx->results_valid = false; ctx->last_call_wtm = false; ctx->last_call_eo = false;
     ctx->timing_valid = false;
@@ -167,6 +175,16 @@ int32_t spf_cont_async(rrrmc_ctx* ctx, int mode, double beta, int64_t iters, int
         ctx->ev_sweep.push_back(e);
     }
     ContParams P{};
+    if (mode == 3) {
+        if (!ctx->eo_cmin) {
+            HIP_TRY(ctx, hipMalloc(&ctx->eo_cmin, sizeof(uint32_t) * R * W));
+            HIP_TRY(ctx, hipMalloc(&ctx->eo_ftau, sizeof(double) * N));
+        }
+        ctx->eo_W = W;
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        HIP_TRY(ctx, hipMemcpy(ctx->eo_ftau, ftau, sizeof(double) * N, hipMemcpyHostToDevice));
+        P.ftau = ctx->eo_ftau; P.cmin = ctx->eo_cmin;
+    }
     double* b = ctx->cs_buf;
     P.A = ctx->d_A; P.J = dblm ? ctx->db_rJ : ctx->pf_J; P.spins = dblm ? ctx->q_spins : ctx->cs_spins;
     P.dJ = dblm ? ctx->db_dJ : nullptr; P.lev_mul = ctx->db_lev_mul; P.lev_div = ctx->db_lev_div;
@@ -190,7 +208,15 @@ int32_t spf_cont_async(rrrmc_ctx* ctx, int mode, double beta, int64_t iters, int
         HIP_TRY(ctx, hipGetLastError());
     }
     HIP_TRY(ctx, hipEventRecord(ctx->ev_sweep[0], st));
-    hipLaunchKernelGGL(cont_sparse_kernel, dim3(rrr_blocks(R)), dim3(rrr_tpb(R)), 0, st, P);
+    const char* no_wave = std::getenv("RRRMC_EO_NO_WAVE");            // tests / timing experiments
+    if (mode == 3 && N <= kEoWaveMaxN && !(no_wave && no_wave[0] == '1')) {
+        // extremal_opt: one wavefront per replica, the ranking in LDS
+        const size_t lds = eo_wave_lds_bytes((int)N);
+        HIP_TRY(ctx, raise_lds_attr(reinterpret_cast<const void*>(eo_cont_wave_kernel), lds));
+        hipLaunchKernelGGL(eo_cont_wave_kernel, dim3((unsigned)R), dim3(64), lds, st, P);
+    } else {
+        hipLaunchKernelGGL(cont_sparse_kernel, dim3(rrr_blocks(R)), dim3(rrr_tpb(R)), 0, st, P);
+    }
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipEventRecord(ctx->ev_sweep[1], st));
     if (!dblm) {
@@ -208,5 +234,6 @@ int32_t spf_cont_async(rrrmc_ctx* ctx, int mode, double beta, int64_t iters, int
     ctx->timing_valid = true;
     ctx->last_call_rrr = true;          // accepted / moves come from q_stats
     ctx->last_call_wtm = mode == 2;
+    ctx->last_call_eo = mode == 3;          // Emin in wt_time, itmin in q_stats[.][1], Cmin in eo_cmin
     return RRRMC_OK;
 }

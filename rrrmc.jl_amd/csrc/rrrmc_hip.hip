@@ -1350,22 +1350,26 @@ int32_t rrrmc_extremal_opt_async(rrrmc_ctx* ctx, const double* ftau, int64_t ite
 {
     int32_t rc = ensure_state(ctx, true);
     if (rc) return rc;
-    if (!sparse_int_model(ctx)) return fail(ctx, RRRMC_ERR_UNSUPPORTED, "extremal_opt is wired for RRRMC_MODEL_SPARSE_PM1 and RRRMC_MODEL_SPARSE_LEVELS");
+    if (ctx->model == RRRMC_MODEL_SPARSE_F64 || ctx->model == RRRMC_MODEL_SPARSE_DISCRETIZED)        // not DiscrGraphs: EOCacheCont
+        return spf_cont_async(ctx, 3, 0.0, iters, step, 1.0, 0.0, 0.0, ftau);
+    if (!sparse_int_model(ctx)) return fail(ctx, RRRMC_ERR_UNSUPPORTED, "extremal_opt is wired for the sparse models (RRRMC_MODEL_SPARSE_PM1 / _LEVELS / _F64 / _DISCRETIZED)");
     return sparse_eo_async(ctx, ftau, iters, step);
 }
 
-int32_t rrrmc_extremal_opt_results(rrrmc_ctx* ctx, int64_t* Emin_out, uint64_t* Cmin_chunks, int64_t* itmin_out)
+namespace {
+// shared by the integer and the Float64 variants: Emin as int64 (q_stats[.][0]) or double (wt_time), never both
+int32_t eo_results(rrrmc_ctx* ctx, int64_t* Emin_i, double* Emin_f, uint64_t* Cmin_chunks, int64_t* itmin_out)
 {
-    if (!ctx) return RRRMC_ERR_INVALID_ARG;
     if (!ctx->last_call_eo || !ctx->results_valid) return fail(ctx, RRRMC_ERR_STATE, "no extremal_opt call has been made");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     std::vector<int64_t> st((size_t)ctx->R * 3);
     HIP_TRY(ctx, hipMemcpy(st.data(), ctx->q_stats, sizeof(int64_t) * st.size(), hipMemcpyDeviceToHost));
     for (int64_t r = 0; r < ctx->R; ++r) {
-        if (Emin_out) Emin_out[r] = st[(size_t)(3 * r)];
+        if (Emin_i) Emin_i[r] = st[(size_t)(3 * r)];
         if (itmin_out) itmin_out[r] = st[(size_t)(3 * r + 1)];
     }
+    if (Emin_f) HIP_TRY(ctx, hipMemcpy(Emin_f, ctx->wt_time, sizeof(double) * ctx->R, hipMemcpyDeviceToHost));
     if (Cmin_chunks) {
         const int64_t nch = (ctx->N + 63) / 64, W = ctx->eo_W;
         std::vector<uint32_t> w((size_t)ctx->R * (size_t)W);
@@ -1375,6 +1379,21 @@ int32_t rrrmc_extremal_opt_results(rrrmc_ctx* ctx, int64_t* Emin_out, uint64_t* 
             for (int64_t q = 0; q < W; ++q) Cmin_chunks[r * nch + (q >> 1)] |= (uint64_t)w[(size_t)(r * W + q)] << (32 * (q & 1));
     }
     return RRRMC_OK;
+}
+}  // namespace
+
+int32_t rrrmc_extremal_opt_results(rrrmc_ctx* ctx, int64_t* Emin_out, uint64_t* Cmin_chunks, int64_t* itmin_out)
+{
+    if (!ctx) return RRRMC_ERR_INVALID_ARG;
+    if (!sparse_int_model(ctx)) return fail(ctx, RRRMC_ERR_STATE, "this model's energies are Float64: use rrrmc_extremal_opt_results_f64");
+    return eo_results(ctx, Emin_out, nullptr, Cmin_chunks, itmin_out);
+}
+
+int32_t rrrmc_extremal_opt_results_f64(rrrmc_ctx* ctx, double* Emin_out, uint64_t* Cmin_chunks, int64_t* itmin_out)
+{
+    if (!ctx) return RRRMC_ERR_INVALID_ARG;
+    if (sparse_int_model(ctx)) return fail(ctx, RRRMC_ERR_STATE, "this model's energies are integers: use rrrmc_extremal_opt_results");
+    return eo_results(ctx, nullptr, Emin_out, Cmin_chunks, itmin_out);
 }
 
 int32_t rrrmc_rrr_stats(rrrmc_ctx* ctx, int64_t* staged_iters_out)

@@ -184,10 +184,11 @@ class Engine:
         self._last = (int(iters), int(step))
         self.sync()
         Es, _ = self.fetch_results()
-        Emin = np.zeros(self.R, np.int64)
+        Emin = np.zeros(self.R, np.float64 if self._f64 else np.int64)
         itmin = np.zeros(self.R, np.int64)
         Cmin = Config(N, self.R)
-        check(lib().rrrmc_extremal_opt_results(self._ctx, Emin, Cmin.s.reshape(-1), itmin), self._ctx)
+        res = lib().rrrmc_extremal_opt_results_f64 if self._f64 else lib().rrrmc_extremal_opt_results     # EOCacheCont / EOCache
+        check(res(self._ctx, Emin, Cmin.s.reshape(-1), itmin), self._ctx)
         return Es, (self.X.energy_value(Emin) if self._units else Emin), Cmin, itmin
 
     def rrr_cache(self):
@@ -321,7 +322,8 @@ def wtmMC(X, beta, samples, *, seed=DEFAULT_SEED, step=1.0, C0=None, quiet=False
 
 
 def extremal_opt(X, tau, iters, *, seed=DEFAULT_SEED, step=1, C0=None, quiet=False, replicas=None, device=0, replica0=0, engine=None):
-    """``extremal_opt(X, τ, iters; seed, step, C0, quiet)`` (src/RRRMC.jl:474-521) for a batch of replicas of a GraphRRG / GraphEA.
+    """``extremal_opt(X, τ, iters; seed, step, C0, quiet)`` (src/RRRMC.jl:474-521) for a batch of replicas of a GraphRRG / GraphEA (EOCache) or of a
+    GraphRRGNormal / GraphEANormal / discretised DoubleGraph (the generic EOCacheCont).
     Returns ``(C, Emin, Cmin, itmin)`` like the reference, with per-replica arrays."""
     own = engine is None
     R = replicas if replicas is not None else (C0.R if C0 is not None else (engine.R if engine else 1))

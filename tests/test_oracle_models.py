@@ -446,3 +446,39 @@ def test_wtm_skn_tracked_energy(oracle):
     assert len(Es) == 4000 and moves > 0 and t > 0
     Em, _, _ = oracle.standard_mc_skn(J, 1.0, 400000, 10, seed, ch)[:3]
     assert abs(Es[500:].mean() - Em[5000:].mean()) < 0.25
+
+
+# ---- extremal_opt with EOCacheCont (DeltaE.jl:557-635) on the Float64 graphs ---------------------------------------------------
+@pytest.mark.parametrize("kind,form", [("rrg", "rrg"), ("ea", "ea"), ("ea2L2", "ea")])
+def test_extremal_opt_cont_invariants(oracle, kind, form):
+    seed = 23
+    A = {"rrg": lambda: oracle.gen_rrg(40, 3, seed), "ea": lambda: oracle.gen_ea(4, 2), "ea2L2": lambda: oracle.gen_ea(2, 3)}[kind]()
+    J = oracle.gen_couplings_gauss(A, seed)
+    N = A.shape[0]
+    ch = oracle.init_config(seed, 0, N)
+    E0 = oracle.spf_energy(A, J, ch, form=form)
+    # the oracle itself checks: ranking sorted, dEs == delta_energy, tracked E == energy(X, C) (runtests.jl:12-20)
+    Es, ch1, Emin, Cmin, itmin = oracle.extremal_opt_cont(A, J, 1.3, 2000, 10, seed, ch, form=form)
+    assert len(Es) == 200 and Emin <= min(E0, Es.min()) + 1e-12 and 0 <= itmin <= 2000
+    assert abs(Emin - oracle.spf_energy(A, J, Cmin, form=form)) < 1e-9
+    assert Emin < E0
+    if N <= 16:
+        def e_of(c):
+            sg = 2 * np.array([(c >> i) & 1 for i in range(N)]) - 1
+            return -0.5 * float((J * sg[:, None] * sg[A]).sum())
+        assert Emin >= min(e_of(c) for c in range(2 ** N)) - 1e-9
+
+
+def test_extremal_opt_cont_ties_are_shuffled(oracle):
+    """Integer-valued Float64 couplings make long runs of equal dE: the ranking stays sorted (checked inside), the walk differs from
+    replica to replica only through the draws, and with tau large the lowest-dE site is taken almost always — so the energy of a
+    +-1.0 graph descends exactly like the discrete cache's walk does in distribution (here: it reaches a local minimum region)."""
+    seed = 5
+    A = oracle.gen_rrg(30, 3, seed)
+    J = oracle.gen_couplings(A, seed).astype(np.float64)
+    ch = oracle.init_config(seed, 0, 30)
+    outs = [oracle.extremal_opt_cont(A, J, 1.5, 400, 1, seed, ch, replica=r) for r in range(4)]
+    E0 = oracle.spf_energy(A, J, ch)
+    for Es, c1, Emin, Cmin, itmin in outs:
+        assert Es[0] == E0 and Emin < E0 and float(Emin).is_integer()
+    assert len({tuple(o[0]) for o in outs}) > 1           # different replicas, different tie orders / draws
