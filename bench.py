@@ -46,23 +46,15 @@ def cpu_baseline(O, X, seconds_target=15.0):
             "sample": "%d replicas x 2^22 iterations of the same graph/beta, single thread, oracle/rrrmc_oracle.c (%.1f s)" % (R, dt)}
 
 
-def device_copy_bandwidth(device, nbytes=1 << 30, reps=10):
+def device_copy_bandwidth(pkg, device, nbytes=1 << 30, reps=10):
     """Measured device-to-device copy rate (read + write bytes per second, GB/s): the practical HBM ceiling of this box
-    that SURVEY.md §8d asks to report beside the nominal 8 TB/s."""
-    import torch
-    with torch.cuda.device(device):
-        a = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
-        b = torch.empty_like(a)
-        a.zero_()
-        b.copy_(a)
-        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        ev0.record()
-        for _ in range(reps):
-            b.copy_(a)
-        ev1.record()
-        torch.cuda.synchronize()
-        ms = ev0.elapsed_time(ev1) / reps
-    return 2.0 * nbytes / (ms * 1e-3) / 1e9
+    that SURVEY.md §8d asks to report beside the nominal 8 TB/s.  Timed inside the library (HIP events on its own stream)."""
+    import ctypes
+    out = ctypes.c_double(0.0)
+    rc = pkg.lib().rrrmc_device_copy_bandwidth(int(device), int(nbytes), int(reps), ctypes.byref(out))
+    if rc != 0:
+        raise RuntimeError("rrrmc_device_copy_bandwidth: status %d" % rc)
+    return out.value
 
 
 def main():
@@ -82,7 +74,8 @@ def main():
     # RRRMC_BENCH_BACKEND=gloo is a debugging aid only: it lets several ranks share one GPU (RCCL refuses that) so that the
     # multi-rank code path can be exercised on a 1-GPU box; the driver's multi-GPU runs use the default, RCCL ("nccl").
     backend = os.environ.get("RRRMC_BENCH_BACKEND", "nccl")
-    if world > 1:
+    # RRRMC_BENCH_FORCE_DIST=1: run the distributed code path (process group, RCCL all_reduce / all_gather) with a single rank too
+    if world > 1 or os.environ.get("RRRMC_BENCH_FORCE_DIST") == "1":
         import torch
         import torch.distributed as dist
         if backend == "nccl":
@@ -169,7 +162,7 @@ def main():
                                "kernel": "sweep_kernel<3, 1>", "avg_launch_ms": avg_ms, "launches": launches,
                                "algorithmic_bytes_per_attempt": bytes_per_attempt}
             try:      # after the timed region: the box's own copy bandwidth, for reference only (peak stays the nominal figure)
-                bw = device_copy_bandwidth(local_rank)
+                bw = device_copy_bandwidth(pkg, local_rank)
                 out["roofline"]["measured_copy_GBps"] = bw
                 out["roofline"]["frac_of_measured_copy"] = achieved / bw
             except Exception as e:      # never let the side measurement hide the bench line

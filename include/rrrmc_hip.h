@@ -66,6 +66,9 @@ RRRMC_API const char *rrrmc_last_error(const rrrmc_ctx *ctx);
 
 /* Number of visible HIP devices (0 when there is none; never fails). */
 RRRMC_API int32_t rrrmc_device_count(void);
+/* Measurement helper (bench.py; SURVEY.md §8d "also report a measured device-copy bandwidth"): times `reps` device-to-device copies of
+ * `nbytes` with HIP events on a private stream and returns (bytes read + bytes written) per second in GB/s. */
+RRRMC_API int32_t rrrmc_device_copy_bandwidth(int32_t device, int64_t nbytes, int32_t reps, double *gbps_out);
 
 /*
  * Create a context for R replicas (chains) of one graph with N spins and K neighbour slots per spin.

@@ -379,6 +379,39 @@ int32_t rrrmc_device_count(void)
     return n;
 }
 
+int32_t rrrmc_device_copy_bandwidth(int32_t device, int64_t nbytes, int32_t reps, double* gbps_out)
+{
+    if (!gbps_out || nbytes < 1 || reps < 1) return fail(nullptr, RRRMC_ERR_INVALID_ARG, "gbps_out is NULL or nbytes / reps < 1");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(nullptr, RRRMC_ERR_HIP, "no HIP device is visible");
+    if (device < 0 || device >= ndev) return fail(nullptr, RRRMC_ERR_INVALID_ARG, "device %d out of range (0..%d)", device, ndev - 1);
+    void *a = nullptr, *b = nullptr;
+    hipStream_t st = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    float ms = 0.f;
+    hipError_t e = hipSetDevice(device);
+    if (e == hipSuccess) e = hipMalloc(&a, (size_t)nbytes);
+    if (e == hipSuccess) e = hipMalloc(&b, (size_t)nbytes);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreate(&e0);
+    if (e == hipSuccess) e = hipEventCreate(&e1);
+    if (e == hipSuccess) e = hipMemsetAsync(a, 1, (size_t)nbytes, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(b, a, (size_t)nbytes, hipMemcpyDeviceToDevice, st);          // warm-up
+    if (e == hipSuccess) e = hipEventRecord(e0, st);
+    for (int i = 0; i < reps && e == hipSuccess; ++i) e = hipMemcpyAsync(b, a, (size_t)nbytes, hipMemcpyDeviceToDevice, st);
+    if (e == hipSuccess) e = hipEventRecord(e1, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    if (st) (void)hipStreamDestroy(st);
+    if (a) (void)hipFree(a);
+    if (b) (void)hipFree(b);
+    if (e != hipSuccess) return fail(nullptr, e == hipErrorOutOfMemory ? RRRMC_ERR_NOMEM : RRRMC_ERR_HIP, "device copy timing failed: %s", hipGetErrorString(e));
+    *gbps_out = 2.0 * (double)nbytes * (double)reps / ((double)ms * 1e-3) / 1e9;          // bytes read + bytes written
+    return RRRMC_OK;
+}
+
 int32_t rrrmc_ctx_create(rrrmc_ctx** out, int32_t model, int64_t N, int64_t K, int64_t R, int32_t device, uint32_t replica0)
 {
     if (!out) return fail(nullptr, RRRMC_ERR_INVALID_ARG, "out is NULL");
