@@ -300,6 +300,68 @@ def rrr_mc_quant(A, J, M, fourK, beta, iters, step, seed, chunks, it0=0, replica
     return out + (cache[:N].copy(), cache[N:].copy()) if want_cache else out
 
 
+# ---- GraphQuant over binary GraphSK slices (GraphQSKT, src/QAliases.jl:34-43; scripts/scripts.jl test_QIsing) ----
+def _jb(Jb):
+    return np.ascontiguousarray(Jb, np.uint64).reshape(-1)
+
+
+def quant_sk_energy(Jb, Nk, M, fourK, chunks):
+    L = lib()
+    L.orc_quant_energy_sk.restype = C.c_double
+    L.orc_quant_energy_sk.argtypes = [C.c_int64, C.c_int64, u64p, C.c_double, u64p, C.POINTER(C.c_double)]
+    qt = C.c_double(0)
+    E = L.orc_quant_energy_sk(int(Nk), int(M), _jb(Jb), float(fourK), np.ascontiguousarray(chunks, np.uint64), C.byref(qt))
+    return float(E), float(qt.value)
+
+
+def standard_mc_quant_sk(Jb, Nk, M, fourK, beta, iters, step, seed, chunks, it0=0, replica=0):
+    """standardMC on GraphQuant(GraphSK slices).  Returns (Es, chunks_out, accepted)."""
+    L = lib()
+    L.orc_standard_mc_quant_sk.restype = C.c_int64
+    L.orc_standard_mc_quant_sk.argtypes = [C.c_int64, C.c_int64, u64p, C.c_double, C.c_double, C.c_int64, C.c_int64,
+                                           C.c_uint64, C.c_uint64, C.c_uint32, u64p, f64p, i64p]
+    ch = np.array(chunks, np.uint64, copy=True)
+    Es = np.zeros(max(iters // step, 1), np.float64)
+    acc = np.zeros(1, np.int64)
+    n = L.orc_standard_mc_quant_sk(int(Nk), int(M), _jb(Jb), float(fourK), float(beta), int(iters), int(step), seed, it0, replica, ch, Es, acc)
+    return Es[:n], ch, int(acc[0])
+
+
+def rrr_mc_quant_sk(Jb, Nk, M, fourK, beta, iters, step, seed, chunks, it0=0, replica=0, staged_thr=0.5, staged_thr_fact=5.0,
+                    want_cache=False):
+    """One chain of rrrMC on GraphQuant(GraphSK slices).  Returns (Es, chunks_out, accepted, staged_its[, pos, set_sizes])."""
+    L = lib()
+    L.orc_rrr_mc_quant_sk.restype = C.c_int64
+    L.orc_rrr_mc_quant_sk.argtypes = [C.c_int64, C.c_int64, u64p, C.c_double, C.c_double, C.c_int64, C.c_int64, C.c_double, C.c_double,
+                                      C.c_uint64, C.c_uint64, C.c_uint32, u64p, f64p, i64p, C.c_void_p]
+    N = int(Nk) * int(M)
+    ch = np.array(chunks, np.uint64, copy=True)
+    Es = np.zeros(max(iters // step, 1), np.float64)
+    stats = np.zeros(2, np.int64)
+    cache = np.zeros(N + 4, np.int32)
+    n = L.orc_rrr_mc_quant_sk(int(Nk), int(M), _jb(Jb), float(fourK), float(beta), int(iters), int(step), float(staged_thr),
+                              float(staged_thr_fact), seed, it0, replica, ch, Es, stats, cache.ctypes.data if want_cache else None)
+    if n < 0:
+        raise AssertionError("DeltaECache / ArraySet consistency check failed")
+    out = (Es[:n], ch, int(stats[0]), int(stats[1]))
+    return out + (cache[:N].copy(), cache[N:].copy()) if want_cache else out
+
+
+def quant_sk_observables(Jb, Nk, M, fourK, beta, Gamma, chunks):
+    """(Qenergy, transverse_mag, overlaps[M//2], energy0, Eslice[M] (the integers n_k: E_k = n_k / sqrt(Nk)), ovs_raw[M//2])."""
+    L = lib()
+    L.orc_quant_observables_sk.restype = C.c_int
+    L.orc_quant_observables_sk.argtypes = [C.c_int64, C.c_int64, u64p, C.c_double, C.c_double, C.c_double, u64p,
+                                           C.POINTER(C.c_double), C.POINTER(C.c_double), f64p, C.POINTER(C.c_int64), i64p, i64p]
+    Q, tm, e0 = C.c_double(0), C.c_double(0), C.c_int64(0)
+    ovs = np.zeros(max(M // 2, 1))
+    Es = np.zeros(M, np.int64)
+    raw = np.zeros(max(M // 2, 1), np.int64)
+    L.orc_quant_observables_sk(int(Nk), int(M), _jb(Jb), float(fourK), float(beta), float(Gamma), np.ascontiguousarray(chunks, np.uint64),
+                               C.byref(Q), C.byref(tm), ovs, C.byref(e0), Es, raw)
+    return Q.value, tm.value, ovs[:M // 2], e0.value, Es, raw[:M // 2]
+
+
 # ---- colour-parallel sweeps (build-defined "checkerboard" sampler) -------------------------------------
 def checkerboard_coloring(L, D):
     """Parity colouring of the periodic L^D lattice in the reference's column-major site order (EA.jl:24-43); L even."""

@@ -816,11 +816,24 @@ static void dec_apply_staged(dec_t *c)
     c->z = c->zp;
 }
 
-/* ---- GraphQuant over M slices of one GraphRRG disorder (A, J): src/graphs/QT.jl:126-321, src/QAliases.jl:43-67 ---- */
+/* binary GraphSK (src/graphs/SK.jl:28-165): defined with its samplers further down, used here as a slice graph */
+typedef struct {
+    int64_t N, nch;
+    double sN;
+    const uint64_t *J;
+    int64_t *lfields, *lfields_last;
+    int64_t move_last;
+} skb_t;
+static double skb_energy(skb_t *X, const uint64_t *s);
+static void skb_update_cache(skb_t *X, const uint64_t *s, int64_t move);
+
+/* ---- GraphQuant over M slices of one GraphRRG disorder (A, J), or of one binary GraphSK disorder (GraphQSKT, src/QAliases.jl:34-43 —
+ * the reference's test_QIsing experiment, scripts/scripts.jl:766-864): src/graphs/QT.jl:126-321 ---- */
 typedef struct {
     qt_t X0;
     int64_t Nk, M, K;
     sparse_t *X1;            /* M slice graphs sharing A, J; each with its own LocalFields */
+    skb_t *S1;               /* or (X1 == NULL) M binary-SK slice graphs sharing J */
     uint64_t **C1;           /* M slice configurations (copies of the slice bits) */
 } quant_t;
 
@@ -837,11 +850,36 @@ static void quant_init(quant_t *Q, int64_t Nk, int64_t M, int64_t K, const int32
         Q->X1[k] = X;
         Q->C1[k] = (uint64_t *)calloc((size_t)((Nk + 63) / 64), 8);
     }
+    Q->S1 = NULL;
+}
+static void quant_init_sk(quant_t *Q, int64_t Nk, int64_t M, const uint64_t *Jb, double fourK)
+{
+    Q->X0.N = Nk * M; Q->X0.M = M; Q->X0.Nk = Nk; Q->X0.fourK = fourK;
+    Q->Nk = Nk; Q->M = M; Q->K = 0;
+    Q->X1 = NULL;
+    Q->S1 = (skb_t *)calloc((size_t)M, sizeof(skb_t));
+    Q->C1 = (uint64_t **)calloc((size_t)M, sizeof(uint64_t *));
+    for (int64_t k = 0; k < M; ++k) {
+        skb_t X = {Nk, (Nk + 63) / 64, sqrt((double)Nk), Jb, NULL, NULL, -1};
+        X.lfields = (int64_t *)calloc((size_t)Nk, 8);
+        X.lfields_last = (int64_t *)calloc((size_t)Nk, 8);
+        Q->S1[k] = X;
+        Q->C1[k] = (uint64_t *)calloc((size_t)((Nk + 63) / 64), 8);
+    }
 }
 static void quant_free(quant_t *Q)
 {
-    for (int64_t k = 0; k < Q->M; ++k) { free(Q->X1[k].lfields); free(Q->X1[k].lfields_last); free(Q->C1[k]); }
-    free(Q->X1); free(Q->C1);
+    for (int64_t k = 0; k < Q->M; ++k) {
+        if (Q->X1) { free(Q->X1[k].lfields); free(Q->X1[k].lfields_last); }
+        if (Q->S1) { free(Q->S1[k].lfields); free(Q->S1[k].lfields_last); }
+        free(Q->C1[k]);
+    }
+    free(Q->X1); free(Q->S1); free(Q->C1);
+}
+/* energy(X1[k], C1[k]) as the Float64 the reference divides: an Int for GraphRRG slices, n / sqrt(Nk) for GraphSK ones (SK.jl:95) */
+static inline double quant_slice_energy(quant_t *Q, int64_t k)
+{
+    return Q->S1 ? skb_energy(&Q->S1[k], Q->C1[k]) : (double)sparse_energy(&Q->X1[k], Q->C1[k]);
 }
 /* energy: QT.jl:185-199 — copies the slice bits into C1[k] and (re)builds every slice cache */
 static double quant_energy(quant_t *Q, const uint64_t *s)
@@ -851,7 +889,7 @@ static double quant_energy(quant_t *Q, const uint64_t *s)
         memset(Q->C1[k], 0, (size_t)((Q->Nk + 63) / 64) * 8);
         for (int64_t i = 0; i < Q->Nk; ++i)
             if (spin_bit(s, k * Q->Nk + i)) Q->C1[k][i >> 6] |= 1ull << (i & 63);
-        E += (double)sparse_energy(&Q->X1[k], Q->C1[k]) / (double)Q->M;
+        E += quant_slice_energy(Q, k) / (double)Q->M;
     }
     return E;
 }
@@ -859,6 +897,7 @@ static double quant_energy(quant_t *Q, const uint64_t *s)
 static inline double quant_residual(const quant_t *Q, int64_t move)
 {
     int64_t k = move / Q->Nk, i = move % Q->Nk;
+    if (Q->S1) return ((double)Q->S1[k].lfields[i] / Q->S1[k].sN) / (double)Q->M;          /* SK.jl:137-140 */
     return (double)sparse_delta_energy(&Q->X1[k], i) / (double)Q->M;
 }
 /* spinflip!(X::GraphQuant, C, move): Interface.jl:89-92 + update_cache! QT.jl:172-183 */
@@ -867,7 +906,8 @@ static void quant_spinflip(quant_t *Q, uint64_t *s, int64_t move)
     bitflip(s, move);
     int64_t k = move / Q->Nk, i = move % Q->Nk;
     bitflip(Q->C1[k], i);
-    sparse_update_cache(&Q->X1[k], Q->C1[k], i);
+    if (Q->S1) skb_update_cache(&Q->S1[k], Q->C1[k], i);
+    else sparse_update_cache(&Q->X1[k], Q->C1[k], i);
 }
 
 /* apply_move!: DeltaE.jl:232-295 with X = GraphQuant, X0 = inner_graph(X) = GraphQT */
@@ -923,17 +963,18 @@ static int accept_cx(double c, double x, uint64_t seed, uint64_t g, uint32_t rep
  *   Es      out     energies sampled before the move of iteration k*step
  *   stats   out     [accepted, staged_its]; cache_out (optional): pos[N] then the four set sizes
  */
-ORC_API int64_t orc_rrr_mc_quant(int64_t Nk, int64_t M, int64_t K, const int32_t *A, const int32_t *J, double fourK,
+static int64_t orc_rrr_mc_quant_impl(quant_t *Q,
                                  double beta, int64_t iters, int64_t step, double staged_thr, double staged_thr_fact,
                                  uint64_t seed, uint64_t it0, uint32_t replica,
                                  uint64_t *chunks, double *Es, int64_t *stats, int32_t *cache_out)
 {
-    quant_t Q;
-    quant_init(&Q, Nk, M, K, A, J, fourK);
+    const int64_t Nk = Q->Nk, M = Q->M;
+    const double fourK = Q->X0.fourK;
+    (void)Nk; (void)M; (void)fourK;
     const int64_t N = Nk * M;
-    double E = quant_energy(&Q, chunks);                                    /* :237 */
+    double E = quant_energy(Q, chunks);                                    /* :237 */
     dec_t cache;
-    dec_init(&cache, &Q.X0, chunks, beta);                                  /* :239-240 */
+    dec_init(&cache, &Q->X0, chunks, beta);                                  /* :239-240 */
     const double lambda = staged_thr_fact / (double)N;                      /* :243 */
     int64_t staged_its = 0, accepted = 0, nsamp = 0;
     double acc_rate = 0.5;
@@ -945,12 +986,12 @@ ORC_API int64_t orc_rrr_mc_quant(int64_t Nk, int64_t M, int64_t K, const int32_t
             staged_its += 1;
             double z = cache.z, dE0;
             int64_t move = dec_rand_move(&cache, seed, g, replica, &dE0);   /* step_rrr: :131-138 */
-            dec_compute_staged(&cache, &Q.X0, chunks, move);
+            dec_compute_staged(&cache, &Q->X0, chunks, move);
             double zp = dec_reverse(&cache);
             double c = z / zp;
-            double dE1 = quant_residual(&Q, move);
+            double dE1 = quant_residual(Q, move);
             if (accept_cx(c, -beta * dE1, seed, g, replica)) {
-                quant_spinflip(&Q, chunks, move);
+                quant_spinflip(Q, chunks, move);
                 dec_apply_staged(&cache);
                 E += dE0 + dE1;
                 accepted += 1;
@@ -959,14 +1000,14 @@ ORC_API int64_t orc_rrr_mc_quant(int64_t Nk, int64_t M, int64_t K, const int32_t
         } else {
             double dE0;
             int64_t move = dec_rand_move(&cache, seed, g, replica, &dE0);
-            double dE1 = quant_residual(&Q, move);
-            double c = dec_apply_move(&cache, &Q, chunks, move);
+            double dE1 = quant_residual(Q, move);
+            double c = dec_apply_move(&cache, Q, chunks, move);
             if (accept_cx(c, -beta * dE1, seed, g, replica)) {
                 E += dE0 + dE1;
                 accepted += 1;
                 acc = 1;
             } else {
-                dec_apply_move(&cache, &Q, chunks, move);
+                dec_apply_move(&cache, Q, chunks, move);
             }
         }
         acc_rate = acc_rate * (1 - lambda) + (double)acc * lambda;          /* :281 */
@@ -986,53 +1027,112 @@ ORC_API int64_t orc_rrr_mc_quant(int64_t Nk, int64_t M, int64_t K, const int32_t
         }
     }
     for (int64_t i = 0; i < N; ++i) {
-        int k = dec_class_of(&cache, qt_delta_energy(&Q.X0, chunks, i), spin_bit(chunks, i));
+        int k = dec_class_of(&cache, qt_delta_energy(&Q->X0, chunks, i), spin_bit(chunks, i));
         if (k != cache.pos[i]) bad = 1;
     }
     if (total != N) bad = 1;
     dec_free(&cache);
-    quant_free(&Q);
     return bad ? -1 : nsamp;
+}
+ORC_API int64_t orc_rrr_mc_quant(int64_t Nk, int64_t M, int64_t K, const int32_t *A, const int32_t *J, double fourK,
+                                 double beta, int64_t iters, int64_t step, double staged_thr, double staged_thr_fact,
+                                 uint64_t seed, uint64_t it0, uint32_t replica,
+                                 uint64_t *chunks, double *Es, int64_t *stats, int32_t *cache_out)
+{
+    quant_t Q;
+    quant_init(&Q, Nk, M, K, A, J, fourK);
+    int64_t r = orc_rrr_mc_quant_impl(&Q, beta, iters, step, staged_thr, staged_thr_fact, seed, it0, replica, chunks, Es, stats, cache_out);
+    quant_free(&Q);
+    return r;
+}
+ORC_API int64_t orc_rrr_mc_quant_sk(int64_t Nk, int64_t M, const uint64_t *Jb, double fourK,
+                                 double beta, int64_t iters, int64_t step, double staged_thr, double staged_thr_fact,
+                                 uint64_t seed, uint64_t it0, uint32_t replica,
+                                 uint64_t *chunks, double *Es, int64_t *stats, int32_t *cache_out)
+{
+    quant_t Q;
+    quant_init_sk(&Q, Nk, M, Jb, fourK);
+    int64_t r = orc_rrr_mc_quant_impl(&Q, beta, iters, step, staged_thr, staged_thr_fact, seed, it0, replica, chunks, Es, stats, cache_out);
+    quant_free(&Q);
+    return r;
 }
 
 /* standardMC (src/RRRMC.jl:81-127) on GraphQuant: delta_energy = delta_energy(X0) + delta_energy_residual (QT.jl:283-286).
  * SITE stream for the spin, ACCEPT_F64 stream for rand(). */
+static int64_t orc_standard_mc_quant_impl(quant_t *Q,
+                                      double beta, int64_t iters, int64_t step, uint64_t seed, uint64_t it0, uint32_t replica,
+                                      uint64_t *chunks, double *Es, int64_t *accepted_out)
+{
+    const int64_t Nk = Q->Nk, M = Q->M;
+    const double fourK = Q->X0.fourK;
+    (void)Nk; (void)M; (void)fourK;
+    const int64_t N = Nk * M;
+    double E = quant_energy(Q, chunks);
+    int64_t accepted = 0, nsamp = 0;
+    for (int64_t it = 1; it <= iters; ++it) {
+        if (it % step == 0) Es[nsamp++] = E;
+        const uint64_t g = it0 + (uint64_t)it;
+        const int64_t i = orc_site(seed, g, N);
+        const double dE = qt_delta_energy(&Q->X0, chunks, i) + quant_residual(Q, i);
+        const double x = -beta * dE;
+        const int acc = (x >= 0) || (orc_rand53(seed, g, replica) < orc_det_exp(x));      /* RRRMC.jl:39 */
+        if (!acc) continue;
+        quant_spinflip(Q, chunks, i);
+        E += dE;
+        accepted += 1;
+    }
+    if (accepted_out) *accepted_out = accepted;
+    return nsamp;
+}
 ORC_API int64_t orc_standard_mc_quant(int64_t Nk, int64_t M, int64_t K, const int32_t *A, const int32_t *J, double fourK,
                                       double beta, int64_t iters, int64_t step, uint64_t seed, uint64_t it0, uint32_t replica,
                                       uint64_t *chunks, double *Es, int64_t *accepted_out)
 {
     quant_t Q;
     quant_init(&Q, Nk, M, K, A, J, fourK);
-    const int64_t N = Nk * M;
-    double E = quant_energy(&Q, chunks);
-    int64_t accepted = 0, nsamp = 0;
-    for (int64_t it = 1; it <= iters; ++it) {
-        if (it % step == 0) Es[nsamp++] = E;
-        const uint64_t g = it0 + (uint64_t)it;
-        const int64_t i = orc_site(seed, g, N);
-        const double dE = qt_delta_energy(&Q.X0, chunks, i) + quant_residual(&Q, i);
-        const double x = -beta * dE;
-        const int acc = (x >= 0) || (orc_rand53(seed, g, replica) < orc_det_exp(x));      /* RRRMC.jl:39 */
-        if (!acc) continue;
-        quant_spinflip(&Q, chunks, i);
-        E += dE;
-        accepted += 1;
-    }
-    if (accepted_out) *accepted_out = accepted;
+    int64_t r = orc_standard_mc_quant_impl(&Q, beta, iters, step, seed, it0, replica, chunks, Es, accepted_out);
     quant_free(&Q);
-    return nsamp;
+    return r;
+}
+ORC_API int64_t orc_standard_mc_quant_sk(int64_t Nk, int64_t M, const uint64_t *Jb, double fourK,
+                                      double beta, int64_t iters, int64_t step, uint64_t seed, uint64_t it0, uint32_t replica,
+                                      uint64_t *chunks, double *Es, int64_t *accepted_out)
+{
+    quant_t Q;
+    quant_init_sk(&Q, Nk, M, Jb, fourK);
+    int64_t r = orc_standard_mc_quant_impl(&Q, beta, iters, step, seed, it0, replica, chunks, Es, accepted_out);
+    quant_free(&Q);
+    return r;
 }
 
 /* energy(X::GraphQuant, C) and its parts, for the tests */
+static double orc_quant_energy_impl(quant_t *Q,
+                                const uint64_t *chunks, double *qt_part)
+{
+    const int64_t Nk = Q->Nk, M = Q->M;
+    const double fourK = Q->X0.fourK;
+    (void)Nk; (void)M; (void)fourK;
+    double E = quant_energy(Q, chunks);
+    if (qt_part) *qt_part = qt_energy(&Q->X0, chunks);
+    return E;
+}
 ORC_API double orc_quant_energy(int64_t Nk, int64_t M, int64_t K, const int32_t *A, const int32_t *J, double fourK,
                                 const uint64_t *chunks, double *qt_part)
 {
     quant_t Q;
     quant_init(&Q, Nk, M, K, A, J, fourK);
-    double E = quant_energy(&Q, chunks);
-    if (qt_part) *qt_part = qt_energy(&Q.X0, chunks);
+    double r = orc_quant_energy_impl(&Q, chunks, qt_part);
     quant_free(&Q);
-    return E;
+    return r;
+}
+ORC_API double orc_quant_energy_sk(int64_t Nk, int64_t M, const uint64_t *Jb, double fourK,
+                                const uint64_t *chunks, double *qt_part)
+{
+    quant_t Q;
+    quant_init_sk(&Q, Nk, M, Jb, fourK);
+    double r = orc_quant_energy_impl(&Q, chunks, qt_part);
+    quant_free(&Q);
+    return r;
 }
 
 /* ---------------------------------------------------------------------------------------------
@@ -1077,29 +1177,30 @@ ORC_API int orc_q2_window(const uint64_t *Cs, int64_t N, int64_t i, int64_t j, d
  *                             (by M*Nk/2 for the last entry when M is even)
  *   Qenergy (QT.jl:253-268): -Gamma*transverse_mag + sum_k energy(X1[k], C1[k]) / N, accumulated in slice order
  * Integer parts (energy0, per-slice energies, raw overlap sums) are returned too: they are what the device computes. */
-ORC_API int orc_quant_observables(int64_t Nk, int64_t M, int64_t K, const int32_t *A, const int32_t *J, double fourK, double beta,
+static int orc_quant_observables_impl(quant_t *Q, double beta,
                                   double Gamma, const uint64_t *chunks, double *Qenergy, double *tmag, double *ovs,
                                   int64_t *energy0_out, int64_t *Eslice_out, int64_t *ovs_raw_out)
 {
-    quant_t Q;
-    quant_init(&Q, Nk, M, K, A, J, fourK);
+    const int64_t Nk = Q->Nk, M = Q->M;
+    const double fourK = Q->X0.fourK;
+    (void)Nk; (void)M; (void)fourK;
     const int64_t N = Nk * M;
-    (void)quant_energy(&Q, chunks);                    /* fills C1[k] */
-    const int64_t e0 = qt_energy0(&Q.X0, chunks);
+    (void)quant_energy(Q, chunks);                    /* fills C1[k] */
+    const int64_t e0 = qt_energy0(&Q->X0, chunks);
     const double p = -(double)e0 / (double)N;
     const double x = beta * fourK / 2;
     const double tm = cosh(x) - p * sinh(x);
     double E = -Gamma * tm;
     for (int64_t k = 0; k < M; ++k) {
-        const int64_t Ek = sparse_energy(&Q.X1[k], Q.C1[k]);
-        if (Eslice_out) Eslice_out[k] = Ek;
-        E += (double)Ek / (double)N;
+        const double Ek = quant_slice_energy(Q, k);            /* GraphSK slices: n / sqrt(Nk), n the integer returned in Eslice_out */
+        if (Eslice_out) Eslice_out[k] = Q->S1 ? (int64_t)llround(Ek * Q->S1[k].sN) : (int64_t)Ek;
+        E += Ek / (double)N;
     }
     for (int64_t d = 0; d < M / 2; ++d) { ovs[d] = 0.0; if (ovs_raw_out) ovs_raw_out[d] = 0; }
     for (int64_t k1 = 0; k1 < M - 1; ++k1)
         for (int64_t k2 = k1 + 1; k2 < M; ++k2) {
             int64_t d = k2 - k1 < M + k1 - k2 ? k2 - k1 : M + k1 - k2;
-            int64_t o = orc_pm1dot(Q.C1[k1], Q.C1[k2], Nk);
+            int64_t o = orc_pm1dot(Q->C1[k1], Q->C1[k2], Nk);
             ovs[d - 1] += (double)o;
             if (ovs_raw_out) ovs_raw_out[d - 1] += o;
         }
@@ -1108,8 +1209,27 @@ ORC_API int orc_quant_observables(int64_t Nk, int64_t M, int64_t K, const int32_
     *Qenergy = E;
     *tmag = tm;
     if (energy0_out) *energy0_out = e0;
-    quant_free(&Q);
     return 0;
+}
+ORC_API int orc_quant_observables(int64_t Nk, int64_t M, int64_t K, const int32_t *A, const int32_t *J, double fourK, double beta,
+                                  double Gamma, const uint64_t *chunks, double *Qenergy, double *tmag, double *ovs,
+                                  int64_t *energy0_out, int64_t *Eslice_out, int64_t *ovs_raw_out)
+{
+    quant_t Q;
+    quant_init(&Q, Nk, M, K, A, J, fourK);
+    int r = orc_quant_observables_impl(&Q, beta, Gamma, chunks, Qenergy, tmag, ovs, energy0_out, Eslice_out, ovs_raw_out);
+    quant_free(&Q);
+    return r;
+}
+ORC_API int orc_quant_observables_sk(int64_t Nk, int64_t M, const uint64_t *Jb, double fourK, double beta,
+                                  double Gamma, const uint64_t *chunks, double *Qenergy, double *tmag, double *ovs,
+                                  int64_t *energy0_out, int64_t *Eslice_out, int64_t *ovs_raw_out)
+{
+    quant_t Q;
+    quant_init_sk(&Q, Nk, M, Jb, fourK);
+    int r = orc_quant_observables_impl(&Q, beta, Gamma, chunks, Qenergy, tmag, ovs, energy0_out, Eslice_out, ovs_raw_out);
+    quant_free(&Q);
+    return r;
 }
 
 /* ---------------------------------------------------------------------------------------------
@@ -1195,14 +1315,6 @@ ORC_API void orc_gen_sk_binary(int64_t N, uint64_t seed, uint64_t *J)
         }
     }
 }
-
-typedef struct {
-    int64_t N, nch;
-    double sN;
-    const uint64_t *J;
-    int64_t *lfields, *lfields_last;
-    int64_t move_last;
-} skb_t;
 
 /* energy: SK.jl:62-96 */
 static double skb_energy(skb_t *X, const uint64_t *s)

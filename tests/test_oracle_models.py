@@ -482,3 +482,37 @@ def test_extremal_opt_cont_ties_are_shuffled(oracle):
     for Es, c1, Emin, Cmin, itmin in outs:
         assert Es[0] == E0 and Emin < E0 and float(Emin).is_integer()
     assert len({tuple(o[0]) for o in outs}) > 1           # different replicas, different tie orders / draws
+
+
+# ---- GraphQuant over binary GraphSK slices: GraphQSKT (src/QAliases.jl:34-43), the graph of scripts.jl:test_QIsing ---------------
+def test_quant_sk_slices_tracked_energy_and_parts(oracle):
+    """GraphQuant(10, 8, 0.5, 2.0, GraphSK, gen_J(10)) (runtests.jl:79) under standardMC and rrrMC (:141-143,153-159): the tracked
+    energy equals energy(X, C) (:12-20; the rrrMC oracle also runs check_consistency), energy = E_QT + sum_k (n_k / sqrt(Nk)) / M
+    with n_k the binary-SK integer energy (SK.jl:62-96)."""
+    seed, Nk, M, beta, Gamma = 41, 10, 8, 2.0, 0.5
+    Jb = oracle.gen_sk_binary(Nk, seed)
+    fourK = oracle.quant_fourK(beta, Gamma, M)
+    ch = oracle.init_config(seed, 0, Nk * M)
+    E0, qt = oracle.quant_sk_energy(Jb, Nk, M, fourK, ch)
+    # parts: slice k's bits against the stand-alone binary-SK energy
+    bits = _bits(ch, Nk * M)
+    acc = qt
+    for k in range(M):
+        sl = np.zeros(1, np.uint64)
+        for i in range(Nk):
+            sl[0] |= np.uint64(int(bits[k * Nk + i]) << i)
+        acc += oracle.skb_energy(Jb, sl) / M
+    assert E0 == acc
+    Es, ch1, nacc = oracle.standard_mc_quant_sk(Jb, Nk, M, fourK, beta, 5000, 1, seed, ch)
+    assert Es[0] == E0 and 0 < nacc < 5000
+    for k in (2, 77, 1234, 5000):
+        _, ck, _ = oracle.standard_mc_quant_sk(Jb, Nk, M, fourK, beta, k - 1, 1, seed, ch)
+        assert abs(Es[k - 1] - oracle.quant_sk_energy(Jb, Nk, M, fourK, ck)[0]) < 1e-11
+    for thr in (0.5, 0.0, 1.0):
+        Er, cr, a, st = oracle.rrr_mc_quant_sk(Jb, Nk, M, fourK, beta, 4000, 1, seed, ch, staged_thr=thr)
+        assert Er[0] == E0 and 0 < a < 4000
+        for k in (3, 500, 4000):
+            _, ck, _, _ = oracle.rrr_mc_quant_sk(Jb, Nk, M, fourK, beta, k - 1, 1, seed, ch, staged_thr=thr)
+            assert abs(Er[k - 1] - oracle.quant_sk_energy(Jb, Nk, M, fourK, ck)[0]) < 1e-11
+    Q, tm, ovs, e0, Esl, raw = oracle.quant_sk_observables(Jb, Nk, M, fourK, beta, Gamma, ch)
+    assert abs(Q - (-Gamma * tm + sum(n / np.sqrt(Nk) / (Nk * M) for n in Esl))) < 1e-12 and len(ovs) == M // 2
