@@ -163,6 +163,13 @@ RRRMC_API int32_t rrrmc_gen_sk_gauss(int64_t N, uint64_t seed, double *J_out);
  * Replaces GraphQuant{fourK,GraphRRG}(...) (QT.jl:139-170). */
 RRRMC_API int32_t rrrmc_ctx_create_quant(rrrmc_ctx **out, int64_t Nk, int64_t K, int64_t M, int64_t R,
                                          int32_t device, uint32_t replica0);
+/* GraphQuant over binary GraphSK slices — GraphQSKT(Nk, M, Gamma, beta) = GraphQuant(Nk, M, Gamma, beta, GraphSK, gen_J(Nk))
+ * (src/QAliases.jl:34-43), the graph of the reference's quantum experiment (scripts/scripts.jl:766-864, test_QIsing).  The slice
+ * couplings are given with rrrmc_set_couplings_bits (Nk rows of ceil(Nk/64) chunks, as for RRRMC_MODEL_SK_BINARY; rrrmc_gen_sk_binary
+ * draws them); everything else is as for rrrmc_ctx_create_quant: rrrmc_quant_set_field, rrrmc_rrr_mc_async, rrrmc_standard_mc_async,
+ * rrrmc_energy_f64, rrrmc_quant_observables.  delta_energy_residual = (lfields[i] / sqrt(Nk)) / M (SK.jl:137-140, QT.jl:270-281) with
+ * the integer field recomputed by popcounts of the slice's spin words against row i of J. */
+RRRMC_API int32_t rrrmc_ctx_create_quant_sk(rrrmc_ctx **out, int64_t Nk, int64_t M, int64_t R, int32_t device, uint32_t replica0);
 /* The Trotter coupling fourK (a type parameter of GraphQuant in the reference, QT.jl:126) and the beta it was derived
  * from: needed by rrrmc_energy_f64 before the first rrrMC call, and by rrrmc_standard_mc_async — standardMC on the GraphQuant
  * (src/RRRMC.jl:81-127 with delta_energy = delta_energy(X0) + delta_energy_residual, QT.jl:283-286; SITE + ACCEPT_F64 streams),

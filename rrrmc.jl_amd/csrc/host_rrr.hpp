@@ -6,6 +6,7 @@ RrrParams quant_params(rrrmc_ctx* ctx, double beta, double fourK)
 {
     RrrParams P{};
     P.A = ctx->d_A; P.J = ctx->d_J;
+    if (ctx->q_sk) { P.Jb = ctx->q_Jb; P.Wk = (int)ctx->q_Wk; P.sN = std::sqrt((double)ctx->qNk); }
     P.spins = ctx->q_spins; P.cls = ctx->q_cls; P.sv = ctx->q_sv; P.spos = ctx->q_spos; P.st = ctx->q_st;
     P.T = ctx->q_T; P.zz = ctx->q_z; P.E_cur = ctx->sk_E; P.acc_rate = ctx->q_accrate; P.stats = ctx->q_stats; P.Es = ctx->sk_Es;
     P.beta = beta; P.fourK = fourK;

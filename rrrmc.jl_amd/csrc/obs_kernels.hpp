@@ -80,10 +80,11 @@ __global__ __launch_bounds__(64) void overlap_chunks_kernel(const uint32_t* cons
 
 // GraphQuant integer observables of every replica.  grid R, block 256, dynamic LDS = (M*WS + M + M/2 + 1) words.
 //   e0[r]            = energy0(X0, C) = -sum_j sigma_j sigma_{j+Nk}                       (QT.jl:68-82)
-//   Eslice[r][k]     = energy(X1[k], C1[k])                                                (RRG.jl:164-189)
+//   Eslice[r][k]     = energy(X1[k], C1[k]) (RRG.jl:164-189), or its integer n for GraphSK slices: E = n / sqrt(Nk) (SK.jl:62-96)
 //   ovs_raw[r][d-1]  = sum over slice pairs at ring distance d of pm1dot(slice k1, slice k2)   (QT.jl:213-233)
 __global__ __launch_bounds__(256) void quant_observables_kernel(const uint32_t* __restrict__ spins, const int32_t* __restrict__ A,
-                                                                const int8_t* __restrict__ J, int Nk, int M, int K, int W,
+                                                                const int8_t* __restrict__ J, const uint32_t* __restrict__ Jb, int Wk,
+                                                                int Nk, int M, int K, int W,
                                                                 int32_t* __restrict__ e0, int32_t* __restrict__ Eslice,
                                                                 int32_t* __restrict__ ovs_raw)
 {
@@ -128,6 +129,11 @@ __global__ __launch_bounds__(256) void quant_observables_kernel(const uint32_t* 
         const uint32_t* Sk = S + k * WS;
         const int sx = (int)((Sk[x >> 5] >> (x & 31)) & 1u);
         int32_t acc = 0;
+        if (Jb) {                                // binary GraphSK slices (SK.jl:62-96): sum_{y != x} (2 J_xy - 1) sigma_x sigma_y by popcounts
+            int sc = 0;
+            for (int w = 0; w < WS; ++w) sc += __popc(Sk[w] ^ Jb[(size_t)x * Wk + w]);
+            acc = (2 * sx - 1) * (Nk - 1 - 2 * (sc - sx));
+        }
         for (int j = 0; j < K; ++j) {
             const int y = A[(size_t)x * K + j];
             const int sy = (int)((Sk[y >> 5] >> (y & 31)) & 1u);

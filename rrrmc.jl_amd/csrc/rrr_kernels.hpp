@@ -25,6 +25,9 @@ struct RrrParams {
     // disorder of the slice graph (shared by slices and replicas)
     const int32_t* A;        // [Nk][K]
     const int8_t* J;         // [Nk][K]
+    const uint32_t* Jb;      // [Nk][Wk]     binary GraphSK slices (GraphQSKT, QAliases.jl:34-43) instead of (A, J): row i of J as 32-bit words; else null
+    double sN;               //              sqrt(Nk) (SK.jl:49), 0 for GraphRRG slices
+    int Wk;
     // per-replica state, replica-contiguous
     uint32_t* spins;         // [R][W]       bit x of replica r: word x >> 5, bit x & 31; x = slice * Nk + i
     uint8_t* cls;            // [R][N]       class of every spin: a + 2 * up  (DeltaECache.pos)
@@ -49,6 +52,7 @@ struct RrrView {             // one replica's slices of the arrays above
     int N, Nk, M, K;
     uint32_t nk_magic;       // ceil(2^32 / Nk): floor(x / Nk) = mulhi(x, nk_magic) exactly for x < 2^16 (x e < 2^32 with e = Nk nk_magic - 2^32 < Nk)
     const int32_t* A; const int8_t* J;
+    const uint32_t* Jb; int Wk; double sN;
     double fourK;
 };
 
@@ -76,11 +80,26 @@ __device__ __forceinline__ int qt_class(const RrrView& v, int i)      // DeltaE.
     const int up = d > 0 || (d == 0 && sbit(v.sp, i) == 1);
     return a + kQL * up;
 }
-// delta_energy of the slice graph (RRG.jl:236-244) recomputed from the slice's spins: 2 sigma_i sum_k J_ik sigma_k
+// delta_energy of the slice graph recomputed from the slice's spins, as the integer the reference caches:
+//   GraphRRG slices (RRG.jl:236-244): 2 sigma_i sum_k J_ik sigma_k;
+//   binary GraphSK slices (SK.jl:62-96,137-140): lfields[i] = 2 sigma_i (Nk - 1 - 2 |{j != i : J_ij xor s_j}|) = sqrt(Nk) * delta_energy —
+//   popcounts of the slice's words against row i of J (J_ii = 0, so position i contributes s_i, taken out again).
 __device__ __forceinline__ int slice_delta(const RrrView& v, int move)
 {
     const int k = (int)__umulhi((uint32_t)move, v.nk_magic), i = move - k * v.Nk, off = k * v.Nk;
     const int si = sbit(v.sp, move);
+    if (v.Jb) {
+        const uint32_t* Ji = v.Jb + (size_t)i * v.Wk;
+        int sc = 0;
+        for (int w = 0; 32 * w < v.Nk; ++w) {
+            const int b0 = off + 32 * w, q = b0 >> 5, sh = b0 & 31, rem = v.Nk - 32 * w;
+            uint32_t bits = v.sp[q] >> sh;
+            if (sh && 32 * (q + 1) < v.N) bits |= v.sp[q + 1] << (32 - sh);
+            if (rem < 32) bits &= (1u << rem) - 1u;
+            sc += __popc(bits ^ Ji[w]);
+        }
+        return 2 * (2 * si - 1) * (v.Nk - 1 - 2 * (sc - si));
+    }
     int acc = 0;
     for (int q = 0; q < v.K; ++q) {
         const int y = v.A[i * v.K + q];
@@ -88,6 +107,16 @@ __device__ __forceinline__ int slice_delta(const RrrView& v, int move)
         acc += (si == sy) ? (int)v.J[i * v.K + q] : -(int)v.J[i * v.K + q];
     }
     return 2 * acc;
+}
+// delta_energy_residual (QT.jl:270-281) = delta_energy(X1[k], C1[k], i) / M; for a GraphSK slice delta_energy = lfields[i] / sN (SK.jl:139)
+__device__ __forceinline__ double slice_res(const RrrView& v, int d)
+{
+    return v.Jb ? ((double)d / v.sN) / (double)v.M : (double)d / (double)v.M;
+}
+// energy(X1[k], C1[k]) / M inside energy(X::GraphQuant, C) (QT.jl:195): n an Int for GraphRRG, n / sN for GraphSK (SK.jl:95)
+__device__ __forceinline__ double slice_energy_over_M(const RrrParams& P, long long n)
+{
+    return P.Jb ? ((double)n / P.sN) / (double)P.M : (double)n / (double)P.M;
 }
 // ArraySet delete! / push! (ArraySets.jl:56-76); one position array serves the four sets (membership is exclusive)
 __device__ __forceinline__ void set_move(const RrrView& v, int j, int k0, int k1)
@@ -116,6 +145,7 @@ __device__ __forceinline__ RrrView rrr_view(const RrrParams& P, int r)
     v.spos = P.spos + (size_t)r * P.N;
     v.t = P.st + (size_t)r * 4;
     v.N = P.N; v.Nk = P.Nk; v.M = P.M; v.K = P.K; v.A = P.A; v.J = P.J; v.fourK = P.fourK;
+    v.Jb = P.Jb; v.Wk = P.Wk; v.sN = P.sN;
     v.nk_magic = (uint32_t)((0x100000000ull + (uint32_t)P.Nk - 1u) / (uint32_t)P.Nk);
     return v;
 }
@@ -141,7 +171,7 @@ __global__ __launch_bounds__(kRrrThreads) void rrr_init_kernel(RrrParams P)
         long long n = 0;                       // RRG.jl:164-189: n = sum_x lf_x / 2, lf_x = -sum_q J sx sy
         for (int i = 0; i < P.Nk; ++i) n -= slice_delta(v, k * P.Nk + i) / 2;     // -(2 sx sum J sy)/2 = lf_x
         n /= 2;
-        E += (double)n / (double)P.M;
+        E += slice_energy_over_M(P, n);
     }
     P.E_cur[r] = E;
     // cache: classes and sets in site order
@@ -223,7 +253,7 @@ __global__ __launch_bounds__(kInitThreads) void rrr_init_coop_kernel(RrrParams P
         for (int k = 0; k < P.M; ++k) {
             long long n = s_slice[k];
             n /= 2;
-            E += (double)n / (double)P.M;
+            E += slice_energy_over_M(P, n);
         }
         P.E_cur[r] = E;
         double z = 0.0;
@@ -352,7 +382,7 @@ __global__ __launch_bounds__(kRrrThreads) void rrr_quant_kernel(RrrParams P)
                 zp += f1 - f0;
             }
             const double c = z / zp;
-            const double dE1 = (double)slice_delta(v, move) / (double)P.M;         // delta_energy_residual, QT.jl:270-281
+            const double dE1 = slice_res(v, slice_delta(v, move));         // delta_energy_residual, QT.jl:270-281
             const double x = -P.beta * dE1;
             bool ok = (c >= 1 && x >= 0);
             if (!ok) {                                                                 // accept(c, x), RRRMC.jl:40-44
@@ -376,7 +406,7 @@ __global__ __launch_bounds__(kRrrThreads) void rrr_quant_kernel(RrrParams P)
             }
         } else {
             // direct branch: apply_move! (DeltaE.jl:232-295), undone by a second apply_move! on rejection
-            const double dE1 = (double)slice_delta(v, move) / (double)P.M;
+            const double dE1 = slice_res(v, slice_delta(v, move));
             double c = 0.0;
             for (int pass = 0; pass < 2; ++pass) {
                 sflip(v.sp, move);
@@ -450,7 +480,7 @@ __global__ __launch_bounds__(kRrrThreads) void quant_standard_kernel(RrrParams P
         if (it == next_sample) { next_sample += P.step; P.Es[ns * P.R + r] = E; ns += 1; }
         const uint64_t g = P.g0 + (uint64_t)it;
         const int move = (int)site_of(P.k0, P.k1, g, (uint32_t)P.N);
-        const double dE = (double)qt_delta(v, move) * P.fourK + (double)slice_delta(v, move) / (double)P.M;
+        const double dE = (double)qt_delta(v, move) * P.fourK + slice_res(v, slice_delta(v, move));
         const double x = -P.beta * dE;
         const bool acc = (x >= 0.0) || (rand53(P.k0, P.k1, g, rep) < det_exp(x));        // RRRMC.jl:39
         if (acc) { sflip(v.sp, move); E += dE; accepted += 1; }

@@ -115,6 +115,9 @@ struct rrrmc_ctx {
     int skb_NW = 0;
     // ---- RRRMC_MODEL_QUANT_RRG ----
     int64_t qM = 0, qNk = 0, qW = 0;      // Trotter slices, spins per slice, 32-bit words per replica
+    uint32_t* q_Jb = nullptr;             // GraphQuant over binary GraphSK slices (GraphQSKT): [Nk][q_Wk] words of J's rows, else null
+    int64_t q_Wk = 0;
+    bool q_sk = false;
     uint32_t* q_spins = nullptr;
     uint8_t* q_cls = nullptr;
     uint16_t* q_sv = nullptr;
@@ -541,6 +544,7 @@ void rrrmc_ctx_destroy(rrrmc_ctx* ctx)
     free_dev(ctx->db_dJ); free_dev(ctx->db_rJ); free_dev(ctx->db_cls); free_dev(ctx->db_sv); free_dev(ctx->db_spos); free_dev(ctx->db_lf); free_dev(ctx->db_undo);
     free_dev(ctx->wt_t); free_dev(ctx->wt_id); free_dev(ctx->wt_pos); free_dev(ctx->wt_time);
     free_dev(ctx->eo_cmin); free_dev(ctx->eo_ftau);
+    free_dev(ctx->q_Jb);
     free_dev(ctx->cs_spins); free_dev(ctx->cs_buf); free_dev(ctx->cs_u16);
     free_dev(ctx->snap); free_dev(ctx->d_pairs); free_dev(ctx->d_ovl); free_dev(ctx->d_qobs);
     for (int i = 0; i < 2; ++i) { free_dev(ctx->d_slots[i]); free_dev(ctx->d_vecs[i]); }
@@ -560,6 +564,8 @@ int32_t rrrmc_set_graph(rrrmc_ctx* ctx, const int32_t* A, const int8_t* J)
     if (!ctx) return RRRMC_ERR_INVALID_ARG;
     if (ctx->model != RRRMC_MODEL_SPARSE_PM1 && ctx->model != RRRMC_MODEL_QUANT_RRG)
         return fail(ctx, RRRMC_ERR_STATE, "rrrmc_set_graph is for sparse +-J models; use rrrmc_set_couplings_dense");
+    if (ctx->model == RRRMC_MODEL_QUANT_RRG && ctx->q_sk)
+        return fail(ctx, RRRMC_ERR_STATE, "this GraphQuant has binary GraphSK slices: give their couplings with rrrmc_set_couplings_bits");
     if (!A || !J) return fail(ctx, RRRMC_ERR_INVALID_ARG, "A and J must not be NULL");
     const int64_t N = ctx->model == RRRMC_MODEL_QUANT_RRG ? ctx->qNk : ctx->N, K = ctx->K;
     for (int64_t q = 0; q < N * K; ++q) {
@@ -1211,11 +1217,23 @@ int32_t rrrmc_colored_sweeps_async(rrrmc_ctx* ctx, double beta, int64_t sweeps, 
 
 // ---- GraphQuant + rrrMC: exported entry points ---------------------------------------------------------------------
 
+namespace {
+int32_t quant_ctx_create(rrrmc_ctx** out, int64_t Nk, int64_t K, int64_t M, int64_t R, int32_t device, uint32_t replica0, bool sk);
+}
 int32_t rrrmc_ctx_create_quant(rrrmc_ctx** out, int64_t Nk, int64_t K, int64_t M, int64_t R, int32_t device, uint32_t replica0)
+{
+    return quant_ctx_create(out, Nk, K, M, R, device, replica0, false);
+}
+int32_t rrrmc_ctx_create_quant_sk(rrrmc_ctx** out, int64_t Nk, int64_t M, int64_t R, int32_t device, uint32_t replica0)
+{
+    return quant_ctx_create(out, Nk, 0, M, R, device, replica0, true);
+}
+namespace {
+int32_t quant_ctx_create(rrrmc_ctx** out, int64_t Nk, int64_t K, int64_t M, int64_t R, int32_t device, uint32_t replica0, bool sk)
 {
     if (!out) return fail(nullptr, RRRMC_ERR_INVALID_ARG, "out is NULL");
     *out = nullptr;
-    if (Nk < 1 || K < 1 || R < 1) return fail(nullptr, RRRMC_ERR_INVALID_ARG, "Nk, K, R must be >= 1");
+    if (Nk < 1 || (!sk && K < 1) || R < 1) return fail(nullptr, RRRMC_ERR_INVALID_ARG, "Nk, K, R must be >= 1");
     if (M <= 2) return fail(nullptr, RRRMC_ERR_INVALID_ARG, "M must be greater than 2, given: %lld", (long long)M);   // QT.jl:47
     if (Nk * M > 65535) return fail(nullptr, RRRMC_ERR_UNSUPPORTED, "N = Nk*M = %lld: the rrrMC kernel indexes spins with 16 bits", (long long)(Nk * M));
     int ndev = 0;
@@ -1226,6 +1244,7 @@ int32_t rrrmc_ctx_create_quant(rrrmc_ctx** out, int64_t Nk, int64_t K, int64_t M
     if (!ctx) return fail(nullptr, RRRMC_ERR_NOMEM, "out of host memory");
     ctx->model = RRRMC_MODEL_QUANT_RRG; ctx->N = Nk * M; ctx->K = K; ctx->R = R; ctx->Rpad = R;
     ctx->qNk = Nk; ctx->qM = M; ctx->qW = 2 * ((Nk * M + 63) / 64);
+    ctx->q_sk = sk; ctx->q_Wk = 2 * ((Nk + 63) / 64);
     ctx->device = device; ctx->replica0 = replica0;
     const int64_t N = ctx->N;
 #define Q_TRY(expr)                                                                                              \
@@ -1241,8 +1260,12 @@ int32_t rrrmc_ctx_create_quant(rrrmc_ctx** out, int64_t Nk, int64_t K, int64_t M
     Q_TRY(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
     Q_TRY(hipEventCreate(&ctx->ev_begin));
     Q_TRY(hipEventCreate(&ctx->ev_end));
-    Q_TRY(hipMalloc(&ctx->d_A, sizeof(int32_t) * Nk * K));
-    Q_TRY(hipMalloc(&ctx->d_J, sizeof(int8_t) * Nk * K));
+    if (sk) {
+        Q_TRY(hipMalloc(&ctx->q_Jb, sizeof(uint32_t) * Nk * ctx->q_Wk));
+    } else {
+        Q_TRY(hipMalloc(&ctx->d_A, sizeof(int32_t) * Nk * K));
+        Q_TRY(hipMalloc(&ctx->d_J, sizeof(int8_t) * Nk * K));
+    }
     Q_TRY(hipMalloc(&ctx->q_spins, sizeof(uint32_t) * R * ctx->qW));
     Q_TRY(hipMalloc(&ctx->q_cls, (size_t)R * N));
     Q_TRY(hipMalloc(&ctx->q_sv, sizeof(uint16_t) * R * 4 * N));
@@ -1258,6 +1281,7 @@ int32_t rrrmc_ctx_create_quant(rrrmc_ctx** out, int64_t Nk, int64_t K, int64_t M
     *out = ctx;
     return RRRMC_OK;
 }
+}  // namespace
 
 namespace {
 // rrrMC(X::DoubleGraph) (standard = false) or standardMC (standard = true) on GraphQuant: thread-per-replica kernels
@@ -1583,9 +1607,11 @@ int32_t rrrmc_standard_mc_f64(rrrmc_ctx* ctx, double beta, int64_t iters, int64_
 int32_t rrrmc_set_couplings_bits(rrrmc_ctx* ctx, const uint64_t* Jc)
 {
     if (!ctx) return RRRMC_ERR_INVALID_ARG;
-    if (ctx->model != RRRMC_MODEL_SK_BINARY) return fail(ctx, RRRMC_ERR_STATE, "rrrmc_set_couplings_bits is for RRRMC_MODEL_SK_BINARY");
+    const bool qsk = ctx->model == RRRMC_MODEL_QUANT_RRG && ctx->q_sk;          // the slice graph of a GraphQSKT
+    if (ctx->model != RRRMC_MODEL_SK_BINARY && !qsk)
+        return fail(ctx, RRRMC_ERR_STATE, "rrrmc_set_couplings_bits is for RRRMC_MODEL_SK_BINARY and for contexts made by rrrmc_ctx_create_quant_sk");
     if (!Jc) return fail(ctx, RRRMC_ERR_INVALID_ARG, "J_chunks is NULL");
-    const int64_t N = ctx->N, nch = (N + 63) / 64;
+    const int64_t N = qsk ? ctx->qNk : ctx->N, nch = (N + 63) / 64;
     auto bit = [&](int64_t i, int64_t j) { return (int)((Jc[i * nch + (j >> 6)] >> (j & 63)) & 1ull); };
     for (int64_t i = 0; i < N; ++i) {        // GraphSK(J; check = true), SK.jl:36-46
         if (bit(i, i)) return fail(ctx, RRRMC_ERR_INVALID_ARG, "diagonal entries of J must be 0, found: J[%lld][%lld] = 1", (long long)i, (long long)i);
@@ -1595,7 +1621,8 @@ int32_t rrrmc_set_couplings_bits(rrrmc_ctx* ctx, const uint64_t* Jc)
     }
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    HIP_TRY(ctx, hipMemcpy(ctx->skb_J, Jc, sizeof(uint64_t) * N * nch, hipMemcpyHostToDevice));     // chunk = two little-endian words
+    HIP_TRY(ctx, hipMemcpy(qsk ? (void*)ctx->q_Jb : (void*)ctx->skb_J, Jc, sizeof(uint64_t) * N * nch, hipMemcpyHostToDevice));     // chunk = two little-endian words
+    if (qsk) ctx->q_cache_valid = false;
     ctx->graph_set = true;
     return RRRMC_OK;
 }
@@ -1712,7 +1739,7 @@ int32_t rrrmc_quant_observables(rrrmc_ctx* ctx, double beta, double Gamma, doubl
     int32_t* d_es = d_e0 + R;
     int32_t* d_ov = d_es + R * M;
     hipLaunchKernelGGL(quant_observables_kernel, dim3((unsigned)R), dim3(256), lds, ctx->stream, ctx->q_spins, ctx->d_A, ctx->d_J,
-                       (int)Nk, (int)M, (int)ctx->K, (int)ctx->qW, d_e0, d_es, d_ov);
+                       ctx->q_sk ? ctx->q_Jb : nullptr, (int)ctx->q_Wk, (int)Nk, (int)M, (int)ctx->K, (int)ctx->qW, d_e0, d_es, d_ov);
     HIP_TRY(ctx, hipGetLastError());
     std::vector<int32_t> h((size_t)R * (size_t)(1 + M + H));
     HIP_TRY(ctx, hipMemcpyAsync(h.data(), ctx->d_qobs, sizeof(int32_t) * h.size(), hipMemcpyDeviceToHost, ctx->stream));
@@ -1725,7 +1752,11 @@ int32_t rrrmc_quant_observables(rrrmc_ctx* ctx, double beta, double Gamma, doubl
         const double p = -(double)h[(size_t)r] / (double)N;
         const double tm = ch - p * sh;
         double E = -Gamma * tm;
-        for (int64_t k = 0; k < M; ++k) E += (double)h[(size_t)(R + r * M + k)] / (double)N;
+        const double sN = std::sqrt((double)Nk);                  // GraphSK slices: energy(X1[k], C1[k]) = n / sqrt(Nk), SK.jl:49,95
+        for (int64_t k = 0; k < M; ++k) {
+            const double Ek = ctx->q_sk ? (double)h[(size_t)(R + r * M + k)] / sN : (double)h[(size_t)(R + r * M + k)];
+            E += Ek / (double)N;
+        }
         if (tmag_out) tmag_out[r] = tm;
         if (Qenergy_out) Qenergy_out[r] = E;
         if (ovs_out) {

@@ -23,13 +23,18 @@ class Engine:
         self._ctx = C.c_void_p()
         self._f64 = X.model_kind not in (MODEL_SPARSE_PM1, MODEL_SPARSE_LEVELS)
         self._units = X.model_kind == MODEL_SPARSE_LEVELS        # device energies are int64 level units: X.energy_value converts
-        if X.model_kind == MODEL_QUANT_RRG:
+        if X.model_kind == MODEL_QUANT_RRG and X.sk_slices:
+            check(lib().rrrmc_ctx_create_quant_sk(C.byref(self._ctx), X.Nk, X.M, self.R, device, replica0))
+        elif X.model_kind == MODEL_QUANT_RRG:
             check(lib().rrrmc_ctx_create_quant(C.byref(self._ctx), X.Nk, X.K, X.M, self.R, device, replica0))
         else:
             check(lib().rrrmc_ctx_create(C.byref(self._ctx), X.model_kind, X.N, X.K, self.R, device, replica0))
         try:
             if X.model_kind == MODEL_QUANT_RRG:
-                check(lib().rrrmc_set_graph(self._ctx, X.A, X.J), self._ctx)
+                if X.sk_slices:
+                    check(lib().rrrmc_set_couplings_bits(self._ctx, X.J.reshape(-1)), self._ctx)
+                else:
+                    check(lib().rrrmc_set_graph(self._ctx, X.A, X.J), self._ctx)
                 check(lib().rrrmc_quant_set_field(self._ctx, X.beta, X.fourK), self._ctx)
             elif X.model_kind == MODEL_SPARSE_DISCRETIZED:
                 check(lib().rrrmc_set_graph_discretized(self._ctx, X.A, X.dJ, X.rJ.reshape(-1), np.asarray(X.LEV, np.int32), len(X.LEV),

@@ -407,7 +407,9 @@ class GraphQuant:
     transformation: M coupled copies ("slices") of a classical graph (src/graphs/QT.jl:126-170).
 
     As the in-tree aliases do (src/QAliases.jl:43-67) the disorder is generated ONCE and shared by all slices:
-    ``GraphQuant(X1, M, Γ, β)`` with ``X1`` a ``GraphRRG``.  ``N = Nk * M`` spins, slice-major.  ``ET = Float64``.
+    ``GraphQuant(X1, M, Γ, β)`` with ``X1`` a ``GraphRRG`` / ``GraphEA`` (±J), or a binary ``GraphSK`` — the reference's
+    ``GraphQSKT(Nk, M, Γ, β)`` (src/QAliases.jl:34-43), the graph of ``scripts.jl:test_QIsing``.  ``N = Nk * M`` spins, slice-major.
+    ``ET = Float64``.
     """
     model_kind = 3          # RRRMC_MODEL_QUANT_RRG
     energy_dtype = np.float64
@@ -419,11 +421,17 @@ class GraphQuant:
         if Gamma < 0:
             raise ValueError("Γ must be >= 0")                                   # QT.jl:164
         self.X1, self.M, self.Gamma, self.beta = X1, int(M), float(Gamma), float(beta)
-        self.Nk, self.K = X1.N, X1.K
+        self.sk_slices = isinstance(X1, GraphSK)
+        self.Nk, self.K = X1.N, (0 if self.sk_slices else X1.K)
         self.N = self.Nk * self.M
-        self.A, self.J = X1.A, X1.J
+        self.A, self.J = (None if self.sk_slices else X1.A), X1.J          # GraphSK slices: J = the bit-packed rows (SK.jl:32)
         # fourK = round(2/β * log(coth(β Γ / M)), digits = MAXDIGITS): QT.jl:165
         self.fourK = round(2.0 / beta * math.log(1.0 / math.tanh(beta * Gamma / M)), 8)
+
+
+def GraphQSKT(Nk, M, Gamma, beta, seed=DEFAULT_SEED):
+    """``GraphQSKT(Nk, M, Γ, β)`` = ``GraphQuant(Nk, M, Γ, β, GraphSK, SK.gen_J(Nk))`` (src/QAliases.jl:34-43)."""
+    return GraphQuant(GraphSK(Nk, seed=seed), M, Gamma, beta)
 
 
 def checkerboard_coloring(L, D):

@@ -1,0 +1,119 @@
+"""GPU parity for GraphQuant over binary GraphSK slices — GraphQSKT (src/QAliases.jl:34-43), the graph of the reference's quantum
+experiment scripts/scripts.jl:766-864 (test_QIsing: standardMC and rrrMC, Qenergy logged at every sample) and of
+test/runtests.jl:79.  SURVEY.md §8a rows a9b x a10-a14.  Bit equality with the oracle (north_star: 1e-6 relative for Float64)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("Nk,M,Gamma,beta,R,iters,step,thr", [
+    (10, 8, 0.5, 2.0, 8, 10000, 100, 0.5),      # runtests.jl:79 GraphQuant(10, 8, 0.5, 2.0, GraphSK, gen_J(10)); default staged_thr
+    (10, 8, 0.5, 2.0, 8, 6000, 100, 0.0),       # always direct (every rejection is undone)
+    (10, 8, 0.5, 2.0, 8, 6000, 100, 1.0),       # always staged
+    (45, 7, 0.3, 1.0, 70, 12000, 250, 0.5),     # slices not word aligned; more than one 64-thread block
+    (64, 16, 0.3, 2.0, 16, 20000, 500, 0.5),    # word-aligned slices
+    (1024, 16, 0.3, 2.0, 3, 20000, 4096, 0.5),  # test_QIsing's geometry (N = 1024, M = 16, beta = 2, Gamma = 0.3)
+])
+def test_rrr_quant_sk_bit_exact(pkg, oracle, Nk, M, Gamma, beta, R, iters, step, thr):
+    seed = 5426732438 + Nk
+    X = pkg.GraphQSKT(Nk, M, Gamma, beta, seed=seed)
+    assert X.fourK == oracle.quant_fourK(beta, Gamma, M) and (X.J == oracle.gen_sk_binary(Nk, seed)).all()
+    Jb = X.J
+    with pkg.Engine(X, R) as eng:
+        eng.seed(seed)
+        eng.init_spins_random()
+        C0 = eng.get_config()
+        E0 = eng.energy()
+        Es, acc, staged = eng.rrr_mc(beta, iters, step, staged_thr=thr)
+        C1 = eng.get_config()
+        pos, sizes = eng.rrr_cache()
+        E1 = eng.energy()
+        Es2, acc2, staged2 = eng.rrr_mc(beta, iters // 4, step, staged_thr=thr)       # continues the streams
+        C2 = eng.get_config()
+    for r in range(R):
+        assert E0[r] == oracle.quant_sk_energy(Jb, Nk, M, X.fourK, C0.s[r])[0]
+        ref = oracle.rrr_mc_quant_sk(Jb, Nk, M, X.fourK, beta, iters, step, seed, C0.s[r], replica=r, staged_thr=thr, want_cache=True)
+        assert np.allclose(Es[r], ref[0], rtol=1e-6, atol=1e-9)
+        assert (Es[r] == ref[0]).all() and (C1.s[r] == ref[1]).all() and acc[r] == ref[2] and staged[r] == ref[3]
+        assert (pos[r] == ref[4]).all() and (sizes[r] == ref[5]).all()
+        assert E1[r] == oracle.quant_sk_energy(Jb, Nk, M, X.fourK, C1.s[r])[0]
+    for r in (0, R - 1):
+        # the second call restarts acc_rate at 0.5 and rebuilds the cache, like a second rrrMC(...; C0 = C) does
+        ref2 = oracle.rrr_mc_quant_sk(Jb, Nk, M, X.fourK, beta, iters // 4, step, seed, C1.s[r], it0=iters, replica=r, staged_thr=thr)
+        assert (Es2[r] == ref2[0]).all() and (C2.s[r] == ref2[1]).all() and acc2[r] == ref2[2]
+
+
+@pytest.mark.parametrize("Nk,M,Gamma,beta,R,iters,step", [
+    (10, 8, 0.5, 2.0, 40, 10000, 100),          # runtests.jl:79 under standardMC (:141-143)
+    (45, 7, 0.3, 1.0, 70, 12000, 250),
+    (1024, 16, 0.3, 2.0, 3, 40000, 4096),       # test_QIsing's ":met" leg
+])
+def test_standard_mc_quant_sk_bit_exact(pkg, oracle, Nk, M, Gamma, beta, R, iters, step):
+    seed = 5426732438 + Nk + 1
+    X = pkg.GraphQSKT(Nk, M, Gamma, beta, seed=seed)
+    Jb = X.J
+    with pkg.Engine(X, R) as eng:
+        eng.seed(seed)
+        eng.init_spins_random()
+        C0 = eng.get_config()
+        Es, acc = eng.standard_mc(beta, iters, step)
+        C1 = eng.get_config()
+        Es2, acc2 = eng.standard_mc(beta, iters // 2, step)
+        C2 = eng.get_config()
+        E2 = eng.energy()
+    for r in range(R):
+        ref = oracle.standard_mc_quant_sk(Jb, Nk, M, X.fourK, beta, iters, step, seed, C0.s[r], replica=r)
+        assert np.allclose(Es[r], ref[0], rtol=1e-6, atol=1e-9)
+        assert (Es[r] == ref[0]).all() and (C1.s[r] == ref[1]).all() and acc[r] == ref[2]
+        ref2 = oracle.standard_mc_quant_sk(Jb, Nk, M, X.fourK, beta, iters // 2, step, seed, ref[1], it0=iters, replica=r)
+        assert (Es2[r] == ref2[0]).all() and (C2.s[r] == ref2[1]).all() and acc2[r] == ref2[2]
+        assert E2[r] == oracle.quant_sk_energy(Jb, Nk, M, X.fourK, C2.s[r])[0]
+    assert 0 < acc.sum() < R * iters
+
+
+def test_quant_sk_lds_and_global_builds_agree(pkg, oracle, monkeypatch):
+    seed = 777
+    X = pkg.GraphQSKT(33, 5, 0.4, 1.2, seed=seed)          # N = 165: unaligned slices, odd sizes
+    out = []
+    for no_lds in ("0", "1"):
+        monkeypatch.setenv("RRRMC_QUANT_NO_LDS", no_lds)
+        with pkg.Engine(X, 9) as eng:
+            eng.seed(seed)
+            eng.init_spins_random()
+            C0 = eng.get_config()
+            a = eng.rrr_mc(1.2, 6000, 100)
+            out.append((a[0], a[1], a[2], eng.get_config().s, eng.rrr_cache()[0], eng.rrr_cache()[1]))
+    for u, v in zip(*out):
+        assert (u == v).all()
+    for r in range(9):
+        ref = oracle.rrr_mc_quant_sk(X.J, 33, 5, X.fourK, 1.2, 6000, 100, seed, C0.s[r], replica=r)
+        assert (out[0][0][r] == ref[0]).all() and out[0][1][r] == ref[2]
+
+
+@pytest.mark.parametrize("Nk,M,R", [(10, 8, 7), (45, 5, 3), (1024, 16, 2)])
+def test_quant_sk_observables(pkg, oracle, Nk, M, R):
+    """Qenergy / transverse_mag / overlaps (QT.jl:113-122, 213-268): what test_QIsing's hook logs at every sample."""
+    seed = 41337 + Nk
+    beta, Gamma = 2.0, 0.3
+    X = pkg.GraphQSKT(Nk, M, Gamma, beta, seed=seed)
+    with pkg.Engine(X, R) as eng:
+        eng.seed(seed)
+        eng.init_spins_random()
+        eng.rrr_mc(beta, 5000, 5000)
+        C = eng.get_config()
+        Q, tm, ov = eng.quant_observables()
+    for r in range(R):
+        Qr, tmr, ovr, *_ = oracle.quant_sk_observables(X.J, Nk, M, X.fourK, beta, Gamma, C.s[r])
+        assert Q[r] == Qr and tm[r] == tmr and (ov[r] == ovr).all()
+
+
+def test_quant_sk_errors(pkg):
+    X = pkg.GraphQSKT(10, 8, 0.5, 2.0, seed=3)
+    with pkg.Engine(X, 2) as eng:
+        A = np.zeros((10, 3), np.int32)
+        rc = pkg.lib().rrrmc_set_graph(eng._ctx, A, np.ones((10, 3), np.int8))
+        assert rc != 0                                     # SK slices take rrrmc_set_couplings_bits
+        bad = X.J.copy()
+        bad[0, 0] |= np.uint64(1)                          # J[1][1] = 1: "diagonal entries of J must be 0" (SK.jl:38)
+        assert pkg.lib().rrrmc_set_couplings_bits(eng._ctx, bad.reshape(-1)) == 1
