@@ -20,7 +20,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import __graft_entry__ as entry  # noqa: E402
 
 
-def main():
+def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--N", type=int, default=10_000)          # scripts.jl:23
     ap.add_argument("--K", type=int, default=3)
@@ -36,7 +36,7 @@ def main():
     ap.add_argument("--met-factor", type=float, default=3.7)
     ap.add_argument("--bkl-factor", type=float, default=94.9)
     ap.add_argument("--wtm-factor", type=float, default=53.0)
-    args = ap.parse_args()
+    args = ap.parse_args(argv)
 
     pkg = entry.load_package()
     os.makedirs(args.out, exist_ok=True)

@@ -21,7 +21,7 @@ class SnapshotLog:
     It returns ``t < t_limit`` like the reference's hook (:63-66).
     """
 
-    def __init__(self, engine, nslots, prefix=None, t_limit=float("inf"), replicas=None):
+    def __init__(self, engine, nslots, prefix=None, t_limit=float("inf"), replicas=None, energy_label="E"):
         self.eng = engine
         self.nslots = int(nslots)
         engine.snapshot_reserve(self.nslots)
@@ -34,7 +34,7 @@ class SnapshotLog:
         if prefix is not None:
             for r in self.replicas:
                 f = open("%s_r%d.txt" % (prefix, r), "w")
-                f.write("#mctime acc E clocktime\n")
+                f.write("#mctime acc %s clocktime\n" % energy_label)          # "QE" in test_QIsing (scripts.jl:802)
                 self.files[r] = f
 
     def __call__(self, it, X, C, accepted, E):
