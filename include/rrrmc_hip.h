@@ -187,7 +187,8 @@ RRRMC_API int32_t rrrmc_rrr_stats(rrrmc_ctx *ctx, int64_t *staged_iters_out);
  * DeltaECacheCont + DynamicSampler (src/DeltaE.jl:297-410, src/DynamicSamplers.jl; results through rrrmc_fetch_results_f64).
  * On RRRMC_MODEL_SPARSE_F64 (GraphRRGNormal / GraphEANormal) rrrmc_rrr_mc_async, rrrmc_bkl_mc_async and rrrmc_wtm_mc_async run the
  * continuous-energy versions (DeltaECacheCont + DynamicSampler, THeap; results through rrrmc_fetch_results_f64); rrrmc_bkl_mc_async
- * also serves RRRMC_MODEL_SK_NORMAL.
+ * also serves RRRMC_MODEL_SK_NORMAL.  RRRMC_MODEL_SK_BINARY (GraphSK, a SimpleGraph{Float64} too: SK.jl:28) runs rrrMC / bklMC / wtmMC
+ * through the same continuous-energy caches over delta_energy = lfields[i] / sqrt(N) (SK.jl:137-140).
  * bklMC(X, beta, iters; step) (src/RRRMC.jl:311-359) on RRRMC_MODEL_SPARSE_PM1: rejection-free Bortz-Kalos-Lebowitz sampler;
  * `iters` counts the skipped rejections too; rrrmc_rrr_stats then returns the number of moves actually made ("true it"). */
 RRRMC_API int32_t rrrmc_bkl_mc_async(rrrmc_ctx *ctx, double beta, int64_t iters, int64_t step);

@@ -819,3 +819,54 @@ def bkl_mc_skn(J, beta, iters, step, seed, chunks, it0=0, replica=0):
     if n < 0:
         raise RuntimeError("bkl_mc_skn: DynamicSampler lost precision")
     return Es[:n], ch, int(stats[0]), int(stats[2])
+
+
+# ---- the continuous-energy samplers on the binary GraphSK (a SimpleGraph{Float64} too: SK.jl:28) ---------------------------------
+def rrr_mc_skb(Jb, beta, iters, step, seed, chunks, it0=0, replica=0, staged_thr=0.8, staged_thr_fact=5.0):
+    """One chain of rrrMC on the binary GraphSK.  Returns (Es, chunks_out, accepted, staged_its)."""
+    L = lib()
+    L.orc_rrr_mc_skb.restype = C.c_int64
+    L.orc_rrr_mc_skb.argtypes = [C.c_int64, u64p, C.c_double, C.c_int64, C.c_int64, C.c_double, C.c_double, C.c_uint64, C.c_uint64,
+                                 C.c_uint32, u64p, f64p, i64p, C.c_void_p, C.c_void_p]
+    N = Jb.shape[0]
+    ch = np.array(chunks, np.uint64, copy=True)
+    Es = np.zeros(max(iters // step, 1), np.float64)
+    stats = np.zeros(2, np.int64)
+    n = L.orc_rrr_mc_skb(N, np.ascontiguousarray(Jb, np.uint64).reshape(-1), float(beta), int(iters), int(step), float(staged_thr),
+                         float(staged_thr_fact), seed, it0, replica, ch, Es, stats, None, None)
+    if n < 0:
+        raise AssertionError("Unrecoverable loss of precision detected in the dynamic sampler")
+    return Es[:n], ch, int(stats[0]), int(stats[1])
+
+
+def bkl_mc_skb(Jb, beta, iters, step, seed, chunks, it0=0, replica=0):
+    """bklMC on the binary GraphSK; returns (Es, chunks, moves, iterations done)."""
+    L = lib()
+    L.orc_bkl_mc_skb.restype = C.c_int64
+    L.orc_bkl_mc_skb.argtypes = [C.c_int64, u64p, C.c_double, C.c_int64, C.c_int64, C.c_uint64, C.c_uint64, C.c_uint32, u64p, f64p, i64p]
+    N = Jb.shape[0]
+    ch = np.array(chunks, np.uint64, copy=True)
+    Es = np.zeros(max(iters // step, 1))
+    stats = np.zeros(3, np.int64)
+    n = L.orc_bkl_mc_skb(N, np.ascontiguousarray(Jb, np.uint64).reshape(-1), float(beta), int(iters), int(step), seed, it0, replica, ch, Es, stats)
+    if n < 0:
+        raise RuntimeError("bkl_mc_skb: DynamicSampler lost precision")
+    return Es[:n], ch, int(stats[0]), int(stats[2])
+
+
+def wtm_mc_skb(Jb, beta, samples, step, seed, chunks, call=0, replica=0):
+    """wtmMC on the binary GraphSK; returns (Es, chunks, num_moves, t)."""
+    L = lib()
+    L.orc_wtm_mc_skb.restype = C.c_int64
+    L.orc_wtm_mc_skb.argtypes = [C.c_int64, u64p, C.c_double, C.c_int64, C.c_double, C.c_uint64, C.c_uint32, C.c_uint32, u64p, f64p, i64p,
+                                 C.POINTER(C.c_double)]
+    N = Jb.shape[0]
+    ch = np.array(chunks, np.uint64, copy=True)
+    Es = np.zeros(max(samples, 1))
+    stats = np.zeros(2, np.int64)
+    t = C.c_double(0)
+    n = L.orc_wtm_mc_skb(N, np.ascontiguousarray(Jb, np.uint64).reshape(-1), float(beta), int(samples), float(step), seed, call, replica,
+                         ch, Es, stats, C.byref(t))
+    if n < 0:
+        raise RuntimeError("wtm_mc_skb: tracked energy != energy(X, C)")
+    return Es[:n], ch, int(stats[0]), t.value

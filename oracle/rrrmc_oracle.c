@@ -1477,6 +1477,14 @@ static int64_t dyns_getel(dyns_t *d, double x)
 
 static inline double prior_of(double x) { return x > 0 ? orc_det_exp(-x) : 1.0; }      /* prior: DeltaE.jl:297 */
 
+/* GraphSKNormal or the binary GraphSK behind the continuous-energy samplers: both are SimpleGraph{Float64} (SK.jl:28,181), the
+ * samplers see delta_energy(X, C, i) (= +lfields[i], SK.jl:278-284, or lfields[i] / sN with integer fields, SK.jl:137-140),
+ * spinflip! and energy only. */
+typedef struct { skn_t *n; skb_t *b; } skx_t;
+static inline double skx_dE(const skx_t *X, int64_t i) { return X->b ? (double)X->b->lfields[i] / X->b->sN : X->n->lfields[i]; }
+static inline void skx_update(skx_t *X, const uint64_t *s, int64_t m) { if (X->b) skb_update_cache(X->b, s, m); else skn_update_cache(X->n, s, m); }
+static inline double skx_energy(skx_t *X, const uint64_t *s) { return X->b ? skb_energy(X->b, s) : skn_energy(X->n, s); }
+
 /* RRR stream for rrrMC(SingleGraph): sub 0 words 0,1 -> rand() of rand_move (getel); sub 1 words 0,1 -> rand() < c */
 
 /*
@@ -1484,19 +1492,16 @@ static inline double prior_of(double x) { return x > 0 ? orc_det_exp(-x) : 1.0; 
  * with X = GraphSKNormal and gen_ΔEcache = DeltaECacheCont (DeltaE.jl:299-316).  One chain.
  * Returns the number of samples, or -1 on the sampler's precision-loss error.
  */
-ORC_API int64_t orc_rrr_mc_skn(int64_t N, const double *J, double beta, int64_t iters, int64_t step,
+static int64_t orc_rrr_mc_skn_impl(skx_t *X, int64_t N, double beta, int64_t iters, int64_t step,
                                double staged_thr, double staged_thr_fact, uint64_t seed, uint64_t it0, uint32_t replica,
                                uint64_t *chunks, double *Es, int64_t *stats, double *dE_out, double *z_out)
 {
-    skn_t X = {N, J, NULL, NULL, -1};
-    X.lfields = (double *)malloc((size_t)N * 8);
-    X.lfields_last = (double *)malloc((size_t)N * 8);
-    double E = skn_energy(&X, chunks);                                        /* :177 */
+    double E = skx_energy(X, chunks);                                        /* :177 */
     /* DeltaECacheCont: DeltaE.jl:304-313 */
     double *dEs = (double *)malloc((size_t)N * 8);
     dyns_t ds;
     dyns_init(&ds, N);
-    for (int64_t i = 0; i < N; ++i) { dEs[i] = X.lfields[i]; ds.v[i] = prior_of(beta * dEs[i]); }
+    for (int64_t i = 0; i < N; ++i) { dEs[i] = skx_dE(X, i); ds.v[i] = prior_of(beta * dEs[i]); }
     dyns_refresh(&ds);
     double *st_dE = (double *)malloc((size_t)N * 8), *st_p = (double *)malloc((size_t)N * 8);
     int64_t *st_j = (int64_t *)malloc((size_t)N * 8);
@@ -1517,14 +1522,14 @@ ORC_API int64_t orc_rrr_mc_skn(int64_t N, const double *J, double beta, int64_t 
             if (move < 0) { bad = 1; break; }
             double dE = dEs[move];
             /* compute_staged!: DeltaE.jl:357-374 */
-            bitflip(chunks, move); skn_update_cache(&X, chunks, move);
+            bitflip(chunks, move); skx_update(X, chunks, move);
             int64_t ns = 0;
-            st_j[ns] = move; st_dE[ns] = X.lfields[move]; st_p[ns] = prior_of(beta * st_dE[ns]); ns++;
+            st_j[ns] = move; st_dE[ns] = skx_dE(X, move); st_p[ns] = prior_of(beta * st_dE[ns]); ns++;
             for (int64_t j = 0; j < N; ++j) {                                 /* AllButOne(N, move): Common.jl:78-92 */
                 if (j == move) continue;
-                st_j[ns] = j; st_dE[ns] = X.lfields[j]; st_p[ns] = prior_of(beta * st_dE[ns]); ns++;
+                st_j[ns] = j; st_dE[ns] = skx_dE(X, j); st_p[ns] = prior_of(beta * st_dE[ns]); ns++;
             }
-            bitflip(chunks, move); skn_update_cache(&X, chunks, move);
+            bitflip(chunks, move); skx_update(X, chunks, move);
             /* compute_reverse_probabilities!: DeltaE.jl:345-355 */
             double zp = ds.z;
             for (int64_t q = 0; q < ns; ++q) zp += st_p[q] - ds.v[st_j[q]];
@@ -1533,7 +1538,7 @@ ORC_API int64_t orc_rrr_mc_skn(int64_t N, const double *J, double beta, int64_t 
             double c = z / zp;
             rrr_draw(seed, g, replica, 1, w);
             if (u53_of(w[0], w[1]) < c) {                                     /* :192-198 */
-                bitflip(chunks, move); skn_update_cache(&X, chunks, move);
+                bitflip(chunks, move); skx_update(X, chunks, move);
                 for (int64_t q = 0; q < ns; ++q) { dEs[st_j[q]] = st_dE[q]; dyns_set(&ds, st_j[q], st_p[q]); }     /* apply_staged! */
                 E += dE;
                 accepted += 1;
@@ -1545,13 +1550,13 @@ ORC_API int64_t orc_rrr_mc_skn(int64_t N, const double *J, double beta, int64_t 
             double dE = dEs[move];
             double c = 0.0;
             for (int pass = 0; pass < 2; ++pass) {                            /* apply_move!: DeltaE.jl:379-410 */
-                bitflip(chunks, move); skn_update_cache(&X, chunks, move);
+                bitflip(chunks, move); skx_update(X, chunks, move);
                 double z = ds.z;
-                dEs[move] = X.lfields[move];
+                dEs[move] = skx_dE(X, move);
                 dyns_set(&ds, move, prior_of(beta * dEs[move]));
                 for (int64_t j = 0; j < N; ++j) {
                     if (j == move) continue;
-                    dEs[j] = X.lfields[j];
+                    dEs[j] = skx_dE(X, j);
                     dyns_set(&ds, j, prior_of(beta * dEs[j]));
                 }
                 double cc = z / ds.z;
@@ -1568,8 +1573,32 @@ ORC_API int64_t orc_rrr_mc_skn(int64_t N, const double *J, double beta, int64_t 
     if (z_out) *z_out = ds.z;
     free(dEs); free(st_dE); free(st_p); free(st_j);
     dyns_free(&ds);
-    free(X.lfields); free(X.lfields_last);
     return bad ? -1 : nsamp;
+}
+ORC_API int64_t orc_rrr_mc_skn(int64_t N, const double *J, double beta, int64_t iters, int64_t step,
+                               double staged_thr, double staged_thr_fact, uint64_t seed, uint64_t it0, uint32_t replica,
+                               uint64_t *chunks, double *Es, int64_t *stats, double *dE_out, double *z_out)
+{
+    skn_t Xn = {N, J, NULL, NULL, -1};
+    Xn.lfields = (double *)malloc((size_t)N * 8);
+    Xn.lfields_last = (double *)malloc((size_t)N * 8);
+    skx_t X = {&Xn, NULL};
+    int64_t r = orc_rrr_mc_skn_impl(&X, N, beta, iters, step, staged_thr, staged_thr_fact, seed, it0, replica, chunks, Es, stats, dE_out, z_out);
+    free(Xn.lfields); free(Xn.lfields_last);
+    return r;
+}
+/* the same sampler on the binary GraphSK (J = bit rows, SK.jl:32) */
+ORC_API int64_t orc_rrr_mc_skb(int64_t N, const uint64_t *Jb, double beta, int64_t iters, int64_t step,
+                               double staged_thr, double staged_thr_fact, uint64_t seed, uint64_t it0, uint32_t replica,
+                               uint64_t *chunks, double *Es, int64_t *stats, double *dE_out, double *z_out)
+{
+    skb_t Xb = {N, (N + 63) / 64, sqrt((double)N), Jb, NULL, NULL, -1};
+    Xb.lfields = (int64_t *)malloc((size_t)N * 8);
+    Xb.lfields_last = (int64_t *)malloc((size_t)N * 8);
+    skx_t X = {NULL, &Xb};
+    int64_t r = orc_rrr_mc_skn_impl(&X, N, beta, iters, step, staged_thr, staged_thr_fact, seed, it0, replica, chunks, Es, stats, dE_out, z_out);
+    free(Xb.lfields); free(Xb.lfields_last);
+    return r;
 }
 
 /* DynamicSampler unit access for the tests: build from v, apply updates (i, x), sample with the given uniforms */
@@ -2518,17 +2547,14 @@ ORC_API int64_t orc_extremal_opt_cont(int form, int64_t N, int64_t K, const int3
 /* wtmMC (src/RRRMC.jl:376-426, src/WaitingTimes.jl) on GraphSKNormal: as orc_wtm_mc_sparse with delta_energy = +lfields[i]
  * (SK.jl:278-284) and neighbors(X, i) = AllButOne (every other spin, in index order: SK.jl:297).  WTM stream: spin i's initial
  * time is draw i, then one draw per updated spin in the order of update_heap! (the moved spin, then j = 0..N-1 except it). */
-ORC_API int64_t orc_wtm_mc_skn(int64_t N, const double *J, double beta, int64_t samples, double step, uint64_t seed, uint32_t call,
+static int64_t orc_wtm_mc_skn_impl(skx_t *X, int64_t N, double beta, int64_t samples, double step, uint64_t seed, uint32_t call,
                                uint32_t replica, uint64_t *chunks, double *Es, int64_t *stats, double *t_out)
 {
-    skn_t X = {N, J, NULL, NULL, -1};
-    X.lfields = (double *)malloc((size_t)N * 8);
-    X.lfields_last = (double *)malloc((size_t)N * 8);
-    double E = skn_energy(&X, chunks);
+    double E = skx_energy(X, chunks);
     double *tm = (double *)malloc((size_t)N * sizeof(double));
     uint64_t nd = 0;
     for (int64_t i = 0; i < N; ++i) {
-        double e = orc_det_exp(beta * X.lfields[i]);
+        double e = orc_det_exp(beta * skx_dE(X, i));
         tm[i] = wtm_gen(e > 1.0 ? e : 1.0, wtm_uniform(seed, nd++, replica, call));
     }
     step /= (double)N;
@@ -2547,13 +2573,13 @@ ORC_API int64_t orc_wtm_mc_skn(int64_t N, const double *J, double beta, int64_t 
         }
         if (out) break;
         t = tp;
-        const double dE = X.lfields[move];
+        const double dE = skx_dE(X, move);
         bitflip(chunks, move);
-        skn_update_cache(&X, chunks, move);
+        skx_update(X, chunks, move);
         for (int64_t q = -1; q < N; ++q) {                                       /* the moved spin first, then every other spin */
             const int64_t j = q < 0 ? move : q;
             if (q == move) continue;
-            double e = orc_det_exp(beta * X.lfields[j]);
+            double e = orc_det_exp(beta * skx_dE(X, j));
             tm[j] = t + wtm_gen(e > 1.0 ? e : 1.0, wtm_uniform(seed, nd++, replica, call));
         }
         E += dE;
@@ -2561,26 +2587,46 @@ ORC_API int64_t orc_wtm_mc_skn(int64_t N, const double *J, double beta, int64_t 
     }
     if (stats) { stats[0] = num_moves; stats[1] = nsamp; }
     if (t_out) *t_out = t;
-    const double Echeck = skn_energy(&X, chunks);
+    const double Echeck = skx_energy(X, chunks);
     int ok = fabs(Echeck - E) < 1e-9 * (1.0 + fabs(E));
-    free(tm); free(X.lfields); free(X.lfields_last);
+    free(tm);
     return ok ? nsamp : -1;
+}
+ORC_API int64_t orc_wtm_mc_skn(int64_t N, const double *J, double beta, int64_t samples, double step, uint64_t seed, uint32_t call,
+                               uint32_t replica, uint64_t *chunks, double *Es, int64_t *stats, double *t_out)
+{
+    skn_t Xn = {N, J, NULL, NULL, -1};
+    Xn.lfields = (double *)malloc((size_t)N * 8);
+    Xn.lfields_last = (double *)malloc((size_t)N * 8);
+    skx_t X = {&Xn, NULL};
+    int64_t r = orc_wtm_mc_skn_impl(&X, N, beta, samples, step, seed, call, replica, chunks, Es, stats, t_out);
+    free(Xn.lfields); free(Xn.lfields_last);
+    return r;
+}
+/* the same sampler on the binary GraphSK (J = bit rows, SK.jl:32) */
+ORC_API int64_t orc_wtm_mc_skb(int64_t N, const uint64_t *Jb, double beta, int64_t samples, double step, uint64_t seed, uint32_t call,
+                               uint32_t replica, uint64_t *chunks, double *Es, int64_t *stats, double *t_out)
+{
+    skb_t Xb = {N, (N + 63) / 64, sqrt((double)N), Jb, NULL, NULL, -1};
+    Xb.lfields = (int64_t *)malloc((size_t)N * 8);
+    Xb.lfields_last = (int64_t *)malloc((size_t)N * 8);
+    skx_t X = {NULL, &Xb};
+    int64_t r = orc_wtm_mc_skn_impl(&X, N, beta, samples, step, seed, call, replica, chunks, Es, stats, t_out);
+    free(Xb.lfields); free(Xb.lfields_last);
+    return r;
 }
 
 /* bklMC (src/RRRMC.jl:311-359) on GraphSKNormal with DeltaECacheCont: rand_skip (DeltaE.jl:319-325),
  * rand_move, apply_step_bkl! = apply_move!(X, C, move, cache, Val{false}) (RRRMC.jl:294-295) over all N - 1 neighbours.
  * RRR stream sub 2 (skip), sub 0 (getel); g counts moves.  stats = [moves, moves, iterations done]. */
-ORC_API int64_t orc_bkl_mc_skn(int64_t N, const double *J, double beta, int64_t iters, int64_t step,
+static int64_t orc_bkl_mc_skn_impl(skx_t *X, int64_t N, double beta, int64_t iters, int64_t step,
                                uint64_t seed, uint64_t it0, uint32_t replica, uint64_t *chunks, double *Es, int64_t *stats)
 {
-    skn_t X = {N, J, NULL, NULL, -1};
-    X.lfields = (double *)malloc((size_t)N * 8);
-    X.lfields_last = (double *)malloc((size_t)N * 8);
-    double E = skn_energy(&X, chunks);
+    double E = skx_energy(X, chunks);
     double *dEs = (double *)malloc((size_t)N * 8);
     dyns_t ds;
     dyns_init(&ds, N);
-    for (int64_t i = 0; i < N; ++i) { dEs[i] = X.lfields[i]; ds.v[i] = prior_of(beta * dEs[i]); }
+    for (int64_t i = 0; i < N; ++i) { dEs[i] = skx_dE(X, i); ds.v[i] = prior_of(beta * dEs[i]); }
     dyns_refresh(&ds);
     int64_t it = 0, nextstep = step, m = 0, accepted = 0, nsamp = 0, bad = 0;
     while (it < iters) {
@@ -2604,12 +2650,12 @@ ORC_API int64_t orc_bkl_mc_skn(int64_t N, const double *J, double beta, int64_t 
             if (nextstep > iters) { out = 1; break; }
         }
         if (out) break;
-        bitflip(chunks, move); skn_update_cache(&X, chunks, move);           /* apply_move!: DeltaE.jl:376-410 */
-        dEs[move] = X.lfields[move];
+        bitflip(chunks, move); skx_update(X, chunks, move);           /* apply_move!: DeltaE.jl:376-410 */
+        dEs[move] = skx_dE(X, move);
         dyns_set(&ds, move, prior_of(beta * dEs[move]));
         for (int64_t j = 0; j < N; ++j) {
             if (j == move) continue;
-            dEs[j] = X.lfields[j];
+            dEs[j] = skx_dE(X, j);
             dyns_set(&ds, j, prior_of(beta * dEs[j]));
         }
         it += skip + 1;
@@ -2618,6 +2664,28 @@ ORC_API int64_t orc_bkl_mc_skn(int64_t N, const double *J, double beta, int64_t 
     }
     if (stats) { stats[0] = accepted; stats[1] = accepted; stats[2] = it; }
     free(dEs); dyns_free(&ds);
-    free(X.lfields); free(X.lfields_last);
     return bad ? -1 : nsamp;
+}
+ORC_API int64_t orc_bkl_mc_skn(int64_t N, const double *J, double beta, int64_t iters, int64_t step,
+                               uint64_t seed, uint64_t it0, uint32_t replica, uint64_t *chunks, double *Es, int64_t *stats)
+{
+    skn_t Xn = {N, J, NULL, NULL, -1};
+    Xn.lfields = (double *)malloc((size_t)N * 8);
+    Xn.lfields_last = (double *)malloc((size_t)N * 8);
+    skx_t X = {&Xn, NULL};
+    int64_t r = orc_bkl_mc_skn_impl(&X, N, beta, iters, step, seed, it0, replica, chunks, Es, stats);
+    free(Xn.lfields); free(Xn.lfields_last);
+    return r;
+}
+/* the same sampler on the binary GraphSK (J = bit rows, SK.jl:32) */
+ORC_API int64_t orc_bkl_mc_skb(int64_t N, const uint64_t *Jb, double beta, int64_t iters, int64_t step,
+                               uint64_t seed, uint64_t it0, uint32_t replica, uint64_t *chunks, double *Es, int64_t *stats)
+{
+    skb_t Xb = {N, (N + 63) / 64, sqrt((double)N), Jb, NULL, NULL, -1};
+    Xb.lfields = (int64_t *)malloc((size_t)N * 8);
+    Xb.lfields_last = (int64_t *)malloc((size_t)N * 8);
+    skx_t X = {NULL, &Xb};
+    int64_t r = orc_bkl_mc_skn_impl(&X, N, beta, iters, step, seed, it0, replica, chunks, Es, stats);
+    free(Xb.lfields); free(Xb.lfields_last);
+    return r;
 }

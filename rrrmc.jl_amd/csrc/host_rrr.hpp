@@ -89,9 +89,19 @@ int32_t sk_rrr_mc_async(rrrmc_ctx* ctx, double beta, int64_t iters, int64_t step
         ctx->ev_sweep.push_back(e);
     }
     hipStream_t st = ctx->stream;
+    // The binary GraphSK is a SimpleGraph{Float64} too (SK.jl:28): the same continuous-energy caches, over delta_energy = lfields[i] / sN
+    // with integer fields — i.e. this kernel on the +-1 matrix (every field and the energy's n stay exact integers in Float64) with
+    // the division by sN = sqrt(N) applied where the reference applies it (SK.jl:95,139).
+    const bool bin = ctx->model == RRRMC_MODEL_SK_BINARY;
+    if (bin) {
+        if (!ctx->sk_J) HIP_TRY(ctx, hipMalloc(&ctx->sk_J, sizeof(double) * N * N));
+        hipLaunchKernelGGL(skb_dense_kernel, dim3((unsigned)((N + 255) / 256), (unsigned)N), dim3(256), 0, st, ctx->skb_J, ctx->sk_J, (int)N, (int)ctx->skb_NW);
+        HIP_TRY(ctx, hipGetLastError());
+    }
     RrrSkParams P{};
     double* b = ctx->rs_buf;
     P.J = ctx->sk_J;
+    P.sN = bin ? std::sqrt((double)N) : 0.0;
     P.lfA = b; b += per * N;
     P.lfB = b; b += per * N;
     P.v = b; b += per * N2;

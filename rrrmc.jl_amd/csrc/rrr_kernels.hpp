@@ -534,6 +534,7 @@ struct RrrSkParams {
     uint32_t call;           // wtmMC: number of the call (WTM stream)
     double stepf;            // wtmMC: step in sweeps
     double* t_out;           // wtmMC: [Rp] final global time
+    double sN;               // binary GraphSK (SK.jl:28-165) run as +-1 couplings: delta_energy = lfields[i] / sN, E = n / sN (sN = sqrt(N)); 0 = GraphSKNormal
 };
 
 struct SkChain {             // one replica's view
@@ -544,6 +545,8 @@ struct SkChain {             // one replica's view
     double z;
     long long trefresh;
     __device__ __forceinline__ double* lf() const { return (cur ? P->lfB : P->lfA) + r; }
+    // delta_energy(X, C, i) from the cached field: +lfields[i] for GraphSKNormal (SK.jl:278-284), lfields[i] / sN for the binary GraphSK (:137-140)
+    __device__ __forceinline__ double dEv(double lfv) const { return P->sN > 0.0 ? lfv / P->sN : lfv; }
     __device__ __forceinline__ double* lfl() const { return (cur ? P->lfA : P->lfB) + r; }
     __device__ __forceinline__ int sbit(int x) const { return (int)((P->spins[(size_t)(x >> 5) * P->Rp + r] >> (x & 31)) & 1u); }
     __device__ __forceinline__ void sflip(int x) { P->spins[(size_t)(x >> 5) * P->Rp + r] ^= 1u << (x & 31); }
@@ -653,9 +656,10 @@ __global__ __launch_bounds__(kRrrThreads) void rrr_skn_kernel(RrrSkParams P)
         n -= lfh;
     }
     double E = n / 2;
+    if (P.sN > 0.0) E = E / P.sN;               // GraphSK: the integer n of SK.jl:62-95 (exact in Float64), then n / sN
     for (int i = 0; i < P.N2; ++i) P.v[(size_t)i * Rp + r] = 0.0;
     for (int i = 0; i < N; ++i) {
-        const double dE = P.lfA[(size_t)i * Rp + r];
+        const double dE = c.dEv(P.lfA[(size_t)i * Rp + r]);
         P.dEs[(size_t)i * Rp + r] = dE;
         P.v[(size_t)i * Rp + r] = prior_of(P.beta * dE);
     }
@@ -717,7 +721,7 @@ __global__ __launch_bounds__(kRrrThreads) void rrr_skn_kernel(RrrSkParams P)
             if (t < old) sift_up(pos); else sift_down(pos);
         };
         for (int i = 0; i < N; ++i) {                 // THeap(X, C, beta): one waiting time per spin, in index order
-            ht[(size_t)i * Rp] = gen_wt(P.lfA[(size_t)i * Rp + r]);
+            ht[(size_t)i * Rp] = gen_wt(c.dEv(P.lfA[(size_t)i * Rp + r]));
             hid[(size_t)i * Rp] = (uint16_t)i; hpos[(size_t)i * Rp] = (uint16_t)i;
         }
         for (int pos = N / 2 - 1; pos >= 0; --pos) sift_down(pos);
@@ -734,13 +738,13 @@ __global__ __launch_bounds__(kRrrThreads) void rrr_skn_kernel(RrrSkParams P)
             }
             if (out) break;
             t = tp;
-            const double dE = c.lf()[(size_t)move * Rp];
+            const double dE = c.dEv(c.lf()[(size_t)move * Rp]);
             c.flip(move);                             // update_heap!: WaitingTimes.jl:40-52
             const double* a = c.lf();
-            update(move, t + gen_wt(a[(size_t)move * Rp]));          // = -dE
+            update(move, t + gen_wt(c.dEv(a[(size_t)move * Rp])));          // = -dE
             for (int j = 0; j < N; ++j) {
                 if (j == move) continue;
-                update(j, t + gen_wt(a[(size_t)j * Rp]));
+                update(j, t + gen_wt(c.dEv(a[(size_t)j * Rp])));
             }
             E += dE;
             accepted += 1;
@@ -776,13 +780,13 @@ __global__ __launch_bounds__(kRrrThreads) void rrr_skn_kernel(RrrSkParams P)
             c.flip(move);
             const double* a = c.lf();
             {
-                const double d = a[(size_t)move * Rp];
+                const double d = c.dEv(a[(size_t)move * Rp]);
                 P.dEs[(size_t)move * Rp + r] = d;
                 c.set(move, prior_of(P.beta * d));
             }
             for (int j = 0; j < N; ++j) {
                 if (j == move) continue;
-                const double d = a[(size_t)j * Rp];
+                const double d = c.dEv(a[(size_t)j * Rp]);
                 P.dEs[(size_t)j * Rp + r] = d;
                 c.set(j, prior_of(P.beta * d));
             }
@@ -812,7 +816,7 @@ __global__ __launch_bounds__(kRrrThreads) void rrr_skn_kernel(RrrSkParams P)
             {
                 const double* a = c.lf();
                 for (int j = 0; j < N; ++j) {
-                    const double d = a[(size_t)j * Rp];
+                    const double d = c.dEv(a[(size_t)j * Rp]);
                     P.st_dE[(size_t)j * Rp + r] = d;
                     P.st_p[(size_t)j * Rp + r] = prior_of(P.beta * d);
                 }
@@ -850,13 +854,13 @@ __global__ __launch_bounds__(kRrrThreads) void rrr_skn_kernel(RrrSkParams P)
                 const double z = c.z;
                 const double* a = c.lf();
                 {
-                    const double d = a[(size_t)move * Rp];
+                    const double d = c.dEv(a[(size_t)move * Rp]);
                     P.dEs[(size_t)move * Rp + r] = d;
                     c.set(move, prior_of(P.beta * d));
                 }
                 for (int j = 0; j < N; ++j) {
                     if (j == move) continue;
-                    const double d = a[(size_t)j * Rp];
+                    const double d = c.dEv(a[(size_t)j * Rp]);
                     P.dEs[(size_t)j * Rp + r] = d;
                     c.set(j, prior_of(P.beta * d));
                 }
@@ -875,6 +879,15 @@ __global__ __launch_bounds__(kRrrThreads) void rrr_skn_kernel(RrrSkParams P)
 }
 
 // layout changes between the SK sweep kernel's spins ([G8][N] bytes, bit = replica & 7) and this kernel's ([W][Rp] words)
+// binary GraphSK couplings (bit rows, SK.jl:32) as the +-1 matrix the kernel above works on: Jt[i][j] = 2 J_ij - 1, zero diagonal
+__global__ __launch_bounds__(256) void skb_dense_kernel(const uint32_t* __restrict__ Jbits, double* __restrict__ Jt, int N, int NW)
+{
+    const int j = blockIdx.x * 256 + threadIdx.x, i = blockIdx.y;
+    if (j >= N) return;
+    const int b = (int)((Jbits[(size_t)i * NW + (j >> 5)] >> (j & 31)) & 1u);
+    Jt[(size_t)i * N + j] = i == j ? 0.0 : (b ? 1.0 : -1.0);
+}
+
 __global__ __launch_bounds__(256) void rrsk_spins_in_kernel(const uint8_t* __restrict__ sk_spins, uint32_t* __restrict__ spins, int N, int /*W*/, int Rp)
 {
     const int r = blockIdx.x * 256 + threadIdx.x, w = blockIdx.y;

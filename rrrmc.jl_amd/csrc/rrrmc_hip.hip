@@ -1353,7 +1353,7 @@ int32_t rrrmc_rrr_mc_async(rrrmc_ctx* ctx, double beta, double fourK, int64_t it
     int32_t rc = ensure_state(ctx, true);
     if (rc) return rc;
     if (!std::isfinite(beta)) return fail(ctx, RRRMC_ERR_INVALID_ARG, "beta must be finite, given: %g", beta);       // RRRMC.jl:230, :166
-    if (ctx->model == RRRMC_MODEL_SK_NORMAL) return sk_rrr_mc_async(ctx, beta, iters, step, staged_thr, staged_thr_fact);
+    if (ctx->model == RRRMC_MODEL_SK_NORMAL || ctx->model == RRRMC_MODEL_SK_BINARY) return sk_rrr_mc_async(ctx, beta, iters, step, staged_thr, staged_thr_fact);
     if (sparse_int_model(ctx)) return sparse_rrr_bkl_async(ctx, 0, beta, iters, step, staged_thr, staged_thr_fact);
     if (ctx->model == RRRMC_MODEL_SPARSE_DISCRETIZED) return dbl_rrr_mc_async(ctx, beta, iters, step, staged_thr, staged_thr_fact);
     if (ctx->model == RRRMC_MODEL_SPARSE_F64) return spf_cont_async(ctx, 0, beta, iters, step, 1.0, staged_thr, staged_thr_fact);
@@ -1367,8 +1367,8 @@ int32_t rrrmc_bkl_mc_async(rrrmc_ctx* ctx, double beta, int64_t iters, int64_t s
     if (rc) return rc;
     if (!std::isfinite(beta)) return fail(ctx, RRRMC_ERR_INVALID_ARG, "beta must be finite, given: %g", beta);
     if (ctx->model == RRRMC_MODEL_SPARSE_F64 || ctx->model == RRRMC_MODEL_SPARSE_DISCRETIZED) return spf_cont_async(ctx, 1, beta, iters, step, 1.0, 0.0, 5.0);
-    if (ctx->model == RRRMC_MODEL_SK_NORMAL) return sk_rrr_mc_async(ctx, beta, iters, step, 0.0, 5.0, 1);
-    if (!sparse_int_model(ctx)) return fail(ctx, RRRMC_ERR_UNSUPPORTED, "bklMC is wired for RRRMC_MODEL_SPARSE_PM1, RRRMC_MODEL_SPARSE_LEVELS, RRRMC_MODEL_SPARSE_F64 and RRRMC_MODEL_SK_NORMAL");
+    if (ctx->model == RRRMC_MODEL_SK_NORMAL || ctx->model == RRRMC_MODEL_SK_BINARY) return sk_rrr_mc_async(ctx, beta, iters, step, 0.0, 5.0, 1);
+    if (!sparse_int_model(ctx)) return fail(ctx, RRRMC_ERR_UNSUPPORTED, "bklMC is wired for the sparse models, RRRMC_MODEL_SK_NORMAL and RRRMC_MODEL_SK_BINARY");
     return sparse_rrr_bkl_async(ctx, 1, beta, iters, step, 0.0, 5.0);
 }
 
@@ -1387,8 +1387,8 @@ int32_t rrrmc_wtm_mc_async(rrrmc_ctx* ctx, double beta, int64_t samples, double 
     int32_t rc = ensure_state(ctx, true);
     if (rc) return rc;
     if (ctx->model == RRRMC_MODEL_SPARSE_F64 || ctx->model == RRRMC_MODEL_SPARSE_DISCRETIZED) return spf_cont_async(ctx, 2, beta, samples, 1, step, 0.0, 5.0);
-    if (ctx->model == RRRMC_MODEL_SK_NORMAL) return sk_rrr_mc_async(ctx, beta, samples, 1, 0.0, 5.0, 2, step);
-    if (!sparse_int_model(ctx)) return fail(ctx, RRRMC_ERR_UNSUPPORTED, "wtmMC is wired for the sparse models and RRRMC_MODEL_SK_NORMAL");
+    if (ctx->model == RRRMC_MODEL_SK_NORMAL || ctx->model == RRRMC_MODEL_SK_BINARY) return sk_rrr_mc_async(ctx, beta, samples, 1, 0.0, 5.0, 2, step);
+    if (!sparse_int_model(ctx)) return fail(ctx, RRRMC_ERR_UNSUPPORTED, "wtmMC is wired for the sparse models, RRRMC_MODEL_SK_NORMAL and RRRMC_MODEL_SK_BINARY");
     return sparse_wtm_async(ctx, beta, samples, step);
 }
 

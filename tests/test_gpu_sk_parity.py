@@ -148,3 +148,38 @@ def test_sk_randomized_shapes(pkg, oracle, N, R, beta, iters, step, binary):
         assert (Es[r] == ref[0]).all() and (C1.s[r] == ref[1]).all() and acc[r] == ref[2]
         ref2 = run(X.J, beta, iters // 2 + 1, step, seed, ref[1], it0=iters, replica=r)
         assert (Es2[r] == ref2[0]).all() and acc2[r] == ref2[2]
+
+
+@pytest.mark.parametrize("N,R,beta,iters,step,thr", [
+    (10, 40, 2.0, 6000, 100, 0.8),            # test/runtests.jl:66 GraphSK(10) under rrrMC (:153), default staged_thr of a SimpleGraph
+    (10, 8, 2.0, 3000, 50, 0.0),              # always direct
+    (10, 8, 2.0, 3000, 50, 1.0),              # always staged
+    (100, 70, 1.0, 3000, 100, 0.8),
+    (333, 9, 1.5, 1500, 100, 0.8),
+])
+def test_binary_sk_rrr_bkl_wtm_bit_exact(pkg, oracle, N, R, beta, iters, step, thr):
+    """The binary GraphSK is a SimpleGraph{Float64} (SK.jl:28): rrrMC / bklMC / wtmMC run DeltaECacheCont / THeap over
+    delta_energy = lfields[i] / sqrt(N) with integer fields (SK.jl:137-140)."""
+    seed = 636000 + N
+    X = pkg.GraphSK(N, seed=seed)
+    with pkg.Engine(X, R) as eng:
+        eng.seed(seed)
+        eng.init_spins_random()
+        C0 = eng.get_config()
+        Es, acc, staged = eng.rrr_mc(beta, iters, step, staged_thr=thr)
+        C1 = eng.get_config()
+        E1 = eng.energy()
+        Eb, mb = eng.bkl_mc(beta, iters * 4, step * 4)
+        C2 = eng.get_config()
+        Ew, mw, tw = eng.wtm_mc(beta, 30, step=1.5)
+        C3 = eng.get_config()
+        Es4, acc4 = eng.standard_mc(beta, 2000, 100)              # the integer-field Metropolis kernel still works afterwards
+    for r in range(R if N <= 100 else 3):
+        ref = oracle.rrr_mc_skb(X.J, beta, iters, step, seed, C0.s[r], replica=r, staged_thr=thr)
+        assert np.allclose(Es[r], ref[0], rtol=1e-6, atol=1e-9)
+        assert (Es[r] == ref[0]).all() and (C1.s[r] == ref[1]).all() and acc[r] == ref[2] and staged[r] == ref[3]
+        assert E1[r] == oracle.skb_energy(X.J, ref[1])
+        rb = oracle.bkl_mc_skb(X.J, beta, iters * 4, step * 4, seed, ref[1], it0=iters, replica=r)
+        assert (Eb[r] == rb[0]).all() and (C2.s[r] == rb[1]).all() and mb[r] == rb[2]
+        rw = oracle.wtm_mc_skb(X.J, beta, 30, 1.5, seed, rb[1], replica=r)
+        assert (Ew[r] == rw[0]).all() and (C3.s[r] == rw[1]).all() and mw[r] == rw[2] and tw[r] == rw[3]

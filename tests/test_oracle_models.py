@@ -516,3 +516,26 @@ def test_quant_sk_slices_tracked_energy_and_parts(oracle):
             assert abs(Er[k - 1] - oracle.quant_sk_energy(Jb, Nk, M, fourK, ck)[0]) < 1e-11
     Q, tm, ovs, e0, Esl, raw = oracle.quant_sk_observables(Jb, Nk, M, fourK, beta, Gamma, ch)
     assert abs(Q - (-Gamma * tm + sum(n / np.sqrt(Nk) / (Nk * M) for n in Esl))) < 1e-12 and len(ovs) == M // 2
+
+
+def test_binary_sk_under_the_continuous_samplers(oracle):
+    """GraphSK(10) (runtests.jl:66) under rrrMC / bklMC / wtmMC (:145-159): a SimpleGraph{Float64}, so DeltaECacheCont over
+    delta_energy = lfields[i] / sqrt(N); the tracked energy equals energy(X, C) at the samples (:12-20)."""
+    seed, N, beta = 77, 10, 2.0
+    Jb = oracle.gen_sk_binary(N, seed)
+    ch = oracle.init_config(seed, 0, N)
+    E0 = oracle.skb_energy(Jb, ch)
+    for thr in (0.8, 0.0, 1.0):
+        Es, c1, acc, st = oracle.rrr_mc_skb(Jb, beta, 3000, 1, seed, ch, staged_thr=thr)
+        assert Es[0] == E0 and 0 < acc < 3000
+        for k in (5, 900, 3000):
+            _, ck, _, _ = oracle.rrr_mc_skb(Jb, beta, k - 1, 1, seed, ch, staged_thr=thr)
+            assert abs(Es[k - 1] - oracle.skb_energy(Jb, ck)) < 1e-11
+    for n in (1, 40):
+        Es, c1, moves, itd = oracle.bkl_mc_skb(Jb, beta, n * 50, 50, seed, ch)
+        assert len(Es) == n and moves > 0
+    Es, c1, moves, t = oracle.wtm_mc_skb(Jb, beta, 50, 1.0, seed, ch)          # checks E == energy(X, C) inside
+    assert len(Es) == 50 and moves > 0 and t > 0
+    # energies of the binary model are multiples of 2 / sqrt(N) apart
+    q = (Es - Es[0]) * np.sqrt(N) / 2
+    assert np.allclose(q, np.round(q), atol=1e-9)
