@@ -33,6 +33,21 @@ def cpu_baseline(O, X, seconds_target=15.0):
     """Single-thread CPU oracle (port of the reference loop) on a bounded sample of the same workload."""
     A, J = X.A, X.J.astype(np.int32)
     iters, R = 1 << 22, 1
+    cpu_model = "unknown"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                cpu_model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    pinned, old_aff = None, None
+    try:      # one pinned core, as SURVEY.md §8d prescribes (taskset -c <first allowed core>)
+        old_aff = os.sched_getaffinity(0)
+        pinned = min(old_aff)
+        os.sched_setaffinity(0, {pinned})
+    except (AttributeError, OSError):
+        pinned = None
     ch = O.init_configs(SEED, 0, R, N_SITES)
     t0 = time.perf_counter()
     O.standard_mc_sparse_batch(A, J, BETA, iters, SAMPLE_STEP, SEED, ch)
@@ -42,8 +57,14 @@ def cpu_baseline(O, X, seconds_target=15.0):
     t0 = time.perf_counter()
     O.standard_mc_sparse_batch(A, J, BETA, iters, SAMPLE_STEP, SEED, ch)
     dt = time.perf_counter() - t0
+    if old_aff is not None and pinned is not None:
+        try:
+            os.sched_setaffinity(0, old_aff)
+        except OSError:
+            pass
     return {"value": R * iters / dt, "unit": "attempts/s", "cores": 1, "kind": "port",
-            "sample": "%d replicas x 2^22 iterations of the same graph/beta, single thread, oracle/rrrmc_oracle.c (%.1f s)" % (R, dt)}
+            "sample": "%d replicas x 2^22 iterations of the same graph/beta, single thread, oracle/rrrmc_oracle.c (%.1f s)" % (R, dt),
+            "cpu_model": cpu_model, "host_cores": os.cpu_count(), "pinned_core": pinned}
 
 
 def device_copy_bandwidth(pkg, device, nbytes=1 << 30, reps=10):
