@@ -870,3 +870,23 @@ def wtm_mc_skb(Jb, beta, samples, step, seed, chunks, call=0, replica=0):
     if n < 0:
         raise RuntimeError("wtm_mc_skb: tracked energy != energy(X, C)")
     return Es[:n], ch, int(stats[0]), t.value
+
+
+def extremal_opt_sk(J, tau, iters, step, seed, chunks, it0=0, replica=0, binary=False):
+    """extremal_opt with EOCacheCont on GraphSKNormal (J dense Float64) or the binary GraphSK (J bit rows, binary=True).
+    Returns (Es, final chunks, Emin, Cmin chunks, itmin)."""
+    L = lib()
+    fn = L.orc_extremal_opt_skb if binary else L.orc_extremal_opt_skn
+    fn.restype = C.c_int64
+    fn.argtypes = [C.c_int64, u64p if binary else f64p, f64p, C.c_int64, C.c_int64, C.c_uint64, C.c_uint64, C.c_uint32, u64p, f64p,
+                   C.POINTER(C.c_double), u64p, C.POINTER(C.c_int64)]
+    N = J.shape[0]
+    Jf = np.ascontiguousarray(J, np.uint64 if binary else np.float64).reshape(-1)
+    ch = np.array(chunks, np.uint64, copy=True)
+    Es = np.zeros(max(iters // step, 1))
+    Cmin = np.zeros_like(ch)
+    Emin, itmin = C.c_double(0), C.c_int64(0)
+    n = fn(N, Jf, eo_ftau(N, tau), int(iters), int(step), seed, it0, replica, ch, Es, C.byref(Emin), Cmin, C.byref(itmin))
+    if n < 0:
+        raise RuntimeError("extremal_opt_sk: inconsistent ranking / energy (%d)" % n)
+    return Es[:n], ch, Emin.value, Cmin, itmin.value

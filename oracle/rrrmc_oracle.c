@@ -2544,6 +2544,74 @@ ORC_API int64_t orc_extremal_opt_cont(int form, int64_t N, int64_t K, const int3
     return ok ? nsamp : -1;
 }
 
+/* extremal_opt with EOCacheCont (see orc_extremal_opt_cont) on the dense SK models: neighbors(X, i) = AllButOne (SK.jl:142,297), so
+ * every delta_energy is refreshed and the whole ranking re-sorted at every flip.  Same streams and tie rule as orc_extremal_opt_cont. */
+static int64_t extremal_opt_sk_impl(skx_t *X, int64_t N, const double *ftau, int64_t iters, int64_t step, uint64_t seed, uint64_t it0,
+                                    uint32_t replica, uint64_t *chunks, double *Es, double *Emin_out, uint64_t *Cmin, int64_t *itmin_out)
+{
+    if (N > 65535) return -2;
+    const int64_t nch = (N + 63) / 64;
+    double E = skx_energy(X, chunks), Emin = E;
+    int64_t itmin = 0, nsamp = 0;
+    memcpy(Cmin, chunks, (size_t)nch * 8);
+    double *dEs = (double *)malloc((size_t)N * 8);
+    int32_t *rank = (int32_t *)malloc((size_t)N * 4), *tmp = (int32_t *)malloc((size_t)N * 4);
+    for (int64_t i = 0; i < N; ++i) { dEs[i] = skx_dE(X, i); rank[i] = (int32_t)i; }
+    eocmp_t cmp = {dEs, seed, 0, replica, 0};
+    eo_sort(&cmp, rank, tmp, N);
+    const double z = ftau[N - 1];
+    for (int64_t it = 1; it <= iters; ++it) {
+        if (it % step == 0) Es[nsamp++] = E;
+        const uint64_t g = it0 + (uint64_t)it;
+        uint32_t w[4];
+        rrr_draw(seed, g, replica, 3, w);
+        const double r = (1 - u53_of(w[0], w[1])) * z;
+        int64_t lo = 0, hi = N;
+        while (lo < hi) { int64_t mid = (lo + hi) >> 1; if (ftau[mid] < r) lo = mid + 1; else hi = mid; }
+        int64_t i = lo + 1;
+        if (i > N) i = N;
+        const int64_t move = rank[i - 1];
+        const double dE = dEs[move];
+        bitflip(chunks, move);
+        skx_update(X, chunks, move);
+        for (int64_t j = 0; j < N; ++j) dEs[j] = skx_dE(X, j);
+        cmp.g = g; cmp.fresh = 1;
+        eo_sort(&cmp, rank, tmp, N);
+        E += dE;
+        if (E < Emin) { Emin = E; memcpy(Cmin, chunks, (size_t)nch * 8); itmin = it; }
+    }
+    int ok = 1;
+    for (int64_t i = 1; i < N && ok; ++i) ok = dEs[rank[i - 1]] <= dEs[rank[i]];
+    const double Ex = skx_energy(X, chunks);
+    if (fabs(Ex - E) > 1e-9 * (fabs(Ex) > 1.0 ? fabs(Ex) : 1.0)) ok = 0;
+    if (Emin_out) *Emin_out = Emin;
+    if (itmin_out) *itmin_out = itmin;
+    free(dEs); free(rank); free(tmp);
+    return ok ? nsamp : -1;
+}
+ORC_API int64_t orc_extremal_opt_skn(int64_t N, const double *J, const double *ftau, int64_t iters, int64_t step, uint64_t seed, uint64_t it0,
+                                     uint32_t replica, uint64_t *chunks, double *Es, double *Emin_out, uint64_t *Cmin, int64_t *itmin_out)
+{
+    skn_t Xn = {N, J, NULL, NULL, -1};
+    Xn.lfields = (double *)malloc((size_t)N * 8);
+    Xn.lfields_last = (double *)malloc((size_t)N * 8);
+    skx_t X = {&Xn, NULL};
+    int64_t r = extremal_opt_sk_impl(&X, N, ftau, iters, step, seed, it0, replica, chunks, Es, Emin_out, Cmin, itmin_out);
+    free(Xn.lfields); free(Xn.lfields_last);
+    return r;
+}
+ORC_API int64_t orc_extremal_opt_skb(int64_t N, const uint64_t *Jb, const double *ftau, int64_t iters, int64_t step, uint64_t seed, uint64_t it0,
+                                     uint32_t replica, uint64_t *chunks, double *Es, double *Emin_out, uint64_t *Cmin, int64_t *itmin_out)
+{
+    skb_t Xb = {N, (N + 63) / 64, sqrt((double)N), Jb, NULL, NULL, -1};
+    Xb.lfields = (int64_t *)malloc((size_t)N * 8);
+    Xb.lfields_last = (int64_t *)malloc((size_t)N * 8);
+    skx_t X = {NULL, &Xb};
+    int64_t r = extremal_opt_sk_impl(&X, N, ftau, iters, step, seed, it0, replica, chunks, Es, Emin_out, Cmin, itmin_out);
+    free(Xb.lfields); free(Xb.lfields_last);
+    return r;
+}
+
 /* wtmMC (src/RRRMC.jl:376-426, src/WaitingTimes.jl) on GraphSKNormal: as orc_wtm_mc_sparse with delta_energy = +lfields[i]
  * (SK.jl:278-284) and neighbors(X, i) = AllButOne (every other spin, in index order: SK.jl:297).  WTM stream: spin i's initial
  * time is draw i, then one draw per updated spin in the order of update_heap! (the moved spin, then j = 0..N-1 except it). */

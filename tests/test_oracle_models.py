@@ -539,3 +539,18 @@ def test_binary_sk_under_the_continuous_samplers(oracle):
     # energies of the binary model are multiples of 2 / sqrt(N) apart
     q = (Es - Es[0]) * np.sqrt(N) / 2
     assert np.allclose(q, np.round(q), atol=1e-9)
+
+
+@pytest.mark.parametrize("binary", [False, True])
+def test_extremal_opt_on_sk_models(oracle, binary):
+    """extremal_opt on GraphSK(10) / GraphSKNormal(10) (runtests.jl:66-67 x :161-164): EOCacheCont with every spin a neighbour."""
+    seed, N = 55, 12
+    J = oracle.gen_sk_binary(N, seed) if binary else oracle.gen_sk_gauss(N, seed)
+    energy = (lambda c: oracle.skb_energy(J, c)) if binary else (lambda c: oracle.skn_energy(J, c))
+    ch = oracle.init_config(seed, 0, N)
+    E0 = energy(ch)
+    Es, c1, Emin, Cmin, itmin = oracle.extremal_opt_sk(J, 1.3, 1500, 10, seed, ch, binary=binary)     # checks ranking + tracked E inside
+    assert len(Es) == 150 and Emin <= min(E0, Es.min()) + 1e-12 and abs(Emin - energy(Cmin)) < 1e-9
+    best = min(energy(np.array([c], np.uint64)) for c in range(2 ** N))
+    assert best - 1e-9 <= Emin and Emin < E0
+    assert Emin <= best + 1e-9                                       # 1500 tau-EO moves find the ground state of 12 spins
