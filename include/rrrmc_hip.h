@@ -209,7 +209,8 @@ RRRMC_API int32_t rrrmc_extremal_opt_results(rrrmc_ctx *ctx, int64_t *Emin_out, 
  * RRRMC_MODEL_SPARSE_DISCRETIZED (the DoubleGraphs) — runs the reference's generic cache, EOCacheCont (src/DeltaE.jl:557-635): the
  * ranking of all spins by delta_energy is re-established after every flip (the kernel slides the K + 1 changed entries to their
  * places instead of re-sorting) and every run of EQUAL values is put in a fresh uniformly random order per move (rankshuffle!,
- * :611-634; the library's restatement: order by a per-(move, site) Philox key).  N <= 65 535.  Energies are Float64:
+ * :611-634; the library's restatement: order by a per-(move, site) Philox key).  N <= 65 535.  RRRMC_MODEL_SK_NORMAL and
+ * RRRMC_MODEL_SK_BINARY run it too (every spin a neighbour: the ranking is re-sorted at every flip; N <= 4096).  Energies are Float64:
  * rrrmc_fetch_results_f64, and rrrmc_extremal_opt_results_f64 for (Emin, Cmin, itmin). */
 RRRMC_API int32_t rrrmc_extremal_opt_results_f64(rrrmc_ctx *ctx, double *Emin_out, uint64_t *Cmin_chunks, int64_t *itmin_out);
 /* parity/debug view of the move-selection cache after the last rrrMC call: pos_out[R * N] = class of every spin

@@ -53,12 +53,21 @@ int32_t quant_run_init(rrrmc_ctx* ctx, double beta, double fourK)
 
 // rrrMC(X::SingleGraph) on GraphSKNormal (RRRMC.jl:149-219): thread-per-replica kernel over interleaved arrays
 // mode 0 = rrrMC(SingleGraph), 1 = bklMC, 2 = wtmMC (iters = samples, stepf = step in sweeps)
-int32_t sk_rrr_mc_async(rrrmc_ctx* ctx, double beta, int64_t iters, int64_t step, double staged_thr, double staged_thr_fact, int mode = 0, double stepf = 1.0)
+// mode 0 rrrMC, 1 bklMC, 2 wtmMC (iters = samples), 3 extremal_opt (ftau = its rank table; beta unused)
+int32_t sk_rrr_mc_async(rrrmc_ctx* ctx, double beta, int64_t iters, int64_t step, double staged_thr, double staged_thr_fact, int mode = 0, double stepf = 1.0,
+                        const double* ftau = nullptr)
 {
     if (iters < 0) return fail(ctx, RRRMC_ERR_INVALID_ARG, "iters must be >= 0, given %lld", (long long)iters);
     if (step < 1) return fail(ctx, RRRMC_ERR_INVALID_ARG, "step must be >= 1, given %lld", (long long)step);
     if (mode == 2 && (!(stepf > 0.0) || !std::isfinite(stepf))) return fail(ctx, RRRMC_ERR_INVALID_ARG, "step must be positive and finite, given %g", stepf);
     if (mode == 2 && ctx->N > 65535) return fail(ctx, RRRMC_ERR_UNSUPPORTED, "N=%lld: the wtmMC heap indexes spins with 16 bits", (long long)ctx->N);
+    if (mode == 3) {
+        if (ctx->N > kEoSkMaxN) return fail(ctx, RRRMC_ERR_UNSUPPORTED, "N=%lld: extremal_opt on the dense SK models keeps the ranking in LDS, N <= %d", (long long)ctx->N, kEoSkMaxN);
+        if (!ftau) return fail(ctx, RRRMC_ERR_INVALID_ARG, "ftau is NULL");
+        for (int64_t i = 0; i < ctx->N; ++i)
+            if (!(ftau[i] > 0.0) || !std::isfinite(ftau[i]) || (i && ftau[i] < ftau[i - 1]))
+                return fail(ctx, RRRMC_ERR_INVALID_ARG, "ftau must be a positive non-decreasing table (cumsum of j^-tau), violated at %lld", (long long)i);
+    }
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     ctx->results_valid = false; ctx->last_call_wtm = false; ctx->last_call_eo = false;
     ctx->timing_valid = false;
@@ -74,7 +83,16 @@ int32_t sk_rrr_mc_async(rrrmc_ctx* ctx, double beta, int64_t iters, int64_t step
         HIP_TRY(ctx, hipMalloc(&ctx->rs_status, sizeof(int32_t) * per));
         HIP_TRY(ctx, hipMalloc(&ctx->q_stats, sizeof(int64_t) * per * 2));
     }
-    if (mode == 2 && !ctx->wt_time) HIP_TRY(ctx, hipMalloc(&ctx->wt_time, sizeof(double) * per));
+    if ((mode == 2 || mode == 3) && !ctx->wt_time) HIP_TRY(ctx, hipMalloc(&ctx->wt_time, sizeof(double) * per));
+    if (mode == 3) {
+        if (!ctx->eo_cmin) {
+            HIP_TRY(ctx, hipMalloc(&ctx->eo_cmin, sizeof(uint32_t) * ctx->R * W));
+            HIP_TRY(ctx, hipMalloc(&ctx->eo_ftau, sizeof(double) * N));
+        }
+        ctx->eo_W = W;
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        HIP_TRY(ctx, hipMemcpy(ctx->eo_ftau, ftau, sizeof(double) * N, hipMemcpyHostToDevice));
+    }
     const int64_t nsamp = mode == 2 ? iters : iters / step;
     const size_t es_need = (size_t)(nsamp > 0 ? nsamp : 1) * Rp;
     if (es_need > ctx->sk_Es_cap) {
@@ -117,12 +135,19 @@ int32_t sk_rrr_mc_async(rrrmc_ctx* ctx, double beta, int64_t iters, int64_t step
     P.N = (int)N; P.N2 = (int)N2; P.levs = levs; P.W = (int)W; P.R = (int)ctx->R; P.Rp = (int)Rp;
     P.mode = mode;
     P.call = ctx->wtm_calls & 0xffffffu; P.stepf = stepf; P.t_out = ctx->wt_time;
+    P.ftau = ctx->eo_ftau; P.cmin = ctx->eo_cmin;
     ctx->stats_stride = 2;
     HIP_TRY(ctx, hipEventRecord(ctx->ev_begin, st));
     hipLaunchKernelGGL(rrsk_spins_in_kernel, dim3((unsigned)((Rp + 255) / 256), (unsigned)W), dim3(256), 0, st, ctx->sk_spins, ctx->rs_spins, (int)N, (int)W, (int)Rp);
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipEventRecord(ctx->ev_sweep[0], st));
-    hipLaunchKernelGGL(rrr_skn_kernel, dim3(rrr_blocks(ctx->R)), dim3(rrr_tpb(ctx->R)), 0, st, P);
+    if (mode == 3) {
+        const size_t lds = eo_sk_lds_bytes((int)N, (int)N2, (int)W);
+        HIP_TRY(ctx, raise_lds_attr(reinterpret_cast<const void*>(eo_sk_wave_kernel), lds));
+        hipLaunchKernelGGL(eo_sk_wave_kernel, dim3((unsigned)ctx->R), dim3(64), lds, st, P);
+    } else {
+        hipLaunchKernelGGL(rrr_skn_kernel, dim3(rrr_blocks(ctx->R)), dim3(rrr_tpb(ctx->R)), 0, st, P);
+    }
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipEventRecord(ctx->ev_sweep[1], st));
     hipLaunchKernelGGL(rrsk_spins_out_kernel, dim3((unsigned)((N + 255) / 256), (unsigned)ctx->G8), dim3(256), 0, st, ctx->rs_spins, ctx->sk_spins, (int)N, (int)Rp);
@@ -135,6 +160,7 @@ int32_t sk_rrr_mc_async(rrrmc_ctx* ctx, double beta, int64_t iters, int64_t step
     ctx->timing_valid = true;
     ctx->last_call_rrr = true;
     ctx->last_call_wtm = mode == 2;
+    ctx->last_call_eo = mode == 3;          // Emin in wt_time, itmin in q_stats[.][1], Cmin in eo_cmin
     return RRRMC_OK;
 }
 

@@ -534,6 +534,8 @@ struct RrrSkParams {
     uint32_t call;           // wtmMC: number of the call (WTM stream)
     double stepf;            // wtmMC: step in sweeps
     double* t_out;           // wtmMC: [Rp] final global time
+    const double* ftau;      // extremal_opt: [N] cumsum(j^-tau)
+    uint32_t* cmin;          // extremal_opt: [R][W] configuration of minimum energy (replica-contiguous words)
     double sN;               // binary GraphSK (SK.jl:28-165) run as +-1 couplings: delta_energy = lfields[i] / sN, E = n / sN (sN = sqrt(N)); 0 = GraphSKNormal
 };
 
@@ -879,6 +881,161 @@ __global__ __launch_bounds__(kRrrThreads) void rrr_skn_kernel(RrrSkParams P)
 }
 
 // layout changes between the SK sweep kernel's spins ([G8][N] bytes, bit = replica & 7) and this kernel's ([W][Rp] words)
+// ---------------------------------------------------------------------------------------------------
+// extremal_opt (src/RRRMC.jl:474-521) with the generic EOCacheCont (src/DeltaE.jl:557-635) on the dense SK models: every spin is a
+// neighbour (AllButOne, SK.jl:142,297), so every delta_energy changes at every flip and the reference re-sorts the whole ranking
+// (sortperm! + rankshuffle!).  One wavefront per replica: fields (with the lfields / lfields_last swap of SK.jl:247-250), spins and
+// the ranking live in LDS; the chain is executed wave-uniformly, the 64 lanes share the O(N) field update (row `move` of J, coalesced)
+// and a bitonic sort of (dE, tie key, site) — tie keys (the restatement of rankshuffle!, see cont_kernels.hpp) only when two values
+// are equal: never with Gaussian couplings, always with the binary model's integer fields.
+// stats = (iterations, itmin), t_out = Emin, cmin = configuration of minimum energy.
+// ---------------------------------------------------------------------------------------------------
+constexpr int kEoSkMaxN = 4096;
+inline size_t eo_sk_lds_bytes(int N, int N2, int W) { return (size_t)N * 16 + (size_t)N2 * 18 + (size_t)W * 4 + 16; }
+
+__global__ __launch_bounds__(64) void eo_sk_wave_kernel(RrrSkParams P)
+{
+    extern __shared__ __align__(16) unsigned char esk_lds[];
+    const int r = blockIdx.x, lane = threadIdx.x;
+    const int N = P.N, N2 = P.N2, Rp = P.Rp, W = P.W;
+    double* fa = reinterpret_cast<double*>(esk_lds);                 // lfields
+    double* fb = fa + N;                                             // lfields_last
+    double* val = fb + N;                                            // [N2] dE by rank
+    unsigned long long* key = reinterpret_cast<unsigned long long*>(val + N2);      // [N2]
+    uint32_t* sp = reinterpret_cast<uint32_t*>(key + N2);            // [W]
+    uint16_t* site = reinterpret_cast<uint16_t*>(sp + W);            // [N2]
+    const uint32_t rep = P.replica0 + (uint32_t)r;
+    auto sbit = [&](int x) { return (int)((sp[x >> 5] >> (x & 31)) & 1u); };
+    auto dEv = [&](double lfv) { return P.sN > 0.0 ? lfv / P.sN : lfv; };
+    for (int w = lane; w < W; w += 64) sp[w] = P.spins[(size_t)w * Rp + r];
+    __syncthreads();
+    // energy(X, C) (SK.jl:212-237): a row per lane, the row sums in row order
+    for (int i = lane; i < N; i += 64) {
+        const int si = sbit(i);
+        double lfh = 0.0;
+        for (int j = 0; j < N; ++j) { const double Jij = P.J[(size_t)j * N + i]; lfh += (si ^ sbit(j)) ? -Jij : Jij; }     // J symmetric: coalesced
+        fa[i] = 2 * lfh;
+        fb[i] = 0.0;
+    }
+    __syncthreads();
+    double n = 0.0;
+    for (int base = 0; base < N; base += 64) {
+        const int i = base + lane;
+        const double h = i < N ? fa[i] * 0.5 : 0.0;                  // = lfh exactly
+        const int m = N - base < 64 ? N - base : 64;
+        for (int l = 0; l < m; ++l) n -= __shfl(h, l);
+    }
+    double E = n / 2;
+    if (P.sN > 0.0) E = E / P.sN;
+    int move_last = -1;
+
+    auto less = [&](int a, int b) {
+        const double xa = val[a], xb = val[b];
+        if (xa < xb) return true;
+        if (xa > xb) return false;
+        const unsigned long long ka = key[a], kb = key[b];
+        if (ka != kb) return ka < kb;
+        return site[a] < site[b];
+    };
+    auto sort_all = [&]() {                                          // bitonic, ascending (dE, key, site); padding sorts last
+        for (int k = 2; k <= N2; k <<= 1)
+            for (int j = k >> 1; j > 0; j >>= 1) {
+                for (int t = lane; t < (N2 >> 1); t += 64) {
+                    const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1)), l = i | j;
+                    const bool up = (i & k) == 0;
+                    if (less(l, i) == up) {
+                        const double x = val[i]; val[i] = val[l]; val[l] = x;
+                        const unsigned long long q = key[i]; key[i] = key[l]; key[l] = q;
+                        const uint16_t u = site[i]; site[i] = site[l]; site[l] = u;
+                    }
+                }
+                __syncthreads();
+            }
+    };
+    // the ranking after the move of iteration g (g = 0: construction, sortperm without shuffle: DeltaE.jl:568)
+    auto rerank = [&](uint64_t g, bool fresh) {
+        const bool keys_first = fresh && P.sN > 0.0;                 // integer fields: ties are the rule
+        for (int p = lane; p < N2; p += 64) {
+            if (p < N) {
+                val[p] = dEv(fa[p]); site[p] = (uint16_t)p;
+                unsigned long long kq = 0ull;
+                if (keys_first) {
+                    const Philox4 o = philox4x32_10((uint32_t)g, (uint32_t)(g >> 32), rep, TAG_RRR | (4u << 8) | ((uint32_t)p << 16), P.k0, P.k1);
+                    kq = ((unsigned long long)o.w[0] << 32) | o.w[1];
+                }
+                key[p] = kq;
+            } else { val[p] = __builtin_huge_val(); key[p] = ~0ull; site[p] = (uint16_t)0xffff; }
+        }
+        __syncthreads();
+        sort_all();
+        if (!fresh || keys_first) return;
+        int part = 0;
+        for (int p = 1 + lane; p < N; p += 64) part += val[p - 1] == val[p] ? 1 : 0;
+        for (int o = 32; o; o >>= 1) part += __shfl_xor(part, o);
+        if (part == 0) return;
+        for (int p = lane; p < N; p += 64) {
+            const Philox4 o = philox4x32_10((uint32_t)g, (uint32_t)(g >> 32), rep, TAG_RRR | (4u << 8) | ((uint32_t)site[p] << 16), P.k0, P.k1);
+            key[p] = ((unsigned long long)o.w[0] << 32) | o.w[1];
+        }
+        __syncthreads();
+        sort_all();
+    };
+    rerank(0, false);
+
+    uint32_t* cm = P.cmin + (size_t)r * W;
+    for (int w = lane; w < W; w += 64) cm[w] = sp[w];
+    double Emin = E;
+    long long itmin = 0, ns = 0, next_sample = P.step;
+    const double z = P.ftau[N - 1];
+    for (long long it = 1; it <= P.iters; ++it) {
+        if (it == next_sample) { next_sample += P.step; if (lane == 0) P.Es[(size_t)ns * Rp + r] = E; ns += 1; }
+        const uint64_t g = P.g0 + (uint64_t)it;
+        const Philox4 o = philox4x32_10((uint32_t)g, (uint32_t)(g >> 32), rep, TAG_RRR | (3u << 8), P.k0, P.k1);
+        const double rr = (1 - (double)((((uint64_t)o.w[0] << 32) | o.w[1]) >> 11) * 0x1.0p-53) * z;      // rand_move: DeltaE.jl:577-590
+        int lo = 0, hi = N;
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if (P.ftau[mid] < rr) lo = mid + 1; else hi = mid; }
+        if (lo > N - 1) lo = N - 1;
+        const int move = site[lo];
+        const double dE = val[lo];
+        __syncthreads();
+        // spinflip!: bit flip + update_cache! (SK.jl:239-276 / :98-135)
+        if (lane == 0) sp[move >> 5] ^= 1u << (move & 31);
+        __syncthreads();
+        if (move_last == move) {
+            double* t = fa; fa = fb; fb = t;
+        } else {
+            const double* Ji = P.J + (size_t)move * N;
+            const int si = sbit(move);
+            const double lfm = fa[move];
+            __syncthreads();
+            for (int j = lane; j < N; j += 64) {
+                const double Js = (si ^ sbit(j)) ? -Ji[j] : Ji[j];
+                const double lfj = fa[j];
+                fb[j] = lfj;
+                fa[j] = lfj + 4 * Js;
+            }
+            __syncthreads();
+            if (lane == 0) { fb[move] = lfm; fa[move] = -lfm; }
+            move_last = move;
+        }
+        __syncthreads();
+        rerank(g, true);
+        E += dE;
+        if (E < Emin) {
+            Emin = E; itmin = it;
+            for (int w = lane; w < W; w += 64) cm[w] = sp[w];
+        }
+    }
+    __syncthreads();
+    for (int w = lane; w < W; w += 64) P.spins[(size_t)w * Rp + r] = sp[w];
+    if (lane == 0) {
+        P.E_cur[r] = E;
+        P.stats[(size_t)r * 2] = P.iters; P.stats[(size_t)r * 2 + 1] = itmin;
+        P.t_out[r] = Emin;
+        P.status[r] = 0;
+    }
+}
+
 // binary GraphSK couplings (bit rows, SK.jl:32) as the +-1 matrix the kernel above works on: Jt[i][j] = 2 J_ij - 1, zero diagonal
 __global__ __launch_bounds__(256) void skb_dense_kernel(const uint32_t* __restrict__ Jbits, double* __restrict__ Jt, int N, int NW)
 {

@@ -1409,7 +1409,9 @@ int32_t rrrmc_extremal_opt_async(rrrmc_ctx* ctx, const double* ftau, int64_t ite
     if (rc) return rc;
     if (ctx->model == RRRMC_MODEL_SPARSE_F64 || ctx->model == RRRMC_MODEL_SPARSE_DISCRETIZED)        // not DiscrGraphs: EOCacheCont
         return spf_cont_async(ctx, 3, 0.0, iters, step, 1.0, 0.0, 0.0, ftau);
-    if (!sparse_int_model(ctx)) return fail(ctx, RRRMC_ERR_UNSUPPORTED, "extremal_opt is wired for the sparse models (RRRMC_MODEL_SPARSE_PM1 / _LEVELS / _F64 / _DISCRETIZED)");
+    if (ctx->model == RRRMC_MODEL_SK_NORMAL || ctx->model == RRRMC_MODEL_SK_BINARY)                 // EOCacheCont, every spin a neighbour
+        return sk_rrr_mc_async(ctx, 0.0, iters, step, 0.0, 5.0, 3, 1.0, ftau);
+    if (!sparse_int_model(ctx)) return fail(ctx, RRRMC_ERR_UNSUPPORTED, "extremal_opt is wired for the sparse models and the SK models, not for a GraphQuant");
     return sparse_eo_async(ctx, ftau, iters, step);
 }
 
@@ -1420,11 +1422,12 @@ int32_t eo_results(rrrmc_ctx* ctx, int64_t* Emin_i, double* Emin_f, uint64_t* Cm
     if (!ctx->last_call_eo || !ctx->results_valid) return fail(ctx, RRRMC_ERR_STATE, "no extremal_opt call has been made");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    std::vector<int64_t> st((size_t)ctx->R * 3);
+    const int64_t ss = ctx->stats_stride;
+    std::vector<int64_t> st((size_t)ctx->R * (size_t)ss);
     HIP_TRY(ctx, hipMemcpy(st.data(), ctx->q_stats, sizeof(int64_t) * st.size(), hipMemcpyDeviceToHost));
     for (int64_t r = 0; r < ctx->R; ++r) {
-        if (Emin_i) Emin_i[r] = st[(size_t)(3 * r)];
-        if (itmin_out) itmin_out[r] = st[(size_t)(3 * r + 1)];
+        if (Emin_i) Emin_i[r] = st[(size_t)(ss * r)];
+        if (itmin_out) itmin_out[r] = st[(size_t)(ss * r + 1)];
     }
     if (Emin_f) HIP_TRY(ctx, hipMemcpy(Emin_f, ctx->wt_time, sizeof(double) * ctx->R, hipMemcpyDeviceToHost));
     if (Cmin_chunks) {

@@ -120,3 +120,37 @@ def test_extremal_opt_cont_wave_and_thread_builds_agree(pkg, oracle, monkeypatch
     for r in (0, R - 1):
         ref = oracle.extremal_opt_cont(X.A, J, 1.3, iters, 50, seed, C0.s[r], replica=r, form=form, **dbl)
         assert (out[0][0][r] == ref[0]).all() and (out[0][4][r] == ref[1]).all() and out[0][1][r] == ref[2] and out[0][3][r] == ref[4]
+
+
+@pytest.mark.parametrize("binary,N,R,tau,iters,step", [
+    (False, 10, 40, 1.3, 3000, 50),           # runtests.jl:67 GraphSKNormal(10) under extremal_opt (:161-164)
+    (True, 10, 40, 1.3, 3000, 50),            # runtests.jl:66 GraphSK(10): integer fields, ties at every move
+    (False, 100, 33, 1.2, 1500, 100),
+    (True, 100, 33, 1.5, 1500, 100),
+    (False, 1024, 3, 1.3, 600, 64),           # BASELINE config 3's size
+    (True, 333, 4, 1.3, 500, 50),
+])
+def test_extremal_opt_on_sk_models(pkg, oracle, binary, N, R, tau, iters, step):
+    """EOCacheCont on the dense SK models: every spin is a neighbour, the whole ranking is rebuilt at every flip (a bitonic sort per
+    move, one wavefront per replica)."""
+    seed = 757000 + N + int(binary)
+    X = pkg.GraphSK(N, seed=seed) if binary else pkg.GraphSKNormal(N, seed=seed)
+    with pkg.Engine(X, R) as eng:
+        eng.seed(seed)
+        eng.init_spins_random()
+        C0 = eng.get_config()
+        Es, Emin, Cmin, itmin = eng.extremal_opt(tau, iters, step)
+        C1 = eng.get_config()
+        E1 = eng.energy()
+        Es2, Emin2, Cmin2, itmin2 = eng.extremal_opt(tau, iters // 2, step)
+        C2 = eng.get_config()
+        Es3, acc3 = eng.standard_mc(1.0, 1000, 100)               # the Metropolis kernel still works afterwards
+    energy = (lambda c: oracle.skb_energy(X.J, c)) if binary else (lambda c: oracle.skn_energy(X.J, c))
+    for r in range(R):
+        ref = oracle.extremal_opt_sk(X.J, tau, iters, step, seed, C0.s[r], replica=r, binary=binary)
+        assert np.allclose(Es[r], ref[0], rtol=1e-6, atol=1e-9)
+        assert (Es[r] == ref[0]).all() and (C1.s[r] == ref[1]).all()
+        assert Emin[r] == ref[2] and (Cmin.s[r] == ref[3]).all() and itmin[r] == ref[4]
+        assert E1[r] == energy(ref[1])
+        ref2 = oracle.extremal_opt_sk(X.J, tau, iters // 2, step, seed, ref[1], it0=iters, replica=r, binary=binary)
+        assert (Es2[r] == ref2[0]).all() and (C2.s[r] == ref2[1]).all() and Emin2[r] == ref2[2] and itmin2[r] == ref2[4]
