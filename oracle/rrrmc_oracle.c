@@ -536,6 +536,8 @@ typedef struct {
     sparse_t *X0;
     int64_t lev_mul;
     double lev_div;
+    const uint64_t *cur_s;   /* the live configuration (GraphQT's delta_energy reads spins: QT.jl:86-103) */
+    void *Q;                 /* a GraphQuant (quant_t *) behind the continuous-energy samplers instead of (A, J): see cont_quant_* */
 } spf_t;
 
 /* energy: RRG.jl:546-574 / EA.jl:584-611 */
@@ -599,7 +601,7 @@ static void spf_update_cache(spf_t *X, const uint64_t *s, int64_t move)
 
 ORC_API double orc_spf_energy(int form, int64_t N, int64_t K, const int32_t *A, const double *J, const uint64_t *chunks, double *lfields_out)
 {
-    spf_t X = {N, K, A, J, NULL, NULL, -1, form, NULL, 1, 1.0};
+    spf_t X = {N, K, A, J, NULL, NULL, -1, form, NULL, 1, 1.0, NULL, NULL};
     X.lfields = (double *)malloc((size_t)N * sizeof(double));
     X.lfields_last = (double *)malloc((size_t)N * sizeof(double));
     double E = spf_energy(&X, chunks);
@@ -614,7 +616,7 @@ ORC_API int64_t orc_standard_mc_spf(int form, int64_t N, int64_t K, const int32_
                                     int64_t step, uint64_t seed, uint64_t it0, uint32_t replica,
                                     uint64_t *chunks, double *Es, int64_t *accepted_out, double *lfields_out)
 {
-    spf_t X = {N, K, A, J, NULL, NULL, -1, form, NULL, 1, 1.0};
+    spf_t X = {N, K, A, J, NULL, NULL, -1, form, NULL, 1, 1.0, NULL, NULL};
     X.lfields = (double *)malloc((size_t)N * sizeof(double));
     X.lfields_last = (double *)malloc((size_t)N * sizeof(double));
     double E = spf_energy(&X, chunks);
@@ -1934,7 +1936,7 @@ ORC_API double orc_dbl_energy_scaled(int form, int64_t N, int64_t K, const int32
                                      int64_t mul, double div)
 {
     sparse_t X0 = {N, K, A, dJ, NULL, NULL, -1, form};
-    spf_t X1 = {N, K, A, rJ, NULL, NULL, -1, form, NULL, 1, 1.0};
+    spf_t X1 = {N, K, A, rJ, NULL, NULL, -1, form, NULL, 1, 1.0, NULL, NULL};
     X0.lfields = (int64_t *)malloc((size_t)N * 8); X0.lfields_last = (int64_t *)malloc((size_t)N * 8);
     X1.lfields = (double *)malloc((size_t)N * 8); X1.lfields_last = (double *)malloc((size_t)N * 8);
     const int64_t E0 = sparse_energy(&X0, chunks);
@@ -1957,7 +1959,7 @@ ORC_API int64_t orc_rrr_double_sparse_scaled(int form, int64_t N, int64_t K, con
     const int64_t L = orc_all_delta_e(K, lev, nlev, dElist, SL_MAX);
     if (L < 1) return -2;
     sparse_t X0 = {N, K, A, dJ, NULL, NULL, -1, form};
-    spf_t X1 = {N, K, A, rJ, NULL, NULL, -1, form, NULL, 1, 1.0};
+    spf_t X1 = {N, K, A, rJ, NULL, NULL, -1, form, NULL, 1, 1.0, NULL, NULL};
     X0.lfields = (int64_t *)malloc((size_t)N * 8); X0.lfields_last = (int64_t *)malloc((size_t)N * 8);
     X1.lfields = (double *)malloc((size_t)N * 8); X1.lfields_last = (double *)malloc((size_t)N * 8);
     double E = lev_to_f64(sparse_energy(&X0, chunks), mul, div);
@@ -2020,7 +2022,7 @@ ORC_API int64_t orc_standard_mc_dbl(int form, int64_t N, int64_t K, const int32_
                                     uint32_t replica, uint64_t *chunks, double *Es, int64_t *accepted_out)
 {
     sparse_t X0 = {N, K, A, dJ, NULL, NULL, -1, form};
-    spf_t X1 = {N, K, A, rJ, NULL, NULL, -1, form, NULL, 1, 1.0};
+    spf_t X1 = {N, K, A, rJ, NULL, NULL, -1, form, NULL, 1, 1.0, NULL, NULL};
     X0.lfields = (int64_t *)malloc((size_t)N * 8); X0.lfields_last = (int64_t *)malloc((size_t)N * 8);
     X1.lfields = (double *)malloc((size_t)N * 8); X1.lfields_last = (double *)malloc((size_t)N * 8);
     double E = lev_to_f64(sparse_energy(&X0, chunks), mul, div);
@@ -2231,6 +2233,17 @@ ORC_API int64_t orc_extremal_opt_sparse(int form, int64_t N, int64_t K, const in
 static int spf_neighbors(const spf_t *X, int64_t i, int64_t *out)
 {
     int n = 0;
+    if (X->Q) {                                        /* neighbors(X::GraphQuant, i): QT.jl:288-321 — the two Trotter neighbours, then the slice's */
+        const quant_t *Q = (const quant_t *)X->Q;
+        int64_t j1, j2;
+        qt_neighbors(&Q->X0, i, &j1, &j2);
+        out[n++] = j1; out[n++] = j2;
+        const int64_t k = i / Q->Nk, x = i % Q->Nk;
+        int64_t nb1[SK_MAX];
+        const int nn = sparse_neighbors(&Q->X1[k], x, nb1);
+        for (int q = 0; q < nn; ++q) out[n++] = nb1[q] + k * Q->Nk;
+        return n;
+    }
     const int32_t *Ax = X->A + i * X->K;
     for (int64_t k = 0; k < X->K; ++k) {
         if (X->ea_form && k > 0 && Ax[k] == Ax[k - 1]) continue;
@@ -2240,12 +2253,14 @@ static int spf_neighbors(const spf_t *X, int64_t i, int64_t *out)
 }
 static inline void spf_spinflip(spf_t *X, uint64_t *s, int64_t i)
 {
+    if (X->Q) { quant_spinflip((quant_t *)X->Q, s, i); return; }
     bitflip(s, i);
     if (X->X0) sparse_update_cache(X->X0, s, i);
     spf_update_cache(X, s, i);
 }
 static inline double spf_dE(const spf_t *X, int64_t i)                                          /* RRG.jl:619-625; DoubleGraph: :493-497 */
 {
+    if (X->Q) return qt_delta_energy(&((const quant_t *)X->Q)->X0, X->cur_s, i) + quant_residual((const quant_t *)X->Q, i);   /* QT.jl:283-286 */
     if (X->X0) return lev_to_f64(sparse_delta_energy(X->X0, i), X->lev_mul, X->lev_div) + (-X->lfields[i]);
     return -X->lfields[i];
 }
@@ -2256,7 +2271,7 @@ static double cont_apply_move(spf_t *X, uint64_t *s, dyns_t *ds, double *dEs, do
     const double z = ds->z;
     dEs[move] = spf_dE(X, move);
     dyns_set(ds, move, prior_of(beta * dEs[move]));
-    int64_t nb[SK_MAX];
+    int64_t nb[SK_MAX + 2];
     int nn = spf_neighbors(X, move, nb);
     for (int q = 0; q < nn; ++q) {
         int64_t j = nb[q];
@@ -2270,14 +2285,17 @@ static int64_t cont_sparse_impl(int mode, int form, int64_t N, int64_t K, const 
                                 const int32_t *dJ, int64_t mul, double div, double beta,
                                 int64_t iters, int64_t step, double stepf, double staged_thr, double staged_thr_fact,
                                 uint64_t seed, uint64_t it0, uint32_t call, uint32_t replica,
-                                uint64_t *chunks, double *Es, int64_t *stats, double *t_out)
+                                uint64_t *chunks, double *Es, int64_t *stats, double *t_out, quant_t *Q)
 {
-    spf_t X = {N, K, A, J, NULL, NULL, -1, form, NULL, 1, 1.0};
+    spf_t X = {N, K, A, J, NULL, NULL, -1, form, NULL, 1, 1.0, NULL, NULL};
     X.lfields = (double *)malloc((size_t)N * 8);
     X.lfields_last = (double *)malloc((size_t)N * 8);
     sparse_t X0 = {N, K, A, dJ, NULL, NULL, -1, form};
     double E = 0.0;
-    if (dJ) {                                                  /* energy(X::DoubleGraph, C) = convert(Float64, E0 + E1): RRG.jl:326-360 */
+    if (Q) {                                                   /* a GraphQuant: energy QT.jl:185-199 */
+        X.Q = Q; X.cur_s = chunks;
+        E = quant_energy(Q, chunks);
+    } else if (dJ) {                                                  /* energy(X::DoubleGraph, C) = convert(Float64, E0 + E1): RRG.jl:326-360 */
         X0.lfields = (int64_t *)malloc((size_t)N * 8);
         X0.lfields_last = (int64_t *)malloc((size_t)N * 8);
         X.X0 = &X0; X.lev_mul = mul; X.lev_div = div;
@@ -2314,7 +2332,7 @@ static int64_t cont_sparse_impl(int mode, int form, int64_t N, int64_t K, const 
             spf_spinflip(&X, chunks, move);
             double e = orc_det_exp(beta * -dE);
             tm[move] = t + wtm_gen(e > 1.0 ? e : 1.0, wtm_uniform(seed, nd++, replica, call));
-            int64_t nb[SK_MAX];
+            int64_t nb[SK_MAX + 2];
             int nn = spf_neighbors(&X, move, nb);
             for (int q = 0; q < nn; ++q) {
                 e = orc_det_exp(beta * spf_dE(&X, nb[q]));
@@ -2351,7 +2369,7 @@ static int64_t cont_sparse_impl(int mode, int form, int64_t N, int64_t K, const 
                     spf_spinflip(&X, chunks, move);                                    /* compute_staged!: DeltaE.jl:357-374 */
                     int ns = 0;
                     st_j[ns] = move; st_dE[ns] = spf_dE(&X, move); st_p[ns] = prior_of(beta * st_dE[ns]); ns++;
-                    int64_t nb[SK_MAX];
+                    int64_t nb[SK_MAX + 2];
                     int nn = spf_neighbors(&X, move, nb);
                     for (int q = 0; q < nn; ++q) { st_j[ns] = nb[q]; st_dE[ns] = spf_dE(&X, nb[q]); st_p[ns] = prior_of(beta * st_dE[ns]); ns++; }
                     spf_spinflip(&X, chunks, move);
@@ -2420,7 +2438,7 @@ ORC_API int64_t orc_cont_sparse(int mode, int form, int64_t N, int64_t K, const 
                                 uint64_t *chunks, double *Es, int64_t *stats, double *t_out)
 {
     return cont_sparse_impl(mode, form, N, K, A, J, NULL, 1, 1.0, beta, iters, step, stepf, staged_thr, staged_thr_fact, seed, it0, call,
-                            replica, chunks, Es, stats, t_out);
+                            replica, chunks, Es, stats, t_out, NULL);
 }
 /* bklMC / wtmMC on the discretised DoubleGraphs: for a graph that is not a DiscrGraph the reference builds the continuous-energy
  * caches over the WHOLE graph (gen_ΔEcache(X::AbstractGraph, ...) -> DeltaECacheCont, DeltaE.jl:315; THeap), with
@@ -2431,7 +2449,7 @@ ORC_API int64_t orc_cont_double(int mode, int form, int64_t N, int64_t K, const 
                                 uint64_t *chunks, double *Es, int64_t *stats, double *t_out)
 {
     return cont_sparse_impl(mode, form, N, K, A, rJ, dJ, mul, div, beta, iters, step, stepf, 0.8, 5.0, seed, it0, call, replica, chunks, Es,
-                            stats, t_out);
+                            stats, t_out, NULL);
 }
 
 /* =============================================================================================
@@ -2482,7 +2500,7 @@ ORC_API int64_t orc_extremal_opt_cont(int form, int64_t N, int64_t K, const int3
                                       uint64_t *chunks, double *Es, double *Emin_out, uint64_t *Cmin, int64_t *itmin_out)
 {
     if (N > 65535) return -2;                                             /* the tie key carries the site in 16 bits */
-    spf_t X = {N, K, A, J, NULL, NULL, -1, form, NULL, 1, 1.0};
+    spf_t X = {N, K, A, J, NULL, NULL, -1, form, NULL, 1, 1.0, NULL, NULL};
     X.lfields = (double *)malloc((size_t)N * 8);
     X.lfields_last = (double *)malloc((size_t)N * 8);
     sparse_t X0 = {N, K, A, dJ, NULL, NULL, -1, form};
@@ -2609,6 +2627,22 @@ ORC_API int64_t orc_extremal_opt_skb(int64_t N, const uint64_t *Jb, const double
     skx_t X = {NULL, &Xb};
     int64_t r = extremal_opt_sk_impl(&X, N, ftau, iters, step, seed, it0, replica, chunks, Es, Emin_out, Cmin, itmin_out);
     free(Xb.lfields); free(Xb.lfields_last);
+    return r;
+}
+
+/* bklMC / wtmMC on a GraphQuant over GraphRRG / GraphEA slices: a DoubleGraph is not a DiscrGraph, so the reference builds the
+ * continuous-energy caches over the WHOLE graph (DeltaE.jl:315, WaitingTimes.jl) with delta_energy = delta_energy(X0) + residual
+ * (QT.jl:283-286) and neighbors(X, i) = the two Trotter neighbours, then the slice graph's (QT.jl:288-321).  mode 1 / 2 as orc_cont_sparse. */
+ORC_API int64_t orc_cont_quant(int mode, int64_t Nk, int64_t M, int64_t K, const int32_t *A, const int32_t *J, double fourK, double beta,
+                               int64_t iters, int64_t step, double stepf, uint64_t seed, uint64_t it0, uint32_t call, uint32_t replica,
+                               uint64_t *chunks, double *Es, int64_t *stats, double *t_out)
+{
+    if (K + 2 > SK_MAX + 2) return -2;
+    quant_t Q;
+    quant_init(&Q, Nk, M, K, A, J, fourK);
+    int64_t r = cont_sparse_impl(mode, 0, Nk * M, K, NULL, NULL, NULL, 1, 1.0, beta, iters, step, stepf, 0.8, 5.0, seed, it0, call, replica,
+                                 chunks, Es, stats, t_out, &Q);
+    quant_free(&Q);
     return r;
 }
 

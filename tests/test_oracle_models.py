@@ -554,3 +554,24 @@ def test_extremal_opt_on_sk_models(oracle, binary):
     best = min(energy(np.array([c], np.uint64)) for c in range(2 ** N))
     assert best - 1e-9 <= Emin and Emin < E0
     assert Emin <= best + 1e-9                                       # 1500 tau-EO moves find the ground state of 12 spins
+
+
+def test_quant_bkl_wtm_tracked_energy(oracle):
+    """bklMC / wtmMC on GraphQuant(10, 8, 0.5, 2.0, GraphRRG, 10, 3) (runtests.jl:78 x :145-151): the continuous-energy caches over the
+    whole DoubleGraph; E at a sample equals energy(X, C) of the configuration reached by the prefix run."""
+    seed, Nk, M, beta, Gamma = 31, 10, 8, 2.0, 0.5
+    A = oracle.gen_rrg(Nk, 3, seed)
+    J = oracle.gen_couplings(A, seed)
+    fourK = oracle.quant_fourK(beta, Gamma, M)
+    ch = oracle.init_config(seed, 0, Nk * M)
+    E0 = oracle.quant_energy(A, J, M, fourK, ch)[0]
+    Es, c1, st, _ = oracle.cont_quant("bkl", A, J, M, fourK, beta, 3000, 1, seed, ch)
+    assert len(Es) == 3000 and Es[0] == E0 and 0 < st[0] <= 3000
+    for k in (2, 40, 777, 3000):          # a run of k iterations stops at its k-th sample, before the pending move: same chain, same state
+        _, ck, _, _ = oracle.cont_quant("bkl", A, J, M, fourK, beta, k, 1, seed, ch)
+        assert abs(Es[k - 1] - oracle.quant_energy(A, J, M, fourK, ck)[0]) < 1e-10
+    Ew, cw, sw, t = oracle.cont_quant("wtm", A, J, M, fourK, beta, 60, 1, seed, ch, stepf=2.0)
+    assert len(Ew) == 60 and sw[0] > 0 and t > 0
+    for k in (1, 7, 60):
+        _, ck, _, _ = oracle.cont_quant("wtm", A, J, M, fourK, beta, k, 1, seed, ch, stepf=2.0)
+        assert abs(Ew[k - 1] - oracle.quant_energy(A, J, M, fourK, ck)[0]) < 1e-10
