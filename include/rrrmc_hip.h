@@ -160,7 +160,9 @@ RRRMC_API int32_t rrrmc_gen_sk_gauss(int64_t N, uint64_t seed, double *J_out);
 /* ---- GraphQuant + rrrMC (RRRMC_MODEL_QUANT_RRG) ---------------------------------------------------------------
  * N = Nk * M spins per replica, slice-major (slice k holds spins k*Nk .. (k+1)*Nk-1, QT.jl:105-108); the slice graph's
  * (A, J) [Nk x K] is given with rrrmc_set_graph.  Energies are Float64: use the _f64 entry points for energy / results.
- * Replaces GraphQuant{fourK,GraphRRG}(...) (QT.jl:139-170). */
+ * Replaces GraphQuant{fourK,GraphRRG}(...) (QT.jl:139-170).  The slice graph must be simple (no repeated bonds: a GraphEA with L = 2 is
+ * refused).  rrrmc_bkl_mc_async / rrrmc_wtm_mc_async run the generic continuous-energy caches over all Nk * M spins (DeltaE.jl:315) with
+ * neighbors(X, i) = the two Trotter neighbours, then the slice graph's (QT.jl:288-321); rrrmc_quant_set_field must have been called. */
 RRRMC_API int32_t rrrmc_ctx_create_quant(rrrmc_ctx **out, int64_t Nk, int64_t K, int64_t M, int64_t R,
                                          int32_t device, uint32_t replica0);
 /* GraphQuant over binary GraphSK slices — GraphQSKT(Nk, M, Gamma, beta) = GraphQuant(Nk, M, Gamma, beta, GraphSK, gen_J(Nk))

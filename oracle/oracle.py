@@ -892,12 +892,12 @@ def extremal_opt_sk(J, tau, iters, step, seed, chunks, it0=0, replica=0, binary=
     return Es[:n], ch, Emin.value, Cmin, itmin.value
 
 
-def cont_quant(mode, A, J, M, fourK, beta, iters, step, seed, chunks, it0=0, call=0, replica=0, stepf=1.0):
+def cont_quant(mode, A, J, M, fourK, beta, iters, step, seed, chunks, it0=0, call=0, replica=0, stepf=1.0, form="rrg"):
     """bklMC ("bkl") / wtmMC ("wtm") on GraphQuant over GraphRRG / GraphEA slices: the continuous-energy caches over the whole graph.
     Returns (Es, chunks, stats[3], t)."""
     L = lib()
     L.orc_cont_quant.restype = C.c_int64
-    L.orc_cont_quant.argtypes = [C.c_int, C.c_int64, C.c_int64, C.c_int64, i32p, i32p, C.c_double, C.c_double, C.c_int64, C.c_int64,
+    L.orc_cont_quant.argtypes = [C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_int64, i32p, i32p, C.c_double, C.c_double, C.c_int64, C.c_int64,
                                  C.c_double, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, u64p, f64p, i64p, C.POINTER(C.c_double)]
     A = np.ascontiguousarray(A, np.int32)
     Nk, K = A.shape
@@ -906,7 +906,7 @@ def cont_quant(mode, A, J, M, fourK, beta, iters, step, seed, chunks, it0=0, cal
     Es = np.zeros(max(iters if m == 2 else iters // step, 1))
     stats = np.zeros(3, np.int64)
     t = C.c_double(0)
-    n = L.orc_cont_quant(m, Nk, int(M), K, A, np.ascontiguousarray(J, np.int32).reshape(-1), float(fourK), float(beta), int(iters), int(step),
+    n = L.orc_cont_quant(m, 1 if form == "ea" else 0, Nk, int(M), K, A, np.ascontiguousarray(J, np.int32).reshape(-1), float(fourK), float(beta), int(iters), int(step),
                          float(stepf), seed, it0, call, replica, ch, Es, stats, C.byref(t))
     if n < 0:
         raise RuntimeError("cont_quant: DynamicSampler lost precision / unsupported (%d)" % n)

@@ -2633,13 +2633,14 @@ ORC_API int64_t orc_extremal_opt_skb(int64_t N, const uint64_t *Jb, const double
 /* bklMC / wtmMC on a GraphQuant over GraphRRG / GraphEA slices: a DoubleGraph is not a DiscrGraph, so the reference builds the
  * continuous-energy caches over the WHOLE graph (DeltaE.jl:315, WaitingTimes.jl) with delta_energy = delta_energy(X0) + residual
  * (QT.jl:283-286) and neighbors(X, i) = the two Trotter neighbours, then the slice graph's (QT.jl:288-321).  mode 1 / 2 as orc_cont_sparse. */
-ORC_API int64_t orc_cont_quant(int mode, int64_t Nk, int64_t M, int64_t K, const int32_t *A, const int32_t *J, double fourK, double beta,
+ORC_API int64_t orc_cont_quant(int mode, int form, int64_t Nk, int64_t M, int64_t K, const int32_t *A, const int32_t *J, double fourK, double beta,
                                int64_t iters, int64_t step, double stepf, uint64_t seed, uint64_t it0, uint32_t call, uint32_t replica,
                                uint64_t *chunks, double *Es, int64_t *stats, double *t_out)
 {
     if (K + 2 > SK_MAX + 2) return -2;
     quant_t Q;
     quant_init(&Q, Nk, M, K, A, J, fourK);
+    for (int64_t k = 0; k < M; ++k) Q.X1[k].ea_form = form;          /* neighbors(X1[k], i): uA of a GraphEA slice (EA.jl:158,292) */
     int64_t r = cont_sparse_impl(mode, 0, Nk * M, K, NULL, NULL, NULL, 1, 1.0, beta, iters, step, stepf, 0.8, 5.0, seed, it0, call, replica,
                                  chunks, Es, stats, t_out, &Q);
     quant_free(&Q);

@@ -39,6 +39,9 @@ struct ContParams {
     double* Es;              // [nsamples][R]
     double* t_out;           // [R]
     int32_t* status;         // [R]  1 = DynamicSampler's "unrecoverable loss of precision"
+    const int8_t* qJ;        // GraphQuant (bklMC / wtmMC over the whole DoubleGraph, DeltaE.jl:315): slice couplings [qNk][K] (A = the slice's table), else null
+    double fourK;            //   delta_energy = qt_delta * fourK + slice_delta / qM (QT.jl:283-286); neighbors = Trotter pair, then the slice's (QT.jl:288-321)
+    int qNk, qM;
     const double* ftau;      // [N]  extremal_opt: cumsum(j^-tau)
     uint32_t* cmin;          // [R][W] extremal_opt: configuration of minimum energy
     double beta, staged_thr, lambda, stepf;
@@ -90,6 +93,7 @@ struct ContChain {
     __device__ void flip(int move)
     {
         sp[move >> 5] ^= 1u << (move & 31);
+        if (P->qJ) return;                       // GraphQuant: nothing is cached, every delta_energy is recomputed from the spins
         const int K = P->K;
         const int32_t* Ax = P->A + (size_t)move * K;
         const double* Jx = P->J + (size_t)move * K;
@@ -131,8 +135,40 @@ struct ContChain {
         }
         return 2 * acc;
     }
+    __device__ __forceinline__ RrrView qview() const
+    {
+        RrrView v{};
+        v.sp = sp; v.N = P->N; v.Nk = P->qNk; v.M = P->qM; v.K = P->K; v.A = P->A; v.J = P->qJ; v.fourK = P->fourK;
+        v.nk_magic = (uint32_t)((0x100000000ull + (uint32_t)P->qNk - 1u) / (uint32_t)P->qNk);
+        return v;
+    }
+    // neighbors(X, move) in the reference's order; returns their number (at most K + 2)
+    __device__ __forceinline__ int nbrs(int move, int* out) const
+    {
+        int n = 0;
+        if (P->qJ) {
+            const RrrView v = qview();
+            int j1, j2;
+            qt_nb(v, move, j1, j2);
+            out[n++] = j1; out[n++] = j2;
+            const int k = move / P->qNk, x = move - k * P->qNk;
+            const int32_t* Ax = P->A + (size_t)x * P->K;
+            for (int q = 0; q < P->K; ++q) {
+                if (q > 0 && Ax[q] == Ax[q - 1]) continue;                 // uA of the slice graph (EA.jl:158)
+                out[n++] = Ax[q] + k * P->qNk;
+            }
+            return n;
+        }
+        const int32_t* Ax = P->A + (size_t)move * P->K;
+        for (int q = 0; q < P->K; ++q) {
+            if (!is_nb(Ax, q)) continue;
+            out[n++] = Ax[q];
+        }
+        return n;
+    }
     __device__ __forceinline__ double dE(int i) const          // RRG.jl:619-625; DoubleGraph: convert(Float64, dE0 + dE1), :493-497
     {
+        if (P->qJ) { const RrrView v = qview(); return (double)qt_delta(v, i) * P->fourK + slice_res(v, slice_delta(v, i)); }
         if (P->dJ) return (double)(dE0(i) * P->lev_mul) / P->lev_div + (-lf[i]);
         return -lf[i];
     }
@@ -195,10 +231,10 @@ struct ContChain {
         const double z0 = z;
         dEs[move] = dE(move);
         set(move, prior_of(P->beta * dEs[move]));
-        const int32_t* Ax = P->A + (size_t)move * P->K;
-        for (int q = 0; q < P->K; ++q) {
-            if (!is_nb(Ax, q)) continue;
-            const int j = Ax[q];
+        int nb[kContKmax + 2];
+        const int nn = nbrs(move, nb);
+        for (int q = 0; q < nn; ++q) {
+            const int j = nb[q];
             dEs[j] = dE(j);
             set(j, prior_of(P->beta * dEs[j]));
         }
@@ -316,7 +352,7 @@ __global__ __launch_bounds__(kRrrThreads) void cont_sparse_kernel(ContParams P)
     c.rep = P.replica0 + (uint32_t)r;
     // energy(X, C): RRG.jl:546-574 / EA.jl:584-611
     double E1 = 0.0;
-    for (int i = 0; i < N; ++i) {
+    for (int i = 0; i < N && !P.qJ; ++i) {
         const int sx = 2 * c.sbit(i) - 1;
         double fl = 0.0;
         for (int q = 0; q < K; ++q) {
@@ -331,6 +367,21 @@ __global__ __launch_bounds__(kRrrThreads) void cont_sparse_kernel(ContParams P)
         long long n0 = 0;
         for (int i = 0; i < N; ++i) n0 -= c.dE0(i) / 2;
         E = (double)((n0 / 2) * P.lev_mul) / P.lev_div + E;
+    }
+    if (P.qJ) {                                  // energy(X::GraphQuant, C): QT.jl:185-199 (as rrr_init_kernel)
+        const RrrView v = c.qview();
+        long long n0 = 0;
+        for (int i = 0; i < P.qNk; ++i) {
+            int sj = c.sbit(i + (P.qM - 1) * P.qNk);
+            for (int k = 0; k < P.qM; ++k) { const int sk = c.sbit(i + k * P.qNk); n0 -= 1 - 2 * (sk ^ sj); sj = sk; }
+        }
+        E = (double)n0 * P.fourK / 4;
+        for (int k = 0; k < P.qM; ++k) {
+            long long n = 0;
+            for (int i = 0; i < P.qNk; ++i) n -= slice_delta(v, k * P.qNk + i) / 2;
+            n /= 2;
+            E += (double)n / (double)P.qM;
+        }
     }
     long long accepted = 0, second = 0, ns = 0, itdone = 0;
     int bad = 0;
@@ -355,12 +406,9 @@ __global__ __launch_bounds__(kRrrThreads) void cont_sparse_kernel(ContParams P)
             const double d = c.dE(move);
             c.flip(move);
             c.heap_update(move, t + c.gen_wt(-d));
-            const int32_t* Ax = P.A + (size_t)move * K;
-            for (int q = 0; q < K; ++q) {
-                if (!c.is_nb(Ax, q)) continue;
-                const int j = Ax[q];
-                c.heap_update(j, t + c.gen_wt(c.dE(j)));
-            }
+            int nb[kContKmax + 2];
+            const int nn = c.nbrs(move, nb);
+            for (int q = 0; q < nn; ++q) c.heap_update(nb[q], t + c.gen_wt(c.dE(nb[q])));
             E += d;
             accepted += 1;
         }

@@ -148,7 +148,10 @@ int32_t spf_cont_async(rrrmc_ctx* ctx, int mode, double beta, int64_t iters, int
     ctx->results_valid = false; ctx->last_call_wtm = false; ctx->last_call_eo = false;
     ctx->timing_valid = false;
     // the discretised DoubleGraphs (bklMC / wtmMC over the whole graph: DeltaE.jl:315) keep their spins in the kernel's layout already
-    const bool dblm = ctx->model == RRRMC_MODEL_SPARSE_DISCRETIZED;
+    const bool quantm = ctx->model == RRRMC_MODEL_QUANT_RRG;          // bklMC / wtmMC over the whole GraphQuant (DeltaE.jl:315): spins in q_spins too
+    if (quantm && ctx->q_sk) return fail(ctx, RRRMC_ERR_UNSUPPORTED, "bklMC / wtmMC on a GraphQuant are wired for GraphRRG / GraphEA slices (a GraphSK slice has Nk - 1 neighbours per spin)");
+    if (quantm && !(ctx->last_fourK > 0.0)) return fail(ctx, RRRMC_ERR_STATE, "a GraphQuant needs fourK: call rrrmc_quant_set_field first");
+    const bool dblm = ctx->model == RRRMC_MODEL_SPARSE_DISCRETIZED || quantm;
     const int64_t N = ctx->N, K = ctx->K, R = ctx->R, W = dblm ? ctx->qW : (N + 31) / 32;
     int levs = 0;
     while (((int64_t)1 << levs) < N) ++levs;
@@ -186,8 +189,9 @@ int32_t spf_cont_async(rrrmc_ctx* ctx, int mode, double beta, int64_t iters, int
         P.ftau = ctx->eo_ftau; P.cmin = ctx->eo_cmin;
     }
     double* b = ctx->cs_buf;
-    P.A = ctx->d_A; P.J = dblm ? ctx->db_rJ : ctx->pf_J; P.spins = dblm ? ctx->q_spins : ctx->cs_spins;
-    P.dJ = dblm ? ctx->db_dJ : nullptr; P.lev_mul = ctx->db_lev_mul; P.lev_div = ctx->db_lev_div;
+    P.A = ctx->d_A; P.J = quantm ? nullptr : dblm ? ctx->db_rJ : ctx->pf_J; P.spins = dblm ? ctx->q_spins : ctx->cs_spins;
+    P.dJ = dblm && !quantm ? ctx->db_dJ : nullptr; P.lev_mul = ctx->db_lev_mul; P.lev_div = ctx->db_lev_div;
+    if (quantm) { P.qJ = ctx->d_J; P.fourK = ctx->last_fourK; P.qNk = (int)ctx->qNk; P.qM = (int)ctx->qM; }
     P.lf = b; b += (size_t)R * N;
     P.dEs = b; b += (size_t)R * N;
     P.v = b; b += (size_t)R * N2;
@@ -227,6 +231,7 @@ int32_t spf_cont_async(rrrmc_ctx* ctx, int mode, double beta, int64_t iters, int
     if (mode == 2) ctx->wtm_calls += 1; else ctx->it_done += (uint64_t)iters;
     ctx->pf_lf_live = false;
     ctx->db_cache_valid = false;
+    if (quantm) ctx->q_cache_valid = false;
     ctx->stats_stride = 3;
     ctx->sweep_launches = 1;
     ctx->nsamp = nsamp;

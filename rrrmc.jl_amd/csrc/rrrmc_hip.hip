@@ -585,6 +585,12 @@ int32_t rrrmc_set_graph(rrrmc_ctx* ctx, const int32_t* A, const int8_t* J)
             if (!found) return fail(ctx, RRRMC_ERR_INVALID_ARG, "bond (%lld,%lld) is not symmetric in (A, J)", (long long)x, (long long)y);
         }
     if (ctx->model == RRRMC_MODEL_QUANT_RRG) {
+        // slice graphs with repeated bonds (GraphEA with L = 2: EA.jl:156) are not covered: the GraphQuant parity tests hold simple graphs only
+        for (int64_t x = 0; x < N; ++x)
+            for (int64_t k = 0; k < K; ++k)
+                for (int64_t l = k + 1; l < K; ++l)
+                    if (A[x * K + k] == A[x * K + l])
+                        return fail(ctx, RRRMC_ERR_UNSUPPORTED, "site %lld lists neighbour %d twice: GraphQuant slices must be simple graphs", (long long)x, A[x * K + k]);
         HIP_TRY(ctx, hipSetDevice(ctx->device));
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
         HIP_TRY(ctx, hipMemcpy(ctx->d_A, A, sizeof(int32_t) * N * K, hipMemcpyHostToDevice));
@@ -1274,7 +1280,7 @@ int32_t quant_ctx_create(rrrmc_ctx** out, int64_t Nk, int64_t K, int64_t M, int6
     Q_TRY(hipMalloc(&ctx->q_T, sizeof(double) * R * 4));
     Q_TRY(hipMalloc(&ctx->q_z, sizeof(double) * R));
     Q_TRY(hipMalloc(&ctx->q_accrate, sizeof(double) * R));
-    Q_TRY(hipMalloc(&ctx->q_stats, sizeof(int64_t) * R * 2));
+    Q_TRY(hipMalloc(&ctx->q_stats, sizeof(int64_t) * R * 3));          // 2 per replica for rrrMC, 3 for the continuous-energy samplers
     Q_TRY(hipMalloc(&ctx->sk_E, sizeof(double) * R));
     Q_TRY(hipMemset(ctx->q_spins, 0, sizeof(uint32_t) * R * ctx->qW));
 #undef Q_TRY
@@ -1366,7 +1372,8 @@ int32_t rrrmc_bkl_mc_async(rrrmc_ctx* ctx, double beta, int64_t iters, int64_t s
     int32_t rc = ensure_state(ctx, true);
     if (rc) return rc;
     if (!std::isfinite(beta)) return fail(ctx, RRRMC_ERR_INVALID_ARG, "beta must be finite, given: %g", beta);
-    if (ctx->model == RRRMC_MODEL_SPARSE_F64 || ctx->model == RRRMC_MODEL_SPARSE_DISCRETIZED) return spf_cont_async(ctx, 1, beta, iters, step, 1.0, 0.0, 5.0);
+    if (ctx->model == RRRMC_MODEL_SPARSE_F64 || ctx->model == RRRMC_MODEL_SPARSE_DISCRETIZED || ctx->model == RRRMC_MODEL_QUANT_RRG)
+        return spf_cont_async(ctx, 1, beta, iters, step, 1.0, 0.0, 5.0);
     if (ctx->model == RRRMC_MODEL_SK_NORMAL || ctx->model == RRRMC_MODEL_SK_BINARY) return sk_rrr_mc_async(ctx, beta, iters, step, 0.0, 5.0, 1);
     if (!sparse_int_model(ctx)) return fail(ctx, RRRMC_ERR_UNSUPPORTED, "bklMC is wired for the sparse models, RRRMC_MODEL_SK_NORMAL and RRRMC_MODEL_SK_BINARY");
     return sparse_rrr_bkl_async(ctx, 1, beta, iters, step, 0.0, 5.0);
@@ -1386,7 +1393,8 @@ int32_t rrrmc_wtm_mc_async(rrrmc_ctx* ctx, double beta, int64_t samples, double 
 {
     int32_t rc = ensure_state(ctx, true);
     if (rc) return rc;
-    if (ctx->model == RRRMC_MODEL_SPARSE_F64 || ctx->model == RRRMC_MODEL_SPARSE_DISCRETIZED) return spf_cont_async(ctx, 2, beta, samples, 1, step, 0.0, 5.0);
+    if (ctx->model == RRRMC_MODEL_SPARSE_F64 || ctx->model == RRRMC_MODEL_SPARSE_DISCRETIZED || ctx->model == RRRMC_MODEL_QUANT_RRG)
+        return spf_cont_async(ctx, 2, beta, samples, 1, step, 0.0, 5.0);
     if (ctx->model == RRRMC_MODEL_SK_NORMAL || ctx->model == RRRMC_MODEL_SK_BINARY) return sk_rrr_mc_async(ctx, beta, samples, 1, 0.0, 5.0, 2, step);
     if (!sparse_int_model(ctx)) return fail(ctx, RRRMC_ERR_UNSUPPORTED, "wtmMC is wired for the sparse models, RRRMC_MODEL_SK_NORMAL and RRRMC_MODEL_SK_BINARY");
     return sparse_wtm_async(ctx, beta, samples, step);

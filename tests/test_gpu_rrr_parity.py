@@ -252,3 +252,43 @@ def test_rrr_sparse_lds_and_global_builds_agree(pkg, oracle, monkeypatch, kind, 
     for r in (0, R - 1):
         ref = oracle.rrr_sparse(X.A, X.J.astype(np.int32), beta, iters, step, seed, C0.s[r], replica=r, staged_thr=thr, form=form)
         assert (out[0][0][r] == ref[0]).all() and (out[0][3][r] == ref[1]).all() and out[0][1][r] == ref[2] and out[0][2][r] == ref[3]
+
+
+@pytest.mark.parametrize("slices,Nk,M,Gamma,beta,R", [
+    ("rrg", 10, 8, 0.5, 2.0, 40),            # test/runtests.jl:78 under bklMC / wtmMC (:145-151)
+    ("ea3x2", 9, 5, 0.4, 1.0, 9),            # GraphEA(3, 2) slices (K = 4)
+    ("rrg", 64, 16, 0.3, 1.5, 70),
+    ("rrg", 1024, 32, 0.5, 2.0, 2),          # BASELINE config 5 geometry
+])
+def test_bkl_and_wtm_on_graph_quant(pkg, oracle, slices, Nk, M, Gamma, beta, R):
+    """A GraphQuant is a DoubleGraph, not a DiscrGraph: bklMC and wtmMC build the continuous-energy caches over all N = Nk M spins
+    (DeltaE.jl:315, WaitingTimes.jl) with delta_energy = delta_energy(X0) + residual (QT.jl:283-286) and neighbors = the Trotter pair,
+    then the slice graph's (QT.jl:288-321)."""
+    seed = 919000 + Nk + M
+    X1 = pkg.GraphEA(3, 2, seed=seed) if slices == "ea3x2" else pkg.GraphRRG(Nk, 3, seed=seed)
+    X = pkg.GraphQuant(X1, M, Gamma, beta)
+    A, J = X1.A, X1.J.astype(np.int32)
+    form = "ea" if slices == "ea3x2" else "rrg"
+    iters, step, samples = (4000, 100, 20) if Nk >= 1024 else (12000, 200, 40)
+    with pkg.Engine(X, R) as eng:
+        eng.seed(seed)
+        eng.init_spins_random()
+        C0 = eng.get_config()
+        Eb, mb = eng.bkl_mc(beta, iters, step)
+        C1 = eng.get_config()
+        E1 = eng.energy()
+        eng.seed(seed)
+        eng.set_config(C0)
+        Ew, mw, tw = eng.wtm_mc(beta, samples, step=2.0)
+        C2 = eng.get_config()
+        Er, ar, st = eng.rrr_mc(beta, 2000, 100)               # the DoubleGraph rrrMC still works after the other samplers
+        C3 = eng.get_config()
+    for r in range(R):
+        b = oracle.cont_quant("bkl", A, J, M, X.fourK, beta, iters, step, seed, C0.s[r], replica=r, form=form)
+        assert np.allclose(Eb[r], b[0], rtol=1e-6, atol=1e-9)
+        assert (Eb[r] == b[0]).all() and (C1.s[r] == b[1]).all() and mb[r] == b[2][0]
+        assert E1[r] == oracle.quant_energy(A, J, M, X.fourK, C1.s[r])[0]
+        w = oracle.cont_quant("wtm", A, J, M, X.fourK, beta, samples, 1, seed, C0.s[r], replica=r, stepf=2.0, form=form)
+        assert (Ew[r] == w[0]).all() and (C2.s[r] == w[1]).all() and mw[r] == w[2][0] and tw[r] == w[3]
+        ref = oracle.rrr_mc_quant(A, J, M, X.fourK, beta, 2000, 100, seed, w[1], replica=r)
+        assert (Er[r] == ref[0]).all() and (C3.s[r] == ref[1]).all() and ar[r] == ref[2]
