@@ -3,15 +3,23 @@
 8192 replicas per MI355X (BASELINE.json configs[1]).
 
   python bench.py --gpus N --steps K --warmup W
+
 One "step" = one sampling call (rrrmc_standard_mc_async) of ITERS iterations for every replica with the
 configuration already resident in HBM; results (energy samples, accepted counts) stay in HBM inside the
-timed region.  For N > 1 launch under torch.distributed.run: one process per GPU, replicas sharded by
-global replica id (no data-path collective; one RCCL all_gather of observables after the timed region).
-Prints ONE JSON line on rank 0.
+timed region.  Replicas are sharded by global replica id, one process per GPU, no data-path collective; the
+only exchange is one all_gather of observables after the timed region (RCCL).
+
+N > 1 runs either way:
+  * under torch.distributed.run (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the environment), or
+  * stand-alone: `python bench.py --gpus N` spawns N fresh rank processes itself (before anything touches the GPU in
+    the parent) and relays rank 0's line.  Fewer than N visible devices is an error, never a silent 1-GPU run.
+Prints ONE JSON line (rank 0).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -27,44 +35,148 @@ ITERS = 1 << 22          # iterations per replica per step (1024 lattice sweeps)
 SAMPLE_STEP = 1 << 12    # energy sample every N iterations
 SEED = 0x5EED
 HBM_PEAK_GBS = 8000.0    # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+PROFILE_DIR = os.path.join(ROOT, "profiles", "r02")
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# stand-alone multi-GPU launcher (the parent never initialises HIP: it only counts devices and spawns children)
+# ----------------------------------------------------------------------------------------------------------------
+def visible_gpu_count():
+    """Devices the rank processes will see, WITHOUT initialising the GPU in this process."""
+    try:
+        import torch
+        return int(torch.cuda.device_count())      # NVML-style count on this image: no HIP context is created
+    except Exception:
+        vis = os.environ.get("HIP_VISIBLE_DEVICES") or os.environ.get("ROCR_VISIBLE_DEVICES")
+        return len([v for v in vis.split(",") if v.strip()]) if vis else 0
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def spawn_ranks(n, argv, child_cmd=None, env_extra=None, timeout=None):
+    """Start n rank processes of this script (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set), wait for all of them and
+    return (exit code, rank 0's stdout).  Other ranks' stdout goes to our stderr.  A failing rank ends the job."""
+    port = free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ)
+        env.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(n), "LOCAL_WORLD_SIZE": str(n),
+                    "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
+        if env_extra:
+            env.update(env_extra)
+        cmd = (child_cmd or [sys.executable, os.path.abspath(__file__)]) + list(argv)
+        procs.append(subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=None, text=True))
+    outs, rc = [""] * n, 0
+    deadline = None if timeout is None else time.time() + timeout
+    try:
+        pending = set(range(n))
+        while pending:
+            for r in sorted(pending):
+                try:
+                    o, _ = procs[r].communicate(timeout=0.2)
+                except subprocess.TimeoutExpired:
+                    continue
+                outs[r] = o or ""
+                pending.discard(r)
+                if procs[r].returncode != 0:
+                    rc = rc or procs[r].returncode
+                    sys.stderr.write("bench.py: rank %d exited with status %d\n" % (r, procs[r].returncode))
+            if rc and pending:               # one rank failed: the others would wait for it at the barrier forever
+                break
+            if deadline is not None and time.time() > deadline:
+                rc = rc or 124
+                sys.stderr.write("bench.py: ranks still running after %.0f s\n" % timeout)
+                break
+    finally:
+        for p in procs:                      # exact PIDs of the children we started
+            if p.poll() is None:
+                p.kill()
+                try:
+                    p.communicate(timeout=10)
+                except Exception:
+                    pass
+    for r in range(1, n):
+        if outs[r].strip():
+            sys.stderr.write("[rank %d stdout] %s\n" % (r, outs[r].strip()))
+    return rc, outs[0]
+
+
+def launch(args, argv):
+    n = args.gpus
+    share = os.environ.get("RRRMC_BENCH_SHARE_GPU") == "1"      # debugging aid: several ranks on one device (forces gloo)
+    have = visible_gpu_count()
+    if have < n and not share:
+        sys.stderr.write("bench.py: --gpus %d requested but only %d GPU(s) are visible; refusing to run a smaller job under that "
+                         "label (RRRMC_BENCH_SHARE_GPU=1 lets ranks share devices for debugging)\n" % (n, have))
+        return 2
+    entry.build_only()                       # compile once, before the ranks start (no GPU use)
+    extra = {"RRRMC_BENCH_BACKEND": "gloo"} if share else None
+    rc, out0 = spawn_ranks(n, argv, env_extra=extra)
+    line = [ln for ln in out0.splitlines() if ln.startswith("{")]
+    if rc != 0 or not line:
+        sys.stderr.write("bench.py: multi-rank run failed (status %d)\n%s\n" % (rc, out0))
+        return rc or 1
+    print(line[-1])
+    return 0
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# CPU baseline (oracle = test infrastructure; used here only as the reported baseline, after the timed region)
+# ----------------------------------------------------------------------------------------------------------------
+def cpu_model_name():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+class pinned_core:
+    """One pinned core, as SURVEY.md §8d prescribes (taskset -c <first allowed core>)."""
+
+    def __enter__(self):
+        self.old, self.core = None, None
+        try:
+            self.old = os.sched_getaffinity(0)
+            self.core = min(self.old)
+            os.sched_setaffinity(0, {self.core})
+        except (AttributeError, OSError):
+            self.core = None
+        return self
+
+    def __exit__(self, *a):
+        if self.old is not None and self.core is not None:
+            try:
+                os.sched_setaffinity(0, self.old)
+            except OSError:
+                pass
 
 
 def cpu_baseline(O, X, seconds_target=15.0):
     """Single-thread CPU oracle (port of the reference loop) on a bounded sample of the same workload."""
     A, J = X.A, X.J.astype(np.int32)
     iters, R = 1 << 22, 1
-    cpu_model = "unknown"
-    try:
-        for line in open("/proc/cpuinfo"):
-            if line.startswith("model name"):
-                cpu_model = line.split(":", 1)[1].strip()
-                break
-    except OSError:
-        pass
-    pinned, old_aff = None, None
-    try:      # one pinned core, as SURVEY.md §8d prescribes (taskset -c <first allowed core>)
-        old_aff = os.sched_getaffinity(0)
-        pinned = min(old_aff)
-        os.sched_setaffinity(0, {pinned})
-    except (AttributeError, OSError):
-        pinned = None
-    ch = O.init_configs(SEED, 0, R, N_SITES)
-    t0 = time.perf_counter()
-    O.standard_mc_sparse_batch(A, J, BETA, iters, SAMPLE_STEP, SEED, ch)
-    dt = time.perf_counter() - t0
-    R = max(1, min(128, int(seconds_target / max(dt, 1e-3))))
-    ch = O.init_configs(SEED, 0, R, N_SITES)
-    t0 = time.perf_counter()
-    O.standard_mc_sparse_batch(A, J, BETA, iters, SAMPLE_STEP, SEED, ch)
-    dt = time.perf_counter() - t0
-    if old_aff is not None and pinned is not None:
-        try:
-            os.sched_setaffinity(0, old_aff)
-        except OSError:
-            pass
+    with pinned_core() as pc:
+        ch = O.init_configs(SEED, 0, R, N_SITES)
+        t0 = time.perf_counter()
+        O.standard_mc_sparse_batch(A, J, BETA, iters, SAMPLE_STEP, SEED, ch)
+        dt = time.perf_counter() - t0
+        R = max(1, min(128, int(seconds_target / max(dt, 1e-3))))
+        ch = O.init_configs(SEED, 0, R, N_SITES)
+        t0 = time.perf_counter()
+        O.standard_mc_sparse_batch(A, J, BETA, iters, SAMPLE_STEP, SEED, ch)
+        dt = time.perf_counter() - t0
     return {"value": R * iters / dt, "unit": "attempts/s", "cores": 1, "kind": "port",
             "sample": "%d replicas x 2^22 iterations of the same graph/beta, single thread, oracle/rrrmc_oracle.c (%.1f s)" % (R, dt),
-            "cpu_model": cpu_model, "host_cores": os.cpu_count(), "pinned_core": pinned}
+            "cpu_model": cpu_model_name(), "host_cores": os.cpu_count(), "pinned_core": pc.core}
 
 
 def device_copy_bandwidth(pkg, device, nbytes=1 << 30, reps=10):
@@ -78,19 +190,139 @@ def device_copy_bandwidth(pkg, device, nbytes=1 << 30, reps=10):
     return out.value
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=6)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--iters", type=int, default=ITERS)
-    ap.add_argument("--replicas", type=int, default=REPLICAS_PER_GPU)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    args = ap.parse_args()
+def load_profile_json(name):
+    p = os.path.join(PROFILE_DIR, name)
+    if os.path.exists(p):
+        try:
+            return json.load(open(p))
+        except ValueError:
+            return None
+    return None
 
+
+# ----------------------------------------------------------------------------------------------------------------
+# secondary configurations (BASELINE.json configs[2..4] at ONE GPU's share), after the headline's timed region
+# ----------------------------------------------------------------------------------------------------------------
+def secondary_c3(pkg, O, device):
+    """configs[2]: GraphSKNormal N=1024, 2048 replicas, standardMC beta=1 (sk_sweep_kernel)."""
+    N, R, beta, iters, step = 1024, 2048, 1.0, 1 << 16, 1 << 10
+    X = pkg.GraphSKNormal(N, seed=SEED)
+    with pkg.Engine(X, R, device=device) as eng:
+        eng.seed(SEED)
+        eng.init_spins_random()
+        eng.standard_mc_async(beta, iters // 8, step); eng.sync()
+        t0 = time.perf_counter()
+        eng.standard_mc_async(beta, iters, step); eng.sync()
+        dt = time.perf_counter() - t0
+        _, k_ms, nl = eng.last_timing()
+        _, acc = eng.fetch_results(want_energies=False)
+    a = float(acc.mean()) / iters
+    bpa = 8 + a * (17 * N + 2)                                   # SURVEY.md §8d, dense SK Float64
+    out = {"workload": "GraphSKNormal(N=1024) standardMC beta=1.0, 2048 replicas, 2^16 iterations per replica", "value": R * iters / dt,
+           "unit": "attempts/s", "kernel": "sk_sweep_kernel", "avg_launch_ms": k_ms / max(nl, 1), "launches": nl, "acceptance": a,
+           "algorithmic_bytes_per_attempt": bpa, "achieved_GBps": bpa * R * iters / (k_ms * 1e-3) / 1e9}
+    out["frac"] = out["achieved_GBps"] / HBM_PEAK_GBS
+    if O is not None:
+        with pinned_core():
+            ch = O.init_configs(SEED, 0, 1, N)[0]
+            it1 = 1 << 13
+            t0 = time.perf_counter()
+            O.standard_mc_skn(X.J, beta, it1, step, SEED, ch)
+            out["cpu_one_core"] = {"value": it1 / (time.perf_counter() - t0), "unit": "attempts/s", "kind": "port",
+                                   "sample": "1 replica x 2^13 iterations, oracle"}
+    return out
+
+
+def secondary_c4(pkg, O, device):
+    """configs[3] at one GPU's share: GraphEA L=64 D=3, 512 of the 4096 replicas, colour-parallel (checkerboard) sweeps."""
+    L, D, R, beta, sweeps, step = 64, 3, 512, 1.0, 256, 16
+    X = pkg.GraphEA(L, D, seed=SEED)
+    with pkg.Engine(X, R, device=device) as eng:
+        eng.seed(SEED)
+        eng.init_spins_random()
+        eng.set_coloring(pkg.checkerboard_coloring(L, D))
+        eng.colored_sweeps_async(beta, 16, 16); eng.sync()
+        t0 = time.perf_counter()
+        eng.colored_sweeps_async(beta, sweeps, step); eng.sync()
+        dt = time.perf_counter() - t0
+        _, dev_ms, nl = eng.last_timing()
+        eng.colored_count_accepted(True)          # acceptance from a short counted call (the timed build does not count)
+        eng.colored_sweeps_async(beta, 16, 16); eng.sync()
+        _, acc = eng.fetch_results(want_energies=False)
+    attempts = float(R) * sweeps * X.N
+    a = float(acc.mean()) / (16 * X.N)
+    bpa = 1 + a * (3 + 3 * X.K)                                  # SURVEY.md §8d: 1 + 21 a for the 6-neighbour lattice
+    out = {"workload": "GraphEA(L=64,D=3,+-J) checkerboard sweeps beta=1.0, 512 replicas (one GPU's share of 4096), 256 sweeps, sample every 16",
+           "value": attempts / dt, "unit": "attempts/s", "kernel": "colored_sweep_kernel<6>", "device_ms": dev_ms, "launches": nl,
+           "acceptance": a, "algorithmic_bytes_per_attempt": bpa, "achieved_GBps": bpa * attempts / (dev_ms * 1e-3) / 1e9}
+    out["frac"] = out["achieved_GBps"] / HBM_PEAK_GBS
+    if O is not None:
+        with pinned_core():
+            ch = O.init_configs(SEED, 0, 1, X.N)[0]
+            t0 = time.perf_counter()
+            O.colored_sweeps_sparse(X.A, X.J.astype(np.int32), pkg.checkerboard_coloring(L, D), beta, 8, 8, SEED, ch)
+            out["cpu_one_core"] = {"value": 8 * X.N / (time.perf_counter() - t0), "unit": "attempts/s", "kind": "port",
+                                   "sample": "1 replica x 8 sweeps, oracle"}
+    return out
+
+
+def secondary_c5(pkg, O, device):
+    """configs[4] at one GPU's share: GraphQuant(GraphRRG(1024,3), M=32) under rrrMC, 128 of the 1024 replicas."""
+    Nk, M, R, beta, Gamma, iters, step = 1024, 32, 128, 2.0, 0.5, 1 << 17, 1 << 12
+    X = pkg.GraphQuant(pkg.GraphRRG(Nk, 3, seed=SEED), M, Gamma, beta)
+    with pkg.Engine(X, R, device=device) as eng:
+        eng.seed(SEED)
+        eng.init_spins_random()
+        eng.rrr_mc(beta, iters // 8, step, want_energies=False)
+        t0 = time.perf_counter()
+        _, acc, staged = eng.rrr_mc(beta, iters, step, want_energies=False)
+        dt = time.perf_counter() - t0
+        _, k_ms, nl = eng.last_timing()
+    a = float(acc.mean()) / iters
+    out = {"workload": "GraphQuant(GraphRRG(1024,3), M=32, Gamma=0.5) rrrMC beta=2.0, 128 replicas (one GPU's share of 1024), 2^17 iterations per replica",
+           "value": R * iters / dt, "unit": "iterations/s", "kernel": eng_kernel_name_quant(), "avg_launch_ms": k_ms / max(nl, 1),
+           "launches": nl, "acceptance": a, "staged_frac": float(staged.mean()) / iters}
+    # SURVEY.md §8d: ~ 6 + a' (12 + 8 + 40 q) bytes per iteration, q = fraction of neighbours changing class (not measured: q = 1 bound)
+    bpa_lo, bpa_hi = 6 + a * (12 + 8), 6 + a * (12 + 8 + 40)
+    out["algorithmic_bytes_per_iteration_range"] = [bpa_lo, bpa_hi]
+    out["achieved_GBps_range"] = [b * R * iters / (k_ms * 1e-3) / 1e9 for b in (bpa_lo, bpa_hi)]
+    out["frac"] = out["achieved_GBps_range"][1] / HBM_PEAK_GBS
+    if O is not None:
+        with pinned_core():
+            ch = O.init_configs(SEED, 0, 1, X.N)[0]
+            it1 = 1 << 20
+            t0 = time.perf_counter()
+            O.rrr_mc_quant(X.X1.A, X.X1.J.astype(np.int32), M, X.fourK, beta, it1, step, SEED, ch)
+            out["cpu_one_core"] = {"value": it1 / (time.perf_counter() - t0), "unit": "iterations/s", "kind": "port",
+                                   "sample": "1 replica x 2^20 iterations, oracle"}
+    return out
+
+
+def eng_kernel_name_quant():
+    return "rrr_quant_wave_kernel" if os.environ.get("RRRMC_QUANT_NO_WAVE") != "1" else "rrr_quant_kernel<true>"
+
+
+def secondary(pkg, O, device):
+    out = {}
+    for name, fn in (("c3_sk_normal", secondary_c3), ("c4_ea_checkerboard", secondary_c4), ("c5_quant_rrr", secondary_c5)):
+        t0 = time.perf_counter()
+        try:
+            out[name] = fn(pkg, O, device)
+            out[name]["wall_s"] = time.perf_counter() - t0
+        except Exception as e:      # a secondary figure never hides the headline line
+            out[name] = {"error": repr(e)}
+    return out
+
+
+# ----------------------------------------------------------------------------------------------------------------
+def run_rank(args):
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world:
+        sys.stderr.write("bench.py: --gpus %d but WORLD_SIZE=%d: the job has %d rank(s) (one per GPU)\n" % (args.gpus, world, world))
+        if rank == 0 and args.gpus > world:
+            return 2
     dist = None
     # RRRMC_BENCH_BACKEND=gloo is a debugging aid only: it lets several ranks share one GPU (RCCL refuses that) so that the
     # multi-rank code path can be exercised on a 1-GPU box; the driver's multi-GPU runs use the default, RCCL ("nccl").
@@ -100,6 +332,9 @@ def main():
         import torch
         import torch.distributed as dist
         if backend == "nccl":
+            if torch.cuda.device_count() <= local_rank:
+                sys.stderr.write("bench.py: rank %d has no device %d (%d visible)\n" % (rank, local_rank, torch.cuda.device_count()))
+                return 2
             torch.cuda.set_device(local_rank)
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
@@ -108,8 +343,15 @@ def main():
             dist.init_process_group(backend)
     n_gpus = world
 
-    entry.build() if rank == 0 and not os.path.exists(os.path.join(ROOT, "rrrmc.jl_amd", "lib", "librrrmc_hip.so")) else None
+    # rank 0 (re)builds if the in-tree library is stale, everybody else waits for it
+    if rank == 0:
+        entry.build_only()
+    if dist is not None:
+        dist.barrier()
     pkg = entry.load_package()
+    if pkg.lib().rrrmc_device_count() <= local_rank:
+        sys.stderr.write("bench.py: device %d is not visible to the HIP library\n" % local_rank)
+        return 2
     X = pkg.GraphRRG(N_SITES, K_DEG, seed=SEED)
     R = args.replicas
     r0, r_local = pkg.shard_bounds(R * world, world, rank)      # weak scaling: R replicas per GPU, ids 0 .. R*world-1
@@ -128,19 +370,24 @@ def main():
     for _ in range(args.warmup):
         eng.standard_mc_async(BETA, args.iters, SAMPLE_STEP)
     barrier()
-    sweep_ms, launches = 0.0, 0
+    eng.timing_accumulate(True)          # one HIP-event pair per sweep launch of the timed region, read after it (no sync inside)
+    barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         eng.standard_mc_async(BETA, args.iters, SAMPLE_STEP)
-        if args.steps <= 64:      # HIP-event bookkeeping of each call (forces that call's completion)
-            _, s, n = eng.last_timing()
-            sweep_ms += s
-            launches += n
     barrier()
-    dt = time.perf_counter() - t0
+    dt_local = time.perf_counter() - t0
+    dt = dt_local
+    sweep_ms, launches = eng.timing_total()
+    eng.timing_accumulate(False)
+    per_rank_ms = [1e3 * dt_local / max(args.steps, 1)]
     if dist is not None:
         import torch
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+        dev = "cuda" if backend == "nccl" else "cpu"
+        t = torch.tensor([dt_local], dtype=torch.float64, device=dev)
+        ts = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(ts, t)
+        per_rank_ms = [1e3 * float(x.item()) / max(args.steps, 1) for x in ts]
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
@@ -162,7 +409,8 @@ def main():
         out = {
             "metric": "spin-flip attempts/sec (whole node), GraphRRG N=4096 K=3 +-J standardMC beta=1.0",
             "value": value, "unit": "attempts/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": 1e3 * dt / max(args.steps, 1), "ms_per_step_per_rank": per_rank_ms,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u32", "data": "synthetic",
             "config": {"workload": "GraphRRG(N=4096,K=3,+-J) standardMC beta=1.0, %d replicas per GPU, %d iterations per replica per step, energy sample every %d"
                                    % (R, args.iters, SAMPLE_STEP),
@@ -173,29 +421,68 @@ def main():
             per_launch_attempts = float(R) * args.iters * args.steps / launches
             avg_ms = sweep_ms / launches
             achieved = bytes_per_attempt * per_launch_attempts / (avg_ms * 1e-3) / 1e9
-            traffic = None     # HBM bytes per sweep launch from the committed PMC passes (same workload), if present
-            tf = os.path.join(ROOT, "profiles", "r01", "traffic.json")
-            if os.path.exists(tf) and R == REPLICAS_PER_GPU and args.iters == ITERS:
-                traffic = json.load(open(tf))["hbm_bytes_per_launch"]
-            out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                               "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                               "algorithmic_bytes_per_launch": bytes_per_attempt * per_launch_attempts,
-                               "kernel": "sweep_kernel<3, 1>", "avg_launch_ms": avg_ms, "launches": launches,
-                               "algorithmic_bytes_per_attempt": bytes_per_attempt}
+            default_shape = R == REPLICAS_PER_GPU and args.iters == ITERS
+            tf = load_profile_json("traffic.json") if default_shape else None
+            vm = load_profile_json("valu_model.json") if default_shape else None
+            roof = {
+                # The replica state never leaves LDS, so the kernel is bound by VALU issue, not by HBM: `achieved` / `frac` are the
+                # SURVEY.md §8d fixed-width ALGORITHMIC bytes over the kernel time (a throughput normalisation against the 8 TB/s
+                # the north star names), `traffic` is what really crosses HBM, and `valu` is the roofline that binds.
+                "bound": "valu", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                "achieved_is": "algorithmic bytes (SURVEY.md §8d: 1 + a(3+3K) per attempt) / kernel time — not measured traffic",
+                "traffic": tf["hbm_bytes_per_launch"] if tf else None,
+                "traffic_source": ("profiles/r02/traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE of this workload, committed; "
+                                   "not measured in this run)") if tf else None,
+                "algorithmic_bytes_per_launch": bytes_per_attempt * per_launch_attempts,
+                "kernel": "sweep_kernel<3, 1>", "avg_launch_ms": avg_ms, "launches": int(launches),
+                "algorithmic_bytes_per_attempt": bytes_per_attempt}
+            if vm:
+                # cycle-weighted VALU utilisation: wave-instructions per launch (PMC, committed) x the mean issue cost of the
+                # kernel's instruction mix (ISA histogram x tools/ubench/valu_rates.hip) over SIMDs x kernel cycles of THIS run
+                cyc = avg_ms * 1e-3 * vm["clock_hz"]
+                roof["valu"] = {"wave_insts_per_launch": vm["valu_insts_per_launch"], "mean_issue_cycles": vm["mean_issue_cycles"],
+                                "simds": vm["simds"], "clock_hz": vm["clock_hz"], "kernel_cycles": cyc,
+                                "achieved": vm["valu_insts_per_launch"] * vm["mean_issue_cycles"] / cyc, "peak": vm["simds"],
+                                "unit": "busy SIMDs", "frac": vm["valu_insts_per_launch"] * vm["mean_issue_cycles"] / (vm["simds"] * cyc),
+                                "source": "profiles/r02/valu_model.json (SQ_INSTS_VALU per launch, ISA histogram, ubench issue costs; committed)"}
+            out["roofline"] = roof
             try:      # after the timed region: the box's own copy bandwidth, for reference only (peak stays the nominal figure)
                 bw = device_copy_bandwidth(pkg, local_rank)
-                out["roofline"]["measured_copy_GBps"] = bw
-                out["roofline"]["frac_of_measured_copy"] = achieved / bw
+                roof["measured_copy_GBps"] = bw
             except Exception as e:      # never let the side measurement hide the bench line
-                out["roofline"]["measured_copy_GBps"] = None
+                roof["measured_copy_GBps"] = None
                 sys.stderr.write("device copy bandwidth not measured: %r\n" % (e,))
-        if not args.no_cpu_baseline and world == 1:      # reported at N = 1 only (rank 0's host cores)
-            out["cpu_baseline"] = cpu_baseline(entry.load_oracle(), X)
-        print(json.dumps(out))
     eng.close()
+    if rank == 0:
+        if world == 1 and not args.no_cpu_baseline:      # reported at N = 1 only (rank 0's host cores)
+            O = entry.load_oracle()
+            out["cpu_baseline"] = cpu_baseline(O, X)
+        if world == 1 and not args.no_secondary:
+            out["secondary"] = secondary(pkg, None if args.no_cpu_baseline else entry.load_oracle(), local_rank)
+        print(json.dumps(out))
+        sys.stdout.flush()
     if dist is not None:
+        dist.barrier()
         dist.destroy_process_group()
+    return 0
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)       # 200 x 9.8 ms: a timed region of ~2 s
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--iters", type=int, default=ITERS)
+    ap.add_argument("--replicas", type=int, default=REPLICAS_PER_GPU)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true")
+    args = ap.parse_args()
+    if args.gpus < 1:
+        ap.error("--gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return launch(args, sys.argv[1:])
+    return run_rank(args)
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -137,6 +137,9 @@ RRRMC_API int32_t rrrmc_fetch_results(rrrmc_ctx *ctx, int64_t *Es_out, int64_t *
  *   is not tracked by this sampler and reads -1). */
 RRRMC_API int32_t rrrmc_set_coloring(rrrmc_ctx *ctx, const int32_t *color, int32_t ncolors);
 RRRMC_API int32_t rrrmc_colored_sweeps_async(rrrmc_ctx *ctx, double beta, int64_t sweeps, int64_t step);
+/* on != 0: the colour sweeps also count every replica's accepted moves (fetched like standardMC's accepted counts; a few per cent
+ * slower: one 32x32 bit transpose per wavefront and site).  Default off: accepted_out reads -1 after a colour-sweep call. */
+RRRMC_API int32_t rrrmc_colored_count_accepted(rrrmc_ctx *ctx, int32_t on);
 
 /* ---- Float64-energy models (RRRMC_MODEL_SK_NORMAL): ET = Float64 (src/graphs/SK.jl:181) --------------------
  * Dense couplings J[N*N] row-major; must be symmetric with a zero diagonal (GraphSKNormal(J; check=true),
@@ -223,6 +226,12 @@ RRRMC_API int32_t rrrmc_rrr_cache(rrrmc_ctx *ctx, int8_t *pos_out, int32_t *size
  *   total_ms   first planner launch -> last sweep kernel end
  *   sweep_ms   sum of the sweep (dominant) kernel's durations,  sweep_launches = how many launches */
 RRRMC_API int32_t rrrmc_last_timing(rrrmc_ctx *ctx, double *total_ms, double *sweep_ms, int32_t *sweep_launches);
+/* Accumulated kernel timing over MANY queued async calls (RRRMC_MODEL_SPARSE_PM1 standardMC): rrrmc_timing_accumulate(ctx, 1)
+ * gives every sweep launch of every following sampling call its own HIP-event pair (both calls synchronise the stream; the
+ * sampling calls in between stay asynchronous); rrrmc_timing_total returns the summed duration of those launches and their count.
+ * rrrmc_timing_accumulate(ctx, 0) returns to the per-call bookkeeping of rrrmc_last_timing. */
+RRRMC_API int32_t rrrmc_timing_accumulate(rrrmc_ctx *ctx, int32_t on);
+RRRMC_API int32_t rrrmc_timing_total(rrrmc_ctx *ctx, double *sweep_ms, int64_t *sweep_launches);
 
 /* Iterations consumed from the current seed's streams so far. */
 RRRMC_API int64_t rrrmc_iterations_done(const rrrmc_ctx *ctx);

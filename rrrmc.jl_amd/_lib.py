@@ -19,10 +19,10 @@ SYMBOLS = [
     "rrrmc_version", "rrrmc_last_error", "rrrmc_device_count", "rrrmc_device_copy_bandwidth", "rrrmc_ctx_create", "rrrmc_ctx_destroy",
     "rrrmc_set_graph", "rrrmc_seed", "rrrmc_init_spins_random", "rrrmc_set_spins", "rrrmc_get_spins",
     "rrrmc_energy", "rrrmc_get_fields", "rrrmc_standard_mc", "rrrmc_standard_mc_async", "rrrmc_sync",
-    "rrrmc_fetch_results", "rrrmc_last_timing", "rrrmc_iterations_done", "rrrmc_gen_rrg", "rrrmc_gen_ea",
+    "rrrmc_fetch_results", "rrrmc_last_timing", "rrrmc_timing_accumulate", "rrrmc_timing_total", "rrrmc_iterations_done", "rrrmc_gen_rrg", "rrrmc_gen_ea",
     "rrrmc_gen_couplings_pm1", "rrrmc_gen_couplings_lev", "rrrmc_set_graph_levels", "rrrmc_set_couplings_dense", "rrrmc_energy_f64", "rrrmc_get_fields_f64",
     "rrrmc_standard_mc_f64", "rrrmc_fetch_results_f64", "rrrmc_gen_sk_gauss",
-    "rrrmc_set_couplings_bits", "rrrmc_gen_sk_binary", "rrrmc_set_coloring", "rrrmc_colored_sweeps_async",
+    "rrrmc_set_couplings_bits", "rrrmc_gen_sk_binary", "rrrmc_set_coloring", "rrrmc_colored_sweeps_async", "rrrmc_colored_count_accepted",
     "rrrmc_ctx_create_quant", "rrrmc_ctx_create_quant_sk", "rrrmc_quant_set_field", "rrrmc_rrr_mc_async", "rrrmc_rrr_stats", "rrrmc_rrr_cache", "rrrmc_bkl_mc_async",
     "rrrmc_snapshot_reserve", "rrrmc_snapshot_store", "rrrmc_snapshot_get", "rrrmc_overlaps", "rrrmc_quant_observables",
     "rrrmc_set_graph_f64", "rrrmc_gen_couplings_gauss", "rrrmc_set_graph_discretized", "rrrmc_set_level_scale", "rrrmc_discretize", "rrrmc_discretize_scaled", "rrrmc_wtm_mc_async", "rrrmc_wtm_times", "rrrmc_extremal_opt_async", "rrrmc_extremal_opt_results", "rrrmc_extremal_opt_results_f64",
@@ -88,6 +88,10 @@ def lib():
     L.rrrmc_fetch_results.argtypes = [vp, vp, vp]
     L.rrrmc_last_timing.restype = C.c_int32
     L.rrrmc_last_timing.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int32)]
+    L.rrrmc_timing_accumulate.restype = C.c_int32
+    L.rrrmc_timing_accumulate.argtypes = [vp, C.c_int32]
+    L.rrrmc_timing_total.restype = C.c_int32
+    L.rrrmc_timing_total.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
     L.rrrmc_iterations_done.restype = C.c_int64
     L.rrrmc_iterations_done.argtypes = [vp]
     L.rrrmc_gen_rrg.restype = C.c_int32
@@ -126,6 +130,8 @@ def lib():
     L.rrrmc_rrr_cache.argtypes = [vp, vp, vp]
     L.rrrmc_set_coloring.restype = C.c_int32
     L.rrrmc_set_coloring.argtypes = [vp, i32p, C.c_int32]
+    L.rrrmc_colored_count_accepted.restype = C.c_int32
+    L.rrrmc_colored_count_accepted.argtypes = [vp, C.c_int32]
     L.rrrmc_colored_sweeps_async.restype = C.c_int32
     L.rrrmc_colored_sweeps_async.argtypes = [vp, C.c_double, C.c_int64, C.c_int64]
     L.rrrmc_set_couplings_bits.restype = C.c_int32

@@ -38,7 +38,7 @@ inline size_t plan_big_lds_bytes(int K)
 template <int K>
 __global__ __launch_bounds__(kPlanThreads) void plan_big_kernel(ChunkDesc* __restrict__ chunks, uint32_t* __restrict__ slots,
                                                                 uint32_t* __restrict__ vecs, const int32_t* __restrict__ A,
-                                                                int N, uint32_t k0, uint32_t k1)
+                                                                int N, uint32_t k0, uint32_t k1, uint64_t gbase)
 {
     extern __shared__ uint32_t pb_lds[];
     uint32_t* s_key = pb_lds;                                            // [kBigChunk]   site << 12 | t, sorted
@@ -59,7 +59,7 @@ __global__ __launch_bounds__(kPlanThreads) void plan_big_kernel(ChunkDesc* __res
     for (int t = tid; t < cp; t += kPlanThreads) {
         uint32_t key = 0xffffffffu;
         if (t < count) {
-            const uint32_t site = site_of(k0, k1, cd.g0 + (uint64_t)t, (uint32_t)N);
+            const uint32_t site = site_of(k0, k1, gbase + cd.g0 + (uint64_t)t, (uint32_t)N);
             s_site[t] = site;
             s_lvl[t] = 1;
             key = (site << 12) | (uint32_t)t;
@@ -158,6 +158,7 @@ struct BigSweepParams {
     uint32_t always_mask;
     uint32_t k0, k1, group0;
     int64_t sample0;
+    uint64_t gbase;           // iterations done before this sampling call (ChunkDesc::g0 is relative to it)
     int N, Rpad, nchunks;
 };
 
@@ -184,7 +185,7 @@ __global__ __launch_bounds__(kBigThreads) void big_sweep_kernel(BigSweepParams P
             for (uint32_t p = start + (uint32_t)tid; p < end; p += kBigThreads) {
                 const uint32_t slot = P.slots[cd.slot_base + p];
                 const uint32_t site = slot & ((1u << kBigSiteBits) - 1u);
-                const uint64_t g = cd.g0 + (uint64_t)(slot >> kBigSiteBits);
+                const uint64_t g = P.gbase + cd.g0 + (uint64_t)(slot >> kBigSiteBits);
                 const uint32_t s = gsp[site];
                 // n = number of unsatisfied bonds, bit-sliced (three planes cover K <= 7)
                 uint32_t n0 = 0u, n1 = 0u, n2 = 0u;

@@ -14,6 +14,7 @@
 #include <string>
 #include <map>
 #include <mutex>
+#include <utility>
 #include <vector>
 
 #include "sk_kernels.hpp"
@@ -65,8 +66,16 @@ struct rrrmc_ctx {
     // plan buffers
     ChunkDesc* d_chunks = nullptr;
     size_t chunks_cap = 0;
-    ChunkDesc* h_chunks = nullptr; // pinned
+    ChunkDesc* h_chunks = nullptr; // pinned staging buffer of the chunk list
     size_t h_chunks_cap = 0;
+    // the chunk list is call-relative (ChunkDesc::g0), i.e. a function of (iters, step, C) only: the list on the device is kept
+    // across calls of the same shape, and the pinned buffer is rewritten only after its last upload has completed (ev_upload)
+    int64_t chunks_iters = -1, chunks_step = -1;
+    int chunks_C = -1;
+    size_t chunks_n = 0;
+    bool upload_pending = false;
+    struct BatchDesc { size_t first, n; int64_t sample0; };
+    std::vector<BatchDesc> chunk_batches;
     uint32_t* d_slots[2] = {nullptr, nullptr};   // double-buffered: the planner of batch b+1 overlaps the sweep of batch b
     uint32_t* d_vecs[2] = {nullptr, nullptr};
     hipStream_t plan_stream = nullptr;
@@ -85,6 +94,13 @@ struct rrrmc_ctx {
     std::vector<hipEvent_t> ev_sweep;   // pairs
     int sweep_launches = 0;
     bool timing_valid = false;
+    // accumulation mode (rrrmc_timing_accumulate): every sweep launch of every sampling call gets its own event pair from a growing
+    // pool, so that a caller can queue many async calls and read the summed kernel time afterwards without a sync per call
+    bool acc_mode = false;
+    std::vector<hipEvent_t> ev_pool;
+    size_t ev_pool_used = 0;
+    size_t last_ev_base = 0;            // first event of the last call's sweeps (in ev_pool when last_ev_pool, else ev_sweep)
+    bool last_ev_pool = false;
 
     // ---- colour-parallel sweeps (any sparse ctx; the only sampler when lds_mode is false) ----
     bool lds_mode = true;               // the LDS-resident random-site kernel is available (the state fits the 160 KiB LDS)
@@ -98,6 +114,7 @@ struct rrrmc_ctx {
     uint64_t sweeps_done = 0;
     std::vector<int32_t> h_A;           // host copy of the neighbour table (colouring check)
     bool colored_call = false;          // the last sampling call was a colored-sweep call
+    bool color_count_acc = false;       // colour sweeps also count every replica's accepted moves (rrrmc_colored_count_accepted)
     // ---- RRRMC_MODEL_SK_NORMAL ----
     double* sk_J = nullptr;        // [N][N]
     double* sk_lf = nullptr;       // [G8][N][8]
@@ -245,10 +262,10 @@ uint64_t threshold64(double p, bool* always)
     switch (k) { case 1: return F<1>; case 2: return F<2>; case 3: return F<3>; case 4: return F<4>; case 5: return F<5>;   \
                  case 6: return F<6>; case 7: return F<7>; case 8: return F<8>; default: return nullptr; }
 
-typedef void (*plan_fn)(ChunkDesc*, uint32_t*, uint32_t*, const int32_t*, int, int, uint32_t, uint32_t);
+typedef void (*plan_fn)(ChunkDesc*, uint32_t*, uint32_t*, const int32_t*, int, int, uint32_t, uint32_t, uint64_t);
 plan_fn plan_for_K(int K) { RRRMC_DISPATCH_UPTO7(K, plan_kernel) }
 
-typedef void (*plan_big_fn)(ChunkDesc*, uint32_t*, uint32_t*, const int32_t*, int, uint32_t, uint32_t);
+typedef void (*plan_big_fn)(ChunkDesc*, uint32_t*, uint32_t*, const int32_t*, int, uint32_t, uint32_t, uint64_t);
 plan_big_fn plan_big_for_K(int K) { RRRMC_DISPATCH_UPTO7(K, plan_big_kernel) }
 typedef void (*big_sweep_fn)(BigSweepParams);
 big_sweep_fn big_sweep_for_K(int K) { RRRMC_DISPATCH_UPTO7(K, big_sweep_kernel) }
@@ -303,14 +320,19 @@ inline unsigned rrr_blocks(int64_t R) { const unsigned t = rrr_tpb(R); return (u
 // models whose device spins are R x W 32-bit words in BitVector order (q_spins, qW)
 // The dynamic-LDS bound is an attribute of the KERNEL, not of a context: contexts of different sizes share it, so it is only ever
 // raised (a later, smaller context must not lower it under an earlier one).
+// hipFuncSetAttribute acts on the CURRENT device's copy of the kernel, so the bound is tracked per (device, kernel): a process
+// with one context per device raises it on each of them.  Callers have made the context's device current.
 hipError_t raise_lds_attr(const void* fn, size_t bytes)
 {
     static std::mutex mu;
-    static std::map<const void*, size_t> cur;
+    static std::map<std::pair<int, const void*>, size_t> cur;
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
     std::lock_guard<std::mutex> lock(mu);
-    size_t& have = cur[fn];
+    size_t& have = cur[std::make_pair(dev, fn)];
     if (bytes <= have) return hipSuccess;
-    const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
     if (e == hipSuccess) have = bytes;
     return e;
 }
@@ -331,7 +353,17 @@ int32_t ensure_state(rrrmc_ctx* ctx, bool need_spins)
 typedef void (*ebs_fn)(const uint32_t*, const int32_t*, const int8_t*, int, uint32_t*);
 ebs_fn energy_bs_for_K(int K) { RRRMC_DISPATCH_UPTO7(K, energy_bs_kernel) }
 typedef void (*csweep_fn)(ColorSweepParams);
-csweep_fn csweep_for_K(int K) { RRRMC_DISPATCH_UPTO7(K, colored_sweep_kernel) }
+csweep_fn csweep_for_K(int K, bool count)
+{
+    if (count) {
+        switch (K) { case 1: return colored_sweep_kernel<1, true>; case 2: return colored_sweep_kernel<2, true>; case 3: return colored_sweep_kernel<3, true>;
+                     case 4: return colored_sweep_kernel<4, true>; case 5: return colored_sweep_kernel<5, true>; case 6: return colored_sweep_kernel<6, true>;
+                     case 7: return colored_sweep_kernel<7, true>; default: return nullptr; }
+    }
+    switch (K) { case 1: return colored_sweep_kernel<1, false>; case 2: return colored_sweep_kernel<2, false>; case 3: return colored_sweep_kernel<3, false>;
+                 case 4: return colored_sweep_kernel<4, false>; case 5: return colored_sweep_kernel<5, false>; case 6: return colored_sweep_kernel<6, false>;
+                 case 7: return colored_sweep_kernel<7, false>; default: return nullptr; }
+}
 
 // bit-sliced energy of every replica into d_E (and, optionally, one row of the sample buffer)
 int32_t run_energy_bs(rrrmc_ctx* ctx, int32_t* es_row)
@@ -552,6 +584,7 @@ void rrrmc_ctx_destroy(rrrmc_ctx* ctx)
     if (ctx->ev_upload) (void)hipEventDestroy(ctx->ev_upload);
     for (hipEvent_t e : ctx->ev_plan) (void)hipEventDestroy(e);
     if (ctx->h_chunks) (void)hipHostFree(ctx->h_chunks);
+    for (hipEvent_t e : ctx->ev_pool) (void)hipEventDestroy(e);
     for (hipEvent_t e : ctx->ev_sweep) (void)hipEventDestroy(e);
     if (ctx->ev_begin) (void)hipEventDestroy(ctx->ev_begin);
     if (ctx->ev_end) (void)hipEventDestroy(ctx->ev_end);
@@ -884,72 +917,86 @@ int32_t rrrmc_standard_mc_async(rrrmc_ctx* ctx, double beta, int64_t iters, int6
         for (int plane = 0; plane < 64; ++plane) P.taum[plane * 4 + n] = ((T >> (63 - plane)) & 1ull) ? ~0u : 0u;
     }
 
-    // chunk list: cuts at every multiple of `step` (a sample precedes the move of iteration k*step) and every C moves
+    // chunk list: cuts at every multiple of `step` (a sample precedes the move of iteration k*step) and every C moves.
+    // ChunkDesc::g0 is relative to the call (the kernels add gbase = it_done), so the list depends on (iters, step, C) only:
+    // back-to-back calls of one shape reuse the list already on the device.  A new shape rewrites the pinned staging buffer —
+    // only after the previous upload from it has completed (several async calls may be queued behind each other).
     const int64_t nsamp = iters / step;
-    std::vector<ChunkDesc> chunks;
-    chunks.reserve((size_t)(iters / C + nsamp + 2));
-    // Every step of the sweep kernel costs about a microsecond whatever its chunk holds, so the iterations between two cuts
-    // (sample points, the end of the call) are divided into the FEWEST chunks of at most C and those are made equally long
-    for (int64_t cur = 1; cur <= iters;) {
-        const int64_t next_sample = (cur / step + 1) * step;
-        int64_t seg_end = next_sample;                        // exclusive end of the segment that may be chunked freely
-        if (seg_end > iters + 1) seg_end = iters + 1;
-        const int64_t seg = seg_end - cur, nch = (seg + C - 1) / C;
-        int64_t end = cur + (seg + nch - 1) / nch;            // ceil(seg / nch) <= C: the remaining chunks re-balance themselves
-        if (end > seg_end) end = seg_end;
-        ChunkDesc cd{};
-        cd.g0 = ctx->it_done + (uint64_t)cur;
-        cd.count = (uint32_t)(end - cur);
-        cd.flags = (cur % step == 0) ? kChunkSampleBefore : 0u;
-        chunks.push_back(cd);
-        cur = end;
+    const bool reuse = ctx->chunks_iters == iters && ctx->chunks_step == step && ctx->chunks_C == C;
+    if (!reuse) {
+        std::vector<ChunkDesc> chunks;
+        chunks.reserve((size_t)(iters / C + nsamp + 2));
+        // Every step of the sweep kernel costs about a microsecond whatever its chunk holds, so the iterations between two cuts
+        // (sample points, the end of the call) are divided into the FEWEST chunks of at most C and those are made equally long
+        for (int64_t cur = 1; cur <= iters;) {
+            const int64_t next_sample = (cur / step + 1) * step;
+            int64_t seg_end = next_sample;                        // exclusive end of the segment that may be chunked freely
+            if (seg_end > iters + 1) seg_end = iters + 1;
+            const int64_t seg = seg_end - cur, nch = (seg + C - 1) / C;
+            int64_t end = cur + (seg + nch - 1) / nch;            // ceil(seg / nch) <= C: the remaining chunks re-balance themselves
+            if (end > seg_end) end = seg_end;
+            ChunkDesc cd{};
+            cd.g0 = (uint64_t)cur;
+            cd.count = (uint32_t)(end - cur);
+            cd.flags = (cur % step == 0) ? kChunkSampleBefore : 0u;
+            chunks.push_back(cd);
+            cur = end;
+        }
+        const size_t nch_all = chunks.size();
+        // batches: bounded by the plan buffers; slot_base restarts in every batch
+        ctx->chunk_batches.clear();
+        {
+            size_t first = 0;
+            int64_t slots = 0, samples = 0, sample0 = 0;
+            for (size_t c = 0; c < nch_all; ++c) {
+                if (c > first && (slots + chunks[c].count > kMaxSlotsPerBatch || (int64_t)(c - first) >= kMaxChunksPerBatch)) {
+                    ctx->chunk_batches.push_back({first, c - first, sample0});
+                    first = c; slots = 0; sample0 = samples;
+                }
+                chunks[c].slot_base = (uint32_t)slots;
+                slots += chunks[c].count;
+                if (chunks[c].flags & kChunkSampleBefore) samples += 1;
+            }
+            if (nch_all > first) ctx->chunk_batches.push_back({first, nch_all - first, sample0});
+        }
+        ctx->chunks_iters = -1;                                   // invalid until the new list is staged
+        if (ctx->upload_pending) { HIP_TRY(ctx, hipEventSynchronize(ctx->ev_upload)); ctx->upload_pending = false; }
+        if (nch_all > ctx->chunks_cap) {
+            // the device list may still be read by queued launches of earlier calls
+            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+            HIP_TRY(ctx, hipStreamSynchronize(ctx->plan_stream));
+            free_dev(ctx->d_chunks);
+            ctx->chunks_cap = 0;
+            HIP_TRY(ctx, hipMalloc(&ctx->d_chunks, sizeof(ChunkDesc) * nch_all));
+            ctx->chunks_cap = nch_all;
+        }
+        if (nch_all > ctx->h_chunks_cap) {
+            if (ctx->h_chunks) { (void)hipHostFree(ctx->h_chunks); ctx->h_chunks = nullptr; }
+            ctx->h_chunks_cap = 0;
+            HIP_TRY(ctx, hipHostMalloc(&ctx->h_chunks, sizeof(ChunkDesc) * nch_all));
+            ctx->h_chunks_cap = nch_all;
+        }
+        if (nch_all) std::memcpy(ctx->h_chunks, chunks.data(), sizeof(ChunkDesc) * nch_all);
+        ctx->chunks_n = nch_all;
     }
-    const size_t nchunks = chunks.size();
+    const size_t nchunks = ctx->chunks_n;
+    const std::vector<rrrmc_ctx::BatchDesc>& batches = ctx->chunk_batches;
 
-    // (re)allocate chunk and sample buffers
-    if (nchunks > ctx->chunks_cap) {
-        free_dev(ctx->d_chunks);
-        ctx->chunks_cap = 0;
-        HIP_TRY(ctx, hipMalloc(&ctx->d_chunks, sizeof(ChunkDesc) * nchunks));
-        ctx->chunks_cap = nchunks;
-    }
-    if (nchunks > ctx->h_chunks_cap) {
-        if (ctx->h_chunks) { (void)hipHostFree(ctx->h_chunks); ctx->h_chunks = nullptr; }
-        ctx->h_chunks_cap = 0;
-        HIP_TRY(ctx, hipHostMalloc(&ctx->h_chunks, sizeof(ChunkDesc) * nchunks));
-        ctx->h_chunks_cap = nchunks;
-    }
     const size_t es_need = (size_t)(nsamp > 0 ? nsamp : 1) * ctx->Rpad;
     if (es_need > ctx->Es_cap) {
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));          // queued launches of earlier calls still write the old buffer
         free_dev(ctx->d_Es);
         ctx->Es_cap = 0;
         HIP_TRY(ctx, hipMalloc(&ctx->d_Es, sizeof(int32_t) * es_need));
         ctx->Es_cap = es_need;
     }
 
-    // batches: bounded by the plan buffers; slot_base restarts in every batch
-    struct Batch { size_t first, n; int64_t sample0; };
-    std::vector<Batch> batches;
-    {
-        size_t first = 0;
-        int64_t slots = 0, samples = 0, sample0 = 0;
-        for (size_t c = 0; c < nchunks; ++c) {
-            if (c > first && (slots + chunks[c].count > kMaxSlotsPerBatch || (int64_t)(c - first) >= kMaxChunksPerBatch)) {
-                batches.push_back({first, c - first, sample0});
-                first = c; slots = 0; sample0 = samples;
-            }
-            chunks[c].slot_base = (uint32_t)slots;
-            slots += chunks[c].count;
-            if (chunks[c].flags & kChunkSampleBefore) samples += 1;
-        }
-        if (nchunks > first) batches.push_back({first, nchunks - first, sample0});
-    }
-    if (nchunks) std::memcpy(ctx->h_chunks, chunks.data(), sizeof(ChunkDesc) * nchunks);
-
-    while (ctx->ev_sweep.size() < 2 * batches.size()) {
+    std::vector<hipEvent_t>& EV = ctx->acc_mode ? ctx->ev_pool : ctx->ev_sweep;
+    const size_t ebase = ctx->acc_mode ? ctx->ev_pool_used : 0;
+    while (EV.size() < ebase + 2 * batches.size()) {
         hipEvent_t e;
         HIP_TRY(ctx, hipEventCreate(&e));
-        ctx->ev_sweep.push_back(e);
+        EV.push_back(e);
     }
     while (ctx->ev_plan.size() < batches.size()) {
         hipEvent_t e;
@@ -963,7 +1010,12 @@ int32_t rrrmc_standard_mc_async(rrrmc_ctx* ctx, double beta, int64_t iters, int6
     rc = run_energy(ctx, nullptr);
     if (rc) return rc;
     HIP_TRY(ctx, hipMemsetAsync(ctx->d_acc, 0, sizeof(int64_t) * ctx->Rpad, st));
-    if (nchunks) HIP_TRY(ctx, hipMemcpyAsync(ctx->d_chunks, ctx->h_chunks, sizeof(ChunkDesc) * nchunks, hipMemcpyHostToDevice, st));
+    if (!reuse) {
+        if (nchunks) HIP_TRY(ctx, hipMemcpyAsync(ctx->d_chunks, ctx->h_chunks, sizeof(ChunkDesc) * nchunks, hipMemcpyHostToDevice, st));
+        ctx->chunks_iters = iters; ctx->chunks_step = step; ctx->chunks_C = C;
+        ctx->upload_pending = true;
+    }
+    // recorded in every call: orders this call's planner behind the previous call's sweeps (they read nvec / the plan buffers)
     HIP_TRY(ctx, hipEventRecord(ctx->ev_upload, st));
     HIP_TRY(ctx, hipStreamWaitEvent(ctx->plan_stream, ctx->ev_upload, 0));
 
@@ -975,13 +1027,14 @@ int32_t rrrmc_standard_mc_async(rrrmc_ctx* ctx, double beta, int64_t iters, int6
     P.k0 = (uint32_t)ctx->seed;
     P.k1 = (uint32_t)(ctx->seed >> 32);
     P.group0 = ctx->replica0 / 32;
+    P.gbase = ctx->it_done;
     P.N = (int)N; P.C = C; P.TS = ctx->TS; P.Rpad = (int)ctx->Rpad;
     sweep_fn fn = ctx->lds_mode ? sweep_for_K((int)K, ctx->sweep_mode) : nullptr;
     BigSweepParams PB{};
     if (ctx->big_mode) {
         PB.spins = ctx->d_spins; PB.A = ctx->d_A; PB.J = ctx->d_J; PB.Es = ctx->d_Es; PB.E_cur = ctx->d_E; PB.acc_cur = ctx->d_acc;
         std::memcpy(PB.taum, P.taum, sizeof(PB.taum));
-        PB.always_mask = P.always_mask; PB.k0 = P.k0; PB.k1 = P.k1; PB.group0 = P.group0;
+        PB.always_mask = P.always_mask; PB.k0 = P.k0; PB.k1 = P.k1; PB.group0 = P.group0; PB.gbase = P.gbase;
         PB.N = (int)N; PB.Rpad = (int)ctx->Rpad;
     }
 #ifdef RRRMC_STAMPS
@@ -992,28 +1045,28 @@ int32_t rrrmc_standard_mc_async(rrrmc_ctx* ctx, double beta, int64_t iters, int6
     // sweep(b-2) has released the plan buffer set b & 1; sweep(b) waits for plan(b).
     const int nb = (int)batches.size();
     auto launch_plan = [&](int b) -> int32_t {
-        const Batch& bt = batches[b];
-        if (b >= 2) HIP_TRY(ctx, hipStreamWaitEvent(ctx->plan_stream, ctx->ev_sweep[2 * (b - 2) + 1], 0));
+        const rrrmc_ctx::BatchDesc& bt = batches[b];
+        if (b >= 2) HIP_TRY(ctx, hipStreamWaitEvent(ctx->plan_stream, EV[ebase + 2 * (b - 2) + 1], 0));
         if (ctx->big_mode)
             hipLaunchKernelGGL(plan_big_for_K((int)K), dim3((unsigned)bt.n), dim3(kPlanThreads), ctx->plan_lds_bytes, ctx->plan_stream,
-                               ctx->d_chunks + bt.first, ctx->d_slots[b & 1], ctx->d_vecs[b & 1], ctx->d_A, (int)N, P.k0, P.k1);
+                               ctx->d_chunks + bt.first, ctx->d_slots[b & 1], ctx->d_vecs[b & 1], ctx->d_A, (int)N, P.k0, P.k1, P.gbase);
         else
             hipLaunchKernelGGL(plan_for_K((int)K), dim3((unsigned)bt.n), dim3(kPlanThreads), ctx->plan_lds_bytes, ctx->plan_stream,
-                               ctx->d_chunks + bt.first, ctx->d_slots[b & 1], ctx->d_vecs[b & 1], ctx->d_A, (int)N, C, P.k0, P.k1);
+                               ctx->d_chunks + bt.first, ctx->d_slots[b & 1], ctx->d_vecs[b & 1], ctx->d_A, (int)N, C, P.k0, P.k1, P.gbase);
         HIP_TRY(ctx, hipGetLastError());
         HIP_TRY(ctx, hipEventRecord(ctx->ev_plan[b], ctx->plan_stream));
         return RRRMC_OK;
     };
     if (nb > 0) { rc = launch_plan(0); if (rc) return rc; }
     for (int b = 0; b < nb; ++b) {
-        const Batch& bt = batches[b];
+        const rrrmc_ctx::BatchDesc& bt = batches[b];
         HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->ev_plan[b], 0));
         P.chunks = ctx->d_chunks + bt.first;
         P.nchunks = (int)bt.n;
         P.sample0 = bt.sample0;
         P.slots = ctx->d_slots[b & 1];
         P.vecs = ctx->d_vecs[b & 1];
-        HIP_TRY(ctx, hipEventRecord(ctx->ev_sweep[2 * b], st));
+        HIP_TRY(ctx, hipEventRecord(EV[ebase + 2 * b], st));
         if (ctx->big_mode) {
             PB.chunks = P.chunks; PB.nchunks = P.nchunks; PB.sample0 = P.sample0; PB.slots = P.slots; PB.vecs = P.vecs;
             hipLaunchKernelGGL(big_sweep_for_K((int)K), dim3((unsigned)ctx->G), dim3(kBigThreads), 0, st, PB);
@@ -1021,13 +1074,16 @@ int32_t rrrmc_standard_mc_async(rrrmc_ctx* ctx, double beta, int64_t iters, int6
             hipLaunchKernelGGL(fn, dim3((unsigned)ctx->G), dim3(kSweepThreads), ctx->lds_bytes, st, P);
         }
         HIP_TRY(ctx, hipGetLastError());
-        HIP_TRY(ctx, hipEventRecord(ctx->ev_sweep[2 * b + 1], st));
+        HIP_TRY(ctx, hipEventRecord(EV[ebase + 2 * b + 1], st));
         // the next plan is enqueued AFTER this sweep so that the sweep's workgroups (one per CU, most of the LDS)
         // are placed first and the planner's small workgroups fill in beside them
         if (b + 1 < nb) { rc = launch_plan(b + 1); if (rc) return rc; }
     }
     HIP_TRY(ctx, hipEventRecord(ctx->ev_end, st));
     ctx->sweep_launches = (int)batches.size();
+    ctx->last_ev_base = ebase;
+    ctx->last_ev_pool = ctx->acc_mode;
+    if (ctx->acc_mode) ctx->ev_pool_used += 2 * batches.size();
     ctx->nsamp = nsamp;
     ctx->it_done += (uint64_t)iters;
     ctx->results_valid = true;
@@ -1095,12 +1151,44 @@ int32_t rrrmc_last_timing(rrrmc_ctx* ctx, double* total_ms, double* sweep_ms, in
     HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev_begin, ctx->ev_end));
     if (total_ms) *total_ms = ms;
     double sw = 0.0;
+    const std::vector<hipEvent_t>& EV = ctx->last_ev_pool ? ctx->ev_pool : ctx->ev_sweep;
+    const size_t eb = ctx->last_ev_pool ? ctx->last_ev_base : 0;
     for (int b = 0; b < ctx->sweep_launches; ++b) {
-        HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev_sweep[2 * b], ctx->ev_sweep[2 * b + 1]));
+        HIP_TRY(ctx, hipEventElapsedTime(&ms, EV[eb + 2 * b], EV[eb + 2 * b + 1]));
         sw += ms;
     }
     if (sweep_ms) *sweep_ms = sw;
     if (sweep_launches) *sweep_launches = ctx->sweep_launches;
+    return RRRMC_OK;
+}
+
+int32_t rrrmc_timing_accumulate(rrrmc_ctx* ctx, int32_t on)
+{
+    if (!ctx) return RRRMC_ERR_INVALID_ARG;
+    if (ctx->model != RRRMC_MODEL_SPARSE_PM1) return fail(ctx, RRRMC_ERR_UNSUPPORTED, "timing accumulation is wired for the +-J sparse standardMC path only");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));      // no queued call may still record into the pool being reset
+    ctx->acc_mode = on != 0;
+    ctx->ev_pool_used = 0;
+    ctx->last_ev_pool = false;
+    ctx->timing_valid = false;
+    return RRRMC_OK;
+}
+
+int32_t rrrmc_timing_total(rrrmc_ctx* ctx, double* sweep_ms, int64_t* sweep_launches)
+{
+    if (!ctx) return RRRMC_ERR_INVALID_ARG;
+    if (!ctx->acc_mode) return fail(ctx, RRRMC_ERR_STATE, "rrrmc_timing_accumulate(ctx, 1) has not been called");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    double sw = 0.0;
+    for (size_t i = 0; i + 1 < ctx->ev_pool_used; i += 2) {
+        float ms = 0.f;
+        HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev_pool[i], ctx->ev_pool[i + 1]));
+        sw += ms;
+    }
+    if (sweep_ms) *sweep_ms = sw;
+    if (sweep_launches) *sweep_launches = (int64_t)(ctx->ev_pool_used / 2);
     return RRRMC_OK;
 }
 
@@ -1153,6 +1241,14 @@ int32_t rrrmc_set_coloring(rrrmc_ctx* ctx, const int32_t* color, int32_t ncolors
     return RRRMC_OK;
 }
 
+int32_t rrrmc_colored_count_accepted(rrrmc_ctx* ctx, int32_t on)
+{
+    if (!ctx) return RRRMC_ERR_INVALID_ARG;
+    if (ctx->model != RRRMC_MODEL_SPARSE_PM1) return fail(ctx, RRRMC_ERR_UNSUPPORTED, "colour-parallel sweeps are for sparse +-J models");
+    ctx->color_count_acc = on != 0;
+    return RRRMC_OK;
+}
+
 int32_t rrrmc_colored_sweeps_async(rrrmc_ctx* ctx, double beta, int64_t sweeps, int64_t step)
 {
     int32_t rc = ensure_state(ctx, true);
@@ -1188,10 +1284,12 @@ int32_t rrrmc_colored_sweeps_async(rrrmc_ctx* ctx, double beta, int64_t sweeps, 
     }
     P.spins = ctx->d_spins; P.A = ctx->d_A; P.J = ctx->d_J;
     P.k0 = (uint32_t)ctx->seed; P.k1 = (uint32_t)(ctx->seed >> 32); P.group0 = ctx->replica0 / 32; P.N = (int)ctx->N;
-    csweep_fn fn = csweep_for_K((int)K);
+    csweep_fn fn = csweep_for_K((int)K, ctx->color_count_acc);
+    P.acc_cur = ctx->d_acc;
     hipStream_t st = ctx->stream;
     HIP_TRY(ctx, hipEventRecord(ctx->ev_begin, st));
-    HIP_TRY(ctx, hipMemsetAsync(ctx->d_acc, 0xff, sizeof(int64_t) * ctx->Rpad, st));      // accepted counts are not tracked: -1
+    // accepted counts: per replica when rrrmc_colored_count_accepted(ctx, 1) was called, else not tracked: -1
+    HIP_TRY(ctx, hipMemsetAsync(ctx->d_acc, ctx->color_count_acc ? 0 : 0xff, sizeof(int64_t) * ctx->Rpad, st));
     HIP_TRY(ctx, hipEventRecord(ctx->ev_sweep[0], st));
     int64_t ns = 0;
     for (int64_t sw = 1; sw <= sweeps; ++sw) {

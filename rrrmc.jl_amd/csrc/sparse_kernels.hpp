@@ -37,7 +37,8 @@ constexpr int kBatchSlots = kRows * kWave;
 constexpr uint32_t kChunkSampleBefore = 1u;       // chunk flag: an energy sample is due before its first move
 
 struct ChunkDesc {
-    uint64_t g0;         // global iteration (1-based) of the chunk's first attempt
+    uint64_t g0;         // iteration (1-based, RELATIVE to the sampling call: the kernels add the call's base `gbase` = iterations done before it)
+                         // of the chunk's first attempt — the list depends on (iters, step, C) only, so back-to-back calls share one upload
     uint32_t count;      // attempts in the chunk (<= C)
     uint32_t slot_base;  // offset of the chunk's slots / vector table in the plan buffers
     uint32_t nvec;       // number of consumer batches, written by plan_kernel
@@ -59,7 +60,7 @@ constexpr uint32_t kNoPred = 0xffffu;
 template <int K>
 __global__ __launch_bounds__(kPlanThreads) void plan_kernel(ChunkDesc* __restrict__ chunks, uint32_t* __restrict__ slots,
                                                             uint32_t* __restrict__ vecs, const int32_t* __restrict__ A,
-                                                            int N, int Cmax, uint32_t k0, uint32_t k1)
+                                                            int N, int Cmax, uint32_t k0, uint32_t k1, uint64_t gbase)
 {
     extern __shared__ uint32_t plds32[];
     // two phases share the first region: the site buckets (until the predecessors are known), then the level counters
@@ -82,7 +83,7 @@ __global__ __launch_bounds__(kPlanThreads) void plan_kernel(ChunkDesc* __restric
     for (int x = tid; x <= N; x += kPlanThreads) s_bin[x] = 0u;
     __syncthreads();
     for (int t = tid; t < count; t += kPlanThreads) {
-        const uint32_t site = site_of(k0, k1, cd.g0 + (uint64_t)t, (uint32_t)N);
+        const uint32_t site = site_of(k0, k1, gbase + cd.g0 + (uint64_t)t, (uint32_t)N);
         s_site[t] = (uint16_t)site;
         s_lvl[t] = 1;
 #pragma unroll
@@ -198,6 +199,7 @@ struct SweepParams {
     uint32_t k0, k1;          // Philox key
     uint32_t group0;          // global id of this ctx's first group
     int64_t sample0;          // index of the first sample this launch may emit
+    uint64_t gbase;           // iterations done before this sampling call (ChunkDesc::g0 is relative to it)
     int N, C, TS, Rpad, nchunks;
     unsigned long long* stamps;   // diagnostic builds (-DRRRMC_STAMPS): [G][16] busy shader cycles per wave, else unused
 };
@@ -268,7 +270,7 @@ __device__ __forceinline__ void produce_chunk(const SweepParams& P, const ChunkD
         const bool live = p < (int)cd.count;
         const uint32_t slot = slots[j];            // P.slots[cd.slot_base + p], requested one step ago (0 for dead lanes)
         const uint32_t site = slot & 0xffffu;
-        const uint64_t g = cd.g0 + (uint64_t)(slot >> 16);
+        const uint64_t g = P.gbase + cd.g0 + (uint64_t)(slot >> 16);
 
         uint32_t f[NQ * 4];        // descriptor words
 #pragma unroll
@@ -355,7 +357,7 @@ __device__ __forceinline__ void fix_chunk(const SweepParams& P, const ChunkDesc&
         if (live) sl = left.slot[i];
 #pragma unroll
         for (int q = 0; q < NT; ++q) { lt[q] = live ? left.lt[q * kLeftMax + i] : 0u; eq[q] = live ? left.eq[q * kLeftMax + i] : 0u; }
-        const uint64_t g = cd.g0 + (uint64_t)(sl >> 16);
+        const uint64_t g = P.gbase + cd.g0 + (uint64_t)(sl >> 16);
         for (uint32_t pb = kProducerBlocks; pb < 16u; ++pb) {
             if (!__any(any_set<NT>(eq))) break;
             refine_block<NT>(lt, eq, accept_planes(P.k0, P.k1, g, group, pb), pb, P.taum);
@@ -568,6 +570,9 @@ __device__ __forceinline__ void tally_hi_tz(TallyState<NS>& t, const uint32_t (&
             v = carry;
         }
         t.Pd[s][TZ] = v;
+        // keeps the four cases of the caller's switch from being merged into one store with a run-time index (which moves the
+        // whole array to scratch memory)
+        asm volatile("" : "+v"(t.Pd[s][TZ]));
     }
 }
 
@@ -894,7 +899,11 @@ __global__ __launch_bounds__(kSweepThreads) void sweep_kernel(SweepParams P)
 #undef RRRMC_T0
 #undef RRRMC_T1
     __syncthreads();
-    for (int x = tid; x < N; x += kSweepThreads) gsp[x] = sp[MODE == 3 ? x : 2 * x];
+    // the write-back loop starts from an opaque copy of the thread id: otherwise its trip count is shared with the staging loop at
+    // the top and kept alive (spilled to scratch memory by the register-hungry tally role) across the whole kernel
+    int tid_wb = tid;
+    asm volatile("" : "+v"(tid_wb));
+    for (int x = tid_wb; x < N; x += kSweepThreads) gsp[x] = sp[MODE == 3 ? x : 2 * x];
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -975,9 +984,12 @@ struct ColorSweepParams {
     uint32_t k0, k1, group0;
     uint64_t sweep;           // global sweep index (1-based)
     int N, nlist;
+    int64_t* acc_cur;         // [Rpad] accepted moves per replica (COUNT builds only)
 };
 
-template <int K>
+// COUNT: also add every replica's accepted moves to P.acc_cur (32x32 bit transpose + popcount per wave, LDS atomics per workgroup,
+// 32 global atomics per workgroup) — the parity / acceptance-rate build; the plain build leaves the counters alone.
+template <int K, bool COUNT = false>
 __global__ __launch_bounds__(256) void colored_sweep_kernel(ColorSweepParams P)
 {
     constexpr int NT = SweepCfg<K>::NT;
@@ -1024,6 +1036,19 @@ __global__ __launch_bounds__(256) void colored_sweep_kernel(ColorSweepParams P)
         rej |= e;
     }
     if (live) sp[x] = s ^ ~rej;
+    if constexpr (COUNT) {
+        __shared__ uint32_t s_acc[32];
+        if (threadIdx.x < 32) s_acc[threadIdx.x] = 0u;
+        __syncthreads();
+        TransposeConsts tc;
+        tc.init((int)(threadIdx.x & 63));
+        uint32_t c = (uint32_t)__popc(transpose32(live ? ~rej : 0u, tc));      // lane r (and r + 32): replica r's accepted moves in this wave half
+        c += (uint32_t)__shfl_xor((int)c, 32);
+        if ((threadIdx.x & 63) < 32 && c) atomicAdd(&s_acc[threadIdx.x & 31], c);
+        __syncthreads();
+        if (threadIdx.x < 32 && s_acc[threadIdx.x])
+            atomicAdd(reinterpret_cast<unsigned long long*>(P.acc_cur) + blockIdx.y * 32 + threadIdx.x, (unsigned long long)s_acc[threadIdx.x]);
+    }
 }
 
 // Bit-sliced energy: U[group*32 + r] += sum over sites of the number of unsatisfied bonds of replica r (every bond

@@ -139,6 +139,10 @@ class Engine:
         color = np.ascontiguousarray(color, np.int32)
         check(lib().rrrmc_set_coloring(self._ctx, color, int(color.max()) + 1), self._ctx)
 
+    def colored_count_accepted(self, on=True):
+        """Make the colour sweeps count every replica's accepted moves (off by default: the counters then read -1)."""
+        check(lib().rrrmc_colored_count_accepted(self._ctx, 1 if on else 0), self._ctx)
+
     def colored_sweeps_async(self, beta, sweeps, step=1):
         check(lib().rrrmc_colored_sweeps_async(self._ctx, float(beta), int(sweeps), int(step)), self._ctx)
         self._last = (int(sweeps), int(step))
@@ -236,6 +240,16 @@ class Engine:
         check(lib().rrrmc_quant_observables(self._ctx, float(X.beta if beta is None else beta), float(X.Gamma if Gamma is None else Gamma),
                                             Q.ctypes.data, tm.ctypes.data, ov.ctypes.data), self._ctx)
         return Q, tm, ov
+
+    def timing_accumulate(self, on=True):
+        """Give every sweep launch of the following async calls its own HIP-event pair (see ``timing_total``)."""
+        check(lib().rrrmc_timing_accumulate(self._ctx, 1 if on else 0), self._ctx)
+
+    def timing_total(self):
+        """(sweep_ms, sweep_launches) summed over every sampling call since ``timing_accumulate()``; synchronises."""
+        s, n = C.c_double(0), C.c_int64(0)
+        check(lib().rrrmc_timing_total(self._ctx, C.byref(s), C.byref(n)), self._ctx)
+        return s.value, n.value
 
     def last_timing(self):
         """(total_ms, sweep_ms, sweep_launches) of the last sampling call, from HIP events on the ctx's stream."""

@@ -27,6 +27,9 @@ template <int OP> __global__ __launch_bounds__(256) void k(uint32_t* out, int it
         if (OP == 11) { REP16(asm volatile("v_mov_b32 %0, %4\n v_mov_b32 %1, %5\n v_mov_b32 %2, %6\n v_mov_b32 %3, %7" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b0), "v"(b1), "v"(b2), "v"(b3));) }
         if (OP == 12) { REP16(asm volatile("v_pk_mul_lo_u16 %0, %0, %4\n v_pk_mul_lo_u16 %1, %1, %5\n v_pk_mul_lo_u16 %2, %2, %6\n v_pk_mul_lo_u16 %3, %3, %7" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b0), "v"(b1), "v"(b2), "v"(b3));) }
         if (OP == 13) { REP16(asm volatile("v_mad_u16 %0, %0, %4, %5\n v_mad_u16 %1, %1, %5, %6\n v_mad_u16 %2, %2, %6, %7\n v_mad_u16 %3, %3, %7, %4" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b0), "v"(b1), "v"(b2), "v"(b3));) }
+        if (OP == 14) { REP16(asm volatile("v_bitop3_b32 %0, %0, %4, %5 bitop3:0x96\n v_bitop3_b32 %1, %1, %5, %6 bitop3:0x96\n v_bitop3_b32 %2, %2, %6, %7 bitop3:0x96\n v_bitop3_b32 %3, %3, %7, %4 bitop3:0x96" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b0), "v"(b1), "v"(b2), "v"(b3));) }
+        if (OP == 15) { REP16(asm volatile("v_alignbit_b32 %0, %0, %4, %5\n v_alignbit_b32 %1, %1, %5, %6\n v_alignbit_b32 %2, %2, %6, %7\n v_alignbit_b32 %3, %3, %7, %4" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b0), "v"(b1), "v"(b2), "v"(b3));) }
+        if (OP == 16) { REP16(asm volatile("v_bcnt_u32_b32 %0, %4, %0\n v_bcnt_u32_b32 %1, %5, %1\n v_bcnt_u32_b32 %2, %6, %2\n v_bcnt_u32_b32 %3, %7, %3" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b0), "v"(b1), "v"(b2), "v"(b3));) }
     }
     out[blockIdx.x * blockDim.x + threadIdx.x] = a0 ^ a1 ^ a2 ^ a3;
 }
@@ -50,5 +53,6 @@ int main()
     run<4>("v_mad_u64_u32", d); run<5>("v_bfi_b32", d); run<6>("v_and_or_b32", d); run<7>("v_mul_u32_u24", d);
     run<8>("v_mad_u32_u24", d); run<9>("v_add_u32", d); run<10>("v_mul_hi_u32_u24", d); run<11>("v_mov_b32", d);
     run<12>("v_pk_mul_lo_u16", d); run<13>("v_mad_u16", d);
+    run<14>("v_bitop3_b32", d); run<15>("v_alignbit_b32", d); run<16>("v_bcnt_u32_b32", d);
     return 0;
 }
