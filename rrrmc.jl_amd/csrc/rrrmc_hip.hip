@@ -19,6 +19,7 @@
 
 #include "sk_kernels.hpp"
 #include "rrr_kernels.hpp"
+#include "quant_wave_kernel.hpp"
 #include "sparse_kernels.hpp"
 #include "bign_kernels.hpp"
 #include "obs_kernels.hpp"
@@ -1425,10 +1426,24 @@ int32_t quant_mc_async(rrrmc_ctx* ctx, bool standard, double beta, double fourK,
     HIP_TRY(ctx, hipEventRecord(ctx->ev_sweep[0], st));
     if (standard) hipLaunchKernelGGL(quant_standard_kernel, dim3(rrr_blocks(ctx->R)), dim3(rrr_tpb(ctx->R)), 0, st, P);
     else {
+        // Few replicas of a cache that fits LDS (config 5: 128 x (Nk = 1024, M = 32)): one WAVEFRONT per replica, wave-uniform chain,
+        // the whole DeltaECache in LDS (quant_wave_kernel.hpp).  Many replicas: the thread-per-replica kernels fill the chip better.
+        const QwLayout ql = qw_layout(ctx->N, ctx->qW, ctx->qNk, ctx->K, (size_t)kLdsLimit);
+        const char* no_wave = std::getenv("RRRMC_QUANT_NO_WAVE");        // timing experiments / cross-checks of the two builds
+        int64_t wave_max_R = 2048;
+        if (const char* e = std::getenv("RRRMC_QUANT_WAVE_MAX_R")) wave_max_R = std::atoll(e);
+        const bool wave_ok = !ctx->q_sk && ctx->K <= 7 && ctx->qNk <= 65535 && ql.cap >= ctx->N + 4 * kQwMinGap && ctx->R <= wave_max_R &&
+                             !(no_wave && no_wave[0] == '1');
         // one replica per workgroup anyway (few replicas): stage its hot state in LDS if it fits (config 5: 115 KB)
         const size_t lds = rrr_quant_lds_bytes(ctx->N, ctx->qW, ctx->qNk, ctx->K);
         const char* no_lds = std::getenv("RRRMC_QUANT_NO_LDS");          // timing experiments
-        if (rrr_tpb(ctx->R) == 1 && lds <= (size_t)kLdsLimit && !(no_lds && no_lds[0] == '1')) {
+        if (wave_ok) {
+            HIP_TRY(ctx, raise_lds_attr(reinterpret_cast<const void*>(rrr_quant_wave_kernel), ql.bytes));
+            QwExtra X{};
+            X.cap = ql.cap; X.off_spos = (uint32_t)ql.off_spos; X.off_sv = (uint32_t)ql.off_sv; X.off_A = (uint32_t)ql.off_A;
+            X.off_J = (uint32_t)ql.off_J; X.off_rng = (uint32_t)ql.off_rng; X.off_exp = (uint32_t)ql.off_exp;
+            hipLaunchKernelGGL(rrr_quant_wave_kernel, dim3((unsigned)ctx->R), dim3(kRrrThreads), ql.bytes, st, P, X);
+        } else if (rrr_tpb(ctx->R) == 1 && lds <= (size_t)kLdsLimit && !(no_lds && no_lds[0] == '1')) {
             if (!ctx->q_lds_attr) {
                 HIP_TRY(ctx, raise_lds_attr(reinterpret_cast<const void*>(rrr_quant_kernel<true>), lds));
                 ctx->q_lds_attr = true;
