@@ -12,11 +12,18 @@
 //   * DeltaECache.pos (the class of every spin): GraphQT's delta_energy is a function of three spin bits, the cache is consistent
 //     between moves (DeltaE.jl:120-136), so the class before a flip is recomputed from the bits before the flip;
 //   * T[1..3] of the three classes with weight 1: they are only ever changed by +-1.0, so they equal the set sizes exactly;
-//     T[4] (weight exp(-beta fourK)) and z are the reference's running Float64 sums, updated in its order.
+//     T[4] (weight exp(-beta fourK)) and z are the reference's running Float64 sums, updated in its order;
 //   * the four ArraySet member arrays (8 bytes per spin in HBM): the sets partition the spins, so they live in ONE LDS array of
 //     N + slack entries as four segments with gaps between them — push! appends into the gap behind its segment, delete! swaps with
-//     the segment's last entry (ArraySets.jl:56-76): the order inside every set is the reference's.  A full gap (rare: the sizes
-//     fluctuate by a few hundred) re-spaces the segments through the replica's HBM arrays.
+//     the segment's last entry (ArraySets.jl:56-76): the order inside every set is the reference's.  A gap that runs low (rare: the
+//     sizes fluctuate by a few hundred) re-spaces the segments through the replica's HBM arrays, between batches of 64 iterations;
+//   * exp and the division by M: the slice graph's delta_energy takes 2K+1 values, so delta_energy_residual and det_exp(-beta dE1)
+//     are tables; c = z / z' is only formed when the accept test needs it (c >= 1 is z >= z').
+// Register discipline: a single wavefront issues one instruction every ~5 cycles whatever its kind, and the compiler moves every value
+// it can prove wave-uniform into scalar registers — of which there are about a hundred; a chain with this much uniform state spills
+// them into VGPR lanes and reloads them with v_readlane at every use (a quarter of the loop in the first version).  So the
+// chain's state is deliberately kept in VECTOR registers (every lane holds the same value: `vz` below is an opaque zero that hides
+// the uniformity); scalar registers are used only for short-lived lane indices.
 // Float64 sums in the reference's order, det_exp shared with the oracle: bit-identical trajectories, energies, accepted / staged
 // counts and final cache.
 #pragma once
@@ -24,32 +31,33 @@
 
 namespace rrrmc {
 
-constexpr int kQwMinGap = 256;          // smallest slack (entries per gap) the host accepts for this build
+constexpr int kQwMinGap = 512;          // smallest slack (entries per gap) the host accepts for this build: 6 pushes x 64 iterations fit
 
-struct QwLayout { size_t off_spos, off_sv, off_A, off_J, off_rng, off_exp, bytes; int cap; };
+struct QwLayout { size_t off_spos, off_sv, off_A, off_J, off_rng, off_tab, bytes; int cap; };
 
-// LDS layout for (N, W, Nk, K): returns cap = N + slack (slack as large as the LDS allows), cap < N + 4 * kQwMinGap means "does not fit"
+// LDS layout for (N, W, Nk, K): cap = N + slack (slack as large as the LDS allows); cap < N + 4 * kQwMinGap means "does not fit"
 inline QwLayout qw_layout(int64_t N, int64_t W, int64_t Nk, int64_t K, size_t lds_limit)
 {
     QwLayout L{};
     size_t o = (size_t)W * 4;
     L.off_spos = o; o += (((size_t)N * 2 + 7) & ~(size_t)7);
-    const size_t fixed_tail = (((size_t)Nk * K * 2 + 7) & ~(size_t)7) + (((size_t)Nk * K + 7) & ~(size_t)7) + 64 * 3 * 8 + 16 * 8 + 64;
+    const size_t fixed_tail = (((size_t)Nk * K * 2 + 7) & ~(size_t)7) + (((size_t)Nk * K + 7) & ~(size_t)7) + 64 * 3 * 8 + 32 * 8 + 64;
     const size_t room = lds_limit > o + fixed_tail ? lds_limit - o - fixed_tail : 0;
     int64_t cap = (int64_t)(room / 2) & ~(int64_t)3;
     if (cap > 2 * N) cap = 2 * N;
+    if (cap > 65532) cap = 65532;           // slots are stored in 16 bits
     L.cap = (int)cap;
     L.off_sv = o; o += (size_t)cap * 2;
     o = (o + 7) & ~(size_t)7;
     L.off_A = o; o += (((size_t)Nk * K * 2 + 7) & ~(size_t)7);
     L.off_J = o; o += (((size_t)Nk * K + 7) & ~(size_t)7);
     L.off_rng = o; o += 64 * 3 * 8;
-    L.off_exp = o; o += 16 * 8;
+    L.off_tab = o; o += 32 * 8;
     L.bytes = o;
     return L;
 }
 
-struct QwExtra { int cap; uint32_t off_spos, off_sv, off_A, off_J, off_rng, off_exp; };
+struct QwExtra { int cap; uint32_t off_spos, off_sv, off_A, off_J, off_rng, off_tab; unsigned long long* stamps; };
 
 __device__ __forceinline__ int qw_uni(int x) { return __builtin_amdgcn_readfirstlane(x); }
 __device__ __forceinline__ double qw_unid(double x)
@@ -73,86 +81,104 @@ __global__ __launch_bounds__(kRrrThreads) void rrr_quant_wave_kernel(RrrParams P
     extern __shared__ uint32_t qw_lds[];
     unsigned char* lds8 = reinterpret_cast<unsigned char*>(qw_lds);
     const int lane = (int)threadIdx.x, r = (int)blockIdx.x;
-    const int N = P.N, Nk = P.Nk, K = P.K, W = P.W, CAP = X.cap;
-    uint32_t* l_sp = qw_lds;                                                      // [W]
-    uint16_t* l_spos = reinterpret_cast<uint16_t*>(lds8 + X.off_spos);            // [N]
-    uint16_t* l_sv = reinterpret_cast<uint16_t*>(lds8 + X.off_sv);                // [CAP] four segments
-    uint16_t* l_A = reinterpret_cast<uint16_t*>(lds8 + X.off_A);                  // [Nk][K]
-    int8_t* l_J = reinterpret_cast<int8_t*>(lds8 + X.off_J);                      // [Nk][K]
-    double* l_rng = reinterpret_cast<double*>(lds8 + X.off_rng);                  // [64][3]: class uniform, member u64 (as bits), accept uniform
-    double* l_exp = reinterpret_cast<double*>(lds8 + X.off_exp);                  // [2K+1]: det_exp(-beta * (2 a / M)), a = -K..K
+    // LDS pointers are kept in vector registers too (an opaque zero is added to each: see "Register discipline" above)
+    int vz;
+    asm volatile("v_mov_b32 %0, 0" : "=v"(vz));
+    uint32_t* l_sp = reinterpret_cast<uint32_t*>(lds8 + vz);                                          // [W]
+    uint16_t* l_spos = reinterpret_cast<uint16_t*>(lds8 + (X.off_spos + (uint32_t)vz));              // [N]
+    uint16_t* l_sv = reinterpret_cast<uint16_t*>(lds8 + (X.off_sv + (uint32_t)vz));                  // [CAP] four segments
+    uint16_t* l_A = reinterpret_cast<uint16_t*>(lds8 + (X.off_A + (uint32_t)vz));                    // [Nk][K]
+    int8_t* l_J = reinterpret_cast<int8_t*>(lds8 + (X.off_J + (uint32_t)vz));                        // [Nk][K]
+    double* l_rng = reinterpret_cast<double*>(lds8 + (X.off_rng + (uint32_t)vz));                    // [64][3]: class uniform, member u64 (as bits), accept uniform
+    double* l_exp = reinterpret_cast<double*>(lds8 + (X.off_tab + (uint32_t)vz));                    // [16]: det_exp(-beta dE1(a)), a = sum_q J sigma sigma + K = 0, 2, .., 2K
+    double* l_dE1 = l_exp + 16;                                                                       // [16]: dE1(a) = 2 (a - K) / M
 
-    uint32_t* g_sp = P.spins + (size_t)r * W;
-    uint8_t* g_cls = P.cls + (size_t)r * N;
-    uint16_t* g_sv = P.sv + (size_t)r * 4 * N;
-    uint16_t* g_spos = P.spos + (size_t)r * N;
+    uint32_t* g_sp = P.spins + (size_t)r * P.W;
+    uint8_t* g_cls = P.cls + (size_t)r * P.N;
+    uint16_t* g_sv = P.sv + (size_t)r * 4 * P.N;
+    uint16_t* g_spos = P.spos + (size_t)r * P.N;
     int32_t* g_t = P.st + (size_t)r * 4;
 
     // ---- stage the replica ------------------------------------------------------------------------------------------------
-    int t[4], base[4];
-    for (int k = 0; k < 4; ++k) t[k] = qw_uni(g_t[k]);
-    auto respace = [&]() {      // equal gaps behind the four segments
-        const int gap = (CAP - N) / 4;
-        base[0] = 0;
-        for (int k = 1; k < 4; ++k) base[k] = base[k - 1] + t[k - 1] + gap;
+    // segment bases and ends (base + size) live in ONE VGPR each (lane q = set q): a lookup by a class index is a v_readlane.
+    // In LDS a spin's position is the ABSOLUTE slot in the segmented array (base of its set + ArraySet position): a delete / push
+    // then needs the two segment ends only.
+    int bv = 0, ev = lane < 4 ? g_t[lane] : 0;      // ev holds the sizes until respace() has placed the segments
+    auto B_ = [&](int q) -> int { return __builtin_amdgcn_readlane(bv, q); };
+    auto E_ = [&](int q) -> int { return __builtin_amdgcn_readlane(ev, q); };
+    auto T_ = [&](int q) -> int { return __builtin_amdgcn_readlane(ev, q) - __builtin_amdgcn_readlane(bv, q); };
+    auto respace = [&](int t0, int t1, int t2, int t3) {      // equal gaps behind the four segments
+        const int gap = (X.cap - P.N) / 4;
+        bv = lane == 1 ? t0 + gap : lane == 2 ? t0 + t1 + 2 * gap : lane == 3 ? t0 + t1 + t2 + 3 * gap : 0;
+        ev = bv + (lane == 0 ? t0 : lane == 1 ? t1 : lane == 2 ? t2 : lane == 3 ? t3 : 0);
     };
-    respace();
-    for (int i = lane; i < W; i += kRrrThreads) l_sp[i] = g_sp[i];
-    for (int i = lane; i < N; i += kRrrThreads) l_spos[i] = g_spos[i];
-    for (int k = 0; k < 4; ++k)
-        for (int i = lane; i < t[k]; i += kRrrThreads) l_sv[base[k] + i] = g_sv[(size_t)k * N + i];
-    for (int i = lane; i < Nk * K; i += kRrrThreads) { l_A[i] = (uint16_t)P.A[i]; l_J[i] = P.J[i]; }
-    if (lane <= 2 * K) {
-        const double dE1 = (double)(2 * (lane - K)) / (double)P.M;               // slice_res(slice_delta) for sum_k +-J = lane - K
-        l_exp[lane] = det_exp(-P.beta * dE1);
+    respace(E_(0), E_(1), E_(2), E_(3));
+    for (int i = lane; i < P.W; i += kRrrThreads) l_sp[i] = g_sp[i];
+    {
+        const int b0 = B_(0), b1 = B_(1), b2 = B_(2), b3 = B_(3);
+        for (int i = lane; i < P.N; i += kRrrThreads) {
+            const int c = g_cls[i];
+            l_spos[i] = (uint16_t)((int)g_spos[i] + (c == 0 ? b0 : c == 1 ? b1 : c == 2 ? b2 : b3));
+        }
     }
+    for (int k = 0; k < 4; ++k) {
+        const int tk = T_(k), bk = B_(k);
+        for (int i = lane; i < tk; i += kRrrThreads) l_sv[bk + i] = g_sv[(size_t)k * P.N + i];
+    }
+    for (int i = lane; i < P.Nk * P.K; i += kRrrThreads) { l_A[i] = (uint16_t)P.A[i]; l_J[i] = P.J[i]; }
+    if (lane <= P.K) {
+        const double dE1 = (double)(2 * (2 * lane - P.K)) / (double)P.M;          // slice_res(slice_delta): sum_q +-J = 2 lane - K
+        l_exp[2 * lane] = det_exp(-P.beta * dE1);
+        l_dE1[2 * lane] = dE1;
+    }
+    uint32_t xge0_s = 0u;                   // bit a: x = -beta dE1(a) >= 0
+    for (int q = 0; q <= P.K; ++q) xge0_s |= (-P.beta * ((double)(2 * (2 * q - P.K)) / (double)P.M) >= 0 ? 1u : 0u) << (2 * q);
     __syncthreads();
 
+    // ---- the chain's state, in vector registers (see "Register discipline" above) --------------------------------------------------
+    const int N = P.N + vz, Nk = P.Nk + vz, K = P.K + vz;
+    const uint32_t xge0 = xge0_s + (uint32_t)vz;
+    const uint32_t nk_magic = (uint32_t)((0x100000000ull + (uint32_t)P.Nk - 1u) / (uint32_t)P.Nk) + (uint32_t)vz;
     const uint32_t rep = P.replica0 + (uint32_t)r;
-    const uint32_t nk_magic = (uint32_t)((0x100000000ull + (uint32_t)Nk - 1u) / (uint32_t)Nk);
-    const double ft1 = P.ft1, fourK = P.fourK;
+    double vzd = __longlong_as_double(((long long)vz << 32) | (uint32_t)vz);      // +0.0, opaque
+    const double ft1 = P.ft1 + vzd, fourK = P.fourK + vzd, lambda = P.lambda + vzd, one_m_lambda = (1 - P.lambda) + vzd, staged_thr = P.staged_thr + vzd;
     // T[0..2] == (double)t[0..2] exactly (weights 1.0); T3 and z are running sums (DeltaE.jl:90-103, 258-282)
-    double T3 = qw_unid(P.T[(size_t)r * 4 + 3]), z = qw_unid(P.zz[r]), E = qw_unid(P.E_cur[r]), acc_rate = qw_unid(P.acc_rate[r]);
+    double T3 = P.T[(size_t)r * 4 + 3], z = P.zz[r], E = P.E_cur[r], acc_rate = P.acc_rate[r];
     long long accepted = P.stats[(size_t)r * 2], staged_its = P.stats[(size_t)r * 2 + 1];
-    accepted = ((long long)qw_uni((int)(accepted >> 32)) << 32) | (uint32_t)qw_uni((int)accepted);
-    staged_its = ((long long)qw_uni((int)(staged_its >> 32)) << 32) | (uint32_t)qw_uni((int)staged_its);
     long long ns = 0, next_sample = P.step;
 
     auto bit_of = [&](int x) -> int { return (int)((l_sp[x >> 5] >> (x & 31)) & 1u); };
-
-    // ArraySet delete!(k0, j) + push!(k1, j) on the segmented array; p = spos[j] (uniform).  Returns the element that took j's place
-    // (the old last of k0; j itself when j was the last) so that the caller can patch cached positions.
-    auto set_move = [&](int j, int k0, int k1, int p) -> int {
-        int b0 = 0, t0 = 0, b1 = 0, t1 = 0;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) { if (q == k0) { b0 = base[q]; t0 = t[q]; } if (q == k1) { b1 = base[q]; t1 = t[q]; } }
-        const int last = qw_uni((int)l_sv[b0 + t0 - 1]);
-        int lim = CAP;
-#pragma unroll
-        for (int q = 0; q < 3; ++q) if (q == k1) lim = base[q + 1];
-        if (b1 + t1 == lim) {
-            // the gap behind segment k1 is used up: write the four segments to the replica's HBM arrays, re-space, read them back
-            __syncthreads();
-            for (int k = 0; k < 4; ++k)
-                for (int i = lane; i < t[k]; i += kRrrThreads) g_sv[(size_t)k * N + i] = l_sv[base[k] + i];
-            __syncthreads();
-            respace();
-            for (int k = 0; k < 4; ++k)
-                for (int i = lane; i < t[k]; i += kRrrThreads) l_sv[base[k] + i] = g_sv[(size_t)k * N + i];
-            __syncthreads();
-#pragma unroll
-            for (int q = 0; q < 4; ++q) { if (q == k0) b0 = base[q]; if (q == k1) b1 = base[q]; }
-        }
-        if (lane == 0) {
-            l_sv[b0 + p] = (uint16_t)last;
+    // ArraySet delete!(S, j) + push!(D, j) (ArraySets.jl:56-76) on the segmented array; p = the slot of j (absolute), act = the move
+    // happens at all (a Trotter neighbour whose class does not change is skipped, DeltaE.jl:257).  Branch-free: an inactive move reads
+    // and discards.  Returns the element that took j's place (the old last of S; j itself when j was the last) so that the caller can
+    // patch the slots it has cached.  The gap behind segment D has room (checked once per batch of 64 iterations).
+    auto set_move = [&](int j, int S, int D, int p, bool act) -> int {
+        const int sS = __builtin_amdgcn_readfirstlane(S), sD = __builtin_amdgcn_readfirstlane(D);
+        const int eS = __builtin_amdgcn_readlane(ev, sS) + vz;
+        const int last = (int)l_sv[eS - 1];
+        const int eD = __builtin_amdgcn_readlane(ev, sD) + vz;
+        if (lane == 0 && act) {
+            l_sv[p] = (uint16_t)last;
             l_spos[last] = (uint16_t)p;
-            l_sv[b1 + t1] = (uint16_t)j;
-            l_spos[j] = (uint16_t)t1;
+            l_sv[eD] = (uint16_t)j;
+            l_spos[j] = (uint16_t)eD;
         }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) { if (q == k0) t[q] -= 1; if (q == k1) t[q] += 1; }
+        ev = !act ? ev : (lane == sS ? eS - 1 : (lane == sD ? eD + 1 : ev));
         return last;
     };
+    // floor(u * t / 2^64) for t < 2^32 (rand(1:t) of the member pick, ArraySets.jl:83)
+    auto mulhi_u64_u32 = [](unsigned long long u, uint32_t t) -> uint32_t {
+        const unsigned long long lo = (unsigned long long)(uint32_t)u * t;
+        const unsigned long long hi = (unsigned long long)(uint32_t)(u >> 32) * t + (lo >> 32);
+        return (uint32_t)(hi >> 32);
+    };
+
+#ifdef RRRMC_STAMPS
+    unsigned long long stamp[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define QW_T(i) { const unsigned long long now_ = __builtin_readcyclecounter(); stamp[i] += now_ - t_last; t_last = now_; }
+#else
+#define QW_T(i)
+#endif
 
     for (long long base_it = 0; base_it < P.iters; base_it += kRrrThreads) {
         // ---- the RRR draws of the next 64 iterations, one iteration per lane (state independent) -------------------------
@@ -165,161 +191,205 @@ __global__ __launch_bounds__(kRrrThreads) void rrr_quant_wave_kernel(RrrParams P
             l_rng[lane * 3 + 1] = __longlong_as_double((long long)(((uint64_t)a.w[2] << 32) | a.w[3]));
             l_rng[lane * 3 + 2] = (double)((((uint64_t)b.w[0] << 32) | b.w[1]) >> 11) * 0x1.0p-53;
         }
+        // A move pushes at most 3 entries into one set (6 with the undo), so a gap of 6 x 64 entries lasts the whole batch: the
+        // segments are re-spaced here, outside the hot loop, when a gap has run low (rare: the set sizes fluctuate by a few hundred)
+        {
+            const int e0 = B_(1) - E_(0), e1 = B_(2) - E_(1), e2 = B_(3) - E_(2), e3 = X.cap - E_(3);
+            const int emin = min(min(e0, e1), min(e2, e3));
+            if (emin < 6 * kRrrThreads) {
+                __syncthreads();
+                const int t0 = T_(0), t1 = T_(1), t2 = T_(2), t3 = T_(3);
+                for (int k = 0; k < 4; ++k) {
+                    const int tk = T_(k), bk = B_(k);
+                    for (int i = lane; i < tk; i += kRrrThreads) g_sv[(size_t)k * P.N + i] = l_sv[bk + i];
+                }
+                __syncthreads();
+                respace(t0, t1, t2, t3);
+                for (int k = 0; k < 4; ++k) {
+                    const int tk = T_(k), bk = B_(k);
+                    for (int i = lane; i < tk; i += kRrrThreads) {
+                        const int x = g_sv[(size_t)k * P.N + i];
+                        l_sv[bk + i] = (uint16_t)x;
+                        l_spos[x] = (uint16_t)(bk + i);
+                    }
+                }
+            }
+        }
         __syncthreads();
-        const long long it_end = base_it + kRrrThreads < P.iters ? base_it + kRrrThreads : P.iters;
-        for (long long it = base_it + 1; it <= it_end; ++it) {
+        const int n_it = (int)(base_it + kRrrThreads < P.iters ? kRrrThreads : P.iters - base_it);
+        double u_cls_n = l_rng[0], u_mem_n = l_rng[1], u_acc_n = l_rng[2];      // the draws of an iteration are requested one iteration ahead
+#ifdef RRRMC_STAMPS
+        unsigned long long t_last = __builtin_readcyclecounter();
+#endif
+        for (int li = 0; li < n_it; ++li) {
+            const long long it = base_it + 1 + li;
             if (it == next_sample) {
                 next_sample += P.step;
                 if (lane == 0) P.Es[ns * P.R + r] = E;
                 ns += 1;
             }
-            const int ri = (int)(it - base_it - 1) * 3;
-            const double u_cls = qw_unid(l_rng[ri]);
-            const unsigned long long u_mem = (unsigned long long)__double_as_longlong(qw_unid(l_rng[ri + 1]));
-            // rand_move (DeltaE.jl:146-167): class proportional to T (linear scan), member uniform
-            const double rr = u_cls * z;
-            const double Tq[4] = {(double)t[0], (double)t[1], (double)t[2], T3};
-            int k = 0;
-            double cT = 0.0;
-            for (k = 0; k < 4; ++k) {
-                cT += Tq[k];
-                if (rr < cT) break;
+            const double u_cls = u_cls_n, u_acc = u_acc_n;
+            const unsigned long long u_mem = (unsigned long long)__double_as_longlong(u_mem_n);
+            {
+                const int nx = (li + 1 < n_it ? li + 1 : li) * 3;
+                u_cls_n = l_rng[nx]; u_mem_n = l_rng[nx + 1]; u_acc_n = l_rng[nx + 2];
             }
-            if (k == 4) k = 3;
-            if (!(rr < cT)) {
-                while ((k == 3 ? T3 : (double)(k == 0 ? t[0] : k == 1 ? t[1] : t[2])) == 0) k -= 1;
+            // rand_move (DeltaE.jl:146-167): class proportional to T (linear scan over the running sums cT), member uniform
+            const int tvv = ev - bv;
+            const int t0 = __builtin_amdgcn_readlane(tvv, 0) + vz, t1 = __builtin_amdgcn_readlane(tvv, 1) + vz, t2 = __builtin_amdgcn_readlane(tvv, 2) + vz;
+            const double rr = u_cls * z;
+            const double c0 = (double)t0, c1 = c0 + (double)t1, c2 = c1 + (double)t2, c3 = c2 + T3;
+            int k = (rr < c0 ? 0 : 1) + (rr < c1 ? 0 : 1) + (rr < c2 ? 0 : 1);
+            if (!(rr < c3)) {      // r >= z by rounding: back off over the empty classes (DeltaE.jl:155-157)
+                k = 3;
+                if (T3 == 0) { k = 2; if (t2 == 0) { k = 1; if (t1 == 0) k = 0; } }
             }
             const double dE0 = k == 0 ? -0.0 : k == 1 ? -fourK : k == 2 ? 0.0 : fourK;
-            int bk = 0, tk = 0;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) if (q == k) { bk = base[q]; tk = t[q]; }
-            const int move = qw_uni((int)l_sv[bk + (int)mulhi64(u_mem, (uint64_t)tk)]);
+            const int sk = __builtin_amdgcn_readfirstlane(k);
+            const int move = (int)l_sv[(__builtin_amdgcn_readlane(bv, sk) + vz) + (int)mulhi_u64_u32(u_mem, (uint32_t)(__builtin_amdgcn_readlane(tvv, sk) + vz))];
+            QW_T(0)
 
             // ---- lane-parallel part: classes of (nb0, nb1, move) before / after the flip, their set positions, the slice bonds ----
             int nb0 = move - Nk; if (nb0 < 0) nb0 += N;
             int nb1 = move + Nk; if (nb1 >= N) nb1 -= N;
             const int ks = (int)__umulhi((uint32_t)move, nk_magic), is = move - ks * Nk, off = ks * Nk;
-            int my_k0 = 0, my_k1 = 0, my_pos = 0, my_sat = 0;
-            if (lane < 3) {
-                const int j = lane == 0 ? nb0 : lane == 1 ? nb1 : move;
-                int j1 = j - Nk; if (j1 < 0) j1 += N;
-                int j2 = j + Nk; if (j2 >= N) j2 -= N;
-                const int sj = bit_of(j), s1 = bit_of(j1), s2 = bit_of(j2);
-                my_k0 = qw_class(sj, s1, s2);
-                my_k1 = qw_class(sj ^ (j == move), s1 ^ (j1 == move), s2 ^ (j2 == move));
-                my_pos = (int)l_spos[j];
-            } else if (lane < 3 + K) {
-                const int q = lane - 3;
-                const int y = (int)l_A[is * K + q];
-                const int sy = bit_of(off + y), si = bit_of(move);
-                my_sat = ((si == sy) == (l_J[is * K + q] > 0)) ? 1 : 0;          // +J_iq sigma_i sigma_y > 0
-            }
-            const unsigned long long satm = __ballot(my_sat != 0);
-            const int npos = __popcll(satm);
-            const int asum = 2 * npos - K;                                        // sum_q J_iq sigma_i sigma_y
-            const double dE1 = (double)(2 * asum) / (double)P.M;                 // delta_energy_residual, QT.jl:270-281
-            const int k0a = __builtin_amdgcn_readlane(my_k0, 0), k1a = __builtin_amdgcn_readlane(my_k1, 0);
-            const int k0b = __builtin_amdgcn_readlane(my_k0, 1), k1b = __builtin_amdgcn_readlane(my_k1, 1);
-            const int k0m = __builtin_amdgcn_readlane(my_k0, 2), k1m = __builtin_amdgcn_readlane(my_k1, 2);
-            int pa = __builtin_amdgcn_readlane(my_pos, 0), pb = __builtin_amdgcn_readlane(my_pos, 1), pm = __builtin_amdgcn_readlane(my_pos, 2);
+            // lanes 0..2: the sites nb0, nb1, move; lanes 3..3+K-1: bond q = lane - 3 of row `is` of the slice graph
+            const int myj = lane == 0 ? nb0 : lane == 1 ? nb1 : move;
+            int j1 = myj - Nk; if (j1 < 0) j1 += N;
+            int j2 = myj + Nk; if (j2 >= N) j2 -= N;
+            const int qk = lane - 3;
+            const bool isq = qk >= 0 && qk < K;
+            const int aidx = isq ? is * K + qk : 0;
+            const int yq = (int)l_A[aidx];
+            const int jq = (int)l_J[aidx];
+            const int sj = bit_of(myj), s1 = bit_of(j1), s2 = bit_of(j2);
+            const int my_k0 = qw_class(sj, s1, s2);
+            const int my_k1 = qw_class(sj ^ (int)(myj == move), s1 ^ (int)(j1 == move), s2 ^ (int)(j2 == move));
+            const int my_pos = (int)l_spos[myj];
+            const int sy = bit_of(isq ? off + yq : 0);
+            const int si = __builtin_amdgcn_readlane(sj, 2) + vz;                 // the moved spin, before the flip
+            // sum_q J_iq sigma_i sigma_y + K = 2 x (bonds with J_iq sigma_i sigma_y > 0): the table index (RRG.jl:236-244)
+            const int ai = 2 * __popcll(__ballot(isq && ((si == sy) == (jq > 0)))) + vz;
+            const int k0a = __builtin_amdgcn_readlane(my_k0, 0) + vz, k1a = __builtin_amdgcn_readlane(my_k1, 0) + vz;
+            const int k0b = __builtin_amdgcn_readlane(my_k0, 1) + vz, k1b = __builtin_amdgcn_readlane(my_k1, 1) + vz;
+            const int k0m = __builtin_amdgcn_readlane(my_k0, 2) + vz, k1m = __builtin_amdgcn_readlane(my_k1, 2) + vz;
+            int pa = __builtin_amdgcn_readlane(my_pos, 0) + vz, pb = __builtin_amdgcn_readlane(my_pos, 1) + vz, pm = __builtin_amdgcn_readlane(my_pos, 2) + vz;
             // k1m == k0m +- 2 always (the moved spin changes direction, DeltaE.jl:275-276)
+            QW_T(1)
 
-            // accept(c, x) (RRRMC.jl:40-44) with x = -beta dE1
-            auto accept = [&](double c) -> bool {
-                const double x = -P.beta * dE1;
-                bool ok = (c >= 1 && x >= 0);
-                if (!ok) {
-                    const double a = c * qw_unid(l_exp[asum + K]);
-                    ok = a >= 1;
-                    if (!ok) ok = qw_unid(l_rng[ri + 2]) < a;
-                }
-                return ok;
+            // accept(c, x) (RRRMC.jl:40-44) with c = z / zp, x = -beta dE1 (dE1 = delta_energy_residual, QT.jl:270-281): c >= 1 is z >= zp
+            // (both positive), so the quotient is only formed when it is needed
+            auto accept = [&](double zz, double zp) -> bool {
+                const bool xok = (xge0 >> ai) & 1u;
+                if (zz >= zp && xok) return true;
+                const double c = zz / zp;
+                const double a = c * l_exp[ai];
+                return a >= 1 || u_acc < a;
             };
+            // class weights: 1.0, except exp(-beta fourK) for class 3; only T3 is a running sum (x - 0.0 and x + 0.0 leave T3 >= +0 as it is)
+            auto w3 = [&](int kk) -> double { return kk == 3 ? ft1 : 0.0; };
             auto fcls = [&](int kk) -> double { return kk == 3 ? ft1 : 1.0; };
             auto flip_move = [&]() { if (lane == 0) l_sp[move >> 5] ^= 1u << (move & 31); };
+            const bool cha = k0a != k1a, chb = k0b != k1b;
 
+            // Float64 bookkeeping of one apply_move! in the reference's order (first neighbour, second neighbour, moved spin,
+            // DeltaE.jl:257-282); a skipped neighbour adds +-0.0, which changes neither T3 (>= +0) nor z' (> 0)
+            const double da0 = cha ? w3(k0a) : 0.0, da1 = cha ? w3(k1a) : 0.0, dza = cha ? fcls(k1a) - fcls(k0a) : 0.0;
+            const double db0 = chb ? w3(k0b) : 0.0, db1 = chb ? w3(k1b) : 0.0, dzb = chb ? fcls(k1b) - fcls(k0b) : 0.0;
+            const double dm0 = w3(k0m), dm1 = w3(k1m), dzm = fcls(k1m) - fcls(k0m);
             bool acc = false;
-            if (acc_rate < P.staged_thr) {
+            if (acc_rate < staged_thr) {
                 // staged branch: step_rrr (RRRMC.jl:131-138) = compute_staged! + compute_reverse_probabilities!, apply_staged! on acceptance
                 staged_its += 1;
                 double T3p = T3, zp = z;
-                if (k0a != k1a) { const double f0 = fcls(k0a), f1 = fcls(k1a); if (k0a == 3) T3p -= f0; if (k1a == 3) T3p += f1; zp += f1 - f0; }
-                if (k0b != k1b) { const double f0 = fcls(k0b), f1 = fcls(k1b); if (k0b == 3) T3p -= f0; if (k1b == 3) T3p += f1; zp += f1 - f0; }
-                { const double f0 = fcls(k0m), f1 = fcls(k1m); if (k0m == 3) T3p -= f0; if (k1m == 3) T3p += f1; zp += f1 - f0; }
-                const double c = z / zp;
-                if (accept(c)) {
+                T3p -= da0; T3p += da1; zp += dza;
+                T3p -= db0; T3p += db1; zp += dzb;
+                T3p -= dm0; T3p += dm1; zp += dzm;
+                if (accept(z, zp)) {
                     flip_move();
-                    if (k0a != k1a) { const int l = set_move(nb0, k0a, k1a, pa); if (l == nb1) pb = pa; if (l == move) pm = pa; }
-                    if (k0b != k1b) { const int l = set_move(nb1, k0b, k1b, pb); if (l == move) pm = pb; }
-                    set_move(move, k0m, k1m, pm);
+                    const int la = set_move(nb0, k0a, k1a, pa, cha);
+                    if (cha && la == nb1) pb = pa;
+                    if (cha && la == move) pm = pa;
+                    const int lb = set_move(nb1, k0b, k1b, pb, chb);
+                    if (chb && lb == move) pm = pb;
+                    set_move(move, k0m, k1m, pm, true);
                     T3 = T3p; z = zp;
-                    E += dE0 + dE1;
+                    E += dE0 + l_dE1[ai];
                     accepted += 1;
                     acc = true;
                 }
+                QW_T(2)
             } else {
                 // direct branch: apply_move! (DeltaE.jl:232-295), undone by a second apply_move! on rejection
                 flip_move();
                 double zp = z;
-                const bool cha = k0a != k1a, chb = k0b != k1b;
-                if (cha) {
-                    const double f0 = fcls(k0a), f1 = fcls(k1a); if (k0a == 3) T3 -= f0; if (k1a == 3) T3 += f1; zp += f1 - f0;
-                    const int l = set_move(nb0, k0a, k1a, pa); if (l == nb1) pb = pa; if (l == move) pm = pa;
-                }
-                if (chb) {
-                    const double f0 = fcls(k0b), f1 = fcls(k1b); if (k0b == 3) T3 -= f0; if (k1b == 3) T3 += f1; zp += f1 - f0;
-                    const int l = set_move(nb1, k0b, k1b, pb); if (l == move) pm = pb;
-                }
+                T3 -= da0; T3 += da1; zp += dza;
+                T3 -= db0; T3 += db1; zp += dzb;
+                T3 -= dm0; T3 += dm1; zp += dzm;
                 {
-                    const double f0 = fcls(k0m), f1 = fcls(k1m); if (k0m == 3) T3 -= f0; if (k1m == 3) T3 += f1; zp += f1 - f0;
-                    set_move(move, k0m, k1m, pm);
+                    const int la = set_move(nb0, k0a, k1a, pa, cha);
+                    if (cha && la == nb1) pb = pa;
+                    if (cha && la == move) pm = pa;
+                    const int lb = set_move(nb1, k0b, k1b, pb, chb);
+                    if (chb && lb == move) pm = pb;
+                    set_move(move, k0m, k1m, pm, true);
                 }
-                const double c = z / zp;
+                QW_T(2)
+                const bool ok = accept(z, zp);
                 z = zp;
-                if (accept(c)) {
-                    E += dE0 + dE1;
+                QW_T(3)
+                if (ok) {
+                    E += dE0 + l_dE1[ai];
                     accepted += 1;
                     acc = true;
                 } else {
-                    // the undo: apply_move! again, from the flipped configuration (classes k1 -> k0, positions re-read)
+                    // the undo: apply_move! again, from the flipped configuration (classes k1 -> k0, slots re-read)
                     flip_move();
                     double zq = z;
-                    int qa = 0, qb = 0, qm = 0;
-                    if (lane < 3) my_pos = (int)l_spos[lane == 0 ? nb0 : lane == 1 ? nb1 : move];
-                    qa = __builtin_amdgcn_readlane(my_pos, 0); qb = __builtin_amdgcn_readlane(my_pos, 1); qm = __builtin_amdgcn_readlane(my_pos, 2);
-                    if (cha) {
-                        const double f0 = fcls(k1a), f1 = fcls(k0a); if (k1a == 3) T3 -= f0; if (k0a == 3) T3 += f1; zq += f1 - f0;
-                        const int l = set_move(nb0, k1a, k0a, qa); if (l == nb1) qb = qa; if (l == move) qm = qa;
-                    }
-                    if (chb) {
-                        const double f0 = fcls(k1b), f1 = fcls(k0b); if (k1b == 3) T3 -= f0; if (k0b == 3) T3 += f1; zq += f1 - f0;
-                        const int l = set_move(nb1, k1b, k0b, qb); if (l == move) qm = qb;
-                    }
-                    {
-                        const double f0 = fcls(k1m), f1 = fcls(k0m); if (k1m == 3) T3 -= f0; if (k0m == 3) T3 += f1; zq += f1 - f0;
-                        set_move(move, k1m, k0m, qm);
-                    }
+                    T3 -= da1; T3 += da0; zq -= dza;
+                    T3 -= db1; T3 += db0; zq -= dzb;
+                    T3 -= dm1; T3 += dm0; zq -= dzm;
+                    const int my_q = (int)l_spos[myj];
+                    int qa = __builtin_amdgcn_readlane(my_q, 0) + vz, qb = __builtin_amdgcn_readlane(my_q, 1) + vz, qm = __builtin_amdgcn_readlane(my_q, 2) + vz;
+                    const int la = set_move(nb0, k1a, k0a, qa, cha);
+                    if (cha && la == nb1) qb = qa;
+                    if (cha && la == move) qm = qa;
+                    const int lb = set_move(nb1, k1b, k0b, qb, chb);
+                    if (chb && lb == move) qm = qb;
+                    set_move(move, k1m, k0m, qm, true);
                     z = zq;
+                    QW_T(4)
                 }
             }
-            acc_rate = acc_rate * (1 - P.lambda) + (acc ? 1.0 : 0.0) * P.lambda;             // RRRMC.jl:281
+            acc_rate = acc_rate * one_m_lambda + (acc ? 1.0 : 0.0) * lambda;                 // RRRMC.jl:281
+            QW_T(5)
         }
     }
+#ifdef RRRMC_STAMPS
+    if (r == 0 && lane == 0 && X.stamps) for (int i = 0; i < 8; ++i) X.stamps[i] = stamp[i];
+#endif
+#undef QW_T
 
     // ---- write the replica back: spins, sets, positions, sizes, the classes (recomputed: the cache is consistent), scalars --------
     __syncthreads();
-    for (int i = lane; i < W; i += kRrrThreads) g_sp[i] = l_sp[i];
-    for (int i = lane; i < N; i += kRrrThreads) {
-        g_spos[i] = l_spos[i];
-        int j1 = i - Nk; if (j1 < 0) j1 += N;
-        int j2 = i + Nk; if (j2 >= N) j2 -= N;
-        g_cls[i] = (uint8_t)qw_class(bit_of(i), bit_of(j1), bit_of(j2));
+    for (int i = lane; i < P.W; i += kRrrThreads) g_sp[i] = l_sp[i];
+    {
+        const int b0 = B_(0), b1 = B_(1), b2 = B_(2), b3 = B_(3);
+        for (int i = lane; i < P.N; i += kRrrThreads) {
+            int j1 = i - P.Nk; if (j1 < 0) j1 += P.N;
+            int j2 = i + P.Nk; if (j2 >= P.N) j2 -= P.N;
+            const int c = qw_class(bit_of(i), bit_of(j1), bit_of(j2));
+            g_cls[i] = (uint8_t)c;
+            g_spos[i] = (uint16_t)((int)l_spos[i] - (c == 0 ? b0 : c == 1 ? b1 : c == 2 ? b2 : b3));
+        }
     }
-    for (int k = 0; k < 4; ++k)
-        for (int i = lane; i < t[k]; i += kRrrThreads) g_sv[(size_t)k * N + i] = l_sv[base[k] + i];
+    for (int k = 0; k < 4; ++k) {
+        const int tk = T_(k), bk = B_(k);
+        for (int i = lane; i < tk; i += kRrrThreads) g_sv[(size_t)k * P.N + i] = l_sv[bk + i];
+    }
+    if (lane < 4) g_t[lane] = ev - bv;
     if (lane == 0) {
-        for (int k = 0; k < 4; ++k) g_t[k] = t[k];
-        P.T[(size_t)r * 4 + 0] = (double)t[0]; P.T[(size_t)r * 4 + 1] = (double)t[1]; P.T[(size_t)r * 4 + 2] = (double)t[2]; P.T[(size_t)r * 4 + 3] = T3;
+        P.T[(size_t)r * 4 + 0] = (double)T_(0); P.T[(size_t)r * 4 + 1] = (double)T_(1); P.T[(size_t)r * 4 + 2] = (double)T_(2); P.T[(size_t)r * 4 + 3] = T3;
         P.zz[r] = z; P.E_cur[r] = E; P.acc_rate[r] = acc_rate;
         P.stats[(size_t)r * 2] = accepted; P.stats[(size_t)r * 2 + 1] = staged_its;
     }

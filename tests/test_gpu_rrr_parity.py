@@ -292,3 +292,33 @@ def test_bkl_and_wtm_on_graph_quant(pkg, oracle, slices, Nk, M, Gamma, beta, R):
         assert (Ew[r] == w[0]).all() and (C2.s[r] == w[1]).all() and mw[r] == w[2][0] and tw[r] == w[3]
         ref = oracle.rrr_mc_quant(A, J, M, X.fourK, beta, 2000, 100, seed, w[1], replica=r)
         assert (Er[r] == ref[0]).all() and (C3.s[r] == ref[1]).all() and ar[r] == ref[2]
+
+
+def test_quant_wave_kernel_equals_thread_kernel_and_respaces(pkg, oracle, monkeypatch):
+    """rrrMC on a GraphQuant has two builds: one wavefront per replica with the DeltaECache in LDS (few replicas) and one thread per
+    replica (many).  Same chain, bit for bit — also when the LDS build is given so little slack between its four set segments
+    that it has to re-space them every few batches (a quench from a random start moves thousands of spins between the classes)."""
+    Nk, M, R, seed, beta, Gamma = 96, 12, 6, 4242, 2.0, 0.5
+    iters, step = 6000, 250
+    X = pkg.GraphQuant(pkg.GraphRRG(Nk, 3, seed=seed), M, Gamma, beta)
+
+    def run():
+        with pkg.Engine(X, R) as eng:
+            eng.seed(seed)
+            eng.init_spins_random()
+            C0 = eng.get_config()
+            Es, acc, staged = eng.rrr_mc(beta, iters, step)
+            Es2, acc2, staged2 = eng.rrr_mc(beta, 777, 100, staged_thr=1.0)      # staged branch, continuing the stream
+            return C0, Es, acc, staged, Es2, acc2, staged2, eng.get_config().s.copy(), eng.rrr_cache()
+
+    monkeypatch.setenv("RRRMC_QUANT_WAVE_SLACK", "2048")
+    wave = run()
+    monkeypatch.delenv("RRRMC_QUANT_WAVE_SLACK")
+    monkeypatch.setenv("RRRMC_QUANT_NO_WAVE", "1")
+    thread = run()
+    for a, b in zip(wave[1:8], thread[1:8]):
+        assert (np.asarray(a) == np.asarray(b)).all()
+    assert (wave[8][0] == thread[8][0]).all() and (wave[8][1] == thread[8][1]).all()
+    A, J = X.X1.A, X.X1.J.astype(np.int32)
+    ref = oracle.rrr_mc_quant(A, J, M, X.fourK, beta, iters, step, seed, wave[0].s[3], replica=3)
+    assert (wave[1][3] == ref[0]).all() and wave[2][3] == ref[2]
