@@ -1,0 +1,165 @@
+# Replay an RNG-free tape (tests/golden/tape_*.txt) through the reference's OWN graph code and compare with the results the tape
+# holds (written by the build's C oracle; the HIP library is checked against the same tapes in tests/test_tapes.py).
+#
+#   julia --project=<an environment that has RRRMC.jl> julia/replay_tape.jl tests/golden/tape_rrg_n128.txt
+#   julia ...                                          julia/replay_tape.jl tests/golden/tape_quant_nk16_m4.txt
+#
+# With the random draws fixed, standardMC / rrrMC are deterministic functions of the reference's energy, delta_energy, spinflip!,
+# DeltaECache and ArraySet code: this script restates only the few lines of the sampler loops that consume random numbers
+# (src/RRRMC.jl:39-44,100-119,249-282; src/DeltaE.jl:146-167) and calls the reference for everything else.
+# It cannot run in the build container (no Julia there): it is the one-command pin for any machine that has Julia.
+# tests/tape_replay.py is the same replay in plain Python.
+using RRRMC
+using RRRMC: Config, energy, delta_energy, spinflip!, getN, inner_graph, delta_energy_residual
+import RRRMC.DeltaE
+import RRRMC.DeltaE: gen_ΔEcache, apply_move!, compute_staged!, compute_reverse_probabilities!, apply_staged!, get_z
+
+function read_tape(path)
+    d = Dict{String,Any}()
+    name, want, buf = "", 0, String[]
+    for line in eachline(path)
+        line = strip(line)
+        (isempty(line) || startswith(line, "#")) && continue
+        if startswith(line, "@")
+            parts = split(line[2:end])
+            if length(parts) == 3 && parts[2] == "array"
+                name, want, buf = String(parts[1]), parse(Int, parts[3]), String[]
+                d[name] = buf
+            else
+                d[String(parts[1])] = String(parts[2])
+                name = ""
+            end
+            continue
+        end
+        name == "" || append!(buf, String.(split(line)))
+    end
+    return d
+end
+
+ints(v) = parse.(Int, v)
+tuples(v, K) = [ntuple(k -> v[(x - 1) * K + k], K) for x = 1:(length(v) ÷ K)]
+function config_from(chunks::Vector{String}, N)
+    C = Config(N, init = false)
+    C.s.chunks .= parse.(UInt64, chunks, base = 16)
+    return C
+end
+chunks_hex(C) = [string(c, base = 16, pad = 16) for c in C.s.chunks]
+
+function replay_standardMC(t)
+    N, K = parse(Int, t["N"]), parse(Int, t["K"])
+    β, iters, step = parse(Float64, t["beta"]), parse(Int, t["iters"]), parse(Int, t["step"])
+    A, J = tuples(ints(t["A"]), K), tuples(ints(t["J"]), K)
+    X = RRRMC.RRG.GraphRRG{Int,(-1, 1),K}(A, J)                  # the inner constructor, src/graphs/RRG.jl:122
+    C = config_from(t["C0"], N)
+    sites, us = ints(t["sites"]), parse.(Float64, t["uniforms"])
+    Es = Int[]
+    E = energy(X, C)                                             # src/RRRMC.jl:95
+    accepted = 0
+    flips = Int[]
+    for it = 1:iters
+        it % step == 0 && push!(Es, E)                           # :104-108
+        i = sites[it]                                            # rand(1:N), :113
+        ΔE = delta_energy(X, C, i)
+        x = -β * ΔE
+        ok = x ≥ 0 || us[it] < exp(x)                            # accept, :39
+        push!(flips, ok)
+        ok || continue
+        spinflip!(X, C, i)
+        E += ΔE
+        accepted += 1
+    end
+    @assert E == energy(X, C)                                    # test/runtests.jl:12-20
+    ok = Es == ints(t["expected_Es"]) && chunks_hex(C) == t["expected_chunks"] &&
+         accepted == parse(Int, t["expected_accepted"]) && flips == ints(t["expected_flips"])
+    println(ok ? "standardMC tape: reference == tape ($(iters) iterations, $(accepted) accepted)" : "standardMC tape: MISMATCH")
+    return ok
+end
+
+function replay_rrrMC_quant(t)
+    Nk, K, M = parse(Int, t["Nk"]), parse(Int, t["K"]), parse(Int, t["M"])
+    β, Γ = parse(Float64, t["beta"]), parse(Float64, t["Gamma"])
+    iters, step = parse(Int, t["iters"]), parse(Int, t["step"])
+    staged_thr, staged_thr_fact = parse(Float64, t["staged_thr"]), parse(Float64, t["staged_thr_fact"])
+    A, J = tuples(ints(t["A"]), K), tuples(ints(t["J"]), K)
+    X = RRRMC.QT.GraphQuant(Nk, M, Γ, β, RRRMC.RRG.GraphRRG{Int,(-1, 1),K}, A, J)     # src/graphs/QT.jl:161-168: M slice graphs over (A, J)
+    N = getN(X)
+    C = config_from(t["C0"], N)
+    ucls, uacc = parse.(Float64, t["u_class"]), parse.(Float64, t["u_accept"])
+    umem = parse.(UInt64, t["u_member"])
+    accept(c, x, u) = (c ≥ 1 && x ≥ 0) || (a = c * exp(x); a ≥ 1 || u < a)           # src/RRRMC.jl:40-44
+    function rand_move(cache, u1, u2)                                                  # src/DeltaE.jl:146-167
+        ΔElist, ascache, T, z = cache.ΔElist, cache.ascache, cache.T, cache.z
+        L = length(ΔElist)
+        r = u1 * z
+        k = 0
+        cT = 0.0
+        for outer k = 1:2L
+            cT += T[k]
+            r < cT && break
+        end
+        r < cT || while T[k] == 0
+            k -= 1
+        end
+        ΔE = k ≤ L ? -ΔElist[k] : ΔElist[k - L]
+        as = ascache[k]
+        move = as.v[Int((UInt128(u2) * as.t) >> 64) + 1]                               # rand(1:t), src/ArraySets.jl:83
+        return move, ΔE
+    end
+    Es = Float64[]
+    E = energy(X, C)
+    X0 = inner_graph(X)
+    cache = gen_ΔEcache(X0, C, β)
+    λ = staged_thr_fact / N
+    staged_its, accepted, acc_rate = 0, 0, 0.5
+    for it = 1:iters                                                                   # src/RRRMC.jl:249-282
+        it % step == 0 && push!(Es, E)
+        acc = false
+        if acc_rate < staged_thr
+            staged_its += 1
+            z = get_z(cache)
+            move, ΔE0 = rand_move(cache, ucls[it], umem[it])
+            compute_staged!(X0, C, move, cache)
+            z′ = compute_reverse_probabilities!(cache)
+            c = z / z′
+            ΔE1 = delta_energy_residual(X, C, move)
+            if accept(c, -β * ΔE1, uacc[it])
+                spinflip!(X, C, move)
+                apply_staged!(cache)
+                E += ΔE0 + ΔE1
+                accepted += 1
+                acc = true
+            end
+        else
+            move, ΔE0 = rand_move(cache, ucls[it], umem[it])
+            ΔE1 = delta_energy_residual(X, C, move)
+            c = apply_move!(X, C, move, cache)
+            if accept(c, -β * ΔE1, uacc[it])
+                E += ΔE0 + ΔE1
+                accepted += 1
+                acc = true
+            else
+                apply_move!(X, C, move, cache)
+            end
+        end
+        acc_rate = acc_rate * (1 - λ) + acc * λ
+    end
+    DeltaE.check_consistency(cache)
+    ok = isapprox(Es, parse.(Float64, t["expected_Es"]), rtol = 1e-12, atol = 1e-12) && chunks_hex(C) == t["expected_chunks"] &&
+         accepted == parse(Int, t["expected_accepted"]) && staged_its == parse(Int, t["expected_staged_its"]) &&
+         [length(a) for a in cache.ascache] == ints(t["expected_sizes"]) && cache.pos == ints(t["expected_pos"])
+    println(ok ? "rrrMC(GraphQuant) tape: reference == tape ($(iters) iterations, $(accepted) accepted, $(staged_its) staged)" :
+                 "rrrMC(GraphQuant) tape: MISMATCH")
+    return ok
+end
+
+function main(paths)
+    allok = true
+    for p in paths
+        t = read_tape(p)
+        allok &= t["kind"] == "standardMC" ? replay_standardMC(t) : replay_rrrMC_quant(t)
+    end
+    exit(allok ? 0 : 1)
+end
+
+main(isempty(ARGS) ? [joinpath(@__DIR__, "..", "tests", "golden", f) for f in
+                      ("tape_rrg_n128.txt", "tape_quant_nk16_m4.txt", "tape_quant_direct.txt")] : ARGS)

@@ -1,0 +1,125 @@
+#!/usr/bin/env python3
+"""Write the RNG-free tapes tests/golden/tape_*.txt: a graph, a start configuration, every random draw of a run (pre-drawn from the
+build's Philox streams) and the results the C oracle obtained.  Replayed by tests/tape_replay.py (plain Python after the Julia
+sources), by julia/replay_tape.jl (the reference's OWN functions, wherever Julia + RRRMC.jl exist: `julia julia/replay_tape.jl
+tests/golden/tape_rrg_n128.txt`) and by the HIP library (tests/test_tapes.py).
+
+A tape is only written if (a) the plain-Python replay — libm exp, Float64 uniforms — reproduces the oracle's run exactly and
+(b) no accept / class-pick decision of the run is closer than 1e-9 (relative) to its threshold, so that the last-bit differences
+between Julia's exp, libm's and the build's det_exp cannot flip a decision of the replay.
+
+  python tests/golden/make_tapes.py      (from the repo root; needs gcc for the oracle)"""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import oracle as O          # noqa: E402
+import tape_replay as TR    # noqa: E402
+
+
+def fmt_array(name, vals):
+    vals = list(vals)
+    lines = ["@%s array %d" % (name, len(vals))]
+    for i in range(0, len(vals), 16):
+        lines.append(" ".join(vals[i:i + 16]))
+    return "\n".join(lines)
+
+
+def u53(u64):
+    return float(int(u64) >> 11) * 2.0 ** -53
+
+
+def write_standard(path, seed, N=128, K=3, beta=1.0, iters=8000, step=250, replica=0):
+    A = O.gen_rrg(N, K, seed)
+    J = O.gen_couplings(A, seed)
+    C0 = O.init_config(seed, replica, N)
+    Es, ch, acc, _lf, sites, flips = O.standard_mc_sparse(A, J, beta, iters, step, seed, C0, replica=replica, trace=True)
+    us = [u53(O.accept_uniform(seed, g, replica)) for g in range(1, iters + 1)]
+    body = ["# RRRMC tape v1 — standardMC(X::GraphRRG{Int,(-1,1),%d}, beta, iters; step, C0) with every random draw pre-drawn" % K,
+            "# (sites 1-based; uniforms are consulted only when delta_energy > 0, src/RRRMC.jl:39).  Written by tests/golden/make_tapes.py",
+            "@kind standardMC", "@N %d" % N, "@K %d" % K, "@beta %r" % beta, "@iters %d" % iters, "@step %d" % step,
+            "@seed %d" % seed, "@replica %d" % replica,
+            fmt_array("A", ("%d" % (v + 1) for v in A.reshape(-1))), fmt_array("J", ("%d" % v for v in J.reshape(-1))),
+            fmt_array("C0", ("%016x" % int(c) for c in C0)),
+            fmt_array("sites", ("%d" % (int(v) + 1) for v in sites)), fmt_array("uniforms", (repr(u) for u in us)),
+            fmt_array("expected_Es", ("%d" % int(e) for e in Es)), fmt_array("expected_chunks", ("%016x" % int(c) for c in ch)),
+            "@expected_accepted %d" % acc, fmt_array("expected_flips", ("%d" % int(f) for f in flips))]
+    tmp = path + ".tmp"
+    open(tmp, "w").write("\n".join(body) + "\n")
+    got = TR.replay_standard_mc(TR.read_tape(tmp))
+    assert got["Es"] == [int(e) for e in Es] and got["chunks"] == [int(c) for c in ch] and got["accepted"] == acc
+    assert got["flips"] == [int(f) for f in flips]
+    if got["min_margin"] < 1e-9:
+        os.remove(tmp)
+        return False
+    os.replace(tmp, path)
+    print("%s: %d iterations, accepted %d, closest decision margin %.2e" % (os.path.basename(path), iters, acc, got["min_margin"]))
+    return True
+
+
+def write_quant(path, seed, Nk=16, K=3, M=4, beta=2.0, Gamma=0.5, iters=3000, step=100, staged_thr=0.5, staged_thr_fact=5.0, replica=0):
+    A = O.gen_rrg(Nk, K, seed)
+    J = O.gen_couplings(A, seed)
+    N = Nk * M
+    fourK = O.quant_fourK(beta, Gamma, M)
+    C0 = O.init_config(seed, replica, N)
+    Es, ch, acc, staged, pos, sizes = O.rrr_mc_quant(A, J, M, fourK, beta, iters, step, seed, C0, replica=replica, staged_thr=staged_thr,
+                                                     staged_thr_fact=staged_thr_fact, want_cache=True)
+    key = np.array([seed & 0xFFFFFFFF, seed >> 32], np.uint32)
+    ucls, umem, uacc = [], [], []
+    for g in range(1, iters + 1):          # RRR stream: sub 0 = (class uniform, member word), sub 1 = acceptance uniform
+        w0 = O.philox([g & 0xFFFFFFFF, g >> 32, replica, 8], key)
+        w1 = O.philox([g & 0xFFFFFFFF, g >> 32, replica, 8 | (1 << 8)], key)
+        ucls.append(u53((int(w0[0]) << 32) | int(w0[1])))
+        umem.append((int(w0[2]) << 32) | int(w0[3]))
+        uacc.append(u53((int(w1[0]) << 32) | int(w1[1])))
+    body = ["# RRRMC tape v1 — rrrMC(X::GraphQuant over GraphRRG{Int,(-1,1),%d} slices, beta, iters; step, C0, staged_thr, staged_thr_fact)" % K,
+            "# with every random draw pre-drawn: u_class = rand() of rand_move (src/DeltaE.jl:148), u_member -> rand(1:t) as",
+            "# floor(u * t / 2^64) + 1 (src/ArraySets.jl:83), u_accept = rand() of accept(c, x) (src/RRRMC.jl:43, only when consulted).",
+            "# All M slices share (A, J).  Written by tests/golden/make_tapes.py",
+            "@kind rrrMC_quant", "@Nk %d" % Nk, "@K %d" % K, "@M %d" % M, "@beta %r" % beta, "@Gamma %r" % Gamma, "@fourK %r" % fourK,
+            "@iters %d" % iters, "@step %d" % step, "@staged_thr %r" % staged_thr, "@staged_thr_fact %r" % staged_thr_fact,
+            "@seed %d" % seed, "@replica %d" % replica,
+            fmt_array("A", ("%d" % (v + 1) for v in A.reshape(-1))), fmt_array("J", ("%d" % v for v in J.reshape(-1))),
+            fmt_array("C0", ("%016x" % int(c) for c in C0)),
+            fmt_array("u_class", (repr(u) for u in ucls)), fmt_array("u_member", ("%d" % u for u in umem)),
+            fmt_array("u_accept", (repr(u) for u in uacc)),
+            fmt_array("expected_Es", (repr(float(e)) for e in Es)), fmt_array("expected_chunks", ("%016x" % int(c) for c in ch)),
+            "@expected_accepted %d" % acc, "@expected_staged_its %d" % staged,
+            fmt_array("expected_sizes", ("%d" % int(v) for v in sizes)), fmt_array("expected_pos", ("%d" % (int(v) + 1) for v in pos))]
+    tmp = path + ".tmp"
+    open(tmp, "w").write("\n".join(body) + "\n")
+    got = TR.replay_rrr_quant(TR.read_tape(tmp))
+    ok = (got["chunks"] == [int(c) for c in ch] and got["accepted"] == acc and got["staged_its"] == staged
+          and got["sizes"] == [int(v) for v in sizes] and got["pos"] == [int(v) + 1 for v in pos]
+          and np.allclose(got["Es"], Es, rtol=1e-12, atol=1e-12) and got["min_margin"] >= 1e-9)
+    if not ok:
+        os.remove(tmp)
+        return False
+    os.replace(tmp, path)
+    print("%s: %d iterations, accepted %d, staged %d, closest decision margin %.2e" % (os.path.basename(path), iters, acc, staged, got["min_margin"]))
+    return True
+
+
+if __name__ == "__main__":
+    O.build()
+    for seed in range(20261003, 20261003 + 50):
+        if write_standard(os.path.join(HERE, "tape_rrg_n128.txt"), seed):
+            break
+    else:
+        raise SystemExit("no seed gave a standardMC tape with a safe decision margin")
+    for seed in range(20261003, 20261003 + 200):
+        if write_quant(os.path.join(HERE, "tape_quant_nk16_m4.txt"), seed):
+            break
+    else:
+        raise SystemExit("no seed gave an rrrMC tape with a safe decision margin")
+    for seed in range(20261003, 20261003 + 200):      # staged_thr = 0: apply_move! and its undo on every rejected move
+        if write_quant(os.path.join(HERE, "tape_quant_direct.txt"), seed, staged_thr=0.0):
+            break
+    else:
+        raise SystemExit("no seed gave a direct-branch rrrMC tape with a safe decision margin")

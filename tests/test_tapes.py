@@ -1,0 +1,154 @@
+"""RNG-free tapes (tests/golden/tape_*.txt): the oracle pinned from outside.
+
+  * CPU: the plain-Python replay (tests/tape_replay.py — written after the Julia sources, libm exp, no code shared with the C
+    oracle) reproduces what the tape holds, i.e. two independent restatements of the reference agree draw for draw; the C oracle run
+    again on the tape's inputs reproduces it too (drift check); the Ising1D closed forms (src/graphs/Ising1D.jl) are a known-answer
+    test of the tape format's bit layout and of delta_energy bookkeeping.
+  * GPU: the HIP library, seeded like the tape, produces the tape's expected results.
+  * Anywhere Julia + RRRMC.jl exist: `julia julia/replay_tape.jl` replays the same files through the reference itself."""
+import os
+
+import numpy as np
+import pytest
+
+import tape_replay as TR
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+STD, QNT, QDIR = (os.path.join(GOLD, f) for f in ("tape_rrg_n128.txt", "tape_quant_nk16_m4.txt", "tape_quant_direct.txt"))
+
+
+def _graph(t, n, K):
+    A = np.array([int(v) - 1 for v in t["A"]], np.int32).reshape(n, K)
+    J = np.array([int(v) for v in t["J"]], np.int32).reshape(n, K)
+    return A, J
+
+
+def test_python_replay_reproduces_the_standard_mc_tape():
+    t = TR.read_tape(STD)
+    got = TR.replay_standard_mc(t)
+    assert got["Es"] == [int(v) for v in t["expected_Es"]]
+    assert got["chunks"] == [int(c, 16) for c in t["expected_chunks"]]
+    assert got["accepted"] == int(t["expected_accepted"]) and got["flips"] == [int(v) for v in t["expected_flips"]]
+    assert got["min_margin"] > 1e-9          # no decision of the tape hinges on the last bits of exp
+
+
+@pytest.mark.parametrize("path", [QNT, QDIR])
+def test_python_replay_reproduces_the_rrr_quant_tapes(path):
+    t = TR.read_tape(path)
+    got = TR.replay_rrr_quant(t)
+    assert got["chunks"] == [int(c, 16) for c in t["expected_chunks"]]
+    assert got["accepted"] == int(t["expected_accepted"]) and got["staged_its"] == int(t["expected_staged_its"])
+    assert got["sizes"] == [int(v) for v in t["expected_sizes"]] and got["pos"] == [int(v) for v in t["expected_pos"]]
+    np.testing.assert_allclose(got["Es"], [float(v) for v in t["expected_Es"]], rtol=1e-12, atol=1e-12)
+    assert got["min_margin"] > 1e-9
+    if path == QDIR:
+        assert got["staged_its"] == 0 and got["accepted"] < int(t["iters"])      # apply_move! and its undo both happen
+    else:
+        assert got["staged_its"] > 0
+
+
+def test_oracle_reproduces_the_tapes(oracle):
+    t = TR.read_tape(STD)
+    N, K, seed = int(t["N"]), int(t["K"]), int(t["seed"])
+    A, J = _graph(t, N, K)
+    assert (A == oracle.gen_rrg(N, K, seed)).all() and (J == oracle.gen_couplings(A, seed)).all()
+    C0 = np.array([int(c, 16) for c in t["C0"]], np.uint64)
+    Es, ch, acc, _lf, sites, flips = oracle.standard_mc_sparse(A, J, float(t["beta"]), int(t["iters"]), int(t["step"]), seed, C0, trace=True)
+    assert [int(e) for e in Es] == [int(v) for v in t["expected_Es"]] and acc == int(t["expected_accepted"])
+    assert [int(c) for c in ch] == [int(c, 16) for c in t["expected_chunks"]]
+    assert [int(s) + 1 for s in sites] == [int(v) for v in t["sites"]] and [int(f) for f in flips] == [int(v) for v in t["expected_flips"]]
+    for path in (QNT, QDIR):
+        t = TR.read_tape(path)
+        Nk, K, M, seed = int(t["Nk"]), int(t["K"]), int(t["M"]), int(t["seed"])
+        A, J = _graph(t, Nk, K)
+        C0 = np.array([int(c, 16) for c in t["C0"]], np.uint64)
+        ref = oracle.rrr_mc_quant(A, J, M, float(t["fourK"]), float(t["beta"]), int(t["iters"]), int(t["step"]), seed, C0,
+                                  staged_thr=float(t["staged_thr"]), staged_thr_fact=float(t["staged_thr_fact"]), want_cache=True)
+        assert [float(e) for e in ref[0]] == [float(v) for v in t["expected_Es"]]
+        assert [int(c) for c in ref[1]] == [int(c, 16) for c in t["expected_chunks"]]
+        assert ref[2] == int(t["expected_accepted"]) and ref[3] == int(t["expected_staged_its"])
+
+
+def test_ising1d_known_answers():
+    """GraphIsing1D (src/graphs/Ising1D.jl:35-93): antiferromagnetic ring (J = -1 in the +-1 convention: the reference stores J = trues
+    and an energy of +sum sigma sigma') in a unit field, E = sum_i sigma_i sigma_{i+1} - sum_i sigma_i, delta_energy as written there,
+    allΔE = (2, 6).  Known answers: the closed-form energies of the uniform and the alternating configurations, delta_energy ==
+    energy difference for every flip, |delta_energy| in allΔE + {... field-shifted values} exactly as the reference's formula gives."""
+    def energy(s):                                        # Ising1D.jl:35-58 in its commented-out direct form (n0) plus the "!!!" field term
+        N = len(s)
+        n = sum((2 * 1 - 1) * (2 * s[i] - 1) * (2 * s[(i + 1) % N] - 1) for i in range(N))
+        return n + N - 2 * sum(s)
+
+    def energy_popcount(s):                               # the BitVector formula the reference actually evaluates (:46-55)
+        N = len(s)
+        J = [1] * N
+        s1 = s[1:] + s[:1]                                # circshift(s, -1)
+        Js = [a & b for a, b in zip(J, s)]
+        Js1 = [a & b for a, b in zip(J, s1)]
+        ss1 = [a & b for a, b in zip(s, s1)]
+        n1 = 8 * sum(a & b for a, b in zip(Js, s1)) - 4 * sum(Js) - 4 * sum(Js1) - 4 * sum(ss1) + 2 * sum(J) + 4 * sum(s) - N
+        return n1 + N - 2 * sum(s)
+
+    def delta_energy(s, move):                            # Ising1D.jl:60-88, move 1-based
+        N = len(s)
+        sg = lambda i: 2 * s[i - 1] - 1
+        d = 0
+        d -= sg(N) * sg(1) if move == 1 else sg(move - 1) * sg(move)
+        d -= sg(N) * sg(1) if move == N else sg(move) * sg(move + 1)
+        return 2 * d + 2 * (2 * s[move - 1] - 1)
+
+    N = 12
+    assert energy([1] * N) == N - N and energy([0] * N) == N + N            # all up: N bonds - N field; all down: N + N
+    assert energy([i & 1 for i in range(N)]) == -N                          # alternating: every bond satisfied, zero magnetisation
+    rng = np.random.default_rng(7)
+    seen = set()
+    for _ in range(50):
+        s = [int(b) for b in rng.integers(0, 2, N)]
+        assert energy(s) == energy_popcount(s)
+        # the BitVector chunk layout of the tapes: site i (1-based) = bit (i-1)&63 of chunk (i-1)>>6
+        assert TR.bits_of_chunks(TR.chunks_of_bits(s), N) == s
+        for move in range(1, N + 1):
+            t = list(s)
+            t[move - 1] ^= 1
+            d = delta_energy(s, move)
+            assert d == energy(t) - energy(s)
+            seen.add(abs(d))
+    assert seen <= {2, 6} and seen == {2, 6}                                # allΔE(GraphIsing1D) = (2, 6), Ising1D.jl:91
+
+
+@pytest.mark.gpu
+def test_hip_library_reproduces_the_standard_mc_tape(pkg):
+    t = TR.read_tape(STD)
+    N, K, seed = int(t["N"]), int(t["K"]), int(t["seed"])
+    X = pkg.GraphRRG(N, K, seed=seed)
+    A, J = _graph(t, N, K)
+    assert (X.A == A).all() and (X.J == J).all()
+    with pkg.Engine(X, 32) as eng:
+        eng.seed(seed)
+        eng.init_spins_random()
+        assert [int(c) for c in eng.get_config().s[0]] == [int(c, 16) for c in t["C0"]]
+        Es, acc = eng.standard_mc(float(t["beta"]), int(t["iters"]), int(t["step"]))
+        C1 = eng.get_config()
+    assert [int(e) for e in Es[0]] == [int(v) for v in t["expected_Es"]] and int(acc[0]) == int(t["expected_accepted"])
+    assert [int(c) for c in C1.s[0]] == [int(c, 16) for c in t["expected_chunks"]]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("path", [QNT, QDIR])
+def test_hip_library_reproduces_the_rrr_quant_tapes(pkg, path):
+    t = TR.read_tape(path)
+    Nk, K, M, seed = int(t["Nk"]), int(t["K"]), int(t["M"]), int(t["seed"])
+    X = pkg.GraphQuant(pkg.GraphRRG(Nk, K, seed=seed), M, float(t["Gamma"]), float(t["beta"]))
+    assert X.fourK == float(t["fourK"])
+    with pkg.Engine(X, 4) as eng:
+        eng.seed(seed)
+        eng.init_spins_random()
+        assert [int(c) for c in eng.get_config().s[0]] == [int(c, 16) for c in t["C0"]]
+        Es, acc, staged = eng.rrr_mc(float(t["beta"]), int(t["iters"]), int(t["step"]), staged_thr=float(t["staged_thr"]),
+                                     staged_thr_fact=float(t["staged_thr_fact"]))
+        C1 = eng.get_config()
+        pos, sizes = eng.rrr_cache()
+    assert [float(e) for e in Es[0]] == [float(v) for v in t["expected_Es"]]
+    assert int(acc[0]) == int(t["expected_accepted"]) and int(staged[0]) == int(t["expected_staged_its"])
+    assert [int(c) for c in C1.s[0]] == [int(c, 16) for c in t["expected_chunks"]]
+    assert [int(v) + 1 for v in pos[0]] == [int(v) for v in t["expected_pos"]] and [int(v) for v in sizes[0]] == [int(v) for v in t["expected_sizes"]]
