@@ -222,6 +222,16 @@ RRRMC_API int32_t rrrmc_extremal_opt_results_f64(rrrmc_ctx *ctx, double *Emin_ou
  * (DeltaECache.pos, 0-based a + 2*up), sizes_out[R * 4] = |class k| (DeltaE.jl:63-73). */
 RRRMC_API int32_t rrrmc_rrr_cache(rrrmc_ctx *ctx, int8_t *pos_out, int32_t *sizes_out);
 
+/* Resumed standardMC calls.  A reference call keeps its incrementally updated cache and its tracked energy E from the first to the last
+ * iteration, hook calls included (src/RRRMC.jl:95-118); a library call starts, like a fresh reference call, from E = energy(X, C) and a
+ * rebuilt cache (:95).  For the integer models the two coincide; for the Float64 models (RRRMC_MODEL_SK_NORMAL / SK_BINARY / SPARSE_F64 /
+ * SPARSE_DISCRETIZED, standardMC on a GraphQuant) the last bits differ.  rrrmc_set_resume(ctx, 1): every following standardMC call that
+ * finds the state left by a previous standardMC call (no rrrmc_set_spins / rrrmc_init_spins_random / other sampler in between) continues
+ * from it — tracked energy, local fields, undo record, move_last — so that a run cut into pieces at the hook points is bit for bit the
+ * run made in one call.  rrrmc_tracked_energy_f64 reads that tracked energy (what the reference hands to its hook), R doubles. */
+RRRMC_API int32_t rrrmc_set_resume(rrrmc_ctx *ctx, int32_t on);
+RRRMC_API int32_t rrrmc_tracked_energy_f64(rrrmc_ctx *ctx, double *E_out);
+
 /* Timing of the last sampling call measured with HIP events on the ctx's stream:
  *   total_ms   first planner launch -> last sweep kernel end
  *   sweep_ms   sum of the sweep (dominant) kernel's durations,  sweep_launches = how many launches */

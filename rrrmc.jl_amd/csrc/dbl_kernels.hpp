@@ -43,6 +43,8 @@ struct RrrDblParams {
     int64_t iters, step;
     uint32_t k0, k1, replica0;
     int N, K, L, W, R, ea_form, energy_only;
+    int32_t* mlast;          // [R] move_last of the residual cache, kept across resumed standardMC calls
+    int resume;              // standardMC continues from E_cur / lf / undo / mlast instead of recomputing them (one chain across hook calls)
     __host__ __device__ __forceinline__ double to_f64(long long units) const { return (double)(units * lev_mul) / lev_div; }
 };
 
@@ -201,8 +203,9 @@ __device__ __forceinline__ bool dbl_accept(double c, double x, uint64_t g, uint3
 
 // energy(X, C) = E0 + E1 (RRG.jl:326-360) — fills the residual fields — and, with `classes`, gen_ΔEcache(X0, C, beta)'s class
 // sets in site order (DeltaE.jl:74-103)
+// the chain's view of replica r's arrays (no computation)
 template <int SLM>
-__device__ __forceinline__ double dbl_init_chain(DblChain<SLM>& c, const RrrDblParams& P, int r, bool classes)
+__device__ __forceinline__ void dbl_bind_chain(DblChain<SLM>& c, const RrrDblParams& P, int r)
 {
     const int N = P.N, K2 = 2 * P.L, K = P.K;
     c.cfg.N = P.N; c.cfg.K = P.K; c.cfg.L = P.L; c.cfg.ea_form = P.ea_form; c.cfg.A = P.A; c.cfg.dJ = P.dJ; c.cfg.rJ = P.rJ;
@@ -211,6 +214,13 @@ __device__ __forceinline__ double dbl_init_chain(DblChain<SLM>& c, const RrrDblP
     c.sp = P.spins + (size_t)r * P.W; c.cls = P.cls + (size_t)r * N; c.sv = P.sv + (size_t)r * K2 * N; c.spos = P.spos + (size_t)r * N;
     c.lf = P.lf + (size_t)r * N; c.undo = P.undo + (size_t)r * (K + 1);
     c.mlast = -1;
+}
+
+template <int SLM>
+__device__ __forceinline__ double dbl_init_chain(DblChain<SLM>& c, const RrrDblParams& P, int r, bool classes)
+{
+    const int N = P.N, K = P.K;
+    dbl_bind_chain(c, P, r);
     long long n0 = 0;
     double E1 = 0.0;
 #pragma unroll
@@ -244,7 +254,14 @@ __global__ __launch_bounds__(kRrrThreads) void dbl_standard_kernel(RrrDblParams 
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= P.R) return;
     DblChain<1> c;           // no class bookkeeping under standardMC
-    double E = dbl_init_chain(c, P, r, false);
+    double E;
+    if (P.resume) {
+        dbl_bind_chain(c, P, r);
+        c.mlast = P.mlast[r];
+        E = P.E_cur[r];
+    } else {
+        E = dbl_init_chain(c, P, r, false);
+    }
     const uint32_t rep = P.replica0 + (uint32_t)r;
     long long accepted = 0, ns = 0;
     long long next_sample = P.step;          // iterations k * step: a counter instead of a 64-bit modulo per iteration
@@ -258,6 +275,7 @@ __global__ __launch_bounds__(kRrrThreads) void dbl_standard_kernel(RrrDblParams 
         if (acc) { c.spinflip(move); E += dE; accepted += 1; }
     }
     P.E_cur[r] = E;
+    P.mlast[r] = c.mlast;
     P.stats[(size_t)r * 2] = accepted; P.stats[(size_t)r * 2 + 1] = 0;
 }
 

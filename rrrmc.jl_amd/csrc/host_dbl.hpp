@@ -96,6 +96,9 @@ int32_t dbl_mc_async(rrrmc_ctx* ctx, bool standard, double beta, int64_t iters, 
     RrrDblParams P = dbl_params(ctx, beta);
     P.staged_thr = staged_thr; P.lambda = staged_thr_fact / (double)ctx->N;
     P.g0 = ctx->it_done; P.iters = iters; P.step = step;
+    if (!ctx->db_mlast) HIP_TRY(ctx, hipMalloc(&ctx->db_mlast, sizeof(int32_t) * (size_t)ctx->R));
+    P.mlast = ctx->db_mlast;
+    P.resume = (standard && ctx->resume && ctx->std_cache_live) ? 1 : 0;      // continue from the tracked energy / residual cache
     hipStream_t st = ctx->stream;
     HIP_TRY(ctx, hipEventRecord(ctx->ev_begin, st));
     HIP_TRY(ctx, hipEventRecord(ctx->ev_sweep[0], st));
@@ -113,6 +116,7 @@ int32_t dbl_mc_async(rrrmc_ctx* ctx, bool standard, double beta, int64_t iters, 
     ctx->timing_valid = true;
     ctx->last_call_rrr = true;          // accepted counts live in q_stats
     ctx->db_cache_valid = !standard;    // the class sets exist only after rrrMC
+    ctx->std_cache_live = standard;
     return RRRMC_OK;
 }
 int32_t dbl_rrr_mc_async(rrrmc_ctx* ctx, double beta, int64_t iters, int64_t step, double staged_thr, double staged_thr_fact)

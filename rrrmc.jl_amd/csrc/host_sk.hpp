@@ -106,8 +106,10 @@ int32_t sk_standard_mc_async(rrrmc_ctx* ctx, double beta, int64_t iters, int64_t
     }
     hipStream_t st = ctx->stream;
     HIP_TRY(ctx, hipEventRecord(ctx->ev_begin, st));
-    int32_t rc = sk_run_energy(ctx);          // E = energy(X, C) at the start of every call, RRRMC.jl:95
-    if (rc) return rc;
+    // E = energy(X, C) at the start of every call (RRRMC.jl:95) — unless the call resumes the previous one (rrrmc_set_resume): then the
+    // tracked energy, both field arrays and move_last continue, as inside one reference call
+    if (!(ctx->resume && ctx->std_cache_live)) { const int32_t rc = sk_run_energy(ctx); if (rc) return rc; }
+    ctx->std_cache_live = true;
     HIP_TRY(ctx, hipMemsetAsync(ctx->d_acc, 0, sizeof(int64_t) * ctx->Rpad, st));
     if (ctx->model == RRRMC_MODEL_SK_BINARY) {
         SkbParams B{};

@@ -97,8 +97,9 @@ int32_t spf_standard_mc_async(rrrmc_ctx* ctx, double beta, int64_t iters, int64_
     }
     hipStream_t st = ctx->stream;
     HIP_TRY(ctx, hipEventRecord(ctx->ev_begin, st));
-    int32_t rc = spf_run_energy(ctx);          // E = energy(X, C) at the start of every call, RRRMC.jl:95
-    if (rc) return rc;
+    // E = energy(X, C) at the start of every call (RRRMC.jl:95) — unless the call resumes the previous one (rrrmc_set_resume)
+    if (!(ctx->resume && ctx->std_cache_live && ctx->pf_lf_live)) { const int32_t rc = spf_run_energy(ctx); if (rc) return rc; }
+    ctx->std_cache_live = true;
     HIP_TRY(ctx, hipMemsetAsync(ctx->d_acc, 0, sizeof(int64_t) * ctx->Rpad, st));
     spf_fn fn = spf_sweep_for_K((int)ctx->K);
     int64_t done = 0;

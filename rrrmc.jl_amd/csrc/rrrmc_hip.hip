@@ -211,6 +211,11 @@ struct rrrmc_ctx {
     int32_t* d_ovl = nullptr;      // [pairs_cap][Rpad]
     int32_t* d_qobs = nullptr;     // GraphQuant: e0[R], Eslice[R][M], ovs_raw[R][M/2]
 
+    // ---- resumed standardMC calls (rrrmc_set_resume): a hooked run of a Float64 model is ONE chain (src/RRRMC.jl:95-118) ----
+    bool resume = false;                // the next standardMC calls continue from the tracked energy and the live cache
+    bool std_cache_live = false;        // the model's cache (fields, undo record) and tracked energy describe the current configuration
+    int32_t* db_mlast = nullptr;        // [R] move_last of the residual cache (RRRMC_MODEL_SPARSE_DISCRETIZED), kept across resumed calls
+
     std::string err;
 };
 
@@ -574,7 +579,7 @@ void rrrmc_ctx_destroy(rrrmc_ctx* ctx)
     free_dev(ctx->rs_buf); free_dev(ctx->rs_spins); free_dev(ctx->rs_status);
     free_dev(ctx->rp_spins); free_dev(ctx->rp_cls); free_dev(ctx->rp_sv); free_dev(ctx->rp_spos);
     free_dev(ctx->pf_J); free_dev(ctx->pf_spins); free_dev(ctx->pf_undo); free_dev(ctx->pf_sites);
-    free_dev(ctx->db_dJ); free_dev(ctx->db_rJ); free_dev(ctx->db_cls); free_dev(ctx->db_sv); free_dev(ctx->db_spos); free_dev(ctx->db_lf); free_dev(ctx->db_undo);
+    free_dev(ctx->db_dJ); free_dev(ctx->db_rJ); free_dev(ctx->db_cls); free_dev(ctx->db_sv); free_dev(ctx->db_spos); free_dev(ctx->db_lf); free_dev(ctx->db_undo); free_dev(ctx->db_mlast);
     free_dev(ctx->wt_t); free_dev(ctx->wt_id); free_dev(ctx->wt_pos); free_dev(ctx->wt_time);
     free_dev(ctx->eo_cmin); free_dev(ctx->eo_ftau);
     free_dev(ctx->q_Jb);
@@ -667,6 +672,7 @@ int64_t rrrmc_iterations_done(const rrrmc_ctx* ctx) { return ctx ? (int64_t)ctx-
 int32_t rrrmc_init_spins_random(rrrmc_ctx* ctx)
 {
     if (!ctx) return RRRMC_ERR_INVALID_ARG;
+    ctx->std_cache_live = false;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     if (chunk_layout(ctx)) {
         const dim3 grid((unsigned)((ctx->qW + 255) / 256), (unsigned)ctx->R);
@@ -707,6 +713,7 @@ int32_t rrrmc_init_spins_random(rrrmc_ctx* ctx)
 
 int32_t rrrmc_set_spins(rrrmc_ctx* ctx, const uint64_t* chunks)
 {
+    if (ctx) ctx->std_cache_live = false;
     if (!ctx) return RRRMC_ERR_INVALID_ARG;
     if (!chunks) return fail(ctx, RRRMC_ERR_INVALID_ARG, "chunks is NULL");
     const int64_t N = ctx->N, nch = (N + 63) / 64;
@@ -1092,6 +1099,26 @@ int32_t rrrmc_standard_mc_async(rrrmc_ctx* ctx, double beta, int64_t iters, int6
     return RRRMC_OK;
 }
 
+int32_t rrrmc_set_resume(rrrmc_ctx* ctx, int32_t on)
+{
+    if (!ctx) return RRRMC_ERR_INVALID_ARG;
+    ctx->resume = on != 0;
+    return RRRMC_OK;
+}
+
+int32_t rrrmc_tracked_energy_f64(rrrmc_ctx* ctx, double* E_out)
+{
+    if (!ctx || !E_out) return RRRMC_ERR_INVALID_ARG;
+    if (sparse_int_model(ctx)) return fail(ctx, RRRMC_ERR_STATE, "integer models: the tracked energy equals rrrmc_energy exactly");
+    if (!ctx->std_cache_live || !ctx->sk_E) return fail(ctx, RRRMC_ERR_STATE, "no standardMC call has left a tracked energy");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    std::vector<double> E((size_t)ctx->Rpad);
+    HIP_TRY(ctx, hipMemcpy(E.data(), ctx->sk_E, sizeof(double) * (size_t)(ctx->model == RRRMC_MODEL_QUANT_RRG || ctx->model == RRRMC_MODEL_SPARSE_DISCRETIZED ? ctx->R : ctx->Rpad), hipMemcpyDeviceToHost));
+    for (int64_t r = 0; r < ctx->R; ++r) E_out[r] = E[(size_t)r];
+    return RRRMC_OK;
+}
+
 int32_t rrrmc_sync(rrrmc_ctx* ctx)
 {
     if (!ctx) return RRRMC_ERR_INVALID_ARG;
@@ -1252,6 +1279,7 @@ int32_t rrrmc_colored_count_accepted(rrrmc_ctx* ctx, int32_t on)
 
 int32_t rrrmc_colored_sweeps_async(rrrmc_ctx* ctx, double beta, int64_t sweeps, int64_t step)
 {
+    if (ctx) ctx->std_cache_live = false;
     int32_t rc = ensure_state(ctx, true);
     if (rc) return rc;
     if (ctx->model != RRRMC_MODEL_SPARSE_PM1) return fail(ctx, RRRMC_ERR_UNSUPPORTED, "colour-parallel sweeps are for sparse +-J models");
@@ -1416,8 +1444,8 @@ int32_t quant_mc_async(rrrmc_ctx* ctx, bool standard, double beta, double fourK,
     HIP_TRY(ctx, hipEventRecord(ctx->ev_begin, st));
     ctx->last_beta = beta; ctx->last_fourK = fourK;
     ctx->stats_stride = 2;
-    rc = quant_run_init(ctx, beta, fourK);
-    if (rc) return rc;
+    const bool cont = standard && ctx->resume && ctx->std_cache_live;      // a resumed standardMC keeps the tracked energy (no cache)
+    if (!cont) { rc = quant_run_init(ctx, beta, fourK); if (rc) return rc; }
     RrrParams P = quant_params(ctx, beta, fourK);
     P.ft1 = host_det_exp(-beta * fourK);
     P.staged_thr = staged_thr;
@@ -1471,12 +1499,14 @@ int32_t quant_mc_async(rrrmc_ctx* ctx, bool standard, double beta, double fourK,
     ctx->timing_valid = true;
     ctx->last_call_rrr = true;          // accepted counts live in q_stats
     ctx->q_cache_valid = !standard;
+    ctx->std_cache_live = standard;
     return RRRMC_OK;
 }
 }  // namespace
 
 int32_t rrrmc_rrr_mc_async(rrrmc_ctx* ctx, double beta, double fourK, int64_t iters, int64_t step, double staged_thr, double staged_thr_fact)
 {
+    if (ctx) ctx->std_cache_live = false;
     int32_t rc = ensure_state(ctx, true);
     if (rc) return rc;
     if (!std::isfinite(beta)) return fail(ctx, RRRMC_ERR_INVALID_ARG, "beta must be finite, given: %g", beta);       // RRRMC.jl:230, :166
@@ -1490,6 +1520,7 @@ int32_t rrrmc_rrr_mc_async(rrrmc_ctx* ctx, double beta, double fourK, int64_t it
 
 int32_t rrrmc_bkl_mc_async(rrrmc_ctx* ctx, double beta, int64_t iters, int64_t step)
 {
+    if (ctx) ctx->std_cache_live = false;
     int32_t rc = ensure_state(ctx, true);
     if (rc) return rc;
     if (!std::isfinite(beta)) return fail(ctx, RRRMC_ERR_INVALID_ARG, "beta must be finite, given: %g", beta);
@@ -1512,6 +1543,7 @@ int32_t rrrmc_quant_set_field(rrrmc_ctx* ctx, double beta, double fourK)
 
 int32_t rrrmc_wtm_mc_async(rrrmc_ctx* ctx, double beta, int64_t samples, double step)
 {
+    if (ctx) ctx->std_cache_live = false;
     int32_t rc = ensure_state(ctx, true);
     if (rc) return rc;
     if (ctx->model == RRRMC_MODEL_SPARSE_F64 || ctx->model == RRRMC_MODEL_SPARSE_DISCRETIZED || ctx->model == RRRMC_MODEL_QUANT_RRG)
@@ -1534,6 +1566,7 @@ int32_t rrrmc_wtm_times(rrrmc_ctx* ctx, double* t_out)
 
 int32_t rrrmc_extremal_opt_async(rrrmc_ctx* ctx, const double* ftau, int64_t iters, int64_t step)
 {
+    if (ctx) ctx->std_cache_live = false;
     int32_t rc = ensure_state(ctx, true);
     if (rc) return rc;
     if (ctx->model == RRRMC_MODEL_SPARSE_F64 || ctx->model == RRRMC_MODEL_SPARSE_DISCRETIZED)        // not DiscrGraphs: EOCacheCont

@@ -118,6 +118,19 @@ class Engine:
                  acc.ctypes.data), self._ctx)
         return (self.X.energy_value(Es) if self._units else Es), acc
 
+    def set_resume(self, on=True):
+        """Make the following standardMC calls continue the previous one (tracked energy, cache) instead of starting like a fresh
+        reference call: a run cut into pieces is then bit for bit the run made in one call (Float64 models; a no-op for integer ones)."""
+        check(lib().rrrmc_set_resume(self._ctx, 1 if on else 0), self._ctx)
+
+    def tracked_energy(self):
+        """The energy the sampler tracks (E += dE per accepted move, src/RRRMC.jl:117) after the last standardMC call."""
+        if not self._f64:
+            return self.energy()
+        E = np.zeros(self.R, np.float64)
+        check(lib().rrrmc_tracked_energy_f64(self._ctx, E), self._ctx)
+        return E
+
     def standard_mc_async(self, beta, iters, step=1):
         check(lib().rrrmc_standard_mc_async(self._ctx, float(beta), int(iters), int(step)), self._ctx)
         self._last = (int(iters), int(step))
@@ -395,7 +408,12 @@ def standardMC(X, beta, iters, *, seed=DEFAULT_SEED, step=1, hook=None, C0=None,
             it = int(iters)
         else:
             samples = []
-            # run up to the move before iteration k*step, call the hook with that state, continue
+            # Run up to the move before iteration k*step, call the hook with that state, continue.  The pieces RESUME one another
+            # (Engine.set_resume): the cache and the tracked energy live on across hook calls as in the reference (RRRMC.jl:95-118), so
+            # the hooked run of a Float64 model is the un-hooked chain bit for bit and the hook sees the tracked E.
+            if it < iters and eng._f64:
+                eng.standard_mc(beta, 0, step=1, want_energies=False)      # E = energy(X, C), fresh cache: the start of a reference call
+            eng.set_resume(True)
             while it < iters:
                 nxt = (it // step + 1) * step          # next sampled iteration
                 n = min(nxt - 1, iters) - it
@@ -405,7 +423,7 @@ def standardMC(X, beta, iters, *, seed=DEFAULT_SEED, step=1, hook=None, C0=None,
                     it += n
                 if nxt > iters:
                     break
-                E = eng.energy()
+                E = eng.tracked_energy()
                 samples.append(E)
                 eng.get_config(Cfg)
                 if not hook(nxt, X, Cfg, accepted.copy(), E):
@@ -414,6 +432,7 @@ def standardMC(X, beta, iters, *, seed=DEFAULT_SEED, step=1, hook=None, C0=None,
                 _, a = eng.standard_mc(beta, 1, step=2, want_energies=False)   # the move of iteration nxt
                 accepted += a
                 it = nxt
+            eng.set_resume(False)
             Es = np.stack(samples, axis=1) if samples else np.zeros((eng.R, 0), X.energy_dtype)
         eng.get_config(Cfg)
         if not quiet:

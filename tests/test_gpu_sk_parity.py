@@ -183,3 +183,36 @@ def test_binary_sk_rrr_bkl_wtm_bit_exact(pkg, oracle, N, R, beta, iters, step, t
         assert (Eb[r] == rb[0]).all() and (C2.s[r] == rb[1]).all() and mb[r] == rb[2]
         rw = oracle.wtm_mc_skb(X.J, beta, 30, 1.5, seed, rb[1], replica=r)
         assert (Ew[r] == rw[0]).all() and (C3.s[r] == rw[1]).all() and mw[r] == rw[2] and tw[r] == rw[3]
+
+
+@pytest.mark.parametrize("kind", ["skn", "skb", "rrgn", "ean", "dbl", "quant"])
+def test_hooked_run_is_the_unhooked_chain_for_float64_models(pkg, oracle, kind):
+    """A run with a hook is ONE reference call (src/RRRMC.jl:95-118): the cache and the tracked E live on across hook calls.  The
+    library's hooked standardMC resumes its pieces (rrrmc_set_resume), so for the Float64 models too the energies handed to the hook
+    — the tracked E — and the final state equal the un-hooked run bit for bit (round 1 re-entered the sampler at every hook point and
+    recomputed E and the fields there: last-bit drift, possibly a forked trajectory)."""
+    seed, R, beta, iters, step = 99, 5, 0.8, 4000, 37
+    X = {"skn": lambda: pkg.GraphSKNormal(96, seed=seed), "skb": lambda: pkg.GraphSK(96, seed=seed),
+         "rrgn": lambda: pkg.GraphRRGNormal(200, 3, seed=seed), "ean": lambda: pkg.GraphEANormal(6, 3, seed=seed),
+         "dbl": lambda: pkg.GraphRRGNormalDiscretized(120, 3, (-1, 0, 1), seed=seed),
+         "quant": lambda: pkg.GraphQuant(pkg.GraphRRG(24, 3, seed=seed), 5, 0.5, 2.0)}[kind]()
+    with pkg.Engine(X, R) as eng:
+        eng.seed(seed)
+        eng.init_spins_random()
+        C0 = eng.get_config()
+        Es_ref, _ = eng.standard_mc(beta, iters, step)
+        C_ref = eng.get_config().s.copy()
+    seen = []
+
+    def hook(it, X_, C, accepted, E):
+        seen.append((it, E.copy(), accepted.copy()))
+        return True
+
+    Cfg = pkg.Config(X.N, R)
+    Cfg.s[:] = C0.s
+    Es, Cend = pkg.standardMC(X, beta, iters, seed=seed, step=step, hook=hook, C0=Cfg, quiet=True, replicas=R)
+    assert Es.shape == Es_ref.shape and (Es == Es_ref).all()           # bit for bit, Float64 included
+    assert (Cend.s == C_ref).all()
+    assert [h[0] for h in seen] == list(range(step, iters + 1, step))
+    assert all((h[1] == Es_ref[:, k]).all() for k, h in enumerate(seen))
+    assert (np.diff(np.stack([h[2] for h in seen]), axis=0) >= 0).all()

@@ -1,0 +1,126 @@
+#!/usr/bin/env python3
+"""Cycle-weighted VALU utilisation model of sweep_kernel<3, 1> (the roofline that binds: the replica state never leaves LDS).
+
+  python tools/valu_model.py         (in the build container: hipcc cross-compiles; reads the committed rocprofv3 / ubench outputs)
+
+Inputs
+  * the kernel's ISA (hipcc -S of a one-kernel translation unit) -> opcode histogram of the whole kernel and of ONE PRODUCER TASK
+    (64 slots: 3 Philox4x32-10 blocks + the bit-sliced threshold refinement) — the producers execute ~85 % of the kernel's VALU
+    wave-instructions, so their mix is taken as the dynamic mix;
+  * profiles/r02/ubench_valu_rates.txt (tools/ubench/valu_rates.hip on the MI355X: ns per wave-instruction per SIMD with 8 waves/SIMD);
+  * profiles/r02/r02a_summary.txt (rocprofv3 --pmc passes of `bench.py --steps 3 --warmup 1`): SQ_INSTS_VALU per launch, GRBM_GUI_ACTIVE.
+Output: profiles/r02/sweep31_isa_hist.txt and profiles/r02/valu_model.json (read by bench.py for roofline.valu)."""
+import collections
+import json
+import os
+import re
+import subprocess
+import sys
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PROF = os.path.join(ROOT, "profiles", "r02")
+SIMDS = 256 * 4
+
+
+def kernel_isa():
+    with tempfile.TemporaryDirectory() as d:
+        src = os.path.join(d, "sw.hip")
+        open(src, "w").write('#include "%s/rrrmc.jl_amd/csrc/sparse_kernels.hpp"\n'
+                             'template __global__ void rrrmc::sweep_kernel<3, 1>(rrrmc::SweepParams);\n' % ROOT)
+        out = os.path.join(d, "sw.s")
+        subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-S", "--cuda-device-only", "-w", "-o", out, src])
+        lines = open(out).read().splitlines()
+    start = next(i for i, l in enumerate(lines) if l.startswith("_ZN5rrrmc12sweep_kernelILi3ELi1EEEvNS_11SweepParamsE:"))
+    end = next(i for i in range(start, len(lines)) if "s_endpgm" in lines[i])
+    return [l.strip() for l in lines[start:end + 1]]
+
+
+def is_inst(l):
+    return bool(l) and not l.startswith((";", ".", "_")) and not l.endswith(":")
+
+
+def ubench_ns():
+    ns = {}
+    for l in open(os.path.join(PROF, "ubench_valu_rates.txt")):
+        m = re.match(r"(\S+)\s+[\d.]+ ms\s+-> ([\d.]+) ns", l)
+        if m:
+            ns[m.group(1)] = float(m.group(2))
+    return ns
+
+
+def cost_ns(op, ns):
+    """ns per wave-instruction per SIMD of one opcode: measured where the ubench has it, else the class it issues like."""
+    base = re.sub(r"_e(32|64)$", "", op)
+    if base in ns:
+        return ns[base]
+    if base.startswith("v_mad_u64") or base.startswith("v_mad_i64"):
+        return ns["v_mad_u64_u32"]
+    if base.startswith(("v_mul_lo", "v_mul_hi")):
+        return ns["v_mul_lo_u32"]
+    three_src = ("v_or3", "v_and_or", "v_bfi", "v_alignbit", "v_lshl_or", "v_lshl_add", "v_add3", "v_xad", "v_add_lshl", "v_perm", "v_bfe", "v_mad_u32_u24", "v_cndmask_b32_e64", "v_lshl_add_u64")
+    if op == "v_cndmask_b32_e64" or base.startswith(three_src):
+        return ns["v_and_or_b32"]
+    if base.startswith("v_bcnt"):
+        return ns["v_bcnt_u32_b32"]
+    return ns["v_xor_b32"]          # one- and two-operand integer ops, moves, compares
+
+
+def pmc():
+    txt = open(os.path.join(PROF, "r02a_summary.txt")).read()
+    blk = lambda tag: txt[txt.index("[%s] void rrrmc::sweep_kernel<3, 1>" % tag):]
+    val = lambda tag, name: float(re.search(r"%s\s+avg=([\d.e+]+)" % name, blk(tag)).group(1))
+    ns = float(re.search(r"sweep_kernel<3, 1>\(rrrmc::SweepParams\)\s+n=\d+ avg_ns=(\d+)", txt).group(1))
+    return {"SQ_INSTS_VALU": val("pmc_sq", "SQ_INSTS_VALU"), "SQ_INSTS_SALU": val("pmc_sq", "SQ_INSTS_SALU"), "SQ_INSTS_LDS": val("pmc_sq", "SQ_INSTS_LDS"),
+            "GRBM_GUI_ACTIVE": val("pmc_lds", "GRBM_GUI_ACTIVE"), "FETCH_SIZE_KB": val("pmc_fetch", "FETCH_SIZE"), "WRITE_SIZE_KB": val("pmc_write", "WRITE_SIZE"),
+            "rocprof_avg_ns": ns}
+
+
+def main():
+    isa = kernel_isa()
+    insts = [l.split()[0] for l in isa if is_inst(l)]
+    whole = collections.Counter(insts)
+    # one producer task = the longest stretch of code between two labels / branches that holds the Philox multiplies
+    blocks, cur = [], []
+    for l in isa:
+        if not is_inst(l) or l.split()[0].startswith(("s_cbranch", "s_branch", "s_barrier")):
+            if cur:
+                blocks.append(cur)
+            cur = []
+        else:
+            cur.append(l.split()[0])
+    task = max(blocks, key=lambda b: sum(o.startswith("v_mad_u64") for o in b))
+    tvalu = collections.Counter(o for o in task if o.startswith("v_"))
+    ns = ubench_ns()
+    n_valu = sum(tvalu.values())
+    task_ns = sum(c * cost_ns(o, ns) for o, c in tvalu.items())
+    P = pmc()
+    clock_hz = P["GRBM_GUI_ACTIVE"] / 8.0 / (P["rocprof_avg_ns"] * 1e-9)          # GRBM_GUI_ACTIVE sums the 8 XCDs
+    mean_ns = task_ns / n_valu
+    model = {"kernel": "sweep_kernel<3, 1>", "simds": SIMDS, "valu_insts_per_launch": P["SQ_INSTS_VALU"], "clock_hz": clock_hz,
+             "mean_issue_ns": mean_ns, "mean_issue_cycles": mean_ns * 1e-9 * clock_hz,
+             "producer_task": {"valu_wave_insts": n_valu, "issue_ns_per_simd": task_ns, "mix": dict(tvalu.most_common())},
+             "pmc": P,
+             "valu_busy_frac_under_rocprof": P["SQ_INSTS_VALU"] * mean_ns * 1e-9 / (SIMDS * P["rocprof_avg_ns"] * 1e-9),
+             "note": "mean issue cost = the producer task's VALU mix (ISA histogram) x tools/ubench/valu_rates.hip (8 waves per SIMD); the producers execute "
+                     "~85 % of the kernel's VALU wave-instructions; SQ_ACTIVE_INST_VALU is not used: on gfx950 it counts one quad-cycle per instruction"}
+    json.dump(model, open(os.path.join(PROF, "valu_model.json"), "w"), indent=1)
+    traffic = {"hbm_bytes_per_launch": (2 * P["FETCH_SIZE_KB"] + P["WRITE_SIZE_KB"]) * 1024.0,
+               "source": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes) of `bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-secondary`, "
+                         "profiles/r02/r02a_summary.txt; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 tallies 128-B requests at 64 B); counters are in KiB"}
+    json.dump(traffic, open(os.path.join(PROF, "traffic.json"), "w"), indent=1)
+    with open(os.path.join(PROF, "sweep31_isa_hist.txt"), "w") as f:
+        f.write("# opcode histogram of sweep_kernel<3, 1> (hipcc -O3 --offload-arch=gfx950 -S), static counts\n")
+        f.write("# whole kernel: %d instructions\n" % len(insts))
+        for o, c in whole.most_common():
+            f.write("%6d %s\n" % (c, o))
+        f.write("\n# one producer task (64 slots x 32 replicas: 3 Philox4x32-10 blocks + threshold refinement): %d instructions, %d VALU, %.0f ns of SIMD issue\n"
+                % (len(task), n_valu, task_ns))
+        for o, c in collections.Counter(task).most_common():
+            f.write("%6d %s   %s\n" % (c, o, ("%.2f ns" % cost_ns(o, ns)) if o.startswith("v_") else ""))
+    print(json.dumps({k: model[k] for k in ("valu_insts_per_launch", "clock_hz", "mean_issue_ns", "mean_issue_cycles", "valu_busy_frac_under_rocprof")}, indent=1))
+    print("traffic per launch: %.1f MB" % (traffic["hbm_bytes_per_launch"] / 1e6))
+
+
+if __name__ == "__main__":
+    sys.exit(main())
