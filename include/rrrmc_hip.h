@@ -179,6 +179,9 @@ RRRMC_API int32_t rrrmc_ctx_create_quant_sk(rrrmc_ctx **out, int64_t Nk, int64_t
  * from: needed by rrrmc_energy_f64 before the first rrrMC call, and by rrrmc_standard_mc_async — standardMC on the GraphQuant
  * (src/RRRMC.jl:81-127 with delta_energy = delta_energy(X0) + delta_energy_residual, QT.jl:283-286; SITE + ACCEPT_F64 streams),
  * which takes fourK from here. */
+/* GraphQuant over GraphEA slices (ea_form = 1; call before rrrmc_set_graph): the slice graph may list a neighbour twice (L = 2: two bonds
+ * to the same site) — delta_energy sums every entry, neighbors() of the continuous-energy caches is the de-duplicated list (EA.jl:158). */
+RRRMC_API int32_t rrrmc_quant_slice_form(rrrmc_ctx *ctx, int32_t ea_form);
 RRRMC_API int32_t rrrmc_quant_set_field(rrrmc_ctx *ctx, double beta, double fourK);
 /* rrrMC(X::DoubleGraph, beta, iters; step, staged_thr, staged_thr_fact) (src/RRRMC.jl:221-290) for all R replicas.
  *   fourK = round(2/beta * log(coth(beta * Gamma / M)), digits = 8)  (QT.jl:165) is computed by the caller.

@@ -845,8 +845,15 @@ static void quant_init(quant_t *Q, int64_t Nk, int64_t M, int64_t K, const int32
     Q->Nk = Nk; Q->M = M; Q->K = K;
     Q->X1 = (sparse_t *)calloc((size_t)M, sizeof(sparse_t));
     Q->C1 = (uint64_t **)calloc((size_t)M, sizeof(uint64_t *));
+    /* which update_cache! the slices follow: GraphRRG's (RRG.jl:191-234) unless a row lists a neighbour twice — only a GraphEA does
+     * (L = 2, EA.jl:156), and its update_cache! walks the de-duplicated uA in the move_last fast path (EA.jl:224-264); without
+     * repeated entries the two forms give the same integers */
+    int form = ORC_FORM_RRG;
+    for (int64_t x = 0; x < Nk && form == ORC_FORM_RRG; ++x)
+        for (int64_t q = 1; q < K; ++q)
+            if (A[x * K + q] == A[x * K + q - 1]) { form = ORC_FORM_EA; break; }
     for (int64_t k = 0; k < M; ++k) {
-        sparse_t X = {Nk, K, A, J, NULL, NULL, -1, 0};
+        sparse_t X = {Nk, K, A, J, NULL, NULL, -1, form};
         X.lfields = (int64_t *)calloc((size_t)Nk, 8);
         X.lfields_last = (int64_t *)calloc((size_t)Nk, 8);
         Q->X1[k] = X;

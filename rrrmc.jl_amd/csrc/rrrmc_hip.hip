@@ -624,12 +624,18 @@ int32_t rrrmc_set_graph(rrrmc_ctx* ctx, const int32_t* A, const int8_t* J)
             if (!found) return fail(ctx, RRRMC_ERR_INVALID_ARG, "bond (%lld,%lld) is not symmetric in (A, J)", (long long)x, (long long)y);
         }
     if (ctx->model == RRRMC_MODEL_QUANT_RRG) {
-        // slice graphs with repeated bonds (GraphEA with L = 2: EA.jl:156) are not covered: the GraphQuant parity tests hold simple graphs only
-        for (int64_t x = 0; x < N; ++x)
+        // Slice graphs that list a neighbour twice (GraphEA with L = 2: two bonds to the same site, EA.jl:24-43,156): delta_energy sums
+        // every entry, neighbors(X1[k], i) is the de-duplicated list uA (EA.jl:158, :292) — GraphEA's rules, announced by the caller with
+        // rrrmc_quant_slice_form(ctx, 1).  A GraphRRG keeps repeated entries in uA (RRG.jl:133): not covered, refused.
+        for (int64_t x = 0; x < N && !ctx->db_ea_form; ++x)
             for (int64_t k = 0; k < K; ++k)
                 for (int64_t l = k + 1; l < K; ++l)
                     if (A[x * K + k] == A[x * K + l])
-                        return fail(ctx, RRRMC_ERR_UNSUPPORTED, "site %lld lists neighbour %d twice: GraphQuant slices must be simple graphs", (long long)x, A[x * K + k]);
+                        return fail(ctx, RRRMC_ERR_UNSUPPORTED, "site %lld lists neighbour %d twice: only GraphEA slices may (call rrrmc_quant_slice_form(ctx, 1) first)", (long long)x, A[x * K + k]);
+        for (int64_t x = 0; x < N && ctx->db_ea_form; ++x)
+            for (int64_t k = 1; k < K; ++k)
+                if (A[x * K + k] < A[x * K + k - 1])
+                    return fail(ctx, RRRMC_ERR_INVALID_ARG, "GraphEA slices: the neighbour rows must be ascending (EA.jl:24-43), violated at site %lld", (long long)x);
         HIP_TRY(ctx, hipSetDevice(ctx->device));
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
         HIP_TRY(ctx, hipMemcpy(ctx->d_A, A, sizeof(int32_t) * N * K, hipMemcpyHostToDevice));
@@ -1529,6 +1535,15 @@ int32_t rrrmc_bkl_mc_async(rrrmc_ctx* ctx, double beta, int64_t iters, int64_t s
     if (ctx->model == RRRMC_MODEL_SK_NORMAL || ctx->model == RRRMC_MODEL_SK_BINARY) return sk_rrr_mc_async(ctx, beta, iters, step, 0.0, 5.0, 1);
     if (!sparse_int_model(ctx)) return fail(ctx, RRRMC_ERR_UNSUPPORTED, "bklMC is wired for the sparse models, RRRMC_MODEL_SK_NORMAL and RRRMC_MODEL_SK_BINARY");
     return sparse_rrr_bkl_async(ctx, 1, beta, iters, step, 0.0, 5.0);
+}
+
+int32_t rrrmc_quant_slice_form(rrrmc_ctx* ctx, int32_t ea_form)
+{
+    if (!ctx) return RRRMC_ERR_INVALID_ARG;
+    if (ctx->model != RRRMC_MODEL_QUANT_RRG || ctx->q_sk) return fail(ctx, RRRMC_ERR_STATE, "rrrmc_quant_slice_form is for a GraphQuant over GraphRRG / GraphEA slices");
+    if (ctx->graph_set) return fail(ctx, RRRMC_ERR_STATE, "rrrmc_quant_slice_form must precede rrrmc_set_graph");
+    ctx->db_ea_form = ea_form ? 1 : 0;
+    return RRRMC_OK;
 }
 
 int32_t rrrmc_quant_set_field(rrrmc_ctx* ctx, double beta, double fourK)

@@ -4,7 +4,7 @@ import ctypes as C
 import numpy as np
 
 from ._lib import RRRMCError, check, lib
-from .graphs import DEFAULT_SEED, Config, nchunks
+from .graphs import DEFAULT_SEED, Config, GraphEA, nchunks
 
 MODEL_SPARSE_PM1 = 1
 MODEL_SK_NORMAL = 2
@@ -34,6 +34,7 @@ class Engine:
                 if X.sk_slices:
                     check(lib().rrrmc_set_couplings_bits(self._ctx, X.J.reshape(-1)), self._ctx)
                 else:
+                    check(lib().rrrmc_quant_slice_form(self._ctx, 1 if isinstance(X.X1, GraphEA) else 0), self._ctx)
                     check(lib().rrrmc_set_graph(self._ctx, X.A, X.J), self._ctx)
                 check(lib().rrrmc_quant_set_field(self._ctx, X.beta, X.fourK), self._ctx)
             elif X.model_kind == MODEL_SPARSE_DISCRETIZED:

@@ -257,6 +257,8 @@ def test_rrr_sparse_lds_and_global_builds_agree(pkg, oracle, monkeypatch, kind, 
 @pytest.mark.parametrize("slices,Nk,M,Gamma,beta,R", [
     ("rrg", 10, 8, 0.5, 2.0, 40),            # test/runtests.jl:78 under bklMC / wtmMC (:145-151)
     ("ea3x2", 9, 5, 0.4, 1.0, 9),            # GraphEA(3, 2) slices (K = 4)
+    ("ea2x3", 8, 6, 0.4, 1.0, 7),            # GraphEA(2, 3) slices: every neighbour listed twice (two bonds, EA.jl:156); uA de-duplicated
+    ("ea2x2", 4, 4, 0.6, 1.5, 5),            # GraphEA(2, 2)
     ("rrg", 64, 16, 0.3, 1.5, 70),
     ("rrg", 1024, 32, 0.5, 2.0, 2),          # BASELINE config 5 geometry
 ])
@@ -265,10 +267,10 @@ def test_bkl_and_wtm_on_graph_quant(pkg, oracle, slices, Nk, M, Gamma, beta, R):
     (DeltaE.jl:315, WaitingTimes.jl) with delta_energy = delta_energy(X0) + residual (QT.jl:283-286) and neighbors = the Trotter pair,
     then the slice graph's (QT.jl:288-321)."""
     seed = 919000 + Nk + M
-    X1 = pkg.GraphEA(3, 2, seed=seed) if slices == "ea3x2" else pkg.GraphRRG(Nk, 3, seed=seed)
+    X1 = pkg.GraphEA(int(slices[2]), int(slices[4]), seed=seed) if slices.startswith("ea") else pkg.GraphRRG(Nk, 3, seed=seed)
     X = pkg.GraphQuant(X1, M, Gamma, beta)
     A, J = X1.A, X1.J.astype(np.int32)
-    form = "ea" if slices == "ea3x2" else "rrg"
+    form = "ea" if slices.startswith("ea") else "rrg"
     iters, step, samples = (4000, 100, 20) if Nk >= 1024 else (12000, 200, 40)
     with pkg.Engine(X, R) as eng:
         eng.seed(seed)
@@ -292,6 +294,15 @@ def test_bkl_and_wtm_on_graph_quant(pkg, oracle, slices, Nk, M, Gamma, beta, R):
         assert (Ew[r] == w[0]).all() and (C2.s[r] == w[1]).all() and mw[r] == w[2][0] and tw[r] == w[3]
         ref = oracle.rrr_mc_quant(A, J, M, X.fourK, beta, 2000, 100, seed, w[1], replica=r)
         assert (Er[r] == ref[0]).all() and (C3.s[r] == ref[1]).all() and ar[r] == ref[2]
+    if slices.startswith("ea2"):             # standardMC on the same GraphQuant (repeated bonds in delta_energy)
+        with pkg.Engine(X, R) as eng:
+            eng.seed(seed)
+            eng.set_config(C0)
+            Es, acc = eng.standard_mc(beta, 3000, 100)
+            C4 = eng.get_config()
+        for r in range(R):
+            ref = oracle.standard_mc_quant(A, J, M, X.fourK, beta, 3000, 100, seed, C0.s[r], replica=r)
+            assert (Es[r] == ref[0]).all() and (C4.s[r] == ref[1]).all() and acc[r] == ref[2]
 
 
 def test_quant_wave_kernel_equals_thread_kernel_and_respaces(pkg, oracle, monkeypatch):
