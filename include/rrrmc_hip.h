@@ -225,6 +225,15 @@ RRRMC_API int32_t rrrmc_extremal_opt_results_f64(rrrmc_ctx *ctx, double *Emin_ou
  * (DeltaECache.pos, 0-based a + 2*up), sizes_out[R * 4] = |class k| (DeltaE.jl:63-73). */
 RRRMC_API int32_t rrrmc_rrr_cache(rrrmc_ctx *ctx, int8_t *pos_out, int32_t *sizes_out);
 
+/* Opt-in FAST standardMC for RRRMC_MODEL_SPARSE_F64 (GraphRRGNormal / GraphEANormal, K <= 4, N <= 8192): replicas bit-sliced and
+ * resident in LDS as for the +-J models, no stored fields — delta_energy takes 2^K values per site, so the accept test runs against
+ * per-site threshold tables.  Same SITE stream as rrrmc_standard_mc_async; the acceptance uniforms come from the ACCEPT bit-plane stream
+ * (as the +-J models) instead of ACCEPT_F64, and delta_energy is the pattern sum 2 sum_k +-|J_ik| instead of the incrementally
+ * updated cache (last-bit differences), so the chain is NOT the one rrrmc_standard_mc_async produces; it is a faithful standardMC
+ * chain with its own oracle restatement (configurations / accepted counts identical to it, energies — re-evaluated at every sample —
+ * within 1e-9 relative).  Two orders of magnitude faster.  Results: rrrmc_sync + rrrmc_fetch_results_f64. */
+RRRMC_API int32_t rrrmc_standard_mc_fast_async(rrrmc_ctx *ctx, double beta, int64_t iters, int64_t step);
+
 /* Resumed standardMC calls.  A reference call keeps its incrementally updated cache and its tracked energy E from the first to the last
  * iteration, hook calls included (src/RRRMC.jl:95-118); a library call starts, like a fresh reference call, from E = energy(X, C) and a
  * rebuilt cache (:95).  For the integer models the two coincide; for the Float64 models (RRRMC_MODEL_SK_NORMAL / SK_BINARY / SPARSE_F64 /

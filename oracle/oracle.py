@@ -562,6 +562,23 @@ def standard_mc_spf(A, J, beta, iters, step, seed, chunks, it0=0, replica=0, for
     return Es[:n], ch, acc.value, lf
 
 
+def standard_mc_spf_fast(A, J, beta, iters, step, seed, chunks, it0=0, replica=0, form="rrg"):
+    """standardMC on GraphRRGNormal / GraphEANormal in the library's FAST mode (pattern delta_energy, ACCEPT bit-plane stream);
+    returns (Es, chunks_out, accepted)."""
+    L = lib()
+    L.orc_standard_mc_spf_fast.restype = C.c_int64
+    L.orc_standard_mc_spf_fast.argtypes = [C.c_int, C.c_int64, C.c_int64, i32p, f64p, C.c_double, C.c_int64, C.c_int64, C.c_uint64, C.c_uint64,
+                                           C.c_uint32, u64p, f64p, C.POINTER(C.c_int64)]
+    A = np.ascontiguousarray(A, np.int32)
+    N, K = A.shape
+    ch = np.array(chunks, np.uint64, copy=True)
+    Es = np.zeros(max(iters // step, 1), np.float64)
+    acc = C.c_int64(0)
+    n = L.orc_standard_mc_spf_fast(1 if form == "ea" else 0, N, K, A, np.ascontiguousarray(J, np.float64).reshape(-1), float(beta), int(iters),
+                                   int(step), seed, it0, replica, ch, Es, C.byref(acc))
+    return Es[:n], ch, int(acc.value)
+
+
 def all_delta_e(K, lev):
     """allΔE for integer levels (RRG.jl:268-281, EA.jl:295-309)"""
     L = lib()

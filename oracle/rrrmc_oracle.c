@@ -640,6 +640,54 @@ ORC_API int64_t orc_standard_mc_spf(int form, int64_t N, int64_t K, const int32_
     return nsamp;
 }
 
+/* The pattern form of delta_energy on GraphRRGNormal / GraphEANormal, used by the library's opt-in FAST standardMC (bit-sliced
+ * replicas, no stored fields): with u_k = "bond k of site i is unsatisfied" (sigma_i sigma_y J_ik < 0),
+ *   delta_energy(i) = 2 sigma_i sum_k J_ik sigma_y = 2 * sum_k (u_k ? -|J_ik| : +|J_ik|),   summed in the order k = 1..K
+ * — the value the reference reads from its incrementally updated cache (RRG.jl:619-625), up to that cache's rounding (documented
+ * deviation of the fast mode: ~1e-16 relative).  Complementing every u_k negates the value exactly. */
+ORC_API double orc_spf_pattern_delta(int64_t K, const double *Jrow, uint32_t u)
+{
+    double s = 0.0;
+    for (int64_t k = 0; k < K; ++k) { const double a = fabs(Jrow[k]); s += ((u >> k) & 1u) ? -a : a; }
+    return 2.0 * s;
+}
+
+/* standardMC (src/RRRMC.jl:81-127) on GraphRRGNormal / GraphEANormal in the library's FAST mode (one chain): SITE stream, delta_energy
+ * in the pattern form above, accept(x) = x >= 0 || u < exp(x) (:39) with the 64-bit uniform of the ACCEPT stream (bit planes, as the
+ * +-J models) against ceil(exp(x) 2^64) — libm exp, computed on the host by oracle and library alike.  E is tracked in Float64
+ * (E += dE); the library re-evaluates the energy at every sample instead, so its samples agree to rounding (1e-6 relative is the
+ * north-star bound for Float64 models), while configurations and accepted counts are identical. */
+ORC_API int64_t orc_standard_mc_spf_fast(int form, int64_t N, int64_t K, const int32_t *A, const double *J, double beta, int64_t iters,
+                                         int64_t step, uint64_t seed, uint64_t it0, uint32_t replica,
+                                         uint64_t *chunks, double *Es, int64_t *accepted_out)
+{
+    spf_t X = {N, K, A, J, NULL, NULL, -1, form, NULL, 1, 1.0, NULL, NULL};
+    X.lfields = (double *)malloc((size_t)N * sizeof(double));
+    X.lfields_last = (double *)malloc((size_t)N * sizeof(double));
+    double E = spf_energy(&X, chunks);                       /* :95 */
+    free(X.lfields); free(X.lfields_last);
+    int64_t accepted = 0, nsamp = 0;
+    for (int64_t it = 1; it <= iters; ++it) {
+        if (it % step == 0) Es[nsamp++] = E;
+        uint64_t g = it0 + (uint64_t)it;
+        int64_t i = orc_site(seed, g, N);
+        uint32_t u = 0;
+        const int si = spin_bit(chunks, i);
+        for (int64_t k = 0; k < K; ++k) {
+            const int sy = spin_bit(chunks, A[i * K + k]);
+            const int neg = J[i * K + k] < 0;
+            u |= (uint32_t)(si ^ sy ^ neg) << k;               /* sigma_i sigma_y J < 0 */
+        }
+        const double dE = orc_spf_pattern_delta(K, J + i * K, u);
+        if (!accept_move(-beta * dE, seed, g, replica)) continue;
+        bitflip(chunks, i);
+        E += dE;
+        accepted += 1;
+    }
+    if (accepted_out) *accepted_out = accepted;
+    return nsamp;
+}
+
 /* =============================================================================================
  * Reduced-rejection-rate path: ArraySet, DeltaECache, GraphQT, GraphQuant, rrrMC(DoubleGraph)
  * ============================================================================================= */

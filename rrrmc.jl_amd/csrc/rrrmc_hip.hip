@@ -24,6 +24,7 @@
 #include "bign_kernels.hpp"
 #include "obs_kernels.hpp"
 #include "spf_kernels.hpp"
+#include "spf_fast_kernels.hpp"
 #include "dbl_kernels.hpp"
 #include "cont_kernels.hpp"
 
@@ -211,6 +212,15 @@ struct rrrmc_ctx {
     int32_t* d_ovl = nullptr;      // [pairs_cap][Rpad]
     int32_t* d_qobs = nullptr;     // GraphQuant: e0[R], Eslice[R][M], ovs_raw[R][M/2]
 
+    // ---- fast standardMC on RRRMC_MODEL_SPARSE_F64 (spf_fast_kernels.hpp; allocated on first use) ----
+    std::vector<double> h_Jf;           // host copy of the couplings (threshold tables per beta)
+    bool pff_ready = false, pff_beta_valid = false;
+    double pff_beta = 0.0;
+    int pff_C = 0;
+    size_t pff_lds = 0, pff_plan_lds = 0;
+    uint16_t* pff_table = nullptr;
+    uint32_t* pff_thr_hi = nullptr; uint32_t* pff_thr_lo = nullptr; uint32_t* pff_flags = nullptr;
+    double* pff_absJ = nullptr;
     // ---- resumed standardMC calls (rrrmc_set_resume): a hooked run of a Float64 model is ONE chain (src/RRRMC.jl:95-118) ----
     bool resume = false;                // the next standardMC calls continue from the tracked energy and the live cache
     bool std_cache_live = false;        // the model's cache (fields, undo record) and tracked energy describe the current configuration
@@ -399,6 +409,78 @@ int32_t run_energy(rrrmc_ctx* ctx, uint8_t* d_nun)
 #include "host_dbl.hpp"
 #include "host_rrr.hpp"
 #include "host_lev.hpp"
+// Chunk list of a random-site sampling call (shared by the +-J kernel and the fast Float64 one): cuts at every multiple of `step`
+// and every C moves.  On return ctx->chunks_n / ctx->chunk_batches describe the list, *reuse_out says whether the list already
+// on the device is the same one (then nothing needs to be uploaded).
+int32_t prepare_chunk_list(rrrmc_ctx* ctx, int64_t iters, int64_t step, int C, bool* reuse_out)
+{
+    // chunk list: cuts at every multiple of `step` (a sample precedes the move of iteration k*step) and every C moves.
+    // ChunkDesc::g0 is relative to the call (the kernels add gbase = it_done), so the list depends on (iters, step, C) only:
+    // back-to-back calls of one shape reuse the list already on the device.  A new shape rewrites the pinned staging buffer —
+    // only after the previous upload from it has completed (several async calls may be queued behind each other).
+    const int64_t nsamp = iters / step;
+    const bool reuse = ctx->chunks_iters == iters && ctx->chunks_step == step && ctx->chunks_C == C;
+    if (!reuse) {
+        std::vector<ChunkDesc> chunks;
+        chunks.reserve((size_t)(iters / C + nsamp + 2));
+        // Every step of the sweep kernel costs about a microsecond whatever its chunk holds, so the iterations between two cuts
+        // (sample points, the end of the call) are divided into the FEWEST chunks of at most C and those are made equally long
+        for (int64_t cur = 1; cur <= iters;) {
+            const int64_t next_sample = (cur / step + 1) * step;
+            int64_t seg_end = next_sample;                        // exclusive end of the segment that may be chunked freely
+            if (seg_end > iters + 1) seg_end = iters + 1;
+            const int64_t seg = seg_end - cur, nch = (seg + C - 1) / C;
+            int64_t end = cur + (seg + nch - 1) / nch;            // ceil(seg / nch) <= C: the remaining chunks re-balance themselves
+            if (end > seg_end) end = seg_end;
+            ChunkDesc cd{};
+            cd.g0 = (uint64_t)cur;
+            cd.count = (uint32_t)(end - cur);
+            cd.flags = (cur % step == 0) ? kChunkSampleBefore : 0u;
+            chunks.push_back(cd);
+            cur = end;
+        }
+        const size_t nch_all = chunks.size();
+        // batches: bounded by the plan buffers; slot_base restarts in every batch
+        ctx->chunk_batches.clear();
+        {
+            size_t first = 0;
+            int64_t slots = 0, samples = 0, sample0 = 0;
+            for (size_t c = 0; c < nch_all; ++c) {
+                if (c > first && (slots + chunks[c].count > kMaxSlotsPerBatch || (int64_t)(c - first) >= kMaxChunksPerBatch)) {
+                    ctx->chunk_batches.push_back({first, c - first, sample0});
+                    first = c; slots = 0; sample0 = samples;
+                }
+                chunks[c].slot_base = (uint32_t)slots;
+                slots += chunks[c].count;
+                if (chunks[c].flags & kChunkSampleBefore) samples += 1;
+            }
+            if (nch_all > first) ctx->chunk_batches.push_back({first, nch_all - first, sample0});
+        }
+        ctx->chunks_iters = -1;                                   // invalid until the new list is staged
+        if (ctx->upload_pending) { HIP_TRY(ctx, hipEventSynchronize(ctx->ev_upload)); ctx->upload_pending = false; }
+        if (nch_all > ctx->chunks_cap) {
+            // the device list may still be read by queued launches of earlier calls
+            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+            HIP_TRY(ctx, hipStreamSynchronize(ctx->plan_stream));
+            free_dev(ctx->d_chunks);
+            ctx->chunks_cap = 0;
+            HIP_TRY(ctx, hipMalloc(&ctx->d_chunks, sizeof(ChunkDesc) * nch_all));
+            ctx->chunks_cap = nch_all;
+        }
+        if (nch_all > ctx->h_chunks_cap) {
+            if (ctx->h_chunks) { (void)hipHostFree(ctx->h_chunks); ctx->h_chunks = nullptr; }
+            ctx->h_chunks_cap = 0;
+            HIP_TRY(ctx, hipHostMalloc(&ctx->h_chunks, sizeof(ChunkDesc) * nch_all));
+            ctx->h_chunks_cap = nch_all;
+        }
+        if (nch_all) std::memcpy(ctx->h_chunks, chunks.data(), sizeof(ChunkDesc) * nch_all);
+        ctx->chunks_n = nch_all;
+    }
+    *reuse_out = reuse;
+    return RRRMC_OK;
+}
+
+#include "host_spf_fast.hpp"
 int32_t quant_mc_async(rrrmc_ctx* ctx, bool standard, double beta, double fourK, int64_t iters, int64_t step, double staged_thr, double staged_thr_fact);
 
 }  // namespace
@@ -580,6 +662,7 @@ void rrrmc_ctx_destroy(rrrmc_ctx* ctx)
     free_dev(ctx->rp_spins); free_dev(ctx->rp_cls); free_dev(ctx->rp_sv); free_dev(ctx->rp_spos);
     free_dev(ctx->pf_J); free_dev(ctx->pf_spins); free_dev(ctx->pf_undo); free_dev(ctx->pf_sites);
     free_dev(ctx->db_dJ); free_dev(ctx->db_rJ); free_dev(ctx->db_cls); free_dev(ctx->db_sv); free_dev(ctx->db_spos); free_dev(ctx->db_lf); free_dev(ctx->db_undo); free_dev(ctx->db_mlast);
+    free_dev(ctx->pff_table); free_dev(ctx->pff_absJ); free_dev(ctx->pff_thr_hi); free_dev(ctx->pff_thr_lo); free_dev(ctx->pff_flags);
     free_dev(ctx->wt_t); free_dev(ctx->wt_id); free_dev(ctx->wt_pos); free_dev(ctx->wt_time);
     free_dev(ctx->eo_cmin); free_dev(ctx->eo_ftau);
     free_dev(ctx->q_Jb);
@@ -931,68 +1014,10 @@ int32_t rrrmc_standard_mc_async(rrrmc_ctx* ctx, double beta, int64_t iters, int6
         for (int plane = 0; plane < 64; ++plane) P.taum[plane * 4 + n] = ((T >> (63 - plane)) & 1ull) ? ~0u : 0u;
     }
 
-    // chunk list: cuts at every multiple of `step` (a sample precedes the move of iteration k*step) and every C moves.
-    // ChunkDesc::g0 is relative to the call (the kernels add gbase = it_done), so the list depends on (iters, step, C) only:
-    // back-to-back calls of one shape reuse the list already on the device.  A new shape rewrites the pinned staging buffer —
-    // only after the previous upload from it has completed (several async calls may be queued behind each other).
+    bool reuse = false;
+    rc = prepare_chunk_list(ctx, iters, step, C, &reuse);
+    if (rc) return rc;
     const int64_t nsamp = iters / step;
-    const bool reuse = ctx->chunks_iters == iters && ctx->chunks_step == step && ctx->chunks_C == C;
-    if (!reuse) {
-        std::vector<ChunkDesc> chunks;
-        chunks.reserve((size_t)(iters / C + nsamp + 2));
-        // Every step of the sweep kernel costs about a microsecond whatever its chunk holds, so the iterations between two cuts
-        // (sample points, the end of the call) are divided into the FEWEST chunks of at most C and those are made equally long
-        for (int64_t cur = 1; cur <= iters;) {
-            const int64_t next_sample = (cur / step + 1) * step;
-            int64_t seg_end = next_sample;                        // exclusive end of the segment that may be chunked freely
-            if (seg_end > iters + 1) seg_end = iters + 1;
-            const int64_t seg = seg_end - cur, nch = (seg + C - 1) / C;
-            int64_t end = cur + (seg + nch - 1) / nch;            // ceil(seg / nch) <= C: the remaining chunks re-balance themselves
-            if (end > seg_end) end = seg_end;
-            ChunkDesc cd{};
-            cd.g0 = (uint64_t)cur;
-            cd.count = (uint32_t)(end - cur);
-            cd.flags = (cur % step == 0) ? kChunkSampleBefore : 0u;
-            chunks.push_back(cd);
-            cur = end;
-        }
-        const size_t nch_all = chunks.size();
-        // batches: bounded by the plan buffers; slot_base restarts in every batch
-        ctx->chunk_batches.clear();
-        {
-            size_t first = 0;
-            int64_t slots = 0, samples = 0, sample0 = 0;
-            for (size_t c = 0; c < nch_all; ++c) {
-                if (c > first && (slots + chunks[c].count > kMaxSlotsPerBatch || (int64_t)(c - first) >= kMaxChunksPerBatch)) {
-                    ctx->chunk_batches.push_back({first, c - first, sample0});
-                    first = c; slots = 0; sample0 = samples;
-                }
-                chunks[c].slot_base = (uint32_t)slots;
-                slots += chunks[c].count;
-                if (chunks[c].flags & kChunkSampleBefore) samples += 1;
-            }
-            if (nch_all > first) ctx->chunk_batches.push_back({first, nch_all - first, sample0});
-        }
-        ctx->chunks_iters = -1;                                   // invalid until the new list is staged
-        if (ctx->upload_pending) { HIP_TRY(ctx, hipEventSynchronize(ctx->ev_upload)); ctx->upload_pending = false; }
-        if (nch_all > ctx->chunks_cap) {
-            // the device list may still be read by queued launches of earlier calls
-            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-            HIP_TRY(ctx, hipStreamSynchronize(ctx->plan_stream));
-            free_dev(ctx->d_chunks);
-            ctx->chunks_cap = 0;
-            HIP_TRY(ctx, hipMalloc(&ctx->d_chunks, sizeof(ChunkDesc) * nch_all));
-            ctx->chunks_cap = nch_all;
-        }
-        if (nch_all > ctx->h_chunks_cap) {
-            if (ctx->h_chunks) { (void)hipHostFree(ctx->h_chunks); ctx->h_chunks = nullptr; }
-            ctx->h_chunks_cap = 0;
-            HIP_TRY(ctx, hipHostMalloc(&ctx->h_chunks, sizeof(ChunkDesc) * nch_all));
-            ctx->h_chunks_cap = nch_all;
-        }
-        if (nch_all) std::memcpy(ctx->h_chunks, chunks.data(), sizeof(ChunkDesc) * nch_all);
-        ctx->chunks_n = nch_all;
-    }
     const size_t nchunks = ctx->chunks_n;
     const std::vector<rrrmc_ctx::BatchDesc>& batches = ctx->chunk_batches;
 
@@ -1103,6 +1128,15 @@ int32_t rrrmc_standard_mc_async(rrrmc_ctx* ctx, double beta, int64_t iters, int6
     ctx->results_valid = true;
     ctx->timing_valid = true;
     return RRRMC_OK;
+}
+
+int32_t rrrmc_standard_mc_fast_async(rrrmc_ctx* ctx, double beta, int64_t iters, int64_t step)
+{
+    int32_t rc = ensure_state(ctx, true);
+    if (rc) return rc;
+    if (ctx->model != RRRMC_MODEL_SPARSE_F64)
+        return fail(ctx, RRRMC_ERR_UNSUPPORTED, "the fast mode exists for RRRMC_MODEL_SPARSE_F64 only (the +-J models always run the bit-sliced kernel)");
+    return spf_fast_mc_async(ctx, beta, iters, step);
 }
 
 int32_t rrrmc_set_resume(rrrmc_ctx* ctx, int32_t on)
@@ -2130,6 +2164,12 @@ int32_t rrrmc_set_graph_f64(rrrmc_ctx* ctx, const int32_t* A, const double* J)
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     HIP_TRY(ctx, hipMemcpy(ctx->d_A, A, sizeof(int32_t) * N * K, hipMemcpyHostToDevice));
     HIP_TRY(ctx, hipMemcpy(ctx->pf_J, J, sizeof(double) * N * K, hipMemcpyHostToDevice));
+    ctx->h_A.assign(A, A + N * K);
+    ctx->h_Jf.assign(J, J + N * K);
+    if (ctx->pff_ready) {            // a new graph: the fast mode's tables are rebuilt on its next call
+        free_dev(ctx->pff_table); free_dev(ctx->pff_absJ); free_dev(ctx->pff_thr_hi); free_dev(ctx->pff_thr_lo); free_dev(ctx->pff_flags);
+        ctx->pff_ready = false;
+    }
     ctx->graph_set = true;
     return RRRMC_OK;
 }

@@ -136,6 +136,17 @@ class Engine:
         check(lib().rrrmc_standard_mc_async(self._ctx, float(beta), int(iters), int(step)), self._ctx)
         self._last = (int(iters), int(step))
 
+    def standard_mc_fast_async(self, beta, iters, step=1):
+        """Opt-in fast standardMC for GraphRRGNormal / GraphEANormal (bit-sliced replicas, per-site threshold tables): a faithful
+        chain, not the bit-exact default one (see include/rrrmc_hip.h).  Then ``sync()`` and ``fetch_results()``."""
+        check(lib().rrrmc_standard_mc_fast_async(self._ctx, float(beta), int(iters), int(step)), self._ctx)
+        self._last = (int(iters), int(step))
+
+    def standard_mc_fast(self, beta, iters, step=1):
+        self.standard_mc_fast_async(beta, iters, step)
+        self.sync()
+        return self.fetch_results()
+
     def sync(self):
         check(lib().rrrmc_sync(self._ctx), self._ctx)
 

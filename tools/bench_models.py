@@ -102,6 +102,31 @@ def bench_spf(N=4096, K=3, R=65536, beta=1.0, iters=1 << 14, step=1 << 12, seed=
         eng.close()
 
 
+def bench_spf_fast(N=4096, K=3, beta=1.0, iters=1 << 20, step=1 << 12, seed=0x5EED):
+    """GraphRRGNormal under the opt-in fast standardMC (bit-sliced replicas, per-site thresholds): python tools/bench_models.py spf_fast 8192"""
+    pkg = entry.load_package()
+    X = pkg.GraphRRGNormal(N, K, seed=seed)
+    for R in ([int(a) for a in sys.argv[2:]] or [8192]):
+        for st in (step, 16 * step):
+            eng = pkg.Engine(X, R)
+            eng.seed(seed)
+            eng.init_spins_random()
+            eng.standard_mc_fast_async(beta, iters // 8, st); eng.sync()
+            t0 = time.perf_counter()
+            eng.standard_mc_fast_async(beta, iters, st); eng.sync()
+            dt = time.perf_counter() - t0
+            total_ms, sweep_ms, nl = eng.last_timing()
+            Es, acc = eng.fetch_results()
+            a = float(acc.mean()) / iters
+            attempts = float(R) * iters
+            bpa = 8 + a * (10 + 17 * K)
+            print(json.dumps({"model": "GraphRRGNormal fast standardMC", "N": N, "K": K, "replicas": R, "beta": beta, "iters": iters, "step": st,
+                              "attempts_per_s": attempts / dt, "kernel_ms": sweep_ms, "launches": nl, "acceptance": a,
+                              "energy_per_spin": float(Es[:, -1].mean()) / N, "algorithmic_bytes_per_attempt": bpa,
+                              "algorithmic_GBps_kernel": bpa * attempts / (sweep_ms * 1e-3) / 1e9}), flush=True)
+            eng.close()
+
+
 def bench_dbl(N=4096, K=3, R=8192, beta=2.0, iters=1 << 14, step=1 << 12, seed=0x5EED):
     """GraphRRGNormalDiscretized(N, K, (-1,0,1)) under rrrMC(X::DoubleGraph) (SURVEY.md §8f rank 3): thread-per-replica kernel."""
     pkg = entry.load_package()
@@ -145,4 +170,4 @@ def bench_ea_random(L=64, D=3, beta=1.0, sweeps=8, seed=0x5EED):
 
 if __name__ == "__main__":
     which = sys.argv[1] if len(sys.argv) > 1 else "sk"
-    {"sk": bench_sk, "ea": bench_ea, "quant": bench_quant, "spf": bench_spf, "dbl": bench_dbl, "ea_random": bench_ea_random}[which]()
+    {"sk": bench_sk, "ea": bench_ea, "quant": bench_quant, "spf": bench_spf, "spf_fast": bench_spf_fast, "dbl": bench_dbl, "ea_random": bench_ea_random}[which]()
