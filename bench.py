@@ -298,13 +298,45 @@ def secondary_c5(pkg, O, device):
     return out
 
 
+def secondary_f64_fast(pkg, O, device):
+    """Float64 sparse model in the opt-in fast mode: GraphRRGNormal(N=4096, K=3) at config 2's geometry (8192 replicas, sample every N)."""
+    N, K, R, beta, iters, step = 4096, 3, 8192, 1.0, 1 << 20, 1 << 12
+    X = pkg.GraphRRGNormal(N, K, seed=SEED)
+    with pkg.Engine(X, R, device=device) as eng:
+        eng.seed(SEED)
+        eng.init_spins_random()
+        eng.standard_mc_fast_async(beta, iters, step); eng.sync()
+        t0 = time.perf_counter()
+        eng.standard_mc_fast_async(beta, iters, step); eng.sync()
+        dt = time.perf_counter() - t0
+        _, k_ms, nl = eng.last_timing()
+        _, acc = eng.fetch_results(want_energies=False)
+    a = float(acc.mean()) / iters
+    bpa = 8 + a * (10 + 17 * K)                                  # SURVEY.md §8d widths: field 8 B, spin 1 B
+    out = {"workload": "GraphRRGNormal(N=4096,K=3) standardMC (fast mode) beta=1.0, 8192 replicas, 2^20 iterations per replica, energy sample every 4096",
+           "value": R * iters / dt, "unit": "attempts/s", "kernel": "spf_fast_kernel<3>", "avg_launch_ms": k_ms / max(nl, 1), "launches": nl,
+           "acceptance": a, "algorithmic_bytes_per_attempt": bpa, "achieved_GBps": bpa * R * iters / (k_ms * 1e-3) / 1e9,
+           "note": "algorithmic bytes of the Float64-field picture (SURVEY.md §8d) over the kernel time: the state lives in LDS, this is a throughput normalisation"}
+    out["frac"] = out["achieved_GBps"] / HBM_PEAK_GBS
+    if O is not None:
+        with pinned_core():
+            ch = O.init_configs(SEED, 0, 1, N)[0]
+            it1 = 1 << 22
+            t0 = time.perf_counter()
+            O.standard_mc_spf(X.A, X.J, beta, it1, step, SEED, ch)
+            out["cpu_one_core"] = {"value": it1 / (time.perf_counter() - t0), "unit": "attempts/s", "kind": "port",
+                                   "sample": "1 replica x 2^22 iterations of the reference's cached-field loop, oracle"}
+    return out
+
+
 def eng_kernel_name_quant():
     return "rrr_quant_wave_kernel" if os.environ.get("RRRMC_QUANT_NO_WAVE") != "1" else "rrr_quant_kernel<true>"
 
 
 def secondary(pkg, O, device):
     out = {}
-    for name, fn in (("c3_sk_normal", secondary_c3), ("c4_ea_checkerboard", secondary_c4), ("c5_quant_rrr", secondary_c5)):
+    for name, fn in (("c3_sk_normal", secondary_c3), ("c4_ea_checkerboard", secondary_c4), ("c5_quant_rrr", secondary_c5),
+                     ("f64_sparse_fast", secondary_f64_fast)):
         t0 = time.perf_counter()
         try:
             out[name] = fn(pkg, O, device)

@@ -37,21 +37,39 @@ int32_t fast_setup(rrrmc_ctx* ctx)
     ctx->pff_lds = fast_lds_bytes(N, (int)K, C);
     ctx->pff_plan_lds = plan_lds_bytes(N, (int)K, C);
     std::vector<uint16_t> table((size_t)N * TS, 0);
-    std::vector<double> absJ((size_t)N * K);
+    std::vector<uint32_t> bond_off;
+    std::vector<double> bond_w;
     for (int64_t x = 0; x < N; ++x)
         for (int64_t k = 0; k < K; ++k) {
             const double j = ctx->h_Jf[(size_t)(x * K + k)];
-            table[(size_t)(x * TS + k)] = (uint16_t)(4 * (2 * ctx->h_A[(size_t)(x * K + k)] + (j < 0 ? 1 : 0)));      // byte offset of word 2y (s_y) or 2y + 1 (~s_y)
-            absJ[(size_t)(x * K + k)] = std::fabs(j);
+            const int64_t y = ctx->h_A[(size_t)(x * K + k)];
+            const uint32_t yoff = (uint32_t)(4 * (2 * y + (j < 0 ? 1 : 0)));      // byte offset of word 2y (s_y) or 2y + 1 (~s_y)
+            table[(size_t)(x * TS + k)] = (uint16_t)yoff;
+            if (y > x) { bond_off.push_back((uint32_t)(8 * x) | (yoff << 16)); bond_w.push_back(std::fabs(j)); }      // every bond once (two entries for a double bond)
         }
+    // the energy phase: blocks of 32 bonds, 32 half-waves -> a multiple of 32 blocks; padding bonds have weight 0
+    const int nblk = (int)(((bond_off.size() + 31) / 32 + 31) / 32 * 32);
+    bond_off.resize((size_t)nblk * 32, 0u);
+    bond_w.resize((size_t)nblk * 32, 0.0);
+    std::vector<double> etab((size_t)nblk * 4 * 256);
+    for (int b = 0; b < nblk; ++b)
+        for (int q = 0; q < 4; ++q)
+            for (int v = 0; v < 256; ++v) {
+                double sum = 0.0;
+                for (int i = 0; i < 8; ++i) { const double w = bond_w[(size_t)b * 32 + q * 8 + i]; sum += ((v >> i) & 1) ? w : -w; }
+                etab[((size_t)b * 4 + q) * 256 + v] = sum;
+            }
+    ctx->pff_nblk = nblk;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipMalloc(&ctx->pff_table, sizeof(uint16_t) * table.size()));
-    HIP_TRY(ctx, hipMalloc(&ctx->pff_absJ, sizeof(double) * absJ.size()));
+    HIP_TRY(ctx, hipMalloc(&ctx->pff_absJ, sizeof(double) * etab.size()));
+    HIP_TRY(ctx, hipMalloc(&ctx->pff_bond_off, sizeof(uint32_t) * bond_off.size()));
     HIP_TRY(ctx, hipMalloc(&ctx->pff_thr_hi, sizeof(uint32_t) * (size_t)N * NT));
     HIP_TRY(ctx, hipMalloc(&ctx->pff_thr_lo, sizeof(uint32_t) * (size_t)N * NT));
     HIP_TRY(ctx, hipMalloc(&ctx->pff_flags, sizeof(uint32_t) * (size_t)N));
     HIP_TRY(ctx, hipMemcpy(ctx->pff_table, table.data(), sizeof(uint16_t) * table.size(), hipMemcpyHostToDevice));
-    HIP_TRY(ctx, hipMemcpy(ctx->pff_absJ, absJ.data(), sizeof(double) * absJ.size(), hipMemcpyHostToDevice));
+    HIP_TRY(ctx, hipMemcpy(ctx->pff_absJ, etab.data(), sizeof(double) * etab.size(), hipMemcpyHostToDevice));
+    HIP_TRY(ctx, hipMemcpy(ctx->pff_bond_off, bond_off.data(), sizeof(uint32_t) * bond_off.size(), hipMemcpyHostToDevice));
     for (int i = 0; i < 2; ++i) {
         if (!ctx->d_slots[i]) HIP_TRY(ctx, hipMalloc(&ctx->d_slots[i], sizeof(uint32_t) * kMaxSlotsPerBatch));
         if (!ctx->d_vecs[i]) HIP_TRY(ctx, hipMalloc(&ctx->d_vecs[i], sizeof(uint32_t) * kMaxSlotsPerBatch));
@@ -152,7 +170,7 @@ int32_t spf_fast_mc_async(rrrmc_ctx* ctx, double beta, int64_t iters, int64_t st
 
     FastParams P{};
     P.spins32 = reinterpret_cast<uint32_t*>(ctx->pf_spins);
-    P.table = ctx->pff_table; P.thr_hi = ctx->pff_thr_hi; P.thr_lo = ctx->pff_thr_lo; P.flags = ctx->pff_flags; P.absJ = ctx->pff_absJ;
+    P.table = ctx->pff_table; P.thr_hi = ctx->pff_thr_hi; P.thr_lo = ctx->pff_thr_lo; P.flags = ctx->pff_flags; P.etab = ctx->pff_absJ; P.bond_off = ctx->pff_bond_off; P.nblk = ctx->pff_nblk;
     P.Es = ctx->sk_Es; P.acc_cur = ctx->d_acc;
     P.k0 = (uint32_t)ctx->seed; P.k1 = (uint32_t)(ctx->seed >> 32);
     P.group0 = ctx->replica0 / 32;

@@ -220,7 +220,9 @@ struct rrrmc_ctx {
     size_t pff_lds = 0, pff_plan_lds = 0;
     uint16_t* pff_table = nullptr;
     uint32_t* pff_thr_hi = nullptr; uint32_t* pff_thr_lo = nullptr; uint32_t* pff_flags = nullptr;
-    double* pff_absJ = nullptr;
+    double* pff_absJ = nullptr;         // the energy phase's tables of partial sums (etab)
+    uint32_t* pff_bond_off = nullptr;
+    int pff_nblk = 0;
     // ---- resumed standardMC calls (rrrmc_set_resume): a hooked run of a Float64 model is ONE chain (src/RRRMC.jl:95-118) ----
     bool resume = false;                // the next standardMC calls continue from the tracked energy and the live cache
     bool std_cache_live = false;        // the model's cache (fields, undo record) and tracked energy describe the current configuration
@@ -662,7 +664,7 @@ void rrrmc_ctx_destroy(rrrmc_ctx* ctx)
     free_dev(ctx->rp_spins); free_dev(ctx->rp_cls); free_dev(ctx->rp_sv); free_dev(ctx->rp_spos);
     free_dev(ctx->pf_J); free_dev(ctx->pf_spins); free_dev(ctx->pf_undo); free_dev(ctx->pf_sites);
     free_dev(ctx->db_dJ); free_dev(ctx->db_rJ); free_dev(ctx->db_cls); free_dev(ctx->db_sv); free_dev(ctx->db_spos); free_dev(ctx->db_lf); free_dev(ctx->db_undo); free_dev(ctx->db_mlast);
-    free_dev(ctx->pff_table); free_dev(ctx->pff_absJ); free_dev(ctx->pff_thr_hi); free_dev(ctx->pff_thr_lo); free_dev(ctx->pff_flags);
+    free_dev(ctx->pff_table); free_dev(ctx->pff_absJ); free_dev(ctx->pff_bond_off); free_dev(ctx->pff_thr_hi); free_dev(ctx->pff_thr_lo); free_dev(ctx->pff_flags);
     free_dev(ctx->wt_t); free_dev(ctx->wt_id); free_dev(ctx->wt_pos); free_dev(ctx->wt_time);
     free_dev(ctx->eo_cmin); free_dev(ctx->eo_ftau);
     free_dev(ctx->q_Jb);
@@ -2167,7 +2169,7 @@ int32_t rrrmc_set_graph_f64(rrrmc_ctx* ctx, const int32_t* A, const double* J)
     ctx->h_A.assign(A, A + N * K);
     ctx->h_Jf.assign(J, J + N * K);
     if (ctx->pff_ready) {            // a new graph: the fast mode's tables are rebuilt on its next call
-        free_dev(ctx->pff_table); free_dev(ctx->pff_absJ); free_dev(ctx->pff_thr_hi); free_dev(ctx->pff_thr_lo); free_dev(ctx->pff_flags);
+        free_dev(ctx->pff_table); free_dev(ctx->pff_absJ); free_dev(ctx->pff_bond_off); free_dev(ctx->pff_thr_hi); free_dev(ctx->pff_thr_lo); free_dev(ctx->pff_flags);
         ctx->pff_ready = false;
     }
     ctx->graph_set = true;

@@ -14,7 +14,8 @@
 //     (threshold words are per lane here, not wave-uniform scalars: one v_bfe_i32 per plane and threshold more than the +-J kernel);
 //   * the consumer picks, per replica, the mask of its pattern pair;
 //   * the energy is not tracked per move (a Float64 sum per replica cannot be bit-sliced): at every sample point all 16 waves
-//     of the workgroup re-evaluate E = sum_bonds |J| (2u - 1) / 2 from the LDS-resident spins, lane = replica, in a fixed order.
+//     of the workgroup re-evaluate E = sum_bonds |J| (unsatisfied ? +1 : -1) from the LDS-resident spins: bit transposes + host-made
+//     tables of the 256 partial sums of every 8 bonds, in a fixed order.
 // Parity contract (tests/test_gpu_spf_fast.py): configurations and accepted counts identical to the oracle's restatement of this mode
 // (orc_standard_mc_spf_fast: same streams, same thresholds, computed on the host with libm exp by both); energies within 1e-9
 // relative of the oracle's tracked Float64 energy (the north star asks 1e-6 for Float64 models).  The mode differs from the default
@@ -40,7 +41,9 @@ struct FastParams {
     const uint32_t* thr_hi;   // [N][NT] bits 63..32 of the thresholds
     const uint32_t* thr_lo;   // [N][NT] bits 31..0 (only the fixer's late planes read them)
     const uint32_t* flags;    // [N] bit c: pair c is accepted on both sides (dE = 0); bit 8 + c: u_1 of the tested side of pair c
-    const double* absJ;       // [N][K] |J|
+    const uint32_t* bond_off; // [nblk * 32] every bond once: byte offset of word s_x | byte offset of the (sign-folded) word of y << 16
+    const double* etab;       // [nblk][4][256] sum of +-|J| over 8 consecutive bonds by their unsatisfied-bits byte (the energy phase)
+    int nblk;                 // blocks of 32 bonds, a multiple of 32 (padded with zero-weight bonds)
     const ChunkDesc* chunks;
     const uint32_t* slots;
     const uint32_t* vecs;
@@ -321,29 +324,32 @@ __global__ __launch_bounds__(kSweepThreads) void spf_fast_kernel(FastParams P)
         return l;
     };
 
-    // ---- energy phase: every wave sums |J| (2u - 1) over its block of sites, lane = replica (the two wave halves take alternate
-    // sites), partials to LDS; the tally wave adds the 32 partials of a replica in a fixed order after the barrier ----
+    // ---- energy phase: E = sum over bonds of |J| (unsatisfied ? +1 : -1), every bond once.  A half-wave takes 32 bonds at a time: lane =
+    // bond computes the bond's unsatisfied word (32 replicas), a 32 x 32 bit transpose turns it into lane = replica with 32 bond bits,
+    // and the four bytes index tables of the 256 possible partial sums of 8 bonds (host-made, L2-resident: the weights do not depend
+    // on the state).  Partials to LDS; the tally wave adds the 32 partials of a replica in a fixed order after the barrier ----
     auto energy_partials = [&]() {
-        const int per = (N + 15) / 16, x0 = wave * per, x1 = (x0 + per < N) ? x0 + per : N;
-        const int h = lane >> 5, rr = lane & 31;
+        TransposeConsts etc;
+        etc.init(lane);
+        const int hw = wave * 2 + (lane >> 5), rr = lane & 31;
         double e = 0.0;
-        for (int x = x0 + h; x < x1; x += 2) {
-            const uint32_t s = sp[2 * x];
-            const uint16_t* row = P.table + (size_t)x * P.TS;
-#pragma unroll
-            for (int k = 0; k < K; ++k) {
-                const uint32_t gk = lds_word<1>(sp, (uint32_t)row[k]);
-                const double a = P.absJ[(size_t)x * K + k];
-                e += (((s ^ gk) >> rr) & 1u) ? a : -a;
-            }
+        for (int b = hw; b < P.nblk; b += 32) {
+            const uint32_t bo = P.bond_off[(size_t)b * 32 + rr];
+            const uint32_t u = lds_word<1>(sp, bo & 0xffffu) ^ lds_word<1>(sp, bo >> 16);
+            const uint32_t t = transpose32(u, etc);
+            const double* tb = P.etab + (size_t)b * 4 * 256;
+            e += tb[t & 255u];
+            e += tb[256 + ((t >> 8) & 255u)];
+            e += tb[512 + ((t >> 16) & 255u)];
+            e += tb[768 + (t >> 24)];
         }
-        epart[(wave * 2 + h) * 32 + rr] = e;
+        epart[hw * 32 + rr] = e;
     };
     auto energy_emit = [&](int64_t sample) {          // tally wave, after the barrier
         if (lane < 32) {
             double e = 0.0;
             for (int q = 0; q < 32; ++q) e += epart[q * 32 + lane];
-            if (P.Es) P.Es[(size_t)sample * P.Rpad + blockIdx.x * 32 + lane] = 0.5 * e;      // every bond is seen from both ends
+            if (P.Es) P.Es[(size_t)sample * P.Rpad + blockIdx.x * 32 + lane] = e;
         }
     };
 
