@@ -196,20 +196,23 @@ int32_t sparse_rrr_bkl_async(rrrmc_ctx* ctx, int mode, double beta, int64_t iter
 {
     if (iters < 0) return fail(ctx, RRRMC_ERR_INVALID_ARG, "iters must be >= 0, given %lld", (long long)iters);
     if (step < 1) return fail(ctx, RRRMC_ERR_INVALID_ARG, "step must be >= 1, given %lld", (long long)step);
-    if (ctx->N > 65535) return fail(ctx, RRRMC_ERR_UNSUPPORTED, "N=%lld: the rrrMC kernel indexes spins with 16 bits", (long long)ctx->N);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     ctx->results_valid = false; ctx->last_call_wtm = false; ctx->last_call_eo = false;
     ctx->timing_valid = false;
     const int64_t N = ctx->N, K = ctx->K, R = ctx->R;
     const int L = ctx->lv.L;
+    // set members / positions are 16-bit spin ids up to N = 65 535, 32-bit beyond (GraphEA(64, 3): N = 262 144)
+    const bool wide_idx = N > 65535;
+    const size_t idx_bytes = wide_idx ? 4 : 2;
+    if (N > (int64_t)1 << 28) return fail(ctx, RRRMC_ERR_UNSUPPORTED, "N=%lld is beyond the rrrMC kernel (N <= 2^28)", (long long)N);
     RpView rv;
     int32_t rc = rp_prepare(ctx, &rv);
     if (rc) return rc;
     const int64_t W = rv.W;
     if (!ctx->rp_cls) {
         HIP_TRY(ctx, hipMalloc(&ctx->rp_cls, (size_t)R * N));
-        HIP_TRY(ctx, hipMalloc(&ctx->rp_sv, sizeof(uint16_t) * R * 2 * L * N));
-        HIP_TRY(ctx, hipMalloc(&ctx->rp_spos, sizeof(uint16_t) * R * N));
+        HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->rp_sv), idx_bytes * R * 2 * L * N));
+        HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->rp_spos), idx_bytes * R * N));
         if (!ctx->q_stats) HIP_TRY(ctx, hipMalloc(&ctx->q_stats, sizeof(int64_t) * R * 3));
     }
     ctx->stats_stride = 3;
@@ -244,13 +247,16 @@ int32_t sparse_rrr_bkl_async(rrrmc_ctx* ctx, int mode, double beta, int64_t iter
         // few replicas run one per workgroup anyway: stage the replica's hot state and the graph in LDS if they fit
         const size_t lds = rrr_sparse_lds_bytes(N, W, K);
         const char* no_lds = std::getenv("RRRMC_RRR_NO_LDS");            // tests / timing experiments
-        const bool use_lds = rrr_tpb(R) == 1 && lds <= (size_t)kLdsLimit && !(no_lds && no_lds[0] == '1');
+        const bool use_lds = !wide_idx && rrr_tpb(R) == 1 && lds <= (size_t)kLdsLimit && !(no_lds && no_lds[0] == '1');
         // the per-class arrays are sized at compile time (2, 4 or 8 levels) so that they stay in registers
         typedef void (*rs_fn)(RrrSparseParams);
         const int slm = L <= 2 ? 0 : (L <= 4 ? 1 : 2);
         static const rs_fn lds_fns[3] = {rrr_sparse_kernel<true, 2>, rrr_sparse_kernel<true, 4>, rrr_sparse_kernel<true, 8>};
         static const rs_fn glb_fns[3] = {rrr_sparse_kernel<false, 2>, rrr_sparse_kernel<false, 4>, rrr_sparse_kernel<false, 8>};
-        if (use_lds) {
+        static const rs_fn wide_fns[3] = {rrr_sparse_kernel<false, 2, uint32_t>, rrr_sparse_kernel<false, 4, uint32_t>, rrr_sparse_kernel<false, 8, uint32_t>};
+        if (wide_idx) {
+            hipLaunchKernelGGL(wide_fns[slm], dim3(rrr_blocks(R)), dim3(rrr_tpb(R)), 0, st, P);
+        } else if (use_lds) {
             HIP_TRY(ctx, raise_lds_attr(reinterpret_cast<const void*>(lds_fns[slm]), lds));
             hipLaunchKernelGGL(lds_fns[slm], dim3((unsigned)R), dim3(kRrrThreads), lds, st, P);
         } else {

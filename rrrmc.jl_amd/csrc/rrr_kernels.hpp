@@ -1088,8 +1088,8 @@ struct RrrSparseParams {
     const int8_t* J;         // [N][K]
     uint32_t* spins;         // [R][W]   replica-contiguous words
     uint8_t* cls;            // [R][N]
-    uint16_t* sv;            // [R][2L][N]
-    uint16_t* spos;          // [R][N]
+    void* sv;                // [R][2L][N]  IDX = uint16_t, or uint32_t when N > 65535 (GraphEA(64, 3): N = 262 144)
+    void* spos;              // [R][N]
     int32_t* E_cur;          // [Rpad]
     int64_t* acc_cur;        // [Rpad]
     int64_t* stats;          // [R][3]   accepted, staged iterations / true moves, iterations done
@@ -1107,13 +1107,13 @@ struct RrrSparseParams {
 // are LDS copies
 // SLM = compile-time bound on the number of levels (2, 4 or 8): the per-class arrays have 2 SLM entries and must stay in REGISTERS
 // (dynamically indexed arrays of 16 doubles end up in scratch memory, a memory round trip per access: 5x slower kernels)
-template <bool LDS, int SLM>
+template <bool LDS, int SLM, typename IDX = uint16_t>
 struct SparseChain {
     // copies of the few parameters the chain needs: a pointer to the kernel's parameter struct would force that struct — and every
     // access to it — into scratch memory
     struct Cfg { int N, K, L, skip_zero; const int32_t* A; const int8_t* J; int dEl[SLM]; double ft[SLM]; };
     Cfg cfg;
-    uint32_t* sp; uint8_t* cls; uint16_t* sv; uint16_t* spos;
+    uint32_t* sp; uint8_t* cls; IDX* sv; IDX* spos;
     const uint16_t* A16; const int8_t* Jl;          // LDS copies of the neighbour table / couplings (LDS build only)
     __device__ __forceinline__ int nbr(int i, int q) const { if constexpr (LDS) return (int)A16[i * cfg.K + q]; else return (int)cfg.A[(size_t)i * cfg.K + q]; }
     __device__ __forceinline__ int cpl(int i, int q) const { if constexpr (LDS) return (int)Jl[i * cfg.K + q]; else return (int)cfg.J[(size_t)i * cfg.K + q]; }
@@ -1185,12 +1185,12 @@ struct SparseChain {
         return x; }
     __device__ __forceinline__ void set_move(int j, int k0, int k1)
     {
-        uint16_t* v0 = sv + (size_t)k0 * cfg.N;
-        uint16_t* v1 = sv + (size_t)k1 * cfg.N;
-        const int p = spos[j], last = v0[tg(k0) - 1];
-        v0[p] = (uint16_t)last; spos[last] = (uint16_t)p; tadd(k0, -1);
+        IDX* v0 = sv + (size_t)k0 * cfg.N;
+        IDX* v1 = sv + (size_t)k1 * cfg.N;
+        const int p = (int)spos[j], last = (int)v0[tg(k0) - 1];
+        v0[p] = (IDX)last; spos[last] = (IDX)p; tadd(k0, -1);
         const int t1 = tg(k1);
-        v1[t1] = (uint16_t)j; spos[j] = (uint16_t)t1; tadd(k1, 1);
+        v1[t1] = (IDX)j; spos[j] = (IDX)t1; tadd(k1, 1);
         cls[j] = (uint8_t)k1;
     }
     // apply_move!: DeltaE.jl:232-295; returns c = z / z'
@@ -1225,7 +1225,7 @@ inline size_t rrr_sparse_lds_bytes(int64_t N, int64_t W, int64_t K)
 // rrr_quant_kernel: the replica's spins, class bytes and set positions and the graph (16-bit neighbour ids, couplings) staged in LDS
 // by all 64 lanes, the two Philox blocks of an rrrMC iteration computed 64 iterations at a time by the whole wavefront; lane 0
 // runs the chain.  The reference's own experiment (scripts/scripts.jl:test_RRG: N = 10^4, K = 3) takes 121 KB.
-template <bool LDS, int SLM>
+template <bool LDS, int SLM, typename IDX = uint16_t>
 __global__ __launch_bounds__(kRrrThreads) void rrr_sparse_kernel(RrrSparseParams P)
 {
     extern __shared__ uint32_t rs_lds[];
@@ -1237,13 +1237,14 @@ __global__ __launch_bounds__(kRrrThreads) void rrr_sparse_kernel(RrrSparseParams
         if (r >= P.R) return;
     }
     const int N = P.N, L = P.L, K2 = 2 * P.L;
-    SparseChain<LDS, SLM> c;
+    static_assert(!LDS || sizeof(IDX) == 2, "the LDS build keeps 16-bit positions");
+    SparseChain<LDS, SLM, IDX> c;
     c.cfg.N = P.N; c.cfg.K = P.K; c.cfg.L = P.L; c.cfg.skip_zero = P.lv.skip_zero; c.cfg.A = P.A; c.cfg.J = P.J;
 #pragma unroll
     for (int k = 0; k < SLM; ++k) { c.cfg.dEl[k] = P.lv.dElist[k]; c.cfg.ft[k] = P.ft[k]; }
-    c.sp = P.spins + (size_t)r * P.W; c.cls = P.cls + (size_t)r * N; c.sv = P.sv + (size_t)r * K2 * N; c.spos = P.spos + (size_t)r * N;
+    c.sp = P.spins + (size_t)r * P.W; c.cls = P.cls + (size_t)r * N; c.sv = static_cast<IDX*>(P.sv) + (size_t)r * K2 * N; c.spos = static_cast<IDX*>(P.spos) + (size_t)r * N;
     c.A16 = nullptr; c.Jl = nullptr;
-    uint32_t* g_sp = c.sp; uint8_t* g_cls = c.cls; uint16_t* g_spos = c.spos;
+    uint32_t* g_sp = c.sp; uint8_t* g_cls = c.cls; IDX* g_spos = c.spos;
     uint32_t* l_rng = nullptr;
     if constexpr (LDS) {
         const int tid = (int)threadIdx.x, nt = (int)blockDim.x, NK = N * P.K;
@@ -1256,7 +1257,7 @@ __global__ __launch_bounds__(kRrrThreads) void rrr_sparse_kernel(RrrSparseParams
         for (int i = tid; i < P.W; i += nt) l_sp[i] = g_sp[i];
         for (int i = tid; i < NK; i += nt) { l_A[i] = (uint16_t)P.A[i]; l_J[i] = P.J[i]; }
         __syncthreads();
-        c.sp = l_sp; c.spos = l_spos; c.cls = l_cls; c.A16 = l_A; c.Jl = l_J;
+        c.sp = l_sp; c.spos = reinterpret_cast<IDX*>(l_spos); c.cls = l_cls; c.A16 = l_A; c.Jl = l_J;
     }
     const bool worker = !LDS || threadIdx.x == 0;
     long long E = 0, accepted = 0, staged_its = 0, ns = 0, itdone = 0;
@@ -1269,8 +1270,8 @@ __global__ __launch_bounds__(kRrrThreads) void rrr_sparse_kernel(RrrSparseParams
         n -= c.dE(i) / 2;                       // lf_x = -sum J sx sy
         const int k = c.klass(i), tk = c.tg(k);
         c.cls[i] = (uint8_t)k;
-        c.sv[(size_t)k * N + tk] = (uint16_t)i;
-        c.spos[i] = (uint16_t)tk;
+        c.sv[(size_t)k * N + tk] = (IDX)i;
+        c.spos[i] = (IDX)tk;
         c.tadd(k, 1);
     }
     E = n / 2;

@@ -69,7 +69,7 @@ def test_config4_lattice_properties(pkg, oracle):
         eng.set_coloring(color)
         C0 = eng.get_config()
         with pytest.raises(pkg.RRRMCError) as e:
-            eng.rrr_mc(1.0, 10, 1)                        # the thread-per-replica samplers index spins with 16 bits
+            eng.wtm_mc(1.0, 2, 1.0)                       # the wtmMC heap still indexes spins with 16 bits (rrrMC / bklMC do not: below)
         assert e.value.code == 3
         Es = eng.colored_sweeps(1.0, 2, 1)
         C1 = eng.get_config()
@@ -81,3 +81,27 @@ def test_config4_lattice_properties(pkg, oracle):
         Es_ref, ch_ref, _ = oracle.colored_sweeps_sparse(A, J, color, 1.0, 2, 1, seed, C0.s[r], replica=r)
         assert (Es[r] == Es_ref).all() and (C1.s[r] == ch_ref).all()
         assert E1[r] == oracle.sparse_energy(A, J, C1.s[r])
+
+
+def test_rrr_and_bkl_on_the_config4_lattice(pkg, oracle):
+    """rrrMC(SingleGraph) and bklMC on GraphEA(64, 3) (N = 262 144 > 65 535: the DeltaECache's set members and positions are 32-bit
+    there) against the oracle, incl. the move counts; and on a lattice just above the 16-bit limit."""
+    for L_, iters in ((64, 3000), (41, 6000)):            # 41^3 = 68 921
+        seed = 6400 + L_
+        X = pkg.GraphEA(L_, 3, seed=seed)
+        A, J = X.A, X.J.astype(np.int32)
+        with pkg.Engine(X, 34) as eng:
+            eng.seed(seed)
+            eng.init_spins_random()
+            C0 = eng.get_config()
+            Es, acc, staged = eng.rrr_mc(1.0, iters, 500)
+            C1 = eng.get_config()
+            eng.seed(seed)
+            eng.set_config(C0)
+            Eb, mb = eng.bkl_mc(1.0, iters, 500)
+            C2 = eng.get_config()
+        for r in (0, 33):
+            ref = oracle.rrr_sparse(A, J, 1.0, iters, 500, seed, C0.s[r], replica=r, form="ea")
+            assert (Es[r] == ref[0]).all() and (C1.s[r] == ref[1]).all() and acc[r] == ref[2] and staged[r] == ref[3]
+            b = oracle.rrr_sparse(A, J, 1.0, iters, 500, seed, C0.s[r], replica=r, form="ea", bkl=True)
+            assert (Eb[r] == b[0]).all() and (C2.s[r] == b[1]).all() and mb[r] == b[2]
