@@ -804,6 +804,27 @@ def extremal_opt_cont(A, J, tau, iters, step, seed, chunks, it0=0, replica=0, fo
     return Es[:n], ch, Emin.value, Cmin, itmin.value
 
 
+def extremal_opt_quant(A, J, M, fourK, tau, iters, step, seed, chunks, it0=0, replica=0, form="rrg"):
+    """extremal_opt on a GraphQuant over GraphRRG / GraphEA slices (EOCacheCont over all Nk M spins).
+    Returns (Es, final chunks, Emin, Cmin chunks, itmin)."""
+    L = lib()
+    L.orc_extremal_opt_quant.restype = C.c_int64
+    L.orc_extremal_opt_quant.argtypes = [C.c_int, C.c_int64, C.c_int64, C.c_int64, i32p, i32p, C.c_double, f64p, C.c_int64, C.c_int64,
+                                         C.c_uint64, C.c_uint64, C.c_uint32, u64p, f64p, C.POINTER(C.c_double), u64p, C.POINTER(C.c_int64)]
+    A = np.ascontiguousarray(A, np.int32)
+    Nk, K = A.shape
+    N = Nk * int(M)
+    ch = np.array(chunks, np.uint64, copy=True)
+    Es = np.zeros(max(iters // step, 1))
+    Cmin = np.zeros_like(ch)
+    Emin, itmin = C.c_double(0), C.c_int64(0)
+    n = L.orc_extremal_opt_quant(1 if form == "ea" else 0, Nk, int(M), K, A, np.ascontiguousarray(J, np.int32), float(fourK), eo_ftau(N, tau),
+                                 int(iters), int(step), seed, it0, replica, ch, Es, C.byref(Emin), Cmin, C.byref(itmin))
+    if n < 0:
+        raise RuntimeError("extremal_opt_quant: inconsistent cache / energy (%d)" % n)
+    return Es[:n], ch, Emin.value, Cmin, itmin.value
+
+
 def wtm_mc_skn(J, beta, samples, step, seed, chunks, call=0, replica=0):
     """wtmMC on GraphSKNormal; returns (Es, chunks, num_moves, t)."""
     L = lib()

@@ -2617,6 +2617,72 @@ ORC_API int64_t orc_extremal_opt_cont(int form, int64_t N, int64_t K, const int3
     return ok ? nsamp : -1;
 }
 
+/* extremal_opt (src/RRRMC.jl:474-521) on a GraphQuant over GraphRRG / GraphEA slices: a DoubleGraph is not a DiscrGraph, so gen_EOcache
+ * builds the generic EOCacheCont (DeltaE.jl:557-635) over all N = Nk M spins with delta_energy = delta_energy(X0) + residual
+ * (QT.jl:283-286) and neighbors(X, i) = the Trotter pair, then the slice graph's (QT.jl:288-321).  Streams and tie rule as
+ * orc_extremal_opt_cont. */
+ORC_API int64_t orc_extremal_opt_quant(int form, int64_t Nk, int64_t M, int64_t K, const int32_t *A, const int32_t *J, double fourK,
+                                       const double *ftau, int64_t iters, int64_t step, uint64_t seed, uint64_t it0, uint32_t replica,
+                                       uint64_t *chunks, double *Es, double *Emin_out, uint64_t *Cmin, int64_t *itmin_out)
+{
+    const int64_t N = Nk * M;
+    if (N > 65535 || K + 2 > SK_MAX + 2) return -2;
+    quant_t Q;
+    quant_init(&Q, Nk, M, K, A, J, fourK);
+    for (int64_t k = 0; k < M; ++k) Q.X1[k].ea_form = form;
+    spf_t X = {N, K, A, NULL, NULL, NULL, -1, form, NULL, 1, 1.0, NULL, NULL};
+    X.Q = &Q; X.cur_s = chunks;
+    double E = quant_energy(&Q, chunks);
+    const int64_t nch = (N + 63) / 64;
+    double Emin = E;
+    int64_t itmin = 0, nsamp = 0;
+    memcpy(Cmin, chunks, (size_t)nch * 8);
+    double *dEs = (double *)malloc((size_t)N * 8);
+    int32_t *rank = (int32_t *)malloc((size_t)N * 4), *tmp = (int32_t *)malloc((size_t)N * 4);
+    for (int64_t i = 0; i < N; ++i) { dEs[i] = spf_dE(&X, i); rank[i] = (int32_t)i; }
+    eocmp_t cmp = {dEs, seed, 0, replica, 0};
+    eo_sort(&cmp, rank, tmp, N);
+    const double z = ftau[N - 1];
+    for (int64_t it = 1; it <= iters; ++it) {
+        if (it % step == 0) Es[nsamp++] = E;
+        const uint64_t g = it0 + (uint64_t)it;
+        uint32_t w[4];
+        rrr_draw(seed, g, replica, 3, w);
+        const double r = (1 - u53_of(w[0], w[1])) * z;
+        int64_t lo = 0, hi = N;
+        while (lo < hi) { int64_t mid = (lo + hi) >> 1; if (ftau[mid] < r) lo = mid + 1; else hi = mid; }
+        int64_t i = lo + 1;
+        if (i > N) i = N;
+        const int64_t move = rank[i - 1];
+        const double dE = dEs[move];
+        spf_spinflip(&X, chunks, move);
+        dEs[move] = spf_dE(&X, move);
+        int64_t nb[SK_MAX + 2];
+        int nn = spf_neighbors(&X, move, nb);
+        for (int q = 0; q < nn; ++q) dEs[nb[q]] = spf_dE(&X, nb[q]);
+        cmp.g = g; cmp.fresh = 1;
+        eo_sort(&cmp, rank, tmp, N);
+        E += dE;
+        if (E < Emin) { Emin = E; memcpy(Cmin, chunks, (size_t)nch * 8); itmin = it; }
+    }
+    int ok = 1;
+    for (int64_t i = 1; i < N && ok; ++i) ok = dEs[rank[i - 1]] <= dEs[rank[i]];
+    for (int64_t i = 0; i < N && ok; ++i) ok = dEs[i] == spf_dE(&X, i);
+    {
+        uint64_t *cp = (uint64_t *)malloc((size_t)nch * 8);
+        memcpy(cp, chunks, (size_t)nch * 8);
+        const double Ex = quant_energy(&Q, cp);
+        const double tol = 1e-9 * (fabs(Ex) > 1.0 ? fabs(Ex) : 1.0);
+        if (fabs(Ex - E) > tol) ok = 0;
+        free(cp);
+    }
+    if (Emin_out) *Emin_out = Emin;
+    if (itmin_out) *itmin_out = itmin;
+    free(dEs); free(rank); free(tmp);
+    quant_free(&Q);
+    return ok ? nsamp : -1;
+}
+
 /* extremal_opt with EOCacheCont (see orc_extremal_opt_cont) on the dense SK models: neighbors(X, i) = AllButOne (SK.jl:142,297), so
  * every delta_energy is refreshed and the whole ranking re-sorted at every flip.  Same streams and tie rule as orc_extremal_opt_cont. */
 static int64_t extremal_opt_sk_impl(skx_t *X, int64_t N, const double *ftau, int64_t iters, int64_t step, uint64_t seed, uint64_t it0,

@@ -437,11 +437,9 @@ __global__ __launch_bounds__(kRrrThreads) void cont_sparse_kernel(ContParams P)
             const double dE = c.v[lo];
             c.flip(move);                                                                                    // apply_move!: :592-609
             nties = c.eo_reinsert(move, c.dE(move), nties);
-            const int32_t* Ax = P.A + (size_t)move * K;
-            for (int q = 0; q < K; ++q) {
-                if (!c.is_nb(Ax, q)) continue;
-                nties = c.eo_reinsert(Ax[q], c.dE(Ax[q]), nties);
-            }
+            int enb[kContKmax + 2];
+            const int enn = c.nbrs(move, enb);                                                               // neighbors(X, move): a GraphQuant's too
+            for (int q = 0; q < enn; ++q) nties = c.eo_reinsert(enb[q], c.dE(enb[q]), nties);
             if (nties > 0) c.eo_order_ties(g);
             E += dE;
             if (E < Emin) {

@@ -150,7 +150,7 @@ int32_t spf_cont_async(rrrmc_ctx* ctx, int mode, double beta, int64_t iters, int
     ctx->timing_valid = false;
     // the discretised DoubleGraphs (bklMC / wtmMC over the whole graph: DeltaE.jl:315) keep their spins in the kernel's layout already
     const bool quantm = ctx->model == RRRMC_MODEL_QUANT_RRG;          // bklMC / wtmMC over the whole GraphQuant (DeltaE.jl:315): spins in q_spins too
-    if (quantm && ctx->q_sk) return fail(ctx, RRRMC_ERR_UNSUPPORTED, "bklMC / wtmMC on a GraphQuant are wired for GraphRRG / GraphEA slices (a GraphSK slice has Nk - 1 neighbours per spin)");
+    if (quantm && ctx->q_sk) return fail(ctx, RRRMC_ERR_UNSUPPORTED, "bklMC / wtmMC / extremal_opt on a GraphQuant are wired for GraphRRG / GraphEA slices (a GraphSK slice has Nk - 1 neighbours per spin)");
     if (quantm && !(ctx->last_fourK > 0.0)) return fail(ctx, RRRMC_ERR_STATE, "a GraphQuant needs fourK: call rrrmc_quant_set_field first");
     const bool dblm = ctx->model == RRRMC_MODEL_SPARSE_DISCRETIZED || quantm;
     const int64_t N = ctx->N, K = ctx->K, R = ctx->R, W = dblm ? ctx->qW : (N + 31) / 32;
@@ -214,7 +214,7 @@ int32_t spf_cont_async(rrrmc_ctx* ctx, int mode, double beta, int64_t iters, int
     }
     HIP_TRY(ctx, hipEventRecord(ctx->ev_sweep[0], st));
     const char* no_wave = std::getenv("RRRMC_EO_NO_WAVE");            // tests / timing experiments
-    if (mode == 3 && N <= kEoWaveMaxN && !(no_wave && no_wave[0] == '1')) {
+    if (mode == 3 && !quantm && N <= kEoWaveMaxN && !(no_wave && no_wave[0] == '1')) {
         // extremal_opt: one wavefront per replica, the ranking in LDS
         const size_t lds = eo_wave_lds_bytes((int)N);
         HIP_TRY(ctx, raise_lds_attr(reinterpret_cast<const void*>(eo_cont_wave_kernel), lds));

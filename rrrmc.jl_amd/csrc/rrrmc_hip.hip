@@ -1620,11 +1620,11 @@ int32_t rrrmc_extremal_opt_async(rrrmc_ctx* ctx, const double* ftau, int64_t ite
     if (ctx) ctx->std_cache_live = false;
     int32_t rc = ensure_state(ctx, true);
     if (rc) return rc;
-    if (ctx->model == RRRMC_MODEL_SPARSE_F64 || ctx->model == RRRMC_MODEL_SPARSE_DISCRETIZED)        // not DiscrGraphs: EOCacheCont
+    if (ctx->model == RRRMC_MODEL_SPARSE_F64 || ctx->model == RRRMC_MODEL_SPARSE_DISCRETIZED || ctx->model == RRRMC_MODEL_QUANT_RRG)        // not DiscrGraphs: EOCacheCont
         return spf_cont_async(ctx, 3, 0.0, iters, step, 1.0, 0.0, 0.0, ftau);
     if (ctx->model == RRRMC_MODEL_SK_NORMAL || ctx->model == RRRMC_MODEL_SK_BINARY)                 // EOCacheCont, every spin a neighbour
         return sk_rrr_mc_async(ctx, 0.0, iters, step, 0.0, 5.0, 3, 1.0, ftau);
-    if (!sparse_int_model(ctx)) return fail(ctx, RRRMC_ERR_UNSUPPORTED, "extremal_opt is wired for the sparse models and the SK models, not for a GraphQuant");
+    if (!sparse_int_model(ctx)) return fail(ctx, RRRMC_ERR_UNSUPPORTED, "extremal_opt is not wired for this model");
     return sparse_eo_async(ctx, ftau, iters, step);
 }
 

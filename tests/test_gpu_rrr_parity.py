@@ -333,3 +333,30 @@ def test_quant_wave_kernel_equals_thread_kernel_and_respaces(pkg, oracle, monkey
     A, J = X.X1.A, X.X1.J.astype(np.int32)
     ref = oracle.rrr_mc_quant(A, J, M, X.fourK, beta, iters, step, seed, wave[0].s[3], replica=3)
     assert (wave[1][3] == ref[0]).all() and wave[2][3] == ref[2]
+
+
+@pytest.mark.parametrize("slices,Nk,M,Gamma,beta,R,tau", [
+    ("rrg", 10, 8, 0.5, 2.0, 20, 1.3),           # test/runtests.jl:78 under extremal_opt (:153-157)
+    ("ea2x3", 8, 6, 0.4, 1.0, 5, 1.8),           # GraphEA(2, 3) slices: repeated bonds
+    ("rrg", 64, 16, 0.5, 2.0, 3, 1.2),
+])
+def test_extremal_opt_on_graph_quant(pkg, oracle, slices, Nk, M, Gamma, beta, R, tau):
+    """extremal_opt on a GraphQuant: not a DiscrGraph, so the reference's generic EOCacheCont ranks all Nk M spins by
+    delta_energy(X0) + residual and re-sorts after every flip; neighbors = the Trotter pair, then the slice graph's."""
+    seed = 77100 + Nk + M
+    X1 = pkg.GraphEA(int(slices[2]), int(slices[4]), seed=seed) if slices.startswith("ea") else pkg.GraphRRG(Nk, 3, seed=seed)
+    X = pkg.GraphQuant(X1, M, Gamma, beta)
+    A, J = X1.A, X1.J.astype(np.int32)
+    form = "ea" if slices.startswith("ea") else "rrg"
+    iters, step = (1500, 100) if Nk >= 64 else (4000, 200)
+    with pkg.Engine(X, R) as eng:
+        eng.seed(seed)
+        eng.init_spins_random()
+        C0 = eng.get_config()
+        Es, Emin, Cmin, itmin = eng.extremal_opt(tau, iters, step)
+        C1 = eng.get_config()
+        Er, ar, st = eng.rrr_mc(beta, 500, 100)                    # the DoubleGraph rrrMC still works afterwards
+    for r in range(R):
+        ref = oracle.extremal_opt_quant(A, J, M, X.fourK, tau, iters, step, seed, C0.s[r], replica=r, form=form)
+        assert (Es[r] == ref[0]).all() and (C1.s[r] == ref[1]).all()
+        assert Emin[r] == ref[2] and (Cmin.s[r] == ref[3]).all() and itmin[r] == ref[4]
