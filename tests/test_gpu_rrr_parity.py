@@ -338,7 +338,7 @@ def test_quant_wave_kernel_equals_thread_kernel_and_respaces(pkg, oracle, monkey
 @pytest.mark.parametrize("slices,Nk,M,Gamma,beta,R,tau", [
     ("rrg", 10, 8, 0.5, 2.0, 20, 1.3),           # test/runtests.jl:78 under extremal_opt (:153-157)
     ("ea2x3", 8, 6, 0.4, 1.0, 5, 1.8),           # GraphEA(2, 3) slices: repeated bonds
-    ("rrg", 64, 16, 0.5, 2.0, 3, 1.2),
+    ("rrg", 32, 8, 0.5, 2.0, 3, 1.2),
 ])
 def test_extremal_opt_on_graph_quant(pkg, oracle, slices, Nk, M, Gamma, beta, R, tau):
     """extremal_opt on a GraphQuant: not a DiscrGraph, so the reference's generic EOCacheCont ranks all Nk M spins by
@@ -348,7 +348,7 @@ def test_extremal_opt_on_graph_quant(pkg, oracle, slices, Nk, M, Gamma, beta, R,
     X = pkg.GraphQuant(X1, M, Gamma, beta)
     A, J = X1.A, X1.J.astype(np.int32)
     form = "ea" if slices.startswith("ea") else "rrg"
-    iters, step = (1500, 100) if Nk >= 64 else (4000, 200)
+    iters, step = (800, 100) if Nk >= 32 else (4000, 200)      # integer-valued slice energies: the ranking is mostly ties, re-keyed at every flip
     with pkg.Engine(X, R) as eng:
         eng.seed(seed)
         eng.init_spins_random()
