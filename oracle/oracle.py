@@ -347,6 +347,48 @@ def rrr_mc_quant_sk(Jb, Nk, M, fourK, beta, iters, step, seed, chunks, it0=0, re
     return out + (cache[:N].copy(), cache[N:].copy()) if want_cache else out
 
 
+def rrr_mc_quant_skn(Jd, Nk, M, fourK, beta, iters, step, seed, chunks, it0=0, replica=0, staged_thr=0.5, staged_thr_fact=5.0,
+                     want_cache=False):
+    """One chain of rrrMC on GraphQuant over GraphSKNormal slices (GraphQSKNormalT; test/runtests.jl:80).
+    Returns (Es, chunks_out, accepted, staged_its[, pos, set_sizes])."""
+    L = lib()
+    L.orc_rrr_mc_quant_skn.restype = C.c_int64
+    L.orc_rrr_mc_quant_skn.argtypes = [C.c_int64, C.c_int64, f64p, C.c_double, C.c_double, C.c_int64, C.c_int64, C.c_double, C.c_double,
+                                       C.c_uint64, C.c_uint64, C.c_uint32, u64p, f64p, i64p, C.c_void_p]
+    N = int(Nk) * int(M)
+    ch = np.array(chunks, np.uint64, copy=True)
+    Es = np.zeros(max(iters // step, 1), np.float64)
+    stats = np.zeros(2, np.int64)
+    cache = np.zeros(N + 4, np.int32)
+    n = L.orc_rrr_mc_quant_skn(int(Nk), int(M), np.ascontiguousarray(Jd, np.float64).reshape(-1), float(fourK), float(beta), int(iters), int(step),
+                               float(staged_thr), float(staged_thr_fact), seed, it0, replica, ch, Es, stats, cache.ctypes.data if want_cache else None)
+    if n < 0:
+        raise AssertionError("DeltaECache / ArraySet consistency check failed")
+    out = (Es[:n], ch, int(stats[0]), int(stats[1]))
+    return out + (cache[:N].copy(), cache[N:].copy()) if want_cache else out
+
+
+def standard_mc_quant_skn(Jd, Nk, M, fourK, beta, iters, step, seed, chunks, it0=0, replica=0):
+    L = lib()
+    L.orc_standard_mc_quant_skn.restype = C.c_int64
+    L.orc_standard_mc_quant_skn.argtypes = [C.c_int64, C.c_int64, f64p, C.c_double, C.c_double, C.c_int64, C.c_int64, C.c_uint64, C.c_uint64,
+                                            C.c_uint32, u64p, f64p, C.POINTER(C.c_int64)]
+    ch = np.array(chunks, np.uint64, copy=True)
+    Es = np.zeros(max(iters // step, 1), np.float64)
+    acc = C.c_int64(0)
+    n = L.orc_standard_mc_quant_skn(int(Nk), int(M), np.ascontiguousarray(Jd, np.float64).reshape(-1), float(fourK), float(beta), int(iters),
+                                    int(step), seed, it0, replica, ch, Es, C.byref(acc))
+    return Es[:n], ch, int(acc.value)
+
+
+def quant_skn_energy(Jd, Nk, M, fourK, chunks):
+    L = lib()
+    L.orc_quant_energy_skn.restype = C.c_double
+    L.orc_quant_energy_skn.argtypes = [C.c_int64, C.c_int64, f64p, C.c_double, u64p]
+    return float(L.orc_quant_energy_skn(int(Nk), int(M), np.ascontiguousarray(Jd, np.float64).reshape(-1), float(fourK),
+                                        np.ascontiguousarray(chunks, np.uint64)))
+
+
 def quant_sk_observables(Jb, Nk, M, fourK, beta, Gamma, chunks):
     """(Qenergy, transverse_mag, overlaps[M//2], energy0, Eslice[M] (the integers n_k: E_k = n_k / sqrt(Nk)), ovs_raw[M//2])."""
     L = lib()

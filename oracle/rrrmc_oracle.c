@@ -884,6 +884,7 @@ typedef struct {
     int64_t Nk, M, K;
     sparse_t *X1;            /* M slice graphs sharing A, J; each with its own LocalFields */
     skb_t *S1;               /* or (X1 == NULL) M binary-SK slice graphs sharing J */
+    skn_t *G1;               /* or M GraphSKNormal slice graphs sharing J (GraphQSKNormalT, src/QAliases.jl:45-46; test/runtests.jl:80) */
     uint64_t **C1;           /* M slice configurations (copies of the slice bits) */
 } quant_t;
 
@@ -907,13 +908,29 @@ static void quant_init(quant_t *Q, int64_t Nk, int64_t M, int64_t K, const int32
         Q->X1[k] = X;
         Q->C1[k] = (uint64_t *)calloc((size_t)((Nk + 63) / 64), 8);
     }
-    Q->S1 = NULL;
+    Q->S1 = NULL; Q->G1 = NULL;
+}
+static void quant_init_skn(quant_t *Q, int64_t Nk, int64_t M, const double *Jd, double fourK)
+{
+    Q->X0.N = Nk * M; Q->X0.M = M; Q->X0.Nk = Nk; Q->X0.fourK = fourK;
+    Q->Nk = Nk; Q->M = M; Q->K = 0;
+    Q->X1 = NULL; Q->S1 = NULL;
+    Q->G1 = (skn_t *)calloc((size_t)M, sizeof(skn_t));
+    Q->C1 = (uint64_t **)calloc((size_t)M, sizeof(uint64_t *));
+    for (int64_t k = 0; k < M; ++k) {
+        skn_t X = {Nk, Jd, NULL, NULL, -1};
+        X.lfields = (double *)calloc((size_t)Nk, 8);
+        X.lfields_last = (double *)calloc((size_t)Nk, 8);
+        Q->G1[k] = X;
+        Q->C1[k] = (uint64_t *)calloc((size_t)((Nk + 63) / 64), 8);
+    }
 }
 static void quant_init_sk(quant_t *Q, int64_t Nk, int64_t M, const uint64_t *Jb, double fourK)
 {
     Q->X0.N = Nk * M; Q->X0.M = M; Q->X0.Nk = Nk; Q->X0.fourK = fourK;
     Q->Nk = Nk; Q->M = M; Q->K = 0;
     Q->X1 = NULL;
+    Q->G1 = NULL;
     Q->S1 = (skb_t *)calloc((size_t)M, sizeof(skb_t));
     Q->C1 = (uint64_t **)calloc((size_t)M, sizeof(uint64_t *));
     for (int64_t k = 0; k < M; ++k) {
@@ -929,13 +946,15 @@ static void quant_free(quant_t *Q)
     for (int64_t k = 0; k < Q->M; ++k) {
         if (Q->X1) { free(Q->X1[k].lfields); free(Q->X1[k].lfields_last); }
         if (Q->S1) { free(Q->S1[k].lfields); free(Q->S1[k].lfields_last); }
+        if (Q->G1) { free(Q->G1[k].lfields); free(Q->G1[k].lfields_last); }
         free(Q->C1[k]);
     }
-    free(Q->X1); free(Q->S1); free(Q->C1);
+    free(Q->X1); free(Q->S1); free(Q->G1); free(Q->C1);
 }
 /* energy(X1[k], C1[k]) as the Float64 the reference divides: an Int for GraphRRG slices, n / sqrt(Nk) for GraphSK ones (SK.jl:95) */
 static inline double quant_slice_energy(quant_t *Q, int64_t k)
 {
+    if (Q->G1) return skn_energy(&Q->G1[k], Q->C1[k]);
     return Q->S1 ? skb_energy(&Q->S1[k], Q->C1[k]) : (double)sparse_energy(&Q->X1[k], Q->C1[k]);
 }
 /* energy: QT.jl:185-199 — copies the slice bits into C1[k] and (re)builds every slice cache */
@@ -954,6 +973,7 @@ static double quant_energy(quant_t *Q, const uint64_t *s)
 static inline double quant_residual(const quant_t *Q, int64_t move)
 {
     int64_t k = move / Q->Nk, i = move % Q->Nk;
+    if (Q->G1) return Q->G1[k].lfields[i] / (double)Q->M;                                   /* SK.jl:278-284 */
     if (Q->S1) return ((double)Q->S1[k].lfields[i] / Q->S1[k].sN) / (double)Q->M;          /* SK.jl:137-140 */
     return (double)sparse_delta_energy(&Q->X1[k], i) / (double)Q->M;
 }
@@ -963,6 +983,7 @@ static void quant_spinflip(quant_t *Q, uint64_t *s, int64_t move)
     bitflip(s, move);
     int64_t k = move / Q->Nk, i = move % Q->Nk;
     bitflip(Q->C1[k], i);
+    if (Q->G1) { skn_update_cache(&Q->G1[k], Q->C1[k], i); return; }
     if (Q->S1) skb_update_cache(&Q->S1[k], Q->C1[k], i);
     else sparse_update_cache(&Q->X1[k], Q->C1[k], i);
 }
@@ -1114,6 +1135,18 @@ ORC_API int64_t orc_rrr_mc_quant_sk(int64_t Nk, int64_t M, const uint64_t *Jb, d
     return r;
 }
 
+ORC_API int64_t orc_rrr_mc_quant_skn(int64_t Nk, int64_t M, const double *Jd, double fourK,
+                                 double beta, int64_t iters, int64_t step, double staged_thr, double staged_thr_fact,
+                                 uint64_t seed, uint64_t it0, uint32_t replica,
+                                 uint64_t *chunks, double *Es, int64_t *stats, int32_t *cache_out)
+{
+    quant_t Q;
+    quant_init_skn(&Q, Nk, M, Jd, fourK);
+    int64_t r = orc_rrr_mc_quant_impl(&Q, beta, iters, step, staged_thr, staged_thr_fact, seed, it0, replica, chunks, Es, stats, cache_out);
+    quant_free(&Q);
+    return r;
+}
+
 /* standardMC (src/RRRMC.jl:81-127) on GraphQuant: delta_energy = delta_energy(X0) + delta_energy_residual (QT.jl:283-286).
  * SITE stream for the spin, ACCEPT_F64 stream for rand(). */
 static int64_t orc_standard_mc_quant_impl(quant_t *Q,
@@ -1160,6 +1193,25 @@ ORC_API int64_t orc_standard_mc_quant_sk(int64_t Nk, int64_t M, const uint64_t *
     int64_t r = orc_standard_mc_quant_impl(&Q, beta, iters, step, seed, it0, replica, chunks, Es, accepted_out);
     quant_free(&Q);
     return r;
+}
+
+ORC_API int64_t orc_standard_mc_quant_skn(int64_t Nk, int64_t M, const double *Jd, double fourK,
+                                      double beta, int64_t iters, int64_t step, uint64_t seed, uint64_t it0, uint32_t replica,
+                                      uint64_t *chunks, double *Es, int64_t *accepted_out)
+{
+    quant_t Q;
+    quant_init_skn(&Q, Nk, M, Jd, fourK);
+    int64_t r = orc_standard_mc_quant_impl(&Q, beta, iters, step, seed, it0, replica, chunks, Es, accepted_out);
+    quant_free(&Q);
+    return r;
+}
+ORC_API double orc_quant_energy_skn(int64_t Nk, int64_t M, const double *Jd, double fourK, const uint64_t *chunks)
+{
+    quant_t Q;
+    quant_init_skn(&Q, Nk, M, Jd, fourK);
+    const double E = quant_energy(&Q, chunks);
+    quant_free(&Q);
+    return E;
 }
 
 /* energy(X::GraphQuant, C) and its parts, for the tests */
