@@ -175,6 +175,11 @@ RRRMC_API int32_t rrrmc_ctx_create_quant(rrrmc_ctx **out, int64_t Nk, int64_t K,
  * rrrmc_energy_f64, rrrmc_quant_observables.  delta_energy_residual = (lfields[i] / sqrt(Nk)) / M (SK.jl:137-140, QT.jl:270-281) with
  * the integer field recomputed by popcounts of the slice's spin words against row i of J. */
 RRRMC_API int32_t rrrmc_ctx_create_quant_sk(rrrmc_ctx **out, int64_t Nk, int64_t M, int64_t R, int32_t device, uint32_t replica0);
+/* GraphQuant over M GraphSKNormal slices sharing one Gaussian coupling matrix (GraphQSKNormalT, src/QAliases.jl:45-46 — one of the graphs
+ * of the reference's own test loop, test/runtests.jl:80): then rrrmc_set_couplings_dense(ctx, J[Nk x Nk]) and rrrmc_quant_set_field.
+ * rrrMC (rrrmc_rrr_mc_async) and standardMC are wired (thread per replica, every slice keeps its Float64 lfields / lfields_last / move_last
+ * exactly as SK.jl:212-276 updates them); bklMC / wtmMC / extremal_opt and the observables are not (RRRMC_ERR_UNSUPPORTED). */
+RRRMC_API int32_t rrrmc_ctx_create_quant_skn(rrrmc_ctx **out, int64_t Nk, int64_t M, int64_t R, int32_t device, uint32_t replica0);
 /* The Trotter coupling fourK (a type parameter of GraphQuant in the reference, QT.jl:126) and the beta it was derived
  * from: needed by rrrmc_energy_f64 before the first rrrMC call, and by rrrmc_standard_mc_async — standardMC on the GraphQuant
  * (src/RRRMC.jl:81-127 with delta_energy = delta_energy(X0) + delta_energy_residual, QT.jl:283-286; SITE + ACCEPT_F64 streams),

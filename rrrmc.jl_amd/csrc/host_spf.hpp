@@ -150,6 +150,7 @@ int32_t spf_cont_async(rrrmc_ctx* ctx, int mode, double beta, int64_t iters, int
     ctx->timing_valid = false;
     // the discretised DoubleGraphs (bklMC / wtmMC over the whole graph: DeltaE.jl:315) keep their spins in the kernel's layout already
     const bool quantm = ctx->model == RRRMC_MODEL_QUANT_RRG;          // bklMC / wtmMC over the whole GraphQuant (DeltaE.jl:315): spins in q_spins too
+    if (quantm && ctx->q_skn) return fail(ctx, RRRMC_ERR_UNSUPPORTED, "bklMC / wtmMC / extremal_opt on a GraphQuant over GraphSKNormal slices are not wired (rrrMC and standardMC are)");
     if (quantm && ctx->q_sk) return fail(ctx, RRRMC_ERR_UNSUPPORTED, "bklMC / wtmMC / extremal_opt on a GraphQuant are wired for GraphRRG / GraphEA slices (a GraphSK slice has Nk - 1 neighbours per spin)");
     if (quantm && !(ctx->last_fourK > 0.0)) return fail(ctx, RRRMC_ERR_STATE, "a GraphQuant needs fourK: call rrrmc_quant_set_field first");
     const bool dblm = ctx->model == RRRMC_MODEL_SPARSE_DISCRETIZED || quantm;

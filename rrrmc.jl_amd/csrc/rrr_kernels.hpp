@@ -28,6 +28,12 @@ struct RrrParams {
     const uint32_t* Jb;      // [Nk][Wk]     binary GraphSK slices (GraphQSKT, QAliases.jl:34-43) instead of (A, J): row i of J as 32-bit words; else null
     double sN;               //              sqrt(Nk) (SK.jl:49), 0 for GraphRRG slices
     int Wk;
+    // GraphSKNormal slices (GraphQSKNormalT, QAliases.jl:45-46; test/runtests.jl:80): Float64 couplings shared by the slices, and every
+    // slice's own cache — lfields / lfields_last (swapped wholesale by the undo path, SK.jl:247-250) and move_last — per replica
+    const double* Jd;        // [Nk][Nk] else null
+    double* slf;             // [R][2][M][Nk]   the two field arrays of every slice
+    int32_t* smv;            // [R][M]          move_last of every slice (-1 = none)
+    uint8_t* scur;           // [R][M]          which of the two arrays is `lfields`
     // per-replica state, replica-contiguous
     uint32_t* spins;         // [R][W]       bit x of replica r: word x >> 5, bit x & 31; x = slice * Nk + i
     uint8_t* cls;            // [R][N]       class of every spin: a + 2 * up  (DeltaECache.pos)
@@ -54,6 +60,7 @@ struct RrrView {             // one replica's slices of the arrays above
     const int32_t* A; const int8_t* J;
     const uint32_t* Jb; int Wk; double sN;
     double fourK;
+    const double* Jd; double* slf; int32_t* smv; uint8_t* scur;      // GraphSKNormal slices (this replica's arrays)
 };
 
 __device__ __forceinline__ int sbit(const uint32_t* sp, int x) { return (int)((sp[x >> 5] >> (x & 31)) & 1u); }
@@ -118,6 +125,39 @@ __device__ __forceinline__ double slice_energy_over_M(const RrrParams& P, long l
 {
     return P.Jb ? ((double)n / P.sN) / (double)P.M : (double)n / (double)P.M;
 }
+// GraphSKNormal slices: delta_energy_residual = delta_energy(X1[k], C1[k], i) / M = lfields[i] / M (SK.jl:278-284, QT.jl:270-281)
+__device__ __forceinline__ double skn_residual(const RrrView& v, int move)
+{
+    const int k = (int)__umulhi((uint32_t)move, v.nk_magic), i = move - k * v.Nk;
+    return v.slf[((size_t)v.scur[k] * v.M + k) * v.Nk + i] / (double)v.M;
+}
+// update_cache! of the slice graph (SK.jl:239-276), called after the bit flip of spinflip!(X::GraphQuant, C, move) (QT.jl:172-183)
+__device__ inline void skn_update(const RrrView& v, int move)
+{
+    const int k = (int)__umulhi((uint32_t)move, v.nk_magic), i = move - k * v.Nk, off = k * v.Nk;
+    const int cur = v.scur[k];
+    if (v.smv[k] == i) { v.scur[k] = (uint8_t)(cur ^ 1); return; }          // :247-250: swap the two arrays, move_last stays
+    double* lf = v.slf + ((size_t)cur * v.M + k) * v.Nk;
+    double* ll = v.slf + ((size_t)(cur ^ 1) * v.M + k) * v.Nk;
+    const double* Ji = v.Jd + (size_t)i * v.Nk;
+    const int si = sbit(v.sp, move);
+    const double lfm = lf[i];
+    for (int j = 0; j < v.Nk; ++j) {
+        const double Jsij = (double)(1 - 2 * (si ^ sbit(v.sp, off + j))) * Ji[j];
+        const double lfj = lf[j];
+        ll[j] = lfj;
+        lf[j] = lfj + 4 * Jsij;
+    }
+    ll[i] = lfm;
+    lf[i] = -lfm;
+    v.smv[k] = i;
+}
+// the residual of a move for either kind of slice
+__device__ __forceinline__ double any_residual(const RrrView& v, int move)
+{
+    return v.Jd ? skn_residual(v, move) : slice_res(v, slice_delta(v, move));
+}
+
 // ArraySet delete! / push! (ArraySets.jl:56-76); one position array serves the four sets (membership is exclusive)
 __device__ __forceinline__ void set_move(const RrrView& v, int j, int k0, int k1)
 {
@@ -146,6 +186,10 @@ __device__ __forceinline__ RrrView rrr_view(const RrrParams& P, int r)
     v.t = P.st + (size_t)r * 4;
     v.N = P.N; v.Nk = P.Nk; v.M = P.M; v.K = P.K; v.A = P.A; v.J = P.J; v.fourK = P.fourK;
     v.Jb = P.Jb; v.Wk = P.Wk; v.sN = P.sN;
+    v.Jd = P.Jd;
+    v.slf = P.Jd ? P.slf + (size_t)r * 2 * P.M * P.Nk : nullptr;
+    v.smv = P.Jd ? P.smv + (size_t)r * P.M : nullptr;
+    v.scur = P.Jd ? P.scur + (size_t)r * P.M : nullptr;
     v.nk_magic = (uint32_t)((0x100000000ull + (uint32_t)P.Nk - 1u) / (uint32_t)P.Nk);
     return v;
 }
@@ -255,6 +299,90 @@ __global__ __launch_bounds__(kInitThreads) void rrr_init_coop_kernel(RrrParams P
             n /= 2;
             E += slice_energy_over_M(P, n);
         }
+        P.E_cur[r] = E;
+        double z = 0.0;
+        for (int k = 0; k < 4; ++k) {
+            v.t[k] = s_tot[k];
+            const double x = (double)s_tot[k] * class_f(k, P.ft1);
+            z += x;
+            P.T[(size_t)r * 4 + k] = x;
+        }
+        P.zz[r] = z;
+        P.acc_rate[r] = 0.5;
+        P.stats[(size_t)r * 2] = 0;
+        P.stats[(size_t)r * 2 + 1] = 0;
+    }
+}
+
+// energy(X::GraphQuant, C) (QT.jl:185-199) and the DeltaECache for GraphSKNormal slices, one workgroup per replica: the slice caches are
+// rebuilt as skn energy does (SK.jl:212-237: lfields[i] = 2 lf_i with lf_i the sequential sum over j, n -= lf_i in site order, n /= 2;
+// lfields_last = 0, move_last = none), the classes as rrr_init_coop_kernel.
+__global__ __launch_bounds__(kInitThreads) void rrr_init_skn_kernel(RrrParams P)
+{
+    __shared__ int s_cnt[4][kInitThreads];
+    __shared__ int s_tot[4];
+    __shared__ long long s_n0;
+    extern __shared__ long long s_slice[];             // [M] slice energies (as doubles)
+    double* s_E = reinterpret_cast<double*>(s_slice);
+    const int r = (int)blockIdx.x, tid = (int)threadIdx.x;
+    const RrrView v = rrr_view(P, r);
+    const int N = P.N, Nk = P.Nk, M = P.M;
+    if (tid == 0) s_n0 = 0;
+    __syncthreads();
+    {
+        long long n0 = 0;
+        for (int x = tid; x < N; x += kInitThreads) {
+            const int i = x % Nk, k = x / Nk;
+            const int prev = i + (k == 0 ? M - 1 : k - 1) * Nk;
+            n0 -= 1 - 2 * (sbit(v.sp, x) ^ sbit(v.sp, prev));
+            // lf_i of slice k: sequential in j (SK.jl:218-226); array 0 becomes lfields, array 1 holds lf_i until the slice sums are done
+            const double* Ji = P.Jd + (size_t)i * Nk;
+            const int si = sbit(v.sp, x);
+            double lf = 0.0;
+            for (int j = 0; j < Nk; ++j) lf += (double)(1 - 2 * (si ^ sbit(v.sp, k * Nk + j))) * Ji[j];
+            v.slf[((size_t)0 * M + k) * Nk + i] = 2 * lf;
+            v.slf[((size_t)1 * M + k) * Nk + i] = lf;
+        }
+        atomicAdd(reinterpret_cast<unsigned long long*>(&s_n0), (unsigned long long)n0);
+    }
+    __syncthreads();
+    for (int k = tid; k < M; k += kInitThreads) {      // n -= lf in site order, n /= 2 (SK.jl:227-232)
+        double n = 0.0;
+        for (int i = 0; i < Nk; ++i) n -= v.slf[((size_t)1 * M + k) * Nk + i];
+        n /= 2;
+        s_E[k] = n;
+        v.smv[k] = -1;
+        v.scur[k] = 0;
+    }
+    __syncthreads();
+    for (int x = tid; x < N; x += kInitThreads) v.slf[(size_t)M * Nk + x] = 0.0;      // lfields_last = 0
+    // classes of this thread's block of spins (as rrr_init_coop_kernel)
+    const int per = (N + kInitThreads - 1) / kInitThreads, x0 = tid * per, x1 = x0 + per < N ? x0 + per : N;
+    int cnt[4] = {0, 0, 0, 0};
+    for (int x = x0; x < x1; ++x) {
+        const int k = qt_class(v, x);
+        v.cls[x] = (uint8_t)k;
+        cnt[k] += 1;
+    }
+    for (int k = 0; k < 4; ++k) s_cnt[k][tid] = cnt[k];
+    __syncthreads();
+    if (tid < 4) {
+        int run = 0;
+        for (int t = 0; t < kInitThreads; ++t) { const int c = s_cnt[tid][t]; s_cnt[tid][t] = run; run += c; }
+        s_tot[tid] = run;
+    }
+    __syncthreads();
+    int off[4];
+    for (int k = 0; k < 4; ++k) off[k] = s_cnt[k][tid];
+    for (int x = x0; x < x1; ++x) {
+        const int k = v.cls[x];
+        v.sv[(size_t)k * N + off[k]] = (uint16_t)x;
+        v.spos[x] = (uint16_t)off[k];
+        off[k] += 1;
+    }
+    if (tid == 0) {
+        double E = (double)s_n0 * P.fourK / 4;
+        for (int k = 0; k < M; ++k) E += s_E[k] / (double)M;
         P.E_cur[r] = E;
         double z = 0.0;
         for (int k = 0; k < 4; ++k) {
@@ -382,7 +510,7 @@ __global__ __launch_bounds__(kRrrThreads) void rrr_quant_kernel(RrrParams P)
                 zp += f1 - f0;
             }
             const double c = z / zp;
-            const double dE1 = slice_res(v, slice_delta(v, move));         // delta_energy_residual, QT.jl:270-281
+            const double dE1 = any_residual(v, move);                      // delta_energy_residual, QT.jl:270-281
             const double x = -P.beta * dE1;
             bool ok = (c >= 1 && x >= 0);
             if (!ok) {                                                                 // accept(c, x), RRRMC.jl:40-44
@@ -397,6 +525,7 @@ __global__ __launch_bounds__(kRrrThreads) void rrr_quant_kernel(RrrParams P)
             }
             if (ok) {
                 sflip(v.sp, move);                                                     // spinflip!(X, C, move)
+                if (v.Jd) skn_update(v, move);
                 for (int q = 0; q < nst; ++q) set_move(v, sj[q], s0[q], s1[q]);        // apply_staged!
                 for (int q = 0; q < 4; ++q) T[q] = Tp[q];
                 z = zp;
@@ -406,10 +535,11 @@ __global__ __launch_bounds__(kRrrThreads) void rrr_quant_kernel(RrrParams P)
             }
         } else {
             // direct branch: apply_move! (DeltaE.jl:232-295), undone by a second apply_move! on rejection
-            const double dE1 = slice_res(v, slice_delta(v, move));
+            const double dE1 = any_residual(v, move);
             double c = 0.0;
             for (int pass = 0; pass < 2; ++pass) {
                 sflip(v.sp, move);
+                if (v.Jd) skn_update(v, move);                                          // the undo pass takes the swap path (move_last == move)
                 double zp = z;
                 for (int q = 0; q < 2; ++q) {
                     const int j = nb[q];
@@ -480,10 +610,10 @@ __global__ __launch_bounds__(kRrrThreads) void quant_standard_kernel(RrrParams P
         if (it == next_sample) { next_sample += P.step; P.Es[ns * P.R + r] = E; ns += 1; }
         const uint64_t g = P.g0 + (uint64_t)it;
         const int move = (int)site_of(P.k0, P.k1, g, (uint32_t)P.N);
-        const double dE = (double)qt_delta(v, move) * P.fourK + slice_res(v, slice_delta(v, move));
+        const double dE = (double)qt_delta(v, move) * P.fourK + any_residual(v, move);
         const double x = -P.beta * dE;
         const bool acc = (x >= 0.0) || (rand53(P.k0, P.k1, g, rep) < det_exp(x));        // RRRMC.jl:39
-        if (acc) { sflip(v.sp, move); E += dE; accepted += 1; }
+        if (acc) { sflip(v.sp, move); if (v.Jd) skn_update(v, move); E += dE; accepted += 1; }
     }
     P.E_cur[r] = E;
     P.stats[(size_t)r * 2] = accepted; P.stats[(size_t)r * 2 + 1] = 0;

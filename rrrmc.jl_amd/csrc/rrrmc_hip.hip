@@ -137,6 +137,10 @@ struct rrrmc_ctx {
     uint32_t* q_Jb = nullptr;             // GraphQuant over binary GraphSK slices (GraphQSKT): [Nk][q_Wk] words of J's rows, else null
     int64_t q_Wk = 0;
     bool q_sk = false;
+    bool q_skn = false;                   // GraphQuant over GraphSKNormal slices (GraphQSKNormalT): couplings in sk_J [Nk][Nk], slice caches below
+    double* q_slf = nullptr;              // [R][2][M][Nk]
+    int32_t* q_smv = nullptr;             // [R][M]
+    uint8_t* q_scur = nullptr;            // [R][M]
     uint32_t* q_spins = nullptr;
     uint8_t* q_cls = nullptr;
     uint16_t* q_sv = nullptr;
@@ -667,7 +671,7 @@ void rrrmc_ctx_destroy(rrrmc_ctx* ctx)
     free_dev(ctx->pff_table); free_dev(ctx->pff_absJ); free_dev(ctx->pff_bond_off); free_dev(ctx->pff_thr_hi); free_dev(ctx->pff_thr_lo); free_dev(ctx->pff_flags);
     free_dev(ctx->wt_t); free_dev(ctx->wt_id); free_dev(ctx->wt_pos); free_dev(ctx->wt_time);
     free_dev(ctx->eo_cmin); free_dev(ctx->eo_ftau);
-    free_dev(ctx->q_Jb);
+    free_dev(ctx->q_Jb); free_dev(ctx->q_slf); free_dev(ctx->q_smv); free_dev(ctx->q_scur);
     free_dev(ctx->cs_spins); free_dev(ctx->cs_buf); free_dev(ctx->cs_u16);
     free_dev(ctx->snap); free_dev(ctx->d_pairs); free_dev(ctx->d_ovl); free_dev(ctx->d_qobs);
     for (int i = 0; i < 2; ++i) { free_dev(ctx->d_slots[i]); free_dev(ctx->d_vecs[i]); }
@@ -1393,7 +1397,7 @@ int32_t rrrmc_colored_sweeps_async(rrrmc_ctx* ctx, double beta, int64_t sweeps, 
 // ---- GraphQuant + rrrMC: exported entry points ---------------------------------------------------------------------
 
 namespace {
-int32_t quant_ctx_create(rrrmc_ctx** out, int64_t Nk, int64_t K, int64_t M, int64_t R, int32_t device, uint32_t replica0, bool sk);
+int32_t quant_ctx_create(rrrmc_ctx** out, int64_t Nk, int64_t K, int64_t M, int64_t R, int32_t device, uint32_t replica0, bool sk, bool skn = false);
 }
 int32_t rrrmc_ctx_create_quant(rrrmc_ctx** out, int64_t Nk, int64_t K, int64_t M, int64_t R, int32_t device, uint32_t replica0)
 {
@@ -1403,12 +1407,16 @@ int32_t rrrmc_ctx_create_quant_sk(rrrmc_ctx** out, int64_t Nk, int64_t M, int64_
 {
     return quant_ctx_create(out, Nk, 0, M, R, device, replica0, true);
 }
+int32_t rrrmc_ctx_create_quant_skn(rrrmc_ctx** out, int64_t Nk, int64_t M, int64_t R, int32_t device, uint32_t replica0)
+{
+    return quant_ctx_create(out, Nk, 0, M, R, device, replica0, false, true);
+}
 namespace {
-int32_t quant_ctx_create(rrrmc_ctx** out, int64_t Nk, int64_t K, int64_t M, int64_t R, int32_t device, uint32_t replica0, bool sk)
+int32_t quant_ctx_create(rrrmc_ctx** out, int64_t Nk, int64_t K, int64_t M, int64_t R, int32_t device, uint32_t replica0, bool sk, bool skn)
 {
     if (!out) return fail(nullptr, RRRMC_ERR_INVALID_ARG, "out is NULL");
     *out = nullptr;
-    if (Nk < 1 || (!sk && K < 1) || R < 1) return fail(nullptr, RRRMC_ERR_INVALID_ARG, "Nk, K, R must be >= 1");
+    if (Nk < 1 || (!sk && !skn && K < 1) || R < 1) return fail(nullptr, RRRMC_ERR_INVALID_ARG, "Nk, K, R must be >= 1");
     if (M <= 2) return fail(nullptr, RRRMC_ERR_INVALID_ARG, "M must be greater than 2, given: %lld", (long long)M);   // QT.jl:47
     if (Nk * M > 65535) return fail(nullptr, RRRMC_ERR_UNSUPPORTED, "N = Nk*M = %lld: the rrrMC kernel indexes spins with 16 bits", (long long)(Nk * M));
     int ndev = 0;
@@ -1419,7 +1427,7 @@ int32_t quant_ctx_create(rrrmc_ctx** out, int64_t Nk, int64_t K, int64_t M, int6
     if (!ctx) return fail(nullptr, RRRMC_ERR_NOMEM, "out of host memory");
     ctx->model = RRRMC_MODEL_QUANT_RRG; ctx->N = Nk * M; ctx->K = K; ctx->R = R; ctx->Rpad = R;
     ctx->qNk = Nk; ctx->qM = M; ctx->qW = 2 * ((Nk * M + 63) / 64);
-    ctx->q_sk = sk; ctx->q_Wk = 2 * ((Nk + 63) / 64);
+    ctx->q_sk = sk; ctx->q_skn = skn; ctx->q_Wk = 2 * ((Nk + 63) / 64);
     ctx->device = device; ctx->replica0 = replica0;
     const int64_t N = ctx->N;
 #define Q_TRY(expr)                                                                                              \
@@ -1435,7 +1443,12 @@ int32_t quant_ctx_create(rrrmc_ctx** out, int64_t Nk, int64_t K, int64_t M, int6
     Q_TRY(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
     Q_TRY(hipEventCreate(&ctx->ev_begin));
     Q_TRY(hipEventCreate(&ctx->ev_end));
-    if (sk) {
+    if (skn) {
+        Q_TRY(hipMalloc(&ctx->sk_J, sizeof(double) * Nk * Nk));
+        Q_TRY(hipMalloc(&ctx->q_slf, sizeof(double) * (size_t)R * 2 * (size_t)M * (size_t)Nk));
+        Q_TRY(hipMalloc(&ctx->q_smv, sizeof(int32_t) * (size_t)R * (size_t)M));
+        Q_TRY(hipMalloc(&ctx->q_scur, (size_t)R * (size_t)M));
+    } else if (sk) {
         Q_TRY(hipMalloc(&ctx->q_Jb, sizeof(uint32_t) * Nk * ctx->q_Wk));
     } else {
         Q_TRY(hipMalloc(&ctx->d_A, sizeof(int32_t) * Nk * K));
@@ -1506,7 +1519,7 @@ int32_t quant_mc_async(rrrmc_ctx* ctx, bool standard, double beta, double fourK,
         const char* no_wave = std::getenv("RRRMC_QUANT_NO_WAVE");        // timing experiments / cross-checks of the two builds
         int64_t wave_max_R = 2048;
         if (const char* e = std::getenv("RRRMC_QUANT_WAVE_MAX_R")) wave_max_R = std::atoll(e);
-        const bool wave_ok = !ctx->q_sk && ctx->K <= 7 && ctx->qNk <= 65535 && ql.cap >= ctx->N + 4 * kQwMinGap && ctx->R <= wave_max_R &&
+        const bool wave_ok = !ctx->q_sk && !ctx->q_skn && ctx->K <= 7 && ctx->qNk <= 65535 && ql.cap >= ctx->N + 4 * kQwMinGap && ctx->R <= wave_max_R &&
                              !(no_wave && no_wave[0] == '1');
         // one replica per workgroup anyway (few replicas): stage its hot state in LDS if it fits (config 5: 115 KB)
         const size_t lds = rrr_quant_lds_bytes(ctx->N, ctx->qW, ctx->qNk, ctx->K);
@@ -1521,7 +1534,7 @@ int32_t quant_mc_async(rrrmc_ctx* ctx, bool standard, double beta, double fourK,
             X.stamps = g_stamps;
 #endif
             hipLaunchKernelGGL(rrr_quant_wave_kernel, dim3((unsigned)ctx->R), dim3(kRrrThreads), ql.bytes, st, P, X);
-        } else if (rrr_tpb(ctx->R) == 1 && lds <= (size_t)kLdsLimit && !(no_lds && no_lds[0] == '1')) {
+        } else if (!ctx->q_skn && rrr_tpb(ctx->R) == 1 && lds <= (size_t)kLdsLimit && !(no_lds && no_lds[0] == '1')) {
             if (!ctx->q_lds_attr) {
                 HIP_TRY(ctx, raise_lds_attr(reinterpret_cast<const void*>(rrr_quant_kernel<true>), lds));
                 ctx->q_lds_attr = true;
@@ -1713,9 +1726,10 @@ int32_t rrrmc_rrr_cache(rrrmc_ctx* ctx, int8_t* pos_out, int32_t* sizes_out)
 int32_t rrrmc_set_couplings_dense(rrrmc_ctx* ctx, const double* J)
 {
     if (!ctx) return RRRMC_ERR_INVALID_ARG;
-    if (ctx->model != RRRMC_MODEL_SK_NORMAL) return fail(ctx, RRRMC_ERR_STATE, "rrrmc_set_couplings_dense is for RRRMC_MODEL_SK_NORMAL");
+    const bool qskn = ctx->model == RRRMC_MODEL_QUANT_RRG && ctx->q_skn;      // the slice graph of a GraphQSKNormalT: J is Nk x Nk
+    if (ctx->model != RRRMC_MODEL_SK_NORMAL && !qskn) return fail(ctx, RRRMC_ERR_STATE, "rrrmc_set_couplings_dense is for RRRMC_MODEL_SK_NORMAL (or a GraphQuant over GraphSKNormal slices)");
     if (!J) return fail(ctx, RRRMC_ERR_INVALID_ARG, "J is NULL");
-    const int64_t N = ctx->N;
+    const int64_t N = qskn ? ctx->qNk : ctx->N;
     for (int64_t i = 0; i < N; ++i) {        // GraphSKNormal(J; check = true), SK.jl:187-194
         if (J[i * N + i] != 0.0) return fail(ctx, RRRMC_ERR_INVALID_ARG, "diagonal entries of J must be 0, found: J[%lld][%lld] = %g", (long long)i, (long long)i, J[i * N + i]);
         for (int64_t j = i + 1; j < N; ++j)
@@ -1946,6 +1960,7 @@ int32_t rrrmc_quant_observables(rrrmc_ctx* ctx, double beta, double Gamma, doubl
     if (rc) return rc;
     if (ctx->model != RRRMC_MODEL_QUANT_RRG) return fail(ctx, RRRMC_ERR_STATE, "rrrmc_quant_observables needs a GraphQuant context");
     if (!(ctx->last_fourK > 0.0)) return fail(ctx, RRRMC_ERR_STATE, "observables of a GraphQuant need fourK: call rrrmc_quant_set_field first");
+    if (ctx->q_skn) return fail(ctx, RRRMC_ERR_UNSUPPORTED, "Qenergy / overlaps are not wired for GraphSKNormal slices");
     const int64_t R = ctx->R, M = ctx->qM, Nk = ctx->qNk, N = ctx->N, H = M / 2;
     const size_t lds = sizeof(uint32_t) * (size_t)(M * ((Nk + 31) / 32) + M + H + 1);
     if (lds > (size_t)64 * 1024) return fail(ctx, RRRMC_ERR_UNSUPPORTED, "N = %lld spins per replica do not fit the observables kernel's LDS", (long long)N);

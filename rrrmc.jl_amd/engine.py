@@ -23,7 +23,9 @@ class Engine:
         self._ctx = C.c_void_p()
         self._f64 = X.model_kind not in (MODEL_SPARSE_PM1, MODEL_SPARSE_LEVELS)
         self._units = X.model_kind == MODEL_SPARSE_LEVELS        # device energies are int64 level units: X.energy_value converts
-        if X.model_kind == MODEL_QUANT_RRG and X.sk_slices:
+        if X.model_kind == MODEL_QUANT_RRG and getattr(X, "skn_slices", False):
+            check(lib().rrrmc_ctx_create_quant_skn(C.byref(self._ctx), X.Nk, X.M, self.R, device, replica0))
+        elif X.model_kind == MODEL_QUANT_RRG and X.sk_slices:
             check(lib().rrrmc_ctx_create_quant_sk(C.byref(self._ctx), X.Nk, X.M, self.R, device, replica0))
         elif X.model_kind == MODEL_QUANT_RRG:
             check(lib().rrrmc_ctx_create_quant(C.byref(self._ctx), X.Nk, X.K, X.M, self.R, device, replica0))
@@ -31,7 +33,9 @@ class Engine:
             check(lib().rrrmc_ctx_create(C.byref(self._ctx), X.model_kind, X.N, X.K, self.R, device, replica0))
         try:
             if X.model_kind == MODEL_QUANT_RRG:
-                if X.sk_slices:
+                if getattr(X, "skn_slices", False):
+                    check(lib().rrrmc_set_couplings_dense(self._ctx, X.J.reshape(-1)), self._ctx)
+                elif X.sk_slices:
                     check(lib().rrrmc_set_couplings_bits(self._ctx, X.J.reshape(-1)), self._ctx)
                 else:
                     check(lib().rrrmc_quant_slice_form(self._ctx, 1 if isinstance(X.X1, GraphEA) else 0), self._ctx)

@@ -422,11 +422,18 @@ class GraphQuant:
             raise ValueError("Γ must be >= 0")                                   # QT.jl:164
         self.X1, self.M, self.Gamma, self.beta = X1, int(M), float(Gamma), float(beta)
         self.sk_slices = isinstance(X1, GraphSK)
-        self.Nk, self.K = X1.N, (0 if self.sk_slices else X1.K)
+        self.skn_slices = isinstance(X1, GraphSKNormal)                    # GraphQSKNormalT (QAliases.jl:45-46; test/runtests.jl:80)
+        dense = self.sk_slices or self.skn_slices
+        self.Nk, self.K = X1.N, (0 if dense else X1.K)
         self.N = self.Nk * self.M
-        self.A, self.J = (None if self.sk_slices else X1.A), X1.J          # GraphSK slices: J = the bit-packed rows (SK.jl:32)
+        self.A, self.J = (None if dense else X1.A), X1.J                   # GraphSK slices: J = the bit-packed rows (SK.jl:32); GraphSKNormal: N x N Float64
         # fourK = round(2/β * log(coth(β Γ / M)), digits = MAXDIGITS): QT.jl:165
         self.fourK = round(2.0 / beta * math.log(1.0 / math.tanh(beta * Gamma / M)), 8)
+
+
+def GraphQSKNormalT(Nk, M, Gamma, beta, seed=DEFAULT_SEED):
+    """``GraphQSKNormalT(Nk, M, Γ, β)`` = ``GraphQuant(Nk, M, Γ, β, GraphSKNormal, SK.gen_J_gauss(Nk))`` (src/QAliases.jl:45-46)."""
+    return GraphQuant(GraphSKNormal(Nk, seed=seed), M, Gamma, beta)
 
 
 def GraphQSKT(Nk, M, Gamma, beta, seed=DEFAULT_SEED):

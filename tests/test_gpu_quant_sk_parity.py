@@ -117,3 +117,42 @@ def test_quant_sk_errors(pkg):
         bad = X.J.copy()
         bad[0, 0] |= np.uint64(1)                          # J[1][1] = 1: "diagonal entries of J must be 0" (SK.jl:38)
         assert pkg.lib().rrrmc_set_couplings_bits(eng._ctx, bad.reshape(-1)) == 1
+
+
+@pytest.mark.parametrize("Nk,M,Gamma,beta,R,iters,step,thr", [
+    (10, 8, 0.5, 2.0, 40, 12000, 100, None),         # test/runtests.jl:80: GraphQuant(10, 8, 0.5, 2.0, GraphSKNormal, SK.gen_J_gauss(10))
+    (10, 8, 0.5, 2.0, 9, 6000, 250, 1.0),            # staged branch only
+    (10, 8, 0.5, 2.0, 9, 6000, 250, 0.0),            # direct branch only: apply_move! and its undo through the slice's swap path
+    (40, 5, 0.3, 1.2, 70, 5000, 100, None),
+    (96, 12, 0.8, 1.0, 3, 3000, 500, None),
+])
+def test_graph_quant_over_sknormal_slices(pkg, oracle, Nk, M, Gamma, beta, R, iters, step, thr):
+    """GraphQuant over GraphSKNormal slices (GraphQSKNormalT): every slice keeps its own Float64 lfields / lfields_last / move_last
+    (SK.jl:212-276); rrrMC(X::DoubleGraph) and standardMC bit for bit against the oracle, incl. the DeltaECache state."""
+    seed = 31000 + Nk * M
+    X = pkg.GraphQSKNormalT(Nk, M, Gamma, beta, seed=seed)
+    J = X.J
+    kw = {} if thr is None else {"staged_thr": thr}
+    with pkg.Engine(X, R) as eng:
+        eng.seed(seed)
+        eng.init_spins_random()
+        C0 = eng.get_config()
+        E0 = eng.energy()
+        Es, acc, staged = eng.rrr_mc(beta, iters, step, **kw)
+        C1 = eng.get_config()
+        pos, sizes = eng.rrr_cache()
+        E1 = eng.energy()
+        Ess, accs = eng.standard_mc(beta, 2000, 100)
+        C2 = eng.get_config()
+        with pytest.raises(pkg.RRRMCError) as e:
+            eng.bkl_mc(beta, 10, 1)
+        assert e.value.code == 3
+    for r in sorted(set([0, 1, R // 2, R - 1])):
+        assert E0[r] == oracle.quant_skn_energy(J, Nk, M, X.fourK, C0.s[r])
+        ref = oracle.rrr_mc_quant_skn(J, Nk, M, X.fourK, beta, iters, step, seed, C0.s[r], replica=r, want_cache=True,
+                                      **({} if thr is None else {"staged_thr": thr}))
+        assert (Es[r] == ref[0]).all() and (C1.s[r] == ref[1]).all() and acc[r] == ref[2] and staged[r] == ref[3]
+        assert (pos[r] == ref[4]).all() and (sizes[r] == ref[5]).all()
+        assert E1[r] == oracle.quant_skn_energy(J, Nk, M, X.fourK, C1.s[r])
+        std = oracle.standard_mc_quant_skn(J, Nk, M, X.fourK, beta, 2000, 100, seed, ref[1], it0=iters, replica=r)
+        assert (Ess[r] == std[0]).all() and (C2.s[r] == std[1]).all() and accs[r] == std[2]
