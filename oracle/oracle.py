@@ -991,3 +991,51 @@ def cont_quant(mode, A, J, M, fourK, beta, iters, step, seed, chunks, it0=0, cal
     if n < 0:
         raise RuntimeError("cont_quant: DynamicSampler lost precision / unsupported (%d)" % n)
     return Es[:n], ch, stats, t.value
+
+
+def _dense_quant_args(Jb, Jd):
+    """(kind, Jb pointer or None, Jd pointer or None): 2 = binary GraphSK slices (bit-packed rows), 3 = GraphSKNormal (Nk x Nk Float64)."""
+    if Jd is not None:
+        a = np.ascontiguousarray(Jd, np.float64).reshape(-1)
+        return 3, None, a.ctypes.data, a
+    a = _jb(Jb)
+    return 2, a.ctypes.data, None, a
+
+
+def cont_quant_dense(mode, Nk, M, fourK, beta, iters, step, seed, chunks, Jb=None, Jd=None, it0=0, call=0, replica=0, stepf=1.0):
+    """bklMC / wtmMC on a GraphQuant over dense slices (GraphQSKT: Jb; GraphQSKNormalT: Jd): every spin has the Trotter pair and the
+    Nk - 1 other spins of its slice as neighbours.  Returns (Es, chunks, stats[3], t)."""
+    L = lib()
+    L.orc_cont_quant_dense.restype = C.c_int64
+    L.orc_cont_quant_dense.argtypes = [C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_int64, C.c_int64,
+                                       C.c_double, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, u64p, f64p, i64p, C.POINTER(C.c_double)]
+    kind, pb, pd, keep = _dense_quant_args(Jb, Jd)
+    ch = np.array(chunks, np.uint64, copy=True)
+    m = {"bkl": 1, "wtm": 2}[mode]
+    Es = np.zeros(max(iters if m == 2 else iters // step, 1))
+    stats = np.zeros(3, np.int64)
+    t = C.c_double(0)
+    n = L.orc_cont_quant_dense(m, kind, int(Nk), int(M), pb, pd, float(fourK), float(beta), int(iters), int(step), float(stepf), seed, it0, call,
+                               replica, ch, Es, stats, C.byref(t))
+    if n < 0:
+        raise RuntimeError("cont_quant_dense: DynamicSampler lost precision / unsupported (%d)" % n)
+    return Es[:n], ch, stats, t.value
+
+
+def extremal_opt_quant_dense(Nk, M, fourK, tau, iters, step, seed, chunks, Jb=None, Jd=None, it0=0, replica=0):
+    """extremal_opt on a GraphQuant over dense slices.  Returns (Es, final chunks, Emin, Cmin chunks, itmin)."""
+    L = lib()
+    L.orc_extremal_opt_quant_dense.restype = C.c_int64
+    L.orc_extremal_opt_quant_dense.argtypes = [C.c_int, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_double, f64p, C.c_int64, C.c_int64,
+                                               C.c_uint64, C.c_uint64, C.c_uint32, u64p, f64p, C.POINTER(C.c_double), u64p, C.POINTER(C.c_int64)]
+    kind, pb, pd, keep = _dense_quant_args(Jb, Jd)
+    N = int(Nk) * int(M)
+    ch = np.array(chunks, np.uint64, copy=True)
+    Es = np.zeros(max(iters // step, 1))
+    Cmin = np.zeros_like(ch)
+    Emin, itmin = C.c_double(0), C.c_int64(0)
+    n = L.orc_extremal_opt_quant_dense(kind, int(Nk), int(M), pb, pd, float(fourK), eo_ftau(N, tau), int(iters), int(step), seed, it0, replica,
+                                       ch, Es, C.byref(Emin), Cmin, C.byref(itmin))
+    if n < 0:
+        raise RuntimeError("extremal_opt_quant_dense: inconsistent cache / energy (%d)" % n)
+    return Es[:n], ch, Emin.value, Cmin, itmin.value

@@ -1731,7 +1731,7 @@ ORC_API int64_t orc_dyns_test(int64_t N, const double *v, int64_t nupd, const in
  * rrrMC(X::SingleGraph) (src/RRRMC.jl:149-219) and bklMC (src/RRRMC.jl:311-359) on the DiscrGraphs GraphRRG / GraphEA
  * with DeltaECache{Int, L} (src/DeltaE.jl:63-295): SURVEY.md §8(f) rank 1.
  * ============================================================================================= */
-enum { SL_MAX = 8, SK_MAX = 8 };
+enum { SL_MAX = 8, SK_MAX = 8, ORC_NB_MAX = 2050 };      /* ORC_NB_MAX: neighbours of a spin of a GraphQuant over dense slices (2 + Nk - 1) */
 typedef struct {
     int64_t N;
     int L;
@@ -2346,6 +2346,10 @@ static int spf_neighbors(const spf_t *X, int64_t i, int64_t *out)
         qt_neighbors(&Q->X0, i, &j1, &j2);
         out[n++] = j1; out[n++] = j2;
         const int64_t k = i / Q->Nk, x = i % Q->Nk;
+        if (!Q->X1) {                                  /* GraphSK / GraphSKNormal slices: AllButOne(Nk, x) (SK.jl:142,297), in index order */
+            for (int64_t j = 0; j < Q->Nk; ++j) if (j != x) out[n++] = j + k * Q->Nk;
+            return n;
+        }
         int64_t nb1[SK_MAX];
         const int nn = sparse_neighbors(&Q->X1[k], x, nb1);
         for (int q = 0; q < nn; ++q) out[n++] = nb1[q] + k * Q->Nk;
@@ -2378,7 +2382,7 @@ static double cont_apply_move(spf_t *X, uint64_t *s, dyns_t *ds, double *dEs, do
     const double z = ds->z;
     dEs[move] = spf_dE(X, move);
     dyns_set(ds, move, prior_of(beta * dEs[move]));
-    int64_t nb[SK_MAX + 2];
+    int64_t nb[ORC_NB_MAX];
     int nn = spf_neighbors(X, move, nb);
     for (int q = 0; q < nn; ++q) {
         int64_t j = nb[q];
@@ -2439,7 +2443,7 @@ static int64_t cont_sparse_impl(int mode, int form, int64_t N, int64_t K, const 
             spf_spinflip(&X, chunks, move);
             double e = orc_det_exp(beta * -dE);
             tm[move] = t + wtm_gen(e > 1.0 ? e : 1.0, wtm_uniform(seed, nd++, replica, call));
-            int64_t nb[SK_MAX + 2];
+            int64_t nb[ORC_NB_MAX];
             int nn = spf_neighbors(&X, move, nb);
             for (int q = 0; q < nn; ++q) {
                 e = orc_det_exp(beta * spf_dE(&X, nb[q]));
@@ -2476,7 +2480,7 @@ static int64_t cont_sparse_impl(int mode, int form, int64_t N, int64_t K, const 
                     spf_spinflip(&X, chunks, move);                                    /* compute_staged!: DeltaE.jl:357-374 */
                     int ns = 0;
                     st_j[ns] = move; st_dE[ns] = spf_dE(&X, move); st_p[ns] = prior_of(beta * st_dE[ns]); ns++;
-                    int64_t nb[SK_MAX + 2];
+                    int64_t nb[ORC_NB_MAX];
                     int nn = spf_neighbors(&X, move, nb);
                     for (int q = 0; q < nn; ++q) { st_j[ns] = nb[q]; st_dE[ns] = spf_dE(&X, nb[q]); st_p[ns] = prior_of(beta * st_dE[ns]); ns++; }
                     spf_spinflip(&X, chunks, move);
@@ -2673,15 +2677,39 @@ ORC_API int64_t orc_extremal_opt_cont(int form, int64_t N, int64_t K, const int3
  * builds the generic EOCacheCont (DeltaE.jl:557-635) over all N = Nk M spins with delta_energy = delta_energy(X0) + residual
  * (QT.jl:283-286) and neighbors(X, i) = the Trotter pair, then the slice graph's (QT.jl:288-321).  Streams and tie rule as
  * orc_extremal_opt_cont. */
+static int64_t extremal_opt_quant_impl(quant_t *Qp, int form, int64_t K, const int32_t *A,
+                                       const double *ftau, int64_t iters, int64_t step, uint64_t seed, uint64_t it0, uint32_t replica,
+                                       uint64_t *chunks, double *Es, double *Emin_out, uint64_t *Cmin, int64_t *itmin_out);
 ORC_API int64_t orc_extremal_opt_quant(int form, int64_t Nk, int64_t M, int64_t K, const int32_t *A, const int32_t *J, double fourK,
                                        const double *ftau, int64_t iters, int64_t step, uint64_t seed, uint64_t it0, uint32_t replica,
                                        uint64_t *chunks, double *Es, double *Emin_out, uint64_t *Cmin, int64_t *itmin_out)
 {
-    const int64_t N = Nk * M;
-    if (N > 65535 || K + 2 > SK_MAX + 2) return -2;
+    if (Nk * M > 65535 || K + 2 > SK_MAX + 2) return -2;
     quant_t Q;
     quant_init(&Q, Nk, M, K, A, J, fourK);
     for (int64_t k = 0; k < M; ++k) Q.X1[k].ea_form = form;
+    const int64_t r = extremal_opt_quant_impl(&Q, form, K, A, ftau, iters, step, seed, it0, replica, chunks, Es, Emin_out, Cmin, itmin_out);
+    quant_free(&Q);
+    return r;
+}
+ORC_API int64_t orc_extremal_opt_quant_dense(int kind, int64_t Nk, int64_t M, const uint64_t *Jb, const double *Jd, double fourK,
+                                             const double *ftau, int64_t iters, int64_t step, uint64_t seed, uint64_t it0, uint32_t replica,
+                                             uint64_t *chunks, double *Es, double *Emin_out, uint64_t *Cmin, int64_t *itmin_out)
+{
+    if (Nk * M > 65535 || Nk + 1 > ORC_NB_MAX) return -2;
+    quant_t Q;
+    if (kind == 3) quant_init_skn(&Q, Nk, M, Jd, fourK); else quant_init_sk(&Q, Nk, M, Jb, fourK);
+    const int64_t r = extremal_opt_quant_impl(&Q, 0, 0, NULL, ftau, iters, step, seed, it0, replica, chunks, Es, Emin_out, Cmin, itmin_out);
+    quant_free(&Q);
+    return r;
+}
+static int64_t extremal_opt_quant_impl(quant_t *Qp, int form, int64_t K, const int32_t *A,
+                                       const double *ftau, int64_t iters, int64_t step, uint64_t seed, uint64_t it0, uint32_t replica,
+                                       uint64_t *chunks, double *Es, double *Emin_out, uint64_t *Cmin, int64_t *itmin_out)
+{
+    quant_t Q = *Qp;                     /* the caller owns (and frees) the slice arrays */
+    const int64_t Nk = Q.Nk, M = Q.M;
+    const int64_t N = Nk * M;
     spf_t X = {N, K, A, NULL, NULL, NULL, -1, form, NULL, 1, 1.0, NULL, NULL};
     X.Q = &Q; X.cur_s = chunks;
     double E = quant_energy(&Q, chunks);
@@ -2709,7 +2737,7 @@ ORC_API int64_t orc_extremal_opt_quant(int form, int64_t Nk, int64_t M, int64_t 
         const double dE = dEs[move];
         spf_spinflip(&X, chunks, move);
         dEs[move] = spf_dE(&X, move);
-        int64_t nb[SK_MAX + 2];
+        int64_t nb[ORC_NB_MAX];
         int nn = spf_neighbors(&X, move, nb);
         for (int q = 0; q < nn; ++q) dEs[nb[q]] = spf_dE(&X, nb[q]);
         cmp.g = g; cmp.fresh = 1;
@@ -2731,7 +2759,6 @@ ORC_API int64_t orc_extremal_opt_quant(int form, int64_t Nk, int64_t M, int64_t 
     if (Emin_out) *Emin_out = Emin;
     if (itmin_out) *itmin_out = itmin;
     free(dEs); free(rank); free(tmp);
-    quant_free(&Q);
     return ok ? nsamp : -1;
 }
 
@@ -2806,6 +2833,19 @@ ORC_API int64_t orc_extremal_opt_skb(int64_t N, const uint64_t *Jb, const double
 /* bklMC / wtmMC on a GraphQuant over GraphRRG / GraphEA slices: a DoubleGraph is not a DiscrGraph, so the reference builds the
  * continuous-energy caches over the WHOLE graph (DeltaE.jl:315, WaitingTimes.jl) with delta_energy = delta_energy(X0) + residual
  * (QT.jl:283-286) and neighbors(X, i) = the two Trotter neighbours, then the slice graph's (QT.jl:288-321).  mode 1 / 2 as orc_cont_sparse. */
+/* the same over dense slices: kind 2 = binary GraphSK (Jb: bit-packed rows), 3 = GraphSKNormal (Jd: Nk x Nk Float64) */
+ORC_API int64_t orc_cont_quant_dense(int mode, int kind, int64_t Nk, int64_t M, const uint64_t *Jb, const double *Jd, double fourK, double beta,
+                                     int64_t iters, int64_t step, double stepf, uint64_t seed, uint64_t it0, uint32_t call, uint32_t replica,
+                                     uint64_t *chunks, double *Es, int64_t *stats, double *t_out)
+{
+    if (Nk + 1 > ORC_NB_MAX) return -2;
+    quant_t Q;
+    if (kind == 3) quant_init_skn(&Q, Nk, M, Jd, fourK); else quant_init_sk(&Q, Nk, M, Jb, fourK);
+    int64_t r = cont_sparse_impl(mode, 0, Nk * M, 0, NULL, NULL, NULL, 1, 1.0, beta, iters, step, stepf, 0.8, 5.0, seed, it0, call, replica,
+                                 chunks, Es, stats, t_out, &Q);
+    quant_free(&Q);
+    return r;
+}
 ORC_API int64_t orc_cont_quant(int mode, int form, int64_t Nk, int64_t M, int64_t K, const int32_t *A, const int32_t *J, double fourK, double beta,
                                int64_t iters, int64_t step, double stepf, uint64_t seed, uint64_t it0, uint32_t call, uint32_t replica,
                                uint64_t *chunks, double *Es, int64_t *stats, double *t_out)

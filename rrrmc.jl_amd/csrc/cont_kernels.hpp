@@ -42,6 +42,11 @@ struct ContParams {
     const int8_t* qJ;        // GraphQuant (bklMC / wtmMC over the whole DoubleGraph, DeltaE.jl:315): slice couplings [qNk][K] (A = the slice's table), else null
     double fourK;            //   delta_energy = qt_delta * fourK + slice_delta / qM (QT.jl:283-286); neighbors = Trotter pair, then the slice's (QT.jl:288-321)
     int qNk, qM;
+    // GraphQuant over DENSE slices (every other spin of the slice is a neighbour): qkind 2 = binary GraphSK (GraphQSKT), 3 = GraphSKNormal
+    // (GraphQSKNormalT); 1 = sparse slices (qJ above), 0 = not a GraphQuant
+    int qkind;
+    const uint32_t* qJb; int qWk; double qsN;                       // binary: rows of J as 32-bit words, sqrt(Nk)
+    const double* qJd; double* qslf; int32_t* qsmv; uint8_t* qscur;  // GraphSKNormal: couplings, per-replica slice caches (as RrrParams)
     const double* ftau;      // [N]  extremal_opt: cumsum(j^-tau)
     uint32_t* cmin;          // [R][W] extremal_opt: configuration of minimum energy
     double beta, staged_thr, lambda, stepf;
@@ -86,6 +91,7 @@ struct ContChain {
     long long trefresh;
     uint32_t rep;
     uint64_t nd;
+    int rloc;                // replica index inside this context (the GraphQuant slice caches are per replica)
 
     __device__ __forceinline__ int sbit(int x) const { return (int)((sp[x >> 5] >> (x & 31)) & 1u); }
     __device__ __forceinline__ bool is_nb(const int32_t* Ax, int q) const { return !(P->ea_form && q > 0 && Ax[q] == Ax[q - 1]); }
@@ -93,7 +99,10 @@ struct ContChain {
     __device__ void flip(int move)
     {
         sp[move >> 5] ^= 1u << (move & 31);
-        if (P->qJ) return;                       // GraphQuant: nothing is cached, every delta_energy is recomputed from the spins
+        if (P->qkind) {                          // GraphQuant: integer slices cache nothing (delta_energy is recomputed from the spins);
+            if (P->qkind == 3) skn_update(qview(), move);      // GraphSKNormal slices keep their Float64 fields (SK.jl:239-276)
+            return;
+        }
         const int K = P->K;
         const int32_t* Ax = P->A + (size_t)move * K;
         const double* Jx = P->J + (size_t)move * K;
@@ -139,6 +148,11 @@ struct ContChain {
     {
         RrrView v{};
         v.sp = sp; v.N = P->N; v.Nk = P->qNk; v.M = P->qM; v.K = P->K; v.A = P->A; v.J = P->qJ; v.fourK = P->fourK;
+        if (P->qkind == 2) { v.Jb = P->qJb; v.Wk = P->qWk; v.sN = P->qsN; }
+        if (P->qkind == 3) {
+            v.Jd = P->qJd;
+            v.slf = P->qslf + (size_t)rloc * 2 * P->qM * P->qNk; v.smv = P->qsmv + (size_t)rloc * P->qM; v.scur = P->qscur + (size_t)rloc * P->qM;
+        }
         v.nk_magic = (uint32_t)((0x100000000ull + (uint32_t)P->qNk - 1u) / (uint32_t)P->qNk);
         return v;
     }
@@ -146,7 +160,7 @@ struct ContChain {
     __device__ __forceinline__ int nbrs(int move, int* out) const
     {
         int n = 0;
-        if (P->qJ) {
+        if (P->qkind) {
             const RrrView v = qview();
             int j1, j2;
             qt_nb(v, move, j1, j2);
@@ -166,9 +180,24 @@ struct ContChain {
         }
         return n;
     }
+    // neighbors(X, move) as (count, q-th neighbour): sparse graphs go through the small list `nb`, a GraphQuant over dense slices has the
+    // Trotter pair followed by the Nk - 1 other spins of the slice in index order (AllButOne, SK.jl:142,297; QT.jl:288-321)
+    __device__ __forceinline__ bool dense() const { return P->qkind >= 2; }
+    __device__ __forceinline__ int nb_count(int move, int* nb) const { return dense() ? P->qNk + 1 : nbrs(move, nb); }
+    __device__ __forceinline__ int nb_at(int move, int q, const int* nb) const
+    {
+        if (!dense()) return nb[q];
+        int j1, j2;
+        const RrrView v = qview();
+        qt_nb(v, move, j1, j2);
+        if (q == 0) return j1;
+        if (q == 1) return j2;
+        const int k = move / P->qNk, x = move - k * P->qNk, jj = q - 2;
+        return k * P->qNk + (jj < x ? jj : jj + 1);
+    }
     __device__ __forceinline__ double dE(int i) const          // RRG.jl:619-625; DoubleGraph: convert(Float64, dE0 + dE1), :493-497
     {
-        if (P->qJ) { const RrrView v = qview(); return (double)qt_delta(v, i) * P->fourK + slice_res(v, slice_delta(v, i)); }
+        if (P->qkind) { const RrrView v = qview(); return (double)qt_delta(v, i) * P->fourK + any_residual(v, i); }
         if (P->dJ) return (double)(dE0(i) * P->lev_mul) / P->lev_div + (-lf[i]);
         return -lf[i];
     }
@@ -232,9 +261,9 @@ struct ContChain {
         dEs[move] = dE(move);
         set(move, prior_of(P->beta * dEs[move]));
         int nb[kContKmax + 2];
-        const int nn = nbrs(move, nb);
+        const int nn = nb_count(move, nb);
         for (int q = 0; q < nn; ++q) {
-            const int j = nb[q];
+            const int j = nb_at(move, q, nb);
             dEs[j] = dE(j);
             set(j, prior_of(P->beta * dEs[j]));
         }
@@ -350,9 +379,10 @@ __global__ __launch_bounds__(kRrrThreads) void cont_sparse_kernel(ContParams P)
     c.hid = P.hid + (size_t)r * N; c.hpos = P.hpos + (size_t)r * N;
     c.mlast = -1; c.z = 0.0; c.trefresh = 0; c.nd = 0;
     c.rep = P.replica0 + (uint32_t)r;
+    c.rloc = r;
     // energy(X, C): RRG.jl:546-574 / EA.jl:584-611
     double E1 = 0.0;
-    for (int i = 0; i < N && !P.qJ; ++i) {
+    for (int i = 0; i < N && !P.qkind; ++i) {
         const int sx = 2 * c.sbit(i) - 1;
         double fl = 0.0;
         for (int q = 0; q < K; ++q) {
@@ -368,7 +398,7 @@ __global__ __launch_bounds__(kRrrThreads) void cont_sparse_kernel(ContParams P)
         for (int i = 0; i < N; ++i) n0 -= c.dE0(i) / 2;
         E = (double)((n0 / 2) * P.lev_mul) / P.lev_div + E;
     }
-    if (P.qJ) {                                  // energy(X::GraphQuant, C): QT.jl:185-199 (as rrr_init_kernel)
+    if (P.qkind) {                               // energy(X::GraphQuant, C): QT.jl:185-199 (as rrr_init_kernel)
         const RrrView v = c.qview();
         long long n0 = 0;
         for (int i = 0; i < P.qNk; ++i) {
@@ -376,11 +406,28 @@ __global__ __launch_bounds__(kRrrThreads) void cont_sparse_kernel(ContParams P)
             for (int k = 0; k < P.qM; ++k) { const int sk = c.sbit(i + k * P.qNk); n0 -= 1 - 2 * (sk ^ sj); sj = sk; }
         }
         E = (double)n0 * P.fourK / 4;
-        for (int k = 0; k < P.qM; ++k) {
+        for (int k = 0; k < P.qM && P.qkind != 3; ++k) {
             long long n = 0;
             for (int i = 0; i < P.qNk; ++i) n -= slice_delta(v, k * P.qNk + i) / 2;
             n /= 2;
-            E += (double)n / (double)P.qM;
+            E += P.qkind == 2 ? ((double)n / P.qsN) / (double)P.qM : (double)n / (double)P.qM;      // GraphSK: n / sqrt(Nk) (SK.jl:95)
+        }
+        for (int k = 0; k < P.qM && P.qkind == 3; ++k) {      // GraphSKNormal slices: rebuild the slice cache as energy does (SK.jl:212-237)
+            double* lf = v.slf + ((size_t)0 * P.qM + k) * P.qNk;
+            double* ll = v.slf + ((size_t)1 * P.qM + k) * P.qNk;
+            double n = 0.0;
+            for (int i = 0; i < P.qNk; ++i) {
+                const double* Ji = P.qJd + (size_t)i * P.qNk;
+                const int si = c.sbit(k * P.qNk + i);
+                double lfi = 0.0;
+                for (int j = 0; j < P.qNk; ++j) lfi += (double)(1 - 2 * (si ^ c.sbit(k * P.qNk + j))) * Ji[j];
+                lf[i] = 2 * lfi;
+                ll[i] = 0.0;
+                n -= lfi;
+            }
+            n /= 2;
+            v.smv[k] = -1; v.scur[k] = 0;
+            E += n / (double)P.qM;
         }
     }
     long long accepted = 0, second = 0, ns = 0, itdone = 0;
@@ -407,8 +454,8 @@ __global__ __launch_bounds__(kRrrThreads) void cont_sparse_kernel(ContParams P)
             c.flip(move);
             c.heap_update(move, t + c.gen_wt(-d));
             int nb[kContKmax + 2];
-            const int nn = c.nbrs(move, nb);
-            for (int q = 0; q < nn; ++q) c.heap_update(nb[q], t + c.gen_wt(c.dE(nb[q])));
+            const int nn = c.nb_count(move, nb);
+            for (int q = 0; q < nn; ++q) { const int j = c.nb_at(move, q, nb); c.heap_update(j, t + c.gen_wt(c.dE(j))); }
             E += d;
             accepted += 1;
         }
@@ -438,8 +485,8 @@ __global__ __launch_bounds__(kRrrThreads) void cont_sparse_kernel(ContParams P)
             c.flip(move);                                                                                    // apply_move!: :592-609
             nties = c.eo_reinsert(move, c.dE(move), nties);
             int enb[kContKmax + 2];
-            const int enn = c.nbrs(move, enb);                                                               // neighbors(X, move): a GraphQuant's too
-            for (int q = 0; q < enn; ++q) nties = c.eo_reinsert(enb[q], c.dE(enb[q]), nties);
+            const int enn = c.nb_count(move, enb);                                                           // neighbors(X, move): a GraphQuant's too
+            for (int q = 0; q < enn; ++q) { const int j = c.nb_at(move, q, enb); nties = c.eo_reinsert(j, c.dE(j), nties); }
             if (nties > 0) c.eo_order_ties(g);
             E += dE;
             if (E < Emin) {
@@ -565,7 +612,7 @@ __global__ __launch_bounds__(64) void eo_cont_wave_kernel(ContParams P)
     c.dEs = P.dEs + (size_t)r * N; c.v = P.v + (size_t)r * P.N2; c.ps = P.ps + (size_t)r * P.N2;
     c.hid = P.hid + (size_t)r * N; c.hpos = P.hpos + (size_t)r * N;
     c.mlast = -1; c.z = 0.0; c.trefresh = 0; c.nd = 0;
-    c.rep = P.replica0 + (uint32_t)r;
+    c.rep = P.replica0 + (uint32_t)r; c.rloc = r;
     unsigned long long* key = reinterpret_cast<unsigned long long*>(c.ps);
     uint32_t* cm = P.cmin + (size_t)r * P.W;
     // energy(X, C) (RRG.jl:546-574 / EA.jl:584-611): the fields site-parallel, their sum in site order

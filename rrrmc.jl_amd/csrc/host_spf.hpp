@@ -150,8 +150,6 @@ int32_t spf_cont_async(rrrmc_ctx* ctx, int mode, double beta, int64_t iters, int
     ctx->timing_valid = false;
     // the discretised DoubleGraphs (bklMC / wtmMC over the whole graph: DeltaE.jl:315) keep their spins in the kernel's layout already
     const bool quantm = ctx->model == RRRMC_MODEL_QUANT_RRG;          // bklMC / wtmMC over the whole GraphQuant (DeltaE.jl:315): spins in q_spins too
-    if (quantm && ctx->q_skn) return fail(ctx, RRRMC_ERR_UNSUPPORTED, "bklMC / wtmMC / extremal_opt on a GraphQuant over GraphSKNormal slices are not wired (rrrMC and standardMC are)");
-    if (quantm && ctx->q_sk) return fail(ctx, RRRMC_ERR_UNSUPPORTED, "bklMC / wtmMC / extremal_opt on a GraphQuant are wired for GraphRRG / GraphEA slices (a GraphSK slice has Nk - 1 neighbours per spin)");
     if (quantm && !(ctx->last_fourK > 0.0)) return fail(ctx, RRRMC_ERR_STATE, "a GraphQuant needs fourK: call rrrmc_quant_set_field first");
     const bool dblm = ctx->model == RRRMC_MODEL_SPARSE_DISCRETIZED || quantm;
     const int64_t N = ctx->N, K = ctx->K, R = ctx->R, W = dblm ? ctx->qW : (N + 31) / 32;
@@ -193,7 +191,12 @@ int32_t spf_cont_async(rrrmc_ctx* ctx, int mode, double beta, int64_t iters, int
     double* b = ctx->cs_buf;
     P.A = ctx->d_A; P.J = quantm ? nullptr : dblm ? ctx->db_rJ : ctx->pf_J; P.spins = dblm ? ctx->q_spins : ctx->cs_spins;
     P.dJ = dblm && !quantm ? ctx->db_dJ : nullptr; P.lev_mul = ctx->db_lev_mul; P.lev_div = ctx->db_lev_div;
-    if (quantm) { P.qJ = ctx->d_J; P.fourK = ctx->last_fourK; P.qNk = (int)ctx->qNk; P.qM = (int)ctx->qM; }
+    if (quantm) {
+        P.qJ = ctx->d_J; P.fourK = ctx->last_fourK; P.qNk = (int)ctx->qNk; P.qM = (int)ctx->qM;
+        P.qkind = ctx->q_skn ? 3 : (ctx->q_sk ? 2 : 1);
+        if (ctx->q_sk) { P.qJb = ctx->q_Jb; P.qWk = (int)ctx->q_Wk; P.qsN = std::sqrt((double)ctx->qNk); }
+        if (ctx->q_skn) { P.qJd = ctx->sk_J; P.qslf = ctx->q_slf; P.qsmv = ctx->q_smv; P.qscur = ctx->q_scur; }
+    }
     P.lf = b; b += (size_t)R * N;
     P.dEs = b; b += (size_t)R * N;
     P.v = b; b += (size_t)R * N2;

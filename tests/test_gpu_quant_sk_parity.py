@@ -144,9 +144,6 @@ def test_graph_quant_over_sknormal_slices(pkg, oracle, Nk, M, Gamma, beta, R, it
         E1 = eng.energy()
         Ess, accs = eng.standard_mc(beta, 2000, 100)
         C2 = eng.get_config()
-        with pytest.raises(pkg.RRRMCError) as e:
-            eng.bkl_mc(beta, 10, 1)
-        assert e.value.code == 3
     for r in sorted(set([0, 1, R // 2, R - 1])):
         assert E0[r] == oracle.quant_skn_energy(J, Nk, M, X.fourK, C0.s[r])
         ref = oracle.rrr_mc_quant_skn(J, Nk, M, X.fourK, beta, iters, step, seed, C0.s[r], replica=r, want_cache=True,
@@ -156,3 +153,41 @@ def test_graph_quant_over_sknormal_slices(pkg, oracle, Nk, M, Gamma, beta, R, it
         assert E1[r] == oracle.quant_skn_energy(J, Nk, M, X.fourK, C1.s[r])
         std = oracle.standard_mc_quant_skn(J, Nk, M, X.fourK, beta, 2000, 100, seed, ref[1], it0=iters, replica=r)
         assert (Ess[r] == std[0]).all() and (C2.s[r] == std[1]).all() and accs[r] == std[2]
+
+
+@pytest.mark.parametrize("kind,Nk,M,Gamma,beta,R", [
+    ("skn", 10, 8, 0.5, 2.0, 12),            # test/runtests.jl:80 under bklMC / wtmMC / extremal_opt (:145-157)
+    ("skb", 10, 8, 0.5, 2.0, 12),            # test/runtests.jl:79 (GraphQSKT)
+    ("skn", 24, 5, 0.3, 1.0, 5),
+    ("skb", 40, 4, 0.6, 1.5, 3),
+])
+def test_cont_samplers_on_graph_quant_over_dense_slices(pkg, oracle, kind, Nk, M, Gamma, beta, R):
+    """bklMC, wtmMC and extremal_opt on a GraphQuant over dense slices (GraphQSKNormalT / GraphQSKT): the generic continuous-energy
+    caches over all Nk M spins, every spin with the Trotter pair and the Nk - 1 other spins of its slice as neighbours
+    (QT.jl:288-321, SK.jl:142,297)."""
+    seed = 52000 + Nk * M
+    X = pkg.GraphQSKNormalT(Nk, M, Gamma, beta, seed=seed) if kind == "skn" else pkg.GraphQSKT(Nk, M, Gamma, beta, seed=seed)
+    kw = {"Jd": X.J} if kind == "skn" else {"Jb": X.J}
+    iters, step, samples, eo_iters = 3000, 100, 12, 1200
+    with pkg.Engine(X, R) as eng:
+        eng.seed(seed)
+        eng.init_spins_random()
+        C0 = eng.get_config()
+        Eb, mb = eng.bkl_mc(beta, iters, step)
+        C1 = eng.get_config()
+        eng.seed(seed)
+        eng.set_config(C0)
+        Ew, mw, tw = eng.wtm_mc(beta, samples, step=2.0)
+        C2 = eng.get_config()
+        eng.seed(seed)
+        eng.set_config(C0)
+        Ee, Emin, Cmin, itmin = eng.extremal_opt(1.4, eo_iters, 100)
+        C3 = eng.get_config()
+        Er, ar, st = eng.rrr_mc(beta, 500, 100)               # the DoubleGraph rrrMC still works afterwards
+    for r in sorted(set([0, R // 2, R - 1])):
+        b = oracle.cont_quant_dense("bkl", Nk, M, X.fourK, beta, iters, step, seed, C0.s[r], replica=r, **kw)
+        assert (Eb[r] == b[0]).all() and (C1.s[r] == b[1]).all() and mb[r] == b[2][0]
+        w = oracle.cont_quant_dense("wtm", Nk, M, X.fourK, beta, samples, 1, seed, C0.s[r], replica=r, stepf=2.0, **kw)
+        assert (Ew[r] == w[0]).all() and (C2.s[r] == w[1]).all() and mw[r] == w[2][0] and tw[r] == w[3]
+        e = oracle.extremal_opt_quant_dense(Nk, M, X.fourK, 1.4, eo_iters, 100, seed, C0.s[r], replica=r, **kw)
+        assert (Ee[r] == e[0]).all() and (C3.s[r] == e[1]).all() and Emin[r] == e[2] and (Cmin.s[r] == e[3]).all() and itmin[r] == e[4]
