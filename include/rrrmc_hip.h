@@ -276,7 +276,7 @@ RRRMC_API int32_t rrrmc_gen_couplings_gauss(int64_t N, int64_t K, const int32_t 
 /* ---- DoubleGraphs with discretised Gaussian couplings (RRRMC_MODEL_SPARSE_DISCRETIZED) --------
  * GraphRRGNormalDiscretized{Int,LEV,K} / GraphEANormalDiscretized{Int,LEV,2D}: couplings cJ ~ Normal(0,1) split by
  * discretize (src/Common.jl:38-72) into integer levels dJ (the inner DiscrGraph X0, which drives the DeltaECache) and
- * Float64 residuals rJ.  Create with rrrmc_ctx_create(model = RRRMC_MODEL_SPARSE_DISCRETIZED, N, K, R); N <= 65535, K <= 8.
+ * Float64 residuals rJ.  Create with rrrmc_ctx_create(model = RRRMC_MODEL_SPARSE_DISCRETIZED, N, K, R); N <= 2^28, K <= 8.
  *   lev[nlev]  the levels (distinct integers in -127..127; allΔE(X0) must have <= 8 values)
  *   ea_form    0: GraphRRG conventions (neighbors = non-zero couplings, RRG.jl:133), 1: GraphEA (repeats removed, EA.jl:158)
  * Sampler: rrrmc_rrr_mc_async (rrrMC(X::DoubleGraph), src/RRRMC.jl:221-290; fourK ignored); results through
@@ -302,7 +302,7 @@ RRRMC_API int32_t rrrmc_discretize_scaled(const double *x, int64_t n, const int3
 /* ---- stand-alone GraphRRG / GraphEA with general levels (RRRMC_MODEL_SPARSE_LEVELS) ----------
  * GraphRRG{ET,LEV,K}(A, J) / GraphEA{ET,LEV,2D}(A, J) with any levels (the reference's tests use (-1,0,1), (-1.0,0.0,1.0), ...:
  * test/runtests.jl:36-60); LEV = (-1, 1) has its own bit-sliced context, RRRMC_MODEL_SPARSE_PM1.  Create with
- * rrrmc_ctx_create(model = RRRMC_MODEL_SPARSE_LEVELS, N, K, R); N <= 65535, K <= 8, allΔE(X) <= 8 values.
+ * rrrmc_ctx_create(model = RRRMC_MODEL_SPARSE_LEVELS, N, K, R); N <= 2^28, K <= 8, allΔE(X) <= 8 values.
  *   J[N*K], lev[nlev]   integer level units in -127..127 (rrrmc_set_level_scale gives their value: Int levels (1, 1.0), DFloat64
  *                       levels (g, 1e5), see above); ea_form as for rrrmc_set_graph_discretized
  * Samplers: rrrmc_standard_mc_async (SITE stream + ACCEPT_F64 stream: rand53 < exp(-beta dE)), rrrmc_rrr_mc_async (rrrMC(X::SingleGraph),

@@ -1731,7 +1731,7 @@ ORC_API int64_t orc_dyns_test(int64_t N, const double *v, int64_t nupd, const in
  * rrrMC(X::SingleGraph) (src/RRRMC.jl:149-219) and bklMC (src/RRRMC.jl:311-359) on the DiscrGraphs GraphRRG / GraphEA
  * with DeltaECache{Int, L} (src/DeltaE.jl:63-295): SURVEY.md §8(f) rank 1.
  * ============================================================================================= */
-enum { SL_MAX = 8, SK_MAX = 8, ORC_NB_MAX = 2050 };      /* ORC_NB_MAX: neighbours of a spin of a GraphQuant over dense slices (2 + Nk - 1) */
+enum { SL_MAX = 8, SK_MAX = 32, ORC_NB_MAX = 2050 };      /* ORC_NB_MAX: neighbours of a spin of a GraphQuant over dense slices (2 + Nk - 1) */
 typedef struct {
     int64_t N;
     int L;

@@ -32,8 +32,8 @@ struct ContParams {
     double* dEs;             // [R][N]   DeltaECacheCont.ΔEs          (wtmMC: heap keys)
     double* v;               // [R][N2]  DynamicSampler.v
     double* ps;              // [R][N2]  DynamicSampler.ps (N2 - 1 used)
-    uint16_t* hid;           // [R][N]   wtmMC: site at heap position
-    uint16_t* hpos;          // [R][N]   wtmMC: heap position of site
+    void* hid;               // [R][N]   wtmMC: site at heap position (uint16_t; uint32_t when N > 65535)
+    void* hpos;              // [R][N]   wtmMC: heap position of site
     double* E_cur;           // [R]
     int64_t* stats;          // [R][3]
     double* Es;              // [nsamples][R]
@@ -83,9 +83,10 @@ __device__ inline void eo_order_ties_impl(const double* v, uint16_t* hid, uint16
     }
 }
 
+template <typename IDX>
 struct ContChain {
     const ContParams* P;
-    uint32_t* sp; double* lf; double* undo; double* dEs; double* v; double* ps; uint16_t* hid; uint16_t* hpos;
+    uint32_t* sp; double* lf; double* undo; double* dEs; double* v; double* ps; IDX* hid; IDX* hpos;
     int mlast;
     double z;
     long long trefresh;
@@ -294,10 +295,10 @@ struct ContChain {
             if (c >= n) break;
             if (c + 1 < n && before(ht[c + 1], hid[c + 1], ht[c], hid[c])) c += 1;
             if (!before(ht[c], hid[c], t, id)) break;
-            ht[pos] = ht[c]; hid[pos] = hid[c]; hpos[hid[c]] = (uint16_t)pos;
+            ht[pos] = ht[c]; hid[pos] = hid[c]; hpos[hid[c]] = (IDX)pos;
             pos = c;
         }
-        ht[pos] = t; hid[pos] = (uint16_t)id; hpos[id] = (uint16_t)pos;
+        ht[pos] = t; hid[pos] = (IDX)id; hpos[id] = (IDX)pos;
     }
     __device__ void sift_up(int pos)
     {
@@ -307,10 +308,10 @@ struct ContChain {
         while (pos > 0) {
             const int par = (pos - 1) >> 1;
             if (!before(t, id, ht[par], hid[par])) break;
-            ht[pos] = ht[par]; hid[pos] = hid[par]; hpos[hid[par]] = (uint16_t)pos;
+            ht[pos] = ht[par]; hid[pos] = hid[par]; hpos[hid[par]] = (IDX)pos;
             pos = par;
         }
-        ht[pos] = t; hid[pos] = (uint16_t)id; hpos[id] = (uint16_t)pos;
+        ht[pos] = t; hid[pos] = (IDX)id; hpos[id] = (IDX)pos;
     }
     __device__ __forceinline__ void heap_update(int i, double t)
     {
@@ -324,7 +325,7 @@ struct ContChain {
     __device__ __forceinline__ void eo_swap(int a, int b)
     {
         const double x = v[a]; v[a] = v[b]; v[b] = x;
-        const uint16_t h = hid[a]; hid[a] = hid[b]; hid[b] = h;
+        const IDX h = hid[a]; hid[a] = hid[b]; hid[b] = h;
     }
     __device__ __forceinline__ bool eo_lt(int a, int b) const { return v[a] < v[b] || (v[a] == v[b] && hid[a] < hid[b]); }
     __device__ void eo_sift(int root, int end)
@@ -354,29 +355,34 @@ struct ContChain {
         if (p < n - 1 && v[p + 1] == old) nties -= 1;
         if (p > 0 && p < n - 1 && v[p - 1] == v[p + 1]) nties += 1;
         if (x > old) {
-            while (p < n - 1 && v[p + 1] < x) { v[p] = v[p + 1]; const uint16_t s = hid[p + 1]; hid[p] = s; hpos[s] = (uint16_t)p; p += 1; }
+            while (p < n - 1 && v[p + 1] < x) { v[p] = v[p + 1]; const IDX s = hid[p + 1]; hid[p] = s; hpos[s] = (IDX)p; p += 1; }
         } else {
-            while (p > 0 && v[p - 1] > x) { v[p] = v[p - 1]; const uint16_t s = hid[p - 1]; hid[p] = s; hpos[s] = (uint16_t)p; p -= 1; }
+            while (p > 0 && v[p - 1] > x) { v[p] = v[p - 1]; const IDX s = hid[p - 1]; hid[p] = s; hpos[s] = (IDX)p; p -= 1; }
         }
         if (p > 0 && p < n - 1 && v[p - 1] == v[p + 1]) nties -= 1;
         if (p > 0 && v[p - 1] == x) nties += 1;
         if (p < n - 1 && v[p + 1] == x) nties += 1;
-        v[p] = x; hid[p] = (uint16_t)j; hpos[j] = (uint16_t)p;
+        v[p] = x; hid[p] = (IDX)j; hpos[j] = (IDX)p;
         return nties;
     }
-    __device__ void eo_order_ties(uint64_t g) { eo_order_ties_impl(v, hid, hpos, reinterpret_cast<unsigned long long*>(ps), P->N, g, rep, P->k0, P->k1); }
+    __device__ void eo_order_ties(uint64_t g) 
+    {
+        // the tie keys address the site in 16 bits of the Philox tag: extremal_opt stays at N <= 65535 (refused on the host beyond)
+        if constexpr (sizeof(IDX) == 2) eo_order_ties_impl(v, hid, hpos, reinterpret_cast<unsigned long long*>(ps), P->N, g, rep, P->k0, P->k1);
+    }
 };
 
+template <typename IDX>
 __global__ __launch_bounds__(kRrrThreads) void cont_sparse_kernel(ContParams P)
 {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= P.R) return;
     const int N = P.N, K = P.K;
-    ContChain c;
+    ContChain<IDX> c;
     c.P = &P;
     c.sp = P.spins + (size_t)r * P.W; c.lf = P.lf + (size_t)r * N; c.undo = P.undo + (size_t)r * (K + 1);
     c.dEs = P.dEs + (size_t)r * N; c.v = P.v + (size_t)r * P.N2; c.ps = P.ps + (size_t)r * P.N2;
-    c.hid = P.hid + (size_t)r * N; c.hpos = P.hpos + (size_t)r * N;
+    c.hid = static_cast<IDX*>(P.hid) + (size_t)r * N; c.hpos = static_cast<IDX*>(P.hpos) + (size_t)r * N;
     c.mlast = -1; c.z = 0.0; c.trefresh = 0; c.nd = 0;
     c.rep = P.replica0 + (uint32_t)r;
     c.rloc = r;
@@ -435,7 +441,7 @@ __global__ __launch_bounds__(kRrrThreads) void cont_sparse_kernel(ContParams P)
     double t = 0.0;
 
     if (P.mode == 2) {
-        for (int i = 0; i < N; ++i) { c.dEs[i] = c.gen_wt(c.dE(i)); c.hid[i] = (uint16_t)i; c.hpos[i] = (uint16_t)i; }
+        for (int i = 0; i < N; ++i) { c.dEs[i] = c.gen_wt(c.dE(i)); c.hid[i] = (IDX)i; c.hpos[i] = (IDX)i; }
         for (int pos = N / 2 - 1; pos >= 0; --pos) c.sift_down(pos, N);
         const double st = P.stepf / (double)N, tmax = st * (double)P.iters;
         double nextstep = st;
@@ -463,10 +469,10 @@ __global__ __launch_bounds__(kRrrThreads) void cont_sparse_kernel(ContParams P)
     } else if (P.mode == 3) {
         // extremal_opt: RRRMC.jl:474-521; stats = (iterations, itmin, iterations), t_out = Emin
         uint32_t* cm = P.cmin + (size_t)r * P.W;
-        for (int i = 0; i < N; ++i) { c.v[i] = c.dE(i); c.hid[i] = (uint16_t)i; }
+        for (int i = 0; i < N; ++i) { c.v[i] = c.dE(i); c.hid[i] = (IDX)i; }
         c.eo_sort_all(N);
         int nties = 0;
-        for (int p = 0; p < N; ++p) { c.hpos[c.hid[p]] = (uint16_t)p; if (p > 0 && c.v[p - 1] == c.v[p]) nties += 1; }
+        for (int p = 0; p < N; ++p) { c.hpos[c.hid[p]] = (IDX)p; if (p > 0 && c.v[p - 1] == c.v[p]) nties += 1; }
         double Emin = E;
         long long itmin = 0;
         for (int w = 0; w < P.W; ++w) cm[w] = c.sp[w];
@@ -606,11 +612,11 @@ __global__ __launch_bounds__(64) void eo_cont_wave_kernel(ContParams P)
     double* v = reinterpret_cast<double*>(eo_lds);
     uint16_t* hid = reinterpret_cast<uint16_t*>(v + N);
     uint16_t* hpos = hid + N;
-    ContChain c;
+    ContChain<uint16_t> c;
     c.P = &P;
     c.sp = P.spins + (size_t)r * P.W; c.lf = P.lf + (size_t)r * N; c.undo = P.undo + (size_t)r * (K + 1);
     c.dEs = P.dEs + (size_t)r * N; c.v = P.v + (size_t)r * P.N2; c.ps = P.ps + (size_t)r * P.N2;
-    c.hid = P.hid + (size_t)r * N; c.hpos = P.hpos + (size_t)r * N;
+    c.hid = static_cast<uint16_t*>(P.hid) + (size_t)r * N; c.hpos = static_cast<uint16_t*>(P.hpos) + (size_t)r * N;
     c.mlast = -1; c.z = 0.0; c.trefresh = 0; c.nd = 0;
     c.rep = P.replica0 + (uint32_t)r; c.rloc = r;
     unsigned long long* key = reinterpret_cast<unsigned long long*>(c.ps);

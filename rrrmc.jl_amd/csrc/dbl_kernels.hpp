@@ -25,8 +25,8 @@ struct RrrDblParams {
     const double* rJ;        // [N][K]
     uint32_t* spins;         // [R][W]   BitVector word order
     uint8_t* cls;            // [R][N]
-    uint16_t* sv;            // [R][2L][N]
-    uint16_t* spos;          // [R][N]
+    void* sv;                // [R][2L][N]  IDX = uint16_t, or uint32_t when N > 65535
+    void* spos;              // [R][N]
     double* lf;              // [R][N]   residual local fields
     double* undo;            // [R][K+1] saved neighbour fields / own field of the last residual update
     double* E_cur;           // [R]
@@ -51,11 +51,11 @@ struct RrrDblParams {
 // SLM = compile-time bound on the number of levels (4 or 8).  As for SparseChain (rrr_kernels.hpp): the chain keeps COPIES of the few
 // parameters it needs (a pointer to the kernel's parameter struct forces the struct into scratch memory) and its per-class arrays
 // are indexed only through fully unrolled selects, so that everything stays in registers.
-template <int SLM>
+template <int SLM, typename IDX = uint16_t>
 struct DblChain {
     struct Cfg { int N, K, L, ea_form; const int32_t* A; const int8_t* dJ; const double* rJ; int dElist[SLM]; double ft[SLM]; };
     Cfg cfg;
-    uint32_t* sp; uint8_t* cls; uint16_t* sv; uint16_t* spos;
+    uint32_t* sp; uint8_t* cls; IDX* sv; IDX* spos;
     double* lf; double* undo;
     int t[2 * SLM];
     double T[2 * SLM], z;
@@ -125,12 +125,12 @@ struct DblChain {
     }
     __device__ __forceinline__ void set_move(int j, int k0, int k1)
     {
-        uint16_t* v0 = sv + (size_t)k0 * cfg.N;
-        uint16_t* v1 = sv + (size_t)k1 * cfg.N;
+        IDX* v0 = sv + (size_t)k0 * cfg.N;
+        IDX* v1 = sv + (size_t)k1 * cfg.N;
         const int p = spos[j], last = v0[tg(k0) - 1];
-        v0[p] = (uint16_t)last; spos[last] = (uint16_t)p; tadd(k0, -1);
+        v0[p] = (IDX)last; spos[last] = (IDX)p; tadd(k0, -1);
         const int t1 = tg(k1);
-        v1[t1] = (uint16_t)j; spos[j] = (uint16_t)t1; tadd(k1, 1);
+        v1[t1] = (IDX)j; spos[j] = (IDX)t1; tadd(k1, 1);
         cls[j] = (uint8_t)k1;
     }
     // update_cache_residual! (RRG.jl:430-466, EA.jl:456-496), called after the flip of `move`
@@ -204,20 +204,20 @@ __device__ __forceinline__ bool dbl_accept(double c, double x, uint64_t g, uint3
 // energy(X, C) = E0 + E1 (RRG.jl:326-360) — fills the residual fields — and, with `classes`, gen_ΔEcache(X0, C, beta)'s class
 // sets in site order (DeltaE.jl:74-103)
 // the chain's view of replica r's arrays (no computation)
-template <int SLM>
-__device__ __forceinline__ void dbl_bind_chain(DblChain<SLM>& c, const RrrDblParams& P, int r)
+template <int SLM, typename IDX>
+__device__ __forceinline__ void dbl_bind_chain(DblChain<SLM, IDX>& c, const RrrDblParams& P, int r)
 {
     const int N = P.N, K2 = 2 * P.L, K = P.K;
     c.cfg.N = P.N; c.cfg.K = P.K; c.cfg.L = P.L; c.cfg.ea_form = P.ea_form; c.cfg.A = P.A; c.cfg.dJ = P.dJ; c.cfg.rJ = P.rJ;
 #pragma unroll
     for (int k = 0; k < SLM; ++k) { c.cfg.dElist[k] = P.dElist[k]; c.cfg.ft[k] = P.ft[k]; }
-    c.sp = P.spins + (size_t)r * P.W; c.cls = P.cls + (size_t)r * N; c.sv = P.sv + (size_t)r * K2 * N; c.spos = P.spos + (size_t)r * N;
+    c.sp = P.spins + (size_t)r * P.W; c.cls = P.cls + (size_t)r * N; c.sv = static_cast<IDX*>(P.sv) + (size_t)r * K2 * N; c.spos = static_cast<IDX*>(P.spos) + (size_t)r * N;
     c.lf = P.lf + (size_t)r * N; c.undo = P.undo + (size_t)r * (K + 1);
     c.mlast = -1;
 }
 
-template <int SLM>
-__device__ __forceinline__ double dbl_init_chain(DblChain<SLM>& c, const RrrDblParams& P, int r, bool classes)
+template <int SLM, typename IDX>
+__device__ __forceinline__ double dbl_init_chain(DblChain<SLM, IDX>& c, const RrrDblParams& P, int r, bool classes)
 {
     const int N = P.N, K = P.K;
     dbl_bind_chain(c, P, r);
@@ -238,8 +238,8 @@ __device__ __forceinline__ double dbl_init_chain(DblChain<SLM>& c, const RrrDblP
         if (classes) {
             const int k = c.klass(i), tk = c.tg(k);
             c.cls[i] = (uint8_t)k;
-            c.sv[(size_t)k * N + tk] = (uint16_t)i;
-            c.spos[i] = (uint16_t)tk;
+            c.sv[(size_t)k * N + tk] = (IDX)i;
+            c.spos[i] = (IDX)tk;
             c.tadd(k, 1);
         }
     }
@@ -279,13 +279,13 @@ __global__ __launch_bounds__(kRrrThreads) void dbl_standard_kernel(RrrDblParams 
     P.stats[(size_t)r * 2] = accepted; P.stats[(size_t)r * 2 + 1] = 0;
 }
 
-template <int SLM>
+template <int SLM, typename IDX>
 __global__ __launch_bounds__(kRrrThreads) void rrr_dbl_kernel(RrrDblParams P)
 {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= P.R) return;
     const int N = P.N, L = P.L, K2 = 2 * P.L, K = P.K;
-    DblChain<SLM> c;
+    DblChain<SLM, IDX> c;
     double E = dbl_init_chain(c, P, r, !P.energy_only);
     if (P.energy_only) { P.E_cur[r] = E; return; }
     c.z = 0.0;

@@ -7,7 +7,7 @@ int32_t dbl_ctx_create(rrrmc_ctx** out, int64_t N, int64_t K, int64_t R, int32_t
 {
     if (N < 1 || K < 1 || R < 1) return fail(nullptr, RRRMC_ERR_INVALID_ARG, "N, K, R must be >= 1 (given N=%lld K=%lld R=%lld)", (long long)N, (long long)K, (long long)R);
     if (K > kDKmax) return fail(nullptr, RRRMC_ERR_UNSUPPORTED, "K=%lld: the DoubleGraph kernel covers K <= %d", (long long)K, kDKmax);
-    if (N > 65535) return fail(nullptr, RRRMC_ERR_UNSUPPORTED, "N=%lld: the rrrMC kernels index spins with 16 bits", (long long)N);
+    if (N > (int64_t)1 << 28) return fail(nullptr, RRRMC_ERR_UNSUPPORTED, "N=%lld is beyond the DoubleGraph kernels (N <= 2^28)", (long long)N);
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
         return fail(nullptr, RRRMC_ERR_HIP, "no HIP device is visible: this library has no CPU path");
@@ -35,8 +35,9 @@ int32_t dbl_ctx_create(rrrmc_ctx** out, int64_t N, int64_t K, int64_t R, int32_t
     DB_TRY(hipMalloc(&ctx->db_rJ, sizeof(double) * N * K));
     DB_TRY(hipMalloc(&ctx->q_spins, sizeof(uint32_t) * R * ctx->qW));
     DB_TRY(hipMalloc(&ctx->db_cls, (size_t)R * N));
-    DB_TRY(hipMalloc(&ctx->db_sv, sizeof(uint16_t) * (size_t)R * 2 * kDLmax * N));
-    DB_TRY(hipMalloc(&ctx->db_spos, sizeof(uint16_t) * (size_t)R * N));
+    const size_t idx_bytes = N > 65535 ? sizeof(uint32_t) : sizeof(uint16_t);          // set members / positions: 32-bit beyond 65 535 spins
+    DB_TRY(hipMalloc(reinterpret_cast<void**>(&ctx->db_sv), idx_bytes * (size_t)R * 2 * kDLmax * N));
+    DB_TRY(hipMalloc(reinterpret_cast<void**>(&ctx->db_spos), idx_bytes * (size_t)R * N));
     DB_TRY(hipMalloc(&ctx->db_lf, sizeof(double) * (size_t)R * N));
     DB_TRY(hipMalloc(&ctx->db_undo, sizeof(double) * (size_t)R * (K + 1)));
     DB_TRY(hipMalloc(&ctx->q_stats, sizeof(int64_t) * R * 3));          // rrrMC / standardMC use a stride of 2, bklMC / wtmMC of 3
@@ -66,7 +67,7 @@ int32_t dbl_run_energy(rrrmc_ctx* ctx)
 {
     RrrDblParams P = dbl_params(ctx, 0.0);
     P.energy_only = 1;
-    hipLaunchKernelGGL(rrr_dbl_kernel<4>, dim3(rrr_blocks(ctx->R)), dim3(rrr_tpb(ctx->R)), 0, ctx->stream, P);          // energy only: the level bound is irrelevant
+    hipLaunchKernelGGL((rrr_dbl_kernel<4, uint16_t>), dim3(rrr_blocks(ctx->R)), dim3(rrr_tpb(ctx->R)), 0, ctx->stream, P);          // energy only: the level bound and the index width are irrelevant
     HIP_TRY(ctx, hipGetLastError());
     return RRRMC_OK;
 }
@@ -103,8 +104,12 @@ int32_t dbl_mc_async(rrrmc_ctx* ctx, bool standard, double beta, int64_t iters, 
     HIP_TRY(ctx, hipEventRecord(ctx->ev_begin, st));
     HIP_TRY(ctx, hipEventRecord(ctx->ev_sweep[0], st));
     if (standard) hipLaunchKernelGGL(dbl_standard_kernel, dim3(rrr_blocks(ctx->R)), dim3(rrr_tpb(ctx->R)), 0, st, P);
-    else if (ctx->db_L <= 4) hipLaunchKernelGGL(rrr_dbl_kernel<4>, dim3(rrr_blocks(ctx->R)), dim3(rrr_tpb(ctx->R)), 0, st, P);   // per-class arrays sized at compile time: registers
-    else hipLaunchKernelGGL(rrr_dbl_kernel<8>, dim3(rrr_blocks(ctx->R)), dim3(rrr_tpb(ctx->R)), 0, st, P);
+    else if (ctx->N > 65535) {
+        if (ctx->db_L <= 4) hipLaunchKernelGGL((rrr_dbl_kernel<4, uint32_t>), dim3(rrr_blocks(ctx->R)), dim3(rrr_tpb(ctx->R)), 0, st, P);
+        else hipLaunchKernelGGL((rrr_dbl_kernel<8, uint32_t>), dim3(rrr_blocks(ctx->R)), dim3(rrr_tpb(ctx->R)), 0, st, P);
+    }
+    else if (ctx->db_L <= 4) hipLaunchKernelGGL((rrr_dbl_kernel<4, uint16_t>), dim3(rrr_blocks(ctx->R)), dim3(rrr_tpb(ctx->R)), 0, st, P);   // per-class arrays sized at compile time: registers
+    else hipLaunchKernelGGL((rrr_dbl_kernel<8, uint16_t>), dim3(rrr_blocks(ctx->R)), dim3(rrr_tpb(ctx->R)), 0, st, P);
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipEventRecord(ctx->ev_sweep[1], st));
     HIP_TRY(ctx, hipEventRecord(ctx->ev_end, st));

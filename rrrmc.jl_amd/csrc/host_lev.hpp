@@ -7,8 +7,8 @@
 int32_t lev_ctx_create(rrrmc_ctx** out, int64_t N, int64_t K, int64_t R, int32_t device, uint32_t replica0)
 {
     if (N < 1 || K < 1 || R < 1) return fail(nullptr, RRRMC_ERR_INVALID_ARG, "N, K, R must be >= 1 (given N=%lld K=%lld R=%lld)", (long long)N, (long long)K, (long long)R);
-    if (K > 8) return fail(nullptr, RRRMC_ERR_UNSUPPORTED, "K=%lld: the general-level kernels cover K <= 8", (long long)K);
-    if (N > 65535) return fail(nullptr, RRRMC_ERR_UNSUPPORTED, "N=%lld: the thread-per-replica kernels index spins with 16 bits", (long long)N);
+    if (K > 16) return fail(nullptr, RRRMC_ERR_UNSUPPORTED, "K=%lld: the general-level kernels cover K <= 16", (long long)K);
+    if (N > (int64_t)1 << 28) return fail(nullptr, RRRMC_ERR_UNSUPPORTED, "N=%lld is beyond the thread-per-replica kernels (N <= 2^28)", (long long)N);
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
         return fail(nullptr, RRRMC_ERR_HIP, "no HIP device is visible: this library has no CPU path");

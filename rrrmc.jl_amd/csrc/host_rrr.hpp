@@ -254,14 +254,19 @@ int32_t sparse_rrr_bkl_async(rrrmc_ctx* ctx, int mode, double beta, int64_t iter
         // few replicas run one per workgroup anyway: stage the replica's hot state and the graph in LDS if they fit
         const size_t lds = rrr_sparse_lds_bytes(N, W, K);
         const char* no_lds = std::getenv("RRRMC_RRR_NO_LDS");            // tests / timing experiments
-        const bool use_lds = !wide_idx && rrr_tpb(R) == 1 && lds <= (size_t)kLdsLimit && !(no_lds && no_lds[0] == '1');
+        const bool big_k = K > 8;                 // the staged path keeps its change list in registers: 8 slots, or 16 for K > 8
+        const bool use_lds = !wide_idx && !big_k && rrr_tpb(R) == 1 && lds <= (size_t)kLdsLimit && !(no_lds && no_lds[0] == '1');
         // the per-class arrays are sized at compile time (2, 4 or 8 levels) so that they stay in registers
         typedef void (*rs_fn)(RrrSparseParams);
         const int slm = L <= 2 ? 0 : (L <= 4 ? 1 : 2);
         static const rs_fn lds_fns[3] = {rrr_sparse_kernel<true, 2>, rrr_sparse_kernel<true, 4>, rrr_sparse_kernel<true, 8>};
         static const rs_fn glb_fns[3] = {rrr_sparse_kernel<false, 2>, rrr_sparse_kernel<false, 4>, rrr_sparse_kernel<false, 8>};
         static const rs_fn wide_fns[3] = {rrr_sparse_kernel<false, 2, uint32_t>, rrr_sparse_kernel<false, 4, uint32_t>, rrr_sparse_kernel<false, 8, uint32_t>};
-        if (wide_idx) {
+        if (big_k) {
+            if (K > 16) return fail(ctx, RRRMC_ERR_UNSUPPORTED, "K=%lld: the rrrMC kernel covers K <= 16", (long long)K);
+            if (wide_idx) hipLaunchKernelGGL((rrr_sparse_kernel<false, 8, uint32_t, 16>), dim3(rrr_blocks(R)), dim3(rrr_tpb(R)), 0, st, P);
+            else hipLaunchKernelGGL((rrr_sparse_kernel<false, 8, uint16_t, 16>), dim3(rrr_blocks(R)), dim3(rrr_tpb(R)), 0, st, P);
+        } else if (wide_idx) {
             hipLaunchKernelGGL(wide_fns[slm], dim3(rrr_blocks(R)), dim3(rrr_tpb(R)), 0, st, P);
         } else if (use_lds) {
             HIP_TRY(ctx, raise_lds_attr(reinterpret_cast<const void*>(lds_fns[slm]), lds));
@@ -290,7 +295,6 @@ int32_t sparse_wtm_async(rrrmc_ctx* ctx, double beta, int64_t samples, double st
     if (samples < 0) return fail(ctx, RRRMC_ERR_INVALID_ARG, "samples must be >= 0, given %lld", (long long)samples);
     if (!(step > 0.0) || !std::isfinite(step)) return fail(ctx, RRRMC_ERR_INVALID_ARG, "step must be positive and finite, given %g", step);
     if (!std::isfinite(beta)) return fail(ctx, RRRMC_ERR_INVALID_ARG, "beta must be finite, given: %g", beta);
-    if (ctx->N > 65535) return fail(ctx, RRRMC_ERR_UNSUPPORTED, "N=%lld: the wtmMC kernel indexes spins with 16 bits", (long long)ctx->N);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     ctx->results_valid = false; ctx->last_call_wtm = false; ctx->last_call_eo = false;
     ctx->timing_valid = false;
@@ -301,8 +305,9 @@ int32_t sparse_wtm_async(rrrmc_ctx* ctx, double beta, int64_t samples, double st
     const int64_t W = rv.W;
     if (!ctx->wt_t) {
         HIP_TRY(ctx, hipMalloc(&ctx->wt_t, sizeof(double) * R * N));
-        HIP_TRY(ctx, hipMalloc(&ctx->wt_id, sizeof(uint16_t) * R * N));
-        HIP_TRY(ctx, hipMalloc(&ctx->wt_pos, sizeof(uint16_t) * R * N));
+        const size_t idx_bytes = N > 65535 ? sizeof(uint32_t) : sizeof(uint16_t);
+        HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->wt_id), idx_bytes * R * N));
+        HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->wt_pos), idx_bytes * R * N));
         HIP_TRY(ctx, hipMalloc(&ctx->wt_time, sizeof(double) * R));
     }
     const size_t es_need = (size_t)(samples > 0 ? samples : 1) * ctx->Rpad;
@@ -334,7 +339,8 @@ int32_t sparse_wtm_async(rrrmc_ctx* ctx, double beta, int64_t samples, double st
     HIP_TRY(ctx, hipEventRecord(ctx->ev_begin, st));
     if ((rc = rp_in(ctx, rv, st))) return rc;
     HIP_TRY(ctx, hipEventRecord(ctx->ev_sweep[0], st));
-    hipLaunchKernelGGL(wtm_sparse_kernel, dim3(rrr_blocks(R)), dim3(rrr_tpb(R)), 0, st, P);
+    if (N > 65535) hipLaunchKernelGGL(wtm_sparse_kernel<uint32_t>, dim3(rrr_blocks(R)), dim3(rrr_tpb(R)), 0, st, P);
+    else hipLaunchKernelGGL(wtm_sparse_kernel<uint16_t>, dim3(rrr_blocks(R)), dim3(rrr_tpb(R)), 0, st, P);
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipEventRecord(ctx->ev_sweep[1], st));
     if ((rc = rp_out(ctx, rv, st))) return rc;
@@ -356,7 +362,6 @@ int32_t sparse_eo_async(rrrmc_ctx* ctx, const double* ftau, int64_t iters, int64
     if (iters < 0) return fail(ctx, RRRMC_ERR_INVALID_ARG, "iters must be >= 0, given %lld", (long long)iters);
     if (step < 1) return fail(ctx, RRRMC_ERR_INVALID_ARG, "step must be >= 1, given %lld", (long long)step);
     if (!ftau) return fail(ctx, RRRMC_ERR_INVALID_ARG, "ftau is NULL");
-    if (ctx->N > 65535) return fail(ctx, RRRMC_ERR_UNSUPPORTED, "N=%lld: the extremal_opt kernel indexes spins with 16 bits", (long long)ctx->N);
     const int64_t N = ctx->N, K = ctx->K, R = ctx->R;
     for (int64_t i = 0; i < N; ++i)
         if (!(ftau[i] > 0.0) || !std::isfinite(ftau[i]) || (i && ftau[i] < ftau[i - 1]))
@@ -372,8 +377,9 @@ int32_t sparse_eo_async(rrrmc_ctx* ctx, const double* ftau, int64_t iters, int64
     ctx->eo_W = W;
     if (!ctx->rp_cls) {
         HIP_TRY(ctx, hipMalloc(&ctx->rp_cls, (size_t)R * N));
-        HIP_TRY(ctx, hipMalloc(&ctx->rp_sv, sizeof(uint16_t) * R * 2 * L * N));
-        HIP_TRY(ctx, hipMalloc(&ctx->rp_spos, sizeof(uint16_t) * R * N));
+        const size_t idx_bytes = N > 65535 ? sizeof(uint32_t) : sizeof(uint16_t);
+        HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->rp_sv), idx_bytes * R * 2 * L * N));
+        HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->rp_spos), idx_bytes * R * N));
         if (!ctx->q_stats) HIP_TRY(ctx, hipMalloc(&ctx->q_stats, sizeof(int64_t) * R * 3));
     }
     if (!ctx->eo_cmin) {
@@ -408,7 +414,8 @@ int32_t sparse_eo_async(rrrmc_ctx* ctx, const double* ftau, int64_t iters, int64
     HIP_TRY(ctx, hipEventRecord(ctx->ev_begin, st));
     if ((rc = rp_in(ctx, rv, st))) return rc;
     HIP_TRY(ctx, hipEventRecord(ctx->ev_sweep[0], st));
-    hipLaunchKernelGGL(eo_sparse_kernel, dim3(rrr_blocks(R)), dim3(rrr_tpb(R)), 0, st, P);
+    if (N > 65535) hipLaunchKernelGGL(eo_sparse_kernel<uint32_t>, dim3(rrr_blocks(R)), dim3(rrr_tpb(R)), 0, st, P);
+    else hipLaunchKernelGGL(eo_sparse_kernel<uint16_t>, dim3(rrr_blocks(R)), dim3(rrr_tpb(R)), 0, st, P);
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipEventRecord(ctx->ev_sweep[1], st));
     if ((rc = rp_out(ctx, rv, st))) return rc;

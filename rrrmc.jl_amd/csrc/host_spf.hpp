@@ -138,7 +138,9 @@ int32_t spf_cont_async(rrrmc_ctx* ctx, int mode, double beta, int64_t iters, int
     if (mode != 2 && step < 1) return fail(ctx, RRRMC_ERR_INVALID_ARG, "step must be >= 1, given %lld", (long long)step);
     if (mode == 2 && (!(stepf > 0.0) || !std::isfinite(stepf))) return fail(ctx, RRRMC_ERR_INVALID_ARG, "step must be positive and finite, given %g", stepf);
     if (!std::isfinite(beta)) return fail(ctx, RRRMC_ERR_INVALID_ARG, "beta must be finite, given: %g", beta);
-    if (ctx->N > 65535) return fail(ctx, RRRMC_ERR_UNSUPPORTED, "N=%lld: the thread-per-replica samplers index spins with 16 bits", (long long)ctx->N);
+    // extremal_opt addresses its tie-break keys with 16 site bits of the Philox tag (and ranks all N spins per move); the others are 32-bit beyond
+    if (mode == 3 && ctx->N > 65535) return fail(ctx, RRRMC_ERR_UNSUPPORTED, "N=%lld: extremal_opt on a continuous-energy graph addresses spins with 16 bits", (long long)ctx->N);
+    if (ctx->N > (int64_t)1 << 28) return fail(ctx, RRRMC_ERR_UNSUPPORTED, "N=%lld is beyond the thread-per-replica samplers (N <= 2^28)", (long long)ctx->N);
     if (mode == 3) {
         if (!ftau) return fail(ctx, RRRMC_ERR_INVALID_ARG, "ftau is NULL");
         for (int64_t i = 0; i < ctx->N; ++i)
@@ -159,7 +161,7 @@ int32_t spf_cont_async(rrrmc_ctx* ctx, int mode, double beta, int64_t iters, int
     if (!ctx->cs_buf) {
         if (!dblm) HIP_TRY(ctx, hipMalloc(&ctx->cs_spins, sizeof(uint32_t) * R * W));
         HIP_TRY(ctx, hipMalloc(&ctx->cs_buf, sizeof(double) * (size_t)R * (size_t)(2 * N + 2 * N2 + K + 1)));
-        HIP_TRY(ctx, hipMalloc(&ctx->cs_u16, sizeof(uint16_t) * (size_t)R * 2 * N));
+        HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->cs_u16), (N > 65535 ? sizeof(uint32_t) : sizeof(uint16_t)) * (size_t)R * 2 * N));
         HIP_TRY(ctx, hipMalloc(&ctx->rs_status, sizeof(int32_t) * R));
         if (!ctx->q_stats) HIP_TRY(ctx, hipMalloc(&ctx->q_stats, sizeof(int64_t) * R * 3));
         if (!ctx->wt_time) HIP_TRY(ctx, hipMalloc(&ctx->wt_time, sizeof(double) * R));
@@ -202,7 +204,8 @@ int32_t spf_cont_async(rrrmc_ctx* ctx, int mode, double beta, int64_t iters, int
     P.v = b; b += (size_t)R * N2;
     P.ps = b; b += (size_t)R * N2;
     P.undo = b;
-    P.hid = ctx->cs_u16; P.hpos = ctx->cs_u16 + (size_t)R * N;
+    P.hid = ctx->cs_u16;
+    P.hpos = N > 65535 ? static_cast<void*>(reinterpret_cast<uint32_t*>(ctx->cs_u16) + (size_t)R * N) : static_cast<void*>(ctx->cs_u16 + (size_t)R * N);
     P.E_cur = ctx->sk_E; P.stats = ctx->q_stats; P.Es = ctx->sk_Es; P.t_out = ctx->wt_time; P.status = ctx->rs_status;
     P.beta = beta; P.staged_thr = staged_thr; P.lambda = staged_thr_fact / (double)N; P.stepf = stepf;
     P.g0 = ctx->it_done; P.iters = iters; P.step = step;
@@ -224,7 +227,8 @@ int32_t spf_cont_async(rrrmc_ctx* ctx, int mode, double beta, int64_t iters, int
         HIP_TRY(ctx, raise_lds_attr(reinterpret_cast<const void*>(eo_cont_wave_kernel), lds));
         hipLaunchKernelGGL(eo_cont_wave_kernel, dim3((unsigned)R), dim3(64), lds, st, P);
     } else {
-        hipLaunchKernelGGL(cont_sparse_kernel, dim3(rrr_blocks(R)), dim3(rrr_tpb(R)), 0, st, P);
+        if (N > 65535) hipLaunchKernelGGL(cont_sparse_kernel<uint32_t>, dim3(rrr_blocks(R)), dim3(rrr_tpb(R)), 0, st, P);
+        else hipLaunchKernelGGL(cont_sparse_kernel<uint16_t>, dim3(rrr_blocks(R)), dim3(rrr_tpb(R)), 0, st, P);
     }
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipEventRecord(ctx->ev_sweep[1], st));

@@ -1355,7 +1355,8 @@ inline size_t rrr_sparse_lds_bytes(int64_t N, int64_t W, int64_t K)
 // rrr_quant_kernel: the replica's spins, class bytes and set positions and the graph (16-bit neighbour ids, couplings) staged in LDS
 // by all 64 lanes, the two Philox blocks of an rrrMC iteration computed 64 iterations at a time by the whole wavefront; lane 0
 // runs the chain.  The reference's own experiment (scripts/scripts.jl:test_RRG: N = 10^4, K = 3) takes 121 KB.
-template <bool LDS, int SLM, typename IDX = uint16_t>
+// NB = compile-time bound on K for the staged path's register-resident change list (8; 16 for the K > 8 graphs: GraphEA with D >= 5)
+template <bool LDS, int SLM, typename IDX = uint16_t, int NB = 8>
 __global__ __launch_bounds__(kRrrThreads) void rrr_sparse_kernel(RrrSparseParams P)
 {
     extern __shared__ uint32_t rs_lds[];
@@ -1451,7 +1452,7 @@ __global__ __launch_bounds__(kRrrThreads) void rrr_sparse_kernel(RrrSparseParams
                 staged_its += 1;
                 // staged changes: slot q = neighbour q (slot kNbMax = the moved spin), live[q] says whether it changes class; fixed slots
                 // and fully unrolled loops keep these arrays in registers
-                constexpr int kNbMax = 8;
+                constexpr int kNbMax = NB;
                 int sj[kNbMax + 1], s0[kNbMax + 1], s1[kNbMax + 1];
                 bool live[kNbMax + 1];
                 c.sflip(move);
@@ -1551,8 +1552,8 @@ struct WtmParams {
     const int8_t* J;         // [N][K]
     uint32_t* spins;         // [R][W]   replica-contiguous words
     double* ht;              // [R][N]   heap keys (next-flip times) by heap position
-    uint16_t* hid;           // [R][N]   site at heap position
-    uint16_t* hpos;          // [R][N]   heap position of site
+    void* hid;               // [R][N]   site at heap position      (uint16_t, or uint32_t when N > 65535)
+    void* hpos;              // [R][N]   heap position of site
     int32_t* E_cur;          // [Rpad]
     int64_t* acc_cur;        // [Rpad]   num_moves
     double* t_out;           // [R]      final global time
@@ -1565,9 +1566,10 @@ struct WtmParams {
     int N, K, W, R, Rpad;
 };
 
+template <typename IDX>
 struct WtmChain {
     const WtmParams* P;
-    uint32_t* sp; double* ht; uint16_t* hid; uint16_t* hpos;
+    uint32_t* sp; double* ht; IDX* hid; IDX* hpos;
     uint32_t rep;
     uint64_t nd;
     __device__ __forceinline__ int sbit(int x) const { return (int)((sp[x >> 5] >> (x & 31)) & 1u); }
@@ -1601,10 +1603,10 @@ struct WtmChain {
             if (c >= n) break;
             if (c + 1 < n && before(ht[c + 1], hid[c + 1], ht[c], hid[c])) c += 1;
             if (!before(ht[c], hid[c], t, id)) break;
-            ht[pos] = ht[c]; hid[pos] = hid[c]; hpos[hid[c]] = (uint16_t)pos;
+            ht[pos] = ht[c]; hid[pos] = hid[c]; hpos[hid[c]] = (IDX)pos;
             pos = c;
         }
-        ht[pos] = t; hid[pos] = (uint16_t)id; hpos[id] = (uint16_t)pos;
+        ht[pos] = t; hid[pos] = (IDX)id; hpos[id] = (IDX)pos;
     }
     __device__ void sift_up(int pos)
     {
@@ -1613,10 +1615,10 @@ struct WtmChain {
         while (pos > 0) {
             const int par = (pos - 1) >> 1;
             if (!before(t, id, ht[par], hid[par])) break;
-            ht[pos] = ht[par]; hid[pos] = hid[par]; hpos[hid[par]] = (uint16_t)pos;
+            ht[pos] = ht[par]; hid[pos] = hid[par]; hpos[hid[par]] = (IDX)pos;
             pos = par;
         }
-        ht[pos] = t; hid[pos] = (uint16_t)id; hpos[id] = (uint16_t)pos;
+        ht[pos] = t; hid[pos] = (IDX)id; hpos[id] = (IDX)pos;
     }
     __device__ __forceinline__ void update(int i, double t)     // update!(theap, i, t)
     {
@@ -1627,14 +1629,15 @@ struct WtmChain {
     }
 };
 
+template <typename IDX>
 __global__ __launch_bounds__(kRrrThreads) void wtm_sparse_kernel(WtmParams P)
 {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= P.R) return;
     const int N = P.N;
-    WtmChain c;
+    WtmChain<IDX> c;
     c.P = &P;
-    c.sp = P.spins + (size_t)r * P.W; c.ht = P.ht + (size_t)r * N; c.hid = P.hid + (size_t)r * N; c.hpos = P.hpos + (size_t)r * N;
+    c.sp = P.spins + (size_t)r * P.W; c.ht = P.ht + (size_t)r * N; c.hid = static_cast<IDX*>(P.hid) + (size_t)r * N; c.hpos = static_cast<IDX*>(P.hpos) + (size_t)r * N;
     c.rep = P.replica0 + (uint32_t)r;
     c.nd = 0;
     // E = energy(X, C); theap = THeap(X, C, beta): one waiting time per spin, in site order (WaitingTimes.jl:26-36)
@@ -1643,8 +1646,8 @@ __global__ __launch_bounds__(kRrrThreads) void wtm_sparse_kernel(WtmParams P)
         const int d = c.dE(i);
         n -= d / 2;
         c.ht[i] = c.gen_wt(d);
-        c.hid[i] = (uint16_t)i;
-        c.hpos[i] = (uint16_t)i;
+        c.hid[i] = (IDX)i;
+        c.hpos[i] = (IDX)i;
     }
     for (int pos = N / 2 - 1; pos >= 0; --pos) c.sift_down(pos, N);
     long long E = n / 2;
@@ -1695,8 +1698,8 @@ struct EoParams {
     uint32_t* spins;         // [R][W]
     uint32_t* cmin;          // [R][W] configuration of minimum energy
     uint8_t* cls;            // [R][N]
-    uint16_t* sv;            // [R][K2][N]
-    uint16_t* spos;          // [R][N]
+    void* sv;                // [R][K2][N]  (uint16_t, or uint32_t when N > 65535)
+    void* spos;              // [R][N]
     int32_t* E_cur;          // [Rpad]
     int64_t* stats;          // [R][3]: Emin, itmin, -
     int32_t* Es;             // [nsamples][Rpad]
@@ -1707,6 +1710,7 @@ struct EoParams {
     int N, K, L, has_zero, W, R, Rpad;
 };
 
+template <typename IDX>
 __global__ __launch_bounds__(kRrrThreads) void eo_sparse_kernel(EoParams P)
 {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1715,8 +1719,8 @@ __global__ __launch_bounds__(kRrrThreads) void eo_sparse_kernel(EoParams P)
     uint32_t* sp = P.spins + (size_t)r * P.W;
     uint32_t* cm = P.cmin + (size_t)r * P.W;
     uint8_t* cls = P.cls + (size_t)r * N;
-    uint16_t* sv = P.sv + (size_t)r * K2 * N;
-    uint16_t* spos = P.spos + (size_t)r * N;
+    IDX* sv = static_cast<IDX*>(P.sv) + (size_t)r * K2 * N;
+    IDX* spos = static_cast<IDX*>(P.spos) + (size_t)r * N;
     int t[2 * kSLmax];
     auto sbit = [&](int x) { return (int)((sp[x >> 5] >> (x & 31)) & 1u); };
     auto dE_of = [&](int i) {
@@ -1740,8 +1744,8 @@ __global__ __launch_bounds__(kRrrThreads) void eo_sparse_kernel(EoParams P)
         n -= d / 2;
         const int k = klass(d);
         cls[i] = (uint8_t)k;
-        sv[(size_t)k * N + t[k]] = (uint16_t)i;
-        spos[i] = (uint16_t)t[k];
+        sv[(size_t)k * N + t[k]] = (IDX)i;
+        spos[i] = (IDX)t[k];
         t[k] += 1;
     }
     long long E = n / 2, Emin = E, itmin = 0, ns = 0;
@@ -1773,11 +1777,11 @@ __global__ __launch_bounds__(kRrrThreads) void eo_sparse_kernel(EoParams P)
             const int j = q < K ? Ax[q] : move;
             const int k0 = cls[j], k1 = klass(dE_of(j));
             if (k0 == k1) continue;
-            uint16_t* v0 = sv + (size_t)k0 * N;
-            uint16_t* v1 = sv + (size_t)k1 * N;
+            IDX* v0 = sv + (size_t)k0 * N;
+            IDX* v1 = sv + (size_t)k1 * N;
             const int p = spos[j], last = v0[t[k0] - 1];
-            v0[p] = (uint16_t)last; spos[last] = (uint16_t)p; t[k0] -= 1;
-            v1[t[k1]] = (uint16_t)j; spos[j] = (uint16_t)t[k1]; t[k1] += 1;
+            v0[p] = (IDX)last; spos[last] = (IDX)p; t[k0] -= 1;
+            v1[t[k1]] = (IDX)j; spos[j] = (IDX)t[k1]; t[k1] += 1;
             cls[j] = (uint8_t)k1;
         }
         E += dE;

@@ -139,7 +139,7 @@ class GraphRRG(_SparsePM1Graph):
     """
 
     def __new__(cls, N=None, K=None, LEV=(-1, 1), seed=DEFAULT_SEED):
-        if cls is GraphRRG and not _is_pm1(LEV):
+        if cls is GraphRRG and (not _is_pm1(LEV) or (K is not None and int(K) > PM1_MAX_K)):
             return object.__new__(GraphRRGLevels)        # GraphRRG{ET,LEV,K} with general levels: its own device context
         return object.__new__(cls)
 
@@ -153,13 +153,18 @@ class GraphRRG(_SparsePM1Graph):
     @classmethod
     def from_AJ(cls, A, J, LEV=(-1, 1)):
         """``GraphRRG{ET,LEV,K}(A, J)`` (RRG.jl:122); J in level units when LEV is not (-1, 1)."""
-        if not _is_pm1(LEV):
+        if not _is_pm1(LEV) or np.shape(A)[1] > PM1_MAX_K:
             self = object.__new__(GraphRRGLevels)
             self._init_levels(A, J, LEV, 0)
             return self
         self = object.__new__(cls)
         _SparsePM1Graph.__init__(self, A, J)
         return self
+
+
+# the bit-sliced +-J kernels count unsatisfied bonds in 3 bit planes (K <= 7); beyond that a +-J graph is a general-level graph with
+# LEV = (-1, 1): same couplings (same COUPLING draws), same chains, integer energies, one thread per replica
+PM1_MAX_K = 7
 
 
 def _is_pm1(LEV):
@@ -170,7 +175,7 @@ def _is_pm1(LEV):
 class GraphRRGLevels(_SparseLevelsGraph, GraphRRG):
     """``GraphRRG(N, K, LEV)`` with LEV other than (-1, 1): Int, Float64 (-> DFloat64) or Fraction levels (test/runtests.jl:37-40)."""
 
-    def __init__(self, N, K, LEV, seed=DEFAULT_SEED):
+    def __init__(self, N, K, LEV=(-1, 1), seed=DEFAULT_SEED):
         A = np.zeros((int(N), int(K)), np.int32)
         check(lib().rrrmc_gen_rrg(N, K, seed, A))
         self._seed = seed
@@ -181,7 +186,7 @@ class GraphEA(_SparsePM1Graph):
     """``GraphEA(L, D)`` — Edwards-Anderson lattice, +-1 couplings (src/graphs/EA.jl:171-193)."""
 
     def __new__(cls, L=None, D=None, LEV=(-1, 1), seed=DEFAULT_SEED):
-        if cls is GraphEA and not _is_pm1(LEV):
+        if cls is GraphEA and (not _is_pm1(LEV) or (D is not None and 2 * int(D) > PM1_MAX_K)):
             return object.__new__(GraphEALevels)
         return object.__new__(cls)
 
@@ -196,7 +201,7 @@ class GraphEA(_SparsePM1Graph):
 
     @classmethod
     def from_AJ(cls, A, J, LEV=(-1, 1)):
-        if not _is_pm1(LEV):
+        if not _is_pm1(LEV) or np.shape(A)[1] > PM1_MAX_K:
             self = object.__new__(GraphEALevels)
             self._init_levels(A, J, LEV, 1)
             return self
@@ -208,7 +213,7 @@ class GraphEA(_SparsePM1Graph):
 class GraphEALevels(_SparseLevelsGraph, GraphEA):
     """``GraphEA(L, D, LEV)`` with LEV other than (-1, 1) (test/runtests.jl:47-50, 57-60)."""
 
-    def __init__(self, L, D, LEV, seed=DEFAULT_SEED):
+    def __init__(self, L, D, LEV=(-1, 1), seed=DEFAULT_SEED):
         N = int(L) ** int(D)
         A = np.zeros((N, 2 * int(D)), np.int32)
         check(lib().rrrmc_gen_ea(L, D, A))

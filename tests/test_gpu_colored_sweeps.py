@@ -68,9 +68,6 @@ def test_config4_lattice_properties(pkg, oracle):
         eng.init_spins_random()
         eng.set_coloring(color)
         C0 = eng.get_config()
-        with pytest.raises(pkg.RRRMCError) as e:
-            eng.wtm_mc(1.0, 2, 1.0)                       # the wtmMC heap still indexes spins with 16 bits (rrrMC / bklMC do not: below)
-        assert e.value.code == 3
         Es = eng.colored_sweeps(1.0, 2, 1)
         C1 = eng.get_config()
         E1 = eng.energy()
@@ -84,8 +81,9 @@ def test_config4_lattice_properties(pkg, oracle):
 
 
 def test_rrr_and_bkl_on_the_config4_lattice(pkg, oracle):
-    """rrrMC(SingleGraph) and bklMC on GraphEA(64, 3) (N = 262 144 > 65 535: the DeltaECache's set members and positions are 32-bit
-    there) against the oracle, incl. the move counts; and on a lattice just above the 16-bit limit."""
+    """rrrMC(SingleGraph), bklMC, wtmMC and extremal_opt on GraphEA(64, 3) (N = 262 144 > 65 535: the DeltaECache's / EOCache's set
+    members and positions and the THeap's ids are 32-bit there) against the oracle, incl. the move counts; and on a lattice just
+    above the 16-bit limit."""
     for L_, iters in ((64, 3000), (41, 6000)):            # 41^3 = 68 921
         seed = 6400 + L_
         X = pkg.GraphEA(L_, 3, seed=seed)
@@ -100,8 +98,21 @@ def test_rrr_and_bkl_on_the_config4_lattice(pkg, oracle):
             eng.set_config(C0)
             Eb, mb = eng.bkl_mc(1.0, iters, 500)
             C2 = eng.get_config()
+            eng.seed(seed)
+            eng.set_config(C0)
+            Ew, mw, tw = eng.wtm_mc(1.0, 8, 200.0)
+            C3 = eng.get_config()
+            eng.seed(seed)
+            eng.set_config(C0)
+            Ee, Emin, Cmin, itmin = eng.extremal_opt(1.3, iters, 500)
+            C4 = eng.get_config()
         for r in (0, 33):
             ref = oracle.rrr_sparse(A, J, 1.0, iters, 500, seed, C0.s[r], replica=r, form="ea")
             assert (Es[r] == ref[0]).all() and (C1.s[r] == ref[1]).all() and acc[r] == ref[2] and staged[r] == ref[3]
             b = oracle.rrr_sparse(A, J, 1.0, iters, 500, seed, C0.s[r], replica=r, form="ea", bkl=True)
             assert (Eb[r] == b[0]).all() and (C2.s[r] == b[1]).all() and mb[r] == b[2]
+            w = oracle.wtm_mc_sparse(A, J, 1.0, 8, 200.0, seed, C0.s[r], replica=r, form="ea")
+            assert (Ew[r] == w[0]).all() and (C3.s[r] == w[1]).all() and mw[r] == w[2] and tw[r] == w[3]
+            assert mw[r] > 100
+            e = oracle.extremal_opt_sparse(A, J, 1.3, iters, 500, seed, C0.s[r], replica=r, form="ea")
+            assert (Ee[r] == e[0]).all() and (C4.s[r] == e[1]).all() and Emin[r] == e[2] and (Cmin.s[r] == e[3]).all() and itmin[r] == e[4]

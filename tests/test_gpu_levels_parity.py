@@ -23,6 +23,14 @@ def _graph(pkg, kind, lev, seed):
         return pkg.GraphEA(2, 3, lev, seed=seed), "ea"               # runtests.jl:47-50 (L = 2: double bonds)
     if kind == "ea3x2":
         return pkg.GraphEA(3, 2, lev, seed=seed), "ea"               # runtests.jl:57-60
+    if kind == "circ200k8":                                          # +-J with K > 7: beyond the bit-plane kernels, runs as a level graph
+        import oracle as O                                           # (gen_RRG's pairing retries practically never succeed at K = 8: a circulant)
+        A = np.sort((np.arange(200)[:, None] + np.array([-4, -3, -2, -1, 1, 2, 3, 4])[None, :]) % 200, axis=1).astype(np.int32)
+        return pkg.GraphRRG.from_AJ(A, O.gen_couplings(A, seed, pkg.level_units(lev)[0]), lev), "rrg"
+    if kind == "ea4x4":
+        return pkg.GraphEA(4, 4, lev, seed=seed), "ea"               # K = 8
+    if kind == "ea3x5":
+        return pkg.GraphEA(3, 5, lev, seed=seed), "ea"               # K = 10
     if kind == "ea6x3":
         return pkg.GraphEA(6, 3, lev, seed=seed), "ea"
     raise KeyError(kind)
@@ -33,6 +41,7 @@ CASES = [
     ("ea2x3", (-1, 0, 1), 16), ("ea2x3", (-1.0, 0.0, 1.0), 8), ("ea3x2", (-1, 0, 1), 33), ("ea3x2", (F(-1), F(0), F(1)), 8),
     ("rrg300", (-2, -1, 1, 2), 64), ("rrg300", (-1.5, -0.5, 0.5, 1.5), 32), ("rrg300", (F(-1, 3), F(1, 3), F(1)), 16),
     ("rrg4096k4", (-1, 0, 1), 6), ("ea6x3", (-0.75, 0.0, 0.75), 40), ("rrg300", (-1.0, 1.0), 16),
+    ("circ200k8", (-1, 1), 33), ("ea4x4", (-1, 1), 16), ("ea3x5", (-1, 1), 16),
 ]
 
 
