@@ -314,7 +314,7 @@ sweep_fn sweep_for_K(int K, int mode)
 size_t sweep_lds_bytes(int64_t N, int K, int TS, int C, bool wide = false, bool single = false)
 {
     const int NT = (K + 1) / 2, NW = NT + (K + 2) / 2, NQ = (NW + 3) / 4;
-    const size_t words = (size_t)(((single ? 1 : 2) * N + 128 + 3) & ~3ll) + (size_t)3 * NQ * 4 * C + (size_t)8 * (C + 64) + (size_t)2 * (4 + kLeftMax * (1 + 2 * NT));
+    const size_t words = (size_t)(((single ? 1 : 2) * N + 128 + 3) & ~3ll) + (size_t)3 * NQ * 4 * C + (size_t)8 * (C + 64) + (size_t)(4 + 2 * kSwLeftMax * (1 + 2 * NT));
     return words * 4 + (wide ? (size_t)0 : (size_t)N * TS * 2);
 }
 
@@ -436,7 +436,15 @@ int32_t prepare_chunk_list(rrrmc_ctx* ctx, int64_t iters, int64_t step, int C, b
             int64_t seg_end = next_sample;                        // exclusive end of the segment that may be chunked freely
             if (seg_end > iters + 1) seg_end = iters + 1;
             const int64_t seg = seg_end - cur, nch = (seg + C - 1) / C;
-            int64_t end = cur + (seg + nch - 1) / nch;            // ceil(seg / nch) <= C: the remaining chunks re-balance themselves
+            int64_t len = (seg + nch - 1) / nch;                  // ceil(seg / nch) <= C: the remaining chunks re-balance themselves
+            if (nch > 1) {
+                // the producers work in 64-slot tasks: whole tasks wherever the segment allows (4096 = 1408 + 1344 + 1344 is 64 tasks,
+                // three times 1366 would be 66)
+                const int64_t up = (len + kWave - 1) / kWave * kWave, down = len / kWave * kWave;
+                if (up <= C) len = up;
+                else if (down > 0 && seg - down <= (nch - 1) * (int64_t)C) len = down;
+            }
+            int64_t end = cur + len;
             if (end > seg_end) end = seg_end;
             ChunkDesc cd{};
             cd.g0 = (uint64_t)cur;

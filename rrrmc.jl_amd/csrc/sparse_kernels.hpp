@@ -22,14 +22,26 @@ namespace rrrmc {
 constexpr int kWave = 64;
 constexpr int kSweepThreads = 1024;              // 16 waves: consumer, tally, fixer and 13 producers
 #ifndef RRRMC_FIXER_WAVE
-#define RRRMC_FIXER_WAVE 13
+#define RRRMC_FIXER_WAVE 14
 #endif
-constexpr int kConsumerWave = 0, kTallyWave = 1, kFixerWave = RRRMC_FIXER_WAVE;   // waves w, w+4, w+8, w+12 share a SIMD
+// waves w, w+4, w+8, w+12 share a SIMD, and a step lasts as long as its most loaded SIMD.  The producers' 64-slot tasks are dealt
+// round-robin to the producer waves in wave order; with the fixer on wave 14 the SIMDs get 5, 5, 6 (+ the fix task), 6 of config 2's 22
+// tasks per chunk next to the consumer (SIMD 0) and the tally wave (SIMD 1).  Merging the fix task into a producer wave was slower
+// (it is a serial chain of two or three Philox blocks: as long as a producer task).
+constexpr int kConsumerWave = 0, kTallyWave = 1, kFixerWave = RRRMC_FIXER_WAVE;
 constexpr int kProducerWaves = kSweepThreads / kWave - 3;
 constexpr int kMaxChunkSlots = 2048;              // longest chunk the host may choose (rrrmc_hip.hip: kMaxChunk)
 constexpr int kProducerTasksMax = (kMaxChunkSlots / kWave + kProducerWaves - 1) / kProducerWaves;   // 64-slot tasks per producer wave and chunk
-constexpr int kProducerBlocks = 3;               // Philox blocks (4 bit planes each) every producer lane computes
-constexpr int kLeftMax = 128;                    // capacity of the per-chunk list of slots still undecided after that
+constexpr int kProducerBlocks = 3;               // Philox blocks (4 bit planes each) every producer lane computes (spf_fast_kernel)
+constexpr int kLeftMax = 128;                    // capacity of the per-chunk list of slots still undecided after that (spf_fast_kernel)
+// sweep_kernel: every lane computes kSwBlocks blocks; the slots still open go through a list to 64-slot "fix tasks" (kSwFixBlocks more
+// blocks for every lane, then a loop), dealt to the fixer wave (tasks 0, 1) and, when the list can hold more than two tasks, to the
+// producer waves with the fewest tasks of their own.  Measured at config 2: (3, 0, 128) 8.78 ms per launch; (2, 2, 384) — a third less
+// Philox work in the producers — 9.52 ms: a producer task only gets 12 % shorter (its list appends are no longer rare) and a fix task
+// costs more than a producer task, so three blocks per lane and a nearly idle fixer wave stay.
+constexpr int kSwBlocks = 3;
+constexpr int kSwFixBlocks = 0;
+constexpr int kSwLeftMax = 128;                  // list capacity per chunk; lanes that find it full finish on their own
 constexpr int kPlanThreads = 256;
 constexpr int kMaxK = 7;                          // 3 bit planes for the unsatisfied-bond count
 constexpr int kRows = 4;                          // rows of 64 slots the consumer keeps in flight
@@ -177,9 +189,10 @@ __global__ __launch_bounds__(kPlanThreads) void plan_kernel(ChunkDesc* __restric
 
 // ---------------------------------------------------------------------------------------------------
 // sweep_kernel: one workgroup = one group of 32 bit-sliced replicas, whole state in LDS.
-//   wave 0      consumer : applies the moves of chunk c-1, level by level (the only state-dependent work)
-//   wave 1      tally    : per-replica accepted-move / energy bookkeeping of chunk c-2, emits energy samples
-//   waves 2..15 producers: acceptance masks + gather offsets (slot descriptors) of chunk c
+//   wave 0      consumer : applies the moves of chunk c-2, level by level (the only state-dependent work)
+//   wave 1      tally    : per-replica accepted-move / energy bookkeeping of chunk c-3, emits energy samples
+//   fixer wave           : finishes the slots of chunk c-1 its producers left open
+//   the other 13 waves   : producers: acceptance masks + gather offsets (slot descriptors) of chunk c
 // One barrier per chunk; descriptors and tally words are double-buffered in LDS.
 // ---------------------------------------------------------------------------------------------------
 struct SweepParams {
@@ -215,9 +228,9 @@ template <int K> struct SweepCfg {
 // list of the slots of one chunk that the producers could not decide within kProducerBlocks blocks
 struct LeftList {
     uint32_t* count;     // [1]
-    uint32_t* slot;      // [kLeftMax]      position in the chunk | (index of the attempt in the chunk << 16)
-    uint32_t* lt;        // [NT][kLeftMax]  masks so far
-    uint32_t* eq;        // [NT][kLeftMax]  replicas still undecided
+    uint32_t* slot;      // [cap]      position in the chunk | (index of the attempt in the chunk << 16)
+    uint32_t* lt;        // [NT][cap]  masks so far
+    uint32_t* eq;        // [NT][cap]  replicas still undecided
 };
 
 template <int NT> __device__ __forceinline__ bool any_set(const uint32_t (&eq)[NT])
@@ -303,14 +316,14 @@ __device__ __forceinline__ void produce_chunk(const SweepParams& P, const ChunkD
             eq[n] = (live && !always) ? 0xffffffffu : 0u;
         }
         // u < T_n, bit-sliced over the 32 replicas, most significant plane first (lazy evaluation of a counter-based
-        // stream: the result does not depend on where we stop).  Every lane computes kProducerBlocks blocks of 4
-        // planes; the ~1.5 % of lanes that still have an undecided replica then hand the slot to the fixer wave
-        // through the leftover list, so that a producer's time does not depend on its unluckiest lane.
+        // stream: the result does not depend on where we stop).  Every lane computes kSwBlocks blocks of 4 planes; the lanes that
+        // still have an undecided replica hand the slot to the fix tasks through the leftover list, so that a producer's time
+        // does not depend on its unluckiest lane.
         // fully unrolled: the block index is a compile-time constant, so the threshold words are loop-invariant scalars
         uint32_t pb = 0;
 #pragma unroll
-        for (int b = 0; b < kProducerBlocks; ++b) refine_block<NT>(lt, eq, accept_planes(P.k0, P.k1, g, group, (uint32_t)b), (uint32_t)b, P.taum);
-        pb = (uint32_t)kProducerBlocks;
+        for (int b = 0; b < kSwBlocks; ++b) refine_block<NT>(lt, eq, accept_planes(P.k0, P.k1, g, group, (uint32_t)b), (uint32_t)b, P.taum);
+        pb = (uint32_t)kSwBlocks;
         bool need = any_set<NT>(eq);
         const unsigned long long bal = __ballot(need);
         if (bal != 0ull) {       // wave-uniform
@@ -318,19 +331,20 @@ __device__ __forceinline__ void produce_chunk(const SweepParams& P, const ChunkD
             if (lane == 0) base = atomicAdd(left.count, (uint32_t)__popcll(bal));
             base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
             const uint32_t idx = base + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
-            if (need && idx < (uint32_t)kLeftMax) {
+            if (need && idx < (uint32_t)kSwLeftMax) {
                 left.slot[idx] = (uint32_t)p | (slot & 0xffff0000u);     // position in the chunk | index of the attempt
 #pragma unroll
-                for (int n = 0; n < NT; ++n) { left.lt[n * kLeftMax + idx] = lt[n]; left.eq[n * kLeftMax + idx] = eq[n]; }
+                for (int n = 0; n < NT; ++n) { left.lt[n * kSwLeftMax + idx] = lt[n]; left.eq[n * kSwLeftMax + idx] = eq[n]; }
                 need = false;
 #pragma unroll
                 for (int n = 0; n < NT; ++n) eq[n] = 0u;
             }
             // list full (practically never): finish those lanes here
-            for (; pb < 16u; ++pb) {
-                if (!__any(any_set<NT>(eq))) break;
-                refine_block<NT>(lt, eq, accept_planes(P.k0, P.k1, g, group, pb), pb, P.taum);
-            }
+            if (base + (uint32_t)__popcll(bal) > (uint32_t)kSwLeftMax)
+                for (; pb < 16u; ++pb) {
+                    if (!__any(any_set<NT>(eq))) break;
+                    refine_block<NT>(lt, eq, accept_planes(P.k0, P.k1, g, group, pb), pb, P.taum);
+                }
         }
         if (live) {
 #pragma unroll
@@ -341,24 +355,38 @@ __device__ __forceinline__ void produce_chunk(const SweepParams& P, const ChunkD
     }
 }
 
-// ---- fixer: finishes the slots the producers left undecided and patches their masks into the descriptors ----
+// ---- fix tasks: finish the slots the producers left undecided and patch their masks into the descriptors ----
+// One task = 64 entries of the chunk's leftover list: kSwFixBlocks more blocks for every lane, then a loop for whatever is still open.
+// Task b of a chunk belongs to worker fix_worker(b): 0 = the fixer wave (tasks 0 and 1), 1 + pw = producer pw — dealt from the LAST
+// producer downwards, the ones with the fewest 64-slot tasks of their own.
+__device__ __forceinline__ int fix_worker(int b)
+{
+    const int r = b % (kProducerWaves + 2);
+    return r < 2 ? 0 : 1 + (kProducerWaves - 1 - (r - 2));
+}
+
 template <int K>
-__device__ __forceinline__ void fix_chunk(const SweepParams& P, const ChunkDesc& cd, uint4* __restrict__ desc, const LeftList& left,
-                                          int lane, uint32_t group)
+__device__ __forceinline__ void fix_tasks(const SweepParams& P, const ChunkDesc& cd, uint4* __restrict__ desc, const LeftList& left,
+                                          int lane, uint32_t group, int worker)
 {
     constexpr int NT = SweepCfg<K>::NT;
     uint32_t n = *left.count;
     n = (uint32_t)__builtin_amdgcn_readfirstlane((int)n);
-    n = n < (uint32_t)kLeftMax ? n : (uint32_t)kLeftMax;
-    for (uint32_t base = 0; base < n; base += kWave) {
-        const uint32_t i = base + (uint32_t)lane;
+    n = n < (uint32_t)kSwLeftMax ? n : (uint32_t)kSwLeftMax;
+    const int ntask = (int)((n + kWave - 1) / kWave);
+    for (int b = 0; b < ntask; ++b) {
+        if (fix_worker(b) != worker) continue;
+        const uint32_t i = (uint32_t)(b * kWave + lane);
         const bool live = i < n;
         uint32_t lt[NT], eq[NT], sl = 0u;
         if (live) sl = left.slot[i];
 #pragma unroll
-        for (int q = 0; q < NT; ++q) { lt[q] = live ? left.lt[q * kLeftMax + i] : 0u; eq[q] = live ? left.eq[q * kLeftMax + i] : 0u; }
+        for (int q = 0; q < NT; ++q) { lt[q] = live ? left.lt[q * kSwLeftMax + i] : 0u; eq[q] = live ? left.eq[q * kSwLeftMax + i] : 0u; }
         const uint64_t g = P.gbase + cd.g0 + (uint64_t)(sl >> 16);
-        for (uint32_t pb = kProducerBlocks; pb < 16u; ++pb) {
+#pragma unroll
+        for (int b2 = 0; b2 < kSwFixBlocks; ++b2)
+            refine_block<NT>(lt, eq, accept_planes(P.k0, P.k1, g, group, (uint32_t)(kSwBlocks + b2)), (uint32_t)(kSwBlocks + b2), P.taum);
+        for (uint32_t pb = kSwBlocks + kSwFixBlocks; pb < 16u; ++pb) {
             if (!__any(any_set<NT>(eq))) break;
             refine_block<NT>(lt, eq, accept_planes(P.k0, P.k1, g, group, pb), pb, P.taum);
         }
@@ -368,7 +396,6 @@ __device__ __forceinline__ void fix_chunk(const SweepParams& P, const ChunkDesc&
             for (int q = 0; q < NT; ++q) m[q] = lt[q];
         }
     }
-    if (lane == 0) *left.count = 0u;
 }
 
 // ---- consumer --------------------------------------------------------------------------------------
@@ -484,20 +511,38 @@ __device__ __forceinline__ void consume_rows(const uint4* __restrict__ desc, uin
     for (int j = 0; j < NR; ++j) gather_words<K, MODE>(w[j], d[j], sp);
 #pragma unroll
     for (int j = 0; j < NR; ++j) {
-        uint32_t n0, n1, n2, acc;
-        slot_logic<K>(d[j], w[j], n0, n1, n2, acc);
-        const uint32_t snew = w[j].s ^ acc;      // spinflip! + update_cache! (Interface.jl:89-92, RRG.jl:191-234)
         // in the last row the lanes past the end of the batch hold a copy of its last slot: they compute and store exactly what
         // that slot's own lane does (same addresses, same values), so they need no special treatment
         int pt = p0 + j * kWave;
         if (j == NR - 1) pt = pt < plast ? pt : plast;
-        lds_store_pair<MODE>(sp, desc_off<K>(d[j], 0), snew);
-        if constexpr (SweepCfg<K>::NS <= 3) {
-            // the tally reads three words for K <= 3 (n2 = 0): a 12-byte LDS write issues faster than a 16-byte one
-            typedef uint32_t v3u __attribute__((ext_vector_type(3)));
-            *reinterpret_cast<v3u*>(tal + pt) = v3u{acc, n0, n1};
+        typedef uint32_t v3u __attribute__((ext_vector_type(3)));
+        if constexpr (K == 3) {
+            // the consumer's row spelled as seven three-input functions (the compiler's own version of slot_logic + flip has eleven
+            // instructions): planes of n = sum_k (s ^ g_k) are self-dual in s for odd K; a0 = M1 & (n0 | M0) is the part of the accept
+            // mask that needed a random number, acc = n1 | a0 (n >= 2: dE <= 0) is left to the tally wave, which has the slack
+            const uint32_t s = w[j].s;
+            const uint32_t n0 = xor3(w[j].g[0], w[j].g[1], w[j].g[2]) ^ s;
+            const uint32_t n1 = bitop3<0xe8>(w[j].g[0], w[j].g[1], w[j].g[2]) ^ s;
+            const uint32_t a0 = bitop3<0xa8>(n0, desc_mask<K>(d[j], 0), desc_mask<K>(d[j], 1));
+            const uint32_t snew = bitop3<0x1e>(s, n1, a0);      // s ^ (n1 | a0): spinflip! + update_cache! (Interface.jl:89-92, RRG.jl:191-234)
+            if constexpr (MODE == 3) sp[desc_off<K>(d[j], 0)] = snew;
+            else {
+                const uint32_t nsnew = bitop3<0xe1>(s, n1, a0);
+                if constexpr (MODE == 2) *reinterpret_cast<uint2*>(sp + desc_off<K>(d[j], 0)) = make_uint2(snew, nsnew);
+                else *reinterpret_cast<uint2*>(reinterpret_cast<char*>(sp) + desc_off<K>(d[j], 0)) = make_uint2(snew, nsnew);
+            }
+            *reinterpret_cast<v3u*>(tal + pt) = v3u{a0, n0, n1};
         } else {
-            tal[pt] = make_uint4(acc, n0, n1, n2);
+            uint32_t n0, n1, n2, acc;
+            slot_logic<K>(d[j], w[j], n0, n1, n2, acc);
+            const uint32_t snew = w[j].s ^ acc;      // spinflip! + update_cache! (Interface.jl:89-92, RRG.jl:191-234)
+            lds_store_pair<MODE>(sp, desc_off<K>(d[j], 0), snew);
+            if constexpr (SweepCfg<K>::NS <= 3) {
+                // the tally reads three words for K <= 3 (n2 = 0): a 12-byte LDS write issues faster than a 16-byte one
+                *reinterpret_cast<v3u*>(tal + pt) = v3u{acc, n0, n1};
+            } else {
+                tal[pt] = make_uint4(acc, n0, n1, n2);
+            }
         }
     }
 }
@@ -523,10 +568,12 @@ __device__ __forceinline__ void consume_chunk(const SweepParams& P, const ChunkD
             const uint32_t vd = __builtin_amdgcn_readlane(myvd, v);
             const int start = (int)(vd & 0xffffu), cm1 = (int)(vd >> 16);   // cm1 = slots - 1
             const int p0 = start + lane, plast = start + cm1;
-            if (cm1 >= 3 * kWave) consume_rows<K, 4, MODE>(desc, sp, tal, C, p0, plast);
-            else if (cm1 >= 2 * kWave) consume_rows<K, 3, MODE>(desc, sp, tal, C, p0, plast);
-            else if (cm1 >= kWave) consume_rows<K, 2, MODE>(desc, sp, tal, C, p0, plast);
-            else consume_rows<K, 1, MODE>(desc, sp, tal, C, p0, plast);
+            switch (cm1 >> 6) {          // rows - 1 (wave-uniform; kWave = 64)
+                case 0: consume_rows<K, 1, MODE>(desc, sp, tal, C, p0, plast); break;
+                case 1: consume_rows<K, 2, MODE>(desc, sp, tal, C, p0, plast); break;
+                case 2: consume_rows<K, 3, MODE>(desc, sp, tal, C, p0, plast); break;
+                default: consume_rows<K, 4, MODE>(desc, sp, tal, C, p0, plast); break;
+            }
         }
     }
 }
@@ -548,11 +595,13 @@ template <int NS> struct TallyState {
     uint32_t ngrp;                 // groups of 8 inputs since the last flush (wave-uniform)
 };
 
+// carry-save adder of three words: sum = a ^ b ^ c (truth table 0x96), carry = majority (0xe8) — two v_bitop3_b32; left to the plain
+// expression the compiler spends five instructions on it (xor, and, and, or, xor)
 #define RRRMC_CSA(sum, carry, a, b, c)                      \
     {                                                       \
-        const uint32_t u_ = (a) ^ (b);                      \
-        carry = ((a) & (b)) | (u_ & (c));                   \
-        sum = u_ ^ (c);                                     \
+        const uint32_t a_ = (a), b_ = (b), c_ = (c);        \
+        carry = bitop3<0xe8>(a_, b_, c_);                   \
+        sum = bitop3<0x96>(a_, b_, c_);                     \
     }
 
 // streaming add of one word of weight 8 when the group count has exactly TZ trailing one bits
@@ -630,7 +679,7 @@ __device__ __forceinline__ uint32_t transpose32(uint32_t a, const TransposeConst
     {                                                                                                \
         const uint32_t o = (uint32_t)__builtin_amdgcn_ds_swizzle((int)a, ((J) << 10) | 0x1f);        \
         const uint32_t sel = __builtin_amdgcn_alignbit(o, o, tc.rot[S]);                             \
-        a = (a & tc.keep[S]) | (sel & ~tc.keep[S]);                                                  \
+        a = bitop3<0xe4>(a, sel, tc.keep[S]);      /* keep ? a : sel */                             \
     }
     RRRMC_TSTAGE(0, 16)
     RRRMC_TSTAGE(1, 8)
@@ -712,23 +761,44 @@ __device__ __forceinline__ void tally_reset(TallyState<NS>& t)
     t.ngrp = 0u;
 }
 
-template <int NS>
-__device__ __forceinline__ void tally_chunk(TallyState<NS>& t, const ChunkDesc& cd, const uint4* __restrict__ tal, int lane)
+template <int NS, int K, bool MASKED>
+__device__ __forceinline__ void tally_group(TallyState<NS>& t, const uint4* __restrict__ tal, int base, int count, int lane)
 {
-    // every lane adds the same number of words (zeros past the end) so that the counters' shape stays wave-uniform
-    for (int base = 0; base < (int)cd.count; base += 8 * kWave) {
-        uint32_t x[8][NS];
+    uint32_t x[8][NS];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int p = base + j * kWave + lane;
-            const uint4 w = p < (int)cd.count ? tal[p] : make_uint4(0u, 0u, 0u, 0u);
+    for (int j = 0; j < 8; ++j) {
+        const int p = base + j * kWave + lane;
+        uint4 w = make_uint4(0u, 0u, 0u, 0u);
+        if constexpr (SweepCfg<K>::NS <= 3) {
+            typedef uint32_t v3u __attribute__((ext_vector_type(3)));
+            if (!MASKED || p < count) { const v3u v = *reinterpret_cast<const v3u*>(tal + p); w.x = v.x; w.y = v.y; w.z = v.z; }
+        } else {
+            if (!MASKED || p < count) w = tal[p];
+        }
+        if constexpr (K == 3) {
+            // the consumer leaves (a0, n0, n1) with acc = n1 | a0 (consume_rows): acc & n0 = (a0 | n1) & n0, acc & n1 = n1
+            x[j][0] = w.x | w.z;
+            x[j][1 % NS] = bitop3<0xa8>(w.x, w.z, w.y);
+            x[j][2 % NS] = w.z;
+        } else {
             x[j][0] = w.x;
             if (NS > 1) x[j][1 % NS] = w.x & w.y;
             if (NS > 2) x[j][2 % NS] = w.x & w.z;
             if (NS > 3) x[j][3 % NS] = w.x & w.w;
         }
-        tally_add8<NS>(t, x);
     }
+    tally_add8<NS>(t, x);
+}
+
+template <int NS, int K>
+__device__ __forceinline__ void tally_chunk(TallyState<NS>& t, const ChunkDesc& cd, const uint4* __restrict__ tal, int lane)
+{
+    // every lane adds the same number of words (zeros past the end) so that the counters' shape stays wave-uniform; only the last
+    // group of 8 x 64 slots can be partial and needs the bounds test
+    const int count = (int)cd.count;
+    int base = 0;
+    for (; base + 8 * kWave <= count; base += 8 * kWave) tally_group<NS, K, false>(t, tal, base, count, lane);
+    if (base < count) tally_group<NS, K, true>(t, tal, base, count, lane);
 }
 
 template <int K, int MODE = 0>
@@ -741,9 +811,12 @@ __global__ __launch_bounds__(kSweepThreads) void sweep_kernel(SweepParams P)
     uint4* desc = reinterpret_cast<uint4*>(sp + (((MODE == 3 ? 1 : 2) * N + 128 + 3) & ~3)); // [3][NQ][C]   (128 spare words behind the spins)
     uint4* tal = desc + 3 * NQ * C;                                  // [2][C + 64]  (64 dummy entries per buffer)
     uint32_t* leftmem = reinterpret_cast<uint32_t*>(tal + 2 * (C + kWave));   // [2] leftover lists
-    constexpr int kLeftWords = 4 + kLeftMax * (1 + 2 * SweepCfg<K>::NT);
+    // leftover lists: 4 count words (three in rotation: chunk c counts in word c % 3, which is cleared during step c - 1 — after its last
+    // readers, the fix tasks of chunk c - 3 in step c - 2, are behind a barrier), then two entry buffers (chunk c uses buffer c & 1)
+    constexpr int kLeftBuf = kSwLeftMax * (1 + 2 * SweepCfg<K>::NT);
+    constexpr int kLeftAll = 4 + 2 * kLeftBuf;
     // [N][TS] neighbour table: a copy in LDS, or (MODE >= 1) the HBM/L2 original
-    const uint16_t* tbl = MODE >= 1 ? P.table : reinterpret_cast<const uint16_t*>(leftmem + 2 * kLeftWords);
+    const uint16_t* tbl = MODE >= 1 ? P.table : reinterpret_cast<const uint16_t*>(leftmem + kLeftAll);
 
     const int tid = threadIdx.x, lane = tid & 63;
     // the wave index as a SCALAR: role dispatch becomes s_cbranch (and s_setprio below really is per wave)
@@ -757,15 +830,15 @@ __global__ __launch_bounds__(kSweepThreads) void sweep_kernel(SweepParams P)
         else *reinterpret_cast<uint2*>(sp + 2 * x) = make_uint2(w, ~w);  // word 2x: the spins of site x, word 2x + 1: their complement
     }
     if constexpr (MODE == 0) {
-        uint16_t* tbl_w = reinterpret_cast<uint16_t*>(leftmem + 2 * kLeftWords);
+        uint16_t* tbl_w = reinterpret_cast<uint16_t*>(leftmem + kLeftAll);
         for (int q = tid; q < N * P.TS; q += kSweepThreads) tbl_w[q] = P.table[q];
     }
-    if (tid < 2) leftmem[tid * kLeftWords] = 0u;
+    if (tid < 4) leftmem[tid] = 0u;
     __syncthreads();
     auto left_list = [&](int c) {
-        uint32_t* m = leftmem + (c & 1) * kLeftWords;
+        uint32_t* m = leftmem + 4 + (c & 1) * kLeftBuf;
         LeftList l;
-        l.count = m; l.slot = m + 4; l.lt = m + 4 + kLeftMax; l.eq = m + 4 + kLeftMax * (1 + SweepCfg<K>::NT);
+        l.count = leftmem + (c % 3); l.slot = m; l.lt = m + kSwLeftMax; l.eq = m + kSwLeftMax * (1 + SweepCfg<K>::NT);
         return l;
     };
 
@@ -839,7 +912,7 @@ __global__ __launch_bounds__(kSweepThreads) void sweep_kernel(SweepParams P)
                     dr.step(tc);
                     if (dr.phase == NS) dr.finish(P, lane, E_run, A_run);
                 }
-                tally_chunk<NS>(ts, cd, tal + ((c - 3) & 1) * tal_stride, lane);
+                tally_chunk<NS, K>(ts, cd, tal + ((c - 3) & 1) * tal_stride, lane);
             }
 #endif
             RRRMC_T1
@@ -856,7 +929,8 @@ __global__ __launch_bounds__(kSweepThreads) void sweep_kernel(SweepParams P)
             RRRMC_T0
             fa = fb;                                        // chunk c-1, requested one step ago
             if (c < P.nchunks) fb = P.chunks[c];
-            if (c >= 1 && c - 1 < P.nchunks) fix_chunk<K>(P, fa, desc + ((c - 1) % 3) * NQ * C, left_list(c - 1), lane, group);
+            if (lane == 0) leftmem[(c + 1) % 3] = 0u;          // the count word of the NEXT chunk's list
+            if (c >= 1 && c - 1 < P.nchunks) fix_tasks<K>(P, fa, desc + ((c - 1) % 3) * NQ * C, left_list(c - 1), lane, group, 0);
             RRRMC_T1
             __syncthreads();
         }
@@ -865,7 +939,7 @@ __global__ __launch_bounds__(kSweepThreads) void sweep_kernel(SweepParams P)
         // The chunk descriptor (scalar loads) and the slot words (one coalesced global load per task) are requested ahead of
         // time — the descriptor two steps, the slots one step before they are used — so a step starts computing right after the
         // barrier instead of waiting a microsecond for HBM/L2 (that latency was a third of a step).
-        ChunkDesc cd0{}, cd1{}, cd2{};
+        ChunkDesc cdp{}, cd0{}, cd1{}, cd2{};
         uint32_t sl0[kProducerTasksMax], sl1[kProducerTasksMax];
 #pragma unroll
         for (int j = 0; j < kProducerTasksMax; ++j) { sl0[j] = 0u; sl1[j] = 0u; }
@@ -880,6 +954,7 @@ __global__ __launch_bounds__(kSweepThreads) void sweep_kernel(SweepParams P)
         if (P.nchunks > 1) cd2 = P.chunks[1];
         for (int c = 0; c < nsteps; ++c) {
             RRRMC_T0
+            cdp = cd0;                                      // chunk c-1: its fix tasks
             cd0 = cd1;
 #pragma unroll
             for (int j = 0; j < kProducerTasksMax; ++j) sl0[j] = sl1[j];
@@ -887,6 +962,8 @@ __global__ __launch_bounds__(kSweepThreads) void sweep_kernel(SweepParams P)
             if (c + 1 < P.nchunks) fetch_slots(cd1, sl1);
             if (c + 2 < P.nchunks) cd2 = P.chunks[c + 2];
 #ifndef RRRMC_ABLATE_PRODUCE
+            if constexpr (kSwLeftMax > 2 * kWave)
+                if (c >= 1 && c - 1 < P.nchunks) fix_tasks<K>(P, cdp, desc + ((c - 1) % 3) * NQ * C, left_list(c - 1), lane, group, 1 + pw);
             if (c < P.nchunks) produce_chunk<K, MODE>(P, cd0, desc + (c % 3) * NQ * C, tbl, left_list(c), pw, lane, group, sl0);
 #endif
             RRRMC_T1

@@ -28,6 +28,11 @@ namespace rrrmc {
 
 constexpr int kFastMaxK = 4;
 
+// role layout of spf_fast_kernel: consumer (wave 0), tally (1), a dedicated fixer wave and 13 producers
+constexpr int kFastFixerWave = 13;
+constexpr int kFastProducerWaves = kSweepThreads / kWave - 3;
+constexpr int kFastProducerTasksMax = (kMaxChunkSlots / kWave + kFastProducerWaves - 1) / kFastProducerWaves;
+
 template <int K> struct FastCfg {
     static constexpr int NT = 1 << (K - 1);              // pattern pairs = thresholds per site
     static constexpr int NOFF = (K + 2) / 2;             // words holding the K+1 16-bit byte offsets
@@ -77,14 +82,14 @@ __device__ __forceinline__ void refine_block_lane(uint32_t (&lt)[NT], uint32_t (
 
 template <int K>
 __device__ __forceinline__ void fast_produce_chunk(const FastParams& P, const ChunkDesc& cd, uint4* __restrict__ desc, const LeftList& left,
-                                                   int pw, int lane, uint32_t group, const uint32_t (&slots)[kProducerTasksMax])
+                                                   int pw, int lane, uint32_t group, const uint32_t (&slots)[kFastProducerTasksMax])
 {
     constexpr int NT = FastCfg<K>::NT, NQ = FastCfg<K>::NQ, NOFF = FastCfg<K>::NOFF;
     const int C = P.C;
     const int ntask = ((int)cd.count + kWave - 1) / kWave;
 #pragma unroll
-    for (int j = 0; j < kProducerTasksMax; ++j) {
-        const int task = pw + j * kProducerWaves;
+    for (int j = 0; j < kFastProducerTasksMax; ++j) {
+        const int task = pw + j * kFastProducerWaves;
         if (task >= ntask) break;
         const int p = task * kWave + lane;
         const bool live = p < (int)cd.count;
@@ -401,7 +406,7 @@ __global__ __launch_bounds__(kSweepThreads) void spf_fast_kernel(FastParams P)
         }
         flush();
         if (lane < 32) P.acc_cur[blockIdx.x * 32 + lane] = A_run;
-    } else if (wave == kFixerWave) {
+    } else if (wave == kFastFixerWave) {
         ChunkDesc fa{}, fb{};
         for (int c = 0; c < nsteps; ++c) {
             fa = fb;
@@ -411,15 +416,15 @@ __global__ __launch_bounds__(kSweepThreads) void spf_fast_kernel(FastParams P)
             __syncthreads();
         }
     } else {
-        const int pw = wave < kFixerWave ? wave - 2 : wave - 3;
+        const int pw = wave < kFastFixerWave ? wave - 2 : wave - 3;
         ChunkDesc cd0{}, cd1{}, cd2{};
-        uint32_t sl0[kProducerTasksMax], sl1[kProducerTasksMax];
+        uint32_t sl0[kFastProducerTasksMax], sl1[kFastProducerTasksMax];
 #pragma unroll
-        for (int j = 0; j < kProducerTasksMax; ++j) { sl0[j] = 0u; sl1[j] = 0u; }
-        auto fetch_slots = [&](const ChunkDesc& cd, uint32_t (&sl)[kProducerTasksMax]) {
+        for (int j = 0; j < kFastProducerTasksMax; ++j) { sl0[j] = 0u; sl1[j] = 0u; }
+        auto fetch_slots = [&](const ChunkDesc& cd, uint32_t (&sl)[kFastProducerTasksMax]) {
 #pragma unroll
-            for (int j = 0; j < kProducerTasksMax; ++j) {
-                const int p = (pw + j * kProducerWaves) * kWave + lane;
+            for (int j = 0; j < kFastProducerTasksMax; ++j) {
+                const int p = (pw + j * kFastProducerWaves) * kWave + lane;
                 sl[j] = p < (int)cd.count ? P.slots[cd.slot_base + p] : 0u;
             }
         };
@@ -428,7 +433,7 @@ __global__ __launch_bounds__(kSweepThreads) void spf_fast_kernel(FastParams P)
         for (int c = 0; c < nsteps; ++c) {
             cd0 = cd1;
 #pragma unroll
-            for (int j = 0; j < kProducerTasksMax; ++j) sl0[j] = sl1[j];
+            for (int j = 0; j < kFastProducerTasksMax; ++j) sl0[j] = sl1[j];
             cd1 = cd2;
             if (c + 1 < P.nchunks) fetch_slots(cd1, sl1);
             if (c + 2 < P.nchunks) cd2 = P.chunks[c + 2];
