@@ -374,6 +374,12 @@ int32_t ensure_state(rrrmc_ctx* ctx, bool need_spins)
 
 typedef void (*ebs_fn)(const uint32_t*, const int32_t*, const int8_t*, int, uint32_t*);
 ebs_fn energy_bs_for_K(int K) { RRRMC_DISPATCH_UPTO7(K, energy_bs_kernel) }
+#ifndef RRRMC_COLOR_GPT
+#define RRRMC_COLOR_GPT 1
+#endif
+// replica groups per thread of the plain colour-sweep kernel (the counting build: 1).  Measured on GraphEA(64, 3), 512 replicas:
+// 1: 2.60, 2: 2.65, 4: 2.51, 8: 2.37 x 10^12 attempts/s — sharing the neighbour row between groups buys nothing
+constexpr int kColorGPT = RRRMC_COLOR_GPT;
 typedef void (*csweep_fn)(ColorSweepParams);
 csweep_fn csweep_for_K(int K, bool count)
 {
@@ -382,9 +388,9 @@ csweep_fn csweep_for_K(int K, bool count)
                      case 4: return colored_sweep_kernel<4, true>; case 5: return colored_sweep_kernel<5, true>; case 6: return colored_sweep_kernel<6, true>;
                      case 7: return colored_sweep_kernel<7, true>; default: return nullptr; }
     }
-    switch (K) { case 1: return colored_sweep_kernel<1, false>; case 2: return colored_sweep_kernel<2, false>; case 3: return colored_sweep_kernel<3, false>;
-                 case 4: return colored_sweep_kernel<4, false>; case 5: return colored_sweep_kernel<5, false>; case 6: return colored_sweep_kernel<6, false>;
-                 case 7: return colored_sweep_kernel<7, false>; default: return nullptr; }
+    switch (K) { case 1: return colored_sweep_kernel<1, false, kColorGPT>; case 2: return colored_sweep_kernel<2, false, kColorGPT>; case 3: return colored_sweep_kernel<3, false, kColorGPT>;
+                 case 4: return colored_sweep_kernel<4, false, kColorGPT>; case 5: return colored_sweep_kernel<5, false, kColorGPT>; case 6: return colored_sweep_kernel<6, false, kColorGPT>;
+                 case 7: return colored_sweep_kernel<7, false, kColorGPT>; default: return nullptr; }
 }
 
 // bit-sliced energy of every replica into d_E (and, optionally, one row of the sample buffer)
@@ -1366,8 +1372,9 @@ int32_t rrrmc_colored_sweeps_async(rrrmc_ctx* ctx, double beta, int64_t sweeps, 
         for (int plane = 0; plane < 64; ++plane) P.taum[plane * 4 + n] = ((T >> (63 - plane)) & 1ull) ? ~0u : 0u;
     }
     P.spins = ctx->d_spins; P.A = ctx->d_A; P.J = ctx->d_J;
-    P.k0 = (uint32_t)ctx->seed; P.k1 = (uint32_t)(ctx->seed >> 32); P.group0 = ctx->replica0 / 32; P.N = (int)ctx->N;
+    P.k0 = (uint32_t)ctx->seed; P.k1 = (uint32_t)(ctx->seed >> 32); P.group0 = ctx->replica0 / 32; P.N = (int)ctx->N; P.G = (int)ctx->G;
     csweep_fn fn = csweep_for_K((int)K, ctx->color_count_acc);
+    const int gpt = ctx->color_count_acc ? 1 : kColorGPT;
     P.acc_cur = ctx->d_acc;
     hipStream_t st = ctx->stream;
     HIP_TRY(ctx, hipEventRecord(ctx->ev_begin, st));
@@ -1386,7 +1393,7 @@ int32_t rrrmc_colored_sweeps_async(rrrmc_ctx* ctx, double beta, int64_t sweeps, 
             if (ctx->color_count[c] == 0) continue;
             P.list = ctx->d_color_list[c];
             P.nlist = ctx->color_count[c];
-            const dim3 grid((unsigned)((P.nlist + 255) / 256), (unsigned)ctx->G);
+            const dim3 grid((unsigned)((P.nlist + 255) / 256), (unsigned)((ctx->G + gpt - 1) / gpt));
             hipLaunchKernelGGL(fn, grid, dim3(256), 0, st, P);
             HIP_TRY(ctx, hipGetLastError());
         }

@@ -28,7 +28,18 @@ constexpr int kSweepThreads = 1024;              // 16 waves: consumer, tally, f
 // round-robin to the producer waves in wave order; with the fixer on wave 14 the SIMDs get 5, 5, 6 (+ the fix task), 6 of config 2's 22
 // tasks per chunk next to the consumer (SIMD 0) and the tally wave (SIMD 1).  Merging the fix task into a producer wave was slower
 // (it is a serial chain of two or three Philox blocks: as long as a producer task).
-constexpr int kConsumerWave = 0, kTallyWave = 1, kFixerWave = RRRMC_FIXER_WAVE;
+#ifndef RRRMC_TALLY_WAVE
+#define RRRMC_TALLY_WAVE 1
+#endif
+constexpr int kConsumerWave = 0, kTallyWave = 1, kFixerWave = RRRMC_FIXER_WAVE;       // spf_fast_kernel keeps (0, 1, kFastFixerWave)
+constexpr int kSwTallyWave = RRRMC_TALLY_WAVE;
+// producer index of a wave of sweep_kernel: its rank among the waves that are neither consumer, tally nor fixer
+__host__ __device__ constexpr int sw_producer_index(int wave)
+{
+    int pw = 0;
+    for (int w = 0; w < wave; ++w) pw += (w != kConsumerWave && w != kSwTallyWave && w != kFixerWave) ? 1 : 0;
+    return pw;
+}
 constexpr int kProducerWaves = kSweepThreads / kWave - 3;
 constexpr int kMaxChunkSlots = 2048;              // longest chunk the host may choose (rrrmc_hip.hip: kMaxChunk)
 constexpr int kProducerTasksMax = (kMaxChunkSlots / kWave + kProducerWaves - 1) / kProducerWaves;   // 64-slot tasks per producer wave and chunk
@@ -448,6 +459,49 @@ __device__ __forceinline__ void gather_words(SlotWords<K>& w, const SlotDesc<K>&
     for (int k = 0; k < K; ++k) w.g[k] = lds_word<MODE>(sp, desc_off<K>(d, 1 + k));
 }
 
+// planes n0, n1, n2 of n = u[0] + ... + u[K-1] (K <= 7 one-bit inputs per replica, 32 replicas per word) with carry-save adders:
+// a full adder of three words is two v_bitop3_b32 (sum 0x96, majority 0xe8), a half adder two plain ops — 8 instructions at K = 6 or 7,
+// 6 at K = 4 or 5, 2 at K = 3, where the ripple form (n0 ^= u, carry into n1, carry into n2) takes 5 per input
+template <int K>
+__device__ __forceinline__ void count_planes(const uint32_t (&u)[K], uint32_t& n0, uint32_t& n1, uint32_t& n2)
+{
+    static_assert(K >= 1 && K <= 7, "three count planes");
+    uint32_t ones[K], twos[4], fours[2];
+    int no = K, nt = 0, nf = 0;
+#pragma unroll
+    for (int k = 0; k < K; ++k) ones[k] = u[k];
+    // reduce the weight-1 column to one word
+#pragma unroll
+    for (int pass = 0; pass < 3; ++pass) {
+        if (no >= 3) {
+            const uint32_t a = ones[no - 1], b = ones[no - 2], c = ones[no - 3];
+            ones[no - 3] = bitop3<0x96>(a, b, c);
+            twos[nt++] = bitop3<0xe8>(a, b, c);
+            no -= 2;
+        }
+    }
+    if constexpr (K >= 2)
+        if (no == 2) { const uint32_t a = ones[0], b = ones[1]; ones[0] = a ^ b; twos[nt++] = a & b; no = 1; }
+    n0 = ones[0];
+    // weight-2 column
+    if (nt >= 3) {
+        const uint32_t a = twos[nt - 1], b = twos[nt - 2], c = twos[nt - 3];
+        twos[nt - 3] = bitop3<0x96>(a, b, c);
+        fours[nf++] = bitop3<0xe8>(a, b, c);
+        nt -= 2;
+    }
+    if (nt == 2) { const uint32_t a = twos[0], b = twos[1]; twos[0] = a ^ b; fours[nf++] = a & b; nt = 1; }
+    n1 = nt ? twos[0] : 0u;
+    n2 = nf == 2 ? (fours[0] ^ fours[1]) : (nf == 1 ? fours[0] : 0u);       // n <= 7: no carry out of the weight-4 column
+}
+
+// replicas whose count n (planes n0, n1, n2) equals the constant N: one three-input function
+template <int NV>
+__device__ __forceinline__ uint32_t count_is(uint32_t n0, uint32_t n1, uint32_t n2)
+{
+    return bitop3<(1u << (((NV & 1) << 2) | (((NV >> 1) & 1) << 1) | ((NV >> 2) & 1)))>(n0, n1, n2);
+}
+
 // accept decision of one slot for the 32 replicas: planes n0..n2 of n = number of unsatisfied bonds, acc = accepted mask
 template <int K>
 __device__ __forceinline__ void slot_logic(const SlotDesc<K>& d, const SlotWords<K>& w, uint32_t& n0, uint32_t& n1, uint32_t& n2, uint32_t& acc)
@@ -464,26 +518,16 @@ __device__ __forceinline__ void slot_logic(const SlotDesc<K>& d, const SlotWords
         // n >= 2: dE <= 0, always accepted; n = 1 needs u < T_1; n = 0 needs u < T_0 (T_0 <= T_1: M_0 is a subset of M_1)
         acc = n1 | (desc_mask<K>(d, 1) & (n0 | desc_mask<K>(d, 0)));
     } else {
-        n0 = 0u; n1 = 0u;
+        uint32_t u[K];
 #pragma unroll
-        for (int k = 0; k < K; ++k) {
-            const uint32_t u = w.g[k] ^ s;
-            const uint32_t c0 = n0 & u;
-            n0 ^= u;
-            const uint32_t c1 = n1 & c0;
-            n1 ^= c0;
-            n2 ^= c1;
-        }
+        for (int k = 0; k < K; ++k) u[k] = w.g[k] ^ s;
+        count_planes<K>(u, n0, n1, n2);
         // classes n = 0..NT-1 have dE > 0 and need u < T_n; every other class is accepted (RRRMC.jl:39)
         uint32_t rej = 0u;
-#pragma unroll
-        for (int n = 0; n < NT; ++n) {
-            uint32_t e = ~desc_mask<K>(d, n);
-            e &= (n & 1) ? n0 : ~n0;
-            e &= (n & 2) ? n1 : ~n1;
-            if (K > 3) e &= (n & 4) ? n2 : ~n2;
-            rej |= e;
-        }
+        if constexpr (NT > 0) rej = bitop3<0xf2>(rej, desc_mask<K>(d, 0), count_is<0>(n0, n1, n2));        // rej | (~M_n & [n == class])
+        if constexpr (NT > 1) rej = bitop3<0xf2>(rej, desc_mask<K>(d, 1), count_is<1>(n0, n1, n2));
+        if constexpr (NT > 2) rej = bitop3<0xf2>(rej, desc_mask<K>(d, 2), count_is<2>(n0, n1, n2));
+        if constexpr (NT > 3) rej = bitop3<0xf2>(rej, desc_mask<K>(d, 3), count_is<3>(n0, n1, n2));
         acc = ~rej;
     }
 }
@@ -875,7 +919,7 @@ __global__ __launch_bounds__(kSweepThreads) void sweep_kernel(SweepParams P)
             RRRMC_T1
             __syncthreads();
         }
-    } else if (wave == kTallyWave) {
+    } else if (wave == kSwTallyWave) {
         // tally: lanes 0..31 own the running energy / accepted count of replica `lane`
         __builtin_amdgcn_s_setprio(2);
         TransposeConsts tc;
@@ -935,7 +979,7 @@ __global__ __launch_bounds__(kSweepThreads) void sweep_kernel(SweepParams P)
             __syncthreads();
         }
     } else {
-        const int pw = wave < kFixerWave ? wave - 2 : wave - 3;     // producer index 0 .. kProducerWaves-1
+        const int pw = sw_producer_index(wave);     // producer index 0 .. kProducerWaves-1
         // The chunk descriptor (scalar loads) and the slot words (one coalesced global load per task) are requested ahead of
         // time — the descriptor two steps, the slots one step before they are used — so a step starts computing right after the
         // barrier instead of waiting a microsecond for HBM/L2 (that latency was a third of a step).
@@ -1060,71 +1104,79 @@ struct ColorSweepParams {
     uint32_t always_mask;
     uint32_t k0, k1, group0;
     uint64_t sweep;           // global sweep index (1-based)
-    int N, nlist;
+    int N, nlist, G;          // G = replica groups of the context
     int64_t* acc_cur;         // [Rpad] accepted moves per replica (COUNT builds only)
 };
 
 // COUNT: also add every replica's accepted moves to P.acc_cur (32x32 bit transpose + popcount per wave, LDS atomics per workgroup,
 // 32 global atomics per workgroup) — the parity / acceptance-rate build; the plain build leaves the counters alone.
-template <int K, bool COUNT = false>
+// GPT = replica groups one thread updates (its site's neighbour row and couplings are loaded once, the gathers of all its groups are
+// in flight together): grid.y = ceil(G / GPT)
+template <int K, bool COUNT = false, int GPT = 1>
 __global__ __launch_bounds__(256) void colored_sweep_kernel(ColorSweepParams P)
 {
     constexpr int NT = SweepCfg<K>::NT;
     const int idx = blockIdx.x * 256 + threadIdx.x;
     const bool live = idx < P.nlist;
-    const uint32_t group = P.group0 + blockIdx.y;
-    uint32_t* sp = P.spins + (size_t)blockIdx.y * P.N;
     const int x = live ? P.list[idx] : 0;
-    const uint32_t s = sp[x];
-    uint32_t n0 = 0u, n1 = 0u, n2 = 0u;
+    int nb[K];
+    uint32_t sgn[K];
 #pragma unroll
-    for (int k = 0; k < K; ++k) {
-        const uint32_t u = s ^ sp[P.A[(size_t)x * K + k]] ^ (P.J[(size_t)x * K + k] < 0 ? 0xffffffffu : 0u);   // bond k unsatisfied
-        const uint32_t c0 = n0 & u;
-        n0 ^= u;
-        const uint32_t c1 = n1 & c0;
-        n1 ^= c0;
-        n2 ^= c1;
-    }
-    uint32_t lt[NT], eq[NT];
+    for (int k = 0; k < K; ++k) { nb[k] = P.A[(size_t)x * K + k]; sgn[k] = P.J[(size_t)x * K + k] < 0 ? 0xffffffffu : 0u; }
+    uint32_t s[GPT], u[GPT][K];
 #pragma unroll
-    for (int n = 0; n < NT; ++n) {
-        const bool always = (P.always_mask >> n) & 1u;
-        // only the replicas that are in class n need the comparison at all
-        uint32_t cls = (n & 1) ? n0 : ~n0;
-        cls &= (n & 2) ? n1 : ~n1;
-        if (K > 3) cls &= (n & 4) ? n2 : ~n2;
-        lt[n] = always ? 0xffffffffu : 0u;
-        eq[n] = (live && !always) ? cls : 0u;
+    for (int j = 0; j < GPT; ++j) {
+        const int gl = (int)blockIdx.y * GPT + j;
+        const uint32_t* sp = P.spins + (size_t)(gl < P.G ? gl : 0) * P.N;
+        s[j] = sp[x];
+#pragma unroll
+        for (int k = 0; k < K; ++k) u[j][k] = sp[nb[k]];
     }
     const uint32_t c3hi = (uint32_t)((P.sweep >> 32) & 0xffffu) << 16;
-    for (uint32_t pb = 0; pb < 16u; ++pb) {
-        if (!__any(any_set<NT>(eq))) break;
-        const Philox4 o = philox4x32_10((uint32_t)x, (uint32_t)P.sweep, group, TAG_SWEEP | (pb << 8) | c3hi, P.k0, P.k1);
-        refine_block<NT>(lt, eq, o, pb, P.taum);
-    }
-    uint32_t rej = 0u;
 #pragma unroll
-    for (int n = 0; n < NT; ++n) {
-        uint32_t e = ~lt[n];
-        e &= (n & 1) ? n0 : ~n0;
-        e &= (n & 2) ? n1 : ~n1;
-        if (K > 3) e &= (n & 4) ? n2 : ~n2;
-        rej |= e;
-    }
-    if (live) sp[x] = s ^ ~rej;
-    if constexpr (COUNT) {
-        __shared__ uint32_t s_acc[32];
-        if (threadIdx.x < 32) s_acc[threadIdx.x] = 0u;
-        __syncthreads();
-        TransposeConsts tc;
-        tc.init((int)(threadIdx.x & 63));
-        uint32_t c = (uint32_t)__popc(transpose32(live ? ~rej : 0u, tc));      // lane r (and r + 32): replica r's accepted moves in this wave half
-        c += (uint32_t)__shfl_xor((int)c, 32);
-        if ((threadIdx.x & 63) < 32 && c) atomicAdd(&s_acc[threadIdx.x & 31], c);
-        __syncthreads();
-        if (threadIdx.x < 32 && s_acc[threadIdx.x])
-            atomicAdd(reinterpret_cast<unsigned long long*>(P.acc_cur) + blockIdx.y * 32 + threadIdx.x, (unsigned long long)s_acc[threadIdx.x]);
+    for (int j = 0; j < GPT; ++j) {
+        const int gl = (int)blockIdx.y * GPT + j;
+        if (gl >= P.G) break;                       // block-uniform
+        const uint32_t group = P.group0 + (uint32_t)gl;
+        uint32_t n0, n1, n2, uu[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) uu[k] = xor3(s[j], u[j][k], sgn[k]);   // bond k unsatisfied
+        count_planes<K>(uu, n0, n1, n2);
+        uint32_t lt[NT], eq[NT], cls[NT];
+        // only the replicas that are in class n need the comparison at all
+        if constexpr (NT > 0) cls[0] = count_is<0>(n0, n1, n2);
+        if constexpr (NT > 1) cls[1] = count_is<1>(n0, n1, n2);
+        if constexpr (NT > 2) cls[2] = count_is<2>(n0, n1, n2);
+        if constexpr (NT > 3) cls[3] = count_is<3>(n0, n1, n2);
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+            const bool always = (P.always_mask >> n) & 1u;
+            lt[n] = always ? 0xffffffffu : 0u;
+            eq[n] = (live && !always) ? cls[n] : 0u;
+        }
+        for (uint32_t pb = 0; pb < 16u; ++pb) {
+            if (!__any(any_set<NT>(eq))) break;
+            const Philox4 o = philox4x32_10((uint32_t)x, (uint32_t)P.sweep, group, TAG_SWEEP | (pb << 8) | c3hi, P.k0, P.k1);
+            refine_block<NT>(lt, eq, o, pb, P.taum);
+        }
+        uint32_t rej = 0u;
+#pragma unroll
+        for (int n = 0; n < NT; ++n) rej = bitop3<0xf2>(rej, lt[n], cls[n]);        // rej | (~lt_n & [n == class])
+        if (live) P.spins[(size_t)gl * P.N + x] = s[j] ^ ~rej;
+        if constexpr (COUNT) {
+            __shared__ uint32_t s_acc[32];
+            __syncthreads();
+            if (threadIdx.x < 32) s_acc[threadIdx.x] = 0u;
+            __syncthreads();
+            TransposeConsts tc;
+            tc.init((int)(threadIdx.x & 63));
+            uint32_t c = (uint32_t)__popc(transpose32(live ? ~rej : 0u, tc));      // lane r (and r + 32): replica r's accepted moves in this wave half
+            c += (uint32_t)__shfl_xor((int)c, 32);
+            if ((threadIdx.x & 63) < 32 && c) atomicAdd(&s_acc[threadIdx.x & 31], c);
+            __syncthreads();
+            if (threadIdx.x < 32 && s_acc[threadIdx.x])
+                atomicAdd(reinterpret_cast<unsigned long long*>(P.acc_cur) + gl * 32 + threadIdx.x, (unsigned long long)s_acc[threadIdx.x]);
+        }
     }
 }
 
@@ -1149,15 +1201,10 @@ __global__ __launch_bounds__(256) void energy_bs_kernel(const uint32_t* __restri
         uint32_t n0 = 0u, n1 = 0u, n2 = 0u;
         if (x < N) {
             const uint32_t s = sp[x];
+            uint32_t u[K];
 #pragma unroll
-            for (int k = 0; k < K; ++k) {
-                const uint32_t u = s ^ sp[A[(size_t)x * K + k]] ^ (J[(size_t)x * K + k] < 0 ? 0xffffffffu : 0u);
-                const uint32_t c0 = n0 & u;
-                n0 ^= u;
-                const uint32_t c1 = n1 & c0;
-                n1 ^= c0;
-                n2 ^= c1;
-            }
+            for (int k = 0; k < K; ++k) u[k] = xor3(s, sp[A[(size_t)x * K + k]], J[(size_t)x * K + k] < 0 ? 0xffffffffu : 0u);
+            count_planes<K>(u, n0, n1, n2);
         }
         tot += (uint32_t)__popc(transpose32(n0, tc)) + ((uint32_t)__popc(transpose32(n1, tc)) << 1) + ((uint32_t)__popc(transpose32(n2, tc)) << 2);
     }
