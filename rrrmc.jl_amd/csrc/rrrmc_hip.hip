@@ -284,7 +284,9 @@ uint64_t threshold64(double p, bool* always)
     switch (k) { case 1: return F<1>; case 2: return F<2>; case 3: return F<3>; case 4: return F<4>; case 5: return F<5>;   \
                  case 6: return F<6>; case 7: return F<7>; case 8: return F<8>; default: return nullptr; }
 
-typedef void (*plan_fn)(ChunkDesc*, uint32_t*, uint32_t*, const int32_t*, int, int, uint32_t, uint32_t, uint64_t);
+typedef void (*plan_fn)(ChunkDesc*, uint32_t*, uint32_t*, const int32_t*, int, int, uint32_t, uint32_t, uint64_t, int);
+// rows of 64 slots per consumer batch of sweep_kernel<K>
+int sweep_rows_for_K(int K) { switch (K) { case 1: return sweep_rows<1>(); case 2: return sweep_rows<2>(); case 3: return sweep_rows<3>(); case 4: return sweep_rows<4>(); case 5: return sweep_rows<5>(); case 6: return sweep_rows<6>(); default: return sweep_rows<7>(); } }
 plan_fn plan_for_K(int K) { RRRMC_DISPATCH_UPTO7(K, plan_kernel) }
 
 typedef void (*plan_big_fn)(ChunkDesc*, uint32_t*, uint32_t*, const int32_t*, int, uint32_t, uint32_t, uint64_t);
@@ -1111,7 +1113,8 @@ int32_t rrrmc_standard_mc_async(rrrmc_ctx* ctx, double beta, int64_t iters, int6
                                ctx->d_chunks + bt.first, ctx->d_slots[b & 1], ctx->d_vecs[b & 1], ctx->d_A, (int)N, P.k0, P.k1, P.gbase);
         else
             hipLaunchKernelGGL(plan_for_K((int)K), dim3((unsigned)bt.n), dim3(kPlanThreads), ctx->plan_lds_bytes, ctx->plan_stream,
-                               ctx->d_chunks + bt.first, ctx->d_slots[b & 1], ctx->d_vecs[b & 1], ctx->d_A, (int)N, C, P.k0, P.k1, P.gbase);
+                               ctx->d_chunks + bt.first, ctx->d_slots[b & 1], ctx->d_vecs[b & 1], ctx->d_A, (int)N, C, P.k0, P.k1, P.gbase,
+                               sweep_rows_for_K((int)K) * kWave);
         HIP_TRY(ctx, hipGetLastError());
         HIP_TRY(ctx, hipEventRecord(ctx->ev_plan[b], ctx->plan_stream));
         return RRRMC_OK;

@@ -55,8 +55,15 @@ constexpr int kSwFixBlocks = 0;
 constexpr int kSwLeftMax = 128;                  // list capacity per chunk; lanes that find it full finish on their own
 constexpr int kPlanThreads = 256;
 constexpr int kMaxK = 7;                          // 3 bit planes for the unsatisfied-bond count
-constexpr int kRows = 4;                          // rows of 64 slots the consumer keeps in flight
-constexpr int kBatchSlots = kRows * kWave;
+// rows of 64 slots the consumer keeps in flight = the longest batch the planner cuts a dependency level into.  A batch costs the
+// consumer about 200 cycles whatever it holds (a dozen scalar instructions and two LDS round trips), so the first, long levels of a
+// chunk should be ONE batch each: as many rows as the register file takes without spilling (8 VGPRs per row at K = 3; measured at
+// config 2: 4 rows 8.99, 8 rows 8.73, 12 rows 8.46, 14 rows 8.34 ms per launch; 15 rows spill)
+#ifndef RRRMC_ROWS
+#define RRRMC_ROWS 14
+#endif
+// (K = 4: 8 rows, no change against 4; K >= 5: 6 rows measured 2 % slower than 4 — the rows are 15 VGPRs each there)
+template <int K> constexpr int sweep_rows() { return K <= 3 ? RRRMC_ROWS : (K == 4 ? (RRRMC_ROWS < 8 ? RRRMC_ROWS : 8) : (RRRMC_ROWS < 4 ? RRRMC_ROWS : 4)); }
 constexpr uint32_t kChunkSampleBefore = 1u;       // chunk flag: an energy sample is due before its first move
 
 struct ChunkDesc {
@@ -83,7 +90,7 @@ constexpr uint32_t kNoPred = 0xffffu;
 template <int K>
 __global__ __launch_bounds__(kPlanThreads) void plan_kernel(ChunkDesc* __restrict__ chunks, uint32_t* __restrict__ slots,
                                                             uint32_t* __restrict__ vecs, const int32_t* __restrict__ A,
-                                                            int N, int Cmax, uint32_t k0, uint32_t k1, uint64_t gbase)
+                                                            int N, int Cmax, uint32_t k0, uint32_t k1, uint64_t gbase, int batch_slots)
 {
     extern __shared__ uint32_t plds32[];
     // two phases share the first region: the site buckets (until the predecessors are known), then the level counters
@@ -180,8 +187,8 @@ __global__ __launch_bounds__(kPlanThreads) void plan_kernel(ChunkDesc* __restric
         for (uint32_t l = 1; l <= maxlvl; ++l) {
             s_start[l] = pos;
             uint32_t n = s_cnt[l], q = pos;
-            while (n > 0) {      // the consumer works on batches of <= kBatchSlots slots that lie inside one level
-                const uint32_t m = n < (uint32_t)kBatchSlots ? n : (uint32_t)kBatchSlots;
+            while (n > 0) {      // the consumer works on batches of <= batch_slots slots that lie inside one level
+                const uint32_t m = n < (uint32_t)batch_slots ? n : (uint32_t)batch_slots;      // the longest batch the consuming kernel takes
                 vecs[cd.slot_base + nvec++] = q | ((m - 1u) << 16);
                 q += m;
                 n -= m;
@@ -591,6 +598,19 @@ __device__ __forceinline__ void consume_rows(const uint4* __restrict__ desc, uin
     }
 }
 
+// consume_rows<NR> for the run-time row count `rows` in LO..HI (wave-uniform): binary search over the instantiations
+template <int K, int MODE, int LO, int HI>
+__device__ __forceinline__ void consume_dispatch(int rows, const uint4* __restrict__ desc, uint32_t* __restrict__ sp, uint4* __restrict__ tal,
+                                                 int C, int p0, int plast)
+{
+    if constexpr (LO >= HI) consume_rows<K, HI, MODE>(desc, sp, tal, C, p0, plast);
+    else {
+        constexpr int MID = (LO + HI) / 2;
+        if (rows <= MID) consume_dispatch<K, MODE, LO, MID>(rows, desc, sp, tal, C, p0, plast);
+        else consume_dispatch<K, MODE, MID + 1, HI>(rows, desc, sp, tal, C, p0, plast);
+    }
+}
+
 // The planner has already cut every dependency level into batches of <= kRows x 64 slots.  Inside a batch the
 // attempts commute, so all its descriptor loads, then all its gathers are issued before the logic and the stores
 // (the single consumer wave is latency-bound: this is its instruction-level parallelism).  A batch is branch-free
@@ -612,12 +632,10 @@ __device__ __forceinline__ void consume_chunk(const SweepParams& P, const ChunkD
             const uint32_t vd = __builtin_amdgcn_readlane(myvd, v);
             const int start = (int)(vd & 0xffffu), cm1 = (int)(vd >> 16);   // cm1 = slots - 1
             const int p0 = start + lane, plast = start + cm1;
-            switch (cm1 >> 6) {          // rows - 1 (wave-uniform; kWave = 64)
-                case 0: consume_rows<K, 1, MODE>(desc, sp, tal, C, p0, plast); break;
-                case 1: consume_rows<K, 2, MODE>(desc, sp, tal, C, p0, plast); break;
-                case 2: consume_rows<K, 3, MODE>(desc, sp, tal, C, p0, plast); break;
-                default: consume_rows<K, 4, MODE>(desc, sp, tal, C, p0, plast); break;
-            }
+            // rows of the batch (wave-uniform; kWave = 64).  Most batches are the short tail levels: one row is tested first, the rest is a
+            // binary tree — a flat switch over 14 cases costs the structurised code two scalar instructions per case on the way out
+            if (cm1 < kWave) consume_rows<K, 1, MODE>(desc, sp, tal, C, p0, plast);
+            else consume_dispatch<K, MODE, 2, (sweep_rows<K>() > 2 ? sweep_rows<K>() : 2)>((cm1 >> 6) + 1, desc, sp, tal, C, p0, plast);
         }
     }
 }

@@ -13,6 +13,8 @@ pkg = e.load_package()
 R, SEED = 8192, 0x5EED
 CASES = [(128, 3, 1.0), (1024, 3, 1.0), (2048, 3, 1.0), (4096, 3, 0.5), (4096, 3, 1.0), (4096, 3, 2.0), (4096, 4, 1.0), (4096, 6, 1.0),
          (8192, 3, 1.0), (10000, 3, 1.0), (16384, 3, 1.0), (24000, 3, 1.0), (32000, 3, 1.0)]
+if os.environ.get("RRRMC_SIZES"):          # e.g. RRRMC_SIZES="1024,3,1.0;4096,6,1.0"
+    CASES = [(int(a), int(b), float(c)) for a, b, c in (x.split(",") for x in os.environ["RRRMC_SIZES"].split(";"))]
 for N, K, beta in CASES:
     X = pkg.GraphRRG(N, K, seed=SEED)
     eng = pkg.Engine(X, R)
