@@ -8,7 +8,7 @@ Inputs
     (64 slots: 3 Philox4x32-10 blocks + the bit-sliced threshold refinement) — the producers execute ~85 % of the kernel's VALU
     wave-instructions, so their mix is taken as the dynamic mix;
   * profiles/r02/ubench_valu_rates.txt (tools/ubench/valu_rates.hip on the MI355X: ns per wave-instruction per SIMD with 8 waves/SIMD);
-  * profiles/r02/r02a_summary.txt (rocprofv3 --pmc passes of `bench.py --steps 3 --warmup 1`): SQ_INSTS_VALU per launch, GRBM_GUI_ACTIVE.
+  * profiles/r02/r02d_summary.txt (or the file named on the command line; rocprofv3 --pmc passes of `bench.py --steps 3 --warmup 1`): SQ_INSTS_VALU per launch, GRBM_GUI_ACTIVE.
 Output: profiles/r02/sweep31_isa_hist.txt and profiles/r02/valu_model.json (read by bench.py for roofline.valu)."""
 import collections
 import json
@@ -21,6 +21,7 @@ import tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PROF = os.path.join(ROOT, "profiles", "r02")
 SIMDS = 256 * 4
+SUMMARY = sys.argv[1] if len(sys.argv) > 1 else "r02d_summary.txt"      # the rocprofv3 summary of the build being modelled
 
 
 def kernel_isa():
@@ -67,7 +68,7 @@ def cost_ns(op, ns):
 
 
 def pmc():
-    txt = open(os.path.join(PROF, "r02a_summary.txt")).read()
+    txt = open(os.path.join(PROF, SUMMARY)).read()
     blk = lambda tag: txt[txt.index("[%s] void rrrmc::sweep_kernel<3, 1>" % tag):]
     val = lambda tag, name: float(re.search(r"%s\s+avg=([\d.e+]+)" % name, blk(tag)).group(1))
     ns = float(re.search(r"sweep_kernel<3, 1>\(rrrmc::SweepParams\)\s+n=\d+ avg_ns=(\d+)", txt).group(1))
@@ -107,7 +108,7 @@ def main():
     json.dump(model, open(os.path.join(PROF, "valu_model.json"), "w"), indent=1)
     traffic = {"hbm_bytes_per_launch": (2 * P["FETCH_SIZE_KB"] + P["WRITE_SIZE_KB"]) * 1024.0,
                "source": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes) of `bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-secondary`, "
-                         "profiles/r02/r02a_summary.txt; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 tallies 128-B requests at 64 B); counters are in KiB"}
+                         "profiles/r02/" + SUMMARY + "; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 tallies 128-B requests at 64 B); counters are in KiB"}
     json.dump(traffic, open(os.path.join(PROF, "traffic.json"), "w"), indent=1)
     with open(os.path.join(PROF, "sweep31_isa_hist.txt"), "w") as f:
         f.write("# opcode histogram of sweep_kernel<3, 1> (hipcc -O3 --offload-arch=gfx950 -S), static counts\n")
