@@ -477,6 +477,10 @@ def run_rank(args):
                                 "achieved": vm["valu_insts_per_launch"] * vm["mean_issue_cycles"] / cyc, "peak": vm["simds"],
                                 "unit": "busy SIMDs", "frac": vm["valu_insts_per_launch"] * vm["mean_issue_cycles"] / (vm["simds"] * cyc),
                                 "source": "profiles/r02/valu_model.json (SQ_INSTS_VALU per launch, ISA histogram, ubench issue costs; committed)"}
+                if vm.get("occupancy_factor_4_waves"):
+                    # the kernel runs 4 waves per SIMD (16-wave workgroups, one per CU): the producer task measured in isolation issues
+                    # 7 % slower there than at the 8 waves per SIMD the per-opcode costs were taken at (tools/ubench/producer_task.hip)
+                    roof["valu"]["frac_at_4_waves_per_simd"] = roof["valu"]["frac"] * vm["occupancy_factor_4_waves"]
             out["roofline"] = roof
             try:      # after the timed region: the box's own copy bandwidth, for reference only (peak stays the nominal figure)
                 bw = device_copy_bandwidth(pkg, local_rank)

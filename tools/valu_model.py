@@ -105,6 +105,19 @@ def main():
              "valu_busy_frac_under_rocprof": P["SQ_INSTS_VALU"] * mean_ns * 1e-9 / (SIMDS * P["rocprof_avg_ns"] * 1e-9),
              "note": "mean issue cost = the producer task's VALU mix (ISA histogram) x tools/ubench/valu_rates.hip (8 waves per SIMD); the producers execute "
                      "~85 % of the kernel's VALU wave-instructions; SQ_ACTIVE_INST_VALU is not used: on gfx950 it counts one quad-cycle per instruction"}
+    # the same task measured directly (tools/ubench/producer_task.hip: the kernel's own Philox + refinement code) at 8 waves per SIMD and
+    # at the 4 waves per SIMD sweep_kernel runs with (16 waves per workgroup, one workgroup per CU): the SIMD's real throughput on this
+    # dependent multiply / bit-op mix is lower at the kernel's occupancy
+    pt = os.path.join(PROF, "ubench_producer_task.txt")
+    if os.path.exists(pt):
+        meas = {}
+        for l in open(pt):
+            m = re.match(r"NT=2 blocks=3\s+(\d+) waves/SIMD:.*-> ([\d.]+) ns per task per SIMD", l)
+            if m:
+                meas[int(m.group(1))] = float(m.group(2))
+        if 4 in meas and 8 in meas:
+            model["producer_task_ubench_ns"] = {"waves_per_simd_4": meas[4], "waves_per_simd_8": meas[8], "waves_per_simd_1": meas.get(1)}
+            model["occupancy_factor_4_waves"] = meas[4] / meas[8]
     json.dump(model, open(os.path.join(PROF, "valu_model.json"), "w"), indent=1)
     traffic = {"hbm_bytes_per_launch": (2 * P["FETCH_SIZE_KB"] + P["WRITE_SIZE_KB"]) * 1024.0,
                "source": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes) of `bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-secondary`, "
