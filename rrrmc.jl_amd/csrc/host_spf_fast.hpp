@@ -184,7 +184,7 @@ int32_t spf_fast_mc_async(rrrmc_ctx* ctx, double beta, int64_t iters, int64_t st
         if (b >= 2) HIP_TRY(ctx, hipStreamWaitEvent(ctx->plan_stream, ctx->ev_sweep[2 * (b - 2) + 1], 0));
         hipLaunchKernelGGL(plan_for_K((int)K), dim3((unsigned)bt.n), dim3(kPlanThreads), ctx->pff_plan_lds, ctx->plan_stream,
                            ctx->d_chunks + bt.first, ctx->d_slots[b & 1], ctx->d_vecs[b & 1], ctx->d_A, (int)N, C, P.k0, P.k1, P.gbase,
-                           4 * kWave);      // spf_fast_kernel's consumer takes batches of up to four rows
+                           kFastRows * kWave);      // the longest batch spf_fast_kernel's consumer takes
         HIP_TRY(ctx, hipGetLastError());
         HIP_TRY(ctx, hipEventRecord(ctx->ev_plan[b], ctx->plan_stream));
         return RRRMC_OK;

@@ -252,6 +252,22 @@ __device__ __forceinline__ void fast_consume_rows(const uint4* __restrict__ desc
     }
 }
 
+#ifndef RRRMC_FAST_ROWS
+#define RRRMC_FAST_ROWS 8
+#endif
+constexpr int kFastRows = RRRMC_FAST_ROWS;          // rows of 64 slots per consumer batch (the planner is told: host_spf_fast.hpp)
+template <int K, int LO, int HI>
+__device__ __forceinline__ void fast_consume_dispatch(int rows, const uint4* __restrict__ desc, uint32_t* __restrict__ sp, uint32_t* __restrict__ tal,
+                                                      int C, int p0, int plast)
+{
+    if constexpr (LO >= HI) fast_consume_rows<K, HI>(desc, sp, tal, C, p0, plast);
+    else {
+        constexpr int MID = (LO + HI) / 2;
+        if (rows <= MID) fast_consume_dispatch<K, LO, MID>(rows, desc, sp, tal, C, p0, plast);
+        else fast_consume_dispatch<K, MID + 1, HI>(rows, desc, sp, tal, C, p0, plast);
+    }
+}
+
 template <int K>
 __device__ __forceinline__ void fast_consume_chunk(const FastParams& P, const ChunkDesc& cd, const uint4* __restrict__ desc,
                                                    uint32_t* __restrict__ sp, uint32_t* __restrict__ tal, int lane, uint32_t first_vd)
@@ -266,10 +282,9 @@ __device__ __forceinline__ void fast_consume_chunk(const FastParams& P, const Ch
             const uint32_t vd = __builtin_amdgcn_readlane(myvd, v);
             const int start = (int)(vd & 0xffffu), cm1 = (int)(vd >> 16);
             const int p0 = start + lane, plast = start + cm1;
-            if (cm1 >= 3 * kWave) fast_consume_rows<K, 4>(desc, sp, tal, C, p0, plast);
-            else if (cm1 >= 2 * kWave) fast_consume_rows<K, 3>(desc, sp, tal, C, p0, plast);
-            else if (cm1 >= kWave) fast_consume_rows<K, 2>(desc, sp, tal, C, p0, plast);
-            else fast_consume_rows<K, 1>(desc, sp, tal, C, p0, plast);
+            // one row first (the short tail levels), the rest by binary search over the instantiations (as consume_chunk, sparse_kernels.hpp)
+            if (cm1 < kWave) fast_consume_rows<K, 1>(desc, sp, tal, C, p0, plast);
+            else fast_consume_dispatch<K, 2, kFastRows>((cm1 >> 6) + 1, desc, sp, tal, C, p0, plast);
         }
     }
 }
