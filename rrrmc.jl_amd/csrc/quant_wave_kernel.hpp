@@ -31,6 +31,7 @@
 
 namespace rrrmc {
 
+constexpr int kQwTabDoubles = 112;      // exp[16], dE1[16], dE0(k) + dE1(a) [4][16], class weights w3[4] and f[4], spare
 constexpr int kQwMinGap = 512;          // smallest slack (entries per gap) the host accepts for this build: 6 pushes x 64 iterations fit
 
 struct QwLayout { size_t off_spos, off_sv, off_A, off_J, off_rng, off_tab, bytes; int cap; };
@@ -41,7 +42,7 @@ inline QwLayout qw_layout(int64_t N, int64_t W, int64_t Nk, int64_t K, size_t ld
     QwLayout L{};
     size_t o = (size_t)W * 4;
     L.off_spos = o; o += (((size_t)N * 2 + 7) & ~(size_t)7);
-    const size_t fixed_tail = (((size_t)Nk * K * 2 + 7) & ~(size_t)7) + (((size_t)Nk * K + 7) & ~(size_t)7) + 64 * 3 * 8 + 32 * 8 + 64;
+    const size_t fixed_tail = (((size_t)Nk * K * 2 + 7) & ~(size_t)7) + (((size_t)Nk * K + 7) & ~(size_t)7) + 64 * 3 * 8 + kQwTabDoubles * 8 + 64;
     const size_t room = lds_limit > o + fixed_tail ? lds_limit - o - fixed_tail : 0;
     int64_t cap = (int64_t)(room / 2) & ~(int64_t)3;
     if (cap > 2 * N) cap = 2 * N;
@@ -52,7 +53,7 @@ inline QwLayout qw_layout(int64_t N, int64_t W, int64_t Nk, int64_t K, size_t ld
     L.off_A = o; o += (((size_t)Nk * K * 2 + 7) & ~(size_t)7);
     L.off_J = o; o += (((size_t)Nk * K + 7) & ~(size_t)7);
     L.off_rng = o; o += 64 * 3 * 8;
-    L.off_tab = o; o += 32 * 8;
+    L.off_tab = o; o += kQwTabDoubles * 8;
     L.bytes = o;
     return L;
 }
@@ -92,6 +93,9 @@ __global__ __launch_bounds__(kRrrThreads) void rrr_quant_wave_kernel(RrrParams P
     double* l_rng = reinterpret_cast<double*>(lds8 + (X.off_rng + (uint32_t)vz));                    // [64][3]: class uniform, member u64 (as bits), accept uniform
     double* l_exp = reinterpret_cast<double*>(lds8 + (X.off_tab + (uint32_t)vz));                    // [16]: det_exp(-beta dE1(a)), a = sum_q J sigma sigma + K = 0, 2, .., 2K
     double* l_dE1 = l_exp + 16;                                                                       // [16]: dE1(a) = 2 (a - K) / M
+    double* l_dEt = l_exp + 32;                                                                       // [4][16]: dE0(k) + dE1(a), the energy change of an accepted move
+    double* l_w3 = l_exp + 96;                                                                        // [4]: class k's share of the running sum T3 (ft1 for k = 3, else 0)
+    double* l_fc = l_exp + 100;                                                                       // [4]: class weights get_class_f (1, 1, 1, ft1)
 
     uint32_t* g_sp = P.spins + (size_t)r * P.W;
     uint8_t* g_cls = P.cls + (size_t)r * P.N;
@@ -130,7 +134,13 @@ __global__ __launch_bounds__(kRrrThreads) void rrr_quant_wave_kernel(RrrParams P
         const double dE1 = (double)(2 * (2 * lane - P.K)) / (double)P.M;          // slice_res(slice_delta): sum_q +-J = 2 lane - K
         l_exp[2 * lane] = det_exp(-P.beta * dE1);
         l_dE1[2 * lane] = dE1;
+        // delta_energy of the move = dE0 (class k: -fourK, -0.0 / 0.0, fourK, DeltaE.jl:80-86) + dE1, added in that order (QT.jl:283-286)
+        for (int k = 0; k < 4; ++k) {
+            const double dE0 = k == 0 ? -0.0 : k == 1 ? -P.fourK : k == 2 ? 0.0 : P.fourK;
+            l_dEt[k * 16 + 2 * lane] = dE0 + dE1;
+        }
     }
+    if (lane < 4) { l_w3[lane] = lane == 3 ? P.ft1 : 0.0; l_fc[lane] = lane == 3 ? P.ft1 : 1.0; }
     uint32_t xge0_s = 0u;                   // bit a: x = -beta dE1(a) >= 0
     for (int q = 0; q <= P.K; ++q) xge0_s |= (-P.beta * ((double)(2 * (2 * q - P.K)) / (double)P.M) >= 0 ? 1u : 0u) << (2 * q);
     __syncthreads();
@@ -148,6 +158,10 @@ __global__ __launch_bounds__(kRrrThreads) void rrr_quant_wave_kernel(RrrParams P
     long long ns = 0, next_sample = P.step;
 
     auto bit_of = [&](int x) -> int { return (int)((l_sp[x >> 5] >> (x & 31)) & 1u); };
+    // every condition of the chain is wave-uniform, but its operands are kept in vector registers on purpose (see the header), so the
+    // compiler would wrap each `if` in an exec-mask region (save, branch if empty, restore); uni() turns it back into a scalar branch
+    // with all lanes active inside
+    auto uni = [](bool c) -> bool { return __ballot(c) != 0ull; };
     // ArraySet delete!(S, j) + push!(D, j) (ArraySets.jl:56-76) on the segmented array; p = the slot of j (absolute), act = the move
     // happens at all (a Trotter neighbour whose class does not change is skipped, DeltaE.jl:257).  Branch-free: an inactive move reads
     // and discards.  Returns the element that took j's place (the old last of S; j itself when j was the last) so that the caller can
@@ -157,13 +171,13 @@ __global__ __launch_bounds__(kRrrThreads) void rrr_quant_wave_kernel(RrrParams P
         const int eS = __builtin_amdgcn_readlane(ev, sS) + vz;
         const int last = (int)l_sv[eS - 1];
         const int eD = __builtin_amdgcn_readlane(ev, sD) + vz;
-        if (lane == 0 && act) {
+        if (act) {               // wave-uniform (the callers pass ballots); all lanes store the same values to the same addresses
             l_sv[p] = (uint16_t)last;
             l_spos[last] = (uint16_t)p;
             l_sv[eD] = (uint16_t)j;
             l_spos[j] = (uint16_t)eD;
+            ev = lane == sS ? eS - 1 : (lane == sD ? eD + 1 : ev);
         }
-        ev = !act ? ev : (lane == sS ? eS - 1 : (lane == sD ? eD + 1 : ev));
         return last;
     };
     // floor(u * t / 2^64) for t < 2^32 (rand(1:t) of the member pick, ArraySets.jl:83)
@@ -221,12 +235,15 @@ __global__ __launch_bounds__(kRrrThreads) void rrr_quant_wave_kernel(RrrParams P
 #ifdef RRRMC_STAMPS
         unsigned long long t_last = __builtin_readcyclecounter();
 #endif
+        // the next sample point as an index into this batch (-1: not in it): a 32-bit compare per iteration instead of a 64-bit one
+        auto sample_li = [&]() -> int { const long long d = next_sample - (base_it + 1); return d >= 0 && d < (long long)n_it ? (int)d : -1; };
+        int li_s = sample_li();
         for (int li = 0; li < n_it; ++li) {
-            const long long it = base_it + 1 + li;
-            if (it == next_sample) {
+            if (li == li_s) {
                 next_sample += P.step;
                 if (lane == 0) P.Es[ns * P.R + r] = E;
                 ns += 1;
+                li_s = sample_li();
             }
             const double u_cls = u_cls_n, u_acc = u_acc_n;
             const unsigned long long u_mem = (unsigned long long)__double_as_longlong(u_mem_n);
@@ -240,11 +257,10 @@ __global__ __launch_bounds__(kRrrThreads) void rrr_quant_wave_kernel(RrrParams P
             const double rr = u_cls * z;
             const double c0 = (double)t0, c1 = c0 + (double)t1, c2 = c1 + (double)t2, c3 = c2 + T3;
             int k = (rr < c0 ? 0 : 1) + (rr < c1 ? 0 : 1) + (rr < c2 ? 0 : 1);
-            if (!(rr < c3)) {      // r >= z by rounding: back off over the empty classes (DeltaE.jl:155-157)
+            if (uni(!(rr < c3))) {      // r >= z by rounding: back off over the empty classes (DeltaE.jl:155-157)
                 k = 3;
                 if (T3 == 0) { k = 2; if (t2 == 0) { k = 1; if (t1 == 0) k = 0; } }
             }
-            const double dE0 = k == 0 ? -0.0 : k == 1 ? -fourK : k == 2 ? 0.0 : fourK;
             const int sk = __builtin_amdgcn_readfirstlane(k);
             const int move = (int)l_sv[(__builtin_amdgcn_readlane(bv, sk) + vz) + (int)mulhi_u64_u32(u_mem, (uint32_t)(__builtin_amdgcn_readlane(tvv, sk) + vz))];
             QW_T(0)
@@ -281,31 +297,32 @@ __global__ __launch_bounds__(kRrrThreads) void rrr_quant_wave_kernel(RrrParams P
             // (both positive), so the quotient is only formed when it is needed
             auto accept = [&](double zz, double zp) -> bool {
                 const bool xok = (xge0 >> ai) & 1u;
-                if (zz >= zp && xok) return true;
+                if (uni(zz >= zp && xok)) return true;
                 const double c = zz / zp;
                 const double a = c * l_exp[ai];
                 return a >= 1 || u_acc < a;
             };
             // class weights: 1.0, except exp(-beta fourK) for class 3; only T3 is a running sum (x - 0.0 and x + 0.0 leave T3 >= +0 as it is)
-            auto w3 = [&](int kk) -> double { return kk == 3 ? ft1 : 0.0; };
-            auto fcls = [&](int kk) -> double { return kk == 3 ? ft1 : 1.0; };
-            auto flip_move = [&]() { if (lane == 0) l_sp[move >> 5] ^= 1u << (move & 31); };
-            const bool cha = k0a != k1a, chb = k0b != k1b;
+            auto w3 = [&](int kk) -> double { return l_w3[kk]; };
+            auto fcls = [&](int kk) -> double { return l_fc[kk]; };
+            auto flip_move = [&]() { l_sp[move >> 5] ^= 1u << (move & 31); };       // every lane: same word, same value
+            const bool cha = uni(k0a != k1a), chb = uni(k0b != k1b);       // scalar conditions (one ballot each)
 
             // Float64 bookkeeping of one apply_move! in the reference's order (first neighbour, second neighbour, moved spin,
             // DeltaE.jl:257-282); a skipped neighbour adds +-0.0, which changes neither T3 (>= +0) nor z' (> 0)
-            const double da0 = cha ? w3(k0a) : 0.0, da1 = cha ? w3(k1a) : 0.0, dza = cha ? fcls(k1a) - fcls(k0a) : 0.0;
-            const double db0 = chb ? w3(k0b) : 0.0, db1 = chb ? w3(k1b) : 0.0, dzb = chb ? fcls(k1b) - fcls(k0b) : 0.0;
+            // (an unchanged neighbour has k0 == k1: its weight difference is +0.0 by itself, and class 0's share of T3 is 0.0)
+            const double da0 = w3(cha ? k0a : 0), da1 = w3(cha ? k1a : 0), dza = fcls(k1a) - fcls(k0a);
+            const double db0 = w3(chb ? k0b : 0), db1 = w3(chb ? k1b : 0), dzb = fcls(k1b) - fcls(k0b);
             const double dm0 = w3(k0m), dm1 = w3(k1m), dzm = fcls(k1m) - fcls(k0m);
             bool acc = false;
-            if (acc_rate < staged_thr) {
+            if (uni(acc_rate < staged_thr)) {
                 // staged branch: step_rrr (RRRMC.jl:131-138) = compute_staged! + compute_reverse_probabilities!, apply_staged! on acceptance
                 staged_its += 1;
                 double T3p = T3, zp = z;
                 T3p -= da0; T3p += da1; zp += dza;
                 T3p -= db0; T3p += db1; zp += dzb;
                 T3p -= dm0; T3p += dm1; zp += dzm;
-                if (accept(z, zp)) {
+                if (uni(accept(z, zp))) {
                     flip_move();
                     const int la = set_move(nb0, k0a, k1a, pa, cha);
                     if (cha && la == nb1) pb = pa;
@@ -314,7 +331,7 @@ __global__ __launch_bounds__(kRrrThreads) void rrr_quant_wave_kernel(RrrParams P
                     if (chb && lb == move) pm = pb;
                     set_move(move, k0m, k1m, pm, true);
                     T3 = T3p; z = zp;
-                    E += dE0 + l_dE1[ai];
+                    E += l_dEt[k * 16 + ai];
                     accepted += 1;
                     acc = true;
                 }
@@ -338,8 +355,8 @@ __global__ __launch_bounds__(kRrrThreads) void rrr_quant_wave_kernel(RrrParams P
                 const bool ok = accept(z, zp);
                 z = zp;
                 QW_T(3)
-                if (ok) {
-                    E += dE0 + l_dE1[ai];
+                if (uni(ok)) {
+                    E += l_dEt[k * 16 + ai];
                     accepted += 1;
                     acc = true;
                 } else {
