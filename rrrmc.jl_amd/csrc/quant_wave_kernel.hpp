@@ -31,18 +31,25 @@
 
 namespace rrrmc {
 
-constexpr int kQwTabDoubles = 112;      // exp[16], dE1[16], dE0(k) + dE1(a) [4][16], class weights w3[4] and f[4], spare
+constexpr int kQwTabDoubles = 112;      // sparse slices: header 16, exp[16], dE1[16], dE0(k) + dE1(a) [4][16]
 constexpr int kQwMinGap = 512;          // smallest slack (entries per gap) the host accepts for this build: 6 pushes x 64 iterations fit
 
 struct QwLayout { size_t off_spos, off_sv, off_A, off_J, off_rng, off_tab, bytes; int cap; };
 
-// LDS layout for (N, W, Nk, K): cap = N + slack (slack as large as the LDS allows); cap < N + 4 * kQwMinGap means "does not fit"
-inline QwLayout qw_layout(int64_t N, int64_t W, int64_t Nk, int64_t K, size_t lds_limit)
+// table area, in doubles: header [w3 4][fc 4][dE0 4][4 spare: word 0 of them is the popcount accumulator of the GraphSK build], then
+// exp[TE], dE1[TE] and, for GraphRRG / GraphEA slices, dE0 + dE1 [4][16]; TE = 16 entries (a = 0 .. 2K) or 2 Nk (binary GraphSK slices:
+// the index is u + s_i Nk with u = |{j != i : J_ij xor s_j}|)
+inline size_t qw_tab_doubles(int64_t Nk, bool sk) { return sk ? (size_t)(16 + 4 * Nk) : (size_t)kQwTabDoubles; }
+
+// LDS layout for (N, W, Nk, K): cap = N + slack (slack as large as the LDS allows); cap < N + 4 * kQwMinGap means "does not fit".
+// sk: binary GraphSK slices (GraphQSKT) — no neighbour table, larger acceptance tables
+inline QwLayout qw_layout(int64_t N, int64_t W, int64_t Nk, int64_t K, size_t lds_limit, bool sk = false)
 {
     QwLayout L{};
     size_t o = (size_t)W * 4;
     L.off_spos = o; o += (((size_t)N * 2 + 7) & ~(size_t)7);
-    const size_t fixed_tail = (((size_t)Nk * K * 2 + 7) & ~(size_t)7) + (((size_t)Nk * K + 7) & ~(size_t)7) + 64 * 3 * 8 + kQwTabDoubles * 8 + 64;
+    const size_t szA = sk ? 0 : (((size_t)Nk * K * 2 + 7) & ~(size_t)7), szJ = sk ? 0 : (((size_t)Nk * K + 7) & ~(size_t)7);
+    const size_t fixed_tail = szA + szJ + 64 * 3 * 8 + qw_tab_doubles(Nk, sk) * 8 + 64;
     const size_t room = lds_limit > o + fixed_tail ? lds_limit - o - fixed_tail : 0;
     int64_t cap = (int64_t)(room / 2) & ~(int64_t)3;
     if (cap > 2 * N) cap = 2 * N;
@@ -50,10 +57,10 @@ inline QwLayout qw_layout(int64_t N, int64_t W, int64_t Nk, int64_t K, size_t ld
     L.cap = (int)cap;
     L.off_sv = o; o += (size_t)cap * 2;
     o = (o + 7) & ~(size_t)7;
-    L.off_A = o; o += (((size_t)Nk * K * 2 + 7) & ~(size_t)7);
-    L.off_J = o; o += (((size_t)Nk * K + 7) & ~(size_t)7);
+    L.off_A = o; o += szA;
+    L.off_J = o; o += szJ;
     L.off_rng = o; o += 64 * 3 * 8;
-    L.off_tab = o; o += kQwTabDoubles * 8;
+    L.off_tab = o; o += qw_tab_doubles(Nk, sk) * 8;
     L.bytes = o;
     return L;
 }
@@ -77,6 +84,10 @@ __device__ __forceinline__ int qw_class(int sk, int s1, int s2)
     return a + kQL * up;
 }
 
+// SK = false: GraphRRG / GraphEA slices (neighbour table and couplings in LDS); SK = true: binary GraphSK slices (GraphQSKT, the
+// reference's test_QIsing experiment): the slice's delta_energy is a popcount over the slice's words against row i of J (SK.jl:62-96),
+// one word per lane, the row read from HBM/L2 as soon as the move is known
+template <bool SK>
 __global__ __launch_bounds__(kRrrThreads) void rrr_quant_wave_kernel(RrrParams P, QwExtra X)
 {
     extern __shared__ uint32_t qw_lds[];
@@ -91,11 +102,15 @@ __global__ __launch_bounds__(kRrrThreads) void rrr_quant_wave_kernel(RrrParams P
     uint16_t* l_A = reinterpret_cast<uint16_t*>(lds8 + (X.off_A + (uint32_t)vz));                    // [Nk][K]
     int8_t* l_J = reinterpret_cast<int8_t*>(lds8 + (X.off_J + (uint32_t)vz));                        // [Nk][K]
     double* l_rng = reinterpret_cast<double*>(lds8 + (X.off_rng + (uint32_t)vz));                    // [64][3]: class uniform, member u64 (as bits), accept uniform
-    double* l_exp = reinterpret_cast<double*>(lds8 + (X.off_tab + (uint32_t)vz));                    // [16]: det_exp(-beta dE1(a)), a = sum_q J sigma sigma + K = 0, 2, .., 2K
-    double* l_dE1 = l_exp + 16;                                                                       // [16]: dE1(a) = 2 (a - K) / M
-    double* l_dEt = l_exp + 32;                                                                       // [4][16]: dE0(k) + dE1(a), the energy change of an accepted move
-    double* l_w3 = l_exp + 96;                                                                        // [4]: class k's share of the running sum T3 (ft1 for k = 3, else 0)
-    double* l_fc = l_exp + 100;                                                                       // [4]: class weights get_class_f (1, 1, 1, ft1)
+    double* l_hdr = reinterpret_cast<double*>(lds8 + (X.off_tab + (uint32_t)vz));
+    double* l_w3 = l_hdr;                                     // [4]: class k's share of the running sum T3 (ft1 for k = 3, else 0)
+    double* l_fc = l_hdr + 4;                                 // [4]: class weights get_class_f (1, 1, 1, ft1)
+    double* l_dE0 = l_hdr + 8;                                // [4]: delta_energy of GraphQT by class: -fourK, -0.0, 0.0, fourK (DeltaE.jl:80-86)
+    uint32_t* l_acc = reinterpret_cast<uint32_t*>(l_hdr + 12);     // SK: the popcount of the move's slice row, summed over the lanes
+    const int TE = SK ? 2 * P.Nk : 16;
+    double* l_exp = l_hdr + 16;                               // [TE]: det_exp(-beta dE1(a))
+    double* l_dE1 = l_exp + TE;                               // [TE]: dE1(a) = delta_energy_residual: 2 (a - K) / M, or ((2 (2 s_i - 1)(Nk - 1 - 2u)) / sqrt(Nk)) / M
+    double* l_dEt = l_dE1 + TE;                               // sparse slices only, [4][16]: dE0(k) + dE1(a), the energy change of an accepted move
 
     uint32_t* g_sp = P.spins + (size_t)r * P.W;
     uint8_t* g_cls = P.cls + (size_t)r * P.N;
@@ -129,20 +144,34 @@ __global__ __launch_bounds__(kRrrThreads) void rrr_quant_wave_kernel(RrrParams P
         const int tk = T_(k), bk = B_(k);
         for (int i = lane; i < tk; i += kRrrThreads) l_sv[bk + i] = g_sv[(size_t)k * P.N + i];
     }
-    for (int i = lane; i < P.Nk * P.K; i += kRrrThreads) { l_A[i] = (uint16_t)P.A[i]; l_J[i] = P.J[i]; }
-    if (lane <= P.K) {
-        const double dE1 = (double)(2 * (2 * lane - P.K)) / (double)P.M;          // slice_res(slice_delta): sum_q +-J = 2 lane - K
-        l_exp[2 * lane] = det_exp(-P.beta * dE1);
-        l_dE1[2 * lane] = dE1;
-        // delta_energy of the move = dE0 (class k: -fourK, -0.0 / 0.0, fourK, DeltaE.jl:80-86) + dE1, added in that order (QT.jl:283-286)
-        for (int k = 0; k < 4; ++k) {
-            const double dE0 = k == 0 ? -0.0 : k == 1 ? -P.fourK : k == 2 ? 0.0 : P.fourK;
-            l_dEt[k * 16 + 2 * lane] = dE0 + dE1;
-        }
+    if (lane < 4) {
+        l_w3[lane] = lane == 3 ? P.ft1 : 0.0; l_fc[lane] = lane == 3 ? P.ft1 : 1.0;
+        l_dE0[lane] = lane == 0 ? -0.0 : lane == 1 ? -P.fourK : lane == 2 ? 0.0 : P.fourK;
     }
-    if (lane < 4) { l_w3[lane] = lane == 3 ? P.ft1 : 0.0; l_fc[lane] = lane == 3 ? P.ft1 : 1.0; }
-    uint32_t xge0_s = 0u;                   // bit a: x = -beta dE1(a) >= 0
-    for (int q = 0; q <= P.K; ++q) xge0_s |= (-P.beta * ((double)(2 * (2 * q - P.K)) / (double)P.M) >= 0 ? 1u : 0u) << (2 * q);
+    uint32_t xge0_s = 0u;                   // sparse slices, bit a: x = -beta dE1(a) >= 0
+    if constexpr (SK) {
+        if (lane == 0) l_acc[0] = 0u;
+        for (int idx = lane; idx < 2 * P.Nk; idx += kRrrThreads) {
+            const int si = idx >= P.Nk ? 1 : 0, u = idx - si * P.Nk;
+            const int d = 2 * (2 * si - 1) * (P.Nk - 1 - 2 * u);              // lfields[i] (SK.jl:62-96), see slice_delta (rrr_kernels.hpp)
+            const double dE1 = ((double)d / P.sN) / (double)P.M;              // slice_res: QT.jl:270-281 over SK.jl:139
+            l_exp[idx] = det_exp(-P.beta * dE1);
+            l_dE1[idx] = dE1;
+        }
+    } else {
+        for (int i = lane; i < P.Nk * P.K; i += kRrrThreads) { l_A[i] = (uint16_t)P.A[i]; l_J[i] = P.J[i]; }
+        if (lane <= P.K) {
+            const double dE1 = (double)(2 * (2 * lane - P.K)) / (double)P.M;          // slice_res(slice_delta): sum_q +-J = 2 lane - K
+            l_exp[2 * lane] = det_exp(-P.beta * dE1);
+            l_dE1[2 * lane] = dE1;
+            // delta_energy of the move = dE0 (class k: -fourK, -0.0 / 0.0, fourK, DeltaE.jl:80-86) + dE1, added in that order (QT.jl:283-286)
+            for (int k = 0; k < 4; ++k) {
+                const double dE0 = k == 0 ? -0.0 : k == 1 ? -P.fourK : k == 2 ? 0.0 : P.fourK;
+                l_dEt[k * 16 + 2 * lane] = dE0 + dE1;
+            }
+        }
+        for (int q = 0; q <= P.K; ++q) xge0_s |= (-P.beta * ((double)(2 * (2 * q - P.K)) / (double)P.M) >= 0 ? 1u : 0u) << (2 * q);
+    }
     __syncthreads();
 
     // ---- the chain's state, in vector registers (see "Register discipline" above) --------------------------------------------------
@@ -151,6 +180,7 @@ __global__ __launch_bounds__(kRrrThreads) void rrr_quant_wave_kernel(RrrParams P
     const uint32_t nk_magic = (uint32_t)((0x100000000ull + (uint32_t)P.Nk - 1u) / (uint32_t)P.Nk) + (uint32_t)vz;
     const uint32_t rep = P.replica0 + (uint32_t)r;
     double vzd = __longlong_as_double(((long long)vz << 32) | (uint32_t)vz);      // +0.0, opaque
+    const double negbeta = -P.beta + vzd;
     const double ft1 = P.ft1 + vzd, fourK = P.fourK + vzd, lambda = P.lambda + vzd, one_m_lambda = (1 - P.lambda) + vzd, staged_thr = P.staged_thr + vzd;
     // T[0..2] == (double)t[0..2] exactly (weights 1.0); T3 and z are running sums (DeltaE.jl:90-103, 258-282)
     double T3 = P.T[(size_t)r * 4 + 3], z = P.zz[r], E = P.E_cur[r], acc_rate = P.acc_rate[r];
@@ -274,18 +304,40 @@ __global__ __launch_bounds__(kRrrThreads) void rrr_quant_wave_kernel(RrrParams P
             int j1 = myj - Nk; if (j1 < 0) j1 += N;
             int j2 = myj + Nk; if (j2 >= N) j2 -= N;
             const int qk = lane - 3;
-            const bool isq = qk >= 0 && qk < K;
-            const int aidx = isq ? is * K + qk : 0;
-            const int yq = (int)l_A[aidx];
-            const int jq = (int)l_J[aidx];
+            const bool isq = !SK && qk >= 0 && qk < K;
+            int yq = 0, jq = 0;
+            if constexpr (!SK) {
+                const int aidx = isq ? is * K + qk : 0;
+                yq = (int)l_A[aidx];
+                jq = (int)l_J[aidx];
+            } else {
+                // binary GraphSK slice: lane w holds word w of the slice (funnel-shifted out of the replica's bit vector: slices need not be
+                // word aligned) against word w of row `is` of J; the popcounts meet in one LDS word (read back before the accept test)
+                const int nw = (Nk + 31) >> 5;
+                const bool wl = lane < nw;
+                const int b0 = off + 32 * (wl ? lane : 0), qw = b0 >> 5, sh = b0 & 31, rem = Nk - 32 * (wl ? lane : 0);
+                uint32_t bits = l_sp[qw] >> sh;
+                if (sh && 32 * (qw + 1) < N) bits |= l_sp[qw + 1] << (32 - sh);
+                if (rem < 32) bits &= (1u << rem) - 1u;
+                const uint32_t jw = wl ? P.Jb[(size_t)is * (size_t)P.Wk + (size_t)lane] : 0u;
+                if (wl) atomicAdd(l_acc, (uint32_t)__popc(bits ^ jw));
+            }
             const int sj = bit_of(myj), s1 = bit_of(j1), s2 = bit_of(j2);
             const int my_k0 = qw_class(sj, s1, s2);
             const int my_k1 = qw_class(sj ^ (int)(myj == move), s1 ^ (int)(j1 == move), s2 ^ (int)(j2 == move));
             const int my_pos = (int)l_spos[myj];
             const int sy = bit_of(isq ? off + yq : 0);
             const int si = __builtin_amdgcn_readlane(sj, 2) + vz;                 // the moved spin, before the flip
-            // sum_q J_iq sigma_i sigma_y + K = 2 x (bonds with J_iq sigma_i sigma_y > 0): the table index (RRG.jl:236-244)
-            const int ai = 2 * __popcll(__ballot(isq && ((si == sy) == (jq > 0)))) + vz;
+            int ai;
+            if constexpr (!SK) {
+                // sum_q J_iq sigma_i sigma_y + K = 2 x (bonds with J_iq sigma_i sigma_y > 0): the table index (RRG.jl:236-244)
+                ai = 2 * __popcll(__ballot(isq && ((si == sy) == (jq > 0)))) + vz;
+            } else {
+                // u = |{j != i : J_ij xor s_j}| = popcount - s_i (J_ii = 0: position i contributes s_i); index u + s_i Nk
+                const int sc = (int)l_acc[0];
+                l_acc[0] = 0u;
+                ai = (sc - si) + si * Nk;
+            }
             const int k0a = __builtin_amdgcn_readlane(my_k0, 0) + vz, k1a = __builtin_amdgcn_readlane(my_k1, 0) + vz;
             const int k0b = __builtin_amdgcn_readlane(my_k0, 1) + vz, k1b = __builtin_amdgcn_readlane(my_k1, 1) + vz;
             const int k0m = __builtin_amdgcn_readlane(my_k0, 2) + vz, k1m = __builtin_amdgcn_readlane(my_k1, 2) + vz;
@@ -296,7 +348,9 @@ __global__ __launch_bounds__(kRrrThreads) void rrr_quant_wave_kernel(RrrParams P
             // accept(c, x) (RRRMC.jl:40-44) with c = z / zp, x = -beta dE1 (dE1 = delta_energy_residual, QT.jl:270-281): c >= 1 is z >= zp
             // (both positive), so the quotient is only formed when it is needed
             auto accept = [&](double zz, double zp) -> bool {
-                const bool xok = (xge0 >> ai) & 1u;
+                bool xok;
+                if constexpr (SK) xok = negbeta * l_dE1[ai] >= 0;      // x = -beta dE1 >= 0
+                else xok = (xge0 >> ai) & 1u;
                 if (uni(zz >= zp && xok)) return true;
                 const double c = zz / zp;
                 const double a = c * l_exp[ai];
@@ -331,7 +385,7 @@ __global__ __launch_bounds__(kRrrThreads) void rrr_quant_wave_kernel(RrrParams P
                     if (chb && lb == move) pm = pb;
                     set_move(move, k0m, k1m, pm, true);
                     T3 = T3p; z = zp;
-                    E += l_dEt[k * 16 + ai];
+                    E += SK ? l_dE0[k] + l_dE1[ai] : l_dEt[k * 16 + ai];
                     accepted += 1;
                     acc = true;
                 }
@@ -356,7 +410,7 @@ __global__ __launch_bounds__(kRrrThreads) void rrr_quant_wave_kernel(RrrParams P
                 z = zp;
                 QW_T(3)
                 if (uni(ok)) {
-                    E += l_dEt[k * 16 + ai];
+                    E += SK ? l_dE0[k] + l_dE1[ai] : l_dEt[k * 16 + ai];
                     accepted += 1;
                     acc = true;
                 } else {

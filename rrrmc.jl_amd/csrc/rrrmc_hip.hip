@@ -1529,7 +1529,7 @@ int32_t quant_mc_async(rrrmc_ctx* ctx, bool standard, double beta, double fourK,
     else {
         // Few replicas of a cache that fits LDS (config 5: 128 x (Nk = 1024, M = 32)): one WAVEFRONT per replica, wave-uniform chain,
         // the whole DeltaECache in LDS (quant_wave_kernel.hpp).  Many replicas: the thread-per-replica kernels fill the chip better.
-        QwLayout ql = qw_layout(ctx->N, ctx->qW, ctx->qNk, ctx->K, (size_t)kLdsLimit);
+        QwLayout ql = qw_layout(ctx->N, ctx->qW, ctx->qNk, ctx->K, (size_t)kLdsLimit, ctx->q_sk);
         if (const char* e = std::getenv("RRRMC_QUANT_WAVE_SLACK")) {      // tests: a small slack makes the segments re-space often
             const int64_t want = ctx->N + std::atoll(e);
             if (want >= ctx->N + 4 * kQwMinGap && want < ql.cap) ql.cap = (int)(want & ~(int64_t)3);
@@ -1537,13 +1537,14 @@ int32_t quant_mc_async(rrrmc_ctx* ctx, bool standard, double beta, double fourK,
         const char* no_wave = std::getenv("RRRMC_QUANT_NO_WAVE");        // timing experiments / cross-checks of the two builds
         int64_t wave_max_R = 2048;
         if (const char* e = std::getenv("RRRMC_QUANT_WAVE_MAX_R")) wave_max_R = std::atoll(e);
-        const bool wave_ok = !ctx->q_sk && !ctx->q_skn && ctx->K <= 7 && ctx->qNk <= 65535 && ql.cap >= ctx->N + 4 * kQwMinGap && ctx->R <= wave_max_R &&
-                             !(no_wave && no_wave[0] == '1');
+        // GraphRRG / GraphEA slices with K <= 7, or binary GraphSK slices of up to 2048 spins (one word of the slice per lane)
+        const bool wave_ok = !ctx->q_skn && (ctx->q_sk ? ctx->qNk <= 2048 : ctx->K <= 7) && ctx->qNk <= 65535 && ql.cap >= ctx->N + 4 * kQwMinGap &&
+                             ctx->R <= wave_max_R && !(no_wave && no_wave[0] == '1');
         // one replica per workgroup anyway (few replicas): stage its hot state in LDS if it fits (config 5: 115 KB)
         const size_t lds = rrr_quant_lds_bytes(ctx->N, ctx->qW, ctx->qNk, ctx->K);
         const char* no_lds = std::getenv("RRRMC_QUANT_NO_LDS");          // timing experiments
         if (wave_ok) {
-            HIP_TRY(ctx, raise_lds_attr(reinterpret_cast<const void*>(rrr_quant_wave_kernel), ql.bytes));
+            HIP_TRY(ctx, raise_lds_attr(ctx->q_sk ? reinterpret_cast<const void*>(rrr_quant_wave_kernel<true>) : reinterpret_cast<const void*>(rrr_quant_wave_kernel<false>), ql.bytes));
             QwExtra X{};
             X.cap = ql.cap; X.off_spos = (uint32_t)ql.off_spos; X.off_sv = (uint32_t)ql.off_sv; X.off_A = (uint32_t)ql.off_A;
             X.off_J = (uint32_t)ql.off_J; X.off_rng = (uint32_t)ql.off_rng; X.off_tab = (uint32_t)ql.off_tab;
@@ -1551,7 +1552,8 @@ int32_t quant_mc_async(rrrmc_ctx* ctx, bool standard, double beta, double fourK,
             if (!g_stamps) HIP_TRY(ctx, hipMalloc(&g_stamps, sizeof(unsigned long long) * 16 * (65536 + 4096)));
             X.stamps = g_stamps;
 #endif
-            hipLaunchKernelGGL(rrr_quant_wave_kernel, dim3((unsigned)ctx->R), dim3(kRrrThreads), ql.bytes, st, P, X);
+            if (ctx->q_sk) hipLaunchKernelGGL(rrr_quant_wave_kernel<true>, dim3((unsigned)ctx->R), dim3(kRrrThreads), ql.bytes, st, P, X);
+            else hipLaunchKernelGGL(rrr_quant_wave_kernel<false>, dim3((unsigned)ctx->R), dim3(kRrrThreads), ql.bytes, st, P, X);
         } else if (!ctx->q_skn && rrr_tpb(ctx->R) == 1 && lds <= (size_t)kLdsLimit && !(no_lds && no_lds[0] == '1')) {
             if (!ctx->q_lds_attr) {
                 HIP_TRY(ctx, raise_lds_attr(reinterpret_cast<const void*>(rrr_quant_kernel<true>), lds));
