@@ -75,6 +75,18 @@ __device__ __forceinline__ double qw_unid(double x)
     return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
 }
 
+// sum of v over the 64 lanes, the same value in every lane: xor-butterflies inside each row of 16 lanes by DPP (quad_perm 1032 / 2301,
+// row_half_mirror, row_mirror: no LDS traffic), the four row sums by v_readlane.  (32 same-address LDS atomics, the first version,
+// serialise in the LDS unit: 3 200 cycles per standardMC iteration.)
+__device__ __forceinline__ int qw_wave_sum(int v)
+{
+    v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, false);      // quad_perm:[1,0,3,2]
+    v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xf, 0xf, false);      // quad_perm:[2,3,0,1]
+    v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xf, 0xf, false);     // row_half_mirror
+    v += __builtin_amdgcn_update_dpp(0, v, 0x140, 0xf, 0xf, false);     // row_mirror
+    return __builtin_amdgcn_readlane(v, 0) + __builtin_amdgcn_readlane(v, 16) + __builtin_amdgcn_readlane(v, 32) + __builtin_amdgcn_readlane(v, 48);
+}
+
 // class a + 2 up of a spin from its bit and its two Trotter neighbours' bits (QT.jl:86-103, DeltaE.jl:80-86)
 __device__ __forceinline__ int qw_class(int sk, int s1, int s2)
 {
@@ -305,14 +317,14 @@ __global__ __launch_bounds__(kRrrThreads) void rrr_quant_wave_kernel(RrrParams P
             int j2 = myj + Nk; if (j2 >= N) j2 -= N;
             const int qk = lane - 3;
             const bool isq = !SK && qk >= 0 && qk < K;
-            int yq = 0, jq = 0;
+            int yq = 0, jq = 0, sk_pc = 0;
             if constexpr (!SK) {
                 const int aidx = isq ? is * K + qk : 0;
                 yq = (int)l_A[aidx];
                 jq = (int)l_J[aidx];
             } else {
                 // binary GraphSK slice: lane w holds word w of the slice (funnel-shifted out of the replica's bit vector: slices need not be
-                // word aligned) against word w of row `is` of J; the popcounts meet in one LDS word (read back before the accept test)
+                // word aligned) against word w of row `is` of J (HBM/L2: the load is consumed after the re-classification below)
                 const int nw = (Nk + 31) >> 5;
                 const bool wl = lane < nw;
                 const int b0 = off + 32 * (wl ? lane : 0), qw = b0 >> 5, sh = b0 & 31, rem = Nk - 32 * (wl ? lane : 0);
@@ -320,7 +332,7 @@ __global__ __launch_bounds__(kRrrThreads) void rrr_quant_wave_kernel(RrrParams P
                 if (sh && 32 * (qw + 1) < N) bits |= l_sp[qw + 1] << (32 - sh);
                 if (rem < 32) bits &= (1u << rem) - 1u;
                 const uint32_t jw = wl ? P.Jb[(size_t)is * (size_t)P.Wk + (size_t)lane] : 0u;
-                if (wl) atomicAdd(l_acc, (uint32_t)__popc(bits ^ jw));
+                sk_pc = wl ? (int)__popc(bits ^ jw) : 0;
             }
             const int sj = bit_of(myj), s1 = bit_of(j1), s2 = bit_of(j2);
             const int my_k0 = qw_class(sj, s1, s2);
@@ -334,8 +346,7 @@ __global__ __launch_bounds__(kRrrThreads) void rrr_quant_wave_kernel(RrrParams P
                 ai = 2 * __popcll(__ballot(isq && ((si == sy) == (jq > 0)))) + vz;
             } else {
                 // u = |{j != i : J_ij xor s_j}| = popcount - s_i (J_ii = 0: position i contributes s_i); index u + s_i Nk
-                const int sc = (int)l_acc[0];
-                l_acc[0] = 0u;
+                const int sc = qw_wave_sum(sk_pc) + vz;
                 ai = (sc - si) + si * Nk;
             }
             const int k0a = __builtin_amdgcn_readlane(my_k0, 0) + vz, k1a = __builtin_amdgcn_readlane(my_k1, 0) + vz;
@@ -463,6 +474,138 @@ __global__ __launch_bounds__(kRrrThreads) void rrr_quant_wave_kernel(RrrParams P
         P.T[(size_t)r * 4 + 0] = (double)T_(0); P.T[(size_t)r * 4 + 1] = (double)T_(1); P.T[(size_t)r * 4 + 2] = (double)T_(2); P.T[(size_t)r * 4 + 3] = T3;
         P.zz[r] = z; P.E_cur[r] = E; P.acc_rate[r] = acc_rate;
         P.stats[(size_t)r * 2] = accepted; P.stats[(size_t)r * 2 + 1] = staged_its;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// standardMC (src/RRRMC.jl:81-127) on a GraphQuant, one wavefront per replica — the Metropolis side of the reference's test_QIsing
+// experiment (scripts/scripts.jl:766-863), which runs few replicas: one thread per replica (quant_standard_kernel) leaves the chip idle.
+// The chain is state independent up to the accept test, so the wave prepares 64 iterations at a time, one per lane: the site (SITE
+// stream), the acceptance uniform (ACCEPT_F64 stream) and — binary GraphSK slices — the site's row of J, fetched into LDS.  Then the
+// 64 iterations run wave-uniformly: three spin bits for GraphQT's delta_energy, the slice's delta_energy lane-parallel (one word of the
+// slice per lane against the row of J, or one bond of the neighbour table per lane), delta_energy and exp(-beta dE) from tables over
+// (Trotter term, slice term), the bit flip.  Bit-identical to quant_standard_kernel: the tables hold the values of its own expressions.
+// LDS: spins [W], rows [64][Wk] (SK), A / J (sparse slices), dE [3][TE], exp(-beta dE) [3][TE].
+// ---------------------------------------------------------------------------------------------------
+struct QsLayout { size_t off_rows, off_A, off_J, off_de, off_ex, off_acc, bytes; int TE; };
+inline QsLayout qs_layout(int64_t W, int64_t Nk, int64_t K, int64_t Wk, bool sk)
+{
+    QsLayout L{};
+    size_t o = ((size_t)W * 4 + 7) & ~(size_t)7;
+    L.off_rows = o; o += sk ? (size_t)64 * Wk * 4 : 0;
+    L.off_A = o; o += sk ? 0 : (((size_t)Nk * K * 2 + 7) & ~(size_t)7);
+    L.off_J = o; o += sk ? 0 : (((size_t)Nk * K + 7) & ~(size_t)7);
+    L.TE = sk ? (int)(2 * Nk) : 16;
+    L.off_de = o; o += (size_t)3 * L.TE * 8;
+    L.off_ex = o; o += (size_t)3 * L.TE * 8;
+    L.off_acc = o; o += 8;
+    L.bytes = o;
+    return L;
+}
+struct QsExtra { uint32_t off_rows, off_A, off_J, off_de, off_ex, off_acc; int TE; };
+
+template <bool SK>
+__global__ __launch_bounds__(kRrrThreads) void quant_standard_wave_kernel(RrrParams P, QsExtra X)
+{
+    extern __shared__ uint32_t qs_lds[];
+    unsigned char* lds8 = reinterpret_cast<unsigned char*>(qs_lds);
+    const int lane = (int)threadIdx.x, r = (int)blockIdx.x;
+    uint32_t* l_sp = qs_lds;                                                     // [W]
+    uint32_t* l_rows = reinterpret_cast<uint32_t*>(lds8 + X.off_rows);           // [64][Wk]  (SK)
+    uint16_t* l_A = reinterpret_cast<uint16_t*>(lds8 + X.off_A);                 // [Nk][K]   (sparse slices)
+    int8_t* l_J = reinterpret_cast<int8_t*>(lds8 + X.off_J);
+    double* l_de = reinterpret_cast<double*>(lds8 + X.off_de);                   // [3][TE]: delta_energy for (qt_delta + 1, slice index)
+    double* l_ex = reinterpret_cast<double*>(lds8 + X.off_ex);                   // [3][TE]: det_exp(-beta delta_energy)
+    uint32_t* l_acc = reinterpret_cast<uint32_t*>(lds8 + X.off_acc);
+    const int TE = X.TE, N = P.N, Nk = P.Nk, K = P.K;
+    uint32_t* g_sp = P.spins + (size_t)r * P.W;
+    for (int i = lane; i < P.W; i += kRrrThreads) l_sp[i] = g_sp[i];
+    if constexpr (!SK)
+        for (int i = lane; i < Nk * K; i += kRrrThreads) { l_A[i] = (uint16_t)P.A[i]; l_J[i] = P.J[i]; }
+    // the tables: exactly quant_standard_kernel's expressions (dE = (double)qt_delta * fourK + residual, x = -beta dE)
+    for (int idx = lane; idx < 3 * TE; idx += kRrrThreads) {
+        const int d0 = idx / TE - 1, a = idx - (d0 + 1) * TE;
+        double res;
+        if constexpr (SK) {
+            const int si = a >= Nk ? 1 : 0, u = a - si * Nk;
+            const int d = 2 * (2 * si - 1) * (Nk - 1 - 2 * u);
+            res = ((double)d / P.sN) / (double)P.M;
+        } else {
+            res = (double)(2 * (a - K)) / (double)P.M;       // a = sum_q J sigma sigma + K (only even a <= 2K occur)
+        }
+        const double dE = (double)d0 * P.fourK + res;
+        l_de[idx] = dE;
+        l_ex[idx] = det_exp(-P.beta * dE);
+    }
+    if (lane == 0) l_acc[0] = 0u;
+    __syncthreads();
+
+    const uint32_t rep = P.replica0 + (uint32_t)r;
+    const uint32_t nk_magic = (uint32_t)((0x100000000ull + (uint32_t)Nk - 1u) / (uint32_t)Nk);
+    double E = P.E_cur[r];
+    long long accepted = 0, ns = 0, next_sample = P.step;
+    auto bit_of = [&](int x) -> int { return (int)((l_sp[x >> 5] >> (x & 31)) & 1u); };
+    for (long long base_it = 0; base_it < P.iters; base_it += kRrrThreads) {
+        const int n_it = (int)(base_it + kRrrThreads < P.iters ? kRrrThreads : P.iters - base_it);
+        // lane j: iteration base_it + 1 + j
+        const uint64_t gl = P.g0 + (uint64_t)(base_it + 1 + (long long)lane);
+        const int mv_l = (int)site_of(P.k0, P.k1, gl, (uint32_t)N);
+        const double u_l = rand53(P.k0, P.k1, gl, rep);
+        const uint32_t u_lo = (uint32_t)(unsigned long long)__double_as_longlong(u_l), u_hi = (uint32_t)((unsigned long long)__double_as_longlong(u_l) >> 32);
+        if constexpr (SK) {
+            // rows of J of the 64 sites: lane w fetches word w of row j, j = 0 .. 63
+            const int nw = (Nk + 31) >> 5;
+            __syncthreads();
+            for (int j = 0; j < n_it; ++j) {
+                const int mvj = __builtin_amdgcn_readlane(mv_l, j);
+                const int ksj = (int)__umulhi((uint32_t)mvj, nk_magic), isj = mvj - ksj * Nk;
+                if (lane < nw) l_rows[j * P.Wk + lane] = P.Jb[(size_t)isj * (size_t)P.Wk + (size_t)lane];
+            }
+            __syncthreads();
+        }
+        for (int j = 0; j < n_it; ++j) {
+            const long long it = base_it + 1 + j;
+            if (it == next_sample) { next_sample += P.step; if (lane == 0) P.Es[ns * P.R + r] = E; ns += 1; }
+            const int move = __builtin_amdgcn_readlane(mv_l, j);
+            const uint32_t ulo = (uint32_t)__builtin_amdgcn_readlane((int)u_lo, j), uhi = (uint32_t)__builtin_amdgcn_readlane((int)u_hi, j);
+            const double u = __longlong_as_double((long long)(((unsigned long long)uhi << 32) | ulo));
+            const int j1 = move - Nk + (move < Nk ? N : 0), j2 = move + Nk - (move + Nk >= N ? N : 0);
+            const int sk = bit_of(move), s1 = bit_of(j1), s2 = bit_of(j2);
+            const int d0 = (sk == s1) - (sk != s2);                               // qt_delta (QT.jl:86-103)
+            const int ks = (int)__umulhi((uint32_t)move, nk_magic), is = move - ks * Nk, off = ks * Nk;
+            int a;
+            if constexpr (SK) {
+                const int nw = (Nk + 31) >> 5;
+                const bool wl = lane < nw;
+                const int b0 = off + 32 * (wl ? lane : 0), qw = b0 >> 5, sh = b0 & 31, rem = Nk - 32 * (wl ? lane : 0);
+                uint32_t bits = l_sp[qw] >> sh;
+                if (sh && 32 * (qw + 1) < N) bits |= l_sp[qw + 1] << (32 - sh);
+                if (rem < 32) bits &= (1u << rem) - 1u;
+                const int sc = qw_wave_sum(wl ? (int)__popc(bits ^ l_rows[j * P.Wk + lane]) : 0);
+                a = (sc - sk) + sk * Nk;
+            } else {
+                const bool isq = lane < K;
+                const int aidx = isq ? is * K + lane : 0;
+                const int yq = (int)l_A[aidx], jq = (int)l_J[aidx];
+                const int sy = bit_of(isq ? off + yq : 0);
+                a = 2 * __popcll(__ballot(isq && ((sk == sy) == (jq > 0))));
+            }
+            const int ci = (d0 + 1) * TE + a;
+            const double dE = l_de[ci];
+            const double x = -P.beta * dE;
+            const bool acc = (x >= 0.0) || (u < l_ex[ci]);                        // RRRMC.jl:39
+            if (__ballot(acc) != 0ull) {                                          // wave-uniform
+                l_sp[move >> 5] ^= 1u << (move & 31);                             // every lane: same word, same value
+                E += dE;
+                accepted += 1;
+            }
+        }
+    }
+    __syncthreads();
+    for (int i = lane; i < P.W; i += kRrrThreads) g_sp[i] = l_sp[i];
+    if (lane == 0) {
+        P.E_cur[r] = E;
+        P.stats[(size_t)r * 2] = accepted; P.stats[(size_t)r * 2 + 1] = 0;
     }
 }
 

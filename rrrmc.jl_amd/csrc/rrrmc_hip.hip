@@ -1525,8 +1525,30 @@ int32_t quant_mc_async(rrrmc_ctx* ctx, bool standard, double beta, double fourK,
     P.lambda = staged_thr_fact / (double)ctx->N;              // RRRMC.jl:243
     P.g0 = ctx->it_done; P.iters = iters; P.step = step;
     HIP_TRY(ctx, hipEventRecord(ctx->ev_sweep[0], st));
-    if (standard) hipLaunchKernelGGL(quant_standard_kernel, dim3(rrr_blocks(ctx->R)), dim3(rrr_tpb(ctx->R)), 0, st, P);
-    else {
+    if (standard) {
+        // few replicas (the reference's test_QIsing runs a handful): one wavefront per replica, 64 iterations prepared at a time
+        // (quant_standard_wave_kernel); many replicas: one thread per replica fills the chip better
+        const QsLayout sl = qs_layout(ctx->qW, ctx->qNk, ctx->K, ctx->q_Wk, ctx->q_sk);
+        const char* no_wave = std::getenv("RRRMC_QUANT_NO_WAVE");        // timing experiments / cross-checks of the two builds
+        int64_t wave_max_R = 2048;
+        if (const char* e = std::getenv("RRRMC_QUANT_WAVE_MAX_R")) wave_max_R = std::atoll(e);
+        const bool wave_ok = !ctx->q_skn && (ctx->q_sk ? ctx->qNk <= 2048 : ctx->K <= 64) && sl.bytes <= (size_t)kLdsLimit && ctx->R <= wave_max_R &&
+                             !(no_wave && no_wave[0] == '1');
+        if (wave_ok) {
+            QsExtra X{};
+            X.off_rows = (uint32_t)sl.off_rows; X.off_A = (uint32_t)sl.off_A; X.off_J = (uint32_t)sl.off_J; X.off_de = (uint32_t)sl.off_de;
+            X.off_ex = (uint32_t)sl.off_ex; X.off_acc = (uint32_t)sl.off_acc; X.TE = sl.TE;
+            if (ctx->q_sk) {
+                HIP_TRY(ctx, raise_lds_attr(reinterpret_cast<const void*>(quant_standard_wave_kernel<true>), sl.bytes));
+                hipLaunchKernelGGL(quant_standard_wave_kernel<true>, dim3((unsigned)ctx->R), dim3(kRrrThreads), sl.bytes, st, P, X);
+            } else {
+                HIP_TRY(ctx, raise_lds_attr(reinterpret_cast<const void*>(quant_standard_wave_kernel<false>), sl.bytes));
+                hipLaunchKernelGGL(quant_standard_wave_kernel<false>, dim3((unsigned)ctx->R), dim3(kRrrThreads), sl.bytes, st, P, X);
+            }
+        } else {
+            hipLaunchKernelGGL(quant_standard_kernel, dim3(rrr_blocks(ctx->R)), dim3(rrr_tpb(ctx->R)), 0, st, P);
+        }
+    } else {
         // Few replicas of a cache that fits LDS (config 5: 128 x (Nk = 1024, M = 32)): one WAVEFRONT per replica, wave-uniform chain,
         // the whole DeltaECache in LDS (quant_wave_kernel.hpp).  Many replicas: the thread-per-replica kernels fill the chip better.
         QwLayout ql = qw_layout(ctx->N, ctx->qW, ctx->qNk, ctx->K, (size_t)kLdsLimit, ctx->q_sk);

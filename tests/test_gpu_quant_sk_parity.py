@@ -191,3 +191,36 @@ def test_cont_samplers_on_graph_quant_over_dense_slices(pkg, oracle, kind, Nk, M
         assert (Ew[r] == w[0]).all() and (C2.s[r] == w[1]).all() and mw[r] == w[2][0] and tw[r] == w[3]
         e = oracle.extremal_opt_quant_dense(Nk, M, X.fourK, 1.4, eo_iters, 100, seed, C0.s[r], replica=r, **kw)
         assert (Ee[r] == e[0]).all() and (C3.s[r] == e[1]).all() and Emin[r] == e[2] and (Cmin.s[r] == e[3]).all() and itmin[r] == e[4]
+
+
+@pytest.mark.parametrize("slices,Nk,M,R", [("sk", 10, 8, 5), ("sk", 70, 6, 3), ("sk", 128, 5, 4), ("rrg", 96, 12, 6), ("ea2x3", 8, 6, 5)])
+def test_quant_wave_builds_equal_thread_builds(pkg, slices, Nk, M, R, monkeypatch):
+    """standardMC and rrrMC on a GraphQuant have two builds each: one wavefront per replica (few replicas; binary GraphSK slices: one
+    word of the slice per lane, slices that are not word aligned included) and one thread per replica (RRRMC_QUANT_NO_WAVE=1).
+    Same chains bit for bit, hooked (resumed) standardMC calls included."""
+    seed, beta, Gamma = 90210 + Nk, 2.0, 0.4
+    if slices == "sk":
+        X = pkg.GraphQSKT(Nk, M, Gamma, beta, seed=seed)
+    elif slices == "rrg":
+        X = pkg.GraphQuant(pkg.GraphRRG(Nk, 3, seed=seed), M, Gamma, beta)
+    else:
+        X = pkg.GraphQuant(pkg.GraphEA(2, 3, seed=seed), M, Gamma, beta)
+
+    def run():
+        with pkg.Engine(X, R) as eng:
+            eng.seed(seed)
+            eng.init_spins_random()
+            a = eng.standard_mc(beta, 5000, 100)
+            c1 = eng.get_config().s.copy()
+            b = eng.standard_mc(beta, 777, 7)               # continues the streams; a batch of 64 iterations ends inside the call
+            c2 = eng.get_config().s.copy()
+            c = eng.rrr_mc(beta, 3000, 100)
+            c3 = eng.get_config().s.copy()
+            return a[0], a[1], c1, b[0], b[1], c2, c[0], c[1], c3
+
+    wave = run()
+    monkeypatch.setenv("RRRMC_QUANT_NO_WAVE", "1")
+    thread = run()
+    for x, y in zip(wave, thread):
+        assert (np.asarray(x) == np.asarray(y)).all()
+    assert wave[1].sum() > 0 and wave[7].sum() > 0
