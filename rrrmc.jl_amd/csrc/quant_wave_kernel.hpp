@@ -96,6 +96,21 @@ __device__ __forceinline__ int qw_class(int sk, int s1, int s2)
     return a + kQL * up;
 }
 
+// qw_class as a table: entry (sk | s1 << 1 | s2 << 2), two bits each
+constexpr int qw_class_c(int sk, int s1, int s2)
+{
+    const int d = (sk == s1 ? 1 : 0) - (sk != s2 ? 1 : 0);
+    return (d != 0 ? 1 : 0) + 2 * ((d > 0 || (d == 0 && sk == 1)) ? 1 : 0);
+}
+constexpr uint32_t qw_class_lut()
+{
+    uint32_t t = 0;
+    for (int i = 0; i < 8; ++i) t |= (uint32_t)qw_class_c(i & 1, (i >> 1) & 1, (i >> 2) & 1) << (2 * i);
+    return t;
+}
+constexpr uint32_t kQwClassLut = qw_class_lut();
+static_assert(kQL == 2, "two levels of allDE(GraphQT)");
+
 // SK = false: GraphRRG / GraphEA slices (neighbour table and couplings in LDS); SK = true: binary GraphSK slices (GraphQSKT, the
 // reference's test_QIsing experiment): the slice's delta_energy is a popcount over the slice's words against row i of J (SK.jl:62-96),
 // one word per lane, the row read from HBM/L2 as soon as the move is known
@@ -191,6 +206,7 @@ __global__ __launch_bounds__(kRrrThreads) void rrr_quant_wave_kernel(RrrParams P
     const uint32_t xge0 = xge0_s + (uint32_t)vz;
     const uint32_t nk_magic = (uint32_t)((0x100000000ull + (uint32_t)P.Nk - 1u) / (uint32_t)P.Nk) + (uint32_t)vz;
     const uint32_t rep = P.replica0 + (uint32_t)r;
+    const int fmask = lane == 0 ? 4 : lane == 1 ? 2 : 1;       // which bit of (sj, s1, s2) is the moved spin, for lanes 0 (nb0), 1 (nb1), 2.. (move)
     double vzd = __longlong_as_double(((long long)vz << 32) | (uint32_t)vz);      // +0.0, opaque
     const double negbeta = -P.beta + vzd;
     const double ft1 = P.ft1 + vzd, fourK = P.fourK + vzd, lambda = P.lambda + vzd, one_m_lambda = (1 - P.lambda) + vzd, staged_thr = P.staged_thr + vzd;
@@ -335,8 +351,11 @@ __global__ __launch_bounds__(kRrrThreads) void rrr_quant_wave_kernel(RrrParams P
                 sk_pc = wl ? (int)__popc(bits ^ jw) : 0;
             }
             const int sj = bit_of(myj), s1 = bit_of(j1), s2 = bit_of(j2);
-            const int my_k0 = qw_class(sj, s1, s2);
-            const int my_k1 = qw_class(sj ^ (int)(myj == move), s1 ^ (int)(j1 == move), s2 ^ (int)(j2 == move));
+            // the class before and after the flip from an 8-entry table in a constant (qw_class over the three bits); which of a lane's
+            // three bits is the moved spin is a lane constant: nb0's upper neighbour, nb1's lower neighbour, the spin itself (M > 2)
+            const int cidx = sj | (s1 << 1) | (s2 << 2);
+            const int my_k0 = (int)((kQwClassLut >> (2 * cidx)) & 3u);
+            const int my_k1 = (int)((kQwClassLut >> (2 * (cidx ^ fmask))) & 3u);
             const int my_pos = (int)l_spos[myj];
             const int sy = bit_of(isq ? off + yq : 0);
             const int si = __builtin_amdgcn_readlane(sj, 2) + vz;                 // the moved spin, before the flip
