@@ -85,6 +85,26 @@ struct ChunkDesc {
 // depths of that DAG, reached by relaxing L(t) = 1 + max L(pred) until nothing changes (as many rounds as there are levels,
 // about ten).  The order of the slots INSIDE a level is arbitrary (they commute), so it is left to LDS atomics.
 // ---------------------------------------------------------------------------------------------------
+// counter[key] += 1 for every active lane, one LDS atomic per DISTINCT key of the wavefront (a level of a chunk holds up to half of
+// its attempts: 64 lanes adding to one LDS word serialise in the LDS unit); returns the lane's slot = old value + its rank among the
+// lanes with the same key.  All lanes of the wavefront must call it together.
+__device__ __forceinline__ uint32_t wave_count_by_key(uint32_t* counter, uint32_t key, bool active)
+{
+    uint32_t slot = 0u;
+    unsigned long long todo = __ballot(active);
+    while (todo) {                                                            // wave-uniform
+        const int leader = __builtin_ctzll(todo);
+        const uint32_t k0 = (uint32_t)__builtin_amdgcn_readlane((int)key, leader);
+        const unsigned long long same = __ballot(active && key == k0);
+        uint32_t base = 0u;
+        if ((int)(threadIdx.x & 63) == leader) base = atomicAdd(&counter[k0], (uint32_t)__popcll(same));
+        base = (uint32_t)__builtin_amdgcn_readlane((int)base, leader);
+        if (active && key == k0) slot = base + (uint32_t)__popcll(same & ((1ull << (threadIdx.x & 63)) - 1ull));
+        todo &= ~same;
+    }
+    return slot;
+}
+
 constexpr uint32_t kNoPred = 0xffffu;
 
 template <int K>
@@ -179,7 +199,18 @@ __global__ __launch_bounds__(kPlanThreads) void plan_kernel(ChunkDesc* __restric
     }
     if (tid == 0) s_maxlvl = 0u;
     __syncthreads();
-    for (int t = tid; t < count; t += kPlanThreads) { atomicAdd(&s_cnt[s_lvl[t]], 1u); atomicMax(&s_maxlvl, (uint32_t)s_lvl[t]); }
+    {
+        uint32_t mymax = 0u;
+        for (int t0 = 0; t0 < count; t0 += kPlanThreads) {        // uniform trip count: the aggregation is a wave-wide operation
+            const int t = t0 + tid;
+            const bool act = t < count;
+            const uint32_t l = act ? (uint32_t)s_lvl[t] : 0u;
+            wave_count_by_key(s_cnt, l, act);
+            mymax = l > mymax ? l : mymax;
+        }
+        for (int o = 32; o > 0; o >>= 1) { const uint32_t m = (uint32_t)__shfl_xor((int)mymax, o); mymax = m > mymax ? m : mymax; }
+        if ((tid & 63) == 0) atomicMax(&s_maxlvl, mymax);
+    }
     __syncthreads();
     if (tid == 0) {
         const uint32_t maxlvl = s_maxlvl;
@@ -198,10 +229,12 @@ __global__ __launch_bounds__(kPlanThreads) void plan_kernel(ChunkDesc* __restric
         chunks[blockIdx.x].nvec = nvec;
     }
     __syncthreads();
-    for (int t = tid; t < count; t += kPlanThreads) {
-        const uint32_t l = s_lvl[t];
-        const uint32_t pos = s_start[l] + atomicAdd(&s_cur[l], 1u);
-        slots[cd.slot_base + pos] = (uint32_t)s_site[t] | ((uint32_t)t << 16);
+    for (int t0 = 0; t0 < count; t0 += kPlanThreads) {
+        const int t = t0 + tid;
+        const bool act = t < count;
+        const uint32_t l = act ? (uint32_t)s_lvl[t] : 0u;
+        const uint32_t pos = wave_count_by_key(s_cur, l, act);
+        if (act) slots[cd.slot_base + s_start[l] + pos] = (uint32_t)s_site[t] | ((uint32_t)t << 16);
     }
 }
 
