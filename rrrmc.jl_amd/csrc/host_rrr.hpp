@@ -250,7 +250,29 @@ int32_t sparse_rrr_bkl_async(rrrmc_ctx* ctx, int mode, double beta, int64_t iter
     HIP_TRY(ctx, hipMemsetAsync(ctx->d_acc, 0, sizeof(int64_t) * ctx->Rpad, st));
     if ((rc = rp_in(ctx, rv, st))) return rc;
     HIP_TRY(ctx, hipEventRecord(ctx->ev_sweep[0], st));
-    {
+    // few replicas: one WAVEFRONT per replica with the whole DeltaECache in LDS (sparse_wave_kernel.hpp); rrrMC only
+    const SwLayout swl = sw_layout(N, W, K, L, (size_t)kLdsLimit);
+    const char* no_wave = std::getenv("RRRMC_RRR_NO_WAVE");              // tests / timing experiments
+    // a replica's workgroup owns its LDS: as many replicas at a time as the CUs hold (256 CUs x workgroups per CU); beyond that the
+    // thread-per-replica kernel fills the chip better
+    int64_t wave_max_R = 256 * std::max<int64_t>(1, (int64_t)(kLdsLimit / std::max<size_t>(swl.bytes, 1)));
+    if (const char* e = std::getenv("RRRMC_RRR_WAVE_MAX_R")) wave_max_R = std::atoll(e);
+    int64_t sw_cap = swl.cap;
+    if (const char* e = std::getenv("RRRMC_RRR_WAVE_SLACK")) {          // tests: a small slack makes the segments re-space often
+        const int64_t want = N + std::atoll(e);
+        if (want >= N + 2 * L * sw_min_gap(K) && want < sw_cap) sw_cap = want & ~(int64_t)3;
+    }
+    const bool wave_ok = mode == 0 && !wide_idx && K <= 7 && L <= 4 && R <= wave_max_R && sw_cap >= N + 2 * L * (int64_t)sw_min_gap(K) &&
+                         !(no_wave && no_wave[0] == '1');
+    if (wave_ok) {
+        SwExtra X{};
+        X.cap = (int)sw_cap; X.off_spos = (uint32_t)swl.off_spos; X.off_sv = (uint32_t)swl.off_sv; X.off_A = (uint32_t)swl.off_A;
+        X.off_J = (uint32_t)swl.off_J; X.off_rng = (uint32_t)swl.off_rng; X.off_tab = (uint32_t)swl.off_tab;
+        typedef void (*sw_fn)(RrrSparseParams, SwExtra);
+        const sw_fn fn = L <= 2 ? (K <= 3 ? rrr_sparse_wave_kernel<2, 3> : rrr_sparse_wave_kernel<2, 7>) : (K <= 4 ? rrr_sparse_wave_kernel<4, 4> : rrr_sparse_wave_kernel<4, 7>);
+        HIP_TRY(ctx, raise_lds_attr(reinterpret_cast<const void*>(fn), swl.bytes));
+        hipLaunchKernelGGL(fn, dim3((unsigned)R), dim3(kRrrThreads), swl.bytes, st, P, X);
+    } else {
         // few replicas run one per workgroup anyway: stage the replica's hot state and the graph in LDS if they fit
         const size_t lds = rrr_sparse_lds_bytes(N, W, K);
         const char* no_lds = std::getenv("RRRMC_RRR_NO_LDS");            // tests / timing experiments

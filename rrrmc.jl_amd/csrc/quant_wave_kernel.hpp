@@ -209,7 +209,7 @@ __global__ __launch_bounds__(kRrrThreads) void rrr_quant_wave_kernel(RrrParams P
     const int fmask = lane == 0 ? 4 : lane == 1 ? 2 : 1;       // which bit of (sj, s1, s2) is the moved spin, for lanes 0 (nb0), 1 (nb1), 2.. (move)
     double vzd = __longlong_as_double(((long long)vz << 32) | (uint32_t)vz);      // +0.0, opaque
     const double negbeta = -P.beta + vzd;
-    const double ft1 = P.ft1 + vzd, fourK = P.fourK + vzd, lambda = P.lambda + vzd, one_m_lambda = (1 - P.lambda) + vzd, staged_thr = P.staged_thr + vzd;
+    const double lambda = P.lambda + vzd, one_m_lambda = (1 - P.lambda) + vzd, staged_thr = P.staged_thr + vzd;
     // T[0..2] == (double)t[0..2] exactly (weights 1.0); T3 and z are running sums (DeltaE.jl:90-103, 258-282)
     double T3 = P.T[(size_t)r * 4 + 3], z = P.zz[r], E = P.E_cur[r], acc_rate = P.acc_rate[r];
     long long accepted = P.stats[(size_t)r * 2], staged_its = P.stats[(size_t)r * 2 + 1];

@@ -20,6 +20,7 @@
 #include "sk_kernels.hpp"
 #include "rrr_kernels.hpp"
 #include "quant_wave_kernel.hpp"
+#include "sparse_wave_kernel.hpp"
 #include "sparse_kernels.hpp"
 #include "bign_kernels.hpp"
 #include "obs_kernels.hpp"

@@ -360,3 +360,54 @@ def test_extremal_opt_on_graph_quant(pkg, oracle, slices, Nk, M, Gamma, beta, R,
         ref = oracle.extremal_opt_quant(A, J, M, X.fourK, tau, iters, step, seed, C0.s[r], replica=r, form=form)
         assert (Es[r] == ref[0]).all() and (C1.s[r] == ref[1]).all()
         assert Emin[r] == ref[2] and (Cmin.s[r] == ref[3]).all() and itmin[r] == ref[4]
+
+
+@pytest.mark.parametrize("kind,R,beta,iters,step,thr", [
+    ("rrg10", 5, 2.0, 5000, 50, 0.5), ("rrg300", 7, 2.0, 8000, 200, 0.0), ("rrg300", 7, 1.0, 8000, 200, 1.0), ("rrg4096", 4, 2.0, 30000, 1000, 0.8),
+    ("ea2x3", 6, 1.0, 4000, 40, 0.5), ("ea5x3", 5, 1.5, 9000, 300, 0.8), ("ea8x3", 3, 3.0, 20000, 500, 0.8), ("rrg300lev", 6, 1.5, 8000, 200, 0.8),
+    ("rrg500k7", 3, 1.2, 6000, 200, 0.8),
+])
+def test_rrr_sparse_wave_kernel_equals_thread_kernel(pkg, oracle, kind, R, beta, iters, step, thr, monkeypatch):
+    """rrrMC(SingleGraph) on GraphRRG / GraphEA has a wavefront-per-replica build (few replicas: the whole DeltaECache in LDS, the 2L sets
+    as segments of one array) next to the thread-per-replica one (RRRMC_RRR_NO_WAVE=1).  Same chains bit for bit — repeated bonds
+    (GraphEA L = 2), zero couplings of a level graph, K = 7, always-direct / always-staged, and with so little slack between the segments
+    that they are re-spaced every few batches — and equal to the oracle."""
+    seed = 515100 + len(kind) + R
+    lev = None
+    if kind == "rrg10":
+        X, form = pkg.GraphRRG(10, 3, seed=seed), "rrg"
+    elif kind == "rrg300":
+        X, form = pkg.GraphRRG(300, 3, seed=seed), "rrg"
+    elif kind == "rrg4096":
+        X, form = pkg.GraphRRG(4096, 3, seed=seed), "rrg"
+    elif kind == "rrg500k7":
+        X, form = pkg.GraphRRG(500, 6, seed=seed), "rrg"
+    elif kind == "rrg300lev":
+        lev = (-1, 0, 1)
+        X, form = pkg.GraphRRG(300, 3, lev, seed=seed), "rrg"
+    else:
+        X, form = pkg.GraphEA(int(kind[2]), 3, seed=seed), "ea"
+
+    def run():
+        with pkg.Engine(X, R) as eng:
+            eng.seed(seed)
+            eng.init_spins_random()
+            C0 = eng.get_config()
+            a = eng.rrr_mc(beta, iters, step, staged_thr=thr)
+            c1 = eng.get_config().s.copy()
+            b = eng.rrr_mc(beta, 333, 10, staged_thr=thr)          # continues the streams, rebuilds the cache
+            c2 = eng.get_config().s.copy()
+            return C0, a[0], a[1], a[2], c1, b[0], b[1], b[2], c2
+
+    wave = run()
+    monkeypatch.setenv("RRRMC_RRR_WAVE_SLACK", str(2 * 4 * 64 * 2 * (X.K + 1)))       # the smallest slack accepted: re-spacing every few batches
+    tight = run()
+    monkeypatch.delenv("RRRMC_RRR_WAVE_SLACK")
+    monkeypatch.setenv("RRRMC_RRR_NO_WAVE", "1")
+    thread = run()
+    for x, y, w in zip(wave[1:], thread[1:], tight[1:]):
+        assert (np.asarray(x) == np.asarray(y)).all() and (np.asarray(w) == np.asarray(y)).all()
+    if lev is None:
+        r = R - 1
+        ref = oracle.rrr_sparse(X.A, X.J.astype(np.int32), beta, iters, step, seed, wave[0].s[r], replica=r, staged_thr=thr, form=form)
+        assert (wave[1][r] == ref[0]).all() and (wave[4][r] == ref[1]).all() and wave[2][r] == ref[2] and wave[3][r] == ref[3]
