@@ -250,7 +250,7 @@ int32_t sparse_rrr_bkl_async(rrrmc_ctx* ctx, int mode, double beta, int64_t iter
     HIP_TRY(ctx, hipMemsetAsync(ctx->d_acc, 0, sizeof(int64_t) * ctx->Rpad, st));
     if ((rc = rp_in(ctx, rv, st))) return rc;
     HIP_TRY(ctx, hipEventRecord(ctx->ev_sweep[0], st));
-    // few replicas: one WAVEFRONT per replica with the whole DeltaECache in LDS (sparse_wave_kernel.hpp); rrrMC only
+    // few replicas: one WAVEFRONT per replica with the whole DeltaECache in LDS (sparse_wave_kernel.hpp)
     const SwLayout swl = sw_layout(N, W, K, L, (size_t)kLdsLimit);
     const char* no_wave = std::getenv("RRRMC_RRR_NO_WAVE");              // tests / timing experiments
     // a replica's workgroup owns its LDS: as many replicas at a time as the CUs hold (256 CUs x workgroups per CU); beyond that the
@@ -262,7 +262,7 @@ int32_t sparse_rrr_bkl_async(rrrmc_ctx* ctx, int mode, double beta, int64_t iter
         const int64_t want = N + std::atoll(e);
         if (want >= N + 2 * L * sw_min_gap(K) && want < sw_cap) sw_cap = want & ~(int64_t)3;
     }
-    const bool wave_ok = mode == 0 && !wide_idx && K <= 7 && L <= 4 && R <= wave_max_R && sw_cap >= N + 2 * L * (int64_t)sw_min_gap(K) &&
+    const bool wave_ok = !wide_idx && K <= 7 && L <= 4 && R <= wave_max_R && sw_cap >= N + 2 * L * (int64_t)sw_min_gap(K) &&
                          !(no_wave && no_wave[0] == '1');
     if (wave_ok) {
         SwExtra X{};

@@ -1,4 +1,4 @@
-// rrrMC(X::SingleGraph) (src/RRRMC.jl:149-219) on GraphRRG / GraphEA with integer levels, one WAVEFRONT per replica — the reference's own
+// rrrMC(X::SingleGraph) (src/RRRMC.jl:149-219) and bklMC (:311-359) on GraphRRG / GraphEA with integer levels, one WAVEFRONT per replica — the reference's own
 // experiment (scripts/scripts.jl:test_RRG) runs a handful of chains, and one thread per replica (rrr_sparse_kernel) leaves the chip idle
 // while each of its set moves waits on HBM/L2.  Same construction as rrr_quant_wave_kernel (quant_wave_kernel.hpp):
 //   * the chain is executed wave-uniformly; the 64 lanes share what is independent inside an iteration: the RRR draws of 64 iterations
@@ -209,12 +209,18 @@ __global__ __launch_bounds__(kRrrThreads) void rrr_sparse_wave_kernel(RrrSparseP
         return (uint32_t)(hi >> 32);
     };
 
-    for (long long base_it = 0; base_it < P.iters; base_it += kRrrThreads) {
+    // bklMC (mode 1; RRRMC.jl:311-359): every move is applied; `it` advances by the geometric skip rand_skip (DeltaE.jl:141-144) + 1, the
+    // moves are numbered m = 1, 2, ... (RRR stream sub 0 for the class / member, sub 2 for the skip), 64 of them prepared at a time
+    const bool bkl = P.mode == 1;
+    long long it_bkl = 0, nextstep = P.step;
+    bool done = false;
+    const double Nd = (double)P.N + vzd;
+    for (long long base_it = 0; !done && (bkl || base_it < P.iters); base_it += kRrrThreads) {
         __syncthreads();
         {
             const uint64_t gl = P.g0 + (uint64_t)(base_it + 1 + (long long)lane);
             const Philox4 a = philox4x32_10((uint32_t)gl, (uint32_t)(gl >> 32), rep, TAG_RRR, P.k0, P.k1);
-            const Philox4 b = philox4x32_10((uint32_t)gl, (uint32_t)(gl >> 32), rep, TAG_RRR | (1u << 8), P.k0, P.k1);
+            const Philox4 b = philox4x32_10((uint32_t)gl, (uint32_t)(gl >> 32), rep, TAG_RRR | ((bkl ? 2u : 1u) << 8), P.k0, P.k1);
             l_rng[lane * 3 + 0] = (double)((((uint64_t)a.w[0] << 32) | a.w[1]) >> 11) * 0x1.0p-53;
             l_rng[lane * 3 + 1] = __longlong_as_double((long long)(((uint64_t)a.w[2] << 32) | a.w[3]));
             l_rng[lane * 3 + 2] = (double)((((uint64_t)b.w[0] << 32) | b.w[1]) >> 11) * 0x1.0p-53;
@@ -256,12 +262,14 @@ __global__ __launch_bounds__(kRrrThreads) void rrr_sparse_wave_kernel(RrrSparseP
             }
         }
         __syncthreads();
-        const int n_it = (int)(base_it + kRrrThreads < P.iters ? kRrrThreads : P.iters - base_it);
+        const int n_it = bkl ? kRrrThreads : (int)(base_it + kRrrThreads < P.iters ? kRrrThreads : P.iters - base_it);
         double u_cls_n = l_rng[0], u_mem_n = l_rng[1], u_acc_n = l_rng[2];
         auto sample_li = [&]() -> int { const long long d = next_sample - (base_it + 1); return d >= 0 && d < (long long)n_it ? (int)d : -1; };
         int li_s = sample_li();
         for (int li = 0; li < n_it; ++li) {
-            if (li == li_s) {
+            if (bkl) {
+                if (it_bkl >= P.iters) { done = true; break; }
+            } else if (li == li_s) {
                 next_sample += P.step;
                 if (lane == 0) P.Es[(size_t)ns * P.Rpad + r] = (int32_t)E;
                 ns += 1;
@@ -293,6 +301,19 @@ __global__ __launch_bounds__(kRrrThreads) void rrr_sparse_wave_kernel(RrrSparseP
             const int tvv = ev - bv;
             const int move = (int)l_sv[(__builtin_amdgcn_readlane(bv, sk) + vz) + (int)mulhi_u64_u32(u_mem, (uint32_t)(__builtin_amdgcn_readlane(tvv, sk) + vz))];
 
+            long long skip = 0;
+            if (bkl) {
+                const double skipf = floor(__ddiv_rn(det_log1p(-u1), det_log1p(-__ddiv_rn(z, Nd))));      // rand_skip, DeltaE.jl:141-144
+                skip = skipf >= 9.0e18 ? (long long)9.0e18 : (long long)skipf;
+                bool out = false;
+                while (it_bkl + skip + 1 >= nextstep) {           // the samples the skipped iterations pass (RRRMC.jl:332-350)
+                    if (lane == 0) P.Es[(size_t)ns * P.Rpad + r] = (int32_t)E;
+                    ns += 1;
+                    nextstep += P.step;
+                    if (nextstep > P.iters) { out = true; break; }
+                }
+                if (out) { done = true; break; }
+            }
             // ---- lane-parallel: lane q < K = neighbour q of the move, lane K = the moved spin ----
             const bool isn = lane < K, isme = lane == K;
             const int rowi = move * K + (isn ? lane : 0);
@@ -333,7 +354,15 @@ __global__ __launch_bounds__(kRrrThreads) void rrr_sparse_wave_kernel(RrrSparseP
             auto flip_move = [&]() { l_sp[move >> 5] ^= 1u << (move & 31); };
 
             bool acc = false;
-            if (uni(acc_rate < staged_thr)) {
+            if (bkl) {
+                flip_move();
+                double zp = z;
+                apply_T(Tv, zp, true);
+                apply_sets(true);
+                z = zp;
+                it_bkl += skip + 1;
+                E += dE; accepted += 1;
+            } else if (uni(acc_rate < staged_thr)) {
                 // staged branch (RRRMC.jl:131-138): T' and z' from copies, the sets only on acceptance
                 staged_its += 1;
                 double Tp = Tv, zp = z;
@@ -370,7 +399,7 @@ __global__ __launch_bounds__(kRrrThreads) void rrr_sparse_wave_kernel(RrrSparseP
     if (lane == 0) {
         P.E_cur[r] = (int32_t)E;
         P.acc_cur[r] = accepted;
-        P.stats[(size_t)r * 3] = accepted; P.stats[(size_t)r * 3 + 1] = staged_its; P.stats[(size_t)r * 3 + 2] = P.iters;
+        P.stats[(size_t)r * 3] = accepted; P.stats[(size_t)r * 3 + 1] = bkl ? accepted : staged_its; P.stats[(size_t)r * 3 + 2] = bkl ? it_bkl : P.iters;
     }
 }
 

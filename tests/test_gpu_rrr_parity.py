@@ -397,7 +397,9 @@ def test_rrr_sparse_wave_kernel_equals_thread_kernel(pkg, oracle, kind, R, beta,
             c1 = eng.get_config().s.copy()
             b = eng.rrr_mc(beta, 333, 10, staged_thr=thr)          # continues the streams, rebuilds the cache
             c2 = eng.get_config().s.copy()
-            return C0, a[0], a[1], a[2], c1, b[0], b[1], b[2], c2
+            k = eng.bkl_mc(beta, 20 * iters, 20 * step)            # bklMC through the same builds
+            c3 = eng.get_config().s.copy()
+            return C0, a[0], a[1], a[2], c1, b[0], b[1], b[2], c2, k[0], k[1], c3
 
     wave = run()
     monkeypatch.setenv("RRRMC_RRR_WAVE_SLACK", str(2 * 4 * 64 * 2 * (X.K + 1)))       # the smallest slack accepted: re-spacing every few batches
