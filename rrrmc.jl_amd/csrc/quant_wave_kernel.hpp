@@ -36,7 +36,7 @@ constexpr int kQwMinGap = 512;          // smallest slack (entries per gap) the 
 
 struct QwLayout { size_t off_spos, off_sv, off_A, off_J, off_rng, off_tab, bytes; int cap; };
 
-// table area, in doubles: header [w3 4][fc 4][dE0 4][4 spare: word 0 of them is the popcount accumulator of the GraphSK build], then
+// table area, in doubles: header [w3 4][fc 4][dE0 4][4 spare], then
 // exp[TE], dE1[TE] and, for GraphRRG / GraphEA slices, dE0 + dE1 [4][16]; TE = 16 entries (a = 0 .. 2K) or 2 Nk (binary GraphSK slices:
 // the index is u + s_i Nk with u = |{j != i : J_ij xor s_j}|)
 inline size_t qw_tab_doubles(int64_t Nk, bool sk) { return sk ? (size_t)(16 + 4 * Nk) : (size_t)kQwTabDoubles; }
@@ -133,7 +133,6 @@ __global__ __launch_bounds__(kRrrThreads) void rrr_quant_wave_kernel(RrrParams P
     double* l_w3 = l_hdr;                                     // [4]: class k's share of the running sum T3 (ft1 for k = 3, else 0)
     double* l_fc = l_hdr + 4;                                 // [4]: class weights get_class_f (1, 1, 1, ft1)
     double* l_dE0 = l_hdr + 8;                                // [4]: delta_energy of GraphQT by class: -fourK, -0.0, 0.0, fourK (DeltaE.jl:80-86)
-    uint32_t* l_acc = reinterpret_cast<uint32_t*>(l_hdr + 12);     // SK: the popcount of the move's slice row, summed over the lanes
     const int TE = SK ? 2 * P.Nk : 16;
     double* l_exp = l_hdr + 16;                               // [TE]: det_exp(-beta dE1(a))
     double* l_dE1 = l_exp + TE;                               // [TE]: dE1(a) = delta_energy_residual: 2 (a - K) / M, or ((2 (2 s_i - 1)(Nk - 1 - 2u)) / sqrt(Nk)) / M
@@ -177,7 +176,6 @@ __global__ __launch_bounds__(kRrrThreads) void rrr_quant_wave_kernel(RrrParams P
     }
     uint32_t xge0_s = 0u;                   // sparse slices, bit a: x = -beta dE1(a) >= 0
     if constexpr (SK) {
-        if (lane == 0) l_acc[0] = 0u;
         for (int idx = lane; idx < 2 * P.Nk; idx += kRrrThreads) {
             const int si = idx >= P.Nk ? 1 : 0, u = idx - si * P.Nk;
             const int d = 2 * (2 * si - 1) * (P.Nk - 1 - 2 * u);              // lfields[i] (SK.jl:62-96), see slice_delta (rrr_kernels.hpp)
@@ -506,7 +504,7 @@ __global__ __launch_bounds__(kRrrThreads) void rrr_quant_wave_kernel(RrrParams P
 // (Trotter term, slice term), the bit flip.  Bit-identical to quant_standard_kernel: the tables hold the values of its own expressions.
 // LDS: spins [W], rows [64][Wk] (SK), A / J (sparse slices), dE [3][TE], exp(-beta dE) [3][TE].
 // ---------------------------------------------------------------------------------------------------
-struct QsLayout { size_t off_rows, off_A, off_J, off_de, off_ex, off_acc, bytes; int TE; };
+struct QsLayout { size_t off_rows, off_A, off_J, off_de, off_ex, bytes; int TE; };
 inline QsLayout qs_layout(int64_t W, int64_t Nk, int64_t K, int64_t Wk, bool sk)
 {
     QsLayout L{};
@@ -517,11 +515,10 @@ inline QsLayout qs_layout(int64_t W, int64_t Nk, int64_t K, int64_t Wk, bool sk)
     L.TE = sk ? (int)(2 * Nk) : 16;
     L.off_de = o; o += (size_t)3 * L.TE * 8;
     L.off_ex = o; o += (size_t)3 * L.TE * 8;
-    L.off_acc = o; o += 8;
     L.bytes = o;
     return L;
 }
-struct QsExtra { uint32_t off_rows, off_A, off_J, off_de, off_ex, off_acc; int TE; };
+struct QsExtra { uint32_t off_rows, off_A, off_J, off_de, off_ex; int TE; };
 
 template <bool SK>
 __global__ __launch_bounds__(kRrrThreads) void quant_standard_wave_kernel(RrrParams P, QsExtra X)
@@ -535,7 +532,6 @@ __global__ __launch_bounds__(kRrrThreads) void quant_standard_wave_kernel(RrrPar
     int8_t* l_J = reinterpret_cast<int8_t*>(lds8 + X.off_J);
     double* l_de = reinterpret_cast<double*>(lds8 + X.off_de);                   // [3][TE]: delta_energy for (qt_delta + 1, slice index)
     double* l_ex = reinterpret_cast<double*>(lds8 + X.off_ex);                   // [3][TE]: det_exp(-beta delta_energy)
-    uint32_t* l_acc = reinterpret_cast<uint32_t*>(lds8 + X.off_acc);
     const int TE = X.TE, N = P.N, Nk = P.Nk, K = P.K;
     uint32_t* g_sp = P.spins + (size_t)r * P.W;
     for (int i = lane; i < P.W; i += kRrrThreads) l_sp[i] = g_sp[i];
@@ -556,7 +552,6 @@ __global__ __launch_bounds__(kRrrThreads) void quant_standard_wave_kernel(RrrPar
         l_de[idx] = dE;
         l_ex[idx] = det_exp(-P.beta * dE);
     }
-    if (lane == 0) l_acc[0] = 0u;
     __syncthreads();
 
     const uint32_t rep = P.replica0 + (uint32_t)r;

@@ -1538,7 +1538,7 @@ int32_t quant_mc_async(rrrmc_ctx* ctx, bool standard, double beta, double fourK,
         if (wave_ok) {
             QsExtra X{};
             X.off_rows = (uint32_t)sl.off_rows; X.off_A = (uint32_t)sl.off_A; X.off_J = (uint32_t)sl.off_J; X.off_de = (uint32_t)sl.off_de;
-            X.off_ex = (uint32_t)sl.off_ex; X.off_acc = (uint32_t)sl.off_acc; X.TE = sl.TE;
+            X.off_ex = (uint32_t)sl.off_ex; X.TE = sl.TE;
             if (ctx->q_sk) {
                 HIP_TRY(ctx, raise_lds_attr(reinterpret_cast<const void*>(quant_standard_wave_kernel<true>), sl.bytes));
                 hipLaunchKernelGGL(quant_standard_wave_kernel<true>, dim3((unsigned)ctx->R), dim3(kRrrThreads), sl.bytes, st, P, X);
