@@ -31,15 +31,15 @@
 
 namespace rrrmc {
 
-constexpr int kQwTabDoubles = 112;      // sparse slices: header 16, exp[16], dE1[16], dE0(k) + dE1(a) [4][16]
+constexpr int kQwTabDoubles = 176;      // sparse slices: header 16, class-pair weights [16][4], exp[16], dE1[16], dE0(k) + dE1(a) [4][16]
 constexpr int kQwMinGap = 512;          // smallest slack (entries per gap) the host accepts for this build: 6 pushes x 64 iterations fit
 
 struct QwLayout { size_t off_spos, off_sv, off_A, off_J, off_rng, off_tab, bytes; int cap; };
 
-// table area, in doubles: header [w3 4][fc 4][dE0 4][4 spare], then
+// table area, in doubles: header [w3 4][fc 4][dE0 4][4 spare], the weights of a class change (k0 -> k1) [16][4], then
 // exp[TE], dE1[TE] and, for GraphRRG / GraphEA slices, dE0 + dE1 [4][16]; TE = 16 entries (a = 0 .. 2K) or 2 Nk (binary GraphSK slices:
 // the index is u + s_i Nk with u = |{j != i : J_ij xor s_j}|)
-inline size_t qw_tab_doubles(int64_t Nk, bool sk) { return sk ? (size_t)(16 + 4 * Nk) : (size_t)kQwTabDoubles; }
+inline size_t qw_tab_doubles(int64_t Nk, bool sk) { return sk ? (size_t)(80 + 4 * Nk) : (size_t)kQwTabDoubles; }
 
 // LDS layout for (N, W, Nk, K): cap = N + slack (slack as large as the LDS allows); cap < N + 4 * kQwMinGap means "does not fit".
 // sk: binary GraphSK slices (GraphQSKT) — no neighbour table, larger acceptance tables
@@ -134,7 +134,8 @@ __global__ __launch_bounds__(kRrrThreads) void rrr_quant_wave_kernel(RrrParams P
     double* l_fc = l_hdr + 4;                                 // [4]: class weights get_class_f (1, 1, 1, ft1)
     double* l_dE0 = l_hdr + 8;                                // [4]: delta_energy of GraphQT by class: -fourK, -0.0, 0.0, fourK (DeltaE.jl:80-86)
     const int TE = SK ? 2 * P.Nk : 16;
-    double* l_exp = l_hdr + 16;                               // [TE]: det_exp(-beta dE1(a))
+    double* l_tri = l_hdr + 16;                               // [k0 * 4 + k1][4]: w3(k0), w3(k1), f(k1) - f(k0), -; entry 0 is all zeros (an unchanged neighbour)
+    double* l_exp = l_hdr + 80;                               // [TE]: det_exp(-beta dE1(a))
     double* l_dE1 = l_exp + TE;                               // [TE]: dE1(a) = delta_energy_residual: 2 (a - K) / M, or ((2 (2 s_i - 1)(Nk - 1 - 2u)) / sqrt(Nk)) / M
     double* l_dEt = l_dE1 + TE;                               // sparse slices only, [4][16]: dE0(k) + dE1(a), the energy change of an accepted move
 
@@ -172,6 +173,16 @@ __global__ __launch_bounds__(kRrrThreads) void rrr_quant_wave_kernel(RrrParams P
     }
     if (lane < 4) {
         l_w3[lane] = lane == 3 ? P.ft1 : 0.0; l_fc[lane] = lane == 3 ? P.ft1 : 1.0;
+    }
+    if (lane < 16) {
+        const int k0 = lane >> 2, k1 = lane & 3;
+        const double f0 = k0 == 3 ? P.ft1 : 1.0, f1 = k1 == 3 ? P.ft1 : 1.0;
+        l_tri[lane * 4 + 0] = k0 == 3 ? P.ft1 : 0.0;
+        l_tri[lane * 4 + 1] = k1 == 3 ? P.ft1 : 0.0;
+        l_tri[lane * 4 + 2] = f1 - f0;
+        l_tri[lane * 4 + 3] = 0.0;
+    }
+    if (lane < 4) {
         l_dE0[lane] = lane == 0 ? -0.0 : lane == 1 ? -P.fourK : lane == 2 ? 0.0 : P.fourK;
     }
     uint32_t xge0_s = 0u;                   // sparse slices, bit a: x = -beta dE1(a) >= 0
@@ -385,17 +396,18 @@ __global__ __launch_bounds__(kRrrThreads) void rrr_quant_wave_kernel(RrrParams P
                 return a >= 1 || u_acc < a;
             };
             // class weights: 1.0, except exp(-beta fourK) for class 3; only T3 is a running sum (x - 0.0 and x + 0.0 leave T3 >= +0 as it is)
-            auto w3 = [&](int kk) -> double { return l_w3[kk]; };
-            auto fcls = [&](int kk) -> double { return l_fc[kk]; };
             auto flip_move = [&]() { l_sp[move >> 5] ^= 1u << (move & 31); };       // every lane: same word, same value
             const bool cha = uni(k0a != k1a), chb = uni(k0b != k1b);       // scalar conditions (one ballot each)
 
             // Float64 bookkeeping of one apply_move! in the reference's order (first neighbour, second neighbour, moved spin,
             // DeltaE.jl:257-282); a skipped neighbour adds +-0.0, which changes neither T3 (>= +0) nor z' (> 0)
             // (an unchanged neighbour has k0 == k1: its weight difference is +0.0 by itself, and class 0's share of T3 is 0.0)
-            const double da0 = w3(cha ? k0a : 0), da1 = w3(cha ? k1a : 0), dza = fcls(k1a) - fcls(k0a);
-            const double db0 = w3(chb ? k0b : 0), db1 = w3(chb ? k1b : 0), dzb = fcls(k1b) - fcls(k0b);
-            const double dm0 = w3(k0m), dm1 = w3(k1m), dzm = fcls(k1m) - fcls(k0m);
+            const double* ta = l_tri + 4 * (cha ? k0a * 4 + k1a : 0);
+            const double* tb = l_tri + 4 * (chb ? k0b * 4 + k1b : 0);
+            const double* tm = l_tri + 4 * (k0m * 4 + k1m);
+            const double da0 = ta[0], da1 = ta[1], dza = ta[2];
+            const double db0 = tb[0], db1 = tb[1], dzb = tb[2];
+            const double dm0 = tm[0], dm1 = tm[1], dzm = tm[2];
             bool acc = false;
             if (uni(acc_rate < staged_thr)) {
                 // staged branch: step_rrr (RRRMC.jl:131-138) = compute_staged! + compute_reverse_probabilities!, apply_staged! on acceptance
