@@ -155,6 +155,7 @@ struct ContChain {
             v.slf = P->qslf + (size_t)rloc * 2 * P->qM * P->qNk; v.smv = P->qsmv + (size_t)rloc * P->qM; v.scur = P->qscur + (size_t)rloc * P->qM;
         }
         v.nk_magic = (uint32_t)((0x100000000ull + (uint32_t)P->qNk - 1u) / (uint32_t)P->qNk);
+        v.wide = P->N > 65535 ? 1 : 0;      // the slice of a spin by division (the multiply-high form is exact below 2^16 only)
         return v;
     }
     // neighbors(X, move) in the reference's order; returns their number (at most K + 2)

@@ -14,6 +14,7 @@ RrrParams quant_params(rrrmc_ctx* ctx, double beta, double fourK)
     P.ft1 = 0.0;
     P.k0 = (uint32_t)ctx->seed; P.k1 = (uint32_t)(ctx->seed >> 32); P.replica0 = ctx->replica0;
     P.Nk = (int)ctx->qNk; P.M = (int)ctx->qM; P.K = (int)ctx->K; P.N = (int)ctx->N; P.W = (int)ctx->qW; P.R = (int)ctx->R;
+    P.wide = ctx->N > 65535 ? 1 : 0;
     return P;
 }
 

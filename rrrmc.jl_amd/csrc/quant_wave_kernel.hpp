@@ -141,8 +141,8 @@ __global__ __launch_bounds__(kRrrThreads) void rrr_quant_wave_kernel(RrrParams P
 
     uint32_t* g_sp = P.spins + (size_t)r * P.W;
     uint8_t* g_cls = P.cls + (size_t)r * P.N;
-    uint16_t* g_sv = P.sv + (size_t)r * 4 * P.N;
-    uint16_t* g_spos = P.spos + (size_t)r * P.N;
+    uint16_t* g_sv = static_cast<uint16_t*>(P.sv) + (size_t)r * 4 * P.N;        // the wave build is 16-bit only (N <= 65 535: the host checks)
+    uint16_t* g_spos = static_cast<uint16_t*>(P.spos) + (size_t)r * P.N;
     int32_t* g_t = P.st + (size_t)r * 4;
 
     // ---- stage the replica ------------------------------------------------------------------------------------------------

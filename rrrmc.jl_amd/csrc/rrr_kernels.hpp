@@ -37,8 +37,8 @@ struct RrrParams {
     // per-replica state, replica-contiguous
     uint32_t* spins;         // [R][W]       bit x of replica r: word x >> 5, bit x & 31; x = slice * Nk + i
     uint8_t* cls;            // [R][N]       class of every spin: a + 2 * up  (DeltaECache.pos)
-    uint16_t* sv;            // [R][4][N]    ArraySet.v of the four classes
-    uint16_t* spos;          // [R][N]       position of the spin inside its set
+    void* sv;                // [R][4][N]    ArraySet.v of the four classes: uint16_t, or uint32_t when `wide` (N > 65 535)
+    void* spos;              // [R][N]       position of the spin inside its set
     int32_t* st;             // [R][4]       set sizes
     double* T;               // [R][4]
     double* zz;              // [R]          z
@@ -51,11 +51,12 @@ struct RrrParams {
     int64_t iters, step;
     uint32_t k0, k1, replica0;
     int Nk, M, K, N, W, R;
+    int wide;                //              sv / spos hold 32-bit entries (thread-per-replica builds only)
 };
 
 struct RrrView {             // one replica's slices of the arrays above
-    uint32_t* sp; uint8_t* cls; uint16_t* sv; uint16_t* spos; int32_t* t;
-    int N, Nk, M, K;
+    uint32_t* sp; uint8_t* cls; void* sv; void* spos; int32_t* t;      // sv / spos: uint16_t entries, uint32_t when wide
+    int N, Nk, M, K, wide;
     uint32_t nk_magic;       // ceil(2^32 / Nk): floor(x / Nk) = mulhi(x, nk_magic) exactly for x < 2^16 (x e < 2^32 with e = Nk nk_magic - 2^32 < Nk)
     const int32_t* A; const int8_t* J;
     const uint32_t* Jb; int Wk; double sN;
@@ -65,6 +66,11 @@ struct RrrView {             // one replica's slices of the arrays above
 
 __device__ __forceinline__ int sbit(const uint32_t* sp, int x) { return (int)((sp[x >> 5] >> (x & 31)) & 1u); }
 __device__ __forceinline__ void sflip(uint32_t* sp, int x) { sp[x >> 5] ^= 1u << (x & 31); }
+// set members / positions: 16-bit entries up to N = 65 535 (and in every LDS build), 32-bit beyond (the branch is kernel-uniform)
+__device__ __forceinline__ int idx_get(const void* a, size_t i, int wide) { return wide ? (int)static_cast<const uint32_t*>(a)[i] : (int)static_cast<const uint16_t*>(a)[i]; }
+__device__ __forceinline__ void idx_set(void* a, size_t i, int x, int wide) { if (wide) static_cast<uint32_t*>(a)[i] = (uint32_t)x; else static_cast<uint16_t*>(a)[i] = (uint16_t)x; }
+// slice of spin x: x / Nk (the multiply-high form is exact for x < 2^16 only)
+__device__ __forceinline__ int slice_of(int x, int Nk, uint32_t nk_magic, int wide) { return wide ? x / Nk : (int)__umulhi((uint32_t)x, nk_magic); }
 
 // GraphQT: neighbours along the Trotter axis (QT.jl:105-108) and delta_energy (QT.jl:86-103)
 __device__ __forceinline__ void qt_nb(const RrrView& v, int i, int& j1, int& j2)
@@ -93,7 +99,7 @@ __device__ __forceinline__ int qt_class(const RrrView& v, int i)      // DeltaE.
 //   popcounts of the slice's words against row i of J (J_ii = 0, so position i contributes s_i, taken out again).
 __device__ __forceinline__ int slice_delta(const RrrView& v, int move)
 {
-    const int k = (int)__umulhi((uint32_t)move, v.nk_magic), i = move - k * v.Nk, off = k * v.Nk;
+    const int k = slice_of(move, v.Nk, v.nk_magic, v.wide), i = move - k * v.Nk, off = k * v.Nk;
     const int si = sbit(v.sp, move);
     if (v.Jb) {
         const uint32_t* Ji = v.Jb + (size_t)i * v.Wk;
@@ -128,13 +134,13 @@ __device__ __forceinline__ double slice_energy_over_M(const RrrParams& P, long l
 // GraphSKNormal slices: delta_energy_residual = delta_energy(X1[k], C1[k], i) / M = lfields[i] / M (SK.jl:278-284, QT.jl:270-281)
 __device__ __forceinline__ double skn_residual(const RrrView& v, int move)
 {
-    const int k = (int)__umulhi((uint32_t)move, v.nk_magic), i = move - k * v.Nk;
+    const int k = slice_of(move, v.Nk, v.nk_magic, v.wide), i = move - k * v.Nk;
     return v.slf[((size_t)v.scur[k] * v.M + k) * v.Nk + i] / (double)v.M;
 }
 // update_cache! of the slice graph (SK.jl:239-276), called after the bit flip of spinflip!(X::GraphQuant, C, move) (QT.jl:172-183)
 __device__ inline void skn_update(const RrrView& v, int move)
 {
-    const int k = (int)__umulhi((uint32_t)move, v.nk_magic), i = move - k * v.Nk, off = k * v.Nk;
+    const int k = slice_of(move, v.Nk, v.nk_magic, v.wide), i = move - k * v.Nk, off = k * v.Nk;
     const int cur = v.scur[k];
     if (v.smv[k] == i) { v.scur[k] = (uint8_t)(cur ^ 1); return; }          // :247-250: swap the two arrays, move_last stays
     double* lf = v.slf + ((size_t)cur * v.M + k) * v.Nk;
@@ -161,15 +167,14 @@ __device__ __forceinline__ double any_residual(const RrrView& v, int move)
 // ArraySet delete! / push! (ArraySets.jl:56-76); one position array serves the four sets (membership is exclusive)
 __device__ __forceinline__ void set_move(const RrrView& v, int j, int k0, int k1)
 {
-    uint16_t* v0 = v.sv + (size_t)k0 * v.N;
-    uint16_t* v1 = v.sv + (size_t)k1 * v.N;
-    const int p = v.spos[j];
-    const int last = v0[v.t[k0] - 1];
-    v0[p] = (uint16_t)last;
-    v.spos[last] = (uint16_t)p;
+    const size_t b0 = (size_t)k0 * v.N, b1 = (size_t)k1 * v.N;
+    const int p = idx_get(v.spos, j, v.wide);
+    const int last = idx_get(v.sv, b0 + v.t[k0] - 1, v.wide);
+    idx_set(v.sv, b0 + p, last, v.wide);
+    idx_set(v.spos, last, p, v.wide);
     v.t[k0] -= 1;
-    v1[v.t[k1]] = (uint16_t)j;
-    v.spos[j] = (uint16_t)v.t[k1];
+    idx_set(v.sv, b1 + v.t[k1], j, v.wide);
+    idx_set(v.spos, j, v.t[k1], v.wide);
     v.t[k1] += 1;
     v.cls[j] = (uint8_t)k1;
 }
@@ -181,8 +186,9 @@ __device__ __forceinline__ RrrView rrr_view(const RrrParams& P, int r)
     RrrView v;
     v.sp = P.spins + (size_t)r * P.W;
     v.cls = P.cls + (size_t)r * P.N;
-    v.sv = P.sv + (size_t)r * 4 * P.N;
-    v.spos = P.spos + (size_t)r * P.N;
+    v.wide = P.wide;
+    v.sv = P.wide ? static_cast<void*>(static_cast<uint32_t*>(P.sv) + (size_t)r * 4 * P.N) : static_cast<void*>(static_cast<uint16_t*>(P.sv) + (size_t)r * 4 * P.N);
+    v.spos = P.wide ? static_cast<void*>(static_cast<uint32_t*>(P.spos) + (size_t)r * P.N) : static_cast<void*>(static_cast<uint16_t*>(P.spos) + (size_t)r * P.N);
     v.t = P.st + (size_t)r * 4;
     v.N = P.N; v.Nk = P.Nk; v.M = P.M; v.K = P.K; v.A = P.A; v.J = P.J; v.fourK = P.fourK;
     v.Jb = P.Jb; v.Wk = P.Wk; v.sN = P.sN;
@@ -223,8 +229,8 @@ __global__ __launch_bounds__(kRrrThreads) void rrr_init_kernel(RrrParams P)
     for (int i = 0; i < P.N; ++i) {
         const int k = qt_class(v, i);
         v.cls[i] = (uint8_t)k;
-        v.sv[(size_t)k * P.N + v.t[k]] = (uint16_t)i;
-        v.spos[i] = (uint16_t)v.t[k];
+        idx_set(v.sv, (size_t)k * P.N + v.t[k], i, v.wide);
+        idx_set(v.spos, i, v.t[k], v.wide);
         v.t[k] += 1;
     }
     double z = 0.0;
@@ -288,8 +294,8 @@ __global__ __launch_bounds__(kInitThreads) void rrr_init_coop_kernel(RrrParams P
     for (int k = 0; k < 4; ++k) off[k] = s_cnt[k][tid];
     for (int x = x0; x < x1; ++x) {
         const int k = v.cls[x];
-        v.sv[(size_t)k * N + off[k]] = (uint16_t)x;
-        v.spos[x] = (uint16_t)off[k];
+        idx_set(v.sv, (size_t)k * N + off[k], x, v.wide);
+        idx_set(v.spos, x, off[k], v.wide);
         off[k] += 1;
     }
     if (tid == 0) {
@@ -376,8 +382,8 @@ __global__ __launch_bounds__(kInitThreads) void rrr_init_skn_kernel(RrrParams P)
     for (int k = 0; k < 4; ++k) off[k] = s_cnt[k][tid];
     for (int x = x0; x < x1; ++x) {
         const int k = v.cls[x];
-        v.sv[(size_t)k * N + off[k]] = (uint16_t)x;
-        v.spos[x] = (uint16_t)off[k];
+        idx_set(v.sv, (size_t)k * N + off[k], x, v.wide);
+        idx_set(v.spos, x, off[k], v.wide);
         off[k] += 1;
     }
     if (tid == 0) {
@@ -423,7 +429,7 @@ __global__ __launch_bounds__(kRrrThreads) void rrr_quant_kernel(RrrParams P)
     }
     RrrView v = rrr_view(P, r);
     uint32_t* l_rng = nullptr;
-    uint32_t* g_sp = v.sp; uint8_t* g_cls = v.cls; uint16_t* g_spos = v.spos; int32_t* g_t = v.t;
+    uint32_t* g_sp = v.sp; uint8_t* g_cls = v.cls; uint16_t* g_spos = static_cast<uint16_t*>(v.spos); int32_t* g_t = v.t;      // (the LDS build is 16-bit only)
     if constexpr (LDS) {
         const int tid = (int)threadIdx.x, nt = (int)blockDim.x;
         uint32_t* l_sp = q_lds;                                               // [W]
@@ -481,7 +487,7 @@ __global__ __launch_bounds__(kRrrThreads) void rrr_quant_kernel(RrrParams P)
         if (!(rr < cT)) while (T[k] == 0) k -= 1;
         const double dE0 = k < kQL ? -dEl[k] : dEl[k - kQL];
         const uint64_t u = ((uint64_t)o.w[2] << 32) | o.w[3];
-        const int move = v.sv[(size_t)k * P.N + (int)mulhi64(u, (uint64_t)v.t[k])];
+        const int move = idx_get(v.sv, (size_t)k * P.N + (size_t)mulhi64(u, (uint64_t)v.t[k]), v.wide);
 
         bool acc = false;
         int nb[2];
@@ -590,7 +596,7 @@ __global__ __launch_bounds__(kRrrThreads) void rrr_quant_kernel(RrrParams P)
         __syncthreads();
         const int tid = (int)threadIdx.x, nt = (int)blockDim.x;
         for (int i = tid; i < P.W; i += nt) g_sp[i] = v.sp[i];
-        for (int i = tid; i < P.N; i += nt) { g_spos[i] = v.spos[i]; g_cls[i] = v.cls[i]; }
+        for (int i = tid; i < P.N; i += nt) { g_spos[i] = static_cast<uint16_t*>(v.spos)[i]; g_cls[i] = v.cls[i]; }
         if (tid < 4) g_t[tid] = v.t[tid];
     }
 }

@@ -1437,7 +1437,7 @@ int32_t quant_ctx_create(rrrmc_ctx** out, int64_t Nk, int64_t K, int64_t M, int6
     *out = nullptr;
     if (Nk < 1 || (!sk && !skn && K < 1) || R < 1) return fail(nullptr, RRRMC_ERR_INVALID_ARG, "Nk, K, R must be >= 1");
     if (M <= 2) return fail(nullptr, RRRMC_ERR_INVALID_ARG, "M must be greater than 2, given: %lld", (long long)M);   // QT.jl:47
-    if (Nk * M > 65535) return fail(nullptr, RRRMC_ERR_UNSUPPORTED, "N = Nk*M = %lld: the rrrMC kernel indexes spins with 16 bits", (long long)(Nk * M));
+    if (Nk * M > (int64_t)1 << 28) return fail(nullptr, RRRMC_ERR_UNSUPPORTED, "N = Nk*M = %lld is beyond the GraphQuant kernels (N <= 2^28)", (long long)(Nk * M));
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
         return fail(nullptr, RRRMC_ERR_HIP, "no HIP device is visible: this library has no CPU path");
@@ -1475,8 +1475,11 @@ int32_t quant_ctx_create(rrrmc_ctx** out, int64_t Nk, int64_t K, int64_t M, int6
     }
     Q_TRY(hipMalloc(&ctx->q_spins, sizeof(uint32_t) * R * ctx->qW));
     Q_TRY(hipMalloc(&ctx->q_cls, (size_t)R * N));
-    Q_TRY(hipMalloc(&ctx->q_sv, sizeof(uint16_t) * R * 4 * N));
-    Q_TRY(hipMalloc(&ctx->q_spos, sizeof(uint16_t) * R * N));
+    {
+        const size_t idx_bytes = N > 65535 ? sizeof(uint32_t) : sizeof(uint16_t);      // set members / positions: 32-bit beyond 65 535 spins
+        Q_TRY(hipMalloc(reinterpret_cast<void**>(&ctx->q_sv), idx_bytes * R * 4 * N));
+        Q_TRY(hipMalloc(reinterpret_cast<void**>(&ctx->q_spos), idx_bytes * R * N));
+    }
     Q_TRY(hipMalloc(&ctx->q_st, sizeof(int32_t) * R * 4));
     Q_TRY(hipMalloc(&ctx->q_T, sizeof(double) * R * 4));
     Q_TRY(hipMalloc(&ctx->q_z, sizeof(double) * R));
@@ -1533,7 +1536,7 @@ int32_t quant_mc_async(rrrmc_ctx* ctx, bool standard, double beta, double fourK,
         const char* no_wave = std::getenv("RRRMC_QUANT_NO_WAVE");        // timing experiments / cross-checks of the two builds
         int64_t wave_max_R = 2048;
         if (const char* e = std::getenv("RRRMC_QUANT_WAVE_MAX_R")) wave_max_R = std::atoll(e);
-        const bool wave_ok = !ctx->q_skn && (ctx->q_sk ? ctx->qNk <= 2048 : ctx->K <= 64) && sl.bytes <= (size_t)kLdsLimit && ctx->R <= wave_max_R &&
+        const bool wave_ok = !ctx->q_skn && ctx->N <= 65535 && (ctx->q_sk ? ctx->qNk <= 2048 : ctx->K <= 64) && sl.bytes <= (size_t)kLdsLimit && ctx->R <= wave_max_R &&
                              !(no_wave && no_wave[0] == '1');
         if (wave_ok) {
             QsExtra X{};
@@ -1561,7 +1564,7 @@ int32_t quant_mc_async(rrrmc_ctx* ctx, bool standard, double beta, double fourK,
         int64_t wave_max_R = 2048;
         if (const char* e = std::getenv("RRRMC_QUANT_WAVE_MAX_R")) wave_max_R = std::atoll(e);
         // GraphRRG / GraphEA slices with K <= 7, or binary GraphSK slices of up to 2048 spins (one word of the slice per lane)
-        const bool wave_ok = !ctx->q_skn && (ctx->q_sk ? ctx->qNk <= 2048 : ctx->K <= 7) && ctx->qNk <= 65535 && ql.cap >= ctx->N + 4 * kQwMinGap &&
+        const bool wave_ok = !ctx->q_skn && ctx->N <= 65535 && (ctx->q_sk ? ctx->qNk <= 2048 : ctx->K <= 7) && ql.cap >= ctx->N + 4 * kQwMinGap &&
                              ctx->R <= wave_max_R && !(no_wave && no_wave[0] == '1');
         // one replica per workgroup anyway (few replicas): stage its hot state in LDS if it fits (config 5: 115 KB)
         const size_t lds = rrr_quant_lds_bytes(ctx->N, ctx->qW, ctx->qNk, ctx->K);
@@ -1577,7 +1580,7 @@ int32_t quant_mc_async(rrrmc_ctx* ctx, bool standard, double beta, double fourK,
 #endif
             if (ctx->q_sk) hipLaunchKernelGGL(rrr_quant_wave_kernel<true>, dim3((unsigned)ctx->R), dim3(kRrrThreads), ql.bytes, st, P, X);
             else hipLaunchKernelGGL(rrr_quant_wave_kernel<false>, dim3((unsigned)ctx->R), dim3(kRrrThreads), ql.bytes, st, P, X);
-        } else if (!ctx->q_skn && rrr_tpb(ctx->R) == 1 && lds <= (size_t)kLdsLimit && !(no_lds && no_lds[0] == '1')) {
+        } else if (!ctx->q_skn && ctx->N <= 65535 && rrr_tpb(ctx->R) == 1 && lds <= (size_t)kLdsLimit && !(no_lds && no_lds[0] == '1')) {
             if (!ctx->q_lds_attr) {
                 HIP_TRY(ctx, raise_lds_attr(reinterpret_cast<const void*>(rrr_quant_kernel<true>), lds));
                 ctx->q_lds_attr = true;

@@ -116,3 +116,49 @@ def test_levels_above_16_bit(pkg, oracle):
         assert Emin[r] == X.energy_value(e[2]) and (Cmin.s[r] == e[3]).all() and itmin[r] == e[4]
         s = oracle.standard_mc_lev(X.A, X.J, beta, 4000, 500, seed, C0.s[r], replica=r, form="ea", mul=mul, div=div)
         assert (Es_s[r] == X.energy_value(s[0])).all() and (C5.s[r] == s[1]).all() and acc_s[r] == s[2]
+
+
+def test_graph_quant_above_16_bit(pkg, oracle):
+    """GraphQuant with N = Nk M > 65 535 (Nk = 1100, M = 60: 66 000 spins): the thread-per-replica builds with 32-bit set members /
+    positions and the slice of a spin by division; rrrMC (incl. the cache), standardMC and bklMC against the oracle, GraphRRG slices;
+    rrrMC over binary GraphSK slices as well."""
+    seed, beta, Gamma = 660001, 2.0, 0.5
+    Nk, M, R = 1100, 60, 3
+    X1 = pkg.GraphRRG(Nk, 3, seed=seed)
+    X = pkg.GraphQuant(X1, M, Gamma, beta)
+    assert X.N == 66000
+    A, J = X1.A, X1.J.astype(np.int32)
+    with pkg.Engine(X, R) as eng:
+        eng.seed(seed)
+        eng.init_spins_random()
+        C0 = eng.get_config()
+        E0 = eng.energy()
+        Es, acc, staged = eng.rrr_mc(beta, 4000, 500)
+        C1 = eng.get_config()
+        pos, sizes = eng.rrr_cache()
+        eng.seed(seed)
+        eng.set_config(C0)
+        Es_s, acc_s = eng.standard_mc(beta, 6000, 500)
+        C2 = eng.get_config()
+        eng.seed(seed)
+        eng.set_config(C0)
+        Eb, mb = eng.bkl_mc(beta, 3000, 500)
+        C3 = eng.get_config()
+    for r in (0, R - 1):
+        assert E0[r] == oracle.quant_energy(A, J, M, X.fourK, C0.s[r])[0]
+        ref = oracle.rrr_mc_quant(A, J, M, X.fourK, beta, 4000, 500, seed, C0.s[r], replica=r, want_cache=True)
+        assert (Es[r] == ref[0]).all() and (C1.s[r] == ref[1]).all() and acc[r] == ref[2] and staged[r] == ref[3]
+        assert (pos[r] == ref[4]).all() and (sizes[r] == ref[5]).all()
+        s = oracle.standard_mc_quant(A, J, M, X.fourK, beta, 6000, 500, seed, C0.s[r], replica=r)
+        assert (Es_s[r] == s[0]).all() and (C2.s[r] == s[1]).all() and acc_s[r] == s[2]
+        b = oracle.cont_quant("bkl", A, J, M, X.fourK, beta, 3000, 500, seed, C0.s[r], replica=r)
+        assert (Eb[r] == b[0]).all() and (C3.s[r] == b[1]).all() and mb[r] == b[2][0]
+    Xs = pkg.GraphQSKT(Nk, M, Gamma, beta, seed=seed)
+    with pkg.Engine(Xs, 2) as eng:
+        eng.seed(seed)
+        eng.init_spins_random()
+        C0 = eng.get_config()
+        Es, acc, staged = eng.rrr_mc(beta, 3000, 500)
+        C1 = eng.get_config()
+    ref = oracle.rrr_mc_quant_sk(Xs.J, Nk, M, Xs.fourK, beta, 3000, 500, seed, C0.s[1], replica=1)
+    assert (Es[1] == ref[0]).all() and (C1.s[1] == ref[1]).all() and acc[1] == ref[2]
