@@ -8,7 +8,7 @@ Inputs
     (64 slots: 3 Philox4x32-10 blocks + the bit-sliced threshold refinement) — the producers execute ~85 % of the kernel's VALU
     wave-instructions, so their mix is taken as the dynamic mix;
   * profiles/r02/ubench_valu_rates.txt (tools/ubench/valu_rates.hip on the MI355X: ns per wave-instruction per SIMD with 8 waves/SIMD);
-  * profiles/r02/r02d_summary.txt (or the file named on the command line; rocprofv3 --pmc passes of `bench.py --steps 3 --warmup 1`): SQ_INSTS_VALU per launch, GRBM_GUI_ACTIVE.
+  * profiles/r02/r02e_summary.txt (or the file named on the command line; rocprofv3 --pmc passes of `bench.py --steps 3 --warmup 1`): SQ_INSTS_VALU per launch, GRBM_GUI_ACTIVE.
 Output: profiles/r02/sweep31_isa_hist.txt and profiles/r02/valu_model.json (read by bench.py for roofline.valu)."""
 import collections
 import json
@@ -21,7 +21,7 @@ import tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PROF = os.path.join(ROOT, "profiles", "r02")
 SIMDS = 256 * 4
-SUMMARY = sys.argv[1] if len(sys.argv) > 1 else "r02d_summary.txt"      # the rocprofv3 summary of the build being modelled
+SUMMARY = sys.argv[1] if len(sys.argv) > 1 else "r02e_summary.txt"      # the rocprofv3 summary of the build being modelled
 
 
 def kernel_isa():
