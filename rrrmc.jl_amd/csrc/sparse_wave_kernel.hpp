@@ -189,20 +189,6 @@ __global__ __launch_bounds__(kRrrThreads) void rrr_sparse_wave_kernel(RrrSparseP
     double acc_rate = 0.5 + vzd;
     long long accepted = 0, staged_its = 0, ns = 0, next_sample = P.step;
 
-    // ArraySet delete!(S, j) + push!(D, j) (ArraySets.jl:56-76) on the segmented array; p = the slot of j (absolute).  Returns the
-    // element that took j's place (the old last of S; j itself when j was the last).
-    auto set_move = [&](int j, int S, int D, int p) -> int {
-        const int sS = __builtin_amdgcn_readfirstlane(S), sD = __builtin_amdgcn_readfirstlane(D);
-        const int eS = __builtin_amdgcn_readlane(ev, sS) + vz;
-        const int last = (int)l_sv[eS - 1];
-        const int eD = __builtin_amdgcn_readlane(ev, sD) + vz;
-        l_sv[p] = (uint16_t)last;               // all lanes store the same values to the same addresses
-        l_spos[last] = (uint16_t)p;
-        l_sv[eD] = (uint16_t)j;
-        l_spos[j] = (uint16_t)eD;
-        ev = lane == sS ? eS - 1 : (lane == sD ? eD + 1 : ev);
-        return last;
-    };
     auto mulhi_u64_u32 = [](unsigned long long u, uint32_t t) -> uint32_t {
         const unsigned long long lo = (unsigned long long)(uint32_t)u * t;
         const unsigned long long hi = (unsigned long long)(uint32_t)(u >> 32) * t + (lo >> 32);
@@ -330,25 +316,37 @@ __global__ __launch_bounds__(kRrrThreads) void rrr_sparse_wave_kernel(RrrSparseP
             // weights and their differences, lane-parallel
             const double my_f0 = l_f[my_k0], my_f1 = l_f[my_k1];
 
-            // one apply_move! in the reference's order (DeltaE.jl:232-295): T and z' only (dir = +1), or with the set moves
-            auto apply_T = [&](double& Tx, double& zx, bool forward) {
+            // one apply_move! in the reference's order (DeltaE.jl:232-295) over the sites that change class: the running sums (WITH_T), the set
+            // moves (WITH_SETS), or both in one pass.  The per-site values are short-lived scalars (v_readlane results used at once).
+            auto bcast_s = [&](double x, int c) -> double {
+                const unsigned long long u = (unsigned long long)__double_as_longlong(x);
+                const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)u, c), hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(u >> 32), c);
+                return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+            };
+            auto apply = [&](double& Tx, double& zx, bool forward, bool with_T, bool with_sets) {
                 for (int q = 0; q <= P.K; ++q) {
                     if (!((chm >> q) & 1ull)) continue;                                 // wave-uniform
-                    const int k0 = __builtin_amdgcn_readlane(forward ? my_k0 : my_k1, q) + vz, k1 = __builtin_amdgcn_readlane(forward ? my_k1 : my_k0, q) + vz;
-                    const double f0 = bcast(forward ? my_f0 : my_f1, q), f1 = bcast(forward ? my_f1 : my_f0, q);
-                    Tx += lane == k0 ? -f0 : (lane == k1 ? f1 : 0.0);
-                    zx += f1 - f0;
-                }
-            };
-            auto apply_sets = [&](bool forward) {
-                for (int q = 0; q <= P.K; ++q) {
-                    if (!((chm >> q) & 1ull)) continue;
-                    const int j = __builtin_amdgcn_readlane(myj, q) + vz;
-                    const int k0 = __builtin_amdgcn_readlane(forward ? my_k0 : my_k1, q) + vz, k1 = __builtin_amdgcn_readlane(forward ? my_k1 : my_k0, q) + vz;
-                    const int p = __builtin_amdgcn_readlane(my_pos, q) + vz;
-                    const int last = set_move(j, k0, k1, p);
-                    // a site still to come that sat at the end of the set has been moved into the freed slot
-                    my_pos = (lane > q && myj == last) ? p : my_pos;
+                    const int k0 = __builtin_amdgcn_readlane(forward ? my_k0 : my_k1, q), k1 = __builtin_amdgcn_readlane(forward ? my_k1 : my_k0, q);
+                    if (with_T) {
+                        const double f0 = bcast_s(forward ? my_f0 : my_f1, q), f1 = bcast_s(forward ? my_f1 : my_f0, q);
+                        Tx += lane == k0 ? -f0 : (lane == k1 ? f1 : 0.0);
+                        zx += f1 - f0;
+                    }
+                    if (with_sets) {
+                        const int j = __builtin_amdgcn_readlane(myj, q) + vz;
+                        const int p = __builtin_amdgcn_readlane(my_pos, q) + vz;
+                        // ArraySet delete!(S = k0, j) + push!(D = k1, j) (ArraySets.jl:56-76) on the segmented array
+                        const int eS = __builtin_amdgcn_readlane(ev, k0) + vz;
+                        const int last = (int)l_sv[eS - 1];
+                        const int eD = __builtin_amdgcn_readlane(ev, k1) + vz;
+                        l_sv[p] = (uint16_t)last;               // all lanes store the same values to the same addresses
+                        l_spos[last] = (uint16_t)p;
+                        l_sv[eD] = (uint16_t)j;
+                        l_spos[j] = (uint16_t)eD;
+                        ev = lane == k0 ? eS - 1 : (lane == k1 ? eD + 1 : ev);
+                        // a site still to come that sat at the end of the set has been moved into the freed slot
+                        my_pos = (lane > q && myj == last) ? p : my_pos;
+                    }
                 }
             };
             auto flip_move = [&]() { l_sp[move >> 5] ^= 1u << (move & 31); };
@@ -357,8 +355,7 @@ __global__ __launch_bounds__(kRrrThreads) void rrr_sparse_wave_kernel(RrrSparseP
             if (bkl) {
                 flip_move();
                 double zp = z;
-                apply_T(Tv, zp, true);
-                apply_sets(true);
+                apply(Tv, zp, true, true, true);
                 z = zp;
                 it_bkl += skip + 1;
                 E += dE; accepted += 1;
@@ -366,10 +363,10 @@ __global__ __launch_bounds__(kRrrThreads) void rrr_sparse_wave_kernel(RrrSparseP
                 // staged branch (RRRMC.jl:131-138): T' and z' from copies, the sets only on acceptance
                 staged_its += 1;
                 double Tp = Tv, zp = z;
-                apply_T(Tp, zp, true);
+                apply(Tp, zp, true, true, false);
                 if (uni(z >= zp || u1 < z / zp)) {          // u1 < 1 <= z / z': the quotient is only formed when it can matter
                     flip_move();
-                    apply_sets(true);
+                    apply(Tp, zp, true, false, true);
                     Tv = Tp; z = zp;
                     E += dE; accepted += 1; acc = true;
                 }
@@ -377,17 +374,15 @@ __global__ __launch_bounds__(kRrrThreads) void rrr_sparse_wave_kernel(RrrSparseP
                 // direct branch: apply_move!, undone by a second apply_move! on rejection
                 flip_move();
                 double zp = z;
-                apply_T(Tv, zp, true);
-                apply_sets(true);
+                apply(Tv, zp, true, true, true);
                 const bool ok = uni(z >= zp || u1 < z / zp);
                 z = zp;
                 if (ok) { E += dE; accepted += 1; acc = true; }
                 else {
                     flip_move();
                     double zq = z;
-                    apply_T(Tv, zq, false);
                     my_pos = (int)l_spos[myj];
-                    apply_sets(false);
+                    apply(Tv, zq, false, true, true);
                     z = zq;
                 }
             }
