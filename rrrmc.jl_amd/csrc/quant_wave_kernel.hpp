@@ -234,7 +234,7 @@ __global__ __launch_bounds__(kRrrThreads) void rrr_quant_wave_kernel(RrrParams P
     // and discards.  Returns the element that took j's place (the old last of S; j itself when j was the last) so that the caller can
     // patch the slots it has cached.  The gap behind segment D has room (checked once per batch of 64 iterations).
     auto set_move = [&](int j, int S, int D, int p, bool act) -> int {
-        const int sS = __builtin_amdgcn_readfirstlane(S), sD = __builtin_amdgcn_readfirstlane(D);
+        const int sS = S, sD = D;               // wave-uniform scalars (v_readlane results)
         const int eS = __builtin_amdgcn_readlane(ev, sS) + vz;
         const int last = (int)l_sv[eS - 1];
         const int eD = __builtin_amdgcn_readlane(ev, sD) + vz;
@@ -377,9 +377,10 @@ __global__ __launch_bounds__(kRrrThreads) void rrr_quant_wave_kernel(RrrParams P
                 const int sc = qw_wave_sum(sk_pc) + vz;
                 ai = (sc - si) + si * Nk;
             }
-            const int k0a = __builtin_amdgcn_readlane(my_k0, 0) + vz, k1a = __builtin_amdgcn_readlane(my_k1, 0) + vz;
-            const int k0b = __builtin_amdgcn_readlane(my_k0, 1) + vz, k1b = __builtin_amdgcn_readlane(my_k1, 1) + vz;
-            const int k0m = __builtin_amdgcn_readlane(my_k0, 2) + vz, k1m = __builtin_amdgcn_readlane(my_k1, 2) + vz;
+            // (the six classes are short-lived scalars: lane selects of the set moves, table indices)
+            const int k0a = __builtin_amdgcn_readlane(my_k0, 0), k1a = __builtin_amdgcn_readlane(my_k1, 0);
+            const int k0b = __builtin_amdgcn_readlane(my_k0, 1), k1b = __builtin_amdgcn_readlane(my_k1, 1);
+            const int k0m = __builtin_amdgcn_readlane(my_k0, 2), k1m = __builtin_amdgcn_readlane(my_k1, 2);
             int pa = __builtin_amdgcn_readlane(my_pos, 0) + vz, pb = __builtin_amdgcn_readlane(my_pos, 1) + vz, pm = __builtin_amdgcn_readlane(my_pos, 2) + vz;
             // k1m == k0m +- 2 always (the moved spin changes direction, DeltaE.jl:275-276)
             QW_T(1)
@@ -397,7 +398,7 @@ __global__ __launch_bounds__(kRrrThreads) void rrr_quant_wave_kernel(RrrParams P
             };
             // class weights: 1.0, except exp(-beta fourK) for class 3; only T3 is a running sum (x - 0.0 and x + 0.0 leave T3 >= +0 as it is)
             auto flip_move = [&]() { l_sp[move >> 5] ^= 1u << (move & 31); };       // every lane: same word, same value
-            const bool cha = uni(k0a != k1a), chb = uni(k0b != k1b);       // scalar conditions (one ballot each)
+            const bool cha = k0a != k1a, chb = k0b != k1b;                   // scalar conditions
 
             // Float64 bookkeeping of one apply_move! in the reference's order (first neighbour, second neighbour, moved spin,
             // DeltaE.jl:257-282); a skipped neighbour adds +-0.0, which changes neither T3 (>= +0) nor z' (> 0)
