@@ -53,7 +53,10 @@ constexpr int kLeftMax = 128;                    // capacity of the per-chunk li
 constexpr int kSwBlocks = 3;
 constexpr int kSwFixBlocks = 0;
 constexpr int kSwLeftMax = 128;                  // list capacity per chunk; lanes that find it full finish on their own
-constexpr int kPlanThreads = 256;
+#ifndef RRRMC_PLAN_THREADS
+#define RRRMC_PLAN_THREADS 512
+#endif
+constexpr int kPlanThreads = RRRMC_PLAN_THREADS;
 constexpr int kMaxK = 7;                          // 3 bit planes for the unsatisfied-bond count
 // rows of 64 slots the consumer keeps in flight = the longest batch the planner cuts a dependency level into.  A batch costs the
 // consumer about 200 cycles whatever it holds (a dozen scalar instructions and two LDS round trips), so the first, long levels of a
