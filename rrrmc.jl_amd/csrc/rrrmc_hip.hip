@@ -81,6 +81,13 @@ struct rrrmc_ctx {
     std::vector<BatchDesc> chunk_batches;
     uint32_t* d_slots[2] = {nullptr, nullptr};   // double-buffered: the planner of batch b+1 overlaps the sweep of batch b
     uint32_t* d_vecs[2] = {nullptr, nullptr};
+    uint32_t* d_nbrs[2] = {nullptr, nullptr};    // big mode: the neighbour row of every slot (K words), written by plan_big_kernel
+    uint32_t* d_masks[2] = {nullptr, nullptr};   // big mode, few groups: acceptance masks of every (slot, group) of a batch (big_mask_kernel)
+    bool big_masks = false;
+    int big_lgr = 5;                             // big_apply_kernel: 2^lgr replicas per workgroup (their spins fit LDS)
+    uint32_t* d_bigimg = nullptr;                // [G * S][ceil(N / S)] the workgroups' LDS images between big_apply_kernel and big_merge_kernel
+    int64_t batch_chunks_max = kMaxChunksPerBatch;
+    int64_t batch_slots_max = kMaxSlotsPerBatch; // slots per batch (plan buffers; the mask buffers when big_masks)
     hipStream_t plan_stream = nullptr;
     hipEvent_t ev_upload = nullptr;
     std::vector<hipEvent_t> ev_plan;     // plan of batch b finished
@@ -290,10 +297,14 @@ typedef void (*plan_fn)(ChunkDesc*, uint32_t*, uint32_t*, const int32_t*, int, i
 int sweep_rows_for_K(int K) { switch (K) { case 1: return sweep_rows<1>(); case 2: return sweep_rows<2>(); case 3: return sweep_rows<3>(); case 4: return sweep_rows<4>(); case 5: return sweep_rows<5>(); case 6: return sweep_rows<6>(); default: return sweep_rows<7>(); } }
 plan_fn plan_for_K(int K) { RRRMC_DISPATCH_UPTO7(K, plan_kernel) }
 
-typedef void (*plan_big_fn)(ChunkDesc*, uint32_t*, uint32_t*, const int32_t*, int, uint32_t, uint32_t, uint64_t);
+typedef void (*plan_big_fn)(ChunkDesc*, uint32_t*, uint32_t*, uint32_t*, const int32_t*, const int8_t*, int, uint32_t, uint32_t, uint64_t, int);
 plan_big_fn plan_big_for_K(int K) { RRRMC_DISPATCH_UPTO7(K, plan_big_kernel) }
 typedef void (*big_sweep_fn)(BigSweepParams);
 big_sweep_fn big_sweep_for_K(int K) { RRRMC_DISPATCH_UPTO7(K, big_sweep_kernel) }
+typedef void (*big_mask_fn)(BigMaskParams);
+big_mask_fn big_mask_for_K(int K) { RRRMC_DISPATCH_UPTO7(K, big_mask_kernel) }
+typedef void (*big_apply_fn)(BigSweepParams, const uint32_t*, uint32_t*, uint32_t, int);
+big_apply_fn big_apply_for_K(int K) { RRRMC_DISPATCH_UPTO7(K, big_apply_kernel) }
 
 typedef void (*sweep_fn)(SweepParams);
 sweep_fn sweep_for_K(int K, int mode)
@@ -469,7 +480,7 @@ int32_t prepare_chunk_list(rrrmc_ctx* ctx, int64_t iters, int64_t step, int C, b
             size_t first = 0;
             int64_t slots = 0, samples = 0, sample0 = 0;
             for (size_t c = 0; c < nch_all; ++c) {
-                if (c > first && (slots + chunks[c].count > kMaxSlotsPerBatch || (int64_t)(c - first) >= kMaxChunksPerBatch)) {
+                if (c > first && (slots + chunks[c].count > ctx->batch_slots_max || (int64_t)(c - first) >= ctx->batch_chunks_max)) {
                     ctx->chunk_batches.push_back({first, c - first, sample0});
                     first = c; slots = 0; sample0 = samples;
                 }
@@ -625,6 +636,18 @@ int32_t rrrmc_ctx_create(rrrmc_ctx** out, int32_t model, int64_t N, int64_t K, i
     ctx->C = C;
     ctx->lds_bytes = ctx->lds_mode ? sweep_lds_bytes(N, (int)K, ctx->TS, C, ctx->wide, ctx->sweep_mode == 3) : 0;
     ctx->plan_lds_bytes = ctx->lds_mode ? plan_lds_bytes(N, (int)K, C) : (ctx->big_mode ? plan_big_lds_bytes((int)K) : 0);
+    ctx->batch_slots_max = kMaxSlotsPerBatch;
+    if (ctx->big_mode) {
+        // few replica groups: the acceptance masks of a batch are made by the whole device first (big_mask_kernel), the per-group
+        // workgroups only apply them.  The mask buffers (2 x G x 4 words per slot) bound the batch.
+        const int64_t per_slot = (int64_t)ctx->G * 16;                      // four mask words per (slot, group)
+        int64_t fit = ((int64_t)1 << 31) / per_slot / kBigChunk * kBigChunk;
+        ctx->big_masks = ctx->G <= 512 && fit >= 16 * kBigChunk;
+        if (const char* e = std::getenv("RRRMC_BIG_NO_MASKS")) { if (e[0] == '1') ctx->big_masks = false; }
+        if (ctx->big_masks && fit < ctx->batch_slots_max) ctx->batch_slots_max = fit;
+        ctx->big_lgr = big_lds_lgr(N);
+        if (ctx->big_masks) ctx->batch_chunks_max = kBigApplyChunks;
+    }
 
 #define CREATE_TRY(expr)                                                                                         \
     do {                                                                                                         \
@@ -650,6 +673,13 @@ int32_t rrrmc_ctx_create(rrrmc_ctx** out, int32_t model, int64_t N, int64_t K, i
     for (int i = 0; i < 2; ++i) {
         CREATE_TRY(hipMalloc(&ctx->d_slots[i], sizeof(uint32_t) * kMaxSlotsPerBatch));
         CREATE_TRY(hipMalloc(&ctx->d_vecs[i], sizeof(uint32_t) * kMaxSlotsPerBatch));
+        if (ctx->big_mode) CREATE_TRY(hipMalloc(&ctx->d_nbrs[i], sizeof(uint32_t) * kMaxSlotsPerBatch * kBigRec));
+        if (ctx->big_masks) CREATE_TRY(hipMalloc(&ctx->d_masks[i], sizeof(uint32_t) * 4 * ctx->batch_slots_max * ctx->G));
+    }
+    if (ctx->big_masks) {
+        const int64_t S = 32 >> ctx->big_lgr;
+        CREATE_TRY(hipMalloc(&ctx->d_bigimg, sizeof(uint32_t) * ctx->G * S * ((N + S - 1) / S)));
+        CREATE_TRY(raise_lds_attr(reinterpret_cast<const void*>(big_apply_for_K((int)K)), big_lds_bytes(N, ctx->big_lgr)));
     }
     CREATE_TRY(hipStreamCreateWithFlags(&ctx->plan_stream, hipStreamNonBlocking));
     CREATE_TRY(hipEventCreateWithFlags(&ctx->ev_upload, hipEventDisableTiming));
@@ -691,7 +721,8 @@ void rrrmc_ctx_destroy(rrrmc_ctx* ctx)
     free_dev(ctx->q_Jb); free_dev(ctx->q_slf); free_dev(ctx->q_smv); free_dev(ctx->q_scur);
     free_dev(ctx->cs_spins); free_dev(ctx->cs_buf); free_dev(ctx->cs_u16);
     free_dev(ctx->snap); free_dev(ctx->d_pairs); free_dev(ctx->d_ovl); free_dev(ctx->d_qobs);
-    for (int i = 0; i < 2; ++i) { free_dev(ctx->d_slots[i]); free_dev(ctx->d_vecs[i]); }
+    for (int i = 0; i < 2; ++i) { free_dev(ctx->d_slots[i]); free_dev(ctx->d_vecs[i]); free_dev(ctx->d_nbrs[i]); free_dev(ctx->d_masks[i]); }
+    free_dev(ctx->d_bigimg);
     if (ctx->plan_stream) { (void)hipStreamSynchronize(ctx->plan_stream); (void)hipStreamDestroy(ctx->plan_stream); }
     if (ctx->ev_upload) (void)hipEventDestroy(ctx->ev_upload);
     for (hipEvent_t e : ctx->ev_plan) (void)hipEventDestroy(e);
@@ -1093,8 +1124,14 @@ int32_t rrrmc_standard_mc_async(rrrmc_ctx* ctx, double beta, int64_t iters, int6
     P.N = (int)N; P.C = C; P.TS = ctx->TS; P.Rpad = (int)ctx->Rpad;
     sweep_fn fn = ctx->lds_mode ? sweep_for_K((int)K, ctx->sweep_mode) : nullptr;
     BigSweepParams PB{};
+    BigMaskParams PM{};
+    if (ctx->big_masks) {
+        std::memcpy(PM.taum, P.taum, sizeof(PM.taum));
+        PM.always_mask = P.always_mask; PM.k0 = P.k0; PM.k1 = P.k1; PM.group0 = P.group0; PM.gbase = P.gbase;
+        PM.cap = (uint32_t)ctx->batch_slots_max;
+    }
     if (ctx->big_mode) {
-        PB.spins = ctx->d_spins; PB.A = ctx->d_A; PB.J = ctx->d_J; PB.Es = ctx->d_Es; PB.E_cur = ctx->d_E; PB.acc_cur = ctx->d_acc;
+        PB.spins = ctx->d_spins; PB.Es = ctx->d_Es; PB.E_cur = ctx->d_E; PB.acc_cur = ctx->d_acc;
         std::memcpy(PB.taum, P.taum, sizeof(PB.taum));
         PB.always_mask = P.always_mask; PB.k0 = P.k0; PB.k1 = P.k1; PB.group0 = P.group0; PB.gbase = P.gbase;
         PB.N = (int)N; PB.Rpad = (int)ctx->Rpad;
@@ -1109,9 +1146,16 @@ int32_t rrrmc_standard_mc_async(rrrmc_ctx* ctx, double beta, int64_t iters, int6
     auto launch_plan = [&](int b) -> int32_t {
         const rrrmc_ctx::BatchDesc& bt = batches[b];
         if (b >= 2) HIP_TRY(ctx, hipStreamWaitEvent(ctx->plan_stream, EV[ebase + 2 * (b - 2) + 1], 0));
-        if (ctx->big_mode)
+        if (ctx->big_mode) {
             hipLaunchKernelGGL(plan_big_for_K((int)K), dim3((unsigned)bt.n), dim3(kPlanThreads), ctx->plan_lds_bytes, ctx->plan_stream,
-                               ctx->d_chunks + bt.first, ctx->d_slots[b & 1], ctx->d_vecs[b & 1], ctx->d_A, (int)N, P.k0, P.k1, P.gbase);
+                               ctx->d_chunks + bt.first, ctx->d_slots[b & 1], ctx->d_nbrs[b & 1], ctx->d_vecs[b & 1], ctx->d_A, ctx->d_J, (int)N, P.k0, P.k1, P.gbase,
+                               ctx->big_masks ? ctx->big_lgr : -1);
+            if (ctx->big_masks) {
+                PM.chunks = ctx->d_chunks + bt.first; PM.slots = ctx->d_slots[b & 1]; PM.masks = ctx->d_masks[b & 1];
+                hipLaunchKernelGGL(big_mask_for_K((int)K), dim3((unsigned)(bt.n * (kBigChunk / kBigMaskThreads)), (unsigned)ctx->G), dim3(kBigMaskThreads), 0,
+                                   ctx->plan_stream, PM);
+            }
+        }
         else
             hipLaunchKernelGGL(plan_for_K((int)K), dim3((unsigned)bt.n), dim3(kPlanThreads), ctx->plan_lds_bytes, ctx->plan_stream,
                                ctx->d_chunks + bt.first, ctx->d_slots[b & 1], ctx->d_vecs[b & 1], ctx->d_A, (int)N, C, P.k0, P.k1, P.gbase,
@@ -1131,8 +1175,16 @@ int32_t rrrmc_standard_mc_async(rrrmc_ctx* ctx, double beta, int64_t iters, int6
         P.vecs = ctx->d_vecs[b & 1];
         HIP_TRY(ctx, hipEventRecord(EV[ebase + 2 * b], st));
         if (ctx->big_mode) {
-            PB.chunks = P.chunks; PB.nchunks = P.nchunks; PB.sample0 = P.sample0; PB.slots = P.slots; PB.vecs = P.vecs;
-            hipLaunchKernelGGL(big_sweep_for_K((int)K), dim3((unsigned)ctx->G), dim3(kBigThreads), 0, st, PB);
+            PB.chunks = P.chunks; PB.nchunks = P.nchunks; PB.sample0 = P.sample0; PB.slots = P.slots; PB.nbrs = ctx->d_nbrs[b & 1]; PB.vecs = P.vecs;
+            if (ctx->big_masks) {
+                const int S = 32 >> ctx->big_lgr;
+                hipLaunchKernelGGL(big_apply_for_K((int)K), dim3((unsigned)(ctx->G * S)), dim3(kBigApplyThreads), big_lds_bytes(N, ctx->big_lgr), st, PB,
+                                   ctx->d_masks[b & 1], ctx->d_bigimg, (uint32_t)ctx->batch_slots_max, ctx->big_lgr);
+                hipLaunchKernelGGL(big_merge_kernel, dim3((unsigned)((N + 255) / 256), (unsigned)ctx->G), dim3(256), 0, st, ctx->d_spins, ctx->d_bigimg,
+                                   (int)N, ctx->big_lgr);
+            }
+            else
+                hipLaunchKernelGGL(big_sweep_for_K((int)K), dim3((unsigned)ctx->G), dim3(kBigThreads), 0, st, PB);
         } else {
             hipLaunchKernelGGL(fn, dim3((unsigned)ctx->G), dim3(kSweepThreads), ctx->lds_bytes, st, P);
         }

@@ -44,7 +44,9 @@ def test_forced_big_path_equals_oracle_and_lds_kernel(pkg, oracle, monkeypatch, 
 @pytest.mark.parametrize("kind,R,beta,iters,step", [
     (("rrg", 20000, 3), 40, 1.0, 60000, 20000),     # beyond the LDS kernel (N > ~17 000)
     (("ea", 30, 3), 33, 1.0, 54000, 27000),         # N = 27 000, K = 6
-    (("ea", 64, 3), 32, 1.0, 40000, 10000),         # BASELINE config 4's lattice (N = 262 144) under the reference's own dynamics
+    (("ea", 64, 3), 32, 1.0, 40000, 10000),         # BASELINE config 4's lattice (N = 262 144) under the reference's own dynamics: 4 replicas per workgroup
+    (("rrg", 40000, 4), 70, 1.0, 90000, 40000),     # 16 replicas per workgroup, three groups (the last one padded)
+    (("ea", 41, 3), 40, 1.5, 70000, 30000),         # N = 68 921: 8 replicas per workgroup, a ragged last LDS word
 ])
 def test_large_graphs_random_site(pkg, oracle, kind, R, beta, iters, step):
     seed = 700000 + kind[1]
@@ -57,7 +59,7 @@ def test_large_graphs_random_site(pkg, oracle, kind, R, beta, iters, step):
         C1 = eng.get_config()
         E1 = eng.energy()
     J = X.J.astype(np.int32)
-    for r in (0, 1, R - 1):
+    for r in sorted({0, 1, 9, 17, R // 2, R - 1}):
         ref = oracle.standard_mc_sparse(X.A, J, beta, iters, step, seed, C0.s[r], replica=r, form=form)
         assert (Es[r] == ref[0]).all() and (C1.s[r] == ref[1]).all() and acc[r] == ref[2]
         assert E1[r] == oracle.sparse_energy(X.A, J, C1.s[r])
