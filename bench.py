@@ -266,6 +266,39 @@ def secondary_c4(pkg, O, device):
     return out
 
 
+def secondary_c4_random(pkg, O, device):
+    """configs[3]'s lattice under the reference's OWN sampler (random-site standardMC, src/RRRMC.jl:81-127) at one GPU's share:
+    plan_big_kernel / big_mask_kernel / big_apply_kernel (spins of 4 replicas per workgroup in LDS)."""
+    L, D, R, beta, sweeps = 64, 3, 512, 1.0, 16
+    X = pkg.GraphEA(L, D, seed=SEED)
+    with pkg.Engine(X, R, device=device) as eng:
+        eng.seed(SEED)
+        eng.init_spins_random()
+        eng.standard_mc_async(beta, X.N, X.N); eng.sync()
+        t0 = time.perf_counter()
+        eng.standard_mc_async(beta, sweeps * X.N, X.N); eng.sync()
+        dt = time.perf_counter() - t0
+        _, dev_ms, nl = eng.last_timing()
+        _, acc = eng.fetch_results(want_energies=False)
+    attempts = float(R) * sweeps * X.N
+    a = float(acc.mean()) / (sweeps * X.N)
+    bpa = 1 + a * (3 + 3 * X.K)
+    out = {"workload": "GraphEA(L=64,D=3,+-J) random-site standardMC beta=1.0, 512 replicas (one GPU's share of 4096), 16 sweeps, sample every sweep",
+           "value": attempts / dt, "unit": "attempts/s", "kernel": "big_apply_kernel<6>", "device_ms": dev_ms, "launches": nl,
+           "acceptance": a, "algorithmic_bytes_per_attempt": bpa, "achieved_GBps": bpa * attempts / (dev_ms * 1e-3) / 1e9,
+           "note": "the spins live in LDS (4 replicas per workgroup); the kernel streams 48 bytes of plan records and masks per attempt "
+                   "and workgroup, which is what bounds it (DESIGN.md 4g)"}
+    out["frac"] = out["achieved_GBps"] / HBM_PEAK_GBS
+    if O is not None:
+        with pinned_core():
+            ch = O.init_configs(SEED, 0, 1, X.N)[0]
+            t0 = time.perf_counter()
+            O.standard_mc_sparse(X.A, X.J.astype(np.int32), beta, 4 * X.N, X.N, SEED, ch, replica=0, form="ea")
+            out["cpu_one_core"] = {"value": 4 * X.N / (time.perf_counter() - t0), "unit": "attempts/s", "kind": "port",
+                                   "sample": "1 replica x 4 sweeps, oracle"}
+    return out
+
+
 def secondary_c5(pkg, O, device):
     """configs[4] at one GPU's share: GraphQuant(GraphRRG(1024,3), M=32) under rrrMC, 128 of the 1024 replicas."""
     Nk, M, R, beta, Gamma, iters, step = 1024, 32, 128, 2.0, 0.5, 1 << 17, 1 << 12
@@ -335,7 +368,8 @@ def eng_kernel_name_quant():
 
 def secondary(pkg, O, device):
     out = {}
-    for name, fn in (("c3_sk_normal", secondary_c3), ("c4_ea_checkerboard", secondary_c4), ("c5_quant_rrr", secondary_c5),
+    for name, fn in (("c3_sk_normal", secondary_c3), ("c4_ea_checkerboard", secondary_c4), ("c4_ea_random_site", secondary_c4_random),
+                     ("c5_quant_rrr", secondary_c5),
                      ("f64_sparse_fast", secondary_f64_fast)):
         t0 = time.perf_counter()
         try:

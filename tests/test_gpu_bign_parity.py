@@ -1,5 +1,6 @@
-"""GPU parity for random-site standardMC on +-J graphs that do not fit the LDS-resident kernel (plan_big_kernel /
-big_sweep_kernel, spins in HBM/L2): bit-identical to the oracle, and to the LDS kernel where both apply."""
+"""GPU parity for random-site standardMC on +-J graphs that do not fit the LDS-resident kernel (plan_big_kernel, then
+big_mask_kernel + big_apply_kernel with the spins of 2^lgr replicas per workgroup in LDS, or big_sweep_kernel with the spins in
+HBM/L2): both bit-identical to the oracle, and to the LDS kernel where both apply."""
 import numpy as np
 import pytest
 
@@ -24,8 +25,9 @@ def test_forced_big_path_equals_oracle_and_lds_kernel(pkg, oracle, monkeypatch, 
     seed = 600000 + kind[1] * 7 + kind[2]
     X, form = _graph(pkg, kind, seed)
     out = []
-    for big in ("1", "0"):
+    for big, no_masks in (("1", "0"), ("0", "0"), ("1", "1")):
         monkeypatch.setenv("RRRMC_FORCE_BIG", big)
+        monkeypatch.setenv("RRRMC_BIG_NO_MASKS", no_masks)
         with pkg.Engine(X, R) as eng:
             eng.seed(seed)
             eng.init_spins_random()
@@ -33,8 +35,8 @@ def test_forced_big_path_equals_oracle_and_lds_kernel(pkg, oracle, monkeypatch, 
             a = eng.standard_mc(beta, iters, step)
             b = eng.standard_mc(beta, iters // 3, step)           # a second call continues the streams
             out.append((a[0], a[1], b[0], b[1], eng.get_config().s, eng.energy()))
-    for u, v in zip(*out):
-        assert (u == v).all()
+    for u, v, w in zip(*out):
+        assert (u == v).all() and (u == w).all()
     ref = oracle.standard_mc_sparse_batch(X.A, X.J.astype(np.int32), beta, iters, step, seed, C0.s, form=form)
     assert (out[0][0] == ref[0]).all() and (out[0][1] == ref[2]).all()
     ref2 = oracle.standard_mc_sparse_batch(X.A, X.J.astype(np.int32), beta, iters // 3, step, seed, ref[1], it0=iters, form=form)
@@ -47,8 +49,11 @@ def test_forced_big_path_equals_oracle_and_lds_kernel(pkg, oracle, monkeypatch, 
     (("ea", 64, 3), 32, 1.0, 40000, 10000),         # BASELINE config 4's lattice (N = 262 144) under the reference's own dynamics: 4 replicas per workgroup
     (("rrg", 40000, 4), 70, 1.0, 90000, 40000),     # 16 replicas per workgroup, three groups (the last one padded)
     (("ea", 41, 3), 40, 1.5, 70000, 30000),         # N = 68 921: 8 replicas per workgroup, a ragged last LDS word
+    (("rrg", 33000, 3), 33, 1.0, 2300000, 500000),  # 562 chunks: two launches of big_apply_kernel (512 chunk headers fit its LDS), samples across them
 ])
-def test_large_graphs_random_site(pkg, oracle, kind, R, beta, iters, step):
+@pytest.mark.parametrize("no_masks", ["0", "1"])       # big_mask_kernel + big_apply_kernel (default) / big_sweep_kernel
+def test_large_graphs_random_site(pkg, oracle, monkeypatch, kind, R, beta, iters, step, no_masks):
+    monkeypatch.setenv("RRRMC_BIG_NO_MASKS", no_masks)
     seed = 700000 + kind[1]
     X, form = _graph(pkg, kind, seed)
     with pkg.Engine(X, R) as eng:
