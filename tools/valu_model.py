@@ -21,7 +21,7 @@ import tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PROF = os.path.join(ROOT, "profiles", "r02")
 SIMDS = 256 * 4
-SUMMARY = sys.argv[1] if len(sys.argv) > 1 else "r02e_summary.txt"      # the rocprofv3 summary of the build being modelled
+SUMMARY = sys.argv[1] if len(sys.argv) > 1 else "r02f_summary.txt"      # the rocprofv3 summary of the build being modelled
 
 
 def kernel_isa():
