@@ -286,7 +286,7 @@ def secondary_c4_random(pkg, O, device):
     out = {"workload": "GraphEA(L=64,D=3,+-J) random-site standardMC beta=1.0, 512 replicas (one GPU's share of 4096), 16 sweeps, sample every sweep",
            "value": attempts / dt, "unit": "attempts/s", "kernel": "big_apply_kernel<6>", "device_ms": dev_ms, "launches": nl,
            "acceptance": a, "algorithmic_bytes_per_attempt": bpa, "achieved_GBps": bpa * attempts / (dev_ms * 1e-3) / 1e9,
-           "note": "the spins live in LDS (4 replicas per workgroup); the kernel streams 48 bytes of plan records and masks per attempt "
+           "note": "the spins live in LDS (4 replicas per workgroup); the kernel streams 36 bytes of plan records and masks per attempt "
                    "and workgroup, which is what bounds it (DESIGN.md 4g)"}
     out["frac"] = out["achieved_GBps"] / HBM_PEAK_GBS
     if O is not None:

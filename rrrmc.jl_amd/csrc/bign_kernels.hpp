@@ -34,7 +34,8 @@ namespace rrrmc {
 constexpr int kBigChunk = 4096;            // attempts per chunk: the index inside the chunk takes 12 bits of a slot word
 constexpr int kBigSiteBits = 20;           // sites take the other 20: N <= 2^20
 constexpr int kBigThreads = 1024;
-constexpr int kBigRec = 8;                 // words of a slot's record: the slot word, then the K <= 7 neighbour words (two 16-byte loads)
+// words of a slot's record: the slot word, then the K neighbour words — one 16-byte load up to K = 3, two beyond
+__host__ __device__ constexpr int big_rec_words(int K) { return K <= 3 ? 4 : 8; }
 
 inline size_t plan_big_lds_bytes(int K)
 {
@@ -53,9 +54,9 @@ __host__ __device__ inline uint32_t big_lds_ref(uint32_t site, int lgr)
 }
 
 //   slots[slot_base + p] = site | (t << 20)   attempts sorted by dependency level (t = index in chunk)
-//   nbrs [(slot_base + p) * 8] = the slot word again, [.. + 1 + k] = k-th neighbour of that site | (J < 0) << 31   (the slot's RECORD:
-//                                                8 words, read by the sweeps as two 16-byte loads; with lgr >= 0 the sites are written
-//                                                as big_lds_ref(site, lgr), the form big_apply_kernel consumes)
+//   nbrs [(slot_base + p) * W] = the slot word again, [.. + 1 + k] = k-th neighbour of that site | (J < 0) << 31   (the slot's RECORD:
+//                                                W = 4 words up to K = 3, 8 beyond: one or two 16-byte loads; with lgr >= 0 the sites
+//                                                are written as big_lds_ref(site, lgr), the form big_apply_kernel consumes)
 //   vecs [slot_base + l] = first slot of level l + 1 (l = 0 .. nvec-1); chunks[c].nvec = number of levels
 template <int K>
 __global__ __launch_bounds__(kPlanThreads) void plan_big_kernel(ChunkDesc* __restrict__ chunks, uint32_t* __restrict__ slots,
@@ -164,7 +165,7 @@ __global__ __launch_bounds__(kPlanThreads) void plan_big_kernel(ChunkDesc* __res
         const uint32_t l = s_lvl[t];
         const uint32_t pos = (uint32_t)s_start[l] + add16(s_cur, l);
         slots[cd.slot_base + pos] = s_site[t] | ((uint32_t)t << kBigSiteBits);
-        nbrs[((size_t)cd.slot_base + pos) * kBigRec] = lgr < 0 ? s_site[t] | ((uint32_t)t << kBigSiteBits) : big_lds_ref(s_site[t], lgr);
+        nbrs[((size_t)cd.slot_base + pos) * big_rec_words(K)] = lgr < 0 ? s_site[t] | ((uint32_t)t << kBigSiteBits) : big_lds_ref(s_site[t], lgr);
         s_lvl[t] = (uint16_t)pos;                                        // the levels are done: keep the slot of attempt t
     }
     __syncthreads();
@@ -172,7 +173,7 @@ __global__ __launch_bounds__(kPlanThreads) void plan_big_kernel(ChunkDesc* __res
     for (int q = tid; q < count * K; q += kPlanThreads) {
         const int t = q / K, k = q - t * K;
         const size_t e = (size_t)s_site[t] * K + k;
-        nbrs[((size_t)cd.slot_base + s_lvl[t]) * kBigRec + 1 + k] = (lgr < 0 ? (uint32_t)A[e] : big_lds_ref((uint32_t)A[e], lgr)) | (J[e] < 0 ? 0x80000000u : 0u);
+        nbrs[((size_t)cd.slot_base + s_lvl[t]) * big_rec_words(K) + 1 + k] = (lgr < 0 ? (uint32_t)A[e] : big_lds_ref((uint32_t)A[e], lgr)) | (J[e] < 0 ? 0x80000000u : 0u);
     }
 }
 
@@ -180,7 +181,7 @@ struct BigSweepParams {
     uint32_t* spins;          // [G][N]   bit-sliced configuration
     const ChunkDesc* chunks;
     const uint32_t* slots;
-    const uint32_t* nbrs;     // [slot][8]   slot word, then neighbour | (J < 0) << 31 for the K neighbours: written by the planner in slot order
+    const uint32_t* nbrs;     // [slot][big_rec_words(K)]   slot word, then neighbour | (J < 0) << 31 for the K neighbours: written by the planner in slot order
     const uint32_t* vecs;
     int32_t* Es;              // [nsamples][Rpad]
     int32_t* E_cur;           // [Rpad]
@@ -278,7 +279,7 @@ __global__ __launch_bounds__(kBigThreads) void big_sweep_kernel(BigSweepParams P
             ns += 1;
         }
         const uint32_t* slots = P.slots + cd.slot_base;
-        const uint32_t* nbrs = P.nbrs + (size_t)cd.slot_base * kBigRec;      // in-chunk offsets below fit 32 bits
+        const uint32_t* nbrs = P.nbrs + (size_t)cd.slot_base * big_rec_words(K);      // in-chunk offsets below fit 32 bits
         for (uint32_t l = 0; l < cd.nvec; ++l) {
             const uint32_t start = P.vecs[cd.slot_base + l];
             const uint32_t end = l + 1 < cd.nvec ? P.vecs[cd.slot_base + l + 1] : cd.count;
@@ -299,7 +300,7 @@ __global__ __launch_bounds__(kBigThreads) void big_sweep_kernel(BigSweepParams P
                     if (live[u]) {
                         slot[u] = slots[p];
 #pragma unroll
-                        for (int k = 0; k < K; ++k) gk[u][k] = nbrs[p * (uint32_t)kBigRec + 1u + (uint32_t)k];
+                        for (int k = 0; k < K; ++k) gk[u][k] = nbrs[p * (uint32_t)big_rec_words(K) + 1u + (uint32_t)k];
                     }
                 }
 #pragma unroll
@@ -376,7 +377,8 @@ __global__ __launch_bounds__(kBigThreads) void big_sweep_kernel(BigSweepParams P
 // big_sweep_kernel gives a replica group one CU, and most of that CU's time goes into the ACCEPT planes — which do not depend on the
 // state.  big_mask_kernel<K> evaluates them for every (slot, group) of a batch on all CUs (lt_n = "u < T_n" for the 32 replicas and every
 // class with dE > 0, resolved to the last replica) and big_apply_kernel<K> runs the levels with what is left: gathers, the bond count,
-// one select per class, the flip.      masks[(group * cap + slot_base + p) * 4 + n]   (cap = slots per batch of the context; one 16-byte load)
+// one select per class, the flip.      masks[(group * cap + slot_base + p) * 4 + n]   (cap = slots per batch of the context; one 16-byte load),
+// or, where the NT * r mask bits of a workgroup's r replicas fit a word: masks[(group * S + sub) * cap + slot_base + p]
 struct BigMaskParams {
     const ChunkDesc* chunks;
     const uint32_t* slots;
@@ -386,8 +388,12 @@ struct BigMaskParams {
     uint32_t k0, k1, group0;
     uint64_t gbase;
     uint32_t cap;
+    int lgr;                  // >= 0: compact masks for big_apply_kernel's workgroups of 2^lgr replicas (NT * 2^lgr <= 32), one word per
+                              // (slot, workgroup): class n's bits at n * r;  < 0: four words per (slot, group)
 };
 constexpr int kBigMaskThreads = 256;
+// one word holds the masks of a workgroup's r replicas for all NT classes?
+__host__ __device__ inline bool big_masks_compact(int K, int lgr) { return lgr <= 4 && (((K + 1) / 2) << lgr) <= 32; }
 
 template <int K>
 __global__ __launch_bounds__(kBigMaskThreads) void big_mask_kernel(BigMaskParams M)
@@ -412,6 +418,16 @@ __global__ __launch_bounds__(kBigMaskThreads) void big_mask_kernel(BigMaskParams
         for (int b = 0; b < kBigEager; ++b) refine_block<NT>(lt, eq, accept_planes(M.k0, M.k1, g, group, (uint32_t)b), (uint32_t)b, M.taum);
         for (uint32_t pb = (uint32_t)kBigEager; pb < 16u && any_set<NT>(eq); ++pb)
             refine_block<NT>(lt, eq, accept_planes(M.k0, M.k1, g, group, pb), pb, M.taum);
+    }
+    if (M.lgr >= 0) {
+        const uint32_t r = 1u << M.lgr, S = 32u >> M.lgr, rm = (1u << r) - 1u;          // r <= 16 here
+        for (uint32_t sub = 0; sub < S; ++sub) {
+            uint32_t w = 0u;
+#pragma unroll
+            for (int n = 0; n < NT; ++n) w |= ((lt[n] >> (sub << M.lgr)) & rm) << ((uint32_t)n << M.lgr);
+            M.masks[((size_t)blockIdx.y * S + sub) * M.cap + cd.slot_base + p] = w;
+        }
+        return;
     }
     uint32_t o[4] = {0u, 0u, 0u, 0u};
 #pragma unroll
@@ -455,11 +471,12 @@ __device__ __forceinline__ void big_lds_barrier()
 
 template <int I> struct BigStage { static constexpr int value = I; };       // a compile-time stage index for the generic lambdas below
 
-template <int K>
-__global__ __launch_bounds__(kBigApplyThreads) void big_apply_kernel(BigSweepParams P, const uint32_t* __restrict__ masks, uint32_t* __restrict__ img,
-                                                                    uint32_t cap, int lgr)
+template <int K, bool CM>
+__device__ __forceinline__ void big_apply_body(const BigSweepParams& P, const uint32_t* __restrict__ masks, uint32_t* __restrict__ img, uint32_t cap, int lgr)
 {
     constexpr int NT = (K + 1) / 2;
+    constexpr int NM = CM ? 1 : NT;                           // mask words per attempt
+    constexpr int REC = big_rec_words(K);
     constexpr int U = 2048 / kBigApplyThreads;                // attempts per thread and round
     constexpr int NTH = kBigApplyThreads;
     constexpr uint32_t RS = (uint32_t)(U * NTH);              // slots per round
@@ -470,7 +487,8 @@ __global__ __launch_bounds__(kBigApplyThreads) void big_apply_kernel(BigSweepPar
     const uint32_t grp = blockIdx.x >> lgS, sub = blockIdx.x & (S - 1u), rsh = sub << lgr;      // replicas rsh .. rsh + r - 1 of group grp
     const uint32_t nwords = ((uint32_t)P.N + S - 1u) >> lgS;
     uint32_t* gsp = P.spins + (size_t)grp * P.N;
-    const char* gmask = reinterpret_cast<const char*>(masks) + (size_t)grp * cap * 16;      // 32-bit byte offsets below: one address register per load
+    // 32-bit byte offsets below: one address register per load
+    const char* gmask = reinterpret_cast<const char*>(masks) + (CM ? (size_t)blockIdx.x * cap * 4 : (size_t)grp * cap * 16);
     const char* recs = reinterpret_cast<const char*>(P.nbrs);
     const uint32_t rep0 = grp * 32u + rsh;
     if (tid < (int)r) { s_E[tid] = P.E_cur[rep0 + tid]; s_A[tid] = 0; }
@@ -525,7 +543,7 @@ __global__ __launch_bounds__(kBigApplyThreads) void big_apply_kernel(BigSweepPar
     // two rounds of records in registers (stage = round mod 2; every index below is a compile-time constant):
     // <= U * kBigApplyThreads attempts of one level each, plus what the round is (wave-uniform): a round at all / the first of its
     // level / the first of its chunk / that chunk starts with a sample
-    uint32_t q_slot[2][U], q_raw[2][U][K], q_m[2][U][NT];
+    uint32_t q_slot[2][U], q_raw[2][U][K], q_m[2][U][NM];
     bool q_live[2][U], q_valid[2], q_first[2], q_cfirst[2], q_sample[2];
     // requests the records of the iterator's round and moves the iterator on
     auto fetch = [&](auto stage) {
@@ -539,22 +557,32 @@ __global__ __launch_bounds__(kBigApplyThreads) void big_apply_kernel(BigSweepPar
 #pragma unroll
             for (int k = 0; k < K; ++k) q_raw[T][u][k] = 0u;
 #pragma unroll
-            for (int n = 0; n < NT; ++n) q_m[T][u][n] = 0u;
+            for (int n = 0; n < NM; ++n) q_m[T][u][n] = 0u;
             // a wavefront without a live lane skips the loads (a scalar branch); inside, every lane loads (a dead lane re-reads the round's
             // first slot): a value defined under a DIVERGENT branch would have to be waited for at the end of the branch, and the point
             // of the exercise is not to wait
             if (__builtin_amdgcn_ballot_w64(q_live[T][u]) != 0ull) {
                 const uint32_t q = sb + (q_live[T][u] ? p : base);
-                // three 16-byte loads per attempt: a CU's vector memory path takes a wavefront's load every ~16 cycles whatever its width
-                const uint4 r0 = *reinterpret_cast<const uint4*>(recs + (q << 5)), r1 = *reinterpret_cast<const uint4*>(recs + (q << 5) + 16u);
-                const uint4 mk = *reinterpret_cast<const uint4*>(gmask + (q << 4));
-                const uint32_t rw[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
-                const uint32_t mw[4] = {mk.x, mk.y, mk.z, mk.w};
+                // 16-byte loads (a CU's vector memory path takes a wavefront's load every ~16 cycles whatever its width; what the loop
+                // pays for is the bytes: 64 per cycle and CU)
+                uint32_t rw[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
+                if constexpr (REC == 4) {
+                    const uint4 r0 = *reinterpret_cast<const uint4*>(recs + (q << 4));
+                    rw[0] = r0.x; rw[1] = r0.y; rw[2] = r0.z; rw[3] = r0.w;
+                } else {
+                    const uint4 r0 = *reinterpret_cast<const uint4*>(recs + (q << 5)), r1 = *reinterpret_cast<const uint4*>(recs + (q << 5) + 16u);
+                    rw[0] = r0.x; rw[1] = r0.y; rw[2] = r0.z; rw[3] = r0.w; rw[4] = r1.x; rw[5] = r1.y; rw[6] = r1.z; rw[7] = r1.w;
+                }
                 q_slot[T][u] = rw[0];
 #pragma unroll
                 for (int k = 0; k < K; ++k) q_raw[T][u][k] = rw[1 + k];
+                if constexpr (CM) q_m[T][u][0] = *reinterpret_cast<const uint32_t*>(gmask + (q << 2));
+                else {
+                    const uint4 mk = *reinterpret_cast<const uint4*>(gmask + (q << 4));
+                    const uint32_t mw[4] = {mk.x, mk.y, mk.z, mk.w};
 #pragma unroll
-                for (int n = 0; n < NT; ++n) q_m[T][u][n] = mw[n];
+                    for (int n = 0; n < NT; ++n) q_m[T][u][n] = mw[n];
+                }
             }
         }
         if (valid) {
@@ -645,10 +673,12 @@ __global__ __launch_bounds__(kBigApplyThreads) void big_apply_kernel(BigSweepPar
                 un[k] = bitop3<0x96>(sw[u], gk[u][k], (uint32_t)((int32_t)q_raw[A][u][k] >> 31));
             count_planes<K>(un, n0, n1, n2);
             uint32_t rej = 0u;                                   // class n (dE = 2 (K - 2n) > 0) needs u < T_n; every other class is accepted
-            if constexpr (NT > 0) rej = bitop3<0xf4>(rej, count_is<0>(n0, n1, n2), q_m[A][u][0] >> rsh);
-            if constexpr (NT > 1) rej = bitop3<0xf4>(rej, count_is<1>(n0, n1, n2), q_m[A][u][1] >> rsh);
-            if constexpr (NT > 2) rej = bitop3<0xf4>(rej, count_is<2>(n0, n1, n2), q_m[A][u][2] >> rsh);
-            if constexpr (NT > 3) rej = bitop3<0xf4>(rej, count_is<3>(n0, n1, n2), q_m[A][u][3] >> rsh);
+            // mask of class n in the low r bits (what lies above is cut off with the rest at the end)
+            auto cmask = [&](int n) -> uint32_t { return CM ? q_m[A][u][0] >> ((uint32_t)n << lgr) : q_m[A][u][CM ? 0 : n] >> rsh; };
+            if constexpr (NT > 0) rej = bitop3<0xf4>(rej, count_is<0>(n0, n1, n2), cmask(0));
+            if constexpr (NT > 1) rej = bitop3<0xf4>(rej, count_is<1>(n0, n1, n2), cmask(1));
+            if constexpr (NT > 2) rej = bitop3<0xf4>(rej, count_is<2>(n0, n1, n2), cmask(2));
+            if constexpr (NT > 3) rej = bitop3<0xf4>(rej, count_is<3>(n0, n1, n2), cmask(3));
             const uint32_t acc = ~rej & rm;
             const uint32_t e0 = q_slot[A][u];
             if (acc)                                             // spinflip! + update_cache! (Interface.jl:89-92, RRG.jl:191-234)
@@ -701,6 +731,19 @@ __global__ __launch_bounds__(kBigApplyThreads) void big_apply_kernel(BigSweepPar
     }
     // the workgroup's image goes to HBM as it is; big_merge_kernel puts the S images of a group back together
     for (uint32_t wd = (uint32_t)tid; wd < nwords; wd += (uint32_t)NTH) img[(size_t)blockIdx.x * nwords + wd] = bl_sp[wd];
+}
+
+template <int K>
+__global__ __launch_bounds__(kBigApplyThreads) void big_apply_kernel(BigSweepParams P, const uint32_t* __restrict__ masks, uint32_t* __restrict__ img,
+                                                                    uint32_t cap, int lgr)
+{
+    big_apply_body<K, false>(P, masks, img, cap, lgr);
+}
+template <int K>       // compact masks: one word per (slot, workgroup)
+__global__ __launch_bounds__(kBigApplyThreads) void big_applyc_kernel(BigSweepParams P, const uint32_t* __restrict__ masks, uint32_t* __restrict__ img,
+                                                                     uint32_t cap, int lgr)
+{
+    big_apply_body<K, true>(P, masks, img, cap, lgr);
 }
 
 // [G][N] words from the [G * S][ceil(N / S)] images big_apply_kernel leaves behind: bits rsh .. rsh + r - 1 of a site's word come from

@@ -84,6 +84,7 @@ struct rrrmc_ctx {
     uint32_t* d_nbrs[2] = {nullptr, nullptr};    // big mode: the neighbour row of every slot (K words), written by plan_big_kernel
     uint32_t* d_masks[2] = {nullptr, nullptr};   // big mode, few groups: acceptance masks of every (slot, group) of a batch (big_mask_kernel)
     bool big_masks = false;
+    bool big_cm = false;                         // compact masks: one word per (slot, workgroup)
     int big_lgr = 5;                             // big_apply_kernel: 2^lgr replicas per workgroup (their spins fit LDS)
     uint32_t* d_bigimg = nullptr;                // [G * S][ceil(N / S)] the workgroups' LDS images between big_apply_kernel and big_merge_kernel
     int64_t batch_chunks_max = kMaxChunksPerBatch;
@@ -305,6 +306,7 @@ typedef void (*big_mask_fn)(BigMaskParams);
 big_mask_fn big_mask_for_K(int K) { RRRMC_DISPATCH_UPTO7(K, big_mask_kernel) }
 typedef void (*big_apply_fn)(BigSweepParams, const uint32_t*, uint32_t*, uint32_t, int);
 big_apply_fn big_apply_for_K(int K) { RRRMC_DISPATCH_UPTO7(K, big_apply_kernel) }
+big_apply_fn big_applyc_for_K(int K) { RRRMC_DISPATCH_UPTO7(K, big_applyc_kernel) }
 
 typedef void (*sweep_fn)(SweepParams);
 sweep_fn sweep_for_K(int K, int mode)
@@ -639,13 +641,15 @@ int32_t rrrmc_ctx_create(rrrmc_ctx** out, int32_t model, int64_t N, int64_t K, i
     ctx->batch_slots_max = kMaxSlotsPerBatch;
     if (ctx->big_mode) {
         // few replica groups: the acceptance masks of a batch are made by the whole device first (big_mask_kernel), the per-group
-        // workgroups only apply them.  The mask buffers (2 x G x 4 words per slot) bound the batch.
-        const int64_t per_slot = (int64_t)ctx->G * 16;                      // four mask words per (slot, group)
-        int64_t fit = ((int64_t)1 << 31) / per_slot / kBigChunk * kBigChunk;
+        // workgroups only apply them.  The mask buffers (2 x at most 4 GiB) bound the batch.
+        ctx->big_lgr = big_lds_lgr(N);
+        ctx->big_cm = big_masks_compact((int)K, ctx->big_lgr);
+        // four mask words per (slot, group), or one per (slot, workgroup) where a workgroup's mask bits fit a word
+        const int64_t per_slot = (int64_t)ctx->G * (ctx->big_cm ? 4 * (32 >> ctx->big_lgr) : 16);
+        int64_t fit = ((int64_t)1 << 32) / per_slot / kBigChunk * kBigChunk;
         ctx->big_masks = ctx->G <= 512 && fit >= 16 * kBigChunk;
         if (const char* e = std::getenv("RRRMC_BIG_NO_MASKS")) { if (e[0] == '1') ctx->big_masks = false; }
         if (ctx->big_masks && fit < ctx->batch_slots_max) ctx->batch_slots_max = fit;
-        ctx->big_lgr = big_lds_lgr(N);
         if (ctx->big_masks) ctx->batch_chunks_max = kBigApplyChunks;
     }
 
@@ -673,13 +677,13 @@ int32_t rrrmc_ctx_create(rrrmc_ctx** out, int32_t model, int64_t N, int64_t K, i
     for (int i = 0; i < 2; ++i) {
         CREATE_TRY(hipMalloc(&ctx->d_slots[i], sizeof(uint32_t) * kMaxSlotsPerBatch));
         CREATE_TRY(hipMalloc(&ctx->d_vecs[i], sizeof(uint32_t) * kMaxSlotsPerBatch));
-        if (ctx->big_mode) CREATE_TRY(hipMalloc(&ctx->d_nbrs[i], sizeof(uint32_t) * kMaxSlotsPerBatch * kBigRec));
-        if (ctx->big_masks) CREATE_TRY(hipMalloc(&ctx->d_masks[i], sizeof(uint32_t) * 4 * ctx->batch_slots_max * ctx->G));
+        if (ctx->big_mode) CREATE_TRY(hipMalloc(&ctx->d_nbrs[i], sizeof(uint32_t) * kMaxSlotsPerBatch * big_rec_words((int)K)));
+        if (ctx->big_masks) CREATE_TRY(hipMalloc(&ctx->d_masks[i], sizeof(uint32_t) * (ctx->big_cm ? (32 >> ctx->big_lgr) : 4) * ctx->batch_slots_max * ctx->G));
     }
     if (ctx->big_masks) {
         const int64_t S = 32 >> ctx->big_lgr;
         CREATE_TRY(hipMalloc(&ctx->d_bigimg, sizeof(uint32_t) * ctx->G * S * ((N + S - 1) / S)));
-        CREATE_TRY(raise_lds_attr(reinterpret_cast<const void*>(big_apply_for_K((int)K)), big_lds_bytes(N, ctx->big_lgr)));
+        CREATE_TRY(raise_lds_attr(reinterpret_cast<const void*>(ctx->big_cm ? big_applyc_for_K((int)K) : big_apply_for_K((int)K)), big_lds_bytes(N, ctx->big_lgr)));
     }
     CREATE_TRY(hipStreamCreateWithFlags(&ctx->plan_stream, hipStreamNonBlocking));
     CREATE_TRY(hipEventCreateWithFlags(&ctx->ev_upload, hipEventDisableTiming));
@@ -1129,6 +1133,7 @@ int32_t rrrmc_standard_mc_async(rrrmc_ctx* ctx, double beta, int64_t iters, int6
         std::memcpy(PM.taum, P.taum, sizeof(PM.taum));
         PM.always_mask = P.always_mask; PM.k0 = P.k0; PM.k1 = P.k1; PM.group0 = P.group0; PM.gbase = P.gbase;
         PM.cap = (uint32_t)ctx->batch_slots_max;
+        PM.lgr = ctx->big_cm ? ctx->big_lgr : -1;
     }
     if (ctx->big_mode) {
         PB.spins = ctx->d_spins; PB.Es = ctx->d_Es; PB.E_cur = ctx->d_E; PB.acc_cur = ctx->d_acc;
@@ -1178,7 +1183,7 @@ int32_t rrrmc_standard_mc_async(rrrmc_ctx* ctx, double beta, int64_t iters, int6
             PB.chunks = P.chunks; PB.nchunks = P.nchunks; PB.sample0 = P.sample0; PB.slots = P.slots; PB.nbrs = ctx->d_nbrs[b & 1]; PB.vecs = P.vecs;
             if (ctx->big_masks) {
                 const int S = 32 >> ctx->big_lgr;
-                hipLaunchKernelGGL(big_apply_for_K((int)K), dim3((unsigned)(ctx->G * S)), dim3(kBigApplyThreads), big_lds_bytes(N, ctx->big_lgr), st, PB,
+                hipLaunchKernelGGL(ctx->big_cm ? big_applyc_for_K((int)K) : big_apply_for_K((int)K), dim3((unsigned)(ctx->G * S)), dim3(kBigApplyThreads), big_lds_bytes(N, ctx->big_lgr), st, PB,
                                    ctx->d_masks[b & 1], ctx->d_bigimg, (uint32_t)ctx->batch_slots_max, ctx->big_lgr);
                 hipLaunchKernelGGL(big_merge_kernel, dim3((unsigned)((N + 255) / 256), (unsigned)ctx->G), dim3(256), 0, st, ctx->d_spins, ctx->d_bigimg,
                                    (int)N, ctx->big_lgr);
