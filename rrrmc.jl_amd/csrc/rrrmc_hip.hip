@@ -88,6 +88,7 @@ struct rrrmc_ctx {
     int big_lgr = 5;                             // big_apply_kernel: 2^lgr replicas per workgroup (their spins fit LDS)
     uint32_t* d_bigimg = nullptr;                // [G * S][ceil(N / S)] the workgroups' LDS images between big_apply_kernel and big_merge_kernel
     int64_t batch_chunks_max = kMaxChunksPerBatch;
+    int64_t batch_first_chunks = 0;              // > 0: the first batch of a call holds at most this many chunks
     int64_t batch_slots_max = kMaxSlotsPerBatch; // slots per batch (plan buffers; the mask buffers when big_masks)
     hipStream_t plan_stream = nullptr;
     hipEvent_t ev_upload = nullptr;
@@ -482,7 +483,9 @@ int32_t prepare_chunk_list(rrrmc_ctx* ctx, int64_t iters, int64_t step, int C, b
             size_t first = 0;
             int64_t slots = 0, samples = 0, sample0 = 0;
             for (size_t c = 0; c < nch_all; ++c) {
-                if (c > first && (slots + chunks[c].count > ctx->batch_slots_max || (int64_t)(c - first) >= ctx->batch_chunks_max)) {
+                // (a short first batch where the plan of a batch is expensive: the sweep starts after plan(0), every later plan overlaps a sweep)
+                const int64_t cmax = (first == 0 && ctx->batch_first_chunks > 0) ? ctx->batch_first_chunks : ctx->batch_chunks_max;
+                if (c > first && (slots + chunks[c].count > ctx->batch_slots_max || (int64_t)(c - first) >= cmax)) {
                     ctx->chunk_batches.push_back({first, c - first, sample0});
                     first = c; slots = 0; sample0 = samples;
                 }
@@ -650,7 +653,7 @@ int32_t rrrmc_ctx_create(rrrmc_ctx** out, int32_t model, int64_t N, int64_t K, i
         ctx->big_masks = ctx->G <= 512 && fit >= 16 * kBigChunk;
         if (const char* e = std::getenv("RRRMC_BIG_NO_MASKS")) { if (e[0] == '1') ctx->big_masks = false; }
         if (ctx->big_masks && fit < ctx->batch_slots_max) ctx->batch_slots_max = fit;
-        if (ctx->big_masks) ctx->batch_chunks_max = kBigApplyChunks;
+        if (ctx->big_masks) { ctx->batch_chunks_max = kBigApplyChunks; ctx->batch_first_chunks = 64; }
     }
 
 #define CREATE_TRY(expr)                                                                                         \
