@@ -3,7 +3,28 @@
 // (fail, HIP_TRY, free_dev, ensure_state); not a stand-alone translation unit.
 // ---- GraphSKNormal (dense Float64) host side -----------------------------------------------------------------------
 typedef void (*sk_fn)(SkParams);
-sk_fn sk_sweep_for(int spt) { RRRMC_DISPATCH_UPTO8(spt, sk_sweep_kernel) }
+sk_fn sk_sweep_for(int spt, int nth)
+{
+    if (nth == 1024) return spt == 1 ? sk_sweep_kernel<1, 1024> : spt == 2 ? sk_sweep_kernel<2, 1024> : nullptr;
+    if (nth == 512) return spt == 1 ? sk_sweep_kernel<1, 512> : spt == 2 ? sk_sweep_kernel<2, 512> : spt == 3 ? sk_sweep_kernel<3, 512> : spt == 4 ? sk_sweep_kernel<4, 512> : nullptr;
+    switch (spt) {
+        case 1: return sk_sweep_kernel<1, 256>; case 2: return sk_sweep_kernel<2, 256>; case 3: return sk_sweep_kernel<3, 256>; case 4: return sk_sweep_kernel<4, 256>;
+        case 5: return sk_sweep_kernel<5, 256>; case 6: return sk_sweep_kernel<6, 256>; case 7: return sk_sweep_kernel<7, 256>; case 8: return sk_sweep_kernel<8, 256>;
+        default: return nullptr;
+    }
+}
+// threads per workgroup of sk_sweep_kernel: 512 beyond N = 256 (measured at N = 1024, 2048 replicas: 256 threads 101.7 ms per 65 536
+// iterations, 512 threads 82.5, 1024 threads 85.1); RRRMC_SK_THREADS = 256 / 512 / 1024 overrides — the builds are bit-identical, the
+// tests compare them
+int sk_threads_for(int64_t N)
+{
+    int nth = N > 256 ? 512 : 256;
+    if (const char* e = std::getenv("RRRMC_SK_THREADS")) {
+        const int v = std::atoi(e);
+        if ((v == 256 || v == 512 || v == 1024) && (N + v - 1) / v <= (v == 256 ? 8 : v == 512 ? 4 : 2)) nth = v;
+    }
+    return nth;
+}
 
 typedef void (*skb_fn)(SkbParams);
 skb_fn skb_sweep_for(int spt) { RRRMC_DISPATCH_UPTO8(spt, skb_sweep_kernel) }
@@ -135,9 +156,9 @@ int32_t sk_standard_mc_async(rrrmc_ctx* ctx, double beta, int64_t iters, int64_t
     P.E_cur = ctx->sk_E; P.acc_cur = ctx->d_acc; P.Es = ctx->sk_Es;
     P.beta = beta; P.g0 = ctx->it_done; P.iters = iters; P.step = step; P.sample0 = 0;
     P.k0 = (uint32_t)ctx->seed; P.k1 = (uint32_t)(ctx->seed >> 32); P.replica0 = ctx->replica0; P.N = (int)ctx->N;
-    const int spt = (int)((ctx->N + kSkThreads - 1) / kSkThreads);
+    const int nth = sk_threads_for(ctx->N), spt = (int)((ctx->N + nth - 1) / nth);
     HIP_TRY(ctx, hipEventRecord(ctx->ev_sweep[0], st));
-    hipLaunchKernelGGL(sk_sweep_for(spt), dim3((unsigned)ctx->G8), dim3(kSkThreads), 0, st, P);
+    hipLaunchKernelGGL(sk_sweep_for(spt, nth), dim3((unsigned)ctx->G8), dim3((unsigned)nth), 0, st, P);
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipEventRecord(ctx->ev_sweep[1], st));
     HIP_TRY(ctx, hipEventRecord(ctx->ev_end, st));

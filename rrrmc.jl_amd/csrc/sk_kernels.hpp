@@ -88,8 +88,17 @@ struct SkParams {
     int N;
 };
 
-template <int SPT>
-__global__ __launch_bounds__(kSkThreads) void sk_sweep_kernel(SkParams P)
+// Workgroup barrier for exchanges that go through LDS only: waits for this wavefront's LDS operations, not for its global loads —
+// __syncthreads() also drains the vector-memory counter, i.e. it would wait for the J-row prefetch at every barrier of the step.
+__device__ __forceinline__ void sk_lds_barrier()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+// NTH threads per workgroup (256, 512 or 1024): a wavefront issues an instruction every ~5 cycles whatever the others do, and a step is a
+// chain of ~700 of them at 256 threads (most in the field update) — more wavefronts with fewer sites each shorten the chain.
+template <int SPT, int NTH>
+__global__ __launch_bounds__(NTH) void sk_sweep_kernel(SkParams P)
 {
     __shared__ double sh_lfi[2][kSkRB];
     __shared__ uint32_t sh_si[2], sh_acc[2], sh_swap[2];
@@ -99,7 +108,7 @@ __global__ __launch_bounds__(kSkThreads) void sk_sweep_kernel(SkParams P)
     uint32_t sb[SPT];
 #pragma unroll
     for (int q = 0; q < SPT; ++q) {
-        const int j = q * kSkThreads + tid;
+        const int j = q * NTH + tid;
         sb[q] = j < N ? P.spins[(size_t)grp * N + j] : 0u;
 #pragma unroll
         for (int r = 0; r < kSkRB; ++r) {
@@ -114,22 +123,41 @@ __global__ __launch_bounds__(kSkThreads) void sk_sweep_kernel(SkParams P)
     if (tid < kSkRB) { E_run = P.E_cur[grp * kSkRB + tid]; A_run = P.acc_cur[grp * kSkRB + tid]; mlast = P.move_last[grp * kSkRB + tid]; }
     int64_t ns = P.sample0;
 
-    double Jq[SPT], Jn[SPT];
-    uint32_t site = P.iters > 0 ? site_of(P.k0, P.k1, P.g0 + 1, (uint32_t)N) : 0u;
+    // The SITE stream and the ACCEPT_F64 uniforms do not depend on the state: they are drawn 64 iterations at a time (lane = iteration)
+    // by the waves that are not on the decision's critical path — wave 1 the sites, waves 2 and 3 the 8 x 64 uniforms — into LDS, one
+    // block ahead; a step then reads its site and its uniform instead of running two Philox blocks between its barriers.
+    __shared__ uint32_t sh_site[2][64];
+    __shared__ double sh_u[2][64][kSkRB];
+    auto prepare = [&](int64_t blk) {          // iterations blk * 64 + 1 .. blk * 64 + 64 -> buffer blk & 1
+        const int buf = (int)(blk & 1);
+        if (tid >= 64 && tid < 128)
+            sh_site[buf][tid - 64] = site_of(P.k0, P.k1, P.g0 + (uint64_t)(blk * 64 + (tid - 64) + 1), (uint32_t)N);
+        else if (tid >= 128 && tid < 256) {
 #pragma unroll
-    for (int q = 0; q < SPT; ++q) { const int j = q * kSkThreads + tid; Jq[q] = j < N ? P.J[(size_t)site * N + j] : 0.0; }
+            for (int k = 0; k < 4; ++k) {
+                const int idx = (tid - 128) + 128 * k, l = idx >> 3, r = idx & 7;
+                sh_u[buf][l][r] = rand53(P.k0, P.k1, P.g0 + (uint64_t)(blk * 64 + l + 1), P.replica0 + (uint32_t)(grp * kSkRB + r));
+            }
+        }
+    };
+    prepare(0);
+    __syncthreads();
+    double Jq[SPT], Jn[SPT];
+    uint32_t site = sh_site[0][0];
+#pragma unroll
+    for (int q = 0; q < SPT; ++q) { const int j = q * NTH + tid; Jq[q] = j < N ? P.J[(size_t)site * N + j] : 0.0; }
 
-    double u_acc = tid < kSkRB ? rand53(P.k0, P.k1, P.g0 + 1, P.replica0 + (uint32_t)(grp * kSkRB + tid)) : 0.0;   // ACCEPT_F64 uniform of iteration 1
     long long next_sample = P.step;          // iterations k * step: a counter instead of a 64-bit modulo per iteration
     for (int64_t it = 1; it <= P.iters; ++it) {
         const int b = (int)(it & 1);
-        const uint64_t g = P.g0 + (uint64_t)it;
-        // prefetch the next site's J row
-        const uint32_t site_n = it < P.iters ? site_of(P.k0, P.k1, g + 1, (uint32_t)N) : site;
+        const int li = (int)((it - 1) & 63), bi = (int)(((it - 1) >> 6) & 1);        // this iteration in its block
+        if (li == 0) prepare(((it - 1) >> 6) + 1);                                   // the next block (its buffer was last read a step ago, before two barriers)
+        // prefetch the next site's J row: it stays in flight across the step's barriers (sk_lds_barrier does not wait for it)
+        const uint32_t site_n = li == 63 ? sh_site[bi ^ 1][0] : sh_site[bi][li + 1];
 #pragma unroll
-        for (int q = 0; q < SPT; ++q) { const int j = q * kSkThreads + tid; Jn[q] = j < N ? P.J[(size_t)site_n * N + j] : 0.0; }
+        for (int q = 0; q < SPT; ++q) { const int j = q * NTH + tid; Jn[q] = j < N ? P.J[(size_t)site_n * N + j] : 0.0; }
 
-        const int qi = (int)(site >> 8), owner = (int)(site & 255u);
+        const int qi = (int)(site / (uint32_t)NTH), owner = (int)(site % (uint32_t)NTH);
         if (tid == owner) {
 #pragma unroll
             for (int q = 0; q < SPT; ++q)
@@ -139,7 +167,7 @@ __global__ __launch_bounds__(kSkThreads) void sk_sweep_kernel(SkParams P)
                     sh_si[b] = sb[q];
                 }
         }
-        __syncthreads();
+        sk_lds_barrier();
         if (tid < 64) {          // the first wave: lanes 0..7 decide, the whole wave ballots
             bool acc = false, swp = false;
             if (tid < kSkRB) {
@@ -149,14 +177,14 @@ __global__ __launch_bounds__(kSkThreads) void sk_sweep_kernel(SkParams P)
                 }
                 const double dE = sh_lfi[b][tid];                       // delta_energy, SK.jl:278-284
                 const double x = -P.beta * dE;
-                acc = (x >= 0.0) || (u_acc < det_exp(x));                // RRRMC.jl:39
+                acc = (x >= 0.0) || (sh_u[bi][li][tid] < det_exp(x));    // RRRMC.jl:39
                 swp = acc && (mlast == (int32_t)site);                  // undo path of update_cache!, SK.jl:247-250
                 if (acc) { E_run += dE; A_run += 1; mlast = (int32_t)site; }
             }
             const unsigned long long ba = __ballot(acc), bs = __ballot(swp);
             if (tid == 0) { sh_acc[b] = (uint32_t)ba; sh_swap[b] = (uint32_t)bs; }
         }
-        __syncthreads();
+        sk_lds_barrier();
         const uint32_t accm = sh_acc[b], swpm = sh_swap[b], si_old = sh_si[b];
         const uint32_t normal = accm & ~swpm;
         const uint32_t si_new = si_old ^ accm;
@@ -205,14 +233,11 @@ __global__ __launch_bounds__(kSkThreads) void sk_sweep_kernel(SkParams P)
         site = site_n;
 #pragma unroll
         for (int q = 0; q < SPT; ++q) Jq[q] = Jn[q];
-        // the next iteration's uniform does not depend on the state: draw it here, next to the field updates, instead of
-        // between the two barriers of the next step
-        if (tid < kSkRB) u_acc = rand53(P.k0, P.k1, g + 1, P.replica0 + (uint32_t)(grp * kSkRB + tid));
     }
 
 #pragma unroll
     for (int q = 0; q < SPT; ++q) {
-        const int j = q * kSkThreads + tid;
+        const int j = q * NTH + tid;
         if (j < N) {
             P.spins[(size_t)grp * N + j] = (uint8_t)sb[q];
 #pragma unroll

@@ -216,3 +216,23 @@ def test_hooked_run_is_the_unhooked_chain_for_float64_models(pkg, oracle, kind):
     assert [h[0] for h in seen] == list(range(step, iters + 1, step))
     assert all((h[1] == Es_ref[:, k]).all() for k, h in enumerate(seen))
     assert (np.diff(np.stack([h[2] for h in seen]), axis=0) >= 0).all()
+
+
+@pytest.mark.parametrize("N,R", [(1024, 16), (700, 8), (2048, 8)])
+def test_skn_thread_counts_agree(pkg, monkeypatch, N, R):
+    """sk_sweep_kernel with 256 / 512 / 1024 threads per workgroup (RRRMC_SK_THREADS): the same chain bit for bit — energies, accepted
+    counts, configurations and the live field cache."""
+    seed = 4242 + N
+    X = pkg.GraphSKNormal(N, seed=seed)
+    outs = []
+    for nth in ("256", "512", "1024"):
+        monkeypatch.setenv("RRRMC_SK_THREADS", nth)
+        with pkg.Engine(X, R) as eng:
+            eng.seed(seed)
+            eng.init_spins_random()
+            Es, acc = eng.standard_mc(1.0, 3000, 100)
+            Es2, acc2 = eng.standard_mc(1.0, 1000, 7)      # a second call continues the streams
+            outs.append((Es, acc, Es2, acc2, eng.get_config().s, eng.fields()))
+    for o in outs[1:]:
+        for u, v in zip(outs[0], o):
+            assert (u == v).all()
