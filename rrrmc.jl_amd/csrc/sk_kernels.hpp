@@ -148,15 +148,15 @@ __global__ __launch_bounds__(NTH) void sk_sweep_kernel(SkParams P)
     for (int q = 0; q < SPT; ++q) { const int j = q * NTH + tid; Jq[q] = j < N ? P.J[(size_t)site * N + j] : 0.0; }
 
     long long next_sample = P.step;          // iterations k * step: a counter instead of a 64-bit modulo per iteration
+#ifdef RRRMC_SK_STAMPS
+    uint64_t st[5] = {0, 0, 0, 0, 0};
+#endif
     for (int64_t it = 1; it <= P.iters; ++it) {
+#ifdef RRRMC_SK_STAMPS
+        const uint64_t t0 = __builtin_amdgcn_s_memtime();
+#endif
         const int b = (int)(it & 1);
         const int li = (int)((it - 1) & 63), bi = (int)(((it - 1) >> 6) & 1);        // this iteration in its block
-        if (li == 0) prepare(((it - 1) >> 6) + 1);                                   // the next block (its buffer was last read a step ago, before two barriers)
-        // prefetch the next site's J row: it stays in flight across the step's barriers (sk_lds_barrier does not wait for it)
-        const uint32_t site_n = li == 63 ? sh_site[bi ^ 1][0] : sh_site[bi][li + 1];
-#pragma unroll
-        for (int q = 0; q < SPT; ++q) { const int j = q * NTH + tid; Jn[q] = j < N ? P.J[(size_t)site_n * N + j] : 0.0; }
-
         const int qi = (int)(site / (uint32_t)NTH), owner = (int)(site % (uint32_t)NTH);
         if (tid == owner) {
 #pragma unroll
@@ -167,7 +167,26 @@ __global__ __launch_bounds__(NTH) void sk_sweep_kernel(SkParams P)
                     sh_si[b] = sb[q];
                 }
         }
+        // What does not depend on the state — the next block of stream values (li = 0; its buffer was last read a step ago, before two
+        // barriers) and the prefetch of the next site's J row (it stays in flight across the barriers: sk_lds_barrier does not wait for
+        // it) — is done by the deciding wavefront before the barrier and by the others after it, while they would wait for the decision:
+        // the barrier then only waits for the owner's publication.
+        uint32_t site_n = 0u;
+        auto stateless = [&]() {
+            if (li == 0) prepare(((it - 1) >> 6) + 1);
+            site_n = li == 63 ? sh_site[bi ^ 1][0] : sh_site[bi][li + 1];
+#pragma unroll
+            for (int q = 0; q < SPT; ++q) { const int j = q * NTH + tid; Jn[q] = j < N ? P.J[(size_t)site_n * N + j] : 0.0; }
+        };
+        if (tid < 64) stateless();
+#ifdef RRRMC_SK_STAMPS
+        const uint64_t t1 = __builtin_amdgcn_s_memtime();
+#endif
         sk_lds_barrier();
+#ifdef RRRMC_SK_STAMPS
+        const uint64_t t2 = __builtin_amdgcn_s_memtime();
+#endif
+        if (tid >= 64) stateless();
         if (tid < 64) {          // the first wave: lanes 0..7 decide, the whole wave ballots
             bool acc = false, swp = false;
             if (tid < kSkRB) {
@@ -184,10 +203,17 @@ __global__ __launch_bounds__(NTH) void sk_sweep_kernel(SkParams P)
             const unsigned long long ba = __ballot(acc), bs = __ballot(swp);
             if (tid == 0) { sh_acc[b] = (uint32_t)ba; sh_swap[b] = (uint32_t)bs; }
         }
+#ifdef RRRMC_SK_STAMPS
+        const uint64_t t3 = __builtin_amdgcn_s_memtime();
+#endif
         sk_lds_barrier();
+#ifdef RRRMC_SK_STAMPS
+        const uint64_t t4 = __builtin_amdgcn_s_memtime();
+#endif
         const uint32_t accm = sh_acc[b], swpm = sh_swap[b], si_old = sh_si[b];
         const uint32_t normal = accm & ~swpm;
         const uint32_t si_new = si_old ^ accm;
+
         if (swpm) {          // workgroup-uniform: swap lfields <-> lfields_last of those replicas
 #pragma unroll
             for (int r = 0; r < kSkRB; ++r)
@@ -216,12 +242,21 @@ __global__ __launch_bounds__(NTH) void sk_sweep_kernel(SkParams P)
                     }
                 }
             if (tid == owner) {
+                // the eight published fields in one go (a read per accepted replica, each behind its own branch, made the owner's
+                // wavefront the one everybody waits for at the next barrier; reading them in every thread up front costs more than
+                // it hides), then selects
+                double lfm[kSkRB];
+#pragma unroll
+                for (int r = 0; r < kSkRB; ++r) lfm[r] = sh_lfi[b][r];
 #pragma unroll
                 for (int q = 0; q < SPT; ++q)
                     if (q == qi) {
 #pragma unroll
-                        for (int r = 0; r < kSkRB; ++r)
-                            if ((normal >> r) & 1u) { const double lfm = sh_lfi[b][r]; lfl[q][r] = lfm; lf[q][r] = -lfm; }   // SK.jl:263-264
+                        for (int r = 0; r < kSkRB; ++r) {
+                            const bool on = (normal >> r) & 1u;
+                            lfl[q][r] = on ? lfm[r] : lfl[q][r];                                                      // SK.jl:263-264
+                            lf[q][r] = on ? -lfm[r] : lf[q][r];
+                        }
                     }
             }
         }
@@ -233,6 +268,9 @@ __global__ __launch_bounds__(NTH) void sk_sweep_kernel(SkParams P)
         site = site_n;
 #pragma unroll
         for (int q = 0; q < SPT; ++q) Jq[q] = Jn[q];
+#ifdef RRRMC_SK_STAMPS
+        { const uint64_t t5 = __builtin_amdgcn_s_memtime(); st[0] += t1 - t0; st[1] += t2 - t1; st[2] += t3 - t2; st[3] += t4 - t3; st[4] += t5 - t4; }
+#endif
     }
 
 #pragma unroll
@@ -247,6 +285,11 @@ __global__ __launch_bounds__(NTH) void sk_sweep_kernel(SkParams P)
             }
         }
     }
+#ifdef RRRMC_SK_STAMPS
+    if (grp == 1 && (tid == 0 || tid == 200))
+        printf("sk stamps tid %d iters %lld: publish %llu barA %llu decide %llu barB %llu apply %llu\n", tid, (long long)P.iters,
+               (unsigned long long)st[0], (unsigned long long)st[1], (unsigned long long)st[2], (unsigned long long)st[3], (unsigned long long)st[4]);
+#endif
     if (tid < kSkRB) { P.E_cur[grp * kSkRB + tid] = E_run; P.acc_cur[grp * kSkRB + tid] = A_run; P.move_last[grp * kSkRB + tid] = mlast; }
 }
 
@@ -401,6 +444,7 @@ __global__ __launch_bounds__(kSkThreads) void skb_sweep_kernel(SkbParams P)
         const uint32_t accm = sh_acc[b], swpm = sh_swap[b], si_old = sh_si[b];
         const uint32_t normal = accm & ~swpm;
         const uint32_t si_new = si_old ^ accm;
+
         if (swpm) {
 #pragma unroll
             for (int r = 0; r < kSkRB; ++r)
