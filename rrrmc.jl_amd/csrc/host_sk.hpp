@@ -27,7 +27,16 @@ int sk_threads_for(int64_t N)
 }
 
 typedef void (*skb_fn)(SkbParams);
-skb_fn skb_sweep_for(int spt) { RRRMC_DISPATCH_UPTO8(spt, skb_sweep_kernel) }
+skb_fn skb_sweep_for(int spt, int nth)
+{
+    if (nth == 1024) return spt == 1 ? skb_sweep_kernel<1, 1024> : spt == 2 ? skb_sweep_kernel<2, 1024> : nullptr;
+    if (nth == 512) return spt == 1 ? skb_sweep_kernel<1, 512> : spt == 2 ? skb_sweep_kernel<2, 512> : spt == 3 ? skb_sweep_kernel<3, 512> : spt == 4 ? skb_sweep_kernel<4, 512> : nullptr;
+    switch (spt) {
+        case 1: return skb_sweep_kernel<1, 256>; case 2: return skb_sweep_kernel<2, 256>; case 3: return skb_sweep_kernel<3, 256>; case 4: return skb_sweep_kernel<4, 256>;
+        case 5: return skb_sweep_kernel<5, 256>; case 6: return skb_sweep_kernel<6, 256>; case 7: return skb_sweep_kernel<7, 256>; case 8: return skb_sweep_kernel<8, 256>;
+        default: return nullptr;
+    }
+}
 
 int32_t sk_ctx_create(rrrmc_ctx** out, int32_t model, int64_t N, int64_t R, int32_t device, uint32_t replica0)
 {
@@ -138,9 +147,9 @@ int32_t sk_standard_mc_async(rrrmc_ctx* ctx, double beta, int64_t iters, int64_t
         B.E_cur = ctx->sk_E; B.acc_cur = ctx->d_acc; B.Es = ctx->sk_Es;
         B.beta = beta; B.sN = std::sqrt((double)ctx->N); B.g0 = ctx->it_done; B.iters = iters; B.step = step; B.sample0 = 0;
         B.k0 = (uint32_t)ctx->seed; B.k1 = (uint32_t)(ctx->seed >> 32); B.replica0 = ctx->replica0; B.N = (int)ctx->N; B.NW = ctx->skb_NW;
-        const int sptb = (int)((ctx->N + kSkThreads - 1) / kSkThreads);
+        const int nthb = sk_threads_for(ctx->N), sptb = (int)((ctx->N + nthb - 1) / nthb);
         HIP_TRY(ctx, hipEventRecord(ctx->ev_sweep[0], st));
-        hipLaunchKernelGGL(skb_sweep_for(sptb), dim3((unsigned)ctx->G8), dim3(kSkThreads), 0, st, B);
+        hipLaunchKernelGGL(skb_sweep_for(sptb, nthb), dim3((unsigned)ctx->G8), dim3((unsigned)nthb), 0, st, B);
         HIP_TRY(ctx, hipGetLastError());
         HIP_TRY(ctx, hipEventRecord(ctx->ev_sweep[1], st));
         HIP_TRY(ctx, hipEventRecord(ctx->ev_end, st));

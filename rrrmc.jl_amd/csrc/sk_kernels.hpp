@@ -375,8 +375,9 @@ struct SkbParams {
     int N, NW;
 };
 
-template <int SPT>
-__global__ __launch_bounds__(kSkThreads) void skb_sweep_kernel(SkbParams P)
+// (the structure of the step: streams from LDS, LDS-only barriers, what the first barrier waits for: as in sk_sweep_kernel)
+template <int SPT, int NTH>
+__global__ __launch_bounds__(NTH) void skb_sweep_kernel(SkbParams P)
 {
     __shared__ int32_t sh_lfi[2][kSkRB];
     __shared__ uint32_t sh_si[2], sh_acc[2], sh_swap[2];
@@ -386,7 +387,7 @@ __global__ __launch_bounds__(kSkThreads) void skb_sweep_kernel(SkbParams P)
     uint32_t sb[SPT];
 #pragma unroll
     for (int q = 0; q < SPT; ++q) {
-        const int j = q * kSkThreads + tid;
+        const int j = q * NTH + tid;
         sb[q] = j < N ? P.spins[(size_t)grp * N + j] : 0u;
 #pragma unroll
         for (int r = 0; r < kSkRB; ++r) {
@@ -400,20 +401,32 @@ __global__ __launch_bounds__(kSkThreads) void skb_sweep_kernel(SkbParams P)
     if (tid < kSkRB) { E_run = P.E_cur[grp * kSkRB + tid]; A_run = P.acc_cur[grp * kSkRB + tid]; mlast = P.move_last[grp * kSkRB + tid]; }
     int64_t ns = P.sample0;
 
-    uint32_t Jq[SPT], Jn[SPT];     // coupling bit of (site, j) for this thread's sites
-    uint32_t site = P.iters > 0 ? site_of(P.k0, P.k1, P.g0 + 1, (uint32_t)N) : 0u;
+    __shared__ uint32_t sh_site[2][64];
+    __shared__ double sh_u[2][64][kSkRB];
+    auto prepare = [&](int64_t blk) {          // iterations blk * 64 + 1 .. blk * 64 + 64 -> buffer blk & 1
+        const int buf = (int)(blk & 1);
+        if (tid >= 64 && tid < 128)
+            sh_site[buf][tid - 64] = site_of(P.k0, P.k1, P.g0 + (uint64_t)(blk * 64 + (tid - 64) + 1), (uint32_t)N);
+        else if (tid >= 128 && tid < 256) {
 #pragma unroll
-    for (int q = 0; q < SPT; ++q) { const int j = q * kSkThreads + tid; Jq[q] = j < N ? (P.Jbits[(size_t)site * P.NW + (j >> 5)] >> (j & 31)) & 1u : 0u; }
+            for (int k = 0; k < 4; ++k) {
+                const int idx = (tid - 128) + 128 * k, l = idx >> 3, r = idx & 7;
+                sh_u[buf][l][r] = rand53(P.k0, P.k1, P.g0 + (uint64_t)(blk * 64 + l + 1), P.replica0 + (uint32_t)(grp * kSkRB + r));
+            }
+        }
+    };
+    prepare(0);
+    __syncthreads();
+    uint32_t Jq[SPT], Jn[SPT];     // coupling bit of (site, j) for this thread's sites
+    uint32_t site = sh_site[0][0];
+#pragma unroll
+    for (int q = 0; q < SPT; ++q) { const int j = q * NTH + tid; Jq[q] = j < N ? (P.Jbits[(size_t)site * P.NW + (j >> 5)] >> (j & 31)) & 1u : 0u; }
 
     long long next_sample = P.step;          // iterations k * step: a counter instead of a 64-bit modulo per iteration
     for (int64_t it = 1; it <= P.iters; ++it) {
         const int b = (int)(it & 1);
-        const uint64_t g = P.g0 + (uint64_t)it;
-        const uint32_t site_n = it < P.iters ? site_of(P.k0, P.k1, g + 1, (uint32_t)N) : site;
-#pragma unroll
-        for (int q = 0; q < SPT; ++q) { const int j = q * kSkThreads + tid; Jn[q] = j < N ? (P.Jbits[(size_t)site_n * P.NW + (j >> 5)] >> (j & 31)) & 1u : 0u; }
-
-        const int qi = (int)(site >> 8), owner = (int)(site & 255u);
+        const int li = (int)((it - 1) & 63), bi = (int)(((it - 1) >> 6) & 1);        // this iteration in its block
+        const int qi = (int)(site / (uint32_t)NTH), owner = (int)(site % (uint32_t)NTH);
         if (tid == owner) {
 #pragma unroll
             for (int q = 0; q < SPT; ++q)
@@ -423,7 +436,16 @@ __global__ __launch_bounds__(kSkThreads) void skb_sweep_kernel(SkbParams P)
                     sh_si[b] = sb[q];
                 }
         }
-        __syncthreads();
+        uint32_t site_n = 0u;
+        auto stateless = [&]() {
+            if (li == 0) prepare(((it - 1) >> 6) + 1);
+            site_n = li == 63 ? sh_site[bi ^ 1][0] : sh_site[bi][li + 1];
+#pragma unroll
+            for (int q = 0; q < SPT; ++q) { const int j = q * NTH + tid; Jn[q] = j < N ? (P.Jbits[(size_t)site_n * P.NW + (j >> 5)] >> (j & 31)) & 1u : 0u; }
+        };
+        if (tid < 64) stateless();
+        sk_lds_barrier();
+        if (tid >= 64) stateless();
         if (tid < 64) {
             bool acc = false, swp = false;
             if (tid < kSkRB) {
@@ -433,14 +455,14 @@ __global__ __launch_bounds__(kSkThreads) void skb_sweep_kernel(SkbParams P)
                 }
                 const double dE = (double)sh_lfi[b][tid] / P.sN;            // delta_energy = lfields / sqrt(N), SK.jl:137-140
                 const double x = -P.beta * dE;
-                acc = (x >= 0.0) || (rand53(P.k0, P.k1, g, P.replica0 + (uint32_t)(grp * kSkRB + tid)) < det_exp(x));
+                acc = (x >= 0.0) || (sh_u[bi][li][tid] < det_exp(x));
                 swp = acc && (mlast == (int32_t)site);
                 if (acc) { E_run += dE; A_run += 1; mlast = (int32_t)site; }
             }
             const unsigned long long ba = __ballot(acc), bs = __ballot(swp);
             if (tid == 0) { sh_acc[b] = (uint32_t)ba; sh_swap[b] = (uint32_t)bs; }
         }
-        __syncthreads();
+        sk_lds_barrier();
         const uint32_t accm = sh_acc[b], swpm = sh_swap[b], si_old = sh_si[b];
         const uint32_t normal = accm & ~swpm;
         const uint32_t si_new = si_old ^ accm;
@@ -469,12 +491,18 @@ __global__ __launch_bounds__(kSkThreads) void skb_sweep_kernel(SkbParams P)
                     }
                 }
             if (tid == owner) {
+                int32_t lfm[kSkRB];
+#pragma unroll
+                for (int r = 0; r < kSkRB; ++r) lfm[r] = sh_lfi[b][r];
 #pragma unroll
                 for (int q = 0; q < SPT; ++q)
                     if (q == qi) {
 #pragma unroll
-                        for (int r = 0; r < kSkRB; ++r)
-                            if ((normal >> r) & 1u) { const int32_t lfm = sh_lfi[b][r]; lfl[q][r] = lfm; lf[q][r] = -lfm; }
+                        for (int r = 0; r < kSkRB; ++r) {
+                            const bool on = (normal >> r) & 1u;
+                            lfl[q][r] = on ? lfm[r] : lfl[q][r];
+                            lf[q][r] = on ? -lfm[r] : lf[q][r];
+                        }
                     }
             }
         }
@@ -489,7 +517,7 @@ __global__ __launch_bounds__(kSkThreads) void skb_sweep_kernel(SkbParams P)
     }
 #pragma unroll
     for (int q = 0; q < SPT; ++q) {
-        const int j = q * kSkThreads + tid;
+        const int j = q * NTH + tid;
         if (j < N) {
             P.spins[(size_t)grp * N + j] = (uint8_t)sb[q];
 #pragma unroll
