@@ -652,7 +652,11 @@ int32_t rrrmc_ctx_create(rrrmc_ctx** out, int32_t model, int64_t N, int64_t K, i
         int64_t fit = ((int64_t)1 << 32) / per_slot / kBigChunk * kBigChunk;
         ctx->big_masks = ctx->G <= 512 && fit >= 16 * kBigChunk;
         if (const char* e = std::getenv("RRRMC_BIG_NO_MASKS")) { if (e[0] == '1') ctx->big_masks = false; }
-        if (ctx->big_masks && fit < ctx->batch_slots_max) ctx->batch_slots_max = fit;
+        if (ctx->big_masks) {
+            // a launch of big_apply_kernel takes at most kBigApplyChunks chunks: no reason to hold masks for more
+            if (fit > (int64_t)kBigApplyChunks * kBigChunk) fit = (int64_t)kBigApplyChunks * kBigChunk;
+            if (fit < ctx->batch_slots_max) ctx->batch_slots_max = fit;
+        }
         if (ctx->big_masks) { ctx->batch_chunks_max = kBigApplyChunks; ctx->batch_first_chunks = 64; }
     }
 
