@@ -121,10 +121,11 @@ struct rrrmc_ctx {
     int sweep_mode = 0;                 // sweep_kernel<K, MODE>: 0 LDS table / byte offsets, 1 HBM table / byte offsets, 2 HBM table / word indices
     int ncolors = 0;
     std::vector<int32_t> color_count;   // sites per colour
-    std::vector<int32_t*> d_color_list; // device lists
+    std::vector<uint32_t*> d_color_list; // device lists: one record per site of the colour (site, neighbour row with coupling signs)
     uint32_t* d_U = nullptr;            // [Rpad] unsatisfied-bond counters of the bit-sliced energy kernel
     uint64_t sweeps_done = 0;
     std::vector<int32_t> h_A;           // host copy of the neighbour table (colouring check)
+    std::vector<uint8_t> h_Jsign;       // host copy of the coupling signs (1 = J < 0), +-J models: colour records
     bool colored_call = false;          // the last sampling call was a colored-sweep call
     bool color_count_acc = false;       // colour sweeps also count every replica's accepted moves (rrrmc_colored_count_accepted)
     // ---- RRRMC_MODEL_SK_NORMAL ----
@@ -717,7 +718,7 @@ void rrrmc_ctx_destroy(rrrmc_ctx* ctx)
     free_dev(ctx->d_A); free_dev(ctx->d_J); free_dev(ctx->d_table); free_dev(ctx->d_spins);
     free_dev(ctx->d_E); free_dev(ctx->d_acc); free_dev(ctx->d_chunks); free_dev(ctx->d_Es);
     free_dev(ctx->d_U);
-    for (int32_t*& l : ctx->d_color_list) free_dev(l);
+    for (uint32_t*& l : ctx->d_color_list) free_dev(l);
     free_dev(ctx->sk_J); free_dev(ctx->sk_lf); free_dev(ctx->sk_lfl); free_dev(ctx->sk_move_last); free_dev(ctx->sk_spins);
     free_dev(ctx->sk_E); free_dev(ctx->sk_Es); free_dev(ctx->skb_J); free_dev(ctx->skb_lf); free_dev(ctx->skb_lfl);
     free_dev(ctx->q_spins); free_dev(ctx->q_cls); free_dev(ctx->q_sv); free_dev(ctx->q_spos); free_dev(ctx->q_st);
@@ -801,6 +802,9 @@ int32_t rrrmc_set_graph(rrrmc_ctx* ctx, const int32_t* A, const int8_t* J)
                 table[x * ctx->TS + k] = ctx->sweep_mode == 3 ? (uint16_t)(A[x * K + k] | (J[x * K + k] < 0 ? 0x8000 : 0))      // one word per site, sign in bit 15
                                                                : (uint16_t)((ctx->sweep_mode == 2 ? 1 : 4) * (2 * A[x * K + k] + (J[x * K + k] < 0 ? 1 : 0)));   // byte offset (word index in mode 2) in the LDS spin array: word 2y = s_y, word 2y + 1 = ~s_y
     ctx->h_A.assign(A, A + N * K);
+    ctx->h_Jsign.resize((size_t)(N * K));
+    for (int64_t e = 0; e < N * K; ++e) ctx->h_Jsign[e] = J[e] < 0 ? 1 : 0;
+    ctx->ncolors = 0;                                           // a colouring holds records of the graph it was set for: set it again
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     HIP_TRY(ctx, hipMemcpy(ctx->d_A, A, sizeof(int32_t) * N * K, hipMemcpyHostToDevice));
@@ -1384,14 +1388,23 @@ int32_t rrrmc_set_coloring(rrrmc_ctx* ctx, const int32_t* color, int32_t ncolors
     }
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    for (int32_t*& l : ctx->d_color_list) free_dev(l);
+    for (uint32_t*& l : ctx->d_color_list) free_dev(l);
     ctx->d_color_list.assign((size_t)ncolors, nullptr);
     ctx->color_count.assign((size_t)ncolors, 0);
+    const int W = K <= 3 ? 4 : 8;                              // words per record (colored_sweep_kernel)
+    std::vector<uint32_t> recs;
     for (int c = 0; c < ncolors; ++c) {
         ctx->color_count[c] = (int32_t)lists[c].size();
         if (lists[c].empty()) continue;
-        HIP_TRY(ctx, hipMalloc(&ctx->d_color_list[c], sizeof(int32_t) * lists[c].size()));
-        HIP_TRY(ctx, hipMemcpy(ctx->d_color_list[c], lists[c].data(), sizeof(int32_t) * lists[c].size(), hipMemcpyHostToDevice));
+        recs.assign(lists[c].size() * (size_t)W, 0u);
+        for (size_t i = 0; i < lists[c].size(); ++i) {
+            const int64_t x = lists[c][i];
+            recs[i * W] = (uint32_t)x;
+            for (int64_t k = 0; k < K; ++k)
+                recs[i * W + 1 + k] = (uint32_t)ctx->h_A[x * K + k] | (ctx->h_Jsign[x * K + k] ? 0x80000000u : 0u);
+        }
+        HIP_TRY(ctx, hipMalloc(&ctx->d_color_list[c], sizeof(uint32_t) * recs.size()));
+        HIP_TRY(ctx, hipMemcpy(ctx->d_color_list[c], recs.data(), sizeof(uint32_t) * recs.size(), hipMemcpyHostToDevice));
     }
     ctx->ncolors = ncolors;
     return RRRMC_OK;
@@ -1459,7 +1472,7 @@ int32_t rrrmc_colored_sweeps_async(rrrmc_ctx* ctx, double beta, int64_t sweeps, 
         P.sweep = ctx->sweeps_done + (uint64_t)sw;
         for (int c = 0; c < ctx->ncolors; ++c) {
             if (ctx->color_count[c] == 0) continue;
-            P.list = ctx->d_color_list[c];
+            P.recs = ctx->d_color_list[c];
             P.nlist = ctx->color_count[c];
             const dim3 grid((unsigned)((P.nlist + 255) / 256), (unsigned)((ctx->G + gpt - 1) / gpt));
             hipLaunchKernelGGL(fn, grid, dim3(256), 0, st, P);

@@ -1153,7 +1153,8 @@ struct ColorSweepParams {
     uint32_t* spins;          // [G][N]
     const int32_t* A;         // [N][K]
     const int8_t* J;          // [N][K]
-    const int32_t* list;      // sites of the colour being updated
+    const uint32_t* recs;     // [nlist][W] the colour's sites as records: site, then neighbour | (J < 0) << 31 for its K neighbours
+                              // (W = 4 words up to K = 3, 8 beyond: one or two 16-byte loads instead of 1 + 2K scattered ones)
     uint32_t taum[64 * 4];    // threshold bit planes, class n = unsatisfied bonds (dE = 2(K - 2n) > 0)
     uint32_t always_mask;
     uint32_t k0, k1, group0;
@@ -1172,11 +1173,19 @@ __global__ __launch_bounds__(256) void colored_sweep_kernel(ColorSweepParams P)
     constexpr int NT = SweepCfg<K>::NT;
     const int idx = blockIdx.x * 256 + threadIdx.x;
     const bool live = idx < P.nlist;
-    const int x = live ? P.list[idx] : 0;
+    constexpr int W = K <= 3 ? 4 : 8;
+    uint32_t rw[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
+    {
+        const uint4* rp = reinterpret_cast<const uint4*>(P.recs) + (size_t)(live ? idx : 0) * (W / 4);
+        const uint4 r0 = rp[0];
+        rw[0] = r0.x; rw[1] = r0.y; rw[2] = r0.z; rw[3] = r0.w;
+        if constexpr (W == 8) { const uint4 r1 = rp[1]; rw[4] = r1.x; rw[5] = r1.y; rw[6] = r1.z; rw[7] = r1.w; }
+    }
+    const int x = (int)rw[0];
     int nb[K];
     uint32_t sgn[K];
 #pragma unroll
-    for (int k = 0; k < K; ++k) { nb[k] = P.A[(size_t)x * K + k]; sgn[k] = P.J[(size_t)x * K + k] < 0 ? 0xffffffffu : 0u; }
+    for (int k = 0; k < K; ++k) { nb[k] = (int)(rw[1 + k] & 0x7fffffffu); sgn[k] = (uint32_t)((int32_t)rw[1 + k] >> 31); }
     uint32_t s[GPT], u[GPT][K];
 #pragma unroll
     for (int j = 0; j < GPT; ++j) {
