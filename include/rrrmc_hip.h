@@ -129,9 +129,10 @@ RRRMC_API int32_t rrrmc_fetch_results(rrrmc_ctx *ctx, int64_t *Es_out, int64_t *
  * config 4: GraphEA L=64, D=3) the engine offers sweeps over a
  * proper colouring: one sweep attempts every site once, colour by colour, all sites of a colour at once, with the
  * reference's delta_energy and accept rule (src/graphs/EA.jl:266-275, src/RRRMC.jl:39).  A ctx of
- * RRRMC_MODEL_SPARSE_PM1 whose state does not fit LDS still runs rrrmc_standard_mc* (random-site, the same chain, through kernels
- * that keep the spins in HBM/L2: N <= 2^20, roughly ten times slower than these sweeps).
- *   color[N] in 0..ncolors-1, adjacent sites must differ (checked).
+ * RRRMC_MODEL_SPARSE_PM1 whose state does not fit the LDS sweep still runs rrrmc_standard_mc* (random-site, the same chain, through
+ * the big-N kernels: N <= 2^20, roughly ten times slower than these sweeps).
+ *   color[N] in 0..ncolors-1, adjacent sites must differ (checked).  Call after rrrmc_set_graph: the colouring is stored as per-site
+ *   records of that graph, and a later rrrmc_set_graph drops it (rrrmc_colored_sweeps_async then returns RRRMC_ERR_STATE).
  *   rrrmc_colored_sweeps_async: `sweeps` sweeps; an energy sample is taken BEFORE sweep k*step (as RRRMC.jl:104-108
  *   with a sweep as the unit); results through rrrmc_sync + rrrmc_fetch_results (Es [R x sweeps/step]; accepted_out
  *   is not tracked by this sampler and reads -1). */
