@@ -50,6 +50,31 @@ __device__ __forceinline__ double det_exp(double x)
     return ldexp(p, (int)k);
 }
 
+// det_exp with its constants handed in (c[0..13] the Taylor coefficients, c[14] = log2(e), c[15], c[16] = ln 2 high / low): the same
+// operations in the same order.  A Float64 constant is two scalar moves at every use; a kernel that evaluates det_exp on its
+// critical path once per step keeps them in vector registers instead (sk_exp_constants: an empty asm hides the values from constant
+// propagation).
+__device__ __forceinline__ void sk_exp_constants(double (&c)[17])
+{
+    const double v[17] = {1.0, 1.0, 0.5, 1.0 / 6, 1.0 / 24, 1.0 / 120, 1.0 / 720, 1.0 / 5040, 1.0 / 40320, 1.0 / 362880,
+                          1.0 / 3628800, 1.0 / 39916800, 1.0 / 479001600, 1.0 / 6227020800.0,
+                          1.44269504088896338700e+00, 6.93147180369123816490e-01, 1.90821492927058770002e-10};
+#pragma unroll
+    for (int i = 0; i < 17; ++i) { c[i] = v[i]; asm volatile("" : "+v"(c[i])); }
+}
+__device__ __forceinline__ double det_exp_c(double x, const double (&c)[17])
+{
+    if (x != x) return x;
+    if (x < -745.2) return 0.0;
+    if (x > 709.7) return __builtin_inf();
+    const double k = floor(__dadd_rn(__dmul_rn(x, c[14]), 0.5));
+    const double r = __dadd_rn(__dadd_rn(x, -__dmul_rn(k, c[15])), -__dmul_rn(k, c[16]));
+    double p = c[13];
+#pragma unroll
+    for (int n = 12; n >= 0; --n) p = __dadd_rn(__dmul_rn(p, r), c[n]);
+    return ldexp(p, (int)k);
+}
+
 // log1p(y) for -1 < y <= 0 with a fixed operation order (rand_skip of bklMC, src/DeltaE.jl:141-144); same sequence as the oracle's
 __device__ __forceinline__ double det_log1p(double y)
 {
@@ -148,6 +173,8 @@ __global__ __launch_bounds__(NTH) void sk_sweep_kernel(SkParams P)
     for (int q = 0; q < SPT; ++q) { const int j = q * NTH + tid; Jq[q] = j < N ? P.J[(size_t)site * N + j] : 0.0; }
 
     long long next_sample = P.step;          // iterations k * step: a counter instead of a 64-bit modulo per iteration
+    double expc[17];
+    sk_exp_constants(expc);
 #ifdef RRRMC_SK_STAMPS
     uint64_t st[5] = {0, 0, 0, 0, 0};
 #endif
@@ -196,7 +223,7 @@ __global__ __launch_bounds__(NTH) void sk_sweep_kernel(SkParams P)
                 }
                 const double dE = sh_lfi[b][tid];                       // delta_energy, SK.jl:278-284
                 const double x = -P.beta * dE;
-                acc = (x >= 0.0) || (sh_u[bi][li][tid] < det_exp(x));    // RRRMC.jl:39
+                acc = (x >= 0.0) || (sh_u[bi][li][tid] < det_exp_c(x, expc));    // RRRMC.jl:39
                 swp = acc && (mlast == (int32_t)site);                  // undo path of update_cache!, SK.jl:247-250
                 if (acc) { E_run += dE; A_run += 1; mlast = (int32_t)site; }
             }
@@ -423,6 +450,8 @@ __global__ __launch_bounds__(NTH) void skb_sweep_kernel(SkbParams P)
     for (int q = 0; q < SPT; ++q) { const int j = q * NTH + tid; Jq[q] = j < N ? (P.Jbits[(size_t)site * P.NW + (j >> 5)] >> (j & 31)) & 1u : 0u; }
 
     long long next_sample = P.step;          // iterations k * step: a counter instead of a 64-bit modulo per iteration
+    double expc[17];
+    sk_exp_constants(expc);
     for (int64_t it = 1; it <= P.iters; ++it) {
         const int b = (int)(it & 1);
         const int li = (int)((it - 1) & 63), bi = (int)(((it - 1) >> 6) & 1);        // this iteration in its block
@@ -455,7 +484,7 @@ __global__ __launch_bounds__(NTH) void skb_sweep_kernel(SkbParams P)
                 }
                 const double dE = (double)sh_lfi[b][tid] / P.sN;            // delta_energy = lfields / sqrt(N), SK.jl:137-140
                 const double x = -P.beta * dE;
-                acc = (x >= 0.0) || (sh_u[bi][li][tid] < det_exp(x));
+                acc = (x >= 0.0) || (sh_u[bi][li][tid] < det_exp_c(x, expc));
                 swp = acc && (mlast == (int32_t)site);
                 if (acc) { E_run += dE; A_run += 1; mlast = (int32_t)site; }
             }
