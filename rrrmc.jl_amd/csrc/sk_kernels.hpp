@@ -176,7 +176,7 @@ __global__ __launch_bounds__(NTH) void sk_sweep_kernel(SkParams P)
     double expc[17];
     sk_exp_constants(expc);
 #ifdef RRRMC_SK_STAMPS
-    uint64_t st[5] = {0, 0, 0, 0, 0};
+    uint64_t st[5] = {0, 0, 0, 0, 0}, st2[2] = {0, 0};
 #endif
     for (int64_t it = 1; it <= P.iters; ++it) {
 #ifdef RRRMC_SK_STAMPS
@@ -240,14 +240,19 @@ __global__ __launch_bounds__(NTH) void sk_sweep_kernel(SkParams P)
         const uint32_t accm = sh_acc[b], swpm = sh_swap[b], si_old = sh_si[b];
         const uint32_t normal = accm & ~swpm;
         const uint32_t si_new = si_old ^ accm;
+#ifdef RRRMC_SK_STAMPS
+        asm volatile("" :: "s"(accm), "s"(swpm), "s"(si_old));
+        const uint64_t t4a = __builtin_amdgcn_s_memtime();
+#endif
 
-        if (swpm) {          // workgroup-uniform: swap lfields <-> lfields_last of those replicas
+        if (swpm) {          // workgroup-uniform and rare: swap lfields <-> lfields_last of those replicas.  Selects, not a branch per
+                             // replica: the branches made the compiler shuttle all the fields through temporaries on the path WITHOUT a swap
 #pragma unroll
-            for (int r = 0; r < kSkRB; ++r)
-                if ((swpm >> r) & 1u) {
+            for (int r = 0; r < kSkRB; ++r) {
+                const bool sw = (swpm >> r) & 1u;
 #pragma unroll
-                    for (int q = 0; q < SPT; ++q) { const double t = lf[q][r]; lf[q][r] = lfl[q][r]; lfl[q][r] = t; }
-                }
+                for (int q = 0; q < SPT; ++q) { const double a0 = lf[q][r], b0 = lfl[q][r]; lf[q][r] = sw ? b0 : a0; lfl[q][r] = sw ? a0 : b0; }
+            }
         }
         if (normal) {        // workgroup-uniform
             // replica outermost: one scalar branch per replica (8 per step) instead of one per (site, replica) pair
@@ -260,14 +265,19 @@ __global__ __launch_bounds__(NTH) void sk_sweep_kernel(SkParams P)
             }
 #pragma unroll
             for (int r = 0; r < kSkRB; ++r)
-                if ((normal >> r) & 1u) {
+                if ((normal >> r) & 1u) {          // (a scalar branch per replica: a third of them move)
 #pragma unroll
                     for (int q = 0; q < SPT; ++q) {
                         const double old = lf[q][r];
                         lfl[q][r] = old;
-                        lf[q][r] = old + (((diff[q] >> r) & 1u) ? -d4[q] : d4[q]);   // lfields[j] = lfj + 4*J*sigma, SK.jl:256-262
+                        // lfields[j] = lfj + 4*J*sigma, SK.jl:256-262; the sign goes into bit 63 of 4 J (x + (-y) is the same operation as the select of -d4)
+                        const double dl = __longlong_as_double(__double_as_longlong(d4[q]) ^ ((long long)((diff[q] >> r) & 1u) << 63));
+                        lf[q][r] = old + dl;
                     }
                 }
+#ifdef RRRMC_SK_STAMPS
+            st2[1] += __builtin_amdgcn_s_memtime() - t4a;
+#endif
             if (tid == owner) {
                 // the eight published fields in one go (a read per accepted replica, each behind its own branch, made the owner's
                 // wavefront the one everybody waits for at the next barrier; reading them in every thread up front costs more than
@@ -296,6 +306,7 @@ __global__ __launch_bounds__(NTH) void sk_sweep_kernel(SkParams P)
 #pragma unroll
         for (int q = 0; q < SPT; ++q) Jq[q] = Jn[q];
 #ifdef RRRMC_SK_STAMPS
+        st2[0] += t4a - t4;
         { const uint64_t t5 = __builtin_amdgcn_s_memtime(); st[0] += t1 - t0; st[1] += t2 - t1; st[2] += t3 - t2; st[3] += t4 - t3; st[4] += t5 - t4; }
 #endif
     }
@@ -316,6 +327,7 @@ __global__ __launch_bounds__(NTH) void sk_sweep_kernel(SkParams P)
     if (grp == 1 && (tid == 0 || tid == 200))
         printf("sk stamps tid %d iters %lld: publish %llu barA %llu decide %llu barB %llu apply %llu\n", tid, (long long)P.iters,
                (unsigned long long)st[0], (unsigned long long)st[1], (unsigned long long)st[2], (unsigned long long)st[3], (unsigned long long)st[4]);
+    if (grp == 1 && (tid == 0 || tid == 200)) printf("   update: lds read %llu, fields (when a move was accepted) %llu\n", (unsigned long long)st2[0], (unsigned long long)st2[1]);
 #endif
     if (tid < kSkRB) { P.E_cur[grp * kSkRB + tid] = E_run; P.acc_cur[grp * kSkRB + tid] = A_run; P.move_last[grp * kSkRB + tid] = mlast; }
 }
@@ -496,13 +508,13 @@ __global__ __launch_bounds__(NTH) void skb_sweep_kernel(SkbParams P)
         const uint32_t normal = accm & ~swpm;
         const uint32_t si_new = si_old ^ accm;
 
-        if (swpm) {
+        if (swpm) {          // (selects, as in sk_sweep_kernel)
 #pragma unroll
-            for (int r = 0; r < kSkRB; ++r)
-                if ((swpm >> r) & 1u) {
+            for (int r = 0; r < kSkRB; ++r) {
+                const bool sw = (swpm >> r) & 1u;
 #pragma unroll
-                    for (int q = 0; q < SPT; ++q) { const int32_t t = lf[q][r]; lf[q][r] = lfl[q][r]; lfl[q][r] = t; }
-                }
+                for (int q = 0; q < SPT; ++q) { const int32_t a0 = lf[q][r], b0 = lfl[q][r]; lf[q][r] = sw ? b0 : a0; lfl[q][r] = sw ? a0 : b0; }
+            }
         }
         if (normal) {
             // replica outermost: one scalar branch per replica instead of one per (site, replica) pair
