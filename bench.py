@@ -223,7 +223,7 @@ def secondary_c3(pkg, O, device):
            "algorithmic_bytes_per_attempt": bpa, "achieved_GBps": bpa * R * iters / (k_ms * 1e-3) / 1e9,
            "note": "algorithmic bytes of the Float64-field picture (SURVEY.md §8d) over the kernel time: the fields live in registers (8 replicas "
                    "per workgroup), the only traffic is the 8 KiB coupling row per step and workgroup from L2; the kernel is bound by the "
-                   "step's dependent chain (publish -> decide -> update, ~2500 cycles), see DESIGN.md 4c"}
+                   "step's dependent chain (publish -> decide -> update, ~2200 cycles), see DESIGN.md 4c"}
     out["frac"] = out["achieved_GBps"] / HBM_PEAK_GBS
     if O is not None:
         with pinned_core():
