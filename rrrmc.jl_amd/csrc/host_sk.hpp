@@ -26,6 +26,24 @@ int sk_threads_for(int64_t N)
     return nth;
 }
 
+// the blocked kernel (sk_block_kernel.hpp): 256 threads up to N = 256, 512 threads (one to four sites per thread) beyond, 1024 on request;
+// nullptr = this shape keeps sk_sweep_kernel
+// row stride of the 4J matrix: rows are zero-padded to a multiple of 1024 so that the blocked kernel's row loads need no bounds test
+int64_t sk_ldJ(int64_t N) { return (N + 1023) / 1024 * 1024; }
+typedef void (*sk_block_fn)(SkBlockParams);
+sk_block_fn sk_block_for(int spt, int nth)
+{
+    if (nth == 256) return spt == 1 ? sk_block_kernel<1, 256> : nullptr;
+    if (nth == 512) return spt == 1 ? sk_block_kernel<1, 512> : spt == 2 ? sk_block_kernel<2, 512> : spt == 3 ? sk_block_kernel<3, 512> : spt == 4 ? sk_block_kernel<4, 512> : nullptr;
+    if (nth == 1024) return spt == 1 ? sk_block_kernel<1, 1024> : spt == 2 ? sk_block_kernel<2, 1024> : nullptr;
+    return nullptr;
+}
+bool sk_legacy_forced()
+{
+    const char* e = std::getenv("RRRMC_SK_LEGACY");
+    return e && e[0] == '1';
+}
+
 typedef void (*skb_fn)(SkbParams);
 skb_fn skb_sweep_for(int spt, int nth)
 {
@@ -75,6 +93,7 @@ int32_t sk_ctx_create(rrrmc_ctx** out, int32_t model, int64_t N, int64_t R, int3
         SK_TRY(hipMemset(ctx->skb_lfl, 0, sizeof(int32_t) * nf));
     } else {
         SK_TRY(hipMalloc(&ctx->sk_J, sizeof(double) * N * N));
+        SK_TRY(hipMalloc(&ctx->sk_J4, sizeof(double) * N * sk_ldJ(N)));
         SK_TRY(hipMalloc(&ctx->sk_lf, sizeof(double) * nf));
         SK_TRY(hipMalloc(&ctx->sk_lfl, sizeof(double) * nf));
         SK_TRY(hipMemset(ctx->sk_lf, 0, sizeof(double) * nf));
@@ -166,6 +185,47 @@ int32_t sk_standard_mc_async(rrrmc_ctx* ctx, double beta, int64_t iters, int64_t
     P.beta = beta; P.g0 = ctx->it_done; P.iters = iters; P.step = step; P.sample0 = 0;
     P.k0 = (uint32_t)ctx->seed; P.k1 = (uint32_t)(ctx->seed >> 32); P.replica0 = ctx->replica0; P.N = (int)ctx->N;
     const int nth = sk_threads_for(ctx->N), spt = (int)((ctx->N + nth - 1) / nth);
+    const sk_block_fn blockk = sk_legacy_forced() ? nullptr : sk_block_for(spt, nth);
+    if (blockk && iters > 0) {
+        // blocked kernel: segments of <= kSkSegIters iterations, each with its state-independent block tables (sites, coupling sub-matrices)
+        const int64_t nseg = (iters + kSkSegIters - 1) / kSkSegIters;
+        const int64_t cap_blk = ((iters < kSkSegIters ? iters : kSkSegIters) + kSkW - 1) / kSkW;
+        if ((size_t)cap_blk > ctx->sk_blk_cap) {
+            free_dev(ctx->sk_blkJw); free_dev(ctx->sk_blkSites);
+            ctx->sk_blk_cap = 0;
+            HIP_TRY(ctx, hipMalloc(&ctx->sk_blkJw, sizeof(double) * (size_t)cap_blk * kSkW * kSkW));
+            HIP_TRY(ctx, hipMalloc(&ctx->sk_blkSites, sizeof(uint32_t) * (size_t)(cap_blk + 1) * kSkW));
+            ctx->sk_blk_cap = (size_t)cap_blk;
+        }
+        while ((int64_t)ctx->ev_sweep.size() < 2 * nseg) {
+            hipEvent_t e;
+            HIP_TRY(ctx, hipEventCreate(&e));
+            ctx->ev_sweep.push_back(e);
+        }
+        SkBlockParams Bk{};
+        Bk.J4 = ctx->sk_J4; Bk.blkJw = ctx->sk_blkJw; Bk.blkSites = ctx->sk_blkSites;
+        Bk.lf = ctx->sk_lf; Bk.lfl = ctx->sk_lfl; Bk.move_last = ctx->sk_move_last; Bk.spins = ctx->sk_spins;
+        Bk.E_cur = ctx->sk_E; Bk.acc_cur = ctx->d_acc; Bk.Es = ctx->sk_Es;
+        Bk.beta = beta; Bk.step = step; Bk.k0 = P.k0; Bk.k1 = P.k1; Bk.replica0 = ctx->replica0; Bk.N = (int)ctx->N; Bk.ldJ = (int)sk_ldJ(ctx->N);
+        for (int64_t sg = 0; sg < nseg; ++sg) {
+            const int64_t base = sg * kSkSegIters, n = iters - base < kSkSegIters ? iters - base : kSkSegIters, nblk = (n + kSkW - 1) / kSkW;
+            Bk.g0 = ctx->it_done + (uint64_t)base; Bk.iters = n; Bk.it_base = base;
+            hipLaunchKernelGGL(sk_block_prep_kernel, dim3((unsigned)(nblk + 1)), dim3(256), 0, st, ctx->sk_J4, ctx->sk_blkSites, ctx->sk_blkJw,
+                               Bk.g0, n, nblk, Bk.k0, Bk.k1, Bk.N, Bk.ldJ);
+            HIP_TRY(ctx, hipGetLastError());
+            HIP_TRY(ctx, hipEventRecord(ctx->ev_sweep[2 * sg], st));
+            hipLaunchKernelGGL(blockk, dim3((unsigned)ctx->G8), dim3((unsigned)nth), 0, st, Bk);
+            HIP_TRY(ctx, hipGetLastError());
+            HIP_TRY(ctx, hipEventRecord(ctx->ev_sweep[2 * sg + 1], st));
+        }
+        HIP_TRY(ctx, hipEventRecord(ctx->ev_end, st));
+        ctx->sweep_launches = (int)nseg;
+        ctx->nsamp = nsamp;
+        ctx->it_done += (uint64_t)iters;
+        ctx->results_valid = true;
+        ctx->timing_valid = true;
+        return RRRMC_OK;
+    }
     HIP_TRY(ctx, hipEventRecord(ctx->ev_sweep[0], st));
     hipLaunchKernelGGL(sk_sweep_for(spt, nth), dim3((unsigned)ctx->G8), dim3((unsigned)nth), 0, st, P);
     HIP_TRY(ctx, hipGetLastError());

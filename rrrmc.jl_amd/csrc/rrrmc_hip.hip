@@ -18,6 +18,7 @@
 #include <vector>
 
 #include "sk_kernels.hpp"
+#include "sk_block_kernel.hpp"
 #include "rrr_kernels.hpp"
 #include "quant_wave_kernel.hpp"
 #include "sparse_wave_kernel.hpp"
@@ -130,6 +131,10 @@ struct rrrmc_ctx {
     bool color_count_acc = false;       // colour sweeps also count every replica's accepted moves (rrrmc_colored_count_accepted)
     // ---- RRRMC_MODEL_SK_NORMAL ----
     double* sk_J = nullptr;        // [N][N]
+    double* sk_J4 = nullptr;       // [N][N] 4 J (exact), RRRMC_MODEL_SK_NORMAL: what update_cache! adds (SK.jl:256-262)
+    double* sk_blkJw = nullptr;    // sk_block_kernel: coupling sub-matrices of a segment's blocks
+    uint32_t* sk_blkSites = nullptr;
+    size_t sk_blk_cap = 0;         // blocks the two buffers hold
     double* sk_lf = nullptr;       // [G8][N][8]
     double* sk_lfl = nullptr;
     int32_t* sk_move_last = nullptr;
@@ -719,6 +724,7 @@ void rrrmc_ctx_destroy(rrrmc_ctx* ctx)
     free_dev(ctx->d_E); free_dev(ctx->d_acc); free_dev(ctx->d_chunks); free_dev(ctx->d_Es);
     free_dev(ctx->d_U);
     for (uint32_t*& l : ctx->d_color_list) free_dev(l);
+    free_dev(ctx->sk_J4); free_dev(ctx->sk_blkJw); free_dev(ctx->sk_blkSites);
     free_dev(ctx->sk_J); free_dev(ctx->sk_lf); free_dev(ctx->sk_lfl); free_dev(ctx->sk_move_last); free_dev(ctx->sk_spins);
     free_dev(ctx->sk_E); free_dev(ctx->sk_Es); free_dev(ctx->skb_J); free_dev(ctx->skb_lf); free_dev(ctx->skb_lfl);
     free_dev(ctx->q_spins); free_dev(ctx->q_cls); free_dev(ctx->q_sv); free_dev(ctx->q_spos); free_dev(ctx->q_st);
@@ -1862,6 +1868,13 @@ int32_t rrrmc_set_couplings_dense(rrrmc_ctx* ctx, const double* J)
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     HIP_TRY(ctx, hipMemcpy(ctx->sk_J, J, sizeof(double) * N * N, hipMemcpyHostToDevice));
+    if (ctx->sk_J4) {          // 4 J, exact: the increment of update_cache! (SK.jl:256-262) as the blocked standardMC kernel adds it
+        const int64_t ld = sk_ldJ(N);
+        std::vector<double> J4((size_t)(N * ld), 0.0);
+        for (int64_t i = 0; i < N; ++i)
+            for (int64_t j = 0; j < N; ++j) J4[(size_t)(i * ld + j)] = 4.0 * J[i * N + j];
+        HIP_TRY(ctx, hipMemcpy(ctx->sk_J4, J4.data(), sizeof(double) * N * ld, hipMemcpyHostToDevice));
+    }
     ctx->graph_set = true;
     return RRRMC_OK;
 }

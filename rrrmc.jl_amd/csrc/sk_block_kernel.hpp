@@ -1,0 +1,381 @@
+// gfx950 kernel for standardMC (src/RRRMC.jl:81-127) on the dense Gaussian SK model GraphSKNormal (src/graphs/SK.jl:170-297), blocked
+// form (round 3; sk_sweep_kernel of sk_kernels.hpp is the one-attempt-per-two-barriers form it replaces, kept as RRRMC_SK_LEGACY=1).
+//
+// The chain is sequential, but most of it is not on its critical path.  The sites and the acceptance uniforms do not depend on the
+// state (SITE / ACCEPT_F64 streams), a rejected attempt changes nothing, and the decision of attempt t only reads ONE local field,
+// lfields[site_t].  So the kernel takes W = 64 attempts at a time (a *block*):
+//
+//   gather   the owners of the block's 64 sites publish those sites' lfields / lfields_last / spin into a *window* (LDS);
+//   decide   one wavefront per replica, lane m = attempt m of the block.  Every lane keeps its verdict u_m < exp(-beta f_m) current,
+//            so the next ACCEPTED attempt is the first set bit of a ballot: rejected attempts cost nothing.  An accepted attempt k
+//            updates the lanes m > k exactly as update_cache! (SK.jl:239-276) updates those sites' entries — f_m += 4 sigma J[k][m]
+//            (one row of the block's 64 x 64 coupling sub-matrix, LDS), lfields[move] = -lfm for a repeated site, the array swap of
+//            SK.jl:247-250 when the previous accepted move was the same site — and re-evaluates their verdicts (one vector det_exp);
+//   apply    all threads apply the block's accepted moves in order to the full field arrays, which live in registers (thread t owns
+//            sites t, t + NTH, ... of the workgroup's 8 replicas, as in sk_sweep_kernel); the row of 4J is prefetched PF steps ahead.
+//
+// Three workgroup barriers per 64 attempts instead of two per attempt, and the chain's length is counted in accepted moves.  Every
+// field — tracked in the window or in the registers — receives the reference's sequence of IEEE operations, so trajectories, energies
+// and the cache are bit-identical to the oracle (tests/emulate_sk_block.py is the CPU model of this schedule, checked against it).
+// The block's sites and its coupling sub-matrix 4 J[site_k][site_m] are the same for every workgroup: sk_block_prep_kernel writes them
+// once per segment of <= kSkSegIters iterations.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "sk_kernels.hpp"
+
+namespace rrrmc {
+
+constexpr int kSkW = 64;                      // attempts per block (= lanes of the deciding wavefront)
+constexpr int64_t kSkSegIters = 1 << 16;      // iterations per launch: 1024 blocks, 32 MiB of coupling sub-matrices
+
+struct SkBlockParams {
+    const double* J4;          // [N][ldJ]  4 * J (exact); rows zero-padded to ldJ = N rounded up to 1024, so that row loads need no bounds test
+    const double* blkJw;       // [nblk][64][64]  4 J[site_k][site_m] of every block of the segment
+    const uint32_t* blkSites;  // [nblk + 1][64]  sites (0 past the end of the segment)
+    double* lf;                // [G][N][kSkRB]
+    double* lfl;
+    int32_t* move_last;        // [G][kSkRB]
+    uint8_t* spins;            // [G][N]
+    double* E_cur;             // [G * kSkRB]
+    int64_t* acc_cur;
+    double* Es;                // [nsamples][G * kSkRB]; may be null
+    double beta;
+    uint64_t g0;               // stream position at the start of the segment
+    int64_t iters, step, it_base;   // this segment's iterations; it_base = iterations of the call before the segment
+    uint32_t k0, k1, replica0;
+    int N, ldJ;
+};
+
+// sites and coupling sub-matrix of every block of a segment (state independent, shared by all workgroups)
+__global__ __launch_bounds__(256) void sk_block_prep_kernel(const double* __restrict__ J4, uint32_t* __restrict__ blkSites, double* __restrict__ blkJw,
+                                                            uint64_t g0, int64_t iters, int64_t nblk, uint32_t k0, uint32_t k1, int N, int ldJ)
+{
+    __shared__ uint32_t s[kSkW];
+    const int64_t b = blockIdx.x;
+    const int tid = threadIdx.x;
+    if (tid < kSkW) {
+        const int64_t it = b * kSkW + tid + 1;
+        const uint32_t v = (b < nblk && it <= iters) ? site_of(k0, k1, g0 + (uint64_t)it, (uint32_t)N) : 0u;
+        s[tid] = v;
+        blkSites[b * kSkW + tid] = v;
+    }
+    __syncthreads();
+    if (b >= nblk) return;
+    for (int e = tid; e < kSkW * kSkW; e += 256) {
+        const int k = e >> 6, m = e & 63;
+        blkJw[b * (kSkW * kSkW) + e] = J4[(size_t)s[k] * ldJ + s[m]];
+    }
+}
+
+// det_exp (sk_kernels.hpp) without branches: the same operations in the same order for every x it does not short-cut
+__device__ __forceinline__ double det_exp_v(double x, const double (&c)[17])
+{
+    const double k = floor(__dadd_rn(__dmul_rn(x, c[14]), 0.5));
+    const double r = __dadd_rn(__dadd_rn(x, -__dmul_rn(k, c[15])), -__dmul_rn(k, c[16]));
+    double p = c[13];
+#pragma unroll
+    for (int n = 12; n >= 0; --n) p = __dadd_rn(__dmul_rn(p, r), c[n]);
+    double e = ldexp(p, (int)k);
+    e = x < -745.2 ? 0.0 : e;
+    e = x > 709.7 ? __builtin_inf() : e;
+    return x != x ? x : e;
+}
+
+__device__ __forceinline__ double sk_readlane_f64(double v, int lane)
+{
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane), hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+    return __hiloint2double(hi, lo);
+}
+
+template <int SPT, int NTH>
+__global__ __launch_bounds__(NTH) void sk_block_kernel(SkBlockParams P)
+{
+    constexpr int NWV = NTH / 64;                          // wavefronts
+    constexpr int RPW = NWV >= kSkRB ? 1 : kSkRB / NWV;    // replicas decided per wavefront
+    constexpr int PF = SPT <= 2 ? 4 : 2;                   // attempts per group of the apply phase (two groups of rows in registers)
+    constexpr int LGN = NTH == 256 ? 8 : NTH == 512 ? 9 : 10;
+    __shared__ double sh_Jw[kSkW * kSkW];
+    __shared__ double sh_wf[kSkW][kSkRB], sh_wfl[kSkW][kSkRB], sh_u[kSkW][kSkRB];
+    __shared__ uint32_t sh_acc[2][kSkW];
+    __shared__ uint8_t sh_wsp[kSkW], sh_cslot[kSkW];
+    __shared__ uint8_t sh_canon[kSkThreads * kSkMaxSPT];
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6), N = P.N;
+    const int grp = blockIdx.x, Rp = gridDim.x * kSkRB;
+
+    double lf[SPT][kSkRB], lfl[SPT][kSkRB];
+    uint32_t sb[SPT];
+#pragma unroll
+    for (int q = 0; q < SPT; ++q) {
+        const int j = q * NTH + tid;
+        sb[q] = j < N ? P.spins[(size_t)grp * N + j] : 0u;
+#pragma unroll
+        for (int r = 0; r < kSkRB; ++r) {
+            lf[q][r] = j < N ? P.lf[((size_t)grp * N + j) * kSkRB + r] : 0.0;
+            lfl[q][r] = j < N ? P.lfl[((size_t)grp * N + j) * kSkRB + r] : 0.0;
+        }
+    }
+    for (int j = tid; j < kSkThreads * kSkMaxSPT; j += NTH) sh_canon[j] = 0xffu;
+    __syncthreads();
+    // per-replica scalar state of the deciding wavefronts (wave-uniform)
+    double E_run[RPW];
+    int64_t A_run[RPW];
+    int32_t mlast[RPW];
+#pragma unroll
+    for (int a = 0; a < RPW; ++a) {
+        const int r = wv + a * NWV;
+        const bool on = r < kSkRB;
+        E_run[a] = on ? P.E_cur[grp * kSkRB + r] : 0.0;
+        A_run[a] = on ? P.acc_cur[grp * kSkRB + r] : 0;
+        mlast[a] = on ? P.move_last[grp * kSkRB + r] : -1;
+    }
+    int64_t ns[RPW], next_sample[RPW];
+#pragma unroll
+    for (int a = 0; a < RPW; ++a) { ns[a] = P.it_base / P.step; next_sample[a] = (P.it_base / P.step + 1) * P.step; }
+    double expc[17];
+    sk_exp_constants(expc);
+
+    const int64_t nblk = (P.iters + kSkW - 1) / kSkW;
+#ifdef RRRMC_SKB_STAMPS
+    uint64_t st[7] = {0, 0, 0, 0, 0, 0, 0};
+#endif
+    // block 0: sites, uniforms, coupling sub-matrix, canonical window slot of every attempted site
+    auto draw_uniforms = [&](int64_t b) {
+        for (int idx = tid; idx < kSkW * kSkRB; idx += NTH) {
+            const int l = idx >> 3, r = idx & 7;
+            sh_u[l][r] = rand53(P.k0, P.k1, P.g0 + (uint64_t)(b * kSkW + l + 1), P.replica0 + (uint32_t)(grp * kSkRB + r));
+        }
+    };
+    uint32_t sv = P.blkSites[lane];                        // sites of the current block, lane = attempt
+    if (nblk > 0) {
+        for (int e = tid; e < kSkW * kSkW; e += NTH) sh_Jw[e] = P.blkJw[e];
+        draw_uniforms(0);
+        if (wv == 0) {
+            sh_canon[sv] = (uint8_t)lane;                  // any one of the lanes that attempt this site wins
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");         // (the read below must see the winner, not this lane's own store)
+            sh_cslot[lane] = sh_canon[sv];
+            sh_acc[0][lane] = 0u;
+        }
+    }
+    // rows of 4J, G attempts at a time and one group ahead: while the moves of one group are applied from one register set, the rows of
+    // the next group load into the other (all of a group's loads are issued at its top, unconditionally — padded rows — and waited for
+    // at the top of the next group: the compiler's vmcnt bookkeeping is exact for that shape, it gave up on a per-step ring)
+    double JA[PF][SPT], JB[PF][SPT];
+#pragma unroll
+    for (int kk = 0; kk < PF; ++kk) {
+        const uint32_t st = (uint32_t)__builtin_amdgcn_readlane((int)sv, kk);
+#pragma unroll
+        for (int q = 0; q < SPT; ++q) JA[kk][q] = P.J4[(size_t)st * P.ldJ + (q * NTH + tid)];
+    }
+    __syncthreads();
+
+    for (int64_t b = 0; b < nblk; ++b) {
+#ifdef RRRMC_SKB_STAMPS
+        const uint64_t tA = __builtin_amdgcn_s_memtime();
+#endif
+        const int pb = (int)(b & 1);
+        const int nv = (int)(P.iters - b * kSkW < kSkW ? P.iters - b * kSkW : kSkW);
+        const uint32_t sv_next = P.blkSites[(b + 1) * kSkW + lane];        // (the buffer has one block of zeros past the end)
+        // ---- gather: owners publish the window
+#pragma unroll
+        for (int q = 0; q < SPT; ++q) {
+            const int j = q * NTH + tid;
+            const uint32_t c = sh_canon[j];
+            if (c != 0xffu) {
+#pragma unroll
+                for (int r = 0; r < kSkRB; ++r) { sh_wf[c][r] = lf[q][r]; sh_wfl[c][r] = lfl[q][r]; }
+                sh_wsp[c] = (uint8_t)sb[q];
+            }
+        }
+#ifdef RRRMC_SKB_STAMPS
+        const uint64_t tB = __builtin_amdgcn_s_memtime();
+#endif
+        sk_lds_barrier();
+#ifdef RRRMC_SKB_STAMPS
+        const uint64_t tC = __builtin_amdgcn_s_memtime();
+#endif
+        // ---- decide: one wavefront per replica, lane = attempt
+#pragma unroll
+        for (int a = 0; a < RPW; ++a) {
+            const int r = wv + a * NWV;
+            if (r < kSkRB) {
+                const uint32_t cs = sh_cslot[lane];
+                double f = sh_wf[cs][r], fl = sh_wfl[cs][r];
+                uint32_t sp = (sh_wsp[cs] >> r) & 1u;
+                const double u = sh_u[lane][r];
+                const bool valid = lane < nv;
+                const int64_t it0 = P.it_base + b * kSkW;               // iteration of lane m (call-relative, 1-based) = it0 + m + 1
+                uint32_t accw = 0u;
+                double x = -P.beta * f;
+                bool ok = valid && ((x >= 0.0) || (u < det_exp_v(x, expc)));          // RRRMC.jl:39
+                unsigned long long B = __ballot(ok);
+                while (B) {
+                    const int k = __builtin_ctzll(B);
+                    while (next_sample[a] <= it0 + k + 1) {             // sample BEFORE the move (RRRMC.jl:104-108)
+                        if (P.Es && lane == 0) P.Es[ns[a] * Rp + grp * kSkRB + r] = E_run[a];
+                        ns[a] += 1; next_sample[a] += P.step;
+                    }
+                    const double dE = sk_readlane_f64(f, k);            // delta_energy, SK.jl:278-284
+                    const int32_t site_k = __builtin_amdgcn_readlane((int)sv, k);
+                    const uint32_t spk = (uint32_t)__builtin_amdgcn_readlane((int)sp, k);
+                    const bool swapped = mlast[a] == site_k;            // undo path of update_cache!, SK.jl:247-250
+                    E_run[a] += dE; A_run[a] += 1;
+                    const bool dup = (int32_t)sv == site_k;
+                    if (lane == k) accw = 1u | (swapped ? 0x100u : 0u) | (spk << 16);
+                    if (swapped) {
+                        const double t = f; f = fl; fl = t;
+                    } else {
+                        const double d = sh_Jw[k * kSkW + lane];
+                        const uint32_t neg = sp ^ spk ^ 1u;             // s_j != s_i (after the flip): sigma = -1
+                        const double dl = __longlong_as_double(__double_as_longlong(d) ^ ((long long)neg << 63));
+                        fl = f;
+                        const double fn = f + dl;                       // lfields[j] = lfj + 4 sigma J, SK.jl:256-262
+                        f = dup ? -fl : fn;                             // lfields[move] = -lfm, SK.jl:263-264
+                        mlast[a] = site_k;
+                    }
+                    sp ^= dup ? 1u : 0u;
+                    x = -P.beta * f;
+                    ok = valid && ((x >= 0.0) || (u < det_exp_v(x, expc)));
+                    B = __ballot(ok) & ((~0ull << k) << 1);
+                }
+                while (next_sample[a] <= it0 + nv) {
+                    if (P.Es && lane == 0) P.Es[ns[a] * Rp + grp * kSkRB + r] = E_run[a];
+                    ns[a] += 1; next_sample[a] += P.step;
+                }
+                if (accw) atomicOr(&sh_acc[pb][lane], accw << r);       // bit r accepted, bit 8 + r swapped, bit 16 + r spin before the flip
+            }
+        }
+#ifdef RRRMC_SKB_STAMPS
+        const uint64_t tD = __builtin_amdgcn_s_memtime();
+#endif
+        sk_lds_barrier();
+#ifdef RRRMC_SKB_STAMPS
+        const uint64_t tE = __builtin_amdgcn_s_memtime();
+#endif
+        // ---- apply: the block's accepted moves on the registers; stage the next block meanwhile
+        const uint32_t accv = sh_acc[pb][lane];
+        const bool more = b + 1 < nblk;
+        double jw_next[(kSkW * kSkW + NTH - 1) / NTH];
+        if (more) {
+#pragma unroll
+            for (int e = 0; e < (kSkW * kSkW + NTH - 1) / NTH; ++e) jw_next[e] = P.blkJw[(b + 1) * (kSkW * kSkW) + e * NTH + tid];
+            if (wv == 0) {
+                sh_canon[sv] = 0xffu;                      // retire this block's window slots, then claim the next block's
+                asm volatile("" ::: "memory");
+                sh_canon[sv_next] = (uint8_t)lane;         // (a wavefront's LDS operations execute in order)
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                sh_cslot[lane] = sh_canon[sv_next];
+                sh_acc[pb ^ 1][lane] = 0u;
+            }
+            draw_uniforms(b + 1);
+        }
+#ifdef RRRMC_SKB_STAMPS
+        const uint64_t tF = __builtin_amdgcn_s_memtime();
+#endif
+        auto apply_step = [&](int k, const double (&d4)[SPT]) {
+            const uint32_t w = (uint32_t)__builtin_amdgcn_readlane((int)accv, k);
+            const uint32_t site = (uint32_t)__builtin_amdgcn_readlane((int)sv, k);
+            if (w) {                                   // somebody accepted this attempt (workgroup-uniform)
+                const uint32_t accm = w & 0xffu, swpm = (w >> 8) & 0xffu, normal = accm & ~swpm;
+                const uint32_t si_new = ((w >> 16) & 0xffu) ^ accm;          // the moved spin after its flip, for the replicas that moved
+                const int qi = (int)(site >> LGN), owner = (int)(site & (NTH - 1));
+                if (swpm) {          // rare: swap lfields <-> lfields_last of those replicas (selects: see sk_sweep_kernel)
+#pragma unroll
+                    for (int r = 0; r < kSkRB; ++r) {
+                        const bool sw = (swpm >> r) & 1u;
+#pragma unroll
+                        for (int q = 0; q < SPT; ++q) { const double a0 = lf[q][r], b0 = lfl[q][r]; lf[q][r] = sw ? b0 : a0; lfl[q][r] = sw ? a0 : b0; }
+                    }
+                }
+                if (normal) {
+                    uint32_t diff[SPT];
+#pragma unroll
+                    for (int q = 0; q < SPT; ++q) diff[q] = si_new ^ sb[q];          // bit r set: s_i != s_j for replica r -> sigma = -1
+#pragma unroll
+                    for (int r = 0; r < kSkRB; ++r)
+                        if ((normal >> r) & 1u) {      // a scalar branch per replica
+#pragma unroll
+                            for (int q = 0; q < SPT; ++q) {
+                                const double old = lf[q][r];
+                                lfl[q][r] = old;
+                                const double dl = __longlong_as_double(__double_as_longlong(d4[q]) ^ ((long long)((diff[q] >> r) & 1u) << 63));
+                                lf[q][r] = old + dl;
+                            }
+                        }
+                    if (tid == owner) {
+#pragma unroll
+                        for (int q = 0; q < SPT; ++q)
+                            if (q == qi) {
+#pragma unroll
+                                for (int r = 0; r < kSkRB; ++r) lf[q][r] = ((normal >> r) & 1u) ? -lfl[q][r] : lf[q][r];      // SK.jl:263-264
+                            }
+                    }
+                }
+                if (tid == owner) {
+#pragma unroll
+                    for (int q = 0; q < SPT; ++q)
+                        if (q == qi) sb[q] ^= accm;    // spinflip!, Interface.jl:89-92
+                }
+            }
+        };
+        for (int k0 = 0; k0 < kSkW; k0 += 2 * PF) {
+#pragma unroll
+            for (int kk = 0; kk < PF; ++kk) {           // rows of attempts k0 + PF .. k0 + 2 PF - 1
+                const uint32_t stn = (uint32_t)__builtin_amdgcn_readlane((int)sv, k0 + PF + kk);
+#pragma unroll
+                for (int q = 0; q < SPT; ++q) JB[kk][q] = P.J4[(size_t)stn * P.ldJ + (q * NTH + tid)];
+            }
+#pragma unroll
+            for (int kk = 0; kk < PF; ++kk) apply_step(k0 + kk, JA[kk]);
+            const uint32_t svn = k0 + 2 * PF < kSkW ? sv : sv_next;       // (the next block's first attempts past the end of this one)
+#pragma unroll
+            for (int kk = 0; kk < PF; ++kk) {           // rows of attempts k0 + 2 PF .. k0 + 3 PF - 1
+                const uint32_t stn = (uint32_t)__builtin_amdgcn_readlane((int)svn, (k0 + 2 * PF + kk) & 63);
+#pragma unroll
+                for (int q = 0; q < SPT; ++q) JA[kk][q] = P.J4[(size_t)stn * P.ldJ + (q * NTH + tid)];
+            }
+#pragma unroll
+            for (int kk = 0; kk < PF; ++kk) apply_step(k0 + PF + kk, JB[kk]);
+        }
+#ifdef RRRMC_SKB_STAMPS
+        const uint64_t tG = __builtin_amdgcn_s_memtime();
+#endif
+        if (more) {
+#pragma unroll
+            for (int e = 0; e < (kSkW * kSkW + NTH - 1) / NTH; ++e) sh_Jw[e * NTH + tid] = jw_next[e];
+        }
+        sv = sv_next;
+        sk_lds_barrier();
+#ifdef RRRMC_SKB_STAMPS
+        { const uint64_t tH = __builtin_amdgcn_s_memtime();
+          st[0] += tB - tA; st[1] += tC - tB; st[2] += tD - tC; st[3] += tE - tD; st[4] += tF - tE; st[5] += tG - tF; st[6] += tH - tG; }
+#endif
+    }
+#ifdef RRRMC_SKB_STAMPS
+    if (grp == 1 && lane == 0 && (wv == 0 || wv == 5))
+        printf("skb stamps wave %d blocks %lld: gather %llu bar1 %llu decide %llu bar2 %llu stage %llu apply %llu tail+bar3 %llu (memtime ticks)\n", wv, (long long)nblk,
+               (unsigned long long)st[0], (unsigned long long)st[1], (unsigned long long)st[2], (unsigned long long)st[3], (unsigned long long)st[4],
+               (unsigned long long)st[5], (unsigned long long)st[6]);
+#endif
+
+#pragma unroll
+    for (int q = 0; q < SPT; ++q) {
+        const int j = q * NTH + tid;
+        if (j < N) {
+            P.spins[(size_t)grp * N + j] = (uint8_t)sb[q];
+#pragma unroll
+            for (int r = 0; r < kSkRB; ++r) {
+                P.lf[((size_t)grp * N + j) * kSkRB + r] = lf[q][r];
+                P.lfl[((size_t)grp * N + j) * kSkRB + r] = lfl[q][r];
+            }
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < RPW; ++a) {
+        const int r = wv + a * NWV;
+        if (r < kSkRB && lane == 0) { P.E_cur[grp * kSkRB + r] = E_run[a]; P.acc_cur[grp * kSkRB + r] = A_run[a]; P.move_last[grp * kSkRB + r] = mlast[a]; }
+    }
+}
+
+}  // namespace rrrmc
