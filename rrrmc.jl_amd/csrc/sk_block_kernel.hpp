@@ -89,6 +89,67 @@ __device__ __forceinline__ double sk_readlane_f64(double v, int lane)
     return __hiloint2double(hi, lo);
 }
 
+// One accepted attempt applied to the fields of ONE replica held by this wavefront (update_cache!, SK.jl:239-276), as one asm statement
+// with its control flow INSIDE: at the C++ level the statement is unconditional straight-line code over tied operands, so every field
+// stays in its register (written as C++ under wave-uniform branches, the compiler's merges copied every field of the replica around
+// each branch — two thirds of the loop).  w = the attempt's word from the deciding wavefronts (bit r accepted, 8 + r undo swap, 16 + r the
+// moved spin before its flip); own = 0 in the wavefronts that do not hold the moved site, else 1 + its q; lb = the moved site's lane bit.
+//   not accepted:  two scalar instructions.
+//   accepted:      lfields_last[j] = lfj (all lanes, all q first); lfields[j] = lfj + 4 sigma J (SK.jl:256-262) as two half-masked adds — sigma = -1 in the
+//                  lanes whose spin equals the moved spin before its flip, i.e. sm ^ S with S = spb ? 0 : ~0, so there is no sign
+//                  arithmetic at all; then lfields[move] = -lfm in the owner's lane (SK.jl:263-264; x * -1.0 is exact) and the spin flip
+//                  in the lane mask (spinflip!, Interface.jl:89-92).
+//   undo swap:     lfields <-> lfields_last (SK.jl:247-250) and the spin flips back.
+// All lanes are active at every call site (uniform control flow of a full workgroup): EXEC returns to all ones.
+#define SK_CPY_Q(LF, LFL) "v_mov_b64 " LFL ", " LF "\n\t"          /* (all lanes: before any of the half-masked adds) */
+#define SK_ADD_Q(LF, LFL, SM, D) \
+    "s_xor_b64 exec, " SM ", %[S]\n\tv_add_f64 " LF ", " LFL ", -" D "\n\ts_not_b64 exec, exec\n\tv_add_f64 " LF ", " LFL ", " D "\n\t"
+#define SK_OWN_Q(QP1, LF, LFL, SM) \
+    "s_cmp_eq_u32 %[own], " #QP1 "\n\ts_cbranch_scc0 1f\n\tv_mul_f64 " LF ", " LFL ", -1.0\n\ts_xor_b64 " SM ", " SM ", %[lb]\n1:\n\t"
+#define SK_SWP_Q(LF, LFL) "v_mov_b64 %[tv], " LF "\n\tv_mov_b64 " LF ", " LFL "\n\tv_mov_b64 " LFL ", %[tv]\n\t"
+#define SK_SWO_Q(QP1, SM) "s_cmp_eq_u32 %[own], " #QP1 "\n\ts_cbranch_scc0 1f\n\ts_xor_b64 " SM ", " SM ", %[lb]\n1:\n\t"
+#define SK_HEAD(R) \
+    "s_bitcmp1_b32 %[w], " #R "\n\ts_cbranch_scc0 9f\n\ts_bitcmp1_b32 %[w], " #R "+8\n\ts_cbranch_scc1 5f\n\t" \
+    "s_bitcmp1_b32 %[w], " #R "+16\n\ts_cselect_b64 %[S], 0, -1\n\t"
+#define SK_MID "s_mov_b64 exec, -1\n\ts_cmp_eq_u32 %[own], 0\n\ts_cbranch_scc1 9f\n\ts_mov_b64 exec, %[lb]\n\t"
+#define SK_TAIL "s_mov_b64 exec, -1\n\ts_branch 9f\n5:\n\t"
+#define SK_APPLY1(R, lf, lfl, sm, d) \
+    asm volatile(SK_HEAD(R) SK_CPY_Q("%[a0]", "%[b0]") SK_ADD_Q("%[a0]", "%[b0]", "%[m0]", "%[d0]") SK_MID SK_OWN_Q(1, "%[a0]", "%[b0]", "%[m0]") SK_TAIL \
+                 SK_SWP_Q("%[a0]", "%[b0]") SK_SWO_Q(1, "%[m0]") "9:" \
+                 : [a0] "+v"(lf[0][R]), [b0] "+v"(lfl[0][R]), [m0] "+s"(sm[0][R]), [S] "=&s"(tS), [tv] "=&v"(tV) \
+                 : [d0] "v"(d[0]), [w] "s"(w), [own] "s"(own), [lb] "s"(lb) : "scc")
+#define SK_APPLY2(R, lf, lfl, sm, d) \
+    asm volatile(SK_HEAD(R) SK_CPY_Q("%[a0]", "%[b0]") SK_CPY_Q("%[a1]", "%[b1]") SK_ADD_Q("%[a0]", "%[b0]", "%[m0]", "%[d0]") SK_ADD_Q("%[a1]", "%[b1]", "%[m1]", "%[d1]") SK_MID \
+                 SK_OWN_Q(1, "%[a0]", "%[b0]", "%[m0]") SK_OWN_Q(2, "%[a1]", "%[b1]", "%[m1]") SK_TAIL \
+                 SK_SWP_Q("%[a0]", "%[b0]") SK_SWP_Q("%[a1]", "%[b1]") SK_SWO_Q(1, "%[m0]") SK_SWO_Q(2, "%[m1]") "9:" \
+                 : [a0] "+v"(lf[0][R]), [b0] "+v"(lfl[0][R]), [m0] "+s"(sm[0][R]), [a1] "+v"(lf[1][R]), [b1] "+v"(lfl[1][R]), [m1] "+s"(sm[1][R]), \
+                   [S] "=&s"(tS), [tv] "=&v"(tV) \
+                 : [d0] "v"(d[0]), [d1] "v"(d[1]), [w] "s"(w), [own] "s"(own), [lb] "s"(lb) : "scc")
+#define SK_APPLY3(R, lf, lfl, sm, d) \
+    asm volatile(SK_HEAD(R) SK_CPY_Q("%[a0]", "%[b0]") SK_CPY_Q("%[a1]", "%[b1]") SK_CPY_Q("%[a2]", "%[b2]") \
+                 SK_ADD_Q("%[a0]", "%[b0]", "%[m0]", "%[d0]") SK_ADD_Q("%[a1]", "%[b1]", "%[m1]", "%[d1]") SK_ADD_Q("%[a2]", "%[b2]", "%[m2]", "%[d2]") SK_MID \
+                 SK_OWN_Q(1, "%[a0]", "%[b0]", "%[m0]") SK_OWN_Q(2, "%[a1]", "%[b1]", "%[m1]") SK_OWN_Q(3, "%[a2]", "%[b2]", "%[m2]") SK_TAIL \
+                 SK_SWP_Q("%[a0]", "%[b0]") SK_SWP_Q("%[a1]", "%[b1]") SK_SWP_Q("%[a2]", "%[b2]") \
+                 SK_SWO_Q(1, "%[m0]") SK_SWO_Q(2, "%[m1]") SK_SWO_Q(3, "%[m2]") "9:" \
+                 : [a0] "+v"(lf[0][R]), [b0] "+v"(lfl[0][R]), [m0] "+s"(sm[0][R]), [a1] "+v"(lf[1][R]), [b1] "+v"(lfl[1][R]), [m1] "+s"(sm[1][R]), \
+                   [a2] "+v"(lf[2][R]), [b2] "+v"(lfl[2][R]), [m2] "+s"(sm[2][R]), [S] "=&s"(tS), [tv] "=&v"(tV) \
+                 : [d0] "v"(d[0]), [d1] "v"(d[1]), [d2] "v"(d[2]), [w] "s"(w), [own] "s"(own), [lb] "s"(lb) : "scc")
+#define SK_APPLY4(R, lf, lfl, sm, d) \
+    asm volatile(SK_HEAD(R) SK_CPY_Q("%[a0]", "%[b0]") SK_CPY_Q("%[a1]", "%[b1]") SK_CPY_Q("%[a2]", "%[b2]") SK_CPY_Q("%[a3]", "%[b3]") \
+                 SK_ADD_Q("%[a0]", "%[b0]", "%[m0]", "%[d0]") SK_ADD_Q("%[a1]", "%[b1]", "%[m1]", "%[d1]") \
+                 SK_ADD_Q("%[a2]", "%[b2]", "%[m2]", "%[d2]") SK_ADD_Q("%[a3]", "%[b3]", "%[m3]", "%[d3]") SK_MID \
+                 SK_OWN_Q(1, "%[a0]", "%[b0]", "%[m0]") SK_OWN_Q(2, "%[a1]", "%[b1]", "%[m1]") SK_OWN_Q(3, "%[a2]", "%[b2]", "%[m2]") \
+                 SK_OWN_Q(4, "%[a3]", "%[b3]", "%[m3]") SK_TAIL \
+                 SK_SWP_Q("%[a0]", "%[b0]") SK_SWP_Q("%[a1]", "%[b1]") SK_SWP_Q("%[a2]", "%[b2]") SK_SWP_Q("%[a3]", "%[b3]") \
+                 SK_SWO_Q(1, "%[m0]") SK_SWO_Q(2, "%[m1]") SK_SWO_Q(3, "%[m2]") SK_SWO_Q(4, "%[m3]") "9:" \
+                 : [a0] "+v"(lf[0][R]), [b0] "+v"(lfl[0][R]), [m0] "+s"(sm[0][R]), [a1] "+v"(lf[1][R]), [b1] "+v"(lfl[1][R]), [m1] "+s"(sm[1][R]), \
+                   [a2] "+v"(lf[2][R]), [b2] "+v"(lfl[2][R]), [m2] "+s"(sm[2][R]), [a3] "+v"(lf[3][R]), [b3] "+v"(lfl[3][R]), [m3] "+s"(sm[3][R]), \
+                   [S] "=&s"(tS), [tv] "=&v"(tV) \
+                 : [d0] "v"(d[0]), [d1] "v"(d[1]), [d2] "v"(d[2]), [d3] "v"(d[3]), [w] "s"(w), [own] "s"(own), [lb] "s"(lb) : "scc")
+#define SK_APPLY_ALL(M, lf, lfl, sm, d) \
+    do { M(0, lf, lfl, sm, d); M(1, lf, lfl, sm, d); M(2, lf, lfl, sm, d); M(3, lf, lfl, sm, d); \
+         M(4, lf, lfl, sm, d); M(5, lf, lfl, sm, d); M(6, lf, lfl, sm, d); M(7, lf, lfl, sm, d); } while (0)
+
 template <int SPT, int NTH>
 __global__ __launch_bounds__(NTH) void sk_block_kernel(SkBlockParams P)
 {
@@ -105,17 +166,24 @@ __global__ __launch_bounds__(NTH) void sk_block_kernel(SkBlockParams P)
     const int grp = blockIdx.x, Rp = gridDim.x * kSkRB;
 
     double lf[SPT][kSkRB], lfl[SPT][kSkRB];
-    uint32_t sb[SPT];
+    unsigned long long sm[SPT][kSkRB];         // spins as wave-uniform lane masks, one per (q, replica): bit l = the spin of site q * NTH + 64 wave + l
 #pragma unroll
     for (int q = 0; q < SPT; ++q) {
         const int j = q * NTH + tid;
-        sb[q] = j < N ? P.spins[(size_t)grp * N + j] : 0u;
+        const uint32_t sb = j < N ? P.spins[(size_t)grp * N + j] : 0u;
 #pragma unroll
         for (int r = 0; r < kSkRB; ++r) {
             lf[q][r] = j < N ? P.lf[((size_t)grp * N + j) * kSkRB + r] : 0.0;
             lfl[q][r] = j < N ? P.lfl[((size_t)grp * N + j) * kSkRB + r] : 0.0;
+            sm[q][r] = __ballot((sb >> r) & 1u);
         }
     }
+    auto spin_byte = [&](int q) {              // the 8 replicas' spins of this lane's site q
+        uint32_t v = 0u;
+#pragma unroll
+        for (int r = 0; r < kSkRB; ++r) v |= (uint32_t)((sm[q][r] >> lane) & 1ull) << r;
+        return v;
+    };
     for (int j = tid; j < kSkThreads * kSkMaxSPT; j += NTH) sh_canon[j] = 0xffu;
     __syncthreads();
     // per-replica scalar state of the deciding wavefronts (wave-uniform)
@@ -185,7 +253,7 @@ __global__ __launch_bounds__(NTH) void sk_block_kernel(SkBlockParams P)
             if (c != 0xffu) {
 #pragma unroll
                 for (int r = 0; r < kSkRB; ++r) { sh_wf[c][r] = lf[q][r]; sh_wfl[c][r] = lfl[q][r]; }
-                sh_wsp[c] = (uint8_t)sb[q];
+                sh_wsp[c] = (uint8_t)spin_byte(q);
             }
         }
 #ifdef RRRMC_SKB_STAMPS
@@ -276,55 +344,26 @@ __global__ __launch_bounds__(NTH) void sk_block_kernel(SkBlockParams P)
         auto apply_step = [&](int k, const double (&d4)[SPT]) {
             const uint32_t w = (uint32_t)__builtin_amdgcn_readlane((int)accv, k);
             const uint32_t site = (uint32_t)__builtin_amdgcn_readlane((int)sv, k);
-            if (w) {                                   // somebody accepted this attempt (workgroup-uniform)
-                const uint32_t accm = w & 0xffu, swpm = (w >> 8) & 0xffu, normal = accm & ~swpm;
-                const uint32_t si_new = ((w >> 16) & 0xffu) ^ accm;          // the moved spin after its flip, for the replicas that moved
-                const int qi = (int)(site >> LGN), owner = (int)(site & (NTH - 1));
-                if (swpm) {          // rare: swap lfields <-> lfields_last of those replicas (selects: see sk_sweep_kernel)
-#pragma unroll
-                    for (int r = 0; r < kSkRB; ++r) {
-                        const bool sw = (swpm >> r) & 1u;
-#pragma unroll
-                        for (int q = 0; q < SPT; ++q) { const double a0 = lf[q][r], b0 = lfl[q][r]; lf[q][r] = sw ? b0 : a0; lfl[q][r] = sw ? a0 : b0; }
-                    }
-                }
-                if (normal) {
-                    uint32_t diff[SPT];
-#pragma unroll
-                    for (int q = 0; q < SPT; ++q) diff[q] = si_new ^ sb[q];          // bit r set: s_i != s_j for replica r -> sigma = -1
-#pragma unroll
-                    for (int r = 0; r < kSkRB; ++r)
-                        if ((normal >> r) & 1u) {      // a scalar branch per replica
-#pragma unroll
-                            for (int q = 0; q < SPT; ++q) {
-                                const double old = lf[q][r];
-                                lfl[q][r] = old;
-                                const double dl = __longlong_as_double(__double_as_longlong(d4[q]) ^ ((long long)((diff[q] >> r) & 1u) << 63));
-                                lf[q][r] = old + dl;
-                            }
-                        }
-                    if (tid == owner) {
-#pragma unroll
-                        for (int q = 0; q < SPT; ++q)
-                            if (q == qi) {
-#pragma unroll
-                                for (int r = 0; r < kSkRB; ++r) lf[q][r] = ((normal >> r) & 1u) ? -lfl[q][r] : lf[q][r];      // SK.jl:263-264
-                            }
-                    }
-                }
-                if (tid == owner) {
-#pragma unroll
-                    for (int q = 0; q < SPT; ++q)
-                        if (q == qi) sb[q] ^= accm;    // spinflip!, Interface.jl:89-92
-                }
-            }
+            const uint32_t own = (int)((site & (NTH - 1)) >> 6) == wv ? (site >> LGN) + 1u : 0u;
+            const unsigned long long lb = 1ull << (site & 63u);
+            unsigned long long tS;
+            double tV;
+            if constexpr (SPT == 1) SK_APPLY_ALL(SK_APPLY1, lf, lfl, sm, d4);
+            else if constexpr (SPT == 2) SK_APPLY_ALL(SK_APPLY2, lf, lfl, sm, d4);
+            else if constexpr (SPT == 3) SK_APPLY_ALL(SK_APPLY3, lf, lfl, sm, d4);
+            else SK_APPLY_ALL(SK_APPLY4, lf, lfl, sm, d4);
+            (void)tS; (void)tV;
         };
         for (int k0 = 0; k0 < kSkW; k0 += 2 * PF) {
 #pragma unroll
             for (int kk = 0; kk < PF; ++kk) {           // rows of attempts k0 + PF .. k0 + 2 PF - 1
                 const uint32_t stn = (uint32_t)__builtin_amdgcn_readlane((int)sv, k0 + PF + kk);
 #pragma unroll
+#ifndef RRRMC_SKB_NOLOAD
                 for (int q = 0; q < SPT; ++q) JB[kk][q] = P.J4[(size_t)stn * P.ldJ + (q * NTH + tid)];
+#else
+                for (int q = 0; q < SPT; ++q) JB[kk][q] = (double)stn;
+#endif
             }
 #pragma unroll
             for (int kk = 0; kk < PF; ++kk) apply_step(k0 + kk, JA[kk]);
@@ -333,7 +372,11 @@ __global__ __launch_bounds__(NTH) void sk_block_kernel(SkBlockParams P)
             for (int kk = 0; kk < PF; ++kk) {           // rows of attempts k0 + 2 PF .. k0 + 3 PF - 1
                 const uint32_t stn = (uint32_t)__builtin_amdgcn_readlane((int)svn, (k0 + 2 * PF + kk) & 63);
 #pragma unroll
+#ifndef RRRMC_SKB_NOLOAD
                 for (int q = 0; q < SPT; ++q) JA[kk][q] = P.J4[(size_t)stn * P.ldJ + (q * NTH + tid)];
+#else
+                for (int q = 0; q < SPT; ++q) JA[kk][q] = (double)stn;
+#endif
             }
 #pragma unroll
             for (int kk = 0; kk < PF; ++kk) apply_step(k0 + PF + kk, JB[kk]);
@@ -363,7 +406,7 @@ __global__ __launch_bounds__(NTH) void sk_block_kernel(SkBlockParams P)
     for (int q = 0; q < SPT; ++q) {
         const int j = q * NTH + tid;
         if (j < N) {
-            P.spins[(size_t)grp * N + j] = (uint8_t)sb[q];
+            P.spins[(size_t)grp * N + j] = (uint8_t)spin_byte(q);
 #pragma unroll
             for (int r = 0; r < kSkRB; ++r) {
                 P.lf[((size_t)grp * N + j) * kSkRB + r] = lf[q][r];
