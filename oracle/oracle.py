@@ -29,14 +29,38 @@ def build(force=False):
     return _SO
 
 
+def build_native():
+    """The -O3 -march=native build for bench.py's cpu_baseline leg.  Built where it is timed; falls back to the portable
+    build when the host compiler refuses.  Select it with RRRMC_ORACLE_NATIVE=1 BEFORE the first call into this module."""
+    import hashlib
+    try:          # the file name carries the host CPU's identity: a build made on another machine (the tree travels) is never loaded here
+        cpu = "".join(l for l in open("/proc/cpuinfo") if l.startswith(("model name", "flags")))[:20000]
+    except OSError:
+        cpu = "unknown"
+    tag = hashlib.sha1(cpu.encode()).hexdigest()[:10]
+    so = os.path.join(_HERE, "_build", "librrrmc_oracle_native_%s.so" % tag)
+    srcs = [os.path.join(_HERE, f) for f in os.listdir(_HERE) if f.endswith((".c", ".h"))]
+    if os.path.exists(so) and all(os.path.getmtime(so) >= os.path.getmtime(s) for s in srcs):
+        return so
+    try:
+        subprocess.check_call(["make", "-s", "-C", _HERE, "native", "NATIVE_SO=%s" % so])
+    except (subprocess.CalledProcessError, OSError):
+        return build()
+    return so
+
+
 _lib = None
+flavour = "x86-64-v2"
 
 
 def lib():
-    global _lib
+    global _lib, flavour
     if _lib is None:
-        build()
-        L = C.CDLL(_SO)
+        so = build()
+        if os.environ.get("RRRMC_ORACLE_NATIVE") == "1":
+            so = build_native()
+            flavour = "native" if "_native_" in os.path.basename(so) else flavour
+        L = C.CDLL(so)
         L.orc_philox.argtypes = [u32p, u32p, u32p]
         L.orc_site_of.restype = C.c_int64
         L.orc_site_of.argtypes = [C.c_uint64, C.c_uint64, C.c_int64]

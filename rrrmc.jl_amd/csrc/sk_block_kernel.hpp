@@ -158,7 +158,7 @@ __global__ __launch_bounds__(NTH) void sk_block_kernel(SkBlockParams P)
     constexpr int PF = SPT <= 2 ? 4 : 2;                   // attempts per group of the apply phase (two groups of rows in registers)
     constexpr int LGN = NTH == 256 ? 8 : NTH == 512 ? 9 : 10;
     __shared__ double sh_Jw[kSkW * kSkW];
-    __shared__ double sh_wf[kSkW][kSkRB], sh_wfl[kSkW][kSkRB], sh_u[kSkW][kSkRB];
+    __shared__ double sh_wf[kSkW][kSkRB], sh_wfl[kSkW][kSkRB], sh_u[kSkW][kSkRB], sh_L[kSkW][kSkRB];
     __shared__ uint32_t sh_acc[2][kSkW];
     __shared__ uint8_t sh_wsp[kSkW], sh_cslot[kSkW];
     __shared__ uint8_t sh_canon[kSkThreads * kSkMaxSPT];
@@ -212,7 +212,9 @@ __global__ __launch_bounds__(NTH) void sk_block_kernel(SkBlockParams P)
     auto draw_uniforms = [&](int64_t b) {
         for (int idx = tid; idx < kSkW * kSkRB; idx += NTH) {
             const int l = idx >> 3, r = idx & 7;
-            sh_u[l][r] = rand53(P.k0, P.k1, P.g0 + (uint64_t)(b * kSkW + l + 1), P.replica0 + (uint32_t)(grp * kSkRB + r));
+            const double u = rand53(P.k0, P.k1, P.g0 + (uint64_t)(b * kSkW + l + 1), P.replica0 + (uint32_t)(grp * kSkRB + r));
+            sh_u[l][r] = u;
+            sh_L[l][r] = log(u);                           // state independent: the verdict's filter (see accept_verdict)
         }
     };
     uint32_t sv = P.blkSites[lane];                        // sites of the current block, lane = attempt
@@ -275,8 +277,20 @@ __global__ __launch_bounds__(NTH) void sk_block_kernel(SkBlockParams P)
                 const bool valid = lane < nv;
                 const int64_t it0 = P.it_base + b * kSkW;               // iteration of lane m (call-relative, 1-based) = it0 + m + 1
                 uint32_t accw = 0u;
-                double x = -P.beta * f;
-                bool ok = valid && ((x >= 0.0) || (u < det_exp_v(x, expc)));          // RRRMC.jl:39
+                // accept iff x >= 0 || u < det_exp(x), x = -beta dE (RRRMC.jl:39).  det_exp is 40 dependent Float64 operations on the
+                // chain's critical path, and u < exp(x) is ln u < x: with ln u drawn ahead, x outside [ln u - m, ln u + m] (m = 1e-9 +
+                // 1e-12 |ln u|, six orders above the error of either function) decides without the exponential; inside (probability
+                // 1e-9 per evaluation), for x < -700 and for u = 0 (m = inf) the exponential is evaluated — by every lane, so the
+                // verdicts are det_exp's verdicts bit for bit in all cases.
+                const double Lu = sh_L[lane][r];
+                const double Lm = 1e-9 - 1e-12 * Lu, Lhi = Lu + Lm, Llo = Lu - Lm;
+                auto verdict = [&](const double x) {
+                    const bool sure_acc = (x >= 0.0) || (x > Lhi), sure_rej = (x < Llo) && (x > -700.0);
+                    bool ok = sure_acc;
+                    if (__ballot(valid && !(sure_acc || sure_rej))) ok = (x >= 0.0) || (u < det_exp_v(x, expc));
+                    return valid && ok;
+                };
+                bool ok = verdict(-P.beta * f);
                 unsigned long long B = __ballot(ok);
                 while (B) {
                     const int k = __builtin_ctzll(B);
@@ -303,8 +317,7 @@ __global__ __launch_bounds__(NTH) void sk_block_kernel(SkBlockParams P)
                         mlast[a] = site_k;
                     }
                     sp ^= dup ? 1u : 0u;
-                    x = -P.beta * f;
-                    ok = valid && ((x >= 0.0) || (u < det_exp_v(x, expc)));
+                    ok = verdict(-P.beta * f);
                     B = __ballot(ok) & ((~0ull << k) << 1);
                 }
                 while (next_sample[a] <= it0 + nv) {
@@ -342,16 +355,24 @@ __global__ __launch_bounds__(NTH) void sk_block_kernel(SkBlockParams P)
         const uint64_t tF = __builtin_amdgcn_s_memtime();
 #endif
         auto apply_step = [&](int k, const double (&d4)[SPT]) {
+#ifdef RRRMC_SKB_ABL_W0
+            const uint32_t w = (uint32_t)__builtin_amdgcn_readlane((int)accv, k) & 0x80000000u;      // timing experiment: nobody accepts
+#else
             const uint32_t w = (uint32_t)__builtin_amdgcn_readlane((int)accv, k);
+#endif
             const uint32_t site = (uint32_t)__builtin_amdgcn_readlane((int)sv, k);
             const uint32_t own = (int)((site & (NTH - 1)) >> 6) == wv ? (site >> LGN) + 1u : 0u;
             const unsigned long long lb = 1ull << (site & 63u);
             unsigned long long tS;
             double tV;
-            if constexpr (SPT == 1) SK_APPLY_ALL(SK_APPLY1, lf, lfl, sm, d4);
-            else if constexpr (SPT == 2) SK_APPLY_ALL(SK_APPLY2, lf, lfl, sm, d4);
-            else if constexpr (SPT == 3) SK_APPLY_ALL(SK_APPLY3, lf, lfl, sm, d4);
-            else SK_APPLY_ALL(SK_APPLY4, lf, lfl, sm, d4);
+#ifdef RRRMC_SKB_ABL_NOASM
+            asm volatile("" :: "s"(w), "s"(own), "s"(lb), "v"(d4[0]));           // timing experiment: the step's prelude and row loads only
+            if constexpr (SPT == 99)
+#endif
+            if constexpr (SPT == 1) { SK_APPLY_ALL(SK_APPLY1, lf, lfl, sm, d4); }
+            else if constexpr (SPT == 2) { SK_APPLY_ALL(SK_APPLY2, lf, lfl, sm, d4); }
+            else if constexpr (SPT == 3) { SK_APPLY_ALL(SK_APPLY3, lf, lfl, sm, d4); }
+            else { SK_APPLY_ALL(SK_APPLY4, lf, lfl, sm, d4); }
             (void)tS; (void)tV;
         };
         for (int k0 = 0; k0 < kSkW; k0 += 2 * PF) {
@@ -362,7 +383,7 @@ __global__ __launch_bounds__(NTH) void sk_block_kernel(SkBlockParams P)
 #ifndef RRRMC_SKB_NOLOAD
                 for (int q = 0; q < SPT; ++q) JB[kk][q] = P.J4[(size_t)stn * P.ldJ + (q * NTH + tid)];
 #else
-                for (int q = 0; q < SPT; ++q) JB[kk][q] = (double)stn;
+                for (int q = 0; q < SPT; ++q) JB[kk][q] = P.J4[(size_t)(stn & 7u) * P.ldJ + (q * NTH + tid)];      // timing experiment: always-hot rows
 #endif
             }
 #pragma unroll
@@ -375,7 +396,7 @@ __global__ __launch_bounds__(NTH) void sk_block_kernel(SkBlockParams P)
 #ifndef RRRMC_SKB_NOLOAD
                 for (int q = 0; q < SPT; ++q) JA[kk][q] = P.J4[(size_t)stn * P.ldJ + (q * NTH + tid)];
 #else
-                for (int q = 0; q < SPT; ++q) JA[kk][q] = (double)stn;
+                for (int q = 0; q < SPT; ++q) JA[kk][q] = P.J4[(size_t)(stn & 7u) * P.ldJ + (q * NTH + tid)];
 #endif
             }
 #pragma unroll
