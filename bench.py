@@ -35,20 +35,36 @@ ITERS = 1 << 22          # iterations per replica per step (1024 lattice sweeps)
 SAMPLE_STEP = 1 << 12    # energy sample every N iterations
 SEED = 0x5EED
 HBM_PEAK_GBS = 8000.0    # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-PROFILE_DIR = os.path.join(ROOT, "profiles", "r02")
+PROFILE_DIRS = [os.path.join(ROOT, "profiles", d) for d in ("r03", "r02")]       # newest first
+SWEEP_KERNEL_SOURCES = ["rrrmc.jl_amd/csrc/sparse_kernels.hpp", "rrrmc.jl_amd/csrc/philox.hpp"]     # what traffic.json / valu_model.json describe
 
 
 # ----------------------------------------------------------------------------------------------------------------
 # stand-alone multi-GPU launcher (the parent never initialises HIP: it only counts devices and spawns children)
 # ----------------------------------------------------------------------------------------------------------------
 def visible_gpu_count():
-    """Devices the rank processes will see, WITHOUT initialising the GPU in this process."""
+    """Devices the rank processes will see, counted WITHOUT any HIP call in this process: the visibility variables if set, else the KFD
+    topology (every node with SIMDs is a GPU); torch's counter only as a last resort (it may fall back to hipGetDeviceCount)."""
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        vis = os.environ.get(var)
+        if vis is not None:
+            return len([v for v in vis.split(",") if v.strip()])
+    topo = "/sys/class/kfd/kfd/topology/nodes"
+    try:
+        n = 0
+        for node in os.listdir(topo):
+            for line in open(os.path.join(topo, node, "properties")):
+                if line.startswith("simd_count") and int(line.split()[1]) > 0:
+                    n += 1
+        if n:
+            return n
+    except (OSError, ValueError):
+        pass
     try:
         import torch
-        return int(torch.cuda.device_count())      # NVML-style count on this image: no HIP context is created
+        return int(torch.cuda.device_count())
     except Exception:
-        vis = os.environ.get("HIP_VISIBLE_DEVICES") or os.environ.get("ROCR_VISIBLE_DEVICES")
-        return len([v for v in vis.split(",") if v.strip()]) if vis else 0
+        return 0
 
 
 def free_port():
@@ -176,7 +192,63 @@ def cpu_baseline(O, X, seconds_target=15.0):
         dt = time.perf_counter() - t0
     return {"value": R * iters / dt, "unit": "attempts/s", "cores": 1, "kind": "port",
             "sample": "%d replicas x 2^22 iterations of the same graph/beta, single thread, oracle/rrrmc_oracle.c (%.1f s)" % (R, dt),
+            "build": "gcc -O3 -march=%s -ffp-contract=off" % O.flavour,
             "cpu_model": cpu_model_name(), "host_cores": os.cpu_count(), "pinned_core": pc.core}
+
+
+def timed_oracle(fn, unit_per_call, min_seconds=1.0, max_calls=64):
+    """Repeat an oracle call until at least `min_seconds` have been timed (SURVEY.md §8d asks for a sample that is not noise);
+    returns (units per second, calls, seconds)."""
+    n, t0 = 0, time.perf_counter()
+    while True:
+        fn(n)
+        n += 1
+        dt = time.perf_counter() - t0
+        if dt >= min_seconds or n >= max_calls:
+            return n * unit_per_call / dt, n, dt
+
+
+def source_stamp(files=None):
+    """sha1 over the sources of the kernel a committed profile describes: a profile JSON whose stamp differs was measured on another build."""
+    import hashlib
+    h = hashlib.sha1()
+    for f in files or SWEEP_KERNEL_SOURCES:
+        try:
+            h.update(open(os.path.join(ROOT, f), "rb").read())
+        except OSError:
+            h.update(b"missing:" + f.encode())
+    return h.hexdigest()[:16]
+
+
+def git_head():
+    try:
+        return subprocess.check_output(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], stderr=subprocess.DEVNULL, text=True).strip()
+    except Exception:
+        return None
+
+
+def verify_timed_region(O, X, C_start, C_end, Es_last, acc_last, it0, steps, iters, replicas, replica0):
+    """Replay the WHOLE timed region (steps x iters iterations from the configuration it started with) of a few replicas through the
+    CPU oracle and compare what the timed run left behind: final configuration, the last step's energy samples and accepted count.
+    The oracle is the checker here, after the timed region; one thread per replica (ctypes releases the GIL)."""
+    import threading
+    A, J = X.A, X.J.astype(np.int32)
+    res = {}
+
+    def one(r):
+        ch = C_start[r].copy()
+        if steps > 1:
+            ch = O.standard_mc_sparse(A, J, BETA, iters * (steps - 1), SAMPLE_STEP, SEED, ch, it0=it0, replica=replica0 + r)[1]
+        o = O.standard_mc_sparse(A, J, BETA, iters, SAMPLE_STEP, SEED, ch, it0=it0 + iters * (steps - 1), replica=replica0 + r)
+        res[r] = bool((o[1] == C_end[r]).all() and (o[0] == Es_last[r]).all() and o[2] == acc_last[r])
+
+    t0 = time.perf_counter()
+    th = [threading.Thread(target=one, args=(r,)) for r in replicas]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    return {"replicas": [int(replica0 + r) for r in replicas], "ok": [res.get(r, False) for r in replicas],
+            "iterations_replayed_per_replica": int(iters) * int(steps), "seconds": time.perf_counter() - t0,
+            "compared": "final configuration, energy samples of the last step, accepted count of the last step (bit-exact)"}
 
 
 def device_copy_bandwidth(pkg, device, nbytes=1 << 30, reps=10):
@@ -191,20 +263,26 @@ def device_copy_bandwidth(pkg, device, nbytes=1 << 30, reps=10):
 
 
 def load_profile_json(name):
-    p = os.path.join(PROFILE_DIR, name)
-    if os.path.exists(p):
-        try:
-            return json.load(open(p))
-        except ValueError:
-            return None
-    return None
+    """Newest committed profile JSON of that name, with its provenance: (dict, 'profiles/rNN/name', stamp_state) where stamp_state is
+    'match' (measured on these kernel sources), 'stale' (another build: the caller drops the derived figures) or 'unstamped'."""
+    for d in PROFILE_DIRS:
+        p = os.path.join(d, name)
+        if os.path.exists(p):
+            try:
+                j = json.load(open(p))
+            except ValueError:
+                continue
+            st = j.get("source_stamp")
+            state = "unstamped" if not st else ("match" if st == source_stamp() else "stale")
+            return j, os.path.relpath(p, ROOT), state
+    return None, None, None
 
 
 # ----------------------------------------------------------------------------------------------------------------
 # secondary configurations (BASELINE.json configs[2..4] at ONE GPU's share), after the headline's timed region
 # ----------------------------------------------------------------------------------------------------------------
 def secondary_c3(pkg, O, device):
-    """configs[2]: GraphSKNormal N=1024, 2048 replicas, standardMC beta=1 (sk_sweep_kernel)."""
+    """configs[2]: GraphSKNormal N=1024, 2048 replicas, standardMC beta=1 (sk_block_kernel)."""
     N, R, beta, iters, step = 1024, 2048, 1.0, 1 << 16, 1 << 10
     X = pkg.GraphSKNormal(N, seed=SEED)
     with pkg.Engine(X, R, device=device) as eng:
@@ -219,20 +297,23 @@ def secondary_c3(pkg, O, device):
     a = float(acc.mean()) / iters
     bpa = 8 + a * (17 * N + 2)                                   # SURVEY.md §8d, dense SK Float64
     out = {"workload": "GraphSKNormal(N=1024) standardMC beta=1.0, 2048 replicas, 2^16 iterations per replica", "value": R * iters / dt,
-           "unit": "attempts/s", "kernel": "sk_sweep_kernel", "avg_launch_ms": k_ms / max(nl, 1), "launches": nl, "acceptance": a,
+           "unit": "attempts/s", "kernel": "sk_sweep_kernel" if os.environ.get("RRRMC_SK_LEGACY") == "1" else "sk_block_kernel<2, 512>",
+           "avg_launch_ms": k_ms / max(nl, 1), "launches": nl, "acceptance": a,
            "algorithmic_bytes_per_attempt": bpa, "achieved_GBps": bpa * R * iters / (k_ms * 1e-3) / 1e9,
            "note": "algorithmic bytes of the Float64-field picture (SURVEY.md §8d) over the kernel time: the fields live in registers (8 replicas "
-                   "per workgroup), the only traffic is the 8 KiB coupling row per step and workgroup from L2; the kernel is bound by the "
-                   "step's dependent chain (publish -> decide -> update, ~2200 cycles), see DESIGN.md 4c"}
+                   "per workgroup), the only traffic is the 8 KiB row of 4J per attempt and workgroup from L2 (floor ~280 cycles per attempt); "
+                   "the kernel is bound by instruction issue of the per-replica field updates, see DESIGN.md 4c"}
     out["frac"] = out["achieved_GBps"] / HBM_PEAK_GBS
+    # FP64 VALU view: the useful work is a * N Float64 adds per attempt and replica (the field update); MI355X vector FP64 = 78.6 TFLOP/s as FMAs
+    out["fp64_adds_per_s"] = a * N * R * iters / (k_ms * 1e-3)
+    out["fp64_valu_frac"] = out["fp64_adds_per_s"] / (78.6e12 / 2)
     if O is not None:
         with pinned_core():
             ch = O.init_configs(SEED, 0, 1, N)[0]
-            it1 = 1 << 13
-            t0 = time.perf_counter()
-            O.standard_mc_skn(X.J, beta, it1, step, SEED, ch)
-            out["cpu_one_core"] = {"value": it1 / (time.perf_counter() - t0), "unit": "attempts/s", "kind": "port",
-                                   "sample": "1 replica x 2^13 iterations, oracle"}
+            it1 = 1 << 16
+            v, n, dt1 = timed_oracle(lambda k: O.standard_mc_skn(X.J, beta, it1, step, SEED, ch, it0=k * it1), it1)
+            out["cpu_one_core"] = {"value": v, "unit": "attempts/s", "kind": "port", "build": O.flavour,
+                                   "sample": "1 replica x %d x 2^16 iterations (%.1f s), oracle" % (n, dt1)}
     return out
 
 
@@ -262,10 +343,10 @@ def secondary_c4(pkg, O, device):
     if O is not None:
         with pinned_core():
             ch = O.init_configs(SEED, 0, 1, X.N)[0]
-            t0 = time.perf_counter()
-            O.colored_sweeps_sparse(X.A, X.J.astype(np.int32), pkg.checkerboard_coloring(L, D), beta, 8, 8, SEED, ch)
-            out["cpu_one_core"] = {"value": 8 * X.N / (time.perf_counter() - t0), "unit": "attempts/s", "kind": "port",
-                                   "sample": "1 replica x 8 sweeps, oracle"}
+            Ji, col = X.J.astype(np.int32), pkg.checkerboard_coloring(L, D)
+            v, n, dt1 = timed_oracle(lambda k: O.colored_sweeps_sparse(X.A, Ji, col, beta, 8, 8, SEED, ch, sweep0=8 * k), 8 * X.N)
+            out["cpu_one_core"] = {"value": v, "unit": "attempts/s", "kind": "port", "build": O.flavour,
+                                   "sample": "1 replica x %d x 8 sweeps (%.1f s), oracle" % (n, dt1)}
     return out
 
 
@@ -295,10 +376,10 @@ def secondary_c4_random(pkg, O, device):
     if O is not None:
         with pinned_core():
             ch = O.init_configs(SEED, 0, 1, X.N)[0]
-            t0 = time.perf_counter()
-            O.standard_mc_sparse(X.A, X.J.astype(np.int32), beta, 4 * X.N, X.N, SEED, ch, replica=0, form="ea")
-            out["cpu_one_core"] = {"value": 4 * X.N / (time.perf_counter() - t0), "unit": "attempts/s", "kind": "port",
-                                   "sample": "1 replica x 4 sweeps, oracle"}
+            Ji = X.J.astype(np.int32)
+            v, n, dt1 = timed_oracle(lambda k: O.standard_mc_sparse(X.A, Ji, beta, 8 * X.N, X.N, SEED, ch, it0=8 * X.N * k, replica=0, form="ea"), 8 * X.N)
+            out["cpu_one_core"] = {"value": v, "unit": "attempts/s", "kind": "port", "build": O.flavour,
+                                   "sample": "1 replica x %d x 8 sweeps (%.1f s), oracle" % (n, dt1)}
     return out
 
 
@@ -326,11 +407,10 @@ def secondary_c5(pkg, O, device):
     if O is not None:
         with pinned_core():
             ch = O.init_configs(SEED, 0, 1, X.N)[0]
-            it1 = 1 << 20
-            t0 = time.perf_counter()
-            O.rrr_mc_quant(X.X1.A, X.X1.J.astype(np.int32), M, X.fourK, beta, it1, step, SEED, ch)
-            out["cpu_one_core"] = {"value": it1 / (time.perf_counter() - t0), "unit": "iterations/s", "kind": "port",
-                                   "sample": "1 replica x 2^20 iterations, oracle"}
+            it1, Ji = 1 << 22, X.X1.J.astype(np.int32)
+            v, n, dt1 = timed_oracle(lambda k: O.rrr_mc_quant(X.X1.A, Ji, M, X.fourK, beta, it1, step, SEED, ch, it0=k * it1), it1)
+            out["cpu_one_core"] = {"value": v, "unit": "iterations/s", "kind": "port", "build": O.flavour,
+                                   "sample": "1 replica x %d x 2^22 iterations (%.1f s), oracle" % (n, dt1)}
     return out
 
 
@@ -357,11 +437,10 @@ def secondary_f64_fast(pkg, O, device):
     if O is not None:
         with pinned_core():
             ch = O.init_configs(SEED, 0, 1, N)[0]
-            it1 = 1 << 22
-            t0 = time.perf_counter()
-            O.standard_mc_spf(X.A, X.J, beta, it1, step, SEED, ch)
-            out["cpu_one_core"] = {"value": it1 / (time.perf_counter() - t0), "unit": "attempts/s", "kind": "port",
-                                   "sample": "1 replica x 2^22 iterations of the reference's cached-field loop, oracle"}
+            it1 = 1 << 24
+            v, n, dt1 = timed_oracle(lambda k: O.standard_mc_spf(X.A, X.J, beta, it1, step, SEED, ch, it0=k * it1), it1)
+            out["cpu_one_core"] = {"value": v, "unit": "attempts/s", "kind": "port", "build": O.flavour,
+                                   "sample": "1 replica x %d x 2^24 iterations of the reference's cached-field loop (%.1f s), oracle" % (n, dt1)}
     return out
 
 
@@ -388,10 +467,9 @@ def run_rank(args):
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus != world:
-        sys.stderr.write("bench.py: --gpus %d but WORLD_SIZE=%d: the job has %d rank(s) (one per GPU)\n" % (args.gpus, world, world))
-        if rank == 0 and args.gpus > world:
-            return 2
+    if args.gpus != world:       # every rank leaves (non-zero): nobody is left waiting at a barrier, and no line is printed under a wrong label
+        sys.stderr.write("bench.py: rank %d: --gpus %d but WORLD_SIZE=%d (one rank per GPU): refusing to run\n" % (rank, args.gpus, world))
+        return 2
     dist = None
     # RRRMC_BENCH_BACKEND=gloo is a debugging aid only: it lets several ranks share one GPU (RCCL refuses that) so that the
     # multi-rank code path can be exercised on a 1-GPU box; the driver's multi-GPU runs use the default, RCCL ("nccl").
@@ -439,6 +517,8 @@ def run_rank(args):
     for _ in range(args.warmup):
         eng.standard_mc_async(BETA, args.iters, SAMPLE_STEP)
     barrier()
+    verify = rank == 0 and not args.no_verify
+    C_start = eng.get_config().s.copy() if verify else None       # what the timed region starts from (outside it)
     eng.timing_accumulate(True)          # one HIP-event pair per sweep launch of the timed region, read after it (no sync inside)
     barrier()
     t0 = time.perf_counter()
@@ -461,6 +541,7 @@ def run_rank(args):
         dt = float(t.item())
 
     Es, acc = eng.fetch_results()
+    C_end = eng.get_config().s.copy() if verify else None
     acc_rate = float(acc.mean()) / args.iters
     e_mean = float(Es[:, -1].mean()) / N_SITES if Es.shape[1] else float("nan")
     if dist is not None:   # the only exchange of the job: gather the per-replica observables over RCCL
@@ -491,8 +572,12 @@ def run_rank(args):
             avg_ms = sweep_ms / launches
             achieved = bytes_per_attempt * per_launch_attempts / (avg_ms * 1e-3) / 1e9
             default_shape = R == REPLICAS_PER_GPU and args.iters == ITERS
-            tf = load_profile_json("traffic.json") if default_shape else None
-            vm = load_profile_json("valu_model.json") if default_shape else None
+            tf, tf_path, tf_state = load_profile_json("traffic.json") if default_shape else (None, None, None)
+            vm, vm_path, vm_state = load_profile_json("valu_model.json") if default_shape else (None, None, None)
+            if tf_state == "stale":
+                tf = None        # measured on other kernel sources: do not report it for this build
+            if vm_state == "stale":
+                vm = None
             roof = {
                 # The replica state never leaves LDS, so the kernel is bound by VALU issue, not by HBM: `achieved` / `frac` are the
                 # SURVEY.md §8d fixed-width ALGORITHMIC bytes over the kernel time (a throughput normalisation against the 8 TB/s
@@ -500,8 +585,10 @@ def run_rank(args):
                 "bound": "valu", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                 "achieved_is": "algorithmic bytes (SURVEY.md §8d: 1 + a(3+3K) per attempt) / kernel time — not measured traffic",
                 "traffic": tf["hbm_bytes_per_launch"] if tf else None,
-                "traffic_source": ("profiles/r02/traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE of this workload, committed; "
-                                   "not measured in this run)") if tf else None,
+                "traffic_source": ("%s (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE of this workload, committed; not measured in this run; "
+                                   "source stamp %s, commit %s)" % (tf_path, tf_state, tf.get("git_commit"))) if tf
+                                  else ("dropped: %s was measured on other kernel sources" % tf_path if tf_state == "stale" else None),
+                "kernel_source_stamp": source_stamp(), "git_head": git_head(),
                 "algorithmic_bytes_per_launch": bytes_per_attempt * per_launch_attempts,
                 "kernel": "sweep_kernel<3, 1>", "avg_launch_ms": avg_ms, "launches": int(launches),
                 "algorithmic_bytes_per_attempt": bytes_per_attempt}
@@ -513,7 +600,10 @@ def run_rank(args):
                                 "simds": vm["simds"], "clock_hz": vm["clock_hz"], "kernel_cycles": cyc,
                                 "achieved": vm["valu_insts_per_launch"] * vm["mean_issue_cycles"] / cyc, "peak": vm["simds"],
                                 "unit": "busy SIMDs", "frac": vm["valu_insts_per_launch"] * vm["mean_issue_cycles"] / (vm["simds"] * cyc),
-                                "source": "profiles/r02/valu_model.json (SQ_INSTS_VALU per launch, ISA histogram, ubench issue costs; committed)"}
+                                # the same count priced at the guide's 2 cycles per wave64 VALU instruction (MI355X_MICROARCH.md), whatever the opcode
+                                "frac_vs_guide_2cycle": vm["valu_insts_per_launch"] * 2.0 / (vm["simds"] * cyc),
+                                "source": "%s (SQ_INSTS_VALU per launch, ISA histogram, ubench issue costs; committed; source stamp %s, commit %s)"
+                                          % (vm_path, vm_state, vm.get("git_commit"))}
                 if vm.get("occupancy_factor_4_waves"):
                     # the kernel runs 4 waves per SIMD (16-wave workgroups, one per CU): the producer task measured in isolation issues
                     # 7 % slower there than at the 8 waves per SIMD the per-opcode costs were taken at (tools/ubench/producer_task.hip)
@@ -526,7 +616,22 @@ def run_rank(args):
                 roof["measured_copy_GBps"] = None
                 sys.stderr.write("device copy bandwidth not measured: %r\n" % (e,))
     eng.close()
+    rc = 0
     if rank == 0:
+        if not args.no_cpu_baseline or verify:
+            os.environ.setdefault("RRRMC_ORACLE_NATIVE", "1")        # the baseline build is -O3 -march=native, made on this host
+        if verify:
+            # the line checks what it timed: replicas {first, middle, last} of this rank's shard, the whole timed region, against the oracle
+            O = entry.load_oracle()
+            v = verify_timed_region(O, X, C_start, C_end, Es, acc, args.warmup * args.iters, args.steps, args.iters,
+                                    sorted({0, R // 2 - 1 if R > 1 else 0, R - 1}), r0)
+            out["verified"] = all(v["ok"])
+            out["verification"] = v
+            if not out["verified"]:
+                sys.stderr.write("bench.py: the timed run does NOT reproduce the oracle's chains: %r\n" % (v,))
+                rc = 3
+        else:
+            out["verified"] = None
         if world == 1 and not args.no_cpu_baseline:      # reported at N = 1 only (rank 0's host cores)
             O = entry.load_oracle()
             out["cpu_baseline"] = cpu_baseline(O, X)
@@ -537,7 +642,7 @@ def run_rank(args):
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
-    return 0
+    return rc
 
 
 def main():
@@ -549,6 +654,7 @@ def main():
     ap.add_argument("--replicas", type=int, default=REPLICAS_PER_GPU)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true")
+    ap.add_argument("--no-verify", action="store_true", help="skip the oracle replay of the timed region (3 replicas; ~10 s at the default size)")
     args = ap.parse_args()
     if args.gpus < 1:
         ap.error("--gpus must be >= 1")
