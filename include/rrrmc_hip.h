@@ -18,8 +18,9 @@
  *    spin value sigma = 2*bit - 1.  Unused high bits of the last chunk are zero.
  *  - neighbour tables are row-major N x K, 0-BASED int32 (the Julia glue subtracts 1 from
  *    reinterpret(Int64, X.A), src/graphs/RRG.jl:118-119); couplings are N x K int8 (+-1).
- *  - a ctx is bound to ONE device and is not re-entrant (the reference's graph objects are stateful
- *    too: src/graphs/RRG.jl:121); multi-GPU = one ctx per process/device with a replica offset.
+ *  - a ctx made by rrrmc_ctx_create is bound to ONE device; rrrmc_ctx_create_multi spreads the replicas of one ctx over several
+ *    (one stream and one host thread per device).  No ctx is re-entrant (the reference's graph objects are stateful too:
+ *    src/graphs/RRG.jl:121).  A multi-process job instead gives every process its own ctx with a replica offset.
  *  - random numbers: Philox4x32-10 streams addressed by (seed; iteration, replica) — see DESIGN.md
  *    "Random-stream contract"; results do not depend on how replicas are sharded over devices.
  */
@@ -81,6 +82,18 @@ RRRMC_API int32_t rrrmc_device_copy_bandwidth(int32_t device, int64_t nbytes, in
  */
 RRRMC_API int32_t rrrmc_ctx_create(rrrmc_ctx **out, int32_t model, int64_t N, int64_t K, int64_t R,
                                    int32_t device, uint32_t replica0);
+/*
+ * One context over SEVERAL devices (rrrmc_ctx_create(..., device_ids[], ndev)): what a reference user gets from one
+ * standardMC call in one process (src/RRRMC.jl:81-88).  The R replicas are sharded over device_ids[0..ndev-1] in whole 32-replica
+ * groups, in global-id order (a device may be named more than once: each entry gets its own shard and stream); replica ids address
+ * the random streams, so every result is the one a single-device context gives.  Every function of this header that takes a ctx
+ * accepts the multi-device context: per-replica buffers ([R], [R x nsamples], [R x chunks] ...) are the caller's full arrays and
+ * arrive gathered; enqueueing calls return when every device has its work queued, rrrmc_sync / fetch / energy calls run one host
+ * thread per device.  rrrmc_last_timing / rrrmc_timing_total report the slowest device.
+ *   model  any rrrmc_model; RRRMC_MODEL_QUANT_RRG takes (N = Nk, K, M) as rrrmc_ctx_create_quant does, M is ignored otherwise.
+ */
+RRRMC_API int32_t rrrmc_ctx_create_multi(rrrmc_ctx **out, int32_t model, int64_t N, int64_t K, int64_t M, int64_t R,
+                                         const int32_t *device_ids, int32_t ndev, uint32_t replica0);
 RRRMC_API void rrrmc_ctx_destroy(rrrmc_ctx *ctx);
 
 /* Disorder: A[N*K] 0-based neighbours, J[N*K] couplings in {-1,+1}; J[x*K+k] belongs to the bond

@@ -1,18 +1,21 @@
 # RRRMCHip.jl — Julia binding of the MI355X library (include/rrrmc_hip.h) behind RRRMC.jl's graph / sampler API.
 #
 # Drop next to src/RRRMC.jl (or `include` it from a session that has RRRMC loaded) and point RRRMC_HIP_LIB at
-# rrrmc.jl_amd/lib/librrrmc_hip.so.  Every ccall below is also exercised, with the same argument types, by the Python ctypes
-# binding rrrmc.jl_amd/_lib.py, which is what the parity tests drive; this file itself has never been executed (there is no Julia
-# in the build image) — julia/replay_tape.jl is the companion that checks the build's oracle against the reference on a machine
-# that has Julia.
+# rrrmc.jl_amd/lib/librrrmc_hip.so.  The file has never been executed (there is no Julia in the build image); what keeps it honest:
+#   * tests/test_julia_binding.py parses every `ccall` below and checks symbol, return type, argument count and argument types against
+#     include/rrrmc_hip.h (a signature drift on either side fails the CPU suite);
+#   * the same ABI is driven from C (tests/abi_smoke.c, compiled against the header) and from Python (rrrmc.jl_amd/_lib.py) on the GPU;
+#   * julia/replay_tape.jl checks the build's oracle against the reference itself on a machine that has Julia.
 #
-# One `Ctx` = one device (`device = k`); replicas of a multi-GPU job are sharded by global replica id (`replica0`), e.g. one Ctx per
-# device from one Julia task each (`Threads.@spawn`) or one process per GPU — the streams are addressed by (seed, global replica,
-# iteration), so the results do not depend on the sharding.
+# One `Ctx` = the R replicas of one graph, on one device (`device = k`) or sharded over several from this one process
+# (`devices = [0, 1, ...]` -> rrrmc_ctx_create_multi: the library runs one stream and one host thread per device and hands back
+# gathered results).  The random streams are addressed by (seed, global replica id, iteration): results never depend on the sharding.
+# Every sampler method takes the Ctx first, then the reference's own arguments and keywords (src/RRRMC.jl:81-88,149,221,311,376,474),
+# and returns per-replica results: `Es` is samples × R (column r = the vector the reference returns for one chain), `Cs::Vector{Config}`.
 module RRRMCHip
 using RRRMC
 const LIB = get(ENV, "RRRMC_HIP_LIB", "librrrmc_hip.so")
-const DEFAULT_SEED = 167432777111
+const DEFAULT_SEED = 167432777111                                  # the reference's default, src/RRRMC.jl:82
 
 check(rc, ctx = C_NULL) = rc == 0 ? nothing :
     (msg = unsafe_string(ccall((:rrrmc_last_error, LIB), Cstring, (Ptr{Cvoid},), ctx));
@@ -21,32 +24,151 @@ check(rc, ctx = C_NULL) = rc == 0 ? nothing :
 mutable struct Ctx
     p::Ptr{Cvoid}
     R::Int
-    function Ctx(p::Ptr{Cvoid}, R::Integer)
-        ctx = new(p, R)
+    N::Int
+    f64::Bool            # energies are Float64 (everything but the integer-coupling sparse graphs)
+    function Ctx(p::Ptr{Cvoid}, R::Integer, N::Integer, f64::Bool)
+        ctx = new(p, R, N, f64)
         finalizer(c -> (c.p == C_NULL || ccall((:rrrmc_ctx_destroy, LIB), Cvoid, (Ptr{Cvoid},), c.p); c.p = C_NULL), ctx)
         return ctx
     end
 end
 
 device_count() = Int(ccall((:rrrmc_device_count, LIB), Int32, ()))
+version() = Int(ccall((:rrrmc_version, LIB), Int32, ()))
 
-# ---- GraphRRG / GraphEA with +-1 couplings (model 1) -------------------------------------------------------------------------
-# X.A / X.J are Vector{NTuple{K,Int}} stored inline (src/graphs/RRG.jl:118-119, EA.jl:141-142): flat N*K row-major, 1-based
-function Ctx(X::Union{RRRMC.RRG.GraphRRG{Int,(-1,1),K}, RRRMC.EA.GraphEA{Int,(-1,1),K}}, R::Integer;
-             device = 0, replica0 = 0) where {K}
-    N = RRRMC.getN(X)
-    A = Int32.(reinterpret(Int, X.A) .- 1)
-    J = Int8.(reinterpret(Int, X.J))
+# model kinds of include/rrrmc_hip.h
+const SPARSE_PM1, SK_NORMAL, QUANT_RRG, SK_BINARY, SPARSE_F64, SPARSE_DISCRETIZED, SPARSE_LEVELS = 1, 2, 3, 4, 5, 6, 7
+
+# rrrmc_ctx_create / rrrmc_ctx_create_quant on one device, rrrmc_ctx_create_multi on several (N = Nk for a GraphQuant)
+function create(model::Integer, N::Integer, K::Integer, M::Integer, R::Integer; device = 0, replica0 = 0, devices = nothing)
     ref = Ref{Ptr{Cvoid}}(C_NULL)
-    check(ccall((:rrrmc_ctx_create, LIB), Int32, (Ref{Ptr{Cvoid}}, Int32, Int64, Int64, Int64, Int32, UInt32),
-                ref, 1, N, K, R, device, replica0))
-    ctx = Ctx(ref[], R)
+    if devices !== nothing
+        ids = Int32.(collect(devices))
+        GC.@preserve ids check(ccall((:rrrmc_ctx_create_multi, LIB), Int32,
+                                     (Ref{Ptr{Cvoid}}, Int32, Int64, Int64, Int64, Int64, Ptr{Int32}, Int32, UInt32),
+                                     ref, model, N, K, M, R, ids, length(ids), replica0))
+    elseif model == QUANT_RRG
+        check(ccall((:rrrmc_ctx_create_quant, LIB), Int32, (Ref{Ptr{Cvoid}}, Int64, Int64, Int64, Int64, Int32, UInt32),
+                    ref, N, K, M, R, device, replica0))
+    else
+        check(ccall((:rrrmc_ctx_create, LIB), Int32, (Ref{Ptr{Cvoid}}, Int32, Int64, Int64, Int64, Int32, UInt32),
+                    ref, model, N, K, R, device, replica0))
+    end
+    return ref[]
+end
+
+# X.A / X.J are Vector{NTuple{K,T}} stored inline (src/graphs/RRG.jl:118-119, EA.jl:141-142): flat N*K row-major, neighbours 1-based
+flatA(X) = Int32.(reinterpret(Int, X.A) .- 1)
+const PM1Graph{K} = Union{RRRMC.RRG.GraphRRG{Int,(-1,1),K}, RRRMC.EA.GraphEA{Int,(-1,1),K}}
+const LevGraph{ET,LEV,K} = Union{RRRMC.RRG.GraphRRG{ET,LEV,K}, RRRMC.EA.GraphEA{ET,LEV,K}}
+const F64Graph{K} = Union{RRRMC.RRG.GraphRRGNormal{K}, RRRMC.EA.GraphEANormal{K}}
+const DiscGraph{ET,LEV,K} = Union{RRRMC.RRG.GraphRRGNormalDiscretized{ET,LEV,K}, RRRMC.EA.GraphEANormalDiscretized{ET,LEV,K}}
+is_ea(X) = X isa RRRMC.EA.GraphEA || X isa RRRMC.EA.GraphEANormal || X isa RRRMC.EA.GraphEANormalDiscretized
+
+# ---- GraphRRG / GraphEA with +-1 couplings (model 1: the bit-sliced kernels, BASELINE configs 1, 2, 4) --------------------------------
+function Ctx(X::PM1Graph{K}, R::Integer; kw...) where {K}
+    N = RRRMC.getN(X)
+    ctx = Ctx(create(SPARSE_PM1, N, K, 0, R; kw...), R, N, false)
+    A = flatA(X); J = Int8.(reinterpret(Int, X.J))
     GC.@preserve A J check(ccall((:rrrmc_set_graph, LIB), Int32, (Ptr{Cvoid}, Ptr{Int32}, Ptr{Int8}), ctx.p, A, J), ctx.p)
     return ctx
 end
 
-function set_configs!(ctx::Ctx, N::Integer, C0::Union{Vector{RRRMC.Config},Nothing})
-    nch = (N + 63) >> 6
+# ---- GraphRRG{ET,LEV,K} / GraphEA{ET,LEV,2D} with other levels (model 7): integer level units + their scale -------------------------
+# Int levels: units = levels, scale (1, 1.0); DFloat64 (src/DFloats.jl: the Int64 payload t = round(x 10^5)): units = t ÷ g, scale (g, 1e5)
+level_units(::Type{Int}, LEV) = (collect(Int, LEV), 1, 1.0)
+function level_units(::Type{RRRMC.DFloats.DFloat64}, LEV)
+    t = [reinterpret(Int64, l) for l in LEV]; g = max(1, gcd(t))
+    return t .÷ g, g, 1e5
+end
+function Ctx(X::LevGraph{ET,LEV,K}, R::Integer; kw...) where {ET,LEV,K}
+    N = RRRMC.getN(X)
+    units, g, dv = level_units(ET, LEV)
+    ctx = Ctx(create(SPARSE_LEVELS, N, K, 0, R; kw...), R, N, false)
+    A = flatA(X); lev = Int32.(units)
+    J = Int8.(ET === Int ? reinterpret(Int, X.J) : reinterpret(Int64, X.J) .÷ g)
+    GC.@preserve A J lev check(ccall((:rrrmc_set_graph_levels, LIB), Int32, (Ptr{Cvoid}, Ptr{Int32}, Ptr{Int8}, Ptr{Int32}, Int32, Int32),
+                                     ctx.p, A, J, lev, length(lev), is_ea(X) ? 1 : 0), ctx.p)
+    check(ccall((:rrrmc_set_level_scale, LIB), Int32, (Ptr{Cvoid}, Int64, Float64), ctx.p, g, dv), ctx.p)
+    return ctx
+end
+
+# ---- GraphRRGNormal / GraphEANormal (model 5: sparse, Float64 couplings; src/graphs/RRG.jl:503-520, EA.jl:534-552) -------------------
+function Ctx(X::F64Graph{K}, R::Integer; kw...) where {K}
+    N = RRRMC.getN(X)
+    ctx = Ctx(create(SPARSE_F64, N, K, 0, R; kw...), R, N, true)
+    A = flatA(X); J = collect(reinterpret(Float64, X.J))
+    GC.@preserve A J check(ccall((:rrrmc_set_graph_f64, LIB), Int32, (Ptr{Cvoid}, Ptr{Int32}, Ptr{Float64}), ctx.p, A, J), ctx.p)
+    return ctx
+end
+
+# ---- GraphRRGNormalDiscretized / GraphEANormalDiscretized (model 6: DoubleGraph, src/graphs/RRG.jl:285-307, EA.jl:311-352) -----------
+function Ctx(X::DiscGraph{ET,LEV,K}, R::Integer; kw...) where {ET,LEV,K}
+    N = RRRMC.getN(X)
+    units, g, dv = level_units(ET, LEV)
+    ctx = Ctx(create(SPARSE_DISCRETIZED, N, K, 0, R; kw...), R, N, true)
+    A = flatA(X); lev = Int32.(units); rJ = collect(reinterpret(Float64, X.rJ))
+    dJ = Int8.(ET === Int ? reinterpret(Int, X.X0.J) : reinterpret(Int64, X.X0.J) .÷ g)
+    GC.@preserve A dJ rJ lev check(ccall((:rrrmc_set_graph_discretized, LIB), Int32,
+                                         (Ptr{Cvoid}, Ptr{Int32}, Ptr{Int8}, Ptr{Float64}, Ptr{Int32}, Int32, Int32),
+                                         ctx.p, A, dJ, rJ, lev, length(lev), is_ea(X) ? 1 : 0), ctx.p)
+    check(ccall((:rrrmc_set_level_scale, LIB), Int32, (Ptr{Cvoid}, Int64, Float64), ctx.p, g, dv), ctx.p)
+    return ctx
+end
+
+# ---- GraphSKNormal (model 2, BASELINE config 3) and the binary GraphSK (model 4) -----------------------------------------------------
+# X.J::Vector{Vector{Float64}} (src/graphs/SK.jl:183) packs to the N×N row-major matrix the library takes
+function Ctx(X::RRRMC.SK.GraphSKNormal, R::Integer; kw...)
+    N = RRRMC.getN(X)
+    ctx = Ctx(create(SK_NORMAL, N, 0, 0, R; kw...), R, N, true)
+    Jm = Matrix{Float64}(undef, N, N); for i = 1:N; Jm[:, i] = X.J[i]; end             # column i of a Julia matrix = row i in C order
+    GC.@preserve Jm check(ccall((:rrrmc_set_couplings_dense, LIB), Int32, (Ptr{Cvoid}, Ptr{Float64}), ctx.p, Jm), ctx.p)
+    return ctx
+end
+# X.J::Vector{BitVector} (SK.jl:31): row i = X.J[i].chunks
+sk_bits(J::Vector{BitVector}) = (Jc = Matrix{UInt64}(undef, length(J[1].chunks), length(J)); for i = 1:length(J); Jc[:, i] = J[i].chunks; end; Jc)
+function Ctx(X::RRRMC.SK.GraphSK, R::Integer; kw...)
+    N = RRRMC.getN(X)
+    ctx = Ctx(create(SK_BINARY, N, 0, 0, R; kw...), R, N, true)
+    Jc = sk_bits(X.J)
+    GC.@preserve Jc check(ccall((:rrrmc_set_couplings_bits, LIB), Int32, (Ptr{Cvoid}, Ptr{UInt64}), ctx.p, Jc), ctx.p)
+    return ctx
+end
+
+# ---- GraphQuant (BASELINE config 5): M Trotter slices of one slice graph (src/graphs/QT.jl:126-170, src/QAliases.jl) -----------------
+# spins are slice-major, so C.s.chunks passes as is.  β is the one the graph's fourK was derived from (QT.jl:165); Γ is only needed
+# by the observables.
+function Ctx(X::RRRMC.QT.GraphQuant{fourK,G}, R::Integer, β::Real; device = 0, replica0 = 0, devices = nothing) where {fourK,G}
+    X1 = X.X1[1]; Nk = X.Nk; M = X.M
+    ref = Ref{Ptr{Cvoid}}(C_NULL)
+    if G <: RRRMC.SK.GraphSK
+        devices === nothing || throw(ArgumentError("a GraphQuant over dense slices has no multi-device context"))
+        check(ccall((:rrrmc_ctx_create_quant_sk, LIB), Int32, (Ref{Ptr{Cvoid}}, Int64, Int64, Int64, Int32, UInt32), ref, Nk, M, R, device, replica0))
+        ctx = Ctx(ref[], R, Nk * M, true)
+        Jc = sk_bits(X1.J)
+        GC.@preserve Jc check(ccall((:rrrmc_set_couplings_bits, LIB), Int32, (Ptr{Cvoid}, Ptr{UInt64}), ctx.p, Jc), ctx.p)
+    elseif G <: RRRMC.SK.GraphSKNormal
+        devices === nothing || throw(ArgumentError("a GraphQuant over dense slices has no multi-device context"))
+        check(ccall((:rrrmc_ctx_create_quant_skn, LIB), Int32, (Ref{Ptr{Cvoid}}, Int64, Int64, Int64, Int32, UInt32), ref, Nk, M, R, device, replica0))
+        ctx = Ctx(ref[], R, Nk * M, true)
+        Jm = Matrix{Float64}(undef, Nk, Nk); for i = 1:Nk; Jm[:, i] = X1.J[i]; end
+        GC.@preserve Jm check(ccall((:rrrmc_set_couplings_dense, LIB), Int32, (Ptr{Cvoid}, Ptr{Float64}), ctx.p, Jm), ctx.p)
+    else
+        K = length(X1.A[1])
+        ctx = Ctx(create(QUANT_RRG, Nk, K, M, R; device = device, replica0 = replica0, devices = devices), R, Nk * M, true)
+        check(ccall((:rrrmc_quant_slice_form, LIB), Int32, (Ptr{Cvoid}, Int32), ctx.p, is_ea(X1) ? 1 : 0), ctx.p)
+        A = flatA(X1); J = Int8.(reinterpret(Int, X1.J))
+        GC.@preserve A J check(ccall((:rrrmc_set_graph, LIB), Int32, (Ptr{Cvoid}, Ptr{Int32}, Ptr{Int8}), ctx.p, A, J), ctx.p)
+    end
+    check(ccall((:rrrmc_quant_set_field, LIB), Int32, (Ptr{Cvoid}, Float64, Float64), ctx.p, β, fourK), ctx.p)
+    return ctx
+end
+
+# ---- configurations ------------------------------------------------------------------------------------------------------------------
+seed!(ctx::Ctx, seed) = seed > 0 && check(ccall((:rrrmc_seed, LIB), Int32, (Ptr{Cvoid}, UInt64), ctx.p, seed), ctx.p)   # seed ≤ 0: keep going (RRRMC.jl:89)
+
+function set_configs!(ctx::Ctx, C0::Union{Vector{RRRMC.Config},Nothing})
+    N = ctx.N; nch = (N + 63) >> 6
     chunks = Matrix{UInt64}(undef, nch, ctx.R)                   # column r = C.s.chunks of replica r
     if C0 ≡ nothing
         check(ccall((:rrrmc_init_spins_random, LIB), Int32, (Ptr{Cvoid},), ctx.p), ctx.p)
@@ -54,133 +176,242 @@ function set_configs!(ctx::Ctx, N::Integer, C0::Union{Vector{RRRMC.Config},Nothi
         all(c -> c.N == N, C0) || throw(ArgumentError("Invalid C0, wrong N, expected $N"))     # src/RRRMC.jl:94
         length(C0) == ctx.R || throw(ArgumentError("Invalid C0, expected $(ctx.R) configurations"))
         for r = 1:ctx.R; chunks[:, r] = C0[r].s.chunks; end
-        check(ccall((:rrrmc_set_spins, LIB), Int32, (Ptr{Cvoid}, Ptr{UInt64}), ctx.p, chunks), ctx.p)
+        GC.@preserve chunks check(ccall((:rrrmc_set_spins, LIB), Int32, (Ptr{Cvoid}, Ptr{UInt64}), ctx.p, chunks), ctx.p)
     end
     return chunks
 end
 
-function get_configs!(ctx::Ctx, N::Integer, chunks::Matrix{UInt64}, C0)
-    check(ccall((:rrrmc_get_spins, LIB), Int32, (Ptr{Cvoid}, Ptr{UInt64}), ctx.p, chunks), ctx.p)
-    Cs = C0 ≡ nothing ? [RRRMC.Config(N, init = false) for _ = 1:ctx.R] : C0      # C0 is mutated in place (src/RRRMC.jl:93)
+function get_configs!(ctx::Ctx, chunks::Matrix{UInt64}, C0)
+    GC.@preserve chunks check(ccall((:rrrmc_get_spins, LIB), Int32, (Ptr{Cvoid}, Ptr{UInt64}), ctx.p, chunks), ctx.p)
+    Cs = C0 ≡ nothing ? [RRRMC.Config(ctx.N, init = false) for _ = 1:ctx.R] : C0      # C0 is mutated in place (src/RRRMC.jl:93)
     for r = 1:ctx.R; Cs[r].s.chunks .= chunks[:, r]; end
     return Cs
 end
 
-"""
-    standardMC(ctx, X, β, iters; seed, step, C0, quiet) -> (Es::Matrix{Int} samples×R, Cs::Vector{Config})
-
-`standardMC` (src/RRRMC.jl:81-127) for `ctx.R` replicas of `X` on the GPU; column `r` of `Es` is replica `r`'s vector.
-`seed ≤ 0` keeps the streams going, as the reference keeps the global RNG (:89).
-"""
-function RRRMC.standardMC(ctx::Ctx, X::RRRMC.Interface.DiscrGraph{Int}, β::Real, iters::Integer; seed = DEFAULT_SEED, step::Integer = 1,
-                          C0::Union{Vector{RRRMC.Config},Nothing} = nothing, quiet = false)
-    N = RRRMC.getN(X)
-    seed > 0 && check(ccall((:rrrmc_seed, LIB), Int32, (Ptr{Cvoid}, UInt64), ctx.p, seed), ctx.p)
-    chunks = set_configs!(ctx, N, C0)
-    Es = Matrix{Int}(undef, iters ÷ step, ctx.R)
-    acc = Vector{Int}(undef, ctx.R)
-    check(ccall((:rrrmc_standard_mc, LIB), Int32, (Ptr{Cvoid}, Float64, Int64, Int64, Ptr{Int64}, Ptr{Int64}),
-                ctx.p, β, iters, step, Es, acc), ctx.p)
-    Cs = get_configs!(ctx, N, chunks, C0)
-    quiet || println("samples = ", size(Es, 1), "\niters = ", iters, "\naccept rate = ", sum(acc) / (iters * ctx.R))
-    return Es, Cs
-end
-
-"""
-    standardMC_hooked(ctx, X, β, iters; step, hook, ...) — the reference's `hook(it, X, C, accepted, E)` (src/RRRMC.jl:61-64), called
-every `step` iterations with the vectors of all replicas.  Integer models: the library is re-entered per segment (`seed = 0` keeps
-the streams going; the recomputed energy equals the tracked one exactly).
-"""
-function standardMC_hooked(ctx::Ctx, X, β::Real, iters::Integer; seed = DEFAULT_SEED, step::Integer = 1, hook = (x...) -> true,
-                           C0::Union{Vector{RRRMC.Config},Nothing} = nothing)
-    N = RRRMC.getN(X)
-    seed > 0 && check(ccall((:rrrmc_seed, LIB), Int32, (Ptr{Cvoid}, UInt64), ctx.p, seed), ctx.p)
-    chunks = set_configs!(ctx, N, C0)
-    Es = Vector{Vector{Int}}()
-    accepted = zeros(Int, ctx.R); acc = similar(accepted); E = similar(accepted)
-    it = 0
-    run!(n) = n > 0 && (check(ccall((:rrrmc_standard_mc, LIB), Int32, (Ptr{Cvoid}, Float64, Int64, Int64, Ptr{Int64}, Ptr{Int64}),
-                                    ctx.p, β, n, n + 1, C_NULL, acc), ctx.p); accepted .+= acc)
-    Cs = nothing
-    while it < iters
-        nxt = (it ÷ step + 1) * step
-        run!(min(nxt - 1, iters) - it); it = min(nxt - 1, iters)
-        nxt > iters && break
-        check(ccall((:rrrmc_energy, LIB), Int32, (Ptr{Cvoid}, Ptr{Int64}), ctx.p, E), ctx.p)
-        push!(Es, copy(E))
-        Cs = get_configs!(ctx, N, chunks, C0)
-        hook(nxt, X, Cs, copy(accepted), E) || (it = nxt; break)
-        run!(1); it = nxt
+"energy(X, C) of every replica (src/Interface.jl:105); also rebuilds the device-side caches, as the reference's `energy` does"
+function energies(ctx::Ctx)
+    if ctx.f64
+        E = Vector{Float64}(undef, ctx.R)
+        check(ccall((:rrrmc_energy_f64, LIB), Int32, (Ptr{Cvoid}, Ptr{Float64}), ctx.p, E), ctx.p)
+        return E
     end
-    return Es, get_configs!(ctx, N, chunks, C0)
+    E = Vector{Int}(undef, ctx.R)
+    check(ccall((:rrrmc_energy, LIB), Int32, (Ptr{Cvoid}, Ptr{Int64}), ctx.p, E), ctx.p)
+    return E
 end
 
-# ---- GraphQuant over GraphRRG / GraphEA slices (config 5) ------------------------------------------------------------------------
-# X.X1[k] are M copies of one slice graph (src/graphs/QT.jl:139-170); spins are slice-major, so C.s.chunks passes as is
-function QuantCtx(X::RRRMC.QT.GraphQuant, R::Integer; device = 0, replica0 = 0)
-    X1 = X.X1[1]; Nk = RRRMC.getN(X1); M = length(X.X1); K = length(X1.A[1])
-    ref = Ref{Ptr{Cvoid}}(C_NULL)
-    check(ccall((:rrrmc_ctx_create_quant, LIB), Int32, (Ref{Ptr{Cvoid}}, Int64, Int64, Int64, Int64, Int32, UInt32),
-                ref, Nk, K, M, R, device, replica0))
-    ctx = Ctx(ref[], R)
-    A = Int32.(reinterpret(Int, X1.A) .- 1); J = Int8.(reinterpret(Int, X1.J))
-    GC.@preserve A J check(ccall((:rrrmc_set_graph, LIB), Int32, (Ptr{Cvoid}, Ptr{Int32}, Ptr{Int8}), ctx.p, A, J), ctx.p)
-    return ctx
+sync(ctx::Ctx) = check(ccall((:rrrmc_sync, LIB), Int32, (Ptr{Cvoid},), ctx.p), ctx.p)
+
+# results of the last sampling call: Es (samples × R, the graph's ET), accepted (R)
+function fetch(ctx::Ctx, nsamples::Integer)
+    acc = Vector{Int}(undef, ctx.R)
+    if ctx.f64
+        Es = Matrix{Float64}(undef, nsamples, ctx.R)
+        check(ccall((:rrrmc_fetch_results_f64, LIB), Int32, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Int64}), ctx.p, Es, acc), ctx.p)
+        return Es, acc
+    end
+    Es = Matrix{Int}(undef, nsamples, ctx.R)
+    check(ccall((:rrrmc_fetch_results, LIB), Int32, (Ptr{Cvoid}, Ptr{Int64}, Ptr{Int64}), ctx.p, Es, acc), ctx.p)
+    return Es, acc
 end
 
+# ---- standardMC (src/RRRMC.jl:81-127) -------------------------------------------------------------------------------------------------
 """
-    rrrMC(ctx, X::GraphQuant{fourK}, β, iters; seed, step, C0, staged_thr, staged_thr_fact)
-        -> (Es::Matrix{Float64} samples×R, Cs, accepted, staged iterations)
+    standardMC(ctx, X, β, iters; seed, step, hook, C0, quiet) -> (Es::Matrix{ET} samples×R, Cs::Vector{Config})
 
-`rrrMC(X::DoubleGraph, ...)` (src/RRRMC.jl:221-290) for `ctx.R` replicas.
+For `ctx.R` replicas of `X` on the GPU(s); `seed ≤ 0` keeps the streams going, as the reference keeps the global RNG (:89).
+With a `hook(it, X, Cs, accepted, E)::Bool` (the reference's hook, :61-64, handed the vectors of all replicas) the run is cut at the
+hook points and RESUMED (`rrrmc_set_resume`): cache and tracked energy live on across the pieces exactly as inside one reference
+call (:95-118), so a hooked run is the un-hooked chain bit for bit — for the Float64 models too — and `E` is the tracked energy.
 """
-function RRRMC.rrrMC(ctx::Ctx, X::RRRMC.QT.GraphQuant{fourK}, β::Real, iters::Integer; seed = DEFAULT_SEED, step::Integer = 1,
-                     C0::Union{Vector{RRRMC.Config},Nothing} = nothing, staged_thr::Real = 0.5, staged_thr_fact::Real = 5.0) where {fourK}
+function RRRMC.standardMC(ctx::Ctx, X::RRRMC.Interface.AbstractGraph, β::Real, iters::Integer; seed = DEFAULT_SEED, step::Integer = 1,
+                          hook = nothing, C0::Union{Vector{RRRMC.Config},Nothing} = nothing, quiet = false)
+    seed!(ctx, seed)
+    chunks = set_configs!(ctx, C0)
+    if hook ≡ nothing
+        check(ccall((:rrrmc_standard_mc_async, LIB), Int32, (Ptr{Cvoid}, Float64, Int64, Int64), ctx.p, β, iters, step), ctx.p)
+        sync(ctx)
+        Es, acc = fetch(ctx, iters ÷ step)
+        Cs = get_configs!(ctx, chunks, C0)
+        quiet || println("samples = ", size(Es, 1), "\niters = ", iters, "\naccept rate = ", sum(acc) / (iters * ctx.R))
+        return Es, Cs
+    end
+    ET = ctx.f64 ? Float64 : Int
+    Es = Vector{Vector{ET}}(); accepted = zeros(Int, ctx.R); it = 0
+    # a piece of n iterations that samples nothing (step n + 1): only the accepted counts are fetched
+    piece!(n) = n > 0 && (check(ccall((:rrrmc_standard_mc_async, LIB), Int32, (Ptr{Cvoid}, Float64, Int64, Int64), ctx.p, β, n, n + 1), ctx.p);
+                          sync(ctx); accepted .+= fetch(ctx, 0)[2])
+    if ctx.f64 && iters > 0          # a call of zero iterations = the start of a reference call: E = energy(X, C), fresh cache (:95)
+        check(ccall((:rrrmc_standard_mc_async, LIB), Int32, (Ptr{Cvoid}, Float64, Int64, Int64), ctx.p, β, 0, 1), ctx.p); sync(ctx)
+    end
+    check(ccall((:rrrmc_set_resume, LIB), Int32, (Ptr{Cvoid}, Int32), ctx.p, 1), ctx.p)
+    try
+        while it < iters
+            nxt = (it ÷ step + 1) * step
+            piece!(min(nxt - 1, iters) - it); it = min(nxt - 1, iters)      # up to just before the sampled iteration
+            nxt > iters && break
+            E = Vector{ET}(undef, ctx.R)                                    # the energy BEFORE the move of iteration nxt (:104-108)
+            if ctx.f64                                                      # what the reference hands to its hook: the tracked E
+                check(ccall((:rrrmc_tracked_energy_f64, LIB), Int32, (Ptr{Cvoid}, Ptr{Float64}), ctx.p, E), ctx.p)
+            else
+                E .= energies(ctx)                                          # integer models: recomputed == tracked, exactly
+            end
+            push!(Es, E)
+            hook(nxt, X, get_configs!(ctx, chunks, C0), copy(accepted), E) || (it = nxt; break)
+            piece!(1); it = nxt
+        end
+    finally
+        check(ccall((:rrrmc_set_resume, LIB), Int32, (Ptr{Cvoid}, Int32), ctx.p, 0), ctx.p)
+    end
+    return isempty(Es) ? Matrix{ET}(undef, 0, ctx.R) : permutedims(reduce(hcat, Es)), get_configs!(ctx, chunks, C0)
+end
+
+# ---- colour-parallel sweeps (build-defined sampler for large lattices: BASELINE config 4) ---------------------------------------------
+"color[x] ∈ 0:ncolors-1, adjacent sites differ (checked by the library); e.g. the checkerboard parity of an even-L lattice"
+set_coloring!(ctx::Ctx, color::Vector{Int32}, ncolors::Integer) =
+    GC.@preserve color check(ccall((:rrrmc_set_coloring, LIB), Int32, (Ptr{Cvoid}, Ptr{Int32}, Int32), ctx.p, color, ncolors), ctx.p)
+count_accepted!(ctx::Ctx, on::Bool) = check(ccall((:rrrmc_colored_count_accepted, LIB), Int32, (Ptr{Cvoid}, Int32), ctx.p, on ? 1 : 0), ctx.p)
+"`sweeps` sweeps over the colouring (one sweep attempts every site once); an energy sample BEFORE sweep k*step -> (Es, Cs)"
+function colored_sweeps(ctx::Ctx, β::Real, sweeps::Integer; seed = DEFAULT_SEED, step::Integer = 1, C0 = nothing)
+    seed!(ctx, seed)
+    chunks = set_configs!(ctx, C0)
+    check(ccall((:rrrmc_colored_sweeps_async, LIB), Int32, (Ptr{Cvoid}, Float64, Int64, Int64), ctx.p, β, sweeps, step), ctx.p)
+    sync(ctx)
+    Es, _ = fetch(ctx, sweeps ÷ step)
+    return Es, get_configs!(ctx, chunks, C0)
+end
+function checkerboard(L::Integer, D::Integer)             # parity of the lattice coordinates, in gen_EA's column-major site order (EA.jl:24-43)
+    iseven(L) || throw(ArgumentError("the checkerboard needs an even L"))
+    return Int32[sum(Tuple(I)) % 2 for I in CartesianIndices(ntuple(_ -> L, D))][:]
+end
+
+# ---- rrrMC (src/RRRMC.jl:149-219 SingleGraph, :221-290 DoubleGraph) -------------------------------------------------------------------
+"""
+    rrrMC(ctx, X, β, iters; seed, step, C0, staged_thr, staged_thr_fact, quiet) -> (Es, Cs, accepted, staged)
+
+Serves `rrrMC(X::SingleGraph)` — GraphRRG / GraphEA (DeltaECache{Int,L}), GraphRRGNormal / GraphEANormal / GraphSKNormal / GraphSK
+(DeltaECacheCont + DynamicSampler) — and `rrrMC(X::DoubleGraph)` — GraphQuant (its fourK is the type parameter, QT.jl:126,165) and the
+discretised graphs.  `staged_thr` defaults as the reference's: 0.5 for a DoubleGraph (:224), 0.8 otherwise (:152).
+"""
+function RRRMC.rrrMC(ctx::Ctx, X::RRRMC.Interface.AbstractGraph, β::Real, iters::Integer; seed = DEFAULT_SEED, step::Integer = 1,
+                     C0::Union{Vector{RRRMC.Config},Nothing} = nothing,
+                     staged_thr::Real = X isa RRRMC.Interface.DoubleGraph ? 0.5 : 0.8, staged_thr_fact::Real = 5.0, quiet = false)
     isfinite(β) || throw(ArgumentError("β must be finite, given: $β"))
-    N = RRRMC.getN(X)
-    seed > 0 && check(ccall((:rrrmc_seed, LIB), Int32, (Ptr{Cvoid}, UInt64), ctx.p, seed), ctx.p)
-    chunks = set_configs!(ctx, N, C0)
+    fourK = X isa RRRMC.QT.GraphQuant ? typeof(X).parameters[1] : 0.0
+    seed!(ctx, seed)
+    chunks = set_configs!(ctx, C0)
     check(ccall((:rrrmc_rrr_mc_async, LIB), Int32, (Ptr{Cvoid}, Float64, Float64, Int64, Int64, Float64, Float64),
-                ctx.p, β, fourK, iters, step, staged_thr, staged_thr_fact), ctx.p)           # fourK: the type parameter, QT.jl:126,165
-    check(ccall((:rrrmc_sync, LIB), Int32, (Ptr{Cvoid},), ctx.p), ctx.p)
-    Es = Matrix{Float64}(undef, iters ÷ step, ctx.R); acc = Vector{Int}(undef, ctx.R); staged = similar(acc)
-    check(ccall((:rrrmc_fetch_results_f64, LIB), Int32, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Int64}), ctx.p, Es, acc), ctx.p)
+                ctx.p, β, fourK, iters, step, staged_thr, staged_thr_fact), ctx.p)
+    sync(ctx)
+    Es, acc = fetch(ctx, iters ÷ step)
+    staged = Vector{Int}(undef, ctx.R)
     check(ccall((:rrrmc_rrr_stats, LIB), Int32, (Ptr{Cvoid}, Ptr{Int64}), ctx.p, staged), ctx.p)
-    return Es, get_configs!(ctx, N, chunks, C0), acc, staged
+    quiet || println("samples = ", size(Es, 1), "\niters = ", iters, "\naccept rate = ", sum(acc) / (iters * ctx.R),
+                     "\nfrac. staged iters = ", sum(staged) / (iters * ctx.R))                     # RRRMC.jl:284-288
+    return Es, get_configs!(ctx, chunks, C0), acc, staged
 end
 
-# ---- GraphSKNormal (config 3) ------------------------------------------------------------------------------------------------------
-# X.J::Vector{Vector{Float64}} (src/graphs/SK.jl:183) packs to the N×N row-major matrix the library takes
-function SKCtx(X::RRRMC.SK.GraphSKNormal, R::Integer; device = 0, replica0 = 0)
-    N = RRRMC.getN(X); ref = Ref{Ptr{Cvoid}}(C_NULL)
-    check(ccall((:rrrmc_ctx_create, LIB), Int32, (Ref{Ptr{Cvoid}}, Int32, Int64, Int64, Int64, Int32, UInt32), ref, 2, N, 0, R, device, replica0))
-    ctx = Ctx(ref[], R)
-    Jm = Matrix{Float64}(undef, N, N); for i = 1:N; Jm[:, i] = X.J[i]; end                 # column i of a Julia matrix = row i in C order
-    check(ccall((:rrrmc_set_couplings_dense, LIB), Int32, (Ptr{Cvoid}, Ptr{Float64}), ctx.p, Jm), ctx.p)
-    return ctx
+# ---- bklMC (src/RRRMC.jl:311-359): `iters` counts the skipped rejections too; `moves` = the moves actually made ("true it") ------------
+function RRRMC.bklMC(ctx::Ctx, X::RRRMC.Interface.AbstractGraph, β::Real, iters::Integer; seed = DEFAULT_SEED, step::Integer = 1,
+                     C0::Union{Vector{RRRMC.Config},Nothing} = nothing, quiet = false)
+    seed!(ctx, seed)
+    chunks = set_configs!(ctx, C0)
+    check(ccall((:rrrmc_bkl_mc_async, LIB), Int32, (Ptr{Cvoid}, Float64, Int64, Int64), ctx.p, β, iters, step), ctx.p)
+    sync(ctx)
+    Es, _ = fetch(ctx, iters ÷ step)
+    moves = Vector{Int}(undef, ctx.R)
+    check(ccall((:rrrmc_rrr_stats, LIB), Int32, (Ptr{Cvoid}, Ptr{Int64}), ctx.p, moves), ctx.p)
+    quiet || println("samples = ", size(Es, 1), "\niters = ", iters, "\ntrue it = ", sum(moves) / ctx.R)
+    return Es, get_configs!(ctx, chunks, C0), moves
 end
 
-function RRRMC.standardMC(ctx::Ctx, X::RRRMC.SK.GraphSKNormal, β::Real, iters::Integer; seed = DEFAULT_SEED, step::Integer = 1,
-                          C0::Union{Vector{RRRMC.Config},Nothing} = nothing, quiet = false)
-    N = RRRMC.getN(X)
-    seed > 0 && check(ccall((:rrrmc_seed, LIB), Int32, (Ptr{Cvoid}, UInt64), ctx.p, seed), ctx.p)
-    chunks = set_configs!(ctx, N, C0)
-    Es = Matrix{Float64}(undef, iters ÷ step, ctx.R); acc = Vector{Int}(undef, ctx.R)
-    check(ccall((:rrrmc_standard_mc_f64, LIB), Int32, (Ptr{Cvoid}, Float64, Int64, Int64, Ptr{Float64}, Ptr{Int64}),
-                ctx.p, β, iters, step, Es, acc), ctx.p)
-    Cs = get_configs!(ctx, N, chunks, C0)
-    quiet || println("samples = ", size(Es, 1), "\niters = ", iters, "\naccept rate = ", sum(acc) / (iters * ctx.R))
-    return Es, Cs
+# ---- wtmMC (src/RRRMC.jl:376-426, src/WaitingTimes.jl): `step::Float64` in sweeps, `samples` energies at global times k*step/N ---------
+function RRRMC.wtmMC(ctx::Ctx, X::RRRMC.Interface.AbstractGraph, β::Real, samples::Integer; seed = DEFAULT_SEED, step::Float64 = 1.0,
+                     C0::Union{Vector{RRRMC.Config},Nothing} = nothing, quiet = false)
+    seed!(ctx, seed)
+    chunks = set_configs!(ctx, C0)
+    check(ccall((:rrrmc_wtm_mc_async, LIB), Int32, (Ptr{Cvoid}, Float64, Int64, Float64), ctx.p, β, samples, step), ctx.p)
+    sync(ctx)
+    Es, moves = fetch(ctx, samples)
+    t = Vector{Float64}(undef, ctx.R)
+    check(ccall((:rrrmc_wtm_times, LIB), Int32, (Ptr{Cvoid}, Ptr{Float64}), ctx.p, t), ctx.p)
+    quiet || println("samples = ", size(Es, 1), "\nnum. moves = ", sum(moves) / ctx.R, "\nglobal time = ", sum(t) / ctx.R)     # :419-423
+    return Es, get_configs!(ctx, chunks, C0), moves, t
 end
 
-# ---- device-side snapshots for the scripts' hooks (scripts/scripts.jl:51-69: copy(C.s) per sample, pm1dot / parseovs afterwards) ----
+# ---- extremal_opt (src/RRRMC.jl:474-521): EOCache{Int,L} on the DiscrGraphs, the generic EOCacheCont elsewhere -------------------------
+"-> (Cs, Emin, Cmin::Vector{Config}, itmin) per replica, the reference's return tuple (:520); `Es` (what the hook would see) as 5th value"
+function RRRMC.extremal_opt(ctx::Ctx, X::RRRMC.Interface.AbstractGraph, τ::Real, iters::Integer; seed = DEFAULT_SEED, step::Integer = 1,
+                            C0::Union{Vector{RRRMC.Config},Nothing} = nothing, quiet = false)
+    N = ctx.N; nch = (N + 63) >> 6
+    ftau = cumsum([j^(-τ) for j = 1:N])                                # as DeltaE.jl:444-445 computes it
+    seed!(ctx, seed)
+    chunks = set_configs!(ctx, C0)
+    GC.@preserve ftau check(ccall((:rrrmc_extremal_opt_async, LIB), Int32, (Ptr{Cvoid}, Ptr{Float64}, Int64, Int64), ctx.p, ftau, iters, step), ctx.p)
+    sync(ctx)
+    Es, _ = fetch(ctx, iters ÷ step)
+    cmin = Matrix{UInt64}(undef, nch, ctx.R); itmin = Vector{Int}(undef, ctx.R)
+    if ctx.f64
+        Emin = Vector{Float64}(undef, ctx.R)
+        check(ccall((:rrrmc_extremal_opt_results_f64, LIB), Int32, (Ptr{Cvoid}, Ptr{Float64}, Ptr{UInt64}, Ptr{Int64}), ctx.p, Emin, cmin, itmin), ctx.p)
+    else
+        Emin = Vector{Int}(undef, ctx.R)
+        check(ccall((:rrrmc_extremal_opt_results, LIB), Int32, (Ptr{Cvoid}, Ptr{Int64}, Ptr{UInt64}, Ptr{Int64}), ctx.p, Emin, cmin, itmin), ctx.p)
+    end
+    Cmin = [RRRMC.Config(N, init = false) for _ = 1:ctx.R]
+    for r = 1:ctx.R; Cmin[r].s.chunks .= cmin[:, r]; end
+    quiet || println("samples = ", size(Es, 1), "\niters = ", iters, "\nEmin = ", minimum(Emin))
+    return get_configs!(ctx, chunks, C0), Emin, Cmin, itmin, Es
+end
+
+# ---- GraphQuant observables of the live configuration (src/graphs/QT.jl:113-122, 213-268) ---------------------------------------------
+function quant_observables(ctx::Ctx, X::RRRMC.QT.GraphQuant, β::Real, Γ::Real)
+    Q = Vector{Float64}(undef, ctx.R); tm = similar(Q); ovs = Matrix{Float64}(undef, X.M ÷ 2, ctx.R)
+    check(ccall((:rrrmc_quant_observables, LIB), Int32, (Ptr{Cvoid}, Float64, Float64, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}),
+                ctx.p, β, Γ, Q, tm, ovs), ctx.p)
+    return Q, tm, ovs                                                   # Qenergy, transverse_mag, overlaps (column r = replica r)
+end
+
+# ---- device-side snapshots for the scripts' hooks (scripts/scripts.jl:51-69: copy(C.s) per sample, pm1dot / parseovs afterwards) -------
 snapshot_reserve(ctx::Ctx, n) = check(ccall((:rrrmc_snapshot_reserve, LIB), Int32, (Ptr{Cvoid}, Int32), ctx.p, n), ctx.p)
 snapshot_store(ctx::Ctx, slot) = check(ccall((:rrrmc_snapshot_store, LIB), Int32, (Ptr{Cvoid}, Int32), ctx.p, slot), ctx.p)
+function snapshot_get(ctx::Ctx, slot)                                    # a column of to_mat's BitMatrix per replica (:13-21)
+    chunks = Matrix{UInt64}(undef, (ctx.N + 63) >> 6, ctx.R)
+    check(ccall((:rrrmc_snapshot_get, LIB), Int32, (Ptr{Cvoid}, Int32, Ptr{UInt64}), ctx.p, slot, chunks), ctx.p)
+    return chunks
+end
 "q[r, p] = pm1dot(replica r of slot ia[p], replica r of slot ib[p]) (0-based slots, -1 = the live configuration)"
 function overlaps(ctx::Ctx, ia::Vector{Int32}, ib::Vector{Int32})
     q = Matrix{Int32}(undef, ctx.R, length(ia))
-    check(ccall((:rrrmc_overlaps, LIB), Int32, (Ptr{Cvoid}, Int64, Ptr{Int32}, Ptr{Int32}, Ptr{Int32}), ctx.p, length(ia), ia, ib, q), ctx.p)
+    GC.@preserve ia ib check(ccall((:rrrmc_overlaps, LIB), Int32, (Ptr{Cvoid}, Int64, Ptr{Int32}, Ptr{Int32}, Ptr{Int32}), ctx.p, length(ia), ia, ib, q), ctx.p)
     return q
+end
+
+# ---- cache views for parity checks against the reference's own objects ----------------------------------------------------------------
+"X.cache.lfields of every replica (N × R), recomputed from the current spins for the integer models (src/Common.jl:27-36)"
+function fields(ctx::Ctx, X)
+    if X isa RRRMC.SK.GraphSKNormal || X isa F64Graph
+        lf = Matrix{Float64}(undef, ctx.N, ctx.R)
+        check(ccall((:rrrmc_get_fields_f64, LIB), Int32, (Ptr{Cvoid}, Ptr{Float64}), ctx.p, lf), ctx.p)
+        return lf
+    end
+    lf = Matrix{Int}(undef, ctx.N, ctx.R)
+    check(ccall((:rrrmc_get_fields, LIB), Int32, (Ptr{Cvoid}, Ptr{Int64}), ctx.p, lf), ctx.p)
+    return lf
+end
+"DeltaECache.pos (N × R, 0-based class a + 2 up) and the class sizes after the last rrrMC call on a DoubleGraph (src/DeltaE.jl:63-73)"
+function rrr_cache(ctx::Ctx, X)
+    stride = X isa RRRMC.QT.GraphQuant ? 4 : 16
+    pos = Matrix{Int8}(undef, ctx.N, ctx.R); sizes = Matrix{Int32}(undef, stride, ctx.R)
+    check(ccall((:rrrmc_rrr_cache, LIB), Int32, (Ptr{Cvoid}, Ptr{Int8}, Ptr{Int32}), ctx.p, pos, sizes), ctx.p)
+    return pos, sizes
+end
+
+"kernel time of the last sampling call: (total ms, dominant-kernel ms, its launches); the slowest device of a multi-device Ctx"
+function last_timing(ctx::Ctx)
+    tot = Ref{Float64}(0.0); sw = Ref{Float64}(0.0); nl = Ref{Int32}(0)
+    check(ccall((:rrrmc_last_timing, LIB), Int32, (Ptr{Cvoid}, Ref{Float64}, Ref{Float64}, Ref{Int32}), ctx.p, tot, sw, nl), ctx.p)
+    return tot[], sw[], Int(nl[])
 end
 
 end # module

@@ -16,7 +16,7 @@ f64p = np.ctypeslib.ndpointer(np.float64, flags="C_CONTIGUOUS")
 
 # every symbol include/rrrmc_hip.h declares
 SYMBOLS = [
-    "rrrmc_version", "rrrmc_last_error", "rrrmc_device_count", "rrrmc_device_copy_bandwidth", "rrrmc_ctx_create", "rrrmc_ctx_destroy",
+    "rrrmc_version", "rrrmc_last_error", "rrrmc_device_count", "rrrmc_device_copy_bandwidth", "rrrmc_ctx_create", "rrrmc_ctx_create_multi", "rrrmc_ctx_destroy",
     "rrrmc_set_graph", "rrrmc_seed", "rrrmc_init_spins_random", "rrrmc_set_spins", "rrrmc_get_spins",
     "rrrmc_energy", "rrrmc_get_fields", "rrrmc_standard_mc", "rrrmc_standard_mc_async", "rrrmc_sync",
     "rrrmc_fetch_results", "rrrmc_last_timing", "rrrmc_timing_accumulate", "rrrmc_timing_total", "rrrmc_set_resume", "rrrmc_tracked_energy_f64", "rrrmc_standard_mc_fast_async", "rrrmc_iterations_done", "rrrmc_gen_rrg", "rrrmc_gen_ea",
@@ -62,6 +62,8 @@ def lib():
     L.rrrmc_device_copy_bandwidth.argtypes = [C.c_int32, C.c_int64, C.c_int32, C.POINTER(C.c_double)]
     L.rrrmc_ctx_create.restype = C.c_int32
     L.rrrmc_ctx_create.argtypes = [C.POINTER(vp), C.c_int32, C.c_int64, C.c_int64, C.c_int64, C.c_int32, C.c_uint32]
+    L.rrrmc_ctx_create_multi.restype = C.c_int32
+    L.rrrmc_ctx_create_multi.argtypes = [C.POINTER(vp), C.c_int32, C.c_int64, C.c_int64, C.c_int64, C.c_int64, i32p, C.c_int32, C.c_uint32]
     L.rrrmc_ctx_destroy.restype = None
     L.rrrmc_ctx_destroy.argtypes = [vp]
     L.rrrmc_set_graph.restype = C.c_int32

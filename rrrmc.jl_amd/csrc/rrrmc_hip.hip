@@ -12,6 +12,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <map>
 #include <mutex>
 #include <utility>
@@ -247,6 +248,11 @@ struct rrrmc_ctx {
     bool resume = false;                // the next standardMC calls continue from the tracked energy and the live cache
     bool std_cache_live = false;        // the model's cache (fields, undo record) and tracked energy describe the current configuration
     int32_t* db_mlast = nullptr;        // [R] move_last of the residual cache (RRRMC_MODEL_SPARSE_DISCRETIZED), kept across resumed calls
+
+    // ---- multi-device context (rrrmc_ctx_create_multi): no device state of its own; one child context per device (own stream), replica
+    //      shards of whole 32-replica groups in global-id order; every entry point forwards to the children ----
+    std::vector<rrrmc_ctx*> kids;
+    std::vector<int64_t> kid_r0;        // first replica of each child, relative to this context's first
 
     std::string err;
 };
@@ -530,6 +536,38 @@ int32_t quant_mc_async(rrrmc_ctx* ctx, bool standard, double beta, double fourK,
 
 }  // namespace
 
+namespace {
+// ---- multi-device contexts -------------------------------------------------------------------------------------------------
+inline bool is_multi(const rrrmc_ctx* c) { return c && !c->kids.empty(); }
+template <typename T> inline T* at_row(T* p, int64_t n) { return p ? p + n : nullptr; }
+inline int64_t nch_of(const rrrmc_ctx* c) { return (c->N + 63) / 64; }
+// f(child, first replica of the child, replicas of the child) on every child: one after the other for calls that only enqueue work on
+// the child's stream (the devices then run concurrently), one host thread per device for calls that wait or copy.  The first failure is
+// reported with the device it came from.
+template <typename F> int32_t multi_each(rrrmc_ctx* ctx, F&& f, bool threads)
+{
+    const size_t n = ctx->kids.size();
+    std::vector<int32_t> rc(n, RRRMC_OK);
+    if (threads && n > 1) {
+        std::vector<std::thread> th;
+        th.reserve(n);
+        for (size_t d = 0; d < n; ++d) th.emplace_back([&, d] { rc[d] = f(ctx->kids[d], ctx->kid_r0[d], ctx->kids[d]->R); });
+        for (std::thread& t : th) t.join();
+    } else {
+        for (size_t d = 0; d < n; ++d) { rc[d] = f(ctx->kids[d], ctx->kid_r0[d], ctx->kids[d]->R); if (rc[d]) break; }
+    }
+    for (size_t d = 0; d < n; ++d)
+        if (rc[d]) { ctx->err = "device " + std::to_string(ctx->kids[d]->device) + " (replicas from " + std::to_string(ctx->kid_r0[d]) + "): " + ctx->kids[d]->err; return rc[d]; }
+    return RRRMC_OK;
+}
+}  // namespace
+// forward to the children of a multi-device context; `c`, `r0` (the child's first replica) and `rn` (its replicas) are visible in `expr`
+#define RRRMC_MULTI(ctx, threads, expr)                                                                                  \
+    do {                                                                                                                 \
+        if (is_multi(ctx))                                                                                               \
+            return multi_each(ctx, [&](rrrmc_ctx* c, int64_t r0, int64_t rn) -> int32_t { (void)r0; (void)rn; return (expr); }, threads); \
+    } while (0)
+
 extern "C" {
 
 
@@ -718,6 +756,11 @@ int32_t rrrmc_ctx_create(rrrmc_ctx** out, int32_t model, int64_t N, int64_t K, i
 void rrrmc_ctx_destroy(rrrmc_ctx* ctx)
 {
     if (!ctx) return;
+    if (is_multi(ctx)) {
+        for (rrrmc_ctx* c : ctx->kids) rrrmc_ctx_destroy(c);
+        delete ctx;
+        return;
+    }
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     free_dev(ctx->d_A); free_dev(ctx->d_J); free_dev(ctx->d_table); free_dev(ctx->d_spins);
@@ -755,6 +798,7 @@ void rrrmc_ctx_destroy(rrrmc_ctx* ctx)
 
 int32_t rrrmc_set_graph(rrrmc_ctx* ctx, const int32_t* A, const int8_t* J)
 {
+    RRRMC_MULTI(ctx, false, rrrmc_set_graph(c, A, J));
     if (!ctx) return RRRMC_ERR_INVALID_ARG;
     if (ctx->model != RRRMC_MODEL_SPARSE_PM1 && ctx->model != RRRMC_MODEL_QUANT_RRG)
         return fail(ctx, RRRMC_ERR_STATE, "rrrmc_set_graph is for sparse +-J models; use rrrmc_set_couplings_dense");
@@ -822,6 +866,7 @@ int32_t rrrmc_set_graph(rrrmc_ctx* ctx, const int32_t* A, const int8_t* J)
 
 int32_t rrrmc_seed(rrrmc_ctx* ctx, uint64_t seed)
 {
+    RRRMC_MULTI(ctx, false, rrrmc_seed(c, seed));
     if (!ctx) return RRRMC_ERR_INVALID_ARG;
     ctx->seed = seed;
     ctx->seeded = true;
@@ -831,10 +876,11 @@ int32_t rrrmc_seed(rrrmc_ctx* ctx, uint64_t seed)
     return RRRMC_OK;
 }
 
-int64_t rrrmc_iterations_done(const rrrmc_ctx* ctx) { return ctx ? (int64_t)ctx->it_done : -1; }
+int64_t rrrmc_iterations_done(const rrrmc_ctx* ctx) { return !ctx ? -1 : is_multi(ctx) ? (int64_t)ctx->kids[0]->it_done : (int64_t)ctx->it_done; }
 
 int32_t rrrmc_init_spins_random(rrrmc_ctx* ctx)
 {
+    RRRMC_MULTI(ctx, false, rrrmc_init_spins_random(c));
     if (!ctx) return RRRMC_ERR_INVALID_ARG;
     ctx->std_cache_live = false;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -877,6 +923,7 @@ int32_t rrrmc_init_spins_random(rrrmc_ctx* ctx)
 
 int32_t rrrmc_set_spins(rrrmc_ctx* ctx, const uint64_t* chunks)
 {
+    RRRMC_MULTI(ctx, true, rrrmc_set_spins(c, at_row(chunks, r0 * nch_of(ctx))));
     if (ctx) ctx->std_cache_live = false;
     if (!ctx) return RRRMC_ERR_INVALID_ARG;
     if (!chunks) return fail(ctx, RRRMC_ERR_INVALID_ARG, "chunks is NULL");
@@ -999,6 +1046,7 @@ int32_t spins_to_chunks(rrrmc_ctx* ctx, const void* src, uint64_t* chunks)
 
 int32_t rrrmc_get_spins(rrrmc_ctx* ctx, uint64_t* chunks)
 {
+    RRRMC_MULTI(ctx, true, rrrmc_get_spins(c, at_row(chunks, r0 * nch_of(ctx))));
     int32_t rc = ensure_state(ctx, true);
     if (rc) return rc;
     if (!chunks) return fail(ctx, RRRMC_ERR_INVALID_ARG, "chunks is NULL");
@@ -1007,6 +1055,7 @@ int32_t rrrmc_get_spins(rrrmc_ctx* ctx, uint64_t* chunks)
 
 int32_t rrrmc_energy(rrrmc_ctx* ctx, int64_t* E_out)
 {
+    RRRMC_MULTI(ctx, true, rrrmc_energy(c, at_row(E_out, r0)));
     int32_t rc = ensure_state(ctx, true);
     if (rc) return rc;
     if (!sparse_int_model(ctx)) return fail(ctx, RRRMC_ERR_STATE, "this model's energies are Float64: use the _f64 entry point");
@@ -1023,6 +1072,7 @@ int32_t rrrmc_energy(rrrmc_ctx* ctx, int64_t* E_out)
 
 int32_t rrrmc_get_fields(rrrmc_ctx* ctx, int64_t* lfields_out)
 {
+    RRRMC_MULTI(ctx, true, rrrmc_get_fields(c, at_row(lfields_out, r0 * ctx->N)));
     int32_t rc = ensure_state(ctx, true);
     if (rc) return rc;
     if (ctx->model == RRRMC_MODEL_SK_BINARY) {       // the live integer cache, lfields = sqrt(N) * delta_energy (SK.jl:137-140)
@@ -1056,6 +1106,7 @@ int32_t rrrmc_get_fields(rrrmc_ctx* ctx, int64_t* lfields_out)
 
 int32_t rrrmc_standard_mc_async(rrrmc_ctx* ctx, double beta, int64_t iters, int64_t step)
 {
+    RRRMC_MULTI(ctx, false, rrrmc_standard_mc_async(c, beta, iters, step));
     int32_t rc = ensure_state(ctx, true);
     if (rc) return rc;
     if (ctx->model == RRRMC_MODEL_SK_NORMAL || ctx->model == RRRMC_MODEL_SK_BINARY) return sk_standard_mc_async(ctx, beta, iters, step);
@@ -1230,6 +1281,7 @@ int32_t rrrmc_standard_mc_async(rrrmc_ctx* ctx, double beta, int64_t iters, int6
 
 int32_t rrrmc_standard_mc_fast_async(rrrmc_ctx* ctx, double beta, int64_t iters, int64_t step)
 {
+    RRRMC_MULTI(ctx, false, rrrmc_standard_mc_fast_async(c, beta, iters, step));
     int32_t rc = ensure_state(ctx, true);
     if (rc) return rc;
     if (ctx->model != RRRMC_MODEL_SPARSE_F64)
@@ -1239,6 +1291,7 @@ int32_t rrrmc_standard_mc_fast_async(rrrmc_ctx* ctx, double beta, int64_t iters,
 
 int32_t rrrmc_set_resume(rrrmc_ctx* ctx, int32_t on)
 {
+    RRRMC_MULTI(ctx, false, rrrmc_set_resume(c, on));
     if (!ctx) return RRRMC_ERR_INVALID_ARG;
     ctx->resume = on != 0;
     return RRRMC_OK;
@@ -1246,6 +1299,7 @@ int32_t rrrmc_set_resume(rrrmc_ctx* ctx, int32_t on)
 
 int32_t rrrmc_tracked_energy_f64(rrrmc_ctx* ctx, double* E_out)
 {
+    RRRMC_MULTI(ctx, true, rrrmc_tracked_energy_f64(c, at_row(E_out, r0)));
     if (!ctx || !E_out) return RRRMC_ERR_INVALID_ARG;
     if (sparse_int_model(ctx)) return fail(ctx, RRRMC_ERR_STATE, "integer models: the tracked energy equals rrrmc_energy exactly");
     if (!ctx->std_cache_live || !ctx->sk_E) return fail(ctx, RRRMC_ERR_STATE, "no standardMC call has left a tracked energy");
@@ -1259,6 +1313,7 @@ int32_t rrrmc_tracked_energy_f64(rrrmc_ctx* ctx, double* E_out)
 
 int32_t rrrmc_sync(rrrmc_ctx* ctx)
 {
+    RRRMC_MULTI(ctx, true, rrrmc_sync(c));
     if (!ctx) return RRRMC_ERR_INVALID_ARG;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -1273,6 +1328,7 @@ int32_t rrrmc_sync(rrrmc_ctx* ctx)
 
 int32_t rrrmc_fetch_results(rrrmc_ctx* ctx, int64_t* Es_out, int64_t* accepted_out)
 {
+    RRRMC_MULTI(ctx, true, rrrmc_fetch_results(c, at_row(Es_out, r0 * c->nsamp), at_row(accepted_out, r0)));
     if (!ctx) return RRRMC_ERR_INVALID_ARG;
     if (!sparse_int_model(ctx)) return fail(ctx, RRRMC_ERR_STATE, "this model's energies are Float64: use rrrmc_fetch_results_f64");
     if (!ctx->results_valid) return fail(ctx, RRRMC_ERR_STATE, "no sampling call has been made");
@@ -1309,6 +1365,20 @@ int32_t rrrmc_standard_mc(rrrmc_ctx* ctx, double beta, int64_t iters, int64_t st
 
 int32_t rrrmc_last_timing(rrrmc_ctx* ctx, double* total_ms, double* sweep_ms, int32_t* sweep_launches)
 {
+    if (is_multi(ctx)) {          // the job's time is its slowest device's
+        double tot = 0.0, sw = 0.0; int32_t nl = 0;
+        for (rrrmc_ctx* c : ctx->kids) {
+            double t = 0.0, w = 0.0; int32_t l = 0;
+            const int32_t rc = rrrmc_last_timing(c, &t, &w, &l);
+            if (rc) { ctx->err = c->err; return rc; }
+            if (t > tot) tot = t;
+            if (w > sw) { sw = w; nl = l; }
+        }
+        if (total_ms) *total_ms = tot;
+        if (sweep_ms) *sweep_ms = sw;
+        if (sweep_launches) *sweep_launches = nl;
+        return RRRMC_OK;
+    }
     if (!ctx) return RRRMC_ERR_INVALID_ARG;
     if (!ctx->timing_valid) return fail(ctx, RRRMC_ERR_STATE, "no sampling call has been made");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -1330,6 +1400,7 @@ int32_t rrrmc_last_timing(rrrmc_ctx* ctx, double* total_ms, double* sweep_ms, in
 
 int32_t rrrmc_timing_accumulate(rrrmc_ctx* ctx, int32_t on)
 {
+    RRRMC_MULTI(ctx, false, rrrmc_timing_accumulate(c, on));
     if (!ctx) return RRRMC_ERR_INVALID_ARG;
     if (ctx->model != RRRMC_MODEL_SPARSE_PM1) return fail(ctx, RRRMC_ERR_UNSUPPORTED, "timing accumulation is wired for the +-J sparse standardMC path only");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -1343,6 +1414,18 @@ int32_t rrrmc_timing_accumulate(rrrmc_ctx* ctx, int32_t on)
 
 int32_t rrrmc_timing_total(rrrmc_ctx* ctx, double* sweep_ms, int64_t* sweep_launches)
 {
+    if (is_multi(ctx)) {
+        double sw = 0.0; int64_t nl = 0;
+        for (rrrmc_ctx* c : ctx->kids) {
+            double w = 0.0; int64_t l = 0;
+            const int32_t rc = rrrmc_timing_total(c, &w, &l);
+            if (rc) { ctx->err = c->err; return rc; }
+            if (w > sw) { sw = w; nl = l; }
+        }
+        if (sweep_ms) *sweep_ms = sw;
+        if (sweep_launches) *sweep_launches = nl;
+        return RRRMC_OK;
+    }
     if (!ctx) return RRRMC_ERR_INVALID_ARG;
     if (!ctx->acc_mode) return fail(ctx, RRRMC_ERR_STATE, "rrrmc_timing_accumulate(ctx, 1) has not been called");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -1379,6 +1462,7 @@ RRRMC_API int32_t rrrmc_debug_step_trace(rrrmc_ctx* ctx, unsigned long long* out
 
 int32_t rrrmc_set_coloring(rrrmc_ctx* ctx, const int32_t* color, int32_t ncolors)
 {
+    RRRMC_MULTI(ctx, false, rrrmc_set_coloring(c, color, ncolors));
     if (!ctx) return RRRMC_ERR_INVALID_ARG;
     if (ctx->model != RRRMC_MODEL_SPARSE_PM1) return fail(ctx, RRRMC_ERR_STATE, "colourings are for sparse +-J models");
     if (!ctx->graph_set) return fail(ctx, RRRMC_ERR_STATE, "rrrmc_set_graph has not been called");
@@ -1418,6 +1502,7 @@ int32_t rrrmc_set_coloring(rrrmc_ctx* ctx, const int32_t* color, int32_t ncolors
 
 int32_t rrrmc_colored_count_accepted(rrrmc_ctx* ctx, int32_t on)
 {
+    RRRMC_MULTI(ctx, false, rrrmc_colored_count_accepted(c, on));
     if (!ctx) return RRRMC_ERR_INVALID_ARG;
     if (ctx->model != RRRMC_MODEL_SPARSE_PM1) return fail(ctx, RRRMC_ERR_UNSUPPORTED, "colour-parallel sweeps are for sparse +-J models");
     ctx->color_count_acc = on != 0;
@@ -1426,6 +1511,7 @@ int32_t rrrmc_colored_count_accepted(rrrmc_ctx* ctx, int32_t on)
 
 int32_t rrrmc_colored_sweeps_async(rrrmc_ctx* ctx, double beta, int64_t sweeps, int64_t step)
 {
+    RRRMC_MULTI(ctx, false, rrrmc_colored_sweeps_async(c, beta, sweeps, step));
     if (ctx) ctx->std_cache_live = false;
     int32_t rc = ensure_state(ctx, true);
     if (rc) return rc;
@@ -1512,6 +1598,45 @@ int32_t rrrmc_ctx_create_quant_sk(rrrmc_ctx** out, int64_t Nk, int64_t M, int64_
 int32_t rrrmc_ctx_create_quant_skn(rrrmc_ctx** out, int64_t Nk, int64_t M, int64_t R, int32_t device, uint32_t replica0)
 {
     return quant_ctx_create(out, Nk, 0, M, R, device, replica0, false, true);
+}
+
+// One context over several devices: the reference's user makes ONE call from ONE process (src/RRRMC.jl:81-88).
+// Replicas never interact, so the context is a list of per-device contexts over shards of whole 32-replica groups in global-id
+// order (the random streams are addressed by global replica id: the results do not depend on ndev); every entry point forwards
+// to the children — enqueue calls one after the other on each device's own stream, waiting / copying calls with one host thread
+// per device — and per-replica buffers are handed over as row ranges of the caller's arrays, so results arrive gathered.
+int32_t rrrmc_ctx_create_multi(rrrmc_ctx** out, int32_t model, int64_t N, int64_t K, int64_t M, int64_t R, const int32_t* device_ids,
+                               int32_t ndev, uint32_t replica0)
+{
+    if (!out) return fail(nullptr, RRRMC_ERR_INVALID_ARG, "out is NULL");
+    *out = nullptr;
+    if (!device_ids || ndev < 1) return fail(nullptr, RRRMC_ERR_INVALID_ARG, "device_ids must name at least one device (ndev = %d)", ndev);
+    if (ndev > 64) return fail(nullptr, RRRMC_ERR_INVALID_ARG, "ndev = %d: at most 64 devices", ndev);
+    if (R < 1) return fail(nullptr, RRRMC_ERR_INVALID_ARG, "R must be >= 1 (given %lld)", (long long)R);
+    if (replica0 % 32) return fail(nullptr, RRRMC_ERR_INVALID_ARG, "replica0 must be a multiple of 32 (given %u)", replica0);
+    rrrmc_ctx* ctx = new (std::nothrow) rrrmc_ctx();
+    if (!ctx) return fail(nullptr, RRRMC_ERR_NOMEM, "out of host memory");
+    ctx->model = model; ctx->K = K; ctx->R = R; ctx->replica0 = replica0; ctx->device = device_ids[0];
+    ctx->N = model == RRRMC_MODEL_QUANT_RRG ? N * M : N;
+    if (model == RRRMC_MODEL_QUANT_RRG) { ctx->qNk = N; ctx->qM = M; }
+    const int64_t groups = (R + 31) / 32;
+    for (int32_t d = 0; d < ndev; ++d) {
+        const int64_t b0 = 32 * (groups * d / ndev), b1 = d + 1 == ndev ? R : std::min<int64_t>(R, 32 * (groups * (d + 1) / ndev));
+        if (b1 <= b0) continue;          // fewer groups than devices: this one stays idle
+        rrrmc_ctx* c = nullptr;
+        const int32_t rc = model == RRRMC_MODEL_QUANT_RRG
+                               ? rrrmc_ctx_create_quant(&c, N, K, M, b1 - b0, device_ids[d], replica0 + (uint32_t)b0)
+                               : rrrmc_ctx_create(&c, model, N, K, b1 - b0, device_ids[d], replica0 + (uint32_t)b0);
+        if (rc) {
+            for (rrrmc_ctx* k : ctx->kids) rrrmc_ctx_destroy(k);
+            delete ctx;
+            return rc;                   // (the text of the failure is already in the creation-error slot)
+        }
+        ctx->kids.push_back(c);
+        ctx->kid_r0.push_back(b0);
+    }
+    *out = ctx;
+    return RRRMC_OK;
 }
 namespace {
 int32_t quant_ctx_create(rrrmc_ctx** out, int64_t Nk, int64_t K, int64_t M, int64_t R, int32_t device, uint32_t replica0, bool sk, bool skn)
@@ -1690,6 +1815,7 @@ int32_t quant_mc_async(rrrmc_ctx* ctx, bool standard, double beta, double fourK,
 
 int32_t rrrmc_rrr_mc_async(rrrmc_ctx* ctx, double beta, double fourK, int64_t iters, int64_t step, double staged_thr, double staged_thr_fact)
 {
+    RRRMC_MULTI(ctx, false, rrrmc_rrr_mc_async(c, beta, fourK, iters, step, staged_thr, staged_thr_fact));
     if (ctx) ctx->std_cache_live = false;
     int32_t rc = ensure_state(ctx, true);
     if (rc) return rc;
@@ -1704,6 +1830,7 @@ int32_t rrrmc_rrr_mc_async(rrrmc_ctx* ctx, double beta, double fourK, int64_t it
 
 int32_t rrrmc_bkl_mc_async(rrrmc_ctx* ctx, double beta, int64_t iters, int64_t step)
 {
+    RRRMC_MULTI(ctx, false, rrrmc_bkl_mc_async(c, beta, iters, step));
     if (ctx) ctx->std_cache_live = false;
     int32_t rc = ensure_state(ctx, true);
     if (rc) return rc;
@@ -1717,6 +1844,7 @@ int32_t rrrmc_bkl_mc_async(rrrmc_ctx* ctx, double beta, int64_t iters, int64_t s
 
 int32_t rrrmc_quant_slice_form(rrrmc_ctx* ctx, int32_t ea_form)
 {
+    RRRMC_MULTI(ctx, false, rrrmc_quant_slice_form(c, ea_form));
     if (!ctx) return RRRMC_ERR_INVALID_ARG;
     if (ctx->model != RRRMC_MODEL_QUANT_RRG || ctx->q_sk) return fail(ctx, RRRMC_ERR_STATE, "rrrmc_quant_slice_form is for a GraphQuant over GraphRRG / GraphEA slices");
     if (ctx->graph_set) return fail(ctx, RRRMC_ERR_STATE, "rrrmc_quant_slice_form must precede rrrmc_set_graph");
@@ -1726,6 +1854,7 @@ int32_t rrrmc_quant_slice_form(rrrmc_ctx* ctx, int32_t ea_form)
 
 int32_t rrrmc_quant_set_field(rrrmc_ctx* ctx, double beta, double fourK)
 {
+    RRRMC_MULTI(ctx, false, rrrmc_quant_set_field(c, beta, fourK));
     if (!ctx) return RRRMC_ERR_INVALID_ARG;
     if (ctx->model != RRRMC_MODEL_QUANT_RRG) return fail(ctx, RRRMC_ERR_STATE, "rrrmc_quant_set_field is for RRRMC_MODEL_QUANT_RRG");
     if (!(fourK > 0.0) || !std::isfinite(fourK) || !std::isfinite(beta)) return fail(ctx, RRRMC_ERR_INVALID_ARG, "beta and fourK must be finite, fourK > 0");
@@ -1736,6 +1865,7 @@ int32_t rrrmc_quant_set_field(rrrmc_ctx* ctx, double beta, double fourK)
 
 int32_t rrrmc_wtm_mc_async(rrrmc_ctx* ctx, double beta, int64_t samples, double step)
 {
+    RRRMC_MULTI(ctx, false, rrrmc_wtm_mc_async(c, beta, samples, step));
     if (ctx) ctx->std_cache_live = false;
     int32_t rc = ensure_state(ctx, true);
     if (rc) return rc;
@@ -1748,6 +1878,7 @@ int32_t rrrmc_wtm_mc_async(rrrmc_ctx* ctx, double beta, int64_t samples, double 
 
 int32_t rrrmc_wtm_times(rrrmc_ctx* ctx, double* t_out)
 {
+    RRRMC_MULTI(ctx, true, rrrmc_wtm_times(c, at_row(t_out, r0)));
     if (!ctx) return RRRMC_ERR_INVALID_ARG;
     if (!ctx->last_call_wtm || !ctx->results_valid) return fail(ctx, RRRMC_ERR_STATE, "no wtmMC call has been made");
     if (!t_out) return fail(ctx, RRRMC_ERR_INVALID_ARG, "t_out is NULL");
@@ -1759,6 +1890,7 @@ int32_t rrrmc_wtm_times(rrrmc_ctx* ctx, double* t_out)
 
 int32_t rrrmc_extremal_opt_async(rrrmc_ctx* ctx, const double* ftau, int64_t iters, int64_t step)
 {
+    RRRMC_MULTI(ctx, false, rrrmc_extremal_opt_async(c, ftau, iters, step));
     if (ctx) ctx->std_cache_live = false;
     int32_t rc = ensure_state(ctx, true);
     if (rc) return rc;
@@ -1799,6 +1931,7 @@ int32_t eo_results(rrrmc_ctx* ctx, int64_t* Emin_i, double* Emin_f, uint64_t* Cm
 
 int32_t rrrmc_extremal_opt_results(rrrmc_ctx* ctx, int64_t* Emin_out, uint64_t* Cmin_chunks, int64_t* itmin_out)
 {
+    RRRMC_MULTI(ctx, true, rrrmc_extremal_opt_results(c, at_row(Emin_out, r0), at_row(Cmin_chunks, r0 * nch_of(ctx)), at_row(itmin_out, r0)));
     if (!ctx) return RRRMC_ERR_INVALID_ARG;
     if (!sparse_int_model(ctx)) return fail(ctx, RRRMC_ERR_STATE, "this model's energies are Float64: use rrrmc_extremal_opt_results_f64");
     return eo_results(ctx, Emin_out, nullptr, Cmin_chunks, itmin_out);
@@ -1806,6 +1939,7 @@ int32_t rrrmc_extremal_opt_results(rrrmc_ctx* ctx, int64_t* Emin_out, uint64_t* 
 
 int32_t rrrmc_extremal_opt_results_f64(rrrmc_ctx* ctx, double* Emin_out, uint64_t* Cmin_chunks, int64_t* itmin_out)
 {
+    RRRMC_MULTI(ctx, true, rrrmc_extremal_opt_results_f64(c, at_row(Emin_out, r0), at_row(Cmin_chunks, r0 * nch_of(ctx)), at_row(itmin_out, r0)));
     if (!ctx) return RRRMC_ERR_INVALID_ARG;
     if (sparse_int_model(ctx)) return fail(ctx, RRRMC_ERR_STATE, "this model's energies are integers: use rrrmc_extremal_opt_results");
     return eo_results(ctx, nullptr, Emin_out, Cmin_chunks, itmin_out);
@@ -1813,6 +1947,7 @@ int32_t rrrmc_extremal_opt_results_f64(rrrmc_ctx* ctx, double* Emin_out, uint64_
 
 int32_t rrrmc_rrr_stats(rrrmc_ctx* ctx, int64_t* staged_iters_out)
 {
+    RRRMC_MULTI(ctx, true, rrrmc_rrr_stats(c, at_row(staged_iters_out, r0)));
     if (!ctx) return RRRMC_ERR_INVALID_ARG;
     if (!ctx->last_call_rrr || !ctx->results_valid) return fail(ctx, RRRMC_ERR_STATE, "no rrrMC call has been made");
     if (!staged_iters_out) return fail(ctx, RRRMC_ERR_INVALID_ARG, "staged_iters_out is NULL");
@@ -1826,6 +1961,7 @@ int32_t rrrmc_rrr_stats(rrrmc_ctx* ctx, int64_t* staged_iters_out)
 
 int32_t rrrmc_rrr_cache(rrrmc_ctx* ctx, int8_t* pos_out, int32_t* sizes_out)
 {
+    RRRMC_MULTI(ctx, true, rrrmc_rrr_cache(c, at_row(pos_out, r0 * ctx->N), at_row(sizes_out, r0 * (ctx->model == RRRMC_MODEL_SPARSE_DISCRETIZED ? 16 : 4))));
     if (!ctx) return RRRMC_ERR_INVALID_ARG;
     if ((ctx->model != RRRMC_MODEL_QUANT_RRG && ctx->model != RRRMC_MODEL_SPARSE_DISCRETIZED) || !ctx->results_valid || !ctx->last_call_rrr)
         return fail(ctx, RRRMC_ERR_STATE, "no rrrMC call has been made");
@@ -1854,6 +1990,7 @@ int32_t rrrmc_rrr_cache(rrrmc_ctx* ctx, int8_t* pos_out, int32_t* sizes_out)
 
 int32_t rrrmc_set_couplings_dense(rrrmc_ctx* ctx, const double* J)
 {
+    RRRMC_MULTI(ctx, false, rrrmc_set_couplings_dense(c, J));
     if (!ctx) return RRRMC_ERR_INVALID_ARG;
     const bool qskn = ctx->model == RRRMC_MODEL_QUANT_RRG && ctx->q_skn;      // the slice graph of a GraphQSKNormalT: J is Nk x Nk
     if (ctx->model != RRRMC_MODEL_SK_NORMAL && !qskn) return fail(ctx, RRRMC_ERR_STATE, "rrrmc_set_couplings_dense is for RRRMC_MODEL_SK_NORMAL (or a GraphQuant over GraphSKNormal slices)");
@@ -1881,6 +2018,7 @@ int32_t rrrmc_set_couplings_dense(rrrmc_ctx* ctx, const double* J)
 
 int32_t rrrmc_energy_f64(rrrmc_ctx* ctx, double* E_out)
 {
+    RRRMC_MULTI(ctx, true, rrrmc_energy_f64(c, at_row(E_out, r0)));
     int32_t rc = ensure_state(ctx, true);
     if (rc) return rc;
     if (sparse_int_model(ctx)) return fail(ctx, RRRMC_ERR_STATE, "this model's energies are integers: use rrrmc_energy");
@@ -1906,6 +2044,7 @@ int32_t rrrmc_energy_f64(rrrmc_ctx* ctx, double* E_out)
 
 int32_t rrrmc_get_fields_f64(rrrmc_ctx* ctx, double* lfields_out)
 {
+    RRRMC_MULTI(ctx, true, rrrmc_get_fields_f64(c, at_row(lfields_out, r0 * ctx->N)));
     int32_t rc = ensure_state(ctx, true);
     if (rc) return rc;
     if (ctx->model != RRRMC_MODEL_SK_NORMAL && ctx->model != RRRMC_MODEL_SPARSE_F64)
@@ -1932,6 +2071,7 @@ int32_t rrrmc_get_fields_f64(rrrmc_ctx* ctx, double* lfields_out)
 
 int32_t rrrmc_fetch_results_f64(rrrmc_ctx* ctx, double* Es_out, int64_t* accepted_out)
 {
+    RRRMC_MULTI(ctx, true, rrrmc_fetch_results_f64(c, at_row(Es_out, r0 * c->nsamp), at_row(accepted_out, r0)));
     if (!ctx) return RRRMC_ERR_INVALID_ARG;
     if (sparse_int_model(ctx)) return fail(ctx, RRRMC_ERR_STATE, "this model's energies are integers: use rrrmc_fetch_results");
     if (!ctx->results_valid) return fail(ctx, RRRMC_ERR_STATE, "no sampling call has been made");
@@ -1972,6 +2112,7 @@ int32_t rrrmc_standard_mc_f64(rrrmc_ctx* ctx, double beta, int64_t iters, int64_
 
 int32_t rrrmc_set_couplings_bits(rrrmc_ctx* ctx, const uint64_t* Jc)
 {
+    RRRMC_MULTI(ctx, false, rrrmc_set_couplings_bits(c, Jc));
     if (!ctx) return RRRMC_ERR_INVALID_ARG;
     const bool qsk = ctx->model == RRRMC_MODEL_QUANT_RRG && ctx->q_sk;          // the slice graph of a GraphQSKT
     if (ctx->model != RRRMC_MODEL_SK_BINARY && !qsk)
@@ -1998,6 +2139,7 @@ int32_t rrrmc_set_couplings_bits(rrrmc_ctx* ctx, const uint64_t* Jc)
 // ---------------------------------------------------------------------------------------------------
 int32_t rrrmc_snapshot_reserve(rrrmc_ctx* ctx, int32_t nslots)
 {
+    RRRMC_MULTI(ctx, false, rrrmc_snapshot_reserve(c, nslots));
     if (!ctx) return RRRMC_ERR_INVALID_ARG;
     if (nslots < 0) return fail(ctx, RRRMC_ERR_INVALID_ARG, "nslots must be >= 0");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -2018,6 +2160,7 @@ int32_t rrrmc_snapshot_reserve(rrrmc_ctx* ctx, int32_t nslots)
 
 int32_t rrrmc_snapshot_store(rrrmc_ctx* ctx, int32_t slot)
 {
+    RRRMC_MULTI(ctx, false, rrrmc_snapshot_store(c, slot));
     int32_t rc = ensure_state(ctx, true);
     if (rc) return rc;
     if (slot < 0 || slot >= ctx->snap_slots) return fail(ctx, RRRMC_ERR_INVALID_ARG, "snapshot slot %d out of range (0..%d)", slot, ctx->snap_slots - 1);
@@ -2030,6 +2173,7 @@ int32_t rrrmc_snapshot_store(rrrmc_ctx* ctx, int32_t slot)
 
 int32_t rrrmc_snapshot_get(rrrmc_ctx* ctx, int32_t slot, uint64_t* chunks)
 {
+    RRRMC_MULTI(ctx, true, rrrmc_snapshot_get(c, slot, at_row(chunks, r0 * nch_of(ctx))));
     if (!ctx) return RRRMC_ERR_INVALID_ARG;
     if (!chunks) return fail(ctx, RRRMC_ERR_INVALID_ARG, "chunks is NULL");
     if (slot < 0 || slot >= ctx->snap_slots || !ctx->snap_valid[(size_t)slot])
@@ -2039,6 +2183,21 @@ int32_t rrrmc_snapshot_get(rrrmc_ctx* ctx, int32_t slot, uint64_t* chunks)
 
 int32_t rrrmc_overlaps(rrrmc_ctx* ctx, int64_t npairs, const int32_t* slotA, const int32_t* slotB, int32_t* q_out)
 {
+    if (is_multi(ctx)) {
+        if (npairs <= 0 || !q_out) return npairs == 0 ? RRRMC_OK : fail(ctx, RRRMC_ERR_INVALID_ARG, "npairs must be >= 0 and q_out not NULL");
+        std::vector<std::vector<int32_t>> q(ctx->kids.size());
+        for (size_t d = 0; d < q.size(); ++d) q[d].resize((size_t)(npairs * ctx->kids[d]->R));
+        const int32_t rc = multi_each(ctx, [&](rrrmc_ctx* c, int64_t r0, int64_t) -> int32_t {
+            size_t d = 0;
+            while (ctx->kid_r0[d] != r0) ++d;
+            return rrrmc_overlaps(c, npairs, slotA, slotB, q[d].data());
+        }, true);
+        if (rc) return rc;
+        for (size_t d = 0; d < q.size(); ++d)
+            for (int64_t pp = 0; pp < npairs; ++pp)
+                std::memcpy(q_out + pp * ctx->R + ctx->kid_r0[d], q[d].data() + pp * ctx->kids[d]->R, sizeof(int32_t) * (size_t)ctx->kids[d]->R);
+        return RRRMC_OK;
+    }
     int32_t rc = ensure_state(ctx, true);
     if (rc) return rc;
     if (npairs < 0) return fail(ctx, RRRMC_ERR_INVALID_ARG, "npairs must be >= 0");
@@ -2092,6 +2251,7 @@ int32_t rrrmc_overlaps(rrrmc_ctx* ctx, int64_t npairs, const int32_t* slotA, con
 
 int32_t rrrmc_quant_observables(rrrmc_ctx* ctx, double beta, double Gamma, double* Qenergy_out, double* tmag_out, double* ovs_out)
 {
+    RRRMC_MULTI(ctx, true, rrrmc_quant_observables(c, beta, Gamma, at_row(Qenergy_out, r0), at_row(tmag_out, r0), at_row(ovs_out, r0 * (c->qM / 2))));
     int32_t rc = ensure_state(ctx, true);
     if (rc) return rc;
     if (ctx->model != RRRMC_MODEL_QUANT_RRG) return fail(ctx, RRRMC_ERR_STATE, "rrrmc_quant_observables needs a GraphQuant context");
@@ -2200,6 +2360,7 @@ int32_t validate_level_graph(rrrmc_ctx* ctx, const int32_t* A, const int8_t* dJ,
 int32_t rrrmc_set_graph_discretized(rrrmc_ctx* ctx, const int32_t* A, const int8_t* dJ, const double* rJ, const int32_t* lev, int32_t nlev,
                                     int32_t ea_form)
 {
+    RRRMC_MULTI(ctx, false, rrrmc_set_graph_discretized(c, A, dJ, rJ, lev, nlev, ea_form));
     if (!ctx) return RRRMC_ERR_INVALID_ARG;
     if (ctx->model != RRRMC_MODEL_SPARSE_DISCRETIZED) return fail(ctx, RRRMC_ERR_STATE, "rrrmc_set_graph_discretized is for RRRMC_MODEL_SPARSE_DISCRETIZED");
     if (!A || !dJ || !rJ || !lev) return fail(ctx, RRRMC_ERR_INVALID_ARG, "A, dJ, rJ, lev must not be NULL");
@@ -2220,6 +2381,7 @@ int32_t rrrmc_set_graph_discretized(rrrmc_ctx* ctx, const int32_t* A, const int8
 
 int32_t rrrmc_set_graph_levels(rrrmc_ctx* ctx, const int32_t* A, const int8_t* J, const int32_t* lev, int32_t nlev, int32_t ea_form)
 {
+    RRRMC_MULTI(ctx, false, rrrmc_set_graph_levels(c, A, J, lev, nlev, ea_form));
     if (!ctx) return RRRMC_ERR_INVALID_ARG;
     if (ctx->model != RRRMC_MODEL_SPARSE_LEVELS) return fail(ctx, RRRMC_ERR_STATE, "rrrmc_set_graph_levels is for RRRMC_MODEL_SPARSE_LEVELS");
     if (!A || !J || !lev) return fail(ctx, RRRMC_ERR_INVALID_ARG, "A, J, lev must not be NULL");
@@ -2241,6 +2403,7 @@ int32_t rrrmc_set_graph_levels(rrrmc_ctx* ctx, const int32_t* A, const int8_t* J
 
 int32_t rrrmc_set_level_scale(rrrmc_ctx* ctx, int64_t mul, double div)
 {
+    RRRMC_MULTI(ctx, false, rrrmc_set_level_scale(c, mul, div));
     if (!ctx) return RRRMC_ERR_INVALID_ARG;
     if (ctx->model != RRRMC_MODEL_SPARSE_DISCRETIZED && ctx->model != RRRMC_MODEL_SPARSE_LEVELS)
         return fail(ctx, RRRMC_ERR_STATE, "rrrmc_set_level_scale is for RRRMC_MODEL_SPARSE_DISCRETIZED and RRRMC_MODEL_SPARSE_LEVELS");
@@ -2293,6 +2456,7 @@ double gauss_draw(uint64_t seed, uint64_t n)
 
 int32_t rrrmc_set_graph_f64(rrrmc_ctx* ctx, const int32_t* A, const double* J)
 {
+    RRRMC_MULTI(ctx, false, rrrmc_set_graph_f64(c, A, J));
     if (!ctx) return RRRMC_ERR_INVALID_ARG;
     if (ctx->model != RRRMC_MODEL_SPARSE_F64) return fail(ctx, RRRMC_ERR_STATE, "rrrmc_set_graph_f64 is for RRRMC_MODEL_SPARSE_F64");
     if (!A || !J) return fail(ctx, RRRMC_ERR_INVALID_ARG, "A and J must not be NULL");

@@ -16,14 +16,23 @@ MODEL_SPARSE_LEVELS = 7
 
 
 class Engine:
-    """R replicas of one graph on one MI355X (one ctx = one device, SURVEY.md §8b "Threading")."""
+    """R replicas of one graph on one MI355X — or, with ``devices=[...]``, on several from this one process: the library shards the
+    replicas by global id over the listed devices (rrrmc_ctx_create_multi; one stream + host thread per device)
+    and every call below is the same call, with gathered results."""
 
-    def __init__(self, X, R=1, device=0, replica0=0):
+    def __init__(self, X, R=1, device=0, replica0=0, devices=None):
         self.X, self.R = X, int(R)
         self._ctx = C.c_void_p()
         self._f64 = X.model_kind not in (MODEL_SPARSE_PM1, MODEL_SPARSE_LEVELS)
         self._units = X.model_kind == MODEL_SPARSE_LEVELS        # device energies are int64 level units: X.energy_value converts
-        if X.model_kind == MODEL_QUANT_RRG and getattr(X, "skn_slices", False):
+        if devices is not None:
+            if X.model_kind == MODEL_QUANT_RRG and (getattr(X, "skn_slices", False) or X.sk_slices):
+                raise RRRMCError(3, "a GraphQuant over dense slices has no multi-device context")
+            ids = np.asarray(list(devices), np.int32)
+            quant = X.model_kind == MODEL_QUANT_RRG
+            check(lib().rrrmc_ctx_create_multi(C.byref(self._ctx), X.model_kind, X.Nk if quant else X.N, X.K, X.M if quant else 0, self.R,
+                                               ids, len(ids), replica0))
+        elif X.model_kind == MODEL_QUANT_RRG and getattr(X, "skn_slices", False):
             check(lib().rrrmc_ctx_create_quant_skn(C.byref(self._ctx), X.Nk, X.M, self.R, device, replica0))
         elif X.model_kind == MODEL_QUANT_RRG and X.sk_slices:
             check(lib().rrrmc_ctx_create_quant_sk(C.byref(self._ctx), X.Nk, X.M, self.R, device, replica0))
@@ -430,25 +439,27 @@ def standardMC(X, beta, iters, *, seed=DEFAULT_SEED, step=1, hook=None, C0=None,
             if it < iters and eng._f64:
                 eng.standard_mc(beta, 0, step=1, want_energies=False)      # E = energy(X, C), fresh cache: the start of a reference call
             eng.set_resume(True)
-            while it < iters:
-                nxt = (it // step + 1) * step          # next sampled iteration
-                n = min(nxt - 1, iters) - it
-                if n > 0:
-                    _, a = eng.standard_mc(beta, n, step=n + 1, want_energies=False)
+            try:        # whatever the hook (or a call) raises, a caller-supplied engine must not stay in resume mode
+                while it < iters:
+                    nxt = (it // step + 1) * step          # next sampled iteration
+                    n = min(nxt - 1, iters) - it
+                    if n > 0:
+                        _, a = eng.standard_mc(beta, n, step=n + 1, want_energies=False)
+                        accepted += a
+                        it += n
+                    if nxt > iters:
+                        break
+                    E = eng.tracked_energy()
+                    samples.append(E)
+                    eng.get_config(Cfg)
+                    if not hook(nxt, X, Cfg, accepted.copy(), E):
+                        it = nxt
+                        break
+                    _, a = eng.standard_mc(beta, 1, step=2, want_energies=False)   # the move of iteration nxt
                     accepted += a
-                    it += n
-                if nxt > iters:
-                    break
-                E = eng.tracked_energy()
-                samples.append(E)
-                eng.get_config(Cfg)
-                if not hook(nxt, X, Cfg, accepted.copy(), E):
                     it = nxt
-                    break
-                _, a = eng.standard_mc(beta, 1, step=2, want_energies=False)   # the move of iteration nxt
-                accepted += a
-                it = nxt
-            eng.set_resume(False)
+            finally:
+                eng.set_resume(False)
             Es = np.stack(samples, axis=1) if samples else np.zeros((eng.R, 0), X.energy_dtype)
         eng.get_config(Cfg)
         if not quiet:
