@@ -1,8 +1,12 @@
 # Replay an RNG-free tape (tests/golden/tape_*.txt) through the reference's OWN graph code and compare with the results the tape
 # holds (written by the build's C oracle; the HIP library is checked against the same tapes in tests/test_tapes.py).
 #
-#   julia --project=<an environment that has RRRMC.jl> julia/replay_tape.jl tests/golden/tape_rrg_n128.txt
-#   julia ...                                          julia/replay_tape.jl tests/golden/tape_quant_nk16_m4.txt
+#   julia --project=<an environment that has RRRMC.jl> julia/replay_tape.jl                     (all seven tapes)
+#   julia ...                                          julia/replay_tape.jl tests/golden/tape_skn_n24.txt ...
+#
+# Tapes: standardMC on GraphRRG(128, 3); rrrMC on a GraphQuant (staged and direct branch); round 3: standardMC on GraphEA(2, 3) (doubled
+# bonds, undo path of update_cache!), on GraphSKNormal(24) and the binary GraphSK(10) (whole-array swap of SK.jl:247-250 / :106-109), and
+# rrrMC on GraphSKNormal(10) through DeltaECacheCont / DynamicSampler (refresh! included).
 #
 # With the random draws fixed, standardMC / rrrMC are deterministic functions of the reference's energy, delta_energy, spinflip!,
 # DeltaECache and ArraySet code: this script restates only the few lines of the sampler loops that consume random numbers
@@ -13,6 +17,7 @@ using RRRMC
 using RRRMC: Config, energy, delta_energy, spinflip!, getN, inner_graph, delta_energy_residual
 import RRRMC.DeltaE
 import RRRMC.DeltaE: gen_ΔEcache, apply_move!, compute_staged!, compute_reverse_probabilities!, apply_staged!, get_z
+import RRRMC.DynamicSamplers: getel
 
 function read_tape(path)
     d = Dict{String,Any}()
@@ -152,14 +157,133 @@ function replay_rrrMC_quant(t)
     return ok
 end
 
+# standardMC (src/RRRMC.jl:81-127) over any graph object of the reference with the draws of the tape; returns (Es, accepted, flips)
+function run_standardMC(X, C, β, iters, step, sites, us)
+    ET = typeof(energy(X, C))
+    Es = ET[]
+    E = energy(X, C)                                             # :95
+    accepted, flips = 0, Int[]
+    for it = 1:iters
+        it % step == 0 && push!(Es, E)                           # :104-108
+        i = sites[it]                                            # rand(1:N), :113
+        ΔE = delta_energy(X, C, i)
+        x = -β * ΔE
+        ok = x ≥ 0 || us[it] < exp(x)                            # accept, :39
+        push!(flips, ok)
+        ok || continue
+        spinflip!(X, C, i)
+        E += ΔE
+        accepted += 1
+    end
+    @assert abs(E - energy(X, C)) < 1e-9                         # test/runtests.jl:12-20
+    return Es, accepted, flips
+end
+
+function replay_standardMC_ea(t)
+    N, K = parse(Int, t["N"]), parse(Int, t["K"])
+    A, J = tuples(ints(t["A"]), K), tuples(ints(t["J"]), K)
+    X = RRRMC.EA.GraphEA{Int,(-1, 1),K}(A, J)                    # the inner constructor, src/graphs/EA.jl:145 (L = 2: uA = every second entry)
+    C = config_from(t["C0"], N)
+    Es, accepted, flips = run_standardMC(X, C, parse(Float64, t["beta"]), parse(Int, t["iters"]), parse(Int, t["step"]),
+                                         ints(t["sites"]), parse.(Float64, t["uniforms"]))
+    ok = Es == ints(t["expected_Es"]) && chunks_hex(C) == t["expected_chunks"] && accepted == parse(Int, t["expected_accepted"]) &&
+         flips == ints(t["expected_flips"])
+    println(ok ? "standardMC(GraphEA L=2) tape: reference == tape ($(accepted) accepted)" : "standardMC(GraphEA L=2) tape: MISMATCH")
+    return ok
+end
+
+function sk_graph(t)
+    N = parse(Int, t["N"])
+    if endswith(t["kind"], "skb")                                # GraphSK(J::Vector{BitVector}), src/graphs/SK.jl:34-48
+        nch = (N + 63) >> 6
+        rows = parse.(UInt64, t["J_chunks"], base = 16)
+        J = BitVector[(b = BitVector(undef, N); b.chunks .= rows[((i - 1) * nch + 1):(i * nch)]; b) for i = 1:N]
+        return RRRMC.SK.GraphSK(J)
+    end
+    Jf = parse.(Float64, t["J"])
+    return RRRMC.SK.GraphSKNormal([Jf[((i - 1) * N + 1):(i * N)] for i = 1:N])       # GraphSKNormal(J; check = true), SK.jl:184-195
+end
+
+function replay_standardMC_sk(t)
+    N = parse(Int, t["N"])
+    X = sk_graph(t)
+    C = config_from(t["C0"], N)
+    Es, accepted, _ = run_standardMC(X, C, parse(Float64, t["beta"]), parse(Int, t["iters"]), parse(Int, t["step"]),
+                                     ints(t["sites"]), parse.(Float64, t["uniforms"]))
+    lf = Float64.(X.cache.lfields)
+    # the same IEEE operations in the same order: the reference reproduces the tape to the last bit wherever its @simd loops are
+    # element-wise (they are); isapprox with a 1e-12 guard keeps the verdict robust to a different summation order in `energy`
+    ok = isapprox(Es, parse.(Float64, t["expected_Es"]), rtol = 1e-12, atol = 1e-12) && chunks_hex(C) == t["expected_chunks"] &&
+         accepted == parse(Int, t["expected_accepted"]) && isapprox(lf, parse.(Float64, t["expected_lfields"]), rtol = 1e-12, atol = 1e-12)
+    println(ok ? "standardMC($(typeof(X))) tape: reference == tape ($(accepted) accepted, bit-equal energies: $(Es == parse.(Float64, t["expected_Es"])))" :
+                 "standardMC($(typeof(X))) tape: MISMATCH")
+    return ok
+end
+
+# rrrMC(X::SingleGraph) (src/RRRMC.jl:149-219) on GraphSKNormal with DeltaECacheCont: rand(dynsmp) = getel(dynsmp, u) (DynamicSamplers.jl:154)
+function replay_rrrMC_skn(t)
+    N = parse(Int, t["N"])
+    β, iters, step = parse(Float64, t["beta"]), parse(Int, t["iters"]), parse(Int, t["step"])
+    staged_thr, staged_thr_fact = parse(Float64, t["staged_thr"]), parse(Float64, t["staged_thr_fact"])
+    X = sk_graph(t)
+    C = config_from(t["C0"], N)
+    umove, uacc = parse.(Float64, t["u_move"]), parse.(Float64, t["u_accept"])
+    Es = Float64[]
+    E = energy(X, C)
+    cache = gen_ΔEcache(X, C, β)                                 # DeltaECacheCont, src/DeltaE.jl:299-315
+    rand_move(u) = (move = getel(cache.dynsmp, u); (move, cache.ΔEs[move]))          # src/DeltaE.jl:327-333
+    λ = staged_thr_fact / N
+    staged_its, accepted, acc_rate = 0, 0, 0.5
+    for it = 1:iters
+        it % step == 0 && push!(Es, E)
+        acc = false
+        if acc_rate < staged_thr
+            staged_its += 1
+            z = get_z(cache)                                     # step_rrr, src/RRRMC.jl:131-138
+            move, ΔE = rand_move(umove[it])
+            compute_staged!(X, C, move, cache)
+            z′ = compute_reverse_probabilities!(cache)
+            c = z / z′
+            if uacc[it] < c                                      # :192
+                spinflip!(X, C, move)
+                apply_staged!(cache)
+                E += ΔE
+                accepted += 1
+                acc = true
+            end
+        else
+            move, ΔE = rand_move(umove[it])
+            c = apply_move!(X, C, move, cache)
+            if uacc[it] < c                                      # :202
+                E += ΔE
+                accepted += 1
+                acc = true
+            else
+                apply_move!(X, C, move, cache)
+            end
+        end
+        acc_rate = acc_rate * (1 - λ) + acc * λ
+    end
+    ok = isapprox(Es, parse.(Float64, t["expected_Es"]), rtol = 1e-10, atol = 1e-10) && chunks_hex(C) == t["expected_chunks"] &&
+         accepted == parse(Int, t["expected_accepted"]) && staged_its == parse(Int, t["expected_staged_its"]) &&
+         isapprox(cache.ΔEs, parse.(Float64, t["expected_dEs"]), rtol = 1e-10, atol = 1e-10) &&
+         isapprox(cache.dynsmp.z, parse(Float64, t["expected_z"]), rtol = 1e-10)
+    println(ok ? "rrrMC(GraphSKNormal) tape: reference == tape ($(accepted) accepted, $(staged_its) staged)" : "rrrMC(GraphSKNormal) tape: MISMATCH")
+    return ok
+end
+
 function main(paths)
     allok = true
     for p in paths
         t = read_tape(p)
-        allok &= t["kind"] == "standardMC" ? replay_standardMC(t) : replay_rrrMC_quant(t)
+        k = t["kind"]
+        allok &= k == "standardMC" ? (get(t, "form", "rrg") == "ea" ? replay_standardMC_ea(t) : replay_standardMC(t)) :
+                 k == "rrrMC_quant" ? replay_rrrMC_quant(t) :
+                 k == "rrrMC_skn" ? replay_rrrMC_skn(t) : replay_standardMC_sk(t)
     end
     exit(allok ? 0 : 1)
 end
 
 main(isempty(ARGS) ? [joinpath(@__DIR__, "..", "tests", "golden", f) for f in
-                      ("tape_rrg_n128.txt", "tape_quant_nk16_m4.txt", "tape_quant_direct.txt")] : ARGS)
+                      ("tape_rrg_n128.txt", "tape_quant_nk16_m4.txt", "tape_quant_direct.txt", "tape_ea_l2_d3.txt", "tape_skn_n24.txt",
+                       "tape_sk_n10.txt", "tape_rrr_skn_n10.txt")] : ARGS)

@@ -106,6 +106,115 @@ def write_quant(path, seed, Nk=16, K=3, M=4, beta=2.0, Gamma=0.5, iters=3000, st
     return True
 
 
+def _finish(path, body, check):
+    tmp = path + ".tmp"
+    open(tmp, "w").write("\n".join(body) + "\n")
+    ok, msg = check(TR.read_tape(tmp))
+    if not ok:
+        os.remove(tmp)
+        return False
+    os.replace(tmp, path)
+    print("%s: %s" % (os.path.basename(path), msg))
+    return True
+
+
+def write_standard_ea(path, seed, L=2, D=3, beta=1.0, iters=3000, step=100, replica=0):
+    """standardMC on GraphEA(2, 3): every site lists each neighbour twice (doubled bonds, EA.jl:250-256) and on 8 sites the same spin is
+    accepted twice in a row often, so the undo fast path (EA.jl:231-240) fires too."""
+    A = O.gen_ea(L, D)
+    N, K = A.shape
+    J = O.gen_couplings(A, seed)
+    C0 = O.init_config(seed, replica, N)
+    Es, ch, acc, _lf, sites, flips = O.standard_mc_sparse(A, J, beta, iters, step, seed, C0, replica=replica, trace=True, form="ea")
+    us = [u53(O.accept_uniform(seed, g, replica)) for g in range(1, iters + 1)]
+    body = ["# RRRMC tape v1 — standardMC(X::GraphEA{Int,(-1,1),%d}, beta, iters; step, C0) on the L = %d, D = %d lattice: every neighbour is" % (K, L, D),
+            "# listed twice (two bonds to the same site).  Sites 1-based; uniforms consulted only when delta_energy > 0 (src/RRRMC.jl:39).",
+            "@kind standardMC", "@form ea", "@L %d" % L, "@D %d" % D, "@N %d" % N, "@K %d" % K, "@beta %r" % beta, "@iters %d" % iters,
+            "@step %d" % step, "@seed %d" % seed, "@replica %d" % replica,
+            fmt_array("A", ("%d" % (v + 1) for v in A.reshape(-1))), fmt_array("J", ("%d" % v for v in J.reshape(-1))),
+            fmt_array("C0", ("%016x" % int(c) for c in C0)),
+            fmt_array("sites", ("%d" % (int(v) + 1) for v in sites)), fmt_array("uniforms", (repr(u) for u in us)),
+            fmt_array("expected_Es", ("%d" % int(e) for e in Es)), fmt_array("expected_chunks", ("%016x" % int(c) for c in ch)),
+            "@expected_accepted %d" % acc, fmt_array("expected_flips", ("%d" % int(f) for f in flips))]
+
+    def check(t):
+        got = TR.replay_standard_mc_ea(t)
+        ok = (got["Es"] == [int(e) for e in Es] and got["chunks"] == [int(c) for c in ch] and got["accepted"] == acc
+              and got["flips"] == [int(f) for f in flips] and got["min_margin"] >= 1e-9 and got["undos"] >= 5)
+        return ok, "%d iterations, accepted %d, %d undo swaps, closest decision margin %.2e" % (iters, acc, got["undos"], got["min_margin"])
+    return _finish(path, body, check)
+
+
+def write_standard_sk(path, seed, N, binary, beta, iters, step, replica=0, want_swaps=1):
+    """standardMC on GraphSKNormal(N) (Float64 cache, SK.jl:212-276) or the binary GraphSK(N) (integer cache, SK.jl:62-135); the tape must
+    contain a consecutive accepted pair at one site, so that the whole-array swap (SK.jl:247-250 / :106-109) fires."""
+    C0 = O.init_config(seed, replica, N)
+    if binary:
+        Jb = O.gen_sk_binary(N, seed)
+        Es, ch, acc, lf = O.standard_mc_skb(Jb, beta, iters, step, seed, C0, replica=replica)
+        Jsec = fmt_array("J_chunks", ("%016x" % int(c) for c in Jb.reshape(-1)))
+    else:
+        Jm = O.gen_sk_gauss(N, seed)
+        Es, ch, acc, lf = O.standard_mc_skn(Jm, beta, iters, step, seed, C0, replica=replica)
+        Jsec = fmt_array("J", (repr(float(v)) for v in Jm.reshape(-1)))
+    sites = [O.site_of(seed, g, N) for g in range(1, iters + 1)]
+    us = [O.rand53(seed, g, replica) for g in range(1, iters + 1)]
+    kind = "standardMC_skb" if binary else "standardMC_skn"
+    body = ["# RRRMC tape v1 — standardMC(X::%s, beta, iters; step, C0) with every random draw pre-drawn" % ("GraphSK (binary couplings, J rows as BitVector chunks)" if binary else "GraphSKNormal (J row-major)"),
+            "# (sites 1-based; uniforms consulted only when delta_energy > 0, src/RRRMC.jl:39).  Written by tests/golden/make_tapes.py",
+            "@kind %s" % kind, "@N %d" % N, "@beta %r" % beta, "@iters %d" % iters, "@step %d" % step, "@seed %d" % seed, "@replica %d" % replica,
+            Jsec, fmt_array("C0", ("%016x" % int(c) for c in C0)),
+            fmt_array("sites", ("%d" % (v + 1) for v in sites)), fmt_array("uniforms", (repr(u) for u in us)),
+            fmt_array("expected_Es", (repr(float(e)) for e in Es)), fmt_array("expected_chunks", ("%016x" % int(c) for c in ch)),
+            "@expected_accepted %d" % acc,
+            fmt_array("expected_lfields", (("%d" % int(v)) if binary else repr(float(v)) for v in lf))]
+
+    def check(t):
+        got = TR.replay_standard_mc_sk(t)
+        ok = (got["chunks"] == [int(c) for c in ch] and got["accepted"] == acc and got["min_margin"] >= 1e-9 and got["swaps"] >= want_swaps
+              and got["Es"] == [float(e) for e in Es] and got["lfields"] == [float(v) for v in lf])         # same IEEE operations: equal bit for bit
+        return ok, "%d iterations, accepted %d, %d array swaps, closest decision margin %.2e" % (iters, acc, got["swaps"], got["min_margin"])
+    ok = _finish(path, body, check)
+    if ok:          # record how many swaps the tape exercises
+        t = open(path).read().replace("@expected_accepted %d" % acc, "@expected_accepted %d\n@expected_swaps %d" % (acc, TR.replay_standard_mc_sk(TR.read_tape(path))["swaps"]))
+        open(path, "w").write(t)
+    return ok
+
+
+def write_rrr_skn(path, seed, N=10, beta=2.0, iters=2500, step=50, staged_thr=0.8, staged_thr_fact=5.0, replica=0):
+    """rrrMC(X::SingleGraph) on GraphSKNormal(N) through DeltaECacheCont + DynamicSampler (DeltaE.jl:299-410, DynamicSamplers.jl): with N = 10
+    every move re-weights all ten spins, so refresh! (every max(N, 100) setindex! calls) happens every tenth move."""
+    Jm = O.gen_sk_gauss(N, seed)
+    C0 = O.init_config(seed, replica, N)
+    Es, ch, acc, staged, dEs, z = O.rrr_mc_skn(Jm, beta, iters, step, seed, C0, replica=replica, staged_thr=staged_thr,
+                                               staged_thr_fact=staged_thr_fact, want_cache=True)
+    key = np.array([seed & 0xFFFFFFFF, seed >> 32], np.uint32)
+    umove, uacc = [], []
+    for g in range(1, iters + 1):          # RRR stream (DESIGN.md §2): sub 0 words 0,1 = rand(dynsmp)'s uniform, sub 1 = rand() of `rand() < c`
+        w0 = O.philox([g & 0xFFFFFFFF, g >> 32, replica, 8], key)
+        w1 = O.philox([g & 0xFFFFFFFF, g >> 32, replica, 8 | (1 << 8)], key)
+        umove.append(u53((int(w0[0]) << 32) | int(w0[1])))
+        uacc.append(u53((int(w1[0]) << 32) | int(w1[1])))
+    body = ["# RRRMC tape v1 — rrrMC(X::GraphSKNormal, beta, iters; step, C0, staged_thr, staged_thr_fact) (SingleGraph method, src/RRRMC.jl:149-219)",
+            "# with every random draw pre-drawn: u_move = rand() inside rand(dynsmp) (src/DynamicSamplers.jl:154), u_accept = rand() of",
+            "# `rand() < c` (src/RRRMC.jl:192,202; drawn at every iteration).  Written by tests/golden/make_tapes.py",
+            "@kind rrrMC_skn", "@N %d" % N, "@beta %r" % beta, "@iters %d" % iters, "@step %d" % step, "@staged_thr %r" % staged_thr,
+            "@staged_thr_fact %r" % staged_thr_fact, "@seed %d" % seed, "@replica %d" % replica,
+            fmt_array("J", (repr(float(v)) for v in Jm.reshape(-1))), fmt_array("C0", ("%016x" % int(c) for c in C0)),
+            fmt_array("u_move", (repr(u) for u in umove)), fmt_array("u_accept", (repr(u) for u in uacc)),
+            fmt_array("expected_Es", (repr(float(e)) for e in Es)), fmt_array("expected_chunks", ("%016x" % int(c) for c in ch)),
+            "@expected_accepted %d" % acc, "@expected_staged_its %d" % staged,
+            fmt_array("expected_dEs", (repr(float(v)) for v in dEs)), "@expected_z %r" % z]
+
+    def check(t):
+        got = TR.replay_rrr_single_sk(t)
+        ok = (got["chunks"] == [int(c) for c in ch] and got["accepted"] == acc and got["staged_its"] == staged and got["min_margin"] >= 1e-9
+              and np.allclose(got["Es"], Es, rtol=1e-12, atol=1e-12) and np.allclose(got["dEs"], dEs, rtol=1e-12, atol=1e-12)
+              and abs(got["z"] - z) <= 1e-12 * max(1.0, abs(z)) and got["refreshes"] >= 3 and 0 < staged < iters)
+        return ok, "%d iterations, accepted %d, staged %d, %d refresh! calls, closest decision margin %.2e" % (iters, acc, staged, got["refreshes"], got["min_margin"])
+    return _finish(path, body, check)
+
+
 if __name__ == "__main__":
     O.build()
     for seed in range(20261003, 20261003 + 50):
@@ -123,3 +232,8 @@ if __name__ == "__main__":
             break
     else:
         raise SystemExit("no seed gave a direct-branch rrrMC tape with a safe decision margin")
+    tries = lambda f, what: next((True for seed in range(20261003, 20261003 + 400) if f(seed)), None) or (_ for _ in ()).throw(SystemExit("no seed gave " + what))
+    tries(lambda sd: write_standard_ea(os.path.join(HERE, "tape_ea_l2_d3.txt"), sd), "a GraphEA(2,3) tape with a safe margin")
+    tries(lambda sd: write_standard_sk(os.path.join(HERE, "tape_skn_n24.txt"), sd, 24, False, 1.0, 6000, 200), "a GraphSKNormal(24) tape with a swap")
+    tries(lambda sd: write_standard_sk(os.path.join(HERE, "tape_sk_n10.txt"), sd, 10, True, 1.0, 4000, 100), "a GraphSK(10) tape with a swap")
+    tries(lambda sd: write_rrr_skn(os.path.join(HERE, "tape_rrr_skn_n10.txt"), sd), "an rrrMC(GraphSKNormal(10)) tape with a safe margin")

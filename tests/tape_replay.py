@@ -298,3 +298,357 @@ def replay_rrr_quant(tape, exp=math.exp):
         acc_rate = acc_rate * (1 - lam) + (1.0 if acc else 0.0) * lam
     return {"Es": Es, "chunks": chunks_of_bits(s), "accepted": accepted, "staged_its": staged_its, "min_margin": margin,
             "sizes": [st.t for st in sets], "pos": pos[1:]}
+
+
+# ---- GraphEA{Int,(-1,1),2D}: src/graphs/EA.jl (a site may list a neighbour twice: L = 2) ------------------------------------
+def ea_unique_neighbours(A):
+    """uA (EA.jl:155-158): every second entry of the sorted neighbour tuple when the lattice has L = 2 (A[1][1] == A[1][2])."""
+    isL2 = A[0][0] == A[0][1]
+    return [list(a[::2]) if isL2 else list(a) for a in A]
+
+
+def ea_energy(A, J, s):
+    """energy (EA.jl:195-222): as GraphRRG's; resets the undo state (move_last = 0, lfields_last = 0)."""
+    E, lfields = rrg_energy(A, J, s)
+    return E, lfields, [0] * len(A), 0
+
+
+def ea_update_cache(A, uA, J, s, lfields, lfields_last, move_last, move):
+    """update_cache! (EA.jl:224-264), called AFTER the bit flip.  Returns the new move_last.  Both branches are restated: the undo
+    fast path (:231-240) swaps the two arrays over the unique neighbours and negates both entries of the moved spin; the normal
+    path (:243-259) walks ALL 2D entries of A[move], so a doubled bond (L = 2) is applied twice."""
+    if move_last == move:
+        for y in uA[move - 1]:
+            lfields[y - 1], lfields_last[y - 1] = lfields_last[y - 1], lfields[y - 1]
+        lfields[move - 1] = -lfields[move - 1]
+        lfields_last[move - 1] = -lfields_last[move - 1]
+        return move_last
+    for y in uA[move - 1]:
+        lfields_last[y - 1] = lfields[y - 1]
+    sx = s[move - 1]
+    for y, Jxy in zip(A[move - 1], J[move - 1]):
+        sxy = 1 - 2 * (sx ^ s[y - 1])
+        lfields[y - 1] = lfields[y - 1] - 4 * sxy * Jxy
+    lfm = lfields[move - 1]
+    lfields_last[move - 1] = lfm
+    lfields[move - 1] = -lfm
+    return move
+
+
+def replay_standard_mc_ea(tape):
+    """standardMC (RRRMC.jl:81-127) on GraphEA{Int,(-1,1),2D}(A, J) with the draws of the tape."""
+    N, K = int(tape["N"]), int(tape["K"])
+    beta, iters, step = float(tape["beta"]), int(tape["iters"]), int(tape["step"])
+    A = [[int(v) for v in tape["A"][x * K:(x + 1) * K]] for x in range(N)]
+    J = [[int(v) for v in tape["J"][x * K:(x + 1) * K]] for x in range(N)]
+    uA = ea_unique_neighbours(A)
+    s = bits_of_chunks([int(c, 16) for c in tape["C0"]], N)
+    sites = [int(v) for v in tape["sites"]]
+    us = [float(v) for v in tape["uniforms"]]
+    E, lfields, lfields_last, move_last = ea_energy(A, J, s)
+    Es, accepted, flips, undos, min_margin = [], 0, [], 0, float("inf")
+    for it in range(1, iters + 1):
+        if it % step == 0:
+            Es.append(E)
+        i = sites[it - 1]
+        dE = -lfields[i - 1]                               # delta_energy, EA.jl:266-275
+        x = -beta * dE
+        ok = x >= 0
+        if not ok:
+            p = math.exp(x)
+            ok = us[it - 1] < p
+            min_margin = min(min_margin, abs(us[it - 1] - p) / p)
+        flips.append(1 if ok else 0)
+        if not ok:
+            continue
+        s[i - 1] ^= 1                                      # spinflip!, Interface.jl:89-92
+        undos += move_last == i
+        move_last = ea_update_cache(A, uA, J, s, lfields, lfields_last, move_last, i)
+        E += dE
+        accepted += 1
+    E1, lf1 = rrg_energy(A, J, s)
+    assert E == E1 and lfields == lf1                      # tracked E == energy(X, C) (test/runtests.jl:12-20), cache == recomputation
+    return {"Es": Es, "chunks": chunks_of_bits(s), "accepted": accepted, "flips": flips, "undos": undos, "min_margin": min_margin}
+
+
+# ---- GraphSKNormal: src/graphs/SK.jl:170-297 ----------------------------------------------------------------------------------
+class SKNormal:
+    """J = N rows of Float64; cache = (lfields, lfields_last, move_last).  delta_energy(i) = +lfields[i] (SK.jl:278-284)."""
+
+    def __init__(self, J):
+        self.N, self.J = len(J), J
+        self.lfields, self.lfields_last, self.move_last, self.swaps = [0.0] * self.N, [0.0] * self.N, 0, 0
+
+    def energy(self, s):                                   # SK.jl:212-237
+        n = 0.0
+        for i in range(self.N):
+            Ji, si, lf = self.J[i], s[i], 0.0
+            for j in range(self.N):
+                lf += (1 - 2 * (si ^ s[j])) * Ji[j]
+            self.lfields[i] = 2 * lf
+            n -= lf
+        n /= 2
+        self.move_last = 0
+        self.lfields_last = [0.0] * self.N
+        return n
+
+    def update_cache(self, s, move):                       # SK.jl:239-276, after the flip
+        if self.move_last == move:
+            self.lfields, self.lfields_last = self.lfields_last, self.lfields      # the whole arrays swap; move_last stays
+            self.swaps += 1
+            return
+        Ji, si = self.J[move - 1], s[move - 1]
+        lfm = self.lfields[move - 1]
+        for j in range(self.N):
+            Jsij = (1 - 2 * (si ^ s[j])) * Ji[j]
+            lfj = self.lfields[j]
+            self.lfields_last[j] = lfj
+            self.lfields[j] = lfj + 4 * Jsij
+        self.lfields_last[move - 1] = lfm
+        self.lfields[move - 1] = -lfm
+        self.move_last = move
+
+    def delta_energy(self, s, move):
+        return self.lfields[move - 1]
+
+    def spinflip(self, s, move):                           # Interface.jl:89-92
+        s[move - 1] ^= 1
+        self.update_cache(s, move)
+
+
+class SKBinary:
+    """GraphSK (SK.jl:28-165): J = N rows of bits (coupling = (2 J_ij - 1) / sqrt(N)), integer cache, delta_energy = lfields / sN."""
+
+    def __init__(self, Jbits):
+        self.N, self.J, self.sN = len(Jbits), Jbits, math.sqrt(len(Jbits))
+        self.lfields, self.lfields_last, self.move_last, self.swaps = [0] * self.N, [0] * self.N, 0, 0
+
+    def energy(self, s):                                   # SK.jl:62-96
+        N = self.N
+        n = -2 * sum(s)
+        for i in range(N):
+            sc = sum(a ^ b for a, b in zip(self.J[i], s))
+            si = s[i]
+            lf = -(2 * si - 1) * (N - 1 - 2 * sc)
+            self.lfields[i] = 2 * (-lf + 2 * si)
+            n += lf
+        assert n % 2 == 0
+        n //= 2
+        self.move_last = 0
+        self.lfields_last = [0] * N
+        return n / self.sN
+
+    def update_cache(self, s, move):                       # SK.jl:98-135
+        if self.move_last == move:
+            self.lfields, self.lfields_last = self.lfields_last, self.lfields
+            self.swaps += 1
+            return
+        Ji, si = self.J[move - 1], s[move - 1]
+        lfm = self.lfields[move - 1]
+        for j in range(self.N):
+            Jsij = si ^ s[j] ^ Ji[j]
+            lfj = self.lfields[j]
+            self.lfields_last[j] = lfj
+            self.lfields[j] = lfj + 8 * Jsij - 4
+        self.lfields_last[move - 1] = lfm
+        self.lfields[move - 1] = -lfm
+        self.move_last = move
+
+    def delta_energy(self, s, move):                       # SK.jl:137-140
+        return self.lfields[move - 1] / self.sN
+
+    def spinflip(self, s, move):
+        s[move - 1] ^= 1
+        self.update_cache(s, move)
+
+
+def _sk_graph(tape):
+    N = int(tape["N"])
+    if tape["kind"].endswith("skb"):
+        rows = [int(c, 16) for c in tape["J_chunks"]]
+        nch = (N + 63) // 64
+        return SKBinary([bits_of_chunks(rows[i * nch:(i + 1) * nch], N) for i in range(N)])
+    Jf = [float(v) for v in tape["J"]]
+    return SKNormal([Jf[i * N:(i + 1) * N] for i in range(N)])
+
+
+def replay_standard_mc_sk(tape):
+    """standardMC (RRRMC.jl:81-127) on GraphSKNormal(J) / GraphSK(J) with the draws of the tape (uniform consulted only when dE > 0)."""
+    N = int(tape["N"])
+    beta, iters, step = float(tape["beta"]), int(tape["iters"]), int(tape["step"])
+    X = _sk_graph(tape)
+    s = bits_of_chunks([int(c, 16) for c in tape["C0"]], N)
+    sites = [int(v) for v in tape["sites"]]
+    us = [float(v) for v in tape["uniforms"]]
+    E = X.energy(s)
+    Es, accepted, flips, min_margin = [], 0, [], float("inf")
+    for it in range(1, iters + 1):
+        if it % step == 0:
+            Es.append(E)
+        i = sites[it - 1]
+        dE = X.delta_energy(s, i)
+        x = -beta * dE
+        ok = x >= 0
+        if not ok:
+            p = math.exp(x)
+            ok = us[it - 1] < p
+            min_margin = min(min_margin, abs(us[it - 1] - p) / p)
+        flips.append(1 if ok else 0)
+        if not ok:
+            continue
+        X.spinflip(s, i)
+        E += dE
+        accepted += 1
+    lf_live = list(X.lfields)
+    E1 = X.energy(s)                                        # the reference's own test: abs(E - energy(X, C)) < 1e-11 scaled (test/runtests.jl:12-20)
+    assert abs(E - E1) < 1e-9 and all(abs(a - b) < 1e-9 for a, b in zip(lf_live, X.lfields))
+    return {"Es": Es, "chunks": chunks_of_bits(s), "accepted": accepted, "flips": flips, "swaps": X.swaps, "min_margin": min_margin,
+            "lfields": lf_live}
+
+
+# ---- DynamicSampler (src/DynamicSamplers.jl) + DeltaECacheCont (src/DeltaE.jl:297-410) + rrrMC(SingleGraph) (src/RRRMC.jl:149-219) ----
+class DynamicSampler:
+    def __init__(self, v):                                  # DynamicSamplers.jl:34-51
+        self.N = len(v)
+        self.levs = max(0, math.ceil(math.log2(self.N)))
+        N2 = 2 ** self.levs
+        self.v = list(v) + [0.0] * (N2 - self.N)
+        self.ps = [0.0] * (N2 - 1)
+        self.tinds, self.tpos = self.buildtable(self.levs)
+        self.z, self.trefresh, self.refreshes, self.margin = 0.0, 0, 0, float("inf")
+        self.refresh()
+        self.refreshes = 0
+
+    @staticmethod
+    def buildtable(levs):                                   # :54-82 (1-based tables kept 1-based: index 0 unused)
+        N2 = 2 ** levs
+        tinds, tpos = [0] * (N2 + 2), [0]
+        j0 = 1
+        for i in range(1, N2 + 1):
+            tinds[i] = j0
+            j1, k, u, off = j0, 0, 1 << (levs - 1) if levs > 0 else 0, 1
+            for _ in range(levs):
+                if (i - 1) & u == 0:
+                    tpos.append(off + k)
+                    j1 += 1
+                    k *= 2
+                else:
+                    k = 2 * k + 1
+                u >>= 1
+                off *= 2
+            j0 = j1
+        tinds[N2 + 1] = j0
+        return tinds, tpos
+
+    def refresh(self):                                      # :84-98
+        z = 0.0
+        for x in self.v:                                    # sum(v) (Julia sums pairwise: last-bit differences, inside the tapes' margins)
+            z += x
+        self.z = z
+        self.ps = [0.0] * len(self.ps)
+        for i in range(1, self.N + 1):
+            for j in range(self.tinds[i], self.tinds[i + 1]):
+                self.ps[self.tpos[j] - 1] += self.v[i - 1]
+        self.trefresh = 0
+        self.refreshes += 1
+
+    def getel(self, x):                                     # :130-152 (the precision-loss branch must not be reached by a tape)
+        x *= self.z
+        k, off = 0, 1
+        for _ in range(self.levs):
+            p = self.ps[off + k - 1]
+            self.margin = min(self.margin, abs(x - p) / self.z)          # how close the walk came to taking the other branch
+            k *= 2
+            if x > p:
+                x -= p
+                k += 1
+            off *= 2
+        assert not (k >= self.N or self.v[k] == 0), "precision-loss branch of getel"
+        return k + 1
+
+    def set(self, i, x):                                    # setindex!, :159-176
+        if self.trefresh >= max(self.N, 100):
+            self.refresh()
+        self.trefresh += 1
+        d = x - self.v[i - 1]
+        self.v[i - 1] = x
+        self.z += d
+        for j in range(self.tinds[i], self.tinds[i + 1]):
+            self.ps[self.tpos[j] - 1] += d
+
+
+def replay_rrr_single_sk(tape, exp=math.exp):
+    """rrrMC(X::SingleGraph) (RRRMC.jl:149-219) on GraphSKNormal(J) with DeltaECacheCont (DeltaE.jl:299-410): rand(dynsmp) = getel(dynsmp, u)
+    with u from the tape, `rand() < c` with the tape's acceptance uniform (drawn at every iteration, :192,202)."""
+    N = int(tape["N"])
+    beta, iters, step = float(tape["beta"]), int(tape["iters"]), int(tape["step"])
+    staged_thr, staged_thr_fact = float(tape["staged_thr"]), float(tape["staged_thr_fact"])
+    X = _sk_graph(tape)
+    s = bits_of_chunks([int(c, 16) for c in tape["C0"]], N)
+    u_move = [float(v) for v in tape["u_move"]]
+    u_acc = [float(v) for v in tape["u_accept"]]
+    prior = lambda x: exp(-x) if x > 0 else 1.0             # DeltaE.jl:297
+    E = X.energy(s)
+    dEs = [X.delta_energy(s, i) for i in range(1, N + 1)]   # DeltaECacheCont, DeltaE.jl:304-313
+    ds = DynamicSampler([prior(beta * d) for d in dEs])
+    neighbors = lambda i: [j for j in range(1, N + 1) if j != i]          # AllButOne(N, i), SK.jl:297
+    lam = staged_thr_fact / N
+    Es, accepted, staged_its, acc_rate, margin = [], 0, 0, 0.5, float("inf")
+
+    def apply_move(move):                                   # DeltaE.jl:379-410 (inner graph of a SingleGraph = itself)
+        X.spinflip(s, move)
+        z = ds.z
+        d = X.delta_energy(s, move)
+        dEs[move - 1] = d
+        ds.set(move, prior(beta * d))
+        for j in neighbors(move):
+            d = X.delta_energy(s, j)
+            dEs[j - 1] = d
+            ds.set(j, prior(beta * d))
+        return z / ds.z
+
+    for it in range(1, iters + 1):
+        if it % step == 0:
+            Es.append(E)
+        acc = False
+        if acc_rate < staged_thr:
+            staged_its += 1
+            z = ds.z                                        # step_rrr, RRRMC.jl:131-138
+            move = ds.getel(u_move[it - 1])
+            dE = dEs[move - 1]
+            X.spinflip(s, move)                             # compute_staged!, DeltaE.jl:357-374
+            staged = []
+            d = X.delta_energy(s, move)
+            staged.append((move, d, prior(beta * d)))
+            for j in neighbors(move):
+                d = X.delta_energy(s, j)
+                staged.append((j, d, prior(beta * d)))
+            X.spinflip(s, move)
+            zp = ds.z                                       # compute_reverse_probabilities!, :345-355
+            for j, _, p in staged:
+                zp += p - ds.v[j - 1]
+            zp = min(max(zp, 2.2250738585072014e-308), float(N))
+            c = z / zp
+            margin = min(margin, abs(u_acc[it - 1] - c) / c)
+            if u_acc[it - 1] < c:
+                X.spinflip(s, move)
+                for j, d, p in staged:                      # apply_staged!, :335-343
+                    dEs[j - 1] = d
+                    ds.set(j, p)
+                E += dE
+                accepted += 1
+                acc = True
+        else:
+            move = ds.getel(u_move[it - 1])
+            dE = dEs[move - 1]
+            c = apply_move(move)
+            margin = min(margin, abs(u_acc[it - 1] - c) / c)
+            if u_acc[it - 1] < c:
+                E += dE
+                accepted += 1
+                acc = True
+            else:
+                apply_move(move)
+        acc_rate = acc_rate * (1 - lam) + (1.0 if acc else 0.0) * lam
+    return {"Es": Es, "chunks": chunks_of_bits(s), "accepted": accepted, "staged_its": staged_its, "min_margin": min(margin, ds.margin),
+            "dEs": dEs, "z": ds.z, "refreshes": ds.refreshes, "swaps": X.swaps}

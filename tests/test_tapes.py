@@ -15,6 +15,8 @@ import tape_replay as TR
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 STD, QNT, QDIR = (os.path.join(GOLD, f) for f in ("tape_rrg_n128.txt", "tape_quant_nk16_m4.txt", "tape_quant_direct.txt"))
+# round 3: the Float64 / doubled-bond / undo-path models (where an order-of-operations slip would hide)
+EA2, SKN, SKB, RSKN = (os.path.join(GOLD, f) for f in ("tape_ea_l2_d3.txt", "tape_skn_n24.txt", "tape_sk_n10.txt", "tape_rrr_skn_n10.txt"))
 
 
 def _graph(t, n, K):
@@ -152,3 +154,101 @@ def test_hip_library_reproduces_the_rrr_quant_tapes(pkg, path):
     assert int(acc[0]) == int(t["expected_accepted"]) and int(staged[0]) == int(t["expected_staged_its"])
     assert [int(c) for c in C1.s[0]] == [int(c, 16) for c in t["expected_chunks"]]
     assert [int(v) + 1 for v in pos[0]] == [int(v) for v in t["expected_pos"]] and [int(v) for v in sizes[0]] == [int(v) for v in t["expected_sizes"]]
+
+
+# ---- round 3 tapes: GraphEA(2, 3) (doubled bonds + undo fast path), GraphSKNormal(24) and binary GraphSK(10) (whole-array swap), rrrMC on
+#      GraphSKNormal(10) through DeltaECacheCont / DynamicSampler (refresh! included) ---------------------------------------------------------
+def _floats(v):
+    return [float(x) for x in v]
+
+
+def test_python_replay_reproduces_the_ea_l2_tape():
+    t = TR.read_tape(EA2)
+    got = TR.replay_standard_mc_ea(t)
+    assert got["Es"] == [int(v) for v in t["expected_Es"]] and got["chunks"] == [int(c, 16) for c in t["expected_chunks"]]
+    assert got["accepted"] == int(t["expected_accepted"]) and got["flips"] == [int(v) for v in t["expected_flips"]]
+    assert got["min_margin"] > 1e-9
+    assert got["undos"] >= 5                                   # update_cache!'s undo branch (EA.jl:231-240) is part of the tape
+    A = [[int(v) for v in t["A"][x * 6:(x + 1) * 6]] for x in range(8)]
+    assert all(a[0] == a[1] and a[2] == a[3] and a[4] == a[5] for a in A)          # every bond doubled (L = 2)
+
+
+@pytest.mark.parametrize("path", [SKN, SKB])
+def test_python_replay_reproduces_the_sk_tapes(path):
+    t = TR.read_tape(path)
+    got = TR.replay_standard_mc_sk(t)
+    assert got["Es"] == _floats(t["expected_Es"])              # the same sequence of IEEE operations: equal bit for bit
+    assert got["chunks"] == [int(c, 16) for c in t["expected_chunks"]] and got["accepted"] == int(t["expected_accepted"])
+    assert got["lfields"] == _floats(t["expected_lfields"])
+    assert got["swaps"] == int(t["expected_swaps"]) >= 1       # a consecutive accepted pair at one site: the array swap of SK.jl:247-250 / :106-109
+    assert got["min_margin"] > 1e-9
+
+
+def test_python_replay_reproduces_the_rrr_sknormal_tape():
+    t = TR.read_tape(RSKN)
+    got = TR.replay_rrr_single_sk(t)
+    assert got["chunks"] == [int(c, 16) for c in t["expected_chunks"]]
+    assert got["accepted"] == int(t["expected_accepted"]) and got["staged_its"] == int(t["expected_staged_its"])
+    np.testing.assert_allclose(got["Es"], _floats(t["expected_Es"]), rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(got["dEs"], _floats(t["expected_dEs"]), rtol=1e-12, atol=1e-12)
+    assert abs(got["z"] - float(t["expected_z"])) < 1e-12
+    assert got["refreshes"] >= 3 and 0 < got["staged_its"] < int(t["iters"])        # refresh! and both branches of the sampler are on the tape
+    assert got["min_margin"] > 1e-9
+
+
+def test_oracle_reproduces_the_round3_tapes(oracle):
+    t = TR.read_tape(EA2)
+    N, K, seed = int(t["N"]), int(t["K"]), int(t["seed"])
+    A, J = _graph(t, N, K)
+    assert (A == oracle.gen_ea(int(t["L"]), int(t["D"]))).all() and (J == oracle.gen_couplings(A, seed)).all()
+    C0 = np.array([int(c, 16) for c in t["C0"]], np.uint64)
+    o = oracle.standard_mc_sparse(A, J, float(t["beta"]), int(t["iters"]), int(t["step"]), seed, C0, form="ea")
+    assert [int(e) for e in o[0]] == [int(v) for v in t["expected_Es"]] and o[2] == int(t["expected_accepted"])
+    assert [int(c) for c in o[1]] == [int(c, 16) for c in t["expected_chunks"]]
+    for path, run, gen in ((SKN, oracle.standard_mc_skn, oracle.gen_sk_gauss), (SKB, oracle.standard_mc_skb, oracle.gen_sk_binary)):
+        t = TR.read_tape(path)
+        N, seed = int(t["N"]), int(t["seed"])
+        Jx = gen(N, seed)
+        C0 = np.array([int(c, 16) for c in t["C0"]], np.uint64)
+        o = run(Jx, float(t["beta"]), int(t["iters"]), int(t["step"]), seed, C0)
+        assert [float(e) for e in o[0]] == _floats(t["expected_Es"]) and o[2] == int(t["expected_accepted"])
+        assert [int(c) for c in o[1]] == [int(c, 16) for c in t["expected_chunks"]] and [float(v) for v in o[3]] == _floats(t["expected_lfields"])
+    t = TR.read_tape(RSKN)
+    N, seed = int(t["N"]), int(t["seed"])
+    C0 = np.array([int(c, 16) for c in t["C0"]], np.uint64)
+    o = oracle.rrr_mc_skn(oracle.gen_sk_gauss(N, seed), float(t["beta"]), int(t["iters"]), int(t["step"]), seed, C0,
+                          staged_thr=float(t["staged_thr"]), staged_thr_fact=float(t["staged_thr_fact"]), want_cache=True)
+    assert [float(e) for e in o[0]] == _floats(t["expected_Es"]) and [int(c) for c in o[1]] == [int(c, 16) for c in t["expected_chunks"]]
+    assert o[2] == int(t["expected_accepted"]) and o[3] == int(t["expected_staged_its"]) and o[5] == float(t["expected_z"])
+
+
+@pytest.mark.gpu
+def test_hip_library_reproduces_the_round3_tapes(pkg):
+    t = TR.read_tape(EA2)
+    seed = int(t["seed"])
+    X = pkg.GraphEA(int(t["L"]), int(t["D"]), seed=seed)
+    with pkg.Engine(X, 32) as eng:
+        eng.seed(seed); eng.init_spins_random()
+        assert [int(c) for c in eng.get_config().s[0]] == [int(c, 16) for c in t["C0"]]
+        Es, acc = eng.standard_mc(float(t["beta"]), int(t["iters"]), int(t["step"]))
+        assert [int(e) for e in Es[0]] == [int(v) for v in t["expected_Es"]] and int(acc[0]) == int(t["expected_accepted"])
+        assert [int(c) for c in eng.get_config().s[0]] == [int(c, 16) for c in t["expected_chunks"]]
+    for path, G in ((SKN, pkg.GraphSKNormal), (SKB, pkg.GraphSK)):
+        t = TR.read_tape(path)
+        seed = int(t["seed"])
+        with pkg.Engine(G(int(t["N"]), seed=seed), 8) as eng:
+            eng.seed(seed); eng.init_spins_random()
+            assert [int(c) for c in eng.get_config().s[0]] == [int(c, 16) for c in t["C0"]]
+            Es, acc = eng.standard_mc(float(t["beta"]), int(t["iters"]), int(t["step"]))
+            assert [float(e) for e in Es[0]] == _floats(t["expected_Es"]) and int(acc[0]) == int(t["expected_accepted"])
+            assert [int(c) for c in eng.get_config().s[0]] == [int(c, 16) for c in t["expected_chunks"]]
+            assert [float(v) for v in eng.fields()[0]] == _floats(t["expected_lfields"])
+    t = TR.read_tape(RSKN)
+    seed = int(t["seed"])
+    with pkg.Engine(pkg.GraphSKNormal(int(t["N"]), seed=seed), 8) as eng:
+        eng.seed(seed); eng.init_spins_random()
+        Es, acc, staged = eng.rrr_mc(float(t["beta"]), int(t["iters"]), int(t["step"]), staged_thr=float(t["staged_thr"]),
+                                     staged_thr_fact=float(t["staged_thr_fact"]))
+        assert [float(e) for e in Es[0]] == _floats(t["expected_Es"])
+        assert int(acc[0]) == int(t["expected_accepted"]) and int(staged[0]) == int(t["expected_staged_its"])
+        assert [int(c) for c in eng.get_config().s[0]] == [int(c, 16) for c in t["expected_chunks"]]
