@@ -261,6 +261,13 @@ RRRMC_API int32_t rrrmc_standard_mc_fast_async(rrrmc_ctx *ctx, double beta, int6
  * from it — tracked energy, local fields, undo record, move_last — so that a run cut into pieces at the hook points is bit for bit the
  * run made in one call.  rrrmc_tracked_energy_f64 reads that tracked energy (what the reference hands to its hook), R doubles. */
 RRRMC_API int32_t rrrmc_set_resume(rrrmc_ctx *ctx, int32_t on);
+/* Debug mode: the reference's latent consistency checks as a switch a user can turn on (its commented-out asserts in update_cache!,
+ * src/graphs/RRG.jl:229-231, SK.jl:125-130, 268-273, and its test suite's hook, test/runtests.jl:12-20).  on != 0: after EVERY standardMC
+ * call the library recomputes energy(X, C) of every replica from the configuration on the device and compares it with the energy the
+ * sampler tracked (exactly for RRRMC_MODEL_SPARSE_PM1; within 1e-10 N for RRRMC_MODEL_SK_NORMAL, where the cached local fields are
+ * compared with recomputed ones too); the following rrrmc_sync (or any synchronous call) returns RRRMC_ERR_STATE and names a replica
+ * if any value differs.  Costs one energy evaluation per call; off by default. */
+RRRMC_API int32_t rrrmc_set_debug_checks(rrrmc_ctx *ctx, int32_t on);
 RRRMC_API int32_t rrrmc_tracked_energy_f64(rrrmc_ctx *ctx, double *E_out);
 
 /* Timing of the last sampling call measured with HIP events on the ctx's stream:

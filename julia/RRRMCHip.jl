@@ -201,6 +201,9 @@ function energies(ctx::Ctx)
 end
 
 sync(ctx::Ctx) = check(ccall((:rrrmc_sync, LIB), Int32, (Ptr{Cvoid},), ctx.p), ctx.p)
+"debug mode: after every standardMC call the library re-runs `energy` (and compares the cached fields) on the device, as the reference's
+commented-out asserts in update_cache! would (src/graphs/RRG.jl:229-231, SK.jl:268-273); a mismatch throws at the next sync"
+debug_checks!(ctx::Ctx, on::Bool = true) = check(ccall((:rrrmc_set_debug_checks, LIB), Int32, (Ptr{Cvoid}, Int32), ctx.p, on ? 1 : 0), ctx.p)
 
 # results of the last sampling call: Es (samples × R, the graph's ET), accepted (R)
 function fetch(ctx::Ctx, nsamples::Integer)

@@ -57,7 +57,9 @@ def lib():
     global _lib, flavour
     if _lib is None:
         so = build()
-        if os.environ.get("RRRMC_ORACLE_NATIVE") == "1":
+        if os.environ.get("RRRMC_ORACLE_LIB"):          # another build of the same sources (tests/test_sanitizers.py: the ASan/UBSan one)
+            so, flavour = os.environ["RRRMC_ORACLE_LIB"], "override"
+        elif os.environ.get("RRRMC_ORACLE_NATIVE") == "1":
             so = build_native()
             flavour = "native" if "_native_" in os.path.basename(so) else flavour
         L = C.CDLL(so)

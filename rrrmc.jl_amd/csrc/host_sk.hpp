@@ -131,6 +131,37 @@ int32_t sk_run_energy(rrrmc_ctx* ctx)
     return RRRMC_OK;
 }
 
+// debug mode (rrrmc_set_debug_checks) after a standardMC call on GraphSKNormal: the reference's commented-out check of update_cache!
+// (SK.jl:268-273: energy(X, C) again, maximum(abs.(lfields_bk - lfields)) < 1e-10) and the test suite's tracked E == energy(X, C)
+// (test/runtests.jl:12-20), on the device: fields and energy recomputed into scratch buffers, compared element-wise
+int32_t sk_debug_check(rrrmc_ctx* ctx)
+{
+    const size_t nf = (size_t)ctx->G8 * ctx->N * kSkRB;
+    if (!ctx->dbg_flag) HIP_TRY(ctx, hipMalloc(&ctx->dbg_flag, sizeof(int32_t) * 2));
+    if (!ctx->dbg_lf) {
+        HIP_TRY(ctx, hipMalloc(&ctx->dbg_lf, sizeof(double) * nf));
+        HIP_TRY(ctx, hipMalloc(&ctx->dbg_lfl, sizeof(double) * nf));
+        HIP_TRY(ctx, hipMalloc(&ctx->dbg_E, sizeof(double) * ctx->Rpad));
+        HIP_TRY(ctx, hipMalloc(&ctx->dbg_ml, sizeof(int32_t) * ctx->Rpad));
+    }
+    hipStream_t st = ctx->stream;
+    HIP_TRY(ctx, hipMemsetAsync(ctx->dbg_flag, 0, sizeof(int32_t) * 2, st));
+    hipLaunchKernelGGL(sk_fields_kernel, dim3((unsigned)((ctx->N + 31) / 32), (unsigned)ctx->G8), dim3(256), 0, st, ctx->sk_J, ctx->sk_spins,
+                       ctx->dbg_lf, ctx->dbg_lfl, ctx->dbg_ml, (int)ctx->N);
+    HIP_TRY(ctx, hipGetLastError());
+    hipLaunchKernelGGL(sk_energy_kernel, dim3((unsigned)((ctx->Rpad + 63) / 64)), dim3(64), 0, st, ctx->dbg_lf, ctx->dbg_E, (int)ctx->N, (int)ctx->Rpad);
+    HIP_TRY(ctx, hipGetLastError());
+    if (dbg_inject()) hipLaunchKernelGGL(dbg_inject_f64_kernel, dim3(1), dim3(1), 0, st, ctx->dbg_E);                 // (RRRMC_DEBUG_INJECT=1: tests only)
+    const double tol = 1e-10 * (double)ctx->N;               // the reference's 1e-10 / 1e-11 at its test sizes, scaled with the length of the sums
+    hipLaunchKernelGGL(dbg_compare_f64_kernel, dim3((unsigned)((nf + 255) / 256)), dim3(256), 0, st, ctx->sk_lf, ctx->dbg_lf, (long long)nf, tol,
+                       (long long)ctx->N * kSkRB, (int)kSkRB, ctx->dbg_flag);
+    HIP_TRY(ctx, hipGetLastError());
+    hipLaunchKernelGGL(dbg_compare_f64_kernel, dim3((unsigned)((ctx->R + 255) / 256)), dim3(256), 0, st, ctx->sk_E, ctx->dbg_E, (long long)ctx->R, tol,
+                       (long long)ctx->Rpad, (int)ctx->Rpad, ctx->dbg_flag);
+    HIP_TRY(ctx, hipGetLastError());
+    return RRRMC_OK;
+}
+
 int32_t sk_standard_mc_async(rrrmc_ctx* ctx, double beta, int64_t iters, int64_t step)
 {
     if (iters < 0) return fail(ctx, RRRMC_ERR_INVALID_ARG, "iters must be >= 0, given %lld", (long long)iters);
@@ -224,7 +255,7 @@ int32_t sk_standard_mc_async(rrrmc_ctx* ctx, double beta, int64_t iters, int64_t
         ctx->it_done += (uint64_t)iters;
         ctx->results_valid = true;
         ctx->timing_valid = true;
-        return RRRMC_OK;
+        return ctx->debug_checks ? sk_debug_check(ctx) : RRRMC_OK;
     }
     HIP_TRY(ctx, hipEventRecord(ctx->ev_sweep[0], st));
     hipLaunchKernelGGL(sk_sweep_for(spt, nth), dim3((unsigned)ctx->G8), dim3((unsigned)nth), 0, st, P);
@@ -236,5 +267,5 @@ int32_t sk_standard_mc_async(rrrmc_ctx* ctx, double beta, int64_t iters, int64_t
     ctx->it_done += (uint64_t)iters;
     ctx->results_valid = true;
     ctx->timing_valid = true;
-    return RRRMC_OK;
+    return ctx->debug_checks ? sk_debug_check(ctx) : RRRMC_OK;
 }

@@ -61,6 +61,8 @@ int32_t fast_setup(rrrmc_ctx* ctx)
             }
     ctx->pff_nblk = nblk;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
+    // (a failure midway leaves pff_ready false: the next call starts over, so whatever an earlier attempt allocated is released first)
+    free_dev(ctx->pff_table); free_dev(ctx->pff_absJ); free_dev(ctx->pff_bond_off); free_dev(ctx->pff_thr_hi); free_dev(ctx->pff_thr_lo); free_dev(ctx->pff_flags);
     HIP_TRY(ctx, hipMalloc(&ctx->pff_table, sizeof(uint16_t) * table.size()));
     HIP_TRY(ctx, hipMalloc(&ctx->pff_absJ, sizeof(double) * etab.size()));
     HIP_TRY(ctx, hipMalloc(&ctx->pff_bond_off, sizeof(uint32_t) * bond_off.size()));

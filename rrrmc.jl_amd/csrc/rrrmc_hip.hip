@@ -79,7 +79,7 @@ struct rrrmc_ctx {
     int chunks_C = -1;
     size_t chunks_n = 0;
     bool upload_pending = false;
-    struct BatchDesc { size_t first, n; int64_t sample0; };
+    typedef ChunkBatch BatchDesc;
     std::vector<BatchDesc> chunk_batches;
     uint32_t* d_slots[2] = {nullptr, nullptr};   // double-buffered: the planner of batch b+1 overlaps the sweep of batch b
     uint32_t* d_vecs[2] = {nullptr, nullptr};
@@ -119,6 +119,7 @@ struct rrrmc_ctx {
     // ---- colour-parallel sweeps (any sparse ctx; the only sampler when lds_mode is false) ----
     bool lds_mode = true;               // the LDS-resident random-site kernel is available (the state fits the 160 KiB LDS)
     bool wide = false;                  // the neighbour table stays in HBM/L2 (longer chunks; needed for 8192 < N)
+    bool big_bufs_ready = false;        // ensure_big_buffers has run
     bool big_mode = false;              // N does not fit LDS: random-site standardMC through plan_big_kernel / big_sweep_kernel (spins in HBM/L2)
     int sweep_mode = 0;                 // sweep_kernel<K, MODE>: 0 LDS table / byte offsets, 1 HBM table / byte offsets, 2 HBM table / word indices
     int ncolors = 0;
@@ -251,6 +252,12 @@ struct rrrmc_ctx {
 
     // ---- multi-device context (rrrmc_ctx_create_multi): no device state of its own; one child context per device (own stream), replica
     //      shards of whole 32-replica groups in global-id order; every entry point forwards to the children ----
+    // ---- debug mode (rrrmc_set_debug_checks): the reference's latent consistency checks (src/graphs/RRG.jl:229-231, SK.jl:268-273),
+    //      run on the device after every standardMC call: tracked energy == energy(X, C), cached fields == recomputed fields ----
+    bool debug_checks = false;
+    int32_t* dbg_flag = nullptr;        // [2]: number of replicas that failed the last check, one of them
+    int32_t* dbg_Ei = nullptr;          // [Rpad] tracked energies (integer models)
+    double* dbg_lf = nullptr; double* dbg_lfl = nullptr; double* dbg_E = nullptr; int32_t* dbg_ml = nullptr;    // recomputed SK cache
     std::vector<rrrmc_ctx*> kids;
     std::vector<int64_t> kid_r0;        // first replica of each child, relative to this context's first
 
@@ -278,25 +285,6 @@ int32_t fail(rrrmc_ctx* ctx, int32_t code, const char* fmt, ...)
     } while (0)
 
 template <typename T> void free_dev(T*& p) { if (p) { (void)hipFree(p); p = nullptr; } }
-
-// ceil(p * 2^64) for 0 < p < 1; *always when p >= 1.  accept(x) = x >= 0 || rand() < exp(x), src/RRRMC.jl:39
-uint64_t threshold64(double p, bool* always)
-{
-    *always = false;
-    if (!(p > 0.0)) return 0;
-    if (p >= 1.0) { *always = true; return ~0ull; }
-    uint64_t bits;
-    std::memcpy(&bits, &p, 8);
-    const int bexp = (int)((bits >> 52) & 0x7ff);
-    uint64_t man = bits & ((1ull << 52) - 1);
-    int e;
-    if (bexp == 0) e = -1074; else { man |= 1ull << 52; e = bexp - 1075; }
-    const int sh = e + 64;
-    if (sh >= 0) return man << sh;
-    const int s = -sh;
-    if (s >= 64) return 1;
-    return (man + ((1ull << s) - 1)) >> s;
-}
 
 // template instantiation tables: runtime K (or sites-per-thread) -> kernel pointer
 #define RRRMC_DISPATCH_UPTO7(k, F)                                                                                     \
@@ -445,6 +433,36 @@ int32_t run_energy(rrrmc_ctx* ctx, uint8_t* d_nun)
 }
 
 
+// ---- debug mode: consistency checks on the device ----------------------------------------------------------------------------
+__global__ void dbg_compare_i32_kernel(const int32_t* a, const int32_t* b, int n, int32_t* flag)
+{
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < n && a[r] != b[r]) { atomicAdd(&flag[0], 1); flag[1] = r; }
+}
+// |a - b| <= tol * scale element-wise; replica of element e = (e / inner) * rb + e % rb (the [G][N][8] field layout; inner = N * 8)
+__global__ void dbg_compare_f64_kernel(const double* a, const double* b, long long n, double tol, long long inner, int rb, int32_t* flag)
+{
+    const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n) return;
+    const double d = a[e] - b[e];
+    if (!(d <= tol && d >= -tol)) { atomicAdd(&flag[0], 1); flag[1] = (int32_t)((e / inner) * rb + e % rb); }
+}
+__global__ void dbg_inject_i32_kernel(int32_t* a) { a[0] += 2; }          // fault injection for the test of the failing branch
+__global__ void dbg_inject_f64_kernel(double* a) { a[0] += 1.0; }
+inline bool dbg_inject() { const char* e = std::getenv("RRRMC_DEBUG_INJECT"); return e && e[0] == '1'; }
+// after a standardMC call of the +-J model: d_E (tracked) against energy(X, C) recomputed from the spins
+int32_t debug_check_pm1(rrrmc_ctx* ctx)
+{
+    if (!ctx->dbg_flag) { HIP_TRY(ctx, hipMalloc(&ctx->dbg_flag, sizeof(int32_t) * 2)); HIP_TRY(ctx, hipMalloc(&ctx->dbg_Ei, sizeof(int32_t) * ctx->Rpad)); }
+    HIP_TRY(ctx, hipMemsetAsync(ctx->dbg_flag, 0, sizeof(int32_t) * 2, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->dbg_Ei, ctx->d_E, sizeof(int32_t) * ctx->Rpad, hipMemcpyDeviceToDevice, ctx->stream));
+    if (dbg_inject()) hipLaunchKernelGGL(dbg_inject_i32_kernel, dim3(1), dim3(1), 0, ctx->stream, ctx->dbg_Ei);       // (RRRMC_DEBUG_INJECT=1: tests only)
+    const int32_t rc = run_energy_bs(ctx, nullptr);          // d_E = energy(X, C): equal to the tracked values, or the flag says so
+    if (rc) return rc;
+    hipLaunchKernelGGL(dbg_compare_i32_kernel, dim3((unsigned)((ctx->R + 255) / 256)), dim3(256), 0, ctx->stream, ctx->dbg_Ei, ctx->d_E, (int)ctx->R, ctx->dbg_flag);
+    HIP_TRY(ctx, hipGetLastError());
+    return RRRMC_OK;
+}
 #include "host_sk.hpp"
 #include "host_spf.hpp"
 #include "host_dbl.hpp"
@@ -459,54 +477,11 @@ int32_t prepare_chunk_list(rrrmc_ctx* ctx, int64_t iters, int64_t step, int C, b
     // ChunkDesc::g0 is relative to the call (the kernels add gbase = it_done), so the list depends on (iters, step, C) only:
     // back-to-back calls of one shape reuse the list already on the device.  A new shape rewrites the pinned staging buffer —
     // only after the previous upload from it has completed (several async calls may be queued behind each other).
-    const int64_t nsamp = iters / step;
     const bool reuse = ctx->chunks_iters == iters && ctx->chunks_step == step && ctx->chunks_C == C;
     if (!reuse) {
         std::vector<ChunkDesc> chunks;
-        chunks.reserve((size_t)(iters / C + nsamp + 2));
-        // Every step of the sweep kernel costs about a microsecond whatever its chunk holds, so the iterations between two cuts
-        // (sample points, the end of the call) are divided into the FEWEST chunks of at most C and those are made equally long
-        for (int64_t cur = 1; cur <= iters;) {
-            const int64_t next_sample = (cur / step + 1) * step;
-            int64_t seg_end = next_sample;                        // exclusive end of the segment that may be chunked freely
-            if (seg_end > iters + 1) seg_end = iters + 1;
-            const int64_t seg = seg_end - cur, nch = (seg + C - 1) / C;
-            int64_t len = (seg + nch - 1) / nch;                  // ceil(seg / nch) <= C: the remaining chunks re-balance themselves
-            if (nch > 1) {
-                // the producers work in 64-slot tasks: whole tasks wherever the segment allows (4096 = 1408 + 1344 + 1344 is 64 tasks,
-                // three times 1366 would be 66)
-                const int64_t up = (len + kWave - 1) / kWave * kWave, down = len / kWave * kWave;
-                if (up <= C) len = up;
-                else if (down > 0 && seg - down <= (nch - 1) * (int64_t)C) len = down;
-            }
-            int64_t end = cur + len;
-            if (end > seg_end) end = seg_end;
-            ChunkDesc cd{};
-            cd.g0 = (uint64_t)cur;
-            cd.count = (uint32_t)(end - cur);
-            cd.flags = (cur % step == 0) ? kChunkSampleBefore : 0u;
-            chunks.push_back(cd);
-            cur = end;
-        }
+        plan_chunk_list(iters, step, C, kWave, ctx->batch_slots_max, ctx->batch_chunks_max, ctx->batch_first_chunks, chunks, ctx->chunk_batches);
         const size_t nch_all = chunks.size();
-        // batches: bounded by the plan buffers; slot_base restarts in every batch
-        ctx->chunk_batches.clear();
-        {
-            size_t first = 0;
-            int64_t slots = 0, samples = 0, sample0 = 0;
-            for (size_t c = 0; c < nch_all; ++c) {
-                // (a short first batch where the plan of a batch is expensive: the sweep starts after plan(0), every later plan overlaps a sweep)
-                const int64_t cmax = (first == 0 && ctx->batch_first_chunks > 0) ? ctx->batch_first_chunks : ctx->batch_chunks_max;
-                if (c > first && (slots + chunks[c].count > ctx->batch_slots_max || (int64_t)(c - first) >= cmax)) {
-                    ctx->chunk_batches.push_back({first, c - first, sample0});
-                    first = c; slots = 0; sample0 = samples;
-                }
-                chunks[c].slot_base = (uint32_t)slots;
-                slots += chunks[c].count;
-                if (chunks[c].flags & kChunkSampleBefore) samples += 1;
-            }
-            if (nch_all > first) ctx->chunk_batches.push_back({first, nch_all - first, sample0});
-        }
         ctx->chunks_iters = -1;                                   // invalid until the new list is staged
         if (ctx->upload_pending) { HIP_TRY(ctx, hipEventSynchronize(ctx->ev_upload)); ctx->upload_pending = false; }
         if (nch_all > ctx->chunks_cap) {
@@ -728,14 +703,9 @@ int32_t rrrmc_ctx_create(rrrmc_ctx** out, int32_t model, int64_t N, int64_t K, i
     for (int i = 0; i < 2; ++i) {
         CREATE_TRY(hipMalloc(&ctx->d_slots[i], sizeof(uint32_t) * kMaxSlotsPerBatch));
         CREATE_TRY(hipMalloc(&ctx->d_vecs[i], sizeof(uint32_t) * kMaxSlotsPerBatch));
-        if (ctx->big_mode) CREATE_TRY(hipMalloc(&ctx->d_nbrs[i], sizeof(uint32_t) * kMaxSlotsPerBatch * big_rec_words((int)K)));
-        if (ctx->big_masks) CREATE_TRY(hipMalloc(&ctx->d_masks[i], sizeof(uint32_t) * (ctx->big_cm ? (32 >> ctx->big_lgr) : 4) * ctx->batch_slots_max * ctx->G));
     }
-    if (ctx->big_masks) {
-        const int64_t S = 32 >> ctx->big_lgr;
-        CREATE_TRY(hipMalloc(&ctx->d_bigimg, sizeof(uint32_t) * ctx->G * S * ((N + S - 1) / S)));
-        CREATE_TRY(raise_lds_attr(reinterpret_cast<const void*>(ctx->big_cm ? big_applyc_for_K((int)K) : big_apply_for_K((int)K)), big_lds_bytes(N, ctx->big_lgr)));
-    }
+    // (the record / mask / image buffers of the big-N random-site path — up to 2 x 128 MiB + 2 x 2 GiB — are allocated by its first
+    //  call, ensure_big_buffers: a context that only runs colour sweeps never pays for them)
     CREATE_TRY(hipStreamCreateWithFlags(&ctx->plan_stream, hipStreamNonBlocking));
     CREATE_TRY(hipEventCreateWithFlags(&ctx->ev_upload, hipEventDisableTiming));
     CREATE_TRY(hipMemset(ctx->d_spins, 0, sizeof(uint32_t) * ctx->G * N));
@@ -784,6 +754,7 @@ void rrrmc_ctx_destroy(rrrmc_ctx* ctx)
     free_dev(ctx->snap); free_dev(ctx->d_pairs); free_dev(ctx->d_ovl); free_dev(ctx->d_qobs);
     for (int i = 0; i < 2; ++i) { free_dev(ctx->d_slots[i]); free_dev(ctx->d_vecs[i]); free_dev(ctx->d_nbrs[i]); free_dev(ctx->d_masks[i]); }
     free_dev(ctx->d_bigimg);
+    free_dev(ctx->dbg_flag); free_dev(ctx->dbg_Ei); free_dev(ctx->dbg_lf); free_dev(ctx->dbg_lfl); free_dev(ctx->dbg_E); free_dev(ctx->dbg_ml);
     if (ctx->plan_stream) { (void)hipStreamSynchronize(ctx->plan_stream); (void)hipStreamDestroy(ctx->plan_stream); }
     if (ctx->ev_upload) (void)hipEventDestroy(ctx->ev_upload);
     for (hipEvent_t e : ctx->ev_plan) (void)hipEventDestroy(e);
@@ -1104,6 +1075,27 @@ int32_t rrrmc_get_fields(rrrmc_ctx* ctx, int64_t* lfields_out)
     return RRRMC_OK;
 }
 
+namespace {
+// buffers of the random-site path for graphs beyond the LDS kernel, on first use
+int32_t ensure_big_buffers(rrrmc_ctx* ctx)
+{
+    if (!ctx->big_mode || ctx->big_bufs_ready) return RRRMC_OK;
+    const int64_t N = ctx->N, K = ctx->K;
+    for (int i = 0; i < 2; ++i) {
+        if (!ctx->d_nbrs[i]) HIP_TRY(ctx, hipMalloc(&ctx->d_nbrs[i], sizeof(uint32_t) * kMaxSlotsPerBatch * big_rec_words((int)K)));
+        if (ctx->big_masks && !ctx->d_masks[i])
+            HIP_TRY(ctx, hipMalloc(&ctx->d_masks[i], sizeof(uint32_t) * (ctx->big_cm ? (32 >> ctx->big_lgr) : 4) * ctx->batch_slots_max * ctx->G));
+    }
+    if (ctx->big_masks) {
+        const int64_t S = 32 >> ctx->big_lgr;
+        if (!ctx->d_bigimg) HIP_TRY(ctx, hipMalloc(&ctx->d_bigimg, sizeof(uint32_t) * ctx->G * S * ((N + S - 1) / S)));
+        HIP_TRY(ctx, raise_lds_attr(reinterpret_cast<const void*>(ctx->big_cm ? big_applyc_for_K((int)K) : big_apply_for_K((int)K)), big_lds_bytes(N, ctx->big_lgr)));
+    }
+    ctx->big_bufs_ready = true;
+    return RRRMC_OK;
+}
+}  // namespace
+
 int32_t rrrmc_standard_mc_async(rrrmc_ctx* ctx, double beta, int64_t iters, int64_t step)
 {
     RRRMC_MULTI(ctx, false, rrrmc_standard_mc_async(c, beta, iters, step));
@@ -1124,6 +1116,7 @@ int32_t rrrmc_standard_mc_async(rrrmc_ctx* ctx, double beta, int64_t iters, int6
     if (step < 1) return fail(ctx, RRRMC_ERR_INVALID_ARG, "step must be >= 1, given %lld", (long long)step);
     if (std::isnan(beta)) return fail(ctx, RRRMC_ERR_INVALID_ARG, "beta is NaN");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
+    { const int32_t rcb = ensure_big_buffers(ctx); if (rcb) return rcb; }
     const int64_t N = ctx->N, K = ctx->K;
     const int C = ctx->C;
     ctx->results_valid = false; ctx->last_call_wtm = false; ctx->last_call_eo = false;
@@ -1276,6 +1269,7 @@ int32_t rrrmc_standard_mc_async(rrrmc_ctx* ctx, double beta, int64_t iters, int6
     ctx->it_done += (uint64_t)iters;
     ctx->results_valid = true;
     ctx->timing_valid = true;
+    if (ctx->debug_checks) { rc = debug_check_pm1(ctx); if (rc) return rc; }
     return RRRMC_OK;
 }
 
@@ -1294,6 +1288,16 @@ int32_t rrrmc_set_resume(rrrmc_ctx* ctx, int32_t on)
     RRRMC_MULTI(ctx, false, rrrmc_set_resume(c, on));
     if (!ctx) return RRRMC_ERR_INVALID_ARG;
     ctx->resume = on != 0;
+    return RRRMC_OK;
+}
+
+int32_t rrrmc_set_debug_checks(rrrmc_ctx* ctx, int32_t on)
+{
+    RRRMC_MULTI(ctx, false, rrrmc_set_debug_checks(c, on));
+    if (!ctx) return RRRMC_ERR_INVALID_ARG;
+    if (ctx->model != RRRMC_MODEL_SPARSE_PM1 && ctx->model != RRRMC_MODEL_SK_NORMAL)
+        return fail(ctx, RRRMC_ERR_UNSUPPORTED, "the debug checks are wired for RRRMC_MODEL_SPARSE_PM1 and RRRMC_MODEL_SK_NORMAL");
+    ctx->debug_checks = on != 0;
     return RRRMC_OK;
 }
 
@@ -1317,6 +1321,14 @@ int32_t rrrmc_sync(rrrmc_ctx* ctx)
     if (!ctx) return RRRMC_ERR_INVALID_ARG;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->debug_checks && ctx->dbg_flag) {
+        int32_t fl[2] = {0, 0};
+        HIP_TRY(ctx, hipMemcpy(fl, ctx->dbg_flag, sizeof fl, hipMemcpyDeviceToHost));
+        HIP_TRY(ctx, hipMemset(ctx->dbg_flag, 0, sizeof fl));
+        if (fl[0])
+            return fail(ctx, RRRMC_ERR_STATE, "debug check failed for %d value(s), e.g. replica %d: the tracked energy / cached fields differ from "
+                                              "energy(X, C) recomputed from the configuration (src/graphs/RRG.jl:229-231, SK.jl:268-273)", fl[0], fl[1]);
+    }
     if (ctx->last_call_rrr && (ctx->model == RRRMC_MODEL_SK_NORMAL || ctx->model == RRRMC_MODEL_SPARSE_F64) && ctx->rs_status) {
         std::vector<int32_t> stt((size_t)ctx->R);
         HIP_TRY(ctx, hipMemcpy(stt.data(), ctx->rs_status, sizeof(int32_t) * stt.size(), hipMemcpyDeviceToHost));
@@ -1619,9 +1631,9 @@ int32_t rrrmc_ctx_create_multi(rrrmc_ctx** out, int32_t model, int64_t N, int64_
     ctx->model = model; ctx->K = K; ctx->R = R; ctx->replica0 = replica0; ctx->device = device_ids[0];
     ctx->N = model == RRRMC_MODEL_QUANT_RRG ? N * M : N;
     if (model == RRRMC_MODEL_QUANT_RRG) { ctx->qNk = N; ctx->qM = M; }
-    const int64_t groups = (R + 31) / 32;
     for (int32_t d = 0; d < ndev; ++d) {
-        const int64_t b0 = 32 * (groups * d / ndev), b1 = d + 1 == ndev ? R : std::min<int64_t>(R, 32 * (groups * (d + 1) / ndev));
+        int64_t b0 = 0, b1 = 0;
+        shard_bounds(R, ndev, d, &b0, &b1);
         if (b1 <= b0) continue;          // fewer groups than devices: this one stays idle
         rrrmc_ctx* c = nullptr;
         const int32_t rc = model == RRRMC_MODEL_QUANT_RRG

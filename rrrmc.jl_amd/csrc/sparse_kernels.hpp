@@ -16,6 +16,7 @@
 #include <stdint.h>
 
 #include "philox.hpp"
+#include "host_plan.hpp"
 
 namespace rrrmc {
 
@@ -67,16 +68,7 @@ constexpr int kMaxK = 7;                          // 3 bit planes for the unsati
 #endif
 // (K = 4: 8 rows, no change against 4; K >= 5: 6 rows measured 2 % slower than 4 — the rows are 15 VGPRs each there)
 template <int K> constexpr int sweep_rows() { return K <= 3 ? RRRMC_ROWS : (K == 4 ? (RRRMC_ROWS < 8 ? RRRMC_ROWS : 8) : (RRRMC_ROWS < 4 ? RRRMC_ROWS : 4)); }
-constexpr uint32_t kChunkSampleBefore = 1u;       // chunk flag: an energy sample is due before its first move
-
-struct ChunkDesc {
-    uint64_t g0;         // iteration (1-based, RELATIVE to the sampling call: the kernels add the call's base `gbase` = iterations done before it)
-                         // of the chunk's first attempt — the list depends on (iters, step, C) only, so back-to-back calls share one upload
-    uint32_t count;      // attempts in the chunk (<= C)
-    uint32_t slot_base;  // offset of the chunk's slots / vector table in the plan buffers
-    uint32_t nvec;       // number of consumer batches, written by plan_kernel
-    uint32_t flags;
-};
+// (ChunkDesc, kChunkSampleBefore: host_plan.hpp — HIP-free, shared with the host's chunk planner and its sanitizer build)
 
 // ---------------------------------------------------------------------------------------------------
 // plan_kernel<K>: one workgroup per chunk (state-independent: the plan is shared by every replica group).

@@ -137,6 +137,12 @@ class Engine:
         reference call: a run cut into pieces is then bit for bit the run made in one call (Float64 models; a no-op for integer ones)."""
         check(lib().rrrmc_set_resume(self._ctx, 1 if on else 0), self._ctx)
 
+    def set_debug_checks(self, on=True):
+        """After every standardMC call the library re-runs ``energy`` on the device and compares it (and, for GraphSKNormal, the cached
+        local fields) with what the sampler tracked — the reference's own commented-out asserts as a switch; a mismatch surfaces as an
+        RRRMCError (status 2) at the next sync."""
+        check(lib().rrrmc_set_debug_checks(self._ctx, 1 if on else 0), self._ctx)
+
     def tracked_energy(self):
         """The energy the sampler tracks (E += dE per accepted move, src/RRRMC.jl:117) after the last standardMC call."""
         if not self._f64:

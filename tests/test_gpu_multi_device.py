@@ -92,5 +92,5 @@ def test_multi_context_errors(pkg):
         assert Es.shape == (40, 8)
     with pkg.Engine(X, 64, devices=[0, 0]) as m:
         with pytest.raises(pkg.RRRMCError) as e:                # an error of a child comes back with the shard it happened on
-            m.standard_mc(1.0, 64, 0)
+            m.standard_mc_async(1.0, -5, 1)
         assert "device 0" in str(e.value)
