@@ -33,14 +33,14 @@ for f in find("trace/**/*kernel_trace.csv"):
         print("%-60s n=%d avg_ns=%.0f total_ms=%.3f %s" % (name[:60], len(d), sum(d) / len(d), sum(d) / 1e6, res[name]))
 print()
 print("== PMC counters: per-kernel average over dispatches ==")
-for d in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_lds"):
+for d in sorted(os.path.basename(p) for p in glob.glob(os.path.join(out, "pmc_*"))):
     for f in find(d + "/**/*counter_collection.csv"):
         agg = defaultdict(lambda: defaultdict(list))
         with open(f) as fh:
             for row in csv.DictReader(fh):
                 agg[row.get("Kernel_Name", "?")][row["Counter_Name"]].append(float(row["Counter_Value"]))
         for name, cs in agg.items():
-            if "sweep" not in name and "plan" not in name:
+            if name.startswith("__amd_rocclr") or "transpose" in name or "init_spins" in name or "spins_in" in name or "spins_out" in name:
                 continue
             print("[%s] %s" % (d, name[:70]))
             for c, v in sorted(cs.items()):

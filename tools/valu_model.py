@@ -19,9 +19,22 @@ import sys
 import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-PROF = os.path.join(ROOT, "profiles", "r02")
+PROF = os.path.join(ROOT, "profiles", os.environ.get("RRRMC_PROF_ROUND", "r03"))
+PROF_OLD = os.path.join(ROOT, "profiles", "r02")
 SIMDS = 256 * 4
-SUMMARY = sys.argv[1] if len(sys.argv) > 1 else "r02f_summary.txt"      # the rocprofv3 summary of the build being modelled
+SUMMARY = sys.argv[1] if len(sys.argv) > 1 else "r03a_summary.txt"      # the rocprofv3 summary of the build being modelled
+sys.path.insert(0, ROOT)
+
+
+def prof_file(name):
+    """newest copy of a ubench / profile output: this round's, else round 2's"""
+    p = os.path.join(PROF, name)
+    return p if os.path.exists(p) else os.path.join(PROF_OLD, name)
+
+
+def provenance():
+    import bench
+    return {"source_stamp": bench.source_stamp(), "git_commit": bench.git_head(), "summary": os.path.relpath(prof_file(SUMMARY), ROOT)}
 
 
 def kernel_isa():
@@ -43,11 +56,17 @@ def is_inst(l):
 
 def ubench_ns():
     ns = {}
-    for l in open(os.path.join(PROF, "ubench_valu_rates.txt")):
+    for l in open(prof_file("ubench_valu_rates.txt")):
         m = re.match(r"(\S+)\s+[\d.]+ ms\s+-> ([\d.]+) ns", l)
         if m:
             ns[m.group(1)] = float(m.group(2))
     return ns
+
+
+def ubench_clock_ghz():
+    """the shader clock the ubench measured for itself (s_memtime over s_memrealtime; round 3), None for an older output"""
+    g = [float(m.group(1)) for m in re.finditer(r"measured ([\d.]+) GHz", open(prof_file("ubench_valu_rates.txt")).read())]
+    return sum(g) / len(g) if g else None
 
 
 def cost_ns(op, ns):
@@ -68,7 +87,7 @@ def cost_ns(op, ns):
 
 
 def pmc():
-    txt = open(os.path.join(PROF, SUMMARY)).read()
+    txt = open(prof_file(SUMMARY)).read()
     blk = lambda tag: txt[txt.index("[%s] void rrrmc::sweep_kernel<3, 1>" % tag):]
     val = lambda tag, name: float(re.search(r"%s\s+avg=([\d.e+]+)" % name, blk(tag)).group(1))
     ns = float(re.search(r"sweep_kernel<3, 1>\(rrrmc::SweepParams\)\s+n=\d+ avg_ns=(\d+)", txt).group(1))
@@ -102,13 +121,16 @@ def main():
              "mean_issue_ns": mean_ns, "mean_issue_cycles": mean_ns * 1e-9 * clock_hz,
              "producer_task": {"valu_wave_insts": n_valu, "issue_ns_per_simd": task_ns, "mix": dict(tvalu.most_common())},
              "pmc": P,
+             # the same count at the guide's 2 cycles per wave64 VALU instruction (MI355X_MICROARCH.md), whatever the opcode
+             "valu_busy_frac_vs_guide_2cycle_under_rocprof": P["SQ_INSTS_VALU"] * 2.0 / (SIMDS * P["rocprof_avg_ns"] * 1e-9 * clock_hz),
+             "ubench_measured_clock_ghz": ubench_clock_ghz(),
              "valu_busy_frac_under_rocprof": P["SQ_INSTS_VALU"] * mean_ns * 1e-9 / (SIMDS * P["rocprof_avg_ns"] * 1e-9),
              "note": "mean issue cost = the producer task's VALU mix (ISA histogram) x tools/ubench/valu_rates.hip (8 waves per SIMD); the producers execute "
                      "~85 % of the kernel's VALU wave-instructions; SQ_ACTIVE_INST_VALU is not used: on gfx950 it counts one quad-cycle per instruction"}
     # the same task measured directly (tools/ubench/producer_task.hip: the kernel's own Philox + refinement code) at 8 waves per SIMD and
     # at the 4 waves per SIMD sweep_kernel runs with (16 waves per workgroup, one workgroup per CU): the SIMD's real throughput on this
     # dependent multiply / bit-op mix is lower at the kernel's occupancy
-    pt = os.path.join(PROF, "ubench_producer_task.txt")
+    pt = prof_file("ubench_producer_task.txt")
     if os.path.exists(pt):
         meas = {}
         for l in open(pt):
@@ -118,10 +140,13 @@ def main():
         if 4 in meas and 8 in meas:
             model["producer_task_ubench_ns"] = {"waves_per_simd_4": meas[4], "waves_per_simd_8": meas[8], "waves_per_simd_1": meas.get(1)}
             model["occupancy_factor_4_waves"] = meas[4] / meas[8]
+    model.update(provenance())
+    os.makedirs(PROF, exist_ok=True)
     json.dump(model, open(os.path.join(PROF, "valu_model.json"), "w"), indent=1)
     traffic = {"hbm_bytes_per_launch": (2 * P["FETCH_SIZE_KB"] + P["WRITE_SIZE_KB"]) * 1024.0,
-               "source": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes) of `bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-secondary`, "
-                         "profiles/r02/" + SUMMARY + "; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 tallies 128-B requests at 64 B); counters are in KiB"}
+               "source": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes) of `bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-secondary`, " \
+                         + os.path.relpath(prof_file(SUMMARY), ROOT) + "; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 tallies 128-B requests at 64 B); counters are in KiB"}
+    traffic.update(provenance())
     json.dump(traffic, open(os.path.join(PROF, "traffic.json"), "w"), indent=1)
     with open(os.path.join(PROF, "sweep31_isa_hist.txt"), "w") as f:
         f.write("# opcode histogram of sweep_kernel<3, 1> (hipcc -O3 --offload-arch=gfx950 -S), static counts\n")
