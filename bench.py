@@ -444,6 +444,35 @@ def secondary_f64_fast(pkg, O, device):
     return out
 
 
+def secondary_f8_rrr(pkg, O, device):
+    """SURVEY.md §8f rank 1 at the reference's experiment size (scripts/scripts.jl:23 test_RRG): rrrMC(X::SingleGraph) on GraphRRG(10^4, 3),
+    beta = 2, thread-per-replica kernel (rrr_sparse_kernel: DeltaECache{Int,2} + ArraySets per replica in HBM/L2)."""
+    N, K, R, beta, iters, step = 10000, 3, 4096, 2.0, 20000, 5000
+    X = pkg.GraphRRG(N, K, seed=SEED)
+    with pkg.Engine(X, R, device=device) as eng:
+        eng.seed(SEED)
+        eng.init_spins_random()
+        eng.standard_mc(beta, 20 * N, 20 * N, want_energies=False)          # a short quench: the reference's runs start from random spins too
+        eng.rrr_mc(beta, iters // 4, step, want_energies=False)
+        t0 = time.perf_counter()
+        _, acc, staged = eng.rrr_mc(beta, iters, step, want_energies=False)
+        dt = time.perf_counter() - t0
+        _, k_ms, nl = eng.last_timing()
+        C1 = eng.get_config().s[0].copy()
+    out = {"workload": "GraphRRG(N=10000,K=3,+-J) rrrMC beta=2.0, 4096 replicas, 20000 iterations per replica (after a 20-sweep Metropolis quench)",
+           "value": R * iters / dt, "unit": "iterations/s", "kernel": "rrr_sparse_kernel<false, 2, unsigned short, 8>", "avg_launch_ms": k_ms / max(nl, 1),
+           "launches": nl, "acceptance": float(acc.mean()) / iters, "staged_frac": float(staged.mean()) / iters,
+           "note": "one thread per replica, every structure of the reference (ArraySet v/pos, T, z) per replica in HBM/L2: divergent scalar code, "
+                   "bound by dependent L2 round trips; profiles/r03/f8_kernels_summary.txt holds the rocprofv3 trace and SQ counters"}
+    if O is not None:
+        with pinned_core():
+            it1, Ji = 1 << 20, X.J.astype(np.int32)
+            v, n, dt1 = timed_oracle(lambda k: O.rrr_sparse(X.A, Ji, beta, it1, it1, SEED, C1, it0=k * it1), it1)
+            out["cpu_one_core"] = {"value": v, "unit": "iterations/s", "kind": "port", "build": O.flavour,
+                                   "sample": "1 replica x %d x 2^20 iterations from a quenched configuration (%.1f s), oracle" % (n, dt1)}
+    return out
+
+
 def eng_kernel_name_quant():
     return "rrr_quant_wave_kernel" if os.environ.get("RRRMC_QUANT_NO_WAVE") != "1" else "rrr_quant_kernel<true>"
 
@@ -452,7 +481,7 @@ def secondary(pkg, O, device):
     out = {}
     for name, fn in (("c3_sk_normal", secondary_c3), ("c4_ea_checkerboard", secondary_c4), ("c4_ea_random_site", secondary_c4_random),
                      ("c5_quant_rrr", secondary_c5),
-                     ("f64_sparse_fast", secondary_f64_fast)):
+                     ("f64_sparse_fast", secondary_f64_fast), ("f8_rrr_rrg_1e4", secondary_f8_rrr)):
         t0 = time.perf_counter()
         try:
             out[name] = fn(pkg, O, device)

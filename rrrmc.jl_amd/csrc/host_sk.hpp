@@ -38,6 +38,28 @@ sk_block_fn sk_block_for(int spt, int nth)
     if (nth == 1024) return spt == 1 ? sk_block_kernel<1, 1024> : spt == 2 ? sk_block_kernel<2, 1024> : nullptr;
     return nullptr;
 }
+// two 4-replica workgroups of 256 threads per group of 8 replicas (co-resident on a compute unit: one decides while the other applies)
+sk_block_fn sk_block_half_for(int spt)
+{
+    switch (spt) {
+        case 1: return sk_block_kernel<1, 256, 4>; case 2: return sk_block_kernel<2, 256, 4>;
+        case 3: return sk_block_kernel<3, 256, 4>; case 4: return sk_block_kernel<4, 256, 4>;
+        default: return nullptr;
+    }
+}
+// Measured (2048 replicas, beta = 1, 65 536 iterations, ms per launch, whole group / split):  N = 128: 30.6 / 19.8,  256: 29.8 / 19.4,
+// 512: 26.4 / 21.5,  768: 30.7 / 24.5,  1024: 30.9 / 26.6.  Beyond N = 1024 the split build would need 512 threads and two workgroups of
+// 8 wavefronts per compute unit, i.e. 128 registers per thread for a state that takes 112 of them: whole groups there.
+// RRRMC_SK_RB = 4 / 8 forces the split / whole-group build (bit-identical; the tests compare them)
+int sk_rb_for(int64_t N)
+{
+    int rb = N <= 1024 ? 4 : 8;
+    if (const char* e = std::getenv("RRRMC_SK_RB")) {
+        const int v = std::atoi(e);
+        if (v == 8 || (v == 4 && N <= 1024)) rb = v;
+    }
+    return rb;
+}
 bool sk_legacy_forced()
 {
     const char* e = std::getenv("RRRMC_SK_LEGACY");
@@ -100,7 +122,7 @@ int32_t sk_ctx_create(rrrmc_ctx** out, int32_t model, int64_t N, int64_t R, int3
         SK_TRY(hipMemset(ctx->sk_lfl, 0, sizeof(double) * nf));
     }
     SK_TRY(hipMalloc(&ctx->sk_move_last, sizeof(int32_t) * ctx->Rpad));
-    SK_TRY(hipMalloc(&ctx->sk_spins, (size_t)ctx->G8 * N));
+    SK_TRY(hipMalloc(&ctx->sk_spins, ((size_t)ctx->G8 * N + 3) / 4 * 4));       // (whole words: sk_block_kernel<.., 4> updates its bits by word atomics)
     SK_TRY(hipMalloc(&ctx->sk_E, sizeof(double) * ctx->Rpad));
     SK_TRY(hipMalloc(&ctx->d_acc, sizeof(int64_t) * ctx->Rpad));
     SK_TRY(hipMemset(ctx->sk_spins, 0, (size_t)ctx->G8 * N));
@@ -216,7 +238,11 @@ int32_t sk_standard_mc_async(rrrmc_ctx* ctx, double beta, int64_t iters, int64_t
     P.beta = beta; P.g0 = ctx->it_done; P.iters = iters; P.step = step; P.sample0 = 0;
     P.k0 = (uint32_t)ctx->seed; P.k1 = (uint32_t)(ctx->seed >> 32); P.replica0 = ctx->replica0; P.N = (int)ctx->N;
     const int nth = sk_threads_for(ctx->N), spt = (int)((ctx->N + nth - 1) / nth);
-    const sk_block_fn blockk = sk_legacy_forced() ? nullptr : sk_block_for(spt, nth);
+    sk_block_fn blockk = sk_legacy_forced() ? nullptr : sk_block_for(spt, nth);
+    int blk_nth = nth, blk_wgs = 1;                       // threads per workgroup, workgroups per group of 8 replicas
+    if (blockk && sk_rb_for(ctx->N) == 4) {
+        if (const sk_block_fn h = sk_block_half_for((int)((ctx->N + 255) / 256))) { blockk = h; blk_nth = 256; blk_wgs = 2; }
+    }
     if (blockk && iters > 0) {
         // blocked kernel: segments of <= kSkSegIters iterations, each with its state-independent block tables (sites, coupling sub-matrices)
         const int64_t nseg = (iters + kSkSegIters - 1) / kSkSegIters;
@@ -245,7 +271,7 @@ int32_t sk_standard_mc_async(rrrmc_ctx* ctx, double beta, int64_t iters, int64_t
                                Bk.g0, n, nblk, Bk.k0, Bk.k1, Bk.N, Bk.ldJ);
             HIP_TRY(ctx, hipGetLastError());
             HIP_TRY(ctx, hipEventRecord(ctx->ev_sweep[2 * sg], st));
-            hipLaunchKernelGGL(blockk, dim3((unsigned)ctx->G8), dim3((unsigned)nth), 0, st, Bk);
+            hipLaunchKernelGGL(blockk, dim3((unsigned)(ctx->G8 * blk_wgs)), dim3((unsigned)blk_nth), 0, st, Bk);
             HIP_TRY(ctx, hipGetLastError());
             HIP_TRY(ctx, hipEventRecord(ctx->ev_sweep[2 * sg + 1], st));
         }

@@ -149,39 +149,47 @@ __device__ __forceinline__ double sk_readlane_f64(double v, int lane)
 #define SK_APPLY_ALL(M, lf, lfl, sm, d) \
     do { M(0, lf, lfl, sm, d); M(1, lf, lfl, sm, d); M(2, lf, lfl, sm, d); M(3, lf, lfl, sm, d); \
          M(4, lf, lfl, sm, d); M(5, lf, lfl, sm, d); M(6, lf, lfl, sm, d); M(7, lf, lfl, sm, d); } while (0)
+#define SK_APPLY_HALF(M, lf, lfl, sm, d) \
+    do { M(0, lf, lfl, sm, d); M(1, lf, lfl, sm, d); M(2, lf, lfl, sm, d); M(3, lf, lfl, sm, d); } while (0)
 
-template <int SPT, int NTH>
+// RB = replicas per workgroup: 8 (one workgroup = one group of the [G][N][8] state) or 4 (two workgroups per group: replicas 4h .. 4h + 3,
+// h = blockIdx.x & 1).  Two 4-replica workgroups of 256 threads per CU instead of one 8-replica workgroup of 512: each tests half as many
+// replicas per attempt, and one decides while the other applies — the phases of a workgroup are separated by barriers, two
+// independent workgroups fill each other's waits.  (The price: each loads its own rows of 4J.)
+template <int SPT, int NTH, int RB = kSkRB>
 __global__ __launch_bounds__(NTH) void sk_block_kernel(SkBlockParams P)
 {
+    static_assert(RB == 8 || RB == 4, "8 or 4 replicas per workgroup");
+    constexpr int NH = kSkRB / RB;                         // workgroups per group of 8 replicas
     constexpr int NWV = NTH / 64;                          // wavefronts
-    constexpr int RPW = NWV >= kSkRB ? 1 : kSkRB / NWV;    // replicas decided per wavefront
+    constexpr int RPW = NWV >= RB ? 1 : RB / NWV;          // replicas decided per wavefront
     constexpr int PF = SPT <= 2 ? 4 : 2;                   // attempts per group of the apply phase (two groups of rows in registers)
     constexpr int LGN = NTH == 256 ? 8 : NTH == 512 ? 9 : 10;
     __shared__ double sh_Jw[kSkW * kSkW];
-    __shared__ double sh_wf[kSkW][kSkRB], sh_wfl[kSkW][kSkRB], sh_u[kSkW][kSkRB], sh_L[kSkW][kSkRB];
+    __shared__ double sh_wf[kSkW][RB], sh_wfl[kSkW][RB], sh_u[kSkW][RB], sh_L[kSkW][RB];
     __shared__ uint32_t sh_acc[2][kSkW];
     __shared__ uint8_t sh_wsp[kSkW], sh_cslot[kSkW];
     __shared__ uint8_t sh_canon[kSkThreads * kSkMaxSPT];
     const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6), N = P.N;
-    const int grp = blockIdx.x, Rp = gridDim.x * kSkRB;
+    const int grp = blockIdx.x / NH, r8 = (blockIdx.x % NH) * RB, Rp = (gridDim.x / NH) * kSkRB;      // r8: this workgroup's first replica inside its group
 
-    double lf[SPT][kSkRB], lfl[SPT][kSkRB];
-    unsigned long long sm[SPT][kSkRB];         // spins as wave-uniform lane masks, one per (q, replica): bit l = the spin of site q * NTH + 64 wave + l
+    double lf[SPT][RB], lfl[SPT][RB];
+    unsigned long long sm[SPT][RB];         // spins as wave-uniform lane masks, one per (q, replica): bit l = the spin of site q * NTH + 64 wave + l
 #pragma unroll
     for (int q = 0; q < SPT; ++q) {
         const int j = q * NTH + tid;
         const uint32_t sb = j < N ? P.spins[(size_t)grp * N + j] : 0u;
 #pragma unroll
-        for (int r = 0; r < kSkRB; ++r) {
-            lf[q][r] = j < N ? P.lf[((size_t)grp * N + j) * kSkRB + r] : 0.0;
-            lfl[q][r] = j < N ? P.lfl[((size_t)grp * N + j) * kSkRB + r] : 0.0;
-            sm[q][r] = __ballot((sb >> r) & 1u);
+        for (int r = 0; r < RB; ++r) {
+            lf[q][r] = j < N ? P.lf[((size_t)grp * N + j) * kSkRB + r8 + r] : 0.0;
+            lfl[q][r] = j < N ? P.lfl[((size_t)grp * N + j) * kSkRB + r8 + r] : 0.0;
+            sm[q][r] = __ballot((sb >> (r8 + r)) & 1u);
         }
     }
     auto spin_byte = [&](int q) {              // the 8 replicas' spins of this lane's site q
         uint32_t v = 0u;
 #pragma unroll
-        for (int r = 0; r < kSkRB; ++r) v |= (uint32_t)((sm[q][r] >> lane) & 1ull) << r;
+        for (int r = 0; r < RB; ++r) v |= (uint32_t)((sm[q][r] >> lane) & 1ull) << r;
         return v;
     };
     for (int j = tid; j < kSkThreads * kSkMaxSPT; j += NTH) sh_canon[j] = 0xffu;
@@ -193,10 +201,10 @@ __global__ __launch_bounds__(NTH) void sk_block_kernel(SkBlockParams P)
 #pragma unroll
     for (int a = 0; a < RPW; ++a) {
         const int r = wv + a * NWV;
-        const bool on = r < kSkRB;
-        E_run[a] = on ? P.E_cur[grp * kSkRB + r] : 0.0;
-        A_run[a] = on ? P.acc_cur[grp * kSkRB + r] : 0;
-        mlast[a] = on ? P.move_last[grp * kSkRB + r] : -1;
+        const bool on = r < RB;
+        E_run[a] = on ? P.E_cur[grp * kSkRB + r8 + r] : 0.0;
+        A_run[a] = on ? P.acc_cur[grp * kSkRB + r8 + r] : 0;
+        mlast[a] = on ? P.move_last[grp * kSkRB + r8 + r] : -1;
     }
     int64_t ns[RPW], next_sample[RPW];
 #pragma unroll
@@ -210,9 +218,9 @@ __global__ __launch_bounds__(NTH) void sk_block_kernel(SkBlockParams P)
 #endif
     // block 0: sites, uniforms, coupling sub-matrix, canonical window slot of every attempted site
     auto draw_uniforms = [&](int64_t b) {
-        for (int idx = tid; idx < kSkW * kSkRB; idx += NTH) {
-            const int l = idx >> 3, r = idx & 7;
-            const double u = rand53(P.k0, P.k1, P.g0 + (uint64_t)(b * kSkW + l + 1), P.replica0 + (uint32_t)(grp * kSkRB + r));
+        for (int idx = tid; idx < kSkW * RB; idx += NTH) {
+            const int l = idx / RB, r = idx % RB;
+            const double u = rand53(P.k0, P.k1, P.g0 + (uint64_t)(b * kSkW + l + 1), P.replica0 + (uint32_t)(grp * kSkRB + r8 + r));
             sh_u[l][r] = u;
             sh_L[l][r] = log(u);                           // state independent: the verdict's filter (see accept_verdict)
         }
@@ -254,7 +262,7 @@ __global__ __launch_bounds__(NTH) void sk_block_kernel(SkBlockParams P)
             const uint32_t c = sh_canon[j];
             if (c != 0xffu) {
 #pragma unroll
-                for (int r = 0; r < kSkRB; ++r) { sh_wf[c][r] = lf[q][r]; sh_wfl[c][r] = lfl[q][r]; }
+                for (int r = 0; r < RB; ++r) { sh_wf[c][r] = lf[q][r]; sh_wfl[c][r] = lfl[q][r]; }
                 sh_wsp[c] = (uint8_t)spin_byte(q);
             }
         }
@@ -269,7 +277,7 @@ __global__ __launch_bounds__(NTH) void sk_block_kernel(SkBlockParams P)
 #pragma unroll
         for (int a = 0; a < RPW; ++a) {
             const int r = wv + a * NWV;
-            if (r < kSkRB) {
+            if (r < RB) {
                 const uint32_t cs = sh_cslot[lane];
                 double f = sh_wf[cs][r], fl = sh_wfl[cs][r];
                 uint32_t sp = (sh_wsp[cs] >> r) & 1u;
@@ -295,7 +303,7 @@ __global__ __launch_bounds__(NTH) void sk_block_kernel(SkBlockParams P)
                 while (B) {
                     const int k = __builtin_ctzll(B);
                     while (next_sample[a] <= it0 + k + 1) {             // sample BEFORE the move (RRRMC.jl:104-108)
-                        if (P.Es && lane == 0) P.Es[ns[a] * Rp + grp * kSkRB + r] = E_run[a];
+                        if (P.Es && lane == 0) P.Es[ns[a] * Rp + grp * kSkRB + r8 + r] = E_run[a];
                         ns[a] += 1; next_sample[a] += P.step;
                     }
                     const double dE = sk_readlane_f64(f, k);            // delta_energy, SK.jl:278-284
@@ -321,7 +329,7 @@ __global__ __launch_bounds__(NTH) void sk_block_kernel(SkBlockParams P)
                     B = __ballot(ok) & ((~0ull << k) << 1);
                 }
                 while (next_sample[a] <= it0 + nv) {
-                    if (P.Es && lane == 0) P.Es[ns[a] * Rp + grp * kSkRB + r] = E_run[a];
+                    if (P.Es && lane == 0) P.Es[ns[a] * Rp + grp * kSkRB + r8 + r] = E_run[a];
                     ns[a] += 1; next_sample[a] += P.step;
                 }
                 if (accw) atomicOr(&sh_acc[pb][lane], accw << r);       // bit r accepted, bit 8 + r swapped, bit 16 + r spin before the flip
@@ -369,10 +377,17 @@ __global__ __launch_bounds__(NTH) void sk_block_kernel(SkBlockParams P)
             asm volatile("" :: "s"(w), "s"(own), "s"(lb), "v"(d4[0]));           // timing experiment: the step's prelude and row loads only
             if constexpr (SPT == 99)
 #endif
-            if constexpr (SPT == 1) { SK_APPLY_ALL(SK_APPLY1, lf, lfl, sm, d4); }
-            else if constexpr (SPT == 2) { SK_APPLY_ALL(SK_APPLY2, lf, lfl, sm, d4); }
-            else if constexpr (SPT == 3) { SK_APPLY_ALL(SK_APPLY3, lf, lfl, sm, d4); }
-            else { SK_APPLY_ALL(SK_APPLY4, lf, lfl, sm, d4); }
+            if constexpr (RB == 8) {
+                if constexpr (SPT == 1) { SK_APPLY_ALL(SK_APPLY1, lf, lfl, sm, d4); }
+                else if constexpr (SPT == 2) { SK_APPLY_ALL(SK_APPLY2, lf, lfl, sm, d4); }
+                else if constexpr (SPT == 3) { SK_APPLY_ALL(SK_APPLY3, lf, lfl, sm, d4); }
+                else { SK_APPLY_ALL(SK_APPLY4, lf, lfl, sm, d4); }
+            } else {
+                if constexpr (SPT == 1) { SK_APPLY_HALF(SK_APPLY1, lf, lfl, sm, d4); }
+                else if constexpr (SPT == 2) { SK_APPLY_HALF(SK_APPLY2, lf, lfl, sm, d4); }
+                else if constexpr (SPT == 3) { SK_APPLY_HALF(SK_APPLY3, lf, lfl, sm, d4); }
+                else { SK_APPLY_HALF(SK_APPLY4, lf, lfl, sm, d4); }
+            }
             (void)tS; (void)tV;
         };
         for (int k0 = 0; k0 < kSkW; k0 += 2 * PF) {
@@ -427,18 +442,26 @@ __global__ __launch_bounds__(NTH) void sk_block_kernel(SkBlockParams P)
     for (int q = 0; q < SPT; ++q) {
         const int j = q * NTH + tid;
         if (j < N) {
-            P.spins[(size_t)grp * N + j] = (uint8_t)spin_byte(q);
+            if constexpr (RB == 8) {
+                P.spins[(size_t)grp * N + j] = (uint8_t)spin_byte(q);
+            } else {
+                // the byte is shared with the group's other workgroup: change this one's four bits only (nobody else writes them, so the
+                // byte in memory still holds their value from before the launch), atomically on the enclosing word
+                const size_t off = (size_t)grp * N + j;
+                const uint32_t was = (P.spins[off] >> r8) & 0xfu, sh = 8u * (uint32_t)(off & 3u) + (uint32_t)r8;
+                atomicXor(reinterpret_cast<uint32_t*>(P.spins + (off & ~(size_t)3)), (was ^ spin_byte(q)) << sh);
+            }
 #pragma unroll
-            for (int r = 0; r < kSkRB; ++r) {
-                P.lf[((size_t)grp * N + j) * kSkRB + r] = lf[q][r];
-                P.lfl[((size_t)grp * N + j) * kSkRB + r] = lfl[q][r];
+            for (int r = 0; r < RB; ++r) {
+                P.lf[((size_t)grp * N + j) * kSkRB + r8 + r] = lf[q][r];
+                P.lfl[((size_t)grp * N + j) * kSkRB + r8 + r] = lfl[q][r];
             }
         }
     }
 #pragma unroll
     for (int a = 0; a < RPW; ++a) {
         const int r = wv + a * NWV;
-        if (r < kSkRB && lane == 0) { P.E_cur[grp * kSkRB + r] = E_run[a]; P.acc_cur[grp * kSkRB + r] = A_run[a]; P.move_last[grp * kSkRB + r] = mlast[a]; }
+        if (r < RB && lane == 0) { P.E_cur[grp * kSkRB + r8 + r] = E_run[a]; P.acc_cur[grp * kSkRB + r8 + r] = A_run[a]; P.move_last[grp * kSkRB + r8 + r] = mlast[a]; }
     }
 }
 

@@ -236,3 +236,32 @@ def test_skn_thread_counts_agree(pkg, monkeypatch, N, R):
     for o in outs[1:]:
         for u, v in zip(outs[0], o):
             assert (u == v).all()
+
+
+@pytest.mark.parametrize("N,R", [(1024, 24), (1000, 13), (700, 8), (300, 9), (256, 16), (37, 5)])
+def test_skn_block_kernel_builds_agree(pkg, oracle, monkeypatch, N, R):
+    """sk_block_kernel with one 8-replica workgroup per group of replicas and with two co-resident 4-replica workgroups
+    (RRRMC_SK_RB = 8 / 4), and the one-attempt-at-a-time sk_sweep_kernel (RRRMC_SK_LEGACY = 1): the same chain bit for bit — energies,
+    accepted counts, configurations (the two halves of a group share each spin byte) and the live field cache; R not a multiple of 4
+    leaves padded replicas in the last workgroups."""
+    seed = 977 + N
+    X = pkg.GraphSKNormal(N, seed=seed)
+    outs = []
+    for env in ({"RRRMC_SK_RB": "8"}, {"RRRMC_SK_RB": "4"}, {"RRRMC_SK_LEGACY": "1"}):
+        for k in ("RRRMC_SK_RB", "RRRMC_SK_LEGACY"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        with pkg.Engine(X, R) as eng:
+            eng.seed(seed)
+            eng.init_spins_random()
+            Es, acc = eng.standard_mc(1.5, 4000, 100)
+            Es2, acc2 = eng.standard_mc(0.7, 1111, 7)      # a second call continues the streams
+            outs.append((Es, acc, Es2, acc2, eng.get_config().s, eng.fields(), eng.energy()))
+    for o in outs[1:]:
+        for u, v in zip(outs[0], o):
+            assert (u == v).all()
+    # and the oracle, for the split build's first call
+    C0 = oracle.init_configs(seed, 0, R, N)
+    Es_ref, ch_ref, acc_ref, lf_ref = oracle.standard_mc_skn_batch(X.J, 1.5, 4000, 100, seed, C0)
+    assert (outs[1][0] == Es_ref).all() and (outs[1][1] == acc_ref).all()

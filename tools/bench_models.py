@@ -14,6 +14,8 @@ import __graft_entry__ as entry  # noqa: E402
 
 
 def bench_sk(N=1024, R=2048, beta=1.0, iters=1 << 16, step=1 << 10, seed=0x5EED):
+    if len(sys.argv) > 2:                                    # python tools/bench_models.py sk N [R]
+        N = int(sys.argv[2]); R = int(sys.argv[3]) if len(sys.argv) > 3 else R
     pkg = entry.load_package()
     X = pkg.GraphSKNormal(N, seed=seed)
     eng = pkg.Engine(X, R)
