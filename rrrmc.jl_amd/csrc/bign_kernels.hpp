@@ -460,6 +460,9 @@ inline size_t big_lds_bytes(int64_t N, int lgr) { return (size_t)((N + (32 >> lg
 #ifndef RRRMC_BIG_APPLY_THREADS
 #define RRRMC_BIG_APPLY_THREADS 1024
 #endif
+#ifndef RRRMC_BIG_ROUND
+#define RRRMC_BIG_ROUND 2048                 // attempts per round of big_apply_kernel
+#endif
 constexpr int kBigApplyThreads = RRRMC_BIG_APPLY_THREADS;      // four wavefronts per SIMD, two attempts per thread and round (512 x 4 measured 12 % slower)
 
 // Workgroup barrier for state that lives in LDS only: waits for this wavefront's LDS operations, not for its global loads —
@@ -477,7 +480,7 @@ __device__ __forceinline__ void big_apply_body(const BigSweepParams& P, const ui
     constexpr int NT = (K + 1) / 2;
     constexpr int NM = CM ? 1 : NT;                           // mask words per attempt
     constexpr int REC = big_rec_words(K);
-    constexpr int U = 2048 / kBigApplyThreads;                // attempts per thread and round
+    constexpr int U = RRRMC_BIG_ROUND / kBigApplyThreads;     // attempts per thread and round
     constexpr int NTH = kBigApplyThreads;
     constexpr uint32_t RS = (uint32_t)(U * NTH);              // slots per round
     extern __shared__ uint32_t bl_sp[];                       // [ceil(N / S)]  r bits per site
@@ -534,7 +537,13 @@ __device__ __forceinline__ void big_apply_body(const BigSweepParams& P, const ui
         nvec = (uint32_t)__builtin_amdgcn_readfirstlane((int)h[2]); flags = (uint32_t)__builtin_amdgcn_readfirstlane((int)h[3]);
     };
     auto lstart = [&](uint32_t l) -> uint32_t {               // first slot of level l of chunk c (l < nvec)
-        const uint32_t v = l < (uint32_t)(kBigHdr - 4) ? hdr[c * kBigHdr + 4 + (int)l] : P.vecs[sb + l];
+        // (written so that the common case is an LDS read and nothing else: as one conditional expression the two became ONE flat load,
+        // whose wait drains the vector-memory counter — i.e. the record prefetch — at every level boundary)
+        uint32_t v = hdr[c * kBigHdr + 4 + (int)(l < (uint32_t)(kBigHdr - 5) ? l : (uint32_t)(kBigHdr - 5))];
+        if (l >= (uint32_t)(kBigHdr - 4)) {                    // (a chunk with more than 8 levels: rare; the load as assembly keeps the two apart)
+            const uint32_t* pv = P.vecs + sb + l;
+            asm volatile("global_load_dword %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(pv) : "memory");
+        }
         return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
     };
     bool valid = P.nchunks > 0, first = true, cfirst = true;
@@ -543,7 +552,24 @@ __device__ __forceinline__ void big_apply_body(const BigSweepParams& P, const ui
     // two rounds of records in registers (stage = round mod 2; every index below is a compile-time constant):
     // <= U * kBigApplyThreads attempts of one level each, plus what the round is (wave-uniform): a round at all / the first of its
     // level / the first of its chunk / that chunk starts with a sample
-    uint32_t q_slot[2][U], q_raw[2][U][K], q_m[2][U][NM];
+    // The loads are inline assembly and so is the wait for them (s_waitcnt vmcnt(kLoads) right after the NEXT round's request: the counter
+    // is in order, "all but the youngest kLoads" is the round about to be worked on, requested a whole round ago).  Every wavefront issues
+    // every load of every round — lanes without an attempt masked off in EXEC, which costs an issue slot and no traffic — so kLoads is a
+    // compile-time constant.  Left to the compiler the same loop drained the counter: with the loads under a wave-uniform "any lane live"
+    // branch the count differs between wavefronts, and with unconditional C++ loads its register allocation reused stage registers as
+    // address temporaries and waited (vmcnt(1)) for the round in flight before requesting the next one.
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    constexpr int kLoads = U * ((REC == 4 ? 1 : 2) + 1);
+    u32x4 q_a[2][U], q_b[2][U], q_mv[2][U];                   // record words 0..3, 4..7 (REC == 8), the four mask words (!CM)
+    uint32_t q_mc[2][U];                                      // the compact mask word (CM)
+#pragma unroll
+    for (int T = 0; T < 2; ++T)
+#pragma unroll
+        for (int u = 0; u < U; ++u) { q_a[T][u] = (u32x4)(0u); q_b[T][u] = (u32x4)(0u); q_mv[T][u] = (u32x4)(0u); q_mc[T][u] = 0u; }
+    auto q_slot = [&](int T, int u) -> uint32_t { return q_a[T][u].x; };
+    auto q_raw = [&](int T, int u, int k) -> uint32_t {
+        return k == 0 ? q_a[T][u].y : k == 1 ? q_a[T][u].z : k == 2 ? q_a[T][u].w : k == 3 ? q_b[T][u].x : k == 4 ? q_b[T][u].y : k == 5 ? q_b[T][u].z : q_b[T][u].w;
+    };
     bool q_live[2][U], q_valid[2], q_first[2], q_cfirst[2], q_sample[2];
     // requests the records of the iterator's round and moves the iterator on
     auto fetch = [&](auto stage) {
@@ -553,37 +579,29 @@ __device__ __forceinline__ void big_apply_body(const BigSweepParams& P, const ui
         for (int u = 0; u < U; ++u) {
             const uint32_t p = base + (uint32_t)(u * NTH + tid);
             q_live[T][u] = valid && p < lend;
-            q_slot[T][u] = 0u;
-#pragma unroll
-            for (int k = 0; k < K; ++k) q_raw[T][u][k] = 0u;
-#pragma unroll
-            for (int n = 0; n < NM; ++n) q_m[T][u][n] = 0u;
-            // a wavefront without a live lane skips the loads (a scalar branch); inside, every lane loads (a dead lane re-reads the round's
-            // first slot): a value defined under a DIVERGENT branch would have to be waited for at the end of the branch, and the point
-            // of the exercise is not to wait
-            if (__builtin_amdgcn_ballot_w64(q_live[T][u]) != 0ull) {
-                const uint32_t q = sb + (q_live[T][u] ? p : base);
-                // 16-byte loads (a CU's vector memory path takes a wavefront's load every ~16 cycles whatever its width; what the loop
-                // pays for is the bytes: 64 per cycle and CU)
-                uint32_t rw[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
-                if constexpr (REC == 4) {
-                    const uint4 r0 = *reinterpret_cast<const uint4*>(recs + (q << 4));
-                    rw[0] = r0.x; rw[1] = r0.y; rw[2] = r0.z; rw[3] = r0.w;
-                } else {
-                    const uint4 r0 = *reinterpret_cast<const uint4*>(recs + (q << 5)), r1 = *reinterpret_cast<const uint4*>(recs + (q << 5) + 16u);
-                    rw[0] = r0.x; rw[1] = r0.y; rw[2] = r0.z; rw[3] = r0.w; rw[4] = r1.x; rw[5] = r1.y; rw[6] = r1.z; rw[7] = r1.w;
-                }
-                q_slot[T][u] = rw[0];
-#pragma unroll
-                for (int k = 0; k < K; ++k) q_raw[T][u][k] = rw[1 + k];
-                if constexpr (CM) q_m[T][u][0] = *reinterpret_cast<const uint32_t*>(gmask + (q << 2));
-                else {
-                    const uint4 mk = *reinterpret_cast<const uint4*>(gmask + (q << 4));
-                    const uint32_t mw[4] = {mk.x, mk.y, mk.z, mk.w};
-#pragma unroll
-                    for (int n = 0; n < NT; ++n) q_m[T][u][n] = mw[n];
-                }
-            }
+            const unsigned long long lm = __builtin_amdgcn_ballot_w64(q_live[T][u]);
+            const uint32_t q = q_live[T][u] ? sb + p : 0u;
+            unsigned long long sv;
+            // 16-byte loads (a CU's vector memory path takes a wavefront's load every ~16 cycles whatever its width; what the loop
+            // pays for is the bytes: 64 per cycle and CU)
+            if constexpr (REC == 4 && CM)
+                asm volatile("s_mov_b64 %[sv], exec\n\ts_mov_b64 exec, %[lm]\n\tglobal_load_dwordx4 %[a], %[o], %[rb]\n\tglobal_load_dword %[m], %[om], %[mb]\n\ts_mov_b64 exec, %[sv]"
+                             : [a] "+v"(q_a[T][u]), [m] "+v"(q_mc[T][u]), [sv] "=&s"(sv)
+                             : [o] "v"(q << 4), [om] "v"(q << 2), [rb] "s"(recs), [mb] "s"(gmask), [lm] "s"(lm) : "memory");
+            else if constexpr (REC == 4 && !CM)
+                asm volatile("s_mov_b64 %[sv], exec\n\ts_mov_b64 exec, %[lm]\n\tglobal_load_dwordx4 %[a], %[o], %[rb]\n\tglobal_load_dwordx4 %[m], %[o], %[mb]\n\ts_mov_b64 exec, %[sv]"
+                             : [a] "+v"(q_a[T][u]), [m] "+v"(q_mv[T][u]), [sv] "=&s"(sv)
+                             : [o] "v"(q << 4), [rb] "s"(recs), [mb] "s"(gmask), [lm] "s"(lm) : "memory");
+            else if constexpr (REC == 8 && CM)
+                asm volatile("s_mov_b64 %[sv], exec\n\ts_mov_b64 exec, %[lm]\n\tglobal_load_dwordx4 %[a], %[o], %[rb]\n\tglobal_load_dwordx4 %[b], %[o], %[rb] offset:16\n\t"
+                             "global_load_dword %[m], %[om], %[mb]\n\ts_mov_b64 exec, %[sv]"
+                             : [a] "+v"(q_a[T][u]), [b] "+v"(q_b[T][u]), [m] "+v"(q_mc[T][u]), [sv] "=&s"(sv)
+                             : [o] "v"(q << 5), [om] "v"(q << 2), [rb] "s"(recs), [mb] "s"(gmask), [lm] "s"(lm) : "memory");
+            else
+                asm volatile("s_mov_b64 %[sv], exec\n\ts_mov_b64 exec, %[lm]\n\tglobal_load_dwordx4 %[a], %[o], %[rb]\n\tglobal_load_dwordx4 %[b], %[o], %[rb] offset:16\n\t"
+                             "global_load_dwordx4 %[m], %[om], %[mb]\n\ts_mov_b64 exec, %[sv]"
+                             : [a] "+v"(q_a[T][u]), [b] "+v"(q_b[T][u]), [m] "+v"(q_mv[T][u]), [sv] "=&s"(sv)
+                             : [o] "v"(q << 5), [om] "v"(q << 4), [rb] "s"(recs), [mb] "s"(gmask), [lm] "s"(lm) : "memory");
         }
         if (valid) {
             base += RS;
@@ -611,9 +629,33 @@ __device__ __forceinline__ void big_apply_body(const BigSweepParams& P, const ui
     uint64_t st_fetch = 0, st_pre = 0, st_lds = 0, st_dec = 0, st_rounds = 0, st_first = 0;
     const uint64_t st_begin = __builtin_amdgcn_s_memtime();
 #endif
+    // waits until at most NL vector-memory loads are outstanding; stage T's registers pass through the statement, so that nothing that
+    // reads them can be scheduled above it
+    auto wait_stage = [&](auto stage, auto nl) {
+        constexpr int T = decltype(stage)::value, NL = decltype(nl)::value;
+        (void)q_a; (void)q_b; (void)q_mv; (void)q_mc;          // (named here so that the lambda captures them: asm operands under if constexpr alone do not)
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+        {
+            if constexpr (REC == 4 && CM) asm volatile("s_waitcnt vmcnt(%[n])" : "+v"(q_a[T][u]), "+v"(q_mc[T][u]) : [n] "n"(NL) : "memory");
+            else if constexpr (REC == 4 && !CM) asm volatile("s_waitcnt vmcnt(%[n])" : "+v"(q_a[T][u]), "+v"(q_mv[T][u]) : [n] "n"(NL) : "memory");
+            else if constexpr (REC == 8 && CM) asm volatile("s_waitcnt vmcnt(%[n])" : "+v"(q_a[T][u]), "+v"(q_b[T][u]), "+v"(q_mc[T][u]) : [n] "n"(NL) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%[n])" : "+v"(q_a[T][u]), "+v"(q_b[T][u]), "+v"(q_mv[T][u]) : [n] "n"(NL) : "memory");
+        }
+    };
     // one round: stage A is executed, the next round is requested into stage C (the one that was executed last)
     auto round = [&](auto stA, auto stC) {
         constexpr int A = decltype(stA)::value;
+#ifdef RRRMC_BIG_STAMPS
+        const uint64_t tf = __builtin_amdgcn_s_memtime();
+#endif
+        // ---- the next round: request its records first; they arrive while this round is worked on ----
+#ifndef RRRMC_BIG_FETCH_LATE
+        fetch(stC);
+        wait_stage(stA, BigStage<kLoads>{});
+#else
+        wait_stage(stA, BigStage<0>{});
+#endif
 #ifdef RRRMC_BIG_STAMPS
         const uint64_t t1 = __builtin_amdgcn_s_memtime();
 #endif
@@ -639,11 +681,11 @@ __device__ __forceinline__ void big_apply_body(const BigSweepParams& P, const ui
 #pragma unroll
             for (int k = 0; k < K; ++k) gk[u][k] = 0u;
             if (__builtin_amdgcn_ballot_w64(q_live[A][u]) != 0ull) {            // scalar branch; a dead lane reads word 0
-                const uint32_t e0 = q_slot[A][u];
+                const uint32_t e0 = q_slot(A, u);
                 sw[u] = *reinterpret_cast<const uint32_t*>(lbytes + (e0 & 0x3fffffu)) >> ((e0 >> 22) & 31u);
 #pragma unroll
                 for (int k = 0; k < K; ++k) {
-                    const uint32_t e = q_raw[A][u][k];
+                    const uint32_t e = q_raw(A, u, k);
                     gk[u][k] = *reinterpret_cast<const uint32_t*>(lbytes + (e & 0x3fffffu)) >> ((e >> 22) & 31u);
                 }
             }
@@ -655,9 +697,9 @@ __device__ __forceinline__ void big_apply_body(const BigSweepParams& P, const ui
         asm volatile("" :: "v"(chk));
         const uint64_t t3 = __builtin_amdgcn_s_memtime();
 #endif
-        // ---- the next round: request its records now — after this round's have been used (the vector-memory counter is in order and
-        // some wavefronts skip their loads: a request placed earlier would have to be waited for together with this round's data) ----
+#ifdef RRRMC_BIG_FETCH_LATE
         fetch(stC);
+#endif
 #ifdef RRRMC_BIG_STAMPS
         const uint64_t t0 = __builtin_amdgcn_s_memtime();
 #endif
@@ -670,17 +712,17 @@ __device__ __forceinline__ void big_apply_body(const BigSweepParams& P, const ui
             uint32_t un[K], n0, n1, n2;
 #pragma unroll
             for (int k = 0; k < K; ++k)                          // bond k unsatisfied: s ^ neighbour ^ (J < 0); bits above r are masked at the end
-                un[k] = bitop3<0x96>(sw[u], gk[u][k], (uint32_t)((int32_t)q_raw[A][u][k] >> 31));
+                un[k] = bitop3<0x96>(sw[u], gk[u][k], (uint32_t)((int32_t)q_raw(A, u, k) >> 31));
             count_planes<K>(un, n0, n1, n2);
             uint32_t rej = 0u;                                   // class n (dE = 2 (K - 2n) > 0) needs u < T_n; every other class is accepted
             // mask of class n in the low r bits (what lies above is cut off with the rest at the end)
-            auto cmask = [&](int n) -> uint32_t { return CM ? q_m[A][u][0] >> ((uint32_t)n << lgr) : q_m[A][u][CM ? 0 : n] >> rsh; };
+            auto cmask = [&](int n) -> uint32_t { return CM ? q_mc[A][u] >> ((uint32_t)n << lgr) : (n == 0 ? q_mv[A][u].x : n == 1 ? q_mv[A][u].y : n == 2 ? q_mv[A][u].z : q_mv[A][u].w) >> rsh; };
             if constexpr (NT > 0) rej = bitop3<0xf4>(rej, count_is<0>(n0, n1, n2), cmask(0));
             if constexpr (NT > 1) rej = bitop3<0xf4>(rej, count_is<1>(n0, n1, n2), cmask(1));
             if constexpr (NT > 2) rej = bitop3<0xf4>(rej, count_is<2>(n0, n1, n2), cmask(2));
             if constexpr (NT > 3) rej = bitop3<0xf4>(rej, count_is<3>(n0, n1, n2), cmask(3));
             const uint32_t acc = ~rej & rm;
-            const uint32_t e0 = q_slot[A][u];
+            const uint32_t e0 = q_slot(A, u);
             if (acc)                                             // spinflip! + update_cache! (Interface.jl:89-92, RRG.jl:191-234)
                 atomicXor(reinterpret_cast<uint32_t*>(const_cast<char*>(lbytes) + (e0 & 0x3fffffu)), acc << ((e0 >> 22) & 31u));
             va[u] = acc; vn0[u] = n0 & acc; vn1[u] = n1 & acc; vn2[u] = n2 & acc;
@@ -706,7 +748,7 @@ __device__ __forceinline__ void big_apply_body(const BigSweepParams& P, const ui
         }
 #ifdef RRRMC_BIG_STAMPS
         const uint64_t t4 = __builtin_amdgcn_s_memtime();
-        st_fetch += t0 - t3; st_pre += t2 - t1; st_lds += t3 - t2; st_dec += t4 - t0; st_rounds += 1; st_first += q_first[A] ? 1 : 0;
+        st_fetch += (t0 - t3) + (t1 - tf); st_pre += t2 - t1; st_lds += t3 - t2; st_dec += t4 - t0; st_rounds += 1; st_first += q_first[A] ? 1 : 0;
 #endif
     };
     fetch(BigStage<0>{});
