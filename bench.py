@@ -297,11 +297,11 @@ def secondary_c3(pkg, O, device):
     a = float(acc.mean()) / iters
     bpa = 8 + a * (17 * N + 2)                                   # SURVEY.md §8d, dense SK Float64
     out = {"workload": "GraphSKNormal(N=1024) standardMC beta=1.0, 2048 replicas, 2^16 iterations per replica", "value": R * iters / dt,
-           "unit": "attempts/s", "kernel": "sk_sweep_kernel" if os.environ.get("RRRMC_SK_LEGACY") == "1" else "sk_block_kernel<2, 512>",
+           "unit": "attempts/s", "kernel": "sk_sweep_kernel" if os.environ.get("RRRMC_SK_LEGACY") == "1" else ("sk_block_kernel<2, 512>" if os.environ.get("RRRMC_SK_RB") == "8" else "sk_block_kernel<4, 256, 4>"),
            "avg_launch_ms": k_ms / max(nl, 1), "launches": nl, "acceptance": a,
            "algorithmic_bytes_per_attempt": bpa, "achieved_GBps": bpa * R * iters / (k_ms * 1e-3) / 1e9,
-           "note": "algorithmic bytes of the Float64-field picture (SURVEY.md §8d) over the kernel time: the fields live in registers (8 replicas "
-                   "per workgroup), the only traffic is the 8 KiB row of 4J per attempt and workgroup from L2 (floor ~280 cycles per attempt); "
+           "note": "algorithmic bytes of the Float64-field picture (SURVEY.md §8d) over the kernel time: the fields live in registers (4 replicas "
+                   "per workgroup, two workgroups per compute unit), the only traffic is the 8 KiB row of 4J per attempt and workgroup from L2 / Infinity Cache; "
                    "the kernel is bound by instruction issue of the per-replica field updates, see DESIGN.md 4c"}
     out["frac"] = out["achieved_GBps"] / HBM_PEAK_GBS
     # FP64 VALU view: the useful work is a * N Float64 adds per attempt and replica (the field update); MI355X vector FP64 = 78.6 TFLOP/s as FMAs

@@ -21,7 +21,10 @@
 namespace rrrmc {
 
 constexpr int kWave = 64;
-constexpr int kSweepThreads = 1024;              // 16 waves: consumer, tally, fixer and 13 producers
+#ifndef RRRMC_SWEEP_THREADS
+#define RRRMC_SWEEP_THREADS 1024
+#endif
+constexpr int kSweepThreads = RRRMC_SWEEP_THREADS;  // 16 waves: consumer, tally, fixer and 13 producers (896 / 960: 11 / 12 producers, timing experiments)
 #ifndef RRRMC_FIXER_WAVE
 #define RRRMC_FIXER_WAVE 14
 #endif
