@@ -6,6 +6,7 @@ ORACLE — TEST INFRASTRUCTURE ONLY: imported by tests/, ``__graft_entry__.smoke
 import ctypes as C
 import os
 import subprocess
+import threading
 
 import numpy as np
 
@@ -42,18 +43,29 @@ def build_native():
     srcs = [os.path.join(_HERE, f) for f in os.listdir(_HERE) if f.endswith((".c", ".h"))]
     if os.path.exists(so) and all(os.path.getmtime(so) >= os.path.getmtime(s) for s in srcs):
         return so
+    tmp = "%s.%d.tmp" % (so, os.getpid())          # built beside its final name and renamed: nobody ever loads a half-written file
     try:
-        subprocess.check_call(["make", "-s", "-C", _HERE, "native", "NATIVE_SO=%s" % so])
+        subprocess.check_call(["make", "-s", "-C", _HERE, "native", "NATIVE_SO=%s" % tmp])
+        os.replace(tmp, so)
     except (subprocess.CalledProcessError, OSError):
         return build()
     return so
 
 
 _lib = None
+_lib_lock = threading.Lock()
 flavour = "x86-64-v2"
 
 
 def lib():
+    global _lib, flavour
+    if _lib is not None:
+        return _lib
+    with _lib_lock:          # (bench.py's verification calls in from several threads at once)
+        return _lib_locked()
+
+
+def _lib_locked():
     global _lib, flavour
     if _lib is None:
         so = build()

@@ -22,7 +22,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PROF = os.path.join(ROOT, "profiles", os.environ.get("RRRMC_PROF_ROUND", "r03"))
 PROF_OLD = os.path.join(ROOT, "profiles", "r02")
 SIMDS = 256 * 4
-SUMMARY = sys.argv[1] if len(sys.argv) > 1 else "r03a_summary.txt"      # the rocprofv3 summary of the build being modelled
+SUMMARY = sys.argv[1] if len(sys.argv) > 1 else "r03b_summary.txt"      # the rocprofv3 summary of the build being modelled
 sys.path.insert(0, ROOT)
 
 
