@@ -558,6 +558,12 @@ __device__ __forceinline__ void big_apply_body(const BigSweepParams& P, const ui
     // compile-time constant.  Left to the compiler the same loop drained the counter: with the loads under a wave-uniform "any lane live"
     // branch the count differs between wavefronts, and with unconditional C++ loads its register allocation reused stage registers as
     // address temporaries and waited (vmcnt(1)) for the round in flight before requesting the next one.
+    // Hand-placed loads and waits are only as safe as the compiler's register allocation lets them be: a stage register that it spilled or
+    // copied between the request and the wait would be read before its data has arrived.  The compact-mask build (the one that matters:
+    // r <= 8) has no scratch and no such copies — tests/test_kernel_resources.py compiles it for every K and checks — and takes this route;
+    // the four-word-mask build (r = 16, 32) spills a few loop invariants at K >= 4 and keeps compiler-managed loads, requested after the
+    // gathers as in round 2.
+    constexpr bool ASM = CM;
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
     constexpr int kLoads = U * ((REC == 4 ? 1 : 2) + 1);
     u32x4 q_a[2][U], q_b[2][U], q_mv[2][U];                   // record words 0..3, 4..7 (REC == 8), the four mask words (!CM)
@@ -579,6 +585,16 @@ __device__ __forceinline__ void big_apply_body(const BigSweepParams& P, const ui
         for (int u = 0; u < U; ++u) {
             const uint32_t p = base + (uint32_t)(u * NTH + tid);
             q_live[T][u] = valid && p < lend;
+            if constexpr (!ASM) {
+                // compiler-managed loads under a wave-uniform "any lane live" branch (a dead lane re-reads the round's first slot)
+                if (__builtin_amdgcn_ballot_w64(q_live[T][u]) != 0ull) {
+                    const uint32_t q = sb + (q_live[T][u] ? p : base);
+                    if constexpr (REC == 4) q_a[T][u] = *reinterpret_cast<const u32x4*>(recs + (q << 4));
+                    else { q_a[T][u] = *reinterpret_cast<const u32x4*>(recs + (q << 5)); q_b[T][u] = *reinterpret_cast<const u32x4*>(recs + (q << 5) + 16u); }
+                    q_mv[T][u] = *reinterpret_cast<const u32x4*>(gmask + (q << 4));
+                }
+                continue;
+            }
             const unsigned long long lm = __builtin_amdgcn_ballot_w64(q_live[T][u]);
             const uint32_t q = q_live[T][u] ? sb + p : 0u;
             unsigned long long sv;
@@ -588,20 +604,11 @@ __device__ __forceinline__ void big_apply_body(const BigSweepParams& P, const ui
                 asm volatile("s_mov_b64 %[sv], exec\n\ts_mov_b64 exec, %[lm]\n\tglobal_load_dwordx4 %[a], %[o], %[rb]\n\tglobal_load_dword %[m], %[om], %[mb]\n\ts_mov_b64 exec, %[sv]"
                              : [a] "+v"(q_a[T][u]), [m] "+v"(q_mc[T][u]), [sv] "=&s"(sv)
                              : [o] "v"(q << 4), [om] "v"(q << 2), [rb] "s"(recs), [mb] "s"(gmask), [lm] "s"(lm) : "memory");
-            else if constexpr (REC == 4 && !CM)
-                asm volatile("s_mov_b64 %[sv], exec\n\ts_mov_b64 exec, %[lm]\n\tglobal_load_dwordx4 %[a], %[o], %[rb]\n\tglobal_load_dwordx4 %[m], %[o], %[mb]\n\ts_mov_b64 exec, %[sv]"
-                             : [a] "+v"(q_a[T][u]), [m] "+v"(q_mv[T][u]), [sv] "=&s"(sv)
-                             : [o] "v"(q << 4), [rb] "s"(recs), [mb] "s"(gmask), [lm] "s"(lm) : "memory");
-            else if constexpr (REC == 8 && CM)
+            else
                 asm volatile("s_mov_b64 %[sv], exec\n\ts_mov_b64 exec, %[lm]\n\tglobal_load_dwordx4 %[a], %[o], %[rb]\n\tglobal_load_dwordx4 %[b], %[o], %[rb] offset:16\n\t"
                              "global_load_dword %[m], %[om], %[mb]\n\ts_mov_b64 exec, %[sv]"
                              : [a] "+v"(q_a[T][u]), [b] "+v"(q_b[T][u]), [m] "+v"(q_mc[T][u]), [sv] "=&s"(sv)
                              : [o] "v"(q << 5), [om] "v"(q << 2), [rb] "s"(recs), [mb] "s"(gmask), [lm] "s"(lm) : "memory");
-            else
-                asm volatile("s_mov_b64 %[sv], exec\n\ts_mov_b64 exec, %[lm]\n\tglobal_load_dwordx4 %[a], %[o], %[rb]\n\tglobal_load_dwordx4 %[b], %[o], %[rb] offset:16\n\t"
-                             "global_load_dwordx4 %[m], %[om], %[mb]\n\ts_mov_b64 exec, %[sv]"
-                             : [a] "+v"(q_a[T][u]), [b] "+v"(q_b[T][u]), [m] "+v"(q_mv[T][u]), [sv] "=&s"(sv)
-                             : [o] "v"(q << 5), [om] "v"(q << 4), [rb] "s"(recs), [mb] "s"(gmask), [lm] "s"(lm) : "memory");
         }
         if (valid) {
             base += RS;
@@ -637,10 +644,8 @@ __device__ __forceinline__ void big_apply_body(const BigSweepParams& P, const ui
 #pragma unroll
         for (int u = 0; u < U; ++u)
         {
-            if constexpr (REC == 4 && CM) asm volatile("s_waitcnt vmcnt(%[n])" : "+v"(q_a[T][u]), "+v"(q_mc[T][u]) : [n] "n"(NL) : "memory");
-            else if constexpr (REC == 4 && !CM) asm volatile("s_waitcnt vmcnt(%[n])" : "+v"(q_a[T][u]), "+v"(q_mv[T][u]) : [n] "n"(NL) : "memory");
-            else if constexpr (REC == 8 && CM) asm volatile("s_waitcnt vmcnt(%[n])" : "+v"(q_a[T][u]), "+v"(q_b[T][u]), "+v"(q_mc[T][u]) : [n] "n"(NL) : "memory");
-            else asm volatile("s_waitcnt vmcnt(%[n])" : "+v"(q_a[T][u]), "+v"(q_b[T][u]), "+v"(q_mv[T][u]) : [n] "n"(NL) : "memory");
+            if constexpr (REC == 4) asm volatile("s_waitcnt vmcnt(%[n])" : "+v"(q_a[T][u]), "+v"(q_mc[T][u]) : [n] "n"(NL) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%[n])" : "+v"(q_a[T][u]), "+v"(q_b[T][u]), "+v"(q_mc[T][u]) : [n] "n"(NL) : "memory");
         }
     };
     // one round: stage A is executed, the next round is requested into stage C (the one that was executed last)
@@ -651,10 +656,12 @@ __device__ __forceinline__ void big_apply_body(const BigSweepParams& P, const ui
 #endif
         // ---- the next round: request its records first; they arrive while this round is worked on ----
 #ifndef RRRMC_BIG_FETCH_LATE
-        fetch(stC);
-        wait_stage(stA, BigStage<kLoads>{});
+        if constexpr (ASM) {
+            fetch(stC);
+            wait_stage(stA, BigStage<kLoads>{});
+        }
 #else
-        wait_stage(stA, BigStage<0>{});
+        if constexpr (ASM) wait_stage(stA, BigStage<0>{});
 #endif
 #ifdef RRRMC_BIG_STAMPS
         const uint64_t t1 = __builtin_amdgcn_s_memtime();
@@ -699,6 +706,8 @@ __device__ __forceinline__ void big_apply_body(const BigSweepParams& P, const ui
 #endif
 #ifdef RRRMC_BIG_FETCH_LATE
         fetch(stC);
+#else
+        if constexpr (!ASM) fetch(stC);
 #endif
 #ifdef RRRMC_BIG_STAMPS
         const uint64_t t0 = __builtin_amdgcn_s_memtime();

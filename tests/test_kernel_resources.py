@@ -1,0 +1,53 @@
+"""Static resource checks of kernels whose correctness depends on what the register allocator did.
+
+big_applyc_kernel<K> (csrc/bign_kernels.hpp) requests its records with inline-assembly loads and waits for them a whole round later with a
+hand-written `s_waitcnt vmcnt(n)`: the compiler does not know that the registers of a stage are in flight in between.  That is sound as
+long as it neither spills nor copies them there — so the build must stay free of scratch memory (a spilled stage register would be
+stored before its data has arrived).  This test cross-compiles the kernels for gfx950 (no GPU needed) and reads the code object's
+metadata.  The four-word-mask build (big_apply_kernel) keeps compiler-managed loads and may spill."""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "rrrmc.jl_amd", "csrc")
+
+TU = r'''
+#include <hip/hip_runtime.h>
+#include "philox.hpp"
+#include "bign_kernels.hpp"
+#define INST(K) template __global__ void rrrmc::big_applyc_kernel<K>(rrrmc::BigSweepParams, const uint32_t*, uint32_t*, uint32_t, int); \
+                template __global__ void rrrmc::big_apply_kernel<K>(rrrmc::BigSweepParams, const uint32_t*, uint32_t*, uint32_t, int);
+INST(1) INST(2) INST(3) INST(4) INST(5) INST(6) INST(7)
+'''
+
+
+def kernel_metadata(asm_text):
+    """{kernel name: {field: int}} from the amdhsa.kernels metadata of a gfx950 assembly listing"""
+    out = {}
+    for item in re.split(r"\n  - ", asm_text[asm_text.index("amdhsa.kernels:"):]):
+        name = re.search(r"\.name:\s+(\S+)", item)
+        if not name:
+            continue
+        out[name.group(1)] = {k: int(v) for k, v in re.findall(r"\.(private_segment_fixed_size|vgpr_count|vgpr_spill_count|sgpr_spill_count):\s+(\d+)", item)}
+    return out
+
+
+@pytest.mark.skipif(shutil.which("hipcc") is None, reason="hipcc not found")
+def test_asm_prefetch_kernels_have_no_scratch(tmp_path):
+    src = tmp_path / "res.hip"
+    src.write_text(TU)
+    asm = tmp_path / "res.s"
+    subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-I", CSRC, "--cuda-device-only", "-S",
+                           str(src), "-o", str(asm)], cwd=str(tmp_path))
+    meta = kernel_metadata(asm.read_text())
+    compact = {n: m for n, m in meta.items() if "big_applyc_kernel" in n}
+    assert len(compact) == 7
+    for n, m in compact.items():
+        assert m["private_segment_fixed_size"] == 0 and m.get("vgpr_spill_count", 0) == 0, (n, m)
+        assert m["vgpr_count"] <= 128, (n, m)              # 1024 threads per workgroup: four wavefronts per SIMD
+    # (the four-word-mask build exists for every K too; it may use scratch — its loads are the compiler's)
+    assert sum("big_apply_kernel" in n for n in meta) == 7
