@@ -282,7 +282,6 @@ __global__ __launch_bounds__(NTH) void sk_block_kernel(SkBlockParams P)
                 double f = sh_wf[cs][r], fl = sh_wfl[cs][r];
                 uint32_t sp = (sh_wsp[cs] >> r) & 1u;
                 const double u = sh_u[lane][r];
-                const bool valid = lane < nv;
                 const int64_t it0 = P.it_base + b * kSkW;               // iteration of lane m (call-relative, 1-based) = it0 + m + 1
                 uint32_t accw = 0u;
                 // accept iff x >= 0 || u < det_exp(x), x = -beta dE (RRRMC.jl:39).  det_exp is 40 dependent Float64 operations on the
@@ -292,19 +291,31 @@ __global__ __launch_bounds__(NTH) void sk_block_kernel(SkBlockParams P)
                 // verdicts are det_exp's verdicts bit for bit in all cases.
                 const double Lu = sh_L[lane][r];
                 const double Lm = 1e-9 - 1e-12 * Lu, Lhi = Lu + Lm, Llo = Lu - Lm;
-                auto verdict = [&](const double x) {
-                    const bool sure_acc = (x >= 0.0) || (x > Lhi), sure_rej = (x < Llo) && (x > -700.0);
-                    bool ok = sure_acc;
-                    if (__ballot(valid && !(sure_acc || sure_rej))) ok = (x >= 0.0) || (u < det_exp_v(x, expc));
-                    return valid && ok;
+                // (the verdicts of the 64 attempts as a lane mask: kept in scalar registers, never round-tripped through a vector bool)
+                const unsigned long long vm = nv >= kSkW ? ~0ull : (1ull << nv) - 1ull;        // the block's valid attempts
+                auto verdict = [&](const double x) -> unsigned long long {
+                    // one compare per ballot, the masks combined by scalar instructions (a ballot of a compound condition goes through a vector bool)
+                    const unsigned long long ge0 = __builtin_amdgcn_ballot_w64(x >= 0.0), hi = __builtin_amdgcn_ballot_w64(x > Lhi);
+                    const unsigned long long lo = __builtin_amdgcn_ballot_w64(x < Llo), fin = __builtin_amdgcn_ballot_w64(x > -700.0);
+                    const unsigned long long sure_acc = ge0 | hi, sure_rej = lo & fin;
+                    unsigned long long m = vm & sure_acc;
+                    unsigned long long need = vm & ~(sure_acc | sure_rej);
+                    asm volatile("" : "+s"(need));                      // (opaque: "any lane" stays one scalar compare)
+                    // a scalar branch the layout treats as cold: the exponential is needed once in ~10^9 evaluations
+                    if (__builtin_expect(need != 0ull, 0)) m = vm & (ge0 | __builtin_amdgcn_ballot_w64(u < det_exp_v(x, expc)));
+                    return m;
                 };
-                bool ok = verdict(-P.beta * f);
-                unsigned long long B = __ballot(ok);
+                // sample points inside this block as a block-relative attempt index (a 32-bit scalar compare per accepted move instead of a
+                // 64-bit one): the sample of iteration it is taken BEFORE its move, i.e. before attempt m = it - it0 - 1 is applied
+                auto sample_rel = [&]() -> int { const int64_t d = next_sample[a] - it0 - 1; return d < (int64_t)kSkW ? (int)d : kSkW; };
+                int ks = sample_rel();
+                unsigned long long B = verdict(-P.beta * f);
                 while (B) {
                     const int k = __builtin_ctzll(B);
-                    while (next_sample[a] <= it0 + k + 1) {             // sample BEFORE the move (RRRMC.jl:104-108)
+                    while (__builtin_expect(k >= ks, 0)) {              // sample BEFORE the move (RRRMC.jl:104-108)
                         if (P.Es && lane == 0) P.Es[ns[a] * Rp + grp * kSkRB + r8 + r] = E_run[a];
                         ns[a] += 1; next_sample[a] += P.step;
+                        ks = sample_rel();
                     }
                     const double dE = sk_readlane_f64(f, k);            // delta_energy, SK.jl:278-284
                     const int32_t site_k = __builtin_amdgcn_readlane((int)sv, k);
@@ -312,8 +323,10 @@ __global__ __launch_bounds__(NTH) void sk_block_kernel(SkBlockParams P)
                     const bool swapped = mlast[a] == site_k;            // undo path of update_cache!, SK.jl:247-250
                     E_run[a] += dE; A_run[a] += 1;
                     const bool dup = (int32_t)sv == site_k;
-                    if (lane == k) accw = 1u | (swapped ? 0x100u : 0u) | (spk << 16);
-                    if (swapped) {
+                    // the attempt's word for the apply phase, written into lane k of accw (v_writelane: this compiler has no builtin for it)
+                    const uint32_t aw = 1u | (swapped ? 0x100u : 0u) | (spk << 16);
+                    asm volatile("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(accw) : "s"(aw), "s"(k) : "m0");       // (one SGPR + M0: the constant bus takes one scalar source)
+                    if (__builtin_expect(swapped, 0)) {
                         const double t = f; f = fl; fl = t;
                     } else {
                         const double d = sh_Jw[k * kSkW + lane];
@@ -325,10 +338,9 @@ __global__ __launch_bounds__(NTH) void sk_block_kernel(SkBlockParams P)
                         mlast[a] = site_k;
                     }
                     sp ^= dup ? 1u : 0u;
-                    ok = verdict(-P.beta * f);
-                    B = __ballot(ok) & ((~0ull << k) << 1);
+                    B = verdict(-P.beta * f) & ((~0ull << k) << 1);
                 }
-                while (next_sample[a] <= it0 + nv) {
+                while (next_sample[a] <= it0 + nv) {                    // the samples behind the block's last accepted move
                     if (P.Es && lane == 0) P.Es[ns[a] * Rp + grp * kSkRB + r8 + r] = E_run[a];
                     ns[a] += 1; next_sample[a] += P.step;
                 }
