@@ -478,7 +478,6 @@ template <int K, bool CM>
 __device__ __forceinline__ void big_apply_body(const BigSweepParams& P, const uint32_t* __restrict__ masks, uint32_t* __restrict__ img, uint32_t cap, int lgr)
 {
     constexpr int NT = (K + 1) / 2;
-    constexpr int NM = CM ? 1 : NT;                           // mask words per attempt
     constexpr int REC = big_rec_words(K);
     constexpr int U = RRRMC_BIG_ROUND / kBigApplyThreads;     // attempts per thread and round
     constexpr int NTH = kBigApplyThreads;

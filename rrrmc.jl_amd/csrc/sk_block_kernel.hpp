@@ -325,7 +325,9 @@ __global__ __launch_bounds__(NTH) void sk_block_kernel(SkBlockParams P)
                     const bool dup = (int32_t)sv == site_k;
                     // the attempt's word for the apply phase, written into lane k of accw (v_writelane: this compiler has no builtin for it)
                     const uint32_t aw = 1u | (swapped ? 0x100u : 0u) | (spk << 16);
-                    asm volatile("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(accw) : "s"(aw), "s"(k) : "m0");       // (one SGPR + M0: the constant bus takes one scalar source)
+                    // (one SGPR + M0: the constant bus takes one scalar source; M0 is the compiler's, so it is put back)
+                    uint32_t m0_keep;
+                    asm volatile("s_mov_b32 %1, m0\n\ts_mov_b32 m0, %3\n\tv_writelane_b32 %0, %2, m0\n\ts_mov_b32 m0, %1" : "+v"(accw), "=&s"(m0_keep) : "s"(aw), "s"(k));
                     if (__builtin_expect(swapped, 0)) {
                         const double t = f; f = fl; fl = t;
                     } else {
