@@ -95,62 +95,79 @@ __device__ __forceinline__ double sk_readlane_f64(double v, int lane)
 // each branch — two thirds of the loop).  w = the attempt's word from the deciding wavefronts (bit r accepted, 8 + r undo swap, 16 + r the
 // moved spin before its flip); own = 0 in the wavefronts that do not hold the moved site, else 1 + its q; lb = the moved site's lane bit.
 //   not accepted:  two scalar instructions.
-//   accepted:      lfields_last[j] = lfj (all lanes, all q first); lfields[j] = lfj + 4 sigma J (SK.jl:256-262) as two half-masked adds — sigma = -1 in the
-//                  lanes whose spin equals the moved spin before its flip, i.e. sm ^ S with S = spb ? 0 : ~0, so there is no sign
-//                  arithmetic at all; then lfields[move] = -lfm in the owner's lane (SK.jl:263-264; x * -1.0 is exact) and the spin flip
+//   accepted:      lfields_last[j] = lfj (all q first); lfields[j] = lfj + 4 sigma J (SK.jl:256-262) as one fused multiply-add per site word,
+//                  D * sigma + lfj with sigma = +-1.0 (exact product: the add's result) — sigma = -1 in the lanes whose spin equals the moved
+//                  spin before its flip; then lfields[move] = -lfm in the owner's lane (SK.jl:263-264; x * -1.0 is exact) and the spin flip
 //                  in the lane mask (spinflip!, Interface.jl:89-92).
 //   undo swap:     lfields <-> lfields_last (SK.jl:247-250) and the spin flips back.
-// All lanes are active at every call site (uniform control flow of a full workgroup): EXEC returns to all ones.
-#define SK_CPY_Q(LF, LFL) "v_mov_b64 " LFL ", " LF "\n\t"          /* (all lanes: before any of the half-masked adds) */
-#define SK_ADD_Q(LF, LFL, SM, D) \
-    "s_xor_b64 exec, " SM ", %[S]\n\tv_add_f64 " LF ", " LFL ", -" D "\n\ts_not_b64 exec, exec\n\tv_add_f64 " LF ", " LFL ", " D "\n\t"
+// All lanes are active at every call site (uniform control flow of a full workgroup): EXEC returns to all ones.  T0 / T1 / TP name the
+// statements' scratch pair (declared as clobbered).
+#define SK_CPY_Q(LF, LFL) "v_mov_b64 " LFL ", " LF "\n\t"
+// lfields[j] = lfj + 4 sigma J as ONE fused multiply-add with sigma = +-1.0 built from the spin mask (x * +-1.0 is exact, so the result is
+// the add's, bit for bit): v[254:255] = {0, sm ? 0xbff00000 : 0x3ff00000}; the sign of the moved spin picks the code path (D or -D as
+// the multiplicand), so EXEC is never written here — the compute unit's one scalar unit is what two co-resident workgroups compete
+// for, and the two half-masked adds of the first version cost two scalar instructions per site word and replica
+#define SK_FMA_Q(LF, LFL, SM, D, T1, TP) "v_cndmask_b32 " T1 ", %[c1], %[cm1], " SM "\n\tv_fma_f64 " LF ", " D ", " TP ", " LFL "\n\t"
 #define SK_OWN_Q(QP1, LF, LFL, SM) \
     "s_cmp_eq_u32 %[own], " #QP1 "\n\ts_cbranch_scc0 1f\n\tv_mul_f64 " LF ", " LFL ", -1.0\n\ts_xor_b64 " SM ", " SM ", %[lb]\n1:\n\t"
-#define SK_SWP_Q(LF, LFL) "v_mov_b64 %[tv], " LF "\n\tv_mov_b64 " LF ", " LFL "\n\tv_mov_b64 " LFL ", %[tv]\n\t"
+#define SK_SWP_Q(LF, LFL, TP) "v_mov_b64 " TP ", " LF "\n\tv_mov_b64 " LF ", " LFL "\n\tv_mov_b64 " LFL ", " TP "\n\t"
 #define SK_SWO_Q(QP1, SM) "s_cmp_eq_u32 %[own], " #QP1 "\n\ts_cbranch_scc0 1f\n\ts_xor_b64 " SM ", " SM ", %[lb]\n1:\n\t"
-#define SK_HEAD(R) \
-    "s_bitcmp1_b32 %[w], " #R "\n\ts_cbranch_scc0 9f\n\ts_bitcmp1_b32 %[w], " #R "+8\n\ts_cbranch_scc1 5f\n\t" \
-    "s_bitcmp1_b32 %[w], " #R "+16\n\ts_cselect_b64 %[S], 0, -1\n\t"
-#define SK_MID "s_mov_b64 exec, -1\n\ts_cmp_eq_u32 %[own], 0\n\ts_cbranch_scc1 9f\n\ts_mov_b64 exec, %[lb]\n\t"
+// not accepted -> 9; undo swap -> 5; then the copies (shared), and the moved spin's sign picks the multiplicand: spin bit 1 -> 4 (sigma = -1 where
+// the lane's spin equals it: +D), else fall through (-D)
+#define SK_HEAD(R, T0) \
+    "s_bitcmp1_b32 %[w], " #R "\n\ts_cbranch_scc0 9f\n\ts_bitcmp1_b32 %[w], " #R "+8\n\ts_cbranch_scc1 5f\n\tv_mov_b32 " T0 ", 0\n\t"
+#define SK_SIGN(R) "s_bitcmp1_b32 %[w], " #R "+16\n\ts_cbranch_scc1 4f\n\t"
+#define SK_MID "6:\n\ts_cmp_eq_u32 %[own], 0\n\ts_cbranch_scc1 9f\n\ts_mov_b64 exec, %[lb]\n\t"
 #define SK_TAIL "s_mov_b64 exec, -1\n\ts_branch 9f\n5:\n\t"
-#define SK_APPLY1(R, lf, lfl, sm, d) \
-    asm volatile(SK_HEAD(R) SK_CPY_Q("%[a0]", "%[b0]") SK_ADD_Q("%[a0]", "%[b0]", "%[m0]", "%[d0]") SK_MID SK_OWN_Q(1, "%[a0]", "%[b0]", "%[m0]") SK_TAIL \
-                 SK_SWP_Q("%[a0]", "%[b0]") SK_SWO_Q(1, "%[m0]") "9:" \
-                 : [a0] "+v"(lf[0][R]), [b0] "+v"(lfl[0][R]), [m0] "+s"(sm[0][R]), [S] "=&s"(tS), [tv] "=&v"(tV) \
-                 : [d0] "v"(d[0]), [w] "s"(w), [own] "s"(own), [lb] "s"(lb) : "scc")
-#define SK_APPLY2(R, lf, lfl, sm, d) \
-    asm volatile(SK_HEAD(R) SK_CPY_Q("%[a0]", "%[b0]") SK_CPY_Q("%[a1]", "%[b1]") SK_ADD_Q("%[a0]", "%[b0]", "%[m0]", "%[d0]") SK_ADD_Q("%[a1]", "%[b1]", "%[m1]", "%[d1]") SK_MID \
+#define SK_OPS_COMMON [c1] "v"(c_one), [cm1] "v"(c_mone), [w] "s"(w), [own] "s"(own), [lb] "s"(lb)
+#define SK_APPLY1(R, lf, lfl, sm, d, T0, T1, TP) \
+    asm volatile(SK_HEAD(R, T0) SK_CPY_Q("%[a0]", "%[b0]") SK_SIGN(R) SK_FMA_Q("%[a0]", "%[b0]", "%[m0]", "-%[d0]", T1, TP) "s_branch 6f\n4:\n\t" \
+                 SK_FMA_Q("%[a0]", "%[b0]", "%[m0]", "%[d0]", T1, TP) SK_MID SK_OWN_Q(1, "%[a0]", "%[b0]", "%[m0]") SK_TAIL \
+                 SK_SWP_Q("%[a0]", "%[b0]", TP) SK_SWO_Q(1, "%[m0]") "9:" \
+                 : [a0] "+v"(lf[0][R]), [b0] "+v"(lfl[0][R]), [m0] "+s"(sm[0][R]) \
+                 : [d0] "v"(d[0]), SK_OPS_COMMON : "scc", T0, T1)
+#define SK_APPLY2(R, lf, lfl, sm, d, T0, T1, TP) \
+    asm volatile(SK_HEAD(R, T0) SK_CPY_Q("%[a0]", "%[b0]") SK_CPY_Q("%[a1]", "%[b1]") SK_SIGN(R) \
+                 SK_FMA_Q("%[a0]", "%[b0]", "%[m0]", "-%[d0]", T1, TP) SK_FMA_Q("%[a1]", "%[b1]", "%[m1]", "-%[d1]", T1, TP) "s_branch 6f\n4:\n\t" \
+                 SK_FMA_Q("%[a0]", "%[b0]", "%[m0]", "%[d0]", T1, TP) SK_FMA_Q("%[a1]", "%[b1]", "%[m1]", "%[d1]", T1, TP) SK_MID \
                  SK_OWN_Q(1, "%[a0]", "%[b0]", "%[m0]") SK_OWN_Q(2, "%[a1]", "%[b1]", "%[m1]") SK_TAIL \
-                 SK_SWP_Q("%[a0]", "%[b0]") SK_SWP_Q("%[a1]", "%[b1]") SK_SWO_Q(1, "%[m0]") SK_SWO_Q(2, "%[m1]") "9:" \
-                 : [a0] "+v"(lf[0][R]), [b0] "+v"(lfl[0][R]), [m0] "+s"(sm[0][R]), [a1] "+v"(lf[1][R]), [b1] "+v"(lfl[1][R]), [m1] "+s"(sm[1][R]), \
-                   [S] "=&s"(tS), [tv] "=&v"(tV) \
-                 : [d0] "v"(d[0]), [d1] "v"(d[1]), [w] "s"(w), [own] "s"(own), [lb] "s"(lb) : "scc")
-#define SK_APPLY3(R, lf, lfl, sm, d) \
-    asm volatile(SK_HEAD(R) SK_CPY_Q("%[a0]", "%[b0]") SK_CPY_Q("%[a1]", "%[b1]") SK_CPY_Q("%[a2]", "%[b2]") \
-                 SK_ADD_Q("%[a0]", "%[b0]", "%[m0]", "%[d0]") SK_ADD_Q("%[a1]", "%[b1]", "%[m1]", "%[d1]") SK_ADD_Q("%[a2]", "%[b2]", "%[m2]", "%[d2]") SK_MID \
+                 SK_SWP_Q("%[a0]", "%[b0]", TP) SK_SWP_Q("%[a1]", "%[b1]", TP) SK_SWO_Q(1, "%[m0]") SK_SWO_Q(2, "%[m1]") "9:" \
+                 : [a0] "+v"(lf[0][R]), [b0] "+v"(lfl[0][R]), [m0] "+s"(sm[0][R]), [a1] "+v"(lf[1][R]), [b1] "+v"(lfl[1][R]), [m1] "+s"(sm[1][R]) \
+                 : [d0] "v"(d[0]), [d1] "v"(d[1]), SK_OPS_COMMON : "scc", T0, T1)
+#define SK_APPLY3(R, lf, lfl, sm, d, T0, T1, TP) \
+    asm volatile(SK_HEAD(R, T0) SK_CPY_Q("%[a0]", "%[b0]") SK_CPY_Q("%[a1]", "%[b1]") SK_CPY_Q("%[a2]", "%[b2]") SK_SIGN(R) \
+                 SK_FMA_Q("%[a0]", "%[b0]", "%[m0]", "-%[d0]", T1, TP) SK_FMA_Q("%[a1]", "%[b1]", "%[m1]", "-%[d1]", T1, TP) SK_FMA_Q("%[a2]", "%[b2]", "%[m2]", "-%[d2]", T1, TP) \
+                 "s_branch 6f\n4:\n\t" \
+                 SK_FMA_Q("%[a0]", "%[b0]", "%[m0]", "%[d0]", T1, TP) SK_FMA_Q("%[a1]", "%[b1]", "%[m1]", "%[d1]", T1, TP) SK_FMA_Q("%[a2]", "%[b2]", "%[m2]", "%[d2]", T1, TP) SK_MID \
                  SK_OWN_Q(1, "%[a0]", "%[b0]", "%[m0]") SK_OWN_Q(2, "%[a1]", "%[b1]", "%[m1]") SK_OWN_Q(3, "%[a2]", "%[b2]", "%[m2]") SK_TAIL \
-                 SK_SWP_Q("%[a0]", "%[b0]") SK_SWP_Q("%[a1]", "%[b1]") SK_SWP_Q("%[a2]", "%[b2]") \
+                 SK_SWP_Q("%[a0]", "%[b0]", TP) SK_SWP_Q("%[a1]", "%[b1]", TP) SK_SWP_Q("%[a2]", "%[b2]", TP) \
                  SK_SWO_Q(1, "%[m0]") SK_SWO_Q(2, "%[m1]") SK_SWO_Q(3, "%[m2]") "9:" \
                  : [a0] "+v"(lf[0][R]), [b0] "+v"(lfl[0][R]), [m0] "+s"(sm[0][R]), [a1] "+v"(lf[1][R]), [b1] "+v"(lfl[1][R]), [m1] "+s"(sm[1][R]), \
-                   [a2] "+v"(lf[2][R]), [b2] "+v"(lfl[2][R]), [m2] "+s"(sm[2][R]), [S] "=&s"(tS), [tv] "=&v"(tV) \
-                 : [d0] "v"(d[0]), [d1] "v"(d[1]), [d2] "v"(d[2]), [w] "s"(w), [own] "s"(own), [lb] "s"(lb) : "scc")
-#define SK_APPLY4(R, lf, lfl, sm, d) \
-    asm volatile(SK_HEAD(R) SK_CPY_Q("%[a0]", "%[b0]") SK_CPY_Q("%[a1]", "%[b1]") SK_CPY_Q("%[a2]", "%[b2]") SK_CPY_Q("%[a3]", "%[b3]") \
-                 SK_ADD_Q("%[a0]", "%[b0]", "%[m0]", "%[d0]") SK_ADD_Q("%[a1]", "%[b1]", "%[m1]", "%[d1]") \
-                 SK_ADD_Q("%[a2]", "%[b2]", "%[m2]", "%[d2]") SK_ADD_Q("%[a3]", "%[b3]", "%[m3]", "%[d3]") SK_MID \
+                   [a2] "+v"(lf[2][R]), [b2] "+v"(lfl[2][R]), [m2] "+s"(sm[2][R]) \
+                 : [d0] "v"(d[0]), [d1] "v"(d[1]), [d2] "v"(d[2]), SK_OPS_COMMON : "scc", T0, T1)
+#define SK_APPLY4(R, lf, lfl, sm, d, T0, T1, TP) \
+    asm volatile(SK_HEAD(R, T0) SK_CPY_Q("%[a0]", "%[b0]") SK_CPY_Q("%[a1]", "%[b1]") SK_CPY_Q("%[a2]", "%[b2]") SK_CPY_Q("%[a3]", "%[b3]") SK_SIGN(R) \
+                 SK_FMA_Q("%[a0]", "%[b0]", "%[m0]", "-%[d0]", T1, TP) SK_FMA_Q("%[a1]", "%[b1]", "%[m1]", "-%[d1]", T1, TP) \
+                 SK_FMA_Q("%[a2]", "%[b2]", "%[m2]", "-%[d2]", T1, TP) SK_FMA_Q("%[a3]", "%[b3]", "%[m3]", "-%[d3]", T1, TP) "s_branch 6f\n4:\n\t" \
+                 SK_FMA_Q("%[a0]", "%[b0]", "%[m0]", "%[d0]", T1, TP) SK_FMA_Q("%[a1]", "%[b1]", "%[m1]", "%[d1]", T1, TP) \
+                 SK_FMA_Q("%[a2]", "%[b2]", "%[m2]", "%[d2]", T1, TP) SK_FMA_Q("%[a3]", "%[b3]", "%[m3]", "%[d3]", T1, TP) SK_MID \
                  SK_OWN_Q(1, "%[a0]", "%[b0]", "%[m0]") SK_OWN_Q(2, "%[a1]", "%[b1]", "%[m1]") SK_OWN_Q(3, "%[a2]", "%[b2]", "%[m2]") \
                  SK_OWN_Q(4, "%[a3]", "%[b3]", "%[m3]") SK_TAIL \
-                 SK_SWP_Q("%[a0]", "%[b0]") SK_SWP_Q("%[a1]", "%[b1]") SK_SWP_Q("%[a2]", "%[b2]") SK_SWP_Q("%[a3]", "%[b3]") \
+                 SK_SWP_Q("%[a0]", "%[b0]", TP) SK_SWP_Q("%[a1]", "%[b1]", TP) SK_SWP_Q("%[a2]", "%[b2]", TP) SK_SWP_Q("%[a3]", "%[b3]", TP) \
                  SK_SWO_Q(1, "%[m0]") SK_SWO_Q(2, "%[m1]") SK_SWO_Q(3, "%[m2]") SK_SWO_Q(4, "%[m3]") "9:" \
                  : [a0] "+v"(lf[0][R]), [b0] "+v"(lfl[0][R]), [m0] "+s"(sm[0][R]), [a1] "+v"(lf[1][R]), [b1] "+v"(lfl[1][R]), [m1] "+s"(sm[1][R]), \
-                   [a2] "+v"(lf[2][R]), [b2] "+v"(lfl[2][R]), [m2] "+s"(sm[2][R]), [a3] "+v"(lf[3][R]), [b3] "+v"(lfl[3][R]), [m3] "+s"(sm[3][R]), \
-                   [S] "=&s"(tS), [tv] "=&v"(tV) \
-                 : [d0] "v"(d[0]), [d1] "v"(d[1]), [d2] "v"(d[2]), [d3] "v"(d[3]), [w] "s"(w), [own] "s"(own), [lb] "s"(lb) : "scc")
-#define SK_APPLY_ALL(M, lf, lfl, sm, d) \
-    do { M(0, lf, lfl, sm, d); M(1, lf, lfl, sm, d); M(2, lf, lfl, sm, d); M(3, lf, lfl, sm, d); \
-         M(4, lf, lfl, sm, d); M(5, lf, lfl, sm, d); M(6, lf, lfl, sm, d); M(7, lf, lfl, sm, d); } while (0)
-#define SK_APPLY_HALF(M, lf, lfl, sm, d) \
-    do { M(0, lf, lfl, sm, d); M(1, lf, lfl, sm, d); M(2, lf, lfl, sm, d); M(3, lf, lfl, sm, d); } while (0)
+                   [a2] "+v"(lf[2][R]), [b2] "+v"(lfl[2][R]), [m2] "+s"(sm[2][R]), [a3] "+v"(lf[3][R]), [b3] "+v"(lfl[3][R]), [m3] "+s"(sm[3][R]) \
+                 : [d0] "v"(d[0]), [d1] "v"(d[1]), [d2] "v"(d[2]), [d3] "v"(d[3]), SK_OPS_COMMON : "scc", T0, T1)
+#define SK_APPLY_ALL(M, lf, lfl, sm, d, SCR) SK_APPLY_ALL_(M, lf, lfl, sm, d, SCR)        /* (SCR expands to the three names below) */
+#define SK_APPLY_ALL_(M, lf, lfl, sm, d, T0, T1, TP) \
+    do { M(0, lf, lfl, sm, d, T0, T1, TP); M(1, lf, lfl, sm, d, T0, T1, TP); M(2, lf, lfl, sm, d, T0, T1, TP); M(3, lf, lfl, sm, d, T0, T1, TP); \
+         M(4, lf, lfl, sm, d, T0, T1, TP); M(5, lf, lfl, sm, d, T0, T1, TP); M(6, lf, lfl, sm, d, T0, T1, TP); M(7, lf, lfl, sm, d, T0, T1, TP); } while (0)
+#define SK_APPLY_HALF(M, lf, lfl, sm, d, SCR) SK_APPLY_HALF_(M, lf, lfl, sm, d, SCR)
+#define SK_APPLY_HALF_(M, lf, lfl, sm, d, T0, T1, TP) \
+    do { M(0, lf, lfl, sm, d, T0, T1, TP); M(1, lf, lfl, sm, d, T0, T1, TP); M(2, lf, lfl, sm, d, T0, T1, TP); M(3, lf, lfl, sm, d, T0, T1, TP); } while (0)
+// the statements' scratch pair: the top of the register file the thread count allows (1024 threads: 128 registers per thread)
+#define SK_SCRATCH_HI "v254", "v255", "v[254:255]"
+#define SK_SCRATCH_LO "v126", "v127", "v[126:127]"
 
 // RB = replicas per workgroup: 8 (one workgroup = one group of the [G][N][8] state) or 4 (two workgroups per group: replicas 4h .. 4h + 3,
 // h = blockIdx.x & 1).  Two 4-replica workgroups of 256 threads per CU instead of one 8-replica workgroup of 512: each tests half as many
@@ -210,6 +227,8 @@ __global__ __launch_bounds__(NTH) void sk_block_kernel(SkBlockParams P)
 #pragma unroll
     for (int a = 0; a < RPW; ++a) { ns[a] = P.it_base / P.step; next_sample[a] = (P.it_base / P.step + 1) * P.step; }
     double expc[17];
+    uint32_t c_one = 0x3ff00000u, c_mone = 0xbff00000u;          // high words of +-1.0 (SK_FMA_Q), kept in vector registers across the loop
+    asm volatile("" : "+v"(c_one), "+v"(c_mone));
     sk_exp_constants(expc);
 
     const int64_t nblk = (P.iters + kSkW - 1) / kSkW;
@@ -385,31 +404,33 @@ __global__ __launch_bounds__(NTH) void sk_block_kernel(SkBlockParams P)
             const uint32_t site = (uint32_t)__builtin_amdgcn_readlane((int)sv, k);
             const uint32_t own = (int)((site & (NTH - 1)) >> 6) == wv ? (site >> LGN) + 1u : 0u;
             const unsigned long long lb = 1ull << (site & 63u);
-            unsigned long long tS;
-            double tV;
 #ifdef RRRMC_SKB_ABL_NOASM
             asm volatile("" :: "s"(w), "s"(own), "s"(lb), "v"(d4[0]));           // timing experiment: the step's prelude and row loads only
             if constexpr (SPT == 99)
 #endif
-            if constexpr (RB == 8) {
-                if constexpr (SPT == 1) { SK_APPLY_ALL(SK_APPLY1, lf, lfl, sm, d4); }
-                else if constexpr (SPT == 2) { SK_APPLY_ALL(SK_APPLY2, lf, lfl, sm, d4); }
-                else if constexpr (SPT == 3) { SK_APPLY_ALL(SK_APPLY3, lf, lfl, sm, d4); }
-                else { SK_APPLY_ALL(SK_APPLY4, lf, lfl, sm, d4); }
+            if constexpr (NTH == 1024) {          // (RB == 8, one or two sites per thread)
+                if constexpr (SPT == 1) { SK_APPLY_ALL(SK_APPLY1, lf, lfl, sm, d4, SK_SCRATCH_LO); }
+                else { SK_APPLY_ALL(SK_APPLY2, lf, lfl, sm, d4, SK_SCRATCH_LO); }
+            } else if constexpr (RB == 8) {
+                if constexpr (SPT == 1) { SK_APPLY_ALL(SK_APPLY1, lf, lfl, sm, d4, SK_SCRATCH_HI); }
+                else if constexpr (SPT == 2) { SK_APPLY_ALL(SK_APPLY2, lf, lfl, sm, d4, SK_SCRATCH_HI); }
+                else if constexpr (SPT == 3) { SK_APPLY_ALL(SK_APPLY3, lf, lfl, sm, d4, SK_SCRATCH_HI); }
+                else { SK_APPLY_ALL(SK_APPLY4, lf, lfl, sm, d4, SK_SCRATCH_HI); }
             } else {
-                if constexpr (SPT == 1) { SK_APPLY_HALF(SK_APPLY1, lf, lfl, sm, d4); }
-                else if constexpr (SPT == 2) { SK_APPLY_HALF(SK_APPLY2, lf, lfl, sm, d4); }
-                else if constexpr (SPT == 3) { SK_APPLY_HALF(SK_APPLY3, lf, lfl, sm, d4); }
-                else { SK_APPLY_HALF(SK_APPLY4, lf, lfl, sm, d4); }
+                if constexpr (SPT == 1) { SK_APPLY_HALF(SK_APPLY1, lf, lfl, sm, d4, SK_SCRATCH_HI); }
+                else if constexpr (SPT == 2) { SK_APPLY_HALF(SK_APPLY2, lf, lfl, sm, d4, SK_SCRATCH_HI); }
+                else if constexpr (SPT == 3) { SK_APPLY_HALF(SK_APPLY3, lf, lfl, sm, d4, SK_SCRATCH_HI); }
+                else { SK_APPLY_HALF(SK_APPLY4, lf, lfl, sm, d4, SK_SCRATCH_HI); }
             }
-            (void)tS; (void)tV;
         };
         for (int k0 = 0; k0 < kSkW; k0 += 2 * PF) {
 #pragma unroll
             for (int kk = 0; kk < PF; ++kk) {           // rows of attempts k0 + PF .. k0 + 2 PF - 1
                 const uint32_t stn = (uint32_t)__builtin_amdgcn_readlane((int)sv, k0 + PF + kk);
 #pragma unroll
-#ifndef RRRMC_SKB_NOLOAD
+#if defined(RRRMC_SKB_HALFROW)
+                for (int q = 0; q < SPT; ++q) JB[kk][q] = q < (SPT + 1) / 2 ? P.J4[(size_t)stn * P.ldJ + (q * NTH + tid)] : JB[kk][q - (SPT + 1) / 2];   // timing experiment: half the row traffic (wrong couplings)
+#elif !defined(RRRMC_SKB_NOLOAD)
                 for (int q = 0; q < SPT; ++q) JB[kk][q] = P.J4[(size_t)stn * P.ldJ + (q * NTH + tid)];
 #else
                 for (int q = 0; q < SPT; ++q) JB[kk][q] = P.J4[(size_t)(stn & 7u) * P.ldJ + (q * NTH + tid)];      // timing experiment: always-hot rows
@@ -422,7 +443,9 @@ __global__ __launch_bounds__(NTH) void sk_block_kernel(SkBlockParams P)
             for (int kk = 0; kk < PF; ++kk) {           // rows of attempts k0 + 2 PF .. k0 + 3 PF - 1
                 const uint32_t stn = (uint32_t)__builtin_amdgcn_readlane((int)svn, (k0 + 2 * PF + kk) & 63);
 #pragma unroll
-#ifndef RRRMC_SKB_NOLOAD
+#if defined(RRRMC_SKB_HALFROW)
+                for (int q = 0; q < SPT; ++q) JA[kk][q] = q < (SPT + 1) / 2 ? P.J4[(size_t)stn * P.ldJ + (q * NTH + tid)] : JA[kk][q - (SPT + 1) / 2];
+#elif !defined(RRRMC_SKB_NOLOAD)
                 for (int q = 0; q < SPT; ++q) JA[kk][q] = P.J4[(size_t)stn * P.ldJ + (q * NTH + tid)];
 #else
                 for (int q = 0; q < SPT; ++q) JA[kk][q] = P.J4[(size_t)(stn & 7u) * P.ldJ + (q * NTH + tid)];
