@@ -228,7 +228,9 @@ __global__ __launch_bounds__(kRrrThreads) void rrr_quant_wave_kernel(RrrParams P
     // every condition of the chain is wave-uniform, but its operands are kept in vector registers on purpose (see the header), so the
     // compiler would wrap each `if` in an exec-mask region (save, branch if empty, restore); uni() turns it back into a scalar branch
     // with all lanes active inside
-    auto uni = [](bool c) -> bool { return __ballot(c) != 0ull; };
+    // (the raw ballot builtin on the comparison, and the mask made opaque: HIP's __ballot(c) != 0 goes through a vector bool — v_cndmask,
+    // v_cmp_ne — before it becomes the scalar condition it was)
+    auto uni = [](bool c) -> bool { unsigned long long m = __builtin_amdgcn_ballot_w64(c); asm volatile("" : "+s"(m)); return m != 0ull; };
     // ArraySet delete!(S, j) + push!(D, j) (ArraySets.jl:56-76) on the segmented array; p = the slot of j (absolute), act = the move
     // happens at all (a Trotter neighbour whose class does not change is skipped, DeltaE.jl:257).  Branch-free: an inactive move reads
     // and discards.  Returns the element that took j's place (the old last of S; j itself when j was the last) so that the caller can
