@@ -10,9 +10,11 @@
 //            so the next ACCEPTED attempt is the first set bit of a ballot: rejected attempts cost nothing.  An accepted attempt k
 //            updates the lanes m > k exactly as update_cache! (SK.jl:239-276) updates those sites' entries — f_m += 4 sigma J[k][m]
 //            (one row of the block's 64 x 64 coupling sub-matrix, LDS), lfields[move] = -lfm for a repeated site, the array swap of
-//            SK.jl:247-250 when the previous accepted move was the same site — and re-evaluates their verdicts (one vector det_exp);
+//            SK.jl:247-250 when the previous accepted move was the same site — and re-evaluates their verdicts (ln u against x, the
+//            exponential only inside a 1e-9 band: see the decide phase);
 //   apply    all threads apply the block's accepted moves in order to the full field arrays, which live in registers (thread t owns
-//            sites t, t + NTH, ... of the workgroup's 8 replicas, as in sk_sweep_kernel); the row of 4J is prefetched PF steps ahead.
+//            sites t, t + NTH, ... of the workgroup's 8 or 4 replicas, as in sk_sweep_kernel); the rows of 4J are loaded a group of
+//            PF attempts ahead.
 //
 // Three workgroup barriers per 64 attempts instead of two per attempt, and the chain's length is counted in accepted moves.  Every
 // field — tracked in the window or in the registers — receives the reference's sequence of IEEE operations, so trajectories, energies
