@@ -272,6 +272,98 @@ function replay_rrrMC_skn(t)
     return ok
 end
 
+# rrrMC(X::SingleGraph) (src/RRRMC.jl:149-219) and bklMC (:311-359) on GraphRRG{Int,(-1,1),K} with the reference's own DeltaECache{Int,L}:
+# gen_ΔEcache, compute_staged!, compute_reverse_probabilities!, apply_staged!, apply_move! are the reference's; rand_move, rand_skip and the
+# `rand() < c` take their rand() from the tape.
+function replay_rrr_bkl_rrg(t)
+    bkl = t["kind"] == "bklMC_rrg"
+    N, K = parse(Int, t["N"]), parse(Int, t["K"])
+    β, iters, step = parse(Float64, t["beta"]), parse(Int, t["iters"]), parse(Int, t["step"])
+    A, J = tuples(ints(t["A"]), K), tuples(ints(t["J"]), K)
+    X = RRRMC.RRG.GraphRRG{Int,(-1, 1),K}(A, J)
+    C = config_from(t["C0"], N)
+    ucls, umem = parse.(Float64, t["u_class"]), parse.(UInt64, t["u_member"])
+    function rand_move(cache, u1, u2)                                                  # src/DeltaE.jl:146-167
+        ΔElist, ascache, T, z = cache.ΔElist, cache.ascache, cache.T, cache.z
+        L = length(ΔElist)
+        r = u1 * z
+        k = 0
+        cT = 0.0
+        for outer k = 1:2L
+            cT += T[k]
+            r < cT && break
+        end
+        r < cT || while T[k] == 0
+            k -= 1
+        end
+        ΔE = k ≤ L ? -ΔElist[k] : ΔElist[k - L]
+        as = ascache[k]
+        return as.v[Int((UInt128(u2) * as.t) >> 64) + 1], ΔE                           # rand(1:t), src/ArraySets.jl:83
+    end
+    Es = Int[]
+    E = energy(X, C)
+    accepted, staged_its, it = 0, 0, 0
+    if !bkl
+        uacc = parse.(Float64, t["u_accept"])
+        staged_thr, λ = parse(Float64, t["staged_thr"]), parse(Float64, t["staged_thr_fact"]) / N
+        cache = gen_ΔEcache(X, C, β)
+        acc_rate = 0.5
+        for it = 1:iters                                                               # src/RRRMC.jl:178-210
+            it % step == 0 && push!(Es, E)
+            acc = false
+            if acc_rate < staged_thr
+                staged_its += 1
+                z = get_z(cache)                                                       # step_rrr, src/RRRMC.jl:131-138
+                move, ΔE = rand_move(cache, ucls[it], umem[it])
+                compute_staged!(X, C, move, cache)
+                c = z / compute_reverse_probabilities!(cache)
+                if uacc[it] < c
+                    spinflip!(X, C, move)
+                    apply_staged!(cache)
+                    E += ΔE; accepted += 1; acc = true
+                end
+            else
+                move, ΔE = rand_move(cache, ucls[it], umem[it])
+                c = apply_move!(X, C, move, cache)
+                if uacc[it] < c
+                    E += ΔE; accepted += 1; acc = true
+                else
+                    apply_move!(X, C, move, cache)
+                end
+            end
+            acc_rate = acc_rate * (1 - λ) + acc * λ
+        end
+        it = iters
+    else
+        uskip = parse.(Float64, t["u_skip"])
+        cache = gen_ΔEcache(X, C, β, false)
+        nextstep, m = step, 0
+        while it < iters                                                               # src/RRRMC.jl:331-349
+            m += 1
+            skip = floor(Int, Base.log1p(-uskip[m]) / Base.log1p(-cache.z / N))        # rand_skip, src/DeltaE.jl:141-144
+            move, ΔE = rand_move(cache, ucls[m], umem[m])
+            out = false
+            while it + skip + 1 ≥ nextstep
+                push!(Es, E)
+                nextstep += step
+                nextstep > iters && (out = true; break)
+            end
+            out && break
+            apply_move!(X, C, move, cache)                                             # apply_step_bkl!, src/RRRMC.jl:297-298
+            it += skip + 1
+            E += ΔE
+            accepted += 1
+        end
+        staged_its = accepted
+    end
+    DeltaE.check_consistency(cache)
+    ok = Es == ints(t["expected_Es"]) && chunks_hex(C) == t["expected_chunks"] && accepted == parse(Int, t["expected_accepted"]) &&
+         staged_its == parse(Int, t["expected_staged_its"]) && it == parse(Int, t["expected_iters_done"]) && E == energy(X, C) &&
+         [length(a) for a in cache.ascache] == ints(t["expected_sizes"]) && cache.pos == ints(t["expected_pos"])
+    println(ok ? "$(t["kind"]) tape: reference == tape ($(it) iterations, $(accepted) moves accepted, $(staged_its) staged)" : "$(t["kind"]) tape: MISMATCH")
+    return ok
+end
+
 function main(paths)
     allok = true
     for p in paths
@@ -279,11 +371,12 @@ function main(paths)
         k = t["kind"]
         allok &= k == "standardMC" ? (get(t, "form", "rrg") == "ea" ? replay_standardMC_ea(t) : replay_standardMC(t)) :
                  k == "rrrMC_quant" ? replay_rrrMC_quant(t) :
-                 k == "rrrMC_skn" ? replay_rrrMC_skn(t) : replay_standardMC_sk(t)
+                 k == "rrrMC_skn" ? replay_rrrMC_skn(t) :
+                 (k == "rrrMC_rrg" || k == "bklMC_rrg") ? replay_rrr_bkl_rrg(t) : replay_standardMC_sk(t)
     end
     exit(allok ? 0 : 1)
 end
 
 main(isempty(ARGS) ? [joinpath(@__DIR__, "..", "tests", "golden", f) for f in
                       ("tape_rrg_n128.txt", "tape_quant_nk16_m4.txt", "tape_quant_direct.txt", "tape_ea_l2_d3.txt", "tape_skn_n24.txt",
-                       "tape_sk_n10.txt", "tape_rrr_skn_n10.txt")] : ARGS)
+                       "tape_sk_n10.txt", "tape_rrr_skn_n10.txt", "tape_rrr_rrg_n64.txt", "tape_bkl_rrg_n64.txt")] : ARGS)

@@ -215,6 +215,45 @@ def write_rrr_skn(path, seed, N=10, beta=2.0, iters=2500, step=50, staged_thr=0.
     return _finish(path, body, check)
 
 
+def write_rrr_bkl_rrg(path, seed, bkl, N=64, K=3, beta=2.0, iters=4000, step=100, staged_thr=0.5, staged_thr_fact=5.0, replica=0):
+    """rrrMC(X::SingleGraph) (bkl = False) or bklMC (bkl = True) on GraphRRG{Int,(-1,1),K} with DeltaECache{Int,L} (SURVEY.md §8f rank 1)."""
+    A = O.gen_rrg(N, K, seed)
+    J = O.gen_couplings(A, seed)
+    C0 = O.init_config(seed, replica, N)
+    Es, ch, acc, staged, its, pos, sizes = O.rrr_sparse(A, J.astype(np.int32), beta, iters, step, seed, C0, replica=replica, staged_thr=staged_thr,
+                                                        staged_thr_fact=staged_thr_fact, bkl=bkl, want_cache=True)
+    key = np.array([seed & 0xFFFFFFFF, seed >> 32], np.uint32)
+    ndraw = acc + 1 if bkl else iters            # bklMC draws once per MOVE (the last one may end the run at a sample point)
+    ucls, umem, uthird = [], [], []
+    for g in range(1, ndraw + 1):                # RRR stream (DESIGN.md §2): sub 0 = (class uniform, member word), sub 1 = `rand() < c`, sub 2 = rand_skip
+        w0 = O.philox([g & 0xFFFFFFFF, g >> 32, replica, 8], key)
+        w1 = O.philox([g & 0xFFFFFFFF, g >> 32, replica, 8 | ((2 if bkl else 1) << 8)], key)
+        ucls.append(u53((int(w0[0]) << 32) | int(w0[1])))
+        umem.append((int(w0[2]) << 32) | int(w0[3]))
+        uthird.append(u53((int(w1[0]) << 32) | int(w1[1])))
+    kind = "bklMC_rrg" if bkl else "rrrMC_rrg"
+    body = ["# RRRMC tape v1 — %s on GraphRRG{Int,(-1,1),%d} with DeltaECache{Int,L} (src/DeltaE.jl:62-295), every random draw pre-drawn:" % ("bklMC (src/RRRMC.jl:311-359)" if bkl else "rrrMC(X::SingleGraph) (src/RRRMC.jl:149-219)", K),
+            "# u_class = rand() of rand_move (src/DeltaE.jl:148), u_member -> rand(1:t) as floor(u * t / 2^64) + 1 (src/ArraySets.jl:83),",
+            "# " + ("u_skip = rand() of rand_skip (src/DeltaE.jl:141-144); one set of draws per MOVE." if bkl else "u_accept = rand() of `rand() < c` (src/RRRMC.jl:192,202).") + "  Written by tests/golden/make_tapes.py",
+            "@kind " + kind, "@N %d" % N, "@K %d" % K, "@beta %r" % beta, "@iters %d" % iters, "@step %d" % step,
+            "@staged_thr %r" % staged_thr, "@staged_thr_fact %r" % staged_thr_fact, "@seed %d" % seed, "@replica %d" % replica,
+            fmt_array("A", ("%d" % (v + 1) for v in A.reshape(-1))), fmt_array("J", ("%d" % v for v in J.reshape(-1))),
+            fmt_array("C0", ("%016x" % int(c) for c in C0)),
+            fmt_array("u_class", (repr(u) for u in ucls)), fmt_array("u_member", ("%d" % u for u in umem)),
+            fmt_array("u_skip" if bkl else "u_accept", (repr(u) for u in uthird)),
+            fmt_array("expected_Es", ("%d" % int(e) for e in Es)), fmt_array("expected_chunks", ("%016x" % int(c) for c in ch)),
+            "@expected_accepted %d" % acc, "@expected_staged_its %d" % staged, "@expected_iters_done %d" % its,
+            fmt_array("expected_sizes", ("%d" % int(v) for v in sizes)), fmt_array("expected_pos", ("%d" % (int(v) + 1) for v in pos))]
+
+    def check(t):
+        got = TR.replay_rrr_bkl_rrg(t)
+        ok = (got["Es"] == [int(e) for e in Es] and got["chunks"] == [int(c) for c in ch] and got["accepted"] == acc and got["staged_its"] == staged
+              and got["iters_done"] == its and got["sizes"] == [int(v) for v in sizes] and got["pos"] == [int(v) + 1 for v in pos]
+              and got["min_margin"] >= 1e-9 and (bkl or 0 < staged < iters))
+        return ok, "%d iterations, %d moves accepted, staged %d, closest decision margin %.2e" % (its, acc, staged, got["min_margin"])
+    return _finish(path, body, check)
+
+
 if __name__ == "__main__":
     O.build()
     for seed in range(20261003, 20261003 + 50):
@@ -237,3 +276,5 @@ if __name__ == "__main__":
     tries(lambda sd: write_standard_sk(os.path.join(HERE, "tape_skn_n24.txt"), sd, 24, False, 1.0, 6000, 200), "a GraphSKNormal(24) tape with a swap")
     tries(lambda sd: write_standard_sk(os.path.join(HERE, "tape_sk_n10.txt"), sd, 10, True, 1.0, 4000, 100), "a GraphSK(10) tape with a swap")
     tries(lambda sd: write_rrr_skn(os.path.join(HERE, "tape_rrr_skn_n10.txt"), sd), "an rrrMC(GraphSKNormal(10)) tape with a safe margin")
+    tries(lambda sd: write_rrr_bkl_rrg(os.path.join(HERE, "tape_rrr_rrg_n64.txt"), sd, False), "an rrrMC(GraphRRG(64,3)) tape with both branches and a safe margin")
+    tries(lambda sd: write_rrr_bkl_rrg(os.path.join(HERE, "tape_bkl_rrg_n64.txt"), sd, True, iters=20000, step=500), "a bklMC(GraphRRG(64,3)) tape with a safe margin")

@@ -652,3 +652,170 @@ def replay_rrr_single_sk(tape, exp=math.exp):
         acc_rate = acc_rate * (1 - lam) + (1.0 if acc else 0.0) * lam
     return {"Es": Es, "chunks": chunks_of_bits(s), "accepted": accepted, "staged_its": staged_its, "min_margin": min(margin, ds.margin),
             "dEs": dEs, "z": ds.z, "refreshes": ds.refreshes, "swaps": X.swaps}
+
+
+# ---- rrrMC(X::SingleGraph) and bklMC on GraphRRG{Int,(-1,1),K}: src/RRRMC.jl:131-219, 311-359; src/DeltaE.jl:62-295 (round 3) -------
+def replay_rrr_bkl_rrg(tape, exp=math.exp, log1p=math.log1p):
+    """kind rrrMC_rrg: rrrMC(X::SingleGraph) with DeltaECache{Int,L} — rand_move's rand() and rand(1:t) (DeltaE.jl:148,164; ArraySets.jl:83)
+    and the `rand() < c` of RRRMC.jl:192,202 taken from the tape.  kind bklMC_rrg: bklMC (RRRMC.jl:311-359) — rand_skip's rand()
+    (DeltaE.jl:141-144) and rand_move's two draws per MOVE from the tape."""
+    bkl = tape["kind"] == "bklMC_rrg"
+    N, K = int(tape["N"]), int(tape["K"])
+    beta, iters, step = float(tape["beta"]), int(tape["iters"]), int(tape["step"])
+    A = [[int(v) for v in tape["A"][x * K:(x + 1) * K]] for x in range(N)]
+    J = [[int(v) for v in tape["J"][x * K:(x + 1) * K]] for x in range(N)]
+    uA = [[y for y, Jxy in zip(a, j) if Jxy != 0] for a, j in zip(A, J)]      # neighbors(X, i) = X.uA[i] (RRG.jl:133,261): the neighbours with a non-zero coupling
+    s = bits_of_chunks([int(c, 16) for c in tape["C0"]], N)
+    u_cls = [float(v) for v in tape["u_class"]]
+    u_mem = [int(v) for v in tape["u_member"]]
+    E, lfields = rrg_energy(A, J, s)
+    # allDeltaE(GraphRRG{Int,(-1,1),K}) (RRG.jl:262-264)
+    dElist = tuple(4 * (d - 1) for d in range(1, K // 2 + 2)) if K % 2 == 0 else tuple(2 * (2 * d - 1) for d in range(1, (K + 1) // 2 + 1))
+    L = len(dElist)
+    delta = lambda i: -lfields[i - 1]                          # delta_energy, RRG.jl:236-244
+
+    def cls(i):                                                # DeltaE.jl:79-84 / :246-250
+        dE = delta(i)
+        return dElist.index(abs(dE)) + 1 + L * (1 if (dE > 0 or (dE == 0 and s[i - 1] == 1)) else 0)
+
+    sets, pos = [ArraySet(N) for _ in range(2 * L)], [0] * (N + 1)
+    for i in range(1, N + 1):
+        pos[i] = cls(i)
+        sets[pos[i] - 1].push(i)
+    ft = [exp(-beta * d) for d in dElist]
+    fcls = lambda k: ft[k - L - 1] if k > L else 1.0           # get_class_f, DeltaE.jl:138-139
+    T = [sets[k - 1].t * fcls(k) for k in range(1, 2 * L + 1)]
+    z = 0.0
+    for x in T:
+        z += x
+    margin = float("inf")
+
+    def rand_move(g):                                          # DeltaE.jl:146-167
+        nonlocal margin
+        r = u_cls[g - 1] * z
+        k, cT = 0, 0.0
+        for k in range(1, 2 * L + 1):
+            cT += T[k - 1]
+            margin = min(margin, abs(r - cT) / z)
+            if r < cT:
+                break
+        if not (r < cT):
+            while T[k - 1] == 0:
+                k -= 1
+        dE = -dElist[k - 1] if k <= L else dElist[k - L - 1]
+        t = sets[k - 1].t
+        return sets[k - 1].v[((u_mem[g - 1] * t) >> 64) + 1], dE
+
+    def flip(i):
+        rrg_spinflip(A, J, s, lfields, i)
+
+    def staged_of(move):                                       # compute_staged! (DeltaE.jl:198-230)
+        flip(move)
+        st = []
+        for j in uA[move - 1]:
+            k0, k1 = pos[j], cls(j)
+            if k0 != k1:
+                st.append((j, k0, k1))
+        k0 = pos[move]
+        st.append((move, k0, k0 - L * (2 * (1 if k0 > L else 0) - 1)))
+        flip(move)
+        return st
+
+    def apply_move(move):                                      # DeltaE.jl:232-295
+        nonlocal z
+        flip(move)
+        zp = z
+        for j in uA[move - 1]:
+            k0, k1 = pos[j], cls(j)
+            if k0 == k1:
+                continue
+            f0, f1 = fcls(k0), fcls(k1)
+            T[k0 - 1] -= f0
+            T[k1 - 1] += f1
+            zp += f1 - f0
+            sets[k0 - 1].delete(j)
+            sets[k1 - 1].push(j)
+            pos[j] = k1
+        k0 = pos[move]
+        k1 = k0 - L * (2 * (1 if k0 > L else 0) - 1)
+        f0, f1 = fcls(k0), fcls(k1)
+        T[k0 - 1] -= f0
+        T[k1 - 1] += f1
+        zp += f1 - f0
+        sets[k0 - 1].delete(move)
+        sets[k1 - 1].push(move)
+        pos[move] = k1
+        c = z / zp
+        z = zp
+        return c
+
+    Es, accepted, staged_its = [], 0, 0
+    if not bkl:
+        u_acc = [float(v) for v in tape["u_accept"]]
+        staged_thr, lam, acc_rate = float(tape["staged_thr"]), float(tape["staged_thr_fact"]) / N, 0.5
+        for it in range(1, iters + 1):
+            if it % step == 0:
+                Es.append(E)
+            acc = False
+            if acc_rate < staged_thr:
+                staged_its += 1
+                z0 = z                                         # step_rrr, RRRMC.jl:131-138
+                move, dE = rand_move(it)
+                st = staged_of(move)
+                Tp, zp = list(T), z                            # compute_reverse_probabilities!, DeltaE.jl:184-196
+                for _, k0, k1 in st:
+                    f0, f1 = fcls(k0), fcls(k1)
+                    Tp[k0 - 1] -= f0
+                    Tp[k1 - 1] += f1
+                    zp += f1 - f0
+                c = z0 / zp
+                margin = min(margin, abs(u_acc[it - 1] - c) / c)
+                if u_acc[it - 1] < c:
+                    flip(move)
+                    for j, k0, k1 in st:                       # apply_staged!, DeltaE.jl:169-182
+                        sets[k0 - 1].delete(j)
+                        sets[k1 - 1].push(j)
+                        pos[j] = k1
+                    T[:] = Tp
+                    z = zp
+                    E += dE
+                    accepted += 1
+                    acc = True
+            else:
+                move, dE = rand_move(it)
+                c = apply_move(move)
+                margin = min(margin, abs(u_acc[it - 1] - c) / c)
+                if u_acc[it - 1] < c:
+                    E += dE
+                    accepted += 1
+                    acc = True
+                else:
+                    apply_move(move)
+            acc_rate = acc_rate * (1 - lam) + (1.0 if acc else 0.0) * lam
+        its_done = iters
+    else:
+        u_skip = [float(v) for v in tape["u_skip"]]
+        it, nextstep, m, out = 0, step, 0, False
+        while it < iters and not out:
+            m += 1
+            q = log1p(-u_skip[m - 1]) / log1p(-z / N)          # rand_skip, DeltaE.jl:141-144
+            skip = int(math.floor(q))
+            margin = min(margin, min(q - skip, skip + 1 - q) / max(q, 1.0))
+            move, dE = rand_move(m)
+            while it + skip + 1 >= nextstep:
+                Es.append(E)
+                nextstep += step
+                if nextstep > iters:
+                    out = True
+                    break
+            if out:
+                break
+            apply_move(move)                                   # apply_step_bkl!, RRRMC.jl:297-298
+            it += skip + 1
+            E += dE
+            accepted += 1
+        staged_its, its_done = accepted, it
+    assert E == rrg_energy(A, J, s)[0]
+    assert all(pos[i] == cls(i) for i in range(1, N + 1))      # check_consistency's class test (DeltaE.jl:120-136)
+    return {"Es": Es, "chunks": chunks_of_bits(s), "accepted": accepted, "staged_its": staged_its, "iters_done": its_done,
+            "min_margin": margin, "sizes": [st.t for st in sets], "pos": pos[1:]}

@@ -252,3 +252,59 @@ def test_hip_library_reproduces_the_round3_tapes(pkg):
         assert [float(e) for e in Es[0]] == _floats(t["expected_Es"])
         assert int(acc[0]) == int(t["expected_accepted"]) and int(staged[0]) == int(t["expected_staged_its"])
         assert [int(c) for c in eng.get_config().s[0]] == [int(c, 16) for c in t["expected_chunks"]]
+
+
+# ---- tapes of the reduced-rejection-rate and rejection-free samplers on GraphRRG: rrrMC(X::SingleGraph) with
+#      DeltaECache{Int,L} (staged and direct branch), bklMC with rand_skip ---------------------------------------------------------------
+RRRG, BKLG = (os.path.join(GOLD, f) for f in ("tape_rrr_rrg_n64.txt", "tape_bkl_rrg_n64.txt"))
+
+
+@pytest.mark.parametrize("path", [RRRG, BKLG])
+def test_python_replay_reproduces_the_rrg_sampler_tapes(path):
+    t = TR.read_tape(path)
+    got = TR.replay_rrr_bkl_rrg(t)
+    assert got["Es"] == [int(v) for v in t["expected_Es"]] and got["chunks"] == [int(c, 16) for c in t["expected_chunks"]]
+    assert got["accepted"] == int(t["expected_accepted"]) and got["staged_its"] == int(t["expected_staged_its"])
+    assert got["iters_done"] == int(t["expected_iters_done"])
+    assert got["sizes"] == [int(v) for v in t["expected_sizes"]] and got["pos"] == [int(v) for v in t["expected_pos"]]      # the DeltaECache after the run
+    assert got["min_margin"] > 1e-9
+    if t["kind"] == "rrrMC_rrg":
+        assert 0 < got["staged_its"] < int(t["iters"])         # both branches of RRRMC.jl:186-208 are on the tape
+    else:
+        assert got["accepted"] < got["iters_done"] // 10       # rand_skip does the work: most iterations are skipped rejections
+
+
+@pytest.mark.parametrize("path", [RRRG, BKLG])
+def test_oracle_reproduces_the_rrg_sampler_tapes(oracle, path):
+    t = TR.read_tape(path)
+    N, K, seed = int(t["N"]), int(t["K"]), int(t["seed"])
+    A, J = _graph(t, N, K)
+    assert (A == oracle.gen_rrg(N, K, seed)).all() and (J == oracle.gen_couplings(A, seed)).all()
+    C0 = np.array([int(c, 16) for c in t["C0"]], np.uint64)
+    Es, ch, acc, staged, its, pos, sizes = oracle.rrr_sparse(A, J, float(t["beta"]), int(t["iters"]), int(t["step"]), seed, C0,
+                                                             staged_thr=float(t["staged_thr"]), staged_thr_fact=float(t["staged_thr_fact"]),
+                                                             bkl=t["kind"] == "bklMC_rrg", want_cache=True)
+    assert [int(e) for e in Es] == [int(v) for v in t["expected_Es"]] and [int(c) for c in ch] == [int(c, 16) for c in t["expected_chunks"]]
+    assert (acc, staged, its) == (int(t["expected_accepted"]), int(t["expected_staged_its"]), int(t["expected_iters_done"]))
+    assert [int(v) + 1 for v in pos] == [int(v) for v in t["expected_pos"]] and [int(v) for v in sizes] == [int(v) for v in t["expected_sizes"]]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("path", [RRRG, BKLG])
+def test_hip_library_reproduces_the_rrg_sampler_tapes(pkg, path):
+    t = TR.read_tape(path)
+    seed = int(t["seed"])
+    X = pkg.GraphRRG(int(t["N"]), int(t["K"]), seed=seed)
+    with pkg.Engine(X, 32) as eng:
+        eng.seed(seed); eng.init_spins_random()
+        assert [int(c) for c in eng.get_config().s[0]] == [int(c, 16) for c in t["C0"]]
+        if t["kind"] == "rrrMC_rrg":
+            Es, acc, staged = eng.rrr_mc(float(t["beta"]), int(t["iters"]), int(t["step"]), staged_thr=float(t["staged_thr"]),
+                                         staged_thr_fact=float(t["staged_thr_fact"]))
+            assert int(staged[0]) == int(t["expected_staged_its"])
+        else:
+            Es, acc = eng.bkl_mc(float(t["beta"]), int(t["iters"]), int(t["step"]))
+        exp_Es = [int(v) for v in t["expected_Es"]]
+        assert [int(e) for e in Es[0][:len(exp_Es)]] == exp_Es and int(acc[0]) == int(t["expected_accepted"])
+        assert [int(c) for c in eng.get_config().s[0]] == [int(c, 16) for c in t["expected_chunks"]]
+        assert eng.iterations_done() >= 0          # (the DeltaECache itself is checked by the replay and the oracle: the C ABI exposes it for GraphQuant only)
