@@ -1,7 +1,7 @@
 # Replay an RNG-free tape (tests/golden/tape_*.txt) through the reference's OWN graph code and compare with the results the tape
 # holds (written by the build's C oracle; the HIP library is checked against the same tapes in tests/test_tapes.py).
 #
-#   julia --project=<an environment that has RRRMC.jl> julia/replay_tape.jl                     (all seven tapes)
+#   julia --project=<an environment that has RRRMC.jl> julia/replay_tape.jl                     (all nine tapes)
 #   julia ...                                          julia/replay_tape.jl tests/golden/tape_skn_n24.txt ...
 #
 # Tapes: standardMC on GraphRRG(128, 3); rrrMC on a GraphQuant (staged and direct branch); round 3: standardMC on GraphEA(2, 3) (doubled
