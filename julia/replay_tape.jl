@@ -1,7 +1,7 @@
 # Replay an RNG-free tape (tests/golden/tape_*.txt) through the reference's OWN graph code and compare with the results the tape
 # holds (written by the build's C oracle; the HIP library is checked against the same tapes in tests/test_tapes.py).
 #
-#   julia --project=<an environment that has RRRMC.jl> julia/replay_tape.jl                     (all nine tapes)
+#   julia --project=<an environment that has RRRMC.jl> julia/replay_tape.jl                     (all ten tapes)
 #   julia ...                                          julia/replay_tape.jl tests/golden/tape_skn_n24.txt ...
 #
 # Tapes: standardMC on GraphRRG(128, 3); rrrMC on a GraphQuant (staged and direct branch); round 3: standardMC on GraphEA(2, 3) (doubled
@@ -18,6 +18,7 @@ using RRRMC: Config, energy, delta_energy, spinflip!, getN, inner_graph, delta_e
 import RRRMC.DeltaE
 import RRRMC.DeltaE: gen_ΔEcache, apply_move!, compute_staged!, compute_reverse_probabilities!, apply_staged!, get_z
 import RRRMC.DynamicSamplers: getel
+import RRRMC.Interface: neighbors
 
 function read_tape(path)
     d = Dict{String,Any}()
@@ -364,6 +365,52 @@ function replay_rrr_bkl_rrg(t)
     return ok
 end
 
+# wtmMC (src/RRRMC.jl:376-426) on GraphRRG{Int,(-1,1),K}: the reference's graph functions and the heap it uses (DataStructures'
+# MutableBinaryMinHeap, src/WaitingTimes.jl:24); THeap(X, C, β) and update_heap! (:26-52) are restated with gen_wt's rand() from the tape.
+function replay_wtmMC_rrg(t)
+    N, K = parse(Int, t["N"]), parse(Int, t["K"])
+    β, samples, step = parse(Float64, t["beta"]), parse(Int, t["samples"]), parse(Float64, t["step"])
+    A, J = tuples(ints(t["A"]), K), tuples(ints(t["J"]), K)
+    X = RRRMC.RRG.GraphRRG{Int,(-1, 1),K}(A, J)
+    C = config_from(t["C0"], N)
+    us = parse.(Float64, t["uniforms"])
+    nd = 0
+    gen_wt(τ) = (nd += 1; -τ * log1p(-us[nd]))                                          # src/WaitingTimes.jl:18-22
+    τΔE(ΔE) = max(1.0, Float64(exp(β * ΔE)))                                           # :16
+    theap = RRRMC.WaitingTimes.THeap()
+    for i = 1:N
+        j = push!(theap, gen_wt(τΔE(delta_energy(X, C, i))))
+        @assert j == i
+    end
+    Es = Int[]
+    E = energy(X, C)
+    step /= N
+    tmax = step * samples
+    tg, nextstep, num_moves, out = 0.0, step, 0, false
+    while tg < tmax && !out                                                            # src/RRRMC.jl:400-417
+        t′, move = RRRMC.WaitingTimes.pick_next(theap)
+        while t′ ≥ nextstep
+            push!(Es, E)
+            nextstep += step
+            nextstep > tmax + 1e-10 && (out = true; break)
+        end
+        out && break
+        tg = t′
+        ΔE = delta_energy(X, C, move)                                                  # update_heap!, src/WaitingTimes.jl:40-52
+        spinflip!(X, C, move)
+        RRRMC.WaitingTimes.update!(theap, move, tg + gen_wt(τΔE(-ΔE)))
+        for j in neighbors(X, move)
+            RRRMC.WaitingTimes.update!(theap, j, tg + gen_wt(τΔE(delta_energy(X, C, j))))
+        end
+        E += ΔE
+        num_moves += 1
+    end
+    ok = Es == ints(t["expected_Es"]) && chunks_hex(C) == t["expected_chunks"] && num_moves == parse(Int, t["expected_num_moves"]) &&
+         isapprox(tg, parse(Float64, t["expected_t"]), rtol = 1e-12) && E == energy(X, C)
+    println(ok ? "wtmMC(GraphRRG) tape: reference == tape ($(num_moves) moves, global time $(tg))" : "wtmMC(GraphRRG) tape: MISMATCH")
+    return ok
+end
+
 function main(paths)
     allok = true
     for p in paths
@@ -372,11 +419,12 @@ function main(paths)
         allok &= k == "standardMC" ? (get(t, "form", "rrg") == "ea" ? replay_standardMC_ea(t) : replay_standardMC(t)) :
                  k == "rrrMC_quant" ? replay_rrrMC_quant(t) :
                  k == "rrrMC_skn" ? replay_rrrMC_skn(t) :
-                 (k == "rrrMC_rrg" || k == "bklMC_rrg") ? replay_rrr_bkl_rrg(t) : replay_standardMC_sk(t)
+                 (k == "rrrMC_rrg" || k == "bklMC_rrg") ? replay_rrr_bkl_rrg(t) :
+                 k == "wtmMC_rrg" ? replay_wtmMC_rrg(t) : replay_standardMC_sk(t)
     end
     exit(allok ? 0 : 1)
 end
 
 main(isempty(ARGS) ? [joinpath(@__DIR__, "..", "tests", "golden", f) for f in
                       ("tape_rrg_n128.txt", "tape_quant_nk16_m4.txt", "tape_quant_direct.txt", "tape_ea_l2_d3.txt", "tape_skn_n24.txt",
-                       "tape_sk_n10.txt", "tape_rrr_skn_n10.txt", "tape_rrr_rrg_n64.txt", "tape_bkl_rrg_n64.txt")] : ARGS)
+                       "tape_sk_n10.txt", "tape_rrr_skn_n10.txt", "tape_rrr_rrg_n64.txt", "tape_bkl_rrg_n64.txt", "tape_wtm_rrg_n64.txt")] : ARGS)

@@ -254,6 +254,38 @@ def write_rrr_bkl_rrg(path, seed, bkl, N=64, K=3, beta=2.0, iters=4000, step=100
     return _finish(path, body, check)
 
 
+def write_wtm_rrg(path, seed, N=64, K=3, beta=1.0, samples=40, step=60.0, replica=0):
+    """wtmMC on GraphRRG{Int,(-1,1),K}: waiting times -tau log1p(-rand()), the earliest spin moves."""
+    A = O.gen_rrg(N, K, seed)
+    J = O.gen_couplings(A, seed)
+    C0 = O.init_config(seed, replica, N)
+    Es, ch, moves, t, Efin = O.wtm_mc_sparse(A, J.astype(np.int32), beta, samples, step, seed, C0, replica=replica)
+    key = np.array([seed & 0xFFFFFFFF, seed >> 32], np.uint32)
+    ndraw = N + (moves + 1) * (K + 1)
+    us = []
+    for n in range(ndraw):                       # WTM stream (oracle/rrrmc_oracle.c): the n-th uniform = 53-bit word (n & 1) of block n >> 1, tag 11, call 0
+        blk = n >> 1
+        w = O.philox([blk & 0xFFFFFFFF, blk >> 32, replica, 11], key)
+        h = n & 1
+        us.append(u53((int(w[2 * h]) << 32) | int(w[2 * h + 1])))
+    body = ["# RRRMC tape v1 — wtmMC(X::GraphRRG{Int,(-1,1),%d}, beta, samples; step, C0) (src/RRRMC.jl:376-426, src/WaitingTimes.jl) with every" % K,
+            "# rand() of gen_wt pre-drawn, in call order: the N initial times of THeap(X, C, beta), then per move the moved spin and its neighbours.",
+            "# Written by tests/golden/make_tapes.py",
+            "@kind wtmMC_rrg", "@N %d" % N, "@K %d" % K, "@beta %r" % beta, "@samples %d" % samples, "@step %r" % step,
+            "@seed %d" % seed, "@replica %d" % replica,
+            fmt_array("A", ("%d" % (v + 1) for v in A.reshape(-1))), fmt_array("J", ("%d" % v for v in J.reshape(-1))),
+            fmt_array("C0", ("%016x" % int(c) for c in C0)), fmt_array("uniforms", (repr(u) for u in us)),
+            fmt_array("expected_Es", ("%d" % int(e) for e in Es)), fmt_array("expected_chunks", ("%016x" % int(c) for c in ch)),
+            "@expected_num_moves %d" % moves, "@expected_t %r" % t]
+
+    def check(tp):
+        got = TR.replay_wtm_rrg(tp)
+        ok = (got["Es"] == [int(e) for e in Es] and got["chunks"] == [int(c) for c in ch] and got["num_moves"] == moves
+              and abs(got["t"] - t) <= 1e-12 * t and got["min_margin"] >= 1e-9 and len(Es) == samples and moves > 5 * N)
+        return ok, "%d samples, %d moves, global time %.4f, %d draws, closest decision margin %.2e" % (len(Es), moves, t, got["draws"], got["min_margin"])
+    return _finish(path, body, check)
+
+
 if __name__ == "__main__":
     O.build()
     for seed in range(20261003, 20261003 + 50):
@@ -278,3 +310,4 @@ if __name__ == "__main__":
     tries(lambda sd: write_rrr_skn(os.path.join(HERE, "tape_rrr_skn_n10.txt"), sd), "an rrrMC(GraphSKNormal(10)) tape with a safe margin")
     tries(lambda sd: write_rrr_bkl_rrg(os.path.join(HERE, "tape_rrr_rrg_n64.txt"), sd, False), "an rrrMC(GraphRRG(64,3)) tape with both branches and a safe margin")
     tries(lambda sd: write_rrr_bkl_rrg(os.path.join(HERE, "tape_bkl_rrg_n64.txt"), sd, True, iters=20000, step=500), "a bklMC(GraphRRG(64,3)) tape with a safe margin")
+    tries(lambda sd: write_wtm_rrg(os.path.join(HERE, "tape_wtm_rrg_n64.txt"), sd), "a wtmMC(GraphRRG(64,3)) tape with a safe margin")

@@ -819,3 +819,56 @@ def replay_rrr_bkl_rrg(tape, exp=math.exp, log1p=math.log1p):
     assert all(pos[i] == cls(i) for i in range(1, N + 1))      # check_consistency's class test (DeltaE.jl:120-136)
     return {"Es": Es, "chunks": chunks_of_bits(s), "accepted": accepted, "staged_its": staged_its, "iters_done": its_done,
             "min_margin": margin, "sizes": [st.t for st in sets], "pos": pos[1:]}
+
+
+# ---- wtmMC on GraphRRG{Int,(-1,1),K}: src/RRRMC.jl:376-426, src/WaitingTimes.jl (round 3) ---------------------------------------
+def replay_wtm_rrg(tape, exp=math.exp, log1p=math.log1p):
+    """wtmMC with every rand() of gen_wt (WaitingTimes.jl:18-22) taken from the tape, in call order: the N initial times of THeap(X, C, beta)
+    (:26-36), then per move the moved spin and its neighbours (update_heap!, :40-52).  The heap is DataStructures' MutableBinaryMinHeap:
+    only "top = smallest time" matters while the times are distinct, which the margin below asserts."""
+    N, K = int(tape["N"]), int(tape["K"])
+    beta, samples, step = float(tape["beta"]), int(tape["samples"]), float(tape["step"])
+    A = [[int(v) for v in tape["A"][x * K:(x + 1) * K]] for x in range(N)]
+    J = [[int(v) for v in tape["J"][x * K:(x + 1) * K]] for x in range(N)]
+    nbrs = [[y for y, Jxy in zip(a, j) if Jxy != 0] for a, j in zip(A, J)]          # neighbors(X, i) = X.uA[i] (RRG.jl:133,261)
+    s = bits_of_chunks([int(c, 16) for c in tape["C0"]], N)
+    us = [float(v) for v in tape["uniforms"]]
+    E, lfields = rrg_energy(A, J, s)
+    nd = 0
+
+    def gen_wt(tau):
+        nonlocal nd
+        u = us[nd]
+        nd += 1
+        return -tau * log1p(-u)
+
+    tau_of = lambda dE: max(1.0, exp(beta * dE))               # WaitingTimes.jl:16
+    tm = [0.0] * (N + 1)
+    for i in range(1, N + 1):
+        tm[i] = gen_wt(tau_of(-lfields[i - 1]))
+    step /= N
+    tmax = step * samples
+    t, nextstep, num_moves, Es, margin, out = 0.0, step, 0, [], float("inf"), False
+    while t < tmax and not out:
+        order = sorted(range(1, N + 1), key=lambda i: tm[i])
+        move, tp = order[0], tm[order[0]]
+        margin = min(margin, (tm[order[1]] - tp) / max(tp, 1e-300))            # pick_next: the top of the heap is unambiguous
+        while tp >= nextstep:
+            Es.append(E)
+            nextstep += step
+            if nextstep > tmax + 1e-10:
+                out = True
+                break
+        margin = min(margin, abs(tp - nextstep) / max(tp, 1e-300), abs(tp - (nextstep - step)) / max(tp, 1e-300))
+        if out:
+            break
+        t = tp
+        dE = -lfields[move - 1]                                # update_heap!, WaitingTimes.jl:40-52
+        rrg_spinflip(A, J, s, lfields, move)
+        tm[move] = t + gen_wt(tau_of(-dE))
+        for j in nbrs[move - 1]:
+            tm[j] = t + gen_wt(tau_of(-lfields[j - 1]))
+        E += dE
+        num_moves += 1
+    assert E == rrg_energy(A, J, s)[0]
+    return {"Es": Es, "chunks": chunks_of_bits(s), "num_moves": num_moves, "t": t, "draws": nd, "min_margin": margin}

@@ -308,3 +308,41 @@ def test_hip_library_reproduces_the_rrg_sampler_tapes(pkg, path):
         assert [int(e) for e in Es[0][:len(exp_Es)]] == exp_Es and int(acc[0]) == int(t["expected_accepted"])
         assert [int(c) for c in eng.get_config().s[0]] == [int(c, 16) for c in t["expected_chunks"]]
         assert eng.iterations_done() >= 0          # (the DeltaECache itself is checked by the replay and the oracle: the C ABI exposes it for GraphQuant only)
+
+
+# ---- wtmMC on GraphRRG: the waiting-time method, every rand() of gen_wt on the tape ----------------------------
+WTMG = os.path.join(GOLD, "tape_wtm_rrg_n64.txt")
+
+
+def test_python_replay_reproduces_the_wtm_tape():
+    t = TR.read_tape(WTMG)
+    got = TR.replay_wtm_rrg(t)
+    assert got["Es"] == [int(v) for v in t["expected_Es"]] and got["chunks"] == [int(c, 16) for c in t["expected_chunks"]]
+    assert got["num_moves"] == int(t["expected_num_moves"]) > 5 * int(t["N"])
+    assert abs(got["t"] - float(t["expected_t"])) <= 1e-12 * got["t"]          # libm's log1p / exp against the oracle's deterministic ones
+    assert got["min_margin"] > 1e-9 and got["draws"] <= len(t["uniforms"])
+
+
+def test_oracle_reproduces_the_wtm_tape(oracle):
+    t = TR.read_tape(WTMG)
+    N, K, seed = int(t["N"]), int(t["K"]), int(t["seed"])
+    A, J = _graph(t, N, K)
+    assert (A == oracle.gen_rrg(N, K, seed)).all() and (J == oracle.gen_couplings(A, seed)).all()
+    C0 = np.array([int(c, 16) for c in t["C0"]], np.uint64)
+    Es, ch, moves, tt, _ = oracle.wtm_mc_sparse(A, J, float(t["beta"]), int(t["samples"]), float(t["step"]), seed, C0)
+    assert [int(e) for e in Es] == [int(v) for v in t["expected_Es"]] and [int(c) for c in ch] == [int(c, 16) for c in t["expected_chunks"]]
+    assert moves == int(t["expected_num_moves"]) and tt == float(t["expected_t"])
+
+
+@pytest.mark.gpu
+def test_hip_library_reproduces_the_wtm_tape(pkg):
+    t = TR.read_tape(WTMG)
+    seed = int(t["seed"])
+    X = pkg.GraphRRG(int(t["N"]), int(t["K"]), seed=seed)
+    with pkg.Engine(X, 32) as eng:
+        eng.seed(seed); eng.init_spins_random()
+        assert [int(c) for c in eng.get_config().s[0]] == [int(c, 16) for c in t["C0"]]
+        Es, moves, tt = eng.wtm_mc(float(t["beta"]), int(t["samples"]), float(t["step"]))
+        assert [int(e) for e in Es[0]] == [int(v) for v in t["expected_Es"]] and int(moves[0]) == int(t["expected_num_moves"])
+        assert float(tt[0]) == float(t["expected_t"])
+        assert [int(c) for c in eng.get_config().s[0]] == [int(c, 16) for c in t["expected_chunks"]]
