@@ -1,7 +1,7 @@
 # Replay an RNG-free tape (tests/golden/tape_*.txt) through the reference's OWN graph code and compare with the results the tape
 # holds (written by the build's C oracle; the HIP library is checked against the same tapes in tests/test_tapes.py).
 #
-#   julia --project=<an environment that has RRRMC.jl> julia/replay_tape.jl                     (all ten tapes)
+#   julia --project=<an environment that has RRRMC.jl> julia/replay_tape.jl                     (all eleven tapes)
 #   julia ...                                          julia/replay_tape.jl tests/golden/tape_skn_n24.txt ...
 #
 # Tapes: standardMC on GraphRRG(128, 3); rrrMC on a GraphQuant (staged and direct branch); round 3: standardMC on GraphEA(2, 3) (doubled
@@ -411,6 +411,52 @@ function replay_wtmMC_rrg(t)
     return ok
 end
 
+# extremal_opt (src/RRRMC.jl:474-521) on GraphRRG{Int,(-1,1),K}: the reference's EOCache (gen_EOcache, apply_move!, src/DeltaE.jl:422-552);
+# rand_move (:484-516) is restated with its two draws from the tape.
+function replay_extremal_opt_rrg(t)
+    N, K = parse(Int, t["N"]), parse(Int, t["K"])
+    τ, iters, step = parse(Float64, t["tau"]), parse(Int, t["iters"]), parse(Int, t["step"])
+    A, J = tuples(ints(t["A"]), K), tuples(ints(t["J"]), K)
+    X = RRRMC.RRG.GraphRRG{Int,(-1, 1),K}(A, J)
+    C = config_from(t["C0"], N)
+    urank, umem = parse.(Float64, t["u_rank"]), parse.(UInt64, t["u_member"])
+    cache = DeltaE.gen_EOcache(X, C, τ)
+    function rand_move(cache, u1, u2)
+        ΔElist, has_zero, ascache, fτ, z = cache.ΔElist, cache.has_zero, cache.ascache, cache.fτ, cache.z
+        L = length(ΔElist)
+        r = (1 - u1) * z
+        i = searchsortedfirst(fτ, r)
+        k = 0
+        tt = 0
+        while i > tt
+            k += 1
+            tt += length(ascache[k])
+        end
+        ΔE = k ≤ L ? -ΔElist[L + 1 - k] : ΔElist[k - L + has_zero]
+        as = ascache[k]
+        return as.v[Int((UInt128(u2) * as.t) >> 64) + 1], ΔE
+    end
+    Es = Int[]
+    E = energy(X, C)
+    Emin, Cmin, itmin = E, copy(C), 0
+    for it = 1:iters                                                                   # src/RRRMC.jl:494-513
+        it % step == 0 && push!(Es, E)
+        move, ΔE = rand_move(cache, urank[it], umem[it])
+        apply_move!(X, C, move, cache)
+        E += ΔE
+        if E < Emin
+            Emin = E
+            copy!(Cmin, C)
+            itmin = it
+        end
+    end
+    DeltaE.check_consistency(cache)
+    ok = Es == ints(t["expected_Es"]) && chunks_hex(C) == t["expected_chunks"] && Emin == parse(Int, t["expected_Emin"]) &&
+         itmin == parse(Int, t["expected_itmin"]) && chunks_hex(Cmin) == t["expected_Cmin"] && E == energy(X, C)
+    println(ok ? "extremal_opt(GraphRRG) tape: reference == tape (Emin $(Emin) at iteration $(itmin))" : "extremal_opt(GraphRRG) tape: MISMATCH")
+    return ok
+end
+
 function main(paths)
     allok = true
     for p in paths
@@ -420,11 +466,12 @@ function main(paths)
                  k == "rrrMC_quant" ? replay_rrrMC_quant(t) :
                  k == "rrrMC_skn" ? replay_rrrMC_skn(t) :
                  (k == "rrrMC_rrg" || k == "bklMC_rrg") ? replay_rrr_bkl_rrg(t) :
-                 k == "wtmMC_rrg" ? replay_wtmMC_rrg(t) : replay_standardMC_sk(t)
+                 k == "wtmMC_rrg" ? replay_wtmMC_rrg(t) :
+                 k == "extremal_opt_rrg" ? replay_extremal_opt_rrg(t) : replay_standardMC_sk(t)
     end
     exit(allok ? 0 : 1)
 end
 
 main(isempty(ARGS) ? [joinpath(@__DIR__, "..", "tests", "golden", f) for f in
                       ("tape_rrg_n128.txt", "tape_quant_nk16_m4.txt", "tape_quant_direct.txt", "tape_ea_l2_d3.txt", "tape_skn_n24.txt",
-                       "tape_sk_n10.txt", "tape_rrr_skn_n10.txt", "tape_rrr_rrg_n64.txt", "tape_bkl_rrg_n64.txt", "tape_wtm_rrg_n64.txt")] : ARGS)
+                       "tape_sk_n10.txt", "tape_rrr_skn_n10.txt", "tape_rrr_rrg_n64.txt", "tape_bkl_rrg_n64.txt", "tape_wtm_rrg_n64.txt", "tape_eo_rrg_n64.txt")] : ARGS)

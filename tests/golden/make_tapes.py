@@ -286,6 +286,37 @@ def write_wtm_rrg(path, seed, N=64, K=3, beta=1.0, samples=40, step=60.0, replic
     return _finish(path, body, check)
 
 
+def write_eo_rrg(path, seed, N=64, K=3, tau=1.3, iters=3000, step=100, replica=0):
+    """extremal_opt on GraphRRG{Int,(-1,1),K} with EOCache{Int,L}."""
+    A = O.gen_rrg(N, K, seed)
+    J = O.gen_couplings(A, seed)
+    C0 = O.init_config(seed, replica, N)
+    Es, ch, Emin, Cmin, itmin = O.extremal_opt_sparse(A, J.astype(np.int32), tau, iters, step, seed, C0, replica=replica)
+    key = np.array([seed & 0xFFFFFFFF, seed >> 32], np.uint32)
+    urank, umem = [], []
+    for g in range(1, iters + 1):                # RRR stream sub 3 (oracle/rrrmc_oracle.c): words 0,1 -> rand() of r, words 2,3 -> the member index
+        w = O.philox([g & 0xFFFFFFFF, g >> 32, replica, 8 | (3 << 8)], key)
+        urank.append(u53((int(w[0]) << 32) | int(w[1])))
+        umem.append((int(w[2]) << 32) | int(w[3]))
+    body = ["# RRRMC tape v1 — extremal_opt(X::GraphRRG{Int,(-1,1),%d}, tau, iters; step, C0) (src/RRRMC.jl:474-521) with EOCache{Int,L}" % K,
+            "# (src/DeltaE.jl:412-555), both draws of rand_move pre-drawn: u_rank = rand() of r = (1 - rand()) z (:487), u_member -> rand(1:t) as",
+            "# floor(u * t / 2^64) + 1 (src/ArraySets.jl:83).  expected_Es = the E handed to the hook every `step` iterations.  Written by tests/golden/make_tapes.py",
+            "@kind extremal_opt_rrg", "@N %d" % N, "@K %d" % K, "@tau %r" % tau, "@iters %d" % iters, "@step %d" % step,
+            "@seed %d" % seed, "@replica %d" % replica,
+            fmt_array("A", ("%d" % (v + 1) for v in A.reshape(-1))), fmt_array("J", ("%d" % v for v in J.reshape(-1))),
+            fmt_array("C0", ("%016x" % int(c) for c in C0)),
+            fmt_array("u_rank", (repr(u) for u in urank)), fmt_array("u_member", ("%d" % u for u in umem)),
+            fmt_array("expected_Es", ("%d" % int(e) for e in Es)), fmt_array("expected_chunks", ("%016x" % int(c) for c in ch)),
+            "@expected_Emin %d" % Emin, fmt_array("expected_Cmin", ("%016x" % int(c) for c in Cmin)), "@expected_itmin %d" % itmin]
+
+    def check(t):
+        got = TR.replay_eo_rrg(t)
+        ok = (got["Es"] == [int(e) for e in Es] and got["chunks"] == [int(c) for c in ch] and got["Emin"] == Emin
+              and got["Cmin"] == [int(c) for c in Cmin] and got["itmin"] == itmin and got["min_margin"] >= 1e-9 and 0 < itmin < iters)
+        return ok, "%d iterations, Emin %d at iteration %d, closest decision margin %.2e" % (iters, Emin, itmin, got["min_margin"])
+    return _finish(path, body, check)
+
+
 if __name__ == "__main__":
     O.build()
     for seed in range(20261003, 20261003 + 50):
@@ -311,3 +342,4 @@ if __name__ == "__main__":
     tries(lambda sd: write_rrr_bkl_rrg(os.path.join(HERE, "tape_rrr_rrg_n64.txt"), sd, False), "an rrrMC(GraphRRG(64,3)) tape with both branches and a safe margin")
     tries(lambda sd: write_rrr_bkl_rrg(os.path.join(HERE, "tape_bkl_rrg_n64.txt"), sd, True, iters=20000, step=500), "a bklMC(GraphRRG(64,3)) tape with a safe margin")
     tries(lambda sd: write_wtm_rrg(os.path.join(HERE, "tape_wtm_rrg_n64.txt"), sd), "a wtmMC(GraphRRG(64,3)) tape with a safe margin")
+    tries(lambda sd: write_eo_rrg(os.path.join(HERE, "tape_eo_rrg_n64.txt"), sd), "an extremal_opt(GraphRRG(64,3)) tape with a safe margin")

@@ -872,3 +872,67 @@ def replay_wtm_rrg(tape, exp=math.exp, log1p=math.log1p):
         num_moves += 1
     assert E == rrg_energy(A, J, s)[0]
     return {"Es": Es, "chunks": chunks_of_bits(s), "num_moves": num_moves, "t": t, "draws": nd, "min_margin": margin}
+
+
+# ---- extremal_opt on GraphRRG{Int,(-1,1),K} with EOCache{Int,L}: src/RRRMC.jl:474-521, src/DeltaE.jl:412-555 (round 3) -----------
+def replay_eo_rrg(tape):
+    """tau-EO with rand_move's two draws from the tape: u_rank = rand() of r = (1 - rand()) z (DeltaE.jl:487), u_member -> rand(1:t)
+    (ArraySets.jl:83).  ftau = cumsum(j^-tau) is recomputed here (sequential sum, libm pow)."""
+    N, K = int(tape["N"]), int(tape["K"])
+    tau, iters, step = float(tape["tau"]), int(tape["iters"]), int(tape["step"])
+    A = [[int(v) for v in tape["A"][x * K:(x + 1) * K]] for x in range(N)]
+    J = [[int(v) for v in tape["J"][x * K:(x + 1) * K]] for x in range(N)]
+    nbrs = [[y for y, Jxy in zip(a, j) if Jxy != 0] for a, j in zip(A, J)]          # neighbors(X, i) = X.uA[i] (RRG.jl:133,261)
+    s = bits_of_chunks([int(c, 16) for c in tape["C0"]], N)
+    u_rank = [float(v) for v in tape["u_rank"]]
+    u_mem = [int(v) for v in tape["u_member"]]
+    E, lfields = rrg_energy(A, J, s)
+    dElist = tuple(4 * (d - 1) for d in range(1, K // 2 + 2)) if K % 2 == 0 else tuple(2 * (2 * d - 1) for d in range(1, (K + 1) // 2 + 1))
+    L, has_zero = len(dElist), 1 if 0 in dElist else 0
+    KK = 2 * L - has_zero
+
+    def findks(dE):                                            # DeltaE.jl:412-421
+        ak = dElist.index(abs(dE)) + 1
+        return ak + L - has_zero if dE >= 0 else L + 1 - ak
+
+    sets, pos = [ArraySet(N) for _ in range(KK)], [0] * (N + 1)
+    for i in range(1, N + 1):
+        pos[i] = findks(-lfields[i - 1])
+        sets[pos[i] - 1].push(i)
+    ftau, c = [], 0.0
+    for j in range(1, N + 1):                                  # cumsum([j^(-tau) for j = 1:N]), DeltaE.jl:444
+        c += j ** (-tau)
+        ftau.append(c)
+    z = ftau[-1]
+    Emin, Cmin, itmin, Es, margin = E, list(s), 0, [], float("inf")
+    for it in range(1, iters + 1):
+        if it % step == 0:
+            Es.append(E)                                       # the hook's E (RRRMC.jl:499-502)
+        r = (1 - u_rank[it - 1]) * z                           # rand_move, DeltaE.jl:484-516
+        i = next(q for q in range(1, N + 1) if ftau[q - 1] >= r)          # searchsortedfirst(ftau, r)
+        margin = min(margin, abs(ftau[i - 1] - r) / z, abs(r - (ftau[i - 2] if i > 1 else 0.0)) / z)
+        k, t = 0, 0
+        while i > t:
+            k += 1
+            t += sets[k - 1].t
+        dE = -dElist[L - k] if k <= L else dElist[k - L + has_zero - 1]
+        tk = sets[k - 1].t
+        move = sets[k - 1].v[((u_mem[it - 1] * tk) >> 64) + 1]
+        rrg_spinflip(A, J, s, lfields, move)                   # apply_move!, DeltaE.jl:518-552
+        for j in nbrs[move - 1]:
+            k0, k1 = pos[j], findks(-lfields[j - 1])
+            if k0 != k1:
+                sets[k0 - 1].delete(j)
+                sets[k1 - 1].push(j)
+                pos[j] = k1
+        k0, k1 = pos[move], findks(-lfields[move - 1])
+        if k0 != k1:
+            sets[k0 - 1].delete(move)
+            sets[k1 - 1].push(move)
+            pos[move] = k1
+        E += dE
+        if E < Emin:
+            Emin, Cmin, itmin = E, list(s), it
+    assert E == rrg_energy(A, J, s)[0]
+    return {"Es": Es, "chunks": chunks_of_bits(s), "Emin": Emin, "Cmin": chunks_of_bits(Cmin), "itmin": itmin, "min_margin": margin,
+            "sizes": [st.t for st in sets], "pos": pos[1:]}

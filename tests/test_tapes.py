@@ -346,3 +346,42 @@ def test_hip_library_reproduces_the_wtm_tape(pkg):
         assert [int(e) for e in Es[0]] == [int(v) for v in t["expected_Es"]] and int(moves[0]) == int(t["expected_num_moves"])
         assert float(tt[0]) == float(t["expected_t"])
         assert [int(c) for c in eng.get_config().s[0]] == [int(c, 16) for c in t["expected_chunks"]]
+
+
+# ---- extremal_opt on GraphRRG with EOCache{Int,L} ------------------------------------------------------------------
+EOG = os.path.join(GOLD, "tape_eo_rrg_n64.txt")
+
+
+def test_python_replay_reproduces_the_extremal_opt_tape():
+    t = TR.read_tape(EOG)
+    got = TR.replay_eo_rrg(t)
+    assert got["Es"] == [int(v) for v in t["expected_Es"]] and got["chunks"] == [int(c, 16) for c in t["expected_chunks"]]
+    assert got["Emin"] == int(t["expected_Emin"]) and got["itmin"] == int(t["expected_itmin"])
+    assert got["Cmin"] == [int(c, 16) for c in t["expected_Cmin"]]
+    assert 0 < got["itmin"] < int(t["iters"]) and got["min_margin"] > 1e-9
+
+
+def test_oracle_reproduces_the_extremal_opt_tape(oracle):
+    t = TR.read_tape(EOG)
+    N, K, seed = int(t["N"]), int(t["K"]), int(t["seed"])
+    A, J = _graph(t, N, K)
+    assert (A == oracle.gen_rrg(N, K, seed)).all() and (J == oracle.gen_couplings(A, seed)).all()
+    C0 = np.array([int(c, 16) for c in t["C0"]], np.uint64)
+    Es, ch, Emin, Cmin, itmin = oracle.extremal_opt_sparse(A, J, float(t["tau"]), int(t["iters"]), int(t["step"]), seed, C0)
+    assert [int(e) for e in Es] == [int(v) for v in t["expected_Es"]] and [int(c) for c in ch] == [int(c, 16) for c in t["expected_chunks"]]
+    assert (Emin, itmin) == (int(t["expected_Emin"]), int(t["expected_itmin"])) and [int(c) for c in Cmin] == [int(c, 16) for c in t["expected_Cmin"]]
+
+
+@pytest.mark.gpu
+def test_hip_library_reproduces_the_extremal_opt_tape(pkg):
+    t = TR.read_tape(EOG)
+    seed = int(t["seed"])
+    X = pkg.GraphRRG(int(t["N"]), int(t["K"]), seed=seed)
+    with pkg.Engine(X, 32) as eng:
+        eng.seed(seed); eng.init_spins_random()
+        assert [int(c) for c in eng.get_config().s[0]] == [int(c, 16) for c in t["C0"]]
+        Es, Emin, Cmin, itmin = eng.extremal_opt(float(t["tau"]), int(t["iters"]), int(t["step"]))
+        assert [int(e) for e in Es[0]] == [int(v) for v in t["expected_Es"]]
+        assert int(Emin[0]) == int(t["expected_Emin"]) and int(itmin[0]) == int(t["expected_itmin"])
+        assert [int(c) for c in Cmin.s[0]] == [int(c, 16) for c in t["expected_Cmin"]]
+        assert [int(c) for c in eng.get_config().s[0]] == [int(c, 16) for c in t["expected_chunks"]]
