@@ -455,7 +455,7 @@ inline int big_lds_lgr(int64_t N)
 }
 constexpr int kBigApplyChunks = 512;         // chunks per launch of big_apply_kernel: their headers (12 words each) sit in LDS beside the spins
 constexpr int kBigHdr = 12;                  // count, slot_base, nvec, flags, first slot of levels 0..7
-inline size_t big_lds_bytes(int64_t N, int lgr) { return (size_t)((N + (32 >> lgr) - 1) / (32 >> lgr)) * 4 + (size_t)kBigApplyChunks * kBigHdr * 4; }
+inline size_t big_lds_bytes(int64_t N, int lgr) { return (size_t)((N + (32 >> lgr) - 1) / (32 >> lgr)) * 4 + (size_t)kBigApplyChunks * kBigHdr * 4 + 64 * 4; }      // image, headers, per-replica E / accepted
 
 #ifndef RRRMC_BIG_APPLY_THREADS
 #define RRRMC_BIG_APPLY_THREADS 1024
@@ -482,9 +482,14 @@ __device__ __forceinline__ void big_apply_body(const BigSweepParams& P, const ui
     constexpr int U = RRRMC_BIG_ROUND / kBigApplyThreads;     // attempts per thread and round
     constexpr int NTH = kBigApplyThreads;
     constexpr uint32_t RS = (uint32_t)(U * NTH);              // slots per round
-    extern __shared__ uint32_t bl_sp[];                       // [ceil(N / S)]  r bits per site
-    __shared__ int32_t s_E[32], s_A[32];
+    // the image starts at LDS address 0 (no static __shared__ in this kernel): a record's reference IS the address its gather uses
+    extern __shared__ uint32_t bl_sp[];                       // [ceil(N / S)]  r bits per site; then the chunk headers; then s_E[32], s_A[32]
     const int tid = threadIdx.x, lane = tid & 63;
+    // gathers address the image by ABSOLUTE LDS address (through the array's name every gather pays an add of the array's link-time address,
+    // which is 0): should the layout ever put something in front of the image, the kernel does nothing and every parity test fails
+    typedef __attribute__((address_space(3))) const uint32_t lds_cu32;
+    if (__builtin_amdgcn_readfirstlane((int)(uint32_t)(size_t)(__attribute__((address_space(3))) uint32_t*)bl_sp) != 0) return;
+    auto lds_word_at = [](uint32_t byte_addr) -> uint32_t { return *(lds_cu32*)(size_t)byte_addr; };
     const uint32_t r = 1u << lgr, lgS = 5u - (uint32_t)lgr, S = 1u << lgS, rm = r == 32u ? 0xffffffffu : (1u << r) - 1u;
     const uint32_t grp = blockIdx.x >> lgS, sub = blockIdx.x & (S - 1u), rsh = sub << lgr;      // replicas rsh .. rsh + r - 1 of group grp
     const uint32_t nwords = ((uint32_t)P.N + S - 1u) >> lgS;
@@ -493,6 +498,8 @@ __device__ __forceinline__ void big_apply_body(const BigSweepParams& P, const ui
     const char* gmask = reinterpret_cast<const char*>(masks) + (CM ? (size_t)blockIdx.x * cap * 4 : (size_t)grp * cap * 16);
     const char* recs = reinterpret_cast<const char*>(P.nbrs);
     const uint32_t rep0 = grp * 32u + rsh;
+    int32_t* s_E = reinterpret_cast<int32_t*>(bl_sp + nwords + (uint32_t)(kBigApplyChunks * kBigHdr));
+    int32_t* s_A = s_E + 32;
     if (tid < (int)r) { s_E[tid] = P.E_cur[rep0 + tid]; s_A[tid] = 0; }
     // this workgroup's bits of every site
     for (uint32_t wd = (uint32_t)tid; wd < nwords; wd += (uint32_t)NTH) {
@@ -683,16 +690,15 @@ __device__ __forceinline__ void big_apply_body(const BigSweepParams& P, const ui
         uint32_t sw[U], gk[U][K];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            sw[u] = 0u;
-#pragma unroll
-            for (int k = 0; k < K; ++k) gk[u][k] = 0u;
-            if (__builtin_amdgcn_ballot_w64(q_live[A][u]) != 0ull) {            // scalar branch; a dead lane reads word 0
+            // every lane gathers, attempt or not (a lane without one follows the references its registers hold from an earlier round — valid
+            // addresses — or word 0): no zero-initialisation, no branch
+            {
                 const uint32_t e0 = q_slot(A, u);
-                sw[u] = *reinterpret_cast<const uint32_t*>(lbytes + (e0 & 0x3fffffu)) >> ((e0 >> 22) & 31u);
+                sw[u] = lds_word_at(e0 & 0x3fffffu) >> ((e0 >> 22) & 31u);
 #pragma unroll
                 for (int k = 0; k < K; ++k) {
                     const uint32_t e = q_raw(A, u, k);
-                    gk[u][k] = *reinterpret_cast<const uint32_t*>(lbytes + (e & 0x3fffffu)) >> ((e >> 22) & 31u);
+                    gk[u][k] = lds_word_at(e & 0x3fffffu) >> ((e >> 22) & 31u);
                 }
             }
         }
