@@ -38,6 +38,21 @@ sk_block_fn sk_block_for(int spt, int nth)
     if (nth == 1024) return spt == 1 ? sk_block_kernel<1, 1024> : spt == 2 ? sk_block_kernel<2, 1024> : nullptr;
     return nullptr;
 }
+// the same kernels for the binary model (BIN: fields and the +-4.0 matrix as doubles, dE = lfields / sqrt(N)); 1024 threads are not offered
+sk_block_fn skb_block_for(int spt, int nth)
+{
+    if (nth == 256) return spt == 1 ? sk_block_kernel<1, 256, 8, true> : nullptr;
+    if (nth == 512) return spt == 1 ? sk_block_kernel<1, 512, 8, true> : spt == 2 ? sk_block_kernel<2, 512, 8, true> : spt == 3 ? sk_block_kernel<3, 512, 8, true> : spt == 4 ? sk_block_kernel<4, 512, 8, true> : nullptr;
+    return nullptr;
+}
+sk_block_fn skb_block_half_for(int spt)
+{
+    switch (spt) {
+        case 1: return sk_block_kernel<1, 256, 4, true>; case 2: return sk_block_kernel<2, 256, 4, true>;
+        case 3: return sk_block_kernel<3, 256, 4, true>; case 4: return sk_block_kernel<4, 256, 4, true>;
+        default: return nullptr;
+    }
+}
 // two 4-replica workgroups of 256 threads per group of 8 replicas (co-resident on a compute unit: one decides while the other applies)
 sk_block_fn sk_block_half_for(int spt)
 {
@@ -213,11 +228,28 @@ int32_t sk_standard_mc_async(rrrmc_ctx* ctx, double beta, int64_t iters, int64_t
     if (!(ctx->resume && ctx->std_cache_live)) { const int32_t rc = sk_run_energy(ctx); if (rc) return rc; }
     ctx->std_cache_live = true;
     HIP_TRY(ctx, hipMemsetAsync(ctx->d_acc, 0, sizeof(int64_t) * ctx->Rpad, st));
-    if (ctx->model == RRRMC_MODEL_SK_BINARY) {
+    const bool binary = ctx->model == RRRMC_MODEL_SK_BINARY;
+    const double sqrtN = std::sqrt((double)ctx->N);
+    if (binary && !sk_legacy_forced() && iters > 0) {
+        // the blocked kernel on the binary model's state as doubles (sk_block_kernel<.., BIN>): the +-4.0 matrix is built from the bit rows
+        // once, the integer fields travel int32 -> Float64 -> int32 around the call (exact)
+        const size_t nf = (size_t)ctx->G8 * ctx->N * kSkRB;
+        const int64_t ld = sk_ldJ(ctx->N);
+        if (!ctx->sk_lf) { HIP_TRY(ctx, hipMalloc(&ctx->sk_lf, sizeof(double) * nf)); HIP_TRY(ctx, hipMalloc(&ctx->sk_lfl, sizeof(double) * nf)); }
+        if (!ctx->sk_J4) HIP_TRY(ctx, hipMalloc(&ctx->sk_J4, sizeof(double) * ctx->N * ld));
+        if (!ctx->skb_J4_valid) {
+            hipLaunchKernelGGL(skb_dense4_kernel, dim3((unsigned)((ld + 255) / 256), (unsigned)ctx->N), dim3(256), 0, st, ctx->skb_J, ctx->sk_J4, (int)ctx->N,
+                               ctx->skb_NW, (int)ld);
+            HIP_TRY(ctx, hipGetLastError());
+            ctx->skb_J4_valid = true;
+        }
+        hipLaunchKernelGGL(skb_fields_to_f64_kernel, dim3((unsigned)((nf + 255) / 256)), dim3(256), 0, st, ctx->skb_lf, ctx->skb_lfl, ctx->sk_lf, ctx->sk_lfl, nf);
+        HIP_TRY(ctx, hipGetLastError());
+    } else if (binary) {
         SkbParams B{};
         B.Jbits = ctx->skb_J; B.lf = ctx->skb_lf; B.lfl = ctx->skb_lfl; B.move_last = ctx->sk_move_last; B.spins = ctx->sk_spins;
         B.E_cur = ctx->sk_E; B.acc_cur = ctx->d_acc; B.Es = ctx->sk_Es;
-        B.beta = beta; B.sN = std::sqrt((double)ctx->N); B.g0 = ctx->it_done; B.iters = iters; B.step = step; B.sample0 = 0;
+        B.beta = beta; B.sN = sqrtN; B.g0 = ctx->it_done; B.iters = iters; B.step = step; B.sample0 = 0;
         B.k0 = (uint32_t)ctx->seed; B.k1 = (uint32_t)(ctx->seed >> 32); B.replica0 = ctx->replica0; B.N = (int)ctx->N; B.NW = ctx->skb_NW;
         const int nthb = sk_threads_for(ctx->N), sptb = (int)((ctx->N + nthb - 1) / nthb);
         HIP_TRY(ctx, hipEventRecord(ctx->ev_sweep[0], st));
@@ -238,11 +270,15 @@ int32_t sk_standard_mc_async(rrrmc_ctx* ctx, double beta, int64_t iters, int64_t
     P.beta = beta; P.g0 = ctx->it_done; P.iters = iters; P.step = step; P.sample0 = 0;
     P.k0 = (uint32_t)ctx->seed; P.k1 = (uint32_t)(ctx->seed >> 32); P.replica0 = ctx->replica0; P.N = (int)ctx->N;
     const int nth = sk_threads_for(ctx->N), spt = (int)((ctx->N + nth - 1) / nth);
-    sk_block_fn blockk = sk_legacy_forced() ? nullptr : sk_block_for(spt, nth);
-    int blk_nth = nth, blk_wgs = 1;                       // threads per workgroup, workgroups per group of 8 replicas
+    int blk_nth = binary && nth == 1024 ? 512 : nth;     // threads per workgroup (the binary build has no 1024-thread form)
+    const int blk_spt = (int)((ctx->N + blk_nth - 1) / blk_nth);
+    sk_block_fn blockk = sk_legacy_forced() ? nullptr : binary ? skb_block_for(blk_spt, blk_nth) : sk_block_for(spt, nth);
+    int blk_wgs = 1;                                      // workgroups per group of 8 replicas
     if (blockk && sk_rb_for(ctx->N) == 4) {
-        if (const sk_block_fn h = sk_block_half_for((int)((ctx->N + 255) / 256))) { blockk = h; blk_nth = 256; blk_wgs = 2; }
+        const int hs = (int)((ctx->N + 255) / 256);
+        if (const sk_block_fn h = binary ? skb_block_half_for(hs) : sk_block_half_for(hs)) { blockk = h; blk_nth = 256; blk_wgs = 2; }
     }
+    if (binary && !blockk) return fail(ctx, RRRMC_ERR_UNSUPPORTED, "internal: no blocked kernel for N=%lld", (long long)ctx->N);
     if (blockk && iters > 0) {
         // blocked kernel: segments of <= kSkSegIters iterations, each with its state-independent block tables (sites, coupling sub-matrices)
         const int64_t nseg = (iters + kSkSegIters - 1) / kSkSegIters;
@@ -263,7 +299,7 @@ int32_t sk_standard_mc_async(rrrmc_ctx* ctx, double beta, int64_t iters, int64_t
         Bk.J4 = ctx->sk_J4; Bk.blkJw = ctx->sk_blkJw; Bk.blkSites = ctx->sk_blkSites;
         Bk.lf = ctx->sk_lf; Bk.lfl = ctx->sk_lfl; Bk.move_last = ctx->sk_move_last; Bk.spins = ctx->sk_spins;
         Bk.E_cur = ctx->sk_E; Bk.acc_cur = ctx->d_acc; Bk.Es = ctx->sk_Es;
-        Bk.beta = beta; Bk.step = step; Bk.k0 = P.k0; Bk.k1 = P.k1; Bk.replica0 = ctx->replica0; Bk.N = (int)ctx->N; Bk.ldJ = (int)sk_ldJ(ctx->N);
+        Bk.beta = beta; Bk.sN = sqrtN; Bk.step = step; Bk.k0 = P.k0; Bk.k1 = P.k1; Bk.replica0 = ctx->replica0; Bk.N = (int)ctx->N; Bk.ldJ = (int)sk_ldJ(ctx->N);
         for (int64_t sg = 0; sg < nseg; ++sg) {
             const int64_t base = sg * kSkSegIters, n = iters - base < kSkSegIters ? iters - base : kSkSegIters, nblk = (n + kSkW - 1) / kSkW;
             Bk.g0 = ctx->it_done + (uint64_t)base; Bk.iters = n; Bk.it_base = base;
@@ -275,13 +311,18 @@ int32_t sk_standard_mc_async(rrrmc_ctx* ctx, double beta, int64_t iters, int64_t
             HIP_TRY(ctx, hipGetLastError());
             HIP_TRY(ctx, hipEventRecord(ctx->ev_sweep[2 * sg + 1], st));
         }
+        if (binary) {
+            const size_t nf = (size_t)ctx->G8 * ctx->N * kSkRB;
+            hipLaunchKernelGGL(skb_fields_from_f64_kernel, dim3((unsigned)((nf + 255) / 256)), dim3(256), 0, st, ctx->sk_lf, ctx->sk_lfl, ctx->skb_lf, ctx->skb_lfl, nf);
+            HIP_TRY(ctx, hipGetLastError());
+        }
         HIP_TRY(ctx, hipEventRecord(ctx->ev_end, st));
         ctx->sweep_launches = (int)nseg;
         ctx->nsamp = nsamp;
         ctx->it_done += (uint64_t)iters;
         ctx->results_valid = true;
         ctx->timing_valid = true;
-        return ctx->debug_checks ? sk_debug_check(ctx) : RRRMC_OK;
+        return ctx->debug_checks && !binary ? sk_debug_check(ctx) : RRRMC_OK;
     }
     HIP_TRY(ctx, hipEventRecord(ctx->ev_sweep[0], st));
     hipLaunchKernelGGL(sk_sweep_for(spt, nth), dim3((unsigned)ctx->G8), dim3((unsigned)nth), 0, st, P);

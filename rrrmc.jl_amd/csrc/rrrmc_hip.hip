@@ -133,7 +133,8 @@ struct rrrmc_ctx {
     bool color_count_acc = false;       // colour sweeps also count every replica's accepted moves (rrrmc_colored_count_accepted)
     // ---- RRRMC_MODEL_SK_NORMAL ----
     double* sk_J = nullptr;        // [N][N]
-    double* sk_J4 = nullptr;       // [N][N] 4 J (exact), RRRMC_MODEL_SK_NORMAL: what update_cache! adds (SK.jl:256-262)
+    double* sk_J4 = nullptr;       // [N][ldJ] 4 J (exact): what update_cache! adds (SK.jl:256-262); RRRMC_MODEL_SK_BINARY: the +-4.0 matrix, built from the bit rows at the first standardMC call
+    bool skb_J4_valid = false;
     double* sk_blkJw = nullptr;    // sk_block_kernel: coupling sub-matrices of a segment's blocks
     uint32_t* sk_blkSites = nullptr;
     size_t sk_blk_cap = 0;         // blocks the two buffers hold
@@ -2142,6 +2143,7 @@ int32_t rrrmc_set_couplings_bits(rrrmc_ctx* ctx, const uint64_t* Jc)
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     HIP_TRY(ctx, hipMemcpy(qsk ? (void*)ctx->q_Jb : (void*)ctx->skb_J, Jc, sizeof(uint64_t) * N * nch, hipMemcpyHostToDevice));     // chunk = two little-endian words
     if (qsk) ctx->q_cache_valid = false;
+    ctx->skb_J4_valid = false;
     ctx->graph_set = true;
     return RRRMC_OK;
 }

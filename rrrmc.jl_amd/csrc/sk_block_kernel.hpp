@@ -44,6 +44,7 @@ struct SkBlockParams {
     int64_t* acc_cur;
     double* Es;                // [nsamples][G * kSkRB]; may be null
     double beta;
+    double sN;                 // BIN: sqrt(N) (delta_energy = lfields / sqrt(N), SK.jl:137-140); unused otherwise
     uint64_t g0;               // stream position at the start of the segment
     int64_t iters, step, it_base;   // this segment's iterations; it_base = iterations of the call before the segment
     uint32_t k0, k1, replica0;
@@ -175,7 +176,11 @@ __device__ __forceinline__ double sk_readlane_f64(double v, int lane)
 // h = blockIdx.x & 1).  Two 4-replica workgroups of 256 threads per CU instead of one 8-replica workgroup of 512: each tests half as many
 // replicas per attempt, and one decides while the other applies — the phases of a workgroup are separated by barriers, two
 // independent workgroups fill each other's waits.  (The price: each loads its own rows of 4J.)
-template <int SPT, int NTH, int RB = kSkRB>
+// BIN: the binary model GraphSK (src/graphs/SK.jl:28-165) through the same kernel.  Its integer cache lfields[i] = sqrt(N) delta_energy(i) and its
+// couplings +-1 are exact in Float64, and update_cache! (SK.jl:98-135: lfj + 8 Jsij - 4, i.e. +-4; lfields[move] = -lfm; the same array swap) is
+// the Gaussian model's with 4 J = +-4.0: the host hands over the fields as doubles and the +-4.0 matrix, the only difference is the scale of the
+// energy — dE = lfields / sqrt(N), the division the reference and the oracle make.
+template <int SPT, int NTH, int RB = kSkRB, bool BIN = false>
 __global__ __launch_bounds__(NTH) void sk_block_kernel(SkBlockParams P)
 {
     static_assert(RB == 8 || RB == 4, "8 or 4 replicas per workgroup");
@@ -330,7 +335,8 @@ __global__ __launch_bounds__(NTH) void sk_block_kernel(SkBlockParams P)
                 // 64-bit one): the sample of iteration it is taken BEFORE its move, i.e. before attempt m = it - it0 - 1 is applied
                 auto sample_rel = [&]() -> int { const int64_t d = next_sample[a] - it0 - 1; return d < (int64_t)kSkW ? (int)d : kSkW; };
                 int ks = sample_rel();
-                unsigned long long B = verdict(-P.beta * f);
+                auto xof = [&](double fv) -> double { if constexpr (BIN) return -P.beta * (fv / P.sN); else return -P.beta * fv; };
+                unsigned long long B = verdict(xof(f));
                 while (B) {
                     const int k = __builtin_ctzll(B);
                     while (__builtin_expect(k >= ks, 0)) {              // sample BEFORE the move (RRRMC.jl:104-108)
@@ -338,7 +344,8 @@ __global__ __launch_bounds__(NTH) void sk_block_kernel(SkBlockParams P)
                         ns[a] += 1; next_sample[a] += P.step;
                         ks = sample_rel();
                     }
-                    const double dE = sk_readlane_f64(f, k);            // delta_energy, SK.jl:278-284
+                    const double fk = sk_readlane_f64(f, k);
+                    const double dE = BIN ? fk / P.sN : fk;             // delta_energy, SK.jl:278-284 (BIN: SK.jl:137-140)
                     const int32_t site_k = __builtin_amdgcn_readlane((int)sv, k);
                     const uint32_t spk = (uint32_t)__builtin_amdgcn_readlane((int)sp, k);
                     const bool swapped = mlast[a] == site_k;            // undo path of update_cache!, SK.jl:247-250
@@ -361,7 +368,7 @@ __global__ __launch_bounds__(NTH) void sk_block_kernel(SkBlockParams P)
                         mlast[a] = site_k;
                     }
                     sp ^= dup ? 1u : 0u;
-                    B = verdict(-P.beta * f) & ((~0ull << k) << 1);
+                    B = verdict(xof(f)) & ((~0ull << k) << 1);
                 }
                 while (next_sample[a] <= it0 + nv) {                    // the samples behind the block's last accepted move
                     if (P.Es && lane == 0) P.Es[ns[a] * Rp + grp * kSkRB + r8 + r] = E_run[a];
@@ -502,6 +509,29 @@ __global__ __launch_bounds__(NTH) void sk_block_kernel(SkBlockParams P)
         const int r = wv + a * NWV;
         if (r < RB && lane == 0) { P.E_cur[grp * kSkRB + r8 + r] = E_run[a]; P.acc_cur[grp * kSkRB + r8 + r] = A_run[a]; P.move_last[grp * kSkRB + r8 + r] = mlast[a]; }
     }
+}
+
+// ---- the binary model's state for sk_block_kernel<.., BIN = true>: int32 fields <-> doubles, bit rows -> the +-4.0 matrix (zero diagonal,
+//      rows zero-padded to ldJ) ------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void skb_fields_to_f64_kernel(const int32_t* __restrict__ a, const int32_t* __restrict__ b, double* __restrict__ fa,
+                                                                 double* __restrict__ fb, size_t n)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) { fa[i] = (double)a[i]; fb[i] = (double)b[i]; }
+}
+__global__ __launch_bounds__(256) void skb_fields_from_f64_kernel(const double* __restrict__ fa, const double* __restrict__ fb, int32_t* __restrict__ a,
+                                                                   int32_t* __restrict__ b, size_t n)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) { a[i] = (int32_t)fa[i]; b[i] = (int32_t)fb[i]; }
+}
+__global__ __launch_bounds__(256) void skb_dense4_kernel(const uint32_t* __restrict__ Jbits, double* __restrict__ J4, int N, int NW, int ldJ)
+{
+    const int j = blockIdx.x * 256 + threadIdx.x, i = blockIdx.y;
+    if (j >= ldJ) return;
+    double v = 0.0;
+    if (j < N && j != i) v = ((Jbits[(size_t)i * NW + (j >> 5)] >> (j & 31)) & 1u) ? 4.0 : -4.0;
+    J4[(size_t)i * ldJ + j] = v;
 }
 
 }  // namespace rrrmc

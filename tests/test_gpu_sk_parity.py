@@ -238,6 +238,33 @@ def test_skn_thread_counts_agree(pkg, monkeypatch, N, R):
             assert (u == v).all()
 
 
+@pytest.mark.parametrize("N,R", [(1024, 16), (700, 9), (300, 8), (64, 5), (2048, 8)])
+def test_binary_sk_block_kernel_builds_agree(pkg, oracle, monkeypatch, N, R):
+    """The binary model through sk_block_kernel<.., BIN> (whole-group and split builds; the integer fields travel as doubles) against the
+    one-attempt-at-a-time skb_sweep_kernel (RRRMC_SK_LEGACY = 1) and the oracle: energies, accepted counts, configurations, the int32 cache."""
+    seed = 4001 + N
+    X = pkg.GraphSK(N, seed=seed)
+    outs = []
+    for env in ({"RRRMC_SK_RB": "8"}, {"RRRMC_SK_RB": "4"}, {"RRRMC_SK_LEGACY": "1"}):
+        for k in ("RRRMC_SK_RB", "RRRMC_SK_LEGACY"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        with pkg.Engine(X, R) as eng:
+            eng.seed(seed)
+            eng.init_spins_random()
+            C0 = eng.get_config().s.copy()
+            Es, acc = eng.standard_mc(1.2, 3000, 100)
+            Es2, acc2 = eng.standard_mc(0.6, 777, 7)
+            outs.append((Es, acc, Es2, acc2, eng.get_config().s, eng.fields(), eng.energy()))
+    for o in outs[1:]:
+        for u, v in zip(outs[0], o):
+            assert (u == v).all()
+    for r in (0, R - 1):
+        ref = oracle.standard_mc_skb(X.J, 1.2, 3000, 100, seed, C0[r], replica=r)
+        assert (outs[0][0][r] == ref[0]).all() and outs[0][1][r] == ref[2]
+
+
 @pytest.mark.parametrize("N,R", [(1024, 24), (1000, 13), (700, 8), (300, 9), (256, 16), (37, 5)])
 def test_skn_block_kernel_builds_agree(pkg, oracle, monkeypatch, N, R):
     """sk_block_kernel with one 8-replica workgroup per group of replicas and with two co-resident 4-replica workgroups
