@@ -34,8 +34,9 @@ REPLICAS_PER_GPU = 8192
 ITERS = 1 << 22          # iterations per replica per step (1024 lattice sweeps)
 SAMPLE_STEP = 1 << 12    # energy sample every N iterations
 SEED = 0x5EED
+HOST_GAP_LIMIT_MS = 0.3  # ms_per_step - kernel ms per step above this fails the run (exit 4): the timed region must be the kernel
 HBM_PEAK_GBS = 8000.0    # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-PROFILE_DIRS = [os.path.join(ROOT, "profiles", d) for d in ("r03", "r02")]       # newest first
+PROFILE_DIRS = [os.path.join(ROOT, "profiles", d) for d in ("r04", "r03", "r02")]       # newest first
 SWEEP_KERNEL_SOURCES = ["rrrmc.jl_amd/csrc/sparse_kernels.hpp", "rrrmc.jl_amd/csrc/philox.hpp"]     # what traffic.json / valu_model.json describe
 
 
@@ -543,12 +544,15 @@ def run_rank(args):
             torch.cuda.synchronize()
         eng.sync()
 
+    verify = rank == 0 and not args.no_verify
+    if verify:
+        eng.snapshot_reserve(1)          # device buffer for the configuration the timed region starts from (allocated before the warm-up)
     for _ in range(args.warmup):
         eng.standard_mc_async(BETA, args.iters, SAMPLE_STEP)
-    barrier()
-    verify = rank == 0 and not args.no_verify
-    C_start = eng.get_config().s.copy() if verify else None       # what the timed region starts from (outside it)
-    eng.timing_accumulate(True)          # one HIP-event pair per sweep launch of the timed region, read after it (no sync inside)
+    if verify:
+        eng.snapshot_store(0)            # device-to-device copy queued behind the warm-up: no host round trip, the GPU never idles before t0
+    # one HIP-event pair per sweep launch of the timed region, read after it (no sync inside); the events are created here, not in the region
+    eng.timing_accumulate(True, reserve_launches=4 * args.steps)
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -571,6 +575,7 @@ def run_rank(args):
 
     Es, acc = eng.fetch_results()
     C_end = eng.get_config().s.copy() if verify else None
+    C_start = eng.snapshot_get(0).s.copy() if verify else None    # what the timed region started from, read back after it
     acc_rate = float(acc.mean()) / args.iters
     e_mean = float(Es[:, -1].mean()) / N_SITES if Es.shape[1] else float("nan")
     if dist is not None:   # the only exchange of the job: gather the per-replica observables over RCCL
@@ -638,6 +643,8 @@ def run_rank(args):
                     # 7 % slower there than at the 8 waves per SIMD the per-opcode costs were taken at (tools/ubench/producer_task.hip)
                     roof["valu"]["frac_at_4_waves_per_simd"] = roof["valu"]["frac"] * vm["occupancy_factor_4_waves"]
             out["roofline"] = roof
+            # what the timed region spent outside the dominant kernel, per step: energy(X, C) + planner at the head of every call, launch gaps
+            out["host_gap_ms_per_step"] = 1e3 * dt / max(args.steps, 1) - sweep_ms / max(args.steps, 1)
             try:      # after the timed region: the box's own copy bandwidth, for reference only (peak stays the nominal figure)
                 bw = device_copy_bandwidth(pkg, local_rank)
                 roof["measured_copy_GBps"] = bw
@@ -661,6 +668,10 @@ def run_rank(args):
                 rc = 3
         else:
             out["verified"] = None
+        if out.get("host_gap_ms_per_step", 0.0) > HOST_GAP_LIMIT_MS and R == REPLICAS_PER_GPU and args.iters == ITERS and world == 1:
+            sys.stderr.write("bench.py: %.3f ms per step of the timed region lie outside the sweep kernel (limit %.1f ms): the line does not "
+                             "measure the kernel\n" % (out["host_gap_ms_per_step"], HOST_GAP_LIMIT_MS))
+            rc = rc or 4
         if world == 1 and not args.no_cpu_baseline:      # reported at N = 1 only (rank 0's host cores)
             O = entry.load_oracle()
             out["cpu_baseline"] = cpu_baseline(O, X)

@@ -277,7 +277,8 @@ RRRMC_API int32_t rrrmc_last_timing(rrrmc_ctx *ctx, double *total_ms, double *sw
 /* Accumulated kernel timing over MANY queued async calls (RRRMC_MODEL_SPARSE_PM1 standardMC): rrrmc_timing_accumulate(ctx, 1)
  * gives every sweep launch of every following sampling call its own HIP-event pair (both calls synchronise the stream; the
  * sampling calls in between stay asynchronous); rrrmc_timing_total returns the summed duration of those launches and their count.
- * rrrmc_timing_accumulate(ctx, 0) returns to the per-call bookkeeping of rrrmc_last_timing. */
+ * rrrmc_timing_accumulate(ctx, 0) returns to the per-call bookkeeping of rrrmc_last_timing.  on > 1 additionally creates the event
+ * pairs of the first `on` launches right away, so that a timed region of queued calls performs no event creation. */
 RRRMC_API int32_t rrrmc_timing_accumulate(rrrmc_ctx *ctx, int32_t on);
 RRRMC_API int32_t rrrmc_timing_total(rrrmc_ctx *ctx, double *sweep_ms, int64_t *sweep_launches);
 

@@ -26,6 +26,7 @@
 #include "sparse_kernels.hpp"
 #include "bign_kernels.hpp"
 #include "obs_kernels.hpp"
+#include "layout_kernels.hpp"
 #include "spf_kernels.hpp"
 #include "spf_fast_kernels.hpp"
 #include "dbl_kernels.hpp"
@@ -95,6 +96,10 @@ struct rrrmc_ctx {
     hipStream_t plan_stream = nullptr;
     hipEvent_t ev_upload = nullptr;
     std::vector<hipEvent_t> ev_plan;     // plan of batch b finished
+    // staging of the caller-layout transfers: BitVector chunks (rrrmc_set_spins / rrrmc_get_spins / rrrmc_snapshot_get) and the
+    // replica-major energy samples (rrrmc_fetch_results); kept across calls, grown on demand
+    unsigned long long* d_io = nullptr;
+    size_t io_cap = 0;                   // bytes
     // results of the last sampling call
     int32_t* d_Es = nullptr;
     size_t Es_cap = 0;
@@ -387,6 +392,18 @@ int32_t ensure_state(rrrmc_ctx* ctx, bool need_spins)
     if (!ctx->graph_set) return fail(ctx, RRRMC_ERR_STATE, "rrrmc_set_graph has not been called");
     if (need_spins && !ctx->spins_set)
         return fail(ctx, RRRMC_ERR_STATE, "no configuration: call rrrmc_init_spins_random or rrrmc_set_spins first");
+    return RRRMC_OK;
+}
+
+// the caller-layout staging buffer (ctx->d_io) holds at least `bytes`
+int32_t ensure_io(rrrmc_ctx* ctx, size_t bytes)
+{
+    if (bytes <= ctx->io_cap) return RRRMC_OK;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    free_dev(ctx->d_io);
+    ctx->io_cap = 0;
+    if (hipMalloc(&ctx->d_io, bytes) != hipSuccess) { ctx->d_io = nullptr; return fail(ctx, RRRMC_ERR_NOMEM, "cannot allocate %zu bytes of transfer staging", bytes); }
+    ctx->io_cap = bytes;
     return RRRMC_OK;
 }
 
@@ -736,7 +753,7 @@ void rrrmc_ctx_destroy(rrrmc_ctx* ctx)
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     free_dev(ctx->d_A); free_dev(ctx->d_J); free_dev(ctx->d_table); free_dev(ctx->d_spins);
     free_dev(ctx->d_E); free_dev(ctx->d_acc); free_dev(ctx->d_chunks); free_dev(ctx->d_Es);
-    free_dev(ctx->d_U);
+    free_dev(ctx->d_U); free_dev(ctx->d_io);
     for (uint32_t*& l : ctx->d_color_list) free_dev(l);
     free_dev(ctx->sk_J4); free_dev(ctx->sk_blkJw); free_dev(ctx->sk_blkSites);
     free_dev(ctx->sk_J); free_dev(ctx->sk_lf); free_dev(ctx->sk_lfl); free_dev(ctx->sk_move_last); free_dev(ctx->sk_spins);
@@ -913,44 +930,22 @@ int32_t rrrmc_set_spins(rrrmc_ctx* ctx, const uint64_t* chunks)
         ctx->spins_set = true;
         return RRRMC_OK;
     }
-    if (ctx->model == RRRMC_MODEL_SPARSE_F64) {
-        std::vector<unsigned long long> bs((size_t)(ctx->pfW * N), 0ull);
-        for (int64_t r = 0; r < ctx->R; ++r) {
-            unsigned long long* dst = bs.data() + (r >> 6) * N;
-            const unsigned long long bit = 1ull << (r & 63);
-            const uint64_t* src = chunks + r * nch;
-            for (int64_t x = 0; x < N; ++x)
-                if ((src[x >> 6] >> (x & 63)) & 1ull) dst[x] |= bit;
-        }
-        HIP_TRY(ctx, hipSetDevice(ctx->device));
-        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-        HIP_TRY(ctx, hipMemcpy(ctx->pf_spins, bs.data(), sizeof(unsigned long long) * bs.size(), hipMemcpyHostToDevice));
-        ctx->pf_lf_live = false;
-        ctx->spins_set = true;
-        return RRRMC_OK;
-    }
-    if (ctx->model == RRRMC_MODEL_SK_NORMAL || ctx->model == RRRMC_MODEL_SK_BINARY) {
-        std::vector<uint8_t> b8((size_t)(ctx->G8 * N), 0);
-        for (int64_t r = 0; r < ctx->R; ++r)
-            for (int64_t x = 0; x < N; ++x)
-                if ((chunks[r * nch + (x >> 6)] >> (x & 63)) & 1ull) b8[(r >> 3) * N + x] |= (uint8_t)(1u << (r & 7));
-        HIP_TRY(ctx, hipSetDevice(ctx->device));
-        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-        HIP_TRY(ctx, hipMemcpy(ctx->sk_spins, b8.data(), b8.size(), hipMemcpyHostToDevice));
-        ctx->spins_set = true;
-        return RRRMC_OK;
-    }
-    std::vector<uint32_t> bs((size_t)(ctx->G * N), 0);
-    for (int64_t r = 0; r < ctx->R; ++r) {
-        uint32_t* dst = bs.data() + (r >> 5) * N;
-        const uint32_t bit = 1u << (r & 31);
-        const uint64_t* src = chunks + r * nch;
-        for (int64_t x = 0; x < N; ++x)
-            if ((src[x >> 6] >> (x & 63)) & 1ull) dst[x] |= bit;
-    }
+    // bit-sliced device layouts: upload the chunks as they are and transpose on the device (layout_kernels.hpp)
     HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const size_t cbytes = sizeof(uint64_t) * (size_t)ctx->R * (size_t)nch;
+    { const int32_t rci = ensure_io(ctx, cbytes); if (rci) return rci; }
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    HIP_TRY(ctx, hipMemcpy(ctx->d_spins, bs.data(), sizeof(uint32_t) * bs.size(), hipMemcpyHostToDevice));
+    HIP_TRY(ctx, hipMemcpy(ctx->d_io, chunks, cbytes, hipMemcpyHostToDevice));
+    if (ctx->model == RRRMC_MODEL_SPARSE_F64) {
+        hipLaunchKernelGGL(spins_unpack_kernel<unsigned long long>, dim3((unsigned)nch, (unsigned)ctx->pfW), dim3(64), 0, ctx->stream, ctx->d_io, ctx->pf_spins, (int)N, (int)nch, (int)ctx->R);
+        ctx->pf_lf_live = false;
+    } else if (ctx->model == RRRMC_MODEL_SK_NORMAL || ctx->model == RRRMC_MODEL_SK_BINARY) {
+        hipLaunchKernelGGL(spins_unpack_kernel<uint8_t>, dim3((unsigned)nch, (unsigned)ctx->G8), dim3(64), 0, ctx->stream, ctx->d_io, ctx->sk_spins, (int)N, (int)nch, (int)ctx->R);
+    } else {
+        hipLaunchKernelGGL(spins_unpack_kernel<uint32_t>, dim3((unsigned)nch, (unsigned)ctx->G), dim3(64), 0, ctx->stream, ctx->d_io, ctx->d_spins, (int)N, (int)nch, (int)ctx->R);
+    }
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     ctx->spins_set = true;
     return RRRMC_OK;
 }
@@ -982,36 +977,17 @@ int32_t spins_to_chunks(rrrmc_ctx* ctx, const void* src, uint64_t* chunks)
         HIP_TRY(ctx, hipMemcpy(chunks, src, sizeof(uint64_t) * ctx->R * nch, hipMemcpyDeviceToHost));
         return RRRMC_OK;
     }
-    if (ctx->model == RRRMC_MODEL_SPARSE_F64) {
-        std::vector<unsigned long long> bs((size_t)(ctx->pfW * N));
-        HIP_TRY(ctx, hipMemcpy(bs.data(), src, sizeof(unsigned long long) * bs.size(), hipMemcpyDeviceToHost));
-        std::memset(chunks, 0, sizeof(uint64_t) * ctx->R * nch);
-        for (int64_t r = 0; r < ctx->R; ++r) {
-            const unsigned long long* w = bs.data() + (r >> 6) * N;
-            const int sh = (int)(r & 63);
-            uint64_t* dst = chunks + r * nch;
-            for (int64_t x = 0; x < N; ++x) dst[x >> 6] |= (uint64_t)((w[x] >> sh) & 1ull) << (x & 63);
-        }
-        return RRRMC_OK;
-    }
-    if (ctx->model == RRRMC_MODEL_SK_NORMAL || ctx->model == RRRMC_MODEL_SK_BINARY) {
-        std::vector<uint8_t> b8((size_t)(ctx->G8 * N));
-        HIP_TRY(ctx, hipMemcpy(b8.data(), src, b8.size(), hipMemcpyDeviceToHost));
-        std::memset(chunks, 0, sizeof(uint64_t) * ctx->R * nch);
-        for (int64_t r = 0; r < ctx->R; ++r)
-            for (int64_t x = 0; x < N; ++x)
-                chunks[r * nch + (x >> 6)] |= (uint64_t)((b8[(r >> 3) * N + x] >> (r & 7)) & 1u) << (x & 63);
-        return RRRMC_OK;
-    }
-    std::vector<uint32_t> bs((size_t)(ctx->G * N));
-    HIP_TRY(ctx, hipMemcpy(bs.data(), src, sizeof(uint32_t) * bs.size(), hipMemcpyDeviceToHost));
-    std::memset(chunks, 0, sizeof(uint64_t) * ctx->R * nch);
-    for (int64_t r = 0; r < ctx->R; ++r) {
-        const uint32_t* w = bs.data() + (r >> 5) * N;
-        const int sh = (int)(r & 31);
-        uint64_t* dst = chunks + r * nch;
-        for (int64_t x = 0; x < N; ++x) dst[x >> 6] |= (uint64_t)((w[x] >> sh) & 1u) << (x & 63);
-    }
+    const size_t cbytes = sizeof(uint64_t) * (size_t)ctx->R * (size_t)nch;
+    { const int32_t rci = ensure_io(ctx, cbytes); if (rci) return rci; }
+    if (ctx->model == RRRMC_MODEL_SPARSE_F64)
+        hipLaunchKernelGGL(spins_pack_kernel<unsigned long long>, dim3((unsigned)nch, (unsigned)ctx->pfW), dim3(64), 0, ctx->stream, (const unsigned long long*)src, ctx->d_io, (int)N, (int)nch, (int)ctx->R);
+    else if (ctx->model == RRRMC_MODEL_SK_NORMAL || ctx->model == RRRMC_MODEL_SK_BINARY)
+        hipLaunchKernelGGL(spins_pack_kernel<uint8_t>, dim3((unsigned)nch, (unsigned)ctx->G8), dim3(64), 0, ctx->stream, (const uint8_t*)src, ctx->d_io, (int)N, (int)nch, (int)ctx->R);
+    else
+        hipLaunchKernelGGL(spins_pack_kernel<uint32_t>, dim3((unsigned)nch, (unsigned)ctx->G), dim3(64), 0, ctx->stream, (const uint32_t*)src, ctx->d_io, (int)N, (int)nch, (int)ctx->R);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipMemcpyAsync(chunks, ctx->d_io, cbytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return RRRMC_OK;
 }
 }  // namespace
@@ -1353,16 +1329,14 @@ int32_t rrrmc_fetch_results(rrrmc_ctx* ctx, int64_t* Es_out, int64_t* accepted_o
         for (int64_t r = 0; r < ctx->R; ++r) accepted_out[r] = acc[r];
     }
     if (Es_out && ctx->nsamp > 0) {
-        int64_t* d_out = nullptr;
         const size_t bytes = sizeof(int64_t) * (size_t)ctx->R * ctx->nsamp;
-        HIP_TRY(ctx, hipMalloc(&d_out, bytes));
+        { const int32_t rci = ensure_io(ctx, bytes); if (rci) return rci; }
+        int64_t* d_out = reinterpret_cast<int64_t*>(ctx->d_io);
         const dim3 grid((unsigned)((ctx->nsamp + 31) / 32), (unsigned)ctx->G);
         hipLaunchKernelGGL(transpose_es_kernel, grid, dim3(256), 0, ctx->stream, ctx->d_Es, d_out, ctx->nsamp, (int)ctx->Rpad, (int)ctx->R);
-        hipError_t e = hipGetLastError();
-        if (e == hipSuccess) e = hipMemcpyAsync(Es_out, d_out, bytes, hipMemcpyDeviceToHost, ctx->stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-        (void)hipFree(d_out);
-        HIP_TRY(ctx, e);
+        HIP_TRY(ctx, hipGetLastError());
+        HIP_TRY(ctx, hipMemcpyAsync(Es_out, d_out, bytes, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     }
     return RRRMC_OK;
 }
@@ -1420,6 +1394,11 @@ int32_t rrrmc_timing_accumulate(rrrmc_ctx* ctx, int32_t on)
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));      // no queued call may still record into the pool being reset
     ctx->acc_mode = on != 0;
     ctx->ev_pool_used = 0;
+    for (int64_t want = 2 * (int64_t)(on > 0 ? on : 0); (int64_t)ctx->ev_pool.size() < want;) {     // on = launches to pre-create event pairs for
+        hipEvent_t e;
+        HIP_TRY(ctx, hipEventCreate(&e));
+        ctx->ev_pool.push_back(e);
+    }
     ctx->last_ev_pool = false;
     ctx->timing_valid = false;
     return RRRMC_OK;

@@ -285,9 +285,10 @@ class Engine:
                                             Q.ctypes.data, tm.ctypes.data, ov.ctypes.data), self._ctx)
         return Q, tm, ov
 
-    def timing_accumulate(self, on=True):
-        """Give every sweep launch of the following async calls its own HIP-event pair (see ``timing_total``)."""
-        check(lib().rrrmc_timing_accumulate(self._ctx, 1 if on else 0), self._ctx)
+    def timing_accumulate(self, on=True, reserve_launches=1):
+        """Give every sweep launch of the following async calls its own HIP-event pair (see ``timing_total``); the events of the
+        first ``reserve_launches`` launches are created now, so that the calls in between create none."""
+        check(lib().rrrmc_timing_accumulate(self._ctx, max(1, int(reserve_launches)) if on else 0), self._ctx)
 
     def timing_total(self):
         """(sweep_ms, sweep_launches) summed over every sampling call since ``timing_accumulate()``; synchronises."""
