@@ -284,22 +284,22 @@ def load_profile_json(name):
 # ----------------------------------------------------------------------------------------------------------------
 def secondary_c3(pkg, O, device):
     """configs[2]: GraphSKNormal N=1024, 2048 replicas, standardMC beta=1 (sk_block_kernel)."""
-    N, R, beta, iters, step = 1024, 2048, 1.0, 1 << 16, 1 << 10
+    N, R, beta, iters, step = 1024, 2048, 1.0, 1 << 20, 1 << 10      # SURVEY.md §8d's C3 shape: 16 segments of the blocked kernel per call
     X = pkg.GraphSKNormal(N, seed=SEED)
     with pkg.Engine(X, R, device=device) as eng:
         eng.seed(SEED)
         eng.init_spins_random()
-        eng.standard_mc_async(beta, iters // 8, step); eng.sync()
+        eng.standard_mc_async(beta, iters // 16, step); eng.sync()
         t0 = time.perf_counter()
         eng.standard_mc_async(beta, iters, step); eng.sync()
-        dt = time.perf_counter() - t0
-        _, k_ms, nl = eng.last_timing()
+        dt = time.perf_counter() - t0                                # end to end: energy(X, C), block tables of every segment, the 16 launches
+        tot_ms, k_ms, nl = eng.last_timing()
         _, acc = eng.fetch_results(want_energies=False)
     a = float(acc.mean()) / iters
     bpa = 8 + a * (17 * N + 2)                                   # SURVEY.md §8d, dense SK Float64
-    out = {"workload": "GraphSKNormal(N=1024) standardMC beta=1.0, 2048 replicas, 2^16 iterations per replica", "value": R * iters / dt,
+    out = {"workload": "GraphSKNormal(N=1024) standardMC beta=1.0, 2048 replicas, 2^20 iterations per replica, energy sample every 1024", "value": R * iters / dt,
            "unit": "attempts/s", "kernel": "sk_sweep_kernel" if os.environ.get("RRRMC_SK_LEGACY") == "1" else ("sk_block_kernel<2, 512>" if os.environ.get("RRRMC_SK_RB") == "8" else "sk_block_kernel<4, 256, 4>"),
-           "avg_launch_ms": k_ms / max(nl, 1), "launches": nl, "acceptance": a,
+           "avg_launch_ms": k_ms / max(nl, 1), "launches": nl, "call_ms": tot_ms, "acceptance": a,
            "algorithmic_bytes_per_attempt": bpa, "achieved_GBps": bpa * R * iters / (k_ms * 1e-3) / 1e9,
            "note": "algorithmic bytes of the Float64-field picture (SURVEY.md §8d) over the kernel time: the fields live in registers (4 replicas "
                    "per workgroup, two workgroups per compute unit), the only traffic is the 8 KiB row of 4J per attempt and workgroup from L2 / Infinity Cache; "
@@ -445,6 +445,41 @@ def secondary_f64_fast(pkg, O, device):
     return out
 
 
+def secondary_f64_exact(pkg, O, device):
+    """The DEFAULT (bit-exact) Float64 sparse path: GraphRRGNormal(N=4096, K=3), spf_sweep_kernel — the reference's cached-field loop
+    (src/graphs/RRG.jl:504-627) with the fields in HBM; the measured HBM traffic per attempt comes from the committed rocprofv3 pass."""
+    N, K, R, beta, iters, step = 4096, 3, 8192, 1.0, 1 << 14, 1 << 12
+    X = pkg.GraphRRGNormal(N, K, seed=SEED)
+    with pkg.Engine(X, R, device=device) as eng:
+        eng.seed(SEED)
+        eng.init_spins_random()
+        eng.standard_mc_async(beta, iters, step); eng.sync()
+        t0 = time.perf_counter()
+        eng.standard_mc_async(beta, iters, step); eng.sync()
+        dt = time.perf_counter() - t0
+        _, k_ms, nl = eng.last_timing()
+        _, acc = eng.fetch_results(want_energies=False)
+    a = float(acc.mean()) / iters
+    bpa = 8 + a * (10 + 17 * K)                                  # SURVEY.md §8d widths: field 8 B, spin 1 B
+    out = {"workload": "GraphRRGNormal(N=4096,K=3) standardMC (exact mode) beta=1.0, 8192 replicas, 2^14 iterations per replica, energy sample every 4096",
+           "value": R * iters / dt, "unit": "attempts/s", "kernel": "spf_sweep_kernel<3>", "avg_launch_ms": k_ms / max(nl, 1), "launches": nl,
+           "acceptance": a, "algorithmic_bytes_per_attempt": bpa, "achieved_GBps": bpa * R * iters / (k_ms * 1e-3) / 1e9}
+    out["frac"] = out["achieved_GBps"] / HBM_PEAK_GBS
+    tf, tf_path, _ = load_profile_json("spf_traffic.json")
+    if tf:
+        out["traffic"] = {"measured_bytes_per_attempt": tf["measured_bytes_per_attempt"], "ratio_to_algorithmic": tf["traffic_ratio"],
+                          "hbm_GBps_at_this_rate": tf["measured_bytes_per_attempt"] * R * iters / (k_ms * 1e-3) / 1e9,
+                          "source": "%s (committed rocprofv3 FETCH_SIZE x2 + WRITE_SIZE pass of the same workload, commit %s; not measured in this run)" % (tf_path, tf.get("git_commit"))}
+    if O is not None:
+        with pinned_core():
+            ch = O.init_configs(SEED, 0, 1, N)[0]
+            it1 = 1 << 24
+            v, n, dt1 = timed_oracle(lambda k: O.standard_mc_spf(X.A, X.J, beta, it1, step, SEED, ch, it0=k * it1), it1)
+            out["cpu_one_core"] = {"value": v, "unit": "attempts/s", "kind": "port", "build": O.flavour,
+                                   "sample": "1 replica x %d x 2^24 iterations (%.1f s), oracle" % (n, dt1)}
+    return out
+
+
 def secondary_f8_rrr(pkg, O, device):
     """SURVEY.md §8f rank 1 at the reference's experiment size (scripts/scripts.jl:23 test_RRG): rrrMC(X::SingleGraph) on GraphRRG(10^4, 3),
     beta = 2, thread-per-replica kernel (rrr_sparse_kernel: DeltaECache{Int,2} + ArraySets per replica in HBM/L2)."""
@@ -482,7 +517,7 @@ def secondary(pkg, O, device):
     out = {}
     for name, fn in (("c3_sk_normal", secondary_c3), ("c4_ea_checkerboard", secondary_c4), ("c4_ea_random_site", secondary_c4_random),
                      ("c5_quant_rrr", secondary_c5),
-                     ("f64_sparse_fast", secondary_f64_fast), ("f8_rrr_rrg_1e4", secondary_f8_rrr)):
+                     ("f64_sparse_exact", secondary_f64_exact), ("f64_sparse_fast", secondary_f64_fast), ("f8_rrr_rrg_1e4", secondary_f8_rrr)):
         t0 = time.perf_counter()
         try:
             out[name] = fn(pkg, O, device)
@@ -651,6 +686,16 @@ def run_rank(args):
             except Exception as e:      # never let the side measurement hide the bench line
                 roof["measured_copy_GBps"] = None
                 sys.stderr.write("device copy bandwidth not measured: %r\n" % (e,))
+    if rank == 0 and world == 1 and not args.no_secondary:
+        # The reference-style SYNCHRONOUS call (src/RRRMC.jl:126 returns Es and C per call): rrrmc_standard_mc + rrrmc_get_spins, i.e. the
+        # sweep plus the transposes and the PCIe transfers of the energy samples (R x 1024 Int64) and the configuration.  Never `value`.
+        t1 = time.perf_counter()
+        nsync = 5
+        for _ in range(nsync):
+            eng.standard_mc(BETA, args.iters, SAMPLE_STEP)
+            eng.get_config()
+        out["sync_value"] = float(R) * args.iters * nsync / (time.perf_counter() - t1)
+        out["sync_value_is"] = "attempts/s of %d synchronous rrrmc_standard_mc + rrrmc_get_spins calls (results copied to host memory after every call: PCIe inclusive)" % nsync
     eng.close()
     rc = 0
     if rank == 0:
