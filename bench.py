@@ -298,12 +298,12 @@ def secondary_c3(pkg, O, device):
     a = float(acc.mean()) / iters
     bpa = 8 + a * (17 * N + 2)                                   # SURVEY.md §8d, dense SK Float64
     out = {"workload": "GraphSKNormal(N=1024) standardMC beta=1.0, 2048 replicas, 2^20 iterations per replica, energy sample every 1024", "value": R * iters / dt,
-           "unit": "attempts/s", "kernel": "sk_sweep_kernel" if os.environ.get("RRRMC_SK_LEGACY") == "1" else ("sk_block_kernel<2, 512>" if os.environ.get("RRRMC_SK_RB") == "8" else "sk_block_kernel<4, 256, 4>"),
+           "unit": "attempts/s", "kernel": "sk_sweep_kernel" if os.environ.get("RRRMC_SK_LEGACY") == "1" else ("sk_block_kernel" if os.environ.get("RRRMC_SK_BLOCK_V1") == "1" else "sk_hblock_kernel<2, 512, 8>"),
            "avg_launch_ms": k_ms / max(nl, 1), "launches": nl, "call_ms": tot_ms, "acceptance": a,
            "algorithmic_bytes_per_attempt": bpa, "achieved_GBps": bpa * R * iters / (k_ms * 1e-3) / 1e9,
-           "note": "algorithmic bytes of the Float64-field picture (SURVEY.md §8d) over the kernel time: the fields live in registers (4 replicas "
-                   "per workgroup, two workgroups per compute unit), the only traffic is the 8 KiB row of 4J per attempt and workgroup from L2 / Infinity Cache; "
-                   "the kernel is bound by instruction issue of the per-replica field updates, see DESIGN.md 4c"}
+           "note": "algorithmic bytes of the Float64-field picture (SURVEY.md §8d) over the kernel time: the fields live in registers (8 replicas "
+                   "per workgroup, one workgroup per compute unit), the only traffic is the 8 KiB row of 4J per attempt and workgroup from L2 / Infinity Cache; "
+                   "see DESIGN.md 4c for the phase budget (decide chain, Float64 multiply-add issue)"}
     out["frac"] = out["achieved_GBps"] / HBM_PEAK_GBS
     # FP64 VALU view: the useful work is a * N Float64 adds per attempt and replica (the field update); MI355X vector FP64 = 78.6 TFLOP/s as FMAs
     out["fp64_adds_per_s"] = a * N * R * iters / (k_ms * 1e-3)

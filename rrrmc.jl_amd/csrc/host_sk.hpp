@@ -53,6 +53,29 @@ sk_block_fn skb_block_half_for(int spt)
         default: return nullptr;
     }
 }
+// round 4: the same shapes with the branch-free bulk phase (sk_hblock_kernel.hpp); RRRMC_SK_BLOCK_V1 = 1 keeps round 3's sk_block_kernel
+// (bit-identical; the tests compare them).  1024 threads per workgroup are not offered by the new kernel (128 registers per thread).
+bool sk_block_v1_forced()
+{
+    const char* e = std::getenv("RRRMC_SK_BLOCK_V1");
+    return e && e[0] == '1';
+}
+template <bool BIN>
+sk_block_fn sk_hblock_for(int spt, int nth)
+{
+    if (nth == 256) return spt == 1 ? sk_hblock_kernel<1, 256, 8, BIN> : nullptr;
+    if (nth == 512) return spt == 1 ? sk_hblock_kernel<1, 512, 8, BIN> : spt == 2 ? sk_hblock_kernel<2, 512, 8, BIN> : spt == 3 ? sk_hblock_kernel<3, 512, 8, BIN> : spt == 4 ? sk_hblock_kernel<4, 512, 8, BIN> : nullptr;
+    return nullptr;
+}
+template <bool BIN>
+sk_block_fn sk_hblock_half_for(int spt)
+{
+    switch (spt) {
+        case 1: return sk_hblock_kernel<1, 256, 4, BIN>; case 2: return sk_hblock_kernel<2, 256, 4, BIN>;
+        case 3: return sk_hblock_kernel<3, 256, 4, BIN>; case 4: return sk_hblock_kernel<4, 256, 4, BIN>;
+        default: return nullptr;
+    }
+}
 // two 4-replica workgroups of 256 threads per group of 8 replicas (co-resident on a compute unit: one decides while the other applies)
 sk_block_fn sk_block_half_for(int spt)
 {
@@ -66,9 +89,11 @@ sk_block_fn sk_block_half_for(int spt)
 // 512: 26.4 / 21.5,  768: 30.7 / 24.5,  1024: 30.9 / 26.6.  Beyond N = 1024 the split build would need 512 threads and two workgroups of
 // 8 wavefronts per compute unit, i.e. 128 registers per thread for a state that takes 112 of them: whole groups there.
 // RRRMC_SK_RB = 4 / 8 forces the split / whole-group build (bit-identical; the tests compare them)
-int sk_rb_for(int64_t N)
+// Round 4's kernel (sk_hblock_kernel), same measurement, whole group / split: N = 128: 17.8 / 12.1,  256: 17.5 / 12.0,  512: 14.3 / 12.2,  768: 15.7 / 16.7,
+// 1024: 15.7 / 21.9 (the split build loads every row of 4J twice per compute unit, and the bulk phase no longer hides that).
+int sk_rb_for(int64_t N, bool v1)
 {
-    int rb = N <= 1024 ? 4 : 8;
+    int rb = N <= (v1 ? 1024 : 512) ? 4 : 8;
     if (const char* e = std::getenv("RRRMC_SK_RB")) {
         const int v = std::atoi(e);
         if (v == 8 || (v == 4 && N <= 1024)) rb = v;
@@ -272,11 +297,14 @@ int32_t sk_standard_mc_async(rrrmc_ctx* ctx, double beta, int64_t iters, int64_t
     const int nth = sk_threads_for(ctx->N), spt = (int)((ctx->N + nth - 1) / nth);
     int blk_nth = binary && nth == 1024 ? 512 : nth;     // threads per workgroup (the binary build has no 1024-thread form)
     const int blk_spt = (int)((ctx->N + blk_nth - 1) / blk_nth);
-    sk_block_fn blockk = sk_legacy_forced() ? nullptr : binary ? skb_block_for(blk_spt, blk_nth) : sk_block_for(spt, nth);
+    const bool v1 = sk_block_v1_forced() || blk_nth == 1024;
+    sk_block_fn blockk = sk_legacy_forced() ? nullptr : v1 ? (binary ? skb_block_for(blk_spt, blk_nth) : sk_block_for(spt, nth))
+                                                           : (binary ? sk_hblock_for<true>(blk_spt, blk_nth) : sk_hblock_for<false>(blk_spt, blk_nth));
     int blk_wgs = 1;                                      // workgroups per group of 8 replicas
-    if (blockk && sk_rb_for(ctx->N) == 4) {
+    if (blockk && sk_rb_for(ctx->N, v1) == 4) {
         const int hs = (int)((ctx->N + 255) / 256);
-        if (const sk_block_fn h = binary ? skb_block_half_for(hs) : sk_block_half_for(hs)) { blockk = h; blk_nth = 256; blk_wgs = 2; }
+        const sk_block_fn h = v1 ? (binary ? skb_block_half_for(hs) : sk_block_half_for(hs)) : (binary ? sk_hblock_half_for<true>(hs) : sk_hblock_half_for<false>(hs));
+        if (h) { blockk = h; blk_nth = 256; blk_wgs = 2; }
     }
     if (binary && !blockk) return fail(ctx, RRRMC_ERR_UNSUPPORTED, "internal: no blocked kernel for N=%lld", (long long)ctx->N);
     if (blockk && iters > 0) {
@@ -295,7 +323,9 @@ int32_t sk_standard_mc_async(rrrmc_ctx* ctx, double beta, int64_t iters, int64_t
             HIP_TRY(ctx, hipEventCreate(&e));
             ctx->ev_sweep.push_back(e);
         }
+        if (!v1 && !ctx->sk_hl) HIP_TRY(ctx, hipMalloc(&ctx->sk_hl, sizeof(double) * (size_t)ctx->Rpad * (size_t)ctx->N));
         SkBlockParams Bk{};
+        Bk.hl = ctx->sk_hl;
         Bk.J4 = ctx->sk_J4; Bk.blkJw = ctx->sk_blkJw; Bk.blkSites = ctx->sk_blkSites;
         Bk.lf = ctx->sk_lf; Bk.lfl = ctx->sk_lfl; Bk.move_last = ctx->sk_move_last; Bk.spins = ctx->sk_spins;
         Bk.E_cur = ctx->sk_E; Bk.acc_cur = ctx->d_acc; Bk.Es = ctx->sk_Es;

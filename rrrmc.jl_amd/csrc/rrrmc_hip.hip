@@ -20,6 +20,7 @@
 
 #include "sk_kernels.hpp"
 #include "sk_block_kernel.hpp"
+#include "sk_hblock_kernel.hpp"
 #include "rrr_kernels.hpp"
 #include "quant_wave_kernel.hpp"
 #include "sparse_wave_kernel.hpp"
@@ -143,6 +144,7 @@ struct rrrmc_ctx {
     double* sk_blkJw = nullptr;    // sk_block_kernel: coupling sub-matrices of a segment's blocks
     uint32_t* sk_blkSites = nullptr;
     size_t sk_blk_cap = 0;         // blocks the two buffers hold
+    double* sk_hl = nullptr;       // [G8 * 8][N] sk_hblock_kernel's lfields_last scratch (valid inside a launch only)
     double* sk_lf = nullptr;       // [G8][N][8]
     double* sk_lfl = nullptr;
     int32_t* sk_move_last = nullptr;
@@ -755,7 +757,7 @@ void rrrmc_ctx_destroy(rrrmc_ctx* ctx)
     free_dev(ctx->d_E); free_dev(ctx->d_acc); free_dev(ctx->d_chunks); free_dev(ctx->d_Es);
     free_dev(ctx->d_U); free_dev(ctx->d_io);
     for (uint32_t*& l : ctx->d_color_list) free_dev(l);
-    free_dev(ctx->sk_J4); free_dev(ctx->sk_blkJw); free_dev(ctx->sk_blkSites);
+    free_dev(ctx->sk_J4); free_dev(ctx->sk_blkJw); free_dev(ctx->sk_blkSites); free_dev(ctx->sk_hl);
     free_dev(ctx->sk_J); free_dev(ctx->sk_lf); free_dev(ctx->sk_lfl); free_dev(ctx->sk_move_last); free_dev(ctx->sk_spins);
     free_dev(ctx->sk_E); free_dev(ctx->sk_Es); free_dev(ctx->skb_J); free_dev(ctx->skb_lf); free_dev(ctx->skb_lfl);
     free_dev(ctx->q_spins); free_dev(ctx->q_cls); free_dev(ctx->q_sv); free_dev(ctx->q_spos); free_dev(ctx->q_st);

@@ -38,6 +38,7 @@ struct SkBlockParams {
     const uint32_t* blkSites;  // [nblk + 1][64]  sites (0 past the end of the segment)
     double* lf;                // [G][N][kSkRB]
     double* lfl;
+    double* hl;                // sk_hblock_kernel: [G * kSkRB][N] scratch, lfields_last in the kernel's sign-free form during a launch
     int32_t* move_last;        // [G][kSkRB]
     uint8_t* spins;            // [G][N]
     double* E_cur;             // [G * kSkRB]

@@ -18,9 +18,14 @@ import numpy as np
 W = 64
 
 
-def run_chain(O, J, beta, iters, step, seed, chunks, it0=0, replica=0, state=None):
+def run_chain(O, J, beta, iters, step, seed, chunks, it0=0, replica=0, state=None, hform=False):
     """One chain of standardMC on GraphSKNormal through the blocked schedule.
-    Returns (Es, chunks_out, accepted, lfields, state) with state = (lfl, move_last) for a resumed call."""
+    Returns (Es, chunks_out, accepted, lfields, state) with state = (lfl, move_last) for a resumed call.
+
+    hform = True models round 4's bulk phase: the registers hold H_j = sigma_j lfields[j] (the field without the site's own sign: a flip of i
+    adds sigma_i' 4 J_ij to EVERY H_j with one wave-uniform sign, and leaves H_i alone), the bulk update of a block is one fused
+    multiply-add per (attempt, site) with a multiplier in {+1, -1, 0} and no branch, lfields_last is copied only where it can be
+    read (before the block's last accepted move and before a move that the next one undoes), and the spins flip once per block."""
     N = J.shape[0]
     ch = np.array(chunks, np.uint64, copy=True)
     sp = np.array([(int(ch[x >> 6]) >> (x & 63)) & 1 for x in range(N)], np.int64)
@@ -31,6 +36,13 @@ def run_chain(O, J, beta, iters, step, seed, chunks, it0=0, replica=0, state=Non
     else:
         lf, lfl, mlast, E = state[0].copy(), state[1].copy(), state[2], state[3]
     J4 = 4.0 * J                                            # exact
+    if hform:
+        sg = lambda: np.where(sp == 1, 1.0, -1.0)
+        H = sg() * lf                                                      # x * +-1.0 is exact
+        sl = sg()
+        if mlast >= 0:
+            sl[mlast] = -sl[mlast]                                         # lfields_last[move_last] belongs to the spin before its last flip
+        Hl = sl * lfl
     Es, acc_total = [], 0
     next_sample = step
     nblk = (iters + W - 1) // W
@@ -40,8 +52,13 @@ def run_chain(O, J, beta, iters, step, seed, chunks, it0=0, replica=0, state=Non
         sites = [O.site_of(seed, it0 + t, N) for t in its]
         us = [O.rand53(seed, it0 + t, replica) for t in its]
         # ---- gather the window
-        f = np.array([lf[s] for s in sites])
-        fl = np.array([lfl[s] for s in sites])
+        if hform:
+            sgn = sg()
+            f = np.array([sgn[s] * H[s] for s in sites])
+            fl = np.array([(-sgn[s] if s == mlast else sgn[s]) * Hl[s] for s in sites])
+        else:
+            f = np.array([lf[s] for s in sites])
+            fl = np.array([lfl[s] for s in sites])
         ws = np.array([sp[s] for s in sites], np.int64)
 
         def verdict(m):
@@ -49,6 +66,7 @@ def run_chain(O, J, beta, iters, step, seed, chunks, it0=0, replica=0, state=Non
             return x >= 0.0 or us[m] < O.det_exp(x)
 
         ok = [verdict(m) for m in range(nv)]
+        ws0 = np.zeros(nv, np.int64)                                     # the moved spin before its flip, per accepted attempt
         moves = []                                                       # (k, swapped)
         pos = 0
         while True:
@@ -59,6 +77,7 @@ def run_chain(O, J, beta, iters, step, seed, chunks, it0=0, replica=0, state=Non
                 Es.append(E)
                 next_sample += step
             dE = f[k]
+            ws0[k] = ws[k]
             E = E + dE
             acc_total += 1
             swapped = mlast == sites[k]
@@ -85,6 +104,23 @@ def run_chain(O, J, beta, iters, step, seed, chunks, it0=0, replica=0, state=Non
         while next_sample <= its[-1]:
             Es.append(E)
             next_sample += step
+        if hform:
+            # what the deciding wavefront leaves behind: per attempt a multiplier, a copy flag, a swap flag; the spins flip once
+            mult, cpy, swp = np.zeros(nv), np.zeros(nv, bool), np.zeros(nv, bool)
+            for n, (k, swapped) in enumerate(moves):
+                swp[k] = swapped
+                if not swapped:
+                    mult[k] = -1.0 if ws0[k] else 1.0                    # sigma_i' = the moved spin AFTER its flip
+                    cpy[k] = n + 1 == len(moves) or moves[n + 1][1]      # last accepted move of the block, or the next one undoes it
+            for k in range(nv):
+                if cpy[k]:
+                    Hl[:] = H
+                if swp[k]:
+                    H, Hl = Hl, H
+                H[:] = H + J4[sites[k]] * mult[k]                        # one fused multiply-add: the product with +-1 / 0 is exact
+            for k, _ in moves:
+                sp[sites[k]] ^= 1
+            continue
         # ---- bulk: the block's accepted moves on the full arrays
         for k, swapped in moves:
             i = sites[k]
@@ -98,6 +134,12 @@ def run_chain(O, J, beta, iters, step, seed, chunks, it0=0, replica=0, state=Non
             lf[:] = lf + sig * J4[i]                                     # lfj + 4 J sigma; sigma * 4J is exact
             lfl[i] = lfm
             lf[i] = -lfm
+    if hform:
+        lf = sg() * H
+        sl = sg()
+        if mlast >= 0:
+            sl[mlast] = -sl[mlast]
+        lfl = sl * Hl
     for x in range(N):
         w, b = x >> 6, x & 63
         ch[w] = np.uint64((int(ch[w]) & ~(1 << b)) | (int(sp[x]) << b))

@@ -245,8 +245,8 @@ def test_binary_sk_block_kernel_builds_agree(pkg, oracle, monkeypatch, N, R):
     seed = 4001 + N
     X = pkg.GraphSK(N, seed=seed)
     outs = []
-    for env in ({"RRRMC_SK_RB": "8"}, {"RRRMC_SK_RB": "4"}, {"RRRMC_SK_LEGACY": "1"}):
-        for k in ("RRRMC_SK_RB", "RRRMC_SK_LEGACY"):
+    for env in ({"RRRMC_SK_RB": "8"}, {"RRRMC_SK_RB": "4"}, {"RRRMC_SK_LEGACY": "1"}, {"RRRMC_SK_BLOCK_V1": "1", "RRRMC_SK_RB": "8"}, {"RRRMC_SK_BLOCK_V1": "1", "RRRMC_SK_RB": "4"}):
+        for k in ("RRRMC_SK_RB", "RRRMC_SK_LEGACY", "RRRMC_SK_BLOCK_V1"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
@@ -274,8 +274,8 @@ def test_skn_block_kernel_builds_agree(pkg, oracle, monkeypatch, N, R):
     seed = 977 + N
     X = pkg.GraphSKNormal(N, seed=seed)
     outs = []
-    for env in ({"RRRMC_SK_RB": "8"}, {"RRRMC_SK_RB": "4"}, {"RRRMC_SK_LEGACY": "1"}):
-        for k in ("RRRMC_SK_RB", "RRRMC_SK_LEGACY"):
+    for env in ({"RRRMC_SK_RB": "8"}, {"RRRMC_SK_RB": "4"}, {"RRRMC_SK_LEGACY": "1"}, {"RRRMC_SK_BLOCK_V1": "1", "RRRMC_SK_RB": "8"}, {"RRRMC_SK_BLOCK_V1": "1", "RRRMC_SK_RB": "4"}):
+        for k in ("RRRMC_SK_RB", "RRRMC_SK_LEGACY", "RRRMC_SK_BLOCK_V1"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)

@@ -5,19 +5,20 @@ sk_block_kernel (csrc/sk_block_kernel.hpp) works in segments of kSkSegIters = 65
 ``it_base`` and the block tables are rebuilt.  The reference's loop (src/RRRMC.jl:100-119) has no seams, so a call that crosses one
 must equal the oracle's single loop bit for bit: energies sampled on, just before and just after a seam, the configuration, the accepted
 count and the live field cache — for the Gaussian (src/graphs/SK.jl:170-297) and the binary model (SK.jl:28-165), for every build of
-the kernel (two 4-replica workgroups per group, one 8-replica workgroup, the one-attempt-at-a-time legacy kernel)."""
+the kernel (sk_hblock_kernel with two 4-replica workgroups per group and with one 8-replica workgroup, round 3's sk_block_kernel, the
+one-attempt-at-a-time legacy kernel)."""
 import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
 
 SEG = 1 << 16
-BUILDS = ({"RRRMC_SK_RB": "4"}, {"RRRMC_SK_RB": "8"}, {"RRRMC_SK_LEGACY": "1"})
+BUILDS = ({"RRRMC_SK_RB": "4"}, {"RRRMC_SK_RB": "8"}, {"RRRMC_SK_LEGACY": "1"}, {"RRRMC_SK_BLOCK_V1": "1"})      # sk_hblock_kernel split / whole, sk_sweep_kernel, round 3's sk_block_kernel
 N_FOR_ITERS = {SEG: 1024, SEG + 1: 300, 2 * SEG + 1: 64, 200000: 256}
 
 
 def _set_build(monkeypatch, env):
-    for k in ("RRRMC_SK_RB", "RRRMC_SK_LEGACY", "RRRMC_SK_THREADS"):
+    for k in ("RRRMC_SK_RB", "RRRMC_SK_LEGACY", "RRRMC_SK_THREADS", "RRRMC_SK_BLOCK_V1"):
         monkeypatch.delenv(k, raising=False)
     for k, v in env.items():
         monkeypatch.setenv(k, v)
