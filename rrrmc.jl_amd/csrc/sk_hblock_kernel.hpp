@@ -65,7 +65,13 @@ __global__ __launch_bounds__(NTH, RB == 4 ? 2 : 1) void sk_hblock_kernel(SkBlock
     constexpr int JPI = NJW >= NIT ? NJW / NIT : 1;        // doubles staged per iteration, in the first NJW / JPI iterations
     static_assert(JPI * NIT == NJW || (JPI == 1 && NJW < NIT), "sub-matrix slices");
     __shared__ double sh_Jw[2][kSkW * kSkW];               // the block's 64 x 64 coupling sub-matrix, double-buffered: the next block's is staged during apply
-    __shared__ double sh_wf[kSkW][RB], sh_wfl[kSkW][RB], sh_u[kSkW][RB], sh_L[kSkW][RB];
+    __shared__ double sh_wf[kSkW][RB], sh_wfl[kSkW][RB];
+    // acceptance uniforms and their logarithms.  Whole-group build: double-buffered, the next block's are drawn by every wavefront behind its
+    // own decisions, while it would wait for the slowest one; the split build (two workgroups per compute unit: 160 KiB of LDS for both)
+    // keeps one buffer and draws them at the top of the bulk phase
+    constexpr int NUB = RB == 8 ? 2 : 1;
+    __shared__ double sh_u[NUB][kSkW][RB], sh_L[NUB][kSkW][RB];
+    __shared__ __attribute__((aligned(4))) uint8_t sh_need[RB];                              // the next block attempts replica r's move_last (its window needs lfields_last)
     __shared__ __attribute__((aligned(16))) double sh_mult[kSkW][RB];     // per (attempt, replica): the multiplier +1.0 / -1.0 / 0.0
     __shared__ uint32_t sh_acc[2][kSkW];                   // per attempt: bit 8 + r = undo swap, bit 24 + r = copy lfields_last first
     __shared__ uint8_t sh_cslot[kSkW];
@@ -123,8 +129,8 @@ __global__ __launch_bounds__(NTH, RB == 4 ? 2 : 1) void sk_hblock_kernel(SkBlock
         for (int idx = tid; idx < kSkW * RB; idx += NTH) {
             const int l = idx / RB, r = idx % RB;
             const double u = rand53(P.k0, P.k1, P.g0 + (uint64_t)(b * kSkW + l + 1), P.replica0 + (uint32_t)(grp * kSkRB + r8 + r));
-            sh_u[l][r] = u;
-            sh_L[l][r] = log(u);
+            sh_u[b & (NUB - 1)][l][r] = u;
+            sh_L[b & (NUB - 1)][l][r] = log(u);
         }
     };
     uint32_t sv = P.blkSites[lane];                        // sites of the current block, lane = attempt
@@ -136,6 +142,7 @@ __global__ __launch_bounds__(NTH, RB == 4 ? 2 : 1) void sk_hblock_kernel(SkBlock
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             sh_cslot[lane] = sh_canon[sv];
             sh_acc[0][lane] = 0u;
+            if (lane < RB) { const int32_t m = sh_mlast[lane]; sh_need[lane] = (m >= 0 && sh_canon[m >= 0 ? m : 0] != 0xffu) ? 1 : 0; }
         }
     }
     double JA[PF][SPT], JB[PF][SPT];
@@ -158,10 +165,12 @@ __global__ __launch_bounds__(NTH, RB == 4 ? 2 : 1) void sk_hblock_kernel(SkBlock
         //      move of the block undoes its last one (later undos read what the block itself tracked), which takes move_last among the
         //      block's sites: only then is it fetched from memory (the deciding wavefront puts the sign of lfields_last[move_last] right)
         bool need_fl[RB];
+        {
+            uint32_t nw[RB / 4];
 #pragma unroll
-        for (int r = 0; r < RB; ++r) {
-            const int32_t m = __builtin_amdgcn_readfirstlane(sh_mlast[r]);
-            need_fl[r] = m >= 0 && __builtin_amdgcn_readfirstlane((int)sh_canon[m >= 0 ? m : 0]) != 0xff;
+            for (int w = 0; w < RB / 4; ++w) nw[w] = (uint32_t)__builtin_amdgcn_readfirstlane((int)reinterpret_cast<const uint32_t*>(sh_need)[w]);
+#pragma unroll
+            for (int r = 0; r < RB; ++r) need_fl[r] = (nw[r / 4] >> (8 * (r & 3))) & 0xffu;
         }
 #pragma unroll
         for (int q = 0; q < SPT; ++q) {
@@ -206,10 +215,10 @@ __global__ __launch_bounds__(NTH, RB == 4 ? 2 : 1) void sk_hblock_kernel(SkBlock
                 double f = sh_wf[cs][r], fl = sh_wfl[cs][r];
                 if ((int32_t)sv == mlast[a]) fl = -fl;
                 uint32_t sp = ((uint32_t)sh_spin[sv] >> (r8 + r)) & 1u;
-                const double u = sh_u[lane][r];
+                const double u = sh_u[pb & (NUB - 1)][lane][r];
                 const int64_t it0 = P.it_base + b * kSkW;
                 uint32_t accw = 0u;
-                const double Lu = sh_L[lane][r];
+                const double Lu = sh_L[pb & (NUB - 1)][lane][r];
                 const double Lm = 1e-9 - 1e-12 * Lu, Lhi = Lu + Lm, Llo = Lu - Lm;
                 const unsigned long long vm = nv >= kSkW ? ~0ull : (1ull << nv) - 1ull;
                 auto verdict = [&](const double x) -> unsigned long long {
@@ -278,6 +287,7 @@ __global__ __launch_bounds__(NTH, RB == 4 ? 2 : 1) void sk_hblock_kernel(SkBlock
                 if (lane == 0) sh_mlast[r] = mlast[a];
             }
         }
+        if constexpr (NUB == 2) { if (b + 1 < nblk) draw_uniforms(b + 1); }
 #ifdef RRRMC_SKB_STAMPS
         const uint64_t tD = __builtin_amdgcn_s_memtime();
 #endif
@@ -297,8 +307,10 @@ __global__ __launch_bounds__(NTH, RB == 4 ? 2 : 1) void sk_hblock_kernel(SkBlock
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 sh_cslot[lane] = sh_canon[sv_next];
                 sh_acc[pb ^ 1][lane] = 0u;
+                // does the next block attempt a replica's move_last?  (sh_mlast is this block's: written before the barrier above)
+                if (lane < RB) { const int32_t m = sh_mlast[lane]; sh_need[lane] = (m >= 0 && sh_canon[m >= 0 ? m : 0] != 0xffu) ? 1 : 0; }
             }
-            draw_uniforms(b + 1);
+            if constexpr (NUB == 1) draw_uniforms(b + 1);
         }
 #ifdef RRRMC_SKB_STAMPS
         const uint64_t tF = __builtin_amdgcn_s_memtime();
