@@ -226,6 +226,10 @@ int32_t spf_cont_async(rrrmc_ctx* ctx, int mode, double beta, int64_t iters, int
         const size_t lds = eo_wave_lds_bytes((int)N);
         HIP_TRY(ctx, raise_lds_attr(reinterpret_cast<const void*>(eo_cont_wave_kernel), lds));
         hipLaunchKernelGGL(eo_cont_wave_kernel, dim3((unsigned)R), dim3(64), lds, st, P);
+    } else if (const char* nw = std::getenv("RRRMC_CONT_NO_WAVE"); (mode == 0 || mode == 1) && !dblm && !ctx->pf_multi_edge && N >= 64 && K <= kContKmax &&
+               cw_lds_bytes(W, levs) <= (size_t)32768 && !(nw && nw[0] == '1')) {
+        // rrrMC / bklMC on the pure Float64 models: one wavefront per replica, the top of the sampler's tree in LDS (cont_wave_kernel.hpp)
+        hipLaunchKernelGGL(cont_wave_kernel, dim3((unsigned)R), dim3(64), cw_lds_bytes(W, levs), st, P);
     } else {
         if (N > 65535) hipLaunchKernelGGL(cont_sparse_kernel<uint32_t>, dim3(rrr_blocks(R)), dim3(rrr_tpb(R)), 0, st, P);
         else hipLaunchKernelGGL(cont_sparse_kernel<uint16_t>, dim3(rrr_blocks(R)), dim3(rrr_tpb(R)), 0, st, P);

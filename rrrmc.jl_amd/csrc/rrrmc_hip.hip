@@ -32,6 +32,7 @@
 #include "spf_fast_kernels.hpp"
 #include "dbl_kernels.hpp"
 #include "cont_kernels.hpp"
+#include "cont_wave_kernel.hpp"
 
 using namespace rrrmc;
 
@@ -206,6 +207,7 @@ struct rrrmc_ctx {
     double* pf_undo = nullptr;     // [W][K+1][64]: live part of lfields_last (see spf_kernels.hpp)
     int32_t* pf_sites = nullptr;   // site stream of one launch
     int64_t pfW = 0;
+    bool pf_multi_edge = false;    // some row of A repeats a neighbour (GraphEANormal with L = 2): the wave build of the continuous samplers is not used
     bool pf_lf_live = false;       // sk_lf holds the local fields of the current configuration (false after the continuous samplers)
     // ---- RRRMC_MODEL_SPARSE_DISCRETIZED (Graph{RRG,EA}NormalDiscretized): spins in q_spins / qW (BitVector word order),
     //      energies in sk_E / sk_Es, statistics in q_stats ----
@@ -2478,6 +2480,8 @@ int32_t rrrmc_set_graph_f64(rrrmc_ctx* ctx, const int32_t* A, const double* J)
     HIP_TRY(ctx, hipMemcpy(ctx->pf_J, J, sizeof(double) * N * K, hipMemcpyHostToDevice));
     ctx->h_A.assign(A, A + N * K);
     ctx->h_Jf.assign(J, J + N * K);
+    ctx->pf_multi_edge = false;
+    for (int64_t q = 1; q < N * K; ++q) if (q % K && A[q] == A[q - 1]) ctx->pf_multi_edge = true;
     if (ctx->pff_ready) {            // a new graph: the fast mode's tables are rebuilt on its next call
         free_dev(ctx->pff_table); free_dev(ctx->pff_absJ); free_dev(ctx->pff_bond_off); free_dev(ctx->pff_thr_hi); free_dev(ctx->pff_thr_lo); free_dev(ctx->pff_flags);
         ctx->pff_ready = false;

@@ -51,6 +51,32 @@ def test_rrr_cont_bit_exact(pkg, oracle, kind, R, beta, iters, step, thr):
         assert (Es2[r] == Es2_ref).all() and (C2.s[r] == ch2_ref).all() and acc2[r] == st2[0]
 
 
+@pytest.mark.parametrize("kind,mode", [("rrg300", "rrr"), ("rrg4096", "rrr"), ("ea5x3", "rrr"), ("rrg300", "bkl"), ("ea5x3", "bkl")])
+def test_cont_wave_kernel_equals_thread_kernel(pkg, oracle, monkeypatch, kind, mode):
+    """cont_wave_kernel (one wavefront per replica, the top of the DynamicSampler's tree in LDS, the bottom in 16-element blocks) against
+    cont_sparse_kernel (RRRMC_CONT_NO_WAVE = 1: one thread per replica, the tree level by level in memory): energies, counts, configurations
+    bit for bit over several refresh! periods (max(N, 100) calls of setindex!, DynamicSamplers.jl:163-165), calls chained."""
+    seed = 818000 + len(kind)
+    X, form = _graph(pkg, kind, seed)
+    R, beta = 7, 2.0
+    iters = 30000 if mode == "bkl" else 6000
+    outs = []
+    for env in (None, "1"):
+        if env is None:
+            monkeypatch.delenv("RRRMC_CONT_NO_WAVE", raising=False)
+        else:
+            monkeypatch.setenv("RRRMC_CONT_NO_WAVE", env)
+        with pkg.Engine(X, R) as eng:
+            eng.seed(seed)
+            eng.init_spins_random()
+            a = eng.rrr_mc(beta, iters, 100) if mode == "rrr" else eng.bkl_mc(beta, iters, 500)
+            b = eng.rrr_mc(beta, 777, 7, staged_thr=1.0) if mode == "rrr" else eng.bkl_mc(beta, 5000, 50)
+            outs.append((a, b, eng.get_config().s.copy(), eng.energy()))
+    for u, w in zip(outs[0][0] + outs[0][1], outs[1][0] + outs[1][1]):
+        assert (np.asarray(u) == np.asarray(w)).all()
+    assert (outs[0][2] == outs[1][2]).all() and (outs[0][3] == outs[1][3]).all()
+
+
 @pytest.mark.parametrize("kind,R,beta,iters,step", [
     ("rrg10", 40, 2.0, 20000, 100), ("rrg300", 64, 2.0, 50000, 1000), ("ea2x3", 16, 1.5, 8000, 64), ("rrg4096", 4, 3.0, 200000, 4096),
 ])

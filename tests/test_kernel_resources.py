@@ -51,3 +51,26 @@ def test_asm_prefetch_kernels_have_no_scratch(tmp_path):
         assert m["vgpr_count"] <= 128, (n, m)              # 1024 threads per workgroup: four wavefronts per SIMD
     # (the four-word-mask build exists for every K too; it may use scratch — its loads are the compiler's)
     assert sum("big_apply_kernel" in n for n in meta) == 7
+
+
+TU_CONT = r'''
+#include <hip/hip_runtime.h>
+#include "cont_wave_kernel.hpp"
+'''
+
+
+@pytest.mark.skipif(shutil.which("hipcc") is None, reason="hipcc not found")
+def test_cont_wave_kernel_has_no_scratch(tmp_path):
+    """cont_wave_kernel (rrrMC / bklMC on the Float64 sparse models, one wavefront per replica) keeps its chain in registers and LDS: no
+    private memory, no register spills; cont_sparse_kernel, the thread-per-replica build it replaces for these modes, indexes small per-move
+    arrays at run time and lives in 544 bytes of scratch (profiles/r03/f8_kernels_summary.txt).  At most 168 registers: three wavefronts per SIMD."""
+    src = tmp_path / "cw.hip"
+    src.write_text(TU_CONT)
+    asm = tmp_path / "cw.s"
+    subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-I", CSRC, "--cuda-device-only", "-S",
+                           str(src), "-o", str(asm)], cwd=str(tmp_path))
+    meta = kernel_metadata(asm.read_text())
+    m = [v for n, v in meta.items() if "cont_wave_kernel" in n and "eo_" not in n]
+    assert len(m) == 1
+    assert m[0]["private_segment_fixed_size"] == 0 and m[0].get("vgpr_spill_count", 0) == 0, m[0]
+    assert m[0]["vgpr_count"] <= 168, m[0]

@@ -42,9 +42,9 @@ with pkg.Engine(Xn, R) as eng:
     eng.seed(1); eng.init_spins_random()
     eng.standard_mc(2.0, 100000, 100000)
     t0 = time.perf_counter(); out = eng.rrr_mc(2.0, 5000, 2500)
-    report("rrrMC GraphRRGNormal(1e4,3) beta=2", "cont_sparse_kernel (rrr)", eng, t0, R * 5000, "iterations")
+    report("rrrMC GraphRRGNormal(1e4,3) beta=2", "cont_wave_kernel (rrr)", eng, t0, R * 5000, "iterations")
     t0 = time.perf_counter(); out = eng.bkl_mc(2.0, 100000, 50000)
-    report("bklMC GraphRRGNormal(1e4,3) beta=2", "cont_sparse_kernel (bkl)", eng, t0, R * float(out[1].mean()), "moves")
+    report("bklMC GraphRRGNormal(1e4,3) beta=2", "cont_wave_kernel (bkl)", eng, t0, R * float(out[1].mean()), "moves")
 
 Xd = pkg.GraphRRGNormalDiscretized(10000, 3, (-1, 0, 1), seed=SEED)     # the model family rrrMC(DoubleGraph) was designed for
 with pkg.Engine(Xd, R) as eng:
