@@ -70,6 +70,12 @@ RRRMC_API int32_t rrrmc_device_count(void);
 /* Measurement helper (bench.py; SURVEY.md §8d "also report a measured device-copy bandwidth"): times `reps` device-to-device copies of
  * `nbytes` with HIP events on a private stream and returns (bytes read + bytes written) per second in GB/s. */
 RRRMC_API int32_t rrrmc_device_copy_bandwidth(int32_t device, int64_t nbytes, int32_t reps, double *gbps_out);
+/* Page-locked host memory for result buffers (optional).  Every entry point accepts ordinary host memory; a buffer from rrrmc_host_alloc
+ * lets the copies of rrrmc_fetch_results / rrrmc_get_spins / rrrmc_standard_mc run at the bus rate instead of through the driver's
+ * staging of pageable memory (the reference returns Es and C from every call, src/RRRMC.jl:126: at config 2 that is 64 MiB per call).
+ * Free with rrrmc_host_free; both are independent of any context. */
+RRRMC_API int32_t rrrmc_host_alloc(int64_t nbytes, void **out);
+RRRMC_API int32_t rrrmc_host_free(void *p);
 
 /*
  * Create a context for R replicas (chains) of one graph with N spins and K neighbour slots per spin.

@@ -411,6 +411,20 @@ function rrr_cache(ctx::Ctx, X)
 end
 
 "kernel time of the last sampling call: (total ms, dominant-kernel ms, its launches); the slowest device of a multi-device Ctx"
+"""
+    host_alloc(T, dims...) -> Array{T}
+
+Result buffers in page-locked host memory (`rrrmc_host_alloc`): `fetch_results!` / `get_spins!` fill them at the bus rate.  Release with
+`host_free(A)`; the array must not be used afterwards.
+"""
+function host_alloc(::Type{T}, dims::Integer...) where {T}
+    p = Ref{Ptr{Cvoid}}(C_NULL)
+    rc = ccall((:rrrmc_host_alloc, LIB), Int32, (Int64, Ref{Ptr{Cvoid}}), Int64(prod(dims) * sizeof(T)), p)
+    rc == 0 || error("rrrmc_host_alloc failed with status $rc")
+    return unsafe_wrap(Array, Ptr{T}(p[]), dims; own = false)
+end
+host_free(A::Array) = (ccall((:rrrmc_host_free, LIB), Int32, (Ptr{Cvoid},), pointer(A)); nothing)
+
 function last_timing(ctx::Ctx)
     tot = Ref{Float64}(0.0); sw = Ref{Float64}(0.0); nl = Ref{Int32}(0)
     check(ccall((:rrrmc_last_timing, LIB), Int32, (Ptr{Cvoid}, Ref{Float64}, Ref{Float64}, Ref{Int32}), ctx.p, tot, sw, nl), ctx.p)

@@ -16,7 +16,7 @@ f64p = np.ctypeslib.ndpointer(np.float64, flags="C_CONTIGUOUS")
 
 # every symbol include/rrrmc_hip.h declares
 SYMBOLS = [
-    "rrrmc_version", "rrrmc_last_error", "rrrmc_device_count", "rrrmc_device_copy_bandwidth", "rrrmc_ctx_create", "rrrmc_ctx_create_multi", "rrrmc_ctx_destroy",
+    "rrrmc_version", "rrrmc_last_error", "rrrmc_device_count", "rrrmc_device_copy_bandwidth", "rrrmc_host_alloc", "rrrmc_host_free", "rrrmc_ctx_create", "rrrmc_ctx_create_multi", "rrrmc_ctx_destroy",
     "rrrmc_set_graph", "rrrmc_seed", "rrrmc_init_spins_random", "rrrmc_set_spins", "rrrmc_get_spins",
     "rrrmc_energy", "rrrmc_get_fields", "rrrmc_standard_mc", "rrrmc_standard_mc_async", "rrrmc_sync",
     "rrrmc_fetch_results", "rrrmc_last_timing", "rrrmc_timing_accumulate", "rrrmc_timing_total", "rrrmc_set_resume", "rrrmc_set_debug_checks", "rrrmc_tracked_energy_f64", "rrrmc_standard_mc_fast_async", "rrrmc_iterations_done", "rrrmc_gen_rrg", "rrrmc_gen_ea",
@@ -58,6 +58,10 @@ def lib():
     L.rrrmc_last_error.restype = C.c_char_p
     L.rrrmc_last_error.argtypes = [vp]
     L.rrrmc_device_count.restype = C.c_int32
+    L.rrrmc_host_alloc.restype = C.c_int32
+    L.rrrmc_host_alloc.argtypes = [C.c_int64, C.POINTER(C.c_void_p)]
+    L.rrrmc_host_free.restype = C.c_int32
+    L.rrrmc_host_free.argtypes = [C.c_void_p]
     L.rrrmc_device_copy_bandwidth.restype = C.c_int32
     L.rrrmc_device_copy_bandwidth.argtypes = [C.c_int32, C.c_int64, C.c_int32, C.POINTER(C.c_double)]
     L.rrrmc_ctx_create.restype = C.c_int32
@@ -194,3 +198,18 @@ def check(rc, ctx=None):
     if rc != 0:
         msg = lib().rrrmc_last_error(ctx)
         raise RRRMCError(rc, msg.decode() if msg else "")
+
+
+def pinned_empty(shape, dtype):
+    """An uninitialised numpy array in page-locked host memory (rrrmc_host_alloc): result buffers handed to ``Engine.standard_mc(out=...)``
+    / ``Engine.get_config(out=...)`` are then filled at the bus rate.  Freed when the array (and every view of it) is gone."""
+    import weakref
+    dt = np.dtype(dtype)
+    n = int(np.prod(shape)) * dt.itemsize
+    p = C.c_void_p()
+    rc = lib().rrrmc_host_alloc(max(n, 1), C.byref(p))
+    if rc != 0 or not p.value:
+        raise RRRMCError(rc or 4, "rrrmc_host_alloc(%d) failed" % n)
+    buf = (C.c_char * max(n, 1)).from_address(p.value)
+    weakref.finalize(buf, lib().rrrmc_host_free, p.value)
+    return np.frombuffer(buf, dtype=dt, count=int(np.prod(shape))).reshape(shape)

@@ -486,9 +486,10 @@ __device__ __forceinline__ void big_apply_body(const BigSweepParams& P, const ui
     extern __shared__ uint32_t bl_sp[];                       // [ceil(N / S)]  r bits per site; then the chunk headers; then s_E[32], s_A[32]
     const int tid = threadIdx.x, lane = tid & 63;
     // gathers address the image by ABSOLUTE LDS address (through the array's name every gather pays an add of the array's link-time address,
-    // which is 0): should the layout ever put something in front of the image, the kernel does nothing and every parity test fails
+    // which is 0): should the layout ever put something in front of the image, the kernel traps — the launch fails with a HIP error at the
+    // next synchronisation instead of leaving stale energies and spins behind
     typedef __attribute__((address_space(3))) const uint32_t lds_cu32;
-    if (__builtin_amdgcn_readfirstlane((int)(uint32_t)(size_t)(__attribute__((address_space(3))) uint32_t*)bl_sp) != 0) return;
+    if (__builtin_amdgcn_readfirstlane((int)(uint32_t)(size_t)(__attribute__((address_space(3))) uint32_t*)bl_sp) != 0) __builtin_trap();
     auto lds_word_at = [](uint32_t byte_addr) -> uint32_t { return *(lds_cu32*)(size_t)byte_addr; };
     const uint32_t r = 1u << lgr, lgS = 5u - (uint32_t)lgr, S = 1u << lgS, rm = r == 32u ? 0xffffffffu : (1u << r) - 1u;
     const uint32_t grp = blockIdx.x >> lgS, sub = blockIdx.x & (S - 1u), rsh = sub << lgr;      // replicas rsh .. rsh + r - 1 of group grp

@@ -199,7 +199,7 @@ int32_t sk_run_energy(rrrmc_ctx* ctx)
 int32_t sk_debug_check(rrrmc_ctx* ctx)
 {
     const size_t nf = (size_t)ctx->G8 * ctx->N * kSkRB;
-    if (!ctx->dbg_flag) HIP_TRY(ctx, hipMalloc(&ctx->dbg_flag, sizeof(int32_t) * 2));
+    if (!ctx->dbg_flag) { HIP_TRY(ctx, hipMalloc(&ctx->dbg_flag, sizeof(int32_t) * 2)); HIP_TRY(ctx, hipMemsetAsync(ctx->dbg_flag, 0, sizeof(int32_t) * 2, ctx->stream)); }
     if (!ctx->dbg_lf) {
         HIP_TRY(ctx, hipMalloc(&ctx->dbg_lf, sizeof(double) * nf));
         HIP_TRY(ctx, hipMalloc(&ctx->dbg_lfl, sizeof(double) * nf));
@@ -207,7 +207,6 @@ int32_t sk_debug_check(rrrmc_ctx* ctx)
         HIP_TRY(ctx, hipMalloc(&ctx->dbg_ml, sizeof(int32_t) * ctx->Rpad));
     }
     hipStream_t st = ctx->stream;
-    HIP_TRY(ctx, hipMemsetAsync(ctx->dbg_flag, 0, sizeof(int32_t) * 2, st));
     hipLaunchKernelGGL(sk_fields_kernel, dim3((unsigned)((ctx->N + 31) / 32), (unsigned)ctx->G8), dim3(256), 0, st, ctx->sk_J, ctx->sk_spins,
                        ctx->dbg_lf, ctx->dbg_lfl, ctx->dbg_ml, (int)ctx->N);
     HIP_TRY(ctx, hipGetLastError());
@@ -255,7 +254,27 @@ int32_t sk_standard_mc_async(rrrmc_ctx* ctx, double beta, int64_t iters, int64_t
     HIP_TRY(ctx, hipMemsetAsync(ctx->d_acc, 0, sizeof(int64_t) * ctx->Rpad, st));
     const bool binary = ctx->model == RRRMC_MODEL_SK_BINARY;
     const double sqrtN = std::sqrt((double)ctx->N);
-    if (binary && !sk_legacy_forced() && iters > 0) {
+    const int nth = sk_threads_for(ctx->N), spt = (int)((ctx->N + nth - 1) / nth);
+    int blk_nth = binary && nth == 1024 ? 512 : nth;     // threads per workgroup (the binary build has no 1024-thread form)
+    const int blk_spt = (int)((ctx->N + blk_nth - 1) / blk_nth);
+    const bool v1 = sk_block_v1_forced() || blk_nth == 1024;
+    sk_block_fn blockk = sk_legacy_forced() ? nullptr : v1 ? (binary ? skb_block_for(blk_spt, blk_nth) : sk_block_for(spt, nth))
+                                                           : (binary ? sk_hblock_for<true>(blk_spt, blk_nth) : sk_hblock_for<false>(blk_spt, blk_nth));
+    int blk_wgs = 1;                                      // workgroups per group of 8 replicas
+    if (blockk && sk_rb_for(ctx->N, v1) == 4) {
+        const int hs = (int)((ctx->N + 255) / 256);
+        const sk_block_fn h = v1 ? (binary ? skb_block_half_for(hs) : sk_block_half_for(hs)) : (binary ? sk_hblock_half_for<true>(hs) : sk_hblock_half_for<false>(hs));
+        if (h) { blockk = h; blk_nth = 256; blk_wgs = 2; }
+    }
+    if (!blockk && !sk_legacy_forced() && ctx->N <= 1024) {
+        // no whole-group build of this shape (e.g. RRRMC_SK_THREADS = 256 beyond N = 256): the split build covers every N <= 1024
+        const int hs = (int)((ctx->N + 255) / 256);
+        const sk_block_fn h = v1 ? (binary ? skb_block_half_for(hs) : sk_block_half_for(hs)) : (binary ? sk_hblock_half_for<true>(hs) : sk_hblock_half_for<false>(hs));
+        if (h) { blockk = h; blk_nth = 256; blk_wgs = 2; }
+    }
+    // (still none: the one-attempt-at-a-time kernels below, for both models)
+
+    if (binary && blockk && iters > 0) {
         // the blocked kernel on the binary model's state as doubles (sk_block_kernel<.., BIN>): the +-4.0 matrix is built from the bit rows
         // once, the integer fields travel int32 -> Float64 -> int32 around the call (exact)
         const size_t nf = (size_t)ctx->G8 * ctx->N * kSkRB;
@@ -294,19 +313,6 @@ int32_t sk_standard_mc_async(rrrmc_ctx* ctx, double beta, int64_t iters, int64_t
     P.E_cur = ctx->sk_E; P.acc_cur = ctx->d_acc; P.Es = ctx->sk_Es;
     P.beta = beta; P.g0 = ctx->it_done; P.iters = iters; P.step = step; P.sample0 = 0;
     P.k0 = (uint32_t)ctx->seed; P.k1 = (uint32_t)(ctx->seed >> 32); P.replica0 = ctx->replica0; P.N = (int)ctx->N;
-    const int nth = sk_threads_for(ctx->N), spt = (int)((ctx->N + nth - 1) / nth);
-    int blk_nth = binary && nth == 1024 ? 512 : nth;     // threads per workgroup (the binary build has no 1024-thread form)
-    const int blk_spt = (int)((ctx->N + blk_nth - 1) / blk_nth);
-    const bool v1 = sk_block_v1_forced() || blk_nth == 1024;
-    sk_block_fn blockk = sk_legacy_forced() ? nullptr : v1 ? (binary ? skb_block_for(blk_spt, blk_nth) : sk_block_for(spt, nth))
-                                                           : (binary ? sk_hblock_for<true>(blk_spt, blk_nth) : sk_hblock_for<false>(blk_spt, blk_nth));
-    int blk_wgs = 1;                                      // workgroups per group of 8 replicas
-    if (blockk && sk_rb_for(ctx->N, v1) == 4) {
-        const int hs = (int)((ctx->N + 255) / 256);
-        const sk_block_fn h = v1 ? (binary ? skb_block_half_for(hs) : sk_block_half_for(hs)) : (binary ? sk_hblock_half_for<true>(hs) : sk_hblock_half_for<false>(hs));
-        if (h) { blockk = h; blk_nth = 256; blk_wgs = 2; }
-    }
-    if (binary && !blockk) return fail(ctx, RRRMC_ERR_UNSUPPORTED, "internal: no blocked kernel for N=%lld", (long long)ctx->N);
     if (blockk && iters > 0) {
         // blocked kernel: segments of <= kSkSegIters iterations, each with its state-independent block tables (sites, coupling sub-matrices)
         const int64_t nseg = (iters + kSkSegIters - 1) / kSkSegIters;

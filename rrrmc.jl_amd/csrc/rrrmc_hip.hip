@@ -265,6 +265,7 @@ struct rrrmc_ctx {
     // ---- debug mode (rrrmc_set_debug_checks): the reference's latent consistency checks (src/graphs/RRG.jl:229-231, SK.jl:268-273),
     //      run on the device after every standardMC call: tracked energy == energy(X, C), cached fields == recomputed fields ----
     bool debug_checks = false;
+    bool multi_poisoned = false;        // multi-device parent: a forwarded call failed on some children only
     int32_t* dbg_flag = nullptr;        // [2]: number of replicas that failed the last check, one of them
     int32_t* dbg_Ei = nullptr;          // [Rpad] tracked energies (integer models)
     double* dbg_lf = nullptr; double* dbg_lfl = nullptr; double* dbg_E = nullptr; int32_t* dbg_ml = nullptr;    // recomputed SK cache
@@ -475,8 +476,10 @@ inline bool dbg_inject() { const char* e = std::getenv("RRRMC_DEBUG_INJECT"); re
 // after a standardMC call of the +-J model: d_E (tracked) against energy(X, C) recomputed from the spins
 int32_t debug_check_pm1(rrrmc_ctx* ctx)
 {
-    if (!ctx->dbg_flag) { HIP_TRY(ctx, hipMalloc(&ctx->dbg_flag, sizeof(int32_t) * 2)); HIP_TRY(ctx, hipMalloc(&ctx->dbg_Ei, sizeof(int32_t) * ctx->Rpad)); }
-    HIP_TRY(ctx, hipMemsetAsync(ctx->dbg_flag, 0, sizeof(int32_t) * 2, ctx->stream));
+    // (the flag is zeroed when it is allocated and by rrrmc_sync after reading it, never here: a mismatch found after an earlier queued call
+    //  must survive until the sync that reports it)
+    if (!ctx->dbg_flag) { HIP_TRY(ctx, hipMalloc(&ctx->dbg_flag, sizeof(int32_t) * 2)); HIP_TRY(ctx, hipMemsetAsync(ctx->dbg_flag, 0, sizeof(int32_t) * 2, ctx->stream)); }
+    if (!ctx->dbg_Ei) HIP_TRY(ctx, hipMalloc(&ctx->dbg_Ei, sizeof(int32_t) * ctx->Rpad));
     HIP_TRY(ctx, hipMemcpyAsync(ctx->dbg_Ei, ctx->d_E, sizeof(int32_t) * ctx->Rpad, hipMemcpyDeviceToDevice, ctx->stream));
     if (dbg_inject()) hipLaunchKernelGGL(dbg_inject_i32_kernel, dim3(1), dim3(1), 0, ctx->stream, ctx->dbg_Ei);       // (RRRMC_DEBUG_INJECT=1: tests only)
     const int32_t rc = run_energy_bs(ctx, nullptr);          // d_E = energy(X, C): equal to the tracked values, or the flag says so
@@ -543,6 +546,8 @@ inline int64_t nch_of(const rrrmc_ctx* c) { return (c->N + 63) / 64; }
 // reported with the device it came from.
 template <typename F> int32_t multi_each(rrrmc_ctx* ctx, F&& f, bool threads)
 {
+    if (ctx->multi_poisoned)
+        return fail(ctx, RRRMC_ERR_STATE, "an earlier call failed on some devices of this multi-device context only: its shards are at different positions; destroy it");
     const size_t n = ctx->kids.size();
     std::vector<int32_t> rc(n, RRRMC_OK);
     if (threads && n > 1) {
@@ -551,10 +556,20 @@ template <typename F> int32_t multi_each(rrrmc_ctx* ctx, F&& f, bool threads)
         for (size_t d = 0; d < n; ++d) th.emplace_back([&, d] { rc[d] = f(ctx->kids[d], ctx->kid_r0[d], ctx->kids[d]->R); });
         for (std::thread& t : th) t.join();
     } else {
-        for (size_t d = 0; d < n; ++d) { rc[d] = f(ctx->kids[d], ctx->kid_r0[d], ctx->kids[d]->R); if (rc[d]) break; }
+        for (size_t d = 0; d < n; ++d) { rc[d] = f(ctx->kids[d], ctx->kid_r0[d], ctx->kids[d]->R); if (rc[d]) { if (d > 0) ctx->multi_poisoned = true; break; } }
     }
     for (size_t d = 0; d < n; ++d)
-        if (rc[d]) { ctx->err = "device " + std::to_string(ctx->kids[d]->device) + " (replicas from " + std::to_string(ctx->kid_r0[d]) + "): " + ctx->kids[d]->err; return rc[d]; }
+        if (rc[d]) {
+            ctx->err = "device " + std::to_string(ctx->kids[d]->device) + " (replicas from " + std::to_string(ctx->kid_r0[d]) + "): " + ctx->kids[d]->err;
+            // the other shards may have run (or queued) the call: unless every shard refused it the same way (an argument error is
+            // detected by all of them before anything is queued), the shards are no longer at one stream position
+            if (threads && n > 1) {
+                bool same = true;
+                for (size_t e = 0; e < n; ++e) same = same && rc[e] == rc[d];
+                if (!same) ctx->multi_poisoned = true;
+            }
+            return rc[d];
+        }
     return RRRMC_OK;
 }
 }  // namespace
@@ -613,6 +628,23 @@ int32_t rrrmc_device_copy_bandwidth(int32_t device, int64_t nbytes, int32_t reps
     if (e != hipSuccess) return fail(nullptr, e == hipErrorOutOfMemory ? RRRMC_ERR_NOMEM : RRRMC_ERR_HIP, "device copy timing failed: %s", hipGetErrorString(e));
     *gbps_out = 2.0 * (double)nbytes * (double)reps / ((double)ms * 1e-3) / 1e9;          // bytes read + bytes written
     return RRRMC_OK;
+}
+
+int32_t rrrmc_host_alloc(int64_t nbytes, void** out)
+{
+    if (!out || nbytes < 0) return RRRMC_ERR_INVALID_ARG;
+    *out = nullptr;
+    if (nbytes == 0) return RRRMC_OK;
+    void* p = nullptr;
+    if (hipHostMalloc(&p, (size_t)nbytes, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return RRRMC_ERR_NOMEM; }
+    *out = p;
+    return RRRMC_OK;
+}
+
+int32_t rrrmc_host_free(void* p)
+{
+    if (!p) return RRRMC_OK;
+    return hipHostFree(p) == hipSuccess ? RRRMC_OK : RRRMC_ERR_HIP;
 }
 
 int32_t rrrmc_ctx_create(rrrmc_ctx** out, int32_t model, int64_t N, int64_t K, int64_t R, int32_t device, uint32_t replica0)

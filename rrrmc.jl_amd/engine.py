@@ -122,11 +122,17 @@ class Engine:
         return lf
 
     # -- sampling ---------------------------------------------------------------------------------
-    def standard_mc(self, beta, iters, step=1, want_energies=True):
-        """Returns (Es[R, iters // step], accepted[R])."""
+    def standard_mc(self, beta, iters, step=1, want_energies=True, out=None):
+        """Returns (Es[R, iters // step], accepted[R]).  ``out=(Es, accepted)``: caller-owned result arrays of those shapes (e.g. from
+        ``pinned_empty``: page-locked memory is filled at the bus rate), reused across calls like the buffers of a C or Julia caller."""
         nsamp = int(iters) // int(step)
-        Es = np.zeros((self.R, nsamp), np.float64 if self._f64 else np.int64)
-        acc = np.zeros(self.R, np.int64)
+        if out is not None:
+            Es, acc = out
+            if Es.shape != (self.R, nsamp) or Es.dtype != (np.float64 if self._f64 else np.int64) or acc.shape != (self.R,) or acc.dtype != np.int64:
+                raise ValueError("out must be (Es[R, iters // step] of the model's energy type, accepted[R] int64)")
+        else:
+            Es = np.zeros((self.R, nsamp), np.float64 if self._f64 else np.int64)
+            acc = np.zeros(self.R, np.int64)
         fn = lib().rrrmc_standard_mc_f64 if self._f64 else lib().rrrmc_standard_mc
         check(fn(self._ctx, float(beta), int(iters), int(step), Es.ctypes.data if (want_energies and nsamp) else None,
                  acc.ctypes.data), self._ctx)

@@ -292,3 +292,26 @@ def test_skn_block_kernel_builds_agree(pkg, oracle, monkeypatch, N, R):
     C0 = oracle.init_configs(seed, 0, R, N)
     Es_ref, ch_ref, acc_ref, lf_ref = oracle.standard_mc_skn_batch(X.J, 1.5, 4000, 100, seed, C0)
     assert (outs[1][0] == Es_ref).all() and (outs[1][1] == acc_ref).all()
+
+
+@pytest.mark.parametrize("binary", [False, True], ids=["gauss", "binary"])
+@pytest.mark.parametrize("N", [700, 1500])
+def test_sk_threads_override_never_leaves_a_model_without_a_kernel(pkg, monkeypatch, binary, N):
+    """RRRMC_SK_THREADS = 256 (documented as a bit-identical override) asks for a workgroup shape the blocked kernels do not have beyond
+    N = 256: up to N = 1024 the split build takes over, beyond it the one-attempt-at-a-time kernels — for the binary model too (it used
+    to fail with 'internal: no blocked kernel').  Same chain as the default build."""
+    seed = 6100 + N
+    X = pkg.GraphSK(N, seed=seed) if binary else pkg.GraphSKNormal(N, seed=seed)
+    outs = []
+    for thr in (None, "256"):
+        for k in ("RRRMC_SK_RB", "RRRMC_SK_LEGACY", "RRRMC_SK_BLOCK_V1", "RRRMC_SK_THREADS"):
+            monkeypatch.delenv(k, raising=False)
+        if thr:
+            monkeypatch.setenv("RRRMC_SK_THREADS", thr)
+        with pkg.Engine(X, 5) as eng:
+            eng.seed(seed)
+            eng.init_spins_random()
+            Es, acc = eng.standard_mc(1.1, 1500, 50)
+            outs.append((Es, acc, eng.get_config().s.copy(), eng.fields()))
+    for u, v in zip(outs[0], outs[1]):
+        assert (u == v).all()

@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 J2C = {
     "Int32": {"int32_t"}, "Int64": {"int64_t"}, "UInt32": {"uint32_t"}, "UInt64": {"uint64_t"}, "Float64": {"double"},
     "Cvoid": {"void"}, "Cstring": {"char*"},
-    "Ptr{Cvoid}": {"rrrmc_ctx*", "void*"}, "Ref{Ptr{Cvoid}}": {"rrrmc_ctx**"},
+    "Ptr{Cvoid}": {"rrrmc_ctx*", "void*"}, "Ref{Ptr{Cvoid}}": {"rrrmc_ctx**", "void**"},
     "Ptr{Int8}": {"int8_t*"}, "Ptr{Int32}": {"int32_t*"}, "Ptr{Int64}": {"int64_t*"}, "Ptr{UInt64}": {"uint64_t*"},
     "Ptr{Float64}": {"double*"}, "Ref{Float64}": {"double*"}, "Ref{Int32}": {"int32_t*"}, "Ref{Int64}": {"int64_t*"},
 }
