@@ -144,3 +144,4 @@ def run_chain(O, J, beta, iters, step, seed, chunks, it0=0, replica=0, state=Non
         w, b = x >> 6, x & 63
         ch[w] = np.uint64((int(ch[w]) & ~(1 << b)) | (int(sp[x]) << b))
     return np.array(Es), ch, acc_total, lf, (lf, lfl, mlast, E)
+

@@ -51,3 +51,4 @@ def test_swaps_do_occur(oracle):
     assert any(a == b for a, b in zip(sites, sites[1:]))
     got = EB.run_chain(oracle, J, 0.3, 700, 7, seed, c0)
     assert got[2] > 300
+
