@@ -26,8 +26,9 @@ mutable struct Ctx
     R::Int
     N::Int
     f64::Bool            # energies are Float64 (everything but the integer-coupling sparse graphs)
+    stopped::Vector{Int} # per replica: the iteration at which its hook ended it in the last hooked standardMC (0 = none)
     function Ctx(p::Ptr{Cvoid}, R::Integer, N::Integer, f64::Bool)
-        ctx = new(p, R, N, f64)
+        ctx = new(p, R, N, f64, zeros(Int, R))
         finalizer(c -> (c.p == C_NULL || ccall((:rrrmc_ctx_destroy, LIB), Cvoid, (Ptr{Cvoid},), c.p); c.p = C_NULL), ctx)
         return ctx
     end
@@ -188,6 +189,14 @@ function get_configs!(ctx::Ctx, chunks::Matrix{UInt64}, C0)
     return Cs
 end
 
+"write `chunks` (column r = replica r) to the device and into the Configs"
+function put_configs!(ctx::Ctx, chunks::Matrix{UInt64}, C0)
+    GC.@preserve chunks check(ccall((:rrrmc_set_spins, LIB), Int32, (Ptr{Cvoid}, Ptr{UInt64}), ctx.p, chunks), ctx.p)
+    Cs = C0 ≡ nothing ? [RRRMC.Config(ctx.N, init = false) for _ = 1:ctx.R] : C0
+    for r = 1:ctx.R; Cs[r].s.chunks .= chunks[:, r]; end
+    return Cs
+end
+
 "energy(X, C) of every replica (src/Interface.jl:105); also rebuilds the device-side caches, as the reference's `energy` does"
 function energies(ctx::Ctx)
     if ctx.f64
@@ -226,6 +235,9 @@ For `ctx.R` replicas of `X` on the GPU(s); `seed ≤ 0` keeps the streams going,
 With a `hook(it, X, Cs, accepted, E)::Bool` (the reference's hook, :61-64, handed the vectors of all replicas) the run is cut at the
 hook points and RESUMED (`rrrmc_set_resume`): cache and tracked energy live on across the pieces exactly as inside one reference
 call (:95-118), so a hooked run is the un-hooked chain bit for bit — for the Float64 models too — and `E` is the tracked energy.
+The reference's hook ends ONE chain (`hook(...) || break`, :107): the hook may also return a `Vector{Bool}`, one flag per replica; a
+replica whose flag is `false` is frozen at that sample (its column of `Es` is `missing`-free up to there and repeated afterwards, its
+`Config` is the one of that moment, and `stopped_at(ctx)` tells the iteration), the others go on; the run ends when none is left.
 """
 function RRRMC.standardMC(ctx::Ctx, X::RRRMC.Interface.AbstractGraph, β::Real, iters::Integer; seed = DEFAULT_SEED, step::Integer = 1,
                           hook = nothing, C0::Union{Vector{RRRMC.Config},Nothing} = nothing, quiet = false)
@@ -248,6 +260,8 @@ function RRRMC.standardMC(ctx::Ctx, X::RRRMC.Interface.AbstractGraph, β::Real, 
         check(ccall((:rrrmc_standard_mc_async, LIB), Int32, (Ptr{Cvoid}, Float64, Int64, Int64), ctx.p, β, 0, 1), ctx.p); sync(ctx)
     end
     check(ccall((:rrrmc_set_resume, LIB), Int32, (Ptr{Cvoid}, Int32), ctx.p, 1), ctx.p)
+    fill!(ctx.stopped, 0)
+    frozen_chunks = copy(chunks)
     try
         while it < iters
             nxt = (it ÷ step + 1) * step
@@ -260,14 +274,35 @@ function RRRMC.standardMC(ctx::Ctx, X::RRRMC.Interface.AbstractGraph, β::Real, 
                 E .= energies(ctx)                                          # integer models: recomputed == tracked, exactly
             end
             push!(Es, E)
-            hook(nxt, X, get_configs!(ctx, chunks, C0), copy(accepted), E) || (it = nxt; break)
+            go = hook(nxt, X, get_configs!(ctx, chunks, C0), copy(accepted), E)
+            if go isa Bool
+                go || (it = nxt; break)
+            else
+                nch = size(chunks, 1)
+                for r in 1:ctx.R
+                    if !go[r] && ctx.stopped[r] == 0                        # frozen now: keep what the reference's chain would return
+                        ctx.stopped[r] = nxt
+                        frozen_chunks[:, r] .= chunks[:, r]
+                    end
+                end
+                all(>(0), ctx.stopped) && (it = nxt; break)
+            end
             piece!(1); it = nxt
         end
     finally
         check(ccall((:rrrmc_set_resume, LIB), Int32, (Ptr{Cvoid}, Int32), ctx.p, 0), ctx.p)
     end
-    return isempty(Es) ? Matrix{ET}(undef, 0, ctx.R) : permutedims(reduce(hcat, Es)), get_configs!(ctx, chunks, C0)
+    Cs = get_configs!(ctx, chunks, C0)
+    if any(>(0), ctx.stopped)                                               # frozen replicas: the configuration of their last hook, on both sides
+        for r in 1:ctx.R
+            ctx.stopped[r] > 0 && (chunks[:, r] .= frozen_chunks[:, r])
+        end
+        Cs = put_configs!(ctx, chunks, C0)
+    end
+    return isempty(Es) ? Matrix{ET}(undef, 0, ctx.R) : permutedims(reduce(hcat, Es)), Cs
 end
+"iteration at which replica r's hook said stop in the last hooked `standardMC` (0 = it ran to the end)"
+stopped_at(ctx::Ctx) = copy(ctx.stopped)
 
 # ---- colour-parallel sweeps (build-defined sampler for large lattices: BASELINE config 4) ---------------------------------------------
 "color[x] ∈ 0:ncolors-1, adjacent sites differ (checked by the library); e.g. the checkerboard parity of an even-L lattice"

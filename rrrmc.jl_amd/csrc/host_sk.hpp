@@ -53,6 +53,7 @@ sk_block_fn skb_block_half_for(int spt)
         default: return nullptr;
     }
 }
+constexpr int kSkMaxN = 4096;         // sk_hblock_kernel<8, 512, 8>: eight sites per thread (the round-3 kernels stop at 2048)
 // round 4: the same shapes with the branch-free bulk phase (sk_hblock_kernel.hpp); RRRMC_SK_BLOCK_V1 = 1 keeps round 3's sk_block_kernel
 // (bit-identical; the tests compare them).  1024 threads per workgroup are not offered by the new kernel (128 registers per thread).
 bool sk_block_v1_forced()
@@ -64,7 +65,8 @@ template <bool BIN>
 sk_block_fn sk_hblock_for(int spt, int nth)
 {
     if (nth == 256) return spt == 1 ? sk_hblock_kernel<1, 256, 8, BIN> : nullptr;
-    if (nth == 512) return spt == 1 ? sk_hblock_kernel<1, 512, 8, BIN> : spt == 2 ? sk_hblock_kernel<2, 512, 8, BIN> : spt == 3 ? sk_hblock_kernel<3, 512, 8, BIN> : spt == 4 ? sk_hblock_kernel<4, 512, 8, BIN> : nullptr;
+    if (nth == 512) return spt == 1 ? sk_hblock_kernel<1, 512, 8, BIN> : spt == 2 ? sk_hblock_kernel<2, 512, 8, BIN> : spt == 3 ? sk_hblock_kernel<3, 512, 8, BIN> : spt == 4 ? sk_hblock_kernel<4, 512, 8, BIN>
+                         : spt <= 6 ? sk_hblock_kernel<6, 512, 8, BIN> : spt <= 8 ? sk_hblock_kernel<8, 512, 8, BIN> : nullptr;      // 2048 < N <= 4096 (round 4)
     return nullptr;
 }
 template <bool BIN>
@@ -121,7 +123,7 @@ skb_fn skb_sweep_for(int spt, int nth)
 int32_t sk_ctx_create(rrrmc_ctx** out, int32_t model, int64_t N, int64_t R, int32_t device, uint32_t replica0)
 {
     if (N < 1 || R < 1) return fail(nullptr, RRRMC_ERR_INVALID_ARG, "N, R must be >= 1 (given N=%lld R=%lld)", (long long)N, (long long)R);
-    if (N > (int64_t)kSkThreads * kSkMaxSPT) return fail(nullptr, RRRMC_ERR_UNSUPPORTED, "N=%lld: the register-resident SK kernel covers N <= %d", (long long)N, kSkThreads * kSkMaxSPT);
+    if (N > kSkMaxN) return fail(nullptr, RRRMC_ERR_UNSUPPORTED, "N=%lld: the register-resident SK kernels cover N <= %d", (long long)N, kSkMaxN);
     if (replica0 % 32) return fail(nullptr, RRRMC_ERR_INVALID_ARG, "replica0 must be a multiple of 32 (given %u)", replica0);
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)

@@ -48,7 +48,7 @@ __device__ __forceinline__ void sk_static_for(F&& f)
 }
 
 #ifndef SKH_PF
-#define SKH_PF(spt) ((spt) <= 2 ? 4 : 2)
+#define SKH_PF(spt) ((spt) <= 2 ? 4 : (spt) <= 4 ? 2 : 1)
 #endif
 
 template <int SPT, int NTH, int RB = kSkRB, bool BIN = false>
@@ -75,8 +75,9 @@ __global__ __launch_bounds__(NTH, RB == 4 ? 2 : 1) void sk_hblock_kernel(SkBlock
     __shared__ __attribute__((aligned(16))) double sh_mult[kSkW][RB];     // per (attempt, replica): the multiplier +1.0 / -1.0 / 0.0
     __shared__ uint32_t sh_acc[2][kSkW];                   // per attempt: bit 8 + r = undo swap, bit 24 + r = copy lfields_last first
     __shared__ uint8_t sh_cslot[kSkW];
-    __shared__ uint8_t sh_canon[kSkThreads * kSkMaxSPT];
-    __shared__ uint32_t sh_spinw[kSkThreads * kSkMaxSPT / 4];     // the spins: byte j = site j, bit = replica of the group
+    constexpr int NMAX = NTH * SPT >= kSkThreads * kSkMaxSPT ? NTH * SPT : kSkThreads * kSkMaxSPT;      // sites this build covers (2048 at least)
+    __shared__ uint8_t sh_canon[NMAX];
+    __shared__ uint32_t sh_spinw[NMAX / 4];                       // the spins: byte j = site j, bit = replica of the group
     __shared__ int32_t sh_mlast[RB];
     uint8_t* const sh_spin = reinterpret_cast<uint8_t*>(sh_spinw);
     const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6), N = P.N;
@@ -103,7 +104,7 @@ __global__ __launch_bounds__(NTH, RB == 4 ? 2 : 1) void sk_hblock_kernel(SkBlock
             }
         }
     }
-    for (int j = tid; j < kSkThreads * kSkMaxSPT; j += NTH) sh_canon[j] = 0xffu;
+    for (int j = tid; j < NMAX; j += NTH) sh_canon[j] = 0xffu;
     if (tid < RB) sh_mlast[tid] = P.move_last[grp * kSkRB + r8 + tid];
     __syncthreads();
     double E_run[RPW];
@@ -326,16 +327,18 @@ __global__ __launch_bounds__(NTH, RB == 4 ? 2 : 1) void sk_hblock_kernel(SkBlock
                 const uint32_t w = (uint32_t)__builtin_amdgcn_readlane((int)accv, k);
 #pragma unroll
                 for (int r = 0; r < RB; ++r) {
+                    // (a wave-uniform base and a 32-bit lane offset: no per-lane 64-bit address is kept across the loop)
+                    double* const hr = hl + (size_t)__builtin_amdgcn_readfirstlane(r * N);
                     if ((w >> (24 + r)) & 1u) {                          // lfields_last = lfields before this move (SK.jl:255-262)
 #pragma unroll
                         for (int q = 0; q < SPT; ++q)
-                            if (tid * SPT + q < N) hl[(size_t)r * N + (tid * SPT + q)] = H[q][r];
+                            if (tid * SPT + q < N) hr[(uint32_t)(tid * SPT + q)] = H[q][r];
                     }
                     if ((w >> (8 + r)) & 1u) {                           // lfields <-> lfields_last (SK.jl:247-250)
 #pragma unroll
                         for (int q = 0; q < SPT; ++q) {
                             if (tid * SPT + q < N) {
-                                double* const px = hl + (size_t)r * N + (tid * SPT + q);
+                                double* const px = hr + (uint32_t)(tid * SPT + q);
                                 const double tmp = *px; *px = H[q][r]; H[q][r] = tmp;
                             }
                         }

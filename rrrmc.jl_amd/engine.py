@@ -332,7 +332,7 @@ def rrrMC(X, beta, iters, *, seed=DEFAULT_SEED, step=1, C0=None, staged_thr=None
         Es, acc, staged = eng.rrr_mc(beta, iters, step, staged_thr, staged_thr_fact)
         Cfg = eng.get_config(C0 if C0 is not None else None)
         if not quiet:
-            print("samples = ", Es.shape[1])
+            print("samples = ", Es.shape[1] if hasattr(Es, "shape") else [len(e) for e in Es])
             print("iters = ", iters)
             print("accept rate = ", float(acc.mean()) / max(iters, 1))
             print("frac. staged iters = ", float(staged.mean()) / max(iters, 1))
@@ -357,7 +357,7 @@ def bklMC(X, beta, iters, *, seed=DEFAULT_SEED, step=1, C0=None, quiet=False, re
         Es, moves = eng.bkl_mc(beta, iters, step)
         Cfg = eng.get_config(C0 if C0 is not None else None)
         if not quiet:
-            print("samples = ", Es.shape[1])
+            print("samples = ", Es.shape[1] if hasattr(Es, "shape") else [len(e) for e in Es])
             print("accept rate = ", float(moves.mean()) / max(iters, 1))
             print("true it = ", float(moves.mean()))
         return Es, Cfg
@@ -381,7 +381,7 @@ def wtmMC(X, beta, samples, *, seed=DEFAULT_SEED, step=1.0, C0=None, quiet=False
         Es, moves, t = eng.wtm_mc(beta, samples, step)
         Cfg = eng.get_config(C0 if C0 is not None else None)
         if not quiet:
-            print("samples = ", Es.shape[1])
+            print("samples = ", Es.shape[1] if hasattr(Es, "shape") else [len(e) for e in Es])
             print("num_moves = ", float(moves.mean()))
             print("global time = ", float(t.mean()))
             print("ratio = ", float(t.mean()) / max(float(moves.mean()), 1.0))
@@ -425,6 +425,10 @@ def standardMC(X, beta, iters, *, seed=DEFAULT_SEED, step=1, hook=None, C0=None,
     reference ``C0`` is resumed and mutated in place, and ``seed <= 0`` does not reseed (meaningful with a
     caller-supplied ``engine``, which carries the stream position).  ``hook(it, X, C, accepted, E)`` is
     called every ``step`` iterations with per-replica arrays; returning False stops the run (:61-64).
+    The reference's hook ends ONE chain (``hook(...) || break``, :107): a hook may therefore also return one flag per replica — a replica
+    whose flag is False is frozen at that sample (its configuration, energy samples and accepted count are what the reference's chain would
+    return; the others go on, replicas being independent), and the run ends when none is left.  With frozen replicas ``Es`` is a list of
+    per-replica vectors of different lengths, as R reference calls would return them.
     """
     own = engine is None
     R = replicas if replicas is not None else (C0.R if C0 is not None else (engine.R if engine else 1))
@@ -446,6 +450,10 @@ def standardMC(X, beta, iters, *, seed=DEFAULT_SEED, step=1, hook=None, C0=None,
             it = int(iters)
         else:
             samples = []
+            frozen = np.zeros(eng.R, bool)                 # replicas whose hook has said "stop" (RRRMC.jl:107), with what they had then
+            frozen_cfg = Config(X.N, eng.R)
+            frozen_nsamp = np.zeros(eng.R, np.int64)
+            frozen_acc = np.zeros(eng.R, np.int64)
             # Run up to the move before iteration k*step, call the hook with that state, continue.  The pieces RESUME one another
             # (Engine.set_resume): the cache and the tracked energy live on across hook calls as in the reference (RRRMC.jl:95-118), so
             # the hooked run of a Float64 model is the un-hooked chain bit for bit and the hook sees the tracked E.
@@ -465,9 +473,23 @@ def standardMC(X, beta, iters, *, seed=DEFAULT_SEED, step=1, hook=None, C0=None,
                     E = eng.tracked_energy()
                     samples.append(E)
                     eng.get_config(Cfg)
-                    if not hook(nxt, X, Cfg, accepted.copy(), E):
-                        it = nxt
-                        break
+                    go = hook(nxt, X, Cfg, accepted.copy(), E)
+                    if np.ndim(go) == 0:
+                        if not go:
+                            it = nxt
+                            break
+                    else:
+                        go = np.asarray(go, bool)
+                        if go.shape != (eng.R,):
+                            raise ValueError("a hook returns one flag, or one per replica (%d)" % eng.R)
+                        new = ~go & ~frozen
+                        frozen_cfg.s[new] = Cfg.s[new]
+                        frozen_nsamp[new] = len(samples)
+                        frozen_acc[new] = accepted[new]
+                        frozen |= new
+                        if frozen.all():
+                            it = nxt
+                            break
                     _, a = eng.standard_mc(beta, 1, step=2, want_energies=False)   # the move of iteration nxt
                     accepted += a
                     it = nxt
@@ -475,8 +497,15 @@ def standardMC(X, beta, iters, *, seed=DEFAULT_SEED, step=1, hook=None, C0=None,
                 eng.set_resume(False)
             Es = np.stack(samples, axis=1) if samples else np.zeros((eng.R, 0), X.energy_dtype)
         eng.get_config(Cfg)
+        if hook is not None and frozen.any():
+            # a frozen replica returns what it had when its hook said stop; the engine is given the same configuration, so that C and the
+            # device agree (its chain went on in the meantime: independent of the others, and discarded here)
+            Cfg.s[frozen] = frozen_cfg.s[frozen]
+            accepted[frozen] = frozen_acc[frozen]
+            eng.set_config(Cfg)
+            Es = [Es[r, :frozen_nsamp[r]] if frozen[r] else Es[r] for r in range(eng.R)]
         if not quiet:
-            print("samples = ", Es.shape[1])
+            print("samples = ", Es.shape[1] if hasattr(Es, "shape") else [len(e) for e in Es])
             print("iters = ", it)
             print("accept rate = ", float(accepted.mean()) / max(it, 1))
         return Es, Cfg

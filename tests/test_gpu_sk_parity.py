@@ -315,3 +315,23 @@ def test_sk_threads_override_never_leaves_a_model_without_a_kernel(pkg, monkeypa
             outs.append((Es, acc, eng.get_config().s.copy(), eng.fields()))
     for u, v in zip(outs[0], outs[1]):
         assert (u == v).all()
+
+
+@pytest.mark.parametrize("binary,N", [(False, 3000), (False, 4096), (True, 2500)])
+def test_dense_sk_beyond_2048_sites(pkg, oracle, binary, N):
+    """src/graphs/SK.jl:181-210 has no size limit; round 3 stopped at N = 2048 (eight sites per thread of the one-attempt-at-a-time kernels).
+    sk_hblock_kernel<6 | 8, 512, 8> covers N <= 4096: same chain as the oracle, both models, a call that crosses no seam and one that does."""
+    seed, R, beta = 8800 + N, 3, 1.0
+    X = pkg.GraphSK(N, seed=seed) if binary else pkg.GraphSKNormal(N, seed=seed)
+    run = oracle.standard_mc_skb if binary else oracle.standard_mc_skn
+    with pkg.Engine(X, R) as eng:
+        eng.seed(seed)
+        eng.init_spins_random()
+        C0 = eng.get_config().s.copy()
+        Es, acc = eng.standard_mc(beta, 3000, 100)
+        C1, lf1 = eng.get_config().s.copy(), eng.fields()
+    for r in (0, R - 1):
+        ref = run(X.J, beta, 3000, 100, seed, C0[r], replica=r)
+        assert (Es[r] == ref[0]).all() and (C1[r] == ref[1]).all() and acc[r] == ref[2] and (lf1[r] == ref[3]).all()
+    with pytest.raises(pkg.RRRMCError):
+        pkg.Engine(pkg.GraphSKNormal(4097, seed=1), 8)

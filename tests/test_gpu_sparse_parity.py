@@ -225,3 +225,29 @@ def test_randomized_shapes(pkg, oracle, monkeypatch, N, K, R, beta, iters, step,
         C1 = eng.get_config()
     ref = oracle.standard_mc_sparse_batch(X.A, X.J.astype(np.int32), beta, iters, step, seed, C0.s)
     assert Es.shape == ref[0].shape and (Es == ref[0]).all() and (C1.s == ref[1]).all() and (acc == ref[2]).all()
+
+
+def test_hook_can_stop_single_replicas(pkg, oracle):
+    """The reference's hook ends ONE chain (`hook(...) || break`, src/RRRMC.jl:107).  A batch hook that returns one flag per replica freezes
+    the replicas it says False for: each returns what a reference call stopped there would — its samples up to that point and the
+    configuration of that moment — while the others run to the end."""
+    N, K, R, beta, iters, step, seed = 64, 3, 6, 1.3, 4000, 100, 4711
+    X = pkg.GraphRRG(N, K, seed=seed)
+    stop_at = {1: 500, 4: 2300}                       # replica -> iteration at which its hook says stop
+
+    def hook(it, X_, C, accepted, E):
+        return np.array([not (r in stop_at and it >= stop_at[r]) for r in range(R)])
+
+    C0 = pkg.Config(N, R)
+    C0.s[:] = oracle.init_configs(seed, 0, R, N)
+    start = C0.s.copy()
+    Es, C1 = pkg.standardMC(X, beta, iters, seed=seed, step=step, hook=hook, C0=C0, quiet=True)
+    assert isinstance(Es, list) and len(Es) == R
+    Ji = X.J.astype(np.int32)
+    for r in range(R):
+        n_it = stop_at.get(r, iters)
+        # the reference chain stopped by its hook at iteration n_it has made n_it - 1 moves and pushed n_it // step samples
+        ref = oracle.standard_mc_sparse(X.A, Ji, beta, n_it - 1 if r in stop_at else iters, step, seed, start[r], replica=r)
+        want = oracle.standard_mc_sparse(X.A, Ji, beta, n_it, step, seed, start[r], replica=r)[0][:n_it // step]
+        assert len(Es[r]) == n_it // step and (np.asarray(Es[r]) == want).all()
+        assert (C1.s[r] == ref[1]).all()
