@@ -14,10 +14,11 @@ import __graft_entry__ as entry  # noqa: E402
 
 
 def bench_sk(N=1024, R=2048, beta=1.0, iters=1 << 16, step=1 << 10, seed=0x5EED):
-    if len(sys.argv) > 2:                                    # python tools/bench_models.py sk N [R]
+    if len(sys.argv) > 2:                                    # python tools/bench_models.py sk N [R] [binary]
         N = int(sys.argv[2]); R = int(sys.argv[3]) if len(sys.argv) > 3 else R
+    binary = len(sys.argv) > 4 and sys.argv[4] == "binary"
     pkg = entry.load_package()
-    X = pkg.GraphSKNormal(N, seed=seed)
+    X = pkg.GraphSK(N, seed=seed) if binary else pkg.GraphSKNormal(N, seed=seed)
     eng = pkg.Engine(X, R)
     eng.seed(seed)
     eng.init_spins_random()
@@ -30,7 +31,7 @@ def bench_sk(N=1024, R=2048, beta=1.0, iters=1 << 16, step=1 << 10, seed=0x5EED)
     a = float(acc.mean()) / iters
     attempts = float(R) * iters
     bytes_per_attempt = 8 + a * (17 * N + 2)                 # SURVEY.md §8d, dense SK Float64
-    out = {"model": "GraphSKNormal", "N": N, "replicas": R, "beta": beta, "iters": iters, "attempts_per_s": attempts / dt,
+    out = {"model": "GraphSK" if binary else "GraphSKNormal", "N": N, "replicas": R, "beta": beta, "iters": iters, "attempts_per_s": attempts / dt,
            "kernel_ms": sweep_ms, "acceptance": a, "energy_per_spin": float(Es[:, -1].mean()) / N,
            "algorithmic_bytes_per_attempt": bytes_per_attempt,
            "algorithmic_GBps_kernel": bytes_per_attempt * attempts / (sweep_ms * 1e-3) / 1e9}
