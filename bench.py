@@ -446,9 +446,10 @@ def secondary_f64_fast(pkg, O, device):
 
 
 def secondary_f64_exact(pkg, O, device):
-    """The DEFAULT (bit-exact) Float64 sparse path: GraphRRGNormal(N=4096, K=3), spf_sweep_kernel — the reference's cached-field loop
-    (src/graphs/RRG.jl:504-627) with the fields in HBM; the measured HBM traffic per attempt comes from the committed rocprofv3 pass."""
-    N, K, R, beta, iters, step = 4096, 3, 8192, 1.0, 1 << 14, 1 << 12
+    """The DEFAULT (bit-exact) Float64 sparse path: GraphRRGNormal(N=4096, K=3), spf_team_kernel — the reference's cached-field loop
+    (src/graphs/RRG.jl:504-627) with the fields in HBM, a team of sixteen wavefronts per group of 64 replicas running the attempts whose
+    neighbourhoods do not meet side by side; the measured HBM traffic per attempt comes from the committed rocprofv3 pass."""
+    N, K, R, beta, iters, step = 4096, 3, 8192, 1.0, 1 << 16, 1 << 12
     X = pkg.GraphRRGNormal(N, K, seed=SEED)
     with pkg.Engine(X, R, device=device) as eng:
         eng.seed(SEED)
@@ -461,8 +462,8 @@ def secondary_f64_exact(pkg, O, device):
         _, acc = eng.fetch_results(want_energies=False)
     a = float(acc.mean()) / iters
     bpa = 8 + a * (10 + 17 * K)                                  # SURVEY.md §8d widths: field 8 B, spin 1 B
-    out = {"workload": "GraphRRGNormal(N=4096,K=3) standardMC (exact mode) beta=1.0, 8192 replicas, 2^14 iterations per replica, energy sample every 4096",
-           "value": R * iters / dt, "unit": "attempts/s", "kernel": "spf_sweep_kernel<3>", "avg_launch_ms": k_ms / max(nl, 1), "launches": nl,
+    out = {"workload": "GraphRRGNormal(N=4096,K=3) standardMC (exact mode) beta=1.0, 8192 replicas, 2^16 iterations per replica, energy sample every 4096",
+           "value": R * iters / dt, "unit": "attempts/s", "kernel": "spf_team_kernel<3, 16, 1>", "avg_launch_ms": k_ms / max(nl, 1), "launches": nl,
            "acceptance": a, "algorithmic_bytes_per_attempt": bpa, "achieved_GBps": bpa * R * iters / (k_ms * 1e-3) / 1e9}
     out["frac"] = out["achieved_GBps"] / HBM_PEAK_GBS
     tf, tf_path, _ = load_profile_json("spf_traffic.json")

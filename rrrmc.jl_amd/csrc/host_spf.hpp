@@ -64,6 +64,43 @@ typedef void (*spf_fn)(SpfParams);
 spf_fn spf_sweep_for_K(int K) { RRRMC_DISPATCH_UPTO8(K, spf_sweep_kernel) }
 spf_fn spf_energy_for_K(int K) { RRRMC_DISPATCH_UPTO8(K, spf_energy_kernel) }
 
+// spf_team_kernel (spf_team_kernel.hpp): a team of wavefronts per group of 64 replicas.  Sixteen wavefronts (fifteen executing) while the
+// records of K + 1 fields per slot fit the LDS and the groups are few enough to own a compute unit each; eight otherwise.
+constexpr int64_t kSpfTeamItersPerLaunch = 1 << 18;     // 2 + 3 K dwords of plan per iteration
+typedef void (*spf_team_fn)(SpfTeamParams);
+template <int NW>
+spf_team_fn spf_team_for_K(int K)
+{
+    switch (K) {
+    case 1: return spf_team_kernel<1, NW, 1>;
+    case 2: return spf_team_kernel<2, NW, 1>;
+    case 3: return spf_team_kernel<3, NW, 1>;
+    case 4: return spf_team_kernel<4, NW, 1>;
+    case 5: return spf_team_kernel<5, NW, 1>;
+    case 6: return spf_team_kernel<6, NW, 1>;
+    case 7: return spf_team_kernel<7, NW, 1>;
+    case 8: return spf_team_kernel<8, NW, 1>;
+    default: return nullptr;
+    }
+}
+inline int spf_team_waves(const rrrmc_ctx* ctx)
+{
+    if (const char* e = std::getenv("RRRMC_SPF_TEAM_WAVES"); e && (e[0] == '8' || (e[0] == '1' && e[1] == '6'))) {        // tests / timing experiments
+        const int nw = e[0] == '8' ? 8 : 16;
+        if (spf_team_lds_bytes((int)ctx->K, nw, 1) <= (size_t)160 * 1024) return nw;
+    }
+    return ctx->pfW <= 256 && ctx->K <= 5 ? 16 : 8;
+}
+// The team kernel is the default; spf_sweep_kernel (one wavefront per group) stays for graphs with repeated neighbours in a row
+// (GraphEANormal with L = 2: two bonds to the same site share one field, update_cache! EA.jl:626-640) and as the cross-check of the tests
+// (RRRMC_SPF_TEAM=0).
+inline bool spf_use_team(const rrrmc_ctx* ctx)
+{
+    if (ctx->pf_multi_edge) return false;
+    const char* e = std::getenv("RRRMC_SPF_TEAM");
+    return !(e && e[0] == '0');
+}
+
 int32_t spf_run_energy(rrrmc_ctx* ctx)
 {
     hipLaunchKernelGGL(spf_energy_for_K((int)ctx->K), dim3((unsigned)ctx->pfW), dim3(64), 0, ctx->stream, spf_params(ctx));
@@ -89,7 +126,7 @@ int32_t spf_standard_mc_async(rrrmc_ctx* ctx, double beta, int64_t iters, int64_
         HIP_TRY(ctx, hipMalloc(&ctx->sk_Es, sizeof(double) * es_need));
         ctx->sk_Es_cap = es_need;
     }
-    const int64_t nl = (iters + kSpfItersPerLaunch - 1) / kSpfItersPerLaunch;
+    const int64_t nl = (iters + kSpfTeamItersPerLaunch - 1) / kSpfTeamItersPerLaunch;      // the shorter of the two launch lengths
     while ((int64_t)ctx->ev_sweep.size() < 2 * (nl > 0 ? nl : 1)) {
         hipEvent_t e;
         HIP_TRY(ctx, hipEventCreate(&e));
@@ -102,10 +139,19 @@ int32_t spf_standard_mc_async(rrrmc_ctx* ctx, double beta, int64_t iters, int64_
     ctx->std_cache_live = true;
     HIP_TRY(ctx, hipMemsetAsync(ctx->d_acc, 0, sizeof(int64_t) * ctx->Rpad, st));
     spf_fn fn = spf_sweep_for_K((int)ctx->K);
+    const bool team = spf_use_team(ctx);
+    const int nw = team ? spf_team_waves(ctx) : 0;
+    spf_team_fn tfn = !team ? nullptr : nw == 16 ? spf_team_for_K<16>((int)ctx->K) : spf_team_for_K<8>((int)ctx->K);
+    const size_t tlds = team ? spf_team_lds_bytes((int)ctx->K, nw, 1) : 0;
+    if (team) {
+        if (!ctx->pf_plan) HIP_TRY(ctx, hipMalloc(&ctx->pf_plan, sizeof(uint32_t) * (size_t)(kSpfTeamItersPerLaunch + 2) * (size_t)spf_plan_stride((int)ctx->K)));
+        HIP_TRY(ctx, raise_lds_attr(reinterpret_cast<const void*>(tfn), tlds));
+    }
+    const int64_t per_launch = team ? kSpfTeamItersPerLaunch : kSpfItersPerLaunch;
     int64_t done = 0;
     int launches = 0;
     while (done < iters) {
-        const int64_t n = std::min<int64_t>(kSpfItersPerLaunch, iters - done);
+        const int64_t n = std::min<int64_t>(per_launch, iters - done);
         const int64_t nsites = n + 2 * kSpfDepth;       // the kernel requests (and never consumes) data of the iterations just past its end
         hipLaunchKernelGGL(spf_sites_kernel, dim3((unsigned)((nsites + 255) / 256)), dim3(256), 0, st, ctx->pf_sites, nsites, ctx->it_done + (uint64_t)done,
                            (uint32_t)ctx->seed, (uint32_t)(ctx->seed >> 32), (uint32_t)ctx->N);
@@ -113,8 +159,17 @@ int32_t spf_standard_mc_async(rrrmc_ctx* ctx, double beta, int64_t iters, int64_
         SpfParams P = spf_params(ctx);
         P.beta = beta; P.g0 = ctx->it_done + (uint64_t)done; P.iters = n; P.step = step;
         P.it_off = done; P.sample0 = done / step;
+        if (team) {
+            hipLaunchKernelGGL(spf_team_plan_kernel, dim3((unsigned)((n + 2 + 255) / 256)), dim3(256), 0, st, ctx->d_A, ctx->pf_J, ctx->pf_sites, ctx->pf_plan, n, (int)ctx->K);
+            HIP_TRY(ctx, hipGetLastError());
+        }
         HIP_TRY(ctx, hipEventRecord(ctx->ev_sweep[2 * launches], st));
-        hipLaunchKernelGGL(fn, dim3((unsigned)ctx->pfW), dim3(64), 0, st, P);
+        if (team) {
+            SpfTeamParams TP{P, ctx->pf_plan};
+            hipLaunchKernelGGL(tfn, dim3((unsigned)ctx->pfW), dim3((unsigned)(nw * 64)), tlds, st, TP);
+        } else {
+            hipLaunchKernelGGL(fn, dim3((unsigned)ctx->pfW), dim3(64), 0, st, P);
+        }
         HIP_TRY(ctx, hipGetLastError());
         HIP_TRY(ctx, hipEventRecord(ctx->ev_sweep[2 * launches + 1], st));
         ++launches;

@@ -29,6 +29,7 @@
 #include "obs_kernels.hpp"
 #include "layout_kernels.hpp"
 #include "spf_kernels.hpp"
+#include "spf_team_kernel.hpp"
 #include "spf_fast_kernels.hpp"
 #include "dbl_kernels.hpp"
 #include "cont_kernels.hpp"
@@ -206,6 +207,7 @@ struct rrrmc_ctx {
     unsigned long long* pf_spins = nullptr;  // [W][N]: bit l = spin of replica 64 w + l
     double* pf_undo = nullptr;     // [W][K+1][64]: live part of lfields_last (see spf_kernels.hpp)
     int32_t* pf_sites = nullptr;   // site stream of one launch
+    uint32_t* pf_plan = nullptr;   // spf_team_kernel: the attempts of one launch (spf_team_kernel.hpp), allocated at its first use
     int64_t pfW = 0;
     bool pf_multi_edge = false;    // some row of A repeats a neighbour (GraphEANormal with L = 2): the wave build of the continuous samplers is not used
     bool pf_lf_live = false;       // sk_lf holds the local fields of the current configuration (false after the continuous samplers)
@@ -798,7 +800,7 @@ void rrrmc_ctx_destroy(rrrmc_ctx* ctx)
     free_dev(ctx->q_T); free_dev(ctx->q_z); free_dev(ctx->q_accrate); free_dev(ctx->q_stats);
     free_dev(ctx->rs_buf); free_dev(ctx->rs_spins); free_dev(ctx->rs_status);
     free_dev(ctx->rp_spins); free_dev(ctx->rp_cls); free_dev(ctx->rp_sv); free_dev(ctx->rp_spos);
-    free_dev(ctx->pf_J); free_dev(ctx->pf_spins); free_dev(ctx->pf_undo); free_dev(ctx->pf_sites);
+    free_dev(ctx->pf_J); free_dev(ctx->pf_spins); free_dev(ctx->pf_undo); free_dev(ctx->pf_sites); free_dev(ctx->pf_plan);
     free_dev(ctx->db_dJ); free_dev(ctx->db_rJ); free_dev(ctx->db_cls); free_dev(ctx->db_sv); free_dev(ctx->db_spos); free_dev(ctx->db_lf); free_dev(ctx->db_undo); free_dev(ctx->db_mlast);
     free_dev(ctx->pff_table); free_dev(ctx->pff_absJ); free_dev(ctx->pff_bond_off); free_dev(ctx->pff_thr_hi); free_dev(ctx->pff_thr_lo); free_dev(ctx->pff_flags);
     free_dev(ctx->wt_t); free_dev(ctx->wt_id); free_dev(ctx->wt_pos); free_dev(ctx->wt_time);
@@ -2513,7 +2515,10 @@ int32_t rrrmc_set_graph_f64(rrrmc_ctx* ctx, const int32_t* A, const double* J)
     ctx->h_A.assign(A, A + N * K);
     ctx->h_Jf.assign(J, J + N * K);
     ctx->pf_multi_edge = false;
-    for (int64_t q = 1; q < N * K; ++q) if (q % K && A[q] == A[q - 1]) ctx->pf_multi_edge = true;
+    for (int64_t x = 0; x < N; ++x)
+        for (int64_t a = 1; a < K; ++a)
+            for (int64_t b = 0; b < a; ++b)
+                if (A[x * K + a] == A[x * K + b]) ctx->pf_multi_edge = true;
     if (ctx->pff_ready) {            // a new graph: the fast mode's tables are rebuilt on its next call
         free_dev(ctx->pff_table); free_dev(ctx->pff_absJ); free_dev(ctx->pff_bond_off); free_dev(ctx->pff_thr_hi); free_dev(ctx->pff_thr_lo); free_dev(ctx->pff_flags);
         ctx->pff_ready = false;

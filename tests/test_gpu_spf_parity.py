@@ -7,6 +7,20 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
+# every test of this module runs through the three builds of the sweep: spf_team_kernel with sixteen and with eight wavefronts per group of
+# 64 replicas (csrc/spf_team_kernel.hpp; the default picks between them by K and the number of groups), and spf_sweep_kernel, one
+# wavefront per group (csrc/spf_kernels.hpp: the build of graphs with repeated neighbours, GraphEANormal with L = 2, whatever is asked for)
+SPF_BUILDS = {"team": {}, "team8": {"RRRMC_SPF_TEAM_WAVES": "8"}, "team16": {"RRRMC_SPF_TEAM_WAVES": "16"}, "single": {"RRRMC_SPF_TEAM": "0"}}
+
+
+@pytest.fixture(autouse=True, params=list(SPF_BUILDS))
+def spf_build(request, monkeypatch):
+    for k in ("RRRMC_SPF_TEAM", "RRRMC_SPF_TEAM_WAVES"):
+        monkeypatch.delenv(k, raising=False)
+    for k, v in SPF_BUILDS[request.param].items():
+        monkeypatch.setenv(k, v)
+    return request.param
+
 
 def _graph(pkg, kind, seed):
     if kind == "rrg10":
@@ -63,8 +77,9 @@ def test_spf_standard_mc_bit_exact(pkg, oracle, kind, R, beta, iters, step):
         assert (Es2[r] == Es2_ref).all() and (C2.s[r] == ch2_ref).all() and acc2[r] == acc2_ref
 
 
-def test_spf_multi_launch_and_replica_offset(pkg, oracle):
-    """More iterations than one launch covers (2^20) with a step that does not divide the launch length, and replica0 != 0."""
+def test_spf_multi_launch_and_replica_offset(pkg, oracle, spf_build):
+    """More iterations than one launch covers (2^18 for the team kernel, 2^20 for the single-wavefront one) with a step that does not divide the
+    launch length, and replica0 != 0."""
     seed, R, iters, step = 424242, 8, (1 << 20) + 5000, 70001
     X = pkg.GraphRRGNormal(64, 3, seed=seed)
     with pkg.Engine(X, R, replica0=96) as eng:
@@ -73,7 +88,7 @@ def test_spf_multi_launch_and_replica_offset(pkg, oracle):
         C0 = eng.get_config()
         Es, acc = eng.standard_mc(0.9, iters, step)
         C1 = eng.get_config()
-        assert eng.last_timing()[2] == 2
+        assert eng.last_timing()[2] == (2 if spf_build == "single" else 5)
     assert Es.shape == (R, iters // step)
     for r in (0, 7):
         assert (C0.s[r] == oracle.init_config(seed, 96 + r, X.N)).all()

@@ -74,3 +74,28 @@ def test_cont_wave_kernel_has_no_scratch(tmp_path):
     assert len(m) == 1
     assert m[0]["private_segment_fixed_size"] == 0 and m[0].get("vgpr_spill_count", 0) == 0, m[0]
     assert m[0]["vgpr_count"] <= 168, m[0]
+
+
+TU_TEAM = r'''
+#include <hip/hip_runtime.h>
+#include "spf_team_kernel.hpp"
+#define INST(K) template __global__ void rrrmc::spf_team_kernel<K, 16, 1>(rrrmc::SpfTeamParams); template __global__ void rrrmc::spf_team_kernel<K, 8, 1>(rrrmc::SpfTeamParams);
+INST(1) INST(2) INST(3) INST(4) INST(5) INST(6) INST(7) INST(8)
+'''
+
+
+@pytest.mark.skipif(shutil.which("hipcc") is None, reason="hipcc not found")
+def test_spf_team_kernel_has_no_scratch_and_fits_its_workgroup(tmp_path):
+    """spf_team_kernel (standardMC on the Float64 sparse models): the sixteen-wavefront build runs 1024 threads per workgroup, i.e. at most
+    128 registers per thread; no build may touch private memory (the executing wavefronts sit in a latency chain, the retiring one is the
+    serial part of the whole kernel)."""
+    src = tmp_path / "team.hip"
+    src.write_text(TU_TEAM)
+    asm = tmp_path / "team.s"
+    subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-I", CSRC, "--cuda-device-only", "-S",
+                           str(src), "-o", str(asm)], cwd=str(tmp_path))
+    meta = {n: m for n, m in kernel_metadata(asm.read_text()).items() if "spf_team_kernel" in n}
+    assert len(meta) == 16
+    for n, m in meta.items():
+        assert m["private_segment_fixed_size"] == 0 and m.get("vgpr_spill_count", 0) == 0, (n, m)       # (scalar registers may spill into vector lanes)
+        assert m["vgpr_count"] <= 128, (n, m)

@@ -80,7 +80,7 @@ def bench_quant(Nk=1024, M=32, R=128, beta=2.0, Gamma=0.5, iters=1 << 16, step=1
         eng.close()
 
 
-def bench_spf(N=4096, K=3, R=65536, beta=1.0, iters=1 << 14, step=1 << 12, seed=0x5EED):
+def bench_spf(N=4096, K=3, R=65536, beta=1.0, iters=1 << 16, step=1 << 12, seed=0x5EED):
     """GraphRRGNormal (Float64 sparse): config-2 geometry with Gaussian couplings; the lane-per-replica
     kernel hides its accept-path latency with occupancy, so it is measured at several replica counts."""
     pkg = entry.load_package()
@@ -99,6 +99,7 @@ def bench_spf(N=4096, K=3, R=65536, beta=1.0, iters=1 << 14, step=1 << 12, seed=
         attempts = float(R) * iters
         bpa = 8 + a * (10 + 17 * K)          # SURVEY.md §8d widths: field 8 B, spin 1 B; lfields_last excluded
         out = {"model": "GraphRRGNormal", "N": N, "K": K, "replicas": R, "beta": beta, "iters": iters, "attempts_per_s": attempts / dt,
+               "build": {k: os.environ[k] for k in ("RRRMC_SPF_TEAM", "RRRMC_SPF_TEAM_WAVES") if k in os.environ} or "default",
                "kernel_ms": sweep_ms, "acceptance": a, "energy_per_spin": float(Es[:, -1].mean()) / N,
                "algorithmic_bytes_per_attempt": bpa, "algorithmic_GBps_kernel": bpa * attempts / (sweep_ms * 1e-3) / 1e9}
         print(json.dumps(out), flush=True)
