@@ -1,12 +1,13 @@
 # Replay an RNG-free tape (tests/golden/tape_*.txt) through the reference's OWN graph code and compare with the results the tape
 # holds (written by the build's C oracle; the HIP library is checked against the same tapes in tests/test_tapes.py).
 #
-#   julia --project=<an environment that has RRRMC.jl> julia/replay_tape.jl                     (all eleven tapes)
+#   julia --project=<an environment that has RRRMC.jl> julia/replay_tape.jl                     (all twelve tapes)
 #   julia ...                                          julia/replay_tape.jl tests/golden/tape_skn_n24.txt ...
 #
 # Tapes: standardMC on GraphRRG(128, 3); rrrMC on a GraphQuant (staged and direct branch); round 3: standardMC on GraphEA(2, 3) (doubled
 # bonds, undo path of update_cache!), on GraphSKNormal(24) and the binary GraphSK(10) (whole-array swap of SK.jl:247-250 / :106-109), and
-# rrrMC on GraphSKNormal(10) through DeltaECacheCont / DynamicSampler (refresh! included).
+# rrrMC on GraphSKNormal(10) through DeltaECacheCont / DynamicSampler (refresh! included); round 4: standardMC on GraphRRGNormal(16, 3)
+# (Float64 sparse model; 263 undo swaps of RRG.jl:566-577).
 #
 # With the random draws fixed, standardMC / rrrMC are deterministic functions of the reference's energy, delta_energy, spinflip!,
 # DeltaECache and ArraySet code: this script restates only the few lines of the sampler loops that consume random numbers
@@ -218,6 +219,27 @@ function replay_standardMC_sk(t)
          accepted == parse(Int, t["expected_accepted"]) && isapprox(lf, parse.(Float64, t["expected_lfields"]), rtol = 1e-12, atol = 1e-12)
     println(ok ? "standardMC($(typeof(X))) tape: reference == tape ($(accepted) accepted, bit-equal energies: $(Es == parse.(Float64, t["expected_Es"])))" :
                  "standardMC($(typeof(X))) tape: MISMATCH")
+    return ok
+end
+
+# standardMC on GraphRRGNormal (src/graphs/RRG.jl:503-609).  The struct has no constructor from (A, J): one is drawn at random by the
+# reference (GraphRRGNormal{K}(N)) and its A and J vectors are overwritten in place with the tape's; energy() rebuilds the cache from them.
+function replay_standardMC_rrgn(t)
+    N, K = parse(Int, t["N"]), parse(Int, t["K"])
+    X = RRRMC.RRG.GraphRRGNormal(N, K)
+    Af, Jf = ints(t["A"]), parse.(Float64, t["J"])
+    for x = 1:N
+        X.A[x] = ntuple(k -> Af[(x - 1) * K + k], K)
+        X.J[x] = ntuple(k -> Jf[(x - 1) * K + k], K)
+    end
+    C = config_from(t["C0"], N)
+    Es, accepted, _ = run_standardMC(X, C, parse(Float64, t["beta"]), parse(Int, t["iters"]), parse(Int, t["step"]),
+                                     ints(t["sites"]), parse.(Float64, t["uniforms"]))
+    lf = Float64.(X.cache.lfields)
+    ok = isapprox(Es, parse.(Float64, t["expected_Es"]), rtol = 1e-12, atol = 1e-12) && chunks_hex(C) == t["expected_chunks"] &&
+         accepted == parse(Int, t["expected_accepted"]) && isapprox(lf, parse.(Float64, t["expected_lfields"]), rtol = 1e-12, atol = 1e-12)
+    println(ok ? "standardMC(GraphRRGNormal) tape: reference == tape ($(accepted) accepted, bit-equal energies: $(Es == parse.(Float64, t["expected_Es"])))" :
+                 "standardMC(GraphRRGNormal) tape: MISMATCH")
     return ok
 end
 
@@ -463,6 +485,7 @@ function main(paths)
         t = read_tape(p)
         k = t["kind"]
         allok &= k == "standardMC" ? (get(t, "form", "rrg") == "ea" ? replay_standardMC_ea(t) : replay_standardMC(t)) :
+                 k == "standardMC_rrgn" ? replay_standardMC_rrgn(t) :
                  k == "rrrMC_quant" ? replay_rrrMC_quant(t) :
                  k == "rrrMC_skn" ? replay_rrrMC_skn(t) :
                  (k == "rrrMC_rrg" || k == "bklMC_rrg") ? replay_rrr_bkl_rrg(t) :
@@ -474,4 +497,4 @@ end
 
 main(isempty(ARGS) ? [joinpath(@__DIR__, "..", "tests", "golden", f) for f in
                       ("tape_rrg_n128.txt", "tape_quant_nk16_m4.txt", "tape_quant_direct.txt", "tape_ea_l2_d3.txt", "tape_skn_n24.txt",
-                       "tape_sk_n10.txt", "tape_rrr_skn_n10.txt", "tape_rrr_rrg_n64.txt", "tape_bkl_rrg_n64.txt", "tape_wtm_rrg_n64.txt", "tape_eo_rrg_n64.txt")] : ARGS)
+                       "tape_sk_n10.txt", "tape_rrr_skn_n10.txt", "tape_rrr_rrg_n64.txt", "tape_bkl_rrg_n64.txt", "tape_wtm_rrg_n64.txt", "tape_eo_rrg_n64.txt", "tape_rrgn_n16.txt")] : ARGS)

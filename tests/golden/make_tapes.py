@@ -181,6 +181,39 @@ def write_standard_sk(path, seed, N, binary, beta, iters, step, replica=0, want_
     return ok
 
 
+def write_standard_rrgn(path, seed, N=16, K=3, beta=1.2, iters=6000, step=200, replica=0, want_undos=5):
+    """standardMC on GraphRRGNormal(N, K) (Float64 couplings and local fields, RRG.jl:503-609): the model of csrc/spf_kernels.hpp and
+    csrc/spf_team_kernel.hpp.  On 16 sites the same spin is accepted twice in a row often enough that the undo branch of update_cache!
+    (RRG.jl:566-577: lfields <-> lfields_last over the neighbours) is on the tape."""
+    A = O.gen_rrg(N, K, seed)
+    J = O.gen_couplings_gauss(A, seed)
+    C0 = O.init_config(seed, replica, N)
+    Es, ch, acc, lf = O.standard_mc_spf(A, J, beta, iters, step, seed, C0, replica=replica)
+    sites = [O.site_of(seed, g, N) for g in range(1, iters + 1)]
+    us = [O.rand53(seed, g, replica) for g in range(1, iters + 1)]
+    body = ["# RRRMC tape v1 — standardMC(X::GraphRRGNormal{%d}, beta, iters; step, C0) with every random draw pre-drawn: A and J as the" % K,
+            "# fields of the reference's struct (rows of K neighbours / couplings), sites 1-based; uniforms consulted only when delta_energy > 0",
+            "# (src/RRRMC.jl:39).  Written by tests/golden/make_tapes.py",
+            "@kind standardMC_rrgn", "@N %d" % N, "@K %d" % K, "@beta %r" % beta, "@iters %d" % iters, "@step %d" % step, "@seed %d" % seed,
+            "@replica %d" % replica,
+            fmt_array("A", ("%d" % (v + 1) for v in A.reshape(-1))), fmt_array("J", (repr(float(v)) for v in J.reshape(-1))),
+            fmt_array("C0", ("%016x" % int(c) for c in C0)),
+            fmt_array("sites", ("%d" % (v + 1) for v in sites)), fmt_array("uniforms", (repr(u) for u in us)),
+            fmt_array("expected_Es", (repr(float(e)) for e in Es)), fmt_array("expected_chunks", ("%016x" % int(c) for c in ch)),
+            "@expected_accepted %d" % acc, fmt_array("expected_lfields", (repr(float(v)) for v in lf))]
+
+    def check(t):
+        got = TR.replay_standard_mc_rrgn(t)
+        ok = (got["chunks"] == [int(c) for c in ch] and got["accepted"] == acc and got["min_margin"] >= 1e-9 and got["undos"] >= want_undos
+              and got["Es"] == [float(e) for e in Es] and got["lfields"] == [float(v) for v in lf])         # same IEEE operations: equal bit for bit
+        return ok, "%d iterations, accepted %d, %d undo swaps, closest decision margin %.2e" % (iters, acc, got["undos"], got["min_margin"])
+    ok = _finish(path, body, check)
+    if ok:
+        t = open(path).read().replace("@expected_accepted %d" % acc, "@expected_accepted %d\n@expected_undos %d" % (acc, TR.replay_standard_mc_rrgn(TR.read_tape(path))["undos"]))
+        open(path, "w").write(t)
+    return ok
+
+
 def write_rrr_skn(path, seed, N=10, beta=2.0, iters=2500, step=50, staged_thr=0.8, staged_thr_fact=5.0, replica=0):
     """rrrMC(X::SingleGraph) on GraphSKNormal(N) through DeltaECacheCont + DynamicSampler (DeltaE.jl:299-410, DynamicSamplers.jl): with N = 10
     every move re-weights all ten spins, so refresh! (every max(N, 100) setindex! calls) happens every tenth move."""
@@ -343,3 +376,4 @@ if __name__ == "__main__":
     tries(lambda sd: write_rrr_bkl_rrg(os.path.join(HERE, "tape_bkl_rrg_n64.txt"), sd, True, iters=20000, step=500), "a bklMC(GraphRRG(64,3)) tape with a safe margin")
     tries(lambda sd: write_wtm_rrg(os.path.join(HERE, "tape_wtm_rrg_n64.txt"), sd), "a wtmMC(GraphRRG(64,3)) tape with a safe margin")
     tries(lambda sd: write_eo_rrg(os.path.join(HERE, "tape_eo_rrg_n64.txt"), sd), "an extremal_opt(GraphRRG(64,3)) tape with a safe margin")
+    tries(lambda sd: write_standard_rrgn(os.path.join(HERE, "tape_rrgn_n16.txt"), sd), "a GraphRRGNormal(16,3) tape with undo swaps and a safe margin")

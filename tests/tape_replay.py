@@ -371,6 +371,78 @@ def replay_standard_mc_ea(tape):
     return {"Es": Es, "chunks": chunks_of_bits(s), "accepted": accepted, "flips": flips, "undos": undos, "min_margin": min_margin}
 
 
+# ---- GraphRRGNormal: src/graphs/RRG.jl:503-627 (SimpleGraph{Float64}: Gaussian couplings, Float64 local fields) --------------------------
+def rrgn_energy(A, J, s):
+    """energy (RRG.jl:531-558): lf -= Jxy * sx * sy per neighbour in the order of A[x]; E1 += lf; lfields[x] = 2 lf; E1 /= 2; the undo
+    state is reset (move_last = 0, lfields_last = 0)."""
+    E1, lfields = 0.0, [0.0] * len(A)
+    for x in range(len(A)):
+        sx = 2 * s[x] - 1
+        lf = 0.0
+        for y, Jxy in zip(A[x], J[x]):
+            lf -= Jxy * sx * (2 * s[y - 1] - 1)
+        E1 += lf
+        lfields[x] = 2 * lf
+    return E1 / 2, lfields, [0.0] * len(A), 0
+
+
+def rrgn_update_cache(A, J, s, lfields, lfields_last, move_last, move):
+    """update_cache! (RRG.jl:560-600), called AFTER the bit flip; returns the new move_last.  Undo branch (:566-577): the neighbours' entries of
+    lfields and lfields_last are swapped, both entries of the moved spin negated, move_last kept.  Normal branch (:579-596): every
+    neighbour's field is saved and changed by -4 sxy Jxy (sxy from the NEW spin of `move`), the moved spin's field saved and negated."""
+    if move_last == move:
+        for y in A[move - 1]:
+            lfields[y - 1], lfields_last[y - 1] = lfields_last[y - 1], lfields[y - 1]
+        lfields[move - 1] = -lfields[move - 1]
+        lfields_last[move - 1] = -lfields_last[move - 1]
+        return move_last
+    sx = s[move - 1]
+    for y, Jxy in zip(A[move - 1], J[move - 1]):
+        sxy = 1 - 2 * (sx ^ s[y - 1])
+        lfy = lfields[y - 1]
+        lfields_last[y - 1] = lfy
+        lfields[y - 1] = lfy - 4 * sxy * Jxy
+    lfm = lfields[move - 1]
+    lfields_last[move - 1] = lfm
+    lfields[move - 1] = -lfm
+    return move
+
+
+def replay_standard_mc_rrgn(tape):
+    """standardMC (RRRMC.jl:81-127) on GraphRRGNormal with the graph and the draws of the tape.  Every quantity is the same sequence of IEEE
+    double operations the reference executes, so the results are compared bit for bit."""
+    N, K = int(tape["N"]), int(tape["K"])
+    beta, iters, step = float(tape["beta"]), int(tape["iters"]), int(tape["step"])
+    A = [[int(v) for v in tape["A"][x * K:(x + 1) * K]] for x in range(N)]
+    J = [[float(v) for v in tape["J"][x * K:(x + 1) * K]] for x in range(N)]
+    s = bits_of_chunks([int(c, 16) for c in tape["C0"]], N)
+    sites = [int(v) for v in tape["sites"]]
+    us = [float(v) for v in tape["uniforms"]]
+    E, lfields, lfields_last, move_last = rrgn_energy(A, J, s)
+    Es, accepted, undos, min_margin = [], 0, 0, float("inf")
+    for it in range(1, iters + 1):
+        if it % step == 0:
+            Es.append(E)
+        i = sites[it - 1]
+        dE = -lfields[i - 1]                               # delta_energy, RRG.jl:602-609
+        x = -beta * dE
+        ok = x >= 0                                        # accept, RRRMC.jl:39
+        if not ok:
+            p = math.exp(x)
+            ok = us[it - 1] < p
+            min_margin = min(min_margin, abs(us[it - 1] - p) / p)
+        if not ok:
+            continue
+        s[i - 1] ^= 1                                      # spinflip!, Interface.jl:89-92
+        undos += move_last == i
+        move_last = rrgn_update_cache(A, J, s, lfields, lfields_last, move_last, i)
+        E += dE
+        accepted += 1
+    E1, lf1, _, _ = rrgn_energy(A, J, s)
+    assert abs(E - E1) <= 1e-9 * max(1.0, abs(E1))         # tracked E == energy(X, C) up to rounding (test/runtests.jl:12-20)
+    return {"Es": Es, "chunks": chunks_of_bits(s), "accepted": accepted, "undos": undos, "min_margin": min_margin, "lfields": lfields}
+
+
 # ---- GraphSKNormal: src/graphs/SK.jl:170-297 ----------------------------------------------------------------------------------
 class SKNormal:
     """J = N rows of Float64; cache = (lfields, lfields_last, move_last).  delta_energy(i) = +lfields[i] (SK.jl:278-284)."""

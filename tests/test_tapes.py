@@ -385,3 +385,51 @@ def test_hip_library_reproduces_the_extremal_opt_tape(pkg):
         assert int(Emin[0]) == int(t["expected_Emin"]) and int(itmin[0]) == int(t["expected_itmin"])
         assert [int(c) for c in Cmin.s[0]] == [int(c, 16) for c in t["expected_Cmin"]]
         assert [int(c) for c in eng.get_config().s[0]] == [int(c, 16) for c in t["expected_chunks"]]
+
+
+# ---- round 4: standardMC on GraphRRGNormal(16, 3) — Float64 couplings and local fields (RRG.jl:503-609), the model of spf_sweep_kernel and of
+#      spf_team_kernel (a team of wavefronts per group of 64 replicas): 263 of the 1032 accepted moves take update_cache!'s undo branch ----------
+RRGN = os.path.join(GOLD, "tape_rrgn_n16.txt")
+
+
+def test_python_replay_reproduces_the_rrg_normal_tape():
+    t = TR.read_tape(RRGN)
+    got = TR.replay_standard_mc_rrgn(t)
+    assert got["Es"] == _floats(t["expected_Es"])              # the same sequence of IEEE operations: equal bit for bit
+    assert got["chunks"] == [int(c, 16) for c in t["expected_chunks"]] and got["accepted"] == int(t["expected_accepted"])
+    assert got["lfields"] == _floats(t["expected_lfields"])
+    assert got["undos"] == int(t["expected_undos"]) >= 5       # update_cache!'s undo branch (RRG.jl:566-577) is part of the tape
+    assert got["min_margin"] > 1e-9
+
+
+def test_oracle_reproduces_the_rrg_normal_tape(oracle):
+    t = TR.read_tape(RRGN)
+    N, K, seed = int(t["N"]), int(t["K"]), int(t["seed"])
+    A = np.array([int(v) - 1 for v in t["A"]], np.int32).reshape(N, K)
+    J = np.array(_floats(t["J"])).reshape(N, K)
+    assert (A == oracle.gen_rrg(N, K, seed)).all() and (J == oracle.gen_couplings_gauss(A, seed)).all()
+    C0 = np.array([int(c, 16) for c in t["C0"]], np.uint64)
+    assert [oracle.site_of(seed, g, N) + 1 for g in range(1, 50)] == [int(v) for v in t["sites"][:49]]
+    o = oracle.standard_mc_spf(A, J, float(t["beta"]), int(t["iters"]), int(t["step"]), seed, C0)
+    assert [float(e) for e in o[0]] == _floats(t["expected_Es"]) and o[2] == int(t["expected_accepted"])
+    assert [int(c) for c in o[1]] == [int(c, 16) for c in t["expected_chunks"]] and [float(v) for v in o[3]] == _floats(t["expected_lfields"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("env", [{}, {"RRRMC_SPF_TEAM_WAVES": "8"}, {"RRRMC_SPF_TEAM": "0"}], ids=["team", "team8", "single"])
+def test_hip_library_reproduces_the_rrg_normal_tape(pkg, monkeypatch, env):
+    for k in ("RRRMC_SPF_TEAM", "RRRMC_SPF_TEAM_WAVES"):
+        monkeypatch.delenv(k, raising=False)
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    t = TR.read_tape(RRGN)
+    seed = int(t["seed"])
+    X = pkg.GraphRRGNormal(int(t["N"]), int(t["K"]), seed=seed)
+    assert [float(v) for v in np.asarray(X.J).reshape(-1)] == _floats(t["J"])
+    with pkg.Engine(X, 8) as eng:
+        eng.seed(seed); eng.init_spins_random()
+        assert [int(c) for c in eng.get_config().s[0]] == [int(c, 16) for c in t["C0"]]
+        Es, acc = eng.standard_mc(float(t["beta"]), int(t["iters"]), int(t["step"]))
+        assert [float(e) for e in Es[0]] == _floats(t["expected_Es"]) and int(acc[0]) == int(t["expected_accepted"])
+        assert [int(c) for c in eng.get_config().s[0]] == [int(c, 16) for c in t["expected_chunks"]]
+        assert [float(v) for v in eng.fields()[0]] == _floats(t["expected_lfields"])
