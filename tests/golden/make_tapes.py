@@ -248,6 +248,42 @@ def write_rrr_skn(path, seed, N=10, beta=2.0, iters=2500, step=50, staged_thr=0.
     return _finish(path, body, check)
 
 
+def write_rrr_rrgn(path, seed, N=64, K=3, beta=2.0, iters=3000, step=100, staged_thr=0.8, staged_thr_fact=5.0, replica=0):
+    """rrrMC(X::SingleGraph) on GraphRRGNormal(N, K) through DeltaECacheCont + DynamicSampler: the model and size range of
+    csrc/cont_wave_kernel.hpp (a wavefront per replica, N >= 64).  A move re-weights K + 1 = 4 spins, so refresh! (every max(N, 100)
+    setindex! calls) happens every 25 moves."""
+    A = O.gen_rrg(N, K, seed)
+    J = O.gen_couplings_gauss(A, seed)
+    C0 = O.init_config(seed, replica, N)
+    Es, ch, stats, _t = O.cont_sparse("rrr", A, J, beta, iters, step, seed, C0, replica=replica, staged_thr=staged_thr, staged_thr_fact=staged_thr_fact)
+    acc, staged = int(stats[0]), int(stats[1])
+    key = np.array([seed & 0xFFFFFFFF, seed >> 32], np.uint32)
+    umove, uacc = [], []
+    for g in range(1, iters + 1):          # RRR stream (DESIGN.md §2): sub 0 words 0,1 = rand(dynsmp)'s uniform, sub 1 = rand() of `rand() < c`
+        w0 = O.philox([g & 0xFFFFFFFF, g >> 32, replica, 8], key)
+        w1 = O.philox([g & 0xFFFFFFFF, g >> 32, replica, 8 | (1 << 8)], key)
+        umove.append(u53((int(w0[0]) << 32) | int(w0[1])))
+        uacc.append(u53((int(w1[0]) << 32) | int(w1[1])))
+    body = ["# RRRMC tape v1 — rrrMC(X::GraphRRGNormal{%d}, beta, iters; step, C0, staged_thr, staged_thr_fact) (SingleGraph method, src/RRRMC.jl:149-219)" % K,
+            "# with every random draw pre-drawn: u_move = rand() inside rand(dynsmp) (src/DynamicSamplers.jl:154), u_accept = rand() of",
+            "# `rand() < c` (src/RRRMC.jl:192,202; drawn at every iteration).  A and J are the fields of the reference's struct.  Written by tests/golden/make_tapes.py",
+            "@kind rrrMC_rrgn", "@N %d" % N, "@K %d" % K, "@beta %r" % beta, "@iters %d" % iters, "@step %d" % step, "@staged_thr %r" % staged_thr,
+            "@staged_thr_fact %r" % staged_thr_fact, "@seed %d" % seed, "@replica %d" % replica,
+            fmt_array("A", ("%d" % (v + 1) for v in A.reshape(-1))), fmt_array("J", (repr(float(v)) for v in J.reshape(-1))),
+            fmt_array("C0", ("%016x" % int(c) for c in C0)),
+            fmt_array("u_move", (repr(u) for u in umove)), fmt_array("u_accept", (repr(u) for u in uacc)),
+            fmt_array("expected_Es", (repr(float(e)) for e in Es)), fmt_array("expected_chunks", ("%016x" % int(c) for c in ch)),
+            "@expected_accepted %d" % acc, "@expected_staged_its %d" % staged]
+
+    def check(t):
+        got = TR.replay_rrr_single_sk(t)
+        ok = (got["chunks"] == [int(c) for c in ch] and got["accepted"] == acc and got["staged_its"] == staged and got["min_margin"] >= 1e-9
+              and np.allclose(got["Es"], Es, rtol=1e-12, atol=1e-12) and got["refreshes"] >= 3 and 0 < staged < iters)
+        return ok, "%d iterations, accepted %d, staged %d, %d refresh! calls, %d undo swaps, closest decision margin %.2e" % (
+            iters, acc, staged, got["refreshes"], got["swaps"], got["min_margin"])
+    return _finish(path, body, check)
+
+
 def write_rrr_bkl_rrg(path, seed, bkl, N=64, K=3, beta=2.0, iters=4000, step=100, staged_thr=0.5, staged_thr_fact=5.0, replica=0):
     """rrrMC(X::SingleGraph) (bkl = False) or bklMC (bkl = True) on GraphRRG{Int,(-1,1),K} with DeltaECache{Int,L} (SURVEY.md §8f rank 1)."""
     A = O.gen_rrg(N, K, seed)
@@ -377,3 +413,4 @@ if __name__ == "__main__":
     tries(lambda sd: write_wtm_rrg(os.path.join(HERE, "tape_wtm_rrg_n64.txt"), sd), "a wtmMC(GraphRRG(64,3)) tape with a safe margin")
     tries(lambda sd: write_eo_rrg(os.path.join(HERE, "tape_eo_rrg_n64.txt"), sd), "an extremal_opt(GraphRRG(64,3)) tape with a safe margin")
     tries(lambda sd: write_standard_rrgn(os.path.join(HERE, "tape_rrgn_n16.txt"), sd), "a GraphRRGNormal(16,3) tape with undo swaps and a safe margin")
+    tries(lambda sd: write_rrr_rrgn(os.path.join(HERE, "tape_rrr_rrgn_n64.txt"), sd), "an rrrMC(GraphRRGNormal(64,3)) tape with both branches and a safe margin")

@@ -443,6 +443,30 @@ def replay_standard_mc_rrgn(tape):
     return {"Es": Es, "chunks": chunks_of_bits(s), "accepted": accepted, "undos": undos, "min_margin": min_margin, "lfields": lfields}
 
 
+class RRGNormal:
+    """GraphRRGNormal as an object with the interface of SKNormal below (for the samplers that work through delta_energy / spinflip!):
+    delta_energy(i) = -lfields[i] (RRG.jl:602-609), neighbors(i) = A[i] (:625)."""
+
+    def __init__(self, A, J):
+        self.N, self.A, self.J = len(A), A, J
+        self.lfields, self.lfields_last, self.move_last, self.swaps = [0.0] * self.N, [0.0] * self.N, 0, 0
+
+    def energy(self, s):
+        E, self.lfields, self.lfields_last, self.move_last = rrgn_energy(self.A, self.J, s)
+        return E
+
+    def delta_energy(self, s, move):
+        return -self.lfields[move - 1]
+
+    def spinflip(self, s, move):                           # Interface.jl:89-92
+        s[move - 1] ^= 1
+        self.swaps += self.move_last == move
+        self.move_last = rrgn_update_cache(self.A, self.J, s, self.lfields, self.lfields_last, self.move_last, move)
+
+    def neighbors(self, move):
+        return list(self.A[move - 1])
+
+
 # ---- GraphSKNormal: src/graphs/SK.jl:170-297 ----------------------------------------------------------------------------------
 class SKNormal:
     """J = N rows of Float64; cache = (lfields, lfields_last, move_last).  delta_energy(i) = +lfields[i] (SK.jl:278-284)."""
@@ -655,7 +679,12 @@ def replay_rrr_single_sk(tape, exp=math.exp):
     N = int(tape["N"])
     beta, iters, step = float(tape["beta"]), int(tape["iters"]), int(tape["step"])
     staged_thr, staged_thr_fact = float(tape["staged_thr"]), float(tape["staged_thr_fact"])
-    X = _sk_graph(tape)
+    if tape["kind"] == "rrrMC_rrgn":                        # the same sampler over GraphRRGNormal (round 4): sparse neighbourhoods
+        K = int(tape["K"])
+        X = RRGNormal([[int(v) for v in tape["A"][x * K:(x + 1) * K]] for x in range(N)],
+                      [[float(v) for v in tape["J"][x * K:(x + 1) * K]] for x in range(N)])
+    else:
+        X = _sk_graph(tape)
     s = bits_of_chunks([int(c, 16) for c in tape["C0"]], N)
     u_move = [float(v) for v in tape["u_move"]]
     u_acc = [float(v) for v in tape["u_accept"]]
@@ -663,7 +692,7 @@ def replay_rrr_single_sk(tape, exp=math.exp):
     E = X.energy(s)
     dEs = [X.delta_energy(s, i) for i in range(1, N + 1)]   # DeltaECacheCont, DeltaE.jl:304-313
     ds = DynamicSampler([prior(beta * d) for d in dEs])
-    neighbors = lambda i: [j for j in range(1, N + 1) if j != i]          # AllButOne(N, i), SK.jl:297
+    neighbors = X.neighbors if hasattr(X, "neighbors") else (lambda i: [j for j in range(1, N + 1) if j != i])     # AllButOne(N, i), SK.jl:297
     lam = staged_thr_fact / N
     Es, accepted, staged_its, acc_rate, margin = [], 0, 0, 0.5, float("inf")
 

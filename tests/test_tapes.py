@@ -433,3 +433,50 @@ def test_hip_library_reproduces_the_rrg_normal_tape(pkg, monkeypatch, env):
         assert [float(e) for e in Es[0]] == _floats(t["expected_Es"]) and int(acc[0]) == int(t["expected_accepted"])
         assert [int(c) for c in eng.get_config().s[0]] == [int(c, 16) for c in t["expected_chunks"]]
         assert [float(v) for v in eng.fields()[0]] == _floats(t["expected_lfields"])
+
+
+# ---- round 4: rrrMC(X::SingleGraph) on GraphRRGNormal(64, 3) through DeltaECacheCont + DynamicSampler: the model and size range of
+#      cont_wave_kernel (one wavefront per replica, the sampler's tree split between LDS and memory); 127 refresh! calls on the tape --------
+RRRGN = os.path.join(GOLD, "tape_rrr_rrgn_n64.txt")
+
+
+def test_python_replay_reproduces_the_rrr_rrg_normal_tape():
+    t = TR.read_tape(RRRGN)
+    got = TR.replay_rrr_single_sk(t)
+    assert got["chunks"] == [int(c, 16) for c in t["expected_chunks"]]
+    assert got["accepted"] == int(t["expected_accepted"]) and got["staged_its"] == int(t["expected_staged_its"])
+    np.testing.assert_allclose(got["Es"], _floats(t["expected_Es"]), rtol=1e-12, atol=1e-12)
+    assert got["refreshes"] >= 3 and 0 < got["staged_its"] < int(t["iters"])        # refresh! and both branches of the sampler are on the tape
+    assert got["min_margin"] > 1e-9
+
+
+def test_oracle_reproduces_the_rrr_rrg_normal_tape(oracle):
+    t = TR.read_tape(RRRGN)
+    N, K, seed = int(t["N"]), int(t["K"]), int(t["seed"])
+    A = np.array([int(v) - 1 for v in t["A"]], np.int32).reshape(N, K)
+    J = np.array(_floats(t["J"])).reshape(N, K)
+    assert (A == oracle.gen_rrg(N, K, seed)).all() and (J == oracle.gen_couplings_gauss(A, seed)).all()
+    C0 = np.array([int(c, 16) for c in t["C0"]], np.uint64)
+    o = oracle.cont_sparse("rrr", A, J, float(t["beta"]), int(t["iters"]), int(t["step"]), seed, C0, staged_thr=float(t["staged_thr"]),
+                           staged_thr_fact=float(t["staged_thr_fact"]))
+    assert [float(e) for e in o[0]] == _floats(t["expected_Es"]) and [int(c) for c in o[1]] == [int(c, 16) for c in t["expected_chunks"]]
+    assert int(o[2][0]) == int(t["expected_accepted"]) and int(o[2][1]) == int(t["expected_staged_its"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("env", [{}, {"RRRMC_CONT_NO_WAVE": "1"}], ids=["wave", "thread"])
+def test_hip_library_reproduces_the_rrr_rrg_normal_tape(pkg, monkeypatch, env):
+    monkeypatch.delenv("RRRMC_CONT_NO_WAVE", raising=False)
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    t = TR.read_tape(RRRGN)
+    seed = int(t["seed"])
+    X = pkg.GraphRRGNormal(int(t["N"]), int(t["K"]), seed=seed)
+    with pkg.Engine(X, 8) as eng:
+        eng.seed(seed); eng.init_spins_random()
+        assert [int(c) for c in eng.get_config().s[0]] == [int(c, 16) for c in t["C0"]]
+        Es, acc, staged = eng.rrr_mc(float(t["beta"]), int(t["iters"]), int(t["step"]), staged_thr=float(t["staged_thr"]),
+                                     staged_thr_fact=float(t["staged_thr_fact"]))
+        assert [float(e) for e in Es[0]] == _floats(t["expected_Es"])
+        assert int(acc[0]) == int(t["expected_accepted"]) and int(staged[0]) == int(t["expected_staged_its"])
+        assert [int(c) for c in eng.get_config().s[0]] == [int(c, 16) for c in t["expected_chunks"]]
