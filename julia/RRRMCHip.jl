@@ -5,7 +5,7 @@
 #   * tests/test_julia_binding.py parses every `ccall` below and checks symbol, return type, argument count and argument types against
 #     include/rrrmc_hip.h (a signature drift on either side fails the CPU suite);
 #   * the same ABI is driven from C (tests/abi_smoke.c, compiled against the header) and from Python (rrrmc.jl_amd/_lib.py) on the GPU;
-#   * julia/replay_tape.jl checks the build's oracle against the reference itself on a machine that has Julia.
+#   * tests/replay_tape.jl checks the build's oracle against the reference itself on a machine that has Julia.
 #
 # One `Ctx` = the R replicas of one graph, on one device (`device = k`) or sharded over several from this one process
 # (`devices = [0, 1, ...]` -> rrrmc_ctx_create_multi: the library runs one stream and one host thread per device and hands back

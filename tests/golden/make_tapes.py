@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Write the RNG-free tapes tests/golden/tape_*.txt: a graph, a start configuration, every random draw of a run (pre-drawn from the
 build's Philox streams) and the results the C oracle obtained.  Replayed by tests/tape_replay.py (plain Python after the Julia
-sources), by julia/replay_tape.jl (the reference's OWN functions, wherever Julia + RRRMC.jl exist: `julia julia/replay_tape.jl
+sources), by tests/replay_tape.jl (the reference's OWN functions, wherever Julia + RRRMC.jl exist: `julia tests/replay_tape.jl
 tests/golden/tape_rrg_n128.txt`) and by the HIP library (tests/test_tapes.py).
 
 A tape is only written if (a) the plain-Python replay — libm exp, Float64 uniforms — reproduces the oracle's run exactly and

@@ -1,8 +1,8 @@
 # Replay an RNG-free tape (tests/golden/tape_*.txt) through the reference's OWN graph code and compare with the results the tape
 # holds (written by the build's C oracle; the HIP library is checked against the same tapes in tests/test_tapes.py).
 #
-#   julia --project=<an environment that has RRRMC.jl> julia/replay_tape.jl                     (all thirteen tapes)
-#   julia ...                                          julia/replay_tape.jl tests/golden/tape_skn_n24.txt ...
+#   julia --project=<an environment that has RRRMC.jl> tests/replay_tape.jl                     (all thirteen tapes)
+#   julia ...                                          tests/replay_tape.jl tests/golden/tape_skn_n24.txt ...
 #
 # Tapes: standardMC on GraphRRG(128, 3); rrrMC on a GraphQuant (staged and direct branch); round 3: standardMC on GraphEA(2, 3) (doubled
 # bonds, undo path of update_cache!), on GraphSKNormal(24) and the binary GraphSK(10) (whole-array swap of SK.jl:247-250 / :106-109), and
@@ -52,6 +52,27 @@ function config_from(chunks::Vector{String}, N)
 end
 chunks_hex(C) = [string(c, base = 16, pad = 16) for c in C.s.chunks]
 
+# rand_move of a DeltaECache (src/DeltaE.jl:146-167) with its two draws taken from the tape: u1 = the rand() of the class pick, u2 = the
+# 64 random bits behind rand(1:t) of the member pick (src/ArraySets.jl:83).  The one restated piece of the reference that both the
+# GraphQuant and the GraphRRG replays share.
+function rand_move(cache, u1, u2)
+    ΔElist, ascache, T, z = cache.ΔElist, cache.ascache, cache.T, cache.z
+    L = length(ΔElist)
+    r = u1 * z
+    k = 0
+    cT = 0.0
+    for outer k = 1:2L
+        cT += T[k]
+        r < cT && break
+    end
+    r < cT || while T[k] == 0
+        k -= 1
+    end
+    ΔE = k ≤ L ? -ΔElist[k] : ΔElist[k - L]
+    as = ascache[k]
+    return as.v[Int((UInt128(u2) * as.t) >> 64) + 1], ΔE
+end
+
 function replay_standardMC(t)
     N, K = parse(Int, t["N"]), parse(Int, t["K"])
     β, iters, step = parse(Float64, t["beta"]), parse(Int, t["iters"]), parse(Int, t["step"])
@@ -94,24 +115,6 @@ function replay_rrrMC_quant(t)
     ucls, uacc = parse.(Float64, t["u_class"]), parse.(Float64, t["u_accept"])
     umem = parse.(UInt64, t["u_member"])
     accept(c, x, u) = (c ≥ 1 && x ≥ 0) || (a = c * exp(x); a ≥ 1 || u < a)           # src/RRRMC.jl:40-44
-    function rand_move(cache, u1, u2)                                                  # src/DeltaE.jl:146-167
-        ΔElist, ascache, T, z = cache.ΔElist, cache.ascache, cache.T, cache.z
-        L = length(ΔElist)
-        r = u1 * z
-        k = 0
-        cT = 0.0
-        for outer k = 1:2L
-            cT += T[k]
-            r < cT && break
-        end
-        r < cT || while T[k] == 0
-            k -= 1
-        end
-        ΔE = k ≤ L ? -ΔElist[k] : ΔElist[k - L]
-        as = ascache[k]
-        move = as.v[Int((UInt128(u2) * as.t) >> 64) + 1]                               # rand(1:t), src/ArraySets.jl:83
-        return move, ΔE
-    end
     Es = Float64[]
     E = energy(X, C)
     X0 = inner_graph(X)
@@ -312,23 +315,6 @@ function replay_rrr_bkl_rrg(t)
     X = RRRMC.RRG.GraphRRG{Int,(-1, 1),K}(A, J)
     C = config_from(t["C0"], N)
     ucls, umem = parse.(Float64, t["u_class"]), parse.(UInt64, t["u_member"])
-    function rand_move(cache, u1, u2)                                                  # src/DeltaE.jl:146-167
-        ΔElist, ascache, T, z = cache.ΔElist, cache.ascache, cache.T, cache.z
-        L = length(ΔElist)
-        r = u1 * z
-        k = 0
-        cT = 0.0
-        for outer k = 1:2L
-            cT += T[k]
-            r < cT && break
-        end
-        r < cT || while T[k] == 0
-            k -= 1
-        end
-        ΔE = k ≤ L ? -ΔElist[k] : ΔElist[k - L]
-        as = ascache[k]
-        return as.v[Int((UInt128(u2) * as.t) >> 64) + 1], ΔE                           # rand(1:t), src/ArraySets.jl:83
-    end
     Es = Int[]
     E = energy(X, C)
     accepted, staged_its, it = 0, 0, 0
@@ -501,6 +487,6 @@ function main(paths)
     exit(allok ? 0 : 1)
 end
 
-main(isempty(ARGS) ? [joinpath(@__DIR__, "..", "tests", "golden", f) for f in
+main(isempty(ARGS) ? [joinpath(@__DIR__, "golden", f) for f in
                       ("tape_rrg_n128.txt", "tape_quant_nk16_m4.txt", "tape_quant_direct.txt", "tape_ea_l2_d3.txt", "tape_skn_n24.txt",
                        "tape_sk_n10.txt", "tape_rrr_skn_n10.txt", "tape_rrr_rrg_n64.txt", "tape_bkl_rrg_n64.txt", "tape_wtm_rrg_n64.txt", "tape_eo_rrg_n64.txt", "tape_rrgn_n16.txt", "tape_rrr_rrgn_n64.txt")] : ARGS)

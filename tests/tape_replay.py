@@ -3,9 +3,9 @@
 A *tape* (tests/golden/tape_*.txt, written by tests/golden/make_tapes.py) holds a graph, a start configuration and every random
 draw of a run, pre-drawn: sites and acceptance uniforms for standardMC, (class uniform, member word, acceptance uniform) for
 rrrMC.  With the draws fixed the reference's loop is a deterministic function of its own graph code, so the same tape can be
-replayed (a) here, statement by statement after the Julia sources cited below, (b) by julia/replay_tape.jl through the reference's
+replayed (a) here, statement by statement after the Julia sources cited below, (b) by tests/replay_tape.jl through the reference's
 OWN functions wherever Julia and RRRMC.jl exist, (c) by the HIP library (tests/test_tapes.py).  The functions mirror
-julia/replay_tape.jl line by line; indices are 1-based as in the tape."""
+tests/replay_tape.jl line by line; indices are 1-based as in the tape."""
 import math
 
 

@@ -5,7 +5,7 @@
     again on the tape's inputs reproduces it too (drift check); the Ising1D closed forms (src/graphs/Ising1D.jl) are a known-answer
     test of the tape format's bit layout and of delta_energy bookkeeping.
   * GPU: the HIP library, seeded like the tape, produces the tape's expected results.
-  * Anywhere Julia + RRRMC.jl exist: `julia julia/replay_tape.jl` replays the same files through the reference itself."""
+  * Anywhere Julia + RRRMC.jl exist: `julia tests/replay_tape.jl` replays the same files through the reference itself."""
 import os
 
 import numpy as np
