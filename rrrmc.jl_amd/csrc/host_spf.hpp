@@ -63,6 +63,7 @@ SpfParams spf_params(rrrmc_ctx* ctx)
 typedef void (*spf_fn)(SpfParams);
 spf_fn spf_sweep_for_K(int K) { RRRMC_DISPATCH_UPTO8(K, spf_sweep_kernel) }
 spf_fn spf_energy_for_K(int K) { RRRMC_DISPATCH_UPTO8(K, spf_energy_kernel) }
+spf_fn spf_fields_for_K(int K) { RRRMC_DISPATCH_UPTO8(K, spf_fields_kernel) }
 
 // spf_team_kernel (spf_team_kernel.hpp): a team of wavefronts per group of 64 replicas.  Sixteen wavefronts (fifteen executing) while the
 // records of K + 1 fields per slot fit the LDS and the groups are few enough to own a compute unit each; eight otherwise.
@@ -103,7 +104,13 @@ inline bool spf_use_team(const rrrmc_ctx* ctx)
 
 int32_t spf_run_energy(rrrmc_ctx* ctx)
 {
-    hipLaunchKernelGGL(spf_energy_for_K((int)ctx->K), dim3((unsigned)ctx->pfW), dim3(64), 0, ctx->stream, spf_params(ctx));
+    if (const char* e = std::getenv("RRRMC_SPF_ENERGY_V1"); e && e[0] == '1') {           // tests: one wavefront per group walks the sites
+        hipLaunchKernelGGL(spf_energy_for_K((int)ctx->K), dim3((unsigned)ctx->pfW), dim3(64), 0, ctx->stream, spf_params(ctx));
+    } else {
+        hipLaunchKernelGGL(spf_fields_for_K((int)ctx->K), dim3((unsigned)(((ctx->N + 3) / 4) * ctx->pfW)), dim3(256), 0, ctx->stream, spf_params(ctx));
+        HIP_TRY(ctx, hipGetLastError());
+        hipLaunchKernelGGL(spf_energy_sum_kernel, dim3((unsigned)ctx->pfW), dim3(64), 0, ctx->stream, spf_params(ctx));
+    }
     HIP_TRY(ctx, hipGetLastError());
     ctx->pf_lf_live = true;
     return RRRMC_OK;

@@ -99,6 +99,48 @@ __global__ __launch_bounds__(64) void spf_energy_kernel(SpfParams P)
     P.move_last[r] = -1;
 }
 
+// The same in two steps for calls that are short beside it (round 4: one wavefront per group walking all N sites took 1.0 ms at N = 4096,
+// 8 % of a 2^16-iteration call of spf_team_kernel): the fields of all sites side by side, then the energy as the reference's sequential sum.
+// lfields[x] = 2 lf is exact, so lf = lfields[x] / 2 is the summand of RRG.jl:546-574 bit for bit.
+// grid W * ceil(N / 4) (one dimension: W may exceed the 65 536 blocks of the others), block 256: one wavefront per site
+template <int K>
+__global__ __launch_bounds__(256) void spf_fields_kernel(SpfParams P)
+{
+    const int N = P.N, nb = (N + 3) / 4;
+    const int lane = threadIdx.x & 63, w = (int)(blockIdx.x / (unsigned)nb), x = (int)(blockIdx.x % (unsigned)nb) * 4 + (int)(threadIdx.x >> 6);
+    if (x >= N) return;
+    const unsigned long long* sp = P.spins + (size_t)w * N;
+    const int sx = 2 * (int)((sp[x] >> lane) & 1ull) - 1;
+    double f = 0.0;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const int y = P.A[(size_t)x * K + k];
+        const int sy = 2 * (int)((sp[y] >> lane) & 1ull) - 1;
+        f = __dadd_rn(f, -__dmul_rn(__dmul_rn(P.J[(size_t)x * K + k], (double)sx), (double)sy));
+    }
+    P.lf[((size_t)w * N + x) * 64 + lane] = __dmul_rn(2.0, f);
+}
+
+// grid W, block 64
+__global__ __launch_bounds__(64) void spf_energy_sum_kernel(SpfParams P)
+{
+    const int lane = threadIdx.x, w = blockIdx.x, N = P.N;
+    const int r = w * 64 + lane;
+    const double* lf = P.lf + (size_t)w * N * 64 + lane;
+    double E1 = 0.0;
+    int x = 0;
+    for (; x + 8 <= N; x += 8) {
+        double v[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = lf[(size_t)(x + q) * 64];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) E1 = __dadd_rn(E1, __dmul_rn(v[q], 0.5));
+    }
+    for (; x < N; ++x) E1 = __dadd_rn(E1, __dmul_rn(lf[(size_t)x * 64], 0.5));
+    P.E_cur[r] = __dmul_rn(E1, 0.5);
+    P.move_last[r] = -1;
+}
+
 // One wavefront = 64 replicas.  Everything an iteration needs is requested ahead of time:
 //   local field of the attempted site          kSpfDepth iterations ahead  (pre[])
 //   neighbour table row (A, J: scalar loads)   kSpfNb + 1 iterations ahead (staging SGPRs)

@@ -132,3 +132,24 @@ def test_lattice_with_six_neighbours_and_many_groups(pkg, oracle, monkeypatch):
     for r in (0, 12345, R - 1):
         ref = oracle.standard_mc_spf(X.A, X.J, beta, iters, step, seed, C0[r], replica=r, form="ea")
         assert (Es[r] == ref[0]).all() and (C1[r] == ref[1]).all() and acc[r] == ref[2] and (lf1[r] == ref[3]).all()
+
+
+@pytest.mark.parametrize("kind,a,b", [("rrg", 4096, 3), ("rrg", 30, 5), ("ea", 2, 3), ("ea", 6, 3), ("rrg", 7, 2)])
+def test_two_step_energy_equals_the_walk(pkg, oracle, monkeypatch, kind, a, b):
+    """energy (RRG.jl:546-574 / EA.jl:584-611) at the start of every call: the fields of all sites side by side and the reference's
+    sequential sum behind them (spf_fields_kernel + spf_energy_sum_kernel) against one wavefront per group walking the sites
+    (spf_energy_kernel, RRRMC_SPF_ENERGY_V1=1) and against the oracle — energies and the field cache bit for bit, doubled bonds included."""
+    seed, R = 4000 + a + b, 200
+    X = pkg.GraphRRGNormal(a, b, seed=seed) if kind == "rrg" else pkg.GraphEANormal(a, b, seed=seed)
+    outs = []
+    for v1 in ("0", "1"):
+        monkeypatch.setenv("RRRMC_SPF_ENERGY_V1", v1)
+        with pkg.Engine(X, R) as eng:
+            eng.seed(seed)
+            eng.init_spins_random()
+            C0 = eng.get_config().s.copy()
+            outs.append((eng.energy(), eng.fields()))
+    assert (outs[0][0] == outs[1][0]).all() and (outs[0][1] == outs[1][1]).all()
+    for r in (0, 63, 64, R - 1):
+        e0, f0 = oracle.spf_energy(X.A, X.J, C0[r], want_fields=True, form=kind)
+        assert outs[0][0][r] == e0 and (outs[0][1][r] == f0).all()
