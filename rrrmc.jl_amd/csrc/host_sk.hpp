@@ -186,8 +186,9 @@ int32_t sk_run_energy(rrrmc_ctx* ctx)
         HIP_TRY(ctx, hipGetLastError());
         return RRRMC_OK;
     }
-    hipLaunchKernelGGL(sk_fields_kernel, grid, dim3(256), 0, ctx->stream, ctx->sk_J, ctx->sk_spins, ctx->sk_lf, ctx->sk_lfl,
-                       ctx->sk_move_last, (int)ctx->N);
+    // one thread per site with the 8 replicas in registers; the debug check below recomputes with the one-chain-per-thread kernel
+    hipLaunchKernelGGL(sk_fields8_kernel, dim3((unsigned)((ctx->N + 255) / 256), (unsigned)ctx->G8), dim3(256), 0, ctx->stream, ctx->sk_J, ctx->sk_spins,
+                       ctx->sk_lf, ctx->sk_lfl, ctx->sk_move_last, (int)ctx->N);
     HIP_TRY(ctx, hipGetLastError());
     hipLaunchKernelGGL(sk_energy_kernel, dim3((unsigned)((ctx->Rpad + 63) / 64)), dim3(64), 0, ctx->stream, ctx->sk_lf, ctx->sk_E,
                        (int)ctx->N, (int)ctx->Rpad);

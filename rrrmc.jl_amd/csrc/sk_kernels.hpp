@@ -354,6 +354,37 @@ __global__ __launch_bounds__(256) void sk_fields_kernel(const double* __restrict
     if (i == 0) move_last[grp * kSkRB + r] = -1;
 }
 
+// The same fields with one thread per SITE and the 8 replicas of the group in registers (round 4: the kernel above is one dependent chain of
+// N additions per thread and took 1.4 ms at N = 1024, 2048 replicas — a quarter of a 16 384-iteration call of sk_hblock_kernel): eight
+// independent chains per thread, one coalesced load of J and one byte of spins (the same for the whole workgroup) per j, the sign applied
+// to the high word.  Every (site, replica) still sums over j in the reference's order (SK.jl:212-237).  grid (ceil(N / 256), G8), block 256
+__global__ __launch_bounds__(256) void sk_fields8_kernel(const double* __restrict__ J, const uint8_t* __restrict__ spins,
+                                                         double* __restrict__ lf, double* __restrict__ lfl,
+                                                         int32_t* __restrict__ move_last, int N)
+{
+    const int grp = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
+    const uint8_t* sp = spins + (size_t)grp * N;
+    if (blockIdx.x == 0 && threadIdx.x < kSkRB) move_last[grp * kSkRB + threadIdx.x] = -1;
+    if (i >= N) return;
+    const uint32_t si = sp[i];
+    double acc[kSkRB];
+#pragma unroll
+    for (int r = 0; r < kSkRB; ++r) acc[r] = 0.0;
+#pragma unroll 4
+    for (int j = 0; j < N; ++j) {
+        const uint32_t x = si ^ (uint32_t)sp[j];                 // bit r: the spins of i and j differ in replica r
+        const double Jij = J[(size_t)j * N + i];                 // = J[i][j]: symmetric, read transposed for coalescing
+        const unsigned long long jb = (unsigned long long)__double_as_longlong(Jij);
+#pragma unroll
+        for (int r = 0; r < kSkRB; ++r)
+            acc[r] += __longlong_as_double((long long)(jb ^ ((unsigned long long)((x >> r) & 1u) << 63)));      // (1 - 2 (si xor sj)) * Ji[j]
+    }
+    double* o = lf + ((size_t)grp * N + i) * kSkRB;
+    double* ol = lfl + ((size_t)grp * N + i) * kSkRB;
+#pragma unroll
+    for (int r = 0; r < kSkRB; ++r) { o[r] = 2 * acc[r]; ol[r] = 0.0; }
+}
+
 __global__ __launch_bounds__(64) void sk_energy_kernel(const double* __restrict__ lf, double* __restrict__ E_out, int N, int Rp)
 {
     const int rep = blockIdx.x * 64 + threadIdx.x;
