@@ -6,7 +6,7 @@ TAG=${1:-r01}
 OUT=$PWD/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
-ARGS="bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-secondary --no-verify"
+ARGS="bench.py --steps ${PROFILE_STEPS:-3} --warmup ${PROFILE_WARMUP:-1} --no-cpu-baseline --no-secondary --no-verify"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 $ARGS > "$OUT/bench_trace.log" 2>&1
 # PMC passes: separate runs, no trace domains (gpurun rule); TCC slots: FETCH_SIZE=3, WRITE_SIZE=2
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -- python3 $ARGS > "$OUT/bench_pmc1.log" 2>&1
