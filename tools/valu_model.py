@@ -144,7 +144,7 @@ def main():
     os.makedirs(PROF, exist_ok=True)
     json.dump(model, open(os.path.join(PROF, "valu_model.json"), "w"), indent=1)
     traffic = {"hbm_bytes_per_launch": (2 * P["FETCH_SIZE_KB"] + P["WRITE_SIZE_KB"]) * 1024.0,
-               "source": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes) of `bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-secondary`, " \
+               "source": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes) of `bench.py --no-cpu-baseline --no-secondary --no-verify` through tools/profile_gpu.sh (round 4: --steps 20 --warmup 5, the driver's counts; earlier rounds --steps 3 --warmup 1), " \
                          + os.path.relpath(prof_file(SUMMARY), ROOT) + "; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 tallies 128-B requests at 64 B); counters are in KiB"}
     traffic.update(provenance())
     json.dump(traffic, open(os.path.join(PROF, "traffic.json"), "w"), indent=1)
