@@ -309,6 +309,15 @@ __global__ __launch_bounds__(NW * 64) void spf_team_kernel(SpfTeamParams TP)
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, SPF_TEAM_SCOPE);
             SPF_STAMP(1);                                           // waiting for the dependency / the slot
 
+#ifdef SPF_TEAM_EXP_NOMEM
+            // timing experiment (tools/ubench/spf_team_bench.hip; wrong results): no global memory traffic at all — what the protocol alone costs
+            const double lfi = 0.25 * (double)((lane + i) & 7) - 1.0;
+            const unsigned long long wi = 0x5555aaaa5555aaaaull;
+            double nf[K];
+            unsigned long long nw[K];
+#pragma unroll
+            for (int k = 0; k < K; ++k) { nf[k] = 0.5 * k; nw[k] = 0x3333cccc3333ccccull + (unsigned long long)y[k]; }
+#else
             const double lfi = lf[(size_t)i * 64];
             const unsigned long long wi = spf_load_spins(sp + i);
             double nf[K];
@@ -318,6 +327,7 @@ __global__ __launch_bounds__(NW * 64) void spf_team_kernel(SpfTeamParams TP)
                 nf[k] = lf[(size_t)y[k] * 64];
                 nw[k] = spf_load_spins(sp + y[k]);
             }
+#endif
             int32_t ml = spf_lds_ld(mlr + lane);
             const int32_t src0 = spf_lds_ld(rsrc + lane);          // may be stale by the time it is used: see the evacuation below
 
@@ -376,7 +386,11 @@ __global__ __launch_bounds__(NW * 64) void spf_team_kernel(SpfTeamParams TP)
                 }
             }
 
+#ifdef SPF_TEAM_EXP_NOMEM
+            if (amask == 0xdeadbeefull) {
+#else
             if (amask != 0ull) {
+#endif
                 // update_cache! (RRG.jl:576-617, EA.jl:613-653).  Full 512-byte lines: lanes that do not accept write back what they read
                 const uint32_t snew = (uint32_t)((wi >> lane) & 1ull) ^ 1u;
 #pragma unroll
