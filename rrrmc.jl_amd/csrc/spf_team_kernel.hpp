@@ -123,7 +123,7 @@ __global__ __launch_bounds__(NW * 64) void spf_team_kernel(SpfTeamParams TP)
 {
     constexpr int NX = NW - 1;
     constexpr int M = 2 * NX * D;                     // slots = attempts in flight at most
-    static_assert(M <= kSpfTeamWindow && M <= 64, "the dependency window covers the attempts in flight; one wavefront read brings all flags");
+    static_assert(M <= kSpfTeamWindow && M < 64, "the dependency window covers the attempts in flight; one wavefront read brings all flags");
     const SpfParams& P = TP.S;
     extern __shared__ __attribute__((aligned(16))) unsigned char spf_team_lds[];
     typedef double slot_t[K + 1][64];
@@ -179,12 +179,17 @@ __global__ __launch_bounds__(NW * 64) void spf_team_kernel(SpfTeamParams TP)
         int32_t f = spf_lds_ld(done + (lane < M ? lane : 0));
         while (it <= n32) {
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");        // compiler barrier: the data reads stay behind the flag read
-            int ready = 0, sj[B];
+            // which slots hold the attempt they are due to hold: one compare over the lanes, then the run of set bits from s0 (with wrap-around)
+            int ready, sj[B];
+            {
+                int d = lane - s0;
+                d += d < 0 ? M : 0;
+                const unsigned long long m = __builtin_amdgcn_ballot_w64(lane < M && f == it + d && it + d <= n32);
+                const unsigned long long rot = ((m >> s0) | (m << (M - s0))) & ((1ull << M) - 1ull);      // bit j: slot (s0 + j) mod M
+                ready = __builtin_ctzll(~rot);
+                ready = ready > B ? B : ready;
 #pragma unroll
-            for (int j = 0; j < B; ++j) {
-                sj[j] = s0 + j >= M ? s0 + j - M : s0 + j;
-                const bool ok = it + j <= n32 && __builtin_amdgcn_readlane(f, sj[j]) == it + j;
-                ready = (ready == j && ok) ? j + 1 : ready;
+                for (int j = 0; j < B; ++j) sj[j] = s0 + j >= M ? s0 + j - M : s0 + j;
             }
 #ifdef SPF_TEAM_STAMPS
             ++rt_rounds; if (ready == 0) ++rt_idle;
