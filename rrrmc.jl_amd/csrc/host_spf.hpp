@@ -92,12 +92,11 @@ inline int spf_team_waves(const rrrmc_ctx* ctx)
     }
     return ctx->pfW <= 256 && ctx->K <= 5 ? 16 : 8;
 }
-// The team kernel is the default; spf_sweep_kernel (one wavefront per group) stays for graphs with repeated neighbours in a row
-// (GraphEANormal with L = 2: two bonds to the same site share one field, update_cache! EA.jl:626-640) and as the cross-check of the tests
-// (RRRMC_SPF_TEAM=0).
+// The team kernel is the default (graphs with two bonds to the same neighbour included: GraphEANormal with L = 2); spf_sweep_kernel (one
+// wavefront per group) stays as the cross-check of the tests (RRRMC_SPF_TEAM=0).
 inline bool spf_use_team(const rrrmc_ctx* ctx)
 {
-    if (ctx->pf_multi_edge) return false;
+    (void)ctx;
     const char* e = std::getenv("RRRMC_SPF_TEAM");
     return !(e && e[0] == '0');
 }

@@ -26,7 +26,7 @@
 //     its own keep area and swings the replica's source over by compare-and-swap.
 // No wavefront ever waits for a later attempt, every wait is on the retired prefix, so the scheme cannot deadlock; everything a caller can see
 // (fields, spins, undo records, move_last, energies, samples, accepted counts) is bit-identical to spf_sweep_kernel and the oracle
-// (tests/test_gpu_spf_parity.py runs both kernels).
+// (tests/test_gpu_spf_parity.py runs every case — two bonds to the same neighbour included — through both kernels).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -398,11 +398,16 @@ __global__ __launch_bounds__(NW * 64) void spf_team_kernel(SpfTeamParams TP)
 #endif
                 // update_cache! (RRG.jl:576-617, EA.jl:613-653).  Full 512-byte lines: lanes that do not accept write back what they read
                 const uint32_t snew = (uint32_t)((wi >> lane) & 1ull) ^ 1u;
+                double vrun = 0.0;
 #pragma unroll
                 for (int k = 0; k < K; ++k) {
+                    // two bonds to the same neighbour (GraphEANormal with L = 2; rows are sorted): the second one continues from the first one's
+                    // result (EA.jl:626-640 walks all entries), and its store — same wavefront, same address, in order — is the one that stays
+                    const bool rep = k > 0 && y[k] == y[k - 1];                  // wave-uniform
                     const uint32_t sbit = (uint32_t)((nw[k] >> lane) & 1ull);
                     const double c = (snew ^ sbit) ? -4.0 : 4.0;                 // 4 * sigma_xy with the NEW s_x
-                    const double v = __dadd_rn(nf[k], -__dmul_rn(c, J[k]));
+                    const double v = __dadd_rn(rep ? vrun : nf[k], -__dmul_rn(c, J[k]));
+                    vrun = v;
                     lf[(size_t)y[k] * 64] = fast ? sv[k] : (slow ? v : nf[k]);
                 }
                 lf[(size_t)i * 64] = acc ? -lfi : lfi;

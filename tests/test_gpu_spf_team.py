@@ -153,3 +153,23 @@ def test_two_step_energy_equals_the_walk(pkg, oracle, monkeypatch, kind, a, b):
     for r in (0, 63, 64, R - 1):
         e0, f0 = oracle.spf_energy(X.A, X.J, C0[r], want_fields=True, form=kind)
         assert outs[0][0][r] == e0 and (outs[0][1][r] == f0).all()
+
+
+@pytest.mark.parametrize("D,beta", [(2, 0.3), (3, 1.0), (4, 0.6)])
+def test_doubled_bonds_through_the_team_kernel(pkg, oracle, monkeypatch, D, beta):
+    """GraphEANormal(2, D): every neighbour is listed twice (two bonds to the same site, EA.jl:158).  update_cache! walks all 2 D entries
+    (EA.jl:626-640), so the second bond's update continues from the first one's result; with 2^D sites nearly every accepted move is
+    followed by an attempt in its neighbourhood, and the undo branch swaps over the UNIQUE neighbours.  All builds, every replica."""
+    seed, R, iters, step = 600 + D, 130, 20000, 333
+    X = pkg.GraphEANormal(2, D, seed=seed)
+    outs = []
+    for env in BUILDS:
+        _set_build(monkeypatch, env)
+        outs.append(_run(pkg, X, R, seed, beta, iters, step))
+    for o in outs[1:]:
+        for u, v in zip(outs[0], o):
+            assert (u == v).all()
+    C0, Es, acc, C1, lf1, Et = outs[0]
+    for r in range(R):
+        ref = oracle.standard_mc_spf(X.A, X.J, beta, iters, step, seed, C0[r], replica=r, form="ea")
+        assert (Es[r] == ref[0]).all() and (C1[r] == ref[1]).all() and acc[r] == ref[2] and (lf1[r] == ref[3]).all()
