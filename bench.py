@@ -481,6 +481,35 @@ def secondary_f64_exact(pkg, O, device):
     return out
 
 
+def secondary_f64_exact_big(pkg, O, device):
+    """The same kernel where it is bound by HBM: 262 144 replicas of GraphRRGNormal(N=4096, K=3) — 8.6 GB of Float64 fields, every attempt
+    reads and writes the K + 1 field lines of its site whole.  The traffic per attempt is the committed rocprofv3 measurement of this shape."""
+    N, K, R, beta, iters, step = 4096, 3, 262144, 1.0, 1 << 14, 1 << 12
+    X = pkg.GraphRRGNormal(N, K, seed=SEED)
+    with pkg.Engine(X, R, device=device) as eng:
+        eng.seed(SEED)
+        eng.init_spins_random()
+        eng.standard_mc_async(beta, iters // 4, step); eng.sync()
+        t0 = time.perf_counter()
+        eng.standard_mc_async(beta, iters, step); eng.sync()
+        dt = time.perf_counter() - t0
+        _, k_ms, nl = eng.last_timing()
+        _, acc = eng.fetch_results(want_energies=False)
+    a = float(acc.mean()) / iters
+    bpa = 8 + a * (10 + 17 * K)
+    out = {"workload": "GraphRRGNormal(N=4096,K=3) standardMC (exact mode) beta=1.0, 262144 replicas, 2^14 iterations per replica, energy sample every 4096",
+           "value": R * iters / dt, "unit": "attempts/s", "kernel": "spf_team_kernel<3, 8, 1>", "avg_launch_ms": k_ms / max(nl, 1), "launches": nl,
+           "acceptance": a, "algorithmic_bytes_per_attempt": bpa, "achieved_GBps": bpa * R * iters / (k_ms * 1e-3) / 1e9}
+    out["frac"] = out["achieved_GBps"] / HBM_PEAK_GBS
+    tf, tf_path, _ = load_profile_json("spf_traffic.json")
+    big = (tf or {}).get("at_262144_replicas")
+    if big:
+        gbps = big["measured_bytes_per_attempt"] * R * iters / (k_ms * 1e-3) / 1e9
+        out["traffic"] = {"measured_bytes_per_attempt": big["measured_bytes_per_attempt"], "hbm_GBps_at_this_rate": gbps, "frac_of_hbm_peak": gbps / HBM_PEAK_GBS,
+                          "source": "%s at_262144_replicas (committed rocprofv3 FETCH_SIZE x2 + WRITE_SIZE pass of this shape, commit %s; not measured in this run)" % (tf_path, tf.get("git_commit"))}
+    return out
+
+
 def secondary_f8_rrr(pkg, O, device):
     """SURVEY.md §8f rank 1 at the reference's experiment size (scripts/scripts.jl:23 test_RRG): rrrMC(X::SingleGraph) on GraphRRG(10^4, 3),
     beta = 2, thread-per-replica kernel (rrr_sparse_kernel: DeltaECache{Int,2} + ArraySets per replica in HBM/L2)."""
@@ -518,7 +547,7 @@ def secondary(pkg, O, device):
     out = {}
     for name, fn in (("c3_sk_normal", secondary_c3), ("c4_ea_checkerboard", secondary_c4), ("c4_ea_random_site", secondary_c4_random),
                      ("c5_quant_rrr", secondary_c5),
-                     ("f64_sparse_exact", secondary_f64_exact), ("f64_sparse_fast", secondary_f64_fast), ("f8_rrr_rrg_1e4", secondary_f8_rrr)):
+                     ("f64_sparse_exact", secondary_f64_exact), ("f64_sparse_exact_262144", secondary_f64_exact_big), ("f64_sparse_fast", secondary_f64_fast), ("f8_rrr_rrg_1e4", secondary_f8_rrr)):
         t0 = time.perf_counter()
         try:
             out[name] = fn(pkg, O, device)
