@@ -94,3 +94,28 @@ def test_multi_context_errors(pkg):
         with pytest.raises(pkg.RRRMCError) as e:                # an error of a child comes back with the shard it happened on
             m.standard_mc_async(1.0, -5, 1)
         assert "device 0" in str(e.value)
+
+
+def test_float64_sparse_multi_equals_single_and_oracle(pkg, oracle):
+    """GraphRRGNormal through one context over several shards: every shard runs its own teams of wavefronts (csrc/spf_team_kernel.hpp) over
+    its own plan table; shards of 64 / 66 and 32 / 32 / 66 replicas, i.e. groups whose upper lanes are padding, in every shard."""
+    seed, N, K, R, beta, iters, step = 977, 300, 3, 130, 1.1, 9000, 700
+    X = pkg.GraphRRGNormal(N, K, seed=seed)
+    with pkg.Engine(X, R) as eng:
+        eng.seed(seed); eng.init_spins_random()
+        C0 = eng.get_config().s.copy()
+        E0 = eng.energy(); lf0 = eng.fields()
+        Es, acc = eng.standard_mc(beta, iters, step)
+        Es2, acc2 = eng.standard_mc(beta, iters // 3, step)
+        C1, lf1 = eng.get_config().s.copy(), eng.fields()
+    for devs in devices_for_test(pkg):
+        with pkg.Engine(X, R, devices=devs) as m:
+            m.seed(seed); m.init_spins_random()
+            assert (m.get_config().s == C0).all() and (m.energy() == E0).all() and (m.fields() == lf0).all()
+            mEs, macc = m.standard_mc(beta, iters, step)
+            mEs2, macc2 = m.standard_mc(beta, iters // 3, step)
+            assert (mEs == Es).all() and (macc == acc).all() and (mEs2 == Es2).all() and (macc2 == acc2).all()
+            assert (m.get_config().s == C1).all() and (m.fields() == lf1).all()
+    for r in (0, 63, 64, 129):
+        ref = oracle.standard_mc_spf(X.A, X.J, beta, iters, step, seed, C0[r], replica=r)
+        assert (Es[r] == ref[0]).all() and acc[r] == ref[2]
