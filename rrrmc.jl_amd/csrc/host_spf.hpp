@@ -90,7 +90,7 @@ inline int spf_team_waves(const rrrmc_ctx* ctx)
         const int nw = e[0] == '8' ? 8 : 16;
         if (spf_team_lds_bytes((int)ctx->K, nw, 1) <= (size_t)160 * 1024) return nw;
     }
-    return ctx->pfW <= 256 && ctx->K <= 5 ? 16 : 8;
+    return ctx->pfW <= 256 && spf_team_lds_bytes((int)ctx->K, 16, 1) <= (size_t)160 * 1024 ? 16 : 8;
 }
 // The team kernel is the default (graphs with two bonds to the same neighbour included: GraphEANormal with L = 2); spf_sweep_kernel (one
 // wavefront per group) stays as the cross-check of the tests (RRRMC_SPF_TEAM=0).
@@ -151,6 +151,10 @@ int32_t spf_standard_mc_async(rrrmc_ctx* ctx, double beta, int64_t iters, int64_
     const size_t tlds = team ? spf_team_lds_bytes((int)ctx->K, nw, 1) : 0;
     if (team) {
         if (!ctx->pf_plan) HIP_TRY(ctx, hipMalloc(&ctx->pf_plan, sizeof(uint32_t) * (size_t)(kSpfTeamItersPerLaunch + 2) * (size_t)spf_plan_stride((int)ctx->K)));
+        if (!ctx->pf_status) {
+            HIP_TRY(ctx, hipMalloc(&ctx->pf_status, sizeof(int32_t)));
+            HIP_TRY(ctx, hipMemsetAsync(ctx->pf_status, 0, sizeof(int32_t), ctx->stream));
+        }
         HIP_TRY(ctx, raise_lds_attr(reinterpret_cast<const void*>(tfn), tlds));
     }
     const int64_t per_launch = team ? kSpfTeamItersPerLaunch : kSpfItersPerLaunch;
@@ -171,7 +175,7 @@ int32_t spf_standard_mc_async(rrrmc_ctx* ctx, double beta, int64_t iters, int64_
         }
         HIP_TRY(ctx, hipEventRecord(ctx->ev_sweep[2 * launches], st));
         if (team) {
-            SpfTeamParams TP{P, ctx->pf_plan};
+            SpfTeamParams TP{P, ctx->pf_plan, ctx->pf_status};
             hipLaunchKernelGGL(tfn, dim3((unsigned)ctx->pfW), dim3((unsigned)(nw * 64)), tlds, st, TP);
         } else {
             hipLaunchKernelGGL(fn, dim3((unsigned)ctx->pfW), dim3(64), 0, st, P);

@@ -208,6 +208,7 @@ struct rrrmc_ctx {
     double* pf_undo = nullptr;     // [W][K+1][64]: live part of lfields_last (see spf_kernels.hpp)
     int32_t* pf_sites = nullptr;   // site stream of one launch
     uint32_t* pf_plan = nullptr;   // spf_team_kernel: the attempts of one launch (spf_team_kernel.hpp), allocated at its first use
+    int32_t* pf_status = nullptr;  // spf_team_kernel: set by a launch whose wait ran into its limit (checked by rrrmc_sync)
     int64_t pfW = 0;
     bool pf_multi_edge = false;    // some row of A repeats a neighbour (GraphEANormal with L = 2): the wave build of the continuous samplers is not used
     bool pf_lf_live = false;       // sk_lf holds the local fields of the current configuration (false after the continuous samplers)
@@ -800,7 +801,7 @@ void rrrmc_ctx_destroy(rrrmc_ctx* ctx)
     free_dev(ctx->q_T); free_dev(ctx->q_z); free_dev(ctx->q_accrate); free_dev(ctx->q_stats);
     free_dev(ctx->rs_buf); free_dev(ctx->rs_spins); free_dev(ctx->rs_status);
     free_dev(ctx->rp_spins); free_dev(ctx->rp_cls); free_dev(ctx->rp_sv); free_dev(ctx->rp_spos);
-    free_dev(ctx->pf_J); free_dev(ctx->pf_spins); free_dev(ctx->pf_undo); free_dev(ctx->pf_sites); free_dev(ctx->pf_plan);
+    free_dev(ctx->pf_J); free_dev(ctx->pf_spins); free_dev(ctx->pf_undo); free_dev(ctx->pf_sites); free_dev(ctx->pf_plan); free_dev(ctx->pf_status);
     free_dev(ctx->db_dJ); free_dev(ctx->db_rJ); free_dev(ctx->db_cls); free_dev(ctx->db_sv); free_dev(ctx->db_spos); free_dev(ctx->db_lf); free_dev(ctx->db_undo); free_dev(ctx->db_mlast);
     free_dev(ctx->pff_table); free_dev(ctx->pff_absJ); free_dev(ctx->pff_bond_off); free_dev(ctx->pff_thr_hi); free_dev(ctx->pff_thr_lo); free_dev(ctx->pff_flags);
     free_dev(ctx->wt_t); free_dev(ctx->wt_id); free_dev(ctx->wt_pos); free_dev(ctx->wt_time);
@@ -1343,6 +1344,16 @@ int32_t rrrmc_sync(rrrmc_ctx* ctx)
         if (fl[0])
             return fail(ctx, RRRMC_ERR_STATE, "debug check failed for %d value(s), e.g. replica %d: the tracked energy / cached fields differ from "
                                               "energy(X, C) recomputed from the configuration (src/graphs/RRG.jl:229-231, SK.jl:268-273)", fl[0], fl[1]);
+    }
+    if (ctx->model == RRRMC_MODEL_SPARSE_F64 && ctx->pf_status && !ctx->last_call_rrr) {
+        int32_t st = 0;
+        HIP_TRY(ctx, hipMemcpy(&st, ctx->pf_status, sizeof st, hipMemcpyDeviceToHost));
+        if (st) {
+            HIP_TRY(ctx, hipMemset(ctx->pf_status, 0, sizeof st));
+            ctx->results_valid = false; ctx->std_cache_live = false; ctx->pf_lf_live = false;
+            return fail(ctx, RRRMC_ERR_STATE, "spf_team_kernel: a wait on the retired prefix ran into its limit (protocol failure); the call's results are void. "
+                                              "RRRMC_SPF_TEAM=0 selects the single-wavefront kernel");
+        }
     }
     if (ctx->last_call_rrr && (ctx->model == RRRMC_MODEL_SK_NORMAL || ctx->model == RRRMC_MODEL_SPARSE_F64) && ctx->rs_status) {
         std::vector<int32_t> stt((size_t)ctx->R);

@@ -160,6 +160,7 @@ int main(int argc, char** argv)
     hipLaunchKernelGGL(energy, dim3(W), dim3(64), 0, 0, params(sb));
     CK(hipDeviceSynchronize());
 
+    int32_t* d_status; CK(hipMalloc(&d_status, sizeof(int32_t))); CK(hipMemset(d_status, 0, sizeof(int32_t)));
     hipEvent_t e0, e1, e2;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1)); CK(hipEventCreate(&e2));
     uint64_t g0 = 0;
@@ -170,7 +171,7 @@ int main(int argc, char** argv)
         hipLaunchKernelGGL(spf_team_plan_kernel, dim3((unsigned)((n + 2 + 255) / 256)), dim3(256), 0, 0, dA, dJ, sites, deps, n, K);
         SpfParams Pa = params(sa), Pb = params(sb);
         Pa.g0 = Pb.g0 = g0; Pa.iters = Pb.iters = n; Pa.it_off = Pb.it_off = off; Pa.sample0 = Pb.sample0 = off / step;
-        SpfTeamParams TP{Pb, deps};
+        SpfTeamParams TP{Pb, deps, d_status};
         CK(hipEventRecord(e0, 0));
         hipLaunchKernelGGL(sweep, dim3(W), dim3(64), 0, 0, Pa);
         CK(hipEventRecord(e1, 0));
@@ -182,6 +183,7 @@ int main(int argc, char** argv)
         g0 += (uint64_t)n; off += n;
         printf("launch %d: %lld iterations x %d replicas  sweep %.3f ms (%.3e attempts/s)  team %.3f ms (%.3e attempts/s)\n", l, n, W * 64, ma,
                (double)W * 64 * n / (ma * 1e-3), mb, (double)W * 64 * n / (mb * 1e-3));
+        { int32_t hs_ = 0; CK(hipMemcpy(&hs_, d_status, sizeof hs_, hipMemcpyDeviceToHost)); if (hs_) { printf("  ABORTED: a wait ran into its limit\n"); ++bad; } }
         bad += diff(sa.lf, sb.lf, (size_t)W * N * 64, "lfields");
         bad += diff(sa.spins, sb.spins, (size_t)W * N, "spins");
         bad += diff(sa.undo, sb.undo, (size_t)W * (K + 1) * 64, "undo");
