@@ -65,32 +65,27 @@ spf_fn spf_sweep_for_K(int K) { RRRMC_DISPATCH_UPTO8(K, spf_sweep_kernel) }
 spf_fn spf_energy_for_K(int K) { RRRMC_DISPATCH_UPTO8(K, spf_energy_kernel) }
 spf_fn spf_fields_for_K(int K) { RRRMC_DISPATCH_UPTO8(K, spf_fields_kernel) }
 
-// spf_team_kernel (spf_team_kernel.hpp): a team of wavefronts per group of 64 replicas.  Sixteen wavefronts (fifteen executing) while the
-// records of K + 1 fields per slot fit the LDS and the groups are few enough to own a compute unit each; eight otherwise.
+// spf_team_kernel (spf_team_kernel.hpp, launched through spf_team_api.hpp): teams of wavefronts walk the chains of a group of 64 replicas.
+// A chain's pace is bound by what one compute unit moves, so the groups are split into teams of 32 or 16 replicas until there are as many teams
+// as compute units; sixteen wavefronts per team (fifteen executing) while the teams are few enough to own a compute unit each and their
+// records fit its LDS, eight otherwise.
 constexpr int64_t kSpfTeamItersPerLaunch = 1 << 18;     // 2 + 3 K dwords of plan per iteration
-typedef void (*spf_team_fn)(SpfTeamParams);
-template <int NW>
-spf_team_fn spf_team_for_K(int K)
+struct SpfTeamBuild { int nw, tw; size_t lds; };
+inline SpfTeamBuild spf_team_build(const rrrmc_ctx* ctx)
 {
-    switch (K) {
-    case 1: return spf_team_kernel<1, NW, 1>;
-    case 2: return spf_team_kernel<2, NW, 1>;
-    case 3: return spf_team_kernel<3, NW, 1>;
-    case 4: return spf_team_kernel<4, NW, 1>;
-    case 5: return spf_team_kernel<5, NW, 1>;
-    case 6: return spf_team_kernel<6, NW, 1>;
-    case 7: return spf_team_kernel<7, NW, 1>;
-    case 8: return spf_team_kernel<8, NW, 1>;
-    default: return nullptr;
-    }
-}
-inline int spf_team_waves(const rrrmc_ctx* ctx)
-{
-    if (const char* e = std::getenv("RRRMC_SPF_TEAM_WAVES"); e && (e[0] == '8' || (e[0] == '1' && e[1] == '6'))) {        // tests / timing experiments
-        const int nw = e[0] == '8' ? 8 : 16;
-        if (spf_team_lds_bytes((int)ctx->K, nw, 1) <= (size_t)160 * 1024) return nw;
-    }
-    return ctx->pfW <= 256 && spf_team_lds_bytes((int)ctx->K, 16, 1) <= (size_t)160 * 1024 ? 16 : 8;
+    const int K = (int)ctx->K;
+    int ncu = 256;
+    if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, ctx->device) != hipSuccess || ncu < 1) ncu = 256;
+    int tw = 64;
+    while (tw > 16 && ctx->pfW * (64 / tw) < ncu) tw /= 2;
+    int nw = ctx->pfW * (64 / tw) <= ncu ? 16 : 8;
+    // tests / timing experiments: RRRMC_SPF_TEAM_WAVES = 8 | 16, RRRMC_SPF_TEAM_WIDTH = 64 | 32 | 16
+    if (const char* e = std::getenv("RRRMC_SPF_TEAM_WIDTH"); e && (!std::strcmp(e, "64") || !std::strcmp(e, "32") || !std::strcmp(e, "16"))) tw = std::atoi(e);
+    if (const char* e = std::getenv("RRRMC_SPF_TEAM_WAVES"); e && (!std::strcmp(e, "8") || !std::strcmp(e, "16"))) nw = std::atoi(e);
+    if (nw == 8) tw = 64;                                  // the eight-wavefront build exists for whole groups only
+    size_t lds = spf_team_build_lds(K, nw, tw);
+    if (!lds && nw == 16 && tw == 64) { nw = 8; lds = spf_team_build_lds(K, nw, tw); }      // K >= 5: the records of sixteen wavefronts x 64 replicas do not fit
+    return SpfTeamBuild{nw, tw, lds};
 }
 // The team kernel is the default (graphs with two bonds to the same neighbour included: GraphEANormal with L = 2); spf_sweep_kernel (one
 // wavefront per group) stays as the cross-check of the tests (RRRMC_SPF_TEAM=0).
@@ -146,16 +141,14 @@ int32_t spf_standard_mc_async(rrrmc_ctx* ctx, double beta, int64_t iters, int64_
     HIP_TRY(ctx, hipMemsetAsync(ctx->d_acc, 0, sizeof(int64_t) * ctx->Rpad, st));
     spf_fn fn = spf_sweep_for_K((int)ctx->K);
     const bool team = spf_use_team(ctx);
-    const int nw = team ? spf_team_waves(ctx) : 0;
-    spf_team_fn tfn = !team ? nullptr : nw == 16 ? spf_team_for_K<16>((int)ctx->K) : spf_team_for_K<8>((int)ctx->K);
-    const size_t tlds = team ? spf_team_lds_bytes((int)ctx->K, nw, 1) : 0;
+    const SpfTeamBuild tb = team ? spf_team_build(ctx) : SpfTeamBuild{0, 0, 0};
+    if (team && !tb.lds) return fail(ctx, RRRMC_ERR_UNSUPPORTED, "spf_team_kernel has no build for K=%lld", (long long)ctx->K);
     if (team) {
         if (!ctx->pf_plan) HIP_TRY(ctx, hipMalloc(&ctx->pf_plan, sizeof(uint32_t) * (size_t)(kSpfTeamItersPerLaunch + 2) * (size_t)spf_plan_stride((int)ctx->K)));
         if (!ctx->pf_status) {
             HIP_TRY(ctx, hipMalloc(&ctx->pf_status, sizeof(int32_t)));
             HIP_TRY(ctx, hipMemsetAsync(ctx->pf_status, 0, sizeof(int32_t), ctx->stream));
         }
-        HIP_TRY(ctx, raise_lds_attr(reinterpret_cast<const void*>(tfn), tlds));
     }
     const int64_t per_launch = team ? kSpfTeamItersPerLaunch : kSpfItersPerLaunch;
     int64_t done = 0;
@@ -170,13 +163,12 @@ int32_t spf_standard_mc_async(rrrmc_ctx* ctx, double beta, int64_t iters, int64_
         P.beta = beta; P.g0 = ctx->it_done + (uint64_t)done; P.iters = n; P.step = step;
         P.it_off = done; P.sample0 = done / step;
         if (team) {
-            hipLaunchKernelGGL(spf_team_plan_kernel, dim3((unsigned)((n + 2 + 255) / 256)), dim3(256), 0, st, ctx->d_A, ctx->pf_J, ctx->pf_sites, ctx->pf_plan, n, (int)ctx->K);
-            HIP_TRY(ctx, hipGetLastError());
+            HIP_TRY(ctx, spf_team_plan_launch(ctx->d_A, ctx->pf_J, ctx->pf_sites, ctx->pf_plan, n, (int)ctx->K, st));
         }
         HIP_TRY(ctx, hipEventRecord(ctx->ev_sweep[2 * launches], st));
         if (team) {
             SpfTeamParams TP{P, ctx->pf_plan, ctx->pf_status};
-            hipLaunchKernelGGL(tfn, dim3((unsigned)ctx->pfW), dim3((unsigned)(nw * 64)), tlds, st, TP);
+            HIP_TRY(ctx, spf_team_launch((int)ctx->K, tb.nw, tb.tw, (int)ctx->pfW, st, TP));
         } else {
             hipLaunchKernelGGL(fn, dim3((unsigned)ctx->pfW), dim3(64), 0, st, P);
         }

@@ -29,7 +29,7 @@
 #include "obs_kernels.hpp"
 #include "layout_kernels.hpp"
 #include "spf_kernels.hpp"
-#include "spf_team_kernel.hpp"
+#include "spf_team_api.hpp"
 #include "spf_fast_kernels.hpp"
 #include "dbl_kernels.hpp"
 #include "cont_kernels.hpp"

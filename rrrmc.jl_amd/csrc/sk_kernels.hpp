@@ -13,90 +13,13 @@
 #include <stdint.h>
 
 #include "philox.hpp"
+#include "det_math.hpp"
 
 namespace rrrmc {
 
 constexpr int kSkThreads = 256;
 constexpr int kSkRB = 8;              // replicas per workgroup
 constexpr int kSkMaxSPT = 8;          // sites per thread -> N <= 2048
-constexpr uint32_t TAG_ACCEPT_F64 = 9;
-constexpr uint32_t TAG_GAUSS = 6;
-
-// rand() of replica `replica` at global iteration g: 53-bit uniform of the ACCEPT_F64 stream
-RRRMC_HD double rand53(uint32_t k0, uint32_t k1, uint64_t g, uint32_t replica)
-{
-    const uint64_t blk = g >> 1;
-    const Philox4 o = philox4x32_10((uint32_t)blk, (uint32_t)(blk >> 32), replica, TAG_ACCEPT_F64, k0, k1);
-    const uint64_t u = (g & 1u) ? (((uint64_t)o.w[2] << 32) | o.w[3]) : (((uint64_t)o.w[0] << 32) | o.w[1]);
-    return (double)(u >> 11) * 0x1.0p-53;
-}
-
-// exp(x) with a fixed operation order and no fused multiply-add: Cody-Waite reduction, degree-13 Taylor polynomial in
-// Horner form, exact scaling.  The oracle evaluates the same sequence, so `rand() < exp(x)` agrees bit for bit.
-__device__ __forceinline__ double det_exp(double x)
-{
-    const double LOG2E = 1.44269504088896338700e+00;
-    const double LN2_HI = 6.93147180369123816490e-01, LN2_LO = 1.90821492927058770002e-10;
-    const double c[14] = {1.0, 1.0, 0.5, 1.0 / 6, 1.0 / 24, 1.0 / 120, 1.0 / 720, 1.0 / 5040, 1.0 / 40320, 1.0 / 362880,
-                          1.0 / 3628800, 1.0 / 39916800, 1.0 / 479001600, 1.0 / 6227020800.0};
-    if (x != x) return x;
-    if (x < -745.2) return 0.0;
-    if (x > 709.7) return __builtin_inf();
-    const double k = floor(__dadd_rn(__dmul_rn(x, LOG2E), 0.5));
-    const double r = __dadd_rn(__dadd_rn(x, -__dmul_rn(k, LN2_HI)), -__dmul_rn(k, LN2_LO));
-    double p = c[13];
-#pragma unroll
-    for (int n = 12; n >= 0; --n) p = __dadd_rn(__dmul_rn(p, r), c[n]);
-    return ldexp(p, (int)k);
-}
-
-// det_exp with its constants handed in (c[0..13] the Taylor coefficients, c[14] = log2(e), c[15], c[16] = ln 2 high / low): the same
-// operations in the same order.  A Float64 constant is two scalar moves at every use; a kernel that evaluates det_exp on its
-// critical path once per step keeps them in vector registers instead (sk_exp_constants: an empty asm hides the values from constant
-// propagation).
-__device__ __forceinline__ void sk_exp_constants(double (&c)[17])
-{
-    const double v[17] = {1.0, 1.0, 0.5, 1.0 / 6, 1.0 / 24, 1.0 / 120, 1.0 / 720, 1.0 / 5040, 1.0 / 40320, 1.0 / 362880,
-                          1.0 / 3628800, 1.0 / 39916800, 1.0 / 479001600, 1.0 / 6227020800.0,
-                          1.44269504088896338700e+00, 6.93147180369123816490e-01, 1.90821492927058770002e-10};
-#pragma unroll
-    for (int i = 0; i < 17; ++i) { c[i] = v[i]; asm volatile("" : "+v"(c[i])); }
-}
-__device__ __forceinline__ double det_exp_c(double x, const double (&c)[17])
-{
-    if (x != x) return x;
-    if (x < -745.2) return 0.0;
-    if (x > 709.7) return __builtin_inf();
-    const double k = floor(__dadd_rn(__dmul_rn(x, c[14]), 0.5));
-    const double r = __dadd_rn(__dadd_rn(x, -__dmul_rn(k, c[15])), -__dmul_rn(k, c[16]));
-    double p = c[13];
-#pragma unroll
-    for (int n = 12; n >= 0; --n) p = __dadd_rn(__dmul_rn(p, r), c[n]);
-    return ldexp(p, (int)k);
-}
-
-// log1p(y) for -1 < y <= 0 with a fixed operation order (rand_skip of bklMC, src/DeltaE.jl:141-144); same sequence as the oracle's
-__device__ __forceinline__ double det_log1p(double y)
-{
-    const double LN2_HI = 6.93147180369123816490e-01, LN2_LO = 1.90821492927058770002e-10;
-    const double u = __dadd_rn(1.0, y);
-    if (u == 1.0) return y;
-    if (!(u > 0.0)) return -__builtin_inf();
-    unsigned long long b = (unsigned long long)__double_as_longlong(u);
-    int e = (int)((b >> 52) & 0x7ff) - 1023;
-    b = (b & ((1ull << 52) - 1)) | (1023ull << 52);
-    double m = __longlong_as_double((long long)b);
-    if (m > 1.4142135623730951) { m = __dmul_rn(m, 0.5); e += 1; }
-    const double s = __ddiv_rn(__dadd_rn(m, -1.0), __dadd_rn(m, 1.0));
-    const double s2 = __dmul_rn(s, s);
-    double p = 1.0 / 21.0;
-#pragma unroll
-    for (int n = 19; n >= 1; n -= 2) p = __dadd_rn(__dmul_rn(p, s2), 1.0 / (double)n);
-    const double lg = __dmul_rn(__dmul_rn(2.0, s), p);
-    const double r = __dadd_rn(__dmul_rn((double)e, LN2_HI), __dadd_rn(lg, __dmul_rn((double)e, LN2_LO)));
-    return __dadd_rn(r, -__ddiv_rn(__dadd_rn(__dadd_rn(u, -1.0), -y), u));
-}
-
 struct SkParams {
     const double* J;        // [N][N]
     double* lf;             // [G][N][kSkRB]  local fields (replica fastest)

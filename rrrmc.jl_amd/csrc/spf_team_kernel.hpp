@@ -1,6 +1,5 @@
 // gfx950 kernel for standardMC (src/RRRMC.jl:81-127) on the Float64-coupling sparse models (GraphRRGNormal / GraphEANormal:
-// src/graphs/RRG.jl:503-627, src/graphs/EA.jl:534-680): a TEAM of wavefronts per group of 64 replicas (round 4), with the chain-ordered
-// part cut down to three instructions per attempt (round 5).
+// src/graphs/RRG.jl:503-627, src/graphs/EA.jl:534-680): a TEAM of wavefronts per group of replicas (round 4), re-cut in round 5.
 //
 // spf_sweep_kernel (spf_kernels.hpp) walks the chain with ONE wavefront per group of 64 replicas: one attempt after the other, ~ 1 us each,
 // whatever the machine has idle (8192 replicas = 128 wavefronts on 1024 SIMDs).  The attempts of a chain are not all dependent on each other:
@@ -8,28 +7,38 @@
 // its neighbours (update_cache!, RRG.jl:576-617) — two attempts whose closed neighbourhoods do not meet commute exactly (no field receives
 // an addition from both, so no rounding order changes).  This kernel runs such attempts side by side:
 //
-//   * NW - 1 executing wavefronts per group take the attempts of the chain in pairs (one Philox block serves iterations 2h, 2h + 1),
-//     pair h on wavefront h mod (NW - 1).  Before it touches memory, the wavefront of attempt t waits until every attempt up to
-//     need(t) = max(dep(t), t - M) has RETIRED (M = slots = attempts in flight at most), dep(t) = the latest earlier attempt within the window
-//     whose closed neighbourhood meets t's (spf_team_plan_kernel: state-independent, once per launch for all groups).  Then it runs the
-//     reference's attempt — accept (RRRMC.jl:39), the K + 1 field updates, the spin word — on the group's [N][64] arrays in HBM / L2, exactly
-//     as spf_sweep_kernel does, and counts its own accepted moves (a count does not care about order).
+//   * spf_team_plan_kernel (state-independent, once per launch for all teams) writes one record per attempt: site, neighbours, couplings, the
+//     64-bit set of the attempts among the previous 64 (the window) that do NOT commute with it, and the latest earlier attempt at the same site.
+//   * NW - 1 executing wavefronts per team take the attempts of the chain in pairs (one Philox block serves iterations 2h, 2h + 1), pair h on
+//     wavefront h mod (NW - 1).  An attempt's loads go out once every attempt of its conflict set has REPORTED (stores performed; one LDS read
+//     of the slots' flags tells) and everything older than the window has retired; unless the pair's second attempt conflicts with the first,
+//     the loads of both go out together and the two are worked off side by side: accept (RRRMC.jl:39 — decided by the hardware's 2^x wherever
+//     that is safe, by the oracle's det_exp in a narrow band around it: identical decisions), the K + 1 field updates, the spin word — on the
+//     group's [N][64] arrays in HBM / L2, exactly as spf_sweep_kernel does.  A wavefront counts its own accepted moves (a count does not care
+//     about order).  Results go into the attempt's SLOT in LDS (slot = iteration mod M), free once attempt it - M has retired.
 //   * one RETIRING wavefront keeps what the reference's loop keeps in chain order: the tracked energy (E += dE is a Float64 running sum:
 //     its order is the chain's), the samples (RRRMC.jl:104-108) and, per replica, WHICH attempt its last accepted move was (tl).  It consumes
-//     the attempts strictly in order, one 16-byte read per attempt: {the attempted site's own field, or +0.0 for a lane that did not accept
-//     (E - 0.0 == E for every E); the attempt's index, or 0}.  Per attempt that is one read, one Float64 add and one integer max.
+//     the attempts strictly in order from their slots: {the attempted site's own field, or +0.0 for a replica that did not accept (E - 0.0 == E
+//     for every E); the attempt's index, or 0} — per attempt two reads, one Float64 add, one integer max — and publishes the retired prefix.
 //   * the undo path (RRG.jl:583-593: a move of the spin that was also the replica's last accepted move swaps lfields <-> lfields_last) needs
-//     move_last as of t - 1.  move_last = site(tl): the executing wavefront reads tl as retired so far and gathers the sites; if an accepting
-//     lane has site(tl) == site(t) it waits until t - 1 has retired — the retiring wavefront then rests until t itself reports — and reads
-//     again; without such a lane no in-flight attempt can make one (an attempt at the same site is a dependency, so it has retired).
+//     move_last as of t - 1.  move_last = site(tl): the executing wavefront reads the prefix and tl as retired so far and gathers the sites; if
+//     an earlier attempt at the same site has not retired yet, or an accepting replica has site(tl) == site(t), it waits until t - 1 has
+//     retired — the retiring wavefront then rests until t itself reports — and reads again; otherwise no attempt in flight can make
+//     move_last equal to this site.
 //   * the undo record of an accepted attempt a (the K neighbour fields before the move and the own field) stays in a's slot until the slot's
-//     next user, attempt a + M, EVACUATES it into its wavefront's keep area — only for the lanes whose last accepted move still is a —
+//     next user, attempt a + M, EVACUATES it into its wavefront's keep area — only for the replicas whose last accepted move still is a —
 //     then marks the slot (ev[slot] = a + M) and only then overwrites it.  So the record of tl = a is in slot(a) iff ev[slot(a)] == a, else in
 //     the keep area of the wavefront that runs attempt a + M: a reader takes the slot's data first and the mark second.  A keep entry is
-//     written for a lane only while that lane's last accepted move is the evacuated one, i.e. while the lane's previous keep entry is dead.
-// No wavefront ever waits for a later attempt, every wait is on the retired prefix, so the scheme cannot deadlock; everything a caller can see
-// (fields, spins, undo records, move_last, energies, samples, accepted counts) is bit-identical to spf_sweep_kernel and the oracle
-// (tests/test_gpu_spf_parity.py runs every case — two bonds to the same neighbour included — through both kernels).
+//     written for a replica only while its last accepted move is the evacuated one, i.e. while its previous keep entry is dead.
+// No wavefront ever waits for a later attempt and no wavefront waits while it holds an unreported attempt that the awaited one could need
+// (the first attempt of a pair is reported before the second waits for the prefix), so the scheme cannot deadlock; every wait is bounded
+// all the same and raises a status word (SpfTeamParams::status).  Everything a caller can see (fields, spins, undo records, move_last,
+// energies, samples, accepted counts) is bit-identical to spf_sweep_kernel and the oracle (tests/test_gpu_spf_parity.py runs every case — two
+// bonds to the same neighbour included — through the builds of both kernels; tools/ubench/spf_team_bench.hip compares every word).
+//
+// What bounds it (profiles/r05/spf_team_*): at 8192 replicas a team's pace is its wavefronts' own instruction streams — about 480
+// instructions per attempt over sixteen wavefronts, a third of them polling and address arithmetic — plus two memory round trips per pair;
+// the retiring wavefront idles two thirds of its time.  From 65 536 replicas on it is HBM.
 //
 // Ordering rests on three hardware facts, all within ONE compute unit (a workgroup never spans two; the kernel must not be built for
 // threadgroup-split mode, where a workgroup's waves may sit on different compute units — hipcc's default is off and build.py passes no
@@ -39,8 +48,11 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
-#include "spf_kernels.hpp"
+#include "philox.hpp"
+#include "det_math.hpp"
+#include "spf_team_params.hpp"
 
 namespace rrrmc {
 
@@ -49,8 +61,17 @@ namespace rrrmc {
 #else
 #define SPF_STAMP(i) do { } while (0)
 #endif
+// -DSPF_TEAM_TRACE (tools/ubench/spf_team_bench.hip only): team 0 writes the clock of eight events of every attempt into the sample buffer
+#ifdef SPF_TEAM_TRACE
+#define SPF_TRACE(it_, e_) do { if (blockIdx.x == 0 && lane == 0) reinterpret_cast<unsigned long long*>(P.Es)[(size_t)(it_) * 8 + (e_)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define SPF_TRACE(it_, e_) do { } while (0)
+#endif
 #ifndef SPF_TEAM_NAP
 #define SPF_TEAM_NAP 1
+#endif
+#ifndef SPF_TEAM_RETIRE_NAP
+#define SPF_TEAM_RETIRE_NAP 1
 #endif
 #ifndef SPF_TEAM_BATCH
 #define SPF_TEAM_BATCH 4
@@ -58,15 +79,7 @@ namespace rrrmc {
 #ifndef SPF_TEAM_SCOPE
 #define SPF_TEAM_SCOPE "workgroup"
 #endif
-constexpr int kSpfTeamWindow = 64;          // dependency window of spf_team_plan_kernel: >= the slots of every build (attempts in flight)
-
-// The attempts of one launch, state-independent, one record of 2 + 3 K dwords per iteration `it` (record 0 and the records behind the last
-// iteration are padding, so that an executing wavefront fetches the two records of a pair with one load):
-//   [0] site   [1] dep   [2 .. 2 + K) the neighbours   [2 + K .. 2 + 3 K) their couplings (Float64, low word first)
-// dep = the latest earlier iteration within the window whose closed neighbourhood meets this one's (0 = none); neighbourhoods meet <=> the
-// sites are at distance <= 2.
-__host__ __device__ constexpr int spf_plan_stride(int K) { return 2 + 3 * K; }
-
+static_assert(kSpfTeamWindow == 64, "the conflicts of an attempt are one 64-bit word");
 __global__ __launch_bounds__(256) void spf_team_plan_kernel(const int32_t* __restrict__ A, const double* __restrict__ J, const int32_t* __restrict__ sites,
                                                             uint32_t* __restrict__ plan, int64_t n, int K)
 {
@@ -81,8 +94,10 @@ __global__ __launch_bounds__(256) void spf_team_plan_kernel(const int32_t* __res
     const int i = sites[t - 1];
     mine[0] = i;
     for (int k = 0; k < K; ++k) mine[1 + k] = A[(size_t)i * K + k];
-    int32_t dep = 0;
-    for (int c = 1; c <= kSpfTeamWindow && c < t && dep == 0; ++c) {
+    int32_t same = 0;
+    unsigned long long conf = 0ull;
+    for (int c = kSpfTeamWindow; c >= 1; --c) {
+        if (c >= t) continue;
         const int j = sites[t - 1 - c];
         bool hit = false;
         for (int a = 0; a <= K; ++a) hit |= mine[a] == j;
@@ -90,39 +105,19 @@ __global__ __launch_bounds__(256) void spf_team_plan_kernel(const int32_t* __res
             const int y = A[(size_t)j * K + k];
             for (int a = 0; a <= K; ++a) hit |= mine[a] == y;
         }
-        if (hit) dep = (int32_t)(t - c);
+        if (hit) conf |= 1ull << (c - 1);
+        if (j == i) same = (int32_t)(t - c);
     }
     o[0] = (uint32_t)i;
-    o[1] = (uint32_t)dep;
+    o[1] = (uint32_t)same;
+    o[2] = (uint32_t)conf;
+    o[3] = (uint32_t)(conf >> 32);
     for (int k = 0; k < K; ++k) {
-        o[2 + k] = (uint32_t)mine[1 + k];
+        o[4 + k] = (uint32_t)mine[1 + k];
         const unsigned long long jb = (unsigned long long)__double_as_longlong(J[(size_t)i * K + k]);
-        o[2 + K + 2 * k] = (uint32_t)jb;
-        o[2 + K + 2 * k + 1] = (uint32_t)(jb >> 32);
+        o[4 + K + 2 * k] = (uint32_t)jb;
+        o[4 + K + 2 * k + 1] = (uint32_t)(jb >> 32);
     }
-}
-
-struct SpfTeamParams {
-    SpfParams S;
-    const uint32_t* plan;       // [iters + 2][2 + 3 K]
-    int32_t* status;            // one word per context, may be null: set to 1 by a workgroup whose wait ran into kSpfTeamSpinLimit (a protocol
-                                // failure: the launch then runs to its end without waiting and its results are void)
-};
-constexpr int32_t kSpfTeamSpinLimit = 1 << 22;      // polls of one wait (each >= 64 cycles asleep): ~ 0.3 s, a thousand times the longest legitimate wait
-
-// what the retiring wavefront reads of an attempt, one 16-byte LDS read per lane
-struct __attribute__((aligned(16))) SpfVt {
-    double v;           // the attempted site's own field before the move (lfields_last[i]), +0.0 for a lane that did not accept
-    uint32_t tag;       // the attempt's launch-relative iteration, 0 for a lane that did not accept
-    uint32_t pad;
-};
-typedef uint32_t spf_u32x4 __attribute__((ext_vector_type(4)));
-
-// record areas: [0, M) the slots, M + x the KEEP of executing wavefront x, M + NX the undo records the launch starts with
-__host__ __device__ constexpr int spf_team_areas(int NW, int D) { return (2 * D + 1) * (NW - 1) + 1; }
-__host__ __device__ constexpr size_t spf_team_lds_bytes(int K, int NW, int D)
-{
-    return (sizeof(double) * (size_t)K * 64 + sizeof(SpfVt) * 64) * (size_t)spf_team_areas(NW, D) + sizeof(int32_t) * (size_t)(64 + 2 * (2 * D * (NW - 1)) + 4);      // tl, done, ev, prefix + abort flag
 }
 
 __device__ __forceinline__ int32_t spf_lds_ld(const int32_t* p)
@@ -138,33 +133,49 @@ __device__ __forceinline__ int32_t spf_lds_uniform(const int32_t* p)
     return __builtin_amdgcn_readfirstlane(spf_lds_ld(p));
 }
 
-// grid W, block NW * 64, dynamic LDS spf_team_lds_bytes(K, NW, D).  D = pairs of slots per executing wavefront: how far the wavefronts
-// may run ahead of the retired prefix (2 D (NW - 1) attempts)
-template <int K, int NW, int D>
+// One Philox block serves two attempts; the spin word of a team is the team's TW bits of the group's 64-bit word
+template <int TW> struct spf_word;
+template <> struct spf_word<64> { typedef unsigned long long type; };
+template <> struct spf_word<32> { typedef uint32_t type; };
+template <> struct spf_word<16> { typedef uint16_t type; };
+
+// grid = teams = W * (64 / TW), block NW * 64, dynamic LDS spf_team_lds_bytes(K, NW, M, TW).
+//   TW = replicas per team (64, 32 or 16): a group of 64 replicas is walked by 64 / TW teams, each on its own lanes' part of the group's
+//        [N][64] field lines and spin words (lanes >= TW of a team's wavefronts idle).  A chain's pace is bound by what ONE compute unit moves
+//        (about 10 bytes per cycle of 512-byte lines that miss its L1), so with fewer groups than compute units narrower teams on more
+//        compute units are faster: the same instructions serve fewer replicas, but each compute unit moves a half or a quarter of the bytes.
+//   M  = slots (attempt `it` uses slot (it + c0) mod M, whoever runs it): how far the wavefronts may run ahead of the retired prefix
+template <int K, int NW, int M, int TW>
 __global__ __launch_bounds__(NW * 64) void spf_team_kernel(SpfTeamParams TP)
 {
     constexpr int NX = NW - 1;
-    constexpr int M = 2 * NX * D;                     // slots = attempts in flight at most
-    constexpr int AREAS = spf_team_areas(NW, D);
-    static_assert(M <= kSpfTeamWindow && M < 64, "the dependency window covers the attempts in flight; one wavefront read brings all flags");
+    constexpr int AREAS = spf_team_areas(NW, M);
+    constexpr int TPG = 64 / TW;                      // teams per group
+    typedef typename spf_word<TW>::type word_t;
+    static_assert(M <= kSpfTeamWindow && M < 64 && M >= 2 * NX, "the dependency window covers the attempts in flight; one wavefront read brings all flags; a pair per executing wavefront");
     static_assert(AREAS == M + NX + 1, "areas");
     const SpfParams& P = TP.S;
     extern __shared__ __attribute__((aligned(16))) unsigned char spf_team_lds[];
-    typedef double nbr_t[K][64];
-    typedef SpfVt vt_t[64];
+    typedef double nbr_t[K][TW];
+    typedef double own_t[TW];
+    typedef uint32_t tag_t[TW];
     nbr_t* const rec = reinterpret_cast<nbr_t*>(spf_team_lds);                                    // [AREAS] the K neighbour fields before the move
-    vt_t* const vt = reinterpret_cast<vt_t*>(spf_team_lds + sizeof(nbr_t) * AREAS);               // [AREAS] own field + tag
-    int32_t* const tl = reinterpret_cast<int32_t*>(spf_team_lds + (sizeof(nbr_t) + sizeof(vt_t)) * AREAS);   // [64] last accepted attempt as retired (0: before the launch)
-    int32_t* const done = tl + 64;                    // [M] iteration whose results the slot holds
+    own_t* const vown = reinterpret_cast<own_t*>(spf_team_lds + sizeof(nbr_t) * AREAS);           // [AREAS] the own field (+0.0: not accepted)
+    tag_t* const vtag = reinterpret_cast<tag_t*>(spf_team_lds + (sizeof(nbr_t) + sizeof(own_t)) * AREAS);    // [AREAS] the tag
+    int32_t* const tl = reinterpret_cast<int32_t*>(spf_team_lds + (sizeof(nbr_t) + sizeof(own_t) + sizeof(tag_t)) * AREAS);   // [TW] last accepted attempt as retired (0: before the launch)
+    int32_t* const done = tl + TW;                    // [M] iteration whose results the slot holds
     int32_t* const ev = done + M;                     // [M] iteration that has evacuated the slot's previous records and may be overwriting it
     int32_t* const shP = ev + M;                      // retired prefix
     int32_t* const abortf = shP + 1;                  // set when a wait ran into its limit: nobody waits any more
 
-    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), w = blockIdx.x, N = P.N;
-    const int r = w * 64 + lane;
-    double* const lf = P.lf + (size_t)w * N * 64 + lane;
-    double* const undo = P.undo + (size_t)w * (K + 1) * 64 + lane;
-    unsigned long long* const sp = P.spins + (size_t)w * N;
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), N = P.N;
+    const int w = (int)(blockIdx.x / (unsigned)TPG), part = (int)(blockIdx.x % (unsigned)TPG);       // group of 64 replicas, the team's part of it
+    const bool act = lane < TW;                       // lanes beyond the team's width idle (they keep valid addresses: lane dl's)
+    const int dl = lane & (TW - 1);
+    const int r = w * 64 + part * TW + dl;
+    double* const lf = P.lf + (size_t)w * N * 64 + part * TW + dl;
+    double* const undo = P.undo + (size_t)w * (K + 1) * 64 + part * TW + dl;
+    word_t* const sp = reinterpret_cast<word_t*>(P.spins + (size_t)w * N) + part;        // word of site x: sp[x * TPG]
     const int64_t iters = P.iters;
     const uint64_t g0 = P.g0, hb = (g0 + 1) >> 1;        // first pair of the launch
     const int32_t c0 = (int32_t)((int64_t)g0 - 2 * (int64_t)hb);       // slot of iteration `it` = (it + c0) mod M; c0 = 0 or -1
@@ -184,9 +195,8 @@ __global__ __launch_bounds__(NW * 64) void spf_team_kernel(SpfTeamParams TP)
 
     if (wv == NW - 1) {
 #pragma unroll
-        for (int k = 0; k < K; ++k) rec[M + NX][k][lane] = undo[(size_t)k * 64];
-        vt[M + NX][lane].v = undo[(size_t)K * 64];
-        tl[lane] = 0;
+        for (int k = 0; k < K; ++k) { const double u_ = undo[(size_t)k * 64]; if (act) rec[M + NX][k][dl] = u_; }
+        { const double u_ = undo[(size_t)K * 64]; if (act) { vown[M + NX][dl] = u_; tl[dl] = 0; } }
         if (lane < M) { done[lane] = 0; ev[lane] = 0; }
         if (lane == 0) { *shP = 0; *abortf = 0; }
     }
@@ -220,7 +230,9 @@ __global__ __launch_bounds__(NW * 64) void spf_team_kernel(SpfTeamParams TP)
         while (it <= n32) {
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");        // compiler barrier: the data reads stay behind the flag read
             if (it == samp) {                                      // sample before the move
-                if (P.Es) P.Es[(size_t)ns * P.Rpad + r] = E;
+#ifndef SPF_TEAM_TRACE
+                if (P.Es && act) P.Es[(size_t)ns * P.Rpad + r] = E;
+#endif
                 ++ns;
                 samp += step32;
             }
@@ -234,7 +246,7 @@ __global__ __launch_bounds__(NW * 64) void spf_team_kernel(SpfTeamParams TP)
             ++rt_rounds; if (ready == 0) ++rt_idle;
 #endif
             if (ready == 0) {
-                __builtin_amdgcn_s_sleep(1);
+                __builtin_amdgcn_s_sleep(SPF_TEAM_RETIRE_NAP);
                 f = spf_lds_ld(fl);
                 if (++idle > kSpfTeamSpinLimit || ((idle & 1023) == 0 && spf_lds_uniform(abortf))) {        // see wait_prefix
                     if (lane == 0) { spf_lds_st(abortf, 1); spf_lds_st(shP, n32); if (TP.status) *TP.status = 1; }
@@ -243,18 +255,19 @@ __global__ __launch_bounds__(NW * 64) void spf_team_kernel(SpfTeamParams TP)
                 continue;
             }
             idle = 0;
-            const SpfVt* const q0 = &vt[s0][lane];
+            const double* const q0 = &vown[s0][dl];
+            const uint32_t* const g0p = &vtag[s0][dl];
             // n attempts, straight-line: n reads, the next look at the flags, then per attempt one add and one max
 #define SPF_RETIRE_CASE(n)                                                                                                      \
             case n: {                                                                                                           \
-                spf_u32x4 q[n];                                                                                                 \
-                _Pragma("unroll") for (int j = 0; j < n; ++j) q[j] = *reinterpret_cast<const spf_u32x4*>(q0 + j * 64); \
+                double q[n];                                                                                                    \
+                uint32_t qt[n];                                                                                                 \
+                _Pragma("unroll") for (int j = 0; j < n; ++j) { q[j] = q0[j * TW]; qt[j] = g0p[j * TW]; }                       \
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");                                                          \
                 f = spf_lds_ld(fl);                                                                                             \
                 _Pragma("unroll") for (int j = 0; j < n; ++j) {                                                                 \
-                    const double vj = __longlong_as_double((long long)(((unsigned long long)q[j].y << 32) | q[j].x));           \
-                    E = __dadd_rn(E, -vj);                         /* dE = -lfields[i] (RRG.jl:619-625); - (+0.0) changes nothing */ \
-                    tlr = (int32_t)q[j].z > tlr ? (int32_t)q[j].z : tlr;                                                        \
+                    E = __dadd_rn(E, -q[j]);                       /* dE = -lfields[i] (RRG.jl:619-625); - (+0.0) changes nothing */ \
+                    tlr = (int32_t)qt[j] > tlr ? (int32_t)qt[j] : tlr;                                                          \
                 }                                                                                                               \
             } break;
             switch (ready) {
@@ -283,9 +296,12 @@ __global__ __launch_bounds__(NW * 64) void spf_team_kernel(SpfTeamParams TP)
             default: break;
             }
 #undef SPF_RETIRE_CASE
-            spf_lds_st(tl + lane, tlr);
+            if (act) spf_lds_st(tl + dl, tlr);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");                // compiler barrier: LDS performs a wavefront's writes in order
             if (lane == 0) spf_lds_st(shP, it + ready - 1);
+#ifdef SPF_TEAM_TRACE
+            for (int j = 0; j < ready; ++j) SPF_TRACE(it + j, 7);
+#endif
             it += ready;
             s0 = s0 + ready >= M ? 0 : s0 + ready;                 // a batch never wraps: ready <= M - s0
         }
@@ -296,9 +312,9 @@ __global__ __launch_bounds__(NW * 64) void spf_team_kernel(SpfTeamParams TP)
         }
 #endif
         if (TP.status && spf_lds_uniform(abortf) && lane == 0) *TP.status = 1;
-        P.E_cur[r] = E;
-        P.move_last[r] = tlr ? P.sites[tlr - 1] : ml0;
-        {
+        if (act) {
+            P.E_cur[r] = E;
+            P.move_last[r] = tlr ? P.sites[tlr - 1] : ml0;
             // every executing wavefront has reported its last attempt: nothing moves any more
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             int area = M + NX;
@@ -307,8 +323,8 @@ __global__ __launch_bounds__(NW * 64) void spf_team_kernel(SpfTeamParams TP)
                 area = spf_lds_ld(ev + sl) == tlr ? sl : M + owner_of(tlr + M);
             }
 #pragma unroll
-            for (int k = 0; k < K; ++k) undo[(size_t)k * 64] = rec[area][k][lane];
-            undo[(size_t)K * 64] = vt[area][lane].v;
+            for (int k = 0; k < K; ++k) undo[(size_t)k * 64] = rec[area][k][dl];
+            undo[(size_t)K * 64] = vown[area][dl];
         }
         return;
     }
@@ -324,6 +340,7 @@ __global__ __launch_bounds__(NW * 64) void spf_team_kernel(SpfTeamParams TP)
         const int64_t rec0 = it_even > iters ? iters : it_even;     // it_even >= 0; clamped: a pair beyond the launch is fetched and never used
         return TP.plan[(size_t)rec0 * S + (lane < 2 * S ? lane : 0)];
     };
+    auto load_word = [&](int x_) -> word_t { return __hip_atomic_load(sp + (size_t)x_ * TPG, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT); };
     auto site_of_tl = [&](int32_t t) -> int32_t {                   // move_last of a lane whose last accepted attempt is t
         const int32_t s = P.sites[(t > 0 ? t : 1) - 1];
         return t > 0 ? s : ml0;
@@ -341,107 +358,194 @@ __global__ __launch_bounds__(NW * 64) void spf_team_kernel(SpfTeamParams TP)
         pr_next = pr_next2;
         pr_next2 = fetch_pair(h + 2 * NX);
         const Philox4 blk = philox4x32_10((uint32_t)blk_id, (uint32_t)(blk_id >> 32), replica, TAG_ACCEPT_F64, P.k0, P.k1);
+        // The two attempts of the pair, A (e = 0) and B (e = 1).  Their state-independent parts first; then, unless B depends on A, the
+        // loads of BOTH go out before either is worked off (one memory latency for the two), and both are reported behind one wait for the stores.
+        int32_t itv[2], sl_[2], site[2], same[2];
+        unsigned long long conf[2];
+        bool valid[2];
+        int y[2][K];
+        double J[2][K], U[2];
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
             const int64_t it = it_even + e;
-            if (it < 1 || it > iters) continue;
-            const int s = (int)((2 * h + (uint64_t)e) % (uint64_t)M);
+            valid[e] = it >= 1 && it <= iters;
+            itv[e] = (int32_t)it;
+            sl_[e] = (int)((2 * h + (uint64_t)e) % (uint64_t)M);
             const int o = e * S;
-            const int i = __builtin_amdgcn_readlane((int)pr, o + 0);
-            const int32_t dep = __builtin_amdgcn_readlane((int)pr, o + 1);
-            int y[K];
-            double J[K];
+            site[e] = __builtin_amdgcn_readlane((int)pr, o + 0);
+            same[e] = __builtin_amdgcn_readlane((int)pr, o + 1);
+            conf[e] = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)pr, o + 3) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)pr, o + 2);
 #pragma unroll
             for (int k = 0; k < K; ++k) {
-                y[k] = __builtin_amdgcn_readlane((int)pr, o + 2 + k);
-                const uint32_t jl = (uint32_t)__builtin_amdgcn_readlane((int)pr, o + 2 + K + 2 * k), jh = (uint32_t)__builtin_amdgcn_readlane((int)pr, o + 2 + K + 2 * k + 1);
-                J[k] = __longlong_as_double((long long)(((unsigned long long)jh << 32) | jl));
+                y[e][k] = __builtin_amdgcn_readlane((int)pr, o + 4 + k);
+                const uint32_t jl = (uint32_t)__builtin_amdgcn_readlane((int)pr, o + 4 + K + 2 * k), jh = (uint32_t)__builtin_amdgcn_readlane((int)pr, o + 4 + K + 2 * k + 1);
+                J[e][k] = __longlong_as_double((long long)(((unsigned long long)jh << 32) | jl));
             }
             const uint64_t u = e ? (((uint64_t)blk.w[2] << 32) | blk.w[3]) : (((uint64_t)blk.w[0] << 32) | blk.w[1]);
-            const double U = (double)(u >> 11) * 0x1.0p-53;
-            const int64_t lo = it - M;                              // the slot's previous use; everything older than the dependency window
-            const int32_t need = (int32_t)(dep > lo ? dep : lo);
-            SPF_STAMP(0);                                           // state-independent preparation
-            wait_prefix(need, SPF_TEAM_NAP);
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, SPF_TEAM_SCOPE);
-            SPF_STAMP(1);                                           // waiting for the dependency / the slot
+            U[e] = (double)(u >> 11) * 0x1.0p-53;
+        }
+        SPF_STAMP(0);                                               // state-independent preparation
+        double lfi[2], nf[2][K];
+        word_t wi[2], nw[2][K];
+        int32_t tlv[2], mls[2], pfx[2];
+        bool reported[2] = {false, false};
 
+        // the loads of attempt e (not behind its slot: nothing of the slot is touched before finish).  They go out
+        //   - behind everything the planner's window does not reach back to (a wavefront's requests may run ahead of the retired prefix by the
+        //     slots plus its own pairs), and
+        //   - behind every attempt of the window that does not commute with this one: those must have REPORTED (their stores performed), not
+        //     retired.  Lane c - 1 looks at iteration j = it - c: the flag of its slot says j, or a later user of the slot, once j has reported.
+        // One LDS round trip brings the flags, the retired prefix and, behind it (tl is written before the prefix), move_last as retired so far —
+        // enough to rule the undo path out if every earlier attempt at this site has retired (same <= prefix).
+        auto request = [&](auto ec) {
+            constexpr int e = decltype(ec)::value;
+            const int32_t j = itv[e] - 1 - lane;
+            const bool mine = j >= 1 && ((conf[e] >> lane) & 1ull);
+            const int32_t* const fj = done + (mine ? (j + c0) % M : 0);
+            int32_t f = spf_lds_ld(fj);
+            int32_t pv = spf_lds_ld(shP);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            int32_t t0 = spf_lds_ld(tl + dl);
+            int32_t pnow = __builtin_amdgcn_readfirstlane(pv);
+            if (pnow < itv[e] - kSpfTeamWindow || __builtin_amdgcn_ballot_w64(mine && f < j) != 0ull) {
+                wait_prefix(itv[e] - kSpfTeamWindow, SPF_TEAM_NAP);
+                int32_t polls = 0;
+                while (__builtin_amdgcn_ballot_w64(mine && spf_lds_ld(fj) < j) != 0ull) {
+                    __builtin_amdgcn_s_sleep(1);
+                    if (++polls > kSpfTeamSpinLimit) { if (lane == 0) spf_lds_st(abortf, 1); break; }
+                    if ((polls & 1023) == 0 && spf_lds_uniform(abortf)) break;
+                }
+                pnow = spf_lds_uniform(shP);
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                t0 = spf_lds_ld(tl + dl);
+            }
+            pfx[e] = pnow;
+            tlv[e] = t0;
+            SPF_TRACE(itv[e], 0);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, SPF_TEAM_SCOPE);
 #ifdef SPF_TEAM_EXP_NOMEM
             // timing experiment (tools/ubench/spf_team_bench.hip; wrong results): no global memory traffic at all — what the protocol alone costs
-            const double lfi = 0.25 * (double)((lane + i) & 7) - 1.0;
-            const unsigned long long wi = 0x5555aaaa5555aaaaull;
-            double nf[K];
-            unsigned long long nw[K];
+            lfi[e] = 0.25 * (double)((dl + site[e]) & 7) - 1.0;
+            wi[e] = (word_t)0x5555aaaa5555aaaaull;
 #pragma unroll
-            for (int k = 0; k < K; ++k) { nf[k] = 0.5 * k; nw[k] = 0x3333cccc3333ccccull + (unsigned long long)y[k]; }
+            for (int k = 0; k < K; ++k) { nf[e][k] = 0.5 * k; nw[e][k] = (word_t)(0x3333cccc3333ccccull + (unsigned long long)y[e][k]); }
 #else
-            const double lfi = lf[(size_t)i * 64];
-            const unsigned long long wi = spf_load_spins(sp + i);
-            double nf[K];
-            unsigned long long nw[K];
+            lfi[e] = lf[(size_t)site[e] * 64];
+            wi[e] = load_word(site[e]);
 #pragma unroll
             for (int k = 0; k < K; ++k) {
-                nf[k] = lf[(size_t)y[k] * 64];
-                nw[k] = spf_load_spins(sp + y[k]);
+                nf[e][k] = lf[(size_t)y[e][k] * 64];
+                nw[e][k] = load_word(y[e][k]);
             }
 #endif
-            int32_t tlv = spf_lds_ld(tl + lane);                    // as retired so far (>= need): later attempts in flight are at other sites
-            int32_t mls = site_of_tl(tlv);
-
-            const double dE = -lfi;                                 // delta_energy: RRG.jl:619-625
+            mls[e] = site_of_tl(tlv[e]);
+        };
+        // the attempt is reported once its field and spin stores have been PERFORMED: a workgroup-scope release does not wait for vector stores
+        // (it relies on one compute unit issuing them in order; loads of another SIMD were seen to overtake them)
+        auto report = [&](auto ec) {
+            constexpr int e = decltype(ec)::value;
+            if (!valid[e] || reported[e]) return;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, SPF_TEAM_SCOPE);
+            if (lane == 0) spf_lds_st(done + sl_[e], itv[e]);
+            SPF_TRACE(itv[e], 6);
+            reported[e] = true;
+        };
+        bool accv[2] = {false, false};
+        unsigned long long amaskv[2] = {0ull, 0ull};
+        auto decide = [&](auto ec) {
+            constexpr int e = decltype(ec)::value;
+            SPF_TRACE(itv[e], 1);
+            const double dE = -lfi[e];                              // delta_energy: RRG.jl:619-625
             const double xx = __dmul_rn(-P.beta, dE);
-            const bool acc = xx >= 0.0 || U < det_exp(xx);          // accept: RRRMC.jl:39
-            const unsigned long long amask = __builtin_amdgcn_ballot_w64(acc);
-            nacc += acc ? 1 : 0;
+            // accept (RRRMC.jl:39): xx >= 0 || U < det_exp(xx).  det_exp is some fifty Float64 instructions in a dependent chain; the hardware's
+            // 2^x (v_exp_f32, 1 ulp) on the Float32 image of xx is within 2e-5 of it wherever it is normal (|xx| < 87: 2^-24 |xx| log2(e) of
+            // argument rounding twice over, the constant, the instruction's ulp; det_exp itself is good to 1e-14), so outside a band of 2^-13
+            // around that estimate the comparison is decided by it, and only a wavefront with a replica INSIDE the band (about one attempt in
+            // two hundred) evaluates det_exp.  Below |xx| = 87 the estimate underflows towards 0 with exp(xx) < 2^-126 far under the smallest
+            // positive U (2^-53): U > 0 is rejected, U == 0 falls into the band.  The decision is det_exp's in every case.
+            {
+                const float e32 = __builtin_amdgcn_exp2f(__fmul_rn((float)xx, 1.44269504088896340736f));
+                const double est = (double)e32;
+                const bool sure_yes = xx >= 0.0 || U[e] < __dmul_rn(est, 1.0 - 0x1.0p-13);
+                const bool sure_no = !(xx >= 0.0) && U[e] > __dmul_rn(est, 1.0 + 0x1.0p-13);
+                bool a_ = sure_yes;
+                if (__builtin_amdgcn_ballot_w64(!sure_yes && !sure_no) != 0ull) a_ = xx >= 0.0 || U[e] < det_exp(xx);
+                accv[e] = a_;
+            }
+            amaskv[e] = __builtin_amdgcn_ballot_w64(accv[e]) & (TW == 64 ? ~0ull : (1ull << (TW & 63)) - 1ull);     // lanes >= TW repeat lane dl
+            nacc += accv[e] ? 1 : 0;
             SPF_STAMP(2);                                           // loads + decision
+            SPF_TRACE(itv[e], 2);
+        };
+        auto finish = [&](auto ec) {
+            constexpr int e = decltype(ec)::value;
+            const int32_t it = itv[e];
+            const int i = site[e], s = sl_[e];
+            const bool acc = accv[e];
+            const unsigned long long amask = amaskv[e];
 
             bool fast = false;
             double sv[K];
 #pragma unroll
             for (int k = 0; k < K; ++k) sv[k] = 0.0;
-            if (__builtin_amdgcn_ballot_w64(acc && mls == i) != 0ull) {
-                // some accepting replica's last retired accepted move is at this site: exact only once everything before this attempt has retired
-                // (the retiring wavefront then rests until this attempt reports, so tl and the records of its lanes are stable)
-                wait_prefix((int32_t)(it - 1), 1);
+            if (same[e] > pfx[e] || __builtin_amdgcn_ballot_w64(acc && mls[e] == i) != 0ull) {
+                // an earlier attempt at this site had not retired when tl was read, or some accepting replica's last retired accepted move is at
+                // this site: exact only once everything before this attempt has retired (the retiring wavefront then rests until this attempt
+                // reports, so tl and the records of its lanes are stable).  The pair's first attempt is among "everything before" the second:
+                // it is reported first
+                if (e == 1) report(std::integral_constant<int, 0>{});
+                pfx[e] = it - 1;
+                wait_prefix(it - 1, 1);
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, SPF_TEAM_SCOPE);
-                tlv = spf_lds_ld(tl + lane);
-                mls = site_of_tl(tlv);
-                fast = acc && mls == i;
+                tlv[e] = spf_lds_ld(tl + dl);
+                mls[e] = site_of_tl(tlv[e]);
+                fast = acc && mls[e] == i;
                 if (fast) {
                     // the record of attempt tlv: the slot's data first, the slot's mark second (see the head of the file)
-                    if (tlv > 0) {
-                        const int sl = (tlv + c0) % M;
+                    if (tlv[e] > 0) {
+                        const int sl = (tlv[e] + c0) % M;
                         double tmp[K];
 #pragma unroll
-                        for (int k = 0; k < K; ++k) tmp[k] = __hip_atomic_load(&rec[sl][k][lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        for (int k = 0; k < K; ++k) tmp[k] = __hip_atomic_load(&rec[sl][k][dl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                        const bool in_slot = spf_lds_ld(ev + sl) == tlv;
+                        const bool in_slot = spf_lds_ld(ev + sl) == tlv[e];
                         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                        const int keep = M + owner_of(tlv + M);
+                        const int keep = M + owner_of(tlv[e] + M);
 #pragma unroll
-                        for (int k = 0; k < K; ++k) sv[k] = in_slot ? tmp[k] : __hip_atomic_load(&rec[in_slot ? sl : keep][k][lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        for (int k = 0; k < K; ++k) sv[k] = in_slot ? tmp[k] : __hip_atomic_load(&rec[in_slot ? sl : keep][k][dl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     } else {
 #pragma unroll
-                        for (int k = 0; k < K; ++k) sv[k] = rec[M + NX][k][lane];
+                        for (int k = 0; k < K; ++k) sv[k] = rec[M + NX][k][dl];
                     }
                 }
             }
             const bool slow = acc && !fast;
+            SPF_TRACE(it, 3);
 
-            // EVACUATION: records of this slot's previous use (attempt it - M) that are still some replica's last accepted move go to the
-            // wavefront's own keep before the slot is marked and written.  A stale look at tl (the lane has accepted since) costs a wasted copy.
-            if (it > (int64_t)M) {
-                const bool live = tlv == (int32_t)(it - M);
+            // the slot: free once its previous use (attempt it - M) has retired.  EVACUATION: that attempt's records that are still some replica's
+            // last accepted move go to the wavefront's own keep before the slot is marked and written.  A stale look at tl (the lane has
+            // accepted since) costs a wasted copy.
+            if (it > M) {
+                // tl as read with the request will do if the slot was free by then: a replica whose last accepted move was not it - M at a prefix
+                // >= it - M has accepted something later
+                if (pfx[e] < it - M) {
+                    wait_prefix(it - M, 1);
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    tlv[e] = spf_lds_ld(tl + dl);
+                }
+                SPF_TRACE(it, 4);
+                const bool live = act && tlv[e] == it - M;
                 if (__builtin_amdgcn_ballot_w64(live) != 0ull) {
                     if (live) {
 #pragma unroll
-                        for (int k = 0; k < K; ++k) rec[M + x][k][lane] = rec[s][k][lane];
-                        vt[M + x][lane].v = vt[s][lane].v;
+                        for (int k = 0; k < K; ++k) rec[M + x][k][dl] = rec[s][k][dl];
+                        vown[M + x][dl] = vown[s][dl];
                     }
                 }
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            if (lane == 0) spf_lds_st(ev + s, (int32_t)it);
+            if (lane == 0) spf_lds_st(ev + s, it);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 
 #ifdef SPF_TEAM_EXP_NOMEM
@@ -450,40 +554,62 @@ __global__ __launch_bounds__(NW * 64) void spf_team_kernel(SpfTeamParams TP)
             if (amask != 0ull) {
 #endif
                 // update_cache! (RRG.jl:576-617, EA.jl:613-653).  Full 512-byte lines: lanes that do not accept write back what they read
-                const uint32_t snew = (uint32_t)((wi >> lane) & 1ull) ^ 1u;
+                const uint32_t snew = (uint32_t)((wi[e] >> dl) & 1u) ^ 1u;
                 double vrun = 0.0;
 #pragma unroll
                 for (int k = 0; k < K; ++k) {
                     // two bonds to the same neighbour (GraphEANormal with L = 2; rows are sorted): the second one continues from the first one's
                     // result (EA.jl:626-640 walks all entries), and its store — same wavefront, same address, in order — is the one that stays
-                    const bool rep = k > 0 && y[k] == y[k - 1];                  // wave-uniform
-                    const uint32_t sbit = (uint32_t)((nw[k] >> lane) & 1ull);
+                    const bool rep = k > 0 && y[e][k] == y[e][k - 1];            // wave-uniform
+                    const uint32_t sbit = (uint32_t)((nw[e][k] >> dl) & 1u);
                     const double c = (snew ^ sbit) ? -4.0 : 4.0;                 // 4 * sigma_xy with the NEW s_x
-                    const double v = __dadd_rn(rep ? vrun : nf[k], -__dmul_rn(c, J[k]));
+                    const double v = __dadd_rn(rep ? vrun : nf[e][k], -__dmul_rn(c, J[e][k]));
                     vrun = v;
-                    lf[(size_t)y[k] * 64] = fast ? sv[k] : (slow ? v : nf[k]);
+                    const double out = fast ? sv[k] : (slow ? v : nf[e][k]);
+                    if (act) lf[(size_t)y[e][k] * 64] = out;
                 }
-                lf[(size_t)i * 64] = acc ? -lfi : lfi;
-                if (lane == 0) __hip_atomic_store(sp + i, wi ^ amask, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (act) lf[(size_t)i * 64] = acc ? -lfi[e] : lfi[e];
+                if (lane == 0) __hip_atomic_store(sp + (size_t)i * TPG, (word_t)(wi[e] ^ (word_t)amask), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
+            if (act) {
 #pragma unroll
-            for (int k = 0; k < K; ++k) rec[s][k][lane] = nf[k];                // lfields_last[y] = lfields[y] (slow) / the swap (fast)
-            vt[s][lane].v = acc ? lfi : 0.0;
-            vt[s][lane].tag = acc ? (uint32_t)it : 0u;
+                for (int k = 0; k < K; ++k) rec[s][k][dl] = nf[e][k];           // lfields_last[y] = lfields[y] (slow) / the swap (fast)
+                vown[s][dl] = acc ? lfi[e] : 0.0;
+                vtag[s][dl] = acc ? (uint32_t)it : 0u;
+            }
             SPF_STAMP(3);                                           // undo test, update, stores issued
-            // the field and spin stores must have been PERFORMED before the attempt is reported: a workgroup-scope release does not wait for
-            // vector stores (it relies on one compute unit issuing them in order; loads of another SIMD were seen to overtake them)
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, SPF_TEAM_SCOPE);
-            if (lane == 0) spf_lds_st(done + s, (int32_t)it);
-            SPF_STAMP(4);                                           // stores performed, attempt reported
+            SPF_TRACE(it, 5);
 #ifdef SPF_TEAM_STAMPS
             ++st_n;
 #endif
+        };
+        const std::integral_constant<int, 0> eA{};
+        const std::integral_constant<int, 1> eB{};
+#ifdef SPF_TEAM_NO_PAIRING
+        const bool together = false;
+#else
+        const bool together = valid[0] && valid[1] && !(conf[1] & 1ull);        // B commutes with A
+#endif
+        if (valid[0]) request(eA);
+        if (valid[1] && (together || !valid[0])) request(eB);
+        SPF_STAMP(1);                                               // waiting for the dependencies, requests out
+        if (valid[0]) decide(eA);
+        if (valid[1] && (together || !valid[0])) decide(eB);
+        if (valid[0]) finish(eA);
+        if (valid[1]) {
+            if (valid[0] && !together) {
+                report(eA);                                         // B's request waits for A's report
+                request(eB);
+                decide(eB);
+            }
+            finish(eB);
         }
+        report(eA);
+        report(eB);
+        SPF_STAMP(4);                                               // stores performed, attempts reported
     }
     // accepted moves: a count, whatever the order (the host clears acc_cur at the start of the call)
-    atomicAdd(reinterpret_cast<unsigned long long*>(P.acc_cur) + r, (unsigned long long)nacc);
+    if (act) atomicAdd(reinterpret_cast<unsigned long long*>(P.acc_cur) + r, (unsigned long long)nacc);
 #ifdef SPF_TEAM_STAMPS
     if (w == 0 && lane == 0) {
         unsigned long long* o = reinterpret_cast<unsigned long long*>(P.Es) + (size_t)x * 8;      // harness only: the sample buffer is not compared in this build

@@ -10,12 +10,13 @@ pytestmark = pytest.mark.gpu
 # every test of this module runs through the three builds of the sweep: spf_team_kernel with sixteen and with eight wavefronts per group of
 # 64 replicas (csrc/spf_team_kernel.hpp; the default picks between them by K and the number of groups), and spf_sweep_kernel, one
 # wavefront per group (csrc/spf_kernels.hpp).  GraphEANormal with L = 2 (two bonds to the same neighbour) runs through all of them
-SPF_BUILDS = {"team": {}, "team8": {"RRRMC_SPF_TEAM_WAVES": "8"}, "team16": {"RRRMC_SPF_TEAM_WAVES": "16"}, "single": {"RRRMC_SPF_TEAM": "0"}}
+SPF_BUILDS = {"team": {}, "team8": {"RRRMC_SPF_TEAM_WAVES": "8"}, "team16": {"RRRMC_SPF_TEAM_WAVES": "16", "RRRMC_SPF_TEAM_WIDTH": "64"},
+              "team32w": {"RRRMC_SPF_TEAM_WIDTH": "32"}, "single": {"RRRMC_SPF_TEAM": "0"}}
 
 
 @pytest.fixture(autouse=True, params=list(SPF_BUILDS))
 def spf_build(request, monkeypatch):
-    for k in ("RRRMC_SPF_TEAM", "RRRMC_SPF_TEAM_WAVES"):
+    for k in ("RRRMC_SPF_TEAM", "RRRMC_SPF_TEAM_WAVES", "RRRMC_SPF_TEAM_WIDTH"):
         monkeypatch.delenv(k, raising=False)
     for k, v in SPF_BUILDS[request.param].items():
         monkeypatch.setenv(k, v)

@@ -8,11 +8,13 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
-BUILDS = ({}, {"RRRMC_SPF_TEAM_WAVES": "8"}, {"RRRMC_SPF_TEAM_WAVES": "16"}, {"RRRMC_SPF_TEAM": "0"})
+# the default picks the team width by the number of groups (few replicas: teams of 16), the others pin a build
+BUILDS = ({}, {"RRRMC_SPF_TEAM_WAVES": "8"}, {"RRRMC_SPF_TEAM_WAVES": "16", "RRRMC_SPF_TEAM_WIDTH": "64"}, {"RRRMC_SPF_TEAM": "0"},
+          {"RRRMC_SPF_TEAM_WIDTH": "32"})
 
 
 def _set_build(monkeypatch, env):
-    for k in ("RRRMC_SPF_TEAM", "RRRMC_SPF_TEAM_WAVES"):
+    for k in ("RRRMC_SPF_TEAM", "RRRMC_SPF_TEAM_WAVES", "RRRMC_SPF_TEAM_WIDTH"):
         monkeypatch.delenv(k, raising=False)
     for k, v in env.items():
         monkeypatch.setenv(k, v)
@@ -173,3 +175,36 @@ def test_doubled_bonds_through_the_team_kernel(pkg, oracle, monkeypatch, D, beta
     for r in range(R):
         ref = oracle.standard_mc_spf(X.A, X.J, beta, iters, step, seed, C0[r], replica=r, form="ea")
         assert (Es[r] == ref[0]).all() and (C1[r] == ref[1]).all() and acc[r] == ref[2] and (lf1[r] == ref[3]).all()
+
+
+@pytest.mark.parametrize("case", range(12))
+def test_random_shapes_team_builds_against_the_single_wavefront_kernel(pkg, monkeypatch, case):
+    """Randomised soak: graph size and degree, replica count (so: team width and number of teams), beta, sampling step and the
+    lengths of three consecutive resumed calls (odd stream offsets, a launch boundary in some) drawn per case; every team build must leave
+    behind exactly what the one-attempt-at-a-time kernel leaves: samples, accepted counts, configurations, field cache, tracked energy."""
+    rng = np.random.default_rng(20251004 + case)
+    K = int(rng.integers(2, 7))
+    N = int(rng.integers(K + 2, 300))
+    N += (N * K) % 2
+    R = int(rng.integers(65, 700))
+    beta = float(rng.choice([0.0, 0.3, 1.0, 2.5]))
+    calls = [(int(rng.integers(1, 9000)), int(rng.integers(1, 500))) for _ in range(2)] + [((1 << 18) + int(rng.integers(0, 50)) if case % 4 == 0 else int(rng.integers(1, 3000)), 977)]
+    seed = 4242 + case
+    X = pkg.GraphRRGNormal(N, K, seed=seed)
+    outs = []
+    for env in (BUILDS[3], BUILDS[0], BUILDS[1], BUILDS[4]) if case % 2 else (BUILDS[3], BUILDS[0], BUILDS[2]):
+        _set_build(monkeypatch, env)
+        with pkg.Engine(X, R) as eng:
+            eng.seed(seed)
+            eng.init_spins_random()
+            got = []
+            eng.standard_mc(beta, 0, 1, want_energies=False)
+            eng.set_resume(True)
+            for iters, step in calls:
+                Es, acc = eng.standard_mc(beta, iters, step)
+                got += [Es, acc]
+            got += [eng.get_config().s.copy(), eng.fields(), eng.tracked_energy()]
+        outs.append(got)
+    for o in outs[1:]:
+        for u, v in zip(outs[0], o):
+            assert (np.asarray(u) == np.asarray(v)).all()

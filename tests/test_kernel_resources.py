@@ -76,29 +76,27 @@ def test_cont_wave_kernel_has_no_scratch(tmp_path):
     assert m[0]["vgpr_count"] <= 168, m[0]
 
 
-TU_TEAM = r'''
-#include <hip/hip_runtime.h>
-#include "spf_team_kernel.hpp"
-#define INST(K) template __global__ void rrrmc::spf_team_kernel<K, 16, 1>(rrrmc::SpfTeamParams); template __global__ void rrrmc::spf_team_kernel<K, 8, 1>(rrrmc::SpfTeamParams);
-INST(1) INST(2) INST(3) INST(4) INST(5) INST(6) INST(7) INST(8)
-'''
+def _spf_team_lds(K, NW, TW):
+    """spf_team_lds_bytes with spf_team_slots (csrc/spf_team_params.hpp)"""
+    M = 2 * (NW - 1)
+    return (8 * (K + 1) * TW + 4 * TW) * (M + NW) + 4 * (TW + 2 * M + 4)
 
 
 @pytest.mark.skipif(shutil.which("hipcc") is None, reason="hipcc not found")
 def test_spf_team_kernel_has_no_scratch_and_fits_its_workgroup(tmp_path):
-    """spf_team_kernel (standardMC on the Float64 sparse models): the sixteen-wavefront build runs 1024 threads per workgroup, i.e. at most
-    128 registers per thread; no build may touch private memory (the executing wavefronts sit in a latency chain, the retiring one is the
-    serial part of the whole kernel)."""
-    src = tmp_path / "team.hip"
-    src.write_text(TU_TEAM)
+    """spf_team_kernel (standardMC on the Float64 sparse models), every build of its translation unit (csrc/spf_team_tu.hip): the
+    sixteen-wavefront builds run 1024 threads per workgroup, i.e. at most 128 registers per thread; no build may touch private memory (a team's
+    pace is its wavefronts' own instruction streams); the builds are the ones whose records fit the 160 KiB of LDS."""
     asm = tmp_path / "team.s"
     subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-I", CSRC, "--cuda-device-only", "-S",
-                           str(src), "-o", str(asm)], cwd=str(tmp_path))
+                           os.path.join(CSRC, "spf_team_tu.hip"), "-o", str(asm)], cwd=str(tmp_path))
     meta = {n: m for n, m in kernel_metadata(asm.read_text()).items() if "spf_team_kernel" in n}
-    assert len(meta) == 16
+    want = [(K, NW, TW) for K in range(1, 9) for NW, TW in ((16, 64), (16, 32), (16, 16), (8, 64)) if _spf_team_lds(K, NW, TW) <= 160 * 1024]
+    assert len(meta) == len(want) == 29
     for n, m in meta.items():
         assert m["private_segment_fixed_size"] == 0 and m.get("vgpr_spill_count", 0) == 0, (n, m)       # (scalar registers may spill into vector lanes)
-        assert m["vgpr_count"] <= 128, (n, m)
+        nw = int(re.search(r"spf_team_kernelILi\d+ELi(\d+)E", n).group(1))
+        assert m["vgpr_count"] <= (128 if nw == 16 else 168), (n, m)      # eight wavefronts: three workgroups per compute unit up to 168
 
 
 TU_SKH = r'''

@@ -416,9 +416,9 @@ def test_oracle_reproduces_the_rrg_normal_tape(oracle):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("env", [{}, {"RRRMC_SPF_TEAM_WAVES": "8"}, {"RRRMC_SPF_TEAM": "0"}], ids=["team", "team8", "single"])
+@pytest.mark.parametrize("env", [{}, {"RRRMC_SPF_TEAM_WAVES": "8"}, {"RRRMC_SPF_TEAM_WIDTH": "32"}, {"RRRMC_SPF_TEAM": "0"}], ids=["team", "team8", "team32w", "single"])
 def test_hip_library_reproduces_the_rrg_normal_tape(pkg, monkeypatch, env):
-    for k in ("RRRMC_SPF_TEAM", "RRRMC_SPF_TEAM_WAVES"):
+    for k in ("RRRMC_SPF_TEAM", "RRRMC_SPF_TEAM_WAVES", "RRRMC_SPF_TEAM_WIDTH"):
         monkeypatch.delenv(k, raising=False)
     for k, v in env.items():
         monkeypatch.setenv(k, v)

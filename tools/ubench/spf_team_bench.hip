@@ -2,7 +2,7 @@
 // group, parity-tested against the oracle by tests/test_gpu_spf_parity.py) and through the team kernel, compares EVERYTHING both leave
 // behind bit for bit (fields, spins, undo records, move_last, energies, samples, accepted counts) and times both.
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off tools/ubench/spf_team_bench.hip -o tools/ubench/spf_team_bench.out
-//   ./tools/ubench/spf_team_bench.out [K = 3 | 4 | 6] [N = 4096] [R = 8192] [iters = 16384] [beta = 1.0] [launches = 3] [NW = 16 | 8] [step = 4096] [D = 1 | 2 | 4]
+//   ./tools/ubench/spf_team_bench.out [K = 3 | 4 | 6] [N = 4096] [R = 8192] [iters = 16384] [beta = 1.0] [launches = 3] [NW = 16 | 8] [step = 4096] [M = slots | 0] [TW = 64 | 32 | 16]
 // K = 3: ring + random perfect matching; K = 4 / 6: periodic square / cubic lattice with N = L^2 / L^3 sites.  Gaussian couplings.
 #include <hip/hip_runtime.h>
 
@@ -12,6 +12,7 @@
 #include <cstring>
 #include <vector>
 
+#include "../../rrrmc.jl_amd/csrc/spf_kernels.hpp"
 #include "../../rrrmc.jl_amd/csrc/spf_team_kernel.hpp"
 
 using namespace rrrmc;
@@ -48,7 +49,7 @@ static long long diff(const T* a, const T* b, size_t n, const char* what)
     if (bad) {
         printf("  MISMATCH %s: %lld of %zu differ, first at %zu\n", what, bad, n, first);
         int shown = 0;
-        for (size_t i = first; i < n && shown < 40; ++i)
+        for (size_t i = first; i < n && shown < 6; ++i)
             if (memcmp(&ha[i], &hb[i], sizeof(T)) != 0) {
                 unsigned long long ua = 0, ub = 0;
                 memcpy(&ua, &ha[i], sizeof(T)); memcpy(&ub, &hb[i], sizeof(T));
@@ -138,16 +139,20 @@ int main(int argc, char** argv)
 
     sweep_fn sweep = K == 3 ? spf_sweep_kernel<3> : K == 4 ? spf_sweep_kernel<4> : spf_sweep_kernel<6>;
     sweep_fn energy = K == 3 ? spf_energy_kernel<3> : K == 4 ? spf_energy_kernel<4> : spf_energy_kernel<6>;
-    const int D = argc > 9 ? atoi(argv[9]) : 1;
+    // M = slots (0: the build's default, spf_team_slots); TW = replicas per team (64 | 32 | 16)
+    int M = argc > 9 ? atoi(argv[9]) : 0;
+    const int TW = argc > 10 ? atoi(argv[10]) : 64;
     team_fn team = nullptr;
-    if (NW == 16 && D == 1) team = K == 3 ? spf_team_kernel<3, 16, 1> : K == 4 ? spf_team_kernel<4, 16, 1> : spf_team_kernel<6, 16, 1>;
-    if (NW == 16 && D == 2) team = K == 3 ? spf_team_kernel<3, 16, 2> : nullptr;
-    if (NW == 8 && D == 1) team = K == 3 ? spf_team_kernel<3, 8, 1> : K == 4 ? spf_team_kernel<4, 8, 1> : spf_team_kernel<6, 8, 1>;
-    if (NW == 8 && D == 2) team = K == 3 ? spf_team_kernel<3, 8, 2> : K == 4 ? spf_team_kernel<4, 8, 2> : spf_team_kernel<6, 8, 2>;
-    if (NW == 8 && D == 4) team = K == 3 ? spf_team_kernel<3, 8, 4> : K == 4 ? spf_team_kernel<4, 8, 4> : nullptr;
+#define TEAM_B(KK, NWW, MM, TT) (K == KK && NW == NWW && M == MM && TW == TT) team = spf_team_kernel<KK, NWW, MM, TT>
+#define TEAM_D(KK, NWW, TT) TEAM_B(KK, NWW, spf_team_slots(KK, NWW, TT), TT)
+    if (M == 0) M = spf_team_slots(K, NW, TW);
+    if TEAM_D(3, 16, 64); else if TEAM_D(4, 16, 64); else if TEAM_D(3, 8, 64); else if TEAM_D(4, 8, 64); else if TEAM_D(6, 8, 64);
+    else if TEAM_D(3, 16, 32); else if TEAM_D(4, 16, 32); else if TEAM_D(6, 16, 32);
+    else if TEAM_D(3, 16, 16); else if TEAM_D(4, 16, 16); else if TEAM_D(6, 16, 16);
+    else if TEAM_B(3, 16, 47, 64); else if TEAM_B(3, 8, 28, 64);
     if (!team) { fprintf(stderr, "no such build\n"); return 1; }
-    const size_t lds = spf_team_lds_bytes(K, NW, D);
-    printf("NW %d D %d: %zu bytes of LDS\n", NW, D, lds);
+    const size_t lds = spf_team_lds_bytes(K, NW, M, TW);
+    printf("NW %d M %d TW %d: %zu bytes of LDS\n", NW, M, TW, lds);
     CK(hipFuncSetAttribute(reinterpret_cast<const void*>(team), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
 
     auto params = [&](State& s) {
@@ -175,7 +180,7 @@ int main(int argc, char** argv)
         CK(hipEventRecord(e0, 0));
         hipLaunchKernelGGL(sweep, dim3(W), dim3(64), 0, 0, Pa);
         CK(hipEventRecord(e1, 0));
-        hipLaunchKernelGGL(team, dim3(W), dim3(NW * 64), lds, 0, TP);
+        hipLaunchKernelGGL(team, dim3(W * (64 / TW)), dim3(NW * 64), lds, 0, TP);
         CK(hipEventRecord(e2, 0));
         CK(hipDeviceSynchronize());
         float ma = 0.f, mb = 0.f;
@@ -190,7 +195,24 @@ int main(int argc, char** argv)
         bad += diff(sa.ml, sb.ml, (size_t)W * 64, "move_last");
         bad += diff(sa.E, sb.E, (size_t)W * 64, "E");
         bad += diff(sa.acc, sb.acc, (size_t)W * 64, "accepted");
-#ifdef SPF_TEAM_STAMPS
+#ifdef SPF_TEAM_TRACE
+        if (l == launches - 1) {
+            std::vector<unsigned long long> tr((size_t)(n + 1) * 8);
+            CK(hipMemcpy(tr.data(), sb.Es, sizeof(unsigned long long) * tr.size(), hipMemcpyDeviceToHost));
+            FILE* f = fopen("gpurun_out/spf_trace.txt", "w");
+            const long long a0 = n / 2, a1 = a0 + 600;
+            if (f) {
+                fprintf(f, "# it wave request work_off decided undo_checked slot_free stores_issued reported retired   (cycles from the first line's request)\n");
+                const unsigned long long t0 = tr[(size_t)a0 * 8];
+                for (long long t = a0; t < a1 && t <= n; ++t) {
+                    fprintf(f, "%lld %d", t, (int)((((unsigned long long)t + (g0 - (uint64_t)n)) >> 1) - ((g0 - (uint64_t)n + 1) >> 1)) % (NW - 1));
+                    for (int q = 0; q < 8; ++q) fprintf(f, " %lld", (long long)(tr[(size_t)t * 8 + q] - t0));
+                    fprintf(f, "\n");
+                }
+                fclose(f);
+            }
+        }
+#elif defined(SPF_TEAM_STAMPS)
         {
             std::vector<unsigned long long> hst(16 * 8);
             CK(hipMemcpy(hst.data(), sb.Es, sizeof(unsigned long long) * hst.size(), hipMemcpyDeviceToHost));
