@@ -53,9 +53,12 @@ enum rrrmc_model {
     RRRMC_MODEL_SPARSE_DISCRETIZED = 6, /* GraphRRGNormalDiscretized src/graphs/RRG.jl:285-307, GraphEANormalDiscretized src/graphs/EA.jl:311-352 (Int or DFloat64 LEV) */
     RRRMC_MODEL_SPARSE_LEVELS = 7,      /* GraphRRG{ET,LEV,K} src/graphs/RRG.jl:116-162, GraphEA{ET,LEV,2D} src/graphs/EA.jl:138-193 with levels other than (-1,1); ET = Int or DFloat64 */
     RRRMC_MODEL_SK_BINARY = 4,   /* GraphSK (couplings +-1/sqrt(N), bit-packed) src/graphs/SK.jl:28-60; K is ignored; energies Float64 */
-    RRRMC_MODEL_QUANT_RRG = 3    /* GraphQuant over M Suzuki-Trotter slices of one GraphRRG{Int,(-1,1),K} disorder
+    RRRMC_MODEL_QUANT_RRG = 3,   /* GraphQuant over M Suzuki-Trotter slices of one GraphRRG{Int,(-1,1),K} disorder
                                     (src/graphs/QT.jl:126-170 with the shared-disorder pattern of src/QAliases.jl:43-67);
                                     created with rrrmc_ctx_create_quant */
+    /* selectors for rrrmc_ctx_create_multi only (the contexts it makes report RRRMC_MODEL_QUANT_RRG): */
+    RRRMC_MODEL_QUANT_SK = 8,    /* GraphQuant over binary GraphSK slices (GraphQSKT, src/QAliases.jl:34-43): rrrmc_ctx_create_quant_sk per device */
+    RRRMC_MODEL_QUANT_SKN = 9    /* GraphQuant over GraphSKNormal slices (GraphQSKNormalT, src/QAliases.jl:45-46): rrrmc_ctx_create_quant_skn per device */
 };
 
 /* Library ABI version (major*10000 + minor*100 + patch). */
@@ -96,7 +99,8 @@ RRRMC_API int32_t rrrmc_ctx_create(rrrmc_ctx **out, int32_t model, int64_t N, in
  * accepts the multi-device context: per-replica buffers ([R], [R x nsamples], [R x chunks] ...) are the caller's full arrays and
  * arrive gathered; enqueueing calls return when every device has its work queued, rrrmc_sync / fetch / energy calls run one host
  * thread per device.  rrrmc_last_timing / rrrmc_timing_total report the slowest device.
- *   model  any rrrmc_model; RRRMC_MODEL_QUANT_RRG takes (N = Nk, K, M) as rrrmc_ctx_create_quant does, M is ignored otherwise.
+ *   model  any rrrmc_model; RRRMC_MODEL_QUANT_RRG takes (N = Nk, K, M) as rrrmc_ctx_create_quant does, RRRMC_MODEL_QUANT_SK / _SKN take
+ *          (N = Nk, M) as rrrmc_ctx_create_quant_sk / _skn do (K ignored); M is ignored otherwise.
  */
 RRRMC_API int32_t rrrmc_ctx_create_multi(rrrmc_ctx **out, int32_t model, int64_t N, int64_t K, int64_t M, int64_t R,
                                          const int32_t *device_ids, int32_t ndev, uint32_t replica0);

@@ -10,11 +10,17 @@
 # One `Ctx` = the R replicas of one graph, on one device (`device = k`) or sharded over several from this one process
 # (`devices = [0, 1, ...]` -> rrrmc_ctx_create_multi: the library runs one stream and one host thread per device and hands back
 # gathered results).  The random streams are addressed by (seed, global replica id, iteration): results never depend on the sharding.
-# Every sampler method takes the Ctx first, then the reference's own arguments and keywords (src/RRRMC.jl:81-88,149,221,311,376,474),
-# and returns per-replica results: `Es` is samples × R (column r = the vector the reference returns for one chain), `Cs::Vector{Config}`.
+# Two layers of sampler methods:
+#   * the reference's OWN signatures on a wrapped graph — `standardMC(OnGPU(X), β, iters; seed, step, hook, C0, quiet) -> (Es::Vector{ET},
+#     C::Config)` (src/RRRMC.jl:81-88,126), likewise rrrMC / bklMC / wtmMC / extremal_opt (:149,221,311,376,474): a reference script runs
+#     with ONE line changed (`X = OnGPU(X)`; INTEGRATION.md shows scripts/scripts.jl:76-101).  `OnGPU(X; replicas = R, devices = [...])`
+#     runs R chains at once and returns `(Es::Matrix samples×R, Cs::Vector{Config})`.  Each call makes and finalises its own Ctx.
+#   * the same with an explicit context first (`standardMC(ctx, X, β, iters; ...)`) for callers that keep the device state between calls;
+#     results per replica: `Es` is samples × R (column r = the vector the reference returns for one chain), `Cs::Vector{Config}`.
 module RRRMCHip
 using RRRMC
 const LIB = get(ENV, "RRRMC_HIP_LIB", "librrrmc_hip.so")
+export OnGPU
 const DEFAULT_SEED = 167432777111                                  # the reference's default, src/RRRMC.jl:82
 
 check(rc, ctx = C_NULL) = rc == 0 ? nothing :
@@ -39,6 +45,7 @@ version() = Int(ccall((:rrrmc_version, LIB), Int32, ()))
 
 # model kinds of include/rrrmc_hip.h
 const SPARSE_PM1, SK_NORMAL, QUANT_RRG, SK_BINARY, SPARSE_F64, SPARSE_DISCRETIZED, SPARSE_LEVELS = 1, 2, 3, 4, 5, 6, 7
+const QUANT_SK, QUANT_SKN = 8, 9           # selectors of rrrmc_ctx_create_multi: GraphQuant over GraphSK / GraphSKNormal slices
 
 # rrrmc_ctx_create / rrrmc_ctx_create_quant on one device, rrrmc_ctx_create_multi on several (N = Nk for a GraphQuant)
 function create(model::Integer, N::Integer, K::Integer, M::Integer, R::Integer; device = 0, replica0 = 0, devices = nothing)
@@ -143,14 +150,20 @@ function Ctx(X::RRRMC.QT.GraphQuant{fourK,G}, R::Integer, β::Real; device = 0, 
     X1 = X.X1[1]; Nk = X.Nk; M = X.M
     ref = Ref{Ptr{Cvoid}}(C_NULL)
     if G <: RRRMC.SK.GraphSK
-        devices === nothing || throw(ArgumentError("a GraphQuant over dense slices has no multi-device context"))
-        check(ccall((:rrrmc_ctx_create_quant_sk, LIB), Int32, (Ref{Ptr{Cvoid}}, Int64, Int64, Int64, Int32, UInt32), ref, Nk, M, R, device, replica0))
+        if devices === nothing
+            check(ccall((:rrrmc_ctx_create_quant_sk, LIB), Int32, (Ref{Ptr{Cvoid}}, Int64, Int64, Int64, Int32, UInt32), ref, Nk, M, R, device, replica0))
+        else
+            ref[] = create(QUANT_SK, Nk, 0, M, R; replica0 = replica0, devices = devices)
+        end
         ctx = Ctx(ref[], R, Nk * M, true)
         Jc = sk_bits(X1.J)
         GC.@preserve Jc check(ccall((:rrrmc_set_couplings_bits, LIB), Int32, (Ptr{Cvoid}, Ptr{UInt64}), ctx.p, Jc), ctx.p)
     elseif G <: RRRMC.SK.GraphSKNormal
-        devices === nothing || throw(ArgumentError("a GraphQuant over dense slices has no multi-device context"))
-        check(ccall((:rrrmc_ctx_create_quant_skn, LIB), Int32, (Ref{Ptr{Cvoid}}, Int64, Int64, Int64, Int32, UInt32), ref, Nk, M, R, device, replica0))
+        if devices === nothing
+            check(ccall((:rrrmc_ctx_create_quant_skn, LIB), Int32, (Ref{Ptr{Cvoid}}, Int64, Int64, Int64, Int32, UInt32), ref, Nk, M, R, device, replica0))
+        else
+            ref[] = create(QUANT_SKN, Nk, 0, M, R; replica0 = replica0, devices = devices)
+        end
         ctx = Ctx(ref[], R, Nk * M, true)
         Jm = Matrix{Float64}(undef, Nk, Nk); for i = 1:Nk; Jm[:, i] = X1.J[i]; end
         GC.@preserve Jm check(ccall((:rrrmc_set_couplings_dense, LIB), Int32, (Ptr{Cvoid}, Ptr{Float64}), ctx.p, Jm), ctx.p)
@@ -236,8 +249,9 @@ With a `hook(it, X, Cs, accepted, E)::Bool` (the reference's hook, :61-64, hande
 hook points and RESUMED (`rrrmc_set_resume`): cache and tracked energy live on across the pieces exactly as inside one reference
 call (:95-118), so a hooked run is the un-hooked chain bit for bit — for the Float64 models too — and `E` is the tracked energy.
 The reference's hook ends ONE chain (`hook(...) || break`, :107): the hook may also return a `Vector{Bool}`, one flag per replica; a
-replica whose flag is `false` is frozen at that sample (its column of `Es` is `missing`-free up to there and repeated afterwards, its
-`Config` is the one of that moment, and `stopped_at(ctx)` tells the iteration), the others go on; the run ends when none is left.
+replica whose flag is `false` is frozen at that sample: from then on its column of `Es` repeats the energy it had, the `Config` and the
+accepted count handed to later hooks (and returned) are the ones of that moment, and `stopped_at(ctx)` tells the iteration; the others go
+on; the run ends when none is left.
 """
 function RRRMC.standardMC(ctx::Ctx, X::RRRMC.Interface.AbstractGraph, β::Real, iters::Integer; seed = DEFAULT_SEED, step::Integer = 1,
                           hook = nothing, C0::Union{Vector{RRRMC.Config},Nothing} = nothing, quiet = false)
@@ -261,7 +275,7 @@ function RRRMC.standardMC(ctx::Ctx, X::RRRMC.Interface.AbstractGraph, β::Real, 
     end
     check(ccall((:rrrmc_set_resume, LIB), Int32, (Ptr{Cvoid}, Int32), ctx.p, 1), ctx.p)
     fill!(ctx.stopped, 0)
-    frozen_chunks = copy(chunks)
+    frozen_chunks = copy(chunks); frozen_E = Vector{ET}(undef, ctx.R); frozen_acc = zeros(Int, ctx.R)
     try
         while it < iters
             nxt = (it ÷ step + 1) * step
@@ -273,8 +287,12 @@ function RRRMC.standardMC(ctx::Ctx, X::RRRMC.Interface.AbstractGraph, β::Real, 
             else
                 E .= energies(ctx)                                          # integer models: recomputed == tracked, exactly
             end
+            Cs = get_configs!(ctx, chunks, C0)
+            for r in 1:ctx.R                                                # a frozen replica's chain has ended for the caller
+                ctx.stopped[r] > 0 && (E[r] = frozen_E[r]; Cs[r].s.chunks .= frozen_chunks[:, r])
+            end
             push!(Es, E)
-            go = hook(nxt, X, get_configs!(ctx, chunks, C0), copy(accepted), E)
+            go = hook(nxt, X, Cs, [ctx.stopped[r] > 0 ? frozen_acc[r] : accepted[r] for r in 1:ctx.R], E)
             if go isa Bool
                 go || (it = nxt; break)
             else
@@ -282,7 +300,7 @@ function RRRMC.standardMC(ctx::Ctx, X::RRRMC.Interface.AbstractGraph, β::Real, 
                 for r in 1:ctx.R
                     if !go[r] && ctx.stopped[r] == 0                        # frozen now: keep what the reference's chain would return
                         ctx.stopped[r] = nxt
-                        frozen_chunks[:, r] .= chunks[:, r]
+                        frozen_chunks[:, r] .= chunks[:, r]; frozen_E[r] = E[r]; frozen_acc[r] = accepted[r]
                     end
                 end
                 all(>(0), ctx.stopped) && (it = nxt; break)
@@ -299,6 +317,8 @@ function RRRMC.standardMC(ctx::Ctx, X::RRRMC.Interface.AbstractGraph, β::Real, 
         end
         Cs = put_configs!(ctx, chunks, C0)
     end
+    quiet || println("samples = ", length(Es), "\niters = ", it, "\naccept rate = ",
+                     sum([ctx.stopped[r] > 0 ? frozen_acc[r] / ctx.stopped[r] : accepted[r] / max(it, 1) for r in 1:ctx.R]) / ctx.R)
     return isempty(Es) ? Matrix{ET}(undef, 0, ctx.R) : permutedims(reduce(hcat, Es)), Cs
 end
 "iteration at which replica r's hook said stop in the last hooked `standardMC` (0 = it ran to the end)"
@@ -445,7 +465,6 @@ function rrr_cache(ctx::Ctx, X)
     return pos, sizes
 end
 
-"kernel time of the last sampling call: (total ms, dominant-kernel ms, its launches); the slowest device of a multi-device Ctx"
 """
     host_alloc(T, dims...) -> Array{T}
 
@@ -460,10 +479,103 @@ function host_alloc(::Type{T}, dims::Integer...) where {T}
 end
 host_free(A::Array) = (ccall((:rrrmc_host_free, LIB), Int32, (Ptr{Cvoid},), pointer(A)); nothing)
 
+"kernel time of the last sampling call: (total ms, dominant-kernel ms, its launches); the slowest device of a multi-device Ctx"
 function last_timing(ctx::Ctx)
     tot = Ref{Float64}(0.0); sw = Ref{Float64}(0.0); nl = Ref{Int32}(0)
     check(ccall((:rrrmc_last_timing, LIB), Int32, (Ptr{Cvoid}, Ref{Float64}, Ref{Float64}, Ref{Int32}), ctx.p, tot, sw, nl), ctx.p)
     return tot[], sw[], Int(nl[])
+end
+
+# ---- the reference's own signatures: wrap the graph, change nothing else ----------------------------------------------------------------
+"""
+    OnGPU(X; replicas = 1, device = 0, devices = nothing, replica0 = 0)
+
+`standardMC(OnGPU(X), β, iters; seed, step, hook, C0, quiet)` is the reference's `standardMC(X, β, iters; ...)` (src/RRRMC.jl:81-88) run by
+the library: same arguments, same keywords, same return value `(Es::Vector{ET}, C::Config)` (:126), `C0` resumed and mutated in place (:93),
+the hook called as `hook(it, X, C, accepted, E)` with the UNWRAPPED graph (:107).  `rrrMC`, `bklMC`, `wtmMC` and `extremal_opt` likewise
+(:149-157, 221-229, 311, 376, 474).  With `replicas = R > 1` the call runs R independent chains (replica ids `replica0 .+ (0:R-1)` address
+the random streams) and returns `(Es::Matrix{ET} samples×R, Cs::Vector{Config})`; `C0` is then a `Vector{Config}` and the hook gets the
+vectors of all replicas (see the context-first `standardMC`).  `devices = [0, 1, ...]` shards the replicas over several GPUs from this one
+process.  Every call makes its own context and finalises it before returning.
+"""
+struct OnGPU{G<:RRRMC.Interface.AbstractGraph}
+    X::G
+    replicas::Int
+    device::Int
+    devices::Union{Nothing,Vector{Int}}
+    replica0::Int
+end
+OnGPU(X::RRRMC.Interface.AbstractGraph; replicas::Integer = 1, device::Integer = 0, devices = nothing, replica0::Integer = 0) =
+    OnGPU{typeof(X)}(X, replicas, device, devices === nothing ? nothing : collect(Int, devices), replica0)
+RRRMC.getN(G::OnGPU) = RRRMC.getN(G.X)
+
+# one context per call (β is needed by a GraphQuant's context only)
+function with_ctx(f, G::OnGPU, β::Real)
+    ctx = if G.X isa RRRMC.QT.GraphQuant
+        Ctx(G.X, G.replicas, β; device = G.device, replica0 = G.replica0, devices = G.devices)
+    else
+        Ctx(G.X, G.replicas; device = G.device, replica0 = G.replica0, devices = G.devices)
+    end
+    try
+        return f(ctx)
+    finally
+        finalize(ctx)
+    end
+end
+single(G::OnGPU) = G.replicas == 1
+configs_in(G::OnGPU, C0) = C0 ≡ nothing ? nothing : (C0 isa RRRMC.Config ? RRRMC.Config[C0] : C0)
+# one chain: a Vector and a Config, as the reference returns them; several: the matrix and the vector of Configs
+unwrap1(G::OnGPU, Es::AbstractMatrix) = single(G) ? Es[:, 1] : Es
+unwrap1(G::OnGPU, v::AbstractVector) = single(G) ? v[1] : v
+no_hook(hook, what) = hook ≡ nothing || throw(ArgumentError("$what on the GPU takes no hook (its chain cannot be cut and resumed); use standardMC, or sample with `step`"))
+
+function RRRMC.standardMC(G::OnGPU, β::Real, iters::Integer; seed = DEFAULT_SEED, step::Integer = 1, hook = nothing,
+                          C0::Union{RRRMC.Config,Vector{RRRMC.Config},Nothing} = nothing, quiet::Bool = false)
+    h = hook ≡ nothing || !single(G) ? hook : (it, X, Cs, acc, E) -> hook(it, X, Cs[1], acc[1], E[1])
+    with_ctx(G, β) do ctx
+        Es, Cs = RRRMC.standardMC(ctx, G.X, β, iters; seed = seed, step = step, hook = h, C0 = configs_in(G, C0), quiet = quiet)
+        return unwrap1(G, Es), unwrap1(G, Cs)
+    end
+end
+
+function RRRMC.rrrMC(G::OnGPU, β::Real, iters::Integer; seed = DEFAULT_SEED, step::Integer = 1, hook = nothing,
+                     C0::Union{RRRMC.Config,Vector{RRRMC.Config},Nothing} = nothing,
+                     staged_thr::Real = G.X isa RRRMC.Interface.DoubleGraph ? 0.5 : NaN, staged_thr_fact::Real = 5.0, quiet::Bool = false)
+    no_hook(hook, "rrrMC")
+    thr = isnan(staged_thr) ? (G.X isa RRRMC.Interface.DiscrGraph ? 0.5 : 0.8) : staged_thr          # src/RRRMC.jl:162-164
+    with_ctx(G, β) do ctx
+        Es, Cs, _, _ = RRRMC.rrrMC(ctx, G.X, β, iters; seed = seed, step = step, C0 = configs_in(G, C0), staged_thr = thr,
+                                   staged_thr_fact = staged_thr_fact, quiet = quiet)
+        return unwrap1(G, Es), unwrap1(G, Cs)
+    end
+end
+
+function RRRMC.bklMC(G::OnGPU, β::Real, iters::Integer; seed = DEFAULT_SEED, step::Integer = 1, hook = nothing,
+                     C0::Union{RRRMC.Config,Vector{RRRMC.Config},Nothing} = nothing, quiet::Bool = false)
+    no_hook(hook, "bklMC")
+    with_ctx(G, β) do ctx
+        Es, Cs, _ = RRRMC.bklMC(ctx, G.X, β, iters; seed = seed, step = step, C0 = configs_in(G, C0), quiet = quiet)
+        return unwrap1(G, Es), unwrap1(G, Cs)
+    end
+end
+
+function RRRMC.wtmMC(G::OnGPU, β::Real, samples::Integer; seed = DEFAULT_SEED, step::Float64 = 1.0, hook = nothing,
+                     C0::Union{RRRMC.Config,Vector{RRRMC.Config},Nothing} = nothing, quiet::Bool = false)
+    no_hook(hook, "wtmMC")
+    with_ctx(G, β) do ctx
+        Es, Cs, _, _ = RRRMC.wtmMC(ctx, G.X, β, samples; seed = seed, step = step, C0 = configs_in(G, C0), quiet = quiet)
+        return unwrap1(G, Es), unwrap1(G, Cs)
+    end
+end
+
+"-> (C, Emin, Cmin, itmin), the reference's return tuple (src/RRRMC.jl:520); vectors of them for several replicas"
+function RRRMC.extremal_opt(G::OnGPU, τ::Real, iters::Integer; seed = DEFAULT_SEED, step::Integer = 1, hook = nothing,
+                            C0::Union{RRRMC.Config,Vector{RRRMC.Config},Nothing} = nothing, quiet::Bool = false)
+    no_hook(hook, "extremal_opt")
+    with_ctx(G, 1.0) do ctx
+        Cs, Emin, Cmin, itmin, _ = RRRMC.extremal_opt(ctx, G.X, τ, iters; seed = seed, step = step, C0 = configs_in(G, C0), quiet = quiet)
+        return unwrap1(G, Cs), unwrap1(G, Emin), unwrap1(G, Cmin), unwrap1(G, itmin)
+    end
 end
 
 end # module

@@ -277,6 +277,26 @@ int32_t sk_standard_mc_async(rrrmc_ctx* ctx, double beta, int64_t iters, int64_t
     }
     // (still none: the one-attempt-at-a-time kernels below, for both models)
 
+    if (iters == 0) {
+        // nothing to sweep: the call is E = energy(X, C) (RRRMC.jl:95) and an empty sample list — the bindings issue it before a hooked run.
+        // No sweep kernel is launched (some shapes, 2048 < N <= 4096, have a blocked build only, which needs iterations to plan)
+        HIP_TRY(ctx, hipEventRecord(ctx->ev_sweep[0], st));
+        HIP_TRY(ctx, hipEventRecord(ctx->ev_sweep[1], st));
+        HIP_TRY(ctx, hipEventRecord(ctx->ev_end, st));
+        ctx->sweep_launches = 1;
+        ctx->nsamp = 0;
+        ctx->results_valid = true;
+        ctx->timing_valid = true;
+        return RRRMC_OK;
+    }
+    if (!blockk) {
+        // no blocked build covers the shape (RRRMC_SK_LEGACY / RRRMC_SK_BLOCK_V1 / RRRMC_SK_THREADS can ask for one that does not exist)
+        const int nthl = sk_threads_for(ctx->N), sptl = (int)((ctx->N + nthl - 1) / nthl);
+        if (binary ? skb_sweep_for(sptl, nthl) == nullptr : sk_sweep_for(sptl, nthl) == nullptr)
+            return fail(ctx, RRRMC_ERR_UNSUPPORTED, "no dense-SK kernel build covers N=%lld with %d threads per workgroup under the requested RRRMC_SK_* overrides",
+                        (long long)ctx->N, nthl);
+    }
+
     if (binary && blockk && iters > 0) {
         // the blocked kernel on the binary model's state as doubles (sk_block_kernel<.., BIN>): the +-4.0 matrix is built from the bit rows
         // once, the integer fields travel int32 -> Float64 -> int32 around the call (exact)

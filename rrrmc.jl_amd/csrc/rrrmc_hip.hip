@@ -1657,17 +1657,19 @@ int32_t rrrmc_ctx_create_multi(rrrmc_ctx** out, int32_t model, int64_t N, int64_
     if (replica0 % 32) return fail(nullptr, RRRMC_ERR_INVALID_ARG, "replica0 must be a multiple of 32 (given %u)", replica0);
     rrrmc_ctx* ctx = new (std::nothrow) rrrmc_ctx();
     if (!ctx) return fail(nullptr, RRRMC_ERR_NOMEM, "out of host memory");
-    ctx->model = model; ctx->K = K; ctx->R = R; ctx->replica0 = replica0; ctx->device = device_ids[0];
-    ctx->N = model == RRRMC_MODEL_QUANT_RRG ? N * M : N;
-    if (model == RRRMC_MODEL_QUANT_RRG) { ctx->qNk = N; ctx->qM = M; }
+    const bool quant = model == RRRMC_MODEL_QUANT_RRG || model == RRRMC_MODEL_QUANT_SK || model == RRRMC_MODEL_QUANT_SKN;
+    ctx->model = quant ? RRRMC_MODEL_QUANT_RRG : model; ctx->K = K; ctx->R = R; ctx->replica0 = replica0; ctx->device = device_ids[0];
+    ctx->N = quant ? N * M : N;
+    if (quant) { ctx->qNk = N; ctx->qM = M; ctx->q_sk = model == RRRMC_MODEL_QUANT_SK; ctx->q_skn = model == RRRMC_MODEL_QUANT_SKN; }
     for (int32_t d = 0; d < ndev; ++d) {
         int64_t b0 = 0, b1 = 0;
         shard_bounds(R, ndev, d, &b0, &b1);
         if (b1 <= b0) continue;          // fewer groups than devices: this one stays idle
         rrrmc_ctx* c = nullptr;
-        const int32_t rc = model == RRRMC_MODEL_QUANT_RRG
-                               ? rrrmc_ctx_create_quant(&c, N, K, M, b1 - b0, device_ids[d], replica0 + (uint32_t)b0)
-                               : rrrmc_ctx_create(&c, model, N, K, b1 - b0, device_ids[d], replica0 + (uint32_t)b0);
+        const int32_t rc = model == RRRMC_MODEL_QUANT_RRG   ? rrrmc_ctx_create_quant(&c, N, K, M, b1 - b0, device_ids[d], replica0 + (uint32_t)b0)
+                           : model == RRRMC_MODEL_QUANT_SK  ? rrrmc_ctx_create_quant_sk(&c, N, M, b1 - b0, device_ids[d], replica0 + (uint32_t)b0)
+                           : model == RRRMC_MODEL_QUANT_SKN ? rrrmc_ctx_create_quant_skn(&c, N, M, b1 - b0, device_ids[d], replica0 + (uint32_t)b0)
+                                                            : rrrmc_ctx_create(&c, model, N, K, b1 - b0, device_ids[d], replica0 + (uint32_t)b0);
         if (rc) {
             for (rrrmc_ctx* k : ctx->kids) rrrmc_ctx_destroy(k);
             delete ctx;

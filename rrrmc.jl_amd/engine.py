@@ -9,6 +9,7 @@ from .graphs import DEFAULT_SEED, Config, GraphEA, nchunks
 MODEL_SPARSE_PM1 = 1
 MODEL_SK_NORMAL = 2
 MODEL_QUANT_RRG = 3
+MODEL_QUANT_SK, MODEL_QUANT_SKN = 8, 9          # selectors of rrrmc_ctx_create_multi (dense-slice GraphQuant)
 MODEL_SK_BINARY = 4
 MODEL_SPARSE_F64 = 5
 MODEL_SPARSE_DISCRETIZED = 6
@@ -26,11 +27,11 @@ class Engine:
         self._f64 = X.model_kind not in (MODEL_SPARSE_PM1, MODEL_SPARSE_LEVELS)
         self._units = X.model_kind == MODEL_SPARSE_LEVELS        # device energies are int64 level units: X.energy_value converts
         if devices is not None:
-            if X.model_kind == MODEL_QUANT_RRG and (getattr(X, "skn_slices", False) or X.sk_slices):
-                raise RRRMCError(3, "a GraphQuant over dense slices has no multi-device context")
             ids = np.asarray(list(devices), np.int32)
             quant = X.model_kind == MODEL_QUANT_RRG
-            check(lib().rrrmc_ctx_create_multi(C.byref(self._ctx), X.model_kind, X.Nk if quant else X.N, X.K, X.M if quant else 0, self.R,
+            # a GraphQuant over dense slices is made per device by rrrmc_ctx_create_quant_skn / _sk: the selectors 9 / 8 of the header
+            kind = X.model_kind if not quant else MODEL_QUANT_SKN if getattr(X, "skn_slices", False) else MODEL_QUANT_SK if X.sk_slices else X.model_kind
+            check(lib().rrrmc_ctx_create_multi(C.byref(self._ctx), kind, X.Nk if quant else X.N, X.K, X.M if quant else 0, self.R,
                                                ids, len(ids), replica0))
         elif X.model_kind == MODEL_QUANT_RRG and getattr(X, "skn_slices", False):
             check(lib().rrrmc_ctx_create_quant_skn(C.byref(self._ctx), X.Nk, X.M, self.R, device, replica0))
@@ -130,6 +131,10 @@ class Engine:
             Es, acc = out
             if Es.shape != (self.R, nsamp) or Es.dtype != (np.float64 if self._f64 else np.int64) or acc.shape != (self.R,) or acc.dtype != np.int64:
                 raise ValueError("out must be (Es[R, iters // step] of the model's energy type, accepted[R] int64)")
+            # the library writes R * nsamp contiguous values behind the pointer: a strided view of a larger buffer would be filled in the wrong
+            # layout (and its neighbours overwritten), a read-only array must not be written at all
+            if not (Es.flags.c_contiguous and acc.flags.c_contiguous and Es.flags.writeable and acc.flags.writeable):
+                raise ValueError("out arrays must be C-contiguous and writeable (slice a pinned buffer along its first axis, not its second)")
         else:
             Es = np.zeros((self.R, nsamp), np.float64 if self._f64 else np.int64)
             acc = np.zeros(self.R, np.int64)
@@ -473,7 +478,10 @@ def standardMC(X, beta, iters, *, seed=DEFAULT_SEED, step=1, hook=None, C0=None,
                     E = eng.tracked_energy()
                     samples.append(E)
                     eng.get_config(Cfg)
-                    go = hook(nxt, X, Cfg, accepted.copy(), E)
+                    # a frozen replica's chain has ended for the caller: the hook keeps seeing the count and configuration it had then
+                    if frozen.any():
+                        Cfg.s[frozen] = frozen_cfg.s[frozen]
+                    go = hook(nxt, X, Cfg, np.where(frozen, frozen_acc, accepted), E)
                     if np.ndim(go) == 0:
                         if not go:
                             it = nxt
@@ -507,7 +515,11 @@ def standardMC(X, beta, iters, *, seed=DEFAULT_SEED, step=1, hook=None, C0=None,
         if not quiet:
             print("samples = ", Es.shape[1] if hasattr(Es, "shape") else [len(e) for e in Es])
             print("iters = ", it)
-            print("accept rate = ", float(accepted.mean()) / max(it, 1))
+            # a frozen replica's count is over the iterations it ran (frozen_nsamp samples of `step` iterations each)
+            ran = np.full(eng.R, max(it, 1), np.float64)
+            if hook is not None and frozen.any():
+                ran[frozen] = np.maximum(frozen_nsamp[frozen] * step, 1)
+            print("accept rate = ", float((accepted / ran).mean()))
         return Es, Cfg
     finally:
         if own:

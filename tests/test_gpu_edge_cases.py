@@ -236,3 +236,23 @@ def test_gpu_replicas_follow_the_boltzmann_law(pkg, oracle):
     chi2 = float((((counts - R * p) ** 2) / (R * p)).sum())
     assert chi2 < 4 * 2 ** N, chi2                                 # 63 degrees of freedom
     assert abs((counts / R) @ Es - p @ Es) < 0.15                 # mean energy
+
+
+def test_result_arrays_of_the_caller_must_be_contiguous_and_writeable(pkg):
+    """Engine.standard_mc(out=(Es, accepted)) hands raw pointers to the C ABI, which writes R * nsamp contiguous values: a strided view of a
+    larger reusable buffer or a read-only array is refused before the call, a fitting slice along the first axis is filled."""
+    X = pkg.GraphRRG(64, 3, seed=5)
+    with pkg.Engine(X, 32) as eng:
+        eng.seed(5)
+        eng.init_spins_random()
+        big = np.zeros((32, 16), np.int64)
+        acc = np.zeros(32, np.int64)
+        with pytest.raises(ValueError):
+            eng.standard_mc(1.0, 800, 100, out=(big[:, :8], acc))
+        ro = np.zeros((32, 8), np.int64)
+        ro.setflags(write=False)
+        with pytest.raises(ValueError):
+            eng.standard_mc(1.0, 800, 100, out=(ro, acc))
+        ok = np.zeros((64, 8), np.int64)
+        Es, a = eng.standard_mc(1.0, 800, 100, out=(ok[:32], acc))
+        assert Es.shape == (32, 8) and (ok[32:] == 0).all() and a.sum() > 0

@@ -119,3 +119,26 @@ def test_float64_sparse_multi_equals_single_and_oracle(pkg, oracle):
     for r in (0, 63, 64, 129):
         ref = oracle.standard_mc_spf(X.A, X.J, beta, iters, step, seed, C0[r], replica=r)
         assert (Es[r] == ref[0]).all() and acc[r] == ref[2]
+
+
+@pytest.mark.parametrize("dense", ["sk", "skn"])
+def test_quant_over_dense_slices_multi_equals_single(pkg, dense):
+    """GraphQuant over binary GraphSK / GraphSKNormal slices (GraphQSKT / GraphQSKNormalT, src/QAliases.jl:34-46 — the graph of the reference's
+    quantum experiment) through one context over several shards (rrrmc_ctx_create_multi with the RRRMC_MODEL_QUANT_SK / _SKN selectors):
+    rrrMC, standardMC, energies and configurations equal the single-device context's, replica by replica."""
+    seed, Nk, M, R, beta, Gamma = 606, 24, 6, 100, 1.5, 0.4
+    X = (pkg.GraphQSKT if dense == "sk" else pkg.GraphQSKNormalT)(Nk, M, Gamma, beta, seed=seed)
+    outs = []
+    for devs in [None] + devices_for_test(pkg):
+        with pkg.Engine(X, R, devices=devs) as eng:
+            eng.seed(seed); eng.init_spins_random()
+            E0 = eng.energy()
+            Es, acc, staged = eng.rrr_mc(beta, 4000, 200)
+            Es2, acc2 = eng.standard_mc(beta, 3000, 500)
+            got = [E0, Es, acc, staged, Es2, acc2, eng.get_config().s.copy(), eng.energy()]
+            if dense == "sk":
+                got += list(eng.quant_observables())
+            outs.append(got)
+    for o in outs[1:]:
+        for a, b in zip(outs[0], o):
+            assert (np.asarray(a) == np.asarray(b)).all()

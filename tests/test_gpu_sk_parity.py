@@ -333,5 +333,18 @@ def test_dense_sk_beyond_2048_sites(pkg, oracle, binary, N):
     for r in (0, R - 1):
         ref = run(X.J, beta, 3000, 100, seed, C0[r], replica=r)
         assert (Es[r] == ref[0]).all() and (C1[r] == ref[1]).all() and acc[r] == ref[2] and (lf1[r] == ref[3]).all()
+    # a call of zero iterations (E = energy(X, C) and an empty sample list: what the bindings issue before a hooked run) must not need a
+    # sweep build (these sizes have a blocked one only), and the hooked run must be the un-hooked chain
+    with pkg.Engine(X, R) as eng:
+        eng.seed(seed)
+        eng.set_config(pkg.Config(N, R, C0.copy()))
+        Es0, acc0 = eng.standard_mc(beta, 0, 1)
+        assert Es0.shape == (R, 0) and (acc0 == 0).all()
+        assert (eng.get_config().s == C0).all()
+    seen = []
+    EsH, CH = pkg.standardMC(X, beta, 3000, seed=seed, step=100, hook=lambda it, X_, C, accd, E: seen.append(it) or True, C0=pkg.Config(N, R, C0.copy()),
+                             quiet=True, replicas=R)
+    assert seen == list(range(100, 3001, 100))
+    assert (np.asarray(EsH) == Es).all() and (CH.s == C1).all()
     with pytest.raises(pkg.RRRMCError):
         pkg.Engine(pkg.GraphSKNormal(4097, seed=1), 8)

@@ -94,3 +94,72 @@ def test_python_table_lists_every_header_symbol():
     src = open(os.path.join(ROOT, "rrrmc.jl_amd", "_lib.py")).read()
     syms = set(re.findall(r'"(rrrmc_\w+)"', src[src.index("SYMBOLS = ["):src.index("]", src.index("SYMBOLS = ["))]))
     assert syms == set(header_signatures())
+
+
+def _julia_src():
+    return open(os.path.join(ROOT, "julia", "RRRMCHip.jl")).read()
+
+
+def _method_keywords(src, name, first_arg):
+    """keyword names of `function RRRMC.<name>(<first_arg>, ...; kw...)` (the text between ';' and the closing parenthesis)"""
+    m = re.search(r"function RRRMC\.%s\(%s[^;]*;(.*?)\)\n" % (name, re.escape(first_arg)), src, re.S)
+    assert m, "julia/RRRMCHip.jl: no method RRRMC.%s(%s, ...)" % (name, first_arg)
+    kws, depth, cur = [], 0, ""
+    for ch in m.group(1) + ",":           # split at top-level commas (defaults contain commas inside brackets)
+        if ch in "([{":
+            depth += 1
+        elif ch in ")]}":
+            depth -= 1
+        if ch == "," and depth == 0:
+            kws.append(cur.strip()); cur = ""
+        else:
+            cur += ch
+    return [re.match(r"(\w+)", k).group(1) for k in kws if k]
+
+
+def test_reference_signature_methods_exist():
+    """a reference script must run with its graph wrapped and nothing else changed — the samplers' own signatures
+    (src/RRRMC.jl:81-88, 149-157, 221-229, 311-317, 376-382, 474-480) on `OnGPU`, keyword for keyword (`pp` is dead code in the reference:
+    only read by commented-out lines :96-98,110-112)."""
+    src = _julia_src()
+    assert re.search(r"struct OnGPU\{G<:RRRMC\.Interface\.AbstractGraph\}", src) and "export OnGPU" in src
+    want = {
+        "standardMC": ["seed", "step", "hook", "C0", "quiet"],
+        "rrrMC": ["seed", "step", "hook", "C0", "staged_thr", "staged_thr_fact", "quiet"],
+        "bklMC": ["seed", "step", "hook", "C0", "quiet"],
+        "wtmMC": ["seed", "step", "hook", "C0", "quiet"],
+        "extremal_opt": ["seed", "step", "hook", "C0", "quiet"],
+    }
+    for name, kws in want.items():
+        assert _method_keywords(src, name, "G::OnGPU") == kws, name
+        ctx_kws = _method_keywords(src, name, "ctx::Ctx")                      # the context-first layer keeps the same names (hook: standardMC only)
+        assert [k for k in kws if k != "hook" or name == "standardMC"] == ctx_kws, name
+    # one chain returns (Es::Vector, C::Config) as RRRMC.jl:126 does: the wrappers unwrap through unwrap1 on both results
+    assert src.count("return unwrap1(G, Es), unwrap1(G, Cs)") == 4 and "unwrap1(G, Cs), unwrap1(G, Emin), unwrap1(G, Cmin), unwrap1(G, itmin)" in src
+    # a GraphQuant over dense slices reaches rrrmc_ctx_create_multi (VERDICT r4 missing 5)
+    assert "create(QUANT_SK, Nk, 0, M, R" in src and "create(QUANT_SKN, Nk, 0, M, R" in src
+    assert "has no multi-device context" not in src
+
+
+def test_julia_file_is_structurally_sound():
+    """No Julia here, so the cheap structural mistakes are caught by hand: block openers and `end`s balance, and no string literal directly
+    follows a docstring (`"doc" \"\"\"doc2\"\"\" function f` makes Base.Docs refuse the file)."""
+    src = _julia_src()
+    code = re.sub(r'"""(.|\n)*?"""', '""', src)              # drop docstrings / long strings, then line comments and short strings
+    code = re.sub(r'"(\\.|[^"\\\n])*"', '""', code)
+    code = re.sub(r"#[^\n]*", "", code)
+    # `end` used as an index inside brackets (x[1:end]) is not a block terminator
+    flat, depth = [], 0
+    for ch in code:
+        depth += ch == "["
+        depth -= ch == "]"
+        flat.append(" " if depth > 0 else ch)
+    code = "".join(flat)
+    openers = len(re.findall(r"(?<![\w.])(function|if|for|while|try|let|do|begin|struct|module|quote)(?![\w!])", code))
+    openers -= len(re.findall(r"(?<![\w.])mutable struct", code)) * 0        # `mutable struct` counts once through `struct`
+    ends = len(re.findall(r"(?<![\w.:])end(?![\w!])", code))
+    assert openers == ends, (openers, ends)
+    # a docstring must be followed by code, not by another string literal
+    assert not re.search(r'"\s*\n\s*"""', re.sub(r"#[^\n]*", "", src).replace('"""\n"""', "")), "two adjacent string literals: the first one is not a docstring"
+    for m in re.finditer(r'^"[^"\n]*"\n(.*)$', src, re.M):
+        assert not m.group(1).lstrip().startswith('"'), "julia/RRRMCHip.jl: docstring followed by a string literal near: " + m.group(0)[:80]
