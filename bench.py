@@ -36,7 +36,7 @@ SAMPLE_STEP = 1 << 12    # energy sample every N iterations
 SEED = 0x5EED
 HOST_GAP_LIMIT_MS = 0.3  # ms_per_step - kernel ms per step above this fails the run (exit 4): the timed region must be the kernel
 HBM_PEAK_GBS = 8000.0    # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-PROFILE_DIRS = [os.path.join(ROOT, "profiles", d) for d in ("r04", "r03", "r02")]       # newest first
+PROFILE_DIRS = [os.path.join(ROOT, "profiles", d) for d in ("r05", "r04", "r03", "r02")]       # newest first
 SWEEP_KERNEL_SOURCES = ["rrrmc.jl_amd/csrc/sparse_kernels.hpp", "rrrmc.jl_amd/csrc/philox.hpp"]     # what traffic.json / valu_model.json describe
 
 
@@ -209,6 +209,42 @@ def timed_oracle(fn, unit_per_call, min_seconds=1.0, max_calls=64):
             return n * unit_per_call / dt, n, dt
 
 
+def timed_oracle_all_cores(fn, args, kwargs, chunks_arg, chunks, unit_per_call, chains, min_seconds=1.5):
+    """SURVEY.md §8d's optional third figure: `chains` INDEPENDENT oracle chains — O.<fn>(*args, replica=c, it0=k * unit_per_call, **kwargs) with
+    argument `chunks_arg` replaced by chunks[c] — one PROCESS each (tools/oracle_worker.py; threads of one process were seen to share cores on
+    the pool's virtualised hosts), every process repeating its call for `min_seconds`.  chains = min(the workload's replicas, the host cores this
+    process may use).  Returns (units per second of all chains together, chains, seconds of the slowest)."""
+    import pickle
+    import tempfile
+    job = {"fn": fn, "args": list(args), "kwargs": dict(kwargs), "chunks_arg": chunks_arg, "chunks": [np.asarray(c) for c in chunks],
+           "it0_stride": int(unit_per_call), "seconds": float(min_seconds)}
+    with tempfile.NamedTemporaryFile(suffix=".pkl", delete=False) as f:
+        pickle.dump(job, f)
+        path = f.name
+    try:
+        env = dict(os.environ, HIP_VISIBLE_DEVICES="", ROCR_VISIBLE_DEVICES="")          # the workers are CPU-only
+        procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tools", "oracle_worker.py"), path, str(c)], stdout=subprocess.PIPE, text=True, env=env)
+                 for c in range(chains)]
+        total, slowest = 0.0, 0.0
+        for p_ in procs:
+            o, _ = p_.communicate(timeout=300)
+            if p_.returncode != 0:
+                raise RuntimeError("oracle worker failed")
+            n, dt = o.split()
+            total += int(n) * unit_per_call / float(dt)
+            slowest = max(slowest, float(dt))
+    finally:
+        os.remove(path)
+    return total, chains, slowest
+
+
+def host_cores():
+    try:
+        return len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        return os.cpu_count() or 1
+
+
 def source_stamp(files=None):
     """sha1 over the sources of the kernel a committed profile describes: a profile JSON whose stamp differs was measured on another build."""
     import hashlib
@@ -274,7 +310,8 @@ def load_profile_json(name):
             except ValueError:
                 continue
             st = j.get("source_stamp")
-            state = "unstamped" if not st else ("match" if st == source_stamp() else "stale")
+            # a profile names the sources it describes ("source_files"; the headline kernel's when absent)
+            state = "unstamped" if not st else ("match" if st == source_stamp(j.get("source_files")) else "stale")
             return j, os.path.relpath(p, ROOT), state
     return None, None, None
 
@@ -308,6 +345,9 @@ def secondary_c3(pkg, O, device):
     # FP64 VALU view: the useful work is a * N Float64 adds per attempt and replica (the field update); MI355X vector FP64 = 78.6 TFLOP/s as FMAs
     out["fp64_adds_per_s"] = a * N * R * iters / (k_ms * 1e-3)
     out["fp64_valu_frac"] = out["fp64_adds_per_s"] / (78.6e12 / 2)
+    out["bound"] = "fp64 vector issue of the bulk update + the serial decide chain of a block (profiles/r05/c3_block_budget.md)"
+    out["bound_frac"] = out["fp64_valu_frac"]
+    out["bound_frac_meaning"] = "useful Float64 field adds per second over the vector FP64 add rate (39.3e12/s)"
     if O is not None:
         with pinned_core():
             ch = O.init_configs(SEED, 0, 1, N)[0]
@@ -341,6 +381,10 @@ def secondary_c4(pkg, O, device):
            "value": attempts / dt, "unit": "attempts/s", "kernel": "colored_sweep_kernel<6>", "device_ms": dev_ms, "launches": nl,
            "acceptance": a, "algorithmic_bytes_per_attempt": bpa, "achieved_GBps": bpa * attempts / (dev_ms * 1e-3) / 1e9}
     out["frac"] = out["achieved_GBps"] / HBM_PEAK_GBS
+    # measured traffic of a colour launch (profiles/r04/c4_summary.txt): 42 MB per 512-replica colour = 0.64 B per attempt (bit planes)
+    out["bound"] = "hbm / L2 (bit-plane spin words of the colour and its neighbours, measured 0.64 B per attempt)"
+    out["bound_frac"] = 0.64 * attempts / (dev_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+    out["bound_frac_meaning"] = "measured bytes per attempt (profiles/r04/c4_summary.txt) at this run's rate over the 8 TB/s peak"
     if O is not None:
         with pinned_core():
             ch = O.init_configs(SEED, 0, 1, X.N)[0]
@@ -374,6 +418,9 @@ def secondary_c4_random(pkg, O, device):
            "note": "the spins live in LDS (4 replicas per workgroup); the kernel streams 36 bytes of plan records and masks per attempt "
                    "and workgroup, which is what bounds it (DESIGN.md 4g)"}
     out["frac"] = out["achieved_GBps"] / HBM_PEAK_GBS
+    out["bound"] = "hbm / L2 stream of plan records and masks (36 B per attempt and workgroup of 4 replicas = 9 B per replica-attempt)"
+    out["bound_frac"] = 9.0 * attempts / (dev_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+    out["bound_frac_meaning"] = "streamed bytes per replica-attempt at this run's rate over the 8 TB/s peak (profiles/r04/c4rand_summary.txt)"
     if O is not None:
         with pinned_core():
             ch = O.init_configs(SEED, 0, 1, X.N)[0]
@@ -405,13 +452,25 @@ def secondary_c5(pkg, O, device):
     out["algorithmic_bytes_per_iteration_range"] = [bpa_lo, bpa_hi]
     out["achieved_GBps_range"] = [b * R * iters / (k_ms * 1e-3) / 1e9 for b in (bpa_lo, bpa_hi)]
     out["frac"] = out["achieved_GBps_range"][1] / HBM_PEAK_GBS
+    # one wavefront per chain: 2413 cycles per iteration measured against an issue + LDS round-trip floor of ~ 2000 (profiles/r04/c5_floor.md)
+    out["bound"] = "latency of ONE wavefront per chain (322 issued instructions + 7 dependent LDS round trips per iteration); 128 chains light 128 of 1024 SIMDs"
+    out["bound_frac"] = 2000.0 / max(k_ms * 1e-3 * 2.1e9 / iters, 1.0)
+    out["bound_frac_meaning"] = "the floor of c5_floor.md (2000 cycles per iteration) over this run's cycles per iteration at 2.1 GHz"
     if O is not None:
+        Ji = X.X1.J.astype(np.int32)
         with pinned_core():
             ch = O.init_configs(SEED, 0, 1, X.N)[0]
-            it1, Ji = 1 << 22, X.X1.J.astype(np.int32)
+            it1 = 1 << 22
             v, n, dt1 = timed_oracle(lambda k: O.rrr_mc_quant(X.X1.A, Ji, M, X.fourK, beta, it1, step, SEED, ch, it0=k * it1), it1)
             out["cpu_one_core"] = {"value": v, "unit": "iterations/s", "kind": "port", "build": O.flavour,
                                    "sample": "1 replica x %d x 2^22 iterations (%.1f s), oracle" % (n, dt1)}
+        nc = min(R, host_cores())
+        chs = O.init_configs(SEED, 0, nc, X.N)
+        it2 = 1 << 20
+        v, nc, dt2 = timed_oracle_all_cores("rrr_mc_quant", (X.X1.A, Ji, M, X.fourK, beta, it2, step, SEED, None), {}, 8, chs, it2, nc)
+        out["cpu_all_cores"] = {"value": v, "unit": "iterations/s", "cores": nc, "kind": "port", "build": O.flavour,
+                                "sample": "%d independent chains (min(replicas, host cores)) x 2^20-iteration calls for %.1f s, one process each, oracle" % (nc, dt2)}
+        out["gpu_over_cpu_all_cores"] = out["value"] / v
     return out
 
 
@@ -433,7 +492,8 @@ def secondary_f64_fast(pkg, O, device):
     out = {"workload": "GraphRRGNormal(N=4096,K=3) standardMC (fast mode) beta=1.0, 8192 replicas, 2^20 iterations per replica, energy sample every 4096",
            "value": R * iters / dt, "unit": "attempts/s", "kernel": "spf_fast_kernel<3>", "avg_launch_ms": k_ms / max(nl, 1), "launches": nl,
            "acceptance": a, "algorithmic_bytes_per_attempt": bpa, "achieved_GBps": bpa * R * iters / (k_ms * 1e-3) / 1e9,
-           "note": "algorithmic bytes of the Float64-field picture (SURVEY.md §8d) over the kernel time: the state lives in LDS, this is a throughput normalisation"}
+           "note": "algorithmic bytes of the Float64-field picture (SURVEY.md §8d) over the kernel time: the state lives in LDS, this is a throughput normalisation",
+           "bound": "valu issue (bit-sliced replicas in LDS, per-lane thresholds; same machinery as the headline kernel)", "bound_frac": None}
     out["frac"] = out["achieved_GBps"] / HBM_PEAK_GBS
     if O is not None:
         with pinned_core():
@@ -445,10 +505,38 @@ def secondary_f64_fast(pkg, O, device):
     return out
 
 
+SPF_TEAM_SOURCES = ["rrrmc.jl_amd/csrc/spf_team_kernel.hpp", "rrrmc.jl_amd/csrc/spf_team_params.hpp", "rrrmc.jl_amd/csrc/spf_team_tu.hip",
+                    "rrrmc.jl_amd/csrc/host_spf.hpp", "rrrmc.jl_amd/csrc/spf_kernels.hpp"]      # what spf_traffic.json describes
+
+
+def spf_team_kernel_name(R, K=3):
+    """the build host_spf.hpp picks for R replicas on a 256-CU device (teams of 64 / 32 / 16 replicas until there are as many teams as CUs)"""
+    W, tw = (R + 63) // 64, 64
+    while tw > 16 and W * (64 // tw) < 256:
+        tw //= 2
+    nw = 16 if W * (64 // tw) <= 256 else 8
+    if nw == 8:
+        tw = 64
+    return "spf_team_kernel<%d, %d, %d, %d>" % (K, nw, 2 * (nw - 1), tw)
+
+
+def spf_traffic(key=None):
+    """The committed rocprofv3 traffic measurement of spf_team_kernel, or (None, why) when it is absent, unstamped or was taken on other sources."""
+    tf, tf_path, state = load_profile_json("spf_traffic.json")
+    if not tf:
+        return None, "no committed spf_traffic.json"
+    if state != "match":
+        return None, "%s is %s (measured on other kernel sources): traffic figures dropped" % (tf_path, state)
+    sub = tf.get(key) if key else tf
+    if not sub:
+        return None, "%s has no entry %s" % (tf_path, key)
+    return (sub, tf, tf_path), None
+
+
 def secondary_f64_exact(pkg, O, device):
     """The DEFAULT (bit-exact) Float64 sparse path: GraphRRGNormal(N=4096, K=3), spf_team_kernel — the reference's cached-field loop
-    (src/graphs/RRG.jl:504-627) with the fields in HBM, a team of sixteen wavefronts per group of 64 replicas running the attempts whose
-    neighbourhoods do not meet side by side; the measured HBM traffic per attempt comes from the committed rocprofv3 pass."""
+    (src/graphs/RRG.jl:504-627) with the fields in HBM, teams of sixteen wavefronts running the attempts whose neighbourhoods do not meet
+    side by side; the measured HBM traffic per attempt comes from the committed rocprofv3 pass."""
     N, K, R, beta, iters, step = 4096, 3, 8192, 1.0, 1 << 16, 1 << 12
     X = pkg.GraphRRGNormal(N, K, seed=SEED)
     with pkg.Engine(X, R, device=device) as eng:
@@ -463,14 +551,25 @@ def secondary_f64_exact(pkg, O, device):
     a = float(acc.mean()) / iters
     bpa = 8 + a * (10 + 17 * K)                                  # SURVEY.md §8d widths: field 8 B, spin 1 B
     out = {"workload": "GraphRRGNormal(N=4096,K=3) standardMC (exact mode) beta=1.0, 8192 replicas, 2^16 iterations per replica, energy sample every 4096",
-           "value": R * iters / dt, "unit": "attempts/s", "kernel": "spf_team_kernel<3, 16, 1>", "avg_launch_ms": k_ms / max(nl, 1), "launches": nl,
+           "value": R * iters / dt, "unit": "attempts/s", "kernel": spf_team_kernel_name(R), "avg_launch_ms": k_ms / max(nl, 1), "launches": nl,
            "acceptance": a, "algorithmic_bytes_per_attempt": bpa, "achieved_GBps": bpa * R * iters / (k_ms * 1e-3) / 1e9}
     out["frac"] = out["achieved_GBps"] / HBM_PEAK_GBS
-    tf, tf_path, _ = load_profile_json("spf_traffic.json")
-    if tf:
+    # what binds it at this replica count: a team's wavefronts' own instruction streams (profiles/r05/spf_team_counters.txt: a wavefront issues
+    # 36 % of its cycles, stalls for an issue slot 17 %, waits 47 %), not memory: the measured traffic is a third of the HBM peak
+    out["bound"] = "wavefront instruction streams of one team per compute unit (issue + two memory round trips per pair of attempts)"
+    got, why = spf_traffic()
+    if got:
+        tf, _, tf_path = got
+        gbps = tf["measured_bytes_per_attempt"] * R * iters / (k_ms * 1e-3) / 1e9
         out["traffic"] = {"measured_bytes_per_attempt": tf["measured_bytes_per_attempt"], "ratio_to_algorithmic": tf["traffic_ratio"],
-                          "hbm_GBps_at_this_rate": tf["measured_bytes_per_attempt"] * R * iters / (k_ms * 1e-3) / 1e9,
-                          "source": "%s (committed rocprofv3 FETCH_SIZE x2 + WRITE_SIZE pass of the same workload, commit %s; not measured in this run)" % (tf_path, tf.get("git_commit"))}
+                          "hbm_GBps_at_this_rate": gbps, "frac_of_hbm_peak": gbps / HBM_PEAK_GBS,
+                          "source": "%s (committed rocprofv3 FETCH_SIZE x2 + WRITE_SIZE pass of the same workload, commit %s, stamp matches these sources; not measured in this run)" % (tf_path, tf.get("git_commit"))}
+        out["bound_frac"] = tf.get("wave_issue_frac")
+        out["bound_frac_meaning"] = "share of a wavefront's cycles in which it issues an instruction (SQ_ACTIVE_INST_ANY / SQ_WAVE_CYCLES of the committed pass)"
+    else:
+        out["traffic"] = None
+        out["traffic_note"] = why
+        out["bound_frac"] = None
     if O is not None:
         with pinned_core():
             ch = O.init_configs(SEED, 0, 1, N)[0]
@@ -498,15 +597,22 @@ def secondary_f64_exact_big(pkg, O, device):
     a = float(acc.mean()) / iters
     bpa = 8 + a * (10 + 17 * K)
     out = {"workload": "GraphRRGNormal(N=4096,K=3) standardMC (exact mode) beta=1.0, 262144 replicas, 2^14 iterations per replica, energy sample every 4096",
-           "value": R * iters / dt, "unit": "attempts/s", "kernel": "spf_team_kernel<3, 8, 1>", "avg_launch_ms": k_ms / max(nl, 1), "launches": nl,
+           "value": R * iters / dt, "unit": "attempts/s", "kernel": spf_team_kernel_name(R), "avg_launch_ms": k_ms / max(nl, 1), "launches": nl,
            "acceptance": a, "algorithmic_bytes_per_attempt": bpa, "achieved_GBps": bpa * R * iters / (k_ms * 1e-3) / 1e9}
     out["frac"] = out["achieved_GBps"] / HBM_PEAK_GBS
-    tf, tf_path, _ = load_profile_json("spf_traffic.json")
-    big = (tf or {}).get("at_262144_replicas")
-    if big:
+    out["bound"] = "hbm (measured traffic: random 512-byte lines read and written whole)"
+    got, why = spf_traffic("at_262144_replicas")
+    if got:
+        big, tf, tf_path = got
         gbps = big["measured_bytes_per_attempt"] * R * iters / (k_ms * 1e-3) / 1e9
         out["traffic"] = {"measured_bytes_per_attempt": big["measured_bytes_per_attempt"], "hbm_GBps_at_this_rate": gbps, "frac_of_hbm_peak": gbps / HBM_PEAK_GBS,
-                          "source": "%s at_262144_replicas (committed rocprofv3 FETCH_SIZE x2 + WRITE_SIZE pass of this shape, commit %s; not measured in this run)" % (tf_path, tf.get("git_commit"))}
+                          "source": "%s at_262144_replicas (committed rocprofv3 FETCH_SIZE x2 + WRITE_SIZE pass of this shape, commit %s, stamp matches these sources; not measured in this run)" % (tf_path, tf.get("git_commit"))}
+        out["bound_frac"] = gbps / HBM_PEAK_GBS
+        out["bound_frac_meaning"] = "measured HBM traffic at this run's rate over the 8 TB/s peak"
+    else:
+        out["traffic"] = None
+        out["traffic_note"] = why
+        out["bound_frac"] = None
     return out
 
 
@@ -536,6 +642,50 @@ def secondary_f8_rrr(pkg, O, device):
             v, n, dt1 = timed_oracle(lambda k: O.rrr_sparse(X.A, Ji, beta, it1, it1, SEED, C1, it0=k * it1), it1)
             out["cpu_one_core"] = {"value": v, "unit": "iterations/s", "kind": "port", "build": O.flavour,
                                    "sample": "1 replica x %d x 2^20 iterations from a quenched configuration (%.1f s), oracle" % (n, dt1)}
+        nc = min(R, host_cores())
+        it2, Ji = 1 << 18, X.J.astype(np.int32)
+        v, nc, dt2 = timed_oracle_all_cores("rrr_sparse", (X.A, Ji, beta, it2, it2, SEED, None), {}, 6, [C1], it2, nc)
+        out["cpu_all_cores"] = {"value": v, "unit": "iterations/s", "cores": nc, "kind": "port", "build": O.flavour,
+                                "sample": "%d independent chains (min(replicas, host cores)) x 2^18-iteration calls for %.1f s from the quenched configuration, one process each, oracle" % (nc, dt2)}
+        out["gpu_over_cpu_all_cores"] = out["value"] / v
+    out["bound"] = "latency: one thread per replica chasing dependent L2 round trips through the reference's per-replica structures (ArraySet v / pos, T, z)"
+    out["bound_frac"] = None
+    return out
+
+
+def secondary_f8_cont(pkg, O, device):
+    """SURVEY.md §8f rank 4 at the reference's experiment size (scripts/scripts.jl:152 test_RRGCont): rrrMC(X::SingleGraph) on
+    GraphRRGNormal(10^4, 3) — DeltaECacheCont + DynamicSampler (src/DeltaE.jl:299-410, src/DynamicSamplers.jl) — cont_wave_kernel, one
+    wavefront per replica with the top of the sampler's tree in LDS."""
+    N, K, R, beta, iters, step = 10000, 3, 4096, 2.0, 5000, 2500
+    X = pkg.GraphRRGNormal(N, K, seed=SEED)
+    with pkg.Engine(X, R, device=device) as eng:
+        eng.seed(SEED)
+        eng.init_spins_random()
+        eng.standard_mc(beta, 10 * N, 10 * N, want_energies=False)          # a short quench first
+        eng.rrr_mc(beta, iters // 4, step, want_energies=False)
+        t0 = time.perf_counter()
+        _, acc, staged = eng.rrr_mc(beta, iters, step, want_energies=False)
+        dt = time.perf_counter() - t0
+        _, k_ms, nl = eng.last_timing()
+        C1 = eng.get_config().s[0].copy()
+    out = {"workload": "GraphRRGNormal(N=10000,K=3) rrrMC beta=2.0, 4096 replicas, 5000 iterations per replica (after a 10-sweep Metropolis quench)",
+           "value": R * iters / dt, "unit": "iterations/s", "kernel": "cont_wave_kernel", "avg_launch_ms": k_ms / max(nl, 1), "launches": nl,
+           "acceptance": float(acc.mean()) / iters,
+           "bound": "latency: one wavefront per replica, log2(N) dependent levels of the sampler's tree per move (upper levels in LDS, the rest in L2)",
+           "bound_frac": None}
+    if O is not None:
+        with pinned_core():
+            it1 = 1 << 16
+            v, n, dt1 = timed_oracle(lambda k: O.cont_sparse("rrr", X.A, X.J, beta, it1, it1, SEED, C1, it0=k * it1), it1)
+            out["cpu_one_core"] = {"value": v, "unit": "iterations/s", "kind": "port", "build": O.flavour,
+                                   "sample": "1 replica x %d x 2^16 iterations from a quenched configuration (%.1f s), oracle" % (n, dt1)}
+        nc = min(R, host_cores())
+        it2 = 1 << 14
+        v, nc, dt2 = timed_oracle_all_cores("cont_sparse", ("rrr", X.A, X.J, beta, it2, it2, SEED, None), {}, 7, [C1], it2, nc)
+        out["cpu_all_cores"] = {"value": v, "unit": "iterations/s", "cores": nc, "kind": "port", "build": O.flavour,
+                                "sample": "%d independent chains (min(replicas, host cores)) x 2^14-iteration calls for %.1f s, one process each, oracle" % (nc, dt2)}
+        out["gpu_over_cpu_all_cores"] = out["value"] / v
     return out
 
 
@@ -547,7 +697,8 @@ def secondary(pkg, O, device):
     out = {}
     for name, fn in (("c3_sk_normal", secondary_c3), ("c4_ea_checkerboard", secondary_c4), ("c4_ea_random_site", secondary_c4_random),
                      ("c5_quant_rrr", secondary_c5),
-                     ("f64_sparse_exact", secondary_f64_exact), ("f64_sparse_exact_262144", secondary_f64_exact_big), ("f64_sparse_fast", secondary_f64_fast), ("f8_rrr_rrg_1e4", secondary_f8_rrr)):
+                     ("f64_sparse_exact", secondary_f64_exact), ("f64_sparse_exact_262144", secondary_f64_exact_big), ("f64_sparse_fast", secondary_f64_fast), ("f8_rrr_rrg_1e4", secondary_f8_rrr),
+                     ("f8_rrr_rrgn_1e4", secondary_f8_cont)):
         t0 = time.perf_counter()
         try:
             out[name] = fn(pkg, O, device)
