@@ -245,6 +245,22 @@ def host_cores():
         return os.cpu_count() or 1
 
 
+CPU_WORKERS_MAX = int(os.environ.get("RRRMC_BENCH_CPU_WORKERS", "64"))       # a one-GPU box of the pool is a SHARE of a 256-core host
+
+
+def cpu_all_cores_entry(out, one_core_value, unit, measured, what):
+    """cpu_all_cores = what `workers` concurrent oracle processes delivered on this box (its effective parallelism is printed: the box is a
+    share of its host), cpu_host_projection = one core x every core the OS shows — the whole-host figure of SURVEY.md §8d where the box
+    cannot be asked for it.  Baselines, never targets."""
+    v, workers, dt = measured
+    nc = host_cores()
+    out["cpu_all_cores"] = {"value": v, "unit": unit, "cores": workers, "kind": "port", "effective_cores": v / one_core_value,
+                            "sample": "%d independent chains (min(replicas, host cores, %d)) %s for %.1f s, one process each, oracle" % (workers, CPU_WORKERS_MAX, what, dt)}
+    out["cpu_host_projection"] = {"value": one_core_value * nc, "unit": unit, "cores": nc, "kind": "projection: cpu_one_core x the cores the OS shows (not measured)"}
+    out["gpu_over_cpu_all_cores"] = out["value"] / v
+    out["gpu_in_host_cores"] = out["value"] / one_core_value
+
+
 def source_stamp(files=None):
     """sha1 over the sources of the kernel a committed profile describes: a profile JSON whose stamp differs was measured on another build."""
     import hashlib
@@ -464,13 +480,11 @@ def secondary_c5(pkg, O, device):
             v, n, dt1 = timed_oracle(lambda k: O.rrr_mc_quant(X.X1.A, Ji, M, X.fourK, beta, it1, step, SEED, ch, it0=k * it1), it1)
             out["cpu_one_core"] = {"value": v, "unit": "iterations/s", "kind": "port", "build": O.flavour,
                                    "sample": "1 replica x %d x 2^22 iterations (%.1f s), oracle" % (n, dt1)}
-        nc = min(R, host_cores())
+        nc = min(R, host_cores(), CPU_WORKERS_MAX)
         chs = O.init_configs(SEED, 0, nc, X.N)
         it2 = 1 << 20
-        v, nc, dt2 = timed_oracle_all_cores("rrr_mc_quant", (X.X1.A, Ji, M, X.fourK, beta, it2, step, SEED, None), {}, 8, chs, it2, nc)
-        out["cpu_all_cores"] = {"value": v, "unit": "iterations/s", "cores": nc, "kind": "port", "build": O.flavour,
-                                "sample": "%d independent chains (min(replicas, host cores)) x 2^20-iteration calls for %.1f s, one process each, oracle" % (nc, dt2)}
-        out["gpu_over_cpu_all_cores"] = out["value"] / v
+        cpu_all_cores_entry(out, out["cpu_one_core"]["value"], "iterations/s",
+                            timed_oracle_all_cores("rrr_mc_quant", (X.X1.A, Ji, M, X.fourK, beta, it2, step, SEED, None), {}, 8, chs, it2, nc), "x 2^20-iteration calls")
     return out
 
 
@@ -517,7 +531,12 @@ def spf_team_kernel_name(R, K=3):
     nw = 16 if W * (64 // tw) <= 256 else 8
     if nw == 8:
         tw = 64
-    return "spf_team_kernel<%d, %d, %d, %d>" % (K, nw, 2 * (nw - 1), tw)
+    def lds(M):
+        return (8 * (K + 1) * tw + 4 * tw) * (M + nw) + 4 * (tw + 2 * M + 4)
+    M = 60 if nw == 16 else 2 * (nw - 1)                      # spf_team_slots (csrc/spf_team_params.hpp)
+    while M > 2 * (nw - 1) and lds(M) > 160 * 1024:
+        M -= 1
+    return "spf_team_kernel<%d, %d, %d, %d>" % (K, nw, M, tw)
 
 
 def spf_traffic(key=None):
@@ -642,12 +661,10 @@ def secondary_f8_rrr(pkg, O, device):
             v, n, dt1 = timed_oracle(lambda k: O.rrr_sparse(X.A, Ji, beta, it1, it1, SEED, C1, it0=k * it1), it1)
             out["cpu_one_core"] = {"value": v, "unit": "iterations/s", "kind": "port", "build": O.flavour,
                                    "sample": "1 replica x %d x 2^20 iterations from a quenched configuration (%.1f s), oracle" % (n, dt1)}
-        nc = min(R, host_cores())
+        nc = min(R, host_cores(), CPU_WORKERS_MAX)
         it2, Ji = 1 << 18, X.J.astype(np.int32)
-        v, nc, dt2 = timed_oracle_all_cores("rrr_sparse", (X.A, Ji, beta, it2, it2, SEED, None), {}, 6, [C1], it2, nc)
-        out["cpu_all_cores"] = {"value": v, "unit": "iterations/s", "cores": nc, "kind": "port", "build": O.flavour,
-                                "sample": "%d independent chains (min(replicas, host cores)) x 2^18-iteration calls for %.1f s from the quenched configuration, one process each, oracle" % (nc, dt2)}
-        out["gpu_over_cpu_all_cores"] = out["value"] / v
+        cpu_all_cores_entry(out, out["cpu_one_core"]["value"], "iterations/s",
+                            timed_oracle_all_cores("rrr_sparse", (X.A, Ji, beta, it2, it2, SEED, None), {}, 6, [C1], it2, nc), "x 2^18-iteration calls from the quenched configuration")
     out["bound"] = "latency: one thread per replica chasing dependent L2 round trips through the reference's per-replica structures (ArraySet v / pos, T, z)"
     out["bound_frac"] = None
     return out
@@ -680,12 +697,10 @@ def secondary_f8_cont(pkg, O, device):
             v, n, dt1 = timed_oracle(lambda k: O.cont_sparse("rrr", X.A, X.J, beta, it1, it1, SEED, C1, it0=k * it1), it1)
             out["cpu_one_core"] = {"value": v, "unit": "iterations/s", "kind": "port", "build": O.flavour,
                                    "sample": "1 replica x %d x 2^16 iterations from a quenched configuration (%.1f s), oracle" % (n, dt1)}
-        nc = min(R, host_cores())
+        nc = min(R, host_cores(), CPU_WORKERS_MAX)
         it2 = 1 << 14
-        v, nc, dt2 = timed_oracle_all_cores("cont_sparse", ("rrr", X.A, X.J, beta, it2, it2, SEED, None), {}, 7, [C1], it2, nc)
-        out["cpu_all_cores"] = {"value": v, "unit": "iterations/s", "cores": nc, "kind": "port", "build": O.flavour,
-                                "sample": "%d independent chains (min(replicas, host cores)) x 2^14-iteration calls for %.1f s, one process each, oracle" % (nc, dt2)}
-        out["gpu_over_cpu_all_cores"] = out["value"] / v
+        cpu_all_cores_entry(out, out["cpu_one_core"]["value"], "iterations/s",
+                            timed_oracle_all_cores("cont_sparse", ("rrr", X.A, X.J, beta, it2, it2, SEED, None), {}, 7, [C1], it2, nc), "x 2^14-iteration calls")
     return out
 
 

@@ -595,7 +595,7 @@ __global__ __launch_bounds__(NW * 64) void spf_team_kernel(SpfTeamParams TP)
         SPF_STAMP(1);                                               // waiting for the dependencies, requests out
         if (valid[0]) decide(eA);
         if (valid[1] && (together || !valid[0])) decide(eB);
-        if (valid[0]) finish(eA);
+        if (valid[0]) finish(eA);               // (finishing A before deciding B was measured: no difference)
         if (valid[1]) {
             if (valid[0] && !together) {
                 report(eA);                                         // B's request waits for A's report

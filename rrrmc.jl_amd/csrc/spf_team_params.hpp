@@ -33,12 +33,14 @@ __host__ __device__ constexpr size_t spf_team_lds_bytes(int K, int NW, int M, in
 {
     return (sizeof(double) * (size_t)(K + 1) * TW + sizeof(uint32_t) * TW) * (size_t)spf_team_areas(NW, M) + sizeof(int32_t) * (size_t)(TW + 2 * M + 4);      // tl, done, ev, prefix + abort flag
 }
-// M = slots = attempts in flight at most: one pair per executing wavefront.  (More slots were measured — up to 60, the LDS full — and bought
-// nothing: a team's pace is its wavefronts' own instruction streams, and small teams leave room for three workgroups per compute unit.)
+// M = slots = attempts in flight at most.  Sixteen-wavefront teams own a compute unit: as many slots as its 160 KiB of LDS hold beside the keep
+// areas, at most 60 (one wavefront read brings all flags; the planner's window is 64) — measured 3-4 % over one pair per wavefront.
+// Eight-wavefront teams (many groups) stay at one pair per executing wavefront: small teams leave room for three workgroups per compute unit.
 __host__ __device__ constexpr int spf_team_slots(int K, int NW, int TW)
 {
-    (void)K; (void)TW;
-    return 2 * (NW - 1);
+    int m = NW == 16 ? 60 : 2 * (NW - 1);
+    while (m > 2 * (NW - 1) && spf_team_lds_bytes(K, NW, m, TW) > (size_t)160 * 1024) --m;
+    return m;
 }
 
 }  // namespace rrrmc

@@ -78,8 +78,12 @@ def test_cont_wave_kernel_has_no_scratch(tmp_path):
 
 def _spf_team_lds(K, NW, TW):
     """spf_team_lds_bytes with spf_team_slots (csrc/spf_team_params.hpp)"""
-    M = 2 * (NW - 1)
-    return (8 * (K + 1) * TW + 4 * TW) * (M + NW) + 4 * (TW + 2 * M + 4)
+    def lds(M):
+        return (8 * (K + 1) * TW + 4 * TW) * (M + NW) + 4 * (TW + 2 * M + 4)
+    M = 60 if NW == 16 else 2 * (NW - 1)
+    while M > 2 * (NW - 1) and lds(M) > 160 * 1024:
+        M -= 1
+    return lds(M)
 
 
 @pytest.mark.skipif(shutil.which("hipcc") is None, reason="hipcc not found")

@@ -149,7 +149,7 @@ int main(int argc, char** argv)
     if TEAM_D(3, 16, 64); else if TEAM_D(4, 16, 64); else if TEAM_D(3, 8, 64); else if TEAM_D(4, 8, 64); else if TEAM_D(6, 8, 64);
     else if TEAM_D(3, 16, 32); else if TEAM_D(4, 16, 32); else if TEAM_D(6, 16, 32);
     else if TEAM_D(3, 16, 16); else if TEAM_D(4, 16, 16); else if TEAM_D(6, 16, 16);
-    else if TEAM_B(3, 16, 47, 64); else if TEAM_B(3, 8, 28, 64);
+    else if TEAM_B(3, 16, 47, 64); else if TEAM_B(3, 8, 28, 64); else if TEAM_B(3, 16, 60, 32); else if TEAM_B(3, 16, 45, 32);
     if (!team) { fprintf(stderr, "no such build\n"); return 1; }
     const size_t lds = spf_team_lds_bytes(K, NW, M, TW);
     printf("NW %d M %d TW %d: %zu bytes of LDS\n", NW, M, TW, lds);
