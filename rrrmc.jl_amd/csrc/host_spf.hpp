@@ -110,6 +110,38 @@ int32_t spf_run_energy(rrrmc_ctx* ctx)
     return RRRMC_OK;
 }
 
+// debug mode (rrrmc_set_debug_checks) after a standardMC call on GraphRRGNormal / GraphEANormal: the reference's commented-out check of
+// update_cache! (RRG.jl:611-615: energy(X, C) again, maximum(abs.(lfields_bk - lfields)) < 1e-10) and the test suite's tracked E == energy(X, C)
+// (test/runtests.jl:12-20), on the device: fields and energy recomputed from the configuration into scratch buffers, compared element-wise.
+// Also the cross-check of spf_team_kernel that needs no second kernel: a lost update shows as a field off by a multiple of 4 J.
+int32_t spf_debug_check(rrrmc_ctx* ctx)
+{
+    const size_t nf = (size_t)ctx->Rpad * (size_t)ctx->N;
+    if (!ctx->dbg_flag) { HIP_TRY(ctx, hipMalloc(&ctx->dbg_flag, sizeof(int32_t) * 2)); HIP_TRY(ctx, hipMemsetAsync(ctx->dbg_flag, 0, sizeof(int32_t) * 2, ctx->stream)); }
+    if (!ctx->dbg_lf) {
+        HIP_TRY(ctx, hipMalloc(&ctx->dbg_lf, sizeof(double) * nf));
+        HIP_TRY(ctx, hipMalloc(&ctx->dbg_E, sizeof(double) * ctx->Rpad));
+        HIP_TRY(ctx, hipMalloc(&ctx->dbg_ml, sizeof(int32_t) * ctx->Rpad));
+    }
+    hipStream_t st = ctx->stream;
+    SpfParams P = spf_params(ctx);
+    P.lf = ctx->dbg_lf; P.E_cur = ctx->dbg_E; P.move_last = ctx->dbg_ml;          // nothing of the live state is written
+    hipLaunchKernelGGL(spf_fields_for_K((int)ctx->K), dim3((unsigned)(((ctx->N + 3) / 4) * ctx->pfW)), dim3(256), 0, st, P);
+    HIP_TRY(ctx, hipGetLastError());
+    hipLaunchKernelGGL(spf_energy_sum_kernel, dim3((unsigned)ctx->pfW), dim3(64), 0, st, P);
+    HIP_TRY(ctx, hipGetLastError());
+    if (dbg_inject()) hipLaunchKernelGGL(dbg_inject_f64_kernel, dim3(1), dim3(1), 0, st, ctx->dbg_E);                 // (RRRMC_DEBUG_INJECT=1: tests only)
+    const double tol = 1e-10 * (double)(ctx->K + 1);             // the reference's 1e-10 per field; the energy is a sum of N of them
+    // fields: [W][N][64], replica of element e = (e / (N * 64)) * 64 + e % 64
+    hipLaunchKernelGGL(dbg_compare_f64_kernel, dim3((unsigned)((nf + 255) / 256)), dim3(256), 0, st, ctx->sk_lf, ctx->dbg_lf, (long long)nf, tol,
+                       (long long)ctx->N * 64, 64, ctx->dbg_flag);
+    HIP_TRY(ctx, hipGetLastError());
+    hipLaunchKernelGGL(dbg_compare_f64_kernel, dim3((unsigned)((ctx->R + 255) / 256)), dim3(256), 0, st, ctx->sk_E, ctx->dbg_E, (long long)ctx->R, 1e-10 * (double)ctx->N,
+                       (long long)ctx->Rpad, (int)ctx->Rpad, ctx->dbg_flag);
+    HIP_TRY(ctx, hipGetLastError());
+    return RRRMC_OK;
+}
+
 int32_t spf_standard_mc_async(rrrmc_ctx* ctx, double beta, int64_t iters, int64_t step)
 {
     if (iters < 0) return fail(ctx, RRRMC_ERR_INVALID_ARG, "iters must be >= 0, given %lld", (long long)iters);
@@ -183,7 +215,7 @@ int32_t spf_standard_mc_async(rrrmc_ctx* ctx, double beta, int64_t iters, int64_
     ctx->it_done += (uint64_t)iters;
     ctx->results_valid = true;
     ctx->timing_valid = true;
-    return RRRMC_OK;
+    return ctx->debug_checks ? spf_debug_check(ctx) : RRRMC_OK;
 }
 
 // rrrMC / bklMC / wtmMC (modes 0 / 1 / 2) with the continuous-energy caches and extremal_opt (mode 3, EOCacheCont; `ftau` = its rank table)

@@ -1311,8 +1311,8 @@ int32_t rrrmc_set_debug_checks(rrrmc_ctx* ctx, int32_t on)
 {
     RRRMC_MULTI(ctx, false, rrrmc_set_debug_checks(c, on));
     if (!ctx) return RRRMC_ERR_INVALID_ARG;
-    if (ctx->model != RRRMC_MODEL_SPARSE_PM1 && ctx->model != RRRMC_MODEL_SK_NORMAL)
-        return fail(ctx, RRRMC_ERR_UNSUPPORTED, "the debug checks are wired for RRRMC_MODEL_SPARSE_PM1 and RRRMC_MODEL_SK_NORMAL");
+    if (ctx->model != RRRMC_MODEL_SPARSE_PM1 && ctx->model != RRRMC_MODEL_SK_NORMAL && ctx->model != RRRMC_MODEL_SPARSE_F64)
+        return fail(ctx, RRRMC_ERR_UNSUPPORTED, "the debug checks are wired for RRRMC_MODEL_SPARSE_PM1, RRRMC_MODEL_SK_NORMAL and RRRMC_MODEL_SPARSE_F64");
     ctx->debug_checks = on != 0;
     return RRRMC_OK;
 }

@@ -145,8 +145,13 @@ template <> struct spf_word<16> { typedef uint16_t type; };
 //        (about 10 bytes per cycle of 512-byte lines that miss its L1), so with fewer groups than compute units narrower teams on more
 //        compute units are faster: the same instructions serve fewer replicas, but each compute unit moves a half or a quarter of the bytes.
 //   M  = slots (attempt `it` uses slot (it + c0) mod M, whoever runs it): how far the wavefronts may run ahead of the retired prefix
+#ifdef SPF_TEAM_WAVES_PER_EU        // experiment (tools/ubench/spf_team_bench.hip): cap the registers so that two sixteen-wavefront teams share a compute unit
+#define SPF_TEAM_OCC __attribute__((amdgpu_waves_per_eu(SPF_TEAM_WAVES_PER_EU, SPF_TEAM_WAVES_PER_EU)))
+#else
+#define SPF_TEAM_OCC
+#endif
 template <int K, int NW, int M, int TW>
-__global__ __launch_bounds__(NW * 64) void spf_team_kernel(SpfTeamParams TP)
+__global__ __launch_bounds__(NW * 64) SPF_TEAM_OCC void spf_team_kernel(SpfTeamParams TP)
 {
     constexpr int NX = NW - 1;
     constexpr int AREAS = spf_team_areas(NW, M);

@@ -8,7 +8,8 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.parametrize("make,R", [(lambda p: p.GraphRRG(512, 3, seed=3), 96), (lambda p: p.GraphEA(8, 3, seed=3), 40),
-                                    (lambda p: p.GraphSKNormal(200, seed=3), 24), (lambda p: p.GraphSKNormal(1024, seed=3), 16)])
+                                    (lambda p: p.GraphSKNormal(200, seed=3), 24), (lambda p: p.GraphSKNormal(1024, seed=3), 16),
+                                    (lambda p: p.GraphRRGNormal(300, 3, seed=3), 130), (lambda p: p.GraphEANormal(5, 3, seed=3), 70)])
 def test_debug_checks_pass_and_change_nothing(pkg, make, R):
     X = make(pkg)
     outs = []
@@ -26,7 +27,7 @@ def test_debug_checks_pass_and_change_nothing(pkg, make, R):
 
 def test_debug_checks_catch_an_inconsistent_state(pkg, monkeypatch):
     """the failing branch: RRRMC_DEBUG_INJECT=1 (a fault injection that exists for this test) shifts one compared value inside the check"""
-    for X, R in ((pkg.GraphRRG(256, 3, seed=5), 64), (pkg.GraphSKNormal(64, seed=5), 8)):
+    for X, R in ((pkg.GraphRRG(256, 3, seed=5), 64), (pkg.GraphSKNormal(64, seed=5), 8), (pkg.GraphRRGNormal(128, 3, seed=5), 70)):
         with pkg.Engine(X, R) as eng:
             eng.seed(5); eng.init_spins_random()
             eng.set_debug_checks(True)
