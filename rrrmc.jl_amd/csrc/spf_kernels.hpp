@@ -103,6 +103,14 @@ __global__ __launch_bounds__(64) void spf_energy_sum_kernel(SpfParams P)
     const double* lf = P.lf + (size_t)w * N * 64 + lane;
     double E1 = 0.0;
     int x = 0;
+    // the sum is the reference's sequential one (its order is fixed); what can be wide is the number of lines in flight per wavefront
+    for (; x + 32 <= N; x += 32) {
+        double v[32];
+#pragma unroll
+        for (int q = 0; q < 32; ++q) v[q] = lf[(size_t)(x + q) * 64];
+#pragma unroll
+        for (int q = 0; q < 32; ++q) E1 = __dadd_rn(E1, __dmul_rn(v[q], 0.5));
+    }
     for (; x + 8 <= N; x += 8) {
         double v[8];
 #pragma unroll

@@ -340,25 +340,28 @@ __global__ __launch_bounds__(NW * 64) SPF_TEAM_OCC void spf_team_kernel(SpfTeamP
     constexpr int S = spf_plan_stride(K);
     static_assert(2 * S <= 64, "the two records of a pair are fetched by one wavefront load");
     // the records of the wavefront's next pair travel one pair ahead of their use
-    auto fetch_pair = [&](uint64_t h) -> uint32_t {
-        const int64_t it_even = (int64_t)(2 * (hb + h) - g0);
-        const int64_t rec0 = it_even > iters ? iters : it_even;     // it_even >= 0; clamped: a pair beyond the launch is fetched and never used
-        return TP.plan[(size_t)rec0 * S + (lane < 2 * S ? lane : 0)];
+    // launch-relative 32-bit arithmetic on the hot path: pair h (h < 2^18) holds iterations 2 h - c0 and 2 h - c0 + 1
+    const int32_t n32 = (int32_t)iters;
+    auto fetch_pair = [&](int32_t h) -> uint32_t {
+        const int32_t it_even = 2 * h - c0;
+        const int32_t rec0 = it_even > n32 ? n32 : it_even;         // it_even >= 0; clamped: a pair beyond the launch is fetched and never used
+        return TP.plan[(uint32_t)rec0 * (uint32_t)S + (uint32_t)(lane < 2 * S ? lane : 0)];
     };
     auto load_word = [&](int x_) -> word_t { return __hip_atomic_load(sp + (size_t)x_ * TPG, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT); };
     auto site_of_tl = [&](int32_t t) -> int32_t {                   // move_last of a lane whose last accepted attempt is t
         const int32_t s = P.sites[(t > 0 ? t : 1) - 1];
         return t > 0 ? s : ml0;
     };
-    uint32_t pr_next = fetch_pair((uint64_t)x), pr_next2 = fetch_pair((uint64_t)x + NX);
+    uint32_t pr_next = fetch_pair(x), pr_next2 = fetch_pair(x + NX);
     int32_t nacc = 0;
 #ifdef SPF_TEAM_STAMPS
     uint64_t st_acc[6] = {0, 0, 0, 0, 0, 0}, st_last = __builtin_amdgcn_s_memtime(), st_n = 0;
 #endif
-    for (uint64_t h = (uint64_t)x;; h += NX) {
-        const uint64_t blk_id = hb + h;
-        const int64_t it_even = (int64_t)(2 * blk_id - g0);         // iteration whose stream index g is even
-        if (it_even > iters) break;
+    int slot_even = (2 * x) % M;                                    // slot of the pair's first attempt: (2 h) mod M, kept by addition (a 64-bit modulo per pair otherwise)
+    for (int32_t h = x;; h += NX, slot_even = slot_even + 2 * NX >= M ? slot_even + 2 * NX - M : slot_even + 2 * NX) {
+        const uint64_t blk_id = hb + (uint64_t)h;
+        const int32_t it_even = 2 * h - c0;                         // iteration whose stream index g is even
+        if (it_even > n32) break;
         const uint32_t pr = pr_next;
         pr_next = pr_next2;
         pr_next2 = fetch_pair(h + 2 * NX);
@@ -372,10 +375,10 @@ __global__ __launch_bounds__(NW * 64) SPF_TEAM_OCC void spf_team_kernel(SpfTeamP
         double J[2][K], U[2];
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
-            const int64_t it = it_even + e;
-            valid[e] = it >= 1 && it <= iters;
-            itv[e] = (int32_t)it;
-            sl_[e] = (int)((2 * h + (uint64_t)e) % (uint64_t)M);
+            const int32_t it = it_even + e;
+            valid[e] = it >= 1 && it <= n32;
+            itv[e] = it;
+            sl_[e] = slot_even + e >= M ? slot_even + e - M : slot_even + e;
             const int o = e * S;
             site[e] = __builtin_amdgcn_readlane((int)pr, o + 0);
             same[e] = __builtin_amdgcn_readlane((int)pr, o + 1);

@@ -24,13 +24,14 @@ def passes(d):
     """{pass: {counter: [per-dispatch values]}} of the spf_team_kernel dispatches, the kernel's name, its total trace time in ms"""
     out, name = {}, None
     for sub in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_sq2", "pmc_sq3"):
-        for f in glob.glob(os.path.join(d, sub, "**", "*counter_collection.csv"), recursive=True):
+        # (gpurun merges every run's files into the same directory: the newest file of a pass is this run's)
+        for f in sorted(glob.glob(os.path.join(d, sub, "**", "*counter_collection.csv"), recursive=True), key=os.path.getmtime)[-1:]:
             for row in csv.DictReader(open(f)):
                 if "spf_team_kernel" in row["Kernel_Name"]:
                     out.setdefault(sub, {}).setdefault(row["Counter_Name"], []).append(float(row["Counter_Value"]))
                     name = row["Kernel_Name"].replace("void rrrmc::", "").split("(")[0]
     ms = 0.0
-    for f in glob.glob(os.path.join(d, "trace", "**", "*kernel_trace.csv"), recursive=True):
+    for f in sorted(glob.glob(os.path.join(d, "trace", "**", "*kernel_trace.csv"), recursive=True), key=os.path.getmtime)[-1:]:
         for row in csv.DictReader(open(f)):
             if "spf_team_kernel" in row["Kernel_Name"]:
                 ms += (int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) * 1e-6
