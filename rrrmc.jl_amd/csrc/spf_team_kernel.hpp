@@ -407,10 +407,22 @@ __global__ __launch_bounds__(NW * 64) SPF_TEAM_OCC void spf_team_kernel(SpfTeamP
         // enough to rule the undo path out if every earlier attempt at this site has retired (same <= prefix).
         auto request = [&](auto ec) {
             constexpr int e = decltype(ec)::value;
+#ifdef SPF_TEAM_EXP_NOPROTO          // timing experiment (wrong results): no look at flags, prefix or tl at all
+          const bool reuse = true;
+          if (e == 0) { pfx[0] = spf_lds_uniform(shP); tlv[0] = 0; mls[0] = -1; }
+#else
+          const bool reuse = e == 1 && valid[0] && conf[1] == 0ull && pfx[0] >= itv[1] - kSpfTeamWindow;         // wave-uniform
+#endif
+          if (reuse) {
+            // the pair's second attempt conflicts with nothing in the window: the first one's look at the prefix and at tl (a moment ago) serves it too
+            pfx[1] = pfx[0];
+            tlv[1] = tlv[0];
+          } else {
             const int32_t j = itv[e] - 1 - lane;
             const bool mine = j >= 1 && ((conf[e] >> lane) & 1ull);
             const int32_t* const fj = done + (mine ? (j + c0) % M : 0);
-            int32_t f = spf_lds_ld(fj);
+            int32_t f = 0x7fffffff;
+            if (conf[e] != 0ull) f = spf_lds_ld(fj);                // (six attempts in seven conflict with nothing in the window)
             int32_t pv = spf_lds_ld(shP);
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             int32_t t0 = spf_lds_ld(tl + dl);
@@ -429,6 +441,7 @@ __global__ __launch_bounds__(NW * 64) SPF_TEAM_OCC void spf_team_kernel(SpfTeamP
             }
             pfx[e] = pnow;
             tlv[e] = t0;
+          }
             SPF_TRACE(itv[e], 0);
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, SPF_TEAM_SCOPE);
 #ifdef SPF_TEAM_EXP_NOMEM
@@ -446,14 +459,20 @@ __global__ __launch_bounds__(NW * 64) SPF_TEAM_OCC void spf_team_kernel(SpfTeamP
                 nw[e][k] = load_word(y[e][k]);
             }
 #endif
-            mls[e] = site_of_tl(tlv[e]);
+#ifdef SPF_TEAM_EXP_NOPROTO
+            mls[e] = -1;
+#else
+            if (reuse) mls[1] = mls[0]; else mls[e] = site_of_tl(tlv[e]);
+#endif
         };
         // the attempt is reported once its field and spin stores have been PERFORMED: a workgroup-scope release does not wait for vector stores
         // (it relies on one compute unit issuing them in order; loads of another SIMD were seen to overtake them)
         auto report = [&](auto ec) {
             constexpr int e = decltype(ec)::value;
             if (!valid[e] || reported[e]) return;
+#ifndef SPF_TEAM_EXP_NOPROTO2
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, SPF_TEAM_SCOPE);
             if (lane == 0) spf_lds_st(done + sl_[e], itv[e]);
             SPF_TRACE(itv[e], 6);
@@ -552,9 +571,11 @@ __global__ __launch_bounds__(NW * 64) SPF_TEAM_OCC void spf_team_kernel(SpfTeamP
                     }
                 }
             }
+#ifndef SPF_TEAM_EXP_NOPROTO2
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             if (lane == 0) spf_lds_st(ev + s, it);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+#endif
 
 #ifdef SPF_TEAM_EXP_NOMEM
             if (amask == 0xdeadbeefull) {
@@ -580,8 +601,10 @@ __global__ __launch_bounds__(NW * 64) SPF_TEAM_OCC void spf_team_kernel(SpfTeamP
                 if (lane == 0) __hip_atomic_store(sp + (size_t)i * TPG, (word_t)(wi[e] ^ (word_t)amask), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
             if (act) {
+#ifndef SPF_TEAM_EXP_NOPROTO2
 #pragma unroll
                 for (int k = 0; k < K; ++k) rec[s][k][dl] = nf[e][k];           // lfields_last[y] = lfields[y] (slow) / the swap (fast)
+#endif
                 vown[s][dl] = acc ? lfi[e] : 0.0;
                 vtag[s][dl] = acc ? (uint32_t)it : 0u;
             }
