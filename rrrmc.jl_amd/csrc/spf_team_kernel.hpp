@@ -156,6 +156,11 @@ __global__ __launch_bounds__(NW * 64) SPF_TEAM_OCC void spf_team_kernel(SpfTeamP
     constexpr int NX = NW - 1;
     constexpr int AREAS = spf_team_areas(NW, M);
     constexpr int TPG = 64 / TW;                      // teams per group
+#ifdef SPF_TEAM_NO_FUSE
+    constexpr bool FUSE = false;
+#else
+    constexpr bool FUSE = TW <= 32 && K <= 6;         // pairs of attempts in the two halves of a wavefront (beyond K = 6 the registers run out)
+#endif
     typedef typename spf_word<TW>::type word_t;
     static_assert(M <= kSpfTeamWindow && M < 64 && M >= 2 * NX, "the dependency window covers the attempts in flight; one wavefront read brings all flags; a pair per executing wavefront");
     static_assert(AREAS == M + NX + 1, "areas");
@@ -318,8 +323,10 @@ __global__ __launch_bounds__(NW * 64) SPF_TEAM_OCC void spf_team_kernel(SpfTeamP
 #endif
         if (TP.status && spf_lds_uniform(abortf) && lane == 0) *TP.status = 1;
         if (act) {
-            P.E_cur[r] = E;
-            P.move_last[r] = tlr ? P.sites[tlr - 1] : ml0;
+            int r_ = r;
+            asm volatile("" : "+v"(r_));            // (the addresses are formed here, not carried from the head of the kernel in registers)
+            P.E_cur[r_] = E;
+            P.move_last[r_] = tlr ? P.sites[tlr - 1] : ml0;
             // every executing wavefront has reported its last attempt: nothing moves any more
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             int area = M + NX;
@@ -352,6 +359,9 @@ __global__ __launch_bounds__(NW * 64) SPF_TEAM_OCC void spf_team_kernel(SpfTeamP
         const int32_t s = P.sites[(t > 0 ? t : 1) - 1];
         return t > 0 ? s : ml0;
     };
+    char* const lfb = reinterpret_cast<char*>(P.lf + (size_t)w * N * 64 + part * TW);                   // wave-uniform bases of the team's lines and words
+    char* const spb = reinterpret_cast<char*>(reinterpret_cast<word_t*>(P.spins + (size_t)w * N) + part);
+    const uint32_t dl8 = (uint32_t)dl * 8u;
     uint32_t pr_next = fetch_pair(x), pr_next2 = fetch_pair(x + NX);
     int32_t nacc = 0;
 #ifdef SPF_TEAM_STAMPS
@@ -380,18 +390,25 @@ __global__ __launch_bounds__(NW * 64) SPF_TEAM_OCC void spf_team_kernel(SpfTeamP
             itv[e] = it;
             sl_[e] = slot_even + e >= M ? slot_even + e - M : slot_even + e;
             const int o = e * S;
-            site[e] = __builtin_amdgcn_readlane((int)pr, o + 0);
             same[e] = __builtin_amdgcn_readlane((int)pr, o + 1);
             conf[e] = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)pr, o + 3) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)pr, o + 2);
-#pragma unroll
-            for (int k = 0; k < K; ++k) {
-                y[e][k] = __builtin_amdgcn_readlane((int)pr, o + 4 + k);
-                const uint32_t jl = (uint32_t)__builtin_amdgcn_readlane((int)pr, o + 4 + K + 2 * k), jh = (uint32_t)__builtin_amdgcn_readlane((int)pr, o + 4 + K + 2 * k + 1);
-                J[e][k] = __longlong_as_double((long long)(((unsigned long long)jh << 32) | jl));
-            }
-            const uint64_t u = e ? (((uint64_t)blk.w[2] << 32) | blk.w[3]) : (((uint64_t)blk.w[0] << 32) | blk.w[1]);
-            U[e] = (double)(u >> 11) * 0x1.0p-53;
         }
+        // what an attempt works with as wave-uniform values (a fused pair takes them per lane instead and skips this)
+        auto scalars = [&]() {
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int o = e * S;
+                site[e] = __builtin_amdgcn_readlane((int)pr, o + 0);
+#pragma unroll
+                for (int k = 0; k < K; ++k) {
+                    y[e][k] = __builtin_amdgcn_readlane((int)pr, o + 4 + k);
+                    const uint32_t jl = (uint32_t)__builtin_amdgcn_readlane((int)pr, o + 4 + K + 2 * k), jh = (uint32_t)__builtin_amdgcn_readlane((int)pr, o + 4 + K + 2 * k + 1);
+                    J[e][k] = __longlong_as_double((long long)(((unsigned long long)jh << 32) | jl));
+                }
+                const uint64_t u = e ? (((uint64_t)blk.w[2] << 32) | blk.w[3]) : (((uint64_t)blk.w[0] << 32) | blk.w[1]);
+                U[e] = (double)(u >> 11) * 0x1.0p-53;
+            }
+        };
         SPF_STAMP(0);                                               // state-independent preparation
         double lfi[2], nf[2][K];
         word_t wi[2], nw[2][K];
@@ -405,7 +422,8 @@ __global__ __launch_bounds__(NW * 64) SPF_TEAM_OCC void spf_team_kernel(SpfTeamP
         //     retired.  Lane c - 1 looks at iteration j = it - c: the flag of its slot says j, or a later user of the slot, once j has reported.
         // One LDS round trip brings the flags, the retired prefix and, behind it (tl is written before the prefix), move_last as retired so far —
         // enough to rule the undo path out if every earlier attempt at this site has retired (same <= prefix).
-        auto request = [&](auto ec) {
+        bool reused = false;
+        auto gate = [&](auto ec) {
             constexpr int e = decltype(ec)::value;
 #ifdef SPF_TEAM_EXP_NOPROTO          // timing experiment (wrong results): no look at flags, prefix or tl at all
           const bool reuse = true;
@@ -442,8 +460,14 @@ __global__ __launch_bounds__(NW * 64) SPF_TEAM_OCC void spf_team_kernel(SpfTeamP
             pfx[e] = pnow;
             tlv[e] = t0;
           }
+            if (e == 1) reused = reuse;
             SPF_TRACE(itv[e], 0);
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, SPF_TEAM_SCOPE);
+        };
+        auto request = [&](auto ec) {
+            constexpr int e = decltype(ec)::value;
+            gate(ec);
+            const bool reuse = e == 1 && reused;
 #ifdef SPF_TEAM_EXP_NOMEM
             // timing experiment (tools/ubench/spf_team_bench.hip; wrong results): no global memory traffic at all — what the protocol alone costs
             lfi[e] = 0.25 * (double)((dl + site[e]) & 7) - 1.0;
@@ -501,7 +525,7 @@ __global__ __launch_bounds__(NW * 64) SPF_TEAM_OCC void spf_team_kernel(SpfTeamP
                 accv[e] = a_;
             }
             amaskv[e] = __builtin_amdgcn_ballot_w64(accv[e]) & (TW == 64 ? ~0ull : (1ull << (TW & 63)) - 1ull);     // lanes >= TW repeat lane dl
-            nacc += accv[e] ? 1 : 0;
+            nacc += accv[e] && act ? 1 : 0;
             SPF_STAMP(2);                                           // loads + decision
             SPF_TRACE(itv[e], 2);
         };
@@ -621,6 +645,131 @@ __global__ __launch_bounds__(NW * 64) SPF_TEAM_OCC void spf_team_kernel(SpfTeamP
 #else
         const bool together = valid[0] && valid[1] && !(conf[1] & 1ull);        // B commutes with A
 #endif
+        if constexpr (FUSE) {
+            if (together) {
+                // FUSED PAIR (teams of 32 or 16 replicas): the two attempts commute, and a wavefront has twice the team's lanes — lanes 0..31 work
+                // attempt A off, lanes 32..63 attempt B for the same replicas, with ONE instruction stream for the loads, the decision, the update
+                // and the records.  What differs per attempt (site, neighbours, couplings, slot, random number) is selected per lane.
+                gate(eA);
+                gate(eB);
+                const bool hi = lane >= 32;
+                const bool fact = (lane & 31) < TW;
+                const int32_t itL = hi ? itv[1] : itv[0];
+                const int sL = hi ? sl_[1] : sl_[0];
+                int32_t tlvL = hi ? tlv[1] : tlv[0];
+                const int32_t pmin = pfx[0] < pfx[1] ? pfx[0] : pfx[1];
+                // the lane's record of the pair: dword f of attempt A in lanes 0..31, of attempt B in lanes 32..63 (a crossbar read of the fetched pair)
+                const int rb = hi ? 4 * S : 0;
+                auto field = [&](int f) -> uint32_t { return (uint32_t)__builtin_amdgcn_ds_bpermute(rb + 4 * f, (int)pr); };
+                const uint32_t siteL = field(0);
+                uint32_t yL[K];
+                double JL[K], nfL[K];
+                word_t nwL[K];
+#pragma unroll
+                for (int k = 0; k < K; ++k) {
+                    yL[k] = field(4 + k);
+                    JL[k] = __longlong_as_double((long long)(((unsigned long long)field(4 + K + 2 * k + 1) << 32) | field(4 + K + 2 * k)));
+                }
+                // 32-bit offsets from the team's wave-uniform bases (N <= 2^20 sites of 512 bytes)
+                auto LF = [&](uint32_t site_) -> double* { return reinterpret_cast<double*>(lfb + (site_ * 512u + dl8)); };
+                auto SP = [&](uint32_t site_) -> word_t* { return reinterpret_cast<word_t*>(spb + site_ * 8u); };
+#ifdef SPF_TEAM_EXP_NOMEM
+                const double lfiL = 0.25 * (double)((dl + siteL) & 7) - 1.0;
+                const word_t wiL = (word_t)0x5555aaaa5555aaaaull;
+#pragma unroll
+                for (int k = 0; k < K; ++k) { nfL[k] = 0.5 * k; nwL[k] = (word_t)(0x3333cccc3333ccccull + (unsigned long long)yL[k]); }
+#else
+                const double lfiL = *LF(siteL);
+                const word_t wiL = __hip_atomic_load(SP(siteL), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+#pragma unroll
+                for (int k = 0; k < K; ++k) { nfL[k] = *LF(yL[k]); nwL[k] = __hip_atomic_load(SP(yL[k]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT); }
+#endif
+                const int32_t mlsL = site_of_tl(tlvL);
+                const uint32_t uh = hi ? blk.w[2] : blk.w[0], ul = hi ? blk.w[3] : blk.w[1];
+                const double UL = (double)((((uint64_t)uh << 32) | ul) >> 11) * 0x1.0p-53;
+                SPF_STAMP(1);
+                bool accL;
+                {
+                    const double xx = __dmul_rn(-P.beta, -lfiL);
+                    const float e32 = __builtin_amdgcn_exp2f(__fmul_rn((float)xx, 1.44269504088896340736f));
+                    const double est = (double)e32;
+                    const bool sure_yes = xx >= 0.0 || UL < __dmul_rn(est, 1.0 - 0x1.0p-13);
+                    const bool sure_no = !(xx >= 0.0) && UL > __dmul_rn(est, 1.0 + 0x1.0p-13);
+                    accL = sure_yes;
+                    if (__builtin_amdgcn_ballot_w64(!sure_yes && !sure_no) != 0ull) accL = xx >= 0.0 || UL < det_exp(xx);
+                }
+                const unsigned long long amask = __builtin_amdgcn_ballot_w64(accL && fact);
+                nacc += accL && fact ? 1 : 0;
+                SPF_STAMP(2);
+                // the undo path may be due (about one pair in a thousand): nothing has been written yet, and the pair starts again below as two
+                // attempts one after the other
+                const bool plain = !(same[0] > pfx[0] || same[1] > pfx[1] || __builtin_amdgcn_ballot_w64(accL && fact && mlsL == (int32_t)siteL) != 0ull);
+                if (plain) {
+                // the slots: free once attempts itA - M and itB - M have retired; their records that are still a replica's last accepted move go to the keep
+                if (itv[1] > M) {
+                    if (pmin < itv[1] - M) {
+                        wait_prefix(itv[1] - M, 1);
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                        tlvL = spf_lds_ld(tl + dl);
+                    }
+                    const bool live = fact && itL > M && tlvL == itL - M;       // at most one of a replica's two lanes
+                    if (__builtin_amdgcn_ballot_w64(live) != 0ull) {
+                        if (live) {
+#pragma unroll
+                            for (int k = 0; k < K; ++k) rec[M + x][k][dl] = rec[sL][k][dl];
+                            vown[M + x][dl] = vown[sL][dl];
+                        }
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                if ((lane & 31) == 0) spf_lds_st(ev + sL, itL);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+#ifdef SPF_TEAM_EXP_NOMEM
+                if (amask == 0xdeadbeefull) {
+#else
+                if (amask != 0ull) {
+#endif
+                    const uint32_t snew = (uint32_t)((wiL >> dl) & 1u) ^ 1u;
+                    double vrun = 0.0;
+#pragma unroll
+                    for (int k = 0; k < K; ++k) {
+                        const bool rep = k > 0 && yL[k] == yL[k - 1];
+                        const uint32_t sbit = (uint32_t)((nwL[k] >> dl) & 1u);
+                        const double c = (snew ^ sbit) ? -4.0 : 4.0;
+                        const double v = __dadd_rn(rep ? vrun : nfL[k], -__dmul_rn(c, JL[k]));
+                        vrun = v;
+                        if (fact) *LF(yL[k]) = accL ? v : nfL[k];
+                    }
+                    if (fact) *LF(siteL) = accL ? -lfiL : lfiL;
+                    if ((lane & 31) == 0) __hip_atomic_store(SP(siteL), (word_t)(wiL ^ (word_t)(hi ? amask >> 32 : amask)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+                if (fact) {
+#pragma unroll
+                    for (int k = 0; k < K; ++k) rec[sL][k][dl] = nfL[k];
+                    vown[sL][dl] = accL ? lfiL : 0.0;
+                    vtag[sL][dl] = accL ? (uint32_t)itL : 0u;
+                }
+                SPF_STAMP(3);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, SPF_TEAM_SCOPE);
+                if ((lane & 31) == 0) spf_lds_st(done + sL, itL);
+                SPF_STAMP(4);
+#ifdef SPF_TEAM_STAMPS
+                st_n += 2;
+#endif
+                continue;
+                }
+                nacc -= accL && fact ? 1 : 0;
+            }
+        }
+        scalars();
+        if constexpr (FUSE) {
+            // what is left over by the fused pairs (a second attempt that depends on the first, the ends of a launch, the undo path): one attempt
+            // after the other, with no overlap to pay registers for
+            if (valid[0]) { request(eA); decide(eA); finish(eA); report(eA); }
+            if (valid[1]) { request(eB); decide(eB); finish(eB); report(eB); }
+            continue;
+        }
         if (valid[0]) request(eA);
         if (valid[1] && (together || !valid[0])) request(eB);
         SPF_STAMP(1);                                               // waiting for the dependencies, requests out
@@ -640,7 +789,8 @@ __global__ __launch_bounds__(NW * 64) SPF_TEAM_OCC void spf_team_kernel(SpfTeamP
         SPF_STAMP(4);                                               // stores performed, attempts reported
     }
     // accepted moves: a count, whatever the order (the host clears acc_cur at the start of the call)
-    if (act) atomicAdd(reinterpret_cast<unsigned long long*>(P.acc_cur) + r, (unsigned long long)nacc);
+    // (a fused pair counts its second attempt in the upper half of the wavefront: two lanes of one replica)
+    if ((lane & 31) < TW) atomicAdd(reinterpret_cast<unsigned long long*>(P.acc_cur) + r, (unsigned long long)nacc);
 #ifdef SPF_TEAM_STAMPS
     if (w == 0 && lane == 0) {
         unsigned long long* o = reinterpret_cast<unsigned long long*>(P.Es) + (size_t)x * 8;      // harness only: the sample buffer is not compared in this build
