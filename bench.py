@@ -573,9 +573,10 @@ def secondary_f64_exact(pkg, O, device):
            "value": R * iters / dt, "unit": "attempts/s", "kernel": spf_team_kernel_name(R), "avg_launch_ms": k_ms / max(nl, 1), "launches": nl,
            "acceptance": a, "algorithmic_bytes_per_attempt": bpa, "achieved_GBps": bpa * R * iters / (k_ms * 1e-3) / 1e9}
     out["frac"] = out["achieved_GBps"] / HBM_PEAK_GBS
-    # what binds it at this replica count: a team's wavefronts' own instruction streams (profiles/r05/spf_team_counters.txt: a wavefront issues
-    # 36 % of its cycles, stalls for an issue slot 17 %, waits 47 %), not memory: the measured traffic is a third of the HBM peak
-    out["bound"] = "wavefront instruction streams of one team per compute unit (issue + two memory round trips per pair of attempts)"
+    # what binds it at this replica count: memory.  The kernel moves the lines of the Float64 fields whole (65 measured bytes per attempt, Infinity
+    # Cache included); the same kernel at 262 144 replicas saturates at 0.65 of the 8 TB/s peak (f64_sparse_exact_262144), and this replica count
+    # — one team of 32 replicas per compute unit, two attempts per wavefront instruction — reaches about 0.8 of that
+    out["bound"] = "hbm (measured traffic: the 256-byte lines of a team's Float64 fields read and written whole; random lines saturate near 0.65 of the peak, see f64_sparse_exact_262144)"
     got, why = spf_traffic()
     if got:
         tf, _, tf_path = got
@@ -583,8 +584,9 @@ def secondary_f64_exact(pkg, O, device):
         out["traffic"] = {"measured_bytes_per_attempt": tf["measured_bytes_per_attempt"], "ratio_to_algorithmic": tf["traffic_ratio"],
                           "hbm_GBps_at_this_rate": gbps, "frac_of_hbm_peak": gbps / HBM_PEAK_GBS,
                           "source": "%s (committed rocprofv3 FETCH_SIZE x2 + WRITE_SIZE pass of the same workload, commit %s, stamp matches these sources; not measured in this run)" % (tf_path, tf.get("git_commit"))}
-        out["bound_frac"] = tf.get("wave_issue_frac")
-        out["bound_frac_meaning"] = "share of a wavefront's cycles in which it issues an instruction (SQ_ACTIVE_INST_ANY / SQ_WAVE_CYCLES of the committed pass)"
+        out["bound_frac"] = gbps / HBM_PEAK_GBS
+        out["bound_frac_meaning"] = "measured bytes per attempt (committed pass) at this run's rate over the 8 TB/s peak"
+        out["wave_issue_frac"] = tf.get("wave_issue_frac")
     else:
         out["traffic"] = None
         out["traffic_note"] = why
