@@ -16,6 +16,12 @@
 //     that is safe, by the oracle's det_exp in a narrow band around it: identical decisions), the K + 1 field updates, the spin word — on the
 //     group's [N][64] arrays in HBM / L2, exactly as spf_sweep_kernel does.  A wavefront counts its own accepted moves (a count does not care
 //     about order).  Results go into the attempt's SLOT in LDS (slot = iteration mod M), free once attempt it - M has retired.
+//   * FUSED PAIRS (teams of 32 or 16 replicas, K <= 6): a wavefront has twice the team's lanes and an instruction costs the same with half
+//     of them idle, so when the pair's attempts commute, lanes 0..31 work off the first and lanes 32..63 the second FOR THE SAME REPLICAS with
+//     one instruction stream — eight loads, one decision, one update, one set of records, one report for the two.  What differs per attempt
+//     (site, neighbours, couplings, slot, random number) is per-lane data: the record fields come from the fetched pair by a crossbar read.
+//     A pair whose undo path may be due (one in a thousand) has written nothing yet and starts again as two attempts one after the other,
+//     like the pairs whose second attempt depends on the first.
 //   * one RETIRING wavefront keeps what the reference's loop keeps in chain order: the tracked energy (E += dE is a Float64 running sum:
 //     its order is the chain's), the samples (RRRMC.jl:104-108) and, per replica, WHICH attempt its last accepted move was (tl).  It consumes
 //     the attempts strictly in order from their slots: {the attempted site's own field, or +0.0 for a replica that did not accept (E - 0.0 == E
@@ -36,9 +42,9 @@
 // energies, samples, accepted counts) is bit-identical to spf_sweep_kernel and the oracle (tests/test_gpu_spf_parity.py runs every case — two
 // bonds to the same neighbour included — through the builds of both kernels; tools/ubench/spf_team_bench.hip compares every word).
 //
-// What bounds it (profiles/r05/spf_team_*): at 8192 replicas a team's pace is its wavefronts' own instruction streams — about 480
-// instructions per attempt over sixteen wavefronts, a third of them polling and address arithmetic — plus two memory round trips per pair;
-// the retiring wavefront idles two thirds of its time.  From 65 536 replicas on it is HBM.
+// What bounds it (profiles/r05/spf_team_*): memory.  65 bytes per attempt cross the L2s (the lines of the K + 1 fields read and written whole);
+// at 8192 replicas (256 teams of 32, fused pairs: about 240 instructions per attempt of a team over sixteen wavefronts) the kernel moves
+// 4.2 TB/s, from 16 384 replicas on 4.6 - 5.2 TB/s, which is what random lines reach of the 8 TB/s.  The retiring wavefront idles most of its time.
 //
 // Ordering rests on three hardware facts, all within ONE compute unit (a workgroup never spans two; the kernel must not be built for
 // threadgroup-split mode, where a workgroup's waves may sit on different compute units — hipcc's default is off and build.py passes no

@@ -208,3 +208,24 @@ def test_random_shapes_team_builds_against_the_single_wavefront_kernel(pkg, monk
     for o in outs[1:]:
         for u, v in zip(outs[0], o):
             assert (np.asarray(u) == np.asarray(v)).all()
+
+
+@pytest.mark.parametrize("kind,a,b,beta", [("rrg", 512, 3, 0.1), ("rrg", 512, 6, 0.5), ("ea", 8, 2, 0.3), ("ea", 5, 3, 1.0), ("rrg", 64, 5, 0.0)])
+def test_fused_pairs_at_every_width(pkg, oracle, monkeypatch, kind, a, b, beta):
+    """Teams of 32 and 16 replicas run the two commuting attempts of a pair in the two halves of a wavefront (K <= 6).  Graphs of a few hundred
+    sites at high acceptance: most pairs are fused, a good share of them restarts on the undo test (an accepting replica whose last accepted
+    move is at the same site), some have a dependent second attempt; the accepted moves of a replica are counted in two lanes.  Widths 16, 32
+    and 64 and the single-wavefront kernel against each other; replicas from both ends of a team against the oracle."""
+    seed, R, iters, step = 4000 + 7 * a + b, 1056, 20001, 501
+    X = pkg.GraphRRGNormal(a, b, seed=seed) if kind == "rrg" else pkg.GraphEANormal(a, b, seed=seed)
+    outs = []
+    for env in ({"RRRMC_SPF_TEAM_WIDTH": "16"}, {"RRRMC_SPF_TEAM_WIDTH": "32"}, {"RRRMC_SPF_TEAM_WAVES": "16", "RRRMC_SPF_TEAM_WIDTH": "64"}, {"RRRMC_SPF_TEAM": "0"}):
+        _set_build(monkeypatch, env)
+        outs.append(_run(pkg, X, R, seed, beta, iters, step))
+    for o in outs[1:]:
+        for u, v in zip(outs[0], o):
+            assert (u == v).all()
+    C0, Es, acc, C1, lf1, Et = outs[0]
+    for r in (0, 15, 16, 31, 32, 63, 64, 1024, R - 1):
+        ref = oracle.standard_mc_spf(X.A, X.J, beta, iters, step, seed, C0[r], replica=r, form=kind)
+        assert (Es[r] == ref[0]).all() and (C1[r] == ref[1]).all() and acc[r] == ref[2] and (lf1[r] == ref[3]).all()
