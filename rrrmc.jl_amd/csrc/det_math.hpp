@@ -51,6 +51,25 @@ __device__ __forceinline__ void sk_exp_constants(double (&c)[17])
 #pragma unroll
     for (int i = 0; i < 17; ++i) { c[i] = v[i]; asm volatile("" : "+v"(c[i])); }
 }
+// The same constants for a path that runs once in a million evaluations: each is moved into its registers by the asm statement itself, so
+// the moves cannot be hoisted out of the enclosing loops (the compiler otherwise materialises all seventeen in the loop preheader and keeps
+// them — or spills them — across the hot path).
+template <unsigned long long B>
+__device__ __forceinline__ double sk_const_here()
+{
+    uint32_t lo, hi;
+    asm volatile("v_mov_b32 %0, %2\n\tv_mov_b32 %1, %3" : "=&v"(lo), "=&v"(hi) : "i"((uint32_t)(B & 0xffffffffull)), "i"((uint32_t)(B >> 32)));
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+#define SK_CONST_HERE(x) sk_const_here<__builtin_bit_cast(unsigned long long, (double)(x))>()
+__device__ __forceinline__ void sk_exp_constants_here(double (&c)[17])
+{
+    c[0] = SK_CONST_HERE(1.0); c[1] = SK_CONST_HERE(1.0); c[2] = SK_CONST_HERE(0.5); c[3] = SK_CONST_HERE(1.0 / 6); c[4] = SK_CONST_HERE(1.0 / 24);
+    c[5] = SK_CONST_HERE(1.0 / 120); c[6] = SK_CONST_HERE(1.0 / 720); c[7] = SK_CONST_HERE(1.0 / 5040); c[8] = SK_CONST_HERE(1.0 / 40320);
+    c[9] = SK_CONST_HERE(1.0 / 362880); c[10] = SK_CONST_HERE(1.0 / 3628800); c[11] = SK_CONST_HERE(1.0 / 39916800);
+    c[12] = SK_CONST_HERE(1.0 / 479001600); c[13] = SK_CONST_HERE(1.0 / 6227020800.0); c[14] = SK_CONST_HERE(1.44269504088896338700e+00);
+    c[15] = SK_CONST_HERE(6.93147180369123816490e-01); c[16] = SK_CONST_HERE(1.90821492927058770002e-10);
+}
 __device__ __forceinline__ double det_exp_c(double x, const double (&c)[17])
 {
     if (x != x) return x;

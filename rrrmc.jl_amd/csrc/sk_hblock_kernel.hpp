@@ -83,6 +83,12 @@ __global__ __launch_bounds__(NTH, RB == 4 ? 2 : 1) void sk_hblock_kernel(SkBlock
     const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6), N = P.N;
     const int grp = blockIdx.x / NH, r8 = (blockIdx.x % NH) * RB, Rp = (gridDim.x / NH) * kSkRB;
 
+    // The thread's sites: pairs of neighbours (one 16-byte load), the pairs 2 NTH apart — a wavefront's load of a row of J, or of lfields_last,
+    // then covers 1024 contiguous bytes.  (SPT contiguous sites per thread put every lane of a 16-byte load into a different 64-byte segment
+    // at SPT = 8: the compute unit's L1 then moved four times the bytes the registers received, and the bulk phase at N = 4096 ran at a
+    // quarter of its Float64 rate.)
+    constexpr int SC = SPT % 2 == 0 ? 2 : 1;
+    auto site_of = [&](int q) -> int { return (q / SC) * (SC * NTH) + SC * tid + (q % SC); };
     double H[SPT][RB];
     double* const hl = P.hl + (size_t)(grp * kSkRB + r8) * (size_t)N;      // this workgroup's replicas: hl[r * N + j]
     {
@@ -91,7 +97,7 @@ __global__ __launch_bounds__(NTH, RB == 4 ? 2 : 1) void sk_hblock_kernel(SkBlock
         for (int r = 0; r < RB; ++r) ml[r] = P.move_last[grp * kSkRB + r8 + r];
 #pragma unroll
         for (int q = 0; q < SPT; ++q) {
-            const int j = tid * SPT + q;
+            const int j = site_of(q);
             const uint32_t sb = j < N ? P.spins[(size_t)grp * N + j] : 0u;
             if (j < N) sh_spin[j] = (uint8_t)sb;
 #pragma unroll
@@ -131,7 +137,10 @@ __global__ __launch_bounds__(NTH, RB == 4 ? 2 : 1) void sk_hblock_kernel(SkBlock
             const int l = idx / RB, r = idx % RB;
             const double u = rand53(P.k0, P.k1, P.g0 + (uint64_t)(b * kSkW + l + 1), P.replica0 + (uint32_t)(grp * kSkRB + r8 + r));
             sh_u[b & (NUB - 1)][l][r] = u;
-            sh_L[b & (NUB - 1)][l][r] = log(u);
+            // ln u for the verdict's filter only (the decision itself is det_exp's): the hardware's log2 on the Float32 image of u, good to
+            // 1.2e-7 |ln u| + 1e-7 — the filter's margin below is sixteen times that.  (The library's log keeps a dozen Float64 constants in
+            // vector registers across the whole block loop; u == 0 or a Float32 denormal gives -inf, i.e. a NaN band: det_exp decides.)
+            sh_L[b & (NUB - 1)][l][r] = (double)__builtin_amdgcn_logf((float)u) * 0.69314718055994530942;
         }
     };
     uint32_t sv = P.blkSites[lane];                        // sites of the current block, lane = attempt
@@ -151,7 +160,7 @@ __global__ __launch_bounds__(NTH, RB == 4 ? 2 : 1) void sk_hblock_kernel(SkBlock
     for (int kk = 0; kk < PF; ++kk) {
         const uint32_t s0 = (uint32_t)__builtin_amdgcn_readlane((int)sv, kk);
 #pragma unroll
-        for (int q = 0; q < SPT; ++q) JA[kk][q] = P.J4[(size_t)s0 * P.ldJ + (tid * SPT + q)];
+        for (int q = 0; q < SPT; ++q) JA[kk][q] = P.J4[(size_t)s0 * P.ldJ + (site_of(q))];
     }
     __syncthreads();
 
@@ -175,7 +184,7 @@ __global__ __launch_bounds__(NTH, RB == 4 ? 2 : 1) void sk_hblock_kernel(SkBlock
         }
 #pragma unroll
         for (int q = 0; q < SPT; ++q) {
-            const int j = tid * SPT + q;
+            const int j = site_of(q);
             const uint32_t c = sh_canon[j];
             if (c != 0xffu) {
                 const uint32_t sb = sh_spin[j];
@@ -191,7 +200,7 @@ __global__ __launch_bounds__(NTH, RB == 4 ? 2 : 1) void sk_hblock_kernel(SkBlock
             if (need_fl[r]) {
 #pragma unroll
                 for (int q = 0; q < SPT; ++q) {
-                    const int j = tid * SPT + q;
+                    const int j = site_of(q);
                     const uint32_t c = sh_canon[j];
                     if (c != 0xffu) {
                         const double hlv = hl[(size_t)r * N + j];
@@ -220,7 +229,7 @@ __global__ __launch_bounds__(NTH, RB == 4 ? 2 : 1) void sk_hblock_kernel(SkBlock
                 const int64_t it0 = P.it_base + b * kSkW;
                 uint32_t accw = 0u;
                 const double Lu = sh_L[pb & (NUB - 1)][lane][r];
-                const double Lm = 1e-9 - 1e-12 * Lu, Lhi = Lu + Lm, Llo = Lu - Lm;
+                const double Lm = 2e-6 - 2e-6 * Lu, Lhi = Lu + Lm, Llo = Lu - Lm;           // (the band: one lane-evaluation in 4e5 falls into it)
                 const unsigned long long vm = nv >= kSkW ? ~0ull : (1ull << nv) - 1ull;
                 auto verdict = [&](const double x) -> unsigned long long {
                     const unsigned long long ge0 = __builtin_amdgcn_ballot_w64(x >= 0.0), hi = __builtin_amdgcn_ballot_w64(x > Lhi);
@@ -229,9 +238,9 @@ __global__ __launch_bounds__(NTH, RB == 4 ? 2 : 1) void sk_hblock_kernel(SkBlock
                     unsigned long long m = vm & sure_acc;
                     unsigned long long need = vm & ~(sure_acc | sure_rej);
                     asm volatile("" : "+s"(need));
-                    if (__builtin_expect(need != 0ull, 0)) {              // once in ~10^9 evaluations: the constants are built here, not kept in registers
+                    if (__builtin_expect(need != 0ull, 0)) {              // once in ~10^4 evaluations of a wavefront: the constants are built here, not kept in registers
                         double expc[17];
-                        sk_exp_constants(expc);
+                        sk_exp_constants_here(expc);
                         m = vm & (ge0 | __builtin_amdgcn_ballot_w64(u < det_exp_v(x, expc)));
                     }
                     return m;
@@ -332,13 +341,13 @@ __global__ __launch_bounds__(NTH, RB == 4 ? 2 : 1) void sk_hblock_kernel(SkBlock
                     if ((w >> (24 + r)) & 1u) {                          // lfields_last = lfields before this move (SK.jl:255-262)
 #pragma unroll
                         for (int q = 0; q < SPT; ++q)
-                            if (tid * SPT + q < N) hr[(uint32_t)(tid * SPT + q)] = H[q][r];
+                            if (site_of(q) < N) hr[(uint32_t)(site_of(q))] = H[q][r];
                     }
                     if ((w >> (8 + r)) & 1u) {                           // lfields <-> lfields_last (SK.jl:247-250)
 #pragma unroll
                         for (int q = 0; q < SPT; ++q) {
-                            if (tid * SPT + q < N) {
-                                double* const px = hr + (uint32_t)(tid * SPT + q);
+                            if (site_of(q) < N) {
+                                double* const px = hr + (uint32_t)(site_of(q));
                                 const double tmp = *px; *px = H[q][r]; H[q][r] = tmp;
                             }
                         }
@@ -376,7 +385,7 @@ __global__ __launch_bounds__(NTH, RB == 4 ? 2 : 1) void sk_hblock_kernel(SkBlock
                 for (int kk = 0; kk < PF; ++kk) {           // rows of attempts k0 + PF .. k0 + 2 PF - 1
                     const uint32_t stn = SKH_ROW((uint32_t)__builtin_amdgcn_readlane((int)sv, k0 + PF + kk));
 #pragma unroll
-                    for (int q = 0; q < SPT; ++q) JB[kk][q] = P.J4[(size_t)stn * P.ldJ + (tid * SPT + q)];
+                    for (int q = 0; q < SPT; ++q) JB[kk][q] = P.J4[(size_t)stn * P.ldJ + (site_of(q))];
                 }
                 sk_static_for<0, PF>([&](auto K_) { constexpr int kk = decltype(K_)::value; apply_step(std::integral_constant<int, g * 2 * PF + kk>{}, k0 + kk, JA[kk], mv); });
                 const uint32_t svn = k0 + 2 * PF < kSkW ? sv : sv_next;
@@ -384,7 +393,7 @@ __global__ __launch_bounds__(NTH, RB == 4 ? 2 : 1) void sk_hblock_kernel(SkBlock
                 for (int kk = 0; kk < PF; ++kk) {           // rows of attempts k0 + 2 PF .. k0 + 3 PF - 1
                     const uint32_t stn = SKH_ROW((uint32_t)__builtin_amdgcn_readlane((int)svn, (k0 + 2 * PF + kk) & 63));
 #pragma unroll
-                    for (int q = 0; q < SPT; ++q) JA[kk][q] = P.J4[(size_t)stn * P.ldJ + (tid * SPT + q)];
+                    for (int q = 0; q < SPT; ++q) JA[kk][q] = P.J4[(size_t)stn * P.ldJ + (site_of(q))];
                 }
                 sk_static_for<0, PF>([&](auto K_) { constexpr int kk = decltype(K_)::value; apply_step(std::integral_constant<int, g * 2 * PF + PF + kk>{}, k0 + PF + kk, JB[kk], mv); });
             });
@@ -421,7 +430,7 @@ __global__ __launch_bounds__(NTH, RB == 4 ? 2 : 1) void sk_hblock_kernel(SkBlock
         for (int r = 0; r < RB; ++r) ml[r] = sh_mlast[r];
 #pragma unroll
         for (int q = 0; q < SPT; ++q) {
-            const int j = tid * SPT + q;
+            const int j = site_of(q);
             if (j < N) {
                 const uint32_t sb = sh_spin[j];
                 const size_t off = (size_t)grp * N + j;

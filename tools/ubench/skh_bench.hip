@@ -31,7 +31,8 @@ static kfn pick(const char* which, int N, int* nth, int* wgs)
     if (N <= 256) { *nth = 256; return h ? sk_hblock_kernel<1, 256, 8> : sk_block_kernel<1, 256>; }
     const int spt = (N + 511) / 512;
     *nth = 512;
-    if (h) return spt == 1 ? sk_hblock_kernel<1, 512, 8> : spt == 2 ? sk_hblock_kernel<2, 512, 8> : spt == 3 ? sk_hblock_kernel<3, 512, 8> : sk_hblock_kernel<4, 512, 8>;
+    if (h) return spt == 1 ? sk_hblock_kernel<1, 512, 8> : spt == 2 ? sk_hblock_kernel<2, 512, 8> : spt == 3 ? sk_hblock_kernel<3, 512, 8> : spt == 4 ? sk_hblock_kernel<4, 512, 8>
+                         : spt <= 6 ? sk_hblock_kernel<6, 512, 8> : sk_hblock_kernel<8, 512, 8>;
     return spt == 1 ? sk_block_kernel<1, 512> : spt == 2 ? sk_block_kernel<2, 512> : spt == 3 ? sk_block_kernel<3, 512> : sk_block_kernel<4, 512>;
 }
 
