@@ -612,7 +612,8 @@ __global__ __launch_bounds__(NW * 64) SPF_TEAM_OCC void spf_team_kernel(SpfTeamP
 #else
             if (amask != 0ull) {
 #endif
-                // update_cache! (RRG.jl:576-617, EA.jl:613-653).  Full 512-byte lines: lanes that do not accept write back what they read
+                // update_cache! (RRG.jl:576-617, EA.jl:613-653).  Only the accepting lanes store (the memory side skips the sectors nobody wrote:
+                // 4 - 7 % of the kernel's time against whole lines written back)
                 const uint32_t snew = (uint32_t)((wi[e] >> dl) & 1u) ^ 1u;
                 double vrun = 0.0;
 #pragma unroll
@@ -625,9 +626,9 @@ __global__ __launch_bounds__(NW * 64) SPF_TEAM_OCC void spf_team_kernel(SpfTeamP
                     const double v = __dadd_rn(rep ? vrun : nf[e][k], -__dmul_rn(c, J[e][k]));
                     vrun = v;
                     const double out = fast ? sv[k] : (slow ? v : nf[e][k]);
-                    if (act) lf[(size_t)y[e][k] * 64] = out;
+                    if (act && acc) lf[(size_t)y[e][k] * 64] = out;
                 }
-                if (act) lf[(size_t)i * 64] = acc ? -lfi[e] : lfi[e];
+                if (act && acc) lf[(size_t)i * 64] = -lfi[e];
                 if (lane == 0) __hip_atomic_store(sp + (size_t)i * TPG, (word_t)(wi[e] ^ (word_t)amask), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
             if (act) {
@@ -744,9 +745,9 @@ __global__ __launch_bounds__(NW * 64) SPF_TEAM_OCC void spf_team_kernel(SpfTeamP
                         const double c = (snew ^ sbit) ? -4.0 : 4.0;
                         const double v = __dadd_rn(rep ? vrun : nfL[k], -__dmul_rn(c, JL[k]));
                         vrun = v;
-                        if (fact) *LF(yL[k]) = accL ? v : nfL[k];
+                        if (fact && accL) *LF(yL[k]) = v;
                     }
-                    if (fact) *LF(siteL) = accL ? -lfiL : lfiL;
+                    if (fact && accL) *LF(siteL) = -lfiL;
                     if ((lane & 31) == 0) __hip_atomic_store(SP(siteL), (word_t)(wiL ^ (word_t)(hi ? amask >> 32 : amask)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 }
                 if (fact) {
