@@ -576,7 +576,7 @@ def secondary_f64_exact(pkg, O, device):
     # what binds it at this replica count: memory.  The kernel moves the lines of the Float64 fields whole (65 measured bytes per attempt, Infinity
     # Cache included); the same kernel at 262 144 replicas saturates at 0.65 of the 8 TB/s peak (f64_sparse_exact_262144), and this replica count
     # — one team of 32 replicas per compute unit, two attempts per wavefront instruction — reaches about 0.8 of that
-    out["bound"] = "hbm (measured traffic: the 256-byte lines of a team's Float64 fields read and written whole; random lines saturate near 0.65 of the peak, see f64_sparse_exact_262144)"
+    out["bound"] = "hbm / memory system (measured traffic: the 256-byte lines of a team's Float64 fields read whole, the accepting lanes' fields written; see f64_sparse_exact_262144)"
     got, why = spf_traffic()
     if got:
         tf, _, tf_path = got
@@ -621,7 +621,7 @@ def secondary_f64_exact_big(pkg, O, device):
            "value": R * iters / dt, "unit": "attempts/s", "kernel": spf_team_kernel_name(R), "avg_launch_ms": k_ms / max(nl, 1), "launches": nl,
            "acceptance": a, "algorithmic_bytes_per_attempt": bpa, "achieved_GBps": bpa * R * iters / (k_ms * 1e-3) / 1e9}
     out["frac"] = out["achieved_GBps"] / HBM_PEAK_GBS
-    out["bound"] = "hbm (measured traffic: random 512-byte lines read and written whole)"
+    out["bound"] = "hbm / memory system (measured traffic: random 512-byte lines read whole, the accepting lanes' fields written)"
     got, why = spf_traffic("at_262144_replicas")
     if got:
         big, tf, tf_path = got

@@ -42,9 +42,9 @@
 // energies, samples, accepted counts) is bit-identical to spf_sweep_kernel and the oracle (tests/test_gpu_spf_parity.py runs every case — two
 // bonds to the same neighbour included — through the builds of both kernels; tools/ubench/spf_team_bench.hip compares every word).
 //
-// What bounds it (profiles/r05/spf_team_*): memory.  65 bytes per attempt cross the L2s (the lines of the K + 1 fields read and written whole);
-// at 8192 replicas (256 teams of 32, fused pairs: about 240 instructions per attempt of a team over sixteen wavefronts) the kernel moves
-// 4.2 TB/s, from 16 384 replicas on 4.6 - 5.2 TB/s, which is what random lines reach of the 8 TB/s.  The retiring wavefront idles most of its time.
+// What bounds it (profiles/r05/spf_team_*): memory.  51 bytes per attempt cross the L2s (the lines of the K + 1 fields are read whole, 34 bytes;
+// only the accepting lanes store, 18 bytes); at 8192 replicas (256 teams of 32, fused pairs: about 240 instructions per attempt of a team
+// over sixteen wavefronts) the kernel moves 3.6 TB/s, at 262 144 replicas 4.3 TB/s.  The retiring wavefront idles most of its time.
 //
 // Ordering rests on three hardware facts, all within ONE compute unit (a workgroup never spans two; the kernel must not be built for
 // threadgroup-split mode, where a workgroup's waves may sit on different compute units — hipcc's default is off and build.py passes no
