@@ -573,9 +573,8 @@ def secondary_f64_exact(pkg, O, device):
            "value": R * iters / dt, "unit": "attempts/s", "kernel": spf_team_kernel_name(R), "avg_launch_ms": k_ms / max(nl, 1), "launches": nl,
            "acceptance": a, "algorithmic_bytes_per_attempt": bpa, "achieved_GBps": bpa * R * iters / (k_ms * 1e-3) / 1e9}
     out["frac"] = out["achieved_GBps"] / HBM_PEAK_GBS
-    # what binds it at this replica count: memory.  The kernel moves the lines of the Float64 fields whole (65 measured bytes per attempt, Infinity
-    # Cache included); the same kernel at 262 144 replicas saturates at 0.65 of the 8 TB/s peak (f64_sparse_exact_262144), and this replica count
-    # — one team of 32 replicas per compute unit, two attempts per wavefront instruction — reaches about 0.8 of that
+    # what binds it at this replica count: the memory system.  The kernel reads the lines of the Float64 fields whole and stores the accepting lanes'
+    # fields (51 measured bytes per attempt, Infinity Cache included); one team of 32 replicas per compute unit, two attempts per wavefront instruction
     out["bound"] = "hbm / memory system (measured traffic: the 256-byte lines of a team's Float64 fields read whole, the accepting lanes' fields written; see f64_sparse_exact_262144)"
     got, why = spf_traffic()
     if got:
