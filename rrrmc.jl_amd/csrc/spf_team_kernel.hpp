@@ -372,6 +372,7 @@ __global__ __launch_bounds__(NW * 64) SPF_TEAM_OCC void spf_team_kernel(SpfTeamP
     int32_t nacc = 0;
 #ifdef SPF_TEAM_STAMPS
     uint64_t st_acc[6] = {0, 0, 0, 0, 0, 0}, st_last = __builtin_amdgcn_s_memtime(), st_n = 0;
+    uint64_t gw[6] = {0, 0, 0, 0, 0, 0};             // gate waits by the window (count, cycles) and by a conflict (count, cycles); slot waits (count, cycles)
 #endif
     int slot_even = (2 * x) % M;                                    // slot of the pair's first attempt: (2 h) mod M, kept by addition (a 64-bit modulo per pair otherwise)
     for (int32_t h = x;; h += NX, slot_even = slot_even + 2 * NX >= M ? slot_even + 2 * NX - M : slot_even + 2 * NX) {
@@ -452,6 +453,9 @@ __global__ __launch_bounds__(NW * 64) SPF_TEAM_OCC void spf_team_kernel(SpfTeamP
             int32_t t0 = spf_lds_ld(tl + dl);
             int32_t pnow = __builtin_amdgcn_readfirstlane(pv);
             if (pnow < itv[e] - kSpfTeamWindow || __builtin_amdgcn_ballot_w64(mine && f < j) != 0ull) {
+#ifdef SPF_TEAM_STAMPS
+                const uint64_t g_t0 = __builtin_amdgcn_s_memtime(); const bool g_byw = pnow < itv[e] - kSpfTeamWindow;
+#endif
                 wait_prefix(itv[e] - kSpfTeamWindow, SPF_TEAM_NAP);
                 int32_t polls = 0;
                 while (__builtin_amdgcn_ballot_w64(mine && spf_lds_ld(fj) < j) != 0ull) {
@@ -462,6 +466,9 @@ __global__ __launch_bounds__(NW * 64) SPF_TEAM_OCC void spf_team_kernel(SpfTeamP
                 pnow = spf_lds_uniform(shP);
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                 t0 = spf_lds_ld(tl + dl);
+#ifdef SPF_TEAM_STAMPS
+                { const uint64_t g_dt = __builtin_amdgcn_s_memtime() - g_t0; if (g_byw) { ++gw[0]; gw[1] += g_dt; } else { ++gw[2]; gw[3] += g_dt; } }
+#endif
             }
             pfx[e] = pnow;
             tlv[e] = t0;
@@ -692,6 +699,7 @@ __global__ __launch_bounds__(NW * 64) SPF_TEAM_OCC void spf_team_kernel(SpfTeamP
                 for (int k = 0; k < K; ++k) { nfL[k] = *LF(yL[k]); nwL[k] = __hip_atomic_load(SP(yL[k]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT); }
 #endif
                 const int32_t mlsL = site_of_tl(tlvL);
+                SPF_TRACE(itv[0], 1); SPF_TRACE(itv[1], 1);
                 const uint32_t uh = hi ? blk.w[2] : blk.w[0], ul = hi ? blk.w[3] : blk.w[1];
                 const double UL = (double)((((uint64_t)uh << 32) | ul) >> 11) * 0x1.0p-53;
                 SPF_STAMP(1);
@@ -706,6 +714,7 @@ __global__ __launch_bounds__(NW * 64) SPF_TEAM_OCC void spf_team_kernel(SpfTeamP
                     if (__builtin_amdgcn_ballot_w64(!sure_yes && !sure_no) != 0ull) accL = xx >= 0.0 || UL < det_exp(xx);
                 }
                 const unsigned long long amask = __builtin_amdgcn_ballot_w64(accL && fact);
+                SPF_TRACE(itv[0], 2); SPF_TRACE(itv[1], 2);
                 nacc += accL && fact ? 1 : 0;
                 SPF_STAMP(2);
                 // the undo path may be due (about one pair in a thousand): nothing has been written yet, and the pair starts again below as two
@@ -715,7 +724,13 @@ __global__ __launch_bounds__(NW * 64) SPF_TEAM_OCC void spf_team_kernel(SpfTeamP
                 // the slots: free once attempts itA - M and itB - M have retired; their records that are still a replica's last accepted move go to the keep
                 if (itv[1] > M) {
                     if (pmin < itv[1] - M) {
+#ifdef SPF_TEAM_STAMPS
+                        const uint64_t g_t0 = __builtin_amdgcn_s_memtime();
+#endif
                         wait_prefix(itv[1] - M, 1);
+#ifdef SPF_TEAM_STAMPS
+                        ++gw[4]; gw[5] += __builtin_amdgcn_s_memtime() - g_t0;
+#endif
                         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                         tlvL = spf_lds_ld(tl + dl);
                     }
@@ -757,9 +772,11 @@ __global__ __launch_bounds__(NW * 64) SPF_TEAM_OCC void spf_team_kernel(SpfTeamP
                     vtag[sL][dl] = accL ? (uint32_t)itL : 0u;
                 }
                 SPF_STAMP(3);
+                SPF_TRACE(itv[0], 5); SPF_TRACE(itv[1], 5);
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, SPF_TEAM_SCOPE);
                 if ((lane & 31) == 0) spf_lds_st(done + sL, itL);
+                SPF_TRACE(itv[0], 6); SPF_TRACE(itv[1], 6);
                 SPF_STAMP(4);
 #ifdef SPF_TEAM_STAMPS
                 st_n += 2;
@@ -803,6 +820,8 @@ __global__ __launch_bounds__(NW * 64) SPF_TEAM_OCC void spf_team_kernel(SpfTeamP
         unsigned long long* o = reinterpret_cast<unsigned long long*>(P.Es) + (size_t)x * 8;      // harness only: the sample buffer is not compared in this build
         for (int q = 0; q < 5; ++q) o[q] = st_acc[q];
         o[5] = st_n;
+        unsigned long long* o2 = reinterpret_cast<unsigned long long*>(P.Es) + (size_t)(NX + 1 + x) * 8;
+        for (int q = 0; q < 6; ++q) o2[q] = gw[q];
     }
 #endif
 }

@@ -23,18 +23,21 @@ struct State {
     unsigned long long* spins; double *lf, *undo, *E, *Es; int32_t* ml; int64_t* acc;
 };
 
+static size_t g_trace_bytes = 0;
 static int alloc_state(State& s, int W, int N, int K, size_t nsamp)
 {
     CK(hipMalloc(&s.spins, sizeof(unsigned long long) * W * N));
     CK(hipMalloc(&s.lf, sizeof(double) * (size_t)W * N * 64));
     CK(hipMalloc(&s.undo, sizeof(double) * (size_t)W * (K + 1) * 64));
     CK(hipMalloc(&s.E, sizeof(double) * W * 64));
-    CK(hipMalloc(&s.Es, sizeof(double) * (nsamp + 1) * W * 64));
+    // (the trace and stamp builds write their clocks into the sample buffer: 8 words per iteration of the longest launch)
+    const size_t es_bytes = sizeof(double) * (nsamp + 1) * W * 64 + (size_t)g_trace_bytes;
+    CK(hipMalloc(&s.Es, es_bytes));
     CK(hipMalloc(&s.ml, sizeof(int32_t) * W * 64));
     CK(hipMalloc(&s.acc, sizeof(int64_t) * W * 64));
     CK(hipMemset(s.undo, 0, sizeof(double) * (size_t)W * (K + 1) * 64));
     CK(hipMemset(s.acc, 0, sizeof(int64_t) * W * 64));
-    CK(hipMemset(s.Es, 0, sizeof(double) * (nsamp + 1) * W * 64));
+    CK(hipMemset(s.Es, 0, es_bytes));
     return 0;
 }
 
@@ -131,6 +134,9 @@ int main(int argc, char** argv)
 
     const size_t nsamp = (size_t)((iters + 8) * launches / step + 2);
     State sa, sb;
+#if defined(SPF_TEAM_TRACE) || defined(SPF_TEAM_STAMPS)
+    g_trace_bytes = (size_t)(iters + launches + 8) * 64 + 4096;
+#endif
     if (alloc_state(sa, W, N, K, nsamp) || alloc_state(sb, W, N, K, nsamp)) return 1;
     std::vector<unsigned long long> hs((size_t)W * N);
     for (auto& v : hs) v = ((unsigned long long)lrand48() << 42) ^ ((unsigned long long)lrand48() << 21) ^ (unsigned long long)lrand48();
@@ -214,7 +220,7 @@ int main(int argc, char** argv)
         }
 #elif defined(SPF_TEAM_STAMPS)
         {
-            std::vector<unsigned long long> hst(16 * 8);
+            std::vector<unsigned long long> hst(32 * 8);
             CK(hipMemcpy(hst.data(), sb.Es, sizeof(unsigned long long) * hst.size(), hipMemcpyDeviceToHost));
             const char* nm[5] = {"prep", "dep/slot wait", "loads+decide", "update", "store ack+report"};
             printf("  retire: %llu looks at the flags, %llu found nothing, %llu cycles: flag checks (idle) %llu, flag checks (productive) %llu, data reads %llu, processing %llu\n", hst[(NW - 1) * 8], hst[(NW - 1) * 8 + 1], hst[(NW - 1) * 8 + 2], hst[(NW - 1) * 8 + 3], hst[(NW - 1) * 8 + 4], hst[(NW - 1) * 8 + 5], hst[(NW - 1) * 8 + 6]);
@@ -222,6 +228,9 @@ int main(int argc, char** argv)
                 printf("  wave %d (%llu attempts), cycles per attempt:", xw, hst[xw * 8 + 5]);
                 for (int q = 0; q < 5; ++q) printf("  %s %.1f", nm[q], (double)hst[xw * 8 + q] / (double)hst[xw * 8 + 5]);
                 printf("\n");
+                const unsigned long long* g = &hst[(NW + xw) * 8];
+                printf("    gate waits: window %llu (%.0f cycles each), conflict %llu (%.0f each); slot waits %llu (%.0f each)\n", g[0], g[0] ? (double)g[1] / g[0] : 0.0,
+                       g[2], g[2] ? (double)g[3] / g[2] : 0.0, g[4], g[4] ? (double)g[5] / g[4] : 0.0);
             }
         }
 #else
