@@ -82,6 +82,12 @@ namespace rrrmc {
 #ifndef SPF_TEAM_BATCH
 #define SPF_TEAM_BATCH 4
 #endif
+#ifndef SPF_TEAM_AGE1
+#define SPF_TEAM_AGE1 24
+#endif
+#ifndef SPF_TEAM_AGE2
+#define SPF_TEAM_AGE2 44
+#endif
 #ifndef SPF_TEAM_SCOPE
 #define SPF_TEAM_SCOPE "workgroup"
 #endif
@@ -666,6 +672,16 @@ __global__ __launch_bounds__(NW * 64) SPF_TEAM_OCC void spf_team_kernel(SpfTeamP
                 // and the records.  What differs per attempt (site, neighbours, couplings, slot, random number) is selected per lane.
                 gate(eA);
                 gate(eB);
+#ifndef SPF_TEAM_NO_AGEPRIO
+                // oldest attempt first: a SIMD's arbiter prefers its older wavefronts, so the younger ones (higher index) fall behind and the whole
+                // team then waits for them at the window; the pair that is closest to the retired prefix takes the higher priority instead
+                {
+                    const int32_t lag = itv[0] - pfx[0];
+                    if (lag < SPF_TEAM_AGE1) __builtin_amdgcn_s_setprio(2);
+                    else if (lag < SPF_TEAM_AGE2) __builtin_amdgcn_s_setprio(1);
+                    else __builtin_amdgcn_s_setprio(0);
+                }
+#endif
                 const bool hi = lane >= 32;
                 const bool fact = (lane & 31) < TW;
                 const int32_t itL = hi ? itv[1] : itv[0];

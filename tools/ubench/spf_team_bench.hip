@@ -224,7 +224,7 @@ int main(int argc, char** argv)
             CK(hipMemcpy(hst.data(), sb.Es, sizeof(unsigned long long) * hst.size(), hipMemcpyDeviceToHost));
             const char* nm[5] = {"prep", "dep/slot wait", "loads+decide", "update", "store ack+report"};
             printf("  retire: %llu looks at the flags, %llu found nothing, %llu cycles: flag checks (idle) %llu, flag checks (productive) %llu, data reads %llu, processing %llu\n", hst[(NW - 1) * 8], hst[(NW - 1) * 8 + 1], hst[(NW - 1) * 8 + 2], hst[(NW - 1) * 8 + 3], hst[(NW - 1) * 8 + 4], hst[(NW - 1) * 8 + 5], hst[(NW - 1) * 8 + 6]);
-            for (int xw = 0; xw < NW - 1; xw += (NW - 2)) {
+            for (int xw = 0; xw < NW - 1; xw += (getenv("SPF_ALL_WAVES") ? 1 : NW - 2)) {
                 printf("  wave %d (%llu attempts), cycles per attempt:", xw, hst[xw * 8 + 5]);
                 for (int q = 0; q < 5; ++q) printf("  %s %.1f", nm[q], (double)hst[xw * 8 + q] / (double)hst[xw * 8 + 5]);
                 printf("\n");
