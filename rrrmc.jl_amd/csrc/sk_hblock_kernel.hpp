@@ -64,6 +64,13 @@ __global__ __launch_bounds__(NTH, RB == 4 ? 2 : 1) void sk_hblock_kernel(SkBlock
     constexpr int NIT = kSkW / (2 * PF);                   // iterations of the apply loop
     constexpr int JPI = NJW >= NIT ? NJW / NIT : 1;        // doubles staged per iteration, in the first NJW / JPI iterations
     static_assert(JPI * NIT == NJW || (JPI == 1 && NJW < NIT), "sub-matrix slices");
+    // Wave priorities (whole-group builds: two wavefronts per SIMD, w and w + 4).  A SIMD's arbiter prefers its OLDER wavefront, which then finishes
+    // a phase a quarter earlier and waits at the barrier for the younger one (profiles/r05/c3_block_budget.md: decide 9.8 K against 12.3 K cycles,
+    // apply 15.2 K against 19.7 K).  Decide: the younger one goes first.  Apply: the two take turns, sixteen attempts at a time (up to four sites
+    // per thread: -7 % of the launch at N = 1024 and 2048); with eight sites per thread the younger one first throughout (-14 % at N = 4096); with six
+    // neither helps (measured: tools/ubench/run_skh.sh, profiles/r05/sk_priorities.txt).
+    constexpr int PRIO_APPLY = RB != 8 ? 0 : SPT <= 4 ? 16 : SPT == 8 ? 1 : 0;
+    constexpr bool PRIO_DECIDE = RB == 8 && SPT != 6;
     __shared__ double sh_Jw[2][kSkW * kSkW];               // the block's 64 x 64 coupling sub-matrix, double-buffered: the next block's is staged during apply
     __shared__ double sh_wf[kSkW][RB], sh_wfl[kSkW][RB];
     // acceptance uniforms and their logarithms.  Whole-group build: double-buffered, the next block's are drawn by every wavefront behind its
@@ -249,6 +256,7 @@ __global__ __launch_bounds__(NTH, RB == 4 ? 2 : 1) void sk_hblock_kernel(SkBlock
                 int ks = sample_rel();
                 auto xof = [&](double fv) -> double { if constexpr (BIN) return -P.beta * (fv / P.sN); else return -P.beta * fv; };
                 unsigned long long B = verdict(xof(f));
+                if constexpr (PRIO_DECIDE) { if (wv >= NWV / 2) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
                 while (B) {
                     const int k = __builtin_ctzll(B);
                     while (__builtin_expect(k >= ks, 0)) {              // sample BEFORE the move (RRRMC.jl:104-108)
@@ -368,6 +376,11 @@ __global__ __launch_bounds__(NTH, RB == 4 ? 2 : 1) void sk_hblock_kernel(SkBlock
 #pragma unroll
         for (int e = 0; e < JPI; ++e) jw_reg[e] = jw_src[e * NTH];
         for (int kb = 0; kb < kSkW; kb += 16) {
+            if constexpr (PRIO_APPLY == 1) {
+                if (wv >= NWV / 2) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
+            } else if constexpr (PRIO_APPLY > 1) {
+                if ((((uint32_t)kb / PRIO_APPLY) ^ (uint32_t)(wv >= NWV / 2)) & 1u) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
+            }
             double mv[RB];
 #pragma unroll
             for (int r = 0; r < RB; ++r) mv[r] = sh_mult[kb + (lane & 15)][r];
