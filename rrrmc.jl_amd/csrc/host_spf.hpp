@@ -91,7 +91,8 @@ inline SpfTeamBuild spf_team_build(const rrrmc_ctx* ctx)
 // wavefront per group) stays as the cross-check of the tests (RRRMC_SPF_TEAM=0).
 inline bool spf_use_team(const rrrmc_ctx* ctx)
 {
-    (void)ctx;
+    // the fused pairs address a team's field lines with 32-bit byte offsets (site * 512 + lane * 8): beyond 2^23 sites the one-wavefront kernel runs
+    if (ctx->N >= (int64_t)1 << 23) return false;
     const char* e = std::getenv("RRRMC_SPF_TEAM");
     return !(e && e[0] == '0');
 }

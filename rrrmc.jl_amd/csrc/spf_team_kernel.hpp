@@ -700,7 +700,7 @@ __global__ __launch_bounds__(NW * 64) SPF_TEAM_OCC void spf_team_kernel(SpfTeamP
                     yL[k] = field(4 + k);
                     JL[k] = __longlong_as_double((long long)(((unsigned long long)field(4 + K + 2 * k + 1) << 32) | field(4 + K + 2 * k)));
                 }
-                // 32-bit offsets from the team's wave-uniform bases (N <= 2^20 sites of 512 bytes)
+                // 32-bit offsets from the team's wave-uniform bases (N < 2^23 sites of 512 bytes: host_spf.hpp, spf_use_team)
                 auto LF = [&](uint32_t site_) -> double* { return reinterpret_cast<double*>(lfb + (site_ * 512u + dl8)); };
                 auto SP = [&](uint32_t site_) -> word_t* { return reinterpret_cast<word_t*>(spb + site_ * 8u); };
 #ifdef SPF_TEAM_EXP_NOMEM
