@@ -317,7 +317,7 @@ def test_sk_threads_override_never_leaves_a_model_without_a_kernel(pkg, monkeypa
         assert (u == v).all()
 
 
-@pytest.mark.parametrize("binary,N", [(False, 3000), (False, 4096), (True, 2500)])
+@pytest.mark.parametrize("binary,N", [(False, 3000), (False, 3585), (False, 4096), (True, 2500)])
 def test_dense_sk_beyond_2048_sites(pkg, oracle, binary, N):
     """src/graphs/SK.jl:181-210 has no size limit; round 3 stopped at N = 2048 (eight sites per thread of the one-attempt-at-a-time kernels).
     sk_hblock_kernel<6 | 8, 512, 8> covers N <= 4096: same chain as the oracle, both models, a call that crosses no seam and one that does."""
