@@ -74,6 +74,7 @@ struct rrrmc_ctx {
     int64_t* d_acc = nullptr;      // [Rpad]
     // plan buffers
     ChunkDesc* d_chunks = nullptr;
+    ChunkDesc* d_chunks_alt = nullptr;   // a second copy of the table: the planner fills in per-chunk fields, and the planner of a call runs beside the previous call's sweeps
     size_t chunks_cap = 0;
     ChunkDesc* h_chunks = nullptr; // pinned staging buffer of the chunk list
     size_t h_chunks_cap = 0;
@@ -99,6 +100,12 @@ struct rrrmc_ctx {
     hipStream_t plan_stream = nullptr;
     hipEvent_t ev_upload = nullptr;
     std::vector<hipEvent_t> ev_plan;     // plan of batch b finished
+    // the two sets of plan buffers across calls: the set a call's first batch takes alternates, and a set is written again only behind the
+    // sweep that read it last — so the planner of a call's first batch runs beside the previous call's last sweep
+    hipEvent_t ev_set_free[2] = {nullptr, nullptr};
+    bool set_used[2] = {false, false};
+    int plan_parity = 0;
+    int call_parity = 0;
     // staging of the caller-layout transfers: BitVector chunks (rrrmc_set_spins / rrrmc_get_spins / rrrmc_snapshot_get) and the
     // replica-major energy samples (rrrmc_fetch_results); kept across calls, grown on demand
     unsigned long long* d_io = nullptr;
@@ -517,8 +524,10 @@ int32_t prepare_chunk_list(rrrmc_ctx* ctx, int64_t iters, int64_t step, int C, b
             HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
             HIP_TRY(ctx, hipStreamSynchronize(ctx->plan_stream));
             free_dev(ctx->d_chunks);
+            free_dev(ctx->d_chunks_alt);
             ctx->chunks_cap = 0;
             HIP_TRY(ctx, hipMalloc(&ctx->d_chunks, sizeof(ChunkDesc) * nch_all));
+            HIP_TRY(ctx, hipMalloc(&ctx->d_chunks_alt, sizeof(ChunkDesc) * nch_all));
             ctx->chunks_cap = nch_all;
         }
         if (nch_all > ctx->h_chunks_cap) {
@@ -791,7 +800,7 @@ void rrrmc_ctx_destroy(rrrmc_ctx* ctx)
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     free_dev(ctx->d_A); free_dev(ctx->d_J); free_dev(ctx->d_table); free_dev(ctx->d_spins);
-    free_dev(ctx->d_E); free_dev(ctx->d_acc); free_dev(ctx->d_chunks); free_dev(ctx->d_Es);
+    free_dev(ctx->d_E); free_dev(ctx->d_acc); free_dev(ctx->d_chunks); free_dev(ctx->d_chunks_alt); free_dev(ctx->d_Es);
     free_dev(ctx->d_U); free_dev(ctx->d_io);
     for (uint32_t*& l : ctx->d_color_list) free_dev(l);
     free_dev(ctx->sk_J4); free_dev(ctx->sk_blkJw); free_dev(ctx->sk_blkSites); free_dev(ctx->sk_hl);
@@ -815,6 +824,7 @@ void rrrmc_ctx_destroy(rrrmc_ctx* ctx)
     if (ctx->plan_stream) { (void)hipStreamSynchronize(ctx->plan_stream); (void)hipStreamDestroy(ctx->plan_stream); }
     if (ctx->ev_upload) (void)hipEventDestroy(ctx->ev_upload);
     for (hipEvent_t e : ctx->ev_plan) (void)hipEventDestroy(e);
+    for (int i = 0; i < 2; ++i) if (ctx->ev_set_free[i]) (void)hipEventDestroy(ctx->ev_set_free[i]);
     if (ctx->h_chunks) (void)hipHostFree(ctx->h_chunks);
     for (hipEvent_t e : ctx->ev_pool) (void)hipEventDestroy(e);
     for (hipEvent_t e : ctx->ev_sweep) (void)hipEventDestroy(e);
@@ -1186,12 +1196,21 @@ int32_t rrrmc_standard_mc_async(rrrmc_ctx* ctx, double beta, int64_t iters, int6
     HIP_TRY(ctx, hipMemsetAsync(ctx->d_acc, 0, sizeof(int64_t) * ctx->Rpad, st));
     if (!reuse) {
         if (nchunks) HIP_TRY(ctx, hipMemcpyAsync(ctx->d_chunks, ctx->h_chunks, sizeof(ChunkDesc) * nchunks, hipMemcpyHostToDevice, st));
+        if (nchunks) HIP_TRY(ctx, hipMemcpyAsync(ctx->d_chunks_alt, ctx->h_chunks, sizeof(ChunkDesc) * nchunks, hipMemcpyHostToDevice, st));
         ctx->chunks_iters = iters; ctx->chunks_step = step; ctx->chunks_C = C;
         ctx->upload_pending = true;
     }
-    // recorded in every call: orders this call's planner behind the previous call's sweeps (they read nvec / the plan buffers)
+    // a new chunk table orders this call's planner behind its upload (and with it behind every earlier sweep); with the table of the previous call
+    // the planner only waits for the sweep that last read the buffer set it is about to write (launch_plan)
     HIP_TRY(ctx, hipEventRecord(ctx->ev_upload, st));
-    HIP_TRY(ctx, hipStreamWaitEvent(ctx->plan_stream, ctx->ev_upload, 0));
+    if (!reuse) HIP_TRY(ctx, hipStreamWaitEvent(ctx->plan_stream, ctx->ev_upload, 0));
+    for (int i = 0; i < 2; ++i)
+        if (!ctx->ev_set_free[i]) HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_set_free[i], hipEventDisableTiming));
+    const int par = ctx->plan_parity;
+    auto set_of = [par](int b) -> int { return (b + par) & 1; };
+    // the chunk table of this call (the planner writes the chunks' level counts into it; the previous call's sweeps still read the other copy; the
+    // call before that has finished before this call's first planner starts: it waits for a sweep of the previous call or for that call's own)
+    ChunkDesc* const d_chunks = (ctx->call_parity ^= 1) ? ctx->d_chunks_alt : ctx->d_chunks;
 
     P.spins = ctx->d_spins;
     P.table = ctx->d_table;
@@ -1222,25 +1241,26 @@ int32_t rrrmc_standard_mc_async(rrrmc_ctx* ctx, double beta, int64_t iters, int6
     if (!g_stamps) HIP_TRY(ctx, hipMalloc(&g_stamps, sizeof(unsigned long long) * 16 * (65536 + 4096)));
     P.stamps = g_stamps;
 #endif
-    // The site-stream planner runs on its own stream, one batch ahead of the sweep: plan(b) may start as soon as
-    // sweep(b-2) has released the plan buffer set b & 1; sweep(b) waits for plan(b).
+    // The site-stream planner runs on its own stream, one batch ahead of the sweep: plan(b) may start as soon as the sweep that last read its
+    // buffer set (sweep(b-2), or a sweep of the previous call) has finished; sweep(b) waits for plan(b).
     const int nb = (int)batches.size();
     auto launch_plan = [&](int b) -> int32_t {
         const rrrmc_ctx::BatchDesc& bt = batches[b];
-        if (b >= 2) HIP_TRY(ctx, hipStreamWaitEvent(ctx->plan_stream, EV[ebase + 2 * (b - 2) + 1], 0));
+        const int set = set_of(b);
+        if (ctx->set_used[set]) HIP_TRY(ctx, hipStreamWaitEvent(ctx->plan_stream, ctx->ev_set_free[set], 0));
         if (ctx->big_mode) {
             hipLaunchKernelGGL(plan_big_for_K((int)K), dim3((unsigned)bt.n), dim3(kPlanThreads), ctx->plan_lds_bytes, ctx->plan_stream,
-                               ctx->d_chunks + bt.first, ctx->d_slots[b & 1], ctx->d_nbrs[b & 1], ctx->d_vecs[b & 1], ctx->d_A, ctx->d_J, (int)N, P.k0, P.k1, P.gbase,
+                               d_chunks + bt.first, ctx->d_slots[set], ctx->d_nbrs[set], ctx->d_vecs[set], ctx->d_A, ctx->d_J, (int)N, P.k0, P.k1, P.gbase,
                                ctx->big_masks ? ctx->big_lgr : -1);
             if (ctx->big_masks) {
-                PM.chunks = ctx->d_chunks + bt.first; PM.slots = ctx->d_slots[b & 1]; PM.masks = ctx->d_masks[b & 1];
+                PM.chunks = d_chunks + bt.first; PM.slots = ctx->d_slots[set]; PM.masks = ctx->d_masks[set];
                 hipLaunchKernelGGL(big_mask_for_K((int)K), dim3((unsigned)(bt.n * (kBigChunk / kBigMaskThreads)), (unsigned)ctx->G), dim3(kBigMaskThreads), 0,
                                    ctx->plan_stream, PM);
             }
         }
         else
             hipLaunchKernelGGL(plan_for_K((int)K), dim3((unsigned)bt.n), dim3(kPlanThreads), ctx->plan_lds_bytes, ctx->plan_stream,
-                               ctx->d_chunks + bt.first, ctx->d_slots[b & 1], ctx->d_vecs[b & 1], ctx->d_A, (int)N, C, P.k0, P.k1, P.gbase,
+                               d_chunks + bt.first, ctx->d_slots[set], ctx->d_vecs[set], ctx->d_A, (int)N, C, P.k0, P.k1, P.gbase,
                                sweep_rows_for_K((int)K) * kWave);
         HIP_TRY(ctx, hipGetLastError());
         HIP_TRY(ctx, hipEventRecord(ctx->ev_plan[b], ctx->plan_stream));
@@ -1250,18 +1270,19 @@ int32_t rrrmc_standard_mc_async(rrrmc_ctx* ctx, double beta, int64_t iters, int6
     for (int b = 0; b < nb; ++b) {
         const rrrmc_ctx::BatchDesc& bt = batches[b];
         HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->ev_plan[b], 0));
-        P.chunks = ctx->d_chunks + bt.first;
+        P.chunks = d_chunks + bt.first;
         P.nchunks = (int)bt.n;
         P.sample0 = bt.sample0;
-        P.slots = ctx->d_slots[b & 1];
-        P.vecs = ctx->d_vecs[b & 1];
+        const int set = set_of(b);
+        P.slots = ctx->d_slots[set];
+        P.vecs = ctx->d_vecs[set];
         HIP_TRY(ctx, hipEventRecord(EV[ebase + 2 * b], st));
         if (ctx->big_mode) {
-            PB.chunks = P.chunks; PB.nchunks = P.nchunks; PB.sample0 = P.sample0; PB.slots = P.slots; PB.nbrs = ctx->d_nbrs[b & 1]; PB.vecs = P.vecs;
+            PB.chunks = P.chunks; PB.nchunks = P.nchunks; PB.sample0 = P.sample0; PB.slots = P.slots; PB.nbrs = ctx->d_nbrs[set]; PB.vecs = P.vecs;
             if (ctx->big_masks) {
                 const int S = 32 >> ctx->big_lgr;
                 hipLaunchKernelGGL(ctx->big_cm ? big_applyc_for_K((int)K) : big_apply_for_K((int)K), dim3((unsigned)(ctx->G * S)), dim3(kBigApplyThreads), big_lds_bytes(N, ctx->big_lgr), st, PB,
-                                   ctx->d_masks[b & 1], ctx->d_bigimg, (uint32_t)ctx->batch_slots_max, ctx->big_lgr);
+                                   ctx->d_masks[set], ctx->d_bigimg, (uint32_t)ctx->batch_slots_max, ctx->big_lgr);
                 hipLaunchKernelGGL(big_merge_kernel, dim3((unsigned)((N + 255) / 256), (unsigned)ctx->G), dim3(256), 0, st, ctx->d_spins, ctx->d_bigimg,
                                    (int)N, ctx->big_lgr);
             }
@@ -1272,11 +1293,14 @@ int32_t rrrmc_standard_mc_async(rrrmc_ctx* ctx, double beta, int64_t iters, int6
         }
         HIP_TRY(ctx, hipGetLastError());
         HIP_TRY(ctx, hipEventRecord(EV[ebase + 2 * b + 1], st));
+        HIP_TRY(ctx, hipEventRecord(ctx->ev_set_free[set], st));
+        ctx->set_used[set] = true;
         // the next plan is enqueued AFTER this sweep so that the sweep's workgroups (one per CU, most of the LDS)
         // are placed first and the planner's small workgroups fill in beside them
         if (b + 1 < nb) { rc = launch_plan(b + 1); if (rc) return rc; }
     }
     HIP_TRY(ctx, hipEventRecord(ctx->ev_end, st));
+    ctx->plan_parity = (par + nb) & 1;
     ctx->sweep_launches = (int)batches.size();
     ctx->last_ev_base = ebase;
     ctx->last_ev_pool = ctx->acc_mode;

@@ -256,3 +256,35 @@ def test_result_arrays_of_the_caller_must_be_contiguous_and_writeable(pkg):
         ok = np.zeros((64, 8), np.int64)
         Es, a = eng.standard_mc(1.0, 800, 100, out=(ok[:32], acc))
         assert Es.shape == (32, 8) and (ok[32:] == 0).all() and a.sum() > 0
+
+
+@pytest.mark.parametrize("N,K,R,iters,step", [(4096, 3, 1024, 1 << 16, 4096), (4096, 3, 96, (1 << 17) + 77, 1000), (216, 6, 64, 50000, 777)])
+def test_queued_calls_of_one_shape_equal_calls_made_one_by_one(pkg, oracle, N, K, R, iters, step):
+    """Back-to-back asynchronous calls of the same (iters, step): the chunk table stays on the device and the planner of call s + 1 runs beside
+    the sweep of call s (its own stream, its own copy of the table and the other set of plan buffers: the planner writes per-chunk level counts
+    that the running sweep reads).  Five queued calls must leave exactly what five calls with a sync between them leave, and the last call's
+    samples are the oracle's for that piece of the chain."""
+    seed, beta, calls = 424242 + N + K, 0.8, 5
+    X = pkg.GraphRRG(N, K, seed=seed) if K == 3 else pkg.GraphEA(6, 3, seed=seed)
+    outs = []
+    for queued in (True, False):
+        with pkg.Engine(X, R) as eng:
+            eng.seed(seed)
+            eng.init_spins_random()
+            C0 = eng.get_config().s.copy()
+            before_last = None
+            for c in range(calls):
+                if c == calls - 1 and not queued:
+                    before_last = eng.get_config().s.copy()
+                eng.standard_mc_async(beta, iters, step)
+                if not queued:
+                    eng.sync()
+            eng.sync()
+            Es, acc = eng.fetch_results()
+            outs.append((C0, Es, acc, eng.get_config().s.copy(), before_last))
+    for u, v in zip(outs[0][:4], outs[1][:4]):
+        assert (u == v).all()
+    C_before = outs[1][4]
+    for r in (0, R // 2, R - 1):
+        ref = oracle.standard_mc_sparse(X.A, X.J.astype(np.int32), beta, iters, step, seed, C_before[r], replica=r, it0=(calls - 1) * iters, form="rrg" if K == 3 else "ea")
+        assert (outs[0][1][r] == ref[0]).all() and (outs[0][3][r] == ref[1]).all() and outs[0][2][r] == ref[2]
