@@ -288,3 +288,27 @@ def test_queued_calls_of_one_shape_equal_calls_made_one_by_one(pkg, oracle, N, K
     for r in (0, R // 2, R - 1):
         ref = oracle.standard_mc_sparse(X.A, X.J.astype(np.int32), beta, iters, step, seed, C_before[r], replica=r, it0=(calls - 1) * iters, form="rrg" if K == 3 else "ea")
         assert (outs[0][1][r] == ref[0]).all() and (outs[0][3][r] == ref[1]).all() and outs[0][2][r] == ref[2]
+
+
+def test_queued_calls_of_alternating_shapes(pkg, oracle):
+    """Queued calls whose (iters, step) changes now and then: a new shape uploads both copies of the chunk table behind everything queued so far and
+    its planner waits for that upload; calls that repeat the previous shape overlap their planner with the previous sweep again.  Queued and
+    synchronised runs must agree after every pattern, several plan batches per call included."""
+    seed, beta, R, N = 777001, 0.7, 256, 4096
+    X = pkg.GraphRRG(N, 3, seed=seed)
+    A_, B_, C_ = (40000, 1000), (1 << 18, 1 << 14), (123457, 99)
+    pattern = [A_, A_, B_, B_, B_, A_, C_, C_, A_, A_, A_, B_]
+    outs = []
+    for queued in (True, False):
+        with pkg.Engine(X, R) as eng:
+            eng.seed(seed)
+            eng.init_spins_random()
+            for iters, step in pattern:
+                eng.standard_mc_async(beta, iters, step)
+                if not queued:
+                    eng.sync()
+            eng.sync()
+            Es, acc = eng.fetch_results()
+            outs.append((Es, acc, eng.get_config().s.copy(), eng.energy()))
+    for u, v in zip(outs[0], outs[1]):
+        assert (u == v).all()
