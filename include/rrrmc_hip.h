@@ -251,7 +251,8 @@ RRRMC_API int32_t rrrmc_extremal_opt_results(rrrmc_ctx *ctx, int64_t *Emin_out, 
  * rrrmc_fetch_results_f64, and rrrmc_extremal_opt_results_f64 for (Emin, Cmin, itmin). */
 RRRMC_API int32_t rrrmc_extremal_opt_results_f64(rrrmc_ctx *ctx, double *Emin_out, uint64_t *Cmin_chunks, int64_t *itmin_out);
 /* parity/debug view of the move-selection cache after the last rrrMC call: pos_out[R * N] = class of every spin
- * (DeltaECache.pos, 0-based a + 2*up), sizes_out[R * 4] = |class k| (DeltaE.jl:63-73). */
+ * (DeltaECache.pos, 0-based a + 2*up), sizes_out[R * 4] = |class k| (DeltaE.jl:63-73).  RRRMC_MODEL_SPARSE_PM1 / _LEVELS (rrrMC and
+ * bklMC; class a + L*up) and RRRMC_MODEL_SPARSE_DISCRETIZED: sizes_out[R * 16], class k of replica r at 16 r + k. */
 RRRMC_API int32_t rrrmc_rrr_cache(rrrmc_ctx *ctx, int8_t *pos_out, int32_t *sizes_out);
 
 /* Opt-in FAST standardMC for RRRMC_MODEL_SPARSE_F64 (GraphRRGNormal / GraphEANormal, K <= 4, N <= 8192): replicas bit-sliced and
@@ -271,6 +272,28 @@ RRRMC_API int32_t rrrmc_standard_mc_fast_async(rrrmc_ctx *ctx, double beta, int6
  * from it — tracked energy, local fields, undo record, move_last — so that a run cut into pieces at the hook points is bit for bit the
  * run made in one call.  rrrmc_tracked_energy_f64 reads that tracked energy (what the reference hands to its hook), R doubles. */
 RRRMC_API int32_t rrrmc_set_resume(rrrmc_ctx *ctx, int32_t on);
+/* Resumed rrrMC / bklMC / wtmMC / extremal_opt calls — the hook of every sampler (src/RRRMC.jl:152,186 · :224,255 · :314,341 · :379,404 · :477,501).
+ * A reference call keeps its whole chain in local variables from the first to the last iteration, hook calls included: the move-selection
+ * cache (DeltaECache: the ArraySets in member order, T, z — src/DeltaE.jl:63-73; DeltaECacheCont: the DynamicSampler's tree and its refresh
+ * countdown — src/DynamicSamplers.jl:18-33; THeap and the global time — src/WaitingTimes.jl; EOCache / EOCacheCont: the ranking), the graph's
+ * own cache, the tracked E, the acc_rate average of rrrMC, `it` / `nextstep` of bklMC, Emin / Cmin / itmin of extremal_opt.  With
+ * rrrmc_set_resume(ctx, 1), a call of one of these samplers that finds the RUN left by a previous call of the SAME sampler with the SAME
+ * parameters (beta, fourK, staged_thr, staged_thr_fact; bklMC: step; wtmMC: step; extremal_opt: ftau) — and nothing in between that changes
+ * the configuration, the disorder, the seed or the caches (rrrmc_set_spins, rrrmc_init_spins_random, rrrmc_seed, rrrmc_set_graph*,
+ * rrrmc_energy*, rrrmc_get_fields, any other sampler) — CONTINUES that run instead of starting one (energy(X, C) + a fresh cache):
+ *   - the run's iteration counter carries on: samples are taken before the iterations that are multiples of `step` of the RUN's count
+ *     (a first call of step - 1 iterations takes none; the next call of `step` iterations takes one before its first move), extremal_opt's
+ *     itmin counts from the start of the run;
+ *   - bklMC: `iters` more iterations are allowed; `it`, `nextstep` and the pending (skip, move) draw carry on — a call of `step` iterations
+ *     ends at the next sample point, with the configuration, E and accepted count the reference hands to its hook there (:336-341);
+ *   - wtmMC: `samples` more samples; the heap, the global time and `nextstep` carry on (:399-404);
+ *   - rrrmc_fetch_results* / rrrmc_rrr_stats return the samples and the accepted / staged counts of the CALL.
+ * A run cut into calls anywhere is bit for bit the run made in one call — energies, configurations, counts and the cache — through every
+ * kernel build (the LDS-resident ones write their state back at the end of a call and read it at the start of the next).
+ * rrrmc_tracked_energy / _f64 read the tracked E without disturbing the run; rrrmc_get_spins, rrrmc_rrr_cache, rrrmc_wtm_times,
+ * rrrmc_extremal_opt_results*, the snapshot and observable calls do not disturb it either.
+ * rrrmc_tracked_energy: the integer models' tracked energy (level units), R values. */
+RRRMC_API int32_t rrrmc_tracked_energy(rrrmc_ctx *ctx, int64_t *E_out);
 /* Debug mode: the reference's latent consistency checks as a switch a user can turn on (its commented-out asserts in update_cache!,
  * src/graphs/RRG.jl:229-231, SK.jl:125-130, 268-273, and its test suite's hook, test/runtests.jl:12-20).  on != 0: after EVERY standardMC
  * call the library recomputes energy(X, C) of every replica from the configuration on the device and compares it with the energy the
@@ -292,6 +315,9 @@ RRRMC_API int32_t rrrmc_last_timing(rrrmc_ctx *ctx, double *total_ms, double *sw
 RRRMC_API int32_t rrrmc_timing_accumulate(rrrmc_ctx *ctx, int32_t on);
 RRRMC_API int32_t rrrmc_timing_total(rrrmc_ctx *ctx, double *sweep_ms, int64_t *sweep_launches);
 
+/* Samples per replica the last sampling call took: the row length of rrrmc_fetch_results*' Es_out.  iters / step for a call that starts a
+ * run; a RESUMED call takes a sample before every iteration that is a multiple of `step` of the run's count (see rrrmc_set_resume). */
+RRRMC_API int64_t rrrmc_results_samples(const rrrmc_ctx *ctx);
 /* Iterations consumed from the current seed's streams so far. */
 RRRMC_API int64_t rrrmc_iterations_done(const rrrmc_ctx *ctx);
 

@@ -76,6 +76,8 @@ def _lib_locked():
             flavour = "native" if "_native_" in os.path.basename(so) else flavour
         L = C.CDLL(so)
         L.orc_philox.argtypes = [u32p, u32p, u32p]
+        L.orc_set_hook.restype = None
+        L.orc_set_hook.argtypes = [HOOK_FN, C.c_void_p]
         L.orc_site_of.restype = C.c_int64
         L.orc_site_of.argtypes = [C.c_uint64, C.c_uint64, C.c_int64]
         L.orc_accept_uniform.restype = C.c_uint64
@@ -142,6 +144,32 @@ def _lib_locked():
 
 
 # ------------------------------------------------------------------------------------------------
+HOOK_FN = C.CFUNCTYPE(C.c_int, C.c_double, C.POINTER(C.c_uint64), C.c_int64, C.c_int64, C.c_double, C.c_double, C.c_void_p)
+
+
+class hooked:
+    """``with hooked(fn) as calls:`` — every sampler of the oracle called inside the block calls ``fn(it, chunks, accepted, E, Emin) -> bool``
+    at its samples, where the reference calls its ``hook`` (src/RRRMC.jl:107,187,256,341,404,501); False ends the chain there.  ``fn=None``
+    records only.  ``calls`` collects ``(it, chunks.copy(), accepted, E, Emin)`` of every hook call of the thread."""
+
+    def __init__(self, fn=None):
+        self.fn, self.calls = fn, []
+
+        def cb(it, chunks, nch, accepted, E, Emin, _user):
+            ch = np.ctypeslib.as_array(chunks, shape=(nch,)).copy()
+            self.calls.append((it, ch, int(accepted), E, Emin))
+            return 1 if (self.fn is None or self.fn(it, ch, int(accepted), E, Emin)) else 0
+
+        self._cb = HOOK_FN(cb)          # keep the trampoline alive for the duration of the block
+
+    def __enter__(self):
+        lib().orc_set_hook(self._cb, None)
+        return self.calls
+
+    def __exit__(self, *a):
+        lib().orc_set_hook(C.cast(None, HOOK_FN), None)
+
+
 def philox(ctr, key):
     out = np.zeros(4, np.uint32)
     lib().orc_philox(np.asarray(ctr, np.uint32), np.asarray(key, np.uint32), out)

@@ -40,6 +40,19 @@ ORC_API void orc_init_config(uint64_t seed, uint32_t replica, int64_t N, uint64_
         if (orc_init_spin(seed, replica, (uint64_t)x)) chunks[x >> 6] |= 1ull << (x & 63);
 }
 
+/* ---------------------------------------------------------------------------------------------
+ * Hooks.  Every sampler of the reference calls `hook(it, X, C, accepted, E)` at each sample and ends the chain when it returns false
+ * (src/RRRMC.jl:104-108 standardMC, :184-188 and :253-257 rrrMC, :339-343 bklMC with `nextstep`, :402-406 wtmMC with the sample's
+ * global time and num_moves, :499-503 extremal_opt with (it, X, C, E, Emin)).  The restatement does the same, inside its loops: a test
+ * registers a callback and sees, at every sample, the iteration (or sample time), the configuration, the count and the energy — what the
+ * HIP library must hand to ITS hooks from a run cut into resumed calls.  No callback: the samplers run to the end as before.
+ * ------------------------------------------------------------------------------------------- */
+typedef int (*orc_hook_fn)(double it, const uint64_t *chunks, int64_t nchunks, int64_t accepted, double E, double Emin, void *user);
+static __thread orc_hook_fn g_hook = 0;
+static __thread void *g_hook_user = 0;
+ORC_API void orc_set_hook(orc_hook_fn f, void *user) { g_hook = f; g_hook_user = user; }
+#define ORC_HOOK(it, acc, E, Emin) (g_hook ? g_hook((double)(it), chunks, (N + 63) / 64, (int64_t)(acc), (double)(E), (double)(Emin), g_hook_user) : 1)
+
 static inline int spin_bit(const uint64_t *chunks, int64_t x) { return (int)((chunks[x >> 6] >> (x & 63)) & 1u); }
 /* unsafe_bitflip!: src/Common.jl:15-23 */
 static inline void bitflip(uint64_t *chunks, int64_t x) { chunks[x >> 6] ^= 1ull << (x & 63); }
@@ -1057,7 +1070,7 @@ static int64_t orc_rrr_mc_quant_impl(quant_t *Q,
     int64_t staged_its = 0, accepted = 0, nsamp = 0;
     double acc_rate = 0.5;
     for (int64_t it = 1; it <= iters; ++it) {                               /* :249-282 */
-        if (it % step == 0) Es[nsamp++] = E;
+        if (it % step == 0) { Es[nsamp++] = E; if (!ORC_HOOK(it, accepted, E, 0)) break; }
         const uint64_t g = it0 + (uint64_t)it;
         int acc = 0;
         if (acc_rate < staged_thr) {
@@ -1619,7 +1632,7 @@ static int64_t orc_rrr_mc_skn_impl(skx_t *X, int64_t N, double beta, int64_t ite
     int64_t staged_its = 0, accepted = 0, nsamp = 0, bad = 0;
     double acc_rate = 0.5;
     for (int64_t it = 1; it <= iters && !bad; ++it) {
-        if (it % step == 0) Es[nsamp++] = E;
+        if (it % step == 0) { Es[nsamp++] = E; if (!ORC_HOOK(it, accepted, E, 0)) break; }
         const uint64_t g = it0 + (uint64_t)it;
         uint32_t w[4];
         rrr_draw(seed, g, replica, 0, w);
@@ -1897,7 +1910,7 @@ static int64_t rrr_bkl_sparse_impl(int mode, int form, int64_t N, int64_t K, con
         const double lambda = staged_thr_fact / (double)N;
         double acc_rate = 0.5;
         for (it = 1; it <= iters; ++it) {
-            if (it % step == 0) Es[nsamp++] = E;
+            if (it % step == 0) { Es[nsamp++] = E; if (!ORC_HOOK(it, accepted, E, 0)) break; }
             const uint64_t g = it0 + (uint64_t)it;
             int acc = 0;
             uint32_t w[4];
@@ -1933,7 +1946,7 @@ static int64_t rrr_bkl_sparse_impl(int mode, int form, int64_t N, int64_t K, con
             int64_t dE, move = decs_rand_move(&c, seed, g, replica, &dE);
             int out = 0;
             while (it + skip + 1 >= nextstep) {
-                Es[nsamp++] = E;
+                Es[nsamp++] = E; if (!ORC_HOOK(nextstep, accepted, E, 0)) { out = 1; break; }
                 nextstep += step;
                 if (nextstep > iters) { out = 1; break; }
             }
@@ -2077,7 +2090,7 @@ ORC_API int64_t orc_rrr_double_sparse_scaled(int form, int64_t N, int64_t K, con
     double acc_rate = 0.5;
     int64_t accepted = 0, staged_its = 0, nsamp = 0;
     for (int64_t it = 1; it <= iters; ++it) {
-        if (it % step == 0) Es[nsamp++] = E;
+        if (it % step == 0) { Es[nsamp++] = E; if (!ORC_HOOK(it, accepted, E, 0)) break; }
         const uint64_t g = it0 + (uint64_t)it;
         int acc = 0;
         if (acc_rate < staged_thr) {
@@ -2200,7 +2213,7 @@ ORC_API int64_t orc_wtm_mc_sparse_lev(int form, int64_t N, int64_t K, const int3
         for (int64_t i = 1; i < N; ++i) if (tm[i] < tm[move]) move = i;          /* pick_next: top_with_handle */
         const double tp = tm[move];
         while (tp >= nextstep) {
-            Es[nsamp++] = E;
+            Es[nsamp++] = E; if (!ORC_HOOK(nextstep, num_moves, E, 0)) { out = 1; break; }
             nextstep += step;
             if (nextstep > tmax + 1e-10) { out = 1; break; }
         }
@@ -2282,7 +2295,7 @@ ORC_API int64_t orc_extremal_opt_sparse_lev(int form, int64_t N, int64_t K, cons
     const double z = ftau[N - 1];
     int64_t nsamp = 0;
     for (int64_t it = 1; it <= iters; ++it) {
-        if (it % step == 0) Es[nsamp++] = E;
+        if (it % step == 0) { Es[nsamp++] = E; if (!ORC_HOOK(it, 0, E, Emin)) break; }
         const uint64_t g = it0 + (uint64_t)it;
         uint32_t w[4];
         rrr_draw(seed, g, replica, 3, w);
@@ -2433,7 +2446,7 @@ static int64_t cont_sparse_impl(int mode, int form, int64_t N, int64_t K, const 
             for (int64_t i = 1; i < N; ++i) if (tm[i] < tm[move]) move = i;
             const double tp = tm[move];
             while (tp >= nextstep) {
-                Es[nsamp++] = E;
+                Es[nsamp++] = E; if (!ORC_HOOK(nextstep, accepted, E, 0)) { out = 1; break; }
                 nextstep += st;
                 if (nextstep > tmax + 1e-10) { out = 1; break; }
             }
@@ -2466,7 +2479,7 @@ static int64_t cont_sparse_impl(int mode, int form, int64_t N, int64_t K, const 
             int64_t st_j[SK_MAX + 1];
             double st_dE[SK_MAX + 1], st_p[SK_MAX + 1];
             for (int64_t it = 1; it <= iters && !bad; ++it) {
-                if (it % step == 0) Es[nsamp++] = E;
+                if (it % step == 0) { Es[nsamp++] = E; if (!ORC_HOOK(it, accepted, E, 0)) break; }
                 const uint64_t g = it0 + (uint64_t)it;
                 uint32_t w[4];
                 rrr_draw(seed, g, replica, 0, w);
@@ -2522,7 +2535,7 @@ static int64_t cont_sparse_impl(int mode, int form, int64_t N, int64_t K, const 
                 const double dE = dEs[move];
                 int out = 0;
                 while (it + skip + 1 >= nextstep) {
-                    Es[nsamp++] = E;
+                    Es[nsamp++] = E; if (!ORC_HOOK(nextstep, accepted, E, 0)) { out = 1; break; }
                     nextstep += step;
                     if (nextstep > iters) { out = 1; break; }
                 }
@@ -2636,7 +2649,7 @@ ORC_API int64_t orc_extremal_opt_cont(int form, int64_t N, int64_t K, const int3
     eo_sort(&cmp, rank, tmp, N);                                          /* sortperm(dEs): no shuffle at construction */
     const double z = ftau[N - 1];
     for (int64_t it = 1; it <= iters; ++it) {
-        if (it % step == 0) Es[nsamp++] = E;
+        if (it % step == 0) { Es[nsamp++] = E; if (!ORC_HOOK(it, 0, E, Emin)) break; }
         const uint64_t g = it0 + (uint64_t)it;
         uint32_t w[4];
         rrr_draw(seed, g, replica, 3, w);
@@ -2724,7 +2737,7 @@ static int64_t extremal_opt_quant_impl(quant_t *Qp, int form, int64_t K, const i
     eo_sort(&cmp, rank, tmp, N);
     const double z = ftau[N - 1];
     for (int64_t it = 1; it <= iters; ++it) {
-        if (it % step == 0) Es[nsamp++] = E;
+        if (it % step == 0) { Es[nsamp++] = E; if (!ORC_HOOK(it, 0, E, Emin)) break; }
         const uint64_t g = it0 + (uint64_t)it;
         uint32_t w[4];
         rrr_draw(seed, g, replica, 3, w);
@@ -2779,7 +2792,7 @@ static int64_t extremal_opt_sk_impl(skx_t *X, int64_t N, const double *ftau, int
     eo_sort(&cmp, rank, tmp, N);
     const double z = ftau[N - 1];
     for (int64_t it = 1; it <= iters; ++it) {
-        if (it % step == 0) Es[nsamp++] = E;
+        if (it % step == 0) { Es[nsamp++] = E; if (!ORC_HOOK(it, 0, E, Emin)) break; }
         const uint64_t g = it0 + (uint64_t)it;
         uint32_t w[4];
         rrr_draw(seed, g, replica, 3, w);
@@ -2883,7 +2896,7 @@ static int64_t orc_wtm_mc_skn_impl(skx_t *X, int64_t N, double beta, int64_t sam
         for (int64_t i = 1; i < N; ++i) if (tm[i] < tm[move]) move = i;          /* pick_next: top_with_handle */
         const double tp = tm[move];
         while (tp >= nextstep) {
-            Es[nsamp++] = E;
+            Es[nsamp++] = E; if (!ORC_HOOK(nextstep, num_moves, E, 0)) { out = 1; break; }
             nextstep += step;
             if (nextstep > tmax + 1e-10) { out = 1; break; }
         }
@@ -2961,7 +2974,7 @@ static int64_t orc_bkl_mc_skn_impl(skx_t *X, int64_t N, double beta, int64_t ite
         const double dE = dEs[move];
         int out = 0;
         while (it + skip + 1 >= nextstep) {
-            Es[nsamp++] = E;
+            Es[nsamp++] = E; if (!ORC_HOOK(nextstep, accepted, E, 0)) { out = 1; break; }
             nextstep += step;
             if (nextstep > iters) { out = 1; break; }
         }

@@ -54,6 +54,9 @@ struct ContParams {
     int64_t iters, step;
     uint32_t k0, k1, replica0, call;
     int N, K, N2, levs, W, R, Rp, ea_form, mode;      // Rp = row stride of Es
+    SmpState S;              // resumed calls (rrr_kernels.hpp)
+    int64_t samples_before;  // wtmMC: samples the run had taken before this (resumed) call
+    double* ps_top;          // cont_wave_kernel: [R][N2 / 16] the LDS part of the sampler's tree between resumed calls
 };
 
 // rankshuffle! (DeltaE.jl:611-634) restated with per-move keys: every run of equal dE is ordered by (Philox key of (g, site), site).
@@ -387,6 +390,16 @@ __global__ __launch_bounds__(kRrrThreads) void cont_sparse_kernel(ContParams P)
     c.mlast = -1; c.z = 0.0; c.trefresh = 0; c.nd = 0;
     c.rep = P.replica0 + (uint32_t)r;
     c.rloc = r;
+    double* const sf = P.S.sf + (size_t)r * kSmpF;
+    long long* const sq = P.S.si + (size_t)r * kSmpI;
+    const bool resume = P.S.resume != 0;
+    double E = 0.0;
+    if (resume) {
+        // a resumed call: local fields and their undo record, the slice caches of a GraphQuant, the sampler's tree (or the heap, or the
+        // ranking) are where the previous call left them; the scalars of the chain come from the slabs
+        c.mlast = (int)sq[SI_MLAST]; c.z = sf[SF_Z]; c.trefresh = sq[SI_TREF]; c.nd = (uint64_t)sq[SI_ND];
+        E = sf[SF_E];
+    } else {
     // energy(X, C): RRG.jl:546-574 / EA.jl:584-611
     double E1 = 0.0;
     for (int i = 0; i < N && !P.qkind; ++i) {
@@ -399,7 +412,7 @@ __global__ __launch_bounds__(kRrrThreads) void cont_sparse_kernel(ContParams P)
         E1 = E1 + fl;
         c.lf[i] = 2.0 * fl;
     }
-    double E = E1 / 2;
+    E = E1 / 2;
     if (P.dJ) {                                  // energy(X::DoubleGraph, C) = convert(Float64, E0 + E1): RRG.jl:326-360
         long long n0 = 0;
         for (int i = 0; i < N; ++i) n0 -= c.dE0(i) / 2;
@@ -437,15 +450,19 @@ __global__ __launch_bounds__(kRrrThreads) void cont_sparse_kernel(ContParams P)
             E += n / (double)P.qM;
         }
     }
+    }
     long long accepted = 0, second = 0, ns = 0, itdone = 0;
     int bad = 0;
     double t = 0.0;
 
     if (P.mode == 2) {
+        const double st = P.stepf / (double)N, tmax = st * (double)(P.samples_before + P.iters);
+        double nextstep = st;
+        if (resume) { t = sf[SF_TIME]; nextstep = sf[SF_NEXT]; }      // the run's heap, global time and next sample time carry on
+        else {
         for (int i = 0; i < N; ++i) { c.dEs[i] = c.gen_wt(c.dE(i)); c.hid[i] = (IDX)i; c.hpos[i] = (IDX)i; }
         for (int pos = N / 2 - 1; pos >= 0; --pos) c.sift_down(pos, N);
-        const double st = P.stepf / (double)N, tmax = st * (double)P.iters;
-        double nextstep = st;
+        }
         bool out = false;
         while (t < tmax && !out) {
             const double tp = c.dEs[0];
@@ -466,19 +483,26 @@ __global__ __launch_bounds__(kRrrThreads) void cont_sparse_kernel(ContParams P)
             E += d;
             accepted += 1;
         }
+        for (; ns < P.iters; ++ns) { P.Es[(size_t)ns * P.Rp + r] = E; nextstep += st; }      // not reached: the loop always emits `samples` samples
         second = accepted; itdone = ns;
+        sf[SF_TIME] = t; sf[SF_NEXT] = nextstep;
     } else if (P.mode == 3) {
         // extremal_opt: RRRMC.jl:474-521; stats = (iterations, itmin, iterations), t_out = Emin
         uint32_t* cm = P.cmin + (size_t)r * P.W;
-        for (int i = 0; i < N; ++i) { c.v[i] = c.dE(i); c.hid[i] = (IDX)i; }
-        c.eo_sort_all(N);
         int nties = 0;
-        for (int p = 0; p < N; ++p) { c.hpos[c.hid[p]] = (IDX)p; if (p > 0 && c.v[p - 1] == c.v[p]) nties += 1; }
         double Emin = E;
         long long itmin = 0;
+        if (resume) {                            // the ranking (v, hid, hpos), Emin / Cmin / itmin of the run carry on
+            for (int p = 1; p < N; ++p) if (c.v[p - 1] == c.v[p]) nties += 1;
+            Emin = sf[SF_EMIN]; itmin = sq[SI_ITMIN];
+        } else {
+        for (int i = 0; i < N; ++i) { c.v[i] = c.dE(i); c.hid[i] = (IDX)i; }
+        c.eo_sort_all(N);
+        for (int p = 0; p < N; ++p) { c.hpos[c.hid[p]] = (IDX)p; if (p > 0 && c.v[p - 1] == c.v[p]) nties += 1; }
         for (int w = 0; w < P.W; ++w) cm[w] = c.sp[w];
+        }
         const double z = P.ftau[N - 1];
-        long long next_sample = P.step;
+        long long next_sample = P.S.samp0;
         for (long long it = 1; it <= P.iters; ++it) {
             if (it == next_sample) { next_sample += P.step; P.Es[(size_t)ns * P.Rp + r] = E; ns += 1; }
             const uint64_t g = P.g0 + (uint64_t)it;
@@ -497,19 +521,22 @@ __global__ __launch_bounds__(kRrrThreads) void cont_sparse_kernel(ContParams P)
             if (nties > 0) c.eo_order_ties(g);
             E += dE;
             if (E < Emin) {
-                Emin = E; itmin = it;
+                Emin = E; itmin = P.S.it0 + it;
                 for (int w = 0; w < P.W; ++w) cm[w] = c.sp[w];
             }
         }
         accepted = P.iters; second = itmin; itdone = P.iters;
         t = Emin;
+        sf[SF_EMIN] = Emin; sq[SI_ITMIN] = itmin;
     } else {
+        if (!resume) {
         for (int i = 0; i < P.N2; ++i) c.v[i] = 0.0;
         for (int i = 0; i < N; ++i) { c.dEs[i] = c.dE(i); c.v[i] = prior_of(P.beta * c.dEs[i]); }      // DeltaECacheCont: DeltaE.jl:304-313
         c.refresh();
+        }
         if (P.mode == 0) {
-            double acc_rate = 0.5;
-            long long next_sample = P.step;          // iterations k * step: a counter instead of a 64-bit modulo per iteration
+            double acc_rate = resume ? sf[SF_ACC] : 0.5;
+            long long next_sample = P.S.samp0;       // iterations k * step of the run: a counter instead of a 64-bit modulo per iteration
             for (long long it = 1; it <= P.iters && !bad; ++it) {
                 if (it == next_sample) { next_sample += P.step; P.Es[(size_t)ns * P.Rp + r] = E; ns += 1; }
                 const uint64_t g = P.g0 + (uint64_t)it;
@@ -551,11 +578,13 @@ __global__ __launch_bounds__(kRrrThreads) void cont_sparse_kernel(ContParams P)
                 acc_rate = acc_rate * (1 - P.lambda) + (acc ? 1.0 : 0.0) * P.lambda;
             }
             itdone = P.iters;
+            sf[SF_ACC] = acc_rate;
         } else {
-            long long it = 0, nextstep = P.step, m = 0;
-            while (it < P.iters) {
-                m += 1;
-                const uint64_t g = P.g0 + (uint64_t)m;
+            // (a resumed call continues the run's loop with `iters` more iterations allowed; the pending move is drawn again: same draw)
+            long long it = 0, nextstep = P.step, m = 0, limit = P.iters;
+            if (resume) { it = sq[SI_IT]; nextstep = sq[SI_NEXT]; m = sq[SI_M]; limit += sq[SI_LIMIT]; }
+            while (it < limit) {
+                const uint64_t g = P.g0 + (uint64_t)(m + 1);
                 const Philox4 o3 = philox4x32_10((uint32_t)g, (uint32_t)(g >> 32), c.rep, TAG_RRR | (2u << 8), P.k0, P.k1);
                 const double us = (double)((((uint64_t)o3.w[0] << 32) | o3.w[1]) >> 11) * 0x1.0p-53;
                 double b = c.z / (double)N;                                     // rand_skip: DeltaE.jl:319-325
@@ -571,21 +600,25 @@ __global__ __launch_bounds__(kRrrThreads) void cont_sparse_kernel(ContParams P)
                 while (it + skip + 1 >= nextstep) {
                     P.Es[(size_t)ns * P.Rp + r] = E; ns += 1;
                     nextstep += P.step;
-                    if (nextstep > P.iters) { out = true; break; }
+                    if (nextstep > limit) { out = true; break; }
                 }
                 if (out) break;
                 c.apply_move(move);                                             // apply_step_bkl!: RRRMC.jl:294-295
+                m += 1;
                 it += skip + 1;
                 E += dE;
                 accepted += 1;
             }
             second = accepted; itdone = it;
+            sq[SI_IT] = it; sq[SI_NEXT] = nextstep; sq[SI_M] = m; sq[SI_LIMIT] = limit;
         }
     }
     P.E_cur[r] = E;
     P.stats[(size_t)r * 3] = accepted; P.stats[(size_t)r * 3 + 1] = second; P.stats[(size_t)r * 3 + 2] = itdone;
     P.t_out[r] = t;
     P.status[r] = bad;
+    sf[SF_E] = E; sf[SF_Z] = c.z;
+    sq[SI_MLAST] = c.mlast; sq[SI_TREF] = c.trefresh; sq[SI_ND] = (long long)c.nd;
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -622,6 +655,23 @@ __global__ __launch_bounds__(64) void eo_cont_wave_kernel(ContParams P)
     c.rep = P.replica0 + (uint32_t)r; c.rloc = r;
     unsigned long long* key = reinterpret_cast<unsigned long long*>(c.ps);
     uint32_t* cm = P.cmin + (size_t)r * P.W;
+    double* const sf = P.S.sf + (size_t)r * kSmpF;
+    long long* const sq = P.S.si + (size_t)r * kSmpI;
+    const bool resume = P.S.resume != 0;
+    double E = 0.0, Emin = 0.0;
+    long long itmin = 0, ns = 0;
+    int nties = 0;
+    if (resume) {
+        // a resumed call: fields and undo record are in HBM; the ranking comes back from the arrays mode 3 of cont_sparse_kernel keeps it in
+        // (v[p], hid[p], hpos[site]: the previous call wrote it there), E / Emin / itmin from the slabs
+        for (int p = lane; p < N; p += 64) { v[p] = c.v[p]; hid[p] = c.hid[p]; hpos[p] = c.hpos[p]; }
+        c.mlast = (int)sq[SI_MLAST];
+        E = sf[SF_E]; Emin = sf[SF_EMIN]; itmin = sq[SI_ITMIN];
+        __syncthreads();
+        int part = 0;
+        for (int p = 1 + lane; p < N; p += 64) part += v[p - 1] == v[p] ? 1 : 0;
+        nties = wave_sum_i32(part);
+    } else {
     // energy(X, C) (RRG.jl:546-574 / EA.jl:584-611): the fields site-parallel, their sum in site order
     for (int i = lane; i < N; i += 64) {
         const int sx = 2 * c.sbit(i) - 1;
@@ -640,7 +690,7 @@ __global__ __launch_bounds__(64) void eo_cont_wave_kernel(ContParams P)
         const int m = N - base < 64 ? N - base : 64;
         for (int l = 0; l < m; ++l) E1 = E1 + __shfl(h, l);
     }
-    double E = E1 / 2;
+    E = E1 / 2;
     if (P.dJ) {                                  // energy(X::DoubleGraph, C) = convert(Float64, E0 + E1): RRG.jl:326-360
         int part = 0;
         for (int i = lane; i < N; i += 64) part -= (int)(c.dE0(i) / 2);
@@ -659,17 +709,16 @@ __global__ __launch_bounds__(64) void eo_cont_wave_kernel(ContParams P)
     __syncthreads();
     for (int i = lane; i < N; i += 64) { const int p = hpos[i]; v[p] = c.dEs[i]; hid[p] = (uint16_t)i; }
     __syncthreads();
-    int nties = 0;
     {
         int part = 0;
         for (int p = 1 + lane; p < N; p += 64) part += v[p - 1] == v[p] ? 1 : 0;
         nties = wave_sum_i32(part);
     }
-    double Emin = E;
-    long long itmin = 0, ns = 0;
+    Emin = E;
     for (int w = lane; w < P.W; w += 64) cm[w] = c.sp[w];
+    }
     const double z = P.ftau[N - 1];
-    long long next_sample = P.step;
+    long long next_sample = P.S.samp0;
 
     // site j takes the value x (ContChain::eo_reinsert, the slide split over the lanes)
     auto reinsert = [&](int j, double x) {
@@ -734,15 +783,19 @@ __global__ __launch_bounds__(64) void eo_cont_wave_kernel(ContParams P)
         if (nties > 0) { eo_order_ties_impl(v, hid, hpos, key, N, g, c.rep, P.k0, P.k1); __syncthreads(); }
         E += dE;
         if (E < Emin) {
-            Emin = E; itmin = it;
+            Emin = E; itmin = P.S.it0 + it;
             for (int w = lane; w < P.W; w += 64) cm[w] = c.sp[w];
         }
     }
+    __syncthreads();
+    for (int p = lane; p < N; p += 64) { c.v[p] = v[p]; c.hid[p] = hid[p]; c.hpos[p] = hpos[p]; }      // the ranking, where a resumed call finds it
     if (lane == 0) {
         P.E_cur[r] = E;
         P.stats[(size_t)r * 3] = P.iters; P.stats[(size_t)r * 3 + 1] = itmin; P.stats[(size_t)r * 3 + 2] = P.iters;
         P.t_out[r] = Emin;
         P.status[r] = 0;
+        sf[SF_E] = E; sf[SF_EMIN] = Emin; sq[SI_ITMIN] = itmin; sq[SI_MLAST] = c.mlast;
+        sf[SF_Z] = 0.0; sq[SI_TREF] = 0; sq[SI_ND] = 0;
     }
 }
 

@@ -288,6 +288,20 @@ __global__ __launch_bounds__(64) void cont_wave_kernel(ContParams P)
         return z0 / z;
     };
 
+    double* const sf = P.S.sf + (size_t)r * kSmpF;
+    long long* const sq = P.S.si + (size_t)r * kSmpI;
+    double* const g_top = P.ps_top + (size_t)r * ((size_t)N2 >> kCwBottom);        // the LDS levels of the tree between resumed calls
+    const bool resume = P.S.resume != 0;
+    double E = 0.0;
+    if (resume) {
+        // a resumed call: fields, weights and the bottom blocks of the tree are in HBM where the previous call left them; the LDS levels,
+        // the undo record (one entry per lane) and the scalars of the chain come back from the slabs
+        for (int i = lane; i < (1 << LT) - 1; i += 64) l_ps[i] = g_top[i];
+        z = sf[SF_Z]; trefresh = sq[SI_TREF]; mlast = (int)sq[SI_MLAST];
+        undo = lane <= K ? sf[SF_UNDO + lane] : 0.0;
+        E = sf[SF_E];
+        __syncthreads();
+    } else {
     // ---- energy(X, C) (RRG.jl:546-574), DeltaECacheCont (DeltaE.jl:304-313) ---------------------------------------------------------------
     double E1 = 0.0;
     for (int i0 = 0; i0 < N; i0 += 64) {
@@ -307,14 +321,16 @@ __global__ __launch_bounds__(64) void cont_wave_kernel(ContParams P)
         for (int t = 0; t < nb; ++t) E1 = E1 + bcd(fl, t);
     }
     for (int i = N + lane; i < N2; i += 64) v[i] = 0.0;
-    double E = E1 / 2;
+    E = E1 / 2;
     refresh();
+    }
 
     long long accepted = 0, second = 0, ns = 0, itdone = 0;
     int bad = 0;
+    double acc_rate = resume ? sf[SF_ACC] : 0.5;
+    long long bk_it = 0, bk_next = P.step, bk_m = 0, bk_limit = P.iters;
     if (P.mode == 0) {
-        double acc_rate = 0.5;
-        long long next_sample = P.step;
+        long long next_sample = P.S.samp0;
         for (long long it = 1; it <= P.iters; ++it) {
             if (it == next_sample) { next_sample += P.step; if (lane == 0) P.Es[(size_t)ns * P.Rp + r] = E; ns += 1; }
             const uint64_t g = P.g0 + (uint64_t)it;
@@ -358,10 +374,12 @@ __global__ __launch_bounds__(64) void cont_wave_kernel(ContParams P)
         }
         itdone = P.iters;
     } else {
-        long long it = 0, nextstep = P.step, m = 0;
-        while (it < P.iters) {
-            m += 1;
-            const uint64_t g = P.g0 + (uint64_t)m;
+        // (a resumed call continues the run's loop with `iters` more iterations allowed; the pending move is drawn again: same draw)
+        if (resume) { bk_it = sq[SI_IT]; bk_next = sq[SI_NEXT]; bk_m = sq[SI_M]; bk_limit += sq[SI_LIMIT]; }
+        long long it = bk_it, nextstep = bk_next, m = bk_m;
+        const long long limit = bk_limit;
+        while (it < limit) {
+            const uint64_t g = P.g0 + (uint64_t)(m + 1);
             const Philox4 o3 = philox4x32_10((uint32_t)g, (uint32_t)(g >> 32), rep, TAG_RRR | (2u << 8), P.k0, P.k1);
             const double us = bcd((double)((((uint64_t)o3.w[0] << 32) | o3.w[1]) >> 11) * 0x1.0p-53, 0);
             double b = z / (double)N;                                           // rand_skip: DeltaE.jl:319-325
@@ -378,23 +396,30 @@ __global__ __launch_bounds__(64) void cont_wave_kernel(ContParams P)
                 if (lane == 0) P.Es[(size_t)ns * P.Rp + r] = E;
                 ns += 1;
                 nextstep += P.step;
-                if (nextstep > P.iters) { out = true; break; }
+                if (nextstep > limit) { out = true; break; }
             }
             if (out) break;
             apply_move(move, true);                                             // apply_step_bkl!: RRRMC.jl:294-295
+            m += 1;
             it += skip + 1;
             E += dE;
             accepted += 1;
         }
         second = accepted; itdone = it;
+        bk_it = it; bk_next = nextstep; bk_m = m;
     }
     __syncthreads();
     for (int i = lane; i < P.W; i += 64) g_sp[i] = l_sp[i];
+    for (int i = lane; i < (1 << LT) - 1; i += 64) g_top[i] = l_ps[i];
+    if (lane <= K) sf[SF_UNDO + lane] = undo;
     if (lane == 0) {
         P.E_cur[r] = E;
         P.stats[(size_t)r * 3] = accepted; P.stats[(size_t)r * 3 + 1] = second; P.stats[(size_t)r * 3 + 2] = itdone;
         P.t_out[r] = 0.0;
         P.status[r] = bad;
+        sf[SF_E] = E; sf[SF_Z] = z; sf[SF_ACC] = acc_rate;
+        sq[SI_TREF] = trefresh; sq[SI_MLAST] = mlast; sq[SI_ND] = 0;
+        sq[SI_IT] = bk_it; sq[SI_NEXT] = bk_next; sq[SI_M] = bk_m; sq[SI_LIMIT] = bk_limit;
     }
 }
 

@@ -45,6 +45,7 @@ struct RrrDblParams {
     int N, K, L, W, R, ea_form, energy_only;
     int32_t* mlast;          // [R] move_last of the residual cache, kept across resumed standardMC calls
     int resume;              // standardMC continues from E_cur / lf / undo / mlast instead of recomputing them (one chain across hook calls)
+    SmpState S;              // rrrMC: resumed calls (rrr_kernels.hpp)
     __host__ __device__ __forceinline__ double to_f64(long long units) const { return (double)(units * lev_mul) / lev_div; }
 };
 
@@ -286,7 +287,21 @@ __global__ __launch_bounds__(kRrrThreads) void rrr_dbl_kernel(RrrDblParams P)
     if (r >= P.R) return;
     const int N = P.N, L = P.L, K2 = 2 * P.L, K = P.K;
     DblChain<SLM, IDX> c;
-    double E = dbl_init_chain(c, P, r, !P.energy_only);
+    double* const sf = P.S.sf ? P.S.sf + (size_t)r * kSmpF : nullptr;
+    long long* const sq = P.S.si ? P.S.si + (size_t)r * kSmpI : nullptr;
+    const bool resume = P.S.resume != 0 && !P.energy_only;
+    double E;
+    if (resume) {
+        // a resumed call: the class sets (member order), T, z, the residual fields with their undo record and move_last, and the tracked
+        // energy are where the previous call left them
+        dbl_bind_chain(c, P, r);
+        c.mlast = P.mlast[r];
+#pragma unroll
+        for (int k = 0; k < 2 * SLM; ++k) { c.t[k] = (int)sq[SI_T0 + k]; c.T[k] = sf[SF_T0 + k]; }
+        c.z = sf[SF_Z];
+        E = sf[SF_E];
+    } else {
+    E = dbl_init_chain(c, P, r, !P.energy_only);
     if (P.energy_only) { P.E_cur[r] = E; return; }
     c.z = 0.0;
 #pragma unroll
@@ -294,11 +309,12 @@ __global__ __launch_bounds__(kRrrThreads) void rrr_dbl_kernel(RrrDblParams P)
 #pragma unroll
     for (int k = 0; k < 2 * SLM; ++k)
         if (k < K2) { const double x = (double)c.t[k] * c.f(k); c.z += x; c.T[k] = x; }
+    }
 
     const uint32_t rep = P.replica0 + (uint32_t)r;
     long long accepted = 0, staged_its = 0, ns = 0;
-    double acc_rate = 0.5;
-    long long next_sample = P.step;          // iterations k * step: a counter instead of a 64-bit modulo per iteration
+    double acc_rate = resume ? sf[SF_ACC] : 0.5;
+    long long next_sample = P.S.samp0;       // iterations k * step of the run: a counter instead of a 64-bit modulo per iteration
     for (long long it = 1; it <= P.iters; ++it) {
         if (it == next_sample) { next_sample += P.step; P.Es[(size_t)ns * P.R + r] = E; ns += 1; }
         const uint64_t g = P.g0 + (uint64_t)it;
@@ -363,6 +379,10 @@ __global__ __launch_bounds__(kRrrThreads) void rrr_dbl_kernel(RrrDblParams P)
     }
     P.E_cur[r] = E;
     P.stats[(size_t)r * 2] = accepted; P.stats[(size_t)r * 2 + 1] = staged_its;
+    P.mlast[r] = c.mlast;
+#pragma unroll
+    for (int k = 0; k < 2 * SLM; ++k) { sq[SI_T0 + k] = c.t[k]; sf[SF_T0 + k] = c.T[k]; }
+    sf[SF_Z] = c.z; sf[SF_E] = E; sf[SF_ACC] = acc_rate;
 }
 
 }  // namespace rrrmc

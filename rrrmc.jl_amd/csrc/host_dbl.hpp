@@ -81,7 +81,10 @@ int32_t dbl_mc_async(rrrmc_ctx* ctx, bool standard, double beta, int64_t iters, 
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     ctx->results_valid = false; ctx->last_call_wtm = false; ctx->last_call_eo = false;
     ctx->timing_valid = false;
-    const int64_t nsamp = iters / step;
+    SmpState S{};
+    if (!standard) { const int32_t rcs = smp_begin(ctx, 1, beta, staged_thr, staged_thr_fact, 0.0, step, nullptr, &S); if (rcs) return rcs; }
+    else S.samp0 = step;
+    const int64_t nsamp = standard ? iters / step : smp_nsamp(ctx, iters, step);
     const size_t es_need = (size_t)(nsamp > 0 ? nsamp : 1) * ctx->R;
     if (es_need > ctx->sk_Es_cap) {
         free_dev(ctx->sk_Es);
@@ -95,6 +98,7 @@ int32_t dbl_mc_async(rrrmc_ctx* ctx, bool standard, double beta, int64_t iters, 
         ctx->ev_sweep.push_back(e);
     }
     RrrDblParams P = dbl_params(ctx, beta);
+    P.S = S;
     P.staged_thr = staged_thr; P.lambda = staged_thr_fact / (double)ctx->N;
     P.g0 = ctx->it_done; P.iters = iters; P.step = step;
     if (!ctx->db_mlast) HIP_TRY(ctx, hipMalloc(&ctx->db_mlast, sizeof(int32_t) * (size_t)ctx->R));
@@ -117,6 +121,7 @@ int32_t dbl_mc_async(rrrmc_ctx* ctx, bool standard, double beta, int64_t iters, 
     ctx->sweep_launches = 1;
     ctx->nsamp = nsamp;
     ctx->it_done += (uint64_t)iters;
+    if (!standard) smp_commit(ctx, 1, iters);
     ctx->results_valid = true;
     ctx->timing_valid = true;
     ctx->last_call_rrr = true;          // accepted counts live in q_stats

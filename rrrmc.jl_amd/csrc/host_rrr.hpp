@@ -79,6 +79,8 @@ int32_t sk_rrr_mc_async(rrrmc_ctx* ctx, double beta, int64_t iters, int64_t step
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     ctx->results_valid = false; ctx->last_call_wtm = false; ctx->last_call_eo = false;
     ctx->timing_valid = false;
+    SmpState S{};
+    { const int32_t rcs = smp_begin(ctx, mode + 1, beta, mode == 2 ? stepf : staged_thr, staged_thr_fact, 0.0, mode == 2 ? 1 : step, ftau, &S); if (rcs) return rcs; }
     const int64_t N = ctx->N, Rp = ctx->Rpad;
     int levs = 0;
     while (((int64_t)1 << levs) < N) ++levs;
@@ -98,10 +100,12 @@ int32_t sk_rrr_mc_async(rrrmc_ctx* ctx, double beta, int64_t iters, int64_t step
             HIP_TRY(ctx, hipMalloc(&ctx->eo_ftau, sizeof(double) * N));
         }
         ctx->eo_W = W;
-        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-        HIP_TRY(ctx, hipMemcpy(ctx->eo_ftau, ftau, sizeof(double) * N, hipMemcpyHostToDevice));
+        if (!S.resume) {                    // (a resumed call: the run's table is on the device already)
+            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+            HIP_TRY(ctx, hipMemcpy(ctx->eo_ftau, ftau, sizeof(double) * N, hipMemcpyHostToDevice));
+        }
     }
-    const int64_t nsamp = mode == 2 ? iters : iters / step;
+    const int64_t nsamp = mode == 2 ? iters : smp_nsamp(ctx, iters, step);
     const size_t es_need = (size_t)(nsamp > 0 ? nsamp : 1) * Rp;
     if (es_need > ctx->sk_Es_cap) {
         free_dev(ctx->sk_Es);
@@ -138,11 +142,13 @@ int32_t sk_rrr_mc_async(rrrmc_ctx* ctx, double beta, int64_t iters, int64_t step
     P.z_out = b;
     P.spins = ctx->rs_spins; P.E_cur = ctx->sk_E; P.stats = ctx->q_stats; P.status = ctx->rs_status; P.Es = ctx->sk_Es;
     P.beta = beta; P.staged_thr = staged_thr; P.lambda = staged_thr_fact / (double)N;
-    P.g0 = ctx->it_done; P.iters = iters; P.step = step;
+    P.g0 = mode == 1 ? ctx->smp_g0 : ctx->it_done;          // bklMC numbers its moves from the start of the RUN
+    P.iters = iters; P.step = step;
     P.k0 = (uint32_t)ctx->seed; P.k1 = (uint32_t)(ctx->seed >> 32); P.replica0 = ctx->replica0;
     P.N = (int)N; P.N2 = (int)N2; P.levs = levs; P.W = (int)W; P.R = (int)ctx->R; P.Rp = (int)Rp;
     P.mode = mode;
-    P.call = ctx->wtm_calls & 0xffffffu; P.stepf = stepf; P.t_out = ctx->wt_time;
+    P.S = S; P.samples_before = mode == 2 ? ctx->smp_it : 0;
+    P.call = ctx->smp_call & 0xffffffu; P.stepf = stepf; P.t_out = ctx->wt_time;
     P.ftau = ctx->eo_ftau; P.cmin = ctx->eo_cmin;
     ctx->stats_stride = 2;
     HIP_TRY(ctx, hipEventRecord(ctx->ev_begin, st));
@@ -163,7 +169,8 @@ int32_t sk_rrr_mc_async(rrrmc_ctx* ctx, double beta, int64_t iters, int64_t step
     HIP_TRY(ctx, hipEventRecord(ctx->ev_end, st));
     ctx->sweep_launches = 1;
     ctx->nsamp = nsamp;
-    if (mode == 2) ctx->wtm_calls += 1; else ctx->it_done += (uint64_t)iters;
+    if (mode == 2) { if (!S.resume) ctx->wtm_calls += 1; } else ctx->it_done += (uint64_t)iters;
+    smp_commit(ctx, mode + 1, iters);
     ctx->results_valid = true;
     ctx->timing_valid = true;
     ctx->last_call_rrr = true;
@@ -213,6 +220,8 @@ int32_t sparse_rrr_bkl_async(rrrmc_ctx* ctx, int mode, double beta, int64_t iter
     const bool wide_idx = N > 65535;
     const size_t idx_bytes = wide_idx ? 4 : 2;
     if (N > (int64_t)1 << 28) return fail(ctx, RRRMC_ERR_UNSUPPORTED, "N=%lld is beyond the rrrMC kernel (N <= 2^28)", (long long)N);
+    SmpState S{};
+    { const int32_t rcs = smp_begin(ctx, mode + 1, beta, staged_thr, staged_thr_fact, 0.0, step, nullptr, &S); if (rcs) return rcs; }
     RpView rv;
     int32_t rc = rp_prepare(ctx, &rv);
     if (rc) return rc;
@@ -224,7 +233,7 @@ int32_t sparse_rrr_bkl_async(rrrmc_ctx* ctx, int mode, double beta, int64_t iter
         if (!ctx->q_stats) HIP_TRY(ctx, hipMalloc(&ctx->q_stats, sizeof(int64_t) * R * 3));
     }
     ctx->stats_stride = 3;
-    const int64_t nsamp = iters / step;
+    const int64_t nsamp = smp_nsamp(ctx, iters, step);
     const size_t es_need = (size_t)(nsamp > 0 ? nsamp : 1) * ctx->Rpad;
     if (es_need > ctx->Es_cap) {
         free_dev(ctx->d_Es);
@@ -238,12 +247,14 @@ int32_t sparse_rrr_bkl_async(rrrmc_ctx* ctx, int mode, double beta, int64_t iter
         ctx->ev_sweep.push_back(e);
     }
     RrrSparseParams P{};
+    P.S = S;
     P.A = ctx->d_A; P.J = ctx->d_J; P.spins = rv.spins; P.cls = ctx->rp_cls; P.sv = ctx->rp_sv; P.spos = ctx->rp_spos;
     P.E_cur = ctx->d_E; P.acc_cur = ctx->d_acc; P.stats = ctx->q_stats; P.Es = ctx->d_Es;
     P.lv = ctx->lv;
     for (int k = 0; k < L && k < kSLmax; ++k) P.ft[k] = host_det_exp(-beta * lv_to_f64(ctx, ctx->lv.dElist[k]));     // exp(-beta dE_k), DeltaE.jl:91
     P.beta = beta; P.staged_thr = staged_thr; P.lambda = staged_thr_fact / (double)N;
-    P.g0 = ctx->it_done; P.iters = iters; P.step = step;
+    P.g0 = mode == 1 ? ctx->smp_g0 : ctx->it_done;          // bklMC numbers its moves from the start of the RUN
+    P.iters = iters; P.step = step;
     P.k0 = (uint32_t)ctx->seed; P.k1 = (uint32_t)(ctx->seed >> 32); P.replica0 = ctx->replica0;
     P.N = (int)N; P.K = (int)K; P.L = L; P.W = (int)W; P.R = (int)R; P.Rpad = (int)ctx->Rpad; P.mode = mode;
     hipStream_t st = ctx->stream;
@@ -305,6 +316,7 @@ int32_t sparse_rrr_bkl_async(rrrmc_ctx* ctx, int mode, double beta, int64_t iter
     ctx->sweep_launches = 1;
     ctx->nsamp = nsamp;
     ctx->it_done += (uint64_t)iters;
+    smp_commit(ctx, mode + 1, iters);
     ctx->results_valid = true;
     ctx->timing_valid = true;
     ctx->last_call_rrr = true;
@@ -322,6 +334,8 @@ int32_t sparse_wtm_async(rrrmc_ctx* ctx, double beta, int64_t samples, double st
     ctx->results_valid = false; ctx->last_call_wtm = false; ctx->last_call_eo = false;
     ctx->timing_valid = false;
     const int64_t N = ctx->N, K = ctx->K, R = ctx->R;
+    SmpState S{};
+    { const int32_t rcs = smp_begin(ctx, 3, beta, step, 0.0, 0.0, 1, nullptr, &S); if (rcs) return rcs; }
     RpView rv;
     int32_t rc = rp_prepare(ctx, &rv);
     if (rc) return rc;
@@ -356,7 +370,8 @@ int32_t sparse_wtm_async(rrrmc_ctx* ctx, double beta, int64_t samples, double st
         }
     (void)K;
     P.step = step / (double)N; P.samples = samples;
-    P.k0 = (uint32_t)ctx->seed; P.k1 = (uint32_t)(ctx->seed >> 32); P.replica0 = ctx->replica0; P.call = ctx->wtm_calls & 0xffffffu;
+    P.S = S; P.samples_before = ctx->smp_it;
+    P.k0 = (uint32_t)ctx->seed; P.k1 = (uint32_t)(ctx->seed >> 32); P.replica0 = ctx->replica0; P.call = ctx->smp_call & 0xffffffu;
     P.N = (int)N; P.K = (int)K; P.W = (int)W; P.R = (int)R; P.Rpad = (int)ctx->Rpad;
     hipStream_t st = ctx->stream;
     HIP_TRY(ctx, hipEventRecord(ctx->ev_begin, st));
@@ -368,7 +383,8 @@ int32_t sparse_wtm_async(rrrmc_ctx* ctx, double beta, int64_t samples, double st
     HIP_TRY(ctx, hipEventRecord(ctx->ev_sweep[1], st));
     if ((rc = rp_out(ctx, rv, st))) return rc;
     HIP_TRY(ctx, hipEventRecord(ctx->ev_end, st));
-    ctx->wtm_calls += 1;
+    if (!S.resume) ctx->wtm_calls += 1;
+    smp_commit(ctx, 3, samples);
     ctx->sweep_launches = 1;
     ctx->nsamp = samples;
     ctx->results_valid = true;
@@ -393,6 +409,8 @@ int32_t sparse_eo_async(rrrmc_ctx* ctx, const double* ftau, int64_t iters, int64
     ctx->results_valid = false; ctx->last_call_wtm = false; ctx->last_call_eo = false;
     ctx->timing_valid = false;
     const int L = ctx->lv.L;
+    SmpState S{};
+    { const int32_t rcs = smp_begin(ctx, 4, 0.0, 0.0, 0.0, 0.0, step, ftau, &S); if (rcs) return rcs; }
     RpView rv;
     int32_t rc = rp_prepare(ctx, &rv);
     if (rc) return rc;
@@ -410,7 +428,7 @@ int32_t sparse_eo_async(rrrmc_ctx* ctx, const double* ftau, int64_t iters, int64
         HIP_TRY(ctx, hipMalloc(&ctx->eo_ftau, sizeof(double) * N));
     }
     ctx->stats_stride = 3;
-    const int64_t nsamp = iters / step;
+    const int64_t nsamp = smp_nsamp(ctx, iters, step);
     const size_t es_need = (size_t)(nsamp > 0 ? nsamp : 1) * ctx->Rpad;
     if (es_need > ctx->Es_cap) {
         free_dev(ctx->d_Es);
@@ -424,10 +442,13 @@ int32_t sparse_eo_async(rrrmc_ctx* ctx, const double* ftau, int64_t iters, int64
         ctx->ev_sweep.push_back(e);
     }
     hipStream_t st = ctx->stream;
-    HIP_TRY(ctx, hipStreamSynchronize(st));
-    HIP_TRY(ctx, hipMemcpy(ctx->eo_ftau, ftau, sizeof(double) * N, hipMemcpyHostToDevice));
-    HIP_TRY(ctx, hipMemset(ctx->eo_cmin, 0, sizeof(uint32_t) * R * 2 * ((N + 63) / 64)));
+    if (!S.resume) {                    // (a resumed call: the run's table and its Cmin are on the device)
+        HIP_TRY(ctx, hipStreamSynchronize(st));
+        HIP_TRY(ctx, hipMemcpy(ctx->eo_ftau, ftau, sizeof(double) * N, hipMemcpyHostToDevice));
+        HIP_TRY(ctx, hipMemset(ctx->eo_cmin, 0, sizeof(uint32_t) * R * 2 * ((N + 63) / 64)));
+    }
     EoParams P{};
+    P.S = S;
     P.A = ctx->d_A; P.J = ctx->d_J; P.ftau = ctx->eo_ftau; P.spins = rv.spins; P.cmin = ctx->eo_cmin;
     P.lv = ctx->lv;
     P.cls = ctx->rp_cls; P.sv = ctx->rp_sv; P.spos = ctx->rp_spos; P.E_cur = ctx->d_E; P.stats = ctx->q_stats; P.Es = ctx->d_Es;
@@ -446,6 +467,7 @@ int32_t sparse_eo_async(rrrmc_ctx* ctx, const double* ftau, int64_t iters, int64
     ctx->sweep_launches = 1;
     ctx->nsamp = nsamp;
     ctx->it_done += (uint64_t)iters;
+    smp_commit(ctx, 4, iters);
     ctx->results_valid = true;
     ctx->timing_valid = true;
     ctx->last_call_rrr = false;

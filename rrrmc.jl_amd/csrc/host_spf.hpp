@@ -248,6 +248,9 @@ int32_t spf_cont_async(rrrmc_ctx* ctx, int mode, double beta, int64_t iters, int
     int levs = 0;
     while (((int64_t)1 << levs) < N) ++levs;
     const int64_t N2 = (int64_t)1 << levs;
+    SmpState S{};
+    { const int32_t rcs = smp_begin(ctx, mode + 1, beta, mode == 2 ? stepf : staged_thr, staged_thr_fact, quantm ? ctx->last_fourK : 0.0, mode == 2 ? 1 : step, ftau, &S); if (rcs) return rcs; }
+    if (!ctx->cs_top) HIP_TRY(ctx, hipMalloc(&ctx->cs_top, sizeof(double) * (size_t)R * (size_t)std::max<int64_t>(N2 >> kCwBottom, 1)));
     if (!ctx->cs_buf) {
         if (!dblm) HIP_TRY(ctx, hipMalloc(&ctx->cs_spins, sizeof(uint32_t) * R * W));
         HIP_TRY(ctx, hipMalloc(&ctx->cs_buf, sizeof(double) * (size_t)R * (size_t)(2 * N + 2 * N2 + K + 1)));
@@ -256,7 +259,7 @@ int32_t spf_cont_async(rrrmc_ctx* ctx, int mode, double beta, int64_t iters, int
         if (!ctx->q_stats) HIP_TRY(ctx, hipMalloc(&ctx->q_stats, sizeof(int64_t) * R * 3));
         if (!ctx->wt_time) HIP_TRY(ctx, hipMalloc(&ctx->wt_time, sizeof(double) * R));
     }
-    const int64_t nsamp = mode == 2 ? iters : iters / step;
+    const int64_t nsamp = mode == 2 ? iters : smp_nsamp(ctx, iters, step);
     const size_t es_need = (size_t)(nsamp > 0 ? nsamp : 1) * ctx->Rpad;
     if (es_need > ctx->sk_Es_cap) {
         free_dev(ctx->sk_Es);
@@ -270,14 +273,17 @@ int32_t spf_cont_async(rrrmc_ctx* ctx, int mode, double beta, int64_t iters, int
         ctx->ev_sweep.push_back(e);
     }
     ContParams P{};
+    P.S = S; P.samples_before = mode == 2 ? ctx->smp_it : 0; P.ps_top = ctx->cs_top;
     if (mode == 3) {
         if (!ctx->eo_cmin) {
             HIP_TRY(ctx, hipMalloc(&ctx->eo_cmin, sizeof(uint32_t) * R * W));
             HIP_TRY(ctx, hipMalloc(&ctx->eo_ftau, sizeof(double) * N));
         }
         ctx->eo_W = W;
-        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-        HIP_TRY(ctx, hipMemcpy(ctx->eo_ftau, ftau, sizeof(double) * N, hipMemcpyHostToDevice));
+        if (!S.resume) {                // (a resumed call: the run's table is on the device already)
+            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+            HIP_TRY(ctx, hipMemcpy(ctx->eo_ftau, ftau, sizeof(double) * N, hipMemcpyHostToDevice));
+        }
         P.ftau = ctx->eo_ftau; P.cmin = ctx->eo_cmin;
     }
     double* b = ctx->cs_buf;
@@ -298,8 +304,9 @@ int32_t spf_cont_async(rrrmc_ctx* ctx, int mode, double beta, int64_t iters, int
     P.hpos = N > 65535 ? static_cast<void*>(reinterpret_cast<uint32_t*>(ctx->cs_u16) + (size_t)R * N) : static_cast<void*>(ctx->cs_u16 + (size_t)R * N);
     P.E_cur = ctx->sk_E; P.stats = ctx->q_stats; P.Es = ctx->sk_Es; P.t_out = ctx->wt_time; P.status = ctx->rs_status;
     P.beta = beta; P.staged_thr = staged_thr; P.lambda = staged_thr_fact / (double)N; P.stepf = stepf;
-    P.g0 = ctx->it_done; P.iters = iters; P.step = step;
-    P.k0 = (uint32_t)ctx->seed; P.k1 = (uint32_t)(ctx->seed >> 32); P.replica0 = ctx->replica0; P.call = ctx->wtm_calls & 0xffffffu;
+    P.g0 = mode == 1 ? ctx->smp_g0 : ctx->it_done;          // bklMC numbers its moves from the start of the RUN
+    P.iters = iters; P.step = step;
+    P.k0 = (uint32_t)ctx->seed; P.k1 = (uint32_t)(ctx->seed >> 32); P.replica0 = ctx->replica0; P.call = ctx->smp_call & 0xffffffu;
     P.N = (int)N; P.K = (int)K; P.N2 = (int)N2; P.levs = levs; P.W = (int)W; P.R = (int)R; P.Rp = (int)ctx->Rpad;
     P.ea_form = 1;           // de-duplicate repeated neighbours (EA.jl:680); a no-op for GraphRRGNormal tables
     P.mode = mode;
@@ -317,8 +324,10 @@ int32_t spf_cont_async(rrrmc_ctx* ctx, int mode, double beta, int64_t iters, int
         HIP_TRY(ctx, raise_lds_attr(reinterpret_cast<const void*>(eo_cont_wave_kernel), lds));
         hipLaunchKernelGGL(eo_cont_wave_kernel, dim3((unsigned)R), dim3(64), lds, st, P);
     } else if (const char* nw = std::getenv("RRRMC_CONT_NO_WAVE"); (mode == 0 || mode == 1) && !dblm && !ctx->pf_multi_edge && N >= 64 && K <= kContKmax &&
-               cw_lds_bytes(W, levs) <= (size_t)32768 && !(nw && nw[0] == '1')) {
+               cw_lds_bytes(W, levs) <= (size_t)32768 && (S.resume ? ctx->smp_build == 1 : !(nw && nw[0] == '1'))) {
         // rrrMC / bklMC on the pure Float64 models: one wavefront per replica, the top of the sampler's tree in LDS (cont_wave_kernel.hpp)
+        // (the two builds keep the tree in different layouts: a resumed call runs the build that holds the run's state)
+        ctx->smp_build = 1;
         hipLaunchKernelGGL(cont_wave_kernel, dim3((unsigned)R), dim3(64), cw_lds_bytes(W, levs), st, P);
     } else {
         if (N > 65535) hipLaunchKernelGGL(cont_sparse_kernel<uint32_t>, dim3(rrr_blocks(R)), dim3(rrr_tpb(R)), 0, st, P);
@@ -331,7 +340,8 @@ int32_t spf_cont_async(rrrmc_ctx* ctx, int mode, double beta, int64_t iters, int
         HIP_TRY(ctx, hipGetLastError());
     }
     HIP_TRY(ctx, hipEventRecord(ctx->ev_end, st));
-    if (mode == 2) ctx->wtm_calls += 1; else ctx->it_done += (uint64_t)iters;
+    if (mode == 2) { if (!S.resume) ctx->wtm_calls += 1; } else ctx->it_done += (uint64_t)iters;
+    smp_commit(ctx, mode + 1, iters);
     ctx->pf_lf_live = false;
     ctx->db_cache_valid = false;
     if (quantm) ctx->q_cache_valid = false;

@@ -222,7 +222,7 @@ __global__ __launch_bounds__(kRrrThreads) void rrr_quant_wave_kernel(RrrParams P
     // T[0..2] == (double)t[0..2] exactly (weights 1.0); T3 and z are running sums (DeltaE.jl:90-103, 258-282)
     double T3 = P.T[(size_t)r * 4 + 3], z = P.zz[r], E = P.E_cur[r], acc_rate = P.acc_rate[r];
     long long accepted = P.stats[(size_t)r * 2], staged_its = P.stats[(size_t)r * 2 + 1];
-    long long ns = 0, next_sample = P.step;
+    long long ns = 0, next_sample = P.samp0;
 
     auto bit_of = [&](int x) -> int { return (int)((l_sp[x >> 5] >> (x & 31)) & 1u); };
     // every condition of the chain is wave-uniform, but its operands are kept in vector registers on purpose (see the header), so the

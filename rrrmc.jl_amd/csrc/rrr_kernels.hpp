@@ -21,6 +21,24 @@ constexpr int kRrrThreads = 64;          // most replicas (threads) a workgroup 
                                         // fewer per workgroup when there are few replicas, to spread them over the CUs (rrr_tpb)
 constexpr int kQL = 2;          // levels of allΔE(GraphQT) = (0.0, fourK), QT.jl:111
 
+// ---- resumed calls (rrrmc_set_resume) -----------------------------------------------------------------------------------------------
+// A reference sampler keeps its chain in local variables from the first to the last iteration, hook calls included (src/RRRMC.jl:175-212
+// rrrMC, :322-350 bklMC, :389-416 wtmMC, :486-516 extremal_opt): the cache object, E, acc_rate, `it` / `nextstep`, the heap's global time,
+// Emin / itmin.  A library call that RESUMES the previous one finds the arrays of the cache where the previous call left them (HBM) and
+// these scalars in two per-replica slabs; the kernels load them instead of running energy(X, C) + gen_ΔEcache, and store them at their end.
+// One layout for every kernel (each uses the entries it has):
+constexpr int kSmpF = 40, kSmpI = 40;
+enum SmpF { SF_Z = 0, SF_ACC = 1, SF_TIME = 2, SF_NEXT = 3, SF_EMIN = 4, SF_E = 5, SF_T0 = 8 /* T[0..15] */, SF_UNDO = 24 /* undo[0..K] of the wave builds */ };
+enum SmpI { SI_IT = 0, SI_NEXT = 1, SI_M = 2, SI_ND = 3, SI_TREF = 4, SI_CUR = 5, SI_MLAST = 6, SI_EMIN = 7, SI_ITMIN = 8, SI_LIMIT = 9,
+            SI_T0 = 16 /* t[0..15] set sizes */ };
+struct SmpState {            // the same four fields in every parameter struct below
+    double* sf;              // [R][kSmpF]
+    long long* si;           // [R][kSmpI]
+    int resume;              // 1: continue the run the slabs (and the cache arrays) describe
+    long long samp0;         // the call's first sample is taken before its iteration samp0 (= step - (run iterations so far) % step)
+    long long it0;           // iterations of the run before this call (extremal_opt's itmin counts from the start of the run)
+};
+
 struct RrrParams {
     // disorder of the slice graph (shared by slices and replicas)
     const int32_t* A;        // [Nk][K]
@@ -52,6 +70,7 @@ struct RrrParams {
     uint32_t k0, k1, replica0;
     int Nk, M, K, N, W, R;
     int wide;                //              sv / spos hold 32-bit entries (thread-per-replica builds only)
+    long long samp0;         //              the call's first sample is taken before its iteration samp0 (resumed calls: see SmpState)
 };
 
 struct RrrView {             // one replica's slices of the arrays above
@@ -454,7 +473,7 @@ __global__ __launch_bounds__(kRrrThreads) void rrr_quant_kernel(RrrParams P)
     int64_t ns = 0;
     const double dEl[2] = {0.0, P.fourK};
 
-    long long next_sample = P.step;          // iterations k * step: a counter instead of a 64-bit modulo per iteration
+    long long next_sample = P.samp0;         // iterations k * step of the run: a counter instead of a 64-bit modulo per iteration
     // LDS build: the chain runs on lane 0 and is bound by its instruction stream, so the state-independent part of an iteration —
     // the two Philox blocks of the RRR stream — is computed for 64 iterations at a time by the whole wavefront (one iteration per lane)
     for (int64_t base = 0; base < P.iters; base += (LDS ? kRrrThreads : P.iters)) {
@@ -673,6 +692,8 @@ struct RrrSkParams {
     const double* ftau;      // extremal_opt: [N] cumsum(j^-tau)
     uint32_t* cmin;          // extremal_opt: [R][W] configuration of minimum energy (replica-contiguous words)
     double sN;               // binary GraphSK (SK.jl:28-165) run as +-1 couplings: delta_energy = lfields[i] / sN, E = n / sN (sN = sqrt(N)); 0 = GraphSKNormal
+    SmpState S;
+    int64_t samples_before;  // wtmMC: samples the run had taken before this (resumed) call
 };
 
 struct SkChain {             // one replica's view
@@ -782,6 +803,16 @@ __global__ __launch_bounds__(kRrrThreads) void rrr_skn_kernel(RrrSkParams P)
     const int N = P.N, Rp = P.Rp;
     SkChain c;
     c.P = &P; c.r = r; c.cur = 0; c.move_last = -1; c.z = 0.0; c.trefresh = 0;
+    double* const sf = P.S.sf + (size_t)r * kSmpF;
+    long long* const sq = P.S.si + (size_t)r * kSmpI;
+    const bool resume = P.S.resume != 0;
+    double E;
+    if (resume) {
+        // a resumed call: fields (and which array is `lfields`), move_last, the sampler's tree with its refresh countdown and z — or the
+        // heap of waiting times — and the tracked energy are where the previous call left them
+        c.cur = (int)sq[SI_CUR]; c.move_last = (int)sq[SI_MLAST]; c.z = sf[SF_Z]; c.trefresh = sq[SI_TREF];
+        E = sf[SF_E];
+    } else {
     // energy: sequential sums in the reference's order
     double n = 0.0;
     for (int i = 0; i < N; ++i) {
@@ -793,7 +824,7 @@ __global__ __launch_bounds__(kRrrThreads) void rrr_skn_kernel(RrrSkParams P)
         P.lfB[(size_t)i * Rp + r] = 0.0;
         n -= lfh;
     }
-    double E = n / 2;
+    E = n / 2;
     if (P.sN > 0.0) E = E / P.sN;               // GraphSK: the integer n of SK.jl:62-95 (exact in Float64), then n / sN
     for (int i = 0; i < P.N2; ++i) P.v[(size_t)i * Rp + r] = 0.0;
     for (int i = 0; i < N; ++i) {
@@ -802,9 +833,10 @@ __global__ __launch_bounds__(kRrrThreads) void rrr_skn_kernel(RrrSkParams P)
         P.v[(size_t)i * Rp + r] = prior_of(P.beta * dE);
     }
     c.refresh();
+    }
 
     const uint32_t rep = P.replica0 + (uint32_t)r;
-    double acc_rate = 0.5;
+    double acc_rate = resume ? sf[SF_ACC] : 0.5;
     long long accepted = 0, staged_its = 0, ns = 0;
     int bad = 0;
     if (P.mode == 2) {
@@ -858,13 +890,16 @@ __global__ __launch_bounds__(kRrrThreads) void rrr_skn_kernel(RrrSkParams P)
             ht[(size_t)pos * Rp] = t;
             if (t < old) sift_up(pos); else sift_down(pos);
         };
+        const double st = P.stepf / (double)N, tmax = st * (double)(P.samples_before + P.iters);
+        double t = 0.0, nextstep = st;
+        if (resume) { t = sf[SF_TIME]; nextstep = sf[SF_NEXT]; nd = (uint64_t)sq[SI_ND]; }      // the run's heap, global time and next sample time
+        else {
         for (int i = 0; i < N; ++i) {                 // THeap(X, C, beta): one waiting time per spin, in index order
             ht[(size_t)i * Rp] = gen_wt(c.dEv(P.lfA[(size_t)i * Rp + r]));
             hid[(size_t)i * Rp] = (uint16_t)i; hpos[(size_t)i * Rp] = (uint16_t)i;
         }
         for (int pos = N / 2 - 1; pos >= 0; --pos) sift_down(pos);
-        const double st = P.stepf / (double)N, tmax = st * (double)P.iters;
-        double t = 0.0, nextstep = st;
+        }
         bool out = false;
         while (t < tmax && !out) {
             const double tp = ht[0];
@@ -887,16 +922,18 @@ __global__ __launch_bounds__(kRrrThreads) void rrr_skn_kernel(RrrSkParams P)
             E += dE;
             accepted += 1;
         }
-        for (; ns < P.iters; ++ns) P.Es[(size_t)ns * Rp + r] = E;   // not reached: the loop always emits `samples` samples
+        for (; ns < P.iters; ++ns) { P.Es[(size_t)ns * Rp + r] = E; nextstep += st; }   // not reached: the loop always emits `samples` samples
         staged_its = accepted;
         P.t_out[r] = t;
+        sf[SF_TIME] = t; sf[SF_NEXT] = nextstep; sq[SI_ND] = (long long)nd;
     }
     if (P.mode == 1) {
         // bklMC (RRRMC.jl:311-359): rand_skip (DeltaE.jl:319-325), rand_move, apply_step_bkl! = apply_move! over all spins
-        long long it = 0, nextstep = P.step, m = 0;
-        while (it < P.iters) {
-            m += 1;
-            const uint64_t g = P.g0 + (uint64_t)m;
+        // (a resumed call continues the run's loop with `iters` more iterations allowed; the pending move is drawn again: same draw)
+        long long it = 0, nextstep = P.step, m = 0, limit = P.iters;
+        if (resume) { it = sq[SI_IT]; nextstep = sq[SI_NEXT]; m = sq[SI_M]; limit += sq[SI_LIMIT]; }
+        while (it < limit) {
+            const uint64_t g = P.g0 + (uint64_t)(m + 1);
             const Philox4 o3 = philox4x32_10((uint32_t)g, (uint32_t)(g >> 32), rep, TAG_RRR | (2u << 8), P.k0, P.k1);
             const double us = (double)((((uint64_t)o3.w[0] << 32) | o3.w[1]) >> 11) * 0x1.0p-53;
             double b = c.z / (double)N;
@@ -912,7 +949,7 @@ __global__ __launch_bounds__(kRrrThreads) void rrr_skn_kernel(RrrSkParams P)
             while (it + skip + 1 >= nextstep) {
                 P.Es[(size_t)ns * Rp + r] = E; ns += 1;
                 nextstep += P.step;
-                if (nextstep > P.iters) { out = true; break; }
+                if (nextstep > limit) { out = true; break; }
             }
             if (out) break;
             c.flip(move);
@@ -928,13 +965,15 @@ __global__ __launch_bounds__(kRrrThreads) void rrr_skn_kernel(RrrSkParams P)
                 P.dEs[(size_t)j * Rp + r] = d;
                 c.set(j, prior_of(P.beta * d));
             }
+            m += 1;
             it += skip + 1;
             E += dE;
             accepted += 1;
         }
         staged_its = accepted;
+        sq[SI_IT] = it; sq[SI_NEXT] = nextstep; sq[SI_M] = m; sq[SI_LIMIT] = limit;
     }
-    long long next_sample = P.step;          // iterations k * step: a counter instead of a 64-bit modulo per iteration
+    long long next_sample = P.S.samp0;       // iterations k * step of the run: a counter instead of a 64-bit modulo per iteration
     for (long long it = 1; P.mode == 0 && it <= P.iters && !bad; ++it) {
         if (it == next_sample) { next_sample += P.step; P.Es[(size_t)ns * Rp + r] = E; ns += 1; }
         const uint64_t g = P.g0 + (uint64_t)it;
@@ -1014,6 +1053,8 @@ __global__ __launch_bounds__(kRrrThreads) void rrr_skn_kernel(RrrSkParams P)
     P.stats[(size_t)r * 2 + 1] = staged_its;
     P.status[r] = bad;
     P.z_out[r] = c.z;
+    sf[SF_E] = E; sf[SF_Z] = c.z; sf[SF_ACC] = acc_rate;
+    sq[SI_CUR] = c.cur; sq[SI_MLAST] = c.move_last; sq[SI_TREF] = c.trefresh;
 }
 
 // layout changes between the SK sweep kernel's spins ([G8][N] bytes, bit = replica & 7) and this kernel's ([W][Rp] words)
@@ -1045,6 +1086,19 @@ __global__ __launch_bounds__(64) void eo_sk_wave_kernel(RrrSkParams P)
     auto dEv = [&](double lfv) { return P.sN > 0.0 ? lfv / P.sN : lfv; };
     for (int w = lane; w < W; w += 64) sp[w] = P.spins[(size_t)w * Rp + r];
     __syncthreads();
+    double* const sf = P.S.sf + (size_t)r * kSmpF;
+    long long* const sq = P.S.si + (size_t)r * kSmpI;
+    const bool resume = P.S.resume != 0;
+    double E;
+    int move_last = -1;
+    if (resume) {
+        // a resumed call: the two field arrays, move_last, E, Emin / itmin as the previous call left them (lfA = lfields, lfB = lfields_last);
+        // the ranking is a function of the fields and of the last move's tie keys: it is re-established below
+        for (int i = lane; i < N; i += 64) { fa[i] = P.lfA[(size_t)i * Rp + r]; fb[i] = P.lfB[(size_t)i * Rp + r]; }
+        E = sf[SF_E];
+        move_last = (int)sq[SI_MLAST];
+        __syncthreads();
+    } else {
     // energy(X, C) (SK.jl:212-237): a row per lane, the row sums in row order
     for (int i = lane; i < N; i += 64) {
         const int si = sbit(i);
@@ -1061,9 +1115,9 @@ __global__ __launch_bounds__(64) void eo_sk_wave_kernel(RrrSkParams P)
         const int m = N - base < 64 ? N - base : 64;
         for (int l = 0; l < m; ++l) n -= __shfl(h, l);
     }
-    double E = n / 2;
+    E = n / 2;
     if (P.sN > 0.0) E = E / P.sN;
-    int move_last = -1;
+    }
 
     auto less = [&](int a, int b) {
         const double xa = val[a], xb = val[b];
@@ -1116,12 +1170,14 @@ __global__ __launch_bounds__(64) void eo_sk_wave_kernel(RrrSkParams P)
         __syncthreads();
         sort_all();
     };
-    rerank(0, false);
+    // (resumed: the ranking after the run's last move, iteration P.g0 of the streams — the same sort of the same values and keys)
+    if (resume && P.S.it0 > 0) rerank(P.g0, true); else rerank(0, false);
 
     uint32_t* cm = P.cmin + (size_t)r * W;
-    for (int w = lane; w < W; w += 64) cm[w] = sp[w];
     double Emin = E;
-    long long itmin = 0, ns = 0, next_sample = P.step;
+    long long itmin = 0, ns = 0, next_sample = P.S.samp0;
+    if (resume) { Emin = sf[SF_EMIN]; itmin = sq[SI_ITMIN]; }
+    else for (int w = lane; w < W; w += 64) cm[w] = sp[w];
     const double z = P.ftau[N - 1];
     for (long long it = 1; it <= P.iters; ++it) {
         if (it == next_sample) { next_sample += P.step; if (lane == 0) P.Es[(size_t)ns * Rp + r] = E; ns += 1; }
@@ -1158,17 +1214,19 @@ __global__ __launch_bounds__(64) void eo_sk_wave_kernel(RrrSkParams P)
         rerank(g, true);
         E += dE;
         if (E < Emin) {
-            Emin = E; itmin = it;
+            Emin = E; itmin = P.S.it0 + it;
             for (int w = lane; w < W; w += 64) cm[w] = sp[w];
         }
     }
     __syncthreads();
     for (int w = lane; w < W; w += 64) P.spins[(size_t)w * Rp + r] = sp[w];
+    for (int i = lane; i < N; i += 64) { P.lfA[(size_t)i * Rp + r] = fa[i]; P.lfB[(size_t)i * Rp + r] = fb[i]; }
     if (lane == 0) {
         P.E_cur[r] = E;
         P.stats[(size_t)r * 2] = P.iters; P.stats[(size_t)r * 2 + 1] = itmin;
         P.t_out[r] = Emin;
         P.status[r] = 0;
+        sf[SF_E] = E; sf[SF_EMIN] = Emin; sq[SI_ITMIN] = itmin; sq[SI_MLAST] = move_last;
     }
 }
 
@@ -1237,6 +1295,7 @@ struct RrrSparseParams {
     uint32_t k0, k1, replica0;
     LevTable lv;
     int N, K, L, W, R, Rpad, mode;      // mode 0 = rrrMC, 1 = bklMC
+    SmpState S;
 };
 
 // LDS = true (one replica per workgroup, see rrr_sparse_kernel): spins, classes, positions and the neighbour table (as 16-bit ids)
@@ -1393,12 +1452,22 @@ __global__ __launch_bounds__(kRrrThreads) void rrr_sparse_kernel(RrrSparseParams
         l_rng = reinterpret_cast<uint32_t*>(l_J + ((NK + 3) & ~3));                       // [64][8]
         for (int i = tid; i < P.W; i += nt) l_sp[i] = g_sp[i];
         for (int i = tid; i < NK; i += nt) { l_A[i] = (uint16_t)P.A[i]; l_J[i] = P.J[i]; }
+        if (P.S.resume)                          // the positions and classes the previous call wrote back
+            for (int i = tid; i < N; i += nt) { l_spos[i] = (uint16_t)g_spos[i]; l_cls[i] = g_cls[i]; }
         __syncthreads();
         c.sp = l_sp; c.spos = reinterpret_cast<IDX*>(l_spos); c.cls = l_cls; c.A16 = l_A; c.Jl = l_J;
     }
     const bool worker = !LDS || threadIdx.x == 0;
     long long E = 0, accepted = 0, staged_its = 0, ns = 0, itdone = 0;
-    if (worker) {
+    double* const sf = P.S.sf + (size_t)r * kSmpF;
+    long long* const si = P.S.si + (size_t)r * kSmpI;
+    if (worker && P.S.resume) {
+        // a resumed call: the cache is where the previous call left it (member order, T, z: DeltaE.jl:63-73), E is the tracked energy
+#pragma unroll
+        for (int k = 0; k < 2 * SLM; ++k) { c.t[k] = (int)si[SI_T0 + k]; c.T[k] = sf[SF_T0 + k]; }
+        c.z = sf[SF_Z];
+        E = P.E_cur[r];
+    } else if (worker) {
     // energy(X, C) and gen_ΔEcache in site order (RRRMC.jl:177-178, DeltaE.jl:74-103)
     long long n = 0;
 #pragma unroll
@@ -1422,8 +1491,8 @@ __global__ __launch_bounds__(kRrrThreads) void rrr_sparse_kernel(RrrSparseParams
 
     const uint32_t rep = P.replica0 + (uint32_t)r;
     if (P.mode == 0) {
-        double acc_rate = 0.5;
-        long long next_sample = P.step;          // iterations k * step: a counter instead of a 64-bit modulo per iteration
+        double acc_rate = (worker && P.S.resume) ? sf[SF_ACC] : 0.5;
+        long long next_sample = P.S.samp0;       // iterations k * step of the run: a counter instead of a 64-bit modulo per iteration
         for (long long base = 0; base < P.iters; base += (LDS ? (long long)kRrrThreads : (long long)P.iters)) {
         if constexpr (LDS) {                     // the draws of the next 64 iterations, one iteration per lane
             __syncthreads();
@@ -1504,11 +1573,14 @@ __global__ __launch_bounds__(kRrrThreads) void rrr_sparse_kernel(RrrSparseParams
         }
         }
         itdone = P.iters;
+        if (worker) sf[SF_ACC] = acc_rate;
     } else if (worker) {
-        long long it = 0, nextstep = P.step, m = 0;
-        while (it < P.iters) {
-            m += 1;
-            const uint64_t g = P.g0 + (uint64_t)m;
+        // a resumed call continues the loop of the run (RRRMC.jl:327-350) with `iters` more iterations allowed: `it`, `nextstep` and the
+        // number of moves made carry on; the draw of the move that was pending at the cut is taken again — same counter, same cache, same draw
+        long long it = 0, nextstep = P.step, m = 0, limit = P.iters;
+        if (P.S.resume) { it = si[SI_IT]; nextstep = si[SI_NEXT]; m = si[SI_M]; limit += si[SI_LIMIT]; }
+        while (it < limit) {
+            const uint64_t g = P.g0 + (uint64_t)(m + 1);
             const Philox4 o3 = philox4x32_10((uint32_t)g, (uint32_t)(g >> 32), rep, TAG_RRR | (2u << 8), P.k0, P.k1);
             const double us = (double)((((uint64_t)o3.w[0] << 32) | o3.w[1]) >> 11) * 0x1.0p-53;
             const double skipf = floor(__ddiv_rn(det_log1p(-us), det_log1p(-__ddiv_rn(c.z, (double)N))));     // rand_skip, DeltaE.jl:141-144
@@ -1522,21 +1594,26 @@ __global__ __launch_bounds__(kRrrThreads) void rrr_sparse_kernel(RrrSparseParams
             while (it + skip + 1 >= nextstep) {
                 P.Es[(size_t)ns * P.Rpad + r] = (int32_t)E; ns += 1;
                 nextstep += P.step;
-                if (nextstep > P.iters) { out = true; break; }
+                if (nextstep > limit) { out = true; break; }
             }
             if (out) break;
             c.apply_move(move);
+            m += 1;
             it += skip + 1;
             E += dE;
             accepted += 1;
         }
         staged_its = accepted;
         itdone = it;
+        si[SI_IT] = it; si[SI_NEXT] = nextstep; si[SI_M] = m; si[SI_LIMIT] = limit;
     }
     if (worker) {
         P.E_cur[r] = (int32_t)E;
         P.acc_cur[r] = accepted;
         P.stats[(size_t)r * 3] = accepted; P.stats[(size_t)r * 3 + 1] = staged_its; P.stats[(size_t)r * 3 + 2] = itdone;
+#pragma unroll
+        for (int k = 0; k < 2 * SLM; ++k) { si[SI_T0 + k] = c.t[k]; sf[SF_T0 + k] = c.T[k]; }
+        sf[SF_Z] = c.z;
     }
     if constexpr (LDS) {
         __syncthreads();
@@ -1570,6 +1647,8 @@ struct WtmParams {
     int64_t samples;
     uint32_t k0, k1, replica0, call;
     int N, K, W, R, Rpad;
+    SmpState S;
+    int64_t samples_before;  // samples the run had taken before this call (a resumed call: tmax = step * (samples_before + samples))
 };
 
 template <typename IDX>
@@ -1646,6 +1725,15 @@ __global__ __launch_bounds__(kRrrThreads) void wtm_sparse_kernel(WtmParams P)
     c.sp = P.spins + (size_t)r * P.W; c.ht = P.ht + (size_t)r * N; c.hid = static_cast<IDX*>(P.hid) + (size_t)r * N; c.hpos = static_cast<IDX*>(P.hpos) + (size_t)r * N;
     c.rep = P.replica0 + (uint32_t)r;
     c.nd = 0;
+    double* const sf = P.S.sf + (size_t)r * kSmpF;
+    long long* const si = P.S.si + (size_t)r * kSmpI;
+    const double step = P.step, tmax = step * (double)(P.samples_before + P.samples);
+    double t = 0.0, nextstep = step;
+    long long E;
+    if (P.S.resume) {
+        // a resumed call: the heap, the global time and the next sample time of the run carry on (RRRMC.jl:396-416), with `samples` more
+        E = P.E_cur[r]; t = sf[SF_TIME]; nextstep = sf[SF_NEXT]; c.nd = (uint64_t)si[SI_ND];
+    } else {
     // E = energy(X, C); theap = THeap(X, C, beta): one waiting time per spin, in site order (WaitingTimes.jl:26-36)
     long long n = 0;
     for (int i = 0; i < N; ++i) {
@@ -1656,9 +1744,8 @@ __global__ __launch_bounds__(kRrrThreads) void wtm_sparse_kernel(WtmParams P)
         c.hpos[i] = (IDX)i;
     }
     for (int pos = N / 2 - 1; pos >= 0; --pos) c.sift_down(pos, N);
-    long long E = n / 2;
-    const double step = P.step, tmax = step * (double)P.samples;
-    double t = 0.0, nextstep = step;
+    E = n / 2;
+    }
     long long moves = 0, ns = 0;
     bool out = false;
     while (t < tmax && !out) {
@@ -1685,10 +1772,11 @@ __global__ __launch_bounds__(kRrrThreads) void wtm_sparse_kernel(WtmParams P)
         E += d;
         moves += 1;
     }
-    for (; ns < P.samples; ++ns) P.Es[(size_t)ns * P.Rpad + r] = (int32_t)E;     // not reached: the loop always emits `samples` samples
+    for (; ns < P.samples; ++ns) { P.Es[(size_t)ns * P.Rpad + r] = (int32_t)E; nextstep += step; }     // not reached: the loop always emits `samples` samples
     P.E_cur[r] = (int32_t)E;
     P.acc_cur[r] = moves;
     P.t_out[r] = t;
+    sf[SF_TIME] = t; sf[SF_NEXT] = nextstep; si[SI_ND] = (long long)c.nd;
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1714,6 +1802,7 @@ struct EoParams {
     uint32_t k0, k1, replica0;
     LevTable lv;
     int N, K, L, has_zero, W, R, Rpad;
+    SmpState S;
 };
 
 template <typename IDX>
@@ -1743,6 +1832,13 @@ __global__ __launch_bounds__(kRrrThreads) void eo_sparse_kernel(EoParams P)
         const int ak = P.lv.find(d < 0 ? -d : d) + 1;
         return (d >= 0 ? ak + L - P.has_zero : L + 1 - ak) - 1;
     };
+    long long* const si = P.S.si + (size_t)r * kSmpI;
+    long long E, Emin, itmin, ns = 0;
+    if (P.S.resume) {
+        // a resumed call: the EOCache (classes, member order), E, Emin / Cmin / itmin of the run carry on (RRRMC.jl:486-516)
+        for (int k = 0; k < K2; ++k) t[k] = (int)si[SI_T0 + k];
+        E = P.E_cur[r]; Emin = si[SI_EMIN]; itmin = si[SI_ITMIN];
+    } else {
     long long n = 0;
     for (int k = 0; k < K2; ++k) t[k] = 0;
     for (int i = 0; i < N; ++i) {
@@ -1754,11 +1850,12 @@ __global__ __launch_bounds__(kRrrThreads) void eo_sparse_kernel(EoParams P)
         spos[i] = (IDX)t[k];
         t[k] += 1;
     }
-    long long E = n / 2, Emin = E, itmin = 0, ns = 0;
+    E = n / 2; Emin = E; itmin = 0;
     for (int w = 0; w < P.W; ++w) cm[w] = sp[w];
+    }
     const double z = P.ftau[N - 1];
     const uint32_t rep = P.replica0 + (uint32_t)r;
-    long long next_sample = P.step;          // iterations k * step: a counter instead of a 64-bit modulo per iteration
+    long long next_sample = P.S.samp0;       // iterations k * step of the run: a counter instead of a 64-bit modulo per iteration
     for (long long it = 1; it <= P.iters; ++it) {
         if (it == next_sample) { next_sample += P.step; P.Es[(size_t)ns * P.Rpad + r] = (int32_t)E; ns += 1; }
         const uint64_t g = P.g0 + (uint64_t)it;
@@ -1792,12 +1889,14 @@ __global__ __launch_bounds__(kRrrThreads) void eo_sparse_kernel(EoParams P)
         }
         E += dE;
         if (E < Emin) {
-            Emin = E; itmin = it;
+            Emin = E; itmin = P.S.it0 + it;
             for (int w = 0; w < P.W; ++w) cm[w] = sp[w];
         }
     }
     P.E_cur[r] = (int32_t)E;
     P.stats[(size_t)r * 3] = Emin; P.stats[(size_t)r * 3 + 1] = itmin; P.stats[(size_t)r * 3 + 2] = P.iters;
+    for (int k = 0; k < K2; ++k) si[SI_T0 + k] = t[k];
+    si[SI_EMIN] = Emin; si[SI_ITMIN] = itmin;
 }
 
 // ---------------------------------------------------------------------------------------------------

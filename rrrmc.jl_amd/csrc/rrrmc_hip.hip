@@ -270,6 +270,20 @@ struct rrrmc_ctx {
     bool std_cache_live = false;        // the model's cache (fields, undo record) and tracked energy describe the current configuration
     int32_t* db_mlast = nullptr;        // [R] move_last of the residual cache (RRRMC_MODEL_SPARSE_DISCRETIZED), kept across resumed calls
 
+    // ---- resumed rrrMC / bklMC / wtmMC / extremal_opt calls (rrrmc_set_resume): the RUN whose chain state is live on the device ----
+    // (the cache arrays of the sampler's kernels plus the two scalar slabs of rrr_kernels.hpp: SmpState)
+    int smp_kind = 0;                   // 0 none, 1 rrrMC, 2 bklMC, 3 wtmMC, 4 extremal_opt
+    double smp_par[4] = {0, 0, 0, 0};   // the run's parameters: beta, staged_thr (wtmMC: step), staged_thr_fact, fourK
+    int64_t smp_step = 0;               // bklMC: step (part of the loop's state: nextstep advances by it)
+    uint64_t smp_g0 = 0;                // it_done when the run began (bklMC numbers its moves from there)
+    int64_t smp_it = 0;                 // iterations of the run so far (wtmMC: samples)
+    uint32_t smp_call = 0;              // wtmMC: the WTM stream's call number of the run
+    int smp_build = 0;                  // which kernel build holds the state, where the builds' layouts differ (cont_wave_kernel = 1)
+    std::vector<double> smp_ftau;       // extremal_opt: the run's rank table
+    double* smp_f = nullptr;            // [R][kSmpF]
+    long long* smp_i = nullptr;         // [R][kSmpI]
+    double* cs_top = nullptr;           // cont_wave_kernel: [R][N2 / 16] LDS levels of the sampler's tree between calls
+
     // ---- multi-device context (rrrmc_ctx_create_multi): no device state of its own; one child context per device (own stream), replica
     //      shards of whole 32-replica groups in global-id order; every entry point forwards to the children ----
     // ---- debug mode (rrrmc_set_debug_checks): the reference's latent consistency checks (src/graphs/RRG.jl:229-231, SK.jl:268-273),
@@ -498,6 +512,39 @@ int32_t debug_check_pm1(rrrmc_ctx* ctx)
     HIP_TRY(ctx, hipGetLastError());
     return RRRMC_OK;
 }
+// ---- resumed calls of the reduced-rejection samplers ---------------------------------------------------------------------------------
+// anything that changes the configuration, the disorder, the streams' position or the caches behind the samplers' back ends the run
+inline void smp_drop(rrrmc_ctx* ctx) { if (ctx) ctx->smp_kind = 0; }
+// Start of a sampler call of `kind` with the given parameters: *S describes it to the kernel.  The call CONTINUES the live run when the
+// context is in resume mode and the run is of the same sampler with the same parameters (the weights of the cache depend on them);
+// otherwise it starts a run as a reference call does: energy(X, C), a fresh cache (src/RRRMC.jl:175-178).
+int32_t smp_begin(rrrmc_ctx* ctx, int kind, double p0, double p1, double p2, double p3, int64_t step, const double* ftau, SmpState* S)
+{
+    if (!ctx->smp_f) {
+        HIP_TRY(ctx, hipMalloc(&ctx->smp_f, sizeof(double) * (size_t)ctx->R * kSmpF));
+        HIP_TRY(ctx, hipMalloc(&ctx->smp_i, sizeof(long long) * (size_t)ctx->R * kSmpI));
+        HIP_TRY(ctx, hipMemsetAsync(ctx->smp_f, 0, sizeof(double) * (size_t)ctx->R * kSmpF, ctx->stream));
+        HIP_TRY(ctx, hipMemsetAsync(ctx->smp_i, 0, sizeof(long long) * (size_t)ctx->R * kSmpI, ctx->stream));
+    }
+    bool cont = ctx->resume && ctx->smp_kind == kind && ctx->smp_par[0] == p0 && ctx->smp_par[1] == p1 && ctx->smp_par[2] == p2 &&
+                ctx->smp_par[3] == p3 && (kind != 2 || ctx->smp_step == step);
+    if (cont && kind == 4)
+        cont = ctx->smp_ftau.size() == (size_t)ctx->N && std::memcmp(ctx->smp_ftau.data(), ftau, sizeof(double) * (size_t)ctx->N) == 0;
+    ctx->smp_kind = 0;                  // live again once the call has been queued (smp_commit)
+    if (!cont) {
+        ctx->smp_par[0] = p0; ctx->smp_par[1] = p1; ctx->smp_par[2] = p2; ctx->smp_par[3] = p3;
+        ctx->smp_step = step; ctx->smp_g0 = ctx->it_done; ctx->smp_it = 0; ctx->smp_call = ctx->wtm_calls; ctx->smp_build = 0;
+        if (kind == 4) ctx->smp_ftau.assign(ftau, ftau + ctx->N);
+    }
+    S->sf = ctx->smp_f; S->si = ctx->smp_i; S->resume = cont ? 1 : 0;
+    S->it0 = ctx->smp_it;
+    S->samp0 = step > 0 ? step - ctx->smp_it % step : 1;
+    return RRRMC_OK;
+}
+// samples a call of `n` more iterations takes, the run being at iteration smp_it (multiples of `step` of the RUN's iteration count)
+inline int64_t smp_nsamp(const rrrmc_ctx* ctx, int64_t n, int64_t step) { return (ctx->smp_it + n) / step - ctx->smp_it / step; }
+inline void smp_commit(rrrmc_ctx* ctx, int kind, int64_t n) { ctx->smp_kind = kind; ctx->smp_it += n; }
+
 #include "host_sk.hpp"
 #include "host_spf.hpp"
 #include "host_dbl.hpp"
@@ -814,6 +861,7 @@ void rrrmc_ctx_destroy(rrrmc_ctx* ctx)
     free_dev(ctx->db_dJ); free_dev(ctx->db_rJ); free_dev(ctx->db_cls); free_dev(ctx->db_sv); free_dev(ctx->db_spos); free_dev(ctx->db_lf); free_dev(ctx->db_undo); free_dev(ctx->db_mlast);
     free_dev(ctx->pff_table); free_dev(ctx->pff_absJ); free_dev(ctx->pff_bond_off); free_dev(ctx->pff_thr_hi); free_dev(ctx->pff_thr_lo); free_dev(ctx->pff_flags);
     free_dev(ctx->wt_t); free_dev(ctx->wt_id); free_dev(ctx->wt_pos); free_dev(ctx->wt_time);
+    free_dev(ctx->smp_f); free_dev(ctx->smp_i); free_dev(ctx->cs_top);
     free_dev(ctx->eo_cmin); free_dev(ctx->eo_ftau);
     free_dev(ctx->q_Jb); free_dev(ctx->q_slf); free_dev(ctx->q_smv); free_dev(ctx->q_scur);
     free_dev(ctx->cs_spins); free_dev(ctx->cs_buf); free_dev(ctx->cs_u16);
@@ -837,6 +885,7 @@ void rrrmc_ctx_destroy(rrrmc_ctx* ctx)
 int32_t rrrmc_set_graph(rrrmc_ctx* ctx, const int32_t* A, const int8_t* J)
 {
     RRRMC_MULTI(ctx, false, rrrmc_set_graph(c, A, J));
+    smp_drop(ctx);
     if (!ctx) return RRRMC_ERR_INVALID_ARG;
     if (ctx->model != RRRMC_MODEL_SPARSE_PM1 && ctx->model != RRRMC_MODEL_QUANT_RRG)
         return fail(ctx, RRRMC_ERR_STATE, "rrrmc_set_graph is for sparse +-J models; use rrrmc_set_couplings_dense");
@@ -905,6 +954,7 @@ int32_t rrrmc_set_graph(rrrmc_ctx* ctx, const int32_t* A, const int8_t* J)
 int32_t rrrmc_seed(rrrmc_ctx* ctx, uint64_t seed)
 {
     RRRMC_MULTI(ctx, false, rrrmc_seed(c, seed));
+    smp_drop(ctx);
     if (!ctx) return RRRMC_ERR_INVALID_ARG;
     ctx->seed = seed;
     ctx->seeded = true;
@@ -914,11 +964,13 @@ int32_t rrrmc_seed(rrrmc_ctx* ctx, uint64_t seed)
     return RRRMC_OK;
 }
 
+int64_t rrrmc_results_samples(const rrrmc_ctx* ctx) { return !ctx ? -1 : is_multi(ctx) ? ctx->kids[0]->nsamp : ctx->nsamp; }
 int64_t rrrmc_iterations_done(const rrrmc_ctx* ctx) { return !ctx ? -1 : is_multi(ctx) ? (int64_t)ctx->kids[0]->it_done : (int64_t)ctx->it_done; }
 
 int32_t rrrmc_init_spins_random(rrrmc_ctx* ctx)
 {
     RRRMC_MULTI(ctx, false, rrrmc_init_spins_random(c));
+    smp_drop(ctx);
     if (!ctx) return RRRMC_ERR_INVALID_ARG;
     ctx->std_cache_live = false;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -962,6 +1014,7 @@ int32_t rrrmc_init_spins_random(rrrmc_ctx* ctx)
 int32_t rrrmc_set_spins(rrrmc_ctx* ctx, const uint64_t* chunks)
 {
     RRRMC_MULTI(ctx, true, rrrmc_set_spins(c, at_row(chunks, r0 * nch_of(ctx))));
+    smp_drop(ctx);
     if (ctx) ctx->std_cache_live = false;
     if (!ctx) return RRRMC_ERR_INVALID_ARG;
     if (!chunks) return fail(ctx, RRRMC_ERR_INVALID_ARG, "chunks is NULL");
@@ -1053,6 +1106,7 @@ int32_t rrrmc_get_spins(rrrmc_ctx* ctx, uint64_t* chunks)
 int32_t rrrmc_energy(rrrmc_ctx* ctx, int64_t* E_out)
 {
     RRRMC_MULTI(ctx, true, rrrmc_energy(c, at_row(E_out, r0)));
+    smp_drop(ctx);
     int32_t rc = ensure_state(ctx, true);
     if (rc) return rc;
     if (!sparse_int_model(ctx)) return fail(ctx, RRRMC_ERR_STATE, "this model's energies are Float64: use the _f64 entry point");
@@ -1070,6 +1124,7 @@ int32_t rrrmc_energy(rrrmc_ctx* ctx, int64_t* E_out)
 int32_t rrrmc_get_fields(rrrmc_ctx* ctx, int64_t* lfields_out)
 {
     RRRMC_MULTI(ctx, true, rrrmc_get_fields(c, at_row(lfields_out, r0 * ctx->N)));
+    smp_drop(ctx);
     int32_t rc = ensure_state(ctx, true);
     if (rc) return rc;
     if (ctx->model == RRRMC_MODEL_SK_BINARY) {       // the live integer cache, lfields = sqrt(N) * delta_energy (SK.jl:137-140)
@@ -1125,6 +1180,7 @@ int32_t ensure_big_buffers(rrrmc_ctx* ctx)
 int32_t rrrmc_standard_mc_async(rrrmc_ctx* ctx, double beta, int64_t iters, int64_t step)
 {
     RRRMC_MULTI(ctx, false, rrrmc_standard_mc_async(c, beta, iters, step));
+    smp_drop(ctx);
     int32_t rc = ensure_state(ctx, true);
     if (rc) return rc;
     if (ctx->model == RRRMC_MODEL_SK_NORMAL || ctx->model == RRRMC_MODEL_SK_BINARY) return sk_standard_mc_async(ctx, beta, iters, step);
@@ -1316,6 +1372,7 @@ int32_t rrrmc_standard_mc_async(rrrmc_ctx* ctx, double beta, int64_t iters, int6
 int32_t rrrmc_standard_mc_fast_async(rrrmc_ctx* ctx, double beta, int64_t iters, int64_t step)
 {
     RRRMC_MULTI(ctx, false, rrrmc_standard_mc_fast_async(c, beta, iters, step));
+    smp_drop(ctx);
     int32_t rc = ensure_state(ctx, true);
     if (rc) return rc;
     if (ctx->model != RRRMC_MODEL_SPARSE_F64)
@@ -1345,12 +1402,28 @@ int32_t rrrmc_tracked_energy_f64(rrrmc_ctx* ctx, double* E_out)
 {
     RRRMC_MULTI(ctx, true, rrrmc_tracked_energy_f64(c, at_row(E_out, r0)));
     if (!ctx || !E_out) return RRRMC_ERR_INVALID_ARG;
-    if (sparse_int_model(ctx)) return fail(ctx, RRRMC_ERR_STATE, "integer models: the tracked energy equals rrrmc_energy exactly");
-    if (!ctx->std_cache_live || !ctx->sk_E) return fail(ctx, RRRMC_ERR_STATE, "no standardMC call has left a tracked energy");
+    if (sparse_int_model(ctx)) return fail(ctx, RRRMC_ERR_STATE, "integer models: use rrrmc_tracked_energy");
+    if ((!ctx->std_cache_live && ctx->smp_kind == 0) || !ctx->sk_E) return fail(ctx, RRRMC_ERR_STATE, "no sampler call has left a tracked energy");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     std::vector<double> E((size_t)ctx->Rpad);
     HIP_TRY(ctx, hipMemcpy(E.data(), ctx->sk_E, sizeof(double) * (size_t)(ctx->model == RRRMC_MODEL_QUANT_RRG || ctx->model == RRRMC_MODEL_SPARSE_DISCRETIZED ? ctx->R : ctx->Rpad), hipMemcpyDeviceToHost));
+    for (int64_t r = 0; r < ctx->R; ++r) E_out[r] = E[(size_t)r];
+    return RRRMC_OK;
+}
+
+// the integer models' tracked energy (level units): what the last sampler call left in E — equal to rrrmc_energy for these models, but
+// read without touching the device state a resumed call continues from
+int32_t rrrmc_tracked_energy(rrrmc_ctx* ctx, int64_t* E_out)
+{
+    RRRMC_MULTI(ctx, true, rrrmc_tracked_energy(c, at_row(E_out, r0)));
+    if (!ctx || !E_out) return RRRMC_ERR_INVALID_ARG;
+    if (!sparse_int_model(ctx)) return fail(ctx, RRRMC_ERR_STATE, "this model's energies are Float64: use rrrmc_tracked_energy_f64");
+    if (!ctx->results_valid || !ctx->d_E) return fail(ctx, RRRMC_ERR_STATE, "no sampler call has left a tracked energy");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    std::vector<int32_t> E((size_t)ctx->Rpad);
+    HIP_TRY(ctx, hipMemcpy(E.data(), ctx->d_E, sizeof(int32_t) * (size_t)ctx->Rpad, hipMemcpyDeviceToHost));
     for (int64_t r = 0; r < ctx->R; ++r) E_out[r] = E[(size_t)r];
     return RRRMC_OK;
 }
@@ -1577,6 +1650,7 @@ int32_t rrrmc_colored_count_accepted(rrrmc_ctx* ctx, int32_t on)
 int32_t rrrmc_colored_sweeps_async(rrrmc_ctx* ctx, double beta, int64_t sweeps, int64_t step)
 {
     RRRMC_MULTI(ctx, false, rrrmc_colored_sweeps_async(c, beta, sweeps, step));
+    smp_drop(ctx);
     if (ctx) ctx->std_cache_live = false;
     int32_t rc = ensure_state(ctx, true);
     if (rc) return rc;
@@ -1779,7 +1853,12 @@ int32_t quant_mc_async(rrrmc_ctx* ctx, bool standard, double beta, double fourK,
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     ctx->results_valid = false; ctx->last_call_wtm = false; ctx->last_call_eo = false;
     ctx->timing_valid = false;
-    const int64_t nsamp = iters / step;
+    // rrrMC: a resumed call finds the DeltaECache (classes, the four sets in member order, T, z), the slice caches, E and acc_rate in
+    // the arrays every build of the kernel reads and writes back: it only skips energy(X, C) + gen_ΔEcache (quant_run_init)
+    SmpState S{};
+    if (!standard) { rc = smp_begin(ctx, 1, beta, staged_thr, staged_thr_fact, fourK, step, nullptr, &S); if (rc) return rc; }
+    else S.samp0 = step;
+    const int64_t nsamp = standard ? iters / step : smp_nsamp(ctx, iters, step);
     const size_t es_need = (size_t)(nsamp > 0 ? nsamp : 1) * ctx->R;
     if (es_need > ctx->sk_Es_cap) {
         free_dev(ctx->sk_Es);
@@ -1796,13 +1875,14 @@ int32_t quant_mc_async(rrrmc_ctx* ctx, bool standard, double beta, double fourK,
     HIP_TRY(ctx, hipEventRecord(ctx->ev_begin, st));
     ctx->last_beta = beta; ctx->last_fourK = fourK;
     ctx->stats_stride = 2;
-    const bool cont = standard && ctx->resume && ctx->std_cache_live;      // a resumed standardMC keeps the tracked energy (no cache)
+    const bool cont = (standard && ctx->resume && ctx->std_cache_live) || S.resume;      // a resumed standardMC keeps the tracked energy (no cache)
     if (!cont) { rc = quant_run_init(ctx, beta, fourK); if (rc) return rc; }
+    else if (!standard) HIP_TRY(ctx, hipMemsetAsync(ctx->q_stats, 0, sizeof(int64_t) * (size_t)ctx->R * 2, st));      // accepted / staged counts are per call
     RrrParams P = quant_params(ctx, beta, fourK);
     P.ft1 = host_det_exp(-beta * fourK);
     P.staged_thr = staged_thr;
     P.lambda = staged_thr_fact / (double)ctx->N;              // RRRMC.jl:243
-    P.g0 = ctx->it_done; P.iters = iters; P.step = step;
+    P.g0 = ctx->it_done; P.iters = iters; P.step = step; P.samp0 = S.samp0;
     HIP_TRY(ctx, hipEventRecord(ctx->ev_sweep[0], st));
     if (standard) {
         // few replicas (the reference's test_QIsing runs a handful): one wavefront per replica, 64 iterations prepared at a time
@@ -1871,6 +1951,7 @@ int32_t quant_mc_async(rrrmc_ctx* ctx, bool standard, double beta, double fourK,
     ctx->sweep_launches = 1;
     ctx->nsamp = nsamp;
     ctx->it_done += (uint64_t)iters;
+    if (!standard) smp_commit(ctx, 1, iters);
     ctx->results_valid = true;
     ctx->timing_valid = true;
     ctx->last_call_rrr = true;          // accepted counts live in q_stats
@@ -1912,6 +1993,7 @@ int32_t rrrmc_bkl_mc_async(rrrmc_ctx* ctx, double beta, int64_t iters, int64_t s
 int32_t rrrmc_quant_slice_form(rrrmc_ctx* ctx, int32_t ea_form)
 {
     RRRMC_MULTI(ctx, false, rrrmc_quant_slice_form(c, ea_form));
+    smp_drop(ctx);
     if (!ctx) return RRRMC_ERR_INVALID_ARG;
     if (ctx->model != RRRMC_MODEL_QUANT_RRG || ctx->q_sk) return fail(ctx, RRRMC_ERR_STATE, "rrrmc_quant_slice_form is for a GraphQuant over GraphRRG / GraphEA slices");
     if (ctx->graph_set) return fail(ctx, RRRMC_ERR_STATE, "rrrmc_quant_slice_form must precede rrrmc_set_graph");
@@ -1922,6 +2004,7 @@ int32_t rrrmc_quant_slice_form(rrrmc_ctx* ctx, int32_t ea_form)
 int32_t rrrmc_quant_set_field(rrrmc_ctx* ctx, double beta, double fourK)
 {
     RRRMC_MULTI(ctx, false, rrrmc_quant_set_field(c, beta, fourK));
+    smp_drop(ctx);
     if (!ctx) return RRRMC_ERR_INVALID_ARG;
     if (ctx->model != RRRMC_MODEL_QUANT_RRG) return fail(ctx, RRRMC_ERR_STATE, "rrrmc_quant_set_field is for RRRMC_MODEL_QUANT_RRG");
     if (!(fourK > 0.0) || !std::isfinite(fourK) || !std::isfinite(beta)) return fail(ctx, RRRMC_ERR_INVALID_ARG, "beta and fourK must be finite, fourK > 0");
@@ -2028,12 +2111,23 @@ int32_t rrrmc_rrr_stats(rrrmc_ctx* ctx, int64_t* staged_iters_out)
 
 int32_t rrrmc_rrr_cache(rrrmc_ctx* ctx, int8_t* pos_out, int32_t* sizes_out)
 {
-    RRRMC_MULTI(ctx, true, rrrmc_rrr_cache(c, at_row(pos_out, r0 * ctx->N), at_row(sizes_out, r0 * (ctx->model == RRRMC_MODEL_SPARSE_DISCRETIZED ? 16 : 4))));
+    RRRMC_MULTI(ctx, true, rrrmc_rrr_cache(c, at_row(pos_out, r0 * ctx->N), at_row(sizes_out, r0 * (ctx->model == RRRMC_MODEL_QUANT_RRG ? 4 : 16))));
     if (!ctx) return RRRMC_ERR_INVALID_ARG;
-    if ((ctx->model != RRRMC_MODEL_QUANT_RRG && ctx->model != RRRMC_MODEL_SPARSE_DISCRETIZED) || !ctx->results_valid || !ctx->last_call_rrr)
+    if ((ctx->model != RRRMC_MODEL_QUANT_RRG && ctx->model != RRRMC_MODEL_SPARSE_DISCRETIZED && !sparse_int_model(ctx)) || !ctx->results_valid || !ctx->last_call_rrr)
         return fail(ctx, RRRMC_ERR_STATE, "no rrrMC call has been made");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (sparse_int_model(ctx)) {          // DeltaECache{Int,L} of rrrMC / bklMC on GraphRRG / GraphEA: classes from the kernels' class bytes, sizes from the run's slab
+        if ((ctx->smp_kind != 1 && ctx->smp_kind != 2) || !ctx->rp_cls) return fail(ctx, RRRMC_ERR_STATE, "no rrrMC / bklMC call has been made");
+        if (pos_out) HIP_TRY(ctx, hipMemcpy(pos_out, ctx->rp_cls, (size_t)ctx->R * ctx->N, hipMemcpyDeviceToHost));
+        if (sizes_out) {
+            std::vector<long long> si((size_t)ctx->R * kSmpI);
+            HIP_TRY(ctx, hipMemcpy(si.data(), ctx->smp_i, sizeof(long long) * si.size(), hipMemcpyDeviceToHost));
+            for (int64_t r = 0; r < ctx->R; ++r)
+                for (int k = 0; k < 16; ++k) sizes_out[r * 16 + k] = k < 2 * ctx->lv.L ? (int32_t)si[(size_t)r * kSmpI + SI_T0 + k] : 0;
+        }
+        return RRRMC_OK;
+    }
     if (ctx->model == RRRMC_MODEL_QUANT_RRG && !ctx->q_cache_valid) return fail(ctx, RRRMC_ERR_STATE, "no rrrMC call has been made");
     if (ctx->model == RRRMC_MODEL_SPARSE_DISCRETIZED) {      // sizes_out[R * 16]: counted from the classes
         if (!ctx->db_cache_valid) return fail(ctx, RRRMC_ERR_STATE, "no rrrMC call has been made");
@@ -2058,6 +2152,7 @@ int32_t rrrmc_rrr_cache(rrrmc_ctx* ctx, int8_t* pos_out, int32_t* sizes_out)
 int32_t rrrmc_set_couplings_dense(rrrmc_ctx* ctx, const double* J)
 {
     RRRMC_MULTI(ctx, false, rrrmc_set_couplings_dense(c, J));
+    smp_drop(ctx);
     if (!ctx) return RRRMC_ERR_INVALID_ARG;
     const bool qskn = ctx->model == RRRMC_MODEL_QUANT_RRG && ctx->q_skn;      // the slice graph of a GraphQSKNormalT: J is Nk x Nk
     if (ctx->model != RRRMC_MODEL_SK_NORMAL && !qskn) return fail(ctx, RRRMC_ERR_STATE, "rrrmc_set_couplings_dense is for RRRMC_MODEL_SK_NORMAL (or a GraphQuant over GraphSKNormal slices)");
@@ -2086,6 +2181,7 @@ int32_t rrrmc_set_couplings_dense(rrrmc_ctx* ctx, const double* J)
 int32_t rrrmc_energy_f64(rrrmc_ctx* ctx, double* E_out)
 {
     RRRMC_MULTI(ctx, true, rrrmc_energy_f64(c, at_row(E_out, r0)));
+    smp_drop(ctx);
     int32_t rc = ensure_state(ctx, true);
     if (rc) return rc;
     if (sparse_int_model(ctx)) return fail(ctx, RRRMC_ERR_STATE, "this model's energies are integers: use rrrmc_energy");
@@ -2180,6 +2276,7 @@ int32_t rrrmc_standard_mc_f64(rrrmc_ctx* ctx, double beta, int64_t iters, int64_
 int32_t rrrmc_set_couplings_bits(rrrmc_ctx* ctx, const uint64_t* Jc)
 {
     RRRMC_MULTI(ctx, false, rrrmc_set_couplings_bits(c, Jc));
+    smp_drop(ctx);
     if (!ctx) return RRRMC_ERR_INVALID_ARG;
     const bool qsk = ctx->model == RRRMC_MODEL_QUANT_RRG && ctx->q_sk;          // the slice graph of a GraphQSKT
     if (ctx->model != RRRMC_MODEL_SK_BINARY && !qsk)
@@ -2429,6 +2526,7 @@ int32_t rrrmc_set_graph_discretized(rrrmc_ctx* ctx, const int32_t* A, const int8
                                     int32_t ea_form)
 {
     RRRMC_MULTI(ctx, false, rrrmc_set_graph_discretized(c, A, dJ, rJ, lev, nlev, ea_form));
+    smp_drop(ctx);
     if (!ctx) return RRRMC_ERR_INVALID_ARG;
     if (ctx->model != RRRMC_MODEL_SPARSE_DISCRETIZED) return fail(ctx, RRRMC_ERR_STATE, "rrrmc_set_graph_discretized is for RRRMC_MODEL_SPARSE_DISCRETIZED");
     if (!A || !dJ || !rJ || !lev) return fail(ctx, RRRMC_ERR_INVALID_ARG, "A, dJ, rJ, lev must not be NULL");
@@ -2450,6 +2548,7 @@ int32_t rrrmc_set_graph_discretized(rrrmc_ctx* ctx, const int32_t* A, const int8
 int32_t rrrmc_set_graph_levels(rrrmc_ctx* ctx, const int32_t* A, const int8_t* J, const int32_t* lev, int32_t nlev, int32_t ea_form)
 {
     RRRMC_MULTI(ctx, false, rrrmc_set_graph_levels(c, A, J, lev, nlev, ea_form));
+    smp_drop(ctx);
     if (!ctx) return RRRMC_ERR_INVALID_ARG;
     if (ctx->model != RRRMC_MODEL_SPARSE_LEVELS) return fail(ctx, RRRMC_ERR_STATE, "rrrmc_set_graph_levels is for RRRMC_MODEL_SPARSE_LEVELS");
     if (!A || !J || !lev) return fail(ctx, RRRMC_ERR_INVALID_ARG, "A, J, lev must not be NULL");
@@ -2472,6 +2571,7 @@ int32_t rrrmc_set_graph_levels(rrrmc_ctx* ctx, const int32_t* A, const int8_t* J
 int32_t rrrmc_set_level_scale(rrrmc_ctx* ctx, int64_t mul, double div)
 {
     RRRMC_MULTI(ctx, false, rrrmc_set_level_scale(c, mul, div));
+    smp_drop(ctx);
     if (!ctx) return RRRMC_ERR_INVALID_ARG;
     if (ctx->model != RRRMC_MODEL_SPARSE_DISCRETIZED && ctx->model != RRRMC_MODEL_SPARSE_LEVELS)
         return fail(ctx, RRRMC_ERR_STATE, "rrrmc_set_level_scale is for RRRMC_MODEL_SPARSE_DISCRETIZED and RRRMC_MODEL_SPARSE_LEVELS");
@@ -2525,6 +2625,7 @@ double gauss_draw(uint64_t seed, uint64_t n)
 int32_t rrrmc_set_graph_f64(rrrmc_ctx* ctx, const int32_t* A, const double* J)
 {
     RRRMC_MULTI(ctx, false, rrrmc_set_graph_f64(c, A, J));
+    smp_drop(ctx);
     if (!ctx) return RRRMC_ERR_INVALID_ARG;
     if (ctx->model != RRRMC_MODEL_SPARSE_F64) return fail(ctx, RRRMC_ERR_STATE, "rrrmc_set_graph_f64 is for RRRMC_MODEL_SPARSE_F64");
     if (!A || !J) return fail(ctx, RRRMC_ERR_INVALID_ARG, "A and J must not be NULL");

@@ -117,11 +117,21 @@ __global__ __launch_bounds__(kRrrThreads) void rrr_sparse_wave_kernel(RrrSparseP
         d0 = 2 * a0; d1 = 2 * a1;
     };
 
+    // the replica's cache in HBM, in the layout of rrr_sparse_kernel (class bytes, positions inside the set, the 2L member arrays): a
+    // resumed call (rrrmc_set_resume) reads it back, every call leaves it there (rrrmc_rrr_cache; the next resumed call)
+    uint8_t* g_cls = P.cls + (size_t)r * P.N;
+    uint16_t* g_spos = static_cast<uint16_t*>(P.spos) + (size_t)r * P.N;
+    uint16_t* g_sv = static_cast<uint16_t*>(P.sv) + (size_t)r * 2 * P.L * P.N;
+    double* const sf = P.S.sf + (size_t)r * kSmpF;
+    long long* const si = P.S.si + (size_t)r * kSmpI;
+    const bool resume = P.S.resume != 0;
+
     // ---- energy(X, C) and gen_DEcache in site order (RRRMC.jl:177-178, DeltaE.jl:74-103) --------------------------------------------
     // pass 1: classes (parked in l_spos) and the energy; pass 2, block of 64 sites by block: stable partition into the segments
     int esum = 0;
     int tcount = 0;                                  // lane c: |set c|
-    for (int i0 = 0; i0 < P.N; i0 += kRrrThreads) {
+    if (resume) tcount = lane < 2 * P.L ? (int)si[SI_T0 + lane] : 0;
+    for (int i0 = 0; !resume && i0 < P.N; i0 += kRrrThreads) {
         const int i = i0 + lane;
         const bool in = i < P.N;
         int k = 0;
@@ -138,7 +148,7 @@ __global__ __launch_bounds__(kRrrThreads) void rrr_sparse_wave_kernel(RrrSparseP
             tcount += lane == c ? n : 0;
         }
     }
-    int E = qw_wave_sum(esum) / 2 + vz;
+    int E = (resume ? P.E_cur[r] : qw_wave_sum(esum) / 2) + vz;
     int bv = 0, ev = 0;
     auto B_ = [&](int q) -> int { return __builtin_amdgcn_readlane(bv, q); };
     auto respace = [&](int tv) {                     // tv: lane c = size of set c; equal gaps behind the 2L segments
@@ -154,7 +164,14 @@ __global__ __launch_bounds__(kRrrThreads) void rrr_sparse_wave_kernel(RrrSparseP
     };
     respace(tcount);
     __syncthreads();
-    {
+    if (resume) {
+        // the sets as the previous call left them: member order is part of the chain's state (rand_move picks v[rand(1:t)], ArraySets.jl:83)
+        for (int i = lane; i < P.N; i += kRrrThreads) l_spos[i] = (uint16_t)((int)g_spos[i] + B_((int)g_cls[i]));
+        for (int c = 0; c < 2 * P.L; ++c) {
+            const int tc = __builtin_amdgcn_readlane(tcount, c), bc = B_(c);
+            for (int i = lane; i < tc; i += kRrrThreads) l_sv[bc + i] = g_sv[(size_t)c * P.N + i];
+        }
+    } else {
         int fill = bv;                               // lane c: next free slot of segment c
         for (int i0 = 0; i0 < P.N; i0 += kRrrThreads) {
             const int i = i0 + lane;
@@ -173,7 +190,7 @@ __global__ __launch_bounds__(kRrrThreads) void rrr_sparse_wave_kernel(RrrSparseP
     }
     __syncthreads();
     // T[k] = t[k] f(k); z = sum over the classes in order
-    double Tv = lane < 2 * P.L ? (double)tcount * l_f[lane < C2 ? lane : 0] : 0.0;
+    double Tv = lane < 2 * P.L ? (resume ? sf[SF_T0 + lane] : (double)tcount * l_f[lane < C2 ? lane : 0]) : 0.0;
     double vzd = __longlong_as_double(((long long)vz << 32) | (uint32_t)vz);      // +0.0, opaque
     auto bcast = [&](double x, int c) -> double {
         const unsigned long long u = (unsigned long long)__double_as_longlong(x);
@@ -183,11 +200,12 @@ __global__ __launch_bounds__(kRrrThreads) void rrr_sparse_wave_kernel(RrrSparseP
     double z = 0.0 + vzd;
 #pragma unroll
     for (int c = 0; c < C2; ++c) if (c < 2 * P.L) z += bcast(Tv, c);
+    if (resume) z = sf[SF_Z] + vzd;                  // the running sum of the run (DeltaE.jl:258-282), not the sum of T
 
     const uint32_t rep = P.replica0 + (uint32_t)r;
     const double lambda = P.lambda + vzd, one_m_lambda = (1 - P.lambda) + vzd, staged_thr = P.staged_thr + vzd;
-    double acc_rate = 0.5 + vzd;
-    long long accepted = 0, staged_its = 0, ns = 0, next_sample = P.step;
+    double acc_rate = (resume ? sf[SF_ACC] : 0.5) + vzd;
+    long long accepted = 0, staged_its = 0, ns = 0, next_sample = P.S.samp0;
 
     auto mulhi_u64_u32 = [](unsigned long long u, uint32_t t) -> uint32_t {
         const unsigned long long lo = (unsigned long long)(uint32_t)u * t;
@@ -197,11 +215,15 @@ __global__ __launch_bounds__(kRrrThreads) void rrr_sparse_wave_kernel(RrrSparseP
 
     // bklMC (mode 1; RRRMC.jl:311-359): every move is applied; `it` advances by the geometric skip rand_skip (DeltaE.jl:141-144) + 1, the
     // moves are numbered m = 1, 2, ... (RRR stream sub 0 for the class / member, sub 2 for the skip), 64 of them prepared at a time
+    // A resumed bklMC call continues the run's loop with `iters` more iterations allowed: `it`, `nextstep` and the number of moves made
+    // carry on (the move that was pending at the cut is drawn again: same counter, same cache, same draw).
     const bool bkl = P.mode == 1;
-    long long it_bkl = 0, nextstep = P.step;
+    long long it_bkl = 0, nextstep = P.step, m_done = 0, limit = P.iters;
+    if (bkl && resume) { it_bkl = si[SI_IT]; nextstep = si[SI_NEXT]; m_done = si[SI_M]; limit += si[SI_LIMIT]; }
+    const long long m_first = m_done;
     bool done = false;
     const double Nd = (double)P.N + vzd;
-    for (long long base_it = 0; !done && (bkl || base_it < P.iters); base_it += kRrrThreads) {
+    for (long long base_it = bkl ? m_first : 0; !done && (bkl || base_it < P.iters); base_it += kRrrThreads) {
         __syncthreads();
         {
             const uint64_t gl = P.g0 + (uint64_t)(base_it + 1 + (long long)lane);
@@ -254,7 +276,7 @@ __global__ __launch_bounds__(kRrrThreads) void rrr_sparse_wave_kernel(RrrSparseP
         int li_s = sample_li();
         for (int li = 0; li < n_it; ++li) {
             if (bkl) {
-                if (it_bkl >= P.iters) { done = true; break; }
+                if (it_bkl >= limit) { done = true; break; }
             } else if (li == li_s) {
                 next_sample += P.step;
                 if (lane == 0) P.Es[(size_t)ns * P.Rpad + r] = (int32_t)E;
@@ -296,7 +318,7 @@ __global__ __launch_bounds__(kRrrThreads) void rrr_sparse_wave_kernel(RrrSparseP
                     if (lane == 0) P.Es[(size_t)ns * P.Rpad + r] = (int32_t)E;
                     ns += 1;
                     nextstep += P.step;
-                    if (nextstep > P.iters) { out = true; break; }
+                    if (nextstep > limit) { out = true; break; }
                 }
                 if (out) { done = true; break; }
             }
@@ -358,6 +380,7 @@ __global__ __launch_bounds__(kRrrThreads) void rrr_sparse_wave_kernel(RrrSparseP
                 apply(Tv, zp, true, true, true);
                 z = zp;
                 it_bkl += skip + 1;
+                m_done += 1;
                 E += dE; accepted += 1;
             } else if (uni(acc_rate < staged_thr)) {
                 // staged branch (RRRMC.jl:131-138): T' and z' from copies, the sets only on acceptance
@@ -391,10 +414,32 @@ __global__ __launch_bounds__(kRrrThreads) void rrr_sparse_wave_kernel(RrrSparseP
     }
     __syncthreads();
     for (int i = lane; i < P.W; i += kRrrThreads) g_sp[i] = l_sp[i];
+    // the cache, in rrr_sparse_kernel's layout: class = the segment that holds the spin's slot, position relative to the segment
+    {
+        const int tv = ev - bv;
+        for (int i = lane; i < P.N; i += kRrrThreads) {
+            const int slot = (int)l_spos[i];
+            int k = 0, b = 0;
+#pragma unroll
+            for (int c = 0; c < C2; ++c) {
+                const int bc = B_(c);
+                if (c < 2 * P.L && slot >= bc) { k = c; b = bc; }
+            }
+            g_cls[i] = (uint8_t)k;
+            g_spos[i] = (uint16_t)(slot - b);
+        }
+        for (int c = 0; c < 2 * P.L; ++c) {
+            const int tc = __builtin_amdgcn_readlane(tv, c), bc = B_(c);
+            for (int i = lane; i < tc; i += kRrrThreads) g_sv[(size_t)c * P.N + i] = l_sv[bc + i];
+        }
+        if (lane < 2 * P.L) { si[SI_T0 + lane] = tv; sf[SF_T0 + lane] = Tv; }
+    }
     if (lane == 0) {
         P.E_cur[r] = (int32_t)E;
         P.acc_cur[r] = accepted;
         P.stats[(size_t)r * 3] = accepted; P.stats[(size_t)r * 3 + 1] = bkl ? accepted : staged_its; P.stats[(size_t)r * 3 + 2] = bkl ? it_bkl : P.iters;
+        sf[SF_Z] = z; sf[SF_ACC] = acc_rate;
+        if (bkl) { si[SI_IT] = it_bkl; si[SI_NEXT] = nextstep; si[SI_M] = m_done; si[SI_LIMIT] = limit; }
     }
 }
 

@@ -162,6 +162,17 @@ class Engine:
         check(lib().rrrmc_tracked_energy_f64(self._ctx, E), self._ctx)
         return E
 
+    def run_energy(self):
+        """The energy the last sampler call tracked (``E += ΔE`` per accepted move: what the reference hands to its hooks), read without
+        disturbing the run a resumed call continues (``energy()`` rebuilds caches, like the reference's ``energy(X, C)``)."""
+        if self._f64:
+            E = np.zeros(self.R, np.float64)
+            check(lib().rrrmc_tracked_energy_f64(self._ctx, E), self._ctx)
+            return E
+        E = np.zeros(self.R, np.int64)
+        check(lib().rrrmc_tracked_energy(self._ctx, E), self._ctx)
+        return self.X.energy_value(E) if self._units else E
+
     def standard_mc_async(self, beta, iters, step=1):
         check(lib().rrrmc_standard_mc_async(self._ctx, float(beta), int(iters), int(step)), self._ctx)
         self._last = (int(iters), int(step))
@@ -181,8 +192,7 @@ class Engine:
         check(lib().rrrmc_sync(self._ctx), self._ctx)
 
     def fetch_results(self, want_energies=True):
-        iters, step = self._last
-        nsamp = iters // step
+        nsamp = int(lib().rrrmc_results_samples(self._ctx))       # iters // step, or what a resumed call took (rrrmc_set_resume)
         Es = np.zeros((self.R, nsamp), np.float64 if self._f64 else np.int64)
         acc = np.zeros(self.R, np.int64)
         fn = lib().rrrmc_fetch_results_f64 if self._f64 else lib().rrrmc_fetch_results
@@ -314,18 +324,96 @@ class Engine:
         return t.value, s.value, n.value
 
 
-def rrrMC(X, beta, iters, *, seed=DEFAULT_SEED, step=1, C0=None, staged_thr=None, staged_thr_fact=5.0, quiet=False,
-          replicas=None, device=0, replica0=0, engine=None):
-    """``rrrMC(X::DoubleGraph, β, iters; seed, step, C0, staged_thr, staged_thr_fact, quiet)`` (src/RRRMC.jl:221-290) for a
-    batch of replicas of a ``GraphQuant``, or ``rrrMC(X::SingleGraph, ...)`` (RRRMC.jl:149-219) for a ``GraphSKNormal``
-    (continuous-energy cache DeltaECacheCont over a DynamicSampler).  Returns ``(Es, C)`` like ``standardMC``."""
-    import math
-    if not math.isfinite(beta):
-        raise ValueError("β must be finite, given: %r" % beta)                     # RRRMC.jl:230
+class EnergyProbe:
+    """``energy(X, C)`` (src/Interface.jl:105) for use INSIDE a hook: the reference's test hook checks ``E ≈ energy(X, C)`` at every sample
+    (test/runtests.jl:12-20).  The sampler's own context must not be asked — ``rrrmc_energy`` rebuilds caches and ends the run a resumed call
+    continues — so the probe keeps a context of its own for the same graph."""
+
+    def __init__(self, X, R=1, device=0):
+        self.eng = Engine(X, R, device=device)
+
+    def __call__(self, C):
+        self.eng.set_config(C)
+        return self.eng.energy()
+
+    def close(self):
+        self.eng.close()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+
+def energy(X, C, device=0):
+    """``energy(X, C)`` of every replica of ``C`` on a context made for the call (see ``EnergyProbe`` for repeated use)."""
+    with EnergyProbe(X, C.R, device) as probe:
+        return probe(C)
+
+
+class _HookRun:
+    """Book-keeping of a hooked run over R replicas.  The reference's hook ends ONE chain (``hook(...) || break``, src/RRRMC.jl:107,187,256,
+    341,404,501); here a hook may return one flag for all replicas or one per replica: a replica whose flag is False is FROZEN at that sample —
+    its configuration, samples and counts are what the reference's chain would return, the hook keeps seeing them — while the others go on
+    (replicas are independent); the run ends when none is left."""
+
+    def __init__(self, X, eng, Cfg):
+        self.X, self.eng, self.Cfg = X, eng, Cfg
+        R = eng.R
+        self.frozen = np.zeros(R, bool)
+        self.cfg = Config(X.N, R)
+        self.nsamp = np.zeros(R, np.int64)
+        self.vals = {}                      # name -> frozen per-replica values (accepted counts, energies, ...)
+        self.samples = []
+
+    def view(self, name, live):
+        """``live`` with the frozen replicas' values of that moment"""
+        live = np.asarray(live)
+        if name not in self.vals:
+            self.vals[name] = np.zeros_like(live)
+        return np.where(self.frozen, self.vals[name], live) if self.frozen.any() else live
+
+    def call(self, hook, it, E, args, live):
+        """Record the sample ``E``, fetch the configuration and call ``hook(it, X, C, *args)``; ``live`` = {name: per-replica array} of
+        what must be kept for a replica that stops here.  Returns False when the run is over."""
+        self.samples.append(np.array(E))
+        self.eng.get_config(self.Cfg)
+        if self.frozen.any():
+            self.Cfg.s[self.frozen] = self.cfg.s[self.frozen]
+        go = hook(it, self.X, self.Cfg, *args)
+        if np.ndim(go) == 0:
+            return bool(go)
+        go = np.asarray(go, bool)
+        if go.shape != (self.eng.R,):
+            raise ValueError("a hook returns one flag, or one per replica (%d)" % self.eng.R)
+        new = ~go & ~self.frozen
+        self.cfg.s[new] = self.Cfg.s[new]
+        self.nsamp[new] = len(self.samples)
+        for name, v in live.items():
+            v = np.asarray(v)
+            if name not in self.vals:
+                self.vals[name] = np.zeros_like(v)
+            self.vals[name][new] = v[new]
+        self.frozen |= new
+        return not self.frozen.all()
+
+    def finish(self, dtype):
+        """(Es, C): the engine is given the frozen replicas' configurations back, so that C and the device agree"""
+        Es = np.stack(self.samples, axis=1) if self.samples else np.zeros((self.eng.R, 0), dtype)
+        self.eng.get_config(self.Cfg)
+        if self.frozen.any():
+            self.Cfg.s[self.frozen] = self.cfg.s[self.frozen]
+            self.eng.set_config(self.Cfg)
+            Es = [Es[r, :self.nsamp[r]] if self.frozen[r] else Es[r] for r in range(self.eng.R)]
+        return Es, self.Cfg
+
+
+def _setup(X, seed, C0, replicas, device, replica0, engine):
     own = engine is None
     R = replicas if replicas is not None else (C0.R if C0 is not None else (engine.R if engine else 1))
     if C0 is not None and C0.N != X.N:
-        raise ValueError("Invalid C0, wrong N, expected %d, given: %d" % (X.N, C0.N))
+        raise ValueError("Invalid C0, wrong N, expected %d, given: %d" % (X.N, C0.N))       # RRRMC.jl:172,234,320,385,482
     eng = engine if engine is not None else Engine(X, R, device=device, replica0=replica0)
     try:
         if seed > 0 or own:
@@ -334,35 +422,102 @@ def rrrMC(X, beta, iters, *, seed=DEFAULT_SEED, step=1, C0=None, staged_thr=None
             eng.set_config(C0)
         elif own:
             eng.init_spins_random()
-        Es, acc, staged = eng.rrr_mc(beta, iters, step, staged_thr, staged_thr_fact)
-        Cfg = eng.get_config(C0 if C0 is not None else None)
+    except Exception:
+        if own:
+            eng.close()
+        raise
+    return own, eng, (C0 if C0 is not None else Config(X.N, eng.R))
+
+
+def _nsamples(Es):
+    return Es.shape[1] if hasattr(Es, "shape") else [len(e) for e in Es]
+
+
+def rrrMC(X, beta, iters, *, seed=DEFAULT_SEED, step=1, hook=None, C0=None, staged_thr=None, staged_thr_fact=5.0, quiet=False,
+          replicas=None, device=0, replica0=0, engine=None):
+    """``rrrMC(X, β, iters; seed, step, hook, C0, staged_thr, staged_thr_fact, quiet)`` (src/RRRMC.jl:149-219 for a SingleGraph, :221-290 for a
+    DoubleGraph) for a batch of replicas.  Returns ``(Es, C)`` like ``standardMC``.
+    ``hook(it, X, C, accepted, E)`` (:186,255) is called every ``step`` iterations — before the move of iteration ``it``, as the reference does
+    (:184-188) — with per-replica arrays; returning False stops the run (one flag per replica: see ``_HookRun``).  The run is cut at the hook
+    points and the pieces RESUME one another (``rrrmc_set_resume``): the DeltaECache, E and the acceptance-rate average live on, so a hooked
+    run is the un-hooked chain bit for bit."""
+    import math
+    if not math.isfinite(beta):
+        raise ValueError("β must be finite, given: %r" % beta)                     # RRRMC.jl:166,230
+    own, eng, Cfg = _setup(X, seed, C0, replicas, device, replica0, engine)
+    try:
+        iters, step = int(iters), int(step)
+        if hook is None:
+            Es, acc, staged = eng.rrr_mc(beta, iters, step, staged_thr, staged_thr_fact)
+            eng.get_config(Cfg)
+            it = iters
+        else:
+            run = _HookRun(X, eng, Cfg)
+            acc = np.zeros(eng.R, np.int64)
+            staged = np.zeros(eng.R, np.int64)
+
+            def piece(n):
+                _, a, st = eng.rrr_mc(beta, n, step, staged_thr, staged_thr_fact, want_energies=False)
+                acc[:] += a
+                staged[:] += st
+
+            eng.set_resume(False)
+            piece(min(step - 1, iters))             # a fresh run (energy(X, C), gen_ΔEcache: :177-178), up to just before the first sampled iteration
+            it = min(step - 1, iters)
+            eng.set_resume(True)
+            try:
+                while it + 1 <= iters:
+                    E = eng.run_energy()
+                    if not run.call(hook, it + 1, run.view("E", E), (run.view("acc", acc), run.view("E", E)), {"acc": acc, "E": E}):
+                        it += 1                     # the reference has counted the iteration its hook ended (:183)
+                        break
+                    n = min(step, iters - it)       # the move of the sampled iteration and the step - 1 after it
+                    piece(n)
+                    it += n
+            finally:
+                eng.set_resume(False)
+            Es, Cfg = run.finish(X.energy_dtype)
+            acc = run.view("acc", acc)
         if not quiet:
-            print("samples = ", Es.shape[1] if hasattr(Es, "shape") else [len(e) for e in Es])
-            print("iters = ", iters)
-            print("accept rate = ", float(acc.mean()) / max(iters, 1))
-            print("frac. staged iters = ", float(staged.mean()) / max(iters, 1))
+            print("samples = ", _nsamples(Es))
+            print("iters = ", it)
+            print("accept rate = ", float(acc.mean()) / max(it, 1))
+            print("frac. staged iters = ", float(staged.mean()) / max(it, 1))
         return Es, Cfg
     finally:
         if own:
             eng.close()
 
 
-def bklMC(X, beta, iters, *, seed=DEFAULT_SEED, step=1, C0=None, quiet=False, replicas=None, device=0, replica0=0, engine=None):
-    """``bklMC(X, β, iters; seed, step, C0, quiet)`` (src/RRRMC.jl:311-359) for a batch of replicas of a GraphRRG / GraphEA."""
-    own = engine is None
-    R = replicas if replicas is not None else (C0.R if C0 is not None else (engine.R if engine else 1))
-    eng = engine if engine is not None else Engine(X, R, device=device, replica0=replica0)
+def bklMC(X, beta, iters, *, seed=DEFAULT_SEED, step=1, hook=None, C0=None, quiet=False, replicas=None, device=0, replica0=0, engine=None):
+    """``bklMC(X, β, iters; seed, step, hook, C0, quiet)`` (src/RRRMC.jl:311-359) for a batch of replicas.  ``hook(nextstep, X, C, accepted, E)``
+    (:341) is called at every sample point the skipped iterations pass; the run is cut there and resumed (``it``, ``nextstep`` and the pending
+    (skip, move) draw carry on): the hooked run is the un-hooked chain bit for bit."""
+    own, eng, Cfg = _setup(X, seed, C0, replicas, device, replica0, engine)
     try:
-        if seed > 0 or own:
-            eng.seed(seed if seed > 0 else 0)
-        if C0 is not None:
-            eng.set_config(C0)
-        elif own:
-            eng.init_spins_random()
-        Es, moves = eng.bkl_mc(beta, iters, step)
-        Cfg = eng.get_config(C0 if C0 is not None else None)
+        iters, step = int(iters), int(step)
+        nsamp = iters // step
+        if hook is None or nsamp == 0:
+            Es, moves = eng.bkl_mc(beta, iters, step)
+            eng.get_config(Cfg)
+        else:
+            run = _HookRun(X, eng, Cfg)
+            moves = np.zeros(eng.R, np.int64)
+            eng.set_resume(False)
+            try:
+                for k in range(1, nsamp + 1):       # a call of `step` iterations ends at the next sample point (the reference goes `out` after the last one, :343)
+                    _, m = eng.bkl_mc(beta, step, step)
+                    eng.set_resume(True)
+                    moves += m
+                    E = eng.run_energy()
+                    if not run.call(hook, k * step, run.view("E", E), (run.view("acc", moves), run.view("E", E)), {"acc": moves, "E": E}):
+                        break
+            finally:
+                eng.set_resume(False)
+            Es, Cfg = run.finish(X.energy_dtype)
+            moves = run.view("acc", moves)
         if not quiet:
-            print("samples = ", Es.shape[1] if hasattr(Es, "shape") else [len(e) for e in Es])
+            print("samples = ", _nsamples(Es))
             print("accept rate = ", float(moves.mean()) / max(iters, 1))
             print("true it = ", float(moves.mean()))
         return Es, Cfg
@@ -371,22 +526,38 @@ def bklMC(X, beta, iters, *, seed=DEFAULT_SEED, step=1, C0=None, quiet=False, re
             eng.close()
 
 
-def wtmMC(X, beta, samples, *, seed=DEFAULT_SEED, step=1.0, C0=None, quiet=False, replicas=None, device=0, replica0=0, engine=None):
-    """``wtmMC(X, β, samples; seed, step, C0, quiet)`` (src/RRRMC.jl:376-426) for a batch of replicas of a GraphRRG / GraphEA."""
-    own = engine is None
-    R = replicas if replicas is not None else (C0.R if C0 is not None else (engine.R if engine else 1))
-    eng = engine if engine is not None else Engine(X, R, device=device, replica0=replica0)
+def wtmMC(X, beta, samples, *, seed=DEFAULT_SEED, step=1.0, hook=None, C0=None, quiet=False, replicas=None, device=0, replica0=0, engine=None):
+    """``wtmMC(X, β, samples; seed, step, hook, C0, quiet)`` (src/RRRMC.jl:376-426) for a batch of replicas.  ``hook(nextstep, X, C, num_moves, E)``
+    (:404) is called at every sample time (``nextstep`` = the global time of the sample, k additions of step / N as :391,405 accumulate it);
+    the run is cut there and resumed (the heap of waiting times, the global time and ``nextstep`` carry on)."""
+    own, eng, Cfg = _setup(X, seed, C0, replicas, device, replica0, engine)
     try:
-        if seed > 0 or own:
-            eng.seed(seed if seed > 0 else 0)
-        if C0 is not None:
-            eng.set_config(C0)
-        elif own:
-            eng.init_spins_random()
-        Es, moves, t = eng.wtm_mc(beta, samples, step)
-        Cfg = eng.get_config(C0 if C0 is not None else None)
+        samples = int(samples)
+        if hook is None:
+            Es, moves, t = eng.wtm_mc(beta, samples, step)
+            eng.get_config(Cfg)
+        else:
+            run = _HookRun(X, eng, Cfg)
+            moves = np.zeros(eng.R, np.int64)
+            t = np.zeros(eng.R)
+            st = float(step) / X.N                  # :391
+            nextstep = st
+            eng.set_resume(False)
+            try:
+                for _ in range(samples):
+                    _, m, t = eng.wtm_mc(beta, 1, step)
+                    eng.set_resume(True)
+                    moves += m
+                    E = eng.run_energy()
+                    if not run.call(hook, nextstep, run.view("E", E), (run.view("acc", moves), run.view("E", E)), {"acc": moves, "E": E, "t": t}):
+                        break
+                    nextstep += st                  # :405
+            finally:
+                eng.set_resume(False)
+            Es, Cfg = run.finish(X.energy_dtype)
+            moves, t = run.view("acc", moves), run.view("t", t)
         if not quiet:
-            print("samples = ", Es.shape[1] if hasattr(Es, "shape") else [len(e) for e in Es])
+            print("samples = ", _nsamples(Es))
             print("num_moves = ", float(moves.mean()))
             print("global time = ", float(t.mean()))
             print("ratio = ", float(t.mean()) / max(float(moves.mean()), 1.0))
@@ -396,25 +567,43 @@ def wtmMC(X, beta, samples, *, seed=DEFAULT_SEED, step=1.0, C0=None, quiet=False
             eng.close()
 
 
-def extremal_opt(X, tau, iters, *, seed=DEFAULT_SEED, step=1, C0=None, quiet=False, replicas=None, device=0, replica0=0, engine=None):
-    """``extremal_opt(X, τ, iters; seed, step, C0, quiet)`` (src/RRRMC.jl:474-521) for a batch of replicas of a GraphRRG / GraphEA (EOCache) or of a
-    GraphRRGNormal / GraphEANormal / discretised DoubleGraph (the generic EOCacheCont).
-    Returns ``(C, Emin, Cmin, itmin)`` like the reference, with per-replica arrays."""
-    own = engine is None
-    R = replicas if replicas is not None else (C0.R if C0 is not None else (engine.R if engine else 1))
-    eng = engine if engine is not None else Engine(X, R, device=device, replica0=replica0)
+def extremal_opt(X, tau, iters, *, seed=DEFAULT_SEED, step=1, hook=None, C0=None, quiet=False, replicas=None, device=0, replica0=0, engine=None):
+    """``extremal_opt(X, τ, iters; seed, step, hook, C0, quiet)`` (src/RRRMC.jl:474-521) for a batch of replicas of a GraphRRG / GraphEA (EOCache) or of
+    any other graph (the generic EOCacheCont).  Returns ``(C, Emin, Cmin, itmin)`` like the reference, with per-replica arrays.
+    ``hook(it, X, C, E, Emin)`` (:501 — note the signature) is called every ``step`` iterations, before the move of iteration ``it``; the run is
+    cut there and resumed (the ranking, E, Emin / Cmin / itmin carry on)."""
+    own, eng, Cfg = _setup(X, seed, C0, replicas, device, replica0, engine)
     try:
-        if seed > 0 or own:
-            eng.seed(seed if seed > 0 else 0)
-        if C0 is not None:
-            eng.set_config(C0)
-        elif own:
-            eng.init_spins_random()
-        _, Emin, Cmin, itmin = eng.extremal_opt(tau, iters, step)
-        Cfg = eng.get_config(C0 if C0 is not None else None)
+        iters, step = int(iters), int(step)
+        if hook is None:
+            _, Emin, Cmin, itmin = eng.extremal_opt(tau, iters, step)
+            eng.get_config(Cfg)
+            it = iters
+        else:
+            run = _HookRun(X, eng, Cfg)
+            eng.set_resume(False)
+            _, Emin, Cmin, itmin = eng.extremal_opt(tau, min(step - 1, iters), step)
+            it = min(step - 1, iters)
+            eng.set_resume(True)
+            try:
+                while it + 1 <= iters:
+                    E = eng.run_energy()
+                    live = {"E": E, "Emin": Emin, "itmin": itmin, "Cmin": Cmin.s}
+                    if not run.call(hook, it + 1, run.view("E", E), (run.view("E", E), run.view("Emin", Emin)), live):
+                        it += 1
+                        break
+                    n = min(step, iters - it)
+                    _, Emin, Cmin, itmin = eng.extremal_opt(tau, n, step)
+                    it += n
+            finally:
+                eng.set_resume(False)
+            _, Cfg = run.finish(X.energy_dtype)
+            Emin, itmin = run.view("Emin", Emin), run.view("itmin", itmin)
+            if run.frozen.any():
+                Cmin.s[run.frozen] = run.vals["Cmin"][run.frozen]
         if not quiet:
-            print("iters = ", iters)
-            print("min [it = %s] = %s" % (itmin.tolist(), Emin.tolist()))
+            print("iters = ", it)
+            print("min [it = %s] = %s" % (np.asarray(itmin).tolist(), np.asarray(Emin).tolist()))
         return Cfg, Emin, Cmin, itmin
     finally:
         if own:
