@@ -166,9 +166,15 @@ __global__ __launch_bounds__(kRrrThreads) void rrr_sparse_wave_kernel(RrrSparseP
     __syncthreads();
     if (resume) {
         // the sets as the previous call left them: member order is part of the chain's state (rand_move picks v[rand(1:t)], ArraySets.jl:83)
-        for (int i = lane; i < P.N; i += kRrrThreads) l_spos[i] = (uint16_t)((int)g_spos[i] + B_((int)g_cls[i]));
+        for (int i = lane; i < P.N; i += kRrrThreads) {
+            const int k = (int)g_cls[i];
+            int b = 0;
+#pragma unroll
+            for (int c = 0; c < C2; ++c) { const int bc = B_(c); b = k == c ? bc : b; }      // (v_readlane takes a wave-uniform lane: select per class)
+            l_spos[i] = (uint16_t)((int)g_spos[i] + b);
+        }
         for (int c = 0; c < 2 * P.L; ++c) {
-            const int tc = __builtin_amdgcn_readlane(tcount, c), bc = B_(c);
+            const int tc = min(__builtin_amdgcn_readlane(tcount, c), P.N), bc = B_(c);
             for (int i = lane; i < tc; i += kRrrThreads) l_sv[bc + i] = g_sv[(size_t)c * P.N + i];
         }
     } else {
@@ -429,7 +435,7 @@ __global__ __launch_bounds__(kRrrThreads) void rrr_sparse_wave_kernel(RrrSparseP
             g_spos[i] = (uint16_t)(slot - b);
         }
         for (int c = 0; c < 2 * P.L; ++c) {
-            const int tc = __builtin_amdgcn_readlane(tv, c), bc = B_(c);
+            const int tc = min(__builtin_amdgcn_readlane(tv, c), P.N), bc = B_(c);        // (|set| <= N: a bound on the stores whatever happened)
             for (int i = lane; i < tc; i += kRrrThreads) g_sv[(size_t)c * P.N + i] = l_sv[bc + i];
         }
         if (lane < 2 * P.L) { si[SI_T0 + lane] = tv; sf[SF_T0 + lane] = Tv; }

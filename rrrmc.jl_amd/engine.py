@@ -266,9 +266,10 @@ class Engine:
         return Es, (self.X.energy_value(Emin) if self._units else Emin), Cmin, itmin
 
     def rrr_cache(self):
-        """(pos[R, N], sizes[R, 4]) of the DeltaECache after the last rrrMC call."""
+        """(pos[R, N], sizes[R, 4]) of the DeltaECache after the last rrrMC call (GraphQuant); sizes[R, 16] for the DiscrGraphs
+        (GraphRRG / GraphEA, rrrMC and bklMC) and the discretised DoubleGraphs, class k of replica r at [r, k]."""
         pos = np.zeros((self.R, self.X.N), np.int8)
-        sizes = np.zeros((self.R, 16 if self.X.model_kind == MODEL_SPARSE_DISCRETIZED else 4), np.int32)
+        sizes = np.zeros((self.R, 4 if self.X.model_kind == MODEL_QUANT_RRG else 16), np.int32)
         check(lib().rrrmc_rrr_cache(self._ctx, pos.ctypes.data, sizes.ctypes.data), self._ctx)
         return pos, sizes
 

@@ -314,6 +314,8 @@ def test_runtests_jl_hook_loop(pkg, oracle):
             kw = dict(quiet=True, replicas=2)
             with pkg.Engine(X, 2) as eng:
                 kw["engine"] = eng
+                eng.seed(SEED)
+                eng.init_spins_random()          # (a call without C0 on a caller's engine continues the engine's configuration)
                 E, C = pkg.standardMC(X, beta, iters, step=st, **kw)
                 E, C = pkg.standardMC(X, beta, iters, step=st, C0=C, hook=checkenergy_hook, **kw)
                 E, C = pkg.standardMC(X, beta, iters, step=st, C0=C, hook=gen_timeout_hook(), **kw)
