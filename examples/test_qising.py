@@ -51,16 +51,18 @@ def main(argv=None):
             eng.init_spins_random()
             log = pkg.SnapshotLog(eng, args.samples, prefix=os.path.join(out, "output_%s_sx%d_s%d" % (alg, args.seedx, args.seed)),
                                   energy_label="QE")
-            accepted = np.zeros(R, np.int64)
             t0 = time.time()
-            for k in range(args.samples):                      # the hook of scripts.jl:803-809: QE instead of E
-                if alg == "met":
-                    _, acc = eng.standard_mc(args.beta, rstep, rstep)
-                else:
-                    _, acc, _ = eng.rrr_mc(args.beta, rstep, rstep)
-                accepted += acc
-                QE, tmag, _ = eng.quant_observables()
-                log((k + 1) * rstep, X, None, accepted, QE)
+            last = {}
+
+            def hook(it, X_, C, acc, E):                       # the hook of scripts.jl:803-809: QE instead of E
+                QE, tmag, _ = eng.quant_observables()          # (reads the live configuration; does not disturb the resumed run)
+                last.update(QE=QE, tmag=tmag, acc=np.array(acc))
+                return log(it, X_, C, acc, QE)
+
+            # one call per sampler with the reference's hook keyword (scripts.jl:815-835): the library cuts the run at the hook points and resumes it
+            fn = pkg.standardMC if alg == "met" else pkg.rrrMC
+            fn(X, args.beta, rstep * args.samples, step=rstep, seed=args.seed, hook=hook, engine=eng, quiet=True)
+            QE, tmag, accepted = last["QE"], last["tmag"], last["acc"]
             log.close()
             wall = time.time() - t0
             cols, chunks = log.to_mat(0)

@@ -8,6 +8,7 @@ With --cont the couplings are Gaussian (GraphRRGNormal) and the samplers use the
 
 Differences from the script: a batch of replicas runs in lockstep (one log / overlap curve per replica), randomness comes from
 the engine's Philox streams, and the snapshots stay in HBM — the BitMatrix dump (`to_mat`) is written for replica 0 only.
+Every sampler is called ONCE with the reference's `hook` keyword (the log / snapshot hook of scripts.jl:51-69), as the script does.
 """
 import argparse
 import os
@@ -49,21 +50,19 @@ def main(argv=None):
             eng.init_spins_random()
             log = pkg.SnapshotLog(eng, args.samples, prefix=os.path.join(args.out, "output_%s_sx%d_s%d" % (alg, args.seedx, args.seed)))
             t0 = time.time()
-            accepted = np.zeros(R, np.int64)
-            for k in range(args.samples):               # the hook loop of the reference, one sampler call per sample
-                if alg == "met":
-                    n = round(args.step * args.met_factor)
-                    Es, acc = eng.standard_mc(args.beta, n, n)
-                elif alg == "bkl":
-                    n = round(args.step * args.bkl_factor)
-                    Es, acc = eng.bkl_mc(args.beta, n, n)
-                elif alg == "rrr":
-                    n = args.step
-                    Es, acc, _ = eng.rrr_mc(args.beta, n, n)
-                else:
-                    Es, acc, _ = eng.wtm_mc(args.beta, 1, step=args.step * args.wtm_factor)        # rtstep, scripts.jl:134-137
-                accepted += acc
-                log((k + 1) * n if alg != "wtm" else k + 1, X, None, accepted, eng.energy())
+            # the reference's calls, hook included (scripts.jl:90-148): one run per sampler, the hook called at every sample — the library cuts
+            # the run there and resumes it, so this is ONE chain per replica, as in the reference
+            kw = dict(seed=args.seed, hook=log, engine=eng, quiet=True)
+            if alg == "met":
+                n = round(args.step * args.met_factor)
+                pkg.standardMC(X, args.beta, n * args.samples, step=n, **kw)
+            elif alg == "bkl":
+                n = round(args.step * args.bkl_factor)
+                pkg.bklMC(X, args.beta, n * args.samples, step=n, **kw)
+            elif alg == "rrr":
+                pkg.rrrMC(X, args.beta, args.step * args.samples, step=args.step, **kw)
+            else:
+                pkg.wtmMC(X, args.beta, args.samples, step=args.step * args.wtm_factor, **kw)        # rtstep, scripts.jl:134-137
             log.close()
             wall = time.time() - t0
             mq2, sq2 = pkg.parseovs(eng, log.clock, pkg.log_range(log.clock[0], log.clock[-1], st0=log.clock[0]))

@@ -343,83 +343,283 @@ function checkerboard(L::Integer, D::Integer)             # parity of the lattic
     return Int32[sum(Tuple(I)) % 2 for I in CartesianIndices(ntuple(_ -> L, D))][:]
 end
 
+# ---- hooked runs of rrrMC / bklMC / wtmMC / extremal_opt --------------------------------------------------------------------------------
+# Every sampler of the reference takes `hook` (src/RRRMC.jl:152,224,314,379,477) and calls it at each sample, inside its loop, with the chain's
+# state of that moment (:186,255,341,404,501).  The library runs a whole call on the device, so the run is cut at the hook points and the pieces
+# RESUME one another (rrrmc_set_resume, include/rrrmc_hip.h): the move-selection cache, the tracked E, rrrMC's acceptance-rate average, bklMC's
+# `it` / `nextstep` and pending draw, wtmMC's heap and global time, extremal_opt's Emin / Cmin / itmin live on the device across the pieces —
+# a hooked run is the un-hooked chain bit for bit (tests/test_gpu_hooks.py checks exactly that through this ABI).
+resume!(ctx::Ctx, on::Bool) = check(ccall((:rrrmc_set_resume, LIB), Int32, (Ptr{Cvoid}, Int32), ctx.p, on ? 1 : 0), ctx.p)
+"samples per replica the last sampling call took (iters ÷ step for a call that starts a run; see rrrmc_set_resume for a resumed one)"
+nsamples(ctx::Ctx) = Int(ccall((:rrrmc_results_samples, LIB), Int64, (Ptr{Cvoid},), ctx.p))
+"the energy the last sampler call tracked — what the reference hands to its hook — read without disturbing the run (`energies` ends it)"
+function run_energy(ctx::Ctx)
+    if ctx.f64
+        E = Vector{Float64}(undef, ctx.R)
+        check(ccall((:rrrmc_tracked_energy_f64, LIB), Int32, (Ptr{Cvoid}, Ptr{Float64}), ctx.p, E), ctx.p)
+        return E
+    end
+    E = Vector{Int}(undef, ctx.R)
+    check(ccall((:rrrmc_tracked_energy, LIB), Int32, (Ptr{Cvoid}, Ptr{Int64}), ctx.p, E), ctx.p)
+    return E
+end
+"accepted moves of the last call, per replica (no energies are copied)"
+function counts(ctx::Ctx)
+    acc = Vector{Int}(undef, ctx.R)
+    if ctx.f64
+        check(ccall((:rrrmc_fetch_results_f64, LIB), Int32, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Int64}), ctx.p, C_NULL, acc), ctx.p)
+    else
+        check(ccall((:rrrmc_fetch_results, LIB), Int32, (Ptr{Cvoid}, Ptr{Int64}, Ptr{Int64}), ctx.p, C_NULL, acc), ctx.p)
+    end
+    return acc
+end
+"staged iterations (rrrMC) / moves made (bklMC) of the last call"
+function stats(ctx::Ctx)
+    st = Vector{Int}(undef, ctx.R)
+    check(ccall((:rrrmc_rrr_stats, LIB), Int32, (Ptr{Cvoid}, Ptr{Int64}), ctx.p, st), ctx.p)
+    return st
+end
+
+# Book-keeping of a hooked run over R replicas.  The reference's hook ends ONE chain (`hook(...) || break`); here the hook may return one
+# `Bool` for all replicas or a `Vector{Bool}`, one flag per replica: a replica whose flag is `false` is frozen at that sample — the `Config`,
+# the counts and the energy handed to later hooks (and returned) are the ones of that moment — the others go on; `stopped_at(ctx)` tells where.
+mutable struct HookRun
+    ctx::Ctx
+    X::RRRMC.Interface.AbstractGraph
+    C0::Union{Vector{RRRMC.Config},Nothing}
+    chunks::Matrix{UInt64}
+    frozen_chunks::Matrix{UInt64}
+    kept::Dict{Symbol,Vector}
+    Es::Vector{Vector}
+end
+function HookRun(ctx::Ctx, X, C0, chunks::Matrix{UInt64})
+    fill!(ctx.stopped, 0)
+    return HookRun(ctx, X, C0, chunks, copy(chunks), Dict{Symbol,Vector}(), Vector{Vector}())
+end
+"`live` with, for the replicas whose hook has ended them, the values they had then"
+function seen(run::HookRun, name::Symbol, live::Vector)
+    haskey(run.kept, name) || return copy(live)
+    return [run.ctx.stopped[r] > 0 ? run.kept[name][r] : live[r] for r in 1:run.ctx.R]
+end
+"record the sample `E`, call `hook(it, X, Cs, args...)`; `live`: what to keep of a replica that stops here.  `false`: the run is over"
+function sample!(run::HookRun, hook, it, E::Vector, args::Tuple, live::Dict{Symbol,<:Vector})
+    ctx = run.ctx
+    push!(run.Es, E)
+    Cs = get_configs!(ctx, run.chunks, run.C0)
+    for r in 1:ctx.R
+        ctx.stopped[r] > 0 && (Cs[r].s.chunks .= run.frozen_chunks[:, r])
+    end
+    go = hook(it, run.X, Cs, args...)
+    go isa Bool && return go
+    for r in 1:ctx.R
+        if !go[r] && ctx.stopped[r] == 0
+            for (name, v) in live
+                haskey(run.kept, name) || (run.kept[name] = copy(v))
+                run.kept[name][r] = v[r]
+            end
+            run.frozen_chunks[:, r] .= run.chunks[:, r]
+            ctx.stopped[r] = it isa Integer ? it : length(run.Es)
+        end
+    end
+    return !all(>(0), ctx.stopped)
+end
+"(Es samples×R, Cs): the frozen replicas get the configuration of their last hook back, on both sides"
+function finish!(run::HookRun, ET)
+    ctx = run.ctx
+    Cs = get_configs!(ctx, run.chunks, run.C0)
+    if any(>(0), ctx.stopped)
+        for r in 1:ctx.R
+            ctx.stopped[r] > 0 && (run.chunks[:, r] .= run.frozen_chunks[:, r])
+        end
+        Cs = put_configs!(ctx, run.chunks, run.C0)
+    end
+    Es = isempty(run.Es) ? Matrix{ET}(undef, 0, ctx.R) : permutedims(reduce(hcat, run.Es))
+    return Es, Cs
+end
+
 # ---- rrrMC (src/RRRMC.jl:149-219 SingleGraph, :221-290 DoubleGraph) -------------------------------------------------------------------
 """
-    rrrMC(ctx, X, β, iters; seed, step, C0, staged_thr, staged_thr_fact, quiet) -> (Es, Cs, accepted, staged)
+    rrrMC(ctx, X, β, iters; seed, step, hook, C0, staged_thr, staged_thr_fact, quiet) -> (Es, Cs, accepted, staged)
 
 Serves `rrrMC(X::SingleGraph)` — GraphRRG / GraphEA (DeltaECache{Int,L}), GraphRRGNormal / GraphEANormal / GraphSKNormal / GraphSK
 (DeltaECacheCont + DynamicSampler) — and `rrrMC(X::DoubleGraph)` — GraphQuant (its fourK is the type parameter, QT.jl:126,165) and the
 discretised graphs.  `staged_thr` defaults as the reference's: 0.5 for a DoubleGraph (:224), 0.8 otherwise (:152).
+`hook(it, X, Cs, accepted, E)` (:186,255) is called every `step` iterations, before the move of iteration `it` (:184-188), with the vectors
+of all replicas; `false` ends the run (a `Vector{Bool}`: per replica, see `HookRun`).
 """
 function RRRMC.rrrMC(ctx::Ctx, X::RRRMC.Interface.AbstractGraph, β::Real, iters::Integer; seed = DEFAULT_SEED, step::Integer = 1,
-                     C0::Union{Vector{RRRMC.Config},Nothing} = nothing,
+                     hook = nothing, C0::Union{Vector{RRRMC.Config},Nothing} = nothing,
                      staged_thr::Real = X isa RRRMC.Interface.DoubleGraph ? 0.5 : 0.8, staged_thr_fact::Real = 5.0, quiet = false)
     isfinite(β) || throw(ArgumentError("β must be finite, given: $β"))
     fourK = X isa RRRMC.QT.GraphQuant ? typeof(X).parameters[1] : 0.0
     seed!(ctx, seed)
     chunks = set_configs!(ctx, C0)
-    check(ccall((:rrrmc_rrr_mc_async, LIB), Int32, (Ptr{Cvoid}, Float64, Float64, Int64, Int64, Float64, Float64),
-                ctx.p, β, fourK, iters, step, staged_thr, staged_thr_fact), ctx.p)
-    sync(ctx)
-    Es, acc = fetch(ctx, iters ÷ step)
-    staged = Vector{Int}(undef, ctx.R)
-    check(ccall((:rrrmc_rrr_stats, LIB), Int32, (Ptr{Cvoid}, Ptr{Int64}), ctx.p, staged), ctx.p)
-    quiet || println("samples = ", size(Es, 1), "\niters = ", iters, "\naccept rate = ", sum(acc) / (iters * ctx.R),
-                     "\nfrac. staged iters = ", sum(staged) / (iters * ctx.R))                     # RRRMC.jl:284-288
-    return Es, get_configs!(ctx, chunks, C0), acc, staged
+    call!(n) = (check(ccall((:rrrmc_rrr_mc_async, LIB), Int32, (Ptr{Cvoid}, Float64, Float64, Int64, Int64, Float64, Float64),
+                            ctx.p, β, fourK, n, step, staged_thr, staged_thr_fact), ctx.p); sync(ctx))
+    if hook ≡ nothing
+        call!(iters)
+        Es, acc = fetch(ctx, nsamples(ctx))
+        staged = stats(ctx)
+        quiet || println("samples = ", size(Es, 1), "\niters = ", iters, "\naccept rate = ", sum(acc) / (iters * ctx.R),
+                         "\nfrac. staged iters = ", sum(staged) / (iters * ctx.R))                     # RRRMC.jl:284-288
+        return Es, get_configs!(ctx, chunks, C0), acc, staged
+    end
+    run = HookRun(ctx, X, C0, chunks)
+    acc = zeros(Int, ctx.R); staged = zeros(Int, ctx.R)
+    piece!(n) = (call!(n); acc .+= counts(ctx); staged .+= stats(ctx))
+    resume!(ctx, false)
+    it = min(step - 1, iters)
+    piece!(it)                                   # a fresh run (energy(X, C), gen_ΔEcache: :177-178), up to just before the first sampled iteration
+    resume!(ctx, true)
+    try
+        while it + 1 ≤ iters
+            E = run_energy(ctx)
+            if !sample!(run, hook, it + 1, seen(run, :E, E), (seen(run, :acc, acc), seen(run, :E, E)), Dict(:acc => acc, :E => E))
+                it += 1                          # the reference has counted the iteration its hook ended (:183)
+                break
+            end
+            n = min(step, iters - it)            # the move of the sampled iteration and the step - 1 after it
+            piece!(n); it += n
+        end
+    finally
+        resume!(ctx, false)
+    end
+    Es, Cs = finish!(run, ctx.f64 ? Float64 : Int)
+    acc = seen(run, :acc, acc)
+    quiet || println("samples = ", size(Es, 1), "\niters = ", it, "\naccept rate = ", sum(acc) / (max(it, 1) * ctx.R),
+                     "\nfrac. staged iters = ", sum(staged) / (max(it, 1) * ctx.R))
+    return Es, Cs, acc, staged
 end
 
 # ---- bklMC (src/RRRMC.jl:311-359): `iters` counts the skipped rejections too; `moves` = the moves actually made ("true it") ------------
+"`hook(nextstep, X, Cs, accepted, E)` (:341) at every sample point the skipped iterations pass: a resumed call of `step` iterations ends there"
 function RRRMC.bklMC(ctx::Ctx, X::RRRMC.Interface.AbstractGraph, β::Real, iters::Integer; seed = DEFAULT_SEED, step::Integer = 1,
-                     C0::Union{Vector{RRRMC.Config},Nothing} = nothing, quiet = false)
+                     hook = nothing, C0::Union{Vector{RRRMC.Config},Nothing} = nothing, quiet = false)
     seed!(ctx, seed)
     chunks = set_configs!(ctx, C0)
-    check(ccall((:rrrmc_bkl_mc_async, LIB), Int32, (Ptr{Cvoid}, Float64, Int64, Int64), ctx.p, β, iters, step), ctx.p)
-    sync(ctx)
-    Es, _ = fetch(ctx, iters ÷ step)
-    moves = Vector{Int}(undef, ctx.R)
-    check(ccall((:rrrmc_rrr_stats, LIB), Int32, (Ptr{Cvoid}, Ptr{Int64}), ctx.p, moves), ctx.p)
+    call!(n) = (check(ccall((:rrrmc_bkl_mc_async, LIB), Int32, (Ptr{Cvoid}, Float64, Int64, Int64), ctx.p, β, n, step), ctx.p); sync(ctx))
+    if hook ≡ nothing || iters < step
+        call!(iters)
+        Es, _ = fetch(ctx, nsamples(ctx))
+        moves = stats(ctx)
+        quiet || println("samples = ", size(Es, 1), "\niters = ", iters, "\ntrue it = ", sum(moves) / ctx.R)
+        return Es, get_configs!(ctx, chunks, C0), moves
+    end
+    run = HookRun(ctx, X, C0, chunks)
+    moves = zeros(Int, ctx.R)
+    resume!(ctx, false)
+    try
+        for k = 1:(iters ÷ step)                 # the reference goes `out` after the last sample (:343): nothing runs behind it
+            call!(step); resume!(ctx, true)
+            moves .+= stats(ctx)
+            E = run_energy(ctx)
+            sample!(run, hook, k * step, seen(run, :E, E), (seen(run, :acc, moves), seen(run, :E, E)), Dict(:acc => moves, :E => E)) || break
+        end
+    finally
+        resume!(ctx, false)
+    end
+    Es, Cs = finish!(run, ctx.f64 ? Float64 : Int)
+    moves = seen(run, :acc, moves)
     quiet || println("samples = ", size(Es, 1), "\niters = ", iters, "\ntrue it = ", sum(moves) / ctx.R)
-    return Es, get_configs!(ctx, chunks, C0), moves
+    return Es, Cs, moves
 end
 
 # ---- wtmMC (src/RRRMC.jl:376-426, src/WaitingTimes.jl): `step::Float64` in sweeps, `samples` energies at global times k*step/N ---------
+"`hook(nextstep, X, Cs, num_moves, E)` (:404) at every sample time (`nextstep`: k additions of step / N, as :391,405 accumulate it)"
 function RRRMC.wtmMC(ctx::Ctx, X::RRRMC.Interface.AbstractGraph, β::Real, samples::Integer; seed = DEFAULT_SEED, step::Float64 = 1.0,
-                     C0::Union{Vector{RRRMC.Config},Nothing} = nothing, quiet = false)
+                     hook = nothing, C0::Union{Vector{RRRMC.Config},Nothing} = nothing, quiet = false)
     seed!(ctx, seed)
     chunks = set_configs!(ctx, C0)
-    check(ccall((:rrrmc_wtm_mc_async, LIB), Int32, (Ptr{Cvoid}, Float64, Int64, Float64), ctx.p, β, samples, step), ctx.p)
-    sync(ctx)
-    Es, moves = fetch(ctx, samples)
-    t = Vector{Float64}(undef, ctx.R)
-    check(ccall((:rrrmc_wtm_times, LIB), Int32, (Ptr{Cvoid}, Ptr{Float64}), ctx.p, t), ctx.p)
-    quiet || println("samples = ", size(Es, 1), "\nnum. moves = ", sum(moves) / ctx.R, "\nglobal time = ", sum(t) / ctx.R)     # :419-423
-    return Es, get_configs!(ctx, chunks, C0), moves, t
+    call!(n) = (check(ccall((:rrrmc_wtm_mc_async, LIB), Int32, (Ptr{Cvoid}, Float64, Int64, Float64), ctx.p, β, n, step), ctx.p); sync(ctx))
+    times() = (t = Vector{Float64}(undef, ctx.R); check(ccall((:rrrmc_wtm_times, LIB), Int32, (Ptr{Cvoid}, Ptr{Float64}), ctx.p, t), ctx.p); t)
+    if hook ≡ nothing
+        call!(samples)
+        Es, moves = fetch(ctx, nsamples(ctx))
+        t = times()
+        quiet || println("samples = ", size(Es, 1), "\nnum. moves = ", sum(moves) / ctx.R, "\nglobal time = ", sum(t) / ctx.R)     # :419-423
+        return Es, get_configs!(ctx, chunks, C0), moves, t
+    end
+    run = HookRun(ctx, X, C0, chunks)
+    moves = zeros(Int, ctx.R); t = zeros(Float64, ctx.R)
+    st = step / ctx.N                            # :391
+    nextstep = st
+    resume!(ctx, false)
+    try
+        for _ = 1:samples
+            call!(1); resume!(ctx, true)
+            moves .+= counts(ctx); t = times()
+            E = run_energy(ctx)
+            sample!(run, hook, nextstep, seen(run, :E, E), (seen(run, :acc, moves), seen(run, :E, E)), Dict(:acc => moves, :E => E, :t => t)) || break
+            nextstep += st                       # :405
+        end
+    finally
+        resume!(ctx, false)
+    end
+    Es, Cs = finish!(run, ctx.f64 ? Float64 : Int)
+    moves = seen(run, :acc, moves); t = seen(run, :t, t)
+    quiet || println("samples = ", size(Es, 1), "\nnum. moves = ", sum(moves) / ctx.R, "\nglobal time = ", sum(t) / ctx.R)
+    return Es, Cs, moves, t
 end
 
 # ---- extremal_opt (src/RRRMC.jl:474-521): EOCache{Int,L} on the DiscrGraphs, the generic EOCacheCont elsewhere -------------------------
-"-> (Cs, Emin, Cmin::Vector{Config}, itmin) per replica, the reference's return tuple (:520); `Es` (what the hook would see) as 5th value"
+"""-> (Cs, Emin, Cmin::Vector{Config}, itmin) per replica, the reference's return tuple (:520); `Es` (what the hook sees) as 5th value.
+`hook(it, X, Cs, E, Emin)` (:501 — not the samplers' signature) every `step` iterations, before the move of iteration `it`."""
 function RRRMC.extremal_opt(ctx::Ctx, X::RRRMC.Interface.AbstractGraph, τ::Real, iters::Integer; seed = DEFAULT_SEED, step::Integer = 1,
-                            C0::Union{Vector{RRRMC.Config},Nothing} = nothing, quiet = false)
+                            hook = nothing, C0::Union{Vector{RRRMC.Config},Nothing} = nothing, quiet = false)
     N = ctx.N; nch = (N + 63) >> 6
     ftau = cumsum([j^(-τ) for j = 1:N])                                # as DeltaE.jl:444-445 computes it
     seed!(ctx, seed)
     chunks = set_configs!(ctx, C0)
-    GC.@preserve ftau check(ccall((:rrrmc_extremal_opt_async, LIB), Int32, (Ptr{Cvoid}, Ptr{Float64}, Int64, Int64), ctx.p, ftau, iters, step), ctx.p)
-    sync(ctx)
-    Es, _ = fetch(ctx, iters ÷ step)
-    cmin = Matrix{UInt64}(undef, nch, ctx.R); itmin = Vector{Int}(undef, ctx.R)
-    if ctx.f64
-        Emin = Vector{Float64}(undef, ctx.R)
-        check(ccall((:rrrmc_extremal_opt_results_f64, LIB), Int32, (Ptr{Cvoid}, Ptr{Float64}, Ptr{UInt64}, Ptr{Int64}), ctx.p, Emin, cmin, itmin), ctx.p)
+    call!(n) = (GC.@preserve ftau check(ccall((:rrrmc_extremal_opt_async, LIB), Int32, (Ptr{Cvoid}, Ptr{Float64}, Int64, Int64), ctx.p, ftau, n, step), ctx.p); sync(ctx))
+    function results()                                                  # Emin, Cmin (chunks), itmin of the run so far
+        cmin = Matrix{UInt64}(undef, nch, ctx.R); itmin = Vector{Int}(undef, ctx.R)
+        if ctx.f64
+            Emin = Vector{Float64}(undef, ctx.R)
+            check(ccall((:rrrmc_extremal_opt_results_f64, LIB), Int32, (Ptr{Cvoid}, Ptr{Float64}, Ptr{UInt64}, Ptr{Int64}), ctx.p, Emin, cmin, itmin), ctx.p)
+        else
+            Emin = Vector{Int}(undef, ctx.R)
+            check(ccall((:rrrmc_extremal_opt_results, LIB), Int32, (Ptr{Cvoid}, Ptr{Int64}, Ptr{UInt64}, Ptr{Int64}), ctx.p, Emin, cmin, itmin), ctx.p)
+        end
+        return Emin, cmin, itmin
+    end
+    ET = ctx.f64 ? Float64 : Int
+    it = iters
+    if hook ≡ nothing
+        call!(iters)
+        Es, _ = fetch(ctx, nsamples(ctx))
+        Emin, cmin, itmin = results()
+        Cs = get_configs!(ctx, chunks, C0)
     else
-        Emin = Vector{Int}(undef, ctx.R)
-        check(ccall((:rrrmc_extremal_opt_results, LIB), Int32, (Ptr{Cvoid}, Ptr{Int64}, Ptr{UInt64}, Ptr{Int64}), ctx.p, Emin, cmin, itmin), ctx.p)
+        run = HookRun(ctx, X, C0, chunks)
+        resume!(ctx, false)
+        it = min(step - 1, iters)
+        call!(it)
+        Emin, cmin, itmin = results()
+        resume!(ctx, true)
+        try
+            while it + 1 ≤ iters
+                E = run_energy(ctx)
+                live = Dict(:E => E, :Emin => Emin, :itmin => itmin, :cmin => [cmin[:, r] for r in 1:ctx.R])
+                if !sample!(run, hook, it + 1, seen(run, :E, E), (seen(run, :E, E), seen(run, :Emin, Emin)), live)
+                    it += 1
+                    break
+                end
+                n = min(step, iters - it)
+                call!(n); it += n
+                Emin, cmin, itmin = results()
+            end
+        finally
+            resume!(ctx, false)
+        end
+        Es, Cs = finish!(run, ET)
+        Emin = seen(run, :Emin, Emin); itmin = seen(run, :itmin, itmin)
+        kept = seen(run, :cmin, [cmin[:, r] for r in 1:ctx.R])
+        for r = 1:ctx.R; cmin[:, r] .= kept[r]; end
     end
     Cmin = [RRRMC.Config(N, init = false) for _ = 1:ctx.R]
     for r = 1:ctx.R; Cmin[r].s.chunks .= cmin[:, r]; end
-    quiet || println("samples = ", size(Es, 1), "\niters = ", iters, "\nEmin = ", minimum(Emin))
-    return get_configs!(ctx, chunks, C0), Emin, Cmin, itmin, Es
+    quiet || println("iters = ", it, "\nmin [it = ", itmin, "] = ", Emin)                             # :516-519
+    return Cs, Emin, Cmin, itmin, Es
 end
 
 # ---- GraphQuant observables of the live configuration (src/graphs/QT.jl:113-122, 213-268) ---------------------------------------------
@@ -527,13 +727,13 @@ configs_in(G::OnGPU, C0) = C0 ≡ nothing ? nothing : (C0 isa RRRMC.Config ? RRR
 # one chain: a Vector and a Config, as the reference returns them; several: the matrix and the vector of Configs
 unwrap1(G::OnGPU, Es::AbstractMatrix) = single(G) ? Es[:, 1] : Es
 unwrap1(G::OnGPU, v::AbstractVector) = single(G) ? v[1] : v
-no_hook(hook, what) = hook ≡ nothing || throw(ArgumentError("$what on the GPU takes no hook (its chain cannot be cut and resumed); use standardMC, or sample with `step`"))
+# the hook of ONE chain takes scalars and the Config (src/RRRMC.jl:61-64); the context-first layer hands vectors over the replicas
+hook1(G::OnGPU, hook) = hook ≡ nothing || !single(G) ? hook : (it, X, Cs, a, b) -> hook(it, X, Cs[1], a[1], b[1])
 
 function RRRMC.standardMC(G::OnGPU, β::Real, iters::Integer; seed = DEFAULT_SEED, step::Integer = 1, hook = nothing,
                           C0::Union{RRRMC.Config,Vector{RRRMC.Config},Nothing} = nothing, quiet::Bool = false)
-    h = hook ≡ nothing || !single(G) ? hook : (it, X, Cs, acc, E) -> hook(it, X, Cs[1], acc[1], E[1])
     with_ctx(G, β) do ctx
-        Es, Cs = RRRMC.standardMC(ctx, G.X, β, iters; seed = seed, step = step, hook = h, C0 = configs_in(G, C0), quiet = quiet)
+        Es, Cs = RRRMC.standardMC(ctx, G.X, β, iters; seed = seed, step = step, hook = hook1(G, hook), C0 = configs_in(G, C0), quiet = quiet)
         return unwrap1(G, Es), unwrap1(G, Cs)
     end
 end
@@ -541,10 +741,9 @@ end
 function RRRMC.rrrMC(G::OnGPU, β::Real, iters::Integer; seed = DEFAULT_SEED, step::Integer = 1, hook = nothing,
                      C0::Union{RRRMC.Config,Vector{RRRMC.Config},Nothing} = nothing,
                      staged_thr::Real = G.X isa RRRMC.Interface.DoubleGraph ? 0.5 : NaN, staged_thr_fact::Real = 5.0, quiet::Bool = false)
-    no_hook(hook, "rrrMC")
     thr = isnan(staged_thr) ? (G.X isa RRRMC.Interface.DiscrGraph ? 0.5 : 0.8) : staged_thr          # src/RRRMC.jl:162-164
     with_ctx(G, β) do ctx
-        Es, Cs, _, _ = RRRMC.rrrMC(ctx, G.X, β, iters; seed = seed, step = step, C0 = configs_in(G, C0), staged_thr = thr,
+        Es, Cs, _, _ = RRRMC.rrrMC(ctx, G.X, β, iters; seed = seed, step = step, hook = hook1(G, hook), C0 = configs_in(G, C0), staged_thr = thr,
                                    staged_thr_fact = staged_thr_fact, quiet = quiet)
         return unwrap1(G, Es), unwrap1(G, Cs)
     end
@@ -552,18 +751,16 @@ end
 
 function RRRMC.bklMC(G::OnGPU, β::Real, iters::Integer; seed = DEFAULT_SEED, step::Integer = 1, hook = nothing,
                      C0::Union{RRRMC.Config,Vector{RRRMC.Config},Nothing} = nothing, quiet::Bool = false)
-    no_hook(hook, "bklMC")
     with_ctx(G, β) do ctx
-        Es, Cs, _ = RRRMC.bklMC(ctx, G.X, β, iters; seed = seed, step = step, C0 = configs_in(G, C0), quiet = quiet)
+        Es, Cs, _ = RRRMC.bklMC(ctx, G.X, β, iters; seed = seed, step = step, hook = hook1(G, hook), C0 = configs_in(G, C0), quiet = quiet)
         return unwrap1(G, Es), unwrap1(G, Cs)
     end
 end
 
 function RRRMC.wtmMC(G::OnGPU, β::Real, samples::Integer; seed = DEFAULT_SEED, step::Float64 = 1.0, hook = nothing,
                      C0::Union{RRRMC.Config,Vector{RRRMC.Config},Nothing} = nothing, quiet::Bool = false)
-    no_hook(hook, "wtmMC")
     with_ctx(G, β) do ctx
-        Es, Cs, _, _ = RRRMC.wtmMC(ctx, G.X, β, samples; seed = seed, step = step, C0 = configs_in(G, C0), quiet = quiet)
+        Es, Cs, _, _ = RRRMC.wtmMC(ctx, G.X, β, samples; seed = seed, step = step, hook = hook1(G, hook), C0 = configs_in(G, C0), quiet = quiet)
         return unwrap1(G, Es), unwrap1(G, Cs)
     end
 end
@@ -571,9 +768,8 @@ end
 "-> (C, Emin, Cmin, itmin), the reference's return tuple (src/RRRMC.jl:520); vectors of them for several replicas"
 function RRRMC.extremal_opt(G::OnGPU, τ::Real, iters::Integer; seed = DEFAULT_SEED, step::Integer = 1, hook = nothing,
                             C0::Union{RRRMC.Config,Vector{RRRMC.Config},Nothing} = nothing, quiet::Bool = false)
-    no_hook(hook, "extremal_opt")
     with_ctx(G, 1.0) do ctx
-        Cs, Emin, Cmin, itmin, _ = RRRMC.extremal_opt(ctx, G.X, τ, iters; seed = seed, step = step, C0 = configs_in(G, C0), quiet = quiet)
+        Cs, Emin, Cmin, itmin, _ = RRRMC.extremal_opt(ctx, G.X, τ, iters; seed = seed, step = step, hook = hook1(G, hook), C0 = configs_in(G, C0), quiet = quiet)
         return unwrap1(G, Cs), unwrap1(G, Emin), unwrap1(G, Cmin), unwrap1(G, itmin)
     end
 end

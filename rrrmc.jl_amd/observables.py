@@ -43,10 +43,10 @@ class SnapshotLog:
             raise RuntimeError("SnapshotLog: all %d snapshot slots are in use" % self.nslots)
         self.eng.snapshot_store(self.count)
         self.count += 1
-        self.mctimes.append(int(it))
+        self.mctimes.append(it)                  # an iteration number; wtmMC hands its hook the sample's global time (src/RRRMC.jl:404)
         self.clock.append(t)
         for r, f in self.files.items():
-            f.write("%d %d %s %s\n" % (it, int(accepted[r]), _julia_num(E[r]), repr(float(t))))
+            f.write("%s %d %s %s\n" % (_julia_num(it), int(accepted[r]), _julia_num(E[r]), repr(float(t))))
         return t < self.t_limit
 
     def close(self):

@@ -141,7 +141,7 @@ def engine_call(eng, smp, n, step, beta, tau, thr):
     return Es, np.stack([np.asarray(Emin, np.float64), np.asarray(itmin, np.float64)], 1)
 
 
-def run_both(pkg, oracle, M, smp, R, iters, step, beta=2.0, tau=1.3, thr=None, tail=None, check=(0,)):
+def run_both(pkg, oracle, M, smp, R, iters, step, beta=2.0, tau=1.3, thr=None, tail=None, check=(0,), engine_kw=None):
     """un-hooked run, hooked run and their resumed continuations on one engine; the oracle's hooked run for the replicas in `check`"""
     X = M.X
     fn = front(pkg, smp)
@@ -160,7 +160,7 @@ def run_both(pkg, oracle, M, smp, R, iters, step, beta=2.0, tau=1.3, thr=None, t
         return True
 
     out = {}
-    with pkg.Engine(X, R) as eng:
+    with pkg.Engine(X, R, **(engine_kw or {})) as eng:
         eng.seed(SEED)
         eng.init_spins_random()
         C0 = eng.get_config()
@@ -282,6 +282,43 @@ def test_quant_config5_geometry_rrr_hooked_through_every_build(pkg, oracle, monk
 def test_quant_runtests_graph_hooked(pkg, oracle, smp, thr):
     """GraphQuant(10, 8, 0.5, 2.0, GraphRRG, 10, 3) of test/runtests.jl:78 under every sampler (bklMC / wtmMC / extremal_opt: the generic caches)"""
     run_both(pkg, oracle, Quant(pkg), smp, 3, 2000, 100, thr=thr, check=(0, 2))
+
+
+# ---- the other graph families: hooked == un-hooked, and the continuation agrees (their un-hooked chains are oracle-checked elsewhere) ----
+class Plain:
+    def __init__(self, X):
+        self.X = X
+
+
+def other_graphs(pkg):
+    return {
+        "rrg-levels": lambda: pkg.GraphRRG(40, 3, LEV=(-1, 0, 1), seed=SEED),                       # RRRMC_MODEL_SPARSE_LEVELS (test/runtests.jl:37)
+        "ea-levels": lambda: pkg.GraphEA(3, 2, LEV=(-1, 0, 1), seed=SEED),
+        "ea-normal-l2": lambda: pkg.GraphEANormal(2, 3, seed=SEED),                                # repeated neighbours: the thread build of the continuous samplers
+        "rrg-discretized": lambda: pkg.GraphRRGNormalDiscretized(40, 3, (-1, 0, 1), seed=SEED),    # rrr_dbl_kernel; bkl / wtm / eo over the whole DoubleGraph
+        "ea-discretized": lambda: pkg.GraphEANormalDiscretized(3, 2, (-1, 0, 1), seed=SEED),
+        "sk-binary": lambda: pkg.GraphSK(20, seed=SEED),                                           # integer fields, delta_energy = lfields / sqrt(N); EO ties
+        "qskt": lambda: pkg.GraphQSKT(12, 4, 0.5, 2.0, seed=SEED),                                 # GraphQuant over binary GraphSK slices
+        "qsknormal": lambda: pkg.GraphQSKNormalT(10, 4, 0.5, 2.0, seed=SEED),                      # GraphQuant over GraphSKNormal slices
+    }
+
+
+@pytest.mark.parametrize("name", ["rrg-levels", "ea-levels", "ea-normal-l2", "rrg-discretized", "ea-discretized", "sk-binary", "qskt", "qsknormal"])
+@pytest.mark.parametrize("smp", ["rrr", "bkl", "wtm", "eo"])
+def test_other_graph_families_hooked(pkg, oracle, name, smp):
+    X = other_graphs(pkg)[name]()
+    try:
+        run_both(pkg, oracle, Plain(X), smp, 3, 1500, 100, check=())
+    except pkg.RRRMCError as e:
+        if e.code == 3:          # RRRMC_ERR_UNSUPPORTED: a sampler the library does not offer for this graph (include/rrrmc_hip.h)
+            pytest.skip(str(e))
+        raise
+
+
+@pytest.mark.parametrize("smp", ["rrr", "bkl", "wtm", "eo"])
+def test_hooked_run_on_a_multi_device_context(pkg, oracle, smp):
+    """rrrmc_ctx_create_multi: two shards (here both on device 0); every shard keeps its own run, the hook sees the gathered replicas"""
+    run_both(pkg, oracle, RRG(pkg, 60), smp, 64, 1000, 100, check=(0, 33, 63), engine_kw={"devices": [0, 0]})
 
 
 # ---- the reference's own test loop ------------------------------------------------------------------------------------------------
