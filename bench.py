@@ -523,20 +523,10 @@ SPF_TEAM_SOURCES = ["rrrmc.jl_amd/csrc/spf_team_kernel.hpp", "rrrmc.jl_amd/csrc/
                     "rrrmc.jl_amd/csrc/host_spf.hpp", "rrrmc.jl_amd/csrc/spf_kernels.hpp"]      # what spf_traffic.json describes
 
 
-def spf_team_kernel_name(R, K=3):
-    """the build host_spf.hpp picks for R replicas on a 256-CU device (teams of 64 / 32 / 16 replicas until there are as many teams as CUs)"""
-    W, tw = (R + 63) // 64, 64
-    while tw > 16 and W * (64 // tw) < 256:
-        tw //= 2
-    nw = 16 if W * (64 // tw) <= 256 else 8
-    if nw == 8:
-        tw = 64
-    def lds(M):
-        return (8 * (K + 1) * tw + 4 * tw) * (M + nw) + 4 * (tw + 2 * M + 4)
-    M = 60 if nw == 16 else 2 * (nw - 1)                      # spf_team_slots (csrc/spf_team_params.hpp)
-    while M > 2 * (nw - 1) and lds(M) > 160 * 1024:
-        M -= 1
-    return "spf_team_kernel<%d, %d, %d, %d>" % (K, nw, M, tw)
+def spf_team_kernel_name(eng, K=3):
+    """the build the library launches for this context, asked of the library (rrrmc_spf_team_build) — not a copy of host_spf.hpp's rule"""
+    nw, tw, m = eng.spf_team_build()
+    return "spf_team_kernel<%d, %d, %d, %d>" % (K, nw, m, tw) if nw else "spf_sweep_kernel<%d>" % K
 
 
 def spf_traffic(key=None):
@@ -567,10 +557,11 @@ def secondary_f64_exact(pkg, O, device):
         dt = time.perf_counter() - t0
         _, k_ms, nl = eng.last_timing()
         _, acc = eng.fetch_results(want_energies=False)
+        kname = spf_team_kernel_name(eng, K)
     a = float(acc.mean()) / iters
     bpa = 8 + a * (10 + 17 * K)                                  # SURVEY.md §8d widths: field 8 B, spin 1 B
     out = {"workload": "GraphRRGNormal(N=4096,K=3) standardMC (exact mode) beta=1.0, 8192 replicas, 2^16 iterations per replica, energy sample every 4096",
-           "value": R * iters / dt, "unit": "attempts/s", "kernel": spf_team_kernel_name(R), "avg_launch_ms": k_ms / max(nl, 1), "launches": nl,
+           "value": R * iters / dt, "unit": "attempts/s", "kernel": kname, "avg_launch_ms": k_ms / max(nl, 1), "launches": nl,
            "acceptance": a, "algorithmic_bytes_per_attempt": bpa, "achieved_GBps": bpa * R * iters / (k_ms * 1e-3) / 1e9}
     out["frac"] = out["achieved_GBps"] / HBM_PEAK_GBS
     # what binds it at this replica count: the memory system.  The kernel reads the lines of the Float64 fields whole and stores the accepting lanes'
@@ -614,10 +605,11 @@ def secondary_f64_exact_big(pkg, O, device):
         dt = time.perf_counter() - t0
         _, k_ms, nl = eng.last_timing()
         _, acc = eng.fetch_results(want_energies=False)
+        kname = spf_team_kernel_name(eng, K)
     a = float(acc.mean()) / iters
     bpa = 8 + a * (10 + 17 * K)
     out = {"workload": "GraphRRGNormal(N=4096,K=3) standardMC (exact mode) beta=1.0, 262144 replicas, 2^14 iterations per replica, energy sample every 4096",
-           "value": R * iters / dt, "unit": "attempts/s", "kernel": spf_team_kernel_name(R), "avg_launch_ms": k_ms / max(nl, 1), "launches": nl,
+           "value": R * iters / dt, "unit": "attempts/s", "kernel": kname, "avg_launch_ms": k_ms / max(nl, 1), "launches": nl,
            "acceptance": a, "algorithmic_bytes_per_attempt": bpa, "achieved_GBps": bpa * R * iters / (k_ms * 1e-3) / 1e9}
     out["frac"] = out["achieved_GBps"] / HBM_PEAK_GBS
     out["bound"] = "hbm / memory system (measured traffic: random 512-byte lines read whole, the accepting lanes' fields written)"

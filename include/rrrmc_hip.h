@@ -315,6 +315,10 @@ RRRMC_API int32_t rrrmc_last_timing(rrrmc_ctx *ctx, double *total_ms, double *sw
 RRRMC_API int32_t rrrmc_timing_accumulate(rrrmc_ctx *ctx, int32_t on);
 RRRMC_API int32_t rrrmc_timing_total(rrrmc_ctx *ctx, double *sweep_ms, int64_t *sweep_launches);
 
+/* The build of spf_team_kernel<K, waves, slots, width> the default standardMC of a RRRMC_MODEL_SPARSE_F64 context launches on its device
+ * (teams of `width` replicas, `waves` wavefronts and `slots` in-flight records each); zeros when the one-wavefront kernel runs instead.
+ * A reporting helper (bench.py names the kernel its measured traffic belongs to); any output may be NULL. */
+RRRMC_API int32_t rrrmc_spf_team_build(rrrmc_ctx *ctx, int32_t *waves_out, int32_t *width_out, int32_t *slots_out);
 /* Samples per replica the last sampling call took: the row length of rrrmc_fetch_results*' Es_out.  iters / step for a call that starts a
  * run; a RESUMED call takes a sample before every iteration that is a multiple of `step` of the run's count (see rrrmc_set_resume). */
 RRRMC_API int64_t rrrmc_results_samples(const rrrmc_ctx *ctx);

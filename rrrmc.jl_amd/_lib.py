@@ -19,7 +19,7 @@ SYMBOLS = [
     "rrrmc_version", "rrrmc_last_error", "rrrmc_device_count", "rrrmc_device_copy_bandwidth", "rrrmc_host_alloc", "rrrmc_host_free", "rrrmc_ctx_create", "rrrmc_ctx_create_multi", "rrrmc_ctx_destroy",
     "rrrmc_set_graph", "rrrmc_seed", "rrrmc_init_spins_random", "rrrmc_set_spins", "rrrmc_get_spins",
     "rrrmc_energy", "rrrmc_get_fields", "rrrmc_standard_mc", "rrrmc_standard_mc_async", "rrrmc_sync",
-    "rrrmc_fetch_results", "rrrmc_last_timing", "rrrmc_timing_accumulate", "rrrmc_timing_total", "rrrmc_set_resume", "rrrmc_set_debug_checks", "rrrmc_tracked_energy_f64", "rrrmc_tracked_energy", "rrrmc_results_samples", "rrrmc_standard_mc_fast_async", "rrrmc_iterations_done", "rrrmc_gen_rrg", "rrrmc_gen_ea",
+    "rrrmc_fetch_results", "rrrmc_last_timing", "rrrmc_timing_accumulate", "rrrmc_timing_total", "rrrmc_set_resume", "rrrmc_set_debug_checks", "rrrmc_tracked_energy_f64", "rrrmc_tracked_energy", "rrrmc_results_samples", "rrrmc_spf_team_build", "rrrmc_standard_mc_fast_async", "rrrmc_iterations_done", "rrrmc_gen_rrg", "rrrmc_gen_ea",
     "rrrmc_gen_couplings_pm1", "rrrmc_gen_couplings_lev", "rrrmc_set_graph_levels", "rrrmc_set_couplings_dense", "rrrmc_energy_f64", "rrrmc_get_fields_f64",
     "rrrmc_standard_mc_f64", "rrrmc_fetch_results_f64", "rrrmc_gen_sk_gauss",
     "rrrmc_set_couplings_bits", "rrrmc_gen_sk_binary", "rrrmc_set_coloring", "rrrmc_colored_sweeps_async", "rrrmc_colored_count_accepted",
@@ -112,6 +112,8 @@ def lib():
     L.rrrmc_timing_accumulate.argtypes = [vp, C.c_int32]
     L.rrrmc_timing_total.restype = C.c_int32
     L.rrrmc_timing_total.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
+    L.rrrmc_spf_team_build.restype = C.c_int32
+    L.rrrmc_spf_team_build.argtypes = [vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
     L.rrrmc_results_samples.restype = C.c_int64
     L.rrrmc_results_samples.argtypes = [vp]
     L.rrrmc_iterations_done.restype = C.c_int64

@@ -69,7 +69,7 @@ spf_fn spf_fields_for_K(int K) { RRRMC_DISPATCH_UPTO8(K, spf_fields_kernel) }
 // A chain's pace is bound by what one compute unit moves, so the groups are split into teams of 32 or 16 replicas until there are as many teams
 // as compute units; sixteen wavefronts per team (fifteen executing) while the teams are few enough to own a compute unit each and their
 // records fit its LDS, eight otherwise.
-constexpr int64_t kSpfTeamItersPerLaunch = 1 << 18;     // 2 + 3 K dwords of plan per iteration
+constexpr int64_t kSpfTeamItersPerLaunch = 1 << 18;     // spf_plan_stride(K) = 4 + 3 K dwords of plan per iteration
 struct SpfTeamBuild { int nw, tw; size_t lds; };
 inline SpfTeamBuild spf_team_build(const rrrmc_ctx* ctx)
 {
@@ -78,10 +78,12 @@ inline SpfTeamBuild spf_team_build(const rrrmc_ctx* ctx)
     if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, ctx->device) != hipSuccess || ncu < 1) ncu = 256;
     int tw = 64;
     while (tw > 16 && ctx->pfW * (64 / tw) < ncu) tw /= 2;
-    int nw = ctx->pfW * (64 / tw) <= ncu ? 16 : 8;
-    // tests / timing experiments: RRRMC_SPF_TEAM_WAVES = 8 | 16, RRRMC_SPF_TEAM_WIDTH = 64 | 32 | 16
-    if (const char* e = std::getenv("RRRMC_SPF_TEAM_WIDTH"); e && (!std::strcmp(e, "64") || !std::strcmp(e, "32") || !std::strcmp(e, "16"))) tw = std::atoi(e);
-    if (const char* e = std::getenv("RRRMC_SPF_TEAM_WAVES"); e && (!std::strcmp(e, "8") || !std::strcmp(e, "16"))) nw = std::atoi(e);
+    // tests / timing experiments: RRRMC_SPF_TEAM_WIDTH = 64 | 32 | 16 first — the number of wavefronts follows from the width that will run;
+    // RRRMC_SPF_TEAM_WAVES = 8 | 16 (a team narrower than a group exists with sixteen wavefronts only: a requested width below 64 keeps 16)
+    bool width_forced = false;
+    if (const char* e = std::getenv("RRRMC_SPF_TEAM_WIDTH"); e && (!std::strcmp(e, "64") || !std::strcmp(e, "32") || !std::strcmp(e, "16"))) { tw = std::atoi(e); width_forced = true; }
+    int nw = (ctx->pfW * (64 / tw) <= ncu || (width_forced && tw < 64)) ? 16 : 8;
+    if (const char* e = std::getenv("RRRMC_SPF_TEAM_WAVES"); e && (!std::strcmp(e, "8") || !std::strcmp(e, "16")) && !(width_forced && tw < 64)) nw = std::atoi(e);
     if (nw == 8) tw = 64;                                  // the eight-wavefront build exists for whole groups only
     size_t lds = spf_team_build_lds(K, nw, tw);
     if (!lds && nw == 16 && tw == 64) { nw = 8; lds = spf_team_build_lds(K, nw, tw); }      // K >= 5: the records of sixteen wavefronts x 64 replicas do not fit

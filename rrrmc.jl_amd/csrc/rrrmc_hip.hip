@@ -574,7 +574,7 @@ int32_t prepare_chunk_list(rrrmc_ctx* ctx, int64_t iters, int64_t step, int C, b
             free_dev(ctx->d_chunks_alt);
             ctx->chunks_cap = 0;
             HIP_TRY(ctx, hipMalloc(&ctx->d_chunks, sizeof(ChunkDesc) * nch_all));
-            HIP_TRY(ctx, hipMalloc(&ctx->d_chunks_alt, sizeof(ChunkDesc) * nch_all));
+            if (ctx->model == RRRMC_MODEL_SPARSE_PM1) HIP_TRY(ctx, hipMalloc(&ctx->d_chunks_alt, sizeof(ChunkDesc) * nch_all));      // (the fast Float64 sampler keeps one table)
             ctx->chunks_cap = nch_all;
         }
         if (nch_all > ctx->h_chunks_cap) {
@@ -638,6 +638,40 @@ template <typename F> int32_t multi_each(rrrmc_ctx* ctx, F&& f, bool threads)
         if (is_multi(ctx))                                                                                               \
             return multi_each(ctx, [&](rrrmc_ctx* c, int64_t r0, int64_t rn) -> int32_t { (void)r0; (void)rn; return (expr); }, threads); \
     } while (0)
+
+namespace {
+// What a finished sampling call may have left for the host to report: the debug mode's mismatch flag, spf_team_kernel's protocol failure, the
+// dynamic sampler's loss of precision.  Called by every entry point that has synchronised the stream and is about to hand results or state
+// back (rrrmc_sync, rrrmc_fetch_results*, rrrmc_get_spins, rrrmc_tracked_energy*): none of them returns the output of a void call as good.
+int32_t post_sync_checks(rrrmc_ctx* ctx)
+{
+    if (ctx->debug_checks && ctx->dbg_flag) {
+        int32_t fl[2] = {0, 0};
+        HIP_TRY(ctx, hipMemcpy(fl, ctx->dbg_flag, sizeof fl, hipMemcpyDeviceToHost));
+        HIP_TRY(ctx, hipMemset(ctx->dbg_flag, 0, sizeof fl));
+        if (fl[0])
+            return fail(ctx, RRRMC_ERR_STATE, "debug check failed for %d value(s), e.g. replica %d: the tracked energy / cached fields differ from "
+                                              "energy(X, C) recomputed from the configuration (src/graphs/RRG.jl:229-231, SK.jl:268-273)", fl[0], fl[1]);
+    }
+    if (ctx->model == RRRMC_MODEL_SPARSE_F64 && ctx->pf_status && !ctx->last_call_rrr) {
+        int32_t st = 0;
+        HIP_TRY(ctx, hipMemcpy(&st, ctx->pf_status, sizeof st, hipMemcpyDeviceToHost));
+        if (st) {
+            HIP_TRY(ctx, hipMemset(ctx->pf_status, 0, sizeof st));
+            ctx->results_valid = false; ctx->std_cache_live = false; ctx->pf_lf_live = false;
+            return fail(ctx, RRRMC_ERR_STATE, "spf_team_kernel: a wait on the retired prefix ran into its limit (protocol failure); the call's results are void. "
+                                              "RRRMC_SPF_TEAM=0 selects the single-wavefront kernel");
+        }
+    }
+    if (ctx->last_call_rrr && (ctx->model == RRRMC_MODEL_SK_NORMAL || ctx->model == RRRMC_MODEL_SPARSE_F64) && ctx->rs_status) {
+        std::vector<int32_t> stt((size_t)ctx->R);
+        HIP_TRY(ctx, hipMemcpy(stt.data(), ctx->rs_status, sizeof(int32_t) * stt.size(), hipMemcpyDeviceToHost));
+        for (int64_t r = 0; r < ctx->R; ++r)
+            if (stt[r]) return fail(ctx, RRRMC_ERR_STATE, "replica %lld: Unrecoverable loss of precision detected in the dynamic sampler", (long long)r);   // DynamicSamplers.jl:147
+    }
+    return RRRMC_OK;
+}
+}  // namespace
 
 extern "C" {
 
@@ -964,6 +998,20 @@ int32_t rrrmc_seed(rrrmc_ctx* ctx, uint64_t seed)
     return RRRMC_OK;
 }
 
+// which build of spf_team_kernel the default standardMC of a RRRMC_MODEL_SPARSE_F64 context launches (bench.py names the kernel its traffic
+// figures belong to from this, not from a copy of the selection rule)
+int32_t rrrmc_spf_team_build(rrrmc_ctx* ctx, int32_t* waves_out, int32_t* width_out, int32_t* slots_out)
+{
+    if (!ctx) return RRRMC_ERR_INVALID_ARG;
+    if (is_multi(ctx)) return rrrmc_spf_team_build(ctx->kids[0], waves_out, width_out, slots_out);
+    if (ctx->model != RRRMC_MODEL_SPARSE_F64) return fail(ctx, RRRMC_ERR_STATE, "rrrmc_spf_team_build is for RRRMC_MODEL_SPARSE_F64");
+    const bool team = spf_use_team(ctx);
+    const SpfTeamBuild tb = team ? spf_team_build(ctx) : SpfTeamBuild{0, 0, 0};
+    if (waves_out) *waves_out = tb.lds ? tb.nw : 0;          // 0: the one-wavefront spf_sweep_kernel runs (RRRMC_SPF_TEAM=0, or no build for this K)
+    if (width_out) *width_out = tb.lds ? tb.tw : 0;
+    if (slots_out) *slots_out = tb.lds ? spf_team_slots((int)ctx->K, tb.nw, tb.tw) : 0;
+    return RRRMC_OK;
+}
 int64_t rrrmc_results_samples(const rrrmc_ctx* ctx) { return !ctx ? -1 : is_multi(ctx) ? ctx->kids[0]->nsamp : ctx->nsamp; }
 int64_t rrrmc_iterations_done(const rrrmc_ctx* ctx) { return !ctx ? -1 : is_multi(ctx) ? (int64_t)ctx->kids[0]->it_done : (int64_t)ctx->it_done; }
 
@@ -1100,6 +1148,9 @@ int32_t rrrmc_get_spins(rrrmc_ctx* ctx, uint64_t* chunks)
     int32_t rc = ensure_state(ctx, true);
     if (rc) return rc;
     if (!chunks) return fail(ctx, RRRMC_ERR_INVALID_ARG, "chunks is NULL");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    { const int32_t rcp = post_sync_checks(ctx); if (rcp) return rcp; }          // the configuration of a call that aborted is not handed out as good
     return spins_to_chunks(ctx, native_spins(ctx), chunks);
 }
 
@@ -1218,6 +1269,10 @@ int32_t rrrmc_standard_mc_async(rrrmc_ctx* ctx, double beta, int64_t iters, int6
     bool reuse = false;
     rc = prepare_chunk_list(ctx, iters, step, C, &reuse);
     if (rc) return rc;
+    // The planner of this call may run beside the previous call's sweeps (two chunk tables, two buffer sets whose turn `plan_parity` tracks).
+    // A call that fails half way leaves that bookkeeping between two states: whatever happens, an early return marks the chunk table stale, so
+    // that the next call takes the fully ordered path (new upload, its planner behind everything queued so far) with either set.
+    struct StaleOnError { rrrmc_ctx* c; bool ok; ~StaleOnError() { if (!ok) c->chunks_iters = -1; } } stale_guard{ctx, false};
     const int64_t nsamp = iters / step;
     const size_t nchunks = ctx->chunks_n;
     const std::vector<rrrmc_ctx::BatchDesc>& batches = ctx->chunk_batches;
@@ -1351,12 +1406,13 @@ int32_t rrrmc_standard_mc_async(rrrmc_ctx* ctx, double beta, int64_t iters, int6
         HIP_TRY(ctx, hipEventRecord(EV[ebase + 2 * b + 1], st));
         HIP_TRY(ctx, hipEventRecord(ctx->ev_set_free[set], st));
         ctx->set_used[set] = true;
+        ctx->plan_parity = (par + b + 1) & 1;          // the set the next batch (of this call or the next) takes: advanced with the sets, batch by batch
         // the next plan is enqueued AFTER this sweep so that the sweep's workgroups (one per CU, most of the LDS)
         // are placed first and the planner's small workgroups fill in beside them
         if (b + 1 < nb) { rc = launch_plan(b + 1); if (rc) return rc; }
     }
     HIP_TRY(ctx, hipEventRecord(ctx->ev_end, st));
-    ctx->plan_parity = (par + nb) & 1;
+    stale_guard.ok = true;
     ctx->sweep_launches = (int)batches.size();
     ctx->last_ev_base = ebase;
     ctx->last_ev_pool = ctx->acc_mode;
@@ -1406,6 +1462,7 @@ int32_t rrrmc_tracked_energy_f64(rrrmc_ctx* ctx, double* E_out)
     if ((!ctx->std_cache_live && ctx->smp_kind == 0) || !ctx->sk_E) return fail(ctx, RRRMC_ERR_STATE, "no sampler call has left a tracked energy");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    { const int32_t rcp = post_sync_checks(ctx); if (rcp) return rcp; }
     std::vector<double> E((size_t)ctx->Rpad);
     HIP_TRY(ctx, hipMemcpy(E.data(), ctx->sk_E, sizeof(double) * (size_t)(ctx->model == RRRMC_MODEL_QUANT_RRG || ctx->model == RRRMC_MODEL_SPARSE_DISCRETIZED ? ctx->R : ctx->Rpad), hipMemcpyDeviceToHost));
     for (int64_t r = 0; r < ctx->R; ++r) E_out[r] = E[(size_t)r];
@@ -1422,6 +1479,7 @@ int32_t rrrmc_tracked_energy(rrrmc_ctx* ctx, int64_t* E_out)
     if (!ctx->results_valid || !ctx->d_E) return fail(ctx, RRRMC_ERR_STATE, "no sampler call has left a tracked energy");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    { const int32_t rcp = post_sync_checks(ctx); if (rcp) return rcp; }
     std::vector<int32_t> E((size_t)ctx->Rpad);
     HIP_TRY(ctx, hipMemcpy(E.data(), ctx->d_E, sizeof(int32_t) * (size_t)ctx->Rpad, hipMemcpyDeviceToHost));
     for (int64_t r = 0; r < ctx->R; ++r) E_out[r] = E[(size_t)r];
@@ -1434,31 +1492,7 @@ int32_t rrrmc_sync(rrrmc_ctx* ctx)
     if (!ctx) return RRRMC_ERR_INVALID_ARG;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    if (ctx->debug_checks && ctx->dbg_flag) {
-        int32_t fl[2] = {0, 0};
-        HIP_TRY(ctx, hipMemcpy(fl, ctx->dbg_flag, sizeof fl, hipMemcpyDeviceToHost));
-        HIP_TRY(ctx, hipMemset(ctx->dbg_flag, 0, sizeof fl));
-        if (fl[0])
-            return fail(ctx, RRRMC_ERR_STATE, "debug check failed for %d value(s), e.g. replica %d: the tracked energy / cached fields differ from "
-                                              "energy(X, C) recomputed from the configuration (src/graphs/RRG.jl:229-231, SK.jl:268-273)", fl[0], fl[1]);
-    }
-    if (ctx->model == RRRMC_MODEL_SPARSE_F64 && ctx->pf_status && !ctx->last_call_rrr) {
-        int32_t st = 0;
-        HIP_TRY(ctx, hipMemcpy(&st, ctx->pf_status, sizeof st, hipMemcpyDeviceToHost));
-        if (st) {
-            HIP_TRY(ctx, hipMemset(ctx->pf_status, 0, sizeof st));
-            ctx->results_valid = false; ctx->std_cache_live = false; ctx->pf_lf_live = false;
-            return fail(ctx, RRRMC_ERR_STATE, "spf_team_kernel: a wait on the retired prefix ran into its limit (protocol failure); the call's results are void. "
-                                              "RRRMC_SPF_TEAM=0 selects the single-wavefront kernel");
-        }
-    }
-    if (ctx->last_call_rrr && (ctx->model == RRRMC_MODEL_SK_NORMAL || ctx->model == RRRMC_MODEL_SPARSE_F64) && ctx->rs_status) {
-        std::vector<int32_t> stt((size_t)ctx->R);
-        HIP_TRY(ctx, hipMemcpy(stt.data(), ctx->rs_status, sizeof(int32_t) * stt.size(), hipMemcpyDeviceToHost));
-        for (int64_t r = 0; r < ctx->R; ++r)
-            if (stt[r]) return fail(ctx, RRRMC_ERR_STATE, "replica %lld: Unrecoverable loss of precision detected in the dynamic sampler", (long long)r);   // DynamicSamplers.jl:147
-    }
-    return RRRMC_OK;
+    return post_sync_checks(ctx);
 }
 
 int32_t rrrmc_fetch_results(rrrmc_ctx* ctx, int64_t* Es_out, int64_t* accepted_out)
@@ -1469,6 +1503,7 @@ int32_t rrrmc_fetch_results(rrrmc_ctx* ctx, int64_t* Es_out, int64_t* accepted_o
     if (!ctx->results_valid) return fail(ctx, RRRMC_ERR_STATE, "no sampling call has been made");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    { const int32_t rcp = post_sync_checks(ctx); if (rcp) return rcp; }          // a call that aborted or failed its checks has no results to hand out
     if (accepted_out) {
         std::vector<int64_t> acc((size_t)ctx->Rpad);
         HIP_TRY(ctx, hipMemcpy(acc.data(), ctx->d_acc, sizeof(int64_t) * ctx->Rpad, hipMemcpyDeviceToHost));
@@ -2240,6 +2275,7 @@ int32_t rrrmc_fetch_results_f64(rrrmc_ctx* ctx, double* Es_out, int64_t* accepte
     if (!ctx->results_valid) return fail(ctx, RRRMC_ERR_STATE, "no sampling call has been made");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    { const int32_t rcp = post_sync_checks(ctx); if (rcp) return rcp; }          // a call that aborted or failed its checks has no results to hand out
     if (accepted_out && ctx->last_call_rrr) {
         std::vector<int64_t> st((size_t)ctx->R * ctx->stats_stride);
         HIP_TRY(ctx, hipMemcpy(st.data(), ctx->q_stats, sizeof(int64_t) * st.size(), hipMemcpyDeviceToHost));

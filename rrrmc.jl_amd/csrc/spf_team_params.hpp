@@ -19,7 +19,7 @@ __host__ __device__ constexpr int spf_plan_stride(int K) { return 4 + 3 * K; }
 
 struct SpfTeamParams {
     SpfParams S;
-    const uint32_t* plan;       // [iters + 2][2 + 3 K]
+    const uint32_t* plan;       // [iters + 2][4 + 3 K]  (spf_plan_stride)
     int32_t* status;            // one word per context, may be null: set to 1 by a workgroup whose wait ran into kSpfTeamSpinLimit (a protocol
                                 // failure: the launch then runs to its end without waiting and its results are void)
 };

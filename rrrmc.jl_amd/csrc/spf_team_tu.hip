@@ -1,4 +1,7 @@
 // Translation unit of spf_team_kernel (spf_team_kernel.hpp) and its launchers (spf_team_api.hpp).
+#include <mutex>
+#include <set>
+
 #include "spf_team_api.hpp"
 #include "spf_team_kernel.hpp"
 
@@ -18,11 +21,20 @@ hipError_t launch_build(int W, hipStream_t st, const SpfTeamParams& TP)
         constexpr int M = spf_team_slots(K, NW, TW);
         constexpr size_t lds = spf_team_lds_bytes(K, NW, M, TW);
         auto fn = spf_team_kernel<K, NW, M, TW>;
-        static bool raised = false;                    // one context at a time launches (the C ABI serialises calls on a context; the flag is idempotent)
-        if (!raised) {
-            const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        // hipFuncSetAttribute acts on the CURRENT device's copy of the kernel (the caller has made the context's device current): the limit is
+        // raised once per (device, build), under a lock — contexts on different devices, driven by different host threads, share this code
+        {
+            static std::mutex mu;
+            static std::set<int> raised;
+            int dev = 0;
+            hipError_t e = hipGetDevice(&dev);
             if (e != hipSuccess) return e;
-            raised = true;
+            std::lock_guard<std::mutex> lock(mu);
+            if (!raised.count(dev)) {
+                e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                if (e != hipSuccess) return e;
+                raised.insert(dev);
+            }
         }
         hipLaunchKernelGGL(fn, dim3((unsigned)W * (64 / TW)), dim3(NW * 64), lds, st, TP);
         return hipGetLastError();

@@ -307,6 +307,13 @@ class Engine:
                                             Q.ctypes.data, tm.ctypes.data, ov.ctypes.data), self._ctx)
         return Q, tm, ov
 
+    def spf_team_build(self):
+        """(waves, width, slots) of the spf_team_kernel build the default standardMC of a GraphRRGNormal / GraphEANormal launches here;
+        zeros when the one-wavefront kernel runs instead."""
+        nw, tw, m = C.c_int32(0), C.c_int32(0), C.c_int32(0)
+        check(lib().rrrmc_spf_team_build(self._ctx, C.byref(nw), C.byref(tw), C.byref(m)), self._ctx)
+        return nw.value, tw.value, m.value
+
     def timing_accumulate(self, on=True, reserve_launches=1):
         """Give every sweep launch of the following async calls its own HIP-event pair (see ``timing_total``); the events of the
         first ``reserve_launches`` launches are created now, so that the calls in between create none."""

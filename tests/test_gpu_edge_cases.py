@@ -312,3 +312,71 @@ def test_queued_calls_of_alternating_shapes(pkg, oracle):
             outs.append((Es, acc, eng.get_config().s.copy(), eng.energy()))
     for u, v in zip(outs[0], outs[1]):
         assert (u == v).all()
+
+
+def _queued_vs_synchronised(pkg, X, R, seed, beta, pattern, engine_kw=None, between=None):
+    """the calls of `pattern` queued back to back, and with a sync after each: (Es, accepted, configuration, energy, configuration before the last call)"""
+    outs = []
+    for queued in (True, False):
+        with pkg.Engine(X, R, **(engine_kw or {})) as eng:
+            eng.seed(seed)
+            eng.init_spins_random()
+            if between is not None:
+                between(eng, None)
+            before_last = None
+            for c, (iters, step) in enumerate(pattern):
+                if c == len(pattern) - 1 and not queued:
+                    before_last = eng.get_config().s.copy()
+                if between is not None and c > 0:
+                    between(eng, c)
+                    if not queued:
+                        eng.sync()
+                eng.standard_mc_async(beta, iters, step)
+                if not queued:
+                    eng.sync()
+            eng.sync()
+            Es, acc = eng.fetch_results()
+            outs.append((Es, acc, eng.get_config().s.copy(), eng.energy(), before_last))
+    for u, v in zip(outs[0][:4], outs[1][:4]):
+        assert (u == v).all()
+    return outs
+
+
+def test_queued_calls_through_a_multi_device_context(pkg, oracle):
+    """the planner of a call runs beside the previous call's sweep on EVERY shard of rrrmc_ctx_create_multi (each child
+    context has its own two chunk tables, buffer sets and plan stream).  Five queued calls == five synchronised ones == the oracle."""
+    seed, beta, R, N, iters, step = 515151, 0.8, 128, 4096, 1 << 16, 4096
+    X = pkg.GraphRRG(N, 3, seed=seed)
+    outs = _queued_vs_synchronised(pkg, X, R, seed, beta, [(iters, step)] * 5, engine_kw={"devices": [0, 0]})
+    for r in (0, 63, 64, 127):          # both shards
+        ref = oracle.standard_mc_sparse(X.A, X.J.astype(np.int32), beta, iters, step, seed, outs[1][4][r], replica=r, it0=4 * iters)
+        assert (outs[0][0][r] == ref[0]).all() and (outs[0][2][r] == ref[1]).all() and outs[0][1][r] == ref[2]
+
+
+@pytest.mark.parametrize("no_masks", ["0", "1"])
+def test_queued_calls_in_big_mode(pkg, oracle, monkeypatch, no_masks):
+    """N = 40 000 does not fit the LDS-resident kernel: plan_big_kernel (+ big_mask_kernel) of call s + 1 runs beside
+    big_apply_kernel / big_sweep_kernel of call s, through the same two chunk tables and buffer sets."""
+    monkeypatch.setenv("RRRMC_BIG_NO_MASKS", no_masks)
+    seed, beta, R, N, iters, step = 616161, 0.9, 64, 40000, 200000, 50000
+    X = pkg.GraphRRG(N, 3, seed=seed)
+    outs = _queued_vs_synchronised(pkg, X, R, seed, beta, [(iters, step)] * 5)
+    for r in (0, 33, 63):
+        ref = oracle.standard_mc_sparse(X.A, X.J.astype(np.int32), beta, iters, step, seed, outs[1][4][r], replica=r, it0=4 * iters)
+        assert (outs[0][0][r] == ref[0]).all() and (outs[0][2][r] == ref[1]).all() and outs[0][1][r] == ref[2]
+
+
+def test_queued_calls_alternating_with_colour_sweeps(pkg, oracle):
+    """a colour-sweep call between two queued standardMC calls of one shape writes the spins the next planner-overlapped
+    sweep reads: the stream orders them, the chunk table stays valid across the other sampler's call."""
+    seed, beta, R = 717171, 0.8, 96
+    X = pkg.GraphEA(8, 3, seed=seed)
+    color = pkg.checkerboard_coloring(8, 3)
+
+    def between(eng, c):
+        if c is None:
+            eng.set_coloring(color)
+        else:
+            eng.colored_sweeps_async(beta, 3, 1)
+
+    _queued_vs_synchronised(pkg, X, R, seed, beta, [(60000, 5000)] * 5, between=between)
