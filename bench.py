@@ -36,8 +36,12 @@ SAMPLE_STEP = 1 << 12    # energy sample every N iterations
 SEED = 0x5EED
 HOST_GAP_LIMIT_MS = 0.3  # ms_per_step - kernel ms per step above this fails the run (exit 4): the timed region must be the kernel
 HBM_PEAK_GBS = 8000.0    # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-PROFILE_DIRS = [os.path.join(ROOT, "profiles", d) for d in ("r05", "r04", "r03", "r02")]       # newest first
-SWEEP_KERNEL_SOURCES = ["rrrmc.jl_amd/csrc/sparse_kernels.hpp", "rrrmc.jl_amd/csrc/philox.hpp"]     # what traffic.json / valu_model.json describe
+PROFILE_DIRS = [os.path.join(ROOT, "profiles", d) for d in ("r06", "r05", "r04", "r03", "r02")]       # newest first
+# what traffic.json / valu_model.json describe: the kernel AND the code that launches it (chunk list, planner overlap, events) — a change to
+# how the kernel is launched moves its time like a change to the kernel, and invalidates the committed figures the same way
+SWEEP_KERNEL_SOURCES = ["rrrmc.jl_amd/csrc/sparse_kernels.hpp", "rrrmc.jl_amd/csrc/philox.hpp", "rrrmc.jl_amd/csrc/host_sweep.hpp",
+                        "rrrmc.jl_amd/csrc/host_plan.hpp"]
+LINE_LIMIT_BYTES = 5000  # the printed line: numbers and short keys (README.md "The bench line" is the legend); the full record goes to stderr / a file
 
 
 # ----------------------------------------------------------------------------------------------------------------
@@ -193,6 +197,7 @@ def cpu_baseline(O, X, seconds_target=15.0):
         dt = time.perf_counter() - t0
     return {"value": R * iters / dt, "unit": "attempts/s", "cores": 1, "kind": "port",
             "sample": "%d replicas x 2^22 iterations of the same graph/beta, single thread, oracle/rrrmc_oracle.c (%.1f s)" % (R, dt),
+            "sample_short": "%d replicas x 2^22 its, 1 thread, %.0f s" % (R, dt),
             "build": "gcc -O3 -march=%s -ffp-contract=off" % O.flavour,
             "cpu_model": cpu_model_name(), "host_cores": os.cpu_count(), "pinned_core": pc.core}
 
@@ -717,6 +722,84 @@ def secondary(pkg, O, device):
 
 
 # ----------------------------------------------------------------------------------------------------------------
+def _sig(x, n=5):
+    """n significant digits (the line is read by people and parsers alike: 4.1832e12, not 4183219876543.21)"""
+    if isinstance(x, bool) or x is None or isinstance(x, (int, str)):
+        return x
+    if isinstance(x, (list, tuple)):
+        return [_sig(v, n) for v in x]
+    try:
+        return float("%.*g" % (n, float(x)))
+    except (TypeError, ValueError):
+        return x
+
+
+def compact_line(full):
+    """The ONE line bench.py prints: the contract's keys, `roofline` and `cpu_baseline` as numbers, and one short record per secondary
+    workload (all five BASELINE configs fit the tail a driver keeps).  Prose — what a figure means, where a committed measurement came from,
+    what a sample was — lives in README.md ("The bench line") and in the full record (stderr, gpurun_out/bench_detail.json)."""
+    keep = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data")
+    out = {k: _sig(full[k], 6) for k in keep if k in full}
+    cfg = full.get("config", {})
+    out["config"] = {"workload": cfg.get("workload"), "replicas_total": cfg.get("replicas_total"), "acceptance": _sig(cfg.get("acceptance")),
+                     "parallelism": cfg.get("parallelism")}
+    r = full.get("roofline")
+    if r:
+        v = r.get("valu") or {}
+        out["roofline"] = {"bound": r.get("bound"), "achieved": _sig(r.get("achieved")), "peak": r.get("peak"), "unit": r.get("unit"), "frac": _sig(r.get("frac")),
+                           "traffic": _sig(r.get("traffic")), "kernel": r.get("kernel"), "avg_launch_ms": _sig(r.get("avg_launch_ms")), "launches": r.get("launches"),
+                           "bytes_per_attempt": _sig(r.get("algorithmic_bytes_per_attempt")), "valu_frac": _sig(v.get("frac")),
+                           "valu_frac_2cyc": _sig(v.get("frac_vs_guide_2cycle")), "copy_GBps": _sig(r.get("measured_copy_GBps")),
+                           "stamp": r.get("kernel_source_stamp"), "profile": r.get("profile_dir")}
+    c = full.get("cpu_baseline")
+    if c:
+        out["cpu_baseline"] = {"value": _sig(c.get("value")), "unit": c.get("unit"), "cores": c.get("cores"), "kind": c.get("kind"),
+                               "sample": c.get("sample_short") or c.get("sample")}
+    for k in ("host_gap_ms_per_step", "sync_value", "sync_value_pageable"):
+        if k in full:
+            out[k] = _sig(full[k])
+    out["verified"] = full.get("verified")
+    sec = full.get("secondary")
+    if sec:
+        short = {}
+        for name, e in sec.items():
+            if "error" in e:
+                short[name] = {"error": str(e["error"])[:80]}
+                continue
+            rec = {"value": _sig(e.get("value")), "unit": e.get("unit"), "kernel": e.get("kernel"), "frac": _sig(e.get("frac")),
+                   "bound_frac": _sig(e.get("bound_frac")), "acc": _sig(e.get("acceptance"), 3)}
+            if e.get("cpu_one_core"):
+                rec["cpu1"] = _sig(e["cpu_one_core"].get("value"))
+            if e.get("cpu_all_cores"):
+                rec["cpuN"] = _sig(e["cpu_all_cores"].get("value"))
+                rec["cores"] = e["cpu_all_cores"].get("cores")
+            if e.get("traffic"):
+                rec["B_meas"] = _sig(e["traffic"].get("measured_bytes_per_attempt"))
+            short[name] = {k: v for k, v in rec.items() if v is not None}
+        out["secondary"] = short
+    out["detail"] = full.get("detail_file")
+    return out
+
+
+def emit(full):
+    """print the compact line on stdout (exactly one line); the full record on stderr and, when it can be written, in a file"""
+    path = os.environ.get("RRRMC_BENCH_DETAIL", os.path.join(ROOT, "gpurun_out", "bench_detail.json"))
+    try:
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        with open(path, "w") as f:
+            json.dump(full, f, indent=1)
+        full["detail_file"] = os.path.relpath(path, ROOT)
+    except OSError:
+        full["detail_file"] = None
+    sys.stderr.write("bench.py full record: %s\n" % json.dumps(full))
+    line = json.dumps(compact_line(full))
+    if len(line) > LINE_LIMIT_BYTES:
+        sys.stderr.write("bench.py: the printed line is %d bytes (limit %d)\n" % (len(line), LINE_LIMIT_BYTES))
+    print(line)
+    sys.stdout.flush()
+
+
+# ----------------------------------------------------------------------------------------------------------------
 def run_rank(args):
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -846,7 +929,7 @@ def run_rank(args):
                 "traffic_source": ("%s (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE of this workload, committed; not measured in this run; "
                                    "source stamp %s, commit %s)" % (tf_path, tf_state, tf.get("git_commit"))) if tf
                                   else ("dropped: %s was measured on other kernel sources" % tf_path if tf_state == "stale" else None),
-                "kernel_source_stamp": source_stamp(), "git_head": git_head(),
+                "kernel_source_stamp": source_stamp(), "git_head": git_head(), "profile_dir": os.path.dirname(tf_path) if tf else None,
                 "algorithmic_bytes_per_launch": bytes_per_attempt * per_launch_attempts,
                 "kernel": "sweep_kernel<3, 1>", "avg_launch_ms": avg_ms, "launches": int(launches),
                 "algorithmic_bytes_per_attempt": bytes_per_attempt}
@@ -920,8 +1003,7 @@ def run_rank(args):
             out["cpu_baseline"] = cpu_baseline(O, X)
         if world == 1 and not args.no_secondary:
             out["secondary"] = secondary(pkg, None if args.no_cpu_baseline else entry.load_oracle(), local_rank)
-        print(json.dumps(out))
-        sys.stdout.flush()
+        emit(out)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -74,3 +74,20 @@ def test_gpus_flag_must_match_world_size_under_torchrun(tmp_path):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "1", "--warmup", "0"],
                        capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 2 and "WORLD_SIZE=1" in r.stderr and not r.stdout.strip()
+
+
+def test_the_printed_line_is_short_and_carries_all_five_configs():
+    """a driver keeps the tail of stdout — the line must hold BASELINE's five configs in a few KB.  The full record of a
+    real run (the committed round-5 line, 14 KB of numbers and prose) is reduced by bench.compact_line: numbers and short keys only."""
+    import bench
+    full = json.load(open(os.path.join(ROOT, "profiles", "r05", "bench_steps20_e.json")))
+    line = json.dumps(bench.compact_line(full))
+    assert len(line) <= bench.LINE_LIMIT_BYTES == 5000
+    got = json.loads(line)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config"):
+        assert k in got, k
+    assert got["config"]["workload"].startswith("GraphRRG(N=4096,K=3")
+    assert set(got["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"} and set(got["cpu_baseline"]) >= {"value", "unit", "cores", "kind", "sample"}
+    for name in ("c3_sk_normal", "c4_ea_checkerboard", "c4_ea_random_site", "c5_quant_rrr"):          # configs 3, 4, 5 (config 2 is the headline, 1 the CPU leg)
+        assert got["secondary"][name]["value"] > 0 and got["secondary"][name]["unit"]
+    assert abs(got["value"] / full["value"] - 1) < 1e-5 and abs(got["roofline"]["frac"] / full["roofline"]["frac"] - 1) < 1e-4
