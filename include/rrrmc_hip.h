@@ -58,7 +58,8 @@ enum rrrmc_model {
                                     created with rrrmc_ctx_create_quant */
     /* selectors for rrrmc_ctx_create_multi only (the contexts it makes report RRRMC_MODEL_QUANT_RRG): */
     RRRMC_MODEL_QUANT_SK = 8,    /* GraphQuant over binary GraphSK slices (GraphQSKT, src/QAliases.jl:34-43): rrrmc_ctx_create_quant_sk per device */
-    RRRMC_MODEL_QUANT_SKN = 9    /* GraphQuant over GraphSKNormal slices (GraphQSKNormalT, src/QAliases.jl:45-46): rrrmc_ctx_create_quant_skn per device */
+    RRRMC_MODEL_QUANT_SKN = 9,   /* GraphQuant over GraphSKNormal slices (GraphQSKNormalT, src/QAliases.jl:45-46): rrrmc_ctx_create_quant_skn per device */
+    RRRMC_MODEL_QUANT_F64 = 10   /* GraphQuant over sparse Float64 slices (GraphQEAT, src/QAliases.jl:50-83): rrrmc_ctx_create_quant_f64 per device */
 };
 
 /* Library ABI version (major*10000 + minor*100 + patch). */
@@ -100,7 +101,8 @@ RRRMC_API int32_t rrrmc_ctx_create(rrrmc_ctx **out, int32_t model, int64_t N, in
  * arrive gathered; enqueueing calls return when every device has its work queued, rrrmc_sync / fetch / energy calls run one host
  * thread per device.  rrrmc_last_timing / rrrmc_timing_total report the slowest device.
  *   model  any rrrmc_model; RRRMC_MODEL_QUANT_RRG takes (N = Nk, K, M) as rrrmc_ctx_create_quant does, RRRMC_MODEL_QUANT_SK / _SKN take
- *          (N = Nk, M) as rrrmc_ctx_create_quant_sk / _skn do (K ignored); M is ignored otherwise.
+ *          (N = Nk, M) as rrrmc_ctx_create_quant_sk / _skn do (K ignored), RRRMC_MODEL_QUANT_F64 takes (N = Nk, K, M) as rrrmc_ctx_create_quant_f64;
+ *          M is ignored otherwise.
  */
 RRRMC_API int32_t rrrmc_ctx_create_multi(rrrmc_ctx **out, int32_t model, int64_t N, int64_t K, int64_t M, int64_t R,
                                          const int32_t *device_ids, int32_t ndev, uint32_t replica0);
@@ -204,6 +206,15 @@ RRRMC_API int32_t rrrmc_ctx_create_quant_sk(rrrmc_ctx **out, int64_t Nk, int64_t
  * rrrMC (rrrmc_rrr_mc_async) and standardMC are wired (thread per replica, every slice keeps its Float64 lfields / lfields_last / move_last
  * exactly as SK.jl:212-276 updates them); bklMC / wtmMC / extremal_opt and the observables are not (RRRMC_ERR_UNSUPPORTED). */
 RRRMC_API int32_t rrrmc_ctx_create_quant_skn(rrrmc_ctx **out, int64_t Nk, int64_t M, int64_t R, int32_t device, uint32_t replica0);
+/* GraphQuant over M sparse Float64 slices sharing one (A, J::Float64) — GraphQEAT = GraphQuant{fourK,GraphEANormal{twoD}}
+ * (src/QAliases.jl:50-83: GraphQEAT(L, D, M, Gamma, beta), GraphQEAT(fname, M, Gamma, beta), GraphQEAT(X::GraphEANormal, M, Gamma, beta)), and the
+ * same over a GraphRRGNormal: then rrrmc_set_graph_f64(ctx, A[Nk x K], J[Nk x K]) (sorted rows, symmetric; a neighbour may repeat: L = 2) and
+ * rrrmc_quant_set_field.  Every slice keeps its own LocalFields{Float64}: lfields, the live part of lfields_last (the K + 1 values the undo
+ * path of update_cache! reads, src/graphs/EA.jl:613-653 / RRG.jl:576-617) and move_last, per replica.  K <= 8.  Samplers: rrrmc_rrr_mc_async
+ * (rrrMC(X::DoubleGraph), src/RRRMC.jl:221-290: delta_energy_residual = -lfields[i] / M, src/graphs/QT.jl:270-281), rrrmc_standard_mc_async, and
+ * the generic caches over all Nk * M spins — rrrmc_bkl_mc_async, rrrmc_wtm_mc_async, rrrmc_extremal_opt_async (neighbors = the two Trotter
+ * neighbours, then the slice graph's, QT.jl:288-321); one thread per replica.  rrrmc_quant_observables is not wired for these slices. */
+RRRMC_API int32_t rrrmc_ctx_create_quant_f64(rrrmc_ctx **out, int64_t Nk, int64_t K, int64_t M, int64_t R, int32_t device, uint32_t replica0);
 /* The Trotter coupling fourK (a type parameter of GraphQuant in the reference, QT.jl:126) and the beta it was derived
  * from: needed by rrrmc_energy_f64 before the first rrrMC call, and by rrrmc_standard_mc_async — standardMC on the GraphQuant
  * (src/RRRMC.jl:81-127 with delta_energy = delta_energy(X0) + delta_energy_residual, QT.jl:283-286; SITE + ACCEPT_F64 streams),

@@ -45,7 +45,7 @@ version() = Int(ccall((:rrrmc_version, LIB), Int32, ()))
 
 # model kinds of include/rrrmc_hip.h
 const SPARSE_PM1, SK_NORMAL, QUANT_RRG, SK_BINARY, SPARSE_F64, SPARSE_DISCRETIZED, SPARSE_LEVELS = 1, 2, 3, 4, 5, 6, 7
-const QUANT_SK, QUANT_SKN = 8, 9           # selectors of rrrmc_ctx_create_multi: GraphQuant over GraphSK / GraphSKNormal slices
+const QUANT_SK, QUANT_SKN, QUANT_F64 = 8, 9, 10      # selectors of rrrmc_ctx_create_multi: GraphQuant over GraphSK / GraphSKNormal / sparse Float64 slices
 
 # rrrmc_ctx_create / rrrmc_ctx_create_quant on one device, rrrmc_ctx_create_multi on several (N = Nk for a GraphQuant)
 function create(model::Integer, N::Integer, K::Integer, M::Integer, R::Integer; device = 0, replica0 = 0, devices = nothing)
@@ -167,6 +167,17 @@ function Ctx(X::RRRMC.QT.GraphQuant{fourK,G}, R::Integer, β::Real; device = 0, 
         ctx = Ctx(ref[], R, Nk * M, true)
         Jm = Matrix{Float64}(undef, Nk, Nk); for i = 1:Nk; Jm[:, i] = X1.J[i]; end
         GC.@preserve Jm check(ccall((:rrrmc_set_couplings_dense, LIB), Int32, (Ptr{Cvoid}, Ptr{Float64}), ctx.p, Jm), ctx.p)
+    elseif G <: F64Graph
+        # GraphQEAT = GraphQuant{fourK,GraphEANormal{twoD}} (src/QAliases.jl:50-83), and the same over a GraphRRGNormal: sparse Float64 slices
+        K = length(X1.A[1])
+        if devices === nothing
+            check(ccall((:rrrmc_ctx_create_quant_f64, LIB), Int32, (Ref{Ptr{Cvoid}}, Int64, Int64, Int64, Int64, Int32, UInt32), ref, Nk, K, M, R, device, replica0))
+        else
+            ref[] = create(QUANT_F64, Nk, K, M, R; replica0 = replica0, devices = devices)
+        end
+        ctx = Ctx(ref[], R, Nk * M, true)
+        A = flatA(X1); J = collect(reinterpret(Float64, X1.J))
+        GC.@preserve A J check(ccall((:rrrmc_set_graph_f64, LIB), Int32, (Ptr{Cvoid}, Ptr{Int32}, Ptr{Float64}), ctx.p, A, J), ctx.p)
     else
         K = length(X1.A[1])
         ctx = Ctx(create(QUANT_RRG, Nk, K, M, R; device = device, replica0 = replica0, devices = devices), R, Nk * M, true)

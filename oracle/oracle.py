@@ -1105,3 +1105,88 @@ def extremal_opt_quant_dense(Nk, M, fourK, tau, iters, step, seed, chunks, Jb=No
     if n < 0:
         raise RuntimeError("extremal_opt_quant_dense: inconsistent cache / energy (%d)" % n)
     return Es[:n], ch, Emin.value, Cmin, itmin.value
+
+
+# ---- GraphQEAT = GraphQuant over sparse Float64 slices (src/QAliases.jl:50-83) ---------------------------------------------------------
+def _spf_args(A, Jf):
+    A = np.ascontiguousarray(A, np.int32)
+    return A, np.ascontiguousarray(Jf, np.float64).reshape(-1), A.shape[0], A.shape[1]
+
+
+def quant_spf_energy(A, Jf, M, fourK, chunks, form="ea"):
+    L = lib()
+    L.orc_quant_energy_spf.restype = C.c_double
+    L.orc_quant_energy_spf.argtypes = [C.c_int, C.c_int64, C.c_int64, C.c_int64, i32p, f64p, C.c_double, u64p]
+    A, J, Nk, K = _spf_args(A, Jf)
+    return float(L.orc_quant_energy_spf(1 if form == "ea" else 0, Nk, int(M), K, A, J, float(fourK), np.ascontiguousarray(chunks, np.uint64)))
+
+
+def rrr_mc_quant_spf(A, Jf, M, fourK, beta, iters, step, seed, chunks, it0=0, replica=0, staged_thr=0.5, staged_thr_fact=5.0, want_cache=False, form="ea"):
+    """One chain of rrrMC(X::DoubleGraph) on a GraphQEAT.  Returns (Es, chunks_out, accepted, staged_its[, pos, set_sizes])."""
+    L = lib()
+    L.orc_rrr_mc_quant_spf.restype = C.c_int64
+    L.orc_rrr_mc_quant_spf.argtypes = [C.c_int, C.c_int64, C.c_int64, C.c_int64, i32p, f64p, C.c_double, C.c_double, C.c_int64, C.c_int64, C.c_double,
+                                       C.c_double, C.c_uint64, C.c_uint64, C.c_uint32, u64p, f64p, i64p, C.c_void_p]
+    A, J, Nk, K = _spf_args(A, Jf)
+    N = Nk * int(M)
+    ch = np.array(chunks, np.uint64, copy=True)
+    Es = np.zeros(max(iters // step, 1), np.float64)
+    stats = np.zeros(2, np.int64)
+    cache = np.zeros(N + 4, np.int32)
+    n = L.orc_rrr_mc_quant_spf(1 if form == "ea" else 0, Nk, int(M), K, A, J, float(fourK), float(beta), int(iters), int(step), float(staged_thr),
+                               float(staged_thr_fact), seed, it0, replica, ch, Es, stats, cache.ctypes.data if want_cache else None)
+    if n < 0:
+        raise AssertionError("DeltaECache / ArraySet consistency check failed")
+    out = (Es[:n], ch, int(stats[0]), int(stats[1]))
+    return out + (cache[:N].copy(), cache[N:].copy()) if want_cache else out
+
+
+def standard_mc_quant_spf(A, Jf, M, fourK, beta, iters, step, seed, chunks, it0=0, replica=0, form="ea"):
+    L = lib()
+    L.orc_standard_mc_quant_spf.restype = C.c_int64
+    L.orc_standard_mc_quant_spf.argtypes = [C.c_int, C.c_int64, C.c_int64, C.c_int64, i32p, f64p, C.c_double, C.c_double, C.c_int64, C.c_int64,
+                                            C.c_uint64, C.c_uint64, C.c_uint32, u64p, f64p, i64p]
+    A, J, Nk, K = _spf_args(A, Jf)
+    ch = np.array(chunks, np.uint64, copy=True)
+    Es = np.zeros(max(iters // step, 1), np.float64)
+    acc = np.zeros(1, np.int64)
+    n = L.orc_standard_mc_quant_spf(1 if form == "ea" else 0, Nk, int(M), K, A, J, float(fourK), float(beta), int(iters), int(step), seed, it0, replica, ch, Es, acc)
+    return Es[:n], ch, int(acc[0])
+
+
+def cont_quant_spf(mode, A, Jf, M, fourK, beta, iters, step, seed, chunks, it0=0, call=0, replica=0, stepf=1.0, form="ea"):
+    """bklMC ("bkl") / wtmMC ("wtm") on a GraphQEAT: the continuous-energy caches over the whole graph.  Returns (Es, chunks, stats[3], t)."""
+    L = lib()
+    L.orc_cont_quant_spf.restype = C.c_int64
+    L.orc_cont_quant_spf.argtypes = [C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_int64, i32p, f64p, C.c_double, C.c_double, C.c_int64, C.c_int64,
+                                     C.c_double, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, u64p, f64p, i64p, C.POINTER(C.c_double)]
+    A, J, Nk, K = _spf_args(A, Jf)
+    ch = np.array(chunks, np.uint64, copy=True)
+    m = {"bkl": 1, "wtm": 2}[mode]
+    Es = np.zeros(max(iters if m == 2 else iters // step, 1))
+    stats = np.zeros(3, np.int64)
+    t = C.c_double(0)
+    n = L.orc_cont_quant_spf(m, 1 if form == "ea" else 0, Nk, int(M), K, A, J, float(fourK), float(beta), int(iters), int(step), float(stepf), seed, it0, call,
+                             replica, ch, Es, stats, C.byref(t))
+    if n < 0:
+        raise RuntimeError("cont_quant_spf: DynamicSampler lost precision / unsupported (%d)" % n)
+    return Es[:n], ch, stats, t.value
+
+
+def extremal_opt_quant_spf(A, Jf, M, fourK, tau, iters, step, seed, chunks, it0=0, replica=0, form="ea"):
+    """extremal_opt on a GraphQEAT (EOCacheCont over all Nk M spins).  Returns (Es, final chunks, Emin, Cmin chunks, itmin)."""
+    L = lib()
+    L.orc_extremal_opt_quant_spf.restype = C.c_int64
+    L.orc_extremal_opt_quant_spf.argtypes = [C.c_int, C.c_int64, C.c_int64, C.c_int64, i32p, f64p, C.c_double, f64p, C.c_int64, C.c_int64,
+                                             C.c_uint64, C.c_uint64, C.c_uint32, u64p, f64p, C.POINTER(C.c_double), u64p, C.POINTER(C.c_int64)]
+    A, J, Nk, K = _spf_args(A, Jf)
+    N = Nk * int(M)
+    ch = np.array(chunks, np.uint64, copy=True)
+    Es = np.zeros(max(iters // step, 1))
+    Cmin = np.zeros_like(ch)
+    Emin, itmin = C.c_double(0), C.c_int64(0)
+    n = L.orc_extremal_opt_quant_spf(1 if form == "ea" else 0, Nk, int(M), K, A, J, float(fourK), eo_ftau(N, tau), int(iters), int(step), seed, it0, replica,
+                                     ch, Es, C.byref(Emin), Cmin, C.byref(itmin))
+    if n < 0:
+        raise RuntimeError("extremal_opt_quant_spf: inconsistent cache / energy (%d)" % n)
+    return Es[:n], ch, Emin.value, Cmin, itmin.value

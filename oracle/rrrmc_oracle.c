@@ -898,6 +898,7 @@ typedef struct {
     sparse_t *X1;            /* M slice graphs sharing A, J; each with its own LocalFields */
     skb_t *S1;               /* or (X1 == NULL) M binary-SK slice graphs sharing J */
     skn_t *G1;               /* or M GraphSKNormal slice graphs sharing J (GraphQSKNormalT, src/QAliases.jl:45-46; test/runtests.jl:80) */
+    spf_t *F1;               /* or M GraphEANormal / GraphRRGNormal slice graphs sharing (A, J::Float64) (GraphQEAT, src/QAliases.jl:50-83) */
     uint64_t **C1;           /* M slice configurations (copies of the slice bits) */
 } quant_t;
 
@@ -921,13 +922,30 @@ static void quant_init(quant_t *Q, int64_t Nk, int64_t M, int64_t K, const int32
         Q->X1[k] = X;
         Q->C1[k] = (uint64_t *)calloc((size_t)((Nk + 63) / 64), 8);
     }
-    Q->S1 = NULL; Q->G1 = NULL;
+    Q->S1 = NULL; Q->G1 = NULL; Q->F1 = NULL;
+}
+/* GraphQuant over M sparse Float64 slice graphs sharing (A, J) — GraphQEAT = GraphQuant{fourK,GraphEANormal{twoD}} (src/QAliases.jl:50-83):
+ * every slice is a GraphEANormal (form = 1: EA.jl:534-680) or GraphRRGNormal (form = 0: RRG.jl:503-627) with its own LocalFields{Float64} */
+static void quant_init_spf(quant_t *Q, int64_t Nk, int64_t M, int64_t K, const int32_t *A, const double *Jf, int form, double fourK)
+{
+    Q->X0.N = Nk * M; Q->X0.M = M; Q->X0.Nk = Nk; Q->X0.fourK = fourK;
+    Q->Nk = Nk; Q->M = M; Q->K = K;
+    Q->X1 = NULL; Q->S1 = NULL; Q->G1 = NULL;
+    Q->F1 = (spf_t *)calloc((size_t)M, sizeof(spf_t));
+    Q->C1 = (uint64_t **)calloc((size_t)M, sizeof(uint64_t *));
+    for (int64_t k = 0; k < M; ++k) {
+        spf_t X = {Nk, K, A, Jf, NULL, NULL, -1, form, NULL, 1, 1.0, NULL, NULL};
+        X.lfields = (double *)calloc((size_t)Nk, 8);
+        X.lfields_last = (double *)calloc((size_t)Nk, 8);
+        Q->F1[k] = X;
+        Q->C1[k] = (uint64_t *)calloc((size_t)((Nk + 63) / 64), 8);
+    }
 }
 static void quant_init_skn(quant_t *Q, int64_t Nk, int64_t M, const double *Jd, double fourK)
 {
     Q->X0.N = Nk * M; Q->X0.M = M; Q->X0.Nk = Nk; Q->X0.fourK = fourK;
     Q->Nk = Nk; Q->M = M; Q->K = 0;
-    Q->X1 = NULL; Q->S1 = NULL;
+    Q->X1 = NULL; Q->S1 = NULL; Q->F1 = NULL;
     Q->G1 = (skn_t *)calloc((size_t)M, sizeof(skn_t));
     Q->C1 = (uint64_t **)calloc((size_t)M, sizeof(uint64_t *));
     for (int64_t k = 0; k < M; ++k) {
@@ -943,7 +961,7 @@ static void quant_init_sk(quant_t *Q, int64_t Nk, int64_t M, const uint64_t *Jb,
     Q->X0.N = Nk * M; Q->X0.M = M; Q->X0.Nk = Nk; Q->X0.fourK = fourK;
     Q->Nk = Nk; Q->M = M; Q->K = 0;
     Q->X1 = NULL;
-    Q->G1 = NULL;
+    Q->G1 = NULL; Q->F1 = NULL;
     Q->S1 = (skb_t *)calloc((size_t)M, sizeof(skb_t));
     Q->C1 = (uint64_t **)calloc((size_t)M, sizeof(uint64_t *));
     for (int64_t k = 0; k < M; ++k) {
@@ -960,14 +978,16 @@ static void quant_free(quant_t *Q)
         if (Q->X1) { free(Q->X1[k].lfields); free(Q->X1[k].lfields_last); }
         if (Q->S1) { free(Q->S1[k].lfields); free(Q->S1[k].lfields_last); }
         if (Q->G1) { free(Q->G1[k].lfields); free(Q->G1[k].lfields_last); }
+        if (Q->F1) { free(Q->F1[k].lfields); free(Q->F1[k].lfields_last); }
         free(Q->C1[k]);
     }
-    free(Q->X1); free(Q->S1); free(Q->G1); free(Q->C1);
+    free(Q->X1); free(Q->S1); free(Q->G1); free(Q->F1); free(Q->C1);
 }
 /* energy(X1[k], C1[k]) as the Float64 the reference divides: an Int for GraphRRG slices, n / sqrt(Nk) for GraphSK ones (SK.jl:95) */
 static inline double quant_slice_energy(quant_t *Q, int64_t k)
 {
     if (Q->G1) return skn_energy(&Q->G1[k], Q->C1[k]);
+    if (Q->F1) return spf_energy(&Q->F1[k], Q->C1[k]);
     return Q->S1 ? skb_energy(&Q->S1[k], Q->C1[k]) : (double)sparse_energy(&Q->X1[k], Q->C1[k]);
 }
 /* energy: QT.jl:185-199 — copies the slice bits into C1[k] and (re)builds every slice cache */
@@ -987,6 +1007,7 @@ static inline double quant_residual(const quant_t *Q, int64_t move)
 {
     int64_t k = move / Q->Nk, i = move % Q->Nk;
     if (Q->G1) return Q->G1[k].lfields[i] / (double)Q->M;                                   /* SK.jl:278-284 */
+    if (Q->F1) return (-Q->F1[k].lfields[i]) / (double)Q->M;                                /* delta_energy = -lfields: EA.jl:655-661, RRG.jl:619-625 */
     if (Q->S1) return ((double)Q->S1[k].lfields[i] / Q->S1[k].sN) / (double)Q->M;          /* SK.jl:137-140 */
     return (double)sparse_delta_energy(&Q->X1[k], i) / (double)Q->M;
 }
@@ -997,6 +1018,7 @@ static void quant_spinflip(quant_t *Q, uint64_t *s, int64_t move)
     int64_t k = move / Q->Nk, i = move % Q->Nk;
     bitflip(Q->C1[k], i);
     if (Q->G1) { skn_update_cache(&Q->G1[k], Q->C1[k], i); return; }
+    if (Q->F1) { spf_update_cache(&Q->F1[k], Q->C1[k], i); return; }
     if (Q->S1) skb_update_cache(&Q->S1[k], Q->C1[k], i);
     else sparse_update_cache(&Q->X1[k], Q->C1[k], i);
 }
@@ -1160,6 +1182,19 @@ ORC_API int64_t orc_rrr_mc_quant_skn(int64_t Nk, int64_t M, const double *Jd, do
     return r;
 }
 
+/* GraphQEAT (src/QAliases.jl:50-83): GraphQuant over sparse Float64 slices */
+ORC_API int64_t orc_rrr_mc_quant_spf(int form, int64_t Nk, int64_t M, int64_t K, const int32_t *A, const double *Jf, double fourK,
+                                 double beta, int64_t iters, int64_t step, double staged_thr, double staged_thr_fact,
+                                 uint64_t seed, uint64_t it0, uint32_t replica,
+                                 uint64_t *chunks, double *Es, int64_t *stats, int32_t *cache_out)
+{
+    quant_t Q;
+    quant_init_spf(&Q, Nk, M, K, A, Jf, form, fourK);
+    int64_t r = orc_rrr_mc_quant_impl(&Q, beta, iters, step, staged_thr, staged_thr_fact, seed, it0, replica, chunks, Es, stats, cache_out);
+    quant_free(&Q);
+    return r;
+}
+
 /* standardMC (src/RRRMC.jl:81-127) on GraphQuant: delta_energy = delta_energy(X0) + delta_energy_residual (QT.jl:283-286).
  * SITE stream for the spin, ACCEPT_F64 stream for rand(). */
 static int64_t orc_standard_mc_quant_impl(quant_t *Q,
@@ -1217,6 +1252,24 @@ ORC_API int64_t orc_standard_mc_quant_skn(int64_t Nk, int64_t M, const double *J
     int64_t r = orc_standard_mc_quant_impl(&Q, beta, iters, step, seed, it0, replica, chunks, Es, accepted_out);
     quant_free(&Q);
     return r;
+}
+ORC_API int64_t orc_standard_mc_quant_spf(int form, int64_t Nk, int64_t M, int64_t K, const int32_t *A, const double *Jf, double fourK,
+                                      double beta, int64_t iters, int64_t step, uint64_t seed, uint64_t it0, uint32_t replica,
+                                      uint64_t *chunks, double *Es, int64_t *accepted_out)
+{
+    quant_t Q;
+    quant_init_spf(&Q, Nk, M, K, A, Jf, form, fourK);
+    int64_t r = orc_standard_mc_quant_impl(&Q, beta, iters, step, seed, it0, replica, chunks, Es, accepted_out);
+    quant_free(&Q);
+    return r;
+}
+ORC_API double orc_quant_energy_spf(int form, int64_t Nk, int64_t M, int64_t K, const int32_t *A, const double *Jf, double fourK, const uint64_t *chunks)
+{
+    quant_t Q;
+    quant_init_spf(&Q, Nk, M, K, A, Jf, form, fourK);
+    const double E = quant_energy(&Q, chunks);
+    quant_free(&Q);
+    return E;
 }
 ORC_API double orc_quant_energy_skn(int64_t Nk, int64_t M, const double *Jd, double fourK, const uint64_t *chunks)
 {
@@ -2359,6 +2412,15 @@ static int spf_neighbors(const spf_t *X, int64_t i, int64_t *out)
         qt_neighbors(&Q->X0, i, &j1, &j2);
         out[n++] = j1; out[n++] = j2;
         const int64_t k = i / Q->Nk, x = i % Q->Nk;
+        if (Q->F1) {                                   /* sparse Float64 slices: neighbors(X1[k], x) = A[x] (RRG.jl:627) / uA[x] (EA.jl:680) */
+            const spf_t *F = &Q->F1[k];
+            const int32_t *Ax = F->A + x * F->K;
+            for (int64_t q = 0; q < F->K; ++q) {
+                if (F->ea_form && q > 0 && Ax[q] == Ax[q - 1]) continue;
+                out[n++] = Ax[q] + k * Q->Nk;
+            }
+            return n;
+        }
         if (!Q->X1) {                                  /* GraphSK / GraphSKNormal slices: AllButOne(Nk, x) (SK.jl:142,297), in index order */
             for (int64_t j = 0; j < Q->Nk; ++j) if (j != x) out[n++] = j + k * Q->Nk;
             return n;
@@ -2705,6 +2767,17 @@ ORC_API int64_t orc_extremal_opt_quant(int form, int64_t Nk, int64_t M, int64_t 
     quant_free(&Q);
     return r;
 }
+ORC_API int64_t orc_extremal_opt_quant_spf(int form, int64_t Nk, int64_t M, int64_t K, const int32_t *A, const double *Jf, double fourK,
+                                           const double *ftau, int64_t iters, int64_t step, uint64_t seed, uint64_t it0, uint32_t replica,
+                                           uint64_t *chunks, double *Es, double *Emin_out, uint64_t *Cmin, int64_t *itmin_out)
+{
+    if (Nk * M > 65535) return -2;
+    quant_t Q;
+    quant_init_spf(&Q, Nk, M, K, A, Jf, form, fourK);
+    const int64_t r = extremal_opt_quant_impl(&Q, form, K, A, ftau, iters, step, seed, it0, replica, chunks, Es, Emin_out, Cmin, itmin_out);
+    quant_free(&Q);
+    return r;
+}
 ORC_API int64_t orc_extremal_opt_quant_dense(int kind, int64_t Nk, int64_t M, const uint64_t *Jb, const double *Jd, double fourK,
                                              const double *ftau, int64_t iters, int64_t step, uint64_t seed, uint64_t it0, uint32_t replica,
                                              uint64_t *chunks, double *Es, double *Emin_out, uint64_t *Cmin, int64_t *itmin_out)
@@ -2855,6 +2928,18 @@ ORC_API int64_t orc_cont_quant_dense(int mode, int kind, int64_t Nk, int64_t M, 
     quant_t Q;
     if (kind == 3) quant_init_skn(&Q, Nk, M, Jd, fourK); else quant_init_sk(&Q, Nk, M, Jb, fourK);
     int64_t r = cont_sparse_impl(mode, 0, Nk * M, 0, NULL, NULL, NULL, 1, 1.0, beta, iters, step, stepf, 0.8, 5.0, seed, it0, call, replica,
+                                 chunks, Es, stats, t_out, &Q);
+    quant_free(&Q);
+    return r;
+}
+ORC_API int64_t orc_cont_quant_spf(int mode, int form, int64_t Nk, int64_t M, int64_t K, const int32_t *A, const double *Jf, double fourK, double beta,
+                                   int64_t iters, int64_t step, double stepf, uint64_t seed, uint64_t it0, uint32_t call, uint32_t replica,
+                                   uint64_t *chunks, double *Es, int64_t *stats, double *t_out)
+{
+    if (K + 2 > SK_MAX + 2) return -2;
+    quant_t Q;
+    quant_init_spf(&Q, Nk, M, K, A, Jf, form, fourK);
+    int64_t r = cont_sparse_impl(mode, 0, Nk * M, K, NULL, NULL, NULL, 1, 1.0, beta, iters, step, stepf, 0.8, 5.0, seed, it0, call, replica,
                                  chunks, Es, stats, t_out, &Q);
     quant_free(&Q);
     return r;

@@ -23,7 +23,7 @@ SYMBOLS = [
     "rrrmc_gen_couplings_pm1", "rrrmc_gen_couplings_lev", "rrrmc_set_graph_levels", "rrrmc_set_couplings_dense", "rrrmc_energy_f64", "rrrmc_get_fields_f64",
     "rrrmc_standard_mc_f64", "rrrmc_fetch_results_f64", "rrrmc_gen_sk_gauss",
     "rrrmc_set_couplings_bits", "rrrmc_gen_sk_binary", "rrrmc_set_coloring", "rrrmc_colored_sweeps_async", "rrrmc_colored_count_accepted",
-    "rrrmc_ctx_create_quant", "rrrmc_ctx_create_quant_sk", "rrrmc_ctx_create_quant_skn", "rrrmc_quant_set_field", "rrrmc_quant_slice_form", "rrrmc_rrr_mc_async", "rrrmc_rrr_stats", "rrrmc_rrr_cache", "rrrmc_bkl_mc_async",
+    "rrrmc_ctx_create_quant", "rrrmc_ctx_create_quant_sk", "rrrmc_ctx_create_quant_skn", "rrrmc_ctx_create_quant_f64", "rrrmc_quant_set_field", "rrrmc_quant_slice_form", "rrrmc_rrr_mc_async", "rrrmc_rrr_stats", "rrrmc_rrr_cache", "rrrmc_bkl_mc_async",
     "rrrmc_snapshot_reserve", "rrrmc_snapshot_store", "rrrmc_snapshot_get", "rrrmc_overlaps", "rrrmc_quant_observables",
     "rrrmc_set_graph_f64", "rrrmc_gen_couplings_gauss", "rrrmc_set_graph_discretized", "rrrmc_set_level_scale", "rrrmc_discretize", "rrrmc_discretize_scaled", "rrrmc_wtm_mc_async", "rrrmc_wtm_times", "rrrmc_extremal_opt_async", "rrrmc_extremal_opt_results", "rrrmc_extremal_opt_results_f64",
 ]
@@ -96,6 +96,8 @@ def lib():
     L.rrrmc_last_timing.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int32)]
     L.rrrmc_ctx_create_quant_skn.restype = C.c_int32
     L.rrrmc_ctx_create_quant_skn.argtypes = [C.POINTER(vp), C.c_int64, C.c_int64, C.c_int64, C.c_int32, C.c_uint32]
+    L.rrrmc_ctx_create_quant_f64.restype = C.c_int32
+    L.rrrmc_ctx_create_quant_f64.argtypes = [C.POINTER(vp), C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int32, C.c_uint32]
     L.rrrmc_quant_slice_form.restype = C.c_int32
     L.rrrmc_quant_slice_form.argtypes = [vp, C.c_int32]
     L.rrrmc_standard_mc_fast_async.restype = C.c_int32

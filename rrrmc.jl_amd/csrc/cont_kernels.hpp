@@ -43,8 +43,9 @@ struct ContParams {
     double fourK;            //   delta_energy = qt_delta * fourK + slice_delta / qM (QT.jl:283-286); neighbors = Trotter pair, then the slice's (QT.jl:288-321)
     int qNk, qM;
     // GraphQuant over DENSE slices (every other spin of the slice is a neighbour): qkind 2 = binary GraphSK (GraphQSKT), 3 = GraphSKNormal
-    // (GraphQSKNormalT); 1 = sparse slices (qJ above), 0 = not a GraphQuant
+    // (GraphQSKNormalT); 1 = sparse +-J slices (qJ above), 4 = sparse Float64 slices (GraphQEAT: qJf and the slice caches below); 0 = not a GraphQuant
     int qkind;
+    const double* qJf; double* qflf; double* qfundo; int32_t* qfml;   // sparse Float64 slices: couplings [qNk][K], per-replica slice caches (as RrrParams)
     const uint32_t* qJb; int qWk; double qsN;                       // binary: rows of J as 32-bit words, sqrt(Nk)
     const double* qJd; double* qslf; int32_t* qsmv; uint8_t* qscur;  // GraphSKNormal: couplings, per-replica slice caches (as RrrParams)
     const double* ftau;      // [N]  extremal_opt: cumsum(j^-tau)
@@ -104,7 +105,7 @@ struct ContChain {
     {
         sp[move >> 5] ^= 1u << (move & 31);
         if (P->qkind) {                          // GraphQuant: integer slices cache nothing (delta_energy is recomputed from the spins);
-            if (P->qkind == 3) skn_update(qview(), move);      // GraphSKNormal slices keep their Float64 fields (SK.jl:239-276)
+            if (P->qkind >= 3) slice_cache_update(qview(), move);      // GraphSKNormal / sparse Float64 slices keep their Float64 fields (SK.jl:239-276, EA.jl:613-653)
             return;
         }
         const int K = P->K;
@@ -157,6 +158,10 @@ struct ContChain {
             v.Jd = P->qJd;
             v.slf = P->qslf + (size_t)rloc * 2 * P->qM * P->qNk; v.smv = P->qsmv + (size_t)rloc * P->qM; v.scur = P->qscur + (size_t)rloc * P->qM;
         }
+        if (P->qkind == 4) {
+            v.Jf = P->qJf;
+            v.flf = P->qflf + (size_t)rloc * P->qM * P->qNk; v.fundo = P->qfundo + (size_t)rloc * P->qM * (P->K + 1); v.fml = P->qfml + (size_t)rloc * P->qM;
+        }
         v.nk_magic = (uint32_t)((0x100000000ull + (uint32_t)P->qNk - 1u) / (uint32_t)P->qNk);
         v.wide = P->N > 65535 ? 1 : 0;      // the slice of a spin by division (the multiply-high form is exact below 2^16 only)
         return v;
@@ -187,7 +192,7 @@ struct ContChain {
     }
     // neighbors(X, move) as (count, q-th neighbour): sparse graphs go through the small list `nb`, a GraphQuant over dense slices has the
     // Trotter pair followed by the Nk - 1 other spins of the slice in index order (AllButOne, SK.jl:142,297; QT.jl:288-321)
-    __device__ __forceinline__ bool dense() const { return P->qkind >= 2; }
+    __device__ __forceinline__ bool dense() const { return P->qkind == 2 || P->qkind == 3; }
     __device__ __forceinline__ int nb_count(int move, int* nb) const { return dense() ? P->qNk + 1 : nbrs(move, nb); }
     __device__ __forceinline__ int nb_at(int move, int q, const int* nb) const
     {
@@ -426,7 +431,24 @@ __global__ __launch_bounds__(kRrrThreads) void cont_sparse_kernel(ContParams P)
             for (int k = 0; k < P.qM; ++k) { const int sk = c.sbit(i + k * P.qNk); n0 -= 1 - 2 * (sk ^ sj); sj = sk; }
         }
         E = (double)n0 * P.fourK / 4;
-        for (int k = 0; k < P.qM && P.qkind != 3; ++k) {
+        for (int k = 0; k < P.qM && P.qkind == 4; ++k) {      // sparse Float64 slices: rebuild the slice cache as energy does (EA.jl:584-611)
+            double* lf = v.flf + (size_t)k * P.qNk;
+            double E1 = 0.0;
+            for (int x = 0; x < P.qNk; ++x) {
+                const int sx = 2 * c.sbit(k * P.qNk + x) - 1;
+                double fl = 0.0;
+                for (int q = 0; q < K; ++q) {
+                    const int sy = 2 * c.sbit(k * P.qNk + P.A[(size_t)x * K + q]) - 1;
+                    fl = fl - P.qJf[(size_t)x * K + q] * (double)sx * (double)sy;
+                }
+                E1 = E1 + fl;
+                lf[x] = 2.0 * fl;
+            }
+            v.fml[k] = -1;
+            for (int q = 0; q <= K; ++q) v.fundo[(size_t)k * (K + 1) + q] = 0.0;
+            E += (E1 / 2) / (double)P.qM;
+        }
+        for (int k = 0; k < P.qM && P.qkind < 3; ++k) {
             long long n = 0;
             for (int i = 0; i < P.qNk; ++i) n -= slice_delta(v, k * P.qNk + i) / 2;
             n /= 2;

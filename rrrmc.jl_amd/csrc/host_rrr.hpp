@@ -8,6 +8,7 @@ RrrParams quant_params(rrrmc_ctx* ctx, double beta, double fourK)
     P.A = ctx->d_A; P.J = ctx->d_J;
     if (ctx->q_sk) { P.Jb = ctx->q_Jb; P.Wk = (int)ctx->q_Wk; P.sN = std::sqrt((double)ctx->qNk); }
     if (ctx->q_skn) { P.Jd = ctx->sk_J; P.slf = ctx->q_slf; P.smv = ctx->q_smv; P.scur = ctx->q_scur; }
+    if (ctx->q_spf) { P.Jf = ctx->q_Jf; P.flf = ctx->q_flf; P.fundo = ctx->q_fundo; P.fml = ctx->q_fml; }
     P.spins = ctx->q_spins; P.cls = ctx->q_cls; P.sv = ctx->q_sv; P.spos = ctx->q_spos; P.st = ctx->q_st;
     P.T = ctx->q_T; P.zz = ctx->q_z; P.E_cur = ctx->sk_E; P.acc_rate = ctx->q_accrate; P.stats = ctx->q_stats; P.Es = ctx->sk_Es;
     P.beta = beta; P.fourK = fourK;
@@ -46,6 +47,12 @@ int32_t quant_run_init(rrrmc_ctx* ctx, double beta, double fourK)
     if (ctx->q_skn) {              // GraphSKNormal slices: Float64 slice caches rebuilt in the reference's summation order
         if ((size_t)ctx->qM * sizeof(long long) > 32768) return fail(ctx, RRRMC_ERR_UNSUPPORTED, "M = %lld slices exceed the init kernel's LDS", (long long)ctx->qM);
         hipLaunchKernelGGL(rrr_init_skn_kernel, dim3((unsigned)ctx->R), dim3(kInitThreads), (size_t)ctx->qM * sizeof(long long), ctx->stream, P);
+        HIP_TRY(ctx, hipGetLastError());
+        return RRRMC_OK;
+    }
+    if (ctx->q_spf) {              // sparse Float64 slices (GraphQEAT): every slice's LocalFields rebuilt in its graph's summation order
+        if ((size_t)ctx->qM * sizeof(long long) > 32768) return fail(ctx, RRRMC_ERR_UNSUPPORTED, "M = %lld slices exceed the init kernel's LDS", (long long)ctx->qM);
+        hipLaunchKernelGGL(rrr_init_spf_kernel, dim3((unsigned)ctx->R), dim3(kInitThreads), (size_t)ctx->qM * sizeof(long long), ctx->stream, P);
         HIP_TRY(ctx, hipGetLastError());
         return RRRMC_OK;
     }

@@ -293,7 +293,8 @@ int32_t spf_cont_async(rrrmc_ctx* ctx, int mode, double beta, int64_t iters, int
     P.dJ = dblm && !quantm ? ctx->db_dJ : nullptr; P.lev_mul = ctx->db_lev_mul; P.lev_div = ctx->db_lev_div;
     if (quantm) {
         P.qJ = ctx->d_J; P.fourK = ctx->last_fourK; P.qNk = (int)ctx->qNk; P.qM = (int)ctx->qM;
-        P.qkind = ctx->q_skn ? 3 : (ctx->q_sk ? 2 : 1);
+        P.qkind = ctx->q_spf ? 4 : ctx->q_skn ? 3 : (ctx->q_sk ? 2 : 1);
+        if (ctx->q_spf) { P.qJ = nullptr; P.qJf = ctx->q_Jf; P.qflf = ctx->q_flf; P.qfundo = ctx->q_fundo; P.qfml = ctx->q_fml; }
         if (ctx->q_sk) { P.qJb = ctx->q_Jb; P.qWk = (int)ctx->q_Wk; P.qsN = std::sqrt((double)ctx->qNk); }
         if (ctx->q_skn) { P.qJd = ctx->sk_J; P.qslf = ctx->q_slf; P.qsmv = ctx->q_smv; P.qscur = ctx->q_scur; }
     }

@@ -52,6 +52,13 @@ struct RrrParams {
     double* slf;             // [R][2][M][Nk]   the two field arrays of every slice
     int32_t* smv;            // [R][M]          move_last of every slice (-1 = none)
     uint8_t* scur;           // [R][M]          which of the two arrays is `lfields`
+    // sparse Float64 slices (GraphQEAT = GraphQuant{fourK,GraphEANormal{twoD}}, QAliases.jl:50-83; GraphRRGNormal slices alike): couplings on the
+    // slice graph's table A, and every slice's own LocalFields{Float64} — lfields, the live part of lfields_last (the K + 1 values the undo
+    // path of update_cache! reads, EA.jl:613-653 / RRG.jl:576-617) and move_last — per replica
+    const double* Jf;        // [Nk][K] else null
+    double* flf;             // [R][M][Nk]
+    double* fundo;           // [R][M][K+1]
+    int32_t* fml;            // [R][M]          move_last of every slice (-1 = none)
     // per-replica state, replica-contiguous
     uint32_t* spins;         // [R][W]       bit x of replica r: word x >> 5, bit x & 31; x = slice * Nk + i
     uint8_t* cls;            // [R][N]       class of every spin: a + 2 * up  (DeltaECache.pos)
@@ -81,6 +88,7 @@ struct RrrView {             // one replica's slices of the arrays above
     const uint32_t* Jb; int Wk; double sN;
     double fourK;
     const double* Jd; double* slf; int32_t* smv; uint8_t* scur;      // GraphSKNormal slices (this replica's arrays)
+    const double* Jf; double* flf; double* fundo; int32_t* fml;      // sparse Float64 slices (this replica's arrays)
 };
 
 __device__ __forceinline__ int sbit(const uint32_t* sp, int x) { return (int)((sp[x >> 5] >> (x & 31)) & 1u); }
@@ -177,10 +185,58 @@ __device__ inline void skn_update(const RrrView& v, int move)
     lf[i] = -lfm;
     v.smv[k] = i;
 }
-// the residual of a move for either kind of slice
+// sparse Float64 slices: delta_energy_residual = delta_energy(X1[k], C1[k], i) / M = -lfields[i] / M (EA.jl:655-661, QT.jl:270-281)
+__device__ __forceinline__ double spf_slice_residual(const RrrView& v, int move)
+{
+    const int k = slice_of(move, v.Nk, v.nk_magic, v.wide), i = move - k * v.Nk;
+    return (-v.flf[(size_t)k * v.Nk + i]) / (double)v.M;
+}
+// update_cache! of a sparse Float64 slice graph (EA.jl:613-653 / RRG.jl:576-617), after the bit flip: the neighbours' fields move by
+// -4 sigma_xy J (a neighbour listed twice — L = 2 — receives both bonds in order), the old values go to the undo record, and a flip of
+// the slice's last moved spin takes the record back instead (the exact undo of a rejected rrrMC move)
+__device__ inline void spf_slice_update(const RrrView& v, int move)
+{
+    const int k = slice_of(move, v.Nk, v.nk_magic, v.wide), i = move - k * v.Nk, off = k * v.Nk, K = v.K;
+    double* lf = v.flf + (size_t)k * v.Nk;
+    double* undo = v.fundo + (size_t)k * (K + 1);
+    const int32_t* Ax = v.A + (size_t)i * K;
+    const double* Jx = v.Jf + (size_t)i * K;
+    const double lfm = lf[i];
+    if (v.fml[k] == i) {
+        for (int q = 0; q < K; ++q) {
+            if (q > 0 && Ax[q] == Ax[q - 1]) continue;
+            const int y = Ax[q];
+            const double tmp = lf[y];
+            lf[y] = undo[q];
+            undo[q] = tmp;
+        }
+        lf[i] = -lfm;
+        undo[K] = -undo[K];
+        return;
+    }
+    const int sx = sbit(v.sp, move);
+    double vv = 0.0;
+    for (int q = 0; q < K; ++q) {
+        const int y = Ax[q];
+        if (!(q > 0 && Ax[q] == Ax[q - 1])) { vv = lf[y]; undo[q] = vv; }
+        const double c = (sx ^ sbit(v.sp, off + y)) ? -4.0 : 4.0;
+        vv = vv - c * Jx[q];
+        if (q == K - 1 || Ax[q + 1] != y) lf[y] = vv;
+    }
+    undo[K] = lfm;
+    lf[i] = -lfm;
+    v.fml[k] = i;
+}
+// the residual of a move for every kind of slice
 __device__ __forceinline__ double any_residual(const RrrView& v, int move)
 {
-    return v.Jd ? skn_residual(v, move) : slice_res(v, slice_delta(v, move));
+    return v.Jd ? skn_residual(v, move) : v.Jf ? spf_slice_residual(v, move) : slice_res(v, slice_delta(v, move));
+}
+// the slice graph's update_cache! after the bit flip of spinflip!(X::GraphQuant, C, move) (QT.jl:172-183); integer slices cache nothing here
+__device__ __forceinline__ void slice_cache_update(const RrrView& v, int move)
+{
+    if (v.Jd) skn_update(v, move);
+    else if (v.Jf) spf_slice_update(v, move);
 }
 
 // ArraySet delete! / push! (ArraySets.jl:56-76); one position array serves the four sets (membership is exclusive)
@@ -215,6 +271,10 @@ __device__ __forceinline__ RrrView rrr_view(const RrrParams& P, int r)
     v.slf = P.Jd ? P.slf + (size_t)r * 2 * P.M * P.Nk : nullptr;
     v.smv = P.Jd ? P.smv + (size_t)r * P.M : nullptr;
     v.scur = P.Jd ? P.scur + (size_t)r * P.M : nullptr;
+    v.Jf = P.Jf;
+    v.flf = P.Jf ? P.flf + (size_t)r * P.M * P.Nk : nullptr;
+    v.fundo = P.Jf ? P.fundo + (size_t)r * P.M * (P.K + 1) : nullptr;
+    v.fml = P.Jf ? P.fml + (size_t)r * P.M : nullptr;
     v.nk_magic = (uint32_t)((0x100000000ull + (uint32_t)P.Nk - 1u) / (uint32_t)P.Nk);
     return v;
 }
@@ -423,6 +483,89 @@ __global__ __launch_bounds__(kInitThreads) void rrr_init_skn_kernel(RrrParams P)
     }
 }
 
+// energy(X::GraphQuant, C) (QT.jl:185-199) and the DeltaECache for sparse Float64 slices (GraphQEAT), one workgroup per replica: every slice's
+// cache is rebuilt as its graph's energy does (EA.jl:584-611 / RRG.jl:546-574: lf_x = -sum_q J sx sy in table order, E1 += lf_x in site order,
+// lfields[x] = 2 lf_x, E1 / 2; move_last = none), one thread per slice (the sums are sequential by construction); the classes as rrr_init_coop_kernel.
+__global__ __launch_bounds__(kInitThreads) void rrr_init_spf_kernel(RrrParams P)
+{
+    __shared__ int s_cnt[4][kInitThreads];
+    __shared__ int s_tot[4];
+    __shared__ long long s_n0;
+    extern __shared__ long long s_slice[];             // [M] slice energies (as doubles)
+    double* s_E = reinterpret_cast<double*>(s_slice);
+    const int r = (int)blockIdx.x, tid = (int)threadIdx.x;
+    const RrrView v = rrr_view(P, r);
+    const int N = P.N, Nk = P.Nk, M = P.M, K = P.K;
+    if (tid == 0) s_n0 = 0;
+    __syncthreads();
+    {
+        long long n0 = 0;
+        for (int x = tid; x < N; x += kInitThreads) {
+            const int i = x % Nk, k = x / Nk;
+            const int prev = i + (k == 0 ? M - 1 : k - 1) * Nk;
+            n0 -= 1 - 2 * (sbit(v.sp, x) ^ sbit(v.sp, prev));
+        }
+        atomicAdd(reinterpret_cast<unsigned long long*>(&s_n0), (unsigned long long)n0);
+    }
+    for (int k = tid; k < M; k += kInitThreads) {
+        double* lf = v.flf + (size_t)k * Nk;
+        double E1 = 0.0;
+        for (int x = 0; x < Nk; ++x) {
+            const int sx = 2 * sbit(v.sp, k * Nk + x) - 1;
+            double fl = 0.0;
+            for (int q = 0; q < K; ++q) {
+                const int sy = 2 * sbit(v.sp, k * Nk + P.A[(size_t)x * K + q]) - 1;
+                fl = fl - P.Jf[(size_t)x * K + q] * (double)sx * (double)sy;
+            }
+            E1 = E1 + fl;
+            lf[x] = 2.0 * fl;
+        }
+        s_E[k] = E1 / 2;
+        v.fml[k] = -1;
+        for (int q = 0; q <= K; ++q) v.fundo[(size_t)k * (K + 1) + q] = 0.0;
+    }
+    __syncthreads();
+    const int per = (N + kInitThreads - 1) / kInitThreads, x0 = tid * per, x1 = x0 + per < N ? x0 + per : N;
+    int cnt[4] = {0, 0, 0, 0};
+    for (int x = x0; x < x1; ++x) {
+        const int k = qt_class(v, x);
+        v.cls[x] = (uint8_t)k;
+        cnt[k] += 1;
+    }
+    for (int k = 0; k < 4; ++k) s_cnt[k][tid] = cnt[k];
+    __syncthreads();
+    if (tid < 4) {
+        int run = 0;
+        for (int t = 0; t < kInitThreads; ++t) { const int c = s_cnt[tid][t]; s_cnt[tid][t] = run; run += c; }
+        s_tot[tid] = run;
+    }
+    __syncthreads();
+    int off[4];
+    for (int k = 0; k < 4; ++k) off[k] = s_cnt[k][tid];
+    for (int x = x0; x < x1; ++x) {
+        const int k = v.cls[x];
+        idx_set(v.sv, (size_t)k * N + off[k], x, v.wide);
+        idx_set(v.spos, x, off[k], v.wide);
+        off[k] += 1;
+    }
+    if (tid == 0) {
+        double E = (double)s_n0 * P.fourK / 4;
+        for (int k = 0; k < M; ++k) E += s_E[k] / (double)M;
+        P.E_cur[r] = E;
+        double z = 0.0;
+        for (int k = 0; k < 4; ++k) {
+            v.t[k] = s_tot[k];
+            const double x = (double)s_tot[k] * class_f(k, P.ft1);
+            z += x;
+            P.T[(size_t)r * 4 + k] = x;
+        }
+        P.zz[r] = z;
+        P.acc_rate[r] = 0.5;
+        P.stats[(size_t)r * 2] = 0;
+        P.stats[(size_t)r * 2 + 1] = 0;
+    }
+}
+
 // bytes of LDS one replica's hot state takes in the LDS-resident build below
 inline size_t rrr_quant_lds_bytes(int64_t N, int64_t W, int64_t Nk, int64_t K)
 {
@@ -550,7 +693,7 @@ __global__ __launch_bounds__(kRrrThreads) void rrr_quant_kernel(RrrParams P)
             }
             if (ok) {
                 sflip(v.sp, move);                                                     // spinflip!(X, C, move)
-                if (v.Jd) skn_update(v, move);
+                slice_cache_update(v, move);
                 for (int q = 0; q < nst; ++q) set_move(v, sj[q], s0[q], s1[q]);        // apply_staged!
                 for (int q = 0; q < 4; ++q) T[q] = Tp[q];
                 z = zp;
@@ -564,7 +707,7 @@ __global__ __launch_bounds__(kRrrThreads) void rrr_quant_kernel(RrrParams P)
             double c = 0.0;
             for (int pass = 0; pass < 2; ++pass) {
                 sflip(v.sp, move);
-                if (v.Jd) skn_update(v, move);                                          // the undo pass takes the swap path (move_last == move)
+                slice_cache_update(v, move);                                          // the undo pass takes the swap path (move_last == move)
                 double zp = z;
                 for (int q = 0; q < 2; ++q) {
                     const int j = nb[q];
@@ -638,7 +781,7 @@ __global__ __launch_bounds__(kRrrThreads) void quant_standard_kernel(RrrParams P
         const double dE = (double)qt_delta(v, move) * P.fourK + any_residual(v, move);
         const double x = -P.beta * dE;
         const bool acc = (x >= 0.0) || (rand53(P.k0, P.k1, g, rep) < det_exp(x));        // RRRMC.jl:39
-        if (acc) { sflip(v.sp, move); if (v.Jd) skn_update(v, move); E += dE; accepted += 1; }
+        if (acc) { sflip(v.sp, move); slice_cache_update(v, move); E += dE; accepted += 1; }
     }
     P.E_cur[r] = E;
     P.stats[(size_t)r * 2] = accepted; P.stats[(size_t)r * 2 + 1] = 0;

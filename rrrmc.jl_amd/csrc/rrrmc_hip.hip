@@ -176,6 +176,11 @@ struct rrrmc_ctx {
     double* q_slf = nullptr;              // [R][2][M][Nk]
     int32_t* q_smv = nullptr;             // [R][M]
     uint8_t* q_scur = nullptr;            // [R][M]
+    bool q_spf = false;                   // GraphQuant over sparse Float64 slices (GraphQEAT, src/QAliases.jl:50-83): table in d_A, couplings and slice caches below
+    double* q_Jf = nullptr;               // [Nk][K]
+    double* q_flf = nullptr;              // [R][M][Nk]
+    double* q_fundo = nullptr;            // [R][M][K+1]
+    int32_t* q_fml = nullptr;             // [R][M]
     uint32_t* q_spins = nullptr;
     uint8_t* q_cls = nullptr;
     uint16_t* q_sv = nullptr;
@@ -857,6 +862,7 @@ void rrrmc_ctx_destroy(rrrmc_ctx* ctx)
     free_dev(ctx->pff_table); free_dev(ctx->pff_absJ); free_dev(ctx->pff_bond_off); free_dev(ctx->pff_thr_hi); free_dev(ctx->pff_thr_lo); free_dev(ctx->pff_flags);
     free_dev(ctx->wt_t); free_dev(ctx->wt_id); free_dev(ctx->wt_pos); free_dev(ctx->wt_time);
     free_dev(ctx->smp_f); free_dev(ctx->smp_i); free_dev(ctx->cs_top);
+    free_dev(ctx->q_Jf); free_dev(ctx->q_flf); free_dev(ctx->q_fundo); free_dev(ctx->q_fml);
     free_dev(ctx->eo_cmin); free_dev(ctx->eo_ftau);
     free_dev(ctx->q_Jb); free_dev(ctx->q_slf); free_dev(ctx->q_smv); free_dev(ctx->q_scur);
     free_dev(ctx->cs_spins); free_dev(ctx->cs_buf); free_dev(ctx->cs_u16);
@@ -1521,7 +1527,7 @@ int32_t rrrmc_colored_sweeps_async(rrrmc_ctx* ctx, double beta, int64_t sweeps, 
 // ---- GraphQuant + rrrMC: exported entry points ---------------------------------------------------------------------
 
 namespace {
-int32_t quant_ctx_create(rrrmc_ctx** out, int64_t Nk, int64_t K, int64_t M, int64_t R, int32_t device, uint32_t replica0, bool sk, bool skn = false);
+int32_t quant_ctx_create(rrrmc_ctx** out, int64_t Nk, int64_t K, int64_t M, int64_t R, int32_t device, uint32_t replica0, bool sk, bool skn = false, bool spf = false);
 }
 int32_t rrrmc_ctx_create_quant(rrrmc_ctx** out, int64_t Nk, int64_t K, int64_t M, int64_t R, int32_t device, uint32_t replica0)
 {
@@ -1531,6 +1537,11 @@ int32_t rrrmc_ctx_create_quant_sk(rrrmc_ctx** out, int64_t Nk, int64_t M, int64_
 {
     return quant_ctx_create(out, Nk, 0, M, R, device, replica0, true);
 }
+int32_t rrrmc_ctx_create_quant_f64(rrrmc_ctx** out, int64_t Nk, int64_t K, int64_t M, int64_t R, int32_t device, uint32_t replica0)
+{
+    return quant_ctx_create(out, Nk, K, M, R, device, replica0, false, false, true);
+}
+
 int32_t rrrmc_ctx_create_quant_skn(rrrmc_ctx** out, int64_t Nk, int64_t M, int64_t R, int32_t device, uint32_t replica0)
 {
     return quant_ctx_create(out, Nk, 0, M, R, device, replica0, false, true);
@@ -1552,10 +1563,10 @@ int32_t rrrmc_ctx_create_multi(rrrmc_ctx** out, int32_t model, int64_t N, int64_
     if (replica0 % 32) return fail(nullptr, RRRMC_ERR_INVALID_ARG, "replica0 must be a multiple of 32 (given %u)", replica0);
     rrrmc_ctx* ctx = new (std::nothrow) rrrmc_ctx();
     if (!ctx) return fail(nullptr, RRRMC_ERR_NOMEM, "out of host memory");
-    const bool quant = model == RRRMC_MODEL_QUANT_RRG || model == RRRMC_MODEL_QUANT_SK || model == RRRMC_MODEL_QUANT_SKN;
+    const bool quant = model == RRRMC_MODEL_QUANT_RRG || model == RRRMC_MODEL_QUANT_SK || model == RRRMC_MODEL_QUANT_SKN || model == RRRMC_MODEL_QUANT_F64;
     ctx->model = quant ? RRRMC_MODEL_QUANT_RRG : model; ctx->K = K; ctx->R = R; ctx->replica0 = replica0; ctx->device = device_ids[0];
     ctx->N = quant ? N * M : N;
-    if (quant) { ctx->qNk = N; ctx->qM = M; ctx->q_sk = model == RRRMC_MODEL_QUANT_SK; ctx->q_skn = model == RRRMC_MODEL_QUANT_SKN; }
+    if (quant) { ctx->qNk = N; ctx->qM = M; ctx->q_sk = model == RRRMC_MODEL_QUANT_SK; ctx->q_skn = model == RRRMC_MODEL_QUANT_SKN; ctx->q_spf = model == RRRMC_MODEL_QUANT_F64; }
     for (int32_t d = 0; d < ndev; ++d) {
         int64_t b0 = 0, b1 = 0;
         shard_bounds(R, ndev, d, &b0, &b1);
@@ -1564,6 +1575,7 @@ int32_t rrrmc_ctx_create_multi(rrrmc_ctx** out, int32_t model, int64_t N, int64_
         const int32_t rc = model == RRRMC_MODEL_QUANT_RRG   ? rrrmc_ctx_create_quant(&c, N, K, M, b1 - b0, device_ids[d], replica0 + (uint32_t)b0)
                            : model == RRRMC_MODEL_QUANT_SK  ? rrrmc_ctx_create_quant_sk(&c, N, M, b1 - b0, device_ids[d], replica0 + (uint32_t)b0)
                            : model == RRRMC_MODEL_QUANT_SKN ? rrrmc_ctx_create_quant_skn(&c, N, M, b1 - b0, device_ids[d], replica0 + (uint32_t)b0)
+                           : model == RRRMC_MODEL_QUANT_F64 ? rrrmc_ctx_create_quant_f64(&c, N, K, M, b1 - b0, device_ids[d], replica0 + (uint32_t)b0)
                                                             : rrrmc_ctx_create(&c, model, N, K, b1 - b0, device_ids[d], replica0 + (uint32_t)b0);
         if (rc) {
             for (rrrmc_ctx* k : ctx->kids) rrrmc_ctx_destroy(k);
@@ -1577,12 +1589,13 @@ int32_t rrrmc_ctx_create_multi(rrrmc_ctx** out, int32_t model, int64_t N, int64_
     return RRRMC_OK;
 }
 namespace {
-int32_t quant_ctx_create(rrrmc_ctx** out, int64_t Nk, int64_t K, int64_t M, int64_t R, int32_t device, uint32_t replica0, bool sk, bool skn)
+int32_t quant_ctx_create(rrrmc_ctx** out, int64_t Nk, int64_t K, int64_t M, int64_t R, int32_t device, uint32_t replica0, bool sk, bool skn, bool spf)
 {
     if (!out) return fail(nullptr, RRRMC_ERR_INVALID_ARG, "out is NULL");
     *out = nullptr;
     if (Nk < 1 || (!sk && !skn && K < 1) || R < 1) return fail(nullptr, RRRMC_ERR_INVALID_ARG, "Nk, K, R must be >= 1");
     if (M <= 2) return fail(nullptr, RRRMC_ERR_INVALID_ARG, "M must be greater than 2, given: %lld", (long long)M);   // QT.jl:47
+    if (spf && K > kContKmax) return fail(nullptr, RRRMC_ERR_UNSUPPORTED, "K=%lld: the Float64 sparse slice kernels cover K <= %d", (long long)K, kContKmax);
     if (Nk * M > (int64_t)1 << 28) return fail(nullptr, RRRMC_ERR_UNSUPPORTED, "N = Nk*M = %lld is beyond the GraphQuant kernels (N <= 2^28)", (long long)(Nk * M));
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
@@ -1592,7 +1605,7 @@ int32_t quant_ctx_create(rrrmc_ctx** out, int64_t Nk, int64_t K, int64_t M, int6
     if (!ctx) return fail(nullptr, RRRMC_ERR_NOMEM, "out of host memory");
     ctx->model = RRRMC_MODEL_QUANT_RRG; ctx->N = Nk * M; ctx->K = K; ctx->R = R; ctx->Rpad = R;
     ctx->qNk = Nk; ctx->qM = M; ctx->qW = 2 * ((Nk * M + 63) / 64);
-    ctx->q_sk = sk; ctx->q_skn = skn; ctx->q_Wk = 2 * ((Nk + 63) / 64);
+    ctx->q_sk = sk; ctx->q_skn = skn; ctx->q_spf = spf; ctx->q_Wk = 2 * ((Nk + 63) / 64);
     ctx->device = device; ctx->replica0 = replica0;
     const int64_t N = ctx->N;
 #define Q_TRY(expr)                                                                                              \
@@ -1615,6 +1628,12 @@ int32_t quant_ctx_create(rrrmc_ctx** out, int64_t Nk, int64_t K, int64_t M, int6
         Q_TRY(hipMalloc(&ctx->q_scur, (size_t)R * (size_t)M));
     } else if (sk) {
         Q_TRY(hipMalloc(&ctx->q_Jb, sizeof(uint32_t) * Nk * ctx->q_Wk));
+    } else if (spf) {
+        Q_TRY(hipMalloc(&ctx->d_A, sizeof(int32_t) * Nk * K));
+        Q_TRY(hipMalloc(&ctx->q_Jf, sizeof(double) * Nk * K));
+        Q_TRY(hipMalloc(&ctx->q_flf, sizeof(double) * (size_t)R * (size_t)M * (size_t)Nk));
+        Q_TRY(hipMalloc(&ctx->q_fundo, sizeof(double) * (size_t)R * (size_t)M * (size_t)(K + 1)));
+        Q_TRY(hipMalloc(&ctx->q_fml, sizeof(int32_t) * (size_t)R * (size_t)M));
     } else {
         Q_TRY(hipMalloc(&ctx->d_A, sizeof(int32_t) * Nk * K));
         Q_TRY(hipMalloc(&ctx->d_J, sizeof(int8_t) * Nk * K));
@@ -1688,7 +1707,7 @@ int32_t quant_mc_async(rrrmc_ctx* ctx, bool standard, double beta, double fourK,
         const char* no_wave = std::getenv("RRRMC_QUANT_NO_WAVE");        // timing experiments / cross-checks of the two builds
         int64_t wave_max_R = 2048;
         if (const char* e = std::getenv("RRRMC_QUANT_WAVE_MAX_R")) wave_max_R = std::atoll(e);
-        const bool wave_ok = !ctx->q_skn && ctx->N <= 65535 && (ctx->q_sk ? ctx->qNk <= 2048 : ctx->K <= 64) && sl.bytes <= (size_t)kLdsLimit && ctx->R <= wave_max_R &&
+        const bool wave_ok = !ctx->q_skn && !ctx->q_spf && ctx->N <= 65535 && (ctx->q_sk ? ctx->qNk <= 2048 : ctx->K <= 64) && sl.bytes <= (size_t)kLdsLimit && ctx->R <= wave_max_R &&
                              !(no_wave && no_wave[0] == '1');
         if (wave_ok) {
             QsExtra X{};
@@ -1716,7 +1735,7 @@ int32_t quant_mc_async(rrrmc_ctx* ctx, bool standard, double beta, double fourK,
         int64_t wave_max_R = 2048;
         if (const char* e = std::getenv("RRRMC_QUANT_WAVE_MAX_R")) wave_max_R = std::atoll(e);
         // GraphRRG / GraphEA slices with K <= 7, or binary GraphSK slices of up to 2048 spins (one word of the slice per lane)
-        const bool wave_ok = !ctx->q_skn && ctx->N <= 65535 && (ctx->q_sk ? ctx->qNk <= 2048 : ctx->K <= 7) && ql.cap >= ctx->N + 4 * kQwMinGap &&
+        const bool wave_ok = !ctx->q_skn && !ctx->q_spf && ctx->N <= 65535 && (ctx->q_sk ? ctx->qNk <= 2048 : ctx->K <= 7) && ql.cap >= ctx->N + 4 * kQwMinGap &&
                              ctx->R <= wave_max_R && !(no_wave && no_wave[0] == '1');
         // one replica per workgroup anyway (few replicas): stage its hot state in LDS if it fits (config 5: 115 KB)
         const size_t lds = rrr_quant_lds_bytes(ctx->N, ctx->qW, ctx->qNk, ctx->K);
@@ -1732,7 +1751,7 @@ int32_t quant_mc_async(rrrmc_ctx* ctx, bool standard, double beta, double fourK,
 #endif
             if (ctx->q_sk) hipLaunchKernelGGL(rrr_quant_wave_kernel<true>, dim3((unsigned)ctx->R), dim3(kRrrThreads), ql.bytes, st, P, X);
             else hipLaunchKernelGGL(rrr_quant_wave_kernel<false>, dim3((unsigned)ctx->R), dim3(kRrrThreads), ql.bytes, st, P, X);
-        } else if (!ctx->q_skn && ctx->N <= 65535 && rrr_tpb(ctx->R) == 1 && lds <= (size_t)kLdsLimit && !(no_lds && no_lds[0] == '1')) {
+        } else if (!ctx->q_skn && !ctx->q_spf && ctx->N <= 65535 && rrr_tpb(ctx->R) == 1 && lds <= (size_t)kLdsLimit && !(no_lds && no_lds[0] == '1')) {
             if (!ctx->q_lds_attr) {
                 HIP_TRY(ctx, raise_lds_attr(reinterpret_cast<const void*>(rrr_quant_kernel<true>), lds));
                 ctx->q_lds_attr = true;
@@ -2219,7 +2238,7 @@ int32_t rrrmc_quant_observables(rrrmc_ctx* ctx, double beta, double Gamma, doubl
     if (rc) return rc;
     if (ctx->model != RRRMC_MODEL_QUANT_RRG) return fail(ctx, RRRMC_ERR_STATE, "rrrmc_quant_observables needs a GraphQuant context");
     if (!(ctx->last_fourK > 0.0)) return fail(ctx, RRRMC_ERR_STATE, "observables of a GraphQuant need fourK: call rrrmc_quant_set_field first");
-    if (ctx->q_skn) return fail(ctx, RRRMC_ERR_UNSUPPORTED, "Qenergy / overlaps are not wired for GraphSKNormal slices");
+    if (ctx->q_skn || ctx->q_spf) return fail(ctx, RRRMC_ERR_UNSUPPORTED, "Qenergy / overlaps are not wired for GraphSKNormal / Float64 sparse slices");
     const int64_t R = ctx->R, M = ctx->qM, Nk = ctx->qNk, N = ctx->N, H = M / 2;
     const size_t lds = sizeof(uint32_t) * (size_t)(M * ((Nk + 31) / 32) + M + H + 1);
     if (lds > (size_t)64 * 1024) return fail(ctx, RRRMC_ERR_UNSUPPORTED, "N = %lld spins per replica do not fit the observables kernel's LDS", (long long)N);
@@ -2425,9 +2444,10 @@ int32_t rrrmc_set_graph_f64(rrrmc_ctx* ctx, const int32_t* A, const double* J)
     RRRMC_MULTI(ctx, false, rrrmc_set_graph_f64(c, A, J));
     smp_drop(ctx);
     if (!ctx) return RRRMC_ERR_INVALID_ARG;
-    if (ctx->model != RRRMC_MODEL_SPARSE_F64) return fail(ctx, RRRMC_ERR_STATE, "rrrmc_set_graph_f64 is for RRRMC_MODEL_SPARSE_F64");
+    const bool qspf = ctx->model == RRRMC_MODEL_QUANT_RRG && ctx->q_spf;          // the slice graph of a GraphQEAT: (A, J) is Nk x K
+    if (ctx->model != RRRMC_MODEL_SPARSE_F64 && !qspf) return fail(ctx, RRRMC_ERR_STATE, "rrrmc_set_graph_f64 is for RRRMC_MODEL_SPARSE_F64 (or a context made by rrrmc_ctx_create_quant_f64)");
     if (!A || !J) return fail(ctx, RRRMC_ERR_INVALID_ARG, "A and J must not be NULL");
-    const int64_t N = ctx->N, K = ctx->K;
+    const int64_t N = qspf ? ctx->qNk : ctx->N, K = ctx->K;
     for (int64_t q = 0; q < N * K; ++q) {
         if (A[q] < 0 || A[q] >= N) return fail(ctx, RRRMC_ERR_INVALID_ARG, "A[%lld] = %d out of range 0..%lld", (long long)q, A[q], (long long)(N - 1));
         if (!std::isfinite(J[q])) return fail(ctx, RRRMC_ERR_INVALID_ARG, "J[%lld] is not finite", (long long)q);
@@ -2447,6 +2467,12 @@ int32_t rrrmc_set_graph_f64(rrrmc_ctx* ctx, const int32_t* A, const double* J)
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     HIP_TRY(ctx, hipMemcpy(ctx->d_A, A, sizeof(int32_t) * N * K, hipMemcpyHostToDevice));
+    if (qspf) {
+        HIP_TRY(ctx, hipMemcpy(ctx->q_Jf, J, sizeof(double) * N * K, hipMemcpyHostToDevice));
+        ctx->q_cache_valid = false;
+        ctx->graph_set = true;
+        return RRRMC_OK;
+    }
     HIP_TRY(ctx, hipMemcpy(ctx->pf_J, J, sizeof(double) * N * K, hipMemcpyHostToDevice));
     ctx->h_A.assign(A, A + N * K);
     ctx->h_Jf.assign(J, J + N * K);

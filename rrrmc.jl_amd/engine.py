@@ -9,7 +9,7 @@ from .graphs import DEFAULT_SEED, Config, GraphEA, nchunks
 MODEL_SPARSE_PM1 = 1
 MODEL_SK_NORMAL = 2
 MODEL_QUANT_RRG = 3
-MODEL_QUANT_SK, MODEL_QUANT_SKN = 8, 9          # selectors of rrrmc_ctx_create_multi (dense-slice GraphQuant)
+MODEL_QUANT_SK, MODEL_QUANT_SKN, MODEL_QUANT_F64 = 8, 9, 10          # selectors of rrrmc_ctx_create_multi (GraphQuant over other slice families)
 MODEL_SK_BINARY = 4
 MODEL_SPARSE_F64 = 5
 MODEL_SPARSE_DISCRETIZED = 6
@@ -30,13 +30,16 @@ class Engine:
             ids = np.asarray(list(devices), np.int32)
             quant = X.model_kind == MODEL_QUANT_RRG
             # a GraphQuant over dense slices is made per device by rrrmc_ctx_create_quant_skn / _sk: the selectors 9 / 8 of the header
-            kind = X.model_kind if not quant else MODEL_QUANT_SKN if getattr(X, "skn_slices", False) else MODEL_QUANT_SK if X.sk_slices else X.model_kind
+            kind = (X.model_kind if not quant else MODEL_QUANT_SKN if getattr(X, "skn_slices", False) else MODEL_QUANT_SK if X.sk_slices
+                    else MODEL_QUANT_F64 if getattr(X, "f64_slices", False) else X.model_kind)
             check(lib().rrrmc_ctx_create_multi(C.byref(self._ctx), kind, X.Nk if quant else X.N, X.K, X.M if quant else 0, self.R,
                                                ids, len(ids), replica0))
         elif X.model_kind == MODEL_QUANT_RRG and getattr(X, "skn_slices", False):
             check(lib().rrrmc_ctx_create_quant_skn(C.byref(self._ctx), X.Nk, X.M, self.R, device, replica0))
         elif X.model_kind == MODEL_QUANT_RRG and X.sk_slices:
             check(lib().rrrmc_ctx_create_quant_sk(C.byref(self._ctx), X.Nk, X.M, self.R, device, replica0))
+        elif X.model_kind == MODEL_QUANT_RRG and getattr(X, "f64_slices", False):
+            check(lib().rrrmc_ctx_create_quant_f64(C.byref(self._ctx), X.Nk, X.K, X.M, self.R, device, replica0))
         elif X.model_kind == MODEL_QUANT_RRG:
             check(lib().rrrmc_ctx_create_quant(C.byref(self._ctx), X.Nk, X.K, X.M, self.R, device, replica0))
         else:
@@ -47,6 +50,8 @@ class Engine:
                     check(lib().rrrmc_set_couplings_dense(self._ctx, X.J.reshape(-1)), self._ctx)
                 elif X.sk_slices:
                     check(lib().rrrmc_set_couplings_bits(self._ctx, X.J.reshape(-1)), self._ctx)
+                elif getattr(X, "f64_slices", False):
+                    check(lib().rrrmc_set_graph_f64(self._ctx, X.A, X.J.reshape(-1)), self._ctx)
                 else:
                     check(lib().rrrmc_quant_slice_form(self._ctx, 1 if isinstance(X.X1, GraphEA) else 0), self._ctx)
                     check(lib().rrrmc_set_graph(self._ctx, X.A, X.J), self._ctx)

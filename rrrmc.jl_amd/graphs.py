@@ -428,6 +428,7 @@ class GraphQuant:
         self.X1, self.M, self.Gamma, self.beta = X1, int(M), float(Gamma), float(beta)
         self.sk_slices = isinstance(X1, GraphSK)
         self.skn_slices = isinstance(X1, GraphSKNormal)                    # GraphQSKNormalT (QAliases.jl:45-46; test/runtests.jl:80)
+        self.f64_slices = isinstance(X1, _SparseF64Graph)                  # GraphQEAT = GraphQuant{fourK,GraphEANormal{twoD}} (QAliases.jl:50-83)
         dense = self.sk_slices or self.skn_slices
         self.Nk, self.K = X1.N, (0 if dense else X1.K)
         self.N = self.Nk * self.M
@@ -439,6 +440,47 @@ class GraphQuant:
 def GraphQSKNormalT(Nk, M, Gamma, beta, seed=DEFAULT_SEED):
     """``GraphQSKNormalT(Nk, M, Γ, β)`` = ``GraphQuant(Nk, M, Γ, β, GraphSKNormal, SK.gen_J_gauss(Nk))`` (src/QAliases.jl:45-46)."""
     return GraphQuant(GraphSKNormal(Nk, seed=seed), M, Gamma, beta)
+
+
+def _gen_J_uniform(A, seed):
+    """``EA.gen_J(Float64, N, A) do 4 * rand() - 2 end`` (src/QAliases.jl:60-62 over src/graphs/EA.jl:45-71): one draw per bond x < y in (x, k) order,
+    mirrored into the first free slot of row y (so that two bonds to the same neighbour — L = 2 — get two draws).  The draws come from a
+    Philox generator keyed by ``seed`` (Julia's stream is not reproducible outside Julia: SURVEY.md appendix B)."""
+    N, K = A.shape
+    rng = np.random.Generator(np.random.Philox(key=int(seed) & (2 ** 64 - 1)))
+    J = np.full((N, K), np.nan)
+    for x in range(N):
+        for k in range(K):
+            y = int(A[x, k])
+            if x < y:
+                Jxy = 4.0 * rng.random() - 2.0
+                assert np.isnan(J[x, k])
+                J[x, k] = Jxy
+                free = np.nonzero(np.isnan(J[y]))[0]
+                J[y, free[0]] = Jxy
+    assert not np.isnan(J).any()
+    return J
+
+
+def GraphQEAT(L, D_or_M, M=None, Gamma=None, beta=None, seed=DEFAULT_SEED):
+    """The reference's three constructors (src/QAliases.jl:50-83), all ``GraphQuant{fourK,GraphEANormal{2D}}`` over ONE shared ``(A, J)``:
+
+    * ``GraphQEAT(L, D, M, Γ, β)`` — couplings uniform in [-2, 2) (``4 rand() - 2``, :60-62);
+    * ``GraphQEAT(fname, M, Γ, β)`` — from the text format of ``gen_AJ`` (EA.jl:73-118);
+    * ``GraphQEAT(X::GraphEANormal, M, Γ, β)``.
+    """
+    if isinstance(L, (str, GraphEANormal)):
+        X1 = GraphEANormal(L) if isinstance(L, str) else L
+        return GraphQuant(X1, D_or_M, M, Gamma)                 # (arguments shifted by one: fname | X, M, Γ, β)
+    D = D_or_M
+    if D < 1:
+        raise ValueError("D must be ≥ 0, given: %d" % D)         # QAliases.jl:58 (the reference's message)
+    N = int(L) ** int(D)
+    A = np.zeros((N, 2 * int(D)), np.int32)
+    check(lib().rrrmc_gen_ea(L, D, A))
+    X1 = GraphEANormal.from_AJ(A, _gen_J_uniform(A, seed))
+    X1.L, X1.D = int(L), int(D)
+    return GraphQuant(X1, M, Gamma, beta)
 
 
 def GraphQSKT(Nk, M, Gamma, beta, seed=DEFAULT_SEED):

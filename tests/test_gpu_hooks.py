@@ -300,10 +300,11 @@ def other_graphs(pkg):
         "sk-binary": lambda: pkg.GraphSK(20, seed=SEED),                                           # integer fields, delta_energy = lfields / sqrt(N); EO ties
         "qskt": lambda: pkg.GraphQSKT(12, 4, 0.5, 2.0, seed=SEED),                                 # GraphQuant over binary GraphSK slices
         "qsknormal": lambda: pkg.GraphQSKNormalT(10, 4, 0.5, 2.0, seed=SEED),                      # GraphQuant over GraphSKNormal slices
+        "qeat": lambda: pkg.GraphQEAT(3, 2, 4, 0.5, 2.0, seed=SEED),                               # GraphQuant over GraphEANormal slices (their Float64 caches and undo records carry on)
     }
 
 
-@pytest.mark.parametrize("name", ["rrg-levels", "ea-levels", "ea-normal-l2", "rrg-discretized", "ea-discretized", "sk-binary", "qskt", "qsknormal"])
+@pytest.mark.parametrize("name", ["rrg-levels", "ea-levels", "ea-normal-l2", "rrg-discretized", "ea-discretized", "sk-binary", "qskt", "qsknormal", "qeat"])
 @pytest.mark.parametrize("smp", ["rrr", "bkl", "wtm", "eo"])
 def test_other_graph_families_hooked(pkg, oracle, name, smp):
     X = other_graphs(pkg)[name]()
