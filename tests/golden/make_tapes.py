@@ -106,6 +106,66 @@ def write_quant(path, seed, Nk=16, K=3, M=4, beta=2.0, Gamma=0.5, iters=3000, st
     return True
 
 
+def gen_J_uniform(A, seed):
+    """EA.gen_J(Float64, N, A) do 4 * rand() - 2 end (src/QAliases.jl:60-62 over src/graphs/EA.jl:45-71): one draw per bond x < y in (x, k) order,
+    mirrored into the first free slot of row y.  The draws are numpy's Philox stream keyed by the seed (the tape stores the couplings)."""
+    N, K = A.shape
+    rng = np.random.Generator(np.random.Philox(key=int(seed)))
+    J = np.full((N, K), np.nan)
+    for x in range(N):
+        for k in range(K):
+            y = int(A[x, k])
+            if x < y:
+                J[x, k] = 4.0 * rng.random() - 2.0
+                J[y, np.nonzero(np.isnan(J[y]))[0][0]] = J[x, k]
+    return J
+
+
+def write_quant_f64(path, seed, L=4, D=2, M=8, beta=2.0, Gamma=0.5, iters=3000, step=100, staged_thr=0.5, staged_thr_fact=5.0, replica=0):
+    """rrrMC(X::DoubleGraph) on GraphQEAT(L, D, M, Γ, β) = GraphQuant{fourK,GraphEANormal{2D}} (src/QAliases.jl:50-83): M slices of ONE lattice
+    with Float64 couplings, every slice with its own LocalFields{Float64} and the exact undo path of update_cache! (EA.jl:613-653) — the
+    rejected direct moves of the run go through it.  The tape must hold staged and direct iterations, and undo swaps."""
+    A = O.gen_ea(L, D)
+    Nk, K = A.shape
+    J = gen_J_uniform(A, seed)
+    N = Nk * M
+    fourK = O.quant_fourK(beta, Gamma, M)
+    C0 = O.init_config(seed, replica, N)
+    Es, ch, acc, staged, pos, sizes = O.rrr_mc_quant_spf(A, J, M, fourK, beta, iters, step, seed, C0, replica=replica, staged_thr=staged_thr,
+                                                         staged_thr_fact=staged_thr_fact, want_cache=True)
+    if not (0 < staged < iters and acc < iters):          # both branches, and rejected (undone) moves
+        return False
+    key = np.array([seed & 0xFFFFFFFF, seed >> 32], np.uint32)
+    ucls, umem, uacc = [], [], []
+    for g in range(1, iters + 1):          # RRR stream (DESIGN.md §2): sub 0 = (class uniform, member word), sub 1 = acceptance uniform
+        w0 = O.philox([g & 0xFFFFFFFF, g >> 32, replica, 8], key)
+        w1 = O.philox([g & 0xFFFFFFFF, g >> 32, replica, 8 | (1 << 8)], key)
+        ucls.append(u53((int(w0[0]) << 32) | int(w0[1])))
+        umem.append((int(w0[2]) << 32) | int(w0[3]))
+        uacc.append(u53((int(w1[0]) << 32) | int(w1[1])))
+    body = ["# RRRMC tape v1 — rrrMC(X::GraphQEAT = GraphQuant{fourK,GraphEANormal{%d}}, beta, iters; step, C0, staged_thr, staged_thr_fact) on the" % K,
+            "# L = %d, D = %d lattice (src/QAliases.jl:50-83): all M slices share (A, J::Float64); draws as in the other rrrMC_quant tapes." % (L, D),
+            "# Written by tests/golden/make_tapes.py",
+            "@kind rrrMC_quant", "@slices f64", "@L %d" % L, "@D %d" % D, "@Nk %d" % Nk, "@K %d" % K, "@M %d" % M, "@beta %r" % beta, "@Gamma %r" % Gamma,
+            "@fourK %r" % fourK, "@iters %d" % iters, "@step %d" % step, "@staged_thr %r" % staged_thr, "@staged_thr_fact %r" % staged_thr_fact,
+            "@seed %d" % seed, "@replica %d" % replica,
+            fmt_array("A", ("%d" % (v + 1) for v in A.reshape(-1))), fmt_array("J", (repr(float(v)) for v in J.reshape(-1))),
+            fmt_array("C0", ("%016x" % int(c) for c in C0)),
+            fmt_array("u_class", (repr(u) for u in ucls)), fmt_array("u_member", ("%d" % u for u in umem)),
+            fmt_array("u_accept", (repr(u) for u in uacc)),
+            fmt_array("expected_Es", (repr(float(e)) for e in Es)), fmt_array("expected_chunks", ("%016x" % int(c) for c in ch)),
+            "@expected_accepted %d" % acc, "@expected_staged_its %d" % staged,
+            fmt_array("expected_sizes", ("%d" % int(v) for v in sizes)), fmt_array("expected_pos", ("%d" % (int(v) + 1) for v in pos))]
+
+    def check(t):
+        got = TR.replay_rrr_quant(t)
+        ok = (got["chunks"] == [int(c) for c in ch] and got["accepted"] == acc and got["staged_its"] == staged
+              and got["sizes"] == [int(v) for v in sizes] and got["pos"] == [int(v) + 1 for v in pos]
+              and got["Es"] == [float(e) for e in Es] and got["min_margin"] >= 1e-9)
+        return ok, "%d iterations, accepted %d, staged %d, closest decision margin %.2e" % (iters, acc, staged, got["min_margin"])
+    return _finish(path, body, check)
+
+
 def _finish(path, body, check):
     tmp = path + ".tmp"
     open(tmp, "w").write("\n".join(body) + "\n")
@@ -414,3 +474,4 @@ if __name__ == "__main__":
     tries(lambda sd: write_eo_rrg(os.path.join(HERE, "tape_eo_rrg_n64.txt"), sd), "an extremal_opt(GraphRRG(64,3)) tape with a safe margin")
     tries(lambda sd: write_standard_rrgn(os.path.join(HERE, "tape_rrgn_n16.txt"), sd), "a GraphRRGNormal(16,3) tape with undo swaps and a safe margin")
     tries(lambda sd: write_rrr_rrgn(os.path.join(HERE, "tape_rrr_rrgn_n64.txt"), sd), "an rrrMC(GraphRRGNormal(64,3)) tape with both branches and a safe margin")
+    tries(lambda sd: write_quant_f64(os.path.join(HERE, "tape_quant_qeat_l4_m8.txt"), sd), "an rrrMC(GraphQEAT(4, 2, 8)) tape with both branches and a safe margin")

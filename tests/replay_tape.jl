@@ -1,7 +1,7 @@
 # Replay an RNG-free tape (tests/golden/tape_*.txt) through the reference's OWN graph code and compare with the results the tape
 # holds (written by the build's C oracle; the HIP library is checked against the same tapes in tests/test_tapes.py).
 #
-#   julia --project=<an environment that has RRRMC.jl> tests/replay_tape.jl                     (all thirteen tapes)
+#   julia --project=<an environment that has RRRMC.jl> tests/replay_tape.jl                     (all fourteen tapes)
 #   julia ...                                          tests/replay_tape.jl tests/golden/tape_skn_n24.txt ...
 #
 # Tapes: standardMC on GraphRRG(128, 3); rrrMC on a GraphQuant (staged and direct branch); round 3: standardMC on GraphEA(2, 3) (doubled
@@ -108,8 +108,15 @@ function replay_rrrMC_quant(t)
     β, Γ = parse(Float64, t["beta"]), parse(Float64, t["Gamma"])
     iters, step = parse(Int, t["iters"]), parse(Int, t["step"])
     staged_thr, staged_thr_fact = parse(Float64, t["staged_thr"]), parse(Float64, t["staged_thr_fact"])
-    A, J = tuples(ints(t["A"]), K), tuples(ints(t["J"]), K)
-    X = RRRMC.QT.GraphQuant(Nk, M, Γ, β, RRRMC.RRG.GraphRRG{Int,(-1, 1),K}, A, J)     # src/graphs/QT.jl:161-168: M slice graphs over (A, J)
+    A = tuples(ints(t["A"]), K)
+    X = if get(t, "slices", "int") == "f64"
+        # GraphQEAT = GraphQuant{fourK,GraphEANormal{twoD}} as its constructors build it (src/QAliases.jl:64,72,82): M slices GraphEANormal{K}(L, A, J)
+        Jf = parse.(Float64, t["J"])
+        Jt = [ntuple(k -> Jf[(x - 1) * K + k], K) for x = 1:Nk]
+        RRRMC.QT.GraphQuant(Nk, M, Γ, β, RRRMC.EA.GraphEANormal{K}, parse(Int, t["L"]), A, Jt)
+    else
+        RRRMC.QT.GraphQuant(Nk, M, Γ, β, RRRMC.RRG.GraphRRG{Int,(-1, 1),K}, A, tuples(ints(t["J"]), K))     # src/graphs/QT.jl:161-168: M slice graphs over (A, J)
+    end
     N = getN(X)
     C = config_from(t["C0"], N)
     ucls, uacc = parse.(Float64, t["u_class"]), parse.(Float64, t["u_accept"])
@@ -489,4 +496,5 @@ end
 
 main(isempty(ARGS) ? [joinpath(@__DIR__, "golden", f) for f in
                       ("tape_rrg_n128.txt", "tape_quant_nk16_m4.txt", "tape_quant_direct.txt", "tape_ea_l2_d3.txt", "tape_skn_n24.txt",
-                       "tape_sk_n10.txt", "tape_rrr_skn_n10.txt", "tape_rrr_rrg_n64.txt", "tape_bkl_rrg_n64.txt", "tape_wtm_rrg_n64.txt", "tape_eo_rrg_n64.txt", "tape_rrgn_n16.txt", "tape_rrr_rrgn_n64.txt")] : ARGS)
+                       "tape_sk_n10.txt", "tape_rrr_skn_n10.txt", "tape_rrr_rrg_n64.txt", "tape_bkl_rrg_n64.txt", "tape_wtm_rrg_n64.txt", "tape_eo_rrg_n64.txt", "tape_rrgn_n16.txt", "tape_rrr_rrgn_n64.txt",
+                       "tape_quant_qeat_l4_m8.txt")] : ARGS)

@@ -145,7 +145,12 @@ def replay_rrr_quant(tape, exp=math.exp):
     fourK = round(2 / beta * math.log(1 / math.tanh(beta * Gamma / M)), 8)      # QT.jl:165
     assert fourK == float(tape["fourK"])
     A = [[int(v) for v in tape["A"][x * K:(x + 1) * K]] for x in range(Nk)]
-    J = [[int(v) for v in tape["J"][x * K:(x + 1) * K]] for x in range(Nk)]
+    # slices: GraphRRG{Int,(-1,1),K} (the default), or — "@slices f64" — sparse Float64 graphs on the same table: GraphQEAT =
+    # GraphQuant{fourK,GraphEANormal{twoD}} (src/QAliases.jl:50-83).  Without repeated neighbours in a row (L > 2) GraphEANormal's energy /
+    # update_cache! (EA.jl:584-653) are the operations of GraphRRGNormal's (RRG.jl:546-617), restated above as rrgn_energy / rrgn_update_cache.
+    f64 = tape.get("slices", "int") == "f64"
+    J = [[(float(v) if f64 else int(v)) for v in tape["J"][x * K:(x + 1) * K]] for x in range(Nk)]
+    assert not f64 or all(len(set(row)) == K for row in A)
     s = bits_of_chunks([int(c, 16) for c in tape["C0"]], N)
     u_cls = [float(v) for v in tape["u_class"]]
     u_mem = [int(v) for v in tape["u_member"]]
@@ -162,9 +167,13 @@ def replay_rrr_quant(tape, exp=math.exp):
     slices = []
     for k in range(M):
         sl = s[k * Nk:(k + 1) * Nk]
-        Ek, lf = rrg_energy(A, J, sl)
+        if f64:
+            Ek, lf, lfl, ml = rrgn_energy(A, J, sl)
+            slices.append([sl, lf, lfl, ml])
+        else:
+            Ek, lf = rrg_energy(A, J, sl)
+            slices.append([sl, lf])
         E += Ek / M
-        slices.append([sl, lf])
     # DeltaECache{Float64,2}(X0 = GraphQT, C, (0.0, fourK), beta) (DeltaE.jl:74-103)
     dElist, L = (0.0, fourK), 2
     sets, pos = [ArraySet(N) for _ in range(2 * L)], [0] * (N + 1)
@@ -191,6 +200,10 @@ def replay_rrr_quant(tape, exp=math.exp):
     def flip_all(move):                                        # spinflip!(X::GraphQuant, C, move): bit + update_cache! (QT.jl:172-183)
         s[move - 1] ^= 1
         k, i = (move - 1) // Nk, (move - 1) % Nk + 1
+        if f64:                                                # C1[k] flipped, then update_cache!(X1[k], C1[k], i) with its undo path
+            slices[k][0][i - 1] ^= 1
+            slices[k][3] = rrgn_update_cache(A, J, slices[k][0], slices[k][1], slices[k][2], slices[k][3], i)
+            return
         rrg_spinflip(A, J, slices[k][0], slices[k][1], i)
 
     def residual(move):                                        # delta_energy_residual (QT.jl:270-281)

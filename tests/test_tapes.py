@@ -480,3 +480,57 @@ def test_hip_library_reproduces_the_rrr_rrg_normal_tape(pkg, monkeypatch, env):
         assert [float(e) for e in Es[0]] == _floats(t["expected_Es"])
         assert int(acc[0]) == int(t["expected_accepted"]) and int(staged[0]) == int(t["expected_staged_its"])
         assert [int(c) for c in eng.get_config().s[0]] == [int(c, 16) for c in t["expected_chunks"]]
+
+
+# ---- round 6 tape: rrrMC(X::DoubleGraph) on GraphQEAT(4, 2, 8) = GraphQuant over GraphEANormal slices (src/QAliases.jl:50-83) ----------------------
+QEAT = os.path.join(GOLD, "tape_quant_qeat_l4_m8.txt")
+
+
+def _qeat_graph(t):
+    Nk, K = int(t["Nk"]), int(t["K"])
+    A = np.array([int(v) - 1 for v in t["A"]], np.int32).reshape(Nk, K)
+    J = np.array([float(v) for v in t["J"]], np.float64).reshape(Nk, K)
+    return A, J
+
+
+def test_python_replay_reproduces_the_qeat_tape():
+    t = TR.read_tape(QEAT)
+    got = TR.replay_rrr_quant(t)
+    assert got["chunks"] == [int(c, 16) for c in t["expected_chunks"]]
+    assert got["accepted"] == int(t["expected_accepted"]) and got["staged_its"] == int(t["expected_staged_its"])
+    assert got["sizes"] == [int(v) for v in t["expected_sizes"]] and got["pos"] == [int(v) for v in t["expected_pos"]]
+    assert got["Es"] == [float(v) for v in t["expected_Es"]]          # Float64 slice caches: the same sequence of IEEE operations, bit for bit
+    assert got["min_margin"] > 1e-9 and 0 < got["staged_its"] < int(t["iters"]) and got["accepted"] < int(t["iters"])
+
+
+def test_oracle_reproduces_the_qeat_tape(oracle):
+    t = TR.read_tape(QEAT)
+    A, J = _qeat_graph(t)
+    assert (A == oracle.gen_ea(int(t["L"]), int(t["D"]))).all()
+    C0 = np.array([int(c, 16) for c in t["C0"]], np.uint64)
+    ref = oracle.rrr_mc_quant_spf(A, J, int(t["M"]), float(t["fourK"]), float(t["beta"]), int(t["iters"]), int(t["step"]), int(t["seed"]), C0,
+                                  staged_thr=float(t["staged_thr"]), staged_thr_fact=float(t["staged_thr_fact"]), want_cache=True)
+    assert [float(e) for e in ref[0]] == [float(v) for v in t["expected_Es"]] and [int(c) for c in ref[1]] == [int(c, 16) for c in t["expected_chunks"]]
+    assert ref[2] == int(t["expected_accepted"]) and ref[3] == int(t["expected_staged_its"])
+    assert [int(v) + 1 for v in ref[4]] == [int(v) for v in t["expected_pos"]] and [int(v) for v in ref[5]] == [int(v) for v in t["expected_sizes"]]
+
+
+@pytest.mark.gpu
+def test_hip_library_reproduces_the_qeat_tape(pkg):
+    t = TR.read_tape(QEAT)
+    A, J = _qeat_graph(t)
+    M, seed = int(t["M"]), int(t["seed"])
+    X = pkg.GraphQEAT(pkg.GraphEANormal.from_AJ(A, J), M, float(t["Gamma"]), float(t["beta"]))
+    assert X.fourK == float(t["fourK"]) and X.f64_slices
+    with pkg.Engine(X, 3) as eng:
+        eng.seed(seed)
+        eng.init_spins_random()
+        assert [int(c) for c in eng.get_config().s[0]] == [int(c, 16) for c in t["C0"]]
+        Es, acc, staged = eng.rrr_mc(float(t["beta"]), int(t["iters"]), int(t["step"]), staged_thr=float(t["staged_thr"]),
+                                     staged_thr_fact=float(t["staged_thr_fact"]))
+        C1 = eng.get_config()
+        pos, sizes = eng.rrr_cache()
+    assert [float(e) for e in Es[0]] == [float(v) for v in t["expected_Es"]]
+    assert int(acc[0]) == int(t["expected_accepted"]) and int(staged[0]) == int(t["expected_staged_its"])
+    assert [int(c) for c in C1.s[0]] == [int(c, 16) for c in t["expected_chunks"]]
+    assert [int(v) + 1 for v in pos[0]] == [int(v) for v in t["expected_pos"]] and [int(v) for v in sizes[0]] == [int(v) for v in t["expected_sizes"]]
