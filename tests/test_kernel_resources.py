@@ -120,8 +120,7 @@ def test_sk_hblock_kernel_builds_have_no_scratch(tmp_path):
     multiply-adds with a DPP operand, sixteen attempts per loop iteration.  The builds of N <= 2048 (up to four sites per thread; the sizes
     the reference's experiments and BASELINE's config 3 use) must be free of private memory — a spilled field would turn every one of those
     multiply-adds into a load, the instruction and a store.  The builds of 2048 < N <= 4096 (six and eight sites per thread: 48 / 64 fields of two registers each beside the
-    row registers) are allowed to spill: they exist so that those sizes run at all (correctness first), and how much they
-    spill is printed, not asserted."""
+    row registers) are allowed to spill within a stated budget: they exist so that those sizes run at all (correctness first)."""
     src = tmp_path / "skh.hip"
     src.write_text(TU_SKH)
     asm = tmp_path / "skh.s"
@@ -134,4 +133,9 @@ def test_sk_hblock_kernel_builds_have_no_scratch(tmp_path):
         print(spt, nth, rb, m)
         if spt <= 4:
             assert m["private_segment_fixed_size"] == 0 and m.get("vgpr_spill_count", 0) == 0, (n, m)
+        else:
+            # the spill BUDGET of the two large builds, as an assertion: 65 / 159 spilled registers, 264 / 640 bytes of private
+            # memory today (fields that do not fit 256 registers beside the row registers); a compiler or source change that spills more fails here
+            budget = {6: (72, 288), 8: (168, 672)}[spt]
+            assert m.get("vgpr_spill_count", 0) <= budget[0] and m["private_segment_fixed_size"] <= budget[1], (n, m, budget)
         assert m["vgpr_count"] <= 256, (n, m)           # two wavefronts per SIMD in every build (512 threads, or two workgroups of 256)
