@@ -1531,24 +1531,106 @@ struct SparseChain {
         v1[t1] = (IDX)j; spos[j] = (IDX)t1; tadd(k1, 1);
         cls[j] = (uint8_t)k1;
     }
-    // apply_move!: DeltaE.jl:232-295; returns c = z / z'
+    // apply_move!: DeltaE.jl:232-295; returns c = z / z'.
+    // One thread walks the chain, so what an iteration costs is its DEPENDENT memory round trips (profiles/r06/f8_floor.md: 20 900 cycles per
+    // iteration of a 16-replica wavefront at N = 10^4, 6 600 of them instruction issue).  Written as the reference's loop — neighbour after neighbour: class, new class,
+    // delete!, push! — every site pays its own chain of three (class byte and table row; the neighbours' bits; position and the set's last member),
+    // because the stores of one site's set move keep the compiler from starting the next site's loads.  Here the K + 1 sites are gathered FIRST
+    // (fixed slots, fully unrolled: registers): classes, new classes, positions and — speculatively — the last member of every set that loses a
+    // site, all of them independent loads; the set moves then run in the reference's order on values that are already there.  A set move changes
+    // what a LATER site of the same iteration gathered in two ways only: the last member of a set another move has touched (then it is read again:
+    // `touched`), and the position of a site that was moved into a freed slot (patched, as the wave builds do).  Same stores, same order.
+    template <int NB, int KM = NB>
     __device__ double apply_move(int move)
     {
         sflip(move);
+        if constexpr (LDS || KM > 6) {
+            // the LDS build has no memory latency to hide, and eight (or sixteen) slots of as many row entries do not fit the registers: the
+            // reference's loop as it stands
+            double zp = z;
+            for (int q = 0; q <= cfg.K; ++q) {
+                if (q < cfg.K && !is_nb(move, q)) continue;
+                const int j = q < cfg.K ? nbr(move, q) : move;
+                const int k0 = cls[j];
+                const int k1 = q < cfg.K ? klass(j) : (k0 >= cfg.L ? k0 - cfg.L : k0 + cfg.L);
+                if (q < cfg.K && k0 == k1) continue;
+                const double f0 = f(k0), f1 = f(k1);
+                Tadd(k0, -f0); Tadd(k1, f1); zp += f1 - f0;
+                set_move(j, k0, k1);
+            }
+            const double cc = z / zp;
+            z = zp;
+            return cc;
+        } else {
+        // K <= KM: slot q < KM = neighbour q, slot KM = the moved spin
+        int sj[KM + 1], s0[KM + 1], s1[KM + 1], sp_[KM + 1], sl[KM + 1];
+        bool live[KM + 1];
+        {
+            // The gather, stage by stage, every load of a stage issued without a branch around it (a slot that holds no neighbour reads the
+            // moved spin's entries instead: harmless, and the stage stays one basic block, so its loads go out together):
+            //   1. the moved spin's row of the table;  2. per neighbour its class byte, its position, its word of spins, its own row;
+            //   3. the words of its neighbours' spins -> delta_energy, the new class;  4. the last member of every set that may lose a site.
+            const int K = cfg.K;
+            int y[KM], cj[KM];
+#pragma unroll
+            for (int q = 0; q < KM; ++q) { const size_t e = (size_t)move * K + (q < K ? q : 0); y[q] = cfg.A[e]; cj[q] = (int)cfg.J[e]; }
+            bool val[KM];
+#pragma unroll
+            for (int q = 0; q < KM; ++q) val[q] = q < K && !(q > 0 && y[q] == y[q - 1]) && !(cfg.skip_zero && cj[q] == 0);      // is_nb
+            int yy[KM][KM], cc[KM][KM];
+            uint32_t wown[KM];
+#pragma unroll
+            for (int q = 0; q < KM; ++q) {
+                const int j = val[q] ? y[q] : move;
+                sj[q] = j;
+                s0[q] = cls[j]; sp_[q] = (int)spos[j]; wown[q] = sp[j >> 5];
+#pragma unroll
+                for (int k = 0; k < KM; ++k) { const size_t e = (size_t)j * K + (k < K ? k : 0); yy[q][k] = cfg.A[e]; cc[q][k] = k < K ? (int)cfg.J[e] : 0; }
+            }
+            s0[KM] = cls[move]; sp_[KM] = (int)spos[move]; sj[KM] = move;
+            uint32_t wnb[KM][KM];
+#pragma unroll
+            for (int q = 0; q < KM; ++q)
+#pragma unroll
+                for (int k = 0; k < KM; ++k) wnb[q][k] = sp[yy[q][k] >> 5];
+#pragma unroll
+            for (int q = 0; q < KM; ++q) {
+                const int sjb = (int)((wown[q] >> (sj[q] & 31)) & 1u);
+                int acc = 0;
+#pragma unroll
+                for (int k = 0; k < KM; ++k) { const int sy = (int)((wnb[q][k] >> (yy[q][k] & 31)) & 1u); acc += (sjb == sy) ? cc[q][k] : -cc[q][k]; }
+                const int d = 2 * acc, a = find(d < 0 ? -d : d);
+                s1[q] = a + cfg.L * ((d > 0 || (d == 0 && sjb == 1)) ? 1 : 0);          // klass(j): DeltaE.jl:80-86
+                live[q] = val[q] && s0[q] != s1[q];
+            }
+            live[KM] = true; s1[KM] = s0[KM] >= cfg.L ? s0[KM] - cfg.L : s0[KM] + cfg.L;
+#pragma unroll
+            for (int q = 0; q <= KM; ++q) { const int tq = tg(s0[q]); sl[q] = (int)sv[(size_t)s0[q] * cfg.N + (tq > 0 ? tq - 1 : 0)]; }
+        }
         double zp = z;
-        for (int q = 0; q <= cfg.K; ++q) {
-            if (q < cfg.K && !is_nb(move, q)) continue;
-            const int j = q < cfg.K ? nbr(move, q) : move;
-            const int k0 = cls[j];
-            const int k1 = q < cfg.K ? klass(j) : (k0 >= cfg.L ? k0 - cfg.L : k0 + cfg.L);
-            if (q < cfg.K && k0 == k1) continue;
+        unsigned touched = 0u;
+#pragma unroll
+        for (int q = 0; q <= KM; ++q) {
+            if (!live[q]) continue;
+            const int j = sj[q], k0 = s0[q], k1 = s1[q], p = sp_[q];
             const double f0 = f(k0), f1 = f(k1);
             Tadd(k0, -f0); Tadd(k1, f1); zp += f1 - f0;
-            set_move(j, k0, k1);
+            IDX* v0 = sv + (size_t)k0 * cfg.N;
+            IDX* v1 = sv + (size_t)k1 * cfg.N;
+            const int last = ((touched >> k0) & 1u) ? (int)v0[tg(k0) - 1] : sl[q];      // ArraySet delete!(k0, j) + push!(k1, j), ArraySets.jl:56-76
+            v0[p] = (IDX)last; spos[last] = (IDX)p; tadd(k0, -1);
+            const int t1 = tg(k1);
+            v1[t1] = (IDX)j; spos[j] = (IDX)t1; tadd(k1, 1);
+            cls[j] = (uint8_t)k1;
+            touched |= (1u << k0) | (1u << k1);
+#pragma unroll
+            for (int q2 = 0; q2 <= KM; ++q2)
+                if (q2 > q && live[q2] && sj[q2] == last) sp_[q2] = p;
         }
-        const double cc = z / zp;
+        const double cc2 = z / zp;
         z = zp;
-        return cc;
+        return cc2;
+        }
     }
 };
 
@@ -1633,6 +1715,17 @@ __global__ __launch_bounds__(kRrrThreads) void rrr_sparse_kernel(RrrSparseParams
     }
 
     const uint32_t rep = P.replica0 + (uint32_t)r;
+    // apply_move! with its gather sized for the graph's degree (kernel-uniform).  always_inline: called out of line, the chain's state would
+    // live in scratch (measured: 3.4e8 against 5.2e8 iterations/s)
+    auto apply = [&](int move) __attribute__((always_inline)) -> double {
+        if constexpr (LDS) return c.template apply_move<NB, NB>(move);
+        else {
+            if (c.cfg.K <= 3) return c.template apply_move<NB, 3>(move);
+            if (c.cfg.K <= 4) return c.template apply_move<NB, 4>(move);
+            if (c.cfg.K <= 6) return c.template apply_move<NB, 6>(move);
+            return c.template apply_move<NB, NB>(move);
+        }
+    };
     if (P.mode == 0) {
         double acc_rate = (worker && P.S.resume) ? sf[SF_ACC] : 0.5;
         long long next_sample = P.S.samp0;       // iterations k * step of the run: a counter instead of a 64-bit modulo per iteration
@@ -1708,9 +1801,9 @@ __global__ __launch_bounds__(kRrrThreads) void rrr_sparse_kernel(RrrSparseParams
                     E += dE; accepted += 1; acc = true;
                 }
             } else {
-                const double cc = c.apply_move(move);
+                const double cc = apply(move);
                 if (u1 < cc) { E += dE; accepted += 1; acc = true; }
-                else c.apply_move(move);
+                else apply(move);
             }
             acc_rate = acc_rate * (1 - P.lambda) + (acc ? 1.0 : 0.0) * P.lambda;
         }
@@ -1740,7 +1833,7 @@ __global__ __launch_bounds__(kRrrThreads) void rrr_sparse_kernel(RrrSparseParams
                 if (nextstep > limit) { out = true; break; }
             }
             if (out) break;
-            c.apply_move(move);
+            apply(move);
             m += 1;
             it += skip + 1;
             E += dE;
