@@ -651,8 +651,8 @@ def secondary_f8_rrr(pkg, O, device):
     out = {"workload": "GraphRRG(N=10000,K=3,+-J) rrrMC beta=2.0, 4096 replicas, 20000 iterations per replica (after a 20-sweep Metropolis quench)",
            "value": R * iters / dt, "unit": "iterations/s", "kernel": "rrr_sparse_kernel<false, 2, unsigned short, 8>", "avg_launch_ms": k_ms / max(nl, 1),
            "launches": nl, "acceptance": float(acc.mean()) / iters, "staged_frac": float(staged.mean()) / iters,
-           "note": "one thread per replica, every structure of the reference (ArraySet v/pos, T, z) per replica in HBM/L2: divergent scalar code, "
-                   "bound by dependent L2 round trips; profiles/r03/f8_kernels_summary.txt holds the rocprofv3 trace and SQ counters"}
+           "note": "one thread per replica, every structure of the reference (ArraySet v/pos, T, z) per replica in HBM: apply_move! gathers its K + 1 "
+                   "sites stage by stage; profiles/r06/f8_kernels_summary.txt holds the rocprofv3 trace and SQ counters"}
     if O is not None:
         with pinned_core():
             it1, Ji = 1 << 20, X.J.astype(np.int32)
@@ -663,8 +663,9 @@ def secondary_f8_rrr(pkg, O, device):
         it2, Ji = 1 << 18, X.J.astype(np.int32)
         cpu_all_cores_entry(out, out["cpu_one_core"]["value"], "iterations/s",
                             timed_oracle_all_cores("rrr_sparse", (X.A, Ji, beta, it2, it2, SEED, None), {}, 6, [C1], it2, nc), "x 2^18-iteration calls from the quenched configuration")
-    out["bound"] = "latency: one thread per replica chasing dependent L2 round trips through the reference's per-replica structures (ArraySet v / pos, T, z)"
-    out["bound_frac"] = None
+    out["bound"] = "latency: one thread per replica, 5 dependent HBM round trips + 1 237 issued instructions per iteration (profiles/r06/f8_floor.md)"
+    out["bound_frac"] = 9450.0 / max(k_ms * 1e-3 * 2.4e9 / iters, 1.0)
+    out["bound_frac_meaning"] = "the floor of f8_floor.md §1 (9 450 cycles per iteration of a wavefront) over this run's cycles per iteration at 2.4 GHz"
     return out
 
 
@@ -687,8 +688,10 @@ def secondary_f8_cont(pkg, O, device):
     out = {"workload": "GraphRRGNormal(N=10000,K=3) rrrMC beta=2.0, 4096 replicas, 5000 iterations per replica (after a 10-sweep Metropolis quench)",
            "value": R * iters / dt, "unit": "iterations/s", "kernel": "cont_wave_kernel", "avg_launch_ms": k_ms / max(nl, 1), "launches": nl,
            "acceptance": float(acc.mean()) / iters,
-           "bound": "latency: one wavefront per replica, log2(N) dependent levels of the sampler's tree per move (upper levels in LDS, the rest in L2)",
-           "bound_frac": None}
+           "bound": "issue: one wavefront per replica, four per SIMD; 1 090 issued instructions per move, the sampler's tree updated in the reference's "
+                    "order of Float64 additions (profiles/r06/f8_floor.md)",
+           "bound_frac": 4710.0 / max(k_ms * 1e-3 * 2.4e9 * 1024.0 / (R * iters), 1.0),
+           "bound_frac_meaning": "the issue cycles of f8_floor.md §2 (4 710 per move of a wavefront) over this run's SIMD cycles per move at 2.4 GHz"}
     if O is not None:
         with pinned_core():
             it1 = 1 << 16
