@@ -366,9 +366,10 @@ def secondary_c3(pkg, O, device):
     # FP64 VALU view: the useful work is a * N Float64 adds per attempt and replica (the field update); MI355X vector FP64 = 78.6 TFLOP/s as FMAs
     out["fp64_adds_per_s"] = a * N * R * iters / (k_ms * 1e-3)
     out["fp64_valu_frac"] = out["fp64_adds_per_s"] / (78.6e12 / 2)
-    out["bound"] = "fp64 vector issue of the bulk update + the serial decide chain of a block (profiles/r05/c3_block_budget.md)"
+    out["bound"] = "instruction issue, two wavefronts per SIMD: the serial decide chain (56 instructions per accepted move) + the fp64 bulk update (profiles/r06/c3_floor.md)"
     out["bound_frac"] = out["fp64_valu_frac"]
-    out["bound_frac_meaning"] = "useful Float64 field adds per second over the vector FP64 add rate (39.3e12/s)"
+    out["bound_frac_meaning"] = ("useful Float64 field adds per second over the vector FP64 add rate (39.3e12/s); against the issue floor of its own "
+                                 "design the block is at 0.77 (profiles/r06/c3_floor.md)")
     if O is not None:
         with pinned_core():
             ch = O.init_configs(SEED, 0, 1, N)[0]

@@ -465,8 +465,15 @@ int32_t sparse_eo_async(rrrmc_ctx* ctx, const double* ftau, int64_t iters, int64
     HIP_TRY(ctx, hipEventRecord(ctx->ev_begin, st));
     if ((rc = rp_in(ctx, rv, st))) return rc;
     HIP_TRY(ctx, hipEventRecord(ctx->ev_sweep[0], st));
-    if (N > 65535) hipLaunchKernelGGL(eo_sparse_kernel<uint32_t>, dim3(rrr_blocks(R)), dim3(rrr_tpb(R)), 0, st, P);
-    else hipLaunchKernelGGL(eo_sparse_kernel<uint16_t>, dim3(rrr_blocks(R)), dim3(rrr_tpb(R)), 0, st, P);
+    {
+        const char* no_lds = std::getenv("RRRMC_EO_NO_FTAU_LDS");       // tests / timing experiments
+        P.ftau_lds = N <= kEoFtauLdsMaxN && !(no_lds && no_lds[0] == '1') ? 1 : 0;
+        const size_t lds = eo_sparse_lds_bytes(N, P.ftau_lds != 0, rrr_tpb(R));
+        typedef void (*eo_fn)(EoParams);
+        const eo_fn fn = N > 65535 ? eo_sparse_kernel<uint32_t> : eo_sparse_kernel<uint16_t>;
+        HIP_TRY(ctx, raise_lds_attr(reinterpret_cast<const void*>(fn), lds));
+        hipLaunchKernelGGL(fn, dim3(rrr_blocks(R)), dim3(rrr_tpb(R)), lds, st, P);
+    }
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipEventRecord(ctx->ev_sweep[1], st));
     if ((rc = rp_out(ctx, rv, st))) return rc;

@@ -10,6 +10,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 #include "philox.hpp"
 #include "sk_kernels.hpp"   // det_exp
@@ -2038,14 +2039,35 @@ struct EoParams {
     uint32_t k0, k1, replica0;
     LevTable lv;
     int N, K, L, has_zero, W, R, Rpad;
+    int ftau_lds;            // the launch carries N doubles of dynamic LDS: the rank table is searched there
     SmpState S;
 };
+
+// rank table in LDS up to this N (80 KB at N = 10^4: one workgroup per CU, which is what rrr_tpb launches anyway)
+constexpr int kEoFtauLdsMaxN = 16384;
+// `E < Emin && (Emin = E; copy!(Cmin, C))` (RRRMC.jl:508-512) is a copy of the whole configuration at every new minimum — every other
+// iteration while a run descends from its random start.  Cmin differs from C by the flips made since the last minimum: up to kEoPend of
+// them are kept per replica and a new minimum toggles those bits of Cmin instead of copying W words; a longer stretch without a minimum
+// (or a resumed call, whose pending flips are not kept) falls back to the copy.  Same Cmin, bit for bit.
+constexpr int kEoPend = 32;
+inline size_t eo_sparse_lds_bytes(int64_t N, bool ftau_lds, unsigned tpb) { return (ftau_lds ? sizeof(double) * (size_t)N : 0) + sizeof(uint32_t) * kEoPend * tpb; }
 
 template <typename IDX>
 __global__ __launch_bounds__(kRrrThreads) void eo_sparse_kernel(EoParams P)
 {
+    extern __shared__ double eo_ftau_lds[];
+    // Cmin follows C lazily: the flips since the last minimum wait here (kEoPend per thread, after the rank table), see below
+    uint32_t* const pend = reinterpret_cast<uint32_t*>(eo_ftau_lds + (P.ftau_lds ? P.N : 0)) + threadIdx.x;
+    const int pstride = blockDim.x;
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (P.ftau_lds) {
+        // rand_move's binary search (DeltaE.jl:473-507) is ceil(log2 N) DEPENDENT probes of a table every replica shares: from LDS they cost
+        // an LDS round trip each instead of an L2 one (profiles/r06/f8_floor.md §3)
+        for (int i = threadIdx.x; i < P.N; i += blockDim.x) eo_ftau_lds[i] = P.ftau[i];
+        __syncthreads();
+    }
     if (r >= P.R) return;
+    const double* const ftab = P.ftau_lds ? eo_ftau_lds : P.ftau;
     const int N = P.N, L = P.L, K = P.K, K2 = 2 * P.L - P.has_zero;
     uint32_t* sp = P.spins + (size_t)r * P.W;
     uint32_t* cm = P.cmin + (size_t)r * P.W;
@@ -2068,12 +2090,75 @@ __global__ __launch_bounds__(kRrrThreads) void eo_sparse_kernel(EoParams P)
         const int ak = P.lv.find(d < 0 ? -d : d) + 1;
         return (d >= 0 ? ak + L - P.has_zero : L + 1 - ak) - 1;
     };
+    auto gather_apply = [&](auto km, int move) __attribute__((always_inline)) {
+        constexpr int KM = decltype(km)::value;
+        int sj[KM + 1], s0[KM + 1], s1[KM + 1], sp_[KM + 1], sl[KM + 1];
+        bool live[KM + 1];
+        int y[KM], cj[KM];
+#pragma unroll
+        for (int q = 0; q < KM; ++q) { const size_t e = (size_t)move * K + (q < K ? q : 0); y[q] = P.A[e]; cj[q] = (int)P.J[e]; }
+        bool val[KM];
+#pragma unroll
+        for (int q = 0; q < KM; ++q) val[q] = q < K && !(q > 0 && y[q] == y[q - 1]) && !(P.lv.skip_zero && cj[q] == 0);     // uA (EA.jl:158, RRG.jl:133)
+        int yy[KM][KM], cc[KM][KM];
+        uint32_t wown[KM];
+#pragma unroll
+        for (int q = 0; q < KM; ++q) {
+            const int j = val[q] ? y[q] : move;              // (a slot without a neighbour reads the moved spin's entries: harmless, never used)
+            sj[q] = j;
+            s0[q] = cls[j]; sp_[q] = (int)spos[j]; wown[q] = sp[j >> 5];
+#pragma unroll
+            for (int k = 0; k < KM; ++k) { const size_t e = (size_t)j * K + (k < K ? k : 0); yy[q][k] = P.A[e]; cc[q][k] = k < K ? (int)P.J[e] : 0; }
+        }
+        s0[KM] = cls[move]; sp_[KM] = (int)spos[move]; sj[KM] = move;
+        uint32_t wnb[KM][KM];
+#pragma unroll
+        for (int q = 0; q < KM; ++q)
+#pragma unroll
+            for (int k = 0; k < KM; ++k) wnb[q][k] = sp[yy[q][k] >> 5];
+#pragma unroll
+        for (int q = 0; q < KM; ++q) {
+            const int sjb = (int)((wown[q] >> (sj[q] & 31)) & 1u);
+            int acc = 0;
+#pragma unroll
+            for (int k = 0; k < KM; ++k) { const int sy = (int)((wnb[q][k] >> (yy[q][k] & 31)) & 1u); acc += (sjb == sy) ? cc[q][k] : -cc[q][k]; }
+            s1[q] = klass(2 * acc);
+            live[q] = val[q] && s0[q] != s1[q];
+        }
+        {   // the moved spin: its delta_energy changed sign, so its class is the mirror of the one it held (dE = 0 keeps its class)
+            const int k0 = s0[KM];
+            const int a0 = k0 < L ? L - 1 - k0 : k0 - L + P.has_zero;
+            s1[KM] = k0 < L ? ((a0 == 0 && P.has_zero) ? k0 : L + a0 - P.has_zero) : L - 1 - a0;
+            live[KM] = s1[KM] != k0;
+        }
+#pragma unroll
+        for (int q = 0; q <= KM; ++q) { const int tq = t[s0[q]]; sl[q] = (int)sv[(size_t)s0[q] * N + (tq > 0 ? tq - 1 : 0)]; }
+        unsigned touched = 0u;
+#pragma unroll
+        for (int q = 0; q <= KM; ++q) {
+            if (!live[q]) continue;
+            const int j = sj[q], k0 = s0[q], k1 = s1[q], p = sp_[q];
+            IDX* v0 = sv + (size_t)k0 * N;
+            IDX* v1 = sv + (size_t)k1 * N;
+            const int last = ((touched >> k0) & 1u) ? (int)v0[t[k0] - 1] : sl[q];
+            v0[p] = (IDX)last; spos[last] = (IDX)p; t[k0] -= 1;
+            v1[t[k1]] = (IDX)j; spos[j] = (IDX)t[k1]; t[k1] += 1;
+            cls[j] = (uint8_t)k1;
+            touched |= (1u << k0) | (1u << k1);
+#pragma unroll
+            for (int q2 = 0; q2 <= KM; ++q2)
+                if (q2 > q && live[q2] && sj[q2] == last) sp_[q2] = p;
+        }
+    };
     long long* const si = P.S.si + (size_t)r * kSmpI;
     long long E, Emin, itmin, ns = 0;
+    int npend = 0;
+    bool pend_over = false;                  // more flips since the last minimum than `pend` holds: the next minimum copies
     if (P.S.resume) {
         // a resumed call: the EOCache (classes, member order), E, Emin / Cmin / itmin of the run carry on (RRRMC.jl:486-516)
         for (int k = 0; k < K2; ++k) t[k] = (int)si[SI_T0 + k];
         E = P.E_cur[r]; Emin = si[SI_EMIN]; itmin = si[SI_ITMIN];
+        pend_over = true;
     } else {
     long long n = 0;
     for (int k = 0; k < K2; ++k) t[k] = 0;
@@ -2099,7 +2184,8 @@ __global__ __launch_bounds__(kRrrThreads) void eo_sparse_kernel(EoParams P)
         // rand_move: DeltaE.jl:473-507
         const double rr = (1 - (double)((((uint64_t)o.w[0] << 32) | o.w[1]) >> 11) * 0x1.0p-53) * z;
         int lo = 0, hi = N;
-        while (lo < hi) { const int mid = (lo + hi) >> 1; if (P.ftau[mid] < rr) lo = mid + 1; else hi = mid; }
+        if (P.ftau_lds) { while (lo < hi) { const int mid = (lo + hi) >> 1; if (eo_ftau_lds[mid] < rr) lo = mid + 1; else hi = mid; } }
+        else { while (lo < hi) { const int mid = (lo + hi) >> 1; if (ftab[mid] < rr) lo = mid + 1; else hi = mid; } }
         int rank = lo + 1;
         if (rank > N) rank = N;
         int k = -1, tt = 0;
@@ -2109,6 +2195,14 @@ __global__ __launch_bounds__(kRrrThreads) void eo_sparse_kernel(EoParams P)
         const int move = sv[(size_t)k * N + (int)mulhi64(((uint64_t)o.w[2] << 32) | o.w[3], (uint64_t)t[k])];
         // apply_move!: DeltaE.jl:509-541
         sp[move >> 5] ^= 1u << (move & 31);
+        if (npend < kEoPend) { pend[npend * pstride] = (uint32_t)move; npend += 1; } else pend_over = true;
+        if (K <= 6) {
+            // the K + 1 sites gathered stage by stage, every load of a stage issued before any is used, then the set moves in the reference's
+            // order on the gathered values — SparseChain::apply_move's scheme (above); slot q < KM = neighbour q, slot KM = the moved spin
+            if (K <= 3) gather_apply(std::integral_constant<int, 3>{}, move);
+            else if (K <= 4) gather_apply(std::integral_constant<int, 4>{}, move);
+            else gather_apply(std::integral_constant<int, 6>{}, move);
+        } else {
         const int32_t* Ax = P.A + (size_t)move * K;
         for (int q = 0; q <= K; ++q) {
             if (q < K && q > 0 && Ax[q] == Ax[q - 1]) continue;                      // uA: repeats removed (EA.jl:158)
@@ -2123,10 +2217,13 @@ __global__ __launch_bounds__(kRrrThreads) void eo_sparse_kernel(EoParams P)
             v1[t[k1]] = (IDX)j; spos[j] = (IDX)t[k1]; t[k1] += 1;
             cls[j] = (uint8_t)k1;
         }
+        }
         E += dE;
         if (E < Emin) {
             Emin = E; itmin = P.S.it0 + it;
-            for (int w = 0; w < P.W; ++w) cm[w] = sp[w];
+            if (pend_over) { for (int w = 0; w < P.W; ++w) cm[w] = sp[w]; }
+            else for (int q = 0; q < npend; ++q) { const uint32_t x = pend[q * pstride]; cm[x >> 5] ^= 1u << (x & 31); }
+            npend = 0; pend_over = false;
         }
     }
     P.E_cur[r] = (int32_t)E;
