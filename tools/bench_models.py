@@ -84,7 +84,13 @@ def bench_spf(N=4096, K=3, R=65536, beta=1.0, iters=1 << 16, step=1 << 12, seed=
     """GraphRRGNormal (Float64 sparse): config-2 geometry with Gaussian couplings; the lane-per-replica
     kernel hides its accept-path latency with occupancy, so it is measured at several replica counts."""
     pkg = entry.load_package()
+    K = int(os.environ.get("BENCH_SPF_K", K))            # (K = 7, 8: the degrees without fused pairs, VERDICT r5 item 7)
     X = pkg.GraphRRGNormal(N, K, seed=seed)
+    model = "GraphRRGNormal"
+    if os.environ.get("BENCH_SPF_EA"):                   # "L,D": GraphEANormal(L, D) instead (K = 2 D; L = 8, D = 4 has the N of the default)
+        L_, D_ = (int(a) for a in os.environ["BENCH_SPF_EA"].split(","))
+        X = pkg.GraphEANormal(L_, D_, seed=seed)
+        N, K, model = X.N, 2 * D_, "GraphEANormal(L=%d,D=%d)" % (L_, D_)
     for R in ([int(a) for a in sys.argv[2:]] or [8192, 65536, 262144]):
         eng = pkg.Engine(X, R)
         eng.seed(seed)
@@ -98,7 +104,7 @@ def bench_spf(N=4096, K=3, R=65536, beta=1.0, iters=1 << 16, step=1 << 12, seed=
         a = float(acc.mean()) / iters
         attempts = float(R) * iters
         bpa = 8 + a * (10 + 17 * K)          # SURVEY.md §8d widths: field 8 B, spin 1 B; lfields_last excluded
-        out = {"model": "GraphRRGNormal", "N": N, "K": K, "replicas": R, "beta": beta, "iters": iters, "attempts_per_s": attempts / dt,
+        out = {"model": model, "N": N, "K": K, "replicas": R, "beta": beta, "iters": iters, "attempts_per_s": attempts / dt,
                "build": {k: os.environ[k] for k in ("RRRMC_SPF_TEAM", "RRRMC_SPF_TEAM_WAVES", "RRRMC_SPF_TEAM_WIDTH") if k in os.environ} or "default",
                "kernel_ms": sweep_ms, "acceptance": a, "energy_per_spin": float(Es[:, -1].mean()) / N,
                "algorithmic_bytes_per_attempt": bpa, "algorithmic_GBps_kernel": bpa * attempts / (sweep_ms * 1e-3) / 1e9}

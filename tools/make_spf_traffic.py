@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""profiles/r05/spf_traffic.json from the rocprofv3 passes of `tools/profile_model.sh <tag> spf <R>` (gpurun_out/prof_<tag>): HBM-side bytes of
+"""profiles/<round>/spf_traffic.json (round = $RRRMC_PROF_ROUND, default r06) from the rocprofv3 passes of `tools/profile_model.sh <tag> spf <R>` (gpurun_out/prof_<tag>): HBM-side bytes of
 spf_team_kernel per attempt, stamped with the sources it was measured on (bench.py drops a stale or unstamped file).
 
   python tools/make_spf_traffic.py gpurun_out/prof_spf8192 [gpurun_out/prof_spf262144]
@@ -71,7 +71,7 @@ def main():
                 "source_files": bench.SPF_TEAM_SOURCES, "source_stamp": bench.source_stamp(bench.SPF_TEAM_SOURCES), "git_commit": bench.git_head()})
     if len(sys.argv) > 2:
         out["at_262144_replicas"] = entry(sys.argv[2], 262144)
-    dst = os.path.join(ROOT, "profiles", "r05", "spf_traffic.json")
+    dst = os.path.join(ROOT, "profiles", os.environ.get("RRRMC_PROF_ROUND", "r06"), "spf_traffic.json")
     os.makedirs(os.path.dirname(dst), exist_ok=True)
     json.dump(out, open(dst, "w"), indent=1)
     print(json.dumps(out, indent=1))
