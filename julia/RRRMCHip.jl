@@ -17,6 +17,14 @@
 #     runs R chains at once and returns `(Es::Matrix samples×R, Cs::Vector{Config})`.  Each call makes and finalises its own Ctx.
 #   * the same with an explicit context first (`standardMC(ctx, X, β, iters; ...)`) for callers that keep the device state between calls;
 #     results per replica: `Es` is samples × R (column r = the vector the reference returns for one chain), `Cs::Vector{Config}`.
+# Hooks (every sampler, as src/RRRMC.jl:152,224,314,379,477): `hook(it, X, C, acc, E)` — `hook(it, X, C, E, Emin)` for extremal_opt — is
+# called at the reference's sample points with the device's own tracked energy and accepted count; returning `false` ends that
+# replica's run (the batch keeps running on the device; the replica's reported energy, configuration and count are those of its stop).
+# Underneath, the sampler calls are RESUMED (`resume!(ctx)` = rrrmc_set_resume): pieces of (step - 1, step, step, ...) iterations for
+# rrrMC / extremal_opt, of `step` iterations for bklMC (each ends at a sample point), of one sample for wtmMC — the library continues the
+# run (DeltaECache / DynamicSampler / THeap / EO ranking, acc_rate, the pending bklMC draw, Emin / Cmin / itmin stay on the device), so a
+# hooked run is the un-hooked run bit for bit (`HookRun`, `sample!`, `finish!` below; tests/test_gpu_hooks.py checks the Python twin of
+# this logic against the oracle on the GPU).
 module RRRMCHip
 using RRRMC
 const LIB = get(ENV, "RRRMC_HIP_LIB", "librrrmc_hip.so")
