@@ -470,7 +470,9 @@ int32_t sparse_eo_async(rrrmc_ctx* ctx, const double* ftau, int64_t iters, int64
         P.ftau_lds = N <= kEoFtauLdsMaxN && !(no_lds && no_lds[0] == '1') ? 1 : 0;
         const size_t lds = eo_sparse_lds_bytes(N, P.ftau_lds != 0, rrr_tpb(R));
         typedef void (*eo_fn)(EoParams);
-        const eo_fn fn = N > 65535 ? eo_sparse_kernel<uint32_t> : eo_sparse_kernel<uint16_t>;
+        static const eo_fn fns[2][3] = {{eo_sparse_kernel<uint16_t, 2>, eo_sparse_kernel<uint16_t, 4>, eo_sparse_kernel<uint16_t, 8>},
+                                        {eo_sparse_kernel<uint32_t, 2>, eo_sparse_kernel<uint32_t, 4>, eo_sparse_kernel<uint32_t, 8>}};
+        const eo_fn fn = fns[N > 65535 ? 1 : 0][L <= 2 ? 0 : (L <= 4 ? 1 : 2)];      // (class counters sized at compile time, as rrr_sparse_kernel's)
         HIP_TRY(ctx, raise_lds_attr(reinterpret_cast<const void*>(fn), lds));
         hipLaunchKernelGGL(fn, dim3(rrr_blocks(R)), dim3(rrr_tpb(R)), lds, st, P);
     }

@@ -2052,7 +2052,57 @@ constexpr int kEoFtauLdsMaxN = 16384;
 constexpr int kEoPend = 32;
 inline size_t eo_sparse_lds_bytes(int64_t N, bool ftau_lds, unsigned tpb) { return (ftau_lds ? sizeof(double) * (size_t)N : 0) + sizeof(uint32_t) * kEoPend * tpb; }
 
-template <typename IDX>
+// The last two members of every class list, followed through the pushes and pops of ONE apply_move! in registers.  A set move
+// (ArraySet delete! + push!, ArraySets.jl:56-76) needs the LAST member of the list it deletes from; gathered before the set moves start, that
+// value is stale as soon as an earlier move of the same iteration touched the list, and re-reading it is a dependent memory round trip in
+// the middle of the store sequence (a fifth of eo_sparse_kernel's time, profiles/r06/f8_floor.md §3).  A push makes the pushed site the last
+// member and the old last the one before; a pop exposes the member before the last (known if it was gathered or pushed), or the moved
+// member itself when the deleted site sat right before the end.  Only a list popped twice beyond what is known falls back to the read.
+// NC = compile-time bound on the number of classes; all accesses are unrolled selects (registers).
+template <int NC>
+struct TailTrack {
+    int l1[NC], l2[NC];
+    unsigned ok1, ok2;
+    __device__ __forceinline__ void clear() { ok1 = 0u; ok2 = 0u;
+#pragma unroll
+        for (int a = 0; a < NC; ++a) { l1[a] = 0; l2[a] = 0; } }
+    __device__ __forceinline__ int get1(int c) const { int x = 0;
+#pragma unroll
+        for (int a = 0; a < NC; ++a) x = c == a ? l1[a] : x;
+        return x; }
+    __device__ __forceinline__ int get2(int c) const { int x = 0;
+#pragma unroll
+        for (int a = 0; a < NC; ++a) x = c == a ? l2[a] : x;
+        return x; }
+    __device__ __forceinline__ void set1(int c, int v) {
+#pragma unroll
+        for (int a = 0; a < NC; ++a) l1[a] = c == a ? v : l1[a];
+        ok1 |= 1u << c; }
+    __device__ __forceinline__ void set2(int c, int v) {
+#pragma unroll
+        for (int a = 0; a < NC; ++a) l2[a] = c == a ? v : l2[a];
+        ok2 |= 1u << c; }
+    __device__ __forceinline__ bool has1(int c) const { return (ok1 >> c) & 1u; }
+    __device__ __forceinline__ bool has2(int c) const { return (ok2 >> c) & 1u; }
+    // what the gather read at the end of list c (count n at that time)
+    __device__ __forceinline__ void note(int c, int n, int last, int before) { if (n >= 1) set1(c, last); if (n >= 2) set2(c, before); }
+    // list c (count n before) lost the member at position p; `last` was moved there
+    __device__ __forceinline__ void popped(int c, int n, int p, int last)
+    {
+        if (p == n - 2) set1(c, last);
+        else if (has2(c)) set1(c, get2(c));
+        else ok1 &= ~(1u << c);
+        ok2 &= ~(1u << c);
+    }
+    __device__ __forceinline__ void pushed(int c, int j)
+    {
+        if (has1(c)) set2(c, get1(c)); else ok2 &= ~(1u << c);
+        set1(c, j);
+    }
+};
+
+// SLM = compile-time bound on the levels of allΔE (2, 4 or 8): the class counters are indexed through unrolled selects of that length
+template <typename IDX, int SLM>
 __global__ __launch_bounds__(kRrrThreads) void eo_sparse_kernel(EoParams P)
 {
     extern __shared__ double eo_ftau_lds[];
@@ -2067,14 +2117,21 @@ __global__ __launch_bounds__(kRrrThreads) void eo_sparse_kernel(EoParams P)
         __syncthreads();
     }
     if (r >= P.R) return;
-    const double* const ftab = P.ftau_lds ? eo_ftau_lds : P.ftau;
     const int N = P.N, L = P.L, K = P.K, K2 = 2 * P.L - P.has_zero;
     uint32_t* sp = P.spins + (size_t)r * P.W;
     uint32_t* cm = P.cmin + (size_t)r * P.W;
     uint8_t* cls = P.cls + (size_t)r * N;
     IDX* sv = static_cast<IDX*>(P.sv) + (size_t)r * K2 * N;
     IDX* spos = static_cast<IDX*>(P.spos) + (size_t)r * N;
-    int t[2 * kSLmax];
+    constexpr int NC = 2 * SLM;
+    int t[NC];
+    auto tg = [&](int k) __attribute__((always_inline)) { int x = 0;
+#pragma unroll
+        for (int a = 0; a < NC; ++a) x = k == a ? t[a] : x;
+        return x; };
+    auto tadd = [&](int k, int d) __attribute__((always_inline)) {
+#pragma unroll
+        for (int a = 0; a < NC; ++a) t[a] = k == a ? t[a] + d : t[a]; };
     auto sbit = [&](int x) { return (int)((sp[x >> 5] >> (x & 31)) & 1u); };
     auto dE_of = [&](int i) {
         const int si = sbit(i);
@@ -2086,13 +2143,32 @@ __global__ __launch_bounds__(kRrrThreads) void eo_sparse_kernel(EoParams P)
         return 2 * acc;
     };
     // findks (DeltaE.jl:412-421), 0-based
-    auto klass = [&](int d) {
-        const int ak = P.lv.find(d < 0 ? -d : d) + 1;
+    auto klass = [&](int d) __attribute__((always_inline)) {
+        const int ad = d < 0 ? -d : d;
+        int a = 0;
+#pragma unroll
+        for (int k = 0; k < SLM; ++k) a = (k < L && P.lv.dElist[k] == ad) ? k : a;
+        const int ak = a + 1;
         return (d >= 0 ? ak + L - P.has_zero : L + 1 - ak) - 1;
+    };
+    // one set move (ArraySet delete!(k0, j) + push!(k1, j), ArraySets.jl:56-76) with the lists' ends followed in registers
+    TailTrack<NC> tk;
+    auto set_move = [&](int j, int k0, int k1, int p) __attribute__((always_inline)) -> int {
+        IDX* v0 = sv + (size_t)k0 * N;
+        IDX* v1 = sv + (size_t)k1 * N;
+        const int n0 = tg(k0);
+        const int last = tk.has1(k0) ? tk.get1(k0) : (int)v0[n0 - 1];
+        v0[p] = (IDX)last; spos[last] = (IDX)p; tadd(k0, -1);
+        tk.popped(k0, n0, p, last);
+        const int n1 = tg(k1);
+        v1[n1] = (IDX)j; spos[j] = (IDX)n1; tadd(k1, 1);
+        tk.pushed(k1, j);
+        cls[j] = (uint8_t)k1;
+        return last;
     };
     auto gather_apply = [&](auto km, int move) __attribute__((always_inline)) {
         constexpr int KM = decltype(km)::value;
-        int sj[KM + 1], s0[KM + 1], s1[KM + 1], sp_[KM + 1], sl[KM + 1];
+        int sj[KM + 1], s0[KM + 1], s1[KM + 1], sp_[KM + 1];
         bool live[KM + 1];
         int y[KM], cj[KM];
 #pragma unroll
@@ -2116,6 +2192,15 @@ __global__ __launch_bounds__(kRrrThreads) void eo_sparse_kernel(EoParams P)
         for (int q = 0; q < KM; ++q)
 #pragma unroll
             for (int k = 0; k < KM; ++k) wnb[q][k] = sp[yy[q][k] >> 5];
+        // the ends of the lists that may lose a site: last member and the one before (independent of the spin words: same trip)
+        int e1[KM + 1], e2[KM + 1], en[KM + 1];
+#pragma unroll
+        for (int q = 0; q <= KM; ++q) {
+            const int n = tg(s0[q]);
+            en[q] = n;
+            e1[q] = (int)sv[(size_t)s0[q] * N + (n > 0 ? n - 1 : 0)];
+            e2[q] = (int)sv[(size_t)s0[q] * N + (n > 1 ? n - 2 : 0)];
+        }
 #pragma unroll
         for (int q = 0; q < KM; ++q) {
             const int sjb = (int)((wown[q] >> (sj[q] & 31)) & 1u);
@@ -2131,23 +2216,17 @@ __global__ __launch_bounds__(kRrrThreads) void eo_sparse_kernel(EoParams P)
             s1[KM] = k0 < L ? ((a0 == 0 && P.has_zero) ? k0 : L + a0 - P.has_zero) : L - 1 - a0;
             live[KM] = s1[KM] != k0;
         }
+        tk.clear();
 #pragma unroll
-        for (int q = 0; q <= KM; ++q) { const int tq = t[s0[q]]; sl[q] = (int)sv[(size_t)s0[q] * N + (tq > 0 ? tq - 1 : 0)]; }
-        unsigned touched = 0u;
+        for (int q = 0; q <= KM; ++q) tk.note(s0[q], en[q], e1[q], e2[q]);
 #pragma unroll
         for (int q = 0; q <= KM; ++q) {
             if (!live[q]) continue;
-            const int j = sj[q], k0 = s0[q], k1 = s1[q], p = sp_[q];
-            IDX* v0 = sv + (size_t)k0 * N;
-            IDX* v1 = sv + (size_t)k1 * N;
-            const int last = ((touched >> k0) & 1u) ? (int)v0[t[k0] - 1] : sl[q];
-            v0[p] = (IDX)last; spos[last] = (IDX)p; t[k0] -= 1;
-            v1[t[k1]] = (IDX)j; spos[j] = (IDX)t[k1]; t[k1] += 1;
-            cls[j] = (uint8_t)k1;
-            touched |= (1u << k0) | (1u << k1);
+            const int p = sp_[q];
+            const int last = set_move(sj[q], s0[q], s1[q], p);
 #pragma unroll
             for (int q2 = 0; q2 <= KM; ++q2)
-                if (q2 > q && live[q2] && sj[q2] == last) sp_[q2] = p;
+                if (q2 > q && live[q2] && sj[q2] == last) sp_[q2] = p;          // a later site of this move that was relocated into the freed slot
         }
     };
     long long* const si = P.S.si + (size_t)r * kSmpI;
@@ -2156,20 +2235,23 @@ __global__ __launch_bounds__(kRrrThreads) void eo_sparse_kernel(EoParams P)
     bool pend_over = false;                  // more flips since the last minimum than `pend` holds: the next minimum copies
     if (P.S.resume) {
         // a resumed call: the EOCache (classes, member order), E, Emin / Cmin / itmin of the run carry on (RRRMC.jl:486-516)
-        for (int k = 0; k < K2; ++k) t[k] = (int)si[SI_T0 + k];
+#pragma unroll
+        for (int k = 0; k < NC; ++k) t[k] = k < K2 ? (int)si[SI_T0 + k] : 0;
         E = P.E_cur[r]; Emin = si[SI_EMIN]; itmin = si[SI_ITMIN];
         pend_over = true;
     } else {
     long long n = 0;
-    for (int k = 0; k < K2; ++k) t[k] = 0;
+#pragma unroll
+    for (int k = 0; k < NC; ++k) t[k] = 0;
     for (int i = 0; i < N; ++i) {
         const int d = dE_of(i);
         n -= d / 2;
         const int k = klass(d);
         cls[i] = (uint8_t)k;
-        sv[(size_t)k * N + t[k]] = (IDX)i;
-        spos[i] = (IDX)t[k];
-        t[k] += 1;
+        const int tk0 = tg(k);
+        sv[(size_t)k * N + tk0] = (IDX)i;
+        spos[i] = (IDX)tk0;
+        tadd(k, 1);
     }
     E = n / 2; Emin = E; itmin = 0;
     for (int w = 0; w < P.W; ++w) cm[w] = sp[w];
@@ -2184,15 +2266,28 @@ __global__ __launch_bounds__(kRrrThreads) void eo_sparse_kernel(EoParams P)
         // rand_move: DeltaE.jl:473-507
         const double rr = (1 - (double)((((uint64_t)o.w[0] << 32) | o.w[1]) >> 11) * 0x1.0p-53) * z;
         int lo = 0, hi = N;
-        if (P.ftau_lds) { while (lo < hi) { const int mid = (lo + hi) >> 1; if (eo_ftau_lds[mid] < rr) lo = mid + 1; else hi = mid; } }
-        else { while (lo < hi) { const int mid = (lo + hi) >> 1; if (ftab[mid] < rr) lo = mid + 1; else hi = mid; } }
+        if (P.ftau_lds) {
+            // searchsortedfirst, two levels per LDS round trip: the probe of this level and both candidates of the next are read together
+            // (same comparisons against the same entries as one probe per level)
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                const int ml = (lo + mid) >> 1, mr = (mid + 1 + hi) >> 1;
+                const double xm = eo_ftau_lds[mid], xl = eo_ftau_lds[ml < N ? ml : N - 1], xr = eo_ftau_lds[mr < N ? mr : N - 1];
+                if (xm < rr) { lo = mid + 1; if (lo < hi) { if (xr < rr) lo = mr + 1; else hi = mr; } }
+                else { hi = mid; if (lo < hi) { if (xl < rr) lo = ml + 1; else hi = ml; } }
+            }
+        } else { while (lo < hi) { const int mid = (lo + hi) >> 1; if (P.ftau[mid] < rr) lo = mid + 1; else hi = mid; } }
         int rank = lo + 1;
         if (rank > N) rank = N;
-        int k = -1, tt = 0;
-        while (rank > tt) { k += 1; tt += t[k]; }
+        int k = 0, tt = t[0];
+#pragma unroll
+        for (int a = 1; a < NC; ++a) { const bool more = rank > tt; k = more ? a : k; tt += more ? t[a] : 0; }
         const int a = k < L ? L - 1 - k : k - L + P.has_zero;                        // index into allΔE
-        const int dE = k < L ? -P.lv.dElist[a] : P.lv.dElist[a];
-        const int move = sv[(size_t)k * N + (int)mulhi64(((uint64_t)o.w[2] << 32) | o.w[3], (uint64_t)t[k])];
+        int dEa = 0;
+#pragma unroll
+        for (int b = 0; b < SLM; ++b) dEa = a == b ? P.lv.dElist[b] : dEa;
+        const int dE = k < L ? -dEa : dEa;
+        const int move = sv[(size_t)k * N + (int)mulhi64(((uint64_t)o.w[2] << 32) | o.w[3], (uint64_t)tg(k))];
         // apply_move!: DeltaE.jl:509-541
         sp[move >> 5] ^= 1u << (move & 31);
         if (npend < kEoPend) { pend[npend * pstride] = (uint32_t)move; npend += 1; } else pend_over = true;
@@ -2203,6 +2298,7 @@ __global__ __launch_bounds__(kRrrThreads) void eo_sparse_kernel(EoParams P)
             else if (K <= 4) gather_apply(std::integral_constant<int, 4>{}, move);
             else gather_apply(std::integral_constant<int, 6>{}, move);
         } else {
+        tk.clear();
         const int32_t* Ax = P.A + (size_t)move * K;
         for (int q = 0; q <= K; ++q) {
             if (q < K && q > 0 && Ax[q] == Ax[q - 1]) continue;                      // uA: repeats removed (EA.jl:158)
@@ -2210,12 +2306,7 @@ __global__ __launch_bounds__(kRrrThreads) void eo_sparse_kernel(EoParams P)
             const int j = q < K ? Ax[q] : move;
             const int k0 = cls[j], k1 = klass(dE_of(j));
             if (k0 == k1) continue;
-            IDX* v0 = sv + (size_t)k0 * N;
-            IDX* v1 = sv + (size_t)k1 * N;
-            const int p = spos[j], last = v0[t[k0] - 1];
-            v0[p] = (IDX)last; spos[last] = (IDX)p; t[k0] -= 1;
-            v1[t[k1]] = (IDX)j; spos[j] = (IDX)t[k1]; t[k1] += 1;
-            cls[j] = (uint8_t)k1;
+            set_move(j, k0, k1, (int)spos[j]);
         }
         }
         E += dE;
@@ -2228,7 +2319,8 @@ __global__ __launch_bounds__(kRrrThreads) void eo_sparse_kernel(EoParams P)
     }
     P.E_cur[r] = (int32_t)E;
     P.stats[(size_t)r * 3] = Emin; P.stats[(size_t)r * 3 + 1] = itmin; P.stats[(size_t)r * 3 + 2] = P.iters;
-    for (int k = 0; k < K2; ++k) si[SI_T0 + k] = t[k];
+#pragma unroll
+    for (int k = 0; k < NC; ++k) if (k < K2) si[SI_T0 + k] = t[k];
     si[SI_EMIN] = Emin; si[SI_ITMIN] = itmin;
 }
 
