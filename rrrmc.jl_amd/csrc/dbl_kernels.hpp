@@ -9,6 +9,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 #include "philox.hpp"
 #include "rrr_kernels.hpp"
@@ -190,6 +191,151 @@ struct DblChain {
         z = zp;
         return cc;
     }
+    // apply_move! / compute_staged! as a staged gather (the scheme of SparseChain::apply_move, rrr_kernels.hpp; profiles/r06/f8_floor.md):
+    // what the flip and the K + 1 set moves read is requested stage by stage — the moved spin's row (A, level couplings, residual
+    // couplings), then per neighbour its residual field, class, position, word of spins and row, then the words of the neighbours'
+    // neighbours and the ends of the lists that may lose a site — BEFORE the spin is flipped in memory (the moved spin's new value is
+    // patched into the gathered words), and the reference's sequence (update_cache_residual!, then the set moves in neighbour order) runs
+    // on the gathered values: same values, same stores in the same order.  A staged move that is rejected writes nothing at all (the
+    // reference flips X0 and flips it back, RRRMC.jl:131-138).  K <= KM <= 6.
+    template <int KM>
+    struct Gathered {
+        int y[KM];
+        double rj[KM], lfm, lfv[KM], un[KM + 1];
+        bool first[KM], lastr[KM], live[KM + 1];
+        int sx, sy[KM];                                     // the moved spin AFTER its flip; the row's neighbour spins
+        int sj[KM + 1], s0[KM + 1], s1[KM + 1], sp_[KM + 1], sl[KM + 1];
+    };
+    template <int KM>
+    __device__ __forceinline__ void gather(int move, Gathered<KM>& G) const
+    {
+        const int K = cfg.K, L = cfg.L;
+        int dj[KM];
+#pragma unroll
+        for (int q = 0; q < KM; ++q) { const size_t e = (size_t)move * K + (q < K ? q : 0); G.y[q] = cfg.A[e]; dj[q] = (int)cfg.dJ[e]; G.rj[q] = cfg.rJ[e]; }
+        G.lfm = lf[move];
+        G.sx = 1 - sbit(move);
+        bool val[KM];
+#pragma unroll
+        for (int q = 0; q < KM; ++q) {
+            G.first[q] = q < K && !(q > 0 && G.y[q] == G.y[q - 1]);
+            G.lastr[q] = q < K && (q == K - 1 || (q + 1 < KM && G.y[q + 1] != G.y[q]));
+            val[q] = q < K && (cfg.ea_form ? G.first[q] : dj[q] != 0);                                  // is_nb
+        }
+        uint32_t wy[KM];
+        int yy[KM][KM], cc[KM][KM];
+#pragma unroll
+        for (int q = 0; q < KM; ++q) {
+            const int j = q < K ? G.y[q] : move;
+            G.lfv[q] = lf[j]; wy[q] = sp[j >> 5]; G.un[q] = undo[q < K ? q : 0];
+            G.sj[q] = j; G.s0[q] = cls[j]; G.sp_[q] = (int)spos[j];
+#pragma unroll
+            for (int k = 0; k < KM; ++k) { const size_t e = (size_t)j * K + (k < K ? k : 0); yy[q][k] = cfg.A[e]; cc[q][k] = k < K ? (int)cfg.dJ[e] : 0; }
+        }
+        G.un[KM] = undo[K];
+        G.s0[KM] = cls[move]; G.sp_[KM] = (int)spos[move]; G.sj[KM] = move;
+        uint32_t wnb[KM][KM];
+#pragma unroll
+        for (int q = 0; q < KM; ++q)
+#pragma unroll
+            for (int k = 0; k < KM; ++k) wnb[q][k] = sp[yy[q][k] >> 5];
+#pragma unroll
+        for (int q = 0; q <= KM; ++q) { const int tq = tg(G.s0[q]); G.sl[q] = (int)sv[(size_t)G.s0[q] * cfg.N + (tq > 0 ? tq - 1 : 0)]; }
+        // the neighbours' new classes (klass: DeltaE.jl:28-60, 80-86) from the gathered words, the moved spin taken as flipped
+#pragma unroll
+        for (int q = 0; q < KM; ++q) {
+            const int sjb = (int)((wy[q] >> (G.sj[q] & 31)) & 1u);
+            G.sy[q] = sjb;
+            int acc = 0;
+#pragma unroll
+            for (int k = 0; k < KM; ++k) {
+                int b = (int)((wnb[q][k] >> (yy[q][k] & 31)) & 1u);
+                b = yy[q][k] == move ? G.sx : b;
+                acc += (sjb == b) ? cc[q][k] : -cc[q][k];
+            }
+            const int d = 2 * acc, ad = d < 0 ? -d : d;
+            int a = 0;
+#pragma unroll
+            for (int k = 0; k < SLM; ++k) a = (k < L && cfg.dElist[k] == ad) ? k : a;
+            G.s1[q] = a + L * ((d > 0 || (d == 0 && sjb == 1)) ? 1 : 0);
+            G.live[q] = val[q] && G.s0[q] != G.s1[q];
+        }
+        G.live[KM] = true; G.s1[KM] = G.s0[KM] >= L ? G.s0[KM] - L : G.s0[KM] + L;
+    }
+    // the weights after the move: T' and z' (the running sums of apply_move! / compute_staged!, in slot order)
+    template <int KM>
+    __device__ __forceinline__ double weights(const Gathered<KM>& G, double* Tp) const
+    {
+        double zp = z;
+#pragma unroll
+        for (int q = 0; q <= KM; ++q)
+            if (G.live[q]) {
+                const double f0 = f(G.s0[q]), f1 = f(G.s1[q]);
+#pragma unroll
+                for (int a = 0; a < 2 * SLM; ++a) Tp[a] = G.s0[q] == a ? Tp[a] - f0 : Tp[a];
+#pragma unroll
+                for (int a = 0; a < 2 * SLM; ++a) Tp[a] = G.s1[q] == a ? Tp[a] + f1 : Tp[a];
+                zp += f1 - f0;
+            }
+        return zp;
+    }
+    // spinflip!(X::DoubleGraph) + the set moves, on the gathered values
+    template <int KM>
+    __device__ __forceinline__ void commit(int move, Gathered<KM>& G)
+    {
+        const int K = cfg.K;
+        sflip(move);
+        // update_cache_residual! (RRG.jl:430-466, EA.jl:456-496)
+        if (mlast == move) {
+#pragma unroll
+            for (int k = 0; k < KM; ++k)
+                if (G.first[k]) { lf[G.y[k]] = G.un[k]; undo[k] = G.lfv[k]; }
+            lf[move] = -G.lfm;
+            undo[K] = -G.un[KM];
+        } else {
+            double v = 0.0;
+#pragma unroll
+            for (int k = 0; k < KM; ++k)
+                if (k < K) {
+                    if (G.first[k]) { v = G.lfv[k]; undo[k] = v; }
+                    const double c4 = (G.sx ^ G.sy[k]) ? -4.0 : 4.0;           // 4 * sigma_xy with the new s_x
+                    v = v - c4 * G.rj[k];
+                    if (G.lastr[k]) lf[G.y[k]] = v;
+                }
+            undo[K] = G.lfm;
+            lf[move] = -G.lfm;
+            mlast = move;
+        }
+        unsigned touched = 0u;
+#pragma unroll
+        for (int q = 0; q <= KM; ++q) {
+            if (!G.live[q]) continue;
+            const int j = G.sj[q], k0 = G.s0[q], k1 = G.s1[q], p = G.sp_[q];
+            IDX* v0 = sv + (size_t)k0 * cfg.N;
+            IDX* v1 = sv + (size_t)k1 * cfg.N;
+            const int last = ((touched >> k0) & 1u) ? (int)v0[tg(k0) - 1] : G.sl[q];    // ArraySet delete!(k0, j) + push!(k1, j), ArraySets.jl:56-76
+            v0[p] = (IDX)last; spos[last] = (IDX)p; tadd(k0, -1);
+            const int t1 = tg(k1);
+            v1[t1] = (IDX)j; spos[j] = (IDX)t1; tadd(k1, 1);
+            cls[j] = (uint8_t)k1;
+            touched |= (1u << k0) | (1u << k1);
+#pragma unroll
+            for (int q2 = 0; q2 <= KM; ++q2)
+                if (q2 > q && G.live[q2] && G.sj[q2] == last) G.sp_[q2] = p;
+        }
+    }
+    // apply_move!(X::DoubleGraph, C, move, cache): DeltaE.jl:232-295; returns c = z / z'
+    template <int KM>
+    __device__ __forceinline__ double apply_move_g(int move)
+    {
+        Gathered<KM> G;
+        gather<KM>(move, G);
+        const double zp = weights<KM>(G, T);
+        commit<KM>(move, G);
+        const double cz = z / zp;
+        z = zp;
+        return cz;
+    }
 };
 
 // accept(c, x): RRRMC.jl:40-44
@@ -312,7 +458,39 @@ __global__ __launch_bounds__(kRrrThreads) void rrr_dbl_kernel(RrrDblParams P)
     }
 
     const uint32_t rep = P.replica0 + (uint32_t)r;
+    // apply_move! with its gather sized for the graph's degree (kernel-uniform); always_inline: out of line the chain would live in scratch
+    auto apply = [&](int move) __attribute__((always_inline)) -> double {
+        if (K <= 3) return c.template apply_move_g<3>(move);
+        if (K <= 4) return c.template apply_move_g<4>(move);
+        if (K <= 6) return c.template apply_move_g<6>(move);
+        return c.apply_move(move);
+    };
     long long accepted = 0, staged_its = 0, ns = 0;
+    // the staged step on the gathered values: nothing is written unless the move is accepted
+    auto staged_km = [&](auto km, int move, uint64_t g, int dE0, double& E, long long& accepted) __attribute__((always_inline)) -> bool {
+        constexpr int KM = decltype(km)::value;
+        typename DblChain<SLM, IDX>::template Gathered<KM> G;
+        c.template gather<KM>(move, G);
+        double Tp[2 * SLM];
+#pragma unroll
+        for (int q = 0; q < 2 * SLM; ++q) Tp[q] = c.T[q];
+        const double zp = c.template weights<KM>(G, Tp);
+        const double cc = c.z / zp;
+        const double dE1 = -G.lfm;                                            // delta_energy_residual
+        if (!dbl_accept(cc, -P.beta * dE1, g, rep, P.k0, P.k1)) return false;
+        c.template commit<KM>(move, G);                                       // spinflip! + apply_staged!
+#pragma unroll
+        for (int q = 0; q < 2 * SLM; ++q) c.T[q] = Tp[q];
+        c.z = zp;
+        E += P.to_f64(dE0) + dE1;
+        accepted += 1;
+        return true;
+    };
+    auto staged = [&](int move, uint64_t g, int dE0, double& E, long long& accepted) __attribute__((always_inline)) -> bool {
+        if (K <= 3) return staged_km(std::integral_constant<int, 3>{}, move, g, dE0, E, accepted);
+        if (K <= 4) return staged_km(std::integral_constant<int, 4>{}, move, g, dE0, E, accepted);
+        return staged_km(std::integral_constant<int, 6>{}, move, g, dE0, E, accepted);
+    };
     double acc_rate = resume ? sf[SF_ACC] : 0.5;
     long long next_sample = P.S.samp0;       // iterations k * step of the run: a counter instead of a 64-bit modulo per iteration
     for (long long it = 1; it <= P.iters; ++it) {
@@ -328,6 +506,8 @@ __global__ __launch_bounds__(kRrrThreads) void rrr_dbl_kernel(RrrDblParams P)
         if (acc_rate < P.staged_thr) {
             // step_rrr(X0, C, cache) (RRRMC.jl:131-138): compute_staged! flips X0 only, and flips it back
             staged_its += 1;
+            if (K <= 6) acc = staged(move, g, dE0, E, accepted);
+            else {
             // staged changes in fixed slots (slot q = neighbour q, slot kDKmax = the moved spin) and fully unrolled loops: registers
             int sj[kDKmax + 1], s0[kDKmax + 1], s1[kDKmax + 1];
             bool live[kDKmax + 1];
@@ -369,11 +549,12 @@ __global__ __launch_bounds__(kRrrThreads) void rrr_dbl_kernel(RrrDblParams P)
                 E += P.to_f64(dE0) + dE1;
                 accepted += 1; acc = true;
             }
+            }
         } else {
             const double dE1 = -c.lf[move];
-            const double cc = c.apply_move(move);
+            const double cc = apply(move);
             if (dbl_accept(cc, -P.beta * dE1, g, rep, P.k0, P.k1)) { E += P.to_f64(dE0) + dE1; accepted += 1; acc = true; }
-            else c.apply_move(move);
+            else apply(move);
         }
         acc_rate = acc_rate * (1 - P.lambda) + (acc ? 1.0 : 0.0) * P.lambda;      // RRRMC.jl:281
     }
