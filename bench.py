@@ -759,7 +759,7 @@ def compact_line(full):
     if c:
         out["cpu_baseline"] = {"value": _sig(c.get("value")), "unit": c.get("unit"), "cores": c.get("cores"), "kind": c.get("kind"),
                                "sample": c.get("sample_short") or c.get("sample")}
-    for k in ("host_gap_ms_per_step", "sync_value", "sync_value_pageable"):
+    for k in ("host_gap_ms_per_step", "sync_value", "sync_value_pageable", "ms_per_step_per_rank"):
         if k in full:
             out[k] = _sig(full[k])
     out["verified"] = full.get("verified")
