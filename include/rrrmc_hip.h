@@ -297,6 +297,8 @@ RRRMC_API int32_t rrrmc_set_resume(rrrmc_ctx *ctx, int32_t on);
  *     itmin counts from the start of the run;
  *   - bklMC: `iters` more iterations are allowed; `it`, `nextstep` and the pending (skip, move) draw carry on — a call of `step` iterations
  *     ends at the next sample point, with the configuration, E and accepted count the reference hands to its hook there (:336-341);
+ *     the reference's loop ends with its LAST SAMPLE (:340-343: the iterations between it and `iters` are never made), so a resumed call
+ *     whose allowance does not reach the run's next sample point makes no move;
  *   - wtmMC: `samples` more samples; the heap, the global time and `nextstep` carry on (:399-404);
  *   - rrrmc_fetch_results* / rrrmc_rrr_stats return the samples and the accepted / staged counts of the CALL.
  * A run cut into calls anywhere is bit for bit the run made in one call — energies, configurations, counts and the cache — through every

@@ -378,7 +378,8 @@ __global__ __launch_bounds__(64) void cont_wave_kernel(ContParams P)
         if (resume) { bk_it = sq[SI_IT]; bk_next = sq[SI_NEXT]; bk_m = sq[SI_M]; bk_limit += sq[SI_LIMIT]; }
         long long it = bk_it, nextstep = bk_next, m = bk_m;
         const long long limit = bk_limit;
-        while (it < limit) {
+        const bool over = resume && nextstep > limit && nextstep > P.step;      // (a resumed call whose allowance does not reach the run's next sample point makes no move: the reference's loop ends with its last sample, RRRMC.jl:340-343)
+        while (!over && it < limit) {
             const uint64_t g = P.g0 + (uint64_t)(m + 1);
             const Philox4 o3 = philox4x32_10((uint32_t)g, (uint32_t)(g >> 32), rep, TAG_RRR | (2u << 8), P.k0, P.k1);
             const double us = bcd((double)((((uint64_t)o3.w[0] << 32) | o3.w[1]) >> 11) * 0x1.0p-53, 0);
@@ -393,6 +394,7 @@ __global__ __launch_bounds__(64) void cont_wave_kernel(ContParams P)
             const double dE = -pf_lf0;
             bool out = false;
             while (it + skip + 1 >= nextstep) {
+                if (nextstep > limit) { out = true; break; }        // (fewer iterations allowed than `step`: the sample point lies beyond this call — no sample, no move)
                 if (lane == 0) P.Es[(size_t)ns * P.Rp + r] = E;
                 ns += 1;
                 nextstep += P.step;

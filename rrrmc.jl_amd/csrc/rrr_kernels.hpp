@@ -1076,7 +1076,8 @@ __global__ __launch_bounds__(kRrrThreads) void rrr_skn_kernel(RrrSkParams P)
         // (a resumed call continues the run's loop with `iters` more iterations allowed; the pending move is drawn again: same draw)
         long long it = 0, nextstep = P.step, m = 0, limit = P.iters;
         if (resume) { it = sq[SI_IT]; nextstep = sq[SI_NEXT]; m = sq[SI_M]; limit += sq[SI_LIMIT]; }
-        while (it < limit) {
+        const bool over = resume && nextstep > limit && nextstep > P.step;      // (a resumed call whose allowance does not reach the run's next sample point makes no move: the reference's loop ends with its last sample, RRRMC.jl:340-343)
+        while (!over && it < limit) {
             const uint64_t g = P.g0 + (uint64_t)(m + 1);
             const Philox4 o3 = philox4x32_10((uint32_t)g, (uint32_t)(g >> 32), rep, TAG_RRR | (2u << 8), P.k0, P.k1);
             const double us = (double)((((uint64_t)o3.w[0] << 32) | o3.w[1]) >> 11) * 0x1.0p-53;
@@ -1091,6 +1092,7 @@ __global__ __launch_bounds__(kRrrThreads) void rrr_skn_kernel(RrrSkParams P)
             const double dE = P.dEs[(size_t)move * Rp + r];
             bool out = false;
             while (it + skip + 1 >= nextstep) {
+                if (nextstep > limit) { out = true; break; }        // (fewer iterations allowed than `step`: the sample point lies beyond this call — no sample, no move)
                 P.Es[(size_t)ns * Rp + r] = E; ns += 1;
                 nextstep += P.step;
                 if (nextstep > limit) { out = true; break; }
@@ -1816,7 +1818,8 @@ __global__ __launch_bounds__(kRrrThreads) void rrr_sparse_kernel(RrrSparseParams
         // number of moves made carry on; the draw of the move that was pending at the cut is taken again — same counter, same cache, same draw
         long long it = 0, nextstep = P.step, m = 0, limit = P.iters;
         if (P.S.resume) { it = si[SI_IT]; nextstep = si[SI_NEXT]; m = si[SI_M]; limit += si[SI_LIMIT]; }
-        while (it < limit) {
+        const bool over = P.S.resume && nextstep > limit && nextstep > P.step;  // (a resumed call whose allowance does not reach the run's next sample point makes no move: the reference's loop ends with its last sample, RRRMC.jl:340-343)
+        while (!over && it < limit) {
             const uint64_t g = P.g0 + (uint64_t)(m + 1);
             const Philox4 o3 = philox4x32_10((uint32_t)g, (uint32_t)(g >> 32), rep, TAG_RRR | (2u << 8), P.k0, P.k1);
             const double us = (double)((((uint64_t)o3.w[0] << 32) | o3.w[1]) >> 11) * 0x1.0p-53;
@@ -1829,6 +1832,7 @@ __global__ __launch_bounds__(kRrrThreads) void rrr_sparse_kernel(RrrSparseParams
             const int move = c.sv[(size_t)k * N + (int)mulhi64(((uint64_t)o.w[2] << 32) | o.w[3], (uint64_t)c.tg(k))];
             bool out = false;
             while (it + skip + 1 >= nextstep) {
+                if (nextstep > limit) { out = true; break; }        // (fewer iterations allowed than `step`: the sample point lies beyond this call — no sample, no move)
                 P.Es[(size_t)ns * P.Rpad + r] = (int32_t)E; ns += 1;
                 nextstep += P.step;
                 if (nextstep > limit) { out = true; break; }

@@ -227,7 +227,7 @@ __global__ __launch_bounds__(kRrrThreads) void rrr_sparse_wave_kernel(RrrSparseP
     long long it_bkl = 0, nextstep = P.step, m_done = 0, limit = P.iters;
     if (bkl && resume) { it_bkl = si[SI_IT]; nextstep = si[SI_NEXT]; m_done = si[SI_M]; limit += si[SI_LIMIT]; }
     const long long m_first = m_done;
-    bool done = false;
+    bool done = bkl && resume && nextstep > limit && nextstep > P.step;          // (a resumed call whose allowance does not reach the run's next sample point makes no move: the reference's loop ends with its last sample, RRRMC.jl:340-343)
     const double Nd = (double)P.N + vzd;
     for (long long base_it = bkl ? m_first : 0; !done && (bkl || base_it < P.iters); base_it += kRrrThreads) {
         __syncthreads();
@@ -321,6 +321,7 @@ __global__ __launch_bounds__(kRrrThreads) void rrr_sparse_wave_kernel(RrrSparseP
                 skip = skipf >= 9.0e18 ? (long long)9.0e18 : (long long)skipf;
                 bool out = false;
                 while (it_bkl + skip + 1 >= nextstep) {           // the samples the skipped iterations pass (RRRMC.jl:332-350)
+                    if (nextstep > limit) { out = true; break; }        // (fewer iterations allowed than `step`: the sample point lies beyond this call — no sample, no move)
                     if (lane == 0) P.Es[(size_t)ns * P.Rpad + r] = (int32_t)E;
                     ns += 1;
                     nextstep += P.step;

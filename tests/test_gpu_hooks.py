@@ -474,3 +474,43 @@ def test_resume_contract(pkg, oracle):
         od = oracle.rrr_sparse(M.A, M.J, 2.0, 300, 100, SEED, ob1[1], it0=1400, replica=0, bkl=True)
         assert (d[0][0] == od[0]).all() and (eng.get_config().s[0] == od[1]).all()
         eng.set_resume(False)
+
+
+# ---- cuts that are not multiples of `step` -------------------------------------------------------------------------------------------------
+BKL_CUTS = [(10, [6, 95, 15]), (3, [72, 63, 1, 260, 656]), (50, [18, 11, 41, 108, 16]), (50, [2, 14, 72, 43, 10]), (7, [4, 395, 49, 35, 38]),
+            (10, [3, 3]), (10, [30, 5, 2, 3, 60])]
+
+
+@pytest.mark.parametrize("step,pieces", BKL_CUTS, ids=["%d-%s" % (s, "_".join(map(str, p))) for s, p in BKL_CUTS])
+@pytest.mark.parametrize("name,build", [("rrg", {}), ("rrg", {"RRRMC_RRR_NO_WAVE": "1"}), ("rrg", {"RRRMC_RRR_NO_WAVE": "1", "RRRMC_RRR_NO_LDS": "1"}),
+                                        ("ea", {}), ("rrgn", {}), ("rrgn", {"RRRMC_CONT_NO_WAVE": "1"}), ("skn", {}), ("quant", {})],
+                         ids=["rrg-wave", "rrg-lds", "rrg-thread", "ea-wave", "rrgn-wave", "rrgn-thread", "skn", "quant"])
+def test_bkl_run_cut_anywhere_is_the_run_made_in_one_call(pkg, oracle, monkeypatch, name, build, step, pieces):
+    """bklMC's loop (RRRMC.jl:327-350) jumps over skipped iterations and ends with its LAST SAMPLE: a resumed call whose allowance ends between
+    two sample points must neither take the sample that lies beyond it nor — once the run's last sample is taken — make another move.
+    Found by tools/hook_soak.py: pieces shorter than `step` at the start, a piece of one iteration right after a sample point."""
+    for k in ("RRRMC_RRR_NO_WAVE", "RRRMC_RRR_NO_LDS", "RRRMC_CONT_NO_WAVE"):
+        monkeypatch.delenv(k, raising=False)
+    for k, v in build.items():
+        monkeypatch.setenv(k, v)
+    M = MODELS[name](pkg)
+    R, beta, total = 70, 1.0, sum(pieces)
+    outs = []
+    for plan in ([total], pieces):
+        with pkg.Engine(M.X, R) as eng:
+            eng.seed(SEED)
+            eng.init_spins_random()
+            C0 = eng.get_config()
+            Es, moves = [], 0
+            for i, n in enumerate(plan):
+                eng.set_resume(i > 0)
+                a, m = eng.bkl_mc(beta, n, step)
+                Es.append(np.asarray(a)); moves = moves + np.asarray(m)
+            eng.set_resume(False)
+            outs.append((np.concatenate(Es, 1), moves, eng.get_config().s.copy(), np.asarray(eng.run_energy())))
+    for a, b in zip(*outs):
+        assert a.shape == b.shape and (a == b).all()
+    assert outs[0][0].shape == (R, total // step)
+    if total >= step:
+        oEs, och, ocnt = M.oracle(oracle, "bkl", C0.s[3], 3, SEED, total, step, beta=beta)
+        assert (outs[1][0][3] == oEs).all() and (outs[1][2][3] == och).all()
