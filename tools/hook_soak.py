@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Soak of the resumed sampler calls (include/rrrmc_hip.h: rrrmc_set_resume): random graphs, samplers, replica counts, kernel builds and CUT
-POINTS — a run made in one call against the same run cut into resumed calls of random lengths (not multiples of `step`), compared bit
+POINTS — a run made in one call against the same run cut into resumed calls of random lengths (not multiples of `step`; standardMC: multiples, its contract), compared bit
 for bit: samples, final configuration, tracked energy, counts, and the DeltaECache where the model has one.  GPU against GPU (the oracle
 is not involved: tests/test_gpu_hooks.py pins both to it on fixed cases).
 
@@ -59,6 +59,9 @@ def call(eng, smp, n, step, beta, tau, thr):
     if smp == "wtm":
         Es, mv, t = eng.wtm_mc(beta, n, float(step))
         return np.asarray(Es), np.asarray(mv, np.float64)[:, None]
+    if smp == "std":
+        Es, acc = eng.standard_mc(beta, n, step)
+        return np.asarray(Es), np.asarray(acc, np.float64)[:, None]
     Es, Emin, Cmin, itmin = eng.extremal_opt(tau, n, step)
     return np.asarray(Es), np.concatenate([np.asarray(Emin, np.float64)[:, None], np.asarray(itmin, np.float64)[:, None], np.asarray(Cmin.s, np.float64)], 1)
 
@@ -89,7 +92,7 @@ envs = [{}, {"RRRMC_RRR_NO_WAVE": "1"}, {"RRRMC_RRR_NO_WAVE": "1", "RRRMC_RRR_NO
 bad, t0, units = 0, time.time(), 0
 for case in range(CASES):
     kind = kinds[int(rng.integers(len(kinds)))]
-    smp = ["rrr", "bkl", "wtm", "eo"][int(rng.integers(4))]
+    smp = ["rrr", "bkl", "wtm", "eo", "std"][int(rng.integers(5))]
     seed = int(rng.integers(1, 1 << 30))
     X = graph(kind, seed)
     R = int(rng.choice([1, 2, 33, 64, 65, 130, 300]))
@@ -102,6 +105,11 @@ for case in range(CASES):
         pieces, left = [], total
         while left:
             n = int(rng.integers(1, left + 1)); pieces.append(n); left -= n
+    elif smp == "std":                                                       # standardMC's contract: cuts at the hook points (multiples of `step`)
+        nst = int(rng.integers(2, 40))
+        total = nst * step
+        cuts = sorted(set(int(c) * step for c in rng.integers(0, nst + 1, size=int(rng.integers(1, 5)))) - {0, total})
+        pieces = [b - a for a, b in zip([0] + cuts, cuts + [total])]
     else:
         total = int(rng.integers(20, 1500))
         cuts = sorted(set(int(c) for c in rng.integers(0, total + 1, size=int(rng.integers(1, 6)))) - {0, total})
