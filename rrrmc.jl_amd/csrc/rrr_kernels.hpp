@@ -1546,8 +1546,8 @@ struct SparseChain {
     template <int NB, int KM = NB>
     __device__ double apply_move(int move)
     {
-        sflip(move);
         if constexpr (LDS || KM > 6) {
+            sflip(move);
             // the LDS build has no memory latency to hide, and eight (or sixteen) slots of as many row entries do not fit the registers: the
             // reference's loop as it stands
             double zp = z;
@@ -1574,9 +1574,12 @@ struct SparseChain {
             //   1. the moved spin's row of the table;  2. per neighbour its class byte, its position, its word of spins, its own row;
             //   3. the words of its neighbours' spins -> delta_energy, the new class;  4. the last member of every set that may lose a site.
             const int K = cfg.K;
+            // (the flip: its word is requested WITH the row — read on its own, before everything else, it is a round trip of its own)
+            const uint32_t wm = sp[move >> 5];
             int y[KM], cj[KM];
 #pragma unroll
             for (int q = 0; q < KM; ++q) { const size_t e = (size_t)move * K + (q < K ? q : 0); y[q] = cfg.A[e]; cj[q] = (int)cfg.J[e]; }
+            sp[move >> 5] = wm ^ (1u << (move & 31));
             bool val[KM];
 #pragma unroll
             for (int q = 0; q < KM; ++q) val[q] = q < K && !(q > 0 && y[q] == y[q - 1]) && !(cfg.skip_zero && cj[q] == 0);      // is_nb
@@ -2051,57 +2054,73 @@ struct EoParams {
 constexpr int kEoFtauLdsMaxN = 16384;
 // `E < Emin && (Emin = E; copy!(Cmin, C))` (RRRMC.jl:508-512) is a copy of the whole configuration at every new minimum — every other
 // iteration while a run descends from its random start.  Cmin differs from C by the flips made since the last minimum: up to kEoPend of
-// them are kept per replica and a new minimum toggles those bits of Cmin instead of copying W words; a longer stretch without a minimum
+// them are kept per replica and a new minimum toggles those bits of Cmin (atomics without a return value) instead of copying W words; a longer stretch without a minimum
 // (or a resumed call, whose pending flips are not kept) falls back to the copy.  Same Cmin, bit for bit.
-constexpr int kEoPend = 32;
+constexpr int kEoPend = 96;
 inline size_t eo_sparse_lds_bytes(int64_t N, bool ftau_lds, unsigned tpb) { return (ftau_lds ? sizeof(double) * (size_t)N : 0) + sizeof(uint32_t) * kEoPend * tpb; }
 
-// The last two members of every class list, followed through the pushes and pops of ONE apply_move! in registers.  A set move
+// The last D members of every class list, followed through the pushes and pops of ONE apply_move! in registers.  A set move
 // (ArraySet delete! + push!, ArraySets.jl:56-76) needs the LAST member of the list it deletes from; gathered before the set moves start, that
 // value is stale as soon as an earlier move of the same iteration touched the list, and re-reading it is a dependent memory round trip in
-// the middle of the store sequence (a fifth of eo_sparse_kernel's time, profiles/r06/f8_floor.md §3).  A push makes the pushed site the last
-// member and the old last the one before; a pop exposes the member before the last (known if it was gathered or pushed), or the moved
-// member itself when the deleted site sat right before the end.  Only a list popped twice beyond what is known falls back to the read.
+// the middle of the store sequence — and with sixteen replicas per wavefront one lane that needs it makes all of them wait (a fifth of
+// eo_sparse_kernel's time, profiles/r06/f8_floor.md §3).  A push makes the pushed site the last member; a pop exposes the member before
+// (known if it was gathered or pushed) and puts the old last member where the deleted site sat — inside the known window or not.  With
+// D = 4 a move of a K = 3 graph (four set moves) never reads a list's end again; beyond what is known the read remains.
 // NC = compile-time bound on the number of classes; all accesses are unrolled selects (registers).
-template <int NC>
+template <int NC, int D>
 struct TailTrack {
-    int l1[NC], l2[NC];
-    unsigned ok1, ok2;
-    __device__ __forceinline__ void clear() { ok1 = 0u; ok2 = 0u;
+    int e[D][NC];            // e[i][c]: the i-th member from the end of list c
+    int kn[NC];              // how many of them are known
+    __device__ __forceinline__ void clear() {
 #pragma unroll
-        for (int a = 0; a < NC; ++a) { l1[a] = 0; l2[a] = 0; } }
-    __device__ __forceinline__ int get1(int c) const { int x = 0;
+        for (int a = 0; a < NC; ++a) { kn[a] = 0;
 #pragma unroll
-        for (int a = 0; a < NC; ++a) x = c == a ? l1[a] : x;
+            for (int i = 0; i < D; ++i) e[i][a] = 0; } }
+    __device__ __forceinline__ int known(int c) const { int x = 0;
+#pragma unroll
+        for (int a = 0; a < NC; ++a) x = c == a ? kn[a] : x;
         return x; }
-    __device__ __forceinline__ int get2(int c) const { int x = 0;
+    __device__ __forceinline__ int last(int c) const { int x = 0;
 #pragma unroll
-        for (int a = 0; a < NC; ++a) x = c == a ? l2[a] : x;
+        for (int a = 0; a < NC; ++a) x = c == a ? e[0][a] : x;
         return x; }
-    __device__ __forceinline__ void set1(int c, int v) {
+    struct Ends { int v[D]; };                         // (by value: a reference to a local array would pin it in scratch memory)
+    // what the gather read at the end of list c (count n at that time): w.v[i] = member n - 1 - i
+    __device__ __forceinline__ void note(int c, int n, Ends w) {
 #pragma unroll
-        for (int a = 0; a < NC; ++a) l1[a] = c == a ? v : l1[a];
-        ok1 |= 1u << c; }
-    __device__ __forceinline__ void set2(int c, int v) {
+        for (int a = 0; a < NC; ++a) {
+            kn[a] = c == a ? (n < D ? n : D) : kn[a];
 #pragma unroll
-        for (int a = 0; a < NC; ++a) l2[a] = c == a ? v : l2[a];
-        ok2 |= 1u << c; }
-    __device__ __forceinline__ bool has1(int c) const { return (ok1 >> c) & 1u; }
-    __device__ __forceinline__ bool has2(int c) const { return (ok2 >> c) & 1u; }
-    // what the gather read at the end of list c (count n at that time)
-    __device__ __forceinline__ void note(int c, int n, int last, int before) { if (n >= 1) set1(c, last); if (n >= 2) set2(c, before); }
-    // list c (count n before) lost the member at position p; `last` was moved there
-    __device__ __forceinline__ void popped(int c, int n, int p, int last)
+            for (int i = 0; i < D; ++i) e[i][a] = c == a ? w.v[i] : e[i][a];
+        } }
+    // list c (count n before) lost the member at position p; `lastm` (its last member) was moved there
+    __device__ __forceinline__ void popped(int c, int n, int p, int lastm)
     {
-        if (p == n - 2) set1(c, last);
-        else if (has2(c)) set1(c, get2(c));
-        else ok1 &= ~(1u << c);
-        ok2 &= ~(1u << c);
+        const int idx = n - 2 - p;                       // where position p sits from the end of the shorter list (-1: the deleted site was the last)
+#pragma unroll
+        for (int a = 0; a < NC; ++a) {
+            const bool me = c == a;
+            int nk = kn[a] > 0 ? kn[a] - 1 : 0;
+#pragma unroll
+            for (int i = 0; i < D; ++i) {
+                const int shifted = i + 1 < D ? e[i + 1 < D ? i + 1 : i][a] : e[i][a];
+                const int x = (idx == i && i <= nk) ? lastm : shifted;                       // inside the known window, or right behind it
+                e[i][a] = me ? x : e[i][a];
+            }
+            if (idx >= 0 && idx == nk && nk < D) nk += 1;
+            kn[a] = me ? nk : kn[a];
+        }
     }
     __device__ __forceinline__ void pushed(int c, int j)
     {
-        if (has1(c)) set2(c, get1(c)); else ok2 &= ~(1u << c);
-        set1(c, j);
+#pragma unroll
+        for (int a = 0; a < NC; ++a) {
+            const bool me = c == a;
+#pragma unroll
+            for (int i = D - 1; i >= 1; --i) e[i][a] = me ? e[i - 1][a] : e[i][a];
+            e[0][a] = me ? j : e[0][a];
+            kn[a] = me ? (kn[a] < D ? kn[a] + 1 : D) : kn[a];
+        }
     }
 };
 
@@ -2156,12 +2175,13 @@ __global__ __launch_bounds__(kRrrThreads) void eo_sparse_kernel(EoParams P)
         return (d >= 0 ? ak + L - P.has_zero : L + 1 - ak) - 1;
     };
     // one set move (ArraySet delete!(k0, j) + push!(k1, j), ArraySets.jl:56-76) with the lists' ends followed in registers
-    TailTrack<NC> tk;
+    constexpr int TD = 4;                        // list members followed from the end
+    TailTrack<NC, TD> tk;
     auto set_move = [&](int j, int k0, int k1, int p) __attribute__((always_inline)) -> int {
         IDX* v0 = sv + (size_t)k0 * N;
         IDX* v1 = sv + (size_t)k1 * N;
         const int n0 = tg(k0);
-        const int last = tk.has1(k0) ? tk.get1(k0) : (int)v0[n0 - 1];
+        const int last = tk.known(k0) > 0 ? tk.last(k0) : (int)v0[n0 - 1];
         v0[p] = (IDX)last; spos[last] = (IDX)p; tadd(k0, -1);
         tk.popped(k0, n0, p, last);
         const int n1 = tg(k1);
@@ -2174,9 +2194,12 @@ __global__ __launch_bounds__(kRrrThreads) void eo_sparse_kernel(EoParams P)
         constexpr int KM = decltype(km)::value;
         int sj[KM + 1], s0[KM + 1], s1[KM + 1], sp_[KM + 1];
         bool live[KM + 1];
+        // (the flip: its word is requested WITH the row — read on its own, before everything else, it is a round trip of its own)
+        const uint32_t wm = sp[move >> 5];
         int y[KM], cj[KM];
 #pragma unroll
         for (int q = 0; q < KM; ++q) { const size_t e = (size_t)move * K + (q < K ? q : 0); y[q] = P.A[e]; cj[q] = (int)P.J[e]; }
+        sp[move >> 5] = wm ^ (1u << (move & 31));
         bool val[KM];
 #pragma unroll
         for (int q = 0; q < KM; ++q) val[q] = q < K && !(q > 0 && y[q] == y[q - 1]) && !(P.lv.skip_zero && cj[q] == 0);     // uA (EA.jl:158, RRG.jl:133)
@@ -2196,14 +2219,15 @@ __global__ __launch_bounds__(kRrrThreads) void eo_sparse_kernel(EoParams P)
         for (int q = 0; q < KM; ++q)
 #pragma unroll
             for (int k = 0; k < KM; ++k) wnb[q][k] = sp[yy[q][k] >> 5];
-        // the ends of the lists that may lose a site: last member and the one before (independent of the spin words: same trip)
-        int e1[KM + 1], e2[KM + 1], en[KM + 1];
+        // the ends of the lists that may lose a site: their last TD members (independent of the spin words: same trip)
+        typename TailTrack<NC, TD>::Ends ee[KM + 1];
+        int en[KM + 1];
 #pragma unroll
         for (int q = 0; q <= KM; ++q) {
             const int n = tg(s0[q]);
             en[q] = n;
-            e1[q] = (int)sv[(size_t)s0[q] * N + (n > 0 ? n - 1 : 0)];
-            e2[q] = (int)sv[(size_t)s0[q] * N + (n > 1 ? n - 2 : 0)];
+#pragma unroll
+            for (int i = 0; i < TD; ++i) ee[q].v[i] = (int)sv[(size_t)s0[q] * N + (n > i ? n - 1 - i : 0)];
         }
 #pragma unroll
         for (int q = 0; q < KM; ++q) {
@@ -2222,7 +2246,7 @@ __global__ __launch_bounds__(kRrrThreads) void eo_sparse_kernel(EoParams P)
         }
         tk.clear();
 #pragma unroll
-        for (int q = 0; q <= KM; ++q) tk.note(s0[q], en[q], e1[q], e2[q]);
+        for (int q = 0; q <= KM; ++q) tk.note(s0[q], en[q], ee[q]);
 #pragma unroll
         for (int q = 0; q <= KM; ++q) {
             if (!live[q]) continue;
@@ -2293,8 +2317,8 @@ __global__ __launch_bounds__(kRrrThreads) void eo_sparse_kernel(EoParams P)
         const int dE = k < L ? -dEa : dEa;
         const int move = sv[(size_t)k * N + (int)mulhi64(((uint64_t)o.w[2] << 32) | o.w[3], (uint64_t)tg(k))];
         // apply_move!: DeltaE.jl:509-541
-        sp[move >> 5] ^= 1u << (move & 31);
         if (npend < kEoPend) { pend[npend * pstride] = (uint32_t)move; npend += 1; } else pend_over = true;
+        if (K > 6) sp[move >> 5] ^= 1u << (move & 31);        // (the gathered forms flip with their first stage)
         if (K <= 6) {
             // the K + 1 sites gathered stage by stage, every load of a stage issued before any is used, then the set moves in the reference's
             // order on the gathered values — SparseChain::apply_move's scheme (above); slot q < KM = neighbour q, slot KM = the moved spin
@@ -2317,7 +2341,7 @@ __global__ __launch_bounds__(kRrrThreads) void eo_sparse_kernel(EoParams P)
         if (E < Emin) {
             Emin = E; itmin = P.S.it0 + it;
             if (pend_over) { for (int w = 0; w < P.W; ++w) cm[w] = sp[w]; }
-            else for (int q = 0; q < npend; ++q) { const uint32_t x = pend[q * pstride]; cm[x >> 5] ^= 1u << (x & 31); }
+            else for (int q = 0; q < npend; ++q) { const uint32_t x = pend[q * pstride]; atomicXor(&cm[x >> 5], 1u << (x & 31)); }    // (no value comes back: nothing waits)
             npend = 0; pend_over = false;
         }
     }
