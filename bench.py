@@ -664,9 +664,9 @@ def secondary_f8_rrr(pkg, O, device):
         it2, Ji = 1 << 18, X.J.astype(np.int32)
         cpu_all_cores_entry(out, out["cpu_one_core"]["value"], "iterations/s",
                             timed_oracle_all_cores("rrr_sparse", (X.A, Ji, beta, it2, it2, SEED, None), {}, 6, [C1], it2, nc), "x 2^18-iteration calls from the quenched configuration")
-    out["bound"] = "latency: one thread per replica, 5 dependent HBM round trips + 1 237 issued instructions per iteration (profiles/r06/f8_floor.md)"
-    out["bound_frac"] = 9450.0 / max(k_ms * 1e-3 * 2.4e9 / iters, 1.0)
-    out["bound_frac_meaning"] = "the floor of f8_floor.md §1 (9 450 cycles per iteration of a wavefront) over this run's cycles per iteration at 2.4 GHz"
+    out["bound"] = "latency: one thread per replica, 4 dependent HBM round trips + 1 237 issued instructions per iteration (profiles/r06/f8_floor.md)"
+    out["bound_frac"] = 8550.0 / max(k_ms * 1e-3 * 2.4e9 / iters, 1.0)
+    out["bound_frac_meaning"] = "the floor of f8_floor.md §1 (8 550 cycles per iteration of a wavefront) over this run's cycles per iteration at 2.4 GHz"
     return out
 
 
