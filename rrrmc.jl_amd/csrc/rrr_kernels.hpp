@@ -1448,6 +1448,71 @@ struct RrrSparseParams {
 // are LDS copies
 // SLM = compile-time bound on the number of levels (2, 4 or 8): the per-class arrays have 2 SLM entries and must stay in REGISTERS
 // (dynamically indexed arrays of 16 doubles end up in scratch memory, a memory round trip per access: 5x slower kernels)
+// The last D members of every class list, followed through the pushes and pops of ONE apply_move! in registers.  A set move
+// (ArraySet delete! + push!, ArraySets.jl:56-76) needs the LAST member of the list it deletes from; gathered before the set moves start, that
+// value is stale as soon as an earlier move of the same iteration touched the list, and re-reading it is a dependent memory round trip in
+// the middle of the store sequence — and with sixteen replicas per wavefront one lane that needs it makes all of them wait (a fifth of
+// eo_sparse_kernel's time, profiles/r06/f8_floor.md §3).  A push makes the pushed site the last member; a pop exposes the member before
+// (known if it was gathered or pushed) and puts the old last member where the deleted site sat — inside the known window or not.  With
+// D = 4 a move of a K = 3 graph (four set moves) never reads a list's end again; beyond what is known the read remains.
+// NC = compile-time bound on the number of classes; all accesses are unrolled selects (registers).
+template <int NC, int D>
+struct TailTrack {
+    int e[D][NC];            // e[i][c]: the i-th member from the end of list c
+    int kn[NC];              // how many of them are known
+    __device__ __forceinline__ void clear() {
+#pragma unroll
+        for (int a = 0; a < NC; ++a) { kn[a] = 0;
+#pragma unroll
+            for (int i = 0; i < D; ++i) e[i][a] = 0; } }
+    __device__ __forceinline__ int known(int c) const { int x = 0;
+#pragma unroll
+        for (int a = 0; a < NC; ++a) x = c == a ? kn[a] : x;
+        return x; }
+    __device__ __forceinline__ int last(int c) const { int x = 0;
+#pragma unroll
+        for (int a = 0; a < NC; ++a) x = c == a ? e[0][a] : x;
+        return x; }
+    struct Ends { int v[D]; };                         // (by value: a reference to a local array would pin it in scratch memory)
+    // what the gather read at the end of list c (count n at that time): w.v[i] = member n - 1 - i
+    __device__ __forceinline__ void note(int c, int n, Ends w) {
+#pragma unroll
+        for (int a = 0; a < NC; ++a) {
+            kn[a] = c == a ? (n < D ? n : D) : kn[a];
+#pragma unroll
+            for (int i = 0; i < D; ++i) e[i][a] = c == a ? w.v[i] : e[i][a];
+        } }
+    // list c (count n before) lost the member at position p; `lastm` (its last member) was moved there
+    __device__ __forceinline__ void popped(int c, int n, int p, int lastm)
+    {
+        const int idx = n - 2 - p;                       // where position p sits from the end of the shorter list (-1: the deleted site was the last)
+#pragma unroll
+        for (int a = 0; a < NC; ++a) {
+            const bool me = c == a;
+            int nk = kn[a] > 0 ? kn[a] - 1 : 0;
+#pragma unroll
+            for (int i = 0; i < D; ++i) {
+                const int shifted = i + 1 < D ? e[i + 1 < D ? i + 1 : i][a] : e[i][a];
+                const int x = (idx == i && i <= nk) ? lastm : shifted;                       // inside the known window, or right behind it
+                e[i][a] = me ? x : e[i][a];
+            }
+            if (idx >= 0 && idx == nk && nk < D) nk += 1;
+            kn[a] = me ? nk : kn[a];
+        }
+    }
+    __device__ __forceinline__ void pushed(int c, int j)
+    {
+#pragma unroll
+        for (int a = 0; a < NC; ++a) {
+            const bool me = c == a;
+#pragma unroll
+            for (int i = D - 1; i >= 1; --i) e[i][a] = me ? e[i - 1][a] : e[i][a];
+            e[0][a] = me ? j : e[0][a];
+            kn[a] = me ? (kn[a] < D ? kn[a] + 1 : D) : kn[a];
+        }
+    }
+};
+
 template <bool LDS, int SLM, typename IDX = uint16_t>
 struct SparseChain {
     // copies of the few parameters the chain needs: a pointer to the kernel's parameter struct would force that struct — and every
@@ -1613,6 +1678,9 @@ struct SparseChain {
 #pragma unroll
             for (int q = 0; q <= KM; ++q) { const int tq = tg(s0[q]); sl[q] = (int)sv[(size_t)s0[q] * cfg.N + (tq > 0 ? tq - 1 : 0)]; }
         }
+        // (following the lists' ends in registers instead — TailTrack, as eo_sparse_kernel does, with the re-read behind a real branch — makes the
+        // set moves free of loads and waits, and this kernel a third SLOWER: 120 against 92 ms, measured twice; it is at the edge of its
+        // registers, 147 scalar ones spilled, with three gather sizes inlined at three call sites: profiles/r06/f8_floor.md)
         double zp = z;
         unsigned touched = 0u;
 #pragma unroll
@@ -2059,71 +2127,6 @@ constexpr int kEoFtauLdsMaxN = 16384;
 constexpr int kEoPend = 96;
 inline size_t eo_sparse_lds_bytes(int64_t N, bool ftau_lds, unsigned tpb) { return (ftau_lds ? sizeof(double) * (size_t)N : 0) + sizeof(uint32_t) * kEoPend * tpb; }
 
-// The last D members of every class list, followed through the pushes and pops of ONE apply_move! in registers.  A set move
-// (ArraySet delete! + push!, ArraySets.jl:56-76) needs the LAST member of the list it deletes from; gathered before the set moves start, that
-// value is stale as soon as an earlier move of the same iteration touched the list, and re-reading it is a dependent memory round trip in
-// the middle of the store sequence — and with sixteen replicas per wavefront one lane that needs it makes all of them wait (a fifth of
-// eo_sparse_kernel's time, profiles/r06/f8_floor.md §3).  A push makes the pushed site the last member; a pop exposes the member before
-// (known if it was gathered or pushed) and puts the old last member where the deleted site sat — inside the known window or not.  With
-// D = 4 a move of a K = 3 graph (four set moves) never reads a list's end again; beyond what is known the read remains.
-// NC = compile-time bound on the number of classes; all accesses are unrolled selects (registers).
-template <int NC, int D>
-struct TailTrack {
-    int e[D][NC];            // e[i][c]: the i-th member from the end of list c
-    int kn[NC];              // how many of them are known
-    __device__ __forceinline__ void clear() {
-#pragma unroll
-        for (int a = 0; a < NC; ++a) { kn[a] = 0;
-#pragma unroll
-            for (int i = 0; i < D; ++i) e[i][a] = 0; } }
-    __device__ __forceinline__ int known(int c) const { int x = 0;
-#pragma unroll
-        for (int a = 0; a < NC; ++a) x = c == a ? kn[a] : x;
-        return x; }
-    __device__ __forceinline__ int last(int c) const { int x = 0;
-#pragma unroll
-        for (int a = 0; a < NC; ++a) x = c == a ? e[0][a] : x;
-        return x; }
-    struct Ends { int v[D]; };                         // (by value: a reference to a local array would pin it in scratch memory)
-    // what the gather read at the end of list c (count n at that time): w.v[i] = member n - 1 - i
-    __device__ __forceinline__ void note(int c, int n, Ends w) {
-#pragma unroll
-        for (int a = 0; a < NC; ++a) {
-            kn[a] = c == a ? (n < D ? n : D) : kn[a];
-#pragma unroll
-            for (int i = 0; i < D; ++i) e[i][a] = c == a ? w.v[i] : e[i][a];
-        } }
-    // list c (count n before) lost the member at position p; `lastm` (its last member) was moved there
-    __device__ __forceinline__ void popped(int c, int n, int p, int lastm)
-    {
-        const int idx = n - 2 - p;                       // where position p sits from the end of the shorter list (-1: the deleted site was the last)
-#pragma unroll
-        for (int a = 0; a < NC; ++a) {
-            const bool me = c == a;
-            int nk = kn[a] > 0 ? kn[a] - 1 : 0;
-#pragma unroll
-            for (int i = 0; i < D; ++i) {
-                const int shifted = i + 1 < D ? e[i + 1 < D ? i + 1 : i][a] : e[i][a];
-                const int x = (idx == i && i <= nk) ? lastm : shifted;                       // inside the known window, or right behind it
-                e[i][a] = me ? x : e[i][a];
-            }
-            if (idx >= 0 && idx == nk && nk < D) nk += 1;
-            kn[a] = me ? nk : kn[a];
-        }
-    }
-    __device__ __forceinline__ void pushed(int c, int j)
-    {
-#pragma unroll
-        for (int a = 0; a < NC; ++a) {
-            const bool me = c == a;
-#pragma unroll
-            for (int i = D - 1; i >= 1; --i) e[i][a] = me ? e[i - 1][a] : e[i][a];
-            e[0][a] = me ? j : e[0][a];
-            kn[a] = me ? (kn[a] < D ? kn[a] + 1 : D) : kn[a];
-        }
-    }
-};
-
 // SLM = compile-time bound on the levels of allΔE (2, 4 or 8): the class counters are indexed through unrolled selects of that length
 template <typename IDX, int SLM>
 __global__ __launch_bounds__(kRrrThreads) void eo_sparse_kernel(EoParams P)
@@ -2181,7 +2184,10 @@ __global__ __launch_bounds__(kRrrThreads) void eo_sparse_kernel(EoParams P)
         IDX* v0 = sv + (size_t)k0 * N;
         IDX* v1 = sv + (size_t)k1 * N;
         const int n0 = tg(k0);
-        const int last = tk.known(k0) > 0 ? tk.last(k0) : (int)v0[n0 - 1];
+        // (a real branch: written as a select the compiler reads the list's end speculatively in EVERY set move, and the wait for it —
+        // vmcnt(0): stores count too on gfx9 — also drains the previous set move's stores, one round trip per set move)
+        int last = tk.last(k0);
+        if (__builtin_expect(tk.known(k0) <= 0, 0)) { last = (int)v0[n0 - 1]; asm volatile("" : "+v"(last)); }
         v0[p] = (IDX)last; spos[last] = (IDX)p; tadd(k0, -1);
         tk.popped(k0, n0, p, last);
         const int n1 = tg(k1);
@@ -2301,6 +2307,7 @@ __global__ __launch_bounds__(kRrrThreads) void eo_sparse_kernel(EoParams P)
                 const int mid = (lo + hi) >> 1;
                 const int ml = (lo + mid) >> 1, mr = (mid + 1 + hi) >> 1;
                 const double xm = eo_ftau_lds[mid], xl = eo_ftau_lds[ml < N ? ml : N - 1], xr = eo_ftau_lds[mr < N ? mr : N - 1];
+                asm volatile("" :: "v"(xm), "v"(xl), "v"(xr));             // (all three here: sunk into the branches below they are two round trips again)
                 if (xm < rr) { lo = mid + 1; if (lo < hi) { if (xr < rr) lo = mr + 1; else hi = mr; } }
                 else { hi = mid; if (lo < hi) { if (xl < rr) lo = ml + 1; else hi = ml; } }
             }
