@@ -2010,6 +2010,9 @@ int32_t rrrmc_energy_f64(rrrmc_ctx* ctx, double* E_out)
         rc = spf_run_energy(ctx);
     } else if (ctx->model == RRRMC_MODEL_SPARSE_DISCRETIZED) {
         rc = dbl_run_energy(ctx);
+        // (this evaluation leaves the residual fields as they are and overwrites the tracked energy: what a resumed standardMC would find is
+        // neither the run's state nor a fresh one — the next call starts fresh, as after the other models' energy calls, which rebuild in place)
+        ctx->std_cache_live = false;
     } else {
         rc = sk_run_energy(ctx);
     }
