@@ -66,11 +66,11 @@ def call(eng, smp, n, step, beta, tau, thr):
     return np.asarray(Es), np.concatenate([np.asarray(Emin, np.float64)[:, None], np.asarray(itmin, np.float64)[:, None], np.asarray(Cmin.s, np.float64)], 1)
 
 
-def run(X, R, smp, pieces, step, beta, tau, thr, seed, env):
+def run(X, R, smp, pieces, step, beta, tau, thr, seed, env, shards=False):
     for k in BUILD_KEYS:
         os.environ.pop(k, None)
     os.environ.update(env)
-    with pkg.Engine(X, R) as eng:
+    with (pkg.Engine(X, R, devices=[0, 0]) if shards else pkg.Engine(X, R)) as eng:          # two shards of one multi-device context on this GPU
         eng.seed(seed)
         eng.init_spins_random()
         Es, cnt = [], None
@@ -114,9 +114,10 @@ for case in range(CASES):
         total = int(rng.integers(20, 1500))
         cuts = sorted(set(int(c) for c in rng.integers(0, total + 1, size=int(rng.integers(1, 6)))) - {0, total})
         pieces = [b - a for a, b in zip([0] + cuts, cuts + [total])]
+    shards = bool(R >= 64 and rng.integers(4) == 0)
     try:
         one = run(X, R, smp, [total], step, beta, tau, thr, seed, env)
-        cut = run(X, R, smp, pieces, step, beta, tau, thr, seed, env)
+        cut = run(X, R, smp, pieces, step, beta, tau, thr, seed, env, shards)          # (and the sharded run against the single context)
     except pkg.RRRMCError as err:                                            # a combination the library refuses (both ways alike)
         print(json.dumps({"case": case, "kind": kind, "smp": smp, "skipped": str(err)[:100]}), flush=True)
         continue
@@ -133,6 +134,6 @@ for case in range(CASES):
                 print(json.dumps({"first_Es_diff": [int(rr[0]), int(cc[0])], "one": float(one[0][rr[0], cc[0]]), "cut": float(cut[0][rr[0], cc[0]]),
                                   "n_diff": int(len(rr))}), flush=True)
     print(json.dumps({"case": case, "kind": kind, "N": int(X.N), "smp": smp, "R": R, "step": step, "pieces": pieces, "beta": beta, "thr": thr,
-                      "env": env, "same": bool(same)}), flush=True)
+                      "env": env, "shards": shards, "same": bool(same)}), flush=True)
 print(json.dumps({"cases": CASES, "mismatches": bad, "replica_units": units, "seconds": round(time.time() - t0, 1)}), flush=True)
 sys.exit(1 if bad else 0)
