@@ -4,7 +4,7 @@ followed in registers, rrr_dbl_kernel with its gathered staged step): random gra
 bonds), temperatures, staged thresholds, kernel builds — a few replicas of every case against the ORACLE (tests/ infrastructure: this tool
 is a test, it ships nothing).
 
-  python3 tools/gather_soak.py [cases] [seed]     -> one line per case, a summary line; exit code 1 on a mismatch"""
+  python3 tests/soak/gather_soak.py [cases] [seed]     -> one line per case, a summary line; exit code 1 on a mismatch"""
 import json
 import os
 import sys
@@ -12,7 +12,7 @@ import time
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "oracle"))
 import __graft_entry__ as e  # noqa: E402

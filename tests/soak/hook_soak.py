@@ -4,7 +4,7 @@ POINTS — a run made in one call against the same run cut into resumed calls of
 for bit: samples, final configuration, tracked energy, counts, and the DeltaECache where the model has one.  GPU against GPU (the oracle
 is not involved: tests/test_gpu_hooks.py pins both to it on fixed cases).
 
-  python3 tools/hook_soak.py [cases] [seed]        -> one line per case, a summary line at the end; exit code 1 on a mismatch"""
+  python3 tests/soak/hook_soak.py [cases] [seed]        -> one line per case, a summary line at the end; exit code 1 on a mismatch"""
 import json
 import os
 import sys
@@ -12,7 +12,7 @@ import time
 
 import numpy as np
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import __graft_entry__ as e  # noqa: E402
 
 pkg = e.load_package()

@@ -3,7 +3,7 @@
 its doubled bonds, chains, 2D, 3D), Trotter numbers, fields, temperatures and all five samplers — a few replicas of every case against the
 ORACLE (orc_*_quant_spf), bit for bit.
 
-  python3 tools/qeat_soak.py [cases] [seed]"""
+  python3 tests/soak/qeat_soak.py [cases] [seed]"""
 import json
 import os
 import sys
@@ -11,7 +11,7 @@ import time
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "oracle"))
 import __graft_entry__ as e  # noqa: E402

@@ -4,7 +4,7 @@ chunk tables, two sets of plan buffers): random +-J graphs (K = 3 .. 6, lattices
 asynchronous standardMC calls of changing (iters, step) — queued back to back against the same calls with a sync after each (everything
 compared), and the last call of some replicas against the oracle.
 
-  python3 tools/queue_soak.py [cases] [seed]"""
+  python3 tests/soak/queue_soak.py [cases] [seed]"""
 import json
 import os
 import sys
@@ -12,7 +12,7 @@ import time
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "oracle"))
 import __graft_entry__ as e  # noqa: E402

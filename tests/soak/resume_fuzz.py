@@ -6,7 +6,7 @@
       next call start a fresh run — i.e. behave exactly as the same call with resume switched off.
 Random graph families, samplers, replica counts.  GPU against GPU; one line per case, exit code 1 on a mismatch.
 
-  python3 tools/resume_fuzz.py [cases] [seed]"""
+  python3 tests/soak/resume_fuzz.py [cases] [seed]"""
 import json
 import os
 import sys
@@ -14,7 +14,7 @@ import time
 
 import numpy as np
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import __graft_entry__ as e  # noqa: E402
 
 pkg = e.load_package()

@@ -1,5 +1,5 @@
 """One-off (GPU box): dense-SK standardMC calls longer than one segment of the blocked kernel (65 536 iterations) against the oracle,
-Gaussian and binary couplings, sample steps that straddle segment boundaries.  python tools/dbg/sk_long.py"""
+Gaussian and binary couplings, sample steps that straddle segment boundaries.  python tests/soak/sk_long.py"""
 import os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

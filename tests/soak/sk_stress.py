@@ -1,6 +1,6 @@
 """One-off stress of the dense-SK standardMC kernels against the oracle (GPU box): seeded random (N, R, beta, iters, step) incl. tiny N
 (duplicate sites inside a 64-attempt block, consecutive moves at one site: the array-swap undo), beta = 0 (every move accepted) and large beta,
-sample points on and off block boundaries, resumed calls.  python tools/dbg/sk_stress.py [cases] [seed] [binary]  (binary: GraphSK, the integer-field model)"""
+sample points on and off block boundaries, resumed calls.  python tests/soak/sk_stress.py [cases] [seed] [binary]  (binary: GraphSK, the integer-field model)"""
 import os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

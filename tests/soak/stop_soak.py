@@ -4,7 +4,7 @@ sample at which its hook returns false — every replica's samples, final config
 iteration is not made) and, for extremal_opt, Emin / Cmin / itmin against the ORACLE run with the same stopping hook (the oracle calls a C
 hook at the reference's sample points).  Graph families and oracle adapters are those of tests/test_gpu_hooks.py.
 
-  python3 tools/stop_soak.py [cases] [seed]"""
+  python3 tests/soak/stop_soak.py [cases] [seed]"""
 import json
 import os
 import sys
@@ -12,7 +12,7 @@ import time
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "oracle"))
 sys.path.insert(0, os.path.join(ROOT, "tests"))

@@ -488,7 +488,7 @@ BKL_CUTS = [(10, [6, 95, 15]), (3, [72, 63, 1, 260, 656]), (50, [18, 11, 41, 108
 def test_bkl_run_cut_anywhere_is_the_run_made_in_one_call(pkg, oracle, monkeypatch, name, build, step, pieces):
     """bklMC's loop (RRRMC.jl:327-350) jumps over skipped iterations and ends with its LAST SAMPLE: a resumed call whose allowance ends between
     two sample points must neither take the sample that lies beyond it nor — once the run's last sample is taken — make another move.
-    Found by tools/hook_soak.py: pieces shorter than `step` at the start, a piece of one iteration right after a sample point."""
+    Found by tests/soak/hook_soak.py: pieces shorter than `step` at the start, a piece of one iteration right after a sample point."""
     for k in ("RRRMC_RRR_NO_WAVE", "RRRMC_RRR_NO_LDS", "RRRMC_CONT_NO_WAVE"):
         monkeypatch.delenv(k, raising=False)
     for k, v in build.items():
