@@ -670,6 +670,59 @@ def secondary_f8_rrr(pkg, O, device):
     return out
 
 
+def secondary_f8_eo(pkg, O, device):
+    """SURVEY.md §8f rank 4 at the reference's experiment size: extremal_opt (src/RRRMC.jl:474-521, EOCache{Int,2}: src/DeltaE.jl:412-555) on
+    GraphRRG(10^4, 3), tau = 1.3, from random spins — eo_sparse_kernel, one thread per replica (rank table in LDS, staged gather, lazy Cmin)."""
+    N, K, R, tau, iters, step = 10000, 3, 4096, 1.3, 20000, 5000
+    X = pkg.GraphRRG(N, K, seed=SEED)
+    with pkg.Engine(X, R, device=device) as eng:
+        eng.seed(SEED)
+        eng.init_spins_random()
+        C0 = eng.get_config().s[0].copy()
+        t0 = time.perf_counter()
+        eng.extremal_opt(tau, iters, step)
+        dt = time.perf_counter() - t0
+        _, k_ms, nl = eng.last_timing()
+    out = {"workload": "GraphRRG(N=10000,K=3,+-J) extremal_opt tau=1.3, 4096 replicas, 20000 iterations per replica from random spins",
+           "value": R * iters / dt, "unit": "iterations/s", "kernel": "eo_sparse_kernel<unsigned short, 2>", "avg_launch_ms": k_ms / max(nl, 1), "launches": nl,
+           "bound": "latency: one thread per replica (profiles/r06/f8_floor.md §3)", "bound_frac": None}
+    if O is not None:
+        with pinned_core():
+            it1, Ji = 1 << 18, X.J.astype(np.int32)
+            v, n, dt1 = timed_oracle(lambda k: O.extremal_opt_sparse(X.A, Ji, tau, it1, it1, SEED, C0, it0=k * it1), it1)
+            out["cpu_one_core"] = {"value": v, "unit": "iterations/s", "kind": "port", "build": O.flavour,
+                                   "sample": "1 replica x %d x 2^18 iterations from random spins, each call a fresh run (%.1f s), oracle" % (n, dt1)}
+    return out
+
+
+def secondary_f8_dbl(pkg, O, device):
+    """SURVEY.md §8f rank 3 (second part) at the same size: rrrMC(X::DoubleGraph) (src/RRRMC.jl:221-290) on GraphRRGNormalDiscretized(10^4, 3,
+    (-1, 0, 1)), beta = 2 — rrr_dbl_kernel, one thread per replica; the model family rrrMC(DoubleGraph) was designed for."""
+    N, K, R, beta, iters, step = 10000, 3, 4096, 2.0, 20000, 5000
+    X = pkg.GraphRRGNormalDiscretized(N, K, (-1, 0, 1), seed=SEED)
+    with pkg.Engine(X, R, device=device) as eng:
+        eng.seed(SEED)
+        eng.init_spins_random()
+        eng.rrr_mc(beta, iters // 4, step, want_energies=False)
+        C1 = eng.get_config().s[0].copy()
+        t0 = time.perf_counter()
+        _, acc, staged = eng.rrr_mc(beta, iters, step, want_energies=False)
+        dt = time.perf_counter() - t0
+        _, k_ms, nl = eng.last_timing()
+    out = {"workload": "GraphRRGNormalDiscretized(N=10000,K=3,levels -1 0 1) rrrMC beta=2.0, 4096 replicas, 20000 iterations per replica",
+           "value": R * iters / dt, "unit": "iterations/s", "kernel": "rrr_dbl_kernel<4, unsigned short>", "avg_launch_ms": k_ms / max(nl, 1), "launches": nl,
+           "acceptance": float(acc.mean()) / iters, "staged_frac": float(staged.mean()) / iters,
+           "bound": "latency / issue: one thread per replica, the staged step on gathered values (profiles/r06/f8_floor.md §3)", "bound_frac": None}
+    if O is not None:
+        with pinned_core():
+            it1 = 1 << 17
+            units, mul, div = O.dfloat_units((-1, 0, 1))
+            v, n, dt1 = timed_oracle(lambda k: O.rrr_double_sparse(X.A, X.dJ, X.rJ, units, beta, it1, it1, SEED, C1, it0=k * it1, mul=mul, div=div), it1)
+            out["cpu_one_core"] = {"value": v, "unit": "iterations/s", "kind": "port", "build": O.flavour,
+                                   "sample": "1 replica x %d x 2^17 iterations (%.1f s), oracle" % (n, dt1)}
+    return out
+
+
 def secondary_f8_cont(pkg, O, device):
     """SURVEY.md §8f rank 4 at the reference's experiment size (scripts/scripts.jl:152 test_RRGCont): rrrMC(X::SingleGraph) on
     GraphRRGNormal(10^4, 3) — DeltaECacheCont + DynamicSampler (src/DeltaE.jl:299-410, src/DynamicSamplers.jl) — cont_wave_kernel, one
@@ -715,7 +768,7 @@ def secondary(pkg, O, device):
     for name, fn in (("c3_sk_normal", secondary_c3), ("c4_ea_checkerboard", secondary_c4), ("c4_ea_random_site", secondary_c4_random),
                      ("c5_quant_rrr", secondary_c5),
                      ("f64_sparse_exact", secondary_f64_exact), ("f64_sparse_exact_262144", secondary_f64_exact_big), ("f64_sparse_fast", secondary_f64_fast), ("f8_rrr_rrg_1e4", secondary_f8_rrr),
-                     ("f8_rrr_rrgn_1e4", secondary_f8_cont)):
+                     ("f8_rrr_rrgn_1e4", secondary_f8_cont), ("f8_eo_rrg_1e4", secondary_f8_eo), ("f8_rrr_disc_1e4", secondary_f8_dbl)):
         t0 = time.perf_counter()
         try:
             out[name] = fn(pkg, O, device)
