@@ -597,6 +597,31 @@ def secondary_f64_exact(pkg, O, device):
     return out
 
 
+def secondary_f64_exact_k8(pkg, O, device):
+    """The same path at the degree whose pairs of attempts are NOT fused (K = 7, 8: registers; VERDICT r5 item 7 asks for the rate in the line):
+    GraphEANormal(L = 8, D = 4), N = 4096, K = 8, 8192 replicas."""
+    L, D, R, beta, iters, step = 8, 4, 8192, 1.0, 1 << 16, 1 << 12
+    X = pkg.GraphEANormal(L, D, seed=SEED)
+    with pkg.Engine(X, R, device=device) as eng:
+        eng.seed(SEED)
+        eng.init_spins_random()
+        eng.standard_mc_async(beta, iters // 4, step); eng.sync()
+        t0 = time.perf_counter()
+        eng.standard_mc_async(beta, iters, step); eng.sync()
+        dt = time.perf_counter() - t0
+        _, k_ms, nl = eng.last_timing()
+        _, acc = eng.fetch_results(want_energies=False)
+        kname = spf_team_kernel_name(eng, 2 * D)
+    a = float(acc.mean()) / iters
+    bpa = 8 + a * (10 + 17 * 2 * D)
+    out = {"workload": "GraphEANormal(L=8,D=4: N=4096,K=8) standardMC (exact mode) beta=1.0, 8192 replicas, 2^16 iterations per replica",
+           "value": R * iters / dt, "unit": "attempts/s", "kernel": kname, "avg_launch_ms": k_ms / max(nl, 1), "launches": nl,
+           "acceptance": a, "algorithmic_bytes_per_attempt": bpa, "achieved_GBps": bpa * R * iters / (k_ms * 1e-3) / 1e9,
+           "bound": "the executing wavefronts' instruction streams: pairs of attempts are not fused beyond K = 6 (DESIGN.md 8.8)", "bound_frac": None}
+    out["frac"] = out["achieved_GBps"] / HBM_PEAK_GBS
+    return out
+
+
 def secondary_f64_exact_big(pkg, O, device):
     """The same kernel where it is bound by HBM: 262 144 replicas of GraphRRGNormal(N=4096, K=3) — 8.6 GB of Float64 fields, every attempt
     reads and writes the K + 1 field lines of its site whole.  The traffic per attempt is the committed rocprofv3 measurement of this shape."""
@@ -767,7 +792,7 @@ def secondary(pkg, O, device):
     out = {}
     for name, fn in (("c3_sk_normal", secondary_c3), ("c4_ea_checkerboard", secondary_c4), ("c4_ea_random_site", secondary_c4_random),
                      ("c5_quant_rrr", secondary_c5),
-                     ("f64_sparse_exact", secondary_f64_exact), ("f64_sparse_exact_262144", secondary_f64_exact_big), ("f64_sparse_fast", secondary_f64_fast), ("f8_rrr_rrg_1e4", secondary_f8_rrr),
+                     ("f64_sparse_exact", secondary_f64_exact), ("f64_sparse_exact_262144", secondary_f64_exact_big), ("f64_sparse_exact_k8", secondary_f64_exact_k8), ("f64_sparse_fast", secondary_f64_fast), ("f8_rrr_rrg_1e4", secondary_f8_rrr),
                      ("f8_rrr_rrgn_1e4", secondary_f8_cont), ("f8_eo_rrg_1e4", secondary_f8_eo), ("f8_rrr_disc_1e4", secondary_f8_dbl)):
         t0 = time.perf_counter()
         try:
