@@ -19,6 +19,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     ("gather_soak.py", 80, 104),        # the staged-gather kernels (rrrMC / bklMC / extremal_opt / rrrMC(DoubleGraph)) against the oracle
     ("queue_soak.py", 30, 105),         # random sequences of queued asynchronous standardMC calls against synchronised ones and the oracle
     ("qeat_soak.py", 40, 106),          # GraphQEAT, all five samplers, against the oracle
+    ("misc_soak.py", 80, 109),          # colour-parallel sweeps, the fast Float64 mode, snapshot overlaps against the oracle
     ("std_family_soak.py", 120, 108),   # standardMC across the model kinds (levels, Float64 sparse, DoubleGraphs, SK, GraphQuant) against the oracle
     ("cont_family_soak.py", 60, 107),   # the continuous-energy samplers on GraphRRGNormal / GraphSKNormal / GraphQuant against the oracle
 ])
