@@ -84,7 +84,12 @@ inline SpfTeamBuild spf_team_build(const rrrmc_ctx* ctx)
     if (const char* e = std::getenv("RRRMC_SPF_TEAM_WIDTH"); e && (!std::strcmp(e, "64") || !std::strcmp(e, "32") || !std::strcmp(e, "16"))) { tw = std::atoi(e); width_forced = true; }
     int nw = (ctx->pfW * (64 / tw) <= ncu || (width_forced && tw < 64)) ? 16 : 8;
     if (const char* e = std::getenv("RRRMC_SPF_TEAM_WAVES"); e && (!std::strcmp(e, "8") || !std::strcmp(e, "16")) && !(width_forced && tw < 64)) nw = std::atoi(e);
-    if (nw == 8) tw = 64;                                  // the eight-wavefront build exists for whole groups only
+    // K = 7, 8 (GraphEANormal in four dimensions): the fused pairs need more registers than a sixteen-wavefront workgroup leaves per thread, so
+    // narrow teams of these degrees run EIGHT wavefronts (256 registers per thread, 42 slots) with fused pairs — 3.5 against 3.0·10¹⁰ attempts/s
+    // at 8192 replicas (profiles/r06/spf_sizes.jsonl); RRRMC_SPF_TEAM_WAVES=16 keeps the sixteen-wavefront build without fusion (the tests' cross-check)
+    const char* wv_env = std::getenv("RRRMC_SPF_TEAM_WAVES");
+    if (K >= 7 && tw < 64 && !(wv_env && !std::strcmp(wv_env, "16"))) nw = 8;
+    if (nw == 8 && !(K >= 7 && tw < 64)) tw = 64;          // (for K <= 6 the eight-wavefront build exists for whole groups only)
     size_t lds = spf_team_build_lds(K, nw, tw);
     if (!lds && nw == 16 && tw == 64) { nw = 8; lds = spf_team_build_lds(K, nw, tw); }      // K >= 5: the records of sixteen wavefronts x 64 replicas do not fit
     return SpfTeamBuild{nw, tw, lds};

@@ -16,7 +16,7 @@
 //     that is safe, by the oracle's det_exp in a narrow band around it: identical decisions), the K + 1 field updates, the spin word — on the
 //     group's [N][64] arrays in HBM / L2, exactly as spf_sweep_kernel does.  A wavefront counts its own accepted moves (a count does not care
 //     about order).  Results go into the attempt's SLOT in LDS (slot = iteration mod M), free once attempt it - M has retired.
-//   * FUSED PAIRS (teams of 32 or 16 replicas, K <= 6): a wavefront has twice the team's lanes and an instruction costs the same with half
+//   * FUSED PAIRS (teams of 32 or 16 replicas; K <= 6 in sixteen-wavefront teams, K = 7, 8 in eight-wavefront ones): a wavefront has twice the team's lanes and an instruction costs the same with half
 //     of them idle, so when the pair's attempts commute, lanes 0..31 work off the first and lanes 32..63 the second FOR THE SAME REPLICAS with
 //     one instruction stream — eight loads, one decision, one update, one set of records, one report for the two.  What differs per attempt
 //     (site, neighbours, couplings, slot, random number) is per-lane data: the record fields come from the fetched pair by a crossbar read.
@@ -171,7 +171,7 @@ __global__ __launch_bounds__(NW * 64) SPF_TEAM_OCC void spf_team_kernel(SpfTeamP
 #ifdef SPF_TEAM_NO_FUSE
     constexpr bool FUSE = false;
 #else
-    constexpr bool FUSE = TW <= 32 && K <= 6;         // pairs of attempts in the two halves of a wavefront (beyond K = 6 the registers run out)
+    constexpr bool FUSE = TW <= 32 && (K <= 6 || NW == 8);    // pairs of attempts in the two halves of a wavefront (beyond K = 6 the registers of a sixteen-wavefront workgroup run out)
 #endif
     typedef typename spf_word<TW>::type word_t;
     static_assert(M <= kSpfTeamWindow && M < 64 && M >= 2 * NX, "the dependency window covers the attempts in flight; one wavefront read brings all flags; a pair per executing wavefront");

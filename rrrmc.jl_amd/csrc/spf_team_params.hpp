@@ -38,7 +38,7 @@ __host__ __device__ constexpr size_t spf_team_lds_bytes(int K, int NW, int M, in
 // Eight-wavefront teams (many groups) stay at one pair per executing wavefront: small teams leave room for three workgroups per compute unit.
 __host__ __device__ constexpr int spf_team_slots(int K, int NW, int TW)
 {
-    int m = NW == 16 ? 60 : 2 * (NW - 1);
+    int m = NW == 16 ? 60 : (TW < 64 ? 42 : 2 * (NW - 1));          // (eight wavefronts narrower than a group: the fused K = 7, 8 builds, one team per compute unit)
     while (m > 2 * (NW - 1) && spf_team_lds_bytes(K, NW, m, TW) > (size_t)160 * 1024) --m;
     return m;
 }

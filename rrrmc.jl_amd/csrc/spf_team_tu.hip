@@ -51,6 +51,10 @@ hipError_t launch_K(int nw, int tw, int W, hipStream_t st, const SpfTeamParams& 
     if (nw == 16 && tw == 32) return launch_build<K, 16, 32>(W, st, TP);
     if (nw == 16 && tw == 16) return launch_build<K, 16, 16>(W, st, TP);
     if (nw == 8 && tw == 64) return launch_build<K, 8, 64>(W, st, TP);
+    if constexpr (K >= 7) {
+        if (nw == 8 && tw == 32) return launch_build<K, 8, 32>(W, st, TP);
+        if (nw == 8 && tw == 16) return launch_build<K, 8, 16>(W, st, TP);
+    }
     return hipErrorInvalidValue;
 }
 
@@ -61,6 +65,8 @@ size_t lds_K(int nw, int tw)
     if (nw == 16 && tw == 32) return build_fits<K, 16, 32>() ? spf_team_lds_bytes(K, 16, spf_team_slots(K, 16, 32), 32) : 0;
     if (nw == 16 && tw == 16) return build_fits<K, 16, 16>() ? spf_team_lds_bytes(K, 16, spf_team_slots(K, 16, 16), 16) : 0;
     if (nw == 8 && tw == 64) return build_fits<K, 8, 64>() ? spf_team_lds_bytes(K, 8, spf_team_slots(K, 8, 64), 64) : 0;
+    if (K >= 7 && nw == 8 && tw == 32) return spf_team_lds_bytes(K, 8, spf_team_slots(K, 8, 32), 32);
+    if (K >= 7 && nw == 8 && tw == 16) return spf_team_lds_bytes(K, 8, spf_team_slots(K, 8, 16), 16);
     return 0;
 }
 

@@ -210,16 +210,32 @@ def test_random_shapes_team_builds_against_the_single_wavefront_kernel(pkg, monk
             assert (np.asarray(u) == np.asarray(v)).all()
 
 
-@pytest.mark.parametrize("kind,a,b,beta", [("rrg", 512, 3, 0.1), ("rrg", 512, 6, 0.5), ("ea", 8, 2, 0.3), ("ea", 5, 3, 1.0), ("rrg", 64, 5, 0.0)])
+def _circulant7(pkg, N, seed):
+    """a 7-regular graph by construction (the pairing model of gen_RRG rarely finds a simple one at this degree): i +- 1, 2, 3 and the antipode"""
+    g = np.random.default_rng(seed)
+    A = np.array([sorted({(i + o) % N for o in (1, 2, 3)} | {(i - o) % N for o in (1, 2, 3)} | {(i + N // 2) % N}) for i in range(N)], np.int32)
+    bond, J = {}, np.zeros((N, 7))
+    for i in range(N):
+        for k, j in enumerate(A[i]):
+            J[i, k] = bond.setdefault((min(i, int(j)), max(i, int(j))), g.standard_normal())
+    return pkg.GraphRRGNormal.from_AJ(A, J)
+
+
+@pytest.mark.parametrize("kind,a,b,beta", [("rrg", 512, 3, 0.1), ("rrg", 512, 6, 0.5), ("ea", 8, 2, 0.3), ("ea", 5, 3, 1.0), ("rrg", 64, 5, 0.0),
+                                           ("circ7", 512, 7, 0.4), ("ea", 4, 4, 0.5), ("ea", 2, 4, 1.0), ("circ7", 66, 7, 0.0)])      # K = 7, 8: fused in eight-wavefront teams
 def test_fused_pairs_at_every_width(pkg, oracle, monkeypatch, kind, a, b, beta):
     """Teams of 32 and 16 replicas run the two commuting attempts of a pair in the two halves of a wavefront (K <= 6).  Graphs of a few hundred
     sites at high acceptance: most pairs are fused, a good share of them restarts on the undo test (an accepting replica whose last accepted
     move is at the same site), some have a dependent second attempt; the accepted moves of a replica are counted in two lanes.  Widths 16, 32
     and 64 and the single-wavefront kernel against each other; replicas from both ends of a team against the oracle."""
     seed, R, iters, step = 4000 + 7 * a + b, 1056, 20001, 501
-    X = pkg.GraphRRGNormal(a, b, seed=seed) if kind == "rrg" else pkg.GraphEANormal(a, b, seed=seed)
+    if kind == "circ7":
+        X, kind = _circulant7(pkg, a, seed), "rrg"
+    else:
+        X = pkg.GraphRRGNormal(a, b, seed=seed) if kind == "rrg" else pkg.GraphEANormal(a, b, seed=seed)
     outs = []
-    for env in ({"RRRMC_SPF_TEAM_WIDTH": "16"}, {"RRRMC_SPF_TEAM_WIDTH": "32"}, {"RRRMC_SPF_TEAM_WAVES": "16", "RRRMC_SPF_TEAM_WIDTH": "64"}, {"RRRMC_SPF_TEAM": "0"}):
+    for env in ({"RRRMC_SPF_TEAM_WIDTH": "16"}, {"RRRMC_SPF_TEAM_WIDTH": "32"}, {"RRRMC_SPF_TEAM_WAVES": "16", "RRRMC_SPF_TEAM_WIDTH": "64"}, {"RRRMC_SPF_TEAM": "0"},
+                {"RRRMC_SPF_TEAM_WAVES": "16", "RRRMC_SPF_TEAM_WIDTH": "32"}):          # (the last: sixteen wavefronts — for K = 7, 8 the build WITHOUT fused pairs)
         _set_build(monkeypatch, env)
         outs.append(_run(pkg, X, R, seed, beta, iters, step))
     for o in outs[1:]:

@@ -80,7 +80,7 @@ def _spf_team_lds(K, NW, TW):
     """spf_team_lds_bytes with spf_team_slots (csrc/spf_team_params.hpp)"""
     def lds(M):
         return (8 * (K + 1) * TW + 4 * TW) * (M + NW) + 4 * (TW + 2 * M + 4)
-    M = 60 if NW == 16 else 2 * (NW - 1)
+    M = 60 if NW == 16 else (42 if TW < 64 else 2 * (NW - 1))
     while M > 2 * (NW - 1) and lds(M) > 160 * 1024:
         M -= 1
     return lds(M)
@@ -96,7 +96,8 @@ def test_spf_team_kernel_has_no_scratch_and_fits_its_workgroup(tmp_path):
                            os.path.join(CSRC, "spf_team_tu.hip"), "-o", str(asm)], cwd=str(tmp_path))
     meta = {n: m for n, m in kernel_metadata(asm.read_text()).items() if "spf_team_kernel" in n}
     want = [(K, NW, TW) for K in range(1, 9) for NW, TW in ((16, 64), (16, 32), (16, 16), (8, 64)) if _spf_team_lds(K, NW, TW) <= 160 * 1024]
-    assert len(meta) == len(want) == 29
+    want += [(K, 8, TW) for K in (7, 8) for TW in (32, 16)]          # the fused K = 7, 8 builds: eight wavefronts, narrow teams
+    assert len(meta) == len(want) == 33
     for n, m in meta.items():
         assert m["private_segment_fixed_size"] == 0 and m.get("vgpr_spill_count", 0) == 0, (n, m)       # (scalar registers may spill into vector lanes)
         nw = int(re.search(r"spf_team_kernelILi\d+ELi(\d+)E", n).group(1))
